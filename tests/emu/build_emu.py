@@ -1,0 +1,54 @@
+"""TEST INFRASTRUCTURE ONLY: compile the HIP sources with the host clang++ against the SIMT emulator
+(tests/emu/hip_emu.h) into tests/emu/libvisiondk_emu.so.  Never loaded by visiondk_amd itself."""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+CSRC = ROOT / "visiondk_amd" / "csrc"
+LIB = HERE / "libvisiondk_emu.so"
+OBJ = HERE / "build"
+CXX = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-mfma", "-mavx2", "-w",
+         "-include", str(HERE / "hip_emu.h"), f"-I{HERE}", f"-I{CSRC}", f"-I{ROOT / 'include'}"]
+
+
+def build(force: bool = False) -> Path:
+    srcs = sorted(CSRC.glob("*.hip")) + [HERE / "hip_emu.cpp"]
+    hdrs = sorted(CSRC.glob("*.h")) + [HERE / "hip_emu.h"] + sorted((ROOT / "include").glob("*.h"))
+    OBJ.mkdir(exist_ok=True)
+    hd = hashlib.sha256(b"".join(p.read_bytes() for p in hdrs) + " ".join(FLAGS).encode()).hexdigest()
+
+    def one(src: Path) -> tuple[Path, bool]:
+        obj = OBJ / (src.stem + ".o")
+        tag = OBJ / (src.stem + ".tag")
+        d = hashlib.sha256(src.read_bytes() + hd.encode()).hexdigest()
+        if obj.exists() and tag.exists() and tag.read_text() == d and not force:
+            return obj, False
+        r = subprocess.run([CXX, *FLAGS, "-c", str(src), "-o", str(obj)], capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError(f"emu compile failed: {src.name}")
+        tag.write_text(d)
+        return obj, True
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        res = list(ex.map(one, srcs))
+    if LIB.exists() and not any(ch for _, ch in res) and not force:
+        return LIB
+    r = subprocess.run([CXX, "-shared", "-fPIC", "-o", str(LIB), *[str(o) for o, _ in res], "-lpthread"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("emu link failed")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,268 @@
+// hip_emu.h — TEST INFRASTRUCTURE ONLY.
+//
+// A tiny SIMT emulator that lets the HIP kernels under visiondk_amd/csrc/ be compiled by the
+// HOST clang++ (-x c++ -include tests/emu/hip_emu.h) and executed on CPU threads, so that the
+// index math of every kernel (MFMA fragment layouts, LDS tiling, masks, reductions) can be
+// parity-checked against the oracle in the GPU-less build container, through the very same C ABI
+// (include/visiondk.h) that the gfx950 library exports.
+//
+// It is NOT a product path: nothing under visiondk_amd/ loads the emulated library; only
+// tests/ build and load it (tests/emu/build_emu.py).  The product library is compiled by hipcc for
+// gfx950 from the same sources with no preprocessor switches.
+//
+// Model: one OS worker thread runs one workgroup at a time; every HIP thread is a ucontext fiber;
+// __syncthreads / wave collectives are cooperative barriers between fibers.  A wave is 64
+// consecutive threads.  MFMA builtins are emulated with the gfx950 fragment layouts documented in
+// /opt/skills/guides/cdna_hip_programming.md §3 (A/B: lane l holds row/col (l & (M-1)) and the 8
+// consecutive k starting at 8*(l / M); C/D: col = l & (M-1), row = f(reg, l / M)).
+#pragma once
+#include <ucontext.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+#include <atomic>
+#include <mutex>
+#include <algorithm>
+
+#define VDK_EMU 1
+
+// ---------------------------------------------------------------- keywords
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct emu_uint3 { unsigned x, y, z; };
+
+// ---------------------------------------------------------------- runtime API subset
+typedef int hipError_t;
+typedef void* hipStream_t;
+#define hipSuccess 0
+#define hipErrorInvalidValue 1
+static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipPeekAtLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+#define hipMemcpyDeviceToDevice 3
+#define hipMemcpyDefault 4
+
+namespace emu {
+
+struct Barrier { int arrived = 0; unsigned gen = 0; };
+
+struct Wave {
+  Barrier bar;
+  int alive = 0;
+  uint64_t x64[64];
+  uint32_t a32[64][8];   // operand exchange (A)
+  uint32_t b32[64][8];   // operand exchange (B)
+};
+
+struct Block;
+struct Fiber {
+  ucontext_t ctx;
+  Block* blk = nullptr;
+  emu_uint3 tid{0, 0, 0};
+  int lin = 0;
+  bool done = false;
+  char* stack = nullptr;
+};
+
+struct Block {
+  ucontext_t sched;
+  std::vector<Fiber> fibers;
+  std::vector<Wave> waves;
+  Barrier bar;
+  int alive = 0;
+  emu_uint3 bid{0, 0, 0};
+  dim3 bdim, gdim;
+  const std::function<void()>* body = nullptr;
+  Fiber* cur = nullptr;
+  bool progress = false;
+};
+
+extern thread_local Block* g_blk;
+static const size_t kStack = 256 * 1024;
+
+inline Fiber* cur() { return g_blk->cur; }
+inline void yield() { Fiber* f = cur(); swapcontext(&f->ctx, &g_blk->sched); }
+
+inline void barrier_wait(Barrier& b, int& alive) {
+  unsigned gen = b.gen;
+  if (++b.arrived >= alive) { b.arrived = 0; b.gen++; g_blk->progress = true; return; }
+  while (b.gen == gen) yield();
+}
+inline void block_barrier() { barrier_wait(g_blk->bar, g_blk->alive); }
+inline Wave& wave() { return g_blk->waves[cur()->lin >> 6]; }
+inline int lane() { return cur()->lin & 63; }
+inline void wave_barrier() { Wave& w = wave(); barrier_wait(w.bar, w.alive); }
+
+void fiber_entry();
+void run_block(Block& b);
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+
+}  // namespace emu
+
+#define threadIdx (emu::cur()->tid)
+#define blockIdx (emu::g_blk->bid)
+#define blockDim (emu::g_blk->bdim)
+#define gridDim (emu::g_blk->gdim)
+
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
+  emu::launch((grid), (block), [=]() { kern(__VA_ARGS__); })
+
+static inline void __syncthreads() { emu::block_barrier(); }
+
+// ---------------------------------------------------------------- cross-lane
+template <class T> static inline T emu_xchg(T v, int src_lane) {
+  static_assert(sizeof(T) <= 8, "xchg");
+  emu::Wave& w = emu::wave();
+  uint64_t bits = 0; memcpy(&bits, &v, sizeof(T));
+  w.x64[emu::lane()] = bits;
+  emu::wave_barrier();
+  uint64_t r = w.x64[src_lane & 63];
+  emu::wave_barrier();
+  T out; memcpy(&out, &r, sizeof(T));
+  return out;
+}
+template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; return emu_xchg(v, emu::lane() ^ mask); }
+template <class T> static inline T __shfl(T v, int src, int width = 64) { (void)width; return emu_xchg(v, src); }
+template <class T> static inline T __shfl_down(T v, int d, int width = 64) { (void)width; int s = emu::lane() + d; if (s > 63) s = emu::lane(); return emu_xchg(v, s); }
+static inline unsigned long long __ballot(int pred) {
+  emu::Wave& w = emu::wave();
+  w.x64[emu::lane()] = pred ? 1 : 0;
+  emu::wave_barrier();
+  unsigned long long m = 0;
+  int base = (emu::cur()->lin >> 6) << 6;
+  int n = (int)emu::g_blk->fibers.size() - base; if (n > 64) n = 64;
+  for (int i = 0; i < n; ++i) if (!emu::g_blk->fibers[base + i].done && w.x64[i]) m |= 1ull << i;
+  emu::wave_barrier();
+  return m;
+}
+static inline int __any(int p) { return __ballot(p) != 0; }
+static inline int __all(int p) {
+  unsigned long long m = __ballot(!p);
+  return m == 0;
+}
+template <class T> static inline T __builtin_amdgcn_readfirstlane_emu(T v) { return emu_xchg(v, 0); }
+#define __builtin_amdgcn_readfirstlane(v) __builtin_amdgcn_readfirstlane_emu(v)
+
+// ---------------------------------------------------------------- atomics (global or LDS)
+static inline float atomicAdd(float* p, float v) {
+  uint32_t* u = (uint32_t*)p; uint32_t old = __atomic_load_n(u, __ATOMIC_RELAXED), nw;
+  float f;
+  do { memcpy(&f, &old, 4); f += v; memcpy(&nw, &f, 4); } while (!__atomic_compare_exchange_n(u, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+  memcpy(&f, &old, 4); return f;
+}
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline int atomicMax(int* p, int v) { int old = __atomic_load_n(p, __ATOMIC_RELAXED); while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return old; }
+static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED); while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return old; }
+static inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+
+// ---------------------------------------------------------------- bit casts / math
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+#define __expf(x) expf(x)
+#define __logf(x) logf(x)
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+template <class T> static inline T min(T a, T b) { return a < b ? a : b; }
+template <class T> static inline T max(T a, T b) { return a > b ? a : b; }
+
+// ---------------------------------------------------------------- MFMA
+typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
+typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
+typedef short emu_s16x8 __attribute__((ext_vector_type(8)));
+
+static inline float emu_bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+
+// v_mfma_f32_32x32x16_bf16: A lane l -> row l&31, k = 8*(l>>5)+e ; B lane l -> col l&31, k = 8*(l>>5)+e
+// D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
+static inline emu_f32x16 emu_mfma_32x32x16_bf16(emu_s16x8 a, emu_s16x8 b, emu_f32x16 c, int, int, int) {
+  emu::Wave& w = emu::wave();
+  int l = emu::lane();
+  memcpy(w.a32[l], &a, 16); memcpy(w.b32[l], &b, 16);
+  emu::wave_barrier();
+  emu_f32x16 d;
+  int j = l & 31, hi = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float acc = c[r];
+    for (int k = 0; k < 16; ++k) {
+      const unsigned short* pa = (const unsigned short*)w.a32[i + 32 * (k >> 3)];
+      const unsigned short* pb = (const unsigned short*)w.b32[j + 32 * (k >> 3)];
+      acc += emu_bf2f(pa[k & 7]) * emu_bf2f(pb[k & 7]);
+    }
+    d[r] = acc;
+  }
+  emu::wave_barrier();
+  return d;
+}
+// v_mfma_f32_16x16x32_bf16: A lane l -> row l&15, k = 8*(l>>4)+e ; D: col = l&15, row = 4*(l>>4)+r
+static inline emu_f32x4 emu_mfma_16x16x32_bf16(emu_s16x8 a, emu_s16x8 b, emu_f32x4 c, int, int, int) {
+  emu::Wave& w = emu::wave();
+  int l = emu::lane();
+  memcpy(w.a32[l], &a, 16); memcpy(w.b32[l], &b, 16);
+  emu::wave_barrier();
+  emu_f32x4 d;
+  int j = l & 15, q = l >> 4;
+  for (int r = 0; r < 4; ++r) {
+    int i = 4 * q + r;
+    float acc = c[r];
+    for (int k = 0; k < 32; ++k) {
+      const unsigned short* pa = (const unsigned short*)w.a32[i + 16 * (k >> 3)];
+      const unsigned short* pb = (const unsigned short*)w.b32[j + 16 * (k >> 3)];
+      acc += emu_bf2f(pa[k & 7]) * emu_bf2f(pb[k & 7]);
+    }
+    d[r] = acc;
+  }
+  emu::wave_barrier();
+  return d;
+}
+// v_mfma_f32_32x32x2_f32: A lane l -> A[l&31][l>>5], B lane l -> B[l>>5][l&31];
+// exact f32: D = fma(a_k1, b_k1, fma(a_k0, b_k0, C))  (k-ordered fmaf chain, guide §3)
+static inline emu_f32x16 emu_mfma_32x32x2_f32(float a, float b, emu_f32x16 c, int, int, int) {
+  emu::Wave& w = emu::wave();
+  int l = emu::lane();
+  memcpy(&w.a32[l][0], &a, 4); memcpy(&w.b32[l][0], &b, 4);
+  emu::wave_barrier();
+  emu_f32x16 d;
+  int j = l & 31, hi = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float a0, a1, b0, b1;
+    memcpy(&a0, &w.a32[i][0], 4); memcpy(&a1, &w.a32[i + 32][0], 4);
+    memcpy(&b0, &w.b32[j][0], 4); memcpy(&b1, &w.b32[j + 32][0], 4);
+    d[r] = fmaf(a1, b1, fmaf(a0, b0, c[r]));
+  }
+  emu::wave_barrier();
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu_mfma_32x32x16_bf16
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu_mfma_16x16x32_bf16
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_32x32x2_f32
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_barrier() __syncthreads()

@@ -1,0 +1,47 @@
+"""ctypes signatures of the C ABI declared in include/visiondk.h.
+
+`bind(cdll)` attaches argtypes/restype for every exported entry point and returns the names it bound;
+`tests/test_abi.py` checks this table against the header and the shared object's symbol table.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+P = C.c_void_p
+I32 = C.c_int32
+I64 = C.c_int64
+F32 = C.c_float
+SZ = C.c_size_t
+PSZ = C.POINTER(C.c_size_t)
+
+# name -> (restype, [argtypes])
+SIGNATURES: dict[str, tuple] = {
+    "vdk_last_error": (C.c_char_p, []),
+    "vdk_is_device_build": (C.c_int, []),
+    "vdk_abi_version": (C.c_int, []),
+    # hot path B
+    "vdk_l2norm_rows": (C.c_int, [P, P, I64, I32, F32, P]),
+    "vdk_cbir_workspace_bytes": (C.c_int, [I64, I32, I64, PSZ]),
+    "vdk_cbir_search": (C.c_int, [P, I64, P, I64, I32, I32, I64, P, P, I64, P, SZ, P]),
+    "vdk_cbir_merge_topk": (C.c_int, [P, P, I32, I64, I32, P, P, P, SZ, P]),
+}
+
+
+class VdkError(RuntimeError):
+    pass
+
+
+def bind(lib: C.CDLL) -> list[str]:
+    bound = []
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+        bound.append(name)
+    return bound
+
+
+def check(lib: C.CDLL, rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib.vdk_last_error()
+        raise VdkError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,182 @@
+"""Hot path B host side: a faiss-like inner-product index on MI355X, and the reference's index()/search().
+
+Mirrors the retrieval seam of the reference (SURVEY.md §8(b) "Retrieval index protocol"):
+
+    faiss_index = faiss.index_factory(dim, "Flat", faiss.METRIC_INNER_PRODUCT)   # cbir/evaluation.py:155
+    faiss_index.train(x); faiss_index.add(x)                                     # :167-168
+    D, I = faiss_index.search(q.astype(np.float32), k=k)                         # :193
+
+`index_factory(dim, "Flat", METRIC_INNER_PRODUCT)` returns a `FlatIPIndex` with the same methods; numpy in /
+numpy out like faiss, or device tensors in / device tensors out to skip the host round trip.  All arithmetic
+happens in the HIP kernels of csrc/cbir.hip through the C ABI; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+METRIC_INNER_PRODUCT = 0  # faiss.METRIC_INNER_PRODUCT
+DEFAULT_CAP = 65536       # candidate-list capacity per query (bounds the stage size, see csrc/cbir.hip)
+
+
+def l2_normalize(x: torch.Tensor, eps: float = 1e-12, backend: Optional[_lib.Backend] = None) -> torch.Tensor:
+    """F.normalize(x, p=2, dim=1, eps) of face_model.py:139 on float32 rows."""
+    be = backend or _lib.load()
+    if x.dtype != torch.float32 or x.dim() != 2:
+        raise ValueError("l2_normalize expects a float32 [n, d] tensor")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    be.check(be.lib.vdk_l2norm_rows(be.ptr(x), be.ptr(out), x.shape[0], x.shape[1], eps, be.stream()), "vdk_l2norm_rows")
+    return out
+
+
+class FlatIPIndex:
+    """Exact inner-product index (faiss IndexFlatIP semantics; ties -> lower index; pads (-FLT_MAX, -1))."""
+
+    def __init__(self, d: int, backend: Optional[_lib.Backend] = None, device=None, cap: int = DEFAULT_CAP,
+                 idx_base: int = 0):
+        if d <= 0:
+            raise ValueError("dimension must be positive")
+        self.d = int(d)
+        self.be = backend or _lib.load()
+        self.device = torch.device(device) if device is not None else torch.device(
+            "cuda", torch.cuda.current_device()) if self.be.device_only else torch.device("cpu")
+        self.cap = int(cap)
+        self.idx_base = int(idx_base)
+        self._dp = (self.d + 3) // 4 * 4          # kernels need d % 4 == 0: zero-pad (adds exact zeros)
+        self._chunks: list[torch.Tensor] = []
+        self._gallery: Optional[torch.Tensor] = None
+        self.is_trained = True
+        self._ws: Optional[torch.Tensor] = None
+
+    # ---- faiss surface ------------------------------------------------------------------------
+    @property
+    def ntotal(self) -> int:
+        return sum(c.shape[0] for c in self._chunks) + (0 if self._gallery is None else self._gallery.shape[0])
+
+    def train(self, x) -> None:  # IndexFlat needs no training (cbir/evaluation.py:167)
+        return None
+
+    def _to_dev(self, x) -> torch.Tensor:
+        if isinstance(x, np.ndarray):
+            if x.dtype != np.float32:
+                raise TypeError("FlatIPIndex only accepts float32 (like faiss)")
+            x = torch.from_numpy(np.ascontiguousarray(x))
+        if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != self.d:
+            raise ValueError(f"expected float32 [n, {self.d}]")
+        x = x.to(self.device, non_blocking=True)
+        if self._dp != self.d:
+            x = torch.nn.functional.pad(x, (0, self._dp - self.d))
+        return x.contiguous()
+
+    def add(self, x) -> None:
+        self._chunks.append(self._to_dev(x))
+
+    def reset(self) -> None:
+        self._chunks, self._gallery = [], None
+
+    def _materialize(self) -> torch.Tensor:
+        if self._chunks:
+            parts = ([self._gallery] if self._gallery is not None else []) + self._chunks
+            self._gallery = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+            self._chunks = []
+        if self._gallery is None:
+            self._gallery = torch.empty((0, self._dp), dtype=torch.float32, device=self.device)
+        return self._gallery
+
+    def _workspace(self, nq: int, k: int, cap: int) -> torch.Tensor:
+        need = C.c_size_t(0)
+        self.be.check(self.be.lib.vdk_cbir_workspace_bytes(nq, k, cap, C.byref(need)), "vdk_cbir_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need.value:
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def search(self, q, k: int):
+        """D [b,k] float32 descending, I [b,k] int64.  numpy in -> numpy out; tensor in -> tensor out."""
+        as_numpy = isinstance(q, np.ndarray)
+        qd = self._to_dev(q)
+        g = self._materialize()
+        nq = qd.shape[0]
+        if not 1 <= k <= 1024:
+            raise ValueError("1 <= k <= 1024")
+        cap = max(self.cap, 2 * k)
+        scores = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        idx = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        if nq:
+            ws = self._workspace(nq, k, cap)
+            be = self.be
+            be.check(be.lib.vdk_cbir_search(be.ptr(qd), nq, be.ptr(g), g.shape[0], self._dp, k, self.idx_base,
+                                            be.ptr(scores), be.ptr(idx), cap, be.ptr(ws), ws.numel(), be.stream()),
+                     "vdk_cbir_search")
+        if as_numpy:
+            return scores.cpu().numpy(), idx.cpu().numpy()
+        return scores, idx
+
+
+def index_factory(d: int, description: str = "Flat", metric: int = METRIC_INNER_PRODUCT, **kw) -> FlatIPIndex:
+    """faiss.index_factory(dim, "Flat", faiss.METRIC_INNER_PRODUCT) of cbir/evaluation.py:155."""
+    if description != "Flat" or metric != METRIC_INNER_PRODUCT:
+        raise NotImplementedError("the reference only builds (\"Flat\", METRIC_INNER_PRODUCT) indexes")
+    return FlatIPIndex(d, **kw)
+
+
+def merge_topk(scores: torch.Tensor, idx: torch.Tensor, backend: Optional[_lib.Backend] = None):
+    """Merge per-shard results [S, nq, k] (idx < 0 = empty) into the global top-k, bit-identical to one search."""
+    be = backend or _lib.load()
+    S, nq, k = scores.shape
+    scores, idx = scores.contiguous(), idx.contiguous()
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=scores.device)
+    cap = max(S * k, 2 * k)
+    need = C.c_size_t(0)
+    be.check(be.lib.vdk_cbir_workspace_bytes(nq, k, cap, C.byref(need)), "vdk_cbir_workspace_bytes")
+    ws = torch.empty(need.value, dtype=torch.uint8, device=scores.device)
+    be.check(be.lib.vdk_cbir_merge_topk(be.ptr(scores), be.ptr(idx), S, nq, k, be.ptr(out_s), be.ptr(out_i),
+                                        be.ptr(ws), ws.numel(), be.stream()), "vdk_cbir_merge_topk")
+    return out_s, out_i
+
+
+# ---- the reference's two functions, same names / argument meaning (engine/cbir/evaluation.py:106,171) ----
+def index(extractor, gallery_dataloader, device, logger=None, index_factory_str: str = "Flat",
+          gallery_embeddings=None, **kw) -> FlatIPIndex:
+    """Encode the gallery (extractor.extract_cbir) and build the inner-product index.
+
+    `gallery_embeddings` may be passed directly (the memmap-load branch of the reference, :124-133).
+    """
+    if gallery_embeddings is None:
+        gallery_embeddings = extractor.extract_cbir(gallery_dataloader, device)
+    if isinstance(gallery_embeddings, np.ndarray):
+        gallery_embeddings = gallery_embeddings.astype(np.float32)  # "faiss only accepts float32" (:165)
+    dim = gallery_embeddings.shape[-1]
+    idx = index_factory(dim, index_factory_str, METRIC_INNER_PRODUCT, device=device, **kw)
+    if logger is not None:
+        logger.console("Adding embeddings...")
+    idx.train(gallery_embeddings)
+    idx.add(gallery_embeddings)
+    return idx
+
+
+def search(extractor, query_dataloader, faiss_index: FlatIPIndex, device, logger=None, k: int = 100,
+           batch_size: int = 256, query_embeddings=None):
+    """Reference search(): query batches of `batch_size` -> concatenated (scores, indices)."""
+    if query_embeddings is None:
+        query_embeddings = extractor.extract_cbir(query_dataloader, device)
+    n = query_embeddings.shape[0]
+    if logger is not None:
+        logger.console("Searching ...")
+    all_s, all_i = [], []
+    for i in range(0, n, batch_size):
+        q = query_embeddings[i:min(i + batch_size, n)]
+        if isinstance(q, np.ndarray):
+            q = q.astype(np.float32)
+        s, ind = faiss_index.search(q, k=k)
+        all_s.append(s)
+        all_i.append(ind)
+    if isinstance(all_s[0], np.ndarray):
+        return np.concatenate(all_s, 0), np.concatenate(all_i, 0)
+    return torch.cat(all_s, 0), torch.cat(all_i, 0)
