@@ -14,6 +14,19 @@ F32 = C.c_float
 SZ = C.c_size_t
 PSZ = C.POINTER(C.c_size_t)
 
+
+
+class GemmDesc(C.Structure):
+    """VdkGemmDesc of include/visiondk.h"""
+    _fields_ = [("A", P), ("lda", I64), ("B", P), ("ldb", I64), ("C", P), ("ldc", I64),
+                ("M", I32), ("N", I32), ("K", I32), ("c_dtype", I32),
+                ("bias", P), ("residual", P), ("ldr", I64), ("act", I32), ("aux", P), ("ldaux", I64),
+                ("alpha", F32), ("splitk", I32)]
+
+
+BF16, F32_ = 0, 1
+ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
+
 # name -> (restype, [argtypes])
 SIGNATURES: dict[str, tuple] = {
     "vdk_last_error": (C.c_char_p, []),
@@ -24,6 +37,10 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_cbir_workspace_bytes": (C.c_int, [I64, I32, I64, PSZ]),
     "vdk_cbir_search": (C.c_int, [P, I64, P, I64, I32, I32, I64, P, P, I64, P, SZ, P]),
     "vdk_cbir_merge_topk": (C.c_int, [P, P, I32, I64, I32, P, P, P, SZ, P]),
+    # hot path A: dense ops
+    "vdk_gemm_splitk_workspace_bytes": (C.c_int, [I32, I32, I32, PSZ]),
+    "vdk_gemm_bf16_nt": (C.c_int, [C.POINTER(GemmDesc), P, SZ, P]),
+    "vdk_transpose_bf16": (C.c_int, [P, I64, I32, I32, P, I64, I32, P]),
 }
 
 

@@ -1,0 +1,294 @@
+// gemm.hip — K2: C[M,N] = A[M,K] * B[N,K]^T on the bf16 MFMA pipe (fp32 accumulate), the one GEMM
+// behind every Linear of the hot path (timm Attention.qkv/proj, Mlp.fc1/fc2, PatchEmbed.proj as a
+// k=stride conv, head; reference call sites models/classifier/classify_model.py:49-54 ->
+// timm vision_transformer; F.linear fwd = NT, dgrad = NT against a transposed weight copy, wgrad = NT
+// on transposed activations).
+//
+// gfx950 structure: 128x128x64 workgroup tile, 4 waves (2x2) x (2x2) v_mfma_f32_32x32x16_bf16 per
+// k-step, global->VGPR->LDS register staging (next tile's loads in flight under the MFMAs), LDS
+// double-buffered with ONE barrier per k-tile, rows padded to 144 B so every ds_read_b128 lane
+// group hits 16 distinct 16-B slots, XCD-aware bijective tile swizzle, epilogue staged through LDS
+// for 16-B coalesced stores with bias / exact-erf GELU / dGELU / fp32 residual fused in.
+#include <hip/hip_runtime.h>
+#include "vdk_device.h"
+#include "vdk_host.h"
+#include "vdk_gemm.h"
+
+#define G_BM 128
+#define G_BN 128
+#define G_BK 64
+#define G_PITCH 72   // bf16 elements per LDS row (64 + 8 pad = 144 B)
+#define G_CP 132     // fp32 pitch of the epilogue staging tile
+
+__device__ __forceinline__ void g_load_tile(u32x4 (&r)[4], const bf16_t* __restrict__ base, long ld, int row0,
+                                            int nrows, int k0, int kend) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int id = threadIdx.x + 256 * j;
+    int row = id >> 3, ch = id & 7;
+    int grow = row0 + row, k = k0 + ch * 8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (grow < nrows && k < kend) v = *(const u32x4*)(base + (long)grow * ld + k);
+    r[j] = v;
+  }
+}
+__device__ __forceinline__ void g_store_tile(const u32x4 (&r)[4], bf16_t* lds) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int id = threadIdx.x + 256 * j;
+    int row = id >> 3, ch = id & 7;
+    *(u32x4*)(lds + row * G_PITCH + ch * 8) = r[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmParams p) {
+  // 2 buffers x (A 128 rows + B 128 rows) x 144 B = 73,728 B; reused as the fp32 epilogue tile (67,584 B)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 128 * G_PITCH * 2];
+  bf16_t* const As = (bf16_t*)smem;                       // [2][128][PITCH]
+  bf16_t* const Bs = As + 2 * 128 * G_PITCH;              // [2][128][PITCH]
+  float* const Cs = (float*)smem;                         // [128][G_CP]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1, hi = lane >> 5, l31 = lane & 31;
+
+  // XCD-aware bijective swizzle (cdna_hip_programming.md T1): blocks that share an XCD's L2 get a
+  // contiguous run of tiles, N-tiles fastest, so they reuse the same A row panel / weight matrix.
+  const int ntn = (p.N + G_BN - 1) / G_BN, ntm = (p.M + G_BM - 1) / G_BM;
+  const int nwg = ntn * ntm;
+  int bid = blockIdx.x;
+  {
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tn = bid % ntn, tm = bid / ntn;
+  const int m0 = tm * G_BM, n0 = tn * G_BN;
+  const int z = blockIdx.y;
+  const int kbeg = z * p.k_per_split;
+  int kend = kbeg + p.k_per_split; if (kend > p.K) kend = p.K;
+  const int nk = (kend - kbeg + G_BK - 1) / G_BK;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 ra[4], rb[4];
+  if (nk > 0) {
+    g_load_tile(ra, p.A, p.lda, m0, p.M, kbeg, kend);
+    g_load_tile(rb, p.B, p.ldb, n0, p.N, kbeg, kend);
+    g_store_tile(ra, As);
+    g_store_tile(rb, Bs);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      g_load_tile(ra, p.A, p.lda, m0, p.M, kbeg + (kt + 1) * G_BK, kend);
+      g_load_tile(rb, p.B, p.ldb, n0, p.N, kbeg + (kt + 1) * G_BK, kend);
+    }
+    const bf16_t* a_base = As + cur * 128 * G_PITCH + (wm * 64 + l31) * G_PITCH + hi * 8;
+    const bf16_t* b_base = Bs + cur * 128 * G_PITCH + (wn * 64 + l31) * G_PITCH + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < G_BK / 16; ++ks) {
+      s16x8 a0 = *(const s16x8*)(a_base + ks * 16);
+      s16x8 a1 = *(const s16x8*)(a_base + 32 * G_PITCH + ks * 16);
+      s16x8 b0 = *(const s16x8*)(b_base + ks * 16);
+      s16x8 b1 = *(const s16x8*)(b_base + 32 * G_PITCH + ks * 16);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      g_store_tile(ra, As + (cur ^ 1) * 128 * G_PITCH);
+      g_store_tile(rb, Bs + (cur ^ 1) * 128 * G_PITCH);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS (fp32) -> coalesced 8-wide row chunks ----------------------
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        int col = wn * 64 + j * 32 + l31;
+        Cs[row * G_CP + col] = acc[i][j][r];
+      }
+  __syncthreads();
+  const int cc = (tid & 15) * 8;
+#pragma unroll 1
+  for (int pass = 0; pass < 8; ++pass) {
+    const int row = pass * 16 + (tid >> 4);
+    const long m = m0 + row;
+    const int n = n0 + cc;
+    if (m >= p.M || n >= p.N) continue;
+    float v[8];
+    {
+      f32x4 x0 = *(const f32x4*)(Cs + row * G_CP + cc);
+      f32x4 x1 = *(const f32x4*)(Cs + row * G_CP + cc + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
+    }
+    if (p.splitk > 1) {  // raw fp32 partials; the reduce kernel finishes the job
+      float* dst = p.slabs + ((long)z * p.M + m) * p.N + n;
+      *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+      *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+      continue;
+    }
+    if (p.alpha != 1.0f) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+    }
+    if (p.bias) {
+      f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+    }
+    if (p.act == VDK_ACT_GELU) {
+      if (p.aux) {  // keep the pre-activation for the backward pass
+        u32x4 u = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        *(u32x4*)(p.aux + m * p.ldaux + n) = u;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+    } else if (p.act == VDK_ACT_DGELU) {  // dL/du = dL/dg * gelu'(u), u = saved pre-activation
+      u32x4 u = *(const u32x4*)(p.aux + m * p.ldaux + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] *= gelu_grad_f(bf_lo(u[e]));
+        v[2 * e + 1] *= gelu_grad_f(bf_hi(u[e]));
+      }
+    }
+    if (p.residual) {
+      const float* rs = p.residual + m * p.ldr + n;
+      f32x4 r0 = *(const f32x4*)rs, r1 = *(const f32x4*)(rs + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+    }
+    if (p.c_dtype == VDK_F32) {
+      float* dst = (float*)p.C + m * p.ldc + n;
+      *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+      *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+    } else {
+      u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+      *(u32x4*)((bf16_t*)p.C + m * p.ldc + n) = o;
+    }
+  }
+}
+
+// out[i] = alpha * sum_s slabs[s][i]  (deterministic split-K combine), optional bf16 output
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int S, long n4 /*=MN/4*/,
+                                                            long mn, float alpha, float* __restrict__ outf,
+                                                            bf16_t* __restrict__ outb) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 s = *(const f32x4*)(slabs + i * 4);
+  for (int k = 1; k < S; ++k) {
+    f32x4 t = *(const f32x4*)(slabs + (long)k * mn + i * 4);
+    s += t;
+  }
+  s *= alpha;
+  if (outf) *(f32x4*)(outf + i * 4) = s;
+  if (outb) *(u32x2*)(outb + i * 4) = (u32x2){pack_bf2(s[0], s[1]), pack_bf2(s[2], s[3])};
+}
+
+// out[c][r] = in[r][c] for r < R, 0 for R <= r < Rpad (bf16).  64x64 tiles through LDS.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, long ldi, int R, int Cc,
+                                                             bf16_t* __restrict__ out, long ldo, int Rpad) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+  // load: 64 rows x 64 cols, each thread 2 elements (one 32-bit word) x 8 passes
+  for (int i = 0; i < 8; ++i) {
+    int row = i * 8 + (tid >> 5), cw = (tid & 31) * 2;
+    int gr = r0 + row, gc = c0 + cw;
+    bf16_t v0 = 0, v1 = 0;
+    if (gr < R) {
+      if (gc + 1 < Cc) { unsigned wv = *(const unsigned*)(in + (long)gr * ldi + gc); v0 = (bf16_t)(wv & 0xffff); v1 = (bf16_t)(wv >> 16); }
+      else if (gc < Cc) v0 = in[(long)gr * ldi + gc];
+    }
+    tile[row][cw] = v0; tile[row][cw + 1] = v1;
+  }
+  __syncthreads();
+  for (int i = 0; i < 8; ++i) {
+    int col = i * 8 + (tid >> 5), rw = (tid & 31) * 2;   // output row = input col
+    int gc = c0 + col, gr = r0 + rw;
+    if (gc < Cc && gr < Rpad) {  // Rpad is even
+      unsigned wv = (unsigned)tile[rw][col] | ((unsigned)tile[rw + 1][col] << 16);
+      *(unsigned*)(out + (long)gc * ldo + gr) = wv;
+    }
+  }
+}
+
+extern "C" {
+
+int vdk_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t splitk, size_t* bytes) {
+  if (!bytes || M <= 0 || N <= 0 || splitk < 1) return vdk_fail(VDK_EINVAL, "vdk_gemm_splitk_workspace_bytes: bad argument");
+  *bytes = splitk > 1 ? (size_t)splitk * M * N * 4 : 0;
+  return VDK_OK;
+}
+
+// C = epilogue(alpha * A[M,K] * B[N,K]^T).  A, B bf16 row-major with leading dims lda/ldb (elements).
+// Requirements: K % 8 == 0, N % 8 == 0, lda/ldb/ldc/ldaux % 8 == 0 (16-B rows), pointers 16-B aligned.
+// splitk > 1: fp32 partial slabs in `ws` then a deterministic combine; only bias-free, act-free,
+// residual-free outputs are allowed in that mode (it is the wgrad path).
+int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!d || !d->A || !d->B || !d->C) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: null pointer");
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: empty problem");
+  if ((d->K & 7) || (d->N & 7) || (d->lda & 7) || (d->ldb & 7) || (d->ldc & 7))
+    return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: K, N, lda, ldb, ldc must be multiples of 8");
+  if (d->c_dtype != VDK_BF16 && d->c_dtype != VDK_F32) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad c_dtype");
+  if ((d->act == VDK_ACT_DGELU && !d->aux) || (d->aux && (d->ldaux & 7))) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad aux");
+  int splitk = d->splitk < 1 ? 1 : d->splitk;
+  GemmParams p;
+  p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C;
+  p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.c_dtype = d->c_dtype; p.bias = (const float*)d->bias; p.residual = (const float*)d->residual; p.ldr = d->ldr;
+  p.act = d->act; p.aux = (bf16_t*)d->aux; p.ldaux = d->ldaux; p.alpha = d->alpha;
+  p.splitk = splitk; p.slabs = nullptr;
+  int kps = d->K;
+  if (splitk > 1) {
+    if (d->bias || d->residual || d->act != VDK_ACT_NONE) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: split-K excludes fused epilogues");
+    if (d->ldc != d->N) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: split-K needs ldc == N");
+    kps = ((d->K + splitk - 1) / splitk + G_BK - 1) / G_BK * G_BK;
+    splitk = (d->K + kps - 1) / kps;
+    p.splitk = splitk;
+    if (splitk > 1) {
+      size_t need = (size_t)splitk * d->M * d->N * 4;
+      if (!ws || ws_bytes < need) return vdk_fail(VDK_EWORKSPACE, "vdk_gemm_bf16_nt: split-K workspace too small");
+      p.slabs = (float*)ws;
+    }
+  }
+  p.k_per_split = kps;
+  const int ntn = (d->N + G_BN - 1) / G_BN, ntm = (d->M + G_BM - 1) / G_BM;
+  hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256), 0, stream, p);
+  if (splitk > 1) {
+    long mn = (long)d->M * d->N, n4 = mn / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream,
+                       (const float*)p.slabs, splitk, n4, mn, d->alpha,
+                       d->c_dtype == VDK_F32 ? (float*)d->C : (float*)nullptr,
+                       d->c_dtype == VDK_BF16 ? (bf16_t*)d->C : (bf16_t*)nullptr);
+  }
+  return vdk_check_launch("vdk_gemm_bf16_nt");
+}
+
+// out[C][ldo] (bf16) = in[R][ldi]^T, rows R..Rpad-1 of the contraction dim zero-filled.  Rpad even.
+int vdk_transpose_bf16(const void* in, int64_t ldi, int32_t R, int32_t Cc, void* out, int64_t ldo, int32_t Rpad,
+                       void* stream) {
+  if (!in || !out || R < 0 || Cc <= 0 || Rpad < R || (Rpad & 1) || ldo < Rpad || (ldi & 1) || (ldo & 1))
+    return vdk_fail(VDK_EINVAL, "vdk_transpose_bf16: bad argument");
+  if (Rpad == 0) return VDK_OK;
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((Rpad + 63) / 64), (unsigned)((Cc + 63) / 64)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)in, (long)ldi, (int)R, (int)Cc, (bf16_t*)out, (long)ldo, (int)Rpad);
+  return vdk_check_launch("vdk_transpose_bf16");
+}
+
+}  // extern "C"

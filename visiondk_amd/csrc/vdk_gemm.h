@@ -1,0 +1,24 @@
+// vdk_gemm.h — internal parameter block of the NT GEMM kernel (public descriptor: include/visiondk.h)
+#pragma once
+#include "visiondk.h"
+#include "vdk_device.h"
+
+typedef VdkGemmDesc GemmDesc;
+
+struct GemmParams {
+  const bf16_t* A; const bf16_t* B; void* C;
+  long lda, ldb, ldc;
+  int M, N, K;
+  int c_dtype;
+  const float* bias;
+  const float* residual; long ldr;
+  int act;
+  bf16_t* aux; long ldaux;
+  float alpha;
+  int splitk; int k_per_split;
+  float* slabs;
+};
+
+// in-library launcher (no descriptor copy through the C ABI)
+extern "C" int vdk_gemm_bf16_nt(const VdkGemmDesc* d, void* ws, size_t ws_bytes, void* stream);
+extern "C" int vdk_transpose_bf16(const void* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, int32_t Rpad, void* stream);

@@ -5,11 +5,7 @@
 #include <stdint.h>
 #include <stddef.h>
 
-#define VDK_OK 0
-#define VDK_EINVAL (-1)
-#define VDK_EWORKSPACE (-2)
-#define VDK_ELAUNCH (-3)
-#define VDK_EUNSUPPORTED (-4)
+#include "visiondk.h"
 
 int vdk_fail(int code, const char* msg);
 int vdk_check_launch(const char* what);
