@@ -84,13 +84,79 @@ typedef struct VdkGemmDesc {
   int64_t ldaux;
   float alpha;
   int32_t splitk;          /* <= 1: none */
+  int32_t row_group;       /* > 0: output row m -> m + m/row_group + 1, residual row -> m % row_group + 1
+                              (PatchEmbed rows written straight into the [B, 1+np, D] token buffer + pos_embed) */
 } VdkGemmDesc;
 int vdk_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t splitk, size_t* bytes);
 int vdk_gemm_bf16_nt(const VdkGemmDesc* d, void* ws, size_t ws_bytes, void* stream);
 
-/* out[c][r] = in[r][c] (bf16), rows R..Rpad-1 of the new contraction dim zero-filled; feeds wgrad. */
+/* out[c][r] = in[r][c] (bf16), rows R..Rpad-1 of the new contraction dim zero-filled; feeds wgrad.
+ * in_row_group > 0: logical row r lives at physical row r + r/in_row_group + 1 (token buffer without cls rows). */
 int vdk_transpose_bf16(const void* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, int32_t Rpad,
-                       void* stream);
+                       int32_t in_row_group, void* stream);
+
+
+/* timm Attention core: softmax(q k^T * scale) v per head, flash-style (the N x N matrix is never
+ * written).  qkv: bf16 [B, N, 3, H, 64] = the fused qkv Linear output (row stride ld elements);
+ * o: bf16 [B, N, H*64] (row stride ldo); lse: f32 [B, H, N] log-sum-exp saved for backward (NULL ok).
+ * head_dim must be 64 (ViT-B/16: 12 heads, ViT-L: 16 heads). */
+int vdk_attention_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H,
+                      int32_t head_dim, float scale, void* stream);
+/* backward: dqkv bf16 [B, N, 3, H, 64] (row stride lddqkv); dvec: f32 scratch [B, H, N]. */
+int vdk_attention_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv,
+                      int64_t lddqkv, float* dvec, int32_t B, int32_t N, int32_t H, int32_t head_dim, float scale, void* stream);
+
+/* F.layer_norm over the last dim (timm blocks' norm1/norm2 and the final norm, eps 1e-6).  x: f32 rows at
+ * stride ldx (so the final norm can run on the cls rows only: ldx = N*C); y: bf16 or f32; mean/rstd: f32 [T]
+ * saved for backward (NULL ok).  C % 4 == 0. */
+int vdk_layernorm_fwd(const float* x, int64_t ldx, int32_t T, int32_t C, const float* gamma, const float* beta, float eps,
+                      void* y, int64_t ldy, int32_t y_dtype, float* mean, float* rstd, void* stream);
+/* backward: dx = LN'(dy) [+ dres] as f32 (dx) and/or bf16 (dxb); dgamma, dbeta f32 [C] overwritten. */
+int vdk_layernorm_bwd_workspace_bytes(int32_t T, int32_t C, size_t* bytes);
+int vdk_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean,
+                      const float* rstd, const float* gamma, const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx,
+                      int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                      void* stream);
+
+/* out[c] = scale * sum_{s<S} in[s*ld + c]  (deterministic; pos_embed/cls gradients, partial combines) */
+int vdk_reduce_rows_f32(const float* in, int64_t ld, int32_t S, int64_t n, float* out, float scale, void* stream);
+/* out[c] = sum_r in[r][c], in bf16 [T, N] — bias gradient of a Linear */
+int vdk_colsum_bf16_workspace_bytes(int32_t T, int32_t N, size_t* bytes);
+int vdk_colsum_bf16(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* nn.CrossEntropyLoss(label_smoothing) fwd+bwd in one pass — models/losses/loss.py:71-73; with yb != NULL it is
+ * mixup_criterion (engine/procedure/train.py:34-35): lam*CE(ya) + (1-lam)*CE(yb).
+ * loss_rows f32 [B] (caller averages); dlogits = grad_scale * dLoss_row/dlogits as bf16 [B, lddl] (columns
+ * C..lddl-1 zeroed: they pad the contraction dim of the head GEMMs) and/or f32 [B, lddf]. */
+int vdk_softmax_ce(const float* logits, int64_t ldl, int32_t B, int32_t C, const int64_t* ya, const int64_t* yb, float lam,
+                   float label_smoothing, float grad_scale, float* loss_rows, void* dlogits_bf16, int64_t lddl,
+                   float* dlogits_f32, int64_t lddf, void* stream);
+/* nn.BCEWithLogitsLoss — models/losses/loss.py:68-70.  loss_rows[b] = sum_c loss(b,c) (caller divides by B*C). */
+int vdk_bce_logits(const float* logits, int64_t ldl, const float* targets, int64_t ldt, int32_t B, int32_t C, float grad_scale,
+                   float* loss_rows, void* dlogits_bf16, int64_t lddl, float* dlogits_f32, int64_t lddf, void* stream);
+
+/* PatchEmbed.proj (Conv2d(3, D, p, stride p)) as an im2col-free GEMM operand: out bf16 [B*gh*gw, Kp],
+ * column k = c*p*p + ky*p + kx, zero-padded to Kp (Kp % 8 == 0). */
+int vdk_patchify_bf16(const float* x, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t patch, void* out, int32_t Kp,
+                      void* stream);
+/* tok[b, 0, :] = cls_token + pos_embed[0]  (timm _pos_embed: cat cls, then add pos) */
+int vdk_cls_rows(float* tok, int64_t batch_stride, int32_t B, int32_t D, const float* cls, const float* pos0, void* stream);
+int vdk_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream);
+/* out[c][r] (bf16) = in[r][c] (f32): the [in,out] copy of a Linear weight for dgrad */
+int vdk_transpose_cast_f32_bf16(const float* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, int32_t Rpad,
+                                void* stream);
+
+/* ---- fused multi-tensor step over FLAT buffers -------------------------------------------------
+ * Trainer.update (engine/procedure/train.py:203-215): [scaler.unscale_] -> clip_grad_norm_(max_norm=10) ->
+ * optimizer.step (torch.optim.SGD momentum/weight_decay, engine/optimizer.py:119-121) -> ema.update
+ * (models/ema.py:28-37), plus the bf16 refresh of the weights the GEMMs read. */
+int vdk_sumsq_workspace_bytes(size_t* bytes);
+int vdk_sumsq_f32(const float* g, int64_t n, float* out, void* ws, size_t ws_bytes, void* stream);
+int vdk_sgd_step(float* params, const float* grads, float* momentum_buf, float* ema, void* params_bf16, int64_t n, float lr,
+                 float momentum, float weight_decay, float grad_scale, const float* normsq, float max_norm, float ema_decay,
+                 int32_t first_step, void* stream);
+/* mixup_data (engine/procedure/train.py:24-32): out[b] = lam*x[b] + (1-lam)*x[perm[b]] */
+int vdk_mixup(const float* x, const int64_t* perm, float lam, int32_t B, int64_t per_sample, float* out, void* stream);
 
 #ifdef __cplusplus
 }

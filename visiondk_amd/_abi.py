@@ -21,7 +21,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("A", P), ("lda", I64), ("B", P), ("ldb", I64), ("C", P), ("ldc", I64),
                 ("M", I32), ("N", I32), ("K", I32), ("c_dtype", I32),
                 ("bias", P), ("residual", P), ("ldr", I64), ("act", I32), ("aux", P), ("ldaux", I64),
-                ("alpha", F32), ("splitk", I32)]
+                ("alpha", F32), ("splitk", I32), ("row_group", I32)]
 
 
 BF16, F32_ = 0, 1
@@ -40,7 +40,25 @@ SIGNATURES: dict[str, tuple] = {
     # hot path A: dense ops
     "vdk_gemm_splitk_workspace_bytes": (C.c_int, [I32, I32, I32, PSZ]),
     "vdk_gemm_bf16_nt": (C.c_int, [C.POINTER(GemmDesc), P, SZ, P]),
-    "vdk_transpose_bf16": (C.c_int, [P, I64, I32, I32, P, I64, I32, P]),
+    "vdk_transpose_bf16": (C.c_int, [P, I64, I32, I32, P, I64, I32, I32, P]),
+    "vdk_attention_fwd": (C.c_int, [P, I64, P, I64, P, I32, I32, I32, I32, F32, P]),
+    "vdk_attention_bwd": (C.c_int, [P, I64, P, P, I64, P, P, I64, P, I32, I32, I32, I32, F32, P]),
+    "vdk_layernorm_fwd": (C.c_int, [P, I64, I32, I32, P, P, F32, P, I64, I32, P, P, P]),
+    "vdk_layernorm_bwd_workspace_bytes": (C.c_int, [I32, I32, PSZ]),
+    "vdk_layernorm_bwd": (C.c_int, [P, I64, I32, P, I64, P, P, P, P, I64, I32, I32, P, I64, P, I64, P, P, P, SZ, P]),
+    "vdk_reduce_rows_f32": (C.c_int, [P, I64, I32, I64, P, F32, P]),
+    "vdk_colsum_bf16_workspace_bytes": (C.c_int, [I32, I32, PSZ]),
+    "vdk_colsum_bf16": (C.c_int, [P, I64, I32, I32, P, P, SZ, P]),
+    "vdk_softmax_ce": (C.c_int, [P, I64, I32, I32, P, P, F32, F32, F32, P, P, I64, P, I64, P]),
+    "vdk_bce_logits": (C.c_int, [P, I64, P, I64, I32, I32, F32, P, P, I64, P, I64, P]),
+    "vdk_patchify_bf16": (C.c_int, [P, I32, I32, I32, I32, I32, P, I32, P]),
+    "vdk_cls_rows": (C.c_int, [P, I64, I32, I32, P, P, P]),
+    "vdk_cast_f32_bf16": (C.c_int, [P, P, I64, P]),
+    "vdk_transpose_cast_f32_bf16": (C.c_int, [P, I64, I32, I32, P, I64, I32, P]),
+    "vdk_sumsq_workspace_bytes": (C.c_int, [PSZ]),
+    "vdk_sumsq_f32": (C.c_int, [P, I64, P, P, SZ, P]),
+    "vdk_sgd_step": (C.c_int, [P, P, P, P, P, I64, F32, F32, F32, F32, P, F32, F32, I32, P]),
+    "vdk_mixup": (C.c_int, [P, P, F32, I32, I64, P, P]),
 }
 
 

@@ -1,0 +1,244 @@
+// elementwise_optim.hip — the HBM-bound glue of hot path A, each a single wide-access pass:
+//   * patchify+cast: im2col-free operand for PatchEmbed's k=stride conv (timm PatchEmbed.proj,
+//     Conv2d(3, D, p, p); reference builds it at models/classifier/classify_model.py:49-54)
+//   * cls-token rows, weight casts (fp32 master -> bf16 [out,in] and transposed [in,out])
+//   * K16/K15/K17 fused multi-tensor step over FLAT parameter buffers: global-norm clip
+//     (engine/procedure/train.py:209 clip_grad_norm_(max_norm=10)), SGD momentum + weight decay
+//     (engine/optimizer.py:119-121 -> torch.optim.SGD), EMA (models/ema.py:28-37), bf16 weight refresh
+//   * K18 mixup blend (engine/procedure/train.py:24-32)
+#include <hip/hip_runtime.h>
+#include "vdk_device.h"
+#include "vdk_host.h"
+
+// P[(b*gh*gw + gy*gw + gx)][c*ps*ps + ky*ps + kx] = x[b][c][gy*ps+ky][gx*ps+kx]   (bf16, K padded to Kp with 0)
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, int B, int Cin, int H, int W, int ps,
+                                                       bf16_t* __restrict__ out, int Kp) {
+  const int gh = H / ps, gw = W / ps, K = Cin * ps * ps;
+  const long nchunk = (long)B * gh * gw * (Kp / 8);
+  long id = (long)blockIdx.x * 256 + threadIdx.x;
+  if (id >= nchunk) return;
+  const int kc = (int)(id % (Kp / 8)) * 8;
+  const long m = id / (Kp / 8);
+  const int gx = (int)(m % gw), gy = (int)((m / gw) % gh), b = (int)(m / ((long)gw * gh));
+  float v[8];
+  if ((ps & 7) == 0 && kc + 8 <= K) {
+    const int c = kc / (ps * ps), rem = kc % (ps * ps), ky = rem / ps, kx = rem % ps;
+    const float* src = x + (((long)b * Cin + c) * H + gy * ps + ky) * W + gx * ps + kx;
+    if ((((size_t)src) & 15) == 0) {
+      f32x4 a = *(const f32x4*)src, bq = *(const f32x4*)(src + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = bq[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = src[e];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = kc + e;
+      float t = 0.f;
+      if (k < K) {
+        const int c = k / (ps * ps), rem = k % (ps * ps), ky = rem / ps, kx = rem % ps;
+        t = x[(((long)b * Cin + c) * H + gy * ps + ky) * W + gx * ps + kx];
+      }
+      v[e] = t;
+    }
+  }
+  *(u32x4*)(out + m * Kp + kc) = (u32x4){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+}
+
+// tok[b][0][:] = cls + pos[0]
+__global__ __launch_bounds__(256) void cls_rows_kernel(float* __restrict__ tok, long batch_stride, int B, int D,
+                                                       const float* __restrict__ cls, const float* __restrict__ pos0) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * D) return;
+  int b = (int)(i / D), d = (int)(i % D);
+  tok[(long)b * batch_stride + d] = cls[d] + pos0[d];
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n4) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 v = *(const f32x4*)(in + i * 4);
+  *(u32x2*)(out + i * 4) = (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+}
+
+// out[c][r] (bf16, ld ldo) = in[r][c] (fp32, ld ldi); zero-fills rows r in [R, Rpad) of the output columns
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ in, long ldi, int R, int Cc,
+                                                             bf16_t* __restrict__ out, long ldo, int Rpad) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tid = threadIdx.x;
+  for (int i = 0; i < 16; ++i) {
+    int row = i * 4 + (tid >> 6), col = tid & 63;
+    int gr = r0 + row, gc = c0 + col;
+    tile[row][col] = (gr < R && gc < Cc) ? in[(long)gr * ldi + gc] : 0.f;
+  }
+  __syncthreads();
+  for (int i = 0; i < 16; ++i) {
+    int col = i * 4 + (tid >> 6), row = tid & 63;  // output row = input col
+    int gc = c0 + col, gr = r0 + row;
+    if (gc < Cc && gr < Rpad) out[(long)gc * ldo + gr] = f2bf(tile[row][col]);
+  }
+}
+
+// partial[b] = sum of g[i]^2 over the block's slice
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 v = *(const f32x4*)(g + i * 4);
+    s = fmaf(v[0], v[0], s); s = fmaf(v[1], v[1], s); s = fmaf(v[2], v[2], s); s = fmaf(v[3], v[3], s);
+  }
+  if (blockIdx.x == 0) for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) s = fmaf(g[i], g[i], s);
+  s = block_sum<4>(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int nb, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
+  s = block_sum<4>(s, red);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+struct SgdArgs {
+  float* p; const float* g; float* m; float* ema; bf16_t* pb;
+  long n;
+  float lr, momentum, weight_decay, max_norm, ema_decay, grad_scale;
+  const float* normsq;   // device scalar: sum g^2 (before grad_scale); NULL = no clipping
+  int first_step;
+};
+// torch.nn.utils.clip_grad_norm_: coef = clamp(max_norm / (norm + 1e-6), max=1); g *= coef
+// torch.optim.SGD (nesterov=False, dampening=0): g += wd*p; buf = first ? g : mom*buf + g; p -= lr*buf
+// ModelEMA.update: v = d*v + (1-d)*p
+__global__ __launch_bounds__(256) void sgd_step_kernel(SgdArgs a) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long n4 = (a.n + 3) >> 2;
+  if (i >= n4) return;
+  float coef = a.grad_scale;
+  if (a.normsq) {
+    float nrm = sqrtf(a.normsq[0]) * fabsf(a.grad_scale);
+    float c = a.max_norm / (nrm + 1e-6f);
+    coef *= (c < 1.0f ? c : 1.0f);
+  }
+  const long base = i * 4;
+  if (base + 4 <= a.n) {
+    f32x4 p = *(const f32x4*)(a.p + base), g = *(const f32x4*)(a.g + base);
+    f32x4 m = a.first_step ? (f32x4){0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(a.m + base);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gg = g[e] * coef + a.weight_decay * p[e];
+      float buf = a.first_step ? gg : a.momentum * m[e] + gg;
+      m[e] = buf;
+      p[e] = p[e] - a.lr * buf;
+    }
+    *(f32x4*)(a.p + base) = p;
+    *(f32x4*)(a.m + base) = m;
+    if (a.ema) {
+      f32x4 v = *(const f32x4*)(a.ema + base);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] * a.ema_decay + (1.0f - a.ema_decay) * p[e];
+      *(f32x4*)(a.ema + base) = v;
+    }
+    if (a.pb) *(u32x2*)(a.pb + base) = (u32x2){pack_bf2(p[0], p[1]), pack_bf2(p[2], p[3])};
+  } else {
+    for (long j = base; j < a.n; ++j) {
+      float p = a.p[j];
+      float gg = a.g[j] * coef + a.weight_decay * p;
+      float buf = a.first_step ? gg : a.momentum * a.m[j] + gg;
+      a.m[j] = buf;
+      p -= a.lr * buf;
+      a.p[j] = p;
+      if (a.ema) a.ema[j] = a.ema[j] * a.ema_decay + (1.0f - a.ema_decay) * p;
+      if (a.pb) a.pb[j] = f2bf(p);
+    }
+  }
+}
+
+// out[b] = lam * x[b] + (1 - lam) * x[perm[b]]   (mixup_data, train.py:24-32)
+__global__ __launch_bounds__(256) void mixup_kernel(const float* __restrict__ x, const long long* __restrict__ perm, float lam,
+                                                    long per_sample4, int B, float* __restrict__ out) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= per_sample4 * B) return;
+  int b = (int)(i / per_sample4); long o = i % per_sample4;
+  f32x4 a = *(const f32x4*)(x + ((long)b * per_sample4 + o) * 4);
+  f32x4 c = *(const f32x4*)(x + ((long)perm[b] * per_sample4 + o) * 4);
+  *(f32x4*)(out + i * 4) = a * lam + c * (1.0f - lam);
+}
+
+extern "C" {
+
+int vdk_patchify_bf16(const float* x, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t patch, void* out, int32_t Kp,
+                      void* stream) {
+  if (!x || !out || B <= 0 || Cin <= 0 || patch <= 0 || H % patch || W % patch || (Kp & 7) || Kp < Cin * patch * patch)
+    return vdk_fail(VDK_EINVAL, "vdk_patchify_bf16: bad argument");
+  long nchunk = (long)B * (H / patch) * (W / patch) * (Kp / 8);
+  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (int)B, (int)Cin,
+                     (int)H, (int)W, (int)patch, (bf16_t*)out, (int)Kp);
+  return vdk_check_launch("vdk_patchify_bf16");
+}
+
+int vdk_cls_rows(float* tok, int64_t batch_stride, int32_t B, int32_t D, const float* cls, const float* pos0, void* stream) {
+  if (!tok || !cls || !pos0 || B <= 0 || D <= 0) return vdk_fail(VDK_EINVAL, "vdk_cls_rows: bad argument");
+  hipLaunchKernelGGL(cls_rows_kernel, dim3((unsigned)(((long)B * D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tok,
+                     (long)batch_stride, (int)B, (int)D, cls, pos0);
+  return vdk_check_launch("vdk_cls_rows");
+}
+
+int vdk_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream) {
+  if (!in || !out || n < 0 || (n & 3)) return vdk_fail(VDK_EINVAL, "vdk_cast_f32_bf16: n % 4 == 0 required");
+  if (n == 0) return VDK_OK;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out,
+                     (long)(n / 4));
+  return vdk_check_launch("vdk_cast_f32_bf16");
+}
+
+int vdk_transpose_cast_f32_bf16(const float* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, int32_t Rpad,
+                                void* stream) {
+  if (!in || !out || R <= 0 || C <= 0 || Rpad < R || ldo < Rpad) return vdk_fail(VDK_EINVAL, "vdk_transpose_cast_f32_bf16: bad argument");
+  hipLaunchKernelGGL(transpose_cast_kernel, dim3((unsigned)((Rpad + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0,
+                     (hipStream_t)stream, in, (long)ldi, (int)R, (int)C, (bf16_t*)out, (long)ldo, (int)Rpad);
+  return vdk_check_launch("vdk_transpose_cast_f32_bf16");
+}
+
+#define SUMSQ_BLOCKS 1024
+int vdk_sumsq_workspace_bytes(size_t* bytes) { if (!bytes) return vdk_fail(VDK_EINVAL, "null"); *bytes = SUMSQ_BLOCKS * 4; return VDK_OK; }
+// out[0] = sum g[i]^2 (deterministic two-stage reduce); g 16-B aligned
+int vdk_sumsq_f32(const float* g, int64_t n, float* out, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!g || !out || n < 0) return vdk_fail(VDK_EINVAL, "vdk_sumsq_f32: bad argument");
+  if (!ws || ws_bytes < SUMSQ_BLOCKS * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_sumsq_f32: workspace too small");
+  long n4 = n / 4;
+  int nb = (int)((n4 + 255) / 256); if (nb > SUMSQ_BLOCKS) nb = SUMSQ_BLOCKS; if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3((unsigned)nb), dim3(256), 0, stream, g, (long)n, (float*)ws);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, nb, out);
+  return vdk_check_launch("vdk_sumsq_f32");
+}
+
+// One fused pass over flat buffers: [clip by global norm] -> SGD(momentum, wd) -> [EMA] -> [bf16 refresh].
+// grad_scale multiplies g first (1/loss_scale, or 1/world for summed all-reduce).  normsq = device scalar
+// holding sum g^2 of the UNscaled grads, or NULL to skip clipping.  m / ema / params_bf16 may be NULL.
+int vdk_sgd_step(float* params, const float* grads, float* momentum_buf, float* ema, void* params_bf16, int64_t n, float lr,
+                 float momentum, float weight_decay, float grad_scale, const float* normsq, float max_norm, float ema_decay,
+                 int32_t first_step, void* stream) {
+  if (!params || !grads || !momentum_buf || n < 0) return vdk_fail(VDK_EINVAL, "vdk_sgd_step: bad argument");
+  if (n == 0) return VDK_OK;
+  SgdArgs a;
+  a.p = params; a.g = grads; a.m = momentum_buf; a.ema = ema; a.pb = (bf16_t*)params_bf16; a.n = n;
+  a.lr = lr; a.momentum = momentum; a.weight_decay = weight_decay; a.max_norm = max_norm; a.ema_decay = ema_decay;
+  a.grad_scale = grad_scale; a.normsq = normsq; a.first_step = first_step;
+  long n4 = (n + 3) / 4;
+  hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return vdk_check_launch("vdk_sgd_step");
+}
+
+int vdk_mixup(const float* x, const int64_t* perm, float lam, int32_t B, int64_t per_sample, float* out, void* stream) {
+  if (!x || !perm || !out || B <= 0 || per_sample <= 0 || (per_sample & 3)) return vdk_fail(VDK_EINVAL, "vdk_mixup: bad argument");
+  long tot = per_sample / 4 * B;
+  hipLaunchKernelGGL(mixup_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (const long long*)perm, lam,
+                     (long)(per_sample / 4), (int)B, out);
+  return vdk_check_launch("vdk_mixup");
+}
+
+}  // extern "C"

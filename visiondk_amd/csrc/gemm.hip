@@ -125,9 +125,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmParams p) {
 #pragma unroll 1
   for (int pass = 0; pass < 8; ++pass) {
     const int row = pass * 16 + (tid >> 4);
-    const long m = m0 + row;
+    const long mi = m0 + row;
     const int n = n0 + cc;
-    if (m >= p.M || n >= p.N) continue;
+    if (mi >= p.M || n >= p.N) continue;
+    // token-row remap (patch embedding -> token buffer): output row skips one cls slot per group and the
+    // residual (pos_embed) row repeats per group
+    const long m = p.row_group > 0 ? mi + mi / p.row_group + 1 : mi;
+    const long mr = p.row_group > 0 ? mi % p.row_group + 1 : mi;
     float v[8];
     {
       f32x4 x0 = *(const f32x4*)(Cs + row * G_CP + cc);
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmParams p) {
       for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
     }
     if (p.splitk > 1) {  // raw fp32 partials; the reduce kernel finishes the job
-      float* dst = p.slabs + ((long)z * p.M + m) * p.N + n;
+      float* dst = p.slabs + ((long)z * p.M + mi) * p.N + n;
       *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
       *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
       continue;
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmParams p) {
       }
     }
     if (p.residual) {
-      const float* rs = p.residual + m * p.ldr + n;
+      const float* rs = p.residual + mr * p.ldr + n;
       f32x4 r0 = *(const f32x4*)rs, r1 = *(const f32x4*)(rs + 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // out[c][r] = in[r][c] for r < R, 0 for R <= r < Rpad (bf16).  64x64 tiles through LDS.
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, long ldi, int R, int Cc,
-                                                             bf16_t* __restrict__ out, long ldo, int Rpad) {
+                                                             bf16_t* __restrict__ out, long ldo, int Rpad, int row_group) {
   __shared__ bf16_t tile[64][66];
   const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int tid = threadIdx.x;
@@ -210,8 +214,9 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
     int gr = r0 + row, gc = c0 + cw;
     bf16_t v0 = 0, v1 = 0;
     if (gr < R) {
-      if (gc + 1 < Cc) { unsigned wv = *(const unsigned*)(in + (long)gr * ldi + gc); v0 = (bf16_t)(wv & 0xffff); v1 = (bf16_t)(wv >> 16); }
-      else if (gc < Cc) v0 = in[(long)gr * ldi + gc];
+      const long sr = row_group > 0 ? (long)gr + gr / row_group + 1 : (long)gr;  // skip one cls row per group
+      if (gc + 1 < Cc) { unsigned wv = *(const unsigned*)(in + sr * ldi + gc); v0 = (bf16_t)(wv & 0xffff); v1 = (bf16_t)(wv >> 16); }
+      else if (gc < Cc) v0 = in[sr * ldi + gc];
     }
     tile[row][cw] = v0; tile[row][cw + 1] = v1;
   }
@@ -252,11 +257,11 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.c_dtype = d->c_dtype; p.bias = (const float*)d->bias; p.residual = (const float*)d->residual; p.ldr = d->ldr;
-  p.act = d->act; p.aux = (bf16_t*)d->aux; p.ldaux = d->ldaux; p.alpha = d->alpha;
+  p.act = d->act; p.aux = (bf16_t*)d->aux; p.ldaux = d->ldaux; p.alpha = d->alpha; p.row_group = d->row_group;
   p.splitk = splitk; p.slabs = nullptr;
   int kps = d->K;
   if (splitk > 1) {
-    if (d->bias || d->residual || d->act != VDK_ACT_NONE) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: split-K excludes fused epilogues");
+    if (d->bias || d->residual || d->act != VDK_ACT_NONE || d->row_group > 0) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: split-K excludes fused epilogues");
     if (d->ldc != d->N) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: split-K needs ldc == N");
     kps = ((d->K + splitk - 1) / splitk + G_BK - 1) / G_BK * G_BK;
     splitk = (d->K + kps - 1) / kps;
@@ -281,13 +286,14 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
 }
 
 // out[C][ldo] (bf16) = in[R][ldi]^T, rows R..Rpad-1 of the contraction dim zero-filled.  Rpad even.
+// in_row_group > 0: logical row r is read from physical row r + r / in_row_group + 1 (token buffer minus cls rows).
 int vdk_transpose_bf16(const void* in, int64_t ldi, int32_t R, int32_t Cc, void* out, int64_t ldo, int32_t Rpad,
-                       void* stream) {
+                       int32_t in_row_group, void* stream) {
   if (!in || !out || R < 0 || Cc <= 0 || Rpad < R || (Rpad & 1) || ldo < Rpad || (ldi & 1) || (ldo & 1))
     return vdk_fail(VDK_EINVAL, "vdk_transpose_bf16: bad argument");
   if (Rpad == 0) return VDK_OK;
   hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((Rpad + 63) / 64), (unsigned)((Cc + 63) / 64)), dim3(256), 0,
-                     (hipStream_t)stream, (const bf16_t*)in, (long)ldi, (int)R, (int)Cc, (bf16_t*)out, (long)ldo, (int)Rpad);
+                     (hipStream_t)stream, (const bf16_t*)in, (long)ldi, (int)R, (int)Cc, (bf16_t*)out, (long)ldo, (int)Rpad, (int)in_row_group);
   return vdk_check_launch("vdk_transpose_bf16");
 }
 

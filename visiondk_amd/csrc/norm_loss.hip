@@ -1,0 +1,315 @@
+// norm_loss.hip — K4 LayerNorm fwd/bwd (timm LayerNorm eps=1e-6 inside vision_transformer blocks and the
+// final `norm`; F.layer_norm over the last dim), column reductions (bias / gamma / beta / pos_embed
+// gradients) and K10 softmax cross-entropy with label smoothing (+ mixup pairs) fwd+bwd
+// (models/losses/loss.py:71-73 `nn.CrossEntropyLoss(label_smoothing)`, engine/procedure/train.py:24-35
+// mixup_criterion; BCE-with-logits loss.py:68-70).  All HBM-bound: one wave per row, 16-B accesses.
+#include <hip/hip_runtime.h>
+#include "vdk_device.h"
+#include "vdk_host.h"
+
+// ------------------------------------------------------------------------------------------------
+// y[r] = (x[r] - mean) * rstd * gamma + beta  (x fp32 rows at stride ldx; y bf16 or fp32; C % 4 == 0)
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx, int T, int C,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, void* __restrict__ y, long ldy, float* __restrict__ mean,
+                                                     float* __restrict__ rstd) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= T) return;
+  const float* xr = x + (long)row * ldx;
+  float s = 0.f;
+  for (int c = lane * 4; c < C; c += 256) { f32x4 v = *(const f32x4*)(xr + c); s += (v[0] + v[1]) + (v[2] + v[3]); }
+  const float mu = wave_sum(s) / (float)C;
+  float q = 0.f;
+  for (int c = lane * 4; c < C; c += 256) {
+    f32x4 v = *(const f32x4*)(xr + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { float d = v[e] - mu; q = fmaf(d, d, q); }
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+  for (int c = lane * 4; c < C; c += 256) {
+    f32x4 v = *(const f32x4*)(xr + c);
+    f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[e] - mu) * rs * g[e] + b[e];
+    if (OUT_BF16) *(u32x2*)((bf16_t*)y + (long)row * ldy + c) = (u32x2){pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+    else *(f32x4*)((float*)y + (long)row * ldy + c) = (f32x4){o[0], o[1], o[2], o[3]};
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ dres],  g = dy * gamma;  per-block partial
+// dgamma = sum dy * xhat, dbeta = sum dy.   MAXJ * 256 >= C.
+template <int MAXJ, bool DY_BF16>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, long lddy, const float* __restrict__ x,
+                                                     long ldx, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                     long lddres, int T, int C, int rows_per_block, float* __restrict__ dx,
+                                                     long lddx, bf16_t* __restrict__ dxb, long lddxb,
+                                                     float* __restrict__ pgamma, float* __restrict__ pbeta) {
+  __shared__ float red[2][4][MAXJ * 256];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block; if (r1 > T) r1 = T;
+  float ag[MAXJ][4], ab[MAXJ][4];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; }
+  const float invC = 1.0f / (float)C;
+  for (int row = r0 + w; row < r1; row += 4) {
+    const float mu = mean[row], rs = rstd[row];
+    const float* xr = x + (long)row * ldx;
+    float s1 = 0.f, s2 = 0.f;
+    float gk[MAXJ][4], xh[MAXJ][4];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = lane * 4 + j * 256;
+      if (c < C) {
+        f32x4 xv = *(const f32x4*)(xr + c);
+        f32x4 gm = *(const f32x4*)(gamma + c);
+        float d[4];
+        if (DY_BF16) {
+          u32x2 u = *(const u32x2*)((const bf16_t*)dy + (long)row * lddy + c);
+          d[0] = bf_lo(u[0]); d[1] = bf_hi(u[0]); d[2] = bf_lo(u[1]); d[3] = bf_hi(u[1]);
+        } else {
+          f32x4 u = *(const f32x4*)((const float*)dy + (long)row * lddy + c);
+          d[0] = u[0]; d[1] = u[1]; d[2] = u[2]; d[3] = u[3];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float h = (xv[e] - mu) * rs;
+          float g = d[e] * gm[e];
+          xh[j][e] = h; gk[j][e] = g;
+          s1 += g; s2 = fmaf(g, h, s2);
+          ag[j][e] = fmaf(d[e], h, ag[j][e]);
+          ab[j][e] += d[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) * invC; s2 = wave_sum(s2) * invC;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = lane * 4 + j * 256;
+      if (c < C) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (gk[j][e] - s1 - xh[j][e] * s2);
+        if (dres) {
+          f32x4 rv = *(const f32x4*)(dres + (long)row * lddres + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] += rv[e];
+        }
+        if (dx) *(f32x4*)(dx + (long)row * lddx + c) = (f32x4){o[0], o[1], o[2], o[3]};
+        if (dxb) *(u32x2*)(dxb + (long)row * lddxb + c) = (u32x2){pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+      }
+    }
+  }
+  // combine the 4 waves' column partials
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[0][w][j * 256 + lane * 4 + e] = ag[j][e];
+      red[1][w][j * 256 + lane * 4 + e] = ab[j][e];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    pgamma[(long)blockIdx.x * C + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    pbeta[(long)blockIdx.x * C + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+  }
+}
+
+// out[c] = sum_{s<S} in[s*ld + c]   (deterministic; S small-ish: partials, batch dim)
+__global__ __launch_bounds__(256) void reduce_rows_f32_kernel(const float* __restrict__ in, long ld, int S, long n,
+                                                              float* __restrict__ out, float scale) {
+  long c = (long)blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) s += in[(long)k * ld + c];
+  out[c] = s * scale;
+}
+
+// partial[split][c] = sum over this split's rows of in[r][c]  (bf16 input, 2 columns per thread)
+__global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const bf16_t* __restrict__ in, long ld, int T, int N,
+                                                                  int rows_per_split, float* __restrict__ partial) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (c >= N) return;
+  const int r0 = blockIdx.y * rows_per_split;
+  int r1 = r0 + rows_per_split; if (r1 > T) r1 = T;
+  float s0 = 0.f, s1 = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    unsigned u = *(const unsigned*)(in + (long)r * ld + c);
+    s0 += bf_lo(u); s1 += bf_hi(u);
+  }
+  partial[(long)blockIdx.y * N + c] = s0;
+  partial[(long)blockIdx.y * N + c + 1] = s1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// softmax cross-entropy, label smoothing eps, optional mixup pair (yb, lam):
+//   loss_r = lse - (1-eps) * (lam * x[ya] + (1-lam) * x[yb]) - eps * mean_c(x)
+//   dlogits = gscale * (softmax - (1-eps) * (lam*1[ya] + (1-lam)*1[yb]) - eps/C)
+// one workgroup per row.  dlogits bf16 [B, lddl] with columns C..lddl-1 zeroed (they pad the K dim of
+// the head dgrad/wgrad GEMMs).
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, long ldl, int C,
+                                                         const long long* __restrict__ ya, const long long* __restrict__ yb,
+                                                         float lam, float eps, float gscale, float* __restrict__ loss_rows,
+                                                         bf16_t* __restrict__ dlogits, long lddl, float* __restrict__ dlogits_f32,
+                                                         long lddf) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* x = logits + (long)row * ldl;
+  float mx = -3.0e38f, sm = 0.f;
+  for (int c = tid; c < C; c += 256) { float v = x[c]; mx = fmaxf(mx, v); sm += v; }
+  mx = block_max<4>(mx, red);
+  sm = block_sum<4>(sm, red);
+  float se = 0.f;
+  for (int c = tid; c < C; c += 256) se += expf(x[c] - mx);
+  se = block_sum<4>(se, red);
+  const float lse = mx + logf(se);
+  const int a = (int)ya[row];
+  const int b = yb ? (int)yb[row] : a;
+  const float wa = yb ? lam : 1.0f, wb = yb ? (1.0f - lam) : 0.0f;
+  if (tid == 0 && loss_rows)
+    loss_rows[row] = lse - (1.0f - eps) * (wa * x[a] + wb * x[b]) - eps * (sm / (float)C);
+  const float inv = 1.0f / se, epsc = eps / (float)C;
+  for (int c = tid; c < (int)lddl || c < C; c += 256) {
+    float g = 0.f;
+    if (c < C) {
+      g = expf(x[c] - mx) * inv - epsc;
+      if (c == a) g -= (1.0f - eps) * wa;
+      if (c == b) g -= (1.0f - eps) * wb;
+      g *= gscale;
+      if (dlogits_f32) dlogits_f32[(long)row * lddf + c] = g;
+    }
+    if (dlogits && c < (int)lddl) dlogits[(long)row * lddl + c] = f2bf(g);
+  }
+}
+
+// BCE-with-logits (mean over all elements): loss_e = max(x,0) - x*t + log1p(exp(-|x|)); d = (sigmoid(x)-t)*gscale
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ logits, long ldl, const float* __restrict__ tgt,
+                                                         long ldt, int C, float gscale, float* __restrict__ loss_rows,
+                                                         bf16_t* __restrict__ dlogits, long lddl, float* __restrict__ dlogits_f32,
+                                                         long lddf) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  float s = 0.f;
+  for (int c = tid; c < (int)lddl || c < C; c += 256) {
+    float g = 0.f;
+    if (c < C) {
+      float x = logits[(long)row * ldl + c], t = tgt[(long)row * ldt + c];
+      s += fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+      g = (1.0f / (1.0f + expf(-x)) - t) * gscale;
+      if (dlogits_f32) dlogits_f32[(long)row * lddf + c] = g;
+    }
+    if (dlogits && c < (int)lddl) dlogits[(long)row * lddl + c] = f2bf(g);
+  }
+  s = block_sum<4>(s, red);
+  if (tid == 0 && loss_rows) loss_rows[row] = s;
+}
+
+extern "C" {
+
+int vdk_layernorm_fwd(const float* x, int64_t ldx, int32_t T, int32_t C, const float* gamma, const float* beta, float eps,
+                      void* y, int64_t ldy, int32_t y_dtype, float* mean, float* rstd, void* stream) {
+  if (!x || !gamma || !beta || !y || T < 0 || C <= 0 || (C & 3) || (ldx & 3) || (ldy & 3))
+    return vdk_fail(VDK_EINVAL, "vdk_layernorm_fwd: bad argument (C, ldx, ldy % 4 == 0)");
+  if (T == 0) return VDK_OK;
+  dim3 grid((unsigned)((T + 3) / 4));
+  if (y_dtype == VDK_BF16)
+    hipLaunchKernelGGL((ln_fwd_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta,
+                       eps, y, (long)ldy, mean, rstd);
+  else
+    hipLaunchKernelGGL((ln_fwd_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta,
+                       eps, y, (long)ldy, mean, rstd);
+  return vdk_check_launch("vdk_layernorm_fwd");
+}
+
+int vdk_reduce_rows_f32(const float* in, int64_t ld, int32_t S, int64_t n, float* out, float scale, void* stream) {
+  if (!in || !out || S < 0 || n < 0) return vdk_fail(VDK_EINVAL, "vdk_reduce_rows_f32: bad argument");
+  if (n == 0) return VDK_OK;
+  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, (long)ld,
+                     (int)S, (long)n, out, scale);
+  return vdk_check_launch("vdk_reduce_rows_f32");
+}
+
+static inline int ln_bwd_blocks(int T) {
+  int nb = (T + 63) / 64;          // >= 64 rows per block keeps the partial buffers small
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  return nb;
+}
+int vdk_layernorm_bwd_workspace_bytes(int32_t T, int32_t C, size_t* bytes) {
+  if (!bytes || T < 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd_workspace_bytes: bad argument");
+  *bytes = (size_t)2 * ln_bwd_blocks(T) * C * 4;
+  return VDK_OK;
+}
+// dy: bf16 or f32 [T, lddy]; x f32 rows (ldx); dres optional f32 residual-stream gradient added to dx;
+// outputs dx (f32, optional), dxb (bf16 copy, optional), dgamma/dbeta [C] (overwritten).
+int vdk_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean,
+                      const float* rstd, const float* gamma, const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx,
+                      int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                      void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!dy || !x || !mean || !rstd || !gamma || !dgamma || !dbeta || T <= 0 || C <= 0 || (C & 3) || C > 4096)
+    return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: bad argument (C % 4 == 0, C <= 4096)");
+  const int nb = ln_bwd_blocks(T);
+  size_t need = (size_t)2 * nb * C * 4;
+  if (!ws || ws_bytes < need) return vdk_fail(VDK_EWORKSPACE, "vdk_layernorm_bwd: workspace too small");
+  float* pg = (float*)ws; float* pb = pg + (size_t)nb * C;
+  const int rpb = (T + nb - 1) / nb;
+  const bool bf = dy_dtype == VDK_BF16;
+#define LNB(MJ, BF) hipLaunchKernelGGL((ln_bwd_kernel<MJ, BF>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
+                                       mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb)
+  if (C <= 1024) { if (bf) LNB(4, true); else LNB(4, false); }
+  else { if (bf) LNB(16, true); else LNB(16, false); }
+#undef LNB
+  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, (const float*)pg, (long)C, nb,
+                     (long)C, dgamma, 1.0f);
+  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, (const float*)pb, (long)C, nb,
+                     (long)C, dbeta, 1.0f);
+  return vdk_check_launch("vdk_layernorm_bwd");
+}
+
+static inline int colsum_splits(int T) { int s = (T + 255) / 256; if (s > 256) s = 256; if (s < 1) s = 1; return s; }
+int vdk_colsum_bf16_workspace_bytes(int32_t T, int32_t N, size_t* bytes) {
+  if (!bytes || T < 0 || N <= 0) return vdk_fail(VDK_EINVAL, "vdk_colsum_bf16_workspace_bytes: bad argument");
+  *bytes = (size_t)colsum_splits(T) * N * 4;
+  return VDK_OK;
+}
+// out[c] = sum_r in[r][c]  (bias gradient of a Linear: column sum of dY), N % 2 == 0
+int vdk_colsum_bf16(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!in || !out || T <= 0 || N <= 0 || (N & 1) || (ld & 1)) return vdk_fail(VDK_EINVAL, "vdk_colsum_bf16: bad argument");
+  const int S = colsum_splits(T);
+  if (!ws || ws_bytes < (size_t)S * N * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_colsum_bf16: workspace too small");
+  const int rps = (T + S - 1) / S;
+  hipLaunchKernelGGL(colsum_bf16_partial_kernel, dim3((unsigned)((N / 2 + 255) / 256), (unsigned)S), dim3(256), 0, stream,
+                     (const bf16_t*)in, (long)ld, (int)T, (int)N, rps, (float*)ws);
+  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, (const float*)ws, (long)N, S,
+                     (long)N, out, 1.0f);
+  return vdk_check_launch("vdk_colsum_bf16");
+}
+
+int vdk_softmax_ce(const float* logits, int64_t ldl, int32_t B, int32_t C, const int64_t* ya, const int64_t* yb, float lam,
+                   float label_smoothing, float grad_scale, float* loss_rows, void* dlogits_bf16, int64_t lddl,
+                   float* dlogits_f32, int64_t lddf, void* stream) {
+  if (!logits || !ya || B <= 0 || C <= 0 || (dlogits_bf16 && lddl < C)) return vdk_fail(VDK_EINVAL, "vdk_softmax_ce: bad argument");
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, logits, (long)ldl, (int)C,
+                     (const long long*)ya, (const long long*)yb, lam, label_smoothing, grad_scale, loss_rows,
+                     (bf16_t*)dlogits_bf16, (long)(dlogits_bf16 ? lddl : 0), dlogits_f32, (long)lddf);
+  return vdk_check_launch("vdk_softmax_ce");
+}
+
+int vdk_bce_logits(const float* logits, int64_t ldl, const float* targets, int64_t ldt, int32_t B, int32_t C, float grad_scale,
+                   float* loss_rows, void* dlogits_bf16, int64_t lddl, float* dlogits_f32, int64_t lddf, void* stream) {
+  if (!logits || !targets || B <= 0 || C <= 0 || (dlogits_bf16 && lddl < C)) return vdk_fail(VDK_EINVAL, "vdk_bce_logits: bad argument");
+  hipLaunchKernelGGL(bce_logits_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, logits, (long)ldl, targets, (long)ldt,
+                     (int)C, grad_scale, loss_rows, (bf16_t*)dlogits_bf16, (long)(dlogits_bf16 ? lddl : 0), dlogits_f32, (long)lddf);
+  return vdk_check_launch("vdk_bce_logits");
+}
+
+}  // extern "C"

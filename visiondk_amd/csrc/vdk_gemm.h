@@ -15,10 +15,11 @@ struct GemmParams {
   int act;
   bf16_t* aux; long ldaux;
   float alpha;
+  int row_group;
   int splitk; int k_per_split;
   float* slabs;
 };
 
 // in-library launcher (no descriptor copy through the C ABI)
 extern "C" int vdk_gemm_bf16_nt(const VdkGemmDesc* d, void* ws, size_t ws_bytes, void* stream);
-extern "C" int vdk_transpose_bf16(const void* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, int32_t Rpad, void* stream);
+extern "C" int vdk_transpose_bf16(const void* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, int32_t Rpad, int32_t in_row_group, void* stream);

@@ -20,7 +20,8 @@ def _be(backend):
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=torch.bfloat16, bias: Optional[torch.Tensor] = None,
             residual: Optional[torch.Tensor] = None, act: int = ACT_NONE, aux: Optional[torch.Tensor] = None,
-            alpha: float = 1.0, splitk: int = 1, out: Optional[torch.Tensor] = None, backend=None) -> torch.Tensor:
+            alpha: float = 1.0, splitk: int = 1, out: Optional[torch.Tensor] = None, row_group: int = 0,
+            backend=None) -> torch.Tensor:
     """out[M,N] = epilogue(alpha * a[M,K] @ b[N,K].T); a, b bf16 (row stride may exceed K)."""
     be = _be(backend)
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
@@ -43,6 +44,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=torch.bfloat16, bias:
     d.ldaux = aux.stride(0) if aux is not None else 0
     d.alpha = alpha
     d.splitk = splitk
+    d.row_group = row_group
     for t in (a, b, out, residual, aux):
         if t is not None and be.device_only and not t.is_cuda:
             raise RuntimeError("visiondk_amd: HIP backend got a CPU tensor (there is no CPU fallback)")
@@ -57,14 +59,176 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=torch.bfloat16, bias:
     return out
 
 
-def transpose_pad(x: torch.Tensor, rpad: Optional[int] = None, backend=None) -> torch.Tensor:
+def transpose_pad(x: torch.Tensor, rpad: Optional[int] = None, backend=None, rows: Optional[int] = None,
+                  row_group: int = 0) -> torch.Tensor:
     """x bf16 [R, C] -> [C, Rpad] with zero-filled padding columns (Rpad even, default: R rounded up to 64)."""
     be = _be(backend)
     assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
     R, Cc = x.shape
+    if rows is not None:
+        R = rows
     if rpad is None:
         rpad = (R + 63) // 64 * 64
     out = torch.empty((Cc, rpad), dtype=torch.bfloat16, device=x.device)
     be.check(be.lib.vdk_transpose_bf16(be.ptr(x) if x.is_contiguous() else x.data_ptr(), x.stride(0), R, Cc,
-                                       be.ptr(out), rpad, rpad, be.stream()), "vdk_transpose_bf16")
+                                       be.ptr(out), rpad, rpad, row_group, be.stream()), "vdk_transpose_bf16")
+    return out
+
+
+def _ws(be, fn, *args, device):
+    need = C.c_size_t(0)
+    be.check(fn(*args, C.byref(need)), fn.__name__)
+    return torch.empty(max(need.value, 16), dtype=torch.uint8, device=device), need.value
+
+
+def attention_fwd(qkv: torch.Tensor, heads: int, scale: Optional[float] = None, backend=None):
+    """qkv bf16 [B, N, 3*heads*64] -> (o bf16 [B, N, heads*64], lse f32 [B, heads, N])."""
+    be = _be(backend)
+    B, N, three_d = qkv.shape
+    D = three_d // 3
+    hd = D // heads
+    scale = hd ** -0.5 if scale is None else scale
+    o = torch.empty((B, N, D), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
+    be.check(be.lib.vdk_attention_fwd(be.ptr(qkv), three_d, be.ptr(o), D, be.ptr(lse), B, N, heads, hd, scale, be.stream()),
+             "vdk_attention_fwd")
+    return o, lse
+
+
+def attention_bwd(qkv, o, dout, lse, heads: int, scale: Optional[float] = None, backend=None) -> torch.Tensor:
+    be = _be(backend)
+    B, N, three_d = qkv.shape
+    D = three_d // 3
+    hd = D // heads
+    scale = hd ** -0.5 if scale is None else scale
+    dqkv = torch.empty_like(qkv)
+    dvec = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
+    be.check(be.lib.vdk_attention_bwd(be.ptr(qkv), three_d, be.ptr(o), be.ptr(dout.contiguous()), D, be.ptr(lse), be.ptr(dqkv),
+                                      three_d, be.ptr(dvec), B, N, heads, hd, scale, be.stream()), "vdk_attention_bwd")
+    return dqkv
+
+
+def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float = 1e-6, out_dtype=torch.bfloat16, rows: Optional[int] = None,
+                  ldx: Optional[int] = None, backend=None):
+    """x f32 [T, C] (or a strided row view via rows/ldx) -> (y, mean, rstd)."""
+    be = _be(backend)
+    C_ = gamma.numel()
+    T = rows if rows is not None else x.numel() // C_
+    ldx = ldx if ldx is not None else C_
+    y = torch.empty((T, C_), dtype=out_dtype, device=x.device)
+    mean = torch.empty(T, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(T, dtype=torch.float32, device=x.device)
+    be.check(be.lib.vdk_layernorm_fwd(be.ptr(x), ldx, T, C_, be.ptr(gamma), be.ptr(beta), eps, be.ptr(y), C_,
+                                      _abi.BF16 if out_dtype == torch.bfloat16 else _abi.F32_, be.ptr(mean), be.ptr(rstd),
+                                      be.stream()), "vdk_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, want_bf16=True, backend=None):
+    """-> (dx f32 [T,C], dx bf16 or None, dgamma, dbeta)"""
+    be = _be(backend)
+    C_ = gamma.numel()
+    T = mean.numel()
+    dx = torch.empty((T, C_), dtype=torch.float32, device=x.device)
+    dxb = torch.empty((T, C_), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    dg = torch.empty(C_, dtype=torch.float32, device=x.device)
+    db = torch.empty(C_, dtype=torch.float32, device=x.device)
+    ws, n = _ws(be, be.lib.vdk_layernorm_bwd_workspace_bytes, T, C_, device=x.device)
+    be.check(be.lib.vdk_layernorm_bwd(be.ptr(dy), C_, _abi.BF16 if dy.dtype == torch.bfloat16 else _abi.F32_, be.ptr(x), C_,
+                                      be.ptr(mean), be.ptr(rstd), be.ptr(gamma), be.ptr(dres), C_, T, C_, be.ptr(dx), C_,
+                                      be.ptr(dxb), C_, be.ptr(dg), be.ptr(db), be.ptr(ws), n, be.stream()), "vdk_layernorm_bwd")
+    return dx, dxb, dg, db
+
+
+def reduce_rows(x: torch.Tensor, scale: float = 1.0, backend=None) -> torch.Tensor:
+    be = _be(backend)
+    S, n = x.shape[0], x[0].numel()
+    out = torch.empty(x.shape[1:], dtype=torch.float32, device=x.device)
+    be.check(be.lib.vdk_reduce_rows_f32(be.ptr(x), n, S, n, be.ptr(out), scale, be.stream()), "vdk_reduce_rows_f32")
+    return out
+
+
+def colsum_bf16(x: torch.Tensor, backend=None) -> torch.Tensor:
+    be = _be(backend)
+    T, N = x.shape
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    ws, n = _ws(be, be.lib.vdk_colsum_bf16_workspace_bytes, T, N, device=x.device)
+    be.check(be.lib.vdk_colsum_bf16(be.ptr(x), N, T, N, be.ptr(out), be.ptr(ws), n, be.stream()), "vdk_colsum_bf16")
+    return out
+
+
+def softmax_ce(logits, ya, yb=None, lam: float = 1.0, label_smoothing: float = 0.0, grad_scale: float = 1.0,
+               pad_to: Optional[int] = None, backend=None):
+    """-> (loss_rows f32 [B], dlogits bf16 [B, pad_to], dlogits f32 [B, C])"""
+    be = _be(backend)
+    B, C_ = logits.shape
+    pad_to = pad_to or (C_ + 7) // 8 * 8
+    loss = torch.empty(B, dtype=torch.float32, device=logits.device)
+    dlb = torch.empty((B, pad_to), dtype=torch.bfloat16, device=logits.device)
+    dlf = torch.empty((B, C_), dtype=torch.float32, device=logits.device)
+    be.check(be.lib.vdk_softmax_ce(be.ptr(logits), C_, B, C_, be.ptr(ya), be.ptr(yb), lam, label_smoothing, grad_scale,
+                                   be.ptr(loss), be.ptr(dlb), pad_to, be.ptr(dlf), C_, be.stream()), "vdk_softmax_ce")
+    return loss, dlb, dlf
+
+
+def bce_logits(logits, targets, grad_scale: float = 1.0, backend=None):
+    be = _be(backend)
+    B, C_ = logits.shape
+    pad_to = (C_ + 7) // 8 * 8
+    loss = torch.empty(B, dtype=torch.float32, device=logits.device)
+    dlb = torch.empty((B, pad_to), dtype=torch.bfloat16, device=logits.device)
+    dlf = torch.empty((B, C_), dtype=torch.float32, device=logits.device)
+    be.check(be.lib.vdk_bce_logits(be.ptr(logits), C_, be.ptr(targets), C_, B, C_, grad_scale, be.ptr(loss), be.ptr(dlb), pad_to,
+                                   be.ptr(dlf), C_, be.stream()), "vdk_bce_logits")
+    return loss, dlb, dlf
+
+
+def patchify(x: torch.Tensor, patch: int, backend=None) -> torch.Tensor:
+    be = _be(backend)
+    B, Cin, H, W = x.shape
+    K = Cin * patch * patch
+    Kp = (K + 7) // 8 * 8
+    out = torch.empty((B * (H // patch) * (W // patch), Kp), dtype=torch.bfloat16, device=x.device)
+    be.check(be.lib.vdk_patchify_bf16(be.ptr(x), B, Cin, H, W, patch, be.ptr(out), Kp, be.stream()), "vdk_patchify_bf16")
+    return out
+
+
+def cast_bf16(x: torch.Tensor, backend=None) -> torch.Tensor:
+    be = _be(backend)
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    be.check(be.lib.vdk_cast_f32_bf16(be.ptr(x), be.ptr(out), x.numel(), be.stream()), "vdk_cast_f32_bf16")
+    return out
+
+
+def transpose_cast(w: torch.Tensor, rpad: Optional[int] = None, backend=None) -> torch.Tensor:
+    """w f32 [R, C] -> bf16 [C, Rpad]"""
+    be = _be(backend)
+    R, Cc = w.shape
+    rpad = rpad or (R + 7) // 8 * 8
+    out = torch.empty((Cc, rpad), dtype=torch.bfloat16, device=w.device)
+    be.check(be.lib.vdk_transpose_cast_f32_bf16(be.ptr(w), Cc, R, Cc, be.ptr(out), rpad, rpad, be.stream()),
+             "vdk_transpose_cast_f32_bf16")
+    return out
+
+
+def sumsq(g: torch.Tensor, backend=None) -> torch.Tensor:
+    be = _be(backend)
+    out = torch.empty(1, dtype=torch.float32, device=g.device)
+    ws, n = _ws(be, be.lib.vdk_sumsq_workspace_bytes, device=g.device)
+    be.check(be.lib.vdk_sumsq_f32(be.ptr(g), g.numel(), be.ptr(out), be.ptr(ws), n, be.stream()), "vdk_sumsq_f32")
+    return out
+
+
+def sgd_step(p, g, m, *, lr, momentum, weight_decay, ema=None, p_bf16=None, grad_scale=1.0, normsq=None, max_norm=10.0,
+             ema_decay=0.0, first_step=False, backend=None) -> None:
+    be = _be(backend)
+    be.check(be.lib.vdk_sgd_step(be.ptr(p), be.ptr(g), be.ptr(m), be.ptr(ema), be.ptr(p_bf16), p.numel(), lr, momentum,
+                                 weight_decay, grad_scale, be.ptr(normsq), max_norm, ema_decay, int(first_step), be.stream()),
+             "vdk_sgd_step")
+
+
+def mixup(x: torch.Tensor, perm: torch.Tensor, lam: float, backend=None) -> torch.Tensor:
+    be = _be(backend)
+    out = torch.empty_like(x)
+    be.check(be.lib.vdk_mixup(be.ptr(x), be.ptr(perm), lam, x.shape[0], x[0].numel(), be.ptr(out), be.stream()), "vdk_mixup")
     return out
