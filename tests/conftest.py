@@ -30,3 +30,15 @@ def hip():
     assert torch.cuda.is_available(), "gpu test without a GPU"
     torch.cuda.set_device(0)
     return _lib.load()
+
+
+@pytest.fixture(params=["emu", pytest.param("hip", marks=pytest.mark.gpu)])
+def be(request):
+    """Every kernel parity test runs twice: on the CPU SIMT emulation (-m "not gpu") and, through the
+    same C ABI, on the real gfx950 library (-m gpu)."""
+    return request.getfixturevalue(request.param)
+
+
+@pytest.fixture
+def dev(be):
+    return "cuda" if be.device_only else "cpu"

@@ -21,20 +21,21 @@ def _ref(qkv, heads):
 
 
 @pytest.mark.parametrize("B,N,H", [(2, 17, 2), (1, 50, 1), (1, 197, 2), (1, 300, 1)])
-def test_attention_fwd_bwd(emu, B, N, H):
+def test_attention_fwd_bwd(be, dev, B, N, H):
     torch.manual_seed(0)
     D = H * 64
     qkv = (torch.randn(B, N, 3 * D) * 1.5).bfloat16()
-    qkv[0, N // 2, :D] *= 4.0   # a peaky row: exercises the online-softmax rescale
-    o, lse = ops.attention_fwd(qkv, H, backend=emu)
+    qkv[0, N // 2, :D] *= 4.0
+    qkv = qkv.to(dev)   # a peaky row: exercises the online-softmax rescale
+    o, lse = ops.attention_fwd(qkv, H, backend=be)
     qr = qkv.float().requires_grad_(True)
     oref, lseref = _ref(qr, H)
     assert _rel(lse, lseref) < 1e-5
     assert _rel(o.float(), oref) < 6e-3        # P and O are rounded to bf16 on the way
-    dout = torch.randn(B, N, D).bfloat16()
+    dout = torch.randn(B, N, D).bfloat16().to(dev)
     oref.backward(dout.float())
     # backward consumes the forward's own (bf16) o
-    dqkv = ops.attention_bwd(qkv, o, dout, lse, H, backend=emu)
+    dqkv = ops.attention_bwd(qkv, o, dout, lse, H, backend=be)
     for i, name in enumerate("qkv"):
         got = dqkv[..., i * D:(i + 1) * D].float(); ref = qr.grad[..., i * D:(i + 1) * D]
         assert _rel(got, ref) < 1.5e-2, name

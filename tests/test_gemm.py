@@ -11,66 +11,66 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 72), (34, 192, 64), (257, 264, 200), (1, 8, 8)])
-def test_gemm_plain(emu, M, N, K):
+def test_gemm_plain(be, dev, M, N, K):
     torch.manual_seed(0)
-    a = torch.randn(M, K).bfloat16(); b = torch.randn(N, K).bfloat16()
+    a = torch.randn(M, K).bfloat16().to(dev); b = torch.randn(N, K).bfloat16().to(dev)
     # asymmetric operands catch transposed fragment layouts
     b[:, 0] += 3.0
     ref = a.float() @ b.float().T
-    out = ops.gemm_nt(a, b, out_dtype=torch.float32, backend=emu)
+    out = ops.gemm_nt(a, b, out_dtype=torch.float32, backend=be)
     assert _rel(out, ref) < 1e-5
-    outb = ops.gemm_nt(a, b, out_dtype=torch.bfloat16, backend=emu)
+    outb = ops.gemm_nt(a, b, out_dtype=torch.bfloat16, backend=be)
     assert _rel(outb.float(), ref.bfloat16().float()) < 3e-3
 
 
-def test_gemm_epilogues(emu):
+def test_gemm_epilogues(be, dev):
     torch.manual_seed(1)
     M, N, K = 150, 144, 128
-    a = torch.randn(M, K).bfloat16(); b = (torch.randn(N, K) * 0.1).bfloat16()
-    bias = torch.randn(N); res = torch.randn(M, N)
+    a = torch.randn(M, K).bfloat16().to(dev); b = (torch.randn(N, K) * 0.1).bfloat16().to(dev)
+    bias = torch.randn(N).to(dev); res = torch.randn(M, N).to(dev)
     pre = a.float() @ b.float().T * 0.5 + bias
-    aux = torch.empty(M, N, dtype=torch.bfloat16)
+    aux = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     out = ops.gemm_nt(a, b, out_dtype=torch.float32, bias=bias, residual=res, act=ops.ACT_GELU, aux=aux, alpha=0.5,
-                      backend=emu)
+                      backend=be)
     ref = torch.nn.functional.gelu(pre) + res
     assert _rel(out, ref) < 1e-5
     assert _rel(aux.float(), pre.bfloat16().float()) < 1e-6
     # dGELU: out = (a @ b^T) * gelu'(u)
-    u = torch.randn(M, N).bfloat16()
-    out2 = ops.gemm_nt(a, b, out_dtype=torch.float32, act=ops.ACT_DGELU, aux=u, backend=emu)
+    u = torch.randn(M, N).bfloat16().to(dev)
+    out2 = ops.gemm_nt(a, b, out_dtype=torch.float32, act=ops.ACT_DGELU, aux=u, backend=be)
     uu = u.float().requires_grad_(True)
     torch.nn.functional.gelu(uu).sum().backward()
     ref2 = (a.float() @ b.float().T) * uu.grad
     assert _rel(out2, ref2) < 1e-5
 
 
-def test_gemm_strided_and_splitk(emu):
+def test_gemm_strided_and_splitk(be, dev):
     torch.manual_seed(2)
     M, N, K = 96, 136, 1000
-    big_a = torch.randn(M, K + 24).bfloat16()
+    big_a = torch.randn(M, K + 24).bfloat16().to(dev)
     a = big_a[:, 8:8 + K]             # lda > K, 16-B aligned start
-    b = torch.randn(N, K).bfloat16()
+    b = torch.randn(N, K).bfloat16().to(dev)
     ref = a.float() @ b.float().T
-    out = ops.gemm_nt(a, b, out_dtype=torch.float32, splitk=4, backend=emu)
+    out = ops.gemm_nt(a, b, out_dtype=torch.float32, splitk=4, backend=be)
     assert _rel(out, ref) < 1e-5
-    out1 = ops.gemm_nt(a, b, out_dtype=torch.float32, splitk=1, backend=emu)
+    out1 = ops.gemm_nt(a, b, out_dtype=torch.float32, splitk=1, backend=be)
     assert _rel(out1, ref) < 1e-5
 
 
 @pytest.mark.parametrize("R,C", [(64, 64), (70, 130), (197, 8), (3, 6)])
-def test_transpose_pad(emu, R, C):
-    x = torch.randn(R, C).bfloat16()
-    y = ops.transpose_pad(x, backend=emu)
+def test_transpose_pad(be, dev, R, C):
+    x = torch.randn(R, C).bfloat16().to(dev)
+    y = ops.transpose_pad(x, backend=be)
     rp = (R + 63) // 64 * 64
     assert y.shape == (C, rp)
     assert torch.equal(y[:, :R], x.T)
     assert torch.count_nonzero(y[:, R:]) == 0
 
 
-def test_wgrad_via_transposes(emu):
+def test_wgrad_via_transposes(be, dev):
     torch.manual_seed(3)
     T, NO, NI = 150, 72, 136
-    dy = torch.randn(T, NO).bfloat16(); x = torch.randn(T, NI).bfloat16()
-    dw = ops.gemm_nt(ops.transpose_pad(dy, backend=emu), ops.transpose_pad(x, backend=emu), out_dtype=torch.float32,
-                     splitk=2, backend=emu)
+    dy = torch.randn(T, NO).bfloat16().to(dev); x = torch.randn(T, NI).bfloat16().to(dev)
+    dw = ops.gemm_nt(ops.transpose_pad(dy, backend=be), ops.transpose_pad(x, backend=be), out_dtype=torch.float32,
+                     splitk=2, backend=be)
     assert _rel(dw, dy.float().T @ x.float()) < 1e-5

@@ -12,121 +12,121 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("T,C", [(10, 768), (7, 64), (33, 1024), (5, 1536)])
-def test_layernorm_fwd_bwd(emu, T, C):
+def test_layernorm_fwd_bwd(be, dev, T, C):
     torch.manual_seed(0)
-    x = torch.randn(T, C) * 2 + 0.5
-    g = torch.randn(C); b = torch.randn(C)
-    y, mean, rstd = ops.layernorm_fwd(x, g, b, eps=1e-6, out_dtype=torch.float32, backend=emu)
+    x = (torch.randn(T, C) * 2 + 0.5).to(dev)
+    g = torch.randn(C).to(dev); b = torch.randn(C).to(dev)
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, eps=1e-6, out_dtype=torch.float32, backend=be)
     xr = x.clone().requires_grad_(True); gr = g.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
     ref = torch.nn.functional.layer_norm(xr, (C,), gr, br, eps=1e-6)
     assert _rel(y, ref) < 1e-6
-    yb, _, _ = ops.layernorm_fwd(x, g, b, eps=1e-6, out_dtype=torch.bfloat16, backend=emu)
+    yb, _, _ = ops.layernorm_fwd(x, g, b, eps=1e-6, out_dtype=torch.bfloat16, backend=be)
     assert torch.equal(yb, y.bfloat16())
-    dy = torch.randn(T, C).bfloat16()
-    dres = torch.randn(T, C)
+    dy = torch.randn(T, C).bfloat16().to(dev)
+    dres = torch.randn(T, C).to(dev)
     ref.backward(dy.float())
-    dx, dxb, dg, db = ops.layernorm_bwd(dy, x, mean, rstd, g, dres=dres, backend=emu)
+    dx, dxb, dg, db = ops.layernorm_bwd(dy, x, mean, rstd, g, dres=dres, backend=be)
     assert _rel(dx, xr.grad + dres) < 2e-6
     assert torch.equal(dxb, dx.bfloat16())
     assert _rel(dg, gr.grad) < 2e-6 and _rel(db, br.grad) < 2e-6
     # f32 dy, no residual
-    dx2, _, dg2, _ = ops.layernorm_bwd(dy.float(), x, mean, rstd, g, dres=None, want_bf16=False, backend=emu)
+    dx2, _, dg2, _ = ops.layernorm_bwd(dy.float(), x, mean, rstd, g, dres=None, want_bf16=False, backend=be)
     assert _rel(dx2, xr.grad) < 2e-6
 
 
-def test_layernorm_strided_rows(emu):
+def test_layernorm_strided_rows(be, dev):
     # final norm applied to the cls rows only: row stride = N*C
     B, N, C = 3, 5, 64
-    x = torch.randn(B, N, C)
-    g = torch.randn(C); b = torch.randn(C)
-    y, _, _ = ops.layernorm_fwd(x, g, b, out_dtype=torch.float32, rows=B, ldx=N * C, backend=emu)
+    x = torch.randn(B, N, C).to(dev)
+    g = torch.randn(C).to(dev); b = torch.randn(C).to(dev)
+    y, _, _ = ops.layernorm_fwd(x, g, b, out_dtype=torch.float32, rows=B, ldx=N * C, backend=be)
     assert _rel(y, torch.nn.functional.layer_norm(x[:, 0], (C,), g, b, 1e-6)) < 1e-6
 
 
-def test_reductions(emu):
-    x = torch.randn(9, 5, 12)
-    assert _rel(ops.reduce_rows(x, 0.5, backend=emu), x.sum(0) * 0.5) < 1e-6
-    y = torch.randn(300, 70).bfloat16()
-    assert _rel(ops.colsum_bf16(y, backend=emu), y.float().sum(0)) < 1e-5
+def test_reductions(be, dev):
+    x = torch.randn(9, 5, 12).to(dev)
+    assert _rel(ops.reduce_rows(x, 0.5, backend=be), x.sum(0) * 0.5) < 1e-6
+    y = torch.randn(300, 70).bfloat16().to(dev)
+    assert _rel(ops.colsum_bf16(y, backend=be), y.float().sum(0)) < 1e-5
 
 
 @pytest.mark.parametrize("B,C,eps", [(6, 1000, 0.05), (3, 5, 0.0), (4, 257, 0.1)])
-def test_softmax_ce(emu, B, C, eps):
+def test_softmax_ce(be, dev, B, C, eps):
     torch.manual_seed(1)
-    logits = torch.randn(B, C) * 3
-    ya = torch.randint(0, C, (B,))
+    logits = (torch.randn(B, C) * 3).to(dev)
+    ya = torch.randint(0, C, (B,)).to(dev)
     lr = logits.clone().requires_grad_(True)
     ref_rows = torch.nn.functional.cross_entropy(lr, ya, label_smoothing=eps, reduction="none")
     ref_rows.mean().backward()
-    loss, dlb, dlf = ops.softmax_ce(logits, ya, label_smoothing=eps, grad_scale=1.0 / B, backend=emu)
+    loss, dlb, dlf = ops.softmax_ce(logits, ya, label_smoothing=eps, grad_scale=1.0 / B, backend=be)
     assert _rel(loss, ref_rows) < 1e-6
     assert _rel(dlf, lr.grad) < 1e-5
     assert torch.equal(dlb[:, :C], dlf.bfloat16()) and torch.count_nonzero(dlb[:, C:]) == 0
     # mixup pair: lam*CE(a) + (1-lam)*CE(b)   (train.py:34-35)
-    yb = torch.randint(0, C, (B,)); lam = 0.3
+    yb = torch.randint(0, C, (B,)).to(dev); lam = 0.3
     lr2 = logits.clone().requires_grad_(True)
     crit = torch.nn.CrossEntropyLoss(label_smoothing=eps, reduction="none")
     rows2 = lam * crit(lr2, ya) + (1 - lam) * crit(lr2, yb)
     rows2.mean().backward()
-    loss2, _, dlf2 = ops.softmax_ce(logits, ya, yb, lam, eps, 1.0 / B, backend=emu)
+    loss2, _, dlf2 = ops.softmax_ce(logits, ya, yb, lam, eps, 1.0 / B, backend=be)
     assert _rel(loss2, rows2) < 1e-6 and _rel(dlf2, lr2.grad) < 1e-5
 
 
-def test_bce(emu):
+def test_bce(be, dev):
     torch.manual_seed(2)
     B, C = 8, 5
-    logits = torch.randn(B, C) * 2
-    t = (torch.rand(B, C) > 0.5).float()
+    logits = (torch.randn(B, C) * 2).to(dev)
+    t = (torch.rand(B, C) > 0.5).float().to(dev)
     lr = logits.clone().requires_grad_(True)
     ref = torch.nn.functional.binary_cross_entropy_with_logits(lr, t)
     ref.backward()
-    loss, _, dlf = ops.bce_logits(logits, t, grad_scale=1.0 / (B * C), backend=emu)
+    loss, _, dlf = ops.bce_logits(logits, t, grad_scale=1.0 / (B * C), backend=be)
     assert abs(loss.sum().item() / (B * C) - ref.item()) < 1e-6
     assert _rel(dlf, lr.grad) < 1e-5
 
 
 @pytest.mark.parametrize("ps,H", [(16, 32), (14, 28), (4, 8)])
-def test_patchify(emu, ps, H):
-    x = torch.randn(2, 3, H, H)
-    p = ops.patchify(x, ps, backend=emu)
+def test_patchify(be, dev, ps, H):
+    x = torch.randn(2, 3, H, H).to(dev)
+    p = ops.patchify(x, ps, backend=be)
     ref = torch.nn.functional.unfold(x, ps, stride=ps).transpose(1, 2).reshape(-1, 3 * ps * ps)  # k = c*ps*ps + ky*ps + kx
     K = 3 * ps * ps
     assert torch.equal(p[:, :K], ref.bfloat16()) and torch.count_nonzero(p[:, K:]) == 0
 
 
-def test_casts(emu):
-    w = torch.randn(20, 12)
-    assert torch.equal(ops.cast_bf16(w, backend=emu), w.bfloat16())
-    wt = ops.transpose_cast(w, backend=emu)
+def test_casts(be, dev):
+    w = torch.randn(20, 12).to(dev)
+    assert torch.equal(ops.cast_bf16(w, backend=be), w.bfloat16())
+    wt = ops.transpose_cast(w, backend=be)
     assert wt.shape == (12, 24) and torch.equal(wt[:, :20], w.T.bfloat16()) and torch.count_nonzero(wt[:, 20:]) == 0
 
 
-def test_sgd_clip_ema_step_matches_torch(emu):
+def test_sgd_clip_ema_step_matches_torch(be, dev):
     torch.manual_seed(3)
     n = 1003
-    p0 = torch.randn(n); ema0 = p0.clone()
+    p0 = torch.randn(n).to(dev); ema0 = p0.clone()
     p_ref = torch.nn.Parameter(p0.clone())
     opt = torch.optim.SGD([p_ref], lr=0.006, momentum=0.937, weight_decay=5e-4)
-    p = p0.clone(); m = torch.zeros(n); ema = ema0.clone(); pb = torch.empty(n, dtype=torch.bfloat16)
+    p = p0.clone(); m = torch.zeros(n, device=dev); ema = ema0.clone(); pb = torch.empty(n, dtype=torch.bfloat16, device=dev)
     ema_ref = ema0.clone()
     for step in range(3):
-        g = torch.randn(n) * (5.0 if step == 1 else 0.1)   # step 1 triggers clipping (norm > 10)
+        g = (torch.randn(n) * (5.0 if step == 1 else 0.1)).to(dev)   # step 1 triggers clipping (norm > 10)
         p_ref.grad = g.clone()
         torch.nn.utils.clip_grad_norm_([p_ref], max_norm=10.0)
         opt.step()
         d = 0.9999 * (1 - math.exp(-(step + 1) / 2000))
         ema_ref = ema_ref * d + (1 - d) * p_ref.detach()
-        nsq = ops.sumsq(g, backend=emu)
+        nsq = ops.sumsq(g, backend=be)
         assert abs(nsq.item() - (g.double() ** 2).sum().item()) / (g.double() ** 2).sum().item() < 1e-6
         ops.sgd_step(p, g, m, lr=0.006, momentum=0.937, weight_decay=5e-4, ema=ema, p_bf16=pb, normsq=nsq, max_norm=10.0,
-                     ema_decay=d, first_step=(step == 0), backend=emu)
+                     ema_decay=d, first_step=(step == 0), backend=be)
         assert _rel(p, p_ref.detach()) < 1e-6
         assert _rel(ema, ema_ref) < 1e-6
         assert torch.equal(pb, p.bfloat16())
 
 
-def test_mixup(emu):
-    x = torch.randn(4, 3, 8, 8)
-    perm = torch.tensor([2, 0, 3, 1])
-    out = ops.mixup(x, perm, 0.3, backend=emu)
+def test_mixup(be, dev):
+    x = torch.randn(4, 3, 8, 8).to(dev)
+    perm = torch.tensor([2, 0, 3, 1]).to(dev)
+    out = ops.mixup(x, perm, 0.3, backend=be)
     assert _rel(out, 0.3 * x + 0.7 * x[perm]) < 1e-6
