@@ -158,6 +158,34 @@ int vdk_sgd_step(float* params, const float* grads, float* momentum_buf, float* 
 /* mixup_data (engine/procedure/train.py:24-32): out[b] = lam*x[b] + (1-lam)*x[perm[b]] */
 int vdk_mixup(const float* x, const int64_t* perm, float lam, int32_t B, int64_t per_sample, float* out, void* stream);
 
+
+/* ---- native ViT engine: timm VisionTransformer forward/backward over flat buffers ---------------------
+ * Replaces `self.model(images)` + `loss.backward()` of Trainer.compute_loss / Trainer.update
+ * (engine/procedure/train.py:177-215) for the model `timm.create_model('vit_*', num_classes=C)` built at
+ * models/classifier/classify_model.py:49-54.  Semantics restated from timm 0.9.16 (requirements.txt:10; not
+ * vendored): patch_embed conv -> cat cls_token -> + pos_embed -> depth x pre-norm blocks (LayerNorm eps,
+ * fused qkv, softmax attention, proj; LayerNorm, fc1, exact GELU, fc2) -> final LayerNorm -> token 0 -> head. */
+typedef struct VdkVitConfig {
+  int32_t batch, img_size, patch_size, in_chans;
+  int32_t dim, depth, heads, mlp_dim, num_classes;
+  float ln_eps;
+} VdkVitConfig;
+typedef void (*vdk_grad_ready_fn)(void* user, int64_t offset, int64_t numel);
+
+/* flat parameter layout: n_floats fp32 elements (params, grads, momentum, ema, and the bf16 copy `wb16` all use
+ * it); tensors are reported in timm state_dict order with timm names; n_transposed = bf16 elements of `wt16`. */
+int vdk_vit_param_count(const VdkVitConfig* cfg, int64_t* n_floats, int32_t* n_tensors, int64_t* n_transposed);
+int vdk_vit_param_info(const VdkVitConfig* cfg, int32_t index, char* name, int32_t name_cap, int64_t* offset, int64_t* numel,
+                       int64_t* shape4, int32_t* ndim);
+int vdk_vit_workspace_bytes(const VdkVitConfig* cfg, size_t* bytes);
+int vdk_vit_refresh_weights(const VdkVitConfig* cfg, const float* params, void* wb16, void* wt16, int32_t skip_wb16, void* stream);
+/* x f32 [B, in_chans, img, img] -> logits f32 [B, Cp], Cp = num_classes rounded up to 8 */
+int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params, const void* wb16, void* ws, size_t ws_bytes,
+                    float* logits, void* stream);
+/* dlogits bf16 [B, Cp] -> grads (flat fp32, overwritten).  on_ready: see csrc/vit_engine.hip (DDP bucket hook). */
+int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* params, const void* wb16, const void* wt16, void* ws,
+                     size_t ws_bytes, float* grads, vdk_grad_ready_fn on_ready, void* user, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

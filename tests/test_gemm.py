@@ -34,7 +34,7 @@ def test_gemm_epilogues(be, dev):
                       backend=be)
     ref = torch.nn.functional.gelu(pre) + res
     assert _rel(out, ref) < 1e-5
-    assert _rel(aux.float(), pre.bfloat16().float()) < 1e-6
+    assert _rel(aux.float(), pre.bfloat16().float()) < 1e-4   # bf16 rounding ties may flip with fp32 summation order
     # dGELU: out = (a @ b^T) * gelu'(u)
     u = torch.randn(M, N).bfloat16().to(dev)
     out2 = ops.gemm_nt(a, b, out_dtype=torch.float32, act=ops.ACT_DGELU, aux=u, backend=be)

@@ -1,0 +1,69 @@
+"""Pin the timm-ViT restatement (oracle/vit_ref.py) against the independent `transformers.ViTModel` through the
+weight map of SURVEY.md §10 (timm itself is not installable here)."""
+import torch
+
+from oracle.vit_ref import VisionTransformerRef
+
+
+def test_vit_ref_matches_transformers():
+    from transformers import ViTConfig, ViTModel
+    torch.manual_seed(0)
+    D, depth, heads, img, ps = 64, 2, 2, 32, 8
+    ref = VisionTransformerRef(img, ps, 3, 10, D, depth, heads, mlp_dim=4 * D).eval()
+    with torch.no_grad():  # make biases / norms non-trivial
+        for p in ref.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+        ref.cls_token.add_(torch.randn_like(ref.cls_token) * 0.1)
+    cfg = ViTConfig(hidden_size=D, num_hidden_layers=depth, num_attention_heads=heads, intermediate_size=4 * D, image_size=img,
+                    patch_size=ps, num_channels=3, layer_norm_eps=1e-6, hidden_act="gelu", hidden_dropout_prob=0.0,
+                    attention_probs_dropout_prob=0.0, qkv_bias=True)
+    hf = ViTModel(cfg, add_pooling_layer=False).eval()
+    sd = ref.state_dict()
+    hsd = hf.state_dict()
+    keys = list(hsd.keys())
+
+    def put(name_options, value):
+        for n in name_options:
+            if n in hsd:
+                assert hsd[n].shape == value.shape, (n, hsd[n].shape, value.shape)
+                hsd[n] = value.clone()
+                return
+        raise KeyError(f"none of {name_options} in HF state_dict; keys sample: {keys[:12]}")
+
+    put(["embeddings.cls_token"], sd["cls_token"])
+    put(["embeddings.position_embeddings"], sd["pos_embed"])
+    put(["embeddings.patch_embeddings.projection.weight"], sd["patch_embed.proj.weight"])
+    put(["embeddings.patch_embeddings.projection.bias"], sd["patch_embed.proj.bias"])
+    for i in range(depth):
+        w, b = sd[f"blocks.{i}.attn.qkv.weight"], sd[f"blocks.{i}.attn.qkv.bias"]
+        for j, nm in enumerate(["query", "key", "value"]):  # timm fused rows: [0:D]=q, [D:2D]=k, [2D:3D]=v
+            short = {"query": "q_proj", "key": "k_proj", "value": "v_proj"}[nm]
+            put([f"encoder.layer.{i}.attention.attention.{nm}.weight", f"layers.{i}.attention.{short}.weight"], w[j * D:(j + 1) * D])
+            put([f"encoder.layer.{i}.attention.attention.{nm}.bias", f"layers.{i}.attention.{short}.bias"], b[j * D:(j + 1) * D])
+        for kind in ("weight", "bias"):
+            put([f"encoder.layer.{i}.attention.output.dense.{kind}", f"layers.{i}.attention.o_proj.{kind}"], sd[f"blocks.{i}.attn.proj.{kind}"])
+            put([f"encoder.layer.{i}.layernorm_before.{kind}", f"layers.{i}.layernorm_before.{kind}"], sd[f"blocks.{i}.norm1.{kind}"])
+            put([f"encoder.layer.{i}.layernorm_after.{kind}", f"layers.{i}.layernorm_after.{kind}"], sd[f"blocks.{i}.norm2.{kind}"])
+            put([f"encoder.layer.{i}.intermediate.dense.{kind}", f"layers.{i}.mlp.fc1.{kind}"], sd[f"blocks.{i}.mlp.fc1.{kind}"])
+            put([f"encoder.layer.{i}.output.dense.{kind}", f"layers.{i}.mlp.fc2.{kind}"], sd[f"blocks.{i}.mlp.fc2.{kind}"])
+    for kind in ("weight", "bias"):
+        put([f"layernorm.{kind}"], sd[f"norm.{kind}"])
+    hf.load_state_dict(hsd)
+    x = torch.randn(3, 3, img, img)
+    with torch.no_grad():
+        feats = ref.forward_features(x)
+        hfeats = hf(pixel_values=x).last_hidden_state
+    rel = ((feats - hfeats).norm() / hfeats.norm()).item()
+    assert rel < 1e-5, rel
+
+
+def test_state_dict_keys_are_timm_names():
+    ref = VisionTransformerRef(32, 8, 3, 10, 64, 2, 1)
+    keys = list(ref.state_dict().keys())
+    for k in ["cls_token", "pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias", "blocks.0.norm1.weight",
+              "blocks.0.attn.qkv.weight", "blocks.0.attn.proj.bias", "blocks.1.mlp.fc1.weight", "blocks.1.mlp.fc2.bias",
+              "norm.weight", "head.weight", "head.bias"]:
+        assert k in keys
+    assert len(keys) == 4 + 12 * 2 + 4
+    assert ref.state_dict()["blocks.0.attn.qkv.weight"].shape == (192, 64)

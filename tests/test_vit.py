@@ -1,0 +1,112 @@
+"""Hot path A end to end: the native ViT engine (forward, backward, fused step) vs the fp32 oracle restatement of
+timm's VisionTransformer, same weights, same inputs.  bf16 MFMA operands vs an fp32 oracle: tolerances are stated
+per check; a wiring mistake (missing residual/bias, transposed weight, wrong gradient) shows up as an O(1) error."""
+import copy
+
+import pytest
+import torch
+
+from oracle.vit_ref import VisionTransformerRef, train_step_reference
+from visiondk_amd import vit
+
+
+def _rel(a, b):
+    return ((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm().clamp_min(1e-30)).item()
+
+
+SPEC = vit.VitSpec(img_size=32, patch_size=8, in_chans=3, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256, ln_eps=1e-6)
+
+
+def _pair(be, dev, seed=0):
+    torch.manual_seed(seed)
+    ref = VisionTransformerRef(SPEC.img_size, SPEC.patch_size, 3, SPEC.num_classes, SPEC.dim, SPEC.depth, SPEC.heads, SPEC.mlp_dim)
+    with torch.no_grad():  # non-trivial biases / norms / cls so every gradient path is exercised
+        for n, p in ref.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.05)
+        ref.cls_token.add_(torch.randn_like(ref.cls_token) * 0.02)
+        for blk in ref.blocks:   # larger weights -> activations of O(1), a more demanding test than N(0, .02)
+            for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2):
+                lin.weight.mul_(4.0)
+    model = vit.VisionTransformer(SPEC, device=dev, backend=be, seed=1)
+    model.load_state_dict(ref.state_dict())
+    return ref, model
+
+
+def test_param_names_and_shapes(be, dev):
+    ref, model = _pair(be, dev)
+    sd_ref, sd = ref.state_dict(), model.state_dict()
+    assert list(sd.keys()) == list(sd_ref.keys())
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(sd_ref[k].shape), k
+        assert torch.equal(sd[k].cpu(), sd_ref[k])
+    assert [n for n, _ in model.named_parameters()] == list(sd_ref.keys())
+
+
+def test_forward_backward_vs_oracle(be, dev):
+    ref, model = _pair(be, dev)
+    torch.manual_seed(5)
+    x = torch.randn(3, 3, 32, 32)
+    y = torch.randint(0, 10, (3,))
+    logits_ref = ref(x)
+    loss_ref = torch.nn.functional.cross_entropy(logits_ref, y, label_smoothing=0.05)
+    loss_ref.backward()
+    logits = model(x.to(dev))
+    loss = torch.nn.functional.cross_entropy(logits, y.to(dev), label_smoothing=0.05)
+    loss.backward()
+    assert _rel(logits, logits_ref) < 2e-2, _rel(logits, logits_ref)          # bf16 operands, fp32 accumulate
+    assert abs(loss.item() - loss_ref.item()) < 5e-3 * abs(loss_ref.item())
+    worst = 0.0
+    for (n, p), (nr, pr) in zip(model.named_parameters(), ref.named_parameters()):
+        assert n == nr
+        assert p.grad is not None, n
+        r = _rel(p.grad, pr.grad)
+        worst = max(worst, r)
+        assert r < 6e-2, (n, r)
+    print("worst grad rel err", worst)
+
+
+def test_fused_step_vs_reference_step(be, dev):
+    ref, model = _pair(be, dev, seed=3)
+    hyp = dict(lr=0.01, momentum=0.937, weight_decay=5e-4)
+    step = vit.FusedTrainStep(model, label_smoothing=0.05, max_norm=10.0, ema=True, **hyp)
+    ema_ref = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    init_sd = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    bufs = None
+    torch.manual_seed(11)
+    for it in range(3):
+        x = torch.randn(4, 3, 32, 32)
+        y = torch.randint(0, 10, (4,))
+        _, loss_ref, _, _, bufs = train_step_reference(ref, x, y, label_smoothing=0.05, max_norm=10.0, momentum_bufs=bufs, ema=ema_ref,
+                                                       updates=it, **hyp)
+        step.step(x.to(dev), y.to(dev))
+        assert abs(step.loss_value() - loss_ref.item()) < 1e-2 * abs(loss_ref.item()), (it, step.loss_value(), loss_ref.item())
+    # compare the UPDATE each tensor received over the 3 steps (weights barely move, so comparing weights proves little)
+    sd = model.state_dict()
+    for n, p in ref.named_parameters():
+        d_ref = p.detach() - init_sd[n]
+        d_got = sd[n].cpu() - init_sd[n]
+        assert _rel(d_got, d_ref) < 8e-2, (n, _rel(d_got, d_ref))
+    for n in ema_ref:
+        got = model.engine.view(step.ema, n).cpu()
+        assert _rel(got - init_sd[n], ema_ref[n] - init_sd[n]) < 8e-2, n
+
+
+def test_mixup_pair_loss(be, dev):
+    ref, model = _pair(be, dev, seed=4)
+    step = vit.FusedTrainStep(model, lr=0.0, momentum=0.0, weight_decay=0.0, label_smoothing=0.1, ema=False)
+    x = torch.randn(4, 3, 32, 32); ya = torch.randint(0, 10, (4,)); yb = torch.randint(0, 10, (4,)); lam = 0.35
+    crit = torch.nn.CrossEntropyLoss(label_smoothing=0.1)
+    out = ref(x)
+    loss_ref = lam * crit(out, ya) + (1 - lam) * crit(out, yb)      # mixup_criterion, train.py:34-35
+    step.step(x.to(dev), ya.to(dev), yb.to(dev), lam)
+    assert abs(step.loss_value() - loss_ref.item()) < 1e-2 * abs(loss_ref.item())
+
+
+def test_deepcopy_for_ema_and_eval(be, dev):
+    ref, model = _pair(be, dev)
+    m2 = copy.deepcopy(model)              # ModelEMA does this (models/ema.py:22)
+    x = torch.randn(2, 3, 32, 32).to(dev)
+    with torch.no_grad():
+        a, b = model(x), m2(x)
+    assert torch.equal(a.cpu(), b.cpu())

@@ -5,6 +5,8 @@ import time
 
 import torch
 
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent))
+
 from visiondk_amd import cbir, ops
 
 

@@ -24,6 +24,14 @@ class GemmDesc(C.Structure):
                 ("alpha", F32), ("splitk", I32), ("row_group", I32)]
 
 
+class VitConfig(C.Structure):
+    """VdkVitConfig of include/visiondk.h"""
+    _fields_ = [("batch", I32), ("img_size", I32), ("patch_size", I32), ("in_chans", I32), ("dim", I32), ("depth", I32),
+                ("heads", I32), ("mlp_dim", I32), ("num_classes", I32), ("ln_eps", F32)]
+
+
+GRAD_READY_FN = C.CFUNCTYPE(None, P, I64, I64)
+
 BF16, F32_ = 0, 1
 ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
 
@@ -59,6 +67,14 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_sumsq_f32": (C.c_int, [P, I64, P, P, SZ, P]),
     "vdk_sgd_step": (C.c_int, [P, P, P, P, P, I64, F32, F32, F32, F32, P, F32, F32, I32, P]),
     "vdk_mixup": (C.c_int, [P, P, F32, I32, I64, P, P]),
+    # native ViT engine
+    "vdk_vit_param_count": (C.c_int, [C.POINTER(VitConfig), C.POINTER(I64), C.POINTER(I32), C.POINTER(I64)]),
+    "vdk_vit_param_info": (C.c_int, [C.POINTER(VitConfig), I32, C.c_char_p, I32, C.POINTER(I64), C.POINTER(I64),
+                                     C.POINTER(I64), C.POINTER(I32)]),
+    "vdk_vit_workspace_bytes": (C.c_int, [C.POINTER(VitConfig), PSZ]),
+    "vdk_vit_refresh_weights": (C.c_int, [C.POINTER(VitConfig), P, P, P, I32, P]),
+    "vdk_vit_forward": (C.c_int, [C.POINTER(VitConfig), P, P, P, P, SZ, P, P]),
+    "vdk_vit_backward": (C.c_int, [C.POINTER(VitConfig), P, P, P, P, P, SZ, P, P, P, P]),
 }
 
 

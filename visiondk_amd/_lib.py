@@ -29,6 +29,9 @@ class Backend:
         if device_only and lib.vdk_is_device_build() != 1:
             raise RuntimeError("refusing to use a non-device build of libvisiondk as the product backend")
 
+    def __deepcopy__(self, memo):  # ModelEMA deep-copies the model (models/ema.py:22); the library handle is shared
+        return self
+
     # ---- plumbing -------------------------------------------------------------------------
     def ptr(self, t: torch.Tensor | None) -> int | None:
         if t is None:

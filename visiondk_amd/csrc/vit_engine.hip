@@ -1,0 +1,422 @@
+// vit_engine.hip — native orchestration of hot path A for timm's VisionTransformer
+// (vit_base_patch16_224 & friends: class token, learned pos_embed, pre-norm blocks, LayerNorm eps 1e-6,
+// fused qkv, exact-erf GELU MLP, final norm, token pooling, Linear head) as created by the reference at
+// models/classifier/classify_model.py:49-54 (`timm.create_model(name, num_classes=...)`) and stepped by
+// engine/procedure/train.py:177-215.  One C call runs the whole forward (saving what backward needs) and one
+// the whole backward, as a fixed sequence of the library's own kernels on ONE stream over caller-owned flat
+// buffers: no autograd graph, no per-tensor launches, no allocation.
+//
+// Data layout (everything in HBM, 288 GB makes recomputation pointless):
+//   params / grads / momentum / ema : flat fp32, identical tensor offsets (timm state_dict order, see
+//                                     vdk_vit_param_info); wb16 = same layout in bf16 (GEMM B operands,
+//                                     refreshed by vdk_sgd_step); wt16 = per-Linear [in, out] bf16 copies for dgrad.
+//   residual stream                 : fp32 [B*N, D] per block boundary (what timm keeps in fp32 under autocast)
+//   GEMM operands / saved tensors   : bf16
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include "vdk_device.h"
+#include "vdk_host.h"
+#include "vdk_gemm.h"
+
+extern "C" {
+int vdk_layernorm_fwd(const float*, int64_t, int32_t, int32_t, const float*, const float*, float, void*, int64_t, int32_t, float*, float*, void*);
+int vdk_layernorm_bwd_workspace_bytes(int32_t, int32_t, size_t*);
+int vdk_layernorm_bwd(const void*, int64_t, int32_t, const float*, int64_t, const float*, const float*, const float*, const float*, int64_t,
+                      int32_t, int32_t, float*, int64_t, void*, int64_t, float*, float*, void*, size_t, void*);
+int vdk_reduce_rows_f32(const float*, int64_t, int32_t, int64_t, float*, float, void*);
+int vdk_colsum_bf16_workspace_bytes(int32_t, int32_t, size_t*);
+int vdk_colsum_bf16(const void*, int64_t, int32_t, int32_t, float*, void*, size_t, void*);
+int vdk_attention_fwd(const void*, int64_t, void*, int64_t, float*, int32_t, int32_t, int32_t, int32_t, float, void*);
+int vdk_attention_bwd(const void*, int64_t, const void*, const void*, int64_t, const float*, void*, int64_t, float*, int32_t, int32_t, int32_t,
+                      int32_t, float, void*);
+int vdk_patchify_bf16(const float*, int32_t, int32_t, int32_t, int32_t, int32_t, void*, int32_t, void*);
+int vdk_cls_rows(float*, int64_t, int32_t, int32_t, const float*, const float*, void*);
+int vdk_cast_f32_bf16(const float*, void*, int64_t, void*);
+int vdk_transpose_cast_f32_bf16(const float*, int64_t, int32_t, int32_t, void*, int64_t, int32_t, void*);
+}
+
+static inline int64_t up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+struct VitDims {
+  int B, img, ps, Cin, D, L, H, M, C, Cp, np, N, T, Kpe, Tp, Bp;
+  float eps;
+};
+static int vit_dims(const VdkVitConfig* c, VitDims* d) {
+  if (!c) return vdk_fail(VDK_EINVAL, "vit: null config");
+  d->B = c->batch; d->img = c->img_size; d->ps = c->patch_size; d->Cin = c->in_chans; d->D = c->dim; d->L = c->depth;
+  d->H = c->heads; d->M = c->mlp_dim; d->C = c->num_classes; d->eps = c->ln_eps;
+  if (d->B <= 0 || d->img <= 0 || d->ps <= 0 || d->img % d->ps || d->Cin <= 0 || d->D <= 0 || d->L <= 0 || d->H <= 0 || d->M <= 0 || d->C <= 0)
+    return vdk_fail(VDK_EINVAL, "vit: bad config value");
+  if (d->D != d->H * 64) return vdk_fail(VDK_EUNSUPPORTED, "vit: head_dim must be 64 (dim == 64 * heads)");
+  if ((d->D & 7) || (d->M & 7)) return vdk_fail(VDK_EUNSUPPORTED, "vit: dim and mlp_dim must be multiples of 8");
+  d->Kpe = d->Cin * d->ps * d->ps;
+  if (d->Kpe & 7) return vdk_fail(VDK_EUNSUPPORTED, "vit: in_chans*patch*patch must be a multiple of 8");
+  d->np = (d->img / d->ps) * (d->img / d->ps);
+  d->N = d->np + 1;
+  d->T = d->B * d->N;
+  d->Cp = (int)up(d->C, 8);
+  d->Tp = (int)up(d->T, 64);
+  d->Bp = (int)up(d->B, 64);
+  return VDK_OK;
+}
+
+// ---------------------------------------------------------------------------- parameter layout
+struct PEntry { char name[64]; int64_t off, numel; int64_t shape[4]; int ndim; };
+struct PLayout {
+  // offsets into the flat fp32/bf16 buffers
+  int64_t cls, pos, pe_w, pe_b, norm_w, norm_b, head_w, head_b, total;
+  struct Blk { int64_t n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b; };
+  Blk blk[64];
+  // offsets into the transposed-weight buffer (bf16 elements)
+  struct BlkT { int64_t qkv, proj, fc1, fc2; } blkT[64];
+  int64_t headT, totalT;
+};
+static int64_t p_take(int64_t& cur, int64_t n) { int64_t o = cur; cur = up(cur + n, 64); return o; }
+static int vit_layout(const VitDims& d, PLayout* p) {
+  if (d.L > 64) return vdk_fail(VDK_EUNSUPPORTED, "vit: depth > 64");
+  int64_t cur = 0;
+  p->cls = p_take(cur, d.D);
+  p->pos = p_take(cur, (int64_t)d.N * d.D);
+  p->pe_w = p_take(cur, (int64_t)d.D * d.Kpe);
+  p->pe_b = p_take(cur, d.D);
+  for (int l = 0; l < d.L; ++l) {
+    PLayout::Blk& b = p->blk[l];
+    b.n1w = p_take(cur, d.D); b.n1b = p_take(cur, d.D);
+    b.qkv_w = p_take(cur, (int64_t)3 * d.D * d.D); b.qkv_b = p_take(cur, 3 * d.D);
+    b.proj_w = p_take(cur, (int64_t)d.D * d.D); b.proj_b = p_take(cur, d.D);
+    b.n2w = p_take(cur, d.D); b.n2b = p_take(cur, d.D);
+    b.fc1_w = p_take(cur, (int64_t)d.M * d.D); b.fc1_b = p_take(cur, d.M);
+    b.fc2_w = p_take(cur, (int64_t)d.D * d.M); b.fc2_b = p_take(cur, d.D);
+  }
+  p->norm_w = p_take(cur, d.D); p->norm_b = p_take(cur, d.D);
+  p->head_w = p_take(cur, (int64_t)d.Cp * d.D);   // rows C..Cp-1 are zero padding (N % 8 for the GEMM)
+  p->head_b = p_take(cur, d.Cp);
+  p->total = cur;
+  int64_t t = 0;
+  for (int l = 0; l < d.L; ++l) {
+    p->blkT[l].qkv = p_take(t, (int64_t)d.D * 3 * d.D);
+    p->blkT[l].proj = p_take(t, (int64_t)d.D * d.D);
+    p->blkT[l].fc1 = p_take(t, (int64_t)d.D * d.M);
+    p->blkT[l].fc2 = p_take(t, (int64_t)d.M * d.D);
+  }
+  p->headT = p_take(t, (int64_t)d.D * d.Cp);
+  p->totalT = t;
+  return VDK_OK;
+}
+
+static void pe_set(PEntry* e, const char* name, int64_t off, int ndim, int64_t s0, int64_t s1 = 1, int64_t s2 = 1, int64_t s3 = 1) {
+  snprintf(e->name, sizeof(e->name), "%s", name);
+  e->off = off; e->ndim = ndim; e->shape[0] = s0; e->shape[1] = s1; e->shape[2] = s2; e->shape[3] = s3;
+  e->numel = s0 * s1 * s2 * s3;
+}
+// timm state_dict order and names; head rows are reported unpadded ([C, D]; the padding rows
+// follow in memory and must stay zero).
+static int vit_entry(const VitDims& d, const PLayout& p, int idx, PEntry* e) {
+  const int per = 12, ntens = 4 + per * d.L + 4;
+  if (idx < 0 || idx >= ntens) return -1;
+  char nm[64];
+  if (idx == 0) { pe_set(e, "cls_token", p.cls, 3, 1, 1, d.D); return 0; }
+  if (idx == 1) { pe_set(e, "pos_embed", p.pos, 3, 1, d.N, d.D); return 0; }
+  if (idx == 2) { pe_set(e, "patch_embed.proj.weight", p.pe_w, 4, d.D, d.Cin, d.ps, d.ps); return 0; }
+  if (idx == 3) { pe_set(e, "patch_embed.proj.bias", p.pe_b, 1, d.D); return 0; }
+  if (idx < 4 + per * d.L) {
+    int l = (idx - 4) / per, k = (idx - 4) % per;
+    const PLayout::Blk& b = p.blk[l];
+    static const char* suffix[12] = {"norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
+                                     "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"};
+    snprintf(nm, sizeof(nm), "blocks.%d.%s", l, suffix[k]);
+    switch (k) {
+      case 0: pe_set(e, nm, b.n1w, 1, d.D); break;
+      case 1: pe_set(e, nm, b.n1b, 1, d.D); break;
+      case 2: pe_set(e, nm, b.qkv_w, 2, 3 * d.D, d.D); break;
+      case 3: pe_set(e, nm, b.qkv_b, 1, 3 * d.D); break;
+      case 4: pe_set(e, nm, b.proj_w, 2, d.D, d.D); break;
+      case 5: pe_set(e, nm, b.proj_b, 1, d.D); break;
+      case 6: pe_set(e, nm, b.n2w, 1, d.D); break;
+      case 7: pe_set(e, nm, b.n2b, 1, d.D); break;
+      case 8: pe_set(e, nm, b.fc1_w, 2, d.M, d.D); break;
+      case 9: pe_set(e, nm, b.fc1_b, 1, d.M); break;
+      case 10: pe_set(e, nm, b.fc2_w, 2, d.D, d.M); break;
+      default: pe_set(e, nm, b.fc2_b, 1, d.D); break;
+    }
+    return 0;
+  }
+  int k = idx - 4 - per * d.L;
+  if (k == 0) pe_set(e, "norm.weight", p.norm_w, 1, d.D);
+  else if (k == 1) pe_set(e, "norm.bias", p.norm_b, 1, d.D);
+  else if (k == 2) pe_set(e, "head.weight", p.head_w, 2, d.C, d.D);
+  else pe_set(e, "head.bias", p.head_b, 1, d.C);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------- workspace plan
+struct WsPlan {
+  size_t total;
+  size_t patches;            // bf16 [B*np, Kpe]
+  size_t X;                  // fp32 (2L+1) x [T, D]  : X[2l] block input, X[2l+1] after attention, X[2L] output
+  size_t stats;              // fp32 L x 4 x [T] (mean1, rstd1, mean2, rstd2) + 2 x [B]
+  size_t h1, qkv, lse, o, h2, u, g;   // per-layer strides below
+  size_t s_h, s_qkv, s_lse, s_u;      // per-layer sizes in bytes
+  size_t hf;                 // bf16 [Bp, D] (zero padded rows)
+  // backward scratch
+  size_t dxa, dxm, dxab, dxmb;   // fp32 [T,D] x2, bf16 [T,D] x2
+  size_t dbig;                   // bf16 [T, max(M, 3D)]  (du / dqkv)
+  size_t dsm;                    // bf16 [T, D]           (dh / do)
+  size_t dvec;                   // fp32 [B,H,N]
+  size_t tA, tB;                 // bf16 [max(M,3D,Cp), Tp] each
+  size_t slabs, slabs_bytes;
+  size_t lnws, lnws_bytes, csws, csws_bytes;
+  size_t dhf;                    // bf16 [B, D]
+  size_t dposall;                // fp32 [N, D]
+};
+static size_t w_take(size_t& cur, size_t n) { size_t o = cur; cur = (cur + n + 255) & ~(size_t)255; return o; }
+static int wgrad_splitk(int M, int N, int K) {
+  if (K < 4096) return 1;
+  int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  int s = (1024 + tiles - 1) / tiles;
+  if (s > 32) s = 32;
+  if (s < 1) s = 1;
+  return s;
+}
+static int vit_plan(const VitDims& d, WsPlan* w) {
+  size_t cur = 0;
+  const size_t T = d.T, D = d.D, M = d.M, L = d.L;
+  w->patches = w_take(cur, (size_t)d.B * d.np * d.Kpe * 2);
+  w->X = w_take(cur, (2 * L + 1) * T * D * 4);
+  w->stats = w_take(cur, (L * 4 * T + 2 * (size_t)d.B) * 4);
+  w->s_h = T * D * 2; w->s_qkv = T * 3 * D * 2; w->s_lse = (size_t)d.B * d.H * d.N * 4; w->s_u = T * M * 2;
+  w->h1 = w_take(cur, L * w->s_h); w->qkv = w_take(cur, L * w->s_qkv); w->lse = w_take(cur, L * w->s_lse);
+  w->o = w_take(cur, L * w->s_h); w->h2 = w_take(cur, L * w->s_h); w->u = w_take(cur, L * w->s_u); w->g = w_take(cur, L * w->s_u);
+  w->hf = w_take(cur, (size_t)d.Bp * D * 2);
+  w->dxa = w_take(cur, T * D * 4); w->dxm = w_take(cur, T * D * 4);
+  w->dxab = w_take(cur, T * D * 2); w->dxmb = w_take(cur, T * D * 2);
+  size_t big = M > 3 * D ? M : 3 * D;
+  w->dbig = w_take(cur, T * big * 2);
+  w->dsm = w_take(cur, T * D * 2);
+  w->dvec = w_take(cur, w->s_lse);
+  size_t trows = big > (size_t)d.Cp ? big : (size_t)d.Cp;
+  if (trows < (size_t)d.Kpe) trows = d.Kpe;
+  size_t tcols = d.Tp > d.Bp ? d.Tp : d.Bp;
+  w->tA = w_take(cur, trows * tcols * 2); w->tB = w_take(cur, trows * tcols * 2);
+  size_t sl = 0;
+  {
+    int sh[5][3] = {{(int)M, (int)D, d.T}, {(int)D, (int)M, d.T}, {3 * (int)D, (int)D, d.T}, {(int)D, (int)D, d.T}, {(int)D, d.Kpe, d.B * d.np}};
+    for (auto& s : sh) { size_t b = (size_t)wgrad_splitk(s[0], s[1], s[2]) * s[0] * s[1] * 4; if (b > sl) sl = b; }
+  }
+  w->slabs_bytes = sl; w->slabs = w_take(cur, sl);
+  vdk_layernorm_bwd_workspace_bytes(d.T, d.D, &w->lnws_bytes); w->lnws = w_take(cur, w->lnws_bytes);
+  size_t cs = 0; vdk_colsum_bf16_workspace_bytes(d.T, (int)big, &cs); w->csws_bytes = cs; w->csws = w_take(cur, cs);
+  w->dhf = w_take(cur, (size_t)d.B * D * 2);
+  w->dposall = w_take(cur, (size_t)d.N * D * 4);
+  w->total = cur;
+  return VDK_OK;
+}
+
+#define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+static int gemm(hipStream_t s, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K, int cdt,
+                const float* bias, const float* res, int64_t ldr, int act, void* aux, int64_t ldaux, int splitk, int row_group, void* ws,
+                size_t wsb) {
+  VdkGemmDesc g;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.c_dtype = cdt; g.bias = bias;
+  g.residual = res; g.ldr = ldr; g.act = act; g.aux = aux; g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = splitk; g.row_group = row_group;
+  return vdk_gemm_bf16_nt(&g, ws, wsb, s);
+}
+
+extern "C" {
+
+int vdk_vit_param_count(const VdkVitConfig* cfg, int64_t* n_floats, int32_t* n_tensors, int64_t* n_transposed) {
+  VitDims d; RC(vit_dims(cfg, &d));
+  PLayout p; RC(vit_layout(d, &p));
+  if (n_floats) *n_floats = p.total;
+  if (n_tensors) *n_tensors = 4 + 12 * d.L + 4;
+  if (n_transposed) *n_transposed = p.totalT;
+  return VDK_OK;
+}
+
+int vdk_vit_param_info(const VdkVitConfig* cfg, int32_t index, char* name, int32_t name_cap, int64_t* offset, int64_t* numel,
+                       int64_t* shape4, int32_t* ndim) {
+  VitDims d; RC(vit_dims(cfg, &d));
+  PLayout p; RC(vit_layout(d, &p));
+  PEntry e;
+  if (vit_entry(d, p, index, &e)) return vdk_fail(VDK_EINVAL, "vdk_vit_param_info: index out of range");
+  if (name && name_cap > 0) snprintf(name, name_cap, "%s", e.name);
+  if (offset) *offset = e.off;
+  if (numel) *numel = e.numel;
+  if (shape4) for (int i = 0; i < 4; ++i) shape4[i] = e.shape[i];
+  if (ndim) *ndim = e.ndim;
+  return VDK_OK;
+}
+
+int vdk_vit_workspace_bytes(const VdkVitConfig* cfg, size_t* bytes) {
+  VitDims d; RC(vit_dims(cfg, &d));
+  WsPlan w; RC(vit_plan(d, &w));
+  if (!bytes) return vdk_fail(VDK_EINVAL, "null");
+  *bytes = w.total;
+  return VDK_OK;
+}
+
+// (Re)build the bf16 operand copies from the fp32 master weights: wb16 (same layout) unless `skip_wb16`
+// (vdk_sgd_step already refreshed it), and the [in, out] transposes the dgrad GEMMs read.
+int vdk_vit_refresh_weights(const VdkVitConfig* cfg, const float* params, void* wb16, void* wt16, int32_t skip_wb16, void* stream) {
+  VitDims d; RC(vit_dims(cfg, &d));
+  PLayout p; RC(vit_layout(d, &p));
+  if (!params || !wb16 || !wt16) return vdk_fail(VDK_EINVAL, "vdk_vit_refresh_weights: null pointer");
+  if (!skip_wb16) RC(vdk_cast_f32_bf16(params, wb16, p.total, stream));
+  bf16_t* wt = (bf16_t*)wt16;
+  for (int l = 0; l < d.L; ++l) {
+    RC(vdk_transpose_cast_f32_bf16(params + p.blk[l].qkv_w, d.D, 3 * d.D, d.D, wt + p.blkT[l].qkv, 3 * d.D, 3 * d.D, stream));
+    RC(vdk_transpose_cast_f32_bf16(params + p.blk[l].proj_w, d.D, d.D, d.D, wt + p.blkT[l].proj, d.D, d.D, stream));
+    RC(vdk_transpose_cast_f32_bf16(params + p.blk[l].fc1_w, d.D, d.M, d.D, wt + p.blkT[l].fc1, d.M, d.M, stream));
+    RC(vdk_transpose_cast_f32_bf16(params + p.blk[l].fc2_w, d.M, d.D, d.M, wt + p.blkT[l].fc2, d.D, d.D, stream));
+  }
+  RC(vdk_transpose_cast_f32_bf16(params + p.head_w, d.D, d.Cp, d.D, wt + p.headT, d.Cp, d.Cp, stream));
+  return VDK_OK;
+}
+
+// x: f32 [B, Cin, img, img] -> logits f32 [B, Cp] (columns C..Cp-1 are padding).  Saves activations in ws.
+int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params, const void* wb16, void* ws, size_t ws_bytes,
+                    float* logits, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  VitDims d; RC(vit_dims(cfg, &d));
+  PLayout p; RC(vit_layout(d, &p));
+  WsPlan w; RC(vit_plan(d, &w));
+  if (!x || !params || !wb16 || !ws || !logits) return vdk_fail(VDK_EINVAL, "vdk_vit_forward: null pointer");
+  if (ws_bytes < w.total) return vdk_fail(VDK_EWORKSPACE, "vdk_vit_forward: workspace too small");
+  char* base = (char*)ws;
+  const bf16_t* wb = (const bf16_t*)wb16;
+  const int T = d.T, D = d.D, M = d.M;
+  float* X = (float*)(base + w.X);
+  float* stats = (float*)(base + w.stats);
+  const size_t XS = (size_t)T * D;
+
+  // patch embedding: im2col-free operand + GEMM whose epilogue drops each patch row at its token slot and adds pos_embed
+  bf16_t* patches = (bf16_t*)(base + w.patches);
+  RC(vdk_patchify_bf16(x, d.B, d.Cin, d.img, d.img, d.ps, patches, d.Kpe, s));
+  RC(gemm(s, patches, d.Kpe, wb + p.pe_w, d.Kpe, X, D, d.B * d.np, D, d.Kpe, VDK_F32, params + p.pe_b, params + p.pos, D, VDK_ACT_NONE,
+          nullptr, 0, 1, d.np, nullptr, 0));
+  RC(vdk_cls_rows(X, (int64_t)d.N * D, d.B, D, params + p.cls, params + p.pos, s));
+
+  const float scale = 0.125f;  // head_dim ** -0.5, head_dim == 64
+  for (int l = 0; l < d.L; ++l) {
+    const PLayout::Blk& b = p.blk[l];
+    float* xin = X + (size_t)(2 * l) * XS; float* xmid = xin + XS; float* xout = xmid + XS;
+    float* mean1 = stats + (size_t)l * 4 * T; float* rstd1 = mean1 + T; float* mean2 = rstd1 + T; float* rstd2 = mean2 + T;
+    bf16_t* h1 = (bf16_t*)(base + w.h1 + l * w.s_h); bf16_t* qkv = (bf16_t*)(base + w.qkv + l * w.s_qkv);
+    float* lse = (float*)(base + w.lse + l * w.s_lse); bf16_t* o = (bf16_t*)(base + w.o + l * w.s_h);
+    bf16_t* h2 = (bf16_t*)(base + w.h2 + l * w.s_h); bf16_t* u = (bf16_t*)(base + w.u + l * w.s_u); bf16_t* g = (bf16_t*)(base + w.g + l * w.s_u);
+    // x = x + proj(attn(norm1(x)))
+    RC(vdk_layernorm_fwd(xin, D, T, D, params + b.n1w, params + b.n1b, d.eps, h1, D, VDK_BF16, mean1, rstd1, s));
+    RC(gemm(s, h1, D, wb + b.qkv_w, D, qkv, 3 * D, T, 3 * D, D, VDK_BF16, params + b.qkv_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
+    RC(vdk_attention_fwd(qkv, 3 * D, o, D, lse, d.B, d.N, d.H, 64, scale, s));
+    RC(gemm(s, o, D, wb + b.proj_w, D, xmid, D, T, D, D, VDK_F32, params + b.proj_b, xin, D, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
+    // x = x + fc2(gelu(fc1(norm2(x))))
+    RC(vdk_layernorm_fwd(xmid, D, T, D, params + b.n2w, params + b.n2b, d.eps, h2, D, VDK_BF16, mean2, rstd2, s));
+    RC(gemm(s, h2, D, wb + b.fc1_w, D, g, M, T, M, D, VDK_BF16, params + b.fc1_b, nullptr, 0, VDK_ACT_GELU, u, M, 1, 0, nullptr, 0));
+    RC(gemm(s, g, M, wb + b.fc2_w, M, xout, D, T, D, M, VDK_F32, params + b.fc2_b, xmid, D, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
+  }
+  // final norm on the class-token rows only (LayerNorm is per token; global_pool='token' keeps token 0), then the head
+  float* xl = X + (size_t)(2 * d.L) * XS;
+  float* meanf = stats + (size_t)d.L * 4 * T; float* rstdf = meanf + d.B;
+  bf16_t* hf = (bf16_t*)(base + w.hf);
+  RC(vdk_layernorm_fwd(xl, (int64_t)d.N * D, d.B, D, params + p.norm_w, params + p.norm_b, d.eps, hf, D, VDK_BF16, meanf, rstdf, s));
+  RC(gemm(s, hf, D, wb + p.head_w, D, logits, d.Cp, d.B, d.Cp, D, VDK_F32, params + p.head_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
+  return VDK_OK;
+}
+
+// wgrad of one Linear: dW[out,in] = dY^T X  and db = colsum(dY); dY bf16 [rows, out], X bf16 [rows, in]
+static int linear_wgrad(hipStream_t s, const VitDims& d, const WsPlan& w, char* base, const bf16_t* dY, int64_t lddy, const bf16_t* Xa,
+                        int64_t ldx, int rows, int rows_pad, int out, int in, float* dW, float* db, int dy_row_group) {
+  bf16_t* tA = (bf16_t*)(base + w.tA); bf16_t* tB = (bf16_t*)(base + w.tB);
+  RC(vdk_transpose_bf16(dY, lddy, rows, out, tA, rows_pad, rows_pad, dy_row_group, s));
+  RC(vdk_transpose_bf16(Xa, ldx, rows, in, tB, rows_pad, rows_pad, 0, s));
+  const int sk = wgrad_splitk(out, in, rows_pad);
+  RC(gemm(s, tA, rows_pad, tB, rows_pad, dW, in, out, in, rows_pad, VDK_F32, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, sk, 0, base + w.slabs,
+          w.slabs_bytes));
+  if (db && dy_row_group == 0) RC(vdk_colsum_bf16(dY, lddy, rows, out, db, base + w.csws, w.csws_bytes, s));
+  return VDK_OK;
+}
+
+// dlogits: bf16 [B, Cp] (what vdk_softmax_ce writes, padding columns zero).  grads: flat fp32, param layout,
+// fully overwritten (zero_grad semantics).  on_ready(user, offset, numel) is called on the host right after the
+// kernels producing grads[offset, offset+numel) have been enqueued (reverse layer order) so that a data-parallel
+// caller can start that bucket's all-reduce on another stream; may be NULL.
+int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* params, const void* wb16, const void* wt16, void* ws,
+                     size_t ws_bytes, float* grads, vdk_grad_ready_fn on_ready, void* user, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  VitDims d; RC(vit_dims(cfg, &d));
+  PLayout p; RC(vit_layout(d, &p));
+  WsPlan w; RC(vit_plan(d, &w));
+  if (!dlogits || !params || !wb16 || !wt16 || !ws || !grads) return vdk_fail(VDK_EINVAL, "vdk_vit_backward: null pointer");
+  if (ws_bytes < w.total) return vdk_fail(VDK_EWORKSPACE, "vdk_vit_backward: workspace too small");
+  char* base = (char*)ws;
+  const bf16_t* wt = (const bf16_t*)wt16;
+  const int T = d.T, D = d.D, M = d.M;
+  float* X = (float*)(base + w.X);
+  float* stats = (float*)(base + w.stats);
+  const size_t XS = (size_t)T * D;
+  float* dxa = (float*)(base + w.dxa); float* dxm = (float*)(base + w.dxm);
+  bf16_t* dxab = (bf16_t*)(base + w.dxab); bf16_t* dxmb = (bf16_t*)(base + w.dxmb);
+  bf16_t* dbig = (bf16_t*)(base + w.dbig); bf16_t* dsm = (bf16_t*)(base + w.dsm);
+  float* dvec = (float*)(base + w.dvec);
+  void* lnws = base + w.lnws;
+
+  // ---- head + final norm -------------------------------------------------------------------------
+  {
+    const bf16_t* dl = (const bf16_t*)dlogits;
+    bf16_t* hf = (bf16_t*)(base + w.hf);
+    RC(linear_wgrad(s, d, w, base, dl, d.Cp, hf, D, d.B, d.Bp, d.Cp, D, grads + p.head_w, grads + p.head_b, 0));
+    bf16_t* dhf = (bf16_t*)(base + w.dhf);
+    RC(gemm(s, dl, d.Cp, wt + p.headT, d.Cp, dhf, D, d.B, D, d.Cp, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
+    if (hipMemsetAsync(dxa, 0, XS * 4, s) != hipSuccess || hipMemsetAsync(dxab, 0, XS * 2, s) != hipSuccess)
+      return vdk_fail(VDK_ELAUNCH, "vdk_vit_backward: memset failed");
+    float* xl = X + (size_t)(2 * d.L) * XS;
+    float* meanf = stats + (size_t)d.L * 4 * T; float* rstdf = meanf + d.B;
+    RC(vdk_layernorm_bwd(dhf, D, VDK_BF16, xl, (int64_t)d.N * D, meanf, rstdf, params + p.norm_w, nullptr, 0, d.B, D, dxa, (int64_t)d.N * D, dxab,
+                         (int64_t)d.N * D, grads + p.norm_w, grads + p.norm_b, lnws, w.lnws_bytes, s));
+    if (on_ready) on_ready(user, p.norm_w, p.total - p.norm_w);
+  }
+  // ---- blocks, last to first ------------------------------------------------------------------------
+  for (int l = d.L - 1; l >= 0; --l) {
+    const PLayout::Blk& b = p.blk[l];
+    float* xin = X + (size_t)(2 * l) * XS; float* xmid = xin + XS;
+    float* mean1 = stats + (size_t)l * 4 * T; float* rstd1 = mean1 + T; float* mean2 = rstd1 + T; float* rstd2 = mean2 + T;
+    bf16_t* h1 = (bf16_t*)(base + w.h1 + l * w.s_h); bf16_t* qkv = (bf16_t*)(base + w.qkv + l * w.s_qkv);
+    float* lse = (float*)(base + w.lse + l * w.s_lse); bf16_t* o = (bf16_t*)(base + w.o + l * w.s_h);
+    bf16_t* h2 = (bf16_t*)(base + w.h2 + l * w.s_h); bf16_t* u = (bf16_t*)(base + w.u + l * w.s_u); bf16_t* g = (bf16_t*)(base + w.g + l * w.s_u);
+    // MLP branch: dxa / dxab hold dL/dx_out
+    RC(linear_wgrad(s, d, w, base, dxab, D, g, M, T, d.Tp, D, M, grads + b.fc2_w, grads + b.fc2_b, 0));
+    RC(gemm(s, dxab, D, wt + p.blkT[l].fc2, D, dbig, M, T, M, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_DGELU, u, M, 1, 0, nullptr, 0));   // du
+    RC(linear_wgrad(s, d, w, base, dbig, M, h2, D, T, d.Tp, M, D, grads + b.fc1_w, grads + b.fc1_b, 0));
+    RC(gemm(s, dbig, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // dh2
+    RC(vdk_layernorm_bwd(dsm, D, VDK_BF16, xmid, D, mean2, rstd2, params + b.n2w, dxa, D, T, D, dxm, D, dxmb, D, grads + b.n2w, grads + b.n2b, lnws,
+                         w.lnws_bytes, s));
+    // attention branch: dxm / dxmb hold dL/dx_mid
+    RC(linear_wgrad(s, d, w, base, dxmb, D, o, D, T, d.Tp, D, D, grads + b.proj_w, grads + b.proj_b, 0));
+    RC(gemm(s, dxmb, D, wt + p.blkT[l].proj, D, dsm, D, T, D, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // do
+    RC(vdk_attention_bwd(qkv, 3 * D, o, dsm, D, lse, dbig, 3 * D, dvec, d.B, d.N, d.H, 64, 0.125f, s));                                    // dqkv
+    RC(linear_wgrad(s, d, w, base, dbig, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, grads + b.qkv_b, 0));
+    RC(gemm(s, dbig, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));  // dh1
+    RC(vdk_layernorm_bwd(dsm, D, VDK_BF16, xin, D, mean1, rstd1, params + b.n1w, dxm, D, T, D, dxa, D, dxab, D, grads + b.n1w, grads + b.n1b, lnws,
+                         w.lnws_bytes, s));
+    if (on_ready) on_ready(user, b.n1w, (l + 1 < d.L ? p.blk[l + 1].n1w : p.norm_w) - b.n1w);
+  }
+  // ---- embeddings -------------------------------------------------------------------------------------
+  {
+    float* dposall = (float*)(base + w.dposall);
+    // d pos_embed[n] = sum_b dx0[b, n];  d cls = d pos_embed[0];  d patch bias = sum_{n >= 1} d pos_embed[n]
+    RC(vdk_reduce_rows_f32(dxa, (int64_t)d.N * D, d.B, (int64_t)d.N * D, grads + p.pos, 1.0f, s));
+    if (hipMemcpyAsync(grads + p.cls, grads + p.pos, (size_t)D * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return vdk_fail(VDK_ELAUNCH, "vdk_vit_backward: memcpy failed");
+    RC(vdk_reduce_rows_f32(grads + p.pos + D, D, d.np, D, grads + p.pe_b, 1.0f, s));
+    (void)dposall;
+    bf16_t* patches = (bf16_t*)(base + w.patches);
+    const int rows = d.B * d.np, rows_pad = (int)up(rows, 64);
+    RC(linear_wgrad(s, d, w, base, dxab, D, patches, d.Kpe, rows, rows_pad, D, d.Kpe, grads + p.pe_w, nullptr, d.np));
+    if (on_ready) on_ready(user, 0, p.blk[0].n1w);
+  }
+  return vdk_check_launch("vdk_vit_backward");
+}
+
+}  // extern "C"

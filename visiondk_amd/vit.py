@@ -1,0 +1,347 @@
+"""Host side of hot path A: timm-compatible VisionTransformer on the native HIP engine (csrc/vit_engine.hip).
+
+Three layers, thinnest first:
+  * `VitEngine`      — owns the flat HBM buffers (fp32 master params, bf16 operand copies, grads, workspace) and
+                       calls vdk_vit_forward / vdk_vit_backward.  No torch arithmetic.
+  * `VisionTransformer(nn.Module)` — what `timm.create_model('vit_*', num_classes=C)` returns to the reference
+                       (models/classifier/classify_model.py:49-54): parameters with timm's state_dict names (views into
+                       the flat buffer), `model(x) -> logits` differentiable through ONE autograd node, so the
+                       reference's Trainer (engine/procedure/train.py:177-215) drives it unchanged.
+  * `FusedTrainStep` — the whole of Trainer.compute_loss + Trainer.update as a fixed kernel sequence: forward, CE,
+                       backward, [bucketed gradient all-reduce], global-norm clip + SGD + EMA + bf16 refresh.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _abi, _lib
+
+
+@dataclass(frozen=True)
+class VitSpec:
+    img_size: int = 224
+    patch_size: int = 16
+    in_chans: int = 3
+    num_classes: int = 1000
+    dim: int = 768
+    depth: int = 12
+    heads: int = 12
+    mlp_dim: int = 3072
+    ln_eps: float = 1e-6
+
+
+# timm 0.9.16 model ids the engine covers (head_dim 64, patch*patch*3 % 8 == 0)
+TIMM_VITS = {
+    "vit_tiny_patch16_224": dict(dim=192, depth=12, heads=3, mlp_dim=768),
+    "vit_small_patch16_224": dict(dim=384, depth=12, heads=6, mlp_dim=1536),
+    "vit_base_patch16_224": dict(dim=768, depth=12, heads=12, mlp_dim=3072),
+    "vit_base_patch32_224": dict(dim=768, depth=12, heads=12, mlp_dim=3072, patch_size=32),
+    "vit_large_patch16_224": dict(dim=1024, depth=24, heads=16, mlp_dim=4096),
+    "vit_base_patch16_384": dict(dim=768, depth=12, heads=12, mlp_dim=3072, img_size=384),
+}
+
+
+def spec_from_timm_name(name: str, num_classes: int, img_size: Optional[int] = None) -> VitSpec:
+    if name not in TIMM_VITS:
+        raise NotImplementedError(f"timm model '{name}' is not covered by the HIP engine yet (have: {sorted(TIMM_VITS)})")
+    kw = dict(TIMM_VITS[name])
+    if img_size is not None:
+        kw["img_size"] = img_size
+    return VitSpec(num_classes=num_classes, **kw)
+
+
+class VitEngine:
+    def __init__(self, spec: VitSpec, device=None, backend: Optional[_lib.Backend] = None):
+        self.spec = spec
+        self.be = backend or _lib.load()
+        self.device = torch.device(device if device is not None else ("cuda" if self.be.device_only else "cpu"))
+        cfg = self._cfg(1)
+        nf, nt, ntr = _abi.I64(0), _abi.I32(0), _abi.I64(0)
+        self.be.check(self.be.lib.vdk_vit_param_count(C.byref(cfg), C.byref(nf), C.byref(nt), C.byref(ntr)), "vdk_vit_param_count")
+        self.n_floats, self.n_tensors, self.n_transposed = nf.value, nt.value, ntr.value
+        self.entries = []
+        name = C.create_string_buffer(96)
+        off, numel, ndim = _abi.I64(0), _abi.I64(0), _abi.I32(0)
+        shape = (_abi.I64 * 4)()
+        for i in range(self.n_tensors):
+            self.be.check(self.be.lib.vdk_vit_param_info(C.byref(cfg), i, name, 96, C.byref(off), C.byref(numel), shape, C.byref(ndim)),
+                          "vdk_vit_param_info")
+            self.entries.append((name.value.decode(), off.value, numel.value, tuple(shape[j] for j in range(ndim.value))))
+        dev = self.device
+        self.params = torch.zeros(self.n_floats, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(self.n_floats, dtype=torch.float32, device=dev)
+        self.wb16 = torch.zeros(self.n_floats, dtype=torch.bfloat16, device=dev)
+        self.wt16 = torch.zeros(self.n_transposed, dtype=torch.bfloat16, device=dev)
+        self.cp = (spec.num_classes + 7) // 8 * 8
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_batch = -1
+        self._logits: Optional[torch.Tensor] = None
+        self._weights_version = None
+
+    # ---- plumbing ------------------------------------------------------------------------------
+    def _cfg(self, batch: int) -> _abi.VitConfig:
+        s = self.spec
+        return _abi.VitConfig(batch, s.img_size, s.patch_size, s.in_chans, s.dim, s.depth, s.heads, s.mlp_dim, s.num_classes, s.ln_eps)
+
+    def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        for n, off, numel, shape in self.entries:
+            if n == name:
+                return flat[off:off + numel].view(shape)
+        raise KeyError(name)
+
+    def _workspace(self, batch: int) -> torch.Tensor:
+        if self._ws is None or self._ws_batch != batch:
+            need = C.c_size_t(0)
+            cfg = self._cfg(batch)
+            self.be.check(self.be.lib.vdk_vit_workspace_bytes(C.byref(cfg), C.byref(need)), "vdk_vit_workspace_bytes")
+            self._ws = None
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+            self._ws_batch = batch
+            self._logits = torch.empty((batch, self.cp), dtype=torch.float32, device=self.device)
+        return self._ws
+
+    def refresh_weights(self, skip_wb16: bool = False) -> None:
+        """Rebuild the bf16 operand copies from the fp32 master weights (after init / load_state_dict / a foreign
+        optimizer step; `FusedTrainStep` refreshes wb16 inside the optimizer kernel and passes skip_wb16=True)."""
+        cfg = self._cfg(1)
+        be = self.be
+        be.check(be.lib.vdk_vit_refresh_weights(C.byref(cfg), be.ptr(self.params), be.ptr(self.wb16), be.ptr(self.wt16),
+                                                int(skip_wb16), be.stream()), "vdk_vit_refresh_weights")
+        self._weights_version = self.params._version
+
+    def _ensure_fresh(self) -> None:
+        if self._weights_version != self.params._version:
+            self.refresh_weights()
+
+    # ---- the two calls -----------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x f32 [B, C, H, W] -> logits f32 [B, Cp] (padded columns beyond num_classes); activations stay in the workspace."""
+        s = self.spec
+        if x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (s.in_chans, s.img_size, s.img_size):
+            raise ValueError(f"expected float32 [B, {s.in_chans}, {s.img_size}, {s.img_size}], got {tuple(x.shape)} {x.dtype}")
+        x = x.contiguous()
+        B = x.shape[0]
+        ws = self._workspace(B)
+        self._ensure_fresh()
+        cfg = self._cfg(B)
+        be = self.be
+        be.check(be.lib.vdk_vit_forward(C.byref(cfg), be.ptr(x), be.ptr(self.params), be.ptr(self.wb16), be.ptr(ws), ws.numel(),
+                                        be.ptr(self._logits), be.stream()), "vdk_vit_forward")
+        return self._logits
+
+    def backward(self, dlogits_bf16: torch.Tensor, on_ready: Optional[Callable[[int, int], None]] = None) -> torch.Tensor:
+        """dlogits bf16 [B, Cp] -> self.grads (flat fp32, overwritten).  Needs the workspace of the matching forward."""
+        B = dlogits_bf16.shape[0]
+        assert dlogits_bf16.dtype == torch.bfloat16 and dlogits_bf16.shape[1] == self.cp and B == self._ws_batch
+        cfg = self._cfg(B)
+        be = self.be
+        cb = _abi.GRAD_READY_FN(lambda user, off, n: on_ready(off, n)) if on_ready is not None else _abi.GRAD_READY_FN(0)
+        be.check(be.lib.vdk_vit_backward(C.byref(cfg), be.ptr(dlogits_bf16), be.ptr(self.params), be.ptr(self.wb16), be.ptr(self.wt16),
+                                         be.ptr(self._ws), self._ws.numel(), be.ptr(self.grads), cb, None, be.stream()),
+                 "vdk_vit_backward")
+        return self.grads
+
+
+# =====================================================================================================
+class _VitFunction(torch.autograd.Function):
+    """model(x) as ONE autograd node: forward = vdk_vit_forward, backward = vdk_vit_backward."""
+
+    @staticmethod
+    def forward(ctx, x, module, *params):
+        eng = module.engine
+        module._sync_flat()
+        logits = eng.forward(x)
+        ctx.module = module
+        ctx.batch = x.shape[0]
+        return logits[:, :eng.spec.num_classes].clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        module = ctx.module
+        eng = module.engine
+        be = eng.be
+        B, Cn = dlogits.shape
+        # bf16 + zero-padded columns for the head GEMMs: one cast kernel on a padded staging buffer
+        stage = torch.zeros((B, eng.cp), dtype=torch.float32, device=dlogits.device)
+        stage[:, :Cn].copy_(dlogits)
+        dl = torch.empty((B, eng.cp), dtype=torch.bfloat16, device=dlogits.device)
+        be.check(be.lib.vdk_cast_f32_bf16(be.ptr(stage), be.ptr(dl), stage.numel(), be.stream()), "vdk_cast_f32_bf16")
+        g = eng.backward(dl)
+        grads = tuple(g[off:off + numel].view(shape) for (_, off, numel, shape) in eng.entries)
+        return (None, None) + grads
+
+
+class VisionTransformer(nn.Module):
+    """Drop-in for the object `timm.create_model('vit_*', pretrained=False, num_classes=C)` hands the reference."""
+
+    def __init__(self, spec: VitSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None):
+        super().__init__()
+        self.spec = spec
+        self.engine = VitEngine(spec, device=device, backend=backend)
+        self.num_classes = spec.num_classes
+        self._names = []
+        for name, off, numel, shape in self.engine.entries:
+            p = nn.Parameter(self.engine.params[off:off + numel].view(shape))
+            pname = name.replace(".", "__")
+            self.register_parameter(pname, p)
+            self._names.append((name, pname))
+        self.reset_parameters(seed)
+
+    # timm names in state_dict()/named_parameters() ---------------------------------------------------
+    def _named_members(self, get_members_fn, prefix='', recurse=True, remove_duplicate=True):
+        for n, v in super()._named_members(get_members_fn, prefix, recurse, remove_duplicate):
+            yield n.replace("__", "."), v
+
+    def state_dict(self, *args, destination=None, prefix='', keep_vars=False):
+        out = {} if destination is None else destination
+        for name, pname in self._names:
+            p = getattr(self, pname)
+            out[prefix + name] = p if keep_vars else p.detach()
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        missing = [n for n, _ in self._names if n not in state_dict]
+        unexpected = [k for k in state_dict if k not in dict(self._names)]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
+        with torch.no_grad():
+            for name, pname in self._names:
+                if name in state_dict:
+                    getattr(self, pname).copy_(state_dict[name].to(self.engine.device).reshape(getattr(self, pname).shape))
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def reset_parameters(self, seed: Optional[int] = None) -> None:
+        """timm defaults + the reference's override (classify_model.py:70-81): N(0,.02) Conv/Linear weights, zero Linear
+        biases (conv bias left at its default init), LayerNorm (1,0), pos_embed trunc-normal .02, cls_token normal 1e-6."""
+        gen = torch.Generator(device="cpu")
+        if seed is not None:
+            gen.manual_seed(seed)
+        else:
+            gen.seed()
+        s = self.spec
+        with torch.no_grad():
+            for name, pname in self._names:
+                p = getattr(self, pname)
+                if name == "pos_embed":
+                    v = torch.empty(p.shape).normal_(0, 0.02, generator=gen).clamp_(-2.0, 2.0)
+                elif name == "cls_token":
+                    v = torch.empty(p.shape).normal_(0, 1e-6, generator=gen)
+                elif name.endswith("norm1.weight") or name.endswith("norm2.weight") or name == "norm.weight":
+                    v = torch.ones(p.shape)
+                elif name == "patch_embed.proj.bias":
+                    bound = 1.0 / math.sqrt(s.in_chans * s.patch_size * s.patch_size)
+                    v = (torch.rand(p.shape, generator=gen) * 2 - 1) * bound
+                elif name.endswith(".bias"):
+                    v = torch.zeros(p.shape)
+                else:
+                    v = torch.empty(p.shape).normal_(0, 0.02, generator=gen)
+                p.copy_(v.to(p.device))
+
+    # keep the flat buffer authoritative even if someone re-pointed a parameter (.to(), deepcopy, p.data = ...)
+    def _sync_flat(self) -> None:
+        eng = self.engine
+        base = eng.params.data_ptr()
+        for (name, off, numel, shape), (_, pname) in zip(eng.entries, self._names):
+            p = getattr(self, pname)
+            if p.data_ptr() != base + off * 4:
+                with torch.no_grad():
+                    eng.params[off:off + numel].view(shape).copy_(p.detach().to(eng.device))
+                    p.data = eng.params[off:off + numel].view(shape)
+
+    def _apply(self, fn, recurse=True):
+        probe = fn(torch.zeros(1, dtype=torch.float32, device=self.engine.device))
+        if probe.device != self.engine.device or probe.dtype != torch.float32:
+            if probe.dtype != torch.float32:
+                raise RuntimeError("visiondk_amd ViT keeps fp32 master weights; bf16 copies are internal")
+            if self.engine.be.device_only and probe.device.type != "cuda":
+                raise RuntimeError("visiondk_amd ViT lives on the GPU (no CPU fallback)")
+            eng = self.engine
+            eng.device = probe.device
+            for attr in ("params", "grads", "wb16", "wt16"):
+                setattr(eng, attr, getattr(eng, attr).to(probe.device))
+            eng._ws, eng._ws_batch, eng._weights_version = None, -1, None
+            for (name, off, numel, shape), (_, pname) in zip(eng.entries, self._names):
+                getattr(self, pname).data = eng.params[off:off + numel].view(shape)
+        return self
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        params = [getattr(self, pname) for _, pname in self._names]
+        return _VitFunction.apply(x, self, *params)
+
+
+def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, device=None, backend=None, img_size=None,
+                 **kwargs) -> VisionTransformer:
+    """`timm.create_model(name, pretrained=..., num_classes=...)` for the ids in TIMM_VITS."""
+    if pretrained:
+        raise RuntimeError("pretrained weights need network access; load a checkpoint with load_state_dict instead")
+    return VisionTransformer(spec_from_timm_name(name, num_classes, img_size), device=device, backend=backend)
+
+
+# =====================================================================================================
+class FusedTrainStep:
+    """Trainer.compute_loss (plain or mixup) + Trainer.update as one fixed kernel sequence over flat buffers.
+
+    loss = CE(label_smoothing) [mixup: lam*CE(ya) + (1-lam)*CE(yb)]  ->  backward  ->  [all-reduce(mean) of the flat
+    gradient in buckets, overlapped with the rest of backward]  ->  clip_grad_norm_(max_norm)  ->  SGD(momentum,
+    weight_decay)  ->  ModelEMA.update  ->  bf16 weight refresh.   (train.py:196,203-215; optimizer.py:119-121; ema.py:28-37)
+    """
+
+    def __init__(self, model: VisionTransformer, lr: float, momentum: float = 0.937, weight_decay: float = 5e-4,
+                 label_smoothing: float = 0.0, max_norm: float = 10.0, ema: bool = True, comm=None):
+        self.model = model
+        self.eng = model.engine
+        self.be = self.eng.be
+        self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
+        self.label_smoothing, self.max_norm = label_smoothing, max_norm
+        dev = self.eng.device
+        self.momentum_buf = torch.zeros_like(self.eng.params)
+        self.ema = self.eng.params.clone() if ema else None
+        self.updates = 0
+        self.comm = comm
+        self._normsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        need = C.c_size_t(0)
+        self.be.check(self.be.lib.vdk_sumsq_workspace_bytes(C.byref(need)), "vdk_sumsq_workspace_bytes")
+        self._sumsq_ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        self._loss_rows: Optional[torch.Tensor] = None
+        self._dl: Optional[torch.Tensor] = None
+        self.param_groups = [{"lr": lr, "momentum": momentum, "weight_decay": weight_decay}]  # Trainer reads param_groups[0]['lr']
+
+    def step(self, x: torch.Tensor, y: torch.Tensor, y_b: Optional[torch.Tensor] = None, lam: float = 1.0) -> torch.Tensor:
+        eng, be = self.eng, self.be
+        model = self.model
+        model._sync_flat()
+        B = x.shape[0]
+        logits = eng.forward(x)
+        if self._loss_rows is None or self._loss_rows.shape[0] != B:
+            self._loss_rows = torch.empty(B, dtype=torch.float32, device=eng.device)
+            self._dl = torch.empty((B, eng.cp), dtype=torch.bfloat16, device=eng.device)
+        world = self.comm.world_size if self.comm is not None else 1
+        be.check(be.lib.vdk_softmax_ce(be.ptr(logits), eng.cp, B, eng.spec.num_classes, be.ptr(y), be.ptr(y_b), lam,
+                                       self.label_smoothing, 1.0 / B, be.ptr(self._loss_rows), be.ptr(self._dl), eng.cp, None, 0,
+                                       be.stream()), "vdk_softmax_ce")
+        if self.comm is not None:
+            self.comm.begin_step(eng.grads)
+            eng.backward(self._dl, on_ready=self.comm.on_grad_ready)
+            self.comm.finish_step()
+        else:
+            eng.backward(self._dl)
+        lr = self.param_groups[0]["lr"]
+        self.updates += 1
+        d = 0.9999 * (1 - math.exp(-self.updates / 2000)) if self.ema is not None else 0.0
+        be.check(be.lib.vdk_sumsq_f32(be.ptr(eng.grads), eng.n_floats, be.ptr(self._normsq), be.ptr(self._sumsq_ws),
+                                      self._sumsq_ws.numel(), be.stream()), "vdk_sumsq_f32")
+        be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema),
+                                     be.ptr(eng.wb16), eng.n_floats, lr, self.momentum, self.weight_decay, 1.0 / world,
+                                     be.ptr(self._normsq), self.max_norm, d, int(self.updates == 1), be.stream()), "vdk_sgd_step")
+        eng.refresh_weights(skip_wb16=True)
+        return self._loss_rows
+
+    def loss_value(self) -> float:
+        """mean loss of the last step (this is the only device->host sync; the reference does it every step, train.py:122)."""
+        return float(self._loss_rows.mean().item())
