@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json's headline metric on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): ViT-B/16 classifier, bf16 MFMA operands / fp32 accumulate + fp32 master weights,
+synthetic ImageNet-1k 224x224, batch 256 PER GPU (weak scaling), one step = forward + CE(label_smoothing 0.05) +
+backward + [RCCL all-reduce of the flat gradient, overlapped] + clip(10) + SGD(0.006, 0.937, 5e-4) + EMA (rank 0), i.e.
+Trainer.compute_loss + Trainer.update of the reference (engine/procedure/train.py:177-215, configs/classification/pet.yaml).
+Inputs are resident in HBM before the timed region.  Secondary metric (same JSON line, key "cbir"): CBIR query-pairs/s,
+10k queries x 1M gallery, D=128, k=100 (configs[3] on one GPU).
+
+Prints ONE JSON line on rank 0 (driver contract) with `roofline` (dominant kernel: the bf16 GEMM, timed live with HIP events
+on its launch stream inside the timed region) and `cpu_baseline` (the oracle restatement timed on this box's host cores,
+bounded sample, rank 0 at N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+VIT_FLOP_PER_IMG = 105.38e9     # fwd+bwd, 2*MACs, attention included
+PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline_vit(seconds_budget: float = 25.0):
+    """Oracle (plain-torch fp32 restatement of the reference's CPU path) fwd+bwd+SGD step, bounded sample."""
+    from oracle.vit_ref import VisionTransformerRef, train_step_reference
+    torch.manual_seed(2)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    bs = 16
+    model = VisionTransformerRef(224, 16, 3, 1000, 768, 12, 12)
+    x = torch.randn(bs, 3, 224, 224)
+    y = torch.randint(0, 1000, (bs,))
+    bufs = None
+    t0 = time.time()
+    _, _, _, _, bufs = train_step_reference(model, x, y, lr=0.006, momentum=0.937, weight_decay=5e-4, label_smoothing=0.05, momentum_bufs=bufs)
+    warm = time.time() - t0
+    steps = max(1, min(4, int((seconds_budget - warm) / max(warm, 1e-3))))
+    t0 = time.time()
+    for _ in range(steps):
+        train_step_reference(model, x, y, lr=0.006, momentum=0.937, weight_decay=5e-4, label_smoothing=0.05, momentum_bufs=bufs)
+    dt = time.time() - t0
+    return {"value": round(bs * steps / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/vit_ref.py ViT-B/16 fp32 fwd+bwd+clip+SGD, bs={bs}, {steps} step(s) after 1 warm-up, torch CPU"}
+
+
+def bench_cbir(dev, nq=10000, n=1_000_000, d=128, k=100, iters=3, with_cpu=True):
+    from visiondk_amd import cbir
+    g = torch.Generator(device="cpu"); g.manual_seed(0)
+    gal = cbir.l2_normalize(torch.randn(n, d, generator=g).to(dev))
+    g.manual_seed(1)
+    qry = cbir.l2_normalize(torch.randn(nq, d, generator=g).to(dev))
+    index = cbir.FlatIPIndex(d, device=dev)
+    index.add(gal)
+    s, i = index.search(qry, k)   # warm-up (allocates the workspace)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        s, i = index.search(qry, k)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    pairs = nq * n / (ms * 1e-3)
+    tflops = 2.0 * nq * n * d / (ms * 1e-3) / 1e12
+    qb = 256
+    alg_bytes = -(-nq // qb) * n * d * 4 + nq * d * 4 + nq * k * 12   # BASELINE.md §2 definition, qb=256, s_g=4
+    out = {"metric": "CBIR query-pairs/sec (exact fp32 inner product + top-100)", "value": pairs, "unit": "pairs/sec",
+           "ms_per_search": ms, "config": {"workload": f"cbir Q={nq} N={n} D={d} k={k} fp32 gallery, 1 GPU"}, "dtype": "f32",
+           "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS,
+                        "traffic": None, "note": "v_mfma_f32_32x32x2_f32 (exact fp32 keeps top-k bit-exact); HBM view: "
+                        f"{alg_bytes / (ms * 1e-3) / 1e9:.0f} GB/s of {PEAK_HBM_GBS:.0f} at qb={qb}, s_g=4 B"}}
+    if with_cpu:
+        from oracle import cbir as ocbir
+        qs = qry[:64].cpu().numpy(); gs = gal[:500_000].cpu().numpy()
+        t0 = time.time(); so, io = ocbir.flat_ip_search(qs, gs, k); dt = time.time() - t0
+        out["cpu_baseline"] = {"value": 64 * 500_000 / dt, "unit": "pairs/sec", "cores": os.cpu_count(), "kind": "port",
+                               "sample": "oracle/cbir_oracle.c (OpenMP, AVX2 fmaf chains): 64 queries x 500k gallery rows, D=128, k=100"}
+        # parity on the sample: the GPU's answer restricted to the same gallery prefix
+        idx2 = cbir.FlatIPIndex(d, device=dev); idx2.add(gal[:500_000])
+        s2, i2 = idx2.search(qry[:64], k)
+        out["parity_vs_oracle"] = {"indices_equal": bool((i2.cpu().numpy() == io).all()),
+                                   "scores_bit_equal": bool((s2.cpu().numpy().view("uint32") == so.view("uint32")).all())}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE: 256)")
+    ap.add_argument("--no-cbir", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    comm = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from visiondk_amd import _lib, comm as vcomm, vit
+    be = _lib.load()
+
+    spec = vit.spec_from_timm_name("vit_base_patch16_224", 1000)
+    model = vit.VisionTransformer(spec, device=dev, seed=2)
+    if world > 1:
+        comm = vcomm.GradAllReduce()
+        comm.broadcast_params(model.engine.params, src=0)
+    step = vit.FusedTrainStep(model, lr=0.006, momentum=0.937, weight_decay=5e-4, label_smoothing=0.05, max_norm=10.0,
+                              ema=(rank == 0), comm=comm)
+    g = torch.Generator(device="cpu"); g.manual_seed(1000 + rank)
+    x = torch.randn(args.batch, 3, 224, 224, generator=g).to(dev)
+    y = torch.randint(0, 1000, (args.batch,), generator=g).to(dev)
+
+    for _ in range(args.warmup):
+        step.step(x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    # live per-launch timing of the dominant kernel (bf16 GEMM) with HIP events on the launch stream
+    launches_per_step = 7 * spec.depth * 2 + 8
+    be.check(be.lib.vdk_prof_begin(launches_per_step * args.steps + 64), "vdk_prof_begin")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.step(x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    gemm_ms, gemm_n, gemm_fl = C.c_double(0), C.c_int64(0), C.c_double(0)
+    be.check(be.lib.vdk_prof_end(C.byref(gemm_ms), C.byref(gemm_n), C.byref(gemm_fl)), "vdk_prof_end")
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = step.loss_value()
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        value = imgs / dt
+        per_gpu_tflops = value / world * VIT_FLOP_PER_IMG / 1e12
+        gemm_avg_ms = gemm_ms.value / max(gemm_n.value, 1)
+        gemm_tflops = gemm_fl.value / max(gemm_ms.value, 1e-9) / 1e9
+        out = {
+            "metric": "images/sec fwd+bwd+optimizer step (ViT-B/16, bs=256 per GPU)", "value": value, "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "ViT-B/16 ICT, synthetic ImageNet-1k 224x224, random-init weights (reference re-init), "
+                                   f"per-GPU batch {args.batch}, CE label_smoothing 0.05, SGD 0.006/0.937/5e-4, clip 10, EMA on rank 0",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": loss},
+            "model_flops_utilisation": {"achieved_tflops_per_gpu": per_gpu_tflops, "peak": PEAK_BF16_TFLOPS, "frac": per_gpu_tflops / PEAK_BF16_TFLOPS,
+                                        "flop_per_image": VIT_FLOP_PER_IMG},
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": gemm_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": gemm_tflops / PEAK_BF16_TFLOPS, "traffic": None,
+                         "avg_launch_ms": gemm_avg_ms, "launches": gemm_n.value, "flops_per_launch": gemm_fl.value / max(gemm_n.value, 1),
+                         "gemm_share_of_step_time": gemm_ms.value / (dt * 1e3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_vit()
+        if world == 1 and not args.no_cbir:
+            del step, model
+            torch.cuda.empty_cache()
+            out["cbir"] = bench_cbir(dev, with_cpu=not args.no_cpu_baseline)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -90,6 +90,11 @@ typedef struct VdkGemmDesc {
 int vdk_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t splitk, size_t* bytes);
 int vdk_gemm_bf16_nt(const VdkGemmDesc* d, void* ws, size_t ws_bytes, void* stream);
 
+/* live GEMM timing for bench.py's `roofline` (HIP events on the launch stream around every GEMM kernel):
+ * begin(max_launches) pre-creates the events; end() synchronises and returns the totals since begin(). */
+int vdk_prof_begin(int32_t max_launches);
+int vdk_prof_end(double* total_ms, int64_t* launches, double* total_flops);
+
 /* out[c][r] = in[r][c] (bf16), rows R..Rpad-1 of the new contraction dim zero-filled; feeds wgrad.
  * in_row_group > 0: logical row r lives at physical row r + r/in_row_group + 1 (token buffer without cls rows). */
 int vdk_transpose_bf16(const void* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, int32_t Rpad,

@@ -56,6 +56,11 @@ static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+typedef void* hipEvent_t;
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 #define hipMemcpyDeviceToDevice 3
 #define hipMemcpyDefault 4
 

@@ -231,7 +231,43 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
   }
 }
 
+// ---- optional live profiling of the GEMM launches (bench.py's `roofline` object) --------------------------------
+// vdk_prof_begin(n) pre-creates n event pairs; while enabled every vdk_gemm_bf16_nt call brackets its kernel(s) with
+// hipEventRecord on the launch stream; vdk_prof_end() synchronises and returns total GEMM time, launches and flops.
+#include <vector>
+static std::vector<hipEvent_t> g_prof_ev;
+static std::vector<double> g_prof_flops;
+static size_t g_prof_used = 0;
+static bool g_prof_on = false;
+
 extern "C" {
+
+int vdk_prof_begin(int32_t max_launches) {
+  if (max_launches < 0) return vdk_fail(VDK_EINVAL, "vdk_prof_begin: bad argument");
+  while (g_prof_ev.size() < (size_t)max_launches * 2) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vdk_prof_begin: hipEventCreate failed");
+    g_prof_ev.push_back(e);
+  }
+  g_prof_flops.clear();
+  g_prof_used = 0;
+  g_prof_on = true;
+  return VDK_OK;
+}
+int vdk_prof_end(double* total_ms, int64_t* launches, double* total_flops) {
+  g_prof_on = false;
+  double ms = 0.0, fl = 0.0;
+  for (size_t i = 0; i + 1 < g_prof_used; i += 2) {
+    if (hipEventSynchronize(g_prof_ev[i + 1]) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vdk_prof_end: event sync failed");
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_prof_ev[i], g_prof_ev[i + 1]) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vdk_prof_end: elapsed failed");
+    ms += t; fl += g_prof_flops[i / 2];
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = (int64_t)(g_prof_used / 2);
+  if (total_flops) *total_flops = fl;
+  return VDK_OK;
+}
 
 int vdk_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t splitk, size_t* bytes) {
   if (!bytes || M <= 0 || N <= 0 || splitk < 1) return vdk_fail(VDK_EINVAL, "vdk_gemm_splitk_workspace_bytes: bad argument");
@@ -274,7 +310,14 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   }
   p.k_per_split = kps;
   const int ntn = (d->N + G_BN - 1) / G_BN, ntm = (d->M + G_BM - 1) / G_BM;
+  const bool prof = g_prof_on && g_prof_used + 2 <= g_prof_ev.size();
+  if (prof) (void)hipEventRecord(g_prof_ev[g_prof_used], stream);
   hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256), 0, stream, p);
+  if (prof) {   // the GEMM kernel only (the split-K combine is a separate, HBM-bound kernel)
+    (void)hipEventRecord(g_prof_ev[g_prof_used + 1], stream);
+    g_prof_flops.push_back(2.0 * d->M * d->N * d->K);
+    g_prof_used += 2;
+  }
   if (splitk > 1) {
     long mn = (long)d->M * d->N, n4 = mn / 4;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream,
