@@ -40,8 +40,9 @@ PEAK_HBM_GBS = 8000.0
 def cpu_baseline_vit(seconds_budget: float = 25.0):
     """Oracle (plain-torch fp32 restatement of the reference's CPU path) fwd+bwd+SGD step, bounded sample."""
     from oracle.vit_ref import VisionTransformerRef, train_step_reference
+    from oracle.cbir import usable_cores
     torch.manual_seed(2)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     bs = 16
     model = VisionTransformerRef(224, 16, 3, 1000, 768, 12, 12)
@@ -90,7 +91,7 @@ def bench_cbir(dev, nq=10000, n=1_000_000, d=128, k=100, iters=3, with_cpu=True)
         from oracle import cbir as ocbir
         qs = qry[:64].cpu().numpy(); gs = gal[:500_000].cpu().numpy()
         t0 = time.time(); so, io = ocbir.flat_ip_search(qs, gs, k); dt = time.time() - t0
-        out["cpu_baseline"] = {"value": 64 * 500_000 / dt, "unit": "pairs/sec", "cores": os.cpu_count(), "kind": "port",
+        out["cpu_baseline"] = {"value": 64 * 500_000 / dt, "unit": "pairs/sec", "cores": ocbir.usable_cores(), "kind": "port",
                                "sample": "oracle/cbir_oracle.c (OpenMP, AVX2 fmaf chains): 64 queries x 500k gallery rows, D=128, k=100"}
         # parity on the sample: the GPU's answer restricted to the same gallery prefix
         idx2 = cbir.FlatIPIndex(d, device=dev); idx2.add(gal[:500_000])

@@ -96,9 +96,10 @@ int vdk_prof_begin(int32_t max_launches);
 int vdk_prof_end(double* total_ms, int64_t* launches, double* total_flops);
 
 /* out[c][r] = in[r][c] (bf16), rows R..Rpad-1 of the new contraction dim zero-filled; feeds wgrad.
- * in_row_group > 0: logical row r lives at physical row r + r/in_row_group + 1 (token buffer without cls rows). */
+ * in_row_group > 0: logical row r lives at physical row r + r/in_row_group + 1 (token buffer without cls rows).
+ * colsum_partial (optional): f32 [ceil(Rpad/64)][C] per-row-tile column sums (the Linear bias gradient rides along). */
 int vdk_transpose_bf16(const void* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, int32_t Rpad,
-                       int32_t in_row_group, void* stream);
+                       int32_t in_row_group, float* colsum_partial, void* stream);
 
 
 /* timm Attention core: softmax(q k^T * scale) v per head, flash-style (the N x N matrix is never

@@ -11,6 +11,19 @@ from .build import build
 _lib = None
 
 
+def usable_cores() -> int:
+    """Host cores this process may really use: min(affinity, cgroup cpu quota) — a 256-core box may grant 16."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
@@ -22,6 +35,8 @@ def lib() -> C.CDLL:
                                            C.c_void_p]
         _lib.oracle_ip_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         _lib.oracle_ip_pair.restype = C.c_float
+        _lib.oracle_set_threads.argtypes = [C.c_int]
+        _lib.oracle_set_threads(usable_cores())
     return _lib
 
 

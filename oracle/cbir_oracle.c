@@ -29,6 +29,13 @@
 
 #define PANEL 16
 
+#ifdef _OPENMP
+#include <omp.h>
+void oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+#else
+void oracle_set_threads(int n) { (void)n; }
+#endif
+
 /* out[r] = x[r] / max(||x[r]||_2, eps); norm accumulated in float64 (torch's vectorised float sum
  * is not order-defined; consumers compare with a 1e-6 relative tolerance). */
 void oracle_l2norm_rows(const float* x, int64_t n, int32_t d, float eps, float* out) {

@@ -74,3 +74,14 @@ def test_wgrad_via_transposes(be, dev):
     dw = ops.gemm_nt(ops.transpose_pad(dy, backend=be), ops.transpose_pad(x, backend=be), out_dtype=torch.float32,
                      splitk=2, backend=be)
     assert _rel(dw, dy.float().T @ x.float()) < 1e-5
+
+
+def test_transpose_fused_colsum(be, dev):
+    torch.manual_seed(4)
+    R, C = 300, 72
+    x = torch.randn(R, C).bfloat16().to(dev)
+    rp = 320
+    part = torch.zeros((rp // 64, C), dtype=torch.float32, device=dev)
+    y = ops.transpose_pad(x, rpad=rp, colsum_partial=part, backend=be)
+    assert torch.equal(y[:, :R], x.T)
+    assert _rel(part.sum(0), x.float().sum(0)) < 1e-6

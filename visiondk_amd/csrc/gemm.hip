@@ -204,7 +204,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // out[c][r] = in[r][c] for r < R, 0 for R <= r < Rpad (bf16).  64x64 tiles through LDS.
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, long ldi, int R, int Cc,
-                                                             bf16_t* __restrict__ out, long ldo, int Rpad, int row_group) {
+                                                             bf16_t* __restrict__ out, long ldo, int Rpad, int row_group,
+                                                             float* __restrict__ colsum_partial) {
   __shared__ bf16_t tile[64][66];
   const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int tid = threadIdx.x;
@@ -221,6 +222,11 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
     tile[row][cw] = v0; tile[row][cw + 1] = v1;
   }
   __syncthreads();
+  if (colsum_partial && tid < 64 && c0 + tid < Cc) {  // bias gradient rides along: per-row-tile column sums
+    float sacc = 0.f;
+    for (int r = 0; r < 64; ++r) sacc += bf2f(tile[r][tid]);
+    colsum_partial[(long)blockIdx.x * Cc + c0 + tid] = sacc;
+  }
   for (int i = 0; i < 8; ++i) {
     int col = i * 8 + (tid >> 5), rw = (tid & 31) * 2;   // output row = input col
     int gc = c0 + col, gr = r0 + rw;
@@ -330,13 +336,15 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
 
 // out[C][ldo] (bf16) = in[R][ldi]^T, rows R..Rpad-1 of the contraction dim zero-filled.  Rpad even.
 // in_row_group > 0: logical row r is read from physical row r + r / in_row_group + 1 (token buffer minus cls rows).
+// colsum_partial (optional): f32 [ceil(Rpad/64)][C] per-row-tile column sums of `in` (Linear bias gradient); reduce with
+// vdk_reduce_rows_f32(colsum_partial, C, ceil(Rpad/64), C, db, 1).
 int vdk_transpose_bf16(const void* in, int64_t ldi, int32_t R, int32_t Cc, void* out, int64_t ldo, int32_t Rpad,
-                       int32_t in_row_group, void* stream) {
+                       int32_t in_row_group, float* colsum_partial, void* stream) {
   if (!in || !out || R < 0 || Cc <= 0 || Rpad < R || (Rpad & 1) || ldo < Rpad || (ldi & 1) || (ldo & 1))
     return vdk_fail(VDK_EINVAL, "vdk_transpose_bf16: bad argument");
   if (Rpad == 0) return VDK_OK;
   hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((Rpad + 63) / 64), (unsigned)((Cc + 63) / 64)), dim3(256), 0,
-                     (hipStream_t)stream, (const bf16_t*)in, (long)ldi, (int)R, (int)Cc, (bf16_t*)out, (long)ldo, (int)Rpad, (int)in_row_group);
+                     (hipStream_t)stream, (const bf16_t*)in, (long)ldi, (int)R, (int)Cc, (bf16_t*)out, (long)ldo, (int)Rpad, (int)in_row_group, colsum_partial);
   return vdk_check_launch("vdk_transpose_bf16");
 }
 

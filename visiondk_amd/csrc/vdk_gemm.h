@@ -22,4 +22,4 @@ struct GemmParams {
 
 // in-library launcher (no descriptor copy through the C ABI)
 extern "C" int vdk_gemm_bf16_nt(const VdkGemmDesc* d, void* ws, size_t ws_bytes, void* stream);
-extern "C" int vdk_transpose_bf16(const void* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, int32_t Rpad, int32_t in_row_group, void* stream);
+extern "C" int vdk_transpose_bf16(const void* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, int32_t Rpad, int32_t in_row_group, float* colsum_partial, void* stream);

@@ -206,7 +206,8 @@ static int vit_plan(const VitDims& d, WsPlan* w) {
   }
   w->slabs_bytes = sl; w->slabs = w_take(cur, sl);
   vdk_layernorm_bwd_workspace_bytes(d.T, d.D, &w->lnws_bytes); w->lnws = w_take(cur, w->lnws_bytes);
-  size_t cs = 0; vdk_colsum_bf16_workspace_bytes(d.T, (int)big, &cs); w->csws_bytes = cs; w->csws = w_take(cur, cs);
+  size_t cs = (size_t)((tcols + 63) / 64) * trows * 4;   // per-row-tile column sums written by the dY transposes
+  w->csws_bytes = cs; w->csws = w_take(cur, cs);
   w->dhf = w_take(cur, (size_t)d.B * D * 2);
   w->dposall = w_take(cur, (size_t)d.N * D * 4);
   w->total = cur;
@@ -329,12 +330,13 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
 static int linear_wgrad(hipStream_t s, const VitDims& d, const WsPlan& w, char* base, const bf16_t* dY, int64_t lddy, const bf16_t* Xa,
                         int64_t ldx, int rows, int rows_pad, int out, int in, float* dW, float* db, int dy_row_group) {
   bf16_t* tA = (bf16_t*)(base + w.tA); bf16_t* tB = (bf16_t*)(base + w.tB);
-  RC(vdk_transpose_bf16(dY, lddy, rows, out, tA, rows_pad, rows_pad, dy_row_group, s));
-  RC(vdk_transpose_bf16(Xa, ldx, rows, in, tB, rows_pad, rows_pad, 0, s));
+  float* csp = (db && dy_row_group == 0) ? (float*)(base + w.csws) : nullptr;   // bias gradient rides along with the dY transpose
+  RC(vdk_transpose_bf16(dY, lddy, rows, out, tA, rows_pad, rows_pad, dy_row_group, csp, s));
+  RC(vdk_transpose_bf16(Xa, ldx, rows, in, tB, rows_pad, rows_pad, 0, nullptr, s));
   const int sk = wgrad_splitk(out, in, rows_pad);
   RC(gemm(s, tA, rows_pad, tB, rows_pad, dW, in, out, in, rows_pad, VDK_F32, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, sk, 0, base + w.slabs,
           w.slabs_bytes));
-  if (db && dy_row_group == 0) RC(vdk_colsum_bf16(dY, lddy, rows, out, db, base + w.csws, w.csws_bytes, s));
+  if (csp) RC(vdk_reduce_rows_f32(csp, out, (rows_pad + 63) / 64, out, db, 1.0f, s));
   return VDK_OK;
 }
 

@@ -60,7 +60,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=torch.bfloat16, bias:
 
 
 def transpose_pad(x: torch.Tensor, rpad: Optional[int] = None, backend=None, rows: Optional[int] = None,
-                  row_group: int = 0) -> torch.Tensor:
+                  row_group: int = 0, colsum_partial: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x bf16 [R, C] -> [C, Rpad] with zero-filled padding columns (Rpad even, default: R rounded up to 64)."""
     be = _be(backend)
     assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
@@ -71,7 +71,7 @@ def transpose_pad(x: torch.Tensor, rpad: Optional[int] = None, backend=None, row
         rpad = (R + 63) // 64 * 64
     out = torch.empty((Cc, rpad), dtype=torch.bfloat16, device=x.device)
     be.check(be.lib.vdk_transpose_bf16(be.ptr(x) if x.is_contiguous() else x.data_ptr(), x.stride(0), R, Cc,
-                                       be.ptr(out), rpad, rpad, row_group, be.stream()), "vdk_transpose_bf16")
+                                       be.ptr(out), rpad, rpad, row_group, be.ptr(colsum_partial), be.stream()), "vdk_transpose_bf16")
     return out
 
 
