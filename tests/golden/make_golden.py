@@ -1,0 +1,139 @@
+"""Generate the committed golden fixtures from the REFERENCE's own code, run in the build container.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+/root/reference's torch-only modules are imported BY FILE PATH (whole-package imports fail: timm / torchvision /
+faiss / torchmetrics are not installable here).  The fixtures travel to the GPU box; /root/reference does
+not.  Everything is seeded; re-running reproduces the files bit-for-bit on the same torch build.
+"""
+import importlib.util
+import math
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REF = Path("/root/reference")
+OUT = Path(__file__).resolve().parent
+sys.dont_write_bytecode = True
+
+
+def load(rel, name):
+    spec = importlib.util.spec_from_file_location(name, REF / rel)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def main():
+    torch.manual_seed(0)
+    loss_m = load("models/losses/loss.py", "ref_loss")
+    ema_m = load("models/ema.py", "ref_ema")
+    sch_m = load("engine/scheduler.py", "ref_sched")
+    opt_m = load("engine/optimizer.py", "ref_opt")
+    arc_m = load("models/faceX/head/arcface.py", "ref_arc")
+    cir_m = load("models/faceX/head/circleloss.py", "ref_circle")
+    mv_m = load("models/faceX/head/mv_softmax.py", "ref_mv")
+
+    # ---- losses (models/losses/loss.py:68-76) ---------------------------------------------------------
+    logits = (torch.randn(8, 257) * 3).requires_grad_(True)
+    y = torch.randint(0, 257, (8,))
+    ce = loss_m.create_Lossfn("ce")(label_smooth=0.05)
+    l = ce(logits, y); l.backward()
+    out = {"ce_logits": logits.detach().numpy(), "ce_labels": y.numpy(), "ce_eps": np.float32(0.05), "ce_loss": l.detach().numpy(),
+           "ce_grad": logits.grad.numpy().copy()}
+    # mixup_criterion (engine/procedure/train.py:34-35)
+    yb = torch.randint(0, 257, (8,)); lam = 0.3
+    lg2 = logits.detach().clone().requires_grad_(True)
+    lm = lam * ce(lg2, y) + (1 - lam) * ce(lg2, yb); lm.backward()
+    out.update(mix_labels_b=yb.numpy(), mix_lam=np.float32(lam), mix_loss=lm.detach().numpy(), mix_grad=lg2.grad.numpy().copy())
+    bl = (torch.randn(8, 5) * 2).requires_grad_(True); bt = (torch.rand(8, 5) > 0.5).float()
+    lb = loss_m.create_Lossfn("bce")()(bl, bt); lb.backward()
+    out.update(bce_logits=bl.detach().numpy(), bce_targets=bt.numpy(), bce_loss=lb.detach().numpy(), bce_grad=bl.grad.numpy().copy())
+    fl = bl.detach().clone().requires_grad_(True)
+    lf = loss_m.create_Lossfn("focal")()(fl, bt); lf.backward()
+    out.update(focal_loss=lf.detach().numpy(), focal_grad=fl.grad.numpy().copy())
+    np.savez(OUT / "losses.npz", **out)
+
+    # ---- EMA (models/ema.py:28-37) over a model state_dict, 3 updates ---------------------------------------
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.LayerNorm(5))
+    ema = ema_m.ModelEMA(model)
+    rec = {"p0": torch.cat([p.detach().flatten() for p in model.parameters()]).numpy()}
+    for it in range(3):
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(torch.randn_like(p) * 0.1)
+        ema.update(model)
+        rec[f"p{it + 1}"] = torch.cat([p.detach().flatten() for p in model.parameters()]).numpy()
+        rec[f"ema{it + 1}"] = torch.cat([p.detach().flatten() for p in ema.ema.parameters()]).numpy()
+    np.savez(OUT / "ema.npz", **rec)
+
+    # ---- LR schedulers (engine/scheduler.py:27-57), stepping once per epoch, 15 epochs ---------------------------
+    sch = {}
+    for name in ["linear", "cosine", "linear_with_warm", "cosine_with_warm"]:
+        for lrf in [None, 0.05]:
+            p = torch.nn.Parameter(torch.zeros(1))
+            opt = torch.optim.SGD([p], lr=0.006, momentum=0.937)
+            s = sch_m.create_Scheduler(name, opt, warm_ep=1 if "warm" in name else 0, epochs=15, lr0=0.006, lrf_ratio=lrf)
+            lrs = []
+            for ep in range(15):
+                lrs.append(opt.param_groups[0]["lr"])
+                opt.step(); s.step()
+            sch[f"{name}_{'none' if lrf is None else 'lrf05'}"] = np.array(lrs, np.float64)
+    np.savez(OUT / "schedulers.npz", **sch)
+
+    # ---- SAM (engine/optimizer.py:29-87): adaptive two-step on a 3-tensor toy problem ---------------------------
+    torch.manual_seed(1)
+    ps = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(3)), torch.nn.Parameter(torch.randn(2, 2))]
+    opt = opt_m.create_Optimizer("sam", lr=0.01, weight_decay=5e-4, momentum=0.937, params=ps)
+    g1 = [torch.randn_like(p) for p in ps]; g2 = [torch.randn_like(p) for p in ps]
+    rec = {"p_init": torch.cat([p.detach().flatten() for p in ps]).numpy(), "g1": torch.cat([g.flatten() for g in g1]).numpy(),
+           "g2": torch.cat([g.flatten() for g in g2]).numpy()}
+    for p, g in zip(ps, g1):
+        p.grad = g.clone()
+    opt.first_step(zero_grad=True)
+    rec["p_perturbed"] = torch.cat([p.detach().flatten() for p in ps]).numpy()
+    for p, g in zip(ps, g2):
+        p.grad = g.clone()
+    opt.second_step(zero_grad=True)
+    rec["p_final"] = torch.cat([p.detach().flatten() for p in ps]).numpy()
+    np.savez(OUT / "sam.npz", **rec)
+
+    # ---- margin heads (models/faceX/head/*.py) + CE, B=8, D=64, C=257 ---------------------------------------------
+    torch.manual_seed(2)
+    heads = {}
+    feats0 = torch.randn(8, 64)
+    labels = torch.randint(0, 257, (8,))
+    for tag, mk in [("arcface", lambda: arc_m.ArcFace(64, 257, margin_arc=0.35, margin_am=0.0, scale=32)),
+                    ("circle", lambda: cir_m.CircleLoss(64, 257, margin=0.25, gamma=256)),
+                    ("mv_am", lambda: mv_m.MV_Softmax(64, 257, is_am=True, margin=0.35, mv_weight=1.12, scale=32)),
+                    ("mv_arc", lambda: mv_m.MV_Softmax(64, 257, is_am=False, margin=0.35, mv_weight=1.12, scale=32))]:
+        torch.manual_seed(3)
+        h = mk()
+        f = feats0.clone().requires_grad_(True)
+        if tag == "arcface":   # plant a target column close to its feature so that cos(theta) > cos(pi - m) branch and a near-1 cosine are hit
+            with torch.no_grad():
+                h.weight[:, labels[0]] = feats0[0] + 0.05 * torch.randn(64)
+        logits = h(f, labels)
+        loss = torch.nn.functional.cross_entropy(logits, labels)
+        loss.backward()
+        heads.update({f"{tag}_weight": h.weight.detach().numpy().copy(), f"{tag}_logits": logits.detach().numpy(),
+                      f"{tag}_loss": loss.detach().numpy(), f"{tag}_dfeats": f.grad.numpy().copy(), f"{tag}_dweight": h.weight.grad.numpy().copy()})
+    heads["feats"] = feats0.numpy(); heads["labels"] = labels.numpy()
+    np.savez(OUT / "heads.npz", **heads)
+
+    # ---- retrieval: IndexFlatIP semantics stated in float64 (faiss is not installable; engine/cbir/evaluation.py:193) ----
+    rng = np.random.default_rng(0)
+    g = rng.standard_normal((1000, 128)).astype(np.float32); q = rng.standard_normal((33, 128)).astype(np.float32)
+    g /= np.linalg.norm(g, axis=1, keepdims=True); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    s64 = q.astype(np.float64) @ g.astype(np.float64).T
+    order = np.argsort(-s64, axis=1, kind="stable")[:, :100]
+    np.savez(OUT / "cbir_small.npz", gallery=g, queries=q, idx_top100=order.astype(np.int64),
+             scores_top100=np.take_along_axis(s64, order, 1))
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,89 @@
+"""Golden fixtures produced by the REFERENCE's own modules (tests/golden/make_golden.py, run where /root/reference
+exists) vs (1) the oracle restatements and (2) the kernels through the C ABI (emulated on CPU, real on -m gpu)."""
+import math
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cbir as ocbir
+from visiondk_amd import cbir, ops, schedule
+
+G = Path(__file__).resolve().parent / "golden"
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).double().cpu(); b = torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def test_ce_and_mixup_kernel_vs_reference_loss(be, dev):
+    z = np.load(G / "losses.npz")
+    logits = torch.from_numpy(z["ce_logits"]).to(dev); y = torch.from_numpy(z["ce_labels"]).to(dev)
+    B = logits.shape[0]
+    loss, _, dlf = ops.softmax_ce(logits, y, label_smoothing=float(z["ce_eps"]), grad_scale=1.0 / B, backend=be)
+    assert abs(loss.mean().item() - float(z["ce_loss"])) < 1e-6 * abs(float(z["ce_loss"])) + 1e-6
+    assert _rel(dlf, z["ce_grad"]) < 1e-5
+    yb = torch.from_numpy(z["mix_labels_b"]).to(dev)
+    loss2, _, dlf2 = ops.softmax_ce(logits, y, yb, float(z["mix_lam"]), float(z["ce_eps"]), 1.0 / B, backend=be)
+    assert abs(loss2.mean().item() - float(z["mix_loss"])) < 2e-6 * abs(float(z["mix_loss"]))
+    assert _rel(dlf2, z["mix_grad"]) < 1e-5
+
+
+def test_bce_kernel_vs_reference_loss(be, dev):
+    z = np.load(G / "losses.npz")
+    x = torch.from_numpy(z["bce_logits"]).to(dev); t = torch.from_numpy(z["bce_targets"]).to(dev)
+    loss, _, dlf = ops.bce_logits(x, t, grad_scale=1.0 / x.numel(), backend=be)
+    assert abs(loss.sum().item() / x.numel() - float(z["bce_loss"])) < 1e-6
+    assert _rel(dlf, z["bce_grad"]) < 1e-5
+
+
+def test_ema_kernel_vs_reference_modelema(be, dev):
+    z = np.load(G / "ema.npz")
+    ema = torch.from_numpy(z["p0"]).clone().to(dev)
+    n = ema.numel()
+    for it in range(3):
+        # feed the fused step a gradient that moves p_{it} to p_{it+1} with lr=1, no momentum/wd, then compare its EMA output
+        p = torch.from_numpy(z[f"p{it}"]).clone().to(dev)
+        g = (torch.from_numpy(z[f"p{it}"]) - torch.from_numpy(z[f"p{it + 1}"])).to(dev)
+        m = torch.zeros(n, device=dev)
+        d = 0.9999 * (1 - math.exp(-(it + 1) / 2000))          # models/ema.py:24
+        ops.sgd_step(p, g, m, lr=1.0, momentum=0.0, weight_decay=0.0, ema=ema, normsq=None, ema_decay=d, first_step=True, backend=be)
+        assert _rel(p, z[f"p{it + 1}"]) < 1e-6
+        assert _rel(ema, z[f"ema{it + 1}"]) < 1e-6
+
+
+def test_schedules_vs_reference_scheduler():
+    z = np.load(G / "schedulers.npz")
+    for key in z.files:
+        name, tag = key.rsplit("_", 1)
+        lrf = None if tag == "none" else 0.05
+        got = [schedule.lr_at(name, t, warm_ep=1 if "warm" in name else 0, epochs=15, lr0=0.006, lrf_ratio=lrf) for t in range(15)]
+        np.testing.assert_allclose(got, z[key], rtol=1e-9, atol=1e-12, err_msg=key)
+
+
+def test_cbir_oracle_and_kernel_vs_float64_fixture(be, dev):
+    z = np.load(G / "cbir_small.npz")
+    q, g = z["queries"], z["gallery"]
+    so, io = ocbir.flat_ip_search(q, g, 100)
+    # the oracle's DEFINED fp32 summation order may swap neighbours whose float64 scores differ by < 2e-6
+    s64 = z["scores_top100"]
+    np.testing.assert_allclose(so, s64, atol=2e-6, rtol=0)
+    diff = io != z["idx_top100"]
+    if diff.any():
+        gaps = np.abs(np.diff(s64, axis=1))
+        rows, cols = np.nonzero(diff)
+        for r, c in zip(rows, cols):
+            near = min(gaps[r, max(c - 1, 0)], gaps[r, min(c, gaps.shape[1] - 1)])
+            assert near < 2e-6, (r, c, near)
+    assert diff.mean() < 0.01
+    index = cbir.FlatIPIndex(128, backend=be, device=dev, cap=4096)
+    index.add(g)
+    s, i = index.search(q, 100)
+    np.testing.assert_array_equal(i, io)
+    np.testing.assert_array_equal(s.view(np.uint32), so.view(np.uint32))
+    # k > N pads with (-FLT_MAX, -1) like faiss
+    s2, i2 = index.search(q[:3], 1024)
+    assert (i2[:, 1000:] == -1).all() and (s2[:, 1000:] == np.float32(-3.4028234663852886e38)).all()
+    assert sorted(i2[0, :1000].tolist()) == list(range(1000))
