@@ -268,6 +268,8 @@ static inline emu_f32x16 emu_mfma_32x32x2_f32(float a, float b, emu_f32x16 c, in
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu_mfma_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu_mfma_16x16x32_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_32x32x2_f32
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_barrier() __syncthreads()

@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   const bf16_t* vb = v + (long)b * N * ld + h * A_HD;
   const int nqt = (N + 31) / 32;
   const int nchunk = (N + A_FWD_KC - 1) / A_FWD_KC;
+  const float scale2 = scale * VDK_LOG2E;
   // every wave runs the same number of q-tile rounds so that barriers stay uniform
   const int rounds = (nqt + 3) / 4;
   for (int rd = 0; rd < rounds; ++rd) {
@@ -128,17 +129,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
           float p[16];
           float mt = -INFINITY;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
+          for (int r = 0; r < 16; ++r) {   // scores in the log2 domain: s2 = s * scale * log2(e)
             const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            float s = (key < N) ? st[r] * scale : -INFINITY;
+            float s = (key < N) ? st[r] * scale2 : -INFINITY;
             p[r] = s; mt = fmaxf(mt, s);
           }
           mt = fmaxf(mt, __shfl_xor(mt, 32));
           const float mn = fmaxf(m, mt);
-          const float alpha = expf(m - mn);
+          const float alpha = fast_exp2(m - mn);
           float ps = 0.f;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { p[r] = expf(p[r] - mn); ps += p[r]; }
+          for (int r = 0; r < 16; ++r) { p[r] = fast_exp2(p[r] - mn); ps += p[r]; }
           l = l * alpha + ps;
           m = mn;
 #pragma unroll
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         *(u32x2*)(orow + d) = (u32x2){pack_bf2(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack_bf2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv)};
         *(u32x2*)(orow + 32 + d) = (u32x2){pack_bf2(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack_bf2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv)};
       }
-      if (hi == 0 && lse) lse[((long)b * H + h) * N + qrow] = m + logf(lt);
+      if (hi == 0 && lse) lse[((long)b * H + h) * N + qrow] = (m + log2f(lt)) * 0.6931471805599453f;  // natural-log LSE
     }
   }
 }
@@ -207,7 +208,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
       for (int e = 0; e < 4; ++e) { dsum = fmaf(bf_lo(a[e]), bf_lo(c[e]), dsum); dsum = fmaf(bf_hi(a[e]), bf_hi(c[e]), dsum); }
     }
     dsum += __shfl_xor(dsum, 32);
-    const float mylse = (active && qrow < N) ? lse[((long)b * H + h) * N + qrow] : 0.f;
+    const float mylse2 = ((active && qrow < N) ? lse[((long)b * H + h) * N + qrow] : 0.f) * VDK_LOG2E;
+    const float scale2 = scale * VDK_LOG2E;
     if (active && qrow < N && hi == 0) dvec[((long)b * H + h) * N + qrow] = dsum;
     f32x16 g0, g1;
 #pragma unroll
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float p = (key < N && qrow < N) ? expf(st[r] * scale - mylse) : 0.f;
+            const float p = (key < N && qrow < N) ? fast_exp2(fmaf(st[r], scale2, -mylse2)) : 0.f;
             ds[r] = p * (dp[r] - dsum);
           }
           s16x8 df[2];
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         a_stage_rows_T(Qt, PT, qb, ld, q0, N, nqp);
         a_stage_rows_T(Ot, PT, dob, ldo, q0, N, nqp);
         for (int i = threadIdx.x; i < nqp; i += 256) {
-          lse_s[i] = (q0 + i < N) ? lse_b[q0 + i] : 0.f;
+          lse_s[i] = (q0 + i < N) ? lse_b[q0 + i] * VDK_LOG2E : 0.f;
           dv_s[i] = (q0 + i < N) ? dvec_b[q0 + i] : 0.f;
         }
         __syncthreads();
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
             for (int e = 0; e < 4; ++e) {
               const int r = 4 * g + e;
               const int qq = q0 + qt * 32 + 8 * g + 4 * hi + e;
-              const float pv = (qq < N && krow < N) ? expf(st[r] * scale - lv[e]) : 0.f;
+              const float pv = (qq < N && krow < N) ? fast_exp2(fmaf(st[r], scale * VDK_LOG2E, -lv[e])) : 0.f;
               p[r] = pv;
               ds[r] = pv * (dp[r] - dvv[e]);
             }

@@ -68,12 +68,32 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return t;
 }
 
-// exact-erf GELU (timm nn.GELU default) and its derivative
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// 2^x on the transcendental unit (v_exp_f32); inputs here are <= ~0 so flushed subnormal results are harmless
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#define VDK_LOG2E 1.4426950408889634f
+
+// erf with |abs err| <= 1.5e-7 (Abramowitz & Stegun 7.1.26): one v_exp_f32, one v_rcp_f32, a 5-term Horner.
+// `e` returns exp(-z*z) so that GELU' can reuse it (pdf(x) = exp(-x^2/2)/sqrt(2 pi) with z = x/sqrt(2)).
+__device__ __forceinline__ float erf_as(float z, float& e) {
+  const float a = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
+  e = fast_exp2(-a * a * VDK_LOG2E);
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float r = 1.0f - p * t * e;
+  return z < 0.f ? -r : r;
+}
+// exact-erf GELU (timm nn.GELU default, approximate='none') and its derivative
+__device__ __forceinline__ float gelu_f(float x) {
+  float e;
+  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f, e));
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float e;
+  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f, e));
+  return fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
 // monotone float -> uint32 key (larger float -> larger key)
