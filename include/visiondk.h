@@ -89,6 +89,9 @@ typedef struct VdkGemmDesc {
 } VdkGemmDesc;
 int vdk_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t splitk, size_t* bytes);
 int vdk_gemm_bf16_nt(const VdkGemmDesc* d, void* ws, size_t ws_bytes, void* stream);
+/* tests / A-B benchmarking only: 0 = automatic choice, 1 = 128x128 register-staged kernel, 2 = 256x256 LDS-DMA kernel
+ * (the latter still requires K and the split size to be multiples of 64). */
+int vdk_gemm_force_kernel(int32_t which);
 
 /* live GEMM timing for bench.py's `roofline` (HIP events on the launch stream around every GEMM kernel):
  * begin(max_launches) pre-creates the events; end() synchronises and returns the totals since begin(). */

@@ -30,6 +30,9 @@
 #include <algorithm>
 
 #define VDK_EMU 1
+#define VDK_PIN2(x, y) ((void)0)
+#define VDK_LDS_PTR(p) ((void*)(p))
+#define VDK_GLOBAL_PTR(p) ((const void*)(p))
 
 // ---------------------------------------------------------------- keywords
 #define __global__
@@ -268,6 +271,15 @@ static inline emu_f32x16 emu_mfma_32x32x2_f32(float a, float b, emu_f32x16 c, in
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu_mfma_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu_mfma_16x16x32_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_32x32x2_f32
+// LDS-DMA: data of lane i lands at (wave-uniform LDS base taken from the first lane) + i*size
+static inline void emu_global_load_lds(const void* gsrc, void* lds_dst, unsigned size, int offset, unsigned) {
+  unsigned long long base = emu_xchg((unsigned long long)(uintptr_t)lds_dst, 0);
+  memcpy((char*)(uintptr_t)base + offset + (size_t)emu::lane() * size, gsrc, size);
+  emu::wave_barrier();
+}
+#define __builtin_amdgcn_global_load_lds(g, l, sz, off, aux) emu_global_load_lds((const void*)(g), (void*)(l), sz, off, aux)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_wave_barrier() emu::wave_barrier()
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

@@ -85,3 +85,25 @@ def test_transpose_fused_colsum(be, dev):
     y = ops.transpose_pad(x, rpad=rp, colsum_partial=part, backend=be)
     assert torch.equal(y[:, :R], x.T)
     assert _rel(part.sum(0), x.float().sum(0)) < 1e-6
+
+
+@pytest.mark.parametrize("M,N,K,splitk", [(256, 256, 64, 1), (300, 264, 192, 1), (512, 256, 256, 1), (130, 520, 128, 1), (256, 256, 512, 2)])
+def test_gemm256_lds_dma_kernel(be, dev, M, N, K, splitk):
+    """the 256x256 LDS-DMA kernel, forced, vs torch fp32 on the same bf16 operands (incl. ragged M/N and split-K)"""
+    torch.manual_seed(5)
+    a = torch.randn(M, K).bfloat16().to(dev); b = torch.randn(N, K).bfloat16().to(dev)
+    b[:, 3] += 2.0
+    bias = torch.randn(N).to(dev); res = torch.randn(M, N).to(dev)
+    ref = a.float() @ b.float().T
+    be.lib.vdk_gemm_force_kernel(2)
+    try:
+        if splitk == 1:
+            out = ops.gemm_nt(a, b, out_dtype=torch.float32, bias=bias, residual=res, backend=be)
+            assert _rel(out, ref + bias + res) < 1e-5
+            outb = ops.gemm_nt(a, b, out_dtype=torch.bfloat16, act=ops.ACT_GELU, backend=be)
+            assert _rel(outb.float(), torch.nn.functional.gelu(ref).bfloat16().float()) < 4e-3
+        else:
+            out = ops.gemm_nt(a, b, out_dtype=torch.float32, splitk=splitk, backend=be)
+            assert _rel(out, ref) < 1e-5
+    finally:
+        be.lib.vdk_gemm_force_kernel(0)

@@ -47,6 +47,28 @@ def main():
         x = torch.randn(T, 3072, device=dev).bfloat16()
         ms = timeit(lambda: ops.transpose_pad(x))
         print(f"transpose [{T},3072] bf16: {ms:.3f} ms  {2*x.numel()*2/ms/1e6:.0f} GB/s")
+    if "gemmab" in what:
+        from visiondk_amd import _lib
+        be = _lib.load()
+        shapes = {"qkv_fwd": (T, 2304, 768, 1), "proj_fwd": (T, 768, 768, 1), "fc1_fwd": (T, 3072, 768, 1), "fc2_fwd": (T, 768, 3072, 1),
+                  "qkv_dgrad": (T, 768, 2304, 1), "fc1_wgrad": (3072, 768, T, 8), "qkv_wgrad": (2304, 768, T, 10), "proj_wgrad": (768, 768, T, 32),
+                  "sq4096": (4096, 4096, 4096, 1), "sq8192": (8192, 8192, 8192, 1)}
+        for name, (M, N, K, sk) in shapes.items():
+            a = torch.randn(M, K, device=dev).bfloat16(); b = torch.randn(N, K, device=dev).bfloat16()
+            out = torch.empty(M, N, device=dev, dtype=torch.float32 if sk > 1 else torch.bfloat16)
+            res = {}
+            outs = {}
+            for which in (1, 2):
+                be.lib.vdk_gemm_force_kernel(which)
+                ms = timeit(lambda: ops.gemm_nt(a, b, out=out, splitk=sk), iters=10, warmup=3)
+                res[which] = 2 * M * N * K / ms / 1e9
+                outs[which] = out.float().clone() if M * N < 2e8 else None
+            be.lib.vdk_gemm_force_kernel(0)
+            diff = ""
+            if outs[1] is not None:
+                diff = f" maxdiff(k1,k2)={(outs[1]-outs[2]).abs().max().item():.3e}"
+            print(f"gemmAB {name:11s} M={M} N={N} K={K} sk={sk}: 128^2 reg-staged {res[1]:7.1f} TF | 256^2 lds-dma {res[2]:7.1f} TF{diff}", flush=True)
+            del a, b, out, outs
     if "attn" in what:
         B, N, H = 256, 197, 12
         qkv = torch.randn(B, N, 3 * H * 64, device=dev).bfloat16()

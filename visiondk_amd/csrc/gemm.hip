@@ -41,6 +41,58 @@ __device__ __forceinline__ void g_store_tile(const u32x4 (&r)[4], bf16_t* lds) {
   }
 }
 
+// ---- shared fused epilogue for one 8-wide row chunk: v[8] = raw accumulators of C[mi][n..n+7] -----------------------
+__device__ __forceinline__ void g_epilogue_store8(const GemmParams& p, long mi, int n, float (&v)[8], int z) {
+    // token-row remap (patch embedding -> token buffer): output row skips one cls slot per group and the
+    // residual (pos_embed) row repeats per group
+    const long m = p.row_group > 0 ? mi + mi / p.row_group + 1 : mi;
+    const long mr = p.row_group > 0 ? mi % p.row_group + 1 : mi;
+    if (p.splitk > 1) {  // raw fp32 partials; the reduce kernel finishes the job
+      float* dst = p.slabs + ((long)z * p.M + mi) * p.N + n;
+      *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+      *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+      return;
+    }
+    if (p.alpha != 1.0f) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+    }
+    if (p.bias) {
+      f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+    }
+    if (p.act == VDK_ACT_GELU) {
+      if (p.aux) {  // keep the pre-activation for the backward pass
+        u32x4 u = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        *(u32x4*)(p.aux + m * p.ldaux + n) = u;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+    } else if (p.act == VDK_ACT_DGELU) {  // dL/du = dL/dg * gelu'(u), u = saved pre-activation
+      u32x4 u = *(const u32x4*)(p.aux + m * p.ldaux + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] *= gelu_grad_f(bf_lo(u[e]));
+        v[2 * e + 1] *= gelu_grad_f(bf_hi(u[e]));
+      }
+    }
+    if (p.residual) {
+      const float* rs = p.residual + mr * p.ldr + n;
+      f32x4 r0 = *(const f32x4*)rs, r1 = *(const f32x4*)(rs + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+    }
+    if (p.c_dtype == VDK_F32) {
+      float* dst = (float*)p.C + m * p.ldc + n;
+      *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+      *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+    } else {
+      u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+      *(u32x4*)((bf16_t*)p.C + m * p.ldc + n) = o;
+    }
+}
+
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmParams p) {
   // 2 buffers x (A 128 rows + B 128 rows) x 144 B = 73,728 B; reused as the fp32 epilogue tile (67,584 B)
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 128 * G_PITCH * 2];
@@ -128,10 +180,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmParams p) {
     const long mi = m0 + row;
     const int n = n0 + cc;
     if (mi >= p.M || n >= p.N) continue;
-    // token-row remap (patch embedding -> token buffer): output row skips one cls slot per group and the
-    // residual (pos_embed) row repeats per group
-    const long m = p.row_group > 0 ? mi + mi / p.row_group + 1 : mi;
-    const long mr = p.row_group > 0 ? mi % p.row_group + 1 : mi;
     float v[8];
     {
       f32x4 x0 = *(const f32x4*)(Cs + row * G_CP + cc);
@@ -139,51 +187,199 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
     }
-    if (p.splitk > 1) {  // raw fp32 partials; the reduce kernel finishes the job
-      float* dst = p.slabs + ((long)z * p.M + mi) * p.N + n;
-      *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
-      *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-      continue;
-    }
-    if (p.alpha != 1.0f) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-    }
-    if (p.bias) {
-      f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-    }
-    if (p.act == VDK_ACT_GELU) {
-      if (p.aux) {  // keep the pre-activation for the backward pass
-        u32x4 u = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-        *(u32x4*)(p.aux + m * p.ldaux + n) = u;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-    } else if (p.act == VDK_ACT_DGELU) {  // dL/du = dL/dg * gelu'(u), u = saved pre-activation
-      u32x4 u = *(const u32x4*)(p.aux + m * p.ldaux + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[2 * e] *= gelu_grad_f(bf_lo(u[e]));
-        v[2 * e + 1] *= gelu_grad_f(bf_hi(u[e]));
-      }
-    }
-    if (p.residual) {
-      const float* rs = p.residual + mr * p.ldr + n;
-      f32x4 r0 = *(const f32x4*)rs, r1 = *(const f32x4*)(rs + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-    }
-    if (p.c_dtype == VDK_F32) {
-      float* dst = (float*)p.C + m * p.ldc + n;
-      *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
-      *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-    } else {
-      u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-      *(u32x4*)((bf16_t*)p.C + m * p.ldc + n) = o;
-    }
+    g_epilogue_store8(p, mi, n, v, z);
   }
+}
+
+
+// =====================================================================================================
+// 256x256x64 "8-segment" kernel (cdna_hip_programming.md §5 template, re-derived for 32x32x16 MFMA):
+//   * 8 waves = 2 (M) x 4 (N), wave tile 128x64 = 4x2 v_mfma_f32_32x32x16_bf16 accumulators (128 regs)
+//   * operands arrive by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.  The DMA image is
+//     lane-linear, so the bank swizzle lives on the SOURCE address: LDS chunk c' of row r holds global chunk
+//     c' ^ ((r >> 1) & 7); reading logical chunk c uses the same involution -> conflict-free ds_read_b128.
+//   * a K-tile is 4 LDS regions of 16 KB: RA0/RA1 = the first/second 64 rows of BOTH waves-rows' 128-row halves,
+//     RB0/RB1 likewise for the 4 wave-columns.  A K-tile is consumed in 4 phases (A0B0, A0B1, A1B1, A1B0), each a
+//     read segment R and an MFMA segment M separated by s_barrier; a region is refilled for tile t+2 (RA1: t+1) a
+//     few segments after its last reader, so HBM latency spans >= 5 segments with only 2 tile buffers (128 KB).
+//   * counted vmcnt: the single wait per K-tile (segment R4) is vmcnt(4) = "everything but the 4 newest DMAs",
+//     never 0 in steady state.
+//   * the two wave-rows run staggered by one barrier interval, so on every SIMD one wave's MFMA segment overlaps
+//     the other wave's LDS reads / DMA issue.
+#define H_REGION 16384
+#define H_TILEBUF (4 * H_REGION)
+#define H_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | (n))   /* vmcnt(n), n < 16; expcnt/lgkmcnt untouched */
+#define H_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+// issue the 2 DMA instructions that fill one region.  is_b: B operand (rows = N index).  sub: 0/1.
+__device__ __forceinline__ void h_issue_region(unsigned char* region, const bf16_t* __restrict__ base, long ld, int row0, int nrows,
+                                               int k0, bool is_b, int sub, int w, int lane) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rr = j * 64 + w * 8 + (lane >> 3);          // region row 0..127
+    const int cp = lane & 7;                              // LDS chunk position
+    const int c = cp ^ ((rr >> 1) & 7);                   // global chunk that lives there
+    int trow;
+    if (is_b) trow = (rr >> 5) * 64 + sub * 32 + (rr & 31);
+    else trow = (rr >> 6) * 128 + sub * 64 + (rr & 63);
+    int grow = row0 + trow;
+    if (grow > nrows - 1) grow = nrows - 1;               // clamp: rows beyond the matrix are masked at the store
+    const bf16_t* src = base + (long)grow * ld + k0 + c * 8;
+    unsigned char* dst = region + (j * 512 + w * 64) * 16;  // wave-uniform base; the DMA adds lane * 16
+    __builtin_amdgcn_global_load_lds(VDK_GLOBAL_PTR(src), VDK_LDS_PTR(dst), 16, 0, 0);
+  }
+}
+// fragment (32 rows x one 16-wide k-step) of region row block `rb` (multiple of 32): lane (l31, hi), k-step ks
+__device__ __forceinline__ s16x8 h_read_frag(const unsigned char* region, int rb, int ks, int l31, int hi) {
+  const int rr = rb + l31;
+  const int c = (ks * 2 + hi) ^ ((rr >> 1) & 7);
+  return *(const s16x8*)(region + rr * 128 + c * 16);
+}
+
+__global__ __launch_bounds__(512) void gemm256_bf16_nt_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * H_TILEBUF];   // 128 KB, ALL of the kernel's LDS
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 2, wc = w & 3, hi = lane >> 5, l31 = lane & 31;
+
+  const int ntn = (p.N + 255) / 256, ntm = (p.M + 255) / 256;
+  const int nwg = ntn * ntm;
+  int bid = blockIdx.x;
+  {
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tn = bid % ntn, tm = bid / ntn;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int z = blockIdx.y;
+  const int kbeg = z * p.k_per_split;
+  int kend = kbeg + p.k_per_split; if (kend > p.K) kend = p.K;
+  const int nk = (kend - kbeg) / 64;                      // launcher guarantees (kend - kbeg) % 64 == 0
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#define H_REG(buf, id) (smem + (buf) * H_TILEBUF + (id) * H_REGION)   /* id: 0 RA0, 1 RA1, 2 RB0, 3 RB1 */
+#define H_ISSUE_A(buf, sub, t) h_issue_region(H_REG(buf, sub), p.A, p.lda, m0, p.M, kbeg + (t) * 64, false, sub, w, lane)
+#define H_ISSUE_B(buf, sub, t) h_issue_region(H_REG(buf, 2 + (sub)), p.B, p.ldb, n0, p.N, kbeg + (t) * 64, true, sub, w, lane)
+
+  // ---- prologue: tile 0 completely, tile 1 except RA1 (issued in tile 0's R1) -----------------------------------
+  if (nk > 0) { H_ISSUE_A(0, 0, 0); H_ISSUE_B(0, 0, 0); H_ISSUE_B(0, 1, 0); H_ISSUE_A(0, 1, 0); }
+  if (nk > 1) { H_ISSUE_A(1, 0, 1); H_ISSUE_B(1, 0, 1); H_ISSUE_B(1, 1, 1); H_WAIT_VM(6); } else { H_WAIT_VM(0); }
+  H_BAR();
+  if (wr == 1) H_BAR();                                   // stagger: the second wave-row runs one interval behind
+
+  s16x8 a0[2][4], a1[2][4], b0[4], b1[4];
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    const unsigned char* RA0 = H_REG(cur, 0); const unsigned char* RA1 = H_REG(cur, 1);
+    const unsigned char* RB0 = H_REG(cur, 2); const unsigned char* RB1 = H_REG(cur, 3);
+    // ---- R1: A0, B0 fragments; DMA RA1 of tile t+1 ------------------------------------------------------------
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b0[ks] = h_read_frag(RB0, wc * 32, ks, l31, hi);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a0[rt][ks] = h_read_frag(RA0, wr * 64 + rt * 32, ks, l31, hi);
+    if (t + 1 < nk) H_ISSUE_A(cur ^ 1, 1, t + 1);
+    H_BAR();
+    // ---- M1 ---------------------------------------------------------------------------------------------------
+    VDK_PIN2(acc[0][0], acc[1][0]);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0][ks], b0[ks], acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1][ks], b0[ks], acc[1][0], 0, 0, 0);
+    }
+    VDK_PIN2(acc[0][0], acc[1][0]);
+    __builtin_amdgcn_s_setprio(0);
+    H_BAR();
+    // ---- R2: B1 fragments ---------------------------------------------------------------------------------------
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b1[ks] = h_read_frag(RB1, wc * 32, ks, l31, hi);
+    H_BAR();
+    // ---- M2 ---------------------------------------------------------------------------------------------------
+    VDK_PIN2(acc[0][1], acc[1][1]);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0][ks], b1[ks], acc[0][1], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1][ks], b1[ks], acc[1][1], 0, 0, 0);
+    }
+    VDK_PIN2(acc[0][1], acc[1][1]);
+    __builtin_amdgcn_s_setprio(0);
+    H_BAR();
+    // ---- R3: A1 fragments; DMA RA0, RB0 of tile t+2 (their last reader was R1) --------------------------------------
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a1[rt][ks] = h_read_frag(RA1, wr * 64 + rt * 32, ks, l31, hi);
+    if (t + 2 < nk) { H_ISSUE_A(cur, 0, t + 2); H_ISSUE_B(cur, 0, t + 2); }
+    H_BAR();
+    // ---- M3 ---------------------------------------------------------------------------------------------------
+    VDK_PIN2(acc[2][1], acc[3][1]);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0][ks], b1[ks], acc[2][1], 0, 0, 0);
+      acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1][ks], b1[ks], acc[3][1], 0, 0, 0);
+    }
+    VDK_PIN2(acc[2][1], acc[3][1]);
+    __builtin_amdgcn_s_setprio(0);
+    H_BAR();
+    // ---- R4: counted wait: tile t+1 fully landed (only the 4 newest DMAs, all of tile t+2, may be outstanding);
+    //      DMA RB1 of tile t+2 (last reader R2).  Two barriers separate this wait from tile t+1's first read.
+    if (t + 2 < nk) { H_WAIT_VM(4); H_ISSUE_B(cur, 1, t + 2); } else { H_WAIT_VM(0); }
+    H_BAR();
+    // ---- M4 ---------------------------------------------------------------------------------------------------
+    VDK_PIN2(acc[2][0], acc[3][0]);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0][ks], b0[ks], acc[2][0], 0, 0, 0);
+      acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1][ks], b0[ks], acc[3][0], 0, 0, 0);
+    }
+    VDK_PIN2(acc[2][0], acc[3][0]);
+    __builtin_amdgcn_s_setprio(0);
+    H_BAR();
+  }
+  if (wr == 0) H_BAR();                                   // match the barrier count of the lagging wave-row
+
+  // ---- epilogue: wave-private 16 KB LDS slab, 64 rows x 64 fp32 at a time -> 8-wide coalesced row chunks ---------
+  float* slab = (float*)(smem + w * 16384);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {   // fully unrolled: acc must be indexed statically (else it lives in scratch)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          slab[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + ct * 32 + l31] = acc[half * 2 + rt][ct][r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int pass = 0; pass < 8; ++pass) {
+      const int row = pass * 8 + (lane >> 3), cc = (lane & 7) * 8;
+      const long mi = (long)m0 + wr * 128 + half * 64 + row;
+      const int n = n0 + wc * 64 + cc;
+      if (mi < p.M && n < p.N) {
+        float v[8];
+        f32x4 x0 = *(const f32x4*)(slab + row * 64 + cc), x1 = *(const f32x4*)(slab + row * 64 + cc + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
+        g_epilogue_store8(p, mi, n, v, z);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+#undef H_REG
+#undef H_ISSUE_A
+#undef H_ISSUE_B
 }
 
 // out[i] = alpha * sum_s slabs[s][i]  (deterministic split-K combine), optional bf16 output
@@ -245,8 +441,11 @@ static std::vector<hipEvent_t> g_prof_ev;
 static std::vector<double> g_prof_flops;
 static size_t g_prof_used = 0;
 static bool g_prof_on = false;
+static int g_force_kernel = 0;   // 0 auto, 1 = 128x128 register-staged, 2 = 256x256 LDS-DMA (tests / A-B benchmarking)
 
 extern "C" {
+
+int vdk_gemm_force_kernel(int32_t which) { g_force_kernel = which; return VDK_OK; }
 
 int vdk_prof_begin(int32_t max_launches) {
   if (max_launches < 0) return vdk_fail(VDK_EINVAL, "vdk_prof_begin: bad argument");
@@ -318,6 +517,12 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   const int ntn = (d->N + G_BN - 1) / G_BN, ntm = (d->M + G_BM - 1) / G_BM;
   const bool prof = g_prof_on && g_prof_used + 2 <= g_prof_ev.size();
   if (prof) (void)hipEventRecord(g_prof_ev[g_prof_used], stream);
+  // big problems go to the 256x256 LDS-DMA kernel (needs whole 64-wide k-tiles per split and >= 1 full wave of tiles)
+  const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * splitk;
+  const bool big = g_force_kernel == 2 || (g_force_kernel == 0 && (d->K % 64 == 0) && (kps % 64 == 0) && tiles256 >= 128 && d->M >= 256 && d->N >= 256);
+  if (big && (d->K % 64 == 0) && (kps % 64 == 0))
+    hipLaunchKernelGGL(gemm256_bf16_nt_kernel, dim3((unsigned)(((d->M + 255) / 256) * ((d->N + 255) / 256)), (unsigned)splitk), dim3(512), 0, stream, p);
+  else
   hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256), 0, stream, p);
   if (prof) {   // the GEMM kernel only (the split-K combine is a separate, HBM-bound kernel)
     (void)hipEventRecord(g_prof_ev[g_prof_used + 1], stream);

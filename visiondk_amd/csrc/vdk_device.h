@@ -16,6 +16,18 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// address-space casts for the LDS-DMA builtin (the CPU SIMT emulation used by tests pre-defines them as plain casts)
+#ifndef VDK_LDS_PTR
+#define VDK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define VDK_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#endif
+
+// pin two MFMA accumulators at a program point: the compiler may not move their producers below / consumers above it
+// (hipcc sinks register-only MFMAs across sched_barrier; cdna_hip_programming.md §5.7 item 3)
+#ifndef VDK_PIN2
+#define VDK_PIN2(x, y) asm volatile("" : "+v"(x), "+v"(y))
+#endif
+
 // ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
