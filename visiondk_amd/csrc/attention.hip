@@ -5,7 +5,7 @@
 //
 // MFMA formulation (v_mfma_f32_32x32x16_bf16, swapped operands so that per-query state is per-LANE):
 //   S^T[key][q]  = K . Q^T        A = K rows from LDS (row-major), B = Q fragments in registers
-//   O^T[d][q]   += V^T . P^T      A = V^T from LDS (transposed image), B = P^T = the S^T accumulator itself:
+//   O^T[d][q]   += V^T . P^T      A = V^T read from the row-major V tile with ds_read_b64_tr_b16, B = P^T = the S^T accumulator itself:
 //                                 C-layout (col = lane&31 = q, row = key(r, lane>>5)) IS a valid B-operand
 //                                 layout when the contraction (key) order is permuted consistently on both
 //                                 operands: k-slot (hi*8 + j) of step s <-> key 16s + 4hi + (j&3) + 8(j>>2).
@@ -19,7 +19,7 @@
 #define A_HD 64
 #define A_RP 72          // row-major LDS pitch (bf16): 64 + 8 -> 144 B rows, conflict-free ds_read_b128
 #define A_FWD_KC 256     // keys staged per chunk (fwd, bwd-dq)
-#define A_BWD_QC 128     // queries staged per chunk (bwd-dkv)
+#define A_BWD_QC 256     // queries staged per chunk (bwd-dkv)
 
 // ---- staging helpers (256 threads) ---------------------------------------------------------------
 // dst[r][0..63] = src[(row0 + r) * ld + 0..63] for r < ntile, zero rows beyond nvalid
@@ -30,20 +30,6 @@ __device__ __forceinline__ void a_stage_rows(bf16_t* dst, const bf16_t* __restri
     u32x4 v = {0u, 0u, 0u, 0u};
     if (row0 + r < nvalid_total) v = *(const u32x4*)(src + (long)(row0 + r) * ld + ch * 8);
     *(u32x4*)(dst + r * A_RP + ch * 8) = v;
-  }
-}
-// dstT[d][r] = src[(row0 + r) * ld + d]; pitchT elements per d-row
-__device__ __forceinline__ void a_stage_rows_T(bf16_t* dstT, int pitchT, const bf16_t* __restrict__ src, long ld, int row0,
-                                               int nvalid_total, int ntile) {
-  for (int id = threadIdx.x; id < ntile * 8; id += 256) {
-    int r = id >> 3, ch = id & 7;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (row0 + r < nvalid_total) v = *(const u32x4*)(src + (long)(row0 + r) * ld + ch * 8);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      dstT[(ch * 8 + 2 * e) * pitchT + r] = (bf16_t)(v[e] & 0xffffu);
-      dstT[(ch * 8 + 2 * e + 1) * pitchT + r] = (bf16_t)(v[e] >> 16);
-    }
   }
 }
 // B-operand fragments of a 32-row tile straight from global: lane (row = l&31, hi): src[row][ks*16 + hi*8 ..+7]
@@ -76,12 +62,11 @@ __device__ __forceinline__ void a_pack_b(const float (&p)[16], s16x8 (&f)[2]) {
     f[s] = *(s16x8*)&u;
   }
 }
-// A-operand from a transposed image T[d][idx]: lane (d, hi), step s -> idx0 + 16s + 4hi + {0..3} and +8
-__device__ __forceinline__ s16x8 a_load_T(const bf16_t* trow /* &T[d][idx0] */, int s, int hi) {
-  u32x2 lo = *(const u32x2*)(trow + 16 * s + 4 * hi);
-  u32x2 up = *(const u32x2*)(trow + 16 * s + 8 + 4 * hi);
-  u32x4 u = {lo[0], lo[1], up[0], up[1]};
-  return *(s16x8*)&u;
+// A-operand X^T[d][idx] read straight from the ROW-major tile X[idx][d] with ds_read_b64_tr_b16: lane (d = d0 + l31, hi),
+// step s -> rows idx0 + 16s + 4hi + {0..3} and + 8 (the permuted contraction order of a_pack_b)
+__device__ __forceinline__ s16x8 a_load_T(const bf16_t* tile /* row-major, pitch A_RP */, int idx0, int d0, int s, int hi, int lane) {
+  const int t1 = idx0 + 16 * s + 4 * hi;
+  return tr_frag8(tile, A_RP, t1, t1 + 8, d0, lane);
 }
 
 // =====================================================================================  forward
@@ -91,8 +76,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                                                        const bf16_t* __restrict__ v, long ld, bf16_t* __restrict__ o, long ldo,
                                                        float* __restrict__ lse, int N, int H, float scale) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[A_FWD_KC * A_RP];
-  __shared__ __attribute__((aligned(16))) bf16_t Vt[A_HD * (A_FWD_KC + 4)];
-  const int PT = A_FWD_KC + 4;
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[A_FWD_KC * A_RP];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const bf16_t* qb = q + (long)b * N * ld + h * A_HD;
@@ -120,7 +104,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       if (nchunk > 1 || rd == 0) {
         __syncthreads();  // previous readers of Ks/Vt are done
         a_stage_rows(Ks, kb, ld, key0, N, nkp);
-        a_stage_rows_T(Vt, PT, vb, ld, key0, N, nkp);
+        a_stage_rows(Vs, vb, ld, key0, N, nkp);
         __syncthreads();
       }
       if (active) {
@@ -128,28 +112,38 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
           f32x16 st = a_mma_rows(Ks + (kt * 32 + l31) * A_RP + hi * 8, qf);
           float p[16];
           float mt = -INFINITY;
+          if (key0 + kt * 32 + 32 > N) {   // only the ragged last tile needs the key mask (wave-uniform branch)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {   // scores in the log2 domain: s2 = s * scale * log2(e)
-            const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            float s = (key < N) ? st[r] * scale2 : -INFINITY;
-            p[r] = s; mt = fmaxf(mt, s);
+            for (int r = 0; r < 16; ++r) {
+              const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+              p[r] = (key < N) ? st[r] * scale2 : -INFINITY;   // scores in the log2 domain
+              mt = fmaxf(mt, p[r]);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { p[r] = st[r] * scale2; mt = fmaxf(mt, p[r]); }
           }
           mt = fmaxf(mt, __shfl_xor(mt, 32));
-          const float mn = fmaxf(m, mt);
-          const float alpha = fast_exp2(m - mn);
+          // deferred rescale (guide T13): keep the old running max while the tile max exceeds it by < 2^8; P is then
+          // bounded by 2^8 instead of 1 (harmless in bf16/fp32) and the 32-register O rescale is skipped almost always.
+          if (__any(mt > m + 8.0f)) {
+            const float mn = fmaxf(m, mt);
+            const float alpha = fast_exp2(m - mn);
+            l *= alpha;
+            m = mn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+          }
           float ps = 0.f;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { p[r] = fast_exp2(p[r] - mn); ps += p[r]; }
-          l = l * alpha + ps;
-          m = mn;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+          for (int r = 0; r < 16; ++r) { p[r] = fast_exp2(p[r] - m); ps += p[r]; }
+          l += ps;
           s16x8 pf[2];
           a_pack_b(p, pf);
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
-            s16x8 a0 = a_load_T(Vt + l31 * PT + kt * 32, s, hi);
-            s16x8 a1 = a_load_T(Vt + (32 + l31) * PT + kt * 32, s, hi);
+            s16x8 a0 = a_load_T(Vs, kt * 32, 0, s, hi, lane);
+            s16x8 a1 = a_load_T(Vs, kt * 32, 32, s, hi, lane);
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, pf[s], o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, pf[s], o1, 0, 0, 0);
           }
@@ -181,8 +175,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                                                           float scale) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[A_FWD_KC * A_RP];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[A_FWD_KC * A_RP];
-  __shared__ __attribute__((aligned(16))) bf16_t Kt[A_HD * (A_FWD_KC + 4)];
-  const int PT = A_FWD_KC + 4;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const bf16_t* qb = q + (long)b * N * ld + h * A_HD;
@@ -222,7 +214,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         __syncthreads();
         a_stage_rows(Ks, kb, ld, key0, N, nkp);
         a_stage_rows(Vs, vb, ld, key0, N, nkp);
-        a_stage_rows_T(Kt, PT, kb, ld, key0, N, nkp);
         __syncthreads();
       }
       if (active) {
@@ -240,8 +231,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
           a_pack_b(ds, df);
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
-            s16x8 a0 = a_load_T(Kt + l31 * PT + kt * 32, s, hi);
-            s16x8 a1 = a_load_T(Kt + (32 + l31) * PT + kt * 32, s, hi);
+            s16x8 a0 = a_load_T(Ks, kt * 32, 0, s, hi, lane);
+            s16x8 a1 = a_load_T(Ks, kt * 32, 32, s, hi, lane);
             g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, df[s], g0, 0, 0, 0);
             g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, df[s], g1, 0, 0, 0);
           }
@@ -269,11 +260,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                                                            float scale) {
   __shared__ __attribute__((aligned(16))) bf16_t Qs[A_BWD_QC * A_RP];
   __shared__ __attribute__((aligned(16))) bf16_t Os[A_BWD_QC * A_RP];
-  __shared__ __attribute__((aligned(16))) bf16_t Qt[A_HD * (A_BWD_QC + 4)];
-  __shared__ __attribute__((aligned(16))) bf16_t Ot[A_HD * (A_BWD_QC + 4)];
   __shared__ __attribute__((aligned(16))) float lse_s[A_BWD_QC];
   __shared__ __attribute__((aligned(16))) float dv_s[A_BWD_QC];
-  const int PT = A_BWD_QC + 4;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const bf16_t* qb = q + (long)b * N * ld + h * A_HD;
@@ -301,8 +289,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         __syncthreads();
         a_stage_rows(Qs, qb, ld, q0, N, nqp);
         a_stage_rows(Os, dob, ldo, q0, N, nqp);
-        a_stage_rows_T(Qt, PT, qb, ld, q0, N, nqp);
-        a_stage_rows_T(Ot, PT, dob, ldo, q0, N, nqp);
         for (int i = threadIdx.x; i < nqp; i += 256) {
           lse_s[i] = (q0 + i < N) ? lse_b[q0 + i] * VDK_LOG2E : 0.f;
           dv_s[i] = (q0 + i < N) ? dvec_b[q0 + i] : 0.f;
@@ -332,12 +318,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
           a_pack_b(ds, df);
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
-            s16x8 ao0 = a_load_T(Ot + l31 * PT + qt * 32, s, hi);
-            s16x8 ao1 = a_load_T(Ot + (32 + l31) * PT + qt * 32, s, hi);
+            s16x8 ao0 = a_load_T(Os, qt * 32, 0, s, hi, lane);
+            s16x8 ao1 = a_load_T(Os, qt * 32, 32, s, hi, lane);
             gv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ao0, pf[s], gv0, 0, 0, 0);
             gv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ao1, pf[s], gv1, 0, 0, 0);
-            s16x8 aq0 = a_load_T(Qt + l31 * PT + qt * 32, s, hi);
-            s16x8 aq1 = a_load_T(Qt + (32 + l31) * PT + qt * 32, s, hi);
+            s16x8 aq0 = a_load_T(Qs, qt * 32, 0, s, hi, lane);
+            s16x8 aq1 = a_load_T(Qs, qt * 32, 32, s, hi, lane);
             gk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq0, df[s], gk0, 0, 0, 0);
             gk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq1, df[s], gk1, 0, 0, 0);
           }

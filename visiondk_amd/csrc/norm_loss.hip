@@ -122,22 +122,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
   }
 }
 
-// out[c] = scale * sum_{s<S} in[s*ld + c]   (deterministic).  Block = 64 columns x 4 row groups; each thread strides
-// over S/4 rows (coalesced 256-B row segments), the 4 groups are combined through LDS in a fixed order.
-__global__ __launch_bounds__(256) void reduce_rows_f32_kernel(const float* __restrict__ in, long ld, int S, long n,
+// out[c] = scale * sum_{s<S} in[s*ld + c]   (deterministic).  Block = 64 columns x 8 row groups; each thread strides
+// over S/8 rows (coalesced 256-B row segments), the 4 groups are combined through LDS in a fixed order.
+__global__ __launch_bounds__(512) void reduce_rows_f32_kernel(const float* __restrict__ in, long ld, int S, long n,
                                                               float* __restrict__ out, float scale) {
-  __shared__ float red[4][64];
+  __shared__ float red[8][64];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const long c = (long)blockIdx.x * 64 + cl;
   float s0 = 0.f, s1 = 0.f;
   if (c < n) {
     int k = rg;
-    for (; k + 4 < S; k += 8) { s0 += in[(long)k * ld + c]; s1 += in[(long)(k + 4) * ld + c]; }
+    for (; k + 8 < S; k += 16) { s0 += in[(long)k * ld + c]; s1 += in[(long)(k + 8) * ld + c]; }
     if (k < S) s0 += in[(long)k * ld + c];
   }
   red[rg][cl] = s0 + s1;
   __syncthreads();
-  if (rg == 0 && c < n) out[c] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) * scale;
+  if (rg == 0 && c < n)
+    out[c] = (((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]))) * scale;
 }
 
 // partial[split][c] = sum over this split's rows of in[r][c]  (bf16 input, 2 columns per thread)
@@ -239,13 +240,13 @@ int vdk_layernorm_fwd(const float* x, int64_t ldx, int32_t T, int32_t C, const f
 int vdk_reduce_rows_f32(const float* in, int64_t ld, int32_t S, int64_t n, float* out, float scale, void* stream) {
   if (!in || !out || S < 0 || n < 0) return vdk_fail(VDK_EINVAL, "vdk_reduce_rows_f32: bad argument");
   if (n == 0) return VDK_OK;
-  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, in, (long)ld,
+  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((n + 63) / 64)), dim3(512), 0, (hipStream_t)stream, in, (long)ld,
                      (int)S, (long)n, out, scale);
   return vdk_check_launch("vdk_reduce_rows_f32");
 }
 
 static inline int ln_bwd_blocks(int T) {
-  int nb = (T + 63) / 64;          // >= 64 rows per block keeps the partial buffers small
+  int nb = (T + 127) / 128;        // >= 128 rows per block keeps the partial buffers (and their reduction) small
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   return nb;
@@ -275,9 +276,9 @@ int vdk_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const floa
   if (C <= 1024) { if (bf) LNB(4, true); else LNB(4, false); }
   else { if (bf) LNB(16, true); else LNB(16, false); }
 #undef LNB
-  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, stream, (const float*)pg, (long)C, nb,
+  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((C + 63) / 64)), dim3(512), 0, stream, (const float*)pg, (long)C, nb,
                      (long)C, dgamma, 1.0f);
-  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, stream, (const float*)pb, (long)C, nb,
+  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((C + 63) / 64)), dim3(512), 0, stream, (const float*)pb, (long)C, nb,
                      (long)C, dbeta, 1.0f);
   return vdk_check_launch("vdk_layernorm_bwd");
 }
@@ -297,7 +298,7 @@ int vdk_colsum_bf16(const void* in, int64_t ld, int32_t T, int32_t N, float* out
   const int rps = (T + S - 1) / S;
   hipLaunchKernelGGL(colsum_bf16_partial_kernel, dim3((unsigned)((N / 2 + 255) / 256), (unsigned)S), dim3(256), 0, stream,
                      (const bf16_t*)in, (long)ld, (int)T, (int)N, rps, (float*)ws);
-  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, stream, (const float*)ws, (long)N, S,
+  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((N + 63) / 64)), dim3(512), 0, stream, (const float*)ws, (long)N, S,
                      (long)N, out, 1.0f);
   return vdk_check_launch("vdk_colsum_bf16");
 }

@@ -19,8 +19,24 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // address-space casts for the LDS-DMA builtin (the CPU SIMT emulation used by tests pre-defines them as plain casts)
 #ifndef VDK_LDS_PTR
 #define VDK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define VDK_LDS_S16X4(p) ((__attribute__((address_space(3))) s16x4*)(p))
 #define VDK_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #endif
+
+// ds_read_b64_tr_b16 (gfx950 LDS transpose read).  Measured semantics (tools/probes/tr_probe.hip): within each 16-lane
+// group, lane i receives element (i % 4) of the 8-byte chunks addressed by lanes i/4, 4 + i/4, 8 + i/4, 12 + i/4.
+// tr_frag8() builds an MFMA 32x32x16 A/B fragment from a ROW-major tile X[t][c] (pitch in elements): lane (l & 31 = column
+// c0 + (l & 31), hi = l >> 5) gets X[t1 + 0..3][c] in slots 0..3 and X[t2 + 0..3][c] in slots 4..7, i.e. the operand whose
+// contraction index runs along the tile's ROWS - no transposed copy of the tile is ever materialised.
+__device__ __forceinline__ s16x8 tr_frag8(const bf16_t* tile, int pitch, int t1, int t2, int c0, int lane) {
+  const int s = lane & 15, chalf = (lane >> 4) & 1;
+  const bf16_t* p1 = tile + (t1 + (s >> 2)) * pitch + c0 + 16 * chalf + 4 * (s & 3);
+  const bf16_t* p2 = tile + (t2 + (s >> 2)) * pitch + c0 + 16 * chalf + 4 * (s & 3);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(p1));
+  s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(p2));
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+  return r;
+}
 
 // pin two MFMA accumulators at a program point: the compiler may not move their producers below / consumers above it
 // (hipcc sinks register-only MFMAs across sched_barrier; cdna_hip_programming.md §5.7 item 3)
@@ -30,14 +46,16 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+// f32 -> bf16 through the compiler's native conversion: v_cvt_pk_bf16_f32 on gfx950 (RNE, NaN-preserving)
+typedef __bf16 vdk_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16_t f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
 }
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  f32x2 v = {lo, hi};
+  vdk_bf16x2 b = __builtin_convertvector(v, vdk_bf16x2);
+  return __builtin_bit_cast(unsigned, b);
 }
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
