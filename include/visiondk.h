@@ -86,6 +86,9 @@ typedef struct VdkGemmDesc {
   int32_t splitk;          /* <= 1: none */
   int32_t row_group;       /* > 0: output row m -> m + m/row_group + 1, residual row -> m % row_group + 1
                               (PatchEmbed rows written straight into the [B, 1+np, D] token buffer + pos_embed) */
+  int32_t trans;           /* 0: C = A[M,K] . B[N,K]^T.  1: TN, A is [K, M] and B is [K, N] row-major, C = A^T . B (wgrad straight from
+                              dY[t][out], X[t][in]); needs K and the split size % 64 == 0, M % 8 == 0, lda/ldb % 8 == 0 */
+  int32_t a_row_group;     /* trans=1 only, > 0: A's k-row t lives at physical row t + t/a_row_group + 1 (token buffer minus cls rows) */
 } VdkGemmDesc;
 int vdk_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t splitk, size_t* bytes);
 int vdk_gemm_bf16_nt(const VdkGemmDesc* d, void* ws, size_t ws_bytes, void* stream);

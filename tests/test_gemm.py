@@ -107,3 +107,21 @@ def test_gemm256_lds_dma_kernel(be, dev, M, N, K, splitk):
             assert _rel(out, ref) < 1e-5
     finally:
         be.lib.vdk_gemm_force_kernel(0)
+
+
+@pytest.mark.parametrize("K,M,N,splitk,rg", [(64, 256, 256, 1, 0), (192, 264, 136, 1, 0), (256, 72, 520, 2, 0), (128, 128, 192, 1, 16)])
+def test_gemm_tn_from_kmajor_operands(be, dev, K, M, N, splitk, rg):
+    """wgrad form C = A^T B with A [K, M], B [K, N] read as they lie (ds_read_b64_tr_b16 fragments), incl. the token-row remap"""
+    torch.manual_seed(6)
+    phys = K + K // rg + 1 if rg else K
+    a_full = torch.randn(phys, M).bfloat16().to(dev); b = torch.randn(K, N).bfloat16().to(dev)
+    b[:, 2] += 1.5
+    if rg:
+        rows = torch.tensor([t + t // rg + 1 for t in range(K)], device=dev)
+        a_log = a_full[rows]
+    else:
+        a_log = a_full
+    ref = a_log.float().T @ b.float()
+    out = ops.gemm_nt(a_full, b, out_dtype=torch.float32, splitk=splitk, trans=True, a_row_group=rg, a_rows=K, backend=be)
+    assert out.shape == (M, N)
+    assert _rel(out, ref) < 1e-5

@@ -110,3 +110,21 @@ def test_deepcopy_for_ema_and_eval(be, dev):
     with torch.no_grad():
         a, b = model(x), m2(x)
     assert torch.equal(a.cpu(), b.cpu())
+
+
+def test_forward_backward_tn_wgrad_path(be, dev):
+    """B=64, N=17: B*N and B*np are multiples of 64, so every wgrad (incl. the patch embedding with its cls-row remap)
+    takes the TN LDS-DMA kernel instead of the transpose fallback."""
+    ref, model = _pair(be, dev, seed=8)
+    torch.manual_seed(9)
+    x = torch.randn(64, 3, 32, 32)
+    y = torch.randint(0, 10, (64,))
+    loss_ref = torch.nn.functional.cross_entropy(ref(x), y, label_smoothing=0.05)
+    loss_ref.backward()
+    logits = model(x.to(dev))
+    loss = torch.nn.functional.cross_entropy(logits, y.to(dev), label_smoothing=0.05)
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 5e-3 * abs(loss_ref.item())
+    for (n, p), (nr, pr) in zip(model.named_parameters(), ref.named_parameters()):
+        r = _rel(p.grad, pr.grad)
+        assert r < 6e-2, (n, r)

@@ -236,7 +236,44 @@ __device__ __forceinline__ s16x8 h_read_frag(const unsigned char* region, int rb
   return *(const s16x8*)(region + rr * 128 + c * 16);
 }
 
-__global__ __launch_bounds__(512) void gemm256_bf16_nt_kernel(GemmParams p) {
+// ---- TN operands: A is [K, M] row-major (element (k, m) at A[k*lda + m]), B is [K, N]: C = A^T . B (wgrad straight from
+// dY[t][out] and X[t][in], no transposed copies).  A region holds the same logical 128 operand-rows x 64 k, stored k-major:
+// [64 k][128 cols] = 64 x 256 B; 16-B chunk c' of k-row t holds global chunk c' ^ (4 * (t & 3)), which spreads the four
+// k-rows of a ds_read_b64_tr_b16 over the four 64-B bank quarters.
+__device__ __forceinline__ void h_issue_region_tn(unsigned char* region, const bf16_t* __restrict__ base, long ld, int col0, int ncols,
+                                                  int k0, bool is_b, int sub, int w, int lane, int row_group) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int L = j * 512 + w * 64 + lane;                 // 16-B slot index inside the region
+    const int trow = L >> 4, cp = L & 15;
+    const int c = cp ^ (4 * (trow & 3));                   // logical chunk (8 columns) that lives at position cp
+    int gcol;
+    if (is_b) gcol = (c >> 2) * 64 + sub * 32 + (c & 3) * 8;
+    else gcol = (c >> 3) * 128 + sub * 64 + (c & 7) * 8;
+    gcol += col0;
+    if (gcol > ncols - 8) gcol = ncols - 8;                // clamp: columns beyond the matrix are masked at the store
+    long krow = k0 + trow;
+    if (row_group > 0) krow = krow + krow / row_group + 1; // token buffer without its cls rows (patch-embed wgrad)
+    const bf16_t* src = base + krow * ld + gcol;
+    unsigned char* dst = region + (j * 512 + w * 64) * 16;
+    __builtin_amdgcn_global_load_lds(VDK_GLOBAL_PTR(src), VDK_LDS_PTR(dst), 16, 0, 0);
+  }
+}
+// fragment of 32 operand-rows (region columns cb .. cb+31), k-step ks: two transpose reads of 4 k-rows each
+__device__ __forceinline__ s16x8 h_read_frag_tn(const unsigned char* region, int cb, int ks, int lane) {
+  const int s = lane & 15, chalf = (lane >> 4) & 1, hi = lane >> 5;
+  const int col = cb + 16 * chalf + 4 * (s & 3);
+  const int t1 = ks * 16 + hi * 8 + (s >> 2), t2 = t1 + 4;
+  const unsigned char* p1 = region + t1 * 256 + (((col >> 3) ^ (4 * (t1 & 3))) * 16) + ((col >> 2) & 1) * 8;
+  const unsigned char* p2 = region + t2 * 256 + (((col >> 3) ^ (4 * (t2 & 3))) * 16) + ((col >> 2) & 1) * 8;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(p1));
+  s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(p2));
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+  return r;
+}
+
+template <bool TN>
+__global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * H_TILEBUF];   // 128 KB, ALL of the kernel's LDS
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -265,8 +302,18 @@ __global__ __launch_bounds__(512) void gemm256_bf16_nt_kernel(GemmParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
 #define H_REG(buf, id) (smem + (buf) * H_TILEBUF + (id) * H_REGION)   /* id: 0 RA0, 1 RA1, 2 RB0, 3 RB1 */
-#define H_ISSUE_A(buf, sub, t) h_issue_region(H_REG(buf, sub), p.A, p.lda, m0, p.M, kbeg + (t) * 64, false, sub, w, lane)
-#define H_ISSUE_B(buf, sub, t) h_issue_region(H_REG(buf, 2 + (sub)), p.B, p.ldb, n0, p.N, kbeg + (t) * 64, true, sub, w, lane)
+#define H_ISSUE_A(buf, sub, t)                                                                                              \
+  do {                                                                                                                     \
+    if (TN) h_issue_region_tn(H_REG(buf, sub), p.A, p.lda, m0, p.M, kbeg + (t) * 64, false, sub, w, lane, p.a_row_group);   \
+    else h_issue_region(H_REG(buf, sub), p.A, p.lda, m0, p.M, kbeg + (t) * 64, false, sub, w, lane);                        \
+  } while (0)
+#define H_ISSUE_B(buf, sub, t)                                                                                              \
+  do {                                                                                                                     \
+    if (TN) h_issue_region_tn(H_REG(buf, 2 + (sub)), p.B, p.ldb, n0, p.N, kbeg + (t) * 64, true, sub, w, lane, 0);          \
+    else h_issue_region(H_REG(buf, 2 + (sub)), p.B, p.ldb, n0, p.N, kbeg + (t) * 64, true, sub, w, lane);                   \
+  } while (0)
+#define H_FRAG_A(reg, rt, ks) (TN ? h_read_frag_tn(reg, wr * 64 + (rt) * 32, ks, lane) : h_read_frag(reg, wr * 64 + (rt) * 32, ks, l31, hi))
+#define H_FRAG_B(reg, ks) (TN ? h_read_frag_tn(reg, wc * 32, ks, lane) : h_read_frag(reg, wc * 32, ks, l31, hi))
 
   // ---- prologue: tile 0 completely, tile 1 except RA1 (issued in tile 0's R1) -----------------------------------
   if (nk > 0) { H_ISSUE_A(0, 0, 0); H_ISSUE_B(0, 0, 0); H_ISSUE_B(0, 1, 0); H_ISSUE_A(0, 1, 0); }
@@ -281,11 +328,11 @@ __global__ __launch_bounds__(512) void gemm256_bf16_nt_kernel(GemmParams p) {
     const unsigned char* RB0 = H_REG(cur, 2); const unsigned char* RB1 = H_REG(cur, 3);
     // ---- R1: A0, B0 fragments; DMA RA1 of tile t+1 ------------------------------------------------------------
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) b0[ks] = h_read_frag(RB0, wc * 32, ks, l31, hi);
+    for (int ks = 0; ks < 4; ++ks) b0[ks] = H_FRAG_B(RB0, ks);
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) a0[rt][ks] = h_read_frag(RA0, wr * 64 + rt * 32, ks, l31, hi);
+      for (int ks = 0; ks < 4; ++ks) a0[rt][ks] = H_FRAG_A(RA0, rt, ks);
     if (t + 1 < nk) H_ISSUE_A(cur ^ 1, 1, t + 1);
     H_BAR();
     // ---- M1 ---------------------------------------------------------------------------------------------------
@@ -301,7 +348,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_nt_kernel(GemmParams p) {
     H_BAR();
     // ---- R2: B1 fragments ---------------------------------------------------------------------------------------
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) b1[ks] = h_read_frag(RB1, wc * 32, ks, l31, hi);
+    for (int ks = 0; ks < 4; ++ks) b1[ks] = H_FRAG_B(RB1, ks);
     H_BAR();
     // ---- M2 ---------------------------------------------------------------------------------------------------
     VDK_PIN2(acc[0][1], acc[1][1]);
@@ -318,7 +365,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_nt_kernel(GemmParams p) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) a1[rt][ks] = h_read_frag(RA1, wr * 64 + rt * 32, ks, l31, hi);
+      for (int ks = 0; ks < 4; ++ks) a1[rt][ks] = H_FRAG_A(RA1, rt, ks);
     if (t + 2 < nk) { H_ISSUE_A(cur, 0, t + 2); H_ISSUE_B(cur, 0, t + 2); }
     H_BAR();
     // ---- M3 ---------------------------------------------------------------------------------------------------
@@ -380,6 +427,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_nt_kernel(GemmParams p) {
 #undef H_REG
 #undef H_ISSUE_A
 #undef H_ISSUE_B
+#undef H_FRAG_A
+#undef H_FRAG_B
 }
 
 // out[i] = alpha * sum_s slabs[s][i]  (deterministic split-K combine), optional bf16 output
@@ -498,7 +547,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.c_dtype = d->c_dtype; p.bias = (const float*)d->bias; p.residual = (const float*)d->residual; p.ldr = d->ldr;
-  p.act = d->act; p.aux = (bf16_t*)d->aux; p.ldaux = d->ldaux; p.alpha = d->alpha; p.row_group = d->row_group;
+  p.act = d->act; p.aux = (bf16_t*)d->aux; p.ldaux = d->ldaux; p.alpha = d->alpha; p.row_group = d->row_group; p.a_row_group = d->a_row_group;
   p.splitk = splitk; p.slabs = nullptr;
   int kps = d->K;
   if (splitk > 1) {
@@ -520,8 +569,12 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   // big problems go to the 256x256 LDS-DMA kernel (needs whole 64-wide k-tiles per split and >= 1 full wave of tiles)
   const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * splitk;
   const bool big = g_force_kernel == 2 || (g_force_kernel == 0 && (d->K % 64 == 0) && (kps % 64 == 0) && tiles256 >= 128 && d->M >= 256 && d->N >= 256);
-  if (big && (d->K % 64 == 0) && (kps % 64 == 0))
-    hipLaunchKernelGGL(gemm256_bf16_nt_kernel, dim3((unsigned)(((d->M + 255) / 256) * ((d->N + 255) / 256)), (unsigned)splitk), dim3(512), 0, stream, p);
+  if (d->trans) {
+    if ((d->K % 64) || (kps % 64) || (d->M & 7) || d->M < 8 || d->N < 8)
+      return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: trans=1 needs K and the split size to be multiples of 64 and M % 8 == 0");
+    hipLaunchKernelGGL((gemm256_bf16_kernel<true>), dim3((unsigned)(((d->M + 255) / 256) * ((d->N + 255) / 256)), (unsigned)splitk), dim3(512), 0, stream, p);
+  } else if (big && (d->K % 64 == 0) && (kps % 64 == 0))
+    hipLaunchKernelGGL((gemm256_bf16_kernel<false>), dim3((unsigned)(((d->M + 255) / 256) * ((d->N + 255) / 256)), (unsigned)splitk), dim3(512), 0, stream, p);
   else
   hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256), 0, stream, p);
   if (prof) {   // the GEMM kernel only (the split-K combine is a separate, HBM-bound kernel)

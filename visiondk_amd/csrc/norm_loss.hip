@@ -141,20 +141,37 @@ __global__ __launch_bounds__(512) void reduce_rows_f32_kernel(const float* __res
     out[c] = (((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]))) * scale;
 }
 
-// partial[split][c] = sum over this split's rows of in[r][c]  (bf16 input, 2 columns per thread)
+// partial[split][c] = sum over this split's rows of in[r][c]  (bf16 input).  Block = 32 column chunks (16 B = 8 columns)
+// x 8 row lanes; every load is 16 B and a wave reads 512 contiguous bytes of a row.
 __global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const bf16_t* __restrict__ in, long ld, int T, int N,
                                                                   int rows_per_split, float* __restrict__ partial) {
-  const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
-  if (c >= N) return;
+  __shared__ float red[8][32][9];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = (blockIdx.x * 32 + cx) * 8;
   const int r0 = blockIdx.y * rows_per_split;
   int r1 = r0 + rows_per_split; if (r1 > T) r1 = T;
-  float s0 = 0.f, s1 = 0.f;
-  for (int r = r0; r < r1; ++r) {
-    unsigned u = *(const unsigned*)(in + (long)r * ld + c);
-    s0 += bf_lo(u); s1 += bf_hi(u);
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (c < N) {
+    for (int r = r0 + ry; r < r1; r += 8) {
+      u32x4 u = *(const u32x4*)(in + (long)r * ld + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(u[e]); acc[2 * e + 1] += bf_hi(u[e]); }
+    }
   }
-  partial[(long)blockIdx.y * N + c] = s0;
-  partial[(long)blockIdx.y * N + c + 1] = s1;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[ry][cx][e] = acc[e];
+  __syncthreads();
+  if (ry == 0 && c < N) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += red[k][cx][e];
+      partial[(long)blockIdx.y * N + c + e] = t;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -283,20 +300,20 @@ int vdk_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const floa
   return vdk_check_launch("vdk_layernorm_bwd");
 }
 
-static inline int colsum_splits(int T) { int s = (T + 255) / 256; if (s > 256) s = 256; if (s < 1) s = 1; return s; }
+static inline int colsum_splits(int T) { int s = (T + 255) / 256; if (s > 128) s = 128; if (s < 1) s = 1; return s; }
 int vdk_colsum_bf16_workspace_bytes(int32_t T, int32_t N, size_t* bytes) {
   if (!bytes || T < 0 || N <= 0) return vdk_fail(VDK_EINVAL, "vdk_colsum_bf16_workspace_bytes: bad argument");
   *bytes = (size_t)colsum_splits(T) * N * 4;
   return VDK_OK;
 }
-// out[c] = sum_r in[r][c]  (bias gradient of a Linear: column sum of dY), N % 2 == 0
+// out[c] = sum_r in[r][c]  (bias gradient of a Linear: column sum of dY), N % 8 == 0, ld % 8 == 0
 int vdk_colsum_bf16(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!in || !out || T <= 0 || N <= 0 || (N & 1) || (ld & 1)) return vdk_fail(VDK_EINVAL, "vdk_colsum_bf16: bad argument");
+  if (!in || !out || T <= 0 || N <= 0 || (N & 7) || (ld & 7)) return vdk_fail(VDK_EINVAL, "vdk_colsum_bf16: bad argument (N, ld % 8 == 0)");
   const int S = colsum_splits(T);
   if (!ws || ws_bytes < (size_t)S * N * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_colsum_bf16: workspace too small");
   const int rps = (T + S - 1) / S;
-  hipLaunchKernelGGL(colsum_bf16_partial_kernel, dim3((unsigned)((N / 2 + 255) / 256), (unsigned)S), dim3(256), 0, stream,
+  hipLaunchKernelGGL(colsum_bf16_partial_kernel, dim3((unsigned)((N / 8 + 31) / 32), (unsigned)S), dim3(256), 0, stream,
                      (const bf16_t*)in, (long)ld, (int)T, (int)N, rps, (float*)ws);
   hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((N + 63) / 64)), dim3(512), 0, stream, (const float*)ws, (long)N, S,
                      (long)N, out, 1.0f);

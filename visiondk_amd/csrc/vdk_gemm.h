@@ -16,6 +16,7 @@ struct GemmParams {
   bf16_t* aux; long ldaux;
   float alpha;
   int row_group;
+  int a_row_group;
   int splitk; int k_per_split;
   float* slabs;
 };

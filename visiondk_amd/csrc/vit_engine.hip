@@ -206,7 +206,8 @@ static int vit_plan(const VitDims& d, WsPlan* w) {
   }
   w->slabs_bytes = sl; w->slabs = w_take(cur, sl);
   vdk_layernorm_bwd_workspace_bytes(d.T, d.D, &w->lnws_bytes); w->lnws = w_take(cur, w->lnws_bytes);
-  size_t cs = (size_t)((tcols + 63) / 64) * trows * 4;   // per-row-tile column sums written by the dY transposes
+  size_t cs = (size_t)((tcols + 63) / 64) * trows * 4;   // per-row-tile column sums written by the dY transposes ...
+  { size_t cs2 = 0; vdk_colsum_bf16_workspace_bytes(d.T, (int)trows, &cs2); if (cs2 > cs) cs = cs2; }   // ... or by vdk_colsum_bf16
   w->csws_bytes = cs; w->csws = w_take(cur, cs);
   w->dhf = w_take(cur, (size_t)d.B * D * 2);
   w->dposall = w_take(cur, (size_t)d.N * D * 4);
@@ -219,7 +220,7 @@ static int vit_plan(const VitDims& d, WsPlan* w) {
 static int gemm(hipStream_t s, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K, int cdt,
                 const float* bias, const float* res, int64_t ldr, int act, void* aux, int64_t ldaux, int splitk, int row_group, void* ws,
                 size_t wsb) {
-  VdkGemmDesc g;
+  VdkGemmDesc g = {};
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.c_dtype = cdt; g.bias = bias;
   g.residual = res; g.ldr = ldr; g.act = act; g.aux = aux; g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = splitk; g.row_group = row_group;
   return vdk_gemm_bf16_nt(&g, ws, wsb, s);
@@ -326,9 +327,21 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
   return VDK_OK;
 }
 
-// wgrad of one Linear: dW[out,in] = dY^T X  and db = colsum(dY); dY bf16 [rows, out], X bf16 [rows, in]
+// wgrad of one Linear: dW[out,in] = dY^T X  and db = colsum(dY); dY bf16 [rows, out], X bf16 [rows, in].
+// Fast path (rows % 64 == 0): the TN LDS-DMA GEMM reads dY and X as they lie (hardware transpose reads) and a vectorised
+// column-sum kernel produces db.  Otherwise (ragged token counts): explicit bf16 transposes feed the NT kernel and db
+// rides along with the dY transpose.
 static int linear_wgrad(hipStream_t s, const VitDims& d, const WsPlan& w, char* base, const bf16_t* dY, int64_t lddy, const bf16_t* Xa,
                         int64_t ldx, int rows, int rows_pad, int out, int in, float* dW, float* db, int dy_row_group) {
+  if ((rows % 64) == 0 && (out % 8) == 0 && (in % 8) == 0 && out >= 8 && in >= 8) {
+    const int sk = wgrad_splitk(out, in, rows);
+    VdkGemmDesc g = {};
+    g.A = dY; g.lda = lddy; g.B = Xa; g.ldb = ldx; g.C = dW; g.ldc = in; g.M = out; g.N = in; g.K = rows; g.c_dtype = VDK_F32;
+    g.alpha = 1.0f; g.splitk = sk; g.trans = 1; g.a_row_group = dy_row_group;
+    RC(vdk_gemm_bf16_nt(&g, base + w.slabs, w.slabs_bytes, s));
+    if (db && dy_row_group == 0) RC(vdk_colsum_bf16(dY, lddy, rows, out, db, base + w.csws, w.csws_bytes, s));
+    return VDK_OK;
+  }
   bf16_t* tA = (bf16_t*)(base + w.tA); bf16_t* tB = (bf16_t*)(base + w.tB);
   float* csp = (db && dy_row_group == 0) ? (float*)(base + w.csws) : nullptr;   // bias gradient rides along with the dY transpose
   RC(vdk_transpose_bf16(dY, lddy, rows, out, tA, rows_pad, rows_pad, dy_row_group, csp, s));

@@ -21,13 +21,17 @@ def _be(backend):
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=torch.bfloat16, bias: Optional[torch.Tensor] = None,
             residual: Optional[torch.Tensor] = None, act: int = ACT_NONE, aux: Optional[torch.Tensor] = None,
             alpha: float = 1.0, splitk: int = 1, out: Optional[torch.Tensor] = None, row_group: int = 0,
-            backend=None) -> torch.Tensor:
+            trans: bool = False, a_row_group: int = 0, a_rows: Optional[int] = None, backend=None) -> torch.Tensor:
     """out[M,N] = epilogue(alpha * a[M,K] @ b[N,K].T); a, b bf16 (row stride may exceed K)."""
     be = _be(backend)
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
-    assert a.stride(1) == 1 and b.stride(1) == 1 and a.shape[1] == b.shape[1]
-    M, K = a.shape
-    N = b.shape[0]
+    assert a.stride(1) == 1 and b.stride(1) == 1 and (trans or a.shape[1] == b.shape[1])
+    if trans:   # a: [K(+), M], b: [K(+), N]
+        K, M = (a_rows if a_rows is not None else a.shape[0]), a.shape[1]
+        N = b.shape[1]
+    else:
+        M, K = a.shape
+        N = b.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
     d = _abi.GemmDesc()
@@ -45,6 +49,8 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=torch.bfloat16, bias:
     d.alpha = alpha
     d.splitk = splitk
     d.row_group = row_group
+    d.trans = int(trans)
+    d.a_row_group = a_row_group
     for t in (a, b, out, residual, aux):
         if t is not None and be.device_only and not t.is_cuda:
             raise RuntimeError("visiondk_amd: HIP backend got a CPU tensor (there is no CPU fallback)")
