@@ -263,7 +263,7 @@ int vdk_reduce_rows_f32(const float* in, int64_t ld, int32_t S, int64_t n, float
 }
 
 static inline int ln_bwd_blocks(int T) {
-  int nb = (T + 127) / 128;        // >= 128 rows per block keeps the partial buffers (and their reduction) small
+  int nb = (T + 63) / 64;          // 64 rows per block: enough waves in flight to stream at HBM rate
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   return nb;

@@ -179,6 +179,18 @@ static int wgrad_splitk(int M, int N, int K) {
   if (s < 1) s = 1;
   return s;
 }
+// TN LDS-DMA kernel: 256x256 tiles, one workgroup per CU -> pick the split count that makes tiles * splits land just under a
+// whole number of 256-CU rounds (a second, nearly empty round would halve the efficiency)
+static int wgrad_splitk_tn(int M, int N, int K) {
+  const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+  int s = 256 / tiles;
+  if (s < 1) s = 1;
+  const int kt = K / 64;
+  if (s > kt / 4) s = kt / 4;            // keep >= 4 k-tiles per split
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  return s;
+}
 static int vit_plan(const VitDims& d, WsPlan* w) {
   size_t cur = 0;
   const size_t T = d.T, D = d.D, M = d.M, L = d.L;
@@ -202,7 +214,10 @@ static int vit_plan(const VitDims& d, WsPlan* w) {
   size_t sl = 0;
   {
     int sh[5][3] = {{(int)M, (int)D, d.T}, {(int)D, (int)M, d.T}, {3 * (int)D, (int)D, d.T}, {(int)D, (int)D, d.T}, {(int)D, d.Kpe, d.B * d.np}};
-    for (auto& s : sh) { size_t b = (size_t)wgrad_splitk(s[0], s[1], s[2]) * s[0] * s[1] * 4; if (b > sl) sl = b; }
+    for (auto& s : sh) {
+      int k1 = wgrad_splitk(s[0], s[1], s[2]), k2 = wgrad_splitk_tn(s[0], s[1], s[2]);
+      size_t b = (size_t)(k1 > k2 ? k1 : k2) * s[0] * s[1] * 4; if (b > sl) sl = b;
+    }
   }
   w->slabs_bytes = sl; w->slabs = w_take(cur, sl);
   vdk_layernorm_bwd_workspace_bytes(d.T, d.D, &w->lnws_bytes); w->lnws = w_take(cur, w->lnws_bytes);
@@ -334,7 +349,7 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
 static int linear_wgrad(hipStream_t s, const VitDims& d, const WsPlan& w, char* base, const bf16_t* dY, int64_t lddy, const bf16_t* Xa,
                         int64_t ldx, int rows, int rows_pad, int out, int in, float* dW, float* db, int dy_row_group) {
   if ((rows % 64) == 0 && (out % 8) == 0 && (in % 8) == 0 && out >= 8 && in >= 8) {
-    const int sk = wgrad_splitk(out, in, rows);
+    const int sk = wgrad_splitk_tn(out, in, rows);
     VdkGemmDesc g = {};
     g.A = dY; g.lda = lddy; g.B = Xa; g.ldb = ldx; g.C = dW; g.ldc = in; g.M = out; g.N = in; g.K = rows; g.c_dtype = VDK_F32;
     g.alpha = 1.0f; g.splitk = sk; g.trans = 1; g.a_row_group = dy_row_group;
