@@ -176,7 +176,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": loss},
             "model_flops_utilisation": {"achieved_tflops_per_gpu": per_gpu_tflops, "peak": PEAK_BF16_TFLOPS, "frac": per_gpu_tflops / PEAK_BF16_TFLOPS,
                                         "flop_per_image": VIT_FLOP_PER_IMG},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": gemm_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "kernel": "gemm256_bf16_kernel<NT|TN> (+ gemm_bf16_nt_kernel on small shapes)", "achieved": gemm_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": gemm_tflops / PEAK_BF16_TFLOPS, "traffic": None,
                          "avg_launch_ms": gemm_avg_ms, "launches": gemm_n.value, "flops_per_launch": gemm_fl.value / max(gemm_n.value, 1),
                          "gemm_share_of_step_time": gemm_ms.value / (dt * 1e3)},

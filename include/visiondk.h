@@ -198,6 +198,41 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
 int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* params, const void* wb16, const void* wt16, void* ws,
                      size_t ws_bytes, float* grads, vdk_grad_ready_fn on_ready, void* user, void* stream);
 
+
+/* ---- margin-softmax heads of the faceX / CBIR training path (fused with the cross-entropy) ------------------------------
+ * ArcFace models/faceX/head/arcface.py:20-36, CircleLoss circleloss.py:21-43, MV_Softmax mv_softmax.py:25-44, followed by
+ * nn.CrossEntropyLoss (engine/procedure/train.py:196).  weight W is [feat_dim, num_class] row-major like the reference's
+ * Parameter.  Pipeline (visiondk_amd/heads.py): vdk_colnorm_fwd + vdk_rownorm_fwd -> cos = f^ W^ (vdk_gemm_bf16_nt, trans=1)
+ * -> vdk_margin_ce (logits / loss / d cos) -> dW^ = f^T dcos (trans=1), df^ = dcos W^T (NT, split-K) -> vdk_colnorm_bwd,
+ * vdk_rownorm_bwd.  MagFace (magface.py) returns a tuple the reference Trainer cannot consume: not built. */
+#define VDK_HEAD_ARCFACE 0
+#define VDK_HEAD_CIRCLE 1
+#define VDK_HEAD_MV_AM 2
+#define VDK_HEAD_MV_ARC 3
+typedef struct VdkMarginHead {
+  int32_t mode;        /* VDK_HEAD_* */
+  float scale;         /* arcface / mv: scale;  circle: gamma */
+  float margin;        /* arcface: margin_arc;  circle: margin;  mv: margin */
+  float margin_am;     /* arcface only */
+  float mv_weight;     /* mv only */
+} VdkMarginHead;
+/* F.normalize(W, dim=0): inv[c] = 1/max(||W[:,c]||, eps); Wb = bf16 [3D, ldb]: the normalised weight as split planes
+ * (hi, hi, lo) stacked along the contraction dim (rows [0,D) alone are the plain bf16 copy); columns C..Cp-1 zero */
+int vdk_colnorm_fwd(const float* W, int64_t ldw, int32_t D, int32_t C, int32_t Cp, float eps, float* inv, void* Wb, int64_t ldb, void* stream);
+int vdk_colnorm_bwd(const float* W, int64_t ldw, const float* inv, const float* dWh, int64_t ldg, int32_t D, int32_t C, float* dW, int64_t ldo,
+                    void* stream);
+/* F.normalize(feats): fh f32 [B, D]; fb bf16 [Bp, D]; fbt bf16 [3D, Bp] = transposed split planes (hi, lo, hi), so that the
+ * K = 3D GEMM fbt^T . Wb accumulates hi*hi + lo*hi + hi*lo (fp32-class cos); rows/cols B..Bp-1 zero; inv f32 [B] */
+int vdk_rownorm_fwd(const float* f, int32_t B, int32_t Bp, int32_t D, float eps, float* fh, void* fb, void* fbt, float* inv, void* stream);
+int vdk_rownorm_bwd(const float* fh, const float* inv, const float* dfh, int64_t lddfh, int32_t B, int32_t D, float* df, void* stream);
+/* cos f32 [B, ldc] -> any of: logits f32 [B, ldl] (what the reference head returns), loss_rows f32 [B] (CE with optional label
+ * smoothing), dcos bf16 [B, lddc] = grad_scale * dLoss/dcos (padding columns zeroed) */
+int vdk_margin_ce(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t C, const int64_t* labels, float label_smoothing,
+                  float grad_scale, float* logits, int64_t ldl, float* loss_rows, void* dcos_bf16, int64_t lddc, void* stream);
+/* backward of the logits-returning form: dcos bf16 = dlogits * d(logit)/d(cos) */
+int vdk_margin_bwd(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t C, const int64_t* labels, const float* dlogits,
+                   int64_t lddl, void* dcos_bf16, int64_t lddc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,58 @@
+"""K11 margin heads vs the golden outputs of the REFERENCE's own ArcFace / CircleLoss / MV_Softmax modules
+(tests/golden/heads.npz, made by tests/golden/make_golden.py).  The GEMMs use bf16 MFMA operands: cos errors of a few 1e-4
+are amplified by the scale (32 / 256) in the logits, so logits are compared in units of the scale; gradients flow through
+single-plane bf16 GEMMs (dcos, f^, W^ rounded to bf16): a few 1e-3 relative."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from visiondk_amd import heads
+
+G = Path(__file__).resolve().parent / "golden" / "heads.npz"
+
+
+def _mk(tag, be, dev):
+    if tag == "arcface":
+        return heads.ArcFace(64, 257, margin_arc=0.35, margin_am=0.0, scale=32, backend=be, device=dev), 32.0
+    if tag == "circle":
+        return heads.CircleLoss(64, 257, margin=0.25, gamma=256, backend=be, device=dev), 256.0
+    if tag == "mv_am":
+        return heads.MV_Softmax(64, 257, is_am=True, margin=0.35, mv_weight=1.12, scale=32, backend=be, device=dev), 32.0
+    return heads.MV_Softmax(64, 257, is_am=False, margin=0.35, mv_weight=1.12, scale=32, backend=be, device=dev), 32.0
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).double().cpu(); b = torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("tag", ["arcface", "circle", "mv_am", "mv_arc"])
+def test_head_logits_loss_and_grads_vs_reference(be, dev, tag):
+    z = np.load(G)
+    h, scale = _mk(tag, be, dev)
+    with torch.no_grad():
+        h.weight.copy_(torch.from_numpy(z[f"{tag}_weight"]).to(dev))
+    feats = torch.from_numpy(z["feats"]).to(dev).requires_grad_(True)
+    labels = torch.from_numpy(z["labels"]).to(dev)
+    logits = h(feats, labels)
+    ref_logits = torch.from_numpy(z[f"{tag}_logits"])
+    # cos is computed with split-bf16 planes (hi*hi + lo*hi + hi*lo): fp32-class accuracy even where the margin is steep
+    assert (logits.detach().cpu() - ref_logits).abs().max().item() / scale < 2e-5
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    loss.backward()
+    assert abs(loss.item() - float(z[f"{tag}_loss"])) < 1e-4 * abs(float(z[f"{tag}_loss"])) + 1e-4
+    assert _rel(feats.grad, z[f"{tag}_dfeats"]) < 5e-2
+    assert _rel(h.weight.grad, z[f"{tag}_dweight"]) < 5e-2
+    # fused form == the autograd form
+    loss_rows, df, dW = h.margin_ce(feats.detach(), labels)
+    assert abs(loss_rows.mean().item() - loss.item()) < 1e-5 * abs(loss.item()) + 1e-6
+    assert _rel(df, feats.grad) < 2e-2 and _rel(dW, h.weight.grad) < 2e-2
+
+
+def test_head_factory_names():
+    f = heads.HeadFactory("arcface", {"feat_dim": 8, "num_class": 16}, backend=None, device="cpu")
+    assert f.head_type == "arcface"
+    with pytest.raises(NotImplementedError):
+        heads.HeadFactory("magface", {}, device="cpu").get_head()

@@ -30,6 +30,12 @@ class VitConfig(C.Structure):
                 ("heads", I32), ("mlp_dim", I32), ("num_classes", I32), ("ln_eps", F32)]
 
 
+class MarginHead(C.Structure):
+    """VdkMarginHead of include/visiondk.h"""
+    _fields_ = [("mode", I32), ("scale", F32), ("margin", F32), ("margin_am", F32), ("mv_weight", F32)]
+
+
+HEAD_ARCFACE, HEAD_CIRCLE, HEAD_MV_AM, HEAD_MV_ARC = 0, 1, 2, 3
 GRAD_READY_FN = C.CFUNCTYPE(None, P, I64, I64)
 
 BF16, F32_ = 0, 1
@@ -70,6 +76,13 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_sumsq_f32": (C.c_int, [P, I64, P, P, SZ, P]),
     "vdk_sgd_step": (C.c_int, [P, P, P, P, P, I64, F32, F32, F32, F32, P, F32, F32, I32, P]),
     "vdk_mixup": (C.c_int, [P, P, F32, I32, I64, P, P]),
+    # margin-softmax heads
+    "vdk_colnorm_fwd": (C.c_int, [P, I64, I32, I32, I32, F32, P, P, I64, P]),
+    "vdk_colnorm_bwd": (C.c_int, [P, I64, P, P, I64, I32, I32, P, I64, P]),
+    "vdk_rownorm_fwd": (C.c_int, [P, I32, I32, I32, F32, P, P, P, P, P]),
+    "vdk_rownorm_bwd": (C.c_int, [P, P, P, I64, I32, I32, P, P]),
+    "vdk_margin_ce": (C.c_int, [C.POINTER(MarginHead), P, I64, I32, I32, P, F32, F32, P, I64, P, P, I64, P]),
+    "vdk_margin_bwd": (C.c_int, [C.POINTER(MarginHead), P, I64, I32, I32, P, P, I64, P, I64, P]),
     # native ViT engine
     "vdk_vit_param_count": (C.c_int, [C.POINTER(VitConfig), C.POINTER(I64), C.POINTER(I32), C.POINTER(I64)]),
     "vdk_vit_param_info": (C.c_int, [C.POINTER(VitConfig), I32, C.c_char_p, I32, C.POINTER(I64), C.POINTER(I64),

@@ -1,0 +1,237 @@
+// margin_head.hip — K11: margin-softmax heads of the faceX / CBIR training path, fused with the cross-entropy.
+//   ArcFace     models/faceX/head/arcface.py:20-36     (normalise W columns + feature rows, cos = f^ W^, clamp, margin at target, x scale)
+//   CircleLoss  models/faceX/head/circleloss.py:21-43  (detached alpha_p / alpha_n re-weighting)
+//   MV-Softmax  models/faceX/head/mv_softmax.py:25-44  (hard-negative re-weighting, AM or arc margin on the target)
+// followed by nn.CrossEntropyLoss (engine/procedure/train.py:196 `criterion(self.model(images, labels), labels)`).
+//
+// The reference materialises >= 6 B x C fp32 temporaries (kernel_norm, cos, sin, cos_m, where, index, output, log-softmax:
+// 2 GB each at B=512, C=1M).  Here: one fp32 cos matrix (GEMM output) and one bf16 d(cos) matrix; margin, scale, softmax,
+// loss and the Jacobian of the margin are evaluated per row on the fly.  The three GEMMs (cos = f^ W^, dW^ = f^T dcos,
+// df^ = dcos W^T) run on the bf16 MFMA kernels of gemm.hip straight from the layouts the tensors already have
+// (W is [feat_dim, num_class] row-major: B operand of the TN kernel forward, B operand of the NT kernel backward).
+#include <hip/hip_runtime.h>
+#include "vdk_device.h"
+#include "vdk_host.h"
+
+struct MarginP {
+  int mode;          // VDK_HEAD_ARCFACE / CIRCLE / MV_AM / MV_ARC
+  float s;           // scale (arcface, mv) or gamma (circle)
+  float m;           // margin
+  float cos_m, sin_m, min_cos, m_am;   // arcface: cos(m), sin(m), cos(pi - m), margin_am
+  float Op, On, dp, dn;                // circle: 1+m, -m, 1-m, m
+  float t;                             // mv_weight
+};
+
+struct RowCtx { float thr, final_gt, dfinal; };   // MV-Softmax per-row quantities derived from gt = cos[i][y_i]
+
+__device__ __forceinline__ RowCtx margin_row_ctx(const MarginP& P, float gt) {
+  RowCtx r; r.thr = 0.f; r.final_gt = gt; r.dfinal = 1.f;
+  if (P.mode == VDK_HEAD_MV_AM) {
+    r.thr = gt - P.m;
+    r.final_gt = gt > P.m ? gt - P.m : gt;
+  } else if (P.mode == VDK_HEAD_MV_ARC) {
+    const float sn = sqrtf(1.0f - gt * gt);
+    const float ctm = gt * P.cos_m - sn * P.sin_m;
+    r.thr = ctm;
+    if (gt > 0.0f) { r.final_gt = ctm; r.dfinal = P.cos_m + gt / sn * P.sin_m; }
+  }
+  return r;
+}
+// logit and d(logit)/d(cos) of one entry
+__device__ __forceinline__ void margin_eval(const MarginP& P, const RowCtx& R, float c_raw, bool tgt, float& logit, float& jac) {
+  if (P.mode == VDK_HEAD_ARCFACE) {
+    const float c = fminf(fmaxf(c_raw, -1.0f), 1.0f);
+    const float cg = (c_raw >= -1.0f && c_raw <= 1.0f) ? 1.0f : 0.0f;   // clamp backward
+    if (!tgt) { logit = P.s * c; jac = P.s * cg; return; }
+    if (c > P.min_cos) {
+      const float sn = sqrtf(1.0f - c * c);
+      logit = P.s * (c * P.cos_m - sn * P.sin_m);
+      jac = P.s * (P.cos_m + c / sn * P.sin_m) * cg;
+    } else { logit = P.s * (c - P.m_am); jac = P.s * cg; }
+  } else if (P.mode == VDK_HEAD_CIRCLE) {
+    const float c = fminf(fmaxf(c_raw, -1.0f), 1.0f);
+    const float cg = (c_raw >= -1.0f && c_raw <= 1.0f) ? 1.0f : 0.0f;
+    if (tgt) { const float a = fmaxf(P.Op - c, 0.f); logit = P.s * a * (c - P.dp); jac = P.s * a * cg; }
+    else { const float a = fmaxf(c - P.On, 0.f); logit = P.s * a * (c - P.dn); jac = P.s * a * cg; }
+  } else {  // MV-Softmax (no clamp)
+    if (tgt) { logit = P.s * R.final_gt; jac = P.s * R.dfinal; }
+    else if (c_raw > R.thr) { logit = P.s * (P.t * c_raw + P.t - 1.0f); jac = P.s * P.t; }
+    else { logit = P.s * c_raw; jac = P.s; }
+  }
+}
+
+// ---- normalisations ------------------------------------------------------------------------------------------------
+// W f32 [D, ldw] (C valid columns) -> inv[c] = 1 / max(||W[:, c]||, eps), and W^ as THREE bf16 planes stacked along the
+// contraction dim, Wb [3D, ldb]: rows [0,D) = hi(W^), [D,2D) = hi(W^), [2D,3D) = lo(W^) with lo = bf16(W^ - hi).  Paired with the
+// feature planes (hi, lo, hi) the cos GEMM accumulates hi*hi + lo*hi + hi*lo: fp32-class accuracy (~2^-16) on the bf16 MFMA
+// pipe.  Columns C..Cp-1 are zero.  The backward GEMMs use the first plane only.
+__global__ __launch_bounds__(256) void colnorm_fwd_kernel(const float* __restrict__ W, long ldw, int D, int C, int Cp, float eps,
+                                                          float* __restrict__ inv, bf16_t* __restrict__ Wb, long ldb) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= Cp) return;
+  float s = 0.f;
+  if (c < C) for (int d = 0; d < D; ++d) { float v = W[(long)d * ldw + c]; s = fmaf(v, v, s); }
+  const float iv = c < C ? 1.0f / fmaxf(sqrtf(s), eps) : 0.f;
+  if (c < C && inv) inv[c] = iv;
+  for (int d = 0; d < D; ++d) {
+    const float v = c < C ? W[(long)d * ldw + c] * iv : 0.f;
+    const bf16_t h = f2bf(v);
+    const bf16_t l = f2bf(v - bf2f(h));
+    Wb[(long)d * ldb + c] = h;
+    Wb[(long)(D + d) * ldb + c] = h;
+    Wb[(long)(2 * D + d) * ldb + c] = l;
+  }
+}
+// dW[:, c] = inv[c] * (dW^[:, c] - W^[:, c] * <W^[:, c], dW^[:, c]>),  W^ = W * inv
+__global__ __launch_bounds__(256) void colnorm_bwd_kernel(const float* __restrict__ W, long ldw, const float* __restrict__ inv,
+                                                          const float* __restrict__ dWh, long ldg, int D, int C, float* __restrict__ dW,
+                                                          long ldo) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float iv = inv[c];
+  float dot = 0.f;
+  for (int d = 0; d < D; ++d) dot = fmaf(W[(long)d * ldw + c] * iv, dWh[(long)d * ldg + c], dot);
+  for (int d = 0; d < D; ++d) dW[(long)d * ldo + c] = iv * (dWh[(long)d * ldg + c] - W[(long)d * ldw + c] * iv * dot);
+}
+// f f32 [B, D] -> f^ as f32 [B, D], bf16 [Bp, D] (hi plane, backward operand) and the transposed split planes
+// fbt [3D, Bp] = (hi, lo, hi) for the cos GEMM; inv[B]; rows B..Bp-1 zero.  one wave per row
+__global__ __launch_bounds__(256) void rownorm_fwd_kernel(const float* __restrict__ f, int B, int Bp, int D, float eps, float* __restrict__ fh,
+                                                          bf16_t* __restrict__ fb, bf16_t* __restrict__ fbt, float* __restrict__ inv) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= Bp) return;
+  float s = 0.f;
+  if (row < B) for (int d = lane; d < D; d += 64) { float v = f[(long)row * D + d]; s = fmaf(v, v, s); }
+  s = wave_sum(s);
+  const float iv = row < B ? 1.0f / fmaxf(sqrtf(s), eps) : 0.f;
+  if (lane == 0 && row < B) inv[row] = iv;
+  for (int d = lane; d < D; d += 64) {
+    const float v = row < B ? f[(long)row * D + d] * iv : 0.f;
+    if (row < B) fh[(long)row * D + d] = v;
+    const bf16_t h = f2bf(v);
+    const bf16_t l = f2bf(v - bf2f(h));
+    fb[(long)row * D + d] = h;
+    fbt[(long)d * Bp + row] = h;
+    fbt[(long)(D + d) * Bp + row] = l;
+    fbt[(long)(2 * D + d) * Bp + row] = h;
+  }
+}
+// df = inv * (df^ - f^ <f^, df^>)
+__global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restrict__ fh, const float* __restrict__ inv, const float* __restrict__ dfh,
+                                                          long lddfh, int B, int D, float* __restrict__ df) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B) return;
+  float dot = 0.f;
+  for (int d = lane; d < D; d += 64) dot = fmaf(fh[(long)row * D + d], dfh[(long)row * lddfh + d], dot);
+  dot = wave_sum(dot);
+  const float iv = inv[row];
+  for (int d = lane; d < D; d += 64) df[(long)row * D + d] = iv * (dfh[(long)row * lddfh + d] - fh[(long)row * D + d] * dot);
+}
+
+// ---- margin + CE per row --------------------------------------------------------------------------------------------
+// cos f32 [B, ldc]; one workgroup per row.  Outputs (all optional): logits f32 [B, ldl], loss_rows [B],
+// dcos bf16 [Bp?, lddc] = gscale * (softmax - target) * jac (columns C..lddc-1 zeroed).
+__global__ __launch_bounds__(256) void margin_ce_kernel(MarginP P, const float* __restrict__ cosv, long ldc, int C, const long long* __restrict__ y,
+                                                        float label_smoothing, float gscale, float* __restrict__ logits, long ldl,
+                                                        float* __restrict__ loss_rows, bf16_t* __restrict__ dcos, long lddc) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* cr = cosv + (long)row * ldc;
+  const int yt = (int)y[row];
+  const RowCtx R = margin_row_ctx(P, cr[yt]);
+  float mx = -3.0e38f, sm = 0.f;
+  for (int c = tid; c < C; c += 256) {
+    float lg, jc; margin_eval(P, R, cr[c], c == yt, lg, jc);
+    if (logits) logits[(long)row * ldl + c] = lg;
+    mx = fmaxf(mx, lg); sm += lg;
+  }
+  mx = block_max<4>(mx, red);
+  if (!loss_rows && !dcos) return;
+  sm = block_sum<4>(sm, red);
+  float se = 0.f;
+  for (int c = tid; c < C; c += 256) { float lg, jc; margin_eval(P, R, cr[c], c == yt, lg, jc); se += expf(lg - mx); }
+  se = block_sum<4>(se, red);
+  const float lse = mx + logf(se);
+  if (tid == 0 && loss_rows) {
+    float lg, jc; margin_eval(P, R, cr[yt], true, lg, jc);
+    loss_rows[row] = lse - (1.0f - label_smoothing) * lg - label_smoothing * (sm / (float)C);
+  }
+  if (!dcos) return;
+  const float inv = 1.0f / se, epsc = label_smoothing / (float)C;
+  for (int c = tid; c < (int)lddc; c += 256) {
+    float g = 0.f;
+    if (c < C) {
+      float lg, jc; margin_eval(P, R, cr[c], c == yt, lg, jc);
+      g = expf(lg - mx) * inv - epsc;
+      if (c == yt) g -= (1.0f - label_smoothing);
+      g *= gscale * jc;
+    }
+    dcos[(long)row * lddc + c] = f2bf(g);
+  }
+}
+// backward of the logits-returning form: dcos = dlogits * jac (bf16, padded columns zeroed)
+__global__ __launch_bounds__(256) void margin_bwd_kernel(MarginP P, const float* __restrict__ cosv, long ldc, int C, const long long* __restrict__ y,
+                                                         const float* __restrict__ dlogits, long lddl, bf16_t* __restrict__ dcos, long lddc) {
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* cr = cosv + (long)row * ldc;
+  const int yt = (int)y[row];
+  const RowCtx R = margin_row_ctx(P, cr[yt]);
+  for (int c = tid; c < (int)lddc; c += 256) {
+    float g = 0.f;
+    if (c < C) { float lg, jc; margin_eval(P, R, cr[c], c == yt, lg, jc); g = dlogits[(long)row * lddl + c] * jc; }
+    dcos[(long)row * lddc + c] = f2bf(g);
+  }
+}
+
+static int fill_params(const VdkMarginHead* h, MarginP* P) {
+  if (!h) return vdk_fail(VDK_EINVAL, "margin head: null config");
+  P->mode = h->mode; P->s = h->scale; P->m = h->margin; P->m_am = h->margin_am; P->t = h->mv_weight;
+  P->cos_m = cosf(h->margin); P->sin_m = sinf(h->margin); P->min_cos = cosf(3.14159265358979323846f - h->margin);
+  P->Op = 1.0f + h->margin; P->On = -h->margin; P->dp = 1.0f - h->margin; P->dn = h->margin;
+  if (h->mode < VDK_HEAD_ARCFACE || h->mode > VDK_HEAD_MV_ARC) return vdk_fail(VDK_EINVAL, "margin head: bad mode");
+  return VDK_OK;
+}
+
+extern "C" {
+
+int vdk_colnorm_fwd(const float* W, int64_t ldw, int32_t D, int32_t C, int32_t Cp, float eps, float* inv, void* Wb, int64_t ldb, void* stream) {
+  if (!W || !Wb || D <= 0 || C <= 0 || Cp < C) return vdk_fail(VDK_EINVAL, "vdk_colnorm_fwd: bad argument");
+  hipLaunchKernelGGL(colnorm_fwd_kernel, dim3((unsigned)((Cp + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, (long)ldw, (int)D, (int)C, (int)Cp, eps,
+                     inv, (bf16_t*)Wb, (long)ldb);
+  return vdk_check_launch("vdk_colnorm_fwd");
+}
+int vdk_colnorm_bwd(const float* W, int64_t ldw, const float* inv, const float* dWh, int64_t ldg, int32_t D, int32_t C, float* dW, int64_t ldo,
+                    void* stream) {
+  if (!W || !inv || !dWh || !dW || D <= 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_colnorm_bwd: bad argument");
+  hipLaunchKernelGGL(colnorm_bwd_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, (long)ldw, inv, dWh, (long)ldg, (int)D,
+                     (int)C, dW, (long)ldo);
+  return vdk_check_launch("vdk_colnorm_bwd");
+}
+int vdk_rownorm_fwd(const float* f, int32_t B, int32_t Bp, int32_t D, float eps, float* fh, void* fb, void* fbt, float* inv, void* stream) {
+  if (!f || !fh || !fb || !fbt || !inv || B <= 0 || Bp < B || D <= 0) return vdk_fail(VDK_EINVAL, "vdk_rownorm_fwd: bad argument");
+  hipLaunchKernelGGL(rownorm_fwd_kernel, dim3((unsigned)((Bp + 3) / 4)), dim3(256), 0, (hipStream_t)stream, f, (int)B, (int)Bp, (int)D, eps, fh, (bf16_t*)fb,
+                     (bf16_t*)fbt, inv);
+  return vdk_check_launch("vdk_rownorm_fwd");
+}
+int vdk_rownorm_bwd(const float* fh, const float* inv, const float* dfh, int64_t lddfh, int32_t B, int32_t D, float* df, void* stream) {
+  if (!fh || !inv || !dfh || !df || B <= 0 || D <= 0) return vdk_fail(VDK_EINVAL, "vdk_rownorm_bwd: bad argument");
+  hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, fh, inv, dfh, (long)lddfh, (int)B, (int)D, df);
+  return vdk_check_launch("vdk_rownorm_bwd");
+}
+int vdk_margin_ce(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t C, const int64_t* labels, float label_smoothing,
+                  float grad_scale, float* logits, int64_t ldl, float* loss_rows, void* dcos_bf16, int64_t lddc, void* stream) {
+  MarginP P; int rc = fill_params(h, &P); if (rc) return rc;
+  if (!cosv || !labels || B <= 0 || C <= 0 || (dcos_bf16 && lddc < C)) return vdk_fail(VDK_EINVAL, "vdk_margin_ce: bad argument");
+  hipLaunchKernelGGL(margin_ce_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, P, cosv, (long)ldc, (int)C, (const long long*)labels,
+                     label_smoothing, grad_scale, logits, (long)ldl, loss_rows, (bf16_t*)dcos_bf16, (long)lddc);
+  return vdk_check_launch("vdk_margin_ce");
+}
+int vdk_margin_bwd(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t C, const int64_t* labels, const float* dlogits,
+                   int64_t lddl, void* dcos_bf16, int64_t lddc, void* stream) {
+  MarginP P; int rc = fill_params(h, &P); if (rc) return rc;
+  if (!cosv || !labels || !dlogits || !dcos_bf16 || B <= 0 || C <= 0 || lddc < C) return vdk_fail(VDK_EINVAL, "vdk_margin_bwd: bad argument");
+  hipLaunchKernelGGL(margin_bwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, P, cosv, (long)ldc, (int)C, (const long long*)labels, dlogits,
+                     (long)lddl, (bf16_t*)dcos_bf16, (long)lddc);
+  return vdk_check_launch("vdk_margin_bwd");
+}
+
+}  // extern "C"

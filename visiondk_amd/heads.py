@@ -1,0 +1,162 @@
+"""Margin-softmax heads of the faceX / CBIR training path on the HIP kernels (csrc/margin_head.hip + the MFMA GEMMs).
+
+Mirrors models/faceX/head/{arcface,circleloss,mv_softmax}.py and `HeadFactory` (head_def.py:14-56): same constructor
+arguments, same `weight` Parameter ([feat_dim, num_class], unit-norm columns init, arcface.py:11-12), `forward(feats, labels)
+-> logits`.  `margin_ce()` is the fused form (head + CrossEntropy, no B x C logits through torch)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _abi, _lib, ops
+
+
+def _up(x: int, a: int) -> int:
+    return (x + a - 1) // a * a
+
+
+class _HeadState:
+    """buffers of one forward (kept for the backward)"""
+    __slots__ = ("cos", "fh", "fb", "fbt", "finv", "winv", "wb", "B", "Bp", "C", "Cp", "D")
+
+
+def _forward_cos(be, feats: torch.Tensor, weight: torch.Tensor) -> _HeadState:
+    st = _HeadState()
+    B, D = feats.shape
+    Cn = weight.shape[1]
+    st.B, st.D, st.C, st.Bp, st.Cp = B, D, Cn, _up(B, 64), _up(Cn, 8)
+    dev = feats.device
+    st.winv = torch.empty(Cn, dtype=torch.float32, device=dev)
+    st.wb = torch.empty((3 * D, st.Cp), dtype=torch.bfloat16, device=dev)   # split planes (hi, hi, lo) along K
+    be.check(be.lib.vdk_colnorm_fwd(be.ptr(weight), Cn, D, Cn, st.Cp, 1e-12, be.ptr(st.winv), be.ptr(st.wb), st.Cp, be.stream()), "vdk_colnorm_fwd")
+    st.fh = torch.empty((B, D), dtype=torch.float32, device=dev)
+    st.fb = torch.empty((st.Bp, D), dtype=torch.bfloat16, device=dev)
+    st.fbt = torch.empty((3 * D, st.Bp), dtype=torch.bfloat16, device=dev)  # split planes (hi, lo, hi)
+    st.finv = torch.empty(B, dtype=torch.float32, device=dev)
+    be.check(be.lib.vdk_rownorm_fwd(be.ptr(feats), B, st.Bp, D, 1e-12, be.ptr(st.fh), be.ptr(st.fb), be.ptr(st.fbt), be.ptr(st.finv), be.stream()),
+             "vdk_rownorm_fwd")
+    # cos[Bp, Cp] = f^ . W^ : TN kernel over K = 3D split planes (hi*hi + lo*hi + hi*lo), A = fbt [3D, Bp], B = wb [3D, Cp]
+    st.cos = ops.gemm_nt(st.fbt, st.wb, out_dtype=torch.float32, trans=True, backend=be)
+    return st
+
+
+def _backward_from_dcos(be, st: _HeadState, weight: torch.Tensor, dcos: torch.Tensor):
+    """dcos bf16 [Bp, Cp] -> (dfeats f32 [B, D], dweight f32 [D, C])"""
+    dev = weight.device
+    # dW^ [D, Cp] = f^T dcos : TN, A = f^ [Bp, D], B = dcos [Bp, Cp]
+    dwh = ops.gemm_nt(st.fb, dcos, out_dtype=torch.float32, trans=True, backend=be)
+    dW = torch.empty((st.D, st.C), dtype=torch.float32, device=dev)
+    be.check(be.lib.vdk_colnorm_bwd(be.ptr(weight), st.C, be.ptr(st.winv), be.ptr(dwh), st.Cp, st.D, st.C, be.ptr(dW), st.C, be.stream()), "vdk_colnorm_bwd")
+    # df^ [Bp, D] = dcos W^T : NT, A = dcos [Bp, Cp], B = W^ [D, Cp]; the contraction is the class dim -> split-K
+    tiles = ((st.Bp + 255) // 256) * ((st.D + 255) // 256)
+    splitk = max(1, min(64, 256 // tiles, st.Cp // 4096)) if st.Cp >= 8192 else 1
+    dfh = ops.gemm_nt(dcos, st.wb[:st.D], out_dtype=torch.float32, splitk=splitk, backend=be)   # hi plane
+    df = torch.empty((st.B, st.D), dtype=torch.float32, device=dev)
+    be.check(be.lib.vdk_rownorm_bwd(be.ptr(st.fh), be.ptr(st.finv), be.ptr(dfh), st.D, st.B, st.D, be.ptr(df), be.stream()), "vdk_rownorm_bwd")
+    return df, dW
+
+
+class _HeadFn(torch.autograd.Function):
+    """head(feats, labels) -> logits, differentiable (the reference form: the loss is applied by the caller)"""
+
+    @staticmethod
+    def forward(ctx, feats, weight, labels, head):
+        be = head.be
+        st = _forward_cos(be, feats.contiguous(), weight)
+        logits = torch.empty((st.B, st.C), dtype=torch.float32, device=feats.device)
+        cfg = head.cfg
+        be.check(be.lib.vdk_margin_ce(C.byref(cfg), be.ptr(st.cos), st.Cp, st.B, st.C, be.ptr(labels), 0.0, 1.0, be.ptr(logits), st.C, None, None, 0,
+                                      be.stream()), "vdk_margin_ce")
+        ctx.st, ctx.head, ctx.labels = st, head, labels
+        ctx.save_for_backward(weight)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        st, head = ctx.st, ctx.head
+        be = head.be
+        (weight,) = ctx.saved_tensors
+        dcos = torch.zeros((st.Bp, st.Cp), dtype=torch.bfloat16, device=dlogits.device)
+        dlogits = dlogits.contiguous()
+        be.check(be.lib.vdk_margin_bwd(C.byref(head.cfg), be.ptr(st.cos), st.Cp, st.B, st.C, be.ptr(ctx.labels), be.ptr(dlogits), st.C, be.ptr(dcos), st.Cp,
+                                       be.stream()), "vdk_margin_bwd")
+        df, dW = _backward_from_dcos(be, st, weight, dcos)
+        return df, dW, None, None
+
+
+class _MarginHead(nn.Module):
+    mode = -1
+
+    def __init__(self, feat_dim: int, num_class: int, backend: Optional[_lib.Backend] = None, device=None):
+        super().__init__()
+        self.be = backend or _lib.load()
+        dev = device if device is not None else ("cuda" if self.be.device_only else "cpu")
+        w = torch.empty(feat_dim, num_class)
+        w.uniform_(-1, 1).renorm_(2, 1, 1e-5).mul_(1e5)     # arcface.py:12 — unit-norm columns
+        self.weight = nn.Parameter(w.to(dev))
+        self.cfg = _abi.MarginHead(self.mode, 1.0, 0.0, 0.0, 0.0)
+
+    def forward(self, feats: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        return _HeadFn.apply(feats, self.weight, labels, self)
+
+    def margin_ce(self, feats: torch.Tensor, labels: torch.Tensor, label_smoothing: float = 0.0, grad_scale: Optional[float] = None):
+        """Fused head + CrossEntropy (mean): returns (loss_rows [B], dfeats [B, D], dweight [D, C]); no autograd, no B x C logits."""
+        be = self.be
+        st = _forward_cos(be, feats.contiguous(), self.weight.detach())
+        loss = torch.empty(st.B, dtype=torch.float32, device=feats.device)
+        dcos = torch.zeros((st.Bp, st.Cp), dtype=torch.bfloat16, device=feats.device)
+        gs = 1.0 / st.B if grad_scale is None else grad_scale
+        be.check(be.lib.vdk_margin_ce(C.byref(self.cfg), be.ptr(st.cos), st.Cp, st.B, st.C, be.ptr(labels), label_smoothing, gs, None, 0, be.ptr(loss),
+                                      be.ptr(dcos), st.Cp, be.stream()), "vdk_margin_ce")
+        df, dW = _backward_from_dcos(be, st, self.weight.detach(), dcos)
+        return loss, df, dW
+
+
+class ArcFace(_MarginHead):
+    """models/faceX/head/arcface.py"""
+    mode = _abi.HEAD_ARCFACE
+
+    def __init__(self, feat_dim, num_class, margin_arc=0.35, margin_am=0.0, scale=32, **kw):
+        super().__init__(feat_dim, num_class, **kw)
+        self.cfg = _abi.MarginHead(self.mode, float(scale), float(margin_arc), float(margin_am), 0.0)
+
+
+class CircleLoss(_MarginHead):
+    """models/faceX/head/circleloss.py"""
+    mode = _abi.HEAD_CIRCLE
+
+    def __init__(self, feat_dim, num_class, margin=0.25, gamma=256, **kw):
+        super().__init__(feat_dim, num_class, **kw)
+        self.cfg = _abi.MarginHead(self.mode, float(gamma), float(margin), 0.0, 0.0)
+
+
+class MV_Softmax(_MarginHead):
+    """models/faceX/head/mv_softmax.py"""
+
+    def __init__(self, feat_dim, num_class, is_am, margin=0.35, mv_weight=1.12, scale=32, **kw):
+        self.mode = _abi.HEAD_MV_AM if is_am else _abi.HEAD_MV_ARC
+        super().__init__(feat_dim, num_class, **kw)
+        self.cfg = _abi.MarginHead(self.mode, float(scale), float(margin), 0.0, float(mv_weight))
+
+
+class HeadFactory:
+    """models/faceX/head/head_def.py:14-56 — head_type in {'arcface', 'circleloss' (yaml alias 'circle'), 'mv-softmax'}."""
+
+    def __init__(self, head_type: str, head_conf: dict, backend=None, device=None):
+        self.head_type, self.head_param, self.kw = head_type, head_conf, dict(backend=backend, device=device)
+
+    def get_head(self):
+        p = self.head_param
+        t = self.head_type.lower()
+        if t == "arcface":
+            return ArcFace(p["feat_dim"], p["num_class"], p.get("margin_arc", 0.35), p.get("margin_am", 0.0), p.get("scale", 32), **self.kw)
+        if t in ("circleloss", "circle"):
+            return CircleLoss(p["feat_dim"], p["num_class"], p.get("margin", 0.25), p.get("gamma", 256), **self.kw)
+        if t in ("mv-softmax", "mv_softmax"):
+            return MV_Softmax(p["feat_dim"], p["num_class"], p["is_am"], p.get("margin", 0.35), p.get("mv_weight", 1.12), p.get("scale", 32), **self.kw)
+        if t == "magface":
+            raise NotImplementedError("MagFace.forward returns a tuple the reference Trainer cannot consume (train.py:196); not built")
+        raise KeyError(f"unknown head type {self.head_type}")
