@@ -130,6 +130,14 @@ int vdk_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const floa
                       int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                       void* stream);
 
+/* nn.BatchNorm1d on [B, F] — last layer of the TimmWrapper neck (models/faceX/backbone/timm_wrapper.py:37,46).  training != 0:
+ * batch statistics (saved for backward) + running-stat update (unbiased var, momentum); else running statistics. */
+int vdk_batchnorm1d_fwd(const float* x, int64_t ldx, int32_t B, int32_t F, const float* gamma, const float* beta, float eps, float momentum,
+                        int32_t training, float* running_mean, float* running_var, float* y, int64_t ldy, float* save_mean, float* save_invstd,
+                        void* stream);
+int vdk_batchnorm1d_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, int32_t B, int32_t F, const float* gamma, const float* save_mean,
+                        const float* save_invstd, float* dx, int64_t lddx, float* dgamma, float* dbeta, void* stream);
+
 /* out[c] = scale * sum_{s<S} in[s*ld + c]  (deterministic; pos_embed/cls gradients, partial combines) */
 int vdk_reduce_rows_f32(const float* in, int64_t ld, int32_t S, int64_t n, float* out, float scale, void* stream);
 /* out[c] = sum_r in[r][c], in bf16 [T, N] — bias gradient of a Linear */

@@ -146,3 +146,19 @@ def train_step_reference(model: nn.Module, x, y, *, lr, momentum, weight_decay, 
             for n, p in model.named_parameters():
                 ema[n].mul_(d).add_(p.detach(), alpha=1 - d)
     return logits.detach(), loss.detach(), grads, total_norm, momentum_bufs
+
+
+class TimmWrapperRef(nn.Module):
+    """Restatement of the reference's TimmWrapper for a transformer backbone (models/faceX/backbone/timm_wrapper.py:16-21,39-54):
+    `timm.create_model(name, num_classes=0, global_pool='')` -> forward = final-normed tokens [B, N, C]; neck =
+    LayerNorm(C) -> Flatten -> Linear(N*C, feat_dim) -> BatchNorm1d(feat_dim)."""
+
+    def __init__(self, feat_dim, img_size=224, patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_dim=None):
+        super().__init__()
+        self.model = VisionTransformerRef(img_size, patch_size, 3, 1, embed_dim, depth, num_heads, mlp_dim)
+        del self.model.head
+        n = (img_size // patch_size) ** 2 + 1
+        self.output_layer = nn.Sequential(nn.LayerNorm(embed_dim), nn.Flatten(1), nn.Linear(n * embed_dim, feat_dim), nn.BatchNorm1d(feat_dim))
+
+    def forward(self, x):
+        return self.output_layer(self.model.forward_features(x))

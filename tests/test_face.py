@@ -1,0 +1,109 @@
+"""faceX / CBIR model path: TimmWrapper (ViT features + neck) + margin head vs the oracle restatement (same weights)."""
+import importlib.util
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.vit_ref import TimmWrapperRef
+from visiondk_amd import face
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).double().cpu(); b = torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+CFG = {"task": "cbir", "image_size": 32,
+       "backbone": {"timm-vit_tiny_patch16_224": {"pretrained": False, "image_size": 32, "feat_dim": 64}},
+       "head": {"arcface": {"feat_dim": 64, "num_class": 40, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
+
+
+class _RefArcFace(torch.nn.Module):   # arcface.py:20-36 restated (the golden test pins the HIP head against the real module)
+    def __init__(self, w, m=0.35, s=32.0):
+        super().__init__()
+        self.weight = torch.nn.Parameter(w.clone()); self.m, self.s = m, s
+
+    def forward(self, f, y):
+        import math
+        kn = torch.nn.functional.normalize(self.weight, dim=0); f = torch.nn.functional.normalize(f)
+        c = (f @ kn).clamp(-1, 1)
+        cm = c * math.cos(self.m) - torch.sqrt(1 - c ** 2) * math.sin(self.m)
+        cm = torch.where(c > math.cos(math.pi - self.m), cm, c)
+        idx = torch.zeros_like(c).scatter_(1, y.view(-1, 1), 1).bool()
+        out = c * 1.0
+        out[idx] = cm[idx]
+        return out * self.s
+
+
+def _build(be, dev):
+    torch.manual_seed(0)
+    wrap = face.get_model(CFG, None, 0, backend=be, device=dev)
+    model = wrap.model
+    bb = model.trainingwrapper["backbone"]
+    spec = bb.model.spec
+    ref = TimmWrapperRef(64, spec.img_size, spec.patch_size, spec.dim, spec.depth, spec.heads, spec.mlp_dim)
+    with torch.no_grad():
+        for blk in ref.model.blocks:
+            for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2):
+                lin.weight.mul_(3.0)
+        for p in ref.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.05)
+    sd = {k: v for k, v in ref.state_dict().items()}
+    missing = bb.load_state_dict({k: v.to(dev) for k, v in sd.items()}, strict=True)
+    return model, ref
+
+
+def test_state_dict_keys_match_reference_layout(be, dev):
+    model, ref = _build(be, dev)
+    keys = list(model.trainingwrapper["backbone"].state_dict().keys())
+    assert keys == list(ref.state_dict().keys())
+    assert "model.blocks.0.attn.qkv.weight" in keys and "output_layer.2.weight" in keys and "output_layer.3.running_var" in keys
+    assert "trainingwrapper.head.weight" in model.state_dict() and "trainingwrapper.backbone.model.cls_token" in model.state_dict()
+
+
+def test_face_forward_backward_vs_oracle(be, dev):
+    model, ref = _build(be, dev)
+    head = model.trainingwrapper["head"]
+    rhead = _RefArcFace(head.weight.detach().cpu())
+    torch.manual_seed(1)
+    x = torch.randn(6, 3, 32, 32); y = torch.randint(0, 40, (6,))
+    model.train(); ref.train()
+    emb_ref = ref(x)
+    loss_ref = torch.nn.functional.cross_entropy(rhead(emb_ref, y), y)
+    loss_ref.backward()
+    logits = model(x.to(dev), y.to(dev))
+    loss = torch.nn.functional.cross_entropy(logits, y.to(dev))
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 2e-2 * abs(loss_ref.item())
+    bb = model.trainingwrapper["backbone"]
+    got = dict(bb.named_parameters()); exp = dict(ref.named_parameters())
+    assert set(got) == set(exp)
+    gmax = max(exp[n].grad.norm().item() for n in exp)
+    for n in exp:
+        if exp[n].grad.norm().item() < 1e-5 * gmax:
+            # analytically zero gradient (the neck LayerNorm bias: train-mode BatchNorm cancels any per-channel shift):
+            # the reference holds fp32 round-off, we hold bf16 round-off; both must be negligible in absolute terms
+            assert got[n].grad.norm().item() < 1e-3 * gmax, n
+            continue
+        r = _rel(got[n].grad, exp[n].grad)
+        assert r < 8e-2, (n, r)
+    assert _rel(head.weight.grad, rhead.weight.grad) < 8e-2
+    # BatchNorm running statistics were updated like torch's
+    assert _rel(bb.output_layer[3].running_mean, ref.output_layer[3].running_mean) < 2e-2
+    assert _rel(bb.output_layer[3].running_var, ref.output_layer[3].running_var) < 2e-2
+
+
+def test_extract_cbir_eval_embeddings(be, dev):
+    model, ref = _build(be, dev)
+    bb = model.trainingwrapper["backbone"]
+    x = torch.randn(5, 3, 32, 32)
+    ref.eval()
+    with torch.no_grad():
+        exp = torch.nn.functional.normalize(ref(x)).numpy()
+    got = face.FeatureExtractor(bb).extract_cbir([x[:3], x[3:]], dev)
+    assert got.shape == (5, 64) and got.dtype == np.float32
+    assert _rel(got, exp) < 2e-2
+    np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, rtol=1e-5)

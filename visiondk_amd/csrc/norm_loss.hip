@@ -237,6 +237,52 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict
   if (tid == 0 && loss_rows) loss_rows[row] = s;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm1d over [B, F] (the TimmWrapper neck's last layer, models/faceX/backbone/timm_wrapper.py:37,46; eps 1e-5,
+// momentum 0.1).  One thread per feature (coalesced across features), B <= a few thousand rows.
+// train: batch mean / biased var normalise; running stats updated with the unbiased var.  eval: running stats.
+__global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__ x, long ldx, int B, int F, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, float momentum, int training,
+                                                       float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ y, long ldy,
+                                                       float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  float mu, var;
+  if (training) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += x[(long)b * ldx + f];
+    mu = s / (float)B;
+    float q = 0.f;
+    for (int b = 0; b < B; ++b) { float d = x[(long)b * ldx + f] - mu; q = fmaf(d, d, q); }
+    var = q / (float)B;
+    if (rmean) rmean[f] = (1.0f - momentum) * rmean[f] + momentum * mu;
+    if (rvar) rvar[f] = (1.0f - momentum) * rvar[f] + momentum * (B > 1 ? q / (float)(B - 1) : var);
+  } else { mu = rmean[f]; var = rvar[f]; }
+  const float is = 1.0f / sqrtf(var + eps);
+  if (save_mean) save_mean[f] = mu;
+  if (save_invstd) save_invstd[f] = is;
+  const float g = gamma[f] * is, bb = beta[f];
+  for (int b = 0; b < B; ++b) y[(long)b * ldy + f] = (x[(long)b * ldx + f] - mu) * g + bb;
+}
+// training-mode backward: dx = gamma * invstd / B * (B * dy - sum(dy) - xhat * sum(dy * xhat))
+__global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx, int B, int F,
+                                                       const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                       const float* __restrict__ save_invstd, float* __restrict__ dx, long lddx,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  const float mu = save_mean[f], is = save_invstd[f];
+  float sg = 0.f, sb = 0.f;
+  for (int b = 0; b < B; ++b) { float d = dy[(long)b * lddy + f]; sb += d; sg = fmaf(d, (x[(long)b * ldx + f] - mu) * is, sg); }
+  dgamma[f] = sg; dbeta[f] = sb;
+  const float k = gamma[f] * is / (float)B;
+  for (int b = 0; b < B; ++b) {
+    const float xh = (x[(long)b * ldx + f] - mu) * is;
+    dx[(long)b * lddx + f] = k * ((float)B * dy[(long)b * lddy + f] - sb - xh * sg);
+  }
+}
+
 extern "C" {
 
 int vdk_layernorm_fwd(const float* x, int64_t ldx, int32_t T, int32_t C, const float* gamma, const float* beta, float eps,
@@ -318,6 +364,24 @@ int vdk_colsum_bf16(const void* in, int64_t ld, int32_t T, int32_t N, float* out
   hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((N + 63) / 64)), dim3(512), 0, stream, (const float*)ws, (long)N, S,
                      (long)N, out, 1.0f);
   return vdk_check_launch("vdk_colsum_bf16");
+}
+
+int vdk_batchnorm1d_fwd(const float* x, int64_t ldx, int32_t B, int32_t F, const float* gamma, const float* beta, float eps, float momentum,
+                        int32_t training, float* running_mean, float* running_var, float* y, int64_t ldy, float* save_mean, float* save_invstd,
+                        void* stream) {
+  if (!x || !gamma || !beta || !y || B <= 0 || F <= 0 || (!training && (!running_mean || !running_var)))
+    return vdk_fail(VDK_EINVAL, "vdk_batchnorm1d_fwd: bad argument");
+  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)B, (int)F, gamma, beta, eps,
+                     momentum, (int)training, running_mean, running_var, y, (long)ldy, save_mean, save_invstd);
+  return vdk_check_launch("vdk_batchnorm1d_fwd");
+}
+int vdk_batchnorm1d_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, int32_t B, int32_t F, const float* gamma, const float* save_mean,
+                        const float* save_invstd, float* dx, int64_t lddx, float* dgamma, float* dbeta, void* stream) {
+  if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || B <= 0 || F <= 0)
+    return vdk_fail(VDK_EINVAL, "vdk_batchnorm1d_bwd: bad argument");
+  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, (long)lddy, x, (long)ldx, (int)B, (int)F,
+                     gamma, save_mean, save_invstd, dx, (long)lddx, dgamma, dbeta);
+  return vdk_check_launch("vdk_batchnorm1d_bwd");
 }
 
 int vdk_softmax_ce(const float* logits, int64_t ldl, int32_t B, int32_t C, const int64_t* ya, const int64_t* yb, float lam,

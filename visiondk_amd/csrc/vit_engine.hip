@@ -46,7 +46,7 @@ static int vit_dims(const VdkVitConfig* c, VitDims* d) {
   if (!c) return vdk_fail(VDK_EINVAL, "vit: null config");
   d->B = c->batch; d->img = c->img_size; d->ps = c->patch_size; d->Cin = c->in_chans; d->D = c->dim; d->L = c->depth;
   d->H = c->heads; d->M = c->mlp_dim; d->C = c->num_classes; d->eps = c->ln_eps;
-  if (d->B <= 0 || d->img <= 0 || d->ps <= 0 || d->img % d->ps || d->Cin <= 0 || d->D <= 0 || d->L <= 0 || d->H <= 0 || d->M <= 0 || d->C <= 0)
+  if (d->B <= 0 || d->img <= 0 || d->ps <= 0 || d->img % d->ps || d->Cin <= 0 || d->D <= 0 || d->L <= 0 || d->H <= 0 || d->M <= 0 || d->C < 0)
     return vdk_fail(VDK_EINVAL, "vit: bad config value");
   if (d->D != d->H * 64) return vdk_fail(VDK_EUNSUPPORTED, "vit: head_dim must be 64 (dim == 64 * heads)");
   if ((d->D & 7) || (d->M & 7)) return vdk_fail(VDK_EUNSUPPORTED, "vit: dim and mlp_dim must be multiples of 8");
@@ -90,8 +90,11 @@ static int vit_layout(const VitDims& d, PLayout* p) {
     b.fc2_w = p_take(cur, (int64_t)d.D * d.M); b.fc2_b = p_take(cur, d.D);
   }
   p->norm_w = p_take(cur, d.D); p->norm_b = p_take(cur, d.D);
-  p->head_w = p_take(cur, (int64_t)d.Cp * d.D);   // rows C..Cp-1 are zero padding (N % 8 for the GEMM)
-  p->head_b = p_take(cur, d.Cp);
+  p->head_w = p->head_b = cur;
+  if (d.C > 0) {
+    p->head_w = p_take(cur, (int64_t)d.Cp * d.D);   // rows C..Cp-1 are zero padding (N % 8 for the GEMM)
+    p->head_b = p_take(cur, d.Cp);
+  }
   p->total = cur;
   int64_t t = 0;
   for (int l = 0; l < d.L; ++l) {
@@ -100,7 +103,8 @@ static int vit_layout(const VitDims& d, PLayout* p) {
     p->blkT[l].fc1 = p_take(t, (int64_t)d.D * d.M);
     p->blkT[l].fc2 = p_take(t, (int64_t)d.M * d.D);
   }
-  p->headT = p_take(t, (int64_t)d.D * d.Cp);
+  p->headT = t;
+  if (d.C > 0) p->headT = p_take(t, (int64_t)d.D * d.Cp);
   p->totalT = t;
   return VDK_OK;
 }
@@ -113,7 +117,7 @@ static void pe_set(PEntry* e, const char* name, int64_t off, int ndim, int64_t s
 // timm state_dict order and names; head rows are reported unpadded ([C, D]; the padding rows
 // follow in memory and must stay zero).
 static int vit_entry(const VitDims& d, const PLayout& p, int idx, PEntry* e) {
-  const int per = 12, ntens = 4 + per * d.L + 4;
+  const int per = 12, ntens = 4 + per * d.L + (d.C > 0 ? 4 : 2);   // feature mode (num_classes = 0) has no head
   if (idx < 0 || idx >= ntens) return -1;
   char nm[64];
   if (idx == 0) { pe_set(e, "cls_token", p.cls, 3, 1, 1, d.D); return 0; }
@@ -196,7 +200,7 @@ static int vit_plan(const VitDims& d, WsPlan* w) {
   const size_t T = d.T, D = d.D, M = d.M, L = d.L;
   w->patches = w_take(cur, (size_t)d.B * d.np * d.Kpe * 2);
   w->X = w_take(cur, (2 * L + 1) * T * D * 4);
-  w->stats = w_take(cur, (L * 4 * T + 2 * (size_t)d.B) * 4);
+  w->stats = w_take(cur, (L * 4 * T + 2 * T) * 4);   // + final norm: B rows (token pooling) or all T rows (feature mode)
   w->s_h = T * D * 2; w->s_qkv = T * 3 * D * 2; w->s_lse = (size_t)d.B * d.H * d.N * 4; w->s_u = T * M * 2;
   w->h1 = w_take(cur, L * w->s_h); w->qkv = w_take(cur, L * w->s_qkv); w->lse = w_take(cur, L * w->s_lse);
   w->o = w_take(cur, L * w->s_h); w->h2 = w_take(cur, L * w->s_h); w->u = w_take(cur, L * w->s_u); w->g = w_take(cur, L * w->s_u);
@@ -247,7 +251,7 @@ int vdk_vit_param_count(const VdkVitConfig* cfg, int64_t* n_floats, int32_t* n_t
   VitDims d; RC(vit_dims(cfg, &d));
   PLayout p; RC(vit_layout(d, &p));
   if (n_floats) *n_floats = p.total;
-  if (n_tensors) *n_tensors = 4 + 12 * d.L + 4;
+  if (n_tensors) *n_tensors = 4 + 12 * d.L + (d.C > 0 ? 4 : 2);
   if (n_transposed) *n_transposed = p.totalT;
   return VDK_OK;
 }
@@ -288,11 +292,12 @@ int vdk_vit_refresh_weights(const VdkVitConfig* cfg, const float* params, void* 
     RC(vdk_transpose_cast_f32_bf16(params + p.blk[l].fc1_w, d.D, d.M, d.D, wt + p.blkT[l].fc1, d.M, d.M, stream));
     RC(vdk_transpose_cast_f32_bf16(params + p.blk[l].fc2_w, d.M, d.D, d.M, wt + p.blkT[l].fc2, d.D, d.D, stream));
   }
-  RC(vdk_transpose_cast_f32_bf16(params + p.head_w, d.D, d.Cp, d.D, wt + p.headT, d.Cp, d.Cp, stream));
+  if (d.C > 0) RC(vdk_transpose_cast_f32_bf16(params + p.head_w, d.D, d.Cp, d.D, wt + p.headT, d.Cp, d.Cp, stream));
   return VDK_OK;
 }
 
-// x: f32 [B, Cin, img, img] -> logits f32 [B, Cp] (columns C..Cp-1 are padding).  Saves activations in ws.
+// x: f32 [B, Cin, img, img] -> logits f32 [B, Cp] (columns C..Cp-1 are padding); feature mode (num_classes = 0): `logits`
+// receives the final-normed tokens f32 [B*N, D].  Saves activations in ws.
 int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params, const void* wb16, void* ws, size_t ws_bytes,
                     float* logits, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
@@ -333,9 +338,14 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
     RC(gemm(s, h2, D, wb + b.fc1_w, D, g, M, T, M, D, VDK_BF16, params + b.fc1_b, nullptr, 0, VDK_ACT_GELU, u, M, 1, 0, nullptr, 0));
     RC(gemm(s, g, M, wb + b.fc2_w, M, xout, D, T, D, M, VDK_F32, params + b.fc2_b, xmid, D, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
   }
-  // final norm on the class-token rows only (LayerNorm is per token; global_pool='token' keeps token 0), then the head
   float* xl = X + (size_t)(2 * d.L) * XS;
-  float* meanf = stats + (size_t)d.L * 4 * T; float* rstdf = meanf + d.B;
+  float* meanf = stats + (size_t)d.L * 4 * T; float* rstdf = meanf + T;
+  if (d.C == 0) {
+    // feature mode (timm num_classes=0, global_pool=''): `logits` receives norm(x) for ALL tokens, f32 [B*N, D]
+    RC(vdk_layernorm_fwd(xl, D, T, D, params + p.norm_w, params + p.norm_b, d.eps, logits, D, VDK_F32, meanf, rstdf, s));
+    return VDK_OK;
+  }
+  // final norm on the class-token rows only (LayerNorm is per token; global_pool='token' keeps token 0), then the head
   bf16_t* hf = (bf16_t*)(base + w.hf);
   RC(vdk_layernorm_fwd(xl, (int64_t)d.N * D, d.B, D, params + p.norm_w, params + p.norm_b, d.eps, hf, D, VDK_BF16, meanf, rstdf, s));
   RC(gemm(s, hf, D, wb + p.head_w, D, logits, d.Cp, d.B, d.Cp, D, VDK_F32, params + p.head_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
@@ -368,7 +378,7 @@ static int linear_wgrad(hipStream_t s, const VitDims& d, const WsPlan& w, char* 
   return VDK_OK;
 }
 
-// dlogits: bf16 [B, Cp] (what vdk_softmax_ce writes, padding columns zero).  grads: flat fp32, param layout,
+// dlogits: bf16 [B, Cp] (what vdk_softmax_ce writes, padding columns zero); in feature mode (num_classes = 0): f32 [B*N, D].  grads: flat fp32, param layout,
 // fully overwritten (zero_grad semantics).  on_ready(user, offset, numel) is called on the host right after the
 // kernels producing grads[offset, offset+numel) have been enqueued (reverse layer order) so that a data-parallel
 // caller can start that bucket's all-reduce on another stream; may be NULL.
@@ -393,7 +403,14 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
   void* lnws = base + w.lnws;
 
   // ---- head + final norm -------------------------------------------------------------------------
-  {
+  if (d.C == 0) {
+    // feature mode: `dlogits` is dL/d norm(x) for all tokens, f32 [B*N, D]
+    float* xl = X + (size_t)(2 * d.L) * XS;
+    float* meanf = stats + (size_t)d.L * 4 * T; float* rstdf = meanf + T;
+    RC(vdk_layernorm_bwd(dlogits, D, VDK_F32, xl, D, meanf, rstdf, params + p.norm_w, nullptr, 0, T, D, dxa, D, dxab, D, grads + p.norm_w, grads + p.norm_b,
+                         lnws, w.lnws_bytes, s));
+    if (on_ready) on_ready(user, p.norm_w, p.total - p.norm_w);
+  } else {
     const bf16_t* dl = (const bf16_t*)dlogits;
     bf16_t* hf = (bf16_t*)(base + w.hf);
     RC(linear_wgrad(s, d, w, base, dl, d.Cp, hf, D, d.B, d.Bp, d.Cp, D, grads + p.head_w, grads + p.head_b, 0));
@@ -402,7 +419,7 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
     if (hipMemsetAsync(dxa, 0, XS * 4, s) != hipSuccess || hipMemsetAsync(dxab, 0, XS * 2, s) != hipSuccess)
       return vdk_fail(VDK_ELAUNCH, "vdk_vit_backward: memset failed");
     float* xl = X + (size_t)(2 * d.L) * XS;
-    float* meanf = stats + (size_t)d.L * 4 * T; float* rstdf = meanf + d.B;
+    float* meanf = stats + (size_t)d.L * 4 * T; float* rstdf = meanf + T;
     RC(vdk_layernorm_bwd(dhf, D, VDK_BF16, xl, (int64_t)d.N * D, meanf, rstdf, params + p.norm_w, nullptr, 0, d.B, D, dxa, (int64_t)d.N * D, dxab,
                          (int64_t)d.N * D, grads + p.norm_w, grads + p.norm_b, lnws, w.lnws_bytes, s));
     if (on_ready) on_ready(user, p.norm_w, p.total - p.norm_w);

@@ -1,0 +1,205 @@
+"""faceX / CBIR model path on the HIP kernels: the reference's `TimmWrapper` (backbone + embedding neck),
+`FaceTrainingModel` / `FaceTrainingWrapper`, `FeatureExtractor`, and the `get_model` factory seam.
+
+Reference: models/faceX/backbone/timm_wrapper.py:5-54, models/faceX/face_model.py:10-54,88-143, models/smartmodel.py:5-10.
+Transformer backbones only for now (timm ViT ids in visiondk_amd.vit.TIMM_VITS): the neck is
+LayerNorm(C) -> Flatten -> Linear(N*C, feat_dim) -> BatchNorm1d(feat_dim) (timm_wrapper.py:39-47).  CNN backbones (ConvNeXt,
+ResNet: BatchNorm2d neck) are the next §8 row.  state_dict keys equal the reference's:
+`model.<timm keys>`, `output_layer.0.*` (LayerNorm), `output_layer.2.*` (Linear), `output_layer.3.*` (BatchNorm1d)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _abi, _lib, heads, ops, vit
+
+
+def _up(x, a):
+    return (x + a - 1) // a * a
+
+
+class _NeckFn(torch.autograd.Function):
+    """LayerNorm(C) -> Flatten -> Linear(N*C, F) -> BatchNorm1d(F) as one autograd node over the HIP kernels"""
+
+    @staticmethod
+    def forward(ctx, tokens, ln_w, ln_b, lin_w, lin_b, bn_w, bn_b, wrapper):
+        be = wrapper.be
+        B, N, D = tokens.shape
+        Fd = lin_w.shape[0]
+        K = N * D
+        Bp = _up(B, 64)
+        dev = tokens.device
+        tokens = tokens.contiguous()
+        bn = wrapper.output_layer[3]
+        # LayerNorm over C (eps 1e-5: nn.LayerNorm default, timm_wrapper.py:42) -> bf16 rows, viewed as [Bp, N*D] (pad rows zero)
+        h = torch.zeros((Bp, K), dtype=torch.bfloat16, device=dev)
+        mean = torch.empty(B * N, dtype=torch.float32, device=dev)
+        rstd = torch.empty(B * N, dtype=torch.float32, device=dev)
+        be.check(be.lib.vdk_layernorm_fwd(be.ptr(tokens), D, B * N, D, be.ptr(ln_w), be.ptr(ln_b), 1e-5, be.ptr(h), D, _abi.BF16, be.ptr(mean),
+                                          be.ptr(rstd), be.stream()), "vdk_layernorm_fwd")
+        wb = ops.cast_bf16(lin_w.detach().contiguous(), backend=be)                      # [F, N*D] bf16
+        z = ops.gemm_nt(h[:B], wb, out_dtype=torch.float32, bias=lin_b.detach(), backend=be)     # [B, F]
+        y = torch.empty_like(z)
+        training = bool(wrapper.training)
+        sm = torch.empty(Fd, dtype=torch.float32, device=dev)
+        si = torch.empty(Fd, dtype=torch.float32, device=dev)
+        be.check(be.lib.vdk_batchnorm1d_fwd(be.ptr(z), Fd, B, Fd, be.ptr(bn_w), be.ptr(bn_b), bn.eps, bn.momentum, int(training),
+                                            be.ptr(bn.running_mean), be.ptr(bn.running_var), be.ptr(y), Fd, be.ptr(sm), be.ptr(si), be.stream()),
+                 "vdk_batchnorm1d_fwd")
+        if training:
+            bn.num_batches_tracked += 1
+        ctx.save_for_backward(tokens, ln_w, bn_w, mean, rstd, h, wb, z, sm, si)
+        ctx.wrapper, ctx.dims = wrapper, (B, N, D, Fd, K, Bp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        tokens, ln_w, bn_w, mean, rstd, h, wb, z, sm, si = ctx.saved_tensors
+        wrapper = ctx.wrapper
+        be = wrapper.be
+        B, N, D, Fd, K, Bp = ctx.dims
+        dev = dy.device
+        dy = dy.contiguous()
+        dz = torch.empty((B, Fd), dtype=torch.float32, device=dev)
+        dbn_w = torch.empty(Fd, dtype=torch.float32, device=dev); dbn_b = torch.empty(Fd, dtype=torch.float32, device=dev)
+        be.check(be.lib.vdk_batchnorm1d_bwd(be.ptr(dy), Fd, be.ptr(z), Fd, B, Fd, be.ptr(bn_w), be.ptr(sm), be.ptr(si), be.ptr(dz), Fd, be.ptr(dbn_w),
+                                            be.ptr(dbn_b), be.stream()), "vdk_batchnorm1d_bwd")
+        dzb = torch.zeros((Bp, _up(Fd, 8)), dtype=torch.bfloat16, device=dev)
+        stage = torch.zeros((Bp, _up(Fd, 8)), dtype=torch.float32, device=dev)
+        stage[:B, :Fd].copy_(dz)
+        be.check(be.lib.vdk_cast_f32_bf16(be.ptr(stage), be.ptr(dzb), stage.numel(), be.stream()), "vdk_cast_f32_bf16")
+        dlin_b = ops.reduce_rows(dz, backend=be)
+        # dW [F, N*D] = dz^T h : TN kernel straight from dz [Bp, F] and h [Bp, N*D]
+        dlin_w = ops.gemm_nt(dzb, h, out_dtype=torch.float32, trans=True, backend=be)[:Fd]
+        # dh [Bp, N*D] = dz W : TN kernel with A = dz^T [F, Bp] (tiny transpose), B = W [F, N*D] as it lies
+        dzt = ops.transpose_pad(dzb, rpad=Bp, backend=be)                    # [Fp, Bp]
+        fpad = dzt.shape[0]
+        if fpad % 64 == 0 and fpad == Fd:
+            dh = ops.gemm_nt(dzt, wb, out_dtype=torch.bfloat16, trans=True, backend=be)            # [Bp, N*D]
+        else:   # feature dims that are not multiples of 64: NT kernel against an explicit W^T copy
+            wbt = ops.transpose_pad(wb, rpad=_up(Fd, 8), backend=be)          # [N*D, Fp]
+            dh = ops.gemm_nt(dzb, wbt, out_dtype=torch.bfloat16, backend=be)
+        dtok, _, dln_w, dln_b = ops.layernorm_bwd(dh[:B].reshape(B * N, D), tokens.view(B * N, D), mean, rstd, ln_w, want_bf16=False, backend=be)
+        return dtok.view(B, N, D), dln_w, dln_b, dlin_w.contiguous(), dlin_b, dbn_w, dbn_b, None
+
+
+class TimmWrapper(nn.Module):
+    """models/faceX/backbone/timm_wrapper.py: timm backbone without head/pool + embedding neck -> [B, feat_dim]."""
+
+    def __init__(self, model_name: str, feat_dim: int, image_size: int, pretrained: bool = True, backend: Optional[_lib.Backend] = None,
+                 device=None, **kwargs):
+        super().__init__()
+        self.be = backend or _lib.load()
+        dev = device if device is not None else ("cuda" if self.be.device_only else "cpu")
+        if model_name not in vit.TIMM_VITS:
+            raise NotImplementedError(f"backbone '{model_name}': only the timm ViT ids {sorted(vit.TIMM_VITS)} run on the HIP engine so far")
+        self.model = vit.create_model(model_name, pretrained=False, num_classes=0, global_pool="", img_size=image_size, device=dev, backend=self.be)
+        tokens, channels = self.model.engine.tokens, self.model.spec.dim
+        self.output_layer = nn.Sequential(nn.LayerNorm(channels), nn.Flatten(1), nn.Linear(tokens * channels, feat_dim), nn.BatchNorm1d(feat_dim)).to(dev)
+
+    def forward(self, x):
+        tok = self.model(x)
+        ol = self.output_layer
+        return _NeckFn.apply(tok, ol[0].weight, ol[0].bias, ol[2].weight, ol[2].bias, ol[3].weight, ol[3].bias, self)
+
+
+class BackboneFactory:
+    """models/faceX/backbone/backbone_def.py:5-26 — config {'timm-<id>': {pretrained, image_size, feat_dim}}"""
+
+    def __init__(self, backbone_conf: dict, backend=None, device=None):
+        (self.name, self.param), = backbone_conf.items()
+        self.kw = dict(backend=backend, device=device)
+
+    def get_backbone(self):
+        assert self.name.startswith("timm-"), "backbone id must look like timm-<timm model id>"
+        model_id = self.name[5:].split(".")[0]          # 'timm-vit_base_patch16_224.augreg2_in21k_ft_in1k' -> architecture id
+        return TimmWrapper(model_id, feat_dim=self.param["feat_dim"], image_size=self.param["image_size"],
+                           pretrained=False, **self.kw)
+
+
+class FaceTrainingModel(nn.Module):
+    """models/faceX/face_model.py:28-54: `forward(data, label) = head(backbone(data), label)`"""
+
+    def __init__(self, model_cfg: dict, backend=None, device=None):
+        super().__init__()
+        backbone = BackboneFactory(model_cfg["backbone"], backend=backend, device=device).get_backbone()
+        (htype, hconf), = model_cfg["head"].items()
+        head = heads.HeadFactory(htype, hconf, backend=backend, device=device).get_head()
+        self.trainingwrapper = nn.ModuleDict({"backbone": backbone, "head": head})
+
+    def forward(self, data, label):
+        feat = self.trainingwrapper["backbone"](data)
+        return self.trainingwrapper["head"](feat, label)
+
+
+class FaceTrainingWrapper:
+    """models/faceX/face_model.py:10-26"""
+
+    def __init__(self, model_cfg, logger=None, backend=None, device=None):
+        self.model = FaceTrainingModel(model_cfg, backend=backend, device=device)
+        self.logger = logger
+
+    def reset_parameters(self):   # defined but never called by the reference; kept for surface parity
+        for m in self.model.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, mean=0, std=0.02)
+                nn.init.constant_(m.bias, 0)
+
+
+class FeatureExtractor:
+    """models/faceX/face_model.py:88-143 — eval forward -> F.normalize -> host numpy (order = loader order)"""
+
+    def __init__(self, model):
+        self.model = model
+
+    def extract_cbir(self, dataloader, device) -> np.ndarray:
+        from . import cbir
+        model = self.model
+        model.eval()
+        feats = []
+        with torch.no_grad():
+            for tensors in dataloader:
+                tensors = tensors.to(device)
+                feature = model(tensors)
+                feature = cbir.l2_normalize(feature.contiguous(), backend=getattr(model, "be", None))
+                feats.append(feature.cpu().numpy())
+        return np.concatenate(feats, axis=0)
+
+
+def get_model(model_cfg: dict, logger=None, rank: int = 0, backend=None, device=None):
+    """models/smartmodel.py:5-10 — task 'face' | 'cbir' -> FaceTrainingWrapper, 'classification' -> VisionWrapper."""
+    assert "task" in model_cfg, "Task is not specified"
+    task = model_cfg["task"]
+    if device is None and (backend is None or backend.device_only):
+        device = f"cuda:{rank}"
+    if task in ("face", "cbir"):
+        return FaceTrainingWrapper(model_cfg, logger, backend=backend, device=device)
+    if task == "classification":
+        return VisionWrapper(model_cfg, logger, rank, backend=backend, device=device)
+    raise ValueError(f"unknown task {task}")
+
+
+class VisionWrapper:
+    """models/classifier/classify_model.py:10-68 — `name: timm-<id>`, `.model`, `.reset_parameters()`, `.load_weight()`"""
+
+    def __init__(self, model_cfg: dict, logger=None, rank: int = 0, backend=None, device=None):
+        self.logger = logger
+        name = model_cfg["name"]
+        assert name.startswith("timm-"), "classifier id must look like timm-<timm model id>"
+        kwargs = model_cfg.get("kwargs") or {}
+        self.model = vit.create_model(name[5:].split(".")[0], pretrained=False, num_classes=model_cfg["num_classes"],
+                                      img_size=model_cfg.get("image_size"), device=device, backend=backend, **kwargs)
+        if not model_cfg.get("pretrained", False):
+            self.reset_parameters()
+
+    def reset_parameters(self):
+        self.model.reset_parameters()
+
+    def load_weight(self, load_path: str, ema: bool = False, device="cpu"):
+        ckpt = torch.load(load_path, map_location=device, weights_only=False)
+        sd = ckpt["ema"].state_dict() if ema and hasattr(ckpt.get("ema"), "state_dict") else ckpt.get("ema" if ema else "model", ckpt)
+        self.model.load_state_dict(sd)

@@ -78,7 +78,8 @@ class VitEngine:
         self.grads = torch.zeros(self.n_floats, dtype=torch.float32, device=dev)
         self.wb16 = torch.zeros(self.n_floats, dtype=torch.bfloat16, device=dev)
         self.wt16 = torch.zeros(self.n_transposed, dtype=torch.bfloat16, device=dev)
-        self.cp = (spec.num_classes + 7) // 8 * 8
+        self.cp = (spec.num_classes + 7) // 8 * 8          # 0 in feature mode (num_classes == 0)
+        self.tokens = (spec.img_size // spec.patch_size) ** 2 + 1
         self._ws: Optional[torch.Tensor] = None
         self._ws_batch = -1
         self._logits: Optional[torch.Tensor] = None
@@ -103,7 +104,8 @@ class VitEngine:
             self._ws = None
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
             self._ws_batch = batch
-            self._logits = torch.empty((batch, self.cp), dtype=torch.float32, device=self.device)
+            shape = (batch, self.cp) if self.cp else (batch * self.tokens, self.spec.dim)   # logits | final-normed tokens
+            self._logits = torch.empty(shape, dtype=torch.float32, device=self.device)
         return self._ws
 
     def refresh_weights(self, skip_wb16: bool = False) -> None:
@@ -136,9 +138,14 @@ class VitEngine:
         return self._logits
 
     def backward(self, dlogits_bf16: torch.Tensor, on_ready: Optional[Callable[[int, int], None]] = None) -> torch.Tensor:
-        """dlogits bf16 [B, Cp] -> self.grads (flat fp32, overwritten).  Needs the workspace of the matching forward."""
-        B = dlogits_bf16.shape[0]
-        assert dlogits_bf16.dtype == torch.bfloat16 and dlogits_bf16.shape[1] == self.cp and B == self._ws_batch
+        """dlogits bf16 [B, Cp] (feature mode: d tokens f32 [B*N, D]) -> self.grads (flat fp32, overwritten).  Needs the
+        workspace of the matching forward."""
+        if self.cp:
+            B = dlogits_bf16.shape[0]
+            assert dlogits_bf16.dtype == torch.bfloat16 and dlogits_bf16.shape[1] == self.cp and B == self._ws_batch
+        else:
+            B = dlogits_bf16.shape[0] // self.tokens
+            assert dlogits_bf16.dtype == torch.float32 and dlogits_bf16.shape == (B * self.tokens, self.spec.dim) and B == self._ws_batch
         cfg = self._cfg(B)
         be = self.be
         cb = _abi.GRAD_READY_FN(lambda user, off, n: on_ready(off, n)) if on_ready is not None else _abi.GRAD_READY_FN(0)
@@ -159,6 +166,8 @@ class _VitFunction(torch.autograd.Function):
         logits = eng.forward(x)
         ctx.module = module
         ctx.batch = x.shape[0]
+        if eng.cp == 0:   # feature mode: [B, N, D] final-normed tokens (timm num_classes=0, global_pool='')
+            return logits.view(x.shape[0], eng.tokens, eng.spec.dim).clone()
         return logits[:, :eng.spec.num_classes].clone()
 
     @staticmethod
@@ -166,6 +175,10 @@ class _VitFunction(torch.autograd.Function):
         module = ctx.module
         eng = module.engine
         be = eng.be
+        if eng.cp == 0:
+            g = eng.backward(dlogits.contiguous().view(-1, eng.spec.dim))
+            grads = tuple(g[off:off + numel].view(shape) for (_, off, numel, shape) in eng.entries)
+            return (None, None) + grads
         B, Cn = dlogits.shape
         # bf16 + zero-padded columns for the head GEMMs: one cast kernel on a padded staging buffer
         stage = torch.zeros((B, eng.cp), dtype=torch.float32, device=dlogits.device)
@@ -177,44 +190,38 @@ class _VitFunction(torch.autograd.Function):
         return (None, None) + grads
 
 
+class _Holder(nn.Module):
+    """empty container mirroring one level of timm's module tree (patch_embed, blocks.3.attn, ...); owns Parameters only"""
+
+
 class VisionTransformer(nn.Module):
-    """Drop-in for the object `timm.create_model('vit_*', pretrained=False, num_classes=C)` hands the reference."""
+    """Drop-in for the object `timm.create_model('vit_*', pretrained=False, num_classes=C)` hands the reference.
+
+    The module tree mirrors timm's (patch_embed.proj, blocks.i.{norm1,attn.qkv,attn.proj,norm2,mlp.fc1,mlp.fc2}, norm, head) with
+    parameter-only holder modules, so named_parameters()/state_dict()/load_state_dict() carry timm's key names at any nesting
+    depth; every Parameter is a view into the engine's flat fp32 buffer."""
 
     def __init__(self, spec: VitSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None):
         super().__init__()
         self.spec = spec
         self.engine = VitEngine(spec, device=device, backend=backend)
         self.num_classes = spec.num_classes
-        self._names = []
+        self._plist = []
         for name, off, numel, shape in self.engine.entries:
             p = nn.Parameter(self.engine.params[off:off + numel].view(shape))
-            pname = name.replace(".", "__")
-            self.register_parameter(pname, p)
-            self._names.append((name, pname))
+            parts = name.split(".")
+            m = self
+            for part in parts[:-1]:
+                if part not in m._modules:
+                    m.add_module(part, _Holder())
+                m = m._modules[part]
+            m.register_parameter(parts[-1], p)
+            self._plist.append((name, p))
         self.reset_parameters(seed)
 
-    # timm names in state_dict()/named_parameters() ---------------------------------------------------
-    def _named_members(self, get_members_fn, prefix='', recurse=True, remove_duplicate=True):
-        for n, v in super()._named_members(get_members_fn, prefix, recurse, remove_duplicate):
-            yield n.replace("__", "."), v
-
-    def state_dict(self, *args, destination=None, prefix='', keep_vars=False):
-        out = {} if destination is None else destination
-        for name, pname in self._names:
-            p = getattr(self, pname)
-            out[prefix + name] = p if keep_vars else p.detach()
-        return out
-
-    def load_state_dict(self, state_dict, strict: bool = True):
-        missing = [n for n, _ in self._names if n not in state_dict]
-        unexpected = [k for k in state_dict if k not in dict(self._names)]
-        if strict and (missing or unexpected):
-            raise RuntimeError(f"load_state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
-        with torch.no_grad():
-            for name, pname in self._names:
-                if name in state_dict:
-                    getattr(self, pname).copy_(state_dict[name].to(self.engine.device).reshape(getattr(self, pname).shape))
-        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+    @property
+    def _names(self):   # (timm name, Parameter) pairs in flat-buffer order
+        return self._plist
 
     def reset_parameters(self, seed: Optional[int] = None) -> None:
         """timm defaults + the reference's override (classify_model.py:70-81): N(0,.02) Conv/Linear weights, zero Linear
@@ -226,8 +233,7 @@ class VisionTransformer(nn.Module):
             gen.seed()
         s = self.spec
         with torch.no_grad():
-            for name, pname in self._names:
-                p = getattr(self, pname)
+            for name, p in self._plist:
                 if name == "pos_embed":
                     v = torch.empty(p.shape).normal_(0, 0.02, generator=gen).clamp_(-2.0, 2.0)
                 elif name == "cls_token":
@@ -247,8 +253,7 @@ class VisionTransformer(nn.Module):
     def _sync_flat(self) -> None:
         eng = self.engine
         base = eng.params.data_ptr()
-        for (name, off, numel, shape), (_, pname) in zip(eng.entries, self._names):
-            p = getattr(self, pname)
+        for (name, off, numel, shape), (_, p) in zip(eng.entries, self._plist):
             if p.data_ptr() != base + off * 4:
                 with torch.no_grad():
                     eng.params[off:off + numel].view(shape).copy_(p.detach().to(eng.device))
@@ -266,18 +271,20 @@ class VisionTransformer(nn.Module):
             for attr in ("params", "grads", "wb16", "wt16"):
                 setattr(eng, attr, getattr(eng, attr).to(probe.device))
             eng._ws, eng._ws_batch, eng._weights_version = None, -1, None
-            for (name, off, numel, shape), (_, pname) in zip(eng.entries, self._names):
-                getattr(self, pname).data = eng.params[off:off + numel].view(shape)
+            for (name, off, numel, shape), (_, p) in zip(eng.entries, self._plist):
+                p.data = eng.params[off:off + numel].view(shape)
         return self
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        params = [getattr(self, pname) for _, pname in self._names]
-        return _VitFunction.apply(x, self, *params)
+        return _VitFunction.apply(x, self, *[p for _, p in self._plist])
 
 
 def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, device=None, backend=None, img_size=None,
-                 **kwargs) -> VisionTransformer:
-    """`timm.create_model(name, pretrained=..., num_classes=...)` for the ids in TIMM_VITS."""
+                 global_pool: str = "token", **kwargs) -> VisionTransformer:
+    """`timm.create_model(name, pretrained=..., num_classes=...)` for the ids in TIMM_VITS.  `num_classes=0, global_pool=''`
+    (what TimmWrapper asks for, timm_wrapper.py:16-21) gives the feature model: forward -> final-normed tokens [B, N, D]."""
+    if num_classes == 0 and global_pool != "":
+        raise NotImplementedError("num_classes=0 is supported with global_pool='' (token features) only")
     if pretrained:
         raise RuntimeError("pretrained weights need network access; load a checkpoint with load_state_dict instead")
     return VisionTransformer(spec_from_timm_name(name, num_classes, img_size), device=device, backend=backend)
