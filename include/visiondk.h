@@ -175,6 +175,16 @@ int vdk_sumsq_f32(const float* g, int64_t n, float* out, void* ws, size_t ws_byt
 int vdk_sgd_step(float* params, const float* grads, float* momentum_buf, float* ema, void* params_bf16, int64_t n, float lr,
                  float momentum, float weight_decay, float grad_scale, const float* normsq, float max_norm, float ema_decay,
                  int32_t first_step, void* stream);
+/* SAM.first_step (engine/optimizer.py:43-55,77-87): normsq_out = sum((|p| or 1) * g)^2; old_params = params;
+ * params += (p^2 or 1) * g * rho / (sqrt(normsq) + 1e-12).  second_step = copy old_params back + vdk_sgd_step on the new grads.
+ * ws: vdk_sumsq_workspace_bytes(). */
+int vdk_sam_first_step(float* params, const float* grads, float* old_params, int64_t n, float rho, int32_t adaptive, float* normsq_out, void* ws,
+                       size_t ws_bytes, void* stream);
+/* OHEMImageSampler.sample (structure/sampler.py:11-31): mask u8 [B]; prob_ws f32 [B] scratch */
+int vdk_ohem_mask(const float* logits, int64_t ldl, int32_t B, int32_t C, const int64_t* labels, int32_t min_kept, float thresh, int64_t ignore_index,
+                  float* prob_ws, uint8_t* mask, void* stream);
+/* top-k per logits row, descending, ties -> lower index (engine/procedure/evaluation.py:106 `argsort(1, descending=True)[:, :k]`) */
+int vdk_topk_rows(const float* x, int64_t ld, int32_t B, int32_t C, int32_t k, int64_t* idx, float* values, void* stream);
 /* mixup_data (engine/procedure/train.py:24-32): out[b] = lam*x[b] + (1-lam)*x[perm[b]] */
 int vdk_mixup(const float* x, const int64_t* perm, float lam, int32_t B, int64_t per_sample, float* out, void* stream);
 

@@ -148,6 +148,37 @@ def train_step_reference(model: nn.Module, x, y, *, lr, momentum, weight_decay, 
     return logits.detach(), loss.detach(), grads, total_norm, momentum_bufs
 
 
+def train_step_reference_sam(model: nn.Module, x, y, *, lr, momentum, weight_decay, label_smoothing, rho=0.05, momentum_bufs=None):
+    """Trainer.update_sam (engine/procedure/train.py:150-175) with engine/optimizer.py's SAM(adaptive=True) over SGD: first
+    fwd/bwd -> e(w) = w^2 * g * rho / (|| |w| * g || + 1e-12) -> w += e(w) -> second fwd/bwd -> w restored -> SGD step (no clip)."""
+    params = list(model.parameters())
+    for p in params:
+        p.grad = None
+    loss = F.cross_entropy(model(x), y, label_smoothing=label_smoothing)
+    loss.backward()
+    with torch.no_grad():
+        gnorm = torch.norm(torch.stack([(p.abs() * p.grad).norm(p=2) for p in params]), p=2)
+        scale = rho / (gnorm + 1e-12)
+        old = [p.detach().clone() for p in params]
+        for p in params:
+            p.add_(p.pow(2) * p.grad * scale)
+    for p in params:
+        p.grad = None
+    F.cross_entropy(model(x), y, label_smoothing=label_smoothing).backward()
+    if momentum_bufs is None:
+        momentum_bufs = {}
+    with torch.no_grad():
+        for (n, p), o in zip(model.named_parameters(), old):
+            p.copy_(o)
+            g = p.grad + weight_decay * p
+            if n not in momentum_bufs:
+                momentum_bufs[n] = g.clone()
+            else:
+                momentum_bufs[n].mul_(momentum).add_(g)
+            p.add_(momentum_bufs[n], alpha=-lr)
+    return loss.detach(), momentum_bufs
+
+
 class TimmWrapperRef(nn.Module):
     """Restatement of the reference's TimmWrapper for a transformer backbone (models/faceX/backbone/timm_wrapper.py:16-21,39-54):
     `timm.create_model(name, num_classes=0, global_pool='')` -> forward = final-normed tokens [B, N, C]; neck =

@@ -87,3 +87,17 @@ def test_cbir_oracle_and_kernel_vs_float64_fixture(be, dev):
     s2, i2 = index.search(q[:3], 1024)
     assert (i2[:, 1000:] == -1).all() and (s2[:, 1000:] == np.float32(-3.4028234663852886e38)).all()
     assert sorted(i2[0, :1000].tolist()) == list(range(1000))
+
+
+def test_sam_two_step_vs_reference_optimizer(be, dev):
+    """engine/optimizer.py SAM(adaptive=True, rho=0.05) first_step / second_step over SGD(lr .01, mom .937, wd 5e-4)"""
+    z = np.load(G / "sam.npz")
+    p = torch.from_numpy(z["p_init"]).clone().to(dev)
+    g1 = torch.from_numpy(z["g1"]).to(dev); g2 = torch.from_numpy(z["g2"]).to(dev)
+    old = torch.empty_like(p); m = torch.zeros_like(p)
+    ops.sam_first_step(p, g1, old, rho=0.05, adaptive=True, backend=be)
+    assert _rel(p, z["p_perturbed"]) < 1e-6
+    assert torch.equal(old.cpu(), torch.from_numpy(z["p_init"]))
+    p.copy_(old)                                   # second_step: back to w, then the base optimizer steps on the new grads
+    ops.sgd_step(p, g2, m, lr=0.01, momentum=0.937, weight_decay=5e-4, normsq=None, first_step=True, backend=be)
+    assert _rel(p, z["p_final"]) < 1e-6

@@ -130,3 +130,36 @@ def test_mixup(be, dev):
     perm = torch.tensor([2, 0, 3, 1]).to(dev)
     out = ops.mixup(x, perm, 0.3, backend=be)
     assert _rel(out, 0.3 * x + 0.7 * x[perm]) < 1e-6
+
+
+def test_ohem_mask_matches_reference_sampler(be, dev):
+    import importlib.util
+    from pathlib import Path
+    ref_path = Path("/root/reference/structure/sampler.py")
+    torch.manual_seed(4)
+    logits = torch.randn(37, 10) * 2; labels = torch.randint(0, 10, (37,)); labels[5] = 255
+    for min_kept, thresh in [(8, 0.2), (100, 0.05), (0, 0.5)]:
+        got = ops.ohem_mask(logits.to(dev), labels.to(dev), min_kept, thresh, backend=be).cpu()
+        # restatement of OHEMImageSampler.sample (structure/sampler.py:11-31)
+        prob = torch.softmax(logits, 1); v1 = labels != 255
+        tp = prob[v1].gather(1, labels[v1].unsqueeze(1)).squeeze(1)
+        sp, si = tp.sort()
+        thr = max(sp[min(min_kept, sp.numel() - 1)].item(), thresh)
+        v2 = torch.zeros_like(labels, dtype=torch.bool)
+        v2[torch.nonzero(v1).squeeze(1)[si[sp < thr]]] = True
+        exp = v1 & v2
+        if ref_path.exists():   # in the build container also run the reference's own class
+            spec = importlib.util.spec_from_file_location("ref_sampler", ref_path); mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+            if not (labels == 255).any():
+                exp = mod.OHEMImageSampler(min_kept, thresh).sample(logits, labels)
+        assert torch.equal(got, exp), (min_kept, thresh)
+
+
+def test_topk_rows(be, dev):
+    torch.manual_seed(5)
+    x = torch.randn(9, 1000); x[2, 7] = x[2, 3] = 9.0      # tie -> lower index first
+    val, idx = ops.topk_rows(x.to(dev), 5, backend=be)
+    rv, ri = torch.topk(x, 5, dim=1)
+    assert torch.equal(val.cpu(), rv)
+    assert idx[2, 0].item() == 3 and idx[2, 1].item() == 7
+    assert torch.equal(idx.cpu()[[0, 1, 3, 4, 5, 6, 7, 8]], ri[[0, 1, 3, 4, 5, 6, 7, 8]])

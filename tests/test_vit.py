@@ -128,3 +128,21 @@ def test_forward_backward_tn_wgrad_path(be, dev):
     for (n, p), (nr, pr) in zip(model.named_parameters(), ref.named_parameters()):
         r = _rel(p.grad, pr.grad)
         assert r < 6e-2, (n, r)
+
+
+def test_fused_sam_step_vs_reference_update_sam(be, dev):
+    from oracle.vit_ref import train_step_reference_sam
+    ref, model = _pair(be, dev, seed=6)
+    hyp = dict(lr=0.01, momentum=0.937, weight_decay=5e-4)
+    step = vit.FusedTrainStep(model, label_smoothing=0.05, ema=False, sam=True, sam_rho=0.05, **hyp)
+    init_sd = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    bufs = None
+    torch.manual_seed(12)
+    for it in range(2):
+        x = torch.randn(4, 3, 32, 32); y = torch.randint(0, 10, (4,))
+        loss_ref, bufs = train_step_reference_sam(ref, x, y, label_smoothing=0.05, rho=0.05, momentum_bufs=bufs, **hyp)
+        step.step(x.to(dev), y.to(dev))
+        assert abs(step.loss_value() - loss_ref.item()) < 1e-2 * abs(loss_ref.item())
+    sd = model.state_dict()
+    for n, p in ref.named_parameters():
+        assert _rel(sd[n].cpu() - init_sd[n], p.detach() - init_sd[n]) < 8e-2, n

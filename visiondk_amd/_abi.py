@@ -78,6 +78,9 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_sumsq_f32": (C.c_int, [P, I64, P, P, SZ, P]),
     "vdk_sgd_step": (C.c_int, [P, P, P, P, P, I64, F32, F32, F32, F32, P, F32, F32, I32, P]),
     "vdk_mixup": (C.c_int, [P, P, F32, I32, I64, P, P]),
+    "vdk_sam_first_step": (C.c_int, [P, P, P, I64, F32, I32, P, P, SZ, P]),
+    "vdk_ohem_mask": (C.c_int, [P, I64, I32, I32, P, I32, F32, I64, P, P, P]),
+    "vdk_topk_rows": (C.c_int, [P, I64, I32, I32, I32, P, P, P]),
     # margin-softmax heads
     "vdk_colnorm_fwd": (C.c_int, [P, I64, I32, I32, I32, F32, P, P, I64, P]),
     "vdk_colnorm_bwd": (C.c_int, [P, I64, P, P, I64, I32, I32, P, I64, P]),

@@ -167,6 +167,95 @@ __global__ __launch_bounds__(256) void mixup_kernel(const float* __restrict__ x,
   *(f32x4*)(out + i * 4) = a * lam + c * (1.0f - lam);
 }
 
+
+// ---- SAM (engine/optimizer.py:29-87): grad norm of (|p| * g) [adaptive] or g, then the climb p += (p^2 | 1) * g * rho / (norm + 1e-12)
+__global__ __launch_bounds__(256) void sumsq_prod_partial_kernel(const float* __restrict__ p, const float* __restrict__ g, long n, int adaptive,
+                                                                 float* __restrict__ partial) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v = adaptive ? fabsf(p[i]) * g[i] : g[i];
+    s = fmaf(v, v, s);
+  }
+  s = block_sum<4>(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sam_perturb_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ old_p, long n,
+                                                          float rho, int adaptive, const float* __restrict__ normsq) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float scale = rho / (sqrtf(normsq[0]) + 1e-12f);
+  const float w = p[i];
+  old_p[i] = w;
+  p[i] = w + (adaptive ? w * w : 1.0f) * g[i] * scale;
+}
+
+// ---- OHEM (structure/sampler.py:11-31): keep the samples whose target probability is below
+// max(sorted_prob[min(min_kept, n-1)], thresh).  Stage 1: target probability per row; stage 2: one workgroup ranks them.
+__global__ __launch_bounds__(256) void target_prob_kernel(const float* __restrict__ logits, long ldl, int C, const long long* __restrict__ y,
+                                                          long long ignore_index, float* __restrict__ prob) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* x = logits + (long)row * ldl;
+  float mx = -3.0e38f;
+  for (int c = tid; c < C; c += 256) mx = fmaxf(mx, x[c]);
+  mx = block_max<4>(mx, red);
+  float se = 0.f;
+  for (int c = tid; c < C; c += 256) se += expf(x[c] - mx);
+  se = block_sum<4>(se, red);
+  if (tid == 0) {
+    const long long t = y[row];
+    prob[row] = (t == ignore_index || t < 0 || t >= C) ? __uint_as_float(0x7f800000u) : expf(x[t] - mx) / se;   // +inf = ignored
+  }
+}
+__global__ __launch_bounds__(256) void ohem_mask_kernel(const float* __restrict__ prob, int B, int min_kept, float thresh, unsigned char* __restrict__ mask) {
+  __shared__ float s_thr;
+  __shared__ int s_valid;
+  if (threadIdx.x == 0) { s_valid = 0; s_thr = 0.f; }
+  __syncthreads();
+  int cnt = 0;
+  for (int i = threadIdx.x; i < B; i += 256) cnt += (prob[i] < __uint_as_float(0x7f800000u)) ? 1 : 0;
+  atomicAdd(&s_valid, cnt);
+  __syncthreads();
+  const int nv = s_valid;
+  if (nv == 0) { for (int i = threadIdx.x; i < B; i += 256) mask[i] = 0; return; }
+  const int kth = min_kept < nv - 1 ? min_kept : nv - 1;
+  for (int i = threadIdx.x; i < B; i += 256) {   // the element with exactly `kth` elements ordered before it is sort_prob[kth]
+    const float pi = prob[i];
+    if (!(pi < __uint_as_float(0x7f800000u))) continue;
+    int rank = 0;
+    for (int j = 0; j < B; ++j) { const float pj = prob[j]; rank += (pj < pi || (pj == pi && j < i)) ? 1 : 0; }
+    if (rank == kth) s_thr = pi;
+  }
+  __syncthreads();
+  const float threshold = fmaxf(s_thr, thresh);
+  for (int i = threadIdx.x; i < B; i += 256) mask[i] = (prob[i] < threshold) ? 1 : 0;
+}
+
+// ---- K14: top-k of each logits row, descending, ties -> lower index (engine/procedure/evaluation.py:106 uses a full argsort)
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ x, long ld, int B, int C, int k, long long* __restrict__ idx,
+                                                        float* __restrict__ val) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B) return;
+  const float* xr = x + (long)row * ld;
+  unsigned long long last = ~0ull;   // key of the previously selected element; keys are unique (value, ~index)
+  for (int j = 0; j < k; ++j) {
+    unsigned long long best = 0ull;
+    for (int c = lane; c < C; c += 64) {
+      const unsigned long long key = ((unsigned long long)f2ord(xr[c]) << 32) | (unsigned)(0x7fffffff - c);
+      if (key < last && key > best) best = key;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { unsigned long long o = __shfl_xor(best, m); best = o > best ? o : best; }
+    last = best;
+    if (lane == 0) {
+      const int c = 0x7fffffff - (int)(unsigned)(best & 0xffffffffu);
+      idx[(long)row * k + j] = (j < C) ? c : -1;
+      if (val) val[(long)row * k + j] = (j < C) ? ord2f((unsigned)(best >> 32)) : -3.4028234663852886e38f;
+    }
+  }
+}
+
 extern "C" {
 
 int vdk_patchify_bf16(const float* x, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t patch, void* out, int32_t Kp,
@@ -231,6 +320,38 @@ int vdk_sgd_step(float* params, const float* grads, float* momentum_buf, float* 
   long n4 = (n + 3) / 4;
   hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return vdk_check_launch("vdk_sgd_step");
+}
+
+// SAM.first_step: normsq_out[0] = sum ((|p| | 1) * g)^2, then p_old = p; p += (p^2 | 1) * g * rho / (sqrt(normsq) + 1e-12)
+int vdk_sam_first_step(float* params, const float* grads, float* old_params, int64_t n, float rho, int32_t adaptive, float* normsq_out, void* ws,
+                       size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!params || !grads || !old_params || !normsq_out || n <= 0) return vdk_fail(VDK_EINVAL, "vdk_sam_first_step: bad argument");
+  if (!ws || ws_bytes < SUMSQ_BLOCKS * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_sam_first_step: workspace too small");
+  int nb = (int)((n + 255) / 256); if (nb > SUMSQ_BLOCKS) nb = SUMSQ_BLOCKS;
+  hipLaunchKernelGGL(sumsq_prod_partial_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)params, grads, (long)n, (int)adaptive, (float*)ws);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, nb, normsq_out);
+  hipLaunchKernelGGL(sam_perturb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, params, grads, old_params, (long)n, rho, (int)adaptive,
+                     (const float*)normsq_out);
+  return vdk_check_launch("vdk_sam_first_step");
+}
+
+// OHEMImageSampler.sample: mask[b] = 1 for the hard examples to keep.  prob_ws: f32 [B] scratch.
+int vdk_ohem_mask(const float* logits, int64_t ldl, int32_t B, int32_t C, const int64_t* labels, int32_t min_kept, float thresh, int64_t ignore_index,
+                  float* prob_ws, uint8_t* mask, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!logits || !labels || !prob_ws || !mask || B <= 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_ohem_mask: bad argument");
+  hipLaunchKernelGGL(target_prob_kernel, dim3((unsigned)B), dim3(256), 0, stream, logits, (long)ldl, (int)C, (const long long*)labels, (long long)ignore_index,
+                     prob_ws);
+  hipLaunchKernelGGL(ohem_mask_kernel, dim3(1), dim3(256), 0, stream, (const float*)prob_ws, (int)B, (int)min_kept, thresh, (unsigned char*)mask);
+  return vdk_check_launch("vdk_ohem_mask");
+}
+
+int vdk_topk_rows(const float* x, int64_t ld, int32_t B, int32_t C, int32_t k, int64_t* idx, float* values, void* stream) {
+  if (!x || !idx || B <= 0 || C <= 0 || k <= 0 || k > 64) return vdk_fail(VDK_EINVAL, "vdk_topk_rows: bad argument (1 <= k <= 64)");
+  hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ld, (int)B, (int)C, (int)k, (long long*)idx,
+                     values);
+  return vdk_check_launch("vdk_topk_rows");
 }
 
 int vdk_mixup(const float* x, const int64_t* perm, float lam, int32_t B, int64_t per_sample, float* out, void* stream) {

@@ -238,3 +238,31 @@ def mixup(x: torch.Tensor, perm: torch.Tensor, lam: float, backend=None) -> torc
     out = torch.empty_like(x)
     be.check(be.lib.vdk_mixup(be.ptr(x), be.ptr(perm), lam, x.shape[0], x[0].numel(), be.ptr(out), be.stream()), "vdk_mixup")
     return out
+
+
+def sam_first_step(p, g, old_p, rho: float = 0.05, adaptive: bool = True, backend=None) -> torch.Tensor:
+    be = _be(backend)
+    nsq = torch.empty(1, dtype=torch.float32, device=p.device)
+    ws, n = _ws(be, be.lib.vdk_sumsq_workspace_bytes, device=p.device)
+    be.check(be.lib.vdk_sam_first_step(be.ptr(p), be.ptr(g), be.ptr(old_p), p.numel(), rho, int(adaptive), be.ptr(nsq), be.ptr(ws), n, be.stream()),
+             "vdk_sam_first_step")
+    return nsq
+
+
+def ohem_mask(logits, labels, min_kept: int, thresh: float, ignore_index: int = 255, backend=None) -> torch.Tensor:
+    be = _be(backend)
+    B, C_ = logits.shape
+    prob = torch.empty(B, dtype=torch.float32, device=logits.device)
+    mask = torch.empty(B, dtype=torch.uint8, device=logits.device)
+    be.check(be.lib.vdk_ohem_mask(be.ptr(logits), C_, B, C_, be.ptr(labels), min_kept, thresh, ignore_index, be.ptr(prob), be.ptr(mask), be.stream()),
+             "vdk_ohem_mask")
+    return mask.bool()
+
+
+def topk_rows(x, k: int, backend=None):
+    be = _be(backend)
+    B, C_ = x.shape
+    idx = torch.empty((B, k), dtype=torch.int64, device=x.device)
+    val = torch.empty((B, k), dtype=torch.float32, device=x.device)
+    be.check(be.lib.vdk_topk_rows(be.ptr(x), C_, B, C_, k, be.ptr(idx), be.ptr(val), be.stream()), "vdk_topk_rows")
+    return val, idx

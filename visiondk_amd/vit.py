@@ -300,7 +300,8 @@ class FusedTrainStep:
     """
 
     def __init__(self, model: VisionTransformer, lr: float, momentum: float = 0.937, weight_decay: float = 5e-4,
-                 label_smoothing: float = 0.0, max_norm: float = 10.0, ema: bool = True, comm=None):
+                 label_smoothing: float = 0.0, max_norm: float = 10.0, ema: bool = True, comm=None, sam: bool = False,
+                 sam_rho: float = 0.05, sam_adaptive: bool = True):
         self.model = model
         self.eng = model.engine
         self.be = self.eng.be
@@ -311,6 +312,9 @@ class FusedTrainStep:
         self.ema = self.eng.params.clone() if ema else None
         self.updates = 0
         self.comm = comm
+        # Trainer.update_sam (train.py:150-175) over engine/optimizer.py's SAM(base SGD): 2 fwd/bwd, first un-synchronised, no clipping
+        self.sam, self.sam_rho, self.sam_adaptive = sam, sam_rho, sam_adaptive
+        self._old_params = torch.empty_like(self.eng.params) if sam else None
         self._normsq = torch.zeros(1, dtype=torch.float32, device=dev)
         need = C.c_size_t(0)
         self.be.check(self.be.lib.vdk_sumsq_workspace_bytes(C.byref(need)), "vdk_sumsq_workspace_bytes")
@@ -319,28 +323,48 @@ class FusedTrainStep:
         self._dl: Optional[torch.Tensor] = None
         self.param_groups = [{"lr": lr, "momentum": momentum, "weight_decay": weight_decay}]  # Trainer reads param_groups[0]['lr']
 
-    def step(self, x: torch.Tensor, y: torch.Tensor, y_b: Optional[torch.Tensor] = None, lam: float = 1.0) -> torch.Tensor:
+    def _fwd_loss_bwd(self, x, y, y_b, lam, sync: bool) -> None:
         eng, be = self.eng, self.be
-        model = self.model
-        model._sync_flat()
         B = x.shape[0]
         logits = eng.forward(x)
         if self._loss_rows is None or self._loss_rows.shape[0] != B:
             self._loss_rows = torch.empty(B, dtype=torch.float32, device=eng.device)
             self._dl = torch.empty((B, eng.cp), dtype=torch.bfloat16, device=eng.device)
-        world = self.comm.world_size if self.comm is not None else 1
         be.check(be.lib.vdk_softmax_ce(be.ptr(logits), eng.cp, B, eng.spec.num_classes, be.ptr(y), be.ptr(y_b), lam,
                                        self.label_smoothing, 1.0 / B, be.ptr(self._loss_rows), be.ptr(self._dl), eng.cp, None, 0,
                                        be.stream()), "vdk_softmax_ce")
-        if self.comm is not None:
+        if self.comm is not None and sync:
             self.comm.begin_step(eng.grads)
             eng.backward(self._dl, on_ready=self.comm.on_grad_ready)
             self.comm.finish_step()
         else:
             eng.backward(self._dl)
+
+    def step(self, x: torch.Tensor, y: torch.Tensor, y_b: Optional[torch.Tensor] = None, lam: float = 1.0) -> torch.Tensor:
+        eng, be = self.eng, self.be
+        self.model._sync_flat()
+        world = self.comm.world_size if self.comm is not None else 1
         lr = self.param_groups[0]["lr"]
         self.updates += 1
         d = 0.9999 * (1 - math.exp(-self.updates / 2000)) if self.ema is not None else 0.0
+        if self.sam:
+            # first forward-backward on w with LOCAL gradients (model.no_sync(), train.py:157-159), then climb to w + e(w)
+            self._fwd_loss_bwd(x, y, y_b, lam, sync=False)
+            loss_first = self._loss_rows.clone()
+            be.check(be.lib.vdk_sam_first_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self._old_params), eng.n_floats, self.sam_rho,
+                                               int(self.sam_adaptive), be.ptr(self._normsq), be.ptr(self._sumsq_ws), self._sumsq_ws.numel(),
+                                               be.stream()), "vdk_sam_first_step")
+            eng.refresh_weights()
+            # second forward-backward at w + e(w) (gradients all-reduced), back to w, base optimizer step (no clipping on this path)
+            self._fwd_loss_bwd(x, y, y_b, lam, sync=True)
+            eng.params.copy_(self._old_params)
+            be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema), be.ptr(eng.wb16),
+                                         eng.n_floats, lr, self.momentum, self.weight_decay, 1.0 / world, None, self.max_norm, d,
+                                         int(self.updates == 1), be.stream()), "vdk_sgd_step")
+            eng.refresh_weights(skip_wb16=True)
+            self._loss_rows.copy_(loss_first)     # update_sam returns the FIRST loss (train.py:175)
+            return self._loss_rows
+        self._fwd_loss_bwd(x, y, y_b, lam, sync=True)
         be.check(be.lib.vdk_sumsq_f32(be.ptr(eng.grads), eng.n_floats, be.ptr(self._normsq), be.ptr(self._sumsq_ws),
                                       self._sumsq_ws.numel(), be.stream()), "vdk_sumsq_f32")
         be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema),
