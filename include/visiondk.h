@@ -151,9 +151,11 @@ int vdk_colsum_bf16(const void* in, int64_t ld, int32_t T, int32_t N, float* out
 int vdk_softmax_ce(const float* logits, int64_t ldl, int32_t B, int32_t C, const int64_t* ya, const int64_t* yb, float lam,
                    float label_smoothing, float grad_scale, float* loss_rows, void* dlogits_bf16, int64_t lddl,
                    float* dlogits_f32, int64_t lddf, void* stream);
-/* nn.BCEWithLogitsLoss — models/losses/loss.py:68-70.  loss_rows[b] = sum_c loss(b,c) (caller divides by B*C). */
+/* nn.BCEWithLogitsLoss — models/losses/loss.py:68-70; focal_gamma > 0: FocalLoss(BCEWithLogits, gamma, alpha), loss.py:27-54,74-76.
+ * loss_rows[b] = sum_c loss(b,c) (caller divides by B*C). */
 int vdk_bce_logits(const float* logits, int64_t ldl, const float* targets, int64_t ldt, int32_t B, int32_t C, float grad_scale,
-                   float* loss_rows, void* dlogits_bf16, int64_t lddl, float* dlogits_f32, int64_t lddf, void* stream);
+                   float focal_gamma, float focal_alpha, float* loss_rows, void* dlogits_bf16, int64_t lddl, float* dlogits_f32, int64_t lddf,
+                   void* stream);
 
 /* PatchEmbed.proj (Conv2d(3, D, p, stride p)) as an im2col-free GEMM operand: out bf16 [B*gh*gw, Kp],
  * column k = c*p*p + ky*p + kx, zero-padded to Kp (Kp % 8 == 0). */

@@ -132,6 +132,26 @@ def main():
     order = np.argsort(-s64, axis=1, kind="stable")[:, :100]
     np.savez(OUT / "cbir_small.npz", gallery=g, queries=q, idx_top100=order.astype(np.int64),
              scores_top100=np.take_along_axis(s64, order, 1))
+    # ---- retrieval metrics: the reference's CBIRMetrics class, exec'd from its own source (engine/cbir/evaluation.py:14-103;
+    #      the module itself cannot be imported: its top-level imports need torchvision / faiss) ------------------------------------
+    src = (REF / "engine/cbir/evaluation.py").read_text().splitlines()
+    ns = {"np": np}
+    from sklearn.metrics import roc_auc_score, ndcg_score
+    ns.update(roc_auc_score=roc_auc_score, ndcg_score=ndcg_score)
+    exec("\n".join(src[13:103]), ns)
+    rng = np.random.default_rng(5)
+    Q, k = 12, 20
+    preds = np.stack([rng.permutation(200)[:k] for _ in range(Q)])
+    labels = [rng.choice(200, size=rng.integers(1, 6), replace=False) for _ in range(Q)]
+    for i in range(Q):   # plant some relevant items among the predictions
+        if i % 3 != 2:
+            preds[i, rng.integers(0, k)] = labels[i][0]
+    scores = np.sort(rng.random((Q, k)))[:, ::-1].copy()
+    m = ns["CBIRMetrics"](cutoffs=[1, 3, 10])
+    sp = [[str(v) for v in row] for row in preds]; sl = [[str(v) for v in row] for row in labels]
+    m.compute_mrr(sp, sl); m.compute_precision(sp, sl); m.compute_recall(sp, sl); m.compute_auc(sp, sl, scores); m.compute_ndcg(sp, sl, scores)
+    np.savez(OUT / "cbir_metrics.npz", preds=preds, scores=scores, labels=np.array([np.pad(l, (0, 6 - len(l)), constant_values=-1) for l in labels]),
+             names=np.array(list(m.metrics.keys())), values=np.array(list(m.metrics.values()), dtype=np.float64))
     print("golden fixtures written to", OUT)
 
 

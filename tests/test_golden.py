@@ -101,3 +101,22 @@ def test_sam_two_step_vs_reference_optimizer(be, dev):
     p.copy_(old)                                   # second_step: back to w, then the base optimizer steps on the new grads
     ops.sgd_step(p, g2, m, lr=0.01, momentum=0.937, weight_decay=5e-4, normsq=None, first_step=True, backend=be)
     assert _rel(p, z["p_final"]) < 1e-6
+
+
+def test_cbir_metrics_vs_reference_class():
+    from visiondk_amd import metrics
+    z = np.load(G / "cbir_metrics.npz")
+    labels = [row[row >= 0] for row in z["labels"]]
+    got = metrics.compute_metrics(z["preds"], z["scores"], labels, cutoffs=(1, 3, 10))
+    exp = dict(zip(z["names"].tolist(), z["values"].tolist()))
+    assert set(got) == set(exp)
+    for k in exp:
+        assert abs(got[k] - exp[k]) < 1e-12, (k, got[k], exp[k])
+
+
+def test_focal_kernel_vs_reference_loss(be, dev):
+    z = np.load(G / "losses.npz")
+    x = torch.from_numpy(z["bce_logits"]).to(dev); t = torch.from_numpy(z["bce_targets"]).to(dev)
+    loss, _, dlf = ops.bce_logits(x, t, grad_scale=1.0 / x.numel(), focal_gamma=1.5, focal_alpha=0.25, backend=be)
+    assert abs(loss.sum().item() / x.numel() - float(z["focal_loss"])) < 1e-6
+    assert _rel(dlf, z["focal_grad"]) < 1e-5

@@ -69,7 +69,7 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_colsum_bf16_workspace_bytes": (C.c_int, [I32, I32, PSZ]),
     "vdk_colsum_bf16": (C.c_int, [P, I64, I32, I32, P, P, SZ, P]),
     "vdk_softmax_ce": (C.c_int, [P, I64, I32, I32, P, P, F32, F32, F32, P, P, I64, P, I64, P]),
-    "vdk_bce_logits": (C.c_int, [P, I64, P, I64, I32, I32, F32, P, P, I64, P, I64, P]),
+    "vdk_bce_logits": (C.c_int, [P, I64, P, I64, I32, I32, F32, F32, F32, P, P, I64, P, I64, P]),
     "vdk_patchify_bf16": (C.c_int, [P, I32, I32, I32, I32, I32, P, I32, P]),
     "vdk_cls_rows": (C.c_int, [P, I64, I32, I32, P, P, P]),
     "vdk_cast_f32_bf16": (C.c_int, [P, P, I64, P]),

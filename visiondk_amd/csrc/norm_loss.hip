@@ -215,20 +215,35 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
   }
 }
 
-// BCE-with-logits (mean over all elements): loss_e = max(x,0) - x*t + log1p(exp(-|x|)); d = (sigmoid(x)-t)*gscale
+// BCE-with-logits: loss_e = max(x,0) - x*t + log1p(exp(-|x|)); d = (sigmoid(x) - t) * gscale.
+// focal_gamma > 0: FocalLoss(BCEWithLogits) of models/losses/loss.py:27-54: loss_e *= alpha_t * (1 - p_t)^gamma with
+// p_t = t*p + (1-t)*(1-p), alpha_t = t*alpha + (1-t)*(1-alpha); the gradient differentiates the modulating factor too.
 __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ logits, long ldl, const float* __restrict__ tgt,
-                                                         long ldt, int C, float gscale, float* __restrict__ loss_rows,
-                                                         bf16_t* __restrict__ dlogits, long lddl, float* __restrict__ dlogits_f32,
-                                                         long lddf) {
+                                                         long ldt, int C, float gscale, float focal_gamma, float focal_alpha,
+                                                         float* __restrict__ loss_rows, bf16_t* __restrict__ dlogits, long lddl,
+                                                         float* __restrict__ dlogits_f32, long lddf) {
   __shared__ float red[4];
   const int row = blockIdx.x, tid = threadIdx.x;
   float s = 0.f;
   for (int c = tid; c < (int)lddl || c < C; c += 256) {
     float g = 0.f;
     if (c < C) {
-      float x = logits[(long)row * ldl + c], t = tgt[(long)row * ldt + c];
-      s += fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
-      g = (1.0f / (1.0f + expf(-x)) - t) * gscale;
+      const float x = logits[(long)row * ldl + c], t = tgt[(long)row * ldt + c];
+      const float bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+      const float p = 1.0f / (1.0f + expf(-x));
+      if (focal_gamma > 0.f) {
+        const float pt = t * p + (1.0f - t) * (1.0f - p);
+        const float at = t * focal_alpha + (1.0f - t) * (1.0f - focal_alpha);
+        const float om = fmaxf(1.0f - pt, 0.f);
+        const float mod = powf(om, focal_gamma);
+        s += bce * at * mod;
+        const float dpt = (2.0f * t - 1.0f) * p * (1.0f - p);
+        const float dmod = om > 0.f ? -focal_gamma * powf(om, focal_gamma - 1.0f) * dpt : 0.f;
+        g = at * ((p - t) * mod + bce * dmod) * gscale;
+      } else {
+        s += bce;
+        g = (p - t) * gscale;
+      }
       if (dlogits_f32) dlogits_f32[(long)row * lddf + c] = g;
     }
     if (dlogits && c < (int)lddl) dlogits[(long)row * lddl + c] = f2bf(g);
@@ -236,7 +251,6 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict
   s = block_sum<4>(s, red);
   if (tid == 0 && loss_rows) loss_rows[row] = s;
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm1d over [B, F] (the TimmWrapper neck's last layer, models/faceX/backbone/timm_wrapper.py:37,46; eps 1e-5,
@@ -395,10 +409,11 @@ int vdk_softmax_ce(const float* logits, int64_t ldl, int32_t B, int32_t C, const
 }
 
 int vdk_bce_logits(const float* logits, int64_t ldl, const float* targets, int64_t ldt, int32_t B, int32_t C, float grad_scale,
-                   float* loss_rows, void* dlogits_bf16, int64_t lddl, float* dlogits_f32, int64_t lddf, void* stream) {
+                   float focal_gamma, float focal_alpha, float* loss_rows, void* dlogits_bf16, int64_t lddl, float* dlogits_f32, int64_t lddf,
+                   void* stream) {
   if (!logits || !targets || B <= 0 || C <= 0 || (dlogits_bf16 && lddl < C)) return vdk_fail(VDK_EINVAL, "vdk_bce_logits: bad argument");
   hipLaunchKernelGGL(bce_logits_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, logits, (long)ldl, targets, (long)ldt,
-                     (int)C, grad_scale, loss_rows, (bf16_t*)dlogits_bf16, (long)(dlogits_bf16 ? lddl : 0), dlogits_f32, (long)lddf);
+                     (int)C, grad_scale, focal_gamma, focal_alpha, loss_rows, (bf16_t*)dlogits_bf16, (long)(dlogits_bf16 ? lddl : 0), dlogits_f32, (long)lddf);
   return vdk_check_launch("vdk_bce_logits");
 }
 

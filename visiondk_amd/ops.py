@@ -177,14 +177,14 @@ def softmax_ce(logits, ya, yb=None, lam: float = 1.0, label_smoothing: float = 0
     return loss, dlb, dlf
 
 
-def bce_logits(logits, targets, grad_scale: float = 1.0, backend=None):
+def bce_logits(logits, targets, grad_scale: float = 1.0, focal_gamma: float = 0.0, focal_alpha: float = 0.25, backend=None):
     be = _be(backend)
     B, C_ = logits.shape
     pad_to = (C_ + 7) // 8 * 8
     loss = torch.empty(B, dtype=torch.float32, device=logits.device)
     dlb = torch.empty((B, pad_to), dtype=torch.bfloat16, device=logits.device)
     dlf = torch.empty((B, C_), dtype=torch.float32, device=logits.device)
-    be.check(be.lib.vdk_bce_logits(be.ptr(logits), C_, be.ptr(targets), C_, B, C_, grad_scale, be.ptr(loss), be.ptr(dlb), pad_to,
+    be.check(be.lib.vdk_bce_logits(be.ptr(logits), C_, be.ptr(targets), C_, B, C_, grad_scale, focal_gamma, focal_alpha, be.ptr(loss), be.ptr(dlb), pad_to,
                                    be.ptr(dlf), C_, be.stream()), "vdk_bce_logits")
     return loss, dlb, dlf
 
