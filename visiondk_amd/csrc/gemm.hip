@@ -409,8 +409,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
         for (int r = 0; r < 16; ++r)
           slab[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + ct * 32 + l31] = acc[half * 2 + rt][ct][r];
     __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-    for (int pass = 0; pass < 8; ++pass) {
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {   // unrolled: the residual / aux / bias loads of all passes are in flight together
       const int row = pass * 8 + (lane >> 3), cc = (lane & 7) * 8;
       const long mi = (long)m0 + wr * 128 + half * 64 + row;
       const int n = n0 + wc * 64 + cc;
