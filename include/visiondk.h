@@ -95,6 +95,9 @@ int vdk_gemm_bf16_nt(const VdkGemmDesc* d, void* ws, size_t ws_bytes, void* stre
 /* tests / A-B benchmarking only: 0 = automatic choice, 1 = 128x128 register-staged kernel, 2 = 256x256 LDS-DMA kernel
  * (the latter still requires K and the split size to be multiples of 64). */
 int vdk_gemm_force_kernel(int32_t which);
+/* profiling aid: when non-NULL, every 256x256 workgroup writes 4 shader-cycle stamps (start, operands landed, main loop done,
+ * stores issued) to buf[4 * workgroup]; NULL (default) disables it */
+int vdk_gemm_debug_stamps(void* device_u64_buffer);
 
 /* live GEMM timing for bench.py's `roofline` (HIP events on the launch stream around every GEMM kernel):
  * begin(max_launches) pre-creates the events; end() synchronises and returns the totals since begin(). */
@@ -216,7 +219,9 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
                     float* logits, void* stream);
 /* dlogits bf16 [B, Cp] -> grads (flat fp32, overwritten).  on_ready: see csrc/vit_engine.hip (DDP bucket hook). */
 int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* params, const void* wb16, const void* wt16, void* ws,
-                     size_t ws_bytes, float* grads, vdk_grad_ready_fn on_ready, void* user, void* stream);
+                     size_t ws_bytes, float* grads, vdk_grad_ready_fn on_ready, void* user, void* stream, void* side_stream);
+/* side_stream (may be NULL = same as stream): a second caller-owned hipStream_t that receives the weight-gradient GEMMs and
+ * bias column sums; ordered against `stream` with events, joined before the call returns control of `stream`. */
 
 
 /* ---- margin-softmax heads of the faceX / CBIR training path (fused with the cross-entropy) ------------------------------

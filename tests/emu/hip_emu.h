@@ -63,6 +63,9 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 typedef void* hipEvent_t;
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+#define hipEventDisableTiming 2
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return 0; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 #define hipMemcpyDeviceToDevice 3
@@ -298,6 +301,7 @@ static inline emu_s16x4 emu_ds_read_tr16_b64(const void* p) {
 }
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu_ds_read_tr16_b64((const void*)(p))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_readcyclecounter() 0ull
 #define __builtin_amdgcn_wave_barrier() emu::wave_barrier()
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))

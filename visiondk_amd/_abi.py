@@ -55,6 +55,7 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_gemm_splitk_workspace_bytes": (C.c_int, [I32, I32, I32, PSZ]),
     "vdk_gemm_bf16_nt": (C.c_int, [C.POINTER(GemmDesc), P, SZ, P]),
     "vdk_gemm_force_kernel": (C.c_int, [I32]),
+    "vdk_gemm_debug_stamps": (C.c_int, [P]),
     "vdk_prof_begin": (C.c_int, [I32]),
     "vdk_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(I64), C.POINTER(C.c_double)]),
     "vdk_transpose_bf16": (C.c_int, [P, I64, I32, I32, P, I64, I32, I32, P, P]),
@@ -95,7 +96,7 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_vit_workspace_bytes": (C.c_int, [C.POINTER(VitConfig), PSZ]),
     "vdk_vit_refresh_weights": (C.c_int, [C.POINTER(VitConfig), P, P, P, I32, P]),
     "vdk_vit_forward": (C.c_int, [C.POINTER(VitConfig), P, P, P, P, SZ, P, P]),
-    "vdk_vit_backward": (C.c_int, [C.POINTER(VitConfig), P, P, P, P, P, SZ, P, P, P, P]),
+    "vdk_vit_backward": (C.c_int, [C.POINTER(VitConfig), P, P, P, P, P, SZ, P, P, P, P, P]),
 }
 
 

@@ -272,7 +272,88 @@ __device__ __forceinline__ s16x8 h_read_frag_tn(const unsigned char* region, int
   return r;
 }
 
-template <bool TN>
+
+// ---- compile-time epilogue variants of the 256x256 kernel ------------------------------------------------------------------
+// E_* flags select what the epilogue does; E_GENERIC falls back to the run-time-flag path (g_epilogue_store8).  The specialised
+// paths have no branches, load the bias once per lane and issue every residual / pre-activation load of a 64-row half before
+// the first use, so their latencies overlap instead of serialising per pass.
+#define E_BIAS 1
+#define E_GELU 2      /* exact GELU, pre-activation saved to aux */
+#define E_DGELU 4     /* multiply by GELU'(aux) */
+#define E_RES 8       /* + fp32 residual */
+#define E_F32 16      /* fp32 output (else bf16) */
+#define E_SPLITK 32   /* raw fp32 partial slab */
+#define E_ROWGRP 64   /* token-row remap (patch embedding) */
+#define E_GENERIC 0x1000
+
+template <int E>
+__device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float* slab, int lane, long mbase /* first row of this 64-row half */,
+                                                int n, int z, const float (&bias8)[8]) {
+  // this lane: rows mbase + pass*8 + (lane >> 3), pass = 0..7, columns n .. n+7
+  const int rsub = lane >> 3, cc = (lane & 7) * 8;
+  if (n >= p.N) return;
+  long mo[8], mr[8];
+  bool ok[8];
+#pragma unroll
+  for (int ps = 0; ps < 8; ++ps) {
+    const long mi = mbase + ps * 8 + rsub;
+    ok[ps] = mi < p.M;
+    mo[ps] = (E & E_ROWGRP) ? mi + mi / p.row_group + 1 : mi;
+    mr[ps] = (E & E_ROWGRP) ? mi % p.row_group + 1 : mi;
+  }
+  f32x4 r0[8], r1[8];
+  u32x4 ux[8];
+  if (E & E_RES) {
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps)
+      if (ok[ps]) { const float* rs = p.residual + mr[ps] * p.ldr + n; r0[ps] = *(const f32x4*)rs; r1[ps] = *(const f32x4*)(rs + 4); }
+  }
+  if (E & E_DGELU) {
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps)
+      if (ok[ps]) ux[ps] = *(const u32x4*)(p.aux + mo[ps] * p.ldaux + n);
+  }
+#pragma unroll
+  for (int ps = 0; ps < 8; ++ps) {
+    if (!ok[ps]) continue;
+    const int row = ps * 8 + rsub;
+    float v[8];
+    f32x4 x0 = *(const f32x4*)(slab + row * 64 + cc), x1 = *(const f32x4*)(slab + row * 64 + cc + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
+    if (E & E_SPLITK) {
+      float* dst = p.slabs + ((long)z * p.M + (mbase + row)) * p.N + n;
+      *(f32x4*)dst = x0; *(f32x4*)(dst + 4) = x1;
+      continue;
+    }
+    if (E & E_BIAS) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+    }
+    if (E & E_GELU) {
+      *(u32x4*)(p.aux + mo[ps] * p.ldaux + n) = (u32x4){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+    }
+    if (E & E_DGELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[2 * e] *= gelu_grad_f(bf_lo(ux[ps][e])); v[2 * e + 1] *= gelu_grad_f(bf_hi(ux[ps][e])); }
+    }
+    if (E & E_RES) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += r0[ps][e]; v[4 + e] += r1[ps][e]; }
+    }
+    if (E & E_F32) {
+      float* dst = (float*)p.C + mo[ps] * p.ldc + n;
+      *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+      *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+    } else {
+      *(u32x4*)((bf16_t*)p.C + mo[ps] * p.ldc + n) = (u32x4){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+    }
+  }
+}
+
+template <bool TN, int E>
 __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * H_TILEBUF];   // 128 KB, ALL of the kernel's LDS
   const int tid = threadIdx.x, lane = tid & 63;
@@ -315,90 +396,91 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
 #define H_FRAG_A(reg, rt, ks) (TN ? h_read_frag_tn(reg, wr * 64 + (rt) * 32, ks, lane) : h_read_frag(reg, wr * 64 + (rt) * 32, ks, l31, hi))
 #define H_FRAG_B(reg, ks) (TN ? h_read_frag_tn(reg, wc * 32, ks, lane) : h_read_frag(reg, wc * 32, ks, l31, hi))
 
-  // ---- prologue: tile 0 completely, tile 1 except RA1 (issued in tile 0's R1) -----------------------------------
+  unsigned long long t_start = 0, t_landed = 0, t_main = 0;
+  if (p.dbg) t_start = __builtin_readcyclecounter();
+  // ---- prologue: tiles 0 and 1 completely ---------------------------------------------------------------------------
   if (nk > 0) { H_ISSUE_A(0, 0, 0); H_ISSUE_B(0, 0, 0); H_ISSUE_B(0, 1, 0); H_ISSUE_A(0, 1, 0); }
-  if (nk > 1) { H_ISSUE_A(1, 0, 1); H_ISSUE_B(1, 0, 1); H_ISSUE_B(1, 1, 1); H_WAIT_VM(6); } else { H_WAIT_VM(0); }
+  if (nk > 1) { H_ISSUE_A(1, 0, 1); H_ISSUE_B(1, 0, 1); H_ISSUE_B(1, 1, 1); H_ISSUE_A(1, 1, 1); H_WAIT_VM(8); } else { H_WAIT_VM(0); }
   H_BAR();
+  if (p.dbg) t_landed = __builtin_readcyclecounter();
   if (wr == 1) H_BAR();                                   // stagger: the second wave-row runs one interval behind
 
+  // K-tile schedule: 4 barrier intervals per tile; wave-row 1 runs one interval behind wave-row 0, so on every SIMD one wave's
+  // 16-MFMA segment overlaps the other wave's LDS reads.  With group 0 at intervals 4t .. 4t+3:
+  //   RA(t): read A0 (8), B0 (4), B1 (4) of tile t;  wait vmcnt(6): RA1 of tile t has landed (read two barriers later, in RB)
+  //   MA(t): DMA RA1 of tile t+1 (2), then 16 MFMA A0 x (B0, B1)
+  //   RB(t): read A1 (8);                             wait vmcnt(2): RA0, RB0, RB1 of tile t+1 have landed (read in RA(t+1))
+  //   MB(t): DMA RA0, RB0, RB1 of tile t+2 (6), then 16 MFMA A1 x (B1, B0)
+  // WAR: every refill is ISSUED >= 2 intervals after the lagging row issued its last read of that region (RA1: read in RB(t-1),
+  // i.e. interval 4t-1 for row 1, refilled at 4t+1; RA0/RB0/RB1: read at 4t+1, refilled at 4t+3), so those reads have retired
+  // behind an lgkmcnt(0) + barrier.  RAW: each wait is followed by two barriers before the first read of the data it covers.
+  // vmcnt is never 0 in steady state: 2-8 DMAs stay in flight across every barrier.
   s16x8 a0[2][4], a1[2][4], b0[4], b1[4];
   for (int t = 0; t < nk; ++t) {
     const int cur = t & 1;
     const unsigned char* RA0 = H_REG(cur, 0); const unsigned char* RA1 = H_REG(cur, 1);
     const unsigned char* RB0 = H_REG(cur, 2); const unsigned char* RB1 = H_REG(cur, 3);
-    // ---- R1: A0, B0 fragments; DMA RA1 of tile t+1 ------------------------------------------------------------
+    // ---- RA --------------------------------------------------------------------------------------------------------
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) b0[ks] = H_FRAG_B(RB0, ks);
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) a0[rt][ks] = H_FRAG_A(RA0, rt, ks);
-    if (t + 1 < nk) H_ISSUE_A(cur ^ 1, 1, t + 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b1[ks] = H_FRAG_B(RB1, ks);
+    if (t + 1 < nk) { H_WAIT_VM(6); } else { H_WAIT_VM(0); }
     H_BAR();
-    // ---- M1 ---------------------------------------------------------------------------------------------------
-    VDK_PIN2(acc[0][0], acc[1][0]);
+    // ---- MA --------------------------------------------------------------------------------------------------------
+    if (t >= 1 && t + 1 < nk) H_ISSUE_A(cur ^ 1, 1, t + 1);   // (tile 1's RA1 was issued by the prologue)
+    VDK_PIN2(acc[0][0], acc[1][0]); VDK_PIN2(acc[0][1], acc[1][1]);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0][ks], b0[ks], acc[0][0], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1][ks], b0[ks], acc[1][0], 0, 0, 0);
-    }
-    VDK_PIN2(acc[0][0], acc[1][0]);
-    __builtin_amdgcn_s_setprio(0);
-    H_BAR();
-    // ---- R2: B1 fragments ---------------------------------------------------------------------------------------
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) b1[ks] = H_FRAG_B(RB1, ks);
-    H_BAR();
-    // ---- M2 ---------------------------------------------------------------------------------------------------
-    VDK_PIN2(acc[0][1], acc[1][1]);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0][ks], b1[ks], acc[0][1], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1][ks], b1[ks], acc[1][1], 0, 0, 0);
     }
-    VDK_PIN2(acc[0][1], acc[1][1]);
+    VDK_PIN2(acc[0][0], acc[1][0]); VDK_PIN2(acc[0][1], acc[1][1]);
     __builtin_amdgcn_s_setprio(0);
     H_BAR();
-    // ---- R3: A1 fragments; DMA RA0, RB0 of tile t+2 (their last reader was R1) --------------------------------------
+    // ---- RB --------------------------------------------------------------------------------------------------------
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) a1[rt][ks] = H_FRAG_A(RA1, rt, ks);
-    if (t + 2 < nk) { H_ISSUE_A(cur, 0, t + 2); H_ISSUE_B(cur, 0, t + 2); }
+    if (t + 1 < nk) { H_WAIT_VM(2); } else { H_WAIT_VM(0); }
     H_BAR();
-    // ---- M3 ---------------------------------------------------------------------------------------------------
-    VDK_PIN2(acc[2][1], acc[3][1]);
+    // ---- MB --------------------------------------------------------------------------------------------------------
+    if (t + 2 < nk) { H_ISSUE_A(cur, 0, t + 2); H_ISSUE_B(cur, 0, t + 2); H_ISSUE_B(cur, 1, t + 2); }
+    VDK_PIN2(acc[2][1], acc[3][1]); VDK_PIN2(acc[2][0], acc[3][0]);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0][ks], b1[ks], acc[2][1], 0, 0, 0);
       acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1][ks], b1[ks], acc[3][1], 0, 0, 0);
-    }
-    VDK_PIN2(acc[2][1], acc[3][1]);
-    __builtin_amdgcn_s_setprio(0);
-    H_BAR();
-    // ---- R4: counted wait: tile t+1 fully landed (only the 4 newest DMAs, all of tile t+2, may be outstanding);
-    //      DMA RB1 of tile t+2 (last reader R2).  Two barriers separate this wait from tile t+1's first read.
-    if (t + 2 < nk) { H_WAIT_VM(4); H_ISSUE_B(cur, 1, t + 2); } else { H_WAIT_VM(0); }
-    H_BAR();
-    // ---- M4 ---------------------------------------------------------------------------------------------------
-    VDK_PIN2(acc[2][0], acc[3][0]);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
       acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0][ks], b0[ks], acc[2][0], 0, 0, 0);
       acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1][ks], b0[ks], acc[3][0], 0, 0, 0);
     }
-    VDK_PIN2(acc[2][0], acc[3][0]);
+    VDK_PIN2(acc[2][1], acc[3][1]); VDK_PIN2(acc[2][0], acc[3][0]);
     __builtin_amdgcn_s_setprio(0);
     H_BAR();
   }
   if (wr == 0) H_BAR();                                   // match the barrier count of the lagging wave-row
+  if (p.dbg) t_main = __builtin_readcyclecounter();
 
   // ---- epilogue: wave-private 16 KB LDS slab, 64 rows x 64 fp32 at a time -> 8-wide coalesced row chunks ---------
   float* slab = (float*)(smem + w * 16384);
+  const int ncol = n0 + wc * 64 + (lane & 7) * 8;
+  float bias8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+  if ((E != E_GENERIC) && (E & E_BIAS) && ncol < p.N) {
+    f32x4 b0v = *(const f32x4*)(p.bias + ncol), b1v = *(const f32x4*)(p.bias + ncol + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bias8[e] = b0v[e]; bias8[4 + e] = b1v[e]; }
+  }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {   // fully unrolled: acc must be indexed statically (else it lives in scratch)
 #pragma unroll
@@ -409,20 +491,29 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
         for (int r = 0; r < 16; ++r)
           slab[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + ct * 32 + l31] = acc[half * 2 + rt][ct][r];
     __builtin_amdgcn_wave_barrier();
+    if (E != E_GENERIC) {
+      h_epilogue_half<E>(p, slab, lane, (long)m0 + wr * 128 + half * 64, ncol, z, bias8);
+    } else {
 #pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {   // unrolled: the residual / aux / bias loads of all passes are in flight together
-      const int row = pass * 8 + (lane >> 3), cc = (lane & 7) * 8;
-      const long mi = (long)m0 + wr * 128 + half * 64 + row;
-      const int n = n0 + wc * 64 + cc;
-      if (mi < p.M && n < p.N) {
-        float v[8];
-        f32x4 x0 = *(const f32x4*)(slab + row * 64 + cc), x1 = *(const f32x4*)(slab + row * 64 + cc + 4);
+      for (int pass = 0; pass < 8; ++pass) {
+        const int row = pass * 8 + (lane >> 3), cc = (lane & 7) * 8;
+        const long mi = (long)m0 + wr * 128 + half * 64 + row;
+        const int n = n0 + wc * 64 + cc;
+        if (mi < p.M && n < p.N) {
+          float v[8];
+          f32x4 x0 = *(const f32x4*)(slab + row * 64 + cc), x1 = *(const f32x4*)(slab + row * 64 + cc + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
-        g_epilogue_store8(p, mi, n, v, z);
+          for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
+          g_epilogue_store8(p, mi, n, v, z);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  if (p.dbg && tid == 0) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the stamp is taken when this wave's stores have left
+    unsigned long long* o = p.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+    o[0] = t_start; o[1] = t_landed; o[2] = t_main; o[3] = __builtin_readcyclecounter();
   }
 #undef H_REG
 #undef H_ISSUE_A
@@ -490,11 +581,13 @@ static std::vector<hipEvent_t> g_prof_ev;
 static std::vector<double> g_prof_flops;
 static size_t g_prof_used = 0;
 static bool g_prof_on = false;
+static void* g_dbg_ptr = nullptr;
 static int g_force_kernel = 0;   // 0 auto, 1 = 128x128 register-staged, 2 = 256x256 LDS-DMA (tests / A-B benchmarking)
 
 extern "C" {
 
 int vdk_gemm_force_kernel(int32_t which) { g_force_kernel = which; return VDK_OK; }
+int vdk_gemm_debug_stamps(void* device_u64_buffer) { g_dbg_ptr = device_u64_buffer; return VDK_OK; }
 
 int vdk_prof_begin(int32_t max_launches) {
   if (max_launches < 0) return vdk_fail(VDK_EINVAL, "vdk_prof_begin: bad argument");
@@ -548,7 +641,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.c_dtype = d->c_dtype; p.bias = (const float*)d->bias; p.residual = (const float*)d->residual; p.ldr = d->ldr;
   p.act = d->act; p.aux = (bf16_t*)d->aux; p.ldaux = d->ldaux; p.alpha = d->alpha; p.row_group = d->row_group; p.a_row_group = d->a_row_group;
-  p.splitk = splitk; p.slabs = nullptr;
+  p.splitk = splitk; p.slabs = nullptr; p.dbg = (unsigned long long*)g_dbg_ptr;
   int kps = d->K;
   if (splitk > 1) {
     if (d->bias || d->residual || d->act != VDK_ACT_NONE || d->row_group > 0) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: split-K excludes fused epilogues");
@@ -569,12 +662,44 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   // big problems go to the 256x256 LDS-DMA kernel (needs whole 64-wide k-tiles per split and >= 1 full wave of tiles)
   const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * splitk;
   const bool big = g_force_kernel == 2 || (g_force_kernel == 0 && (d->K % 64 == 0) && (kps % 64 == 0) && tiles256 >= 128 && d->M >= 256 && d->N >= 256);
+  // compile-time epilogue variant (the common ViT forms); anything else takes the run-time-flag path
+  int E = E_GENERIC;
+  {
+    const bool bias = d->bias != nullptr, res = d->residual != nullptr, f32 = d->c_dtype == VDK_F32, rg = d->row_group > 0;
+    const bool plain_alpha = d->alpha == 1.0f;
+    if (splitk > 1) E = E_SPLITK;
+    else if (plain_alpha && !rg && !res && d->act == VDK_ACT_NONE && !f32) E = bias ? E_BIAS : 0;
+    else if (plain_alpha && !rg && !res && d->act == VDK_ACT_GELU && !f32 && bias && d->aux) E = E_BIAS | E_GELU;
+    else if (plain_alpha && !rg && !res && d->act == VDK_ACT_DGELU && !f32 && !bias) E = E_DGELU;
+    else if (plain_alpha && !rg && res && d->act == VDK_ACT_NONE && f32 && bias) E = E_BIAS | E_RES | E_F32;
+    else if (plain_alpha && rg && res && d->act == VDK_ACT_NONE && f32 && bias) E = E_BIAS | E_RES | E_F32 | E_ROWGRP;
+    else if (plain_alpha && !rg && !res && d->act == VDK_ACT_NONE && f32 && !bias) E = E_F32;
+  }
+  const dim3 grid256((unsigned)(((d->M + 255) / 256) * ((d->N + 255) / 256)), (unsigned)splitk);
+#define LAUNCH256(TNF, EE) hipLaunchKernelGGL((gemm256_bf16_kernel<TNF, EE>), grid256, dim3(512), 0, stream, p)
   if (d->trans) {
     if ((d->K % 64) || (kps % 64) || (d->M & 7) || d->M < 8 || d->N < 8)
       return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: trans=1 needs K and the split size to be multiples of 64 and M % 8 == 0");
-    hipLaunchKernelGGL((gemm256_bf16_kernel<true>), dim3((unsigned)(((d->M + 255) / 256) * ((d->N + 255) / 256)), (unsigned)splitk), dim3(512), 0, stream, p);
-  } else if (big && (d->K % 64 == 0) && (kps % 64 == 0))
-    hipLaunchKernelGGL((gemm256_bf16_kernel<false>), dim3((unsigned)(((d->M + 255) / 256) * ((d->N + 255) / 256)), (unsigned)splitk), dim3(512), 0, stream, p);
+    switch (E) {
+      case E_SPLITK: LAUNCH256(true, E_SPLITK); break;
+      case E_F32: LAUNCH256(true, E_F32); break;
+      case 0: LAUNCH256(true, 0); break;
+      default: LAUNCH256(true, E_GENERIC); break;
+    }
+  } else if (big && (d->K % 64 == 0) && (kps % 64 == 0)) {
+    switch (E) {
+      case 0: LAUNCH256(false, 0); break;
+      case E_BIAS: LAUNCH256(false, E_BIAS); break;
+      case E_BIAS | E_GELU: LAUNCH256(false, E_BIAS | E_GELU); break;
+      case E_DGELU: LAUNCH256(false, E_DGELU); break;
+      case E_BIAS | E_RES | E_F32: LAUNCH256(false, E_BIAS | E_RES | E_F32); break;
+      case E_BIAS | E_RES | E_F32 | E_ROWGRP: LAUNCH256(false, E_BIAS | E_RES | E_F32 | E_ROWGRP); break;
+      case E_SPLITK: LAUNCH256(false, E_SPLITK); break;
+      case E_F32: LAUNCH256(false, E_F32); break;
+      default: LAUNCH256(false, E_GENERIC); break;
+    }
+  }
+#undef LAUNCH256
   else
   hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256), 0, stream, p);
   if (prof) {   // the GEMM kernel only (the split-K combine is a separate, HBM-bound kernel)

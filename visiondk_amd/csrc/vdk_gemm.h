@@ -19,6 +19,7 @@ struct GemmParams {
   int a_row_group;
   int splitk; int k_per_split;
   float* slabs;
+  unsigned long long* dbg;   // debug only: 4 cycle stamps per workgroup (start, operands landed, main loop done, end)
 };
 
 // in-library launcher (no descriptor copy through the C ABI)

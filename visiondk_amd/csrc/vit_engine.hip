@@ -164,8 +164,9 @@ struct WsPlan {
   size_t s_h, s_qkv, s_lse, s_u;      // per-layer sizes in bytes
   size_t hf;                 // bf16 [Bp, D] (zero padded rows)
   // backward scratch
-  size_t dxa, dxm, dxab, dxmb;   // fp32 [T,D] x2, bf16 [T,D] x2
-  size_t dbig;                   // bf16 [T, max(M, 3D)]  (du / dqkv)
+  size_t dxa, dxm;               // fp32 [T,D] x2 (main stream only)
+  size_t dxab[3], dxmb[2];       // bf16 [T,D]: dxab(l) is written at the END of layer l+1 -> 3 buffers; dxmb ping-pongs on the layer parity
+  size_t du[2], dqkv[2];         // bf16 [T,M], [T,3D], ping-pong per layer parity
   size_t dsm;                    // bf16 [T, D]           (dh / do)
   size_t dvec;                   // fp32 [B,H,N]
   size_t tA, tB;                 // bf16 [max(M,3D,Cp), Tp] each
@@ -206,9 +207,12 @@ static int vit_plan(const VitDims& d, WsPlan* w) {
   w->o = w_take(cur, L * w->s_h); w->h2 = w_take(cur, L * w->s_h); w->u = w_take(cur, L * w->s_u); w->g = w_take(cur, L * w->s_u);
   w->hf = w_take(cur, (size_t)d.Bp * D * 2);
   w->dxa = w_take(cur, T * D * 4); w->dxm = w_take(cur, T * D * 4);
-  w->dxab = w_take(cur, T * D * 2); w->dxmb = w_take(cur, T * D * 2);
   size_t big = M > 3 * D ? M : 3 * D;
-  w->dbig = w_take(cur, T * big * 2);
+  for (int i = 0; i < 3; ++i) w->dxab[i] = w_take(cur, T * D * 2);
+  for (int i = 0; i < 2; ++i) {
+    w->dxmb[i] = w_take(cur, T * D * 2);
+    w->du[i] = w_take(cur, T * M * 2); w->dqkv[i] = w_take(cur, T * 3 * D * 2);
+  }
   w->dsm = w_take(cur, T * D * 2);
   w->dvec = w_take(cur, w->s_lse);
   size_t trows = big > (size_t)d.Cp ? big : (size_t)d.Cp;
@@ -235,6 +239,27 @@ static int vit_plan(const VitDims& d, WsPlan* w) {
 }
 
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+// Events that order the main (dgrad) stream and the side (wgrad) stream of vdk_vit_backward.  Created once per process,
+// timing disabled, re-recorded on every call (the only library-owned state; streams and memory stay the caller's).
+#include <vector>
+static std::vector<hipEvent_t> g_ev;
+static int ev_get(size_t i, hipEvent_t* e) {
+  while (g_ev.size() <= i) {
+    hipEvent_t x;
+    if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vit: hipEventCreate failed");
+    g_ev.push_back(x);
+  }
+  *e = g_ev[i];
+  return VDK_OK;
+}
+// "everything enqueued so far on `from` happens before anything enqueued later on `to`"
+static int ev_order(size_t slot, hipStream_t from, hipStream_t to) {
+  if (from == to) return VDK_OK;
+  hipEvent_t e; RC(ev_get(slot, &e));
+  if (hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vit: event record/wait failed");
+  return VDK_OK;
+}
 
 static int gemm(hipStream_t s, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K, int cdt,
                 const float* bias, const float* res, int64_t ldr, int act, void* aux, int64_t ldaux, int splitk, int row_group, void* ws,
@@ -383,8 +408,11 @@ static int linear_wgrad(hipStream_t s, const VitDims& d, const WsPlan& w, char* 
 // kernels producing grads[offset, offset+numel) have been enqueued (reverse layer order) so that a data-parallel
 // caller can start that bucket's all-reduce on another stream; may be NULL.
 int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* params, const void* wb16, const void* wt16, void* ws,
-                     size_t ws_bytes, float* grads, vdk_grad_ready_fn on_ready, void* user, void* stream_) {
+                     size_t ws_bytes, float* grads, vdk_grad_ready_fn on_ready, void* user, void* stream_, void* side_stream_) {
   hipStream_t s = (hipStream_t)stream_;
+  // s2: where the weight-gradient GEMMs + bias column sums go.  They are compute-bound with tiny outputs and independent of
+  // the dgrad chain (whose short-K GEMMs have HBM-bound epilogues): interleaving the two across CUs overlaps MFMA with HBM.
+  hipStream_t s2 = side_stream_ ? (hipStream_t)side_stream_ : s;
   VitDims d; RC(vit_dims(cfg, &d));
   PLayout p; RC(vit_layout(d, &p));
   WsPlan w; RC(vit_plan(d, &w));
@@ -397,18 +425,26 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
   float* stats = (float*)(base + w.stats);
   const size_t XS = (size_t)T * D;
   float* dxa = (float*)(base + w.dxa); float* dxm = (float*)(base + w.dxm);
-  bf16_t* dxab = (bf16_t*)(base + w.dxab); bf16_t* dxmb = (bf16_t*)(base + w.dxmb);
-  bf16_t* dbig = (bf16_t*)(base + w.dbig); bf16_t* dsm = (bf16_t*)(base + w.dsm);
+  // bf16 gradient operands rotate over the layers (dxab: 3 buffers, the others: parity): the side stream may still be reading
+  // layer l+1's copies while the main stream writes layer l's.  Main waits for "side finished layer l+2" before it starts layer l.
+#define DXAB(l) ((bf16_t*)(base + w.dxab[((l) + 3) % 3]))
+#define DXMB(l) ((bf16_t*)(base + w.dxmb[((l) + 2) & 1]))
+#define DU(l) ((bf16_t*)(base + w.du[((l) + 2) & 1]))
+#define DQKV(l) ((bf16_t*)(base + w.dqkv[((l) + 2) & 1]))
+  bf16_t* dsm = (bf16_t*)(base + w.dsm);
   float* dvec = (float*)(base + w.dvec);
   void* lnws = base + w.lnws;
+  const size_t EV_SIDE_DONE = 8;   // slots [8, 8 + L + 2): side stream finished layer l (index l + 1; 0 = embeddings)
+  size_t ev_p = EV_SIDE_DONE + d.L + 4;   // producer events, a fresh slot per use
+  RC(ev_order(0, s, s2));           // the side stream starts after whatever precedes this call on the main stream
 
   // ---- head + final norm -------------------------------------------------------------------------
   if (d.C == 0) {
     // feature mode: `dlogits` is dL/d norm(x) for all tokens, f32 [B*N, D]
     float* xl = X + (size_t)(2 * d.L) * XS;
     float* meanf = stats + (size_t)d.L * 4 * T; float* rstdf = meanf + T;
-    RC(vdk_layernorm_bwd(dlogits, D, VDK_F32, xl, D, meanf, rstdf, params + p.norm_w, nullptr, 0, T, D, dxa, D, dxab, D, grads + p.norm_w, grads + p.norm_b,
-                         lnws, w.lnws_bytes, s));
+    RC(vdk_layernorm_bwd(dlogits, D, VDK_F32, xl, D, meanf, rstdf, params + p.norm_w, nullptr, 0, T, D, dxa, D, DXAB(d.L - 1), D, grads + p.norm_w,
+                         grads + p.norm_b, lnws, w.lnws_bytes, s));
     if (on_ready) on_ready(user, p.norm_w, p.total - p.norm_w);
   } else {
     const bf16_t* dl = (const bf16_t*)dlogits;
@@ -416,11 +452,11 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
     RC(linear_wgrad(s, d, w, base, dl, d.Cp, hf, D, d.B, d.Bp, d.Cp, D, grads + p.head_w, grads + p.head_b, 0));
     bf16_t* dhf = (bf16_t*)(base + w.dhf);
     RC(gemm(s, dl, d.Cp, wt + p.headT, d.Cp, dhf, D, d.B, D, d.Cp, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
-    if (hipMemsetAsync(dxa, 0, XS * 4, s) != hipSuccess || hipMemsetAsync(dxab, 0, XS * 2, s) != hipSuccess)
+    if (hipMemsetAsync(dxa, 0, XS * 4, s) != hipSuccess || hipMemsetAsync(DXAB(d.L - 1), 0, XS * 2, s) != hipSuccess)
       return vdk_fail(VDK_ELAUNCH, "vdk_vit_backward: memset failed");
     float* xl = X + (size_t)(2 * d.L) * XS;
     float* meanf = stats + (size_t)d.L * 4 * T; float* rstdf = meanf + T;
-    RC(vdk_layernorm_bwd(dhf, D, VDK_BF16, xl, (int64_t)d.N * D, meanf, rstdf, params + p.norm_w, nullptr, 0, d.B, D, dxa, (int64_t)d.N * D, dxab,
+    RC(vdk_layernorm_bwd(dhf, D, VDK_BF16, xl, (int64_t)d.N * D, meanf, rstdf, params + p.norm_w, nullptr, 0, d.B, D, dxa, (int64_t)d.N * D, DXAB(d.L - 1),
                          (int64_t)d.N * D, grads + p.norm_w, grads + p.norm_b, lnws, w.lnws_bytes, s));
     if (on_ready) on_ready(user, p.norm_w, p.total - p.norm_w);
   }
@@ -432,22 +468,33 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
     bf16_t* h1 = (bf16_t*)(base + w.h1 + l * w.s_h); bf16_t* qkv = (bf16_t*)(base + w.qkv + l * w.s_qkv);
     float* lse = (float*)(base + w.lse + l * w.s_lse); bf16_t* o = (bf16_t*)(base + w.o + l * w.s_h);
     bf16_t* h2 = (bf16_t*)(base + w.h2 + l * w.s_h); bf16_t* u = (bf16_t*)(base + w.u + l * w.s_u); bf16_t* g = (bf16_t*)(base + w.g + l * w.s_u);
+    bf16_t* dxab = DXAB(l); bf16_t* dxmb = DXMB(l); bf16_t* du = DU(l); bf16_t* dqkv = DQKV(l);
+    // WAR: this layer overwrites the parity buffers the side stream read two layers ago
+    if (s2 != s && l + 2 <= d.L - 1) { hipEvent_t e; RC(ev_get(EV_SIDE_DONE + l + 3, &e)); if (hipStreamWaitEvent(s, e, 0) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vit: wait failed"); }
     // MLP branch: dxa / dxab hold dL/dx_out
-    RC(linear_wgrad(s, d, w, base, dxab, D, g, M, T, d.Tp, D, M, grads + b.fc2_w, grads + b.fc2_b, 0));
-    RC(gemm(s, dxab, D, wt + p.blkT[l].fc2, D, dbig, M, T, M, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_DGELU, u, M, 1, 0, nullptr, 0));   // du
-    RC(linear_wgrad(s, d, w, base, dbig, M, h2, D, T, d.Tp, M, D, grads + b.fc1_w, grads + b.fc1_b, 0));
-    RC(gemm(s, dbig, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // dh2
+    RC(ev_order(ev_p++, s, s2));
+    RC(linear_wgrad(s2, d, w, base, dxab, D, g, M, T, d.Tp, D, M, grads + b.fc2_w, grads + b.fc2_b, 0));
+    RC(gemm(s, dxab, D, wt + p.blkT[l].fc2, D, du, M, T, M, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_DGELU, u, M, 1, 0, nullptr, 0));   // du
+    RC(ev_order(ev_p++, s, s2));
+    RC(linear_wgrad(s2, d, w, base, du, M, h2, D, T, d.Tp, M, D, grads + b.fc1_w, grads + b.fc1_b, 0));
+    RC(gemm(s, du, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // dh2
     RC(vdk_layernorm_bwd(dsm, D, VDK_BF16, xmid, D, mean2, rstd2, params + b.n2w, dxa, D, T, D, dxm, D, dxmb, D, grads + b.n2w, grads + b.n2b, lnws,
                          w.lnws_bytes, s));
     // attention branch: dxm / dxmb hold dL/dx_mid
-    RC(linear_wgrad(s, d, w, base, dxmb, D, o, D, T, d.Tp, D, D, grads + b.proj_w, grads + b.proj_b, 0));
+    RC(ev_order(ev_p++, s, s2));
+    RC(linear_wgrad(s2, d, w, base, dxmb, D, o, D, T, d.Tp, D, D, grads + b.proj_w, grads + b.proj_b, 0));
     RC(gemm(s, dxmb, D, wt + p.blkT[l].proj, D, dsm, D, T, D, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // do
-    RC(vdk_attention_bwd(qkv, 3 * D, o, dsm, D, lse, dbig, 3 * D, dvec, d.B, d.N, d.H, 64, 0.125f, s));                                    // dqkv
-    RC(linear_wgrad(s, d, w, base, dbig, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, grads + b.qkv_b, 0));
-    RC(gemm(s, dbig, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));  // dh1
-    RC(vdk_layernorm_bwd(dsm, D, VDK_BF16, xin, D, mean1, rstd1, params + b.n1w, dxm, D, T, D, dxa, D, dxab, D, grads + b.n1w, grads + b.n1b, lnws,
+    RC(vdk_attention_bwd(qkv, 3 * D, o, dsm, D, lse, dqkv, 3 * D, dvec, d.B, d.N, d.H, 64, 0.125f, s));                                    // dqkv
+    RC(ev_order(ev_p++, s, s2));
+    RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, grads + b.qkv_b, 0));
+    RC(gemm(s, dqkv, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));  // dh1
+    RC(vdk_layernorm_bwd(dsm, D, VDK_BF16, xin, D, mean1, rstd1, params + b.n1w, dxm, D, T, D, dxa, D, DXAB(l - 1), D, grads + b.n1w, grads + b.n1b, lnws,
                          w.lnws_bytes, s));
-    if (on_ready) on_ready(user, b.n1w, (l + 1 < d.L ? p.blk[l + 1].n1w : p.norm_w) - b.n1w);
+    if (s2 != s) { hipEvent_t e; RC(ev_get(EV_SIDE_DONE + l + 1, &e)); if (hipEventRecord(e, s2) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vit: record failed"); }
+    if (on_ready) {
+      if (s2 != s) { hipEvent_t e; RC(ev_get(EV_SIDE_DONE + l + 1, &e)); if (hipStreamWaitEvent(s, e, 0) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vit: wait failed"); }
+      on_ready(user, b.n1w, (l + 1 < d.L ? p.blk[l + 1].n1w : p.norm_w) - b.n1w);
+    }
   }
   // ---- embeddings -------------------------------------------------------------------------------------
   {
@@ -460,9 +507,15 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
     (void)dposall;
     bf16_t* patches = (bf16_t*)(base + w.patches);
     const int rows = d.B * d.np, rows_pad = (int)up(rows, 64);
-    RC(linear_wgrad(s, d, w, base, dxab, D, patches, d.Kpe, rows, rows_pad, D, d.Kpe, grads + p.pe_w, nullptr, d.np));
+    RC(ev_order(ev_p++, s, s2));
+    RC(linear_wgrad(s2, d, w, base, DXAB(-1), D, patches, d.Kpe, rows, rows_pad, D, d.Kpe, grads + p.pe_w, nullptr, d.np));
+    RC(ev_order(ev_p++, s2, s));      // join: everything the side stream produced is ordered before what follows on the main stream
     if (on_ready) on_ready(user, 0, p.blk[0].n1w);
   }
+#undef DXAB
+#undef DXMB
+#undef DU
+#undef DQKV
   return vdk_check_launch("vdk_vit_backward");
 }
 

@@ -84,6 +84,23 @@ class VitEngine:
         self._ws_batch = -1
         self._logits: Optional[torch.Tensor] = None
         self._weights_version = None
+        # optional side stream for the weight-gradient GEMMs of vdk_vit_backward.  Measured on MI355X (ViT-B/16 bs256): no gain
+        # (49.4 ms/step either way; one 128-KB-LDS workgroup per CU means the two kernels only time-share CUs), so it is off
+        # unless VDK_SIDE_STREAM=1.
+        import os
+        self.side_stream = (torch.cuda.Stream(device=self.device)
+                            if (os.environ.get("VDK_SIDE_STREAM") == "1" and self.be.device_only and self.device.type == "cuda") else None)
+
+    def __deepcopy__(self, memo):   # ModelEMA deep-copies the model; streams and library handles are not copyable
+        import copy
+        new = object.__new__(VitEngine)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k == "side_stream":
+                new.side_stream = torch.cuda.Stream(device=self.device) if v is not None else None
+            else:
+                setattr(new, k, copy.deepcopy(v, memo))
+        return new
 
     # ---- plumbing ------------------------------------------------------------------------------
     def _cfg(self, batch: int) -> _abi.VitConfig:
@@ -150,7 +167,8 @@ class VitEngine:
         be = self.be
         cb = _abi.GRAD_READY_FN(lambda user, off, n: on_ready(off, n)) if on_ready is not None else _abi.GRAD_READY_FN(0)
         be.check(be.lib.vdk_vit_backward(C.byref(cfg), be.ptr(dlogits_bf16), be.ptr(self.params), be.ptr(self.wb16), be.ptr(self.wt16),
-                                         be.ptr(self._ws), self._ws.numel(), be.ptr(self.grads), cb, None, be.stream()),
+                                         be.ptr(self._ws), self._ws.numel(), be.ptr(self.grads), cb, None, be.stream(),
+                                         self.side_stream.cuda_stream if self.side_stream is not None else None),
                  "vdk_vit_backward")
         return self.grads
 
