@@ -199,6 +199,7 @@ static inline float __fdividef(float a, float b) { return a / b; }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+static inline int __ffs(int x) { return __builtin_ffs(x); }
 static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 template <class T> static inline T min(T a, T b) { return a < b ? a : b; }
 template <class T> static inline T max(T a, T b) { return a > b ? a : b; }
@@ -301,6 +302,7 @@ static inline emu_s16x4 emu_ds_read_tr16_b64(const void* p) {
 }
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu_ds_read_tr16_b64((const void*)(p))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define VDK_WAVE_LDS_SYNC() emu::wave_barrier()
 #define __builtin_readcyclecounter() 0ull
 #define __builtin_amdgcn_wave_barrier() emu::wave_barrier()
 #define __builtin_amdgcn_exp2f(x) exp2f(x)

@@ -17,14 +17,29 @@ def _data(nq, n, d, seed=0, normalize=True):
     return q, g
 
 
+METHOD = "auto"
+
+
+@pytest.fixture(autouse=True, params=["prefilter", "exact_scan"])
+def _method(request):
+    """every case runs through both search paths: bf16 pre-filter + exact re-score (d <= 128) and the all-pairs fp32 scan"""
+    global METHOD
+    METHOD = request.param
+    yield
+    METHOD = "auto"
+
+
 def _search(be, q, g, k, cap=4096, idx_base=0):
-    idx = cbir.FlatIPIndex(q.shape[1], backend=be, device="cuda" if be.device_only else "cpu", cap=cap, idx_base=idx_base)
+    method = METHOD if q.shape[1] <= 128 else "exact_scan"
+    idx = cbir.FlatIPIndex(q.shape[1], backend=be, device="cuda" if be.device_only else "cpu", cap=cap, idx_base=idx_base, method=method)
     idx.add(g)
     return idx.search(q, k)
 
 
 @pytest.mark.parametrize("nq,n,d,k", [(33, 1000, 128, 100), (5, 700, 64, 10), (130, 300, 128, 7), (3, 50, 128, 100),
-                                      (4, 0, 128, 5), (9, 1300, 260, 20), (2, 129, 12, 129)])
+                                      (4, 0, 128, 5), (9, 1300, 260, 20), (2, 129, 12, 129),
+                                      (70, 6000, 128, 10), (600, 1400, 96, 5),
+                                      (3, 2000, 128, 300)])                      # k > 256: workgroup-per-query ranking kernels   # last two: threshold bootstrap active (N/k >= 128)
 def test_search_bit_exact(be, dev, nq, n, d, k):
     q, g = _data(nq, n, d)
     s, i = _search(be, q, g, k)
@@ -60,6 +75,31 @@ def test_sorted_gallery_worst_case(be, dev):
     s, i = _search(be, q, g, 32, cap=300)
     so, io = ocbir.flat_ip_search(q, g, 32)
     np.testing.assert_array_equal(i, io)
+
+
+@pytest.mark.parametrize("k", [25, 6])   # k=6: the threshold bootstrap runs (N/k >= 128), k=25: pass-everything ramp
+def test_prefilter_bound_adversarial(be, dev, k):
+    """Cases built to break a sloppy bf16 pre-filter: un-normalised rows with norms spread over 1e-3..1e3, a cluster of
+    gallery rows whose exact scores differ from the k-th best by far less than a bf16 ulp, and sign-mixed large terms that
+    cancel (|s| << sum |q_k g_k|).  The survivors' exact re-score must still give the oracle's top-k bit for bit."""
+    rng = np.random.default_rng(21)
+    d, n, nq = 128, 2500, 9
+    g = rng.standard_normal((n, d)).astype(np.float32) * (10.0 ** rng.uniform(-3, 3, size=(n, 1))).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32) * (10.0 ** rng.uniform(-2, 2, size=(nq, 1))).astype(np.float32)
+    # near-tie cluster: 200 copies of one strong row, each perturbed in the last bits of a few coordinates
+    base = (q[0] / np.linalg.norm(q[0]) * 900.0).astype(np.float32)
+    for j in range(200):
+        r = base.copy()
+        c = rng.integers(0, d, 3)
+        r[c] = np.nextafter(r[c], np.float32(np.inf) * (1 if j % 2 else -1)).astype(np.float32)
+        g[300 + 7 * j] = r
+    # cancelling rows: large alternating-sign components
+    alt = (np.where(np.arange(d) % 2 == 0, 1.0, -1.0) * 500.0).astype(np.float32)
+    g[5] = alt * np.sign(q[1]); g[6] = -g[5]
+    s, i = _search(be, q, g, k, cap=600)
+    so, io = ocbir.flat_ip_search(q, g, k)
+    np.testing.assert_array_equal(i, io)
+    np.testing.assert_array_equal(s.view(np.uint32), so.view(np.uint32))
 
 
 def test_idx_base_and_merge(be, dev):

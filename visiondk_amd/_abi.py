@@ -50,6 +50,9 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_l2norm_rows": (C.c_int, [P, P, I64, I32, F32, P]),
     "vdk_cbir_workspace_bytes": (C.c_int, [I64, I32, I64, PSZ]),
     "vdk_cbir_search": (C.c_int, [P, I64, P, I64, I32, I32, I64, P, P, I64, P, SZ, P]),
+    "vdk_cbir_prepare_gallery": (C.c_int, [P, I64, I32, P, P, P, P]),
+    "vdk_cbir_fast_workspace_bytes": (C.c_int, [I64, I32, I64, PSZ]),
+    "vdk_cbir_search_fast": (C.c_int, [P, I64, P, P, P, I64, I32, I32, I64, P, P, I64, P, SZ, P]),
     "vdk_cbir_merge_topk": (C.c_int, [P, P, I32, I64, I32, P, P, P, SZ, P]),
     # hot path A: dense ops
     "vdk_gemm_splitk_workspace_bytes": (C.c_int, [I32, I32, I32, PSZ]),

@@ -39,9 +39,14 @@ class FlatIPIndex:
     """Exact inner-product index (faiss IndexFlatIP semantics; ties -> lower index; pads (-FLT_MAX, -1))."""
 
     def __init__(self, d: int, backend: Optional[_lib.Backend] = None, device=None, cap: int = DEFAULT_CAP,
-                 idx_base: int = 0):
+                 idx_base: int = 0, method: str = "auto"):
+        """method: "prefilter" = bf16-MFMA candidate filter with a rigorous error bound + exact fp32 re-scoring (d <= 128),
+        "exact_scan" = every pair scored on the fp32 MFMA; "auto" picks prefilter when d <= 128.  Both return bit-identical
+        results (tests/test_cbir.py runs every case through both)."""
         if d <= 0:
             raise ValueError("dimension must be positive")
+        if method not in ("auto", "prefilter", "exact_scan"):
+            raise ValueError("method must be auto | prefilter | exact_scan")
         self.d = int(d)
         self.be = backend or _lib.load()
         self.device = torch.device(device) if device is not None else torch.device(
@@ -49,6 +54,11 @@ class FlatIPIndex:
         self.cap = int(cap)
         self.idx_base = int(idx_base)
         self._dp = (self.d + 3) // 4 * 4          # kernels need d % 4 == 0: zero-pad (adds exact zeros)
+        if method == "prefilter" and self._dp > 128:
+            raise ValueError("the prefilter path needs d <= 128")
+        self.method = "exact_scan" if (method == "exact_scan" or self._dp > 128) else "prefilter"
+        self._gb: Optional[torch.Tensor] = None   # bf16 [N, 128] copy + max row norm, built once per gallery state
+        self._gmax: Optional[torch.Tensor] = None
         self._chunks: list[torch.Tensor] = []
         self._gallery: Optional[torch.Tensor] = None
         self.is_trained = True
@@ -78,20 +88,34 @@ class FlatIPIndex:
         self._chunks.append(self._to_dev(x))
 
     def reset(self) -> None:
-        self._chunks, self._gallery = [], None
+        self._chunks, self._gallery, self._gb, self._gmax = [], None, None, None
 
     def _materialize(self) -> torch.Tensor:
         if self._chunks:
             parts = ([self._gallery] if self._gallery is not None else []) + self._chunks
             self._gallery = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
             self._chunks = []
+            self._gb = None
         if self._gallery is None:
             self._gallery = torch.empty((0, self._dp), dtype=torch.float32, device=self.device)
         return self._gallery
 
+    def _prepare(self) -> None:
+        """add()-time work of the prefilter path: bf16 copy of the gallery and its largest row norm."""
+        g = self._materialize()
+        if self._gb is not None:
+            return
+        be, n = self.be, g.shape[0]
+        self._gb = torch.empty((max(n, 1), 128), dtype=torch.bfloat16, device=self.device)
+        self._gmax = torch.zeros(1, dtype=torch.int32, device=self.device)
+        norms = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
+        be.check(be.lib.vdk_cbir_prepare_gallery(be.ptr(g) if n else None, n, self._dp, be.ptr(self._gb), be.ptr(norms),
+                                                 be.ptr(self._gmax), be.stream()), "vdk_cbir_prepare_gallery")
+
     def _workspace(self, nq: int, k: int, cap: int) -> torch.Tensor:
         need = C.c_size_t(0)
-        self.be.check(self.be.lib.vdk_cbir_workspace_bytes(nq, k, cap, C.byref(need)), "vdk_cbir_workspace_bytes")
+        fn = self.be.lib.vdk_cbir_fast_workspace_bytes if self.method == "prefilter" else self.be.lib.vdk_cbir_workspace_bytes
+        self.be.check(fn(nq, k, cap, C.byref(need)), "vdk_cbir_workspace_bytes")
         if self._ws is None or self._ws.numel() < need.value:
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
         return self._ws
@@ -110,9 +134,15 @@ class FlatIPIndex:
         if nq:
             ws = self._workspace(nq, k, cap)
             be = self.be
-            be.check(be.lib.vdk_cbir_search(be.ptr(qd), nq, be.ptr(g), g.shape[0], self._dp, k, self.idx_base,
-                                            be.ptr(scores), be.ptr(idx), cap, be.ptr(ws), ws.numel(), be.stream()),
-                     "vdk_cbir_search")
+            if self.method == "prefilter":
+                self._prepare()
+                be.check(be.lib.vdk_cbir_search_fast(be.ptr(qd), nq, be.ptr(g), be.ptr(self._gb), be.ptr(self._gmax), g.shape[0],
+                                                     self._dp, k, self.idx_base, be.ptr(scores), be.ptr(idx), cap, be.ptr(ws),
+                                                     ws.numel(), be.stream()), "vdk_cbir_search_fast")
+            else:
+                be.check(be.lib.vdk_cbir_search(be.ptr(qd), nq, be.ptr(g), g.shape[0], self._dp, k, self.idx_base,
+                                                be.ptr(scores), be.ptr(idx), cap, be.ptr(ws), ws.numel(), be.stream()),
+                         "vdk_cbir_search")
         if as_numpy:
             return scores.cpu().numpy(), idx.cpu().numpy()
         return scores, idx

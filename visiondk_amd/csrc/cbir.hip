@@ -16,6 +16,7 @@
 //  * "swapped" operands: A = gallery rows, B = queries, so a lane owns one query column and the
 //    threshold compare is per-lane.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "vdk_device.h"
 #include "vdk_host.h"
 
@@ -207,7 +208,7 @@ __device__ __forceinline__ unsigned long long cbir_key(float s, int idx) {
 }
 __global__ __launch_bounds__(256) void cbir_select_kernel(CbirCand cand, long nq, int k, float* __restrict__ thr,
                                                           float* __restrict__ out_score, long long* __restrict__ out_idx,
-                                                          int write_out) {
+                                                          int write_out, unsigned* __restrict__ carry) {
   __shared__ unsigned long long keys[CB_SORT_MAX];
   const long q = blockIdx.x;
   const int tid = threadIdx.x;
@@ -258,8 +259,10 @@ __global__ __launch_bounds__(256) void cbir_select_kernel(CbirCand cand, long nq
     cand.idx[q * cand.cap + i] = (int)(unsigned)(key & 0xffffffffu);
   }
   if (tid == 0) {
+    if (carry) carry[q] = (unsigned)have;
     cand.cnt[q] = (unsigned)have;
-    thr[q] = (have >= k) ? ord2f(~(unsigned)(keys[k - 1] >> 32)) : __uint_as_float(0xff800000u);  // -inf
+    // monotone: a bootstrap threshold (a valid lower bound of the k-th best) stays in force until k rows are ranked
+    if (have >= k) thr[q] = fmaxf(thr[q], ord2f(~(unsigned)(keys[k - 1] >> 32)));
   }
   if (write_out) {
     for (int i = tid; i < k; i += 256) {
@@ -272,6 +275,388 @@ __global__ __launch_bounds__(256) void cbir_select_kernel(CbirCand cand, long nq
         out_idx[q * k + i] = -1;
       }
     }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------ K13c
+// Wave-per-query ranking for k <= 256 (the common case: the reference searches k = 100).  Same contract as
+// cbir_select_kernel, optionally fused with the exact re-scoring of the prefilter path (Q != nullptr: entries
+// [carry[q], cnt[q]) hold only an index and get the oracle's k-ordered fmaf chain here).  A wave sorts up to CW_KEYS keys
+// in its own 8 KB LDS region with wave-synchronous bitonic steps (no workgroup barriers), so 20 waves per CU hide each
+// other's global-latency chains; typical steady-state input is k carried keys + ~10 new ones.
+// the oracle's score of one pair: k-ordered fmaf chain from +0 (oracle/cbir_oracle.c oracle_ip_pair), loads batched 8 deep
+__device__ __forceinline__ float cbir_exact_ip(const float* __restrict__ qrow, const float* __restrict__ g, int D) {
+  float acc = 0.f;
+  int c = 0;
+  for (; c + 32 <= D; c += 32) {
+    f32x4 gv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gv[j] = *(const f32x4*)(g + c + 4 * j);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const f32x4 qv = *(const f32x4*)(qrow + c + 4 * j);
+      acc = fmaf(qv[0], gv[j][0], acc); acc = fmaf(qv[1], gv[j][1], acc); acc = fmaf(qv[2], gv[j][2], acc); acc = fmaf(qv[3], gv[j][3], acc);
+    }
+  }
+  for (; c < D; c += 4) {
+    const f32x4 gv = *(const f32x4*)(g + c);
+    const f32x4 qv = *(const f32x4*)(qrow + c);
+    acc = fmaf(qv[0], gv[0], acc); acc = fmaf(qv[1], gv[1], acc); acc = fmaf(qv[2], gv[2], acc); acc = fmaf(qv[3], gv[3], acc);
+  }
+  return acc + 0.0f;
+}
+
+#define CW_KEYS 1024
+__global__ __launch_bounds__(256) void cbir_rank_wave_kernel(const float* __restrict__ Q, const float* __restrict__ G, int D, long idx_base,
+                                                             CbirCand cand, long nq, int k, float* __restrict__ thr, float* __restrict__ out_score,
+                                                             long long* __restrict__ out_idx, int write_out, unsigned* __restrict__ carry) {
+  __shared__ unsigned long long keys_all[4][CW_KEYS];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long q = (long)blockIdx.x * 4 + w;
+  if (q >= nq) return;   // wave-uniform
+  unsigned long long* K = keys_all[w];
+  unsigned n_total = cand.cnt[q];
+  if ((long)n_total > cand.cap) n_total = (unsigned)cand.cap;
+  const unsigned exact_upto = Q ? carry[q] : n_total;   // entries below this index already hold exact scores
+  const float thr_q = thr[q];
+  float* cs = cand.score + q * cand.cap;
+  int* ci = cand.idx + q * cand.cap;
+  int keep = 64; while (keep < k) keep <<= 1;   // pow2 >= k, <= 256
+  const float* qrow = Q ? Q + q * (long)D : nullptr;
+
+  unsigned consumed = 0, have = 0;
+  if (Q && n_total - exact_upto <= 64 && exact_upto <= (unsigned)k) {
+    // steady state of the prefilter path: entries [0, c0) are the sorted carry, at most 64 new ones follow.  Rank-merge in
+    // registers: every new key is broadcast, each lane counts how many of its carry keys precede it (ballots), no sort.
+    const unsigned c0 = exact_upto;
+    unsigned long long nk = ~0ull;
+    bool v = false;
+    if ((unsigned)lane < n_total - c0) {
+      const int gi = ci[c0 + lane];
+      const float sc = cbir_exact_ip(qrow, G + ((long)gi - idx_base) * (long)D, D);
+      if (!(sc < thr_q)) { nk = cbir_key(sc, gi); v = true; }
+    }
+    const unsigned long long vb = __ballot(v);
+    unsigned long long ck[4];
+    unsigned sh[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const unsigned j = lane + 64 * m;
+      ck[m] = j < c0 ? cbir_key(cs[j], ci[j]) : ~0ull;
+    }
+    unsigned myrank = 0;
+    for (unsigned long long b = vb; b; b &= b - 1) {
+      const int src = __ffsll(b) - 1;
+      const unsigned long long x = __shfl(nk, src);
+      unsigned less = (unsigned)__popcll(__ballot(v && nk < x));
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        less += (unsigned)__popcll(__ballot(ck[m] < x));
+        sh[m] += (unsigned)(x < ck[m]);
+      }
+      if (lane == src) myrank = less;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const unsigned j = lane + 64 * m;
+      if (j < c0 && j + sh[m] < (unsigned)k) K[j + sh[m]] = ck[m];
+    }
+    if (v && myrank < (unsigned)k) K[myrank] = nk;
+    have = c0 + (unsigned)__popcll(vb);
+    if (have > (unsigned)k) have = (unsigned)k;
+    consumed = n_total;
+    VDK_WAVE_LDS_SYNC();
+  }
+  while (consumed < n_total) {
+    unsigned take = n_total - consumed;
+    if (take > CW_KEYS - (unsigned)keep) take = CW_KEYS - (unsigned)keep;
+    const unsigned n = have + take;
+    unsigned sortn = 64; while (sortn < n) sortn <<= 1;
+    unsigned valid = 0;
+    for (unsigned i = lane; i < sortn - have; i += 64) {
+      unsigned long long key = ~0ull;
+      if (i < take) {
+        const unsigned e = consumed + i;
+        const int gi = ci[e];
+        float sc;
+        if (e >= exact_upto) {
+          sc = cbir_exact_ip(qrow, G + ((long)gi - idx_base) * (long)D, D);
+        } else {
+          sc = cs[e];
+        }
+        // a row strictly below the current k-th best can never enter the top-k (ties stay: the index decides)
+        if (!(sc < thr_q)) { key = cbir_key(sc, gi); ++valid; }
+      }
+      K[have + i] = key;
+    }
+    valid = (unsigned)wave_sum((float)valid);   // exact: counts <= 1024
+    VDK_WAVE_LDS_SYNC();
+    for (unsigned size = 2; size <= sortn; size <<= 1)
+      for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+        for (unsigned p = lane; p < (sortn >> 1); p += 64) {
+          const unsigned lo = ((p / stride) * 2 * stride) + (p % stride), hi2 = lo + stride;
+          const bool asc = ((lo & size) == 0);
+          const unsigned long long a = K[lo], b = K[hi2];
+          if ((a > b) == asc) { K[lo] = b; K[hi2] = a; }
+        }
+        VDK_WAVE_LDS_SYNC();
+      }
+    consumed += take;
+    have += valid;
+    if (have > (unsigned)k) have = (unsigned)k;
+  }
+
+  for (unsigned i = lane; i < have; i += 64) {
+    const unsigned long long key = K[i];
+    cs[i] = ord2f(~(unsigned)(key >> 32));
+    ci[i] = (int)(unsigned)(key & 0xffffffffu);
+  }
+  if (lane == 0) {
+    if (carry) carry[q] = have;
+    cand.cnt[q] = have;
+    if (have >= (unsigned)k) thr[q] = fmaxf(thr_q, ord2f(~(unsigned)(K[k - 1] >> 32)));
+  }
+  if (write_out) {
+    for (int i = lane; i < k; i += 64) {
+      if ((unsigned)i < have) {
+        const unsigned long long key = K[i];
+        out_score[q * k + i] = ord2f(~(unsigned)(key >> 32));
+        out_idx[q * k + i] = (long long)(int)(unsigned)(key & 0xffffffffu);
+      } else {
+        out_score[q * k + i] = -3.4028234663852886e38f;
+        out_idx[q * k + i] = -1;
+      }
+    }
+  }
+}
+
+// =====================================================================================================================
+// K13 fast path (D <= 128): bf16-MFMA candidate pre-filter with a RIGOROUS error bound + exact fp32 re-scoring.
+//   * gallery and queries are additionally kept as bf16 rows padded to 128 columns (Gb built once per index).
+//   * approximate score s' = sum_k bf16(q_k) * bf16(g_k) (exact products, fp32 accumulation).  With delta = 2^-8 the relative
+//     rounding error of RNE to bf16:  |s' - s| <= (2 delta + delta^2) * sum |q_k||g_k| + accumulation <= EPS_REL * ||q|| * max_n ||g_n||,
+//     EPS_REL = 0.00786 (2^-7 + 2^-16 + 128 * 2^-24 rounded up).
+//   * a row can only belong to the final top-k if its exact score beats the current exact k-th best `thr`; such a row has
+//     s' > thr - eps_q, so the filter `s' > thr - eps_q` never drops a true member.  Survivors (a few thousand per query over
+//     the whole scan) get their EXACT score from the same k-ordered fmaf chain as the oracle (cbir_rescore_kernel) before
+//     the select kernel ranks them -> results are bit-identical to the exact scan, at bf16 MFMA speed.
+#define CF_EPS_REL 0.00786f
+#define CF_BQ 512
+#define CF_BG 128
+#define CF_E 6144
+#define CF_EFLUSH 4096
+
+// Qb / Gb rows: bf16 [rows, 128] (zero padded); norms: ||row||_2 of the fp32 source
+__global__ __launch_bounds__(256) void cbir_cast_rows_kernel(const float* __restrict__ x, long n, int D, bf16_t* __restrict__ xb, float* __restrict__ norms) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  float s = 0.f;
+  for (int c = lane * 2; c < 128; c += 128) {
+    float a = c < D ? x[row * (long)D + c] : 0.f, b = c + 1 < D ? x[row * (long)D + c + 1] : 0.f;
+    s = fmaf(a, a, s); s = fmaf(b, b, s);
+    *(unsigned*)(xb + row * 128 + c) = pack_bf2(a, b);
+  }
+  s = wave_sum(s);
+  if (lane == 0 && norms) norms[row] = sqrtf(s) * 1.0000002f;   // never under-estimate
+}
+__global__ __launch_bounds__(256) void cbir_max_kernel(const float* __restrict__ v, long n, unsigned* __restrict__ out_bits) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, v[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));   // non-negative floats order like their bit patterns
+}
+
+// grid: id -> split = id % nsplit, qblock = id / nsplit.  512 threads = 8 waves; wave w owns 64 queries (two 32-wide column
+// tiles whose bf16 fragments stay in 64 VGPRs for the whole scan) and scores them against all 128 rows of every gallery
+// tile, 64 rows at a time.  Gallery tiles arrive by LDS-DMA into a 3-deep ring (two tiles = 64 KB in flight while one is
+// consumed): the DMA has ~2 us latency under load, so depth, not bandwidth, is what keeps the MFMAs fed.
+//
+// BOOT = true is the threshold bootstrap: no candidates are produced, the kernel only reports, per query, the largest
+// approximate score of every 128-row tile of a gallery sample (gm[q][tile]).  The k-th largest of these G >= k group maxima,
+// minus eps_q, is a lower bound of the exact k-th best score (k distinct rows reach it), i.e. a valid filter threshold before
+// any row is ranked: the scan starts with a tight cut instead of a pass-everything ramp (cbir_boot_thr_kernel).
+#define CF_NBUF 3
+template <bool BOOT>
+__global__ __launch_bounds__(512) void cbir_prefilter_kernel(const bf16_t* __restrict__ Qb, const float* __restrict__ qnorm, long nq,
+                                                             const bf16_t* __restrict__ Gb, const unsigned* __restrict__ gmax_bits, long g_begin,
+                                                             long g_end, long rows_per_split, int nsplit, long idx_base,
+                                                             const float* __restrict__ thr, CbirCand cand, float* __restrict__ gm, long gm_ld) {
+  __shared__ __attribute__((aligned(16))) unsigned char Gs[CF_NBUF * CF_BG * 256];   // 3 x 32 KB
+  __shared__ int e_idx[CF_E];
+  __shared__ unsigned short e_q[CF_E];
+  __shared__ unsigned s_cnt;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int split = blockIdx.x % nsplit;
+  const long q0 = (long)(blockIdx.x / nsplit) * CF_BQ;
+  const long r_begin = g_begin + (long)split * rows_per_split;
+  long r_end = r_begin + rows_per_split;
+  if (r_end > g_end) r_end = g_end;
+  if (tid == 0) s_cnt = 0;
+  if (r_begin >= r_end) return;
+
+  s16x8 qf[2][8];
+  float cut[2];
+  const float gmax = __uint_as_float(gmax_bits[0]);
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const long q = q0 + w * 64 + qt * 32 + l31;
+    const bool ok = q < nq;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      s16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ok) v = *(const s16x8*)(Qb + q * 128 + ks * 16 + hi * 8);
+      qf[qt][ks] = v;
+    }
+    // pass <=> s' > thr - eps_q ; +inf for padding queries
+    cut[qt] = (ok && !BOOT) ? thr[q] - CF_EPS_REL * qnorm[q] * gmax : __uint_as_float(0x7f800000u);
+  }
+  float bm[2] = {__uint_as_float(0xff800000u), __uint_as_float(0xff800000u)};
+
+  const long ntile = (r_end - r_begin + CF_BG - 1) / CF_BG;
+  // DMA one 128-row tile (4 x 1 KB per wave): LDS slot (row, cp) holds chunk cp ^ (row & 15) of that row
+#define CF_ISSUE(buf, t)                                                                                                  \
+  do {                                                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                        \
+      const int L = j * 512 + w * 64 + lane;                                                                              \
+      const int row = L >> 4, cp = L & 15, c = cp ^ (row & 15);                                                           \
+      long grow = r_begin + (long)(t) * CF_BG + row;                                                                      \
+      if (grow > r_end - 1) grow = r_end - 1;                                                                             \
+      const bf16_t* src = Gb + grow * 128 + c * 8;                                                                        \
+      unsigned char* dst = Gs + (buf) * (CF_BG * 256) + (j * 512 + w * 64) * 16;                                          \
+      __builtin_amdgcn_global_load_lds(VDK_GLOBAL_PTR(src), VDK_LDS_PTR(dst), 16, 0, 0);                                   \
+    }                                                                                                                     \
+  } while (0)
+  CF_ISSUE(0, 0);
+  if (ntile > 1) CF_ISSUE(1, 1);
+  if (ntile > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | 4); else __builtin_amdgcn_s_waitcnt(0x0F70);   // tile 0 landed
+  __syncthreads();
+  int cur = 0;
+  for (long t = 0; t < ntile; ++t) {
+    // ring slot (cur + 2) % 3 was consumed during iteration t - 1 (everybody passed the barrier that ended it)
+    int nxt2 = cur + 2; if (nxt2 >= CF_NBUF) nxt2 -= CF_NBUF;
+    if (t + 2 < ntile) CF_ISSUE(nxt2, t + 2);
+    const unsigned char* Gt = Gs + cur * (CF_BG * 256);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        s16x8 af[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const int row = h * 64 + rt * 32 + l31;
+          af[rt] = *(const s16x8*)(Gt + row * 256 + (((ks * 2 + hi) ^ (row & 15)) * 16));
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) acc[rt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt], qf[qt][ks], acc[rt][qt], 0, 0, 0);
+      }
+      // cheap reject: per 32x32 block the lane's maximum against its cut; the survivors' slow path is rare after the first stages
+      const long row0 = r_begin + t * CF_BG + h * 64;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          float m = acc[rt][qt][0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rt][qt][r]);
+          if (BOOT) {
+            bm[qt] = fmaxf(bm[qt], m);   // rows past r_end are copies of row r_end - 1 (clamped DMA): the maximum is unaffected
+            if (h == 1 && rt == 1) {     // tile complete: one group maximum per (query, 128-row tile)
+              const float tm = fmaxf(bm[qt], __shfl_xor(bm[qt], 32));
+              const long q = q0 + w * 64 + qt * 32 + l31;
+              if (hi == 0 && q < nq) gm[q * gm_ld + (r_begin - g_begin) / CF_BG + t] = tm;
+              bm[qt] = __uint_as_float(0xff800000u);
+            }
+          } else if (__any(m > cut[qt])) {
+            // only the lanes that own a survivor run this; their slot requests go out as ONE ds_add_rtn (the LDS unit
+            // serialises the active lanes), no cross-lane traffic on the wave's critical path
+            if (m > cut[qt]) {
+              unsigned pm = 0;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) pm |= (unsigned)(acc[rt][qt][r] > cut[qt]) << r;
+              if (t == ntile - 1) {   // ragged last tile: rows past r_end are clamped copies
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                  if (row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= r_end) pm &= ~(1u << r);
+              }
+              unsigned pos = atomicAdd(&s_cnt, (unsigned)__popc(pm));
+              const unsigned short ql = (unsigned short)(w * 64 + qt * 32 + l31);
+              while (pm) {
+                const int r = __ffs(pm) - 1;
+                pm &= pm - 1;
+                const int gidx = (int)(idx_base + row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
+                if (pos < CF_E) { e_idx[pos] = gidx; e_q[pos] = ql; }
+                else cbir_global_append(cand, q0 + ql, 0.f, gidx);
+                ++pos;
+              }
+            }
+          }
+        }
+    }
+    // tile t + 1 must have landed: only tile t + 2's four DMAs may still be in flight
+    if (t + 2 < ntile) __builtin_amdgcn_s_waitcnt(0x0F70 | 4); else __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    unsigned n = s_cnt;
+    if (n >= CF_EFLUSH || t == ntile - 1) {
+      if (n > CF_E) n = CF_E;
+      for (unsigned i = tid; i < n; i += 512) cbir_global_append(cand, q0 + e_q[i], 0.f, e_idx[i]);
+      __syncthreads();
+      if (tid == 0) s_cnt = 0;
+      __syncthreads();
+    }
+    cur = cur + 1 == CF_NBUF ? 0 : cur + 1;
+  }
+#undef CF_ISSUE
+}
+
+// thr[q] = (k-th largest of the G group maxima) - eps_q (see BOOT above).  One workgroup per query, bitonic sort in LDS.
+#define CF_BOOT_MAXG 4096
+__global__ __launch_bounds__(256) void cbir_boot_thr_kernel(const float* __restrict__ gm, int G, int k, const float* __restrict__ qnorm,
+                                                            const unsigned* __restrict__ gmax_bits, float* __restrict__ thr) {
+  __shared__ unsigned keys[CF_BOOT_MAXG];
+  const long q = blockIdx.x;
+  const int tid = threadIdx.x;
+  unsigned sortn = 64; while (sortn < (unsigned)G) sortn <<= 1;
+  for (unsigned i = tid; i < sortn; i += 256) keys[i] = i < (unsigned)G ? ~f2ord(gm[q * G + i]) : 0xffffffffu;   // ascending key = descending score
+  __syncthreads();
+  for (unsigned size = 2; size <= sortn; size <<= 1)
+    for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+      for (unsigned p = tid; p < (sortn >> 1); p += 256) {
+        const unsigned lo = ((p / stride) * 2 * stride) + (p % stride), hi2 = lo + stride;
+        const bool asc = ((lo & size) == 0);
+        const unsigned a = keys[lo], b = keys[hi2];
+        if ((a > b) == asc) { keys[lo] = b; keys[hi2] = a; }
+      }
+      __syncthreads();
+    }
+  if (tid == 0) thr[q] = ord2f(~keys[k - 1]) - CF_EPS_REL * qnorm[q] * __uint_as_float(gmax_bits[0]);
+}
+
+// exact scores of the new candidates of every query: entries [carry[q], cnt[q]) of its list.  One workgroup per query; one
+// candidate per thread, k-ordered fmaf chain from +0 (bit-identical to oracle_ip_pair and to the fp32-MFMA scan).
+__global__ __launch_bounds__(256) void cbir_rescore_kernel(const float* __restrict__ Q, const float* __restrict__ G, int D, long idx_base, CbirCand cand,
+                                                           const unsigned* __restrict__ carry) {
+  __shared__ __attribute__((aligned(16))) float qs[512];
+  const long q = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += 256) qs[c] = Q[q * (long)D + c];
+  __syncthreads();
+  unsigned n = cand.cnt[q];
+  if ((long)n > cand.cap) n = (unsigned)cand.cap;
+  for (unsigned i = carry[q] + threadIdx.x; i < n; i += 256) {
+    cand.score[q * cand.cap + i] = cbir_exact_ip(qs, G + ((long)cand.idx[q * cand.cap + i] - idx_base) * (long)D, D);
   }
 }
 
@@ -307,6 +692,19 @@ int vdk_l2norm_rows(const float* x, float* out, int64_t n, int32_t d, float eps,
   hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, out,
                      (long)n, (int)d, eps);
   return vdk_check_launch("l2norm_rows_kernel");
+}
+
+// rank every query's candidate list: wave-per-query kernel for k <= 256, workgroup-per-query kernels above.
+// Q != nullptr: entries [carry[q], cnt[q]) carry only an index and are re-scored exactly first (prefilter path).
+static void cb_rank(hipStream_t stream, const float* Q, const float* G, int D, long idx_base, const CbirCand& cand, long nq, int k, float* thr,
+                    float* out_scores, long long* out_idx, int write_out, unsigned* carry) {
+  if (k <= 256) {
+    hipLaunchKernelGGL(cbir_rank_wave_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, Q, G, D, idx_base, cand, nq, k, thr, out_scores, out_idx,
+                       write_out, carry);
+  } else {
+    if (Q) hipLaunchKernelGGL(cbir_rescore_kernel, dim3((unsigned)nq), dim3(256), 0, stream, Q, G, D, idx_base, cand, (const unsigned*)carry);
+    hipLaunchKernelGGL(cbir_select_kernel, dim3((unsigned)nq), dim3(256), 0, stream, cand, nq, k, thr, out_scores, out_idx, write_out, carry);
+  }
 }
 
 static inline size_t cb_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -369,16 +767,103 @@ int vdk_cbir_search(const float* Q, int64_t nq, const float* G, int64_t N, int32
     long rps = ((tiles + nsplit - 1) / nsplit) * CB_BG;
     hipLaunchKernelGGL(cbir_score_filter_kernel, dim3((unsigned)(qblocks * nsplit)), dim3(512), 0, stream, Q, (long)nq, G,
                        (int)D, begin, end, rps, nsplit, (long)idx_base, (const float*)thr, cand);
-    hipLaunchKernelGGL(cbir_select_kernel, dim3((unsigned)nq), dim3(256), 0, stream, cand, (long)nq, (int)k, thr,
-                       out_scores, (long long*)out_idx, (int)(end == N));
+    cb_rank(stream, nullptr, nullptr, 0, 0, cand, (long)nq, (int)k, thr, out_scores, (long long*)out_idx, (int)(end == N), nullptr);
     begin = end;
     stage *= 8;
     if (stage > max_stage) stage = max_stage;
   }
   if (N == 0)
-    hipLaunchKernelGGL(cbir_select_kernel, dim3((unsigned)nq), dim3(256), 0, stream, cand, (long)nq, (int)k, thr, out_scores,
-                       (long long*)out_idx, 1);
+    cb_rank(stream, nullptr, nullptr, 0, 0, cand, (long)nq, (int)k, thr, out_scores, (long long*)out_idx, 1, nullptr);
   return vdk_check_launch("vdk_cbir_search");
+}
+
+// ---- fast path host side -----------------------------------------------------------------------------------------------
+// Per-index preparation (IndexFlatIP.add time, not per search): Gb = bf16 [N, 128] zero-padded copy of G, gmax_bits[0] = bit
+// pattern of max_n ||G[n]|| (a float >= 0).  gnorm_ws: f32 [N] scratch.
+int vdk_cbir_prepare_gallery(const float* G, int64_t N, int32_t D, void* Gb, float* gnorm_ws, uint32_t* gmax_bits, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if ((!G && N > 0) || !Gb || !gnorm_ws || !gmax_bits || N < 0 || D <= 0 || D > 128) return vdk_fail(VDK_EINVAL, "vdk_cbir_prepare_gallery: bad argument (D <= 128)");
+  if (hipMemsetAsync(gmax_bits, 0, 4, stream) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vdk_cbir_prepare_gallery: memset failed");
+  if (N == 0) return VDK_OK;
+  hipLaunchKernelGGL(cbir_cast_rows_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, G, (long)N, (int)D, (bf16_t*)Gb, gnorm_ws);
+  hipLaunchKernelGGL(cbir_max_kernel, dim3(256), dim3(256), 0, stream, (const float*)gnorm_ws, (long)N, (unsigned*)gmax_bits);
+  return vdk_check_launch("vdk_cbir_prepare_gallery");
+}
+
+int vdk_cbir_fast_workspace_bytes(int64_t nq, int32_t k, int64_t cap, size_t* bytes) {
+  size_t b = 0;
+  int rc = vdk_cbir_workspace_bytes(nq, k, cap, &b);
+  if (rc) return rc;
+  b += cb_align((size_t)nq * 128 * 2);   // Qb
+  b += cb_align((size_t)nq * 4);         // query norms
+  b += cb_align((size_t)nq * 4);         // carry
+  b += cb_align((size_t)nq * CF_BOOT_MAXG * 4 < (size_t)nq * 4 * k * 4 ? (size_t)nq * CF_BOOT_MAXG * 4 : (size_t)nq * 4 * k * 4);   // bootstrap group maxima [nq, G <= min(4k, 4096)]
+  *bytes = b;
+  return VDK_OK;
+}
+
+// Same contract and bit-identical results as vdk_cbir_search, for D <= 128: bf16 pre-filter + exact re-scoring.
+int vdk_cbir_search_fast(const float* Q, int64_t nq, const float* G, const void* Gb, const uint32_t* gmax_bits, int64_t N, int32_t D, int32_t k,
+                         int64_t idx_base, float* out_scores, int64_t* out_idx, int64_t cap, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!Q || (!G && N > 0) || (!Gb && N > 0) || !gmax_bits || !out_scores || !out_idx || nq < 0 || N < 0 || D <= 0 || D > 128 || (D & 3) || k <= 0 || k > 1024)
+    return vdk_fail(VDK_EINVAL, "vdk_cbir_search_fast: bad argument (need D % 4 == 0, D <= 128, 1 <= k <= 1024)");
+  if (idx_base + N > 0x7fffffffLL) return vdk_fail(VDK_EINVAL, "vdk_cbir_search_fast: index range exceeds int32");
+  if (nq == 0) return VDK_OK;
+  size_t need = 0;
+  int rc = vdk_cbir_fast_workspace_bytes(nq, k, cap, &need);
+  if (rc) return rc;
+  if (!ws || ws_bytes < need) return vdk_fail(VDK_EWORKSPACE, "vdk_cbir_search_fast: workspace too small");
+  CbirCand cand; float* thr;
+  rc = cb_carve(ws, ws_bytes, nq, k, cap, &cand, &thr);
+  if (rc) return rc;
+  size_t base_bytes = 0; vdk_cbir_workspace_bytes(nq, k, cap, &base_bytes);
+  char* p = (char*)ws + base_bytes;
+  bf16_t* Qb = (bf16_t*)p; p += cb_align((size_t)nq * 128 * 2);
+  float* qnorm = (float*)p; p += cb_align((size_t)nq * 4);
+  unsigned* carry = (unsigned*)p; p += cb_align((size_t)nq * 4);
+  float* gm = (float*)p;
+  hipLaunchKernelGGL(cbir_init_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, cand.cnt, thr, cand.overflow, (long)nq);
+  if (hipMemsetAsync(carry, 0, (size_t)nq * 4, stream) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vdk_cbir_search_fast: memset failed");
+  hipLaunchKernelGGL(cbir_cast_rows_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, Q, (long)nq, (int)D, Qb, qnorm);
+  const long qblocks = (long)((nq + CF_BQ - 1) / CF_BQ);
+  const long max_stage = cap - k;
+  long begin = 0, stage = 512;
+  // threshold bootstrap on a sample of NG full 128-row tiles, k <= NG <= min(4k, 4096)
+  long NG = N / CF_BG;
+  if (NG > 4L * k) NG = 4L * k;
+  if (NG > CF_BOOT_MAXG) NG = CF_BOOT_MAXG;
+  if (NG >= k) {
+    long ns = 256 / qblocks;
+    if (ns > NG / 4) ns = NG / 4;
+    if (ns < 1) ns = 1;
+    const long rps = ((NG + ns - 1) / ns) * CF_BG;
+    hipLaunchKernelGGL(cbir_prefilter_kernel<true>, dim3((unsigned)(qblocks * ns)), dim3(512), 0, stream, (const bf16_t*)Qb, (const float*)qnorm, (long)nq,
+                       (const bf16_t*)Gb, (const unsigned*)gmax_bits, 0L, NG * CF_BG, rps, (int)ns, (long)idx_base, (const float*)thr, cand, gm, NG);
+    hipLaunchKernelGGL(cbir_boot_thr_kernel, dim3((unsigned)nq), dim3(256), 0, stream, (const float*)gm, (int)NG, (int)k, (const float*)qnorm,
+                       (const unsigned*)gmax_bits, thr);
+    stage = max_stage;   // the cut is already tight: no ramp
+  }
+  if (stage > max_stage) stage = max_stage;
+  while (begin < N) {
+    long end = begin + stage; if (end > N) end = N;
+    const long rows = end - begin, tiles = (rows + CF_BG - 1) / CF_BG;
+    // one round of workgroups over the 256 CUs: qblocks * nsplit <= 256, every split at least 4 tiles long
+    long nsplit_l = 256 / qblocks;
+    if (nsplit_l > tiles / 4) nsplit_l = tiles / 4;
+    if (nsplit_l < 1) nsplit_l = 1;
+    const int nsplit = (int)nsplit_l;
+    const long rps = ((tiles + nsplit - 1) / nsplit) * CF_BG;
+    hipLaunchKernelGGL(cbir_prefilter_kernel<false>, dim3((unsigned)(qblocks * nsplit)), dim3(512), 0, stream, (const bf16_t*)Qb, (const float*)qnorm, (long)nq,
+                       (const bf16_t*)Gb, (const unsigned*)gmax_bits, begin, end, rps, nsplit, (long)idx_base, (const float*)thr, cand, (float*)nullptr, 0L);
+    cb_rank(stream, Q, G, (int)D, (long)idx_base, cand, (long)nq, (int)k, thr, out_scores, (long long*)out_idx, (int)(end == N), carry);
+    begin = end;
+    stage *= 8;
+    if (stage > max_stage) stage = max_stage;
+  }
+  if (N == 0)
+    cb_rank(stream, Q, G, (int)D, (long)idx_base, cand, (long)nq, (int)k, thr, out_scores, (long long*)out_idx, 1, carry);
+  return vdk_check_launch("vdk_cbir_search_fast");
 }
 
 // Merge S per-shard results (scores [S,nq,k], idx [S,nq,k], -1 = empty) into the global top-k with the
@@ -396,8 +881,7 @@ int vdk_cbir_merge_topk(const float* scores, const int64_t* idx, int32_t S, int6
                      cand.overflow, (long)nq);
   hipLaunchKernelGGL(cbir_fill_from_lists_kernel, dim3((unsigned)nq), dim3(256), 0, stream, cand, scores,
                      (const long long*)idx, (int)S, (long)nq, (int)k);
-  hipLaunchKernelGGL(cbir_select_kernel, dim3((unsigned)nq), dim3(256), 0, stream, cand, (long)nq, (int)k, thr, out_scores,
-                     (long long*)out_idx, 1);
+  cb_rank(stream, nullptr, nullptr, 0, 0, cand, (long)nq, (int)k, thr, out_scores, (long long*)out_idx, 1, nullptr);
   return vdk_check_launch("vdk_cbir_merge_topk");
 }
 

@@ -40,6 +40,11 @@ __device__ __forceinline__ s16x8 tr_frag8(const bf16_t* tile, int pitch, int t1,
 
 // pin two MFMA accumulators at a program point: the compiler may not move their producers below / consumers above it
 // (hipcc sinks register-only MFMAs across sched_barrier; cdna_hip_programming.md §5.7 item 3)
+// wave-synchronous LDS hand-off: the LDS unit executes one wave's ds ops in issue order, so a lane's ds_write is visible to
+// the next ds_read of any lane of the SAME wave; only the compiler has to be kept from reordering across the point.
+#ifndef VDK_WAVE_LDS_SYNC
+#define VDK_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
 #ifndef VDK_PIN2
 #define VDK_PIN2(x, y) asm volatile("" : "+v"(x), "+v"(y))
 #endif
