@@ -57,9 +57,10 @@ int vdk_cbir_workspace_bytes(int64_t nq, int32_t k, int64_t cap, size_t* bytes);
 int vdk_cbir_search(const float* Q, int64_t nq, const float* G, int64_t N, int32_t D, int32_t k, int64_t idx_base,
                     float* out_scores, int64_t* out_idx, int64_t cap, void* ws, size_t ws_bytes, void* stream);
 /* Fast path of the same search for D <= 128 (bit-identical results): a bf16-MFMA pre-filter with the rigorous bound
- * |s' - s| <= 0.00786 * ||q|| * max||g|| keeps every row that could still enter the top-k; only those survivors (a few thousand
- * per query) get the exact fp32 fmaf-chain score before ranking.  vdk_cbir_prepare_gallery runs once per index (add time):
- * Gb = bf16 [N, 128] zero-padded copy, gmax_bits = bits of max_n ||G[n]||, gnorm_ws = f32 [N] scratch. */
+ * |s' - s| <= ||q~-q|| max||g~|| + ||q|| max||g~-g|| (+ accumulation), all norms measured, keeps every row that could still enter the
+ * top-k; only those survivors (about a thousand per query) get the exact fp32 fmaf-chain score before ranking.
+ * vdk_cbir_prepare_gallery runs once per index (add time): Gb = bf16 [N, 128] zero-padded copy, gmax_bits = uint32[4] receiving the
+ * bits of max_n (||g||, ||g~||, ||g~-g||), gnorm_ws = f32 [3N] scratch. */
 int vdk_cbir_prepare_gallery(const float* G, int64_t N, int32_t D, void* Gb, float* gnorm_ws, uint32_t* gmax_bits, void* stream);
 int vdk_cbir_fast_workspace_bytes(int64_t nq, int32_t k, int64_t cap, size_t* bytes);
 int vdk_cbir_search_fast(const float* Q, int64_t nq, const float* G, const void* Gb, const uint32_t* gmax_bits, int64_t N, int32_t D, int32_t k,

@@ -107,8 +107,8 @@ class FlatIPIndex:
             return
         be, n = self.be, g.shape[0]
         self._gb = torch.empty((max(n, 1), 128), dtype=torch.bfloat16, device=self.device)
-        self._gmax = torch.zeros(1, dtype=torch.int32, device=self.device)
-        norms = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
+        self._gmax = torch.zeros(4, dtype=torch.int32, device=self.device)
+        norms = torch.empty(3 * max(n, 1), dtype=torch.float32, device=self.device)
         be.check(be.lib.vdk_cbir_prepare_gallery(be.ptr(g) if n else None, n, self._dp, be.ptr(self._gb), be.ptr(norms),
                                                  be.ptr(self._gmax), be.stream()), "vdk_cbir_prepare_gallery")
 

@@ -435,38 +435,55 @@ __global__ __launch_bounds__(256) void cbir_rank_wave_kernel(const float* __rest
 // =====================================================================================================================
 // K13 fast path (D <= 128): bf16-MFMA candidate pre-filter with a RIGOROUS error bound + exact fp32 re-scoring.
 //   * gallery and queries are additionally kept as bf16 rows padded to 128 columns (Gb built once per index).
-//   * approximate score s' = sum_k bf16(q_k) * bf16(g_k) (exact products, fp32 accumulation).  With delta = 2^-8 the relative
-//     rounding error of RNE to bf16:  |s' - s| <= (2 delta + delta^2) * sum |q_k||g_k| + accumulation <= EPS_REL * ||q|| * max_n ||g_n||,
-//     EPS_REL = 0.00786 (2^-7 + 2^-16 + 128 * 2^-24 rounded up).
+//   * approximate score s' = sum_k q~_k g~_k with q~ = bf16(q), g~ = bf16(g) (products exact in fp32, fp32 accumulation).
+//     Exactly:  s' - s = sum (q~ - q) g~ + sum q (g~ - g),  so by Cauchy-Schwarz
+//         |s' - s| <= ||q~ - q|| * max_n ||g~_n||  +  ||q|| * max_n ||g~_n - g_n||  +  acc,
+//     where the rounding-error norms are MEASURED per row by the cast kernel (typically 0.0016 ||x||, against the worst case
+//     2^-8 ||x||) and acc <= 4e-5 ||q~|| max ||g~|| covers the MFMA's fp32 accumulation (128 terms x 2^-24, 5x margin).
+//     All norms are rounded up (x 1.000002).
 //   * a row can only belong to the final top-k if its exact score beats the current exact k-th best `thr`; such a row has
 //     s' > thr - eps_q, so the filter `s' > thr - eps_q` never drops a true member.  Survivors (a few thousand per query over
 //     the whole scan) get their EXACT score from the same k-ordered fmaf chain as the oracle (cbir_rescore_kernel) before
 //     the select kernel ranks them -> results are bit-identical to the exact scan, at bf16 MFMA speed.
-#define CF_EPS_REL 0.00786f
 #define CF_BQ 512
 #define CF_BG 128
-#define CF_E 6144
-#define CF_EFLUSH 4096
+#define CF_WE 768      // staged survivors per wave
 
-// Qb / Gb rows: bf16 [rows, 128] (zero padded); norms: ||row||_2 of the fp32 source
-__global__ __launch_bounds__(256) void cbir_cast_rows_kernel(const float* __restrict__ x, long n, int D, bf16_t* __restrict__ xb, float* __restrict__ norms) {
+// Qb / Gb rows: bf16 [rows, 128] (zero padded); norms3[row] = (||x||, ||bf16(x)||, ||bf16(x) - x||), each rounded up
+__global__ __launch_bounds__(256) void cbir_cast_rows_kernel(const float* __restrict__ x, long n, int D, bf16_t* __restrict__ xb, float* __restrict__ norms3) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
-  float s = 0.f;
-  for (int c = lane * 2; c < 128; c += 128) {
-    float a = c < D ? x[row * (long)D + c] : 0.f, b = c + 1 < D ? x[row * (long)D + c + 1] : 0.f;
-    s = fmaf(a, a, s); s = fmaf(b, b, s);
-    *(unsigned*)(xb + row * 128 + c) = pack_bf2(a, b);
+  const int c = lane * 2;
+  const float a = c < D ? x[row * (long)D + c] : 0.f, b = c + 1 < D ? x[row * (long)D + c + 1] : 0.f;
+  const unsigned pk = pack_bf2(a, b);
+  *(unsigned*)(xb + row * 128 + c) = pk;
+  const float at = __uint_as_float(pk << 16), bt = __uint_as_float(pk & 0xffff0000u);
+  const float ea = at - a, eb = bt - b;   // exact (Sterbenz) or a correctly rounded difference: error << the 2e-6 margin
+  float sx = fmaf(b, b, a * a), st = fmaf(bt, bt, at * at), se = fmaf(eb, eb, ea * ea);
+  sx = wave_sum(sx); st = wave_sum(st); se = wave_sum(se);
+  if (lane == 0) {
+    norms3[row * 3 + 0] = sqrtf(sx) * 1.000002f;
+    norms3[row * 3 + 1] = sqrtf(st) * 1.000002f;
+    norms3[row * 3 + 2] = sqrtf(se) * 1.000002f;
   }
-  s = wave_sum(s);
-  if (lane == 0 && norms) norms[row] = sqrtf(s) * 1.0000002f;   // never under-estimate
 }
-__global__ __launch_bounds__(256) void cbir_max_kernel(const float* __restrict__ v, long n, unsigned* __restrict__ out_bits) {
-  float m = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, v[i]);
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));   // non-negative floats order like their bit patterns
+// out_bits[j] = bits of max_row norms3[row][j]  (non-negative floats order like their bit patterns)
+__global__ __launch_bounds__(256) void cbir_max3_kernel(const float* __restrict__ v, long n, unsigned* __restrict__ out_bits) {
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    m0 = fmaxf(m0, v[i * 3]); m1 = fmaxf(m1, v[i * 3 + 1]); m2 = fmaxf(m2, v[i * 3 + 2]);
+  }
+  m0 = wave_max(m0); m1 = wave_max(m1); m2 = wave_max(m2);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(out_bits, __float_as_uint(m0)); atomicMax(out_bits + 1, __float_as_uint(m1)); atomicMax(out_bits + 2, __float_as_uint(m2));
+  }
+}
+// eps_q of the header comment
+__device__ __forceinline__ float cbir_eps(const float* __restrict__ qn3, long q, const unsigned* __restrict__ gstat_bits) {
+  const float gt = __uint_as_float(gstat_bits[1]), ge = __uint_as_float(gstat_bits[2]);
+  const float qn = qn3[q * 3], qt = qn3[q * 3 + 1], qe = qn3[q * 3 + 2];
+  return 1.00001f * (qe * gt + qn * ge) + 4e-5f * qt * gt;
 }
 
 // grid: id -> split = id % nsplit, qblock = id / nsplit.  512 threads = 8 waves; wave w owns 64 queries (two 32-wide column
@@ -479,29 +496,34 @@ __global__ __launch_bounds__(256) void cbir_max_kernel(const float* __restrict__
 // minus eps_q, is a lower bound of the exact k-th best score (k distinct rows reach it), i.e. a valid filter threshold before
 // any row is ranked: the scan starts with a tight cut instead of a pass-everything ramp (cbir_boot_thr_kernel).
 #define CF_NBUF 3
+#ifndef CF_EXP
+#define CF_EXP 0
+#endif
 template <bool BOOT>
 __global__ __launch_bounds__(512) void cbir_prefilter_kernel(const bf16_t* __restrict__ Qb, const float* __restrict__ qnorm, long nq,
                                                              const bf16_t* __restrict__ Gb, const unsigned* __restrict__ gmax_bits, long g_begin,
                                                              long g_end, long rows_per_split, int nsplit, long idx_base,
                                                              const float* __restrict__ thr, CbirCand cand, float* __restrict__ gm, long gm_ld) {
   __shared__ __attribute__((aligned(16))) unsigned char Gs[CF_NBUF * CF_BG * 256];   // 3 x 32 KB
-  __shared__ int e_idx[CF_E];
-  __shared__ unsigned short e_q[CF_E];
-  __shared__ unsigned s_cnt;
+  // survivors are staged per WAVE (no shared counter, no workgroup barrier): slots come from ballots, flushes are wave-local
+  __shared__ int e_idx[8][CF_WE];
+  __shared__ unsigned short e_rank[8][CF_WE];
+  __shared__ unsigned char e_q[8][CF_WE];
+  __shared__ unsigned f_cnt[8][64], f_base[8][64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
+  const unsigned long long lane_lt = (1ull << lane) - 1ull;
+  unsigned wcnt = 0;   // wave-uniform number of staged survivors
   const int split = blockIdx.x % nsplit;
   const long q0 = (long)(blockIdx.x / nsplit) * CF_BQ;
   const long r_begin = g_begin + (long)split * rows_per_split;
   long r_end = r_begin + rows_per_split;
   if (r_end > g_end) r_end = g_end;
-  if (tid == 0) s_cnt = 0;
   if (r_begin >= r_end) return;
 
   s16x8 qf[2][8];
   float cut[2];
-  const float gmax = __uint_as_float(gmax_bits[0]);
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     const long q = q0 + w * 64 + qt * 32 + l31;
@@ -513,10 +535,32 @@ __global__ __launch_bounds__(512) void cbir_prefilter_kernel(const bf16_t* __res
       qf[qt][ks] = v;
     }
     // pass <=> s' > thr - eps_q ; +inf for padding queries
-    cut[qt] = (ok && !BOOT) ? thr[q] - CF_EPS_REL * qnorm[q] * gmax : __uint_as_float(0x7f800000u);
+    cut[qt] = (ok && !BOOT) ? thr[q] - cbir_eps(qnorm, q, gmax_bits) : __uint_as_float(0x7f800000u);
   }
   float bm[2] = {__uint_as_float(0xff800000u), __uint_as_float(0xff800000u)};
 
+  // wave-local flush of the staged survivors: rank every entry inside its query with LDS atomics, reserve each query's slots
+  // with ONE global atomic per lane (lane L <-> the wave's L-th query), then scatter.  Wave-synchronous, no workgroup barrier.
+#define CF_FLUSH()                                                                                                        \
+  do {                                                                                                                    \
+    f_cnt[w][lane] = 0;                                                                                                   \
+    VDK_WAVE_LDS_SYNC();                                                                                                  \
+    for (unsigned i_ = lane; i_ < wcnt; i_ += 64) e_rank[w][i_] = (unsigned short)atomicAdd(&f_cnt[w][e_q[w][i_]], 1u);      \
+    VDK_WAVE_LDS_SYNC();                                                                                                  \
+    {                                                                                                                     \
+      const unsigned c_ = f_cnt[w][lane];                                                                                 \
+      f_base[w][lane] = c_ ? atomicAdd(&cand.cnt[q0 + w * 64 + lane], c_) : 0u;                                           \
+    }                                                                                                                     \
+    VDK_WAVE_LDS_SYNC();                                                                                                  \
+    for (unsigned i_ = lane; i_ < wcnt; i_ += 64) {                                                                       \
+      const unsigned ql_ = e_q[w][i_];                                                                                    \
+      const long pos_ = (long)f_base[w][ql_] + e_rank[w][i_];                                                             \
+      if (pos_ < cand.cap) cand.idx[(q0 + w * 64 + ql_) * cand.cap + pos_] = e_idx[w][i_];                                \
+      else atomicOr(cand.overflow, 1u);                                                                                   \
+    }                                                                                                                     \
+    VDK_WAVE_LDS_SYNC();                                                                                                  \
+    wcnt = 0;                                                                                                             \
+  } while (0)
   const long ntile = (r_end - r_begin + CF_BG - 1) / CF_BG;
   // DMA one 128-row tile (4 x 1 KB per wave): LDS slot (row, cp) holds chunk cp ^ (row & 15) of that row
 #define CF_ISSUE(buf, t)                                                                                                  \
@@ -539,8 +583,16 @@ __global__ __launch_bounds__(512) void cbir_prefilter_kernel(const bf16_t* __res
   for (long t = 0; t < ntile; ++t) {
     // ring slot (cur + 2) % 3 was consumed during iteration t - 1 (everybody passed the barrier that ended it)
     int nxt2 = cur + 2; if (nxt2 >= CF_NBUF) nxt2 -= CF_NBUF;
+#if CF_EXP != 2
     if (t + 2 < ntile) CF_ISSUE(nxt2, t + 2);
+#endif
     const unsigned char* Gt = Gs + cur * (CF_BG * 256);
+    // A fragments run two k-steps ahead of the MFMAs that consume them (hipcc alone emits read -> wait -> 4 MFMAs per k-step,
+    // exposing the LDS latency 16 times per tile); the first two of the second half are fetched before the first half's filter
+#define CF_ALD(hh, ks, rt) (*(const s16x8*)(Gt + ((hh) * 64 + (rt) * 32 + l31) * 256 + ((((ks) * 2 + hi) ^ (l31 & 15)) * 16)))
+    s16x8 af[3][2];
+    af[0][0] = CF_ALD(0, 0, 0); af[0][1] = CF_ALD(0, 0, 1);
+    af[1][0] = CF_ALD(0, 1, 0); af[1][1] = CF_ALD(0, 1, 1);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       f32x16 acc[2][2];
@@ -552,16 +604,18 @@ __global__ __launch_bounds__(512) void cbir_prefilter_kernel(const bf16_t* __res
           for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        s16x8 af[2];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          const int row = h * 64 + rt * 32 + l31;
-          af[rt] = *(const s16x8*)(Gt + row * 256 + (((ks * 2 + hi) ^ (row & 15)) * 16));
+        const int step = h * 8 + ks;           // 0..15 over the tile
+        if (step + 2 < 16) {
+          const int nh = (step + 2) >> 3, nks = (step + 2) & 7;
+          af[(step + 2) % 3][0] = CF_ALD(nh, nks, 0);
+          af[(step + 2) % 3][1] = CF_ALD(nh, nks, 1);
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads up here: the scheduler otherwise sinks them next to their use
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-          for (int qt = 0; qt < 2; ++qt) acc[rt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt], qf[qt][ks], acc[rt][qt], 0, 0, 0);
+          for (int qt = 0; qt < 2; ++qt) acc[rt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[step % 3][rt], qf[qt][ks], acc[rt][qt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       // cheap reject: per 32x32 block the lane's maximum against its cut; the survivors' slow path is rare after the first stages
       const long row0 = r_begin + t * CF_BG + h * 64;
@@ -570,8 +624,10 @@ __global__ __launch_bounds__(512) void cbir_prefilter_kernel(const bf16_t* __res
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
           float m = acc[rt][qt][0];
+#if CF_EXP != 1
 #pragma unroll
           for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rt][qt][r]);
+#endif
           if (BOOT) {
             bm[qt] = fmaxf(bm[qt], m);   // rows past r_end are copies of row r_end - 1 (clamped DMA): the maximum is unaffected
             if (h == 1 && rt == 1) {     // tile complete: one group maximum per (query, 128-row tile)
@@ -581,10 +637,11 @@ __global__ __launch_bounds__(512) void cbir_prefilter_kernel(const bf16_t* __res
               bm[qt] = __uint_as_float(0xff800000u);
             }
           } else if (__any(m > cut[qt])) {
-            // only the lanes that own a survivor run this; their slot requests go out as ONE ds_add_rtn (the LDS unit
-            // serialises the active lanes), no cross-lane traffic on the wave's critical path
-            if (m > cut[qt]) {
-              unsigned pm = 0;
+            // only lanes that own a survivor build their row mask; slots are handed out lane by lane through SGPRs
+            // (v_readlane of each owner's count) -- no atomics, no LDS round trip on the wave's critical path
+            const bool own = m > cut[qt];
+            unsigned pm = 0;
+            if (own) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) pm |= (unsigned)(acc[rt][qt][r] > cut[qt]) << r;
               if (t == ntile - 1) {   // ragged last tile: rows past r_end are clamped copies
@@ -592,34 +649,47 @@ __global__ __launch_bounds__(512) void cbir_prefilter_kernel(const bf16_t* __res
                 for (int r = 0; r < 16; ++r)
                   if (row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= r_end) pm &= ~(1u << r);
               }
-              unsigned pos = atomicAdd(&s_cnt, (unsigned)__popc(pm));
-              const unsigned short ql = (unsigned short)(w * 64 + qt * 32 + l31);
-              while (pm) {
-                const int r = __ffs(pm) - 1;
-                pm &= pm - 1;
-                const int gidx = (int)(idx_base + row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
-                if (pos < CF_E) { e_idx[pos] = gidx; e_q[pos] = ql; }
-                else cbir_global_append(cand, q0 + ql, 0.f, gidx);
+            }
+            const unsigned c = (unsigned)__popc(pm);
+            unsigned long long bl = __ballot(c != 0);
+            // worst case 64 lanes x 16 rows = 1024 > CF_WE: a flush may be needed between two owners
+            unsigned pos = 0;
+            for (unsigned long long b = bl; b; b &= b - 1) {
+              const int L = __ffsll(b) - 1;
+              const unsigned cL = (unsigned)VDK_READLANE(c, L);
+              if (wcnt + cL > CF_WE) {
+                // stage what was granted so far, then flush (uniform branch)
+                if (c && (bl & ~b & (1ull << lane))) {
+                  unsigned pp = pos, mm = pm;
+                  while (mm) { const int r = __ffs(mm) - 1; mm &= mm - 1; e_idx[w][pp] = (int)(idx_base + row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi); e_q[w][pp] = (unsigned char)(qt * 32 + l31); ++pp; }
+                }
+                bl = b;   // owners before L are done
+                CF_FLUSH();
+              }
+              if (lane == L) pos = wcnt;
+              wcnt += cL;
+            }
+            if (c && (bl & (1ull << lane))) {
+              unsigned mm = pm;
+              while (mm) {
+                const int r = __ffs(mm) - 1;
+                mm &= mm - 1;
+                e_idx[w][pos] = (int)(idx_base + row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
+                e_q[w][pos] = (unsigned char)(qt * 32 + l31);
                 ++pos;
               }
             }
           }
         }
-    }
+        }
     // tile t + 1 must have landed: only tile t + 2's four DMAs may still be in flight
     if (t + 2 < ntile) __builtin_amdgcn_s_waitcnt(0x0F70 | 4); else __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-    unsigned n = s_cnt;
-    if (n >= CF_EFLUSH || t == ntile - 1) {
-      if (n > CF_E) n = CF_E;
-      for (unsigned i = tid; i < n; i += 512) cbir_global_append(cand, q0 + e_q[i], 0.f, e_idx[i]);
-      __syncthreads();
-      if (tid == 0) s_cnt = 0;
-      __syncthreads();
-    }
     cur = cur + 1 == CF_NBUF ? 0 : cur + 1;
   }
 #undef CF_ISSUE
+  if (!BOOT && wcnt) { CF_FLUSH(); }
+#undef CF_FLUSH
 }
 
 // thr[q] = (k-th largest of the G group maxima) - eps_q (see BOOT above).  One workgroup per query, bitonic sort in LDS.
@@ -642,7 +712,7 @@ __global__ __launch_bounds__(256) void cbir_boot_thr_kernel(const float* __restr
       }
       __syncthreads();
     }
-  if (tid == 0) thr[q] = ord2f(~keys[k - 1]) - CF_EPS_REL * qnorm[q] * __uint_as_float(gmax_bits[0]);
+  if (tid == 0) thr[q] = ord2f(~keys[k - 1]) - cbir_eps(qnorm, q, gmax_bits);
 }
 
 // exact scores of the new candidates of every query: entries [carry[q], cnt[q]) of its list.  One workgroup per query; one
@@ -778,15 +848,15 @@ int vdk_cbir_search(const float* Q, int64_t nq, const float* G, int64_t N, int32
 }
 
 // ---- fast path host side -----------------------------------------------------------------------------------------------
-// Per-index preparation (IndexFlatIP.add time, not per search): Gb = bf16 [N, 128] zero-padded copy of G, gmax_bits[0] = bit
+// Per-index preparation (IndexFlatIP.add time, not per search): Gb = bf16 [N, 128] zero-padded copy of G, gmax_bits[0..2] = bit
 // pattern of max_n ||G[n]|| (a float >= 0).  gnorm_ws: f32 [N] scratch.
 int vdk_cbir_prepare_gallery(const float* G, int64_t N, int32_t D, void* Gb, float* gnorm_ws, uint32_t* gmax_bits, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if ((!G && N > 0) || !Gb || !gnorm_ws || !gmax_bits || N < 0 || D <= 0 || D > 128) return vdk_fail(VDK_EINVAL, "vdk_cbir_prepare_gallery: bad argument (D <= 128)");
-  if (hipMemsetAsync(gmax_bits, 0, 4, stream) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vdk_cbir_prepare_gallery: memset failed");
+  if (hipMemsetAsync(gmax_bits, 0, 16, stream) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vdk_cbir_prepare_gallery: memset failed");
   if (N == 0) return VDK_OK;
   hipLaunchKernelGGL(cbir_cast_rows_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, G, (long)N, (int)D, (bf16_t*)Gb, gnorm_ws);
-  hipLaunchKernelGGL(cbir_max_kernel, dim3(256), dim3(256), 0, stream, (const float*)gnorm_ws, (long)N, (unsigned*)gmax_bits);
+  hipLaunchKernelGGL(cbir_max3_kernel, dim3(256), dim3(256), 0, stream, (const float*)gnorm_ws, (long)N, (unsigned*)gmax_bits);
   return vdk_check_launch("vdk_cbir_prepare_gallery");
 }
 
@@ -795,7 +865,7 @@ int vdk_cbir_fast_workspace_bytes(int64_t nq, int32_t k, int64_t cap, size_t* by
   int rc = vdk_cbir_workspace_bytes(nq, k, cap, &b);
   if (rc) return rc;
   b += cb_align((size_t)nq * 128 * 2);   // Qb
-  b += cb_align((size_t)nq * 4);         // query norms
+  b += cb_align((size_t)nq * 12);        // query norms (||q||, ||q~||, ||q~ - q||)
   b += cb_align((size_t)nq * 4);         // carry
   b += cb_align((size_t)nq * CF_BOOT_MAXG * 4 < (size_t)nq * 4 * k * 4 ? (size_t)nq * CF_BOOT_MAXG * 4 : (size_t)nq * 4 * k * 4);   // bootstrap group maxima [nq, G <= min(4k, 4096)]
   *bytes = b;
@@ -820,7 +890,7 @@ int vdk_cbir_search_fast(const float* Q, int64_t nq, const float* G, const void*
   size_t base_bytes = 0; vdk_cbir_workspace_bytes(nq, k, cap, &base_bytes);
   char* p = (char*)ws + base_bytes;
   bf16_t* Qb = (bf16_t*)p; p += cb_align((size_t)nq * 128 * 2);
-  float* qnorm = (float*)p; p += cb_align((size_t)nq * 4);
+  float* qnorm = (float*)p; p += cb_align((size_t)nq * 12);
   unsigned* carry = (unsigned*)p; p += cb_align((size_t)nq * 4);
   float* gm = (float*)p;
   hipLaunchKernelGGL(cbir_init_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, cand.cnt, thr, cand.overflow, (long)nq);

@@ -45,6 +45,10 @@ __device__ __forceinline__ s16x8 tr_frag8(const bf16_t* tile, int pitch, int t1,
 #ifndef VDK_WAVE_LDS_SYNC
 #define VDK_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
+// value of a 32-bit VGPR in a wave-uniform lane -> SGPR broadcast (v_readlane_b32, no LDS round trip)
+#ifndef VDK_READLANE
+#define VDK_READLANE(v, l) __builtin_amdgcn_readlane((int)(v), (l))
+#endif
 #ifndef VDK_PIN2
 #define VDK_PIN2(x, y) asm volatile("" : "+v"(x), "+v"(y))
 #endif
