@@ -307,7 +307,7 @@ __device__ __forceinline__ float cbir_exact_ip(const float* __restrict__ qrow, c
   return acc + 0.0f;
 }
 
-#define CW_KEYS 1024
+#define CW_KEYS 512
 __global__ __launch_bounds__(256) void cbir_rank_wave_kernel(const float* __restrict__ Q, const float* __restrict__ G, int D, long idx_base,
                                                              CbirCand cand, long nq, int k, float* __restrict__ thr, float* __restrict__ out_score,
                                                              long long* __restrict__ out_idx, int write_out, unsigned* __restrict__ carry) {
