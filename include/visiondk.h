@@ -203,6 +203,31 @@ int vdk_topk_rows(const float* x, int64_t ld, int32_t B, int32_t C, int32_t k, i
 int vdk_mixup(const float* x, const int64_t* perm, float lam, int32_t B, int64_t per_sample, float* out, void* stream);
 
 
+/* ---- CNN backbone pieces (timm ConvNeXt behind TimmWrapper, models/faceX/backbone/timm_wrapper.py:16-37) --------------------
+ * All activations are NHWC f32 / bf16 rows, so pointwise / 4x4-stem / 2x2-downsample convolutions are vdk_gemm_bf16_nt and
+ * LayerNorm2d is vdk_layernorm_*.  ConvNeXtBlock.conv_dw (Conv2d(C, C, 7, padding 3, groups=C)):
+ * out = bias + res + dwconv(in, wt) with wt tap-major f32 [49][C] (vdk_dwconv7_weight_prep); flip = 1 turns the same kernel into
+ * the input gradient (taps reversed; res = shortcut gradient; out_bf16 = copy for the next GEMM).  bias / res / out / out_bf16 may be NULL. */
+int vdk_dwconv7_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out, void* out_bf16, int32_t B, int32_t H, int32_t W,
+                    int32_t C, int32_t flip, void* stream);
+int vdk_dwconv7_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C, size_t* bytes);
+/* dw f32 [C][49] (= conv_dw.weight [C,1,7,7]) and db f32 [C] from the block input `in` and the gradient `dy` of the conv output */
+int vdk_dwconv7_wgrad(const float* in, const float* dy, float* dw, float* db, int32_t B, int32_t H, int32_t W, int32_t C, void* ws, size_t ws_bytes,
+                      void* stream);
+int vdk_dwconv7_weight_prep(const float* w, float* wt, int32_t C, void* stream);
+/* stride-2 2x2 convolution (ConvNeXt downsample) as a GEMM: space-to-depth operand bf16 [B*H/2*W/2][4C] with k = (2*(y&1) + (x&1))*C + c
+ * (inverse = 1: depth-to-space, for the input gradient); weight [Co][Ci][2][2] -> bf16 [Co][4Ci] in the same k order + its transpose;
+ * gradient back to the timm layout. */
+int vdk_space_to_depth2_bf16(const void* in, void* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t inverse, void* stream);
+int vdk_conv2x2_weight_prep(const float* w, void* wb, void* wtb, int32_t Co, int32_t Ci, void* stream);
+int vdk_conv2x2_wgrad_unpermute(const float* dwp, float* dw, int32_t Co, int32_t Ci, void* stream);
+/* ConvNeXtBlock layer scale (x * gamma after mlp.fc2) folded into fc2: W2p = gamma (.) W2 (bf16 [C][M]), W2pt = W2p^T, b2p = gamma (.) b2;
+ * vdk_layerscale_grad applies the chain rule to the folded gradients: dW2 = gamma (.) dW2p, db2 = gamma (.) db2p,
+ * dgamma[c] = sum_k dW2p[c][k] W2[c][k] + db2p[c] b2[c]. */
+int vdk_layerscale_weight_prep(const float* w2, const float* b2, const float* gamma, void* w2p, void* w2pt, float* b2p, int32_t C, int32_t M, void* stream);
+int vdk_layerscale_grad(const float* dw2p, const float* db2p, const float* w2, const float* b2, const float* gamma, float* dw2, float* db2, float* dgamma,
+                        int32_t C, int32_t M, void* stream);
+
 /* ---- native ViT engine: timm VisionTransformer forward/backward over flat buffers ---------------------
  * Replaces `self.model(images)` + `loss.backward()` of Trainer.compute_loss / Trainer.update
  * (engine/procedure/train.py:177-215) for the model `timm.create_model('vit_*', num_classes=C)` built at

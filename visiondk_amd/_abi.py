@@ -93,6 +93,15 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_margin_ce": (C.c_int, [C.POINTER(MarginHead), P, I64, I32, I32, P, F32, F32, P, I64, P, P, I64, P]),
     "vdk_margin_bwd": (C.c_int, [C.POINTER(MarginHead), P, I64, I32, I32, P, P, I64, P, I64, P]),
     # native ViT engine
+    "vdk_dwconv7_fwd": (C.c_int, [P, P, P, P, P, P, I32, I32, I32, I32, I32, P]),
+    "vdk_dwconv7_wgrad_workspace_bytes": (C.c_int, [I32, I32, I32, I32, PSZ]),
+    "vdk_dwconv7_wgrad": (C.c_int, [P, P, P, P, I32, I32, I32, I32, P, SZ, P]),
+    "vdk_dwconv7_weight_prep": (C.c_int, [P, P, I32, P]),
+    "vdk_space_to_depth2_bf16": (C.c_int, [P, P, I32, I32, I32, I32, I32, P]),
+    "vdk_conv2x2_weight_prep": (C.c_int, [P, P, P, I32, I32, P]),
+    "vdk_conv2x2_wgrad_unpermute": (C.c_int, [P, P, I32, I32, P]),
+    "vdk_layerscale_weight_prep": (C.c_int, [P, P, P, P, P, P, I32, I32, P]),
+    "vdk_layerscale_grad": (C.c_int, [P, P, P, P, P, P, P, P, I32, I32, P]),
     "vdk_vit_param_count": (C.c_int, [C.POINTER(VitConfig), C.POINTER(I64), C.POINTER(I32), C.POINTER(I64)]),
     "vdk_vit_param_info": (C.c_int, [C.POINTER(VitConfig), I32, C.c_char_p, I32, C.POINTER(I64), C.POINTER(I64),
                                      C.POINTER(I64), C.POINTER(I32)]),

@@ -1,0 +1,302 @@
+// conv.hip — the convolution side of hot path A for CNN backbones (timm ConvNeXt behind TimmWrapper,
+// /root/reference models/faceX/backbone/timm_wrapper.py:16-37; configs/faceX/cbir.yaml:4-8).
+//
+// Everything is NHWC ("rows x channels", the same layout as the transformer's token rows), so ConvNeXt's pointwise convs, its
+// 4x4/4 stem and its 2x2/2 downsamples are the existing MFMA GEMM, LayerNorm2d is the existing row LayerNorm, and what is left
+// is HBM/VALU-bound:
+//   * K6  depthwise 7x7 (ConvNeXtBlock.conv_dw, groups=C, padding 3): forward, input gradient (same kernel, flipped taps, with
+//         the shortcut gradient added and a bf16 copy written for the next GEMM) and weight/bias gradient;
+//   * space-to-depth / depth-to-space for the stride-2 2x2 convolutions (im2col-free GEMM operands);
+//   * weight preparation: tap-major depthwise weights, (ky,kx,cin)-ordered 2x2 weights, layer-scale folded into fc2
+//     (W2' = gamma (.) W2) and the chain rule back (dW2 = gamma (.) dW2', dgamma = <dW2', W2> + db2' b2).
+#include <hip/hip_runtime.h>
+#include "vdk_device.h"
+#include "vdk_host.h"
+
+#define DW_T 8          // output tile edge
+#define DW_H (DW_T + 6)  // input tile edge (halo 3)
+#define DW_CC 64        // channels per workgroup
+
+// ------------------------------------------------------------------------------------ K6 forward / input gradient
+// out[b,y,x,c] = bias[c] + res[b,y,x,c] + sum_{i,j} wt[(flip ? 48 - (7i+j) : 7i+j)][c] * in[b, y+i-3, x+j-3, c]   (zero padding)
+// grid: (tiles_x * tiles_y * B, ceil(C / 64)); 128 threads = 8 columns x 16 channel quads; a thread owns an 8-row output strip of one
+// column and one channel quad: for every horizontal tap it reads the 14 inputs of its column once and feeds 7 x 8 FMAs.
+__global__ __launch_bounds__(128) void dwconv7_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
+                                                      const float* __restrict__ res, float* __restrict__ out, bf16_t* __restrict__ outb, int B, int H,
+                                                      int W, int C, int flip) {
+  __shared__ __attribute__((aligned(16))) float xs[DW_H * DW_H * DW_CC];   // 50 176 B
+  __shared__ __attribute__((aligned(16))) float ws[49 * DW_CC];            // 12 544 B
+  const int tid = threadIdx.x;
+  const int tx_n = (W + DW_T - 1) / DW_T, ty_n = (H + DW_T - 1) / DW_T;
+  const int tile = blockIdx.x % (tx_n * ty_n), b = blockIdx.x / (tx_n * ty_n);
+  const int y0 = (tile / tx_n) * DW_T, x0 = (tile % tx_n) * DW_T;
+  const int c0 = blockIdx.y * DW_CC;
+  for (int i = tid; i < DW_H * DW_H * (DW_CC / 4); i += 128) {
+    const int cq = i & 15, p = i >> 4, py = p / DW_H, px = p % DW_H;
+    const int y = y0 + py - 3, x = x0 + px - 3, c = c0 + cq * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (y >= 0 && y < H && x >= 0 && x < W && c < C) v = *(const f32x4*)(in + (((long)b * H + y) * W + x) * C + c);
+    *(f32x4*)(xs + p * DW_CC + cq * 4) = v;
+  }
+  for (int i = tid; i < 49 * (DW_CC / 4); i += 128) {
+    const int cq = i & 15, t = i >> 4, c = c0 + cq * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) v = *(const f32x4*)(wt + (long)(flip ? 48 - t : t) * C + c);
+    *(f32x4*)(ws + t * DW_CC + cq * 4) = v;
+  }
+  __syncthreads();
+  const int cq = tid & 15, col = tid >> 4, c = c0 + cq * 4;
+  f32x4 acc[DW_T];
+  {
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias && c < C) b4 = *(const f32x4*)(bias + c);
+#pragma unroll
+    for (int o = 0; o < DW_T; ++o) acc[o] = b4;
+  }
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    f32x4 wj[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) wj[i] = *(const f32x4*)(ws + (i * 7 + j) * DW_CC + cq * 4);
+#pragma unroll
+    for (int r = 0; r < DW_H; ++r) {
+      const f32x4 v = *(const f32x4*)(xs + (r * DW_H + col + j) * DW_CC + cq * 4);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int o = r - i;
+        if (o >= 0 && o < DW_T) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(v[e], wj[i][e], acc[o][e]);
+        }
+      }
+    }
+  }
+  const int x = x0 + col;
+  if (x < W && c < C) {
+#pragma unroll
+    for (int o = 0; o < DW_T; ++o) {
+      const int y = y0 + o;
+      if (y < H) {
+        const long off = (((long)b * H + y) * W + x) * C + c;
+        f32x4 v = acc[o];
+        if (res) { const f32x4 r4 = *(const f32x4*)(res + off); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
+        if (out) *(f32x4*)(out + off) = v;
+        if (outb) *(u32x2*)(outb + off) = (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ K6 weight / bias gradient
+// dw[c][7i+j] = sum_{b,y,x} dy[b,y,x,c] * in[b, y+i-3, x+j-3, c];  db[c] = sum dy[b,y,x,c].
+// grid: (S slices, ceil(C / 64)); 448 threads = 7 vertical taps x 64 channels; a workgroup walks its share of the (image, tile) list,
+// stages the input tile (with halo) and the dy tile in LDS, and every thread keeps the 7 horizontal taps of its (channel, i) in
+// registers: per output row 8 dy values and 14 inputs feed 56 FMAs.  Partials per slice are combined by vdk_reduce_rows_f32.
+__global__ __launch_bounds__(448) void dwconv7_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ dy, float* __restrict__ part, int B,
+                                                            int H, int W, int C, int S) {
+  __shared__ __attribute__((aligned(16))) float xs[DW_H * DW_H * DW_CC];
+  __shared__ __attribute__((aligned(16))) float ds[DW_T * DW_T * DW_CC];   // 16 384 B
+  const int tid = threadIdx.x, cl = tid & 63, ti = tid >> 6;
+  const int tx_n = (W + DW_T - 1) / DW_T, ty_n = (H + DW_T - 1) / DW_T;
+  const long items = (long)B * tx_n * ty_n;
+  const int c0 = blockIdx.y * DW_CC;
+  float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float accb = 0.f;
+  for (long it = blockIdx.x; it < items; it += S) {
+    const int tile = (int)(it % (tx_n * ty_n)), b = (int)(it / (tx_n * ty_n));
+    const int y0 = (tile / tx_n) * DW_T, x0 = (tile % tx_n) * DW_T;
+    __syncthreads();
+    for (int i = tid; i < DW_H * DW_H * (DW_CC / 4); i += 448) {
+      const int cq = i & 15, p = i >> 4, py = p / DW_H, px = p % DW_H;
+      const int y = y0 + py - 3, x = x0 + px - 3, c = c0 + cq * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (y >= 0 && y < H && x >= 0 && x < W && c < C) v = *(const f32x4*)(in + (((long)b * H + y) * W + x) * C + c);
+      *(f32x4*)(xs + p * DW_CC + cq * 4) = v;
+    }
+    for (int i = tid; i < DW_T * DW_T * (DW_CC / 4); i += 448) {
+      const int cq = i & 15, p = i >> 4, py = p / DW_T, px = p % DW_T;
+      const int y = y0 + py, x = x0 + px, c = c0 + cq * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (y < H && x < W && c < C) v = *(const f32x4*)(dy + (((long)b * H + y) * W + x) * C + c);
+      *(f32x4*)(ds + p * DW_CC + cq * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < DW_T; ++h) {
+      float d[DW_T], xv[DW_H];
+#pragma unroll
+      for (int w = 0; w < DW_T; ++w) d[w] = ds[(h * DW_T + w) * DW_CC + cl];
+#pragma unroll
+      for (int w = 0; w < DW_H; ++w) xv[w] = xs[((h + ti) * DW_H + w) * DW_CC + cl];
+#pragma unroll
+      for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int w = 0; w < DW_T; ++w) acc[j] = fmaf(d[w], xv[w + j], acc[j]);
+      if (ti == 0) {
+#pragma unroll
+        for (int w = 0; w < DW_T; ++w) accb += d[w];
+      }
+    }
+  }
+  const int c = c0 + cl;
+  if (c < C) {
+    float* p = part + (long)blockIdx.x * ((long)C * 50);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) p[(long)c * 49 + ti * 7 + j] = acc[j];
+    if (ti == 0) p[(long)C * 49 + c] = accb;
+  }
+}
+
+// ------------------------------------------------------------------------------------ stride-2 2x2 conv operands
+// space-to-depth: out[(b, y/2, x/2)][(2*(y&1) + (x&1)) * C + c] = in[(b, y, x)][c]   (bf16, 16-byte chunks); inverse = depth-to-space
+__global__ __launch_bounds__(256) void s2d2_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int B, int H, int W, int C, int inverse) {
+  const long n = (long)B * H * W * (C / 8);
+  const long id = (long)blockIdx.x * 256 + threadIdx.x;
+  if (id >= n) return;
+  const int c8 = (int)(id % (C / 8));
+  const long p = id / (C / 8);
+  const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((long)W * H));
+  const long a = p * C + c8 * 8;                                                                             // NHWC element
+  const long d = ((((long)b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * 4 + ((y & 1) * 2 + (x & 1))) * C + c8 * 8;   // depth-major element
+  if (inverse) *(u32x4*)(out + a) = *(const u32x4*)(in + d);
+  else *(u32x4*)(out + d) = *(const u32x4*)(in + a);
+}
+
+// ------------------------------------------------------------------------------------ weight preparation
+// depthwise weight [C][49] -> tap-major [49][C]
+__global__ __launch_bounds__(256) void dw_weight_prep_kernel(const float* __restrict__ w, float* __restrict__ wt, int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= C * 49) return;
+  const int t = i / C, c = i % C;
+  wt[i] = w[c * 49 + t];
+}
+// 2x2 conv weight [Co][Ci][2][2] -> wb bf16 [Co][4*Ci] with k = (2*ky + kx) * Ci + ci, and its transpose wtb bf16 [4*Ci][Co]
+__global__ __launch_bounds__(256) void conv2x2_weight_prep_kernel(const float* __restrict__ w, bf16_t* __restrict__ wb, bf16_t* __restrict__ wtb, int Co,
+                                                                  int Ci) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)Co * Ci * 4) return;
+  const int q = (int)(i & 3);
+  const long rest = i >> 2;
+  const int ci = (int)(rest % Ci), co = (int)(rest / Ci);
+  const bf16_t v = f2bf(w[i]);
+  const long k = (long)q * Ci + ci;
+  wb[(long)co * 4 * Ci + k] = v;
+  wtb[k * Co + co] = v;
+}
+// gradient back: dWp f32 [Co][4*Ci] (k order above) -> dW f32 [Co][Ci][2][2]
+__global__ __launch_bounds__(256) void conv2x2_wgrad_unpermute_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Co, int Ci) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)Co * Ci * 4) return;
+  const int q = (int)(i & 3);
+  const long rest = i >> 2;
+  const int ci = (int)(rest % Ci), co = (int)(rest / Ci);
+  dw[i] = dwp[(long)co * 4 * Ci + (long)q * Ci + ci];
+}
+// layer scale folded into fc2:  W2p = gamma (.) W2 (bf16 [C][M]),  W2pt = W2p^T (bf16 [M][C]),  b2p = gamma (.) b2 (f32)
+__global__ __launch_bounds__(256) void lscale_weight_prep_kernel(const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ gamma,
+                                                                 bf16_t* __restrict__ w2p, bf16_t* __restrict__ w2pt, float* __restrict__ b2p, int C, int M) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < C) b2p[i] = gamma[i] * b2[i];
+  if (i >= (long)C * M) return;
+  const int k = (int)(i % M), c = (int)(i / M);
+  const bf16_t v = f2bf(gamma[c] * w2[i]);
+  w2p[i] = v;
+  w2pt[(long)k * C + c] = v;
+}
+// chain rule back through the fold (one wave per output channel c):
+//   dW2[c][k] = gamma[c] dW2p[c][k];  db2[c] = gamma[c] db2p[c];  dgamma[c] = sum_k dW2p[c][k] W2[c][k] + db2p[c] b2[c]
+__global__ __launch_bounds__(256) void lscale_grad_kernel(const float* __restrict__ dw2p, const float* __restrict__ db2p, const float* __restrict__ w2,
+                                                          const float* __restrict__ b2, const float* __restrict__ gamma, float* __restrict__ dw2,
+                                                          float* __restrict__ db2, float* __restrict__ dgamma, int C, int M) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  const float g = gamma[c];
+  float s = 0.f;
+  for (int k = lane; k < M; k += 64) {
+    const float d = dw2p[(long)c * M + k];
+    s = fmaf(d, w2[(long)c * M + k], s);
+    dw2[(long)c * M + k] = g * d;
+  }
+  s = wave_sum(s);
+  if (lane == 0) {
+    const float d = db2p[c];
+    db2[c] = g * d;
+    dgamma[c] = fmaf(d, b2[c], s);
+  }
+}
+
+extern "C" {
+
+int vdk_dwconv7_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out, void* out_bf16, int32_t B, int32_t H, int32_t W,
+                    int32_t C, int32_t flip, void* stream) {
+  if (!in || !wt || (!out && !out_bf16) || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return vdk_fail(VDK_EINVAL, "vdk_dwconv7_fwd: bad argument (C % 4 == 0)");
+  const unsigned tiles = (unsigned)(((W + DW_T - 1) / DW_T) * ((H + DW_T - 1) / DW_T));
+  hipLaunchKernelGGL(dwconv7_kernel, dim3(tiles * (unsigned)B, (unsigned)((C + DW_CC - 1) / DW_CC)), dim3(128), 0, (hipStream_t)stream, in, wt, bias, res, out,
+                     (bf16_t*)out_bf16, (int)B, (int)H, (int)W, (int)C, (int)flip);
+  return vdk_check_launch("vdk_dwconv7_fwd");
+}
+
+static int dw_slices(int B, int H, int W, int C) {
+  const long items = (long)B * ((W + DW_T - 1) / DW_T) * ((H + DW_T - 1) / DW_T);
+  long s = 1024 / ((C + DW_CC - 1) / DW_CC);
+  if (s > items) s = items;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+int vdk_dwconv7_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C, size_t* bytes) {
+  if (!bytes || B <= 0 || H <= 0 || W <= 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_dwconv7_wgrad_workspace_bytes: bad argument");
+  *bytes = (size_t)dw_slices(B, H, W, C) * C * 50 * 4;
+  return VDK_OK;
+}
+int vdk_reduce_rows_f32(const float*, int64_t, int32_t, int64_t, float*, float, void*);
+/* dw f32 [C][49] (timm conv_dw.weight [C,1,7,7]) and db f32 [C]; ws: vdk_dwconv7_wgrad_workspace_bytes */
+int vdk_dwconv7_wgrad(const float* in, const float* dy, float* dw, float* db, int32_t B, int32_t H, int32_t W, int32_t C, void* ws, size_t ws_bytes,
+                      void* stream) {
+  if (!in || !dy || !dw || !db || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return vdk_fail(VDK_EINVAL, "vdk_dwconv7_wgrad: bad argument (C % 4 == 0)");
+  const int S = dw_slices(B, H, W, C);
+  if (!ws || ws_bytes < (size_t)S * C * 50 * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_dwconv7_wgrad: workspace too small");
+  hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3((unsigned)S, (unsigned)((C + DW_CC - 1) / DW_CC)), dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B,
+                     (int)H, (int)W, (int)C, S);
+  int rc = vdk_reduce_rows_f32((const float*)ws, (int64_t)C * 50, S, (int64_t)C * 49, dw, 1.0f, stream);
+  if (rc) return rc;
+  return vdk_reduce_rows_f32((const float*)ws + (size_t)C * 49, (int64_t)C * 50, S, C, db, 1.0f, stream);
+}
+
+int vdk_space_to_depth2_bf16(const void* in, void* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t inverse, void* stream) {
+  if (!in || !out || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 7)) return vdk_fail(VDK_EINVAL, "vdk_space_to_depth2_bf16: bad argument (H, W even; C % 8 == 0)");
+  const long n = (long)B * H * W * (C / 8);
+  hipLaunchKernelGGL(s2d2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, (int)B, (int)H, (int)W,
+                     (int)C, (int)inverse);
+  return vdk_check_launch("vdk_space_to_depth2_bf16");
+}
+
+int vdk_dwconv7_weight_prep(const float* w, float* wt, int32_t C, void* stream) {
+  if (!w || !wt || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_dwconv7_weight_prep: bad argument");
+  hipLaunchKernelGGL(dw_weight_prep_kernel, dim3((unsigned)((C * 49 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, wt, (int)C);
+  return vdk_check_launch("vdk_dwconv7_weight_prep");
+}
+int vdk_conv2x2_weight_prep(const float* w, void* wb, void* wtb, int32_t Co, int32_t Ci, void* stream) {
+  if (!w || !wb || !wtb || Co <= 0 || Ci <= 0) return vdk_fail(VDK_EINVAL, "vdk_conv2x2_weight_prep: bad argument");
+  hipLaunchKernelGGL(conv2x2_weight_prep_kernel, dim3((unsigned)(((long)Co * Ci * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wb, (bf16_t*)wtb,
+                     (int)Co, (int)Ci);
+  return vdk_check_launch("vdk_conv2x2_weight_prep");
+}
+int vdk_conv2x2_wgrad_unpermute(const float* dwp, float* dw, int32_t Co, int32_t Ci, void* stream) {
+  if (!dwp || !dw || Co <= 0 || Ci <= 0) return vdk_fail(VDK_EINVAL, "vdk_conv2x2_wgrad_unpermute: bad argument");
+  hipLaunchKernelGGL(conv2x2_wgrad_unpermute_kernel, dim3((unsigned)(((long)Co * Ci * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dwp, dw, (int)Co, (int)Ci);
+  return vdk_check_launch("vdk_conv2x2_wgrad_unpermute");
+}
+int vdk_layerscale_weight_prep(const float* w2, const float* b2, const float* gamma, void* w2p, void* w2pt, float* b2p, int32_t C, int32_t M, void* stream) {
+  if (!w2 || !b2 || !gamma || !w2p || !w2pt || !b2p || C <= 0 || M < C) return vdk_fail(VDK_EINVAL, "vdk_layerscale_weight_prep: bad argument");
+  hipLaunchKernelGGL(lscale_weight_prep_kernel, dim3((unsigned)(((long)C * M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w2, b2, gamma, (bf16_t*)w2p,
+                     (bf16_t*)w2pt, b2p, (int)C, (int)M);
+  return vdk_check_launch("vdk_layerscale_weight_prep");
+}
+int vdk_layerscale_grad(const float* dw2p, const float* db2p, const float* w2, const float* b2, const float* gamma, float* dw2, float* db2, float* dgamma,
+                        int32_t C, int32_t M, void* stream) {
+  if (!dw2p || !db2p || !w2 || !b2 || !gamma || !dw2 || !db2 || !dgamma || C <= 0 || M <= 0) return vdk_fail(VDK_EINVAL, "vdk_layerscale_grad: bad argument");
+  hipLaunchKernelGGL(lscale_grad_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dw2p, db2p, w2, b2, gamma, dw2, db2, dgamma, (int)C, (int)M);
+  return vdk_check_launch("vdk_layerscale_grad");
+}
+
+}  // extern "C"

@@ -266,3 +266,94 @@ def topk_rows(x, k: int, backend=None):
     val = torch.empty((B, k), dtype=torch.float32, device=x.device)
     be.check(be.lib.vdk_topk_rows(be.ptr(x), C_, B, C_, k, be.ptr(idx), be.ptr(val), be.stream()), "vdk_topk_rows")
     return val, idx
+
+
+# ---- CNN backbone pieces (csrc/conv.hip) -------------------------------------------------------------------------------
+def dwconv7_weight_prep(w: torch.Tensor, backend=None) -> torch.Tensor:
+    """conv_dw.weight [C,1,7,7] f32 -> tap-major [49, C] f32"""
+    be = _be(backend)
+    Cc = w.shape[0]
+    w = w.reshape(Cc, 49).contiguous()
+    wt = torch.empty((49, Cc), dtype=torch.float32, device=w.device)
+    be.check(be.lib.vdk_dwconv7_weight_prep(be.ptr(w), be.ptr(wt), Cc, be.stream()), "vdk_dwconv7_weight_prep")
+    return wt
+
+
+def dwconv7(x: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, *, flip: bool = False,
+            want_bf16: bool = False, backend=None):
+    """x f32 [B,H,W,C] (NHWC); wt [49,C]; returns f32 [B,H,W,C] (and a bf16 copy if want_bf16)."""
+    be = _be(backend)
+    assert x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+    B, H, W, Cc = x.shape
+    out = torch.empty_like(x)
+    outb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    be.check(be.lib.vdk_dwconv7_fwd(be.ptr(x), be.ptr(wt), be.ptr(bias) if bias is not None else None, be.ptr(res) if res is not None else None,
+                                    be.ptr(out), be.ptr(outb) if outb is not None else None, B, H, W, Cc, int(flip), be.stream()), "vdk_dwconv7_fwd")
+    return (out, outb) if want_bf16 else out
+
+
+def dwconv7_wgrad(x: torch.Tensor, dy: torch.Tensor, backend=None):
+    """-> (dw f32 [C,49], db f32 [C])"""
+    be = _be(backend)
+    B, H, W, Cc = x.shape
+    need = C.c_size_t(0)
+    be.check(be.lib.vdk_dwconv7_wgrad_workspace_bytes(B, H, W, Cc, C.byref(need)), "vdk_dwconv7_wgrad_workspace_bytes")
+    ws = torch.empty(need.value, dtype=torch.uint8, device=x.device)
+    dw = torch.empty((Cc, 49), dtype=torch.float32, device=x.device)
+    db = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    be.check(be.lib.vdk_dwconv7_wgrad(be.ptr(x), be.ptr(dy), be.ptr(dw), be.ptr(db), B, H, W, Cc, be.ptr(ws), ws.numel(), be.stream()), "vdk_dwconv7_wgrad")
+    return dw, db
+
+
+def space_to_depth2(x: torch.Tensor, inverse: bool = False, backend=None) -> torch.Tensor:
+    """bf16 [B,H,W,C] -> [B,H/2,W/2,4C] (k = (2*(y&1)+(x&1))*C + c); inverse: the other way round"""
+    be = _be(backend)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    if inverse:
+        B, h, w, c4 = x.shape
+        out = torch.empty((B, 2 * h, 2 * w, c4 // 4), dtype=torch.bfloat16, device=x.device)
+        B, H, W, Cc = out.shape
+    else:
+        B, H, W, Cc = x.shape
+        out = torch.empty((B, H // 2, W // 2, 4 * Cc), dtype=torch.bfloat16, device=x.device)
+    be.check(be.lib.vdk_space_to_depth2_bf16(be.ptr(x), be.ptr(out), B, H, W, Cc, int(inverse), be.stream()), "vdk_space_to_depth2_bf16")
+    return out
+
+
+def conv2x2_weight_prep(w: torch.Tensor, backend=None):
+    """Conv2d weight [Co,Ci,2,2] f32 -> (bf16 [Co,4Ci], bf16 [4Ci,Co])"""
+    be = _be(backend)
+    Co, Ci = w.shape[:2]
+    w = w.contiguous()
+    wb = torch.empty((Co, 4 * Ci), dtype=torch.bfloat16, device=w.device)
+    wtb = torch.empty((4 * Ci, Co), dtype=torch.bfloat16, device=w.device)
+    be.check(be.lib.vdk_conv2x2_weight_prep(be.ptr(w), be.ptr(wb), be.ptr(wtb), Co, Ci, be.stream()), "vdk_conv2x2_weight_prep")
+    return wb, wtb
+
+
+def conv2x2_wgrad_unpermute(dwp: torch.Tensor, Ci: int, backend=None) -> torch.Tensor:
+    be = _be(backend)
+    Co = dwp.shape[0]
+    dw = torch.empty((Co, Ci, 2, 2), dtype=torch.float32, device=dwp.device)
+    be.check(be.lib.vdk_conv2x2_wgrad_unpermute(be.ptr(dwp.contiguous()), be.ptr(dw), Co, Ci, be.stream()), "vdk_conv2x2_wgrad_unpermute")
+    return dw
+
+
+def layerscale_weight_prep(w2: torch.Tensor, b2: torch.Tensor, gamma: torch.Tensor, backend=None):
+    be = _be(backend)
+    Cc, M = w2.shape
+    w2p = torch.empty((Cc, M), dtype=torch.bfloat16, device=w2.device)
+    w2pt = torch.empty((M, Cc), dtype=torch.bfloat16, device=w2.device)
+    b2p = torch.empty(Cc, dtype=torch.float32, device=w2.device)
+    be.check(be.lib.vdk_layerscale_weight_prep(be.ptr(w2.contiguous()), be.ptr(b2), be.ptr(gamma), be.ptr(w2p), be.ptr(w2pt), be.ptr(b2p), Cc, M, be.stream()),
+             "vdk_layerscale_weight_prep")
+    return w2p, w2pt, b2p
+
+
+def layerscale_grad(dw2p: torch.Tensor, db2p: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, gamma: torch.Tensor, backend=None):
+    be = _be(backend)
+    Cc, M = w2.shape
+    dw2 = torch.empty_like(w2); db2 = torch.empty_like(b2); dg = torch.empty_like(gamma)
+    be.check(be.lib.vdk_layerscale_grad(be.ptr(dw2p.contiguous()), be.ptr(db2p), be.ptr(w2.contiguous()), be.ptr(b2), be.ptr(gamma), be.ptr(dw2), be.ptr(db2),
+                                        be.ptr(dg), Cc, M, be.stream()), "vdk_layerscale_grad")
+    return dw2, db2, dg
