@@ -275,6 +275,30 @@ typedef struct VdkMarginHead {
   float margin_am;     /* arcface only */
   float mv_weight;     /* mv only */
 } VdkMarginHead;
+/* ---- native ConvNeXt engine: timm ConvNeXt in feature mode (num_classes=0, global_pool='') over flat buffers --------------------
+ * Replaces `self.model(x)` of TimmWrapper.forward (models/faceX/backbone/timm_wrapper.py:16-21,51) and its backward for the CNN
+ * backbones of the face / CBIR path (`convnext_base`, configs/faceX/cbir.yaml:4-8).  Semantics restated from timm 0.9.16 (not vendored;
+ * oracle/convnext_ref.py): stem Conv4x4/4 + LayerNorm2d, stages of [LayerNorm2d + Conv2x2/2] + ConvNeXtBlocks (dwconv7x7, LayerNorm, fc1, GELU,
+ * fc2, layer scale, shortcut), head.norm.  Input NCHW f32 as the dataloader provides it; output the head-normed map as NHWC rows. */
+typedef struct VdkConvNextConfig {
+  int32_t batch, img_size, in_chans;
+  int32_t depths[4];
+  int32_t dims[4];
+  float ln_eps;
+} VdkConvNextConfig;
+/* flat parameter layout (timm state_dict order and names) + size of `wx`, the derived operand copies kept next to `wb16` */
+int vdk_convnext_param_count(const VdkConvNextConfig* cfg, int64_t* n_floats, int32_t* n_tensors, size_t* wx_bytes);
+int vdk_convnext_param_info(const VdkConvNextConfig* cfg, int32_t index, char* name, int32_t name_cap, int64_t* offset, int64_t* numel, int64_t* shape4,
+                            int32_t* ndim);
+int vdk_convnext_workspace_bytes(const VdkConvNextConfig* cfg, size_t* bytes);
+int vdk_convnext_refresh_weights(const VdkConvNextConfig* cfg, const float* params, void* wb16, void* wx, int32_t skip_wb16, void* stream);
+/* x f32 [B, in_chans, img, img] -> out f32 [B*(img/32)^2, dims[3]] (row (b, y, x), channel-contiguous) */
+int vdk_convnext_forward(const VdkConvNextConfig* cfg, const float* x, const float* params, const void* wb16, const void* wx, void* ws, size_t ws_bytes,
+                         float* out, void* stream);
+/* dout f32 (same shape as out) -> grads (flat fp32, overwritten); on_ready as in vdk_vit_backward */
+int vdk_convnext_backward(const VdkConvNextConfig* cfg, const float* dout, const float* params, const void* wb16, const void* wx, void* ws, size_t ws_bytes,
+                          float* grads, vdk_grad_ready_fn on_ready, void* user, void* stream);
+
 /* F.normalize(W, dim=0): inv[c] = 1/max(||W[:,c]||, eps); Wb = bf16 [3D, ldb]: the normalised weight as split planes
  * (hi, hi, lo) stacked along the contraction dim (rows [0,D) alone are the plain bf16 copy); columns C..Cp-1 zero */
 int vdk_colnorm_fwd(const float* W, int64_t ldw, int32_t D, int32_t C, int32_t Cp, float eps, float* inv, void* Wb, int64_t ldb, void* stream);

@@ -22,7 +22,7 @@
 // grid: (tiles_x * tiles_y * B, ceil(C / 64)); 128 threads = 8 columns x 16 channel quads; a thread owns an 8-row output strip of one
 // column and one channel quad: for every horizontal tap it reads the 14 inputs of its column once and feeds 7 x 8 FMAs.
 __global__ __launch_bounds__(128) void dwconv7_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
-                                                      const float* __restrict__ res, float* __restrict__ out, bf16_t* __restrict__ outb, int B, int H,
+                                                      const float* res, float* out /* may alias res */, bf16_t* __restrict__ outb, int B, int H,
                                                       int W, int C, int flip) {
   __shared__ __attribute__((aligned(16))) float xs[DW_H * DW_H * DW_CC];   // 50 176 B
   __shared__ __attribute__((aligned(16))) float ws[49 * DW_CC];            // 12 544 B

@@ -1,0 +1,432 @@
+// convnext_engine.hip — native forward/backward of timm ConvNeXt in feature mode (num_classes=0, global_pool=''), the CNN backbone
+// the reference's face / CBIR path builds at models/faceX/backbone/timm_wrapper.py:16-21 (`convnext_base` in configs/faceX/cbir.yaml:4-8).
+// Semantics restated from timm 0.9.16 (un-vendored; see oracle/convnext_ref.py, pinned against transformers.ConvNextModel):
+//   stem Conv 4x4/4 + LayerNorm2d -> 4 stages [ (LayerNorm2d + Conv 2x2/2 for stages 1-3) + depth x ConvNeXtBlock ] -> head.norm (LayerNorm2d)
+//   ConvNeXtBlock: x + gamma * fc2(GELU(fc1(LayerNorm(dwconv7x7(x)))))
+//
+// MI355X design: activations are NHWC rows (f32 residual stream, bf16 GEMM operands) exactly like the transformer's token rows, so
+// the stem (patchify), the downsamples (space-to-depth) and the pointwise convs all run on the LDS-DMA MFMA GEMM with fused
+// bias / GELU / residual epilogues, LayerNorm2d is the row LayerNorm kernel, and only the depthwise 7x7 (csrc/conv.hip) is new.
+// The layer scale is folded into fc2 at weight-refresh time (W2' = gamma (.) W2), so it costs nothing on the activation path; its
+// gradient comes from weight-sized tensors (vdk_layerscale_grad).  One C call per forward, one per backward; no allocation, no sync.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "vdk_device.h"
+#include "vdk_host.h"
+
+extern "C" {
+int vdk_gemm_bf16_nt(const VdkGemmDesc*, void*, size_t, void*);
+int vdk_layernorm_fwd(const float*, int64_t, int32_t, int32_t, const float*, const float*, float, void*, int64_t, int32_t, float*, float*, void*);
+int vdk_layernorm_bwd_workspace_bytes(int32_t, int32_t, size_t*);
+int vdk_layernorm_bwd(const void*, int64_t, int32_t, const float*, int64_t, const float*, const float*, const float*, const float*, int64_t, int32_t, int32_t,
+                      float*, int64_t, void*, int64_t, float*, float*, void*, size_t, void*);
+int vdk_reduce_rows_f32(const float*, int64_t, int32_t, int64_t, float*, float, void*);
+int vdk_colsum_bf16_workspace_bytes(int32_t, int32_t, size_t*);
+int vdk_colsum_bf16(const void*, int64_t, int32_t, int32_t, float*, void*, size_t, void*);
+int vdk_patchify_bf16(const float*, int32_t, int32_t, int32_t, int32_t, int32_t, void*, int32_t, void*);
+int vdk_cast_f32_bf16(const float*, void*, int64_t, void*);
+int vdk_transpose_cast_f32_bf16(const float*, int64_t, int32_t, int32_t, void*, int64_t, int32_t, void*);
+int vdk_transpose_bf16(const void*, int64_t, int32_t, int32_t, void*, int64_t, int32_t, int32_t, float*, void*);
+int vdk_dwconv7_fwd(const float*, const float*, const float*, const float*, float*, void*, int32_t, int32_t, int32_t, int32_t, int32_t, void*);
+int vdk_dwconv7_wgrad_workspace_bytes(int32_t, int32_t, int32_t, int32_t, size_t*);
+int vdk_dwconv7_wgrad(const float*, const float*, float*, float*, int32_t, int32_t, int32_t, int32_t, void*, size_t, void*);
+int vdk_dwconv7_weight_prep(const float*, float*, int32_t, void*);
+int vdk_space_to_depth2_bf16(const void*, void*, int32_t, int32_t, int32_t, int32_t, int32_t, void*);
+int vdk_conv2x2_weight_prep(const float*, void*, void*, int32_t, int32_t, void*);
+int vdk_conv2x2_wgrad_unpermute(const float*, float*, int32_t, int32_t, void*);
+int vdk_layerscale_weight_prep(const float*, const float*, const float*, void*, void*, float*, int32_t, int32_t, void*);
+int vdk_layerscale_grad(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int32_t, int32_t, void*);
+}
+
+#define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+static inline int64_t up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+namespace {
+
+struct CnDims {
+  int B, img, Cin, Kst;   // Kst = Cin * 16: K of the stem GEMM
+  int depth[4], C[4], H[4], R[4];
+  int nblk;
+  float eps;
+};
+int cn_dims(const VdkConvNextConfig* c, CnDims* d) {
+  if (!c) return vdk_fail(VDK_EINVAL, "convnext: null config");
+  if (c->batch <= 0 || c->img_size <= 0 || (c->img_size % 32) || c->in_chans <= 0) return vdk_fail(VDK_EINVAL, "convnext: bad config (img_size % 32 == 0)");
+  d->B = c->batch; d->img = c->img_size; d->Cin = c->in_chans; d->Kst = c->in_chans * 16; d->eps = c->ln_eps; d->nblk = 0;
+  for (int i = 0; i < 4; ++i) {
+    if (c->depths[i] <= 0 || c->dims[i] <= 0 || (c->dims[i] & 7)) return vdk_fail(VDK_EINVAL, "convnext: bad config (dims % 8 == 0, depths > 0)");
+    d->depth[i] = c->depths[i]; d->C[i] = c->dims[i]; d->H[i] = c->img_size >> (2 + i);
+    const int64_t r = (int64_t)c->batch * d->H[i] * d->H[i];
+    if (r > 0x7fffffffLL) return vdk_fail(VDK_EINVAL, "convnext: batch x resolution too large");
+    d->R[i] = (int)r;
+    d->nblk += c->depths[i];
+  }
+  return VDK_OK;
+}
+
+struct PEntry { char name[64]; int64_t off, numel; int64_t shape[4]; int ndim; };
+struct BlkP { int64_t gamma, dw_w, dw_b, nw, nb, fc1_w, fc1_b, fc2_w, fc2_b; };
+struct StageP { int64_t ds_nw, ds_nb, ds_w, ds_b; std::vector<BlkP> blk; };
+struct PLayout {
+  int64_t stem_w, stem_b, stem_nw, stem_nb, head_nw, head_nb, total;
+  StageP st[4];
+  std::vector<PEntry> entries;
+};
+int64_t p_take(int64_t& cur, int64_t n) { int64_t o = cur; cur = up(cur + n, 64); return o; }
+void add_entry(PLayout* p, const char* name, int64_t off, int ndim, int64_t s0, int64_t s1 = 1, int64_t s2 = 1, int64_t s3 = 1) {
+  PEntry e; memset(&e, 0, sizeof(e));
+  snprintf(e.name, sizeof(e.name), "%s", name);
+  e.off = off; e.ndim = ndim; e.shape[0] = s0; e.shape[1] = s1; e.shape[2] = s2; e.shape[3] = s3; e.numel = s0 * s1 * s2 * s3;
+  p->entries.push_back(e);
+}
+// timm state_dict order and names
+void cn_layout(const CnDims& d, PLayout* p) {
+  int64_t cur = 0;
+  char nm[64];
+  p->entries.clear();
+  p->stem_w = p_take(cur, (int64_t)d.C[0] * d.Kst); add_entry(p, "stem.0.weight", p->stem_w, 4, d.C[0], d.Cin, 4, 4);
+  p->stem_b = p_take(cur, d.C[0]); add_entry(p, "stem.0.bias", p->stem_b, 1, d.C[0]);
+  p->stem_nw = p_take(cur, d.C[0]); add_entry(p, "stem.1.weight", p->stem_nw, 1, d.C[0]);
+  p->stem_nb = p_take(cur, d.C[0]); add_entry(p, "stem.1.bias", p->stem_nb, 1, d.C[0]);
+  for (int i = 0; i < 4; ++i) {
+    StageP& s = p->st[i];
+    const int C = d.C[i], M = 4 * C;
+    s.ds_nw = s.ds_nb = s.ds_w = s.ds_b = -1;
+    if (i > 0) {
+      const int Ci = d.C[i - 1];
+      s.ds_nw = p_take(cur, Ci); snprintf(nm, 64, "stages.%d.downsample.0.weight", i); add_entry(p, nm, s.ds_nw, 1, Ci);
+      s.ds_nb = p_take(cur, Ci); snprintf(nm, 64, "stages.%d.downsample.0.bias", i); add_entry(p, nm, s.ds_nb, 1, Ci);
+      s.ds_w = p_take(cur, (int64_t)C * Ci * 4); snprintf(nm, 64, "stages.%d.downsample.1.weight", i); add_entry(p, nm, s.ds_w, 4, C, Ci, 2, 2);
+      s.ds_b = p_take(cur, C); snprintf(nm, 64, "stages.%d.downsample.1.bias", i); add_entry(p, nm, s.ds_b, 1, C);
+    }
+    s.blk.resize(d.depth[i]);
+    for (int j = 0; j < d.depth[i]; ++j) {
+      BlkP& b = s.blk[j];
+      b.gamma = p_take(cur, C); snprintf(nm, 64, "stages.%d.blocks.%d.gamma", i, j); add_entry(p, nm, b.gamma, 1, C);
+      b.dw_w = p_take(cur, (int64_t)C * 49); snprintf(nm, 64, "stages.%d.blocks.%d.conv_dw.weight", i, j); add_entry(p, nm, b.dw_w, 4, C, 1, 7, 7);
+      b.dw_b = p_take(cur, C); snprintf(nm, 64, "stages.%d.blocks.%d.conv_dw.bias", i, j); add_entry(p, nm, b.dw_b, 1, C);
+      b.nw = p_take(cur, C); snprintf(nm, 64, "stages.%d.blocks.%d.norm.weight", i, j); add_entry(p, nm, b.nw, 1, C);
+      b.nb = p_take(cur, C); snprintf(nm, 64, "stages.%d.blocks.%d.norm.bias", i, j); add_entry(p, nm, b.nb, 1, C);
+      b.fc1_w = p_take(cur, (int64_t)M * C); snprintf(nm, 64, "stages.%d.blocks.%d.mlp.fc1.weight", i, j); add_entry(p, nm, b.fc1_w, 2, M, C);
+      b.fc1_b = p_take(cur, M); snprintf(nm, 64, "stages.%d.blocks.%d.mlp.fc1.bias", i, j); add_entry(p, nm, b.fc1_b, 1, M);
+      b.fc2_w = p_take(cur, (int64_t)C * M); snprintf(nm, 64, "stages.%d.blocks.%d.mlp.fc2.weight", i, j); add_entry(p, nm, b.fc2_w, 2, C, M);
+      b.fc2_b = p_take(cur, C); snprintf(nm, 64, "stages.%d.blocks.%d.mlp.fc2.bias", i, j); add_entry(p, nm, b.fc2_b, 1, C);
+    }
+  }
+  p->head_nw = p_take(cur, d.C[3]); add_entry(p, "head.norm.weight", p->head_nw, 1, d.C[3]);
+  p->head_nb = p_take(cur, d.C[3]); add_entry(p, "head.norm.bias", p->head_nb, 1, d.C[3]);
+  p->total = cur;
+}
+
+// derived operand copies (`wx`, byte offsets): per block the tap-major depthwise weight, fc1^T, the layer-scale-folded fc2 and its
+// transpose + bias; per downsample the (ky,kx,cin)-ordered weight and its transpose
+struct BlkX { size_t dwt, fc1t, fc2p, fc2pt, b2p; };
+struct XLayout { size_t total; size_t dsw[4], dswt[4]; std::vector<BlkX> blk[4]; };
+size_t w_take(size_t& cur, size_t n) { size_t o = cur; cur = (cur + n + 255) & ~(size_t)255; return o; }
+void cn_xlayout(const CnDims& d, XLayout* x) {
+  size_t cur = 0;
+  for (int i = 0; i < 4; ++i) {
+    const size_t C = d.C[i], M = 4 * C;
+    x->dsw[i] = x->dswt[i] = 0;
+    if (i > 0) { x->dsw[i] = w_take(cur, C * 4 * d.C[i - 1] * 2); x->dswt[i] = w_take(cur, C * 4 * d.C[i - 1] * 2); }
+    x->blk[i].resize(d.depth[i]);
+    for (int j = 0; j < d.depth[i]; ++j) {
+      BlkX& b = x->blk[i][j];
+      b.dwt = w_take(cur, 49 * C * 4); b.fc1t = w_take(cur, C * M * 2); b.fc2p = w_take(cur, C * M * 2); b.fc2pt = w_take(cur, C * M * 2); b.b2p = w_take(cur, C * 4);
+    }
+  }
+  x->total = cur;
+}
+
+int wgrad_splitk(int M, int N, int K) {
+  if (K < 4096) return 1;
+  int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  int s = (1024 + tiles - 1) / tiles;
+  if (s > 32) s = 32;
+  return s < 1 ? 1 : s;
+}
+int wgrad_splitk_tn(int M, int N, int K) {   // see csrc/vit_engine.hip: tiles * splits just under a whole number of 256-CU rounds
+  const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+  int s = 256 / tiles;
+  if (s < 1) s = 1;
+  const int kt = K / 64;
+  if (s > kt / 4) s = kt / 4;
+  if (s > 64) s = 64;
+  return s < 1 ? 1 : s;
+}
+
+struct BlkW { size_t t, stats, h, u, g; };
+struct WsPlan {
+  size_t total;
+  size_t patches, y0, stats0;
+  size_t X[4];                       // f32 (depth + 1) x [R, C]
+  size_t ds_stats[4], ds_h[4], ds_A[4];
+  std::vector<BlkW> blk[4];
+  size_t head_stats;
+  // backward scratch (sized by the largest stage)
+  size_t dxa, dxb, dt, du, dh, dA, dhds, dw2p, db2p, dwdsp;
+  size_t slabs, slabs_bytes, lnws, lnws_bytes, csws, csws_bytes, dwws, dwws_bytes, tA, tB;
+};
+void cn_plan(const CnDims& d, WsPlan* w) {
+  size_t cur = 0;
+  w->patches = w_take(cur, (size_t)d.R[0] * d.Kst * 2);
+  w->y0 = w_take(cur, (size_t)d.R[0] * d.C[0] * 4);
+  w->stats0 = w_take(cur, (size_t)d.R[0] * 2 * 4);
+  size_t rc = 0, rm = 0, ra = 0, rh = 0, cm = 0, wds = 0, sl = 0, ln = 0, cs = 0, dww = 0, tr = 0;
+  auto wg = [&](int out, int in, int rows) {
+    const int k1 = wgrad_splitk(out, in, (int)up(rows, 64)), k2 = wgrad_splitk_tn(out, in, rows);
+    const size_t b = (size_t)(k1 > k2 ? k1 : k2) * out * in * 4; if (b > sl) sl = b;
+    size_t c2 = 0; vdk_colsum_bf16_workspace_bytes(rows, out, &c2);
+    const size_t c1 = (size_t)((up(rows, 64) + 63) / 64) * out * 4;
+    if (c2 > cs) cs = c2;
+    if (c1 > cs) cs = c1;
+    if (rows % 64) { const size_t t = (size_t)(out > in ? out : in) * up(rows, 64) * 2; if (t > tr) tr = t; }
+  };
+  wg(d.C[0], d.Kst, d.R[0]);
+  for (int i = 0; i < 4; ++i) {
+    const size_t R = d.R[i], C = d.C[i], M = 4 * C;
+    w->ds_stats[i] = w->ds_h[i] = w->ds_A[i] = 0;
+    if (i > 0) {
+      const size_t Rp = d.R[i - 1], Ci = d.C[i - 1];
+      w->ds_stats[i] = w_take(cur, Rp * 2 * 4); w->ds_h[i] = w_take(cur, Rp * Ci * 2); w->ds_A[i] = w_take(cur, R * 4 * Ci * 2);
+      if (R * 4 * Ci > ra) ra = R * 4 * Ci;
+      if (Rp * Ci > rh) rh = Rp * Ci;
+      if (C * 4 * Ci > wds) wds = C * 4 * Ci;
+      wg((int)C, (int)(4 * Ci), (int)R);
+      size_t l = 0; vdk_layernorm_bwd_workspace_bytes((int)Rp, (int)Ci, &l); if (l > ln) ln = l;
+    }
+    w->X[i] = w_take(cur, (size_t)(d.depth[i] + 1) * R * C * 4);
+    w->blk[i].resize(d.depth[i]);
+    for (int j = 0; j < d.depth[i]; ++j) {
+      BlkW& b = w->blk[i][j];
+      b.t = w_take(cur, R * C * 4); b.stats = w_take(cur, R * 2 * 4); b.h = w_take(cur, R * C * 2); b.u = w_take(cur, R * M * 2); b.g = w_take(cur, R * M * 2);
+    }
+    if (R * C > rc) rc = R * C;
+    if (R * M > rm) rm = R * M;
+    if (C * M > cm) cm = C * M;
+    wg((int)C, (int)M, (int)R); wg((int)M, (int)C, (int)R);
+    size_t l = 0; vdk_layernorm_bwd_workspace_bytes((int)R, (int)C, &l); if (l > ln) ln = l;
+    size_t q = 0; vdk_dwconv7_wgrad_workspace_bytes(d.B, d.H[i], d.H[i], (int)C, &q); if (q > dww) dww = q;
+  }
+  w->head_stats = w_take(cur, (size_t)d.R[3] * 2 * 4);
+  w->dxa = w_take(cur, rc * 4); w->dxb = w_take(cur, rc * 2); w->dt = w_take(cur, rc * 4); w->du = w_take(cur, rm * 2); w->dh = w_take(cur, rc * 2);
+  w->dA = w_take(cur, ra * 2 + 256); w->dhds = w_take(cur, rh * 2 + 256);
+  w->dw2p = w_take(cur, cm * 4); w->db2p = w_take(cur, 4096 * 4); w->dwdsp = w_take(cur, wds * 4 + 256);
+  w->slabs_bytes = sl; w->slabs = w_take(cur, sl + 256);
+  w->lnws_bytes = ln; w->lnws = w_take(cur, ln + 256);
+  w->csws_bytes = cs; w->csws = w_take(cur, cs + 256);
+  w->dwws_bytes = dww; w->dwws = w_take(cur, dww + 256);
+  w->tA = w_take(cur, tr + 256); w->tB = w_take(cur, tr + 256);
+  w->total = cur;
+}
+
+int gemm(hipStream_t s, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K, int cdt, const float* bias,
+         const float* res, int64_t ldr, int act, void* aux, int64_t ldaux) {
+  VdkGemmDesc g = {};
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.c_dtype = cdt; g.bias = bias;
+  g.residual = res; g.ldr = ldr; g.act = act; g.aux = aux; g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = 1;
+  return vdk_gemm_bf16_nt(&g, nullptr, 0, s);
+}
+// dW[out,in] = dY^T X, db = colsum(dY)   (dY bf16 [rows,out], X bf16 [rows,in]); TN LDS-DMA kernel when rows % 64 == 0, else explicit transposes
+int linear_wgrad(hipStream_t s, const WsPlan& w, char* base, const bf16_t* dY, const bf16_t* X, int rows, int out, int in, float* dW, float* db) {
+  if ((rows % 64) == 0) {
+    VdkGemmDesc g = {};
+    g.A = dY; g.lda = out; g.B = X; g.ldb = in; g.C = dW; g.ldc = in; g.M = out; g.N = in; g.K = rows; g.c_dtype = VDK_F32;
+    g.alpha = 1.0f; g.splitk = wgrad_splitk_tn(out, in, rows); g.trans = 1;
+    RC(vdk_gemm_bf16_nt(&g, base + w.slabs, w.slabs_bytes, s));
+    return vdk_colsum_bf16(dY, out, rows, out, db, base + w.csws, w.csws_bytes, s);
+  }
+  const int rp = (int)up(rows, 64);
+  bf16_t* tA = (bf16_t*)(base + w.tA); bf16_t* tB = (bf16_t*)(base + w.tB);
+  float* csp = (float*)(base + w.csws);
+  RC(vdk_transpose_bf16(dY, out, rows, out, tA, rp, rp, 0, csp, s));
+  RC(vdk_transpose_bf16(X, in, rows, in, tB, rp, rp, 0, nullptr, s));
+  VdkGemmDesc g = {};
+  g.A = tA; g.lda = rp; g.B = tB; g.ldb = rp; g.C = dW; g.ldc = in; g.M = out; g.N = in; g.K = rp; g.c_dtype = VDK_F32; g.alpha = 1.0f;
+  g.splitk = wgrad_splitk(out, in, rp);
+  RC(vdk_gemm_bf16_nt(&g, base + w.slabs, w.slabs_bytes, s));
+  return vdk_reduce_rows_f32(csp, out, (rp + 63) / 64, out, db, 1.0f, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int vdk_convnext_param_count(const VdkConvNextConfig* cfg, int64_t* n_floats, int32_t* n_tensors, size_t* wx_bytes) {
+  CnDims d; RC(cn_dims(cfg, &d));
+  PLayout p; cn_layout(d, &p);
+  XLayout x; cn_xlayout(d, &x);
+  if (n_floats) *n_floats = p.total;
+  if (n_tensors) *n_tensors = (int32_t)p.entries.size();
+  if (wx_bytes) *wx_bytes = x.total;
+  return VDK_OK;
+}
+
+int vdk_convnext_param_info(const VdkConvNextConfig* cfg, int32_t index, char* name, int32_t name_cap, int64_t* offset, int64_t* numel, int64_t* shape4,
+                            int32_t* ndim) {
+  CnDims d; RC(cn_dims(cfg, &d));
+  PLayout p; cn_layout(d, &p);
+  if (index < 0 || index >= (int32_t)p.entries.size()) return vdk_fail(VDK_EINVAL, "vdk_convnext_param_info: index out of range");
+  const PEntry& e = p.entries[index];
+  if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s", e.name);
+  if (offset) *offset = e.off;
+  if (numel) *numel = e.numel;
+  if (shape4) for (int i = 0; i < 4; ++i) shape4[i] = e.shape[i];
+  if (ndim) *ndim = e.ndim;
+  return VDK_OK;
+}
+
+int vdk_convnext_workspace_bytes(const VdkConvNextConfig* cfg, size_t* bytes) {
+  CnDims d; RC(cn_dims(cfg, &d));
+  WsPlan w; cn_plan(d, &w);
+  if (!bytes) return vdk_fail(VDK_EINVAL, "null");
+  *bytes = w.total;
+  return VDK_OK;
+}
+
+// wb16 = bf16 copy of the flat parameters (stem and fc1 operands are read from it as they lie) unless skip_wb16; wx = derived copies
+int vdk_convnext_refresh_weights(const VdkConvNextConfig* cfg, const float* params, void* wb16, void* wx, int32_t skip_wb16, void* stream) {
+  CnDims d; RC(cn_dims(cfg, &d));
+  PLayout p; cn_layout(d, &p);
+  XLayout x; cn_xlayout(d, &x);
+  if (!params || !wb16 || !wx) return vdk_fail(VDK_EINVAL, "vdk_convnext_refresh_weights: null pointer");
+  if (!skip_wb16) RC(vdk_cast_f32_bf16(params, wb16, p.total, stream));
+  char* xb = (char*)wx;
+  for (int i = 0; i < 4; ++i) {
+    const int C = d.C[i], M = 4 * C;
+    if (i > 0) RC(vdk_conv2x2_weight_prep(params + p.st[i].ds_w, xb + x.dsw[i], xb + x.dswt[i], C, d.C[i - 1], stream));
+    for (int j = 0; j < d.depth[i]; ++j) {
+      const BlkP& b = p.st[i].blk[j]; const BlkX& bx = x.blk[i][j];
+      RC(vdk_dwconv7_weight_prep(params + b.dw_w, (float*)(xb + bx.dwt), C, stream));
+      RC(vdk_transpose_cast_f32_bf16(params + b.fc1_w, C, M, C, xb + bx.fc1t, M, M, stream));
+      RC(vdk_layerscale_weight_prep(params + b.fc2_w, params + b.fc2_b, params + b.gamma, xb + bx.fc2p, xb + bx.fc2pt, (float*)(xb + bx.b2p), C, M, stream));
+    }
+  }
+  return VDK_OK;
+}
+
+// x f32 [B, Cin, img, img] (NCHW, as the reference's dataloader hands it) -> out f32 [B * (img/32)^2, dims[3]]: the head-normed map in NHWC rows
+int vdk_convnext_forward(const VdkConvNextConfig* cfg, const float* x, const float* params, const void* wb16, const void* wx, void* ws, size_t ws_bytes,
+                         float* out, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  CnDims d; RC(cn_dims(cfg, &d));
+  PLayout p; cn_layout(d, &p);
+  XLayout xl; cn_xlayout(d, &xl);
+  WsPlan w; cn_plan(d, &w);
+  if (!x || !params || !wb16 || !wx || !ws || !out) return vdk_fail(VDK_EINVAL, "vdk_convnext_forward: null pointer");
+  if (ws_bytes < w.total) return vdk_fail(VDK_EWORKSPACE, "vdk_convnext_forward: workspace too small");
+  char* base = (char*)ws;
+  const bf16_t* wb = (const bf16_t*)wb16;
+  const char* xb = (const char*)wx;
+  // stem: Conv2d(Cin, C0, 4, stride 4) as patchify + GEMM, then LayerNorm2d
+  bf16_t* patches = (bf16_t*)(base + w.patches);
+  float* y0 = (float*)(base + w.y0);
+  float* st0 = (float*)(base + w.stats0);
+  RC(vdk_patchify_bf16(x, d.B, d.Cin, d.img, d.img, 4, patches, d.Kst, s));
+  RC(gemm(s, patches, d.Kst, wb + p.stem_w, d.Kst, y0, d.C[0], d.R[0], d.C[0], d.Kst, VDK_F32, params + p.stem_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0));
+  RC(vdk_layernorm_fwd(y0, d.C[0], d.R[0], d.C[0], params + p.stem_nw, params + p.stem_nb, d.eps, base + w.X[0], d.C[0], VDK_F32, st0, st0 + d.R[0], s));
+  for (int i = 0; i < 4; ++i) {
+    const int R = d.R[i], C = d.C[i], M = 4 * C, H = d.H[i];
+    float* X = (float*)(base + w.X[i]);
+    const size_t XS = (size_t)R * C;
+    if (i > 0) {
+      // downsample: LayerNorm2d -> Conv2d(Ci, C, 2, stride 2) as space-to-depth + GEMM
+      const int Rp = d.R[i - 1], Ci = d.C[i - 1];
+      const float* xprev = (const float*)(base + w.X[i - 1]) + (size_t)d.depth[i - 1] * Rp * Ci;
+      float* dst = (float*)(base + w.ds_stats[i]);
+      RC(vdk_layernorm_fwd(xprev, Ci, Rp, Ci, params + p.st[i].ds_nw, params + p.st[i].ds_nb, d.eps, base + w.ds_h[i], Ci, VDK_BF16, dst, dst + Rp, s));
+      RC(vdk_space_to_depth2_bf16(base + w.ds_h[i], base + w.ds_A[i], d.B, d.H[i - 1], d.H[i - 1], Ci, 0, s));
+      RC(gemm(s, base + w.ds_A[i], 4 * Ci, xb + xl.dsw[i], 4 * Ci, X, C, R, C, 4 * Ci, VDK_F32, params + p.st[i].ds_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0));
+    }
+    for (int j = 0; j < d.depth[i]; ++j) {
+      const BlkP& b = p.st[i].blk[j]; const BlkX& bx = xl.blk[i][j]; const BlkW& bw = w.blk[i][j];
+      float* xin = X + (size_t)j * XS; float* xout = xin + XS;
+      float* t = (float*)(base + bw.t); float* st = (float*)(base + bw.stats);
+      RC(vdk_dwconv7_fwd(xin, (const float*)(xb + bx.dwt), params + b.dw_b, nullptr, t, nullptr, d.B, H, H, C, 0, s));
+      RC(vdk_layernorm_fwd(t, C, R, C, params + b.nw, params + b.nb, d.eps, base + bw.h, C, VDK_BF16, st, st + R, s));
+      RC(gemm(s, base + bw.h, C, wb + b.fc1_w, C, base + bw.g, M, R, M, C, VDK_BF16, params + b.fc1_b, nullptr, 0, VDK_ACT_GELU, base + bw.u, M));
+      RC(gemm(s, base + bw.g, M, xb + bx.fc2p, M, xout, C, R, C, M, VDK_F32, (const float*)(xb + bx.b2p), xin, C, VDK_ACT_NONE, nullptr, 0));
+    }
+  }
+  const float* xlast = (const float*)(base + w.X[3]) + (size_t)d.depth[3] * d.R[3] * d.C[3];
+  float* hs = (float*)(base + w.head_stats);
+  RC(vdk_layernorm_fwd(xlast, d.C[3], d.R[3], d.C[3], params + p.head_nw, params + p.head_nb, d.eps, out, d.C[3], VDK_F32, hs, hs + d.R[3], s));
+  return vdk_check_launch("vdk_convnext_forward");
+}
+
+// dout f32 [B * (img/32)^2, dims[3]] -> grads (flat fp32, param layout, fully overwritten).  on_ready(user, offset, numel): see vdk_vit_backward.
+int vdk_convnext_backward(const VdkConvNextConfig* cfg, const float* dout, const float* params, const void* wb16, const void* wx, void* ws, size_t ws_bytes,
+                          float* grads, vdk_grad_ready_fn on_ready, void* user, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  CnDims d; RC(cn_dims(cfg, &d));
+  PLayout p; cn_layout(d, &p);
+  XLayout xl; cn_xlayout(d, &xl);
+  WsPlan w; cn_plan(d, &w);
+  if (!dout || !params || !wb16 || !wx || !ws || !grads) return vdk_fail(VDK_EINVAL, "vdk_convnext_backward: null pointer");
+  if (ws_bytes < w.total) return vdk_fail(VDK_EWORKSPACE, "vdk_convnext_backward: workspace too small");
+  char* base = (char*)ws;
+  const char* xb = (const char*)wx;
+  float* dxa = (float*)(base + w.dxa); bf16_t* dxb = (bf16_t*)(base + w.dxb);
+  float* dt = (float*)(base + w.dt); bf16_t* du = (bf16_t*)(base + w.du); bf16_t* dh = (bf16_t*)(base + w.dh);
+  float* dw2p = (float*)(base + w.dw2p); float* db2p = (float*)(base + w.db2p);
+  void* lnws = base + w.lnws;
+  {
+    const float* xlast = (const float*)(base + w.X[3]) + (size_t)d.depth[3] * d.R[3] * d.C[3];
+    const float* hs = (const float*)(base + w.head_stats);
+    RC(vdk_layernorm_bwd(dout, d.C[3], VDK_F32, xlast, d.C[3], hs, hs + d.R[3], params + p.head_nw, nullptr, 0, d.R[3], d.C[3], dxa, d.C[3], dxb, d.C[3],
+                         grads + p.head_nw, grads + p.head_nb, lnws, w.lnws_bytes, s));
+    if (on_ready) on_ready(user, p.head_nw, p.total - p.head_nw);
+  }
+  for (int i = 3; i >= 0; --i) {
+    const int R = d.R[i], C = d.C[i], M = 4 * C, H = d.H[i];
+    const float* X = (const float*)(base + w.X[i]);
+    const size_t XS = (size_t)R * C;
+    if (C > 4096) return vdk_fail(VDK_EUNSUPPORTED, "vdk_convnext_backward: dims <= 4096");
+    for (int j = d.depth[i] - 1; j >= 0; --j) {
+      const BlkP& b = p.st[i].blk[j]; const BlkX& bx = xl.blk[i][j]; const BlkW& bw = w.blk[i][j];
+      const float* xin = X + (size_t)j * XS;
+      const float* st = (const float*)(base + bw.stats);
+      // dxa / dxb = dL/d(block output).  MLP branch with the layer scale folded into fc2:
+      RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + bw.g), R, C, M, dw2p, db2p));
+      RC(vdk_layerscale_grad(dw2p, db2p, params + b.fc2_w, params + b.fc2_b, params + b.gamma, grads + b.fc2_w, grads + b.fc2_b, grads + b.gamma, C, M, s));
+      RC(gemm(s, dxb, C, xb + bx.fc2pt, C, du, M, R, M, C, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_DGELU, base + bw.u, M));
+      RC(linear_wgrad(s, w, base, du, (const bf16_t*)(base + bw.h), R, M, C, grads + b.fc1_w, grads + b.fc1_b));
+      RC(gemm(s, du, M, xb + bx.fc1t, M, dh, C, R, C, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0));
+      RC(vdk_layernorm_bwd(dh, C, VDK_BF16, (const float*)(base + bw.t), C, st, st + R, params + b.nw, nullptr, 0, R, C, dt, C, nullptr, 0, grads + b.nw,
+                           grads + b.nb, lnws, w.lnws_bytes, s));
+      // depthwise conv: weight/bias gradient, then input gradient + shortcut gradient (in place on dxa) and its bf16 copy
+      RC(vdk_dwconv7_wgrad(xin, dt, grads + b.dw_w, grads + b.dw_b, d.B, H, H, C, base + w.dwws, w.dwws_bytes, s));
+      RC(vdk_dwconv7_fwd(dt, (const float*)(xb + bx.dwt), nullptr, dxa, dxa, dxb, d.B, H, H, C, 1, s));
+      if (on_ready) {
+        const int64_t end = (j + 1 < d.depth[i]) ? p.st[i].blk[j + 1].gamma : (i < 3 ? p.st[i + 1].ds_nw : p.head_nw);
+        on_ready(user, b.gamma, end - b.gamma);
+      }
+    }
+    if (i > 0) {
+      // dxa / dxb = dL/d(downsample conv output) [R, C]
+      const int Rp = d.R[i - 1], Ci = d.C[i - 1];
+      float* dwdsp = (float*)(base + w.dwdsp);
+      RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + w.ds_A[i]), R, C, 4 * Ci, dwdsp, grads + p.st[i].ds_b));
+      RC(vdk_conv2x2_wgrad_unpermute(dwdsp, grads + p.st[i].ds_w, C, Ci, s));
+      RC(gemm(s, dxb, C, xb + xl.dswt[i], C, base + w.dA, 4 * Ci, R, 4 * Ci, C, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0));
+      RC(vdk_space_to_depth2_bf16(base + w.dA, base + w.dhds, d.B, d.H[i - 1], d.H[i - 1], Ci, 1, s));
+      const float* xprev = (const float*)(base + w.X[i - 1]) + (size_t)d.depth[i - 1] * Rp * Ci;
+      const float* dst = (const float*)(base + w.ds_stats[i]);
+      RC(vdk_layernorm_bwd(base + w.dhds, Ci, VDK_BF16, xprev, Ci, dst, dst + Rp, params + p.st[i].ds_nw, nullptr, 0, Rp, Ci, dxa, Ci, dxb, Ci,
+                           grads + p.st[i].ds_nw, grads + p.st[i].ds_nb, lnws, w.lnws_bytes, s));
+      if (on_ready) on_ready(user, p.st[i].ds_nw, p.st[i].blk[0].gamma - p.st[i].ds_nw);
+    } else {
+      // stem: LayerNorm2d backward (bf16 gradient of the conv output), then the conv's weight / bias gradient
+      const float* st0 = (const float*)(base + w.stats0);
+      RC(vdk_layernorm_bwd(dxa, C, VDK_F32, (const float*)(base + w.y0), C, st0, st0 + R, params + p.stem_nw, nullptr, 0, R, C, nullptr, 0, dh, C,
+                           grads + p.stem_nw, grads + p.stem_nb, lnws, w.lnws_bytes, s));
+      RC(linear_wgrad(s, w, base, dh, (const bf16_t*)(base + w.patches), R, C, d.Kst, grads + p.stem_w, grads + p.stem_b));
+      if (on_ready) on_ready(user, 0, p.st[0].blk[0].gamma);
+    }
+  }
+  return vdk_check_launch("vdk_convnext_backward");
+}
+
+}  // extern "C"
