@@ -6,7 +6,7 @@ import torch.nn.functional as F
 from visiondk_amd import ops
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 64), (1, 7, 7, 16), (2, 14, 10, 72), (1, 20, 17, 8)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 64), (1, 7, 7, 16), (2, 14, 10, 72), (1, 20, 17, 8), (1, 14, 14, 64), (1, 7, 28, 8)])
 def test_dwconv7_fwd_dgrad_wgrad(be, dev, B, H, W, C):
     torch.manual_seed(0)
     x = torch.randn(B, C, H, W)

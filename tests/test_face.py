@@ -107,3 +107,69 @@ def test_extract_cbir_eval_embeddings(be, dev):
     assert got.shape == (5, 64) and got.dtype == np.float32
     assert _rel(got, exp) < 2e-2
     np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, rtol=1e-5)
+
+
+# ---- CNN backbone (timm ConvNeXt) + BatchNorm2d neck: timm_wrapper.py:30-37 ----------------------------------------------------------
+def _build_cnn(be, dev, monkeypatch):
+    from oracle.convnext_ref import TimmWrapperCNNRef
+    from visiondk_amd import convnext
+    depths, dims, img = (1, 1, 2, 1), (8, 16, 24, 32), 64
+    monkeypatch.setitem(convnext.TIMM_CONVNEXTS, "convnext_test", dict(depths=depths, dims=dims))
+    cfg = {"task": "cbir", "image_size": img,
+           "backbone": {"timm-convnext_test": {"pretrained": False, "image_size": img, "feat_dim": 64}},
+           "head": {"arcface": {"feat_dim": 64, "num_class": 40, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
+    torch.manual_seed(0)
+    model = face.get_model(cfg, None, 0, backend=be, device=dev).model
+    ref = TimmWrapperCNNRef(64, img, 3, depths, dims)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if n.endswith("gamma"):
+                p.copy_(torch.rand_like(p) * 0.5 + 0.25)
+            elif p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.05)
+            elif "model." in n:
+                p.copy_(torch.randn_like(p) * (0.5 / (p[0].numel() ** 0.5)))
+    bb = model.trainingwrapper["backbone"]
+    bb.load_state_dict({k: v.to(dev) for k, v in ref.state_dict().items()}, strict=True)
+    return model, ref, img
+
+
+def test_cnn_backbone_state_dict_and_training_step(be, dev, monkeypatch):
+    model, ref, img = _build_cnn(be, dev, monkeypatch)
+    bb = model.trainingwrapper["backbone"]
+    assert list(bb.state_dict().keys()) == list(ref.state_dict().keys())
+    assert "model.stages.2.blocks.1.conv_dw.weight" in bb.state_dict() and "output_layer.0.running_var" in bb.state_dict()
+    head = model.trainingwrapper["head"]
+    rhead = _RefArcFace(head.weight.detach().cpu())
+    torch.manual_seed(1)
+    x = torch.randn(8, 3, img, img); y = torch.randint(0, 40, (8,))
+    model.train(); ref.train()
+    loss_ref = torch.nn.functional.cross_entropy(rhead(ref(x), y), y)
+    loss_ref.backward()
+    loss = torch.nn.functional.cross_entropy(model(x.to(dev), y.to(dev)), y.to(dev))
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 2e-2 * abs(loss_ref.item())
+    got = dict(bb.named_parameters()); exp = dict(ref.named_parameters())
+    assert set(got) == set(exp)
+    gmax = max(exp[n].grad.norm().item() for n in exp)
+    for n in exp:
+        if exp[n].grad.norm().item() < 1e-5 * gmax:
+            assert got[n].grad.norm().item() < 1e-3 * gmax, n     # analytically zero (e.g. the Linear bias in front of a train-mode BatchNorm1d)
+            continue
+        r = _rel(got[n].grad, exp[n].grad)
+        assert r < 8e-2, (n, r)
+    assert _rel(head.weight.grad, rhead.weight.grad) < 8e-2
+    for i in (0, 3):   # BatchNorm2d and BatchNorm1d running statistics follow torch's update
+        assert _rel(bb.output_layer[i].running_mean, ref.output_layer[i].running_mean) < 2e-2
+        assert _rel(bb.output_layer[i].running_var, ref.output_layer[i].running_var) < 2e-2
+
+
+def test_cnn_extract_cbir_eval_embeddings(be, dev, monkeypatch):
+    model, ref, img = _build_cnn(be, dev, monkeypatch)
+    bb = model.trainingwrapper["backbone"]
+    x = torch.randn(5, 3, img, img)
+    ref.eval()
+    with torch.no_grad():
+        exp = torch.nn.functional.normalize(ref(x)).numpy()
+    got = face.FeatureExtractor(bb).extract_cbir([x[:3], x[3:]], dev)
+    assert got.shape == (5, 64) and _rel(got, exp) < 2e-2

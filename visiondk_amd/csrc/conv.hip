@@ -19,26 +19,29 @@
 
 // ------------------------------------------------------------------------------------ K6 forward / input gradient
 // out[b,y,x,c] = bias[c] + res[b,y,x,c] + sum_{i,j} wt[(flip ? 48 - (7i+j) : 7i+j)][c] * in[b, y+i-3, x+j-3, c]   (zero padding)
-// grid: (tiles_x * tiles_y * B, ceil(C / 64)); 128 threads = 8 columns x 16 channel quads; a thread owns an 8-row output strip of one
-// column and one channel quad: for every horizontal tap it reads the 14 inputs of its column once and feeds 7 x 8 FMAs.
-__global__ __launch_bounds__(128) void dwconv7_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
-                                                      const float* res, float* out /* may alias res */, bf16_t* __restrict__ outb, int B, int H,
-                                                      int W, int C, int flip) {
-  __shared__ __attribute__((aligned(16))) float xs[DW_H * DW_H * DW_CC];   // 50 176 B
+// Output tile TH x TW (7 x 14 for ConvNeXt's 56/28/14 maps, 7 x 7 for the 7 x 7 map, 8 x 8 otherwise), 64 channels per workgroup.
+// grid: (tiles_x * tiles_y * B, ceil(C / 64)); TW * 16 threads = TW columns x 16 channel quads; a thread owns a TH-row output strip of
+// one column and one channel quad: for every horizontal tap it reads the TH + 6 inputs of its column once and feeds 7 x TH FMAs.
+template <int TH, int TW>
+__global__ __launch_bounds__(TW * 16) void dwconv7_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
+                                                          const float* res, float* out /* may alias res */, bf16_t* __restrict__ outb, int B, int H,
+                                                          int W, int C, int flip) {
+  constexpr int IH = TH + 6, IW = TW + 6, NT = TW * 16;
+  __shared__ __attribute__((aligned(16))) float xs[IH * IW * DW_CC];
   __shared__ __attribute__((aligned(16))) float ws[49 * DW_CC];            // 12 544 B
   const int tid = threadIdx.x;
-  const int tx_n = (W + DW_T - 1) / DW_T, ty_n = (H + DW_T - 1) / DW_T;
+  const int tx_n = (W + TW - 1) / TW, ty_n = (H + TH - 1) / TH;
   const int tile = blockIdx.x % (tx_n * ty_n), b = blockIdx.x / (tx_n * ty_n);
-  const int y0 = (tile / tx_n) * DW_T, x0 = (tile % tx_n) * DW_T;
+  const int y0 = (tile / tx_n) * TH, x0 = (tile % tx_n) * TW;
   const int c0 = blockIdx.y * DW_CC;
-  for (int i = tid; i < DW_H * DW_H * (DW_CC / 4); i += 128) {
-    const int cq = i & 15, p = i >> 4, py = p / DW_H, px = p % DW_H;
+  for (int i = tid; i < IH * IW * (DW_CC / 4); i += NT) {
+    const int cq = i & 15, p = i >> 4, py = p / IW, px = p % IW;
     const int y = y0 + py - 3, x = x0 + px - 3, c = c0 + cq * 4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (y >= 0 && y < H && x >= 0 && x < W && c < C) v = *(const f32x4*)(in + (((long)b * H + y) * W + x) * C + c);
     *(f32x4*)(xs + p * DW_CC + cq * 4) = v;
   }
-  for (int i = tid; i < 49 * (DW_CC / 4); i += 128) {
+  for (int i = tid; i < 49 * (DW_CC / 4); i += NT) {
     const int cq = i & 15, t = i >> 4, c = c0 + cq * 4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (c < C) v = *(const f32x4*)(wt + (long)(flip ? 48 - t : t) * C + c);
@@ -46,25 +49,25 @@ __global__ __launch_bounds__(128) void dwconv7_kernel(const float* __restrict__ 
   }
   __syncthreads();
   const int cq = tid & 15, col = tid >> 4, c = c0 + cq * 4;
-  f32x4 acc[DW_T];
+  f32x4 acc[TH];
   {
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     if (bias && c < C) b4 = *(const f32x4*)(bias + c);
 #pragma unroll
-    for (int o = 0; o < DW_T; ++o) acc[o] = b4;
+    for (int o = 0; o < TH; ++o) acc[o] = b4;
   }
-#pragma unroll
+#pragma unroll 1   // one horizontal tap at a time: unrolling all 7 makes hipcc hoist ~100 LDS reads and spill
   for (int j = 0; j < 7; ++j) {
     f32x4 wj[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) wj[i] = *(const f32x4*)(ws + (i * 7 + j) * DW_CC + cq * 4);
 #pragma unroll
-    for (int r = 0; r < DW_H; ++r) {
-      const f32x4 v = *(const f32x4*)(xs + (r * DW_H + col + j) * DW_CC + cq * 4);
+    for (int r = 0; r < IH; ++r) {
+      const f32x4 v = *(const f32x4*)(xs + (r * IW + col + j) * DW_CC + cq * 4);
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         const int o = r - i;
-        if (o >= 0 && o < DW_T) {
+        if (o >= 0 && o < TH) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(v[e], wj[i][e], acc[o][e]);
         }
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(128) void dwconv7_kernel(const float* __restrict__ 
   const int x = x0 + col;
   if (x < W && c < C) {
 #pragma unroll
-    for (int o = 0; o < DW_T; ++o) {
+    for (int o = 0; o < TH; ++o) {
       const int y = y0 + o;
       if (y < H) {
         const long off = (((long)b * H + y) * W + x) * C + c;
@@ -92,49 +95,51 @@ __global__ __launch_bounds__(128) void dwconv7_kernel(const float* __restrict__ 
 // grid: (S slices, ceil(C / 64)); 448 threads = 7 vertical taps x 64 channels; a workgroup walks its share of the (image, tile) list,
 // stages the input tile (with halo) and the dy tile in LDS, and every thread keeps the 7 horizontal taps of its (channel, i) in
 // registers: per output row 8 dy values and 14 inputs feed 56 FMAs.  Partials per slice are combined by vdk_reduce_rows_f32.
+template <int TH, int TW>
 __global__ __launch_bounds__(448) void dwconv7_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ dy, float* __restrict__ part, int B,
                                                             int H, int W, int C, int S) {
-  __shared__ __attribute__((aligned(16))) float xs[DW_H * DW_H * DW_CC];
-  __shared__ __attribute__((aligned(16))) float ds[DW_T * DW_T * DW_CC];   // 16 384 B
+  constexpr int IH = TH + 6, IW = TW + 6;
+  __shared__ __attribute__((aligned(16))) float xs[IH * IW * DW_CC];
+  __shared__ __attribute__((aligned(16))) float ds[TH * TW * DW_CC];
   const int tid = threadIdx.x, cl = tid & 63, ti = tid >> 6;
-  const int tx_n = (W + DW_T - 1) / DW_T, ty_n = (H + DW_T - 1) / DW_T;
+  const int tx_n = (W + TW - 1) / TW, ty_n = (H + TH - 1) / TH;
   const long items = (long)B * tx_n * ty_n;
   const int c0 = blockIdx.y * DW_CC;
   float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float accb = 0.f;
   for (long it = blockIdx.x; it < items; it += S) {
     const int tile = (int)(it % (tx_n * ty_n)), b = (int)(it / (tx_n * ty_n));
-    const int y0 = (tile / tx_n) * DW_T, x0 = (tile % tx_n) * DW_T;
+    const int y0 = (tile / tx_n) * TH, x0 = (tile % tx_n) * TW;
     __syncthreads();
-    for (int i = tid; i < DW_H * DW_H * (DW_CC / 4); i += 448) {
-      const int cq = i & 15, p = i >> 4, py = p / DW_H, px = p % DW_H;
+    for (int i = tid; i < IH * IW * (DW_CC / 4); i += 448) {
+      const int cq = i & 15, p = i >> 4, py = p / IW, px = p % IW;
       const int y = y0 + py - 3, x = x0 + px - 3, c = c0 + cq * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (y >= 0 && y < H && x >= 0 && x < W && c < C) v = *(const f32x4*)(in + (((long)b * H + y) * W + x) * C + c);
       *(f32x4*)(xs + p * DW_CC + cq * 4) = v;
     }
-    for (int i = tid; i < DW_T * DW_T * (DW_CC / 4); i += 448) {
-      const int cq = i & 15, p = i >> 4, py = p / DW_T, px = p % DW_T;
+    for (int i = tid; i < TH * TW * (DW_CC / 4); i += 448) {
+      const int cq = i & 15, p = i >> 4, py = p / TW, px = p % TW;
       const int y = y0 + py, x = x0 + px, c = c0 + cq * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (y < H && x < W && c < C) v = *(const f32x4*)(dy + (((long)b * H + y) * W + x) * C + c);
       *(f32x4*)(ds + p * DW_CC + cq * 4) = v;
     }
     __syncthreads();
+#pragma unroll 1
+    for (int h = 0; h < TH; ++h) {
+      float d[TW], xv[IW];
 #pragma unroll
-    for (int h = 0; h < DW_T; ++h) {
-      float d[DW_T], xv[DW_H];
+      for (int w = 0; w < TW; ++w) d[w] = ds[(h * TW + w) * DW_CC + cl];
 #pragma unroll
-      for (int w = 0; w < DW_T; ++w) d[w] = ds[(h * DW_T + w) * DW_CC + cl];
-#pragma unroll
-      for (int w = 0; w < DW_H; ++w) xv[w] = xs[((h + ti) * DW_H + w) * DW_CC + cl];
+      for (int w = 0; w < IW; ++w) xv[w] = xs[((h + ti) * IW + w) * DW_CC + cl];
 #pragma unroll
       for (int j = 0; j < 7; ++j)
 #pragma unroll
-        for (int w = 0; w < DW_T; ++w) acc[j] = fmaf(d[w], xv[w + j], acc[j]);
+        for (int w = 0; w < TW; ++w) acc[j] = fmaf(d[w], xv[w + j], acc[j]);
       if (ti == 0) {
 #pragma unroll
-        for (int w = 0; w < DW_T; ++w) accb += d[w];
+        for (int w = 0; w < TW; ++w) accb += d[w];
       }
     }
   }
@@ -230,14 +235,25 @@ extern "C" {
 int vdk_dwconv7_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out, void* out_bf16, int32_t B, int32_t H, int32_t W,
                     int32_t C, int32_t flip, void* stream) {
   if (!in || !wt || (!out && !out_bf16) || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return vdk_fail(VDK_EINVAL, "vdk_dwconv7_fwd: bad argument (C % 4 == 0)");
-  const unsigned tiles = (unsigned)(((W + DW_T - 1) / DW_T) * ((H + DW_T - 1) / DW_T));
-  hipLaunchKernelGGL(dwconv7_kernel, dim3(tiles * (unsigned)B, (unsigned)((C + DW_CC - 1) / DW_CC)), dim3(128), 0, (hipStream_t)stream, in, wt, bias, res, out,
-                     (bf16_t*)out_bf16, (int)B, (int)H, (int)W, (int)C, (int)flip);
+  const unsigned cy = (unsigned)((C + DW_CC - 1) / DW_CC);
+#define DW_LAUNCH(TH, TW)                                                                                                                          \
+  hipLaunchKernelGGL((dwconv7_kernel<TH, TW>), dim3((unsigned)(((W + TW - 1) / TW) * ((H + TH - 1) / TH)) * (unsigned)B, cy), dim3(TW * 16), 0,       \
+                     (hipStream_t)stream, in, wt, bias, res, out, (bf16_t*)out_bf16, (int)B, (int)H, (int)W, (int)C, (int)flip)
+  if (H % 7 == 0 && W % 14 == 0) DW_LAUNCH(7, 14);
+  else if (H % 7 == 0 && W % 7 == 0) DW_LAUNCH(7, 7);
+  else DW_LAUNCH(8, 8);
+#undef DW_LAUNCH
   return vdk_check_launch("vdk_dwconv7_fwd");
 }
 
+static void dw_wgrad_tile(int H, int W, int* th, int* tw) {
+  if (H % 7 == 0 && W % 14 == 0) { *th = 7; *tw = 14; }
+  else if (H % 7 == 0 && W % 7 == 0) { *th = 7; *tw = 7; }
+  else { *th = 8; *tw = 8; }
+}
 static int dw_slices(int B, int H, int W, int C) {
-  const long items = (long)B * ((W + DW_T - 1) / DW_T) * ((H + DW_T - 1) / DW_T);
+  int th, tw; dw_wgrad_tile(H, W, &th, &tw);
+  const long items = (long)B * ((W + tw - 1) / tw) * ((H + th - 1) / th);
   long s = 1024 / ((C + DW_CC - 1) / DW_CC);
   if (s > items) s = items;
   if (s < 1) s = 1;
@@ -255,8 +271,11 @@ int vdk_dwconv7_wgrad(const float* in, const float* dy, float* dw, float* db, in
   if (!in || !dy || !dw || !db || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return vdk_fail(VDK_EINVAL, "vdk_dwconv7_wgrad: bad argument (C % 4 == 0)");
   const int S = dw_slices(B, H, W, C);
   if (!ws || ws_bytes < (size_t)S * C * 50 * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_dwconv7_wgrad: workspace too small");
-  hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3((unsigned)S, (unsigned)((C + DW_CC - 1) / DW_CC)), dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B,
-                     (int)H, (int)W, (int)C, S);
+  int th, tw; dw_wgrad_tile(H, W, &th, &tw);
+  const dim3 grid((unsigned)S, (unsigned)((C + DW_CC - 1) / DW_CC));
+  if (tw == 14) hipLaunchKernelGGL((dwconv7_wgrad_kernel<7, 14>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
+  else if (tw == 7) hipLaunchKernelGGL((dwconv7_wgrad_kernel<7, 7>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
+  else hipLaunchKernelGGL((dwconv7_wgrad_kernel<8, 8>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
   int rc = vdk_reduce_rows_f32((const float*)ws, (int64_t)C * 50, S, (int64_t)C * 49, dw, 1.0f, stream);
   if (rc) return rc;
   return vdk_reduce_rows_f32((const float*)ws + (size_t)C * 49, (int64_t)C * 50, S, C, db, 1.0f, stream);

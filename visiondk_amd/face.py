@@ -2,10 +2,10 @@
 `FaceTrainingModel` / `FaceTrainingWrapper`, `FeatureExtractor`, and the `get_model` factory seam.
 
 Reference: models/faceX/backbone/timm_wrapper.py:5-54, models/faceX/face_model.py:10-54,88-143, models/smartmodel.py:5-10.
-Transformer backbones only for now (timm ViT ids in visiondk_amd.vit.TIMM_VITS): the neck is
-LayerNorm(C) -> Flatten -> Linear(N*C, feat_dim) -> BatchNorm1d(feat_dim) (timm_wrapper.py:39-47).  CNN backbones (ConvNeXt,
-ResNet: BatchNorm2d neck) are the next §8 row.  state_dict keys equal the reference's:
-`model.<timm keys>`, `output_layer.0.*` (LayerNorm), `output_layer.2.*` (Linear), `output_layer.3.*` (BatchNorm1d)."""
+Transformer backbones (timm ViT ids in visiondk_amd.vit.TIMM_VITS): neck LayerNorm(C) -> Flatten -> Linear(N*C, feat_dim) ->
+BatchNorm1d(feat_dim) (timm_wrapper.py:39-47).  CNN backbones (timm ConvNeXt ids in visiondk_amd.convnext.TIMM_CONVNEXTS): neck
+BatchNorm2d(C) -> Flatten -> Linear(C*H*W, feat_dim) -> BatchNorm1d(feat_dim) (timm_wrapper.py:30-37).  state_dict keys equal the
+reference's: `model.<timm keys>`, `output_layer.0.*` (LayerNorm | BatchNorm2d), `output_layer.2.*` (Linear), `output_layer.3.*`."""
 from __future__ import annotations
 
 import ctypes as C
@@ -15,7 +15,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _abi, _lib, heads, ops, vit
+from . import _abi, _lib, convnext, heads, ops, vit
 
 
 def _up(x, a):
@@ -87,6 +87,75 @@ class _NeckFn(torch.autograd.Function):
         return dtok.view(B, N, D), dln_w, dln_b, dlin_w.contiguous(), dlin_b, dbn_w, dbn_b, None
 
 
+class _NeckCNNFn(torch.autograd.Function):
+    """BatchNorm2d(C) -> Flatten -> Linear(C*H*W, F) -> BatchNorm1d(F) (timm_wrapper.py:30-37) as one autograd node.  The feature map
+    lives as NHWC rows [B*H*W, C], so BatchNorm2d is the row BatchNorm kernel over B*H*W samples, and the Linear runs on the NHWC
+    flattening against a column-permuted view of its weight (W'[f, p*C + c] = W[f, c*HW + p]: a layout change, no arithmetic)."""
+
+    @staticmethod
+    def forward(ctx, fmap, bn2_w, bn2_b, lin_w, lin_b, bn_w, bn_b, wrapper):
+        be = wrapper.be
+        B, Cc, Hh, Ww = fmap.shape
+        HW, K, Fd = Hh * Ww, Cc * Hh * Ww, lin_w.shape[0]
+        Bp = _up(B, 64)
+        dev = fmap.device
+        rows = fmap.permute(0, 2, 3, 1).contiguous().view(B * HW, Cc)          # no copy when the backbone handed an NHWC-backed view
+        bn2, bn = wrapper.output_layer[0], wrapper.output_layer[3]
+        training = bool(wrapper.training)
+        y2 = torch.zeros((Bp * HW, Cc), dtype=torch.float32, device=dev)
+        sm2 = torch.empty(Cc, dtype=torch.float32, device=dev); si2 = torch.empty(Cc, dtype=torch.float32, device=dev)
+        be.check(be.lib.vdk_batchnorm1d_fwd(be.ptr(rows), Cc, B * HW, Cc, be.ptr(bn2_w), be.ptr(bn2_b), bn2.eps, bn2.momentum, int(training),
+                                            be.ptr(bn2.running_mean), be.ptr(bn2.running_var), be.ptr(y2), Cc, be.ptr(sm2), be.ptr(si2), be.stream()),
+                 "vdk_batchnorm1d_fwd")
+        h = ops.cast_bf16(y2, backend=be).view(Bp, K)                           # bf16 [Bp, HW*C], pad rows zero
+        wperm = lin_w.detach().view(Fd, Cc, HW).permute(0, 2, 1).reshape(Fd, K).contiguous()
+        wb = ops.cast_bf16(wperm, backend=be)
+        z = ops.gemm_nt(h[:B], wb, out_dtype=torch.float32, bias=lin_b.detach(), backend=be)
+        y = torch.empty_like(z)
+        sm = torch.empty(Fd, dtype=torch.float32, device=dev); si = torch.empty(Fd, dtype=torch.float32, device=dev)
+        be.check(be.lib.vdk_batchnorm1d_fwd(be.ptr(z), Fd, B, Fd, be.ptr(bn_w), be.ptr(bn_b), bn.eps, bn.momentum, int(training),
+                                            be.ptr(bn.running_mean), be.ptr(bn.running_var), be.ptr(y), Fd, be.ptr(sm), be.ptr(si), be.stream()),
+                 "vdk_batchnorm1d_fwd")
+        if training:
+            bn.num_batches_tracked += 1
+            bn2.num_batches_tracked += 1
+        ctx.save_for_backward(rows, bn2_w, bn_w, h, wb, z, sm, si, sm2, si2)
+        ctx.wrapper, ctx.dims = wrapper, (B, Cc, Hh, Ww, Fd, K, Bp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows, bn2_w, bn_w, h, wb, z, sm, si, sm2, si2 = ctx.saved_tensors
+        be = ctx.wrapper.be
+        B, Cc, Hh, Ww, Fd, K, Bp = ctx.dims
+        HW = Hh * Ww
+        dev = dy.device
+        dy = dy.contiguous()
+        dz = torch.empty((B, Fd), dtype=torch.float32, device=dev)
+        dbn_w = torch.empty(Fd, dtype=torch.float32, device=dev); dbn_b = torch.empty(Fd, dtype=torch.float32, device=dev)
+        be.check(be.lib.vdk_batchnorm1d_bwd(be.ptr(dy), Fd, be.ptr(z), Fd, B, Fd, be.ptr(bn_w), be.ptr(sm), be.ptr(si), be.ptr(dz), Fd, be.ptr(dbn_w),
+                                            be.ptr(dbn_b), be.stream()), "vdk_batchnorm1d_bwd")
+        stage = torch.zeros((Bp, _up(Fd, 8)), dtype=torch.float32, device=dev)
+        stage[:B, :Fd].copy_(dz)
+        dzb = ops.cast_bf16(stage, backend=be)
+        dlin_b = ops.reduce_rows(dz, backend=be)
+        dwp = ops.gemm_nt(dzb, h, out_dtype=torch.float32, trans=True, backend=be)[:Fd]                      # [F, HW*C]
+        dlin_w = dwp.view(Fd, HW, Cc).permute(0, 2, 1).reshape(Fd, K)                                          # back to the NCHW column order
+        dzt = ops.transpose_pad(dzb, rpad=Bp, backend=be)
+        fpad = dzt.shape[0]
+        if fpad % 64 == 0 and fpad == Fd:
+            dh = ops.gemm_nt(dzt, wb, out_dtype=torch.float32, trans=True, backend=be)                         # [Bp, HW*C]
+        else:
+            wbt = ops.transpose_pad(wb, rpad=_up(Fd, 8), backend=be)
+            dh = ops.gemm_nt(dzb, wbt, out_dtype=torch.float32, backend=be)
+        dh = dh[:B].reshape(B * HW, Cc)
+        dx = torch.empty((B * HW, Cc), dtype=torch.float32, device=dev)
+        dbn2_w = torch.empty(Cc, dtype=torch.float32, device=dev); dbn2_b = torch.empty(Cc, dtype=torch.float32, device=dev)
+        be.check(be.lib.vdk_batchnorm1d_bwd(be.ptr(dh), Cc, be.ptr(rows), Cc, B * HW, Cc, be.ptr(bn2_w), be.ptr(sm2), be.ptr(si2), be.ptr(dx), Cc,
+                                            be.ptr(dbn2_w), be.ptr(dbn2_b), be.stream()), "vdk_batchnorm1d_bwd")
+        return dx.view(B, Hh, Ww, Cc).permute(0, 3, 1, 2), dbn2_w, dbn2_b, dlin_w.contiguous(), dlin_b, dbn_w, dbn_b, None
+
+
 class TimmWrapper(nn.Module):
     """models/faceX/backbone/timm_wrapper.py: timm backbone without head/pool + embedding neck -> [B, feat_dim]."""
 
@@ -95,16 +164,23 @@ class TimmWrapper(nn.Module):
         super().__init__()
         self.be = backend or _lib.load()
         dev = device if device is not None else ("cuda" if self.be.device_only else "cpu")
-        if model_name not in vit.TIMM_VITS:
-            raise NotImplementedError(f"backbone '{model_name}': only the timm ViT ids {sorted(vit.TIMM_VITS)} run on the HIP engine so far")
-        self.model = vit.create_model(model_name, pretrained=False, num_classes=0, global_pool="", img_size=image_size, device=dev, backend=self.be)
-        tokens, channels = self.model.engine.tokens, self.model.spec.dim
-        self.output_layer = nn.Sequential(nn.LayerNorm(channels), nn.Flatten(1), nn.Linear(tokens * channels, feat_dim), nn.BatchNorm1d(feat_dim)).to(dev)
+        self.is_cnn = model_name in convnext.TIMM_CONVNEXTS
+        if self.is_cnn:
+            self.model = convnext.create_model(model_name, pretrained=False, num_classes=0, global_pool="", img_size=image_size, device=dev, backend=self.be)
+            channels, hw = self.model.engine.out_ch, self.model.engine.out_hw
+            self.output_layer = nn.Sequential(nn.BatchNorm2d(channels), nn.Flatten(1), nn.Linear(channels * hw * hw, feat_dim), nn.BatchNorm1d(feat_dim)).to(dev)
+        elif model_name in vit.TIMM_VITS:
+            self.model = vit.create_model(model_name, pretrained=False, num_classes=0, global_pool="", img_size=image_size, device=dev, backend=self.be)
+            tokens, channels = self.model.engine.tokens, self.model.spec.dim
+            self.output_layer = nn.Sequential(nn.LayerNorm(channels), nn.Flatten(1), nn.Linear(tokens * channels, feat_dim), nn.BatchNorm1d(feat_dim)).to(dev)
+        else:
+            raise NotImplementedError(f"backbone '{model_name}': the HIP engines cover {sorted(vit.TIMM_VITS)} and {sorted(convnext.TIMM_CONVNEXTS)}")
 
     def forward(self, x):
-        tok = self.model(x)
+        feat = self.model(x)
         ol = self.output_layer
-        return _NeckFn.apply(tok, ol[0].weight, ol[0].bias, ol[2].weight, ol[2].bias, ol[3].weight, ol[3].bias, self)
+        fn = _NeckCNNFn if self.is_cnn else _NeckFn
+        return fn.apply(feat, ol[0].weight, ol[0].bias, ol[2].weight, ol[2].bias, ol[3].weight, ol[3].bias, self)
 
 
 class BackboneFactory:
