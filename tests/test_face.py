@@ -173,3 +173,57 @@ def test_cnn_extract_cbir_eval_embeddings(be, dev, monkeypatch):
         exp = torch.nn.functional.normalize(ref(x)).numpy()
     got = face.FeatureExtractor(bb).extract_cbir([x[:3], x[3:]], dev)
     assert got.shape == (5, 64) and _rel(got, exp) < 2e-2
+
+
+def test_face_train_step_matches_reference_update(be, dev, monkeypatch):
+    """FaceTrainStep == compute_loss(face=True) + Trainer.update on the oracle (CE -> backward -> clip_grad_norm_ -> SGD -> EMA), 2 steps,
+    with the clip active (max_norm below the gradient norm)."""
+    import math
+    model, ref, img = _build_cnn(be, dev, monkeypatch)
+    head = model.trainingwrapper["head"]
+    rhead = _RefArcFace(head.weight.detach().cpu())
+    bb = model.trainingwrapper["backbone"]
+    lr, mom, wd, max_norm = 0.05, 0.9, 5e-4, 0.5
+    step = face.FaceTrainStep(model, lr=lr, momentum=mom, weight_decay=wd, max_norm=max_norm, ema=True)
+    params = list(ref.parameters()) + [rhead.weight]
+    opt = torch.optim.SGD(params, lr=lr, momentum=mom, weight_decay=wd)
+    ema_ref = {k: v.clone() for k, v in ref.state_dict().items() if v.dtype.is_floating_point}
+    start = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    model.train(); ref.train()
+    torch.manual_seed(5)
+    for it in range(2):
+        x = torch.randn(8, 3, img, img); y = torch.randint(0, 40, (8,))
+        opt.zero_grad()
+        loss_ref = torch.nn.functional.cross_entropy(rhead(ref(x), y), y)
+        loss_ref.backward()
+        total = torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
+        assert total > max_norm          # the clip is active
+        opt.step()
+        d = 0.9999 * (1 - math.exp(-(it + 1) / 2000))
+        for k, v in ref.state_dict().items():
+            if v.dtype.is_floating_point:
+                ema_ref[k].mul_(d).add_(v.detach(), alpha=1 - d)
+        rows = step.step(x.to(dev), y.to(dev))
+        assert abs(rows.mean().item() - loss_ref.item()) < 3e-2 * abs(loss_ref.item())
+    got = dict(bb.named_parameters())
+    worst = 0.0
+    for n, p in ref.named_parameters():
+        upd_ref = p.detach() - start[n]
+        upd = got[n].detach().cpu() - start[n]
+        if upd_ref.norm() < 1e-7:
+            continue
+        r = _rel(upd, upd_ref)
+        worst = max(worst, r)
+        # a batch-constant shift in front of a train-mode BatchNorm1d has an analytically zero gradient: those two updates are weight decay
+        # plus round-off (fp32 in the oracle, bf16 here)
+        tol = 0.3 if n in ("output_layer.0.bias", "output_layer.2.bias") else 0.12
+        assert r < tol, (n, r)
+    assert _rel(head.weight.detach(), rhead.weight.detach()) < 1e-3
+    # EMA of a backbone tensor, a neck tensor and a BatchNorm running statistic
+    eng = bb.model.engine
+    name, off, numel, shape = eng.entries[5]
+    assert _rel(step.ema_flat[off:off + numel].view(shape), ema_ref["model." + name]) < 1e-4
+    small_names = [n for n, _ in bb.output_layer.named_parameters()]
+    assert _rel(step.ema_small[small_names.index("2.weight")], ema_ref["output_layer.2.weight"]) < 1e-4
+    buf_names = [n for n, b in bb.output_layer.named_buffers() if b.dtype.is_floating_point]
+    assert _rel(step.ema_buf[buf_names.index("0.running_var")], ema_ref["output_layer.0.running_var"]) < 1e-3

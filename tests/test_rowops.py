@@ -163,3 +163,29 @@ def test_topk_rows(be, dev):
     assert torch.equal(val.cpu(), rv)
     assert idx[2, 0].item() == 3 and idx[2, 1].item() == 7
     assert torch.equal(idx.cpu()[[0, 1, 3, 4, 5, 6, 7, 8]], ri[[0, 1, 3, 4, 5, 6, 7, 8]])
+
+
+@pytest.mark.parametrize("B,F", [(40, 72), (300, 100), (1000, 33)])   # small-batch kernel and the row-parallel kernel (B >= 256)
+def test_batchnorm_rows_fwd_bwd(be, dev, B, F):
+    torch.manual_seed(B)
+    x = torch.randn(B, F) * 2 + 0.5
+    bn = torch.nn.BatchNorm1d(F)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(F) + 0.5); bn.bias.copy_(torch.randn(F) * 0.1)
+        bn.running_mean.copy_(torch.randn(F) * 0.1); bn.running_var.copy_(torch.rand(F) + 0.5)
+    rm, rv = bn.running_mean.clone().to(dev), bn.running_var.clone().to(dev)
+    xr = x.clone().requires_grad_(True)
+    y = bn(xr)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    yk, sm, si = ops.batchnorm_fwd(x.to(dev), bn.weight.detach().to(dev), bn.bias.detach().to(dev), rm, rv, training=True, backend=be)
+    torch.testing.assert_close(yk.cpu(), y.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rm.cpu(), bn.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv.cpu(), bn.running_var, rtol=1e-5, atol=1e-6)
+    dx, dg, db = ops.batchnorm_bwd(dy.to(dev), x.to(dev), bn.weight.detach().to(dev), sm, si, backend=be)
+    torch.testing.assert_close(dx.cpu(), xr.grad, rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(dg.cpu(), bn.weight.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.cpu(), bn.bias.grad, rtol=1e-4, atol=1e-4)
+    bn.eval()
+    ye, _, _ = ops.batchnorm_fwd(x.to(dev), bn.weight.detach().to(dev), bn.bias.detach().to(dev), rm, rv, training=False, backend=be)
+    torch.testing.assert_close(ye.cpu(), bn(x).detach(), rtol=1e-4, atol=1e-5)

@@ -1,0 +1,32 @@
+"""cfg3: ConvNeXt-B + neck (feat_dim 512) + ArcFace(C = 1 000 000, m = .35, s = 32), bs 512 on one GPU; one step = compute_loss(face=True)
++ Trainer.update (fwd, fused head+CE, bwd, clip 10, SGD, EMA).  usage: python tools/bench_cfg3.py [batch] [steps] [num_class]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from visiondk_amd import face
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+ncls = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
+dev = torch.device("cuda:0")
+cfg = {"task": "cbir", "image_size": 224, "backbone": {"timm-convnext_base": {"pretrained": False, "image_size": 224, "feat_dim": 512}},
+       "head": {"arcface": {"feat_dim": 512, "num_class": ncls, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
+torch.manual_seed(0)
+model = face.get_model(cfg, None, 0).model.train()
+step = face.FaceTrainStep(model, lr=0.01, momentum=0.9, weight_decay=5e-4, max_norm=10.0, ema=True)
+g = torch.Generator(device="cpu"); g.manual_seed(0)
+x = torch.randn(B, 3, 224, 224, generator=g).to(dev)
+y = torch.randint(0, ncls, (B,), generator=g).to(dev)
+losses = []
+for _ in range(2):
+    losses.append(step.step(x, y).mean().item())
+torch.cuda.synchronize()
+t0 = time.time()
+for _ in range(steps):
+    rows = step.step(x, y)
+torch.cuda.synchronize()
+dt = (time.time() - t0) / steps
+losses.append(rows.mean().item())
+flop = (92.1e9 + 0.15e9 + 3.07e9 * ncls / 1e6) * B
+print(json.dumps({"workload": f"cfg3 ConvNeXt-B + neck512 + ArcFace(C={ncls}) bs={B}, fwd+bwd+clip+SGD+EMA, bf16 operands / fp32 master", "ms_per_step": dt * 1e3,
+                  "images_per_sec": B / dt, "tflops": flop / dt / 1e12, "losses": losses, "max_mem_gib": torch.cuda.max_memory_allocated() / 2**30}))

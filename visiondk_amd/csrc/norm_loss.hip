@@ -297,6 +297,70 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
   }
 }
 
+// Row-parallel variants for many samples (BatchNorm2d of the CNN neck on NHWC rows: B*H*W = 25 088 samples x 1024 channels at cfg3).
+// A workgroup owns 32 columns; its 512 threads = 32 columns x 16 row groups stride over the rows, the column sums meet in LDS.  Same
+// arithmetic as above (mean, then centred variance), deterministic, no workspace.
+#define BNR_COLS 32
+#define BNR_RG 16
+__device__ __forceinline__ float bnr_colsum(float v, float* red /*[16][32]*/, int cl, int rg) {
+  red[rg * BNR_COLS + cl] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < BNR_RG; ++i) t += red[i * BNR_COLS + cl];
+  __syncthreads();
+  return t;
+}
+__global__ __launch_bounds__(512) void bnrows_fwd_kernel(const float* __restrict__ x, long ldx, int B, int F, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, float momentum, int training,
+                                                         float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ y, long ldy,
+                                                         float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  __shared__ float red[BNR_RG * BNR_COLS];
+  const int cl = threadIdx.x & (BNR_COLS - 1), rg = threadIdx.x / BNR_COLS;
+  const int f = blockIdx.x * BNR_COLS + cl;
+  const bool ok = f < F;
+  float mu = 0.f, var = 1.f;
+  if (training) {
+    float s = 0.f;
+    if (ok) for (int b = rg; b < B; b += BNR_RG) s += x[(long)b * ldx + f];
+    mu = bnr_colsum(s, red, cl, rg) / (float)B;
+    float q = 0.f;
+    if (ok) for (int b = rg; b < B; b += BNR_RG) { const float d = x[(long)b * ldx + f] - mu; q = fmaf(d, d, q); }
+    q = bnr_colsum(q, red, cl, rg);
+    var = q / (float)B;
+    if (ok && rg == 0) {
+      if (rmean) rmean[f] = (1.0f - momentum) * rmean[f] + momentum * mu;
+      if (rvar) rvar[f] = (1.0f - momentum) * rvar[f] + momentum * (B > 1 ? q / (float)(B - 1) : var);
+    }
+  } else if (ok) { mu = rmean[f]; var = rvar[f]; }
+  if (!ok) return;
+  const float is = 1.0f / sqrtf(var + eps);
+  if (rg == 0) { if (save_mean) save_mean[f] = mu; if (save_invstd) save_invstd[f] = is; }
+  const float g = gamma[f] * is, bb = beta[f];
+  for (int b = rg; b < B; b += BNR_RG) y[(long)b * ldy + f] = (x[(long)b * ldx + f] - mu) * g + bb;
+}
+__global__ __launch_bounds__(512) void bnrows_bwd_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx, int B, int F,
+                                                         const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                         const float* __restrict__ save_invstd, float* __restrict__ dx, long lddx,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[BNR_RG * BNR_COLS];
+  const int cl = threadIdx.x & (BNR_COLS - 1), rg = threadIdx.x / BNR_COLS;
+  const int f = blockIdx.x * BNR_COLS + cl;
+  const bool ok = f < F;
+  const float mu = ok ? save_mean[f] : 0.f, is = ok ? save_invstd[f] : 0.f;
+  float sg = 0.f, sb = 0.f;
+  if (ok) for (int b = rg; b < B; b += BNR_RG) { const float d = dy[(long)b * lddy + f]; sb += d; sg = fmaf(d, (x[(long)b * ldx + f] - mu) * is, sg); }
+  sb = bnr_colsum(sb, red, cl, rg);
+  sg = bnr_colsum(sg, red, cl, rg);
+  if (!ok) return;
+  if (rg == 0) { dgamma[f] = sg; dbeta[f] = sb; }
+  const float k = gamma[f] * is / (float)B;
+  for (int b = rg; b < B; b += BNR_RG) {
+    const float xh = (x[(long)b * ldx + f] - mu) * is;
+    dx[(long)b * lddx + f] = k * ((float)B * dy[(long)b * lddy + f] - sb - xh * sg);
+  }
+}
+
 extern "C" {
 
 int vdk_layernorm_fwd(const float* x, int64_t ldx, int32_t T, int32_t C, const float* gamma, const float* beta, float eps,
@@ -385,16 +449,24 @@ int vdk_batchnorm1d_fwd(const float* x, int64_t ldx, int32_t B, int32_t F, const
                         void* stream) {
   if (!x || !gamma || !beta || !y || B <= 0 || F <= 0 || (!training && (!running_mean || !running_var)))
     return vdk_fail(VDK_EINVAL, "vdk_batchnorm1d_fwd: bad argument");
-  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)B, (int)F, gamma, beta, eps,
-                     momentum, (int)training, running_mean, running_var, y, (long)ldy, save_mean, save_invstd);
+  if (B >= 256)   // many samples (BatchNorm2d on NHWC rows, large batches): row-parallel kernel
+    hipLaunchKernelGGL(bnrows_fwd_kernel, dim3((unsigned)((F + BNR_COLS - 1) / BNR_COLS)), dim3(512), 0, (hipStream_t)stream, x, (long)ldx, (int)B, (int)F, gamma,
+                       beta, eps, momentum, (int)training, running_mean, running_var, y, (long)ldy, save_mean, save_invstd);
+  else
+    hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)B, (int)F, gamma, beta, eps,
+                       momentum, (int)training, running_mean, running_var, y, (long)ldy, save_mean, save_invstd);
   return vdk_check_launch("vdk_batchnorm1d_fwd");
 }
 int vdk_batchnorm1d_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, int32_t B, int32_t F, const float* gamma, const float* save_mean,
                         const float* save_invstd, float* dx, int64_t lddx, float* dgamma, float* dbeta, void* stream) {
   if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || B <= 0 || F <= 0)
     return vdk_fail(VDK_EINVAL, "vdk_batchnorm1d_bwd: bad argument");
-  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, (long)lddy, x, (long)ldx, (int)B, (int)F,
-                     gamma, save_mean, save_invstd, dx, (long)lddx, dgamma, dbeta);
+  if (B >= 256)
+    hipLaunchKernelGGL(bnrows_bwd_kernel, dim3((unsigned)((F + BNR_COLS - 1) / BNR_COLS)), dim3(512), 0, (hipStream_t)stream, dy, (long)lddy, x, (long)ldx, (int)B,
+                       (int)F, gamma, save_mean, save_invstd, dx, (long)lddx, dgamma, dbeta);
+  else
+    hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, (long)lddy, x, (long)ldx, (int)B, (int)F,
+                       gamma, save_mean, save_invstd, dx, (long)lddx, dgamma, dbeta);
   return vdk_check_launch("vdk_batchnorm1d_bwd");
 }
 

@@ -279,3 +279,89 @@ class VisionWrapper:
         ckpt = torch.load(load_path, map_location=device, weights_only=False)
         sd = ckpt["ema"].state_dict() if ema and hasattr(ckpt.get("ema"), "state_dict") else ckpt.get("ema" if ema else "model", ckpt)
         self.model.load_state_dict(sd)
+
+
+class FaceTrainStep:
+    """Trainer.compute_loss(face=True) + Trainer.update for the face / CBIR task (engine/procedure/train.py:192-215,217-226) as a fixed
+    kernel sequence: backbone forward (native engine) -> neck -> margin head fused with CrossEntropy (no B x C logits through torch) ->
+    backward -> clip_grad_norm_(max_norm) over ALL parameters -> SGD(momentum, weight_decay) -> ModelEMA.update (models/ema.py:28-37).
+
+    The backbone's parameters live in the engine's flat buffer (one optimizer launch); the neck and head tensors (7 of them) get one
+    launch each with the same global clip factor.  BatchNorm running statistics enter the EMA like every float entry of state_dict()."""
+
+    def __init__(self, model: "FaceTrainingModel", lr: float, momentum: float = 0.9, weight_decay: float = 5e-4, label_smoothing: float = 0.0,
+                 max_norm: float = 10.0, ema: bool = True):
+        self.model = model
+        self.bb = model.trainingwrapper["backbone"]
+        self.head = model.trainingwrapper["head"]
+        self.eng = self.bb.model.engine
+        self.be = self.eng.be
+        self.lr, self.momentum, self.weight_decay, self.label_smoothing, self.max_norm = lr, momentum, weight_decay, label_smoothing, max_norm
+        self.param_groups = [{"lr": lr, "momentum": momentum, "weight_decay": weight_decay}]
+        self.updates = 0
+        self.small = [p for p in self.bb.output_layer.parameters()] + [self.head.weight]
+        self.buffers = [b for b in self.bb.output_layer.buffers() if b.dtype.is_floating_point]
+        mk = lambda t: torch.zeros_like(t)
+        self.mom_flat = mk(self.eng.params)
+        self.mom_small = [mk(p) for p in self.small]
+        self.ema_flat = self.eng.params.clone() if ema else None
+        self.ema_small = [p.detach().clone() for p in self.small] if ema else [None] * len(self.small)
+        self.ema_buf = [b.detach().clone() for b in self.buffers] if ema else []
+        self._zero = [mk(b) for b in self.buffers]
+        self._zero_m = [mk(b) for b in self.buffers]
+        self._nsq = torch.zeros(1, dtype=torch.float32, device=self.eng.device)
+        self._nsq_part = torch.zeros(1, dtype=torch.float32, device=self.eng.device)
+        need = C.c_size_t(0)
+        self.be.check(self.be.lib.vdk_sumsq_workspace_bytes(C.byref(need)), "vdk_sumsq_workspace_bytes")
+        self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.eng.device)
+        self.loss_rows: Optional[torch.Tensor] = None
+
+    def _sumsq(self, g: torch.Tensor) -> None:
+        be = self.be
+        be.check(be.lib.vdk_sumsq_f32(be.ptr(g), g.numel(), be.ptr(self._nsq_part), be.ptr(self._ws), self._ws.numel(), be.stream()), "vdk_sumsq_f32")
+        self._nsq += self._nsq_part          # 1-element accumulate of per-buffer partial norms
+
+    def step(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        import math
+        bb, eng, be = self.bb, self.eng, self.be
+        bb.model._sync_flat()
+        self.updates += 1
+        d = 0.9999 * (1 - math.exp(-self.updates / 2000)) if self.ema_flat is not None else 0.0
+        lr = self.param_groups[0]["lr"]
+        B = x.shape[0]
+        # forward: backbone engine -> neck (autograd node over the HIP kernels) -> fused head + CE
+        out = eng.forward(x)
+        if bb.is_cnn:
+            feat = out.view(B, eng.out_hw, eng.out_hw, eng.out_ch).permute(0, 3, 1, 2).detach().requires_grad_(True)
+        else:
+            feat = out.view(B, eng.tokens, eng.spec.dim).detach().requires_grad_(True)
+        ol = bb.output_layer
+        fn = _NeckCNNFn if bb.is_cnn else _NeckFn
+        emb = fn.apply(feat, ol[0].weight, ol[0].bias, ol[2].weight, ol[2].bias, ol[3].weight, ol[3].bias, bb)
+        self.loss_rows, demb, dW = self.head.margin_ce(emb.detach(), y, self.label_smoothing)
+        for p in self.small:
+            p.grad = None
+        emb.backward(demb)
+        self.head.weight.grad = dW
+        dfeat = feat.grad
+        if bb.is_cnn:
+            eng.backward(dfeat.permute(0, 2, 3, 1).contiguous().view(-1, eng.out_ch))
+        else:
+            eng.backward(dfeat.contiguous().view(-1, eng.spec.dim))
+        # clip_grad_norm_ over every parameter, then SGD + EMA
+        self._nsq.zero_()
+        self._sumsq(eng.grads)
+        for p in self.small:
+            self._sumsq(p.grad.contiguous())
+        first = int(self.updates == 1)
+        be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.mom_flat), be.ptr(self.ema_flat), be.ptr(eng.wb16), eng.n_floats, lr,
+                                     self.momentum, self.weight_decay, 1.0, be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step")
+        for p, m, e in zip(self.small, self.mom_small, self.ema_small):
+            g = p.grad.contiguous()
+            be.check(be.lib.vdk_sgd_step(be.ptr(p.data), be.ptr(g), be.ptr(m), be.ptr(e), None, p.numel(), lr, self.momentum, self.weight_decay, 1.0,
+                                         be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step")
+        for b, z, zm, e in zip(self.buffers, self._zero, self._zero_m, self.ema_buf):   # EMA of the BatchNorm running statistics (lr = 0: value untouched)
+            be.check(be.lib.vdk_sgd_step(be.ptr(b), be.ptr(z), be.ptr(zm), be.ptr(e), None, b.numel(), 0.0, 0.0, 0.0, 1.0, None, self.max_norm, d, first,
+                                         be.stream()), "vdk_sgd_step")
+        eng.refresh_weights(skip_wb16=True)
+        return self.loss_rows

@@ -357,3 +357,24 @@ def layerscale_grad(dw2p: torch.Tensor, db2p: torch.Tensor, w2: torch.Tensor, b2
     be.check(be.lib.vdk_layerscale_grad(be.ptr(dw2p.contiguous()), be.ptr(db2p), be.ptr(w2.contiguous()), be.ptr(b2), be.ptr(gamma), be.ptr(dw2), be.ptr(db2),
                                         be.ptr(dg), Cc, M, be.stream()), "vdk_layerscale_grad")
     return dw2, db2, dg
+
+
+def batchnorm_fwd(x: torch.Tensor, gamma, beta, running_mean, running_var, *, training: bool, eps: float = 1e-5, momentum: float = 0.1, backend=None):
+    """nn.BatchNorm1d on rows [B, F] (also BatchNorm2d on NHWC rows [B*H*W, C]) -> (y, save_mean, save_invstd); running stats updated in place"""
+    be = _be(backend)
+    B, F = x.shape
+    y = torch.empty_like(x)
+    sm = torch.empty(F, dtype=torch.float32, device=x.device); si = torch.empty(F, dtype=torch.float32, device=x.device)
+    be.check(be.lib.vdk_batchnorm1d_fwd(be.ptr(x), x.stride(0), B, F, be.ptr(gamma), be.ptr(beta), eps, momentum, int(training), be.ptr(running_mean),
+                                        be.ptr(running_var), be.ptr(y), F, be.ptr(sm), be.ptr(si), be.stream()), "vdk_batchnorm1d_fwd")
+    return y, sm, si
+
+
+def batchnorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma, save_mean, save_invstd, backend=None):
+    be = _be(backend)
+    B, F = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(F, dtype=torch.float32, device=x.device); db = torch.empty(F, dtype=torch.float32, device=x.device)
+    be.check(be.lib.vdk_batchnorm1d_bwd(be.ptr(dy), dy.stride(0), be.ptr(x), x.stride(0), B, F, be.ptr(gamma), be.ptr(save_mean), be.ptr(save_invstd), be.ptr(dx),
+                                        F, be.ptr(dg), be.ptr(db), be.stream()), "vdk_batchnorm1d_bwd")
+    return dx, dg, db
