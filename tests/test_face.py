@@ -16,7 +16,7 @@ def _rel(a, b):
 
 
 CFG = {"task": "cbir", "image_size": 32,
-       "backbone": {"timm-vit_tiny_patch16_224": {"pretrained": False, "image_size": 32, "feat_dim": 64}},
+       "backbone": {"timm-vit_test_patch16": {"pretrained": False, "image_size": 32, "feat_dim": 64}},
        "head": {"arcface": {"feat_dim": 64, "num_class": 40, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
 
 
@@ -38,6 +38,8 @@ class _RefArcFace(torch.nn.Module):   # arcface.py:20-36 restated (the golden te
 
 
 def _build(be, dev):
+    from visiondk_amd import vit
+    vit.TIMM_VITS.setdefault("vit_test_patch16", dict(dim=128, depth=3, heads=2, mlp_dim=512))   # a 3-block ViT keeps the emulated run short
     torch.manual_seed(0)
     wrap = face.get_model(CFG, None, 0, backend=be, device=dev)
     model = wrap.model
