@@ -61,6 +61,18 @@ def cpu_baseline_vit(seconds_budget: float = 25.0):
             "sample": f"oracle/vit_ref.py ViT-B/16 fp32 fwd+bwd+clip+SGD, bs={bs}, {steps} step(s) after 1 warm-up, torch CPU"}
 
 
+def pmc_traffic_per_launch():
+    """HBM-side bytes per GEMM launch from the committed PMC passes of this same command (rocprofv3 cannot run inside the timed process):
+    profiles/r01_pmc_traffic.json is written by tools/pmc_traffic.py from two `rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE}` runs,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  None if the artifact is absent."""
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f)["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def bench_cbir(dev, nq=10000, n=1_000_000, d=128, k=100, iters=3, with_cpu=True):
     from visiondk_amd import cbir
     g = torch.Generator(device="cpu"); g.manual_seed(0)
@@ -164,6 +176,8 @@ def main():
     dt = time.perf_counter() - t0
     gemm_ms, gemm_n, gemm_fl = C.c_double(0), C.c_int64(0), C.c_double(0)
     be.check(be.lib.vdk_prof_end(C.byref(gemm_ms), C.byref(gemm_n), C.byref(gemm_fl)), "vdk_prof_end")
+    gemm_bytes = C.c_double(0)
+    be.check(be.lib.vdk_prof_bytes(C.byref(gemm_bytes)), "vdk_prof_bytes")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -186,7 +200,8 @@ def main():
             "model_flops_utilisation": {"achieved_tflops_per_gpu": per_gpu_tflops, "peak": PEAK_BF16_TFLOPS, "frac": per_gpu_tflops / PEAK_BF16_TFLOPS,
                                         "flop_per_image": VIT_FLOP_PER_IMG},
             "roofline": {"bound": "mfma", "kernel": "gemm256_bf16_kernel<NT|TN> (+ gemm_bf16_nt_kernel on small shapes)", "achieved": gemm_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": gemm_tflops / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": gemm_tflops / PEAK_BF16_TFLOPS, "traffic": pmc_traffic_per_launch(),
+                         "algorithmic_bytes_per_launch": gemm_bytes.value / max(gemm_n.value, 1),
                          "avg_launch_ms": gemm_avg_ms, "launches": gemm_n.value, "flops_per_launch": gemm_fl.value / max(gemm_n.value, 1),
                          "gemm_share_of_step_time": gemm_ms.value / (dt * 1e3)},
         }

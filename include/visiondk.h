@@ -112,6 +112,7 @@ int vdk_gemm_debug_stamps(void* device_u64_buffer);
  * begin(max_launches) pre-creates the events; end() synchronises and returns the totals since begin(). */
 int vdk_prof_begin(int32_t max_launches);
 int vdk_prof_end(double* total_ms, int64_t* launches, double* total_flops);
+int vdk_prof_bytes(double* total_bytes);   /* algorithmic bytes of those launches (every operand / output / epilogue tensor counted once) */
 
 /* out[c][r] = in[r][c] (bf16), rows R..Rpad-1 of the new contraction dim zero-filled; feeds wgrad.
  * in_row_group > 0: logical row r lives at physical row r + r/in_row_group + 1 (token buffer without cls rows).

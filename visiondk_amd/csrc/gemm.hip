@@ -579,6 +579,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 #include <vector>
 static std::vector<hipEvent_t> g_prof_ev;
 static std::vector<double> g_prof_flops;
+static double g_prof_bytes = 0.0;   // algorithmic bytes of the profiled launches: every operand / output / epilogue tensor counted once
 static size_t g_prof_used = 0;
 static bool g_prof_on = false;
 static void* g_dbg_ptr = nullptr;
@@ -597,6 +598,7 @@ int vdk_prof_begin(int32_t max_launches) {
     g_prof_ev.push_back(e);
   }
   g_prof_flops.clear();
+  g_prof_bytes = 0.0;
   g_prof_used = 0;
   g_prof_on = true;
   return VDK_OK;
@@ -613,6 +615,13 @@ int vdk_prof_end(double* total_ms, int64_t* launches, double* total_flops) {
   if (total_ms) *total_ms = ms;
   if (launches) *launches = (int64_t)(g_prof_used / 2);
   if (total_flops) *total_flops = fl;
+  return VDK_OK;
+}
+
+/* algorithmic bytes (each operand / output / epilogue tensor once) of the launches covered by the last vdk_prof_begin .. vdk_prof_end */
+int vdk_prof_bytes(double* total_bytes) {
+  if (!total_bytes) return vdk_fail(VDK_EINVAL, "vdk_prof_bytes: null");
+  *total_bytes = g_prof_bytes;
   return VDK_OK;
 }
 
@@ -705,6 +714,15 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   if (prof) {   // the GEMM kernel only (the split-K combine is a separate, HBM-bound kernel)
     (void)hipEventRecord(g_prof_ev[g_prof_used + 1], stream);
     g_prof_flops.push_back(2.0 * d->M * d->N * d->K);
+    {
+      const double mn = (double)d->M * d->N;
+      double b = ((double)d->M * d->K + (double)d->N * d->K) * 2.0 + mn * (d->c_dtype == VDK_F32 ? 4.0 : 2.0);
+      if (d->residual) b += mn * 4.0;
+      if (d->aux) b += mn * 2.0;
+      if (d->bias) b += d->N * 4.0;
+      if (d->splitk > 1) b += 2.0 * d->splitk * mn * 4.0;   // slabs written, then read by the reduce
+      g_prof_bytes += b;
+    }
     g_prof_used += 2;
   }
   if (splitk > 1) {
