@@ -226,6 +226,24 @@ class FaceTrainingWrapper:
                 nn.init.constant_(m.bias, 0)
 
 
+class FaceModelLoader:
+    """models/faceX/face_model.py:56-86 — build the backbone from the config and load a reference checkpoint: `ckpt['state_dict']` (the training
+    backbone) or `ckpt['ema']` (a state_dict for the face / CBIR tasks, train.py:266-278); keys are the reference's (`model.<timm keys>`,
+    `output_layer.*`), strict."""
+
+    def __init__(self, model_cfg: dict, backend=None, device=None):
+        self.model = BackboneFactory(model_cfg["backbone"], backend=backend, device=device).get_backbone()
+
+    def load_weight_default(self, model_path):
+        self.model.load_state_dict(torch.load(model_path, weights_only=False, map_location="cpu")["state_dict"], strict=True)
+        return self.model
+
+    def load_weight(self, model_path, ema: bool = False):
+        ckpt = torch.load(model_path, weights_only=False, map_location="cpu")
+        self.model.load_state_dict(ckpt["ema"] if ema else ckpt["state_dict"], strict=True)
+        return self.model
+
+
 class FeatureExtractor:
     """models/faceX/face_model.py:88-143 — eval forward -> F.normalize -> host numpy (order = loader order)"""
 
