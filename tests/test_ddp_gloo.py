@@ -59,3 +59,83 @@ def test_two_rank_step_equals_single_process(tmp_path, emu):
     d_ddp = r0["params"] - p0
     rel = ((d_ddp - d_single).norm() / d_single.norm()).item()
     assert rel < 2e-2, rel
+
+
+# ---- face / CBIR task: 2-rank FaceTrainStep (ConvNeXt backbone + BatchNorm neck + ArcFace) and sharded gallery search --------------------------
+FACE_CFG = {"task": "cbir", "image_size": 64, "backbone": {"timm-convnext_test": {"pretrained": False, "image_size": 64, "feat_dim": 64}},
+            "head": {"arcface": {"feat_dim": 64, "num_class": 24, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
+
+
+def _face_model(be, seed):
+    from visiondk_amd import convnext, face
+    convnext.TIMM_CONVNEXTS["convnext_test"] = dict(depths=(1, 1, 1, 1), dims=(8, 16, 24, 32))
+    torch.manual_seed(seed)
+    model = face.get_model(FACE_CFG, None, 0, backend=be, device="cpu").model.train()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("gamma"):
+                p.fill_(0.4)
+    return model
+
+
+def _face_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["VDK_EMU_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.emu.emu_backend import load_emu
+    from visiondk_amd import cbir, comm, face
+    be = load_emu()
+    model = _face_model(be, 100 + rank)                      # ranks start different; the step object broadcasts rank 0's weights
+    c = comm.GradAllReduce(bucket_bytes=20_000)
+    step = face.FaceTrainStep(model, lr=0.05, momentum=0.9, weight_decay=5e-4, max_norm=10.0, ema=True, comm=c)
+    init = {k: v.clone() for k, v in model.state_dict().items()}      # after the broadcast: rank 0's weights everywhere
+    torch.manual_seed(7)
+    x = torch.randn(8, 3, 64, 64); y = torch.randint(0, 24, (8,))
+    lo, hi = rank * 4, rank * 4 + 4
+    step.step(x[lo:hi], y[lo:hi])
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    # sharded gallery search: rank r holds rows [r*150, r*150+150) of a 300-row gallery and its own 5 queries
+    g = torch.Generator().manual_seed(3)
+    gal = torch.nn.functional.normalize(torch.randn(300, 32, generator=g)); qry = torch.nn.functional.normalize(torch.randn(10, 32, generator=g))
+    s, i = cbir.search_sharded(qry[rank * 5:rank * 5 + 5], gal[rank * 150:rank * 150 + 150], k=7, idx_base=rank * 150, backend=be, device="cpu", cap=200)
+    torch.save({"sd": sd, "init": init, "grads": step.eng.grads.clone(), "head_grad": model.trainingwrapper["head"].weight.grad.clone(), "s": s, "i": i}, f"{out_dir}/face{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_two_rank_face_step_and_sharded_search(tmp_path, emu):
+    port = 29500 + ((os.getpid() + 137) % 500)
+    mp.start_processes(_face_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "face0.pt"); r1 = torch.load(tmp_path / "face1.pt")
+    for k in r0["init"]:
+        assert torch.equal(r0["init"][k], r1["init"][k]), k  # broadcast at construction
+    for k in r0["sd"]:
+        if "running" in k or "num_batches" in k:
+            continue                                          # BatchNorm statistics are per-rank between the per-forward broadcasts (torch DDP semantics)
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k      # replicas stay bit-identical
+    assert torch.equal(r0["grads"], r1["grads"]) and torch.equal(r0["head_grad"], r1["head_grad"])
+    # the all-reduced gradient is the sum of the two local gradients (each computed on its half with rank 0's weights)
+    from visiondk_amd import face
+    total, total_head = None, None
+    torch.manual_seed(7)
+    x = torch.randn(8, 3, 64, 64); y = torch.randint(0, 24, (8,))
+    for r in range(2):
+        model = _face_model(emu, 100)
+        model.load_state_dict(r0["init"], strict=True)
+        st = face.FaceTrainStep(model, lr=0.0, momentum=0.0, weight_decay=0.0, ema=False)
+        st.step(x[r * 4:r * 4 + 4], y[r * 4:r * 4 + 4])
+        total = st.eng.grads.clone() if total is None else total + st.eng.grads
+        hg = model.trainingwrapper["head"].weight.grad
+        total_head = hg.clone() if total_head is None else total_head + hg
+    assert torch.equal(total, r0["grads"]) and torch.equal(total_head, r0["head_grad"])
+    # sharded search == single search over the whole gallery, bit for bit, each rank holding its own queries' results
+    import numpy as np
+    from oracle import cbir as ocbir
+    g = torch.Generator().manual_seed(3)
+    gal = torch.nn.functional.normalize(torch.randn(300, 32, generator=g)); qry = torch.nn.functional.normalize(torch.randn(10, 32, generator=g))
+    so, io = ocbir.flat_ip_search(qry.numpy(), gal.numpy(), 7)
+    got_s = torch.cat([r0["s"], r1["s"]]).numpy(); got_i = torch.cat([r0["i"], r1["i"]]).numpy()
+    np.testing.assert_array_equal(got_i, io)
+    np.testing.assert_array_equal(got_s.view(np.uint32), so.view(np.uint32))

@@ -210,3 +210,29 @@ def search(extractor, query_dataloader, faiss_index: FlatIPIndex, device, logger
     if isinstance(all_s[0], np.ndarray):
         return np.concatenate(all_s, 0), np.concatenate(all_i, 0)
     return torch.cat(all_s, 0), torch.cat(all_i, 0)
+
+
+def search_sharded(queries: torch.Tensor, local_gallery: torch.Tensor, k: int, idx_base: int, group=None, backend=None, device=None, cap: int = DEFAULT_CAP):
+    """Multi-GPU search (path B): the gallery is row-sharded (`local_gallery` = this rank's rows, global row ids starting at
+    `idx_base`), every rank holds its own query block.  Queries are all-gathered, each rank searches its shard, the per-shard top-k lists are
+    all-gathered and merged with the same (score desc, index asc) rule -> every rank returns the global (scores, indices) of ITS queries,
+    bit-identical to a single-GPU search over the whole gallery.  One process per GPU; two collectives, both outside the scan."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    nq_local = torch.tensor([queries.shape[0]], dtype=torch.int64, device=queries.device)
+    counts = [torch.zeros_like(nq_local) for _ in range(world)]
+    dist.all_gather(counts, nq_local, group=group)
+    counts = [int(c.item()) for c in counts]
+    qmax = max(counts)
+    qpad = torch.zeros((qmax, queries.shape[1]), dtype=torch.float32, device=queries.device)
+    qpad[:queries.shape[0]] = queries
+    gathered = [torch.empty_like(qpad) for _ in range(world)]
+    dist.all_gather(gathered, qpad, group=group)
+    allq = torch.cat([g[:c] for g, c in zip(gathered, counts)], 0)
+    index = FlatIPIndex(queries.shape[1], backend=backend, device=device if device is not None else queries.device, cap=cap, idx_base=idx_base)
+    index.add(local_gallery)
+    s, i = index.search(allq, k)                                  # [sum nq, k] for this shard, global row ids
+    parts_s = [torch.empty_like(s) for _ in range(world)]; parts_i = [torch.empty_like(i) for _ in range(world)]
+    dist.all_gather(parts_s, s.contiguous(), group=group); dist.all_gather(parts_i, i.contiguous(), group=group)
+    lo = sum(counts[:rank]); hi = lo + counts[rank]
+    return merge_topk(torch.stack([p[lo:hi] for p in parts_s]).contiguous(), torch.stack([p[lo:hi] for p in parts_i]).contiguous(), backend=backend)

@@ -308,8 +308,13 @@ class FaceTrainStep:
     launch each with the same global clip factor.  BatchNorm running statistics enter the EMA like every float entry of state_dict()."""
 
     def __init__(self, model: "FaceTrainingModel", lr: float, momentum: float = 0.9, weight_decay: float = 5e-4, label_smoothing: float = 0.0,
-                 max_norm: float = 10.0, ema: bool = True):
+                 max_norm: float = 10.0, ema: bool = True, comm=None):
+        """comm: visiondk_amd.comm.GradAllReduce for data parallelism (one process per GPU): parameters and BatchNorm buffers are broadcast from
+        rank 0 at construction and the buffers again before every forward (torch DDP's broadcast_buffers=True, which the reference's
+        DDP wrap at vision_engine.py:510 uses); the backbone's flat gradient is all-reduced in buckets while backward is still running, the neck /
+        head gradients right after; BatchNorm statistics stay per-rank (the reference's default, SyncBN is its opt-in flag)."""
         self.model = model
+        self.comm = comm
         self.bb = model.trainingwrapper["backbone"]
         self.head = model.trainingwrapper["head"]
         self.eng = self.bb.model.engine
@@ -333,6 +338,17 @@ class FaceTrainStep:
         self.be.check(self.be.lib.vdk_sumsq_workspace_bytes(C.byref(need)), "vdk_sumsq_workspace_bytes")
         self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.eng.device)
         self.loss_rows: Optional[torch.Tensor] = None
+        if comm is not None and comm.world_size > 1:
+            import torch.distributed as dist
+            comm.broadcast_params(self.eng.params)
+            for t in self.small + self.buffers:
+                dist.broadcast(t.data, src=0, group=comm.group)
+            if ema:
+                self.ema_flat.copy_(self.eng.params)
+                for e, p in zip(self.ema_small, self.small):
+                    e.copy_(p.detach())
+                for e, b in zip(self.ema_buf, self.buffers):
+                    e.copy_(b)
 
     def _sumsq(self, g: torch.Tensor) -> None:
         be = self.be
@@ -347,6 +363,11 @@ class FaceTrainStep:
         d = 0.9999 * (1 - math.exp(-self.updates / 2000)) if self.ema_flat is not None else 0.0
         lr = self.param_groups[0]["lr"]
         B = x.shape[0]
+        world = self.comm.world_size if self.comm is not None else 1
+        if world > 1:
+            import torch.distributed as dist
+            for b in self.buffers:
+                dist.broadcast(b, src=0, group=self.comm.group)
         # forward: backbone engine -> neck (autograd node over the HIP kernels) -> fused head + CE
         out = eng.forward(x)
         if bb.is_cnn:
@@ -362,21 +383,31 @@ class FaceTrainStep:
         emb.backward(demb)
         self.head.weight.grad = dW
         dfeat = feat.grad
-        if bb.is_cnn:
-            eng.backward(dfeat.permute(0, 2, 3, 1).contiguous().view(-1, eng.out_ch))
+        dfeat = dfeat.permute(0, 2, 3, 1).contiguous().view(-1, eng.out_ch) if bb.is_cnn else dfeat.contiguous().view(-1, eng.spec.dim)
+        if world > 1:
+            import torch.distributed as dist
+            self.comm.begin_step(eng.grads)
+            eng.backward(dfeat, on_ready=self.comm.on_grad_ready)
+            small_work = []
+            for p in self.small:
+                p.grad = p.grad.contiguous()
+                small_work.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.comm.group, async_op=True))
+            self.comm.finish_step()
+            for w_ in small_work:
+                w_.wait()
         else:
-            eng.backward(dfeat.contiguous().view(-1, eng.spec.dim))
-        # clip_grad_norm_ over every parameter, then SGD + EMA
+            eng.backward(dfeat)
+        # clip_grad_norm_ over every parameter (of the rank-averaged gradient), then SGD + EMA
         self._nsq.zero_()
         self._sumsq(eng.grads)
         for p in self.small:
             self._sumsq(p.grad.contiguous())
         first = int(self.updates == 1)
         be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.mom_flat), be.ptr(self.ema_flat), be.ptr(eng.wb16), eng.n_floats, lr,
-                                     self.momentum, self.weight_decay, 1.0, be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step")
+                                     self.momentum, self.weight_decay, 1.0 / world, be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step")
         for p, m, e in zip(self.small, self.mom_small, self.ema_small):
             g = p.grad.contiguous()
-            be.check(be.lib.vdk_sgd_step(be.ptr(p.data), be.ptr(g), be.ptr(m), be.ptr(e), None, p.numel(), lr, self.momentum, self.weight_decay, 1.0,
+            be.check(be.lib.vdk_sgd_step(be.ptr(p.data), be.ptr(g), be.ptr(m), be.ptr(e), None, p.numel(), lr, self.momentum, self.weight_decay, 1.0 / world,
                                          be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step")
         for b, z, zm, e in zip(self.buffers, self._zero, self._zero_m, self.ema_buf):   # EMA of the BatchNorm running statistics (lr = 0: value untouched)
             be.check(be.lib.vdk_sgd_step(be.ptr(b), be.ptr(z), be.ptr(zm), be.ptr(e), None, b.numel(), 0.0, 0.0, 0.0, 1.0, None, self.max_norm, d, first,
