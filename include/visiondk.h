@@ -204,6 +204,33 @@ int vdk_topk_rows(const float* x, int64_t ld, int32_t B, int32_t C, int32_t k, i
 int vdk_mixup(const float* x, const int64_t* perm, float lam, int32_t B, int64_t per_sample, float* out, void* stream);
 
 
+/* ---- PRECISE inference path: fp32-in / fp32-out contractions on the fp32 MFMA (v_mfma_f32_32x32x2_f32) -------------------------
+ * For evaluation / embedding extraction within 1e-3 (measured ~1e-6) of the reference's PyTorch-CPU fp32 path (north_star's tolerance); the
+ * training path keeps bf16 MFMA operands.  C[z] = epilogue(alpha * A[z] B[z]^T): A [M, K] rows, B [N, K] rows or (b_kmajor) [K, N];
+ * K, lda, ldb % 4 == 0; z = (z1, z2) with z1 < batch1, z2 < batch2 and element strides s?1 / s?2 (0 batches = 1). */
+typedef struct VdkGemmF32Desc {
+  const float* A; int64_t lda;
+  const float* B; int64_t ldb;
+  float* C; int64_t ldc;
+  int32_t M, N, K;
+  const float* bias;          /* [N] or NULL */
+  const float* residual;      /* f32 [M, ldr] or NULL, added after the activation */
+  int64_t ldr;
+  int32_t act;                /* VDK_ACT_NONE | VDK_ACT_GELU (exact erf) */
+  float alpha;                /* 0 means 1 */
+  const float* col_scale;     /* [N] or NULL: multiplies the activated value before the residual (ConvNeXt layer scale) */
+  int32_t b_kmajor;
+  int32_t batch1, batch2;
+  int64_t sa1, sa2, sb1, sb2, sc1, sc2;
+} VdkGemmF32Desc;
+int vdk_gemm_f32_nt(const VdkGemmF32Desc* d, void* stream);
+/* in-place softmax(scale * x) over the first `cols` columns of every row; columns [cols, ld) are zeroed */
+int vdk_softmax_rows_f32(float* x, int64_t ld, int64_t rows, int32_t cols, float scale, void* stream);
+/* fp32 operands of the k = stride convolutions for the precise path: PatchEmbed / ConvNeXt stem (NCHW input, k = c*p*p + ky*p + kx) and the
+ * 2x2 stride-2 downsample on NHWC rows (k = c*4 + 2*ky + kx, the weight's own flattening) */
+int vdk_patchify_f32(const float* x, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t patch, float* out, void* stream);
+int vdk_space_to_depth2_f32(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+
 /* ---- CNN backbone pieces (timm ConvNeXt behind TimmWrapper, models/faceX/backbone/timm_wrapper.py:16-37) --------------------
  * All activations are NHWC f32 / bf16 rows, so pointwise / 4x4-stem / 2x2-downsample convolutions are vdk_gemm_bf16_nt and
  * LayerNorm2d is vdk_layernorm_*.  ConvNeXtBlock.conv_dw (Conv2d(C, C, 7, padding 3, groups=C)):
@@ -255,6 +282,10 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
 /* dlogits bf16 [B, Cp] -> grads (flat fp32, overwritten).  on_ready: see csrc/vit_engine.hip (DDP bucket hook). */
 int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* params, const void* wb16, const void* wt16, void* ws,
                      size_t ws_bytes, float* grads, vdk_grad_ready_fn on_ready, void* user, void* stream, void* side_stream);
+/* PRECISE forward (evaluation / embedding extraction): same network, fp32 activations, every contraction on the fp32 MFMA, reads the fp32 master
+ * weights; agrees with the reference's PyTorch-CPU fp32 path to ~1e-6 (north_star asks for 1e-3).  Nothing is kept for a backward. */
+int vdk_vit_workspace_f32_bytes(const VdkVitConfig* cfg, size_t* bytes);
+int vdk_vit_forward_f32(const VdkVitConfig* cfg, const float* x, const float* params, void* ws, size_t ws_bytes, float* logits, void* stream);
 /* side_stream (may be NULL = same as stream): a second caller-owned hipStream_t that receives the weight-gradient GEMMs and
  * bias column sums; ordered against `stream` with events, joined before the call returns control of `stream`. */
 
@@ -296,6 +327,10 @@ int vdk_convnext_refresh_weights(const VdkConvNextConfig* cfg, const float* para
 /* x f32 [B, in_chans, img, img] -> out f32 [B*(img/32)^2, dims[3]] (row (b, y, x), channel-contiguous) */
 int vdk_convnext_forward(const VdkConvNextConfig* cfg, const float* x, const float* params, const void* wb16, const void* wx, void* ws, size_t ws_bytes,
                          float* out, void* stream);
+/* PRECISE forward, as vdk_vit_forward_f32 (wx: only the tap-major depthwise weights are read from it) */
+int vdk_convnext_workspace_f32_bytes(const VdkConvNextConfig* cfg, size_t* bytes);
+int vdk_convnext_forward_f32(const VdkConvNextConfig* cfg, const float* x, const float* params, const void* wx, void* ws, size_t ws_bytes, float* out,
+                             void* stream);
 /* dout f32 (same shape as out) -> grads (flat fp32, overwritten); on_ready as in vdk_vit_backward */
 int vdk_convnext_backward(const VdkConvNextConfig* cfg, const float* dout, const float* params, const void* wb16, const void* wx, void* ws, size_t ws_bytes,
                           float* grads, vdk_grad_ready_fn on_ready, void* user, void* stream);

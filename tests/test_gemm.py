@@ -125,3 +125,27 @@ def test_gemm_tn_from_kmajor_operands(be, dev, K, M, N, splitk, rg):
     out = ops.gemm_nt(a_full, b, out_dtype=torch.float32, splitk=splitk, trans=True, a_row_group=rg, a_rows=K, backend=be)
     assert out.shape == (M, N)
     assert _rel(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(70, 40, 64), (130, 200, 100), (5, 64, 200)])
+def test_gemm_f32_precise(be, dev, M, N, K):
+    """fp32 MFMA GEMM (precise inference path) vs float64 numpy: every element within fp32 round-off of the exact product"""
+    torch.manual_seed(M)
+    a, b = torch.randn(M, K), torch.randn(N, K)
+    bias, res = torch.randn(N), torch.randn(M, N)
+    ref = (a.double() @ b.double().t())
+    out = ops.gemm_f32(a.to(dev), b.to(dev), backend=be)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=2e-5)
+    out = ops.gemm_f32(a.to(dev), b.to(dev), bias=bias.to(dev), residual=res.to(dev), act=ops.ACT_GELU, alpha=0.5, backend=be)
+    ref2 = torch.nn.functional.gelu(0.5 * ref + bias.double()) + res.double()
+    torch.testing.assert_close(out.cpu().double(), ref2, rtol=1e-5, atol=2e-5)
+    if N % 4 == 0:
+        out = ops.gemm_f32(a.to(dev), b.t().contiguous().to(dev), b_kmajor=True, backend=be)
+        torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=2e-5)
+
+
+def test_softmax_rows_f32(be, dev):
+    x = torch.randn(37, 200) * 3
+    y = ops.softmax_rows_f32(x.clone().to(dev), cols=197, scale=0.125, backend=be).cpu()
+    torch.testing.assert_close(y[:, :197], torch.softmax(x[:, :197] * 0.125, dim=1), rtol=1e-5, atol=1e-7)
+    assert (y[:, 197:] == 0).all()

@@ -30,6 +30,12 @@ class VitConfig(C.Structure):
                 ("heads", I32), ("mlp_dim", I32), ("num_classes", I32), ("ln_eps", F32)]
 
 
+class GemmF32Desc(C.Structure):
+    _fields_ = [("A", P), ("lda", I64), ("B", P), ("ldb", I64), ("C", P), ("ldc", I64), ("M", I32), ("N", I32), ("K", I32), ("bias", P), ("residual", P),
+                ("ldr", I64), ("act", I32), ("alpha", C.c_float), ("col_scale", P), ("b_kmajor", I32), ("batch1", I32), ("batch2", I32), ("sa1", I64), ("sa2", I64),
+                ("sb1", I64), ("sb2", I64), ("sc1", I64), ("sc2", I64)]
+
+
 class ConvNextConfig(C.Structure):
     _fields_ = [("batch", I32), ("img_size", I32), ("in_chans", I32), ("depths", I32 * 4), ("dims", I32 * 4), ("ln_eps", C.c_float)]
 
@@ -98,6 +104,10 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_margin_ce": (C.c_int, [C.POINTER(MarginHead), P, I64, I32, I32, P, F32, F32, P, I64, P, P, I64, P]),
     "vdk_margin_bwd": (C.c_int, [C.POINTER(MarginHead), P, I64, I32, I32, P, P, I64, P, I64, P]),
     # native ViT engine
+    "vdk_gemm_f32_nt": (C.c_int, [C.POINTER(GemmF32Desc), P]),
+    "vdk_softmax_rows_f32": (C.c_int, [P, I64, I64, I32, C.c_float, P]),
+    "vdk_patchify_f32": (C.c_int, [P, I32, I32, I32, I32, I32, P, P]),
+    "vdk_space_to_depth2_f32": (C.c_int, [P, P, I32, I32, I32, I32, P]),
     "vdk_dwconv7_fwd": (C.c_int, [P, P, P, P, P, P, I32, I32, I32, I32, I32, P]),
     "vdk_dwconv7_wgrad_workspace_bytes": (C.c_int, [I32, I32, I32, I32, PSZ]),
     "vdk_dwconv7_wgrad": (C.c_int, [P, P, P, P, I32, I32, I32, I32, P, SZ, P]),
@@ -114,6 +124,10 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_vit_refresh_weights": (C.c_int, [C.POINTER(VitConfig), P, P, P, I32, P]),
     "vdk_vit_forward": (C.c_int, [C.POINTER(VitConfig), P, P, P, P, SZ, P, P]),
     "vdk_vit_backward": (C.c_int, [C.POINTER(VitConfig), P, P, P, P, P, SZ, P, P, P, P, P]),
+    "vdk_vit_workspace_f32_bytes": (C.c_int, [C.POINTER(VitConfig), PSZ]),
+    "vdk_vit_forward_f32": (C.c_int, [C.POINTER(VitConfig), P, P, P, SZ, P, P]),
+    "vdk_convnext_workspace_f32_bytes": (C.c_int, [C.POINTER(ConvNextConfig), PSZ]),
+    "vdk_convnext_forward_f32": (C.c_int, [C.POINTER(ConvNextConfig), P, P, P, P, SZ, P, P]),
     "vdk_convnext_param_count": (C.c_int, [C.POINTER(ConvNextConfig), C.POINTER(I64), C.POINTER(I32), PSZ]),
     "vdk_convnext_param_info": (C.c_int, [C.POINTER(ConvNextConfig), I32, C.c_char_p, I32, C.POINTER(I64), C.POINTER(I64), C.POINTER(I64), C.POINTER(I32)]),
     "vdk_convnext_workspace_bytes": (C.c_int, [C.POINTER(ConvNextConfig), PSZ]),

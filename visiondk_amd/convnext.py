@@ -110,6 +110,25 @@ class ConvNeXtEngine:
                                              be.ptr(self._out), be.stream()), "vdk_convnext_forward")
         return self._out
 
+    def forward_precise(self, x: torch.Tensor) -> torch.Tensor:
+        """Evaluation forward with fp32 activations and fp32-MFMA contractions (vdk_convnext_forward_f32) -> f32 [B*h*w, C] NHWC rows"""
+        s = self.spec
+        if x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (s.in_chans, s.img_size, s.img_size):
+            raise ValueError(f"expected float32 [B, {s.in_chans}, {s.img_size}, {s.img_size}], got {tuple(x.shape)} {x.dtype}")
+        x = x.contiguous()
+        B = x.shape[0]
+        self._ensure_fresh()                      # the tap-major depthwise weights live in wx
+        cfg = self._cfg(B)
+        be = self.be
+        need = C.c_size_t(0)
+        be.check(be.lib.vdk_convnext_workspace_f32_bytes(C.byref(cfg), C.byref(need)), "vdk_convnext_workspace_f32_bytes")
+        if getattr(self, "_ws32", None) is None or self._ws32.numel() < need.value:
+            self._ws32 = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        out = torch.empty((B * self.out_hw * self.out_hw, self.out_ch), dtype=torch.float32, device=self.device)
+        be.check(be.lib.vdk_convnext_forward_f32(C.byref(cfg), be.ptr(x), be.ptr(self.params), be.ptr(self.wx), be.ptr(self._ws32), self._ws32.numel(),
+                                                 be.ptr(out), be.stream()), "vdk_convnext_forward_f32")
+        return out
+
     def backward(self, dout: torch.Tensor, on_ready: Optional[Callable[[int, int], None]] = None) -> torch.Tensor:
         """dout f32 [B*h*w, C] -> self.grads (flat fp32, overwritten).  Needs the workspace of the matching forward."""
         assert dout.dtype == torch.float32 and dout.is_contiguous() and dout.shape == self._out.shape
@@ -215,6 +234,14 @@ class ConvNeXt(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return _ConvNeXtFunction.apply(x, self, *[p for _, p in self._plist])
+
+    @torch.no_grad()
+    def forward_precise(self, x: torch.Tensor) -> torch.Tensor:
+        """`model(x)` for evaluation with fp32-MFMA contractions (no autograd) -> [B, C, H/32, W/32]"""
+        eng = self.engine
+        self._sync_flat()
+        out = eng.forward_precise(x)
+        return out.view(x.shape[0], eng.out_hw, eng.out_hw, eng.out_ch).permute(0, 3, 1, 2)
 
 
 def create_model(name: str, pretrained: bool = False, num_classes: int = 0, global_pool: str = "", device=None, backend=None, img_size: int = 224,

@@ -38,6 +38,9 @@ int vdk_conv2x2_weight_prep(const float*, void*, void*, int32_t, int32_t, void*)
 int vdk_conv2x2_wgrad_unpermute(const float*, float*, int32_t, int32_t, void*);
 int vdk_layerscale_weight_prep(const float*, const float*, const float*, void*, void*, float*, int32_t, int32_t, void*);
 int vdk_layerscale_grad(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int32_t, int32_t, void*);
+int vdk_gemm_f32_nt(const VdkGemmF32Desc*, void*);
+int vdk_patchify_f32(const float*, int32_t, int32_t, int32_t, int32_t, int32_t, float*, void*);
+int vdk_space_to_depth2_f32(const float*, float*, int32_t, int32_t, int32_t, int32_t, void*);
 }
 
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
@@ -427,6 +430,82 @@ int vdk_convnext_backward(const VdkConvNextConfig* cfg, const float* dout, const
     }
   }
   return vdk_check_launch("vdk_convnext_backward");
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PRECISE forward (evaluation / embedding extraction): fp32 activations, contractions on the fp32 MFMA (csrc/gemm_f32.hip), the
+// depthwise conv and LayerNorm are fp32 already.  Reads the fp32 master weights (and the tap-major depthwise copy in `wx`).
+namespace {
+struct CnWsF32 { size_t total, big, xa, xb, t, h; };
+void cn_plan_f32(const CnDims& d, CnWsF32* w) {
+  size_t rc = 0, rm = 0, pk = (size_t)d.R[0] * d.Kst;
+  for (int i = 0; i < 4; ++i) {
+    const size_t r = (size_t)d.R[i] * d.C[i];
+    if (r > rc) rc = r;
+    if (4 * r > rm) rm = 4 * r;                      // fc1 output [R, 4C]; also covers the space-to-depth operand [R_i, 4 C_{i-1}]
+  }
+  if (pk > rm) rm = pk;
+  size_t cur = 0;
+  w->big = w_take(cur, rm * 4); w->xa = w_take(cur, rc * 4); w->xb = w_take(cur, rc * 4); w->t = w_take(cur, rc * 4); w->h = w_take(cur, rc * 4);
+  w->total = cur;
+}
+int gemm32(hipStream_t s, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, const float* bias, const float* cscale,
+           const float* res, int64_t ldr, int act) {
+  VdkGemmF32Desc g = {};
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.col_scale = cscale; g.residual = res; g.ldr = ldr;
+  g.act = act; g.alpha = 1.0f;
+  return vdk_gemm_f32_nt(&g, s);
+}
+}  // namespace
+
+extern "C" {
+
+int vdk_convnext_workspace_f32_bytes(const VdkConvNextConfig* cfg, size_t* bytes) {
+  CnDims d; RC(cn_dims(cfg, &d));
+  if (!bytes) return vdk_fail(VDK_EINVAL, "null");
+  CnWsF32 w; cn_plan_f32(d, &w);
+  *bytes = w.total;
+  return VDK_OK;
+}
+
+int vdk_convnext_forward_f32(const VdkConvNextConfig* cfg, const float* x, const float* params, const void* wx, void* ws, size_t ws_bytes, float* out,
+                             void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  CnDims d; RC(cn_dims(cfg, &d));
+  PLayout p; cn_layout(d, &p);
+  XLayout xl; cn_xlayout(d, &xl);
+  CnWsF32 w; cn_plan_f32(d, &w);
+  if (!x || !params || !wx || !ws || !out) return vdk_fail(VDK_EINVAL, "vdk_convnext_forward_f32: null pointer");
+  if (ws_bytes < w.total) return vdk_fail(VDK_EWORKSPACE, "vdk_convnext_forward_f32: workspace too small");
+  char* base = (char*)ws;
+  const char* xb_ = (const char*)wx;
+  float* big = (float*)(base + w.big); float* xa = (float*)(base + w.xa); float* xb = (float*)(base + w.xb); float* t = (float*)(base + w.t);
+  float* h = (float*)(base + w.h);
+  // stem
+  RC(vdk_patchify_f32(x, d.B, d.Cin, d.img, d.img, 4, big, s));
+  RC(gemm32(s, big, d.Kst, params + p.stem_w, d.Kst, t, d.C[0], d.R[0], d.C[0], d.Kst, params + p.stem_b, nullptr, nullptr, 0, VDK_ACT_NONE));
+  RC(vdk_layernorm_fwd(t, d.C[0], d.R[0], d.C[0], params + p.stem_nw, params + p.stem_nb, d.eps, xa, d.C[0], VDK_F32, nullptr, nullptr, s));
+  for (int i = 0; i < 4; ++i) {
+    const int R = d.R[i], C = d.C[i], M = 4 * C, H = d.H[i];
+    if (i > 0) {
+      const int Rp = d.R[i - 1], Ci = d.C[i - 1];
+      RC(vdk_layernorm_fwd(xa, Ci, Rp, Ci, params + p.st[i].ds_nw, params + p.st[i].ds_nb, d.eps, h, Ci, VDK_F32, nullptr, nullptr, s));
+      RC(vdk_space_to_depth2_f32(h, big, d.B, d.H[i - 1], d.H[i - 1], Ci, s));
+      RC(gemm32(s, big, 4 * Ci, params + p.st[i].ds_w, 4 * Ci, xa, C, R, C, 4 * Ci, params + p.st[i].ds_b, nullptr, nullptr, 0, VDK_ACT_NONE));
+    }
+    for (int j = 0; j < d.depth[i]; ++j) {
+      const BlkP& b = p.st[i].blk[j]; const BlkX& bx = xl.blk[i][j];
+      RC(vdk_dwconv7_fwd(xa, (const float*)(xb_ + bx.dwt), params + b.dw_b, nullptr, t, nullptr, d.B, H, H, C, 0, s));
+      RC(vdk_layernorm_fwd(t, C, R, C, params + b.nw, params + b.nb, d.eps, h, C, VDK_F32, nullptr, nullptr, s));
+      RC(gemm32(s, h, C, params + b.fc1_w, C, big, M, R, M, C, params + b.fc1_b, nullptr, nullptr, 0, VDK_ACT_GELU));
+      RC(gemm32(s, big, M, params + b.fc2_w, M, xb, C, R, C, M, params + b.fc2_b, params + b.gamma, xa, C, VDK_ACT_NONE));
+      float* sw = xa; xa = xb; xb = sw;
+    }
+  }
+  RC(vdk_layernorm_fwd(xa, d.C[3], d.R[3], d.C[3], params + p.head_nw, params + p.head_nb, d.eps, out, d.C[3], VDK_F32, nullptr, nullptr, s));
+  return vdk_check_launch("vdk_convnext_forward_f32");
 }
 
 }  // extern "C"

@@ -34,6 +34,9 @@ int vdk_patchify_bf16(const float*, int32_t, int32_t, int32_t, int32_t, int32_t,
 int vdk_cls_rows(float*, int64_t, int32_t, int32_t, const float*, const float*, void*);
 int vdk_cast_f32_bf16(const float*, void*, int64_t, void*);
 int vdk_transpose_cast_f32_bf16(const float*, int64_t, int32_t, int32_t, void*, int64_t, int32_t, void*);
+int vdk_gemm_f32_nt(const VdkGemmF32Desc*, void*);
+int vdk_softmax_rows_f32(float*, int64_t, int64_t, int32_t, float, void*);
+int vdk_patchify_f32(const float*, int32_t, int32_t, int32_t, int32_t, int32_t, float*, void*);
 }
 
 static inline int64_t up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -517,6 +520,98 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
 #undef DU
 #undef DQKV
   return vdk_check_launch("vdk_vit_backward");
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PRECISE forward (evaluation / embedding extraction): the same network with every contraction on the fp32 MFMA
+// (csrc/gemm_f32.hip), fp32 activations throughout, attention with materialised fp32 scores.  Reads the fp32 master weights
+// directly; nothing is saved for a backward.  Logits / tokens agree with the reference's PyTorch-CPU fp32 path to ~1e-6.
+struct WsF32 { size_t total, patches, xa, xb, h, qkv, S, o, u; int Np; };
+static void vit_plan_f32(const VitDims& d, WsF32* w) {
+  size_t cur = 0;
+  const size_t T = d.T, D = d.D;
+  w->Np = (int)up(d.N, 4);
+  w->patches = w_take(cur, (size_t)d.B * d.np * d.Kpe * 4);
+  w->xa = w_take(cur, T * D * 4); w->xb = w_take(cur, T * D * 4); w->h = w_take(cur, T * D * 4);
+  w->qkv = w_take(cur, (T + 8) * 3 * D * 4);                      // + pad rows: the P V contraction reads K = Np >= N value rows
+  w->S = w_take(cur, (size_t)d.B * d.H * d.N * w->Np * 4);
+  w->o = w_take(cur, T * D * 4);
+  w->u = w_take(cur, T * (size_t)d.M * 4);
+  w->total = cur;
+}
+static int gemm32(hipStream_t s, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, const float* bias,
+                  const float* res, int64_t ldr, int act) {
+  VdkGemmF32Desc g = {};
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.residual = res; g.ldr = ldr; g.act = act;
+  g.alpha = 1.0f;
+  return vdk_gemm_f32_nt(&g, s);
+}
+
+extern "C" {
+
+int vdk_vit_workspace_f32_bytes(const VdkVitConfig* cfg, size_t* bytes) {
+  VitDims d; RC(vit_dims(cfg, &d));
+  if (!bytes) return vdk_fail(VDK_EINVAL, "null");
+  WsF32 w; vit_plan_f32(d, &w);
+  *bytes = w.total;
+  return VDK_OK;
+}
+
+// x f32 [B, Cin, img, img] -> logits f32 [B, Cp] (num_classes > 0) or final-normed tokens f32 [B*N, D] (num_classes == 0)
+int vdk_vit_forward_f32(const VdkVitConfig* cfg, const float* x, const float* params, void* ws, size_t ws_bytes, float* logits, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  VitDims d; RC(vit_dims(cfg, &d));
+  PLayout p; RC(vit_layout(d, &p));
+  WsF32 w; vit_plan_f32(d, &w);
+  if (!x || !params || !ws || !logits) return vdk_fail(VDK_EINVAL, "vdk_vit_forward_f32: null pointer");
+  if (ws_bytes < w.total) return vdk_fail(VDK_EWORKSPACE, "vdk_vit_forward_f32: workspace too small");
+  if ((long)d.B * d.H > 65535) return vdk_fail(VDK_EUNSUPPORTED, "vdk_vit_forward_f32: batch * heads <= 65535");
+  char* base = (char*)ws;
+  const int T = d.T, D = d.D, M = d.M, N = d.N, Np = w.Np;
+  float* patches = (float*)(base + w.patches);
+  float* xa = (float*)(base + w.xa); float* xb = (float*)(base + w.xb); float* h = (float*)(base + w.h);
+  float* qkv = (float*)(base + w.qkv); float* S = (float*)(base + w.S); float* o = (float*)(base + w.o); float* u = (float*)(base + w.u);
+  if (hipMemsetAsync(qkv + (size_t)T * 3 * D, 0, (size_t)8 * 3 * D * 4, s) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vdk_vit_forward_f32: memset failed");
+  // patch embedding per image (batch index = image): rows 1..N-1 of its token block, + pos_embed; then the cls rows
+  RC(vdk_patchify_f32(x, d.B, d.Cin, d.img, d.img, d.ps, patches, s));
+  {
+    VdkGemmF32Desc g = {};
+    g.A = patches; g.lda = d.Kpe; g.B = params + p.pe_w; g.ldb = d.Kpe; g.C = xa + D; g.ldc = D; g.M = d.np; g.N = D; g.K = d.Kpe;
+    g.bias = params + p.pe_b; g.residual = params + p.pos + D; g.ldr = D; g.alpha = 1.0f;
+    g.batch1 = d.B; g.batch2 = 1; g.sa1 = (int64_t)d.np * d.Kpe; g.sc1 = (int64_t)N * D;
+    if (d.B > 65535) return vdk_fail(VDK_EUNSUPPORTED, "vdk_vit_forward_f32: batch <= 65535");
+    RC(vdk_gemm_f32_nt(&g, s));
+  }
+  RC(vdk_cls_rows(xa, (int64_t)N * D, d.B, D, params + p.cls, params + p.pos, s));
+  for (int l = 0; l < d.L; ++l) {
+    const PLayout::Blk& b = p.blk[l];
+    RC(vdk_layernorm_fwd(xa, D, T, D, params + b.n1w, params + b.n1b, d.eps, h, D, VDK_F32, nullptr, nullptr, s));
+    RC(gemm32(s, h, D, params + b.qkv_w, D, qkv, 3 * D, T, 3 * D, D, params + b.qkv_b, nullptr, 0, VDK_ACT_NONE));
+    {   // S[b, head] = Q K^T (scale applied inside the softmax), then P = softmax(S / 8), then O = P V
+      VdkGemmF32Desc g = {};
+      g.A = qkv; g.lda = 3 * D; g.B = qkv + D; g.ldb = 3 * D; g.C = S; g.ldc = Np; g.M = N; g.N = N; g.K = 64; g.alpha = 1.0f;
+      g.batch1 = d.B; g.batch2 = d.H; g.sa1 = (int64_t)N * 3 * D; g.sa2 = 64; g.sb1 = g.sa1; g.sb2 = 64; g.sc1 = (int64_t)d.H * N * Np; g.sc2 = (int64_t)N * Np;
+      RC(vdk_gemm_f32_nt(&g, s));
+      RC(vdk_softmax_rows_f32(S, Np, (int64_t)d.B * d.H * N, N, 0.125f, s));
+      VdkGemmF32Desc v = {};
+      v.A = S; v.lda = Np; v.B = qkv + 2 * D; v.ldb = 3 * D; v.b_kmajor = 1; v.C = o; v.ldc = D; v.M = N; v.N = 64; v.K = Np; v.alpha = 1.0f;
+      v.batch1 = d.B; v.batch2 = d.H; v.sa1 = g.sc1; v.sa2 = g.sc2; v.sb1 = (int64_t)N * 3 * D; v.sb2 = 64; v.sc1 = (int64_t)N * D; v.sc2 = 64;
+      RC(vdk_gemm_f32_nt(&v, s));
+    }
+    RC(gemm32(s, o, D, params + b.proj_w, D, xb, D, T, D, D, params + b.proj_b, xa, D, VDK_ACT_NONE));
+    RC(vdk_layernorm_fwd(xb, D, T, D, params + b.n2w, params + b.n2b, d.eps, h, D, VDK_F32, nullptr, nullptr, s));
+    RC(gemm32(s, h, D, params + b.fc1_w, D, u, M, T, M, D, params + b.fc1_b, nullptr, 0, VDK_ACT_GELU));
+    RC(gemm32(s, u, M, params + b.fc2_w, M, xa, D, T, D, M, params + b.fc2_b, xb, D, VDK_ACT_NONE));
+  }
+  if (d.C == 0) {
+    RC(vdk_layernorm_fwd(xa, D, T, D, params + p.norm_w, params + p.norm_b, d.eps, logits, D, VDK_F32, nullptr, nullptr, s));
+    return vdk_check_launch("vdk_vit_forward_f32");
+  }
+  RC(vdk_layernorm_fwd(xa, (int64_t)N * D, d.B, D, params + p.norm_w, params + p.norm_b, d.eps, h, D, VDK_F32, nullptr, nullptr, s));
+  RC(gemm32(s, h, D, params + p.head_w, D, logits, d.Cp, d.B, d.Cp, D, params + p.head_b, nullptr, 0, VDK_ACT_NONE));
+  return vdk_check_launch("vdk_vit_forward_f32");
 }
 
 }  // extern "C"

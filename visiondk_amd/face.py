@@ -176,6 +176,29 @@ class TimmWrapper(nn.Module):
         else:
             raise NotImplementedError(f"backbone '{model_name}': the HIP engines cover {sorted(vit.TIMM_VITS)} and {sorted(convnext.TIMM_CONVNEXTS)}")
 
+    @torch.no_grad()
+    def forward_precise(self, x):
+        """Evaluation embedding with fp32 activations and fp32-MFMA contractions end to end (backbone + neck in eval mode): agrees with the reference's
+        PyTorch-CPU fp32 embedding to ~1e-6, so downstream cosine top-k lists match the reference's.  Used by FeatureExtractor(precise=True)."""
+        be, ol = self.be, self.output_layer
+        feat = self.model.forward_precise(x)
+        B = x.shape[0]
+        if self.is_cnn:
+            Cc, HW = feat.shape[1], feat.shape[2] * feat.shape[3]
+            rows = feat.permute(0, 2, 3, 1).contiguous().view(B * HW, Cc)
+            y, _, _ = ops.batchnorm_fwd(rows, ol[0].weight.detach(), ol[0].bias.detach(), ol[0].running_mean, ol[0].running_var, training=False, eps=ol[0].eps,
+                                        backend=be)
+            a = y.view(B, HW * Cc)
+            w = ol[2].weight.detach().view(-1, Cc, HW).permute(0, 2, 1).reshape(-1, HW * Cc).contiguous()     # NCHW-flatten columns -> NHWC-flatten columns
+        else:
+            N, D = feat.shape[1], feat.shape[2]
+            y, _, _ = ops.layernorm_fwd(feat.contiguous().view(B * N, D), ol[0].weight.detach(), ol[0].bias.detach(), eps=ol[0].eps, out_dtype=torch.float32, backend=be)
+            a = y.view(B, N * D)
+            w = ol[2].weight.detach().contiguous()
+        z = ops.gemm_f32(a, w, bias=ol[2].bias.detach(), backend=be)
+        out, _, _ = ops.batchnorm_fwd(z, ol[3].weight.detach(), ol[3].bias.detach(), ol[3].running_mean, ol[3].running_var, training=False, eps=ol[3].eps, backend=be)
+        return out
+
     def forward(self, x):
         feat = self.model(x)
         ol = self.output_layer
@@ -247,8 +270,10 @@ class FaceModelLoader:
 class FeatureExtractor:
     """models/faceX/face_model.py:88-143 — eval forward -> F.normalize -> host numpy (order = loader order)"""
 
-    def __init__(self, model):
+    def __init__(self, model, precise: bool = False):
+        """precise=True: embeddings from the fp32-MFMA forward (TimmWrapper.forward_precise), ~1e-6 from the reference's CPU embeddings"""
         self.model = model
+        self.precise = precise
 
     def extract_cbir(self, dataloader, device) -> np.ndarray:
         from . import cbir
@@ -258,7 +283,7 @@ class FeatureExtractor:
         with torch.no_grad():
             for tensors in dataloader:
                 tensors = tensors.to(device)
-                feature = model(tensors)
+                feature = model.forward_precise(tensors) if self.precise else model(tensors)
                 feature = cbir.l2_normalize(feature.contiguous(), backend=getattr(model, "be", None))
                 feats.append(feature.cpu().numpy())
         return np.concatenate(feats, axis=0)

@@ -378,3 +378,29 @@ def batchnorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma, save_mean, save_invs
     be.check(be.lib.vdk_batchnorm1d_bwd(be.ptr(dy), dy.stride(0), be.ptr(x), x.stride(0), B, F, be.ptr(gamma), be.ptr(save_mean), be.ptr(save_invstd), be.ptr(dx),
                                         F, be.ptr(dg), be.ptr(db), be.stream()), "vdk_batchnorm1d_bwd")
     return dx, dg, db
+
+
+# ---- precise (fp32 MFMA) path ---------------------------------------------------------------------------------------------
+def gemm_f32(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, act: int = ACT_NONE, alpha: float = 1.0, b_kmajor: bool = False, backend=None):
+    """out f32 [M, N] = epilogue(alpha * a[M, K] @ b[N, K].T)  (b_kmajor: b is [K, N]); fp32 operands, fp32 MFMA"""
+    be = _be(backend)
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1
+    M, K = a.shape
+    N = b.shape[1] if b_kmajor else b.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    d = _abi.GemmF32Desc()
+    d.A, d.lda, d.B, d.ldb, d.C, d.ldc = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), N
+    d.M, d.N, d.K = M, N, K
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.residual = residual.data_ptr() if residual is not None else None
+    d.ldr = residual.stride(0) if residual is not None else 0
+    d.act, d.alpha, d.b_kmajor = act, alpha, int(b_kmajor)
+    be.check(be.lib.vdk_gemm_f32_nt(C.byref(d), be.stream()), "vdk_gemm_f32_nt")
+    return out
+
+
+def softmax_rows_f32(x: torch.Tensor, cols: int, scale: float = 1.0, backend=None) -> torch.Tensor:
+    be = _be(backend)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+    be.check(be.lib.vdk_softmax_rows_f32(be.ptr(x), x.shape[1], x.shape[0], cols, scale, be.stream()), "vdk_softmax_rows_f32")
+    return x

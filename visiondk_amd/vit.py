@@ -154,6 +154,26 @@ class VitEngine:
                                         be.ptr(self._logits), be.stream()), "vdk_vit_forward")
         return self._logits
 
+    def forward_precise(self, x: torch.Tensor) -> torch.Tensor:
+        """Evaluation forward with every contraction on the fp32 MFMA (vdk_vit_forward_f32): logits f32 [B, Cp] / tokens f32 [B*N, D] within
+        ~1e-6 of the reference's PyTorch-CPU fp32 path.  Reads the fp32 master weights; keeps nothing for a backward."""
+        s = self.spec
+        if x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (s.in_chans, s.img_size, s.img_size):
+            raise ValueError(f"expected float32 [B, {s.in_chans}, {s.img_size}, {s.img_size}], got {tuple(x.shape)} {x.dtype}")
+        x = x.contiguous()
+        B = x.shape[0]
+        cfg = self._cfg(B)
+        be = self.be
+        need = C.c_size_t(0)
+        be.check(be.lib.vdk_vit_workspace_f32_bytes(C.byref(cfg), C.byref(need)), "vdk_vit_workspace_f32_bytes")
+        if getattr(self, "_ws32", None) is None or self._ws32.numel() < need.value:
+            self._ws32 = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        shape = (B, self.cp) if self.cp else (B * self.tokens, s.dim)
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        be.check(be.lib.vdk_vit_forward_f32(C.byref(cfg), be.ptr(x), be.ptr(self.params), be.ptr(self._ws32), self._ws32.numel(), be.ptr(out), be.stream()),
+                 "vdk_vit_forward_f32")
+        return out
+
     def backward(self, dlogits_bf16: torch.Tensor, on_ready: Optional[Callable[[int, int], None]] = None) -> torch.Tensor:
         """dlogits bf16 [B, Cp] (feature mode: d tokens f32 [B*N, D]) -> self.grads (flat fp32, overwritten).  Needs the
         workspace of the matching forward."""
@@ -295,6 +315,16 @@ class VisionTransformer(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return _VitFunction.apply(x, self, *[p for _, p in self._plist])
+
+    @torch.no_grad()
+    def forward_precise(self, x: torch.Tensor) -> torch.Tensor:
+        """`model(x)` for evaluation with fp32-MFMA contractions (no autograd): logits [B, C] or, in feature mode, tokens [B, N, D]"""
+        eng = self.engine
+        self._sync_flat()
+        out = eng.forward_precise(x)
+        if eng.cp == 0:
+            return out.view(x.shape[0], eng.tokens, eng.spec.dim)
+        return out[:, :eng.spec.num_classes]
 
 
 def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, device=None, backend=None, img_size=None,
