@@ -15,7 +15,8 @@
 
 #define DW_T 8          // output tile edge
 #define DW_H (DW_T + 6)  // input tile edge (halo 3)
-#define DW_CC 64        // channels per workgroup
+#define DW_CC 64        // channels per workgroup (weight gradient: one lane per channel)
+#define DWF_CC 64       // channels per workgroup of the forward / input-gradient kernel (32 measured no better: the kernel is bound by its global -> LDS staging phase, not by occupancy)
 
 // ------------------------------------------------------------------------------------ K6 forward / input gradient
 // out[b,y,x,c] = bias[c] + res[b,y,x,c] + sum_{i,j} wt[(flip ? 48 - (7i+j) : 7i+j)][c] * in[b, y+i-3, x+j-3, c]   (zero padding)
@@ -23,32 +24,32 @@
 // grid: (tiles_x * tiles_y * B, ceil(C / 64)); TW * 16 threads = TW columns x 16 channel quads; a thread owns a TH-row output strip of
 // one column and one channel quad: for every horizontal tap it reads the TH + 6 inputs of its column once and feeds 7 x TH FMAs.
 template <int TH, int TW>
-__global__ __launch_bounds__(TW * 16) void dwconv7_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
+__global__ __launch_bounds__(TW * (DWF_CC / 4)) void dwconv7_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
                                                           const float* res, float* out /* may alias res */, bf16_t* __restrict__ outb, int B, int H,
                                                           int W, int C, int flip) {
-  constexpr int IH = TH + 6, IW = TW + 6, NT = TW * 16;
-  __shared__ __attribute__((aligned(16))) float xs[IH * IW * DW_CC];
-  __shared__ __attribute__((aligned(16))) float ws[49 * DW_CC];            // 12 544 B
+  constexpr int IH = TH + 6, IW = TW + 6, NT = TW * (DWF_CC / 4);
+  __shared__ __attribute__((aligned(16))) float xs[IH * IW * DWF_CC];
+  __shared__ __attribute__((aligned(16))) float ws[49 * DWF_CC];            // 12 544 B
   const int tid = threadIdx.x;
   const int tx_n = (W + TW - 1) / TW, ty_n = (H + TH - 1) / TH;
   const int tile = blockIdx.x % (tx_n * ty_n), b = blockIdx.x / (tx_n * ty_n);
   const int y0 = (tile / tx_n) * TH, x0 = (tile % tx_n) * TW;
-  const int c0 = blockIdx.y * DW_CC;
-  for (int i = tid; i < IH * IW * (DW_CC / 4); i += NT) {
-    const int cq = i & 15, p = i >> 4, py = p / IW, px = p % IW;
+  const int c0 = blockIdx.y * DWF_CC;
+  for (int i = tid; i < IH * IW * (DWF_CC / 4); i += NT) {
+    const int cq = i % (DWF_CC / 4), p = i / (DWF_CC / 4), py = p / IW, px = p % IW;
     const int y = y0 + py - 3, x = x0 + px - 3, c = c0 + cq * 4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (y >= 0 && y < H && x >= 0 && x < W && c < C) v = *(const f32x4*)(in + (((long)b * H + y) * W + x) * C + c);
-    *(f32x4*)(xs + p * DW_CC + cq * 4) = v;
+    *(f32x4*)(xs + p * DWF_CC + cq * 4) = v;
   }
-  for (int i = tid; i < 49 * (DW_CC / 4); i += NT) {
-    const int cq = i & 15, t = i >> 4, c = c0 + cq * 4;
+  for (int i = tid; i < 49 * (DWF_CC / 4); i += NT) {
+    const int cq = i % (DWF_CC / 4), t = i / (DWF_CC / 4), c = c0 + cq * 4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (c < C) v = *(const f32x4*)(wt + (long)(flip ? 48 - t : t) * C + c);
-    *(f32x4*)(ws + t * DW_CC + cq * 4) = v;
+    *(f32x4*)(ws + t * DWF_CC + cq * 4) = v;
   }
   __syncthreads();
-  const int cq = tid & 15, col = tid >> 4, c = c0 + cq * 4;
+  const int cq = tid % (DWF_CC / 4), col = tid / (DWF_CC / 4), c = c0 + cq * 4;
   f32x4 acc[TH];
   {
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
@@ -60,10 +61,10 @@ __global__ __launch_bounds__(TW * 16) void dwconv7_kernel(const float* __restric
   for (int j = 0; j < 7; ++j) {
     f32x4 wj[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) wj[i] = *(const f32x4*)(ws + (i * 7 + j) * DW_CC + cq * 4);
+    for (int i = 0; i < 7; ++i) wj[i] = *(const f32x4*)(ws + (i * 7 + j) * DWF_CC + cq * 4);
 #pragma unroll
     for (int r = 0; r < IH; ++r) {
-      const f32x4 v = *(const f32x4*)(xs + (r * IW + col + j) * DW_CC + cq * 4);
+      const f32x4 v = *(const f32x4*)(xs + (r * IW + col + j) * DWF_CC + cq * 4);
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         const int o = r - i;
@@ -235,9 +236,9 @@ extern "C" {
 int vdk_dwconv7_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out, void* out_bf16, int32_t B, int32_t H, int32_t W,
                     int32_t C, int32_t flip, void* stream) {
   if (!in || !wt || (!out && !out_bf16) || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return vdk_fail(VDK_EINVAL, "vdk_dwconv7_fwd: bad argument (C % 4 == 0)");
-  const unsigned cy = (unsigned)((C + DW_CC - 1) / DW_CC);
+  const unsigned cy = (unsigned)((C + DWF_CC - 1) / DWF_CC);
 #define DW_LAUNCH(TH, TW)                                                                                                                          \
-  hipLaunchKernelGGL((dwconv7_kernel<TH, TW>), dim3((unsigned)(((W + TW - 1) / TW) * ((H + TH - 1) / TH)) * (unsigned)B, cy), dim3(TW * 16), 0,       \
+  hipLaunchKernelGGL((dwconv7_kernel<TH, TW>), dim3((unsigned)(((W + TW - 1) / TW) * ((H + TH - 1) / TH)) * (unsigned)B, cy), dim3(TW * (DWF_CC / 4)), 0, \
                      (hipStream_t)stream, in, wt, bias, res, out, (bf16_t*)out_bf16, (int)B, (int)H, (int)W, (int)C, (int)flip)
   if (H % 7 == 0 && W % 14 == 0) DW_LAUNCH(7, 14);
   else if (H % 7 == 0 && W % 7 == 0) DW_LAUNCH(7, 7);
