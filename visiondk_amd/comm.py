@@ -17,7 +17,7 @@ import torch.distributed as dist
 
 
 class GradAllReduce:
-    def __init__(self, group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 64 << 20):
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 32 << 20):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
