@@ -79,6 +79,13 @@ int vdk_cbir_merge_topk(const float* scores, const int64_t* idx, int32_t S, int6
  *   fwd: A = x, B = W[out,in];  dgrad: A = dy, B = W^T[in,out];  wgrad: A = dy^T, B = x^T (split-K).
  * epilogue order: *alpha, +bias[N] (f32), act, +residual[M,N] (f32), store as c_dtype.
  * K, N, lda, ldb, ldc, ldaux % 8 == 0.  splitk > 1 needs ws of vdk_gemm_splitk_workspace_bytes(). */
+/* Implicit-GEMM convolution (im2col-free): when VdkGemmDesc.conv is set, A is an NHWC bf16 tensor [B, H, W, Cin] gathered on the fly.  GEMM row
+ * m = (b, oy, ox) over the OH x OW row grid, GEMM column k = (ky*KW + kx)*Cin + c, so B must hold the weight as [N][KH*KW*Cin] in that order
+ * (vdk_conv_weight_prep).  transposed = 0: forward conv (source pixel oy*stride + ky - pad); transposed = 1: the input gradient of that conv
+ * (rows = input pixels, A = dY [B, H, W, Cin=Cout], source pixel (oy + pad - ky)/stride when it divides).  Cin % 8 == 0; K == KH*KW*Cin. */
+typedef struct VdkConvGeom {
+  int32_t Cin, H, W, OH, OW, KH, KW, stride, pad, transposed;
+} VdkConvGeom;
 typedef struct VdkGemmDesc {
   const void* A; int64_t lda;
   const void* B; int64_t ldb;
@@ -98,6 +105,7 @@ typedef struct VdkGemmDesc {
   int32_t trans;           /* 0: C = A[M,K] . B[N,K]^T.  1: TN, A is [K, M] and B is [K, N] row-major, C = A^T . B (wgrad straight from
                               dY[t][out], X[t][in]); needs K and the split size % 64 == 0, M % 8 == 0, lda/ldb % 8 == 0 */
   int32_t a_row_group;     /* trans=1 only, > 0: A's k-row t lives at physical row t + t/a_row_group + 1 (token buffer minus cls rows) */
+  const VdkConvGeom* conv; /* NULL: dense A.  else: implicit-GEMM convolution operand (lda ignored) */
 } VdkGemmDesc;
 int vdk_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t splitk, size_t* bytes);
 int vdk_gemm_bf16_nt(const VdkGemmDesc* d, void* ws, size_t ws_bytes, void* stream);
@@ -307,6 +315,32 @@ typedef struct VdkMarginHead {
   float margin_am;     /* arcface only */
   float mv_weight;     /* mv only */
 } VdkMarginHead;
+/* ---- BatchNorm-based CNN pieces (timm ResNet BasicBlock family, `timm-resnet18` = BASELINE.json configs[0]) -------------------------
+ * Convolutions run as implicit GEMMs (VdkGemmDesc.conv); these are the layouts and the non-GEMM layers around them.
+ * vdk_conv_weight_prep: w f32 [Co][Ci][KH][KW] -> wf bf16 [Co][KH*KW*Cip] (forward operand, ci padded to Cip % 8 == 0 with zeros) and, if wd != NULL,
+ * wd bf16 [Cip][KH*KW*Co] (input-gradient operand); vdk_conv_wgrad_unpermute: dWp f32 [Co][KH*KW*Cip] -> dW f32 [Co][Ci][KH][KW]. */
+int vdk_conv_weight_prep(const float* w, void* wf, void* wd, int32_t Co, int32_t Ci, int32_t Cip, int32_t KH, int32_t KW, void* stream);
+int vdk_conv_wgrad_unpermute(const float* dwp, float* dw, int32_t Co, int32_t Ci, int32_t Cip, int32_t KH, int32_t KW, void* stream);
+/* image f32 NCHW -> bf16 NHWC with the channels zero-padded to Cp (the 7x7 stem becomes an ordinary implicit conv with Cin = 8) */
+int vdk_nchw_to_nhwc_bf16(const float* x, void* out, int32_t B, int32_t C, int32_t H, int32_t W, int32_t Cp, void* stream);
+/* explicit im2col (bf16 NHWC -> [B*OH*OW][KH*KW*C]); used only for the weight gradient (TN GEMM dY^T . col) */
+int vdk_im2col_bf16(const void* in, void* col, int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                    void* stream);
+/* nn.BatchNorm2d on NHWC rows x f32 [R, C] fused with the BasicBlock tail: out = [relu](bn(x) [+ res]) as bf16 and / or f32; res f32 or bf16.
+ * Backward (training mode): dout f32 = gradient of out, out_bf16 = out (ReLU mask, NULL = no ReLU) -> dy_bf16 (gradient of x, the conv GEMMs' operand),
+ * dres f32 (gradient of res = masked dout, optional), dgamma, dbeta. */
+int vdk_bn_rows_workspace_bytes(int64_t R, int32_t C, size_t* bytes);
+int vdk_bn_act_fwd(const float* x, int64_t R, int32_t C, const float* gamma, const float* beta, float eps, float momentum, int32_t training, float* running_mean,
+                   float* running_var, const float* res_f32, const void* res_bf16, int32_t relu, void* out_bf16, float* out_f32, float* save_mean, float* save_invstd,
+                   void* ws, size_t ws_bytes, void* stream);
+int vdk_bn_act_bwd(const float* x, const float* dout, const void* out_bf16, int64_t R, int32_t C, const float* gamma, const float* save_mean, const float* save_invstd,
+                   void* dy_bf16, float* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+/* nn.MaxPool2d(3, 2, 1) on bf16 NHWC (backward routes to the FIRST maximum in (ky, kx) order, like torch) and global average pooling */
+int vdk_maxpool3s2_fwd(const void* in, void* out, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+int vdk_maxpool3s2_bwd(const void* in, const float* dout, float* din, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+int vdk_avgpool_fwd(const void* in, void* out, int32_t B, int32_t Bp, int32_t HW, int32_t C, void* stream);
+int vdk_avgpool_bwd(const void* dfeat, int64_t ld, float* dout, int32_t B, int32_t HW, int32_t C, void* stream);
+
 /* ---- native ConvNeXt engine: timm ConvNeXt in feature mode (num_classes=0, global_pool='') over flat buffers --------------------
  * Replaces `self.model(x)` of TimmWrapper.forward (models/faceX/backbone/timm_wrapper.py:16-21,51) and its backward for the CNN
  * backbones of the face / CBIR path (`convnext_base`, configs/faceX/cbir.yaml:4-8).  Semantics restated from timm 0.9.16 (not vendored;

@@ -1,0 +1,74 @@
+"""TEST INFRASTRUCTURE: plain-torch fp32 restatement of timm's ResNet (BasicBlock family) — BASELINE.json configs[0] is "ResNet-18 ICT on
+toy-multi-cls.csv" (`timm-resnet18` through models/classifier/classify_model.py:49-54).  timm==0.9.16 is un-vendored and not installable here; the
+architecture below is the published one (it equals torchvision's) and tests/test_oracle_resnet.py pins it against the independent
+`transformers.ResNetModel` through a weight map.  PARITY PINNING: the reference has no tests or golden vectors for this path.
+
+timm 0.9.16 `resnet18` as restated (state_dict keys equal timm's):
+  * conv1 = Conv2d(in_chans, 64, 7, stride 2, padding 3, bias=False); bn1 = BatchNorm2d(64) (eps 1e-5, momentum 0.1); act1 = ReLU
+  * maxpool = MaxPool2d(3, stride 2, padding 1)
+  * layer1..4, 2 BasicBlocks each, widths (64, 128, 256, 512), first block of layers 2-4 has stride 2 and
+    downsample = Sequential(Conv2d(cin, cout, 1, stride 2, bias=False), BatchNorm2d(cout))
+  * BasicBlock(x): shortcut = x (or downsample(x)); x = act1(bn1(conv1(x))) [3x3, stride, padding 1, no bias]; x = bn2(conv2(x)) [3x3, stride 1];
+    x = act2(x + shortcut)
+  * global_pool = adaptive average pool -> flatten; fc = Linear(512, num_classes)
+The reference's re-init (classify_model.py:70-81) then overwrites Conv2d/Linear weights with N(0, 0.02), Linear bias 0, BatchNorm (1, 0).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, stride=1, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        shortcut = x if self.downsample is None else self.downsample(x)
+        x = F.relu(self.bn1(self.conv1(x)))
+        x = self.bn2(self.conv2(x))
+        return F.relu(x + shortcut)
+
+
+class ResNetRef(nn.Module):
+    def __init__(self, num_classes=1000, in_chans=3, widths=(64, 128, 256, 512), depths=(2, 2, 2, 2)):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_chans, widths[0], 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(widths[0])
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        cin = widths[0]
+        for i, (w, d) in enumerate(zip(widths, depths)):
+            blocks = []
+            for j in range(d):
+                blocks.append(BasicBlock(cin, w, 2 if (j == 0 and i > 0) else 1))
+                cin = w
+            setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
+        self.fc = nn.Linear(widths[-1], num_classes)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        """classify_model.py:70-81"""
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                nn.init.normal_(m.weight, mean=0, std=0.02)
+                if getattr(m, "bias", None) is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight); nn.init.zeros_(m.bias)
+
+    def forward_features(self, x):
+        x = self.maxpool(F.relu(self.bn1(self.conv1(x))))
+        for i in range(1, 5):
+            x = getattr(self, f"layer{i}")(x)
+        return x
+
+    def forward(self, x):
+        return self.fc(self.forward_features(x).mean((-2, -1)))

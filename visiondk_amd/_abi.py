@@ -21,7 +21,12 @@ class GemmDesc(C.Structure):
     _fields_ = [("A", P), ("lda", I64), ("B", P), ("ldb", I64), ("C", P), ("ldc", I64),
                 ("M", I32), ("N", I32), ("K", I32), ("c_dtype", I32),
                 ("bias", P), ("residual", P), ("ldr", I64), ("act", I32), ("aux", P), ("ldaux", I64),
-                ("alpha", F32), ("splitk", I32), ("row_group", I32), ("trans", I32), ("a_row_group", I32)]
+                ("alpha", F32), ("splitk", I32), ("row_group", I32), ("trans", I32), ("a_row_group", I32), ("conv", P)]
+
+
+class ConvGeom(C.Structure):
+    """VdkConvGeom of include/visiondk.h"""
+    _fields_ = [("Cin", I32), ("H", I32), ("W", I32), ("OH", I32), ("OW", I32), ("KH", I32), ("KW", I32), ("stride", I32), ("pad", I32), ("transposed", I32)]
 
 
 class VitConfig(C.Structure):
@@ -124,6 +129,17 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_vit_refresh_weights": (C.c_int, [C.POINTER(VitConfig), P, P, P, I32, P]),
     "vdk_vit_forward": (C.c_int, [C.POINTER(VitConfig), P, P, P, P, SZ, P, P]),
     "vdk_vit_backward": (C.c_int, [C.POINTER(VitConfig), P, P, P, P, P, SZ, P, P, P, P, P]),
+    "vdk_conv_weight_prep": (C.c_int, [P, P, P, I32, I32, I32, I32, I32, P]),
+    "vdk_conv_wgrad_unpermute": (C.c_int, [P, P, I32, I32, I32, I32, I32, P]),
+    "vdk_nchw_to_nhwc_bf16": (C.c_int, [P, P, I32, I32, I32, I32, I32, P]),
+    "vdk_im2col_bf16": (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, P]),
+    "vdk_bn_rows_workspace_bytes": (C.c_int, [I64, I32, PSZ]),
+    "vdk_bn_act_fwd": (C.c_int, [P, I64, I32, P, P, C.c_float, C.c_float, I32, P, P, P, P, I32, P, P, P, P, P, SZ, P]),
+    "vdk_bn_act_bwd": (C.c_int, [P, P, P, I64, I32, P, P, P, P, P, P, P, P, SZ, P]),
+    "vdk_maxpool3s2_fwd": (C.c_int, [P, P, I32, I32, I32, I32, P]),
+    "vdk_maxpool3s2_bwd": (C.c_int, [P, P, P, I32, I32, I32, I32, P]),
+    "vdk_avgpool_fwd": (C.c_int, [P, P, I32, I32, I32, I32, P]),
+    "vdk_avgpool_bwd": (C.c_int, [P, I64, P, I32, I32, I32, P]),
     "vdk_vit_workspace_f32_bytes": (C.c_int, [C.POINTER(VitConfig), PSZ]),
     "vdk_vit_forward_f32": (C.c_int, [C.POINTER(VitConfig), P, P, P, SZ, P, P]),
     "vdk_convnext_workspace_f32_bytes": (C.c_int, [C.POINTER(ConvNextConfig), PSZ]),

@@ -41,6 +41,41 @@ __device__ __forceinline__ void g_store_tile(const u32x4 (&r)[4], bf16_t* lds) {
   }
 }
 
+// ---- implicit-GEMM convolution: the A tile is gathered from an NHWC tensor, no im2col buffer --------------------------------------
+// GEMM row m = (b, oy, ox) of the cOH x cOW row grid, GEMM column k = (ky, kx, c) with c fastest (Cin % 8 == 0, so a 16-byte chunk stays inside one
+// tap).  Forward gather: source pixel (oy*stride + ky - pad, ox*stride + kx - pad) of the cH x cW tensor.  Transposed gather (input gradient of the
+// same convolution, rows = input pixels, A = dY): source pixel ((oy + pad - ky) / stride, (ox + pad - kx) / stride) when both divide.  Out of range -> 0.
+struct ConvRows { int b[4], oy[4], ox[4]; };
+__device__ __forceinline__ void g_conv_rows(ConvRows& cr, const GemmParams& p, int row0) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int id = threadIdx.x + 256 * j, m = row0 + (id >> 3);
+    const int hw = p.cOH * p.cOW, b = m / hw, rem = m - b * hw, oy = rem / p.cOW;
+    cr.b[j] = m < p.M ? b : -1; cr.oy[j] = oy; cr.ox[j] = rem - oy * p.cOW;
+  }
+}
+__device__ __forceinline__ void g_load_tile_conv(u32x4 (&r)[4], const GemmParams& p, const ConvRows& cr, int k0, int kend) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int id = threadIdx.x + 256 * j, ch = id & 7, k = k0 + ch * 8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (cr.b[j] >= 0 && k < kend) {
+      const int tap = k / p.cCin, c = k - tap * p.cCin, ky = tap / p.cKW, kx = tap - ky * p.cKW;
+      int y, x; bool ok;
+      if (!p.ctrans) {
+        y = cr.oy[j] * p.cstride + ky - p.cpad; x = cr.ox[j] * p.cstride + kx - p.cpad;
+        ok = y >= 0 && y < p.cH && x >= 0 && x < p.cW;
+      } else {
+        const int ty = cr.oy[j] + p.cpad - ky, tx = cr.ox[j] + p.cpad - kx;
+        y = ty / p.cstride; x = tx / p.cstride;
+        ok = ty >= 0 && tx >= 0 && y * p.cstride == ty && x * p.cstride == tx && y < p.cH && x < p.cW;
+      }
+      if (ok) v = *(const u32x4*)(p.A + (((long)cr.b[j] * p.cH + y) * p.cW + x) * p.cCin + c);
+    }
+    r[j] = v;
+  }
+}
+
 // ---- shared fused epilogue for one 8-wide row chunk: v[8] = raw accumulators of C[mi][n..n+7] -----------------------
 __device__ __forceinline__ void g_epilogue_store8(const GemmParams& p, long mi, int n, float (&v)[8], int z) {
     // token-row remap (patch embedding -> token buffer): output row skips one cls slot per group and the
@@ -93,6 +128,7 @@ __device__ __forceinline__ void g_epilogue_store8(const GemmParams& p, long mi, 
     }
 }
 
+template <bool CONV>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmParams p) {
   // 2 buffers x (A 128 rows + B 128 rows) x 144 B = 73,728 B; reused as the fp32 epilogue tile (67,584 B)
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 128 * G_PITCH * 2];
@@ -128,8 +164,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   u32x4 ra[4], rb[4];
+  ConvRows cr;
+  if (CONV) g_conv_rows(cr, p, m0);
   if (nk > 0) {
-    g_load_tile(ra, p.A, p.lda, m0, p.M, kbeg, kend);
+    if (CONV) g_load_tile_conv(ra, p, cr, kbeg, kend); else g_load_tile(ra, p.A, p.lda, m0, p.M, kbeg, kend);
     g_load_tile(rb, p.B, p.ldb, n0, p.N, kbeg, kend);
     g_store_tile(ra, As);
     g_store_tile(rb, Bs);
@@ -138,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmParams p) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      g_load_tile(ra, p.A, p.lda, m0, p.M, kbeg + (kt + 1) * G_BK, kend);
+      if (CONV) g_load_tile_conv(ra, p, cr, kbeg + (kt + 1) * G_BK, kend); else g_load_tile(ra, p.A, p.lda, m0, p.M, kbeg + (kt + 1) * G_BK, kend);
       g_load_tile(rb, p.B, p.ldb, n0, p.N, kbeg + (kt + 1) * G_BK, kend);
     }
     const bf16_t* a_base = As + cur * 128 * G_PITCH + (wm * 64 + l31) * G_PITCH + hi * 8;
@@ -639,8 +677,14 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   hipStream_t stream = (hipStream_t)stream_;
   if (!d || !d->A || !d->B || !d->C) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: null pointer");
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: empty problem");
-  if ((d->K & 7) || (d->N & 7) || (d->lda & 7) || (d->ldb & 7) || (d->ldc & 7))
+  if ((d->K & 7) || (d->N & 7) || (!d->conv && (d->lda & 7)) || (d->ldb & 7) || (d->ldc & 7))
     return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: K, N, lda, ldb, ldc must be multiples of 8");
+  if (d->conv) {
+    const VdkConvGeom* c = d->conv;
+    if (d->trans || c->Cin <= 0 || (c->Cin & 7) || c->KH <= 0 || c->KW <= 0 || c->stride <= 0 || c->pad < 0 || c->OH <= 0 || c->OW <= 0 || c->H <= 0 || c->W <= 0 ||
+        d->K != c->KH * c->KW * c->Cin || (d->M % (c->OH * c->OW)))
+      return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad convolution geometry (Cin % 8 == 0, K == KH*KW*Cin, M == B*OH*OW)");
+  }
   if (d->c_dtype != VDK_BF16 && d->c_dtype != VDK_F32) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad c_dtype");
   if ((d->act == VDK_ACT_DGELU && !d->aux) || (d->aux && (d->ldaux & 7))) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad aux");
   int splitk = d->splitk < 1 ? 1 : d->splitk;
@@ -651,6 +695,11 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   p.c_dtype = d->c_dtype; p.bias = (const float*)d->bias; p.residual = (const float*)d->residual; p.ldr = d->ldr;
   p.act = d->act; p.aux = (bf16_t*)d->aux; p.ldaux = d->ldaux; p.alpha = d->alpha; p.row_group = d->row_group; p.a_row_group = d->a_row_group;
   p.splitk = splitk; p.slabs = nullptr; p.dbg = (unsigned long long*)g_dbg_ptr;
+  p.conv_on = d->conv != nullptr;
+  if (d->conv) {
+    const VdkConvGeom* c = d->conv;
+    p.cCin = c->Cin; p.cH = c->H; p.cW = c->W; p.cOH = c->OH; p.cOW = c->OW; p.cKH = c->KH; p.cKW = c->KW; p.cstride = c->stride; p.cpad = c->pad; p.ctrans = c->transposed;
+  }
   int kps = d->K;
   if (splitk > 1) {
     if (d->bias || d->residual || d->act != VDK_ACT_NONE || d->row_group > 0) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: split-K excludes fused epilogues");
@@ -670,7 +719,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   if (prof) (void)hipEventRecord(g_prof_ev[g_prof_used], stream);
   // big problems go to the 256x256 LDS-DMA kernel (needs whole 64-wide k-tiles per split and >= 1 full wave of tiles)
   const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * splitk;
-  const bool big = g_force_kernel == 2 || (g_force_kernel == 0 && (d->K % 64 == 0) && (kps % 64 == 0) && tiles256 >= 128 && d->M >= 256 && d->N >= 256);
+  const bool big = !d->conv && (g_force_kernel == 2 || (g_force_kernel == 0 && (d->K % 64 == 0) && (kps % 64 == 0) && tiles256 >= 128 && d->M >= 256 && d->N >= 256));
   // compile-time epilogue variant (the common ViT forms); anything else takes the run-time-flag path
   int E = E_GENERIC;
   {
@@ -709,8 +758,10 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
     }
   }
 #undef LAUNCH256
+  else if (d->conv)
+    hipLaunchKernelGGL(gemm_bf16_nt_kernel<true>, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256), 0, stream, p);
   else
-  hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(gemm_bf16_nt_kernel<false>, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256), 0, stream, p);
   if (prof) {   // the GEMM kernel only (the split-K combine is a separate, HBM-bound kernel)
     (void)hipEventRecord(g_prof_ev[g_prof_used + 1], stream);
     g_prof_flops.push_back(2.0 * d->M * d->N * d->K);

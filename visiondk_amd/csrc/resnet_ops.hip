@@ -1,0 +1,343 @@
+// resnet_ops.hip — what a BatchNorm-based CNN (timm ResNet BasicBlock family: `timm-resnet18`, BASELINE.json configs[0], built through
+// /root/reference models/classifier/classify_model.py:49-54) needs besides the implicit-GEMM convolution of csrc/gemm.hip (VdkConvGeom):
+//   * weight layouts for the implicit GEMM: [Co][(ky,kx,ci)] forward, [Ci][(ky,kx,co)] input gradient, and the gradient back to [Co][Ci][KH][KW];
+//   * NCHW f32 image -> NHWC bf16 with the channel count padded to a multiple of 8 (so the 7x7 stem is an ordinary implicit conv);
+//   * explicit bf16 im2col, used ONLY for the weight gradient (contraction over pixels: TN GEMM dY^T . col);
+//   * BatchNorm2d on NHWC rows with many samples and few channels (64 ... 512): slice-parallel statistics, fused normalise + residual + ReLU -> bf16,
+//     and the matching backward (ReLU mask from the saved output, dgamma / dbeta, bf16 dY for the conv GEMMs, f32 shortcut gradient);
+//   * MaxPool2d(3, 2, 1) forward / backward with torch's first-maximum tie rule, global average pool forward / backward.
+#include <hip/hip_runtime.h>
+#include "vdk_device.h"
+#include "vdk_host.h"
+
+// ------------------------------------------------------------------------------------ weight layouts
+// w f32 [Co][Ci][KH][KW] -> wf bf16 [Co][KH*KW*Cip] (k = (ky*KW + kx)*Cip + ci, ci >= Ci zero) and wd bf16 [Cip][KH*KW*Co] (k = (ky*KW + kx)*Co + co)
+__global__ __launch_bounds__(256) void conv_weight_prep_kernel(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t* __restrict__ wd, int Co, int Ci, int Cip,
+                                                               int KH, int KW) {
+  const long n = (long)Co * Cip * KH * KW;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int ci = (int)(i % Cip);
+  long r = i / Cip;
+  const int t = (int)(r % (KH * KW)), co = (int)(r / (KH * KW));
+  const float v = ci < Ci ? w[((long)co * Ci + ci) * KH * KW + t] : 0.f;
+  const bf16_t b = f2bf(v);
+  wf[i] = b;
+  if (wd) wd[((long)ci * KH * KW + t) * Co + co] = b;
+}
+// dwp f32 [Co][KH*KW*Cip] -> dw f32 [Co][Ci][KH][KW]
+__global__ __launch_bounds__(256) void conv_wgrad_unpermute_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Co, int Ci, int Cip, int KH, int KW) {
+  const long n = (long)Co * Ci * KH * KW;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int t = (int)(i % (KH * KW));
+  long r = i / (KH * KW);
+  const int ci = (int)(r % Ci), co = (int)(r / Ci);
+  dw[i] = dwp[((long)co * KH * KW + t) * Cip + ci];
+}
+// x f32 [B][C][H][W] -> out bf16 [B][H][W][Cp] (channels >= C zero)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int B, int C, int H, int W, int Cp) {
+  const long n = (long)B * H * W * Cp;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % Cp);
+  const long p = i / Cp;
+  const int xx = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((long)W * H));
+  out[i] = f2bf(c < C ? x[(((long)b * C + c) * H + y) * W + xx] : 0.f);
+}
+// explicit im2col for the weight gradient: col bf16 [B*OH*OW][KH*KW*C] (k = (ky*KW + kx)*C + c) from in bf16 [B][H][W][C]; 16-byte chunks
+__global__ __launch_bounds__(256) void im2col_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ col, int B, int H, int W, int C, int OH, int OW, int KH,
+                                                          int KW, int stride, int pad) {
+  const int c8n = C / 8;
+  const long n = (long)B * OH * OW * KH * KW * c8n;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c8 = (int)(i % c8n);
+  long r = i / c8n;
+  const int t = (int)(r % (KH * KW));
+  const long m = r / (KH * KW);
+  const int ox = (int)(m % OW), oy = (int)((m / OW) % OH), b = (int)(m / ((long)OW * OH));
+  const int ky = t / KW, kx = t % KW, y = oy * stride + ky - pad, x = ox * stride + kx - pad;
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (y >= 0 && y < H && x >= 0 && x < W) v = *(const u32x4*)(in + (((long)b * H + y) * W + x) * C + c8 * 8);
+  *(u32x4*)(col + (m * KH * KW + t) * C + c8 * 8) = v;
+}
+
+// ------------------------------------------------------------------------------------ BatchNorm2d on NHWC rows
+// statistics: grid (S slices, ceil(C / 64)); 512 threads = 64 columns x 8 row groups; a slice owns rows [s*rps, (s+1)*rps)
+// MODE 0: (sum x, sum x^2);  MODE 1 (backward): g = dout * (relu ? out > 0 : 1): (sum g, sum g * xhat)
+template <int MODE>
+__global__ __launch_bounds__(512) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dout, const bf16_t* __restrict__ outb,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd, long R, int C, long rps,
+                                                         float* __restrict__ part /*[S][2][C]*/) {
+  __shared__ float red[2][8][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.y * 64 + cl;
+  const long r0 = (long)blockIdx.x * rps;
+  long r1 = r0 + rps; if (r1 > R) r1 = R;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < C) {
+    const float mu = MODE ? mean[c] : 0.f, is = MODE ? invstd[c] : 0.f;
+    for (long r = r0 + rg; r < r1; r += 8) {
+      if (MODE == 0) { const float v = x[r * C + c]; a0 += v; a1 = fmaf(v, v, a1); }
+      else {
+        float g = dout[r * C + c];
+        if (outb && !(bf2f(outb[r * C + c]) > 0.f)) g = 0.f;
+        a0 += g; a1 = fmaf(g, (x[r * C + c] - mu) * is, a1);
+      }
+    }
+  }
+  red[0][rg][cl] = a0; red[1][rg][cl] = a1;
+  __syncthreads();
+  if (rg < 2 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[rg][i][cl];
+    part[((long)blockIdx.x * 2 + rg) * C + c] = t;
+  }
+}
+// forward finalize: mean / biased var -> invstd, running statistics (unbiased var); eval mode: running statistics
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ part, int S, long R, int C, float eps, float momentum, int training,
+                                                              float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ save_mean,
+                                                              float* __restrict__ save_invstd) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float mu, var;
+  if (training) {
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < S; ++i) { s += part[((long)i * 2) * C + c]; q += part[((long)i * 2 + 1) * C + c]; }
+    const double m = s / (double)R;
+    double v = q / (double)R - m * m; if (v < 0.0) v = 0.0;
+    mu = (float)m; var = (float)v;
+    if (rmean) rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mu;
+    if (rvar) rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (R > 1 ? (float)(v * (double)R / (double)(R - 1)) : var);
+  } else { mu = rmean[c]; var = rvar[c]; }
+  save_mean[c] = mu; save_invstd[c] = 1.0f / sqrtf(var + eps);
+}
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ part, int S, int C, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ sums /*[2][C]*/) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double sb = 0.0, sg = 0.0;
+  for (int i = 0; i < S; ++i) { sb += part[((long)i * 2) * C + c]; sg += part[((long)i * 2 + 1) * C + c]; }
+  dbeta[c] = (float)sb; dgamma[c] = (float)sg; sums[c] = (float)sb; sums[C + c] = (float)sg;
+}
+// y = gamma * (x - mean) * invstd + beta [+ res] [relu] -> bf16 (and / or f32); 4 channels per thread (C % 4 == 0)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, long n4, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ res_f32,
+                                                       const bf16_t* __restrict__ res_bf16, int relu, bf16_t* __restrict__ outb, float* __restrict__ outf) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)((i * 4) % C);
+  f32x4 v = *(const f32x4*)(x + i * 4);
+  const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c), mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu[e]) * (g[e] * is[e]) + b[e];
+  if (res_f32) { const f32x4 r = *(const f32x4*)(res_f32 + i * 4); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
+  if (res_bf16) { const u32x2 r = *(const u32x2*)(res_bf16 + i * 4); v[0] += bf_lo(r[0]); v[1] += bf_hi(r[0]); v[2] += bf_lo(r[1]); v[3] += bf_hi(r[1]); }
+  if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+  if (outb) *(u32x2*)(outb + i * 4) = (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+  if (outf) *(f32x4*)(outf + i * 4) = v;
+}
+// g = dout * mask;  dy = gamma * invstd / R * (R g - sum g - xhat * sum(g xhat)) -> bf16;  dres = g (f32, optional: the shortcut's gradient)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dout, const bf16_t* __restrict__ outb, long n4, int C,
+                                                           float Rf, const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ sums, bf16_t* __restrict__ dyb, float* __restrict__ dres) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)((i * 4) % C);
+  const f32x4 xv = *(const f32x4*)(x + i * 4);
+  f32x4 g = *(const f32x4*)(dout + i * 4);
+  if (outb) {
+    const u32x2 o = *(const u32x2*)(outb + i * 4);
+    if (!(bf_lo(o[0]) > 0.f)) g[0] = 0.f;
+    if (!(bf_hi(o[0]) > 0.f)) g[1] = 0.f;
+    if (!(bf_lo(o[1]) > 0.f)) g[2] = 0.f;
+    if (!(bf_hi(o[1]) > 0.f)) g[3] = 0.f;
+  }
+  const f32x4 ga = *(const f32x4*)(gamma + c), mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c);
+  const f32x4 sb = *(const f32x4*)(sums + c), sg = *(const f32x4*)(sums + C + c);
+  float d[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float xh = (xv[e] - mu[e]) * is[e];
+    d[e] = ga[e] * is[e] / Rf * (Rf * g[e] - sb[e] - xh * sg[e]);
+  }
+  *(u32x2*)(dyb + i * 4) = (u32x2){pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
+  if (dres) *(f32x4*)(dres + i * 4) = g;
+}
+
+// ------------------------------------------------------------------------------------ pooling
+// MaxPool2d(3, stride 2, padding 1) on NHWC bf16 (out-of-range taps are -inf, like torch)
+__global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int B, int H, int W, int C, int OH, int OW) {
+  const long n = (long)B * OH * OW * C;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const long p = i / C;
+  const int ox = (int)(p % OW), oy = (int)((p / OW) % OH), b = (int)(p / ((long)OW * OH));
+  float m = -3.0e38f;
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx) {
+      const int y = oy * 2 + ky - 1, x = ox * 2 + kx - 1;
+      if (y >= 0 && y < H && x >= 0 && x < W) m = fmaxf(m, bf2f(in[(((long)b * H + y) * W + x) * C + c]));
+    }
+  out[i] = f2bf(m);
+}
+// din[b,y,x,c] = sum over the (up to 4) windows containing (y,x) in which it is the FIRST maximum in (ky, kx) scan order (torch's argmax rule) of dout
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const bf16_t* __restrict__ in, const float* __restrict__ dout, float* __restrict__ din, int B, int H, int W,
+                                                             int C, int OH, int OW) {
+  const long n = (long)B * H * W * C;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const long p = i / C;
+  const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((long)W * H));
+  const float v = bf2f(in[i]);
+  float acc = 0.f;
+  for (int oy = (y + 1 - 2 + 1) / 2; oy <= (y + 1) / 2; ++oy) {     // windows with oy*2 - 1 <= y <= oy*2 + 1
+    if (oy < 0 || oy >= OH) continue;
+    for (int ox = (x + 1 - 2 + 1) / 2; ox <= (x + 1) / 2; ++ox) {
+      if (ox < 0 || ox >= OW) continue;
+      const int myk = (y - (oy * 2 - 1)) * 3 + (x - (ox * 2 - 1));
+      bool win = true;
+      for (int k = 0; k < 9 && win; ++k) {
+        const int yy = oy * 2 - 1 + k / 3, xx = ox * 2 - 1 + k % 3;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W || k == myk) continue;
+        const float o = bf2f(in[(((long)b * H + yy) * W + xx) * C + c]);
+        if (o > v || (o == v && k < myk)) win = false;
+      }
+      if (win) acc += dout[(((long)b * OH + oy) * OW + ox) * C + c];
+    }
+  }
+  din[i] = acc;
+}
+// global average pool: out bf16 [Bp][C] (rows >= B zero) = mean over HW of in bf16 [B][HW][C]
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int B, int Bp, int HW, int C) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)Bp * C) return;
+  const int c = (int)(i % C), b = (int)(i / C);
+  float s = 0.f;
+  if (b < B) for (int p = 0; p < HW; ++p) s += bf2f(in[((long)b * HW + p) * C + c]);
+  out[i] = f2bf(s / (float)HW);
+}
+// dout f32 [B*HW][C] = dfeat[b][c] / HW  (dfeat bf16 [B][ld])
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf16_t* __restrict__ dfeat, long ld, float* __restrict__ dout, int B, int HW, int C) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * HW * C) return;
+  const int c = (int)(i % C);
+  const int b = (int)(i / ((long)HW * C));
+  dout[i] = bf2f(dfeat[(long)b * ld + c]) / (float)HW;
+}
+
+static inline int bn_slices(long R, int C) {
+  long s = 1024 / ((C + 63) / 64);
+  if (s > (R + 255) / 256) s = (R + 255) / 256;
+  return (int)(s < 1 ? 1 : s);
+}
+
+extern "C" {
+
+int vdk_conv_weight_prep(const float* w, void* wf, void* wd, int32_t Co, int32_t Ci, int32_t Cip, int32_t KH, int32_t KW, void* stream) {
+  if (!w || !wf || Co <= 0 || Ci <= 0 || Cip < Ci || (Cip & 7) || KH <= 0 || KW <= 0) return vdk_fail(VDK_EINVAL, "vdk_conv_weight_prep: bad argument (Cip % 8 == 0)");
+  const long n = (long)Co * Cip * KH * KW;
+  hipLaunchKernelGGL(conv_weight_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wf, (bf16_t*)wd, (int)Co, (int)Ci, (int)Cip,
+                     (int)KH, (int)KW);
+  return vdk_check_launch("vdk_conv_weight_prep");
+}
+int vdk_conv_wgrad_unpermute(const float* dwp, float* dw, int32_t Co, int32_t Ci, int32_t Cip, int32_t KH, int32_t KW, void* stream) {
+  if (!dwp || !dw || Co <= 0 || Ci <= 0 || Cip < Ci || KH <= 0 || KW <= 0) return vdk_fail(VDK_EINVAL, "vdk_conv_wgrad_unpermute: bad argument");
+  const long n = (long)Co * Ci * KH * KW;
+  hipLaunchKernelGGL(conv_wgrad_unpermute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dwp, dw, (int)Co, (int)Ci, (int)Cip, (int)KH, (int)KW);
+  return vdk_check_launch("vdk_conv_wgrad_unpermute");
+}
+int vdk_nchw_to_nhwc_bf16(const float* x, void* out, int32_t B, int32_t C, int32_t H, int32_t W, int32_t Cp, void* stream) {
+  if (!x || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cp < C) return vdk_fail(VDK_EINVAL, "vdk_nchw_to_nhwc_bf16: bad argument");
+  const long n = (long)B * H * W * Cp;
+  hipLaunchKernelGGL(nchw_to_nhwc_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)out, (int)B, (int)C, (int)H, (int)W, (int)Cp);
+  return vdk_check_launch("vdk_nchw_to_nhwc_bf16");
+}
+int vdk_im2col_bf16(const void* in, void* col, int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                    void* stream) {
+  if (!in || !col || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || OH <= 0 || OW <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
+    return vdk_fail(VDK_EINVAL, "vdk_im2col_bf16: bad argument (C % 8 == 0)");
+  const long n = (long)B * OH * OW * KH * KW * (C / 8);
+  hipLaunchKernelGGL(im2col_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)col, (int)B, (int)H, (int)W, (int)C,
+                     (int)OH, (int)OW, (int)KH, (int)KW, (int)stride, (int)pad);
+  return vdk_check_launch("vdk_im2col_bf16");
+}
+
+int vdk_bn_rows_workspace_bytes(int64_t R, int32_t C, size_t* bytes) {
+  if (!bytes || R <= 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_bn_rows_workspace_bytes: bad argument");
+  *bytes = ((size_t)bn_slices(R, C) * 2 * C + 2 * (size_t)C) * 4;
+  return VDK_OK;
+}
+/* BatchNorm2d (+ residual, + ReLU) on NHWC rows: x f32 [R, C] -> out_bf16 and / or out_f32; training != 0: batch statistics (saved) and running update */
+int vdk_bn_act_fwd(const float* x, int64_t R, int32_t C, const float* gamma, const float* beta, float eps, float momentum, int32_t training, float* running_mean,
+                   float* running_var, const float* res_f32, const void* res_bf16, int32_t relu, void* out_bf16, float* out_f32, float* save_mean, float* save_invstd,
+                   void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !gamma || !beta || !save_mean || !save_invstd || (!out_bf16 && !out_f32) || R <= 0 || C <= 0 || (C & 3) || (!training && (!running_mean || !running_var)))
+    return vdk_fail(VDK_EINVAL, "vdk_bn_act_fwd: bad argument (C % 4 == 0)");
+  const int S = bn_slices(R, C);
+  if (!ws || ws_bytes < ((size_t)S * 2 * C + 2 * (size_t)C) * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_bn_act_fwd: workspace too small");
+  float* part = (float*)ws;
+  const long rps = (R + S - 1) / S;
+  if (training)
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3((unsigned)S, (unsigned)((C + 63) / 64)), dim3(512), 0, stream, x, (const float*)nullptr, (const bf16_t*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (long)R, (int)C, rps, part);
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, (const float*)part, S, (long)R, (int)C, eps, momentum, (int)training,
+                     running_mean, running_var, save_mean, save_invstd);
+  const long n4 = R * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, n4, (int)C, gamma, beta, (const float*)save_mean,
+                     (const float*)save_invstd, res_f32, (const bf16_t*)res_bf16, (int)relu, (bf16_t*)out_bf16, out_f32);
+  return vdk_check_launch("vdk_bn_act_fwd");
+}
+/* backward of the above (training mode): dout f32 = gradient of the block output; out_bf16 = that output (ReLU mask; NULL = no ReLU) */
+int vdk_bn_act_bwd(const float* x, const float* dout, const void* out_bf16, int64_t R, int32_t C, const float* gamma, const float* save_mean, const float* save_invstd,
+                   void* dy_bf16, float* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !dout || !gamma || !save_mean || !save_invstd || !dy_bf16 || !dgamma || !dbeta || R <= 0 || C <= 0 || (C & 3))
+    return vdk_fail(VDK_EINVAL, "vdk_bn_act_bwd: bad argument (C % 4 == 0)");
+  const int S = bn_slices(R, C);
+  if (!ws || ws_bytes < ((size_t)S * 2 * C + 2 * (size_t)C) * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_bn_act_bwd: workspace too small");
+  float* part = (float*)ws; float* sums = part + (size_t)S * 2 * C;
+  const long rps = (R + S - 1) / S;
+  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3((unsigned)S, (unsigned)((C + 63) / 64)), dim3(512), 0, stream, x, dout, (const bf16_t*)out_bf16, save_mean, save_invstd,
+                     (long)R, (int)C, rps, part);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, (const float*)part, S, (int)C, dgamma, dbeta, sums);
+  const long n4 = R * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, dout, (const bf16_t*)out_bf16, n4, (int)C, (float)R, gamma, save_mean,
+                     save_invstd, (const float*)sums, (bf16_t*)dy_bf16, dres);
+  return vdk_check_launch("vdk_bn_act_bwd");
+}
+
+int vdk_maxpool3s2_fwd(const void* in, void* out, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+  if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_maxpool3s2_fwd: bad argument");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const long n = (long)B * OH * OW * C;
+  hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, (int)B, (int)H, (int)W, (int)C,
+                     OH, OW);
+  return vdk_check_launch("vdk_maxpool3s2_fwd");
+}
+int vdk_maxpool3s2_bwd(const void* in, const float* dout, float* din, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+  if (!in || !dout || !din || B <= 0 || H <= 0 || W <= 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_maxpool3s2_bwd: bad argument");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const long n = (long)B * H * W * C;
+  hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, dout, din, (int)B, (int)H, (int)W, (int)C, OH,
+                     OW);
+  return vdk_check_launch("vdk_maxpool3s2_bwd");
+}
+int vdk_avgpool_fwd(const void* in, void* out, int32_t B, int32_t Bp, int32_t HW, int32_t C, void* stream) {
+  if (!in || !out || B <= 0 || Bp < B || HW <= 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_avgpool_fwd: bad argument");
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((unsigned)(((long)Bp * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, (int)B, (int)Bp, (int)HW,
+                     (int)C);
+  return vdk_check_launch("vdk_avgpool_fwd");
+}
+int vdk_avgpool_bwd(const void* dfeat, int64_t ld, float* dout, int32_t B, int32_t HW, int32_t C, void* stream) {
+  if (!dfeat || !dout || B <= 0 || HW <= 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_avgpool_bwd: bad argument");
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((unsigned)(((long)B * HW * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dfeat, (long)ld, dout, (int)B, (int)HW,
+                     (int)C);
+  return vdk_check_launch("vdk_avgpool_bwd");
+}
+
+}  // extern "C"

@@ -19,6 +19,8 @@ struct GemmParams {
   int a_row_group;
   int splitk; int k_per_split;
   float* slabs;
+  // implicit-GEMM convolution (conv_on): A is an NHWC tensor gathered on the fly, see VdkConvGeom
+  int conv_on, cCin, cH, cW, cOH, cOW, cKH, cKW, cstride, cpad, ctrans;
   unsigned long long* dbg;   // debug only: 4 cycle stamps per workgroup (start, operands landed, main loop done, end)
 };
 

@@ -404,3 +404,113 @@ def softmax_rows_f32(x: torch.Tensor, cols: int, scale: float = 1.0, backend=Non
     assert x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
     be.check(be.lib.vdk_softmax_rows_f32(be.ptr(x), x.shape[1], x.shape[0], cols, scale, be.stream()), "vdk_softmax_rows_f32")
     return x
+
+
+# ---- BatchNorm-based CNN pieces (csrc/resnet_ops.hip + the implicit-GEMM convolution of csrc/gemm.hip) ----------------------------------------
+def conv_weight_prep(w: torch.Tensor, cip: Optional[int] = None, backend=None):
+    """w f32 [Co,Ci,KH,KW] -> (wf bf16 [Co, KH*KW*Cip], wd bf16 [Cip, KH*KW*Co])"""
+    be = _be(backend)
+    Co, Ci, KH, KW = w.shape
+    cip = cip or (Ci + 7) // 8 * 8
+    w = w.contiguous()
+    wf = torch.empty((Co, KH * KW * cip), dtype=torch.bfloat16, device=w.device)
+    wd = torch.empty((cip, KH * KW * Co), dtype=torch.bfloat16, device=w.device)
+    be.check(be.lib.vdk_conv_weight_prep(be.ptr(w), be.ptr(wf), be.ptr(wd), Co, Ci, cip, KH, KW, be.stream()), "vdk_conv_weight_prep")
+    return wf, wd
+
+
+def conv_gemm(a_nhwc: torch.Tensor, wmat: torch.Tensor, *, oh: int, ow: int, kh: int, kw: int, stride: int, pad: int, transposed: bool = False,
+              out_dtype=torch.float32, residual: Optional[torch.Tensor] = None, backend=None) -> torch.Tensor:
+    """Implicit-GEMM convolution: a bf16 [B,H,W,Cin] gathered on the fly, wmat bf16 [N, kh*kw*Cin] -> [B*oh*ow, N]"""
+    be = _be(backend)
+    B, H, W, Cin = a_nhwc.shape
+    N = wmat.shape[0]
+    out = torch.empty((B * oh * ow, N), dtype=out_dtype, device=a_nhwc.device)
+    geom = _abi.ConvGeom(Cin, H, W, oh, ow, kh, kw, stride, pad, int(transposed))
+    d = _abi.GemmDesc()
+    d.A, d.lda, d.B, d.ldb, d.C, d.ldc = a_nhwc.data_ptr(), 0, wmat.data_ptr(), wmat.stride(0), out.data_ptr(), N
+    d.M, d.N, d.K = B * oh * ow, N, kh * kw * Cin
+    d.c_dtype = _abi.BF16 if out_dtype == torch.bfloat16 else _abi.F32_
+    d.residual = residual.data_ptr() if residual is not None else None
+    d.ldr = residual.stride(0) if residual is not None else 0
+    d.act, d.alpha, d.splitk = ACT_NONE, 1.0, 1
+    d.conv = C.cast(C.pointer(geom), C.c_void_p)
+    be.check(be.lib.vdk_gemm_bf16_nt(C.byref(d), None, 0, be.stream()), "vdk_gemm_bf16_nt(conv)")
+    return out
+
+
+def im2col(a_nhwc: torch.Tensor, oh: int, ow: int, kh: int, kw: int, stride: int, pad: int, backend=None) -> torch.Tensor:
+    be = _be(backend)
+    B, H, W, Cc = a_nhwc.shape
+    col = torch.empty((B * oh * ow, kh * kw * Cc), dtype=torch.bfloat16, device=a_nhwc.device)
+    be.check(be.lib.vdk_im2col_bf16(be.ptr(a_nhwc), be.ptr(col), B, H, W, Cc, oh, ow, kh, kw, stride, pad, be.stream()), "vdk_im2col_bf16")
+    return col
+
+
+def conv_wgrad_unpermute(dwp: torch.Tensor, ci: int, kh: int, kw: int, backend=None) -> torch.Tensor:
+    be = _be(backend)
+    Co = dwp.shape[0]
+    cip = dwp.shape[1] // (kh * kw)
+    dw = torch.empty((Co, ci, kh, kw), dtype=torch.float32, device=dwp.device)
+    be.check(be.lib.vdk_conv_wgrad_unpermute(be.ptr(dwp.contiguous()), be.ptr(dw), Co, ci, cip, kh, kw, be.stream()), "vdk_conv_wgrad_unpermute")
+    return dw
+
+
+def nchw_to_nhwc_bf16(x: torch.Tensor, cp: int, backend=None) -> torch.Tensor:
+    be = _be(backend)
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, H, W, cp), dtype=torch.bfloat16, device=x.device)
+    be.check(be.lib.vdk_nchw_to_nhwc_bf16(be.ptr(x.contiguous()), be.ptr(out), B, Cc, H, W, cp, be.stream()), "vdk_nchw_to_nhwc_bf16")
+    return out
+
+
+def _bn_ws(be, R, Cc, device):
+    need = C.c_size_t(0)
+    be.check(be.lib.vdk_bn_rows_workspace_bytes(R, Cc, C.byref(need)), "vdk_bn_rows_workspace_bytes")
+    return torch.empty(need.value, dtype=torch.uint8, device=device)
+
+
+def bn_act_fwd(x: torch.Tensor, gamma, beta, running_mean, running_var, *, training=True, eps=1e-5, momentum=0.1, res=None, relu=True, want_f32=False, backend=None):
+    """x f32 [R, C] -> (out bf16, out f32 | None, save_mean, save_invstd)"""
+    be = _be(backend)
+    R, Cc = x.shape
+    ws = _bn_ws(be, R, Cc, x.device)
+    outb = torch.empty((R, Cc), dtype=torch.bfloat16, device=x.device)
+    outf = torch.empty((R, Cc), dtype=torch.float32, device=x.device) if want_f32 else None
+    sm = torch.empty(Cc, dtype=torch.float32, device=x.device); si = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    rf = res if (res is not None and res.dtype == torch.float32) else None
+    rb = res if (res is not None and res.dtype == torch.bfloat16) else None
+    be.check(be.lib.vdk_bn_act_fwd(be.ptr(x), R, Cc, be.ptr(gamma), be.ptr(beta), eps, momentum, int(training), be.ptr(running_mean), be.ptr(running_var),
+                                   be.ptr(rf) if rf is not None else None, be.ptr(rb) if rb is not None else None, int(relu), be.ptr(outb),
+                                   be.ptr(outf) if outf is not None else None, be.ptr(sm), be.ptr(si), be.ptr(ws), ws.numel(), be.stream()), "vdk_bn_act_fwd")
+    return outb, outf, sm, si
+
+
+def bn_act_bwd(x, dout, out_bf16, gamma, save_mean, save_invstd, want_dres=True, backend=None):
+    """-> (dy bf16 [R,C], dres f32 | None, dgamma, dbeta)"""
+    be = _be(backend)
+    R, Cc = x.shape
+    ws = _bn_ws(be, R, Cc, x.device)
+    dy = torch.empty((R, Cc), dtype=torch.bfloat16, device=x.device)
+    dres = torch.empty((R, Cc), dtype=torch.float32, device=x.device) if want_dres else None
+    dg = torch.empty(Cc, dtype=torch.float32, device=x.device); db = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    be.check(be.lib.vdk_bn_act_bwd(be.ptr(x), be.ptr(dout), be.ptr(out_bf16) if out_bf16 is not None else None, R, Cc, be.ptr(gamma), be.ptr(save_mean),
+                                   be.ptr(save_invstd), be.ptr(dy), be.ptr(dres) if dres is not None else None, be.ptr(dg), be.ptr(db), be.ptr(ws), ws.numel(),
+                                   be.stream()), "vdk_bn_act_bwd")
+    return dy, dres, dg, db
+
+
+def maxpool3s2(x_nhwc: torch.Tensor, backend=None) -> torch.Tensor:
+    be = _be(backend)
+    B, H, W, Cc = x_nhwc.shape
+    out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), dtype=torch.bfloat16, device=x_nhwc.device)
+    be.check(be.lib.vdk_maxpool3s2_fwd(be.ptr(x_nhwc), be.ptr(out), B, H, W, Cc, be.stream()), "vdk_maxpool3s2_fwd")
+    return out
+
+
+def maxpool3s2_bwd(x_nhwc: torch.Tensor, dout: torch.Tensor, backend=None) -> torch.Tensor:
+    be = _be(backend)
+    B, H, W, Cc = x_nhwc.shape
+    din = torch.empty((B, H, W, Cc), dtype=torch.float32, device=x_nhwc.device)
+    be.check(be.lib.vdk_maxpool3s2_bwd(be.ptr(x_nhwc), be.ptr(dout.contiguous()), be.ptr(din), B, H, W, Cc, be.stream()), "vdk_maxpool3s2_bwd")
+    return din
