@@ -369,6 +369,31 @@ int vdk_convnext_forward_f32(const VdkConvNextConfig* cfg, const float* x, const
 int vdk_convnext_backward(const VdkConvNextConfig* cfg, const float* dout, const float* params, const void* wb16, const void* wx, void* ws, size_t ws_bytes,
                           float* grads, vdk_grad_ready_fn on_ready, void* user, void* stream);
 
+/* ---- native ResNet engine: timm BasicBlock ResNets (resnet18 / resnet34) over flat buffers ---------------------------------------------
+ * Replaces `self.model(images)` + `loss.backward()` for the classifier built by timm.create_model('resnet18', num_classes=C)
+ * (models/classifier/classify_model.py:49-54; `timm-resnet18` is the reference's CPU plumbing config).  Semantics restated from timm 0.9.16
+ * (oracle/resnet_ref.py).  Every convolution is an implicit GEMM (VdkGemmDesc.conv) in forward and input gradient. */
+typedef struct VdkResNetConfig {
+  int32_t batch, img_size, in_chans;
+  int32_t widths[4];
+  int32_t depths[4];
+  int32_t num_classes;
+  float bn_eps, bn_momentum;
+} VdkResNetConfig;
+/* trainable parameters live in one flat f32 buffer (params / grads), BatchNorm running statistics in another (buffers); `wx` = derived operand copies */
+int vdk_resnet_param_count(const VdkResNetConfig* cfg, int64_t* n_floats, int32_t* n_tensors, int64_t* n_buffer_floats, int32_t* n_buffers, size_t* wx_bytes);
+/* which = 0: parameters, 1: buffers (running_mean / running_var); timm state_dict names */
+int vdk_resnet_param_info(const VdkResNetConfig* cfg, int32_t which, int32_t index, char* name, int32_t name_cap, int64_t* offset, int64_t* numel, int64_t* shape4,
+                          int32_t* ndim);
+int vdk_resnet_workspace_bytes(const VdkResNetConfig* cfg, size_t* bytes);
+int vdk_resnet_refresh_weights(const VdkResNetConfig* cfg, const float* params, void* wb16, void* wx, int32_t skip_wb16, void* stream);
+/* x f32 [B, in_chans, img, img] -> logits f32 [B, Cp] (Cp = num_classes rounded up to 8); training != 0: batch statistics + running update */
+int vdk_resnet_forward(const VdkResNetConfig* cfg, const float* x, const float* params, float* buffers, const void* wb16, const void* wx, int32_t training, void* ws,
+                       size_t ws_bytes, float* logits, void* stream);
+/* dlogits bf16 [B, Cp] (padding columns zero) -> grads (flat f32, overwritten); on_ready as in vdk_vit_backward */
+int vdk_resnet_backward(const VdkResNetConfig* cfg, const void* dlogits, const float* params, const void* wb16, const void* wx, void* ws, size_t ws_bytes, float* grads,
+                        vdk_grad_ready_fn on_ready, void* user, void* stream);
+
 /* F.normalize(W, dim=0): inv[c] = 1/max(||W[:,c]||, eps); Wb = bf16 [3D, ldb]: the normalised weight as split planes
  * (hi, hi, lo) stacked along the contraction dim (rows [0,D) alone are the plain bf16 copy); columns C..Cp-1 zero */
 int vdk_colnorm_fwd(const float* W, int64_t ldw, int32_t D, int32_t C, int32_t Cp, float eps, float* inv, void* Wb, int64_t ldb, void* stream);

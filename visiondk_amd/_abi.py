@@ -45,6 +45,11 @@ class ConvNextConfig(C.Structure):
     _fields_ = [("batch", I32), ("img_size", I32), ("in_chans", I32), ("depths", I32 * 4), ("dims", I32 * 4), ("ln_eps", C.c_float)]
 
 
+class ResNetConfig(C.Structure):
+    _fields_ = [("batch", I32), ("img_size", I32), ("in_chans", I32), ("widths", I32 * 4), ("depths", I32 * 4), ("num_classes", I32), ("bn_eps", C.c_float),
+                ("bn_momentum", C.c_float)]
+
+
 class MarginHead(C.Structure):
     """VdkMarginHead of include/visiondk.h"""
     _fields_ = [("mode", I32), ("scale", F32), ("margin", F32), ("margin_am", F32), ("mv_weight", F32)]
@@ -144,6 +149,12 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_vit_forward_f32": (C.c_int, [C.POINTER(VitConfig), P, P, P, SZ, P, P]),
     "vdk_convnext_workspace_f32_bytes": (C.c_int, [C.POINTER(ConvNextConfig), PSZ]),
     "vdk_convnext_forward_f32": (C.c_int, [C.POINTER(ConvNextConfig), P, P, P, P, SZ, P, P]),
+    "vdk_resnet_param_count": (C.c_int, [C.POINTER(ResNetConfig), C.POINTER(I64), C.POINTER(I32), C.POINTER(I64), C.POINTER(I32), PSZ]),
+    "vdk_resnet_param_info": (C.c_int, [C.POINTER(ResNetConfig), I32, I32, C.c_char_p, I32, C.POINTER(I64), C.POINTER(I64), C.POINTER(I64), C.POINTER(I32)]),
+    "vdk_resnet_workspace_bytes": (C.c_int, [C.POINTER(ResNetConfig), PSZ]),
+    "vdk_resnet_refresh_weights": (C.c_int, [C.POINTER(ResNetConfig), P, P, P, I32, P]),
+    "vdk_resnet_forward": (C.c_int, [C.POINTER(ResNetConfig), P, P, P, P, P, I32, P, SZ, P, P]),
+    "vdk_resnet_backward": (C.c_int, [C.POINTER(ResNetConfig), P, P, P, P, P, SZ, P, P, P, P]),
     "vdk_convnext_param_count": (C.c_int, [C.POINTER(ConvNextConfig), C.POINTER(I64), C.POINTER(I32), PSZ]),
     "vdk_convnext_param_info": (C.c_int, [C.POINTER(ConvNextConfig), I32, C.c_char_p, I32, C.POINTER(I64), C.POINTER(I64), C.POINTER(I64), C.POINTER(I32)]),
     "vdk_convnext_workspace_bytes": (C.c_int, [C.POINTER(ConvNextConfig), PSZ]),

@@ -1,0 +1,245 @@
+"""Host side of hot path A for BatchNorm CNNs: timm-compatible BasicBlock ResNets on the native HIP engine (csrc/resnet_engine.hip).
+
+`create_model('resnet18', pretrained=False, num_classes=C)` is what the reference's VisionWrapper asks timm for (models/classifier/classify_model.py:49-54;
+`timm-resnet18` is the reference's CPU-runnable config, BASELINE.json configs[0]).  The module tree mirrors timm's (conv1, bn1, layer{1..4}.{j}.{conv1,bn1,conv2,bn2,
+downsample.0/1}, fc) with parameter / buffer holder modules, so state_dict() has timm's keys in timm's order (including running_mean / running_var /
+num_batches_tracked) and reference checkpoints load unchanged.  No torch arithmetic."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _abi, _lib
+
+
+@dataclass(frozen=True)
+class ResNetSpec:
+    img_size: int = 224
+    in_chans: int = 3
+    widths: Tuple[int, int, int, int] = (64, 128, 256, 512)
+    depths: Tuple[int, int, int, int] = (2, 2, 2, 2)
+    num_classes: int = 1000
+    bn_eps: float = 1e-5
+    bn_momentum: float = 0.1
+
+
+TIMM_RESNETS = {"resnet18": dict(depths=(2, 2, 2, 2)), "resnet34": dict(depths=(3, 4, 6, 3))}
+
+
+class ResNetEngine:
+    def __init__(self, spec: ResNetSpec, device=None, backend: Optional[_lib.Backend] = None):
+        self.spec = spec
+        self.be = backend or _lib.load()
+        self.device = torch.device(device if device is not None else ("cuda" if self.be.device_only else "cpu"))
+        cfg = self._cfg(1)
+        nf, nt, nbf, nb, wx = _abi.I64(0), _abi.I32(0), _abi.I64(0), _abi.I32(0), C.c_size_t(0)
+        self.be.check(self.be.lib.vdk_resnet_param_count(C.byref(cfg), C.byref(nf), C.byref(nt), C.byref(nbf), C.byref(nb), C.byref(wx)), "vdk_resnet_param_count")
+        self.n_floats = nf.value
+        name = C.create_string_buffer(96)
+        off, numel, ndim = _abi.I64(0), _abi.I64(0), _abi.I32(0)
+        shape = (_abi.I64 * 4)()
+
+        def entries(which, n):
+            out = []
+            for i in range(n):
+                self.be.check(self.be.lib.vdk_resnet_param_info(C.byref(cfg), which, i, name, 96, C.byref(off), C.byref(numel), shape, C.byref(ndim)),
+                              "vdk_resnet_param_info")
+                out.append((name.value.decode(), off.value, numel.value, tuple(shape[j] for j in range(ndim.value))))
+            return out
+        self.entries = entries(0, nt.value)
+        self.buffer_entries = entries(1, nb.value)
+        dev = self.device
+        self.params = torch.zeros(nf.value, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(nf.value, dtype=torch.float32, device=dev)
+        self.buffers = torch.zeros(nbf.value, dtype=torch.float32, device=dev)
+        self.wb16 = torch.zeros(nf.value, dtype=torch.bfloat16, device=dev)
+        self.wx = torch.zeros(wx.value, dtype=torch.uint8, device=dev)
+        self.cp = (spec.num_classes + 7) // 8 * 8
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_batch = -1
+        self._logits: Optional[torch.Tensor] = None
+        self._weights_version = None
+
+    def _cfg(self, batch: int) -> _abi.ResNetConfig:
+        s = self.spec
+        return _abi.ResNetConfig(batch, s.img_size, s.in_chans, (_abi.I32 * 4)(*s.widths), (_abi.I32 * 4)(*s.depths), s.num_classes, s.bn_eps, s.bn_momentum)
+
+    def _workspace(self, batch: int) -> torch.Tensor:
+        if self._ws is None or self._ws_batch != batch:
+            need = C.c_size_t(0)
+            cfg = self._cfg(batch)
+            self.be.check(self.be.lib.vdk_resnet_workspace_bytes(C.byref(cfg), C.byref(need)), "vdk_resnet_workspace_bytes")
+            self._ws = None
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+            self._ws_batch = batch
+            self._logits = torch.empty((batch, self.cp), dtype=torch.float32, device=self.device)
+        return self._ws
+
+    def refresh_weights(self, skip_wb16: bool = False) -> None:
+        cfg = self._cfg(1)
+        be = self.be
+        be.check(be.lib.vdk_resnet_refresh_weights(C.byref(cfg), be.ptr(self.params), be.ptr(self.wb16), be.ptr(self.wx), int(skip_wb16), be.stream()),
+                 "vdk_resnet_refresh_weights")
+        self._weights_version = self.params._version
+
+    def forward(self, x: torch.Tensor, training: bool) -> torch.Tensor:
+        s = self.spec
+        if x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (s.in_chans, s.img_size, s.img_size):
+            raise ValueError(f"expected float32 [B, {s.in_chans}, {s.img_size}, {s.img_size}], got {tuple(x.shape)} {x.dtype}")
+        x = x.contiguous()
+        B = x.shape[0]
+        ws = self._workspace(B)
+        if self._weights_version != self.params._version:
+            self.refresh_weights()
+        cfg = self._cfg(B)
+        be = self.be
+        be.check(be.lib.vdk_resnet_forward(C.byref(cfg), be.ptr(x), be.ptr(self.params), be.ptr(self.buffers), be.ptr(self.wb16), be.ptr(self.wx), int(training),
+                                           be.ptr(ws), ws.numel(), be.ptr(self._logits), be.stream()), "vdk_resnet_forward")
+        return self._logits
+
+    def backward(self, dlogits_bf16: torch.Tensor, on_ready: Optional[Callable[[int, int], None]] = None) -> torch.Tensor:
+        B = dlogits_bf16.shape[0]
+        assert dlogits_bf16.dtype == torch.bfloat16 and dlogits_bf16.shape[1] == self.cp and B == self._ws_batch
+        cfg = self._cfg(B)
+        be = self.be
+        cb = _abi.GRAD_READY_FN(lambda user, off, n: on_ready(off, n)) if on_ready is not None else _abi.GRAD_READY_FN(0)
+        be.check(be.lib.vdk_resnet_backward(C.byref(cfg), be.ptr(dlogits_bf16), be.ptr(self.params), be.ptr(self.wb16), be.ptr(self.wx), be.ptr(self._ws),
+                                            self._ws.numel(), be.ptr(self.grads), cb, None, be.stream()), "vdk_resnet_backward")
+        return self.grads
+
+
+class _ResNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, module, *params):
+        eng = module.engine
+        module._sync_flat()
+        logits = eng.forward(x, module.training)
+        ctx.module = module
+        return logits[:, :eng.spec.num_classes].clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        eng = ctx.module.engine
+        be = eng.be
+        B, Cn = dlogits.shape
+        stage = torch.zeros((B, eng.cp), dtype=torch.float32, device=dlogits.device)
+        stage[:, :Cn].copy_(dlogits)
+        dl = torch.empty((B, eng.cp), dtype=torch.bfloat16, device=dlogits.device)
+        be.check(be.lib.vdk_cast_f32_bf16(be.ptr(stage), be.ptr(dl), stage.numel(), be.stream()), "vdk_cast_f32_bf16")
+        g = eng.backward(dl)
+        return (None, None) + tuple(g[off:off + numel].view(shape) for (_, off, numel, shape) in eng.entries)
+
+
+class _Holder(nn.Module):
+    """empty container mirroring one level of timm's module tree; owns Parameters / buffers only"""
+
+
+class ResNet(nn.Module):
+    """Drop-in for `timm.create_model('resnet18' | 'resnet34', pretrained=False, num_classes=C)`."""
+
+    def __init__(self, spec: ResNetSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None):
+        super().__init__()
+        self.spec = spec
+        self.engine = ResNetEngine(spec, device=device, backend=backend)
+        self.num_classes = spec.num_classes
+        eng = self.engine
+        self._plist, self._blist = [], []
+        bufs = {n: (off, numel, shape) for n, off, numel, shape in eng.buffer_entries}
+
+        def holder(path):
+            m = self
+            for part in path:
+                if part not in m._modules:
+                    m.add_module(part, _Holder())
+                m = m._modules[part]
+            return m
+        for name, off, numel, shape in eng.entries:
+            parts = name.split(".")
+            m = holder(parts[:-1])
+            p = nn.Parameter(eng.params[off:off + numel].view(shape))
+            m.register_parameter(parts[-1], p)
+            self._plist.append((name, p))
+            if parts[-1] == "bias" and ".".join(parts[:-1]) + ".running_mean" in bufs:      # a BatchNorm: its buffers follow weight / bias, like nn.BatchNorm2d
+                for bn in ("running_mean", "running_var"):
+                    boff, bnum, bshape = bufs[".".join(parts[:-1]) + "." + bn]
+                    t = eng.buffers[boff:boff + bnum].view(bshape)
+                    m.register_buffer(bn, t)
+                    self._blist.append((".".join(parts[:-1]) + "." + bn, boff, bnum, bshape, m, bn))
+                m.register_buffer("num_batches_tracked", torch.zeros((), dtype=torch.long, device=eng.device))
+        self.reset_parameters(seed)
+
+    def reset_parameters(self, seed: Optional[int] = None) -> None:
+        """the reference's re-init (classify_model.py:70-81): N(0, .02) Conv / Linear weights, zero Linear bias, BatchNorm (1, 0); running stats (0, 1)"""
+        gen = torch.Generator(device="cpu")
+        if seed is not None:
+            gen.manual_seed(seed)
+        else:
+            gen.seed()
+        with torch.no_grad():
+            for name, p in self._plist:
+                if name.endswith(".bias"):
+                    v = torch.zeros(p.shape)
+                elif p.dim() == 1:
+                    v = torch.ones(p.shape)
+                else:
+                    v = torch.empty(p.shape).normal_(0, 0.02, generator=gen)
+                p.copy_(v.to(p.device))
+            for name, off, numel, shape, m, bn in self._blist:
+                getattr(m, bn).fill_(1.0 if bn == "running_var" else 0.0)
+
+    def _sync_flat(self) -> None:
+        eng = self.engine
+        base = eng.params.data_ptr()
+        for (name, off, numel, shape), (_, p) in zip(eng.entries, self._plist):
+            if p.data_ptr() != base + off * 4:
+                with torch.no_grad():
+                    eng.params[off:off + numel].view(shape).copy_(p.detach().to(eng.device))
+                    p.data = eng.params[off:off + numel].view(shape)
+        bbase = eng.buffers.data_ptr()
+        for name, off, numel, shape, m, bn in self._blist:
+            t = getattr(m, bn)
+            if t.data_ptr() != bbase + off * 4:       # load_state_dict copies in place, so this only triggers after .to() / deepcopy
+                with torch.no_grad():
+                    eng.buffers[off:off + numel].view(shape).copy_(t.to(eng.device))
+                    m._buffers[bn] = eng.buffers[off:off + numel].view(shape)
+
+    def _apply(self, fn, recurse=True):
+        probe = fn(torch.zeros(1, dtype=torch.float32, device=self.engine.device))
+        if probe.device != self.engine.device or probe.dtype != torch.float32:
+            if probe.dtype != torch.float32:
+                raise RuntimeError("visiondk_amd ResNet keeps fp32 master weights; bf16 copies are internal")
+            if self.engine.be.device_only and probe.device.type != "cuda":
+                raise RuntimeError("visiondk_amd ResNet lives on the GPU (no CPU fallback)")
+            eng = self.engine
+            eng.device = probe.device
+            for attr in ("params", "grads", "buffers", "wb16", "wx"):
+                setattr(eng, attr, getattr(eng, attr).to(probe.device))
+            eng._ws, eng._ws_batch, eng._weights_version = None, -1, None
+            for (name, off, numel, shape), (_, p) in zip(eng.entries, self._plist):
+                p.data = eng.params[off:off + numel].view(shape)
+            for name, off, numel, shape, m, bn in self._blist:
+                m._buffers[bn] = eng.buffers[off:off + numel].view(shape)
+                m._buffers["num_batches_tracked"] = m._buffers["num_batches_tracked"].to(probe.device)
+        return self
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training:
+            for m in self.modules():
+                if "num_batches_tracked" in m._buffers:
+                    m._buffers["num_batches_tracked"] += 1
+        if torch.is_grad_enabled():
+            return _ResNetFunction.apply(x, self, *[p for _, p in self._plist])
+        self._sync_flat()
+        return self.engine.forward(x, self.training)[:, :self.spec.num_classes].clone()
+
+
+def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, device=None, backend=None, img_size: Optional[int] = None, **kwargs) -> ResNet:
+    if name not in TIMM_RESNETS:
+        raise NotImplementedError(f"timm model '{name}' is not covered by the HIP engine yet (have: {sorted(TIMM_RESNETS)})")
+    if pretrained:
+        raise RuntimeError("pretrained weights need network access; load a checkpoint with load_state_dict instead")
+    return ResNet(ResNetSpec(img_size=img_size or 224, num_classes=num_classes, **TIMM_RESNETS[name]), device=device, backend=backend)
