@@ -101,3 +101,40 @@ def test_eval_mode_uses_running_statistics(be, dev):
     model.eval(); ref.eval()
     with torch.no_grad():
         assert _rel(model(x.to(dev)), ref(x)) < 3e-2
+
+
+def test_train_step_bce_matches_reference_update(be, dev):
+    """ResNetTrainStep == compute_loss (BCEWithLogits, the reference's multi-label config) + Trainer.update: clip_grad_norm_ -> SGD(momentum, wd) -> EMA"""
+    import math
+    model, ref = _pair(be, dev, img=64)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear)):
+                m.weight.copy_(m.weight.bfloat16().float())
+    model.load_state_dict(ref.state_dict(), strict=True)
+    lr, mom, wd, max_norm = 0.05, 0.9, 5e-4, 0.05
+    step = resnet.ResNetTrainStep(model, lr=lr, momentum=mom, weight_decay=wd, loss="bce", max_norm=max_norm, ema=True)
+    opt = torch.optim.SGD(ref.parameters(), lr=lr, momentum=mom, weight_decay=wd)
+    start = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    ema_ref = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    ref.train()
+    torch.manual_seed(3)
+    for it in range(1):   # one step: after it the fp32 masters are no longer bf16-representable and the oracle would need weight rounding hooks too
+        x = torch.randn(8, 3, 64, 64); t = (torch.rand(8, 5) > 0.5).float()
+        opt.zero_grad()
+        loss_r = torch.nn.functional.binary_cross_entropy_with_logits(_forward_with_engine_rounding(ref, x), t)
+        loss_r.backward()
+        assert torch.nn.utils.clip_grad_norm_(list(ref.parameters()), max_norm=max_norm) > max_norm
+        opt.step()
+        d = 0.9999 * (1 - math.exp(-(it + 1) / 2000))
+        for n, p in ref.named_parameters():
+            ema_ref[n].mul_(d).add_(p.detach(), alpha=1 - d)
+        rows = step.step(x.to(dev), t.to(dev))
+        assert abs(rows.sum().item() / (8 * 5) - loss_r.item()) < 2e-2 * abs(loss_r.item())
+    got = dict(model.named_parameters())
+    for n, p in ref.named_parameters():
+        upd_ref, upd = p.detach() - start[n], got[n].detach().cpu() - start[n]
+        assert _rel(upd, upd_ref) < 0.15, (n, _rel(upd, upd_ref))
+    eng = model.engine
+    name, off, numel, shape = eng.entries[3]
+    assert _rel(step.ema[off:off + numel].view(shape), ema_ref[name]) < 1e-4

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _abi, _lib, convnext, heads, ops, vit
+from . import _abi, _lib, convnext, heads, ops, resnet, vit
 
 
 def _up(x, a):
@@ -310,8 +310,10 @@ class VisionWrapper:
         name = model_cfg["name"]
         assert name.startswith("timm-"), "classifier id must look like timm-<timm model id>"
         kwargs = model_cfg.get("kwargs") or {}
-        self.model = vit.create_model(name[5:].split(".")[0], pretrained=False, num_classes=model_cfg["num_classes"],
-                                      img_size=model_cfg.get("image_size"), device=device, backend=backend, **kwargs)
+        arch = name[5:].split(".")[0]
+        factory = resnet.create_model if arch in resnet.TIMM_RESNETS else vit.create_model       # timm-resnet18 | timm-vit_*
+        self.model = factory(arch, pretrained=False, num_classes=model_cfg["num_classes"], img_size=model_cfg.get("image_size"), device=device,
+                             backend=backend, **kwargs)
         if not model_cfg.get("pretrained", False):
             self.reset_parameters()
 

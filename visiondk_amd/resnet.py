@@ -243,3 +243,54 @@ def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, d
     if pretrained:
         raise RuntimeError("pretrained weights need network access; load a checkpoint with load_state_dict instead")
     return ResNet(ResNetSpec(img_size=img_size or 224, num_classes=num_classes, **TIMM_RESNETS[name]), device=device, backend=backend)
+
+
+class ResNetTrainStep:
+    """Trainer.compute_loss + Trainer.update (engine/procedure/train.py:177-215) for the ResNet classifier as a fixed kernel sequence: forward ->
+    BCE-with-logits (multi-label CSV datasets, checks.py:163-167; mean over B*C like nn.BCEWithLogitsLoss) or CE(label_smoothing) -> backward ->
+    clip_grad_norm_(max_norm) -> SGD(momentum, weight_decay) -> EMA -> bf16 weight refresh.  `param_groups[0]['lr']` stays readable / writable."""
+
+    def __init__(self, model: ResNet, lr: float, momentum: float = 0.937, weight_decay: float = 5e-4, loss: str = "bce", label_smoothing: float = 0.0,
+                 max_norm: float = 10.0, ema: bool = True):
+        assert loss in ("bce", "ce")
+        self.model, self.eng, self.be = model, model.engine, model.engine.be
+        self.loss, self.label_smoothing, self.max_norm = loss, label_smoothing, max_norm
+        self.param_groups = [{"lr": lr, "momentum": momentum, "weight_decay": weight_decay}]
+        self.momentum_buf = torch.zeros_like(self.eng.params)
+        self.ema = self.eng.params.clone() if ema else None
+        self.updates = 0
+        self._normsq = torch.zeros(1, dtype=torch.float32, device=self.eng.device)
+        need = C.c_size_t(0)
+        self.be.check(self.be.lib.vdk_sumsq_workspace_bytes(C.byref(need)), "vdk_sumsq_workspace_bytes")
+        self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.eng.device)
+        self.loss_rows: Optional[torch.Tensor] = None
+
+    def step(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        import math
+        eng, be, model = self.eng, self.be, self.model
+        model._sync_flat()
+        model.train()
+        for m in model.modules():
+            if "num_batches_tracked" in m._buffers:
+                m._buffers["num_batches_tracked"] += 1
+        self.updates += 1
+        g = self.param_groups[0]
+        B, ncls = x.shape[0], eng.spec.num_classes
+        logits = eng.forward(x, True)
+        if self.loss_rows is None or self.loss_rows.shape[0] != B:
+            self.loss_rows = torch.empty(B, dtype=torch.float32, device=eng.device)
+            self._dl = torch.zeros((B, eng.cp), dtype=torch.bfloat16, device=eng.device)
+        if self.loss == "bce":
+            be.check(be.lib.vdk_bce_logits(be.ptr(logits), eng.cp, be.ptr(y), y.stride(0), B, ncls, 1.0 / (B * ncls), 0.0, 0.25, be.ptr(self.loss_rows),
+                                           be.ptr(self._dl), eng.cp, None, 0, be.stream()), "vdk_bce_logits")
+        else:
+            be.check(be.lib.vdk_softmax_ce(be.ptr(logits), eng.cp, B, ncls, be.ptr(y), None, 1.0, self.label_smoothing, 1.0 / B, be.ptr(self.loss_rows),
+                                           be.ptr(self._dl), eng.cp, None, 0, be.stream()), "vdk_softmax_ce")
+        eng.backward(self._dl)
+        be.check(be.lib.vdk_sumsq_f32(be.ptr(eng.grads), eng.n_floats, be.ptr(self._normsq), be.ptr(self._ws), self._ws.numel(), be.stream()), "vdk_sumsq_f32")
+        d = 0.9999 * (1 - math.exp(-self.updates / 2000)) if self.ema is not None else 0.0
+        be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema), be.ptr(eng.wb16), eng.n_floats, g["lr"],
+                                     g["momentum"], g["weight_decay"], 1.0, be.ptr(self._normsq), self.max_norm, d, int(self.updates == 1), be.stream()),
+                 "vdk_sgd_step")
+        eng.refresh_weights(skip_wb16=True)
+        return self.loss_rows
