@@ -1,10 +1,29 @@
 // hip_emu.cpp — TEST INFRASTRUCTURE ONLY (see hip_emu.h).  Fiber scheduler for the SIMT emulator.
 #include "hip_emu.h"
 #include <sys/mman.h>
+#include <mutex>
+
+// void emu_switch(Ctx* from, Ctx* to): save the System V callee-saved registers on the current stack, swap stack pointers, restore, return
+__asm__(
+    ".text\n"
+    ".globl emu_switch\n"
+    ".type emu_switch,@function\n"
+    "emu_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n"
+    "  movq (%rsi), %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+    "  ret\n"
+    ".size emu_switch,.-emu_switch\n");
 
 namespace emu {
 
 thread_local Block* g_blk = nullptr;
+
+static void fiber_trampoline() {
+  fiber_entry();          // never returns: a finished fiber switches back to the scheduler for good
+  abort();
+}
 
 void fiber_entry() {
   Block* b = g_blk;
@@ -18,7 +37,7 @@ void fiber_entry() {
   w.alive--;
   if (b->alive > 0 && b->bar.arrived >= b->alive && b->bar.arrived > 0) { b->bar.arrived = 0; b->bar.gen++; }
   if (w.alive > 0 && w.bar.arrived >= w.alive && w.bar.arrived > 0) { w.bar.arrived = 0; w.bar.gen++; }
-  swapcontext(&f->ctx, &b->sched);
+  emu_switch(&f->ctx, &b->sched);
 }
 
 struct StackPool {
@@ -32,7 +51,11 @@ struct StackPool {
     return stacks[i];
   }
 };
-static thread_local StackPool g_pool;
+// One pool per worker slot, kept for the life of the process (launches are serialised by g_launch_mu): the stacks are mapped once, not once per
+// launch and thread.
+static StackPool g_pools[256];
+static thread_local int g_slot = 0;
+static std::mutex g_launch_mu;
 
 void run_block(Block& b) {
   g_blk = &b;
@@ -46,10 +69,14 @@ void run_block(Block& b) {
     f.blk = &b; f.lin = i; f.done = false;
     f.tid.x = i % b.bdim.x; f.tid.y = (i / b.bdim.x) % b.bdim.y; f.tid.z = i / (b.bdim.x * b.bdim.y);
     b.waves[i >> 6].alive++;
-    f.stack = g_pool.get(i);
-    getcontext(&f.ctx);
-    f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = kStack; f.ctx.uc_link = nullptr;
-    makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+    f.stack = g_pools[g_slot].get(i);
+    // initial frame: six zeroed callee-saved registers + the trampoline as return address; after the first `ret` rsp == top, and top is 8 mod 16
+    // as the ABI expects at a function's first instruction
+    uintptr_t top = ((uintptr_t)(f.stack + kStack) & ~(uintptr_t)15) - 8;
+    void** sp = (void**)top;
+    *--sp = (void*)fiber_trampoline;
+    for (int r = 0; r < 6; ++r) *--sp = nullptr;
+    f.ctx.sp = sp;
   }
   int remaining = n;
   while (remaining > 0) {
@@ -59,7 +86,7 @@ void run_block(Block& b) {
       Fiber& f = b.fibers[i];
       if (f.done) continue;
       b.cur = &f;
-      swapcontext(&b.sched, &f.ctx);
+      emu_switch(&b.sched, &f.ctx);
       if (!f.done) remaining++;
     }
     if (remaining > 0 && !b.progress) {
@@ -78,8 +105,11 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   if (const char* e = getenv("VDK_EMU_THREADS")) nthr = (unsigned)atoi(e);
   if (nthr < 1) nthr = 1;
   if (nthr > total) nthr = (unsigned)total;
+  if (nthr > 256) nthr = 256;
+  std::lock_guard<std::mutex> lk(g_launch_mu);
   std::atomic<size_t> next{0};
-  auto worker = [&]() {
+  auto worker = [&](int slot) {
+    g_slot = slot;
     Block b;
     b.bdim = block; b.gdim = grid; b.body = &body;
     for (;;) {
@@ -89,9 +119,9 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
       run_block(b);
     }
   };
-  if (nthr == 1) { worker(); return; }
+  if (nthr == 1) { worker(0); return; }
   std::vector<std::thread> th;
-  for (unsigned t = 0; t < nthr; ++t) th.emplace_back(worker);
+  for (unsigned t = 0; t < nthr; ++t) th.emplace_back(worker, (int)t);
   for (auto& t : th) t.join();
 }
 

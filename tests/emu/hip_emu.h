@@ -16,7 +16,6 @@
 // /opt/skills/guides/cdna_hip_programming.md §3 (A/B: lane l holds row/col (l & (M-1)) and the 8
 // consecutive k starting at 8*(l / M); C/D: col = l & (M-1), row = f(reg, l / M)).
 #pragma once
-#include <ucontext.h>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -84,8 +83,13 @@ struct Wave {
 };
 
 struct Block;
+// minimal cooperative context: the callee-saved registers live on the fiber's own stack, only the stack pointer is kept here (glibc's swapcontext
+// costs a sigprocmask system call per switch, which dominated the emulated run time)
+struct Ctx { void* sp = nullptr; };
+extern "C" void emu_switch(Ctx* from, Ctx* to);
+
 struct Fiber {
-  ucontext_t ctx;
+  Ctx ctx;
   Block* blk = nullptr;
   emu_uint3 tid{0, 0, 0};
   int lin = 0;
@@ -94,7 +98,7 @@ struct Fiber {
 };
 
 struct Block {
-  ucontext_t sched;
+  Ctx sched;
   std::vector<Fiber> fibers;
   std::vector<Wave> waves;
   Barrier bar;
@@ -110,7 +114,7 @@ extern thread_local Block* g_blk;
 static const size_t kStack = 256 * 1024;
 
 inline Fiber* cur() { return g_blk->cur; }
-inline void yield() { Fiber* f = cur(); swapcontext(&f->ctx, &g_blk->sched); }
+inline void yield() { Fiber* f = cur(); emu_switch(&f->ctx, &g_blk->sched); }
 
 inline void barrier_wait(Barrier& b, int& alive) {
   unsigned gen = b.gen;

@@ -62,7 +62,7 @@ def test_two_rank_step_equals_single_process(tmp_path, emu):
 
 
 # ---- face / CBIR task: 2-rank FaceTrainStep (ConvNeXt backbone + BatchNorm neck + ArcFace) and sharded gallery search --------------------------
-FACE_CFG = {"task": "cbir", "image_size": 64, "backbone": {"timm-convnext_test": {"pretrained": False, "image_size": 64, "feat_dim": 64}},
+FACE_CFG = {"task": "cbir", "image_size": 32, "backbone": {"timm-convnext_test": {"pretrained": False, "image_size": 32, "feat_dim": 64}},
             "head": {"arcface": {"feat_dim": 64, "num_class": 24, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
 
 
@@ -91,7 +91,7 @@ def _face_worker(rank, world, port, out_dir):
     step = face.FaceTrainStep(model, lr=0.05, momentum=0.9, weight_decay=5e-4, max_norm=10.0, ema=True, comm=c)
     init = {k: v.clone() for k, v in model.state_dict().items()}      # after the broadcast: rank 0's weights everywhere
     torch.manual_seed(7)
-    x = torch.randn(8, 3, 64, 64); y = torch.randint(0, 24, (8,))
+    x = torch.randn(8, 3, 32, 32); y = torch.randint(0, 24, (8,))
     lo, hi = rank * 4, rank * 4 + 4
     step.step(x[lo:hi], y[lo:hi])
     sd = {k: v.clone() for k, v in model.state_dict().items()}
@@ -120,7 +120,7 @@ def test_two_rank_face_step_and_sharded_search(tmp_path, emu):
     from visiondk_amd import face
     total, total_head = None, None
     torch.manual_seed(7)
-    x = torch.randn(8, 3, 64, 64); y = torch.randint(0, 24, (8,))
+    x = torch.randn(8, 3, 32, 32); y = torch.randint(0, 24, (8,))
     for r in range(2):
         model = _face_model(emu, 100)
         model.load_state_dict(r0["init"], strict=True)

@@ -115,7 +115,7 @@ def test_extract_cbir_eval_embeddings(be, dev):
 def _build_cnn(be, dev, monkeypatch):
     from oracle.convnext_ref import TimmWrapperCNNRef
     from visiondk_amd import convnext
-    depths, dims, img = (1, 1, 2, 1), (8, 16, 24, 32), 64
+    depths, dims, img = (1, 1, 2, 1), (8, 16, 24, 32), 32
     monkeypatch.setitem(convnext.TIMM_CONVNEXTS, "convnext_test", dict(depths=depths, dims=dims))
     cfg = {"task": "cbir", "image_size": img,
            "backbone": {"timm-convnext_test": {"pretrained": False, "image_size": img, "feat_dim": 64}},

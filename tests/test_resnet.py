@@ -106,7 +106,7 @@ def test_eval_mode_uses_running_statistics(be, dev):
 def test_train_step_bce_matches_reference_update(be, dev):
     """ResNetTrainStep == compute_loss (BCEWithLogits, the reference's multi-label config) + Trainer.update: clip_grad_norm_ -> SGD(momentum, wd) -> EMA"""
     import math
-    model, ref = _pair(be, dev, img=64)
+    model, ref = _pair(be, dev, widths=(8, 8, 16, 16), depths=(1, 1, 1, 1), img=64)
     with torch.no_grad():
         for m in ref.modules():
             if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear)):
