@@ -152,6 +152,28 @@ def main():
     m.compute_mrr(sp, sl); m.compute_precision(sp, sl); m.compute_recall(sp, sl); m.compute_auc(sp, sl, scores); m.compute_ndcg(sp, sl, scores)
     np.savez(OUT / "cbir_metrics.npz", preds=preds, scores=scores, labels=np.array([np.pad(l, (0, 6 - len(l)), constant_values=-1) for l in labels]),
              names=np.array(list(m.metrics.keys())), values=np.array(list(m.metrics.values()), dtype=np.float64))
+    # ---- face pair verification: the reference's own Evaluator (engine/faceX/evaluation.py:18-118), exec'd from its source range ----------------------
+    src = (REF / "engine/faceX/evaluation.py").read_text().splitlines()
+    ns = {"np": np, "os": __import__("os")}
+    exec("\n".join(src[17:118]), ns)
+    rng = np.random.default_rng(9)
+    n_img, dim, n_pairs = 400, 32, 6000                       # the reference hard-codes 10 folds of 600 pairs
+    ident = rng.integers(0, 80, n_img)
+    centers = rng.standard_normal((80, dim))
+    feats = centers[ident] + 0.9 * rng.standard_normal((n_img, dim))
+    feats = (feats / np.linalg.norm(feats, axis=1, keepdims=True)).astype(np.float32)
+    a, b = rng.integers(0, n_img, n_pairs), rng.integers(0, n_img, n_pairs)
+    same = rng.random(n_pairs) < 0.5
+    for i in np.where(same)[0]:                               # make about half of the pairs genuine
+        cand = np.where(ident == ident[a[i]])[0]
+        b[i] = rng.choice(cand)
+    label = (ident[a] == ident[b]).astype(np.int64)
+    names = [f"id{ident[i]:03d}/img{i:04d}.jpg" for i in range(n_img)]
+    pair_list = [[names[x], names[y], str(int(l))] for x, y, l in zip(a, b, label)]
+    ev = ns["Evaluator"](None)
+    mean, std = ev.test_one_model(pair_list, {n: f for n, f in zip(names, feats)})
+    thr = ev.getThreshold(np.array([feats[x] @ feats[y] for x, y in zip(a[:5400], b[:5400])], dtype=np.float32), label[:5400].astype(np.int8))
+    np.savez(OUT / "face_pairs.npz", feats=feats, a=a, b=b, label=label, mean=np.float64(mean), std=np.float64(std), thr_first_5400=np.float64(thr))
     print("golden fixtures written to", OUT)
 
 

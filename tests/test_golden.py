@@ -120,3 +120,18 @@ def test_focal_kernel_vs_reference_loss(be, dev):
     loss, _, dlf = ops.bce_logits(x, t, grad_scale=1.0 / x.numel(), focal_gamma=1.5, focal_alpha=0.25, backend=be)
     assert abs(loss.sum().item() / x.numel() - float(z["focal_loss"])) < 1e-6
     assert _rel(dlf, z["focal_grad"]) < 1e-5
+
+
+def test_face_pair_verification_matches_reference_evaluator():
+    """visiondk_amd.evaluate.FaceEvaluator vs the reference's own Evaluator (engine/faceX/evaluation.py:18-118) run on the same embeddings / pair list
+    (tests/golden/make_golden.py)."""
+    from visiondk_amd.evaluate import FaceEvaluator
+    d = np.load(G / "face_pairs.npz")
+    feats, a, b, label = d["feats"], d["a"], d["b"], d["label"]
+    names = [f"id/img{i:04d}.jpg" for i in range(len(feats))]
+    pair_list = [[names[x], names[y], str(int(l))] for x, y, l in zip(a, b, label)]
+    ev = FaceEvaluator()
+    mean, std = ev.test_one_model(pair_list, {n: f for n, f in zip(names, feats)})
+    assert mean == float(d["mean"]) and abs(std - float(d["std"])) < 1e-15
+    thr = ev.get_threshold(np.array([feats[x] @ feats[y] for x, y in zip(a[:5400], b[:5400])], dtype=np.float32), label[:5400].astype(np.int8))
+    assert thr == float(d["thr_first_5400"])

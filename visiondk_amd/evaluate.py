@@ -64,3 +64,48 @@ def valuate(model, dataloader, device, pbar=None, is_training: bool = False, los
     say(f"mprecision:{precision.mean():.3f}, mrecall:{recall.mean():.3f}, mf1-score:{f1.mean():.3f}")
     out = (float(precision.mean()), float(recall.mean()), float(f1.mean()))
     return out + (loss,) if lossfn else out
+
+
+class FaceEvaluator:
+    """The reference's face pair-verification `Evaluator` (engine/faceX/evaluation.py:18-118): 10 folds of 600 pairs, cosine score of the two unit
+    embeddings of each pair, threshold picked on the other 9 folds as the argmax of TPR - FPR over 1000 evenly spaced thresholds, accuracy on the held-out
+    fold; returns (mean accuracy, standard error).  Embeddings come from `face.FeatureExtractor.extract_face` (device work); this is host bookkeeping."""
+
+    def __init__(self, feature_extractor=None):
+        self.feature_extractor = feature_extractor
+
+    def test(self, pair_list, feature_dataloader, device):
+        assert len(pair_list) % 10 == 0, "make sure the number of rows is a multiple of 10 in pair.txt"
+        return self.test_one_model(pair_list, self.feature_extractor.extract_face(feature_dataloader, device))
+
+    @staticmethod
+    def get_threshold(score_list: np.ndarray, label_list: np.ndarray, num_thresholds: int = 1000) -> float:
+        pos, neg = score_list[label_list == 1], score_list[label_list == 0]
+        smin, smax = np.min(score_list), np.max(score_list)
+        step = (smax - smin) / num_thresholds
+        thr = smin + step * np.array(range(1, num_thresholds + 1))
+        tpr = (pos[None, :] > thr[:, None]).sum(1) / pos.size
+        fpr = (neg[None, :] > thr[:, None]).sum(1) / neg.size
+        return thr[int(np.argmax(tpr - fpr))]
+
+    def test_one_model(self, test_pair_list, image_name2feature, is_normalize: bool = True):
+        import os
+        nps = len(test_pair_list)
+        scores = np.zeros((10, nps // 10), dtype=np.float32)
+        labels = np.zeros((10, nps // 10), dtype=np.int8)
+        for index, pair in enumerate(test_pair_list):
+            f1, f2 = image_name2feature[os.path.normpath(pair[0])], image_name2feature[os.path.normpath(pair[1])]
+            if not is_normalize:
+                f1, f2 = f1 / np.linalg.norm(f1), f2 / np.linalg.norm(f2)
+            scores[index // 600][index % 600] = np.dot(f1, f2)          # the reference hard-codes 600 pairs per fold
+            labels[index // 600][index % 600] = int(pair[2])
+        accs = []
+        keep = np.ones(10, dtype=bool)
+        for k in range(10):
+            keep[k] = False
+            thr = self.get_threshold(scores[keep].flatten(), labels[keep].flatten())
+            keep[k] = True
+            tp = np.sum(scores[k][labels[k] == 1] > thr)
+            tn = np.sum(scores[k][labels[k] == 0] < thr)
+            accs.append((tp + tn) / 600)
+        return float(np.mean(accs)), float(np.std(accs, ddof=1) / np.sqrt(10))

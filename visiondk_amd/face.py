@@ -275,6 +275,22 @@ class FeatureExtractor:
         self.model = model
         self.precise = precise
 
+    def extract_face(self, dataloader, device) -> dict:
+        """face_model.py:93-117 — {`<parent dir>/<file name>`: unit embedding} for a loader yielding (_, tensors, file_realpaths)"""
+        import os
+        from . import cbir
+        model = self.model
+        model.eval()
+        out = {}
+        with torch.no_grad():
+            for _, tensors, paths in dataloader:
+                tensors = tensors.to(device)
+                f = model.forward_precise(tensors) if self.precise else model(tensors)
+                f = cbir.l2_normalize(f.contiguous(), backend=getattr(model, "be", None)).cpu().numpy()
+                for path, feat in zip(paths, f):
+                    out[os.path.join(os.path.basename(os.path.dirname(path)), os.path.basename(path))] = feat
+        return out
+
     def extract_cbir(self, dataloader, device) -> np.ndarray:
         from . import cbir
         model = self.model
