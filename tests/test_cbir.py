@@ -123,3 +123,31 @@ def test_l2_normalize(be, dev):
     y = cbir.l2_normalize(x, backend=be)
     ref = torch.nn.functional.normalize(x, p=2, dim=1, eps=1e-12)
     torch.testing.assert_close(y, ref, rtol=1e-6, atol=1e-7)
+
+
+def test_index_memmap_save_and_load_like_the_reference(be, dev, tmp_path):
+    """cbir.index() with the reference's memmap arguments (engine/cbir/evaluation.py:110-152): save the extracted gallery, reload it (fp16 file -> float32
+    index, the reference's default load dtype), search."""
+    q, g = _data(5, 400, 64, seed=11)
+
+    class _Ext:
+        def extract_cbir(self, loader, device):
+            return loader
+
+    path = str(tmp_path / "gallery.mm")
+    device = "cuda" if be.device_only else "cpu"
+    idx = cbir.index(_Ext(), g, device, None, "Flat", memmap_save_path=path, backend=be, cap=2048)          # saved in the embeddings' dtype (float32)
+    s1, i1 = idx.search(q, 10)
+    idx2 = cbir.index(_Ext(), None, device, None, "Flat", memmap_feat_dim=64, memmap_dtype=np.float32, memmap_save_path=path, memmap_load_embedding=True,
+                      backend=be, cap=2048)
+    s2, i2 = idx2.search(q, 10)
+    np.testing.assert_array_equal(i1, i2); np.testing.assert_array_equal(s1, s2)
+    so, io = ocbir.flat_ip_search(q, g, 10)
+    np.testing.assert_array_equal(i1, io)
+    # fp16 file (the reference's default memmap_dtype for loading): values are the fp16-rounded gallery
+    path16 = str(tmp_path / "gallery16.mm")
+    mm = np.memmap(path16, shape=g.shape, mode="w+", dtype=np.float16); mm[:] = g.astype(np.float16); mm.flush()
+    idx3 = cbir.index(_Ext(), None, device, None, "Flat", memmap_feat_dim=64, memmap_save_path=path16, memmap_load_embedding=True, backend=be, cap=2048)
+    s3, i3 = idx3.search(q, 10)
+    so3, io3 = ocbir.flat_ip_search(q, g.astype(np.float16).astype(np.float32), 10)
+    np.testing.assert_array_equal(i3, io3)

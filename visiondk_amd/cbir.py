@@ -172,18 +172,32 @@ def merge_topk(scores: torch.Tensor, idx: torch.Tensor, backend: Optional[_lib.B
 
 
 # ---- the reference's two functions, same names / argument meaning (engine/cbir/evaluation.py:106,171) ----
-def index(extractor, gallery_dataloader, device, logger=None, index_factory_str: str = "Flat",
-          gallery_embeddings=None, **kw) -> FlatIPIndex:
-    """Encode the gallery (extractor.extract_cbir) and build the inner-product index.
-
-    `gallery_embeddings` may be passed directly (the memmap-load branch of the reference, :124-133).
-    """
+def index(extractor, gallery_dataloader, device, logger=None, index_factory: str = "Flat", memmap_feat_dim: Optional[int] = None,
+          memmap_dtype=np.float16, memmap_save_path: Optional[str] = None, memmap_load_embedding: bool = False, gallery_embeddings=None,
+          **kw) -> FlatIPIndex:
+    """engine/cbir/evaluation.py:104-169, same arguments: encode the gallery (extractor.extract_cbir) or load it from a memmap file
+    (`memmap_load_embedding`, dtype `memmap_dtype` — fp16 by default like the reference — reshaped to [-1, memmap_feat_dim]); optionally save the
+    freshly extracted embeddings to `memmap_save_path` in their own dtype, in batches of 10 000 rows; build the inner-product index; add the
+    embeddings as float32 ("faiss only accepts float32", :165).  `gallery_embeddings` may also be passed directly (device tensor or ndarray)."""
     if gallery_embeddings is None:
-        gallery_embeddings = extractor.extract_cbir(gallery_dataloader, device)
+        if memmap_load_embedding:
+            if memmap_save_path is None or memmap_feat_dim is None:
+                raise ValueError("memmap_load_embedding needs memmap_save_path and memmap_feat_dim")
+            dt = np.dtype(str(memmap_dtype).replace("torch.", "")) if not isinstance(memmap_dtype, (type, np.dtype)) else np.dtype(memmap_dtype)
+            gallery_embeddings = np.memmap(memmap_save_path, mode="r", dtype=dt).reshape(-1, memmap_feat_dim)
+        else:
+            gallery_embeddings = extractor.extract_cbir(gallery_dataloader, device)
+            if memmap_save_path is not None:
+                if logger is not None:
+                    logger.console(f"saving embeddings at {memmap_save_path}...")
+                mm = np.memmap(memmap_save_path, shape=gallery_embeddings.shape, mode="w+", dtype=gallery_embeddings.dtype)
+                for i in range(0, gallery_embeddings.shape[0], 10000):
+                    mm[i:i + 10000] = gallery_embeddings[i:i + 10000]
+                mm.flush()
     if isinstance(gallery_embeddings, np.ndarray):
-        gallery_embeddings = gallery_embeddings.astype(np.float32)  # "faiss only accepts float32" (:165)
+        gallery_embeddings = np.ascontiguousarray(gallery_embeddings.astype(np.float32))
     dim = gallery_embeddings.shape[-1]
-    idx = index_factory(dim, index_factory_str, METRIC_INNER_PRODUCT, device=device, **kw)
+    idx = globals()["index_factory"](dim, index_factory, METRIC_INNER_PRODUCT, device=device, **kw) if isinstance(index_factory, str) else index_factory
     if logger is not None:
         logger.console("Adding embeddings...")
     idx.train(gallery_embeddings)
