@@ -138,3 +138,13 @@ def test_train_step_bce_matches_reference_update(be, dev):
     eng = model.engine
     name, off, numel, shape = eng.entries[3]
     assert _rel(step.ema[off:off + numel].view(shape), ema_ref[name]) < 1e-4
+
+
+def test_progressive_resizing_other_resolution(be, dev):
+    """the same model at another input size (engine/vision_engine.py:181-222 changes the resolution between epochs)"""
+    model, ref = _pair(be, dev, img=32)
+    model.eval(); ref.eval()
+    for size in (32, 64):
+        x = torch.randn(2, 3, size, size)
+        with torch.no_grad():
+            assert _rel(model(x.to(dev)), ref(x)) < 3e-2

@@ -64,18 +64,20 @@ class ResNetEngine:
         self._logits: Optional[torch.Tensor] = None
         self._weights_version = None
 
-    def _cfg(self, batch: int) -> _abi.ResNetConfig:
+    def _cfg(self, batch: int, img: Optional[int] = None) -> _abi.ResNetConfig:
         s = self.spec
-        return _abi.ResNetConfig(batch, s.img_size, s.in_chans, (_abi.I32 * 4)(*s.widths), (_abi.I32 * 4)(*s.depths), s.num_classes, s.bn_eps, s.bn_momentum)
+        return _abi.ResNetConfig(batch, img or s.img_size, s.in_chans, (_abi.I32 * 4)(*s.widths), (_abi.I32 * 4)(*s.depths), s.num_classes, s.bn_eps, s.bn_momentum)
 
-    def _workspace(self, batch: int) -> torch.Tensor:
-        if self._ws is None or self._ws_batch != batch:
+    def _workspace(self, batch: int, img: int) -> torch.Tensor:
+        """keyed on (batch, image size): the reference's progressive resizing (engine/vision_engine.py:181-222) changes the input resolution between
+        epochs; a fully convolutional network with a global pool takes any multiple of 32"""
+        if self._ws is None or self._ws_batch != (batch, img):
             need = C.c_size_t(0)
-            cfg = self._cfg(batch)
+            cfg = self._cfg(batch, img)
             self.be.check(self.be.lib.vdk_resnet_workspace_bytes(C.byref(cfg), C.byref(need)), "vdk_resnet_workspace_bytes")
             self._ws = None
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
-            self._ws_batch = batch
+            self._ws_batch = (batch, img)
             self._logits = torch.empty((batch, self.cp), dtype=torch.float32, device=self.device)
         return self._ws
 
@@ -88,14 +90,14 @@ class ResNetEngine:
 
     def forward(self, x: torch.Tensor, training: bool) -> torch.Tensor:
         s = self.spec
-        if x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (s.in_chans, s.img_size, s.img_size):
-            raise ValueError(f"expected float32 [B, {s.in_chans}, {s.img_size}, {s.img_size}], got {tuple(x.shape)} {x.dtype}")
+        if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != s.in_chans or x.shape[2] != x.shape[3] or x.shape[2] % 32:
+            raise ValueError(f"expected float32 [B, {s.in_chans}, S, S] with S % 32 == 0, got {tuple(x.shape)} {x.dtype}")
         x = x.contiguous()
-        B = x.shape[0]
-        ws = self._workspace(B)
+        B, img = x.shape[0], x.shape[2]
+        ws = self._workspace(B, img)
         if self._weights_version != self.params._version:
             self.refresh_weights()
-        cfg = self._cfg(B)
+        cfg = self._cfg(B, img)
         be = self.be
         be.check(be.lib.vdk_resnet_forward(C.byref(cfg), be.ptr(x), be.ptr(self.params), be.ptr(self.buffers), be.ptr(self.wb16), be.ptr(self.wx), int(training),
                                            be.ptr(ws), ws.numel(), be.ptr(self._logits), be.stream()), "vdk_resnet_forward")
@@ -103,8 +105,8 @@ class ResNetEngine:
 
     def backward(self, dlogits_bf16: torch.Tensor, on_ready: Optional[Callable[[int, int], None]] = None) -> torch.Tensor:
         B = dlogits_bf16.shape[0]
-        assert dlogits_bf16.dtype == torch.bfloat16 and dlogits_bf16.shape[1] == self.cp and B == self._ws_batch
-        cfg = self._cfg(B)
+        assert dlogits_bf16.dtype == torch.bfloat16 and dlogits_bf16.shape[1] == self.cp and B == self._ws_batch[0]
+        cfg = self._cfg(B, self._ws_batch[1])
         be = self.be
         cb = _abi.GRAD_READY_FN(lambda user, off, n: on_ready(off, n)) if on_ready is not None else _abi.GRAD_READY_FN(0)
         be.check(be.lib.vdk_resnet_backward(C.byref(cfg), be.ptr(dlogits_bf16), be.ptr(self.params), be.ptr(self.wb16), be.ptr(self.wx), be.ptr(self._ws),
