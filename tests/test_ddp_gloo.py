@@ -139,3 +139,46 @@ def test_two_rank_face_step_and_sharded_search(tmp_path, emu):
     got_s = torch.cat([r0["s"], r1["s"]]).numpy(); got_i = torch.cat([r0["i"], r1["i"]]).numpy()
     np.testing.assert_array_equal(got_i, io)
     np.testing.assert_array_equal(got_s.view(np.uint32), so.view(np.uint32))
+
+
+# ---- BatchNorm CNN: 2-rank ResNetTrainStep ------------------------------------------------------------------------------------------------------------
+def _resnet_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["VDK_EMU_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.emu.emu_backend import load_emu
+    from visiondk_amd import comm, resnet
+    be = load_emu()
+    spec = resnet.ResNetSpec(img_size=32, widths=(8, 8, 16, 16), depths=(1, 1, 1, 1), num_classes=5)
+    model = resnet.ResNet(spec, device="cpu", backend=be, seed=50 + rank)
+    step = resnet.ResNetTrainStep(model, lr=0.05, loss="bce", ema=False, comm=comm.GradAllReduce(bucket_bytes=8_000))
+    init = model.engine.params.clone()
+    torch.manual_seed(7)
+    x = torch.randn(8, 3, 32, 32); t = (torch.rand(8, 5) > 0.5).float()
+    step.step(x[rank * 4:rank * 4 + 4], t[rank * 4:rank * 4 + 4])
+    torch.save({"init": init, "params": model.engine.params.clone(), "grads": model.engine.grads.clone(), "buffers": model.engine.buffers.clone()}, f"{out_dir}/rn{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_two_rank_resnet_step(tmp_path, emu):
+    port = 29500 + ((os.getpid() + 271) % 500)
+    mp.start_processes(_resnet_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "rn0.pt"); r1 = torch.load(tmp_path / "rn1.pt")
+    assert torch.equal(r0["init"], r1["init"]) and torch.equal(r0["params"], r1["params"]) and torch.equal(r0["grads"], r1["grads"])
+    # the reduced gradient == the sum of the two local gradients computed from rank 0's initial weights (BatchNorm statistics are per rank)
+    from visiondk_amd import resnet
+    spec = resnet.ResNetSpec(img_size=32, widths=(8, 8, 16, 16), depths=(1, 1, 1, 1), num_classes=5)
+    torch.manual_seed(7)
+    x = torch.randn(8, 3, 32, 32); t = (torch.rand(8, 5) > 0.5).float()
+    total = None
+    for r in range(2):
+        model = resnet.ResNet(spec, device="cpu", backend=emu, seed=0)
+        with torch.no_grad():
+            model.engine.params.copy_(r0["init"])
+        st = resnet.ResNetTrainStep(model, lr=0.0, momentum=0.0, weight_decay=0.0, loss="bce", ema=False)
+        st.step(x[r * 4:r * 4 + 4], t[r * 4:r * 4 + 4])
+        total = model.engine.grads.clone() if total is None else total + model.engine.grads
+    assert torch.equal(total, r0["grads"])

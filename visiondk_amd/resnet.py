@@ -253,8 +253,12 @@ class ResNetTrainStep:
     clip_grad_norm_(max_norm) -> SGD(momentum, weight_decay) -> EMA -> bf16 weight refresh.  `param_groups[0]['lr']` stays readable / writable."""
 
     def __init__(self, model: ResNet, lr: float, momentum: float = 0.937, weight_decay: float = 5e-4, loss: str = "bce", label_smoothing: float = 0.0,
-                 max_norm: float = 10.0, ema: bool = True):
+                 max_norm: float = 10.0, ema: bool = True, comm=None):
+        """comm: visiondk_amd.comm.GradAllReduce (one process per GPU): weights and BatchNorm buffers broadcast from rank 0 at construction, buffers again
+        before every forward (torch DDP's broadcast_buffers), the flat gradient all-reduced in buckets from inside vdk_resnet_backward; BatchNorm statistics
+        stay per rank (SyncBN is the reference's opt-in flag and is not built)."""
         assert loss in ("bce", "ce")
+        self.comm = comm
         self.model, self.eng, self.be = model, model.engine, model.engine.be
         self.loss, self.label_smoothing, self.max_norm = loss, label_smoothing, max_norm
         self.param_groups = [{"lr": lr, "momentum": momentum, "weight_decay": weight_decay}]
@@ -266,10 +270,20 @@ class ResNetTrainStep:
         self.be.check(self.be.lib.vdk_sumsq_workspace_bytes(C.byref(need)), "vdk_sumsq_workspace_bytes")
         self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.eng.device)
         self.loss_rows: Optional[torch.Tensor] = None
+        if comm is not None and comm.world_size > 1:
+            import torch.distributed as dist
+            comm.broadcast_params(self.eng.params)
+            dist.broadcast(self.eng.buffers, src=0, group=comm.group)
+            if ema:
+                self.ema.copy_(self.eng.params)
 
     def step(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         import math
         eng, be, model = self.eng, self.be, self.model
+        world = self.comm.world_size if self.comm is not None else 1
+        if world > 1:
+            import torch.distributed as dist
+            dist.broadcast(eng.buffers, src=0, group=self.comm.group)
         model._sync_flat()
         model.train()
         for m in model.modules():
@@ -288,11 +302,16 @@ class ResNetTrainStep:
         else:
             be.check(be.lib.vdk_softmax_ce(be.ptr(logits), eng.cp, B, ncls, be.ptr(y), None, 1.0, self.label_smoothing, 1.0 / B, be.ptr(self.loss_rows),
                                            be.ptr(self._dl), eng.cp, None, 0, be.stream()), "vdk_softmax_ce")
-        eng.backward(self._dl)
+        if world > 1:
+            self.comm.begin_step(eng.grads)
+            eng.backward(self._dl, on_ready=self.comm.on_grad_ready)
+            self.comm.finish_step()
+        else:
+            eng.backward(self._dl)
         be.check(be.lib.vdk_sumsq_f32(be.ptr(eng.grads), eng.n_floats, be.ptr(self._normsq), be.ptr(self._ws), self._ws.numel(), be.stream()), "vdk_sumsq_f32")
         d = 0.9999 * (1 - math.exp(-self.updates / 2000)) if self.ema is not None else 0.0
         be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema), be.ptr(eng.wb16), eng.n_floats, g["lr"],
-                                     g["momentum"], g["weight_decay"], 1.0, be.ptr(self._normsq), self.max_norm, d, int(self.updates == 1), be.stream()),
+                                     g["momentum"], g["weight_decay"], 1.0 / world, be.ptr(self._normsq), self.max_norm, d, int(self.updates == 1), be.stream()),
                  "vdk_sgd_step")
         eng.refresh_weights(skip_wb16=True)
         return self.loss_rows
