@@ -106,11 +106,14 @@ typedef struct VdkGemmDesc {
                               dY[t][out], X[t][in]); needs K and the split size % 64 == 0, M % 8 == 0, lda/ldb % 8 == 0 */
   int32_t a_row_group;     /* trans=1 only, > 0: A's k-row t lives at physical row t + t/a_row_group + 1 (token buffer minus cls rows) */
   const VdkConvGeom* conv; /* NULL: dense A.  else: implicit-GEMM convolution operand (lda ignored) */
+  float* a_colsum;         /* NULL, or f32 [vdk_gemm_a_colsum_rows(M,N,K)][K]: by-product of the NT 256x256 kernel, partial column sums of A, one row per 256-row tile
+                              (sum the rows -> colsum(A) = bias gradient of the Linear whose dY is this dgrad GEMM's A); error if that kernel does not serve the problem */
 } VdkGemmDesc;
 int vdk_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t splitk, size_t* bytes);
 int vdk_gemm_bf16_nt(const VdkGemmDesc* d, void* ws, size_t ws_bytes, void* stream);
 /* tests / A-B benchmarking only: 0 = automatic choice, 1 = 128x128 register-staged kernel, 2 = 256x256 LDS-DMA kernel
  * (the latter still requires K and the split size to be multiples of 64). */
+int vdk_gemm_a_colsum_rows(int32_t M, int32_t N, int32_t K);   /* rows of VdkGemmDesc.a_colsum, 0 = by-product not available for this problem */
 int vdk_gemm_force_kernel(int32_t which);
 /* profiling aid: when non-NULL, every 256x256 workgroup writes 4 shader-cycle stamps (start, operands landed, main loop done,
  * stores issued) to buf[4 * workgroup]; NULL (default) disables it */

@@ -149,3 +149,21 @@ def test_softmax_rows_f32(be, dev):
     y = ops.softmax_rows_f32(x.clone().to(dev), cols=197, scale=0.125, backend=be).cpu()
     torch.testing.assert_close(y[:, :197], torch.softmax(x[:, :197] * 0.125, dim=1), rtol=1e-5, atol=1e-7)
     assert (y[:, 197:] == 0).all()
+
+
+def test_gemm256_a_colsum_byproduct(be, dev):
+    """bias gradient fused into the dgrad GEMM: the 256x256 NT kernel's tn == 0 workgroups also emit column sums of the A operand"""
+    torch.manual_seed(5)
+    M, N, K = 512, 512, 192
+    a = torch.randn(M, K).bfloat16(); b = torch.randn(N, K).bfloat16()
+    be.lib.vdk_gemm_force_kernel(2)
+    try:
+        rows = be.lib.vdk_gemm_a_colsum_rows(M, N, K)
+        assert rows == M // 256
+        part = torch.full((rows, K), float("nan"), dtype=torch.float32, device=dev)
+        out = ops.gemm_nt(a.to(dev), b.to(dev), out_dtype=torch.float32, a_colsum=part, backend=be)
+    finally:
+        be.lib.vdk_gemm_force_kernel(0)
+    torch.testing.assert_close(out.cpu(), a.float() @ b.float().t(), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(part.sum(0).cpu(), a.float().sum(0), rtol=1e-5, atol=1e-4)
+    assert be.lib.vdk_gemm_a_colsum_rows(300, 512, 192) == 0        # ragged M: by-product not available

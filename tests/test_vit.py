@@ -146,3 +146,30 @@ def test_fused_sam_step_vs_reference_update_sam(be, dev):
     sd = model.state_dict()
     for n, p in ref.named_parameters():
         assert _rel(sd[n].cpu() - init_sd[n], p.detach() - init_sd[n]) < 8e-2, n
+
+
+def test_backward_bias_gradients_from_dgrad_gemm_byproduct(be, dev):
+    """With T % 256 == 0 and the 256x256 kernel in use, the Linear bias gradients come out of the dgrad GEMMs (VdkGemmDesc.a_colsum) instead of a separate
+    pass over dY: same gradients as the stand-alone column-sum path."""
+    spec = vit.VitSpec(img_size=32, patch_size=16, in_chans=3, num_classes=8, dim=64, depth=2, heads=1, mlp_dim=256, ln_eps=1e-6)
+    model = vit.VisionTransformer(spec, device=dev, backend=be, seed=3)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias"):
+                p.add_(torch.randn_like(p) * 0.1)
+    eng = model.engine
+    torch.manual_seed(0)
+    x = torch.randn(256, 3, 32, 32, device=dev)                       # T = 256 * 5 tokens: a whole number of 256-row tiles
+    dl = (torch.randn(256, eng.cp, device=dev) * 0.1).bfloat16()
+    grads = {}
+    for mode in (1, 2):                                               # 1: 128x128 kernel -> stand-alone colsum; 2: 256x256 kernel -> by-product
+        be.lib.vdk_gemm_force_kernel(mode)
+        try:
+            eng.forward(x)
+            grads[mode] = eng.backward(dl).clone()
+        finally:
+            be.lib.vdk_gemm_force_kernel(0)
+    for name, off, numel, shape in eng.entries:
+        a, b = grads[2][off:off + numel], grads[1][off:off + numel]
+        rel = ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+        assert rel < (2e-3 if name.endswith("bias") else 2e-2), (name, rel)

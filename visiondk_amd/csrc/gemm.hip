@@ -393,7 +393,8 @@ __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float
 
 template <bool TN, int E>
 __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * H_TILEBUF];   // 128 KB, ALL of the kernel's LDS
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * H_TILEBUF];   // 128 KB: operand buffers, reused by the epilogue
+  __shared__ float cs_lds[8][64];                                              // + 2 KB: per-wave column sums of the a_colsum by-product
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w >> 2, wc = w & 3, hi = lane >> 5, l31 = lane & 31;
@@ -454,6 +455,14 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
   // behind an lgkmcnt(0) + barrier.  RAW: each wait is followed by two barriers before the first read of the data it covers.
   // vmcnt is never 0 in steady state: 2-8 DMAs stay in flight across every barrier.
   s16x8 a0[2][4], a1[2][4], b0[4], b1[4];
+  // optional by-product (NT only): column sums of the A operand = bias gradient of the Linear whose dY this dgrad GEMM reads.  Only the tn == 0
+  // workgroup of a row tile does it; wave w adds region rows 16w .. 16w+15 of RA0 (in RA) and RA1 (in RB), lane = k column, straight from the staged tile.
+  // Lane = (k pair kp, row parity rh): 8 ds_read_b32 per region; the 8 waves' sums meet in cs_lds one K-tile later (wave-row 1 lags one interval).
+  // The K-tiles of a row tile are dealt round-robin to its ntn workgroups (tile t belongs to tn == t % ntn): every workgroup pays 1/ntn of the extra
+  // LDS reads instead of one workgroup per row tile paying all of them and holding up its whole round.
+  const bool cs_en = !TN && p.colsum_part != nullptr;
+  float cs0 = 0.f, cs1 = 0.f;
+  const int cs_kp = lane & 31, cs_rh = lane >> 5;
   for (int t = 0; t < nk; ++t) {
     const int cur = t & 1;
     const unsigned char* RA0 = H_REG(cur, 0); const unsigned char* RA1 = H_REG(cur, 1);
@@ -467,6 +476,23 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
       for (int ks = 0; ks < 4; ++ks) a0[rt][ks] = H_FRAG_A(RA0, rt, ks);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) b1[ks] = H_FRAG_B(RB1, ks);
+    const bool cs_on = cs_en && (t % ntn) == tn;
+    if (cs_en) {
+      if (t > 0 && w == 0 && ((t - 1) % ntn) == tn) {   // K-tile t-1: all eight waves' sums are in cs_lds (the lagging wave-row wrote them one barrier ago)
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v += cs_lds[i][lane];
+        p.colsum_part[(long)tm * p.K + kbeg + (t - 1) * 64 + lane] = v;
+      }
+    }
+    if (cs_on) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rr = w * 16 + 2 * i + cs_rh;
+        const unsigned u = *(const unsigned*)(RA0 + rr * 128 + (((cs_kp >> 2) ^ ((rr >> 1) & 7)) * 16) + (cs_kp & 3) * 4);
+        cs0 += bf_lo(u); cs1 += bf_hi(u);
+      }
+    }
     if (t + 1 < nk) { H_WAIT_VM(6); } else { H_WAIT_VM(0); }
     H_BAR();
     // ---- MA --------------------------------------------------------------------------------------------------------
@@ -488,6 +514,18 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) a1[rt][ks] = H_FRAG_A(RA1, rt, ks);
+    if (cs_on) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rr = w * 16 + 2 * i + cs_rh;
+        const unsigned u = *(const unsigned*)(RA1 + rr * 128 + (((cs_kp >> 2) ^ ((rr >> 1) & 7)) * 16) + (cs_kp & 3) * 4);
+        cs0 += bf_lo(u); cs1 += bf_hi(u);
+      }
+      cs0 += __shfl_xor(cs0, 32); cs1 += __shfl_xor(cs1, 32);
+      if (cs_rh == 0) { cs_lds[w][2 * cs_kp] = cs0; cs_lds[w][2 * cs_kp + 1] = cs1; }
+      cs0 = 0.f; cs1 = 0.f;
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the sums are in LDS before this wave passes the barrier (wave 0 reads them one interval later)
+    }
     if (t + 1 < nk) { H_WAIT_VM(2); } else { H_WAIT_VM(0); }
     H_BAR();
     // ---- MB --------------------------------------------------------------------------------------------------------
@@ -506,6 +544,12 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
     H_BAR();
   }
   if (wr == 0) H_BAR();                                   // match the barrier count of the lagging wave-row
+  if (cs_en && nk > 0 && w == 0 && ((nk - 1) % ntn) == tn) {   // last K-tile's column sums (every wave is past its final RB)
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v += cs_lds[i][lane];
+    p.colsum_part[(long)tm * p.K + kbeg + (nk - 1) * 64 + lane] = v;
+  }
   if (p.dbg) t_main = __builtin_readcyclecounter();
 
   // ---- epilogue: wave-private 16 KB LDS slab, 64 rows x 64 fp32 at a time -> 8-wide coalesced row chunks ---------
@@ -625,6 +669,13 @@ static int g_force_kernel = 0;   // 0 auto, 1 = 128x128 register-staged, 2 = 256
 
 extern "C" {
 
+/* rows of the a_colsum by-product ([rows][K] f32) if the NT problem (M, N, K) is served by the 256x256 kernel and M % 256 == 0, else 0 */
+int vdk_gemm_a_colsum_rows(int32_t M, int32_t N, int32_t K) {
+  const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+  const bool big = g_force_kernel == 2 || (g_force_kernel == 0 && (K % 64 == 0) && tiles256 >= 128 && M >= 256 && N >= 256);
+  return (big && (K % 64 == 0) && (M % 256 == 0)) ? (M / 256) : 0;
+}
+
 int vdk_gemm_force_kernel(int32_t which) { g_force_kernel = which; return VDK_OK; }
 int vdk_gemm_debug_stamps(void* device_u64_buffer) { g_dbg_ptr = device_u64_buffer; return VDK_OK; }
 
@@ -695,6 +746,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   p.c_dtype = d->c_dtype; p.bias = (const float*)d->bias; p.residual = (const float*)d->residual; p.ldr = d->ldr;
   p.act = d->act; p.aux = (bf16_t*)d->aux; p.ldaux = d->ldaux; p.alpha = d->alpha; p.row_group = d->row_group; p.a_row_group = d->a_row_group;
   p.splitk = splitk; p.slabs = nullptr; p.dbg = (unsigned long long*)g_dbg_ptr;
+  p.colsum_part = nullptr;
   p.conv_on = d->conv != nullptr;
   if (d->conv) {
     const VdkConvGeom* c = d->conv;
@@ -745,6 +797,10 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
       default: LAUNCH256(true, E_GENERIC); break;
     }
   } else if (big && (d->K % 64 == 0) && (kps % 64 == 0)) {
+    if (d->a_colsum) {
+      if (d->M % 256) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: a_colsum needs M % 256 == 0");
+      p.colsum_part = d->a_colsum;
+    }
     switch (E) {
       case 0: LAUNCH256(false, 0); break;
       case E_BIAS: LAUNCH256(false, E_BIAS); break;
@@ -758,6 +814,8 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
     }
   }
 #undef LAUNCH256
+  else if (d->a_colsum)
+    return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: a_colsum is a by-product of the 256x256 NT kernel only (see vdk_gemm_a_colsum_rows)");
   else if (d->conv)
     hipLaunchKernelGGL(gemm_bf16_nt_kernel<true>, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256), 0, stream, p);
   else

@@ -19,6 +19,7 @@ struct GemmParams {
   int a_row_group;
   int splitk; int k_per_split;
   float* slabs;
+  float* colsum_part;        // 256-kernel, NT only: per (row tile, wave) column sums of A, f32 [ceil(M/256)*8][K] (bias gradient fused into the dgrad GEMM)
   // implicit-GEMM convolution (conv_on): A is an NHWC tensor gathered on the fly, see VdkConvGeom
   int conv_on, cCin, cH, cW, cOH, cOW, cKH, cKW, cstride, cpad, ctrans;
   unsigned long long* dbg;   // debug only: 4 cycle stamps per workgroup (start, operands landed, main loop done, end)

@@ -35,6 +35,7 @@ int vdk_cls_rows(float*, int64_t, int32_t, int32_t, const float*, const float*, 
 int vdk_cast_f32_bf16(const float*, void*, int64_t, void*);
 int vdk_transpose_cast_f32_bf16(const float*, int64_t, int32_t, int32_t, void*, int64_t, int32_t, void*);
 int vdk_gemm_f32_nt(const VdkGemmF32Desc*, void*);
+int vdk_gemm_a_colsum_rows(int32_t, int32_t, int32_t);
 int vdk_softmax_rows_f32(float*, int64_t, int64_t, int32_t, float, void*);
 int vdk_patchify_f32(const float*, int32_t, int32_t, int32_t, int32_t, int32_t, float*, void*);
 }
@@ -234,6 +235,7 @@ static int vit_plan(const VitDims& d, WsPlan* w) {
   vdk_layernorm_bwd_workspace_bytes(d.T, d.D, &w->lnws_bytes); w->lnws = w_take(cur, w->lnws_bytes);
   size_t cs = (size_t)((tcols + 63) / 64) * trows * 4;   // per-row-tile column sums written by the dY transposes ...
   { size_t cs2 = 0; vdk_colsum_bf16_workspace_bytes(d.T, (int)trows, &cs2); if (cs2 > cs) cs = cs2; }   // ... or by vdk_colsum_bf16
+  { size_t cs3 = (size_t)((d.T + 255) / 256) * trows * 4; if (cs3 > cs) cs = cs3; }                      // ... or by the dgrad GEMM's a_colsum by-product
   w->csws_bytes = cs; w->csws = w_take(cur, cs);
   w->dhf = w_take(cur, (size_t)d.B * D * 2);
   w->dposall = w_take(cur, (size_t)d.N * D * 4);
@@ -406,6 +408,21 @@ static int linear_wgrad(hipStream_t s, const VitDims& d, const WsPlan& w, char* 
   return VDK_OK;
 }
 
+// dgrad GEMM  dX[rows, in] = act'(dY[rows, out] . Wt[in, out]^T)  that also delivers db = colsum(dY) for the same Linear: when the 256x256 NT kernel
+// serves the problem the column sums are a by-product of its A tiles (no extra pass over dY); returns 1 in *fused then, else the caller runs vdk_colsum_bf16.
+static int dgrad_with_bias(hipStream_t s, const WsPlan& w, char* base, const bf16_t* dY, int64_t lddy, const bf16_t* Wt, int64_t ldw, void* dX, int64_t lddx, int rows,
+                           int in, int out, int act, void* aux, int64_t ldaux, float* db, int* fused) {
+  const int prow = vdk_gemm_a_colsum_rows(rows, in, out);
+  *fused = (db && prow > 0 && (size_t)prow * out * 4 <= w.csws_bytes) ? 1 : 0;
+  VdkGemmDesc g = {};
+  g.A = dY; g.lda = lddy; g.B = Wt; g.ldb = ldw; g.C = dX; g.ldc = lddx; g.M = rows; g.N = in; g.K = out; g.c_dtype = VDK_BF16; g.act = act; g.aux = aux;
+  g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = 1;
+  if (*fused) g.a_colsum = (float*)(base + w.csws);
+  RC(vdk_gemm_bf16_nt(&g, nullptr, 0, s));
+  if (*fused) RC(vdk_reduce_rows_f32((const float*)(base + w.csws), out, prow, out, db, 1.0f, s));
+  return VDK_OK;
+}
+
 // dlogits: bf16 [B, Cp] (what vdk_softmax_ce writes, padding columns zero); in feature mode (num_classes = 0): f32 [B*N, D].  grads: flat fp32, param layout,
 // fully overwritten (zero_grad semantics).  on_ready(user, offset, numel) is called on the host right after the
 // kernels producing grads[offset, offset+numel) have been enqueued (reverse layer order) so that a data-parallel
@@ -474,23 +491,44 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
     bf16_t* dxab = DXAB(l); bf16_t* dxmb = DXMB(l); bf16_t* du = DU(l); bf16_t* dqkv = DQKV(l);
     // WAR: this layer overwrites the parity buffers the side stream read two layers ago
     if (s2 != s && l + 2 <= d.L - 1) { hipEvent_t e; RC(ev_get(EV_SIDE_DONE + l + 3, &e)); if (hipStreamWaitEvent(s, e, 0) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vit: wait failed"); }
+    // Every Linear: dgrad GEMM on the main stream (its bias gradient is a by-product of the A tiles when the 256x256 kernel serves it), weight gradient
+    // straight from dY / X on the side stream.  The column sums live in csws, which the side stream's fallback paths also use: fused mode is main-stream only.
+    int fz = 0;
+    const bool one_stream = (s2 == s);
     // MLP branch: dxa / dxab hold dL/dx_out
     RC(ev_order(ev_p++, s, s2));
-    RC(linear_wgrad(s2, d, w, base, dxab, D, g, M, T, d.Tp, D, M, grads + b.fc2_w, grads + b.fc2_b, 0));
-    RC(gemm(s, dxab, D, wt + p.blkT[l].fc2, D, du, M, T, M, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_DGELU, u, M, 1, 0, nullptr, 0));   // du
-    RC(ev_order(ev_p++, s, s2));
-    RC(linear_wgrad(s2, d, w, base, du, M, h2, D, T, d.Tp, M, D, grads + b.fc1_w, grads + b.fc1_b, 0));
-    RC(gemm(s, du, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // dh2
+    if (one_stream) {
+      RC(dgrad_with_bias(s, w, base, dxab, D, wt + p.blkT[l].fc2, D, du, M, T, M, D, VDK_ACT_DGELU, u, M, grads + b.fc2_b, &fz));                       // du
+      RC(linear_wgrad(s2, d, w, base, dxab, D, g, M, T, d.Tp, D, M, grads + b.fc2_w, fz ? nullptr : grads + b.fc2_b, 0));
+      RC(dgrad_with_bias(s, w, base, du, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, VDK_ACT_NONE, nullptr, 0, grads + b.fc1_b, &fz));                  // dh2
+      RC(linear_wgrad(s2, d, w, base, du, M, h2, D, T, d.Tp, M, D, grads + b.fc1_w, fz ? nullptr : grads + b.fc1_b, 0));
+    } else {
+      RC(linear_wgrad(s2, d, w, base, dxab, D, g, M, T, d.Tp, D, M, grads + b.fc2_w, grads + b.fc2_b, 0));
+      RC(gemm(s, dxab, D, wt + p.blkT[l].fc2, D, du, M, T, M, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_DGELU, u, M, 1, 0, nullptr, 0));   // du
+      RC(ev_order(ev_p++, s, s2));
+      RC(linear_wgrad(s2, d, w, base, du, M, h2, D, T, d.Tp, M, D, grads + b.fc1_w, grads + b.fc1_b, 0));
+      RC(gemm(s, du, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // dh2
+    }
     RC(vdk_layernorm_bwd(dsm, D, VDK_BF16, xmid, D, mean2, rstd2, params + b.n2w, dxa, D, T, D, dxm, D, dxmb, D, grads + b.n2w, grads + b.n2b, lnws,
                          w.lnws_bytes, s));
     // attention branch: dxm / dxmb hold dL/dx_mid
     RC(ev_order(ev_p++, s, s2));
-    RC(linear_wgrad(s2, d, w, base, dxmb, D, o, D, T, d.Tp, D, D, grads + b.proj_w, grads + b.proj_b, 0));
-    RC(gemm(s, dxmb, D, wt + p.blkT[l].proj, D, dsm, D, T, D, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // do
+    if (one_stream) {
+      RC(dgrad_with_bias(s, w, base, dxmb, D, wt + p.blkT[l].proj, D, dsm, D, T, D, D, VDK_ACT_NONE, nullptr, 0, grads + b.proj_b, &fz));              // do
+      RC(linear_wgrad(s2, d, w, base, dxmb, D, o, D, T, d.Tp, D, D, grads + b.proj_w, fz ? nullptr : grads + b.proj_b, 0));
+    } else {
+      RC(linear_wgrad(s2, d, w, base, dxmb, D, o, D, T, d.Tp, D, D, grads + b.proj_w, grads + b.proj_b, 0));
+      RC(gemm(s, dxmb, D, wt + p.blkT[l].proj, D, dsm, D, T, D, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // do
+    }
     RC(vdk_attention_bwd(qkv, 3 * D, o, dsm, D, lse, dqkv, 3 * D, dvec, d.B, d.N, d.H, 64, 0.125f, s));                                    // dqkv
     RC(ev_order(ev_p++, s, s2));
-    RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, grads + b.qkv_b, 0));
-    RC(gemm(s, dqkv, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));  // dh1
+    if (one_stream) {
+      RC(dgrad_with_bias(s, w, base, dqkv, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, VDK_ACT_NONE, nullptr, 0, grads + b.qkv_b, &fz));    // dh1
+      RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, fz ? nullptr : grads + b.qkv_b, 0));
+    } else {
+      RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, grads + b.qkv_b, 0));
+      RC(gemm(s, dqkv, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));  // dh1
+    }
     RC(vdk_layernorm_bwd(dsm, D, VDK_BF16, xin, D, mean1, rstd1, params + b.n1w, dxm, D, T, D, dxa, D, DXAB(l - 1), D, grads + b.n1w, grads + b.n1b, lnws,
                          w.lnws_bytes, s));
     if (s2 != s) { hipEvent_t e; RC(ev_get(EV_SIDE_DONE + l + 1, &e)); if (hipEventRecord(e, s2) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vit: record failed"); }
