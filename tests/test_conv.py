@@ -6,7 +6,7 @@ import torch.nn.functional as F
 from visiondk_amd import ops
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 64), (1, 7, 7, 16), (2, 14, 10, 72), (1, 20, 17, 8), (1, 14, 14, 64), (1, 7, 28, 8)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 64), (1, 7, 7, 16), (2, 14, 10, 72), (1, 20, 17, 8), (1, 14, 14, 64), (1, 7, 28, 8), (2, 56, 56, 24), (2, 28, 28, 40), (3, 14, 14, 72), (2, 7, 7, 136), (1, 14, 28, 8)])   # square 56/28/14/7: the row-streaming kernel
 def test_dwconv7_fwd_dgrad_wgrad(be, dev, B, H, W, C):
     torch.manual_seed(0)
     x = torch.randn(B, C, H, W)

@@ -91,6 +91,98 @@ __global__ __launch_bounds__(TW * (DWF_CC / 4)) void dwconv7_kernel(const float*
   }
 }
 
+// Row-streaming variant for ConvNeXt's square maps (W = 56 / 28 / 14 / 7): one workgroup owns an image and a channel chunk and walks down the map in
+// strips of 7 output rows, keeping the 13 input rows a strip needs in an LDS ring (6 of them are reused by the next strip) while the next 7 rows are
+// prefetched into registers.  Every input element is read from HBM once (the tiled kernel above re-reads its halo: 2.65x), x-halo columns are zeros.
+// threads = W columns x CC/4 channel quads; a thread owns one column x one quad and produces the strip's 7 outputs of that column.
+template <int W, int CC>
+__global__ __launch_bounds__(W * (CC / 4)) void dwconv7_rows_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
+                                                                      const float* res, float* out /* may alias res */, bf16_t* __restrict__ outb, int B, int C,
+                                                                      int flip) {
+  constexpr int H = W, IW = W + 6, CQ = CC / 4, NT = W * CQ, RD = 13, NEW = 7;
+  constexpr int PF = (NEW * IW * CQ + NT - 1) / NT;                      // prefetch registers (float4) per thread
+  __shared__ __attribute__((aligned(16))) float ring[RD * IW * CC];
+  __shared__ __attribute__((aligned(16))) float ws[49 * CC];
+  const int tid = threadIdx.x;
+  const int nchunk = (C + CC - 1) / CC;
+  const int c0 = (blockIdx.x % nchunk) * CC, b = blockIdx.x / nchunk;    // channel chunk fastest: neighbouring workgroups share cache lines
+  for (int i = tid; i < 49 * CQ; i += NT) {
+    const int cq = i % CQ, t = i / CQ, c = c0 + cq * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) v = *(const f32x4*)(wt + (long)(flip ? 48 - t : t) * C + c);
+    *(f32x4*)(ws + t * CC + cq * 4) = v;
+  }
+  // element e of a block of rows [y0, y0 + n): row y0 + e / (IW*CQ), padded column px = (e / CQ) % IW (image column px - 3), quad e % CQ
+  auto load_elem = [&](int y, int px, int cq) -> f32x4 {
+    const int x = px - 3, c = c0 + cq * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (y >= 0 && y < H && x >= 0 && x < W && c < C) v = *(const f32x4*)(in + (((long)b * H + y) * W + x) * C + c);
+    return v;
+  };
+  // first strip: rows -3 .. 9 straight into the ring (row y lives in slot (y + 3) % 13)
+  for (int e = tid; e < RD * IW * CQ; e += NT) {
+    const int cq = e % CQ, px = (e / CQ) % IW, r = e / (CQ * IW);
+    *(f32x4*)(ring + ((r % RD) * IW + px) * CC + cq * 4) = load_elem(r - 3, px, cq);
+  }
+  __syncthreads();
+  const int cq = tid % CQ, col = tid / CQ, c = c0 + cq * 4;
+  f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+  if (bias && c < C) b4 = *(const f32x4*)(bias + c);
+  for (int s0 = 0; s0 < H; s0 += NEW) {
+    // prefetch the 7 new rows of the next strip: rows s0 + 10 .. s0 + 16
+    f32x4 pf[PF];
+    const bool more = s0 + NEW < H;
+    if (more) {
+#pragma unroll
+      for (int k = 0; k < PF; ++k) {
+        const int e = tid + k * NT;
+        if (e < NEW * IW * CQ) { const int q = e % CQ, px = (e / CQ) % IW, r = e / (CQ * IW); pf[k] = load_elem(s0 + 10 + r, px, q); }
+      }
+    }
+    f32x4 acc[NEW];
+#pragma unroll
+    for (int o = 0; o < NEW; ++o) acc[o] = b4;
+#pragma unroll 1
+    for (int j = 0; j < 7; ++j) {
+      f32x4 wj[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) wj[i] = *(const f32x4*)(ws + (i * 7 + j) * CC + cq * 4);
+#pragma unroll
+      for (int r = 0; r < RD; ++r) {                                   // input row s0 - 3 + r, ring slot (s0 + r) % 13
+        const f32x4 v = *(const f32x4*)(ring + (((s0 + r) % RD) * IW + col + j) * CC + cq * 4);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          const int o = r - i;
+          if (o >= 0 && o < NEW) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(v[e], wj[i][e], acc[o][e]);
+          }
+        }
+      }
+    }
+    if (c < C) {
+#pragma unroll
+      for (int o = 0; o < NEW; ++o) {
+        const long off = (((long)b * H + s0 + o) * W + col) * C + c;
+        f32x4 v = acc[o];
+        if (res) { const f32x4 r4 = *(const f32x4*)(res + off); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
+        if (out) *(f32x4*)(out + off) = v;
+        if (outb) *(u32x2*)(outb + off) = (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+      }
+    }
+    if (more) {
+      __syncthreads();                                                   // everybody is done reading rows s0 - 3 .. s0 + 3
+#pragma unroll
+      for (int k = 0; k < PF; ++k) {
+        const int e = tid + k * NT;
+        if (e < NEW * IW * CQ) { const int q = e % CQ, px = (e / CQ) % IW, r = e / (CQ * IW); *(f32x4*)(ring + (((s0 + 13 + r) % RD) * IW + px) * CC + q * 4) = pf[k]; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+
 // ------------------------------------------------------------------------------------ K6 weight / bias gradient
 // dw[c][7i+j] = sum_{b,y,x} dy[b,y,x,c] * in[b, y+i-3, x+j-3, c];  db[c] = sum dy[b,y,x,c].
 // grid: (S slices, ceil(C / 64)); 448 threads = 7 vertical taps x 64 channels; a workgroup walks its share of the (image, tile) list,
@@ -240,10 +332,18 @@ int vdk_dwconv7_fwd(const float* in, const float* wt, const float* bias, const f
 #define DW_LAUNCH(TH, TW)                                                                                                                          \
   hipLaunchKernelGGL((dwconv7_kernel<TH, TW>), dim3((unsigned)(((W + TW - 1) / TW) * ((H + TH - 1) / TH)) * (unsigned)B, cy), dim3(TW * (DWF_CC / 4)), 0, \
                      (hipStream_t)stream, in, wt, bias, res, out, (bf16_t*)out_bf16, (int)B, (int)H, (int)W, (int)C, (int)flip)
-  if (H % 7 == 0 && W % 14 == 0) DW_LAUNCH(7, 14);
+#define DW_ROWS(WW, CCC)                                                                                                                             \
+  hipLaunchKernelGGL((dwconv7_rows_kernel<WW, CCC>), dim3((unsigned)B * (unsigned)((C + CCC - 1) / CCC)), dim3(WW * (CCC / 4)), 0, (hipStream_t)stream, in, wt, bias, \
+                     res, out, (bf16_t*)out_bf16, (int)B, (int)C, (int)flip)
+  if (H == W && W == 56) DW_ROWS(56, 16);
+  else if (H == W && W == 28) DW_ROWS(28, 32);
+  else if (H == W && W == 14) DW_ROWS(14, 64);
+  else if (H == W && W == 7) DW_ROWS(7, 128);
+  else if (H % 7 == 0 && W % 14 == 0) DW_LAUNCH(7, 14);
   else if (H % 7 == 0 && W % 7 == 0) DW_LAUNCH(7, 7);
   else DW_LAUNCH(8, 8);
 #undef DW_LAUNCH
+#undef DW_ROWS
   return vdk_check_launch("vdk_dwconv7_fwd");
 }
 

@@ -39,6 +39,7 @@ int vdk_conv2x2_wgrad_unpermute(const float*, float*, int32_t, int32_t, void*);
 int vdk_layerscale_weight_prep(const float*, const float*, const float*, void*, void*, float*, int32_t, int32_t, void*);
 int vdk_layerscale_grad(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int32_t, int32_t, void*);
 int vdk_gemm_f32_nt(const VdkGemmF32Desc*, void*);
+int vdk_gemm_a_colsum_rows(int32_t, int32_t, int32_t);
 int vdk_patchify_f32(const float*, int32_t, int32_t, int32_t, int32_t, int32_t, float*, void*);
 int vdk_space_to_depth2_f32(const float*, float*, int32_t, int32_t, int32_t, int32_t, void*);
 }
@@ -185,6 +186,7 @@ void cn_plan(const CnDims& d, WsPlan* w) {
     const size_t c1 = (size_t)((up(rows, 64) + 63) / 64) * out * 4;
     if (c2 > cs) cs = c2;
     if (c1 > cs) cs = c1;
+    { const size_t c3 = (size_t)((rows + 255) / 256) * out * 4; if (c3 > cs) cs = c3; }   // a_colsum by-product of the dgrad GEMM
     if (rows % 64) { const size_t t = (size_t)(out > in ? out : in) * up(rows, 64) * 2; if (t > tr) tr = t; }
   };
   wg(d.C[0], d.Kst, d.R[0]);
@@ -239,18 +241,34 @@ int linear_wgrad(hipStream_t s, const WsPlan& w, char* base, const bf16_t* dY, c
     g.A = dY; g.lda = out; g.B = X; g.ldb = in; g.C = dW; g.ldc = in; g.M = out; g.N = in; g.K = rows; g.c_dtype = VDK_F32;
     g.alpha = 1.0f; g.splitk = wgrad_splitk_tn(out, in, rows); g.trans = 1;
     RC(vdk_gemm_bf16_nt(&g, base + w.slabs, w.slabs_bytes, s));
-    return vdk_colsum_bf16(dY, out, rows, out, db, base + w.csws, w.csws_bytes, s);
+    return db ? vdk_colsum_bf16(dY, out, rows, out, db, base + w.csws, w.csws_bytes, s) : VDK_OK;
   }
   const int rp = (int)up(rows, 64);
   bf16_t* tA = (bf16_t*)(base + w.tA); bf16_t* tB = (bf16_t*)(base + w.tB);
-  float* csp = (float*)(base + w.csws);
+  float* csp = db ? (float*)(base + w.csws) : nullptr;
   RC(vdk_transpose_bf16(dY, out, rows, out, tA, rp, rp, 0, csp, s));
   RC(vdk_transpose_bf16(X, in, rows, in, tB, rp, rp, 0, nullptr, s));
   VdkGemmDesc g = {};
   g.A = tA; g.lda = rp; g.B = tB; g.ldb = rp; g.C = dW; g.ldc = in; g.M = out; g.N = in; g.K = rp; g.c_dtype = VDK_F32; g.alpha = 1.0f;
   g.splitk = wgrad_splitk(out, in, rp);
   RC(vdk_gemm_bf16_nt(&g, base + w.slabs, w.slabs_bytes, s));
-  return vdk_reduce_rows_f32(csp, out, (rp + 63) / 64, out, db, 1.0f, s);
+  return db ? vdk_reduce_rows_f32(csp, out, (rp + 63) / 64, out, db, 1.0f, s) : VDK_OK;
+}
+
+
+// dgrad GEMM dX[rows, in] = act'(dY[rows, out] . Wt[in, out]^T) that also delivers db' = colsum(dY) as a by-product of its A tiles when the 256x256 kernel serves
+// the problem (see csrc/vit_engine.hip); *fused tells the caller whether db was produced
+int dgrad_with_bias(hipStream_t s, const WsPlan& w, char* base, const void* dY, const void* Wt, void* dX, int rows, int in, int out, int act, void* aux, float* db,
+                    int* fused) {
+  const int prow = vdk_gemm_a_colsum_rows(rows, in, out);
+  *fused = (db && prow > 0 && (size_t)prow * out * 4 <= w.csws_bytes) ? 1 : 0;
+  VdkGemmDesc g = {};
+  g.A = dY; g.lda = out; g.B = Wt; g.ldb = out; g.C = dX; g.ldc = in; g.M = rows; g.N = in; g.K = out; g.c_dtype = VDK_BF16; g.act = act; g.aux = aux; g.ldaux = in;
+  g.alpha = 1.0f; g.splitk = 1;
+  if (*fused) g.a_colsum = (float*)(base + w.csws);
+  RC(vdk_gemm_bf16_nt(&g, nullptr, 0, s));
+  if (*fused) RC(vdk_reduce_rows_f32((const float*)(base + w.csws), out, prow, out, db, 1.0f, s));
+  return VDK_OK;
 }
 
 }  // namespace
@@ -391,12 +409,13 @@ int vdk_convnext_backward(const VdkConvNextConfig* cfg, const float* dout, const
       const BlkP& b = p.st[i].blk[j]; const BlkX& bx = xl.blk[i][j]; const BlkW& bw = w.blk[i][j];
       const float* xin = X + (size_t)j * XS;
       const float* st = (const float*)(base + bw.stats);
-      // dxa / dxb = dL/d(block output).  MLP branch with the layer scale folded into fc2:
-      RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + bw.g), R, C, M, dw2p, db2p));
+      // dxa / dxb = dL/d(block output).  MLP branch with the layer scale folded into fc2; the bias gradients ride along with the dgrad GEMMs when possible
+      int fz = 0;
+      RC(dgrad_with_bias(s, w, base, dxb, xb + bx.fc2pt, du, R, M, C, VDK_ACT_DGELU, base + bw.u, db2p, &fz));
+      RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + bw.g), R, C, M, dw2p, fz ? nullptr : db2p));
       RC(vdk_layerscale_grad(dw2p, db2p, params + b.fc2_w, params + b.fc2_b, params + b.gamma, grads + b.fc2_w, grads + b.fc2_b, grads + b.gamma, C, M, s));
-      RC(gemm(s, dxb, C, xb + bx.fc2pt, C, du, M, R, M, C, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_DGELU, base + bw.u, M));
-      RC(linear_wgrad(s, w, base, du, (const bf16_t*)(base + bw.h), R, M, C, grads + b.fc1_w, grads + b.fc1_b));
-      RC(gemm(s, du, M, xb + bx.fc1t, M, dh, C, R, C, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0));
+      RC(dgrad_with_bias(s, w, base, du, xb + bx.fc1t, dh, R, C, M, VDK_ACT_NONE, nullptr, grads + b.fc1_b, &fz));
+      RC(linear_wgrad(s, w, base, du, (const bf16_t*)(base + bw.h), R, M, C, grads + b.fc1_w, fz ? nullptr : grads + b.fc1_b));
       RC(vdk_layernorm_bwd(dh, C, VDK_BF16, (const float*)(base + bw.t), C, st, st + R, params + b.nw, nullptr, 0, R, C, dt, C, nullptr, 0, grads + b.nw,
                            grads + b.nb, lnws, w.lnws_bytes, s));
       // depthwise conv: weight/bias gradient, then input gradient + shortcut gradient (in place on dxa) and its bf16 copy
