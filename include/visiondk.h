@@ -331,13 +331,17 @@ int vdk_im2col_bf16(const void* in, void* col, int32_t B, int32_t H, int32_t W, 
                     void* stream);
 /* nn.BatchNorm2d on NHWC rows x f32 [R, C] fused with the BasicBlock tail: out = [relu](bn(x) [+ res]) as bf16 and / or f32; res f32 or bf16.
  * Backward (training mode): dout f32 = gradient of out, out_bf16 = out (ReLU mask, NULL = no ReLU) -> dy_bf16 (gradient of x, the conv GEMMs' operand),
- * dres f32 (gradient of res = masked dout, optional), dgamma, dbeta. */
+ * dres f32 (gradient of res = masked dout, optional), dgamma, dbeta.  sync != NULL turns both into SyncBatchNorm: forward all-reduces (sum x, sum x^2, count),
+ * backward (sum g, sum g x^, count); dgamma / dbeta stay local sums like torch.nn.SyncBatchNorm (the gradient all-reduce follows). */
+/* SyncBatchNorm hook (the reference's opt-in, engine/vision_engine.py:224-225): called on the host with a device vector of n floats whose producer kernel is
+ * already enqueued on `stream`; the callee enqueues a SUM all-reduce of it over the data-parallel ranks, ordered before later work on `stream`. */
+typedef void (*vdk_stat_sync_fn)(void* user, float* stats, int64_t n);
 int vdk_bn_rows_workspace_bytes(int64_t R, int32_t C, size_t* bytes);
 int vdk_bn_act_fwd(const float* x, int64_t R, int32_t C, const float* gamma, const float* beta, float eps, float momentum, int32_t training, float* running_mean,
                    float* running_var, const float* res_f32, const void* res_bf16, int32_t relu, void* out_bf16, float* out_f32, float* save_mean, float* save_invstd,
-                   void* ws, size_t ws_bytes, void* stream);
+                   void* ws, size_t ws_bytes, vdk_stat_sync_fn sync, void* user, void* stream);
 int vdk_bn_act_bwd(const float* x, const float* dout, const void* out_bf16, int64_t R, int32_t C, const float* gamma, const float* save_mean, const float* save_invstd,
-                   void* dy_bf16, float* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+                   void* dy_bf16, float* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, vdk_stat_sync_fn sync, void* user, void* stream);
 /* nn.MaxPool2d(3, 2, 1) on bf16 NHWC (backward routes to the FIRST maximum in (ky, kx) order, like torch) and global average pooling */
 int vdk_maxpool3s2_fwd(const void* in, void* out, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 int vdk_maxpool3s2_bwd(const void* in, const float* dout, float* din, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
@@ -392,10 +396,11 @@ int vdk_resnet_workspace_bytes(const VdkResNetConfig* cfg, size_t* bytes);
 int vdk_resnet_refresh_weights(const VdkResNetConfig* cfg, const float* params, void* wb16, void* wx, int32_t skip_wb16, void* stream);
 /* x f32 [B, in_chans, img, img] -> logits f32 [B, Cp] (Cp = num_classes rounded up to 8); training != 0: batch statistics + running update */
 int vdk_resnet_forward(const VdkResNetConfig* cfg, const float* x, const float* params, float* buffers, const void* wb16, const void* wx, int32_t training, void* ws,
-                       size_t ws_bytes, float* logits, void* stream);
+                       size_t ws_bytes, float* logits, vdk_stat_sync_fn bn_sync, void* bn_user, void* stream);
 /* dlogits bf16 [B, Cp] (padding columns zero) -> grads (flat f32, overwritten); on_ready as in vdk_vit_backward */
 int vdk_resnet_backward(const VdkResNetConfig* cfg, const void* dlogits, const float* params, const void* wb16, const void* wx, void* ws, size_t ws_bytes, float* grads,
-                        vdk_grad_ready_fn on_ready, void* user, void* stream);
+                        vdk_grad_ready_fn on_ready, void* user, vdk_stat_sync_fn bn_sync, void* bn_user, void* stream);
+/* bn_sync != NULL: every BatchNorm of the network runs as SyncBatchNorm (pass the same hook to forward and backward) */
 
 /* F.normalize(W, dim=0): inv[c] = 1/max(||W[:,c]||, eps); Wb = bf16 [3D, ldb]: the normalised weight as split planes
  * (hi, hi, lo) stacked along the contraction dim (rows [0,D) alone are the plain bf16 copy); columns C..Cp-1 zero */

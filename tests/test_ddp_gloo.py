@@ -182,3 +182,49 @@ def test_two_rank_resnet_step(tmp_path, emu):
         st.step(x[r * 4:r * 4 + 4], t[r * 4:r * 4 + 4])
         total = model.engine.grads.clone() if total is None else total + model.engine.grads
     assert torch.equal(total, r0["grads"])
+
+
+# ---- SyncBatchNorm: 2 ranks x half batch == 1 process x whole batch (statistics all-reduced inside forward and backward) -------------------------------
+def _syncbn_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["VDK_EMU_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.emu.emu_backend import load_emu
+    from visiondk_amd import comm, resnet
+    be = load_emu()
+    spec = resnet.ResNetSpec(img_size=32, widths=(8, 8, 16, 16), depths=(1, 1, 1, 1), num_classes=5)
+    model = resnet.ResNet(spec, device="cpu", backend=be, seed=50 + rank)
+    step = resnet.ResNetTrainStep(model, lr=0.05, loss="bce", ema=False, comm=comm.GradAllReduce(bucket_bytes=8_000), sync_bn=True)
+    init = model.engine.params.clone()
+    torch.manual_seed(7)
+    x = torch.randn(8, 3, 32, 32); t = (torch.rand(8, 5) > 0.5).float()
+    rows = step.step(x[rank * 4:rank * 4 + 4], t[rank * 4:rank * 4 + 4])
+    torch.save({"init": init, "params": model.engine.params.clone(), "grads": model.engine.grads.clone(), "buffers": model.engine.buffers.clone(), "loss": rows.clone()},
+               f"{out_dir}/sbn{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_two_rank_syncbn_equals_single_process(tmp_path, emu):
+    port = 29500 + ((os.getpid() + 389) % 500)
+    mp.start_processes(_syncbn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "sbn0.pt"); r1 = torch.load(tmp_path / "sbn1.pt")
+    assert torch.equal(r0["params"], r1["params"]) and torch.equal(r0["grads"], r1["grads"])
+    assert torch.equal(r0["buffers"], r1["buffers"])           # running statistics come from the global batch on every rank
+    from visiondk_amd import resnet
+    spec = resnet.ResNetSpec(img_size=32, widths=(8, 8, 16, 16), depths=(1, 1, 1, 1), num_classes=5)
+    model = resnet.ResNet(spec, device="cpu", backend=emu, seed=0)
+    with torch.no_grad():
+        model.engine.params.copy_(r0["init"])
+    st = resnet.ResNetTrainStep(model, lr=0.05, loss="bce", ema=False)
+    torch.manual_seed(7)
+    x = torch.randn(8, 3, 32, 32); t = (torch.rand(8, 5) > 0.5).float()
+    rows = st.step(x, t)
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    # per-rank BCE rows use gscale 1/(4*5); the summed gradient over 2 ranks / 2 is the whole-batch mean gradient
+    assert rel(r0["grads"] / 2, model.engine.grads) < 2e-3
+    assert rel(r0["buffers"], model.engine.buffers) < 1e-5
+    assert rel(r0["params"] - r0["init"], model.engine.params - r0["init"]) < 2e-3
+    assert rel(torch.cat([r0["loss"], r1["loss"]]), rows) < 1e-4

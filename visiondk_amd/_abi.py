@@ -57,6 +57,7 @@ class MarginHead(C.Structure):
 
 HEAD_ARCFACE, HEAD_CIRCLE, HEAD_MV_AM, HEAD_MV_ARC = 0, 1, 2, 3
 GRAD_READY_FN = C.CFUNCTYPE(None, P, I64, I64)
+STAT_SYNC_FN = C.CFUNCTYPE(None, P, P, I64)   # vdk_stat_sync_fn(user, stats, n)
 
 BF16, F32_ = 0, 1
 ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
@@ -140,8 +141,8 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_nchw_to_nhwc_bf16": (C.c_int, [P, P, I32, I32, I32, I32, I32, P]),
     "vdk_im2col_bf16": (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, P]),
     "vdk_bn_rows_workspace_bytes": (C.c_int, [I64, I32, PSZ]),
-    "vdk_bn_act_fwd": (C.c_int, [P, I64, I32, P, P, C.c_float, C.c_float, I32, P, P, P, P, I32, P, P, P, P, P, SZ, P]),
-    "vdk_bn_act_bwd": (C.c_int, [P, P, P, I64, I32, P, P, P, P, P, P, P, P, SZ, P]),
+    "vdk_bn_act_fwd": (C.c_int, [P, I64, I32, P, P, C.c_float, C.c_float, I32, P, P, P, P, I32, P, P, P, P, P, SZ, P, P, P]),
+    "vdk_bn_act_bwd": (C.c_int, [P, P, P, I64, I32, P, P, P, P, P, P, P, P, SZ, P, P, P]),
     "vdk_maxpool3s2_fwd": (C.c_int, [P, P, I32, I32, I32, I32, P]),
     "vdk_maxpool3s2_bwd": (C.c_int, [P, P, P, I32, I32, I32, I32, P]),
     "vdk_avgpool_fwd": (C.c_int, [P, P, I32, I32, I32, I32, P]),
@@ -154,8 +155,8 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_resnet_param_info": (C.c_int, [C.POINTER(ResNetConfig), I32, I32, C.c_char_p, I32, C.POINTER(I64), C.POINTER(I64), C.POINTER(I64), C.POINTER(I32)]),
     "vdk_resnet_workspace_bytes": (C.c_int, [C.POINTER(ResNetConfig), PSZ]),
     "vdk_resnet_refresh_weights": (C.c_int, [C.POINTER(ResNetConfig), P, P, P, I32, P]),
-    "vdk_resnet_forward": (C.c_int, [C.POINTER(ResNetConfig), P, P, P, P, P, I32, P, SZ, P, P]),
-    "vdk_resnet_backward": (C.c_int, [C.POINTER(ResNetConfig), P, P, P, P, P, SZ, P, P, P, P]),
+    "vdk_resnet_forward": (C.c_int, [C.POINTER(ResNetConfig), P, P, P, P, P, I32, P, SZ, P, P, P, P]),
+    "vdk_resnet_backward": (C.c_int, [C.POINTER(ResNetConfig), P, P, P, P, P, SZ, P, P, P, P, P, P]),
     "vdk_convnext_param_count": (C.c_int, [C.POINTER(ConvNextConfig), C.POINTER(I64), C.POINTER(I32), PSZ]),
     "vdk_convnext_param_info": (C.c_int, [C.POINTER(ConvNextConfig), I32, C.c_char_p, I32, C.POINTER(I64), C.POINTER(I64), C.POINTER(I64), C.POINTER(I32)]),
     "vdk_convnext_workspace_bytes": (C.c_int, [C.POINTER(ConvNextConfig), PSZ]),

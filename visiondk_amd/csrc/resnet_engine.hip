@@ -28,8 +28,9 @@ int vdk_nchw_to_nhwc_bf16(const float*, void*, int32_t, int32_t, int32_t, int32_
 int vdk_im2col_bf16(const void*, void*, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, void*);
 int vdk_bn_rows_workspace_bytes(int64_t, int32_t, size_t*);
 int vdk_bn_act_fwd(const float*, int64_t, int32_t, const float*, const float*, float, float, int32_t, float*, float*, const float*, const void*, int32_t, void*, float*,
-                   float*, float*, void*, size_t, void*);
-int vdk_bn_act_bwd(const float*, const float*, const void*, int64_t, int32_t, const float*, const float*, const float*, void*, float*, float*, float*, void*, size_t, void*);
+                   float*, float*, void*, size_t, vdk_stat_sync_fn, void*, void*);
+int vdk_bn_act_bwd(const float*, const float*, const void*, int64_t, int32_t, const float*, const float*, const float*, void*, float*, float*, float*, void*, size_t,
+                   vdk_stat_sync_fn, void*, void*);
 int vdk_maxpool3s2_fwd(const void*, void*, int32_t, int32_t, int32_t, int32_t, void*);
 int vdk_maxpool3s2_bwd(const void*, const float*, float*, int32_t, int32_t, int32_t, int32_t, void*);
 int vdk_avgpool_fwd(const void*, void*, int32_t, int32_t, int32_t, int32_t, void*);
@@ -144,7 +145,7 @@ int wgrad_splitk_tn(int M, int N, int K) {
 void rn_plan(const RnDims& d, WsPlan* w) {
   size_t cur = 0;
   w->img = w_take(cur, (size_t)d.B * d.img * d.img * d.Cinp * 2);
-  w->y0 = w_take(cur, (size_t)d.R0 * d.stem.co * 4); w->a0 = w_take(cur, (size_t)d.R0 * d.stem.co * 2); w->st0 = w_take(cur, (size_t)d.stem.co * 2 * 4);
+  w->y0 = w_take(cur, (size_t)d.R0 * d.stem.co * 4); w->a0 = w_take(cur, (size_t)d.R0 * d.stem.co * 2); w->st0 = w_take(cur, ((size_t)d.stem.co * 2 + 4) * 4);
   w->ap = w_take(cur, (size_t)d.Rp * d.stem.co * 2);
   size_t rc = (size_t)d.R0 * d.stem.co, colmax = (size_t)d.R0 * 49 * d.Cinp, dwpmax = (size_t)d.stem.co * 49 * d.Cinp, sl = 0, bn = 0, cs = 0, tr = 0;
   auto wg = [&](int out, int in, int rows) {
@@ -163,9 +164,9 @@ void rn_plan(const RnDims& d, WsPlan* w) {
     const Blk& b = d.blk[i]; BlkW& bw = w->blk[i];
     const size_t n = (size_t)b.R * b.c1.co;
     bw.y1 = w_take(cur, n * 4); bw.a1 = w_take(cur, n * 2); bw.y2 = w_take(cur, n * 4); bw.out = w_take(cur, n * 2);
-    bw.st1 = w_take(cur, (size_t)b.c1.co * 2 * 4); bw.st2 = w_take(cur, (size_t)b.c1.co * 2 * 4);
+    bw.st1 = w_take(cur, ((size_t)b.c1.co * 2 + 4) * 4); bw.st2 = w_take(cur, ((size_t)b.c1.co * 2 + 4) * 4);
     bw.yd = bw.idf = bw.std_ = 0;
-    if (b.ds) { bw.yd = w_take(cur, n * 4); bw.idf = w_take(cur, n * 4); bw.std_ = w_take(cur, (size_t)b.c1.co * 2 * 4); }
+    if (b.ds) { bw.yd = w_take(cur, n * 4); bw.idf = w_take(cur, n * 4); bw.std_ = w_take(cur, ((size_t)b.c1.co * 2 + 4) * 4); }
     const size_t nin = (size_t)d.B * b.c1.hin * b.c1.hin * b.c1.cip;
     if (n > rc) rc = n;
     if (nin > rc) rc = nin;
@@ -284,7 +285,7 @@ int vdk_resnet_refresh_weights(const VdkResNetConfig* cfg, const float* params, 
 
 // x f32 [B, Cin, img, img] -> logits f32 [B, Cp]; training != 0: batch statistics (running statistics in `buffers` updated), activations kept for backward
 int vdk_resnet_forward(const VdkResNetConfig* cfg, const float* x, const float* params, float* buffers, const void* wb16, const void* wx, int32_t training, void* ws,
-                       size_t ws_bytes, float* logits, void* stream_) {
+                       size_t ws_bytes, float* logits, vdk_stat_sync_fn bn_sync, void* bn_user, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   RnDims d; RC(rn_dims(cfg, &d));
   WsPlan w; rn_plan(d, &w);
@@ -295,7 +296,7 @@ int vdk_resnet_forward(const VdkResNetConfig* cfg, const float* x, const float* 
   auto bn = [&](const Bn& b, const float* xin, long R, size_t st, const float* rf, const void* rb, int relu, void* ob, float* of) {
     float* sm = (float*)(base + st);
     return vdk_bn_act_fwd(xin, R, b.c, params + b.g, params + b.b, d.eps, d.mom, training, buffers + b.rm, buffers + b.rv, rf, rb, relu, ob, of, sm, sm + b.c, bnws,
-                          w.bnws_bytes, s);
+                          w.bnws_bytes, training ? bn_sync : nullptr, bn_user, s);
   };
   RC(vdk_nchw_to_nhwc_bf16(x, base + w.img, d.B, d.Cin, d.img, d.img, d.Cinp, s));
   RC(conv_gemm(s, d.stem, d.B, false, base + w.img, xb + d.stem.wf, base + w.y0, VDK_F32, nullptr));
@@ -327,7 +328,7 @@ int vdk_resnet_forward(const VdkResNetConfig* cfg, const float* x, const float* 
 
 // dlogits bf16 [B, Cp] (padding columns zero) -> grads (flat fp32, param layout, fully overwritten).  Needs the workspace of a training-mode forward.
 int vdk_resnet_backward(const VdkResNetConfig* cfg, const void* dlogits, const float* params, const void* wb16, const void* wx, void* ws, size_t ws_bytes, float* grads,
-                        vdk_grad_ready_fn on_ready, void* user, void* stream_) {
+                        vdk_grad_ready_fn on_ready, void* user, vdk_stat_sync_fn bn_sync, void* bn_user, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   RnDims d; RC(rn_dims(cfg, &d));
   WsPlan w; rn_plan(d, &w);
@@ -339,7 +340,7 @@ int vdk_resnet_backward(const VdkResNetConfig* cfg, const void* dlogits, const f
   void* bnws = base + w.bnws;
   auto bnb = [&](const Bn& b, const float* xin, const float* dout, const void* mask, long R, size_t st, float* dr) {
     const float* sm = (const float*)(base + st);
-    return vdk_bn_act_bwd(xin, dout, mask, R, b.c, params + b.g, sm, sm + b.c, dyb, dr, grads + b.g, grads + b.b, bnws, w.bnws_bytes, s);
+    return vdk_bn_act_bwd(xin, dout, mask, R, b.c, params + b.g, sm, sm + b.c, dyb, dr, grads + b.g, grads + b.b, bnws, w.bnws_bytes, bn_sync, bn_user, s);
   };
   // fc: weight / bias gradient, feature gradient, average-pool backward
   const Blk& last = d.blk.back();

@@ -95,31 +95,39 @@ __global__ __launch_bounds__(512) void bn_partial_kernel(const float* __restrict
     part[((long)blockIdx.x * 2 + rg) * C + c] = t;
   }
 }
-// forward finalize: mean / biased var -> invstd, running statistics (unbiased var); eval mode: running statistics
-__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ part, int S, long R, int C, float eps, float momentum, int training,
-                                                              float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ save_mean,
-                                                              float* __restrict__ save_invstd) {
+// combine the slice partials into ONE vector sums[2C + 1] = (sum_0[C], sum_1[C], count): what a SyncBatchNorm all-reduces across ranks
+__global__ __launch_bounds__(256) void bn_combine_kernel(const float* __restrict__ part, int S, int C, float count, float* __restrict__ sums) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) sums[2 * C] = count;
+  if (i >= 2 * C) return;
+  const int which = i / C, c = i - which * C;
+  double s = 0.0;
+  for (int k = 0; k < S; ++k) s += part[((long)k * 2 + which) * C + c];
+  sums[i] = (float)s;
+}
+// forward finalize from sums (sum x, sum x^2, count): mean / biased var -> invstd, running statistics (unbiased var); eval mode: running statistics
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ sums, int C, float eps, float momentum, int training, float* __restrict__ rmean,
+                                                              float* __restrict__ rvar, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                              float* __restrict__ save_count) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   float mu, var;
   if (training) {
-    double s = 0.0, q = 0.0;
-    for (int i = 0; i < S; ++i) { s += part[((long)i * 2) * C + c]; q += part[((long)i * 2 + 1) * C + c]; }
-    const double m = s / (double)R;
-    double v = q / (double)R - m * m; if (v < 0.0) v = 0.0;
+    const double R = (double)sums[2 * C];
+    const double m = (double)sums[c] / R;
+    double v = (double)sums[C + c] / R - m * m; if (v < 0.0) v = 0.0;
     mu = (float)m; var = (float)v;
     if (rmean) rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mu;
-    if (rvar) rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (R > 1 ? (float)(v * (double)R / (double)(R - 1)) : var);
+    if (rvar) rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (R > 1.0 ? (float)(v * R / (R - 1.0)) : var);
+    if (c == 0 && save_count) save_count[0] = (float)R;
   } else { mu = rmean[c]; var = rvar[c]; }
   save_mean[c] = mu; save_invstd[c] = 1.0f / sqrtf(var + eps);
 }
-__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ part, int S, int C, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              float* __restrict__ sums /*[2][C]*/) {
+// backward: weight / bias gradients from the LOCAL sums (data-parallel training all-reduces gradients later, like torch's SyncBatchNorm)
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  double sb = 0.0, sg = 0.0;
-  for (int i = 0; i < S; ++i) { sb += part[((long)i * 2) * C + c]; sg += part[((long)i * 2 + 1) * C + c]; }
-  dbeta[c] = (float)sb; dgamma[c] = (float)sg; sums[c] = (float)sb; sums[C + c] = (float)sg;
+  dbeta[c] = sums[c]; dgamma[c] = sums[C + c];
 }
 // y = gamma * (x - mean) * invstd + beta [+ res] [relu] -> bf16 (and / or f32); 4 channels per thread (C % 4 == 0)
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, long n4, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 // g = dout * mask;  dy = gamma * invstd / R * (R g - sum g - xhat * sum(g xhat)) -> bf16;  dres = g (f32, optional: the shortcut's gradient)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dout, const bf16_t* __restrict__ outb, long n4, int C,
-                                                           float Rf, const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ count, const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ sums, bf16_t* __restrict__ dyb, float* __restrict__ dres) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
@@ -156,6 +164,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
   const f32x4 ga = *(const f32x4*)(gamma + c), mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c);
   const f32x4 sb = *(const f32x4*)(sums + c), sg = *(const f32x4*)(sums + C + c);
+  const float Rf = count[0];   // samples behind the statistics: local rows, or all ranks' rows under SyncBatchNorm
   float d[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -268,46 +277,56 @@ int vdk_im2col_bf16(const void* in, void* col, int32_t B, int32_t H, int32_t W, 
 
 int vdk_bn_rows_workspace_bytes(int64_t R, int32_t C, size_t* bytes) {
   if (!bytes || R <= 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_bn_rows_workspace_bytes: bad argument");
-  *bytes = ((size_t)bn_slices(R, C) * 2 * C + 2 * (size_t)C) * 4;
+  *bytes = ((size_t)bn_slices(R, C) * 2 * C + 2 * (size_t)C + 64) * 4;
   return VDK_OK;
 }
-/* BatchNorm2d (+ residual, + ReLU) on NHWC rows: x f32 [R, C] -> out_bf16 and / or out_f32; training != 0: batch statistics (saved) and running update */
+/* BatchNorm2d (+ residual, + ReLU) on NHWC rows: x f32 [R, C] -> out_bf16 and / or out_f32; training != 0: batch statistics (saved) and running update.
+ * save_stats: f32 [2C + 1] = (mean, invstd, sample count).  sync != NULL (SyncBatchNorm, the reference's opt-in at engine/vision_engine.py:224-225): called on
+ * the host with the device vector (sum x, sum x^2, count) [2C + 1] after its producer is enqueued; the callee enqueues a SUM all-reduce over the ranks. */
 int vdk_bn_act_fwd(const float* x, int64_t R, int32_t C, const float* gamma, const float* beta, float eps, float momentum, int32_t training, float* running_mean,
                    float* running_var, const float* res_f32, const void* res_bf16, int32_t relu, void* out_bf16, float* out_f32, float* save_mean, float* save_invstd,
-                   void* ws, size_t ws_bytes, void* stream_) {
+                   void* ws, size_t ws_bytes, vdk_stat_sync_fn sync, void* user, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !gamma || !beta || !save_mean || !save_invstd || (!out_bf16 && !out_f32) || R <= 0 || C <= 0 || (C & 3) || (!training && (!running_mean || !running_var)))
     return vdk_fail(VDK_EINVAL, "vdk_bn_act_fwd: bad argument (C % 4 == 0)");
   const int S = bn_slices(R, C);
-  if (!ws || ws_bytes < ((size_t)S * 2 * C + 2 * (size_t)C) * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_bn_act_fwd: workspace too small");
-  float* part = (float*)ws;
+  if (!ws || ws_bytes < ((size_t)S * 2 * C + 2 * (size_t)C + 64) * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_bn_act_fwd: workspace too small");
+  float* part = (float*)ws; float* sums = part + (size_t)S * 2 * C;
   const long rps = (R + S - 1) / S;
-  if (training)
+  if (training) {
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3((unsigned)S, (unsigned)((C + 63) / 64)), dim3(512), 0, stream, x, (const float*)nullptr, (const bf16_t*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (long)R, (int)C, rps, part);
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, (const float*)part, S, (long)R, (int)C, eps, momentum, (int)training,
-                     running_mean, running_var, save_mean, save_invstd);
+    hipLaunchKernelGGL(bn_combine_kernel, dim3((unsigned)((2 * C + 255) / 256)), dim3(256), 0, stream, (const float*)part, S, (int)C, (float)R, sums);
+    if (sync) sync(user, sums, 2 * (int64_t)C + 1);
+  }
+  // the sample count is kept right behind invstd when the two save vectors are adjacent (engines allocate [2C + 1])
+  float* save_count = (save_invstd == save_mean + C) ? save_invstd + C : nullptr;
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, (const float*)sums, (int)C, eps, momentum, (int)training, running_mean,
+                     running_var, save_mean, save_invstd, save_count);
   const long n4 = R * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, n4, (int)C, gamma, beta, (const float*)save_mean,
                      (const float*)save_invstd, res_f32, (const bf16_t*)res_bf16, (int)relu, (bf16_t*)out_bf16, out_f32);
   return vdk_check_launch("vdk_bn_act_fwd");
 }
-/* backward of the above (training mode): dout f32 = gradient of the block output; out_bf16 = that output (ReLU mask; NULL = no ReLU) */
+/* backward of the above (training mode): dout f32 = gradient of the block output; out_bf16 = that output (ReLU mask; NULL = no ReLU).  sync != NULL: the vector
+ * (sum g, sum g x^, local count) [2C + 1] is all-reduced before dy is formed (dgamma / dbeta stay local, like torch.nn.SyncBatchNorm). */
 int vdk_bn_act_bwd(const float* x, const float* dout, const void* out_bf16, int64_t R, int32_t C, const float* gamma, const float* save_mean, const float* save_invstd,
-                   void* dy_bf16, float* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream_) {
+                   void* dy_bf16, float* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, vdk_stat_sync_fn sync, void* user, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !dout || !gamma || !save_mean || !save_invstd || !dy_bf16 || !dgamma || !dbeta || R <= 0 || C <= 0 || (C & 3))
     return vdk_fail(VDK_EINVAL, "vdk_bn_act_bwd: bad argument (C % 4 == 0)");
   const int S = bn_slices(R, C);
-  if (!ws || ws_bytes < ((size_t)S * 2 * C + 2 * (size_t)C) * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_bn_act_bwd: workspace too small");
+  if (!ws || ws_bytes < ((size_t)S * 2 * C + 2 * (size_t)C + 64) * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_bn_act_bwd: workspace too small");
   float* part = (float*)ws; float* sums = part + (size_t)S * 2 * C;
   const long rps = (R + S - 1) / S;
   hipLaunchKernelGGL(bn_partial_kernel<1>, dim3((unsigned)S, (unsigned)((C + 63) / 64)), dim3(512), 0, stream, x, dout, (const bf16_t*)out_bf16, save_mean, save_invstd,
                      (long)R, (int)C, rps, part);
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, (const float*)part, S, (int)C, dgamma, dbeta, sums);
+  hipLaunchKernelGGL(bn_combine_kernel, dim3((unsigned)((2 * C + 255) / 256)), dim3(256), 0, stream, (const float*)part, S, (int)C, (float)R, sums);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, (const float*)sums, (int)C, dgamma, dbeta);
+  if (sync) sync(user, sums, 2 * (int64_t)C + 1);
   const long n4 = R * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, dout, (const bf16_t*)out_bf16, n4, (int)C, (float)R, gamma, save_mean,
-                     save_invstd, (const float*)sums, (bf16_t*)dy_bf16, dres);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, dout, (const bf16_t*)out_bf16, n4, (int)C, (const float*)(sums + 2 * C),
+                     gamma, save_mean, save_invstd, (const float*)sums, (bf16_t*)dy_bf16, dres);
   return vdk_check_launch("vdk_bn_act_bwd");
 }
 

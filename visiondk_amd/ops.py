@@ -483,7 +483,7 @@ def bn_act_fwd(x: torch.Tensor, gamma, beta, running_mean, running_var, *, train
     rb = res if (res is not None and res.dtype == torch.bfloat16) else None
     be.check(be.lib.vdk_bn_act_fwd(be.ptr(x), R, Cc, be.ptr(gamma), be.ptr(beta), eps, momentum, int(training), be.ptr(running_mean), be.ptr(running_var),
                                    be.ptr(rf) if rf is not None else None, be.ptr(rb) if rb is not None else None, int(relu), be.ptr(outb),
-                                   be.ptr(outf) if outf is not None else None, be.ptr(sm), be.ptr(si), be.ptr(ws), ws.numel(), be.stream()), "vdk_bn_act_fwd")
+                                   be.ptr(outf) if outf is not None else None, be.ptr(sm), be.ptr(si), be.ptr(ws), ws.numel(), None, None, be.stream()), "vdk_bn_act_fwd")
     return outb, outf, sm, si
 
 
@@ -497,7 +497,7 @@ def bn_act_bwd(x, dout, out_bf16, gamma, save_mean, save_invstd, want_dres=True,
     dg = torch.empty(Cc, dtype=torch.float32, device=x.device); db = torch.empty(Cc, dtype=torch.float32, device=x.device)
     be.check(be.lib.vdk_bn_act_bwd(be.ptr(x), be.ptr(dout), be.ptr(out_bf16) if out_bf16 is not None else None, R, Cc, be.ptr(gamma), be.ptr(save_mean),
                                    be.ptr(save_invstd), be.ptr(dy), be.ptr(dres) if dres is not None else None, be.ptr(dg), be.ptr(db), be.ptr(ws), ws.numel(),
-                                   be.stream()), "vdk_bn_act_bwd")
+                                   None, None, be.stream()), "vdk_bn_act_bwd")
     return dy, dres, dg, db
 
 

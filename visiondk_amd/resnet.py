@@ -88,7 +88,19 @@ class ResNetEngine:
                  "vdk_resnet_refresh_weights")
         self._weights_version = self.params._version
 
-    def forward(self, x: torch.Tensor, training: bool) -> torch.Tensor:
+    def _sync_cb(self, group):
+        """vdk_stat_sync_fn for SyncBatchNorm: all-reduce (SUM) the statistics vector the engine hands over; it lives inside the workspace tensor"""
+        if group is False:
+            return _abi.STAT_SYNC_FN(0)
+        import torch.distributed as dist
+
+        def cb(user, ptr, n):
+            off = ptr - self._ws.data_ptr()
+            dist.all_reduce(self._ws[off:off + 4 * n].view(torch.float32), op=dist.ReduceOp.SUM, group=group)
+        return _abi.STAT_SYNC_FN(cb)
+
+    def forward(self, x: torch.Tensor, training: bool, sync_group=False) -> torch.Tensor:
+        """sync_group: False = per-rank BatchNorm statistics; None or a process group = SyncBatchNorm over that group"""
         s = self.spec
         if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != s.in_chans or x.shape[2] != x.shape[3] or x.shape[2] % 32:
             raise ValueError(f"expected float32 [B, {s.in_chans}, S, S] with S % 32 == 0, got {tuple(x.shape)} {x.dtype}")
@@ -99,18 +111,19 @@ class ResNetEngine:
             self.refresh_weights()
         cfg = self._cfg(B, img)
         be = self.be
+        cb = self._sync_cb(sync_group)
         be.check(be.lib.vdk_resnet_forward(C.byref(cfg), be.ptr(x), be.ptr(self.params), be.ptr(self.buffers), be.ptr(self.wb16), be.ptr(self.wx), int(training),
-                                           be.ptr(ws), ws.numel(), be.ptr(self._logits), be.stream()), "vdk_resnet_forward")
+                                           be.ptr(ws), ws.numel(), be.ptr(self._logits), cb, None, be.stream()), "vdk_resnet_forward")
         return self._logits
 
-    def backward(self, dlogits_bf16: torch.Tensor, on_ready: Optional[Callable[[int, int], None]] = None) -> torch.Tensor:
+    def backward(self, dlogits_bf16: torch.Tensor, on_ready: Optional[Callable[[int, int], None]] = None, sync_group=False) -> torch.Tensor:
         B = dlogits_bf16.shape[0]
         assert dlogits_bf16.dtype == torch.bfloat16 and dlogits_bf16.shape[1] == self.cp and B == self._ws_batch[0]
         cfg = self._cfg(B, self._ws_batch[1])
         be = self.be
         cb = _abi.GRAD_READY_FN(lambda user, off, n: on_ready(off, n)) if on_ready is not None else _abi.GRAD_READY_FN(0)
         be.check(be.lib.vdk_resnet_backward(C.byref(cfg), be.ptr(dlogits_bf16), be.ptr(self.params), be.ptr(self.wb16), be.ptr(self.wx), be.ptr(self._ws),
-                                            self._ws.numel(), be.ptr(self.grads), cb, None, be.stream()), "vdk_resnet_backward")
+                                            self._ws.numel(), be.ptr(self.grads), cb, None, self._sync_cb(sync_group), None, be.stream()), "vdk_resnet_backward")
         return self.grads
 
 
@@ -253,12 +266,14 @@ class ResNetTrainStep:
     clip_grad_norm_(max_norm) -> SGD(momentum, weight_decay) -> EMA -> bf16 weight refresh.  `param_groups[0]['lr']` stays readable / writable."""
 
     def __init__(self, model: ResNet, lr: float, momentum: float = 0.937, weight_decay: float = 5e-4, loss: str = "bce", label_smoothing: float = 0.0,
-                 max_norm: float = 10.0, ema: bool = True, comm=None):
-        """comm: visiondk_amd.comm.GradAllReduce (one process per GPU): weights and BatchNorm buffers broadcast from rank 0 at construction, buffers again
+                 max_norm: float = 10.0, ema: bool = True, comm=None, sync_bn: bool = False):
+        """sync_bn: SyncBatchNorm over comm's group (the reference's `sync_bn` flag -> nn.SyncBatchNorm.convert_sync_batchnorm, vision_engine.py:224-225).
+        comm: visiondk_amd.comm.GradAllReduce (one process per GPU): weights and BatchNorm buffers broadcast from rank 0 at construction, buffers again
         before every forward (torch DDP's broadcast_buffers), the flat gradient all-reduced in buckets from inside vdk_resnet_backward; BatchNorm statistics
         stay per rank (SyncBN is the reference's opt-in flag and is not built)."""
         assert loss in ("bce", "ce")
         self.comm = comm
+        self.sync_group = (comm.group if (sync_bn and comm is not None and comm.world_size > 1) else False)
         self.model, self.eng, self.be = model, model.engine, model.engine.be
         self.loss, self.label_smoothing, self.max_norm = loss, label_smoothing, max_norm
         self.param_groups = [{"lr": lr, "momentum": momentum, "weight_decay": weight_decay}]
@@ -292,7 +307,7 @@ class ResNetTrainStep:
         self.updates += 1
         g = self.param_groups[0]
         B, ncls = x.shape[0], eng.spec.num_classes
-        logits = eng.forward(x, True)
+        logits = eng.forward(x, True, sync_group=self.sync_group)
         if self.loss_rows is None or self.loss_rows.shape[0] != B:
             self.loss_rows = torch.empty(B, dtype=torch.float32, device=eng.device)
             self._dl = torch.zeros((B, eng.cp), dtype=torch.bfloat16, device=eng.device)
@@ -304,7 +319,7 @@ class ResNetTrainStep:
                                            be.ptr(self._dl), eng.cp, None, 0, be.stream()), "vdk_softmax_ce")
         if world > 1:
             self.comm.begin_step(eng.grads)
-            eng.backward(self._dl, on_ready=self.comm.on_grad_ready)
+            eng.backward(self._dl, on_ready=self.comm.on_grad_ready, sync_group=self.sync_group)
             self.comm.finish_step()
         else:
             eng.backward(self._dl)
