@@ -496,9 +496,6 @@ __device__ __forceinline__ float cbir_eps(const float* __restrict__ qn3, long q,
 // minus eps_q, is a lower bound of the exact k-th best score (k distinct rows reach it), i.e. a valid filter threshold before
 // any row is ranked: the scan starts with a tight cut instead of a pass-everything ramp (cbir_boot_thr_kernel).
 #define CF_NBUF 3
-#ifndef CF_EXP
-#define CF_EXP 0
-#endif
 template <bool BOOT>
 __global__ __launch_bounds__(512) void cbir_prefilter_kernel(const bf16_t* __restrict__ Qb, const float* __restrict__ qnorm, long nq,
                                                              const bf16_t* __restrict__ Gb, const unsigned* __restrict__ gmax_bits, long g_begin,
@@ -583,9 +580,7 @@ __global__ __launch_bounds__(512) void cbir_prefilter_kernel(const bf16_t* __res
   for (long t = 0; t < ntile; ++t) {
     // ring slot (cur + 2) % 3 was consumed during iteration t - 1 (everybody passed the barrier that ended it)
     int nxt2 = cur + 2; if (nxt2 >= CF_NBUF) nxt2 -= CF_NBUF;
-#if CF_EXP != 2
     if (t + 2 < ntile) CF_ISSUE(nxt2, t + 2);
-#endif
     const unsigned char* Gt = Gs + cur * (CF_BG * 256);
     // A fragments run two k-steps ahead of the MFMAs that consume them (hipcc alone emits read -> wait -> 4 MFMAs per k-step,
     // exposing the LDS latency 16 times per tile); the first two of the second half are fetched before the first half's filter
@@ -624,10 +619,8 @@ __global__ __launch_bounds__(512) void cbir_prefilter_kernel(const bf16_t* __res
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
           float m = acc[rt][qt][0];
-#if CF_EXP != 1
 #pragma unroll
           for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rt][qt][r]);
-#endif
           if (BOOT) {
             bm[qt] = fmaxf(bm[qt], m);   // rows past r_end are copies of row r_end - 1 (clamped DMA): the maximum is unaffected
             if (h == 1 && rt == 1) {     // tile complete: one group maximum per (query, 128-row tile)
