@@ -177,8 +177,9 @@ def test_cnn_extract_cbir_eval_embeddings(be, dev, monkeypatch):
     assert got.shape == (5, 64) and _rel(got, exp) < 2e-2
 
 
-def test_face_train_step_matches_reference_update(be, dev, monkeypatch):
-    """FaceTrainStep == compute_loss(face=True) + Trainer.update on the oracle (CE -> backward -> clip_grad_norm_ -> SGD -> EMA), 2 steps,
+@pytest.mark.parametrize("layer_wise", [False, True])
+def test_face_train_step_matches_reference_update(be, dev, monkeypatch, layer_wise):
+    """layer_wise: the head's parameter group runs at 10 x lr (built/layer_optimizer.py:26-29, cbir.yaml:113).  FaceTrainStep == compute_loss(face=True) + Trainer.update on the oracle (CE -> backward -> clip_grad_norm_ -> SGD -> EMA), 2 steps,
     with the clip active (max_norm below the gradient norm)."""
     import math
     model, ref, img = _build_cnn(be, dev, monkeypatch)
@@ -186,9 +187,11 @@ def test_face_train_step_matches_reference_update(be, dev, monkeypatch):
     rhead = _RefArcFace(head.weight.detach().cpu())
     bb = model.trainingwrapper["backbone"]
     lr, mom, wd, max_norm = 0.05, 0.9, 5e-4, 0.5
-    step = face.FaceTrainStep(model, lr=lr, momentum=mom, weight_decay=wd, max_norm=max_norm, ema=True)
+    step = face.FaceTrainStep(model, lr=lr, momentum=mom, weight_decay=wd, max_norm=max_norm, ema=True, layer_wise=layer_wise)
     params = list(ref.parameters()) + [rhead.weight]
-    opt = torch.optim.SGD(params, lr=lr, momentum=mom, weight_decay=wd)
+    opt = torch.optim.SGD([{"params": list(ref.parameters()), "lr": lr}, {"params": [rhead.weight], "lr": lr * 10 if layer_wise else lr}],
+                          lr=lr, momentum=mom, weight_decay=wd)
+    assert [g["lr"] for g in step.param_groups] == [g["lr"] for g in opt.param_groups][:len(step.param_groups)]
     ema_ref = {k: v.clone() for k, v in ref.state_dict().items() if v.dtype.is_floating_point}
     start = {n: p.detach().clone() for n, p in ref.named_parameters()}
     model.train(); ref.train()

@@ -63,6 +63,32 @@ def test_schedules_vs_reference_scheduler():
         np.testing.assert_allclose(got, z[key], rtol=1e-9, atol=1e-12, err_msg=key)
 
 
+def test_layer_wise_groups_follow_torch_schedulers():
+    """Two parameter groups as built/layer_optimizer.py:26-29 makes them (head at 10 x lr0), driven by the torch schedulers the reference's
+    engine/scheduler.py:27-57 assembles: every group scales from its own initial lr, the cosine floor is lrf_ratio * lr0 for both."""
+    import torch
+    from torch.optim.lr_scheduler import CosineAnnealingLR, LinearLR, SequentialLR
+    lr0, epochs, warm = 0.006, 15, 2
+    for name in schedule.SCHEDULERS:
+        for lrf in (None, 0.05):
+            f = 0.1 if lrf is None else lrf
+            a, b = torch.nn.Parameter(torch.zeros(1)), torch.nn.Parameter(torch.zeros(1))
+            opt = torch.optim.SGD([{"params": [a], "lr": lr0}, {"params": [b], "lr": lr0 * 10}], lr=lr0, momentum=0.9)
+            if name == "linear":
+                sch = LinearLR(opt, start_factor=1, end_factor=f, total_iters=epochs)
+            elif name == "cosine":
+                sch = CosineAnnealingLR(opt, T_max=epochs, eta_min=f * lr0)
+            else:
+                tail = (LinearLR(opt, start_factor=1, end_factor=f, total_iters=epochs - warm) if name == "linear_with_warm"
+                        else CosineAnnealingLR(opt, T_max=epochs - warm, eta_min=f * lr0))
+                sch = SequentialLR(opt, schedulers=[LinearLR(opt, start_factor=0.1, end_factor=1, total_iters=warm), tail], milestones=[warm])
+            for t in range(epochs):
+                kw = dict(warm_ep=warm if "warm" in name else 0, epochs=epochs, lr0=lr0, lrf_ratio=lrf)
+                np.testing.assert_allclose(schedule.lr_at(name, t, **kw), opt.param_groups[0]["lr"], rtol=1e-9, err_msg=f"{name} {t}")
+                np.testing.assert_allclose(schedule.lr_at(name, t, base_lr=lr0 * 10, **kw), opt.param_groups[1]["lr"], rtol=1e-9, err_msg=f"{name} head {t}")
+                opt.step(); sch.step()
+
+
 def test_cbir_oracle_and_kernel_vs_float64_fixture(be, dev):
     z = np.load(G / "cbir_small.npz")
     q, g = z["queries"], z["gallery"]

@@ -13,7 +13,7 @@ cfg = {"task": "cbir", "image_size": 224, "backbone": {"timm-convnext_base": {"p
        "head": {"arcface": {"feat_dim": 512, "num_class": ncls, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
 torch.manual_seed(0)
 model = face.get_model(cfg, None, 0).model.train()
-step = face.FaceTrainStep(model, lr=0.01, momentum=0.9, weight_decay=5e-4, max_norm=10.0, ema=True)
+step = face.FaceTrainStep(model, lr=0.01, momentum=0.9, weight_decay=5e-4, max_norm=10.0, ema=True, layer_wise=True)   # cbir.yaml:111-113
 g = torch.Generator(device="cpu"); g.manual_seed(0)
 x = torch.randn(B, 3, 224, 224, generator=g).to(dev)
 y = torch.randint(0, ncls, (B,), generator=g).to(dev)

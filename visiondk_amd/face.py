@@ -351,8 +351,10 @@ class FaceTrainStep:
     launch each with the same global clip factor.  BatchNorm running statistics enter the EMA like every float entry of state_dict()."""
 
     def __init__(self, model: "FaceTrainingModel", lr: float, momentum: float = 0.9, weight_decay: float = 5e-4, label_smoothing: float = 0.0,
-                 max_norm: float = 10.0, ema: bool = True, comm=None):
-        """comm: visiondk_amd.comm.GradAllReduce for data parallelism (one process per GPU): parameters and BatchNorm buffers are broadcast from
+                 max_norm: float = 10.0, ema: bool = True, comm=None, layer_wise: bool = False):
+        """layer_wise: the second entry of the yaml's `optimizer` list (cbir.yaml:113): two parameter groups, backbone + neck at lr and the
+        margin head at 10 x lr (built/layer_optimizer.py:26-29); `param_groups[1]['lr']` is then the head's rate and a scheduler drives both.
+        comm: visiondk_amd.comm.GradAllReduce for data parallelism (one process per GPU): parameters and BatchNorm buffers are broadcast from
         rank 0 at construction and the buffers again before every forward (torch DDP's broadcast_buffers=True, which the reference's
         DDP wrap at vision_engine.py:510 uses); the backbone's flat gradient is all-reduced in buckets while backward is still running, the neck /
         head gradients right after; BatchNorm statistics stay per-rank (the reference's default, SyncBN is its opt-in flag)."""
@@ -364,6 +366,8 @@ class FaceTrainStep:
         self.be = self.eng.be
         self.lr, self.momentum, self.weight_decay, self.label_smoothing, self.max_norm = lr, momentum, weight_decay, label_smoothing, max_norm
         self.param_groups = [{"lr": lr, "momentum": momentum, "weight_decay": weight_decay}]
+        if layer_wise:
+            self.param_groups.append({"lr": lr * 10, "momentum": momentum, "weight_decay": weight_decay})
         self.updates = 0
         self.small = [p for p in self.bb.output_layer.parameters()] + [self.head.weight]
         self.buffers = [b for b in self.bb.output_layer.buffers() if b.dtype.is_floating_point]
@@ -405,6 +409,7 @@ class FaceTrainStep:
         self.updates += 1
         d = 0.9999 * (1 - math.exp(-self.updates / 2000)) if self.ema_flat is not None else 0.0
         lr = self.param_groups[0]["lr"]
+        lr_head = self.param_groups[-1]["lr"]
         B = x.shape[0]
         world = self.comm.world_size if self.comm is not None else 1
         if world > 1:
@@ -450,7 +455,7 @@ class FaceTrainStep:
                                      self.momentum, self.weight_decay, 1.0 / world, be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step")
         for p, m, e in zip(self.small, self.mom_small, self.ema_small):
             g = p.grad.contiguous()
-            be.check(be.lib.vdk_sgd_step(be.ptr(p.data), be.ptr(g), be.ptr(m), be.ptr(e), None, p.numel(), lr, self.momentum, self.weight_decay, 1.0 / world,
+            be.check(be.lib.vdk_sgd_step(be.ptr(p.data), be.ptr(g), be.ptr(m), be.ptr(e), None, p.numel(), lr_head if p is self.head.weight else lr, self.momentum, self.weight_decay, 1.0 / world,
                                          be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step")
         for b, z, zm, e in zip(self.buffers, self._zero, self._zero_m, self.ema_buf):   # EMA of the BatchNorm running statistics (lr = 0: value untouched)
             be.check(be.lib.vdk_sgd_step(be.ptr(b), be.ptr(z), be.ptr(zm), be.ptr(e), None, b.numel(), 0.0, 0.0, 0.0, 1.0, None, self.max_norm, d, first,
