@@ -348,6 +348,22 @@ int vdk_maxpool3s2_bwd(const void* in, const float* dout, float* din, int32_t B,
 int vdk_avgpool_fwd(const void* in, void* out, int32_t B, int32_t Bp, int32_t HW, int32_t C, void* stream);
 int vdk_avgpool_bwd(const void* dfeat, int64_t ld, float* dout, int32_t B, int32_t HW, int32_t C, void* stream);
 
+/* ---- the step in front of the path: validation-time input pipeline ------------------------------------------------
+ * Replaces, for a whole batch, the per-image CPU chain the val / CBIR-gallery dataloaders run (configs/classification/pet.yaml:94-101,
+ * configs/faceX/cbir.yaml:92-99):  ResizeAndPadding2Square(size, training=False) (dataset/transforms.py:325-362: long side to `size` with PIL BILINEAR,
+ * `int(side * (size / max_side))`, centred on a zero canvas)  ->  to_tensor (:466-468: uint8 HWC -> float32 CHW / 255)  ->  normalize (:474-477).
+ * Bit-exact with Pillow's 8-bit two-pass resampling and torchvision's float32 expressions (oracle/preprocess_ref.py).
+ *   pixels   device, uint8: decoded RGB images back to back, each HWC with row stride 3*w; image b starts at byte offsets[b]; the allocation must extend
+ *            to a multiple of 4 bytes (rows are staged with aligned dword loads)
+ *   offsets  device int64 [B];   wh  device int32 [B][2] = (width, height);   max_side  >= every width and height (host-known; sizes the coefficient tables)
+ *   out      device float32 [B][3][S][S];   S <= 1024, sides <= 8192
+ *   status   device int32 [B] or NULL: 0 ok; 1 = an output side truncates to 0 (PIL raises ValueError("height and width must be > 0")), the image's
+ *            output is then the normalised zero canvas; 2 = non-positive side or side > 8192 */
+int vdk_preprocess_workspace_bytes(int32_t B, int32_t S, int32_t max_side, size_t* bytes);
+int vdk_preprocess_resize_pad_normalize(const uint8_t* pixels, const int64_t* offsets, const int32_t* wh, int32_t B, int32_t S, int32_t max_side, float mean0,
+                                        float mean1, float mean2, float std0, float std1, float std2, float* out, int32_t* status, void* ws, size_t ws_bytes,
+                                        void* stream);
+
 /* ---- native ConvNeXt engine: timm ConvNeXt in feature mode (num_classes=0, global_pool='') over flat buffers --------------------
  * Replaces `self.model(x)` of TimmWrapper.forward (models/faceX/backbone/timm_wrapper.py:16-21,51) and its backward for the CNN
  * backbones of the face / CBIR path (`convnext_base`, configs/faceX/cbir.yaml:4-8).  Semantics restated from timm 0.9.16 (not vendored;

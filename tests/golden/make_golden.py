@@ -174,6 +174,24 @@ def main():
     mean, std = ev.test_one_model(pair_list, {n: f for n, f in zip(names, feats)})
     thr = ev.getThreshold(np.array([feats[x] @ feats[y] for x, y in zip(a[:5400], b[:5400])], dtype=np.float32), label[:5400].astype(np.int8))
     np.savez(OUT / "face_pairs.npz", feats=feats, a=a, b=b, label=label, mean=np.float64(mean), std=np.float64(std), thr_first_5400=np.float64(thr))
+    # ---- validation-time input pipeline: the reference's own ResizeAndPadding2Square (dataset/transforms.py:325-365), exec'd from its source range
+    # (the module itself imports cv2 / torchvision, which are not installed); ToTensor + Normalize are torchvision's two float32 tensor expressions.
+    from PIL import Image, ImageOps
+    src = (REF / "dataset/transforms.py").read_text().splitlines()
+    ns = {"Image": Image, "ImageOps": ImageOps, "random": __import__("random")}
+    exec("\n".join(src[324:365]), ns)
+    rng = np.random.default_rng(11)
+    fix = {}
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    for i, (w, h, size) in enumerate([(61, 47, 64), (47, 61, 64), (130, 20, 64), (33, 33, 64), (20, 200, 64), (200, 150, 96), (49, 49, 224), (9, 5, 32)]):
+        yy, xx = np.mgrid[0:h, 0:w]
+        arr = np.stack([(xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)), rng.integers(0, 256, (h, w))], axis=2).astype(np.uint8)
+        arr[h // 3: h // 2, w // 4: w // 2] = rng.integers(0, 256, (h // 2 - h // 3, w // 2 - w // 4, 3), dtype=np.uint8)
+        out = np.asarray(ns["ResizeAndPadding2Square"](size=size, training=False)(Image.fromarray(arr)))
+        t = torch.from_numpy(out.copy()).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+        t.sub_(torch.as_tensor(mean, dtype=torch.float32)[:, None, None]).div_(torch.as_tensor(std, dtype=torch.float32)[:, None, None])
+        fix[f"in{i}"], fix[f"u8_{i}"], fix[f"f32_{i}"], fix[f"size{i}"] = arr, out, t.numpy(), np.int64(size)
+    np.savez_compressed(OUT / "preprocess.npz", n=np.int64(8), mean=np.array(mean), std=np.array(std), **fix)
     print("golden fixtures written to", OUT)
 
 

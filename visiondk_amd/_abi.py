@@ -147,6 +147,8 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_maxpool3s2_bwd": (C.c_int, [P, P, P, I32, I32, I32, I32, P]),
     "vdk_avgpool_fwd": (C.c_int, [P, P, I32, I32, I32, I32, P]),
     "vdk_avgpool_bwd": (C.c_int, [P, I64, P, I32, I32, I32, P]),
+    "vdk_preprocess_workspace_bytes": (C.c_int, [I32, I32, I32, PSZ]),
+    "vdk_preprocess_resize_pad_normalize": (C.c_int, [P, P, P, I32, I32, I32, F32, F32, F32, F32, F32, F32, P, P, P, SZ, P]),
     "vdk_vit_workspace_f32_bytes": (C.c_int, [C.POINTER(VitConfig), PSZ]),
     "vdk_vit_forward_f32": (C.c_int, [C.POINTER(VitConfig), P, P, P, SZ, P, P]),
     "vdk_convnext_workspace_f32_bytes": (C.c_int, [C.POINTER(ConvNextConfig), PSZ]),
