@@ -353,8 +353,8 @@ int vdk_avgpool_bwd(const void* dfeat, int64_t ld, float* dout, int32_t B, int32
  * configs/faceX/cbir.yaml:92-99):  ResizeAndPadding2Square(size, training=False) (dataset/transforms.py:325-362: long side to `size` with PIL BILINEAR,
  * `int(side * (size / max_side))`, centred on a zero canvas)  ->  to_tensor (:466-468: uint8 HWC -> float32 CHW / 255)  ->  normalize (:474-477).
  * Bit-exact with Pillow's 8-bit two-pass resampling and torchvision's float32 expressions (oracle/preprocess_ref.py).
- *   pixels   device, uint8: decoded RGB images back to back, each HWC with row stride 3*w; image b starts at byte offsets[b]; the allocation must extend
- *            to a multiple of 4 bytes (rows are staged with aligned dword loads)
+ *   pixels   device, uint8, 16-byte aligned: decoded RGB images back to back, each HWC with row stride 3*w; image b starts at byte offsets[b]; the
+ *            allocation must extend to a multiple of 16 bytes (rows are staged with aligned 16-byte loads)
  *   offsets  device int64 [B];   wh  device int32 [B][2] = (width, height);   max_side  >= every width and height (host-known; sizes the coefficient tables)
  *   out      device float32 [B][3][S][S];   S <= 1024, sides <= 8192
  *   status   device int32 [B] or NULL: 0 ok; 1 = an output side truncates to 0 (PIL raises ValueError("height and width must be > 0")), the image's

@@ -315,3 +315,4 @@ static inline emu_s16x4 emu_ds_read_tr16_b64(const void* p) {
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_barrier() __syncthreads()
+static inline int __mul24(int a, int b) { return a * b; }

@@ -191,6 +191,16 @@ def main():
         t = torch.from_numpy(out.copy()).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
         t.sub_(torch.as_tensor(mean, dtype=torch.float32)[:, None, None]).div_(torch.as_tensor(std, dtype=torch.float32)[:, None, None])
         fix[f"in{i}"], fix[f"u8_{i}"], fix[f"f32_{i}"], fix[f"size{i}"] = arr, out, t.numpy(), np.int64(size)
+    # soft BCE targets: the reference's own staticmethod (dataset/basedataset.py:198-231), exec'd from its source range
+    import textwrap
+    src = (REF / "dataset/basedataset.py").read_text().splitlines()
+    ns = {"torch": torch}
+    exec(textwrap.dedent("\n".join(src[197:231])), ns)
+    slt = ns["set_label_transforms"].__func__ if hasattr(ns["set_label_transforms"], "__func__") else ns["set_label_transforms"]
+    fix["lab_int"] = slt(3, 7, 0.1).numpy()
+    fix["lab_list"] = slt([0, 1, 0, 0, 1, 0, 1], 7, 0.2).numpy()
+    fix["lab_onehot"] = slt(torch.tensor([1., 0., 0., 1., 0., 0., 0.]), 7, 0.1).numpy()
+    fix["lab_onehot_nosmooth"] = slt(torch.tensor([1., 0., 0., 1., 0., 0., 0.]), 7, 0.0).numpy()
     np.savez_compressed(OUT / "preprocess.npz", n=np.int64(8), mean=np.array(mean), std=np.array(std), **fix)
     print("golden fixtures written to", OUT)
 

@@ -71,7 +71,7 @@ def test_status_codes_and_host_errors(be, dev):
     # the raw ABI reports the same condition per image and still writes the normalised zero canvas for it
     good = np.random.default_rng(0).integers(0, 256, (20, 30, 3), dtype=np.uint8)
     bad = np.full((2, 900, 3), 200, dtype=np.uint8)
-    flat = np.concatenate([good.reshape(-1), bad.reshape(-1), np.zeros(8, np.uint8)])
+    flat = np.concatenate([good.reshape(-1), bad.reshape(-1), np.zeros(32, np.uint8)])
     px = torch.from_numpy(flat).to(dev)
     off = torch.tensor([0, good.size], dtype=torch.int64, device=dev)
     wh = torch.tensor([[30, 20], [900, 2]], dtype=torch.int32, device=dev)
@@ -88,6 +88,16 @@ def test_status_codes_and_host_errors(be, dev):
     canvas = ref.to_tensor_normalize(np.zeros((S, S, 3), np.uint8), m, s)
     assert np.array_equal(_bits(out[1].cpu().numpy()), _bits(canvas))
     assert be.lib.vdk_preprocess_workspace_bytes(2, S, 9000, C.byref(need)) < 0       # sides above 8192 are refused, not truncated
+
+
+def test_soft_targets_vs_reference_staticmethod():
+    z = np.load(G / "preprocess.npz")
+    slt = preprocess.set_label_transforms
+    assert np.array_equal(slt(3, 7, 0.1).numpy(), z["lab_int"])
+    assert np.array_equal(slt([0, 1, 0, 0, 1, 0, 1], 7, 0.2).numpy(), z["lab_list"])
+    onehot = torch.tensor([1., 0., 0., 1., 0., 0., 0.])
+    assert np.array_equal(slt(onehot, 7, 0.1).numpy(), z["lab_onehot"])
+    assert np.array_equal(slt(onehot, 7, 0.0).numpy(), z["lab_onehot_nosmooth"])
 
 
 def test_yaml_list_factory_matches_reference_format(be, dev):

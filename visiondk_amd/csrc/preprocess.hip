@@ -19,7 +19,6 @@
 
 #define PP_PRECISION_BITS 22
 #define PP_MAX_SIDE 8192
-#define PP_LDS_BYTES 32768
 #define PP_THREADS 256
 
 struct PPGeom {
@@ -98,19 +97,32 @@ __device__ __forceinline__ int pp_clip8(int acc) {
   return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
-// CPT output columns per thread (S <= CPT * 256), TB output rows per workgroup
-template <int CPT, int TB>
-__global__ __launch_bounds__(PP_THREADS) void pp_resample_kernel(const unsigned char* __restrict__ pixels, const long* __restrict__ offsets, int S, int KS,
+#define PP_KREG 8   // horizontal taps kept in registers (scale <= 3.5); wider windows read their coefficients from the table
+#define PP_KV 24    // vertical taps per output row kept in LDS (scale <= 11.5)
+
+// CPT output columns per thread (S <= CPT * 256), TB output rows per workgroup, NV 16-byte staging loads per thread and chunk: the chunk buffer holds
+// NV * 4 KB (at least one input row), at most 2 * NV rows
+template <int CPT, int TB, int NV>
+__global__ __launch_bounds__(PP_THREADS, CPT == 1 ? 3 : 1) void pp_resample_kernel(const unsigned char* __restrict__ pixels, const long* __restrict__ offsets, int S, int KS,
                                                                  const PPGeom* __restrict__ geom, const int* __restrict__ tabs, float m0, float m1, float m2, float s0,
                                                                  float s1, float s2, float* __restrict__ out) {
-  __shared__ unsigned int stage[PP_LDS_BYTES / 4 + 2];
+  constexpr int PP_LDS_BYTES = NV * 16 * PP_THREADS, PP_RB = 2 * NV;
+  __shared__ __attribute__((aligned(16))) unsigned int stage[PP_LDS_BYTES / 4 + 16];
+  __shared__ unsigned int hbuf[PP_RB][CPT * PP_THREADS];        // horizontally resampled rows of the chunk, RGB packed per column (read back by the owner only)
   const int b = blockIdx.y, y0 = blockIdx.x * TB, tid = threadIdx.x;
   const PPGeom g = geom[b];
   const int* kh = tabs + (size_t)b * pp_image_stride(S, KS);
   const int* bh = kh + (size_t)S * KS;
   const int* kv = bh + 2 * S;
   const int* bv = kv + (size_t)S * KS;
-  const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+  __shared__ float lut[3][256];                                 // to_tensor + normalize of every uint8 value, per channel
+  __shared__ int kvl[TB][PP_KV];                                // vertical coefficients of the band's rows (tap windows up to PP_KV rows)
+  {
+    const float u = (float)tid / 255.0f;                        // PP_THREADS == 256
+    lut[0][tid] = (u - m0) / s0;
+    lut[1][tid] = (u - m1) / s1;
+    lut[2][tid] = (u - m2) / s2;
+  }
 
   int acc[CPT][TB][3];
 #pragma unroll
@@ -125,58 +137,98 @@ __global__ __launch_bounds__(PP_THREADS) void pp_resample_kernel(const unsigned 
   if (ya < 0) ya = 0;
   if (yb > g.nh) yb = g.nh;
   const bool any_rows = g.status == 0 && ya < yb;
-  int xmin[CPT], xcnt[CPT], xx[CPT];
+  int xmin[CPT], xcnt[CPT], xx[CPT], kreg[CPT][PP_KREG];
 #pragma unroll
   for (int c = 0; c < CPT; ++c) {
     xx[c] = tid + c * PP_THREADS - g.pl;
     const bool on = any_rows && xx[c] >= 0 && xx[c] < g.nw;
     xmin[c] = on ? bh[2 * xx[c]] : 0;
     xcnt[c] = on ? bh[2 * xx[c] + 1] : 0;
+#pragma unroll
+    for (int i = 0; i < PP_KREG; ++i) kreg[c][i] = i < xcnt[c] ? kh[(size_t)xx[c] * KS + i] : 0;
   }
+  for (int t = tid; t < TB * PP_KV; t += PP_THREADS) {
+    const int j = t / PP_KV, i = t % PP_KV, y = y0 + j - g.pt;
+    kvl[j][i] = (any_rows && y >= ya && y < yb && i < bv[2 * y + 1]) ? kv[(size_t)y * KS + i] : 0;
+  }
+  __syncthreads();
   if (any_rows) {
+    // tap windows of the band's output rows (uniform)
+    int vmin[TB], vcnt[TB];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      const int y = y0 + j - g.pt;
+      const bool on = y >= ya && y < yb;
+      vmin[j] = on ? bv[2 * y] : 0;
+      vcnt[j] = on ? bv[2 * y + 1] : 0;
+    }
     const int rbeg = bv[2 * ya], rend = bv[2 * (yb - 1)] + bv[2 * (yb - 1) + 1];
     const int w3 = g.w * 3;
-    int rb = PP_LDS_BYTES / w3;                      // rows per staged chunk
-    if (rb > 16) rb = 16;
+    int rb = (PP_LDS_BYTES - 32) / w3;               // rows per staged chunk
+    if (rb > PP_RB) rb = PP_RB;
     const unsigned char* img = pixels + offsets[b];
     for (int r0 = rbeg; r0 < rend; r0 += rb) {
       const int nr = rend - r0 < rb ? rend - r0 : rb;
       const unsigned char* src = img + (size_t)r0 * w3;
-      const size_t mis = (size_t)src & 3;
-      const unsigned int* src4 = (const unsigned int*)(src - mis);
-      const int ndw = (int)((mis + (size_t)nr * w3 + 3) / 4);
-      __syncthreads();
-      for (int i = tid; i < ndw; i += PP_THREADS) stage[i] = src4[i];
-      __syncthreads();
-      const unsigned char* lrow = (const unsigned char*)stage + mis;
-      for (int rr = 0; rr < nr; ++rr, lrow += w3) {
-        const int r = r0 + rr;
+      const size_t mis = (size_t)src & 15;
+      const u32x4* src16 = (const u32x4*)(src - mis);
+      const int n16 = (int)((mis + (size_t)nr * w3 + 15) / 16);          // <= PP_LDS_BYTES / 16
+      // all loads of the chunk in flight before the first LDS write (a load -> store loop would serialise on the HBM latency)
+      u32x4 v[NV];
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-          // horizontal pass for (r, xx[c]): three channels at once
-          int h0 = 1 << (PP_PRECISION_BITS - 1), h1 = h0, h2 = h0;
-          const int* k = kh + (size_t)(xx[c] < 0 ? 0 : xx[c]) * KS;
-          const unsigned char* p = lrow + xmin[c] * 3;
-          for (int i = 0; i < xcnt[c]; ++i, p += 3) {
-            const int kc = k[i];
-            h0 += p[0] * kc;
-            h1 += p[1] * kc;
-            h2 += p[2] * kc;
-          }
-          h0 = pp_clip8(h0); h1 = pp_clip8(h1); h2 = pp_clip8(h2);
-          // vertical pass: row r feeds the output rows whose tap window contains it
+      for (int i = 0; i < NV; ++i)
+        if (tid + i * PP_THREADS < n16) v[i] = src16[tid + i * PP_THREADS];
+      __syncthreads();
 #pragma unroll
-          for (int j = 0; j < TB; ++j) {
-            const int y = y0 + j - g.pt;
-            if (y >= ya && y < yb) {
-              const int idx = r - bv[2 * y];
-              if ((unsigned)idx < (unsigned)bv[2 * y + 1]) {
-                const int kc = kv[(size_t)y * KS + idx];
-                acc[c][j][0] += h0 * kc;
-                acc[c][j][1] += h1 * kc;
-                acc[c][j][2] += h2 * kc;
-              }
+      for (int i = 0; i < NV; ++i)
+        if (tid + i * PP_THREADS < n16) ((u32x4*)stage)[tid + i * PP_THREADS] = v[i];
+      __syncthreads();
+      // horizontal pass of the chunk's rows: three channels per tap, result rounded to uint8 like Pillow's intermediate image
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) {
+        const unsigned char* lrow = (const unsigned char*)stage + mis + xmin[c] * 3;
+        if (xcnt[c] <= PP_KREG) {
+          for (int rr = 0; rr < nr; ++rr, lrow += w3) {
+            int h0 = 1 << (PP_PRECISION_BITS - 1), h1 = h0, h2 = h0;
+#pragma unroll
+            for (int i = 0; i < PP_KREG; ++i) {          // taps beyond the window carry a zero coefficient (the bytes they read lie inside `stage`)
+              h0 += __mul24((int)lrow[3 * i], kreg[c][i]);
+              h1 += __mul24((int)lrow[3 * i + 1], kreg[c][i]);
+              h2 += __mul24((int)lrow[3 * i + 2], kreg[c][i]);
             }
+            hbuf[rr][tid + c * PP_THREADS] = (unsigned)pp_clip8(h0) | ((unsigned)pp_clip8(h1) << 8) | ((unsigned)pp_clip8(h2) << 16);
+          }
+        } else {
+          const int* k = kh + (size_t)xx[c] * KS;
+          for (int rr = 0; rr < nr; ++rr, lrow += w3) {
+            int h0 = 1 << (PP_PRECISION_BITS - 1), h1 = h0, h2 = h0;
+            const unsigned char* p = lrow;
+            for (int i = 0; i < xcnt[c]; ++i, p += 3) {
+              const int kc = k[i];
+              h0 += __mul24((int)p[0], kc);
+              h1 += __mul24((int)p[1], kc);
+              h2 += __mul24((int)p[2], kc);
+            }
+            hbuf[rr][tid + c * PP_THREADS] = (unsigned)pp_clip8(h0) | ((unsigned)pp_clip8(h1) << 8) | ((unsigned)pp_clip8(h2) << 16);
+          }
+        }
+      }
+      // vertical pass: every output row of the band takes the chunk rows inside its tap window
+#pragma unroll
+      for (int j = 0; j < TB; ++j) {
+        int lo = vmin[j] - r0, hi = vmin[j] + vcnt[j] - r0;
+        if (lo < 0) lo = 0;
+        if (hi > nr) hi = nr;
+        const bool in_lds = vcnt[j] <= PP_KV;
+        const int* kvj = in_lds ? &kvl[j][0] + (r0 - vmin[j]) : kv + (size_t)(y0 + j - g.pt) * KS + (r0 - vmin[j]);
+        for (int rr = lo; rr < hi; ++rr) {
+          const int kc = kvj[rr];
+#pragma unroll
+          for (int c = 0; c < CPT; ++c) {
+            const unsigned px = hbuf[rr][tid + c * PP_THREADS];
+            acc[c][j][0] += __mul24((int)(px & 255u), kc);
+            acc[c][j][1] += __mul24((int)((px >> 8) & 255u), kc);
+            acc[c][j][2] += __mul24((int)((px >> 16) & 255u), kc);
           }
         }
       }
@@ -184,22 +236,20 @@ __global__ __launch_bounds__(PP_THREADS) void pp_resample_kernel(const unsigned 
   }
   // to_tensor + normalize; everything outside the pasted image is the zero canvas of ImageOps.expand
   const size_t plane = (size_t)S * S;
-  float* ob = out + (size_t)b * 3 * plane;
+  float* ob = out + (size_t)b * 3 * plane + (size_t)y0 * S;
 #pragma unroll
   for (int c = 0; c < CPT; ++c) {
     const int ox = tid + c * PP_THREADS;
-    if (ox >= S) continue;
-    const bool col_in = xx[c] >= 0 && xx[c] < g.nw;
+    const bool col_in = any_rows && xx[c] >= 0 && xx[c] < g.nw;
 #pragma unroll
     for (int j = 0; j < TB; ++j) {
-      const int oy = y0 + j;
-      if (oy >= S) continue;
-      const int y = oy - g.pt;
-      const bool in = any_rows && col_in && y >= ya && y < yb;
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        const int u = in ? pp_clip8(acc[c][j][ch]) : 0;
-        ob[ch * plane + (size_t)oy * S + ox] = ((float)u / 255.0f - mean[ch]) / stdv[ch];
+      const int y = y0 + j - g.pt;
+      const bool in = col_in && y >= ya && y < yb;
+      const int u0 = in ? pp_clip8(acc[c][j][0]) : 0, u1 = in ? pp_clip8(acc[c][j][1]) : 0, u2 = in ? pp_clip8(acc[c][j][2]) : 0;
+      if (ox < S && y0 + j < S) {
+        ob[(size_t)j * S + ox] = lut[0][u0];
+        ob[plane + (size_t)j * S + ox] = lut[1][u1];
+        ob[2 * plane + (size_t)j * S + ox] = lut[2][u2];
       }
     }
   }
@@ -231,12 +281,13 @@ int vdk_preprocess_resize_pad_normalize(const uint8_t* pixels, const int64_t* of
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(pp_coeff_kernel, dim3((unsigned)B, 2), dim3(PP_THREADS), 0, st, (const int*)wh, (int)S, KS, geom, tabs, (int*)status);
   if (int e = vdk_check_launch("vdk_preprocess_resize_pad_normalize(coefficients)")) return e;
-#define PP_LAUNCH(CPT, TB)                                                                                                                                    \
-  hipLaunchKernelGGL((pp_resample_kernel<CPT, TB>), dim3((unsigned)((S + TB - 1) / TB), (unsigned)B), dim3(PP_THREADS), 0, st, (const unsigned char*)pixels, \
+#define PP_LAUNCH(CPT, TB, NV)                                                                                                                                    \
+  hipLaunchKernelGGL((pp_resample_kernel<CPT, TB, NV>), dim3((unsigned)((S + TB - 1) / TB), (unsigned)B), dim3(PP_THREADS), 0, st, (const unsigned char*)pixels, \
                      (const long*)offsets, (int)S, KS, (const PPGeom*)geom, (const int*)tabs, mean0, mean1, mean2, std0, std1, std2, out)
-  if (S <= PP_THREADS) PP_LAUNCH(1, 16);
-  else if (S <= 2 * PP_THREADS) PP_LAUNCH(2, 16);
-  else PP_LAUNCH(4, 8);
+  // NV = 8: 32 KB chunk buffer (one 8192-pixel row fits), 16 rows per chunk; a 16 KB / 8-row variant at 4 waves per SIMD measured 11 % slower (spills, twice the chunks)
+  if (S <= PP_THREADS) PP_LAUNCH(1, 16, 8);
+  else if (S <= 2 * PP_THREADS) PP_LAUNCH(2, 16, 8);
+  else PP_LAUNCH(4, 8, 8);
 #undef PP_LAUNCH
   return vdk_check_launch("vdk_preprocess_resize_pad_normalize");
 }

@@ -71,7 +71,7 @@ class ValPipeline:
         offsets[1:] = np.cumsum(sizes)[:-1]
         total = int(sizes.sum())
         pinned = self.device.type == "cuda"
-        buf = torch.empty((total + 3) // 4 * 4 + 4, dtype=torch.uint8, pin_memory=pinned)
+        buf = torch.empty((total + 15) // 16 * 16 + 16, dtype=torch.uint8, pin_memory=pinned)     # the kernel stages rows with aligned 16-byte loads
         nb = buf.numpy()
         for a, o in zip(arrs, offsets):
             nb[o:o + a.size] = a.reshape(-1)
@@ -114,3 +114,18 @@ def create_AugTransforms(augments: List[dict], device=None, backend=None) -> Val
     nm = augments[2]["normalize"]
     nm = {} if nm == "no_params" else dict(nm)
     return ValPipeline(size=rp.get("size", 224), mean=nm.get("mean", IMAGENET_MEAN), std=nm.get("std", IMAGENET_STD), device=device, backend=backend)
+
+
+def set_label_transforms(label, num_classes: int, label_smooth: float) -> torch.Tensor:
+    """dataset/basedataset.py:198-231 — the soft target vector the BCE / focal losses consume (`vdk_bce_logits` takes it as is):
+    one-hot rows from the csv are mapped y -> y * (1 - a) + a / 2; an int class index or a list of 0/1 flags becomes a vector filled with a / 2
+    whose positive entries hold 1 - a / 2."""
+    if isinstance(label, torch.Tensor) and label.size(0) == num_classes:
+        return label * (1 - label_smooth) + (label_smooth * 0.5) if label_smooth > 0 else label
+    vector = torch.zeros(num_classes).fill_(0.5 * label_smooth)
+    if isinstance(label, int):
+        vector[label] = 1 - 0.5 * label_smooth
+    elif isinstance(label, (list, tuple)):
+        indices = torch.nonzero(torch.tensor(label)).squeeze()
+        vector[indices] = 1 - 0.5 * label_smooth
+    return vector
