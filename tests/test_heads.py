@@ -51,6 +51,27 @@ def test_head_logits_loss_and_grads_vs_reference(be, dev, tag):
     assert _rel(df, feats.grad) < 2e-2 and _rel(dW, h.weight.grad) < 2e-2
 
 
+@pytest.mark.parametrize("tag", ["arcface", "circle", "mv_am", "mv_arc"])
+def test_wide_head_fused_form_equals_autograd_form(be, dev, tag):
+    """C >= 4096 takes the vectorised online-softmax kernel (16-byte loads, cos read twice); it must give what the logits-returning form followed by
+    torch's CrossEntropy (label smoothing on) gives.  C is not a multiple of 4: the scalar tail and the zeroed padding columns are covered."""
+    torch.manual_seed(3)
+    D, Cn, B = 64, 5003, 6
+    if tag == "arcface":
+        h = heads.ArcFace(D, Cn, margin_arc=0.35, margin_am=0.0, scale=32, backend=be, device=dev)
+    elif tag == "circle":
+        h = heads.CircleLoss(D, Cn, margin=0.25, gamma=64, backend=be, device=dev)
+    else:
+        h = heads.MV_Softmax(D, Cn, is_am=(tag == "mv_am"), margin=0.35, mv_weight=1.12, scale=32, backend=be, device=dev)
+    feats = torch.randn(B, D, device=dev, requires_grad=True)
+    labels = torch.tensor([0, 5002, 1234, 4096, 17, 4999], device=dev)
+    loss = torch.nn.functional.cross_entropy(h(feats, labels), labels, label_smoothing=0.1)
+    loss.backward()
+    loss_rows, df, dW = h.margin_ce(feats.detach(), labels, label_smoothing=0.1)
+    assert abs(loss_rows.mean().item() - loss.item()) < 2e-6 * abs(loss.item())
+    assert _rel(df, feats.grad) < 2e-2 and _rel(dW, h.weight.grad) < 2e-2
+
+
 def test_head_factory_names():
     f = heads.HeadFactory("arcface", {"feat_dim": 8, "num_class": 16}, backend=None, device="cpu")
     assert f.head_type == "arcface"

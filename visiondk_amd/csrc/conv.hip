@@ -200,25 +200,47 @@ __global__ __launch_bounds__(448) void dwconv7_wgrad_kernel(const float* __restr
   const int c0 = blockIdx.y * DW_CC;
   float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float accb = 0.f;
-  for (long it = blockIdx.x; it < items; it += S) {
+  // software pipeline: the next item's tile loads are issued into registers before this item's FMAs and written to LDS after them, so the HBM latency
+  // hides under the compute (with one workgroup per CU at 92 KB of LDS, load -> barrier -> compute per item left the CU idle for a round trip per item)
+  constexpr int XS_N = IH * IW * (DW_CC / 4), DS_N = TH * TW * (DW_CC / 4), PFX = (XS_N + 447) / 448, PFD = (DS_N + 447) / 448;
+  f32x4 px[PFX], pd[PFD];
+  auto fetch = [&](long it) {
     const int tile = (int)(it % (tx_n * ty_n)), b = (int)(it / (tx_n * ty_n));
     const int y0 = (tile / tx_n) * TH, x0 = (tile % tx_n) * TW;
-    __syncthreads();
-    for (int i = tid; i < IH * IW * (DW_CC / 4); i += 448) {
-      const int cq = i & 15, p = i >> 4, py = p / IW, px = p % IW;
-      const int y = y0 + py - 3, x = x0 + px - 3, c = c0 + cq * 4;
+#pragma unroll
+    for (int k = 0; k < PFX; ++k) {
+      const int i = tid + k * 448;
+      const int cq = i & 15, p = i >> 4, py = p / IW, pxx = p % IW;
+      const int y = y0 + py - 3, x = x0 + pxx - 3, c = c0 + cq * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (y >= 0 && y < H && x >= 0 && x < W && c < C) v = *(const f32x4*)(in + (((long)b * H + y) * W + x) * C + c);
-      *(f32x4*)(xs + p * DW_CC + cq * 4) = v;
+      if (i < XS_N && y >= 0 && y < H && x >= 0 && x < W && c < C) v = *(const f32x4*)(in + (((long)b * H + y) * W + x) * C + c);
+      px[k] = v;
     }
-    for (int i = tid; i < TH * TW * (DW_CC / 4); i += 448) {
-      const int cq = i & 15, p = i >> 4, py = p / TW, px = p % TW;
-      const int y = y0 + py, x = x0 + px, c = c0 + cq * 4;
+#pragma unroll
+    for (int k = 0; k < PFD; ++k) {
+      const int i = tid + k * 448;
+      const int cq = i & 15, p = i >> 4, py = p / TW, pxx = p % TW;
+      const int y = y0 + py, x = x0 + pxx, c = c0 + cq * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (y < H && x < W && c < C) v = *(const f32x4*)(dy + (((long)b * H + y) * W + x) * C + c);
-      *(f32x4*)(ds + p * DW_CC + cq * 4) = v;
+      if (i < DS_N && y < H && x < W && c < C) v = *(const f32x4*)(dy + (((long)b * H + y) * W + x) * C + c);
+      pd[k] = v;
+    }
+  };
+  if ((long)blockIdx.x < items) fetch(blockIdx.x);
+  for (long it = blockIdx.x; it < items; it += S) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PFX; ++k) {
+      const int i = tid + k * 448;
+      if (i < XS_N) *(f32x4*)(xs + (i >> 4) * DW_CC + (i & 15) * 4) = px[k];
+    }
+#pragma unroll
+    for (int k = 0; k < PFD; ++k) {
+      const int i = tid + k * 448;
+      if (i < DS_N) *(f32x4*)(ds + (i >> 4) * DW_CC + (i & 15) * 4) = pd[k];
     }
     __syncthreads();
+    if (it + S < items) fetch(it + S);
 #pragma unroll 1
     for (int h = 0; h < TH; ++h) {
       float d[TW], xv[IW];
