@@ -32,6 +32,23 @@ def test_dwconv7_fwd_dgrad_wgrad(be, dev, B, H, W, C):
     torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,W,C,per_chunk", [(5, 14, 72, 2), (4, 7, 136, 1), (3, 28, 40, 1), (3, 56, 24, 2)])
+def test_dwconv7_persistent_workgroups_walk_over_images(be, dev, B, W, C, per_chunk, monkeypatch):
+    """The row-streaming kernel is persistent: a workgroup keeps its channel chunk and walks over images, prefetching the next image's first rows under
+    the last strip of the current one.  Real launches give a workgroup several images only for B > 512 / chunks, so the tests force it."""
+    monkeypatch.setenv("VDK_DW_ROWS_PER_CHUNK", str(per_chunk))
+    torch.manual_seed(1)
+    x = torch.randn(B, C, W, W)
+    w = torch.randn(C, 1, 7, 7) * 0.1
+    b = torch.randn(C)
+    skip = torch.randn_like(x)
+    y = F.conv2d(x, w, b, padding=3, groups=C)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
+    wt = ops.dwconv7_weight_prep(w.to(dev), backend=be)
+    yk = ops.dwconv7(nhwc(x), wt, b.to(dev), nhwc(skip), backend=be)
+    torch.testing.assert_close(yk.cpu().permute(0, 3, 1, 2), y + skip, rtol=1e-5, atol=1e-5)
+
+
 def test_conv2x2_stride2_as_gemm(be, dev):
     torch.manual_seed(1)
     B, H, W, Ci, Co = 2, 8, 4, 16, 24

@@ -10,6 +10,7 @@
 //   * weight preparation: tap-major depthwise weights, (ky,kx,cin)-ordered 2x2 weights, layer-scale folded into fc2
 //     (W2' = gamma (.) W2) and the chain rule back (dW2 = gamma (.) dW2', dgamma = <dW2', W2> + db2' b2).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "vdk_device.h"
 #include "vdk_host.h"
 
@@ -91,93 +92,100 @@ __global__ __launch_bounds__(TW * (DWF_CC / 4)) void dwconv7_kernel(const float*
   }
 }
 
-// Row-streaming variant for ConvNeXt's square maps (W = 56 / 28 / 14 / 7): one workgroup owns an image and a channel chunk and walks down the map in
-// strips of 7 output rows, keeping the 13 input rows a strip needs in an LDS ring (6 of them are reused by the next strip) while the next 7 rows are
-// prefetched into registers.  Every input element is read from HBM once (the tiled kernel above re-reads its halo: 2.65x), x-halo columns are zeros.
+// Row-streaming variant for ConvNeXt's square maps (W = 56 / 28 / 14 / 7): a PERSISTENT workgroup owns a channel chunk and walks over images; within an
+// image it walks down the map in strips of 7 output rows, keeping the 13 input rows a strip needs in an LDS ring (6 of them are reused by the next strip).
+// The rows the NEXT step needs -- the next strip's 7 new rows, or the first 13 rows of the next image at an image's last strip -- are loaded into registers
+// before the strip's FMAs and written to the ring after them, so no HBM round trip is exposed between images (with 2 workgroups per CU at 79 KB of LDS a
+// load -> barrier -> compute sequence per image left the CU waiting: 210 us against an 85 us byte floor at 14 x 14 x 512).
+// Every input element is read from HBM once (the tiled kernel above re-reads its halo: 2.65x), x-halo columns are zeros.
 // threads = W columns x CC/4 channel quads; a thread owns one column x one quad and produces the strip's 7 outputs of that column.
 template <int W, int CC>
-__global__ __launch_bounds__(W * (CC / 4)) void dwconv7_rows_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
+__global__ __launch_bounds__(W * (CC / 4), 2) void dwconv7_rows_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
                                                                       const float* res, float* out /* may alias res */, bf16_t* __restrict__ outb, int B, int C,
                                                                       int flip) {
   constexpr int H = W, IW = W + 6, CQ = CC / 4, NT = W * CQ, RD = 13, NEW = 7;
-  constexpr int PF = (NEW * IW * CQ + NT - 1) / NT;                      // prefetch registers (float4) per thread
   __shared__ __attribute__((aligned(16))) float ring[RD * IW * CC];
   __shared__ __attribute__((aligned(16))) float ws[49 * CC];
   const int tid = threadIdx.x;
   const int nchunk = (C + CC - 1) / CC;
-  const int c0 = (blockIdx.x % nchunk) * CC, b = blockIdx.x / nchunk;    // channel chunk fastest: neighbouring workgroups share cache lines
-  for (int i = tid; i < 49 * CQ; i += NT) {
-    const int cq = i % CQ, t = i / CQ, c = c0 + cq * 4;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (c < C) v = *(const f32x4*)(wt + (long)(flip ? 48 - t : t) * C + c);
-    *(f32x4*)(ws + t * CC + cq * 4) = v;
-  }
-  // element e of a block of rows [y0, y0 + n): row y0 + e / (IW*CQ), padded column px = (e / CQ) % IW (image column px - 3), quad e % CQ
-  auto load_elem = [&](int y, int px, int cq) -> f32x4 {
-    const int x = px - 3, c = c0 + cq * 4;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (y >= 0 && y < H && x >= 0 && x < W && c < C) v = *(const f32x4*)(in + (((long)b * H + y) * W + x) * C + c);
-    return v;
-  };
-  // first strip: rows -3 .. 9 straight into the ring (row y lives in slot (y + 3) % 13)
-  for (int e = tid; e < RD * IW * CQ; e += NT) {
-    const int cq = e % CQ, px = (e / CQ) % IW, r = e / (CQ * IW);
-    *(f32x4*)(ring + ((r % RD) * IW + px) * CC + cq * 4) = load_elem(r - 3, px, cq);
-  }
-  __syncthreads();
+  const int c0 = (blockIdx.x % nchunk) * CC;                             // gridDim.x is a multiple of nchunk: the chunk (and its taps) stay with the workgroup
+  const int bstep = gridDim.x / nchunk;
   const int cq = tid % CQ, col = tid / CQ, c = c0 + cq * 4;
-  f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-  if (bias && c < C) b4 = *(const f32x4*)(bias + c);
-  for (int s0 = 0; s0 < H; s0 += NEW) {
-    // prefetch the 7 new rows of the next strip: rows s0 + 10 .. s0 + 16
-    f32x4 pf[PF];
-    const bool more = s0 + NEW < H;
-    if (more) {
+  for (int i = tid; i < 49 * CQ; i += NT) {
+    const int q = i % CQ, t = i / CQ, cc = c0 + q * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (cc < C) v = *(const f32x4*)(wt + (long)(flip ? 48 - t : t) * C + cc);
+    *(f32x4*)(ws + t * CC + q * 4) = v;
+  }
+  for (int i = tid; i < RD * 6 * CQ; i += NT) {                          // x-halo columns: zero once, never written again
+    const int q = i % CQ, h = (i / CQ) % 6, slot = i / (6 * CQ);
+    *(f32x4*)(ring + (slot * IW + (h < 3 ? h : W + h)) * CC + q * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  // a block of rows [y0, y0 + n): the thread moves its own (column, quad) element of every row -- one register per row, the address pattern of its outputs
+  f32x4 pf[RD];
+  auto issue = [&](int bb, int y0, int n) {
 #pragma unroll
-      for (int k = 0; k < PF; ++k) {
-        const int e = tid + k * NT;
-        if (e < NEW * IW * CQ) { const int q = e % CQ, px = (e / CQ) % IW, r = e / (CQ * IW); pf[k] = load_elem(s0 + 10 + r, px, q); }
+    for (int k = 0; k < RD; ++k) {
+      const int y = y0 + k;
+      if (k < n) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (y >= 0 && y < H && c < C) v = *(const f32x4*)(in + (((long)bb * H + y) * W + col) * C + c);
+        pf[k] = v;
       }
     }
-    f32x4 acc[NEW];
+  };
+  auto commit = [&](int y0, int n) {                                     // row y lives in ring slot (y + 3) % 13
 #pragma unroll
-    for (int o = 0; o < NEW; ++o) acc[o] = b4;
+    for (int k = 0; k < RD; ++k)
+      if (k < n) *(f32x4*)(ring + (((y0 + 3 + k) % RD) * IW + col + 3) * CC + cq * 4) = pf[k];
+  };
+  f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+  if (bias && c < C) b4 = *(const f32x4*)(bias + c);
+  int b = blockIdx.x / nchunk;
+  if (b < B) { issue(b, -3, RD); commit(-3, RD); }
+  __syncthreads();
+  for (; b < B; b += bstep) {
+    for (int s0 = 0; s0 < H; s0 += NEW) {
+      // what the next step needs: rows s0 + 10 .. s0 + 16 of this image, or rows -3 .. 9 of the workgroup's next image
+      const bool more = s0 + NEW < H, next_img = !more && b + bstep < B;
+      if (more) issue(b, s0 + 10, NEW);
+      else if (next_img) issue(b + bstep, -3, RD);
+      f32x4 acc[NEW];
+#pragma unroll
+      for (int o = 0; o < NEW; ++o) acc[o] = b4;
 #pragma unroll 1
-    for (int j = 0; j < 7; ++j) {
-      f32x4 wj[7];
+      for (int j = 0; j < 7; ++j) {
+        f32x4 wj[7];
 #pragma unroll
-      for (int i = 0; i < 7; ++i) wj[i] = *(const f32x4*)(ws + (i * 7 + j) * CC + cq * 4);
+        for (int i = 0; i < 7; ++i) wj[i] = *(const f32x4*)(ws + (i * 7 + j) * CC + cq * 4);
 #pragma unroll
-      for (int r = 0; r < RD; ++r) {                                   // input row s0 - 3 + r, ring slot (s0 + r) % 13
-        const f32x4 v = *(const f32x4*)(ring + (((s0 + r) % RD) * IW + col + j) * CC + cq * 4);
+        for (int r = 0; r < RD; ++r) {                                   // input row s0 - 3 + r, ring slot (s0 + r) % 13
+          const f32x4 v = *(const f32x4*)(ring + (((s0 + r) % RD) * IW + col + j) * CC + cq * 4);
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-          const int o = r - i;
-          if (o >= 0 && o < NEW) {
+          for (int i = 0; i < 7; ++i) {
+            const int o = r - i;
+            if (o >= 0 && o < NEW) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(v[e], wj[i][e], acc[o][e]);
+              for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(v[e], wj[i][e], acc[o][e]);
+            }
           }
         }
       }
-    }
-    if (c < C) {
+      if (c < C) {
 #pragma unroll
-      for (int o = 0; o < NEW; ++o) {
-        const long off = (((long)b * H + s0 + o) * W + col) * C + c;
-        f32x4 v = acc[o];
-        if (res) { const f32x4 r4 = *(const f32x4*)(res + off); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
-        if (out) *(f32x4*)(out + off) = v;
-        if (outb) *(u32x2*)(outb + off) = (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        for (int o = 0; o < NEW; ++o) {
+          const long off = (((long)b * H + s0 + o) * W + col) * C + c;
+          f32x4 v = acc[o];
+          if (res) { const f32x4 r4 = *(const f32x4*)(res + off); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
+          if (out) *(f32x4*)(out + off) = v;
+          if (outb) *(u32x2*)(outb + off) = (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        }
       }
-    }
-    if (more) {
-      __syncthreads();                                                   // everybody is done reading rows s0 - 3 .. s0 + 3
-#pragma unroll
-      for (int k = 0; k < PF; ++k) {
-        const int e = tid + k * NT;
-        if (e < NEW * IW * CQ) { const int q = e % CQ, px = (e / CQ) % IW, r = e / (CQ * IW); *(f32x4*)(ring + (((s0 + 13 + r) % RD) * IW + px) * CC + q * 4) = pf[k]; }
+      if (more || next_img) {
+        __syncthreads();                                                 // everybody is done reading the ring rows about to be replaced
+        if (more) commit(s0 + 10, NEW); else commit(-3, RD);
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
 }
@@ -347,6 +355,14 @@ __global__ __launch_bounds__(256) void lscale_grad_kernel(const float* __restric
 
 extern "C" {
 
+// persistent grid of the row-streaming kernel: about two workgroups per CU (their LDS footprint), a whole number of images per channel chunk
+static unsigned dw_rows_grid(int B, int nchunk) {
+  int per_chunk = (2 * 256 + nchunk - 1) / nchunk;
+  if (const char* e = getenv("VDK_DW_ROWS_PER_CHUNK")) { const int v = atoi(e); if (v > 0) per_chunk = v; }   // tests: force several images per workgroup
+  if (per_chunk > B) per_chunk = B;
+  if (per_chunk < 1) per_chunk = 1;
+  return (unsigned)per_chunk * (unsigned)nchunk;
+}
 int vdk_dwconv7_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out, void* out_bf16, int32_t B, int32_t H, int32_t W,
                     int32_t C, int32_t flip, void* stream) {
   if (!in || !wt || (!out && !out_bf16) || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return vdk_fail(VDK_EINVAL, "vdk_dwconv7_fwd: bad argument (C % 4 == 0)");
@@ -355,7 +371,7 @@ int vdk_dwconv7_fwd(const float* in, const float* wt, const float* bias, const f
   hipLaunchKernelGGL((dwconv7_kernel<TH, TW>), dim3((unsigned)(((W + TW - 1) / TW) * ((H + TH - 1) / TH)) * (unsigned)B, cy), dim3(TW * (DWF_CC / 4)), 0, \
                      (hipStream_t)stream, in, wt, bias, res, out, (bf16_t*)out_bf16, (int)B, (int)H, (int)W, (int)C, (int)flip)
 #define DW_ROWS(WW, CCC)                                                                                                                             \
-  hipLaunchKernelGGL((dwconv7_rows_kernel<WW, CCC>), dim3((unsigned)B * (unsigned)((C + CCC - 1) / CCC)), dim3(WW * (CCC / 4)), 0, (hipStream_t)stream, in, wt, bias, \
+  hipLaunchKernelGGL((dwconv7_rows_kernel<WW, CCC>), dim3(dw_rows_grid(B, (C + CCC - 1) / CCC)), dim3(WW * (CCC / 4)), 0, (hipStream_t)stream, in, wt, bias, \
                      res, out, (bf16_t*)out_bf16, (int)B, (int)C, (int)flip)
   if (H == W && W == 56) DW_ROWS(56, 16);
   else if (H == W && W == 28) DW_ROWS(28, 32);
