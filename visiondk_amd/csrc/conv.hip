@@ -386,14 +386,15 @@ int vdk_dwconv7_fwd(const float* in, const float* wt, const float* bias, const f
 }
 
 static void dw_wgrad_tile(int H, int W, int* th, int* tw) {
-  if (H % 7 == 0 && W % 14 == 0) { *th = 7; *tw = 14; }
+  if (H % 14 == 0 && W % 14 == 0) { *th = 14; *tw = 14; }      // 152 KB of LDS, one workgroup per CU: a 14 x 14 map is one tile, no halo re-reads
+  else if (H % 7 == 0 && W % 14 == 0) { *th = 7; *tw = 14; }
   else if (H % 7 == 0 && W % 7 == 0) { *th = 7; *tw = 7; }
   else { *th = 8; *tw = 8; }
 }
 static int dw_slices(int B, int H, int W, int C) {
   int th, tw; dw_wgrad_tile(H, W, &th, &tw);
   const long items = (long)B * ((W + tw - 1) / tw) * ((H + th - 1) / th);
-  long s = 1024 / ((C + DW_CC - 1) / DW_CC);
+  long s = (th == 14 ? 256 : 1024) / ((C + DW_CC - 1) / DW_CC);   // 14 x 14 tiles: one resident workgroup per CU, several items each (pipelined)
   if (s > items) s = items;
   if (s < 1) s = 1;
   return (int)s;
@@ -412,7 +413,8 @@ int vdk_dwconv7_wgrad(const float* in, const float* dy, float* dw, float* db, in
   if (!ws || ws_bytes < (size_t)S * C * 50 * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_dwconv7_wgrad: workspace too small");
   int th, tw; dw_wgrad_tile(H, W, &th, &tw);
   const dim3 grid((unsigned)S, (unsigned)((C + DW_CC - 1) / DW_CC));
-  if (tw == 14) hipLaunchKernelGGL((dwconv7_wgrad_kernel<7, 14>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
+  if (th == 14) hipLaunchKernelGGL((dwconv7_wgrad_kernel<14, 14>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
+  else if (tw == 14) hipLaunchKernelGGL((dwconv7_wgrad_kernel<7, 14>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
   else if (tw == 7) hipLaunchKernelGGL((dwconv7_wgrad_kernel<7, 7>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
   else hipLaunchKernelGGL((dwconv7_wgrad_kernel<8, 8>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
   int rc = vdk_reduce_rows_f32((const float*)ws, (int64_t)C * 50, S, (int64_t)C * 49, dw, 1.0f, stream);

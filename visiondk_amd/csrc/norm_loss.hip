@@ -9,7 +9,10 @@
 
 // ------------------------------------------------------------------------------------------------
 // y[r] = (x[r] - mean) * rstd * gamma + beta  (x fp32 rows at stride ldx; y bf16 or fp32; C % 4 == 0)
-template <bool OUT_BF16>
+// MAXJ * 256 >= C: the row is loaded ONCE into registers (all loads in flight together) and mean, variance and output come from there; re-reading x for
+// each of the three passes cost three dependent memory round trips per row (stage-0 ConvNeXt rows, C = 128: 672 us against a 246 us byte floor).
+// The summation order per lane is the one of the three-pass form, so results are bit-identical to it.
+template <bool OUT_BF16, int MAXJ>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx, int T, int C,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, void* __restrict__ y, long ldy, float* __restrict__ mean,
@@ -18,25 +21,35 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   const int lane = threadIdx.x & 63;
   if (row >= T) return;
   const float* xr = x + (long)row * ldx;
+  f32x4 v[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) { const int c = lane * 4 + j * 256; if (c < C) v[j] = *(const f32x4*)(xr + c); }
   float s = 0.f;
-  for (int c = lane * 4; c < C; c += 256) { f32x4 v = *(const f32x4*)(xr + c); s += (v[0] + v[1]) + (v[2] + v[3]); }
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) { const int c = lane * 4 + j * 256; if (c < C) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]); }
   const float mu = wave_sum(s) / (float)C;
   float q = 0.f;
-  for (int c = lane * 4; c < C; c += 256) {
-    f32x4 v = *(const f32x4*)(xr + c);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { float d = v[e] - mu; q = fmaf(d, d, q); }
+  for (int j = 0; j < MAXJ; ++j) {
+    const int c = lane * 4 + j * 256;
+    if (c < C) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { float d = v[j][e] - mu; q = fmaf(d, d, q); }
+    }
   }
   const float rs = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
   if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
-  for (int c = lane * 4; c < C; c += 256) {
-    f32x4 v = *(const f32x4*)(xr + c);
-    f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
-    float o[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (v[e] - mu) * rs * g[e] + b[e];
-    if (OUT_BF16) *(u32x2*)((bf16_t*)y + (long)row * ldy + c) = (u32x2){pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
-    else *(f32x4*)((float*)y + (long)row * ldy + c) = (f32x4){o[0], o[1], o[2], o[3]};
+  for (int j = 0; j < MAXJ; ++j) {
+    const int c = lane * 4 + j * 256;
+    if (c < C) {
+      f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mu) * rs * g[e] + b[e];
+      if (OUT_BF16) *(u32x2*)((bf16_t*)y + (long)row * ldy + c) = (u32x2){pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+      else *(f32x4*)((float*)y + (long)row * ldy + c) = (f32x4){o[0], o[1], o[2], o[3]};
+    }
   }
 }
 
@@ -368,13 +381,15 @@ int vdk_layernorm_fwd(const float* x, int64_t ldx, int32_t T, int32_t C, const f
   if (!x || !gamma || !beta || !y || T < 0 || C <= 0 || (C & 3) || (ldx & 3) || (ldy & 3))
     return vdk_fail(VDK_EINVAL, "vdk_layernorm_fwd: bad argument (C, ldx, ldy % 4 == 0)");
   if (T == 0) return VDK_OK;
+  if (C > 4096) return vdk_fail(VDK_EUNSUPPORTED, "vdk_layernorm_fwd: C <= 4096");
   dim3 grid((unsigned)((T + 3) / 4));
-  if (y_dtype == VDK_BF16)
-    hipLaunchKernelGGL((ln_fwd_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta,
-                       eps, y, (long)ldy, mean, rstd);
-  else
-    hipLaunchKernelGGL((ln_fwd_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta,
-                       eps, y, (long)ldy, mean, rstd);
+#define LNF(BF, MJ) hipLaunchKernelGGL((ln_fwd_kernel<BF, MJ>), grid, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta, eps, y, \
+                                       (long)ldy, mean, rstd)
+  const bool bf = y_dtype == VDK_BF16;
+  if (C <= 256) { if (bf) LNF(true, 1); else LNF(false, 1); }
+  else if (C <= 1024) { if (bf) LNF(true, 4); else LNF(false, 4); }
+  else { if (bf) LNF(true, 16); else LNF(false, 16); }
+#undef LNF
   return vdk_check_launch("vdk_layernorm_fwd");
 }
 
