@@ -201,6 +201,11 @@ int vdk_sumsq_f32(const float* g, int64_t n, float* out, void* ws, size_t ws_byt
 int vdk_sgd_step(float* params, const float* grads, float* momentum_buf, float* ema, void* params_bf16, int64_t n, float lr,
                  float momentum, float weight_decay, float grad_scale, const float* normsq, float max_norm, float ema_decay,
                  int32_t first_step, void* stream);
+/* The same pass for a train step captured in a hipGraph (torch.cuda.CUDAGraph): by-value kernel arguments freeze at capture, but the scheduler changes lr
+ * (engine/scheduler.py) and ModelEMA's decay warms up every update (models/ema.py:24), so lr, momentum, weight_decay, ema_decay and first_step (!= 0)
+ * are read from DEVICE memory `hyper` f32 [5] when the kernel runs. */
+int vdk_sgd_step_graph(float* params, const float* grads, float* momentum_buf, float* ema, void* params_bf16, int64_t n, const float* hyper, float grad_scale,
+                       const float* normsq, float max_norm, void* stream);
 /* SAM.first_step (engine/optimizer.py:43-55,77-87): normsq_out = sum((|p| or 1) * g)^2; old_params = params;
  * params += (p^2 or 1) * g * rho / (sqrt(normsq) + 1e-12).  second_step = copy old_params back + vdk_sgd_step on the new grads.
  * ws: vdk_sumsq_workspace_bytes(). */
@@ -342,9 +347,11 @@ int vdk_bn_act_fwd(const float* x, int64_t R, int32_t C, const float* gamma, con
                    void* ws, size_t ws_bytes, vdk_stat_sync_fn sync, void* user, void* stream);
 int vdk_bn_act_bwd(const float* x, const float* dout, const void* out_bf16, int64_t R, int32_t C, const float* gamma, const float* save_mean, const float* save_invstd,
                    void* dy_bf16, float* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, vdk_stat_sync_fn sync, void* user, void* stream);
-/* nn.MaxPool2d(3, 2, 1) on bf16 NHWC (backward routes to the FIRST maximum in (ky, kx) order, like torch) and global average pooling */
-int vdk_maxpool3s2_fwd(const void* in, void* out, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
-int vdk_maxpool3s2_bwd(const void* in, const float* dout, float* din, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+/* nn.MaxPool2d(3, 2, 1) on bf16 NHWC (backward routes to the FIRST maximum in (ky, kx) order, like torch) and global average pooling.
+ * argmax (optional, uint8 [B, OH, OW, C]): the winning window position 0..8 written by the forward; the backward uses it when given (in may then be NULL),
+ * else it re-derives the winners from `in`. */
+int vdk_maxpool3s2_fwd(const void* in, void* out, uint8_t* argmax, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+int vdk_maxpool3s2_bwd(const void* in, const uint8_t* argmax, const float* dout, float* din, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 int vdk_avgpool_fwd(const void* in, void* out, int32_t B, int32_t Bp, int32_t HW, int32_t C, void* stream);
 int vdk_avgpool_bwd(const void* dfeat, int64_t ld, float* dout, int32_t B, int32_t HW, int32_t C, void* stream);
 

@@ -148,3 +148,48 @@ def test_progressive_resizing_other_resolution(be, dev):
         x = torch.randn(2, 3, size, size)
         with torch.no_grad():
             assert _rel(model(x.to(dev)), ref(x)) < 3e-2
+
+
+def test_sgd_step_with_device_hyperparameters_equals_by_value_form(be, dev):
+    """vdk_sgd_step_graph reads lr / momentum / weight decay / EMA decay / first-step flag from device memory (what a hipGraph replay needs); same bits."""
+    torch.manual_seed(0)
+    n = 1000 + 3
+    p0, g, m0, e0 = torch.randn(n), torch.randn(n), torch.randn(n), torch.randn(n)
+    nsq = (g * g).sum().reshape(1)
+    for first in (1, 0):
+        outs = []
+        for form in ("value", "device"):
+            p, m, e = p0.clone().to(dev), m0.clone().to(dev), e0.clone().to(dev)
+            pb = torch.empty(n, dtype=torch.bfloat16, device=dev)
+            if form == "value":
+                be.check(be.lib.vdk_sgd_step(be.ptr(p), be.ptr(g.to(dev)), be.ptr(m), be.ptr(e), be.ptr(pb), n, 0.03, 0.9, 5e-4, 0.5, be.ptr(nsq.to(dev)), 2.0, 0.37,
+                                             first, be.stream()), "sgd")
+            else:
+                hyper = torch.tensor([0.03, 0.9, 5e-4, 0.37, float(first)], dtype=torch.float32, device=dev)
+                be.check(be.lib.vdk_sgd_step_graph(be.ptr(p), be.ptr(g.to(dev)), be.ptr(m), be.ptr(e), be.ptr(pb), n, be.ptr(hyper), 0.5, be.ptr(nsq.to(dev)), 2.0,
+                                                   be.stream()), "sgd graph")
+            outs.append((p.cpu(), m.cpu(), e.cpu(), pb.float().cpu()))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_graph_captured_step_equals_eager_step(hip):
+    """ResNetTrainStep(graph=True): the whole step replayed from a hipGraph, with a learning rate that changes between steps and the EMA warm-up decay,
+    gives bit-identical weights, momentum, EMA, BatchNorm statistics and losses to the eager launch sequence."""
+    res = []
+    for graph in (False, True):
+        spec = resnet.ResNetSpec(img_size=64, widths=(16, 32, 64, 128), depths=(2, 2, 2, 2), num_classes=5)
+        model = resnet.ResNet(spec, device="cuda", backend=hip, seed=3)
+        step = resnet.ResNetTrainStep(model, lr=0.05, momentum=0.9, weight_decay=5e-4, loss="bce", max_norm=1.0, ema=True, graph=graph)
+        gen = torch.Generator().manual_seed(0)
+        losses = []
+        for it in range(5):
+            x = torch.randn(8, 3, 64, 64, generator=gen).cuda()
+            y = (torch.rand(8, 5, generator=gen) > 0.5).float().cuda()
+            step.param_groups[0]["lr"] = 0.05 * (0.8 ** it)
+            losses.append(step.step(x, y).clone())
+        torch.cuda.synchronize()
+        res.append((model.engine.params.clone(), step.momentum_buf.clone(), step.ema.clone(), model.engine.buffers.clone(), torch.stack(losses)))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

@@ -78,3 +78,8 @@ def test_maxpool_first_max_rule_and_avgpool(be, dev):
     assert torch.equal(yk.float().cpu().permute(0, 3, 1, 2), y.detach())
     din = ops.maxpool3s2_bwd(a, nhwc(dy).to(dev), backend=be)
     torch.testing.assert_close(din.cpu().permute(0, 3, 1, 2), xr.grad, rtol=1e-6, atol=1e-6)
+    # the forward's argmax map (what the engine keeps) routes the gradient to the same winners, bit for bit, without re-reading the windows
+    yk2, arg = ops.maxpool3s2(a, want_argmax=True, backend=be)
+    assert torch.equal(yk2, yk) and arg.dtype == torch.uint8 and int(arg.max()) <= 8
+    din2 = ops.maxpool3s2_bwd(a, nhwc(dy).to(dev), argmax=arg, backend=be)
+    assert torch.equal(din2, din)

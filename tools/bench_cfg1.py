@@ -13,7 +13,8 @@ dev = torch.device("cuda:0")
 cfg = {"task": "classification", "name": "timm-resnet18", "image_size": 224, "num_classes": 5, "pretrained": False, "kwargs": {}}
 wrap = face.get_model(cfg, None, 0)
 model = wrap.model
-step = resnet.ResNetTrainStep(model, lr=0.01, momentum=0.937, weight_decay=5e-4, loss="bce", max_norm=10.0, ema=True)
+use_graph = os.environ.get("VDK_CFG1_EAGER", "0") != "1"           # default: the step replayed from a hipGraph (launch-bound at this size)
+step = resnet.ResNetTrainStep(model, lr=0.01, momentum=0.937, weight_decay=5e-4, loss="bce", max_norm=10.0, ema=True, graph=use_graph)
 g = torch.Generator(device="cpu"); g.manual_seed(0)
 x = torch.randn(B, 3, 224, 224, generator=g); t = (torch.rand(B, 5, generator=g) > 0.5).float()
 xd, td = x.to(dev), t.to(dev)
@@ -37,6 +38,6 @@ opt = torch.optim.SGD(ref.parameters(), lr=0.01, momentum=0.937, weight_decay=5e
 def cpu_step():
     opt.zero_grad(); torch.nn.functional.binary_cross_entropy_with_logits(ref(x), t).backward(); torch.nn.utils.clip_grad_norm_(ref.parameters(), 10.0); opt.step()
 cpu_step(); c0 = time.time(); cpu_step(); cpu_step(); cdt = (time.time() - c0) / 2
-print(json.dumps({"workload": f"cfg1 ResNet-18, 5 labels, BCE, bs={B}, 224x224, fwd+bwd+clip+SGD+EMA", "images_per_sec": B / dt, "ms_per_step": dt * 1e3,
+print(json.dumps({"workload": f"cfg1 ResNet-18, 5 labels, BCE, bs={B}, 224x224, fwd+bwd+clip+SGD+EMA", "launch": "hipGraph replay" if use_graph else "eager", "images_per_sec": B / dt, "ms_per_step": dt * 1e3,
                   "first_loss": loss0, "first_loss_oracle_fp32": loss_ref, "last_loss": rows.sum().item() / (B * 5),
                   "cpu_baseline": {"images_per_sec": B / cdt, "cores": usable_cores(), "kind": "port", "sample": "oracle/resnet_ref.py fwd+bwd+clip+SGD, 2 steps"}}))

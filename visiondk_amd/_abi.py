@@ -104,6 +104,7 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_sumsq_workspace_bytes": (C.c_int, [PSZ]),
     "vdk_sumsq_f32": (C.c_int, [P, I64, P, P, SZ, P]),
     "vdk_sgd_step": (C.c_int, [P, P, P, P, P, I64, F32, F32, F32, F32, P, F32, F32, I32, P]),
+    "vdk_sgd_step_graph": (C.c_int, [P, P, P, P, P, I64, P, F32, P, F32, P]),
     "vdk_mixup": (C.c_int, [P, P, F32, I32, I64, P, P]),
     "vdk_sam_first_step": (C.c_int, [P, P, P, I64, F32, I32, P, P, SZ, P]),
     "vdk_ohem_mask": (C.c_int, [P, I64, I32, I32, P, I32, F32, I64, P, P, P]),
@@ -143,8 +144,8 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_bn_rows_workspace_bytes": (C.c_int, [I64, I32, PSZ]),
     "vdk_bn_act_fwd": (C.c_int, [P, I64, I32, P, P, C.c_float, C.c_float, I32, P, P, P, P, I32, P, P, P, P, P, SZ, P, P, P]),
     "vdk_bn_act_bwd": (C.c_int, [P, P, P, I64, I32, P, P, P, P, P, P, P, P, SZ, P, P, P]),
-    "vdk_maxpool3s2_fwd": (C.c_int, [P, P, I32, I32, I32, I32, P]),
-    "vdk_maxpool3s2_bwd": (C.c_int, [P, P, P, I32, I32, I32, I32, P]),
+    "vdk_maxpool3s2_fwd": (C.c_int, [P, P, P, I32, I32, I32, I32, P]),
+    "vdk_maxpool3s2_bwd": (C.c_int, [P, P, P, P, I32, I32, I32, I32, P]),
     "vdk_avgpool_fwd": (C.c_int, [P, P, I32, I32, I32, I32, P]),
     "vdk_avgpool_bwd": (C.c_int, [P, I64, P, I32, I32, I32, P]),
     "vdk_preprocess_workspace_bytes": (C.c_int, [I32, I32, I32, PSZ]),

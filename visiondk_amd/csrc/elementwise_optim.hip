@@ -108,11 +108,14 @@ struct SgdArgs {
   float lr, momentum, weight_decay, max_norm, ema_decay, grad_scale;
   const float* normsq;   // device scalar: sum g^2 (before grad_scale); NULL = no clipping
   int first_step;
+  const float* hyper;    // device [5] or NULL: lr, momentum, weight_decay, ema_decay, first_step (!= 0) override the by-value fields, so that a step
+                         // captured in a hipGraph can be replayed while the schedule and the EMA warm-up move on
 };
 // torch.nn.utils.clip_grad_norm_: coef = clamp(max_norm / (norm + 1e-6), max=1); g *= coef
 // torch.optim.SGD (nesterov=False, dampening=0): g += wd*p; buf = first ? g : mom*buf + g; p -= lr*buf
 // ModelEMA.update: v = d*v + (1-d)*p
 __global__ __launch_bounds__(256) void sgd_step_kernel(SgdArgs a) {
+  if (a.hyper) { a.lr = a.hyper[0]; a.momentum = a.hyper[1]; a.weight_decay = a.hyper[2]; a.ema_decay = a.hyper[3]; a.first_step = a.hyper[4] != 0.f; }
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const long n4 = (a.n + 3) >> 2;
   if (i >= n4) return;
@@ -308,18 +311,31 @@ int vdk_sumsq_f32(const float* g, int64_t n, float* out, void* ws, size_t ws_byt
 // One fused pass over flat buffers: [clip by global norm] -> SGD(momentum, wd) -> [EMA] -> [bf16 refresh].
 // grad_scale multiplies g first (1/loss_scale, or 1/world for summed all-reduce).  normsq = device scalar
 // holding sum g^2 of the UNscaled grads, or NULL to skip clipping.  m / ema / params_bf16 may be NULL.
-int vdk_sgd_step(float* params, const float* grads, float* momentum_buf, float* ema, void* params_bf16, int64_t n, float lr,
-                 float momentum, float weight_decay, float grad_scale, const float* normsq, float max_norm, float ema_decay,
-                 int32_t first_step, void* stream) {
+static int sgd_launch(const char* what, float* params, const float* grads, float* momentum_buf, float* ema, void* params_bf16, int64_t n, float lr, float momentum,
+                      float weight_decay, float grad_scale, const float* normsq, float max_norm, float ema_decay, int32_t first_step, const float* hyper,
+                      void* stream) {
   if (!params || !grads || !momentum_buf || n < 0) return vdk_fail(VDK_EINVAL, "vdk_sgd_step: bad argument");
   if (n == 0) return VDK_OK;
   SgdArgs a;
   a.p = params; a.g = grads; a.m = momentum_buf; a.ema = ema; a.pb = (bf16_t*)params_bf16; a.n = n;
   a.lr = lr; a.momentum = momentum; a.weight_decay = weight_decay; a.max_norm = max_norm; a.ema_decay = ema_decay;
-  a.grad_scale = grad_scale; a.normsq = normsq; a.first_step = first_step;
+  a.grad_scale = grad_scale; a.normsq = normsq; a.first_step = first_step; a.hyper = hyper;
   long n4 = (n + 3) / 4;
   hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
-  return vdk_check_launch("vdk_sgd_step");
+  return vdk_check_launch(what);
+}
+int vdk_sgd_step(float* params, const float* grads, float* momentum_buf, float* ema, void* params_bf16, int64_t n, float lr,
+                 float momentum, float weight_decay, float grad_scale, const float* normsq, float max_norm, float ema_decay,
+                 int32_t first_step, void* stream) {
+  return sgd_launch("vdk_sgd_step", params, grads, momentum_buf, ema, params_bf16, n, lr, momentum, weight_decay, grad_scale, normsq, max_norm, ema_decay, first_step,
+                    nullptr, stream);
+}
+// The same pass with lr, momentum, weight_decay, ema_decay and first_step read from DEVICE memory (hyper f32 [5]) at run time: the form a step captured in a
+// hipGraph uses, because by-value kernel arguments are frozen at capture while the LR schedule and ModelEMA's warm-up decay change every step.
+int vdk_sgd_step_graph(float* params, const float* grads, float* momentum_buf, float* ema, void* params_bf16, int64_t n, const float* hyper, float grad_scale,
+                       const float* normsq, float max_norm, void* stream) {
+  if (!hyper) return vdk_fail(VDK_EINVAL, "vdk_sgd_step_graph: hyper is NULL");
+  return sgd_launch("vdk_sgd_step_graph", params, grads, momentum_buf, ema, params_bf16, n, 0.f, 0.f, 0.f, grad_scale, normsq, max_norm, 0.f, 0, hyper, stream);
 }
 
 // SAM.first_step: normsq_out[0] = sum ((|p| | 1) * g)^2, then p_old = p; p += (p^2 | 1) * g * rho / (sqrt(normsq) + 1e-12)

@@ -31,8 +31,8 @@ int vdk_bn_act_fwd(const float*, int64_t, int32_t, const float*, const float*, f
                    float*, float*, void*, size_t, vdk_stat_sync_fn, void*, void*);
 int vdk_bn_act_bwd(const float*, const float*, const void*, int64_t, int32_t, const float*, const float*, const float*, void*, float*, float*, float*, void*, size_t,
                    vdk_stat_sync_fn, void*, void*);
-int vdk_maxpool3s2_fwd(const void*, void*, int32_t, int32_t, int32_t, int32_t, void*);
-int vdk_maxpool3s2_bwd(const void*, const float*, float*, int32_t, int32_t, int32_t, int32_t, void*);
+int vdk_maxpool3s2_fwd(const void*, void*, uint8_t*, int32_t, int32_t, int32_t, int32_t, void*);
+int vdk_maxpool3s2_bwd(const void*, const uint8_t*, const float*, float*, int32_t, int32_t, int32_t, int32_t, void*);
 int vdk_avgpool_fwd(const void*, void*, int32_t, int32_t, int32_t, int32_t, void*);
 int vdk_avgpool_bwd(const void*, int64_t, float*, int32_t, int32_t, int32_t, void*);
 }
@@ -122,7 +122,7 @@ int rn_dims(const VdkResNetConfig* c, RnDims* d, std::vector<PEntry>* pe = nullp
 
 struct BlkW { size_t y1, a1, y2, out, st1, st2, yd, idf, std_; };
 struct WsPlan {
-  size_t total, img, y0, a0, st0, ap, feat;
+  size_t total, img, y0, a0, st0, ap, apk, feat;
   std::vector<BlkW> blk;
   size_t da, db, dyb, dres, tmp, col, dwp, slabs, slabs_bytes, bnws, bnws_bytes, csws, csws_bytes, tA, tB, dfeat, dbn;
 };
@@ -146,7 +146,7 @@ void rn_plan(const RnDims& d, WsPlan* w) {
   size_t cur = 0;
   w->img = w_take(cur, (size_t)d.B * d.img * d.img * d.Cinp * 2);
   w->y0 = w_take(cur, (size_t)d.R0 * d.stem.co * 4); w->a0 = w_take(cur, (size_t)d.R0 * d.stem.co * 2); w->st0 = w_take(cur, ((size_t)d.stem.co * 2 + 4) * 4);
-  w->ap = w_take(cur, (size_t)d.Rp * d.stem.co * 2);
+  w->ap = w_take(cur, (size_t)d.Rp * d.stem.co * 2); w->apk = w_take(cur, (size_t)d.Rp * d.stem.co);   // pooled map and its argmax bytes
   size_t rc = (size_t)d.R0 * d.stem.co, colmax = (size_t)d.R0 * 49 * d.Cinp, dwpmax = (size_t)d.stem.co * 49 * d.Cinp, sl = 0, bn = 0, cs = 0, tr = 0;
   auto wg = [&](int out, int in, int rows) {
     const int k1 = wgrad_splitk(out, in, (int)up(rows, 64)), k2 = wgrad_splitk_tn(out, in, rows);
@@ -301,7 +301,7 @@ int vdk_resnet_forward(const VdkResNetConfig* cfg, const float* x, const float* 
   RC(vdk_nchw_to_nhwc_bf16(x, base + w.img, d.B, d.Cin, d.img, d.img, d.Cinp, s));
   RC(conv_gemm(s, d.stem, d.B, false, base + w.img, xb + d.stem.wf, base + w.y0, VDK_F32, nullptr));
   RC(bn(d.stem_bn, (const float*)(base + w.y0), d.R0, w.st0, nullptr, nullptr, 1, base + w.a0, nullptr));
-  RC(vdk_maxpool3s2_fwd(base + w.a0, base + w.ap, d.B, d.H0, d.H0, d.stem.co, s));
+  RC(vdk_maxpool3s2_fwd(base + w.a0, base + w.ap, (uint8_t*)(base + w.apk), d.B, d.H0, d.H0, d.stem.co, s));
   const void* ain = base + w.ap;
   for (size_t i = 0; i < d.blk.size(); ++i) {
     const Blk& b = d.blk[i]; const BlkW& bw = w.blk[i];
@@ -377,7 +377,7 @@ int vdk_resnet_backward(const VdkResNetConfig* cfg, const void* dlogits, const f
     }
   }
   // stem: max-pool backward, BatchNorm + ReLU backward, conv weight gradient (no input gradient: the image is a leaf)
-  RC(vdk_maxpool3s2_bwd(base + w.a0, da, db, d.B, d.H0, d.H0, d.stem.co, s));
+  RC(vdk_maxpool3s2_bwd(base + w.a0, (const uint8_t*)(base + w.apk), da, db, d.B, d.H0, d.H0, d.stem.co, s));
   RC(bnb(d.stem_bn, (const float*)(base + w.y0), db, base + w.a0, d.R0, w.st0, nullptr));
   RC(conv_wgrad(s, w, base, d.stem, d.B, dyb, base + w.img, grads + d.stem.w));
   if (on_ready) on_ready(user, 0, d.blk[0].c1.w);

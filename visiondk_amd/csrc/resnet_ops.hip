@@ -96,14 +96,26 @@ __global__ __launch_bounds__(512) void bn_partial_kernel(const float* __restrict
   }
 }
 // combine the slice partials into ONE vector sums[2C + 1] = (sum_0[C], sum_1[C], count): what a SyncBatchNorm all-reduces across ranks
+// 16 columns x 16 slice groups per workgroup (a thread per column walking all S partials serially took 40 - 260 us per call: 20 % of a ResNet-18 step
+// at batch 32); fp64 accumulation, fixed combination order
 __global__ __launch_bounds__(256) void bn_combine_kernel(const float* __restrict__ part, int S, int C, float count, float* __restrict__ sums) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) sums[2 * C] = count;
-  if (i >= 2 * C) return;
-  const int which = i / C, c = i - which * C;
+  __shared__ double red[16][17];
+  const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + col;
+  if (blockIdx.x == 0 && threadIdx.x == 0) sums[2 * C] = count;
   double s = 0.0;
-  for (int k = 0; k < S; ++k) s += part[((long)k * 2 + which) * C + c];
-  sums[i] = (float)s;
+  if (i < 2 * C) {
+    const int which = i / C, c = i - which * C;
+    for (int k = grp; k < S; k += 16) s += part[((long)k * 2 + which) * C + c];
+  }
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && i < 2 * C) {
+    double t = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][col];
+    sums[i] = (float)t;
+  }
 }
 // forward finalize from sums (sum x, sum x^2, count): mean / biased var -> invstd, running statistics (unbiased var); eval mode: running statistics
 __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ sums, int C, float eps, float momentum, int training, float* __restrict__ rmean,
@@ -177,7 +189,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------ pooling
 // MaxPool2d(3, stride 2, padding 1) on NHWC bf16 (out-of-range taps are -inf, like torch)
-__global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int B, int H, int W, int C, int OH, int OW) {
+// argmax (optional): the window position 0..8 in (ky, kx) scan order of the FIRST maximum, one byte per output element -- what the backward needs
+__global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, unsigned char* __restrict__ argmax, int B, int H,
+                                                             int W, int C, int OH, int OW) {
   const long n = (long)B * OH * OW * C;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -185,37 +199,47 @@ __global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const bf16_t* __res
   const long p = i / C;
   const int ox = (int)(p % OW), oy = (int)((p / OW) % OH), b = (int)(p / ((long)OW * OH));
   float m = -3.0e38f;
+  int km = 0;
   for (int ky = 0; ky < 3; ++ky)
     for (int kx = 0; kx < 3; ++kx) {
       const int y = oy * 2 + ky - 1, x = ox * 2 + kx - 1;
-      if (y >= 0 && y < H && x >= 0 && x < W) m = fmaxf(m, bf2f(in[(((long)b * H + y) * W + x) * C + c]));
+      if (y >= 0 && y < H && x >= 0 && x < W) {
+        const float v = bf2f(in[(((long)b * H + y) * W + x) * C + c]);
+        if (v > m) { m = v; km = ky * 3 + kx; }
+      }
     }
   out[i] = f2bf(m);
+  if (argmax) argmax[i] = (unsigned char)km;
 }
-// din[b,y,x,c] = sum over the (up to 4) windows containing (y,x) in which it is the FIRST maximum in (ky, kx) scan order (torch's argmax rule) of dout
-__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const bf16_t* __restrict__ in, const float* __restrict__ dout, float* __restrict__ din, int B, int H, int W,
-                                                             int C, int OH, int OW) {
+// din[b,y,x,c] = sum over the (up to 4) windows containing (y,x) in which it is the FIRST maximum in (ky, kx) scan order (torch's argmax rule) of dout.
+// With the forward's argmax map: one byte and (on a hit) one dout per window; without it the 9 window entries are re-read per window (36 loads per element:
+// 733 us for 32 x 112 x 112 x 64 against 60 us with the map).
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const bf16_t* __restrict__ in, const unsigned char* __restrict__ argmax, const float* __restrict__ dout,
+                                                             float* __restrict__ din, int B, int H, int W, int C, int OH, int OW) {
   const long n = (long)B * H * W * C;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int c = (int)(i % C);
   const long p = i / C;
   const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((long)W * H));
-  const float v = bf2f(in[i]);
+  const float v = argmax ? 0.f : bf2f(in[i]);
   float acc = 0.f;
   for (int oy = (y + 1 - 2 + 1) / 2; oy <= (y + 1) / 2; ++oy) {     // windows with oy*2 - 1 <= y <= oy*2 + 1
     if (oy < 0 || oy >= OH) continue;
     for (int ox = (x + 1 - 2 + 1) / 2; ox <= (x + 1) / 2; ++ox) {
       if (ox < 0 || ox >= OW) continue;
       const int myk = (y - (oy * 2 - 1)) * 3 + (x - (ox * 2 - 1));
+      const long o = (((long)b * OH + oy) * OW + ox) * C + c;
       bool win = true;
-      for (int k = 0; k < 9 && win; ++k) {
-        const int yy = oy * 2 - 1 + k / 3, xx = ox * 2 - 1 + k % 3;
-        if (yy < 0 || yy >= H || xx < 0 || xx >= W || k == myk) continue;
-        const float o = bf2f(in[(((long)b * H + yy) * W + xx) * C + c]);
-        if (o > v || (o == v && k < myk)) win = false;
-      }
-      if (win) acc += dout[(((long)b * OH + oy) * OW + ox) * C + c];
+      if (argmax) win = argmax[o] == myk;
+      else
+        for (int k = 0; k < 9 && win; ++k) {
+          const int yy = oy * 2 - 1 + k / 3, xx = ox * 2 - 1 + k % 3;
+          if (yy < 0 || yy >= H || xx < 0 || xx >= W || k == myk) continue;
+          const float q = bf2f(in[(((long)b * H + yy) * W + xx) * C + c]);
+          if (q > v || (q == v && k < myk)) win = false;
+        }
+      if (win) acc += dout[o];
     }
   }
   din[i] = acc;
@@ -296,7 +320,7 @@ int vdk_bn_act_fwd(const float* x, int64_t R, int32_t C, const float* gamma, con
   if (training) {
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3((unsigned)S, (unsigned)((C + 63) / 64)), dim3(512), 0, stream, x, (const float*)nullptr, (const bf16_t*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (long)R, (int)C, rps, part);
-    hipLaunchKernelGGL(bn_combine_kernel, dim3((unsigned)((2 * C + 255) / 256)), dim3(256), 0, stream, (const float*)part, S, (int)C, (float)R, sums);
+    hipLaunchKernelGGL(bn_combine_kernel, dim3((unsigned)((2 * C + 15) / 16)), dim3(256), 0, stream, (const float*)part, S, (int)C, (float)R, sums);
     if (sync) sync(user, sums, 2 * (int64_t)C + 1);
   }
   // the sample count is kept right behind invstd when the two save vectors are adjacent (engines allocate [2C + 1])
@@ -321,7 +345,7 @@ int vdk_bn_act_bwd(const float* x, const float* dout, const void* out_bf16, int6
   const long rps = (R + S - 1) / S;
   hipLaunchKernelGGL(bn_partial_kernel<1>, dim3((unsigned)S, (unsigned)((C + 63) / 64)), dim3(512), 0, stream, x, dout, (const bf16_t*)out_bf16, save_mean, save_invstd,
                      (long)R, (int)C, rps, part);
-  hipLaunchKernelGGL(bn_combine_kernel, dim3((unsigned)((2 * C + 255) / 256)), dim3(256), 0, stream, (const float*)part, S, (int)C, (float)R, sums);
+  hipLaunchKernelGGL(bn_combine_kernel, dim3((unsigned)((2 * C + 15) / 16)), dim3(256), 0, stream, (const float*)part, S, (int)C, (float)R, sums);
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, (const float*)sums, (int)C, dgamma, dbeta);
   if (sync) sync(user, sums, 2 * (int64_t)C + 1);
   const long n4 = R * C / 4;
@@ -330,20 +354,20 @@ int vdk_bn_act_bwd(const float* x, const float* dout, const void* out_bf16, int6
   return vdk_check_launch("vdk_bn_act_bwd");
 }
 
-int vdk_maxpool3s2_fwd(const void* in, void* out, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+int vdk_maxpool3s2_fwd(const void* in, void* out, uint8_t* argmax, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
   if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_maxpool3s2_fwd: bad argument");
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const long n = (long)B * OH * OW * C;
-  hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, (int)B, (int)H, (int)W, (int)C,
-                     OH, OW);
+  hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, (unsigned char*)argmax, (int)B, (int)H,
+                     (int)W, (int)C, OH, OW);
   return vdk_check_launch("vdk_maxpool3s2_fwd");
 }
-int vdk_maxpool3s2_bwd(const void* in, const float* dout, float* din, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
-  if (!in || !dout || !din || B <= 0 || H <= 0 || W <= 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_maxpool3s2_bwd: bad argument");
+int vdk_maxpool3s2_bwd(const void* in, const uint8_t* argmax, const float* dout, float* din, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+  if ((!in && !argmax) || !dout || !din || B <= 0 || H <= 0 || W <= 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_maxpool3s2_bwd: bad argument");
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const long n = (long)B * H * W * C;
-  hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, dout, din, (int)B, (int)H, (int)W, (int)C, OH,
-                     OW);
+  hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (const unsigned char*)argmax, dout, din, (int)B, (int)H,
+                     (int)W, (int)C, OH, OW);
   return vdk_check_launch("vdk_maxpool3s2_bwd");
 }
 int vdk_avgpool_fwd(const void* in, void* out, int32_t B, int32_t Bp, int32_t HW, int32_t C, void* stream) {

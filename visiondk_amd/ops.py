@@ -501,17 +501,19 @@ def bn_act_bwd(x, dout, out_bf16, gamma, save_mean, save_invstd, want_dres=True,
     return dy, dres, dg, db
 
 
-def maxpool3s2(x_nhwc: torch.Tensor, backend=None) -> torch.Tensor:
+def maxpool3s2(x_nhwc: torch.Tensor, want_argmax: bool = False, backend=None):
+    """nn.MaxPool2d(3, 2, 1) on bf16 NHWC; want_argmax: also the uint8 map of winning window positions (first maximum) for the backward"""
     be = _be(backend)
     B, H, W, Cc = x_nhwc.shape
     out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), dtype=torch.bfloat16, device=x_nhwc.device)
-    be.check(be.lib.vdk_maxpool3s2_fwd(be.ptr(x_nhwc), be.ptr(out), B, H, W, Cc, be.stream()), "vdk_maxpool3s2_fwd")
-    return out
+    arg = torch.empty(out.shape, dtype=torch.uint8, device=x_nhwc.device) if want_argmax else None
+    be.check(be.lib.vdk_maxpool3s2_fwd(be.ptr(x_nhwc), be.ptr(out), be.ptr(arg), B, H, W, Cc, be.stream()), "vdk_maxpool3s2_fwd")
+    return (out, arg) if want_argmax else out
 
 
-def maxpool3s2_bwd(x_nhwc: torch.Tensor, dout: torch.Tensor, backend=None) -> torch.Tensor:
+def maxpool3s2_bwd(x_nhwc: torch.Tensor, dout: torch.Tensor, argmax: Optional[torch.Tensor] = None, backend=None) -> torch.Tensor:
     be = _be(backend)
     B, H, W, Cc = x_nhwc.shape
     din = torch.empty((B, H, W, Cc), dtype=torch.float32, device=x_nhwc.device)
-    be.check(be.lib.vdk_maxpool3s2_bwd(be.ptr(x_nhwc), be.ptr(dout.contiguous()), be.ptr(din), B, H, W, Cc, be.stream()), "vdk_maxpool3s2_bwd")
+    be.check(be.lib.vdk_maxpool3s2_bwd(be.ptr(x_nhwc), be.ptr(argmax), be.ptr(dout.contiguous()), be.ptr(din), B, H, W, Cc, be.stream()), "vdk_maxpool3s2_bwd")
     return din

@@ -266,8 +266,11 @@ class ResNetTrainStep:
     clip_grad_norm_(max_norm) -> SGD(momentum, weight_decay) -> EMA -> bf16 weight refresh.  `param_groups[0]['lr']` stays readable / writable."""
 
     def __init__(self, model: ResNet, lr: float, momentum: float = 0.937, weight_decay: float = 5e-4, loss: str = "bce", label_smoothing: float = 0.0,
-                 max_norm: float = 10.0, ema: bool = True, comm=None, sync_bn: bool = False):
-        """sync_bn: SyncBatchNorm over comm's group (the reference's `sync_bn` flag -> nn.SyncBatchNorm.convert_sync_batchnorm, vision_engine.py:224-225).
+                 max_norm: float = 10.0, ema: bool = True, comm=None, sync_bn: bool = False, graph: bool = False):
+        """graph: capture the whole step (about 250 launches of a few microseconds each at ResNet-18 / bs 32: launch-bound) once per batch shape in a hipGraph
+        (torch.cuda.CUDAGraph) and replay it; the per-step scalars (lr, momentum, weight decay, EMA decay, first-step flag) travel through a 5-float
+        device vector (vdk_sgd_step_graph).  Single-process only; results are bit-identical to the eager sequence.
+        sync_bn: SyncBatchNorm over comm's group (the reference's `sync_bn` flag -> nn.SyncBatchNorm.convert_sync_batchnorm, vision_engine.py:224-225).
         comm: visiondk_amd.comm.GradAllReduce (one process per GPU): weights and BatchNorm buffers broadcast from rank 0 at construction, buffers again
         before every forward (torch DDP's broadcast_buffers), the flat gradient all-reduced in buckets from inside vdk_resnet_backward; BatchNorm statistics
         stay per rank (SyncBN is the reference's opt-in flag and is not built)."""
@@ -285,6 +288,12 @@ class ResNetTrainStep:
         self.be.check(self.be.lib.vdk_sumsq_workspace_bytes(C.byref(need)), "vdk_sumsq_workspace_bytes")
         self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.eng.device)
         self.loss_rows: Optional[torch.Tensor] = None
+        if graph and comm is not None and comm.world_size > 1:
+            raise NotImplementedError("graph capture of the data-parallel step (host callbacks issue the collectives) is not built")
+        self.graph = graph
+        self._graphs = {}                       # (B, y shape/dtype) -> (CUDAGraph, static x, static y)
+        self._hyper = torch.zeros(5, dtype=torch.float32, device=self.eng.device) if graph else None
+        self._hyper_ring = [(torch.zeros(5, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(8)] if graph else []
         if comm is not None and comm.world_size > 1:
             import torch.distributed as dist
             comm.broadcast_params(self.eng.params)
@@ -293,18 +302,62 @@ class ResNetTrainStep:
                 self.ema.copy_(self.eng.params)
 
     def step(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        if self.graph:
+            return self._step_graph(x, y)
+        return self._step_eager(x, y, None)
+
+    def _step_graph(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        import math
+        model = self.model
+        model._sync_flat()
+        model.train()
+        self.updates += 1
+        g = self.param_groups[0]
+        d = 0.9999 * (1 - math.exp(-self.updates / 2000)) if self.ema is not None else 0.0
+        for m in model.modules():
+            if "num_batches_tracked" in m._buffers:
+                m._buffers["num_batches_tracked"] += 1
+        host, ev = self._hyper_ring[self.updates % len(self._hyper_ring)]     # pinned staging slots: a slot is rewritten only after its copy has run
+        ev.synchronize()
+        host.copy_(torch.tensor([g["lr"], g["momentum"], g["weight_decay"], d, 1.0 if self.updates == 1 else 0.0]))
+        self._hyper.copy_(host, non_blocking=True)
+        ev.record()
+        key = (tuple(x.shape), tuple(y.shape), y.dtype)
+        if key not in self._graphs:
+            sx, sy = x.clone(), y.clone()
+            eng = self.eng
+            eng._workspace(x.shape[0], x.shape[-1])                          # allocations and the weight refresh happen before the capture, not inside it
+            if eng._weights_version != eng.params._version:
+                eng.refresh_weights()
+            if self.loss_rows is None or self.loss_rows.shape[0] != x.shape[0]:
+                self.loss_rows = torch.empty(x.shape[0], dtype=torch.float32, device=self.eng.device)
+                self._dl = torch.zeros((x.shape[0], self.eng.cp), dtype=torch.bfloat16, device=self.eng.device)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                self._step_eager(sx, sy, self._hyper, count=False)
+            self._graphs[key] = (gr, sx, sy, self.loss_rows)
+        gr, sx, sy, rows = self._graphs[key]
+        sx.copy_(x, non_blocking=True)
+        sy.copy_(y, non_blocking=True)
+        gr.replay()
+        self.loss_rows = rows
+        return rows
+
+    def _step_eager(self, x: torch.Tensor, y: torch.Tensor, hyper, count: bool = True) -> torch.Tensor:
         import math
         eng, be, model = self.eng, self.be, self.model
         world = self.comm.world_size if self.comm is not None else 1
         if world > 1:
             import torch.distributed as dist
             dist.broadcast(eng.buffers, src=0, group=self.comm.group)
-        model._sync_flat()
-        model.train()
-        for m in model.modules():
-            if "num_batches_tracked" in m._buffers:
-                m._buffers["num_batches_tracked"] += 1
-        self.updates += 1
+        if count:
+            model._sync_flat()
+            model.train()
+            self.updates += 1
+            for m in model.modules():
+                if "num_batches_tracked" in m._buffers:
+                    m._buffers["num_batches_tracked"] += 1
         g = self.param_groups[0]
         B, ncls = x.shape[0], eng.spec.num_classes
         logits = eng.forward(x, True, sync_group=self.sync_group)
@@ -324,9 +377,13 @@ class ResNetTrainStep:
         else:
             eng.backward(self._dl)
         be.check(be.lib.vdk_sumsq_f32(be.ptr(eng.grads), eng.n_floats, be.ptr(self._normsq), be.ptr(self._ws), self._ws.numel(), be.stream()), "vdk_sumsq_f32")
-        d = 0.9999 * (1 - math.exp(-self.updates / 2000)) if self.ema is not None else 0.0
-        be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema), be.ptr(eng.wb16), eng.n_floats, g["lr"],
-                                     g["momentum"], g["weight_decay"], 1.0 / world, be.ptr(self._normsq), self.max_norm, d, int(self.updates == 1), be.stream()),
-                 "vdk_sgd_step")
+        if hyper is not None:
+            be.check(be.lib.vdk_sgd_step_graph(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema), be.ptr(eng.wb16), eng.n_floats,
+                                               be.ptr(hyper), 1.0 / world, be.ptr(self._normsq), self.max_norm, be.stream()), "vdk_sgd_step_graph")
+        else:
+            d = 0.9999 * (1 - math.exp(-self.updates / 2000)) if self.ema is not None else 0.0
+            be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema), be.ptr(eng.wb16), eng.n_floats, g["lr"],
+                                         g["momentum"], g["weight_decay"], 1.0 / world, be.ptr(self._normsq), self.max_norm, d, int(self.updates == 1), be.stream()),
+                     "vdk_sgd_step")
         eng.refresh_weights(skip_wb16=True)
         return self.loss_rows
