@@ -366,6 +366,9 @@ int vdk_avgpool_bwd(const void* dfeat, int64_t ld, float* dout, int32_t B, int32
  *   out      device float32 [B][3][S][S];   S <= 1024, sides <= 8192
  *   status   device int32 [B] or NULL: 0 ok; 1 = an output side truncates to 0 (PIL raises ValueError("height and width must be > 0")), the image's
  *            output is then the normalised zero canvas; 2 = non-positive side or side > 8192 */
+/* global average pool over the HW rows of every image of an f32 NHWC map, and its backward (f32 and / or bf16 map gradient): timm's classifier heads */
+int vdk_avgpool_rows_f32_fwd(const float* in, float* out, int32_t B, int32_t HW, int32_t C, void* stream);
+int vdk_avgpool_rows_f32_bwd(const float* dpool, float* dmap, void* dmap_bf16, int32_t B, int32_t HW, int32_t C, void* stream);
 int vdk_preprocess_workspace_bytes(int32_t B, int32_t S, int32_t max_side, size_t* bytes);
 int vdk_preprocess_resize_pad_normalize(const uint8_t* pixels, const int64_t* offsets, const int32_t* wh, int32_t B, int32_t S, int32_t max_side, float mean0,
                                         float mean1, float mean2, float std0, float std1, float std2, float* out, int32_t* status, void* ws, size_t ws_bytes,
@@ -381,6 +384,8 @@ typedef struct VdkConvNextConfig {
   int32_t depths[4];
   int32_t dims[4];
   float ln_eps;
+  int32_t num_classes;   /* 0: feature mode (num_classes=0, global_pool=''), what TimmWrapper builds; > 0: timm's classifier head -- global average pool ->
+                          * head.norm -> head.fc -- what VisionWrapper.create_model builds (models/classifier/classify_model.py:49-54, `timm-convnext_*`) */
 } VdkConvNextConfig;
 /* flat parameter layout (timm state_dict order and names) + size of `wx`, the derived operand copies kept next to `wb16` */
 int vdk_convnext_param_count(const VdkConvNextConfig* cfg, int64_t* n_floats, int32_t* n_tensors, size_t* wx_bytes);
@@ -388,15 +393,16 @@ int vdk_convnext_param_info(const VdkConvNextConfig* cfg, int32_t index, char* n
                             int32_t* ndim);
 int vdk_convnext_workspace_bytes(const VdkConvNextConfig* cfg, size_t* bytes);
 int vdk_convnext_refresh_weights(const VdkConvNextConfig* cfg, const float* params, void* wb16, void* wx, int32_t skip_wb16, void* stream);
-/* x f32 [B, in_chans, img, img] -> out f32 [B*(img/32)^2, dims[3]] (row (b, y, x), channel-contiguous) */
+/* x f32 [B, in_chans, img, img] -> out f32 [B*(img/32)^2, dims[3]] (row (b, y, x), channel-contiguous); classifier mode: logits f32 [B, up(num_classes, 8)] */
 int vdk_convnext_forward(const VdkConvNextConfig* cfg, const float* x, const float* params, const void* wb16, const void* wx, void* ws, size_t ws_bytes,
                          float* out, void* stream);
 /* PRECISE forward, as vdk_vit_forward_f32 (wx: only the tap-major depthwise weights are read from it) */
 int vdk_convnext_workspace_f32_bytes(const VdkConvNextConfig* cfg, size_t* bytes);
 int vdk_convnext_forward_f32(const VdkConvNextConfig* cfg, const float* x, const float* params, const void* wx, void* ws, size_t ws_bytes, float* out,
                              void* stream);
-/* dout f32 (same shape as out) -> grads (flat fp32, overwritten); on_ready as in vdk_vit_backward */
-int vdk_convnext_backward(const VdkConvNextConfig* cfg, const float* dout, const float* params, const void* wb16, const void* wx, void* ws, size_t ws_bytes,
+/* dout f32 (same shape as out) -> grads (flat fp32, overwritten); on_ready as in vdk_vit_backward.  Classifier mode: dout = dlogits bf16
+ * [up(B, 64), up(num_classes, 8)], padding rows / columns zero (as vdk_resnet_backward takes it) */
+int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout, const float* params, const void* wb16, const void* wx, void* ws, size_t ws_bytes,
                           float* grads, vdk_grad_ready_fn on_ready, void* user, void* stream);
 
 /* ---- native ResNet engine: timm BasicBlock ResNets (resnet18 / resnet34) over flat buffers ---------------------------------------------

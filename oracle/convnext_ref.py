@@ -69,22 +69,31 @@ class ConvNeXtStage(nn.Module):
 
 
 class _Head(nn.Module):
-    def __init__(self, dim, eps):
+    """timm NormMlpClassifierHead (hidden_size=None): global_pool -> norm (LayerNorm2d) -> flatten -> fc.  num_classes=0, global_pool='' (TimmWrapper):
+    pool, flatten and fc are Identity, the norm runs per pixel.  num_classes>0 (VisionWrapper, models/classifier/classify_model.py:49-54): global average
+    pool to [B, C, 1, 1] FIRST, then the norm on the pooled vector, then Linear(C, num_classes)."""
+
+    def __init__(self, dim, eps, num_classes=0):
         super().__init__()
         self.norm = LayerNorm2d(dim, eps=eps)
+        self.num_classes = num_classes
+        if num_classes > 0:
+            self.fc = nn.Linear(dim, num_classes)
 
     def forward(self, x):
+        if self.num_classes > 0:
+            return self.fc(self.norm(x.mean((-2, -1), keepdim=True)).flatten(1))
         return self.norm(x)
 
 
 class ConvNeXtRef(nn.Module):
     """timm ConvNeXt with num_classes=0, global_pool='' (what TimmWrapper builds): [B, Cin, H, W] -> [B, dims[-1], H/32, W/32]."""
 
-    def __init__(self, in_chans=3, depths=(3, 3, 27, 3), dims=(128, 256, 512, 1024), eps=1e-6):
+    def __init__(self, in_chans=3, depths=(3, 3, 27, 3), dims=(128, 256, 512, 1024), eps=1e-6, num_classes=0):
         super().__init__()
         self.stem = nn.Sequential(nn.Conv2d(in_chans, dims[0], 4, stride=4, bias=True), LayerNorm2d(dims[0], eps=eps))
         self.stages = nn.Sequential(*[ConvNeXtStage(dims[max(i - 1, 0)], dims[i], depths[i], i == 0, eps) for i in range(4)])
-        self.head = _Head(dims[-1], eps)
+        self.head = _Head(dims[-1], eps, num_classes)
         self.reset_parameters()
 
     def reset_parameters(self):

@@ -7,10 +7,10 @@ from oracle.convnext_ref import ConvNeXtRef
 from visiondk_amd import convnext
 
 
-def _pair(be, dev, depths, dims, img, seed=0):
-    spec = convnext.ConvNeXtSpec(img_size=img, depths=depths, dims=dims)
+def _pair(be, dev, depths, dims, img, seed=0, num_classes=0):
+    spec = convnext.ConvNeXtSpec(img_size=img, depths=depths, dims=dims, num_classes=num_classes)
     model = convnext.ConvNeXt(spec, device=dev, backend=be, seed=seed)
-    ref = ConvNeXtRef(3, depths, dims)
+    ref = ConvNeXtRef(3, depths, dims, num_classes=num_classes)
     torch.manual_seed(seed)
     with torch.no_grad():   # non-trivial values everywhere (timm's init leaves biases at 0 and gamma at 1e-6: gradients would hide bugs)
         for n, p in ref.named_parameters():
@@ -55,3 +55,71 @@ def test_forward_backward_vs_oracle(be, dev, B, img, depths, dims):
     # the bulk is far better than the bound
     worst.sort()
     assert worst[len(worst) // 2][0] < 2e-2, worst[len(worst) // 2]
+
+
+@pytest.mark.parametrize("B,img,depths,dims,ncls", [(3, 32, (1, 1, 2, 1), (8, 16, 24, 32), 5), (6, 64, (1, 1, 1, 2), (16, 32, 64, 72), 37)])
+def test_classifier_head_vs_oracle(be, dev, B, img, depths, dims, ncls):
+    """timm.create_model('convnext_*', num_classes=N) as VisionWrapper builds it: global average pool -> head.norm -> head.fc; logits, CE loss and every
+    parameter gradient (incl. the padded fc rows staying out of the state_dict) against the oracle."""
+    model, ref = _pair(be, dev, depths, dims, img, num_classes=ncls)
+    assert list(model.state_dict().keys()) == list(ref.state_dict().keys())
+    assert model.state_dict()["head.fc.weight"].shape == (ncls, dims[3])
+    torch.manual_seed(4)
+    x = torch.randn(B, 3, img, img)
+    t = torch.randint(0, ncls, (B,))
+    y = model(x.to(dev))
+    yr = ref(x)
+    assert y.shape == (B, ncls)
+    assert ((y.detach().cpu() - yr.detach()).norm() / yr.detach().norm()).item() < 2e-2
+    loss = torch.nn.functional.cross_entropy(y, t.to(dev))
+    loss_r = torch.nn.functional.cross_entropy(yr, t)
+    assert abs(loss.item() - loss_r.item()) < 2e-2 * abs(loss_r.item())
+    loss.backward(); loss_r.backward()
+    worst = []
+    for (n, p), (nr, pr) in zip(model.named_parameters(), ref.named_parameters()):
+        assert n == nr
+        r = ((p.grad.detach().cpu() - pr.grad).norm() / (pr.grad.norm() + 1e-12)).item()
+        worst.append((r, n))
+        assert r < 8e-2, (n, r)
+    worst.sort()
+    assert worst[len(worst) // 2][0] < 3e-2, worst[len(worst) // 2]
+
+
+def test_classifier_train_step_matches_reference_update(be, dev):
+    """get_model(task=classification, name=timm-convnext_*) -> VisionWrapper -> ClassifierTrainStep: CE(label_smoothing) -> backward -> clip_grad_norm_ ->
+    SGD(momentum, wd) -> EMA against the same sequence on the oracle (one step, clip active)."""
+    import math
+    from visiondk_amd import resnet
+    ncls, img = 6, 32
+    model, ref = _pair(be, dev, (1, 1, 1, 1), (8, 16, 24, 32), img, num_classes=ncls)
+    lr, mom, wd, max_norm = 0.05, 0.9, 5e-4, 0.05
+    step = resnet.ClassifierTrainStep(model, lr=lr, momentum=mom, weight_decay=wd, loss="ce", label_smoothing=0.1, max_norm=max_norm, ema=True)
+    opt = torch.optim.SGD(ref.parameters(), lr=lr, momentum=mom, weight_decay=wd)
+    start = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    torch.manual_seed(5)
+    x = torch.randn(5, 3, img, img); t = torch.randint(0, ncls, (5,))
+    loss_r = torch.nn.functional.cross_entropy(ref(x), t, label_smoothing=0.1)
+    loss_r.backward()
+    assert torch.nn.utils.clip_grad_norm_(list(ref.parameters()), max_norm=max_norm) > max_norm
+    opt.step()
+    rows = step.step(x.to(dev), t.to(dev))
+    assert abs(rows.mean().item() - loss_r.item()) < 2e-2 * abs(loss_r.item())
+    got = dict(model.named_parameters())
+    for n, p in ref.named_parameters():
+        upd_ref, upd = p.detach() - start[n], got[n].detach().cpu() - start[n]
+        r = ((upd - upd_ref).norm() / (upd_ref.norm() + 1e-12)).item()
+        assert r < 0.12, (n, r)
+    d = 0.9999 * (1 - math.exp(-1 / 2000))
+    name, off, numel, shape = model.engine.entries[-2]                      # head.fc.weight: EMA = d * start + (1 - d) * updated
+    exp = d * start[name] + (1 - d) * ref.state_dict()[name]
+    got_ema = step.ema[off:off + numel].view(shape).cpu()
+    assert ((got_ema - exp).norm() / exp.norm()).item() < 1e-4
+
+
+def test_vision_wrapper_routes_convnext_classifier(be, dev, monkeypatch):
+    from visiondk_amd import face
+    monkeypatch.setitem(convnext.TIMM_CONVNEXTS, "convnext_tiny", dict(depths=(1, 1, 1, 1), dims=(8, 16, 24, 32)))   # a miniature under the timm id
+    cfg = {"task": "classification", "name": "timm-convnext_tiny.in12k_ft_in1k", "image_size": 32, "num_classes": 4, "pretrained": False, "kwargs": {}}
+    wrap = face.VisionWrapper(cfg, None, 0, backend=be, device=dev)
+    y = wrap.model(torch.randn(2, 3, 32, 32).to(dev))
+    assert y.shape == (2, 4) and "head.fc.weight" in wrap.model.state_dict()

@@ -1,5 +1,7 @@
 """cfg3 backbone leg: ConvNeXt-B forward + backward on the native engine (images/sec), optionally with the TimmWrapper neck + ArcFace.
-usage: python tools/bench_convnext.py [batch] [steps] [--face]"""
+--classifier: the classification task on the same backbone (pet.yaml's `timm-convnext_base`, 35 classes): get_model -> VisionWrapper -> ClassifierTrainStep
+(CE label smoothing 0.05 + clip + SGD + EMA), the full step.
+usage: python tools/bench_convnext.py [batch] [steps] [--face | --classifier]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,6 +19,14 @@ if "--face" in sys.argv:
     def step():
         loss = torch.nn.functional.cross_entropy(model(x, y), y)
         loss.backward()
+elif "--classifier" in sys.argv:
+    from visiondk_amd import resnet
+    cfg = {"task": "classification", "name": "timm-convnext_base.clip_laion2b_augreg_ft_in1k", "image_size": 224, "num_classes": 35, "pretrained": False, "kwargs": {}}
+    model = face.get_model(cfg, None, 0).model
+    ts = resnet.ClassifierTrainStep(model, lr=0.006, momentum=0.937, weight_decay=5e-4, loss="ce", label_smoothing=0.05, max_norm=10.0, ema=True)
+    y = torch.randint(0, 35, (B,), device=dev)
+    def step():
+        ts.step(x, y)
 else:
     model = convnext.create_model("convnext_base", device=dev)
     eng = model.engine

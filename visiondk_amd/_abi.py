@@ -42,7 +42,7 @@ class GemmF32Desc(C.Structure):
 
 
 class ConvNextConfig(C.Structure):
-    _fields_ = [("batch", I32), ("img_size", I32), ("in_chans", I32), ("depths", I32 * 4), ("dims", I32 * 4), ("ln_eps", C.c_float)]
+    _fields_ = [("batch", I32), ("img_size", I32), ("in_chans", I32), ("depths", I32 * 4), ("dims", I32 * 4), ("ln_eps", C.c_float), ("num_classes", I32)]
 
 
 class ResNetConfig(C.Structure):
@@ -148,6 +148,8 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_maxpool3s2_bwd": (C.c_int, [P, P, P, P, I32, I32, I32, I32, P]),
     "vdk_avgpool_fwd": (C.c_int, [P, P, I32, I32, I32, I32, P]),
     "vdk_avgpool_bwd": (C.c_int, [P, I64, P, I32, I32, I32, P]),
+    "vdk_avgpool_rows_f32_fwd": (C.c_int, [P, P, I32, I32, I32, P]),
+    "vdk_avgpool_rows_f32_bwd": (C.c_int, [P, P, P, I32, I32, I32, P]),
     "vdk_preprocess_workspace_bytes": (C.c_int, [I32, I32, I32, PSZ]),
     "vdk_preprocess_resize_pad_normalize": (C.c_int, [P, P, P, I32, I32, I32, F32, F32, F32, F32, F32, F32, P, P, P, SZ, P]),
     "vdk_vit_workspace_f32_bytes": (C.c_int, [C.POINTER(VitConfig), PSZ]),

@@ -27,6 +27,7 @@ class ConvNeXtSpec:
     depths: Tuple[int, int, int, int] = (3, 3, 27, 3)
     dims: Tuple[int, int, int, int] = (128, 256, 512, 1024)
     ln_eps: float = 1e-6
+    num_classes: int = 0          # 0: feature mode (TimmWrapper); > 0: timm's classifier head (global average pool -> head.norm -> head.fc)
 
 
 # timm 0.9.16 model ids the engine covers (dims % 8 == 0)
@@ -64,14 +65,16 @@ class ConvNeXtEngine:
         self.wx = torch.zeros(wx.value, dtype=torch.uint8, device=dev)
         self.out_hw = spec.img_size // 32
         self.out_ch = spec.dims[3]
+        self.cp = (spec.num_classes + 7) // 8 * 8          # logits row stride in classifier mode
         self._ws: Optional[torch.Tensor] = None
         self._ws_batch = -1
         self._out: Optional[torch.Tensor] = None
         self._weights_version = None
+        self.buffers = torch.zeros(0, dtype=torch.float32, device=dev)      # no BatchNorm: nothing to broadcast (the train step shared with the ResNet engine asks)
 
     def _cfg(self, batch: int) -> _abi.ConvNextConfig:
         s = self.spec
-        return _abi.ConvNextConfig(batch, s.img_size, s.in_chans, (_abi.I32 * 4)(*s.depths), (_abi.I32 * 4)(*s.dims), s.ln_eps)
+        return _abi.ConvNextConfig(batch, s.img_size, s.in_chans, (_abi.I32 * 4)(*s.depths), (_abi.I32 * 4)(*s.dims), s.ln_eps, s.num_classes)
 
     def _workspace(self, batch: int) -> torch.Tensor:
         if self._ws is None or self._ws_batch != batch:
@@ -81,7 +84,10 @@ class ConvNeXtEngine:
             self._ws = None
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
             self._ws_batch = batch
-            self._out = torch.empty((batch * self.out_hw * self.out_hw, self.out_ch), dtype=torch.float32, device=self.device)
+            if self.spec.num_classes > 0:
+                self._out = torch.empty((batch, self.cp), dtype=torch.float32, device=self.device)
+            else:
+                self._out = torch.empty((batch * self.out_hw * self.out_hw, self.out_ch), dtype=torch.float32, device=self.device)
         return self._ws
 
     def refresh_weights(self, skip_wb16: bool = False) -> None:
@@ -95,8 +101,13 @@ class ConvNeXtEngine:
         if self._weights_version != self.params._version:
             self.refresh_weights()
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """x f32 [B, Cin, H, W] (NCHW) -> f32 [B*h*w, C] NHWC rows of the head-normed map; activations stay in the workspace."""
+    def dlogits_rows(self, batch: int) -> int:
+        """rows of the bf16 dlogits buffer backward() expects in classifier mode (the fc weight gradient contracts over 64-row K tiles)"""
+        return (batch + 63) // 64 * 64
+
+    def forward(self, x: torch.Tensor, training: bool = True, sync_group=False) -> torch.Tensor:
+        """x f32 [B, Cin, H, W] (NCHW) -> f32 [B*h*w, C] NHWC rows of the head-normed map, or (classifier mode) logits f32 [B, cp]; activations stay in
+        the workspace."""
         s = self.spec
         if x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (s.in_chans, s.img_size, s.img_size):
             raise ValueError(f"expected float32 [B, {s.in_chans}, {s.img_size}, {s.img_size}], got {tuple(x.shape)} {x.dtype}")
@@ -115,6 +126,8 @@ class ConvNeXtEngine:
         s = self.spec
         if x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (s.in_chans, s.img_size, s.img_size):
             raise ValueError(f"expected float32 [B, {s.in_chans}, {s.img_size}, {s.img_size}], got {tuple(x.shape)} {x.dtype}")
+        if s.num_classes > 0:
+            raise NotImplementedError("the fp32-MFMA evaluation forward is built for feature mode (embeddings); classifier logits use forward()")
         x = x.contiguous()
         B = x.shape[0]
         self._ensure_fresh()                      # the tap-major depthwise weights live in wx
@@ -129,9 +142,13 @@ class ConvNeXtEngine:
                                                  be.ptr(out), be.stream()), "vdk_convnext_forward_f32")
         return out
 
-    def backward(self, dout: torch.Tensor, on_ready: Optional[Callable[[int, int], None]] = None) -> torch.Tensor:
-        """dout f32 [B*h*w, C] -> self.grads (flat fp32, overwritten).  Needs the workspace of the matching forward."""
-        assert dout.dtype == torch.float32 and dout.is_contiguous() and dout.shape == self._out.shape
+    def backward(self, dout: torch.Tensor, on_ready: Optional[Callable[[int, int], None]] = None, sync_group=False) -> torch.Tensor:
+        """dout f32 [B*h*w, C] (feature mode) or dlogits bf16 [up(B, 64), cp] with zero padding (classifier mode) -> self.grads (flat fp32, overwritten).
+        Needs the workspace of the matching forward."""
+        if self.spec.num_classes > 0:
+            assert dout.dtype == torch.bfloat16 and dout.is_contiguous() and tuple(dout.shape) == ((self._ws_batch + 63) // 64 * 64, self.cp)
+        else:
+            assert dout.dtype == torch.float32 and dout.is_contiguous() and dout.shape == self._out.shape
         cfg = self._cfg(self._ws_batch)
         be = self.be
         cb = _abi.GRAD_READY_FN(lambda user, off, n: on_ready(off, n)) if on_ready is not None else _abi.GRAD_READY_FN(0)
@@ -150,13 +167,20 @@ class _ConvNeXtFunction(torch.autograd.Function):
         out = eng.forward(x)
         ctx.module = module
         B = x.shape[0]
+        if eng.spec.num_classes > 0:
+            return out[:, :eng.spec.num_classes].clone()
         # [B*h*w, C] NHWC rows -> the NCHW tensor timm returns (a strided view of a private copy; no arithmetic)
         return out.view(B, eng.out_hw, eng.out_hw, eng.out_ch).clone().permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, dout):
         eng = ctx.module.engine
-        d = dout.permute(0, 2, 3, 1).contiguous().view(-1, eng.out_ch)
+        if eng.spec.num_classes > 0:
+            B, n = dout.shape
+            d = torch.zeros(((B + 63) // 64 * 64, eng.cp), dtype=torch.bfloat16, device=dout.device)
+            d[:B, :n] = dout.to(torch.bfloat16)
+        else:
+            d = dout.permute(0, 2, 3, 1).contiguous().view(-1, eng.out_ch)
         g = eng.backward(d)
         return (None, None) + tuple(g[off:off + numel].view(shape) for (_, off, numel, shape) in eng.entries)
 
@@ -166,13 +190,14 @@ class _Holder(nn.Module):
 
 
 class ConvNeXt(nn.Module):
-    """Drop-in for `timm.create_model('convnext_*', pretrained=False, num_classes=0, global_pool='')`."""
+    """Drop-in for `timm.create_model('convnext_*', pretrained=False, num_classes=0, global_pool='')` (feature mode, TimmWrapper) and for
+    `timm.create_model('convnext_*', num_classes=N)` (classifier: head = global average pool -> head.norm -> head.fc, VisionWrapper)."""
 
     def __init__(self, spec: ConvNeXtSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None):
         super().__init__()
         self.spec = spec
         self.engine = ConvNeXtEngine(spec, device=device, backend=backend)
-        self.num_classes = 0
+        self.num_classes = spec.num_classes
         self.num_features = spec.dims[3]
         self._plist = []
         for name, off, numel, shape in self.engine.entries:
@@ -203,6 +228,8 @@ class ConvNeXt(nn.Module):
                     v = torch.ones(p.shape) if name.endswith("weight") else torch.zeros(p.shape)
                 elif name.endswith(".bias"):
                     v = torch.zeros(p.shape)
+                elif name == "head.fc.weight":
+                    v = torch.empty(p.shape).normal_(0, 0.02, generator=gen).clamp_(-2.0, 2.0)      # timm: trunc_normal_(.02) then * head_init_scale (1.0)
                 else:
                     v = torch.empty(p.shape).normal_(0, 0.02, generator=gen).clamp_(-2.0, 2.0)
                 p.copy_(v.to(p.device))
@@ -248,8 +275,10 @@ def create_model(name: str, pretrained: bool = False, num_classes: int = 0, glob
                  **kwargs) -> ConvNeXt:
     if name not in TIMM_CONVNEXTS:
         raise NotImplementedError(f"timm model '{name}' is not covered by the HIP engine yet (have: {sorted(TIMM_CONVNEXTS)})")
-    if num_classes != 0 or global_pool != "":
-        raise NotImplementedError("ConvNeXt is built in feature mode (num_classes=0, global_pool=''), what TimmWrapper asks for")
+    if num_classes == 0 and global_pool != "":
+        raise NotImplementedError("feature mode is built with global_pool='' (what TimmWrapper asks for)")
+    if num_classes > 0 and global_pool not in ("", "avg"):
+        raise NotImplementedError("the classifier head is built with timm's default global average pool")
     if pretrained:
         raise RuntimeError("pretrained weights need network access; load a checkpoint with load_state_dict instead")
-    return ConvNeXt(ConvNeXtSpec(img_size=img_size, **TIMM_CONVNEXTS[name]), device=device, backend=backend)
+    return ConvNeXt(ConvNeXtSpec(img_size=img_size, num_classes=num_classes, **TIMM_CONVNEXTS[name]), device=device, backend=backend)

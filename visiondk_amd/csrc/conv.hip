@@ -290,6 +290,27 @@ __global__ __launch_bounds__(256) void s2d2_kernel(const bf16_t* __restrict__ in
   else *(u32x4*)(out + d) = *(const u32x4*)(in + a);
 }
 
+// ------------------------------------------------------------------------------------ global average pool on f32 NHWC rows (timm SelectAdaptivePool2d('avg'))
+// out[b][c] = mean over the HW rows of image b; backward spreads dpool / HW over the rows (f32 and / or bf16 copy)
+__global__ __launch_bounds__(256) void avgpool_rows_f32_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int HW, int C) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * C) return;
+  const int c = (int)(i % C), b = (int)(i / C);
+  const float* p = in + (long)b * HW * C + c;
+  float s = 0.f;
+  for (int r = 0; r < HW; ++r) s += p[(long)r * C];
+  out[i] = s / (float)HW;
+}
+__global__ __launch_bounds__(256) void avgpool_rows_f32_bwd_kernel(const float* __restrict__ dpool, float* __restrict__ dmap, bf16_t* __restrict__ dmapb, int B, int HW,
+                                                                   int C) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * HW * C) return;
+  const int c = (int)(i % C), b = (int)(i / ((long)HW * C));
+  const float g = dpool[(long)b * C + c] / (float)HW;
+  if (dmap) dmap[i] = g;
+  if (dmapb) dmapb[i] = f2bf(g);
+}
+
 // ------------------------------------------------------------------------------------ weight preparation
 // depthwise weight [C][49] -> tap-major [49][C]
 __global__ __launch_bounds__(256) void dw_weight_prep_kernel(const float* __restrict__ w, float* __restrict__ wt, int C) {
@@ -428,6 +449,18 @@ int vdk_space_to_depth2_bf16(const void* in, void* out, int32_t B, int32_t H, in
   hipLaunchKernelGGL(s2d2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, (int)B, (int)H, (int)W,
                      (int)C, (int)inverse);
   return vdk_check_launch("vdk_space_to_depth2_bf16");
+}
+
+int vdk_avgpool_rows_f32_fwd(const float* in, float* out, int32_t B, int32_t HW, int32_t C, void* stream) {
+  if (!in || !out || B <= 0 || HW <= 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_avgpool_rows_f32_fwd: bad argument");
+  hipLaunchKernelGGL(avgpool_rows_f32_fwd_kernel, dim3((unsigned)(((long)B * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, (int)B, (int)HW, (int)C);
+  return vdk_check_launch("vdk_avgpool_rows_f32_fwd");
+}
+int vdk_avgpool_rows_f32_bwd(const float* dpool, float* dmap, void* dmap_bf16, int32_t B, int32_t HW, int32_t C, void* stream) {
+  if (!dpool || (!dmap && !dmap_bf16) || B <= 0 || HW <= 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_avgpool_rows_f32_bwd: bad argument");
+  hipLaunchKernelGGL(avgpool_rows_f32_bwd_kernel, dim3((unsigned)(((long)B * HW * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dpool, dmap, (bf16_t*)dmap_bf16,
+                     (int)B, (int)HW, (int)C);
+  return vdk_check_launch("vdk_avgpool_rows_f32_bwd");
 }
 
 int vdk_dwconv7_weight_prep(const float* w, float* wt, int32_t C, void* stream) {

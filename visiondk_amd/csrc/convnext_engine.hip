@@ -42,6 +42,8 @@ int vdk_gemm_f32_nt(const VdkGemmF32Desc*, void*);
 int vdk_gemm_a_colsum_rows(int32_t, int32_t, int32_t);
 int vdk_patchify_f32(const float*, int32_t, int32_t, int32_t, int32_t, int32_t, float*, void*);
 int vdk_space_to_depth2_f32(const float*, float*, int32_t, int32_t, int32_t, int32_t, void*);
+int vdk_avgpool_rows_f32_fwd(const float*, float*, int32_t, int32_t, int32_t, void*);
+int vdk_avgpool_rows_f32_bwd(const float*, float*, void*, int32_t, int32_t, int32_t, void*);
 }
 
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
@@ -54,11 +56,14 @@ struct CnDims {
   int depth[4], C[4], H[4], R[4];
   int nblk;
   float eps;
+  int ncls, Cp, Bp;        // classifier mode (ncls > 0): timm's head = global average pool -> head.norm -> head.fc; Cp = classes padded to 8, Bp = batch padded to 64
 };
 int cn_dims(const VdkConvNextConfig* c, CnDims* d) {
   if (!c) return vdk_fail(VDK_EINVAL, "convnext: null config");
   if (c->batch <= 0 || c->img_size <= 0 || (c->img_size % 32) || c->in_chans <= 0) return vdk_fail(VDK_EINVAL, "convnext: bad config (img_size % 32 == 0)");
   d->B = c->batch; d->img = c->img_size; d->Cin = c->in_chans; d->Kst = c->in_chans * 16; d->eps = c->ln_eps; d->nblk = 0;
+  if (c->num_classes < 0) return vdk_fail(VDK_EINVAL, "convnext: num_classes < 0");
+  d->ncls = c->num_classes; d->Cp = (int)up(c->num_classes, 8); d->Bp = (int)up(c->batch, 64);
   for (int i = 0; i < 4; ++i) {
     if (c->depths[i] <= 0 || c->dims[i] <= 0 || (c->dims[i] & 7)) return vdk_fail(VDK_EINVAL, "convnext: bad config (dims % 8 == 0, depths > 0)");
     d->depth[i] = c->depths[i]; d->C[i] = c->dims[i]; d->H[i] = c->img_size >> (2 + i);
@@ -74,7 +79,7 @@ struct PEntry { char name[64]; int64_t off, numel; int64_t shape[4]; int ndim; }
 struct BlkP { int64_t gamma, dw_w, dw_b, nw, nb, fc1_w, fc1_b, fc2_w, fc2_b; };
 struct StageP { int64_t ds_nw, ds_nb, ds_w, ds_b; std::vector<BlkP> blk; };
 struct PLayout {
-  int64_t stem_w, stem_b, stem_nw, stem_nb, head_nw, head_nb, total;
+  int64_t stem_w, stem_b, stem_nw, stem_nb, head_nw, head_nb, fc_w, fc_b, total;
   StageP st[4];
   std::vector<PEntry> entries;
 };
@@ -121,13 +126,18 @@ void cn_layout(const CnDims& d, PLayout* p) {
   }
   p->head_nw = p_take(cur, d.C[3]); add_entry(p, "head.norm.weight", p->head_nw, 1, d.C[3]);
   p->head_nb = p_take(cur, d.C[3]); add_entry(p, "head.norm.bias", p->head_nb, 1, d.C[3]);
+  p->fc_w = p->fc_b = 0;
+  if (d.ncls > 0) {          // rows >= ncls of the stored [Cp, C3] weight are padding (zero gradient, untouched by state_dict I/O)
+    p->fc_w = p_take(cur, (int64_t)d.Cp * d.C[3]); add_entry(p, "head.fc.weight", p->fc_w, 2, d.ncls, d.C[3]);
+    p->fc_b = p_take(cur, d.Cp); add_entry(p, "head.fc.bias", p->fc_b, 1, d.ncls);
+  }
   p->total = cur;
 }
 
 // derived operand copies (`wx`, byte offsets): per block the tap-major depthwise weight, fc1^T, the layer-scale-folded fc2 and its
 // transpose + bias; per downsample the (ky,kx,cin)-ordered weight and its transpose
 struct BlkX { size_t dwt, fc1t, fc2p, fc2pt, b2p; };
-struct XLayout { size_t total; size_t dsw[4], dswt[4]; std::vector<BlkX> blk[4]; };
+struct XLayout { size_t total; size_t dsw[4], dswt[4]; std::vector<BlkX> blk[4]; size_t fct; };   // fct: head.fc^T [C3, Cp] bf16 (classifier mode)
 size_t w_take(size_t& cur, size_t n) { size_t o = cur; cur = (cur + n + 255) & ~(size_t)255; return o; }
 void cn_xlayout(const CnDims& d, XLayout* x) {
   size_t cur = 0;
@@ -141,6 +151,7 @@ void cn_xlayout(const CnDims& d, XLayout* x) {
       b.dwt = w_take(cur, 49 * C * 4); b.fc1t = w_take(cur, C * M * 2); b.fc2p = w_take(cur, C * M * 2); b.fc2pt = w_take(cur, C * M * 2); b.b2p = w_take(cur, C * 4);
     }
   }
+  x->fct = d.ncls > 0 ? w_take(cur, (size_t)d.C[3] * d.Cp * 2) : 0;
   x->total = cur;
 }
 
@@ -169,6 +180,7 @@ struct WsPlan {
   size_t ds_stats[4], ds_h[4], ds_A[4];
   std::vector<BlkW> blk[4];
   size_t head_stats;
+  size_t pooled, pstats, feat, dfeat, dpool;   // classifier mode: pooled f32 [B, C3], its LayerNorm statistics, normed bf16 [Bp, C3], and their gradients
   // backward scratch (sized by the largest stage)
   size_t dxa, dxb, dt, du, dh, dA, dhds, dw2p, db2p, dwdsp;
   size_t slabs, slabs_bytes, lnws, lnws_bytes, csws, csws_bytes, dwws, dwws_bytes, tA, tB;
@@ -216,6 +228,13 @@ void cn_plan(const CnDims& d, WsPlan* w) {
     size_t q = 0; vdk_dwconv7_wgrad_workspace_bytes(d.B, d.H[i], d.H[i], (int)C, &q); if (q > dww) dww = q;
   }
   w->head_stats = w_take(cur, (size_t)d.R[3] * 2 * 4);
+  w->pooled = w->pstats = w->feat = w->dfeat = w->dpool = 0;
+  if (d.ncls > 0) {
+    w->pooled = w_take(cur, (size_t)d.B * d.C[3] * 4); w->pstats = w_take(cur, (size_t)d.B * 2 * 4); w->feat = w_take(cur, (size_t)d.Bp * d.C[3] * 2);
+    w->dfeat = w_take(cur, (size_t)d.Bp * d.C[3] * 4); w->dpool = w_take(cur, (size_t)d.B * d.C[3] * 4);
+    wg(d.Cp, d.C[3], d.Bp);
+    size_t l = 0; vdk_layernorm_bwd_workspace_bytes(d.B, d.C[3], &l); if (l > ln) ln = l;
+  }
   w->dxa = w_take(cur, rc * 4); w->dxb = w_take(cur, rc * 2); w->dt = w_take(cur, rc * 4); w->du = w_take(cur, rm * 2); w->dh = w_take(cur, rc * 2);
   w->dA = w_take(cur, ra * 2 + 256); w->dhds = w_take(cur, rh * 2 + 256);
   w->dw2p = w_take(cur, cm * 4); w->db2p = w_take(cur, 4096 * 4); w->dwdsp = w_take(cur, wds * 4 + 256);
@@ -325,6 +344,7 @@ int vdk_convnext_refresh_weights(const VdkConvNextConfig* cfg, const float* para
       RC(vdk_layerscale_weight_prep(params + b.fc2_w, params + b.fc2_b, params + b.gamma, xb + bx.fc2p, xb + bx.fc2pt, (float*)(xb + bx.b2p), C, M, stream));
     }
   }
+  if (d.ncls > 0) RC(vdk_transpose_cast_f32_bf16(params + p.fc_w, d.C[3], d.Cp, d.C[3], xb + x.fct, d.Cp, d.Cp, stream));
   return VDK_OK;
 }
 
@@ -372,15 +392,25 @@ int vdk_convnext_forward(const VdkConvNextConfig* cfg, const float* x, const flo
     }
   }
   const float* xlast = (const float*)(base + w.X[3]) + (size_t)d.depth[3] * d.R[3] * d.C[3];
+  if (d.ncls > 0) {
+    // timm ConvNeXt head with num_classes > 0 (NormMlpClassifierHead): global average pool -> LayerNorm (head.norm) -> Linear (head.fc); out = logits f32 [B, Cp]
+    float* pooled = (float*)(base + w.pooled); float* ps = (float*)(base + w.pstats);
+    RC(vdk_avgpool_rows_f32_fwd(xlast, pooled, d.B, d.H[3] * d.H[3], d.C[3], s));
+    if (d.Bp > d.B && hipMemsetAsync(base + w.feat + (size_t)d.B * d.C[3] * 2, 0, (size_t)(d.Bp - d.B) * d.C[3] * 2, s) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vdk_convnext_forward: memset");
+    RC(vdk_layernorm_fwd(pooled, d.C[3], d.B, d.C[3], params + p.head_nw, params + p.head_nb, d.eps, base + w.feat, d.C[3], VDK_BF16, ps, ps + d.B, s));
+    RC(gemm(s, base + w.feat, d.C[3], wb + p.fc_w, d.C[3], out, d.Cp, d.B, d.Cp, d.C[3], VDK_F32, params + p.fc_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0));
+    return vdk_check_launch("vdk_convnext_forward");
+  }
   float* hs = (float*)(base + w.head_stats);
   RC(vdk_layernorm_fwd(xlast, d.C[3], d.R[3], d.C[3], params + p.head_nw, params + p.head_nb, d.eps, out, d.C[3], VDK_F32, hs, hs + d.R[3], s));
   return vdk_check_launch("vdk_convnext_forward");
 }
 
-// dout f32 [B * (img/32)^2, dims[3]] -> grads (flat fp32, param layout, fully overwritten).  on_ready(user, offset, numel): see vdk_vit_backward.
-int vdk_convnext_backward(const VdkConvNextConfig* cfg, const float* dout, const float* params, const void* wb16, const void* wx, void* ws, size_t ws_bytes,
+// dout f32 [B * (img/32)^2, dims[3]] (feature mode) or dlogits bf16 [up(B, 64), up(num_classes, 8)] (classifier mode) -> grads (flat fp32, param layout, fully overwritten).  on_ready(user, offset, numel): see vdk_vit_backward.
+int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout_, const float* params, const void* wb16, const void* wx, void* ws, size_t ws_bytes,
                           float* grads, vdk_grad_ready_fn on_ready, void* user, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
+  const float* dout = (const float*)dout_;
   CnDims d; RC(cn_dims(cfg, &d));
   PLayout p; cn_layout(d, &p);
   XLayout xl; cn_xlayout(d, &xl);
@@ -393,7 +423,18 @@ int vdk_convnext_backward(const VdkConvNextConfig* cfg, const float* dout, const
   float* dt = (float*)(base + w.dt); bf16_t* du = (bf16_t*)(base + w.du); bf16_t* dh = (bf16_t*)(base + w.dh);
   float* dw2p = (float*)(base + w.dw2p); float* db2p = (float*)(base + w.db2p);
   void* lnws = base + w.lnws;
-  {
+  if (d.ncls > 0) {
+    // dout = dlogits bf16 [Bp, Cp] (rows >= B and columns >= num_classes zero): fc weight / bias gradient, feature gradient, head.norm backward on the
+    // pooled rows, then the pooled gradient spread over the map (1 / HW each)
+    const bf16_t* dl = (const bf16_t*)dout_;
+    RC(linear_wgrad(s, w, base, dl, (const bf16_t*)(base + w.feat), d.Bp, d.Cp, d.C[3], grads + p.fc_w, grads + p.fc_b));
+    RC(gemm(s, dl, d.Cp, xb + xl.fct, d.Cp, base + w.dfeat, d.C[3], d.B, d.C[3], d.Cp, VDK_F32, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0));
+    const float* ps = (const float*)(base + w.pstats);
+    RC(vdk_layernorm_bwd(base + w.dfeat, d.C[3], VDK_F32, (const float*)(base + w.pooled), d.C[3], ps, ps + d.B, params + p.head_nw, nullptr, 0, d.B, d.C[3],
+                         (float*)(base + w.dpool), d.C[3], nullptr, 0, grads + p.head_nw, grads + p.head_nb, lnws, w.lnws_bytes, s));
+    RC(vdk_avgpool_rows_f32_bwd((const float*)(base + w.dpool), dxa, dxb, d.B, d.H[3] * d.H[3], d.C[3], s));
+    if (on_ready) on_ready(user, p.head_nw, p.total - p.head_nw);
+  } else {
     const float* xlast = (const float*)(base + w.X[3]) + (size_t)d.depth[3] * d.R[3] * d.C[3];
     const float* hs = (const float*)(base + w.head_stats);
     RC(vdk_layernorm_bwd(dout, d.C[3], VDK_F32, xlast, d.C[3], hs, hs + d.R[3], params + p.head_nw, nullptr, 0, d.R[3], d.C[3], dxa, d.C[3], dxb, d.C[3],

@@ -327,8 +327,9 @@ class VisionWrapper:
         assert name.startswith("timm-"), "classifier id must look like timm-<timm model id>"
         kwargs = model_cfg.get("kwargs") or {}
         arch = name[5:].split(".")[0]
-        factory = resnet.create_model if arch in resnet.TIMM_RESNETS else vit.create_model       # timm-resnet18 | timm-vit_*
-        self.model = factory(arch, pretrained=False, num_classes=model_cfg["num_classes"], img_size=model_cfg.get("image_size"), device=device,
+        # timm-resnet18 | timm-convnext_* (pet.yaml:21-22) | timm-vit_*
+        factory = resnet.create_model if arch in resnet.TIMM_RESNETS else (convnext.create_model if arch in convnext.TIMM_CONVNEXTS else vit.create_model)
+        self.model = factory(arch, pretrained=False, num_classes=model_cfg["num_classes"], img_size=model_cfg.get("image_size") or 224, device=device,
                              backend=backend, **kwargs)
         if not model_cfg.get("pretrained", False):
             self.reset_parameters()

@@ -261,7 +261,8 @@ def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, d
 
 
 class ResNetTrainStep:
-    """Trainer.compute_loss + Trainer.update (engine/procedure/train.py:177-215) for the ResNet classifier as a fixed kernel sequence: forward ->
+    """Trainer.compute_loss + Trainer.update (engine/procedure/train.py:177-215) for a CNN classifier -- the ResNet engine, or the ConvNeXt engine in
+    classifier mode (`ClassifierTrainStep` is the same class) -- as a fixed kernel sequence: forward ->
     BCE-with-logits (multi-label CSV datasets, checks.py:163-167; mean over B*C like nn.BCEWithLogitsLoss) or CE(label_smoothing) -> backward ->
     clip_grad_norm_(max_norm) -> SGD(momentum, weight_decay) -> EMA -> bf16 weight refresh.  `param_groups[0]['lr']` stays readable / writable."""
 
@@ -301,6 +302,9 @@ class ResNetTrainStep:
             if ema:
                 self.ema.copy_(self.eng.params)
 
+    def _dl_rows(self, B: int) -> int:
+        return self.eng.dlogits_rows(B) if hasattr(self.eng, "dlogits_rows") else B
+
     def step(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         if self.graph:
             return self._step_graph(x, y)
@@ -326,12 +330,15 @@ class ResNetTrainStep:
         if key not in self._graphs:
             sx, sy = x.clone(), y.clone()
             eng = self.eng
-            eng._workspace(x.shape[0], x.shape[-1])                          # allocations and the weight refresh happen before the capture, not inside it
+            if isinstance(eng, ResNetEngine):                                # allocations and the weight refresh happen before the capture, not inside it
+                eng._workspace(x.shape[0], x.shape[-1])
+            else:
+                eng._workspace(x.shape[0])
             if eng._weights_version != eng.params._version:
                 eng.refresh_weights()
             if self.loss_rows is None or self.loss_rows.shape[0] != x.shape[0]:
                 self.loss_rows = torch.empty(x.shape[0], dtype=torch.float32, device=self.eng.device)
-                self._dl = torch.zeros((x.shape[0], self.eng.cp), dtype=torch.bfloat16, device=self.eng.device)
+                self._dl = torch.zeros((self._dl_rows(x.shape[0]), self.eng.cp), dtype=torch.bfloat16, device=self.eng.device)
             torch.cuda.synchronize()
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
@@ -363,7 +370,7 @@ class ResNetTrainStep:
         logits = eng.forward(x, True, sync_group=self.sync_group)
         if self.loss_rows is None or self.loss_rows.shape[0] != B:
             self.loss_rows = torch.empty(B, dtype=torch.float32, device=eng.device)
-            self._dl = torch.zeros((B, eng.cp), dtype=torch.bfloat16, device=eng.device)
+            self._dl = torch.zeros((self._dl_rows(B), eng.cp), dtype=torch.bfloat16, device=eng.device)
         if self.loss == "bce":
             be.check(be.lib.vdk_bce_logits(be.ptr(logits), eng.cp, be.ptr(y), y.stride(0), B, ncls, 1.0 / (B * ncls), 0.0, 0.25, be.ptr(self.loss_rows),
                                            be.ptr(self._dl), eng.cp, None, 0, be.stream()), "vdk_bce_logits")
@@ -387,3 +394,6 @@ class ResNetTrainStep:
                      "vdk_sgd_step")
         eng.refresh_weights(skip_wb16=True)
         return self.loss_rows
+
+
+ClassifierTrainStep = ResNetTrainStep      # engine-agnostic: needs forward(x, training) -> logits f32 [B, cp], backward(dlogits bf16), flat params / grads / wb16
