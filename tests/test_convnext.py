@@ -123,3 +123,37 @@ def test_vision_wrapper_routes_convnext_classifier(be, dev, monkeypatch):
     wrap = face.VisionWrapper(cfg, None, 0, backend=be, device=dev)
     y = wrap.model(torch.randn(2, 3, 32, 32).to(dev))
     assert y.shape == (2, 4) and "head.fc.weight" in wrap.model.state_dict()
+
+
+def test_classifier_sam_and_mixup_step_match_reference_sequence(be, dev):
+    """update_sam (train.py:150-175) with a CE mixup pair: loss at w -> e(w) = rho * w^2 * g / ||w * g|| -> loss at w + e(w) -> back to w -> SGD with the second
+    gradient (no clipping) -> the FIRST loss is returned."""
+    from visiondk_amd import resnet
+    ncls, img = 6, 32
+    model, ref = _pair(be, dev, (1, 1, 1, 1), (8, 16, 24, 32), img, num_classes=ncls)
+    lr, mom, wd, rho = 0.05, 0.9, 5e-4, 0.05
+    step = resnet.ClassifierTrainStep(model, lr=lr, momentum=mom, weight_decay=wd, loss="ce", label_smoothing=0.05, ema=False, sam=True, sam_rho=rho)
+    params = list(ref.parameters())
+    start = [p.detach().clone() for p in params]
+    opt = torch.optim.SGD(params, lr=lr, momentum=mom, weight_decay=wd)
+    torch.manual_seed(6)
+    x = torch.randn(5, 3, img, img); ya = torch.randint(0, ncls, (5,)); yb = torch.randint(0, ncls, (5,)); lam = 0.3
+    ce = lambda out: lam * torch.nn.functional.cross_entropy(out, ya, label_smoothing=0.05) + (1 - lam) * torch.nn.functional.cross_entropy(out, yb, label_smoothing=0.05)
+    loss1 = ce(ref(x)); loss1.backward()
+    with torch.no_grad():
+        norm = torch.stack([(p.abs() * p.grad).norm(2) for p in params]).norm(2)
+        for p in params:
+            p.add_(p.pow(2) * p.grad * (rho / (norm + 1e-12)))
+    opt.zero_grad()
+    ce(ref(x)).backward()
+    with torch.no_grad():
+        for p, s0 in zip(params, start):
+            p.copy_(s0)
+    opt.step()
+    rows = step.step(x.to(dev), ya.to(dev), yb.to(dev), lam)
+    assert abs(rows.mean().item() - loss1.item()) < 2e-2 * abs(loss1.item())
+    got = dict(model.named_parameters())
+    for (n, p), s0 in zip(ref.named_parameters(), start):
+        upd_ref, upd = p.detach() - s0, got[n].detach().cpu() - s0
+        r = ((upd - upd_ref).norm() / (upd_ref.norm() + 1e-12)).item()
+        assert r < 0.12, (n, r)

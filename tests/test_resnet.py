@@ -193,3 +193,27 @@ def test_graph_captured_step_equals_eager_step(hip):
         res.append((model.engine.params.clone(), step.momentum_buf.clone(), step.ema.clone(), model.engine.buffers.clone(), torch.stack(losses)))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+def test_sam_step_freezes_running_statistics_in_the_second_pass(be, dev):
+    """SAM on a BatchNorm network (optimizer.py:92-106, train.py:152,164): the first pass updates the running statistics, the second runs with momentum 0;
+    torch still counts both forwards in num_batches_tracked.  BCE mixup pair = one soft target."""
+    res = {}
+    for sam in (False, True):
+        model, ref = _pair(be, dev, widths=(8, 8, 16, 16), depths=(1, 1, 1, 1), img=32)
+        step = resnet.ResNetTrainStep(model, lr=0.05, momentum=0.9, weight_decay=5e-4, loss="bce", ema=False, sam=sam)
+        torch.manual_seed(8)
+        x = torch.randn(8, 3, 32, 32); ya = (torch.rand(8, 5) > 0.5).float(); yb = (torch.rand(8, 5) > 0.5).float()
+        rows = step.step(x.to(dev), ya.to(dev), yb.to(dev), 0.25)
+        res[sam] = (model.engine.buffers.clone().cpu(), model.engine.params.clone().cpu(), rows.clone().cpu(),
+                    int(model.state_dict()["bn1.num_batches_tracked"]))
+    assert torch.equal(res[True][0], res[False][0])                 # running mean / var: one update, from the pass at w
+    assert torch.equal(res[True][2], res[False][2])                 # the returned loss is the first pass's
+    assert not torch.equal(res[True][1], res[False][1])             # but the weights moved along the gradient taken at w + e(w)
+    assert res[False][3] == 1 and res[True][3] == 2
+    # the soft-target fold: BCE(pred, lam * ya + (1 - lam) * yb) == lam * BCE(pred, ya) + (1 - lam) * BCE(pred, yb)
+    ref.train()
+    out = ref(x)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+    exp = 0.25 * bce(out, ya) + 0.75 * bce(out, yb)
+    assert abs(res[False][2].sum().item() / 40 - exp.item()) < 3e-2 * abs(exp.item())

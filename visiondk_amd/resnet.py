@@ -64,9 +64,10 @@ class ResNetEngine:
         self._logits: Optional[torch.Tensor] = None
         self._weights_version = None
 
-    def _cfg(self, batch: int, img: Optional[int] = None) -> _abi.ResNetConfig:
+    def _cfg(self, batch: int, img: Optional[int] = None, bn_momentum: Optional[float] = None) -> _abi.ResNetConfig:
         s = self.spec
-        return _abi.ResNetConfig(batch, img or s.img_size, s.in_chans, (_abi.I32 * 4)(*s.widths), (_abi.I32 * 4)(*s.depths), s.num_classes, s.bn_eps, s.bn_momentum)
+        return _abi.ResNetConfig(batch, img or s.img_size, s.in_chans, (_abi.I32 * 4)(*s.widths), (_abi.I32 * 4)(*s.depths), s.num_classes, s.bn_eps,
+                                 s.bn_momentum if bn_momentum is None else bn_momentum)
 
     def _workspace(self, batch: int, img: int) -> torch.Tensor:
         """keyed on (batch, image size): the reference's progressive resizing (engine/vision_engine.py:181-222) changes the input resolution between
@@ -99,8 +100,9 @@ class ResNetEngine:
             dist.all_reduce(self._ws[off:off + 4 * n].view(torch.float32), op=dist.ReduceOp.SUM, group=group)
         return _abi.STAT_SYNC_FN(cb)
 
-    def forward(self, x: torch.Tensor, training: bool, sync_group=False) -> torch.Tensor:
-        """sync_group: False = per-rank BatchNorm statistics; None or a process group = SyncBatchNorm over that group"""
+    def forward(self, x: torch.Tensor, training: bool, sync_group=False, bn_momentum: Optional[float] = None) -> torch.Tensor:
+        """sync_group: False = per-rank BatchNorm statistics; None or a process group = SyncBatchNorm over that group.
+        bn_momentum: override of the running-statistics momentum for this pass (SAM's second pass runs with 0, optimizer.py:92-98)"""
         s = self.spec
         if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != s.in_chans or x.shape[2] != x.shape[3] or x.shape[2] % 32:
             raise ValueError(f"expected float32 [B, {s.in_chans}, S, S] with S % 32 == 0, got {tuple(x.shape)} {x.dtype}")
@@ -109,7 +111,7 @@ class ResNetEngine:
         ws = self._workspace(B, img)
         if self._weights_version != self.params._version:
             self.refresh_weights()
-        cfg = self._cfg(B, img)
+        cfg = self._cfg(B, img, bn_momentum)
         be = self.be
         cb = self._sync_cb(sync_group)
         be.check(be.lib.vdk_resnet_forward(C.byref(cfg), be.ptr(x), be.ptr(self.params), be.ptr(self.buffers), be.ptr(self.wb16), be.ptr(self.wx), int(training),
@@ -267,8 +269,12 @@ class ResNetTrainStep:
     clip_grad_norm_(max_norm) -> SGD(momentum, weight_decay) -> EMA -> bf16 weight refresh.  `param_groups[0]['lr']` stays readable / writable."""
 
     def __init__(self, model: ResNet, lr: float, momentum: float = 0.937, weight_decay: float = 5e-4, loss: str = "bce", label_smoothing: float = 0.0,
-                 max_norm: float = 10.0, ema: bool = True, comm=None, sync_bn: bool = False, graph: bool = False):
-        """graph: capture the whole step (about 250 launches of a few microseconds each at ResNet-18 / bs 32: launch-bound) once per batch shape in a hipGraph
+                 max_norm: float = 10.0, ema: bool = True, comm=None, sync_bn: bool = False, graph: bool = False, sam: bool = False, sam_rho: float = 0.05,
+                 sam_adaptive: bool = True):
+        """sam: Trainer.update_sam (train.py:150-175) over engine/optimizer.py's SAM(base SGD): forward-backward at w with LOCAL gradients, climb to w + e(w),
+        forward-backward there with the BatchNorm running statistics frozen (momentum 0) and the gradients all-reduced, back to w, base SGD step
+        (no clipping on this path), EMA; the returned loss is the first pass's.
+        graph: capture the whole step (about 250 launches of a few microseconds each at ResNet-18 / bs 32: launch-bound) once per batch shape in a hipGraph
         (torch.cuda.CUDAGraph) and replay it; the per-step scalars (lr, momentum, weight decay, EMA decay, first-step flag) travel through a 5-float
         device vector (vdk_sgd_step_graph).  Single-process only; results are bit-identical to the eager sequence.
         sync_bn: SyncBatchNorm over comm's group (the reference's `sync_bn` flag -> nn.SyncBatchNorm.convert_sync_batchnorm, vision_engine.py:224-225).
@@ -292,6 +298,8 @@ class ResNetTrainStep:
         if graph and comm is not None and comm.world_size > 1:
             raise NotImplementedError("graph capture of the data-parallel step (host callbacks issue the collectives) is not built")
         self.graph = graph
+        self.sam, self.sam_rho, self.sam_adaptive = sam, sam_rho, sam_adaptive
+        self._old_params = torch.empty_like(self.eng.params) if sam else None
         self._graphs = {}                       # (B, y shape/dtype) -> (CUDAGraph, static x, static y)
         self._hyper = torch.zeros(5, dtype=torch.float32, device=self.eng.device) if graph else None
         self._hyper_ring = [(torch.zeros(5, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(8)] if graph else []
@@ -305,10 +313,16 @@ class ResNetTrainStep:
     def _dl_rows(self, B: int) -> int:
         return self.eng.dlogits_rows(B) if hasattr(self.eng, "dlogits_rows") else B
 
-    def step(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    def step(self, x: torch.Tensor, y: torch.Tensor, y_b: Optional[torch.Tensor] = None, lam: float = 1.0) -> torch.Tensor:
+        """y_b, lam: mixup_criterion (train.py:34-35): lam * loss(pred, y) + (1 - lam) * loss(pred, y_b).  CE takes the pair as is; BCE-with-logits is
+        linear in its targets, so the pair is folded into one soft target."""
+        if y_b is not None and self.loss == "bce":
+            y, y_b = lam * y + (1.0 - lam) * y_b, None
         if self.graph:
+            if y_b is not None:
+                raise NotImplementedError("graph replay with a CE mixup pair (lam is a by-value kernel argument)")
             return self._step_graph(x, y)
-        return self._step_eager(x, y, None)
+        return self._step_eager(x, y, None, y_b=y_b, lam=lam)
 
     def _step_graph(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         import math
@@ -351,7 +365,7 @@ class ResNetTrainStep:
         self.loss_rows = rows
         return rows
 
-    def _step_eager(self, x: torch.Tensor, y: torch.Tensor, hyper, count: bool = True) -> torch.Tensor:
+    def _step_eager(self, x: torch.Tensor, y: torch.Tensor, hyper, count: bool = True, y_b: Optional[torch.Tensor] = None, lam: float = 1.0) -> torch.Tensor:
         import math
         eng, be, model = self.eng, self.be, self.model
         world = self.comm.world_size if self.comm is not None else 1
@@ -367,30 +381,50 @@ class ResNetTrainStep:
                     m._buffers["num_batches_tracked"] += 1
         g = self.param_groups[0]
         B, ncls = x.shape[0], eng.spec.num_classes
-        logits = eng.forward(x, True, sync_group=self.sync_group)
         if self.loss_rows is None or self.loss_rows.shape[0] != B:
             self.loss_rows = torch.empty(B, dtype=torch.float32, device=eng.device)
             self._dl = torch.zeros((self._dl_rows(B), eng.cp), dtype=torch.bfloat16, device=eng.device)
-        if self.loss == "bce":
-            be.check(be.lib.vdk_bce_logits(be.ptr(logits), eng.cp, be.ptr(y), y.stride(0), B, ncls, 1.0 / (B * ncls), 0.0, 0.25, be.ptr(self.loss_rows),
-                                           be.ptr(self._dl), eng.cp, None, 0, be.stream()), "vdk_bce_logits")
+
+        def fwd_loss_bwd(sync: bool, bn_momentum=None):
+            kw = {} if bn_momentum is None else {"bn_momentum": bn_momentum}
+            logits = eng.forward(x, True, sync_group=self.sync_group, **kw)
+            if self.loss == "bce":
+                be.check(be.lib.vdk_bce_logits(be.ptr(logits), eng.cp, be.ptr(y), y.stride(0), B, ncls, 1.0 / (B * ncls), 0.0, 0.25, be.ptr(self.loss_rows),
+                                               be.ptr(self._dl), eng.cp, None, 0, be.stream()), "vdk_bce_logits")
+            else:
+                be.check(be.lib.vdk_softmax_ce(be.ptr(logits), eng.cp, B, ncls, be.ptr(y), be.ptr(y_b), lam, self.label_smoothing, 1.0 / B, be.ptr(self.loss_rows),
+                                               be.ptr(self._dl), eng.cp, None, 0, be.stream()), "vdk_softmax_ce")
+            if world > 1 and sync:
+                self.comm.begin_step(eng.grads)
+                eng.backward(self._dl, on_ready=self.comm.on_grad_ready, sync_group=self.sync_group)
+                self.comm.finish_step()
+            else:
+                eng.backward(self._dl, sync_group=self.sync_group)
+
+        if self.sam:
+            fwd_loss_bwd(sync=False)                                          # model.no_sync() in the reference: local gradients
+            loss_first = self.loss_rows.clone()
+            be.check(be.lib.vdk_sam_first_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self._old_params), eng.n_floats, self.sam_rho, int(self.sam_adaptive),
+                                               be.ptr(self._normsq), be.ptr(self._ws), self._ws.numel(), be.stream()), "vdk_sam_first_step")
+            eng.refresh_weights()
+            for m in model.modules():                                         # torch's BatchNorm counts every training forward, whatever the momentum
+                if "num_batches_tracked" in m._buffers:
+                    m._buffers["num_batches_tracked"] += 1
+            fwd_loss_bwd(sync=True, bn_momentum=0.0 if hasattr(eng, "spec") and hasattr(eng.spec, "bn_momentum") else None)
+            eng.params.copy_(self._old_params)
+            self.loss_rows.copy_(loss_first)                                  # update_sam returns the FIRST loss (train.py:175)
+            nsq = None                                                        # no clipping on the SAM path
         else:
-            be.check(be.lib.vdk_softmax_ce(be.ptr(logits), eng.cp, B, ncls, be.ptr(y), None, 1.0, self.label_smoothing, 1.0 / B, be.ptr(self.loss_rows),
-                                           be.ptr(self._dl), eng.cp, None, 0, be.stream()), "vdk_softmax_ce")
-        if world > 1:
-            self.comm.begin_step(eng.grads)
-            eng.backward(self._dl, on_ready=self.comm.on_grad_ready, sync_group=self.sync_group)
-            self.comm.finish_step()
-        else:
-            eng.backward(self._dl)
-        be.check(be.lib.vdk_sumsq_f32(be.ptr(eng.grads), eng.n_floats, be.ptr(self._normsq), be.ptr(self._ws), self._ws.numel(), be.stream()), "vdk_sumsq_f32")
+            fwd_loss_bwd(sync=True)
+            be.check(be.lib.vdk_sumsq_f32(be.ptr(eng.grads), eng.n_floats, be.ptr(self._normsq), be.ptr(self._ws), self._ws.numel(), be.stream()), "vdk_sumsq_f32")
+            nsq = be.ptr(self._normsq)
         if hyper is not None:
             be.check(be.lib.vdk_sgd_step_graph(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema), be.ptr(eng.wb16), eng.n_floats,
-                                               be.ptr(hyper), 1.0 / world, be.ptr(self._normsq), self.max_norm, be.stream()), "vdk_sgd_step_graph")
+                                               be.ptr(hyper), 1.0 / world, nsq, self.max_norm, be.stream()), "vdk_sgd_step_graph")
         else:
             d = 0.9999 * (1 - math.exp(-self.updates / 2000)) if self.ema is not None else 0.0
             be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema), be.ptr(eng.wb16), eng.n_floats, g["lr"],
-                                         g["momentum"], g["weight_decay"], 1.0 / world, be.ptr(self._normsq), self.max_norm, d, int(self.updates == 1), be.stream()),
+                                         g["momentum"], g["weight_decay"], 1.0 / world, nsq, self.max_norm, d, int(self.updates == 1), be.stream()),
                      "vdk_sgd_step")
         eng.refresh_weights(skip_wb16=True)
         return self.loss_rows
