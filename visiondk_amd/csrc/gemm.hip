@@ -447,9 +447,9 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
   // K-tile schedule: 4 barrier intervals per tile; wave-row 1 runs one interval behind wave-row 0, so on every SIMD one wave's
   // 16-MFMA segment overlaps the other wave's LDS reads.  With group 0 at intervals 4t .. 4t+3:
   //   RA(t): read A0 (8), B0 (4), B1 (4) of tile t;  wait vmcnt(6): RA1 of tile t has landed (read two barriers later, in RB)
-  //   MA(t): DMA RA1 of tile t+1 (2), then 16 MFMA A0 x (B0, B1)
+  //   MA(t): 16 MFMA A0 x (B0, B1) with the DMA of RA1 of tile t+1 (2) issued after the 6th
   //   RB(t): read A1 (8);                             wait vmcnt(2): RA0, RB0, RB1 of tile t+1 have landed (read in RA(t+1))
-  //   MB(t): DMA RA0, RB0, RB1 of tile t+2 (6), then 16 MFMA A1 x (B1, B0)
+  //   MB(t): 16 MFMA A1 x (B1, B0) with the DMAs of RA0, RB0, RB1 of tile t+2 (6) issued in pairs after the 2nd, 6th and 10th
   // WAR: every refill is ISSUED >= 2 intervals after the lagging row issued its last read of that region (RA1: read in RB(t-1),
   // i.e. interval 4t-1 for row 1, refilled at 4t+1; RA0/RB0/RB1: read at 4t+1, refilled at 4t+3), so those reads have retired
   // behind an lgkmcnt(0) + barrier.  RAW: each wait is followed by two barriers before the first read of the data it covers.
@@ -496,13 +496,17 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
     if (t + 1 < nk) { H_WAIT_VM(6); } else { H_WAIT_VM(0); }
     H_BAR();
     // ---- MA --------------------------------------------------------------------------------------------------------
-    if (t >= 1 && t + 1 < nk) H_ISSUE_A(cur ^ 1, 1, t + 1);   // (tile 1's RA1 was issued by the prologue)
+    // The DMA instructions are issued BETWEEN the MFMAs of the segment, not in front of them: an LDS-DMA costs 60-180 issue cycles, and a batch of two
+    // (MA) or six (MB) ahead of the first MFMA left the matrix pipe idle that long in every interval (+10 % at 4096^3 when interleaved).
     VDK_PIN2(acc[0][0], acc[1][0]); VDK_PIN2(acc[0][1], acc[1][1]);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0][ks], b0[ks], acc[0][0], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1][ks], b0[ks], acc[1][0], 0, 0, 0);
+      if (ks == 1 && t >= 1 && t + 1 < nk) {                  // (tile 1's RA1 was issued by the prologue)
+        __builtin_amdgcn_sched_barrier(0); H_ISSUE_A(cur ^ 1, 1, t + 1); __builtin_amdgcn_sched_barrier(0);
+      }
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0][ks], b1[ks], acc[0][1], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1][ks], b1[ks], acc[1][1], 0, 0, 0);
     }
@@ -529,13 +533,19 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
     if (t + 1 < nk) { H_WAIT_VM(2); } else { H_WAIT_VM(0); }
     H_BAR();
     // ---- MB --------------------------------------------------------------------------------------------------------
-    if (t + 2 < nk) { H_ISSUE_A(cur, 0, t + 2); H_ISSUE_B(cur, 0, t + 2); H_ISSUE_B(cur, 1, t + 2); }
     VDK_PIN2(acc[2][1], acc[3][1]); VDK_PIN2(acc[2][0], acc[3][0]);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0][ks], b1[ks], acc[2][1], 0, 0, 0);
       acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1][ks], b1[ks], acc[3][1], 0, 0, 0);
+      if (t + 2 < nk) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks == 0) H_ISSUE_A(cur, 0, t + 2);
+        if (ks == 1) H_ISSUE_B(cur, 0, t + 2);
+        if (ks == 2) H_ISSUE_B(cur, 1, t + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0][ks], b0[ks], acc[2][0], 0, 0, 0);
       acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1][ks], b0[ks], acc[3][0], 0, 0, 0);
     }
