@@ -39,3 +39,20 @@ def test_attention_fwd_bwd(be, dev, B, N, H):
     for i, name in enumerate("qkv"):
         got = dqkv[..., i * D:(i + 1) * D].float(); ref = qr.grad[..., i * D:(i + 1) * D]
         assert _rel(got, ref) < 1.5e-2, name
+
+
+@pytest.mark.parametrize("grid", [1, 2, 3])
+def test_attention_fwd_persistent_workgroups(be, dev, grid, monkeypatch):
+    """For N <= 256 the forward kernel is persistent over (batch, head) items with the next item's K / V prefetched under the current one's q-tile rounds;
+    real launches give a workgroup several items only for B * H > 512, so the tests force it (1 = one workgroup walks over everything)."""
+    monkeypatch.setenv("VDK_ATTN_GRID", str(grid))
+    torch.manual_seed(1)
+    B, N, H = 3, 45, 2
+    D = H * 64
+    qkv = (torch.randn(B, N, 3 * D) * 1.2).bfloat16().to(dev)
+    o, lse = ops.attention_fwd(qkv, H, backend=be)
+    oref, lseref = _ref(qkv.float(), H)
+    assert _rel(lse, lseref) < 1e-5 and _rel(o.float(), oref) < 6e-3
+    monkeypatch.delenv("VDK_ATTN_GRID")
+    o2, lse2 = ops.attention_fwd(qkv, H, backend=be)            # one item per workgroup: bit-identical
+    assert torch.equal(o, o2) and torch.equal(lse, lse2)

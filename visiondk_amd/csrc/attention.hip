@@ -13,6 +13,7 @@
 // and O is rescaled by a per-lane factor.  Backward: kernel 1 owns query tiles (dQ, D = rowsum(dO*O)),
 // kernel 2 owns key tiles (dK, dV); both recompute P from the saved log-sum-exp.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "vdk_device.h"
 #include "vdk_host.h"
 
@@ -74,19 +75,50 @@ __device__ __forceinline__ s16x8 a_load_T(const bf16_t* tile /* row-major, pitch
 // lse: float [B, H, N].  grid = B*H, block = 256.
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                        const bf16_t* __restrict__ v, long ld, bf16_t* __restrict__ o, long ldo,
-                                                       float* __restrict__ lse, int N, int H, float scale) {
+                                                       float* __restrict__ lse, int N, int H, float scale, int nitems) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[A_FWD_KC * A_RP];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[A_FWD_KC * A_RP];
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
-  const bf16_t* qb = q + (long)b * N * ld + h * A_HD;
-  const bf16_t* kb = k + (long)b * N * ld + h * A_HD;
-  const bf16_t* vb = v + (long)b * N * ld + h * A_HD;
   const int nqt = (N + 31) / 32;
   const int nchunk = (N + A_FWD_KC - 1) / A_FWD_KC;
   const float scale2 = scale * VDK_LOG2E;
   // every wave runs the same number of q-tile rounds so that barriers stay uniform
   const int rounds = (nqt + 3) / 4;
+  // One chunk of keys (N <= 256, ViT-B/16 at 224: 197): the workgroup is PERSISTENT over (batch, head) items and the next item's K / V rows are loaded
+  // into registers before this item's q-tile rounds and written to LDS after them -- with two workgroups per CU (74 KB of LDS each) a
+  // load -> barrier -> compute sequence per item left the HBM round trip exposed.  Longer sequences keep one item per workgroup and stage per chunk.
+  const bool persistent = nchunk == 1;
+  const int nkp1 = (N + 31) / 32 * 32;
+  constexpr int PFN = A_FWD_KC * 8 / 256;                  // 16-byte pieces per thread and matrix
+  u32x4 pk[PFN], pv[PFN];
+  auto prefetch = [&](int item) {
+    const bf16_t* kb2 = k + (long)(item / H) * N * ld + (item % H) * A_HD;
+    const bf16_t* vb2 = v + (long)(item / H) * N * ld + (item % H) * A_HD;
+#pragma unroll
+    for (int i = 0; i < PFN; ++i) {
+      const int id = threadIdx.x + i * 256, r = id >> 3, ch = id & 7;
+      u32x4 a = {0u, 0u, 0u, 0u}, c2 = {0u, 0u, 0u, 0u};
+      if (id < nkp1 * 8 && r < N) { a = *(const u32x4*)(kb2 + (long)r * ld + ch * 8); c2 = *(const u32x4*)(vb2 + (long)r * ld + ch * 8); }
+      pk[i] = a; pv[i] = c2;
+    }
+  };
+  const int n_items = nitems;
+  if (persistent && (int)blockIdx.x < n_items) prefetch(blockIdx.x);
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+  const int b = item / H, h = item % H;
+  const bf16_t* qb = q + (long)b * N * ld + h * A_HD;
+  const bf16_t* kb = k + (long)b * N * ld + h * A_HD;
+  const bf16_t* vb = v + (long)b * N * ld + h * A_HD;
+  if (persistent) {
+    __syncthreads();                                        // the previous item's readers of Ks / Vs are done
+#pragma unroll
+    for (int i = 0; i < PFN; ++i) {
+      const int id = threadIdx.x + i * 256, r = id >> 3, ch = id & 7;
+      if (id < nkp1 * 8) { *(u32x4*)(Ks + r * A_RP + ch * 8) = pk[i]; *(u32x4*)(Vs + r * A_RP + ch * 8) = pv[i]; }
+    }
+    __syncthreads();
+    if (item + (int)gridDim.x < n_items) prefetch(item + gridDim.x);
+  }
   for (int rd = 0; rd < rounds; ++rd) {
     const int qt = rd * 4 + w;
     const bool active = qt < nqt;
@@ -101,7 +133,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       const int key0 = c * A_FWD_KC;
       int nk = N - key0; if (nk > A_FWD_KC) nk = A_FWD_KC;
       const int nkp = (nk + 31) / 32 * 32;
-      if (nchunk > 1 || rd == 0) {
+      if (!persistent) {
         __syncthreads();  // previous readers of Ks/Vt are done
         a_stage_rows(Ks, kb, ld, key0, N, nkp);
         a_stage_rows(Vs, vb, ld, key0, N, nkp);
@@ -164,6 +196,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       if (hi == 0 && lse) lse[((long)b * H + h) * N + qrow] = (m + log2f(lt)) * 0.6931471805599453f;  // natural-log LSE
     }
   }
+  }   // items
 }
 
 // =====================================================================================  backward 1: dQ (+ D)
@@ -356,8 +389,12 @@ int vdk_attention_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* 
   if ((ld & 7) || (ldo & 7)) return vdk_fail(VDK_EINVAL, "vdk_attention_fwd: ld % 8");
   const bf16_t* base = (const bf16_t*)qkv;
   const long D = (long)H * A_HD;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, base, base + D, base + 2 * D,
-                     (long)ld, (bf16_t*)o, (long)ldo, lse, (int)N, (int)H, scale);
+  int grid = B * H;
+  int cap = 512;                                            // persistent: two workgroups per CU walk over the (batch, head) items
+  if (const char* e = getenv("VDK_ATTN_GRID")) { const int v = atoi(e); if (v > 0) cap = v; }   // tests: force several items per workgroup
+  if (N <= A_FWD_KC && grid > cap) grid = cap;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, base, base + D, base + 2 * D,
+                     (long)ld, (bf16_t*)o, (long)ldo, lse, (int)N, (int)H, scale, (int)(B * H));
   return vdk_check_launch("vdk_attention_fwd");
 }
 
