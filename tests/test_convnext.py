@@ -157,3 +157,16 @@ def test_classifier_sam_and_mixup_step_match_reference_sequence(be, dev):
         upd_ref, upd = p.detach() - s0, got[n].detach().cpu() - s0
         r = ((upd - upd_ref).norm() / (upd_ref.norm() + 1e-12)).item()
         assert r < 0.12, (n, r)
+
+
+def test_classifier_takes_other_resolutions(be, dev):
+    """progressive resizing (vision_engine.py:181-222): the classifier's global-average-pool head is resolution-agnostic, so the engine follows the input size"""
+    model, ref = _pair(be, dev, (1, 1, 1, 1), (8, 16, 24, 32), 64, num_classes=5)
+    for img in (32, 96, 64):
+        x = torch.randn(2, 3, img, img)
+        y = model(x.to(dev))
+        yr = ref(x)
+        assert ((y.detach().cpu() - yr.detach()).norm() / yr.detach().norm()).item() < 2e-2, img
+    y.sum().backward()
+    with pytest.raises(ValueError):
+        model(torch.randn(2, 3, 48, 48).to(dev))

@@ -68,18 +68,24 @@ class ConvNeXtEngine:
         self.cp = (spec.num_classes + 7) // 8 * 8          # logits row stride in classifier mode
         self._ws: Optional[torch.Tensor] = None
         self._ws_batch = -1
+        self._ws_img = spec.img_size
         self._out: Optional[torch.Tensor] = None
         self._weights_version = None
         self.buffers = torch.zeros(0, dtype=torch.float32, device=dev)      # no BatchNorm: nothing to broadcast (the train step shared with the ResNet engine asks)
 
-    def _cfg(self, batch: int) -> _abi.ConvNextConfig:
+    def _cfg(self, batch: int, img: Optional[int] = None) -> _abi.ConvNextConfig:
         s = self.spec
-        return _abi.ConvNextConfig(batch, s.img_size, s.in_chans, (_abi.I32 * 4)(*s.depths), (_abi.I32 * 4)(*s.dims), s.ln_eps, s.num_classes)
+        return _abi.ConvNextConfig(batch, img or s.img_size, s.in_chans, (_abi.I32 * 4)(*s.depths), (_abi.I32 * 4)(*s.dims), s.ln_eps, s.num_classes)
 
-    def _workspace(self, batch: int) -> torch.Tensor:
-        if self._ws is None or self._ws_batch != batch:
+    def _workspace(self, batch: int, img: Optional[int] = None) -> torch.Tensor:
+        """keyed on (batch, image size): the classifier (global average pool head) takes any multiple of 32 -- the reference's progressive resizing
+        (engine/vision_engine.py:181-222) changes the input resolution between epochs; feature mode stays at spec.img_size (the neck's Linear fixes it)"""
+        img = img or self.spec.img_size
+        if self._ws is None or self._ws_batch != batch or self._ws_img != img:
             need = C.c_size_t(0)
-            cfg = self._cfg(batch)
+            cfg = self._cfg(batch, img)
+            self._ws_img = img
+            self.out_hw = img // 32
             self.be.check(self.be.lib.vdk_convnext_workspace_bytes(C.byref(cfg), C.byref(need)), "vdk_convnext_workspace_bytes")
             self._ws = None
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
@@ -109,13 +115,19 @@ class ConvNeXtEngine:
         """x f32 [B, Cin, H, W] (NCHW) -> f32 [B*h*w, C] NHWC rows of the head-normed map, or (classifier mode) logits f32 [B, cp]; activations stay in
         the workspace."""
         s = self.spec
-        if x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (s.in_chans, s.img_size, s.img_size):
-            raise ValueError(f"expected float32 [B, {s.in_chans}, {s.img_size}, {s.img_size}], got {tuple(x.shape)} {x.dtype}")
+        ok = x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == s.in_chans and x.shape[2] == x.shape[3]
+        if ok and s.num_classes > 0:
+            ok = x.shape[2] % 32 == 0 and x.shape[2] >= 32
+        elif ok:
+            ok = x.shape[2] == s.img_size
+        if not ok:
+            want = "S, S] with S % 32 == 0" if s.num_classes > 0 else f"{s.img_size}, {s.img_size}]"
+            raise ValueError(f"expected float32 [B, {s.in_chans}, {want}, got {tuple(x.shape)} {x.dtype}")
         x = x.contiguous()
-        B = x.shape[0]
-        ws = self._workspace(B)
+        B, img = x.shape[0], x.shape[2]
+        ws = self._workspace(B, img)
         self._ensure_fresh()
-        cfg = self._cfg(B)
+        cfg = self._cfg(B, img)
         be = self.be
         be.check(be.lib.vdk_convnext_forward(C.byref(cfg), be.ptr(x), be.ptr(self.params), be.ptr(self.wb16), be.ptr(self.wx), be.ptr(ws), ws.numel(),
                                              be.ptr(self._out), be.stream()), "vdk_convnext_forward")
@@ -149,7 +161,7 @@ class ConvNeXtEngine:
             assert dout.dtype == torch.bfloat16 and dout.is_contiguous() and tuple(dout.shape) == ((self._ws_batch + 63) // 64 * 64, self.cp)
         else:
             assert dout.dtype == torch.float32 and dout.is_contiguous() and dout.shape == self._out.shape
-        cfg = self._cfg(self._ws_batch)
+        cfg = self._cfg(self._ws_batch, self._ws_img)
         be = self.be
         cb = _abi.GRAD_READY_FN(lambda user, off, n: on_ready(off, n)) if on_ready is not None else _abi.GRAD_READY_FN(0)
         be.check(be.lib.vdk_convnext_backward(C.byref(cfg), be.ptr(dout), be.ptr(self.params), be.ptr(self.wb16), be.ptr(self.wx), be.ptr(self._ws),
