@@ -438,6 +438,8 @@ int vdk_dwconv7_wgrad(const float* in, const float* dy, float* dw, float* db, in
   else if (tw == 14) hipLaunchKernelGGL((dwconv7_wgrad_kernel<7, 14>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
   else if (tw == 7) hipLaunchKernelGGL((dwconv7_wgrad_kernel<7, 7>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
   else hipLaunchKernelGGL((dwconv7_wgrad_kernel<8, 8>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
+  if (db == dw + (size_t)C * 49)     // conv_dw.weight / conv_dw.bias of the flat gradient buffer: the partial rows [49 C | C] reduce in one launch
+    return vdk_reduce_rows_f32((const float*)ws, (int64_t)C * 50, S, (int64_t)C * 50, dw, 1.0f, stream);
   int rc = vdk_reduce_rows_f32((const float*)ws, (int64_t)C * 50, S, (int64_t)C * 49, dw, 1.0f, stream);
   if (rc) return rc;
   return vdk_reduce_rows_f32((const float*)ws + (size_t)C * 49, (int64_t)C * 50, S, C, db, 1.0f, stream);

@@ -334,18 +334,19 @@ int vdk_convnext_refresh_weights(const VdkConvNextConfig* cfg, const float* para
   if (!params || !wb16 || !wx) return vdk_fail(VDK_EINVAL, "vdk_convnext_refresh_weights: null pointer");
   if (!skip_wb16) RC(vdk_cast_f32_bf16(params, wb16, p.total, stream));
   char* xb = (char*)wx;
+  std::vector<VdkTcItem> jobs;      // the fc1^T (and head.fc^T) copies of all blocks in one launch
   for (int i = 0; i < 4; ++i) {
     const int C = d.C[i], M = 4 * C;
     if (i > 0) RC(vdk_conv2x2_weight_prep(params + p.st[i].ds_w, xb + x.dsw[i], xb + x.dswt[i], C, d.C[i - 1], stream));
     for (int j = 0; j < d.depth[i]; ++j) {
       const BlkP& b = p.st[i].blk[j]; const BlkX& bx = x.blk[i][j];
       RC(vdk_dwconv7_weight_prep(params + b.dw_w, (float*)(xb + bx.dwt), C, stream));
-      RC(vdk_transpose_cast_f32_bf16(params + b.fc1_w, C, M, C, xb + bx.fc1t, M, M, stream));
+      jobs.push_back(VdkTcItem{params + b.fc1_w, xb + bx.fc1t, C, M, C, M, M});
       RC(vdk_layerscale_weight_prep(params + b.fc2_w, params + b.fc2_b, params + b.gamma, xb + bx.fc2p, xb + bx.fc2pt, (float*)(xb + bx.b2p), C, M, stream));
     }
   }
-  if (d.ncls > 0) RC(vdk_transpose_cast_f32_bf16(params + p.fc_w, d.C[3], d.Cp, d.C[3], xb + x.fct, d.Cp, d.Cp, stream));
-  return VDK_OK;
+  if (d.ncls > 0) jobs.push_back(VdkTcItem{params + p.fc_w, xb + x.fct, d.C[3], d.Cp, d.C[3], d.Cp, d.Cp});
+  return vdk_transpose_cast_batch(jobs.data(), (int)jobs.size(), stream);
 }
 
 // x f32 [B, Cin, img, img] (NCHW, as the reference's dataloader hands it) -> out f32 [B * (img/32)^2, dims[3]]: the head-normed map in NHWC rows

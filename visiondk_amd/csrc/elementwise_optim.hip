@@ -81,6 +81,30 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
   }
 }
 
+// the same for a table of jobs passed by value (<= TC_MAX per launch): block -> job by a scan over the tile prefix sums
+#define TC_MAX 64
+struct TcTable { VdkTcItem it[TC_MAX]; int tile0[TC_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void transpose_cast_batch_kernel(TcTable t) {
+  __shared__ float tile[64][65];
+  int j = 0;
+  while (j + 1 < t.n && (int)blockIdx.x >= t.tile0[j + 1]) ++j;
+  const VdkTcItem& a = t.it[j];
+  const int local = blockIdx.x - t.tile0[j], ntr = (a.Rpad + 63) / 64;
+  const int r0 = (local % ntr) * 64, c0 = (local / ntr) * 64, tid = threadIdx.x;
+  const float* in = a.in; bf16_t* out = (bf16_t*)a.out;
+  for (int i = 0; i < 16; ++i) {
+    int row = i * 4 + (tid >> 6), col = tid & 63;
+    int gr = r0 + row, gc = c0 + col;
+    tile[row][col] = (gr < a.R && gc < a.C) ? in[(long)gr * a.ldi + gc] : 0.f;
+  }
+  __syncthreads();
+  for (int i = 0; i < 16; ++i) {
+    int col = i * 4 + (tid >> 6), row = tid & 63;
+    int gc = c0 + col, gr = r0 + row;
+    if (gc < a.C && gr < a.Rpad) out[(long)gc * a.ldo + gr] = f2bf(tile[row][col]);
+  }
+}
+
 // partial[b] = sum of g[i]^2 over the block's slice
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ partial) {
   __shared__ float red[4];
@@ -257,6 +281,24 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
       if (val) val[(long)row * k + j] = (j < C) ? ord2f((unsigned)(best >> 32)) : -3.4028234663852886e38f;
     }
   }
+}
+
+int vdk_transpose_cast_batch(const VdkTcItem* items, int n, void* stream) {
+  if (!items || n < 0) return vdk_fail(VDK_EINVAL, "vdk_transpose_cast_batch: bad argument");
+  for (int base = 0; base < n; base += TC_MAX) {
+    TcTable t;
+    t.n = n - base < TC_MAX ? n - base : TC_MAX;
+    int tiles = 0;
+    for (int j = 0; j < t.n; ++j) {
+      const VdkTcItem& a = items[base + j];
+      if (!a.in || !a.out || a.R <= 0 || a.C <= 0 || a.Rpad < a.R || a.ldo < a.Rpad) return vdk_fail(VDK_EINVAL, "vdk_transpose_cast_batch: bad item");
+      t.it[j] = a; t.tile0[j] = tiles;
+      tiles += ((a.Rpad + 63) / 64) * ((a.C + 63) / 64);
+    }
+    t.tile0[t.n] = tiles;
+    hipLaunchKernelGGL(transpose_cast_batch_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, t);
+  }
+  return vdk_check_launch("vdk_transpose_cast_batch");
 }
 
 extern "C" {

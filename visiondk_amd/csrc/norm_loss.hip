@@ -130,8 +130,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
-    pgamma[(long)blockIdx.x * C + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
-    pbeta[(long)blockIdx.x * C + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    // per-block partials side by side, [block][2C]: one reduction launch serves dgamma and dbeta when they are adjacent in the gradient buffer
+    pgamma[(long)blockIdx.x * 2 * C + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    pbeta[(long)blockIdx.x * 2 * C + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
   }
 }
 
@@ -424,7 +425,7 @@ int vdk_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const floa
   const int nb = ln_bwd_blocks(T);
   size_t need = (size_t)2 * nb * C * 4;
   if (!ws || ws_bytes < need) return vdk_fail(VDK_EWORKSPACE, "vdk_layernorm_bwd: workspace too small");
-  float* pg = (float*)ws; float* pb = pg + (size_t)nb * C;
+  float* pg = (float*)ws; float* pb = pg + C;          // rows of 2C: [dgamma partial | dbeta partial]
   const int rpb = (T + nb - 1) / nb;
   const bool bf = dy_dtype == VDK_BF16;
 #define LNB(MJ, BF) hipLaunchKernelGGL((ln_bwd_kernel<MJ, BF>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
@@ -432,10 +433,15 @@ int vdk_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const floa
   if (C <= 1024) { if (bf) LNB(4, true); else LNB(4, false); }
   else { if (bf) LNB(16, true); else LNB(16, false); }
 #undef LNB
-  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((C + 63) / 64)), dim3(512), 0, stream, (const float*)pg, (long)C, nb,
-                     (long)C, dgamma, 1.0f);
-  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((C + 63) / 64)), dim3(512), 0, stream, (const float*)pb, (long)C, nb,
-                     (long)C, dbeta, 1.0f);
+  if (dbeta == dgamma + C) {        // norm.weight / norm.bias of the flat gradient buffer (C % 64 == 0): one launch
+    hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((2 * C + 63) / 64)), dim3(512), 0, stream, (const float*)pg, (long)(2 * C), nb,
+                       (long)(2 * C), dgamma, 1.0f);
+  } else {
+    hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((C + 63) / 64)), dim3(512), 0, stream, (const float*)pg, (long)(2 * C), nb,
+                       (long)C, dgamma, 1.0f);
+    hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((C + 63) / 64)), dim3(512), 0, stream, (const float*)pb, (long)(2 * C), nb,
+                       (long)C, dbeta, 1.0f);
+  }
   return vdk_check_launch("vdk_layernorm_bwd");
 }
 

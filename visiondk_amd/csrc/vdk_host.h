@@ -9,3 +9,8 @@
 
 int vdk_fail(int code, const char* msg);
 int vdk_check_launch(const char* what);
+
+// In-library helper (C++ linkage, not part of the C ABI): many transpose + cast jobs (out[c][r] bf16 = in[r][c] f32, rows [R, Rpad) zero-filled) in ONE launch.
+// A weight refresh of a 12-layer ViT is 49 such jobs of ~10 us each; as separate launches they sit at the launch-latency floor.
+struct VdkTcItem { const float* in; void* out; int ldi, R, C, ldo, Rpad; };
+int vdk_transpose_cast_batch(const VdkTcItem* items, int n, void* stream);

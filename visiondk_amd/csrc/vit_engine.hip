@@ -316,14 +316,16 @@ int vdk_vit_refresh_weights(const VdkVitConfig* cfg, const float* params, void* 
   if (!params || !wb16 || !wt16) return vdk_fail(VDK_EINVAL, "vdk_vit_refresh_weights: null pointer");
   if (!skip_wb16) RC(vdk_cast_f32_bf16(params, wb16, p.total, stream));
   bf16_t* wt = (bf16_t*)wt16;
+  std::vector<VdkTcItem> jobs;      // every [in, out] transposed operand copy of the step in one launch (49 jobs for 12 layers)
+  auto add = [&](const float* in, int ldi, int R, int Cc, bf16_t* out, int ldo, int Rpad) { jobs.push_back(VdkTcItem{in, out, ldi, R, Cc, ldo, Rpad}); };
   for (int l = 0; l < d.L; ++l) {
-    RC(vdk_transpose_cast_f32_bf16(params + p.blk[l].qkv_w, d.D, 3 * d.D, d.D, wt + p.blkT[l].qkv, 3 * d.D, 3 * d.D, stream));
-    RC(vdk_transpose_cast_f32_bf16(params + p.blk[l].proj_w, d.D, d.D, d.D, wt + p.blkT[l].proj, d.D, d.D, stream));
-    RC(vdk_transpose_cast_f32_bf16(params + p.blk[l].fc1_w, d.D, d.M, d.D, wt + p.blkT[l].fc1, d.M, d.M, stream));
-    RC(vdk_transpose_cast_f32_bf16(params + p.blk[l].fc2_w, d.M, d.D, d.M, wt + p.blkT[l].fc2, d.D, d.D, stream));
+    add(params + p.blk[l].qkv_w, d.D, 3 * d.D, d.D, wt + p.blkT[l].qkv, 3 * d.D, 3 * d.D);
+    add(params + p.blk[l].proj_w, d.D, d.D, d.D, wt + p.blkT[l].proj, d.D, d.D);
+    add(params + p.blk[l].fc1_w, d.D, d.M, d.D, wt + p.blkT[l].fc1, d.M, d.M);
+    add(params + p.blk[l].fc2_w, d.M, d.D, d.M, wt + p.blkT[l].fc2, d.D, d.D);
   }
-  if (d.C > 0) RC(vdk_transpose_cast_f32_bf16(params + p.head_w, d.D, d.Cp, d.D, wt + p.headT, d.Cp, d.Cp, stream));
-  return VDK_OK;
+  if (d.C > 0) add(params + p.head_w, d.D, d.Cp, d.D, wt + p.headT, d.Cp, d.Cp);
+  return vdk_transpose_cast_batch(jobs.data(), (int)jobs.size(), stream);
 }
 
 // x: f32 [B, Cin, img, img] -> logits f32 [B, Cp] (columns C..Cp-1 are padding); feature mode (num_classes = 0): `logits`
