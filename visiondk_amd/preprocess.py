@@ -117,15 +117,18 @@ def create_AugTransforms(augments: List[dict], device=None, backend=None) -> Val
 
 
 def set_label_transforms(label, num_classes: int, label_smooth: float) -> torch.Tensor:
-    """dataset/basedataset.py:198-231 — the soft target vector the BCE / focal losses consume (`vdk_bce_logits` takes it as is):
-    one-hot rows from the csv are mapped y -> y * (1 - a) + a / 2; an int class index or a list of 0/1 flags becomes a vector filled with a / 2
-    whose positive entries hold 1 - a / 2."""
+    """Soft target vector for the BCE / focal losses (`vdk_bce_logits` consumes it as is); same contract as the reference's
+    ImageDatasets.set_label_transforms (dataset/basedataset.py:198-231): with a = label_smooth, negatives sit at a / 2 and positives at 1 - a / 2.
+    Accepted label forms: a one-hot / multi-hot float tensor of length num_classes (csv datasets), a class index, or a list of 0/1 flags."""
+    half = 0.5 * label_smooth
     if isinstance(label, torch.Tensor) and label.size(0) == num_classes:
-        return label * (1 - label_smooth) + (label_smooth * 0.5) if label_smooth > 0 else label
-    vector = torch.zeros(num_classes).fill_(0.5 * label_smooth)
+        return label if label_smooth <= 0 else label * (1 - label_smooth) + half
+    hot = torch.zeros(num_classes, dtype=torch.bool)
     if isinstance(label, int):
-        vector[label] = 1 - 0.5 * label_smooth
+        hot[label] = True
     elif isinstance(label, (list, tuple)):
-        indices = torch.nonzero(torch.tensor(label)).squeeze()
-        vector[indices] = 1 - 0.5 * label_smooth
-    return vector
+        flags = torch.as_tensor(label)
+        hot[: flags.numel()] = flags != 0
+    target = torch.full((num_classes,), half)
+    target[hot] = 1 - half
+    return target
