@@ -214,6 +214,9 @@ def search(extractor, query_dataloader, faiss_index: FlatIPIndex, device, logger
     if logger is not None:
         logger.console("Searching ...")
     all_s, all_i = [], []
+    # The reference walks over the queries in batches of `batch_size` (256) to bound faiss's temporary memory; every query's result is independent of the
+    # batching, and a 256-query launch leaves most of the GPU idle, so the device calls here take up to 16384 queries (one H2D / D2H per chunk).
+    batch_size = max(batch_size, 16384)
     for i in range(0, n, batch_size):
         q = query_embeddings[i:min(i + batch_size, n)]
         if isinstance(q, np.ndarray):
