@@ -99,7 +99,7 @@ def bench_cbir(dev, nq=10000, n=1_000_000, d=128, k=100, iters=3, with_cpu=True)
     index = cbir.FlatIPIndex(d, device=dev)
     index.add(gal)
     q_host = qry.cpu().numpy()
-    cbir.search(None, None, index, dev, None, k, 256, query_embeddings=q_host[:512])
+    cbir.search(None, None, index, dev, None, k, 256, query_embeddings=q_host)      # warm-up at the same size: the workspace is keyed on it
     torch.cuda.synchronize(); t0 = time.time()
     s_h, i_h = cbir.search(None, None, index, dev, None, k, 256, query_embeddings=q_host)
     host_ms = (time.time() - t0) * 1e3
