@@ -228,3 +228,49 @@ def test_two_rank_syncbn_equals_single_process(tmp_path, emu):
     assert rel(r0["buffers"], model.engine.buffers) < 1e-5
     assert rel(r0["params"] - r0["init"], model.engine.params - r0["init"]) < 2e-3
     assert rel(torch.cat([r0["loss"], r1["loss"]]), rows) < 1e-4
+
+
+# ---- ConvNeXt classifier (no BatchNorm): 2 ranks x half batch == 1 process x whole batch, SAM path included ------------------------------------------
+def _convnext_cls_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["VDK_EMU_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.emu.emu_backend import load_emu
+    from visiondk_amd import comm, convnext, resnet
+    be = load_emu()
+    spec = convnext.ConvNeXtSpec(img_size=32, depths=(1, 1, 1, 1), dims=(8, 16, 24, 32), num_classes=6)
+    out = {}
+    for sam in (False, True):
+        model = convnext.ConvNeXt(spec, device="cpu", backend=be, seed=70 + rank)
+        step = resnet.ClassifierTrainStep(model, lr=0.05, loss="ce", label_smoothing=0.05, ema=False, sam=sam, comm=comm.GradAllReduce(bucket_bytes=4_000))
+        init = model.engine.params.clone()
+        torch.manual_seed(9)
+        x = torch.randn(8, 3, 32, 32); t = torch.randint(0, 6, (8,))
+        step.step(x[rank * 4:rank * 4 + 4], t[rank * 4:rank * 4 + 4])
+        out[sam] = {"init": init, "params": model.engine.params.clone(), "grads": model.engine.grads.clone()}
+    torch.save(out, f"{out_dir}/cn{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_two_rank_convnext_classifier_step(tmp_path, emu):
+    port = 29500 + ((os.getpid() + 389) % 500)
+    mp.start_processes(_convnext_cls_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "cn0.pt"); r1 = torch.load(tmp_path / "cn1.pt")
+    from visiondk_amd import convnext, resnet
+    spec = convnext.ConvNeXtSpec(img_size=32, depths=(1, 1, 1, 1), dims=(8, 16, 24, 32), num_classes=6)
+    torch.manual_seed(9)
+    x = torch.randn(8, 3, 32, 32); t = torch.randint(0, 6, (8,))
+    for sam in (False, True):
+        a, b = r0[sam], r1[sam]
+        assert torch.equal(a["init"], b["init"]) and torch.equal(a["params"], b["params"]) and torch.equal(a["grads"], b["grads"])
+    # plain step: no BatchNorm, so two ranks x 4 samples == one process x 8 samples (mean loss over the global batch: the summed gradient is scaled by 1/world)
+    model = convnext.ConvNeXt(spec, device="cpu", backend=emu, seed=0)
+    with torch.no_grad():
+        model.engine.params.copy_(r0[False]["init"])
+    st = resnet.ClassifierTrainStep(model, lr=0.05, loss="ce", label_smoothing=0.05, ema=False)
+    st.step(x, t)
+    rel = ((model.engine.params - r0[False]["params"]).norm() / (model.engine.params - r0[False]["init"]).norm()).item()
+    assert rel < 2e-2, rel
