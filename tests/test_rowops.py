@@ -11,7 +11,7 @@ def _rel(a, b):
     return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 
 
-@pytest.mark.parametrize("T,C", [(10, 768), (7, 64), (33, 1024), (5, 1536)])
+@pytest.mark.parametrize("T,C", [(10, 768), (7, 64), (33, 1024), (5, 1536), (21, 128), (9, 96), (17, 256)])   # C <= 128: two rows per wave
 def test_layernorm_fwd_bwd(be, dev, T, C):
     torch.manual_seed(0)
     x = (torch.randn(T, C) * 2 + 0.5).to(dev)

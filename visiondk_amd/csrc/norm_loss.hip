@@ -53,6 +53,40 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
+// C <= 128: a row is at most 32 lanes x 4 floats, so a wave takes TWO rows (one per half) instead of idling half of its lanes; same arithmetic per row
+// (the half-wave butterfly adds the same 32 lane partials in the same order as the full-wave one does when lanes 32..63 hold zeros)
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void ln_fwd_narrow_kernel(const float* __restrict__ x, long ldx, int T, int C, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, void* __restrict__ y, long ldy, float* __restrict__ mean,
+                                                            float* __restrict__ rstd) {
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int l32 = threadIdx.x & 31, c = l32 * 4;
+  const bool on = row < T && c < C;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (on) v = *(const f32x4*)(x + (long)row * ldx + c);
+  float s = on ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  const float mu = s / (float)C;
+  float q = 0.f;
+  if (on) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { float d = v[e] - mu; q = fmaf(d, d, q); }
+  }
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+  const float rs = 1.0f / sqrtf(q / (float)C + eps);
+  if (row < T && l32 == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+  if (on) {
+    f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+    float o4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o4[e] = (v[e] - mu) * rs * g[e] + b[e];
+    if (OUT_BF16) *(u32x2*)((bf16_t*)y + (long)row * ldy + c) = (u32x2){pack_bf2(o4[0], o4[1]), pack_bf2(o4[2], o4[3])};
+    else *(f32x4*)((float*)y + (long)row * ldy + c) = (f32x4){o4[0], o4[1], o4[2], o4[3]};
+  }
+}
+
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ dres],  g = dy * gamma;  per-block partial
 // dgamma = sum dy * xhat, dbeta = sum dy.   MAXJ * 256 >= C.
 template <int MAXJ, bool DY_BF16>
@@ -387,7 +421,12 @@ int vdk_layernorm_fwd(const float* x, int64_t ldx, int32_t T, int32_t C, const f
 #define LNF(BF, MJ) hipLaunchKernelGGL((ln_fwd_kernel<BF, MJ>), grid, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta, eps, y, \
                                        (long)ldy, mean, rstd)
   const bool bf = y_dtype == VDK_BF16;
-  if (C <= 256) { if (bf) LNF(true, 1); else LNF(false, 1); }
+  if (C <= 128) {
+    const dim3 g8((unsigned)((T + 7) / 8));
+    if (bf) hipLaunchKernelGGL((ln_fwd_narrow_kernel<true>), g8, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta, eps, y, (long)ldy, mean, rstd);
+    else hipLaunchKernelGGL((ln_fwd_narrow_kernel<false>), g8, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta, eps, y, (long)ldy, mean, rstd);
+  }
+  else if (C <= 256) { if (bf) LNF(true, 1); else LNF(false, 1); }
   else if (C <= 1024) { if (bf) LNF(true, 4); else LNF(false, 4); }
   else { if (bf) LNF(true, 16); else LNF(false, 16); }
 #undef LNF
