@@ -220,10 +220,12 @@ def search(extractor, query_dataloader, faiss_index: FlatIPIndex, device, logger
     for i in range(0, n, batch_size):
         q = query_embeddings[i:min(i + batch_size, n)]
         if isinstance(q, np.ndarray):
-            q = q.astype(np.float32)
+            q = np.asarray(q, dtype=np.float32)          # no copy when the embeddings already are float32
         s, ind = faiss_index.search(q, k=k)
         all_s.append(s)
         all_i.append(ind)
+    if len(all_s) == 1:
+        return all_s[0], all_i[0]
     if isinstance(all_s[0], np.ndarray):
         return np.concatenate(all_s, 0), np.concatenate(all_i, 0)
     return torch.cat(all_s, 0), torch.cat(all_i, 0)
