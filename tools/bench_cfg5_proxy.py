@@ -1,0 +1,27 @@
+"""cfg5 (stretch) is SigLIP-class ViT-L/14 @336 with Mixup + SAM on fp8 MFMA, global batch 1024.  What the engine runs today of that recipe:
+ViT-L/16 @224 (timm `vit_large_patch16_224`, one of pet.yaml's listed models) in bf16 with the same training protocol -- a Mixup pair every step and
+Trainer.update_sam (two forward-backward passes) -- so the number below is a PROXY with the differences named: patch 16 instead of 14, 224 instead of 336
+(197 instead of 576 tokens), cls token + linear head instead of a MAP head, bf16 instead of fp8.  usage: python tools/bench_cfg5_proxy.py [batch] [steps]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from visiondk_amd import vit
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = torch.device("cuda:0")
+model = vit.create_model("vit_large_patch16_224", num_classes=1000, device=dev)
+out = {"workload": f"cfg5 proxy: ViT-L/16 @224 bf16, bs {B}, Mixup pair + SAM (2 fwd/bwd per step), CE label smoothing 0.05, SGD + EMA"}
+x = torch.randn(B, 3, 224, 224, device=dev); ya = torch.randint(0, 1000, (B,), device=dev); yb = torch.randint(0, 1000, (B,), device=dev)
+flop_img = 3 * 2 * (304.3e6 * 197 + 24 * 2 * 197 * 197 * 1024)      # fwd+bwd, 2*MACs: Linear layers (304 M weights x tokens) + attention
+for sam in (False, True):
+    step = vit.FusedTrainStep(model, lr=0.006, momentum=0.937, weight_decay=5e-4, label_smoothing=0.05, max_norm=10.0, ema=True, sam=sam)
+    for _ in range(2): step.step(x, ya, yb, 0.4)
+    torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(steps): step.step(x, ya, yb, 0.4)
+    torch.cuda.synchronize(); dt = (time.time() - t0) / steps
+    key = "sam" if sam else "plain"
+    out[f"{key}_images_per_sec"] = B / dt; out[f"{key}_ms_per_step"] = dt * 1e3
+    out[f"{key}_model_tflops"] = flop_img * B * (2 if sam else 1) / dt / 1e12
+out["max_mem_gib"] = torch.cuda.max_memory_allocated() / 2**30
+print(json.dumps(out))
