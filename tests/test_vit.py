@@ -173,3 +173,29 @@ def test_backward_bias_gradients_from_dgrad_gemm_byproduct(be, dev):
         a, b = grads[2][off:off + numel], grads[1][off:off + numel]
         rel = ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
         assert rel < (2e-3 if name.endswith("bias") else 2e-2), (name, rel)
+
+
+def test_patch14_padded_operand_copies_vs_oracle(be, dev):
+    """timm's patch-14 models (vit_large_patch14_224, pet.yaml's *_patch14_* ids): in_chans * 14 * 14 = 588 is not a multiple of 8, so the patch-embedding GEMM
+    reads zero-padded copies ([D, 592] weight, [rows, 592] patches) while the parameter and its gradient keep their [D, 3, 14, 14] shape."""
+    spec = vit.VitSpec(img_size=42, patch_size=14, in_chans=3, num_classes=7, dim=64, depth=1, heads=1, mlp_dim=128, ln_eps=1e-6)
+    torch.manual_seed(2)
+    ref = VisionTransformerRef(spec.img_size, spec.patch_size, 3, spec.num_classes, spec.dim, spec.depth, spec.heads, spec.mlp_dim)
+    with torch.no_grad():
+        ref.patch_embed.proj.weight.mul_(3.0)
+        for n, p in ref.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.05)
+    model = vit.VisionTransformer(spec, device=dev, backend=be, seed=1)
+    model.load_state_dict(ref.state_dict())
+    assert tuple(model.state_dict()["patch_embed.proj.weight"].shape) == (64, 3, 14, 14)
+    x = torch.randn(3, 3, 42, 42); y = torch.randint(0, 7, (3,))
+    lr_ = torch.nn.functional.cross_entropy(ref(x), y); lr_.backward()
+    logits = model(x.to(dev))
+    loss = torch.nn.functional.cross_entropy(logits, y.to(dev)); loss.backward()
+    assert abs(loss.item() - lr_.item()) < 1e-2 * abs(lr_.item())
+    for (n, p), (nr, pr) in zip(model.named_parameters(), ref.named_parameters()):
+        assert n == nr and p.grad.shape == pr.grad.shape
+        assert _rel(p.grad, pr.grad) < 6e-2, (n, _rel(p.grad, pr.grad))
+    with pytest.raises(Exception):
+        model.forward_precise(x.to(dev))        # the fp32-MFMA path keeps the K % 8 requirement

@@ -105,6 +105,13 @@ __global__ __launch_bounds__(256) void transpose_cast_batch_kernel(TcTable t) {
   }
 }
 
+__global__ __launch_bounds__(256) void cast_pad_rows_kernel(const float* __restrict__ in, long ldi, int R, int Cc, bf16_t* __restrict__ out, long ldo) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)R * ldo) return;
+  const int c = (int)(i % ldo);
+  const long r = i / ldo;
+  out[i] = f2bf(c < Cc ? in[r * ldi + c] : 0.f);
+}
 // partial[b] = sum of g[i]^2 over the block's slice
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ partial) {
   __shared__ float red[4];
@@ -299,6 +306,13 @@ int vdk_transpose_cast_batch(const VdkTcItem* items, int n, void* stream) {
     hipLaunchKernelGGL(transpose_cast_batch_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, t);
   }
   return vdk_check_launch("vdk_transpose_cast_batch");
+}
+
+int vdk_cast_pad_rows(const float* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, void* stream) {
+  if (!in || !out || R <= 0 || C <= 0 || ldo < C || ldi < C) return vdk_fail(VDK_EINVAL, "vdk_cast_pad_rows: bad argument");
+  hipLaunchKernelGGL(cast_pad_rows_kernel, dim3((unsigned)(((long)R * ldo + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, (long)ldi, (int)R, (int)C, (bf16_t*)out,
+                     (long)ldo);
+  return vdk_check_launch("vdk_cast_pad_rows");
 }
 
 extern "C" {

@@ -14,3 +14,5 @@ int vdk_check_launch(const char* what);
 // A weight refresh of a 12-layer ViT is 49 such jobs of ~10 us each; as separate launches they sit at the launch-latency floor.
 struct VdkTcItem { const float* in; void* out; int ldi, R, C, ldo, Rpad; };
 int vdk_transpose_cast_batch(const VdkTcItem* items, int n, void* stream);
+// out bf16 [R, ldo] = in f32 [R, C] (row stride ldi) with the columns [C, ldo) zero-filled (operand copies of weights whose row length is not a multiple of 8)
+int vdk_cast_pad_rows(const float* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, void* stream);

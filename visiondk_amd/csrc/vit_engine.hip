@@ -43,7 +43,7 @@ int vdk_patchify_f32(const float*, int32_t, int32_t, int32_t, int32_t, int32_t, 
 static inline int64_t up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 struct VitDims {
-  int B, img, ps, Cin, D, L, H, M, C, Cp, np, N, T, Kpe, Tp, Bp;
+  int B, img, ps, Cin, D, L, H, M, C, Cp, np, N, T, Kraw, Kpe, Tp, Bp;   // Kraw = in_chans * patch^2, Kpe = Kraw padded to 8 (patch 14: 588 -> 592)
   float eps;
 };
 static int vit_dims(const VdkVitConfig* c, VitDims* d) {
@@ -54,8 +54,8 @@ static int vit_dims(const VdkVitConfig* c, VitDims* d) {
     return vdk_fail(VDK_EINVAL, "vit: bad config value");
   if (d->D != d->H * 64) return vdk_fail(VDK_EUNSUPPORTED, "vit: head_dim must be 64 (dim == 64 * heads)");
   if ((d->D & 7) || (d->M & 7)) return vdk_fail(VDK_EUNSUPPORTED, "vit: dim and mlp_dim must be multiples of 8");
-  d->Kpe = d->Cin * d->ps * d->ps;
-  if (d->Kpe & 7) return vdk_fail(VDK_EUNSUPPORTED, "vit: in_chans*patch*patch must be a multiple of 8");
+  d->Kraw = d->Cin * d->ps * d->ps;
+  d->Kpe = (int)up(d->Kraw, 8);     // patch 14 (timm vit_*_patch14_*: K = 588): the GEMM operands are zero-padded copies, the parameter itself stays [D, Kraw]
   d->np = (d->img / d->ps) * (d->img / d->ps);
   d->N = d->np + 1;
   d->T = d->B * d->N;
@@ -82,7 +82,7 @@ static int vit_layout(const VitDims& d, PLayout* p) {
   int64_t cur = 0;
   p->cls = p_take(cur, d.D);
   p->pos = p_take(cur, (int64_t)d.N * d.D);
-  p->pe_w = p_take(cur, (int64_t)d.D * d.Kpe);
+  p->pe_w = p_take(cur, (int64_t)d.D * d.Kraw);
   p->pe_b = p_take(cur, d.D);
   for (int l = 0; l < d.L; ++l) {
     PLayout::Blk& b = p->blk[l];
@@ -162,6 +162,7 @@ static int vit_entry(const VitDims& d, const PLayout& p, int idx, PEntry* e) {
 struct WsPlan {
   size_t total;
   size_t patches;            // bf16 [B*np, Kpe]
+  size_t pepad, dwpe;        // Kraw != Kpe only: bf16 [D, Kpe] zero-padded copy of patch_embed.proj.weight, f32 [D, Kpe] its padded gradient
   size_t X;                  // fp32 (2L+1) x [T, D]  : X[2l] block input, X[2l+1] after attention, X[2L] output
   size_t stats;              // fp32 L x 4 x [T] (mean1, rstd1, mean2, rstd2) + 2 x [B]
   size_t h1, qkv, lse, o, h2, u, g;   // per-layer strides below
@@ -204,6 +205,8 @@ static int vit_plan(const VitDims& d, WsPlan* w) {
   size_t cur = 0;
   const size_t T = d.T, D = d.D, M = d.M, L = d.L;
   w->patches = w_take(cur, (size_t)d.B * d.np * d.Kpe * 2);
+  w->pepad = w->dwpe = 0;
+  if (d.Kraw != d.Kpe) { w->pepad = w_take(cur, D * d.Kpe * 2); w->dwpe = w_take(cur, D * d.Kpe * 4); }
   w->X = w_take(cur, (2 * L + 1) * T * D * 4);
   w->stats = w_take(cur, (L * 4 * T + 2 * T) * 4);   // + final norm: B rows (token pooling) or all T rows (feature mode)
   w->s_h = T * D * 2; w->s_qkv = T * 3 * D * 2; w->s_lse = (size_t)d.B * d.H * d.N * 4; w->s_u = T * M * 2;
@@ -348,7 +351,12 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
   // patch embedding: im2col-free operand + GEMM whose epilogue drops each patch row at its token slot and adds pos_embed
   bf16_t* patches = (bf16_t*)(base + w.patches);
   RC(vdk_patchify_bf16(x, d.B, d.Cin, d.img, d.img, d.ps, patches, d.Kpe, s));
-  RC(gemm(s, patches, d.Kpe, wb + p.pe_w, d.Kpe, X, D, d.B * d.np, D, d.Kpe, VDK_F32, params + p.pe_b, params + p.pos, D, VDK_ACT_NONE,
+  const bf16_t* pew = wb + p.pe_w;
+  if (d.Kraw != d.Kpe) {           // rows of 588 bf16 are not 16-byte aligned: the GEMM reads a zero-padded [D, Kpe] copy rebuilt from the master weights
+    RC(vdk_cast_pad_rows(params + p.pe_w, d.Kraw, D, d.Kraw, base + w.pepad, d.Kpe, s));
+    pew = (const bf16_t*)(base + w.pepad);
+  }
+  RC(gemm(s, patches, d.Kpe, pew, d.Kpe, X, D, d.B * d.np, D, d.Kpe, VDK_F32, params + p.pe_b, params + p.pos, D, VDK_ACT_NONE,
           nullptr, 0, 1, d.np, nullptr, 0));
   RC(vdk_cls_rows(X, (int64_t)d.N * D, d.B, D, params + p.cls, params + p.pos, s));
 
@@ -551,7 +559,10 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
     bf16_t* patches = (bf16_t*)(base + w.patches);
     const int rows = d.B * d.np, rows_pad = (int)up(rows, 64);
     RC(ev_order(ev_p++, s, s2));
-    RC(linear_wgrad(s2, d, w, base, DXAB(-1), D, patches, d.Kpe, rows, rows_pad, D, d.Kpe, grads + p.pe_w, nullptr, d.np));
+    float* dwpe = d.Kraw != d.Kpe ? (float*)(base + w.dwpe) : grads + p.pe_w;
+    RC(linear_wgrad(s2, d, w, base, DXAB(-1), D, patches, d.Kpe, rows, rows_pad, D, d.Kpe, dwpe, nullptr, d.np));
+    if (d.Kraw != d.Kpe && hipMemcpy2DAsync(grads + p.pe_w, (size_t)d.Kraw * 4, dwpe, (size_t)d.Kpe * 4, (size_t)d.Kraw * 4, D, hipMemcpyDeviceToDevice, s2) != hipSuccess)
+      return vdk_fail(VDK_ELAUNCH, "vdk_vit_backward: memcpy2d failed");   // drop the padding columns
     RC(ev_order(ev_p++, s2, s));      // join: everything the side stream produced is ordered before what follows on the main stream
     if (on_ready) on_ready(user, 0, p.blk[0].n1w);
   }
@@ -603,6 +614,7 @@ int vdk_vit_workspace_f32_bytes(const VdkVitConfig* cfg, size_t* bytes) {
 int vdk_vit_forward_f32(const VdkVitConfig* cfg, const float* x, const float* params, void* ws, size_t ws_bytes, float* logits, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   VitDims d; RC(vit_dims(cfg, &d));
+  if (d.Kraw != d.Kpe) return vdk_fail(VDK_EUNSUPPORTED, "vdk_vit_forward_f32: in_chans*patch*patch must be a multiple of 8 on the fp32 path");
   PLayout p; RC(vit_layout(d, &p));
   WsF32 w; vit_plan_f32(d, &w);
   if (!x || !params || !ws || !logits) return vdk_fail(VDK_EINVAL, "vdk_vit_forward_f32: null pointer");

@@ -36,7 +36,7 @@ class VitSpec:
     ln_eps: float = 1e-6
 
 
-# timm 0.9.16 model ids the engine covers (head_dim 64, patch*patch*3 % 8 == 0)
+# timm 0.9.16 model ids the engine covers (head_dim 64; patch 14 works through zero-padded operand copies of the patch-embedding weight)
 TIMM_VITS = {
     "vit_tiny_patch16_224": dict(dim=192, depth=12, heads=3, mlp_dim=768),
     "vit_small_patch16_224": dict(dim=384, depth=12, heads=6, mlp_dim=1536),
@@ -44,6 +44,7 @@ TIMM_VITS = {
     "vit_base_patch32_224": dict(dim=768, depth=12, heads=12, mlp_dim=3072, patch_size=32),
     "vit_large_patch16_224": dict(dim=1024, depth=24, heads=16, mlp_dim=4096),
     "vit_base_patch16_384": dict(dim=768, depth=12, heads=12, mlp_dim=3072, img_size=384),
+    "vit_large_patch14_224": dict(dim=1024, depth=24, heads=16, mlp_dim=4096, patch_size=14),
 }
 
 
