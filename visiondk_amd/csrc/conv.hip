@@ -394,7 +394,7 @@ int vdk_dwconv7_fwd(const float* in, const float* wt, const float* bias, const f
 #define DW_ROWS(WW, CCC)                                                                                                                             \
   hipLaunchKernelGGL((dwconv7_rows_kernel<WW, CCC>), dim3(dw_rows_grid(B, (C + CCC - 1) / CCC)), dim3(WW * (CCC / 4)), 0, (hipStream_t)stream, in, wt, bias, \
                      res, out, (bf16_t*)out_bf16, (int)B, (int)C, (int)flip)
-  if (H == W && W == 56) DW_ROWS(56, 16);
+  if (H == W && W == 56) DW_ROWS(56, 32);      // 32 channels = one 128-byte line per pixel (with 16 the two halves of a line went to different XCDs: 669 -> 640 us)
   else if (H == W && W == 28) DW_ROWS(28, 32);
   else if (H == W && W == 14) DW_ROWS(14, 64);
   else if (H == W && W == 7) DW_ROWS(7, 128);
