@@ -123,6 +123,8 @@ def test_vision_wrapper_routes_convnext_classifier(be, dev, monkeypatch):
     wrap = face.VisionWrapper(cfg, None, 0, backend=be, device=dev)
     y = wrap.model(torch.randn(2, 3, 32, 32).to(dev))
     assert y.shape == (2, 4) and "head.fc.weight" in wrap.model.state_dict()
+    with pytest.raises(NotImplementedError):       # options of the reference's model config that are not built fail loudly instead of being ignored
+        face.VisionWrapper(dict(cfg, backbone_freeze=True), None, 0, backend=be, device=dev)
 
 
 def test_classifier_sam_and_mixup_step_match_reference_sequence(be, dev):

@@ -326,6 +326,9 @@ class VisionWrapper:
         name = model_cfg["name"]
         assert name.startswith("timm-"), "classifier id must look like timm-<timm model id>"
         kwargs = model_cfg.get("kwargs") or {}
+        for opt in ("backbone_freeze", "bn_freeze", "bn_freeze_affine", "attention_pool"):   # classify_model.py:16-33: accepted keys; only the defaults are built
+            if model_cfg.get(opt, False):
+                raise NotImplementedError(f"model.{opt}=True is not built on the HIP engines (the flat optimizer updates every parameter; no pooler swap)")
         arch = name[5:].split(".")[0]
         # timm-resnet18 | timm-convnext_* (pet.yaml:21-22) | timm-vit_*
         factory = resnet.create_model if arch in resnet.TIMM_RESNETS else (convnext.create_model if arch in convnext.TIMM_CONVNEXTS else vit.create_model)
