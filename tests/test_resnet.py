@@ -217,3 +217,21 @@ def test_sam_step_freezes_running_statistics_in_the_second_pass(be, dev):
     bce = torch.nn.functional.binary_cross_entropy_with_logits
     exp = 0.25 * bce(out, ya) + 0.75 * bce(out, yb)
     assert abs(res[False][2].sum().item() / 40 - exp.item()) < 3e-2 * abs(exp.item())
+
+
+def test_focal_switch_uses_the_reference_focal_loss(be, dev):
+    """set_focal(gamma, alpha): loss = alpha_t * (1 - p_t)^gamma * BCE (models/losses/loss.py:27-54,75), mean over B * C"""
+    model, ref = _pair(be, dev, widths=(8, 8, 16, 16), depths=(1, 1, 1, 1), img=32)
+    step = resnet.ResNetTrainStep(model, lr=0.0, momentum=0.0, weight_decay=0.0, loss="bce", ema=False)
+    step.set_focal(2.0, 0.25)
+    torch.manual_seed(4)
+    x = torch.randn(6, 3, 32, 32); t = (torch.rand(6, 5) > 0.5).float()
+    rows = step.step(x.to(dev), t.to(dev))
+    ref.train()
+    out = ref(x)
+    p = torch.sigmoid(out)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(out, t, reduction="none")
+    pt = t * p + (1 - t) * (1 - p)
+    at = t * 0.25 + (1 - t) * 0.75
+    exp = (at * (1 - pt) ** 2.0 * bce).mean()
+    assert abs(rows.sum().item() / 30 - exp.item()) < 4e-2 * abs(exp.item())

@@ -298,6 +298,7 @@ class ResNetTrainStep:
         if graph and comm is not None and comm.world_size > 1:
             raise NotImplementedError("graph capture of the data-parallel step (host callbacks issue the collectives) is not built")
         self.graph = graph
+        self.focal_gamma, self.focal_alpha = 0.0, 0.25          # set_focal(): the reference switches BCE -> focal at `strategy.focal[0]` epochs (vision_engine.py:160,367-368)
         self.sam, self.sam_rho, self.sam_adaptive = sam, sam_rho, sam_adaptive
         self._old_params = torch.empty_like(self.eng.params) if sam else None
         self._graphs = {}                       # (B, y shape/dtype) -> (CUDAGraph, static x, static y)
@@ -309,6 +310,14 @@ class ResNetTrainStep:
             dist.broadcast(self.eng.buffers, src=0, group=comm.group)
             if ema:
                 self.ema.copy_(self.eng.params)
+
+    def set_focal(self, gamma: float = 2.0, alpha: float = 0.25) -> None:
+        """Trainer's focal switch (engine/vision_engine.py:367-368): from now on the BCE loss is the reference's focal loss (models/losses/loss.py:27-54,75);
+        gamma = 0 switches back.  A captured graph holds the old values by value: graphs are dropped."""
+        if self.loss != "bce":
+            raise ValueError("the reference's focal loss replaces the BCE loss (multi-label datasets)")
+        self.focal_gamma, self.focal_alpha = float(gamma), float(alpha)
+        self._graphs = {}
 
     def _dl_rows(self, B: int) -> int:
         return self.eng.dlogits_rows(B) if hasattr(self.eng, "dlogits_rows") else B
@@ -389,7 +398,7 @@ class ResNetTrainStep:
             kw = {} if bn_momentum is None else {"bn_momentum": bn_momentum}
             logits = eng.forward(x, True, sync_group=self.sync_group, **kw)
             if self.loss == "bce":
-                be.check(be.lib.vdk_bce_logits(be.ptr(logits), eng.cp, be.ptr(y), y.stride(0), B, ncls, 1.0 / (B * ncls), 0.0, 0.25, be.ptr(self.loss_rows),
+                be.check(be.lib.vdk_bce_logits(be.ptr(logits), eng.cp, be.ptr(y), y.stride(0), B, ncls, 1.0 / (B * ncls), self.focal_gamma, self.focal_alpha, be.ptr(self.loss_rows),
                                                be.ptr(self._dl), eng.cp, None, 0, be.stream()), "vdk_bce_logits")
             else:
                 be.check(be.lib.vdk_softmax_ce(be.ptr(logits), eng.cp, B, ncls, be.ptr(y), be.ptr(y_b), lam, self.label_smoothing, 1.0 / B, be.ptr(self.loss_rows),
