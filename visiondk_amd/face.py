@@ -326,7 +326,9 @@ class VisionWrapper:
         name = model_cfg["name"]
         assert name.startswith("timm-"), "classifier id must look like timm-<timm model id>"
         kwargs = model_cfg.get("kwargs") or {}
-        for opt in ("backbone_freeze", "bn_freeze", "bn_freeze_affine", "attention_pool"):   # classify_model.py:16-33: accepted keys; only the defaults are built
+        # classify_model.py:16-33,60-66: accepted keys.  In the reference backbone_freeze / bn_freeze call self.freeze_*() from inside create_model, before
+        # self.model exists (AttributeError), so only their defaults are live configurations; attention_pool swaps timm's pooler (built/attention_based_pooler.py)
+        for opt in ("backbone_freeze", "bn_freeze", "bn_freeze_affine", "attention_pool"):
             if model_cfg.get(opt, False):
                 raise NotImplementedError(f"model.{opt}=True is not built on the HIP engines (the flat optimizer updates every parameter; no pooler swap)")
         arch = name[5:].split(".")[0]
