@@ -330,7 +330,7 @@ class VisionWrapper:
         # self.model exists (AttributeError), so only their defaults are live configurations; attention_pool swaps timm's pooler (built/attention_based_pooler.py)
         for opt in ("backbone_freeze", "bn_freeze", "bn_freeze_affine", "attention_pool"):
             if model_cfg.get(opt, False):
-                raise NotImplementedError(f"model.{opt}=True is not built on the HIP engines (the flat optimizer updates every parameter; no pooler swap)")
+                raise NotImplementedError(f"model.{opt}=True is not built on the HIP engines (it raises AttributeError in the reference as well)")
         arch = name[5:].split(".")[0]
         # timm-resnet18 | timm-convnext_* (pet.yaml:21-22) | timm-vit_*
         factory = resnet.create_model if arch in resnet.TIMM_RESNETS else (convnext.create_model if arch in convnext.TIMM_CONVNEXTS else vit.create_model)
