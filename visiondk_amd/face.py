@@ -327,8 +327,9 @@ class VisionWrapper:
         assert name.startswith("timm-"), "classifier id must look like timm-<timm model id>"
         kwargs = model_cfg.get("kwargs") or {}
         # classify_model.py:16-33,60-66: accepted keys.  In the reference backbone_freeze / bn_freeze call self.freeze_*() from inside create_model, before
-        # self.model exists (AttributeError), so only their defaults are live configurations; attention_pool swaps timm's pooler (built/attention_based_pooler.py)
-        for opt in ("backbone_freeze", "bn_freeze", "bn_freeze_affine", "attention_pool"):
+        # self.model exists (AttributeError), so only their defaults are live configurations.  attention_pool=True is a no-op there (atten_pool_replace
+        # returns the model unchanged, built/attention_based_pooler.py:30-47) and is accepted as such here.
+        for opt in ("backbone_freeze", "bn_freeze", "bn_freeze_affine"):
             if model_cfg.get(opt, False):
                 raise NotImplementedError(f"model.{opt}=True is not built on the HIP engines (it raises AttributeError in the reference as well)")
         arch = name[5:].split(".")[0]
