@@ -235,3 +235,15 @@ def test_focal_switch_uses_the_reference_focal_loss(be, dev):
     at = t * 0.25 + (1 - t) * 0.75
     exp = (at * (1 - pt) ** 2.0 * bce).mean()
     assert abs(rows.sum().item() / 30 - exp.item()) < 4e-2 * abs(exp.item())
+
+
+def test_ohem_prepass_cnn_step(be, dev):
+    model, ref = _pair(be, dev, widths=(8, 8, 16, 16), depths=(1, 1, 1, 1), img=32)
+    step = resnet.ResNetTrainStep(model, lr=0.01, loss="ce", ema=False)
+    torch.manual_seed(12)
+    x = torch.randn(10, 3, 32, 32); y = torch.randint(0, 5, (10,))
+    before = model.engine.buffers.clone()
+    xs, ys = step.ohem_select(x.to(dev), y.to(dev), 3, 0.1)
+    assert 0 < xs.shape[0] <= 10 and not torch.equal(before, model.engine.buffers)      # the pre-pass runs in training mode, as in the reference
+    rows = step.step(xs, ys)
+    assert rows.shape[0] == xs.shape[0] and torch.isfinite(rows).all()

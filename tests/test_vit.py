@@ -199,3 +199,27 @@ def test_patch14_padded_operand_copies_vs_oracle(be, dev):
         assert _rel(p.grad, pr.grad) < 6e-2, (n, _rel(p.grad, pr.grad))
     with pytest.raises(Exception):
         model.forward_precise(x.to(dev))        # the fp32-MFMA path keeps the K % 8 requirement
+
+
+def test_ohem_prepass_then_step_on_the_kept_samples(be, dev):
+    """train.py:113-117: valid = sampler.sample(model(images), labels); images, labels = images[valid], labels[valid]; then the ordinary step on the subset"""
+    ref, model = _pair(be, dev)
+    step = vit.FusedTrainStep(model, lr=0.01, momentum=0.9, weight_decay=5e-4, label_smoothing=0.0, ema=False)
+    torch.manual_seed(11)
+    x = torch.randn(12, 3, 32, 32); y = torch.randint(0, 10, (12,))
+    with torch.no_grad():
+        prob = torch.softmax(ref(x), 1)
+    tp = prob.gather(1, y.unsqueeze(1)).squeeze(1)
+    sp, si = tp.sort()
+    min_kept, thresh = 5, 0.05
+    thr = max(sp[min(min_kept, sp.numel() - 1)].item(), thresh)
+    keep_ref = torch.zeros(12, dtype=torch.bool); keep_ref[si[sp < thr]] = True
+    xs, ys = step.ohem_select(x.to(dev), y.to(dev), min_kept, thresh)
+    margin = (tp - thr).abs().min().item()
+    if margin > 2e-3:                                     # bf16 logits: only compare when no sample sits on the threshold
+        assert torch.equal(ys.cpu(), y[keep_ref]) and xs.shape[0] == int(keep_ref.sum())
+    assert 0 < xs.shape[0] < 12
+    rows = step.step(xs, ys)                              # a batch size the engine has not seen: the workspace is reused (grow-only)
+    assert rows.shape[0] == xs.shape[0] and torch.isfinite(rows).all()
+    rows2 = step.step(x.to(dev), y.to(dev))
+    assert rows2.shape[0] == 12

@@ -87,8 +87,9 @@ class ConvNeXtEngine:
             self._ws_img = img
             self.out_hw = img // 32
             self.be.check(self.be.lib.vdk_convnext_workspace_bytes(C.byref(cfg), C.byref(need)), "vdk_convnext_workspace_bytes")
-            self._ws = None
-            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+            if self._ws is None or self._ws.numel() < need.value:      # grow-only (OHEM: a different batch size every iteration)
+                self._ws = None
+                self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
             self._ws_batch = batch
             if self.spec.num_classes > 0:
                 self._out = torch.empty((batch, self.cp), dtype=torch.float32, device=self.device)

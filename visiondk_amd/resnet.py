@@ -76,8 +76,9 @@ class ResNetEngine:
             need = C.c_size_t(0)
             cfg = self._cfg(batch, img)
             self.be.check(self.be.lib.vdk_resnet_workspace_bytes(C.byref(cfg), C.byref(need)), "vdk_resnet_workspace_bytes")
-            self._ws = None
-            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+            if self._ws is None or self._ws.numel() < need.value:      # grow-only (OHEM: a different batch size every iteration)
+                self._ws = None
+                self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
             self._ws_batch = (batch, img)
             self._logits = torch.empty((batch, self.cp), dtype=torch.float32, device=self.device)
         return self._ws
@@ -318,6 +319,21 @@ class ResNetTrainStep:
             raise ValueError("the reference's focal loss replaces the BCE loss (multi-label datasets)")
         self.focal_gamma, self.focal_alpha = float(gamma), float(alpha)
         self._graphs = {}
+
+    def ohem_select(self, x: torch.Tensor, y: torch.Tensor, min_kept: int, thresh: float, ignore_index: int = 255):
+        """OHEM-Softmax pre-pass (engine/procedure/train.py:113-117, structure/sampler.py:11-31): one extra no-grad forward in TRAINING mode, as the reference
+        runs it (BatchNorm running statistics move), keep the samples whose target probability is below max(thresh, the min_kept-th smallest).
+        Single-label (class-index) targets only, like the sampler's `gather`."""
+        from . import ops
+        self.model._sync_flat()
+        self.model.train()
+        for m in self.model.modules():
+            if "num_batches_tracked" in m._buffers:
+                m._buffers["num_batches_tracked"] += 1
+        logits = self.eng.forward(x, True, sync_group=self.sync_group)
+        mask = ops.ohem_mask(logits[:, :self.eng.spec.num_classes].contiguous(), y, min_kept, thresh, ignore_index, backend=self.be)
+        keep = mask.nonzero().squeeze(1)
+        return x[keep].contiguous(), y[keep].contiguous()
 
     def _dl_rows(self, B: int) -> int:
         return self.eng.dlogits_rows(B) if hasattr(self.eng, "dlogits_rows") else B

@@ -119,8 +119,9 @@ class VitEngine:
             need = C.c_size_t(0)
             cfg = self._cfg(batch)
             self.be.check(self.be.lib.vdk_vit_workspace_bytes(C.byref(cfg), C.byref(need)), "vdk_vit_workspace_bytes")
-            self._ws = None
-            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+            if self._ws is None or self._ws.numel() < need.value:      # grow-only: OHEM hands the step a different (smaller) batch every iteration
+                self._ws = None
+                self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
             self._ws_batch = batch
             shape = (batch, self.cp) if self.cp else (batch * self.tokens, self.spec.dim)   # logits | final-normed tokens
             self._logits = torch.empty(shape, dtype=torch.float32, device=self.device)
@@ -388,6 +389,17 @@ class FusedTrainStep:
             self.comm.finish_step()
         else:
             eng.backward(self._dl)
+
+    def ohem_select(self, x: torch.Tensor, y: torch.Tensor, min_kept: int, thresh: float, ignore_index: int = 255):
+        """OHEM-Softmax pre-pass of the reference's loop (engine/procedure/train.py:113-117, structure/sampler.py:11-31): one extra no-grad forward in
+        training mode, keep the samples whose target probability is below max(thresh, the min_kept-th smallest); returns the kept (images, labels).
+        The batch that reaches step() then changes size from iteration to iteration (workspaces only grow)."""
+        from . import ops
+        self.model._sync_flat()
+        logits = self.eng.forward(x)
+        mask = ops.ohem_mask(logits[:, :self.eng.spec.num_classes].contiguous(), y, min_kept, thresh, ignore_index, backend=self.be)
+        keep = mask.nonzero().squeeze(1)          # the one host sync boolean indexing costs in the reference too
+        return x[keep].contiguous(), y[keep].contiguous()
 
     def step(self, x: torch.Tensor, y: torch.Tensor, y_b: Optional[torch.Tensor] = None, lam: float = 1.0) -> torch.Tensor:
         eng, be = self.eng, self.be
