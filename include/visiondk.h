@@ -445,6 +445,16 @@ int vdk_rownorm_bwd(const float* fh, const float* inv, const float* dfh, int64_t
 int vdk_margin_ce(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t C, const int64_t* labels, float label_smoothing,
                   float grad_scale, float* logits, int64_t ldl, float* loss_rows, void* dcos_bf16, int64_t lddc, void* stream);
 /* backward of the logits-returning form: dcos bf16 = dlogits * d(logit)/d(cos) */
+/* Class-sharded margin head for data-parallel training with a large identity count (instead of all-reducing the [D, C] head gradient --
+ * 2 GB at C = 10^6 -- every rank keeps a column shard of the head, the features are all-gathered and only per-row scalars and the [B, D] feature gradient
+ * cross the links).  The fused vdk_margin_ce splits into three local passes around the collectives: target cosine (SUM), per-row statistics
+ * (max, sum exp(. - max), sum logit, target logit: MAX / rescaled SUM / SUM / SUM), gradient with the global max and sum.  cosv is the shard's [B, Cloc] block,
+ * global column = c_base + local column; same margins as arcface.py / circleloss.py / mv_softmax.py (see vdk_margin_ce). */
+int vdk_margin_target_cos(const float* cosv, int64_t ldc, int32_t B, int32_t Cloc, int64_t c_base, const int64_t* labels, float* gt, void* stream);
+int vdk_margin_stats(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t Cloc, int64_t c_base, const int64_t* labels, const float* gt,
+                     float* stats /* [B][4] */, void* stream);
+int vdk_margin_grad(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t Cloc, int64_t c_base, int64_t C_total, const int64_t* labels,
+                    const float* gt, const float* gmax, const float* gsum, float label_smoothing, float grad_scale, void* dcos_bf16, int64_t lddc, void* stream);
 int vdk_margin_bwd(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t C, const int64_t* labels, const float* dlogits,
                    int64_t lddl, void* dcos_bf16, int64_t lddc, void* stream);
 

@@ -274,3 +274,96 @@ def test_two_rank_convnext_classifier_step(tmp_path, emu):
     st.step(x, t)
     rel = ((model.engine.params - r0[False]["params"]).norm() / (model.engine.params - r0[False]["init"]).norm()).item()
     assert rel < 2e-2, rel
+
+
+# ---- class-sharded margin head: 2 ranks x (half of the classes, half of the batch) == the full head on the whole batch -----------------------------------
+def _sharded_head_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["VDK_EMU_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.emu.emu_backend import load_emu
+    from visiondk_amd import heads
+    be = load_emu()
+    D, Cn, B = 64, 96, 6
+    torch.manual_seed(21)
+    W = torch.randn(D, Cn); feats = torch.randn(2 * B, D); labels = torch.randint(0, Cn, (2 * B,))
+    labels[0], labels[B] = 3, 90                                  # targets on both shards for both ranks' samples
+    out = {}
+    for tag in ("arcface", "mv_arc"):
+        head = (heads.ArcFace(D, Cn, backend=be, device="cpu") if tag == "arcface" else heads.MV_Softmax(D, Cn, is_am=False, backend=be, device="cpu"))
+        c0 = rank * (Cn // 2)
+        loss, df, dW = heads.sharded_margin_ce(head, feats[rank * B:(rank + 1) * B].contiguous(), labels[rank * B:(rank + 1) * B].contiguous(),
+                                               W[:, c0:c0 + Cn // 2].contiguous(), c0, Cn, label_smoothing=0.1)
+        out[tag] = (loss, df, dW)
+    torch.save(out, f"{out_dir}/sh{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_two_rank_class_sharded_head_equals_full_head(tmp_path, emu):
+    port = 29500 + ((os.getpid() + 457) % 500)
+    mp.start_processes(_sharded_head_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r = [torch.load(tmp_path / f"sh{i}.pt") for i in range(2)]
+    from visiondk_amd import heads
+    D, Cn, B = 64, 96, 6
+    torch.manual_seed(21)
+    W = torch.randn(D, Cn); feats = torch.randn(2 * B, D); labels = torch.randint(0, Cn, (2 * B,))
+    labels[0], labels[B] = 3, 90
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    for tag in ("arcface", "mv_arc"):
+        head = (heads.ArcFace(D, Cn, backend=emu, device="cpu") if tag == "arcface" else heads.MV_Softmax(D, Cn, is_am=False, backend=emu, device="cpu"))
+        with torch.no_grad():
+            head.weight.copy_(W)
+        # the full head on the whole batch with the same per-sample gradient scale (1 / B_local)
+        loss, df, dW = head.margin_ce(feats, labels, label_smoothing=0.1, grad_scale=1.0 / B)
+        got_loss = torch.cat([r[0][tag][0], r[1][tag][0]]); got_df = torch.cat([r[0][tag][1], r[1][tag][1]]); got_dW = torch.cat([r[0][tag][2], r[1][tag][2]], 1)
+        assert rel(got_loss, loss) < 1e-5, (tag, rel(got_loss, loss))
+        assert rel(got_df, df) < 5e-3 and rel(got_dW, dW) < 5e-3, (tag, rel(got_df, df), rel(got_dW, dW))     # bf16 dcos planes, different split of the class sum
+
+
+# ---- FaceTrainStep(shard_head=True) == FaceTrainStep with the replicated head: same weights after a step --------------------------------------------------
+def _face_shard_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["VDK_EMU_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.emu.emu_backend import load_emu
+    from visiondk_amd import comm, face
+    be = load_emu()
+    out = {}
+    torch.manual_seed(7)
+    x = torch.randn(8, 3, 32, 32); y = torch.randint(0, 24, (8,))
+    lo, hi = rank * 4, rank * 4 + 4
+    init = None
+    for shard in (False, True):
+        model = _face_model(be, 100)
+        if init is None:
+            init = {k: v.clone() for k, v in model.state_dict().items()}
+        model.load_state_dict(init)                            # the same initial weights for both variants (the backbone's own init is unseeded)
+        step = face.FaceTrainStep(model, lr=0.05, momentum=0.9, weight_decay=5e-4, max_norm=0.5, ema=True, comm=comm.GradAllReduce(bucket_bytes=20_000),
+                                  shard_head=shard, layer_wise=True)
+        rows = step.step(x[lo:hi], y[lo:hi])
+        head_w = step.gather_head().detach().clone()
+        head_ema = step.gather_head(ema=True).detach().clone() if shard else step.ema_small[-1].clone()
+        out[shard] = {"rows": rows.clone(), "params": step.eng.params.clone(), "head": head_w, "head_ema": head_ema,
+                      "neck": [p.detach().clone() for p in step.bb.output_layer.parameters()]}
+    torch.save(out, f"{out_dir}/fs{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_two_rank_face_step_with_class_sharded_head(tmp_path, emu):
+    port = 29500 + ((os.getpid() + 523) % 500)
+    mp.start_processes(_face_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "fs0.pt"); r1 = torch.load(tmp_path / "fs1.pt")
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    for r in (r0, r1):
+        a, b = r[True], r[False]
+        assert rel(a["rows"], b["rows"]) < 1e-5                                   # same loss rows
+        assert rel(a["params"], b["params"]) < 1e-4 and rel(a["head"], b["head"]) < 1e-4 and rel(a["head_ema"], b["head_ema"]) < 1e-5
+        for p, q in zip(a["neck"], b["neck"]):
+            assert rel(p, q) < 1e-3
+    assert torch.equal(r0[True]["head"], r1[True]["head"]) and torch.equal(r0[True]["params"], r1[True]["params"])   # replicas agree after the gather

@@ -115,6 +115,9 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_rownorm_fwd": (C.c_int, [P, I32, I32, I32, F32, P, P, P, P, P]),
     "vdk_rownorm_bwd": (C.c_int, [P, P, P, I64, I32, I32, P, P]),
     "vdk_margin_ce": (C.c_int, [C.POINTER(MarginHead), P, I64, I32, I32, P, F32, F32, P, I64, P, P, I64, P]),
+    "vdk_margin_target_cos": (C.c_int, [P, I64, I32, I32, I64, P, P, P]),
+    "vdk_margin_stats": (C.c_int, [C.POINTER(MarginHead), P, I64, I32, I32, I64, P, P, P, P]),
+    "vdk_margin_grad": (C.c_int, [C.POINTER(MarginHead), P, I64, I32, I32, I64, I64, P, P, P, P, F32, F32, P, I64, P]),
     "vdk_margin_bwd": (C.c_int, [C.POINTER(MarginHead), P, I64, I32, I32, P, P, I64, P, I64, P]),
     # native ViT engine
     "vdk_gemm_f32_nt": (C.c_int, [C.POINTER(GemmF32Desc), P]),

@@ -229,6 +229,60 @@ __global__ __launch_bounds__(256) void margin_ce_vec_kernel(MarginP P, const flo
   }
   for (int c = C4 + tid; c < (int)lddc; c += 256) dr[c] = f2bf(c < C ? grad(cr[c], c) : 0.f);
 }
+// ---- class-sharded head (one shard of the weight per GPU: SURVEY 8(e), "class-sharded head") -----------------------------------------------------
+// The softmax of a row spans all shards, so the fused kernel above splits into three local passes around two small all-reduces:
+//   margin_target_cos:  gt[b] = cos[b, y_b - c_base] if this shard owns the target column else 0        (SUM over shards = the target cosine)
+//   margin_stats:       stats[b] = (max_c logit, sum_c exp(logit - max), sum_c logit, target logit or 0)  (MAX / rescaled SUM over shards = the global LSE)
+//   margin_grad:        dcos = gscale * (exp(logit - M) / S - eps / C_total - (1 - eps) [c is the target]) * jac     with the GLOBAL M, S
+// cos is this shard's [B, Cloc] block (global column = c_base + c); MV-Softmax needs the global target cosine gt for every column's margin.
+__global__ __launch_bounds__(256) void margin_target_cos_kernel(const float* __restrict__ cosv, long ldc, int B, int Cloc, long c_base, const long long* __restrict__ y,
+                                                                float* __restrict__ gt) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const long t = (long)y[b] - c_base;
+  gt[b] = (t >= 0 && t < Cloc) ? cosv[(long)b * ldc + t] : 0.f;
+}
+__global__ __launch_bounds__(256) void margin_stats_kernel(MarginP P, const float* __restrict__ cosv, long ldc, int Cloc, long c_base, const long long* __restrict__ y,
+                                                           const float* __restrict__ gt, float* __restrict__ stats) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* cr = cosv + (long)row * ldc;
+  const long yt = (long)y[row] - c_base;                 // local target column (may lie outside this shard)
+  const RowCtx R = margin_row_ctx(P, gt[row]);
+  float m = -3.0e38f, se = 0.f, sm = 0.f, tl = 0.f;
+  for (int c = tid; c < Cloc; c += 256) {
+    float lg, jc; margin_eval(P, R, cr[c], c == yt, lg, jc);
+    sm += lg;
+    if (c == yt) tl = lg;
+    if (lg > m) { se *= expf(m - lg); m = lg; }
+    se += expf(lg - m);
+  }
+  const float mx = block_max<4>(m, red);
+  se = block_sum<4>(se * expf(m - mx), red);
+  sm = block_sum<4>(sm, red);
+  tl = block_sum<4>(tl, red);
+  if (tid == 0) { float* o = stats + (long)row * 4; o[0] = mx; o[1] = se; o[2] = sm; o[3] = tl; }
+}
+__global__ __launch_bounds__(256) void margin_grad_kernel(MarginP P, const float* __restrict__ cosv, long ldc, int Cloc, long c_base, long C_total,
+                                                          const long long* __restrict__ y, const float* __restrict__ gt, const float* __restrict__ gmax,
+                                                          const float* __restrict__ gsum, float label_smoothing, float gscale, bf16_t* __restrict__ dcos, long lddc) {
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* cr = cosv + (long)row * ldc;
+  const long yt = (long)y[row] - c_base;
+  const RowCtx R = margin_row_ctx(P, gt[row]);
+  const float mx = gmax[row], inv = 1.0f / gsum[row], epsc = label_smoothing / (float)C_total;
+  for (int c = tid; c < (int)lddc; c += 256) {
+    float g = 0.f;
+    if (c < Cloc) {
+      float lg, jc; margin_eval(P, R, cr[c], c == yt, lg, jc);
+      g = expf(lg - mx) * inv - epsc;
+      if (c == yt) g -= (1.0f - label_smoothing);
+      g *= gscale * jc;
+    }
+    dcos[(long)row * lddc + c] = f2bf(g);
+  }
+}
+
 // backward of the logits-returning form: dcos = dlogits * jac (bf16, padded columns zeroed)
 __global__ __launch_bounds__(256) void margin_bwd_kernel(MarginP P, const float* __restrict__ cosv, long ldc, int C, const long long* __restrict__ y,
                                                          const float* __restrict__ dlogits, long lddl, bf16_t* __restrict__ dcos, long lddc) {
@@ -291,6 +345,29 @@ int vdk_margin_ce(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_
     hipLaunchKernelGGL(margin_ce_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, P, cosv, (long)ldc, (int)C, (const long long*)labels,
                        label_smoothing, grad_scale, logits, (long)ldl, loss_rows, (bf16_t*)dcos_bf16, (long)lddc);
   return vdk_check_launch("vdk_margin_ce");
+}
+int vdk_margin_target_cos(const float* cosv, int64_t ldc, int32_t B, int32_t Cloc, int64_t c_base, const int64_t* labels, float* gt, void* stream) {
+  if (!cosv || !labels || !gt || B <= 0 || Cloc <= 0) return vdk_fail(VDK_EINVAL, "vdk_margin_target_cos: bad argument");
+  hipLaunchKernelGGL(margin_target_cos_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cosv, (long)ldc, (int)B, (int)Cloc, (long)c_base,
+                     (const long long*)labels, gt);
+  return vdk_check_launch("vdk_margin_target_cos");
+}
+int vdk_margin_stats(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t Cloc, int64_t c_base, const int64_t* labels, const float* gt,
+                     float* stats, void* stream) {
+  MarginP P; int rc = fill_params(h, &P); if (rc) return rc;
+  if (!cosv || !labels || !gt || !stats || B <= 0 || Cloc <= 0) return vdk_fail(VDK_EINVAL, "vdk_margin_stats: bad argument");
+  hipLaunchKernelGGL(margin_stats_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, P, cosv, (long)ldc, (int)Cloc, (long)c_base, (const long long*)labels, gt,
+                     stats);
+  return vdk_check_launch("vdk_margin_stats");
+}
+int vdk_margin_grad(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t Cloc, int64_t c_base, int64_t C_total, const int64_t* labels,
+                    const float* gt, const float* gmax, const float* gsum, float label_smoothing, float grad_scale, void* dcos_bf16, int64_t lddc, void* stream) {
+  MarginP P; int rc = fill_params(h, &P); if (rc) return rc;
+  if (!cosv || !labels || !gt || !gmax || !gsum || !dcos_bf16 || B <= 0 || Cloc <= 0 || C_total < Cloc || lddc < Cloc)
+    return vdk_fail(VDK_EINVAL, "vdk_margin_grad: bad argument");
+  hipLaunchKernelGGL(margin_grad_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, P, cosv, (long)ldc, (int)Cloc, (long)c_base, (long)C_total,
+                     (const long long*)labels, gt, gmax, gsum, label_smoothing, grad_scale, (bf16_t*)dcos_bf16, (long)lddc);
+  return vdk_check_launch("vdk_margin_grad");
 }
 int vdk_margin_bwd(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t C, const int64_t* labels, const float* dlogits,
                    int64_t lddl, void* dcos_bf16, int64_t lddc, void* stream) {

@@ -358,8 +358,11 @@ class FaceTrainStep:
     launch each with the same global clip factor.  BatchNorm running statistics enter the EMA like every float entry of state_dict()."""
 
     def __init__(self, model: "FaceTrainingModel", lr: float, momentum: float = 0.9, weight_decay: float = 5e-4, label_smoothing: float = 0.0,
-                 max_norm: float = 10.0, ema: bool = True, comm=None, layer_wise: bool = False):
-        """layer_wise: the second entry of the yaml's `optimizer` list (cbir.yaml:113): two parameter groups, backbone + neck at lr and the
+                 max_norm: float = 10.0, ema: bool = True, comm=None, layer_wise: bool = False, shard_head: bool = False):
+        """shard_head (with comm): every rank keeps the columns [rank * C / world, (rank + 1) * C / world) of the margin head, trains them with
+        `heads.sharded_margin_ce` (features all-gathered, per-row softmax statistics and the [B, D] feature gradient all-reduced) and never all-reduces the
+        [D, C] head gradient (2 GB at C = 10^6).  `gather_head()` writes the shards back into `head.weight` for evaluation / checkpoints.
+        layer_wise: the second entry of the yaml's `optimizer` list (cbir.yaml:113): two parameter groups, backbone + neck at lr and the
         margin head at 10 x lr (built/layer_optimizer.py:26-29); `param_groups[1]['lr']` is then the head's rate and a scheduler drives both.
         comm: visiondk_amd.comm.GradAllReduce for data parallelism (one process per GPU): parameters and BatchNorm buffers are broadcast from
         rank 0 at construction and the buffers again before every forward (torch DDP's broadcast_buffers=True, which the reference's
@@ -376,7 +379,8 @@ class FaceTrainStep:
         if layer_wise:
             self.param_groups.append({"lr": lr * 10, "momentum": momentum, "weight_decay": weight_decay})
         self.updates = 0
-        self.small = [p for p in self.bb.output_layer.parameters()] + [self.head.weight]
+        self.shard_head = bool(shard_head and comm is not None and comm.world_size > 1)
+        self.small = [p for p in self.bb.output_layer.parameters()] + ([] if self.shard_head else [self.head.weight])
         self.buffers = [b for b in self.bb.output_layer.buffers() if b.dtype.is_floating_point]
         mk = lambda t: torch.zeros_like(t)
         self.mom_flat = mk(self.eng.params)
@@ -395,7 +399,7 @@ class FaceTrainStep:
         if comm is not None and comm.world_size > 1:
             import torch.distributed as dist
             comm.broadcast_params(self.eng.params)
-            for t in self.small + self.buffers:
+            for t in self.small + self.buffers + ([self.head.weight] if self.shard_head else []):
                 dist.broadcast(t.data, src=0, group=comm.group)
             if ema:
                 self.ema_flat.copy_(self.eng.params)
@@ -403,6 +407,16 @@ class FaceTrainStep:
                     e.copy_(p.detach())
                 for e, b in zip(self.ema_buf, self.buffers):
                     e.copy_(b)
+        if self.shard_head:
+            Cn = self.head.weight.shape[1]
+            if Cn % comm.world_size:
+                raise ValueError("shard_head needs num_class % world_size == 0")
+            self.c_per = Cn // comm.world_size
+            self.c0 = comm.rank * self.c_per
+            self.hs = self.head.weight.detach()[:, self.c0:self.c0 + self.c_per].contiguous()      # this rank's columns, trained in place of head.weight
+            self.hs_mom = torch.zeros_like(self.hs)
+            self.hs_ema = self.hs.clone() if ema else None
+            self._nsq_head = torch.zeros(1, dtype=torch.float32, device=self.eng.device)
 
     def _sumsq(self, g: torch.Tensor) -> None:
         be = self.be
@@ -432,11 +446,16 @@ class FaceTrainStep:
         ol = bb.output_layer
         fn = _NeckCNNFn if bb.is_cnn else _NeckFn
         emb = fn.apply(feat, ol[0].weight, ol[0].bias, ol[2].weight, ol[2].bias, ol[3].weight, ol[3].bias, bb)
-        self.loss_rows, demb, dW = self.head.margin_ce(emb.detach(), y, self.label_smoothing)
+        if self.shard_head:
+            self.loss_rows, demb, dW = heads.sharded_margin_ce(self.head, emb.detach(), y, self.hs, self.c0, self.head.weight.shape[1], group=self.comm.group,
+                                                              label_smoothing=self.label_smoothing)
+        else:
+            self.loss_rows, demb, dW = self.head.margin_ce(emb.detach(), y, self.label_smoothing)
         for p in self.small:
             p.grad = None
         emb.backward(demb)
-        self.head.weight.grad = dW
+        if not self.shard_head:
+            self.head.weight.grad = dW
         dfeat = feat.grad
         dfeat = dfeat.permute(0, 2, 3, 1).contiguous().view(-1, eng.out_ch) if bb.is_cnn else dfeat.contiguous().view(-1, eng.spec.dim)
         if world > 1:
@@ -457,6 +476,11 @@ class FaceTrainStep:
         self._sumsq(eng.grads)
         for p in self.small:
             self._sumsq(p.grad.contiguous())
+        if self.shard_head:                                            # the head's share of the global gradient norm: sum over the shards
+            import torch.distributed as dist
+            be.check(be.lib.vdk_sumsq_f32(be.ptr(dW), dW.numel(), be.ptr(self._nsq_head), be.ptr(self._ws), self._ws.numel(), be.stream()), "vdk_sumsq_f32")
+            dist.all_reduce(self._nsq_head, op=dist.ReduceOp.SUM, group=self.comm.group)
+            self._nsq += self._nsq_head
         first = int(self.updates == 1)
         be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.mom_flat), be.ptr(self.ema_flat), be.ptr(eng.wb16), eng.n_floats, lr,
                                      self.momentum, self.weight_decay, 1.0 / world, be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step")
@@ -464,8 +488,23 @@ class FaceTrainStep:
             g = p.grad.contiguous()
             be.check(be.lib.vdk_sgd_step(be.ptr(p.data), be.ptr(g), be.ptr(m), be.ptr(e), None, p.numel(), lr_head if p is self.head.weight else lr, self.momentum, self.weight_decay, 1.0 / world,
                                          be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step")
+        if self.shard_head:
+            be.check(be.lib.vdk_sgd_step(be.ptr(self.hs), be.ptr(dW), be.ptr(self.hs_mom), be.ptr(self.hs_ema), None, self.hs.numel(), lr_head, self.momentum,
+                                         self.weight_decay, 1.0 / world, be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step")
         for b, z, zm, e in zip(self.buffers, self._zero, self._zero_m, self.ema_buf):   # EMA of the BatchNorm running statistics (lr = 0: value untouched)
             be.check(be.lib.vdk_sgd_step(be.ptr(b), be.ptr(z), be.ptr(zm), be.ptr(e), None, b.numel(), 0.0, 0.0, 0.0, 1.0, None, self.max_norm, d, first,
                                          be.stream()), "vdk_sgd_step")
         eng.refresh_weights(skip_wb16=True)
         return self.loss_rows
+
+    def gather_head(self, ema: bool = False) -> torch.Tensor:
+        """shard_head: all-gather the column shards (or their EMA) into `head.weight` ([D, C], every rank) for evaluation and checkpoints"""
+        if not self.shard_head:
+            return self.head.weight
+        import torch.distributed as dist
+        src = self.hs_ema if ema else self.hs
+        parts = [torch.empty_like(src) for _ in range(self.comm.world_size)]
+        dist.all_gather(parts, src, group=self.comm.group)
+        with torch.no_grad():
+            self.head.weight.copy_(torch.cat(parts, 1))
+        return self.head.weight

@@ -160,3 +160,50 @@ class HeadFactory:
         if t == "magface":
             raise NotImplementedError("MagFace.forward returns a tuple the reference Trainer cannot consume (train.py:196); not built")
         raise KeyError(f"unknown head type {self.head_type}")
+
+
+def sharded_margin_ce(head: _MarginHead, feats: torch.Tensor, labels: torch.Tensor, weight_shard: torch.Tensor, c_base: int, num_class: int, group=None,
+                      label_smoothing: float = 0.0, grad_scale: Optional[float] = None):
+    """Class-sharded form of `head.margin_ce` for data-parallel training with many identities: this rank holds the weight columns
+    [c_base, c_base + weight_shard.shape[1]) of the [D, num_class] head.  Features and labels of ALL ranks are all-gathered (B_total x D floats), every rank
+    scores them against its shard, three small all-reduces ([B_total] target cosine, [B_total] max, [B_total, 3] sums) give the global softmax statistics,
+    and the feature gradient is summed over the shards ([B_total, D]).  The [D, C] head gradient never crosses a link: each rank gets the gradient of its own
+    shard.  Returns (loss_rows of the LOCAL samples, dfeats of the local samples, dweight of the shard); grad_scale defaults to 1 / B_local, the scale
+    `margin_ce` uses, so that the optimizer's 1 / world factor applies to both forms alike."""
+    import torch.distributed as dist
+    be = head.be
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B, D = feats.shape
+    if world > 1:
+        fl = [torch.empty_like(feats) for _ in range(world)]; ll = [torch.empty_like(labels) for _ in range(world)]
+        dist.all_gather(fl, feats.contiguous(), group=group); dist.all_gather(ll, labels.contiguous(), group=group)   # equal per-rank batches (DistributedSampler, drop_last)
+        fall, lall = torch.cat(fl, 0), torch.cat(ll, 0)
+    else:
+        fall, lall = feats.contiguous(), labels.contiguous()
+    Bt, Cloc = fall.shape[0], weight_shard.shape[1]
+    st = _forward_cos(be, fall, weight_shard.detach())
+    dev = feats.device
+    gt = torch.empty(Bt, dtype=torch.float32, device=dev)
+    be.check(be.lib.vdk_margin_target_cos(be.ptr(st.cos), st.Cp, Bt, Cloc, c_base, be.ptr(lall), be.ptr(gt), be.stream()), "vdk_margin_target_cos")
+    if world > 1:
+        dist.all_reduce(gt, op=dist.ReduceOp.SUM, group=group)
+    stats = torch.empty((Bt, 4), dtype=torch.float32, device=dev)
+    be.check(be.lib.vdk_margin_stats(C.byref(head.cfg), be.ptr(st.cos), st.Cp, Bt, Cloc, c_base, be.ptr(lall), be.ptr(gt), be.ptr(stats), be.stream()), "vdk_margin_stats")
+    gmax = stats[:, 0].contiguous()
+    if world > 1:
+        dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
+    sums = torch.stack([stats[:, 1] * torch.exp(stats[:, 0] - gmax), stats[:, 2], stats[:, 3]], 1).contiguous()
+    if world > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    gsum = sums[:, 0].contiguous()
+    loss_all = gmax + torch.log(gsum) - (1.0 - label_smoothing) * sums[:, 2] - label_smoothing * sums[:, 1] / num_class
+    dcos = torch.zeros((st.Bp, st.Cp), dtype=torch.bfloat16, device=dev)
+    gs = 1.0 / B if grad_scale is None else grad_scale
+    be.check(be.lib.vdk_margin_grad(C.byref(head.cfg), be.ptr(st.cos), st.Cp, Bt, Cloc, c_base, num_class, be.ptr(lall), be.ptr(gt), be.ptr(gmax), be.ptr(gsum),
+                                    label_smoothing, gs, be.ptr(dcos), st.Cp, be.stream()), "vdk_margin_grad")
+    df_all, dW = _backward_from_dcos(be, st, weight_shard.detach(), dcos)      # df of every sample w.r.t. THIS shard's columns
+    if world > 1:
+        dist.all_reduce(df_all, op=dist.ReduceOp.SUM, group=group)
+    lo = rank * B
+    return loss_all[lo:lo + B].contiguous(), df_all[lo:lo + B].contiguous(), dW
