@@ -72,6 +72,25 @@ def test_wide_head_fused_form_equals_autograd_form(be, dev, tag):
     assert _rel(df, feats.grad) < 2e-2 and _rel(dW, h.weight.grad) < 2e-2
 
 
+@pytest.mark.parametrize("tag", ["arcface", "circle", "mv_am"])
+def test_sharded_form_with_one_shard_equals_fused_form(be, dev, tag):
+    """heads.sharded_margin_ce without a process group = one shard holding every class: its three local passes (target cosine, statistics, gradient) must
+    reproduce the fused kernel; C = 5003 exercises the 16-byte path, its scalar tail and the zeroed padding columns."""
+    torch.manual_seed(5)
+    D, Cn, B = 64, 5003, 5
+    if tag == "arcface":
+        h = heads.ArcFace(D, Cn, backend=be, device=dev)
+    elif tag == "circle":
+        h = heads.CircleLoss(D, Cn, margin=0.25, gamma=64, backend=be, device=dev)
+    else:
+        h = heads.MV_Softmax(D, Cn, is_am=True, backend=be, device=dev)
+    feats = torch.randn(B, D, device=dev)
+    labels = torch.tensor([0, 5002, 77, 4096, 2500], device=dev)
+    l1, df1, dW1 = h.margin_ce(feats, labels, label_smoothing=0.1)
+    l2, df2, dW2 = heads.sharded_margin_ce(h, feats, labels, h.weight.detach(), 0, Cn, label_smoothing=0.1)
+    assert _rel(l2, l1) < 1e-6 and _rel(df2, df1) < 1e-3 and _rel(dW2, dW1) < 1e-3
+
+
 def test_head_factory_names():
     f = heads.HeadFactory("arcface", {"feat_dim": 8, "num_class": 16}, backend=None, device="cpu")
     assert f.head_type == "arcface"

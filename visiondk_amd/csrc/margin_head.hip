@@ -250,13 +250,29 @@ __global__ __launch_bounds__(256) void margin_stats_kernel(MarginP P, const floa
   const long yt = (long)y[row] - c_base;                 // local target column (may lie outside this shard)
   const RowCtx R = margin_row_ctx(P, gt[row]);
   float m = -3.0e38f, se = 0.f, sm = 0.f, tl = 0.f;
-  for (int c = tid; c < Cloc; c += 256) {
-    float lg, jc; margin_eval(P, R, cr[c], c == yt, lg, jc);
+  auto visit = [&](float cv, int c) {
+    float lg, jc; margin_eval(P, R, cv, c == yt, lg, jc);
     sm += lg;
     if (c == yt) tl = lg;
     if (lg > m) { se *= expf(m - lg); m = lg; }
     se += expf(lg - m);
+  };
+  // 16-byte loads, four in flight per thread (see margin_ce_vec_kernel); scalar loop for unaligned blocks and the tail
+  const int C4 = (((ldc & 3) == 0) && (((size_t)cosv & 15) == 0)) ? (Cloc & ~3) : 0;
+  for (int base = tid * 4; base < C4; base += 256 * 4 * MCE_U) {
+    f32x4 v[MCE_U];
+#pragma unroll
+    for (int u = 0; u < MCE_U; ++u) { const int c = base + u * 1024; if (c < C4) v[u] = *(const f32x4*)(cr + c); }
+#pragma unroll
+    for (int u = 0; u < MCE_U; ++u) {
+      const int c = base + u * 1024;
+      if (c < C4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) visit(v[u][e], c + e);
+      }
+    }
   }
+  for (int c = C4 + tid; c < Cloc; c += 256) visit(cr[c], c);
   const float mx = block_max<4>(m, red);
   se = block_sum<4>(se * expf(m - mx), red);
   sm = block_sum<4>(sm, red);
@@ -271,16 +287,26 @@ __global__ __launch_bounds__(256) void margin_grad_kernel(MarginP P, const float
   const long yt = (long)y[row] - c_base;
   const RowCtx R = margin_row_ctx(P, gt[row]);
   const float mx = gmax[row], inv = 1.0f / gsum[row], epsc = label_smoothing / (float)C_total;
-  for (int c = tid; c < (int)lddc; c += 256) {
-    float g = 0.f;
-    if (c < Cloc) {
-      float lg, jc; margin_eval(P, R, cr[c], c == yt, lg, jc);
-      g = expf(lg - mx) * inv - epsc;
-      if (c == yt) g -= (1.0f - label_smoothing);
-      g *= gscale * jc;
+  auto grad = [&](float cv, int c) -> float {
+    float lg, jc; margin_eval(P, R, cv, c == yt, lg, jc);
+    float g = expf(lg - mx) * inv - epsc;
+    if (c == yt) g -= (1.0f - label_smoothing);
+    return g * gscale * jc;
+  };
+  bf16_t* dr = dcos + (long)row * lddc;
+  const bool al = ((ldc & 3) == 0) && (((size_t)cosv & 15) == 0) && ((lddc & 3) == 0) && (((size_t)dcos & 7) == 0);
+  const int C4 = al ? (Cloc & ~3) : 0;
+  for (int base = tid * 4; base < C4; base += 256 * 4 * MCE_U) {
+    f32x4 v[MCE_U];
+#pragma unroll
+    for (int u = 0; u < MCE_U; ++u) { const int c = base + u * 1024; if (c < C4) v[u] = *(const f32x4*)(cr + c); }
+#pragma unroll
+    for (int u = 0; u < MCE_U; ++u) {
+      const int c = base + u * 1024;
+      if (c < C4) *(u32x2*)(dr + c) = (u32x2){pack_bf2(grad(v[u][0], c), grad(v[u][1], c + 1)), pack_bf2(grad(v[u][2], c + 2), grad(v[u][3], c + 3))};
     }
-    dcos[(long)row * lddc + c] = f2bf(g);
   }
+  for (int c = C4 + tid; c < (int)lddc; c += 256) dr[c] = f2bf(c < Cloc ? grad(cr[c], c) : 0.f);
 }
 
 // backward of the logits-returning form: dcos = dlogits * jac (bf16, padded columns zeroed)
