@@ -415,6 +415,9 @@ typedef struct VdkResNetConfig {
   int32_t depths[4];
   int32_t num_classes;
   float bn_eps, bn_momentum;
+  int32_t mid[4];        /* all 0: BasicBlock network (resnet18 / 34), `widths` = block channels.  > 0: Bottleneck network (resnet50 / 101 / 152,
+                          * wide_resnet*_2): inner width of the 1x1 -> 3x3 -> 1x1 blocks, `widths` = block OUTPUT channels (4 x planes) */
+  int32_t stem_width;    /* 0: widths[0] (basic) or 64 (bottleneck) */
 } VdkResNetConfig;
 /* trainable parameters live in one flat f32 buffer (params / grads), BatchNorm running statistics in another (buffers); `wx` = derived operand copies */
 int vdk_resnet_param_count(const VdkResNetConfig* cfg, int64_t* n_floats, int32_t* n_tensors, int64_t* n_buffer_floats, int32_t* n_buffers, size_t* wx_bytes);

@@ -38,17 +38,41 @@ class BasicBlock(nn.Module):
         return F.relu(x + shortcut)
 
 
-class ResNetRef(nn.Module):
-    def __init__(self, num_classes=1000, in_chans=3, widths=(64, 128, 256, 512), depths=(2, 2, 2, 2)):
+class Bottleneck(nn.Module):
+    """timm / torchvision v1.5 Bottleneck (resnet50 / 101 / 152, wide_resnet*_2: `timm-wide_resnet101_2` is one of pet.yaml's listed models): 1x1 (cin -> mid),
+    3x3 with the block's stride (mid -> mid), 1x1 (mid -> cout = 4 * planes); mid = planes * base_width / 64; downsample as in BasicBlock."""
+
+    def __init__(self, cin, mid, cout, stride):
         super().__init__()
-        self.conv1 = nn.Conv2d(in_chans, widths[0], 7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(widths[0])
+        self.conv1 = nn.Conv2d(cin, mid, 1, bias=False); self.bn1 = nn.BatchNorm2d(mid)
+        self.conv2 = nn.Conv2d(mid, mid, 3, stride=stride, padding=1, bias=False); self.bn2 = nn.BatchNorm2d(mid)
+        self.conv3 = nn.Conv2d(mid, cout, 1, bias=False); self.bn3 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        shortcut = x if self.downsample is None else self.downsample(x)
+        x = F.relu(self.bn1(self.conv1(x)))
+        x = F.relu(self.bn2(self.conv2(x)))
+        x = self.bn3(self.conv3(x))
+        return F.relu(x + shortcut)
+
+
+class ResNetRef(nn.Module):
+    def __init__(self, num_classes=1000, in_chans=3, widths=(64, 128, 256, 512), depths=(2, 2, 2, 2), mid=None, stem_width=None):
+        """mid = None: BasicBlocks with `widths` channels.  mid = (m1..m4): Bottlenecks, `widths` are the block OUTPUT channels (4 * planes)."""
+        super().__init__()
+        stem_width = stem_width or (widths[0] if mid is None else 64)
+        self.conv1 = nn.Conv2d(in_chans, stem_width, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(stem_width)
         self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
-        cin = widths[0]
+        cin = stem_width
         for i, (w, d) in enumerate(zip(widths, depths)):
             blocks = []
             for j in range(d):
-                blocks.append(BasicBlock(cin, w, 2 if (j == 0 and i > 0) else 1))
+                st = 2 if (j == 0 and i > 0) else 1
+                blocks.append(BasicBlock(cin, w, st) if mid is None else Bottleneck(cin, mid[i], w, st))
                 cin = w
             setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
         self.fc = nn.Linear(widths[-1], num_classes)

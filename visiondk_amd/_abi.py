@@ -47,7 +47,7 @@ class ConvNextConfig(C.Structure):
 
 class ResNetConfig(C.Structure):
     _fields_ = [("batch", I32), ("img_size", I32), ("in_chans", I32), ("widths", I32 * 4), ("depths", I32 * 4), ("num_classes", I32), ("bn_eps", C.c_float),
-                ("bn_momentum", C.c_float)]
+                ("bn_momentum", C.c_float), ("mid", I32 * 4), ("stem_width", I32)]
 
 
 class MarginHead(C.Structure):

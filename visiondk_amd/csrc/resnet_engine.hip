@@ -44,7 +44,7 @@ inline int64_t up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 struct Conv { int ci, cip, co, k, s, p, hin, hout; int64_t w; size_t wf, wd; };         // w: param offset; wf / wd: byte offsets in wx
 struct Bn { int c; int64_t g, b, rm, rv; };                                                // param offsets (g, b), buffer offsets (rm, rv)
-struct Blk { Conv c1, c2, cd; Bn b1, b2, bd; bool ds; int R; };
+struct Blk { Conv c1, c2, c3, cd; Bn b1, b2, b3, bd; bool ds, bott; int R, Ra; };   // bott: Bottleneck (1x1, 3x3 / stride, 1x1); Ra = rows after c1, R = rows of the block output
 struct RnDims {
   int B, Bp, img, Cin, Cinp, C, Cp, H0, Hp, R0, Rp;
   float eps, mom;
@@ -88,29 +88,47 @@ int rn_dims(const VdkResNetConfig* c, RnDims* d, std::vector<PEntry>* pe = nullp
   int64_t pcur = 0, bcur = 0; size_t xcur = 0;
   for (int i = 0; i < 4; ++i)
     if (c->widths[i] <= 0 || (c->widths[i] & 7) || c->depths[i] <= 0) return vdk_fail(VDK_EINVAL, "resnet: bad config (widths % 8 == 0, depths > 0)");
-  mk_conv(&d->stem, d->Cin, c->widths[0], 7, 2, 3, d->img, pcur, xcur, false, "conv1.weight", pe);
-  mk_bn(&d->stem_bn, c->widths[0], pcur, bcur, "bn1", pe, be);
+  const bool bott = c->mid[0] > 0;
+  for (int i = 0; i < 4; ++i)
+    if (bott && (c->mid[i] <= 0 || (c->mid[i] & 7))) return vdk_fail(VDK_EINVAL, "resnet: bad config (mid % 8 == 0 for every stage of a bottleneck network)");
+  const int stem_w = c->stem_width > 0 ? c->stem_width : (bott ? 64 : c->widths[0]);
+  if (stem_w & 7) return vdk_fail(VDK_EINVAL, "resnet: bad config (stem_width % 8 == 0)");
+  mk_conv(&d->stem, d->Cin, stem_w, 7, 2, 3, d->img, pcur, xcur, false, "conv1.weight", pe);
+  mk_bn(&d->stem_bn, stem_w, pcur, bcur, "bn1", pe, be);
   d->H0 = d->stem.hout; d->Hp = (d->H0 - 1) / 2 + 1;
   d->R0 = d->B * d->H0 * d->H0; d->Rp = d->B * d->Hp * d->Hp;
   d->blk.clear();
-  int cin = c->widths[0], h = d->Hp;
+  int cin = stem_w, h = d->Hp;
   char nm[64], pf[64];
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < c->depths[i]; ++j) {
       Blk b;
+      b.bott = bott;
       const int co = c->widths[i], s = (j == 0 && i > 0) ? 2 : 1;
-      snprintf(nm, 64, "layer%d.%d.conv1.weight", i + 1, j); mk_conv(&b.c1, cin, co, 3, s, 1, h, pcur, xcur, true, nm, pe);
-      snprintf(pf, 64, "layer%d.%d.bn1", i + 1, j); mk_bn(&b.b1, co, pcur, bcur, pf, pe, be);
-      snprintf(nm, 64, "layer%d.%d.conv2.weight", i + 1, j); mk_conv(&b.c2, co, co, 3, 1, 1, b.c1.hout, pcur, xcur, true, nm, pe);
-      snprintf(pf, 64, "layer%d.%d.bn2", i + 1, j); mk_bn(&b.b2, co, pcur, bcur, pf, pe, be);
+      if (!bott) {
+        snprintf(nm, 64, "layer%d.%d.conv1.weight", i + 1, j); mk_conv(&b.c1, cin, co, 3, s, 1, h, pcur, xcur, true, nm, pe);
+        snprintf(pf, 64, "layer%d.%d.bn1", i + 1, j); mk_bn(&b.b1, co, pcur, bcur, pf, pe, be);
+        snprintf(nm, 64, "layer%d.%d.conv2.weight", i + 1, j); mk_conv(&b.c2, co, co, 3, 1, 1, b.c1.hout, pcur, xcur, true, nm, pe);
+        snprintf(pf, 64, "layer%d.%d.bn2", i + 1, j); mk_bn(&b.b2, co, pcur, bcur, pf, pe, be);
+      } else {          // timm / torchvision v1.5 Bottleneck: the stride sits on the 3x3
+        const int md = c->mid[i];
+        snprintf(nm, 64, "layer%d.%d.conv1.weight", i + 1, j); mk_conv(&b.c1, cin, md, 1, 1, 0, h, pcur, xcur, true, nm, pe);
+        snprintf(pf, 64, "layer%d.%d.bn1", i + 1, j); mk_bn(&b.b1, md, pcur, bcur, pf, pe, be);
+        snprintf(nm, 64, "layer%d.%d.conv2.weight", i + 1, j); mk_conv(&b.c2, md, md, 3, s, 1, h, pcur, xcur, true, nm, pe);
+        snprintf(pf, 64, "layer%d.%d.bn2", i + 1, j); mk_bn(&b.b2, md, pcur, bcur, pf, pe, be);
+        snprintf(nm, 64, "layer%d.%d.conv3.weight", i + 1, j); mk_conv(&b.c3, md, co, 1, 1, 0, b.c2.hout, pcur, xcur, true, nm, pe);
+        snprintf(pf, 64, "layer%d.%d.bn3", i + 1, j); mk_bn(&b.b3, co, pcur, bcur, pf, pe, be);
+      }
+      const int hout = b.c2.hout;
       b.ds = (s != 1 || cin != co);
       if (b.ds) {
         snprintf(nm, 64, "layer%d.%d.downsample.0.weight", i + 1, j); mk_conv(&b.cd, cin, co, 1, s, 0, h, pcur, xcur, true, nm, pe);
         snprintf(pf, 64, "layer%d.%d.downsample.1", i + 1, j); mk_bn(&b.bd, co, pcur, bcur, pf, pe, be);
       }
-      b.R = d->B * b.c1.hout * b.c1.hout;
+      b.Ra = d->B * b.c1.hout * b.c1.hout;
+      b.R = d->B * hout * hout;
       d->blk.push_back(b);
-      cin = co; h = b.c1.hout;
+      cin = co; h = hout;
     }
   d->wlast = cin;
   d->fc_w = p_take(pcur, (int64_t)d->Cp * cin); add_entry(pe, "fc.weight", d->fc_w, 2, d->C, cin);
@@ -120,7 +138,7 @@ int rn_dims(const VdkResNetConfig* c, RnDims* d, std::vector<PEntry>* pe = nullp
   return VDK_OK;
 }
 
-struct BlkW { size_t y1, a1, y2, out, st1, st2, yd, idf, std_; };
+struct BlkW { size_t y1, a1, y2, a2, y3, out, st1, st2, st3, yd, idf, std_; };
 struct WsPlan {
   size_t total, img, y0, a0, st0, ap, apk, feat;
   std::vector<BlkW> blk;
@@ -162,22 +180,26 @@ void rn_plan(const RnDims& d, WsPlan* w) {
   w->blk.resize(d.blk.size());
   for (size_t i = 0; i < d.blk.size(); ++i) {
     const Blk& b = d.blk[i]; BlkW& bw = w->blk[i];
-    const size_t n = (size_t)b.R * b.c1.co;
-    bw.y1 = w_take(cur, n * 4); bw.a1 = w_take(cur, n * 2); bw.y2 = w_take(cur, n * 4); bw.out = w_take(cur, n * 2);
-    bw.st1 = w_take(cur, ((size_t)b.c1.co * 2 + 4) * 4); bw.st2 = w_take(cur, ((size_t)b.c1.co * 2 + 4) * 4);
+    const int cout = b.bott ? b.c3.co : b.c2.co;
+    const size_t n1 = (size_t)b.Ra * b.c1.co, n2 = (size_t)b.R * b.c2.co, n = (size_t)b.R * cout;
+    bw.y1 = w_take(cur, n1 * 4); bw.a1 = w_take(cur, n1 * 2); bw.y2 = w_take(cur, n2 * 4);
+    bw.a2 = bw.y3 = bw.st3 = 0;
+    if (b.bott) { bw.a2 = w_take(cur, n2 * 2); bw.y3 = w_take(cur, n * 4); bw.st3 = w_take(cur, ((size_t)cout * 2 + 4) * 4); }
+    bw.out = w_take(cur, n * 2);
+    bw.st1 = w_take(cur, ((size_t)b.c1.co * 2 + 4) * 4); bw.st2 = w_take(cur, ((size_t)b.c2.co * 2 + 4) * 4);
     bw.yd = bw.idf = bw.std_ = 0;
-    if (b.ds) { bw.yd = w_take(cur, n * 4); bw.idf = w_take(cur, n * 4); bw.std_ = w_take(cur, ((size_t)b.c1.co * 2 + 4) * 4); }
+    if (b.ds) { bw.yd = w_take(cur, n * 4); bw.idf = w_take(cur, n * 4); bw.std_ = w_take(cur, ((size_t)cout * 2 + 4) * 4); }
     const size_t nin = (size_t)d.B * b.c1.hin * b.c1.hin * b.c1.cip;
-    if (n > rc) rc = n;
-    if (nin > rc) rc = nin;
-    const size_t c1 = (size_t)b.R * 9 * b.c1.cip, c2 = (size_t)b.R * 9 * b.c2.cip;
-    if (c1 > colmax) colmax = c1;
-    if (c2 > colmax) colmax = c2;
-    const size_t d1 = (size_t)b.c1.co * 9 * b.c1.cip, d2 = (size_t)b.c2.co * 9 * b.c2.cip;
-    if (d1 > dwpmax) dwpmax = d1;
-    if (d2 > dwpmax) dwpmax = d2;
-    wg(b.c1.co, 9 * b.c1.cip, b.R); wg(b.c2.co, 9 * b.c2.cip, b.R); bnw(b.R, b.c1.co);
-    if (b.ds) wg(b.cd.co, b.cd.cip, b.R);
+    for (size_t q : {n, n1, n2, nin}) if (q > rc) rc = q;
+    auto conv_sizes = [&](const Conv& c, int rows) {
+      const size_t cl = (size_t)rows * c.k * c.k * c.cip, dw = (size_t)c.co * c.k * c.k * c.cip;
+      if (cl > colmax) colmax = cl;
+      if (dw > dwpmax) dwpmax = dw;
+      wg(c.co, c.k * c.k * c.cip, rows);
+    };
+    conv_sizes(b.c1, b.Ra); conv_sizes(b.c2, b.R); bnw(b.Ra, b.c1.co); bnw(b.R, b.c2.co);
+    if (b.bott) { conv_sizes(b.c3, b.R); bnw(b.R, b.c3.co); }
+    if (b.ds) { conv_sizes(b.cd, b.R); bnw(b.R, b.cd.co); }
   }
   wg(d.Cp, d.wlast, d.B);
   w->feat = w_take(cur, (size_t)d.Bp * d.wlast * 2);
@@ -279,7 +301,7 @@ int vdk_resnet_refresh_weights(const VdkResNetConfig* cfg, const float* params, 
   char* xb = (char*)wx;
   auto prep = [&](const Conv& c) { return vdk_conv_weight_prep(params + c.w, xb + c.wf, c.wd ? xb + c.wd : nullptr, c.co, c.ci, c.cip, c.k, c.k, stream); };
   RC(prep(d.stem));
-  for (const Blk& b : d.blk) { RC(prep(b.c1)); RC(prep(b.c2)); if (b.ds) RC(prep(b.cd)); }
+  for (const Blk& b : d.blk) { RC(prep(b.c1)); RC(prep(b.c2)); if (b.bott) RC(prep(b.c3)); if (b.ds) RC(prep(b.cd)); }
   return vdk_transpose_cast_f32_bf16(params + d.fc_w, d.wlast, d.Cp, d.wlast, xb + d.fct, d.Cp, d.Cp, stream);
 }
 
@@ -306,19 +328,25 @@ int vdk_resnet_forward(const VdkResNetConfig* cfg, const float* x, const float* 
   for (size_t i = 0; i < d.blk.size(); ++i) {
     const Blk& b = d.blk[i]; const BlkW& bw = w.blk[i];
     RC(conv_gemm(s, b.c1, d.B, false, ain, xb + b.c1.wf, base + bw.y1, VDK_F32, nullptr));
-    RC(bn(b.b1, (const float*)(base + bw.y1), b.R, bw.st1, nullptr, nullptr, 1, base + bw.a1, nullptr));
+    RC(bn(b.b1, (const float*)(base + bw.y1), b.Ra, bw.st1, nullptr, nullptr, 1, base + bw.a1, nullptr));
     RC(conv_gemm(s, b.c2, d.B, false, base + bw.a1, xb + b.c2.wf, base + bw.y2, VDK_F32, nullptr));
+    const Bn* blast = &b.b2; const float* ylast = (const float*)(base + bw.y2); size_t stlast = bw.st2;
+    if (b.bott) {
+      RC(bn(b.b2, (const float*)(base + bw.y2), b.R, bw.st2, nullptr, nullptr, 1, base + bw.a2, nullptr));
+      RC(conv_gemm(s, b.c3, d.B, false, base + bw.a2, xb + b.c3.wf, base + bw.y3, VDK_F32, nullptr));
+      blast = &b.b3; ylast = (const float*)(base + bw.y3); stlast = bw.st3;
+    }
     if (b.ds) {
       RC(conv_gemm(s, b.cd, d.B, false, ain, xb + b.cd.wf, base + bw.yd, VDK_F32, nullptr));
       RC(bn(b.bd, (const float*)(base + bw.yd), b.R, bw.std_, nullptr, nullptr, 0, nullptr, (float*)(base + bw.idf)));
-      RC(bn(b.b2, (const float*)(base + bw.y2), b.R, bw.st2, (const float*)(base + bw.idf), nullptr, 1, base + bw.out, nullptr));
+      RC(bn(*blast, ylast, b.R, stlast, (const float*)(base + bw.idf), nullptr, 1, base + bw.out, nullptr));
     } else {
-      RC(bn(b.b2, (const float*)(base + bw.y2), b.R, bw.st2, nullptr, ain, 1, base + bw.out, nullptr));
+      RC(bn(*blast, ylast, b.R, stlast, nullptr, ain, 1, base + bw.out, nullptr));
     }
     ain = base + bw.out;
   }
   const Blk& last = d.blk.back();
-  RC(vdk_avgpool_fwd(ain, base + w.feat, d.B, d.Bp, last.c1.hout * last.c1.hout, d.wlast, s));
+  RC(vdk_avgpool_fwd(ain, base + w.feat, d.B, d.Bp, last.c2.hout * last.c2.hout, d.wlast, s));
   VdkGemmDesc g = {};
   g.A = base + w.feat; g.lda = d.wlast; g.B = (const bf16_t*)wb16 + d.fc_w; g.ldb = d.wlast; g.C = logits; g.ldc = d.Cp; g.M = d.B; g.N = d.Cp; g.K = d.wlast;
   g.c_dtype = VDK_F32; g.bias = params + d.fc_b; g.alpha = 1.0f; g.splitk = 1;
@@ -344,7 +372,7 @@ int vdk_resnet_backward(const VdkResNetConfig* cfg, const void* dlogits, const f
   };
   // fc: weight / bias gradient, feature gradient, average-pool backward
   const Blk& last = d.blk.back();
-  const int hw = last.c1.hout * last.c1.hout;
+  const int hw = last.c2.hout * last.c2.hout;
   RC(linear_wgrad(s, w, base, (const bf16_t*)dlogits, (const bf16_t*)(base + w.feat), d.B, d.Cp, d.wlast, grads + d.fc_w, grads + d.fc_b));
   {
     VdkGemmDesc g = {};
@@ -358,10 +386,20 @@ int vdk_resnet_backward(const VdkResNetConfig* cfg, const void* dlogits, const f
   for (int i = (int)d.blk.size() - 1; i >= 0; --i) {
     const Blk& b = d.blk[i]; const BlkW& bw = w.blk[i];
     const void* ain = i > 0 ? base + w.blk[i - 1].out : base + w.ap;
-    RC(bnb(b.b2, (const float*)(base + bw.y2), da, base + bw.out, b.R, bw.st2, dres));          // dyb = dL/dy2, dres = masked dout (shortcut gradient)
-    RC(conv_wgrad(s, w, base, b.c2, d.B, dyb, base + bw.a1, grads + b.c2.w));
-    RC(conv_gemm(s, b.c2, d.B, true, dyb, xb + b.c2.wd, db, VDK_F32, nullptr));                 // db = dL/da1
-    RC(bnb(b.b1, (const float*)(base + bw.y1), db, base + bw.a1, b.R, bw.st1, nullptr));        // dyb = dL/dy1
+    if (b.bott) {
+      RC(bnb(b.b3, (const float*)(base + bw.y3), da, base + bw.out, b.R, bw.st3, dres));        // dyb = dL/dy3, dres = masked dout (shortcut gradient)
+      RC(conv_wgrad(s, w, base, b.c3, d.B, dyb, base + bw.a2, grads + b.c3.w));
+      RC(conv_gemm(s, b.c3, d.B, true, dyb, xb + b.c3.wd, db, VDK_F32, nullptr));               // db = dL/da2
+      RC(bnb(b.b2, (const float*)(base + bw.y2), db, base + bw.a2, b.R, bw.st2, nullptr));      // dyb = dL/dy2
+      RC(conv_wgrad(s, w, base, b.c2, d.B, dyb, base + bw.a1, grads + b.c2.w));
+      RC(conv_gemm(s, b.c2, d.B, true, dyb, xb + b.c2.wd, tmp, VDK_F32, nullptr));              // tmp = dL/da1 (rows at the block's input resolution)
+      RC(bnb(b.b1, (const float*)(base + bw.y1), tmp, base + bw.a1, b.Ra, bw.st1, nullptr));    // dyb = dL/dy1
+    } else {
+      RC(bnb(b.b2, (const float*)(base + bw.y2), da, base + bw.out, b.R, bw.st2, dres));        // dyb = dL/dy2, dres = masked dout (shortcut gradient)
+      RC(conv_wgrad(s, w, base, b.c2, d.B, dyb, base + bw.a1, grads + b.c2.w));
+      RC(conv_gemm(s, b.c2, d.B, true, dyb, xb + b.c2.wd, db, VDK_F32, nullptr));               // db = dL/da1
+      RC(bnb(b.b1, (const float*)(base + bw.y1), db, base + bw.a1, b.R, bw.st1, nullptr));      // dyb = dL/dy1
+    }
     RC(conv_wgrad(s, w, base, b.c1, d.B, dyb, ain, grads + b.c1.w));
     if (b.ds) {
       RC(conv_gemm(s, b.c1, d.B, true, dyb, xb + b.c1.wd, tmp, VDK_F32, nullptr));              // main-branch part of dL/d(block input)

@@ -25,9 +25,18 @@ class ResNetSpec:
     num_classes: int = 1000
     bn_eps: float = 1e-5
     bn_momentum: float = 0.1
+    mid: Tuple[int, int, int, int] = (0, 0, 0, 0)      # > 0: Bottleneck network, inner width of the 1x1 -> 3x3 -> 1x1 blocks; `widths` = block output channels
+    stem_width: int = 0                                # 0: widths[0] (BasicBlock) / 64 (Bottleneck)
 
 
-TIMM_RESNETS = {"resnet18": dict(depths=(2, 2, 2, 2)), "resnet34": dict(depths=(3, 4, 6, 3))}
+_BOTT = dict(widths=(256, 512, 1024, 2048))
+TIMM_RESNETS = {
+    "resnet18": dict(depths=(2, 2, 2, 2)), "resnet34": dict(depths=(3, 4, 6, 3)),
+    # Bottleneck family (timm / torchvision v1.5: stride on the 3x3); wide_resnet*_2: base_width 128 doubles the inner width (pet.yaml:15 lists wide_resnet101_2)
+    "resnet50": dict(depths=(3, 4, 6, 3), mid=(64, 128, 256, 512), **_BOTT), "resnet101": dict(depths=(3, 4, 23, 3), mid=(64, 128, 256, 512), **_BOTT),
+    "resnet152": dict(depths=(3, 8, 36, 3), mid=(64, 128, 256, 512), **_BOTT),
+    "wide_resnet50_2": dict(depths=(3, 4, 6, 3), mid=(128, 256, 512, 1024), **_BOTT), "wide_resnet101_2": dict(depths=(3, 4, 23, 3), mid=(128, 256, 512, 1024), **_BOTT),
+}
 
 
 class ResNetEngine:
@@ -67,7 +76,7 @@ class ResNetEngine:
     def _cfg(self, batch: int, img: Optional[int] = None, bn_momentum: Optional[float] = None) -> _abi.ResNetConfig:
         s = self.spec
         return _abi.ResNetConfig(batch, img or s.img_size, s.in_chans, (_abi.I32 * 4)(*s.widths), (_abi.I32 * 4)(*s.depths), s.num_classes, s.bn_eps,
-                                 s.bn_momentum if bn_momentum is None else bn_momentum)
+                                 s.bn_momentum if bn_momentum is None else bn_momentum, (_abi.I32 * 4)(*s.mid), s.stem_width)
 
     def _workspace(self, batch: int, img: int) -> torch.Tensor:
         """keyed on (batch, image size): the reference's progressive resizing (engine/vision_engine.py:181-222) changes the input resolution between
