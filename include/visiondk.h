@@ -132,6 +132,11 @@ int vdk_transpose_bf16(const void* in, int64_t ldi, int32_t R, int32_t C, void* 
                        int32_t in_row_group, float* colsum_partial, void* stream);
 
 
+/* N <= 256 keys: forward with the whole (batch, head) item in LDS and an exact (non-online) softmax, N <= 224: fused single-kernel backward
+ * (csrc/attention_small.hip); longer sequences: flash-style kernels (csrc/attention.hip).  on = 1 forces the long-sequence kernels at every N
+ * (A/B timing, tests), 0 the default routing, -1 hands the choice back to the VDK_ATTN_LEGACY environment variable. */
+int vdk_attention_force_legacy(int32_t on);
+
 /* timm Attention core: softmax(q k^T * scale) v per head, flash-style (the N x N matrix is never
  * written).  qkv: bf16 [B, N, 3, H, 64] = the fused qkv Linear output (row stride ld elements);
  * o: bf16 [B, N, H*64] (row stride ldo); lse: f32 [B, H, N] log-sum-exp saved for backward (NULL ok).

@@ -27,6 +27,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import bf16ops as ops   # fp32 mode = plain torch (bit-identical to F.linear / softmax / F.gelu); bf16_operands mode: see oracle/bf16ops.py
+
 
 class PatchEmbed(nn.Module):
     def __init__(self, patch_size: int, in_chans: int, embed_dim: int):
@@ -34,7 +36,14 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=True)
 
     def forward(self, x):
-        return self.proj(x).flatten(2).transpose(1, 2)
+        if ops.mode() == "fp32":
+            return self.proj(x).flatten(2).transpose(1, 2)
+        # the same stride == kernel convolution as a GEMM over (c, ky, kx) patches, bf16 operands; the bias gradient is the fp32 column sum
+        # (the engine derives it from the fp32 pos_embed gradient rows, csrc/vit_engine.hip)
+        p = self.proj.kernel_size[0]
+        B, Cc, H, W = x.shape
+        pt = x.reshape(B, Cc, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B, (H // p) * (W // p), Cc * p * p)
+        return ops.linear(pt, self.proj.weight.reshape(self.proj.out_channels, -1), self.proj.bias, bias_grad_unrounded=True)
 
 
 class Attention(nn.Module):
@@ -48,12 +57,10 @@ class Attention(nn.Module):
 
     def forward(self, x):
         B, N, C = x.shape
-        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
+        qkv = ops.q(ops.linear(x, self.qkv.weight, self.qkv.bias)).reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
         q, k, v = qkv.unbind(0)
-        attn = (q * self.scale) @ k.transpose(-2, -1)
-        attn = attn.softmax(dim=-1)
-        x = (attn @ v).transpose(1, 2).reshape(B, N, C)
-        return self.proj(x)
+        x = ops.q(ops.attention(q, k, v, self.scale)).transpose(1, 2).reshape(B, N, C)
+        return ops.linear(x, self.proj.weight, self.proj.bias)
 
 
 class Mlp(nn.Module):
@@ -64,7 +71,7 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden, dim)
 
     def forward(self, x):
-        return self.fc2(self.act(self.fc1(x)))
+        return ops.linear(ops.gelu(ops.linear(x, self.fc1.weight, self.fc1.bias)), self.fc2.weight, self.fc2.bias)
 
 
 class Block(nn.Module):
@@ -76,8 +83,8 @@ class Block(nn.Module):
         self.mlp = Mlp(dim, mlp_dim)
 
     def forward(self, x):
-        x = x + self.attn(self.norm1(x))
-        return x + self.mlp(self.norm2(x))
+        x = x + self.attn(ops.q(self.norm1(x)))
+        return x + self.mlp(ops.q(self.norm2(x)))
 
 
 class VisionTransformerRef(nn.Module):
@@ -115,7 +122,13 @@ class VisionTransformerRef(nn.Module):
         return self.norm(x)
 
     def forward(self, x):
-        return self.head(self.forward_features(x)[:, 0])
+        if ops.mode() == "fp32":
+            return self.head(self.forward_features(x)[:, 0])
+        # LayerNorm is per token: norm(x)[:, 0] == norm(x[:, 0]); the engine normalises the class-token rows only
+        x = self.patch_embed(x)
+        x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embed
+        x = self.blocks(x)
+        return ops.linear(ops.q(self.norm(x[:, 0])), self.head.weight, self.head.bias)
 
 
 def train_step_reference(model: nn.Module, x, y, *, lr, momentum, weight_decay, label_smoothing, max_norm=10.0,

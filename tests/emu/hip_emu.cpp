@@ -57,8 +57,20 @@ static StackPool g_pools[256];
 static thread_local int g_slot = 0;
 static std::mutex g_launch_mu;
 
+static const size_t kDynLds = 160 * 1024;
+static thread_local unsigned char* g_dyn = nullptr;
+unsigned char* dyn_lds() {
+  if (!g_dyn) { if (posix_memalign((void**)&g_dyn, 256, kDynLds)) abort(); }
+  return g_dyn;
+}
+
 void run_block(Block& b) {
   g_blk = &b;
+  if (b.dyn_lds_bytes) {
+    if (b.dyn_lds_bytes > kDynLds) { fprintf(stderr, "[hip_emu] dynamic LDS request %zu > 160 KB\n", b.dyn_lds_bytes); abort(); }
+    unsigned short* p = (unsigned short*)dyn_lds();
+    for (size_t i = 0; i < kDynLds / 2; ++i) p[i] = 0x7fc0;   // bf16 NaN (0x7fc07fc0 is an f32 NaN too)
+  }
   int n = (int)(b.bdim.x * b.bdim.y * b.bdim.z);
   b.fibers.assign(n, Fiber());
   b.waves.assign((n + 63) / 64, Wave());
@@ -98,7 +110,7 @@ void run_block(Block& b) {
   g_blk = nullptr;
 }
 
-void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+void launch(dim3 grid, dim3 block, const std::function<void()>& body, size_t dyn_lds_bytes) {
   size_t total = (size_t)grid.x * grid.y * grid.z;
   if (total == 0) return;
   unsigned nthr = std::thread::hardware_concurrency();
@@ -111,7 +123,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   auto worker = [&](int slot) {
     g_slot = slot;
     Block b;
-    b.bdim = block; b.gdim = grid; b.body = &body;
+    b.bdim = block; b.gdim = grid; b.body = &body; b.dyn_lds_bytes = dyn_lds_bytes;
     for (;;) {
       size_t i = next.fetch_add(1);
       if (i >= total) break;

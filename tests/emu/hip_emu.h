@@ -112,6 +112,7 @@ struct Block {
   const std::function<void()>* body = nullptr;
   Fiber* cur = nullptr;
   bool progress = false;
+  size_t dyn_lds_bytes = 0;
 };
 
 extern thread_local Block* g_blk;
@@ -132,7 +133,8 @@ inline void wave_barrier() { Wave& w = wave(); barrier_wait(w.bar, w.alive); }
 
 void fiber_entry();
 void run_block(Block& b);
-void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void launch(dim3 grid, dim3 block, const std::function<void()>& body, size_t dyn_lds_bytes = 0);
+unsigned char* dyn_lds();
 
 }  // namespace emu
 
@@ -142,7 +144,12 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 #define gridDim (emu::g_blk->gdim)
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
-  emu::launch((grid), (block), [=]() { kern(__VA_ARGS__); })
+  emu::launch((grid), (block), [=]() { kern(__VA_ARGS__); }, (size_t)(shmem))
+// dynamic LDS (`extern __shared__`): one 160 KB arena per worker thread, poisoned with bf16 NaNs before every workgroup so that reads of
+// never-written LDS show up in the parity tests instead of passing on stale data
+#define VDK_DYN_LDS(name) unsigned char* const name = emu::dyn_lds()
+#define hipFuncAttributeMaxDynamicSharedMemorySize 8
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
 
 static inline void __syncthreads() { emu::block_barrier(); }
 

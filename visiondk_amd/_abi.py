@@ -85,6 +85,7 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(I64), C.POINTER(C.c_double)]),
     "vdk_prof_bytes": (C.c_int, [C.POINTER(C.c_double)]),
     "vdk_transpose_bf16": (C.c_int, [P, I64, I32, I32, P, I64, I32, I32, P, P]),
+    "vdk_attention_force_legacy": (C.c_int, [I32]),
     "vdk_attention_fwd": (C.c_int, [P, I64, P, I64, P, I32, I32, I32, I32, F32, P]),
     "vdk_attention_bwd": (C.c_int, [P, I64, P, P, I64, P, P, I64, P, I32, I32, I32, I32, F32, P]),
     "vdk_layernorm_fwd": (C.c_int, [P, I64, I32, I32, P, P, F32, P, I64, I32, P, P, P]),

@@ -378,7 +378,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   }
 }
 
+// short sequences (attention_small.hip): everything of one (batch, head) item in LDS, exact softmax, fused backward
+int vdk_attention_small_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H, float scale, void* stream);
+int vdk_attention_small_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv, int64_t ldd, int32_t B, int32_t N, int32_t H,
+                            float scale, void* stream);
+static int g_attn_legacy = -1;   // -1: env VDK_ATTN_LEGACY decides; 0 / 1: forced by vdk_attention_force_legacy (A/B benchmarking, tests of the long-sequence kernels at small N)
+static bool attn_legacy() {
+  if (g_attn_legacy >= 0) return g_attn_legacy == 1;
+  const char* e = getenv("VDK_ATTN_LEGACY");
+  return e && e[0] == '1';
+}
+
 extern "C" {
+
+int vdk_attention_force_legacy(int32_t on) { g_attn_legacy = on < 0 ? -1 : (on ? 1 : 0); return VDK_OK; }
 
 // qkv: bf16 [B, N, 3, H, 64] (timm's fused qkv Linear output, row stride ld = 3*H*64); o: bf16 [B, N, H*64];
 // lse: f32 [B, H, N] (saved for backward; may be NULL for inference).
@@ -387,6 +400,10 @@ int vdk_attention_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* 
   if (!qkv || !o || B <= 0 || N <= 0 || H <= 0) return vdk_fail(VDK_EINVAL, "vdk_attention_fwd: bad argument");
   if (head_dim != A_HD) return vdk_fail(VDK_EUNSUPPORTED, "vdk_attention_fwd: head_dim must be 64");
   if ((ld & 7) || (ldo & 7)) return vdk_fail(VDK_EINVAL, "vdk_attention_fwd: ld % 8");
+  if (N <= 256 && !attn_legacy()) {
+    const int rc = vdk_attention_small_fwd(qkv, ld, o, ldo, lse, B, N, H, scale, stream);
+    if (rc != VDK_EUNSUPPORTED) return rc ? rc : vdk_check_launch("vdk_attention_fwd");
+  }
   const bf16_t* base = (const bf16_t*)qkv;
   const long D = (long)H * A_HD;
   int grid = B * H;
@@ -405,6 +422,10 @@ int vdk_attention_bwd(const void* qkv, int64_t ld, const void* o, const void* do
   if (!qkv || !o || !dout || !lse || !dqkv || !dvec || B <= 0 || N <= 0 || H <= 0) return vdk_fail(VDK_EINVAL, "vdk_attention_bwd: bad argument");
   if (head_dim != A_HD) return vdk_fail(VDK_EUNSUPPORTED, "vdk_attention_bwd: head_dim must be 64");
   if ((ld & 7) || (ldo & 7) || (lddqkv & 7)) return vdk_fail(VDK_EINVAL, "vdk_attention_bwd: ld % 8");
+  if (N <= 224 && !attn_legacy()) {
+    const int rc = vdk_attention_small_bwd(qkv, ld, o, dout, ldo, lse, dqkv, lddqkv, B, N, H, scale, stream_);
+    if (rc != VDK_EUNSUPPORTED) return rc ? rc : vdk_check_launch("vdk_attention_bwd");
+  }
   const bf16_t* base = (const bf16_t*)qkv;
   bf16_t* dbase = (bf16_t*)dqkv;
   const long D = (long)H * A_HD;

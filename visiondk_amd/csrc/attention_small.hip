@@ -1,0 +1,402 @@
+// attention_small.hip — K3 for short sequences (N <= 256 keys: ViT-B/16 at 224 has N = 197): the whole (batch, head) problem lives in one CU's LDS.
+// Same operator as attention.hip (timm `Attention`: softmax(q k^T / sqrt(hd)) v behind models/classifier/classify_model.py:49-54 and
+// models/faceX/backbone/timm_wrapper.py:16-21), different structure:
+//
+//   * operands arrive by LDS-DMA (global_load_lds_dwordx4, 8 rows of 128 B per wave-instruction): no staging registers, so the kernels stay
+//     under 256 VGPRs and keep two waves per SIMD (the register-prefetching forward of attention.hip sat at 270 registers = ONE wave per SIMD, i.e.
+//     no overlap at all between one (batch, head) item's loads and another's MFMAs: 153 us per layer against a 62 us HBM floor);
+//   * the 16-byte chunk c of row r is stored at chunk position c ^ f(r), f(r) = 4*bit1(r) + bits3:2(r) (swizzle on the DMA's SOURCE address,
+//     cdna_hip_programming.md rule 21): conflict-free both for ds_read_b128 row fragments and for ds_read_b64_tr_b16 transposed fragments
+//     (tools/lds_banks.py prints the bank multiplicities);
+//   * FORWARD keeps all of S^T = K Q^T for a 32-query tile in registers (16 * NKT accumulators), so the softmax is the textbook one:
+//     exact row maximum, P normalised in fp32 and rounded to bf16 ONCE as the operand of P V — the rounding point autocast has in the reference
+//     (engine/procedure/train.py:118) and the one oracle/bf16ops.py restates; no online rescale, no data-dependent branch;
+//   * BACKWARD is ONE kernel with 5 GEMM-equivalents per (query tile, key tile) block instead of two kernels with 7: a wave owns a key tile (dK, dV
+//     accumulate in its registers over the query tiles); dS is handed through a wave-private 2 KB LDS tile to become the B operand of
+//     dQ^T += K^T dS^T, and dQ accumulates in an fp32 LDS tile per query tile.  The waves walk the query tiles staggered (wave w takes tile
+//     (w + t) mod n in step t), so no two waves touch the same dQ tile inside a step: no atomics, a fixed summation order, bit-reproducible.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include "vdk_device.h"
+#include "vdk_host.h"
+
+#define AS_ROW 128   // bytes per staged row: 64 bf16
+
+__device__ __forceinline__ int as_f(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+
+// rows [0, R8) of a [N, 64] bf16 operand (row stride ld elements) -> arr, 8 rows per wave-instruction, rows >= N read row N-1 (finite filler)
+__device__ __forceinline__ void as_dma_rows(unsigned char* arr, const bf16_t* __restrict__ src, long ld, int N, int R8, int w, int nw, int lane) {
+  for (int j = w; j < (R8 >> 3); j += nw) {
+    const int row = 8 * j + (lane >> 3);
+    const int c = (lane & 7) ^ as_f(row);
+    const int srow = row < N ? row : N - 1;
+    const bf16_t* g = src + (long)srow * ld + c * 8;
+    __builtin_amdgcn_global_load_lds(VDK_GLOBAL_PTR(g), VDK_LDS_PTR(arr + j * 1024), 16, 0, 0);
+  }
+}
+// MFMA A/B fragment of a row-major staged tile: lane (row, hi) -> the 16 bytes at k = 16*ks + 8*hi
+__device__ __forceinline__ s16x8 as_row_frag(const unsigned char* arr, int row, int ks, int hi) {
+  return *(const s16x8*)(arr + row * AS_ROW + (((2 * ks + hi) ^ as_f(row)) << 4));
+}
+// transposed fragment: lane (column d0 + (lane & 31), hi) gets rows t1 + 4*hi + {0..3} in slots 0..3 and the same + 8 in slots 4..7 (the permuted
+// contraction order that makes an MFMA C-layout tile directly usable as the other operand, see attention.hip)
+__device__ __forceinline__ s16x8 as_tr_frag(const unsigned char* arr, int t1, int d0, int lane) {
+  const int s = lane & 15, chalf = (lane >> 4) & 1, hi = lane >> 5;
+  const int r1 = t1 + 4 * hi + (s >> 2), r2 = r1 + 8;
+  const int byte = 2 * d0 + 32 * chalf + 8 * (s & 3);
+  const unsigned char* p1 = arr + r1 * AS_ROW + (((byte >> 4) ^ as_f(r1)) << 4) + (byte & 8);
+  const unsigned char* p2 = arr + r2 * AS_ROW + (((byte >> 4) ^ as_f(r2)) << 4) + (byte & 8);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(p1));
+  s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(p2));
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+  return r;
+}
+__device__ __forceinline__ f32x16 as_zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+// 16 C-layout values -> the two B-operand fragments (k-slot j of step s <-> accumulator register 8*s + j)
+__device__ __forceinline__ void as_pack_b(const f32x16& p, s16x8 (&f)[2]) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    u32x4 u = {pack_bf2(p[8 * s + 0], p[8 * s + 1]), pack_bf2(p[8 * s + 2], p[8 * s + 3]), pack_bf2(p[8 * s + 4], p[8 * s + 5]), pack_bf2(p[8 * s + 6], p[8 * s + 7])};
+    f[s] = *(s16x8*)&u;
+  }
+}
+// a wave's 32 x 64 bf16 output tile (C-layout of a transposed product: lane = row, registers = 4 consecutive columns per group) -> its private 4 KB
+// LDS tile (16-byte chunk ^ (row & 7)) -> 128-byte coalesced global rows
+__device__ __forceinline__ void as_store_tile(unsigned char* tile, const f32x16& x0, const f32x16& x1, float mul, bf16_t* __restrict__ dst, long ld, int row0, int N,
+                                              int lane) {
+  const int l31 = lane & 31, hi = lane >> 5;
+  if (row0 + l31 < N) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ch = g ^ (l31 & 7), ch1 = (4 + g) ^ (l31 & 7);
+      *(u32x2*)(tile + l31 * AS_ROW + (ch << 4) + 8 * hi) = (u32x2){pack_bf2(x0[4 * g] * mul, x0[4 * g + 1] * mul), pack_bf2(x0[4 * g + 2] * mul, x0[4 * g + 3] * mul)};
+      *(u32x2*)(tile + l31 * AS_ROW + (ch1 << 4) + 8 * hi) = (u32x2){pack_bf2(x1[4 * g] * mul, x1[4 * g + 1] * mul), pack_bf2(x1[4 * g + 2] * mul, x1[4 * g + 3] * mul)};
+    }
+  }
+  VDK_WAVE_LDS_SYNC();
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = 8 * p + (lane >> 3), cp = lane & 7;
+    if (row0 + r < N) {
+      const u32x4 v = *(const u32x4*)(tile + r * AS_ROW + ((cp ^ (r & 7)) << 4));
+      *(u32x4*)(dst + (long)(row0 + r) * ld + cp * 8) = v;
+    }
+  }
+  VDK_WAVE_LDS_SYNC();
+}
+
+// =====================================================================================  forward
+// LDS (dynamic): Q [R8 rows] | K [R8] | V [R8] | zero rows up to 32*NKT of the V array.  R8 = N rounded up to 8.  Tile reads beyond R8 fall into the
+// next array (finite data whose contribution is masked) or into the zero rows (V: P is exactly 0 there).  A wave's O tile is staged in its own Q rows.
+template <int NKT>
+__global__ __launch_bounds__(256, (NKT <= 7 ? 2 : 1)) void attn_s_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld,
+                                                                              bf16_t* __restrict__ o, long ldo, float* __restrict__ lse, int N, int H, float scale, int nitems) {
+  VDK_DYN_LDS(smem);
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int R8 = (N + 7) & ~7;
+  unsigned char* const Qs = smem;
+  unsigned char* const Ks = smem + R8 * AS_ROW;
+  unsigned char* const Vs = smem + 2 * R8 * AS_ROW;
+  for (int i = tid * 16; i < (32 * NKT - R8) * AS_ROW; i += 256 * 16) *(u32x4*)(Vs + R8 * AS_ROW + i) = (u32x4){0u, 0u, 0u, 0u};
+  const int nqt = (N + 31) >> 5;
+  const float scale2 = scale * VDK_LOG2E;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / H, h = item - b * H;
+    const long off = (long)b * N * ld + h * 64;
+    __syncthreads();                                   // the previous item's readers are done (first pass: the zero rows are written)
+    as_dma_rows(Qs, q + off, ld, N, R8, w, 4, lane);
+    as_dma_rows(Ks, k + off, ld, N, R8, w, 4, lane);
+    as_dma_rows(Vs, v + off, ld, N, R8, w, 4, lane);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's DMAs have landed
+    __syncthreads();
+    for (int qt = w; qt < nqt; qt += 4) {
+      const int qrow = qt * 32 + l31;
+      s16x8 qf[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) qf[ks] = as_row_frag(Qs, qrow, ks, hi);
+      f32x16 st[NKT];
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        st[kt] = as_zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag(Ks, kt * 32 + l31, ks, hi), qf[ks], st[kt], 0, 0, 0);
+      }
+      if (N & 31) {                                    // ragged last key tile (wave-uniform)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if ((NKT - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= N) st[NKT - 1][r] = -INFINITY;
+      }
+      float m = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, st[kt][r]);
+      m = fmaxf(m, __shfl_xor(m, 32));                 // the two half-waves hold the same queries, different keys
+      const float m2 = m * scale2;
+      float l = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float p = fast_exp2(fmaf(st[kt][r], scale2, -m2)); st[kt][r] = p; l += p; }
+      l += __shfl_xor(l, 32);
+      const float inv = 1.0f / l;
+      f32x16 o0 = as_zero16(), o1 = as_zero16();
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        f32x16 pn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pn[r] = st[kt][r] * inv;
+        s16x8 pf[2];
+        as_pack_b(pn, pf);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Vs, kt * 32 + 16 * s, 0, lane), pf[s], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Vs, kt * 32 + 16 * s, 32, lane), pf[s], o1, 0, 0, 0);
+        }
+      }
+      as_store_tile(Qs + qt * 32 * AS_ROW, o0, o1, 1.0f, o + (long)b * N * ldo + h * 64, ldo, qt * 32, N, lane);
+      if (lse && hi == 0 && qrow < N) lse[((long)b * H + h) * N + qrow] = (m2 + log2f(l)) * 0.6931471805599453f;
+    }
+  }
+}
+
+// =====================================================================================  backward (fused)
+// 512 threads, one workgroup per CU.  LDS (dynamic): Q [R8] | dO [R8] | zero rows up to 32*NKT of the dO array | 8 wave tiles of 4 KB (a wave's K tile,
+// then its dS^T hand-off tile, then its dK / dV store tile) | dQ f32 [32*NKT][64] (chunk ^ (row & 15)) | lse2 [32*NKT] | D [32*NKT].
+template <int NKT>
+__global__ __launch_bounds__(512, 2) void attn_s_bwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld,
+                                                            const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, long ldo, const float* __restrict__ lse,
+                                                            bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long ldd, int N, int H, float scale,
+                                                            int nitems) {
+  VDK_DYN_LDS(smem);
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int R8 = (N + 7) & ~7;
+  constexpr int NP = 32 * NKT;
+  unsigned char* const Qs = smem;
+  unsigned char* const Os = smem + R8 * AS_ROW;                       // dO rows, then zero rows up to NP
+  unsigned char* const Wt = smem + (R8 + NP) * AS_ROW + w * 4096;     // this wave's 4 KB tile
+  unsigned char* const dQs = smem + (R8 + NP) * AS_ROW + 8 * 4096;    // f32 [NP][64]
+  float* const lse2 = (float*)(dQs + NP * 256);
+  float* const Dv = lse2 + NP;
+  for (int i = tid * 16; i < (NP - R8) * AS_ROW; i += 512 * 16) *(u32x4*)(Os + R8 * AS_ROW + i) = (u32x4){0u, 0u, 0u, 0u};
+  const int nt = (N + 31) >> 5;                                       // query tiles == key tiles
+  const bool act = w < nt;                                            // wave w owns key tile w
+  const float scale2 = scale * VDK_LOG2E;
+  const int krow = w * 32 + l31;
+  const bool ragged = (N & 31) != 0;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / H, h = item - b * H;
+    const long off = (long)b * N * ld + h * 64, offo = (long)b * N * ldo + h * 64;
+    __syncthreads();                                                  // everything of the previous item has left the LDS
+    as_dma_rows(Qs, q + off, ld, N, R8, w, 8, lane);
+    as_dma_rows(Os, dout + offo, ldo, N, R8, w, 8, lane);
+    s16x8 kf[4], vf[4];
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                                   // own K tile: 32 rows = 4 DMA instructions
+        const int row = w * 32 + 8 * j + (lane >> 3), lrow = 8 * j + (lane >> 3);
+        const int c = (lane & 7) ^ as_f(lrow);
+        const bf16_t* g = k + off + (long)(row < N ? row : N - 1) * ld + c * 8;
+        __builtin_amdgcn_global_load_lds(VDK_GLOBAL_PTR(g), VDK_LDS_PTR(Wt + j * 1024), 16, 0, 0);
+      }
+      const long kr = (long)(krow < N ? krow : N - 1) * ld;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = *(const s16x8*)(k + off + kr + ks * 16 + hi * 8);
+        vf[ks] = *(const s16x8*)(v + off + kr + ks * 16 + hi * 8);
+      }
+    }
+    // D = rowsum(dO * O) needs O once: 8 threads per row, 16 bytes each, NP rows over 512 threads
+    u32x4 opiece[(NP * 8 + 511) / 512];
+#pragma unroll
+    for (int p = 0; p < (NP * 8 + 511) / 512; ++p) {
+      const int id = tid + 512 * p, row = id >> 3;
+      opiece[p] = (u32x4){0u, 0u, 0u, 0u};
+      if (row < N) opiece[p] = *(const u32x4*)(o + offo + (long)row * ldo + (id & 7) * 8);
+    }
+    for (int i = tid; i < NP; i += 512) lse2[i] = i < N ? lse[((long)b * H + h) * N + i] * VDK_LOG2E : 0.f;
+    for (int i = tid * 16; i < NP * 256; i += 512 * 16) *(f32x4*)(dQs + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < (NP * 8 + 511) / 512; ++p) {
+      const int id = tid + 512 * p, row = id >> 3, cp = id & 7;
+      float d = 0.f;
+      if (row < NP) {
+        const u32x4 a = *(const u32x4*)(Os + row * AS_ROW + ((cp ^ as_f(row)) << 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { d = fmaf(bf_lo(a[e]), bf_lo(opiece[p][e]), d); d = fmaf(bf_hi(a[e]), bf_hi(opiece[p][e]), d); }
+      }
+      d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
+      if (row < NP && cp == 0) Dv[row] = row < N ? d : 0.f;
+    }
+    s16x8 kT[2][2];
+    if (act) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) { kT[s][0] = as_tr_frag(Wt, 16 * s, 0, lane); kT[s][1] = as_tr_frag(Wt, 16 * s, 32, lane); }
+    }
+    __syncthreads();                                                  // D is complete; K^T fragments are in registers (the wave tile is free)
+    f32x16 gk0 = as_zero16(), gk1 = as_zero16(), gv0 = as_zero16(), gv1 = as_zero16();
+    for (int t = 0; t < nt; ++t) {
+      if (act) {
+        int qt = w + t; if (qt >= nt) qt -= nt;
+        const int q0 = qt * 32;
+        f32x16 st = as_zero16(), dp = as_zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag(Qs, q0 + l31, ks, hi), kf[ks], st, 0, 0, 0);   // S[q][key]
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag(Os, q0 + l31, ks, hi), vf[ks], dp, 0, 0, 0);   // dP[q][key]
+        }
+        f32x16 pv, ds;
+        const bool edge = ragged && (qt == nt - 1 || w == nt - 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 lv = *(const f32x4*)(lse2 + q0 + 8 * g + 4 * hi);
+          const f32x4 dd = *(const f32x4*)(Dv + q0 + 8 * g + 4 * hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            float p = fast_exp2(fmaf(st[r], scale2, -lv[e]));
+            if (edge && (q0 + 8 * g + 4 * hi + e >= N || krow >= N)) p = 0.f;
+            pv[r] = p;
+            ds[r] = p * (dp[r] - dd[e]);
+          }
+        }
+        s16x8 pf[2], df[2];
+        as_pack_b(pv, pf);
+        as_pack_b(ds, df);
+        // dS^T hand-off tile [key][q], 64-byte rows, 16-byte chunk ^ ((key >> 1) & 3): lane = key row, 4 consecutive queries per 8-byte store
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const u32x4 u0 = *(const u32x4*)&df[g >> 1];
+          const int e0 = (g & 1) * 2;
+          *(u32x2*)(Wt + l31 * 64 + ((g ^ ((l31 >> 1) & 3)) << 4) + 8 * hi) = (u32x2){u0[e0], u0[e0 + 1]};
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          gv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Os, q0 + 16 * s, 0, lane), pf[s], gv0, 0, 0, 0);     // dV^T[d][key] += dO^T P
+          gv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Os, q0 + 16 * s, 32, lane), pf[s], gv1, 0, 0, 0);
+          gk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Qs, q0 + 16 * s, 0, lane), df[s], gk0, 0, 0, 0);     // dK^T[d][key] += Q^T dS
+          gk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Qs, q0 + 16 * s, 32, lane), df[s], gk1, 0, 0, 0);
+        }
+        VDK_WAVE_LDS_SYNC();
+        f32x16 a0 = as_zero16(), a1 = as_zero16();                    // dQ^T[d][q] partial of this key tile
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          // B fragment: lane (q = l31, hi) <- keys 16s + 4hi + {0..3} and + 8 of column q
+          const int sl = lane & 15, chalf = (lane >> 4) & 1;
+          const int r1 = 16 * s + 4 * hi + (sl >> 2), r2 = r1 + 8;
+          const int byte = 32 * chalf + 8 * (sl & 3);
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(Wt + r1 * 64 + (((byte >> 4) ^ ((r1 >> 1) & 3)) << 4) + (byte & 8)));
+          s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(Wt + r2 * 64 + (((byte >> 4) ^ ((r2 >> 1) & 3)) << 4) + (byte & 8)));
+          const s16x8 bt = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+          a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[s][0], bt, a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[s][1], bt, a1, 0, 0, 0);
+        }
+        VDK_WAVE_LDS_SYNC();                                          // the hand-off tile may be rewritten in the next step
+        unsigned char* drow = dQs + (q0 + l31) * 256;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4* p0 = (f32x4*)(drow + (((2 * g + hi) ^ (l31 & 15)) << 4));
+          f32x4* p1 = (f32x4*)(drow + (((8 + 2 * g + hi) ^ (l31 & 15)) << 4));
+          f32x4 x0 = *p0, x1 = *p1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { x0[e] += a0[4 * g + e]; x1[e] += a1[4 * g + e]; }
+          *p0 = x0; *p1 = x1;
+        }
+      }
+      __syncthreads();                                                // step boundary: the dQ tiles change hands
+    }
+    // ---- outputs: dK, dV from registers through the wave tile; dQ from the fp32 LDS tile -----------------------------------------------
+    if (act) {
+      as_store_tile(Wt, gk0, gk1, scale, dk + (long)b * N * ldd + h * 64, ldd, w * 32, N, lane);
+      as_store_tile(Wt, gv0, gv1, 1.0f, dv + (long)b * N * ldd + h * 64, ldd, w * 32, N, lane);
+    }
+    for (int id = tid; id < N * 8; id += 512) {
+      const int row = id >> 3, cp = id & 7;                          // 8 columns: f32 chunks 2cp, 2cp+1
+      const f32x4 x0 = *(const f32x4*)(dQs + row * 256 + (((2 * cp) ^ (row & 15)) << 4));
+      const f32x4 x1 = *(const f32x4*)(dQs + row * 256 + (((2 * cp + 1) ^ (row & 15)) << 4));
+      *(u32x4*)(dq + (long)b * N * ldd + h * 64 + (long)row * ldd + cp * 8) =
+          (u32x4){pack_bf2(x0[0] * scale, x0[1] * scale), pack_bf2(x0[2] * scale, x0[3] * scale), pack_bf2(x1[0] * scale, x1[1] * scale), pack_bf2(x1[2] * scale, x1[3] * scale)};
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+template <int NKT>
+static int launch_fwd(const bf16_t* base, long D, long ld, bf16_t* o, long ldo, float* lse, int B, int N, int H, float scale, int grid, hipStream_t s) {
+  const int R8 = (N + 7) & ~7;
+  const size_t lds = (size_t)(2 * R8 + 32 * NKT) * AS_ROW;
+  if (hipFuncSetAttribute((const void*)attn_s_fwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return vdk_fail(VDK_ELAUNCH, "vdk_attention_fwd: LDS attribute");
+  hipLaunchKernelGGL((attn_s_fwd_kernel<NKT>), dim3((unsigned)grid), dim3(256), lds, s, base, base + D, base + 2 * D, ld, o, ldo, lse, N, H, scale, B * H);
+  return VDK_OK;
+}
+template <int NKT>
+static int launch_bwd(const bf16_t* base, long D, long ld, const bf16_t* o, const bf16_t* dout, long ldo, const float* lse, bf16_t* dbase, long ldd, int B, int N, int H,
+                      float scale, int grid, hipStream_t s) {
+  const int R8 = (N + 7) & ~7, NP = 32 * NKT;
+  const size_t lds = (size_t)(R8 + NP) * AS_ROW + 8 * 4096 + (size_t)NP * 256 + (size_t)NP * 8;
+  if (hipFuncSetAttribute((const void*)attn_s_bwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return vdk_fail(VDK_ELAUNCH, "vdk_attention_bwd: LDS attribute");
+  hipLaunchKernelGGL((attn_s_bwd_kernel<NKT>), dim3((unsigned)grid), dim3(512), lds, s, base, base + D, base + 2 * D, ld, o, dout, ldo, lse, dbase, dbase + D, dbase + 2 * D, ldd,
+                     N, H, scale, B * H);
+  return VDK_OK;
+}
+
+static int grid_cap(int dflt) {
+  if (const char* e = getenv("VDK_ATTN_GRID")) { const int v = atoi(e); if (v > 0) return v; }   // tests: force several items per workgroup
+  return dflt;
+}
+
+// in-library entry points (attention.hip routes N <= 256 / N <= 224 here); return VDK_EUNSUPPORTED to let the caller fall back
+int vdk_attention_small_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H, float scale, void* stream) {
+  const int nkt = (N + 31) / 32;
+  if (nkt < 1 || nkt > 8) return VDK_EUNSUPPORTED;
+  const bf16_t* base = (const bf16_t*)qkv;
+  const long D = (long)H * 64;
+  int grid = B * H;
+  const int cap = grid_cap(512);
+  if (grid > cap) grid = cap;
+  hipStream_t s = (hipStream_t)stream;
+  switch (nkt) {
+    case 1: return launch_fwd<1>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s);
+    case 2: return launch_fwd<2>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s);
+    case 3: return launch_fwd<3>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s);
+    case 4: return launch_fwd<4>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s);
+    case 5: return launch_fwd<5>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s);
+    case 6: return launch_fwd<6>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s);
+    case 7: return launch_fwd<7>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s);
+    default: return launch_fwd<8>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s);
+  }
+}
+
+int vdk_attention_small_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv, int64_t ldd, int32_t B, int32_t N, int32_t H,
+                            float scale, void* stream) {
+  const int nkt = (N + 31) / 32;
+  if (nkt < 1 || nkt > 7) return VDK_EUNSUPPORTED;
+  const bf16_t* base = (const bf16_t*)qkv;
+  const long D = (long)H * 64;
+  int grid = B * H;
+  const int cap = grid_cap(256);
+  if (grid > cap) grid = cap;
+  hipStream_t s = (hipStream_t)stream;
+#define BW(n) launch_bwd<n>(base, D, ld, (const bf16_t*)o, (const bf16_t*)dout, ldo, lse, (bf16_t*)dqkv, ldd, B, N, H, scale, grid, s)
+  switch (nkt) {
+    case 1: return BW(1);
+    case 2: return BW(2);
+    case 3: return BW(3);
+    case 4: return BW(4);
+    case 5: return BW(5);
+    case 6: return BW(6);
+    default: return BW(7);
+  }
+#undef BW
+}

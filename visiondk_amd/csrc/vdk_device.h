@@ -23,6 +23,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define VDK_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #endif
 
+// dynamic LDS region of a kernel (16-byte aligned base, cdna_hip_programming.md G17); the test emulator substitutes a per-thread arena
+#ifndef VDK_DYN_LDS
+#define VDK_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+
 // ds_read_b64_tr_b16 (gfx950 LDS transpose read).  Measured semantics (tools/probes/tr_probe.hip): within each 16-lane
 // group, lane i receives element (i % 4) of the 8-byte chunks addressed by lanes i/4, 4 + i/4, 8 + i/4, 12 + i/4.
 // tr_frag8() builds an MFMA 32x32x16 A/B fragment from a ROW-major tile X[t][c] (pitch in elements): lane (l & 31 = column
