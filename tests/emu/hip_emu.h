@@ -318,6 +318,7 @@ static inline emu_s16x4 emu_ds_read_tr16_b64(const void* p) {
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu_ds_read_tr16_b64((const void*)(p))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define VDK_WAVE_LDS_SYNC() emu::wave_barrier()
+#define VDK_LDS_ADD_F32(p, v) (*(p) += (v))
 #define VDK_READLANE(v, l) __shfl((int)(v), (l))
 #define __builtin_readcyclecounter() 0ull
 #define __builtin_amdgcn_wave_barrier() emu::wave_barrier()

@@ -1,0 +1,138 @@
+"""The data-parallel exchange on the REAL stack: torch.distributed backend "nccl" (= RCCL on ROCm) on the one MI355X a test box has, world_size 1.
+The reference's only parallelism is NCCL DDP (main.py:39-40, engine/vision_engine.py:313,510, train.py:157-159); the 2-rank gloo tests
+(tests/test_ddp_gloo.py) prove the arithmetic of the exchange on CPU, these prove that the stream-ordered GPU path executes: the gradient buckets are
+all-reduced by RCCL kernels on RCCL's stream, ordered against the backward kernels of the launch stream, while backward is still being enqueued.
+`GradAllReduce(always_communicate=True)` issues every collective although a one-rank group makes each an identity, so results must equal the
+communication-free step BIT FOR BIT."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rccl():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    t = torch.arange(8, dtype=torch.float32, device="cuda:0")
+    dist.all_reduce(t)                                   # the communicator is created lazily: make RCCL really come up here
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(8, dtype=torch.float32))
+    yield
+    dist.destroy_process_group()
+
+
+def test_vit_step_buckets_through_rccl_equal_the_plain_step(hip, rccl):
+    from tests.test_vit import SPEC
+    from visiondk_amd import comm, vit
+    res = []
+    for use_comm in (False, True):
+        model = vit.VisionTransformer(SPEC, device="cuda:0", backend=hip, seed=11)
+        c = comm.GradAllReduce(bucket_bytes=100_000, always_communicate=True) if use_comm else None      # small buckets: several collectives per backward
+        step = vit.FusedTrainStep(model, lr=0.01, label_smoothing=0.05, ema=True, comm=c)
+        torch.manual_seed(7)
+        for _ in range(3):
+            x = torch.randn(8, 3, 32, 32).cuda(); y = torch.randint(0, 10, (8,)).cuda()
+            step.step(x, y)
+        torch.cuda.synchronize()
+        res.append((model.engine.params.clone(), model.engine.grads.clone(), step.ema.clone(), step.loss_value()))
+        if use_comm:
+            assert c.collectives >= 1 + 3 * 3            # the parameter broadcast + at least 3 buckets per step
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2]) and res[0][3] == res[1][3]
+
+
+def test_vit_base_step_with_32mb_buckets_through_rccl(hip, rccl):
+    """the bench's geometry (ViT-B/16, 86.6 M parameters, 32 MB buckets) at batch 8"""
+    from visiondk_amd import comm, vit
+    res = []
+    for use_comm in (False, True):
+        model = vit.VisionTransformer(vit.spec_from_timm_name("vit_base_patch16_224", 1000), device="cuda:0", backend=hip, seed=3)
+        c = comm.GradAllReduce(always_communicate=True) if use_comm else None
+        step = vit.FusedTrainStep(model, lr=0.006, label_smoothing=0.05, ema=False, comm=c)
+        torch.manual_seed(9)
+        x = torch.randn(8, 3, 224, 224).cuda(); y = torch.randint(0, 1000, (8,)).cuda()
+        step.step(x, y); step.step(x, y)
+        torch.cuda.synchronize()
+        res.append(model.engine.params.clone())
+        if use_comm:
+            assert c.collectives >= 1 + 2 * 5             # one bucket closes every two layers (28 MB of gradients per layer) + the embeddings
+    assert torch.equal(res[0], res[1])
+
+
+def _face_model(be, seed, classes=24):
+    from visiondk_amd import convnext, face
+    convnext.TIMM_CONVNEXTS["convnext_test"] = dict(depths=(1, 1, 1, 1), dims=(8, 16, 24, 32))
+    cfg = {"task": "cbir", "image_size": 32, "backbone": {"timm-convnext_test": {"pretrained": False, "image_size": 32, "feat_dim": 64}},
+           "head": {"arcface": {"feat_dim": 64, "num_class": classes, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
+    torch.manual_seed(seed)
+    model = face.get_model(cfg, None, 0, backend=be, device="cuda:0").model.train()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("gamma"):
+                p.fill_(0.4)
+    return model
+
+
+@pytest.mark.parametrize("shard_head", [False, True])
+def test_face_step_through_rccl(hip, rccl, shard_head):
+    """FaceTrainStep(comm=...): backbone buckets + neck / head gradients + BatchNorm buffer broadcasts through RCCL; with shard_head the class-sharded margin
+    head (all-gathered features, three small all-reduces for the softmax across the shards, one for the feature gradient) on one rank holding all the classes."""
+    from visiondk_amd import comm, face
+    res = []
+    for use_comm in (False, True):
+        model = _face_model(hip, 21)
+        c = comm.GradAllReduce(bucket_bytes=20_000, always_communicate=True) if use_comm else None
+        step = face.FaceTrainStep(model, lr=0.05, momentum=0.9, weight_decay=5e-4, max_norm=10.0, ema=True, comm=c, shard_head=shard_head and use_comm)
+        torch.manual_seed(5)
+        for _ in range(2):
+            x = torch.randn(8, 3, 32, 32).cuda(); y = torch.randint(0, 24, (8,)).cuda()
+            rows = step.step(x, y)
+        if shard_head and use_comm:
+            step.gather_head()
+        torch.cuda.synchronize()
+        res.append(({k: v.clone() for k, v in model.state_dict().items()}, rows.clone()))
+    for k in res[0][0]:
+        a, b = res[0][0][k].float(), res[1][0][k].float()
+        if shard_head:      # the sharded head is a different kernel sequence (local statistics + global combine): same math, fp32 rounding differs
+            assert ((a - b).norm() / a.norm().clamp_min(1e-30)).item() < 2e-3, k
+        else:
+            assert torch.equal(a, b), k
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-4 if shard_head else 0, atol=0)
+
+
+def test_resnet_step_with_sync_batchnorm_through_rccl(hip, rccl):
+    """ResNetTrainStep(sync_bn=True): the (sum, sum of squares, count) / (sum g, sum g x^, count) vectors of every BatchNorm go through RCCL between the statistics kernel
+    and its consumer, in forward and backward (the reference's sync_bn flag, vision_engine.py:224-225).  One rank: the all-reduce is an identity."""
+    from visiondk_amd import comm, resnet
+    res = []
+    for use_comm in (False, True):
+        torch.manual_seed(31)
+        model = resnet.ResNet(resnet.ResNetSpec(img_size=32, num_classes=5, widths=(8, 8, 16, 16), depths=(1, 1, 1, 1)), device="cuda:0", backend=hip)
+        c = comm.GradAllReduce(bucket_bytes=10_000, always_communicate=True) if use_comm else None
+        step = resnet.ResNetTrainStep(model, lr=0.05, momentum=0.9, weight_decay=5e-4, loss="bce", ema=True, comm=c, sync_bn=use_comm)
+        torch.manual_seed(6)
+        for _ in range(2):
+            x = torch.randn(8, 3, 32, 32).cuda(); t = (torch.rand(8, 5) > 0.5).float().cuda()
+            step.step(x, t)
+        torch.cuda.synchronize()
+        res.append((model.engine.params.clone(), model.engine.buffers.clone(), step.ema_buffers.clone()))
+    for a, b in zip(res[0], res[1]):
+        assert ((a - b).norm() / a.norm()).item() < 1e-5
+
+
+def test_sharded_gallery_search_through_rccl(hip, rccl):
+    import numpy as np
+    from oracle import cbir as ocbir
+    from visiondk_amd import cbir
+    g = torch.Generator().manual_seed(3)
+    gal = torch.nn.functional.normalize(torch.randn(5000, 128, generator=g)); qry = torch.nn.functional.normalize(torch.randn(70, 128, generator=g))
+    s, i = cbir.search_sharded(qry.cuda(), gal.cuda(), k=100, idx_base=0, backend=hip, device="cuda:0")
+    so, io = ocbir.flat_ip_search(qry.numpy(), gal.numpy(), 100)
+    np.testing.assert_array_equal(i.cpu().numpy(), io)
+    np.testing.assert_array_equal(s.cpu().numpy().view("uint32"), so.view("uint32"))

@@ -118,6 +118,7 @@ def test_train_step_bce_matches_reference_update(be, dev):
     model.load_state_dict(ref.state_dict(), strict=True)
     lr, mom, wd, max_norm = 0.05, 0.9, 5e-4, 0.05
     step = resnet.ResNetTrainStep(model, lr=lr, momentum=mom, weight_decay=wd, loss="bce", max_norm=max_norm, ema=True)
+    buffers0 = model.engine.buffers.clone()
     opt = torch.optim.SGD(ref.parameters(), lr=lr, momentum=mom, weight_decay=wd)
     start = {n: p.detach().clone() for n, p in ref.named_parameters()}
     ema_ref = {n: p.detach().clone() for n, p in ref.named_parameters()}
@@ -142,6 +143,15 @@ def test_train_step_bce_matches_reference_update(be, dev):
     eng = model.engine
     name, off, numel, shape = eng.entries[3]
     assert _rel(step.ema[off:off + numel].view(shape), ema_ref[name]) < 1e-4
+    # ModelEMA averages every floating state_dict() entry (models/ema.py:28-37): the BatchNorm running statistics as well
+    d = 0.9999 * (1 - math.exp(-1 / 2000))
+    for (bn, boff, bnum, bshape) in eng.buffer_entries:
+        if bn.endswith("running_mean") or bn.endswith("running_var"):
+            init = buffers0[boff:boff + bnum].view(bshape).cpu()
+            live = eng.buffers[boff:boff + bnum].view(bshape).cpu()
+            exp = d * init + (1 - d) * live
+            assert torch.allclose(step.ema_buffers[boff:boff + bnum].view(bshape).cpu(), exp, rtol=1e-5, atol=1e-7), bn
+            assert (live - init).abs().max() > 1e-4                     # the statistics did move
 
 
 def test_progressive_resizing_other_resolution(be, dev):
@@ -239,6 +249,34 @@ def test_focal_switch_uses_the_reference_focal_loss(be, dev):
     at = t * 0.25 + (1 - t) * 0.75
     exp = (at * (1 - pt) ** 2.0 * bce).mean()
     assert abs(rows.sum().item() / 30 - exp.item()) < 4e-2 * abs(exp.item())
+
+
+def test_focal_loss_with_mixup_pair_is_evaluated_per_target(be, dev):
+    """focal(pred, t) is not linear in t: lam * focal(pred, y) + (1 - lam) * focal(pred, y_b) (mixup_criterion, train.py:34-35) != focal(pred, lam*y + (1-lam)*y_b)"""
+    model, ref = _pair(be, dev, widths=(8, 8, 16, 16), depths=(1, 1, 1, 1), img=32)
+    step = resnet.ResNetTrainStep(model, lr=0.0, momentum=0.0, weight_decay=0.0, loss="bce", ema=False)
+    step.set_focal(2.0, 0.25)
+    torch.manual_seed(5)
+    x = torch.randn(6, 3, 32, 32); ya = (torch.rand(6, 5) > 0.5).float(); yb = (torch.rand(6, 5) > 0.5).float(); lam = 0.3
+    rows = step.step(x.to(dev), ya.to(dev), yb.to(dev), lam)
+    ref.train()
+    out = ref(x)
+
+    def focal(t):
+        p = torch.sigmoid(out)
+        bce = torch.nn.functional.binary_cross_entropy_with_logits(out, t, reduction="none")
+        pt = t * p + (1 - t) * (1 - p)
+        at = t * 0.25 + (1 - t) * 0.75
+        return (at * (1 - pt) ** 2.0 * bce).mean()
+
+    exp = lam * focal(ya) + (1 - lam) * focal(yb)
+    folded = focal(lam * ya + (1 - lam) * yb)
+    assert abs(exp.item() - folded.item()) > 0.05 * abs(exp.item())          # the two forms really differ on this input
+    assert abs(rows.sum().item() / 30 - exp.item()) < 4e-2 * abs(exp.item())
+    exp.backward()
+    eng = model.engine
+    off, numel, shape = next((o, n, sh) for (nm, o, n, sh) in eng.entries if nm == "fc.weight")
+    assert _rel(eng.grads[off:off + numel].view(shape), ref.fc.weight.grad) < 8e-2
 
 
 def test_ohem_prepass_cnn_step(be, dev):

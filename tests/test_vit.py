@@ -223,3 +223,31 @@ def test_ohem_prepass_then_step_on_the_kept_samples(be, dev):
     assert rows.shape[0] == xs.shape[0] and torch.isfinite(rows).all()
     rows2 = step.step(x.to(dev), y.to(dev))
     assert rows2.shape[0] == 12
+
+
+def test_step_reads_momentum_and_weight_decay_from_param_groups(be, dev):
+    """The reference's Trainer rewrites optimizer.param_groups[i]['momentum'] after the warm-up (warmup_momentum 0.8 -> 0.937, engine/vision_engine.py:169-171,350-352);
+    a fused step that captured the constructor's value would silently ignore the switch."""
+    ref, m1 = _pair(be, dev, seed=6)
+    _, m2 = _pair(be, dev, seed=6)
+    s1 = vit.FusedTrainStep(m1, lr=0.01, momentum=0.8, weight_decay=5e-4, ema=False)
+    s2 = vit.FusedTrainStep(m2, lr=0.01, momentum=0.937, weight_decay=1e-3, ema=False)
+    torch.manual_seed(12)
+    x = torch.randn(4, 3, 32, 32).to(dev); y = torch.randint(0, 10, (4,)).to(dev)
+    s1.step(x, y); s2.step(x, y)                       # first step: the momentum buffer is the gradient itself; weight decay already differs
+    s1.param_groups[0]["momentum"] = 0.937             # what Trainer does once the warm-up is over
+    s1.param_groups[0]["weight_decay"] = 1e-3
+    s2.param_groups[0]["weight_decay"] = 1e-3
+    m1.engine.params.copy_(m2.engine.params); s1.momentum_buf.copy_(s2.momentum_buf); m1.engine.refresh_weights()
+    s1.step(x, y); s2.step(x, y)
+    assert torch.equal(m1.engine.params, m2.engine.params)
+    s1.param_groups[0]["momentum"] = 0.5
+    s1.step(x, y); s2.step(x, y)
+    assert not torch.equal(m1.engine.params, m2.engine.params)
+
+
+def test_default_initialisation_follows_torch_manual_seed(be, dev):
+    torch.manual_seed(123); a = vit.VisionTransformer(SPEC, device=dev, backend=be)
+    torch.manual_seed(123); b = vit.VisionTransformer(SPEC, device=dev, backend=be)
+    torch.manual_seed(124); c = vit.VisionTransformer(SPEC, device=dev, backend=be)
+    assert torch.equal(a.engine.params, b.engine.params) and not torch.equal(a.engine.params, c.engine.params)

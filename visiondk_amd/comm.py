@@ -17,20 +17,28 @@ import torch.distributed as dist
 
 
 class GradAllReduce:
-    def __init__(self, group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 32 << 20):
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 32 << 20, always_communicate: bool = False):
+        """always_communicate: issue every collective even in a one-rank group (where they are identities).  The GPU tests use it to drive the real
+        stream-ordered RCCL path on a single MI355X (backend "nccl", world_size 1) and require bit-identical results to the communication-free step."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.active = self.world_size > 1 or always_communicate
+        self.collectives = 0               # issued so far (tests / logs)
         self.bucket_bytes = bucket_bytes   # xGMI is per-link bound: fewer, larger collectives than DDP's 25 MB
         self._grads: Optional[torch.Tensor] = None
         self._pending: List = []
         self._lo = self._hi = None
 
-    def broadcast_params(self, flat_params: torch.Tensor, src: int = 0) -> None:
-        """DDP-constructor semantics (C2): every rank starts from rank `src`'s weights."""
+    def broadcast_params(self, flat_params: torch.Tensor, src: int = 0, engine=None) -> None:
+        """DDP-constructor semantics (C2): every rank starts from rank `src`'s weights.  c10d collectives do not bump tensor versions, so the engine whose
+        bf16 operand copies derive from `flat_params` is told explicitly that they are stale (a forward may have run before the step was constructed)."""
         dist.broadcast(flat_params, src=src, group=self.group)
+        self.collectives += 1
+        if engine is not None:
+            engine._weights_version = None
 
     # ---- per step -----------------------------------------------------------------------------------
     def begin_step(self, flat_grads: torch.Tensor) -> None:
@@ -43,11 +51,12 @@ class GradAllReduce:
             return
         sl = self._grads[self._lo:self._hi]
         self._pending.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.collectives += 1
         self._lo = self._hi = None
 
     def on_grad_ready(self, offset: int, numel: int) -> None:
         """Called from inside vdk_vit_backward, ranges arrive in descending, contiguous order."""
-        if self.world_size == 1:
+        if not self.active:
             return
         if self._lo is None:
             self._lo, self._hi = offset, offset + numel
@@ -60,7 +69,7 @@ class GradAllReduce:
             self._flush()
 
     def finish_step(self) -> None:
-        if self.world_size == 1:
+        if not self.active:
             return
         self._flush()
         for w in self._pending:

@@ -229,10 +229,8 @@ class ConvNeXt(nn.Module):
         """timm's own init (trunc_normal .02 Conv/Linear weights, zero biases, LayerNorm (1,0), layer scale 1e-6): the reference's
         FaceTrainingWrapper.reset_parameters is defined but never called."""
         gen = torch.Generator(device="cpu")
-        if seed is not None:
-            gen.manual_seed(seed)
-        else:
-            gen.seed()
+        # no explicit seed: drawn from torch's global generator, so torch.manual_seed(s) reproduces the initialisation as it does for the reference's model
+        gen.manual_seed(seed if seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
         with torch.no_grad():
             for name, p in self._plist:
                 if name.endswith(".gamma"):

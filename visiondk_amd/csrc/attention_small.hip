@@ -167,23 +167,33 @@ __global__ __launch_bounds__(256, (NKT <= 7 ? 2 : 1)) void attn_s_fwd_kernel(con
 }
 
 // =====================================================================================  backward (fused)
-// 512 threads, one workgroup per CU.  LDS (dynamic): Q [R8] | dO [R8] | zero rows up to 32*NKT of the dO array | 8 wave tiles of 4 KB (a wave's K tile,
-// then its dS^T hand-off tile, then its dK / dV store tile) | dQ f32 [32*NKT][64] (chunk ^ (row & 15)) | lse2 [32*NKT] | D [32*NKT].
+// 512 threads, one workgroup per CU, persistent over (batch, head) items.  LDS (dynamic): Q [R8] | dO [R8] | zero rows up to 32*NKT of the dO array |
+// 8 wave tiles of 4 KB (a wave's K tile, later its store tile) | 8 dS^T hand-off tiles of 2 KB | dQ f32 [32*NKT][64] | lse2 [32*NKT] | D [32*NKT].
+// Register budget (two waves per SIMD = 256): the dK / dV accumulators (64) and the V fragments (16) stay resident; the K row fragments and the K^T
+// fragments are re-read from the wave's K tile every step (12 LDS reads against 32 registers that had pushed lane-constant addresses into scratch).
+// dQ accumulates in fp32 LDS rows (16-byte chunk ^ (q & 15): conflict-free ds_read_b128 / ds_write_b128 with lane = query); step 0 stores (every query tile
+// is visited by exactly one wave per step), later steps read-add-write -- no zeroing pass.  (ds_add_f32 was measured and dropped: 164 cycles per
+// wave-instruction on gfx950, 1.55 ms for the kernel against 0.3 ms with the explicit read-modify-write.)
+// The next item's operands are requested as soon as the last step's barrier has passed (Q / dO by LDS-DMA, the K / V fragments and the O pieces for D into
+// registers), so they travel while this item's dK / dV / dQ are written out; a one-workgroup-per-CU kernel has nobody else to hide that latency behind.
+
 template <int NKT>
 __global__ __launch_bounds__(512, 2) void attn_s_bwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld,
                                                             const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, long ldo, const float* __restrict__ lse,
                                                             bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long ldd, int N, int H, float scale,
-                                                            int nitems) {
+                                                            int nitems, int dbg /* timing-only ablation mask (VDK_ATTN_DBG), 0 in production */) {
   VDK_DYN_LDS(smem);
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int R8 = (N + 7) & ~7;
   constexpr int NP = 32 * NKT;
+  constexpr int NPC = (NP * 8 + 511) / 512;                           // 16-byte O pieces per thread for D = rowsum(dO * O)
   unsigned char* const Qs = smem;
   unsigned char* const Os = smem + R8 * AS_ROW;                       // dO rows, then zero rows up to NP
-  unsigned char* const Wt = smem + (R8 + NP) * AS_ROW + w * 4096;     // this wave's 4 KB tile
-  unsigned char* const dQs = smem + (R8 + NP) * AS_ROW + 8 * 4096;    // f32 [NP][64]
-  float* const lse2 = (float*)(dQs + NP * 256);
+  unsigned char* const Wt = smem + (R8 + NP) * AS_ROW + w * 4096;     // this wave's 4 KB tile: its K rows during the steps, its store tile afterwards
+  unsigned char* const Ht = smem + (R8 + NP) * AS_ROW + 8 * 4096 + w * 2048;   // this wave's 2 KB dS^T hand-off tile
+  float* const dQt = (float*)(smem + (R8 + NP) * AS_ROW + 8 * 6144);  // f32 [NP][64]
+  float* const lse2 = dQt + NP * 64;
   float* const Dv = lse2 + NP;
   for (int i = tid * 16; i < (NP - R8) * AS_ROW; i += 512 * 16) *(u32x4*)(Os + R8 * AS_ROW + i) = (u32x4){0u, 0u, 0u, 0u};
   const int nt = (N + 31) >> 5;                                       // query tiles == key tiles
@@ -191,42 +201,49 @@ __global__ __launch_bounds__(512, 2) void attn_s_bwd_kernel(const bf16_t* __rest
   const float scale2 = scale * VDK_LOG2E;
   const int krow = w * 32 + l31;
   const bool ragged = (N & 31) != 0;
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const int b = item / H, h = item - b * H;
+
+  s16x8 vf[4];
+  u32x4 opiece[NPC];
+  // everything of item `it` that does not need this workgroup's wave tiles: Q / dO by DMA, K / V fragments, O pieces, lse
+  auto request = [&](int it) {
+    const int b = it / H, h = it - b * H;
     const long off = (long)b * N * ld + h * 64, offo = (long)b * N * ldo + h * 64;
-    __syncthreads();                                                  // everything of the previous item has left the LDS
     as_dma_rows(Qs, q + off, ld, N, R8, w, 8, lane);
     as_dma_rows(Os, dout + offo, ldo, N, R8, w, 8, lane);
-    s16x8 kf[4], vf[4];
     if (act) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {                                   // own K tile: 32 rows = 4 DMA instructions
-        const int row = w * 32 + 8 * j + (lane >> 3), lrow = 8 * j + (lane >> 3);
-        const int c = (lane & 7) ^ as_f(lrow);
-        const bf16_t* g = k + off + (long)(row < N ? row : N - 1) * ld + c * 8;
-        __builtin_amdgcn_global_load_lds(VDK_GLOBAL_PTR(g), VDK_LDS_PTR(Wt + j * 1024), 16, 0, 0);
-      }
       const long kr = (long)(krow < N ? krow : N - 1) * ld;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        kf[ks] = *(const s16x8*)(k + off + kr + ks * 16 + hi * 8);
-        vf[ks] = *(const s16x8*)(v + off + kr + ks * 16 + hi * 8);
-      }
+      for (int ks = 0; ks < 4; ++ks) vf[ks] = *(const s16x8*)(v + off + kr + ks * 16 + hi * 8);
     }
-    // D = rowsum(dO * O) needs O once: 8 threads per row, 16 bytes each, NP rows over 512 threads
-    u32x4 opiece[(NP * 8 + 511) / 512];
 #pragma unroll
-    for (int p = 0; p < (NP * 8 + 511) / 512; ++p) {
+    for (int p = 0; p < NPC; ++p) {
       const int id = tid + 512 * p, row = id >> 3;
       opiece[p] = (u32x4){0u, 0u, 0u, 0u};
-      if (row < N) opiece[p] = *(const u32x4*)(o + offo + (long)row * ldo + (id & 7) * 8);
+      if (row < N && !(dbg & 64)) opiece[p] = *(const u32x4*)(o + offo + (long)row * ldo + (id & 7) * 8);
     }
     for (int i = tid; i < NP; i += 512) lse2[i] = i < N ? lse[((long)b * H + h) * N + i] * VDK_LOG2E : 0.f;
-    for (int i = tid * 16; i < NP * 256; i += 512 * 16) *(f32x4*)(dQs + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
-    __builtin_amdgcn_s_waitcnt(0x0F70);
+  };
+  auto request_ktile = [&](int it) {                                  // own K tile: 32 rows = 4 DMA instructions into the wave tile
+    if (!act) return;
+    const int b = it / H, h = it - b * H;
+    const long off = (long)b * N * ld + h * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = w * 32 + 8 * j + (lane >> 3), lrow = 8 * j + (lane >> 3);
+      const int c = (lane & 7) ^ as_f(lrow);
+      const bf16_t* g = k + off + (long)(row < N ? row : N - 1) * ld + c * 8;
+      __builtin_amdgcn_global_load_lds(VDK_GLOBAL_PTR(g), VDK_LDS_PTR(Wt + j * 1024), 16, 0, 0);
+    }
+  };
+
+  __syncthreads();                                                    // the zero rows are written
+  if ((int)blockIdx.x < nitems) { request(blockIdx.x); request_ktile(blockIdx.x); }
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / H, h = item - b * H;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): this wave's DMAs (and the previous item's stores) are done
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < (NP * 8 + 511) / 512; ++p) {
+    for (int p = 0; p < NPC; ++p) {
       const int id = tid + 512 * p, row = id >> 3, cp = id & 7;
       float d = 0.f;
       if (row < NP) {
@@ -237,21 +254,16 @@ __global__ __launch_bounds__(512, 2) void attn_s_bwd_kernel(const bf16_t* __rest
       d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
       if (row < NP && cp == 0) Dv[row] = row < N ? d : 0.f;
     }
-    s16x8 kT[2][2];
-    if (act) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) { kT[s][0] = as_tr_frag(Wt, 16 * s, 0, lane); kT[s][1] = as_tr_frag(Wt, 16 * s, 32, lane); }
-    }
-    __syncthreads();                                                  // D is complete; K^T fragments are in registers (the wave tile is free)
+    __syncthreads();                                                  // D is complete
     f32x16 gk0 = as_zero16(), gk1 = as_zero16(), gv0 = as_zero16(), gv1 = as_zero16();
     for (int t = 0; t < nt; ++t) {
-      if (act) {
+      if (act && !(dbg & 8)) {
         int qt = w + t; if (qt >= nt) qt -= nt;
         const int q0 = qt * 32;
         f32x16 st = as_zero16(), dp = as_zero16();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag(Qs, q0 + l31, ks, hi), kf[ks], st, 0, 0, 0);   // S[q][key]
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag(Qs, q0 + l31, ks, hi), as_row_frag(Wt, l31, ks, hi), st, 0, 0, 0);   // S[q][key]
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag(Os, q0 + l31, ks, hi), vf[ks], dp, 0, 0, 0);   // dP[q][key]
         }
         f32x16 pv, ds;
@@ -277,8 +289,9 @@ __global__ __launch_bounds__(512, 2) void attn_s_bwd_kernel(const bf16_t* __rest
         for (int g = 0; g < 4; ++g) {
           const u32x4 u0 = *(const u32x4*)&df[g >> 1];
           const int e0 = (g & 1) * 2;
-          *(u32x2*)(Wt + l31 * 64 + ((g ^ ((l31 >> 1) & 3)) << 4) + 8 * hi) = (u32x2){u0[e0], u0[e0 + 1]};
+          *(u32x2*)(Ht + l31 * 64 + ((g ^ ((l31 >> 1) & 3)) << 4) + 8 * hi) = (u32x2){u0[e0], u0[e0 + 1]};
         }
+        if (!(dbg & 4))
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           gv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Os, q0 + 16 * s, 0, lane), pf[s], gv0, 0, 0, 0);     // dV^T[d][key] += dO^T P
@@ -287,45 +300,56 @@ __global__ __launch_bounds__(512, 2) void attn_s_bwd_kernel(const bf16_t* __rest
           gk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Qs, q0 + 16 * s, 32, lane), df[s], gk1, 0, 0, 0);
         }
         VDK_WAVE_LDS_SYNC();
-        f32x16 a0 = as_zero16(), a1 = as_zero16();                    // dQ^T[d][q] partial of this key tile
+        if (!(dbg & 2)) {                                             // dQ^T[d][q] partial of this key tile: K^T (A, from the K tile) x dS^T (B, from the hand-off tile)
+          s16x8 bt[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          // B fragment: lane (q = l31, hi) <- keys 16s + 4hi + {0..3} and + 8 of column q
-          const int sl = lane & 15, chalf = (lane >> 4) & 1;
-          const int r1 = 16 * s + 4 * hi + (sl >> 2), r2 = r1 + 8;
-          const int byte = 32 * chalf + 8 * (sl & 3);
-          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(Wt + r1 * 64 + (((byte >> 4) ^ ((r1 >> 1) & 3)) << 4) + (byte & 8)));
-          s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(Wt + r2 * 64 + (((byte >> 4) ^ ((r2 >> 1) & 3)) << 4) + (byte & 8)));
-          const s16x8 bt = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
-          a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[s][0], bt, a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[s][1], bt, a1, 0, 0, 0);
+          for (int s = 0; s < 2; ++s) {
+            // B fragment: lane (q = l31, hi) <- keys 16s + 4hi + {0..3} and + 8 of column q
+            const int sl = lane & 15, chalf = (lane >> 4) & 1;
+            const int r1 = 16 * s + 4 * hi + (sl >> 2), r2 = r1 + 8;
+            const int byte = 32 * chalf + 8 * (sl & 3);
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(Ht + r1 * 64 + (((byte >> 4) ^ ((r1 >> 1) & 3)) << 4) + (byte & 8)));
+            s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(Ht + r2 * 64 + (((byte >> 4) ^ ((r2 >> 1) & 3)) << 4) + (byte & 8)));
+            bt[s] = (s16x8){lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+          }
+          unsigned char* const drow = (unsigned char*)dQt + (q0 + l31) * 256;   // dQ f32 [q][64], 16-byte chunk ^ (q & 15)
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            f32x16 a = as_zero16();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Wt, 16 * s, 32 * half, lane), bt[s], a, 0, 0, 0);
+            if (!(dbg & 1)) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {                           // registers 4g .. 4g+3 = d 8g + 4hi + {0..3} (+ 32 * half): one 16-byte chunk
+                f32x4* const pp = (f32x4*)(drow + (((8 * half + 2 * g + hi) ^ (l31 & 15)) << 4));
+                f32x4 x = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+                if (t != 0) x += *pp;                                 // step 0 stores: every query tile is visited by exactly one wave per step, no zeroing pass
+                *pp = x;
+              }
+            }
+          }
         }
         VDK_WAVE_LDS_SYNC();                                          // the hand-off tile may be rewritten in the next step
-        unsigned char* drow = dQs + (q0 + l31) * 256;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4* p0 = (f32x4*)(drow + (((2 * g + hi) ^ (l31 & 15)) << 4));
-          f32x4* p1 = (f32x4*)(drow + (((8 + 2 * g + hi) ^ (l31 & 15)) << 4));
-          f32x4 x0 = *p0, x1 = *p1;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { x0[e] += a0[4 * g + e]; x1[e] += a1[4 * g + e]; }
-          *p0 = x0; *p1 = x1;
-        }
       }
       __syncthreads();                                                // step boundary: the dQ tiles change hands
     }
-    // ---- outputs: dK, dV from registers through the wave tile; dQ from the fp32 LDS tile -----------------------------------------------
-    if (act) {
+    // ---- the next item's operands start travelling now (Q / dO arrays, lse2 and the fragment registers are free) ----------------------------
+    const int nxt = item + gridDim.x;
+    if (nxt < nitems) request(nxt);
+    // ---- outputs: dK, dV from registers and dQ from the d-major LDS tile, all through the wave tile -> 128-byte rows ---------------------------
+    if (act && !(dbg & 32)) {
       as_store_tile(Wt, gk0, gk1, scale, dk + (long)b * N * ldd + h * 64, ldd, w * 32, N, lane);
       as_store_tile(Wt, gv0, gv1, 1.0f, dv + (long)b * N * ldd + h * 64, ldd, w * 32, N, lane);
     }
-    for (int id = tid; id < N * 8; id += 512) {
-      const int row = id >> 3, cp = id & 7;                          // 8 columns: f32 chunks 2cp, 2cp+1
-      const f32x4 x0 = *(const f32x4*)(dQs + row * 256 + (((2 * cp) ^ (row & 15)) << 4));
-      const f32x4 x1 = *(const f32x4*)(dQs + row * 256 + (((2 * cp + 1) ^ (row & 15)) << 4));
-      *(u32x4*)(dq + (long)b * N * ldd + h * 64 + (long)row * ldd + cp * 8) =
-          (u32x4){pack_bf2(x0[0] * scale, x0[1] * scale), pack_bf2(x0[2] * scale, x0[3] * scale), pack_bf2(x1[0] * scale, x1[1] * scale), pack_bf2(x1[2] * scale, x1[3] * scale)};
-    }
+    if (!(dbg & 16))
+      for (int id = tid; id < N * 8; id += 512) {
+        const int row = id >> 3, cp = id & 7;                         // 8 columns: f32 chunks 2cp, 2cp+1
+        const f32x4 x0 = *(const f32x4*)((const unsigned char*)dQt + row * 256 + (((2 * cp) ^ (row & 15)) << 4));
+        const f32x4 x1 = *(const f32x4*)((const unsigned char*)dQt + row * 256 + (((2 * cp + 1) ^ (row & 15)) << 4));
+        *(u32x4*)(dq + (long)b * N * ldd + h * 64 + (long)row * ldd + cp * 8) =
+            (u32x4){pack_bf2(x0[0] * scale, x0[1] * scale), pack_bf2(x0[2] * scale, x0[3] * scale), pack_bf2(x1[0] * scale, x1[1] * scale), pack_bf2(x1[2] * scale, x1[3] * scale)};
+      }
+    if (nxt < nitems) request_ktile(nxt);                             // the wave tile is free again
   }
 }
 
@@ -343,11 +367,14 @@ template <int NKT>
 static int launch_bwd(const bf16_t* base, long D, long ld, const bf16_t* o, const bf16_t* dout, long ldo, const float* lse, bf16_t* dbase, long ldd, int B, int N, int H,
                       float scale, int grid, hipStream_t s) {
   const int R8 = (N + 7) & ~7, NP = 32 * NKT;
-  const size_t lds = (size_t)(R8 + NP) * AS_ROW + 8 * 4096 + (size_t)NP * 256 + (size_t)NP * 8;
+  const size_t lds = (size_t)(R8 + NP) * AS_ROW + 8 * 6144 + (size_t)NP * 256 + (size_t)NP * 8;   // arrays | wave tiles + hand-off tiles | dQ^T f32 | lse2, D
+  if (lds > 160 * 1024) return VDK_EUNSUPPORTED;                                                  // N in 209 .. 224: the two-kernel backward of attention.hip
   if (hipFuncSetAttribute((const void*)attn_s_bwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return vdk_fail(VDK_ELAUNCH, "vdk_attention_bwd: LDS attribute");
+  int dbg = 0;
+  if (const char* e = getenv("VDK_ATTN_DBG")) dbg = atoi(e);
   hipLaunchKernelGGL((attn_s_bwd_kernel<NKT>), dim3((unsigned)grid), dim3(512), lds, s, base, base + D, base + 2 * D, ld, o, dout, ldo, lse, dbase, dbase + D, dbase + 2 * D, ldd,
-                     N, H, scale, B * H);
+                     N, H, scale, B * H, dbg);
   return VDK_OK;
 }
 

@@ -379,7 +379,7 @@ class FaceTrainStep:
         if layer_wise:
             self.param_groups.append({"lr": lr * 10, "momentum": momentum, "weight_decay": weight_decay})
         self.updates = 0
-        self.shard_head = bool(shard_head and comm is not None and comm.world_size > 1)
+        self.shard_head = bool(shard_head and comm is not None and comm.active)
         self.small = [p for p in self.bb.output_layer.parameters()] + ([] if self.shard_head else [self.head.weight])
         self.buffers = [b for b in self.bb.output_layer.buffers() if b.dtype.is_floating_point]
         mk = lambda t: torch.zeros_like(t)
@@ -396,9 +396,9 @@ class FaceTrainStep:
         self.be.check(self.be.lib.vdk_sumsq_workspace_bytes(C.byref(need)), "vdk_sumsq_workspace_bytes")
         self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.eng.device)
         self.loss_rows: Optional[torch.Tensor] = None
-        if comm is not None and comm.world_size > 1:
+        if comm is not None and comm.active:
             import torch.distributed as dist
-            comm.broadcast_params(self.eng.params)
+            comm.broadcast_params(self.eng.params, engine=self.eng)
             for t in self.small + self.buffers + ([self.head.weight] if self.shard_head else []):
                 dist.broadcast(t.data, src=0, group=comm.group)
             if ema:
@@ -429,11 +429,15 @@ class FaceTrainStep:
         bb.model._sync_flat()
         self.updates += 1
         d = 0.9999 * (1 - math.exp(-self.updates / 2000)) if self.ema_flat is not None else 0.0
-        lr = self.param_groups[0]["lr"]
-        lr_head = self.param_groups[-1]["lr"]
+        # lr, momentum and weight decay are re-read every step: the reference's Trainer writes param_groups[i]['momentum'] after the warm-up
+        # (vision_engine.py:169-171,544-546) and a scheduler drives every group's 'lr'; with layer_wise the last group is the margin head's
+        g0, gh = self.param_groups[0], self.param_groups[-1]
+        lr, mom, wd = g0["lr"], g0["momentum"], g0["weight_decay"]
+        lr_head, mom_head, wd_head = gh["lr"], gh["momentum"], gh["weight_decay"]
         B = x.shape[0]
         world = self.comm.world_size if self.comm is not None else 1
-        if world > 1:
+        active = self.comm is not None and self.comm.active
+        if active:
             import torch.distributed as dist
             for b in self.buffers:
                 dist.broadcast(b, src=0, group=self.comm.group)
@@ -458,7 +462,7 @@ class FaceTrainStep:
             self.head.weight.grad = dW
         dfeat = feat.grad
         dfeat = dfeat.permute(0, 2, 3, 1).contiguous().view(-1, eng.out_ch) if bb.is_cnn else dfeat.contiguous().view(-1, eng.spec.dim)
-        if world > 1:
+        if active:
             import torch.distributed as dist
             self.comm.begin_step(eng.grads)
             eng.backward(dfeat, on_ready=self.comm.on_grad_ready)
@@ -483,14 +487,15 @@ class FaceTrainStep:
             self._nsq += self._nsq_head
         first = int(self.updates == 1)
         be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.mom_flat), be.ptr(self.ema_flat), be.ptr(eng.wb16), eng.n_floats, lr,
-                                     self.momentum, self.weight_decay, 1.0 / world, be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step")
+                                     mom, wd, 1.0 / world, be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step")
         for p, m, e in zip(self.small, self.mom_small, self.ema_small):
             g = p.grad.contiguous()
-            be.check(be.lib.vdk_sgd_step(be.ptr(p.data), be.ptr(g), be.ptr(m), be.ptr(e), None, p.numel(), lr_head if p is self.head.weight else lr, self.momentum, self.weight_decay, 1.0 / world,
-                                         be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step")
+            is_head = p is self.head.weight
+            be.check(be.lib.vdk_sgd_step(be.ptr(p.data), be.ptr(g), be.ptr(m), be.ptr(e), None, p.numel(), lr_head if is_head else lr, mom_head if is_head else mom,
+                                         wd_head if is_head else wd, 1.0 / world, be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step")
         if self.shard_head:
-            be.check(be.lib.vdk_sgd_step(be.ptr(self.hs), be.ptr(dW), be.ptr(self.hs_mom), be.ptr(self.hs_ema), None, self.hs.numel(), lr_head, self.momentum,
-                                         self.weight_decay, 1.0 / world, be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step")
+            be.check(be.lib.vdk_sgd_step(be.ptr(self.hs), be.ptr(dW), be.ptr(self.hs_mom), be.ptr(self.hs_ema), None, self.hs.numel(), lr_head, mom_head,
+                                         wd_head, 1.0 / world, be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step")
         for b, z, zm, e in zip(self.buffers, self._zero, self._zero_m, self.ema_buf):   # EMA of the BatchNorm running statistics (lr = 0: value untouched)
             be.check(be.lib.vdk_sgd_step(be.ptr(b), be.ptr(z), be.ptr(zm), be.ptr(e), None, b.numel(), 0.0, 0.0, 0.0, 1.0, None, self.max_norm, d, first,
                                          be.stream()), "vdk_sgd_step")

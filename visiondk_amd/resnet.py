@@ -202,10 +202,8 @@ class ResNet(nn.Module):
     def reset_parameters(self, seed: Optional[int] = None) -> None:
         """the reference's re-init (classify_model.py:70-81): N(0, .02) Conv / Linear weights, zero Linear bias, BatchNorm (1, 0); running stats (0, 1)"""
         gen = torch.Generator(device="cpu")
-        if seed is not None:
-            gen.manual_seed(seed)
-        else:
-            gen.seed()
+        # no explicit seed: drawn from torch's global generator, so torch.manual_seed(s) reproduces the initialisation as it does for the reference's model
+        gen.manual_seed(seed if seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
         with torch.no_grad():
             for name, p in self._plist:
                 if name.endswith(".bias"):
@@ -293,33 +291,41 @@ class ResNetTrainStep:
         stay per rank (SyncBN is the reference's opt-in flag and is not built)."""
         assert loss in ("bce", "ce")
         self.comm = comm
-        self.sync_group = (comm.group if (sync_bn and comm is not None and comm.world_size > 1) else False)
+        self.sync_group = (comm.group if (sync_bn and comm is not None and comm.active) else False)
         self.model, self.eng, self.be = model, model.engine, model.engine.be
         self.loss, self.label_smoothing, self.max_norm = loss, label_smoothing, max_norm
         self.param_groups = [{"lr": lr, "momentum": momentum, "weight_decay": weight_decay}]
         self.momentum_buf = torch.zeros_like(self.eng.params)
         self.ema = self.eng.params.clone() if ema else None
+        # ModelEMA averages EVERY floating entry of state_dict() (models/ema.py:28-37): the BatchNorm running statistics too, and the reference validates and
+        # checkpoints from that copy -- an EMA of the weights alone would pair lagged weights with live statistics
+        has_buf = ema and getattr(self.eng, "buffers", None) is not None and self.eng.buffers.numel() > 0     # the ConvNeXt classifier has no BatchNorm
+        self.ema_buffers = self.eng.buffers.clone() if has_buf else None
+        self._zero_b = torch.zeros_like(self.eng.buffers) if has_buf else None       # gradient / momentum stand-ins of the lr = 0 pass that carries the EMA
+        self._zero_bm = torch.zeros_like(self.eng.buffers) if has_buf else None
         self.updates = 0
         self._normsq = torch.zeros(1, dtype=torch.float32, device=self.eng.device)
         need = C.c_size_t(0)
         self.be.check(self.be.lib.vdk_sumsq_workspace_bytes(C.byref(need)), "vdk_sumsq_workspace_bytes")
         self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.eng.device)
         self.loss_rows: Optional[torch.Tensor] = None
-        if graph and comm is not None and comm.world_size > 1:
+        if graph and comm is not None and comm.active:
             raise NotImplementedError("graph capture of the data-parallel step (host callbacks issue the collectives) is not built")
         self.graph = graph
         self.focal_gamma, self.focal_alpha = 0.0, 0.25          # set_focal(): the reference switches BCE -> focal at `strategy.focal[0]` epochs (vision_engine.py:160,367-368)
         self.sam, self.sam_rho, self.sam_adaptive = sam, sam_rho, sam_adaptive
         self._old_params = torch.empty_like(self.eng.params) if sam else None
         self._graphs = {}                       # (B, y shape/dtype) -> (CUDAGraph, static x, static y)
-        self._hyper = torch.zeros(5, dtype=torch.float32, device=self.eng.device) if graph else None
-        self._hyper_ring = [(torch.zeros(5, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(8)] if graph else []
-        if comm is not None and comm.world_size > 1:
+        self._hyper = torch.zeros(10, dtype=torch.float32, device=self.eng.device) if graph else None   # [0:5] the step's scalars, [5:10] the same with lr = momentum = wd = 0 (EMA of the buffers)
+        self._hyper_ring = [(torch.zeros(10, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(8)] if graph else []
+        if comm is not None and comm.active:
             import torch.distributed as dist
-            comm.broadcast_params(self.eng.params)
+            comm.broadcast_params(self.eng.params, engine=self.eng)
             dist.broadcast(self.eng.buffers, src=0, group=comm.group)
             if ema:
                 self.ema.copy_(self.eng.params)
+                if self.ema_buffers is not None:
+                    self.ema_buffers.copy_(self.eng.buffers)
 
     def set_focal(self, gamma: float = 2.0, alpha: float = 0.25) -> None:
         """Trainer's focal switch (engine/vision_engine.py:367-368): from now on the BCE loss is the reference's focal loss (models/losses/loss.py:27-54,75);
@@ -351,6 +357,12 @@ class ResNetTrainStep:
         """y_b, lam: mixup_criterion (train.py:34-35): lam * loss(pred, y) + (1 - lam) * loss(pred, y_b).  CE takes the pair as is; BCE-with-logits is
         linear in its targets, so the pair is folded into one soft target."""
         if y_b is not None and self.loss == "bce":
+            if self.focal_gamma > 0.0:
+                # focal(pred, t) is NOT linear in t (alpha_t and (1 - p_t)^gamma depend on it): the pair cannot be folded into one soft target.
+                # The reference's mixup_criterion evaluates the loss twice; so does the kernel sequence (second pass accumulates), eager mode only.
+                if self.graph:
+                    raise NotImplementedError("graph replay of focal loss with a mixup pair")
+                return self._step_eager(x, y, None, y_b=y_b, lam=lam)
             y, y_b = lam * y + (1.0 - lam) * y_b, None
         if self.graph:
             if y_b is not None:
@@ -371,7 +383,8 @@ class ResNetTrainStep:
                 m._buffers["num_batches_tracked"] += 1
         host, ev = self._hyper_ring[self.updates % len(self._hyper_ring)]     # pinned staging slots: a slot is rewritten only after its copy has run
         ev.synchronize()
-        host.copy_(torch.tensor([g["lr"], g["momentum"], g["weight_decay"], d, 1.0 if self.updates == 1 else 0.0]))
+        first = 1.0 if self.updates == 1 else 0.0
+        host.copy_(torch.tensor([g["lr"], g["momentum"], g["weight_decay"], d, first, 0.0, 0.0, 0.0, d, first]))
         self._hyper.copy_(host, non_blocking=True)
         ev.record()
         key = (tuple(x.shape), tuple(y.shape), y.dtype)
@@ -403,7 +416,8 @@ class ResNetTrainStep:
         import math
         eng, be, model = self.eng, self.be, self.model
         world = self.comm.world_size if self.comm is not None else 1
-        if world > 1:
+        active = self.comm is not None and self.comm.active
+        if active:
             import torch.distributed as dist
             dist.broadcast(eng.buffers, src=0, group=self.comm.group)
         if count:
@@ -422,13 +436,24 @@ class ResNetTrainStep:
         def fwd_loss_bwd(sync: bool, bn_momentum=None):
             kw = {} if bn_momentum is None else {"bn_momentum": bn_momentum}
             logits = eng.forward(x, True, sync_group=self.sync_group, **kw)
-            if self.loss == "bce":
+            if self.loss == "bce" and y_b is not None:
+                # focal loss with a mixup pair: lam * focal(pred, y) + (1 - lam) * focal(pred, y_b) (mixup_criterion, train.py:34-35) -- two evaluations, gradients added in fp32
+                rows2 = torch.empty_like(self.loss_rows)
+                g1 = torch.zeros((self._dl.shape[0], eng.cp), dtype=torch.float32, device=eng.device)
+                g2 = torch.zeros_like(g1)
+                for tgt, wgt, rows, gg in ((y, lam, self.loss_rows, g1), (y_b, 1.0 - lam, rows2, g2)):
+                    be.check(be.lib.vdk_bce_logits(be.ptr(logits), eng.cp, be.ptr(tgt), tgt.stride(0), B, ncls, wgt / (B * ncls), self.focal_gamma, self.focal_alpha, be.ptr(rows),
+                                                   None, 0, be.ptr(gg), eng.cp, be.stream()), "vdk_bce_logits")
+                self.loss_rows.mul_(lam).add_(rows2, alpha=1.0 - lam)
+                g1.add_(g2)
+                be.check(be.lib.vdk_cast_f32_bf16(be.ptr(g1), be.ptr(self._dl), g1.numel(), be.stream()), "vdk_cast_f32_bf16")
+            elif self.loss == "bce":
                 be.check(be.lib.vdk_bce_logits(be.ptr(logits), eng.cp, be.ptr(y), y.stride(0), B, ncls, 1.0 / (B * ncls), self.focal_gamma, self.focal_alpha, be.ptr(self.loss_rows),
                                                be.ptr(self._dl), eng.cp, None, 0, be.stream()), "vdk_bce_logits")
             else:
                 be.check(be.lib.vdk_softmax_ce(be.ptr(logits), eng.cp, B, ncls, be.ptr(y), be.ptr(y_b), lam, self.label_smoothing, 1.0 / B, be.ptr(self.loss_rows),
                                                be.ptr(self._dl), eng.cp, None, 0, be.stream()), "vdk_softmax_ce")
-            if world > 1 and sync:
+            if active and sync:
                 self.comm.begin_step(eng.grads)
                 eng.backward(self._dl, on_ready=self.comm.on_grad_ready, sync_group=self.sync_group)
                 self.comm.finish_step()
@@ -455,11 +480,17 @@ class ResNetTrainStep:
         if hyper is not None:
             be.check(be.lib.vdk_sgd_step_graph(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema), be.ptr(eng.wb16), eng.n_floats,
                                                be.ptr(hyper), 1.0 / world, nsq, self.max_norm, be.stream()), "vdk_sgd_step_graph")
+            if self.ema_buffers is not None:
+                be.check(be.lib.vdk_sgd_step_graph(be.ptr(eng.buffers), be.ptr(self._zero_b), be.ptr(self._zero_bm), be.ptr(self.ema_buffers), None, eng.buffers.numel(),
+                                                   be.ptr(hyper[5:]), 1.0, None, self.max_norm, be.stream()), "vdk_sgd_step_graph")
         else:
             d = 0.9999 * (1 - math.exp(-self.updates / 2000)) if self.ema is not None else 0.0
             be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema), be.ptr(eng.wb16), eng.n_floats, g["lr"],
                                          g["momentum"], g["weight_decay"], 1.0 / world, nsq, self.max_norm, d, int(self.updates == 1), be.stream()),
                      "vdk_sgd_step")
+            if self.ema_buffers is not None:      # lr = 0: the statistics themselves are untouched, their EMA moves with the same decay
+                be.check(be.lib.vdk_sgd_step(be.ptr(eng.buffers), be.ptr(self._zero_b), be.ptr(self._zero_bm), be.ptr(self.ema_buffers), None, eng.buffers.numel(), 0.0, 0.0, 0.0,
+                                             1.0, None, self.max_norm, d, int(self.updates == 1), be.stream()), "vdk_sgd_step")
         eng.refresh_weights(skip_wb16=True)
         return self.loss_rows
 

@@ -267,10 +267,9 @@ class VisionTransformer(nn.Module):
         """timm defaults + the reference's override (classify_model.py:70-81): N(0,.02) Conv/Linear weights, zero Linear
         biases (conv bias left at its default init), LayerNorm (1,0), pos_embed trunc-normal .02, cls_token normal 1e-6."""
         gen = torch.Generator(device="cpu")
-        if seed is not None:
-            gen.manual_seed(seed)
-        else:
-            gen.seed()
+        # no explicit seed: draw it from torch's global generator, so that `torch.manual_seed(s)` reproduces the initialisation like it does for the
+        # reference's model (and data-parallel ranks seeded alike start alike even before the broadcast)
+        gen.manual_seed(seed if seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
         s = self.spec
         with torch.no_grad():
             for name, p in self._plist:
@@ -371,7 +370,12 @@ class FusedTrainStep:
         self._sumsq_ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
         self._loss_rows: Optional[torch.Tensor] = None
         self._dl: Optional[torch.Tensor] = None
-        self.param_groups = [{"lr": lr, "momentum": momentum, "weight_decay": weight_decay}]  # Trainer reads param_groups[0]['lr']
+        # Trainer reads param_groups[0]['lr'] and WRITES 'momentum' after the warm-up (vision_engine.py:169-171,350-352): every step reads all three from here
+        self.param_groups = [{"lr": lr, "momentum": momentum, "weight_decay": weight_decay}]
+        if comm is not None and comm.active:          # DDP-constructor semantics: every rank starts from rank 0's weights
+            comm.broadcast_params(self.eng.params, src=0, engine=self.eng)
+            if self.ema is not None:
+                self.ema.copy_(self.eng.params)
 
     def _fwd_loss_bwd(self, x, y, y_b, lam, sync: bool) -> None:
         eng, be = self.eng, self.be
@@ -405,7 +409,8 @@ class FusedTrainStep:
         eng, be = self.eng, self.be
         self.model._sync_flat()
         world = self.comm.world_size if self.comm is not None else 1
-        lr = self.param_groups[0]["lr"]
+        g0 = self.param_groups[0]
+        lr, momentum, weight_decay = g0["lr"], g0["momentum"], g0["weight_decay"]
         self.updates += 1
         d = 0.9999 * (1 - math.exp(-self.updates / 2000)) if self.ema is not None else 0.0
         if self.sam:
@@ -420,7 +425,7 @@ class FusedTrainStep:
             self._fwd_loss_bwd(x, y, y_b, lam, sync=True)
             eng.params.copy_(self._old_params)
             be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema), be.ptr(eng.wb16),
-                                         eng.n_floats, lr, self.momentum, self.weight_decay, 1.0 / world, None, self.max_norm, d,
+                                         eng.n_floats, lr, momentum, weight_decay, 1.0 / world, None, self.max_norm, d,
                                          int(self.updates == 1), be.stream()), "vdk_sgd_step")
             eng.refresh_weights(skip_wb16=True)
             self._loss_rows.copy_(loss_first)     # update_sam returns the FIRST loss (train.py:175)
@@ -429,7 +434,7 @@ class FusedTrainStep:
         be.check(be.lib.vdk_sumsq_f32(be.ptr(eng.grads), eng.n_floats, be.ptr(self._normsq), be.ptr(self._sumsq_ws),
                                       self._sumsq_ws.numel(), be.stream()), "vdk_sumsq_f32")
         be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema),
-                                     be.ptr(eng.wb16), eng.n_floats, lr, self.momentum, self.weight_decay, 1.0 / world,
+                                     be.ptr(eng.wb16), eng.n_floats, lr, momentum, weight_decay, 1.0 / world,
                                      be.ptr(self._normsq), self.max_norm, d, int(self.updates == 1), be.stream()), "vdk_sgd_step")
         eng.refresh_weights(skip_wb16=True)
         return self._loss_rows
