@@ -32,6 +32,7 @@ extern "C" {
 /* dtypes */
 #define VDK_BF16 0
 #define VDK_F32 1
+#define VDK_F16 2   /* IEEE half: gallery storage of the retrieval index (faiss useFloat16) */
 /* GEMM epilogue activations */
 #define VDK_ACT_NONE 0
 #define VDK_ACT_GELU 1   /* exact-erf GELU (timm Mlp act_layer=nn.GELU); optional pre-activation saved to aux */
@@ -65,6 +66,15 @@ int vdk_cbir_prepare_gallery(const float* G, int64_t N, int32_t D, void* Gb, flo
 int vdk_cbir_fast_workspace_bytes(int64_t nq, int32_t k, int64_t cap, size_t* bytes);
 int vdk_cbir_search_fast(const float* Q, int64_t nq, const float* G, const void* Gb, const uint32_t* gmax_bits, int64_t N, int32_t D, int32_t k,
                          int64_t idx_base, float* out_scores, int64_t* out_idx, int64_t cap, void* ws, size_t ws_bytes, void* stream);
+/* vdk_cbir_search_fast generalised (csrc/cbir.hip): D <= 512 (face embeddings, timm_wrapper.py:33-47), fp16 gallery STORAGE (g_dtype VDK_F16: G holds half rows; faiss
+ * GpuClonerOptions.useFloat16 at engine/cbir/evaluation.py:157-162), and schedule 1 = bootstrap + two stages with candidate lists of `cap` entries whose overflow is
+ * REPORTED in *overflow_out (device u32) instead of being impossible by construction -- the caller repeats with schedule 0 if it is set.  Gb / gmax_bits from
+ * vdk_cbir_prepare_gallery (Gb = bf16 [N, DP], DP = D rounded up to 128).  Workspace: vdk_cbir_fast2_workspace_bytes. */
+int vdk_cbir_fast2_workspace_bytes(int64_t nq, int32_t D, int32_t k, int64_t cap, size_t* bytes);
+int vdk_cbir_search_fast2(const float* Q, int64_t nq, const void* G, int32_t g_dtype, const void* Gb, const uint32_t* gmax_bits, int64_t N, int32_t D, int32_t k,
+                          int64_t idx_base, float* out_scores, int64_t* out_idx, int64_t cap, int32_t schedule, uint32_t* overflow_out, void* ws, size_t ws_bytes,
+                          void* stream);
+
 /* merge S per-shard results [S, nq, k] (idx < 0 = empty) — the gallery-sharded multi-GPU search
  * (north_star; the reference replicates instead, cbir/evaluation.py:157-162).
  * workspace: vdk_cbir_workspace_bytes(nq, k, max(S*k, 2k)). */

@@ -22,7 +22,7 @@ METHOD = "auto"
 
 @pytest.fixture(autouse=True, params=["prefilter", "exact_scan"])
 def _method(request):
-    """every case runs through both search paths: bf16 pre-filter + exact re-score (d <= 128) and the all-pairs fp32 scan"""
+    """every case runs through both search paths: bf16 pre-filter + exact re-score (d <= 512) and the all-pairs fp32 scan"""
     global METHOD
     METHOD = request.param
     yield
@@ -30,7 +30,7 @@ def _method(request):
 
 
 def _search(be, q, g, k, cap=4096, idx_base=0):
-    method = METHOD if q.shape[1] <= 128 else "exact_scan"
+    method = METHOD if q.shape[1] <= 512 else "exact_scan"
     idx = cbir.FlatIPIndex(q.shape[1], backend=be, device="cuda" if be.device_only else "cpu", cap=cap, idx_base=idx_base, method=method)
     idx.add(g)
     return idx.search(q, k)
@@ -151,3 +151,69 @@ def test_index_memmap_save_and_load_like_the_reference(be, dev, tmp_path):
     s3, i3 = idx3.search(q, 10)
     so3, io3 = ocbir.flat_ip_search(q, g.astype(np.float16).astype(np.float32), 10)
     np.testing.assert_array_equal(i3, io3)
+
+
+@pytest.mark.parametrize("nq,n,d,k", [(40, 3000, 256, 10), (9, 1300, 260, 20), (300, 2500, 384, 5), (70, 5000, 512, 10), (5, 900, 512, 100), (3, 40, 512, 7)])
+def test_wide_embeddings_through_the_prefilter(be, dev, nq, n, d, k):
+    """128 < d <= 512 (face embeddings: feat_dim 512): the wide pre-filter kernels (32-row gallery tiles, one 32-query tile per wave), bootstrap included for the
+    larger cases; bit-identical to the oracle like every other path"""
+    q, g = _data(nq, n, d, seed=11)
+    index = cbir.FlatIPIndex(d, backend=be, device="cuda" if be.device_only else "cpu", method="prefilter", cap=4096)
+    index.add(g)
+    s, i = index.search(q, k)
+    so, io = ocbir.flat_ip_search(q, g, k)
+    np.testing.assert_array_equal(i, io)
+    np.testing.assert_array_equal(s.view(np.uint32), so.view(np.uint32))
+
+
+@pytest.mark.parametrize("d", [128, 512])
+def test_float16_storage_matches_the_oracle_on_fp16_rounded_vectors(be, dev, d):
+    """faiss's GPU index stores fp16 (useFloat16, engine/cbir/evaluation.py:157-162): scores = fp32 sums of fp16 x fp16 products.  Oracle: the same fp32 search on the
+    fp16-rounded vectors -- bit-exact; against the fp32-storage result only near-ties may swap (reported)."""
+    q, g = _data(50, 4000, d, seed=13)
+    dv = "cuda" if be.device_only else "cpu"
+    i16 = cbir.FlatIPIndex(d, backend=be, device=dv, storage="float16", cap=4096)
+    i16.add(g)
+    assert i16._materialize().dtype == torch.float16
+    s, i = i16.search(q, 20)
+    so, io = ocbir.flat_ip_search(q.astype(np.float16).astype(np.float32), g.astype(np.float16).astype(np.float32), 20)
+    np.testing.assert_array_equal(i, io)
+    np.testing.assert_array_equal(s.view(np.uint32), so.view(np.uint32))
+    s32, i32 = ocbir.flat_ip_search(q, g, 20)
+    rep = cbir.fp16_swap_report(s32, i32, i)
+    assert rep["max_fp32_gap_swapped"] < 2.0 ** -10 and rep["entered_from_outside_topk"] <= rep["positions"]
+    print(rep)
+
+
+def test_optimistic_schedule_detects_overflow_and_repeats(be, dev, monkeypatch):
+    """bootstrap + two stages with short candidate lists: an overflowing query sets the device flag and the search is repeated with the guaranteed schedule"""
+    q, g = _data(6, 6000, 128, seed=17)
+    order = np.argsort(g @ q[0])                      # adversarial for query 0: similarity rises with the row index, every row beats the running threshold
+    g = np.ascontiguousarray(g[order])
+    dv = "cuda" if be.device_only else "cpu"
+    so, io = ocbir.flat_ip_search(q, g, 5)
+    monkeypatch.setattr(cbir, "OPTIMISTIC_CAP", 64)
+    index = cbir.FlatIPIndex(128, backend=be, device=dv, cap=8192, optimistic=True)
+    index.add(g)
+    s, i = index.search(q, 5)
+    assert index.fallbacks == 1
+    np.testing.assert_array_equal(i, io)
+    np.testing.assert_array_equal(s.view(np.uint32), so.view(np.uint32))
+    monkeypatch.setattr(cbir, "OPTIMISTIC_CAP", 8192)
+    index2 = cbir.FlatIPIndex(128, backend=be, device=dv, cap=8192, optimistic=True)
+    index2.add(g)
+    s, i = index2.search(q, 5)
+    assert index2.fallbacks == 0
+    np.testing.assert_array_equal(i, io)
+
+
+@pytest.mark.parametrize("nq,n,k,cap", [(70, 9000, 10, 700), (5, 30000, 100, 1500)])
+def test_many_stage_search_is_exact(be, dev, nq, n, k, cap, monkeypatch):
+    """many stages with a small list capacity (the schedule VDK_CBIR_PIPELINE=1 runs with the ranking on a second stream: tools/_gpu_job runs this file under it)"""
+    q, g = _data(nq, n, 128, seed=19)
+    dv = "cuda" if be.device_only else "cpu"
+    a = cbir.FlatIPIndex(128, backend=be, device=dv, cap=cap, method="prefilter"); a.add(g)
+    s1, i1 = a.search(q, k)
+    so, io = ocbir.flat_ip_search(q, g, k)
+    np.testing.assert_array_equal(i1, io)
+    np.testing.assert_array_equal(s1.view(np.uint32), so.view(np.uint32))

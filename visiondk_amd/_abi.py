@@ -55,6 +55,7 @@ class MarginHead(C.Structure):
     _fields_ = [("mode", I32), ("scale", F32), ("margin", F32), ("margin_am", F32), ("mv_weight", F32)]
 
 
+F16_ = 2   # VDK_F16
 HEAD_ARCFACE, HEAD_CIRCLE, HEAD_MV_AM, HEAD_MV_ARC = 0, 1, 2, 3
 GRAD_READY_FN = C.CFUNCTYPE(None, P, I64, I64)
 STAT_SYNC_FN = C.CFUNCTYPE(None, P, P, I64)   # vdk_stat_sync_fn(user, stats, n)
@@ -74,6 +75,8 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_cbir_prepare_gallery": (C.c_int, [P, I64, I32, P, P, P, P]),
     "vdk_cbir_fast_workspace_bytes": (C.c_int, [I64, I32, I64, PSZ]),
     "vdk_cbir_search_fast": (C.c_int, [P, I64, P, P, P, I64, I32, I32, I64, P, P, I64, P, SZ, P]),
+    "vdk_cbir_fast2_workspace_bytes": (C.c_int, [I64, I32, I32, I64, PSZ]),
+    "vdk_cbir_search_fast2": (C.c_int, [P, I64, P, I32, P, P, I64, I32, I32, I64, P, P, I64, I32, P, P, SZ, P]),
     "vdk_cbir_merge_topk": (C.c_int, [P, P, I32, I64, I32, P, P, P, SZ, P]),
     # hot path A: dense ops
     "vdk_gemm_splitk_workspace_bytes": (C.c_int, [I32, I32, I32, PSZ]),

@@ -21,7 +21,10 @@ import torch
 from . import _lib
 
 METRIC_INNER_PRODUCT = 0  # faiss.METRIC_INNER_PRODUCT
-DEFAULT_CAP = 65536       # candidate-list capacity per query (bounds the stage size, see csrc/cbir.hip)
+DEFAULT_CAP = 98304       # candidate-list capacity per query of the GUARANTEED schedule = rows per stage + k (csrc/cbir.hip).  Swept on the MI355X at 10 k x 1 M:
+                          # 32 k 4.21 ms, 64 k 3.88, 96 k 3.54, 128 k 3.53, 192 k 3.69, 256 k 3.89 (fewer launches against looser thresholds per stage); the lists
+                          # are address space more than memory: a search touches ~10^3 of a query's 98 304 slots
+OPTIMISTIC_CAP = 8192     # ... of the optimistic schedule (bootstrap + two stages; ~10^3 survivors per query in a 10^6-row scan; overflow is detected and repaired)
 
 
 def l2_normalize(x: torch.Tensor, eps: float = 1e-12, backend: Optional[_lib.Backend] = None) -> torch.Tensor:
@@ -39,25 +42,41 @@ class FlatIPIndex:
     """Exact inner-product index (faiss IndexFlatIP semantics; ties -> lower index; pads (-FLT_MAX, -1))."""
 
     def __init__(self, d: int, backend: Optional[_lib.Backend] = None, device=None, cap: int = DEFAULT_CAP,
-                 idx_base: int = 0, method: str = "auto"):
-        """method: "prefilter" = bf16-MFMA candidate filter with a rigorous error bound + exact fp32 re-scoring (d <= 128),
-        "exact_scan" = every pair scored on the fp32 MFMA; "auto" picks prefilter when d <= 128.  Both return bit-identical
-        results (tests/test_cbir.py runs every case through both)."""
+                 idx_base: int = 0, method: str = "auto", storage: str = "float32", optimistic: bool = False):
+        """method: "prefilter" = bf16-MFMA candidate filter with a rigorous error bound + exact fp32 re-scoring (d <= 512),
+        "exact_scan" = every pair scored on the fp32 MFMA; "auto" picks prefilter when d <= 512.  Both return bit-identical
+        results (tests/test_cbir.py runs every case through both).
+        storage: "float32", or "float16" = what the reference's GPU index stores (faiss GpuClonerOptions.useFloat16 = True, engine/cbir/evaluation.py:157-162):
+        the gallery is kept in fp16 (half the HBM footprint), queries are rounded to fp16 on arrival and every score is the fp32 k-ordered sum of the
+        fp16 x fp16 products -- bit-identical to the fp32 index fed the fp16-rounded vectors (the oracle of tests/test_cbir.py); prefilter path only.
+        optimistic: prefilter path: bootstrap + two stages with OPTIMISTIC_CAP-entry candidate lists (6 launches per search instead of 34 at 10^6 rows); a
+        list overflow is reported by the kernels and the search is repeated with the guaranteed schedule (one device flag read per search).  Measured
+        SLOWER than the default at 10 k x 1 M (4.5 vs 3.6 ms: the thresholds of a 16-stage scan rise stage by stage and leave ~10^3 survivors per query, two
+        stages leave 2.6 x 10^3 and the ranking kernel's register merge no longer applies), so it is off by default; the default is the guaranteed
+        sequential schedule (VDK_CBIR_PIPELINE=1 overlaps the ranking of stage i with the scan of stage i + 1 on a second stream: also measured slower)."""
         if d <= 0:
             raise ValueError("dimension must be positive")
         if method not in ("auto", "prefilter", "exact_scan"):
             raise ValueError("method must be auto | prefilter | exact_scan")
+        if storage not in ("float32", "float16"):
+            raise ValueError("storage must be float32 | float16")
         self.d = int(d)
         self.be = backend or _lib.load()
         self.device = torch.device(device) if device is not None else torch.device(
             "cuda", torch.cuda.current_device()) if self.be.device_only else torch.device("cpu")
         self.cap = int(cap)
         self.idx_base = int(idx_base)
-        self._dp = (self.d + 3) // 4 * 4          # kernels need d % 4 == 0: zero-pad (adds exact zeros)
-        if method == "prefilter" and self._dp > 128:
-            raise ValueError("the prefilter path needs d <= 128")
-        self.method = "exact_scan" if (method == "exact_scan" or self._dp > 128) else "prefilter"
-        self._gb: Optional[torch.Tensor] = None   # bf16 [N, 128] copy + max row norm, built once per gallery state
+        self.storage = storage
+        align = 8 if storage == "float16" else 4
+        self._dp = (self.d + align - 1) // align * align     # kernels need d % 4 == 0 (8 for fp16 rows): zero-pad (adds exact zeros)
+        if method == "prefilter" and self._dp > 512:
+            raise ValueError("the prefilter path needs d <= 512")
+        self.method = "exact_scan" if (method == "exact_scan" or self._dp > 512) else "prefilter"
+        if storage == "float16" and self.method != "prefilter":
+            raise ValueError("float16 storage is served by the prefilter path (d <= 512)")
+        self.optimistic = bool(optimistic)
+        self.fallbacks = 0                        # searches whose optimistic pass overflowed and were repeated with the guaranteed schedule
+        self._gb: Optional[torch.Tensor] = None   # bf16 [N, DP] copy (DP = d rounded up to 128) + row-norm maxima, built once per gallery state
         self._gmax: Optional[torch.Tensor] = None
         self._chunks: list[torch.Tensor] = []
         self._gallery: Optional[torch.Tensor] = None
@@ -85,7 +104,8 @@ class FlatIPIndex:
         return x.contiguous()
 
     def add(self, x) -> None:
-        self._chunks.append(self._to_dev(x))
+        x = self._to_dev(x)
+        self._chunks.append(x.half() if self.storage == "float16" else x)
 
     def reset(self) -> None:
         self._chunks, self._gallery, self._gb, self._gmax = [], None, None, None
@@ -97,7 +117,7 @@ class FlatIPIndex:
             self._chunks = []
             self._gb = None
         if self._gallery is None:
-            self._gallery = torch.empty((0, self._dp), dtype=torch.float32, device=self.device)
+            self._gallery = torch.empty((0, self._dp), dtype=torch.float16 if self.storage == "float16" else torch.float32, device=self.device)
         return self._gallery
 
     def _prepare(self) -> None:
@@ -106,16 +126,20 @@ class FlatIPIndex:
         if self._gb is not None:
             return
         be, n = self.be, g.shape[0]
-        self._gb = torch.empty((max(n, 1), 128), dtype=torch.bfloat16, device=self.device)
+        wide = (self._dp + 127) // 128 * 128
+        self._gb = torch.empty((max(n, 1), wide), dtype=torch.bfloat16, device=self.device)
         self._gmax = torch.zeros(4, dtype=torch.int32, device=self.device)
         norms = torch.empty(3 * max(n, 1), dtype=torch.float32, device=self.device)
-        be.check(be.lib.vdk_cbir_prepare_gallery(be.ptr(g) if n else None, n, self._dp, be.ptr(self._gb), be.ptr(norms),
+        g32 = g.float() if g.dtype != torch.float32 else g        # fp16 storage: a transient fp32 view of the stored values (exact), add()-time only
+        be.check(be.lib.vdk_cbir_prepare_gallery(be.ptr(g32) if n else None, n, self._dp, be.ptr(self._gb), be.ptr(norms),
                                                  be.ptr(self._gmax), be.stream()), "vdk_cbir_prepare_gallery")
 
     def _workspace(self, nq: int, k: int, cap: int) -> torch.Tensor:
         need = C.c_size_t(0)
-        fn = self.be.lib.vdk_cbir_fast_workspace_bytes if self.method == "prefilter" else self.be.lib.vdk_cbir_workspace_bytes
-        self.be.check(fn(nq, k, cap, C.byref(need)), "vdk_cbir_workspace_bytes")
+        if self.method == "prefilter":
+            self.be.check(self.be.lib.vdk_cbir_fast2_workspace_bytes(nq, self._dp, k, cap, C.byref(need)), "vdk_cbir_fast2_workspace_bytes")
+        else:
+            self.be.check(self.be.lib.vdk_cbir_workspace_bytes(nq, k, cap, C.byref(need)), "vdk_cbir_workspace_bytes")
         if self._ws is None or self._ws.numel() < need.value:
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
         return self._ws
@@ -132,20 +156,58 @@ class FlatIPIndex:
         scores = torch.empty((nq, k), dtype=torch.float32, device=self.device)
         idx = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         if nq:
-            ws = self._workspace(nq, k, cap)
             be = self.be
             if self.method == "prefilter":
                 self._prepare()
-                be.check(be.lib.vdk_cbir_search_fast(be.ptr(qd), nq, be.ptr(g), be.ptr(self._gb), be.ptr(self._gmax), g.shape[0],
-                                                     self._dp, k, self.idx_base, be.ptr(scores), be.ptr(idx), cap, be.ptr(ws),
-                                                     ws.numel(), be.stream()), "vdk_cbir_search_fast")
+                if self.storage == "float16":
+                    qd = qd.half().float()            # faiss multiplies fp16 x fp16 (fp32 accumulation): the queries are rounded like the stored rows
+                from . import _abi
+                gdt = _abi.F16_ if self.storage == "float16" else _abi.F32_
+
+                def run(schedule: int, cap_: int, flag):
+                    ws = self._workspace(nq, k, cap_)
+                    be.check(be.lib.vdk_cbir_search_fast2(be.ptr(qd), nq, be.ptr(g), gdt, be.ptr(self._gb), be.ptr(self._gmax), g.shape[0], self._dp, k,
+                                                          self.idx_base, be.ptr(scores), be.ptr(idx), cap_, schedule, be.ptr(flag), be.ptr(ws), ws.numel(),
+                                                          be.stream()), "vdk_cbir_search_fast2")
+                done = False
+                if self.optimistic:
+                    if getattr(self, "_flag", None) is None:
+                        self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+                    run(1, max(min(cap, OPTIMISTIC_CAP), 2 * k), self._flag)
+                    done = int(self._flag.item()) == 0        # the one host read of the optimistic schedule
+                    if not done:
+                        self.fallbacks += 1
+                if not done:
+                    run(0, cap, None)
             else:
+                ws = self._workspace(nq, k, cap)
                 be.check(be.lib.vdk_cbir_search(be.ptr(qd), nq, be.ptr(g), g.shape[0], self._dp, k, self.idx_base,
                                                 be.ptr(scores), be.ptr(idx), cap, be.ptr(ws), ws.numel(), be.stream()),
                          "vdk_cbir_search")
         if as_numpy:
             return scores.cpu().numpy(), idx.cpu().numpy()
         return scores, idx
+
+
+def fp16_swap_report(scores32: np.ndarray, idx32: np.ndarray, idx16: np.ndarray) -> dict:
+    """How an fp16-storage result differs from the fp32 one ("allow swaps only between neighbours whose fp32 scores differ by < 2^-10 and report
+    the count"): positions whose index differs, how many of them are pure re-orderings inside the same top-k set, and the largest fp32 score gap a
+    differing position spans (against the fp32 list's own score at that rank)."""
+    diff = idx32 != idx16
+    rows = np.nonzero(diff.any(1))[0]
+    entered = 0
+    worst = 0.0
+    for r in rows:
+        s32 = {int(i): float(s) for i, s in zip(idx32[r], scores32[r])}
+        for pos in np.nonzero(diff[r])[0]:
+            j = int(idx16[r, pos])
+            if j in s32:
+                worst = max(worst, abs(s32[j] - float(scores32[r, pos])))
+            else:
+                entered += 1                              # a row that was not in the fp32 top-k at all: it can only have been within rounding of the k-th score
+                worst = max(worst, 0.0)
+    return {"positions": int(diff.sum()), "rows_affected": int(len(rows)), "entered_from_outside_topk": int(entered), "max_fp32_gap_swapped": worst,
+            "total_positions": int(idx32.size)}
 
 
 def index_factory(d: int, description: str = "Flat", metric: int = METRIC_INNER_PRODUCT, **kw) -> FlatIPIndex:

@@ -307,10 +307,45 @@ __device__ __forceinline__ float cbir_exact_ip(const float* __restrict__ qrow, c
   return acc + 0.0f;
 }
 
+// the same chain over a gallery row STORED in fp16 (faiss GpuClonerOptions.useFloat16, engine/cbir/evaluation.py:157-162): every element converts exactly to
+// fp32, so the score equals cbir_exact_ip on the fp16-rounded row
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float cbir_exact_ip_h(const float* __restrict__ qrow, const _Float16* __restrict__ g, int D) {
+  float acc = 0.f;
+  int c = 0;
+  for (; c + 64 <= D; c += 64) {          // loads batched 8 deep like the fp32 chain (the chain itself is latency-bound, the loads must not be)
+    f16x8_t gv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gv[j] = *(const f16x8_t*)(g + c + 8 * j);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const f32x4 q0 = *(const f32x4*)(qrow + c + 8 * j), q1 = *(const f32x4*)(qrow + c + 8 * j + 4);
+      acc = fmaf(q0[0], (float)gv[j][0], acc); acc = fmaf(q0[1], (float)gv[j][1], acc); acc = fmaf(q0[2], (float)gv[j][2], acc); acc = fmaf(q0[3], (float)gv[j][3], acc);
+      acc = fmaf(q1[0], (float)gv[j][4], acc); acc = fmaf(q1[1], (float)gv[j][5], acc); acc = fmaf(q1[2], (float)gv[j][6], acc); acc = fmaf(q1[3], (float)gv[j][7], acc);
+    }
+  }
+  for (; c + 8 <= D; c += 8) {
+    const f16x8_t gv = *(const f16x8_t*)(g + c);
+    const f32x4 q0 = *(const f32x4*)(qrow + c), q1 = *(const f32x4*)(qrow + c + 4);
+    acc = fmaf(q0[0], (float)gv[0], acc); acc = fmaf(q0[1], (float)gv[1], acc); acc = fmaf(q0[2], (float)gv[2], acc); acc = fmaf(q0[3], (float)gv[3], acc);
+    acc = fmaf(q1[0], (float)gv[4], acc); acc = fmaf(q1[1], (float)gv[5], acc); acc = fmaf(q1[2], (float)gv[6], acc); acc = fmaf(q1[3], (float)gv[7], acc);
+  }
+  for (; c < D; ++c) acc = fmaf(qrow[c], (float)g[c], acc);
+  return acc + 0.0f;
+}
+// G: fp32 rows, or fp16 rows when g_half
+__device__ __forceinline__ float cbir_exact_ip_any(const float* __restrict__ qrow, const float* __restrict__ G, long row, int D, int g_half) {
+  return g_half ? cbir_exact_ip_h(qrow, (const _Float16*)G + row * (long)D, D) : cbir_exact_ip(qrow, G + row * (long)D, D);
+}
+
 #define CW_KEYS 512
 __global__ __launch_bounds__(256) void cbir_rank_wave_kernel(const float* __restrict__ Q, const float* __restrict__ G, int D, long idx_base,
                                                              CbirCand cand, long nq, int k, float* __restrict__ thr, float* __restrict__ out_score,
-                                                             long long* __restrict__ out_idx, int write_out, unsigned* __restrict__ carry) {
+                                                             long long* __restrict__ out_idx, int write_out, unsigned* __restrict__ carry, int g_half,
+                                                             CbirCand dst, int reserve) {
+  // reserve == 0: one list per query, [0, carry) = sorted exact entries, [carry, cnt) = new ones, the result goes back to [0, have).
+  // reserve == k (pipelined schedule): slots [0, k) of a list are reserved for the carry, the pre-filter appends from slot k on; the result is written to the
+  // OTHER list set `dst` (which the next stage's pre-filter is filling concurrently from ITS slot k on), and this list's counter is re-armed to k.
   __shared__ unsigned long long keys_all[4][CW_KEYS];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -319,7 +354,10 @@ __global__ __launch_bounds__(256) void cbir_rank_wave_kernel(const float* __rest
   unsigned long long* K = keys_all[w];
   unsigned n_total = cand.cnt[q];
   if ((long)n_total > cand.cap) n_total = (unsigned)cand.cap;
-  const unsigned exact_upto = Q ? carry[q] : n_total;   // entries below this index already hold exact scores
+  const unsigned c0 = Q ? carry[q] : n_total;           // sorted entries with exact scores at the front
+  const unsigned new0 = reserve ? (unsigned)reserve : c0;   // where the new (index-only) entries start
+  const unsigned n_new = n_total > new0 ? n_total - new0 : 0u;
+  const unsigned n_all = c0 + n_new;                     // logical entry e < c0: slot e, else slot new0 + (e - c0)
   const float thr_q = thr[q];
   float* cs = cand.score + q * cand.cap;
   int* ci = cand.idx + q * cand.cap;
@@ -327,15 +365,14 @@ __global__ __launch_bounds__(256) void cbir_rank_wave_kernel(const float* __rest
   const float* qrow = Q ? Q + q * (long)D : nullptr;
 
   unsigned consumed = 0, have = 0;
-  if (Q && n_total - exact_upto <= 64 && exact_upto <= (unsigned)k) {
+  if (Q && n_new <= 64 && c0 <= (unsigned)k) {
     // steady state of the prefilter path: entries [0, c0) are the sorted carry, at most 64 new ones follow.  Rank-merge in
     // registers: every new key is broadcast, each lane counts how many of its carry keys precede it (ballots), no sort.
-    const unsigned c0 = exact_upto;
     unsigned long long nk = ~0ull;
     bool v = false;
-    if ((unsigned)lane < n_total - c0) {
-      const int gi = ci[c0 + lane];
-      const float sc = cbir_exact_ip(qrow, G + ((long)gi - idx_base) * (long)D, D);
+    if ((unsigned)lane < n_new) {
+      const int gi = ci[new0 + lane];
+      const float sc = cbir_exact_ip_any(qrow, G, (long)gi - idx_base, D, g_half);
       if (!(sc < thr_q)) { nk = cbir_key(sc, gi); v = true; }
     }
     const unsigned long long vb = __ballot(v);
@@ -366,11 +403,11 @@ __global__ __launch_bounds__(256) void cbir_rank_wave_kernel(const float* __rest
     if (v && myrank < (unsigned)k) K[myrank] = nk;
     have = c0 + (unsigned)__popcll(vb);
     if (have > (unsigned)k) have = (unsigned)k;
-    consumed = n_total;
+    consumed = n_all;
     VDK_WAVE_LDS_SYNC();
   }
-  while (consumed < n_total) {
-    unsigned take = n_total - consumed;
+  while (consumed < n_all) {
+    unsigned take = n_all - consumed;
     if (take > CW_KEYS - (unsigned)keep) take = CW_KEYS - (unsigned)keep;
     const unsigned n = have + take;
     unsigned sortn = 64; while (sortn < n) sortn <<= 1;
@@ -378,11 +415,11 @@ __global__ __launch_bounds__(256) void cbir_rank_wave_kernel(const float* __rest
     for (unsigned i = lane; i < sortn - have; i += 64) {
       unsigned long long key = ~0ull;
       if (i < take) {
-        const unsigned e = consumed + i;
+        const unsigned el = consumed + i, e = el < c0 ? el : new0 + (el - c0);
         const int gi = ci[e];
         float sc;
-        if (e >= exact_upto) {
-          sc = cbir_exact_ip(qrow, G + ((long)gi - idx_base) * (long)D, D);
+        if (el >= c0) {
+          sc = cbir_exact_ip_any(qrow, G, (long)gi - idx_base, D, g_half);
         } else {
           sc = cs[e];
         }
@@ -408,14 +445,16 @@ __global__ __launch_bounds__(256) void cbir_rank_wave_kernel(const float* __rest
     if (have > (unsigned)k) have = (unsigned)k;
   }
 
+  float* os = reserve ? dst.score + q * dst.cap : cs;
+  int* oi = reserve ? dst.idx + q * dst.cap : ci;
   for (unsigned i = lane; i < have; i += 64) {
     const unsigned long long key = K[i];
-    cs[i] = ord2f(~(unsigned)(key >> 32));
-    ci[i] = (int)(unsigned)(key & 0xffffffffu);
+    os[i] = ord2f(~(unsigned)(key >> 32));
+    oi[i] = (int)(unsigned)(key & 0xffffffffu);
   }
   if (lane == 0) {
     if (carry) carry[q] = have;
-    cand.cnt[q] = have;
+    cand.cnt[q] = reserve ? (unsigned)reserve : have;
     if (have >= (unsigned)k) thr[q] = fmaxf(thr_q, ord2f(~(unsigned)(K[k - 1] >> 32)));
   }
   if (write_out) {
@@ -450,17 +489,19 @@ __global__ __launch_bounds__(256) void cbir_rank_wave_kernel(const float* __rest
 #define CF_WE 768      // staged survivors per wave
 
 // Qb / Gb rows: bf16 [rows, 128] (zero padded); norms3[row] = (||x||, ||bf16(x)||, ||bf16(x) - x||), each rounded up
-__global__ __launch_bounds__(256) void cbir_cast_rows_kernel(const float* __restrict__ x, long n, int D, bf16_t* __restrict__ xb, float* __restrict__ norms3) {
+__global__ __launch_bounds__(256) void cbir_cast_rows_kernel(const float* __restrict__ x, long n, int D, int DP, bf16_t* __restrict__ xb, float* __restrict__ norms3) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
-  const int c = lane * 2;
-  const float a = c < D ? x[row * (long)D + c] : 0.f, b = c + 1 < D ? x[row * (long)D + c + 1] : 0.f;
-  const unsigned pk = pack_bf2(a, b);
-  *(unsigned*)(xb + row * 128 + c) = pk;
-  const float at = __uint_as_float(pk << 16), bt = __uint_as_float(pk & 0xffff0000u);
-  const float ea = at - a, eb = bt - b;   // exact (Sterbenz) or a correctly rounded difference: error << the 2e-6 margin
-  float sx = fmaf(b, b, a * a), st = fmaf(bt, bt, at * at), se = fmaf(eb, eb, ea * ea);
+  float sx = 0.f, st = 0.f, se = 0.f;
+  for (int c = lane * 2; c < DP; c += 128) {      // DP = D rounded up to 128 columns (zero padded)
+    const float a = c < D ? x[row * (long)D + c] : 0.f, b = c + 1 < D ? x[row * (long)D + c + 1] : 0.f;
+    const unsigned pk = pack_bf2(a, b);
+    *(unsigned*)(xb + row * (long)DP + c) = pk;
+    const float at = __uint_as_float(pk << 16), bt = __uint_as_float(pk & 0xffff0000u);
+    const float ea = at - a, eb = bt - b;   // exact (Sterbenz) or a correctly rounded difference: error << the 2e-6 margin
+    sx += fmaf(b, b, a * a); st += fmaf(bt, bt, at * at); se += fmaf(eb, eb, ea * ea);
+  }
   sx = wave_sum(sx); st = wave_sum(st); se = wave_sum(se);
   if (lane == 0) {
     norms3[row * 3 + 0] = sqrtf(sx) * 1.000002f;
@@ -479,11 +520,14 @@ __global__ __launch_bounds__(256) void cbir_max3_kernel(const float* __restrict_
     atomicMax(out_bits, __float_as_uint(m0)); atomicMax(out_bits + 1, __float_as_uint(m1)); atomicMax(out_bits + 2, __float_as_uint(m2));
   }
 }
+__global__ void cbir_gstat_init_kernel(unsigned* __restrict__ bits, unsigned chunks) { if (threadIdx.x < 4) bits[threadIdx.x] = threadIdx.x == 3 ? chunks : 0u; }
 // eps_q of the header comment
+// (the accumulation term scales with the contraction length: 4e-5 covers 128 terms with a 5x margin, gstat_bits[3] holds DP / 128)
 __device__ __forceinline__ float cbir_eps(const float* __restrict__ qn3, long q, const unsigned* __restrict__ gstat_bits) {
   const float gt = __uint_as_float(gstat_bits[1]), ge = __uint_as_float(gstat_bits[2]);
   const float qn = qn3[q * 3], qt = qn3[q * 3 + 1], qe = qn3[q * 3 + 2];
-  return 1.00001f * (qe * gt + qn * ge) + 4e-5f * qt * gt;
+  const float len = gstat_bits[3] > 1u ? (float)gstat_bits[3] : 1.0f;
+  return 1.00001f * (qe * gt + qn * ge) + 4e-5f * len * qt * gt;
 }
 
 // grid: id -> split = id % nsplit, qblock = id / nsplit.  512 threads = 8 waves; wave w owns 64 queries (two 32-wide column
@@ -495,6 +539,48 @@ __device__ __forceinline__ float cbir_eps(const float* __restrict__ qn3, long q,
 // approximate score of every 128-row tile of a gallery sample (gm[q][tile]).  The k-th largest of these G >= k group maxima,
 // minus eps_q, is a lower bound of the exact k-th best score (k distinct rows reach it), i.e. a valid filter threshold before
 // any row is ranked: the scan starts with a tight cut instead of a pass-everything ramp (cbir_boot_thr_kernel).
+// survivors of one 32 x 32 accumulator block (lane = query QL of the wave, register r = row ROWB + (r & 3) + 8 (r >> 2) + 4 hi) -> the wave's staging arrays.
+// Only lanes that own a survivor build their row mask; slots are handed out lane by lane through SGPRs (v_readlane of each owner's count): no atomics,
+// no LDS round trip on the wave's critical path.  LAST: the tile may reach past r_end (rows there are clamped copies).
+#define CF_STAGE(ACC, CUTV, QL, ROWB, LAST)                                                                                                       \
+  do {                                                                                                                                            \
+    const bool own_ = m > (CUTV);                                                                                                                 \
+    unsigned pm = 0;                                                                                                                              \
+    if (own_) {                                                                                                                                   \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) pm |= (unsigned)((ACC)[r] > (CUTV)) << r;                                                     \
+      if (LAST) {                                                                                                                                 \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                                            \
+          if ((ROWB) + (r & 3) + 8 * (r >> 2) + 4 * hi >= r_end) pm &= ~(1u << r);                                                                 \
+      }                                                                                                                                           \
+    }                                                                                                                                             \
+    const unsigned c = (unsigned)__popc(pm);                                                                                                      \
+    unsigned long long bl = __ballot(c != 0);                                                                                                     \
+    unsigned pos = 0;   /* worst case 64 lanes x 16 rows = 1024 > CF_WE: a flush may be needed between two owners */                              \
+    for (unsigned long long b = bl; b; b &= b - 1) {                                                                                              \
+      const int L = __ffsll(b) - 1;                                                                                                               \
+      const unsigned cL = (unsigned)VDK_READLANE(c, L);                                                                                           \
+      if (wcnt + cL > CF_WE) {   /* stage what was granted so far, then flush (uniform branch) */                                                 \
+        if (c && (bl & ~b & (1ull << lane))) {                                                                                                    \
+          unsigned pp = pos, mm = pm;                                                                                                             \
+          while (mm) { const int r = __ffs(mm) - 1; mm &= mm - 1; e_idx[w][pp] = (int)(idx_base + (ROWB) + (r & 3) + 8 * (r >> 2) + 4 * hi); e_q[w][pp] = (unsigned char)(QL); ++pp; } \
+        }                                                                                                                                         \
+        bl = b;   /* owners before L are done */                                                                                                  \
+        CF_FLUSH();                                                                                                                               \
+      }                                                                                                                                           \
+      if (lane == L) pos = wcnt;                                                                                                                  \
+      wcnt += cL;                                                                                                                                 \
+    }                                                                                                                                             \
+    if (c && (bl & (1ull << lane))) {                                                                                                             \
+      unsigned mm = pm;                                                                                                                           \
+      while (mm) {                                                                                                                                \
+        const int r = __ffs(mm) - 1;                                                                                                              \
+        mm &= mm - 1;                                                                                                                             \
+        e_idx[w][pos] = (int)(idx_base + (ROWB) + (r & 3) + 8 * (r >> 2) + 4 * hi);                                                                \
+        e_q[w][pos] = (unsigned char)(QL);                                                                                                        \
+        ++pos;                                                                                                                                    \
+      }                                                                                                                                           \
+    }                                                                                                                                             \
+  } while (0)
 #define CF_NBUF 3
 template <bool BOOT>
 __global__ __launch_bounds__(512) void cbir_prefilter_kernel(const bf16_t* __restrict__ Qb, const float* __restrict__ qnorm, long nq,
@@ -519,6 +605,7 @@ __global__ __launch_bounds__(512) void cbir_prefilter_kernel(const bf16_t* __res
   if (r_end > g_end) r_end = g_end;
   if (r_begin >= r_end) return;
 
+  const long qw0 = q0 + w * 64;   // first query of this wave (CF_FLUSH)
   s16x8 qf[2][8];
   float cut[2];
 #pragma unroll
@@ -546,13 +633,13 @@ __global__ __launch_bounds__(512) void cbir_prefilter_kernel(const bf16_t* __res
     VDK_WAVE_LDS_SYNC();                                                                                                  \
     {                                                                                                                     \
       const unsigned c_ = f_cnt[w][lane];                                                                                 \
-      f_base[w][lane] = c_ ? atomicAdd(&cand.cnt[q0 + w * 64 + lane], c_) : 0u;                                           \
+      f_base[w][lane] = c_ ? atomicAdd(&cand.cnt[qw0 + lane], c_) : 0u;                                                     \
     }                                                                                                                     \
     VDK_WAVE_LDS_SYNC();                                                                                                  \
     for (unsigned i_ = lane; i_ < wcnt; i_ += 64) {                                                                       \
       const unsigned ql_ = e_q[w][i_];                                                                                    \
       const long pos_ = (long)f_base[w][ql_] + e_rank[w][i_];                                                             \
-      if (pos_ < cand.cap) cand.idx[(q0 + w * 64 + ql_) * cand.cap + pos_] = e_idx[w][i_];                                \
+      if (pos_ < cand.cap) cand.idx[(qw0 + ql_) * cand.cap + pos_] = e_idx[w][i_];                                        \
       else atomicOr(cand.overflow, 1u);                                                                                   \
     }                                                                                                                     \
     VDK_WAVE_LDS_SYNC();                                                                                                  \
@@ -630,48 +717,7 @@ __global__ __launch_bounds__(512) void cbir_prefilter_kernel(const bf16_t* __res
               bm[qt] = __uint_as_float(0xff800000u);
             }
           } else if (__any(m > cut[qt])) {
-            // only lanes that own a survivor build their row mask; slots are handed out lane by lane through SGPRs
-            // (v_readlane of each owner's count) -- no atomics, no LDS round trip on the wave's critical path
-            const bool own = m > cut[qt];
-            unsigned pm = 0;
-            if (own) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) pm |= (unsigned)(acc[rt][qt][r] > cut[qt]) << r;
-              if (t == ntile - 1) {   // ragged last tile: rows past r_end are clamped copies
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                  if (row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= r_end) pm &= ~(1u << r);
-              }
-            }
-            const unsigned c = (unsigned)__popc(pm);
-            unsigned long long bl = __ballot(c != 0);
-            // worst case 64 lanes x 16 rows = 1024 > CF_WE: a flush may be needed between two owners
-            unsigned pos = 0;
-            for (unsigned long long b = bl; b; b &= b - 1) {
-              const int L = __ffsll(b) - 1;
-              const unsigned cL = (unsigned)VDK_READLANE(c, L);
-              if (wcnt + cL > CF_WE) {
-                // stage what was granted so far, then flush (uniform branch)
-                if (c && (bl & ~b & (1ull << lane))) {
-                  unsigned pp = pos, mm = pm;
-                  while (mm) { const int r = __ffs(mm) - 1; mm &= mm - 1; e_idx[w][pp] = (int)(idx_base + row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi); e_q[w][pp] = (unsigned char)(qt * 32 + l31); ++pp; }
-                }
-                bl = b;   // owners before L are done
-                CF_FLUSH();
-              }
-              if (lane == L) pos = wcnt;
-              wcnt += cL;
-            }
-            if (c && (bl & (1ull << lane))) {
-              unsigned mm = pm;
-              while (mm) {
-                const int r = __ffs(mm) - 1;
-                mm &= mm - 1;
-                e_idx[w][pos] = (int)(idx_base + row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
-                e_q[w][pos] = (unsigned char)(qt * 32 + l31);
-                ++pos;
-              }
-            }
+            CF_STAGE(acc[rt][qt], cut[qt], qt * 32 + l31, row0 + rt * 32, t == ntile - 1);
           }
         }
         }
@@ -682,8 +728,101 @@ __global__ __launch_bounds__(512) void cbir_prefilter_kernel(const bf16_t* __res
   }
 #undef CF_ISSUE
   if (!BOOT && wcnt) { CF_FLUSH(); }
-#undef CF_FLUSH
 }
+
+// The same filter for 128 < D <= 512 (face embeddings: feat_dim 512, models/faceX/backbone/timm_wrapper.py:33-47).  NK = DP / 16 k-steps (16, 24 or 32): a wave
+// keeps ONE 32-query tile's fragments (4 NK registers) and a ring slot holds a 32-row gallery tile (32 x DP x 2 B <= 32 KB), so a workgroup covers 256 queries.
+// Every wave reads the whole tile for NK MFMAs -- half the operand reuse of the D <= 128 kernel, LDS-bound near 50 % of its MFMA rate, still ~5x the all-pairs
+// fp32 scan these dimensions fell back to.  BOOT: gm[q][tile] per 32-row tile.
+template <bool BOOT, int NK>
+__global__ __launch_bounds__(512) void cbir_prefilter_wide_kernel(const bf16_t* __restrict__ Qb, const float* __restrict__ qnorm, long nq,
+                                                                  const bf16_t* __restrict__ Gb, const unsigned* __restrict__ gmax_bits, long g_begin,
+                                                                  long g_end, long rows_per_split, int nsplit, long idx_base,
+                                                                  const float* __restrict__ thr, CbirCand cand, float* __restrict__ gm, long gm_ld) {
+  constexpr int RB = NK * 32;           // bytes per row
+  constexpr int CH = RB / 16;           // 16-byte chunks per row
+  constexpr int TILEB = 32 * RB;        // one ring slot
+  __shared__ __attribute__((aligned(16))) unsigned char Gs[CF_NBUF * TILEB];
+  __shared__ int e_idx[8][CF_WE];
+  __shared__ unsigned short e_rank[8][CF_WE];
+  __shared__ unsigned char e_q[8][CF_WE];
+  __shared__ unsigned f_cnt[8][64], f_base[8][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  unsigned wcnt = 0;
+  const int split = blockIdx.x % nsplit;
+  const long q0 = (long)(blockIdx.x / nsplit) * 256;
+  const long r_begin = g_begin + (long)split * rows_per_split;
+  long r_end = r_begin + rows_per_split;
+  if (r_end > g_end) r_end = g_end;
+  if (r_begin >= r_end) return;
+  const long qw0 = q0 + w * 32;
+  const long q = qw0 + l31;
+  const bool ok = q < nq;
+  s16x8 qf[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    s16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ok) v = *(const s16x8*)(Qb + q * (long)(RB / 2) + ks * 16 + hi * 8);
+    qf[ks] = v;
+  }
+  const float cut = (ok && !BOOT) ? thr[q] - cbir_eps(qnorm, q, gmax_bits) : __uint_as_float(0x7f800000u);
+  const long ntile = (r_end - r_begin + 31) / 32;
+  // DMA one 32-row tile: NK / 8 instructions per wave; LDS slot (row, cp) holds chunk cp ^ (row & 15) of that row
+#define CW_ISSUE(buf, t)                                                                                                  \
+  do {                                                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < NK / 8; ++j) {                                                                   \
+      const int L = j * 512 + w * 64 + lane;                                                                              \
+      const int row = L / CH, cp = L % CH, c = cp ^ (row & 15);                                                           \
+      long grow = r_begin + (long)(t) * 32 + row;                                                                         \
+      if (grow > r_end - 1) grow = r_end - 1;                                                                             \
+      const bf16_t* src = Gb + grow * (long)(RB / 2) + c * 8;                                                             \
+      unsigned char* dst = Gs + (buf) * TILEB + (j * 512 + w * 64) * 16;                                                  \
+      __builtin_amdgcn_global_load_lds(VDK_GLOBAL_PTR(src), VDK_LDS_PTR(dst), 16, 0, 0);                                   \
+    }                                                                                                                     \
+  } while (0)
+  CW_ISSUE(0, 0);
+  if (ntile > 1) CW_ISSUE(1, 1);
+  if (ntile > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (NK / 8)); else __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  int cur = 0;
+  for (long t = 0; t < ntile; ++t) {
+    int nxt2 = cur + 2; if (nxt2 >= CF_NBUF) nxt2 -= CF_NBUF;
+    if (t + 2 < ntile) CW_ISSUE(nxt2, t + 2);
+    const unsigned char* Gt = Gs + cur * TILEB + l31 * RB;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < NK; ks += 2) {      // two accumulators: consecutive MFMAs do not wait for each other
+      const s16x8 a0 = *(const s16x8*)(Gt + (((ks * 2 + hi) ^ (l31 & 15)) << 4));
+      const s16x8 a1 = *(const s16x8*)(Gt + ((((ks + 1) * 2 + hi) ^ (l31 & 15)) << 4));
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[ks], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[ks + 1], acc1, 0, 0, 0);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = acc0[r] + acc1[r];
+    float m = acc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+    const long row0 = r_begin + t * 32;
+    if (BOOT) {
+      const float tm = fmaxf(m, __shfl_xor(m, 32));
+      if (hi == 0 && ok) gm[q * gm_ld + (r_begin - g_begin) / 32 + t] = tm;
+    } else if (__any(m > cut)) {
+      CF_STAGE(acc, cut, l31, row0, t == ntile - 1);
+    }
+    if (t + 2 < ntile) __builtin_amdgcn_s_waitcnt(0x0F70 | (NK / 8)); else __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    cur = cur + 1 == CF_NBUF ? 0 : cur + 1;
+  }
+#undef CW_ISSUE
+  if (!BOOT && wcnt) { CF_FLUSH(); }
+}
+#undef CF_FLUSH
+#undef CF_STAGE
 
 // thr[q] = (k-th largest of the G group maxima) - eps_q (see BOOT above).  One workgroup per query, bitonic sort in LDS.
 #define CF_BOOT_MAXG 4096
@@ -711,7 +850,7 @@ __global__ __launch_bounds__(256) void cbir_boot_thr_kernel(const float* __restr
 // exact scores of the new candidates of every query: entries [carry[q], cnt[q]) of its list.  One workgroup per query; one
 // candidate per thread, k-ordered fmaf chain from +0 (bit-identical to oracle_ip_pair and to the fp32-MFMA scan).
 __global__ __launch_bounds__(256) void cbir_rescore_kernel(const float* __restrict__ Q, const float* __restrict__ G, int D, long idx_base, CbirCand cand,
-                                                           const unsigned* __restrict__ carry) {
+                                                           const unsigned* __restrict__ carry, int g_half) {
   __shared__ __attribute__((aligned(16))) float qs[512];
   const long q = blockIdx.x;
   for (int c = threadIdx.x; c < D; c += 256) qs[c] = Q[q * (long)D + c];
@@ -719,7 +858,7 @@ __global__ __launch_bounds__(256) void cbir_rescore_kernel(const float* __restri
   unsigned n = cand.cnt[q];
   if ((long)n > cand.cap) n = (unsigned)cand.cap;
   for (unsigned i = carry[q] + threadIdx.x; i < n; i += 256) {
-    cand.score[q * cand.cap + i] = cbir_exact_ip(qs, G + ((long)cand.idx[q * cand.cap + i] - idx_base) * (long)D, D);
+    cand.score[q * cand.cap + i] = cbir_exact_ip_any(qs, G, (long)cand.idx[q * cand.cap + i] - idx_base, D, g_half);
   }
 }
 
@@ -746,6 +885,50 @@ __global__ void cbir_fill_from_lists_kernel(CbirCand cand, const float* __restri
   (void)n;
 }
 
+// ---- second stream + events of the pipelined schedule (created once per process; timing disabled) ------------------------------------------------------
+#include <vector>
+static hipStream_t g_cb_s2 = nullptr;
+static std::vector<hipEvent_t> g_cb_ev;
+static int g_cb_pipeline = -1;
+static bool cb_pipeline_enabled() {
+  // default OFF: measured on the MI355X (10 k x 1 M x 128, k = 100) the pipelined schedule is SLOWER, 5.1 ms against 3.6 - 3.85 ms sequential -- the ranking
+  // workgroups take CU slots and LDS from the one-workgroup-per-CU scan (its launches average 276 us instead of 171 us) and the one-stage-older thresholds let
+  // more rows survive.  Kept behind VDK_CBIR_PIPELINE=1 with its tests (bit-identical results).
+  if (g_cb_pipeline < 0) { const char* e = getenv("VDK_CBIR_PIPELINE"); g_cb_pipeline = (e && e[0] == '1') ? 1 : 0; }
+  return g_cb_pipeline == 1;
+}
+static hipStream_t cb_side_stream() {
+  if (!g_cb_s2 && hipStreamCreateWithFlags(&g_cb_s2, hipStreamNonBlocking) != hipSuccess) g_cb_s2 = nullptr;
+  return g_cb_s2;
+}
+static int cb_event(size_t i, hipEvent_t* e) {
+  while (g_cb_ev.size() <= i) {
+    hipEvent_t x;
+    if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) return 1;
+    g_cb_ev.push_back(x);
+  }
+  *e = g_cb_ev[i];
+  return 0;
+}
+static int cb_record(size_t slot, hipStream_t on) { hipEvent_t e; if (cb_event(slot, &e)) return 1; return hipEventRecord(e, on) != hipSuccess; }
+static int cb_wait(size_t slot, hipStream_t who) { hipEvent_t e; if (cb_event(slot, &e)) return 1; return hipStreamWaitEvent(who, e, 0) != hipSuccess; }
+static int cb_order(size_t slot, hipStream_t from, hipStream_t to) { return cb_record(slot, from) || cb_wait(slot, to); }
+__global__ void cbir_arm_kernel(unsigned* __restrict__ cnt_a, unsigned* __restrict__ cnt_b, long nq, unsigned reserve) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nq) { cnt_a[i] = reserve; cnt_b[i] = reserve; }
+}
+
+template <bool BOOT>
+static void cb_launch_prefilter(hipStream_t stream, int DP, unsigned grid, const bf16_t* Qb, const float* qnorm, long nq, const bf16_t* Gb, const unsigned* gmax_bits, long begin,
+                                long end, long rps, int nsplit, long idx_base, const float* thr, const CbirCand& cand, float* gm, long gm_ld) {
+  switch (DP) {
+    case 128: hipLaunchKernelGGL(cbir_prefilter_kernel<BOOT>, dim3(grid), dim3(512), 0, stream, Qb, qnorm, nq, Gb, gmax_bits, begin, end, rps, nsplit, idx_base, thr, cand, gm, gm_ld); break;
+    case 256: hipLaunchKernelGGL((cbir_prefilter_wide_kernel<BOOT, 16>), dim3(grid), dim3(512), 0, stream, Qb, qnorm, nq, Gb, gmax_bits, begin, end, rps, nsplit, idx_base, thr, cand, gm, gm_ld); break;
+    case 384: hipLaunchKernelGGL((cbir_prefilter_wide_kernel<BOOT, 24>), dim3(grid), dim3(512), 0, stream, Qb, qnorm, nq, Gb, gmax_bits, begin, end, rps, nsplit, idx_base, thr, cand, gm, gm_ld); break;
+    default: hipLaunchKernelGGL((cbir_prefilter_wide_kernel<BOOT, 32>), dim3(grid), dim3(512), 0, stream, Qb, qnorm, nq, Gb, gmax_bits, begin, end, rps, nsplit, idx_base, thr, cand, gm, gm_ld); break;
+  }
+}
+
 // ------------------------------------------------------------------------------------ host side
 extern "C" {
 
@@ -760,12 +943,12 @@ int vdk_l2norm_rows(const float* x, float* out, int64_t n, int32_t d, float eps,
 // rank every query's candidate list: wave-per-query kernel for k <= 256, workgroup-per-query kernels above.
 // Q != nullptr: entries [carry[q], cnt[q]) carry only an index and are re-scored exactly first (prefilter path).
 static void cb_rank(hipStream_t stream, const float* Q, const float* G, int D, long idx_base, const CbirCand& cand, long nq, int k, float* thr,
-                    float* out_scores, long long* out_idx, int write_out, unsigned* carry) {
+                    float* out_scores, long long* out_idx, int write_out, unsigned* carry, int g_half = 0, const CbirCand* dst = nullptr, int reserve = 0) {
   if (k <= 256) {
     hipLaunchKernelGGL(cbir_rank_wave_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, Q, G, D, idx_base, cand, nq, k, thr, out_scores, out_idx,
-                       write_out, carry);
+                       write_out, carry, g_half, dst ? *dst : cand, reserve);
   } else {
-    if (Q) hipLaunchKernelGGL(cbir_rescore_kernel, dim3((unsigned)nq), dim3(256), 0, stream, Q, G, D, idx_base, cand, (const unsigned*)carry);
+    if (Q) hipLaunchKernelGGL(cbir_rescore_kernel, dim3((unsigned)nq), dim3(256), 0, stream, Q, G, D, idx_base, cand, (const unsigned*)carry, g_half);
     hipLaunchKernelGGL(cbir_select_kernel, dim3((unsigned)nq), dim3(256), 0, stream, cand, nq, k, thr, out_scores, out_idx, write_out, carry);
   }
 }
@@ -841,92 +1024,163 @@ int vdk_cbir_search(const float* Q, int64_t nq, const float* G, int64_t N, int32
 }
 
 // ---- fast path host side -----------------------------------------------------------------------------------------------
-// Per-index preparation (IndexFlatIP.add time, not per search): Gb = bf16 [N, 128] zero-padded copy of G, gmax_bits[0..2] = bit
-// pattern of max_n ||G[n]|| (a float >= 0).  gnorm_ws: f32 [N] scratch.
+static inline int cb_dp(int D) { return (D + 127) / 128 * 128; }   // padded width of the bf16 copies
+static bool cb_pipeline_enabled();
+
+// Per-index preparation (IndexFlatIP.add time, not per search): Gb = bf16 [N, DP] zero-padded copy of G (DP = D rounded up to 128), gmax_bits[0..2] = bit
+// patterns of max_n (||g||, ||bf16(g)||, ||bf16(g) - g||), gmax_bits[3] = DP / 128.  gnorm_ws: f32 [3 N] scratch.  D <= 512.
 int vdk_cbir_prepare_gallery(const float* G, int64_t N, int32_t D, void* Gb, float* gnorm_ws, uint32_t* gmax_bits, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if ((!G && N > 0) || !Gb || !gnorm_ws || !gmax_bits || N < 0 || D <= 0 || D > 128) return vdk_fail(VDK_EINVAL, "vdk_cbir_prepare_gallery: bad argument (D <= 128)");
-  if (hipMemsetAsync(gmax_bits, 0, 16, stream) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vdk_cbir_prepare_gallery: memset failed");
-  if (N == 0) return VDK_OK;
-  hipLaunchKernelGGL(cbir_cast_rows_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, G, (long)N, (int)D, (bf16_t*)Gb, gnorm_ws);
+  if ((!G && N > 0) || !Gb || !gnorm_ws || !gmax_bits || N < 0 || D <= 0 || D > 512) return vdk_fail(VDK_EINVAL, "vdk_cbir_prepare_gallery: bad argument (D <= 512)");
+  const int DP = cb_dp(D);
+  hipLaunchKernelGGL(cbir_gstat_init_kernel, dim3(1), dim3(64), 0, stream, (unsigned*)gmax_bits, (unsigned)(DP / 128));
+  if (N == 0) return vdk_check_launch("vdk_cbir_prepare_gallery");
+  hipLaunchKernelGGL(cbir_cast_rows_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, G, (long)N, (int)D, DP, (bf16_t*)Gb, gnorm_ws);
   hipLaunchKernelGGL(cbir_max3_kernel, dim3(256), dim3(256), 0, stream, (const float*)gnorm_ws, (long)N, (unsigned*)gmax_bits);
   return vdk_check_launch("vdk_cbir_prepare_gallery");
 }
 
-int vdk_cbir_fast_workspace_bytes(int64_t nq, int32_t k, int64_t cap, size_t* bytes) {
+static size_t cb_fast_bytes(int64_t nq, int32_t k, int64_t cap, int DP) {
   size_t b = 0;
-  int rc = vdk_cbir_workspace_bytes(nq, k, cap, &b);
-  if (rc) return rc;
-  b += cb_align((size_t)nq * 128 * 2);   // Qb
+  vdk_cbir_workspace_bytes(nq, k, cap, &b);
+  if (cb_pipeline_enabled()) b += cb_align((size_t)nq * cap * 4) + cb_align((size_t)nq * cap * 4) + cb_align((size_t)nq * 4);   // second list set of the pipelined schedule (score, idx, cnt)
+  b += cb_align((size_t)nq * DP * 2);    // Qb
   b += cb_align((size_t)nq * 12);        // query norms (||q||, ||q~||, ||q~ - q||)
   b += cb_align((size_t)nq * 4);         // carry
   b += cb_align((size_t)nq * CF_BOOT_MAXG * 4 < (size_t)nq * 4 * k * 4 ? (size_t)nq * CF_BOOT_MAXG * 4 : (size_t)nq * 4 * k * 4);   // bootstrap group maxima [nq, G <= min(4k, 4096)]
-  *bytes = b;
+  return b;
+}
+int vdk_cbir_fast_workspace_bytes(int64_t nq, int32_t k, int64_t cap, size_t* bytes) {   // D <= 128
+  size_t b = 0;
+  int rc = vdk_cbir_workspace_bytes(nq, k, cap, &b);
+  if (rc) return rc;
+  *bytes = cb_fast_bytes(nq, k, cap, 128);
+  return VDK_OK;
+}
+int vdk_cbir_fast2_workspace_bytes(int64_t nq, int32_t D, int32_t k, int64_t cap, size_t* bytes) {
+  size_t b = 0;
+  int rc = vdk_cbir_workspace_bytes(nq, k, cap, &b);
+  if (rc) return rc;
+  if (D <= 0 || D > 512) return vdk_fail(VDK_EINVAL, "vdk_cbir_fast2_workspace_bytes: D <= 512");
+  *bytes = cb_fast_bytes(nq, k, cap, cb_dp(D));
   return VDK_OK;
 }
 
-// Same contract and bit-identical results as vdk_cbir_search, for D <= 128: bf16 pre-filter + exact re-scoring.
-int vdk_cbir_search_fast(const float* Q, int64_t nq, const float* G, const void* Gb, const uint32_t* gmax_bits, int64_t N, int32_t D, int32_t k,
-                         int64_t idx_base, float* out_scores, int64_t* out_idx, int64_t cap, void* ws, size_t ws_bytes, void* stream_) {
+// Bit-identical results to vdk_cbir_search for D <= 512: bf16 pre-filter with a rigorous error bound + exact re-scoring of the survivors.
+//   g_dtype   VDK_F32: G is the fp32 gallery.  VDK_F16: G holds the rows in fp16 (faiss's useFloat16 storage, engine/cbir/evaluation.py:157-162); scores are the
+//             k-ordered fp32 fmaf chain over those fp16 values (pass queries that are fp16-representable to reproduce faiss's fp16 x fp16 -> fp32 product).
+//   schedule  0: guaranteed -- stages of at most cap - k rows, candidate lists cannot overflow whatever the data (16 prefilter + 16 rank launches at 1 M rows, cap 65 536).
+//             1: optimistic -- bootstrap, one stage over the first eighth of the gallery, one over the rest (2 + 4 launches); the lists hold `cap` entries and
+//                *overflow_out (device u32, may be NULL) is set when a query produced more survivors than that: the results are then INVALID and the caller
+//                repeats the search with schedule 0 (visiondk_amd/cbir.py does).  Typical survivors per query: ~10^3 over a 10^6-row scan.
+int vdk_cbir_search_fast2(const float* Q, int64_t nq, const void* G, int32_t g_dtype, const void* Gb, const uint32_t* gmax_bits, int64_t N, int32_t D, int32_t k,
+                          int64_t idx_base, float* out_scores, int64_t* out_idx, int64_t cap, int32_t schedule, uint32_t* overflow_out, void* ws, size_t ws_bytes,
+                          void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!Q || (!G && N > 0) || (!Gb && N > 0) || !gmax_bits || !out_scores || !out_idx || nq < 0 || N < 0 || D <= 0 || D > 128 || (D & 3) || k <= 0 || k > 1024)
-    return vdk_fail(VDK_EINVAL, "vdk_cbir_search_fast: bad argument (need D % 4 == 0, D <= 128, 1 <= k <= 1024)");
-  if (idx_base + N > 0x7fffffffLL) return vdk_fail(VDK_EINVAL, "vdk_cbir_search_fast: index range exceeds int32");
+  if (!Q || (!G && N > 0) || (!Gb && N > 0) || !gmax_bits || !out_scores || !out_idx || nq < 0 || N < 0 || D <= 0 || D > 512 || (D & 3) || k <= 0 || k > 1024)
+    return vdk_fail(VDK_EINVAL, "vdk_cbir_search_fast2: bad argument (need D % 4 == 0, D <= 512, 1 <= k <= 1024)");
+  if (g_dtype != VDK_F32 && g_dtype != VDK_F16) return vdk_fail(VDK_EINVAL, "vdk_cbir_search_fast2: g_dtype must be VDK_F32 or VDK_F16");
+  if (g_dtype == VDK_F16 && (D & 7)) return vdk_fail(VDK_EINVAL, "vdk_cbir_search_fast2: fp16 storage needs D % 8 == 0");
+  if (idx_base + N > 0x7fffffffLL) return vdk_fail(VDK_EINVAL, "vdk_cbir_search_fast2: index range exceeds int32");
   if (nq == 0) return VDK_OK;
-  size_t need = 0;
-  int rc = vdk_cbir_fast_workspace_bytes(nq, k, cap, &need);
-  if (rc) return rc;
-  if (!ws || ws_bytes < need) return vdk_fail(VDK_EWORKSPACE, "vdk_cbir_search_fast: workspace too small");
+  const int DP = cb_dp(D), g_half = g_dtype == VDK_F16;
+  const int QB = DP == 128 ? CF_BQ : 256, BG = DP == 128 ? CF_BG : 32;      // queries per workgroup, rows per gallery tile
+  size_t need = cb_fast_bytes(nq, k, cap, DP);
+  if (!ws || ws_bytes < need) return vdk_fail(VDK_EWORKSPACE, "vdk_cbir_search_fast2: workspace too small");
   CbirCand cand; float* thr;
-  rc = cb_carve(ws, ws_bytes, nq, k, cap, &cand, &thr);
+  int rc = cb_carve(ws, ws_bytes, nq, k, cap, &cand, &thr);
   if (rc) return rc;
   size_t base_bytes = 0; vdk_cbir_workspace_bytes(nq, k, cap, &base_bytes);
   char* p = (char*)ws + base_bytes;
-  bf16_t* Qb = (bf16_t*)p; p += cb_align((size_t)nq * 128 * 2);
+  CbirCand cand2 = cand;                                   // second list set (pipelined schedule only)
+  if (cb_pipeline_enabled()) {
+    cand2.score = (float*)p; p += cb_align((size_t)nq * cap * 4);
+    cand2.idx = (int*)p; p += cb_align((size_t)nq * cap * 4);
+    cand2.cnt = (unsigned*)p; p += cb_align((size_t)nq * 4);
+  }
+  bf16_t* Qb = (bf16_t*)p; p += cb_align((size_t)nq * DP * 2);
   float* qnorm = (float*)p; p += cb_align((size_t)nq * 12);
   unsigned* carry = (unsigned*)p; p += cb_align((size_t)nq * 4);
   float* gm = (float*)p;
+  const float* Gf = (const float*)G;
   hipLaunchKernelGGL(cbir_init_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, cand.cnt, thr, cand.overflow, (long)nq);
-  if (hipMemsetAsync(carry, 0, (size_t)nq * 4, stream) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vdk_cbir_search_fast: memset failed");
-  hipLaunchKernelGGL(cbir_cast_rows_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, Q, (long)nq, (int)D, Qb, qnorm);
-  const long qblocks = (long)((nq + CF_BQ - 1) / CF_BQ);
+  if (hipMemsetAsync(carry, 0, (size_t)nq * 4, stream) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vdk_cbir_search_fast2: memset failed");
+  hipLaunchKernelGGL(cbir_cast_rows_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, Q, (long)nq, (int)D, DP, Qb, qnorm);
+  const long qblocks = (long)((nq + QB - 1) / QB);
   const long max_stage = cap - k;
   long begin = 0, stage = 512;
-  // threshold bootstrap on a sample of NG full 128-row tiles, k <= NG <= min(4k, 4096)
-  long NG = N / CF_BG;
+  bool booted = false;
+  // threshold bootstrap on a sample of NG full tiles, k <= NG <= min(4k, 4096)
+  long NG = N / BG;
   if (NG > 4L * k) NG = 4L * k;
   if (NG > CF_BOOT_MAXG) NG = CF_BOOT_MAXG;
   if (NG >= k) {
     long ns = 256 / qblocks;
     if (ns > NG / 4) ns = NG / 4;
     if (ns < 1) ns = 1;
-    const long rps = ((NG + ns - 1) / ns) * CF_BG;
-    hipLaunchKernelGGL(cbir_prefilter_kernel<true>, dim3((unsigned)(qblocks * ns)), dim3(512), 0, stream, (const bf16_t*)Qb, (const float*)qnorm, (long)nq,
-                       (const bf16_t*)Gb, (const unsigned*)gmax_bits, 0L, NG * CF_BG, rps, (int)ns, (long)idx_base, (const float*)thr, cand, gm, NG);
+    const long rps = ((NG + ns - 1) / ns) * BG;
+    cb_launch_prefilter<true>(stream, DP, (unsigned)(qblocks * ns), Qb, qnorm, (long)nq, (const bf16_t*)Gb, (const unsigned*)gmax_bits, 0L, NG * BG, rps, (int)ns, (long)idx_base,
+                              thr, cand, gm, NG);
     hipLaunchKernelGGL(cbir_boot_thr_kernel, dim3((unsigned)nq), dim3(256), 0, stream, (const float*)gm, (int)NG, (int)k, (const float*)qnorm,
                        (const unsigned*)gmax_bits, thr);
     stage = max_stage;   // the cut is already tight: no ramp
+    booted = true;
   }
   if (stage > max_stage) stage = max_stage;
+  const bool optimistic = schedule == 1 && booted;      // without a bootstrap threshold the first stage passes everything: keep the guaranteed ramp
+  if (optimistic) { stage = (N / 8 + BG - 1) / BG * BG; if (stage < BG) stage = BG; }
+  // Pipelined stages (k <= 256, more than two stages ahead): the ranking of stage i runs on a second stream while the pre-filter of stage i + 1 scans, so only
+  // the scan is on the critical path.  Two list sets alternate; a list's slots [0, k) are reserved for the carried top-k, which the ranking writes into the
+  // OTHER set; stage i + 1 filters with the threshold of stage i - 1 (any earlier threshold is a valid lower bound: the results stay bit-identical,
+  // a few more rows survive).  Dependencies: P(i) after R(i-2) [threshold, list reuse]; R(i) after P(i) and R(i-1) [same stream].
+  const bool pipelined = !optimistic && k <= 256 && cb_pipeline_enabled() && (N - begin) > 2 * stage;
+  hipStream_t s2 = stream;
+  if (pipelined) {
+    s2 = cb_side_stream();
+    if (!s2) return vdk_fail(VDK_ELAUNCH, "vdk_cbir_search_fast2: side stream");
+    hipLaunchKernelGGL(cbir_arm_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, cand.cnt, cand2.cnt, (long)nq, (unsigned)k);
+    if (cb_order(0, stream, s2)) return vdk_fail(VDK_ELAUNCH, "vdk_cbir_search_fast2: event");     // s2 starts after the setup on `stream`
+  }
+  long si = 0;
   while (begin < N) {
     long end = begin + stage; if (end > N) end = N;
-    const long rows = end - begin, tiles = (rows + CF_BG - 1) / CF_BG;
+    const long rows = end - begin, tiles = (rows + BG - 1) / BG;
     // one round of workgroups over the 256 CUs: qblocks * nsplit <= 256, every split at least 4 tiles long
     long nsplit_l = 256 / qblocks;
     if (nsplit_l > tiles / 4) nsplit_l = tiles / 4;
     if (nsplit_l < 1) nsplit_l = 1;
     const int nsplit = (int)nsplit_l;
-    const long rps = ((tiles + nsplit - 1) / nsplit) * CF_BG;
-    hipLaunchKernelGGL(cbir_prefilter_kernel<false>, dim3((unsigned)(qblocks * nsplit)), dim3(512), 0, stream, (const bf16_t*)Qb, (const float*)qnorm, (long)nq,
-                       (const bf16_t*)Gb, (const unsigned*)gmax_bits, begin, end, rps, nsplit, (long)idx_base, (const float*)thr, cand, (float*)nullptr, 0L);
-    cb_rank(stream, Q, G, (int)D, (long)idx_base, cand, (long)nq, (int)k, thr, out_scores, (long long*)out_idx, (int)(end == N), carry);
+    const long rps = ((tiles + nsplit - 1) / nsplit) * BG;
+    const CbirCand& cur = (pipelined && (si & 1)) ? cand2 : cand;
+    const CbirCand& oth = (pipelined && (si & 1)) ? cand : cand2;
+    if (pipelined && si >= 2 && cb_wait(2 + (si - 2) % 4, stream)) return vdk_fail(VDK_ELAUNCH, "vdk_cbir_search_fast2: event");   // P(i) after R(i-2)
+    cb_launch_prefilter<false>(stream, DP, (unsigned)(qblocks * nsplit), Qb, qnorm, (long)nq, (const bf16_t*)Gb, (const unsigned*)gmax_bits, begin, end, rps, nsplit, (long)idx_base,
+                               thr, cur, nullptr, 0L);
+    if (pipelined) {
+      if (cb_order(1, stream, s2)) return vdk_fail(VDK_ELAUNCH, "vdk_cbir_search_fast2: event");                                   // R(i) after P(i)
+      cb_rank(s2, Q, Gf, (int)D, (long)idx_base, cur, (long)nq, (int)k, thr, out_scores, (long long*)out_idx, (int)(end == N), carry, g_half, &oth, (int)k);
+      if (cb_record(2 + si % 4, s2)) return vdk_fail(VDK_ELAUNCH, "vdk_cbir_search_fast2: event");
+    } else {
+      cb_rank(stream, Q, Gf, (int)D, (long)idx_base, cand, (long)nq, (int)k, thr, out_scores, (long long*)out_idx, (int)(end == N), carry, g_half);
+    }
     begin = end;
-    stage *= 8;
-    if (stage > max_stage) stage = max_stage;
+    ++si;
+    if (optimistic) stage = N;   // the rest in one stage
+    else { stage *= 8; if (stage > max_stage) stage = max_stage; }
   }
+  if (pipelined && si > 0 && cb_wait(2 + (si - 1) % 4, stream)) return vdk_fail(VDK_ELAUNCH, "vdk_cbir_search_fast2: event");      // join: results are ordered before what follows on `stream`
   if (N == 0)
-    cb_rank(stream, Q, G, (int)D, (long)idx_base, cand, (long)nq, (int)k, thr, out_scores, (long long*)out_idx, 1, carry);
-  return vdk_check_launch("vdk_cbir_search_fast");
+    cb_rank(stream, Q, Gf, (int)D, (long)idx_base, cand, (long)nq, (int)k, thr, out_scores, (long long*)out_idx, 1, carry, g_half);
+  if (overflow_out && hipMemcpyAsync(overflow_out, cand.overflow, 4, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+    return vdk_fail(VDK_ELAUNCH, "vdk_cbir_search_fast2: memcpy failed");
+  return vdk_check_launch("vdk_cbir_search_fast2");
+}
+
+// the original entry point: fp32 gallery, D <= 128, guaranteed schedule
+int vdk_cbir_search_fast(const float* Q, int64_t nq, const float* G, const void* Gb, const uint32_t* gmax_bits, int64_t N, int32_t D, int32_t k,
+                         int64_t idx_base, float* out_scores, int64_t* out_idx, int64_t cap, void* ws, size_t ws_bytes, void* stream_) {
+  if (D > 128) return vdk_fail(VDK_EINVAL, "vdk_cbir_search_fast: D <= 128 (vdk_cbir_search_fast2 takes D <= 512)");
+  return vdk_cbir_search_fast2(Q, nq, G, VDK_F32, Gb, gmax_bits, N, D, k, idx_base, out_scores, out_idx, cap, 0, nullptr, ws, ws_bytes, stream_);
 }
 
 // Merge S per-shard results (scores [S,nq,k], idx [S,nq,k], -1 = empty) into the global top-k with the

@@ -189,6 +189,28 @@ __global__ __launch_bounds__(512) void reduce_rows_f32_kernel(const float* __res
     out[c] = (((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]))) * scale;
 }
 
+// Several such reductions in ONE launch (the six small ones a transformer block's backward leaves behind: two LayerNorm dgamma|dbeta pairs, four Linear
+// bias gradients): ~10 us each as separate launches, i.e. at the launch-latency floor.  Jobs travel by value in the kernel arguments.
+struct ReduceBatch { VdkReduceJob job[8]; int first_block[9]; int n; };
+__global__ __launch_bounds__(512) void reduce_rows_batch_kernel(ReduceBatch b) {
+  __shared__ float red[8][64];
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.first_block[j + 1]) ++j;
+  const VdkReduceJob jb = b.job[j];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const long c = (long)((int)blockIdx.x - b.first_block[j]) * 64 + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < jb.n) {
+    int k = rg;
+    for (; k + 8 < jb.S; k += 16) { s0 += jb.in[(long)k * jb.ld + c]; s1 += jb.in[(long)(k + 8) * jb.ld + c]; }
+    if (k < jb.S) s0 += jb.in[(long)k * jb.ld + c];
+  }
+  red[rg][cl] = s0 + s1;
+  __syncthreads();
+  if (rg == 0 && c < jb.n)
+    jb.out[c] = (((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]))) * jb.scale;
+}
+
 // partial[split][c] = sum over this split's rows of in[r][c]  (bf16 input).  Block = 32 column chunks (16 B = 8 columns)
 // x 8 row lanes; every load is 16 B and a wave reads 512 contiguous bytes of a row.
 __global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const bf16_t* __restrict__ in, long ld, int T, int N,
@@ -454,10 +476,10 @@ int vdk_layernorm_bwd_workspace_bytes(int32_t T, int32_t C, size_t* bytes) {
 }
 // dy: bf16 or f32 [T, lddy]; x f32 rows (ldx); dres optional f32 residual-stream gradient added to dx;
 // outputs dx (f32, optional), dxb (bf16 copy, optional), dgamma/dbeta [C] (overwritten).
-int vdk_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean,
-                      const float* rstd, const float* gamma, const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx,
-                      int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                      void* stream_) {
+static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean,
+                       const float* rstd, const float* gamma, const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx,
+                       int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                       void* stream_, VdkReduceJob* deferred) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!dy || !x || !mean || !rstd || !gamma || !dgamma || !dbeta || T <= 0 || C <= 0 || (C & 3) || C > 4096)
     return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: bad argument (C % 4 == 0, C <= 4096)");
@@ -472,6 +494,11 @@ int vdk_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const floa
   if (C <= 1024) { if (bf) LNB(4, true); else LNB(4, false); }
   else { if (bf) LNB(16, true); else LNB(16, false); }
 #undef LNB
+  if (deferred && dbeta == dgamma + C) {      // the caller batches the partial-sum reduction with others (vdk_reduce_rows_batch)
+    *deferred = VdkReduceJob{pg, (long)(2 * C), nb, (long)(2 * C), dgamma, 1.0f};
+    return vdk_check_launch("vdk_layernorm_bwd");
+  }
+  if (deferred) deferred->in = nullptr;
   if (dbeta == dgamma + C) {        // norm.weight / norm.bias of the flat gradient buffer (C % 64 == 0): one launch
     hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((2 * C + 63) / 64)), dim3(512), 0, stream, (const float*)pg, (long)(2 * C), nb,
                        (long)(2 * C), dgamma, 1.0f);
@@ -482,6 +509,12 @@ int vdk_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const floa
                        (long)C, dbeta, 1.0f);
   }
   return vdk_check_launch("vdk_layernorm_bwd");
+}
+int vdk_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean,
+                      const float* rstd, const float* gamma, const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx,
+                      int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                      void* stream_) {
+  return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, mean, rstd, gamma, dres, lddres, T, C, dx, lddx, dxb, lddxb, dgamma, dbeta, ws, ws_bytes, stream_, nullptr);
 }
 
 static inline int colsum_splits(int T) { int s = (T + 255) / 256; if (s > 128) s = 128; if (s < 1) s = 1; return s; }
@@ -550,3 +583,29 @@ int vdk_bce_logits(const float* logits, int64_t ldl, const float* targets, int64
 }
 
 }  // extern "C"
+
+// ---- in-library helpers (C++ linkage, declared in vdk_host.h) ---------------------------------------------------------------------------------
+// LayerNorm backward whose dgamma | dbeta partial-sum reduction is left to the caller: *job describes it (job->in == NULL if it was done here after all)
+int vdk_layernorm_bwd_deferred(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
+                               const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx, int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta,
+                               void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job) {
+  return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, mean, rstd, gamma, dres, lddres, T, C, dx, lddx, dxb, lddxb, dgamma, dbeta, ws, ws_bytes, stream, job);
+}
+int vdk_reduce_rows_batch(const VdkReduceJob* jobs, int n, void* stream) {
+  if (n < 0 || (n > 0 && !jobs)) return vdk_fail(VDK_EINVAL, "vdk_reduce_rows_batch: bad argument");
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    ReduceBatch b;
+    b.n = 0;
+    int blocks = 0;
+    for (int i = i0; i < n && b.n < 8; ++i) {
+      if (!jobs[i].in || jobs[i].n <= 0) continue;
+      b.first_block[b.n] = blocks;
+      b.job[b.n++] = jobs[i];
+      blocks += (int)((jobs[i].n + 63) / 64);
+    }
+    b.first_block[b.n] = blocks;
+    if (blocks > 0) hipLaunchKernelGGL(reduce_rows_batch_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, b);
+  }
+  return vdk_check_launch("vdk_reduce_rows_batch");
+}
+

@@ -16,3 +16,10 @@ struct VdkTcItem { const float* in; void* out; int ldi, R, C, ldo, Rpad; };
 int vdk_transpose_cast_batch(const VdkTcItem* items, int n, void* stream);
 // out bf16 [R, ldo] = in f32 [R, C] (row stride ldi) with the columns [C, ldo) zero-filled (operand copies of weights whose row length is not a multiple of 8)
 int vdk_cast_pad_rows(const float* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, void* stream);
+
+// out[c] = scale * sum_{s < S} in[s * ld + c], c < n: one of up to 8 row reductions that vdk_reduce_rows_batch runs in a single launch
+struct VdkReduceJob { const float* in; long ld; int S; long n; float* out; float scale; };
+int vdk_reduce_rows_batch(const VdkReduceJob* jobs, int n, void* stream);
+int vdk_layernorm_bwd_deferred(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
+                               const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx, int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta,
+                               void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job);

@@ -176,7 +176,7 @@ struct WsPlan {
   size_t dvec;                   // fp32 [B,H,N]
   size_t tA, tB;                 // bf16 [max(M,3D,Cp), Tp] each
   size_t slabs, slabs_bytes;
-  size_t lnws, lnws_bytes, csws, csws_bytes;
+  size_t lnws, lnws_bytes, csws, csws_bytes;   // lnws: 2 buffers of lnws_bytes, csws: 5 of csws_bytes (a block's deferred reductions read them at its end)
   size_t dhf;                    // bf16 [B, D]
   size_t dposall;                // fp32 [N, D]
 };
@@ -235,11 +235,11 @@ static int vit_plan(const VitDims& d, WsPlan* w) {
     }
   }
   w->slabs_bytes = sl; w->slabs = w_take(cur, sl);
-  vdk_layernorm_bwd_workspace_bytes(d.T, d.D, &w->lnws_bytes); w->lnws = w_take(cur, w->lnws_bytes);
+  vdk_layernorm_bwd_workspace_bytes(d.T, d.D, &w->lnws_bytes); w->lnws_bytes = (w->lnws_bytes + 255) & ~(size_t)255; w->lnws = w_take(cur, 2 * w->lnws_bytes);
   size_t cs = (size_t)((tcols + 63) / 64) * trows * 4;   // per-row-tile column sums written by the dY transposes ...
   { size_t cs2 = 0; vdk_colsum_bf16_workspace_bytes(d.T, (int)trows, &cs2); if (cs2 > cs) cs = cs2; }   // ... or by vdk_colsum_bf16
   { size_t cs3 = (size_t)((d.T + 255) / 256) * trows * 4; if (cs3 > cs) cs = cs3; }                      // ... or by the dgrad GEMM's a_colsum by-product
-  w->csws_bytes = cs; w->csws = w_take(cur, cs);
+  w->csws_bytes = (cs + 255) & ~(size_t)255; w->csws = w_take(cur, 5 * w->csws_bytes);   // slots 0..3: a block's four fused bias-gradient partials (pending until its end), slot 4: immediate users
   w->dhf = w_take(cur, (size_t)d.B * D * 2);
   w->dposall = w_take(cur, (size_t)d.N * D * 4);
   w->total = cur;
@@ -404,11 +404,11 @@ static int linear_wgrad(hipStream_t s, const VitDims& d, const WsPlan& w, char* 
     g.A = dY; g.lda = lddy; g.B = Xa; g.ldb = ldx; g.C = dW; g.ldc = in; g.M = out; g.N = in; g.K = rows; g.c_dtype = VDK_F32;
     g.alpha = 1.0f; g.splitk = sk; g.trans = 1; g.a_row_group = dy_row_group;
     RC(vdk_gemm_bf16_nt(&g, base + w.slabs, w.slabs_bytes, s));
-    if (db && dy_row_group == 0) RC(vdk_colsum_bf16(dY, lddy, rows, out, db, base + w.csws, w.csws_bytes, s));
+    if (db && dy_row_group == 0) RC(vdk_colsum_bf16(dY, lddy, rows, out, db, base + w.csws + 4 * w.csws_bytes, w.csws_bytes, s));
     return VDK_OK;
   }
   bf16_t* tA = (bf16_t*)(base + w.tA); bf16_t* tB = (bf16_t*)(base + w.tB);
-  float* csp = (db && dy_row_group == 0) ? (float*)(base + w.csws) : nullptr;   // bias gradient rides along with the dY transpose
+  float* csp = (db && dy_row_group == 0) ? (float*)(base + w.csws + 4 * w.csws_bytes) : nullptr;   // bias gradient rides along with the dY transpose
   RC(vdk_transpose_bf16(dY, lddy, rows, out, tA, rows_pad, rows_pad, dy_row_group, csp, s));
   RC(vdk_transpose_bf16(Xa, ldx, rows, in, tB, rows_pad, rows_pad, 0, nullptr, s));
   const int sk = wgrad_splitk(out, in, rows_pad);
@@ -420,16 +420,18 @@ static int linear_wgrad(hipStream_t s, const VitDims& d, const WsPlan& w, char* 
 
 // dgrad GEMM  dX[rows, in] = act'(dY[rows, out] . Wt[in, out]^T)  that also delivers db = colsum(dY) for the same Linear: when the 256x256 NT kernel
 // serves the problem the column sums are a by-product of its A tiles (no extra pass over dY); returns 1 in *fused then, else the caller runs vdk_colsum_bf16.
+// The partial sums land in column-sum buffer `slot` (0..3) and their reduction is appended to `jobs` for the block's one batched launch.
 static int dgrad_with_bias(hipStream_t s, const WsPlan& w, char* base, const bf16_t* dY, int64_t lddy, const bf16_t* Wt, int64_t ldw, void* dX, int64_t lddx, int rows,
-                           int in, int out, int act, void* aux, int64_t ldaux, float* db, int* fused) {
+                           int in, int out, int act, void* aux, int64_t ldaux, float* db, int* fused, int slot, VdkReduceJob* jobs, int* njobs) {
   const int prow = vdk_gemm_a_colsum_rows(rows, in, out);
   *fused = (db && prow > 0 && (size_t)prow * out * 4 <= w.csws_bytes) ? 1 : 0;
+  float* const part = (float*)(base + w.csws + (size_t)slot * w.csws_bytes);
   VdkGemmDesc g = {};
   g.A = dY; g.lda = lddy; g.B = Wt; g.ldb = ldw; g.C = dX; g.ldc = lddx; g.M = rows; g.N = in; g.K = out; g.c_dtype = VDK_BF16; g.act = act; g.aux = aux;
   g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = 1;
-  if (*fused) g.a_colsum = (float*)(base + w.csws);
+  if (*fused) g.a_colsum = part;
   RC(vdk_gemm_bf16_nt(&g, nullptr, 0, s));
-  if (*fused) RC(vdk_reduce_rows_f32((const float*)(base + w.csws), out, prow, out, db, 1.0f, s));
+  if (*fused) jobs[(*njobs)++] = VdkReduceJob{part, (long)out, prow, (long)out, db, 1.0f};
   return VDK_OK;
 }
 
@@ -505,12 +507,14 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
     // straight from dY / X on the side stream.  The column sums live in csws, which the side stream's fallback paths also use: fused mode is main-stream only.
     int fz = 0;
     const bool one_stream = (s2 == s);
+    VdkReduceJob jobs[8]; int nj = 0;          // this block's small reductions (LayerNorm dgamma | dbeta, Linear bias gradients): one launch at its end
+    char* const lnws0 = base + w.lnws; char* const lnws1 = lnws0 + w.lnws_bytes;
     // MLP branch: dxa / dxab hold dL/dx_out
     RC(ev_order(ev_p++, s, s2));
     if (one_stream) {
-      RC(dgrad_with_bias(s, w, base, dxab, D, wt + p.blkT[l].fc2, D, du, M, T, M, D, VDK_ACT_DGELU, u, M, grads + b.fc2_b, &fz));                       // du
+      RC(dgrad_with_bias(s, w, base, dxab, D, wt + p.blkT[l].fc2, D, du, M, T, M, D, VDK_ACT_DGELU, u, M, grads + b.fc2_b, &fz, 0, jobs, &nj));   // du
       RC(linear_wgrad(s2, d, w, base, dxab, D, g, M, T, d.Tp, D, M, grads + b.fc2_w, fz ? nullptr : grads + b.fc2_b, 0));
-      RC(dgrad_with_bias(s, w, base, du, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, VDK_ACT_NONE, nullptr, 0, grads + b.fc1_b, &fz));                  // dh2
+      RC(dgrad_with_bias(s, w, base, du, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, VDK_ACT_NONE, nullptr, 0, grads + b.fc1_b, &fz, 1, jobs, &nj));   // dh2
       RC(linear_wgrad(s2, d, w, base, du, M, h2, D, T, d.Tp, M, D, grads + b.fc1_w, fz ? nullptr : grads + b.fc1_b, 0));
     } else {
       RC(linear_wgrad(s2, d, w, base, dxab, D, g, M, T, d.Tp, D, M, grads + b.fc2_w, grads + b.fc2_b, 0));
@@ -519,12 +523,13 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
       RC(linear_wgrad(s2, d, w, base, du, M, h2, D, T, d.Tp, M, D, grads + b.fc1_w, grads + b.fc1_b, 0));
       RC(gemm(s, du, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // dh2
     }
-    RC(vdk_layernorm_bwd(dsm, D, VDK_BF16, xmid, D, mean2, rstd2, params + b.n2w, dxa, D, T, D, dxm, D, dxmb, D, grads + b.n2w, grads + b.n2b, lnws,
-                         w.lnws_bytes, s));
+    RC(vdk_layernorm_bwd_deferred(dsm, D, VDK_BF16, xmid, D, mean2, rstd2, params + b.n2w, dxa, D, T, D, dxm, D, dxmb, D, grads + b.n2w, grads + b.n2b, lnws0,
+                                  w.lnws_bytes, s, &jobs[nj]));
+    ++nj;
     // attention branch: dxm / dxmb hold dL/dx_mid
     RC(ev_order(ev_p++, s, s2));
     if (one_stream) {
-      RC(dgrad_with_bias(s, w, base, dxmb, D, wt + p.blkT[l].proj, D, dsm, D, T, D, D, VDK_ACT_NONE, nullptr, 0, grads + b.proj_b, &fz));              // do
+      RC(dgrad_with_bias(s, w, base, dxmb, D, wt + p.blkT[l].proj, D, dsm, D, T, D, D, VDK_ACT_NONE, nullptr, 0, grads + b.proj_b, &fz, 2, jobs, &nj));   // do
       RC(linear_wgrad(s2, d, w, base, dxmb, D, o, D, T, d.Tp, D, D, grads + b.proj_w, fz ? nullptr : grads + b.proj_b, 0));
     } else {
       RC(linear_wgrad(s2, d, w, base, dxmb, D, o, D, T, d.Tp, D, D, grads + b.proj_w, grads + b.proj_b, 0));
@@ -533,14 +538,16 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
     RC(vdk_attention_bwd(qkv, 3 * D, o, dsm, D, lse, dqkv, 3 * D, dvec, d.B, d.N, d.H, 64, 0.125f, s));                                    // dqkv
     RC(ev_order(ev_p++, s, s2));
     if (one_stream) {
-      RC(dgrad_with_bias(s, w, base, dqkv, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, VDK_ACT_NONE, nullptr, 0, grads + b.qkv_b, &fz));    // dh1
+      RC(dgrad_with_bias(s, w, base, dqkv, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, VDK_ACT_NONE, nullptr, 0, grads + b.qkv_b, &fz, 3, jobs, &nj));   // dh1
       RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, fz ? nullptr : grads + b.qkv_b, 0));
     } else {
       RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, grads + b.qkv_b, 0));
       RC(gemm(s, dqkv, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));  // dh1
     }
-    RC(vdk_layernorm_bwd(dsm, D, VDK_BF16, xin, D, mean1, rstd1, params + b.n1w, dxm, D, T, D, dxa, D, DXAB(l - 1), D, grads + b.n1w, grads + b.n1b, lnws,
-                         w.lnws_bytes, s));
+    RC(vdk_layernorm_bwd_deferred(dsm, D, VDK_BF16, xin, D, mean1, rstd1, params + b.n1w, dxm, D, T, D, dxa, D, DXAB(l - 1), D, grads + b.n1w, grads + b.n1b, lnws1,
+                                  w.lnws_bytes, s, &jobs[nj]));
+    ++nj;
+    RC(vdk_reduce_rows_batch(jobs, nj, s));
     if (s2 != s) { hipEvent_t e; RC(ev_get(EV_SIDE_DONE + l + 1, &e)); if (hipEventRecord(e, s2) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vit: record failed"); }
     if (on_ready) {
       if (s2 != s) { hipEvent_t e; RC(ev_get(EV_SIDE_DONE + l + 1, &e)); if (hipStreamWaitEvent(s, e, 0) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vit: wait failed"); }
