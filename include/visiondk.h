@@ -337,6 +337,7 @@ typedef struct VdkMarginHead {
   float margin;        /* arcface: margin_arc;  circle: margin;  mv: margin */
   float margin_am;     /* arcface only */
   float mv_weight;     /* mv only */
+  const float* row_margin;   /* arcface only, optional (NULL): f32 [B] per-row margin_arc -- MagFace's magnitude-aware margin, models/faceX/head/magface.py:26-31 */
 } VdkMarginHead;
 /* ---- BatchNorm-based CNN pieces (timm ResNet BasicBlock family, `timm-resnet18` = BASELINE.json configs[0]) -------------------------
  * Convolutions run as implicit GEMMs (VdkGemmDesc.conv); these are the layouts and the non-GEMM layers around them.
@@ -362,6 +363,10 @@ int vdk_bn_act_fwd(const float* x, int64_t R, int32_t C, const float* gamma, con
                    void* ws, size_t ws_bytes, vdk_stat_sync_fn sync, void* user, void* stream);
 int vdk_bn_act_bwd(const float* x, const float* dout, const void* out_bf16, int64_t R, int32_t C, const float* gamma, const float* save_mean, const float* save_invstd,
                    void* dy_bf16, float* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, vdk_stat_sync_fn sync, void* user, void* stream);
+/* vdk_bn_act_bwd without an activation mask and with the input gradient in fp32: the BatchNorm2d / BatchNorm1d of the embedding neck
+ * (models/faceX/backbone/timm_wrapper.py:30-38) as SyncBatchNorm (sync != NULL); its forward is vdk_bn_act_fwd(relu = 0, out_f32). */
+int vdk_bn_rows_bwd(const float* x, const float* dout, int64_t R, int32_t C, const float* gamma, const float* save_mean, const float* save_invstd, float* dx,
+                    float* dgamma, float* dbeta, void* ws, size_t ws_bytes, vdk_stat_sync_fn sync, void* user, void* stream);
 /* nn.MaxPool2d(3, 2, 1) on bf16 NHWC (backward routes to the FIRST maximum in (ky, kx) order, like torch) and global average pooling.
  * argmax (optional, uint8 [B, OH, OW, C]): the winning window position 0..8 written by the forward; the backward uses it when given (in may then be NULL),
  * else it re-derives the winners from `in`. */

@@ -123,6 +123,7 @@ def main():
                       f"{tag}_loss": loss.detach().numpy(), f"{tag}_dfeats": f.grad.numpy().copy(), f"{tag}_dweight": h.weight.grad.numpy().copy()})
     heads["feats"] = feats0.numpy(); heads["labels"] = labels.numpy()
     np.savez(OUT / "heads.npz", **heads)
+    make_magface()
 
     # ---- retrieval: IndexFlatIP semantics stated in float64 (faiss is not installable; engine/cbir/evaluation.py:193) ----
     rng = np.random.default_rng(0)
@@ -205,5 +206,26 @@ def main():
     print("golden fixtures written to", OUT)
 
 
+def make_magface():
+    """models/faceX/head/magface.py (dead upstream: its tuple output is never consumed) -> tests/golden/magface.npz; loss = CE(logits) + mean(lamda * loss_g)"""
+    mag_m = load("models/faceX/head/magface.py", "ref_mag")
+    torch.manual_seed(21)
+    feats0 = torch.randn(8, 64) * torch.tensor([0.5, 1.5, 3.0, 6.0, 9.0, 12.0, 14.0, 20.0]).view(8, 1)    # norms ~4 .. 160: both clamp ends and the linear part of the margin
+    labels = torch.randint(0, 257, (8,))
+    torch.manual_seed(22)
+    h = mag_m.MagFace(64, 257, margin_am=0.0, scale=32, l_a=10, u_a=110, l_margin=0.45, u_margin=0.8, lamda=20)
+    with torch.no_grad():
+        h.weight[:, labels[3]] = feats0[3] + 0.3 * torch.randn(64)        # a target column close to its feature: the active margin branch with a large cosine
+    f = feats0.clone().requires_grad_(True)
+    logits, reg = h(f, labels)
+    loss = torch.nn.functional.cross_entropy(logits, labels) + reg.mean()
+    loss.backward()
+    np.savez(OUT / "magface.npz", feats=feats0.numpy(), labels=labels.numpy(), weight=h.weight.detach().numpy().copy(), logits=logits.detach().numpy(),
+             reg=reg.detach().numpy(), loss=loss.detach().numpy(), dfeats=f.grad.numpy().copy(), dweight=h.weight.grad.numpy().copy())
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "magface":
+        make_magface()
+        raise SystemExit(0)
     main()

@@ -367,3 +367,52 @@ def test_two_rank_face_step_with_class_sharded_head(tmp_path, emu):
         for p, q in zip(a["neck"], b["neck"]):
             assert rel(p, q) < 1e-3
     assert torch.equal(r0[True]["head"], r1[True]["head"]) and torch.equal(r0[True]["params"], r1[True]["params"])   # replicas agree after the gather
+
+
+# ---- SyncBatchNorm in the embedding neck: 2 ranks x half batch == 1 process x whole batch ----------------------------------------------------------
+def _face_syncbn_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["VDK_EMU_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.emu.emu_backend import load_emu
+    from visiondk_amd import comm, face
+    be = load_emu()
+    model = _face_model(be, 100)
+    c = comm.GradAllReduce(bucket_bytes=20_000)
+    step = face.FaceTrainStep(model, lr=0.05, momentum=0.9, weight_decay=5e-4, max_norm=10.0, ema=False, comm=c, sync_bn=True)
+    torch.manual_seed(7)
+    x = torch.randn(8, 3, 32, 32); y = torch.randint(0, 24, (8,))
+    step.step(x[rank * 4:rank * 4 + 4], y[rank * 4:rank * 4 + 4])
+    torch.save({k: v.clone() for k, v in model.state_dict().items()}, f"{out_dir}/sbn{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_two_rank_face_step_with_sync_batchnorm_equals_whole_batch(tmp_path, emu):
+    """FaceTrainStep(sync_bn=True): the neck's BatchNorm2d and BatchNorm1d use the statistics of BOTH ranks' samples (forward) and the global gradient sums (backward),
+    so two ranks on half the batch each leave the weights -- and the running statistics -- a single process on the whole batch leaves (the ConvNeXt backbone has
+    no BatchNorm).  Without sync_bn the statistics are per rank and the running statistics differ at 1e-2."""
+    port = 29500 + ((os.getpid() + 271) % 500)
+    mp.start_processes(_face_syncbn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "sbn0.pt"); r1 = torch.load(tmp_path / "sbn1.pt")
+    from visiondk_amd import face
+    model = _face_model(emu, 100)
+    init = {k: v.clone() for k, v in model.state_dict().items()}
+    step = face.FaceTrainStep(model, lr=0.05, momentum=0.9, weight_decay=5e-4, max_norm=10.0, ema=False)
+    torch.manual_seed(7)
+    x = torch.randn(8, 3, 32, 32); y = torch.randint(0, 24, (8,))
+    step.step(x, y)
+    sd = model.state_dict()
+    for k in sd:
+        if "num_batches" in k or k.endswith("model.head.norm.bias"):
+            continue      # head.norm.bias sits right in front of the BatchNorm2d, which removes per-channel shifts: its true gradient is 0, what is computed is rounding noise
+        a, b = r0[k].float(), sd[k].float()
+        assert torch.equal(r0[k], r1[k]) or "running" in k, k            # replicas identical (running statistics are identical too: they come from the global sums)
+        if "running" in k:
+            assert torch.allclose(r0[k], r1[k]) and torch.allclose(a, b, rtol=1e-4, atol=1e-5), k
+        else:
+            da, db = a - init[k].float(), b - init[k].float()
+            rel = ((da - db).norm() / db.norm().clamp_min(1e-12)).item()
+            assert rel < 3e-2, (k, rel)

@@ -91,8 +91,24 @@ def test_sharded_form_with_one_shard_equals_fused_form(be, dev, tag):
     assert _rel(l2, l1) < 1e-6 and _rel(df2, df1) < 1e-3 and _rel(dW2, dW1) < 1e-3
 
 
+def test_magface_vs_reference_module(be, dev):
+    """MagFace (models/faceX/head/magface.py:26-47): logits, the magnitude regulariser and the gradients of CE(logits) + mean(regulariser), including the path through
+    the magnitude-dependent margin, against the reference module's own outputs (tests/golden/magface.npz)"""
+    z = np.load(G.parent / "magface.npz")
+    h = heads.HeadFactory("magface", {"feat_dim": 64, "num_class": 257}, backend=be, device=dev).get_head()
+    with torch.no_grad():
+        h.weight.copy_(torch.from_numpy(z["weight"]).to(dev))
+    feats = torch.from_numpy(z["feats"]).to(dev).requires_grad_(True)
+    labels = torch.from_numpy(z["labels"]).to(dev)
+    logits, reg = h(feats, labels)
+    assert (logits.detach().cpu() - torch.from_numpy(z["logits"])).abs().max().item() / 32.0 < 2e-5
+    assert torch.allclose(reg.detach().cpu(), torch.from_numpy(z["reg"]), rtol=1e-6, atol=1e-7)
+    loss = torch.nn.functional.cross_entropy(logits, labels) + reg.mean()
+    loss.backward()
+    assert abs(loss.item() - float(z["loss"])) < 1e-4 * abs(float(z["loss"]))
+    assert _rel(feats.grad, z["dfeats"]) < 5e-2 and _rel(h.weight.grad, z["dweight"]) < 5e-2
+
+
 def test_head_factory_names():
     f = heads.HeadFactory("arcface", {"feat_dim": 8, "num_class": 16}, backend=None, device="cpu")
     assert f.head_type == "arcface"
-    with pytest.raises(NotImplementedError):
-        heads.HeadFactory("magface", {}, device="cpu").get_head()

@@ -79,8 +79,8 @@ def _face_model(be, seed, classes=24):
     return model
 
 
-@pytest.mark.parametrize("shard_head", [False, True])
-def test_face_step_through_rccl(hip, rccl, shard_head):
+@pytest.mark.parametrize("shard_head,sync_bn", [(False, False), (True, False), (False, True)])
+def test_face_step_through_rccl(hip, rccl, shard_head, sync_bn):
     """FaceTrainStep(comm=...): backbone buckets + neck / head gradients + BatchNorm buffer broadcasts through RCCL; with shard_head the class-sharded margin
     head (all-gathered features, three small all-reduces for the softmax across the shards, one for the feature gradient) on one rank holding all the classes."""
     from visiondk_amd import comm, face
@@ -88,7 +88,8 @@ def test_face_step_through_rccl(hip, rccl, shard_head):
     for use_comm in (False, True):
         model = _face_model(hip, 21)
         c = comm.GradAllReduce(bucket_bytes=20_000, always_communicate=True) if use_comm else None
-        step = face.FaceTrainStep(model, lr=0.05, momentum=0.9, weight_decay=5e-4, max_norm=10.0, ema=True, comm=c, shard_head=shard_head and use_comm)
+        step = face.FaceTrainStep(model, lr=0.05, momentum=0.9, weight_decay=5e-4, max_norm=10.0, ema=True, comm=c, shard_head=shard_head and use_comm,
+                                  sync_bn=sync_bn and use_comm)
         torch.manual_seed(5)
         for _ in range(2):
             x = torch.randn(8, 3, 32, 32).cuda(); y = torch.randint(0, 24, (8,)).cuda()
@@ -99,11 +100,13 @@ def test_face_step_through_rccl(hip, rccl, shard_head):
         res.append(({k: v.clone() for k, v in model.state_dict().items()}, rows.clone()))
     for k in res[0][0]:
         a, b = res[0][0][k].float(), res[1][0][k].float()
-        if shard_head:      # the sharded head is a different kernel sequence (local statistics + global combine): same math, fp32 rounding differs
+        if shard_head or sync_bn:      # the sharded head / the three-kernel SyncBatchNorm are different kernel sequences: same math, fp32 rounding differs
+            if k.endswith("model.head.norm.bias"):
+                continue                   # analytically zero gradient in front of the BatchNorm2d: pure rounding noise
             assert ((a - b).norm() / a.norm().clamp_min(1e-30)).item() < 2e-3, k
         else:
             assert torch.equal(a, b), k
-    assert torch.allclose(res[0][1], res[1][1], rtol=1e-4 if shard_head else 0, atol=0)
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-4 if (shard_head or sync_bn) else 0, atol=0)
 
 
 def test_resnet_step_with_sync_batchnorm_through_rccl(hip, rccl):

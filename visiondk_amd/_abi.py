@@ -52,7 +52,7 @@ class ResNetConfig(C.Structure):
 
 class MarginHead(C.Structure):
     """VdkMarginHead of include/visiondk.h"""
-    _fields_ = [("mode", I32), ("scale", F32), ("margin", F32), ("margin_am", F32), ("mv_weight", F32)]
+    _fields_ = [("mode", I32), ("scale", F32), ("margin", F32), ("margin_am", F32), ("mv_weight", F32), ("row_margin", P)]
 
 
 F16_ = 2   # VDK_F16
@@ -151,6 +151,7 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_bn_rows_workspace_bytes": (C.c_int, [I64, I32, PSZ]),
     "vdk_bn_act_fwd": (C.c_int, [P, I64, I32, P, P, C.c_float, C.c_float, I32, P, P, P, P, I32, P, P, P, P, P, SZ, P, P, P]),
     "vdk_bn_act_bwd": (C.c_int, [P, P, P, I64, I32, P, P, P, P, P, P, P, P, SZ, P, P, P]),
+    "vdk_bn_rows_bwd": (C.c_int, [P, P, I64, I32, P, P, P, P, P, P, P, SZ, P, P, P]),
     "vdk_maxpool3s2_fwd": (C.c_int, [P, P, P, I32, I32, I32, I32, P]),
     "vdk_maxpool3s2_bwd": (C.c_int, [P, P, P, P, I32, I32, I32, I32, P]),
     "vdk_avgpool_fwd": (C.c_int, [P, P, I32, I32, I32, I32, P]),

@@ -20,7 +20,15 @@ struct MarginP {
   float cos_m, sin_m, min_cos, m_am;   // arcface: cos(m), sin(m), cos(pi - m), margin_am
   float Op, On, dp, dn;                // circle: 1+m, -m, 1-m, m
   float t;                             // mv_weight
+  const float* row_margin;             // arcface only, optional: per-row additive angular margin (MagFace's magnitude-aware margin), overrides m
 };
+// MagFace (models/faceX/head/magface.py:26-47): ArcFace whose margin is a function of the row's feature norm; the kernels take it per row
+__device__ __forceinline__ void margin_row_params(MarginP& P, int row) {
+  if (P.row_margin) {
+    const float m = P.row_margin[row];
+    P.m = m; P.cos_m = cosf(m); P.sin_m = sinf(m); P.min_cos = cosf(3.14159265358979323846f - m);
+  }
+}
 
 struct RowCtx { float thr, final_gt, dfinal; };   // MV-Softmax per-row quantities derived from gt = cos[i][y_i]
 
@@ -135,6 +143,7 @@ __global__ __launch_bounds__(256) void margin_ce_kernel(MarginP P, const float* 
                                                         float* __restrict__ loss_rows, bf16_t* __restrict__ dcos, long lddc) {
   __shared__ float red[4];
   const int row = blockIdx.x, tid = threadIdx.x;
+  margin_row_params(P, row);
   const float* cr = cosv + (long)row * ldc;
   const int yt = (int)y[row];
   const RowCtx R = margin_row_ctx(P, cr[yt]);
@@ -176,6 +185,7 @@ __global__ __launch_bounds__(256) void margin_ce_vec_kernel(MarginP P, const flo
                                                             long lddc) {
   __shared__ float red[4];
   const int row = blockIdx.x, tid = threadIdx.x;
+  margin_row_params(P, row);
   const float* cr = cosv + (long)row * ldc;
   const int yt = (int)y[row];
   const RowCtx R = margin_row_ctx(P, cr[yt]);
@@ -246,6 +256,7 @@ __global__ __launch_bounds__(256) void margin_stats_kernel(MarginP P, const floa
                                                            const float* __restrict__ gt, float* __restrict__ stats) {
   __shared__ float red[4];
   const int row = blockIdx.x, tid = threadIdx.x;
+  margin_row_params(P, row);
   const float* cr = cosv + (long)row * ldc;
   const long yt = (long)y[row] - c_base;                 // local target column (may lie outside this shard)
   const RowCtx R = margin_row_ctx(P, gt[row]);
@@ -283,6 +294,7 @@ __global__ __launch_bounds__(256) void margin_grad_kernel(MarginP P, const float
                                                           const long long* __restrict__ y, const float* __restrict__ gt, const float* __restrict__ gmax,
                                                           const float* __restrict__ gsum, float label_smoothing, float gscale, bf16_t* __restrict__ dcos, long lddc) {
   const int row = blockIdx.x, tid = threadIdx.x;
+  margin_row_params(P, row);
   const float* cr = cosv + (long)row * ldc;
   const long yt = (long)y[row] - c_base;
   const RowCtx R = margin_row_ctx(P, gt[row]);
@@ -313,6 +325,7 @@ __global__ __launch_bounds__(256) void margin_grad_kernel(MarginP P, const float
 __global__ __launch_bounds__(256) void margin_bwd_kernel(MarginP P, const float* __restrict__ cosv, long ldc, int C, const long long* __restrict__ y,
                                                          const float* __restrict__ dlogits, long lddl, bf16_t* __restrict__ dcos, long lddc) {
   const int row = blockIdx.x, tid = threadIdx.x;
+  margin_row_params(P, row);
   const float* cr = cosv + (long)row * ldc;
   const int yt = (int)y[row];
   const RowCtx R = margin_row_ctx(P, cr[yt]);
@@ -328,6 +341,7 @@ static int fill_params(const VdkMarginHead* h, MarginP* P) {
   P->mode = h->mode; P->s = h->scale; P->m = h->margin; P->m_am = h->margin_am; P->t = h->mv_weight;
   P->cos_m = cosf(h->margin); P->sin_m = sinf(h->margin); P->min_cos = cosf(3.14159265358979323846f - h->margin);
   P->Op = 1.0f + h->margin; P->On = -h->margin; P->dp = 1.0f - h->margin; P->dn = h->margin;
+  P->row_margin = h->mode == VDK_HEAD_ARCFACE ? h->row_margin : nullptr;
   if (h->mode < VDK_HEAD_ARCFACE || h->mode > VDK_HEAD_MV_ARC) return vdk_fail(VDK_EINVAL, "margin head: bad mode");
   return VDK_OK;
 }

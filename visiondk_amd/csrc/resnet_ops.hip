@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // g = dout * mask;  dy = gamma * invstd / R * (R g - sum g - xhat * sum(g xhat)) -> bf16;  dres = g (f32, optional: the shortcut's gradient)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dout, const bf16_t* __restrict__ outb, long n4, int C,
                                                            const float* __restrict__ count, const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const float* __restrict__ sums, bf16_t* __restrict__ dyb, float* __restrict__ dres) {
+                                                           const float* __restrict__ sums, bf16_t* __restrict__ dyb, float* __restrict__ dres, float* __restrict__ dxf) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const int c = (int)((i * 4) % C);
@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const float xh = (xv[e] - mu[e]) * is[e];
     d[e] = ga[e] * is[e] / Rf * (Rf * g[e] - sb[e] - xh * sg[e]);
   }
-  *(u32x2*)(dyb + i * 4) = (u32x2){pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
+  if (dyb) *(u32x2*)(dyb + i * 4) = (u32x2){pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
+  if (dxf) *(f32x4*)(dxf + i * 4) = (f32x4){d[0], d[1], d[2], d[3]};
   if (dres) *(f32x4*)(dres + i * 4) = g;
 }
 
@@ -350,8 +351,29 @@ int vdk_bn_act_bwd(const float* x, const float* dout, const void* out_bf16, int6
   if (sync) sync(user, sums, 2 * (int64_t)C + 1);
   const long n4 = R * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, dout, (const bf16_t*)out_bf16, n4, (int)C, (const float*)(sums + 2 * C),
-                     gamma, save_mean, save_invstd, (const float*)sums, (bf16_t*)dy_bf16, dres);
+                     gamma, save_mean, save_invstd, (const float*)sums, (bf16_t*)dy_bf16, dres, (float*)nullptr);
   return vdk_check_launch("vdk_bn_act_bwd");
+}
+// The same backward with the input gradient in fp32 and no activation mask: the BatchNorm2d / BatchNorm1d of the embedding neck
+// (models/faceX/backbone/timm_wrapper.py:30-38) under SyncBatchNorm (engine/vision_engine.py:224-225 converts EVERY BatchNorm of the model).
+int vdk_bn_rows_bwd(const float* x, const float* dout, int64_t R, int32_t C, const float* gamma, const float* save_mean, const float* save_invstd, float* dx,
+                    float* dgamma, float* dbeta, void* ws, size_t ws_bytes, vdk_stat_sync_fn sync, void* user, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !dout || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || R <= 0 || C <= 0 || (C & 3))
+    return vdk_fail(VDK_EINVAL, "vdk_bn_rows_bwd: bad argument (C % 4 == 0)");
+  const int S = bn_slices(R, C);
+  if (!ws || ws_bytes < ((size_t)S * 2 * C + 2 * (size_t)C + 64) * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_bn_rows_bwd: workspace too small");
+  float* part = (float*)ws; float* sums = part + (size_t)S * 2 * C;
+  const long rps = (R + S - 1) / S;
+  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3((unsigned)S, (unsigned)((C + 63) / 64)), dim3(512), 0, stream, x, dout, (const bf16_t*)nullptr, save_mean, save_invstd,
+                     (long)R, (int)C, rps, part);
+  hipLaunchKernelGGL(bn_combine_kernel, dim3((unsigned)((2 * C + 15) / 16)), dim3(256), 0, stream, (const float*)part, S, (int)C, (float)R, sums);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, (const float*)sums, (int)C, dgamma, dbeta);
+  if (sync) sync(user, sums, 2 * (int64_t)C + 1);
+  const long n4 = R * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, dout, (const bf16_t*)nullptr, n4, (int)C, (const float*)(sums + 2 * C),
+                     gamma, save_mean, save_invstd, (const float*)sums, (bf16_t*)nullptr, (float*)nullptr, dx);
+  return vdk_check_launch("vdk_bn_rows_bwd");
 }
 
 int vdk_maxpool3s2_fwd(const void* in, void* out, uint8_t* argmax, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {

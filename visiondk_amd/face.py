@@ -22,6 +22,40 @@ def _up(x, a):
     return (x + a - 1) // a * a
 
 
+def _bn_sync_cb(ws: torch.Tensor, group):
+    """vdk_stat_sync_fn of the neck's SyncBatchNorm: SUM all-reduce of the statistics vector the kernel sequence hands over (it lives inside `ws`)"""
+    import torch.distributed as dist
+
+    def cb(user, ptr, n):
+        off = ptr - ws.data_ptr()
+        dist.all_reduce(ws[off:off + 4 * n].view(torch.float32), op=dist.ReduceOp.SUM, group=group)
+    return _abi.STAT_SYNC_FN(cb)
+
+
+def _bn_rows_fwd(be, x, R, Cc, w, b, bn, training, y, sm, si, sync_group):
+    """BatchNorm over R rows of x f32 [R, Cc] -> y f32.  sync_group False: the fused per-rank kernel; None / a process group (training): SyncBatchNorm -- statistics
+    kernel, all-reduce of (sum x, sum x^2, count), apply (the reference converts every BatchNorm when `sync_bn` is set, engine/vision_engine.py:224-225)."""
+    if sync_group is False or not training:
+        be.check(be.lib.vdk_batchnorm1d_fwd(be.ptr(x), Cc, R, Cc, be.ptr(w), be.ptr(b), bn.eps, bn.momentum, int(training), be.ptr(bn.running_mean),
+                                            be.ptr(bn.running_var), be.ptr(y), Cc, be.ptr(sm), be.ptr(si), be.stream()), "vdk_batchnorm1d_fwd")
+        return
+    ws = ops._bn_ws(be, R, Cc, x.device)
+    cb = _bn_sync_cb(ws, sync_group)
+    be.check(be.lib.vdk_bn_act_fwd(be.ptr(x), R, Cc, be.ptr(w), be.ptr(b), bn.eps, bn.momentum, 1, be.ptr(bn.running_mean), be.ptr(bn.running_var), None, None, 0,
+                                   None, be.ptr(y), be.ptr(sm), be.ptr(si), be.ptr(ws), ws.numel(), cb, None, be.stream()), "vdk_bn_act_fwd")
+
+
+def _bn_rows_bwd(be, dy, x, R, Cc, w, sm, si, dx, dw, db, sync_group):
+    if sync_group is False:
+        be.check(be.lib.vdk_batchnorm1d_bwd(be.ptr(dy), Cc, be.ptr(x), Cc, R, Cc, be.ptr(w), be.ptr(sm), be.ptr(si), be.ptr(dx), Cc, be.ptr(dw), be.ptr(db), be.stream()),
+                 "vdk_batchnorm1d_bwd")
+        return
+    ws = ops._bn_ws(be, R, Cc, x.device)
+    cb = _bn_sync_cb(ws, sync_group)
+    be.check(be.lib.vdk_bn_rows_bwd(be.ptr(x), be.ptr(dy), R, Cc, be.ptr(w), be.ptr(sm), be.ptr(si), be.ptr(dx), be.ptr(dw), be.ptr(db), be.ptr(ws), ws.numel(), cb, None,
+                                    be.stream()), "vdk_bn_rows_bwd")
+
+
 class _NeckFn(torch.autograd.Function):
     """LayerNorm(C) -> Flatten -> Linear(N*C, F) -> BatchNorm1d(F) as one autograd node over the HIP kernels"""
 
@@ -47,13 +81,12 @@ class _NeckFn(torch.autograd.Function):
         training = bool(wrapper.training)
         sm = torch.empty(Fd, dtype=torch.float32, device=dev)
         si = torch.empty(Fd, dtype=torch.float32, device=dev)
-        be.check(be.lib.vdk_batchnorm1d_fwd(be.ptr(z), Fd, B, Fd, be.ptr(bn_w), be.ptr(bn_b), bn.eps, bn.momentum, int(training),
-                                            be.ptr(bn.running_mean), be.ptr(bn.running_var), be.ptr(y), Fd, be.ptr(sm), be.ptr(si), be.stream()),
-                 "vdk_batchnorm1d_fwd")
+        sg = getattr(wrapper, "sync_group", False)
+        _bn_rows_fwd(be, z, B, Fd, bn_w, bn_b, bn, training, y, sm, si, sg)
         if training:
             bn.num_batches_tracked += 1
         ctx.save_for_backward(tokens, ln_w, bn_w, mean, rstd, h, wb, z, sm, si)
-        ctx.wrapper, ctx.dims = wrapper, (B, N, D, Fd, K, Bp)
+        ctx.wrapper, ctx.dims, ctx.sg = wrapper, (B, N, D, Fd, K, Bp), sg
         return y
 
     @staticmethod
@@ -66,8 +99,7 @@ class _NeckFn(torch.autograd.Function):
         dy = dy.contiguous()
         dz = torch.empty((B, Fd), dtype=torch.float32, device=dev)
         dbn_w = torch.empty(Fd, dtype=torch.float32, device=dev); dbn_b = torch.empty(Fd, dtype=torch.float32, device=dev)
-        be.check(be.lib.vdk_batchnorm1d_bwd(be.ptr(dy), Fd, be.ptr(z), Fd, B, Fd, be.ptr(bn_w), be.ptr(sm), be.ptr(si), be.ptr(dz), Fd, be.ptr(dbn_w),
-                                            be.ptr(dbn_b), be.stream()), "vdk_batchnorm1d_bwd")
+        _bn_rows_bwd(be, dy, z, B, Fd, bn_w, sm, si, dz, dbn_w, dbn_b, ctx.sg)
         dzb = torch.zeros((Bp, _up(Fd, 8)), dtype=torch.bfloat16, device=dev)
         stage = torch.zeros((Bp, _up(Fd, 8)), dtype=torch.float32, device=dev)
         stage[:B, :Fd].copy_(dz)
@@ -104,23 +136,20 @@ class _NeckCNNFn(torch.autograd.Function):
         training = bool(wrapper.training)
         y2 = torch.zeros((Bp * HW, Cc), dtype=torch.float32, device=dev)
         sm2 = torch.empty(Cc, dtype=torch.float32, device=dev); si2 = torch.empty(Cc, dtype=torch.float32, device=dev)
-        be.check(be.lib.vdk_batchnorm1d_fwd(be.ptr(rows), Cc, B * HW, Cc, be.ptr(bn2_w), be.ptr(bn2_b), bn2.eps, bn2.momentum, int(training),
-                                            be.ptr(bn2.running_mean), be.ptr(bn2.running_var), be.ptr(y2), Cc, be.ptr(sm2), be.ptr(si2), be.stream()),
-                 "vdk_batchnorm1d_fwd")
+        sg = getattr(wrapper, "sync_group", False)
+        _bn_rows_fwd(be, rows, B * HW, Cc, bn2_w, bn2_b, bn2, training, y2, sm2, si2, sg)
         h = ops.cast_bf16(y2, backend=be).view(Bp, K)                           # bf16 [Bp, HW*C], pad rows zero
         wperm = lin_w.detach().view(Fd, Cc, HW).permute(0, 2, 1).reshape(Fd, K).contiguous()
         wb = ops.cast_bf16(wperm, backend=be)
         z = ops.gemm_nt(h[:B], wb, out_dtype=torch.float32, bias=lin_b.detach(), backend=be)
         y = torch.empty_like(z)
         sm = torch.empty(Fd, dtype=torch.float32, device=dev); si = torch.empty(Fd, dtype=torch.float32, device=dev)
-        be.check(be.lib.vdk_batchnorm1d_fwd(be.ptr(z), Fd, B, Fd, be.ptr(bn_w), be.ptr(bn_b), bn.eps, bn.momentum, int(training),
-                                            be.ptr(bn.running_mean), be.ptr(bn.running_var), be.ptr(y), Fd, be.ptr(sm), be.ptr(si), be.stream()),
-                 "vdk_batchnorm1d_fwd")
+        _bn_rows_fwd(be, z, B, Fd, bn_w, bn_b, bn, training, y, sm, si, sg)
         if training:
             bn.num_batches_tracked += 1
             bn2.num_batches_tracked += 1
         ctx.save_for_backward(rows, bn2_w, bn_w, h, wb, z, sm, si, sm2, si2)
-        ctx.wrapper, ctx.dims = wrapper, (B, Cc, Hh, Ww, Fd, K, Bp)
+        ctx.wrapper, ctx.dims, ctx.sg = wrapper, (B, Cc, Hh, Ww, Fd, K, Bp), sg
         return y
 
     @staticmethod
@@ -133,8 +162,7 @@ class _NeckCNNFn(torch.autograd.Function):
         dy = dy.contiguous()
         dz = torch.empty((B, Fd), dtype=torch.float32, device=dev)
         dbn_w = torch.empty(Fd, dtype=torch.float32, device=dev); dbn_b = torch.empty(Fd, dtype=torch.float32, device=dev)
-        be.check(be.lib.vdk_batchnorm1d_bwd(be.ptr(dy), Fd, be.ptr(z), Fd, B, Fd, be.ptr(bn_w), be.ptr(sm), be.ptr(si), be.ptr(dz), Fd, be.ptr(dbn_w),
-                                            be.ptr(dbn_b), be.stream()), "vdk_batchnorm1d_bwd")
+        _bn_rows_bwd(be, dy, z, B, Fd, bn_w, sm, si, dz, dbn_w, dbn_b, ctx.sg)
         stage = torch.zeros((Bp, _up(Fd, 8)), dtype=torch.float32, device=dev)
         stage[:B, :Fd].copy_(dz)
         dzb = ops.cast_bf16(stage, backend=be)
@@ -151,8 +179,7 @@ class _NeckCNNFn(torch.autograd.Function):
         dh = dh[:B].reshape(B * HW, Cc)
         dx = torch.empty((B * HW, Cc), dtype=torch.float32, device=dev)
         dbn2_w = torch.empty(Cc, dtype=torch.float32, device=dev); dbn2_b = torch.empty(Cc, dtype=torch.float32, device=dev)
-        be.check(be.lib.vdk_batchnorm1d_bwd(be.ptr(dh), Cc, be.ptr(rows), Cc, B * HW, Cc, be.ptr(bn2_w), be.ptr(sm2), be.ptr(si2), be.ptr(dx), Cc,
-                                            be.ptr(dbn2_w), be.ptr(dbn2_b), be.stream()), "vdk_batchnorm1d_bwd")
+        _bn_rows_bwd(be, dh.contiguous(), rows, B * HW, Cc, bn2_w, sm2, si2, dx, dbn2_w, dbn2_b, ctx.sg)
         return dx.view(B, Hh, Ww, Cc).permute(0, 3, 1, 2), dbn2_w, dbn2_b, dlin_w.contiguous(), dlin_b, dbn_w, dbn_b, None
 
 
@@ -358,7 +385,7 @@ class FaceTrainStep:
     launch each with the same global clip factor.  BatchNorm running statistics enter the EMA like every float entry of state_dict()."""
 
     def __init__(self, model: "FaceTrainingModel", lr: float, momentum: float = 0.9, weight_decay: float = 5e-4, label_smoothing: float = 0.0,
-                 max_norm: float = 10.0, ema: bool = True, comm=None, layer_wise: bool = False, shard_head: bool = False):
+                 max_norm: float = 10.0, ema: bool = True, comm=None, layer_wise: bool = False, shard_head: bool = False, sync_bn: bool = False):
         """shard_head (with comm): every rank keeps the columns [rank * C / world, (rank + 1) * C / world) of the margin head, trains them with
         `heads.sharded_margin_ce` (features all-gathered, per-row softmax statistics and the [B, D] feature gradient all-reduced) and never all-reduces the
         [D, C] head gradient (2 GB at C = 10^6).  `gather_head()` writes the shards back into `head.weight` for evaluation / checkpoints.
@@ -371,6 +398,9 @@ class FaceTrainStep:
         self.model = model
         self.comm = comm
         self.bb = model.trainingwrapper["backbone"]
+        # sync_bn (the reference's `sync_bn` flag converts every BatchNorm of the model, engine/vision_engine.py:224-225): the neck's BatchNorm2d / BatchNorm1d
+        # all-reduce their batch statistics (forward) and gradient sums (backward) over comm's group
+        self.bb.sync_group = comm.group if (sync_bn and comm is not None and comm.active) else False
         self.head = model.trainingwrapper["head"]
         self.eng = self.bb.model.engine
         self.be = self.eng.be

@@ -6,6 +6,7 @@ arguments, same `weight` Parameter ([feat_dim, num_class], unit-norm columns ini
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import Optional
 
 import torch
@@ -142,6 +143,64 @@ class MV_Softmax(_MarginHead):
         self.cfg = _abi.MarginHead(self.mode, float(scale), float(margin), 0.0, float(mv_weight))
 
 
+class _MagFn(torch.autograd.Function):
+    """ArcFace logits with a per-row margin tensor that itself carries gradient (MagFace): d logit[b, y_b] / d m_b = -s sin(theta + m_b) where the margin branch is active"""
+
+    @staticmethod
+    def forward(ctx, feats, weight, labels, margins, head):
+        be = head.be
+        st = _forward_cos(be, feats.contiguous(), weight)
+        logits = torch.empty((st.B, st.C), dtype=torch.float32, device=feats.device)
+        margins = margins.detach().contiguous().float()
+        cfg = _abi.MarginHead(_abi.HEAD_ARCFACE, head.cfg.scale, 0.0, head.cfg.margin_am, 0.0, be.ptr(margins))
+        be.check(be.lib.vdk_margin_ce(C.byref(cfg), be.ptr(st.cos), st.Cp, st.B, st.C, be.ptr(labels), 0.0, 1.0, be.ptr(logits), st.C, None, None, 0,
+                                      be.stream()), "vdk_margin_ce")
+        ctx.st, ctx.head, ctx.labels, ctx.margins, ctx.cfg = st, head, labels, margins, cfg
+        ctx.save_for_backward(weight)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        st, head, m = ctx.st, ctx.head, ctx.margins
+        be = head.be
+        (weight,) = ctx.saved_tensors
+        dcos = torch.zeros((st.Bp, st.Cp), dtype=torch.bfloat16, device=dlogits.device)
+        dlogits = dlogits.contiguous()
+        be.check(be.lib.vdk_margin_bwd(C.byref(ctx.cfg), be.ptr(st.cos), st.Cp, st.B, st.C, be.ptr(ctx.labels), be.ptr(dlogits), st.C, be.ptr(dcos), st.Cp,
+                                       be.stream()), "vdk_margin_bwd")
+        df, dW = _backward_from_dcos(be, st, weight, dcos)
+        # the margin's own gradient: B target entries, host-side tensor arithmetic on [B] vectors
+        rows = torch.arange(st.B, device=dlogits.device)
+        c = st.cos[:st.B].gather(1, ctx.labels.view(-1, 1)).squeeze(1).clamp(-1.0, 1.0)
+        active = c > torch.cos(math.pi - m)
+        dm = dlogits[rows, ctx.labels] * (-head.cfg.scale) * (torch.sqrt(1.0 - c * c) * torch.cos(m) + c * torch.sin(m)) * active
+        return df, dW, None, dm, None
+
+
+class MagFace(_MarginHead):
+    """models/faceX/head/magface.py: ArcFace with the margin growing with the feature magnitude, `forward -> (logits, lamda * loss_g)` exactly like the reference
+    module (a tuple the reference's Trainer cannot consume, train.py:196: dead code upstream, kept for head_def.py:26-36's sake)."""
+    mode = _abi.HEAD_ARCFACE
+
+    def __init__(self, feat_dim, num_class, margin_am=0.0, scale=32, l_a=10, u_a=110, l_margin=0.45, u_margin=0.8, lamda=20, **kw):
+        super().__init__(feat_dim, num_class, **kw)
+        self.cfg = _abi.MarginHead(self.mode, float(scale), 0.0, float(margin_am), 0.0)
+        self.l_a, self.u_a, self.l_margin, self.u_margin, self.lamda = l_a, u_a, l_margin, u_margin, lamda
+
+    def calc_margin(self, x):
+        return (self.u_margin - self.l_margin) / (self.u_a - self.l_a) * (x - self.l_a) + self.l_margin
+
+    def forward(self, feats: torch.Tensor, labels: torch.Tensor):
+        x_norm = torch.norm(feats, dim=1, keepdim=True).clamp(self.l_a, self.u_a)
+        ada_margin = self.calc_margin(x_norm)
+        loss_g = 1 / (self.u_a ** 2) * x_norm + 1 / x_norm
+        logits = _MagFn.apply(feats, self.weight, labels, ada_margin.squeeze(1), self)
+        return logits, self.lamda * loss_g
+
+    def margin_ce(self, *a, **k):
+        raise NotImplementedError("MagFace returns (logits, regulariser) like the reference module; use forward()")
+
+
 class HeadFactory:
     """models/faceX/head/head_def.py:14-56 — head_type in {'arcface', 'circleloss' (yaml alias 'circle'), 'mv-softmax'}."""
 
@@ -158,7 +217,8 @@ class HeadFactory:
         if t in ("mv-softmax", "mv_softmax"):
             return MV_Softmax(p["feat_dim"], p["num_class"], p["is_am"], p.get("margin", 0.35), p.get("mv_weight", 1.12), p.get("scale", 32), **self.kw)
         if t == "magface":
-            raise NotImplementedError("MagFace.forward returns a tuple the reference Trainer cannot consume (train.py:196); not built")
+            return MagFace(p["feat_dim"], p["num_class"], p.get("margin_am", 0.0), p.get("scale", 32), p.get("l_a", 10), p.get("u_a", 110), p.get("l_margin", 0.45),
+                           p.get("u_margin", 0.8), p.get("lamda", 20), **self.kw)
         raise KeyError(f"unknown head type {self.head_type}")
 
 
