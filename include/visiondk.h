@@ -121,6 +121,15 @@ typedef struct VdkGemmDesc {
 } VdkGemmDesc;
 int vdk_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t splitk, size_t* bytes);
 int vdk_gemm_bf16_nt(const VdkGemmDesc* d, void* ws, size_t ws_bytes, void* stream);
+/* OCP fp8 operands on the block-scaled MFMA (csrc/gemm_fp8.hip): the Linear GEMMs of BASELINE.json configs[4] ("SigLIP ViT-L/14 336 ... fp8 MFMA"; the reference has
+ * no fp8 code -- this is timm's Linear, models/classifier/classify_model.py:49-54, under per-tensor delayed scaling).  fmt 0 = e4m3 (activations, weights), 1 = e5m2 (gradients).
+ *   vdk_quant_fp8         x (bf16 | f32, n % 16 == 0) -> fp8(clamp(x * scale[0])); amax[0] = max(amax[0], max |x|) (device scalars; scale NULL = 1, amax NULL = skip)
+ *   vdk_fp8_scale_update  n tensors: scale = fmt_max / (margin * amax), scale_inv = 1 / scale (kept while amax == 0), amax := 0
+ *   vdk_gemm_fp8_nt       C = epilogue(a_scale_inv[0] * b_scale_inv[0] * A . B^T), A [M, K] (a_fmt), B [N, K] (e4m3), fp32 accumulation; epilogue fields of the
+ *                         descriptor as for vdk_gemm_bf16_nt; needs M, N >= 256, K % 128 == 0, lda / ldb % 16 == 0 (elements = bytes); no split-K / TN / conv. */
+int vdk_quant_fp8(const void* x, int32_t x_dtype, int64_t n, const float* scale, void* out_fp8, int32_t fmt, float* amax, void* stream);
+int vdk_fp8_scale_update(float* amax, float* scale, float* scale_inv, int32_t n, int32_t fmt, float margin, void* stream);
+int vdk_gemm_fp8_nt(const VdkGemmDesc* d, int32_t a_fmt, int32_t b_fmt, const float* a_scale_inv, const float* b_scale_inv, void* stream);
 /* tests / A-B benchmarking only: 0 = automatic choice, 1 = 128x128 register-staged kernel, 2 = 256x256 LDS-DMA kernel
  * (the latter still requires K and the split size to be multiples of 64). */
 int vdk_gemm_a_colsum_rows(int32_t M, int32_t N, int32_t K);   /* rows of VdkGemmDesc.a_colsum, 0 = by-product not available for this problem */

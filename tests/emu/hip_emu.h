@@ -200,6 +200,7 @@ static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __A
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline int atomicMax(int* p, int v) { int old = __atomic_load_n(p, __ATOMIC_RELAXED); while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return old; }
+static inline float fminf_(float a, float b) { return a < b ? a : b; }
 static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED); while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return old; }
 static inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
@@ -290,6 +291,76 @@ static inline emu_f32x16 emu_mfma_32x32x2_f32(float a, float b, emu_f32x16 c, in
   emu::wave_barrier();
   return d;
 }
+// ---- OCP fp8 (e4m3fn: bias 7, no inf, S.1111.111 = NaN; e5m2: IEEE-like, bias 15) ---------------------------------------------------------
+static inline float emu_fp8_to_f32(unsigned char v, int fmt) {
+  const int s = v >> 7;
+  float r;
+  if (fmt == 0) {
+    const int e = (v >> 3) & 15, m = v & 7;
+    if (e == 15 && m == 7) r = NAN;
+    else if (e == 0) r = ldexpf((float)m, -9);             // subnormal: m * 2^-3 * 2^-6
+    else r = ldexpf(1.0f + m / 8.0f, e - 7);
+  } else {
+    const int e = (v >> 2) & 31, m = v & 3;
+    if (e == 31) r = m ? NAN : INFINITY;
+    else if (e == 0) r = ldexpf((float)m, -16);            // m * 2^-2 * 2^-14
+    else r = ldexpf(1.0f + m / 4.0f, e - 15);
+  }
+  return s ? -r : r;
+}
+// round to nearest even, saturating to the format's largest finite value (the kernels clamp before converting, so saturation is never exercised differently)
+static inline unsigned char emu_f32_to_fp8(float x, int fmt) {
+  const int mb = fmt == 0 ? 3 : 2, bias = fmt == 0 ? 7 : 15, emax = fmt == 0 ? 8 : 15;
+  const float maxv = fmt == 0 ? 448.0f : 57344.0f;
+  unsigned char sgn = std::signbit(x) ? 0x80 : 0;
+  if (std::isnan(x)) return sgn | 0x7f;
+  float a = fabsf(x);
+  if (a > maxv) a = maxv;
+  if (a == 0.f) return sgn;
+  int e; frexpf(a, &e); e -= 1;                             // a = 1.f * 2^e
+  if (e < 1 - bias) e = 1 - bias;                           // subnormal range: fixed exponent
+  const float q = ldexpf(1.0f, e - mb);                     // spacing
+  float r = nearbyintf(a / q) * q;                          // RNE (default rounding mode)
+  if (r > maxv) r = maxv;
+  int e2; frexpf(r, &e2); e2 -= 1;
+  unsigned char bits;
+  if (r < ldexpf(1.0f, 1 - bias)) bits = (unsigned char)lrintf(r / ldexpf(1.0f, 1 - bias - mb));     // subnormal mantissa
+  else bits = (unsigned char)(((e2 + bias) << mb) | ((int)lrintf((r / ldexpf(1.0f, e2) - 1.0f) * (1 << mb)) & ((1 << mb) - 1)));
+  (void)emax;
+  return sgn | bits;
+}
+static inline int emu_cvt_pk_f8(float a, float b, int old, bool hi_word, int fmt) {
+  const unsigned pk = (unsigned)emu_f32_to_fp8(a, fmt) | ((unsigned)emu_f32_to_fp8(b, fmt) << 8);
+  const unsigned o = (unsigned)old;
+  return (int)(hi_word ? ((o & 0x0000ffffu) | (pk << 16)) : ((o & 0xffff0000u) | pk));
+}
+#define __builtin_amdgcn_cvt_pk_fp8_f32(a, b, old, sel) emu_cvt_pk_f8((a), (b), (old), (sel), 0)
+#define __builtin_amdgcn_cvt_pk_bf8_f32(a, b, old, sel) emu_cvt_pk_f8((a), (b), (old), (sel), 1)
+// v_mfma_scale_f32_32x32x64_f8f6f4 with 8-bit formats: A lane l -> row l & 31, k = 32 * (l >> 5) + byte; B likewise with col; D as the other 32x32 shapes.
+// scale_a / scale_b: E8M0 bytes (127 = 2^0)
+typedef int emu_i32x8 __attribute__((ext_vector_type(8)));
+static inline emu_f32x16 emu_mfma_scale_32x32x64_f8(emu_i32x8 a, emu_i32x8 b, emu_f32x16 c, int fa, int fb, int, int sa, int, int sb) {
+  emu::Wave& w = emu::wave();
+  int l = emu::lane();
+  memcpy(w.a32[l], &a, 32); memcpy(w.b32[l], &b, 32);
+  emu::wave_barrier();
+  emu_f32x16 d;
+  const float sc = ldexpf(1.0f, (sa & 255) - 127) * ldexpf(1.0f, (sb & 255) - 127);
+  int j = l & 31, hi = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float acc = 0.f;
+    for (int k = 0; k < 64; ++k) {
+      const unsigned char* pa = (const unsigned char*)w.a32[i + 32 * (k >> 5)];
+      const unsigned char* pb = (const unsigned char*)w.b32[j + 32 * (k >> 5)];
+      acc += emu_fp8_to_f32(pa[k & 31], fa) * emu_fp8_to_f32(pb[k & 31], fb);
+    }
+    d[r] = c[r] + acc * sc;
+  }
+  emu::wave_barrier();
+  return d;
+}
+#define __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4 emu_mfma_scale_32x32x64_f8
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu_mfma_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu_mfma_16x16x32_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_32x32x2_f32

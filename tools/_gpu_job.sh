@@ -1,3 +1,2 @@
-mkdir -p gpurun_out/r2h
-python tools/cbir_capsweep.py 2>/dev/null | tee gpurun_out/r2h/capsweep.json
-VDK_CBIR_PIPELINE=1 python -m pytest tests/test_cbir.py -m gpu -q 2>&1 | tail -2
+mkdir -p gpurun_out/r2i
+python tools/bench_gemm_fp8.py 2>&1 | tail -1 | tee gpurun_out/r2i/gemm_fp8.json

@@ -83,6 +83,9 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_gemm_bf16_nt": (C.c_int, [C.POINTER(GemmDesc), P, SZ, P]),
     "vdk_gemm_a_colsum_rows": (C.c_int, [I32, I32, I32]),
     "vdk_gemm_force_kernel": (C.c_int, [I32]),
+    "vdk_quant_fp8": (C.c_int, [P, I32, I64, P, P, I32, P, P]),
+    "vdk_fp8_scale_update": (C.c_int, [P, P, P, I32, I32, F32, P]),
+    "vdk_gemm_fp8_nt": (C.c_int, [P, I32, I32, P, P, P]),
     "vdk_gemm_debug_stamps": (C.c_int, [P]),
     "vdk_prof_begin": (C.c_int, [I32]),
     "vdk_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(I64), C.POINTER(C.c_double)]),

@@ -66,6 +66,52 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=torch.bfloat16, bias:
     return out
 
 
+FP8_E4M3, FP8_E5M2 = 0, 1
+
+
+def quant_fp8(x: torch.Tensor, scale: Optional[torch.Tensor] = None, fmt: int = FP8_E4M3, amax: Optional[torch.Tensor] = None, backend=None) -> torch.Tensor:
+    """x (bf16 | f32, numel % 16 == 0) -> uint8 tensor of OCP fp8 bytes = fp8(clamp(x * scale[0])); amax[0] (f32 device scalar) accumulates max |x| (delayed scaling)"""
+    be = _be(backend)
+    assert x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32) and x.numel() % 16 == 0
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    be.check(be.lib.vdk_quant_fp8(be.ptr(x), _abi.BF16 if x.dtype == torch.bfloat16 else _abi.F32_, x.numel(), be.ptr(scale) if scale is not None else None, be.ptr(out), fmt,
+                                  be.ptr(amax) if amax is not None else None, be.stream()), "vdk_quant_fp8")
+    return out
+
+
+def fp8_scale_update(amax: torch.Tensor, scale: torch.Tensor, scale_inv: torch.Tensor, fmt: int = FP8_E4M3, margin: float = 1.0, backend=None) -> None:
+    """delayed scaling bookkeeping for n tensors at once: scale = fmt_max / (margin * amax), scale_inv = 1 / scale (unchanged where amax == 0), amax := 0"""
+    be = _be(backend)
+    be.check(be.lib.vdk_fp8_scale_update(be.ptr(amax), be.ptr(scale), be.ptr(scale_inv), amax.numel(), fmt, margin, be.stream()), "vdk_fp8_scale_update")
+
+
+def gemm_fp8_nt(a8: torch.Tensor, b8: torch.Tensor, a_scale_inv: Optional[torch.Tensor] = None, b_scale_inv: Optional[torch.Tensor] = None, *, a_fmt: int = FP8_E4M3,
+                out_dtype=torch.bfloat16, bias=None, residual=None, act: int = ACT_NONE, aux=None, backend=None) -> torch.Tensor:
+    """out[M,N] = epilogue(a_scale_inv * b_scale_inv * a8[M,K] @ b8[N,K].T): uint8 tensors of fp8 bytes (a: e4m3 or e5m2, b: e4m3), fp32 accumulation on the scaled MFMA"""
+    be = _be(backend)
+    assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and a8.dim() == 2 and b8.dim() == 2 and a8.shape[1] == b8.shape[1]
+    M, K = a8.shape
+    N = b8.shape[0]
+    out = torch.empty((M, N), dtype=out_dtype, device=a8.device)
+    d = _abi.GemmDesc()
+    d.A, d.lda, d.B, d.ldb, d.C, d.ldc = a8.data_ptr(), a8.stride(0), b8.data_ptr(), b8.stride(0), out.data_ptr(), out.stride(0)
+    d.M, d.N, d.K = M, N, K
+    d.c_dtype = _abi.F32_ if out_dtype == torch.float32 else _abi.BF16
+    d.bias = be.ptr(bias) if bias is not None else None
+    d.residual = residual.data_ptr() if residual is not None else None
+    d.ldr = residual.stride(0) if residual is not None else 0
+    d.act = act
+    d.aux = aux.data_ptr() if aux is not None else None
+    d.ldaux = aux.stride(0) if aux is not None else 0
+    d.alpha, d.splitk = 1.0, 1
+    for t in (a8, b8, out, residual, aux):
+        if t is not None and be.device_only and not t.is_cuda:
+            raise RuntimeError("visiondk_amd: HIP backend got a CPU tensor (there is no CPU fallback)")
+    be.check(be.lib.vdk_gemm_fp8_nt(C.byref(d), a_fmt, FP8_E4M3, be.ptr(a_scale_inv) if a_scale_inv is not None else None,
+                                    be.ptr(b_scale_inv) if b_scale_inv is not None else None, be.stream()), "vdk_gemm_fp8_nt")
+    return out
+
+
 def transpose_pad(x: torch.Tensor, rpad: Optional[int] = None, backend=None, rows: Optional[int] = None,
                   row_group: int = 0, colsum_partial: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x bf16 [R, C] -> [C, Rpad] with zero-filled padding columns (Rpad even, default: R rounded up to 64)."""
