@@ -96,3 +96,27 @@ class ResNetRef(nn.Module):
 
     def forward(self, x):
         return self.fc(self.forward_features(x).mean((-2, -1)))
+
+
+def _q(t):
+    """bf16 round trip with a straight-through gradient: where the engine stores an activation in bf16"""
+    return t + (t.bfloat16().to(t.dtype) - t).detach()
+
+
+def forward_bf16_storage(ref, x):
+    """The oracle's forward with the engine's storage precision made explicit: conv operands (image, activations) are bf16, conv outputs / BatchNorm /
+    shortcut sums are fp32, the BatchNorm'd shortcut stays fp32.  With ReLU + small-batch BatchNorm a plain fp32 run differs from ANY bf16 run by tens of
+    percent in the gradients (a pre-activation that rounds across zero flips its mask; torch's own CPU autocast shows 25-40 % here), so the comparison
+    has to put the rounding points in the same places."""
+    F = torch.nn.functional
+    a = ref.maxpool(_q(F.relu(ref.bn1(ref.conv1(_q(x))))))
+    for i in range(1, 5):
+        for blk in getattr(ref, f"layer{i}"):
+            idn = a if blk.downsample is None else blk.downsample(a)
+            a1 = _q(F.relu(blk.bn1(blk.conv1(a))))
+            if hasattr(blk, "conv3"):                       # Bottleneck
+                a2 = _q(F.relu(blk.bn2(blk.conv2(a1))))
+                a = _q(F.relu(blk.bn3(blk.conv3(a2)) + idn))
+            else:
+                a = _q(F.relu(blk.bn2(blk.conv2(a1)) + idn))
+    return ref.fc(_q(a.mean((-2, -1))))

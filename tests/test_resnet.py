@@ -36,28 +36,7 @@ def test_state_dict_matches_timm_layout(be, dev):
         assert model.state_dict()[k].shape == v.shape and torch.equal(model.state_dict()[k].cpu(), v), k
 
 
-def _q(t):
-    """bf16 round trip with a straight-through gradient: where the engine stores an activation in bf16"""
-    return t + (t.bfloat16().float() - t).detach()
-
-
-def _forward_with_engine_rounding(ref, x):
-    """The oracle's forward with the engine's storage precision made explicit: conv operands (image, activations) are bf16, conv outputs / BatchNorm /
-    shortcut sums are fp32, the BatchNorm'd shortcut stays fp32.  With ReLU + small-batch BatchNorm a plain fp32 run differs from ANY bf16 run by tens of
-    percent in the gradients (a pre-activation that rounds across zero flips its mask; torch's own CPU autocast shows 25-40 % here), so the comparison
-    has to put the rounding points in the same places."""
-    F = torch.nn.functional
-    a = ref.maxpool(_q(F.relu(ref.bn1(ref.conv1(_q(x))))))
-    for i in range(1, 5):
-        for blk in getattr(ref, f"layer{i}"):
-            idn = a if blk.downsample is None else blk.downsample(a)
-            a1 = _q(F.relu(blk.bn1(blk.conv1(a))))
-            if hasattr(blk, "conv3"):                       # Bottleneck
-                a2 = _q(F.relu(blk.bn2(blk.conv2(a1))))
-                a = _q(F.relu(blk.bn3(blk.conv3(a2)) + idn))
-            else:
-                a = _q(F.relu(blk.bn2(blk.conv2(a1)) + idn))
-    return ref.fc(_q(a.mean((-2, -1))))
+from oracle.resnet_ref import forward_bf16_storage as _forward_with_engine_rounding  # noqa: E402
 
 
 def test_training_step_vs_oracle_bce(be, dev):
