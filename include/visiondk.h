@@ -88,7 +88,11 @@ int vdk_cbir_merge_topk(const float* scores, const int64_t* idx, int32_t S, int6
  *   C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T), bf16 operands, fp32 accumulation on MFMA.
  *   fwd: A = x, B = W[out,in];  dgrad: A = dy, B = W^T[in,out];  wgrad: A = dy^T, B = x^T (split-K).
  * epilogue order: *alpha, +bias[N] (f32), act, +residual[M,N] (f32), store as c_dtype.
- * K, N, lda, ldb, ldc, ldaux % 8 == 0.  splitk > 1 needs ws of vdk_gemm_splitk_workspace_bytes(). */
+ * K, N, lda, ldb, ldc, ldaux % 8 == 0.  splitk > 1 needs ws of vdk_gemm_splitk_workspace_bytes().
+ * splitk == -1: stream-K allowed.  ws is then a PERSISTENT workspace of vdk_gemm_streamk_workspace_bytes() whose first 64 KB (tile counters) the caller zeroed
+ * once and every launch leaves zero; the launcher uses it when whole-tile rounds would leave the last round mostly empty (one persistent workgroup per CU, each
+ * owning a contiguous range of (tile, k-tile) units; partial tiles are combined by the last arriver in K order: bit-reproducible, nobody spins).  One workspace
+ * serves one stream at a time. */
 /* Implicit-GEMM convolution (im2col-free): when VdkGemmDesc.conv is set, A is an NHWC bf16 tensor [B, H, W, Cin] gathered on the fly.  GEMM row
  * m = (b, oy, ox) over the OH x OW row grid, GEMM column k = (ky*KW + kx)*Cin + c, so B must hold the weight as [N][KH*KW*Cin] in that order
  * (vdk_conv_weight_prep).  transposed = 0: forward conv (source pixel oy*stride + ky - pad); transposed = 1: the input gradient of that conv
@@ -120,6 +124,8 @@ typedef struct VdkGemmDesc {
                               (sum the rows -> colsum(A) = bias gradient of the Linear whose dY is this dgrad GEMM's A); error if that kernel does not serve the problem */
 } VdkGemmDesc;
 int vdk_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t splitk, size_t* bytes);
+int vdk_gemm_streamk_workspace_bytes(size_t* bytes);
+int vdk_gemm_streamk_grid(int32_t workgroups);   /* tests / tuning: persistent workgroups of the stream-K launch (multiple of 8; 0 = one per CU) */
 int vdk_gemm_bf16_nt(const VdkGemmDesc* d, void* ws, size_t ws_bytes, void* stream);
 /* OCP fp8 operands on the block-scaled MFMA (csrc/gemm_fp8.hip): the Linear GEMMs of BASELINE.json configs[4] ("SigLIP ViT-L/14 336 ... fp8 MFMA"; the reference has
  * no fp8 code -- this is timm's Linear, models/classifier/classify_model.py:49-54, under per-tensor delayed scaling).  fmt 0 = e4m3 (activations, weights), 1 = e5m2 (gradients).
@@ -131,7 +137,7 @@ int vdk_quant_fp8(const void* x, int32_t x_dtype, int64_t n, const float* scale,
 int vdk_fp8_scale_update(float* amax, float* scale, float* scale_inv, int32_t n, int32_t fmt, float margin, void* stream);
 int vdk_gemm_fp8_nt(const VdkGemmDesc* d, int32_t a_fmt, int32_t b_fmt, const float* a_scale_inv, const float* b_scale_inv, void* stream);
 /* tests / A-B benchmarking only: 0 = automatic choice, 1 = 128x128 register-staged kernel, 2 = 256x256 LDS-DMA kernel
- * (the latter still requires K and the split size to be multiples of 64). */
+ * (the latter still requires K and the split size to be multiples of 64), 3 = stream-K whenever splitk == -1 lends a workspace, 4 = never stream-K. */
 int vdk_gemm_a_colsum_rows(int32_t M, int32_t N, int32_t K);   /* rows of VdkGemmDesc.a_colsum, 0 = by-product not available for this problem */
 int vdk_gemm_force_kernel(int32_t which);
 /* profiling aid: when non-NULL, every 256x256 workgroup writes 4 shader-cycle stamps (start, operands landed, main loop done,

@@ -30,6 +30,11 @@
 
 #define VDK_EMU 1
 #define VDK_PIN2(x, y) ((void)0)
+#define VDK_AGENT_ST_U64(p, v) (*(unsigned long long*)(p) = (unsigned long long)(v))
+#define VDK_AGENT_LD_U64(p) (*(const unsigned long long*)(p))
+#define VDK_AGENT_ST_I32(p, v) (*(int*)(p) = (int)(v))
+#define VDK_AGENT_LD_I32(p) (*(const int*)(p))
+#define VDK_AGENT_ADD_I32(p, v) __atomic_fetch_add((int*)(p), (int)(v), __ATOMIC_RELAXED)
 #define VDK_LDS_PTR(p) ((void*)(p))
 #define VDK_LDS_S16X4(p) (p)
 #define VDK_GLOBAL_PTR(p) ((const void*)(p))
@@ -65,6 +70,9 @@ static inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, siz
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 #define hipStreamNonBlocking 1
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { static int token; *s = (hipStream_t)&token; return 0; }   // everything runs in program order
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+enum { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 16; return 0; }   // the emulated "device" has 16 CUs (stream-K grids)
 typedef void* hipEvent_t;
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }

@@ -167,3 +167,38 @@ def test_gemm256_a_colsum_byproduct(be, dev):
     torch.testing.assert_close(out.cpu(), a.float() @ b.float().t(), rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(part.sum(0).cpu(), a.float().sum(0), rtol=1e-5, atol=1e-4)
     assert be.lib.vdk_gemm_a_colsum_rows(300, 512, 192) == 0        # ragged M: by-product not available
+
+
+@pytest.mark.parametrize("M,N,K,grid", [(768, 512, 256, 8), (768, 512, 256, 16), (600, 776, 384, 8), (512, 512, 1024, 24)])
+def test_gemm256_stream_k(be, dev, M, N, K, grid):
+    """stream-K launch of the 256x256 kernel (persistent workgroups over (tile, k-tile) units, partial tiles combined by the last arriver in K order), forced, with a
+    small grid so that every workgroup owns partial tiles: all fused epilogues + the a_colsum by-product; equal to the whole-tile launch to fp32 summation order,
+    bit-identical from launch to launch, tile counters left at zero"""
+    torch.manual_seed(6)
+    a = torch.randn(M, K).bfloat16().to(dev); b = (torch.randn(N, K) * 0.1).bfloat16().to(dev)
+    bias = torch.randn(N).to(dev); res = torch.randn(M, N).to(dev)
+    ref = a.float() @ b.float().T
+    ws = ops.streamk_workspace(dev, backend=be)
+    be.lib.vdk_gemm_streamk_grid(grid); be.lib.vdk_gemm_force_kernel(3)
+    try:
+        ws = ops.streamk_workspace(dev, backend=be)
+        out = ops.gemm_nt(a, b, out_dtype=torch.float32, bias=bias, residual=res, streamk_ws=ws, backend=be)
+        assert _rel(out, ref + bias + res) < 1e-5
+        out2 = ops.gemm_nt(a, b, out_dtype=torch.float32, bias=bias, residual=res, streamk_ws=ws, backend=be)
+        assert torch.equal(out, out2)
+        u = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+        g = ops.gemm_nt(a, b, bias=bias, act=ops.ACT_GELU, aux=u, streamk_ws=ws, backend=be)
+        assert _rel(u.float(), ref + bias) < 4e-3 and _rel(g.float(), torch.nn.functional.gelu(ref + bias)) < 4e-3
+        plain = ops.gemm_nt(a, b, streamk_ws=ws, backend=be)
+        be.lib.vdk_gemm_force_kernel(2)
+        assert _rel(plain.float(), ops.gemm_nt(a, b, backend=be).float()) < 1e-3
+        be.lib.vdk_gemm_force_kernel(3)
+        if M % 256 == 0:
+            rows = be.lib.vdk_gemm_a_colsum_rows(M, N, K)
+            part = torch.full((rows, K), float("nan"), dtype=torch.float32, device=dev)
+            o3 = ops.gemm_nt(a, b, out_dtype=torch.float32, a_colsum=part, streamk_ws=ws, backend=be)
+            assert _rel(o3, ref) < 1e-5
+            torch.testing.assert_close(part.sum(0).cpu(), a.float().sum(0).cpu(), rtol=1e-5, atol=1e-4)
+        assert int(ws[:65536].view(torch.int32).abs().sum()) == 0
+    finally:
+        be.lib.vdk_gemm_force_kernel(0); be.lib.vdk_gemm_streamk_grid(0)

@@ -80,6 +80,8 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_cbir_merge_topk": (C.c_int, [P, P, I32, I64, I32, P, P, P, SZ, P]),
     # hot path A: dense ops
     "vdk_gemm_splitk_workspace_bytes": (C.c_int, [I32, I32, I32, PSZ]),
+    "vdk_gemm_streamk_workspace_bytes": (C.c_int, [PSZ]),
+    "vdk_gemm_streamk_grid": (C.c_int, [I32]),
     "vdk_gemm_bf16_nt": (C.c_int, [C.POINTER(GemmDesc), P, SZ, P]),
     "vdk_gemm_a_colsum_rows": (C.c_int, [I32, I32, I32]),
     "vdk_gemm_force_kernel": (C.c_int, [I32]),

@@ -10,6 +10,7 @@
 // group hits 16 distinct 16-B slots, XCD-aware bijective tile swizzle, epilogue staged through LDS
 // for 16-B coalesced stores with bias / exact-erf GELU / dGELU / fp32 residual fused in.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "vdk_device.h"
 #include "vdk_host.h"
 #include "vdk_gemm.h"
@@ -260,27 +261,70 @@ __device__ __forceinline__ s16x8 h_read_frag_tn(const unsigned char* region, int
 }
 
 
-template <bool TN, int E>
+// SK (stream-K): a persistent launch of G = gridDim.x workgroups (one per CU).  The work is the list of (tile, k-tile) units in tile-raster order; workgroup at
+// position pos = xcd * (G / 8) + slot-in-xcd (so neighbouring ranges share an XCD's L2) owns the contiguous range [pos * U / G, (pos + 1) * U / G): a partial tile
+// at its head, whole tiles, a partial tile at its tail.  Whole tiles take the normal epilogue.  A partial segment stores its raw accumulators to its own fp32 slab
+// (2 per workgroup: head / tail), publishes them (release fence + device-scope atomic add of its k-tile count on the tile's counter), and whoever completes the
+// count re-reads every contributor's slab IN K ORDER (its own included: the sum order is fixed by the partition, not by arrival -> bit-reproducible), resets
+// the counter for the next launch and runs the epilogue.  Nobody waits for anybody: no co-residency requirement, no deadlock with RCCL kernels on the same CUs.
+template <bool TN, int E, bool SK, bool CS>
 __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * H_TILEBUF];   // 128 KB: operand buffers, reused by the epilogue
   __shared__ float cs_lds[8][64];                                              // + 2 KB: per-wave column sums of the a_colsum by-product
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = w >> 2, wc = w & 3, hi = lane >> 5, l31 = lane & 31;
-
+  __shared__ int sk_last, sk_st[4];
+  const int tid0 = threadIdx.x;
   const int ntn = (p.N + 255) / 256, ntm = (p.M + 255) / 256;
   const int nwg = ntn * ntm;
-  int bid = blockIdx.x;
-  {
-    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int nkt = p.K / 64;                               // SK: k-tiles per output tile
+  const int z = SK ? 0 : blockIdx.y;
+  // SK state lives in LDS, not in registers: the main loop already uses every VGPR and nearly every SGPR (loop-carried scalars spilled 34 VGPRs into the K loop)
+  //   sk_st[0] = cursor in the tail's unit space, [1] = end of this workgroup's tail range, [2] = whole-tile rounds done, [3] = start of the tail range
+  if (SK) {
+    if (tid0 == 0) {
+      const int G = gridDim.x, pos = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+      const long U = (long)(nwg - nwg / G * G) * nkt;
+      sk_st[0] = sk_st[3] = (int)(pos * U / G); sk_st[1] = (int)((pos + 1) * U / G); sk_st[2] = 0;
+    }
   }
-  const int tn = bid % ntn, tm = bid / ntn;
+  do {
+  // SK: the lane / wave ids go through an opaque asm every segment, so nothing derived from them (DMA source offsets, fragment addresses, epilogue addresses) is
+  // hoisted out of the segment loop and kept alive -- i.e. spilled -- across the K loop of every segment
+  int tid = tid0;
+#ifndef VDK_EMU
+  if (SK) asm volatile("" : "+v"(tid));
+#endif
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 2, wc = w & 3, hi = lane >> 5, l31 = lane & 31;
+  int tile, kbeg, nk;
+  if (SK) {
+    // hybrid: floor(tiles / G) rounds of whole tiles (an XCD's G/8 workgroups on G/8 consecutive tiles, like the one-tile-per-workgroup launch: they walk the
+    // same A / B panels in step, which is what keeps those panels in that XCD's L2), then the remaining tiles' k-tiles dealt evenly
+    __syncthreads();                                      // state visible; the previous segment's epilogue / slab traffic is done with the LDS
+    const int G = gridDim.x, R = nwg / G;
+    const int dp = __builtin_amdgcn_readfirstlane(sk_st[2]), u = __builtin_amdgcn_readfirstlane(sk_st[0]), ue = __builtin_amdgcn_readfirstlane(sk_st[1]);
+    if (dp < R) {
+      tile = (blockIdx.x & 7) * (R * (G >> 3)) + dp * (G >> 3) + (blockIdx.x >> 3);
+      kbeg = 0; nk = nkt;
+    } else {
+      if (u >= ue) break;
+      tile = u / nkt;
+      const int kt0 = u - tile * nkt;
+      nk = nkt - kt0; if (nk > ue - u) nk = ue - u;
+      kbeg = kt0 * 64;
+      tile += R * G;
+    }
+  } else {
+    int bid = blockIdx.x;
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    kbeg = z * p.k_per_split;
+    int kend = kbeg + p.k_per_split; if (kend > p.K) kend = p.K;
+    nk = (kend - kbeg) / 64;                              // launcher guarantees (kend - kbeg) % 64 == 0
+  }
+  const int tn = tile % ntn, tm = tile / ntn;
   const int m0 = tm * 256, n0 = tn * 256;
-  const int z = blockIdx.y;
-  const int kbeg = z * p.k_per_split;
-  int kend = kbeg + p.k_per_split; if (kend > p.K) kend = p.K;
-  const int nk = (kend - kbeg) / 64;                      // launcher guarantees (kend - kbeg) % 64 == 0
+  const int kt_abs0 = kbeg / 64;
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -305,12 +349,12 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
 #define H_FRAG_B(reg, ks) (TN ? h_read_frag_tn(reg, wc * 32, ks, lane) : h_read_frag(reg, wc * 32, ks, l31, hi))
 
   unsigned long long t_start = 0, t_landed = 0, t_main = 0;
-  if (p.dbg) t_start = __builtin_readcyclecounter();
+  if (!SK && p.dbg) t_start = __builtin_readcyclecounter();
   // ---- prologue: tiles 0 and 1 completely ---------------------------------------------------------------------------
   if (nk > 0) { H_ISSUE_A(0, 0, 0); H_ISSUE_B(0, 0, 0); H_ISSUE_B(0, 1, 0); H_ISSUE_A(0, 1, 0); }
   if (nk > 1) { H_ISSUE_A(1, 0, 1); H_ISSUE_B(1, 0, 1); H_ISSUE_B(1, 1, 1); H_ISSUE_A(1, 1, 1); H_WAIT_VM(8); } else { H_WAIT_VM(0); }
   H_BAR();
-  if (p.dbg) t_landed = __builtin_readcyclecounter();
+  if (!SK && p.dbg) t_landed = __builtin_readcyclecounter();
   if (wr == 1) H_BAR();                                   // stagger: the second wave-row runs one interval behind
 
   // K-tile schedule: 4 barrier intervals per tile; wave-row 1 runs one interval behind wave-row 0, so on every SIMD one wave's
@@ -329,7 +373,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
   // Lane = (k pair kp, row parity rh): 8 ds_read_b32 per region; the 8 waves' sums meet in cs_lds one K-tile later (wave-row 1 lags one interval).
   // The K-tiles of a row tile are dealt round-robin to its ntn workgroups (tile t belongs to tn == t % ntn): every workgroup pays 1/ntn of the extra
   // LDS reads instead of one workgroup per row tile paying all of them and holding up its whole round.
-  const bool cs_en = !TN && p.colsum_part != nullptr;
+  const bool cs_en = CS;                                 // compile-time: the by-product costs ~8 VGPRs the other variants need (256 are in use)
   float cs0 = 0.f, cs1 = 0.f;
   const int cs_kp = lane & 31, cs_rh = lane >> 5;
   for (int t = 0; t < nk; ++t) {
@@ -345,9 +389,9 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
       for (int ks = 0; ks < 4; ++ks) a0[rt][ks] = H_FRAG_A(RA0, rt, ks);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) b1[ks] = H_FRAG_B(RB1, ks);
-    const bool cs_on = cs_en && (t % ntn) == tn;
+    const bool cs_on = cs_en && ((kt_abs0 + t) % ntn) == tn;
     if (cs_en) {
-      if (t > 0 && w == 0 && ((t - 1) % ntn) == tn) {   // K-tile t-1: all eight waves' sums are in cs_lds (the lagging wave-row wrote them one barrier ago)
+      if (t > 0 && w == 0 && ((kt_abs0 + t - 1) % ntn) == tn) {   // K-tile t-1: all eight waves' sums are in cs_lds (the lagging wave-row wrote them one barrier ago)
         float v = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) v += cs_lds[i][lane];
@@ -423,13 +467,84 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
     H_BAR();
   }
   if (wr == 0) H_BAR();                                   // match the barrier count of the lagging wave-row
-  if (cs_en && nk > 0 && w == 0 && ((nk - 1) % ntn) == tn) {   // last K-tile's column sums (every wave is past its final RB)
+  if (cs_en && nk > 0 && w == 0 && ((kt_abs0 + nk - 1) % ntn) == tn) {   // last K-tile's column sums (every wave is past its final RB)
     float v = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) v += cs_lds[i][lane];
     p.colsum_part[(long)tm * p.K + kbeg + (nk - 1) * 64 + lane] = v;
   }
-  if (p.dbg) t_main = __builtin_readcyclecounter();
+  if (!SK && p.dbg) t_main = __builtin_readcyclecounter();
+
+  if (SK && nk < nkt) {
+    // ---- partial tile: publish the raw accumulators; the workgroup that completes the tile's k-tile count finishes it ----------------------------------
+    // Slab traffic uses device-scope relaxed accesses (sc1 write-through stores, L2-bypassing loads) ordered by s_waitcnt + barrier around one device-scope
+    // atomic per segment: no L2 write-back / invalidate.  With two contributors (every tile when there are at least as many tiles as workgroups) the sum of
+    // the two parts is commutative, so the later one adds the earlier one's slab to its registers and, when it can see beforehand that it is the later one,
+    // does not write its own.  Three or more: everybody writes, the last arriver re-reads all of them in K order (own included) -> same bits on every launch.
+    const long WGF = 65536;                                // floats per slab (256 x 256)
+    const int sk_G = gridDim.x, sk_pos = (blockIdx.x & 7) * (sk_G >> 3) + (blockIdx.x >> 3);
+    const long sk_U = (long)(nwg - nwg / sk_G * sk_G) * nkt;
+    const bool sk_first = __builtin_amdgcn_readfirstlane(sk_st[0]) == __builtin_amdgcn_readfirstlane(sk_st[3]);
+    const long tb = (long)(tile - nwg / sk_G * sk_G) * nkt, te = tb + nkt;
+    int p_lo = (int)(tb * sk_G / sk_U);
+    while ((long)(p_lo + 1) * sk_U / sk_G <= tb) ++p_lo;
+    while ((long)p_lo * sk_U / sk_G > tb) --p_lo;
+    int ncontrib = 0;
+    for (int pp = p_lo; (long)pp * sk_U / sk_G < te; ++pp)
+      if ((long)(pp + 1) * sk_U / sk_G > (long)pp * sk_U / sk_G) ++ncontrib;
+    if (tid == 0) sk_last = (ncontrib == 2 && VDK_AGENT_LD_I32(p.sk_cnt + tile) + nk == nkt) ? 2 : 0;
+    __syncthreads();
+    int last = sk_last;
+    if (last == 0) {
+      float* my = p.slabs + ((long)sk_pos * 2 + (sk_first ? 0 : 1)) * WGF + w * 8192 + lane * 2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            const unsigned long long v = ((unsigned long long)__float_as_uint(acc[i][j][2 * g + 1]) << 32) | __float_as_uint(acc[i][j][2 * g]);
+            VDK_AGENT_ST_U64(my + ((i * 2 + j) * 8 + g) * 128, v);
+          }
+      __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's write-through stores have completed at device scope
+      __syncthreads();
+      if (tid == 0) sk_last = (VDK_AGENT_ADD_I32(p.sk_cnt + tile, nk) + nk == nkt) ? 1 : 0;
+      __syncthreads();
+      last = sk_last;
+    }
+    if (tid == 0) sk_st[0] += nk;                          // (read again behind the barrier at the top of the next segment)
+    if (last == 0) continue;
+    if (tid == 0) VDK_AGENT_ST_I32(p.sk_cnt + tile, 0);     // self-cleaning: the next launch finds zeros
+    if (ncontrib != 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    for (int pp = p_lo;; ++pp) {
+      const long cs_ = (long)pp * sk_U / sk_G, ce_ = (long)(pp + 1) * sk_U / sk_G;
+      if (cs_ >= te) break;
+      if (ce_ == cs_) continue;
+      if (ncontrib == 2 && pp == sk_pos) continue;          // own part is in the registers
+      const float* src = p.slabs + ((long)pp * 2 + (cs_ >= tb ? 0 : 1)) * WGF + w * 8192 + lane * 2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            const unsigned long long v = VDK_AGENT_LD_U64(src + ((i * 2 + j) * 8 + g) * 128);
+            acc[i][j][2 * g] += __uint_as_float((unsigned)v); acc[i][j][2 * g + 1] += __uint_as_float((unsigned)(v >> 32));
+          }
+    }
+  } else if (SK) {
+    if (tid == 0) {
+      if (sk_st[2] < nwg / (int)gridDim.x) sk_st[2] += 1;
+      else sk_st[0] += nk;
+    }
+  }
 
   // ---- epilogue: wave-private 16 KB LDS slab, 64 rows x 64 fp32 at a time -> 8-wide coalesced row chunks ---------
   float* slab = (float*)(smem + w * 16384);
@@ -471,11 +586,12 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (p.dbg && tid == 0) {
+  if (!SK && p.dbg && tid == 0) {
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the stamp is taken when this wave's stores have left
     unsigned long long* o = p.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
     o[0] = t_start; o[1] = t_landed; o[2] = t_main; o[3] = __builtin_readcyclecounter();
   }
+  } while (SK);
 #undef H_REG
 #undef H_ISSUE_A
 #undef H_ISSUE_B
@@ -544,18 +660,44 @@ static double g_prof_bytes = 0.0;   // algorithmic bytes of the profiled launche
 static size_t g_prof_used = 0;
 static bool g_prof_on = false;
 static void* g_dbg_ptr = nullptr;
-static int g_force_kernel = 0;   // 0 auto, 1 = 128x128 register-staged, 2 = 256x256 LDS-DMA (tests / A-B benchmarking)
+static int g_force_kernel = 0;   // 0 auto, 1 = 128x128 register-staged, 2 = 256x256 LDS-DMA, 3 = 256x256 stream-K whenever a workspace is passed, 4 = never stream-K (tests / A-B benchmarking)
+static int g_sk_grid = 0;        // stream-K workgroups; 0 = one per CU of the current device
+#define SK_CNT_BYTES 65536       // 16384 tile counters in front of the slabs
+static int sk_grid() {
+  if (g_sk_grid > 0) return g_sk_grid;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    cus = n & ~7;
+  }
+  return cus;
+}
 
 extern "C" {
 
 /* rows of the a_colsum by-product ([rows][K] f32) if the NT problem (M, N, K) is served by the 256x256 kernel and M % 256 == 0, else 0 */
 int vdk_gemm_a_colsum_rows(int32_t M, int32_t N, int32_t K) {
   const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  const bool big = g_force_kernel == 2 || (g_force_kernel == 0 && (K % 64 == 0) && tiles256 >= 128 && M >= 256 && N >= 256);
+  const bool big = g_force_kernel == 2 || g_force_kernel == 3 || ((g_force_kernel == 0 || g_force_kernel == 4) && (K % 64 == 0) && tiles256 >= 128 && M >= 256 && N >= 256);
   return (big && (K % 64 == 0) && (M % 256 == 0)) ? (M / 256) : 0;
 }
 
 int vdk_gemm_force_kernel(int32_t which) { g_force_kernel = which; return VDK_OK; }
+
+/* stream-K (VdkGemmDesc.splitk == -1): `ws` of vdk_gemm_bf16_nt is then a PERSISTENT workspace of this many bytes whose first 64 KB (the tile counters) the caller
+   zeroed once; every launch leaves them zero again.  One workspace serves one stream at a time. */
+int vdk_gemm_streamk_workspace_bytes(size_t* bytes) {
+  if (!bytes) return vdk_fail(VDK_EINVAL, "vdk_gemm_streamk_workspace_bytes: null");
+  *bytes = (size_t)SK_CNT_BYTES + (size_t)sk_grid() * 2 * 65536 * 4;
+  return VDK_OK;
+}
+/* tests / tuning: number of persistent workgroups (multiple of 8; 0 = one per CU) */
+int vdk_gemm_streamk_grid(int32_t g) {
+  if (g < 0 || (g & 7)) return vdk_fail(VDK_EINVAL, "vdk_gemm_streamk_grid: must be a multiple of 8");
+  g_sk_grid = g;
+  return VDK_OK;
+}
 int vdk_gemm_debug_stamps(void* device_u64_buffer) { g_dbg_ptr = device_u64_buffer; return VDK_OK; }
 
 int vdk_prof_begin(int32_t max_launches) {
@@ -624,7 +766,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.c_dtype = d->c_dtype; p.bias = (const float*)d->bias; p.residual = (const float*)d->residual; p.ldr = d->ldr;
   p.act = d->act; p.aux = (bf16_t*)d->aux; p.ldaux = d->ldaux; p.alpha = d->alpha; p.row_group = d->row_group; p.a_row_group = d->a_row_group;
-  p.splitk = splitk; p.slabs = nullptr; p.dbg = (unsigned long long*)g_dbg_ptr;
+  p.splitk = splitk; p.slabs = nullptr; p.sk_cnt = nullptr; p.dbg = (unsigned long long*)g_dbg_ptr;
   p.colsum_part = nullptr;
   p.conv_on = d->conv != nullptr;
   if (d->conv) {
@@ -650,7 +792,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   if (prof) (void)hipEventRecord(g_prof_ev[g_prof_used], stream);
   // big problems go to the 256x256 LDS-DMA kernel (needs whole 64-wide k-tiles per split and >= 1 full wave of tiles)
   const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * splitk;
-  const bool big = !d->conv && (g_force_kernel == 2 || (g_force_kernel == 0 && (d->K % 64 == 0) && (kps % 64 == 0) && tiles256 >= 128 && d->M >= 256 && d->N >= 256));
+  const bool big = !d->conv && (g_force_kernel == 2 || g_force_kernel == 3 || ((g_force_kernel == 0 || g_force_kernel == 4) && (d->K % 64 == 0) && (kps % 64 == 0) && tiles256 >= 128 && d->M >= 256 && d->N >= 256));
   // compile-time epilogue variant (the common ViT forms); anything else takes the run-time-flag path
   int E = E_GENERIC;
   {
@@ -664,8 +806,33 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
     else if (plain_alpha && rg && res && d->act == VDK_ACT_NONE && f32 && bias) E = E_BIAS | E_RES | E_F32 | E_ROWGRP;
     else if (plain_alpha && !rg && !res && d->act == VDK_ACT_NONE && f32 && !bias) E = E_F32;
   }
-  const dim3 grid256((unsigned)(((d->M + 255) / 256) * ((d->N + 255) / 256)), (unsigned)splitk);
-#define LAUNCH256(TNF, EE) hipLaunchKernelGGL((gemm256_bf16_kernel<TNF, EE>), grid256, dim3(512), 0, stream, p)
+  dim3 grid256((unsigned)(((d->M + 255) / 256) * ((d->N + 255) / 256)), (unsigned)splitk);
+  // stream-K when the caller lent a workspace (splitk == -1) and whole-tile rounds would leave the last one mostly empty (N = 768 at T = 50 432: 591 tiles = 2.31 rounds)
+  bool sk = false;
+  if (d->splitk == -1 && !d->trans && !d->a_colsum && big && ws && g_force_kernel != 4) {   // (with the a_colsum by-product the persistent form spills)
+    const long T = (long)grid256.x, G = sk_grid();
+    const long rounds = (T + G - 1) / G;
+    // Measured on MI355X (tools/bench_gemm_sk.py, round 2): the persistent form is NOT faster than hardware-dispatched rounds -- N = 768 / K = 3072 at T = 50 432:
+    // 261 us against 225 us -- so it is opt-in (VDK_GEMM_STREAMK=1 or vdk_gemm_force_kernel(3)); see DESIGN.md section 6.
+    static const bool optin = getenv("VDK_GEMM_STREAMK") && atoi(getenv("VDK_GEMM_STREAMK")) > 0;
+    const bool worth = optin && T >= G && (double)T / (double)(rounds * G) < 0.94;
+    if ((worth || g_force_kernel == 3) && T <= SK_CNT_BYTES / 4 && T * (d->K / 64) >= G && ws_bytes >= (size_t)SK_CNT_BYTES + (size_t)G * 2 * 65536 * 4) {
+      sk = true;
+      p.sk_cnt = (int*)ws; p.slabs = (float*)((char*)ws + SK_CNT_BYTES);
+      grid256 = dim3((unsigned)G, 1u);
+    }
+  }
+#define LAUNCH256X(TNF, EE, CSF)                                                                                         \
+  do {                                                                                                                   \
+    if (sk) hipLaunchKernelGGL((gemm256_bf16_kernel<TNF, EE, !TNF, CSF>), grid256, dim3(512), 0, stream, p);              \
+    else hipLaunchKernelGGL((gemm256_bf16_kernel<TNF, EE, false, CSF>), grid256, dim3(512), 0, stream, p);                \
+  } while (0)
+#define LAUNCH256(TNF, EE) LAUNCH256X(TNF, EE, false)
+#define LAUNCH256CS(EE)                                                                                                  \
+  do {                                                                                                                   \
+    if (p.colsum_part) hipLaunchKernelGGL((gemm256_bf16_kernel<false, EE, false, true>), grid256, dim3(512), 0, stream, p); \
+    else LAUNCH256X(false, EE, false);                                                                                   \
+  } while (0)
   if (d->trans) {
     if ((d->K % 64) || (kps % 64) || (d->M & 7) || d->M < 8 || d->N < 8)
       return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: trans=1 needs K and the split size to be multiples of 64 and M % 8 == 0");
@@ -679,19 +846,22 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
     if (d->a_colsum) {
       if (d->M % 256) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: a_colsum needs M % 256 == 0");
       p.colsum_part = d->a_colsum;
+      if (E != 0 && E != E_DGELU && E != E_F32) E = E_GENERIC;   // the by-product is compiled into the dgrad forms only
     }
     switch (E) {
-      case 0: LAUNCH256(false, 0); break;
+      case 0: LAUNCH256CS(0); break;
       case E_BIAS: LAUNCH256(false, E_BIAS); break;
       case E_BIAS | E_GELU: LAUNCH256(false, E_BIAS | E_GELU); break;
-      case E_DGELU: LAUNCH256(false, E_DGELU); break;
+      case E_DGELU: LAUNCH256CS(E_DGELU); break;
       case E_BIAS | E_RES | E_F32: LAUNCH256(false, E_BIAS | E_RES | E_F32); break;
       case E_BIAS | E_RES | E_F32 | E_ROWGRP: LAUNCH256(false, E_BIAS | E_RES | E_F32 | E_ROWGRP); break;
       case E_SPLITK: LAUNCH256(false, E_SPLITK); break;
-      case E_F32: LAUNCH256(false, E_F32); break;
-      default: LAUNCH256(false, E_GENERIC); break;
+      case E_F32: LAUNCH256CS(E_F32); break;
+      default: LAUNCH256CS(E_GENERIC); break;
     }
   }
+#undef LAUNCH256CS
+#undef LAUNCH256X
 #undef LAUNCH256
   else if (d->a_colsum)
     return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: a_colsum is a by-product of the 256x256 NT kernel only (see vdk_gemm_a_colsum_rows)");

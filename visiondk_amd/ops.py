@@ -21,8 +21,9 @@ def _be(backend):
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=torch.bfloat16, bias: Optional[torch.Tensor] = None,
             residual: Optional[torch.Tensor] = None, act: int = ACT_NONE, aux: Optional[torch.Tensor] = None,
             alpha: float = 1.0, splitk: int = 1, out: Optional[torch.Tensor] = None, row_group: int = 0,
-            trans: bool = False, a_row_group: int = 0, a_rows: Optional[int] = None, a_colsum: Optional[torch.Tensor] = None, backend=None) -> torch.Tensor:
-    """out[M,N] = epilogue(alpha * a[M,K] @ b[N,K].T); a, b bf16 (row stride may exceed K)."""
+            trans: bool = False, a_row_group: int = 0, a_rows: Optional[int] = None, a_colsum: Optional[torch.Tensor] = None,
+            streamk_ws: Optional[torch.Tensor] = None, backend=None) -> torch.Tensor:
+    """out[M,N] = epilogue(alpha * a[M,K] @ b[N,K].T); a, b bf16 (row stride may exceed K).  streamk_ws: persistent workspace from streamk_workspace() -> stream-K allowed"""
     be = _be(backend)
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
     assert a.stride(1) == 1 and b.stride(1) == 1 and (trans or a.shape[1] == b.shape[1])
@@ -57,6 +58,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=torch.bfloat16, bias:
             raise RuntimeError("visiondk_amd: HIP backend got a CPU tensor (there is no CPU fallback)")
     ws = None
     nbytes = 0
+    if streamk_ws is not None:
+        assert splitk <= 1
+        d.splitk = -1
+        ws, nbytes = streamk_ws, streamk_ws.numel()
     if splitk > 1:
         need = C.c_size_t(0)
         be.check(be.lib.vdk_gemm_splitk_workspace_bytes(M, N, splitk, C.byref(need)), "vdk_gemm_splitk_workspace_bytes")
@@ -64,6 +69,14 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=torch.bfloat16, bias:
         nbytes = need.value
     be.check(be.lib.vdk_gemm_bf16_nt(C.byref(d), be.ptr(ws), nbytes, be.stream()), "vdk_gemm_bf16_nt")
     return out
+
+
+def streamk_workspace(device, backend=None) -> torch.Tensor:
+    """persistent stream-K workspace (zeroed tile counters + accumulator slabs) for gemm_nt(streamk_ws=...); one per stream"""
+    be = _be(backend)
+    need = C.c_size_t(0)
+    be.check(be.lib.vdk_gemm_streamk_workspace_bytes(C.byref(need)), "vdk_gemm_streamk_workspace_bytes")
+    return torch.zeros(need.value, dtype=torch.uint8, device=device)
 
 
 FP8_E4M3, FP8_E5M2 = 0, 1
