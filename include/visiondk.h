@@ -122,6 +122,8 @@ typedef struct VdkGemmDesc {
   const VdkConvGeom* conv; /* NULL: dense A.  else: implicit-GEMM convolution operand (lda ignored) */
   float* a_colsum;         /* NULL, or f32 [vdk_gemm_a_colsum_rows(M,N,K)][K]: by-product of the NT 256x256 kernel, partial column sums of A, one row per 256-row tile
                               (sum the rows -> colsum(A) = bias gradient of the Linear whose dY is this dgrad GEMM's A); error if that kernel does not serve the problem */
+  float* c_colsum;         /* optional by-product of the 256x256 NT kernel with a plain or dGELU bf16 epilogue: f32 [vdk_gemm_c_colsum_rows(M, N, K)][N] partial column sums of the
+                              STORED (bf16-rounded) output (sum the rows -> colsum(C) = bias gradient of the Linear whose dY this GEMM's output is) */
 } VdkGemmDesc;
 int vdk_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t splitk, size_t* bytes);
 int vdk_gemm_streamk_workspace_bytes(size_t* bytes);
@@ -138,6 +140,7 @@ int vdk_fp8_scale_update(float* amax, float* scale, float* scale_inv, int32_t n,
 int vdk_gemm_fp8_nt(const VdkGemmDesc* d, int32_t a_fmt, int32_t b_fmt, const float* a_scale_inv, const float* b_scale_inv, void* stream);
 /* tests / A-B benchmarking only: 0 = automatic choice, 1 = 128x128 register-staged kernel, 2 = 256x256 LDS-DMA kernel
  * (the latter still requires K and the split size to be multiples of 64), 3 = stream-K whenever splitk == -1 lends a workspace, 4 = never stream-K. */
+int vdk_gemm_c_colsum_rows(int32_t M, int32_t N, int32_t K);   /* rows of VdkGemmDesc.c_colsum, 0 = by-product not available for this problem */
 int vdk_gemm_a_colsum_rows(int32_t M, int32_t N, int32_t K);   /* rows of VdkGemmDesc.a_colsum, 0 = by-product not available for this problem */
 int vdk_gemm_force_kernel(int32_t which);
 /* profiling aid: when non-NULL, every 256x256 workgroup writes 4 shader-cycle stamps (start, operands landed, main loop done,

@@ -202,3 +202,23 @@ def test_gemm256_stream_k(be, dev, M, N, K, grid):
         assert int(ws[:65536].view(torch.int32).abs().sum()) == 0
     finally:
         be.lib.vdk_gemm_force_kernel(0); be.lib.vdk_gemm_streamk_grid(0)
+
+
+@pytest.mark.parametrize("M", [512, 300])
+def test_gemm256_c_colsum_byproduct(be, dev, M):
+    """bias gradient fused into the PRODUCER of dY: the 256x256 NT kernel's plain / dGELU bf16 epilogues also emit column sums of what they store"""
+    torch.manual_seed(7)
+    N, K = 512, 192
+    a = torch.randn(M, K).bfloat16().to(dev); b = (torch.randn(N, K) * 0.2).bfloat16().to(dev); u = torch.randn(M, N).bfloat16().to(dev)
+    be.lib.vdk_gemm_force_kernel(2)
+    try:
+        rows = be.lib.vdk_gemm_c_colsum_rows(M, N, K)
+        assert rows == 2 * ((M + 255) // 256)
+        for act in (ops.ACT_NONE, ops.ACT_DGELU):
+            part = torch.full((rows, N), float("nan"), dtype=torch.float32, device=dev)
+            out = ops.gemm_nt(a, b, act=act, aux=u if act else None, c_colsum=part, backend=be)
+            ref = ops.gemm_nt(a, b, act=act, aux=u if act else None, backend=be)
+            assert torch.equal(out, ref)
+            torch.testing.assert_close(part.sum(0).cpu(), out.float().sum(0).cpu(), rtol=1e-5, atol=1e-4)
+    finally:
+        be.lib.vdk_gemm_force_kernel(0)

@@ -21,7 +21,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("A", P), ("lda", I64), ("B", P), ("ldb", I64), ("C", P), ("ldc", I64),
                 ("M", I32), ("N", I32), ("K", I32), ("c_dtype", I32),
                 ("bias", P), ("residual", P), ("ldr", I64), ("act", I32), ("aux", P), ("ldaux", I64),
-                ("alpha", F32), ("splitk", I32), ("row_group", I32), ("trans", I32), ("a_row_group", I32), ("conv", P), ("a_colsum", P)]
+                ("alpha", F32), ("splitk", I32), ("row_group", I32), ("trans", I32), ("a_row_group", I32), ("conv", P), ("a_colsum", P), ("c_colsum", P)]
 
 
 class ConvGeom(C.Structure):
@@ -84,6 +84,7 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_gemm_streamk_grid": (C.c_int, [I32]),
     "vdk_gemm_bf16_nt": (C.c_int, [C.POINTER(GemmDesc), P, SZ, P]),
     "vdk_gemm_a_colsum_rows": (C.c_int, [I32, I32, I32]),
+    "vdk_gemm_c_colsum_rows": (C.c_int, [I32, I32, I32]),
     "vdk_gemm_force_kernel": (C.c_int, [I32]),
     "vdk_quant_fp8": (C.c_int, [P, I32, I64, P, P, I32, P, P]),
     "vdk_fp8_scale_update": (C.c_int, [P, P, P, I32, I32, F32, P]),

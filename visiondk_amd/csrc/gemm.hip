@@ -549,9 +549,9 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
   // ---- epilogue: wave-private 16 KB LDS slab, 64 rows x 64 fp32 at a time -> 8-wide coalesced row chunks ---------
   float* slab = (float*)(smem + w * 16384);
   const int ncol = n0 + wc * 64 + (lane & 7) * 8;
-  float bias8[8];
+  float bias8[8], ocs8[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+  for (int e = 0; e < 8; ++e) { bias8[e] = 0.f; ocs8[e] = 0.f; }
   if ((E != E_GENERIC) && (E & E_BIAS) && ncol < p.N) {
     f32x4 b0v = *(const f32x4*)(p.bias + ncol), b1v = *(const f32x4*)(p.bias + ncol + 4);
 #pragma unroll
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
           slab[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + ct * 32 + l31] = acc[half * 2 + rt][ct][r];
     __builtin_amdgcn_wave_barrier();
     if (E != E_GENERIC) {
-      h_epilogue_half<E>(p, slab, lane, (long)m0 + wr * 128 + half * 64, ncol, z, bias8);
+      h_epilogue_half<E>(p, slab, lane, (long)m0 + wr * 128 + half * 64, ncol, z, bias8, ocs8);
     } else {
 #pragma unroll
       for (int pass = 0; pass < 8; ++pass) {
@@ -585,6 +585,19 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
       }
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  if ((E != E_GENERIC) && (E & E_OCS)) {   // lanes with the same (lane & 7) hold the same 8 columns: sum over the 8 row slots, one partial row per (row tile, wave row)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = ocs8[e];
+      v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+      ocs8[e] = v;
+    }
+    if (lane < 8 && ncol < p.N) {
+      float* dst = p.ocs_part + ((long)tm * 2 + wr) * p.N + ncol;
+      *(f32x4*)dst = (f32x4){ocs8[0], ocs8[1], ocs8[2], ocs8[3]};
+      *(f32x4*)(dst + 4) = (f32x4){ocs8[4], ocs8[5], ocs8[6], ocs8[7]};
+    }
   }
   if (!SK && p.dbg && tid == 0) {
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the stamp is taken when this wave's stores have left
@@ -683,6 +696,13 @@ int vdk_gemm_a_colsum_rows(int32_t M, int32_t N, int32_t K) {
   return (big && (K % 64 == 0) && (M % 256 == 0)) ? (M / 256) : 0;
 }
 
+/* rows of the c_colsum by-product ([rows][N] f32: column sums of the stored bf16 output per (row tile, wave row)) if the 256x256 NT kernel serves (M, N, K), else 0 */
+int vdk_gemm_c_colsum_rows(int32_t M, int32_t N, int32_t K) {
+  const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+  const bool big = g_force_kernel == 2 || g_force_kernel == 3 || ((g_force_kernel == 0 || g_force_kernel == 4) && (K % 64 == 0) && tiles256 >= 128 && M >= 256 && N >= 256);
+  return (big && (K % 64 == 0)) ? 2 * ((M + 255) / 256) : 0;
+}
+
 int vdk_gemm_force_kernel(int32_t which) { g_force_kernel = which; return VDK_OK; }
 
 /* stream-K (VdkGemmDesc.splitk == -1): `ws` of vdk_gemm_bf16_nt is then a PERSISTENT workspace of this many bytes whose first 64 KB (the tile counters) the caller
@@ -767,7 +787,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   p.c_dtype = d->c_dtype; p.bias = (const float*)d->bias; p.residual = (const float*)d->residual; p.ldr = d->ldr;
   p.act = d->act; p.aux = (bf16_t*)d->aux; p.ldaux = d->ldaux; p.alpha = d->alpha; p.row_group = d->row_group; p.a_row_group = d->a_row_group;
   p.splitk = splitk; p.slabs = nullptr; p.sk_cnt = nullptr; p.dbg = (unsigned long long*)g_dbg_ptr;
-  p.colsum_part = nullptr;
+  p.colsum_part = nullptr; p.ocs_part = nullptr;
   p.conv_on = d->conv != nullptr;
   if (d->conv) {
     const VdkConvGeom* c = d->conv;
@@ -848,7 +868,14 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
       p.colsum_part = d->a_colsum;
       if (E != 0 && E != E_DGELU && E != E_F32) E = E_GENERIC;   // the by-product is compiled into the dgrad forms only
     }
+    if (d->c_colsum) {   // compiled into the dGELU form (dL/du = bias gradient of fc1) and the plain bf16 form
+      if ((E != E_DGELU && E != 0) || d->a_colsum) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: c_colsum goes with a plain or dGELU bf16 epilogue and without a_colsum");
+      p.ocs_part = d->c_colsum;
+      E |= E_OCS;
+    }
     switch (E) {
+      case E_OCS: LAUNCH256(false, E_OCS); break;
+      case E_DGELU | E_OCS: LAUNCH256(false, E_DGELU | E_OCS); break;
       case 0: LAUNCH256CS(0); break;
       case E_BIAS: LAUNCH256(false, E_BIAS); break;
       case E_BIAS | E_GELU: LAUNCH256(false, E_BIAS | E_GELU); break;
@@ -863,8 +890,8 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
 #undef LAUNCH256CS
 #undef LAUNCH256X
 #undef LAUNCH256
-  else if (d->a_colsum)
-    return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: a_colsum is a by-product of the 256x256 NT kernel only (see vdk_gemm_a_colsum_rows)");
+  else if (d->a_colsum || d->c_colsum)
+    return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: a_colsum / c_colsum are by-products of the 256x256 NT kernel only (see vdk_gemm_a_colsum_rows)");
   else if (d->conv)
     hipLaunchKernelGGL(gemm_bf16_nt_kernel<true>, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256), 0, stream, p);
   else

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512) void gemm256_fp8_kernel(Fp8Params q) {
   p.alpha = p.alpha * (q.a_scale_inv ? q.a_scale_inv[0] : 1.0f) * (q.b_scale_inv ? q.b_scale_inv[0] : 1.0f);
   float* slab = (float*)(smem + w * 16384);
   const int ncol = n0 + wc * 64 + (lane & 7) * 8;
-  float bias8[8];
+  float bias8[8], ocs_unused[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
   if ((E & E_BIAS) && ncol < p.N) {
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512) void gemm256_fp8_kernel(Fp8Params q) {
         for (int r = 0; r < 16; ++r)
           slab[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + ct * 32 + l31] = acc[half * 2 + rt][ct][r] * p.alpha;
     __builtin_amdgcn_wave_barrier();
-    h_epilogue_half<E>(p, slab, lane, (long)m0 + wr * 128 + half * 64, ncol, 0, bias8);
+    h_epilogue_half<E>(p, slab, lane, (long)m0 + wr * 128 + half * 64, ncol, 0, bias8, ocs_unused);
     __builtin_amdgcn_wave_barrier();
   }
 #undef F_REG
@@ -267,7 +267,7 @@ int vdk_gemm_fp8_nt(const VdkGemmDesc* d, int32_t a_fmt, int32_t b_fmt, const fl
   if (!d || !d->A || !d->B || !d->C) return vdk_fail(VDK_EINVAL, "vdk_gemm_fp8_nt: null pointer");
   if (d->M < 256 || d->N < 256 || d->K <= 0 || (d->K % 128) || (d->N & 7) || (d->lda & 15) || (d->ldb & 15) || (d->ldc & 7))
     return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_fp8_nt: needs M, N >= 256, K % 128 == 0, N % 8 == 0, lda / ldb % 16 == 0");
-  if (d->splitk > 1 || d->trans || d->conv || d->row_group > 0 || d->a_colsum) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_fp8_nt: split-K / TN / conv / row remap stay on the bf16 kernels");
+  if (d->splitk > 1 || d->trans || d->conv || d->row_group > 0 || d->a_colsum || d->c_colsum) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_fp8_nt: split-K / TN / conv / row remap stay on the bf16 kernels");
   if (!((a_fmt == 0 || a_fmt == 1) && b_fmt == 0)) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_fp8_nt: formats (e4m3, e4m3) and (e5m2, e4m3)");
   if ((d->act == VDK_ACT_DGELU && !d->aux) || (d->aux && (d->ldaux & 7))) return vdk_fail(VDK_EINVAL, "vdk_gemm_fp8_nt: bad aux");
   Fp8Params q;

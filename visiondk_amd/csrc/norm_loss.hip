@@ -89,22 +89,24 @@ __global__ __launch_bounds__(256) void ln_fwd_narrow_kernel(const float* __restr
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ dres],  g = dy * gamma;  per-block partial
 // dgamma = sum dy * xhat, dbeta = sum dy.   MAXJ * 256 >= C.
-template <int MAXJ, bool DY_BF16>
+// OCS: also per-block column sums of the bf16-rounded output dxb (= the bias gradient of the Linear whose dY this tensor is: the producer sums what it stores,
+// instead of the consuming dgrad GEMM re-reading its A tiles from LDS) -> pout [block][C].
+template <int MAXJ, bool DY_BF16, bool OCS>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, long lddy, const float* __restrict__ x,
                                                      long ldx, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      long lddres, int T, int C, int rows_per_block, float* __restrict__ dx,
                                                      long lddx, bf16_t* __restrict__ dxb, long lddxb,
-                                                     float* __restrict__ pgamma, float* __restrict__ pbeta) {
-  __shared__ float red[2][4][MAXJ * 256];
+                                                     float* __restrict__ pgamma, float* __restrict__ pbeta, float* __restrict__ pout) {
+  __shared__ float red[4][MAXJ * 256];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r0 = blockIdx.x * rows_per_block;
   int r1 = r0 + rows_per_block; if (r1 > T) r1 = T;
-  float ag[MAXJ][4], ab[MAXJ][4];
+  float ag[MAXJ][4], ab[MAXJ][4], ao[OCS ? MAXJ : 1][4];
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; }
+    for (int e = 0; e < 4; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; if (OCS) ao[j][e] = 0.f; }
   const float invC = 1.0f / (float)C;
   for (int row = r0 + w; row < r1; row += 4) {
     const float mu = mean[row], rs = rstd[row];
@@ -150,23 +152,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
           for (int e = 0; e < 4; ++e) o[e] += rv[e];
         }
         if (dx) *(f32x4*)(dx + (long)row * lddx + c) = (f32x4){o[0], o[1], o[2], o[3]};
-        if (dxb) *(u32x2*)(dxb + (long)row * lddxb + c) = (u32x2){pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+        if (dxb) {
+          const u32x2 ob = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+          *(u32x2*)(dxb + (long)row * lddxb + c) = ob;
+          if (OCS) { ao[j][0] += bf_lo(ob[0]); ao[j][1] += bf_hi(ob[0]); ao[j][2] += bf_lo(ob[1]); ao[j][3] += bf_hi(ob[1]); }
+        }
       }
     }
   }
-  // combine the 4 waves' column partials
+  // combine the 4 waves' column partials: one 16 KB buffer, one phase per quantity (the kernel is HBM-bound: LDS per block decides how many blocks a CU holds)
 #pragma unroll
-  for (int j = 0; j < MAXJ; ++j)
+  for (int ph = 0; ph < (OCS ? 3 : 2); ++ph) {
+    if (ph) __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      red[0][w][j * 256 + lane * 4 + e] = ag[j][e];
-      red[1][w][j * 256 + lane * 4 + e] = ab[j][e];
+    for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[w][j * 256 + lane * 4 + e] = ph == 0 ? ag[j][e] : (ph == 1 ? ab[j][e] : ao[OCS ? j : 0][e]);
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+      // per-block partials side by side, [block][2C]: one reduction launch serves dgamma and dbeta when they are adjacent in the gradient buffer
+      if (ph == 0) pgamma[(long)blockIdx.x * 2 * C + c] = v;
+      else if (ph == 1) pbeta[(long)blockIdx.x * 2 * C + c] = v;
+      else pout[(long)blockIdx.x * C + c] = v;
     }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    // per-block partials side by side, [block][2C]: one reduction launch serves dgamma and dbeta when they are adjacent in the gradient buffer
-    pgamma[(long)blockIdx.x * 2 * C + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
-    pbeta[(long)blockIdx.x * 2 * C + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
   }
 }
 
@@ -471,7 +480,7 @@ static inline int ln_bwd_blocks(int T) {
 }
 int vdk_layernorm_bwd_workspace_bytes(int32_t T, int32_t C, size_t* bytes) {
   if (!bytes || T < 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd_workspace_bytes: bad argument");
-  *bytes = (size_t)2 * ln_bwd_blocks(T) * C * 4;
+  *bytes = (size_t)3 * ln_bwd_blocks(T) * C * 4;      // [blocks][dgamma | dbeta] + [blocks][column sums of the bf16 output] (in-library by-product)
   return VDK_OK;
 }
 // dy: bf16 or f32 [T, lddy]; x f32 rows (ldx); dres optional f32 residual-stream gradient added to dx;
@@ -479,21 +488,29 @@ int vdk_layernorm_bwd_workspace_bytes(int32_t T, int32_t C, size_t* bytes) {
 static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean,
                        const float* rstd, const float* gamma, const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx,
                        int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                       void* stream_, VdkReduceJob* deferred) {
+                       void* stream_, VdkReduceJob* deferred, float* dxb_colsum = nullptr, VdkReduceJob* deferred2 = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!dy || !x || !mean || !rstd || !gamma || !dgamma || !dbeta || T <= 0 || C <= 0 || (C & 3) || C > 4096)
     return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: bad argument (C % 4 == 0, C <= 4096)");
   const int nb = ln_bwd_blocks(T);
-  size_t need = (size_t)2 * nb * C * 4;
+  const bool ocs = dxb_colsum != nullptr;
+  if (ocs && (!dxb || !deferred2 || C > 1024)) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: the output column sums need dxb, a job slot and C <= 1024");
+  size_t need = (size_t)(ocs ? 3 : 2) * nb * C * 4;
   if (!ws || ws_bytes < need) return vdk_fail(VDK_EWORKSPACE, "vdk_layernorm_bwd: workspace too small");
   float* pg = (float*)ws; float* pb = pg + C;          // rows of 2C: [dgamma partial | dbeta partial]
+  float* po = pg + (size_t)2 * nb * C;                 // rows of C: column sums of dxb
   const int rpb = (T + nb - 1) / nb;
   const bool bf = dy_dtype == VDK_BF16;
-#define LNB(MJ, BF) hipLaunchKernelGGL((ln_bwd_kernel<MJ, BF>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
-                                       mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb)
-  if (C <= 1024) { if (bf) LNB(4, true); else LNB(4, false); }
-  else { if (bf) LNB(16, true); else LNB(16, false); }
+#define LNB(MJ, BF, OC) hipLaunchKernelGGL((ln_bwd_kernel<MJ, BF, OC>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
+                                           mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po)
+  // MAXJ = 3 (C <= 768, ViT-B) keeps the kernel at <= 128 VGPRs = 4 blocks per CU: T / 64 = 788 blocks are then ONE round on 256 CUs (at 3 per CU they are two: +45 %)
+  if (ocs && C <= 768) { if (bf) LNB(3, true, true); else LNB(3, false, true); }
+  else if (ocs) { if (bf) LNB(4, true, true); else LNB(4, false, true); }
+  else if (C <= 768) { if (bf) LNB(3, true, false); else LNB(3, false, false); }
+  else if (C <= 1024) { if (bf) LNB(4, true, false); else LNB(4, false, false); }
+  else { if (bf) LNB(16, true, false); else LNB(16, false, false); }
 #undef LNB
+  if (ocs) *deferred2 = VdkReduceJob{po, (long)C, nb, (long)C, dxb_colsum, 1.0f};
   if (deferred && dbeta == dgamma + C) {      // the caller batches the partial-sum reduction with others (vdk_reduce_rows_batch)
     *deferred = VdkReduceJob{pg, (long)(2 * C), nb, (long)(2 * C), dgamma, 1.0f};
     return vdk_check_launch("vdk_layernorm_bwd");
@@ -588,8 +605,8 @@ int vdk_bce_logits(const float* logits, int64_t ldl, const float* targets, int64
 // LayerNorm backward whose dgamma | dbeta partial-sum reduction is left to the caller: *job describes it (job->in == NULL if it was done here after all)
 int vdk_layernorm_bwd_deferred(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
                                const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx, int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta,
-                               void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job) {
-  return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, mean, rstd, gamma, dres, lddres, T, C, dx, lddx, dxb, lddxb, dgamma, dbeta, ws, ws_bytes, stream, job);
+                               void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job, float* dxb_colsum, VdkReduceJob* job2) {
+  return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, mean, rstd, gamma, dres, lddres, T, C, dx, lddx, dxb, lddxb, dgamma, dbeta, ws, ws_bytes, stream, job, dxb_colsum, job2);
 }
 int vdk_reduce_rows_batch(const VdkReduceJob* jobs, int n, void* stream) {
   if (n < 0 || (n > 0 && !jobs)) return vdk_fail(VDK_EINVAL, "vdk_reduce_rows_batch: bad argument");

@@ -20,6 +20,7 @@ struct GemmParams {
   int splitk; int k_per_split;
   float* slabs;              // split-K: [splitk][M][N] partial sums; stream-K: [2 * grid][256 * 256] raw accumulator slabs
   int* sk_cnt;               // stream-K: per-tile k-tile counters (zero between launches)
+  float* ocs_part;           // 256-kernel, E_OCS: per (row tile, wave row) column sums of the stored bf16 output, f32 [2 * ceil(M/256)][N]
   float* colsum_part;        // 256-kernel, NT only: per (row tile, wave) column sums of A, f32 [ceil(M/256)*8][K] (bias gradient fused into the dgrad GEMM)
   // implicit-GEMM convolution (conv_on): A is an NHWC tensor gathered on the fly, see VdkConvGeom
   int conv_on, cCin, cH, cW, cOH, cOW, cKH, cKW, cstride, cpad, ctrans;

@@ -67,11 +67,12 @@ __device__ __forceinline__ void g_epilogue_store8(const GemmParams& p, long mi, 
 #define E_F32 16      /* fp32 output (else bf16) */
 #define E_SPLITK 32   /* raw fp32 partial slab */
 #define E_ROWGRP 64   /* token-row remap (patch embedding) */
+#define E_OCS 128     /* by-product: column sums of the stored (bf16-rounded) output over this wave's 128 rows -> p.ocs_part (bias gradient of the next Linear back) */
 #define E_GENERIC 0x1000
 
 template <int E>
 __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float* slab, int lane, long mbase /* first row of this 64-row half */,
-                                                int n, int z, const float (&bias8)[8]) {
+                                                int n, int z, const float (&bias8)[8], float (&ocs)[8]) {
   // this lane: rows mbase + pass*8 + (lane >> 3), pass = 0..7, columns n .. n+7
   const int rsub = lane >> 3, cc = (lane & 7) * 8;
   if (n >= p.N) return;
@@ -131,7 +132,12 @@ __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float
       *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
       *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
     } else {
-      *(u32x4*)((bf16_t*)p.C + mo[ps] * p.ldc + n) = (u32x4){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+      const u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+      *(u32x4*)((bf16_t*)p.C + mo[ps] * p.ldc + n) = o;
+      if (E & E_OCS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ocs[2 * e] += bf_lo(o[e]); ocs[2 * e + 1] += bf_hi(o[e]); }
+      }
     }
   }
 }

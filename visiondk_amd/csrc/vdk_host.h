@@ -22,4 +22,5 @@ struct VdkReduceJob { const float* in; long ld; int S; long n; float* out; float
 int vdk_reduce_rows_batch(const VdkReduceJob* jobs, int n, void* stream);
 int vdk_layernorm_bwd_deferred(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
                                const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx, int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta,
-                               void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job);
+                               void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job,
+                               float* dxb_colsum = nullptr /* [C]: column sums of the bf16 output dxb (a Linear's bias gradient), reduction described by *job2 */, VdkReduceJob* job2 = nullptr);

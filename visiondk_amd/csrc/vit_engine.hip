@@ -238,7 +238,7 @@ static int vit_plan(const VitDims& d, WsPlan* w) {
   vdk_layernorm_bwd_workspace_bytes(d.T, d.D, &w->lnws_bytes); w->lnws_bytes = (w->lnws_bytes + 255) & ~(size_t)255; w->lnws = w_take(cur, 2 * w->lnws_bytes);
   size_t cs = (size_t)((tcols + 63) / 64) * trows * 4;   // per-row-tile column sums written by the dY transposes ...
   { size_t cs2 = 0; vdk_colsum_bf16_workspace_bytes(d.T, (int)trows, &cs2); if (cs2 > cs) cs = cs2; }   // ... or by vdk_colsum_bf16
-  { size_t cs3 = (size_t)((d.T + 255) / 256) * trows * 4; if (cs3 > cs) cs = cs3; }                      // ... or by the dgrad GEMM's a_colsum by-product
+  { size_t cs3 = (size_t)2 * ((d.T + 255) / 256) * trows * 4; if (cs3 > cs) cs = cs3; }                  // ... or by a dgrad GEMM's a_colsum / c_colsum by-product
   w->csws_bytes = (cs + 255) & ~(size_t)255; w->csws = w_take(cur, 5 * w->csws_bytes);   // slots 0..3: a block's four fused bias-gradient partials (pending until its end), slot 4: immediate users
   w->dhf = w_take(cur, (size_t)d.B * D * 2);
   w->dposall = w_take(cur, (size_t)d.N * D * 4);
@@ -421,17 +421,26 @@ static int linear_wgrad(hipStream_t s, const VitDims& d, const WsPlan& w, char* 
 // dgrad GEMM  dX[rows, in] = act'(dY[rows, out] . Wt[in, out]^T)  that also delivers db = colsum(dY) for the same Linear: when the 256x256 NT kernel
 // serves the problem the column sums are a by-product of its A tiles (no extra pass over dY); returns 1 in *fused then, else the caller runs vdk_colsum_bf16.
 // The partial sums land in column-sum buffer `slot` (0..3) and their reduction is appended to `jobs` for the block's one batched launch.
+// dbx (optional): bias gradient of the Linear whose dY is this GEMM's OUTPUT dX (the previous Linear in the backward order) = column sums of the stored bf16 dX,
+// accumulated in the epilogue (c_colsum by-product, partials in buffer `slot + 4`... the caller passes a distinct slot); *fusedx says whether that happened.
 static int dgrad_with_bias(hipStream_t s, const WsPlan& w, char* base, const bf16_t* dY, int64_t lddy, const bf16_t* Wt, int64_t ldw, void* dX, int64_t lddx, int rows,
-                           int in, int out, int act, void* aux, int64_t ldaux, float* db, int* fused, int slot, VdkReduceJob* jobs, int* njobs) {
-  const int prow = vdk_gemm_a_colsum_rows(rows, in, out);
+                           int in, int out, int act, void* aux, int64_t ldaux, float* db, int* fused, int slot, VdkReduceJob* jobs, int* njobs,
+                           float* dbx = nullptr, int* fusedx = nullptr, int slotx = 0) {
+  const int prow = db ? vdk_gemm_a_colsum_rows(rows, in, out) : 0;
   *fused = (db && prow > 0 && (size_t)prow * out * 4 <= w.csws_bytes) ? 1 : 0;
+  const int xrow = dbx ? vdk_gemm_c_colsum_rows(rows, in, out) : 0;
+  const int fx = (dbx && !*fused && xrow > 0 && (size_t)xrow * in * 4 <= w.csws_bytes) ? 1 : 0;
+  if (fusedx) *fusedx = fx;
   float* const part = (float*)(base + w.csws + (size_t)slot * w.csws_bytes);
+  float* const partx = (float*)(base + w.csws + (size_t)slotx * w.csws_bytes);
   VdkGemmDesc g = {};
   g.A = dY; g.lda = lddy; g.B = Wt; g.ldb = ldw; g.C = dX; g.ldc = lddx; g.M = rows; g.N = in; g.K = out; g.c_dtype = VDK_BF16; g.act = act; g.aux = aux;
   g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = 1;
   if (*fused) g.a_colsum = part;
+  if (fx) g.c_colsum = partx;
   RC(vdk_gemm_bf16_nt(&g, nullptr, 0, s));
   if (*fused) jobs[(*njobs)++] = VdkReduceJob{part, (long)out, prow, (long)out, db, 1.0f};
+  if (fx) jobs[(*njobs)++] = VdkReduceJob{partx, (long)in, xrow, (long)in, dbx, 1.0f};
   return VDK_OK;
 }
 
@@ -471,6 +480,7 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
   RC(ev_order(0, s, s2));           // the side stream starts after whatever precedes this call on the main stream
 
   // ---- head + final norm -------------------------------------------------------------------------
+  bool last_fc2_bias_done = false;   // fc2.bias gradient of block l is produced with DXAB(l): by the final norm's backward (l = L-1) or by block l+1's norm1 backward
   if (d.C == 0) {
     // feature mode: `dlogits` is dL/d norm(x) for all tokens, f32 [B*N, D]
     float* xl = X + (size_t)(2 * d.L) * XS;
@@ -488,11 +498,19 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
       return vdk_fail(VDK_ELAUNCH, "vdk_vit_backward: memset failed");
     float* xl = X + (size_t)(2 * d.L) * XS;
     float* meanf = stats + (size_t)d.L * 4 * T; float* rstdf = meanf + T;
+    if (s2 == s && D <= 1024) {   // db of the last block's fc2 = column sums of DXAB(L-1) (only the cls rows are non-zero): by-product of this kernel
+      VdkReduceJob fj[2];
+      RC(vdk_layernorm_bwd_deferred(dhf, D, VDK_BF16, xl, (int64_t)d.N * D, meanf, rstdf, params + p.norm_w, nullptr, 0, d.B, D, dxa, (int64_t)d.N * D, DXAB(d.L - 1),
+                                    (int64_t)d.N * D, grads + p.norm_w, grads + p.norm_b, lnws, w.lnws_bytes, s, &fj[0], grads + p.blk[d.L - 1].fc2_b, &fj[1]));
+      if (fj[0].in) RC(vdk_reduce_rows_batch(fj, 2, s)); else RC(vdk_reduce_rows_batch(fj + 1, 1, s));
+      last_fc2_bias_done = true;
+    } else
     RC(vdk_layernorm_bwd(dhf, D, VDK_BF16, xl, (int64_t)d.N * D, meanf, rstdf, params + p.norm_w, nullptr, 0, d.B, D, dxa, (int64_t)d.N * D, DXAB(d.L - 1),
                          (int64_t)d.N * D, grads + p.norm_w, grads + p.norm_b, lnws, w.lnws_bytes, s));
     if (on_ready) on_ready(user, p.norm_w, p.total - p.norm_w);
   }
   // ---- blocks, last to first ------------------------------------------------------------------------
+  bool fc2_bias_from_norm1 = false;
   for (int l = d.L - 1; l >= 0; --l) {
     const PLayout::Blk& b = p.blk[l];
     float* xin = X + (size_t)(2 * l) * XS; float* xmid = xin + XS;
@@ -512,9 +530,19 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
     // MLP branch: dxa / dxab hold dL/dx_out
     RC(ev_order(ev_p++, s, s2));
     if (one_stream) {
-      RC(dgrad_with_bias(s, w, base, dxab, D, wt + p.blkT[l].fc2, D, du, M, T, M, D, VDK_ACT_DGELU, u, M, grads + b.fc2_b, &fz, 0, jobs, &nj));   // du
-      RC(linear_wgrad(s2, d, w, base, dxab, D, g, M, T, d.Tp, D, M, grads + b.fc2_w, fz ? nullptr : grads + b.fc2_b, 0));
-      RC(dgrad_with_bias(s, w, base, du, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, VDK_ACT_NONE, nullptr, 0, grads + b.fc1_b, &fz, 1, jobs, &nj));   // dh2
+      // Bias gradients ride with the PRODUCER of each dY (it sums what it stores): fc2.bias with DXAB(l) (norm backward of the block above), fc1.bias with du
+      // (dGELU epilogue below), proj.bias with dxmb (norm2 backward below); only qkv.bias still comes from the A tiles of the dh1 GEMM (dqkv is attention's output).
+      int fx = 0;
+      const bool have_fc2b = (l == d.L - 1) ? last_fc2_bias_done : fc2_bias_from_norm1;
+      RC(dgrad_with_bias(s, w, base, dxab, D, wt + p.blkT[l].fc2, D, du, M, T, M, D, VDK_ACT_DGELU, u, M, have_fc2b ? nullptr : grads + b.fc2_b, &fz, 0, jobs, &nj,
+                         grads + b.fc1_b, &fx, 1));   // du
+      RC(linear_wgrad(s2, d, w, base, dxab, D, g, M, T, d.Tp, D, M, grads + b.fc2_w, (fz || have_fc2b) ? nullptr : grads + b.fc2_b, 0));
+      if (fx) {
+        RC(gemm(s, du, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // dh2
+        fz = 1;
+      } else {
+        RC(dgrad_with_bias(s, w, base, du, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, VDK_ACT_NONE, nullptr, 0, grads + b.fc1_b, &fz, 1, jobs, &nj));   // dh2
+      }
       RC(linear_wgrad(s2, d, w, base, du, M, h2, D, T, d.Tp, M, D, grads + b.fc1_w, fz ? nullptr : grads + b.fc1_b, 0));
     } else {
       RC(linear_wgrad(s2, d, w, base, dxab, D, g, M, T, d.Tp, D, M, grads + b.fc2_w, grads + b.fc2_b, 0));
@@ -523,12 +551,16 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
       RC(linear_wgrad(s2, d, w, base, du, M, h2, D, T, d.Tp, M, D, grads + b.fc1_w, grads + b.fc1_b, 0));
       RC(gemm(s, du, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // dh2
     }
+    const bool ocs_ln = one_stream && D <= 1024;
     RC(vdk_layernorm_bwd_deferred(dsm, D, VDK_BF16, xmid, D, mean2, rstd2, params + b.n2w, dxa, D, T, D, dxm, D, dxmb, D, grads + b.n2w, grads + b.n2b, lnws0,
-                                  w.lnws_bytes, s, &jobs[nj]));
-    ++nj;
+                                  w.lnws_bytes, s, &jobs[nj], ocs_ln ? grads + b.proj_b : nullptr, ocs_ln ? &jobs[nj + 1] : nullptr));
+    nj += ocs_ln ? 2 : 1;
     // attention branch: dxm / dxmb hold dL/dx_mid
     RC(ev_order(ev_p++, s, s2));
-    if (one_stream) {
+    if (one_stream && ocs_ln) {
+      RC(gemm(s, dxmb, D, wt + p.blkT[l].proj, D, dsm, D, T, D, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // do
+      RC(linear_wgrad(s2, d, w, base, dxmb, D, o, D, T, d.Tp, D, D, grads + b.proj_w, nullptr, 0));
+    } else if (one_stream) {
       RC(dgrad_with_bias(s, w, base, dxmb, D, wt + p.blkT[l].proj, D, dsm, D, T, D, D, VDK_ACT_NONE, nullptr, 0, grads + b.proj_b, &fz, 2, jobs, &nj));   // do
       RC(linear_wgrad(s2, d, w, base, dxmb, D, o, D, T, d.Tp, D, D, grads + b.proj_w, fz ? nullptr : grads + b.proj_b, 0));
     } else {
@@ -544,9 +576,11 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
       RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, grads + b.qkv_b, 0));
       RC(gemm(s, dqkv, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));  // dh1
     }
+    const bool ocs_n1 = ocs_ln && l > 0;      // DXAB(l - 1) is dY of block l-1's fc2 (for l == 0 it feeds the patch embedding, whose bias comes from d pos_embed)
     RC(vdk_layernorm_bwd_deferred(dsm, D, VDK_BF16, xin, D, mean1, rstd1, params + b.n1w, dxm, D, T, D, dxa, D, DXAB(l - 1), D, grads + b.n1w, grads + b.n1b, lnws1,
-                                  w.lnws_bytes, s, &jobs[nj]));
-    ++nj;
+                                  w.lnws_bytes, s, &jobs[nj], ocs_n1 ? grads + p.blk[l - 1].fc2_b : nullptr, ocs_n1 ? &jobs[nj + 1] : nullptr));
+    nj += ocs_n1 ? 2 : 1;
+    fc2_bias_from_norm1 = ocs_n1;
     RC(vdk_reduce_rows_batch(jobs, nj, s));
     if (s2 != s) { hipEvent_t e; RC(ev_get(EV_SIDE_DONE + l + 1, &e)); if (hipEventRecord(e, s2) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vit: record failed"); }
     if (on_ready) {

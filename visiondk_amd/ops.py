@@ -22,7 +22,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=torch.bfloat16, bias:
             residual: Optional[torch.Tensor] = None, act: int = ACT_NONE, aux: Optional[torch.Tensor] = None,
             alpha: float = 1.0, splitk: int = 1, out: Optional[torch.Tensor] = None, row_group: int = 0,
             trans: bool = False, a_row_group: int = 0, a_rows: Optional[int] = None, a_colsum: Optional[torch.Tensor] = None,
-            streamk_ws: Optional[torch.Tensor] = None, backend=None) -> torch.Tensor:
+            streamk_ws: Optional[torch.Tensor] = None, c_colsum: Optional[torch.Tensor] = None, backend=None) -> torch.Tensor:
     """out[M,N] = epilogue(alpha * a[M,K] @ b[N,K].T); a, b bf16 (row stride may exceed K).  streamk_ws: persistent workspace from streamk_workspace() -> stream-K allowed"""
     be = _be(backend)
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
@@ -53,6 +53,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=torch.bfloat16, bias:
     d.trans = int(trans)
     d.a_row_group = a_row_group
     d.a_colsum = a_colsum.data_ptr() if a_colsum is not None else None      # f32 [vdk_gemm_a_colsum_rows(M, N, K), K] by-product (sum rows -> colsum(a))
+    d.c_colsum = c_colsum.data_ptr() if c_colsum is not None else None      # f32 [vdk_gemm_c_colsum_rows(M, N, K), N] by-product (sum rows -> colsum(stored bf16 out))
     for t in (a, b, out, residual, aux):
         if t is not None and be.device_only and not t.is_cuda:
             raise RuntimeError("visiondk_amd: HIP backend got a CPU tensor (there is no CPU fallback)")
