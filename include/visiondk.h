@@ -474,12 +474,12 @@ int vdk_resnet_backward(const VdkResNetConfig* cfg, const void* dlogits, const f
 
 /* F.normalize(W, dim=0): inv[c] = 1/max(||W[:,c]||, eps); Wb = bf16 [3D, ldb]: the normalised weight as split planes
  * (hi, hi, lo) stacked along the contraction dim (rows [0,D) alone are the plain bf16 copy); columns C..Cp-1 zero */
-int vdk_colnorm_fwd(const float* W, int64_t ldw, int32_t D, int32_t C, int32_t Cp, float eps, float* inv, void* Wb, int64_t ldb, void* stream);
+int vdk_colnorm_fwd(const float* W, int64_t ldw, int32_t D, int32_t C, int32_t Cp, float eps, float* inv, void* Wb, int64_t ldb, int32_t planes, void* stream);
 int vdk_colnorm_bwd(const float* W, int64_t ldw, const float* inv, const float* dWh, int64_t ldg, int32_t D, int32_t C, float* dW, int64_t ldo,
                     void* stream);
 /* F.normalize(feats): fh f32 [B, D]; fb bf16 [Bp, D]; fbt bf16 [3D, Bp] = transposed split planes (hi, lo, hi), so that the
  * K = 3D GEMM fbt^T . Wb accumulates hi*hi + lo*hi + hi*lo (fp32-class cos); rows/cols B..Bp-1 zero; inv f32 [B] */
-int vdk_rownorm_fwd(const float* f, int32_t B, int32_t Bp, int32_t D, float eps, float* fh, void* fb, void* fbt, float* inv, void* stream);
+int vdk_rownorm_fwd(const float* f, int32_t B, int32_t Bp, int32_t D, float eps, float* fh, void* fb, void* fbt, float* inv, int32_t planes, void* stream);
 int vdk_rownorm_bwd(const float* fh, const float* inv, const float* dfh, int64_t lddfh, int32_t B, int32_t D, float* df, void* stream);
 /* cos f32 [B, ldc] -> any of: logits f32 [B, ldl] (what the reference head returns), loss_rows f32 [B] (CE with optional label
  * smoothing), dcos bf16 [B, lddc] = grad_scale * dLoss/dcos (padding columns zeroed) */

@@ -112,3 +112,37 @@ def test_magface_vs_reference_module(be, dev):
 def test_head_factory_names():
     f = heads.HeadFactory("arcface", {"feat_dim": 8, "num_class": 16}, backend=None, device="cpu")
     assert f.head_type == "arcface"
+
+
+@pytest.mark.parametrize("D,C", [(64, 260), (512, 520), (192, 264)])
+def test_tiled_column_normalisation_and_single_plane_cos(be, dev, D, C):
+    """the register-tiled colnorm kernels (16-byte aligned rows, D <= 512) against torch, and the single-plane cos (cos_planes = 1: both operands rounded to bf16 once,
+    what torch.mm computes under the reference's autocast, train.py:118) against exactly that arithmetic"""
+    torch.manual_seed(3)
+    h = heads.ArcFace(D, C, margin_arc=0.35, margin_am=0.0, scale=32, backend=be, device=dev)
+    B = 24
+    feats = torch.randn(B, D); labels = torch.randint(0, C, (B,))
+    w = h.weight.detach().cpu()
+    st3 = heads._forward_cos(be, feats.to(dev), h.weight.detach(), 3)
+    st1 = heads._forward_cos(be, feats.to(dev), h.weight.detach(), 1)
+    wn = torch.nn.functional.normalize(w, dim=0); fn = torch.nn.functional.normalize(feats)
+    assert _rel(st3.winv[:C], 1.0 / w.norm(dim=0)) < 1e-6 and _rel(st1.winv[:C], 1.0 / w.norm(dim=0)) < 1e-6
+    assert torch.equal(st1.wb[:D, :C].cpu(), wn.bfloat16()) or _rel(st1.wb[:D, :C].float(), wn.bfloat16().float()) < 1e-3      # (1-ulp differences where x * (1/n) != x / n)
+    assert float(st1.wb[:, C:].float().abs().sum()) == 0.0
+    assert (st3.cos[:B, :C].cpu() - fn @ wn).abs().max().item() < 5e-6
+    ref1 = st1.fb[:B].float().cpu() @ st1.wb[:D, :C].float().cpu()
+    assert (st1.cos[:B, :C].cpu() - ref1).abs().max().item() < 5e-6
+    assert (st1.cos[:B, :C].cpu() - fn @ wn).abs().max().item() < 4e-3
+    # the fused step in both modes against fp32 autograd of the reference arithmetic; column-normalisation backward through the tiled kernel
+    wr = w.clone().requires_grad_(True); fr = feats.clone().requires_grad_(True)
+    kn = torch.nn.functional.normalize(wr, dim=0); f2 = torch.nn.functional.normalize(fr)
+    c = (f2 @ kn).clamp(-1, 1)
+    import math
+    cm = torch.where(c > math.cos(math.pi - 0.35), c * math.cos(0.35) - torch.sqrt(1 - c ** 2) * math.sin(0.35), c)
+    idx = torch.zeros_like(c).scatter_(1, labels.view(-1, 1), 1).bool()
+    loss = torch.nn.functional.cross_entropy(torch.where(idx, cm, c) * 32, labels)
+    loss.backward()
+    for planes, tol in ((3, 1e-2), (1, 2e-2)):
+        lr, df, dW = h.margin_ce(feats.to(dev), labels.to(dev), cos_planes=planes)
+        assert abs(lr.mean().item() - loss.item()) < (1e-4 if planes == 3 else 5e-3) * abs(loss.item())
+        assert _rel(df, fr.grad) < tol and _rel(dW, wr.grad) < tol

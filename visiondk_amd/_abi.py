@@ -120,9 +120,9 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_ohem_mask": (C.c_int, [P, I64, I32, I32, P, I32, F32, I64, P, P, P]),
     "vdk_topk_rows": (C.c_int, [P, I64, I32, I32, I32, P, P, P]),
     # margin-softmax heads
-    "vdk_colnorm_fwd": (C.c_int, [P, I64, I32, I32, I32, F32, P, P, I64, P]),
+    "vdk_colnorm_fwd": (C.c_int, [P, I64, I32, I32, I32, F32, P, P, I64, I32, P]),
     "vdk_colnorm_bwd": (C.c_int, [P, I64, P, P, I64, I32, I32, P, I64, P]),
-    "vdk_rownorm_fwd": (C.c_int, [P, I32, I32, I32, F32, P, P, P, P, P]),
+    "vdk_rownorm_fwd": (C.c_int, [P, I32, I32, I32, F32, P, P, P, P, I32, P]),
     "vdk_rownorm_bwd": (C.c_int, [P, P, P, I64, I32, I32, P, P]),
     "vdk_margin_ce": (C.c_int, [C.POINTER(MarginHead), P, I64, I32, I32, P, F32, F32, P, I64, P, P, I64, P]),
     "vdk_margin_target_cos": (C.c_int, [P, I64, I32, I32, I64, P, P, P]),

@@ -74,7 +74,7 @@ __device__ __forceinline__ void margin_eval(const MarginP& P, const RowCtx& R, f
 // feature planes (hi, lo, hi) the cos GEMM accumulates hi*hi + lo*hi + hi*lo: fp32-class accuracy (~2^-16) on the bf16 MFMA
 // pipe.  Columns C..Cp-1 are zero.  The backward GEMMs use the first plane only.
 __global__ __launch_bounds__(256) void colnorm_fwd_kernel(const float* __restrict__ W, long ldw, int D, int C, int Cp, float eps,
-                                                          float* __restrict__ inv, bf16_t* __restrict__ Wb, long ldb) {
+                                                          float* __restrict__ inv, bf16_t* __restrict__ Wb, long ldb, int planes) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= Cp) return;
   float s = 0.f;
@@ -86,8 +86,7 @@ __global__ __launch_bounds__(256) void colnorm_fwd_kernel(const float* __restric
     const bf16_t h = f2bf(v);
     const bf16_t l = f2bf(v - bf2f(h));
     Wb[(long)d * ldb + c] = h;
-    Wb[(long)(D + d) * ldb + c] = h;
-    Wb[(long)(2 * D + d) * ldb + c] = l;
+    if (planes == 3) { Wb[(long)(D + d) * ldb + c] = h; Wb[(long)(2 * D + d) * ldb + c] = l; }
   }
 }
 // dW[:, c] = inv[c] * (dW^[:, c] - W^[:, c] * <W^[:, c], dW^[:, c]>),  W^ = W * inv
@@ -101,10 +100,112 @@ __global__ __launch_bounds__(256) void colnorm_bwd_kernel(const float* __restric
   for (int d = 0; d < D; ++d) dot = fmaf(W[(long)d * ldw + c] * iv, dWh[(long)d * ldg + c], dot);
   for (int d = 0; d < D; ++d) dW[(long)d * ldo + c] = iv * (dWh[(long)d * ldg + c] - W[(long)d * ldw + c] * iv * dot);
 }
+// Tiled forms (D <= 16 * 32, 16-byte aligned rows): a 512-thread block owns 64 columns x all D rows as 32 row groups x 16 column quads; every thread keeps
+// its D / 32 rows x 4 columns in registers, so W (and dW^) are read from HBM exactly once with 16-byte loads, many in flight (the thread-per-column loops above
+// issue one dependent 4-byte load at a time: 1.6 / 1.9 ms at C = 10^6 where 5 / 6 GB of traffic cost 1.0 / 1.2 ms).  planes: 3 = (hi, hi, lo), 1 = hi only.
+template <int RPT>
+__global__ __launch_bounds__(512) void colnorm_fwd_tiled_kernel(const float* __restrict__ W, long ldw, int D, int C, int Cp, float eps, float* __restrict__ inv,
+                                                                bf16_t* __restrict__ Wb, long ldb, int planes) {
+  __shared__ float red[32][65];
+  __shared__ float tot[64];
+  const int tid = threadIdx.x, q = tid & 15, rg = tid >> 4;
+  const int c0 = blockIdx.x * 64 + q * 4;
+  f32x4 v[RPT];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int d = rg + 32 * i;
+    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+    if (d < D && c0 < C) {
+      const float* src = W + (long)d * ldw + c0;
+      if (c0 + 3 < C) x = *(const f32x4*)src;
+      else { x[0] = src[0]; if (c0 + 1 < C) x[1] = src[1]; if (c0 + 2 < C) x[2] = src[2]; }
+    }
+    v[i] = x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = fmaf(x[e], x[e], s[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[rg][q * 4 + e] = s[e];
+  __syncthreads();
+  if (tid < 64) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) t += red[r][tid];
+    const int c = blockIdx.x * 64 + tid;
+    const float iv = c < C ? 1.0f / fmaxf(sqrtf(t), eps) : 0.f;
+    tot[tid] = iv;
+    if (c < C && inv) inv[c] = iv;
+  }
+  __syncthreads();
+  if (c0 >= Cp) return;
+  float iv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) iv[e] = tot[q * 4 + e];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int d = rg + 32 * i;
+    if (d >= D) continue;
+    float n[4]; bf16_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { n[e] = v[i][e] * iv[e]; h[e] = f2bf(n[e]); l[e] = f2bf(n[e] - bf2f(h[e])); }
+    const u32x2 hv = {(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+    *(u32x2*)(Wb + (long)d * ldb + c0) = hv;
+    if (planes == 3) {
+      *(u32x2*)(Wb + (long)(D + d) * ldb + c0) = hv;
+      *(u32x2*)(Wb + (long)(2 * D + d) * ldb + c0) = (u32x2){(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+    }
+  }
+}
+template <int RPT>
+__global__ __launch_bounds__(512) void colnorm_bwd_tiled_kernel(const float* __restrict__ W, long ldw, const float* __restrict__ inv, const float* __restrict__ dWh,
+                                                                long ldg, int D, int C, float* __restrict__ dW, long ldo) {
+  __shared__ float red[32][65];
+  __shared__ float tot[64];
+  const int tid = threadIdx.x, q = tid & 15, rg = tid >> 4;
+  const int c0 = blockIdx.x * 64 + q * 4;          // C % 4 == 0 here (launcher): a quad is all valid or all beyond C
+  const bool ok = c0 < C;
+  f32x4 iv = {0.f, 0.f, 0.f, 0.f};
+  if (ok) iv = *(const f32x4*)(inv + c0);
+  f32x4 wv[RPT], gv[RPT];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int d = rg + 32 * i;
+    f32x4 x = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
+    if (d < D && ok) { x = *(const f32x4*)(W + (long)d * ldw + c0); g = *(const f32x4*)(dWh + (long)d * ldg + c0); }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { x[e] *= iv[e]; s[e] = fmaf(x[e], g[e], s[e]); }
+    wv[i] = x; gv[i] = g;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[rg][q * 4 + e] = s[e];
+  __syncthreads();
+  if (tid < 64) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) t += red[r][tid];
+    tot[tid] = t;
+  }
+  __syncthreads();
+  if (!ok) return;
+  float dot[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) dot[e] = tot[q * 4 + e];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int d = rg + 32 * i;
+    if (d >= D) continue;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = iv[e] * (gv[i][e] - wv[i][e] * dot[e]);
+    *(f32x4*)(dW + (long)d * ldo + c0) = o;
+  }
+}
 // f f32 [B, D] -> f^ as f32 [B, D], bf16 [Bp, D] (hi plane, backward operand) and the transposed split planes
 // fbt [3D, Bp] = (hi, lo, hi) for the cos GEMM; inv[B]; rows B..Bp-1 zero.  one wave per row
 __global__ __launch_bounds__(256) void rownorm_fwd_kernel(const float* __restrict__ f, int B, int Bp, int D, float eps, float* __restrict__ fh,
-                                                          bf16_t* __restrict__ fb, bf16_t* __restrict__ fbt, float* __restrict__ inv) {
+                                                          bf16_t* __restrict__ fb, bf16_t* __restrict__ fbt, float* __restrict__ inv, int planes) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= Bp) return;
   float s = 0.f;
@@ -119,8 +220,7 @@ __global__ __launch_bounds__(256) void rownorm_fwd_kernel(const float* __restric
     const bf16_t l = f2bf(v - bf2f(h));
     fb[(long)row * D + d] = h;
     fbt[(long)d * Bp + row] = h;
-    fbt[(long)(D + d) * Bp + row] = l;
-    fbt[(long)(2 * D + d) * Bp + row] = h;
+    if (planes == 3) { fbt[(long)(D + d) * Bp + row] = l; fbt[(long)(2 * D + d) * Bp + row] = h; }
   }
 }
 // df = inv * (df^ - f^ <f^, df^>)
@@ -180,6 +280,9 @@ __global__ __launch_bounds__(256) void margin_ce_kernel(MarginP P, const float* 
 // Training form (no logits output) for wide heads: the same arithmetic with 16-byte loads, four of them in flight per thread (a 4-byte strided loop keeps
 // ~1 KB in flight per workgroup: 1 TB/s at C = 10^6), and an online softmax so that cos is read twice instead of three times.
 #define MCE_U 4
+// v_exp_f32 on x * log2(e): 2 instructions against libm expf's ~12 (range reduction + polynomial); relative error ~2^-22 on |x| < 90, i.e. inside the rounding of the
+// softmax sums.  The narrow-head kernel above (golden-vector comparisons) keeps expf.
+__device__ __forceinline__ float vexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __global__ __launch_bounds__(256) void margin_ce_vec_kernel(MarginP P, const float* __restrict__ cosv, long ldc, int C, const long long* __restrict__ y,
                                                             float label_smoothing, float gscale, float* __restrict__ loss_rows, bf16_t* __restrict__ dcos,
                                                             long lddc) {
@@ -194,8 +297,18 @@ __global__ __launch_bounds__(256) void margin_ce_vec_kernel(MarginP P, const flo
   auto visit = [&](float cv, int c) {
     float lg, jc; margin_eval(P, R, cv, c == yt, lg, jc);
     sm += lg;
-    if (lg > m) { se *= expf(m - lg); m = lg; }
-    se += expf(lg - m);
+    if (lg > m) { se *= vexp(m - lg); m = lg; }
+    se += vexp(lg - m);
+  };
+  // four logits per running-maximum update: 5 exponentials per 4 entries instead of 8 (the kernel is VALU-bound, not HBM-bound: ~40 lane-ops per entry and pass)
+  auto visit4 = [&](const f32x4& cv, int c) {
+    float lg[4], jc;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) margin_eval(P, R, cv[e], c + e == yt, lg[e], jc);
+    sm += (lg[0] + lg[1]) + (lg[2] + lg[3]);
+    const float m4 = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+    if (m4 > m) { se *= vexp(m - m4); m = m4; }
+    se += (vexp(lg[0] - m) + vexp(lg[1] - m)) + (vexp(lg[2] - m) + vexp(lg[3] - m));
   };
   for (int base = tid * 4; base < C4; base += 256 * 4 * MCE_U) {
     f32x4 v[MCE_U];
@@ -204,15 +317,12 @@ __global__ __launch_bounds__(256) void margin_ce_vec_kernel(MarginP P, const flo
 #pragma unroll
     for (int u = 0; u < MCE_U; ++u) {
       const int c = base + u * 1024;
-      if (c < C4) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) visit(v[u][e], c + e);
-      }
+      if (c < C4) visit4(v[u], c);
     }
   }
   for (int c = C4 + tid; c < C; c += 256) visit(cr[c], c);
   const float mx = block_max<4>(m, red);
-  se = block_sum<4>(se * expf(m - mx), red);
+  se = block_sum<4>(se * vexp(m - mx), red);
   sm = block_sum<4>(sm, red);
   if (tid == 0 && loss_rows) {
     float lg, jc; margin_eval(P, R, cr[yt], true, lg, jc);
@@ -222,7 +332,7 @@ __global__ __launch_bounds__(256) void margin_ce_vec_kernel(MarginP P, const flo
   const float inv = 1.0f / se, epsc = label_smoothing / (float)C;
   auto grad = [&](float cv, int c) -> float {
     float lg, jc; margin_eval(P, R, cv, c == yt, lg, jc);
-    float g = expf(lg - mx) * inv - epsc;
+    float g = vexp(lg - mx) * inv - epsc;
     if (c == yt) g -= (1.0f - label_smoothing);
     return g * gscale * jc;
   };
@@ -268,6 +378,15 @@ __global__ __launch_bounds__(256) void margin_stats_kernel(MarginP P, const floa
     if (lg > m) { se *= expf(m - lg); m = lg; }
     se += expf(lg - m);
   };
+  auto visit4 = [&](const f32x4& cv, int c) {
+    float lg[4], jc;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { margin_eval(P, R, cv[e], c + e == yt, lg[e], jc); if (c + e == yt) tl = lg[e]; }
+    sm += (lg[0] + lg[1]) + (lg[2] + lg[3]);
+    const float m4 = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+    if (m4 > m) { se *= expf(m - m4); m = m4; }
+    se += (expf(lg[0] - m) + expf(lg[1] - m)) + (expf(lg[2] - m) + expf(lg[3] - m));
+  };
   // 16-byte loads, four in flight per thread (see margin_ce_vec_kernel); scalar loop for unaligned blocks and the tail
   const int C4 = (((ldc & 3) == 0) && (((size_t)cosv & 15) == 0)) ? (Cloc & ~3) : 0;
   for (int base = tid * 4; base < C4; base += 256 * 4 * MCE_U) {
@@ -277,10 +396,7 @@ __global__ __launch_bounds__(256) void margin_stats_kernel(MarginP P, const floa
 #pragma unroll
     for (int u = 0; u < MCE_U; ++u) {
       const int c = base + u * 1024;
-      if (c < C4) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) visit(v[u][e], c + e);
-      }
+      if (c < C4) visit4(v[u], c);
     }
   }
   for (int c = C4 + tid; c < Cloc; c += 256) visit(cr[c], c);
@@ -348,23 +464,40 @@ static int fill_params(const VdkMarginHead* h, MarginP* P) {
 
 extern "C" {
 
-int vdk_colnorm_fwd(const float* W, int64_t ldw, int32_t D, int32_t C, int32_t Cp, float eps, float* inv, void* Wb, int64_t ldb, void* stream) {
-  if (!W || !Wb || D <= 0 || C <= 0 || Cp < C) return vdk_fail(VDK_EINVAL, "vdk_colnorm_fwd: bad argument");
-  hipLaunchKernelGGL(colnorm_fwd_kernel, dim3((unsigned)((Cp + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, (long)ldw, (int)D, (int)C, (int)Cp, eps,
-                     inv, (bf16_t*)Wb, (long)ldb);
+int vdk_colnorm_fwd(const float* W, int64_t ldw, int32_t D, int32_t C, int32_t Cp, float eps, float* inv, void* Wb, int64_t ldb, int32_t planes, void* stream) {
+  if (!W || !Wb || D <= 0 || C <= 0 || Cp < C || (planes != 1 && planes != 3)) return vdk_fail(VDK_EINVAL, "vdk_colnorm_fwd: bad argument (planes = 1 or 3)");
+  const bool tiled = D <= 512 && (ldw % 4 == 0) && (ldb % 4 == 0) && (Cp % 4 == 0) && (((uintptr_t)W | (uintptr_t)Wb) % 16 == 0);
+  if (tiled) {
+    const dim3 grid((unsigned)((Cp + 63) / 64));
+#define CNF(R) hipLaunchKernelGGL((colnorm_fwd_tiled_kernel<R>), grid, dim3(512), 0, (hipStream_t)stream, W, (long)ldw, (int)D, (int)C, (int)Cp, eps, inv, (bf16_t*)Wb, (long)ldb, (int)planes)
+    if (D <= 128) CNF(4); else if (D <= 256) CNF(8); else CNF(16);
+#undef CNF
+  } else {
+    hipLaunchKernelGGL(colnorm_fwd_kernel, dim3((unsigned)((Cp + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, (long)ldw, (int)D, (int)C, (int)Cp, eps,
+                       inv, (bf16_t*)Wb, (long)ldb, (int)planes);
+  }
   return vdk_check_launch("vdk_colnorm_fwd");
 }
 int vdk_colnorm_bwd(const float* W, int64_t ldw, const float* inv, const float* dWh, int64_t ldg, int32_t D, int32_t C, float* dW, int64_t ldo,
                     void* stream) {
   if (!W || !inv || !dWh || !dW || D <= 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_colnorm_bwd: bad argument");
-  hipLaunchKernelGGL(colnorm_bwd_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, (long)ldw, inv, dWh, (long)ldg, (int)D,
-                     (int)C, dW, (long)ldo);
+  const bool tiled = D <= 512 && (C % 4 == 0) && (ldw % 4 == 0) && (ldg % 4 == 0) && (ldo % 4 == 0) &&
+                     (((uintptr_t)W | (uintptr_t)dWh | (uintptr_t)dW | (uintptr_t)inv) % 16 == 0);
+  if (tiled) {
+    const dim3 grid((unsigned)((C + 63) / 64));
+#define CNB(R) hipLaunchKernelGGL((colnorm_bwd_tiled_kernel<R>), grid, dim3(512), 0, (hipStream_t)stream, W, (long)ldw, inv, dWh, (long)ldg, (int)D, (int)C, dW, (long)ldo)
+    if (D <= 128) CNB(4); else if (D <= 256) CNB(8); else CNB(16);
+#undef CNB
+  } else {
+    hipLaunchKernelGGL(colnorm_bwd_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, (long)ldw, inv, dWh, (long)ldg, (int)D,
+                       (int)C, dW, (long)ldo);
+  }
   return vdk_check_launch("vdk_colnorm_bwd");
 }
-int vdk_rownorm_fwd(const float* f, int32_t B, int32_t Bp, int32_t D, float eps, float* fh, void* fb, void* fbt, float* inv, void* stream) {
-  if (!f || !fh || !fb || !fbt || !inv || B <= 0 || Bp < B || D <= 0) return vdk_fail(VDK_EINVAL, "vdk_rownorm_fwd: bad argument");
+int vdk_rownorm_fwd(const float* f, int32_t B, int32_t Bp, int32_t D, float eps, float* fh, void* fb, void* fbt, float* inv, int32_t planes, void* stream) {
+  if (!f || !fh || !fb || !fbt || !inv || B <= 0 || Bp < B || D <= 0 || (planes != 1 && planes != 3)) return vdk_fail(VDK_EINVAL, "vdk_rownorm_fwd: bad argument");
   hipLaunchKernelGGL(rownorm_fwd_kernel, dim3((unsigned)((Bp + 3) / 4)), dim3(256), 0, (hipStream_t)stream, f, (int)B, (int)Bp, (int)D, eps, fh, (bf16_t*)fb,
-                     (bf16_t*)fbt, inv);
+                     (bf16_t*)fbt, inv, (int)planes);
   return vdk_check_launch("vdk_rownorm_fwd");
 }
 int vdk_rownorm_bwd(const float* fh, const float* inv, const float* dfh, int64_t lddfh, int32_t B, int32_t D, float* df, void* stream) {

@@ -385,8 +385,10 @@ class FaceTrainStep:
     launch each with the same global clip factor.  BatchNorm running statistics enter the EMA like every float entry of state_dict()."""
 
     def __init__(self, model: "FaceTrainingModel", lr: float, momentum: float = 0.9, weight_decay: float = 5e-4, label_smoothing: float = 0.0,
-                 max_norm: float = 10.0, ema: bool = True, comm=None, layer_wise: bool = False, shard_head: bool = False, sync_bn: bool = False):
-        """shard_head (with comm): every rank keeps the columns [rank * C / world, (rank + 1) * C / world) of the margin head, trains them with
+                 max_norm: float = 10.0, ema: bool = True, comm=None, layer_wise: bool = False, shard_head: bool = False, sync_bn: bool = False,
+                 cos_planes: int = 3):
+        """cos_planes: 3 = fp32-class cosines in the head (split-bf16 planes: the reference's CPU path), 1 = single bf16 operands (the reference's GPU path: the head runs
+        under autocast, train.py:118).  shard_head (with comm): every rank keeps the columns [rank * C / world, (rank + 1) * C / world) of the margin head, trains them with
         `heads.sharded_margin_ce` (features all-gathered, per-row softmax statistics and the [B, D] feature gradient all-reduced) and never all-reduces the
         [D, C] head gradient (2 GB at C = 10^6).  `gather_head()` writes the shards back into `head.weight` for evaluation / checkpoints.
         layer_wise: the second entry of the yaml's `optimizer` list (cbir.yaml:113): two parameter groups, backbone + neck at lr and the
@@ -395,6 +397,7 @@ class FaceTrainStep:
         rank 0 at construction and the buffers again before every forward (torch DDP's broadcast_buffers=True, which the reference's
         DDP wrap at vision_engine.py:510 uses); the backbone's flat gradient is all-reduced in buckets while backward is still running, the neck /
         head gradients right after; BatchNorm statistics stay per-rank (the reference's default, SyncBN is its opt-in flag)."""
+        self.cos_planes = cos_planes
         self.model = model
         self.comm = comm
         self.bb = model.trainingwrapper["backbone"]
@@ -484,7 +487,7 @@ class FaceTrainStep:
             self.loss_rows, demb, dW = heads.sharded_margin_ce(self.head, emb.detach(), y, self.hs, self.c0, self.head.weight.shape[1], group=self.comm.group,
                                                               label_smoothing=self.label_smoothing)
         else:
-            self.loss_rows, demb, dW = self.head.margin_ce(emb.detach(), y, self.label_smoothing)
+            self.loss_rows, demb, dW = self.head.margin_ce(emb.detach(), y, self.label_smoothing, cos_planes=self.cos_planes)
         for p in self.small:
             p.grad = None
         emb.backward(demb)

@@ -24,20 +24,22 @@ class _HeadState:
     __slots__ = ("cos", "fh", "fb", "fbt", "finv", "winv", "wb", "B", "Bp", "C", "Cp", "D")
 
 
-def _forward_cos(be, feats: torch.Tensor, weight: torch.Tensor) -> _HeadState:
+def _forward_cos(be, feats: torch.Tensor, weight: torch.Tensor, planes: int = 3) -> _HeadState:
+    """planes = 3: cos from split-bf16 planes (hi*hi + lo*hi + hi*lo: fp32-class, what the reference's CPU path computes); planes = 1: one bf16 plane per operand --
+    exactly the reference's GPU path, where train.py:118 runs the head under autocast and torch.mm(feats, kernel_norm) rounds both operands to bf16"""
     st = _HeadState()
     B, D = feats.shape
     Cn = weight.shape[1]
     st.B, st.D, st.C, st.Bp, st.Cp = B, D, Cn, _up(B, 64), _up(Cn, 8)
     dev = feats.device
     st.winv = torch.empty(Cn, dtype=torch.float32, device=dev)
-    st.wb = torch.empty((3 * D, st.Cp), dtype=torch.bfloat16, device=dev)   # split planes (hi, hi, lo) along K
-    be.check(be.lib.vdk_colnorm_fwd(be.ptr(weight), Cn, D, Cn, st.Cp, 1e-12, be.ptr(st.winv), be.ptr(st.wb), st.Cp, be.stream()), "vdk_colnorm_fwd")
+    st.wb = torch.empty((planes * D, st.Cp), dtype=torch.bfloat16, device=dev)   # split planes (hi, hi, lo) along K
+    be.check(be.lib.vdk_colnorm_fwd(be.ptr(weight), Cn, D, Cn, st.Cp, 1e-12, be.ptr(st.winv), be.ptr(st.wb), st.Cp, planes, be.stream()), "vdk_colnorm_fwd")
     st.fh = torch.empty((B, D), dtype=torch.float32, device=dev)
     st.fb = torch.empty((st.Bp, D), dtype=torch.bfloat16, device=dev)
-    st.fbt = torch.empty((3 * D, st.Bp), dtype=torch.bfloat16, device=dev)  # split planes (hi, lo, hi)
+    st.fbt = torch.empty((planes * D, st.Bp), dtype=torch.bfloat16, device=dev)  # split planes (hi, lo, hi)
     st.finv = torch.empty(B, dtype=torch.float32, device=dev)
-    be.check(be.lib.vdk_rownorm_fwd(be.ptr(feats), B, st.Bp, D, 1e-12, be.ptr(st.fh), be.ptr(st.fb), be.ptr(st.fbt), be.ptr(st.finv), be.stream()),
+    be.check(be.lib.vdk_rownorm_fwd(be.ptr(feats), B, st.Bp, D, 1e-12, be.ptr(st.fh), be.ptr(st.fb), be.ptr(st.fbt), be.ptr(st.finv), planes, be.stream()),
              "vdk_rownorm_fwd")
     # cos[Bp, Cp] = f^ . W^ : TN kernel over K = 3D split planes (hi*hi + lo*hi + hi*lo), A = fbt [3D, Bp], B = wb [3D, Cp]
     st.cos = ops.gemm_nt(st.fbt, st.wb, out_dtype=torch.float32, trans=True, backend=be)
@@ -103,12 +105,15 @@ class _MarginHead(nn.Module):
     def forward(self, feats: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         return _HeadFn.apply(feats, self.weight, labels, self)
 
-    def margin_ce(self, feats: torch.Tensor, labels: torch.Tensor, label_smoothing: float = 0.0, grad_scale: Optional[float] = None):
-        """Fused head + CrossEntropy (mean): returns (loss_rows [B], dfeats [B, D], dweight [D, C]); no autograd, no B x C logits."""
+    def margin_ce(self, feats: torch.Tensor, labels: torch.Tensor, label_smoothing: float = 0.0, grad_scale: Optional[float] = None, cos_planes: int = 3):
+        """Fused head + CrossEntropy (mean): returns (loss_rows [B], dfeats [B, D], dweight [D, C]); no autograd, no B x C logits.
+        cos_planes = 1: the cosines from single bf16 operands, as the reference's autocast path computes them (see _forward_cos)"""
         be = self.be
-        st = _forward_cos(be, feats.contiguous(), self.weight.detach())
+        st = _forward_cos(be, feats.contiguous(), self.weight.detach(), cos_planes)
         loss = torch.empty(st.B, dtype=torch.float32, device=feats.device)
-        dcos = torch.zeros((st.Bp, st.Cp), dtype=torch.bfloat16, device=feats.device)
+        dcos = torch.empty((st.Bp, st.Cp), dtype=torch.bfloat16, device=feats.device)    # rows < B are written whole (padding columns zeroed) by the kernel
+        if st.Bp > st.B:
+            dcos[st.B:].zero_()
         gs = 1.0 / st.B if grad_scale is None else grad_scale
         be.check(be.lib.vdk_margin_ce(C.byref(self.cfg), be.ptr(st.cos), st.Cp, st.B, st.C, be.ptr(labels), label_smoothing, gs, None, 0, be.ptr(loss),
                                       be.ptr(dcos), st.Cp, be.stream()), "vdk_margin_ce")
