@@ -13,7 +13,7 @@ happens in the HIP kernels of csrc/cbir.hip through the C ABI; there is no CPU f
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional
+from typing import Optional, Sequence
 
 import numpy as np
 import torch
@@ -293,27 +293,58 @@ def search(extractor, query_dataloader, faiss_index: FlatIPIndex, device, logger
     return torch.cat(all_s, 0), torch.cat(all_i, 0)
 
 
-def search_sharded(queries: torch.Tensor, local_gallery: torch.Tensor, k: int, idx_base: int, group=None, backend=None, device=None, cap: int = DEFAULT_CAP):
+def search_sharded(queries: torch.Tensor, local_gallery: torch.Tensor, k: int, idx_base: int, group=None, backend=None, device=None, cap: int = DEFAULT_CAP,
+                   query_counts: Optional[Sequence[int]] = None, index: Optional["FlatIPIndex"] = None):
     """Multi-GPU search (path B): the gallery is row-sharded (`local_gallery` = this rank's rows, global row ids starting at
-    `idx_base`), every rank holds its own query block.  Queries are all-gathered, each rank searches its shard, the per-shard top-k lists are
-    all-gathered and merged with the same (score desc, index asc) rule -> every rank returns the global (scores, indices) of ITS queries,
-    bit-identical to a single-GPU search over the whole gallery.  One process per GPU; two collectives, both outside the scan."""
+    `idx_base`), every rank holds its own query block.  Queries are all-gathered (one flat-tensor collective), each rank searches its shard, and every rank
+    receives from every shard ONLY the top-k lists of its own queries (one all-to-all per tensor: 1/world of an all-gather's traffic over xGMI), merged with the
+    same (score desc, index asc) rule -> the global (scores, indices) of ITS queries, bit-identical to a single-GPU search over the whole gallery.
+    One process per GPU; the collectives stay outside the scan.  query_counts: per-rank query counts if the caller knows them (equal blocks: the usual case) --
+    saves the count exchange and its host synchronisation; index: a prebuilt FlatIPIndex over this rank's shard (else built here)."""
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    nq_local = torch.tensor([queries.shape[0]], dtype=torch.int64, device=queries.device)
-    counts = [torch.zeros_like(nq_local) for _ in range(world)]
-    dist.all_gather(counts, nq_local, group=group)
-    counts = [int(c.item()) for c in counts]
-    qmax = max(counts)
-    qpad = torch.zeros((qmax, queries.shape[1]), dtype=torch.float32, device=queries.device)
-    qpad[:queries.shape[0]] = queries
-    gathered = [torch.empty_like(qpad) for _ in range(world)]
-    dist.all_gather(gathered, qpad, group=group)
-    allq = torch.cat([g[:c] for g, c in zip(gathered, counts)], 0)
-    index = FlatIPIndex(queries.shape[1], backend=backend, device=device if device is not None else queries.device, cap=cap, idx_base=idx_base)
-    index.add(local_gallery)
+    dev = queries.device
+    if query_counts is None:
+        nq_local = torch.tensor([queries.shape[0]], dtype=torch.int64, device=dev)
+        call = torch.zeros(world, dtype=torch.int64, device=dev)
+        _all_gather_flat(dist, call, nq_local, group)
+        counts = [int(c) for c in call.tolist()]
+    else:
+        counts = [int(c) for c in query_counts]
+        assert len(counts) == world and counts[rank] == queries.shape[0]
+    qmax, D = max(counts), queries.shape[1]
+    if queries.shape[0] == qmax:
+        qpad = queries.contiguous().float()
+    else:
+        qpad = torch.zeros((qmax, D), dtype=torch.float32, device=dev)
+        qpad[:queries.shape[0]] = queries
+    gathered = torch.empty((world, qmax, D), dtype=torch.float32, device=dev)
+    _all_gather_flat(dist, gathered, qpad, group)
+    allq = gathered.view(world * qmax, D) if min(counts) == qmax else torch.cat([gathered[r, :c] for r, c in enumerate(counts)], 0)
+    if index is None:
+        index = FlatIPIndex(D, backend=backend, device=device if device is not None else dev, cap=cap, idx_base=idx_base)
+        index.add(local_gallery)
     s, i = index.search(allq, k)                                  # [sum nq, k] for this shard, global row ids
-    parts_s = [torch.empty_like(s) for _ in range(world)]; parts_i = [torch.empty_like(i) for _ in range(world)]
-    dist.all_gather(parts_s, s.contiguous(), group=group); dist.all_gather(parts_i, i.contiguous(), group=group)
-    lo = sum(counts[:rank]); hi = lo + counts[rank]
-    return merge_topk(torch.stack([p[lo:hi] for p in parts_s]).contiguous(), torch.stack([p[lo:hi] for p in parts_i]).contiguous(), backend=backend)
+    s = s.contiguous(); i = i.contiguous()
+    mine = counts[rank]
+    try:        # shard r -> rank q: the rows of q's queries (all-to-all with uneven splits = counts)
+        rs = torch.empty((world * mine, k), dtype=s.dtype, device=dev); ri = torch.empty((world * mine, k), dtype=i.dtype, device=dev)
+        dist.all_to_all_single(rs, s, output_split_sizes=[mine] * world, input_split_sizes=counts, group=group)
+        dist.all_to_all_single(ri, i, output_split_sizes=[mine] * world, input_split_sizes=counts, group=group)
+        ps, pi = rs.view(world, mine, k), ri.view(world, mine, k)
+    except (RuntimeError, NotImplementedError):   # a backend without all-to-all: gather everything, keep this rank's slice
+        parts_s = [torch.empty_like(s) for _ in range(world)]; parts_i = [torch.empty_like(i) for _ in range(world)]
+        dist.all_gather(parts_s, s, group=group); dist.all_gather(parts_i, i, group=group)
+        lo = sum(counts[:rank]); hi = lo + mine
+        ps = torch.stack([p[lo:hi] for p in parts_s]).contiguous(); pi = torch.stack([p[lo:hi] for p in parts_i]).contiguous()
+    return merge_topk(ps, pi, backend=backend)
+
+
+def _all_gather_flat(dist, out: torch.Tensor, inp: torch.Tensor, group) -> None:
+    """all-gather into ONE preallocated tensor (no per-rank list, no concatenation copies); list form only where the backend lacks the flat collective"""
+    try:
+        dist.all_gather_into_tensor(out.view(-1), inp.contiguous().view(-1), group=group)
+    except (RuntimeError, NotImplementedError, AttributeError):
+        world = dist.get_world_size(group)
+        parts = list(out.view(world, -1).unbind(0))
+        dist.all_gather(parts, inp.contiguous().view(-1), group=group)
