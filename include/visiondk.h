@@ -115,7 +115,8 @@ typedef struct VdkGemmDesc {
   float alpha;
   int32_t splitk;          /* <= 1: none */
   int32_t row_group;       /* > 0: output row m -> m + m/row_group + 1, residual row -> m % row_group + 1
-                              (PatchEmbed rows written straight into the [B, 1+np, D] token buffer + pos_embed) */
+                              (PatchEmbed rows written straight into the [B, 1+np, D] token buffer + pos_embed);
+                              < 0: output rows stay, residual row -> m % |row_group| (the same without a class token: [B, np, D] + pos_embed) */
   int32_t trans;           /* 0: C = A[M,K] . B[N,K]^T.  1: TN, A is [K, M] and B is [K, N] row-major, C = A^T . B (wgrad straight from
                               dY[t][out], X[t][in]); needs K and the split size % 64 == 0, M % 8 == 0, lda/ldb % 8 == 0 */
   int32_t a_row_group;     /* trans=1 only, > 0: A's k-row t lives at physical row t + t/a_row_group + 1 (token buffer minus cls rows) */
@@ -315,6 +316,8 @@ typedef struct VdkVitConfig {
   int32_t batch, img_size, patch_size, in_chans;
   int32_t dim, depth, heads, mlp_dim, num_classes;
   float ln_eps;
+  int32_t no_class_token;  /* 1: timm class_token=False (SigLIP): N = num_patches tokens, no cls_token parameter; feature mode only (num_classes == 0: pooling + head on top,
+                              visiondk_amd/vit.py AttentionPoolLatent) */
 } VdkVitConfig;
 typedef void (*vdk_grad_ready_fn)(void* user, int64_t offset, int64_t numel);
 
@@ -471,6 +474,13 @@ int vdk_resnet_forward(const VdkResNetConfig* cfg, const float* x, const float* 
 int vdk_resnet_backward(const VdkResNetConfig* cfg, const void* dlogits, const float* params, const void* wb16, const void* wx, void* ws, size_t ws_bytes, float* grads,
                         vdk_grad_ready_fn on_ready, void* user, vdk_stat_sync_fn bn_sync, void* bn_user, void* stream);
 /* bn_sync != NULL: every BatchNorm of the network runs as SyncBatchNorm (pass the same hook to forward and backward) */
+
+/* timm AttentionPoolLatent (global_pool='map', SigLIP): ONE projected latent query q (f32 [H*64]) against the N tokens of every image; kv = bf16 [B*N, ldkv]
+ * output of the kv Linear (k | v halves of H*64 each).  fwd: out f32 [B, ldo] = softmax_n(scale <q_h, k_n>) . v; probs f32 [B, H, N] (optional, for the backward).
+ * bwd: dout f32 [B, lddo] -> dkv bf16 [B*N, lddkv], dq_part f32 [B, H*64] (sum the rows -> dL/dq).  head_dim 64, N <= 4096. */
+int vdk_attn_pool_fwd(const float* q, const void* kv, int64_t ldkv, int32_t B, int32_t N, int32_t H, float scale, float* out, int64_t ldo, float* probs, void* stream);
+int vdk_attn_pool_bwd(const float* q, const void* kv, int64_t ldkv, const float* probs, const float* dout, int64_t lddo, int32_t B, int32_t N, int32_t H, float scale,
+                      void* dkv, int64_t lddkv, float* dq_part, void* stream);
 
 /* F.normalize(W, dim=0): inv[c] = 1/max(||W[:,c]||, eps); Wb = bf16 [3D, ldb]: the normalised weight as split planes
  * (hi, hi, lo) stacked along the contraction dim (rows [0,D) alone are the plain bf16 copy); columns C..Cp-1 zero */

@@ -192,6 +192,63 @@ def train_step_reference_sam(model: nn.Module, x, y, *, lr, momentum, weight_dec
     return loss.detach(), momentum_bufs
 
 
+class AttentionPoolLatentRef(nn.Module):
+    """timm layers/attention_pool.py AttentionPoolLatent as the SigLIP ViTs build it (global_pool='map': latent_len 1, qkv_bias, no qk_norm, pool_type 'token',
+    norm_layer = LayerNorm(eps 1e-6), mlp_ratio 4, exact-erf GELU):
+        q = q(latent) -> [B, H, 1, hd];  k, v = kv(x) -> [B, H, N, hd];  x = softmax(q k^T / sqrt(hd)) v -> [B, 1, D];  x = proj(x);  x = x + mlp(norm(x));  x[:, 0]
+    tests/test_oracle_vit.py pins it against transformers' SiglipMultiheadAttentionPoolingHead (same arithmetic through nn.MultiheadAttention) via a weight map."""
+
+    def __init__(self, dim: int, num_heads: int, mlp_dim: int = None, eps: float = 1e-6):
+        super().__init__()
+        self.num_heads, self.head_dim = num_heads, dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.latent = nn.Parameter(torch.zeros(1, 1, dim))
+        self.q = nn.Linear(dim, dim)
+        self.kv = nn.Linear(dim, 2 * dim)
+        self.proj = nn.Linear(dim, dim)
+        self.norm = nn.LayerNorm(dim, eps=eps)
+        self.mlp = Mlp(dim, mlp_dim or 4 * dim)
+        nn.init.trunc_normal_(self.latent, std=dim ** -0.5)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        q = self.q(self.latent.expand(B, -1, -1)).reshape(B, 1, self.num_heads, self.head_dim).transpose(1, 2)
+        kv = self.kv(x).reshape(B, N, 2, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
+        k, v = kv.unbind(0)
+        a = torch.softmax((q * self.scale) @ k.transpose(-2, -1), dim=-1)
+        x = (a @ v).transpose(1, 2).reshape(B, 1, C)
+        x = self.proj(x)
+        x = x + self.mlp(self.norm(x))
+        return x[:, 0]
+
+
+class SiglipVisionTransformerRef(nn.Module):
+    """timm VisionTransformer(class_token=False, global_pool='map') -- the vit_*_siglip_* family (BASELINE.json configs[4]): no cls token, pos_embed over the
+    patches only, the usual pre-norm blocks, norm, AttentionPoolLatent, head.  state_dict names equal timm's (pos_embed, patch_embed.*, blocks.*, norm.*, attn_pool.*, head.*)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12, num_heads=12, mlp_dim=None, eps=1e-6):
+        super().__init__()
+        mlp_dim = mlp_dim or 4 * embed_dim
+        n = (img_size // patch_size) ** 2
+        self.patch_embed = PatchEmbed(patch_size, in_chans, embed_dim)
+        self.pos_embed = nn.Parameter(torch.randn(1, n, embed_dim) * .02)
+        self.blocks = nn.Sequential(*[Block(embed_dim, num_heads, mlp_dim, eps) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=eps)
+        self.attn_pool = AttentionPoolLatentRef(embed_dim, num_heads, mlp_dim, eps)
+        self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                nn.init.normal_(m.weight, mean=0, std=0.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def forward_features(self, x):
+        return self.norm(self.blocks(self.patch_embed(x) + self.pos_embed))
+
+    def forward(self, x):
+        return self.head(self.attn_pool(self.forward_features(x)))
+
+
 class TimmWrapperRef(nn.Module):
     """Restatement of the reference's TimmWrapper for a transformer backbone (models/faceX/backbone/timm_wrapper.py:16-21,39-54):
     `timm.create_model(name, num_classes=0, global_pool='')` -> forward = final-normed tokens [B, N, C]; neck =

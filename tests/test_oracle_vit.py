@@ -67,3 +67,55 @@ def test_state_dict_keys_are_timm_names():
         assert k in keys
     assert len(keys) == 4 + 12 * 2 + 4
     assert ref.state_dict()["blocks.0.attn.qkv.weight"].shape == (192, 64)
+
+
+def test_siglip_map_pool_ref_matches_transformers():
+    """oracle/vit_ref.SiglipVisionTransformerRef (timm class_token=False + global_pool='map' AttentionPoolLatent) against transformers.SiglipVisionModel:
+    last_hidden_state and pooler_output (nn.MultiheadAttention with the probe as the only query) through the timm <- HF weight map of timm's own converter
+    (in_proj rows [0:D] -> attn_pool.q, [D:3D] -> attn_pool.kv, probe -> latent)."""
+    from transformers import SiglipVisionConfig, SiglipVisionModel
+    from oracle.vit_ref import SiglipVisionTransformerRef
+    torch.manual_seed(0)
+    D, depth, heads, img, ps = 128, 2, 2, 32, 8
+    ref = SiglipVisionTransformerRef(img, ps, 3, 0, D, depth, heads, mlp_dim=2 * D).eval()
+    with torch.no_grad():
+        for p in ref.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    cfg = SiglipVisionConfig(hidden_size=D, intermediate_size=2 * D, num_hidden_layers=depth, num_attention_heads=heads, image_size=img, patch_size=ps,
+                             hidden_act="gelu", layer_norm_eps=1e-6, attention_dropout=0.0)
+    hf = SiglipVisionModel(cfg).eval()
+    sd, hsd = ref.state_dict(), hf.state_dict()
+    pre = "vision_model." if any(k.startswith("vision_model.") for k in hsd) else ""
+
+    def put(name, value):
+        assert hsd[pre + name].shape == value.shape, (name, hsd[pre + name].shape, value.shape)
+        hsd[pre + name] = value.clone()
+
+    put("embeddings.patch_embedding.weight", sd["patch_embed.proj.weight"]); put("embeddings.patch_embedding.bias", sd["patch_embed.proj.bias"])
+    put("embeddings.position_embedding.weight", sd["pos_embed"][0])
+    for i in range(depth):
+        w, b = sd[f"blocks.{i}.attn.qkv.weight"], sd[f"blocks.{i}.attn.qkv.bias"]
+        for j, nm in enumerate(["q_proj", "k_proj", "v_proj"]):
+            put(f"encoder.layers.{i}.self_attn.{nm}.weight", w[j * D:(j + 1) * D]); put(f"encoder.layers.{i}.self_attn.{nm}.bias", b[j * D:(j + 1) * D])
+        for kind in ("weight", "bias"):
+            put(f"encoder.layers.{i}.self_attn.out_proj.{kind}", sd[f"blocks.{i}.attn.proj.{kind}"])
+            put(f"encoder.layers.{i}.layer_norm1.{kind}", sd[f"blocks.{i}.norm1.{kind}"]); put(f"encoder.layers.{i}.layer_norm2.{kind}", sd[f"blocks.{i}.norm2.{kind}"])
+            put(f"encoder.layers.{i}.mlp.fc1.{kind}", sd[f"blocks.{i}.mlp.fc1.{kind}"]); put(f"encoder.layers.{i}.mlp.fc2.{kind}", sd[f"blocks.{i}.mlp.fc2.{kind}"])
+    for kind in ("weight", "bias"):
+        put(f"post_layernorm.{kind}", sd[f"norm.{kind}"])
+        put(f"head.layernorm.{kind}", sd[f"attn_pool.norm.{kind}"])
+        put(f"head.attention.out_proj.{kind}", sd[f"attn_pool.proj.{kind}"])
+        put(f"head.mlp.fc1.{kind}", sd[f"attn_pool.mlp.fc1.{kind}"]); put(f"head.mlp.fc2.{kind}", sd[f"attn_pool.mlp.fc2.{kind}"])
+    put("head.probe", sd["attn_pool.latent"])
+    put("head.attention.in_proj_weight", torch.cat([sd["attn_pool.q.weight"], sd["attn_pool.kv.weight"]], 0))
+    put("head.attention.in_proj_bias", torch.cat([sd["attn_pool.q.bias"], sd["attn_pool.kv.bias"]], 0))
+    hf.load_state_dict(hsd)
+    x = torch.randn(3, 3, img, img)
+    with torch.no_grad():
+        feats = ref.forward_features(x)
+        pooled = ref.attn_pool(feats)
+        out = hf(pixel_values=x)
+    assert ((feats - out.last_hidden_state).norm() / out.last_hidden_state.norm()).item() < 1e-5
+    assert ((pooled - out.pooler_output).norm() / out.pooler_output.norm()).item() < 1e-5
+    assert list(sd.keys())[:3] == ["pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias"] and "attn_pool.latent" in sd and "cls_token" not in sd

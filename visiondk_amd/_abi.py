@@ -32,7 +32,7 @@ class ConvGeom(C.Structure):
 class VitConfig(C.Structure):
     """VdkVitConfig of include/visiondk.h"""
     _fields_ = [("batch", I32), ("img_size", I32), ("patch_size", I32), ("in_chans", I32), ("dim", I32), ("depth", I32),
-                ("heads", I32), ("mlp_dim", I32), ("num_classes", I32), ("ln_eps", F32)]
+                ("heads", I32), ("mlp_dim", I32), ("num_classes", I32), ("ln_eps", F32), ("no_class_token", I32)]
 
 
 class GemmF32Desc(C.Structure):
@@ -120,6 +120,8 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_ohem_mask": (C.c_int, [P, I64, I32, I32, P, I32, F32, I64, P, P, P]),
     "vdk_topk_rows": (C.c_int, [P, I64, I32, I32, I32, P, P, P]),
     # margin-softmax heads
+    "vdk_attn_pool_fwd": (C.c_int, [P, P, I64, I32, I32, I32, F32, P, I64, P, P]),
+    "vdk_attn_pool_bwd": (C.c_int, [P, P, I64, P, P, I64, I32, I32, I32, F32, P, I64, P, P]),
     "vdk_colnorm_fwd": (C.c_int, [P, I64, I32, I32, I32, F32, P, P, I64, I32, P]),
     "vdk_colnorm_bwd": (C.c_int, [P, I64, P, P, I64, I32, I32, P, I64, P]),
     "vdk_rownorm_fwd": (C.c_int, [P, I32, I32, I32, F32, P, P, P, P, I32, P]),

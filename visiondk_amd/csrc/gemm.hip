@@ -785,7 +785,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.c_dtype = d->c_dtype; p.bias = (const float*)d->bias; p.residual = (const float*)d->residual; p.ldr = d->ldr;
-  p.act = d->act; p.aux = (bf16_t*)d->aux; p.ldaux = d->ldaux; p.alpha = d->alpha; p.row_group = d->row_group; p.a_row_group = d->a_row_group;
+  p.act = d->act; p.aux = (bf16_t*)d->aux; p.ldaux = d->ldaux; p.alpha = d->alpha; p.row_group = d->row_group < 0 ? -d->row_group : d->row_group; p.row_shift = d->row_group > 0 ? 1 : 0; p.a_row_group = d->a_row_group;
   p.splitk = splitk; p.slabs = nullptr; p.sk_cnt = nullptr; p.dbg = (unsigned long long*)g_dbg_ptr;
   p.colsum_part = nullptr; p.ocs_part = nullptr;
   p.conv_on = d->conv != nullptr;
@@ -795,7 +795,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   }
   int kps = d->K;
   if (splitk > 1) {
-    if (d->bias || d->residual || d->act != VDK_ACT_NONE || d->row_group > 0) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: split-K excludes fused epilogues");
+    if (d->bias || d->residual || d->act != VDK_ACT_NONE || d->row_group != 0) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: split-K excludes fused epilogues");
     if (d->ldc != d->N) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: split-K needs ldc == N");
     kps = ((d->K + splitk - 1) / splitk + G_BK - 1) / G_BK * G_BK;
     splitk = (d->K + kps - 1) / kps;
@@ -816,7 +816,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   // compile-time epilogue variant (the common ViT forms); anything else takes the run-time-flag path
   int E = E_GENERIC;
   {
-    const bool bias = d->bias != nullptr, res = d->residual != nullptr, f32 = d->c_dtype == VDK_F32, rg = d->row_group > 0;
+    const bool bias = d->bias != nullptr, res = d->residual != nullptr, f32 = d->c_dtype == VDK_F32, rg = d->row_group != 0;
     const bool plain_alpha = d->alpha == 1.0f;
     if (splitk > 1) E = E_SPLITK;
     else if (plain_alpha && !rg && !res && d->act == VDK_ACT_NONE && !f32) E = bias ? E_BIAS : 0;

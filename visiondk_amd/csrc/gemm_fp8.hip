@@ -267,14 +267,14 @@ int vdk_gemm_fp8_nt(const VdkGemmDesc* d, int32_t a_fmt, int32_t b_fmt, const fl
   if (!d || !d->A || !d->B || !d->C) return vdk_fail(VDK_EINVAL, "vdk_gemm_fp8_nt: null pointer");
   if (d->M < 256 || d->N < 256 || d->K <= 0 || (d->K % 128) || (d->N & 7) || (d->lda & 15) || (d->ldb & 15) || (d->ldc & 7))
     return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_fp8_nt: needs M, N >= 256, K % 128 == 0, N % 8 == 0, lda / ldb % 16 == 0");
-  if (d->splitk > 1 || d->trans || d->conv || d->row_group > 0 || d->a_colsum || d->c_colsum) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_fp8_nt: split-K / TN / conv / row remap stay on the bf16 kernels");
+  if (d->splitk > 1 || d->trans || d->conv || d->row_group != 0 || d->a_colsum || d->c_colsum) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_fp8_nt: split-K / TN / conv / row remap stay on the bf16 kernels");
   if (!((a_fmt == 0 || a_fmt == 1) && b_fmt == 0)) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_fp8_nt: formats (e4m3, e4m3) and (e5m2, e4m3)");
   if ((d->act == VDK_ACT_DGELU && !d->aux) || (d->aux && (d->ldaux & 7))) return vdk_fail(VDK_EINVAL, "vdk_gemm_fp8_nt: bad aux");
   Fp8Params q;
   GemmParams& p = q.g;
   p.A = nullptr; p.B = nullptr; p.C = d->C; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.M = d->M; p.N = d->N; p.K = d->K; p.c_dtype = d->c_dtype;
   p.bias = (const float*)d->bias; p.residual = (const float*)d->residual; p.ldr = d->ldr; p.act = d->act; p.aux = (bf16_t*)d->aux; p.ldaux = d->ldaux;
-  p.alpha = d->alpha; p.row_group = 0; p.a_row_group = 0; p.splitk = 1; p.k_per_split = d->K; p.slabs = nullptr; p.colsum_part = nullptr; p.conv_on = 0; p.dbg = nullptr;
+  p.alpha = d->alpha; p.row_group = 0; p.row_shift = 0; p.a_row_group = 0; p.splitk = 1; p.k_per_split = d->K; p.slabs = nullptr; p.colsum_part = nullptr; p.conv_on = 0; p.dbg = nullptr;
   q.A = (const unsigned char*)d->A; q.B = (const unsigned char*)d->B; q.a_scale_inv = a_scale_inv; q.b_scale_inv = b_scale_inv;
   const bool bias = d->bias != nullptr, res = d->residual != nullptr, f32 = d->c_dtype == VDK_F32;
   int E = -1;

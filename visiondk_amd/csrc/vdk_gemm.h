@@ -15,7 +15,8 @@ struct GemmParams {
   int act;
   bf16_t* aux; long ldaux;
   float alpha;
-  int row_group;
+  int row_group;             // > 0: token-row remap period (|VdkGemmDesc.row_group|)
+  int row_shift;             // 1: one cls slot per group is skipped (desc.row_group > 0); 0: rows stay, only the residual row repeats per group (desc.row_group < 0)
   int a_row_group;
   int splitk; int k_per_split;
   float* slabs;              // split-K: [splitk][M][N] partial sums; stream-K: [2 * grid][256 * 256] raw accumulator slabs

@@ -7,8 +7,8 @@
 __device__ __forceinline__ void g_epilogue_store8(const GemmParams& p, long mi, int n, float (&v)[8], int z) {
     // token-row remap (patch embedding -> token buffer): output row skips one cls slot per group and the
     // residual (pos_embed) row repeats per group
-    const long m = p.row_group > 0 ? mi + mi / p.row_group + 1 : mi;
-    const long mr = p.row_group > 0 ? mi % p.row_group + 1 : mi;
+    const long m = p.row_group > 0 ? mi + (mi / p.row_group + 1) * p.row_shift : mi;
+    const long mr = p.row_group > 0 ? mi % p.row_group + p.row_shift : mi;
     if (p.splitk > 1) {  // raw fp32 partials; the reduce kernel finishes the job
       float* dst = p.slabs + ((long)z * p.M + mi) * p.N + n;
       *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
@@ -82,8 +82,8 @@ __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float
   for (int ps = 0; ps < 8; ++ps) {
     const long mi = mbase + ps * 8 + rsub;
     ok[ps] = mi < p.M;
-    mo[ps] = (E & E_ROWGRP) ? mi + mi / p.row_group + 1 : mi;
-    mr[ps] = (E & E_ROWGRP) ? mi % p.row_group + 1 : mi;
+    mo[ps] = (E & E_ROWGRP) ? mi + (mi / p.row_group + 1) * p.row_shift : mi;
+    mr[ps] = (E & E_ROWGRP) ? mi % p.row_group + p.row_shift : mi;
   }
   f32x4 r0[8], r1[8];
   u32x4 ux[8];

@@ -43,7 +43,7 @@ int vdk_patchify_f32(const float*, int32_t, int32_t, int32_t, int32_t, int32_t, 
 static inline int64_t up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 struct VitDims {
-  int B, img, ps, Cin, D, L, H, M, C, Cp, np, N, T, Kraw, Kpe, Tp, Bp;   // Kraw = in_chans * patch^2, Kpe = Kraw padded to 8 (patch 14: 588 -> 592)
+  int B, img, ps, Cin, D, L, H, M, C, Cp, np, N, T, Kraw, Kpe, Tp, Bp, cls;   // cls: 1 = class token in row 0 of every image's token block   // Kraw = in_chans * patch^2, Kpe = Kraw padded to 8 (patch 14: 588 -> 592)
   float eps;
 };
 static int vit_dims(const VdkVitConfig* c, VitDims* d) {
@@ -57,7 +57,9 @@ static int vit_dims(const VdkVitConfig* c, VitDims* d) {
   d->Kraw = d->Cin * d->ps * d->ps;
   d->Kpe = (int)up(d->Kraw, 8);     // patch 14 (timm vit_*_patch14_*: K = 588): the GEMM operands are zero-padded copies, the parameter itself stays [D, Kraw]
   d->np = (d->img / d->ps) * (d->img / d->ps);
-  d->N = d->np + 1;
+  d->cls = c->no_class_token ? 0 : 1;
+  if (!d->cls && d->C > 0) return vdk_fail(VDK_EUNSUPPORTED, "vit: no_class_token is feature mode only (num_classes == 0)");
+  d->N = d->np + d->cls;
   d->T = d->B * d->N;
   d->Cp = (int)up(d->C, 8);
   d->Tp = (int)up(d->T, 64);
@@ -80,7 +82,7 @@ static int64_t p_take(int64_t& cur, int64_t n) { int64_t o = cur; cur = up(cur +
 static int vit_layout(const VitDims& d, PLayout* p) {
   if (d.L > 64) return vdk_fail(VDK_EUNSUPPORTED, "vit: depth > 64");
   int64_t cur = 0;
-  p->cls = p_take(cur, d.D);
+  p->cls = d.cls ? p_take(cur, d.D) : 0;
   p->pos = p_take(cur, (int64_t)d.N * d.D);
   p->pe_w = p_take(cur, (int64_t)d.D * d.Kraw);
   p->pe_b = p_take(cur, d.D);
@@ -122,6 +124,7 @@ static void pe_set(PEntry* e, const char* name, int64_t off, int ndim, int64_t s
 // follow in memory and must stay zero).
 static int vit_entry(const VitDims& d, const PLayout& p, int idx, PEntry* e) {
   const int per = 12, ntens = 4 + per * d.L + (d.C > 0 ? 4 : 2);   // feature mode (num_classes = 0) has no head
+  if (!d.cls) { if (idx < 0) return -1; ++idx; }                    // class_token=False: the state dict starts at pos_embed
   if (idx < 0 || idx >= ntens) return -1;
   char nm[64];
   if (idx == 0) { pe_set(e, "cls_token", p.cls, 3, 1, 1, d.D); return 0; }
@@ -284,7 +287,7 @@ int vdk_vit_param_count(const VdkVitConfig* cfg, int64_t* n_floats, int32_t* n_t
   VitDims d; RC(vit_dims(cfg, &d));
   PLayout p; RC(vit_layout(d, &p));
   if (n_floats) *n_floats = p.total;
-  if (n_tensors) *n_tensors = 4 + 12 * d.L + (d.C > 0 ? 4 : 2);
+  if (n_tensors) *n_tensors = 3 + d.cls + 12 * d.L + (d.C > 0 ? 4 : 2);
   if (n_transposed) *n_transposed = p.totalT;
   return VDK_OK;
 }
@@ -357,8 +360,8 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
     pew = (const bf16_t*)(base + w.pepad);
   }
   RC(gemm(s, patches, d.Kpe, pew, d.Kpe, X, D, d.B * d.np, D, d.Kpe, VDK_F32, params + p.pe_b, params + p.pos, D, VDK_ACT_NONE,
-          nullptr, 0, 1, d.np, nullptr, 0));
-  RC(vdk_cls_rows(X, (int64_t)d.N * D, d.B, D, params + p.cls, params + p.pos, s));
+          nullptr, 0, 1, d.cls ? d.np : -d.np, nullptr, 0));
+  if (d.cls) RC(vdk_cls_rows(X, (int64_t)d.N * D, d.B, D, params + p.cls, params + p.pos, s));
 
   const float scale = 0.125f;  // head_dim ** -0.5, head_dim == 64
   for (int l = 0; l < d.L; ++l) {
@@ -593,15 +596,15 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
     float* dposall = (float*)(base + w.dposall);
     // d pos_embed[n] = sum_b dx0[b, n];  d cls = d pos_embed[0];  d patch bias = sum_{n >= 1} d pos_embed[n]
     RC(vdk_reduce_rows_f32(dxa, (int64_t)d.N * D, d.B, (int64_t)d.N * D, grads + p.pos, 1.0f, s));
-    if (hipMemcpyAsync(grads + p.cls, grads + p.pos, (size_t)D * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    if (d.cls && hipMemcpyAsync(grads + p.cls, grads + p.pos, (size_t)D * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
       return vdk_fail(VDK_ELAUNCH, "vdk_vit_backward: memcpy failed");
-    RC(vdk_reduce_rows_f32(grads + p.pos + D, D, d.np, D, grads + p.pe_b, 1.0f, s));
+    RC(vdk_reduce_rows_f32(grads + p.pos + (size_t)d.cls * D, D, d.np, D, grads + p.pe_b, 1.0f, s));
     (void)dposall;
     bf16_t* patches = (bf16_t*)(base + w.patches);
     const int rows = d.B * d.np, rows_pad = (int)up(rows, 64);
     RC(ev_order(ev_p++, s, s2));
     float* dwpe = d.Kraw != d.Kpe ? (float*)(base + w.dwpe) : grads + p.pe_w;
-    RC(linear_wgrad(s2, d, w, base, DXAB(-1), D, patches, d.Kpe, rows, rows_pad, D, d.Kpe, dwpe, nullptr, d.np));
+    RC(linear_wgrad(s2, d, w, base, DXAB(-1), D, patches, d.Kpe, rows, rows_pad, D, d.Kpe, dwpe, nullptr, d.cls ? d.np : 0));
     if (d.Kraw != d.Kpe && hipMemcpy2DAsync(grads + p.pe_w, (size_t)d.Kraw * 4, dwpe, (size_t)d.Kpe * 4, (size_t)d.Kraw * 4, D, hipMemcpyDeviceToDevice, s2) != hipSuccess)
       return vdk_fail(VDK_ELAUNCH, "vdk_vit_backward: memcpy2d failed");   // drop the padding columns
     RC(ev_order(ev_p++, s2, s));      // join: everything the side stream produced is ordered before what follows on the main stream
@@ -671,13 +674,13 @@ int vdk_vit_forward_f32(const VdkVitConfig* cfg, const float* x, const float* pa
   RC(vdk_patchify_f32(x, d.B, d.Cin, d.img, d.img, d.ps, patches, s));
   {
     VdkGemmF32Desc g = {};
-    g.A = patches; g.lda = d.Kpe; g.B = params + p.pe_w; g.ldb = d.Kpe; g.C = xa + D; g.ldc = D; g.M = d.np; g.N = D; g.K = d.Kpe;
-    g.bias = params + p.pe_b; g.residual = params + p.pos + D; g.ldr = D; g.alpha = 1.0f;
+    g.A = patches; g.lda = d.Kpe; g.B = params + p.pe_w; g.ldb = d.Kpe; g.C = xa + (size_t)d.cls * D; g.ldc = D; g.M = d.np; g.N = D; g.K = d.Kpe;
+    g.bias = params + p.pe_b; g.residual = params + p.pos + (size_t)d.cls * D; g.ldr = D; g.alpha = 1.0f;
     g.batch1 = d.B; g.batch2 = 1; g.sa1 = (int64_t)d.np * d.Kpe; g.sc1 = (int64_t)N * D;
     if (d.B > 65535) return vdk_fail(VDK_EUNSUPPORTED, "vdk_vit_forward_f32: batch <= 65535");
     RC(vdk_gemm_f32_nt(&g, s));
   }
-  RC(vdk_cls_rows(xa, (int64_t)N * D, d.B, D, params + p.cls, params + p.pos, s));
+  if (d.cls) RC(vdk_cls_rows(xa, (int64_t)N * D, d.B, D, params + p.cls, params + p.pos, s));
   for (int l = 0; l < d.L; ++l) {
     const PLayout::Blk& b = p.blk[l];
     RC(vdk_layernorm_fwd(xa, D, T, D, params + b.n1w, params + b.n1b, d.eps, h, D, VDK_F32, nullptr, nullptr, s));

@@ -13,6 +13,7 @@ Three layers, thinnest first:
 from __future__ import annotations
 
 import ctypes as C
+import dataclasses
 import math
 from dataclasses import dataclass
 from typing import Callable, Optional
@@ -20,7 +21,7 @@ from typing import Callable, Optional
 import torch
 import torch.nn as nn
 
-from . import _abi, _lib
+from . import _abi, _lib, ops
 
 
 @dataclass(frozen=True)
@@ -34,6 +35,7 @@ class VitSpec:
     heads: int = 12
     mlp_dim: int = 3072
     ln_eps: float = 1e-6
+    class_token: bool = True      # timm class_token=False (the SigLIP ViTs): tokens are the patches only; feature mode (num_classes=0) in the engine
 
 
 # timm 0.9.16 model ids the engine covers (head_dim 64; patch 14 works through zero-padded operand copies of the patch-embedding weight)
@@ -45,6 +47,10 @@ TIMM_VITS = {
     "vit_large_patch16_224": dict(dim=1024, depth=24, heads=16, mlp_dim=4096),
     "vit_base_patch16_384": dict(dim=768, depth=12, heads=12, mlp_dim=3072, img_size=384),
     "vit_large_patch14_224": dict(dim=1024, depth=24, heads=16, mlp_dim=4096, patch_size=14),
+    # class_token=False + global_pool='map' (SigLIP): served by VisionTransformerMap
+    "vit_base_patch16_siglip_224": dict(dim=768, depth=12, heads=12, mlp_dim=3072, class_token=False),
+    "vit_large_patch16_siglip_256": dict(dim=1024, depth=24, heads=16, mlp_dim=4096, img_size=256, class_token=False),
+    "vit_large_patch14_siglip_336": dict(dim=1024, depth=24, heads=16, mlp_dim=4096, patch_size=14, img_size=336, class_token=False),   # BASELINE.json configs[4]'s geometry
 }
 
 
@@ -80,7 +86,7 @@ class VitEngine:
         self.wb16 = torch.zeros(self.n_floats, dtype=torch.bfloat16, device=dev)
         self.wt16 = torch.zeros(self.n_transposed, dtype=torch.bfloat16, device=dev)
         self.cp = (spec.num_classes + 7) // 8 * 8          # 0 in feature mode (num_classes == 0)
-        self.tokens = (spec.img_size // spec.patch_size) ** 2 + 1
+        self.tokens = (spec.img_size // spec.patch_size) ** 2 + (1 if spec.class_token else 0)
         self._ws: Optional[torch.Tensor] = None
         self._ws_batch = -1
         self._logits: Optional[torch.Tensor] = None
@@ -106,7 +112,7 @@ class VitEngine:
     # ---- plumbing ------------------------------------------------------------------------------
     def _cfg(self, batch: int) -> _abi.VitConfig:
         s = self.spec
-        return _abi.VitConfig(batch, s.img_size, s.patch_size, s.in_chans, s.dim, s.depth, s.heads, s.mlp_dim, s.num_classes, s.ln_eps)
+        return _abi.VitConfig(batch, s.img_size, s.patch_size, s.in_chans, s.dim, s.depth, s.heads, s.mlp_dim, s.num_classes, s.ln_eps, 0 if s.class_token else 1)
 
     def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
         for n, off, numel, shape in self.entries:
@@ -328,15 +334,188 @@ class VisionTransformer(nn.Module):
         return out[:, :eng.spec.num_classes]
 
 
+# ---- global_pool='map': timm AttentionPoolLatent on the HIP kernels ----------------------------------------------------------------------
+def _gelu(u):
+    return 0.5 * u * (1.0 + torch.erf(u * 0.7071067811865476))
+
+
+def _gelu_grad(u):
+    return 0.5 * (1.0 + torch.erf(u * 0.7071067811865476)) + u * torch.exp(-0.5 * u * u) * 0.3989422804014327
+
+
+def _pad4(t: torch.Tensor) -> torch.Tensor:
+    """zero-pad the contraction (last) dim to a multiple of 4 (16-byte rows for the fp32 GEMM)"""
+    k = t.shape[-1]
+    return t.contiguous() if k % 4 == 0 else torch.nn.functional.pad(t, (0, 4 - k % 4)).contiguous()
+
+
+def _wgrad_f32(dy: torch.Tensor, x: torch.Tensor, be) -> torch.Tensor:
+    """dW [out, in] = dy^T x for [rows, out] / [rows, in] fp32 operands with few rows (the pooled [B, D] tail): fp32 MFMA GEMM over the transposed operands"""
+    return ops.gemm_f32(_pad4(dy.t()), _pad4(x.t()), backend=be)
+
+
+class _AttnPoolFn(torch.autograd.Function):
+    """AttentionPoolLatent.forward as one autograd node: the kv Linear over all tokens on the bf16 MFMA GEMM (the only part with real work: 2 T D^2 MACs), the
+    one-query attention in csrc/attn_pool.hip, the [B, D]-sized tail (proj, LayerNorm, MLP) on the fp32 MFMA GEMM; the backward mirrors it (TN weight gradient
+    straight from dkv / tokens)."""
+
+    @staticmethod
+    def forward(ctx, tokens, latent, q_w, q_b, kv_w, kv_b, proj_w, proj_b, n_w, n_b, fc1_w, fc1_b, fc2_w, fc2_b, mod):
+        be = mod.be
+        B, N, D = tokens.shape
+        H = mod.num_heads
+        dev = tokens.device
+        tok = tokens.detach().contiguous().view(B * N, D)
+        tb = ops.cast_bf16(tok, backend=be)
+        kv = ops.gemm_nt(tb, ops.cast_bf16(kv_w.detach().contiguous(), backend=be), bias=kv_b.detach(), backend=be)          # bf16 [T, 2D]
+        q = ops.gemm_f32(latent.detach().reshape(1, D).contiguous(), q_w.detach(), bias=q_b.detach(), backend=be).view(D)
+        pooled = torch.empty((B, D), dtype=torch.float32, device=dev)
+        probs = torch.empty((B, H, N), dtype=torch.float32, device=dev)
+        be.check(be.lib.vdk_attn_pool_fwd(be.ptr(q), be.ptr(kv), 2 * D, B, N, H, mod.scale, be.ptr(pooled), D, be.ptr(probs), be.stream()), "vdk_attn_pool_fwd")
+        y1 = ops.gemm_f32(pooled, proj_w.detach(), bias=proj_b.detach(), backend=be)
+        h, mean, rstd = ops.layernorm_fwd(y1, n_w.detach(), n_b.detach(), eps=mod.eps, out_dtype=torch.float32, backend=be)
+        u = ops.gemm_f32(h, fc1_w.detach(), bias=fc1_b.detach(), backend=be)
+        g = _gelu(u)
+        out = ops.gemm_f32(g, fc2_w.detach(), bias=fc2_b.detach(), residual=y1, backend=be)
+        ctx.save_for_backward(tb, kv, q, probs, pooled, y1, h, mean, rstd, u, g, latent, q_w, kv_w, proj_w, n_w, fc1_w, fc2_w)
+        ctx.mod, ctx.dims = mod, (B, N, D, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        tb, kv, q, probs, pooled, y1, h, mean, rstd, u, g, latent, q_w, kv_w, proj_w, n_w, fc1_w, fc2_w = ctx.saved_tensors
+        mod = ctx.mod
+        be = mod.be
+        B, N, D, H = ctx.dims
+        dev = dout.device
+        dout = dout.contiguous().float()
+        f32 = lambda a, b, **k: ops.gemm_f32(a, b.detach(), backend=be, **k)
+        dg = f32(dout, fc2_w, b_kmajor=True)                               # [B, Dm] = dout . W2
+        dfc2_w, dfc2_b = _wgrad_f32(dout, g, be), dout.sum(0)
+        du = dg * _gelu_grad(u)
+        dfc1_w, dfc1_b = _wgrad_f32(du, h, be), du.sum(0)
+        dh = f32(du, fc1_w, b_kmajor=True)
+        dy1, _, dn_w, dn_b = ops.layernorm_bwd(dh, y1, mean, rstd, n_w.detach(), dres=dout, want_bf16=False, backend=be)   # + the skip connection
+        dproj_w, dproj_b = _wgrad_f32(dy1, pooled, be), dy1.sum(0)
+        dpooled = f32(dy1, proj_w, b_kmajor=True)
+        dkv = torch.empty((B * N, 2 * D), dtype=torch.bfloat16, device=dev)
+        dq_part = torch.empty((B, D), dtype=torch.float32, device=dev)
+        be.check(be.lib.vdk_attn_pool_bwd(be.ptr(q), be.ptr(kv), 2 * D, be.ptr(probs), be.ptr(dpooled), D, B, N, H, mod.scale, be.ptr(dkv), 2 * D, be.ptr(dq_part),
+                                          be.stream()), "vdk_attn_pool_bwd")
+        dq = ops.reduce_rows(dq_part, backend=be)                          # [D]
+        lat = latent.detach().reshape(1, D)
+        dq_w, dq_b = dq.view(D, 1) * lat, dq
+        dlatent = f32(dq.view(1, D).contiguous(), q_w, b_kmajor=True).view(latent.shape)
+        T = B * N
+        if T % 64 == 0:
+            dkv_w = ops.gemm_nt(dkv, tb, out_dtype=torch.float32, trans=True, backend=be)                    # [2D, D] = dkv^T tokens, operands as they lie
+        else:
+            Tp = (T + 63) // 64 * 64
+            dkv_w = ops.gemm_nt(ops.transpose_pad(dkv, rpad=Tp, backend=be), ops.transpose_pad(tb, rpad=Tp, backend=be), out_dtype=torch.float32, backend=be)
+        dkv_b = ops.colsum_bf16(dkv, backend=be)
+        dtok = ops.gemm_nt(dkv, ops.transpose_cast(kv_w.detach().contiguous(), backend=be), out_dtype=torch.float32, backend=be)   # [T, D] = dkv . Wkv
+        return (dtok.view(B, N, D), dlatent, dq_w, dq_b, dkv_w, dkv_b, dproj_w, dproj_b, dn_w, dn_b, dfc1_w, dfc1_b, dfc2_w, dfc2_b, None)
+
+
+class AttentionPoolLatent(nn.Module):
+    """timm.layers.AttentionPoolLatent as the SigLIP ViTs configure it (latent_len 1, qkv_bias, no qk_norm, LayerNorm eps 1e-6, mlp_ratio 4, exact GELU, pool 'token');
+    parameter names equal timm's (latent, q, kv, proj, norm, mlp.fc1, mlp.fc2).  head_dim 64."""
+
+    def __init__(self, dim: int, num_heads: int, mlp_dim: Optional[int] = None, eps: float = 1e-6, backend: Optional[_lib.Backend] = None, device=None):
+        super().__init__()
+        assert dim == num_heads * 64, "head_dim must be 64"
+        self.be = backend or _lib.load()
+        dev = device if device is not None else ("cuda" if self.be.device_only else "cpu")
+        self.num_heads, self.scale, self.eps = num_heads, 0.125, eps
+        mlp_dim = mlp_dim or 4 * dim
+        self.latent = nn.Parameter(torch.empty(1, 1, dim, device=dev))
+        self.q, self.kv, self.proj = _Holder(), _Holder(), _Holder()
+        self.norm, self.mlp = _Holder(), _Holder()
+        self.mlp.fc1, self.mlp.fc2 = _Holder(), _Holder()
+        for holder, shape in ((self.q, (dim, dim)), (self.kv, (2 * dim, dim)), (self.proj, (dim, dim)), (self.mlp.fc1, (mlp_dim, dim)), (self.mlp.fc2, (dim, mlp_dim))):
+            holder.weight = nn.Parameter(torch.empty(shape, device=dev)); holder.bias = nn.Parameter(torch.zeros(shape[0], device=dev))
+        self.norm.weight = nn.Parameter(torch.ones(dim, device=dev)); self.norm.bias = nn.Parameter(torch.zeros(dim, device=dev))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        with torch.no_grad():
+            D = self.latent.shape[-1]
+            self.latent.copy_(torch.empty(1, 1, D).normal_(0, D ** -0.5).clamp_(-2 * D ** -0.5, 2 * D ** -0.5).to(self.latent.device))
+            for h in (self.q, self.kv, self.proj, self.mlp.fc1, self.mlp.fc2):     # the reference's reset_parameters override: N(0, .02) Linear weights, zero biases
+                h.weight.copy_(torch.empty(h.weight.shape).normal_(0, 0.02).to(h.weight.device)); h.bias.zero_()
+
+    def forward(self, tokens: torch.Tensor) -> torch.Tensor:
+        return _AttnPoolFn.apply(tokens, self.latent, self.q.weight, self.q.bias, self.kv.weight, self.kv.bias, self.proj.weight, self.proj.bias, self.norm.weight,
+                                 self.norm.bias, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, self)
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the fp32 MFMA GEMM (the classifier head on pooled [B, D] rows)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, be):
+        ctx.save_for_backward(x, w); ctx.be = be
+        return ops.gemm_f32(x.contiguous(), w.detach(), bias=b.detach(), backend=be)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        Cn = dy.shape[1]
+        if Cn % 4:      # class counts that are not multiples of 4: zero columns / rows keep the contraction 16-byte aligned
+            dx = ops.gemm_f32(_pad4(dy), torch.nn.functional.pad(w.detach(), (0, 0, 0, 4 - Cn % 4)).contiguous(), b_kmajor=True, backend=ctx.be)
+        else:
+            dx = ops.gemm_f32(dy, w.detach(), b_kmajor=True, backend=ctx.be)
+        return dx, _wgrad_f32(dy, x, ctx.be), dy.sum(0), None
+
+
+class VisionTransformerMap(nn.Module):
+    """timm VisionTransformer(class_token=False, global_pool='map', num_classes=C): the vit_*_siglip_* family (BASELINE.json configs[4]).  The trunk is the native
+    engine in feature mode without a class token; attn_pool and head run as autograd nodes over the same kernels.  state_dict names equal timm's."""
+
+    def __init__(self, spec: VitSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None):
+        super().__init__()
+        import dataclasses
+        self.spec = spec
+        self.num_classes = spec.num_classes
+        trunk = VisionTransformer(dataclasses.replace(spec, num_classes=0, class_token=False), device=device, backend=backend, seed=seed)
+        self.engine = trunk.engine
+        self._trunk = [trunk]                 # not a registered submodule: its parameters are re-registered below under timm's flat names
+        for name, child in trunk._modules.items():
+            self.add_module(name, child)
+        for name, p in trunk._parameters.items():
+            self.register_parameter(name, p)
+        be = trunk.engine.be
+        dev = trunk.engine.device
+        self.attn_pool = AttentionPoolLatent(spec.dim, spec.heads, spec.mlp_dim, spec.ln_eps, backend=be, device=dev)
+        self.head = _Holder()
+        if spec.num_classes > 0:
+            self.head.weight = nn.Parameter(torch.empty(spec.num_classes, spec.dim, device=dev).normal_(0, 0.02)); self.head.bias = nn.Parameter(torch.zeros(spec.num_classes, device=dev))
+
+    def forward_features(self, x: torch.Tensor) -> torch.Tensor:
+        return self._trunk[0](x)              # [B, N, D], final-normed
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        pooled = self.attn_pool(self.forward_features(x))
+        if self.num_classes == 0:
+            return pooled
+        return _LinearFn.apply(pooled, self.head.weight, self.head.bias, self.engine.be)
+
+
 def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, device=None, backend=None, img_size=None,
                  global_pool: str = "token", **kwargs) -> VisionTransformer:
     """`timm.create_model(name, pretrained=..., num_classes=...)` for the ids in TIMM_VITS.  `num_classes=0, global_pool=''`
     (what TimmWrapper asks for, timm_wrapper.py:16-21) gives the feature model: forward -> final-normed tokens [B, N, D]."""
-    if num_classes == 0 and global_pool != "":
-        raise NotImplementedError("num_classes=0 is supported with global_pool='' (token features) only")
     if pretrained:
         raise RuntimeError("pretrained weights need network access; load a checkpoint with load_state_dict instead")
-    return VisionTransformer(spec_from_timm_name(name, num_classes, img_size), device=device, backend=backend)
+    spec = spec_from_timm_name(name, num_classes, img_size)
+    if not spec.class_token:      # the SigLIP family: attention-pool head (timm's default global_pool for these ids is 'map'); global_pool='' -> token features
+        if global_pool == "":
+            return VisionTransformer(dataclasses.replace(spec, num_classes=0), device=device, backend=backend)
+        return VisionTransformerMap(spec, device=device, backend=backend)
+    if num_classes == 0 and global_pool != "":
+        raise NotImplementedError("num_classes=0 is supported with global_pool='' (token features) only")
+    return VisionTransformer(spec, device=device, backend=backend)
 
 
 # =====================================================================================================
@@ -442,3 +621,98 @@ class FusedTrainStep:
     def loss_value(self) -> float:
         """mean loss of the last step (this is the only device->host sync; the reference does it every step, train.py:122)."""
         return float(self._loss_rows.mean().item())
+
+
+class MapTrainStep:
+    """FusedTrainStep for VisionTransformerMap (class_token=False + attention-pool head): the same Trainer.compute_loss / update / update_sam sequence
+    (train.py:150-215) over ONE flat fp32 buffer that holds the engine's parameters followed by the attn_pool / head parameters, so the gradient norm, SAM's
+    e(w), the clipped SGD step and the EMA are single kernels over everything.  The trunk runs through the engine's forward / backward directly (no autograd
+    copies of 300 M gradients); only the pooled [B, D] tail goes through autograd nodes.  Single process (no gradient exchange hooks yet)."""
+
+    def __init__(self, model: VisionTransformerMap, lr: float, momentum: float = 0.937, weight_decay: float = 5e-4, label_smoothing: float = 0.0,
+                 max_norm: float = 10.0, ema: bool = True, sam: bool = False, sam_rho: float = 0.05, sam_adaptive: bool = True):
+        self.model, self.eng = model, model.engine
+        eng = self.eng
+        self.be = eng.be
+        dev = eng.device
+        trunk = model._trunk[0]
+        trunk._sync_flat()
+        self.extras = [p for p in model.attn_pool.parameters()] + [p for p in model.head.parameters()]
+        n = eng.n_floats
+        offs, cur = [], n
+        for p in self.extras:
+            offs.append(cur); cur += (p.numel() + 63) // 64 * 64
+        self.n_total = cur
+        big = torch.zeros(cur, dtype=torch.float32, device=dev)
+        big[:n].copy_(eng.params)
+        eng.params = big[:n]
+        for (name, off, numel, shape), (_, p) in zip(eng.entries, trunk._plist):
+            p.data = eng.params[off:off + numel].view(shape)
+        self.gbig = torch.zeros(cur, dtype=torch.float32, device=dev)
+        eng.grads = self.gbig[:n]
+        for p, off in zip(self.extras, offs):
+            big[off:off + p.numel()].copy_(p.detach().reshape(-1))
+            p.data = big[off:off + p.numel()].view(p.shape)
+            p.grad = self.gbig[off:off + p.numel()].view(p.shape)          # autograd accumulates in place into the flat gradient buffer
+        eng._weights_version = None
+        self.big = big
+        self.param_groups = [{"lr": lr, "momentum": momentum, "weight_decay": weight_decay}]
+        self.label_smoothing, self.max_norm = label_smoothing, max_norm
+        self.momentum_buf = torch.zeros_like(big)
+        self.ema = big.clone() if ema else None
+        self.sam, self.sam_rho, self.sam_adaptive = sam, sam_rho, sam_adaptive
+        self._old = torch.empty_like(big) if sam else None
+        self._normsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        need = C.c_size_t(0)
+        self.be.check(self.be.lib.vdk_sumsq_workspace_bytes(C.byref(need)), "vdk_sumsq_workspace_bytes")
+        self._sumsq_ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        self.updates = 0
+        self._loss_rows = None
+
+    def _fwd_loss_bwd(self, x, y, y_b, lam):
+        eng, m = self.eng, self.model
+        B = x.shape[0]
+        self.gbig[eng.n_floats:].zero_()
+        tokens = eng.forward(x).view(B, eng.tokens, eng.spec.dim).detach().requires_grad_(True)
+        pooled = m.attn_pool(tokens)
+        logits = _LinearFn.apply(pooled, m.head.weight, m.head.bias, self.be)
+        self._loss_rows, _, dlf = ops.softmax_ce(logits.detach().contiguous(), y, y_b, lam, self.label_smoothing, 1.0 / B, backend=self.be)
+        logits.backward(dlf)
+        eng.backward(tokens.grad.contiguous().view(-1, eng.spec.dim))
+
+    def step(self, x: torch.Tensor, y: torch.Tensor, y_b: Optional[torch.Tensor] = None, lam: float = 1.0) -> torch.Tensor:
+        eng, be, n = self.eng, self.be, self.eng.n_floats
+        g0 = self.param_groups[0]
+        lr, momentum, weight_decay = g0["lr"], g0["momentum"], g0["weight_decay"]
+        self.updates += 1
+        d = 0.9999 * (1 - math.exp(-self.updates / 2000)) if self.ema is not None else 0.0
+        first = int(self.updates == 1)
+        nx = self.n_total - n
+
+        def sgd(normsq):
+            be.check(be.lib.vdk_sgd_step(be.ptr(self.big), be.ptr(self.gbig), be.ptr(self.momentum_buf), be.ptr(self.ema), be.ptr(eng.wb16), n, lr, momentum,
+                                         weight_decay, 1.0, normsq, self.max_norm, d, first, be.stream()), "vdk_sgd_step")
+            ex = lambda t: be.ptr(t[n:]) if t is not None else None
+            be.check(be.lib.vdk_sgd_step(ex(self.big), ex(self.gbig), ex(self.momentum_buf), ex(self.ema), None, nx, lr, momentum, weight_decay, 1.0, normsq,
+                                         self.max_norm, d, first, be.stream()), "vdk_sgd_step")
+            eng.refresh_weights(skip_wb16=True)
+
+        if self.sam:
+            self._fwd_loss_bwd(x, y, y_b, lam)
+            loss_first = self._loss_rows.clone()
+            be.check(be.lib.vdk_sam_first_step(be.ptr(self.big), be.ptr(self.gbig), be.ptr(self._old), self.n_total, self.sam_rho, int(self.sam_adaptive),
+                                               be.ptr(self._normsq), be.ptr(self._sumsq_ws), self._sumsq_ws.numel(), be.stream()), "vdk_sam_first_step")
+            eng.refresh_weights()
+            self._fwd_loss_bwd(x, y, y_b, lam)
+            self.big.copy_(self._old)
+            sgd(None)
+            self._loss_rows = loss_first
+            return self._loss_rows
+        self._fwd_loss_bwd(x, y, y_b, lam)
+        be.check(be.lib.vdk_sumsq_f32(be.ptr(self.gbig), self.n_total, be.ptr(self._normsq), be.ptr(self._sumsq_ws), self._sumsq_ws.numel(), be.stream()), "vdk_sumsq_f32")
+        sgd(be.ptr(self._normsq))
+        return self._loss_rows
+
+    def loss_value(self) -> float:
+        return float(self._loss_rows.mean().item())
+
