@@ -318,6 +318,13 @@ typedef struct VdkVitConfig {
   float ln_eps;
   int32_t no_class_token;  /* 1: timm class_token=False (SigLIP): N = num_patches tokens, no cls_token parameter; feature mode only (num_classes == 0: pooling + head on top,
                               visiondk_amd/vit.py AttentionPoolLatent) */
+  int32_t fp8;             /* BASELINE.json configs[4] "fp8 MFMA": 0 = bf16 operands; 1 = the four Linears of every block run their forward and input-gradient GEMMs on OCP fp8
+                              operands (e4m3 activations / weights, e5m2 gradients, per-tensor DELAYED scaling: this step's scale comes from the last step's amax);
+                              2 = the same with CURRENT scaling (an amax pass in front of every quantisation: calibration steps).  Weight gradients stay bf16 TN GEMMs. */
+  void* fp8_w;             /* fp8 != 0: e4m3 operand copies, n_floats bytes in the parameter layout followed by n_transposed bytes in the wt16 layout (vdk_vit_refresh_weights) */
+  float* fp8_state;        /* fp8 != 0: f32 [3][12 * depth]: amax | scale | 1 / scale; slot 12 l + k, k = 0..3 h1, attn out, h2, gelu out (e4m3), 4..7 qkv / proj / fc1 / fc2
+                              weights (e4m3), 8..11 dL/d(fc2 out), dL/du, dL/d(proj out), dL/dqkv (e5m2).  Initialise scale = 1/scale = 1, amax = 0; call vdk_vit_fp8_update
+                              after every backward. */
 } VdkVitConfig;
 typedef void (*vdk_grad_ready_fn)(void* user, int64_t offset, int64_t numel);
 
@@ -327,6 +334,8 @@ int vdk_vit_param_count(const VdkVitConfig* cfg, int64_t* n_floats, int32_t* n_t
 int vdk_vit_param_info(const VdkVitConfig* cfg, int32_t index, char* name, int32_t name_cap, int64_t* offset, int64_t* numel,
                        int64_t* shape4, int32_t* ndim);
 int vdk_vit_workspace_bytes(const VdkVitConfig* cfg, size_t* bytes);
+/* delayed scaling bookkeeping of the fp8 mode: scale = fmt_max / amax for every slot with amax > 0, amax := 0 */
+int vdk_vit_fp8_update(const VdkVitConfig* cfg, void* stream);
 int vdk_vit_refresh_weights(const VdkVitConfig* cfg, const float* params, void* wb16, void* wt16, int32_t skip_wb16, void* stream);
 /* x f32 [B, in_chans, img, img] -> logits f32 [B, Cp], Cp = num_classes rounded up to 8 */
 int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params, const void* wb16, void* ws, size_t ws_bytes,

@@ -32,7 +32,7 @@ class ConvGeom(C.Structure):
 class VitConfig(C.Structure):
     """VdkVitConfig of include/visiondk.h"""
     _fields_ = [("batch", I32), ("img_size", I32), ("patch_size", I32), ("in_chans", I32), ("dim", I32), ("depth", I32),
-                ("heads", I32), ("mlp_dim", I32), ("num_classes", I32), ("ln_eps", F32), ("no_class_token", I32)]
+                ("heads", I32), ("mlp_dim", I32), ("num_classes", I32), ("ln_eps", F32), ("no_class_token", I32), ("fp8", I32), ("fp8_w", P), ("fp8_state", P)]
 
 
 class GemmF32Desc(C.Structure):
@@ -148,6 +148,7 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_vit_param_count": (C.c_int, [C.POINTER(VitConfig), C.POINTER(I64), C.POINTER(I32), C.POINTER(I64)]),
     "vdk_vit_param_info": (C.c_int, [C.POINTER(VitConfig), I32, C.c_char_p, I32, C.POINTER(I64), C.POINTER(I64),
                                      C.POINTER(I64), C.POINTER(I32)]),
+    "vdk_vit_fp8_update": (C.c_int, [C.POINTER(VitConfig), P]),
     "vdk_vit_workspace_bytes": (C.c_int, [C.POINTER(VitConfig), PSZ]),
     "vdk_vit_refresh_weights": (C.c_int, [C.POINTER(VitConfig), P, P, P, I32, P]),
     "vdk_vit_forward": (C.c_int, [C.POINTER(VitConfig), P, P, P, P, SZ, P, P]),

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void quant_fp8_kernel(const void* __restrict__
       for (int e = 0; e < 4; ++e) { am = fmaxf(am, fabsf(v[4 * j + e])); c[e] = fminf(fmaxf(v[4 * j + e] * s, -lim), lim); }
       o[j] = f_pack4(c[0], c[1], c[2], c[3], fmt);
     }
-    *(u32x4*)(out + i * 16) = (u32x4){o[0], o[1], o[2], o[3]};
+    if (out) *(u32x4*)(out + i * 16) = (u32x4){o[0], o[1], o[2], o[3]};      // out == NULL: amax pass only (current scaling: amax, scale update, then the real pass)
   }
   if (amax) {
     am = block_max<4>(am, red);
@@ -244,7 +244,7 @@ extern "C" {
 
 // x (bf16 | f32, n elements, n % 16 == 0) -> fp8 (fmt 0 = e4m3, 1 = e5m2) with the device scalar `scale` (NULL = 1); amax (device scalar, may be NULL) accumulates max |x|
 int vdk_quant_fp8(const void* x, int32_t x_dtype, int64_t n, const float* scale, void* out_fp8, int32_t fmt, float* amax, void* stream) {
-  if (!x || !out_fp8 || n < 0 || (n & 15) || (fmt != 0 && fmt != 1) || (x_dtype != VDK_BF16 && x_dtype != VDK_F32)) return vdk_fail(VDK_EINVAL, "vdk_quant_fp8: bad argument (n % 16 == 0)");
+  if (!x || (!out_fp8 && !amax) || n < 0 || (n & 15) || (fmt != 0 && fmt != 1) || (x_dtype != VDK_BF16 && x_dtype != VDK_F32)) return vdk_fail(VDK_EINVAL, "vdk_quant_fp8: bad argument (n % 16 == 0)");
   if (n == 0) return VDK_OK;
   const long n16 = n / 16;
   long blocks = (n16 + 255) / 256; if (blocks > 4096) blocks = 4096;

@@ -38,12 +38,15 @@ int vdk_gemm_f32_nt(const VdkGemmF32Desc*, void*);
 int vdk_gemm_a_colsum_rows(int32_t, int32_t, int32_t);
 int vdk_softmax_rows_f32(float*, int64_t, int64_t, int32_t, float, void*);
 int vdk_patchify_f32(const float*, int32_t, int32_t, int32_t, int32_t, int32_t, float*, void*);
+int vdk_quant_fp8(const void*, int32_t, int64_t, const float*, void*, int32_t, float*, void*);
+int vdk_fp8_scale_update(float*, float*, float*, int32_t, int32_t, float, void*);
+int vdk_gemm_fp8_nt(const VdkGemmDesc*, int32_t, int32_t, const float*, const float*, void*);
 }
 
 static inline int64_t up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 struct VitDims {
-  int B, img, ps, Cin, D, L, H, M, C, Cp, np, N, T, Kraw, Kpe, Tp, Bp, cls;   // cls: 1 = class token in row 0 of every image's token block   // Kraw = in_chans * patch^2, Kpe = Kraw padded to 8 (patch 14: 588 -> 592)
+  int B, img, ps, Cin, D, L, H, M, C, Cp, np, N, T, Kraw, Kpe, Tp, Bp, cls, fp8;   // cls: 1 = class token in row 0 of every image's token block   // Kraw = in_chans * patch^2, Kpe = Kraw padded to 8 (patch 14: 588 -> 592)
   float eps;
 };
 static int vit_dims(const VdkVitConfig* c, VitDims* d) {
@@ -64,6 +67,9 @@ static int vit_dims(const VdkVitConfig* c, VitDims* d) {
   d->Cp = (int)up(d->C, 8);
   d->Tp = (int)up(d->T, 64);
   d->Bp = (int)up(d->B, 64);
+  d->fp8 = c->fp8;
+  if (d->fp8 < 0 || d->fp8 > 2) return vdk_fail(VDK_EINVAL, "vit: fp8 must be 0, 1 or 2");
+  if (d->fp8 && (d->D < 256 || (d->D % 128) || (d->M % 128))) return vdk_fail(VDK_EUNSUPPORTED, "vit: the fp8 mode needs dim >= 256, dim and mlp_dim % 128 == 0");
   return VDK_OK;
 }
 
@@ -182,6 +188,7 @@ struct WsPlan {
   size_t lnws, lnws_bytes, csws, csws_bytes;   // lnws: 2 buffers of lnws_bytes, csws: 5 of csws_bytes (a block's deferred reductions read them at its end)
   size_t dhf;                    // bf16 [B, D]
   size_t dposall;                // fp32 [N, D]
+  size_t a8;                     // fp8 mode: the quantised A operand of the GEMM about to run, [T, max(M, 3D)] bytes
 };
 static size_t w_take(size_t& cur, size_t n) { size_t o = cur; cur = (cur + n + 255) & ~(size_t)255; return o; }
 static int wgrad_splitk(int M, int N, int K) {
@@ -245,11 +252,51 @@ static int vit_plan(const VitDims& d, WsPlan* w) {
   w->csws_bytes = (cs + 255) & ~(size_t)255; w->csws = w_take(cur, 5 * w->csws_bytes);   // slots 0..3: a block's four fused bias-gradient partials (pending until its end), slot 4: immediate users
   w->dhf = w_take(cur, (size_t)d.B * D * 2);
   w->dposall = w_take(cur, (size_t)d.N * D * 4);
+  w->a8 = d.fp8 ? w_take(cur, T * (M > 3 * D ? M : 3 * D)) : 0;
   w->total = cur;
   return VDK_OK;
 }
 
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+// ---- fp8 mode (VdkVitConfig.fp8): OCP e4m3 / e5m2 operands for the forward and input-gradient GEMMs of the block Linears ------------------------------------
+struct F8 {
+  int mode; unsigned char* w8; unsigned char* wt8; float* amax; float* sc; float* si; unsigned char* a8;
+};
+static int f8_init(const VdkVitConfig* cfg, const VitDims& d, const PLayout& p, F8* f, unsigned char* a8) {
+  f->mode = d.fp8; f->a8 = a8;
+  if (!d.fp8) return VDK_OK;
+  if (!cfg->fp8_w || !cfg->fp8_state) return vdk_fail(VDK_EINVAL, "vit: fp8 mode without fp8_w / fp8_state");
+  if (a8 && d.T < 256) return vdk_fail(VDK_EUNSUPPORTED, "vit: the fp8 mode needs batch * tokens >= 256");
+  f->w8 = (unsigned char*)cfg->fp8_w; f->wt8 = f->w8 + p.total;
+  const int S = 12 * d.L;
+  f->amax = cfg->fp8_state; f->sc = f->amax + S; f->si = f->sc + S;
+  return VDK_OK;
+}
+// x (bf16 | f32, n values) -> fp8 bytes with the slot's scale; records amax for the next scale.  mode 2: the scale is refreshed from THIS tensor first (current scaling)
+static int f8_quant(hipStream_t s, const F8& f, const void* x, int xdt, long n, int slot, int fmt, unsigned char* out, int force_current = 0) {
+  if (f.mode == 2 || force_current) {
+    RC(vdk_quant_fp8(x, xdt, n, nullptr, nullptr, fmt, f.amax + slot, s));
+    RC(vdk_fp8_scale_update(f.amax + slot, f.sc + slot, f.si + slot, 1, fmt, 1.0f, s));
+  }
+  return vdk_quant_fp8(x, xdt, n, f.sc + slot, out, fmt, f.amax + slot, s);
+}
+// C = epilogue(A8[M, K] . W8[N, K]^T / (scale_a scale_w)): `a` is quantised into the scratch operand first
+static int gemm8(hipStream_t s, const F8& f, const void* a, int slot_a, int a_fmt, const unsigned char* w8, int slot_w, int64_t ldb, void* Cc, int64_t ldc, int M, int N,
+                 int K, int cdt, const float* bias, const float* res, int64_t ldr, int act, void* aux, int64_t ldaux) {
+  RC(f8_quant(s, f, a, VDK_BF16, (long)M * K, slot_a, a_fmt, f.a8));
+  VdkGemmDesc g = {};
+  g.A = f.a8; g.lda = K; g.B = w8; g.ldb = ldb; g.C = Cc; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.c_dtype = cdt; g.bias = bias; g.residual = res; g.ldr = ldr;
+  g.act = act; g.aux = aux; g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = 1;
+  return vdk_gemm_fp8_nt(&g, a_fmt, 0, f.si + slot_a, f.si + slot_w, s);
+}
+__global__ void vit_fp8_update_kernel(float* __restrict__ amax, float* __restrict__ sc, float* __restrict__ si, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = amax[i], fmax = (i % 12) >= 8 ? 57344.0f : 448.0f;       // slots 8..11 of a layer are e5m2 gradients
+  if (a > 0.f) { const float v = fmax / a; sc[i] = v; si[i] = 1.0f / v; }
+  amax[i] = 0.f;
+}
 
 // Events that order the main (dgrad) stream and the side (wgrad) stream of vdk_vit_backward.  Created once per process,
 // timing disabled, re-recorded on every call (the only library-owned state; streams and memory stay the caller's).
@@ -331,7 +378,30 @@ int vdk_vit_refresh_weights(const VdkVitConfig* cfg, const float* params, void* 
     add(params + p.blk[l].fc2_w, d.M, d.D, d.M, wt + p.blkT[l].fc2, d.D, d.D);
   }
   if (d.C > 0) add(params + p.head_w, d.D, d.Cp, d.D, wt + p.headT, d.Cp, d.Cp);
-  return vdk_transpose_cast_batch(jobs.data(), (int)jobs.size(), stream);
+  RC(vdk_transpose_cast_batch(jobs.data(), (int)jobs.size(), stream));
+  if (d.fp8) {     // e4m3 copies of the block Linears' weights, both orientations, one scale per tensor taken from the weights themselves (current scaling)
+    F8 f; RC(f8_init(cfg, d, p, &f, nullptr));
+    hipStream_t s = (hipStream_t)stream;
+    for (int l = 0; l < d.L; ++l) {
+      const PLayout::Blk& b = p.blk[l]; const PLayout::BlkT& bt = p.blkT[l];
+      const int64_t off[4] = {b.qkv_w, b.proj_w, b.fc1_w, b.fc2_w}, offT[4] = {bt.qkv, bt.proj, bt.fc1, bt.fc2};
+      const long n[4] = {(long)3 * d.D * d.D, (long)d.D * d.D, (long)d.M * d.D, (long)d.D * d.M};
+      for (int k = 0; k < 4; ++k) {
+        RC(f8_quant(s, f, params + off[k], VDK_F32, n[k], 12 * l + 4 + k, 0, f.w8 + off[k], 1));
+        RC(vdk_quant_fp8(wt + offT[k], VDK_BF16, n[k], f.sc + 12 * l + 4 + k, f.wt8 + offT[k], 0, nullptr, s));
+      }
+    }
+  }
+  return VDK_OK;
+}
+
+int vdk_vit_fp8_update(const VdkVitConfig* cfg, void* stream) {
+  VitDims d; RC(vit_dims(cfg, &d));
+  if (!d.fp8) return VDK_OK;
+  if (!cfg->fp8_state) return vdk_fail(VDK_EINVAL, "vdk_vit_fp8_update: null state");
+  const int S = 12 * d.L;
+  hipLaunchKernelGGL(vit_fp8_update_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cfg->fp8_state, cfg->fp8_state + S, cfg->fp8_state + 2 * S, S);
+  return vdk_check_launch("vdk_vit_fp8_update");
 }
 
 // x: f32 [B, Cin, img, img] -> logits f32 [B, Cp] (columns C..Cp-1 are padding); feature mode (num_classes = 0): `logits`
@@ -364,6 +434,7 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
   if (d.cls) RC(vdk_cls_rows(X, (int64_t)d.N * D, d.B, D, params + p.cls, params + p.pos, s));
 
   const float scale = 0.125f;  // head_dim ** -0.5, head_dim == 64
+  F8 f8; RC(f8_init(cfg, d, p, &f8, (unsigned char*)(base + w.a8)));
   for (int l = 0; l < d.L; ++l) {
     const PLayout::Blk& b = p.blk[l];
     float* xin = X + (size_t)(2 * l) * XS; float* xmid = xin + XS; float* xout = xmid + XS;
@@ -373,6 +444,16 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
     bf16_t* h2 = (bf16_t*)(base + w.h2 + l * w.s_h); bf16_t* u = (bf16_t*)(base + w.u + l * w.s_u); bf16_t* g = (bf16_t*)(base + w.g + l * w.s_u);
     // x = x + proj(attn(norm1(x)))
     RC(vdk_layernorm_fwd(xin, D, T, D, params + b.n1w, params + b.n1b, d.eps, h1, D, VDK_BF16, mean1, rstd1, s));
+    if (f8.mode) {
+      const int sl = 12 * l;
+      RC(gemm8(s, f8, h1, sl + 0, 0, f8.w8 + b.qkv_w, sl + 4, D, qkv, 3 * D, T, 3 * D, D, VDK_BF16, params + b.qkv_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0));
+      RC(vdk_attention_fwd(qkv, 3 * D, o, D, lse, d.B, d.N, d.H, 64, scale, s));
+      RC(gemm8(s, f8, o, sl + 1, 0, f8.w8 + b.proj_w, sl + 5, D, xmid, D, T, D, D, VDK_F32, params + b.proj_b, xin, D, VDK_ACT_NONE, nullptr, 0));
+      RC(vdk_layernorm_fwd(xmid, D, T, D, params + b.n2w, params + b.n2b, d.eps, h2, D, VDK_BF16, mean2, rstd2, s));
+      RC(gemm8(s, f8, h2, sl + 2, 0, f8.w8 + b.fc1_w, sl + 6, D, g, M, T, M, D, VDK_BF16, params + b.fc1_b, nullptr, 0, VDK_ACT_GELU, u, M));
+      RC(gemm8(s, f8, g, sl + 3, 0, f8.w8 + b.fc2_w, sl + 7, M, xout, D, T, D, M, VDK_F32, params + b.fc2_b, xmid, D, VDK_ACT_NONE, nullptr, 0));
+      continue;
+    }
     RC(gemm(s, h1, D, wb + b.qkv_w, D, qkv, 3 * D, T, 3 * D, D, VDK_BF16, params + b.qkv_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
     RC(vdk_attention_fwd(qkv, 3 * D, o, D, lse, d.B, d.N, d.H, 64, scale, s));
     RC(gemm(s, o, D, wb + b.proj_w, D, xmid, D, T, D, D, VDK_F32, params + b.proj_b, xin, D, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
@@ -514,6 +595,7 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
   }
   // ---- blocks, last to first ------------------------------------------------------------------------
   bool fc2_bias_from_norm1 = false;
+  F8 f8; RC(f8_init(cfg, d, p, &f8, (unsigned char*)(base + w.a8)));
   for (int l = d.L - 1; l >= 0; --l) {
     const PLayout::Blk& b = p.blk[l];
     float* xin = X + (size_t)(2 * l) * XS; float* xmid = xin + XS;
@@ -532,7 +614,16 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
     char* const lnws0 = base + w.lnws; char* const lnws1 = lnws0 + w.lnws_bytes;
     // MLP branch: dxa / dxab hold dL/dx_out
     RC(ev_order(ev_p++, s, s2));
-    if (one_stream) {
+    if (f8.mode) {
+      // fp8 operands (e5m2 gradient x e4m3 transposed weight) for the two input-gradient GEMMs; the weight gradients stay bf16 TN GEMMs from the same bf16 tensors.
+      // fc2.bias comes with DXAB(l) when the norm backward above produced it; fc1.bias is a column-sum pass over du (the fp8 kernel has no by-products).
+      const int sl = 12 * l;
+      const bool have_fc2b = one_stream && ((l == d.L - 1) ? last_fc2_bias_done : fc2_bias_from_norm1);
+      RC(gemm8(s, f8, dxab, sl + 8, 1, f8.wt8 + p.blkT[l].fc2, sl + 7, D, du, M, T, M, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_DGELU, u, M));          // du
+      RC(linear_wgrad(s2, d, w, base, dxab, D, g, M, T, d.Tp, D, M, grads + b.fc2_w, have_fc2b ? nullptr : grads + b.fc2_b, 0));
+      RC(gemm8(s, f8, du, sl + 9, 1, f8.wt8 + p.blkT[l].fc1, sl + 6, M, dsm, D, T, D, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0));      // dh2
+      RC(linear_wgrad(s2, d, w, base, du, M, h2, D, T, d.Tp, M, D, grads + b.fc1_w, grads + b.fc1_b, 0));
+    } else if (one_stream) {
       // Bias gradients ride with the PRODUCER of each dY (it sums what it stores): fc2.bias with DXAB(l) (norm backward of the block above), fc1.bias with du
       // (dGELU epilogue below), proj.bias with dxmb (norm2 backward below); only qkv.bias still comes from the A tiles of the dh1 GEMM (dqkv is attention's output).
       int fx = 0;
@@ -560,7 +651,10 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
     nj += ocs_ln ? 2 : 1;
     // attention branch: dxm / dxmb hold dL/dx_mid
     RC(ev_order(ev_p++, s, s2));
-    if (one_stream && ocs_ln) {
+    if (f8.mode) {
+      RC(gemm8(s, f8, dxmb, 12 * l + 10, 1, f8.wt8 + p.blkT[l].proj, 12 * l + 5, D, dsm, D, T, D, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0));   // do
+      RC(linear_wgrad(s2, d, w, base, dxmb, D, o, D, T, d.Tp, D, D, grads + b.proj_w, ocs_ln ? nullptr : grads + b.proj_b, 0));
+    } else if (one_stream && ocs_ln) {
       RC(gemm(s, dxmb, D, wt + p.blkT[l].proj, D, dsm, D, T, D, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // do
       RC(linear_wgrad(s2, d, w, base, dxmb, D, o, D, T, d.Tp, D, D, grads + b.proj_w, nullptr, 0));
     } else if (one_stream) {
@@ -572,7 +666,10 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
     }
     RC(vdk_attention_bwd(qkv, 3 * D, o, dsm, D, lse, dqkv, 3 * D, dvec, d.B, d.N, d.H, 64, 0.125f, s));                                    // dqkv
     RC(ev_order(ev_p++, s, s2));
-    if (one_stream) {
+    if (f8.mode) {
+      RC(gemm8(s, f8, dqkv, 12 * l + 11, 1, f8.wt8 + p.blkT[l].qkv, 12 * l + 4, 3 * D, dsm, D, T, D, 3 * D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0));   // dh1
+      RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, grads + b.qkv_b, 0));
+    } else if (one_stream) {
       RC(dgrad_with_bias(s, w, base, dqkv, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, VDK_ACT_NONE, nullptr, 0, grads + b.qkv_b, &fz, 3, jobs, &nj));   // dh1
       RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, fz ? nullptr : grads + b.qkv_b, 0));
     } else {

@@ -68,6 +68,9 @@ class VitEngine:
         self.spec = spec
         self.be = backend or _lib.load()
         self.device = torch.device(device if device is not None else ("cuda" if self.be.device_only else "cpu"))
+        self.fp8 = 0                     # 0 = bf16 operands; see enable_fp8
+        self.fp8_w: Optional[torch.Tensor] = None
+        self.fp8_state: Optional[torch.Tensor] = None
         cfg = self._cfg(1)
         nf, nt, ntr = _abi.I64(0), _abi.I32(0), _abi.I64(0)
         self.be.check(self.be.lib.vdk_vit_param_count(C.byref(cfg), C.byref(nf), C.byref(nt), C.byref(ntr)), "vdk_vit_param_count")
@@ -112,7 +115,8 @@ class VitEngine:
     # ---- plumbing ------------------------------------------------------------------------------
     def _cfg(self, batch: int) -> _abi.VitConfig:
         s = self.spec
-        return _abi.VitConfig(batch, s.img_size, s.patch_size, s.in_chans, s.dim, s.depth, s.heads, s.mlp_dim, s.num_classes, s.ln_eps, 0 if s.class_token else 1)
+        return _abi.VitConfig(batch, s.img_size, s.patch_size, s.in_chans, s.dim, s.depth, s.heads, s.mlp_dim, s.num_classes, s.ln_eps, 0 if s.class_token else 1,
+                              self.fp8, self.be.ptr(self.fp8_w) if self.fp8 else None, self.be.ptr(self.fp8_state) if self.fp8 else None)
 
     def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
         for n, off, numel, shape in self.entries:
@@ -141,6 +145,26 @@ class VitEngine:
         be.check(be.lib.vdk_vit_refresh_weights(C.byref(cfg), be.ptr(self.params), be.ptr(self.wb16), be.ptr(self.wt16),
                                                 int(skip_wb16), be.stream()), "vdk_vit_refresh_weights")
         self._weights_version = self.params._version
+
+    def enable_fp8(self, mode: int = 1) -> None:
+        """BASELINE.json configs[4] "fp8 MFMA": the forward and input-gradient GEMMs of every block Linear on OCP fp8 operands (csrc/gemm_fp8.hip) with per-tensor
+        scaling; mode 1 = delayed scaling (this step's scale from the last step's amax), 2 = current scaling (an amax pass per tensor: calibration), 0 = off.
+        Weight gradients, attention, LayerNorm, the embeddings and the head stay as they are.  Call fp8_update() after every backward."""
+        assert mode in (0, 1, 2)
+        if mode and self.fp8_w is None:
+            L = self.spec.depth
+            self.fp8_w = torch.zeros(self.n_floats + self.n_transposed, dtype=torch.uint8, device=self.device)
+            st = torch.zeros((3, 12 * L), dtype=torch.float32, device=self.device)
+            st[1:] = 1.0
+            self.fp8_state = st
+        if bool(mode) != bool(self.fp8):
+            self._ws, self._ws_batch, self._weights_version = None, -1, None        # the workspace gains / loses the quantised-operand scratch; fp8 weight copies to build
+        self.fp8 = mode
+
+    def fp8_update(self) -> None:
+        if self.fp8:
+            cfg = self._cfg(1)
+            self.be.check(self.be.lib.vdk_vit_fp8_update(C.byref(cfg), self.be.stream()), "vdk_vit_fp8_update")
 
     def _ensure_fresh(self) -> None:
         if self._weights_version != self.params._version:
@@ -572,6 +596,7 @@ class FusedTrainStep:
             self.comm.finish_step()
         else:
             eng.backward(self._dl)
+        eng.fp8_update()
 
     def ohem_select(self, x: torch.Tensor, y: torch.Tensor, min_kept: int, thresh: float, ignore_index: int = 255):
         """OHEM-Softmax pre-pass of the reference's loop (engine/procedure/train.py:113-117, structure/sampler.py:11-31): one extra no-grad forward in
@@ -591,6 +616,8 @@ class FusedTrainStep:
         g0 = self.param_groups[0]
         lr, momentum, weight_decay = g0["lr"], g0["momentum"], g0["weight_decay"]
         self.updates += 1
+        if eng.fp8:
+            eng.fp8 = 2 if self.updates == 1 else 1          # first step: current scaling (nothing to delay from yet)
         d = 0.9999 * (1 - math.exp(-self.updates / 2000)) if self.ema is not None else 0.0
         if self.sam:
             # first forward-backward on w with LOCAL gradients (model.no_sync(), train.py:157-159), then climb to w + e(w)
@@ -679,12 +706,15 @@ class MapTrainStep:
         self._loss_rows, _, dlf = ops.softmax_ce(logits.detach().contiguous(), y, y_b, lam, self.label_smoothing, 1.0 / B, backend=self.be)
         logits.backward(dlf)
         eng.backward(tokens.grad.contiguous().view(-1, eng.spec.dim))
+        eng.fp8_update()
 
     def step(self, x: torch.Tensor, y: torch.Tensor, y_b: Optional[torch.Tensor] = None, lam: float = 1.0) -> torch.Tensor:
         eng, be, n = self.eng, self.be, self.eng.n_floats
         g0 = self.param_groups[0]
         lr, momentum, weight_decay = g0["lr"], g0["momentum"], g0["weight_decay"]
         self.updates += 1
+        if eng.fp8:
+            eng.fp8 = 2 if self.updates == 1 else 1          # first step: current scaling (nothing to delay from yet)
         d = 0.9999 * (1 - math.exp(-self.updates / 2000)) if self.ema is not None else 0.0
         first = int(self.updates == 1)
         nx = self.n_total - n
