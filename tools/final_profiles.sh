@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round-end measurement set on one MI355X box (run through gpurun): the bench line, the rocprofv3 kernel-trace summary of the same timed command, the PMC traffic
+# passes of the GEMM (FETCH_SIZE / WRITE_SIZE in separate runs, as MI355X_MICROARCH.md prescribes) and of one CBIR search.  Everything lands in gpurun_out/final/;
+# the summaries worth judging are copied into profiles/ by hand.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/final
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+BARGS="--steps 20 --warmup 3 --no-parity --no-cpu-baseline --no-cbir"
+rocprofv3 --kernel-trace --stats -d /tmp/p_trace -o t -- python $R/bench.py $BARGS > $O/trace_stdout.txt 2>&1
+python $R/tools/rocpd_stats.py $(find /tmp/p_trace -name "*.db" | head -1) > $O/bench_kernel_stats.txt
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c -d /tmp/p_$c -o p --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-parity --no-cpu-baseline --no-cbir > $O/pmc_${c}_stdout.txt 2>&1
+done
+F=$(find /tmp/p_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find /tmp/p_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+python $R/tools/pmc_traffic.py "$F" "$W" gemm256 $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
+tail -3 $O/pmc_traffic.txt
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c -d /tmp/c_$c -o p --output-format csv -- python $R/tools/cbir_pmc_run.py 4 > $O/cbir_pmc_${c}_stdout.txt 2>&1
+done
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/c_SQ -o p --output-format csv -- python $R/tools/cbir_pmc_run.py 4 > $O/cbir_pmc_SQ_stdout.txt 2>&1
+CF=$(find /tmp/c_FETCH_SIZE -name "*counter_collection.csv" | head -1); CW=$(find /tmp/c_WRITE_SIZE -name "*counter_collection.csv" | head -1); CS=$(find /tmp/c_SQ -name "*counter_collection.csv" | head -1)
+python $R/tools/pmc_cbir.py "$CF" "$CW" "${CS:--}" 4 $O/cbir_pmc.json > $O/cbir_pmc.txt 2>&1
+tail -8 $O/cbir_pmc.txt
+cd $R
+cp $O/pmc_traffic.json profiles/r02_pmc_traffic.json 2>/dev/null; cp $O/cbir_pmc.json profiles/r02_cbir_pmc.json 2>/dev/null    # the bench line below reads them
+python bench.py > $O/bench_stdout.txt 2> $O/bench_stderr.txt
+tail -1 $O/bench_stdout.txt > $O/bench.json
+python -c "
+import json;d=json.load(open('$O/bench.json'));print(d['value'],d['ms_per_step'],d['roofline'],d['cpu_baseline']);print(json.dumps(d['cbir'])[:1500])"
