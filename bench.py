@@ -80,6 +80,9 @@ def parity_vit(be, dev):
     return out
 
 
+GEMM_EVENT_STRIDE = 4      # steps between two event-timed steps of the timed region
+
+
 def pmc_traffic_per_launch():
     """HBM-side bytes per GEMM launch from the committed PMC passes of this same command (rocprofv3 cannot run inside the timed process):
     profiles/r0N_pmc_traffic.json is written by tools/pmc_traffic.py from two `rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE}` runs,
@@ -260,10 +263,14 @@ def main():
         dist.barrier()
     # live per-launch timing of the dominant kernel (bf16 GEMM) with HIP events on the launch stream
     launches_per_step = 7 * spec.depth * 2 + 8
-    be.check(be.lib.vdk_prof_begin(launches_per_step * args.steps + 64), "vdk_prof_begin")
+    if os.environ.get("VDK_BENCH_NO_EVENTS") != "1":      # (diagnostic: what the per-launch HIP events themselves cost)
+        be.check(be.lib.vdk_prof_begin(launches_per_step * args.steps + 64), "vdk_prof_begin")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    ev = os.environ.get("VDK_BENCH_NO_EVENTS") != "1"
+    for it in range(args.steps):
+        if ev:      # every GEMM launch of every 4th timed step carries a (start, stop) event pair: a timed dispatch costs ~5 us of queue time, 0.7-1.0 ms per step if all 149 are timed
+            be.lib.vdk_prof_pause(0 if it % GEMM_EVENT_STRIDE == 0 else 1)
         step.step(x, y)
     torch.cuda.synchronize()
     if world > 1:
@@ -297,8 +304,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm256_bf16_kernel<NT|TN> (+ gemm_bf16_nt_kernel on small shapes)", "achieved": gemm_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": gemm_tflops / PEAK_BF16_TFLOPS, "traffic": pmc_traffic_per_launch(),
                          "algorithmic_bytes_per_launch": gemm_bytes.value / max(gemm_n.value, 1),
-                         "avg_launch_ms": gemm_avg_ms, "launches": gemm_n.value, "flops_per_launch": gemm_fl.value / max(gemm_n.value, 1),
-                         "gemm_share_of_step_time": gemm_ms.value / (dt * 1e3)},
+                         "avg_launch_ms": gemm_avg_ms, "launches": gemm_n.value, "timed_launches": f"every GEMM dispatch of every {GEMM_EVENT_STRIDE}th step of the timed region (start / stop events attached to the dispatch itself)", "flops_per_launch": gemm_fl.value / max(gemm_n.value, 1),
+                         "gemm_share_of_step_time": (gemm_ms.value / max(1, -(-args.steps // GEMM_EVENT_STRIDE))) / (dt / args.steps * 1e3)},
         }
         if parity is not None:
             out["parity"] = parity

@@ -151,6 +151,7 @@ int vdk_gemm_debug_stamps(void* device_u64_buffer);
 /* live GEMM timing for bench.py's `roofline` (HIP events on the launch stream around every GEMM kernel):
  * begin(max_launches) pre-creates the events; end() synchronises and returns the totals since begin(). */
 int vdk_prof_begin(int32_t max_launches);
+int vdk_prof_pause(int32_t paused);   /* suspend (1) / resume (0) recording between vdk_prof_begin and vdk_prof_end */
 int vdk_prof_end(double* total_ms, int64_t* launches, double* total_flops);
 int vdk_prof_bytes(double* total_bytes);   /* algorithmic bytes of those launches (every operand / output / epilogue tensor counted once) */
 

@@ -74,6 +74,8 @@ static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 enum { hipDeviceAttributeMultiprocessorCount = 63 };
 static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 16; return 0; }   // the emulated "device" has 16 CUs (stream-K grids)
 typedef void* hipEvent_t;
+#define VDK_EMU_NO_HIP_EXT 1
+#define hipExtLaunchKernelGGL(kern, grid, block, shmem, stream, ev0, ev1, flags, ...) hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__)
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 #define hipEventDisableTiming 2

@@ -1,5 +1,4 @@
-mkdir -p gpurun_out/final
-python bench.py > gpurun_out/final/bench_stdout.txt 2> gpurun_out/final/bench_stderr.txt
-tail -1 gpurun_out/final/bench_stdout.txt > gpurun_out/final/bench.json
-python -c "
-import json;d=json.load(open('gpurun_out/final/bench.json'));print(d['value'],d['ms_per_step'],d['roofline']['frac']);c=d['cbir'];print(c['ms_per_step'] if 'ms_per_step' in c else c['ms_per_search'], c['float16_storage']['ms_per_search'], c['d512']['ms_per_search'], c['optimistic_two_stage_schedule']['ms_per_search'])"
+for i in 1 2; do
+python bench.py --steps 20 --warmup 3 --no-parity --no-cbir --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys;d=json.loads(sys.stdin.read());print('events',d['ms_per_step'],d['value'])"
+VDK_BENCH_NO_EVENTS=1 python bench.py --steps 20 --warmup 3 --no-parity --no-cbir --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys;d=json.loads(sys.stdin.read());print('no events',d['ms_per_step'],d['value'])"
+done

@@ -91,6 +91,7 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_gemm_fp8_nt": (C.c_int, [P, I32, I32, P, P, P]),
     "vdk_gemm_debug_stamps": (C.c_int, [P]),
     "vdk_prof_begin": (C.c_int, [I32]),
+    "vdk_prof_pause": (C.c_int, [I32]),
     "vdk_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(I64), C.POINTER(C.c_double)]),
     "vdk_prof_bytes": (C.c_int, [C.POINTER(C.c_double)]),
     "vdk_transpose_bf16": (C.c_int, [P, I64, I32, I32, P, I64, I32, I32, P, P]),

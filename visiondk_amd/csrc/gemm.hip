@@ -10,6 +10,9 @@
 // group hits 16 distinct 16-B slots, XCD-aware bijective tile swizzle, epilogue staged through LDS
 // for 16-B coalesced stores with bias / exact-erf GELU / dGELU / fp32 residual fused in.
 #include <hip/hip_runtime.h>
+#ifndef VDK_EMU_NO_HIP_EXT
+#include <hip/hip_ext.h>
+#endif
 #include <cstdlib>
 #include "vdk_device.h"
 #include "vdk_host.h"
@@ -664,8 +667,9 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 }
 
 // ---- optional live profiling of the GEMM launches (bench.py's `roofline` object) --------------------------------
-// vdk_prof_begin(n) pre-creates n event pairs; while enabled every vdk_gemm_bf16_nt call brackets its kernel(s) with
-// hipEventRecord on the launch stream; vdk_prof_end() synchronises and returns total GEMM time, launches and flops.
+// vdk_prof_begin(n) pre-creates n event pairs; while enabled every vdk_gemm_bf16_nt call attaches a (start, stop) pair to its GEMM dispatch itself
+// (hipExtLaunchKernelGGL: the timestamps of the dispatch packet's own completion signal -- no extra packets in the queue; bracketing with hipEventRecord cost
+// 1.0 ms of the 43 ms step, two marker packets around each of its 149 GEMMs); vdk_prof_end() synchronises and returns total GEMM time, launches and flops.
 #include <vector>
 static std::vector<hipEvent_t> g_prof_ev;
 static std::vector<double> g_prof_flops;
@@ -733,6 +737,8 @@ int vdk_prof_begin(int32_t max_launches) {
   g_prof_on = true;
   return VDK_OK;
 }
+/* suspend / resume the event recording between vdk_prof_begin and vdk_prof_end (bench.py samples every 4th step: a timed dispatch costs ~5 us of queue time) */
+int vdk_prof_pause(int32_t paused) { g_prof_on = !paused && !g_prof_ev.empty(); return VDK_OK; }
 int vdk_prof_end(double* total_ms, int64_t* launches, double* total_flops) {
   g_prof_on = false;
   double ms = 0.0, fl = 0.0;
@@ -809,7 +815,6 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   p.k_per_split = kps;
   const int ntn = (d->N + G_BN - 1) / G_BN, ntm = (d->M + G_BM - 1) / G_BM;
   const bool prof = g_prof_on && g_prof_used + 2 <= g_prof_ev.size();
-  if (prof) (void)hipEventRecord(g_prof_ev[g_prof_used], stream);
   // big problems go to the 256x256 LDS-DMA kernel (needs whole 64-wide k-tiles per split and >= 1 full wave of tiles)
   const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * splitk;
   const bool big = !d->conv && (g_force_kernel == 2 || g_force_kernel == 3 || ((g_force_kernel == 0 || g_force_kernel == 4) && (d->K % 64 == 0) && (kps % 64 == 0) && tiles256 >= 128 && d->M >= 256 && d->N >= 256));
@@ -842,15 +847,20 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
       grid256 = dim3((unsigned)G, 1u);
     }
   }
+#define VDK_GEMM_LAUNCH(KERN, GRID, BLOCK)                                                                                                   \
+  do {                                                                                                                                       \
+    if (prof) hipExtLaunchKernelGGL(KERN, GRID, BLOCK, 0, stream, g_prof_ev[g_prof_used], g_prof_ev[g_prof_used + 1], 0, p);                 \
+    else hipLaunchKernelGGL(KERN, GRID, BLOCK, 0, stream, p);                                                                                \
+  } while (0)
 #define LAUNCH256X(TNF, EE, CSF)                                                                                         \
   do {                                                                                                                   \
-    if (sk) hipLaunchKernelGGL((gemm256_bf16_kernel<TNF, EE, !TNF, CSF>), grid256, dim3(512), 0, stream, p);              \
-    else hipLaunchKernelGGL((gemm256_bf16_kernel<TNF, EE, false, CSF>), grid256, dim3(512), 0, stream, p);                \
+    if (sk) VDK_GEMM_LAUNCH((gemm256_bf16_kernel<TNF, EE, !TNF, CSF>), grid256, dim3(512));                               \
+    else VDK_GEMM_LAUNCH((gemm256_bf16_kernel<TNF, EE, false, CSF>), grid256, dim3(512));                                 \
   } while (0)
 #define LAUNCH256(TNF, EE) LAUNCH256X(TNF, EE, false)
 #define LAUNCH256CS(EE)                                                                                                  \
   do {                                                                                                                   \
-    if (p.colsum_part) hipLaunchKernelGGL((gemm256_bf16_kernel<false, EE, false, true>), grid256, dim3(512), 0, stream, p); \
+    if (p.colsum_part) VDK_GEMM_LAUNCH((gemm256_bf16_kernel<false, EE, false, true>), grid256, dim3(512));                \
     else LAUNCH256X(false, EE, false);                                                                                   \
   } while (0)
   if (d->trans) {
@@ -893,11 +903,10 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   else if (d->a_colsum || d->c_colsum)
     return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: a_colsum / c_colsum are by-products of the 256x256 NT kernel only (see vdk_gemm_a_colsum_rows)");
   else if (d->conv)
-    hipLaunchKernelGGL(gemm_bf16_nt_kernel<true>, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256), 0, stream, p);
+    VDK_GEMM_LAUNCH(gemm_bf16_nt_kernel<true>, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256));
   else
-    hipLaunchKernelGGL(gemm_bf16_nt_kernel<false>, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256), 0, stream, p);
+    VDK_GEMM_LAUNCH(gemm_bf16_nt_kernel<false>, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256));
   if (prof) {   // the GEMM kernel only (the split-K combine is a separate, HBM-bound kernel)
-    (void)hipEventRecord(g_prof_ev[g_prof_used + 1], stream);
     g_prof_flops.push_back(2.0 * d->M * d->N * d->K);
     {
       const double mn = (double)d->M * d->N;
