@@ -17,7 +17,7 @@
  *       (acc = fmaf(q[k], g[k], acc)), with -0.0 canonicalised to +0.0 at the end;
  *   (2) tie order: equal scores are ordered by ascending gallery index.
  * PARITY PINNING: the reference has no tests/golden vectors for this path; the
- * oracle is pinned in tests/test_oracle_cbir.py against numpy's float64 `Q @ G.T` + stable argsort
+ * oracle is pinned in tests/test_golden.py (test_cbir_oracle_vs_float64_numpy) against numpy's float64 `Q @ G.T` + stable argsort
  * (scores within 2e-6, indices equal wherever the float64 gap exceeds that) and against the committed
  * fixture tests/golden/cbir_small.npz produced by tests/golden/make_golden.py.
  */
