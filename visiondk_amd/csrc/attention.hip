@@ -380,8 +380,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 
 // short sequences (attention_small.hip): everything of one (batch, head) item in LDS, exact softmax, fused backward
 int vdk_attention_small_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H, float scale, void* stream);
-int vdk_attention_small_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv, int64_t ldd, int32_t B, int32_t N, int32_t H,
-                            float scale, void* stream);
+int vdk_attention_small_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv, int64_t ldd, float* dvec, int32_t B, int32_t N,
+                            int32_t H, float scale, void* stream);
 static int g_attn_legacy = -1;   // -1: env VDK_ATTN_LEGACY decides; 0 / 1: forced by vdk_attention_force_legacy (A/B benchmarking, tests of the long-sequence kernels at small N)
 static bool attn_legacy() {
   if (g_attn_legacy >= 0) return g_attn_legacy == 1;
@@ -423,7 +423,7 @@ int vdk_attention_bwd(const void* qkv, int64_t ld, const void* o, const void* do
   if (head_dim != A_HD) return vdk_fail(VDK_EUNSUPPORTED, "vdk_attention_bwd: head_dim must be 64");
   if ((ld & 7) || (ldo & 7) || (lddqkv & 7)) return vdk_fail(VDK_EINVAL, "vdk_attention_bwd: ld % 8");
   if (N <= 224 && !attn_legacy()) {
-    const int rc = vdk_attention_small_bwd(qkv, ld, o, dout, ldo, lse, dqkv, lddqkv, B, N, H, scale, stream_);
+    const int rc = vdk_attention_small_bwd(qkv, ld, o, dout, ldo, lse, dqkv, lddqkv, dvec, B, N, H, scale, stream_);
     if (rc != VDK_EUNSUPPORTED) return rc ? rc : vdk_check_launch("vdk_attention_bwd");
   }
   const bf16_t* base = (const bf16_t*)qkv;

@@ -353,6 +353,322 @@ __global__ __launch_bounds__(512, 2) void attn_s_bwd_kernel(const bf16_t* __rest
   }
 }
 
+// =====================================================================================  backward (recompute form)
+// Same contract as attn_s_bwd_kernel, different trade: 28 MFMAs per (query tile, key tile) pair instead of 20, and in exchange NO shared accumulator, no hand-off
+// tile, no read-modify-write and no barrier inside an item's compute.  Q, K, V, dO of the item are all LDS-resident (by LDS-DMA); a wave first owns KEY tile w --
+// S = Q K^T and dP = dO V^T per query tile, dV^T += dO^T P, dK^T += Q^T dS in its registers -- and then QUERY tile w -- S^T = K Q^T and dP^T = V dO^T per key tile
+// (the transposed products put the query on the lane, which is what the B operand of dQ^T += K^T dS^T needs), dQ^T in its registers.  MFMA time was ~40 us of the fused
+// kernel's 340 us; what it spent was the dQ traffic in LDS (68 us) and one workgroup barrier per step.
+// LDS (dynamic): Q [R8] | K [R8] | V [R8] | dO [R8] | zero rows up to 32*NKT of the dO array | 8 wave store tiles of 4 KB | lse2 [32*NKT] | D [32*NKT].
+template <int NKT>
+__global__ __launch_bounds__(512, 2) void attn_s_bwd2_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld,
+                                                             const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, long ldo, const float* __restrict__ lse,
+                                                             bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long ldd, int N, int H, float scale,
+                                                             int nitems) {
+  VDK_DYN_LDS(smem);
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int R8 = (N + 7) & ~7;
+  constexpr int NP = 32 * NKT;
+  constexpr int NPC = (NP * 8 + 511) / 512;                           // 16-byte O pieces per thread for D = rowsum(dO * O)
+  unsigned char* const Qs = smem;
+  unsigned char* const Ks = smem + R8 * AS_ROW;
+  unsigned char* const Vs = smem + 2 * R8 * AS_ROW;
+  unsigned char* const Os = smem + 3 * R8 * AS_ROW;                   // dO rows, then zero rows up to NP
+  unsigned char* const Wt = smem + (3 * R8 + NP) * AS_ROW + w * 4096;  // this wave's store tile
+  float* const lse2 = (float*)(smem + (3 * R8 + NP) * AS_ROW + 8 * 4096);
+  float* const Dv = lse2 + NP;
+  for (int i = tid * 16; i < (NP - R8) * AS_ROW; i += 512 * 16) *(u32x4*)(Os + R8 * AS_ROW + i) = (u32x4){0u, 0u, 0u, 0u};
+  const int nt = (N + 31) >> 5;                                       // query tiles == key tiles
+  const bool act = w < nt;
+  const float scale2 = scale * VDK_LOG2E;
+  const bool ragged = (N & 31) != 0;
+  u32x4 opiece[NPC];
+  auto request = [&](int it) {
+    const int b = it / H, h = it - b * H;
+    const long off = (long)b * N * ld + h * 64, offo = (long)b * N * ldo + h * 64;
+    as_dma_rows(Qs, q + off, ld, N, R8, w, 8, lane);
+    as_dma_rows(Ks, k + off, ld, N, R8, w, 8, lane);
+    as_dma_rows(Vs, v + off, ld, N, R8, w, 8, lane);
+    as_dma_rows(Os, dout + offo, ldo, N, R8, w, 8, lane);
+#pragma unroll
+    for (int p = 0; p < NPC; ++p) {
+      const int id = tid + 512 * p, row = id >> 3;
+      opiece[p] = (u32x4){0u, 0u, 0u, 0u};
+      if (row < N) opiece[p] = *(const u32x4*)(o + offo + (long)row * ldo + (id & 7) * 8);
+    }
+    for (int i = tid; i < NP; i += 512) lse2[i] = i < N ? lse[((long)b * H + h) * N + i] * VDK_LOG2E : 0.f;
+  };
+  __syncthreads();                                                    // the zero rows are written
+  if ((int)blockIdx.x < nitems) request(blockIdx.x);
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / H, h = item - b * H;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): this wave's DMAs (and the previous item's stores) are done
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NPC; ++p) {
+      const int id = tid + 512 * p, row = id >> 3, cp = id & 7;
+      float d = 0.f;
+      if (row < NP) {
+        const u32x4 a = *(const u32x4*)(Os + row * AS_ROW + ((cp ^ as_f(row)) << 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { d = fmaf(bf_lo(a[e]), bf_lo(opiece[p][e]), d); d = fmaf(bf_hi(a[e]), bf_hi(opiece[p][e]), d); }
+      }
+      d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
+      if (row < NP && cp == 0) Dv[row] = row < N ? d : 0.f;
+    }
+    __syncthreads();                                                  // D is complete
+    if (act) {
+      // ---- phase A: key tile w -------------------------------------------------------------------------------------------------------------
+      {
+        f32x16 gk0 = as_zero16(), gk1 = as_zero16(), gv0 = as_zero16(), gv1 = as_zero16();
+        const int krow = w * 32 + l31;
+        s16x8 kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { kf[ks] = as_row_frag(Ks, krow, ks, hi); vf[ks] = as_row_frag(Vs, krow, ks, hi); }
+        for (int qt = 0; qt < nt; ++qt) {
+          const int q0 = qt * 32;
+          f32x16 st = as_zero16(), dp = as_zero16();
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag(Qs, q0 + l31, ks, hi), kf[ks], st, 0, 0, 0);   // S[q][key]: lane = key, registers = queries
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag(Os, q0 + l31, ks, hi), vf[ks], dp, 0, 0, 0);   // dP[q][key]
+          }
+          f32x16 pv, ds;
+          const bool edge = ragged && (qt == nt - 1 || w == nt - 1);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 lv = *(const f32x4*)(lse2 + q0 + 8 * g + 4 * hi);
+            const f32x4 dd = *(const f32x4*)(Dv + q0 + 8 * g + 4 * hi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * g + e;
+              float p = fast_exp2(fmaf(st[r], scale2, -lv[e]));
+              if (edge && (q0 + 8 * g + 4 * hi + e >= N || krow >= N)) p = 0.f;
+              pv[r] = p;
+              ds[r] = p * (dp[r] - dd[e]);
+            }
+          }
+          s16x8 pf[2], df[2];
+          as_pack_b(pv, pf);
+          as_pack_b(ds, df);
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            gv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Os, q0 + 16 * s, 0, lane), pf[s], gv0, 0, 0, 0);     // dV^T[d][key] += dO^T P
+            gv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Os, q0 + 16 * s, 32, lane), pf[s], gv1, 0, 0, 0);
+            gk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Qs, q0 + 16 * s, 0, lane), df[s], gk0, 0, 0, 0);     // dK^T[d][key] += Q^T dS
+            gk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Qs, q0 + 16 * s, 32, lane), df[s], gk1, 0, 0, 0);
+          }
+        }
+        // the key tile's gradients leave now (wave-private store tile): their 64 accumulators are free for phase B
+        as_store_tile(Wt, gk0, gk1, scale, dk + (long)b * N * ldd + h * 64, ldd, w * 32, N, lane);
+        as_store_tile(Wt, gv0, gv1, 1.0f, dv + (long)b * N * ldd + h * 64, ldd, w * 32, N, lane);
+      }
+      // ---- phase B: query tile w (transposed products: lane = query) ---------------------------------------------------------------------------
+      {
+        f32x16 gq0 = as_zero16(), gq1 = as_zero16();
+        const int qrow = w * 32 + l31;
+        s16x8 qf[4], gf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qf[ks] = as_row_frag(Qs, qrow, ks, hi); gf[ks] = as_row_frag(Os, qrow, ks, hi); }
+        const float lq = lse2[qrow], dq_ = Dv[qrow];
+        for (int kt = 0; kt < nt; ++kt) {
+          const int k0 = kt * 32;
+          f32x16 st = as_zero16(), dp = as_zero16();
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag(Ks, k0 + l31, ks, hi), qf[ks], st, 0, 0, 0);   // S^T[key][q]: lane = query, registers = keys
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag(Vs, k0 + l31, ks, hi), gf[ks], dp, 0, 0, 0);   // dP^T[key][q]
+          }
+          f32x16 ds;
+          const bool edge = ragged && (kt == nt - 1 || w == nt - 1);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float p = fast_exp2(fmaf(st[r], scale2, -lq));
+            if (edge && (k0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= N || qrow >= N)) p = 0.f;
+            ds[r] = p * (dp[r] - dq_);
+          }
+          s16x8 df[2];
+          as_pack_b(ds, df);
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            gq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Ks, k0 + 16 * s, 0, lane), df[s], gq0, 0, 0, 0);     // dQ^T[d][q] += K^T dS^T
+            gq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Ks, k0 + 16 * s, 32, lane), df[s], gq1, 0, 0, 0);
+          }
+        }
+        as_store_tile(Wt, gq0, gq1, scale, dq + (long)b * N * ldd + h * 64, ldd, w * 32, N, lane);
+      }
+    }
+    __syncthreads();                                                  // every wave is done with the item's arrays
+    const int nxt = item + gridDim.x;
+    if (nxt < nitems) request(nxt);
+  }
+}
+
+// =====================================================================================  backward (split recompute form: two kernels, two workgroups per CU)
+// The recompute form's two phases as two kernels of 256 threads whose LDS footprint (two operand arrays + 4 store tiles: 72 KB at N = 197) lets TWO workgroups share a
+// CU, like the forward: one workgroup's operand loads and gradient stores overlap the other's MFMAs, which the single 139 KB workgroup of the one-kernel forms cannot do
+// (its load, compute and store phases are serial: 325-360 us against a 125 us HBM floor).  Q, K, V, dO are read twice (once per kernel).
+//   kv kernel: Q, dO LDS-resident; a wave takes key tiles w, w+4, ...: K / V fragments straight from global, dK^T / dV^T in registers.  It also computes
+//              D = rowsum(dO * O) (it holds dO) and writes it to `dvec` for the q kernel.
+//   q kernel:  K, V LDS-resident; a wave takes query tiles w, w+4, ...: Q / dO fragments straight from global, transposed products (lane = query), dQ^T in registers.
+template <int NKT>
+__global__ __launch_bounds__(256, 2) void attn_s_bwd_kv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld,
+                                                               const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, long ldo, const float* __restrict__ lse,
+                                                               float* __restrict__ dvec, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long ldd, int N, int H, float scale,
+                                                               int nitems) {
+  VDK_DYN_LDS(smem);
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int R8 = (N + 7) & ~7;
+  constexpr int NP = 32 * NKT;
+  constexpr int NPC = (NP * 8 + 255) / 256;
+  unsigned char* const Qs = smem;
+  unsigned char* const Os = smem + R8 * AS_ROW;                       // dO rows, then zero rows up to NP
+  unsigned char* const Wt = smem + (R8 + NP) * AS_ROW + w * 4096;
+  float* const lse2 = (float*)(smem + (R8 + NP) * AS_ROW + 4 * 4096);
+  float* const Dv = lse2 + NP;
+  for (int i = tid * 16; i < (NP - R8) * AS_ROW; i += 256 * 16) *(u32x4*)(Os + R8 * AS_ROW + i) = (u32x4){0u, 0u, 0u, 0u};
+  const int nt = (N + 31) >> 5;
+  const float scale2 = scale * VDK_LOG2E;
+  const bool ragged = (N & 31) != 0;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / H, h = item - b * H;
+    const long off = (long)b * N * ld + h * 64, offo = (long)b * N * ldo + h * 64;
+    __syncthreads();                                                  // the previous item's readers are done (first pass: the zero rows are written)
+    as_dma_rows(Qs, q + off, ld, N, R8, w, 4, lane);
+    as_dma_rows(Os, dout + offo, ldo, N, R8, w, 4, lane);
+    u32x4 opiece[NPC];
+#pragma unroll
+    for (int p = 0; p < NPC; ++p) {
+      const int id = tid + 256 * p, row = id >> 3;
+      opiece[p] = (u32x4){0u, 0u, 0u, 0u};
+      if (row < N) opiece[p] = *(const u32x4*)(o + offo + (long)row * ldo + (id & 7) * 8);
+    }
+    for (int i = tid; i < NP; i += 256) lse2[i] = i < N ? lse[((long)b * H + h) * N + i] * VDK_LOG2E : 0.f;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0)
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NPC; ++p) {
+      const int id = tid + 256 * p, row = id >> 3, cp = id & 7;
+      float d = 0.f;
+      if (row < NP) {
+        const u32x4 a = *(const u32x4*)(Os + row * AS_ROW + ((cp ^ as_f(row)) << 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { d = fmaf(bf_lo(a[e]), bf_lo(opiece[p][e]), d); d = fmaf(bf_hi(a[e]), bf_hi(opiece[p][e]), d); }
+      }
+      d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
+      if (row < NP && cp == 0) { Dv[row] = row < N ? d : 0.f; if (row < N) dvec[((long)b * H + h) * N + row] = d; }
+    }
+    __syncthreads();                                                  // D is complete
+    for (int kt = w; kt < nt; kt += 4) {
+      f32x16 gk0 = as_zero16(), gk1 = as_zero16(), gv0 = as_zero16(), gv1 = as_zero16();
+      const int krow = kt * 32 + l31;
+      const long kr = (long)(krow < N ? krow : N - 1) * ld;
+      s16x8 kf[4], vf[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { kf[ks] = *(const s16x8*)(k + off + kr + ks * 16 + hi * 8); vf[ks] = *(const s16x8*)(v + off + kr + ks * 16 + hi * 8); }
+      for (int qt = 0; qt < nt; ++qt) {
+        const int q0 = qt * 32;
+        f32x16 st = as_zero16(), dp = as_zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag(Qs, q0 + l31, ks, hi), kf[ks], st, 0, 0, 0);   // S[q][key]: lane = key, registers = queries
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag(Os, q0 + l31, ks, hi), vf[ks], dp, 0, 0, 0);   // dP[q][key]
+        }
+        f32x16 pv, ds;
+        const bool edge = ragged && (qt == nt - 1 || kt == nt - 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 lv = *(const f32x4*)(lse2 + q0 + 8 * g + 4 * hi);
+          const f32x4 dd = *(const f32x4*)(Dv + q0 + 8 * g + 4 * hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            float p = fast_exp2(fmaf(st[r], scale2, -lv[e]));
+            if (edge && (q0 + 8 * g + 4 * hi + e >= N || krow >= N)) p = 0.f;
+            pv[r] = p;
+            ds[r] = p * (dp[r] - dd[e]);
+          }
+        }
+        s16x8 pf[2], df[2];
+        as_pack_b(pv, pf);
+        as_pack_b(ds, df);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          gv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Os, q0 + 16 * s, 0, lane), pf[s], gv0, 0, 0, 0);     // dV^T[d][key] += dO^T P
+          gv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Os, q0 + 16 * s, 32, lane), pf[s], gv1, 0, 0, 0);
+          gk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Qs, q0 + 16 * s, 0, lane), df[s], gk0, 0, 0, 0);     // dK^T[d][key] += Q^T dS
+          gk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Qs, q0 + 16 * s, 32, lane), df[s], gk1, 0, 0, 0);
+        }
+      }
+      as_store_tile(Wt, gk0, gk1, scale, dk + (long)b * N * ldd + h * 64, ldd, kt * 32, N, lane);
+      as_store_tile(Wt, gv0, gv1, 1.0f, dv + (long)b * N * ldd + h * 64, ldd, kt * 32, N, lane);
+    }
+  }
+}
+
+template <int NKT>
+__global__ __launch_bounds__(256, 2) void attn_s_bwd_q_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld,
+                                                              const bf16_t* __restrict__ dout, long ldo, const float* __restrict__ lse, const float* __restrict__ dvec,
+                                                              bf16_t* __restrict__ dq, long ldd, int N, int H, float scale, int nitems) {
+  VDK_DYN_LDS(smem);
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int R8 = (N + 7) & ~7;
+  constexpr int NP = 32 * NKT;
+  unsigned char* const Ks = smem;
+  unsigned char* const Vs = smem + R8 * AS_ROW;                       // V rows, then zero rows up to NP
+  unsigned char* const Wt = smem + (R8 + NP) * AS_ROW + w * 4096;
+  for (int i = tid * 16; i < (NP - R8) * AS_ROW; i += 256 * 16) *(u32x4*)(Vs + R8 * AS_ROW + i) = (u32x4){0u, 0u, 0u, 0u};
+  const int nt = (N + 31) >> 5;
+  const float scale2 = scale * VDK_LOG2E;
+  const bool ragged = (N & 31) != 0;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / H, h = item - b * H;
+    const long off = (long)b * N * ld + h * 64, offo = (long)b * N * ldo + h * 64;
+    __syncthreads();
+    as_dma_rows(Ks, k + off, ld, N, R8, w, 4, lane);
+    as_dma_rows(Vs, v + off, ld, N, R8, w, 4, lane);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    for (int qt = w; qt < nt; qt += 4) {
+      f32x16 gq0 = as_zero16(), gq1 = as_zero16();
+      const int qrow = qt * 32 + l31;
+      const int qr = qrow < N ? qrow : N - 1;
+      s16x8 qf[4], gf[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { qf[ks] = *(const s16x8*)(q + off + (long)qr * ld + ks * 16 + hi * 8); gf[ks] = *(const s16x8*)(dout + offo + (long)qr * ldo + ks * 16 + hi * 8); }
+      const float lq = lse[((long)b * H + h) * N + qr] * VDK_LOG2E, dq_ = dvec[((long)b * H + h) * N + qr];
+      for (int kt = 0; kt < nt; ++kt) {
+        const int k0 = kt * 32;
+        f32x16 st = as_zero16(), dp = as_zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag(Ks, k0 + l31, ks, hi), qf[ks], st, 0, 0, 0);   // S^T[key][q]: lane = query, registers = keys
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag(Vs, k0 + l31, ks, hi), gf[ks], dp, 0, 0, 0);   // dP^T[key][q]
+        }
+        f32x16 ds;
+        const bool edge = ragged && (kt == nt - 1 || qt == nt - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float p = fast_exp2(fmaf(st[r], scale2, -lq));
+          if (edge && (k0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= N || qrow >= N)) p = 0.f;
+          ds[r] = p * (dp[r] - dq_);
+        }
+        s16x8 df[2];
+        as_pack_b(ds, df);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          gq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Ks, k0 + 16 * s, 0, lane), df[s], gq0, 0, 0, 0);     // dQ^T[d][q] += K^T dS^T
+          gq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Ks, k0 + 16 * s, 32, lane), df[s], gq1, 0, 0, 0);
+        }
+      }
+      as_store_tile(Wt, gq0, gq1, scale, dq + (long)b * N * ldd + h * 64, ldd, qt * 32, N, lane);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------------
 template <int NKT>
 static int launch_fwd(const bf16_t* base, long D, long ld, bf16_t* o, long ldo, float* lse, int B, int N, int H, float scale, int grid, hipStream_t s) {
@@ -377,7 +693,42 @@ static int launch_bwd(const bf16_t* base, long D, long ld, const bf16_t* o, cons
                      N, H, scale, B * H, dbg);
   return VDK_OK;
 }
+template <int NKT>
+static int launch_bwd2(const bf16_t* base, long D, long ld, const bf16_t* o, const bf16_t* dout, long ldo, const float* lse, bf16_t* dbase, long ldd, int B, int N, int H,
+                       float scale, int grid, hipStream_t s) {
+  const int R8 = (N + 7) & ~7, NP = 32 * NKT;
+  const size_t lds = (size_t)(3 * R8 + NP) * AS_ROW + 8 * 4096 + (size_t)NP * 8;   // Q | K | V | dO + zero rows | wave store tiles | lse2, D
+  if (lds > 160 * 1024) return VDK_EUNSUPPORTED;
+  if (hipFuncSetAttribute((const void*)attn_s_bwd2_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return vdk_fail(VDK_ELAUNCH, "vdk_attention_bwd: LDS attribute");
+  hipLaunchKernelGGL((attn_s_bwd2_kernel<NKT>), dim3((unsigned)grid), dim3(512), lds, s, base, base + D, base + 2 * D, ld, o, dout, ldo, lse, dbase, dbase + D, dbase + 2 * D, ldd,
+                     N, H, scale, B * H);
+  return VDK_OK;
+}
+static int grid_cap3(int dflt);
+template <int NKT>
+static int launch_bwd3(const bf16_t* base, long D, long ld, const bf16_t* o, const bf16_t* dout, long ldo, const float* lse, float* dvec, bf16_t* dbase, long ldd, int B, int N,
+                       int H, float scale, hipStream_t s) {
+  const int R8 = (N + 7) & ~7, NP = 32 * NKT;
+  const size_t lds_kv = (size_t)(R8 + NP) * AS_ROW + 4 * 4096 + (size_t)NP * 8, lds_q = (size_t)(R8 + NP) * AS_ROW + 4 * 4096;
+  if (lds_kv > 80 * 1024 || !dvec) return VDK_EUNSUPPORTED;             // two workgroups per CU are the point
+  if (hipFuncSetAttribute((const void*)attn_s_bwd_kv_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv) != hipSuccess ||
+      hipFuncSetAttribute((const void*)attn_s_bwd_q_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q) != hipSuccess)
+    return vdk_fail(VDK_ELAUNCH, "vdk_attention_bwd: LDS attribute");
+  int grid = B * H;
+  const int cap = grid_cap3(512);
+  if (grid > cap) grid = cap;
+  hipLaunchKernelGGL((attn_s_bwd_kv_kernel<NKT>), dim3((unsigned)grid), dim3(256), lds_kv, s, base, base + D, base + 2 * D, ld, o, dout, ldo, lse, dvec, dbase + D, dbase + 2 * D, ldd,
+                     N, H, scale, B * H);
+  hipLaunchKernelGGL((attn_s_bwd_q_kernel<NKT>), dim3((unsigned)grid), dim3(256), lds_q, s, base, base + D, base + 2 * D, ld, dout, ldo, lse, (const float*)dvec, dbase, ldd, N, H,
+                     scale, B * H);
+  return VDK_OK;
+}
+static int g_bwd_form = -1;        // -1: environment VDK_ATTN_BWD_FORM (default 3); 3 = split recompute form (two kernels, 2 workgroups / CU), 2 = one-kernel recompute form, 1 = fused form with the shared dQ tile
+int vdk_attention_small_bwd_form(int form) { g_bwd_form = form; return VDK_OK; }
 
+static int grid_cap(int dflt);
+static int grid_cap3(int dflt) { return grid_cap(dflt); }
 static int grid_cap(int dflt) {
   if (const char* e = getenv("VDK_ATTN_GRID")) { const int v = atoi(e); if (v > 0) return v; }   // tests: force several items per workgroup
   return dflt;
@@ -405,8 +756,8 @@ int vdk_attention_small_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, f
   }
 }
 
-int vdk_attention_small_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv, int64_t ldd, int32_t B, int32_t N, int32_t H,
-                            float scale, void* stream) {
+int vdk_attention_small_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv, int64_t ldd, float* dvec, int32_t B, int32_t N,
+                            int32_t H, float scale, void* stream) {
   const int nkt = (N + 31) / 32;
   if (nkt < 1 || nkt > 7) return VDK_EUNSUPPORTED;
   const bf16_t* base = (const bf16_t*)qkv;
@@ -415,7 +766,20 @@ int vdk_attention_small_bwd(const void* qkv, int64_t ld, const void* o, const vo
   const int cap = grid_cap(256);
   if (grid > cap) grid = cap;
   hipStream_t s = (hipStream_t)stream;
-#define BW(n) launch_bwd<n>(base, D, ld, (const bf16_t*)o, (const bf16_t*)dout, ldo, lse, (bf16_t*)dqkv, ldd, B, N, H, scale, grid, s)
+  int form = g_bwd_form;
+  if (form < 0) { const char* e = getenv("VDK_ATTN_BWD_FORM"); form = e ? atoi(e) : 3; }
+  if (form == 3) {
+    int rc = VDK_EUNSUPPORTED;
+    switch (nkt) {
+#define B3(n) case n: rc = launch_bwd3<n>(base, D, ld, (const bf16_t*)o, (const bf16_t*)dout, ldo, lse, dvec, (bf16_t*)dqkv, ldd, B, N, H, scale, s); break;
+      B3(1) B3(2) B3(3) B3(4) B3(5) B3(6) B3(7)
+#undef B3
+    }
+    if (rc != VDK_EUNSUPPORTED) return rc;
+    form = 2;
+  }
+#define BW(n) (form == 2 ? launch_bwd2<n>(base, D, ld, (const bf16_t*)o, (const bf16_t*)dout, ldo, lse, (bf16_t*)dqkv, ldd, B, N, H, scale, grid, s) \
+                         : launch_bwd<n>(base, D, ld, (const bf16_t*)o, (const bf16_t*)dout, ldo, lse, (bf16_t*)dqkv, ldd, B, N, H, scale, grid, s))
   switch (nkt) {
     case 1: return BW(1);
     case 2: return BW(2);
