@@ -51,6 +51,35 @@ __device__ __forceinline__ s16x8 as_tr_frag(const unsigned char* arr, int t1, in
   s16x8 r = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
   return r;
 }
+// Lane-only parts of the two fragment addresses.  as_f() looks at bits 1..3 of the row, so for a tile that starts at a multiple of 32 (row fragments) / 16 (transposed
+// fragments) the swizzle depends on the lane alone: address = array + tile_row0 * 128 + lane offset.  With the tile loops fully unrolled the middle term is an immediate of
+// the ds_read, and the ~20 VALU instructions per fragment address (266 VALU instructions per 16 MFMAs in the backward: PMC SQ_INSTS_VALU, 52 % VALU-active against 23 %
+// MFMA-busy) drop out of the inner loops.
+struct AsLane { int row[4]; int tr[2][2]; };
+__device__ __forceinline__ AsLane as_lane(int lane) {
+  AsLane a;
+  const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) a.row[ks] = l31 * AS_ROW + (((2 * ks + hi) ^ as_f(l31)) << 4);
+  const int s = lane & 15, chalf = (lane >> 4) & 1;
+  const int r1 = 4 * hi + (s >> 2), r2 = r1 + 8;
+#pragma unroll
+  for (int dh = 0; dh < 2; ++dh) {
+    const int byte = 64 * dh + 32 * chalf + 8 * (s & 3);
+    a.tr[dh][0] = r1 * AS_ROW + (((byte >> 4) ^ as_f(r1)) << 4) + (byte & 8);
+    a.tr[dh][1] = r2 * AS_ROW + (((byte >> 4) ^ as_f(r2)) << 4) + (byte & 8);
+  }
+  return a;
+}
+// row fragment of the 32-row tile at `tile` (= array + tile_row0 * AS_ROW)
+__device__ __forceinline__ s16x8 as_row_frag_l(const unsigned char* tile, const AsLane& a, int ks) { return *(const s16x8*)(tile + a.row[ks]); }
+// transposed fragment of the 16 rows at `tile`, column half dh (d0 = 32 * dh)
+__device__ __forceinline__ s16x8 as_tr_frag_l(const unsigned char* tile, const AsLane& a, int dh) {
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(tile + a.tr[dh][0]));
+  s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(tile + a.tr[dh][1]));
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+  return r;
+}
 __device__ __forceinline__ f32x16 as_zero16() {
   f32x16 z;
 #pragma unroll
@@ -106,6 +135,7 @@ __global__ __launch_bounds__(256, (NKT <= 7 ? 2 : 1)) void attn_s_fwd_kernel(con
   for (int i = tid * 16; i < (32 * NKT - R8) * AS_ROW; i += 256 * 16) *(u32x4*)(Vs + R8 * AS_ROW + i) = (u32x4){0u, 0u, 0u, 0u};
   const int nqt = (N + 31) >> 5;
   const float scale2 = scale * VDK_LOG2E;
+  const AsLane al = as_lane(lane);
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int b = item / H, h = item - b * H;
     const long off = (long)b * N * ld + h * 64;
@@ -125,7 +155,7 @@ __global__ __launch_bounds__(256, (NKT <= 7 ? 2 : 1)) void attn_s_fwd_kernel(con
       for (int kt = 0; kt < NKT; ++kt) {
         st[kt] = as_zero16();
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag(Ks, kt * 32 + l31, ks, hi), qf[ks], st[kt], 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks) st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Ks + kt * 32 * AS_ROW, al, ks), qf[ks], st[kt], 0, 0, 0);
       }
       if (N & 31) {                                    // ragged last key tile (wave-uniform)
 #pragma unroll
@@ -156,8 +186,8 @@ __global__ __launch_bounds__(256, (NKT <= 7 ? 2 : 1)) void attn_s_fwd_kernel(con
         as_pack_b(pn, pf);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Vs, kt * 32 + 16 * s, 0, lane), pf[s], o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Vs, kt * 32 + 16 * s, 32, lane), pf[s], o1, 0, 0, 0);
+          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Vs + (kt * 32 + 16 * s) * AS_ROW, al, 0), pf[s], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Vs + (kt * 32 + 16 * s) * AS_ROW, al, 1), pf[s], o1, 0, 0, 0);
         }
       }
       as_store_tile(Qs + qt * 32 * AS_ROW, o0, o1, 1.0f, o + (long)b * N * ldo + h * 64, ldo, qt * 32, N, lane);
@@ -532,6 +562,7 @@ __global__ __launch_bounds__(256, 2) void attn_s_bwd_kv_kernel(const bf16_t* __r
   const int nt = (N + 31) >> 5;
   const float scale2 = scale * VDK_LOG2E;
   const bool ragged = (N & 31) != 0;
+  const AsLane al = as_lane(lane);
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int b = item / H, h = item - b * H;
     const long off = (long)b * N * ld + h * 64, offo = (long)b * N * ldo + h * 64;
@@ -568,16 +599,19 @@ __global__ __launch_bounds__(256, 2) void attn_s_bwd_kv_kernel(const bf16_t* __r
       s16x8 kf[4], vf[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) { kf[ks] = *(const s16x8*)(k + off + kr + ks * 16 + hi * 8); vf[ks] = *(const s16x8*)(v + off + kr + ks * 16 + hi * 8); }
-      for (int qt = 0; qt < nt; ++qt) {
+#pragma unroll
+      for (int qt = 0; qt < NKT; ++qt) {                              // (the launcher instantiates NKT == number of tiles)
         const int q0 = qt * 32;
         f32x16 st = as_zero16(), dp = as_zero16();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag(Qs, q0 + l31, ks, hi), kf[ks], st, 0, 0, 0);   // S[q][key]: lane = key, registers = queries
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag(Os, q0 + l31, ks, hi), vf[ks], dp, 0, 0, 0);   // dP[q][key]
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Qs + q0 * AS_ROW, al, ks), kf[ks], st, 0, 0, 0);   // S[q][key]: lane = key, registers = queries
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Os + q0 * AS_ROW, al, ks), vf[ks], dp, 0, 0, 0);   // dP[q][key]
         }
         f32x16 pv, ds;
-        const bool edge = ragged && (qt == nt - 1 || kt == nt - 1);
+        // Masking: only rows of the last query tile beyond N must be silenced (they would add into valid sums).  Lanes of keys beyond N need nothing: a lane is a column
+        // of S, dP, dV^T and dK^T, whatever it holds stays in its own column, and those columns are never stored.
+        const bool edge = ragged && qt == NKT - 1;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 lv = *(const f32x4*)(lse2 + q0 + 8 * g + 4 * hi);
@@ -586,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void attn_s_bwd_kv_kernel(const bf16_t* __r
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * g + e;
             float p = fast_exp2(fmaf(st[r], scale2, -lv[e]));
-            if (edge && (q0 + 8 * g + 4 * hi + e >= N || krow >= N)) p = 0.f;
+            if (edge && q0 + 8 * g + 4 * hi + e >= N) p = 0.f;
             pv[r] = p;
             ds[r] = p * (dp[r] - dd[e]);
           }
@@ -595,11 +629,11 @@ __global__ __launch_bounds__(256, 2) void attn_s_bwd_kv_kernel(const bf16_t* __r
         as_pack_b(pv, pf);
         as_pack_b(ds, df);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          gv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Os, q0 + 16 * s, 0, lane), pf[s], gv0, 0, 0, 0);     // dV^T[d][key] += dO^T P
-          gv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Os, q0 + 16 * s, 32, lane), pf[s], gv1, 0, 0, 0);
-          gk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Qs, q0 + 16 * s, 0, lane), df[s], gk0, 0, 0, 0);     // dK^T[d][key] += Q^T dS
-          gk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Qs, q0 + 16 * s, 32, lane), df[s], gk1, 0, 0, 0);
+        for (int s2 = 0; s2 < 2; ++s2) {
+          gv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Os + (q0 + 16 * s2) * AS_ROW, al, 0), pf[s2], gv0, 0, 0, 0);     // dV^T[d][key] += dO^T P
+          gv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Os + (q0 + 16 * s2) * AS_ROW, al, 1), pf[s2], gv1, 0, 0, 0);
+          gk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Qs + (q0 + 16 * s2) * AS_ROW, al, 0), df[s2], gk0, 0, 0, 0);     // dK^T[d][key] += Q^T dS
+          gk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Qs + (q0 + 16 * s2) * AS_ROW, al, 1), df[s2], gk1, 0, 0, 0);
         }
       }
       as_store_tile(Wt, gk0, gk1, scale, dk + (long)b * N * ldd + h * 64, ldd, kt * 32, N, lane);
@@ -624,6 +658,7 @@ __global__ __launch_bounds__(256, 2) void attn_s_bwd_q_kernel(const bf16_t* __re
   const int nt = (N + 31) >> 5;
   const float scale2 = scale * VDK_LOG2E;
   const bool ragged = (N & 31) != 0;
+  const AsLane al = as_lane(lane);
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int b = item / H, h = item - b * H;
     const long off = (long)b * N * ld + h * 64, offo = (long)b * N * ldo + h * 64;
@@ -640,28 +675,31 @@ __global__ __launch_bounds__(256, 2) void attn_s_bwd_q_kernel(const bf16_t* __re
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) { qf[ks] = *(const s16x8*)(q + off + (long)qr * ld + ks * 16 + hi * 8); gf[ks] = *(const s16x8*)(dout + offo + (long)qr * ldo + ks * 16 + hi * 8); }
       const float lq = lse[((long)b * H + h) * N + qr] * VDK_LOG2E, dq_ = dvec[((long)b * H + h) * N + qr];
-      for (int kt = 0; kt < nt; ++kt) {
+      // (explicit software pipelining of the fragment reads -- next pair's row fragments and this pair's transposed fragments requested before the exponentials -- was
+      //  measured: no gain here, and in the kv kernel it cost 80 spilled registers: 388 vs 309 us.  The per-item fixed costs dominate: operand loads, D, barriers, stores.)
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
         const int k0 = kt * 32;
         f32x16 st = as_zero16(), dp = as_zero16();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag(Ks, k0 + l31, ks, hi), qf[ks], st, 0, 0, 0);   // S^T[key][q]: lane = query, registers = keys
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag(Vs, k0 + l31, ks, hi), gf[ks], dp, 0, 0, 0);   // dP^T[key][q]
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Ks + k0 * AS_ROW, al, ks), qf[ks], st, 0, 0, 0);   // S^T[key][q]: lane = query, registers = keys
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Vs + k0 * AS_ROW, al, ks), gf[ks], dp, 0, 0, 0);   // dP^T[key][q]
         }
         f32x16 ds;
-        const bool edge = ragged && (kt == nt - 1 || qt == nt - 1);
+        const bool edge = ragged && kt == NKT - 1;                     // keys beyond N in the last key tile; a lane (= query) beyond N only spoils its own, unstored column
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float p = fast_exp2(fmaf(st[r], scale2, -lq));
-          if (edge && (k0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= N || qrow >= N)) p = 0.f;
+          if (edge && k0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= N) p = 0.f;
           ds[r] = p * (dp[r] - dq_);
         }
         s16x8 df[2];
         as_pack_b(ds, df);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          gq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Ks, k0 + 16 * s, 0, lane), df[s], gq0, 0, 0, 0);     // dQ^T[d][q] += K^T dS^T
-          gq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag(Ks, k0 + 16 * s, 32, lane), df[s], gq1, 0, 0, 0);
+        for (int s2 = 0; s2 < 2; ++s2) {
+          gq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Ks + (k0 + 16 * s2) * AS_ROW, al, 0), df[s2], gq0, 0, 0, 0);     // dQ^T[d][q] += K^T dS^T
+          gq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Ks + (k0 + 16 * s2) * AS_ROW, al, 1), df[s2], gq1, 0, 0, 0);
         }
       }
       as_store_tile(Wt, gq0, gq1, scale, dq + (long)b * N * ldd + h * 64, ldd, qt * 32, N, lane);
