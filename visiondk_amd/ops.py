@@ -170,7 +170,8 @@ def attention_bwd(qkv, o, dout, lse, heads: int, scale: Optional[float] = None, 
     scale = hd ** -0.5 if scale is None else scale
     dqkv = torch.empty_like(qkv)
     dvec = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
-    be.check(be.lib.vdk_attention_bwd(be.ptr(qkv), three_d, be.ptr(o), be.ptr(dout.contiguous()), D, be.ptr(lse), be.ptr(dqkv),
+    dout = dout.contiguous()      # keep the (possibly new) tensor alive across the launch: a temporary would be freed before the kernel is enqueued
+    be.check(be.lib.vdk_attention_bwd(be.ptr(qkv), three_d, be.ptr(o), be.ptr(dout), D, be.ptr(lse), be.ptr(dqkv),
                                       three_d, be.ptr(dvec), B, N, heads, hd, scale, be.stream()), "vdk_attention_bwd")
     return dqkv
 
@@ -396,7 +397,8 @@ def conv2x2_wgrad_unpermute(dwp: torch.Tensor, Ci: int, backend=None) -> torch.T
     be = _be(backend)
     Co = dwp.shape[0]
     dw = torch.empty((Co, Ci, 2, 2), dtype=torch.float32, device=dwp.device)
-    be.check(be.lib.vdk_conv2x2_wgrad_unpermute(be.ptr(dwp.contiguous()), be.ptr(dw), Co, Ci, be.stream()), "vdk_conv2x2_wgrad_unpermute")
+    dwp = dwp.contiguous()      # keep the (possibly new) tensor alive across the launch: a temporary would be freed before the kernel is enqueued
+    be.check(be.lib.vdk_conv2x2_wgrad_unpermute(be.ptr(dwp), be.ptr(dw), Co, Ci, be.stream()), "vdk_conv2x2_wgrad_unpermute")
     return dw
 
 
@@ -406,7 +408,8 @@ def layerscale_weight_prep(w2: torch.Tensor, b2: torch.Tensor, gamma: torch.Tens
     w2p = torch.empty((Cc, M), dtype=torch.bfloat16, device=w2.device)
     w2pt = torch.empty((M, Cc), dtype=torch.bfloat16, device=w2.device)
     b2p = torch.empty(Cc, dtype=torch.float32, device=w2.device)
-    be.check(be.lib.vdk_layerscale_weight_prep(be.ptr(w2.contiguous()), be.ptr(b2), be.ptr(gamma), be.ptr(w2p), be.ptr(w2pt), be.ptr(b2p), Cc, M, be.stream()),
+    w2 = w2.contiguous()      # keep the (possibly new) tensor alive across the launch: a temporary would be freed before the kernel is enqueued
+    be.check(be.lib.vdk_layerscale_weight_prep(be.ptr(w2), be.ptr(b2), be.ptr(gamma), be.ptr(w2p), be.ptr(w2pt), be.ptr(b2p), Cc, M, be.stream()),
              "vdk_layerscale_weight_prep")
     return w2p, w2pt, b2p
 
@@ -415,7 +418,9 @@ def layerscale_grad(dw2p: torch.Tensor, db2p: torch.Tensor, w2: torch.Tensor, b2
     be = _be(backend)
     Cc, M = w2.shape
     dw2 = torch.empty_like(w2); db2 = torch.empty_like(b2); dg = torch.empty_like(gamma)
-    be.check(be.lib.vdk_layerscale_grad(be.ptr(dw2p.contiguous()), be.ptr(db2p), be.ptr(w2.contiguous()), be.ptr(b2), be.ptr(gamma), be.ptr(dw2), be.ptr(db2),
+    dw2p = dw2p.contiguous()      # keep the (possibly new) tensor alive across the launch: a temporary would be freed before the kernel is enqueued
+    w2 = w2.contiguous()      # keep the (possibly new) tensor alive across the launch: a temporary would be freed before the kernel is enqueued
+    be.check(be.lib.vdk_layerscale_grad(be.ptr(dw2p), be.ptr(db2p), be.ptr(w2), be.ptr(b2), be.ptr(gamma), be.ptr(dw2), be.ptr(db2),
                                         be.ptr(dg), Cc, M, be.stream()), "vdk_layerscale_grad")
     return dw2, db2, dg
 
@@ -513,7 +518,8 @@ def conv_wgrad_unpermute(dwp: torch.Tensor, ci: int, kh: int, kw: int, backend=N
     Co = dwp.shape[0]
     cip = dwp.shape[1] // (kh * kw)
     dw = torch.empty((Co, ci, kh, kw), dtype=torch.float32, device=dwp.device)
-    be.check(be.lib.vdk_conv_wgrad_unpermute(be.ptr(dwp.contiguous()), be.ptr(dw), Co, ci, cip, kh, kw, be.stream()), "vdk_conv_wgrad_unpermute")
+    dwp = dwp.contiguous()      # keep the (possibly new) tensor alive across the launch: a temporary would be freed before the kernel is enqueued
+    be.check(be.lib.vdk_conv_wgrad_unpermute(be.ptr(dwp), be.ptr(dw), Co, ci, cip, kh, kw, be.stream()), "vdk_conv_wgrad_unpermute")
     return dw
 
 
@@ -521,7 +527,8 @@ def nchw_to_nhwc_bf16(x: torch.Tensor, cp: int, backend=None) -> torch.Tensor:
     be = _be(backend)
     B, Cc, H, W = x.shape
     out = torch.empty((B, H, W, cp), dtype=torch.bfloat16, device=x.device)
-    be.check(be.lib.vdk_nchw_to_nhwc_bf16(be.ptr(x.contiguous()), be.ptr(out), B, Cc, H, W, cp, be.stream()), "vdk_nchw_to_nhwc_bf16")
+    x = x.contiguous()      # keep the (possibly new) tensor alive across the launch: a temporary would be freed before the kernel is enqueued
+    be.check(be.lib.vdk_nchw_to_nhwc_bf16(be.ptr(x), be.ptr(out), B, Cc, H, W, cp, be.stream()), "vdk_nchw_to_nhwc_bf16")
     return out
 
 
@@ -575,5 +582,6 @@ def maxpool3s2_bwd(x_nhwc: torch.Tensor, dout: torch.Tensor, argmax: Optional[to
     be = _be(backend)
     B, H, W, Cc = x_nhwc.shape
     din = torch.empty((B, H, W, Cc), dtype=torch.float32, device=x_nhwc.device)
-    be.check(be.lib.vdk_maxpool3s2_bwd(be.ptr(x_nhwc), be.ptr(argmax), be.ptr(dout.contiguous()), be.ptr(din), B, H, W, Cc, be.stream()), "vdk_maxpool3s2_bwd")
+    dout = dout.contiguous()      # keep the (possibly new) tensor alive across the launch: a temporary would be freed before the kernel is enqueued
+    be.check(be.lib.vdk_maxpool3s2_bwd(be.ptr(x_nhwc), be.ptr(argmax), be.ptr(dout), be.ptr(din), B, H, W, Cc, be.stream()), "vdk_maxpool3s2_bwd")
     return din
