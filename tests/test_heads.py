@@ -1,7 +1,7 @@
 """K11 margin heads vs the golden outputs of the REFERENCE's own ArcFace / CircleLoss / MV_Softmax modules
 (tests/golden/heads.npz, made by tests/golden/make_golden.py).  The GEMMs use bf16 MFMA operands: cos errors of a few 1e-4
 are amplified by the scale (32 / 256) in the logits, so logits are compared in units of the scale; gradients flow through
-single-plane bf16 GEMMs (dcos, f^, W^ rounded to bf16): a few 1e-3 relative."""
+single-plane bf16 GEMMs (dcos, f^, W^ rounded to bf16): 2e-3 ... 3e-3 relative against the reference's modules (bound 8e-3)."""
 from pathlib import Path
 
 import numpy as np
@@ -43,8 +43,8 @@ def test_head_logits_loss_and_grads_vs_reference(be, dev, tag):
     loss = torch.nn.functional.cross_entropy(logits, labels)
     loss.backward()
     assert abs(loss.item() - float(z[f"{tag}_loss"])) < 1e-4 * abs(float(z[f"{tag}_loss"])) + 1e-4
-    assert _rel(feats.grad, z[f"{tag}_dfeats"]) < 5e-2
-    assert _rel(h.weight.grad, z[f"{tag}_dweight"]) < 5e-2
+    assert _rel(feats.grad, z[f"{tag}_dfeats"]) < 8e-3        # measured 2.0e-3 ... 2.8e-3 (dcos, f^ and W^ enter the backward GEMMs rounded to bf16 once)
+    assert _rel(h.weight.grad, z[f"{tag}_dweight"]) < 8e-3
     # fused form == the autograd form
     loss_rows, df, dW = h.margin_ce(feats.detach(), labels)
     assert abs(loss_rows.mean().item() - loss.item()) < 1e-5 * abs(loss.item()) + 1e-6
