@@ -416,3 +416,50 @@ def test_two_rank_face_step_with_sync_batchnorm_equals_whole_batch(tmp_path, emu
             da, db = a - init[k].float(), b - init[k].float()
             rel = ((da - db).norm() / db.norm().clamp_min(1e-12)).item()
             assert rel < 3e-2, (k, rel)
+
+
+# ---- SigLIP-family model (no class token + attention-pool head): MapTrainStep over 2 ranks, plain and SAM -----------------------------------------
+def _map_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["VDK_EMU_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.emu.emu_backend import load_emu
+    from visiondk_amd import comm, vit
+    be = load_emu()
+    out = {}
+    for sam in (False, True):
+        torch.manual_seed(100 + rank)                     # ranks start DIFFERENT on purpose: the constructor broadcasts rank 0's weights (trunk and head)
+        model = vit.VisionTransformerMap(vit.VitSpec(img_size=32, patch_size=8, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256, class_token=False), device="cpu",
+                                         backend=be, seed=100 + rank)
+        c = comm.GradAllReduce(bucket_bytes=200_000)
+        step = vit.MapTrainStep(model, lr=0.02, momentum=0.9, weight_decay=5e-4, label_smoothing=0.05, ema=False, sam=sam, comm=c)
+        torch.manual_seed(7)
+        x = torch.randn(4, 3, 32, 32); y = torch.randint(0, 10, (4,))
+        step.step(x[rank * 2:rank * 2 + 2], y[rank * 2:rank * 2 + 2])
+        out[sam] = {"params": step.big.clone(), "grads": step.gbig.clone(), "collectives": c.collectives}
+    torch.save(out, f"{out_dir}/rank{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_two_rank_map_step_equals_single_process(tmp_path, emu):
+    port = 29500 + (os.getpid() % 500)
+    mp.start_processes(_map_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "rank0.pt"); r1 = torch.load(tmp_path / "rank1.pt")
+    from visiondk_amd import vit
+    for sam in (False, True):
+        assert torch.equal(r0[sam]["params"], r1[sam]["params"]) and torch.equal(r0[sam]["grads"], r1[sam]["grads"])      # replicas bit-identical
+        assert r0[sam]["collectives"] >= 3                   # broadcast + the head bucket + at least one trunk bucket
+        torch.manual_seed(100)
+        model = vit.VisionTransformerMap(vit.VitSpec(img_size=32, patch_size=8, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256, class_token=False), device="cpu",
+                                         backend=emu, seed=100)
+        step = vit.MapTrainStep(model, lr=0.02, momentum=0.9, weight_decay=5e-4, label_smoothing=0.05, ema=False, sam=sam)
+        p0 = step.big.clone()
+        torch.manual_seed(7)
+        x = torch.randn(4, 3, 32, 32); y = torch.randint(0, 10, (4,))
+        step.step(x, y)
+        d_single = step.big - p0; d_ddp = r0[sam]["params"] - p0
+        rel = ((d_ddp - d_single).norm() / d_single.norm()).item()
+        assert rel < (3e-2 if not sam else 2e-1), (sam, rel)      # SAM: the first pass is local (per-rank e(w)), as in the reference's no_sync()

@@ -654,11 +654,14 @@ class MapTrainStep:
     """FusedTrainStep for VisionTransformerMap (class_token=False + attention-pool head): the same Trainer.compute_loss / update / update_sam sequence
     (train.py:150-215) over ONE flat fp32 buffer that holds the engine's parameters followed by the attn_pool / head parameters, so the gradient norm, SAM's
     e(w), the clipped SGD step and the EMA are single kernels over everything.  The trunk runs through the engine's forward / backward directly (no autograd
-    copies of 300 M gradients); only the pooled [B, D] tail goes through autograd nodes.  Single process (no gradient exchange hooks yet)."""
+    copies of 300 M gradients); only the pooled [B, D] tail goes through autograd nodes.  comm (GradAllReduce): data parallel like FusedTrainStep -- the pooling head's
+    gradients (produced first) leave as one bucket, the trunk's in flat buckets from inside vdk_vit_backward, overlapped with the rest of the backward; the SAM
+    step's first pass stays local (model.no_sync(), train.py:157-159)."""
 
     def __init__(self, model: VisionTransformerMap, lr: float, momentum: float = 0.937, weight_decay: float = 5e-4, label_smoothing: float = 0.0,
-                 max_norm: float = 10.0, ema: bool = True, sam: bool = False, sam_rho: float = 0.05, sam_adaptive: bool = True):
+                 max_norm: float = 10.0, ema: bool = True, sam: bool = False, sam_rho: float = 0.05, sam_adaptive: bool = True, comm=None):
         self.model, self.eng = model, model.engine
+        self.comm = comm
         eng = self.eng
         self.be = eng.be
         dev = eng.device
@@ -695,8 +698,12 @@ class MapTrainStep:
         self._sumsq_ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
         self.updates = 0
         self._loss_rows = None
+        if comm is not None and comm.active:          # DDP-constructor semantics: every rank starts from rank 0's weights (trunk and head alike)
+            comm.broadcast_params(self.big, src=0, engine=eng)
+            if self.ema is not None:
+                self.ema.copy_(self.big)
 
-    def _fwd_loss_bwd(self, x, y, y_b, lam):
+    def _fwd_loss_bwd(self, x, y, y_b, lam, sync: bool = True):
         eng, m = self.eng, self.model
         B = x.shape[0]
         self.gbig[eng.n_floats:].zero_()
@@ -705,7 +712,15 @@ class MapTrainStep:
         logits = _LinearFn.apply(pooled, m.head.weight, m.head.bias, self.be)
         self._loss_rows, _, dlf = ops.softmax_ce(logits.detach().contiguous(), y, y_b, lam, self.label_smoothing, 1.0 / B, backend=self.be)
         logits.backward(dlf)
-        eng.backward(tokens.grad.contiguous().view(-1, eng.spec.dim))
+        dtok = tokens.grad.contiguous().view(-1, eng.spec.dim)
+        if self.comm is not None and sync and self.comm.active:
+            self.comm.begin_step(self.gbig)
+            self.comm.on_grad_ready(eng.n_floats, self.n_total - eng.n_floats)      # the head's gradients are complete: first bucket
+            self.comm._flush()
+            eng.backward(dtok, on_ready=self.comm.on_grad_ready)
+            self.comm.finish_step()
+        else:
+            eng.backward(dtok)
         eng.fp8_update()
 
     def step(self, x: torch.Tensor, y: torch.Tensor, y_b: Optional[torch.Tensor] = None, lam: float = 1.0) -> torch.Tensor:
@@ -718,17 +733,18 @@ class MapTrainStep:
         d = 0.9999 * (1 - math.exp(-self.updates / 2000)) if self.ema is not None else 0.0
         first = int(self.updates == 1)
         nx = self.n_total - n
+        gs = 1.0 / (self.comm.world_size if self.comm is not None else 1)
 
         def sgd(normsq):
             be.check(be.lib.vdk_sgd_step(be.ptr(self.big), be.ptr(self.gbig), be.ptr(self.momentum_buf), be.ptr(self.ema), be.ptr(eng.wb16), n, lr, momentum,
-                                         weight_decay, 1.0, normsq, self.max_norm, d, first, be.stream()), "vdk_sgd_step")
+                                         weight_decay, gs, normsq, self.max_norm, d, first, be.stream()), "vdk_sgd_step")
             ex = lambda t: be.ptr(t[n:]) if t is not None else None
-            be.check(be.lib.vdk_sgd_step(ex(self.big), ex(self.gbig), ex(self.momentum_buf), ex(self.ema), None, nx, lr, momentum, weight_decay, 1.0, normsq,
+            be.check(be.lib.vdk_sgd_step(ex(self.big), ex(self.gbig), ex(self.momentum_buf), ex(self.ema), None, nx, lr, momentum, weight_decay, gs, normsq,
                                          self.max_norm, d, first, be.stream()), "vdk_sgd_step")
             eng.refresh_weights(skip_wb16=True)
 
         if self.sam:
-            self._fwd_loss_bwd(x, y, y_b, lam)
+            self._fwd_loss_bwd(x, y, y_b, lam, sync=False)
             loss_first = self._loss_rows.clone()
             be.check(be.lib.vdk_sam_first_step(be.ptr(self.big), be.ptr(self.gbig), be.ptr(self._old), self.n_total, self.sam_rho, int(self.sam_adaptive),
                                                be.ptr(self._normsq), be.ptr(self._sumsq_ws), self._sumsq_ws.numel(), be.stream()), "vdk_sam_first_step")
