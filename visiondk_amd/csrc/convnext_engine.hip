@@ -40,6 +40,7 @@ int vdk_layerscale_weight_prep(const float*, const float*, const float*, void*, 
 int vdk_layerscale_grad(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int32_t, int32_t, void*);
 int vdk_gemm_f32_nt(const VdkGemmF32Desc*, void*);
 int vdk_gemm_a_colsum_rows(int32_t, int32_t, int32_t);
+int vdk_gemm_c_colsum_rows(int32_t, int32_t, int32_t);
 int vdk_patchify_f32(const float*, int32_t, int32_t, int32_t, int32_t, int32_t, float*, void*);
 int vdk_space_to_depth2_f32(const float*, float*, int32_t, int32_t, int32_t, int32_t, void*);
 int vdk_avgpool_rows_f32_fwd(const float*, float*, int32_t, int32_t, int32_t, void*);
@@ -198,7 +199,7 @@ void cn_plan(const CnDims& d, WsPlan* w) {
     const size_t c1 = (size_t)((up(rows, 64) + 63) / 64) * out * 4;
     if (c2 > cs) cs = c2;
     if (c1 > cs) cs = c1;
-    { const size_t c3 = (size_t)((rows + 255) / 256) * out * 4; if (c3 > cs) cs = c3; }   // a_colsum by-product of the dgrad GEMM
+    { const size_t c3 = (size_t)2 * ((rows + 255) / 256) * out * 4; if (c3 > cs) cs = c3; }   // a_colsum / c_colsum by-products of the dgrad GEMMs
     if (rows % 64) { const size_t t = (size_t)(out > in ? out : in) * up(rows, 64) * 2; if (t > tr) tr = t; }
   };
   wg(d.C[0], d.Kst, d.R[0]);
@@ -453,11 +454,26 @@ int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout_, const
       const float* st = (const float*)(base + bw.stats);
       // dxa / dxb = dL/d(block output).  MLP branch with the layer scale folded into fc2; the bias gradients ride along with the dgrad GEMMs when possible
       int fz = 0;
+      // fc1.bias = column sums of du, accumulated by the dGELU epilogue that stores du (c_colsum: the PRODUCER sums what it writes); the fc2' bias is a column-sum pass over
+      // the [R, C] gradient dxb (4x narrower than du).  Both input-gradient GEMMs then run the plain 225-register variants instead of the a_colsum ones (256 + spills).
+      const int xrow = vdk_gemm_c_colsum_rows(R, M, C);
+      if (xrow > 0 && (size_t)xrow * M * 4 <= w.csws_bytes) {
+        VdkGemmDesc g = {};
+        g.A = dxb; g.lda = C; g.B = xb + bx.fc2pt; g.ldb = C; g.C = du; g.ldc = M; g.M = R; g.N = M; g.K = C; g.c_dtype = VDK_BF16; g.act = VDK_ACT_DGELU; g.aux = base + bw.u;
+        g.ldaux = M; g.alpha = 1.0f; g.splitk = 1; g.c_colsum = (float*)(base + w.csws);
+        RC(vdk_gemm_bf16_nt(&g, nullptr, 0, s));
+        RC(vdk_reduce_rows_f32((const float*)(base + w.csws), M, xrow, M, grads + b.fc1_b, 1.0f, s));
+        RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + bw.g), R, C, M, dw2p, db2p));          // db2p by vdk_colsum_bf16 inside
+        RC(vdk_layerscale_grad(dw2p, db2p, params + b.fc2_w, params + b.fc2_b, params + b.gamma, grads + b.fc2_w, grads + b.fc2_b, grads + b.gamma, C, M, s));
+        RC(gemm(s, du, M, xb + bx.fc1t, M, dh, C, R, C, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0));
+        RC(linear_wgrad(s, w, base, du, (const bf16_t*)(base + bw.h), R, M, C, grads + b.fc1_w, nullptr));
+      } else {
       RC(dgrad_with_bias(s, w, base, dxb, xb + bx.fc2pt, du, R, M, C, VDK_ACT_DGELU, base + bw.u, db2p, &fz));
       RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + bw.g), R, C, M, dw2p, fz ? nullptr : db2p));
       RC(vdk_layerscale_grad(dw2p, db2p, params + b.fc2_w, params + b.fc2_b, params + b.gamma, grads + b.fc2_w, grads + b.fc2_b, grads + b.gamma, C, M, s));
       RC(dgrad_with_bias(s, w, base, du, xb + bx.fc1t, dh, R, C, M, VDK_ACT_NONE, nullptr, grads + b.fc1_b, &fz));
       RC(linear_wgrad(s, w, base, du, (const bf16_t*)(base + bw.h), R, M, C, grads + b.fc1_w, fz ? nullptr : grads + b.fc1_b));
+      }
       RC(vdk_layernorm_bwd(dh, C, VDK_BF16, (const float*)(base + bw.t), C, st, st + R, params + b.nw, nullptr, 0, R, C, dt, C, nullptr, 0, grads + b.nw,
                            grads + b.nb, lnws, w.lnws_bytes, s));
       // depthwise conv: weight/bias gradient, then input gradient + shortcut gradient (in place on dxa) and its bf16 copy
