@@ -1047,7 +1047,7 @@ static size_t cb_fast_bytes(int64_t nq, int32_t k, int64_t cap, int DP) {
   b += cb_align((size_t)nq * DP * 2);    // Qb
   b += cb_align((size_t)nq * 12);        // query norms (||q||, ||q~||, ||q~ - q||)
   b += cb_align((size_t)nq * 4);         // carry
-  b += cb_align((size_t)nq * CF_BOOT_MAXG * 4 < (size_t)nq * 4 * k * 4 ? (size_t)nq * CF_BOOT_MAXG * 4 : (size_t)nq * 4 * k * 4);   // bootstrap group maxima [nq, G <= min(4k, 4096)]
+  b += cb_align((size_t)nq * CF_BOOT_MAXG * 4);   // bootstrap group maxima [nq, G <= 4096]
   return b;
 }
 int vdk_cbir_fast_workspace_bytes(int64_t nq, int32_t k, int64_t cap, size_t* bytes) {   // D <= 128
@@ -1112,7 +1112,8 @@ int vdk_cbir_search_fast2(const float* Q, int64_t nq, const void* G, int32_t g_d
   bool booted = false;
   // threshold bootstrap on a sample of NG full tiles, k <= NG <= min(4k, 4096)
   long NG = N / BG;
-  if (NG > 4L * k) NG = 4L * k;
+  static const long boot_mult = [] { const char* e = getenv("VDK_CBIR_BOOT_MULT"); const long v = e ? atol(e) : 0; return v > 0 ? v : 4L; }();   // sample = boot_mult * k tiles (tuning knob)
+  if (NG > boot_mult * k) NG = boot_mult * k;
   if (NG > CF_BOOT_MAXG) NG = CF_BOOT_MAXG;
   if (NG >= k) {
     long ns = 256 / qblocks;
