@@ -217,3 +217,21 @@ def test_many_stage_search_is_exact(be, dev, nq, n, k, cap, monkeypatch):
     so, io = ocbir.flat_ip_search(q, g, k)
     np.testing.assert_array_equal(i1, io)
     np.testing.assert_array_equal(s1.view(np.uint32), so.view(np.uint32))
+
+
+def test_small_candidate_lists_equal_guaranteed_schedule_and_fall_back_on_overflow(be, dev):
+    """FlatIPIndex(small_lists=True): same stages, 16 384-entry lists, overflow reported and repaired -> results bit-equal to the guaranteed schedule; an adversarial gallery of
+    identical rows (every row survives every threshold) overflows the small lists and must take the fallback."""
+    rng = np.random.default_rng(11)
+    g = ocbir.l2norm_rows(rng.standard_normal((6000, 128), dtype=np.float32)); q = ocbir.l2norm_rows(rng.standard_normal((70, 128), dtype=np.float32))
+    a = cbir.FlatIPIndex(128, backend=be, device=dev, cap=2048); a.add(g)
+    b = cbir.FlatIPIndex(128, backend=be, device=dev, cap=2048, small_lists=True); b.add(g)
+    sa, ia = a.search(q, 50); sb, ib = b.search(q, 50)
+    np.testing.assert_array_equal(ia, ib); np.testing.assert_array_equal(sa.view(np.uint32), sb.view(np.uint32))
+    so, io = ocbir.flat_ip_search(q, g, 50)
+    np.testing.assert_array_equal(ib, io)
+    same = np.repeat(g[:1], 40000, axis=0)
+    c = cbir.FlatIPIndex(128, backend=be, device=dev, cap=32768 + 64, small_lists=True); c.add(same)
+    sc, ic = c.search(q[:4], 10)
+    assert c.fallbacks == 1
+    np.testing.assert_array_equal(ic, np.tile(np.arange(10), (4, 1)))

@@ -24,6 +24,7 @@ METRIC_INNER_PRODUCT = 0  # faiss.METRIC_INNER_PRODUCT
 DEFAULT_CAP = 98304       # candidate-list capacity per query of the GUARANTEED schedule = rows per stage + k (csrc/cbir.hip).  Swept on the MI355X at 10 k x 1 M:
                           # 32 k 4.21 ms, 64 k 3.88, 96 k 3.54, 128 k 3.53, 192 k 3.69, 256 k 3.89 (fewer launches against looser thresholds per stage); the lists
                           # are address space more than memory: a search touches ~10^3 of a query's 98 304 slots
+SMALL_LIST_CAP = 16384    # staged schedule with small candidate lists (`small_lists=True`): stages of cap - k rows like the guaranteed schedule, lists of this many entries
 OPTIMISTIC_CAP = 8192     # ... of the optimistic schedule (bootstrap + two stages; ~10^3 survivors per query in a 10^6-row scan; overflow is detected and repaired)
 
 
@@ -42,7 +43,7 @@ class FlatIPIndex:
     """Exact inner-product index (faiss IndexFlatIP semantics; ties -> lower index; pads (-FLT_MAX, -1))."""
 
     def __init__(self, d: int, backend: Optional[_lib.Backend] = None, device=None, cap: int = DEFAULT_CAP,
-                 idx_base: int = 0, method: str = "auto", storage: str = "float32", optimistic: bool = False):
+                 idx_base: int = 0, method: str = "auto", storage: str = "float32", optimistic: bool = False, small_lists: bool = True):
         """method: "prefilter" = bf16-MFMA candidate filter with a rigorous error bound + exact fp32 re-scoring (d <= 512),
         "exact_scan" = every pair scored on the fp32 MFMA; "auto" picks prefilter when d <= 512.  Both return bit-identical
         results (tests/test_cbir.py runs every case through both).
@@ -75,6 +76,11 @@ class FlatIPIndex:
         if storage == "float16" and self.method != "prefilter":
             raise ValueError("float16 storage is served by the prefilter path (d <= 512)")
         self.optimistic = bool(optimistic)
+        # small_lists: the guaranteed schedule's stages (cap - k rows each) with candidate lists of SMALL_LIST_CAP entries instead of `cap`: the workspace shrinks from
+        # nq * cap * 8 B (7.9 GB at 10 k queries) to nq * 16 384 * 8 B (1.3 GB); a list that overflows is reported by the kernels and the search is repeated with the
+        # guaranteed schedule (one device flag read per search, like `optimistic`).  Default since round 2: measured equal in time (3.52-3.55 vs 3.56-3.58 ms at 10 k x 1 M), results
+        # bit-identical.  small_lists=False is the fully asynchronous guaranteed schedule (no host read, no data-dependent retry).
+        self.small_lists = bool(small_lists)
         self.fallbacks = 0                        # searches whose optimistic pass overflowed and were repeated with the guaranteed schedule
         self._gb: Optional[torch.Tensor] = None   # bf16 [N, DP] copy (DP = d rounded up to 128) + row-norm maxima, built once per gallery state
         self._gmax: Optional[torch.Tensor] = None
@@ -170,6 +176,13 @@ class FlatIPIndex:
                                                           self.idx_base, be.ptr(scores), be.ptr(idx), cap_, schedule, be.ptr(flag), be.ptr(ws), ws.numel(),
                                                           be.stream()), "vdk_cbir_search_fast2")
                 done = False
+                if self.small_lists and not self.optimistic:
+                    if getattr(self, "_flag", None) is None:
+                        self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+                    run(max(1024, cap - k), max(min(cap, SMALL_LIST_CAP), 2 * k), self._flag)      # schedule >= 1024 = stage length in rows
+                    done = int(self._flag.item()) == 0
+                    if not done:
+                        self.fallbacks += 1
                 if self.optimistic:
                     if getattr(self, "_flag", None) is None:
                         self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)

@@ -1107,7 +1107,9 @@ int vdk_cbir_search_fast2(const float* Q, int64_t nq, const void* G, int32_t g_d
   if (hipMemsetAsync(carry, 0, (size_t)nq * 4, stream) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vdk_cbir_search_fast2: memset failed");
   hipLaunchKernelGGL(cbir_cast_rows_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, Q, (long)nq, (int)D, DP, Qb, qnorm);
   const long qblocks = (long)((nq + QB - 1) / QB);
-  const long max_stage = cap - k;
+  // schedule >= 1024: staged like the guaranteed schedule, but the stage length is `schedule` rows whatever the list capacity: the lists hold `cap` entries (a stage yields
+  // ~10^2 survivors per query behind a bootstrap threshold, not its 10^5 rows), overflow is REPORTED through *overflow_out and the caller repeats with schedule 0.
+  const long max_stage = schedule >= 1024 ? (long)schedule : cap - k;
   long begin = 0, stage = 512;
   bool booted = false;
   // threshold bootstrap on a sample of NG full tiles, k <= NG <= min(4k, 4096)
