@@ -501,6 +501,15 @@ int vdk_colnorm_bwd(const float* W, int64_t ldw, const float* inv, const float* 
  * K = 3D GEMM fbt^T . Wb accumulates hi*hi + lo*hi + hi*lo (fp32-class cos); rows/cols B..Bp-1 zero; inv f32 [B] */
 int vdk_rownorm_fwd(const float* f, int32_t B, int32_t Bp, int32_t D, float eps, float* fh, void* fb, void* fbt, float* inv, int32_t planes, void* stream);
 int vdk_rownorm_bwd(const float* fh, const float* inv, const float* dfh, int64_t lddfh, int32_t B, int32_t D, float* df, void* stream);
+/* The fused form of the wide heads (the B x C cosines never reach memory as fp32): the cos GEMM f^ W^ (TN: fbt bf16 [K, Bp], wb bf16 [K, Cp]; K = D or 3 D split
+ * planes) runs twice with the head applied to the tile in registers.  pass 1 -> stats f32 [B][ceil(Cp / 64)][4] (per 64-column slice: max logit, sum exp(logit - max), sum
+ * logit) and tlogit [B]; vdk_margin_rowstat -> rowstat f32 [B][2] = (row max, 1 / sum exp) and loss_rows; pass 2 -> dcos bf16 [Bp, lddc] = grad_scale * dLoss/dcos (rows >= B,
+ * columns >= C zero).  gt (MV-Softmax only, else NULL): the target cosines, vdk_margin_target_cos_direct.  VDK_EUNSUPPORTED when the 256x256 TN kernel cannot serve the shape. */
+int vdk_margin_cos_pass(const VdkMarginHead* h, int32_t pass, const void* fbt, int64_t ld_f, const void* wb, int64_t ld_w, int32_t B, int32_t Bp, int32_t C, int32_t Cp, int32_t K,
+                        const int64_t* labels, const float* gt, float* stats, float* tlogit, const float* rowstat, float label_smoothing, float grad_scale, void* dcos,
+                        int64_t lddc, void* stream);
+int vdk_margin_rowstat(const float* stats, int64_t nslice, const float* tlogit, int32_t B, int32_t C, float label_smoothing, float* rowstat, float* loss_rows, void* stream);
+int vdk_margin_target_cos_direct(const void* fbt, int64_t ld_f, const void* wb, int64_t ld_w, int32_t K, int32_t B, const int64_t* labels, float* gt, void* stream);   /* gt[b] = sum_k fbt[k][b] wb[k][y_b] */
 /* cos f32 [B, ldc] -> any of: logits f32 [B, ldl] (what the reference head returns), loss_rows f32 [B] (CE with optional label
  * smoothing), dcos bf16 [B, lddc] = grad_scale * dLoss/dcos (padding columns zeroed) */
 int vdk_margin_ce(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t C, const int64_t* labels, float label_smoothing,

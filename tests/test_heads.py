@@ -146,3 +146,26 @@ def test_tiled_column_normalisation_and_single_plane_cos(be, dev, D, C):
         lr, df, dW = h.margin_ce(feats.to(dev), labels.to(dev), cos_planes=planes)
         assert abs(lr.mean().item() - loss.item()) < (1e-4 if planes == 3 else 5e-3) * abs(loss.item())
         assert _rel(df, fr.grad) < tol and _rel(dW, wr.grad) < tol
+
+
+@pytest.mark.parametrize("tag,planes", [("arcface", 3), ("arcface", 1), ("circle", 3), ("mv_am", 3), ("mv_arc", 1)])
+def test_epilogue_fused_head_equals_materialised_form(be, dev, tag, planes):
+    """margin_ce(fused=True): the cos GEMM runs twice with the head in its epilogue (pass 1: per-slice softmax partials, pass 2: d cos from the row statistics), cos never
+    written as fp32 -- against the form that materialises cos (same GEMM operands, same margin code): loss rows 1e-5, gradients 2e-3 (dcos is rounded to bf16 in both;
+    ragged B and C exercise the row / column masks).  The 256x256 TN kernel is forced (the toy width would not select it)."""
+    torch.manual_seed(9)
+    D, Cn, B = 64, 1003, 70
+    h = {"arcface": lambda: heads.ArcFace(D, Cn, margin_arc=0.35, margin_am=0.0, scale=32, backend=be, device=dev),
+         "circle": lambda: heads.CircleLoss(D, Cn, margin=0.25, gamma=64, backend=be, device=dev),
+         "mv_am": lambda: heads.MV_Softmax(D, Cn, is_am=True, margin=0.35, mv_weight=1.12, scale=32, backend=be, device=dev),
+         "mv_arc": lambda: heads.MV_Softmax(D, Cn, is_am=False, margin=0.35, mv_weight=1.12, scale=32, backend=be, device=dev)}[tag]()
+    feats = torch.randn(B, D).to(dev); labels = torch.randint(0, Cn, (B,)).to(dev)
+    labels[0] = Cn - 1; labels[1] = 0
+    l0, df0, dW0 = h.margin_ce(feats, labels, label_smoothing=0.1, cos_planes=planes, fused=False)
+    be.lib.vdk_gemm_force_kernel(2)
+    try:
+        l1, df1, dW1 = h.margin_ce(feats, labels, label_smoothing=0.1, cos_planes=planes, fused=True)
+    finally:
+        be.lib.vdk_gemm_force_kernel(0)
+    assert (l1.cpu() - l0.cpu()).abs().max().item() < 1e-5 * l0.abs().max().item() + 1e-5
+    assert _rel(df1, df0) < 2e-3 and _rel(dW1, dW0) < 2e-3

@@ -18,17 +18,18 @@ def main():
     h = heads.ArcFace(D, C, margin_arc=0.35, margin_am=0.0, scale=32, backend=be, device="cuda")
     f = torch.randn(B, D, device="cuda"); y = torch.randint(0, C, (B,), device="cuda")
     out = {"B": B, "D": D, "C": C}
-    for planes in (3, 1):
+    for planes, fused in ((3, False), (1, False), (3, True), (1, True)):
+        key = f"{planes}_{'epilogue_fused' if fused else 'materialised_cos'}"
         for _ in range(2):
-            h.margin_ce(f, y, cos_planes=planes)
+            h.margin_ce(f, y, cos_planes=planes, fused=fused)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(); e0.record()
         n = 5
         for _ in range(n):
-            loss, df, dW = h.margin_ce(f, y, cos_planes=planes)
+            loss, df, dW = h.margin_ce(f, y, cos_planes=planes, fused=fused)
         e1.record(); torch.cuda.synchronize()
-        out[f"ms_cos_planes_{planes}"] = e0.elapsed_time(e1) / n
-        out[f"loss_{planes}"] = loss.mean().item()
+        out[f"ms_cos_planes_{key}"] = e0.elapsed_time(e1) / n
+        out[f"loss_{key}"] = loss.mean().item()
     print(json.dumps(out))
 
 

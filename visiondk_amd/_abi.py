@@ -56,6 +56,7 @@ class MarginHead(C.Structure):
 
 
 F16_ = 2   # VDK_F16
+EUNSUPPORTED = -4   # VDK_EUNSUPPORTED
 HEAD_ARCFACE, HEAD_CIRCLE, HEAD_MV_AM, HEAD_MV_ARC = 0, 1, 2, 3
 GRAD_READY_FN = C.CFUNCTYPE(None, P, I64, I64)
 STAT_SYNC_FN = C.CFUNCTYPE(None, P, P, I64)   # vdk_stat_sync_fn(user, stats, n)
@@ -121,6 +122,9 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_ohem_mask": (C.c_int, [P, I64, I32, I32, P, I32, F32, I64, P, P, P]),
     "vdk_topk_rows": (C.c_int, [P, I64, I32, I32, I32, P, P, P]),
     # margin-softmax heads
+    "vdk_margin_cos_pass": (C.c_int, [P, I32, P, I64, P, I64, I32, I32, I32, I32, I32, P, P, P, P, P, F32, F32, P, I64, P]),
+    "vdk_margin_rowstat": (C.c_int, [P, I64, P, I32, I32, F32, P, P, P]),
+    "vdk_margin_target_cos_direct": (C.c_int, [P, I64, P, I64, I32, I32, P, P, P]),
     "vdk_attn_pool_fwd": (C.c_int, [P, P, I64, I32, I32, I32, F32, P, I64, P, P]),
     "vdk_attn_pool_bwd": (C.c_int, [P, P, I64, P, P, I64, I32, I32, I32, F32, P, I64, P, P]),
     "vdk_colnorm_fwd": (C.c_int, [P, I64, I32, I32, I32, F32, P, P, I64, I32, P]),

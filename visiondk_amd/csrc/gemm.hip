@@ -691,6 +691,7 @@ static int sk_grid() {
   return cus;
 }
 
+#define RC_MARGIN(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 extern "C" {
 
 /* rows of the a_colsum by-product ([rows][K] f32) if the NT problem (M, N, K) is served by the 256x256 kernel and M % 256 == 0, else 0 */
@@ -927,6 +928,32 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
                        d->c_dtype == VDK_BF16 ? (bf16_t*)d->C : (bf16_t*)nullptr);
   }
   return vdk_check_launch("vdk_gemm_bf16_nt");
+}
+
+// The cos GEMM of the margin heads with the head applied to the tile in registers ("B x C logits are never written").  cos[Bp, Cp] = f^ W^ is the TN product of
+// fbt [K, Bp] (the normalised features, transposed; K = D or 3 D split planes) and wb [K, Cp] (the column-normalised weight); nothing of it reaches memory as fp32:
+//   pass 1 (E_MSTAT): per (row, 64-column slice) partials (max logit, sum exp(logit - max), sum logit) -> stats f32 [B][ceil(Cp / 64)][4], the target's logit -> tlogit [B];
+//                     vdk_margin_rowstat (margin_head.hip) reduces them to the row statistics and the loss;
+//   pass 2 (E_MGRAD): the same product again, its epilogue writes d(loss)/d(cos) as bf16 [Bp, lddc] from the row statistics (rows >= B and columns >= C zero).
+// Needs the 256x256 TN kernel: K % 64 == 0, Bp % 8 == 0, Cp % 8 == 0; returns VDK_EUNSUPPORTED otherwise (callers keep the materialised form).
+int vdk_margin_cos_pass(const VdkMarginHead* h, int32_t pass, const void* fbt, int64_t ld_f, const void* wb, int64_t ld_w, int32_t B, int32_t Bp, int32_t C, int32_t Cp, int32_t K,
+                        const int64_t* labels, const float* gt, float* stats, float* tlogit, const float* rowstat, float label_smoothing, float grad_scale, void* dcos,
+                        int64_t lddc, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!h || !fbt || !wb || !labels || B <= 0 || Bp < B || C <= 0 || Cp < C || (pass != 1 && pass != 2)) return vdk_fail(VDK_EINVAL, "vdk_margin_cos_pass: bad argument");
+  if ((pass == 1 && (!stats || !tlogit)) || (pass == 2 && (!rowstat || !dcos))) return vdk_fail(VDK_EINVAL, "vdk_margin_cos_pass: missing buffer for this pass");
+  if ((K % 64) || (Bp & 7) || (Cp & 7) || (ld_f & 7) || (ld_w & 7) || (pass == 2 && (lddc & 7)) || Bp < 8 || Cp < 256)
+    return VDK_EUNSUPPORTED;
+  GemmParams p = {};
+  p.A = (const bf16_t*)fbt; p.B = (const bf16_t*)wb; p.C = dcos; p.lda = ld_f; p.ldb = ld_w; p.ldc = lddc; p.M = Bp; p.N = Cp; p.K = K; p.c_dtype = VDK_BF16;
+  p.alpha = 1.0f; p.splitk = 1; p.k_per_split = K;
+  RC_MARGIN(fill_params(h, &p.me.P));
+  p.me.labels = (const long long*)labels; p.me.gt = gt; p.me.stats = stats; p.me.nslice = (Cp + 63) / 64; p.me.tlogit = tlogit; p.me.rowstat = rowstat;
+  p.me.smoothing = label_smoothing; p.me.gscale = grad_scale; p.me.epsc = label_smoothing / (float)C; p.me.B = B; p.me.C = C;
+  const dim3 grid((unsigned)(((Bp + 255) / 256) * ((Cp + 255) / 256)), 1u);
+  if (pass == 1) hipLaunchKernelGGL((gemm256_bf16_kernel<true, E_MSTAT, false, false>), grid, dim3(512), 0, stream, p);
+  else hipLaunchKernelGGL((gemm256_bf16_kernel<true, E_MGRAD, false, false>), grid, dim3(512), 0, stream, p);
+  return vdk_check_launch("vdk_margin_cos_pass");
 }
 
 // out[C][ldo] (bf16) = in[R][ldi]^T, rows R..Rpad-1 of the contraction dim zero-filled.  Rpad even.

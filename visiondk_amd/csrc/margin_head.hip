@@ -12,61 +12,7 @@
 #include <hip/hip_runtime.h>
 #include "vdk_device.h"
 #include "vdk_host.h"
-
-struct MarginP {
-  int mode;          // VDK_HEAD_ARCFACE / CIRCLE / MV_AM / MV_ARC
-  float s;           // scale (arcface, mv) or gamma (circle)
-  float m;           // margin
-  float cos_m, sin_m, min_cos, m_am;   // arcface: cos(m), sin(m), cos(pi - m), margin_am
-  float Op, On, dp, dn;                // circle: 1+m, -m, 1-m, m
-  float t;                             // mv_weight
-  const float* row_margin;             // arcface only, optional: per-row additive angular margin (MagFace's magnitude-aware margin), overrides m
-};
-// MagFace (models/faceX/head/magface.py:26-47): ArcFace whose margin is a function of the row's feature norm; the kernels take it per row
-__device__ __forceinline__ void margin_row_params(MarginP& P, int row) {
-  if (P.row_margin) {
-    const float m = P.row_margin[row];
-    P.m = m; P.cos_m = cosf(m); P.sin_m = sinf(m); P.min_cos = cosf(3.14159265358979323846f - m);
-  }
-}
-
-struct RowCtx { float thr, final_gt, dfinal; };   // MV-Softmax per-row quantities derived from gt = cos[i][y_i]
-
-__device__ __forceinline__ RowCtx margin_row_ctx(const MarginP& P, float gt) {
-  RowCtx r; r.thr = 0.f; r.final_gt = gt; r.dfinal = 1.f;
-  if (P.mode == VDK_HEAD_MV_AM) {
-    r.thr = gt - P.m;
-    r.final_gt = gt > P.m ? gt - P.m : gt;
-  } else if (P.mode == VDK_HEAD_MV_ARC) {
-    const float sn = sqrtf(1.0f - gt * gt);
-    const float ctm = gt * P.cos_m - sn * P.sin_m;
-    r.thr = ctm;
-    if (gt > 0.0f) { r.final_gt = ctm; r.dfinal = P.cos_m + gt / sn * P.sin_m; }
-  }
-  return r;
-}
-// logit and d(logit)/d(cos) of one entry
-__device__ __forceinline__ void margin_eval(const MarginP& P, const RowCtx& R, float c_raw, bool tgt, float& logit, float& jac) {
-  if (P.mode == VDK_HEAD_ARCFACE) {
-    const float c = fminf(fmaxf(c_raw, -1.0f), 1.0f);
-    const float cg = (c_raw >= -1.0f && c_raw <= 1.0f) ? 1.0f : 0.0f;   // clamp backward
-    if (!tgt) { logit = P.s * c; jac = P.s * cg; return; }
-    if (c > P.min_cos) {
-      const float sn = sqrtf(1.0f - c * c);
-      logit = P.s * (c * P.cos_m - sn * P.sin_m);
-      jac = P.s * (P.cos_m + c / sn * P.sin_m) * cg;
-    } else { logit = P.s * (c - P.m_am); jac = P.s * cg; }
-  } else if (P.mode == VDK_HEAD_CIRCLE) {
-    const float c = fminf(fmaxf(c_raw, -1.0f), 1.0f);
-    const float cg = (c_raw >= -1.0f && c_raw <= 1.0f) ? 1.0f : 0.0f;
-    if (tgt) { const float a = fmaxf(P.Op - c, 0.f); logit = P.s * a * (c - P.dp); jac = P.s * a * cg; }
-    else { const float a = fmaxf(c - P.On, 0.f); logit = P.s * a * (c - P.dn); jac = P.s * a * cg; }
-  } else {  // MV-Softmax (no clamp)
-    if (tgt) { logit = P.s * R.final_gt; jac = P.s * R.dfinal; }
-    else if (c_raw > R.thr) { logit = P.s * (P.t * c_raw + P.t - 1.0f); jac = P.s * P.t; }
-    else { logit = P.s * c_raw; jac = P.s; }
-  }
-}
+#include "vdk_margin.h"
 
 // ---- normalisations ------------------------------------------------------------------------------------------------
 // W f32 [D, ldw] (C valid columns) -> inv[c] = 1 / max(||W[:, c]||, eps), and W^ as THREE bf16 planes stacked along the
@@ -452,14 +398,39 @@ __global__ __launch_bounds__(256) void margin_bwd_kernel(MarginP P, const float*
   }
 }
 
-static int fill_params(const VdkMarginHead* h, MarginP* P) {
-  if (!h) return vdk_fail(VDK_EINVAL, "margin head: null config");
-  P->mode = h->mode; P->s = h->scale; P->m = h->margin; P->m_am = h->margin_am; P->t = h->mv_weight;
-  P->cos_m = cosf(h->margin); P->sin_m = sinf(h->margin); P->min_cos = cosf(3.14159265358979323846f - h->margin);
-  P->Op = 1.0f + h->margin; P->On = -h->margin; P->dp = 1.0f - h->margin; P->dn = h->margin;
-  P->row_margin = h->mode == VDK_HEAD_ARCFACE ? h->row_margin : nullptr;
-  if (h->mode < VDK_HEAD_ARCFACE || h->mode > VDK_HEAD_MV_ARC) return vdk_fail(VDK_EINVAL, "margin head: bad mode");
-  return VDK_OK;
+// ---- the fused form's small kernels (the cos GEMM applies the head in its epilogue: vdk_margin_cos_pass in gemm.hip) ---------------------------------------------
+// row statistics from the per-slice partials of pass 1: rowstat[b] = (max, 1 / sum exp(logit - max)), loss_rows[b] = lse - (1 - eps) logit_target - eps mean(logit)
+__global__ __launch_bounds__(256) void margin_rowstat_kernel(const float* __restrict__ stats, long nslice, const float* __restrict__ tlogit, int C, float label_smoothing,
+                                                             float* __restrict__ rowstat, float* __restrict__ loss_rows) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const f32x4* sr = (const f32x4*)stats + (long)row * nslice;
+  float m = -3.0e38f, se = 0.f, sl = 0.f;
+  for (long i = tid; i < nslice; i += 256) {
+    const f32x4 v = sr[i];
+    sl += v[2];
+    if (v[0] > m) { se *= vdk_vexp(m - v[0]); m = v[0]; }
+    se += v[1] * vdk_vexp(v[0] - m);
+  }
+  const float mx = block_max<4>(m, red);
+  se = block_sum<4>(se * vdk_vexp(m - mx), red);
+  sl = block_sum<4>(sl, red);
+  if (tid == 0) {
+    rowstat[2 * row] = mx; rowstat[2 * row + 1] = 1.0f / se;
+    if (loss_rows) loss_rows[row] = mx + logf(se) - (1.0f - label_smoothing) * tlogit[row] - label_smoothing * (sl / (float)C);
+  }
+}
+// gt[b] = sum_k fbt[k][b] * wb[k][y_b]: the target cosine from the very operands of the cos GEMM (bf16 planes, fp32 accumulation), so that MV-Softmax's thresholds see
+// the same number the GEMM's tile holds for that column (up to summation order); one wave per row
+__global__ __launch_bounds__(256) void margin_target_cos_direct_kernel(const bf16_t* __restrict__ fbt, long ld_f, const bf16_t* __restrict__ wb, long ld_w, int K, int B,
+                                                                       const long long* __restrict__ y, float* __restrict__ gt) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B) return;
+  const long yt = y[row];
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s = fmaf(bf2f(fbt[(long)k * ld_f + row]), bf2f(wb[(long)k * ld_w + yt]), s);
+  s = wave_sum(s);
+  if (lane == 0) gt[row] = s;
 }
 
 extern "C" {
@@ -504,6 +475,17 @@ int vdk_rownorm_bwd(const float* fh, const float* inv, const float* dfh, int64_t
   if (!fh || !inv || !dfh || !df || B <= 0 || D <= 0) return vdk_fail(VDK_EINVAL, "vdk_rownorm_bwd: bad argument");
   hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, fh, inv, dfh, (long)lddfh, (int)B, (int)D, df);
   return vdk_check_launch("vdk_rownorm_bwd");
+}
+int vdk_margin_rowstat(const float* stats, int64_t nslice, const float* tlogit, int32_t B, int32_t C, float label_smoothing, float* rowstat, float* loss_rows, void* stream) {
+  if (!stats || !tlogit || !rowstat || B <= 0 || C <= 0 || nslice <= 0) return vdk_fail(VDK_EINVAL, "vdk_margin_rowstat: bad argument");
+  hipLaunchKernelGGL(margin_rowstat_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, stats, (long)nslice, tlogit, (int)C, label_smoothing, rowstat, loss_rows);
+  return vdk_check_launch("vdk_margin_rowstat");
+}
+int vdk_margin_target_cos_direct(const void* fbt, int64_t ld_f, const void* wb, int64_t ld_w, int32_t K, int32_t B, const int64_t* labels, float* gt, void* stream) {
+  if (!fbt || !wb || !labels || !gt || B <= 0 || K <= 0) return vdk_fail(VDK_EINVAL, "vdk_margin_target_cos_direct: bad argument");
+  hipLaunchKernelGGL(margin_target_cos_direct_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)fbt, (long)ld_f, (const bf16_t*)wb, (long)ld_w,
+                     (int)K, (int)B, (const long long*)labels, gt);
+  return vdk_check_launch("vdk_margin_target_cos_direct");
 }
 int vdk_margin_ce(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t C, const int64_t* labels, float label_smoothing,
                   float grad_scale, float* logits, int64_t ldl, float* loss_rows, void* dcos_bf16, int64_t lddc, void* stream) {

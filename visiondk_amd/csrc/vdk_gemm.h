@@ -2,6 +2,7 @@
 #pragma once
 #include "visiondk.h"
 #include "vdk_device.h"
+#include "vdk_margin.h"
 
 typedef VdkGemmDesc GemmDesc;
 
@@ -25,6 +26,7 @@ struct GemmParams {
   float* colsum_part;        // 256-kernel, NT only: per (row tile, wave) column sums of A, f32 [ceil(M/256)*8][K] (bias gradient fused into the dgrad GEMM)
   // implicit-GEMM convolution (conv_on): A is an NHWC tensor gathered on the fly, see VdkConvGeom
   int conv_on, cCin, cH, cW, cOH, cOW, cKH, cKW, cstride, cpad, ctrans;
+  MarginEpi me;              // E_MSTAT / E_MGRAD epilogues (margin-softmax head: cos tiles never leave the registers as fp32)
   unsigned long long* dbg;   // debug only: 4 cycle stamps per workgroup (start, operands landed, main loop done, end)
 };
 

@@ -68,6 +68,8 @@ __device__ __forceinline__ void g_epilogue_store8(const GemmParams& p, long mi, 
 #define E_SPLITK 32   /* raw fp32 partial slab */
 #define E_ROWGRP 64   /* token-row remap (patch embedding) */
 #define E_OCS 128     /* by-product: column sums of the stored (bf16-rounded) output over this wave's 128 rows -> p.ocs_part (bias gradient of the next Linear back) */
+#define E_MSTAT 256   /* margin head, pass 1: per-(row, 64-column slice) online-softmax partials of the margin logits; nothing is stored to C */
+#define E_MGRAD 512   /* margin head, pass 2: C = bf16 d(loss)/d(cos) from the row statistics */
 #define E_GENERIC 0x1000
 
 template <int E>
@@ -75,6 +77,43 @@ __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float
                                                 int n, int z, const float (&bias8)[8], float (&ocs)[8]) {
   // this lane: rows mbase + pass*8 + (lane >> 3), pass = 0..7, columns n .. n+7
   const int rsub = lane >> 3, cc = (lane & 7) * 8;
+  if (E & E_MSTAT) {     // margin logits of this lane's 8 columns -> (max, sum exp, sum) merged over the 8 lanes that share a row -> one partial per (row, 64-column slice)
+    const MarginEpi& me = p.me;
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      const long mi = mbase + ps * 8 + rsub;
+      const bool rok = mi < me.B;
+      const int row = ps * 8 + rsub;
+      f32x4 x0 = *(const f32x4*)(slab + row * 64 + cc), x1 = *(const f32x4*)(slab + row * 64 + cc + 4);
+      float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+      MarginP P = me.P;
+      long yt = -1; RowCtx R; R.thr = 0.f; R.final_gt = 0.f; R.dfinal = 1.f;
+      if (rok) { margin_row_params(P, (int)mi); yt = me.labels[mi]; R = margin_row_ctx(P, me.gt ? me.gt[mi] : 0.f); }
+      float m = -3.0e38f, sl = 0.f, lg[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        lg[e] = -3.0e38f;
+        if (rok && n + e < me.C) {
+          float jc; margin_eval(P, R, v[e], (long)(n + e) == yt, lg[e], jc);
+          sl += lg[e]; m = fmaxf(m, lg[e]);
+          if ((long)(n + e) == yt) me.tlogit[mi] = lg[e];
+        }
+      }
+      float se = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) se += (lg[e] > -1.0e38f) ? vdk_vexp(lg[e] - m) : 0.f;
+#pragma unroll
+      for (int off = 1; off < 8; off <<= 1) {
+        const float m2 = __shfl_xor(m, off), s2 = __shfl_xor(se, off);
+        sl += __shfl_xor(sl, off);
+        const float M = fmaxf(m, m2);
+        se = se * vdk_vexp(m - M) + s2 * vdk_vexp(m2 - M);      // (both factors are exp(0) = 1 or exp(-huge) = 0 when a side is empty: m = m2 = -3e38 gives 1 * 0 + 1 * 0)
+        m = M;
+      }
+      if (rok && (lane & 7) == 0 && n < p.N) *(f32x4*)(me.stats + ((long)mi * me.nslice + (n >> 6)) * 4) = (f32x4){m, se, sl, 0.f};
+    }
+    return;
+  }
   if (n >= p.N) return;
   long mo[8], mr[8];
   bool ok[8];
@@ -126,6 +165,26 @@ __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float
     if (E & E_RES) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] += r0[ps][e]; v[4 + e] += r1[ps][e]; }
+    }
+    if (E & E_MGRAD) {     // v = cos -> gscale * (softmax - eps / C - (1 - eps) [c is the target]) * d(logit)/d(cos); rows >= B and columns >= C are zero
+      const MarginEpi& me = p.me;
+      const long mi = mbase + row;
+      if (mi < me.B) {
+        MarginP P = me.P; margin_row_params(P, (int)mi);
+        const long yt = me.labels[mi];
+        const RowCtx R = margin_row_ctx(P, me.gt ? me.gt[mi] : 0.f);
+        const float M = me.rowstat[2 * mi], inv = me.rowstat[2 * mi + 1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float lgv, jc; margin_eval(P, R, v[e], (long)(n + e) == yt, lgv, jc);
+          float gd = vdk_vexp(lgv - M) * inv - me.epsc;
+          if ((long)(n + e) == yt) gd -= (1.0f - me.smoothing);
+          v[e] = (n + e < me.C) ? gd * me.gscale * jc : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      }
     }
     if (E & E_F32) {
       float* dst = (float*)p.C + mo[ps] * p.ldc + n;
