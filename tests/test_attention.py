@@ -28,7 +28,7 @@ def legacy(request, be):
     be.lib.vdk_attention_force_legacy(-1)
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 17, 2), (1, 50, 1), (1, 197, 2), (2, 224, 1), (1, 256, 1), (1, 300, 1)])
+@pytest.mark.parametrize("B,N,H", [(2, 17, 2), (1, 50, 1), (1, 197, 2), (2, 224, 1), (1, 256, 1), (1, 300, 1), (2, 257, 2), (1, 577, 1), (9, 384, 1)])
 def test_attention_fwd_bwd(be, dev, B, N, H, legacy):
     torch.manual_seed(0)
     D = H * 64
@@ -104,4 +104,22 @@ def test_attention_fwd_persistent_workgroups(be, dev, grid, monkeypatch, legacy)
     assert _rel(lse, lseref) < 1e-5 and _rel(o.float(), oref) < 6e-3
     monkeypatch.delenv("VDK_ATTN_GRID")
     o2, lse2 = ops.attention_fwd(qkv, H, backend=be)            # one item per workgroup: bit-identical
+    assert torch.equal(o, o2) and torch.equal(lse, lse2)
+
+
+@pytest.mark.parametrize("grid", [1, 8, 24])
+def test_attention_long_fwd_units_per_workgroup(be, dev, grid, monkeypatch):
+    """N > 256 (csrc/attention_long.hip): a work unit is (batch, head, group of 4 query tiles), dealt to XCDs by item mod 8, and a workgroup walks over its units with the
+    K / V chunk buffers running on across unit boundaries (the next unit's first chunk is requested under the current unit's last).  B * H = 10 items (two residues mod 8 hold
+    two items, six hold one), N = 290 -> 10 query tiles = 3 groups (the last with two idle waves), 4 chunks of 96 keys (the last ragged).  Any grid gives the same bits."""
+    monkeypatch.setenv("VDK_ATTN_GRID", str(grid))
+    torch.manual_seed(2)
+    B, N, H = 5, 290, 2
+    D = H * 64
+    qkv = (torch.randn(B, N, 3 * D) * 1.2).bfloat16().to(dev)
+    o, lse = ops.attention_fwd(qkv, H, backend=be)
+    oref, lseref = _ref(qkv.float(), H)
+    assert _rel(lse, lseref) < 1e-5 and _rel(o.float(), oref) < 6e-3
+    monkeypatch.delenv("VDK_ATTN_GRID")
+    o2, lse2 = ops.attention_fwd(qkv, H, backend=be)
     assert torch.equal(o, o2) and torch.equal(lse, lse2)

@@ -1,5 +1,5 @@
-mkdir -p gpurun_out/final
-python bench.py > gpurun_out/final/bench_stdout.txt 2> gpurun_out/final/bench_stderr.txt
-tail -1 gpurun_out/final/bench_stdout.txt > gpurun_out/final/bench.json
-python -c "
-import json;d=json.load(open('gpurun_out/final/bench.json'));c=d['cbir'];print(d['value'],d['ms_per_step'],d['roofline']['frac'],c['ms_per_search'],c['small_candidate_lists'])"
+mkdir -p gpurun_out/r2x
+python -m pytest tests/test_attention.py tests/test_rowops.py tests/test_siglip.py -m gpu -x -q 2>&1 | tail -3
+python tools/bench_attention.py 128 576 16 | tee gpurun_out/r2x/attn_576.json
+python tools/bench_attention.py 256 257 16 | tee gpurun_out/r2x/attn_257.json
+python tools/bench_cfg5.py 128 3 | tee gpurun_out/r2x/cfg5.json

@@ -382,6 +382,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 int vdk_attention_small_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H, float scale, void* stream);
 int vdk_attention_small_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv, int64_t ldd, float* dvec, int32_t B, int32_t N,
                             int32_t H, float scale, void* stream);
+// long sequences (attention_long.hip): K / V streamed through a double-buffered LDS chunk by LDS-DMA, online softmax
+int vdk_attention_long_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H, float scale, void* stream);
 static int g_attn_legacy = -1;   // -1: env VDK_ATTN_LEGACY decides; 0 / 1: forced by vdk_attention_force_legacy (A/B benchmarking, tests of the long-sequence kernels at small N)
 static bool attn_legacy() {
   if (g_attn_legacy >= 0) return g_attn_legacy == 1;
@@ -403,6 +405,10 @@ int vdk_attention_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* 
   if (N <= 256 && !attn_legacy()) {
     const int rc = vdk_attention_small_fwd(qkv, ld, o, ldo, lse, B, N, H, scale, stream);
     if (rc != VDK_EUNSUPPORTED) return rc ? rc : vdk_check_launch("vdk_attention_fwd");
+  }
+  if (N > 256 && !attn_legacy()) {
+    const int rc = vdk_attention_long_fwd(qkv, ld, o, ldo, lse, B, N, H, scale, stream);
+    return rc ? rc : vdk_check_launch("vdk_attention_fwd");
   }
   const bf16_t* base = (const bf16_t*)qkv;
   const long D = (long)H * A_HD;

@@ -472,15 +472,18 @@ int vdk_reduce_rows_f32(const float* in, int64_t ld, int32_t S, int64_t n, float
   return vdk_check_launch("vdk_reduce_rows_f32");
 }
 
-static inline int ln_bwd_blocks(int T) {
+static inline int ln_bwd_blocks(int T, int C) {
   int nb = (T + 63) / 64;          // 64 rows per block: enough waves in flight to stream at HBM rate
-  if (nb > 1024) nb = 1024;
+  // never more blocks than are resident at once: C <= 768 runs 4 blocks per CU (<= 128 VGPRs), wider rows 3 (136 VGPRs) -- T / 64 = 1152 blocks of ViT-L/14 at 336 were 1.5
+  // rounds on 768 slots, i.e. the time of two; one round of fatter blocks costs 1.5
+  const int slots = C <= 768 ? 1024 : 768;
+  if (nb > slots) nb = slots;
   if (nb < 1) nb = 1;
   return nb;
 }
 int vdk_layernorm_bwd_workspace_bytes(int32_t T, int32_t C, size_t* bytes) {
   if (!bytes || T < 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd_workspace_bytes: bad argument");
-  *bytes = (size_t)3 * ln_bwd_blocks(T) * C * 4;      // [blocks][dgamma | dbeta] + [blocks][column sums of the bf16 output] (in-library by-product)
+  *bytes = (size_t)3 * ln_bwd_blocks(T, C) * C * 4;      // [blocks][dgamma | dbeta] + [blocks][column sums of the bf16 output] (in-library by-product)
   return VDK_OK;
 }
 // dy: bf16 or f32 [T, lddy]; x f32 rows (ldx); dres optional f32 residual-stream gradient added to dx;
@@ -492,7 +495,7 @@ static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const flo
   hipStream_t stream = (hipStream_t)stream_;
   if (!dy || !x || !mean || !rstd || !gamma || !dgamma || !dbeta || T <= 0 || C <= 0 || (C & 3) || C > 4096)
     return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: bad argument (C % 4 == 0, C <= 4096)");
-  const int nb = ln_bwd_blocks(T);
+  const int nb = ln_bwd_blocks(T, C);
   const bool ocs = dxb_colsum != nullptr;
   if (ocs && (!dxb || !deferred2 || C > 1024)) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: the output column sums need dxb, a job slot and C <= 1024");
   size_t need = (size_t)(ocs ? 3 : 2) * nb * C * 4;
