@@ -163,8 +163,8 @@ int vdk_transpose_bf16(const void* in, int64_t ldi, int32_t R, int32_t C, void* 
 
 
 /* N <= 256 keys: forward with the whole (batch, head) item in LDS and an exact (non-online) softmax, N <= 224: recompute-form backward in two kernels
- * (csrc/attention_small.hip); longer sequences: forward with K / V streamed through a double-buffered LDS chunk (csrc/attention_long.hip), flash-style
- * backward (csrc/attention.hip).  on = 1 forces the round-1 flash-style kernels of csrc/attention.hip at every N (A/B timing, tests), 0 the default
+ * (csrc/attention_small.hip); longer sequences: forward and recompute-form backward with the other operand streamed through a double-buffered LDS chunk
+ * (csrc/attention_long.hip).  on = 1 forces the round-1 flash-style kernels of csrc/attention.hip at every N (A/B timing, tests), 0 the default
  * routing, -1 hands the choice back to the VDK_ATTN_LEGACY environment variable. */
 int vdk_attention_force_legacy(int32_t on);
 

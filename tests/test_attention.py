@@ -123,3 +123,46 @@ def test_attention_long_fwd_units_per_workgroup(be, dev, grid, monkeypatch):
     monkeypatch.delenv("VDK_ATTN_GRID")
     o2, lse2 = ops.attention_fwd(qkv, H, backend=be)
     assert torch.equal(o, o2) and torch.equal(lse, lse2)
+
+
+@pytest.mark.parametrize("grid", [1, 8, 24])
+def test_attention_long_bwd_units_per_workgroup(be, dev, grid, monkeypatch):
+    """N > 224 backward (csrc/attention_long.hip): the q kernel (dQ, D) and the kv kernel (dK, dV) walk the same unit numbering as the forward, the chunk buffers (and
+    the kv kernel's staged lse / D values) run on across unit boundaries.  Any grid gives the same bits; the flash-style kernels agree within the bf16 rounding of dS."""
+    torch.manual_seed(3)
+    B, N, H = 5, 290, 2
+    D = H * 64
+    qkv = (torch.randn(B, N, 3 * D) * 1.2).bfloat16().to(dev)
+    dout = torch.randn(B, N, D).bfloat16().to(dev)
+    o, lse = ops.attention_fwd(qkv, H, backend=be)
+    monkeypatch.setenv("VDK_ATTN_GRID", str(grid))
+    d = ops.attention_bwd(qkv, o, dout, lse, H, backend=be)
+    monkeypatch.delenv("VDK_ATTN_GRID")
+    d2 = ops.attention_bwd(qkv, o, dout, lse, H, backend=be)
+    assert torch.equal(d, d2)
+    be.lib.vdk_attention_force_legacy(1)
+    try:
+        d3 = ops.attention_bwd(qkv, o, dout, lse, H, backend=be)
+    finally:
+        be.lib.vdk_attention_force_legacy(-1)
+    assert _rel(d.float(), d3.float()) < 6e-3
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 17, 2), (1, 50, 1), (2, 197, 1), (1, 224, 1)])
+def test_attention_streaming_kernels_at_short_n(be, dev, B, N, H, monkeypatch):
+    """The streaming kernels of csrc/attention_long.hip forced at short N (VDK_ATTN_LONG_MIN): single-chunk sequences, chunks with whole tiles beyond N (skipped), groups
+    with idle waves -- against torch fp32 and, for the backward, against the LDS-resident kernels (same recompute form, same rounding points: dS rounded to bf16)."""
+    torch.manual_seed(4)
+    D = H * 64
+    qkv = (torch.randn(B, N, 3 * D) * 1.3).bfloat16().to(dev)
+    dout = torch.randn(B, N, D).bfloat16().to(dev)
+    o_s, lse_s = ops.attention_fwd(qkv, H, backend=be)
+    d_s = ops.attention_bwd(qkv, o_s, dout, lse_s, H, backend=be)
+    monkeypatch.setenv("VDK_ATTN_LONG_MIN", "1")
+    o, lse = ops.attention_fwd(qkv, H, backend=be)
+    d = ops.attention_bwd(qkv, o_s, dout, lse_s, H, backend=be)
+    monkeypatch.delenv("VDK_ATTN_LONG_MIN")
+    oref, lseref = _ref(qkv.float(), H)
+    assert _rel(lse, lseref) < 1e-5 and _rel(o.float(), oref) < 6e-3
+    assert _rel(o.float(), o_s.float()) < 6e-3
+    assert _rel(d.float(), d_s.float()) < 2e-3

@@ -1,10 +1,7 @@
 mkdir -p gpurun_out/r2x
-for s in 0 30 60 100 0 60; do
-  echo "stagger $s"; VDK_GEMM_STAGGER=$s python bench.py --no-cbir --no-cpu-baseline --no-parity --steps 20 2>/dev/null | python -c "
-import sys,json
-for l in sys.stdin:
-    l=l.strip()
-    if l.startswith('{'):
-        d=json.loads(l); print(d['ms_per_step'], d['value'], d['roofline']['achieved'], d['roofline'].get('by_variant', ''))
-"
-done 2>&1 | tee gpurun_out/r2x/stagger.txt
+python -m pytest tests/test_attention.py -m gpu -x -q 2>&1 | tail -3
+echo default; python tools/bench_attention.py 256 197 12 | tee gpurun_out/r2x/attn_197_default.json
+echo streaming; VDK_ATTN_LONG_MIN=1 python tools/bench_attention.py 256 197 12 | tee gpurun_out/r2x/attn_197_streaming.json
+python tools/bench_attention.py 128 576 16 | tee gpurun_out/r2x/attn_576.json
+python tools/bench_attention.py 256 257 16 | tee gpurun_out/r2x/attn_257.json
+python tools/bench_attention.py 128 577 16 | tee gpurun_out/r2x/attn_577.json

@@ -384,11 +384,22 @@ int vdk_attention_small_bwd(const void* qkv, int64_t ld, const void* o, const vo
                             int32_t H, float scale, void* stream);
 // long sequences (attention_long.hip): K / V streamed through a double-buffered LDS chunk by LDS-DMA, online softmax
 int vdk_attention_long_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H, float scale, void* stream);
+int vdk_attention_long_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv, int64_t ldd, float* dvec, int32_t B, int32_t N,
+                           int32_t H, float scale, void* stream);
 static int g_attn_legacy = -1;   // -1: env VDK_ATTN_LEGACY decides; 0 / 1: forced by vdk_attention_force_legacy (A/B benchmarking, tests of the long-sequence kernels at small N)
 static bool attn_legacy() {
   if (g_attn_legacy >= 0) return g_attn_legacy == 1;
   const char* e = getenv("VDK_ATTN_LEGACY");
   return e && e[0] == '1';
+}
+
+static int attn_long_min() {           // A/B and tests: VDK_ATTN_LONG_MIN=n routes every N >= n to the streaming kernels of attention_long.hip (default: beyond the LDS-resident range)
+  const char* e = getenv("VDK_ATTN_LONG_MIN");                          // (read per launch: the tests switch it inside one process)
+  return e ? atoi(e) : 1 << 30;
+}
+static bool attn_long_bwd_off() {      // A/B: VDK_ATTN_LONG_BWD=0 keeps the flash-style backward for N > 224 while the forward is routed
+  static const bool off = getenv("VDK_ATTN_LONG_BWD") && getenv("VDK_ATTN_LONG_BWD")[0] == '0';
+  return off;
 }
 
 extern "C" {
@@ -402,11 +413,11 @@ int vdk_attention_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* 
   if (!qkv || !o || B <= 0 || N <= 0 || H <= 0) return vdk_fail(VDK_EINVAL, "vdk_attention_fwd: bad argument");
   if (head_dim != A_HD) return vdk_fail(VDK_EUNSUPPORTED, "vdk_attention_fwd: head_dim must be 64");
   if ((ld & 7) || (ldo & 7)) return vdk_fail(VDK_EINVAL, "vdk_attention_fwd: ld % 8");
-  if (N <= 256 && !attn_legacy()) {
+  if (N <= 256 && N < attn_long_min() && !attn_legacy()) {
     const int rc = vdk_attention_small_fwd(qkv, ld, o, ldo, lse, B, N, H, scale, stream);
     if (rc != VDK_EUNSUPPORTED) return rc ? rc : vdk_check_launch("vdk_attention_fwd");
   }
-  if (N > 256 && !attn_legacy()) {
+  if ((N > 256 || N >= attn_long_min()) && !attn_legacy()) {
     const int rc = vdk_attention_long_fwd(qkv, ld, o, ldo, lse, B, N, H, scale, stream);
     return rc ? rc : vdk_check_launch("vdk_attention_fwd");
   }
@@ -428,9 +439,13 @@ int vdk_attention_bwd(const void* qkv, int64_t ld, const void* o, const void* do
   if (!qkv || !o || !dout || !lse || !dqkv || !dvec || B <= 0 || N <= 0 || H <= 0) return vdk_fail(VDK_EINVAL, "vdk_attention_bwd: bad argument");
   if (head_dim != A_HD) return vdk_fail(VDK_EUNSUPPORTED, "vdk_attention_bwd: head_dim must be 64");
   if ((ld & 7) || (ldo & 7) || (lddqkv & 7)) return vdk_fail(VDK_EINVAL, "vdk_attention_bwd: ld % 8");
-  if (N <= 224 && !attn_legacy()) {
+  if (N <= 224 && N < attn_long_min() && !attn_legacy()) {
     const int rc = vdk_attention_small_bwd(qkv, ld, o, dout, ldo, lse, dqkv, lddqkv, dvec, B, N, H, scale, stream_);
     if (rc != VDK_EUNSUPPORTED) return rc ? rc : vdk_check_launch("vdk_attention_bwd");
+  }
+  if ((N > 224 || N >= attn_long_min()) && !attn_legacy() && !attn_long_bwd_off()) {
+    const int rc = vdk_attention_long_bwd(qkv, ld, o, dout, ldo, lse, dqkv, lddqkv, dvec, B, N, H, scale, stream_);
+    return rc ? rc : vdk_check_launch("vdk_attention_bwd");
   }
   const bf16_t* base = (const bf16_t*)qkv;
   bf16_t* dbase = (bf16_t*)dqkv;

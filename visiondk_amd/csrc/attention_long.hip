@@ -1,4 +1,4 @@
-// attention_long.hip — K3 forward for sequences beyond the LDS-resident range (N > 256 keys: ViT-L/14 at 336 has N = 576 / 577, ViT-L/14 at 224 N = 257).
+// attention_long.hip — K3 forward and backward for sequences beyond the LDS-resident range (N > 256 keys: ViT-L/14 at 336 has N = 576 / 577, ViT-L/14 at 224 N = 257).
 // Same operator as attention.hip / attention_small.hip (timm `Attention`: softmax(q k^T / sqrt(hd)) v behind models/classifier/classify_model.py:49-54 and
 // models/faceX/backbone/timm_wrapper.py:16-21).  The flash-style forward of attention.hip stages K / V chunks through REGISTERS (270 VGPRs = one wave per SIMD, a
 // load -> barrier -> compute sequence per chunk): 1037 us per layer at B*H = 2048, N = 576 = 168 TFLOP/s, against 381 TFLOP/s of the short-sequence kernel on its shapes.
@@ -21,8 +21,8 @@
 #define AL_ARR (AL_CROWS * AS_ROW)         // one operand of one chunk: 12 KB
 #define AL_BUF (2 * AL_ARR)                // K rows | V rows
 
-// rows [r0, r0 + 96) of K and V -> buf, rows >= N read row N-1 (finite filler; its scores are masked)
-__device__ __forceinline__ void al_dma_chunk(unsigned char* buf, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld, int N, int r0, int w, int lane) {
+// rows [r0, r0 + 96) of two [N, 64] operands (row strides lda / ldb) -> buf, rows >= N read row N-1 (finite filler; its contribution is masked)
+__device__ __forceinline__ void al_dma_chunk2(unsigned char* buf, const bf16_t* __restrict__ a, long lda, const bf16_t* __restrict__ b, long ldb, int N, int r0, int w, int lane) {
 #pragma unroll
   for (int j0 = 0; j0 < AL_CROWS / 32; ++j0) {
     const int j = w + 4 * j0;
@@ -30,10 +30,12 @@ __device__ __forceinline__ void al_dma_chunk(unsigned char* buf, const bf16_t* _
     const int c = (lane & 7) ^ as_f(lrow);
     int srow = r0 + lrow;
     srow = srow < N ? srow : N - 1;
-    const long so = (long)srow * ld + c * 8;
-    __builtin_amdgcn_global_load_lds(VDK_GLOBAL_PTR(k + so), VDK_LDS_PTR(buf + j * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(VDK_GLOBAL_PTR(v + so), VDK_LDS_PTR(buf + AL_ARR + j * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(VDK_GLOBAL_PTR(a + (long)srow * lda + c * 8), VDK_LDS_PTR(buf + j * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(VDK_GLOBAL_PTR(b + (long)srow * ldb + c * 8), VDK_LDS_PTR(buf + AL_ARR + j * 1024), 16, 0, 0);
   }
+}
+__device__ __forceinline__ void al_dma_chunk(unsigned char* buf, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld, int N, int r0, int w, int lane) {
+  al_dma_chunk2(buf, k, ld, v, ld, N, r0, w, lane);
 }
 
 // LDS (dynamic): chunk buffer 0 | chunk buffer 1 | 4 wave store tiles of 4 KB
@@ -81,12 +83,15 @@ __global__ __launch_bounds__(256, 2) void attn_l_fwd_kernel(const bf16_t* __rest
       const unsigned char* const Kb = smem + (cc & 1) * AL_BUF;
       const unsigned char* const Vb = Kb + AL_ARR;
       const int key0 = c * AL_CROWS;
+      const int nv = (N - key0 + 31) >> 5;                            // key tiles of this chunk that hold a valid key (wave-uniform; >= AL_CT except in the last chunk)
       f32x16 st[AL_CT];
 #pragma unroll
       for (int kt = 0; kt < AL_CT; ++kt) {
         st[kt] = as_zero16();
+        if (kt < nv) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Kb + kt * 32 * AS_ROW, al, ks), qf[ks], st[kt], 0, 0, 0);
+          for (int ks = 0; ks < 4; ++ks) st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Kb + kt * 32 * AS_ROW, al, ks), qf[ks], st[kt], 0, 0, 0);
+        }
       }
       if (key0 + AL_CROWS > N) {                                     // the last chunk holds keys beyond N (wave-uniform)
 #pragma unroll
@@ -114,6 +119,7 @@ __global__ __launch_bounds__(256, 2) void attn_l_fwd_kernel(const bf16_t* __rest
       }
 #pragma unroll
       for (int kt = 0; kt < AL_CT; ++kt) {
+        if (kt >= nv) break;                                         // nothing but masked keys: P = 0
 #pragma unroll
         for (int r = 0; r < 16; ++r) { const float p = fast_exp2(fmaf(st[kt][r], scale2, -m)); st[kt][r] = p; l += p; }
         s16x8 pf[2];
@@ -135,16 +141,235 @@ __global__ __launch_bounds__(256, 2) void attn_l_fwd_kernel(const bf16_t* __rest
   }
 }
 
+// =====================================================================================  backward
+// The recompute form of attention_small.hip (dQ by query-tile owner, dK / dV by key-tile owner: 28 instead of 20 MFMAs per tile pair, no shared accumulator, no atomics, fixed
+// summation order) on the forward's streaming structure.  The q kernel runs first: it also computes D = rowsum(dO * O) for its query tile (it holds the dO fragments) and
+// writes it to `dvec` for the kv kernel.
+//   q kernel:  unit = (b, head, group of 4 query tiles); Q / dO / O fragments from global, K / V chunks through the double buffer, dQ^T (lane = query) in registers.
+//   kv kernel: unit = (b, head, group of 4 key tiles); K / V fragments from global, Q / dO chunks through the double buffer together with the chunk's 96 lse and D values
+//              (staged through one register per thread: loaded under the previous chunk, written to LDS before the chunk's barrier); dK^T, dV^T (lane = key) in registers.
+__global__ __launch_bounds__(256, 2) void attn_l_bwd_q_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld,
+                                                              const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, long ldo, const float* __restrict__ lse,
+                                                              float* __restrict__ dvec, bf16_t* __restrict__ dq, long ldd, int N, int H, float scale, int nitems, int G) {
+  VDK_DYN_LDS(smem);
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* const Wt = smem + 2 * AL_BUF + w * 4096;
+  const int nt = (N + 31) >> 5, nch = (N + AL_CROWS - 1) / AL_CROWS;
+  const float scale2 = scale * VDK_LOG2E;
+  const AsLane al = as_lane(lane);
+  const int x = blockIdx.x & 7, tstride = gridDim.x >> 3;
+  int t = blockIdx.x >> 3;
+  int item = (t / G) * 8 + x;
+  int cc = 0;
+  if (item < nitems) {
+    const long off0 = (long)(item / H) * N * ld + (item % H) * 64;
+    al_dma_chunk(smem, k + off0, v + off0, ld, N, 0, w, lane);
+  }
+  while (item < nitems) {
+    const int g = t % G;
+    const int b = item / H, h = item - b * H;
+    const long off = (long)b * N * ld + h * 64, offo = (long)b * N * ldo + h * 64;
+    const int qt = 4 * g + w;
+    const bool active = qt < nt;
+    const int qrow = qt * 32 + l31;
+    const int qr = qrow < N ? qrow : N - 1;
+    s16x8 qf[4], gf[4];
+    float dsum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = *(const s16x8*)(q + off + (long)qr * ld + ks * 16 + hi * 8);
+      gf[ks] = *(const s16x8*)(dout + offo + (long)qr * ldo + ks * 16 + hi * 8);
+      const u32x4 of = *(const u32x4*)(o + offo + (long)qr * ldo + ks * 16 + hi * 8);
+      const u32x4 gu = *(const u32x4*)&gf[ks];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { dsum = fmaf(bf_lo(gu[e]), bf_lo(of[e]), dsum); dsum = fmaf(bf_hi(gu[e]), bf_hi(of[e]), dsum); }
+    }
+    dsum += __shfl_xor(dsum, 32);                                    // the two half-waves hold the two halves of a query's 64 channels
+    const float lq = lse[((long)b * H + h) * N + qr] * VDK_LOG2E;
+    if (active && hi == 0 && qrow < N) dvec[((long)b * H + h) * N + qrow] = dsum;
+    const int tn = t + tstride;
+    const int itemn = (tn / G) * 8 + x;
+    const long offn = (long)(itemn / H) * N * ld + (itemn % H) * 64;
+    f32x16 gq0 = as_zero16(), gq1 = as_zero16();
+    for (int c = 0; c < nch; ++c, ++cc) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+      unsigned char* const nb = smem + ((cc + 1) & 1) * AL_BUF;
+      if (c + 1 < nch) al_dma_chunk(nb, k + off, v + off, ld, N, (c + 1) * AL_CROWS, w, lane);
+      else if (itemn < nitems) al_dma_chunk(nb, k + offn, v + offn, ld, N, 0, w, lane);
+      if (!active) continue;
+      const unsigned char* const Kb = smem + (cc & 1) * AL_BUF;
+      const unsigned char* const Vb = Kb + AL_ARR;
+      const int key0 = c * AL_CROWS;
+      const bool edge = key0 + AL_CROWS > N;                         // keys beyond N in this chunk (wave-uniform); a lane (= query) beyond N only spoils its own, unstored column
+#pragma unroll
+      for (int kt = 0; kt < AL_CT; ++kt) {
+        if (key0 + kt * 32 >= N) break;                              // a tile of nothing but keys beyond N (wave-uniform)
+        f32x16 st = as_zero16(), dp = as_zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Kb + kt * 32 * AS_ROW, al, ks), qf[ks], st, 0, 0, 0);   // S^T[key][q]: lane = query, registers = keys
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Vb + kt * 32 * AS_ROW, al, ks), gf[ks], dp, 0, 0, 0);   // dP^T[key][q]
+        }
+        f32x16 ds;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float p = fast_exp2(fmaf(st[r], scale2, -lq));
+          if (edge && key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= N) p = 0.f;
+          ds[r] = p * (dp[r] - dsum);
+        }
+        s16x8 df[2];
+        as_pack_b(ds, df);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          gq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Kb + (kt * 32 + 16 * s2) * AS_ROW, al, 0), df[s2], gq0, 0, 0, 0);   // dQ^T[d][q] += K^T dS^T
+          gq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Kb + (kt * 32 + 16 * s2) * AS_ROW, al, 1), df[s2], gq1, 0, 0, 0);
+        }
+      }
+    }
+    if (active) as_store_tile(Wt, gq0, gq1, scale, dq + (long)b * N * ldd + h * 64, ldd, qt * 32, N, lane);
+    t = tn;
+    item = itemn;
+  }
+}
+
+#define AL_BUFKV (AL_BUF + 1024)           // Q rows | dO rows | 128 lse values | 128 D values
+__global__ __launch_bounds__(256, 2) void attn_l_bwd_kv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld,
+                                                               const bf16_t* __restrict__ dout, long ldo, const float* __restrict__ lse, const float* __restrict__ dvec,
+                                                               bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long ldd, int N, int H, float scale, int nitems, int G) {
+  VDK_DYN_LDS(smem);
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* const Wt = smem + 2 * AL_BUFKV + w * 4096;
+  const int nt = (N + 31) >> 5, nch = (N + AL_CROWS - 1) / AL_CROWS;
+  const float scale2 = scale * VDK_LOG2E;
+  const AsLane al = as_lane(lane);
+  const int x = blockIdx.x & 7, tstride = gridDim.x >> 3;
+  int t = blockIdx.x >> 3;
+  int item = (t / G) * 8 + x;
+  int cc = 0;
+  // thread tid < 128 stages lse value tid of a chunk, thread 128 + i the D value i (96 of each are used)
+  const int srow_l = tid & 127;
+  float staged = 0.f;
+  auto stage_load = [&](int it, int r0) {
+    int row = r0 + srow_l;
+    row = row < N ? row : N - 1;
+    const float* src = tid < 128 ? lse : dvec;
+    staged = src[(long)it * N + row];
+  };
+  if (item < nitems) {
+    const long off0 = (long)(item / H) * N * ld + (item % H) * 64, offo0 = (long)(item / H) * N * ldo + (item % H) * 64;
+    al_dma_chunk2(smem, q + off0, ld, dout + offo0, ldo, N, 0, w, lane);
+    stage_load(item, 0);
+  }
+  while (item < nitems) {
+    const int g = t % G;
+    const int b = item / H, h = item - b * H;
+    const long off = (long)b * N * ld + h * 64, offo = (long)b * N * ldo + h * 64;
+    const int kt = 4 * g + w;
+    const bool active = kt < nt;
+    const int krow = kt * 32 + l31;
+    const long kr = (long)(krow < N ? krow : N - 1) * ld;
+    s16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { kf[ks] = *(const s16x8*)(k + off + kr + ks * 16 + hi * 8); vf[ks] = *(const s16x8*)(v + off + kr + ks * 16 + hi * 8); }
+    const int tn = t + tstride;
+    const int itemn = (tn / G) * 8 + x;
+    const long offn = (long)(itemn / H) * N * ld + (itemn % H) * 64, offon = (long)(itemn / H) * N * ldo + (itemn % H) * 64;
+    f32x16 gk0 = as_zero16(), gk1 = as_zero16(), gv0 = as_zero16(), gv1 = as_zero16();
+    for (int c = 0; c < nch; ++c, ++cc) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);                            // this wave's part of chunk cc has landed, and so has its staged lse / D value
+      ((float*)(smem + (cc & 1) * AL_BUFKV + AL_BUF))[tid] = staged;  // (buffer cc & 1 was last read in chunk cc - 2: everybody is past that since the previous barrier)
+      __syncthreads();
+      unsigned char* const nb = smem + ((cc + 1) & 1) * AL_BUFKV;
+      if (c + 1 < nch) { al_dma_chunk2(nb, q + off, ld, dout + offo, ldo, N, (c + 1) * AL_CROWS, w, lane); stage_load(item, (c + 1) * AL_CROWS); }
+      else if (itemn < nitems) { al_dma_chunk2(nb, q + offn, ld, dout + offon, ldo, N, 0, w, lane); stage_load(itemn, 0); }
+      if (!active) continue;
+      const unsigned char* const Qb = smem + (cc & 1) * AL_BUFKV;
+      const unsigned char* const Ob = Qb + AL_ARR;
+      const float* const lseb = (const float*)(Qb + AL_BUF);
+      const float* const Db = lseb + 128;
+      const int q0c = c * AL_CROWS;
+      const bool edge = q0c + AL_CROWS > N;                          // query rows beyond N in this chunk must be silenced (they would add into valid sums); wave-uniform
+#pragma unroll
+      for (int qt = 0; qt < AL_CT; ++qt) {
+        if (q0c + qt * 32 >= N) break;                               // a tile of nothing but query rows beyond N (wave-uniform)
+        f32x16 st = as_zero16(), dp = as_zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Qb + qt * 32 * AS_ROW, al, ks), kf[ks], st, 0, 0, 0);   // S[q][key]: lane = key, registers = queries
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Ob + qt * 32 * AS_ROW, al, ks), vf[ks], dp, 0, 0, 0);   // dP[q][key]
+        }
+        f32x16 pv, ds;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 lv = *(const f32x4*)(lseb + qt * 32 + 8 * g4 + 4 * hi);
+          const f32x4 dd = *(const f32x4*)(Db + qt * 32 + 8 * g4 + 4 * hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g4 + e;
+            float p = fast_exp2(fmaf(st[r], scale2, -lv[e] * VDK_LOG2E));
+            if (edge && q0c + qt * 32 + 8 * g4 + 4 * hi + e >= N) p = 0.f;
+            pv[r] = p;
+            ds[r] = p * (dp[r] - dd[e]);
+          }
+        }
+        s16x8 pf[2], df[2];
+        as_pack_b(pv, pf);
+        as_pack_b(ds, df);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          gv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Ob + (qt * 32 + 16 * s2) * AS_ROW, al, 0), pf[s2], gv0, 0, 0, 0);     // dV^T[d][key] += dO^T P
+          gv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Ob + (qt * 32 + 16 * s2) * AS_ROW, al, 1), pf[s2], gv1, 0, 0, 0);
+          gk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Qb + (qt * 32 + 16 * s2) * AS_ROW, al, 0), df[s2], gk0, 0, 0, 0);     // dK^T[d][key] += Q^T dS
+          gk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Qb + (qt * 32 + 16 * s2) * AS_ROW, al, 1), df[s2], gk1, 0, 0, 0);
+        }
+      }
+    }
+    if (active) {
+      as_store_tile(Wt, gk0, gk1, scale, dk + (long)b * N * ldd + h * 64, ldd, kt * 32, N, lane);
+      as_store_tile(Wt, gv0, gv1, 1.0f, dv + (long)b * N * ldd + h * 64, ldd, kt * 32, N, lane);
+    }
+    t = tn;
+    item = itemn;
+  }
+}
+
+static int al_grid(long units) {
+  int cap = 512;                                                     // two workgroups per CU
+  if (const char* e = getenv("VDK_ATTN_GRID")) { const int v = atoi(e); if (v > 0) cap = v; }   // tests: force several units per workgroup
+  long grid = units < cap ? units : cap;
+  return (int)((grid + 7) / 8 * 8);                                  // every XCD residue must be present: items are dealt to XCDs by item mod 8
+}
+
+// dqkv: bf16 [B, N, 3, H, 64]; dvec: f32 scratch [B, H, N]
+int vdk_attention_long_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv, int64_t ldd, float* dvec, int32_t B, int32_t N,
+                           int32_t H, float scale, void* stream) {
+  const bf16_t* base = (const bf16_t*)qkv;
+  bf16_t* dbase = (bf16_t*)dqkv;
+  const long D = (long)H * 64;
+  const int nt = (N + 31) / 32, G = (nt + 3) / 4;
+  const int grid = al_grid((long)B * H * G);
+  const size_t lds_q = 2 * AL_BUF + 4 * 4096, lds_kv = 2 * AL_BUFKV + 4 * 4096;
+  if (hipFuncSetAttribute((const void*)attn_l_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q) != hipSuccess ||
+      hipFuncSetAttribute((const void*)attn_l_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv) != hipSuccess)
+    return vdk_fail(VDK_ELAUNCH, "vdk_attention_bwd: LDS attribute");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_l_bwd_q_kernel, dim3((unsigned)grid), dim3(256), lds_q, s, base, base + D, base + 2 * D, (long)ld, (const bf16_t*)o, (const bf16_t*)dout, (long)ldo, lse, dvec,
+                     dbase, (long)ldd, (int)N, (int)H, scale, (int)(B * H), G);
+  hipLaunchKernelGGL(attn_l_bwd_kv_kernel, dim3((unsigned)grid), dim3(256), lds_kv, s, base, base + D, base + 2 * D, (long)ld, (const bf16_t*)dout, (long)ldo, lse, (const float*)dvec,
+                     dbase + D, dbase + 2 * D, (long)ldd, (int)N, (int)H, scale, (int)(B * H), G);
+  return VDK_OK;
+}
+
 // in-library entry point (attention.hip routes N > 256 here)
 int vdk_attention_long_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H, float scale, void* stream) {
   const bf16_t* base = (const bf16_t*)qkv;
   const long D = (long)H * 64;
   const int nt = (N + 31) / 32, G = (nt + 3) / 4;
   const long units = (long)B * H * G;
-  int cap = 512;                                                     // two workgroups per CU
-  if (const char* e = getenv("VDK_ATTN_GRID")) { const int v = atoi(e); if (v > 0) cap = v; }   // tests: force several units per workgroup
-  long grid = units < cap ? units : cap;
-  grid = (grid + 7) / 8 * 8;                                         // every XCD residue must be present: items are dealt to XCDs by item mod 8
+  const int grid = al_grid(units);
   const size_t lds = 2 * AL_BUF + 4 * 4096;
   if (hipFuncSetAttribute((const void*)attn_l_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return vdk_fail(VDK_ELAUNCH, "vdk_attention_fwd: LDS attribute");
