@@ -139,6 +139,11 @@ int vdk_gemm_bf16_nt(const VdkGemmDesc* d, void* ws, size_t ws_bytes, void* stre
 int vdk_quant_fp8(const void* x, int32_t x_dtype, int64_t n, const float* scale, void* out_fp8, int32_t fmt, float* amax, void* stream);
 int vdk_fp8_scale_update(float* amax, float* scale, float* scale_inv, int32_t n, int32_t fmt, float margin, void* stream);
 int vdk_gemm_fp8_nt(const VdkGemmDesc* d, int32_t a_fmt, int32_t b_fmt, const float* a_scale_inv, const float* b_scale_inv, void* stream);
+/* the same GEMM, and the epilogue that stores the bf16 C also writes what vdk_quant_fp8(C, out_scale, out_fmt) would (bit-identical) and accumulates max |C| into out_amax:
+ * the output of fc1 + GELU / of the dGELU input-gradient GEMM is the A operand of the next fp8 GEMM (timm Mlp, models/classifier/classify_model.py:49-54), so the separate
+ * quantisation pass over it (2 B read + 1 B written per element) disappears.  GELU (+ bias + aux) and DGELU epilogues only, bf16 C, N % 64 == 0, ldo8 % 8 == 0. */
+int vdk_gemm_fp8_nt_q8(const VdkGemmDesc* d, int32_t a_fmt, int32_t b_fmt, const float* a_scale_inv, const float* b_scale_inv, void* out8, int64_t ldo8, int32_t out_fmt,
+                       const float* out_scale, float* out_amax, void* stream);
 /* tests / A-B benchmarking only: 0 = automatic choice, 1 = 128x128 register-staged kernel, 2 = 256x256 LDS-DMA kernel
  * (the latter still requires K and the split size to be multiples of 64), 3 = stream-K whenever splitk == -1 lends a workspace, 4 = never stream-K. */
 int vdk_gemm_c_colsum_rows(int32_t M, int32_t N, int32_t K);   /* rows of VdkGemmDesc.c_colsum, 0 = by-product not available for this problem */

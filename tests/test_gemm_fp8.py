@@ -78,6 +78,35 @@ def test_fp8_gemm_fused_epilogues(be, dev):
     assert _rel(du.float(), (_deq(dy, 1) @ _deq(b, 0).t()) * gp) < 3e-3
 
 
+@pytest.mark.parametrize("M", [256, 300])
+def test_fp8_copy_of_the_output_rides_with_the_epilogue(be, dev, M):
+    """vdk_gemm_fp8_nt_q8: the GELU / dGELU epilogues also write the fp8 quantisation of the bf16 tensor they store (the A operand of the next fp8 GEMM) and accumulate its
+    amax -- bit-identical to the separate vdk_quant_fp8 pass over that tensor, which is what the engine's fp8 mode runs without the fusion."""
+    torch.manual_seed(5)
+    N, K = 512, 256
+    a = ops.quant_fp8(torch.randn(M, K).to(dev), None, FP8_E4M3, None, backend=be) if M % 16 == 0 else ops.quant_fp8(torch.randn(304, K).to(dev), None, FP8_E4M3, None, backend=be)[:M]
+    b = ops.quant_fp8((torch.randn(N, K) * 0.1).to(dev), None, FP8_E4M3, None, backend=be)
+    bias = torch.randn(N, device=dev) * 0.1
+    u = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    sc = torch.tensor([37.0], device=dev); am = torch.zeros(1, device=dev)
+    g, g8 = ops.gemm_fp8_nt(a, b, bias=bias, act=ACT_GELU, aux=u, backend=be, q8={"fmt": FP8_E4M3, "scale": sc, "amax": am})
+    g_plain = ops.gemm_fp8_nt(a, b, bias=bias, act=ACT_GELU, aux=torch.zeros_like(u), backend=be)
+    assert torch.equal(g, g_plain)
+    am_ref = torch.zeros(1, device=dev)
+    gpad = torch.zeros((M + 15) // 16 * 16, N, dtype=torch.bfloat16, device=dev); gpad[:M] = g
+    ref8 = ops.quant_fp8(gpad, sc, FP8_E4M3, am_ref, backend=be)[:M]
+    assert torch.equal(g8, ref8) and torch.equal(am, am_ref) and am.item() > 0
+    dy = ops.quant_fp8(torch.randn((M + 15) // 16 * 16, K).to(dev), None, FP8_E5M2, None, backend=be)[:M]
+    sc2 = torch.tensor([900.0], device=dev); am2 = torch.zeros(1, device=dev)
+    du, du8 = ops.gemm_fp8_nt(dy, b, a_fmt=FP8_E5M2, act=ACT_DGELU, aux=u, backend=be, q8={"fmt": FP8_E5M2, "scale": sc2, "amax": am2})
+    am2_ref = torch.zeros(1, device=dev)
+    dpad = torch.zeros((M + 15) // 16 * 16, N, dtype=torch.bfloat16, device=dev); dpad[:M] = du
+    ref8 = ops.quant_fp8(dpad, sc2, FP8_E5M2, am2_ref, backend=be)[:M]
+    assert torch.equal(du8, ref8) and torch.equal(am2, am2_ref)
+    with pytest.raises(RuntimeError):        # the plain bias form has no fp8 by-product
+        ops.gemm_fp8_nt(a, b, bias=bias, backend=be, q8={"fmt": FP8_E4M3, "scale": sc, "amax": am})
+
+
 def test_fp8_linear_error_against_fp32(be, dev):
     """the stated fp8 tolerance: a Linear with per-tensor scaled e4m3 operands against the fp32 product -- 2^-4 relative rounding per
     operand element averages to a few percent of the output norm: <= 5e-2 here (measured 3.6e-2), against 4e-3 for bf16 operands"""

@@ -84,3 +84,22 @@ def test_fp8_train_steps_track_the_bf16_run(be, dev):
     print(losses)
     assert all(abs(a - b) < 5e-2 * abs(a) for a, b in zip(losses[0], losses[1]))
     assert losses[1][-1] < losses[1][0]
+
+
+def test_fp8_copies_from_the_gelu_epilogues_change_nothing(be, dev, monkeypatch):
+    """delayed scaling: the fp8 copies of the GELU output and of d(pre-activation) are written by the fc1 / dGELU epilogues (vdk_gemm_fp8_nt_q8) instead of separate
+    quantisation passes -- same bytes, same amax, so logits, every gradient and the recorded scaling state are bit-identical with the fusion switched off"""
+    _, model = _pair(be, dev)
+    torch.manual_seed(3)
+    x = torch.randn(4, 3, 64, 64); y = torch.randint(0, 10, (4,))
+    model.engine.enable_fp8(2); _fwd_bwd(model, x, y, dev); model.engine.fp8_update()          # calibration pass: scales for the delayed mode
+    model.engine.enable_fp8(1)
+    st0 = model.engine.fp8_state.clone()
+    la, ga = _fwd_bwd(model, x, y, dev)
+    sta = model.engine.fp8_state.clone()
+    model.engine.fp8_state.copy_(st0)
+    monkeypatch.setenv("VDK_FP8_FUSED_QUANT", "0")
+    lb, gb = _fwd_bwd(model, x, y, dev)
+    stb = model.engine.fp8_state.clone()
+    assert torch.equal(la, lb) and all(torch.equal(ga[n], gb[n]) for n in ga)
+    assert torch.equal(sta, stb) and float(sta[0].max()) > 0                                  # amax of this pass recorded identically

@@ -1,7 +1,4 @@
 mkdir -p gpurun_out/r2x
-python -m pytest tests/test_attention.py -m gpu -x -q 2>&1 | tail -3
-echo default; python tools/bench_attention.py 256 197 12 | tee gpurun_out/r2x/attn_197_default.json
-echo streaming; VDK_ATTN_LONG_MIN=1 python tools/bench_attention.py 256 197 12 | tee gpurun_out/r2x/attn_197_streaming.json
-python tools/bench_attention.py 128 576 16 | tee gpurun_out/r2x/attn_576.json
-python tools/bench_attention.py 256 257 16 | tee gpurun_out/r2x/attn_257.json
-python tools/bench_attention.py 128 577 16 | tee gpurun_out/r2x/attn_577.json
+python tools/_q8_probe.py | tee gpurun_out/r2x/q8_probe.json
+python -m pytest tests/test_gemm_fp8.py tests/test_vit_fp8.py -m gpu -x -q 2>&1 | tail -3
+python tools/bench_cfg5.py 128 3 | tee gpurun_out/r2x/cfg5.json

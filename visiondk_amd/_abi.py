@@ -90,6 +90,7 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_quant_fp8": (C.c_int, [P, I32, I64, P, P, I32, P, P]),
     "vdk_fp8_scale_update": (C.c_int, [P, P, P, I32, I32, F32, P]),
     "vdk_gemm_fp8_nt": (C.c_int, [P, I32, I32, P, P, P]),
+    "vdk_gemm_fp8_nt_q8": (C.c_int, [P, I32, I32, P, P, P, I64, I32, P, P, P]),
     "vdk_gemm_debug_stamps": (C.c_int, [P]),
     "vdk_prof_begin": (C.c_int, [I32]),
     "vdk_prof_pause": (C.c_int, [I32]),

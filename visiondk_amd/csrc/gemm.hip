@@ -560,6 +560,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { bias8[e] = b0v[e]; bias8[4 + e] = b1v[e]; }
   }
+  float q8_unused = 0.f;                                  // (the fp8 by-product E_Q8 is instantiated by the fp8 kernel only)
 #pragma unroll
   for (int half = 0; half < 2; ++half) {   // fully unrolled: acc must be indexed statically (else it lives in scratch)
 #pragma unroll
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
           slab[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + ct * 32 + l31] = acc[half * 2 + rt][ct][r];
     __builtin_amdgcn_wave_barrier();
     if (E != E_GENERIC) {
-      h_epilogue_half<E>(p, slab, lane, (long)m0 + wr * 128 + half * 64, ncol, z, bias8, ocs8);
+      h_epilogue_half<E>(p, slab, lane, (long)m0 + wr * 128 + half * 64, ncol, z, bias8, ocs8, q8_unused);
     } else {
 #pragma unroll
       for (int pass = 0; pass < 8; ++pass) {

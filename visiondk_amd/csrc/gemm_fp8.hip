@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512) void gemm256_fp8_kernel(Fp8Params q) {
   p.alpha = p.alpha * (q.a_scale_inv ? q.a_scale_inv[0] : 1.0f) * (q.b_scale_inv ? q.b_scale_inv[0] : 1.0f);
   float* slab = (float*)(smem + w * 16384);
   const int ncol = n0 + wc * 64 + (lane & 7) * 8;
-  float bias8[8], ocs_unused[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float bias8[8], ocs_unused[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q8am = 0.f;
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
   if ((E & E_BIAS) && ncol < p.N) {
@@ -181,8 +181,24 @@ __global__ __launch_bounds__(512) void gemm256_fp8_kernel(Fp8Params q) {
         for (int r = 0; r < 16; ++r)
           slab[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + ct * 32 + l31] = acc[half * 2 + rt][ct][r] * p.alpha;
     __builtin_amdgcn_wave_barrier();
-    h_epilogue_half<E>(p, slab, lane, (long)m0 + wr * 128 + half * 64, ncol, 0, bias8, ocs_unused);
+    h_epilogue_half<E>(p, slab, lane, (long)m0 + wr * 128 + half * 64, ncol, 0, bias8, ocs_unused, q8am);
     __builtin_amdgcn_wave_barrier();
+  }
+  if ((E & E_Q8) && p.q8_amax) {
+    // amax of the by-product: ONE atomic per workgroup, and only when it can raise the value (an atomic per wave and half was measured: 73 728 same-address atomics per
+    // GEMM = +340 us on a 630 us kernel; the fp8 stores themselves are free).  The plain read may be stale, but the value only grows: skipping on "not larger" is safe.
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) q8am = fmaxf(q8am, __shfl_xor(q8am, off));
+    __syncthreads();                                      // every wave is done with its slab (the reduction slots alias the first one)
+    float* red = (float*)smem;
+    if (lane == 0) red[w] = q8am;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = red[0];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) m = fmaxf(m, red[i]);
+      if (m > *(volatile float*)p.q8_amax) atomicMax((unsigned*)p.q8_amax, __float_as_uint(m));      // non-negative floats order like their bit patterns
+    }
   }
 #undef F_REG
 #undef F_ISSUE_A
@@ -263,6 +279,12 @@ int vdk_fp8_scale_update(float* amax, float* scale, float* scale_inv, int32_t n,
 // M % 256 == 0 is not required (rows are masked), N % 8 == 0, K % 128 == 0, M, N >= 256.  Epilogue fields of the descriptor as for vdk_gemm_bf16_nt (bias, GELU + aux,
 // DGELU, residual, c_dtype); splitk / trans / conv / row_group / a_colsum are not served (VDK_EUNSUPPORTED): the bf16 kernels keep those.
 int vdk_gemm_fp8_nt(const VdkGemmDesc* d, int32_t a_fmt, int32_t b_fmt, const float* a_scale_inv, const float* b_scale_inv, void* stream_) {
+  return vdk_gemm_fp8_nt_q8(d, a_fmt, b_fmt, a_scale_inv, b_scale_inv, nullptr, 0, 0, nullptr, nullptr, stream_);
+}
+// + an fp8 copy of the bf16 output (out8 [M, ldo8] bytes, out_fmt, device scalar out_scale, amax accumulated into out_amax): what vdk_quant_fp8 would make of C, written by
+// the epilogue that stores C -- for the GELU and dGELU forms (bf16 C, N % 64 == 0), whose outputs are the A operands of the next fp8 GEMM
+int vdk_gemm_fp8_nt_q8(const VdkGemmDesc* d, int32_t a_fmt, int32_t b_fmt, const float* a_scale_inv, const float* b_scale_inv, void* out8, int64_t ldo8, int32_t out_fmt,
+                       const float* out_scale, float* out_amax, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!d || !d->A || !d->B || !d->C) return vdk_fail(VDK_EINVAL, "vdk_gemm_fp8_nt: null pointer");
   if (d->M < 256 || d->N < 256 || d->K <= 0 || (d->K % 128) || (d->N & 7) || (d->lda & 15) || (d->ldb & 15) || (d->ldc & 7))
@@ -284,6 +306,13 @@ int vdk_gemm_fp8_nt(const VdkGemmDesc* d, int32_t a_fmt, int32_t b_fmt, const fl
   else if (res && d->act == VDK_ACT_NONE && f32 && bias) E = E_BIAS | E_RES | E_F32;
   else if (!res && d->act == VDK_ACT_NONE && f32 && !bias) E = E_F32;
   if (E < 0) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_fp8_nt: epilogue combination not instantiated");
+  p.q8 = nullptr; p.ldq8 = 0; p.q8_scale = nullptr; p.q8_amax = nullptr; p.q8_fmt = 0;
+  if (out8) {
+    if ((E != (E_BIAS | E_GELU) && E != E_DGELU) || (d->N & 63) || (ldo8 & 7) || ldo8 < d->N || (out_fmt != 0 && out_fmt != 1))
+      return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_fp8_nt_q8: the fp8 copy rides with the GELU / dGELU epilogues only (bf16 C, N % 64 == 0, ldo8 % 8 == 0)");
+    p.q8 = (unsigned char*)out8; p.ldq8 = ldo8; p.q8_scale = out_scale; p.q8_amax = out_amax; p.q8_fmt = out_fmt;
+    E |= E_Q8;
+  }
   const dim3 grid((unsigned)(((d->M + 255) / 256) * ((d->N + 255) / 256)));
 #define L8(AFv, EE) hipLaunchKernelGGL((gemm256_fp8_kernel<AFv, 0, EE>), grid, dim3(512), 0, stream, q)
 #define L8E(AFv)                                                   \
@@ -292,6 +321,8 @@ int vdk_gemm_fp8_nt(const VdkGemmDesc* d, int32_t a_fmt, int32_t b_fmt, const fl
     case E_BIAS: L8(AFv, E_BIAS); break;                          \
     case E_BIAS | E_GELU: L8(AFv, E_BIAS | E_GELU); break;        \
     case E_DGELU: L8(AFv, E_DGELU); break;                        \
+    case E_BIAS | E_GELU | E_Q8: L8(AFv, E_BIAS | E_GELU | E_Q8); break; \
+    case E_DGELU | E_Q8: L8(AFv, E_DGELU | E_Q8); break;          \
     case E_BIAS | E_RES | E_F32: L8(AFv, E_BIAS | E_RES | E_F32); break; \
     default: L8(AFv, E_F32); break;                               \
   }

@@ -70,11 +70,12 @@ __device__ __forceinline__ void g_epilogue_store8(const GemmParams& p, long mi, 
 #define E_OCS 128     /* by-product: column sums of the stored (bf16-rounded) output over this wave's 128 rows -> p.ocs_part (bias gradient of the next Linear back) */
 #define E_MSTAT 256   /* margin head, pass 1: per-(row, 64-column slice) online-softmax partials of the margin logits; nothing is stored to C */
 #define E_MGRAD 512   /* margin head, pass 2: C = bf16 d(loss)/d(cos) from the row statistics */
+#define E_Q8 1024     /* by-product: fp8(clamp(stored bf16 value * q8_scale)) -> p.q8, max |value| -> p.q8_amax: bit-identical to vdk_quant_fp8 over the stored tensor */
 #define E_GENERIC 0x1000
 
 template <int E>
 __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float* slab, int lane, long mbase /* first row of this 64-row half */,
-                                                int n, int z, const float (&bias8)[8], float (&ocs)[8]) {
+                                                int n, int z, const float (&bias8)[8], float (&ocs)[8], float& q8am) {
   // this lane: rows mbase + pass*8 + (lane >> 3), pass = 0..7, columns n .. n+7
   const int rsub = lane >> 3, cc = (lane & 7) * 8;
   if (E & E_MSTAT) {     // margin logits of this lane's 8 columns -> (max, sum exp, sum) merged over the 8 lanes that share a row -> one partial per (row, 64-column slice)
@@ -126,6 +127,8 @@ __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float
   }
   f32x4 r0[8], r1[8];
   u32x4 ux[8];
+  float q8s = 1.0f, q8lim = 448.0f;      // (q8am: this lane's running max |stored value|, reduced by the kernel once per workgroup)
+  if (E & E_Q8) { q8s = p.q8_scale ? p.q8_scale[0] : 1.0f; q8lim = p.q8_fmt == 0 ? 448.0f : 57344.0f; }
   if (E & E_RES) {
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps)
@@ -197,7 +200,24 @@ __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float
 #pragma unroll
         for (int e = 0; e < 4; ++e) { ocs[2 * e] += bf_lo(o[e]); ocs[2 * e + 1] += bf_hi(o[e]); }
       }
+      if (E & E_Q8) {
+        float c[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = bf_lo(o[e]), b = bf_hi(o[e]);
+          q8am = fmaxf(q8am, fmaxf(fabsf(a), fabsf(b)));
+          c[2 * e] = fminf(fmaxf(a * q8s, -q8lim), q8lim); c[2 * e + 1] = fminf(fmaxf(b * q8s, -q8lim), q8lim);
+        }
+        int lo = 0, up = 0;
+        if (p.q8_fmt == 0) {
+          lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], lo, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
+          up = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], up, false); up = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], up, true);
+        } else {
+          lo = __builtin_amdgcn_cvt_pk_bf8_f32(c[0], c[1], lo, false); lo = __builtin_amdgcn_cvt_pk_bf8_f32(c[2], c[3], lo, true);
+          up = __builtin_amdgcn_cvt_pk_bf8_f32(c[4], c[5], up, false); up = __builtin_amdgcn_cvt_pk_bf8_f32(c[6], c[7], up, true);
+        }
+        *(u32x2*)(p.q8 + mo[ps] * p.ldq8 + n) = (u32x2){(unsigned)lo, (unsigned)up};
+      }
     }
   }
 }
-

@@ -13,6 +13,7 @@
 //   residual stream                 : fp32 [B*N, D] per block boundary (what timm keeps in fp32 under autocast)
 //   GEMM operands / saved tensors   : bf16
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 #include "vdk_device.h"
@@ -41,6 +42,7 @@ int vdk_patchify_f32(const float*, int32_t, int32_t, int32_t, int32_t, int32_t, 
 int vdk_quant_fp8(const void*, int32_t, int64_t, const float*, void*, int32_t, float*, void*);
 int vdk_fp8_scale_update(float*, float*, float*, int32_t, int32_t, float, void*);
 int vdk_gemm_fp8_nt(const VdkGemmDesc*, int32_t, int32_t, const float*, const float*, void*);
+int vdk_gemm_fp8_nt_q8(const VdkGemmDesc*, int32_t, int32_t, const float*, const float*, void*, int64_t, int32_t, const float*, float*, void*);
 }
 
 static inline int64_t up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -189,6 +191,7 @@ struct WsPlan {
   size_t dhf;                    // bf16 [B, D]
   size_t dposall;                // fp32 [N, D]
   size_t a8;                     // fp8 mode: the quantised A operand of the GEMM about to run, [T, max(M, 3D)] bytes
+  size_t a8b;                    // fp8 mode: the fp8 copy a GELU / dGELU epilogue writes for the NEXT GEMM (while a8 is still being read), [T, M] bytes
 };
 static size_t w_take(size_t& cur, size_t n) { size_t o = cur; cur = (cur + n + 255) & ~(size_t)255; return o; }
 static int wgrad_splitk(int M, int N, int K) {
@@ -253,6 +256,7 @@ static int vit_plan(const VitDims& d, WsPlan* w) {
   w->dhf = w_take(cur, (size_t)d.B * D * 2);
   w->dposall = w_take(cur, (size_t)d.N * D * 4);
   w->a8 = d.fp8 ? w_take(cur, T * (M > 3 * D ? M : 3 * D)) : 0;
+  w->a8b = d.fp8 ? w_take(cur, T * M) : 0;
   w->total = cur;
   return VDK_OK;
 }
@@ -261,10 +265,10 @@ static int vit_plan(const VitDims& d, WsPlan* w) {
 
 // ---- fp8 mode (VdkVitConfig.fp8): OCP e4m3 / e5m2 operands for the forward and input-gradient GEMMs of the block Linears ------------------------------------
 struct F8 {
-  int mode; unsigned char* w8; unsigned char* wt8; float* amax; float* sc; float* si; unsigned char* a8;
+  int mode; unsigned char* w8; unsigned char* wt8; float* amax; float* sc; float* si; unsigned char* a8; unsigned char* a8b;
 };
-static int f8_init(const VdkVitConfig* cfg, const VitDims& d, const PLayout& p, F8* f, unsigned char* a8) {
-  f->mode = d.fp8; f->a8 = a8;
+static int f8_init(const VdkVitConfig* cfg, const VitDims& d, const PLayout& p, F8* f, unsigned char* a8, unsigned char* a8b) {
+  f->mode = d.fp8; f->a8 = a8; f->a8b = a8b;
   if (!d.fp8) return VDK_OK;
   if (!cfg->fp8_w || !cfg->fp8_state) return vdk_fail(VDK_EINVAL, "vit: fp8 mode without fp8_w / fp8_state");
   if (a8 && d.T < 256) return vdk_fail(VDK_EUNSUPPORTED, "vit: the fp8 mode needs batch * tokens >= 256");
@@ -281,13 +285,20 @@ static int f8_quant(hipStream_t s, const F8& f, const void* x, int xdt, long n, 
   }
   return vdk_quant_fp8(x, xdt, n, f.sc + slot, out, fmt, f.amax + slot, s);
 }
-// C = epilogue(A8[M, K] . W8[N, K]^T / (scale_a scale_w)): `a` is quantised into the scratch operand first
+// C = epilogue(A8[M, K] . W8[N, K]^T / (scale_a scale_w)): `a` is quantised into the scratch operand first -- unless the GEMM that produced it already wrote its fp8 copy
+// (a_ready: f.a8b, made by that GEMM's epilogue with slot_a's scale).  q8_slot >= 0: this GEMM's epilogue writes the fp8 copy of ITS bf16 output for the next one (delayed
+// scaling only: the scale must be known before the values are; the calibration step and mode 2 keep the separate pass).
+static bool f8_fused(const F8& f) {
+  const char* e = getenv("VDK_FP8_FUSED_QUANT");                        // A/B and tests: 0 keeps the separate quantisation passes (read per call: the tests switch it in-process)
+  return f.mode == 1 && !(e && e[0] == '0');
+}
 static int gemm8(hipStream_t s, const F8& f, const void* a, int slot_a, int a_fmt, const unsigned char* w8, int slot_w, int64_t ldb, void* Cc, int64_t ldc, int M, int N,
-                 int K, int cdt, const float* bias, const float* res, int64_t ldr, int act, void* aux, int64_t ldaux) {
-  RC(f8_quant(s, f, a, VDK_BF16, (long)M * K, slot_a, a_fmt, f.a8));
+                 int K, int cdt, const float* bias, const float* res, int64_t ldr, int act, void* aux, int64_t ldaux, bool a_ready = false, int q8_slot = -1, int q8_fmt = 0) {
+  if (!a_ready) RC(f8_quant(s, f, a, VDK_BF16, (long)M * K, slot_a, a_fmt, f.a8));
   VdkGemmDesc g = {};
-  g.A = f.a8; g.lda = K; g.B = w8; g.ldb = ldb; g.C = Cc; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.c_dtype = cdt; g.bias = bias; g.residual = res; g.ldr = ldr;
+  g.A = a_ready ? f.a8b : f.a8; g.lda = K; g.B = w8; g.ldb = ldb; g.C = Cc; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.c_dtype = cdt; g.bias = bias; g.residual = res; g.ldr = ldr;
   g.act = act; g.aux = aux; g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = 1;
+  if (q8_slot >= 0) return vdk_gemm_fp8_nt_q8(&g, a_fmt, 0, f.si + slot_a, f.si + slot_w, f.a8b, N, q8_fmt, f.sc + q8_slot, f.amax + q8_slot, s);
   return vdk_gemm_fp8_nt(&g, a_fmt, 0, f.si + slot_a, f.si + slot_w, s);
 }
 __global__ void vit_fp8_update_kernel(float* __restrict__ amax, float* __restrict__ sc, float* __restrict__ si, int n) {
@@ -380,7 +391,7 @@ int vdk_vit_refresh_weights(const VdkVitConfig* cfg, const float* params, void* 
   if (d.C > 0) add(params + p.head_w, d.D, d.Cp, d.D, wt + p.headT, d.Cp, d.Cp);
   RC(vdk_transpose_cast_batch(jobs.data(), (int)jobs.size(), stream));
   if (d.fp8) {     // e4m3 copies of the block Linears' weights, both orientations, one scale per tensor taken from the weights themselves (current scaling)
-    F8 f; RC(f8_init(cfg, d, p, &f, nullptr));
+    F8 f; RC(f8_init(cfg, d, p, &f, nullptr, nullptr));
     hipStream_t s = (hipStream_t)stream;
     for (int l = 0; l < d.L; ++l) {
       const PLayout::Blk& b = p.blk[l]; const PLayout::BlkT& bt = p.blkT[l];
@@ -434,7 +445,7 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
   if (d.cls) RC(vdk_cls_rows(X, (int64_t)d.N * D, d.B, D, params + p.cls, params + p.pos, s));
 
   const float scale = 0.125f;  // head_dim ** -0.5, head_dim == 64
-  F8 f8; RC(f8_init(cfg, d, p, &f8, (unsigned char*)(base + w.a8)));
+  F8 f8; RC(f8_init(cfg, d, p, &f8, (unsigned char*)(base + w.a8), (unsigned char*)(base + w.a8b)));
   for (int l = 0; l < d.L; ++l) {
     const PLayout::Blk& b = p.blk[l];
     float* xin = X + (size_t)(2 * l) * XS; float* xmid = xin + XS; float* xout = xmid + XS;
@@ -450,8 +461,9 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
       RC(vdk_attention_fwd(qkv, 3 * D, o, D, lse, d.B, d.N, d.H, 64, scale, s));
       RC(gemm8(s, f8, o, sl + 1, 0, f8.w8 + b.proj_w, sl + 5, D, xmid, D, T, D, D, VDK_F32, params + b.proj_b, xin, D, VDK_ACT_NONE, nullptr, 0));
       RC(vdk_layernorm_fwd(xmid, D, T, D, params + b.n2w, params + b.n2b, d.eps, h2, D, VDK_BF16, mean2, rstd2, s));
-      RC(gemm8(s, f8, h2, sl + 2, 0, f8.w8 + b.fc1_w, sl + 6, D, g, M, T, M, D, VDK_BF16, params + b.fc1_b, nullptr, 0, VDK_ACT_GELU, u, M));
-      RC(gemm8(s, f8, g, sl + 3, 0, f8.w8 + b.fc2_w, sl + 7, M, xout, D, T, D, M, VDK_F32, params + b.fc2_b, xmid, D, VDK_ACT_NONE, nullptr, 0));
+      const bool fq = f8_fused(f8) && (M % 64) == 0;                 // g's fp8 copy comes out of the fc1 + GELU epilogue
+      RC(gemm8(s, f8, h2, sl + 2, 0, f8.w8 + b.fc1_w, sl + 6, D, g, M, T, M, D, VDK_BF16, params + b.fc1_b, nullptr, 0, VDK_ACT_GELU, u, M, false, fq ? sl + 3 : -1, 0));
+      RC(gemm8(s, f8, g, sl + 3, 0, f8.w8 + b.fc2_w, sl + 7, M, xout, D, T, D, M, VDK_F32, params + b.fc2_b, xmid, D, VDK_ACT_NONE, nullptr, 0, fq));
       continue;
     }
     RC(gemm(s, h1, D, wb + b.qkv_w, D, qkv, 3 * D, T, 3 * D, D, VDK_BF16, params + b.qkv_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
@@ -595,7 +607,7 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
   }
   // ---- blocks, last to first ------------------------------------------------------------------------
   bool fc2_bias_from_norm1 = false;
-  F8 f8; RC(f8_init(cfg, d, p, &f8, (unsigned char*)(base + w.a8)));
+  F8 f8; RC(f8_init(cfg, d, p, &f8, (unsigned char*)(base + w.a8), (unsigned char*)(base + w.a8b)));
   for (int l = d.L - 1; l >= 0; --l) {
     const PLayout::Blk& b = p.blk[l];
     float* xin = X + (size_t)(2 * l) * XS; float* xmid = xin + XS;
@@ -619,9 +631,10 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
       // fc2.bias comes with DXAB(l) when the norm backward above produced it; fc1.bias is a column-sum pass over du (the fp8 kernel has no by-products).
       const int sl = 12 * l;
       const bool have_fc2b = one_stream && ((l == d.L - 1) ? last_fc2_bias_done : fc2_bias_from_norm1);
-      RC(gemm8(s, f8, dxab, sl + 8, 1, f8.wt8 + p.blkT[l].fc2, sl + 7, D, du, M, T, M, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_DGELU, u, M));          // du
+      const bool fq = f8_fused(f8) && (M % 64) == 0;                 // du's e5m2 copy comes out of the dGELU epilogue
+      RC(gemm8(s, f8, dxab, sl + 8, 1, f8.wt8 + p.blkT[l].fc2, sl + 7, D, du, M, T, M, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_DGELU, u, M, false, fq ? sl + 9 : -1, 1));   // du
       RC(linear_wgrad(s2, d, w, base, dxab, D, g, M, T, d.Tp, D, M, grads + b.fc2_w, have_fc2b ? nullptr : grads + b.fc2_b, 0));
-      RC(gemm8(s, f8, du, sl + 9, 1, f8.wt8 + p.blkT[l].fc1, sl + 6, M, dsm, D, T, D, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0));      // dh2
+      RC(gemm8(s, f8, du, sl + 9, 1, f8.wt8 + p.blkT[l].fc1, sl + 6, M, dsm, D, T, D, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, fq));      // dh2
       RC(linear_wgrad(s2, d, w, base, du, M, h2, D, T, d.Tp, M, D, grads + b.fc1_w, grads + b.fc1_b, 0));
     } else if (one_stream) {
       // Bias gradients ride with the PRODUCER of each dY (it sums what it stores): fc2.bias with DXAB(l) (norm backward of the block above), fc1.bias with du

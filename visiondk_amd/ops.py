@@ -100,8 +100,10 @@ def fp8_scale_update(amax: torch.Tensor, scale: torch.Tensor, scale_inv: torch.T
 
 
 def gemm_fp8_nt(a8: torch.Tensor, b8: torch.Tensor, a_scale_inv: Optional[torch.Tensor] = None, b_scale_inv: Optional[torch.Tensor] = None, *, a_fmt: int = FP8_E4M3,
-                out_dtype=torch.bfloat16, bias=None, residual=None, act: int = ACT_NONE, aux=None, backend=None) -> torch.Tensor:
-    """out[M,N] = epilogue(a_scale_inv * b_scale_inv * a8[M,K] @ b8[N,K].T): uint8 tensors of fp8 bytes (a: e4m3 or e5m2, b: e4m3), fp32 accumulation on the scaled MFMA"""
+                out_dtype=torch.bfloat16, bias=None, residual=None, act: int = ACT_NONE, aux=None, backend=None, q8: Optional[dict] = None) -> torch.Tensor:
+    """out[M,N] = epilogue(a_scale_inv * b_scale_inv * a8[M,K] @ b8[N,K].T): uint8 tensors of fp8 bytes (a: e4m3 or e5m2, b: e4m3), fp32 accumulation on the scaled MFMA.
+    q8 = {"fmt": FP8_E4M3 | FP8_E5M2, "scale": f32[1] | None, "amax": f32[1] | None}: the epilogue also writes the fp8 quantisation of `out` (GELU / DGELU forms) and
+    the call returns (out, out8) -- bit-identical to quant_fp8(out, ...)."""
     be = _be(backend)
     assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and a8.dim() == 2 and b8.dim() == 2 and a8.shape[1] == b8.shape[1]
     M, K = a8.shape
@@ -121,6 +123,12 @@ def gemm_fp8_nt(a8: torch.Tensor, b8: torch.Tensor, a_scale_inv: Optional[torch.
     for t in (a8, b8, out, residual, aux):
         if t is not None and be.device_only and not t.is_cuda:
             raise RuntimeError("visiondk_amd: HIP backend got a CPU tensor (there is no CPU fallback)")
+    if q8 is not None:
+        out8 = torch.empty((M, N), dtype=torch.uint8, device=a8.device)
+        be.check(be.lib.vdk_gemm_fp8_nt_q8(C.byref(d), a_fmt, FP8_E4M3, be.ptr(a_scale_inv) if a_scale_inv is not None else None,
+                                           be.ptr(b_scale_inv) if b_scale_inv is not None else None, out8.data_ptr(), out8.stride(0), int(q8.get("fmt", FP8_E4M3)),
+                                           be.ptr(q8.get("scale")), be.ptr(q8.get("amax")), be.stream()), "vdk_gemm_fp8_nt_q8")
+        return out, out8
     be.check(be.lib.vdk_gemm_fp8_nt(C.byref(d), a_fmt, FP8_E4M3, be.ptr(a_scale_inv) if a_scale_inv is not None else None,
                                     be.ptr(b_scale_inv) if b_scale_inv is not None else None, be.stream()), "vdk_gemm_fp8_nt")
     return out
