@@ -188,6 +188,10 @@ int vdk_attention_bwd(const void* qkv, int64_t ld, const void* o, const void* do
  * saved for backward (NULL ok).  C % 4 == 0. */
 int vdk_layernorm_fwd(const float* x, int64_t ldx, int32_t T, int32_t C, const float* gamma, const float* beta, float eps,
                       void* y, int64_t ldy, int32_t y_dtype, float* mean, float* rstd, void* stream);
+/* vdk_layernorm_fwd with bf16 y, and the fp8 quantisation of y written by the same kernel (out8 [T, ldo8] bytes = what vdk_quant_fp8(y, out_scale, out_fmt) gives, amax
+ * accumulated into out_amax): the engine's fp8 mode feeds norm1 / norm2 outputs to fp8 GEMMs.  128 < C <= 1024, ldo8 % 4 == 0. */
+int vdk_layernorm_fwd_q8(const float* x, int64_t ldx, int32_t T, int32_t C, const float* gamma, const float* beta, float eps, void* y, int64_t ldy, float* mean, float* rstd,
+                         void* out8, int64_t ldo8, int32_t out_fmt, const float* out_scale, float* out_amax, void* stream);
 /* backward: dx = LN'(dy) [+ dres] as f32 (dx) and/or bf16 (dxb); dgamma, dbeta f32 [C] overwritten. */
 int vdk_layernorm_bwd_workspace_bytes(int32_t T, int32_t C, size_t* bytes);
 int vdk_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean,

@@ -2,7 +2,7 @@
 class_token=False + global_pool='map': 576 patch tokens, AttentionPoolLatent head, visiondk_amd/vit.py VisionTransformerMap) with the reference's protocol (a Mixup
 pair every step, Trainer.update_sam = two forward-backward passes, clip-free SAM step, EMA) on ONE GPU at the per-GPU batch.  Operand precision: bf16 in the engine
 and, in the *_fp8 entries, the engine's fp8 mode (forward and input-gradient GEMMs of the block Linears on e4m3 / e5m2 operands with delayed per-tensor scaling, csrc/gemm_fp8.hip;
-weight gradients stay bf16).
+weight gradients stay bf16).  VDK_FP8_FUSED_QUANT=0 restores the separate quantisation passes (A/B).
 usage: python tools/bench_cfg5.py [batch] [steps]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +15,7 @@ dev = torch.device("cuda:0")
 model = vit.create_model("vit_large_patch14_siglip_336", num_classes=1000, device=dev)
 ntok = model.engine.tokens
 out = {"workload": f"cfg5: vit_large_patch14_siglip_336 ({ntok} tokens, MAP head) bf16 operands, per-GPU batch {B}, Mixup pair + SAM (2 fwd/bwd per step), CE ls 0.05, SGD + EMA",
-       "dtype": "*_bf16: bf16 operands; *_fp8: fp8 operands in the forward / input-gradient GEMMs of the block Linears (quantisation as separate passes), bf16 weight gradients"}
+       "dtype": "*_bf16: bf16 operands; *_fp8: fp8 operands in the forward / input-gradient GEMMs of the block Linears (fp8 copies of the LayerNorm / GELU / dGELU outputs written by the producing kernels, attention outputs quantised by a separate pass), bf16 weight gradients"}
 x = torch.randn(B, 3, 336, 336, device=dev); ya = torch.randint(0, 1000, (B,), device=dev)
 perm = torch.randperm(B, device=dev); yb = ya[perm].contiguous()
 flop_img = 3 * 2 * (302.3e6 * ntok + 24 * 2 * ntok * ntok * 1024 + 2 * 1024 * 1024 * ntok)      # fwd+bwd, 2*MACs: block Linears + attention + the kv Linear of the MAP head

@@ -101,6 +101,7 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_attention_fwd": (C.c_int, [P, I64, P, I64, P, I32, I32, I32, I32, F32, P]),
     "vdk_attention_bwd": (C.c_int, [P, I64, P, P, I64, P, P, I64, P, I32, I32, I32, I32, F32, P]),
     "vdk_layernorm_fwd": (C.c_int, [P, I64, I32, I32, P, P, F32, P, I64, I32, P, P, P]),
+    "vdk_layernorm_fwd_q8": (C.c_int, [P, I64, I32, I32, P, P, C.c_float, P, I64, P, P, P, I64, I32, P, P, P]),
     "vdk_layernorm_bwd_workspace_bytes": (C.c_int, [I32, I32, PSZ]),
     "vdk_layernorm_bwd": (C.c_int, [P, I64, I32, P, I64, P, P, P, P, I64, I32, I32, P, I64, P, I64, P, P, P, SZ, P]),
     "vdk_batchnorm1d_fwd": (C.c_int, [P, I64, I32, I32, P, P, F32, F32, I32, P, P, P, I64, P, P, P]),

@@ -12,11 +12,32 @@
 // MAXJ * 256 >= C: the row is loaded ONCE into registers (all loads in flight together) and mean, variance and output come from there; re-reading x for
 // each of the three passes cost three dependent memory round trips per row (stage-0 ConvNeXt rows, C = 128: 672 us against a 246 us byte floor).
 // The summation order per lane is the one of the three-pass form, so results are bit-identical to it.
-template <bool OUT_BF16, int MAXJ>
+// Q8 (fp8 mode of the ViT engine): the bf16 row is also written as fp8(clamp(value * q8_scale)) and max |value| goes to q8_amax -- what vdk_quant_fp8 would make of y
+// (bit-identical: the ROUNDED bf16 values are quantised), without the extra pass over the tensor.  One wave per row: a wave publishes its maximum only when it can raise the
+// (monotone) global value, so after the first wavefront almost nobody touches the atomic.
+__device__ __forceinline__ unsigned ln_q8_pack4(const u32x2 bf, float s, float lim, int fmt, float& am) {
+  float c[4];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const float a = bf_lo(bf[e]), b = bf_hi(bf[e]);
+    am = fmaxf(am, fmaxf(fabsf(a), fabsf(b)));
+    c[2 * e] = fminf(fmaxf(a * s, -lim), lim); c[2 * e + 1] = fminf(fmaxf(b * s, -lim), lim);
+  }
+  int v = 0;
+  if (fmt == 0) { v = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], v, false); v = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], v, true); }
+  else { v = __builtin_amdgcn_cvt_pk_bf8_f32(c[0], c[1], v, false); v = __builtin_amdgcn_cvt_pk_bf8_f32(c[2], c[3], v, true); }
+  return (unsigned)v;
+}
+__device__ __forceinline__ void ln_q8_publish(float am, float* amax, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) am = fmaxf(am, __shfl_xor(am, off));
+  if (lane == 0 && amax && am > *(volatile float*)amax) atomicMax((unsigned*)amax, __float_as_uint(am));      // non-negative floats order like their bit patterns
+}
+template <bool OUT_BF16, int MAXJ, bool Q8 = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx, int T, int C,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, void* __restrict__ y, long ldy, float* __restrict__ mean,
-                                                     float* __restrict__ rstd) {
+                                                     float* __restrict__ rstd, LnQ8 q8 = LnQ8()) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= T) return;
@@ -39,6 +60,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
   const float rs = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
   if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+  float q8s = 1.0f, q8lim = 448.0f, q8am = 0.f;
+  if (Q8) { q8s = q8.scale ? q8.scale[0] : 1.0f; q8lim = q8.fmt == 0 ? 448.0f : 57344.0f; }
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j) {
     const int c = lane * 4 + j * 256;
@@ -47,10 +70,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
       float o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mu) * rs * g[e] + b[e];
-      if (OUT_BF16) *(u32x2*)((bf16_t*)y + (long)row * ldy + c) = (u32x2){pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+      if (OUT_BF16) {
+        const u32x2 ob = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+        *(u32x2*)((bf16_t*)y + (long)row * ldy + c) = ob;
+        if (Q8) *(unsigned*)(q8.out + (long)row * q8.ld + c) = ln_q8_pack4(ob, q8s, q8lim, q8.fmt, q8am);
+      }
       else *(f32x4*)((float*)y + (long)row * ldy + c) = (f32x4){o[0], o[1], o[2], o[3]};
     }
   }
+  if (Q8) ln_q8_publish(q8am, q8.amax, lane);
 }
 
 // C <= 128: a row is at most 32 lanes x 4 floats, so a wave takes TWO rows (one per half) instead of idling half of its lanes; same arithmetic per row
@@ -91,14 +119,16 @@ __global__ __launch_bounds__(256) void ln_fwd_narrow_kernel(const float* __restr
 // dgamma = sum dy * xhat, dbeta = sum dy.   MAXJ * 256 >= C.
 // OCS: also per-block column sums of the bf16-rounded output dxb (= the bias gradient of the Linear whose dY this tensor is: the producer sums what it stores,
 // instead of the consuming dgrad GEMM re-reading its A tiles from LDS) -> pout [block][C].
-template <int MAXJ, bool DY_BF16, bool OCS>
+template <int MAXJ, bool DY_BF16, bool OCS, bool Q8 = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, long lddy, const float* __restrict__ x,
                                                      long ldx, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      long lddres, int T, int C, int rows_per_block, float* __restrict__ dx,
                                                      long lddx, bf16_t* __restrict__ dxb, long lddxb,
-                                                     float* __restrict__ pgamma, float* __restrict__ pbeta, float* __restrict__ pout) {
+                                                     float* __restrict__ pgamma, float* __restrict__ pbeta, float* __restrict__ pout, LnQ8 q8 = LnQ8()) {
   __shared__ float red[4][MAXJ * 256];
+  float q8s = 1.0f, q8lim = 448.0f, q8am = 0.f;
+  if (Q8) { q8s = q8.scale ? q8.scale[0] : 1.0f; q8lim = q8.fmt == 0 ? 448.0f : 57344.0f; }
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r0 = blockIdx.x * rows_per_block;
   int r1 = r0 + rows_per_block; if (r1 > T) r1 = T;
@@ -156,10 +186,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
           const u32x2 ob = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
           *(u32x2*)(dxb + (long)row * lddxb + c) = ob;
           if (OCS) { ao[j][0] += bf_lo(ob[0]); ao[j][1] += bf_hi(ob[0]); ao[j][2] += bf_lo(ob[1]); ao[j][3] += bf_hi(ob[1]); }
+          if (Q8) *(unsigned*)(q8.out + (long)row * q8.ld + c) = ln_q8_pack4(ob, q8s, q8lim, q8.fmt, q8am);
         }
       }
     }
   }
+  if (Q8) ln_q8_publish(q8am, q8.amax, lane);
   // combine the 4 waves' column partials: one 16 KB buffer, one phase per quantity (the kernel is HBM-bound: LDS per block decides how many blocks a CU holds)
 #pragma unroll
   for (int ph = 0; ph < (OCS ? 3 : 2); ++ph) {
@@ -464,6 +496,23 @@ int vdk_layernorm_fwd(const float* x, int64_t ldx, int32_t T, int32_t C, const f
   return vdk_check_launch("vdk_layernorm_fwd");
 }
 
+// vdk_layernorm_fwd with bf16 y, plus the fp8 copy of y (out8 [T, ldo8] bytes) and its amax: see LnQ8.  128 < C <= 1024 (the ViT widths), ldo8 % 4 == 0
+int vdk_layernorm_fwd_q8(const float* x, int64_t ldx, int32_t T, int32_t C, const float* gamma, const float* beta, float eps, void* y, int64_t ldy, float* mean, float* rstd,
+                         void* out8, int64_t ldo8, int32_t out_fmt, const float* out_scale, float* out_amax, void* stream) {
+  if (!x || !gamma || !beta || !y || !out8 || T < 0 || C <= 0 || (C & 3) || (ldx & 3) || (ldy & 3) || (ldo8 & 3) || (out_fmt != 0 && out_fmt != 1))
+    return vdk_fail(VDK_EINVAL, "vdk_layernorm_fwd_q8: bad argument (C, ldx, ldy, ldo8 % 4 == 0)");
+  if (C <= 128 || C > 1024) return vdk_fail(VDK_EUNSUPPORTED, "vdk_layernorm_fwd_q8: 128 < C <= 1024");
+  if (T == 0) return VDK_OK;
+  const LnQ8 q8 = {(unsigned char*)out8, (long)ldo8, out_scale, out_amax, (int)out_fmt};
+  if (C <= 256)
+    hipLaunchKernelGGL((ln_fwd_kernel<true, 1, true>), dim3((unsigned)((T + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta, eps, y, (long)ldy,
+                       mean, rstd, q8);
+  else
+    hipLaunchKernelGGL((ln_fwd_kernel<true, 4, true>), dim3((unsigned)((T + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta, eps, y, (long)ldy,
+                       mean, rstd, q8);
+  return vdk_check_launch("vdk_layernorm_fwd_q8");
+}
+
 int vdk_reduce_rows_f32(const float* in, int64_t ld, int32_t S, int64_t n, float* out, float scale, void* stream) {
   if (!in || !out || S < 0 || n < 0) return vdk_fail(VDK_EINVAL, "vdk_reduce_rows_f32: bad argument");
   if (n == 0) return VDK_OK;
@@ -491,7 +540,7 @@ int vdk_layernorm_bwd_workspace_bytes(int32_t T, int32_t C, size_t* bytes) {
 static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean,
                        const float* rstd, const float* gamma, const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx,
                        int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                       void* stream_, VdkReduceJob* deferred, float* dxb_colsum = nullptr, VdkReduceJob* deferred2 = nullptr) {
+                       void* stream_, VdkReduceJob* deferred, float* dxb_colsum = nullptr, VdkReduceJob* deferred2 = nullptr, const LnQ8* q8 = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!dy || !x || !mean || !rstd || !gamma || !dgamma || !dbeta || T <= 0 || C <= 0 || (C & 3) || C > 4096)
     return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: bad argument (C % 4 == 0, C <= 4096)");
@@ -507,7 +556,14 @@ static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const flo
 #define LNB(MJ, BF, OC) hipLaunchKernelGGL((ln_bwd_kernel<MJ, BF, OC>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
                                            mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po)
   // MAXJ = 3 (C <= 768, ViT-B) keeps the kernel at <= 128 VGPRs = 4 blocks per CU: T / 64 = 788 blocks are then ONE round on 256 CUs (at 3 per CU they are two: +45 %)
-  if (ocs && C <= 768) { if (bf) LNB(3, true, true); else LNB(3, false, true); }
+  if (q8) {
+    if (!ocs || !bf || !q8->out || (q8->ld & 3)) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: the fp8 copy needs bf16 dy, the column-sum form and ld % 4 == 0");
+#define LNBQ(MJ) hipLaunchKernelGGL((ln_bwd_kernel<MJ, true, true, true>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
+                                    mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po, *q8)
+    if (C <= 768) LNBQ(3); else LNBQ(4);
+#undef LNBQ
+  }
+  else if (ocs && C <= 768) { if (bf) LNB(3, true, true); else LNB(3, false, true); }
   else if (ocs) { if (bf) LNB(4, true, true); else LNB(4, false, true); }
   else if (C <= 768) { if (bf) LNB(3, true, false); else LNB(3, false, false); }
   else if (C <= 1024) { if (bf) LNB(4, true, false); else LNB(4, false, false); }
@@ -608,8 +664,8 @@ int vdk_bce_logits(const float* logits, int64_t ldl, const float* targets, int64
 // LayerNorm backward whose dgamma | dbeta partial-sum reduction is left to the caller: *job describes it (job->in == NULL if it was done here after all)
 int vdk_layernorm_bwd_deferred(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
                                const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx, int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta,
-                               void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job, float* dxb_colsum, VdkReduceJob* job2) {
-  return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, mean, rstd, gamma, dres, lddres, T, C, dx, lddx, dxb, lddxb, dgamma, dbeta, ws, ws_bytes, stream, job, dxb_colsum, job2);
+                               void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job, float* dxb_colsum, VdkReduceJob* job2, const LnQ8* dxb_q8) {
+  return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, mean, rstd, gamma, dres, lddres, T, C, dx, lddx, dxb, lddxb, dgamma, dbeta, ws, ws_bytes, stream, job, dxb_colsum, job2, dxb_q8);
 }
 int vdk_reduce_rows_batch(const VdkReduceJob* jobs, int n, void* stream) {
   if (n < 0 || (n > 0 && !jobs)) return vdk_fail(VDK_EINVAL, "vdk_reduce_rows_batch: bad argument");

@@ -20,7 +20,10 @@ int vdk_cast_pad_rows(const float* in, int64_t ldi, int32_t R, int32_t C, void* 
 // out[c] = scale * sum_{s < S} in[s * ld + c], c < n: one of up to 8 row reductions that vdk_reduce_rows_batch runs in a single launch
 struct VdkReduceJob { const float* in; long ld; int S; long n; float* out; float scale; };
 int vdk_reduce_rows_batch(const VdkReduceJob* jobs, int n, void* stream);
+// fp8 copy of a LayerNorm kernel's bf16 output (fp8 mode of the ViT engine): out [rows, ld] bytes = fp8(clamp(value * scale[0])), amax[0] = max(amax[0], max |value|)
+struct LnQ8 { unsigned char* out; long ld; const float* scale; float* amax; int fmt; };
 int vdk_layernorm_bwd_deferred(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
                                const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx, int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta,
                                void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job,
-                               float* dxb_colsum = nullptr /* [C]: column sums of the bf16 output dxb (a Linear's bias gradient), reduction described by *job2 */, VdkReduceJob* job2 = nullptr);
+                               float* dxb_colsum = nullptr /* [C]: column sums of the bf16 output dxb (a Linear's bias gradient), reduction described by *job2 */, VdkReduceJob* job2 = nullptr,
+                               const LnQ8* dxb_q8 = nullptr /* with dxb_colsum, C <= 1024, bf16 dy: dxb's fp8 copy rides along */);

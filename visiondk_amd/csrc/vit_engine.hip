@@ -43,6 +43,7 @@ int vdk_quant_fp8(const void*, int32_t, int64_t, const float*, void*, int32_t, f
 int vdk_fp8_scale_update(float*, float*, float*, int32_t, int32_t, float, void*);
 int vdk_gemm_fp8_nt(const VdkGemmDesc*, int32_t, int32_t, const float*, const float*, void*);
 int vdk_gemm_fp8_nt_q8(const VdkGemmDesc*, int32_t, int32_t, const float*, const float*, void*, int64_t, int32_t, const float*, float*, void*);
+int vdk_layernorm_fwd_q8(const float*, int64_t, int32_t, int32_t, const float*, const float*, float, void*, int64_t, float*, float*, void*, int64_t, int32_t, const float*, float*, void*);
 }
 
 static inline int64_t up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -286,17 +287,18 @@ static int f8_quant(hipStream_t s, const F8& f, const void* x, int xdt, long n, 
   return vdk_quant_fp8(x, xdt, n, f.sc + slot, out, fmt, f.amax + slot, s);
 }
 // C = epilogue(A8[M, K] . W8[N, K]^T / (scale_a scale_w)): `a` is quantised into the scratch operand first -- unless the GEMM that produced it already wrote its fp8 copy
-// (a_ready: f.a8b, made by that GEMM's epilogue with slot_a's scale).  q8_slot >= 0: this GEMM's epilogue writes the fp8 copy of ITS bf16 output for the next one (delayed
+// (a_pre: f.a8b made by a GEMM epilogue, or f.a8 filled by a LayerNorm kernel, with slot_a's scale).  q8_slot >= 0: this GEMM's epilogue writes the fp8 copy of ITS bf16 output for the next one (delayed
 // scaling only: the scale must be known before the values are; the calibration step and mode 2 keep the separate pass).
 static bool f8_fused(const F8& f) {
   const char* e = getenv("VDK_FP8_FUSED_QUANT");                        // A/B and tests: 0 keeps the separate quantisation passes (read per call: the tests switch it in-process)
   return f.mode == 1 && !(e && e[0] == '0');
 }
 static int gemm8(hipStream_t s, const F8& f, const void* a, int slot_a, int a_fmt, const unsigned char* w8, int slot_w, int64_t ldb, void* Cc, int64_t ldc, int M, int N,
-                 int K, int cdt, const float* bias, const float* res, int64_t ldr, int act, void* aux, int64_t ldaux, bool a_ready = false, int q8_slot = -1, int q8_fmt = 0) {
-  if (!a_ready) RC(f8_quant(s, f, a, VDK_BF16, (long)M * K, slot_a, a_fmt, f.a8));
+                 int K, int cdt, const float* bias, const float* res, int64_t ldr, int act, void* aux, int64_t ldaux, const unsigned char* a_pre = nullptr, int q8_slot = -1,
+                 int q8_fmt = 0) {
+  if (!a_pre) RC(f8_quant(s, f, a, VDK_BF16, (long)M * K, slot_a, a_fmt, f.a8));
   VdkGemmDesc g = {};
-  g.A = a_ready ? f.a8b : f.a8; g.lda = K; g.B = w8; g.ldb = ldb; g.C = Cc; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.c_dtype = cdt; g.bias = bias; g.residual = res; g.ldr = ldr;
+  g.A = a_pre ? a_pre : f.a8; g.lda = K; g.B = w8; g.ldb = ldb; g.C = Cc; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.c_dtype = cdt; g.bias = bias; g.residual = res; g.ldr = ldr;
   g.act = act; g.aux = aux; g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = 1;
   if (q8_slot >= 0) return vdk_gemm_fp8_nt_q8(&g, a_fmt, 0, f.si + slot_a, f.si + slot_w, f.a8b, N, q8_fmt, f.sc + q8_slot, f.amax + q8_slot, s);
   return vdk_gemm_fp8_nt(&g, a_fmt, 0, f.si + slot_a, f.si + slot_w, s);
@@ -454,18 +456,22 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
     float* lse = (float*)(base + w.lse + l * w.s_lse); bf16_t* o = (bf16_t*)(base + w.o + l * w.s_h);
     bf16_t* h2 = (bf16_t*)(base + w.h2 + l * w.s_h); bf16_t* u = (bf16_t*)(base + w.u + l * w.s_u); bf16_t* g = (bf16_t*)(base + w.g + l * w.s_u);
     // x = x + proj(attn(norm1(x)))
-    RC(vdk_layernorm_fwd(xin, D, T, D, params + b.n1w, params + b.n1b, d.eps, h1, D, VDK_BF16, mean1, rstd1, s));
     if (f8.mode) {
+      // fp8 mode, delayed scaling: the LayerNorm kernels write the fp8 copy of h1 / h2 straight into the operand scratch, the fc1 + GELU epilogue the one of g
       const int sl = 12 * l;
-      RC(gemm8(s, f8, h1, sl + 0, 0, f8.w8 + b.qkv_w, sl + 4, D, qkv, 3 * D, T, 3 * D, D, VDK_BF16, params + b.qkv_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0));
+      const bool fl = f8_fused(f8) && D > 128 && D <= 1024, fq = f8_fused(f8) && (M % 64) == 0;
+      if (fl) RC(vdk_layernorm_fwd_q8(xin, D, T, D, params + b.n1w, params + b.n1b, d.eps, h1, D, mean1, rstd1, f8.a8, D, 0, f8.sc + sl + 0, f8.amax + sl + 0, s));
+      else RC(vdk_layernorm_fwd(xin, D, T, D, params + b.n1w, params + b.n1b, d.eps, h1, D, VDK_BF16, mean1, rstd1, s));
+      RC(gemm8(s, f8, h1, sl + 0, 0, f8.w8 + b.qkv_w, sl + 4, D, qkv, 3 * D, T, 3 * D, D, VDK_BF16, params + b.qkv_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0, fl ? f8.a8 : nullptr));
       RC(vdk_attention_fwd(qkv, 3 * D, o, D, lse, d.B, d.N, d.H, 64, scale, s));
       RC(gemm8(s, f8, o, sl + 1, 0, f8.w8 + b.proj_w, sl + 5, D, xmid, D, T, D, D, VDK_F32, params + b.proj_b, xin, D, VDK_ACT_NONE, nullptr, 0));
-      RC(vdk_layernorm_fwd(xmid, D, T, D, params + b.n2w, params + b.n2b, d.eps, h2, D, VDK_BF16, mean2, rstd2, s));
-      const bool fq = f8_fused(f8) && (M % 64) == 0;                 // g's fp8 copy comes out of the fc1 + GELU epilogue
-      RC(gemm8(s, f8, h2, sl + 2, 0, f8.w8 + b.fc1_w, sl + 6, D, g, M, T, M, D, VDK_BF16, params + b.fc1_b, nullptr, 0, VDK_ACT_GELU, u, M, false, fq ? sl + 3 : -1, 0));
-      RC(gemm8(s, f8, g, sl + 3, 0, f8.w8 + b.fc2_w, sl + 7, M, xout, D, T, D, M, VDK_F32, params + b.fc2_b, xmid, D, VDK_ACT_NONE, nullptr, 0, fq));
+      if (fl) RC(vdk_layernorm_fwd_q8(xmid, D, T, D, params + b.n2w, params + b.n2b, d.eps, h2, D, mean2, rstd2, f8.a8, D, 0, f8.sc + sl + 2, f8.amax + sl + 2, s));
+      else RC(vdk_layernorm_fwd(xmid, D, T, D, params + b.n2w, params + b.n2b, d.eps, h2, D, VDK_BF16, mean2, rstd2, s));
+      RC(gemm8(s, f8, h2, sl + 2, 0, f8.w8 + b.fc1_w, sl + 6, D, g, M, T, M, D, VDK_BF16, params + b.fc1_b, nullptr, 0, VDK_ACT_GELU, u, M, fl ? f8.a8 : nullptr, fq ? sl + 3 : -1, 0));
+      RC(gemm8(s, f8, g, sl + 3, 0, f8.w8 + b.fc2_w, sl + 7, M, xout, D, T, D, M, VDK_F32, params + b.fc2_b, xmid, D, VDK_ACT_NONE, nullptr, 0, fq ? f8.a8b : nullptr));
       continue;
     }
+    RC(vdk_layernorm_fwd(xin, D, T, D, params + b.n1w, params + b.n1b, d.eps, h1, D, VDK_BF16, mean1, rstd1, s));
     RC(gemm(s, h1, D, wb + b.qkv_w, D, qkv, 3 * D, T, 3 * D, D, VDK_BF16, params + b.qkv_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
     RC(vdk_attention_fwd(qkv, 3 * D, o, D, lse, d.B, d.N, d.H, 64, scale, s));
     RC(gemm(s, o, D, wb + b.proj_w, D, xmid, D, T, D, D, VDK_F32, params + b.proj_b, xin, D, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
@@ -606,7 +612,7 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
     if (on_ready) on_ready(user, p.norm_w, p.total - p.norm_w);
   }
   // ---- blocks, last to first ------------------------------------------------------------------------
-  bool fc2_bias_from_norm1 = false;
+  bool fc2_bias_from_norm1 = false, dxab8_ready = false;
   F8 f8; RC(f8_init(cfg, d, p, &f8, (unsigned char*)(base + w.a8), (unsigned char*)(base + w.a8b)));
   for (int l = d.L - 1; l >= 0; --l) {
     const PLayout::Blk& b = p.blk[l];
@@ -632,9 +638,10 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
       const int sl = 12 * l;
       const bool have_fc2b = one_stream && ((l == d.L - 1) ? last_fc2_bias_done : fc2_bias_from_norm1);
       const bool fq = f8_fused(f8) && (M % 64) == 0;                 // du's e5m2 copy comes out of the dGELU epilogue
-      RC(gemm8(s, f8, dxab, sl + 8, 1, f8.wt8 + p.blkT[l].fc2, sl + 7, D, du, M, T, M, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_DGELU, u, M, false, fq ? sl + 9 : -1, 1));   // du
+      RC(gemm8(s, f8, dxab, sl + 8, 1, f8.wt8 + p.blkT[l].fc2, sl + 7, D, du, M, T, M, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_DGELU, u, M, dxab8_ready ? f8.a8 : nullptr,
+               fq ? sl + 9 : -1, 1));   // du (DXAB(l)'s e5m2 copy is in the operand scratch when the norm1 backward of the block above wrote it)
       RC(linear_wgrad(s2, d, w, base, dxab, D, g, M, T, d.Tp, D, M, grads + b.fc2_w, have_fc2b ? nullptr : grads + b.fc2_b, 0));
-      RC(gemm8(s, f8, du, sl + 9, 1, f8.wt8 + p.blkT[l].fc1, sl + 6, M, dsm, D, T, D, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, fq));      // dh2
+      RC(gemm8(s, f8, du, sl + 9, 1, f8.wt8 + p.blkT[l].fc1, sl + 6, M, dsm, D, T, D, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, fq ? f8.a8b : nullptr));      // dh2
       RC(linear_wgrad(s2, d, w, base, du, M, h2, D, T, d.Tp, M, D, grads + b.fc1_w, grads + b.fc1_b, 0));
     } else if (one_stream) {
       // Bias gradients ride with the PRODUCER of each dY (it sums what it stores): fc2.bias with DXAB(l) (norm backward of the block above), fc1.bias with du
@@ -659,13 +666,15 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
       RC(gemm(s, du, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // dh2
     }
     const bool ocs_ln = one_stream && D <= 1024;
+    const bool lq = f8.mode && f8_fused(f8) && ocs_ln;               // the norm backward kernels write the e5m2 copies of dxmb / DXAB(l - 1) into the operand scratch
+    const LnQ8 q8m = {f8.a8, (long)D, f8.sc + 12 * l + 10, f8.amax + 12 * l + 10, 1};
     RC(vdk_layernorm_bwd_deferred(dsm, D, VDK_BF16, xmid, D, mean2, rstd2, params + b.n2w, dxa, D, T, D, dxm, D, dxmb, D, grads + b.n2w, grads + b.n2b, lnws0,
-                                  w.lnws_bytes, s, &jobs[nj], ocs_ln ? grads + b.proj_b : nullptr, ocs_ln ? &jobs[nj + 1] : nullptr));
+                                  w.lnws_bytes, s, &jobs[nj], ocs_ln ? grads + b.proj_b : nullptr, ocs_ln ? &jobs[nj + 1] : nullptr, lq ? &q8m : nullptr));
     nj += ocs_ln ? 2 : 1;
     // attention branch: dxm / dxmb hold dL/dx_mid
     RC(ev_order(ev_p++, s, s2));
     if (f8.mode) {
-      RC(gemm8(s, f8, dxmb, 12 * l + 10, 1, f8.wt8 + p.blkT[l].proj, 12 * l + 5, D, dsm, D, T, D, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0));   // do
+      RC(gemm8(s, f8, dxmb, 12 * l + 10, 1, f8.wt8 + p.blkT[l].proj, 12 * l + 5, D, dsm, D, T, D, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, lq ? f8.a8 : nullptr));   // do
       RC(linear_wgrad(s2, d, w, base, dxmb, D, o, D, T, d.Tp, D, D, grads + b.proj_w, ocs_ln ? nullptr : grads + b.proj_b, 0));
     } else if (one_stream && ocs_ln) {
       RC(gemm(s, dxmb, D, wt + p.blkT[l].proj, D, dsm, D, T, D, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // do
@@ -690,8 +699,11 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
       RC(gemm(s, dqkv, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));  // dh1
     }
     const bool ocs_n1 = ocs_ln && l > 0;      // DXAB(l - 1) is dY of block l-1's fc2 (for l == 0 it feeds the patch embedding, whose bias comes from d pos_embed)
+    const bool lq1 = lq && ocs_n1;
+    const LnQ8 q8a = {f8.a8, (long)D, f8.sc + 12 * (l - 1) + 8, f8.amax + 12 * (l - 1) + 8, 1};
     RC(vdk_layernorm_bwd_deferred(dsm, D, VDK_BF16, xin, D, mean1, rstd1, params + b.n1w, dxm, D, T, D, dxa, D, DXAB(l - 1), D, grads + b.n1w, grads + b.n1b, lnws1,
-                                  w.lnws_bytes, s, &jobs[nj], ocs_n1 ? grads + p.blk[l - 1].fc2_b : nullptr, ocs_n1 ? &jobs[nj + 1] : nullptr));
+                                  w.lnws_bytes, s, &jobs[nj], ocs_n1 ? grads + p.blk[l - 1].fc2_b : nullptr, ocs_n1 ? &jobs[nj + 1] : nullptr, lq1 ? &q8a : nullptr));
+    dxab8_ready = lq1;
     nj += ocs_n1 ? 2 : 1;
     fc2_bias_from_norm1 = ocs_n1;
     RC(vdk_reduce_rows_batch(jobs, nj, s));
