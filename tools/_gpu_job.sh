@@ -1,3 +1,2 @@
 mkdir -p gpurun_out/r2x
-python -m pytest tests/test_gemm_fp8.py tests/test_vit_fp8.py tests/test_rowops.py -m gpu -x -q 2>&1 | tail -3
-python tools/bench_cfg5.py 128 3 | tee gpurun_out/r2x/cfg5.json
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 tools/bench_comm_overhead.py 2>&1 | tail -2 | tee gpurun_out/r2x/comm_overhead.json
