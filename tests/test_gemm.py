@@ -87,7 +87,7 @@ def test_transpose_fused_colsum(be, dev):
     assert _rel(part.sum(0), x.float().sum(0)) < 1e-6
 
 
-@pytest.mark.parametrize("M,N,K,splitk", [(256, 256, 64, 1), (300, 264, 192, 1), (512, 256, 256, 1), (130, 520, 128, 1), (256, 256, 512, 2)])
+@pytest.mark.parametrize("M,N,K,splitk", [(256, 256, 64, 1), (300, 264, 192, 1), (512, 256, 256, 1), (130, 520, 128, 1), (256, 256, 512, 2), (520, 128, 192, 1)])
 def test_gemm256_lds_dma_kernel(be, dev, M, N, K, splitk):
     """the 256x256 LDS-DMA kernel, forced, vs torch fp32 on the same bf16 operands (incl. ragged M/N and split-K)"""
     torch.manual_seed(5)

@@ -427,8 +427,21 @@ int vdk_dwconv7_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C
 }
 int vdk_reduce_rows_f32(const float*, int64_t, int32_t, int64_t, float*, float, void*);
 /* dw f32 [C][49] (timm conv_dw.weight [C,1,7,7]) and db f32 [C]; ws: vdk_dwconv7_wgrad_workspace_bytes */
+static int dw_wgrad_impl(const float* in, const float* dy, float* dw, float* db, int32_t B, int32_t H, int32_t W, int32_t C, void* ws, size_t ws_bytes, void* stream,
+                         VdkReduceJob* job);
 int vdk_dwconv7_wgrad(const float* in, const float* dy, float* dw, float* db, int32_t B, int32_t H, int32_t W, int32_t C, void* ws, size_t ws_bytes,
                       void* stream) {
+  return dw_wgrad_impl(in, dy, dw, db, B, H, W, C, ws, ws_bytes, stream, nullptr);
+}
+}  // extern "C"
+int vdk_dwconv7_wgrad_deferred(const float* in, const float* dy, float* dw, float* db, int32_t B, int32_t H, int32_t W, int32_t C, void* ws, size_t ws_bytes, void* stream,
+                               VdkReduceJob* job) {
+  if (!job || db != dw + (size_t)C * 49) return vdk_fail(VDK_EINVAL, "vdk_dwconv7_wgrad_deferred: needs a job slot and db == dw + 49 C");
+  return dw_wgrad_impl(in, dy, dw, db, B, H, W, C, ws, ws_bytes, stream, job);
+}
+extern "C" {
+static int dw_wgrad_impl(const float* in, const float* dy, float* dw, float* db, int32_t B, int32_t H, int32_t W, int32_t C, void* ws, size_t ws_bytes, void* stream,
+                         VdkReduceJob* job) {
   if (!in || !dy || !dw || !db || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return vdk_fail(VDK_EINVAL, "vdk_dwconv7_wgrad: bad argument (C % 4 == 0)");
   const int S = dw_slices(B, H, W, C);
   if (!ws || ws_bytes < (size_t)S * C * 50 * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_dwconv7_wgrad: workspace too small");
@@ -438,6 +451,7 @@ int vdk_dwconv7_wgrad(const float* in, const float* dy, float* dw, float* db, in
   else if (tw == 14) hipLaunchKernelGGL((dwconv7_wgrad_kernel<7, 14>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
   else if (tw == 7) hipLaunchKernelGGL((dwconv7_wgrad_kernel<7, 7>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
   else hipLaunchKernelGGL((dwconv7_wgrad_kernel<8, 8>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
+  if (job) { *job = VdkReduceJob{(const float*)ws, (long)C * 50, S, (long)C * 50, dw, 1.0f}; return vdk_check_launch("vdk_dwconv7_wgrad"); }
   if (db == dw + (size_t)C * 49)     // conv_dw.weight / conv_dw.bias of the flat gradient buffer: the partial rows [49 C | C] reduce in one launch
     return vdk_reduce_rows_f32((const float*)ws, (int64_t)C * 50, S, (int64_t)C * 50, dw, 1.0f, stream);
   int rc = vdk_reduce_rows_f32((const float*)ws, (int64_t)C * 50, S, (int64_t)C * 49, dw, 1.0f, stream);

@@ -184,7 +184,7 @@ struct WsPlan {
   size_t pooled, pstats, feat, dfeat, dpool;   // classifier mode: pooled f32 [B, C3], its LayerNorm statistics, normed bf16 [Bp, C3], and their gradients
   // backward scratch (sized by the largest stage)
   size_t dxa, dxb, dt, du, dh, dA, dhds, dw2p, db2p, dwdsp;
-  size_t slabs, slabs_bytes, lnws, lnws_bytes, csws, csws_bytes, dwws, dwws_bytes, tA, tB;
+  size_t slabs, slabs_bytes, lnws, lnws_bytes, csws, csws_bytes, csws2, dwws, dwws_bytes, tA, tB;
 };
 void cn_plan(const CnDims& d, WsPlan* w) {
   size_t cur = 0;
@@ -241,7 +241,7 @@ void cn_plan(const CnDims& d, WsPlan* w) {
   w->dw2p = w_take(cur, cm * 4); w->db2p = w_take(cur, 4096 * 4); w->dwdsp = w_take(cur, wds * 4 + 256);
   w->slabs_bytes = sl; w->slabs = w_take(cur, sl + 256);
   w->lnws_bytes = ln; w->lnws = w_take(cur, ln + 256);
-  w->csws_bytes = cs; w->csws = w_take(cur, cs + 256);
+  w->csws_bytes = cs; w->csws = w_take(cur, cs + 256); w->csws2 = w_take(cur, cs + 256);   // two: a block's deferred reductions keep both alive until its batch launch
   w->dwws_bytes = dww; w->dwws = w_take(cur, dww + 256);
   w->tA = w_take(cur, tr + 256); w->tB = w_take(cur, tr + 256);
   w->total = cur;
@@ -462,11 +462,34 @@ int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout_, const
         g.A = dxb; g.lda = C; g.B = xb + bx.fc2pt; g.ldb = C; g.C = du; g.ldc = M; g.M = R; g.N = M; g.K = C; g.c_dtype = VDK_BF16; g.act = VDK_ACT_DGELU; g.aux = base + bw.u;
         g.ldaux = M; g.alpha = 1.0f; g.splitk = 1; g.c_colsum = (float*)(base + w.csws);
         RC(vdk_gemm_bf16_nt(&g, nullptr, 0, s));
-        RC(vdk_reduce_rows_f32((const float*)(base + w.csws), M, xrow, M, grads + b.fc1_b, 1.0f, s));
-        RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + bw.g), R, C, M, dw2p, db2p));          // db2p by vdk_colsum_bf16 inside
-        RC(vdk_layerscale_grad(dw2p, db2p, params + b.fc2_w, params + b.fc2_b, params + b.gamma, grads + b.fc2_w, grads + b.fc2_b, grads + b.gamma, C, M, s));
+        // The block's four small reductions (fc1.bias from the dGELU epilogue's column sums, the fc2' bias column sums, LayerNorm dgamma | dbeta, depthwise dw | db) run as
+        // ONE launch after the depthwise weight-gradient kernel; the layer-scale kernel that needs db2p follows it.
+        VdkReduceJob jobs[4]; int nj = 0;
+        jobs[nj++] = VdkReduceJob{(const float*)(base + w.csws), (long)M, xrow, (long)M, grads + b.fc1_b, 1.0f};
+        const bool tn = (R % 64) == 0 && b.dw_b == b.dw_w + (int64_t)C * 49;
+        if (tn) {
+          RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + bw.g), R, C, M, dw2p, nullptr));
+          RC(vdk_colsum_bf16_deferred(dxb, C, R, C, db2p, base + w.csws2, w.csws_bytes, s, &jobs[nj])); ++nj;
+        } else {
+          RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + bw.g), R, C, M, dw2p, db2p));        // db2p by vdk_colsum_bf16 / the transposes' by-product inside
+        }
         RC(gemm(s, du, M, xb + bx.fc1t, M, dh, C, R, C, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0));
         RC(linear_wgrad(s, w, base, du, (const bf16_t*)(base + bw.h), R, M, C, grads + b.fc1_w, nullptr));
+        if (tn) {
+          RC(vdk_layernorm_bwd_deferred(dh, C, VDK_BF16, (const float*)(base + bw.t), C, st, st + R, params + b.nw, nullptr, 0, R, C, dt, C, nullptr, 0, grads + b.nw,
+                                        grads + b.nb, lnws, w.lnws_bytes, s, &jobs[nj])); ++nj;
+          RC(vdk_dwconv7_wgrad_deferred(xin, dt, grads + b.dw_w, grads + b.dw_b, d.B, H, H, C, base + w.dwws, w.dwws_bytes, s, &jobs[nj])); ++nj;
+          RC(vdk_reduce_rows_batch(jobs, nj, s));
+          RC(vdk_layerscale_grad(dw2p, db2p, params + b.fc2_w, params + b.fc2_b, params + b.gamma, grads + b.fc2_w, grads + b.fc2_b, grads + b.gamma, C, M, s));
+          RC(vdk_dwconv7_fwd(dt, (const float*)(xb + bx.dwt), nullptr, dxa, dxa, dxb, d.B, H, H, C, 1, s));
+          if (on_ready) {
+            const int64_t end = (j + 1 < d.depth[i]) ? p.st[i].blk[j + 1].gamma : (i < 3 ? p.st[i + 1].ds_nw : p.head_nw);
+            on_ready(user, b.gamma, end - b.gamma);
+          }
+          continue;
+        }
+        RC(vdk_reduce_rows_batch(jobs, nj, s));
+        RC(vdk_layerscale_grad(dw2p, db2p, params + b.fc2_w, params + b.fc2_b, params + b.gamma, grads + b.fc2_w, grads + b.fc2_b, grads + b.gamma, C, M, s));
       } else {
       RC(dgrad_with_bias(s, w, base, dxb, xb + bx.fc2pt, du, R, M, C, VDK_ACT_DGELU, base + bw.u, db2p, &fz));
       RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + bw.g), R, C, M, dw2p, fz ? nullptr : db2p));

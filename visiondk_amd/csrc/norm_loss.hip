@@ -265,7 +265,17 @@ __global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const bf16_t* 
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
   if (c < N) {
-    for (int r = r0 + ry; r < r1; r += 8) {
+    int r = r0 + ry;
+    for (; r + 24 < r1; r += 32) {                      // four independent 16-byte loads in flight per thread (the summation order per thread is unchanged)
+      u32x4 u[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) u[k] = *(const u32x4*)(in + (long)(r + 8 * k) * ld + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(u[k][e]); acc[2 * e + 1] += bf_hi(u[k][e]); }
+    }
+    for (; r < r1; r += 8) {
       u32x4 u = *(const u32x4*)(in + (long)r * ld + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(u[e]); acc[2 * e + 1] += bf_hi(u[e]); }
@@ -593,17 +603,24 @@ int vdk_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const floa
   return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, mean, rstd, gamma, dres, lddres, T, C, dx, lddx, dxb, lddxb, dgamma, dbeta, ws, ws_bytes, stream_, nullptr);
 }
 
-static inline int colsum_splits(int T) { int s = (T + 255) / 256; if (s > 128) s = 128; if (s < 1) s = 1; return s; }
+// row splits of the column-sum pass: enough workgroups to stream at HBM rate whatever the width -- a [1.6 M, 128] gradient (ConvNeXt stage 0) is ONE column block, and 128
+// splits of it were 128 workgroups on 256 CUs: 1 TB/s.  About 1024 workgroups in all (four 16-byte loads in flight per thread), at least 64 rows each.
+static inline int colsum_splits(int T, int N) {
+  const int bx = (N / 8 + 31) / 32;
+  int target = 1024 / (bx > 0 ? bx : 1); if (target < 128) target = 128;
+  int s = (T + 63) / 64; if (s > target) s = target; if (s < 1) s = 1;
+  return s;
+}
 int vdk_colsum_bf16_workspace_bytes(int32_t T, int32_t N, size_t* bytes) {
   if (!bytes || T < 0 || N <= 0) return vdk_fail(VDK_EINVAL, "vdk_colsum_bf16_workspace_bytes: bad argument");
-  *bytes = (size_t)colsum_splits(T) * N * 4;
+  *bytes = (size_t)colsum_splits(T, N) * N * 4;
   return VDK_OK;
 }
 // out[c] = sum_r in[r][c]  (bias gradient of a Linear: column sum of dY), N % 8 == 0, ld % 8 == 0
 int vdk_colsum_bf16(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!in || !out || T <= 0 || N <= 0 || (N & 7) || (ld & 7)) return vdk_fail(VDK_EINVAL, "vdk_colsum_bf16: bad argument (N, ld % 8 == 0)");
-  const int S = colsum_splits(T);
+  const int S = colsum_splits(T, N);
   if (!ws || ws_bytes < (size_t)S * N * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_colsum_bf16: workspace too small");
   const int rps = (T + S - 1) / S;
   hipLaunchKernelGGL(colsum_bf16_partial_kernel, dim3((unsigned)((N / 8 + 31) / 32), (unsigned)S), dim3(256), 0, stream,
@@ -666,6 +683,17 @@ int vdk_layernorm_bwd_deferred(const void* dy, int64_t lddy, int32_t dy_dtype, c
                                const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx, int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta,
                                void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job, float* dxb_colsum, VdkReduceJob* job2, const LnQ8* dxb_q8) {
   return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, mean, rstd, gamma, dres, lddres, T, C, dx, lddx, dxb, lddxb, dgamma, dbeta, ws, ws_bytes, stream, job, dxb_colsum, job2, dxb_q8);
+}
+// vdk_colsum_bf16 whose final reduction over the row splits is left to the caller (*job describes it)
+int vdk_colsum_bf16_deferred(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream_, VdkReduceJob* job) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!in || !out || !job || T <= 0 || N <= 0 || (N & 7) || (ld & 7)) return vdk_fail(VDK_EINVAL, "vdk_colsum_bf16: bad argument (N, ld % 8 == 0)");
+  const int S = colsum_splits(T, N);
+  if (!ws || ws_bytes < (size_t)S * N * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_colsum_bf16: workspace too small");
+  const int rps = (T + S - 1) / S;
+  hipLaunchKernelGGL(colsum_bf16_partial_kernel, dim3((unsigned)((N / 8 + 31) / 32), (unsigned)S), dim3(256), 0, stream, (const bf16_t*)in, (long)ld, (int)T, (int)N, rps, (float*)ws);
+  *job = VdkReduceJob{(const float*)ws, (long)N, S, (long)N, out, 1.0f};
+  return vdk_check_launch("vdk_colsum_bf16");
 }
 int vdk_reduce_rows_batch(const VdkReduceJob* jobs, int n, void* stream) {
   if (n < 0 || (n > 0 && !jobs)) return vdk_fail(VDK_EINVAL, "vdk_reduce_rows_batch: bad argument");
