@@ -103,6 +103,13 @@ def test_fp8_copy_of_the_output_rides_with_the_epilogue(be, dev, M):
     dpad = torch.zeros((M + 15) // 16 * 16, N, dtype=torch.bfloat16, device=dev); dpad[:M] = du
     ref8 = ops.quant_fp8(dpad, sc2, FP8_E5M2, am2_ref, backend=be)[:M]
     assert torch.equal(du8, ref8) and torch.equal(am2, am2_ref)
+    # column sums of the stored du (the bias gradient of fc1) from the same epilogue, with and without the fp8 copy
+    for q8 in (None, {"fmt": FP8_E5M2, "scale": sc2, "amax": torch.zeros(1, device=dev)}):
+        part = torch.full((2 * ((M + 255) // 256), N), float("nan"), device=dev)
+        r = ops.gemm_fp8_nt(dy, b, a_fmt=FP8_E5M2, act=ACT_DGELU, aux=u, backend=be, q8=q8, c_colsum=part)
+        du2 = r[0] if q8 is not None else r
+        assert torch.equal(du2, du)
+        assert _rel(part.sum(0), du.float().sum(0)) < 1e-5
     with pytest.raises(RuntimeError):        # the plain bias form has no fp8 by-product
         ops.gemm_fp8_nt(a, b, bias=bias, backend=be, q8={"fmt": FP8_E4M3, "scale": sc, "amax": am})
 

@@ -1,4 +1,4 @@
 mkdir -p gpurun_out/r2x
-python -m pytest tests/test_convnext.py tests/test_parity_fullsize_gpu.py tests/test_gemm.py tests/test_conv.py -m gpu -x -q 2>&1 | tail -3
-echo "n256 default(128)"; python tools/bench_cfg3.py 512 4 | tee gpurun_out/r2x/cfg3.json | cut -c1-330
-echo "n256 min 256"; VDK_GEMM_MIN_N256=256 python tools/bench_cfg3.py 512 4 | cut -c1-330
+python -m pytest tests/test_gemm_fp8.py tests/test_vit_fp8.py tests/test_siglip.py -m gpu -x -q 2>&1 | tail -2
+python tools/bench_cfg5.py 128 3 | tee gpurun_out/r2x/cfg5.json | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print({k:round(v,1) for k,v in d.items() if 'images_per_sec' in k or 'ms_per_step' in k})"

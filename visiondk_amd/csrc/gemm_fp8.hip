@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512) void gemm256_fp8_kernel(Fp8Params q) {
   p.alpha = p.alpha * (q.a_scale_inv ? q.a_scale_inv[0] : 1.0f) * (q.b_scale_inv ? q.b_scale_inv[0] : 1.0f);
   float* slab = (float*)(smem + w * 16384);
   const int ncol = n0 + wc * 64 + (lane & 7) * 8;
-  float bias8[8], ocs_unused[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q8am = 0.f;
+  float bias8[8], ocs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q8am = 0.f;
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
   if ((E & E_BIAS) && ncol < p.N) {
@@ -181,8 +181,21 @@ __global__ __launch_bounds__(512) void gemm256_fp8_kernel(Fp8Params q) {
         for (int r = 0; r < 16; ++r)
           slab[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + ct * 32 + l31] = acc[half * 2 + rt][ct][r] * p.alpha;
     __builtin_amdgcn_wave_barrier();
-    h_epilogue_half<E>(p, slab, lane, (long)m0 + wr * 128 + half * 64, ncol, 0, bias8, ocs_unused, q8am);
+    h_epilogue_half<E>(p, slab, lane, (long)m0 + wr * 128 + half * 64, ncol, 0, bias8, ocs8, q8am);
     __builtin_amdgcn_wave_barrier();
+  }
+  if (E & E_OCS) {   // column sums of the stored bf16 output (c_colsum, as in gemm.hip): lanes with the same (lane & 7) hold the same 8 columns; one partial row per (row tile, wave row)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = ocs8[e];
+      v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+      ocs8[e] = v;
+    }
+    if (lane < 8 && ncol < p.N) {
+      float* dst = p.ocs_part + ((long)(m0 >> 8) * 2 + wr) * p.N + ncol;
+      *(f32x4*)dst = (f32x4){ocs8[0], ocs8[1], ocs8[2], ocs8[3]};
+      *(f32x4*)(dst + 4) = (f32x4){ocs8[4], ocs8[5], ocs8[6], ocs8[7]};
+    }
   }
   if ((E & E_Q8) && p.q8_amax) {
     // amax of the by-product: ONE atomic per workgroup, and only when it can raise the value (an atomic per wave and half was measured: 73 728 same-address atomics per
@@ -289,14 +302,15 @@ int vdk_gemm_fp8_nt_q8(const VdkGemmDesc* d, int32_t a_fmt, int32_t b_fmt, const
   if (!d || !d->A || !d->B || !d->C) return vdk_fail(VDK_EINVAL, "vdk_gemm_fp8_nt: null pointer");
   if (d->M < 256 || d->N < 256 || d->K <= 0 || (d->K % 128) || (d->N & 7) || (d->lda & 15) || (d->ldb & 15) || (d->ldc & 7))
     return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_fp8_nt: needs M, N >= 256, K % 128 == 0, N % 8 == 0, lda / ldb % 16 == 0");
-  if (d->splitk > 1 || d->trans || d->conv || d->row_group != 0 || d->a_colsum || d->c_colsum) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_fp8_nt: split-K / TN / conv / row remap stay on the bf16 kernels");
+  if (d->splitk > 1 || d->trans || d->conv || d->row_group != 0 || d->a_colsum || (d->c_colsum && d->act != VDK_ACT_DGELU))
+    return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_fp8_nt: split-K / TN / conv / row remap stay on the bf16 kernels (c_colsum: with the dGELU epilogue only)");
   if (!((a_fmt == 0 || a_fmt == 1) && b_fmt == 0)) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_fp8_nt: formats (e4m3, e4m3) and (e5m2, e4m3)");
   if ((d->act == VDK_ACT_DGELU && !d->aux) || (d->aux && (d->ldaux & 7))) return vdk_fail(VDK_EINVAL, "vdk_gemm_fp8_nt: bad aux");
   Fp8Params q;
   GemmParams& p = q.g;
   p.A = nullptr; p.B = nullptr; p.C = d->C; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.M = d->M; p.N = d->N; p.K = d->K; p.c_dtype = d->c_dtype;
   p.bias = (const float*)d->bias; p.residual = (const float*)d->residual; p.ldr = d->ldr; p.act = d->act; p.aux = (bf16_t*)d->aux; p.ldaux = d->ldaux;
-  p.alpha = d->alpha; p.row_group = 0; p.row_shift = 0; p.a_row_group = 0; p.splitk = 1; p.k_per_split = d->K; p.slabs = nullptr; p.colsum_part = nullptr; p.conv_on = 0; p.dbg = nullptr;
+  p.alpha = d->alpha; p.row_group = 0; p.row_shift = 0; p.a_row_group = 0; p.splitk = 1; p.k_per_split = d->K; p.slabs = nullptr; p.colsum_part = nullptr; p.ocs_part = (float*)d->c_colsum; p.conv_on = 0; p.dbg = nullptr;
   q.A = (const unsigned char*)d->A; q.B = (const unsigned char*)d->B; q.a_scale_inv = a_scale_inv; q.b_scale_inv = b_scale_inv;
   const bool bias = d->bias != nullptr, res = d->residual != nullptr, f32 = d->c_dtype == VDK_F32;
   int E = -1;
@@ -313,6 +327,7 @@ int vdk_gemm_fp8_nt_q8(const VdkGemmDesc* d, int32_t a_fmt, int32_t b_fmt, const
     p.q8 = (unsigned char*)out8; p.ldq8 = ldo8; p.q8_scale = out_scale; p.q8_amax = out_amax; p.q8_fmt = out_fmt;
     E |= E_Q8;
   }
+  if (d->c_colsum) E |= E_OCS;      // [2 * ceil(M / 256)][N] partial rows (vdk_gemm_c_colsum_rows), dGELU form only (checked above)
   const dim3 grid((unsigned)(((d->M + 255) / 256) * ((d->N + 255) / 256)));
 #define L8(AFv, EE) hipLaunchKernelGGL((gemm256_fp8_kernel<AFv, 0, EE>), grid, dim3(512), 0, stream, q)
 #define L8E(AFv)                                                   \
@@ -323,6 +338,8 @@ int vdk_gemm_fp8_nt_q8(const VdkGemmDesc* d, int32_t a_fmt, int32_t b_fmt, const
     case E_DGELU: L8(AFv, E_DGELU); break;                        \
     case E_BIAS | E_GELU | E_Q8: L8(AFv, E_BIAS | E_GELU | E_Q8); break; \
     case E_DGELU | E_Q8: L8(AFv, E_DGELU | E_Q8); break;          \
+    case E_DGELU | E_OCS: L8(AFv, E_DGELU | E_OCS); break;        \
+    case E_DGELU | E_OCS | E_Q8: L8(AFv, E_DGELU | E_OCS | E_Q8); break; \
     case E_BIAS | E_RES | E_F32: L8(AFv, E_BIAS | E_RES | E_F32); break; \
     default: L8(AFv, E_F32); break;                               \
   }

@@ -28,19 +28,30 @@ __device__ __forceinline__ unsigned ln_q8_pack4(const u32x2 bf, float s, float l
   else { v = __builtin_amdgcn_cvt_pk_bf8_f32(c[0], c[1], v, false); v = __builtin_amdgcn_cvt_pk_bf8_f32(c[2], c[3], v, true); }
   return (unsigned)v;
 }
-__device__ __forceinline__ void ln_q8_publish(float am, float* amax, int lane) {
+// block-wide (4 waves, every thread arrives): one atomic per workgroup, and only when it can raise the (monotone) global value -- same-address atomics cost ~4.6 ns each
+__device__ __forceinline__ void ln_q8_publish(float am, float* amax, int lane, float* red4) {
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) am = fmaxf(am, __shfl_xor(am, off));
-  if (lane == 0 && amax && am > *(volatile float*)amax) atomicMax((unsigned*)amax, __float_as_uint(am));      // non-negative floats order like their bit patterns
+  if (lane == 0) red4[threadIdx.x >> 6] = am;
+  __syncthreads();
+  if (threadIdx.x == 0 && amax) {
+    const float m = fmaxf(fmaxf(red4[0], red4[1]), fmaxf(red4[2], red4[3]));
+    if (m > *(volatile float*)amax) atomicMax((unsigned*)amax, __float_as_uint(m));      // non-negative floats order like their bit patterns
+  }
 }
 template <bool OUT_BF16, int MAXJ, bool Q8 = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx, int T, int C,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, void* __restrict__ y, long ldy, float* __restrict__ mean,
                                                      float* __restrict__ rstd, LnQ8 q8 = LnQ8()) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (row >= T) return;
+  __shared__ float q8red[4];
+  float q8s = 1.0f, q8lim = 448.0f, q8am = 0.f;
+  if (Q8) { q8s = q8.scale ? q8.scale[0] : 1.0f; q8lim = q8.fmt == 0 ? 448.0f : 57344.0f; }
+  // Q8: a bounded grid whose waves walk over rows, so that the amax is published by at most gridDim * 4 waves (one row per wave = 73 728 publishing waves at ViT-L/14 @336
+  // cost more than the quantisation pass the by-product replaces: 171 vs 80 + 43 us); otherwise one row per wave, a single trip through the loop
+  const int rstride = Q8 ? (int)gridDim.x * 4 : T;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < T; row += rstride) {
   const float* xr = x + (long)row * ldx;
   f32x4 v[MAXJ];
 #pragma unroll
@@ -60,8 +71,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
   const float rs = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
   if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
-  float q8s = 1.0f, q8lim = 448.0f, q8am = 0.f;
-  if (Q8) { q8s = q8.scale ? q8.scale[0] : 1.0f; q8lim = q8.fmt == 0 ? 448.0f : 57344.0f; }
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j) {
     const int c = lane * 4 + j * 256;
@@ -78,7 +87,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
       else *(f32x4*)((float*)y + (long)row * ldy + c) = (f32x4){o[0], o[1], o[2], o[3]};
     }
   }
-  if (Q8) ln_q8_publish(q8am, q8.amax, lane);
+  }
+  if (Q8) ln_q8_publish(q8am, q8.amax, lane, q8red);
 }
 
 // C <= 128: a row is at most 32 lanes x 4 floats, so a wave takes TWO rows (one per half) instead of idling half of its lanes; same arithmetic per row
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
       }
     }
   }
-  if (Q8) ln_q8_publish(q8am, q8.amax, lane);
+  if (Q8) ln_q8_publish(q8am, q8.amax, lane, &red[0][0]);      // (red is free until the combine below; the combine starts with its own barrier-separated phase)
   // combine the 4 waves' column partials: one 16 KB buffer, one phase per quantity (the kernel is HBM-bound: LDS per block decides how many blocks a CU holds)
 #pragma unroll
   for (int ph = 0; ph < (OCS ? 3 : 2); ++ph) {
@@ -514,11 +524,12 @@ int vdk_layernorm_fwd_q8(const float* x, int64_t ldx, int32_t T, int32_t C, cons
   if (C <= 128 || C > 1024) return vdk_fail(VDK_EUNSUPPORTED, "vdk_layernorm_fwd_q8: 128 < C <= 1024");
   if (T == 0) return VDK_OK;
   const LnQ8 q8 = {(unsigned char*)out8, (long)ldo8, out_scale, out_amax, (int)out_fmt};
+  unsigned nblk = (unsigned)((T + 3) / 4); if (nblk > 1024) nblk = 1024;      // 4 blocks per CU: each wave walks over T / 4096 rows and publishes its amax once
   if (C <= 256)
-    hipLaunchKernelGGL((ln_fwd_kernel<true, 1, true>), dim3((unsigned)((T + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta, eps, y, (long)ldy,
+    hipLaunchKernelGGL((ln_fwd_kernel<true, 1, true>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta, eps, y, (long)ldy,
                        mean, rstd, q8);
   else
-    hipLaunchKernelGGL((ln_fwd_kernel<true, 4, true>), dim3((unsigned)((T + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta, eps, y, (long)ldy,
+    hipLaunchKernelGGL((ln_fwd_kernel<true, 4, true>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta, eps, y, (long)ldy,
                        mean, rstd, q8);
   return vdk_check_launch("vdk_layernorm_fwd_q8");
 }

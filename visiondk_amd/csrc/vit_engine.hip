@@ -295,11 +295,11 @@ static bool f8_fused(const F8& f) {
 }
 static int gemm8(hipStream_t s, const F8& f, const void* a, int slot_a, int a_fmt, const unsigned char* w8, int slot_w, int64_t ldb, void* Cc, int64_t ldc, int M, int N,
                  int K, int cdt, const float* bias, const float* res, int64_t ldr, int act, void* aux, int64_t ldaux, const unsigned char* a_pre = nullptr, int q8_slot = -1,
-                 int q8_fmt = 0) {
+                 int q8_fmt = 0, float* c_colsum = nullptr) {
   if (!a_pre) RC(f8_quant(s, f, a, VDK_BF16, (long)M * K, slot_a, a_fmt, f.a8));
   VdkGemmDesc g = {};
   g.A = a_pre ? a_pre : f.a8; g.lda = K; g.B = w8; g.ldb = ldb; g.C = Cc; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.c_dtype = cdt; g.bias = bias; g.residual = res; g.ldr = ldr;
-  g.act = act; g.aux = aux; g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = 1;
+  g.act = act; g.aux = aux; g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = 1; g.c_colsum = c_colsum;
   if (q8_slot >= 0) return vdk_gemm_fp8_nt_q8(&g, a_fmt, 0, f.si + slot_a, f.si + slot_w, f.a8b, N, q8_fmt, f.sc + q8_slot, f.amax + q8_slot, s);
   return vdk_gemm_fp8_nt(&g, a_fmt, 0, f.si + slot_a, f.si + slot_w, s);
 }
@@ -638,11 +638,16 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
       const int sl = 12 * l;
       const bool have_fc2b = one_stream && ((l == d.L - 1) ? last_fc2_bias_done : fc2_bias_from_norm1);
       const bool fq = f8_fused(f8) && (M % 64) == 0;                 // du's e5m2 copy comes out of the dGELU epilogue
+      // fc1.bias = column sums of du, accumulated by the dGELU epilogue that stores it (c_colsum, as in the bf16 path) -- the column-sum pass over the [T, 4D] tensor goes
+      const int xrow = one_stream ? 2 * ((T + 255) / 256) : 0;
+      const bool fo = xrow > 0 && (size_t)xrow * M * 4 <= w.csws_bytes;
+      float* const partx = (float*)(base + w.csws + (size_t)1 * w.csws_bytes);
       RC(gemm8(s, f8, dxab, sl + 8, 1, f8.wt8 + p.blkT[l].fc2, sl + 7, D, du, M, T, M, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_DGELU, u, M, dxab8_ready ? f8.a8 : nullptr,
-               fq ? sl + 9 : -1, 1));   // du (DXAB(l)'s e5m2 copy is in the operand scratch when the norm1 backward of the block above wrote it)
+               fq ? sl + 9 : -1, 1, fo ? partx : nullptr));   // du (DXAB(l)'s e5m2 copy is in the operand scratch when the norm1 backward of the block above wrote it)
+      if (fo) jobs[nj++] = VdkReduceJob{partx, (long)M, xrow, (long)M, grads + b.fc1_b, 1.0f};
       RC(linear_wgrad(s2, d, w, base, dxab, D, g, M, T, d.Tp, D, M, grads + b.fc2_w, have_fc2b ? nullptr : grads + b.fc2_b, 0));
       RC(gemm8(s, f8, du, sl + 9, 1, f8.wt8 + p.blkT[l].fc1, sl + 6, M, dsm, D, T, D, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, fq ? f8.a8b : nullptr));      // dh2
-      RC(linear_wgrad(s2, d, w, base, du, M, h2, D, T, d.Tp, M, D, grads + b.fc1_w, grads + b.fc1_b, 0));
+      RC(linear_wgrad(s2, d, w, base, du, M, h2, D, T, d.Tp, M, D, grads + b.fc1_w, fo ? nullptr : grads + b.fc1_b, 0));
     } else if (one_stream) {
       // Bias gradients ride with the PRODUCER of each dY (it sums what it stores): fc2.bias with DXAB(l) (norm backward of the block above), fc1.bias with du
       // (dGELU epilogue below), proj.bias with dxmb (norm2 backward below); only qkv.bias still comes from the A tiles of the dh1 GEMM (dqkv is attention's output).

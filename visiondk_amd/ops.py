@@ -100,7 +100,8 @@ def fp8_scale_update(amax: torch.Tensor, scale: torch.Tensor, scale_inv: torch.T
 
 
 def gemm_fp8_nt(a8: torch.Tensor, b8: torch.Tensor, a_scale_inv: Optional[torch.Tensor] = None, b_scale_inv: Optional[torch.Tensor] = None, *, a_fmt: int = FP8_E4M3,
-                out_dtype=torch.bfloat16, bias=None, residual=None, act: int = ACT_NONE, aux=None, backend=None, q8: Optional[dict] = None) -> torch.Tensor:
+                out_dtype=torch.bfloat16, bias=None, residual=None, act: int = ACT_NONE, aux=None, backend=None, q8: Optional[dict] = None,
+                c_colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = epilogue(a_scale_inv * b_scale_inv * a8[M,K] @ b8[N,K].T): uint8 tensors of fp8 bytes (a: e4m3 or e5m2, b: e4m3), fp32 accumulation on the scaled MFMA.
     q8 = {"fmt": FP8_E4M3 | FP8_E5M2, "scale": f32[1] | None, "amax": f32[1] | None}: the epilogue also writes the fp8 quantisation of `out` (GELU / DGELU forms) and
     the call returns (out, out8) -- bit-identical to quant_fp8(out, ...)."""
@@ -120,6 +121,9 @@ def gemm_fp8_nt(a8: torch.Tensor, b8: torch.Tensor, a_scale_inv: Optional[torch.
     d.aux = aux.data_ptr() if aux is not None else None
     d.ldaux = aux.stride(0) if aux is not None else 0
     d.alpha, d.splitk = 1.0, 1
+    if c_colsum is not None:       # f32 [2 * ceil(M / 256), N] partial column sums of the stored bf16 output (dGELU form): sum(0) = the bias gradient of the Linear before
+        assert c_colsum.dtype == torch.float32 and c_colsum.is_contiguous() and c_colsum.shape == (2 * ((M + 255) // 256), N)
+        d.c_colsum = be.ptr(c_colsum)
     for t in (a8, b8, out, residual, aux):
         if t is not None and be.device_only and not t.is_cuda:
             raise RuntimeError("visiondk_amd: HIP backend got a CPU tensor (there is no CPU fallback)")
