@@ -28,7 +28,7 @@ def legacy(request, be):
     be.lib.vdk_attention_force_legacy(-1)
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 17, 2), (1, 50, 1), (1, 197, 2), (2, 224, 1), (1, 256, 1), (1, 300, 1), (2, 257, 2), (1, 577, 1), (9, 384, 1)])
+@pytest.mark.parametrize("B,N,H", [(2, 17, 2), (1, 50, 1), (1, 197, 2), (2, 224, 1), (1, 256, 1), (1, 300, 1), (2, 257, 2), (1, 577, 1), (9, 384, 1), (3, 240, 2)])
 def test_attention_fwd_bwd(be, dev, B, N, H, legacy):
     torch.manual_seed(0)
     D = H * 64
