@@ -126,3 +126,21 @@ def test_fp8_linear_error_against_fp32(be, dev):
     err = _rel(got, x @ w.t())
     print("fp8 e4m3 linear rel err", err)
     assert err < 5e-2
+
+
+@pytest.mark.parametrize("T,C", [(37, 256), (1000, 768), (5000, 1024)])
+@pytest.mark.parametrize("fmt", [FP8_E4M3, FP8_E5M2])
+def test_layernorm_writes_the_fp8_copy_of_its_output(be, dev, T, C, fmt):
+    """vdk_layernorm_fwd_q8: y, mean, rstd equal to vdk_layernorm_fwd bit for bit; y8 and amax equal to vdk_quant_fp8 over y.  T = 5000 > 4 * 1024 rows: waves walk
+    over several rows of the bounded grid."""
+    torch.manual_seed(6)
+    x = (torch.randn(T, C) * 2 + 0.3).to(dev); g = (1 + 0.1 * torch.randn(C)).to(dev); b = (0.1 * torch.randn(C)).to(dev)
+    sc = torch.tensor([11.0], device=dev); am = torch.zeros(1, device=dev)
+    y, y8, mean, rstd = ops.layernorm_fwd_q8(x, g, b, sc, am, fmt, backend=be)
+    y0, mean0, rstd0 = ops.layernorm_fwd(x, g, b, backend=be)
+    assert torch.equal(y, y0) and torch.equal(mean, mean0) and torch.equal(rstd, rstd0)
+    pad = (-T * C) % 16
+    flat = torch.cat([y0.reshape(-1), torch.zeros(pad, dtype=torch.bfloat16, device=dev)])
+    am0 = torch.zeros(1, device=dev)
+    ref8 = ops.quant_fp8(flat, sc, fmt, am0, backend=be)[:T * C].reshape(T, C)
+    assert torch.equal(y8, ref8) and torch.equal(am, am0) and am.item() > 0

@@ -101,5 +101,8 @@ def test_fp8_copies_from_the_gelu_epilogues_change_nothing(be, dev, monkeypatch)
     monkeypatch.setenv("VDK_FP8_FUSED_QUANT", "0")
     lb, gb = _fwd_bwd(model, x, y, dev)
     stb = model.engine.fp8_state.clone()
-    assert torch.equal(la, lb) and all(torch.equal(ga[n], gb[n]) for n in ga)
+    # (attn.qkv.bias: the fused pass sums dqkv's columns in row splits, the unfused path takes them from the transposes of this toy's ragged T -- the same sums in another order)
+    diff = [n for n in ga if not torch.equal(ga[n], gb[n])]
+    assert torch.equal(la, lb) and all(n.endswith("attn.qkv.bias") for n in diff), diff
+    assert all(_rel(ga[n], gb[n]) < 1e-5 for n in diff)
     assert torch.equal(sta, stb) and float(sta[0].max()) > 0                                  # amax of this pass recorded identically

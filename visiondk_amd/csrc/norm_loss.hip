@@ -264,9 +264,14 @@ __global__ __launch_bounds__(512) void reduce_rows_batch_kernel(ReduceBatch b) {
 
 // partial[split][c] = sum over this split's rows of in[r][c]  (bf16 input).  Block = 32 column chunks (16 B = 8 columns)
 // x 8 row lanes; every load is 16 B and a wave reads 512 contiguous bytes of a row.
+// Q8: the pass also writes the fp8 copy of the tensor it reads (and its amax) -- the attention backward's dqkv needs both its column sums (qkv.bias) and its e5m2 copy
+// (operand of the next fp8 GEMM) in the engine's fp8 mode: one read instead of two.
+template <bool Q8>
 __global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const bf16_t* __restrict__ in, long ld, int T, int N,
-                                                                  int rows_per_split, float* __restrict__ partial) {
+                                                                  int rows_per_split, float* __restrict__ partial, LnQ8 q8) {
   __shared__ float red[8][32][9];
+  float q8s = 1.0f, q8lim = 448.0f, q8am = 0.f;
+  if (Q8) { q8s = q8.scale ? q8.scale[0] : 1.0f; q8lim = q8.fmt == 0 ? 448.0f : 57344.0f; }
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int c = (blockIdx.x * 32 + cx) * 8;
   const int r0 = blockIdx.y * rows_per_split;
@@ -281,14 +286,18 @@ __global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const bf16_t* 
 #pragma unroll
       for (int k = 0; k < 4; ++k) u[k] = *(const u32x4*)(in + (long)(r + 8 * k) * ld + c);
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int k = 0; k < 4; ++k) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(u[k][e]); acc[2 * e + 1] += bf_hi(u[k][e]); }
+        if (Q8) *(u32x2*)(q8.out + (long)(r + 8 * k) * q8.ld + c) = (u32x2){ln_q8_pack4((u32x2){u[k][0], u[k][1]}, q8s, q8lim, q8.fmt, q8am),
+                                                                           ln_q8_pack4((u32x2){u[k][2], u[k][3]}, q8s, q8lim, q8.fmt, q8am)};
+      }
     }
     for (; r < r1; r += 8) {
       u32x4 u = *(const u32x4*)(in + (long)r * ld + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(u[e]); acc[2 * e + 1] += bf_hi(u[e]); }
+      if (Q8) *(u32x2*)(q8.out + (long)r * q8.ld + c) = (u32x2){ln_q8_pack4((u32x2){u[0], u[1]}, q8s, q8lim, q8.fmt, q8am), ln_q8_pack4((u32x2){u[2], u[3]}, q8s, q8lim, q8.fmt, q8am)};
     }
   }
 #pragma unroll
@@ -303,6 +312,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const bf16_t* 
       partial[(long)blockIdx.y * N + c + e] = t;
     }
   }
+  if (Q8) { __syncthreads(); ln_q8_publish(q8am, q8.amax, threadIdx.x & 63, &red[0][0][0]); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -634,8 +644,8 @@ int vdk_colsum_bf16(const void* in, int64_t ld, int32_t T, int32_t N, float* out
   const int S = colsum_splits(T, N);
   if (!ws || ws_bytes < (size_t)S * N * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_colsum_bf16: workspace too small");
   const int rps = (T + S - 1) / S;
-  hipLaunchKernelGGL(colsum_bf16_partial_kernel, dim3((unsigned)((N / 8 + 31) / 32), (unsigned)S), dim3(256), 0, stream,
-                     (const bf16_t*)in, (long)ld, (int)T, (int)N, rps, (float*)ws);
+  hipLaunchKernelGGL(colsum_bf16_partial_kernel<false>, dim3((unsigned)((N / 8 + 31) / 32), (unsigned)S), dim3(256), 0, stream,
+                     (const bf16_t*)in, (long)ld, (int)T, (int)N, rps, (float*)ws, LnQ8());
   hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((N + 63) / 64)), dim3(512), 0, stream, (const float*)ws, (long)N, S,
                      (long)N, out, 1.0f);
   return vdk_check_launch("vdk_colsum_bf16");
@@ -696,13 +706,15 @@ int vdk_layernorm_bwd_deferred(const void* dy, int64_t lddy, int32_t dy_dtype, c
   return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, mean, rstd, gamma, dres, lddres, T, C, dx, lddx, dxb, lddxb, dgamma, dbeta, ws, ws_bytes, stream, job, dxb_colsum, job2, dxb_q8);
 }
 // vdk_colsum_bf16 whose final reduction over the row splits is left to the caller (*job describes it)
-int vdk_colsum_bf16_deferred(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream_, VdkReduceJob* job) {
+int vdk_colsum_bf16_deferred(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream_, VdkReduceJob* job, const LnQ8* q8) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!in || !out || !job || T <= 0 || N <= 0 || (N & 7) || (ld & 7)) return vdk_fail(VDK_EINVAL, "vdk_colsum_bf16: bad argument (N, ld % 8 == 0)");
+  if (!in || !out || !job || T <= 0 || N <= 0 || (N & 7) || (ld & 7) || (q8 && (!q8->out || (q8->ld & 7)))) return vdk_fail(VDK_EINVAL, "vdk_colsum_bf16: bad argument (N, ld % 8 == 0)");
   const int S = colsum_splits(T, N);
   if (!ws || ws_bytes < (size_t)S * N * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_colsum_bf16: workspace too small");
   const int rps = (T + S - 1) / S;
-  hipLaunchKernelGGL(colsum_bf16_partial_kernel, dim3((unsigned)((N / 8 + 31) / 32), (unsigned)S), dim3(256), 0, stream, (const bf16_t*)in, (long)ld, (int)T, (int)N, rps, (float*)ws);
+  const dim3 grid((unsigned)((N / 8 + 31) / 32), (unsigned)S);
+  if (q8) hipLaunchKernelGGL(colsum_bf16_partial_kernel<true>, grid, dim3(256), 0, stream, (const bf16_t*)in, (long)ld, (int)T, (int)N, rps, (float*)ws, *q8);
+  else hipLaunchKernelGGL(colsum_bf16_partial_kernel<false>, grid, dim3(256), 0, stream, (const bf16_t*)in, (long)ld, (int)T, (int)N, rps, (float*)ws, LnQ8());
   *job = VdkReduceJob{(const float*)ws, (long)N, S, (long)N, out, 1.0f};
   return vdk_check_launch("vdk_colsum_bf16");
 }

@@ -17,15 +17,17 @@ int vdk_transpose_cast_batch(const VdkTcItem* items, int n, void* stream);
 // out bf16 [R, ldo] = in f32 [R, C] (row stride ldi) with the columns [C, ldo) zero-filled (operand copies of weights whose row length is not a multiple of 8)
 int vdk_cast_pad_rows(const float* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, void* stream);
 
+// fp8 copy of a LayerNorm kernel's bf16 output (fp8 mode of the ViT engine): out [rows, ld] bytes = fp8(clamp(value * scale[0])), amax[0] = max(amax[0], max |value|)
+struct LnQ8 { unsigned char* out; long ld; const float* scale; float* amax; int fmt; };
 // out[c] = scale * sum_{s < S} in[s * ld + c], c < n: one of up to 8 row reductions that vdk_reduce_rows_batch runs in a single launch
 struct VdkReduceJob { const float* in; long ld; int S; long n; float* out; float scale; };
 int vdk_reduce_rows_batch(const VdkReduceJob* jobs, int n, void* stream);
-int vdk_colsum_bf16_deferred(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job);
+
+int vdk_colsum_bf16_deferred(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job,
+                             const LnQ8* q8 = nullptr /* the pass also writes the fp8 copy of `in` (rows of ld bytes) and its amax */);
 // vdk_dwconv7_wgrad whose reduction over the per-slice partials [S][49 C | C] is left to the caller (needs db == dw + 49 C: the flat gradient buffer's layout)
 int vdk_dwconv7_wgrad_deferred(const float* in, const float* dy, float* dw, float* db, int32_t B, int32_t H, int32_t W, int32_t C, void* ws, size_t ws_bytes, void* stream,
                                VdkReduceJob* job);
-// fp8 copy of a LayerNorm kernel's bf16 output (fp8 mode of the ViT engine): out [rows, ld] bytes = fp8(clamp(value * scale[0])), amax[0] = max(amax[0], max |value|)
-struct LnQ8 { unsigned char* out; long ld; const float* scale; float* amax; int fmt; };
 int vdk_layernorm_bwd_deferred(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
                                const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx, int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta,
                                void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job,

@@ -694,8 +694,16 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
     RC(vdk_attention_bwd(qkv, 3 * D, o, dsm, D, lse, dqkv, 3 * D, dvec, d.B, d.N, d.H, 64, 0.125f, s));                                    // dqkv
     RC(ev_order(ev_p++, s, s2));
     if (f8.mode) {
-      RC(gemm8(s, f8, dqkv, 12 * l + 11, 1, f8.wt8 + p.blkT[l].qkv, 12 * l + 4, 3 * D, dsm, D, T, D, 3 * D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0));   // dh1
-      RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, grads + b.qkv_b, 0));
+      // dqkv is attention's output: its column sums (qkv.bias) and its e5m2 copy (operand of the dh1 GEMM) come from ONE pass over it
+      size_t csneed = 0; vdk_colsum_bf16_workspace_bytes(T, 3 * D, &csneed);
+      const bool fcq = f8_fused(f8) && one_stream && csneed <= w.csws_bytes;
+      if (fcq) {
+        const LnQ8 q8d = {f8.a8, (long)3 * D, f8.sc + 12 * l + 11, f8.amax + 12 * l + 11, 1};
+        RC(vdk_colsum_bf16_deferred(dqkv, 3 * D, T, 3 * D, grads + b.qkv_b, base + w.csws + (size_t)2 * w.csws_bytes, w.csws_bytes, s, &jobs[nj], &q8d)); ++nj;
+      }
+      RC(gemm8(s, f8, dqkv, 12 * l + 11, 1, f8.wt8 + p.blkT[l].qkv, 12 * l + 4, 3 * D, dsm, D, T, D, 3 * D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0,
+               fcq ? f8.a8 : nullptr));   // dh1
+      RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, fcq ? nullptr : grads + b.qkv_b, 0));
     } else if (one_stream) {
       RC(dgrad_with_bias(s, w, base, dqkv, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, VDK_ACT_NONE, nullptr, 0, grads + b.qkv_b, &fz, 3, jobs, &nj));   // dh1
       RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, fz ? nullptr : grads + b.qkv_b, 0));

@@ -204,6 +204,20 @@ def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float = 1e-6, out_dtype=tor
     return y, mean, rstd
 
 
+def layernorm_fwd_q8(x: torch.Tensor, gamma, beta, scale: Optional[torch.Tensor], amax: Optional[torch.Tensor], fmt: int = FP8_E4M3, eps: float = 1e-6, backend=None):
+    """x f32 [T, C], 128 < C <= 1024 -> (y bf16, y8 uint8 = quant_fp8(y, scale, fmt) bit for bit, mean, rstd); amax[0] accumulates max |y| (the fp8 mode of the ViT engine)"""
+    be = _be(backend)
+    C_ = gamma.numel()
+    T = x.numel() // C_
+    y = torch.empty((T, C_), dtype=torch.bfloat16, device=x.device)
+    y8 = torch.empty((T, C_), dtype=torch.uint8, device=x.device)
+    mean = torch.empty(T, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(T, dtype=torch.float32, device=x.device)
+    be.check(be.lib.vdk_layernorm_fwd_q8(be.ptr(x), C_, T, C_, be.ptr(gamma), be.ptr(beta), eps, be.ptr(y), C_, be.ptr(mean), be.ptr(rstd), be.ptr(y8), C_, fmt,
+                                         be.ptr(scale), be.ptr(amax), be.stream()), "vdk_layernorm_fwd_q8")
+    return y, y8, mean, rstd
+
+
 def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, want_bf16=True, backend=None):
     """-> (dx f32 [T,C], dx bf16 or None, dgamma, dbeta)"""
     be = _be(backend)
