@@ -68,3 +68,31 @@ def test_vit_base_logits_precise_vs_oracle(hip):
         exp = ref(x)
     assert _rel(model.forward_precise(x.cuda()), exp) < 1e-4
     assert _rel(model(x.cuda()).detach(), exp) < 3e-2
+
+
+@pytest.mark.parametrize("B,N,H", [(8, 576, 16), (4, 577, 16), (8, 257, 16)])
+def test_attention_at_vit_large_sequence_lengths(hip, B, N, H):
+    """The streaming attention kernels (csrc/attention_long.hip) at the sequence lengths they serve -- ViT-L/14 at 336 (576 tokens, SigLIP: no class token; 577 with one)
+    and at 224 (257) -- with enough (batch, head) items that workgroups walk over several units: forward against torch fp32 on the same bf16 inputs, backward against
+    torch autograd, and both against the flash-style kernels of csrc/attention.hip (a second implementation with different tiling and summation order)."""
+    from visiondk_amd import ops
+    torch.manual_seed(7)
+    D = H * 64
+    qkv = (torch.randn(B, N, 3 * D, device="cuda") * 1.3).bfloat16()
+    dout = torch.randn(B, N, D, device="cuda").bfloat16()
+    o, lse = ops.attention_fwd(qkv, H, backend=hip)
+    d = ops.attention_bwd(qkv, o, dout, lse, H, backend=hip)
+    hip.lib.vdk_attention_force_legacy(1)
+    try:
+        o2, lse2 = ops.attention_fwd(qkv, H, backend=hip)
+        d2 = ops.attention_bwd(qkv, o, dout, lse, H, backend=hip)
+    finally:
+        hip.lib.vdk_attention_force_legacy(-1)
+    x = qkv.float().requires_grad_(True)
+    q, k, v = (t.reshape(B, N, H, 64).transpose(1, 2) for t in x.split(D, dim=2))
+    att = (q * 0.125) @ k.transpose(-2, -1)
+    ref = (att.softmax(-1) @ v).transpose(1, 2).reshape(B, N, D)
+    ref.backward(dout.float())
+    assert _rel(lse, torch.logsumexp(att, -1).detach()) < 1e-5 and _rel(lse, lse2) < 1e-6
+    assert _rel(o.float(), ref.detach()) < 6e-3 and _rel(o.float(), o2.float()) < 6e-3
+    assert _rel(d.float(), x.grad) < 1.5e-2 and _rel(d.float(), d2.float()) < 6e-3
