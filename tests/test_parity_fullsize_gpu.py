@@ -130,3 +130,18 @@ def test_siglip_vit_large_336_forward_backward_vs_oracle(hip):
     assert _rel(lo.detach(), lr.detach()) < 8e-3 and abs(loss.item() - loss_r.item()) < 5e-4 * abs(loss_r.item())
     assert errs[0][0] < 1.5e-2, errs[:4]
     assert errs[len(errs) // 2][0] < 1e-2
+    # the same model with fp8 operands in the block Linears (current scaling = the calibration step, then delayed scaling from the recorded maxima)
+    def run():
+        for q in model.parameters():
+            q.grad = None
+        l8 = model(x.cuda()); torch.nn.functional.cross_entropy(l8, y.cuda()).backward()
+        e8 = sorted(((_rel(got[n].grad, p.grad), n) for n, p in ref.named_parameters()), reverse=True)
+        return _rel(l8.detach(), lr.detach()), e8
+    model.engine.enable_fp8(2); lc, ec = run(); model.engine.fp8_update()
+    model.engine.enable_fp8(1); ld, ed = run()
+    model.engine.enable_fp8(0)
+    print({"fp8_current": (lc, ec[0], ec[len(ec) // 2]), "fp8_delayed": (ld, ed[0], ed[len(ed) // 2])})
+    # measured: logits 6.8e-2, worst gradient 1.33e-1 (pos_embed), median 7.6e-2 -- e4m3 / e5m2 operands (2^-4 / 2^-3 relative rounding) through 24 blocks; the delayed-scaling
+    # pass (fp8 copies written by the producing kernels) reproduces the calibration pass exactly on the same data
+    assert lc < 1e-1 and ld < 1e-1 and ec[0][0] < 2e-1 and ed[0][0] < 2e-1 and ec[len(ec) // 2][0] < 1.2e-1
+    assert abs(lc - ld) < 1e-6
