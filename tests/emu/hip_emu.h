@@ -381,6 +381,19 @@ static inline void emu_global_load_lds(const void* gsrc, void* lds_dst, unsigned
   emu::wave_barrier();
 }
 #define __builtin_amdgcn_global_load_lds(g, l, sz, off, aux) emu_global_load_lds((const void*)(g), (void*)(l), sz, off, aux)
+// buffer_load ... lds through a raw buffer descriptor: byte offset = voffset + soffset + imm; accesses that do not fit below num_records return zeros
+struct emu_buffer_rsrc { const unsigned char* base; unsigned num_records; };
+typedef emu_buffer_rsrc __amdgpu_buffer_rsrc_t;
+static inline emu_buffer_rsrc __builtin_amdgcn_make_buffer_rsrc(void* p, short, int num_records, int) { return emu_buffer_rsrc{(const unsigned char*)p, (unsigned)num_records}; }
+static inline void emu_buffer_load_lds(emu_buffer_rsrc rs, void* lds_dst, unsigned size, unsigned voff, unsigned soff, int ioff, int) {
+  unsigned long long base = emu_xchg((unsigned long long)(uintptr_t)lds_dst, 0);
+  const unsigned long long off = (unsigned long long)voff + soff + (unsigned)ioff;
+  char* dst = (char*)(uintptr_t)base + ioff + (size_t)emu::lane() * size;
+  if (off + size <= rs.num_records) memcpy(dst, rs.base + off, size); else memset(dst, 0, size);
+  emu::wave_barrier();
+}
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, l, sz, voff, soff, ioff, aux) emu_buffer_load_lds((rs), (void*)(l), sz, voff, soff, ioff, aux)
+#define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
 // ds_read_b64_tr_b16, semantics measured on gfx950 (tools/probes/tr_probe.hip): within each 16-lane group, lane i's
 // element j = element (i % 4) of the 8-byte chunk addressed by lane 4*j + i/4 of the same group.
 typedef short emu_s16x4 __attribute__((ext_vector_type(4)));

@@ -87,18 +87,20 @@ def test_transpose_fused_colsum(be, dev):
     assert _rel(part.sum(0), x.float().sum(0)) < 1e-6
 
 
-@pytest.mark.parametrize("M,N,K,splitk", [(256, 256, 64, 1), (300, 264, 192, 1), (512, 256, 256, 1), (130, 520, 128, 1), (256, 256, 512, 2), (520, 128, 192, 1)])
-def test_gemm256_lds_dma_kernel(be, dev, M, N, K, splitk):
-    """the 256x256 LDS-DMA kernel, forced, vs torch fp32 on the same bf16 operands (incl. ragged M/N and split-K)"""
+@pytest.mark.parametrize("kern", [2, 5])
+@pytest.mark.parametrize("M,N,K,splitk", [(256, 256, 64, 1), (300, 264, 192, 1), (512, 256, 256, 1), (130, 520, 128, 1), (256, 256, 512, 2), (520, 128, 192, 1), (264, 256, 320, 1)])
+def test_gemm256_lds_dma_kernel(be, dev, M, N, K, splitk, kern):
+    """the 256x256 LDS-DMA kernels (2: eight waves, 5: four waves / one per SIMD), forced, vs torch fp32 on the same bf16 operands (incl. ragged M/N, 1..5 k-tiles and split-K)"""
     torch.manual_seed(5)
     a = torch.randn(M, K).bfloat16().to(dev); b = torch.randn(N, K).bfloat16().to(dev)
     b[:, 3] += 2.0
     bias = torch.randn(N).to(dev); res = torch.randn(M, N).to(dev)
     ref = a.float() @ b.float().T
-    be.lib.vdk_gemm_force_kernel(2)
+    be.lib.vdk_gemm_force_kernel(kern)
     try:
         if splitk == 1:
             out = ops.gemm_nt(a, b, out_dtype=torch.float32, bias=bias, residual=res, backend=be)
+            assert be.lib.vdk_gemm_last_kernel() == kern
             assert _rel(out, ref + bias + res) < 1e-5
             outb = ops.gemm_nt(a, b, out_dtype=torch.bfloat16, act=ops.ACT_GELU, backend=be)
             assert _rel(outb.float(), torch.nn.functional.gelu(ref).bfloat16().float()) < 4e-3
@@ -109,8 +111,9 @@ def test_gemm256_lds_dma_kernel(be, dev, M, N, K, splitk):
         be.lib.vdk_gemm_force_kernel(0)
 
 
-@pytest.mark.parametrize("K,M,N,splitk,rg", [(64, 256, 256, 1, 0), (192, 264, 136, 1, 0), (256, 72, 520, 2, 0), (128, 128, 192, 1, 16)])
-def test_gemm_tn_from_kmajor_operands(be, dev, K, M, N, splitk, rg):
+@pytest.mark.parametrize("kern", [2, 5])
+@pytest.mark.parametrize("K,M,N,splitk,rg", [(64, 256, 256, 1, 0), (192, 264, 136, 1, 0), (256, 72, 520, 2, 0), (128, 128, 192, 1, 16), (320, 520, 264, 1, 0)])
+def test_gemm_tn_from_kmajor_operands(be, dev, K, M, N, splitk, rg, kern):
     """wgrad form C = A^T B with A [K, M], B [K, N] read as they lie (ds_read_b64_tr_b16 fragments), incl. the token-row remap"""
     torch.manual_seed(6)
     phys = K + K // rg + 1 if rg else K
@@ -122,7 +125,12 @@ def test_gemm_tn_from_kmajor_operands(be, dev, K, M, N, splitk, rg):
     else:
         a_log = a_full
     ref = a_log.float().T @ b.float()
-    out = ops.gemm_nt(a_full, b, out_dtype=torch.float32, splitk=splitk, trans=True, a_row_group=rg, a_rows=K, backend=be)
+    be.lib.vdk_gemm_force_kernel(kern)   # (the token-row remap is served by the eight-wave kernel either way)
+    try:
+        out = ops.gemm_nt(a_full, b, out_dtype=torch.float32, splitk=splitk, trans=True, a_row_group=rg, a_rows=K, backend=be)
+        assert be.lib.vdk_gemm_last_kernel() == (2 if rg else kern)
+    finally:
+        be.lib.vdk_gemm_force_kernel(0)
     assert out.shape == (M, N)
     assert _rel(out, ref) < 1e-5
 
@@ -204,13 +212,14 @@ def test_gemm256_stream_k(be, dev, M, N, K, grid):
         be.lib.vdk_gemm_force_kernel(0); be.lib.vdk_gemm_streamk_grid(0)
 
 
+@pytest.mark.parametrize("kern", [2, 5])
 @pytest.mark.parametrize("M", [512, 300])
-def test_gemm256_c_colsum_byproduct(be, dev, M):
+def test_gemm256_c_colsum_byproduct(be, dev, M, kern):
     """bias gradient fused into the PRODUCER of dY: the 256x256 NT kernel's plain / dGELU bf16 epilogues also emit column sums of what they store"""
     torch.manual_seed(7)
     N, K = 512, 192
     a = torch.randn(M, K).bfloat16().to(dev); b = (torch.randn(N, K) * 0.2).bfloat16().to(dev); u = torch.randn(M, N).bfloat16().to(dev)
-    be.lib.vdk_gemm_force_kernel(2)
+    be.lib.vdk_gemm_force_kernel(kern)
     try:
         rows = be.lib.vdk_gemm_c_colsum_rows(M, N, K)
         assert rows == 2 * ((M + 255) // 256)

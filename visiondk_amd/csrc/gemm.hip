@@ -680,6 +680,13 @@ static bool g_prof_on = false;
 static void* g_dbg_ptr = nullptr;
 static int g_force_kernel = 0;   // 0 auto, 1 = 128x128 register-staged, 2 = 256x256 LDS-DMA, 3 = 256x256 stream-K whenever a workspace is passed, 4 = never stream-K (tests / A-B benchmarking)
 static int g_sk_grid = 0;        // stream-K workgroups; 0 = one per CU of the current device
+static thread_local int g_last_kernel = 0;
+// which 256x256 structure serves the big problems: the 4-wave kernel of gemm_w4.hip (default) or the 8-wave kernel above (VDK_GEMM_W4=0, vdk_gemm_force_kernel(2 / 3);
+// vdk_gemm_force_kernel(5) = the 4-wave kernel whenever it can serve)
+static bool w4_enabled() {
+  static const bool on = !(getenv("VDK_GEMM_W4") && atoi(getenv("VDK_GEMM_W4")) == 0);
+  return (on || g_force_kernel == 5) && g_force_kernel != 2 && g_force_kernel != 3;
+}
 #define SK_CNT_BYTES 65536       // 16384 tile counters in front of the slabs
 static int sk_grid() {
   if (g_sk_grid > 0) return g_sk_grid;
@@ -698,18 +705,19 @@ extern "C" {
 /* rows of the a_colsum by-product ([rows][K] f32) if the NT problem (M, N, K) is served by the 256x256 kernel and M % 256 == 0, else 0 */
 int vdk_gemm_a_colsum_rows(int32_t M, int32_t N, int32_t K) {
   const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  const bool big = g_force_kernel == 2 || g_force_kernel == 3 || ((g_force_kernel == 0 || g_force_kernel == 4) && (K % 64 == 0) && tiles256 >= 128 && M >= 256 && N >= 256);
+  const bool big = g_force_kernel == 2 || g_force_kernel == 3 || g_force_kernel == 5 || ((g_force_kernel == 0 || g_force_kernel == 4) && (K % 64 == 0) && tiles256 >= 128 && M >= 256 && N >= 256);
   return (big && (K % 64 == 0) && (M % 256 == 0)) ? (M / 256) : 0;
 }
 
 /* rows of the c_colsum by-product ([rows][N] f32: column sums of the stored bf16 output per (row tile, wave row)) if the 256x256 NT kernel serves (M, N, K), else 0 */
 int vdk_gemm_c_colsum_rows(int32_t M, int32_t N, int32_t K) {
   const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  const bool big = g_force_kernel == 2 || g_force_kernel == 3 || ((g_force_kernel == 0 || g_force_kernel == 4) && (K % 64 == 0) && tiles256 >= 128 && M >= 256 && N >= 256);
+  const bool big = g_force_kernel == 2 || g_force_kernel == 3 || g_force_kernel == 5 || ((g_force_kernel == 0 || g_force_kernel == 4) && (K % 64 == 0) && tiles256 >= 128 && M >= 256 && N >= 256);
   return (big && (K % 64 == 0)) ? 2 * ((M + 255) / 256) : 0;
 }
 
 int vdk_gemm_force_kernel(int32_t which) { g_force_kernel = which; return VDK_OK; }
+int vdk_gemm_last_kernel(void) { return g_last_kernel; }
 
 /* stream-K (VdkGemmDesc.splitk == -1): `ws` of vdk_gemm_bf16_nt is then a PERSISTENT workspace of this many bytes whose first 64 KB (the tile counters) the caller
    zeroed once; every launch leaves them zero again.  One workspace serves one stream at a time. */
@@ -788,7 +796,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   if (d->c_dtype != VDK_BF16 && d->c_dtype != VDK_F32) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad c_dtype");
   if ((d->act == VDK_ACT_DGELU && !d->aux) || (d->aux && (d->ldaux & 7))) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad aux");
   int splitk = d->splitk < 1 ? 1 : d->splitk;
-  GemmParams p;
+  GemmParams p = {};
   p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C;
   p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
   p.M = d->M; p.N = d->N; p.K = d->K;
@@ -819,7 +827,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   const bool prof = g_prof_on && g_prof_used + 2 <= g_prof_ev.size();
   // big problems go to the 256x256 LDS-DMA kernel (needs whole 64-wide k-tiles per split and >= 1 full wave of tiles)
   const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * splitk;
-  const bool big = !d->conv && (g_force_kernel == 2 || g_force_kernel == 3 || ((g_force_kernel == 0 || g_force_kernel == 4) && (d->K % 64 == 0) && (kps % 64 == 0) && tiles256 >= 128 && d->M >= 256 && d->N >= 256));
+  const bool big = !d->conv && (g_force_kernel == 2 || g_force_kernel == 3 || g_force_kernel == 5 || ((g_force_kernel == 0 || g_force_kernel == 4) && (d->K % 64 == 0) && (kps % 64 == 0) && tiles256 >= 128 && d->M >= 256 && d->N >= 256));
   // compile-time epilogue variant (the common ViT forms); anything else takes the run-time-flag path
   int E = E_GENERIC;
   {
@@ -856,6 +864,10 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   } while (0)
 #define LAUNCH256X(TNF, EE, CSF)                                                                                         \
   do {                                                                                                                   \
+    if (!sk && !(CSF) && w4_enabled() && vdk_gemm_w4_serves(p, TNF) &&                                                   \
+        vdk_gemm_w4_launch(p, TNF, EE, grid256.x, grid256.y, stream, prof ? (void*)g_prof_ev[g_prof_used] : nullptr,     \
+                           prof ? (void*)g_prof_ev[g_prof_used + 1] : nullptr)) { g_last_kernel = 5; break; }            \
+    g_last_kernel = sk ? 3 : 2;                                                                                          \
     if (sk) VDK_GEMM_LAUNCH((gemm256_bf16_kernel<TNF, EE, !TNF, CSF>), grid256, dim3(512));                               \
     else VDK_GEMM_LAUNCH((gemm256_bf16_kernel<TNF, EE, false, CSF>), grid256, dim3(512));                                 \
   } while (0)
@@ -904,10 +916,13 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
 #undef LAUNCH256
   else if (d->a_colsum || d->c_colsum)
     return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: a_colsum / c_colsum are by-products of the 256x256 NT kernel only (see vdk_gemm_a_colsum_rows)");
-  else if (d->conv)
+  else if (d->conv) {
+    g_last_kernel = 1;
     VDK_GEMM_LAUNCH(gemm_bf16_nt_kernel<true>, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256));
-  else
+  } else {
+    g_last_kernel = 1;
     VDK_GEMM_LAUNCH(gemm_bf16_nt_kernel<false>, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256));
+  }
   if (prof) {   // the GEMM kernel only (the split-K combine is a separate, HBM-bound kernel)
     g_prof_flops.push_back(2.0 * d->M * d->N * d->K);
     {
@@ -952,7 +967,9 @@ int vdk_margin_cos_pass(const VdkMarginHead* h, int32_t pass, const void* fbt, i
   p.me.labels = (const long long*)labels; p.me.gt = gt; p.me.stats = stats; p.me.nslice = (Cp + 63) / 64; p.me.tlogit = tlogit; p.me.rowstat = rowstat;
   p.me.smoothing = label_smoothing; p.me.gscale = grad_scale; p.me.epsc = label_smoothing / (float)C; p.me.B = B; p.me.C = C;
   const dim3 grid((unsigned)(((Bp + 255) / 256) * ((Cp + 255) / 256)), 1u);
-  if (pass == 1) hipLaunchKernelGGL((gemm256_bf16_kernel<true, E_MSTAT, false, false>), grid, dim3(512), 0, stream, p);
+  g_last_kernel = 2;
+  if (w4_enabled() && vdk_gemm_w4_serves(p, true) && vdk_gemm_w4_launch(p, true, pass == 1 ? E_MSTAT : E_MGRAD, grid.x, 1u, stream, nullptr, nullptr)) g_last_kernel = 5;
+  else if (pass == 1) hipLaunchKernelGGL((gemm256_bf16_kernel<true, E_MSTAT, false, false>), grid, dim3(512), 0, stream, p);
   else hipLaunchKernelGGL((gemm256_bf16_kernel<true, E_MGRAD, false, false>), grid, dim3(512), 0, stream, p);
   return vdk_check_launch("vdk_margin_cos_pass");
 }

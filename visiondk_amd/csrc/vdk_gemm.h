@@ -35,3 +35,7 @@ struct GemmParams {
 // in-library launcher (no descriptor copy through the C ABI)
 extern "C" int vdk_gemm_bf16_nt(const VdkGemmDesc* d, void* ws, size_t ws_bytes, void* stream);
 extern "C" int vdk_transpose_bf16(const void* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, int32_t Rpad, int32_t in_row_group, float* colsum_partial, void* stream);
+
+// gemm_w4.hip: the 4-wave (one wave per SIMD) 256x256 kernel.  serves(): the problem fits its 32-bit buffer offsets and asks for no by-product it lacks.
+bool vdk_gemm_w4_serves(const GemmParams& p, bool trans);
+bool vdk_gemm_w4_launch(const GemmParams& p, bool trans, int E, unsigned tiles, unsigned splitk, void* stream, void* ev0, void* ev1);

@@ -73,15 +73,15 @@ __device__ __forceinline__ void g_epilogue_store8(const GemmParams& p, long mi, 
 #define E_Q8 1024     /* by-product: fp8(clamp(stored bf16 value * q8_scale)) -> p.q8, max |value| -> p.q8_amax: bit-identical to vdk_quant_fp8 over the stored tensor */
 #define E_GENERIC 0x1000
 
-template <int E>
-__device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float* slab, int lane, long mbase /* first row of this 64-row half */,
+template <int E, int NPS = 8 /* row passes: the slab holds NPS * 8 rows x 64 fp32 */>
+__device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float* slab, int lane, long mbase /* first row of this slab */,
                                                 int n, int z, const float (&bias8)[8], float (&ocs)[8], float& q8am) {
-  // this lane: rows mbase + pass*8 + (lane >> 3), pass = 0..7, columns n .. n+7
+  // this lane: rows mbase + pass*8 + (lane >> 3), pass = 0..NPS-1, columns n .. n+7
   const int rsub = lane >> 3, cc = (lane & 7) * 8;
   if (E & E_MSTAT) {     // margin logits of this lane's 8 columns -> (max, sum exp, sum) merged over the 8 lanes that share a row -> one partial per (row, 64-column slice)
     const MarginEpi& me = p.me;
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
+    for (int ps = 0; ps < NPS; ++ps) {
       const long mi = mbase + ps * 8 + rsub;
       const bool rok = mi < me.B;
       const int row = ps * 8 + rsub;
@@ -116,31 +116,31 @@ __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float
     return;
   }
   if (n >= p.N) return;
-  long mo[8], mr[8];
-  bool ok[8];
+  long mo[NPS], mr[NPS];
+  bool ok[NPS];
 #pragma unroll
-  for (int ps = 0; ps < 8; ++ps) {
+  for (int ps = 0; ps < NPS; ++ps) {
     const long mi = mbase + ps * 8 + rsub;
     ok[ps] = mi < p.M;
     mo[ps] = (E & E_ROWGRP) ? mi + (mi / p.row_group + 1) * p.row_shift : mi;
     mr[ps] = (E & E_ROWGRP) ? mi % p.row_group + p.row_shift : mi;
   }
-  f32x4 r0[8], r1[8];
-  u32x4 ux[8];
+  f32x4 r0[NPS], r1[NPS];
+  u32x4 ux[NPS];
   float q8s = 1.0f, q8lim = 448.0f;      // (q8am: this lane's running max |stored value|, reduced by the kernel once per workgroup)
   if (E & E_Q8) { q8s = p.q8_scale ? p.q8_scale[0] : 1.0f; q8lim = p.q8_fmt == 0 ? 448.0f : 57344.0f; }
   if (E & E_RES) {
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps)
+    for (int ps = 0; ps < NPS; ++ps)
       if (ok[ps]) { const float* rs = p.residual + mr[ps] * p.ldr + n; r0[ps] = *(const f32x4*)rs; r1[ps] = *(const f32x4*)(rs + 4); }
   }
   if (E & E_DGELU) {
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps)
+    for (int ps = 0; ps < NPS; ++ps)
       if (ok[ps]) ux[ps] = *(const u32x4*)(p.aux + mo[ps] * p.ldaux + n);
   }
 #pragma unroll
-  for (int ps = 0; ps < 8; ++ps) {
+  for (int ps = 0; ps < NPS; ++ps) {
     if (!ok[ps]) continue;
     const int row = ps * 8 + rsub;
     float v[8];
