@@ -392,6 +392,19 @@ static inline void emu_buffer_load_lds(emu_buffer_rsrc rs, void* lds_dst, unsign
   if (off + size <= rs.num_records) memcpy(dst, rs.base + off, size); else memset(dst, 0, size);
   emu::wave_barrier();
 }
+typedef unsigned emu_u32x4 __attribute__((ext_vector_type(4)));
+static inline void emu_buffer_store_b128(emu_u32x4 v, emu_buffer_rsrc rs, unsigned voff, unsigned soff, int) {
+  const unsigned long long off = (unsigned long long)voff + soff;
+  if (off + 16 <= rs.num_records) memcpy((unsigned char*)rs.base + off, &v, 16);
+}
+static inline emu_u32x4 emu_buffer_load_b128(emu_buffer_rsrc rs, unsigned voff, unsigned soff, int) {
+  const unsigned long long off = (unsigned long long)voff + soff;
+  emu_u32x4 v = {0u, 0u, 0u, 0u};
+  if (off + 16 <= rs.num_records) memcpy(&v, rs.base + off, 16);
+  return v;
+}
+#define __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, aux) emu_buffer_store_b128((v), (rs), (unsigned)(voff), (unsigned)(soff), (aux))
+#define __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, aux) emu_buffer_load_b128((rs), (unsigned)(voff), (unsigned)(soff), (aux))
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, l, sz, voff, soff, ioff, aux) emu_buffer_load_lds((rs), (void*)(l), sz, voff, soff, ioff, aux)
 #define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
 // ds_read_b64_tr_b16, semantics measured on gfx950 (tools/probes/tr_probe.hip): within each 16-lane group, lane i's

@@ -88,7 +88,8 @@ def test_transpose_fused_colsum(be, dev):
 
 
 @pytest.mark.parametrize("kern", [2, 5])
-@pytest.mark.parametrize("M,N,K,splitk", [(256, 256, 64, 1), (300, 264, 192, 1), (512, 256, 256, 1), (130, 520, 128, 1), (256, 256, 512, 2), (520, 128, 192, 1), (264, 256, 320, 1)])
+@pytest.mark.parametrize("M,N,K,splitk", [(256, 256, 64, 1), (300, 264, 192, 1), (512, 256, 256, 1), (130, 520, 128, 1), (256, 256, 512, 2), (520, 128, 192, 1), (264, 256, 384, 1),
+                                          (776, 520, 256, 1), (264, 256, 768, 3)])
 def test_gemm256_lds_dma_kernel(be, dev, M, N, K, splitk, kern):
     """the 256x256 LDS-DMA kernels (2: eight waves, 5: four waves / one per SIMD), forced, vs torch fp32 on the same bf16 operands (incl. ragged M/N, 1..5 k-tiles and split-K)"""
     torch.manual_seed(5)
@@ -100,7 +101,7 @@ def test_gemm256_lds_dma_kernel(be, dev, M, N, K, splitk, kern):
     try:
         if splitk == 1:
             out = ops.gemm_nt(a, b, out_dtype=torch.float32, bias=bias, residual=res, backend=be)
-            assert be.lib.vdk_gemm_last_kernel() == kern
+            assert be.lib.vdk_gemm_last_kernel() == (kern if K % 128 == 0 else 2)   # the four-wave kernel multiplies k-tiles in pairs
             assert _rel(out, ref + bias + res) < 1e-5
             outb = ops.gemm_nt(a, b, out_dtype=torch.bfloat16, act=ops.ACT_GELU, backend=be)
             assert _rel(outb.float(), torch.nn.functional.gelu(ref).bfloat16().float()) < 4e-3
@@ -112,7 +113,7 @@ def test_gemm256_lds_dma_kernel(be, dev, M, N, K, splitk, kern):
 
 
 @pytest.mark.parametrize("kern", [2, 5])
-@pytest.mark.parametrize("K,M,N,splitk,rg", [(64, 256, 256, 1, 0), (192, 264, 136, 1, 0), (256, 72, 520, 2, 0), (128, 128, 192, 1, 16), (320, 520, 264, 1, 0)])
+@pytest.mark.parametrize("K,M,N,splitk,rg", [(64, 256, 256, 1, 0), (192, 264, 136, 1, 0), (256, 72, 520, 2, 0), (128, 128, 192, 1, 16), (384, 520, 264, 1, 0), (512, 264, 136, 2, 0)])
 def test_gemm_tn_from_kmajor_operands(be, dev, K, M, N, splitk, rg, kern):
     """wgrad form C = A^T B with A [K, M], B [K, N] read as they lie (ds_read_b64_tr_b16 fragments), incl. the token-row remap"""
     torch.manual_seed(6)
@@ -128,7 +129,7 @@ def test_gemm_tn_from_kmajor_operands(be, dev, K, M, N, splitk, rg, kern):
     be.lib.vdk_gemm_force_kernel(kern)   # (the token-row remap is served by the eight-wave kernel either way)
     try:
         out = ops.gemm_nt(a_full, b, out_dtype=torch.float32, splitk=splitk, trans=True, a_row_group=rg, a_rows=K, backend=be)
-        assert be.lib.vdk_gemm_last_kernel() == (2 if rg else kern)
+        assert be.lib.vdk_gemm_last_kernel() == (2 if rg or K % 128 else kern)
     finally:
         be.lib.vdk_gemm_force_kernel(0)
     assert out.shape == (M, N)
@@ -217,7 +218,7 @@ def test_gemm256_stream_k(be, dev, M, N, K, grid):
 def test_gemm256_c_colsum_byproduct(be, dev, M, kern):
     """bias gradient fused into the PRODUCER of dY: the 256x256 NT kernel's plain / dGELU bf16 epilogues also emit column sums of what they store"""
     torch.manual_seed(7)
-    N, K = 512, 192
+    N, K = 512, 256
     a = torch.randn(M, K).bfloat16().to(dev); b = (torch.randn(N, K) * 0.2).bfloat16().to(dev); u = torch.randn(M, N).bfloat16().to(dev)
     be.lib.vdk_gemm_force_kernel(kern)
     try:
@@ -229,5 +230,41 @@ def test_gemm256_c_colsum_byproduct(be, dev, M, kern):
             ref = ops.gemm_nt(a, b, act=act, aux=u if act else None, backend=be)
             assert torch.equal(out, ref)
             torch.testing.assert_close(part.sum(0).cpu(), out.float().sum(0).cpu(), rtol=1e-5, atol=1e-4)
+    finally:
+        be.lib.vdk_gemm_force_kernel(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(1300, 776, 256), (2050, 520, 128)])
+def test_gemm_w4_persistent_walk(be, dev, M, N, K):
+    """more output tiles than CUs (the emulated device has 16): the four-wave kernel walks its tiles with the DMA cursor running into the next tile;
+    every fused epilogue form against torch fp32 on the same bf16 operands, ragged M / N"""
+    torch.manual_seed(11)
+    a = torch.randn(M, K).bfloat16().to(dev); b = (torch.randn(N, K) * 0.3).bfloat16().to(dev)
+    b[:, 5] += 1.0
+    bias = torch.randn(N).to(dev); res = torch.randn(M, N).to(dev); u = torch.randn(M, N).bfloat16().to(dev)
+    ref = a.float() @ b.float().T
+    be.lib.vdk_gemm_force_kernel(5)
+    try:
+        out = ops.gemm_nt(a, b, bias=bias, backend=be)                                                    # bias -> bf16 (row-staged form)
+        assert be.lib.vdk_gemm_last_kernel() == 5
+        assert _rel(out.float(), (ref + bias).bfloat16().float()) < 3e-3
+        out = ops.gemm_nt(a, b, backend=be)                                                               # plain bf16
+        assert _rel(out.float(), ref.bfloat16().float()) < 3e-3
+        aux = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        out = ops.gemm_nt(a, b, bias=bias, act=ops.ACT_GELU, aux=aux, backend=be)                          # bias + GELU + saved pre-activation
+        assert _rel(aux.float(), (ref + bias).bfloat16().float()) < 3e-3
+        assert _rel(out.float(), torch.nn.functional.gelu(ref + bias).bfloat16().float()) < 4e-3
+        rows = be.lib.vdk_gemm_c_colsum_rows(M, N, K)
+        part = torch.full((rows, N), float("nan"), dtype=torch.float32, device=dev)
+        out = ops.gemm_nt(a, b, act=ops.ACT_DGELU, aux=u, c_colsum=part, backend=be)                       # dGELU + column sums of the stored output
+        uu = u.float().requires_grad_(True)
+        torch.nn.functional.gelu(uu).sum().backward()
+        assert _rel(out.float(), (ref * uu.grad).bfloat16().float()) < 4e-3
+        torch.testing.assert_close(part.sum(0).cpu(), out.float().sum(0).cpu(), rtol=1e-4, atol=1e-3)
+        out = ops.gemm_nt(a, b, out_dtype=torch.float32, bias=bias, residual=res, backend=be)              # fp32 + residual (slab form)
+        assert _rel(out, ref + bias + res) < 1e-5
+        out = ops.gemm_nt(a, b, out_dtype=torch.float32, alpha=0.5, backend=be)                            # run-time-flag form
+        assert _rel(out, 0.5 * ref) < 1e-5
+        assert be.lib.vdk_gemm_last_kernel() == 5
     finally:
         be.lib.vdk_gemm_force_kernel(0)

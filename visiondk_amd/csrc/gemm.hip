@@ -813,7 +813,8 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   if (splitk > 1) {
     if (d->bias || d->residual || d->act != VDK_ACT_NONE || d->row_group != 0) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: split-K excludes fused epilogues");
     if (d->ldc != d->N) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: split-K needs ldc == N");
-    kps = ((d->K + splitk - 1) / splitk + G_BK - 1) / G_BK * G_BK;
+    const int kq = (d->K % 128 == 0) ? 128 : G_BK;     // whole PAIRS of k-tiles per split where K allows it (the four-wave kernel multiplies k-tiles in pairs)
+    kps = ((d->K + splitk - 1) / splitk + kq - 1) / kq * kq;
     splitk = (d->K + kps - 1) / kps;
     p.splitk = splitk;
     if (splitk > 1) {

@@ -1,20 +1,27 @@
-// gemm_w4.hip — K2, second structure: the 256x256x64 bf16 GEMM as FOUR waves, one per SIMD.
+// gemm_w4.hip — K2, second structure: the 256x256x64 bf16 GEMM as FOUR waves, one per SIMD, persistent over its output tiles.
 //
 // Same product as gemm.hip (C[M,N] = A[M,K] * B[N,K]^T, or C = A^T B for the weight gradients; every Linear of the hot path,
 // reference call sites models/classifier/classify_model.py:49-54 -> timm vision_transformer), different machine mapping:
 //   * one workgroup = 4 waves = the CU's 4 SIMDs, one wave each with the whole 512-register file: wave tile 128x128 = 4x4
 //     v_mfma_f32_32x32x16_bf16 accumulators = 256 AGPRs.  Per 64-deep k-tile a wave reads 32 fragments for 64 MFMAs (the 8-wave
-//     kernel: 48 per 64) and no second wave competes for its SIMD's matrix pipe.
-//   * operands arrive by LDS-DMA (buffer_load_dwordx4 ... lds): per-lane offsets are loop-invariant, the k / tile position lives in
-//     the scalar offset, rows beyond the matrix read as zero through the descriptor's bounds check.  LDS image and bank swizzle
-//     as in gemm.hip (source-side involution, cdna_hip_programming.md rule 21).
+//     kernel: 48 per 64) and no second wave competes for its SIMD's matrix pipe (measured at 8192^3: 78 % of the elapsed cycles
+//     are MFMA cycles against 70 %; the chip then clocks to its power budget).
+//   * operands arrive by LDS-DMA (buffer_load_dwordx4 ... lds, inline asm: the compiler neither waits for it nor serialises LDS
+//     reads behind it): per-lane offsets are loop-invariant, the k / tile position lives in the scalar offset, rows beyond the
+//     matrix read as zero through the descriptor's bounds check.  LDS image and bank swizzle as in gemm.hip (source-side
+//     involution, cdna_hip_programming.md rule 21).
 //   * a k-tile is 4 regions of 16 KB (RA0 / RA1 = first / second 64 rows of both wave-rows, RB0 / RB1 likewise for the wave
 //     columns) consumed in 4 phases of 16 MFMAs: A0B0, A0B1, A1B1, A1B0.  The fragments of a phase are read from LDS one phase
 //     EARLIER, behind the previous phase's MFMAs, so a region is free again a phase before its tile is multiplied and its
-//     refill (k-tile t+2) has 6 phases (~3 k cycles) to land with only two tile buffers (128 KB):
+//     refill (k-tile t+2 of the stream) has 6 phases (~3 k cycles) to land with only two tile buffers (128 KB):
 //         phase g reads the region whose DMA group was issued in phase g-6; every phase issues one group of 4 pieces per wave
 //         => the single wait per phase is vmcnt(20) ("all but the 5 newest groups"), never 0 in steady state.
-//   * 32 KB of LDS beside the operand ring stage the epilogue (4 waves x 32 rows x 64 fp32), so the ring is never torn down.
+//   * the k-tile stream does not stop at an output tile's end: a workgroup walks its tiles (XCD-local raster) and the DMA cursor,
+//     two k-tiles ahead of the MFMAs, moves on to the next tile's operands while the current tile finishes, so the next tile's
+//     first operands land and its first fragments are read under the current tile's last MFMAs and its epilogue.
+//   * the MFMAs take the B fragment as their first operand: a lane then owns ONE output row and groups of 4 consecutive columns,
+//     so the epilogue packs bf16 rows with 8-byte LDS writes into 32 KB of staging beside the operand ring (never torn down) and
+//     stores whole 256-byte row segments.
 #include <hip/hip_runtime.h>
 #ifndef VDK_EMU_NO_HIP_EXT
 #include <hip/hip_ext.h>
@@ -32,60 +39,88 @@
 #define W4_RA1 16384
 #define W4_RB0 32768
 #define W4_RB1 49152
+#define W4_OOB 0x80000000u   /* scalar offset of a DMA that must read nothing: beyond every descriptor (operands stay below 2 GB), so it lands zeros */
 
 #define W4_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))   /* vmcnt(n), n < 64; expcnt / lgkmcnt untouched */
 #define W4_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
 #define W4_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 
-// ---- LDS-DMA of one operand: scalar state + loop-invariant lane offsets -------------------------------------------------------------
+// ---- LDS-DMA -----------------------------------------------------------------------------------------------------------------------
+// One piece = one buffer_load_dwordx4 ... lds: 64 lanes x 16 B land at LDS [dst, dst + 1024) in lane order; the source of lane l is
+// descriptor base + voff(l) + soff.  The compiler does not see the instruction (cdna_hip_programming.md §5.7): completion is counted by
+// hand with W4_WAIT_VM, and no s_waitcnt vmcnt(0) appears in front of the LDS reads (with the builtin form hipcc put one in front of
+// every ds_read_b64_tr_b16 of the TN kernel: 3x slower).
+#ifdef VDK_EMU
+typedef emu_buffer_rsrc w4_rsrc_t;
+__device__ __forceinline__ w4_rsrc_t w4_make_rsrc(const void* base, unsigned bytes) { return emu_buffer_rsrc{(const unsigned char*)base, bytes}; }
+#define W4_DMA16(rs, voff, dst, soff) emu_buffer_load_lds((rs), (void*)(dst), 16, (voff), (soff), 0, 0)
+#else
+typedef u32x4 w4_rsrc_t;
+__device__ __forceinline__ w4_rsrc_t w4_make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  w4_rsrc_t r = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)),
+                 (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+  return r;
+}
+#define W4_DMA16(rs, voff, dst, soff)                                                                                                 \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"                                              \
+               ::"s"((unsigned)(unsigned long long)VDK_LDS_PTR(dst)), "v"(voff), "s"(rs), "s"(soff) : "memory")
+#endif
+
 // piece j (0..3) of wave w fills LDS bytes [(4w + j) * 1024, +1024) of a region.
 //   NT (operand [rows, K] row-major): the piece is region rows 32w + 8j .. +7 (lane: row i = lane >> 3, 16-B position cp = lane & 7, which holds global
 //      chunk cp ^ (4 (j & 1) + (i >> 1)) = cp ^ ((row >> 1) & 7)); region row r is operand row (r >> 6) * 128 + sub * 64 + (r & 63).
 //   TN (operand [K, cols] row-major): the piece is k-rows 4 (4w + j) .. +3 of the region's [64 k][128 cols] image (lane: k-row lane >> 4, position
 //      cp = lane & 15 holding chunk c = cp ^ (4 (k-row & 3)), i.e. operand columns (c >> 3) * 128 + sub * 64 + (c & 7) * 8 .. +7).
 struct W4Dma {
-  __amdgpu_buffer_rsrc_t rs;
+  w4_rsrc_t rs;
   unsigned voff0, voff1;     // lane byte offsets of even / odd pieces (TN: equal)
-  unsigned sbase;            // scalar: tile origin + this wave's share, bytes
   unsigned sub_stride;       // scalar: bytes from the sub 0 region's source to the sub 1 region's
   unsigned piece_stride;     // scalar: bytes between consecutive pieces
-  unsigned kpos;             // scalar: byte offset of the NEXT k-tile to be issued
   unsigned kstep;            // scalar: bytes per k-tile
+  unsigned kbeg;             // scalar: byte offset of a tile's first k-tile
+  unsigned wave_off;         // scalar: this wave's share inside a tile, bytes
+  unsigned ldb;              // scalar: operand row pitch, bytes
 };
 
 template <bool TN>
-__device__ __forceinline__ void w4_dma_init(W4Dma& d, const bf16_t* base, long ld, int origin /* first operand row (NT) / column (TN) of the tile */, int extent /* operand rows (NT) */,
-                                            int K, int kbeg, int w, int lane) {
+__device__ __forceinline__ void w4_dma_init(W4Dma& d, const bf16_t* base, long ld, int extent /* operand rows (NT) */, int K, int kbeg, int w, int lane) {
   const unsigned ldb = (unsigned)ld * 2u;
+  d.ldb = ldb;
   if (!TN) {
-    d.rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((unsigned)extent * ldb), 0x00020000);
+    d.rs = w4_make_rsrc(base, (unsigned)extent * ldb);
     const unsigned i = (unsigned)lane >> 3, cp = (unsigned)lane & 7u;
     d.voff0 = i * ldb + ((cp ^ (i >> 1)) << 4);
     d.voff1 = i * ldb + ((cp ^ (4u + (i >> 1))) << 4);
-    d.sbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)origin + (unsigned)(w >> 1) * 128u + (unsigned)(w & 1) * 32u) * ldb));
+    d.wave_off = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)(w >> 1) * 128u + (unsigned)(w & 1) * 32u) * ldb));
     d.sub_stride = 64u * ldb;
     d.piece_stride = 8u * ldb;
-    d.kpos = (unsigned)kbeg * 2u;
+    d.kbeg = (unsigned)kbeg * 2u;
     d.kstep = 128u;
   } else {
-    d.rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((unsigned)K * ldb), 0x00020000);
+    d.rs = w4_make_rsrc(base, (unsigned)K * ldb);
     const unsigned kr = (unsigned)lane >> 4, cp = (unsigned)lane & 15u, c = cp ^ (4u * (kr & 3u));
     d.voff0 = d.voff1 = kr * ldb + ((c >> 3) * 128u + (c & 7u) * 8u) * 2u;
-    d.sbase = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)origin * 2u + (unsigned)w * 16u * ldb));
+    d.wave_off = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)w * 16u * ldb));
     d.sub_stride = 128u;
     d.piece_stride = 4u * ldb;
-    d.kpos = (unsigned)kbeg * ldb;
+    d.kbeg = (unsigned)kbeg * ldb;
     d.kstep = 64u * ldb;
   }
 }
-// one piece: j = 0..3 of the region `sub` (0 / 1) of the k-tile at d.kpos + kahead * d.kstep, into LDS at dst (wave-uniform)
-__device__ __forceinline__ void w4_piece(const W4Dma& d, unsigned char* dst, int sub, int j, unsigned kofs) {
-  const unsigned so = d.sbase + (unsigned)sub * d.sub_stride + (unsigned)j * d.piece_stride + kofs;
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rs, VDK_LDS_PTR(dst), 16, (j & 1) ? d.voff1 : d.voff0, so, 0, 0);
+// scalar offset of a tile's origin (first operand row (NT) / column (TN)) for this wave
+template <bool TN>
+__device__ __forceinline__ unsigned w4_tile_base(const W4Dma& d, int origin) {
+  return (TN ? (unsigned)origin * 2u : (unsigned)origin * d.ldb) + d.wave_off;
 }
-__device__ __forceinline__ void w4_region(const W4Dma& d, unsigned char* region, int sub, int w, unsigned kofs) {
+// piece j of region `sub` of the k-tile at scalar offset so0 (tile base + k offset)
+__device__ __forceinline__ void w4_piece(const W4Dma& d, unsigned char* dst, int sub, int j, unsigned so0) {
+  const unsigned so = so0 + (unsigned)sub * d.sub_stride + (unsigned)j * d.piece_stride;
+  W4_DMA16(d.rs, (j & 1) ? d.voff1 : d.voff0, dst, so);
+}
+__device__ __forceinline__ void w4_region(const W4Dma& d, unsigned char* region, int sub, int w, unsigned so0) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) w4_piece(d, region + (4 * w + j) * 1024, sub, j, kofs);
+  for (int j = 0; j < 4; ++j) w4_piece(d, region + (4 * w + j) * 1024, sub, j, so0);
 }
 
 // ---- fragments -----------------------------------------------------------------------------------------------------------------------
@@ -129,20 +164,23 @@ __device__ __forceinline__ s16x8 w4_frag(const unsigned char* region, const unsi
 }
 
 // ---- one phase: 16 MFMAs (2 x 2 accumulators x 4 k-steps) with 8 fragment reads and 4 DMA pieces spread behind them -------------------
-// RD: 0 none, 1 read 8 fragments from `rd_region` through offsets rd_off into RDST[2][4].  IS: issue the 4 pieces of (dma, is_region, is_sub).
-template <bool TN, bool RD, bool IS>
+// c[i][j]: i = A block (rows of C), j = B block (columns of C); the MFMA is (B fragment, A fragment): D rows = C columns, so lane l holds C row l & 31.
+// RD: the phase reads 8 fragments from `rd_region` through offsets rd_off into RDST[2][4].  It issues the 4 pieces of (dma, is_region, is_sub) at scalar offset so0.
+// FIRST: the accumulators start from zero (first k-tile of an output tile).
+template <bool TN, bool RD, bool FIRST>
 __device__ __forceinline__ void w4_phase(f32x16 (&c00), f32x16 (&c01), f32x16 (&c10), f32x16 (&c11), const s16x8 (&X)[2][4], const s16x8 (&Y)[2][4],
                                          const unsigned char* rd_region, const unsigned* rd_off, s16x8 (&RDST)[2][4],
-                                         const W4Dma& dma, unsigned char* is_region, int is_sub, int w) {
+                                         const W4Dma& dma, unsigned char* is_region, int is_sub, unsigned so0, int w) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[0][ks], Y[0][ks], c00, 0, 0, 0);
+    c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Y[0][ks], X[0][ks], (FIRST && ks == 0) ? zero : c00, 0, 0, 0);
     if (RD) RDST[0][ks] = w4_frag<TN>(rd_region, rd_off, 0, ks);
-    c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[0][ks], Y[1][ks], c01, 0, 0, 0);
+    c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Y[1][ks], X[0][ks], (FIRST && ks == 0) ? zero : c01, 0, 0, 0);
     if (RD) RDST[1][ks] = w4_frag<TN>(rd_region, rd_off, 1, ks);
-    c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[1][ks], Y[0][ks], c10, 0, 0, 0);
-    if (IS) w4_piece(dma, is_region + (4 * w + ks) * 1024, is_sub, ks, dma.kpos + 2u * dma.kstep);   // k-tile t+2 (kpos is the tile being multiplied)
-    c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[1][ks], Y[1][ks], c11, 0, 0, 0);
+    c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Y[0][ks], X[1][ks], (FIRST && ks == 0) ? zero : c10, 0, 0, 0);
+    w4_piece(dma, is_region + (4 * w + ks) * 1024, is_sub, ks, so0);
+    c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Y[1][ks], X[1][ks], (FIRST && ks == 0) ? zero : c11, 0, 0, 0);
   }
   // the order above is the order wanted in the instruction stream: one LDS read (TN: one pair) or one DMA piece in the shadow of each MFMA, never a batch in
   // front of the phase (left alone, the scheduler hoists all 8 reads and 4 pieces above the first MFMA: ~100 idle matrix-pipe cycles per phase)
@@ -154,213 +192,348 @@ __device__ __forceinline__ void w4_phase(f32x16 (&c00), f32x16 (&c01), f32x16 (&
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     if (RD) __builtin_amdgcn_sched_group_barrier(0x100, TN ? 2 : 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    if (IS) { __builtin_amdgcn_sched_group_barrier(0x004, 3, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); }
+    __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
   }
 #endif
 }
 
 // ---- one k-tile -----------------------------------------------------------------------------------------------------------------------
-// CUR: buffer of this k-tile.  V2..V4 / VN: vmcnt that must hold before the barrier of phases 2..4 / of the NEXT k-tile's phase 1 (-1: no wait); each is waited
-// for at the END of the phase before, so it never sits between a phase's reads and its MFMAs.  ISSUE: refill this buffer with k-tile t+2.  NEXT: prefetch the
-// first fragments (A0, B0) of k-tile t+1 in phases 3 / 4.  B0 holds this tile's B0 fragments, B0N receives the next tile's.
+// CUR: buffer of this k-tile.  VM: vmcnt that must hold before the barrier of the next phase (-1: no wait needed, the first k-tile after a deep wait); it is
+// waited for at the END of a phase, so it never sits between a phase's reads and its MFMAs.  Every k-tile refills its own buffer with the stream's k-tile
+// t+2 (scalar offsets soa / sob: wherever the DMA cursor stands, possibly the next output tile or W4_OOB).  NEXT: phases 3 / 4 read the first fragments (A0, B0)
+// of k-tile t+1 (not in an output tile's last k-tile: the epilogue wants the registers, the next tile reads them afterwards).  B0 holds this tile's B0
+// fragments, B0N receives the next tile's.
 template <int V>
 __device__ __forceinline__ void w4_phase_end() {
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (V >= 0) W4_WAIT_VM(V);
   W4_WAIT_LGKM0();          // this phase's fragment reads have returned: the next phase may multiply them, and (after its barrier) anyone may overwrite their region
 }
-template <bool TN, int CUR, int V2, int V3, int V4, int VN, bool ISSUE, bool NEXT>
-__device__ __forceinline__ void w4_ktile(unsigned char* smem, const W4Frag<TN>& F, W4Dma& da, W4Dma& db, int w, f32x16 (&acc)[4][4],
+template <bool TN, int CUR, int VM, bool FIRST, bool NEXT>
+__device__ __forceinline__ void w4_ktile(unsigned char* smem, const W4Frag<TN>& F, const W4Dma& da, const W4Dma& db, unsigned soa, unsigned sob, int w, f32x16 (&acc)[4][4],
                                          s16x8 (&A0)[2][4], s16x8 (&A1)[2][4], s16x8 (&B0)[2][4], s16x8 (&B1)[2][4], s16x8 (&B0N)[2][4]) {
   unsigned char* const buf = smem + CUR * W4_TILEBUF;
   unsigned char* const nbuf = smem + (CUR ^ 1) * W4_TILEBUF;
-  // P1: A0 x B0; read B1(t); refill RA0 (read in P3 of the previous tile)
+  // P1: A0 x B0; read B1(t); refill RA0 (read in P3 of the previous k-tile)
   W4_BAR();
-  w4_phase<TN, true, ISSUE>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], A0, B0, buf + W4_RB1, F.b, B1, da, buf + W4_RA0, 0, w);
-  w4_phase_end<V2>();
-  // P2: A0 x B1; read A1(t); refill RB0 (read in P4 of the previous tile)
+  w4_phase<TN, true, FIRST>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], A0, B0, buf + W4_RB1, F.b, B1, da, buf + W4_RA0, 0, soa, w);
+  w4_phase_end<VM>();
+  // P2: A0 x B1; read A1(t); refill RB0 (read in P4 of the previous k-tile)
   W4_BAR();
-  w4_phase<TN, true, ISSUE>(acc[0][2], acc[0][3], acc[1][2], acc[1][3], A0, B1, buf + W4_RA1, F.a, A1, db, buf + W4_RB0, 0, w);
-  w4_phase_end<V3>();
+  w4_phase<TN, true, FIRST>(acc[0][2], acc[0][3], acc[1][2], acc[1][3], A0, B1, buf + W4_RA1, F.a, A1, db, buf + W4_RB0, 0, sob, w);
+  w4_phase_end<VM>();
   // P3: A1 x B1; read A0(t+1); refill RB1 (read in P1)
   W4_BAR();
-  w4_phase<TN, NEXT, ISSUE>(acc[2][2], acc[2][3], acc[3][2], acc[3][3], A1, B1, nbuf + W4_RA0, F.a, A0, db, buf + W4_RB1, 1, w);
-  w4_phase_end<V4>();
+  w4_phase<TN, NEXT, FIRST>(acc[2][2], acc[2][3], acc[3][2], acc[3][3], A1, B1, nbuf + W4_RA0, F.a, A0, db, buf + W4_RB1, 1, sob, w);
+  w4_phase_end<VM>();
   // P4: A1 x B0; read B0(t+1); refill RA1 (read in P2)
   W4_BAR();
-  w4_phase<TN, NEXT, ISSUE>(acc[2][0], acc[2][1], acc[3][0], acc[3][1], A1, B0, nbuf + W4_RB0, F.b, B0N, da, buf + W4_RA1, 1, w);
-  w4_phase_end<VN>();
-  da.kpos += da.kstep; db.kpos += db.kstep;
+  w4_phase<TN, NEXT, FIRST>(acc[2][0], acc[2][1], acc[3][0], acc[3][1], A1, B0, nbuf + W4_RB0, F.b, B0N, da, buf + W4_RA1, 1, soa, w);
+  w4_phase_end<VM>();
 }
 
-template <bool TN, int E>
+// ---- epilogue -------------------------------------------------------------------------------------------------------------------------
+// Accumulator layout: acc[rt][ct][4 g + e] = C[m0 + wr*128 + rt*32 + l31][n0 + wc*128 + ct*32 + 8 g + 4 hi + e].
+// Fast forms (bf16 output: plain, bias, bias + GELU with the saved pre-activation, dGELU, either with the column sums of the stored output): everything is computed
+// in that layout and only bf16 rows go through the wave's 8 KB staging ([32 rows][128 bf16], 16-byte chunk c of row r at position c ^ (r & 15): the 8-byte
+// writes of 16 rows and the 16-byte reads of a row pair both hit every bank once); a row leaves as one 256-byte segment.
+// Everything else (fp32 outputs, residuals, split-K slabs, margin heads, run-time flags): 32 x 64 fp32 slabs through the same staging and vdk_gemm_epilogue.h.
+template <int E>
+__device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* stage, f32x16 (&acc)[4][4], int lane, int wr, int wc, int m0, int n0, int z, int tm) {
+  constexpr bool FAST = (E == 0 || E == E_BIAS || E == (E_BIAS | E_GELU) || E == E_DGELU || E == (E_DGELU | E_OCS) || E == E_OCS);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int mrow0 = m0 + wr * 128, ncol0 = n0 + wc * 128;
+  if constexpr (FAST) {
+    const int rrow = lane >> 4, rc = lane & 15;                 // row-pass coordinates: rows pass * 4 + rrow, 16-byte chunk rc (8 columns)
+    const int ncol = ncol0 + rc * 8;
+    const bool nok = ncol < p.N;
+    float bias[4][4][4];
+    if (E & E_BIAS) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = ncol0 + ct * 32 + 8 * g + 4 * hi;
+          f32x4 b = {0.f, 0.f, 0.f, 0.f};
+          if (n < p.N) b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bias[ct][g][e] = b[e];
+        }
+    }
+    float ocs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ocs[e] = 0.f;
+    unsigned char* const wbase = stage + l31 * 256 + hi * 8;    // + ((ct * 4 + g) ^ (l31 & 15)) * 16
+    // Rows leave (and the dGELU operand arrives) through buffer descriptors: the lane part of the offset is loop-invariant, the row block is a scalar, rows
+    // beyond M fall outside num_records and columns beyond N get an out-of-range lane offset, so there is neither 64-bit address arithmetic nor a branch.
+    const unsigned lane_out = nok ? (unsigned)rrow * (unsigned)p.ldc * 2u + (unsigned)ncol * 2u : W4_OOB;
+    const unsigned lane_aux = nok ? (unsigned)rrow * (unsigned)p.ldaux * 2u + (unsigned)ncol * 2u : W4_OOB;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((unsigned)p.M * (unsigned)p.ldc * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_aux = __builtin_amdgcn_make_buffer_rsrc((E & (E_GELU | E_DGELU)) ? (void*)p.aux : p.C, 0,
+                                                                            (int)((unsigned)p.M * (unsigned)((E & (E_GELU | E_DGELU)) ? p.ldaux : p.ldc) * 2u), 0x00020000);
+    // rows of the staged 32 x 128 block -> the tensor behind rs (row pitch ldbytes); OCS: what is stored also goes into the column sums
+    auto rows_out = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned lane_off, unsigned ldbytes, int rt, bool with_ocs) {
+      VDK_WAVE_LDS_SYNC();
+      const unsigned srow = (unsigned)(mrow0 + rt * 32) * ldbytes;
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {
+        const int row = ps * 4 + rrow;
+        const u32x4 d = *(const u32x4*)(stage + row * 256 + ((rc ^ (row & 15)) << 4));
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs, lane_off, srow + (unsigned)(ps * 4) * ldbytes, 0);
+        if (with_ocs) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { ocs[2 * e] += bf_lo(d[e]); ocs[2 * e + 1] += bf_hi(d[e]); }
+        }
+      }
+      VDK_WAVE_LDS_SYNC();
+    };
+    W4_WAIT_VM(4);                                              // deep wait: every DMA group but the newest has landed (the next tile's first k-tile then runs without waits)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+#ifndef VDK_EMU
+      __builtin_amdgcn_sched_barrier(0);                        // one 32-row block at a time: blocks interleaved by the scheduler keep several of them in registers
+#endif
+      u32x2 held[4][4];                                         // GELU: the activated values wait here (packed) while the pre-activation rows leave
+      if (E & E_DGELU) {
+        // the saved pre-activation u of these 32 rows: whole row segments -> staging -> this lane's layout
+        const unsigned srow = (unsigned)(mrow0 + rt * 32) * (unsigned)p.ldaux * 2u;
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+          const int row = ps * 4 + rrow;
+          const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs_aux, lane_aux, srow + (unsigned)(ps * 4) * (unsigned)p.ldaux * 2u, 0);   // (out of range: zeros)
+          *(u32x4*)(stage + row * 256 + ((rc ^ (row & 15)) << 4)) = d;
+        }
+        VDK_WAVE_LDS_SYNC();
+      }
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          unsigned char* const wp = wbase + (((ct * 4 + g) ^ (l31 & 15)) << 4);
+          float v[4];
+          if (E & E_DGELU) {
+            const u32x2 u = *(const u32x2*)wp;                  // (the same 8 bytes this lane overwrites below: u goes out, dL/du comes in)
+            v[0] = acc[rt][ct][4 * g + 0] * gelu_grad_f(bf_lo(u[0])); v[1] = acc[rt][ct][4 * g + 1] * gelu_grad_f(bf_hi(u[0]));
+            v[2] = acc[rt][ct][4 * g + 2] * gelu_grad_f(bf_lo(u[1])); v[3] = acc[rt][ct][4 * g + 3] * gelu_grad_f(bf_hi(u[1]));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[rt][ct][4 * g + e] + ((E & E_BIAS) ? bias[ct][g][e] : 0.f);
+          }
+          *(u32x2*)wp = (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+          if (E & E_GELU) held[ct][g] = (u32x2){pack_bf2(gelu_f(v[0]), gelu_f(v[1])), pack_bf2(gelu_f(v[2]), gelu_f(v[3]))};
+#ifndef VDK_EMU
+          if ((E & (E_GELU | E_DGELU)) && g == 3) __builtin_amdgcn_sched_barrier(0);   // 16 activations in flight are plenty; all 64 at once spill
+#endif
+        }
+      if (E & E_GELU) {
+        rows_out(rs_aux, lane_aux, (unsigned)p.ldaux * 2u, rt, false);   // the pre-activation, for the backward pass
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) *(u32x2*)(wbase + (((ct * 4 + g) ^ (l31 & 15)) << 4)) = held[ct][g];
+      }
+      rows_out(rs_out, lane_out, (unsigned)p.ldc * 2u, rt, (E & E_OCS) != 0);
+    }
+    if (E & E_OCS) {   // lanes with the same chunk rc hold the same 8 columns: sum over the 4 row slots, one partial row per (row tile, wave row)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float s = ocs[e];
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        ocs[e] = s;
+      }
+      if (lane < 16 && nok) {
+        float* dst = p.ocs_part + ((long)tm * 2 + wr) * p.N + ncol;
+        *(f32x4*)dst = (f32x4){ocs[0], ocs[1], ocs[2], ocs[3]};
+        *(f32x4*)(dst + 4) = (f32x4){ocs[4], ocs[5], ocs[6], ocs[7]};
+      }
+    }
+  } else {
+    float* const slab = (float*)stage;
+    float q8_unused = 0.f;
+    W4_WAIT_VM(4);
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp) {
+      const int ncol = ncol0 + cp * 64 + (lane & 7) * 8;
+      float bias8[8], ocs8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { bias8[e] = 0.f; ocs8[e] = 0.f; }
+      if ((E != E_GENERIC) && (E & E_BIAS) && ncol < p.N) {
+        f32x4 b0v = *(const f32x4*)(p.bias + ncol), b1v = *(const f32x4*)(p.bias + ncol + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bias8[e] = b0v[e]; bias8[4 + e] = b1v[e]; }
+      }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+        for (int ctl = 0; ctl < 2; ++ctl)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x16& a = acc[rt][cp * 2 + ctl];
+            const f32x4 x = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+            *(f32x4*)(slab + l31 * 64 + (((ctl * 8 + 2 * g + hi) ^ (l31 & 15)) << 2)) = x;
+          }
+        VDK_WAVE_LDS_SYNC();
+        const long mbase = (long)mrow0 + rt * 32;
+        if (E != E_GENERIC) {
+          h_epilogue_half<E, 4, true>(p, slab, lane, mbase, ncol, z, bias8, ocs8, q8_unused);
+        } else {
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + (lane >> 3), ch = (lane & 7) * 2, sw = row & 15;
+            const long mi = mbase + row;
+            if (mi < p.M && ncol < p.N) {
+              float v[8];
+              f32x4 x0 = *(const f32x4*)(slab + row * 64 + ((ch ^ sw) << 2)), x1 = *(const f32x4*)(slab + row * 64 + (((ch + 1) ^ sw) << 2));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
+              g_epilogue_store8(p, mi, ncol, v, z);
+            }
+          }
+        }
+        VDK_WAVE_LDS_SYNC();
+      }
+    }
+  }
+}
+
+// ---- the kernel -----------------------------------------------------------------------------------------------------------------------
+// PERSIST: gridDim.x workgroups (a multiple of 8, at most one per CU) walk the output tiles; workgroup b serves the tiles start(x) + s, + s + G/8, ... of its
+// XCD's contiguous share (x = b & 7, s = b >> 3): at any time an XCD's workgroups multiply G/8 consecutive tiles, which share A row panels / the weight matrix
+// in that XCD's L2.  Otherwise: one tile per workgroup (blockIdx.x, same XCD raster) and blockIdx.y = split-K slice.
+// Every k-range holds an even number (>= 2) of whole k-tiles (launcher).
+template <bool TN, int E, bool PERSIST>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[W4_SMEM];   // 128 KB operand ring + 32 KB epilogue staging: the CU's whole LDS, one object
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = w >> 1, wc = w & 1, hi = lane >> 5, l31 = lane & 31;
+  const int wr = w >> 1, wc = w & 1;
   const int ntn = (p.N + 255) / 256, ntm = (p.M + 255) / 256;
   const int nwg = ntn * ntm;
-  const int z = blockIdx.y;
-  int tile;
-  {
-    const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int tn = tile % ntn, tm = tile / ntn;
-  const int m0 = tm * 256, n0 = tn * 256;
+  const int z = PERSIST ? 0 : (int)blockIdx.y;
   const int kbeg = z * p.k_per_split;
   int kend = kbeg + p.k_per_split; if (kend > p.K) kend = p.K;
-  const int nk = (kend - kbeg) / 64;                      // launcher guarantees whole k-tiles
+  const int nk = (kend - kbeg) / 64;
+  // this workgroup's tiles: start + slot, + slot + stride, ... while < start + cnt
+  int t_start, t_cnt, t_stride, t_idx;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    t_start = xcd * q + (xcd < r ? xcd : r);
+    t_cnt = q + (xcd < r ? 1 : 0);
+    t_idx = bid >> 3;
+    t_stride = PERSIST ? (int)(gridDim.x >> 3) : (1 << 30);
+  }
+  if (t_idx >= t_cnt || nk < 2) return;                   // (uniform: the whole workgroup leaves before any barrier)
 
   W4Dma da, db;
-  w4_dma_init<TN>(da, p.A, p.lda, m0, p.M, p.K, kbeg, w, lane);
-  w4_dma_init<TN>(db, p.B, p.ldb, n0, p.N, p.K, kbeg, w, lane);
+  w4_dma_init<TN>(da, p.A, p.lda, p.M, p.K, kbeg, w, lane);
+  w4_dma_init<TN>(db, p.B, p.ldb, p.N, p.K, kbeg, w, lane);
   W4Frag<TN> F;
   w4_frag_init<TN>(F, wr, wc, lane);
+
+  // DMA cursor: the next k-tile of the stream to be issued (two k-tiles ahead of the MFMAs)
+  int c_idx = t_idx, c_left = nk;
+  unsigned c_ta, c_tb, c_ka = da.kbeg, c_kb = db.kbeg;
+  {
+    const int tile = t_start + c_idx;
+    c_ta = w4_tile_base<TN>(da, (tile / ntn) * 256); c_tb = w4_tile_base<TN>(db, (tile % ntn) * 256);
+  }
+#define W4_CURSOR_ADVANCE()                                                                                         \
+  do {                                                                                                              \
+    c_ka += da.kstep; c_kb += db.kstep;                                                                             \
+    if (--c_left == 0) {                                                                                            \
+      c_idx += t_stride; c_ka = da.kbeg; c_kb = db.kbeg;                                                            \
+      if (c_idx < t_cnt) {                                                                                          \
+        const int tile_ = t_start + c_idx;                                                                          \
+        c_ta = w4_tile_base<TN>(da, (tile_ / ntn) * 256); c_tb = w4_tile_base<TN>(db, (tile_ % ntn) * 256);         \
+        c_left = nk;                                                                                                \
+      } else { c_ta = W4_OOB; c_tb = W4_OOB; c_left = 0x7fffffff; }                                                 \
+    }                                                                                                               \
+  } while (0)
 
   f32x16 acc[4][4];
   s16x8 A0[2][4], A1[2][4], B1[2][4], BX[2][4], BY[2][4];
 
-  if (nk > 0) {
-    // ---- prologue: k-tiles 0 and 1 completely, in the steady state's issue order (RA0, RB0, RB1, RA1); k-tile nk-2 lives in buffer 0, nk-1 in buffer 1 ----
-    const int b0 = nk & 1;
-    {
-      unsigned char* const buf = smem + b0 * W4_TILEBUF;
-      w4_region(da, buf + W4_RA0, 0, w, da.kpos); w4_region(db, buf + W4_RB0, 0, w, db.kpos);
-      w4_region(db, buf + W4_RB1, 1, w, db.kpos); w4_region(da, buf + W4_RA1, 1, w, da.kpos);
-    }
-    if (nk > 1) {
-      unsigned char* const buf = smem + (b0 ^ 1) * W4_TILEBUF;
-      w4_region(da, buf + W4_RA0, 0, w, da.kpos + da.kstep); w4_region(db, buf + W4_RB0, 0, w, db.kpos + db.kstep);
-      w4_region(db, buf + W4_RB1, 1, w, db.kpos + db.kstep); w4_region(da, buf + W4_RA1, 1, w, da.kpos + da.kstep);
-    }
+  // ---- prologue: the stream's k-tiles 0 and 1 completely, in the steady state's issue order (RA0, RB0, RB1, RA1) --------------------------------------
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if (nk > 1) { W4_WAIT_VM(24); } else { W4_WAIT_VM(8); }
-    W4_BAR();
-    const int S = nk >= 2 ? nk - 2 : 0;                   // steady k-tiles (refill + next-tile prefetch)
-    const bool odd = S & 1;                               // the first k-tile then sits in buffer 1 and starts from the BY fragment set
-    {
-      const unsigned char* const buf = smem + b0 * W4_TILEBUF;
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) A0[rt][ks] = w4_frag<TN>(buf + W4_RA0, F.a, rt, ks);
-      if (b0) {
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) BY[rt][ks] = w4_frag<TN>(buf + W4_RB0, F.b, rt, ks);
-      } else {
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) BX[rt][ks] = w4_frag<TN>(buf + W4_RB0, F.b, rt, ks);
-      }
-    }
-    // (b0 == 1  <=>  nk odd  <=>  S odd for nk >= 2; for nk == 1 the only k-tile is the buffer-1 tail below, which reads BY)
-    __builtin_amdgcn_sched_barrier(0);
-    if (nk > 1) { W4_WAIT_VM(20); } else { W4_WAIT_VM(4); }   // RB1 of k-tile 0, read in its phase 1
-    W4_WAIT_LGKM0();
-    int done = 0;
-    if (odd) { w4_ktile<TN, 1, 20, 20, 20, 20, true, true>(smem, F, da, db, w, acc, A0, A1, BY, B1, BX); done = 1; }
-    for (; done < S; done += 2) {
-      w4_ktile<TN, 0, 20, 20, 20, 20, true, true>(smem, F, da, db, w, acc, A0, A1, BX, B1, BY);
-      w4_ktile<TN, 1, 20, 20, 20, 20, true, true>(smem, F, da, db, w, acc, A0, A1, BY, B1, BX);
-    }
-    if (nk > 1) w4_ktile<TN, 0, 16, 12, 8, 4, false, true>(smem, F, da, db, w, acc, A0, A1, BX, B1, BY);
-    w4_ktile<TN, 1, 0, -1, -1, -1, false, false>(smem, F, da, db, w, acc, A0, A1, BY, B1, BX);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int b = 0; b < 2; ++b) {
+    unsigned char* const buf = smem + b * W4_TILEBUF;
+    w4_region(da, buf + W4_RA0, 0, w, c_ta + c_ka); w4_region(db, buf + W4_RB0, 0, w, c_tb + c_kb);
+    w4_region(db, buf + W4_RB1, 1, w, c_tb + c_kb); w4_region(da, buf + W4_RA1, 1, w, c_ta + c_ka);
+    W4_CURSOR_ADVANCE();
   }
+  W4_WAIT_VM(4);                                          // deep wait: everything but the newest group
 
-  // ---- epilogue: wave-private 8 KB staging slab, 32 rows x 64 fp32 at a time -> 8-wide coalesced row chunks (vdk_gemm_epilogue.h) -----------------
-  float* const slab = (float*)(smem + W4_STAGE + w * 8192);
-  float q8_unused = 0.f;
+  for (;;) {
+    // ---- one output tile: nk k-tiles.  Its first fragments come from buffer 0 (landed: the deep wait above / in the previous epilogue, made workgroup-wide by the
+    // barrier); the first k-tile starts the accumulators from zero and needs no DMA waits; the last one leaves the fragment registers to the epilogue ----------
+    W4_BAR();
 #pragma unroll
-  for (int cp = 0; cp < 2; ++cp) {
-    const int ncol = n0 + wc * 128 + cp * 64 + (lane & 7) * 8;
-    float bias8[8], ocs8[8];
+    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { bias8[e] = 0.f; ocs8[e] = 0.f; }
-    if ((E != E_GENERIC) && (E & E_BIAS) && ncol < p.N) {
-      f32x4 b0v = *(const f32x4*)(p.bias + ncol), b1v = *(const f32x4*)(p.bias + ncol + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { bias8[e] = b0v[e]; bias8[4 + e] = b1v[e]; }
+      for (int ks = 0; ks < 4; ++ks) { A0[rt][ks] = w4_frag<TN>(smem + W4_RA0, F.a, rt, ks); BX[rt][ks] = w4_frag<TN>(smem + W4_RB0, F.b, rt, ks); }
+    __builtin_amdgcn_sched_barrier(0);
+    W4_WAIT_LGKM0();
+    w4_ktile<TN, 0, -1, true, true>(smem, F, da, db, c_ta + c_ka, c_tb + c_kb, w, acc, A0, A1, BX, B1, BY);
+    W4_CURSOR_ADVANCE();
+    for (int t = 2; t < nk; t += 2) {
+      w4_ktile<TN, 1, 20, false, true>(smem, F, da, db, c_ta + c_ka, c_tb + c_kb, w, acc, A0, A1, BY, B1, BX);
+      W4_CURSOR_ADVANCE();
+      w4_ktile<TN, 0, 20, false, true>(smem, F, da, db, c_ta + c_ka, c_tb + c_kb, w, acc, A0, A1, BX, B1, BY);
+      W4_CURSOR_ADVANCE();
     }
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          slab[((r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + ct * 32 + l31] = acc[rt][cp * 2 + ct][r];
-      __builtin_amdgcn_wave_barrier();
-      const long mbase = (long)m0 + wr * 128 + rt * 32;
-      if (E != E_GENERIC) {
-        h_epilogue_half<E, 4>(p, slab, lane, mbase, ncol, z, bias8, ocs8, q8_unused);
-      } else {
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-          const int row = pass * 8 + (lane >> 3), cc = (lane & 7) * 8;
-          const long mi = mbase + row;
-          if (mi < p.M && ncol < p.N) {
-            float v[8];
-            f32x4 x0 = *(const f32x4*)(slab + row * 64 + cc), x1 = *(const f32x4*)(slab + row * 64 + cc + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
-            g_epilogue_store8(p, mi, ncol, v, z);
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    if ((E != E_GENERIC) && (E & E_OCS)) {   // lanes with the same (lane & 7) hold the same 8 columns: sum over the 8 row slots, one partial row per (row tile, wave row)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float v = ocs8[e];
-        v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-        ocs8[e] = v;
-      }
-      if (lane < 8 && ncol < p.N) {
-        float* dst = p.ocs_part + ((long)tm * 2 + wr) * p.N + ncol;
-        *(f32x4*)dst = (f32x4){ocs8[0], ocs8[1], ocs8[2], ocs8[3]};
-        *(f32x4*)(dst + 4) = (f32x4){ocs8[4], ocs8[5], ocs8[6], ocs8[7]};
-      }
-    }
+    w4_ktile<TN, 1, 20, false, false>(smem, F, da, db, c_ta + c_ka, c_tb + c_kb, w, acc, A0, A1, BY, B1, BX);
+    W4_CURSOR_ADVANCE();
+    const int tile = t_start + t_idx;
+    const int tn = tile % ntn, tm = tile / ntn;
+    w4_epilogue<E>(p, smem + W4_STAGE + w * 8192, acc, lane, wr, wc, tm * 256, tn * 256, z, tm);
+    t_idx += t_stride;
+    if (t_idx >= t_cnt) break;
   }
+  W4_WAIT_VM(0);                                          // the cursor's last (out-of-range) pieces still write zeros into this workgroup's LDS
+#undef W4_CURSOR_ADVANCE
 }
 
 // ---- launcher (called by vdk_gemm_bf16_nt / vdk_margin_cos_pass in gemm.hip) ------------------------------------------------------------------------
-// Serves what the 8-wave 256x256 kernel serves except its a_colsum by-product and stream-K.  Operand byte sizes stay below 2 GB (32-bit buffer offsets).
+// Serves what the 8-wave 256x256 kernel serves except its a_colsum by-product, the token-row remap of the A operand and stream-K.  Operand byte sizes stay
+// below 2 GB (32-bit buffer offsets, W4_OOB beyond them); every split holds an even number of k-tiles.
 bool vdk_gemm_w4_serves(const GemmParams& p, bool trans) {
-  const double lim = 2147483648.0 - 4096.0;
-  if (p.colsum_part || p.sk_cnt || p.a_row_group > 0 || p.q8) return false;
+  const double lim = 2147483648.0 - 65536.0;
+  if (p.colsum_part || p.sk_cnt || p.a_row_group > 0) return false;
+  if ((p.K % 128) || (p.k_per_split % 128) || p.K < 128) return false;
+  if (((double)p.M + 256.0) * (double)p.ldc * 2.0 >= lim || (p.aux && ((double)p.M + 256.0) * (double)p.ldaux * 2.0 >= lim)) return false;   // bf16 rows leave through 32-bit buffer offsets
   if (!trans) return ((double)p.M + 256.0) * (double)p.lda * 2.0 < lim && ((double)p.N + 256.0) * (double)p.ldb * 2.0 < lim;
   return ((double)p.K + 64.0) * (double)p.lda * 2.0 < lim && ((double)p.K + 64.0) * (double)p.ldb * 2.0 < lim;
 }
 
-#define W4_LAUNCH(TNF, EE)                                                                                                          \
-  do {                                                                                                                              \
-    if (ev0) hipExtLaunchKernelGGL((gemm_w4_kernel<TNF, EE>), grid, dim3(256), 0, stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, p);  \
-    else hipLaunchKernelGGL((gemm_w4_kernel<TNF, EE>), grid, dim3(256), 0, stream, p);                                              \
-    return true;                                                                                                                    \
+static int w4_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    cus = n & ~7;
+  }
+  return cus;
+}
+
+#define W4_LAUNCH(TNF, EE)                                                                                                                    \
+  do {                                                                                                                                        \
+    if (persist) {                                                                                                                            \
+      if (ev0) hipExtLaunchKernelGGL((gemm_w4_kernel<TNF, EE, true>), pgrid, dim3(256), 0, stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, p);   \
+      else hipLaunchKernelGGL((gemm_w4_kernel<TNF, EE, true>), pgrid, dim3(256), 0, stream, p);                                               \
+    } else {                                                                                                                                  \
+      if (ev0) hipExtLaunchKernelGGL((gemm_w4_kernel<TNF, EE, false>), grid, dim3(256), 0, stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, p);   \
+      else hipLaunchKernelGGL((gemm_w4_kernel<TNF, EE, false>), grid, dim3(256), 0, stream, p);                                               \
+    }                                                                                                                                         \
+    return true;                                                                                                                              \
   } while (0)
 
 bool vdk_gemm_w4_launch(const GemmParams& p, bool trans, int E, unsigned tiles, unsigned splitk, void* stream_, void* ev0, void* ev1) {
   hipStream_t stream = (hipStream_t)stream_;
   const dim3 grid(tiles, splitk);
+  const unsigned G = (unsigned)w4_cus();
+  const bool persist = splitk == 1 && tiles > G;          // more tiles than CUs: walk them (with one tile per workgroup there is nothing to prefetch)
+  const dim3 pgrid(G, 1u);
   if (trans) {
     switch (E) {
       case E_SPLITK: W4_LAUNCH(true, E_SPLITK);

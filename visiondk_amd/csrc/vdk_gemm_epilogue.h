@@ -73,7 +73,8 @@ __device__ __forceinline__ void g_epilogue_store8(const GemmParams& p, long mi, 
 #define E_Q8 1024     /* by-product: fp8(clamp(stored bf16 value * q8_scale)) -> p.q8, max |value| -> p.q8_amax: bit-identical to vdk_quant_fp8 over the stored tensor */
 #define E_GENERIC 0x1000
 
-template <int E, int NPS = 8 /* row passes: the slab holds NPS * 8 rows x 64 fp32 */>
+// SWZ: the slab's 16-byte chunk c of row r lives at chunk position c ^ (r & 15) (bank-conflict-free for the row-per-lane writes of gemm_w4.hip)
+template <int E, int NPS = 8 /* row passes: the slab holds NPS * 8 rows x 64 fp32 */, bool SWZ = false>
 __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float* slab, int lane, long mbase /* first row of this slab */,
                                                 int n, int z, const float (&bias8)[8], float (&ocs)[8], float& q8am) {
   // this lane: rows mbase + pass*8 + (lane >> 3), pass = 0..NPS-1, columns n .. n+7
@@ -84,8 +85,8 @@ __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float
     for (int ps = 0; ps < NPS; ++ps) {
       const long mi = mbase + ps * 8 + rsub;
       const bool rok = mi < me.B;
-      const int row = ps * 8 + rsub;
-      f32x4 x0 = *(const f32x4*)(slab + row * 64 + cc), x1 = *(const f32x4*)(slab + row * 64 + cc + 4);
+      const int row = ps * 8 + rsub, sw = SWZ ? (row & 15) : 0;
+      f32x4 x0 = *(const f32x4*)(slab + row * 64 + (((cc >> 2) ^ sw) << 2)), x1 = *(const f32x4*)(slab + row * 64 + ((((cc >> 2) + 1) ^ sw) << 2));
       float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
       MarginP P = me.P;
       long yt = -1; RowCtx R; R.thr = 0.f; R.final_gt = 0.f; R.dfinal = 1.f;
@@ -142,9 +143,9 @@ __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float
 #pragma unroll
   for (int ps = 0; ps < NPS; ++ps) {
     if (!ok[ps]) continue;
-    const int row = ps * 8 + rsub;
+    const int row = ps * 8 + rsub, sw = SWZ ? (row & 15) : 0;
     float v[8];
-    f32x4 x0 = *(const f32x4*)(slab + row * 64 + cc), x1 = *(const f32x4*)(slab + row * 64 + cc + 4);
+    f32x4 x0 = *(const f32x4*)(slab + row * 64 + (((cc >> 2) ^ sw) << 2)), x1 = *(const f32x4*)(slab + row * 64 + ((((cc >> 2) + 1) ^ sw) << 2));
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
     if (E & E_SPLITK) {
