@@ -239,6 +239,11 @@ __device__ __forceinline__ void w4_ktile(unsigned char* smem, const W4Frag<TN>& 
 // in that layout and only bf16 rows go through the wave's 8 KB staging ([32 rows][128 bf16], 16-byte chunk c of row r at position c ^ (r & 15): the 8-byte
 // writes of 16 rows and the 16-byte reads of a row pair both hit every bank once); a row leaves as one 256-byte segment.
 // Everything else (fp32 outputs, residuals, split-K slabs, margin heads, run-time flags): 32 x 64 fp32 slabs through the same staging and vdk_gemm_epilogue.h.
+#ifdef VDK_EMU
+#define W4_EPI_SYNC() VDK_WAVE_LDS_SYNC()
+#else
+#define W4_EPI_SYNC() do { __builtin_amdgcn_s_waitcnt(0xC07F); VDK_WAVE_LDS_SYNC(); } while (0)   /* EXPERIMENT: drain the LDS queue at every staging hand-off */
+#endif
 template <int E>
 __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* stage, f32x16 (&acc)[4][4], int lane, int wr, int wc, int m0, int n0, int z, int tm) {
   constexpr bool FAST = (E == 0 || E == E_BIAS || E == (E_BIAS | E_GELU) || E == E_DGELU || E == (E_DGELU | E_OCS) || E == E_OCS);
@@ -274,19 +279,28 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
                                                                             (int)((unsigned)p.M * (unsigned)((E & (E_GELU | E_DGELU)) ? p.ldaux : p.ldc) * 2u), 0x00020000);
     // rows of the staged 32 x 128 block -> the tensor behind rs (row pitch ldbytes); OCS: what is stored also goes into the column sums
     auto rows_out = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned lane_off, unsigned ldbytes, int rt, bool with_ocs) {
-      VDK_WAVE_LDS_SYNC();
+      W4_EPI_SYNC();
       const unsigned srow = (unsigned)(mrow0 + rt * 32) * ldbytes;
+      u32x4 d[8];
 #pragma unroll
       for (int ps = 0; ps < 8; ++ps) {
         const int row = ps * 4 + rrow;
-        const u32x4 d = *(const u32x4*)(stage + row * 256 + ((rc ^ (row & 15)) << 4));
-        __builtin_amdgcn_raw_buffer_store_b128(d, rs, lane_off, srow + (unsigned)(ps * 4) * ldbytes, 0);
-        if (with_ocs) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { ocs[2 * e] += bf_lo(d[e]); ocs[2 * e + 1] += bf_hi(d[e]); }
-        }
+        d[ps] = *(const u32x4*)(stage + row * 256 + ((rc ^ (row & 15)) << 4));
       }
-      VDK_WAVE_LDS_SYNC();
+      if (with_ocs) {
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { ocs[2 * e] += bf_lo(d[ps][e]); ocs[2 * e + 1] += bf_hi(d[ps][e]); }
+      }
+      // Everything that reads the row registers comes BEFORE the stores, and the row block goes into the VECTOR offset.  Measured on the MI355X with
+      // buffer_store_dwordx4 v[a:a+3], v, s[..], s offen followed within four instructions by VALU writes of v[a:a+3] (the column-sum arithmetic): dword 1 of
+      // lanes 12-15 / 28-31 / 44-47 / 60-63 reached memory already overwritten.  The compiler pads the wide-store data hazard only for the form without a
+      // scalar-offset register.
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps)
+        __builtin_amdgcn_raw_buffer_store_b128(d[ps], rs, lane_off + (srow + (unsigned)(ps * 4) * ldbytes), 0, 0);
+      W4_EPI_SYNC();
     };
     W4_WAIT_VM(4);                                              // deep wait: every DMA group but the newest has landed (the next tile's first k-tile then runs without waits)
 #pragma unroll
@@ -304,7 +318,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
           const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs_aux, lane_aux, srow + (unsigned)(ps * 4) * (unsigned)p.ldaux * 2u, 0);   // (out of range: zeros)
           *(u32x4*)(stage + row * 256 + ((rc ^ (row & 15)) << 4)) = d;
         }
-        VDK_WAVE_LDS_SYNC();
+        W4_EPI_SYNC();
       }
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)
@@ -373,7 +387,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
             const f32x4 x = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
             *(f32x4*)(slab + l31 * 64 + (((ctl * 8 + 2 * g + hi) ^ (l31 & 15)) << 2)) = x;
           }
-        VDK_WAVE_LDS_SYNC();
+        W4_EPI_SYNC();
         const long mbase = (long)mrow0 + rt * 32;
         if (E != E_GENERIC) {
           h_epilogue_half<E, 4, true>(p, slab, lane, mbase, ncol, z, bias8, ocs8, q8_unused);
@@ -391,7 +405,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
             }
           }
         }
-        VDK_WAVE_LDS_SYNC();
+        W4_EPI_SYNC();
       }
     }
   }
@@ -484,6 +498,14 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
     }
     w4_ktile<TN, 1, 20, false, false>(smem, F, da, db, c_ta + c_ka, c_tb + c_kb, w, acc, A0, A1, BY, B1, BX);
     W4_CURSOR_ADVANCE();
+    // The accumulators become opaque here: without it the compiler reads (and shuffles) them from inside the last MFMA phase, a few wait states behind the MFMA
+    // that writes them, and on the MI355X some (lane, register) pairs then carry whatever the register held before (measured: the columns 4 g + 2, 4 g + 3 of
+    // one 32-column block, lanes with bit 2 set).  The s_nop covers the last MFMA's passes.
+#ifndef VDK_EMU
+    asm volatile("s_nop 15\n\ts_nop 15"
+                 : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[1][3]),
+                   "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]), "+a"(acc[3][3]));
+#endif
     const int tile = t_start + t_idx;
     const int tn = tile % ntn, tm = tile / ntn;
     w4_epilogue<E>(p, smem + W4_STAGE + w * 8192, acc, lane, wr, wc, tm * 256, tn * 256, z, tm);
