@@ -150,8 +150,9 @@ int vdk_gemm_c_colsum_rows(int32_t M, int32_t N, int32_t K);   /* rows of VdkGem
 int vdk_gemm_a_colsum_rows(int32_t M, int32_t N, int32_t K);   /* rows of VdkGemmDesc.a_colsum, 0 = by-product not available for this problem */
 int vdk_gemm_force_kernel(int32_t which);
 /* tests / tuning: which structure served the calling thread's last vdk_gemm_bf16_nt / vdk_margin_cos_pass: 1 = 128x128 register-staged, 2 = 256x256 eight waves,
- * 3 = its stream-K form, 5 = 256x256 four waves (one per SIMD, gemm_w4.hip; the default for big problems; which = 5 forces it wherever it can serve,
- * environment VDK_GEMM_W4=0 disables it) */
+ * 3 = its stream-K form, 5 = 256x256 four waves (one per SIMD, persistent; gemm_w4.hip; the default for big problems; which = 5 forces it wherever it can
+ * serve, environment VDK_GEMM_W4=0 disables it), 6 = 256x128 four waves with two workgroups per CU (gemm_w4h_kernel: the default for the long epilogues --
+ * GELU, dGELU, fp32 residual; which = 6 forces it; environment VDK_GEMM_W4H = bit mask 1 GELU | 2 dGELU | 4 residual | 8 other NT | 16 TN) */
 int vdk_gemm_last_kernel(void);
 /* profiling aid: when non-NULL, every 256x256 workgroup writes 4 shader-cycle stamps (start, operands landed, main loop done,
  * stores issued) to buf[4 * workgroup]; NULL (default) disables it */

@@ -87,11 +87,11 @@ def test_transpose_fused_colsum(be, dev):
     assert _rel(part.sum(0), x.float().sum(0)) < 1e-6
 
 
-@pytest.mark.parametrize("kern", [2, 5])
+@pytest.mark.parametrize("kern", [2, 5, 6])
 @pytest.mark.parametrize("M,N,K,splitk", [(256, 256, 64, 1), (300, 264, 192, 1), (512, 256, 256, 1), (130, 520, 128, 1), (256, 256, 512, 2), (520, 128, 192, 1), (264, 256, 384, 1),
                                           (776, 520, 256, 1), (264, 256, 768, 3)])
 def test_gemm256_lds_dma_kernel(be, dev, M, N, K, splitk, kern):
-    """the 256x256 LDS-DMA kernels (2: eight waves, 5: four waves / one per SIMD), forced, vs torch fp32 on the same bf16 operands (incl. ragged M/N, 1..5 k-tiles and split-K)"""
+    """the 256x256 LDS-DMA kernels (2: eight waves, 5: four waves / one per SIMD, 6: four waves on 256x128 tiles, two workgroups per CU), forced, vs torch fp32 on the same bf16 operands (incl. ragged M/N, 1..5 k-tiles and split-K)"""
     torch.manual_seed(5)
     a = torch.randn(M, K).bfloat16().to(dev); b = torch.randn(N, K).bfloat16().to(dev)
     b[:, 3] += 2.0
@@ -101,7 +101,7 @@ def test_gemm256_lds_dma_kernel(be, dev, M, N, K, splitk, kern):
     try:
         if splitk == 1:
             out = ops.gemm_nt(a, b, out_dtype=torch.float32, bias=bias, residual=res, backend=be)
-            assert be.lib.vdk_gemm_last_kernel() == (kern if K % 128 == 0 else 2)   # the four-wave kernel multiplies k-tiles in pairs
+            assert be.lib.vdk_gemm_last_kernel() == (2 if kern == 5 and K % 128 else kern)   # the persistent four-wave kernel multiplies k-tiles in pairs
             assert _rel(out, ref + bias + res) < 1e-5
             outb = ops.gemm_nt(a, b, out_dtype=torch.bfloat16, act=ops.ACT_GELU, backend=be)
             assert _rel(outb.float(), torch.nn.functional.gelu(ref).bfloat16().float()) < 4e-3
@@ -112,7 +112,7 @@ def test_gemm256_lds_dma_kernel(be, dev, M, N, K, splitk, kern):
         be.lib.vdk_gemm_force_kernel(0)
 
 
-@pytest.mark.parametrize("kern", [2, 5])
+@pytest.mark.parametrize("kern", [2, 5, 6])
 @pytest.mark.parametrize("K,M,N,splitk,rg", [(64, 256, 256, 1, 0), (192, 264, 136, 1, 0), (256, 72, 520, 2, 0), (128, 128, 192, 1, 16), (384, 520, 264, 1, 0), (512, 264, 136, 2, 0)])
 def test_gemm_tn_from_kmajor_operands(be, dev, K, M, N, splitk, rg, kern):
     """wgrad form C = A^T B with A [K, M], B [K, N] read as they lie (ds_read_b64_tr_b16 fragments), incl. the token-row remap"""
@@ -129,7 +129,7 @@ def test_gemm_tn_from_kmajor_operands(be, dev, K, M, N, splitk, rg, kern):
     be.lib.vdk_gemm_force_kernel(kern)   # (the token-row remap is served by the eight-wave kernel either way)
     try:
         out = ops.gemm_nt(a_full, b, out_dtype=torch.float32, splitk=splitk, trans=True, a_row_group=rg, a_rows=K, backend=be)
-        assert be.lib.vdk_gemm_last_kernel() == (2 if rg or K % 128 else kern)
+        assert be.lib.vdk_gemm_last_kernel() == (2 if rg or (kern == 5 and K % 128) else kern)
     finally:
         be.lib.vdk_gemm_force_kernel(0)
     assert out.shape == (M, N)
@@ -213,7 +213,7 @@ def test_gemm256_stream_k(be, dev, M, N, K, grid):
         be.lib.vdk_gemm_force_kernel(0); be.lib.vdk_gemm_streamk_grid(0)
 
 
-@pytest.mark.parametrize("kern", [2, 5])
+@pytest.mark.parametrize("kern", [2, 5, 6])
 @pytest.mark.parametrize("M", [512, 300])
 def test_gemm256_c_colsum_byproduct(be, dev, M, kern):
     """bias gradient fused into the PRODUCER of dY: the 256x256 NT kernel's plain / dGELU bf16 epilogues also emit column sums of what they store"""
@@ -234,8 +234,9 @@ def test_gemm256_c_colsum_byproduct(be, dev, M, kern):
         be.lib.vdk_gemm_force_kernel(0)
 
 
+@pytest.mark.parametrize("kern", [5, 6])
 @pytest.mark.parametrize("M,N,K", [(1300, 776, 256), (2050, 520, 128)])
-def test_gemm_w4_persistent_walk(be, dev, M, N, K):
+def test_gemm_w4_persistent_walk(be, dev, M, N, K, kern):
     """more output tiles than CUs (the emulated device has 16): the four-wave kernel walks its tiles with the DMA cursor running into the next tile;
     every fused epilogue form against torch fp32 on the same bf16 operands, ragged M / N"""
     torch.manual_seed(11)
@@ -243,10 +244,10 @@ def test_gemm_w4_persistent_walk(be, dev, M, N, K):
     b[:, 5] += 1.0
     bias = torch.randn(N).to(dev); res = torch.randn(M, N).to(dev); u = torch.randn(M, N).bfloat16().to(dev)
     ref = a.float() @ b.float().T
-    be.lib.vdk_gemm_force_kernel(5)
+    be.lib.vdk_gemm_force_kernel(kern)
     try:
         out = ops.gemm_nt(a, b, bias=bias, backend=be)                                                    # bias -> bf16 (row-staged form)
-        assert be.lib.vdk_gemm_last_kernel() == 5
+        assert be.lib.vdk_gemm_last_kernel() == kern
         assert _rel(out.float(), (ref + bias).bfloat16().float()) < 3e-3
         out = ops.gemm_nt(a, b, backend=be)                                                               # plain bf16
         assert _rel(out.float(), ref.bfloat16().float()) < 3e-3
@@ -265,6 +266,6 @@ def test_gemm_w4_persistent_walk(be, dev, M, N, K):
         assert _rel(out, ref + bias + res) < 1e-5
         out = ops.gemm_nt(a, b, out_dtype=torch.float32, alpha=0.5, backend=be)                            # run-time-flag form
         assert _rel(out, 0.5 * ref) < 1e-5
-        assert be.lib.vdk_gemm_last_kernel() == 5
+        assert be.lib.vdk_gemm_last_kernel() == kern
     finally:
         be.lib.vdk_gemm_force_kernel(0)

@@ -70,34 +70,39 @@ def main():
 
         run(2); assert be.lib.vdk_gemm_last_kernel() == 2; r2 = o.clone()
         o.fill_(float("nan"))
+        run(6); assert be.lib.vdk_gemm_last_kernel() == 6; r6 = o.clone()
+        o.fill_(float("nan"))
         run(5); assert be.lib.vdk_gemm_last_kernel() == 5; r5 = o.clone()
         torch.cuda.synchronize()
         maxdiff = (r2.float() - r5.float()).abs().max().item()
-        nbad = int((r2 != r5).sum().item())
+        nbad = int((r2 != r5).sum().item()) + int((r2 != r6).sum().item())
         # repeat screen: the four-wave kernel against its own first result
         unstable = 0
-        for _ in range(20):
+        for _ in range(10):
             run(5)
             unstable += int((o != r5).sum().item() > 0)
+            run(6)
+            unstable += int((o != r6).sum().item() > 0)
         ref_err = None
         if M * N <= 4096 * 4096 and ep in ("plain", "tn"):
             ref = (a.float().T @ b.float()) if trans else (a.float() @ b.float().T)
             ref_err = ((r5.float() - ref).norm() / ref.norm()).item()
-        t = {2: [], 5: []}
+        t = {2: [], 5: [], 6: []}
         iters = 10
-        for kern in (2, 5):
+        for kern in (2, 5, 6):
             timed(lambda: run(kern), 3)
         for _ in range(rounds):
-            for kern in (2, 5):
+            for kern in (2, 5, 6):
                 t[kern].append(timed(lambda: run(kern), iters))
         fl = 2.0 * M * N * K
         rec = {"name": name, "M": M, "N": N, "K": K, "epilogue": ep, "maxdiff_w8_w4": maxdiff, "n_differ": nbad, "unstable_repeats": unstable, "rel_err_vs_torch": ref_err}
-        for kern, key in ((2, "w8"), (5, "w4")):
+        for kern, key in ((2, "w8"), (5, "w4"), (6, "w4h")):
             ts = sorted(t[kern])
             rec[key + "_us_median"] = ts[len(ts) // 2] * 1e6
             rec[key + "_us_min"] = ts[0] * 1e6
             rec[key + "_tflops_median"] = fl / ts[len(ts) // 2] / 1e12
         rec["speedup"] = rec["w8_us_median"] / rec["w4_us_median"]
+        rec["speedup_h"] = rec["w8_us_median"] / rec["w4h_us_median"]
         res["shapes"].append(rec)
         print(json.dumps(rec), flush=True)
     be.lib.vdk_gemm_force_kernel(0)

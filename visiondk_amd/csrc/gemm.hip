@@ -683,9 +683,25 @@ static int g_sk_grid = 0;        // stream-K workgroups; 0 = one per CU of the c
 static thread_local int g_last_kernel = 0;
 // which 256x256 structure serves the big problems: the 4-wave kernel of gemm_w4.hip (default) or the 8-wave kernel above (VDK_GEMM_W4=0, vdk_gemm_force_kernel(2 / 3);
 // vdk_gemm_force_kernel(5) = the 4-wave kernel whenever it can serve)
-static bool w4_enabled() {
+static bool w4_enabled_env() {
   static const bool on = !(getenv("VDK_GEMM_W4") && atoi(getenv("VDK_GEMM_W4")) == 0);
-  return (on || g_force_kernel == 5) && g_force_kernel != 2 && g_force_kernel != 3;
+  return on;
+}
+// ... and which epilogue forms go to the 256x128 / two-workgroups-per-CU form instead (gemm_w4h_kernel): the ones whose epilogue is long (GELU / dGELU arithmetic,
+// fp32 residual traffic) -- a second resident workgroup multiplies meanwhile.  VDK_GEMM_W4H: bit mask over {1: GELU, 2: dGELU, 4: residual, 8: everything else NT, 16: TN}.
+static bool w4h_wanted(int E, bool trans) {
+  static const int mask = getenv("VDK_GEMM_W4H") ? atoi(getenv("VDK_GEMM_W4H")) : (1 | 2 | 4);
+  if (g_force_kernel == 6) return true;
+  if (g_force_kernel == 2 || g_force_kernel == 3 || g_force_kernel == 5 || g_force_kernel == 6 || !w4_enabled_env()) return false;
+  if (trans) return (mask & 16) != 0;
+  if (E == E_GENERIC) return false;
+  if (E & E_GELU) return (mask & 1) != 0;
+  if (E & E_DGELU) return (mask & 2) != 0;
+  if (E & E_RES) return (mask & 4) != 0;
+  return (mask & 8) != 0;
+}
+static bool w4_enabled() {
+  return (w4_enabled_env() || g_force_kernel == 5) && g_force_kernel != 2 && g_force_kernel != 3 && g_force_kernel != 6;
 }
 #define SK_CNT_BYTES 65536       // 16384 tile counters in front of the slabs
 static int sk_grid() {
@@ -705,14 +721,14 @@ extern "C" {
 /* rows of the a_colsum by-product ([rows][K] f32) if the NT problem (M, N, K) is served by the 256x256 kernel and M % 256 == 0, else 0 */
 int vdk_gemm_a_colsum_rows(int32_t M, int32_t N, int32_t K) {
   const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  const bool big = g_force_kernel == 2 || g_force_kernel == 3 || g_force_kernel == 5 || ((g_force_kernel == 0 || g_force_kernel == 4) && (K % 64 == 0) && tiles256 >= 128 && M >= 256 && N >= 256);
+  const bool big = g_force_kernel == 2 || g_force_kernel == 3 || g_force_kernel == 5 || g_force_kernel == 6 || ((g_force_kernel == 0 || g_force_kernel == 4) && (K % 64 == 0) && tiles256 >= 128 && M >= 256 && N >= 256);
   return (big && (K % 64 == 0) && (M % 256 == 0)) ? (M / 256) : 0;
 }
 
 /* rows of the c_colsum by-product ([rows][N] f32: column sums of the stored bf16 output per (row tile, wave row)) if the 256x256 NT kernel serves (M, N, K), else 0 */
 int vdk_gemm_c_colsum_rows(int32_t M, int32_t N, int32_t K) {
   const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  const bool big = g_force_kernel == 2 || g_force_kernel == 3 || g_force_kernel == 5 || ((g_force_kernel == 0 || g_force_kernel == 4) && (K % 64 == 0) && tiles256 >= 128 && M >= 256 && N >= 256);
+  const bool big = g_force_kernel == 2 || g_force_kernel == 3 || g_force_kernel == 5 || g_force_kernel == 6 || ((g_force_kernel == 0 || g_force_kernel == 4) && (K % 64 == 0) && tiles256 >= 128 && M >= 256 && N >= 256);
   return (big && (K % 64 == 0)) ? 2 * ((M + 255) / 256) : 0;
 }
 
@@ -828,7 +844,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   const bool prof = g_prof_on && g_prof_used + 2 <= g_prof_ev.size();
   // big problems go to the 256x256 LDS-DMA kernel (needs whole 64-wide k-tiles per split and >= 1 full wave of tiles)
   const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * splitk;
-  const bool big = !d->conv && (g_force_kernel == 2 || g_force_kernel == 3 || g_force_kernel == 5 || ((g_force_kernel == 0 || g_force_kernel == 4) && (d->K % 64 == 0) && (kps % 64 == 0) && tiles256 >= 128 && d->M >= 256 && d->N >= 256));
+  const bool big = !d->conv && (g_force_kernel == 2 || g_force_kernel == 3 || g_force_kernel == 5 || g_force_kernel == 6 || ((g_force_kernel == 0 || g_force_kernel == 4) && (d->K % 64 == 0) && (kps % 64 == 0) && tiles256 >= 128 && d->M >= 256 && d->N >= 256));
   // compile-time epilogue variant (the common ViT forms); anything else takes the run-time-flag path
   int E = E_GENERIC;
   {
@@ -865,6 +881,9 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   } while (0)
 #define LAUNCH256X(TNF, EE, CSF)                                                                                         \
   do {                                                                                                                   \
+    if (!sk && !(CSF) && w4h_wanted(EE, TNF) && vdk_gemm_w4h_serves(p, TNF) &&                                           \
+        vdk_gemm_w4h_launch(p, TNF, EE, grid256.y, stream, prof ? (void*)g_prof_ev[g_prof_used] : nullptr,               \
+                            prof ? (void*)g_prof_ev[g_prof_used + 1] : nullptr)) { g_last_kernel = 6; break; }           \
     if (!sk && !(CSF) && w4_enabled() && vdk_gemm_w4_serves(p, TNF) &&                                                   \
         vdk_gemm_w4_launch(p, TNF, EE, grid256.x, grid256.y, stream, prof ? (void*)g_prof_ev[g_prof_used] : nullptr,     \
                            prof ? (void*)g_prof_ev[g_prof_used + 1] : nullptr)) { g_last_kernel = 5; break; }            \

@@ -84,7 +84,8 @@ struct W4Dma {
 };
 
 template <bool TN>
-__device__ __forceinline__ void w4_dma_init(W4Dma& d, const bf16_t* base, long ld, int extent /* operand rows (NT) */, int K, int kbeg, int w, int lane) {
+__device__ __forceinline__ void w4_dma_init(W4Dma& d, const bf16_t* base, long ld, int extent /* operand rows (NT) */, int K, int kbeg, int w, int lane,
+                                            unsigned blk = 128u /* operand rows (NT) / columns (TN) between the two halves of a region: 128, or 64 for the 128-wide B of gemm_w4h_kernel */) {
   const unsigned ldb = (unsigned)ld * 2u;
   d.ldb = ldb;
   if (!TN) {
@@ -92,7 +93,7 @@ __device__ __forceinline__ void w4_dma_init(W4Dma& d, const bf16_t* base, long l
     const unsigned i = (unsigned)lane >> 3, cp = (unsigned)lane & 7u;
     d.voff0 = i * ldb + ((cp ^ (i >> 1)) << 4);
     d.voff1 = i * ldb + ((cp ^ (4u + (i >> 1))) << 4);
-    d.wave_off = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)(w >> 1) * 128u + (unsigned)(w & 1) * 32u) * ldb));
+    d.wave_off = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)(w >> 1) * blk + (unsigned)(w & 1) * 32u) * ldb));
     d.sub_stride = 64u * ldb;
     d.piece_stride = 8u * ldb;
     d.kbeg = (unsigned)kbeg * 2u;
@@ -100,7 +101,7 @@ __device__ __forceinline__ void w4_dma_init(W4Dma& d, const bf16_t* base, long l
   } else {
     d.rs = w4_make_rsrc(base, (unsigned)K * ldb);
     const unsigned kr = (unsigned)lane >> 4, cp = (unsigned)lane & 15u, c = cp ^ (4u * (kr & 3u));
-    d.voff0 = d.voff1 = kr * ldb + ((c >> 3) * 128u + (c & 7u) * 8u) * 2u;
+    d.voff0 = d.voff1 = kr * ldb + ((c >> 3) * blk + (c & 7u) * 8u) * 2u;
     d.wave_off = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)w * 16u * ldb));
     d.sub_stride = 128u;
     d.piece_stride = 4u * ldb;
@@ -244,19 +245,26 @@ __device__ __forceinline__ void w4_ktile(unsigned char* smem, const W4Frag<TN>& 
 #else
 #define W4_EPI_SYNC() do { __builtin_amdgcn_s_waitcnt(0xC07F); VDK_WAVE_LDS_SYNC(); } while (0)   /* EXPERIMENT: drain the LDS queue at every staging hand-off */
 #endif
-template <int E>
-__device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* stage, f32x16 (&acc)[4][4], int lane, int wr, int wc, int m0, int n0, int z, int tm) {
+// NCT: 32-column blocks per wave (4: the 256x256 tile of gemm_w4_kernel, staging rows of 256 B, 4 rows per 64-lane pass; 2: the 256x128 tile of gemm_w4h_kernel,
+// staging rows of 128 B with chunk c of row r at position c ^ ((r >> 1) & 7), 8 rows per pass).  DEEP: vmcnt waited for before the first global access (-1: none).
+template <int E, int NCT, int DEEP>
+__device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* stage, f32x16 (&acc)[4][NCT], int lane, int wr, int wc, int m0, int n0, int z, int tm, unsigned long long (&ts)[5]) {
+  constexpr int NCH = NCT * 4;            // 16-byte chunks per staged row
+  constexpr int RPP = 64 / NCH;           // rows per 64-lane pass
+  constexpr int NPS = 32 / RPP;           // passes per 32-row block
+  constexpr int ROWB = NCT * 64;          // staged row, bytes
   constexpr bool FAST = (E == 0 || E == E_BIAS || E == (E_BIAS | E_GELU) || E == E_DGELU || E == (E_DGELU | E_OCS) || E == E_OCS);
   const int l31 = lane & 31, hi = lane >> 5;
-  const int mrow0 = m0 + wr * 128, ncol0 = n0 + wc * 128;
+  const int mrow0 = m0 + wr * 128, ncol0 = n0 + wc * (NCT * 32);
+  const int swz_w = NCT == 4 ? (l31 & 15) : ((l31 >> 1) & 7);   // staging swizzle of this lane's row
   if constexpr (FAST) {
-    const int rrow = lane >> 4, rc = lane & 15;                 // row-pass coordinates: rows pass * 4 + rrow, 16-byte chunk rc (8 columns)
+    const int rrow = lane / NCH, rc = lane % NCH;               // row-pass coordinates: rows pass * RPP + rrow, 16-byte chunk rc (8 columns)
     const int ncol = ncol0 + rc * 8;
     const bool nok = ncol < p.N;
-    float bias[4][4][4];
+    float bias[NCT][4][4];
     if (E & E_BIAS) {
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
+      for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = ncol0 + ct * 32 + 8 * g + 4 * hi;
@@ -269,7 +277,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
     float ocs[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) ocs[e] = 0.f;
-    unsigned char* const wbase = stage + l31 * 256 + hi * 8;    // + ((ct * 4 + g) ^ (l31 & 15)) * 16
+    unsigned char* const wbase = stage + l31 * ROWB + hi * 8;   // + ((ct * 4 + g) ^ swz_w) * 16
     // Rows leave (and the dGELU operand arrives) through buffer descriptors: the lane part of the offset is loop-invariant, the row block is a scalar, rows
     // beyond M fall outside num_records and columns beyond N get an out-of-range lane offset, so there is neither 64-bit address arithmetic nor a branch.
     const unsigned lane_out = nok ? (unsigned)rrow * (unsigned)p.ldc * 2u + (unsigned)ncol * 2u : W4_OOB;
@@ -281,15 +289,15 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
     auto rows_out = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned lane_off, unsigned ldbytes, int rt, bool with_ocs) {
       W4_EPI_SYNC();
       const unsigned srow = (unsigned)(mrow0 + rt * 32) * ldbytes;
-      u32x4 d[8];
+      u32x4 d[NPS];
 #pragma unroll
-      for (int ps = 0; ps < 8; ++ps) {
-        const int row = ps * 4 + rrow;
-        d[ps] = *(const u32x4*)(stage + row * 256 + ((rc ^ (row & 15)) << 4));
+      for (int ps = 0; ps < NPS; ++ps) {
+        const int row = ps * RPP + rrow;
+        d[ps] = *(const u32x4*)(stage + row * ROWB + ((rc ^ (NCT == 4 ? (row & 15) : ((row >> 1) & 7))) << 4));
       }
       if (with_ocs) {
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps)
+        for (int ps = 0; ps < NPS; ++ps)
 #pragma unroll
           for (int e = 0; e < 4; ++e) { ocs[2 * e] += bf_lo(d[ps][e]); ocs[2 * e + 1] += bf_hi(d[ps][e]); }
       }
@@ -298,33 +306,35 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
       // lanes 12-15 / 28-31 / 44-47 / 60-63 reached memory already overwritten.  The compiler pads the wide-store data hazard only for the form without a
       // scalar-offset register.
 #pragma unroll
-      for (int ps = 0; ps < 8; ++ps)
-        __builtin_amdgcn_raw_buffer_store_b128(d[ps], rs, lane_off + (srow + (unsigned)(ps * 4) * ldbytes), 0, 0);
+      for (int ps = 0; ps < NPS; ++ps)
+        __builtin_amdgcn_raw_buffer_store_b128(d[ps], rs, lane_off + (srow + (unsigned)(ps * RPP) * ldbytes), 0, 0);
       W4_EPI_SYNC();
     };
-    W4_WAIT_VM(4);                                              // deep wait: every DMA group but the newest has landed (the next tile's first k-tile then runs without waits)
+    if constexpr (DEEP >= 0) W4_WAIT_VM(DEEP);                  // deep wait: every DMA group but the newest has landed (the next tile's first k-tile then runs without waits)
+    if (p.dbg) ts[0] = __builtin_readcyclecounter();
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
+      if (p.dbg && rt > 0) ts[rt] = __builtin_readcyclecounter();
 #ifndef VDK_EMU
       __builtin_amdgcn_sched_barrier(0);                        // one 32-row block at a time: blocks interleaved by the scheduler keep several of them in registers
 #endif
-      u32x2 held[4][4];                                         // GELU: the activated values wait here (packed) while the pre-activation rows leave
+      u32x2 held[NCT][4];                                         // GELU: the activated values wait here (packed) while the pre-activation rows leave
       if (E & E_DGELU) {
         // the saved pre-activation u of these 32 rows: whole row segments -> staging -> this lane's layout
         const unsigned srow = (unsigned)(mrow0 + rt * 32) * (unsigned)p.ldaux * 2u;
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-          const int row = ps * 4 + rrow;
-          const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs_aux, lane_aux, srow + (unsigned)(ps * 4) * (unsigned)p.ldaux * 2u, 0);   // (out of range: zeros)
-          *(u32x4*)(stage + row * 256 + ((rc ^ (row & 15)) << 4)) = d;
+        for (int ps = 0; ps < NPS; ++ps) {
+          const int row = ps * RPP + rrow;
+          const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs_aux, lane_aux, srow + (unsigned)(ps * RPP) * (unsigned)p.ldaux * 2u, 0);   // (out of range: zeros)
+          *(u32x4*)(stage + row * ROWB + ((rc ^ (NCT == 4 ? (row & 15) : ((row >> 1) & 7))) << 4)) = d;
         }
         W4_EPI_SYNC();
       }
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
+      for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          unsigned char* const wp = wbase + (((ct * 4 + g) ^ (l31 & 15)) << 4);
+          unsigned char* const wp = wbase + (((ct * 4 + g) ^ swz_w) << 4);
           float v[4];
           if (E & E_DGELU) {
             const u32x2 u = *(const u32x2*)wp;                  // (the same 8 bytes this lane overwrites below: u goes out, dL/du comes in)
@@ -343,9 +353,9 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
       if (E & E_GELU) {
         rows_out(rs_aux, lane_aux, (unsigned)p.ldaux * 2u, rt, false);   // the pre-activation, for the backward pass
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) *(u32x2*)(wbase + (((ct * 4 + g) ^ (l31 & 15)) << 4)) = held[ct][g];
+          for (int g = 0; g < 4; ++g) *(u32x2*)(wbase + (((ct * 4 + g) ^ swz_w) << 4)) = held[ct][g];
       }
       rows_out(rs_out, lane_out, (unsigned)p.ldc * 2u, rt, (E & E_OCS) != 0);
     }
@@ -353,10 +363,11 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float s = ocs[e];
+        if (NCT == 2) s += __shfl_xor(s, 8);
         s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
         ocs[e] = s;
       }
-      if (lane < 16 && nok) {
+      if (lane < NCH && nok) {
         float* dst = p.ocs_part + ((long)tm * 2 + wr) * p.N + ncol;
         *(f32x4*)dst = (f32x4){ocs[0], ocs[1], ocs[2], ocs[3]};
         *(f32x4*)(dst + 4) = (f32x4){ocs[4], ocs[5], ocs[6], ocs[7]};
@@ -365,9 +376,10 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
   } else {
     float* const slab = (float*)stage;
     float q8_unused = 0.f;
-    W4_WAIT_VM(4);
+    if constexpr (DEEP >= 0) W4_WAIT_VM(DEEP);
+    if (p.dbg) ts[0] = __builtin_readcyclecounter();
 #pragma unroll
-    for (int cp = 0; cp < 2; ++cp) {
+    for (int cp = 0; cp < NCT / 2; ++cp) {
       const int ncol = ncol0 + cp * 64 + (lane & 7) * 8;
       float bias8[8], ocs8[8];
 #pragma unroll
@@ -478,7 +490,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
   }
   W4_WAIT_VM(4);                                          // deep wait: everything but the newest group
 
+  int dbg_i = 0;
   for (;;) {
+    unsigned long long t_top = 0, t_main = 0;
+    if (p.dbg) t_top = __builtin_readcyclecounter();
     // ---- one output tile: nk k-tiles.  Its first fragments come from buffer 0 (landed: the deep wait above / in the previous epilogue, made workgroup-wide by the
     // barrier); the first k-tile starts the accumulators from zero and needs no DMA waits; the last one leaves the fragment registers to the epilogue ----------
     W4_BAR();
@@ -498,6 +513,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
     }
     w4_ktile<TN, 1, 20, false, false>(smem, F, da, db, c_ta + c_ka, c_tb + c_kb, w, acc, A0, A1, BY, B1, BX);
     W4_CURSOR_ADVANCE();
+    if (p.dbg) t_main = __builtin_readcyclecounter();
     // The accumulators become opaque here: without it the compiler reads (and shuffles) them from inside the last MFMA phase, a few wait states behind the MFMA
     // that writes them, and on the MI355X some (lane, register) pairs then carry whatever the register held before (measured: the columns 4 g + 2, 4 g + 3 of
     // one 32-column block, lanes with bit 2 set).  The s_nop covers the last MFMA's passes.
@@ -508,12 +524,151 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
 #endif
     const int tile = t_start + t_idx;
     const int tn = tile % ntn, tm = tile / ntn;
-    w4_epilogue<E>(p, smem + W4_STAGE + w * 8192, acc, lane, wr, wc, tm * 256, tn * 256, z, tm);
+    unsigned long long ts[5] = {0, 0, 0, 0, 0};
+    w4_epilogue<E, 4, 4>(p, smem + W4_STAGE + w * 8192, acc, lane, wr, wc, tm * 256, tn * 256, z, tm, ts);
+    if (p.dbg && tid == 0 && dbg_i < 8) {   // debug only: shader-cycle stamps of this workgroup's first 8 tiles: top, main loop done, epilogue issued
+      unsigned long long* o = p.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + dbg_i) * 8;
+      o[0] = t_top; o[1] = t_main; o[2] = __builtin_readcyclecounter(); o[3] = (unsigned long long)(t_start + t_idx);
+      o[4] = ts[0]; o[5] = ts[1]; o[6] = ts[2]; o[7] = ts[3];
+    }
+    ++dbg_i;
     t_idx += t_stride;
     if (t_idx >= t_cnt) break;
   }
   W4_WAIT_VM(0);                                          // the cursor's last (out-of-range) pieces still write zeros into this workgroup's LDS
 #undef W4_CURSOR_ADVANCE
+}
+
+// =====================================================================================================================================
+// gemm_w4h_kernel — the same building blocks as a 256 x 128 tile with TWO workgroups per CU (80 KB of LDS and 256 registers per wave each): every SIMD hosts
+// one wave of each workgroup, so while one workgroup runs its epilogue (the GELU / dGELU arithmetic, the fp32 residual traffic: 30-70 k cycles in which a
+// single resident workgroup leaves the matrix pipe idle) the other one multiplies.  Per wave: 128 x 64 = 4 x 2 accumulators.
+//   * a k-tile is 3 regions of 16 KB: RA0 / RA1 (first / second 64 rows of both wave-rows) and RB (the 128 columns); 5 region slots form the ring, the stream's
+//     region q = 3 t + r lives in slot q % 5 and is refilled with region q + 5 once it has been read;
+//   * 2 phases of 16 MFMAs per k-tile: P1 = A0 x B (reads A1(t); refills the slots of RA0(t) and RB(t) with RA1(t+1) and RA0(t+2)), P2 = A1 x B (reads A0(t+1),
+//     and B(t+1) IN PLACE: a B fragment register is reloaded right behind the last MFMA of the phase that uses it; refills RA1(t)'s slot with RB(t+2));
+//   * every phase end waits vmcnt(8): the group read next was issued two phases earlier, only the 8 newest pieces may be in flight.
+#define W4H_SMEM 81920
+#define W4H_SLOT 16384
+
+template <bool TN, bool FIRST>
+__device__ __forceinline__ void w4h_ktile(unsigned char* smem, const W4Frag<TN>& F, const W4Dma& da, const W4Dma& db, unsigned s_a1n /* RA1(t+1) */, unsigned s_a0nn /* RA0(t+2) */,
+                                          unsigned s_bnn /* RB(t+2) */, int w, unsigned oA0, unsigned oB, unsigned oA1, unsigned oA0n, unsigned oBn,
+                                          f32x16 (&acc)[4][2], s16x8 (&A0)[2][4], s16x8 (&A1)[2][4], s16x8 (&B)[2][4]) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // ---- P1: A0 x B ----
+  W4_BAR();
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B[0][ks], A0[0][ks], (FIRST && ks == 0) ? zero : acc[0][0], 0, 0, 0);
+    A1[0][ks] = w4_frag<TN>(smem + oA1, F.a, 0, ks);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B[1][ks], A0[0][ks], (FIRST && ks == 0) ? zero : acc[0][1], 0, 0, 0);
+    A1[1][ks] = w4_frag<TN>(smem + oA1, F.a, 1, ks);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B[0][ks], A0[1][ks], (FIRST && ks == 0) ? zero : acc[1][0], 0, 0, 0);
+    // issue order inside the phase: the 4 pieces of RA1(t+1) first, then the 4 of RA0(t+2) (the vmcnt(8) of the phase ends counts on it)
+    if (ks < 2) w4_piece(da, smem + oA0 + (4 * w + 2 * ks) * 1024, 1, 2 * ks, s_a1n); else w4_piece(da, smem + oB + (4 * w + 2 * (ks - 2)) * 1024, 0, 2 * (ks - 2), s_a0nn);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B[1][ks], A0[1][ks], (FIRST && ks == 0) ? zero : acc[1][1], 0, 0, 0);
+    if (ks < 2) w4_piece(da, smem + oA0 + (4 * w + 2 * ks + 1) * 1024, 1, 2 * ks + 1, s_a1n); else w4_piece(da, smem + oB + (4 * w + 2 * (ks - 2) + 1) * 1024, 0, 2 * (ks - 2) + 1, s_a0nn);
+  }
+#ifndef VDK_EMU
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, TN ? 2 : 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, TN ? 2 : 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
+  }
+#endif
+  w4_phase_end<8>();
+  // ---- P2: A1 x B ----
+  W4_BAR();
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B[0][ks], A1[0][ks], (FIRST && ks == 0) ? zero : acc[2][0], 0, 0, 0);
+    A0[0][ks] = w4_frag<TN>(smem + oA0n, F.a, 0, ks);
+    acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B[1][ks], A1[0][ks], (FIRST && ks == 0) ? zero : acc[2][1], 0, 0, 0);
+    A0[1][ks] = w4_frag<TN>(smem + oA0n, F.a, 1, ks);
+    acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B[0][ks], A1[1][ks], (FIRST && ks == 0) ? zero : acc[3][0], 0, 0, 0);
+    w4_piece(db, smem + oA1 + (4 * w + ks) * 1024, 0, ks, s_bnn);
+    acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B[1][ks], A1[1][ks], (FIRST && ks == 0) ? zero : acc[3][1], 0, 0, 0);
+    B[0][ks] = w4_frag<TN>(smem + oBn, F.b, 0, ks);      // (k-tile t+1's fragments, into the registers the four MFMAs above have just read)
+    B[1][ks] = w4_frag<TN>(smem + oBn, F.b, 1, ks);
+  }
+#ifndef VDK_EMU
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, TN ? 2 : 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, TN ? 2 : 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, TN ? 4 : 2, 0);
+  }
+#endif
+  w4_phase_end<8>();
+}
+
+template <bool TN, int E>
+__global__ __launch_bounds__(256, 2) void gemm_w4h_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[W4H_SMEM];   // 5 region slots; the epilogue staging (4 x 8 KB) reuses the first two
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 1, wc = w & 1;
+  const int ntn = (p.N + 127) / 128, ntm = (p.M + 255) / 256;
+  const int nwg = ntn * ntm;
+  const int z = blockIdx.y;
+  int tile;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tn = tile % ntn, tm = tile / ntn;
+  const int m0 = tm * 256, n0 = tn * 128;
+  const int kbeg = z * p.k_per_split;
+  int kend = kbeg + p.k_per_split; if (kend > p.K) kend = p.K;
+  const int nk = (kend - kbeg) / 64;                      // launcher guarantees whole k-tiles, nk >= 1
+
+  W4Dma da, db;
+  w4_dma_init<TN>(da, p.A, p.lda, p.M, p.K, kbeg, w, lane, 128u);
+  w4_dma_init<TN>(db, p.B, p.ldb, p.N, p.K, kbeg, w, lane, 64u);
+  W4Frag<TN> F;
+  w4_frag_init<TN>(F, wr, wc, lane);
+  const unsigned ta = w4_tile_base<TN>(da, m0) + da.kbeg, tb = w4_tile_base<TN>(db, n0) + db.kbeg;
+#define W4H_KA(t) ((t) < nk ? ta + (unsigned)(t) * da.kstep : W4_OOB)
+#define W4H_KB(t) ((t) < nk ? tb + (unsigned)(t) * db.kstep : W4_OOB)
+
+  f32x16 acc[4][2];
+  s16x8 A0[2][4], A1[2][4], B[2][4];
+  // ---- prologue: the stream's regions 0..4 (RA0(0), RB(0), RA1(0), RA0(1), RB(1)) into slots 0..4 ----
+  w4_region(da, smem + 0 * W4H_SLOT, 0, w, W4H_KA(0)); w4_region(db, smem + 1 * W4H_SLOT, 0, w, W4H_KB(0)); w4_region(da, smem + 2 * W4H_SLOT, 1, w, W4H_KA(0));
+  w4_region(da, smem + 3 * W4H_SLOT, 0, w, W4H_KA(1)); w4_region(db, smem + 4 * W4H_SLOT, 0, w, W4H_KB(1));
+  W4_WAIT_VM(12);                                         // RA0(0), RB(0)
+  W4_BAR();
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { A0[rt][ks] = w4_frag<TN>(smem, F.a, rt, ks); B[rt][ks] = w4_frag<TN>(smem + W4H_SLOT, F.b, rt, ks); }
+  __builtin_amdgcn_sched_barrier(0);
+  W4_WAIT_VM(8);                                          // RA1(0), read in phase 1
+  W4_WAIT_LGKM0();
+
+  unsigned q5 = 0;                                        // (3 t) mod 5
+#define W4H_SLOT_OF(i) ((((q5 + (i)) >= 5u) ? (q5 + (i) - 5u) : (q5 + (i))) * (unsigned)W4H_SLOT)
+  w4h_ktile<TN, true>(smem, F, da, db, W4H_KA(1), W4H_KA(2), W4H_KB(2), w, W4H_SLOT_OF(0), W4H_SLOT_OF(1), W4H_SLOT_OF(2), W4H_SLOT_OF(3), W4H_SLOT_OF(4), acc, A0, A1, B);
+  q5 = 3;
+  for (int t = 1; t < nk; ++t) {
+    w4h_ktile<TN, false>(smem, F, da, db, W4H_KA(t + 1), W4H_KA(t + 2), W4H_KB(t + 2), w, W4H_SLOT_OF(0), W4H_SLOT_OF(1), W4H_SLOT_OF(2), W4H_SLOT_OF(3), W4H_SLOT_OF(4), acc, A0, A1, B);
+    q5 = q5 + 3 >= 5 ? q5 - 2 : q5 + 3;
+  }
+#undef W4H_SLOT_OF
+#undef W4H_KA
+#undef W4H_KB
+  W4_WAIT_VM(0);                                          // the out-of-range pieces behind the last k-tile still write zeros into the ring the epilogue is about to reuse
+  W4_BAR();
+#ifndef VDK_EMU
+  asm volatile("s_nop 15\n\ts_nop 15"
+               : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
+#endif
+  unsigned long long ts[5] = {0, 0, 0, 0, 0};
+  w4_epilogue<E, 2, -1>(p, smem + w * 8192, acc, lane, wr, wc, m0, n0, z, tm, ts);
 }
 
 // ---- launcher (called by vdk_gemm_bf16_nt / vdk_margin_cos_pass in gemm.hip) ------------------------------------------------------------------------
@@ -524,6 +679,16 @@ bool vdk_gemm_w4_serves(const GemmParams& p, bool trans) {
   if (p.colsum_part || p.sk_cnt || p.a_row_group > 0) return false;
   if ((p.K % 128) || (p.k_per_split % 128) || p.K < 128) return false;
   if (((double)p.M + 256.0) * (double)p.ldc * 2.0 >= lim || (p.aux && ((double)p.M + 256.0) * (double)p.ldaux * 2.0 >= lim)) return false;   // bf16 rows leave through 32-bit buffer offsets
+  if (!trans) return ((double)p.M + 256.0) * (double)p.lda * 2.0 < lim && ((double)p.N + 256.0) * (double)p.ldb * 2.0 < lim;
+  return ((double)p.K + 64.0) * (double)p.lda * 2.0 < lim && ((double)p.K + 64.0) * (double)p.ldb * 2.0 < lim;
+}
+
+// the 256x128 / two-workgroups-per-CU form: any whole number of k-tiles; same size limits
+bool vdk_gemm_w4h_serves(const GemmParams& p, bool trans) {
+  const double lim = 2147483648.0 - 65536.0;
+  if (p.colsum_part || p.sk_cnt || p.a_row_group > 0) return false;
+  if ((p.K % 64) || (p.k_per_split % 64) || p.K < 64) return false;
+  if (((double)p.M + 256.0) * (double)p.ldc * 2.0 >= lim || (p.aux && ((double)p.M + 256.0) * (double)p.ldaux * 2.0 >= lim)) return false;
   if (!trans) return ((double)p.M + 256.0) * (double)p.lda * 2.0 < lim && ((double)p.N + 256.0) * (double)p.ldb * 2.0 < lim;
   return ((double)p.K + 64.0) * (double)p.lda * 2.0 < lim && ((double)p.K + 64.0) * (double)p.ldb * 2.0 < lim;
 }
@@ -578,6 +743,40 @@ bool vdk_gemm_w4_launch(const GemmParams& p, bool trans, int E, unsigned tiles, 
     case E_SPLITK: W4_LAUNCH(false, E_SPLITK);
     case E_F32: W4_LAUNCH(false, E_F32);
     default: W4_LAUNCH(false, E_GENERIC);
+  }
+  return false;
+}
+
+#define W4H_LAUNCH(TNF, EE)                                                                                                             \
+  do {                                                                                                                                  \
+    if (ev0) hipExtLaunchKernelGGL((gemm_w4h_kernel<TNF, EE>), grid, dim3(256), 0, stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, p);     \
+    else hipLaunchKernelGGL((gemm_w4h_kernel<TNF, EE>), grid, dim3(256), 0, stream, p);                                                 \
+    return true;                                                                                                                        \
+  } while (0)
+
+bool vdk_gemm_w4h_launch(const GemmParams& p, bool trans, int E, unsigned splitk, void* stream_, void* ev0, void* ev1) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const dim3 grid((unsigned)(((p.M + 255) / 256) * ((p.N + 127) / 128)), splitk);
+  if (trans) {
+    switch (E) {
+      case E_SPLITK: W4H_LAUNCH(true, E_SPLITK);
+      case E_F32: W4H_LAUNCH(true, E_F32);
+      case 0: W4H_LAUNCH(true, 0);
+      default: W4H_LAUNCH(true, E_GENERIC);
+    }
+  }
+  switch (E) {
+    case 0: W4H_LAUNCH(false, 0);
+    case E_OCS: W4H_LAUNCH(false, E_OCS);
+    case E_DGELU | E_OCS: W4H_LAUNCH(false, E_DGELU | E_OCS);
+    case E_BIAS: W4H_LAUNCH(false, E_BIAS);
+    case E_BIAS | E_GELU: W4H_LAUNCH(false, E_BIAS | E_GELU);
+    case E_DGELU: W4H_LAUNCH(false, E_DGELU);
+    case E_BIAS | E_RES | E_F32: W4H_LAUNCH(false, E_BIAS | E_RES | E_F32);
+    case E_BIAS | E_RES | E_F32 | E_ROWGRP: W4H_LAUNCH(false, E_BIAS | E_RES | E_F32 | E_ROWGRP);
+    case E_SPLITK: W4H_LAUNCH(false, E_SPLITK);
+    case E_F32: W4H_LAUNCH(false, E_F32);
+    default: W4H_LAUNCH(false, E_GENERIC);
   }
   return false;
 }

@@ -39,3 +39,5 @@ extern "C" int vdk_transpose_bf16(const void* in, int64_t ldi, int32_t R, int32_
 // gemm_w4.hip: the 4-wave (one wave per SIMD) 256x256 kernel.  serves(): the problem fits its 32-bit buffer offsets and asks for no by-product it lacks.
 bool vdk_gemm_w4_serves(const GemmParams& p, bool trans);
 bool vdk_gemm_w4_launch(const GemmParams& p, bool trans, int E, unsigned tiles, unsigned splitk, void* stream, void* ev0, void* ev1);
+bool vdk_gemm_w4h_serves(const GemmParams& p, bool trans);
+bool vdk_gemm_w4h_launch(const GemmParams& p, bool trans, int E, unsigned splitk, void* stream, void* ev0, void* ev1);
