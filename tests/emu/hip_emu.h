@@ -434,6 +434,7 @@ static inline emu_s16x4 emu_ds_read_tr16_b64(const void* p) {
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_barrier() __syncthreads()
 static inline int __mul24(int a, int b) { return a * b; }

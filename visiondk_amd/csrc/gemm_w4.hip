@@ -342,9 +342,11 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
             v[2] = acc[rt][ct][4 * g + 2] * gelu_grad_f(bf_lo(u[1])); v[3] = acc[rt][ct][4 * g + 3] * gelu_grad_f(bf_hi(u[1]));
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[rt][ct][4 * g + e] + ((E & E_BIAS) ? bias[ct][g][e] : 0.f);
+            for (int e = 0; e < 4; ++e) v[e] = (E & E_BIAS) ? acc[rt][ct][4 * g + e] + bias[ct][g][e] : acc[rt][ct][4 * g + e];
           }
           *(u32x2*)wp = (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+          // (the activations stay in hipcc's order, value pair by value pair on packed fp32 ops: a lone wave issues a VALU instruction every ~8 cycles whatever
+          //  the dependencies, so instruction COUNT is the cost -- a stage-by-stage 8-wide form without packed ops measured 10-25 % slower)
           if (E & E_GELU) held[ct][g] = (u32x2){pack_bf2(gelu_f(v[0]), gelu_f(v[1])), pack_bf2(gelu_f(v[2]), gelu_f(v[3]))};
 #ifndef VDK_EMU
           if ((E & (E_GELU | E_DGELU)) && g == 3) __builtin_amdgcn_sched_barrier(0);   // 16 activations in flight are plenty; all 64 at once spill
@@ -637,6 +639,23 @@ __global__ __launch_bounds__(256, 2) void gemm_w4h_kernel(GemmParams p) {
 
   f32x16 acc[4][2];
   s16x8 A0[2][4], A1[2][4], B[2][4];
+  unsigned long long t_top = 0, t_land = 0, t_main = 0, rt_top = 0;
+  if (p.dbg) {
+    t_top = __builtin_readcyclecounter();
+#ifndef VDK_EMU
+    rt_top = __builtin_amdgcn_s_memrealtime();
+#endif
+  }
+  // Optional start delay for the second slot's first workgroups (p.stagger cycles; VDK_GEMM_W4H_STAGGER).  The idea: the dispatcher fills both slots of every
+  // CU at the same moment and equal tiles could keep the pair in lock-step (both in the prologue, both in the main loop, both in the epilogue).  Measured
+  // (tools/w4h_stamps.py, per-CU time lines from s_memrealtime + HW_ID): the pair is 8-10 us apart after its first workgroups anyway, and a forced half-period
+  // offset changed the long-epilogue GEMMs by 0 to -2 %.  Off by default.
+#ifndef VDK_EMU
+  if (p.stagger > 0 && blockIdx.y == 0 && blockIdx.x >= (unsigned)p.stagger_lo && blockIdx.x < (unsigned)(2 * p.stagger_lo)) {
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
   // ---- prologue: the stream's regions 0..4 (RA0(0), RB(0), RA1(0), RA0(1), RB(1)) into slots 0..4 ----
   w4_region(da, smem + 0 * W4H_SLOT, 0, w, W4H_KA(0)); w4_region(db, smem + 1 * W4H_SLOT, 0, w, W4H_KB(0)); w4_region(da, smem + 2 * W4H_SLOT, 1, w, W4H_KA(0));
   w4_region(da, smem + 3 * W4H_SLOT, 0, w, W4H_KA(1)); w4_region(db, smem + 4 * W4H_SLOT, 0, w, W4H_KB(1));
@@ -650,6 +669,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w4h_kernel(GemmParams p) {
   W4_WAIT_VM(8);                                          // RA1(0), read in phase 1
   W4_WAIT_LGKM0();
 
+  if (p.dbg) t_land = __builtin_readcyclecounter();
   unsigned q5 = 0;                                        // (3 t) mod 5
 #define W4H_SLOT_OF(i) ((((q5 + (i)) >= 5u) ? (q5 + (i) - 5u) : (q5 + (i))) * (unsigned)W4H_SLOT)
   w4h_ktile<TN, true>(smem, F, da, db, W4H_KA(1), W4H_KA(2), W4H_KB(2), w, W4H_SLOT_OF(0), W4H_SLOT_OF(1), W4H_SLOT_OF(2), W4H_SLOT_OF(3), W4H_SLOT_OF(4), acc, A0, A1, B);
@@ -661,6 +681,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w4h_kernel(GemmParams p) {
 #undef W4H_SLOT_OF
 #undef W4H_KA
 #undef W4H_KB
+  if (p.dbg) t_main = __builtin_readcyclecounter();
   W4_WAIT_VM(0);                                          // the out-of-range pieces behind the last k-tile still write zeros into the ring the epilogue is about to reuse
   W4_BAR();
 #ifndef VDK_EMU
@@ -669,6 +690,14 @@ __global__ __launch_bounds__(256, 2) void gemm_w4h_kernel(GemmParams p) {
 #endif
   unsigned long long ts[5] = {0, 0, 0, 0, 0};
   w4_epilogue<E, 2, -1>(p, smem + w * 8192, acc, lane, wr, wc, m0, n0, z, tm, ts);
+  if (p.dbg && tid == 0) {   // debug only: shader-cycle stamps (start, first operands landed, main loop done, epilogue entered, its 32-row blocks 1..3, end)
+    unsigned long long* o = p.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+    o[0] = t_top; o[1] = t_main; o[2] = __builtin_readcyclecounter(); o[3] = t_land; o[4] = ts[0];
+#ifndef VDK_EMU
+    o[5] = rt_top; o[6] = __builtin_amdgcn_s_memrealtime();                       // the 100 MHz counter is common to the chip: a time line across CUs
+    o[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // XCC_ID, HW_ID
+#endif
+  }
 }
 
 // ---- launcher (called by vdk_gemm_bf16_nt / vdk_margin_cos_pass in gemm.hip) ------------------------------------------------------------------------
@@ -754,9 +783,20 @@ bool vdk_gemm_w4_launch(const GemmParams& p, bool trans, int E, unsigned tiles, 
     return true;                                                                                                                        \
   } while (0)
 
-bool vdk_gemm_w4h_launch(const GemmParams& p, bool trans, int E, unsigned splitk, void* stream_, void* ev0, void* ev1) {
+bool vdk_gemm_w4h_launch(const GemmParams& p_, bool trans, int E, unsigned splitk, void* stream_, void* ev0, void* ev1) {
   hipStream_t stream = (hipStream_t)stream_;
+  GemmParams p = p_;
   const dim3 grid((unsigned)(((p.M + 255) / 256) * ((p.N + 127) / 128)), splitk);
+  {
+    // start delay of the second slot's first workgroups: half of (prologue + main loop at ~2400 cycles per k-tile with a shared pipe + epilogue estimate)
+    static const int stag_pct = getenv("VDK_GEMM_W4H_STAGGER") ? atoi(getenv("VDK_GEMM_W4H_STAGGER")) : 0;   // measured null to -2 % at 50 / 100 / 150 % (tools/w4h_stagger_ab.py): the pair drifts apart by itself; opt-in
+    const int cus = w4_cus();
+    const int nk = (p.k_per_split < p.K ? p.k_per_split : p.K) / 64;
+    int epi = 7000;
+    if (E != E_GENERIC && (E & E_GELU)) epi = 20000; else if (E != E_GENERIC && (E & E_DGELU)) epi = 30000; else if (E == E_GENERIC || (E & (E_RES | E_F32 | E_SPLITK))) epi = 30000;
+    p.stagger_lo = cus;
+    p.stagger = ((int)grid.x >= 2 * cus && splitk == 1) ? (int)((long)(4000 + nk * 2400 + epi) / 2 * stag_pct / 100) : 0;
+  }
   if (trans) {
     switch (E) {
       case E_SPLITK: W4H_LAUNCH(true, E_SPLITK);
