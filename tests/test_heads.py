@@ -169,3 +169,32 @@ def test_epilogue_fused_head_equals_materialised_form(be, dev, tag, planes):
         be.lib.vdk_gemm_force_kernel(0)
     assert (l1.cpu() - l0.cpu()).abs().max().item() < 1e-5 * l0.abs().max().item() + 1e-5
     assert _rel(df1, df0) < 2e-3 and _rel(dW1, dW0) < 2e-3
+
+
+@pytest.mark.parametrize("kern", [2, 5])
+def test_epilogue_fused_head_on_both_256_kernels(be, dev, kern):
+    """the margin-head epilogues (per-slice softmax partials, d cos from the row statistics) on the eight-wave and on the four-wave 256x256 TN kernel (K = 3 planes x 128)"""
+    torch.manual_seed(10)
+    D, Cn, B = 128, 777, 40
+    h = heads.ArcFace(D, Cn, margin_arc=0.35, margin_am=0.0, scale=32, backend=be, device=dev)
+    feats = torch.randn(B, D).to(dev); labels = torch.randint(0, Cn, (B,)).to(dev)
+    l0, df0, dW0 = h.margin_ce(feats, labels, label_smoothing=0.1, cos_planes=3, fused=False)
+    be.lib.vdk_gemm_force_kernel(kern)
+    try:
+        l1, df1, dW1 = h.margin_ce(feats, labels, label_smoothing=0.1, cos_planes=3, fused=True)
+        assert be.lib.vdk_gemm_last_kernel() in (kern, 1, 2, 5)     # (the backward GEMMs run after the cos passes)
+    finally:
+        be.lib.vdk_gemm_force_kernel(0)
+    assert (l1.cpu() - l0.cpu()).abs().max().item() < 1e-5 * l0.abs().max().item() + 1e-5
+    assert _rel(df1, df0) < 2e-3 and _rel(dW1, dW0) < 2e-3
+
+
+def test_fused_head_falls_back_on_unserved_shapes(be, dev):
+    """fused=True on a class count the 256x256 TN kernel does not serve (padded C < 256 -> VDK_EUNSUPPORTED): the materialised form takes over, no error"""
+    torch.manual_seed(12)
+    D, Cn, B = 64, 100, 24
+    h = heads.ArcFace(D, Cn, margin_arc=0.35, margin_am=0.0, scale=32, backend=be, device=dev)
+    feats = torch.randn(B, D).to(dev); labels = torch.randint(0, Cn, (B,)).to(dev)
+    l0, df0, dW0 = h.margin_ce(feats, labels, label_smoothing=0.1, cos_planes=1, fused=False)
+    l1, df1, dW1 = h.margin_ce(feats, labels, label_smoothing=0.1, cos_planes=1, fused=True)
+    assert torch.equal(l0.cpu(), l1.cpu()) and torch.equal(df0.cpu(), df1.cpu()) and torch.equal(dW0.cpu(), dW1.cpu())

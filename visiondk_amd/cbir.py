@@ -136,10 +136,22 @@ class FlatIPIndex:
         wide = (self._dp + 127) // 128 * 128
         self._gb = torch.empty((max(n, 1), wide), dtype=torch.bfloat16, device=self.device)
         self._gmax = torch.zeros(4, dtype=torch.int32, device=self.device)
-        norms = torch.empty(3 * max(n, 1), dtype=torch.float32, device=self.device)
-        g32 = g.float() if g.dtype != torch.float32 else g        # fp16 storage: a transient fp32 view of the stored values (exact), add()-time only
-        be.check(be.lib.vdk_cbir_prepare_gallery(be.ptr(g32) if n else None, n, self._dp, be.ptr(self._gb), be.ptr(norms),
-                                                 be.ptr(self._gmax), be.stream()), "vdk_cbir_prepare_gallery")
+        if g.dtype == torch.float32 or n == 0:
+            norms = torch.empty(3 * max(n, 1), dtype=torch.float32, device=self.device)
+            be.check(be.lib.vdk_cbir_prepare_gallery(be.ptr(g) if n else None, n, self._dp, be.ptr(self._gb), be.ptr(norms),
+                                                     be.ptr(self._gmax), be.stream()), "vdk_cbir_prepare_gallery")
+            return
+        # fp16 storage: the fp32 values the kernel wants exist only for one bounded block of rows at a time (a whole-gallery .float() would be twice the fp16
+        # footprint again, exactly where fp16 was chosen to fit); the three norm maxima are positive floats, so their bit patterns combine with an integer max
+        step = 1 << 16
+        norms = torch.empty(3 * step, dtype=torch.float32, device=self.device)
+        gm = torch.zeros(4, dtype=torch.int32, device=self.device)
+        for r0 in range(0, n, step):
+            blk = g[r0:r0 + step].float()
+            be.check(be.lib.vdk_cbir_prepare_gallery(be.ptr(blk), blk.shape[0], self._dp, be.ptr(self._gb[r0:r0 + step]), be.ptr(norms), be.ptr(gm), be.stream()),
+                     "vdk_cbir_prepare_gallery")
+            self._gmax[:3] = torch.maximum(self._gmax[:3], gm[:3]) if r0 else gm[:3]
+            self._gmax[3] = gm[3]
 
     def _workspace(self, nq: int, k: int, cap: int) -> torch.Tensor:
         need = C.c_size_t(0)

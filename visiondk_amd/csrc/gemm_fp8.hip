@@ -265,7 +265,7 @@ __global__ void fp8_scale_update_kernel(float* __restrict__ amax, float* __restr
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float a = amax[i];
-  if (a > 0.f) { const float s = fmt_max / (a * margin); scale[i] = s; scale_inv[i] = 1.0f / s; }
+  if (a > 0.f && a < 3.0e38f) { const float s = fmt_max / (a * margin); scale[i] = s; scale_inv[i] = 1.0f / s; }   // (non-finite amax: keep the previous scale, see vit_fp8_update_kernel)
   amax[i] = 0.f;
 }
 

@@ -307,7 +307,7 @@ __global__ void vit_fp8_update_kernel(float* __restrict__ amax, float* __restric
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float a = amax[i], fmax = (i % 12) >= 8 ? 57344.0f : 448.0f;       // slots 8..11 of a layer are e5m2 gradients
-  if (a > 0.f) { const float v = fmax / a; sc[i] = v; si[i] = 1.0f / v; }
+  if (a > 0.f && a < 3.0e38f) { const float v = fmax / a; sc[i] = v; si[i] = 1.0f / v; }   // a non-finite amax (one overflowed step) keeps the previous scale instead of poisoning it: scale 0 / inf would make every later output NaN, fmaxf would then drop the NaNs and the a > 0 guard would keep scale 0 forever
   amax[i] = 0.f;
 }
 

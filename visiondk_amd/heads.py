@@ -139,7 +139,8 @@ class _MarginHead(nn.Module):
                                                     be.ptr(rowstat), label_smoothing, gs_, be.ptr(dcos), st.Cp, be.stream()), "vdk_margin_cos_pass")
                 df, dW = _backward_from_dcos(be, st, self.weight.detach(), dcos)
                 return loss, df, dW
-            be.check(rc, "vdk_margin_cos_pass")      # (VDK_EUNSUPPORTED: the 256x256 TN kernel does not serve this shape)
+            if rc != _abi.EUNSUPPORTED:      # every other error is an error; VDK_EUNSUPPORTED = the 256x256 TN kernel does not serve this shape -> the materialised form below
+                be.check(rc, "vdk_margin_cos_pass")
             st.cos = ops.gemm_nt(st.fbt, st.wb, out_dtype=torch.float32, trans=True, backend=be)      # shapes the 256x256 TN kernel does not serve: the materialised form
         else:
             st = _forward_cos(be, feats.contiguous(), self.weight.detach(), cos_planes)

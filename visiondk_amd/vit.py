@@ -445,7 +445,8 @@ class AttentionPoolLatent(nn.Module):
     """timm.layers.AttentionPoolLatent as the SigLIP ViTs configure it (latent_len 1, qkv_bias, no qk_norm, LayerNorm eps 1e-6, mlp_ratio 4, exact GELU, pool 'token');
     parameter names equal timm's (latent, q, kv, proj, norm, mlp.fc1, mlp.fc2).  head_dim 64."""
 
-    def __init__(self, dim: int, num_heads: int, mlp_dim: Optional[int] = None, eps: float = 1e-6, backend: Optional[_lib.Backend] = None, device=None):
+    def __init__(self, dim: int, num_heads: int, mlp_dim: Optional[int] = None, eps: float = 1e-6, backend: Optional[_lib.Backend] = None, device=None,
+                 generator: Optional[torch.Generator] = None):
         super().__init__()
         assert dim == num_heads * 64, "head_dim must be 64"
         self.be = backend or _lib.load()
@@ -459,14 +460,16 @@ class AttentionPoolLatent(nn.Module):
         for holder, shape in ((self.q, (dim, dim)), (self.kv, (2 * dim, dim)), (self.proj, (dim, dim)), (self.mlp.fc1, (mlp_dim, dim)), (self.mlp.fc2, (dim, mlp_dim))):
             holder.weight = nn.Parameter(torch.empty(shape, device=dev)); holder.bias = nn.Parameter(torch.zeros(shape[0], device=dev))
         self.norm.weight = nn.Parameter(torch.ones(dim, device=dev)); self.norm.bias = nn.Parameter(torch.zeros(dim, device=dev))
-        self.reset_parameters()
+        self.reset_parameters(generator)
 
-    def reset_parameters(self):
+    def reset_parameters(self, generator: Optional[torch.Generator] = None):
         with torch.no_grad():
             D = self.latent.shape[-1]
-            self.latent.copy_(torch.empty(1, 1, D).normal_(0, D ** -0.5).clamp_(-2 * D ** -0.5, 2 * D ** -0.5).to(self.latent.device))
+            lat = torch.empty(1, 1, D)
+            torch.nn.init.trunc_normal_(lat, std=D ** -0.5, a=-2 * D ** -0.5, b=2 * D ** -0.5, generator=generator)     # timm: trunc_normal_tf_(latent, std=D^-0.5)
+            self.latent.copy_(lat.to(self.latent.device))
             for h in (self.q, self.kv, self.proj, self.mlp.fc1, self.mlp.fc2):     # the reference's reset_parameters override: N(0, .02) Linear weights, zero biases
-                h.weight.copy_(torch.empty(h.weight.shape).normal_(0, 0.02).to(h.weight.device)); h.bias.zero_()
+                h.weight.copy_(torch.empty(h.weight.shape).normal_(0, 0.02, generator=generator).to(h.weight.device)); h.bias.zero_()
 
     def forward(self, tokens: torch.Tensor) -> torch.Tensor:
         return _AttnPoolFn.apply(tokens, self.latent, self.q.weight, self.q.bias, self.kv.weight, self.kv.bias, self.proj.weight, self.proj.bias, self.norm.weight,
@@ -511,10 +514,13 @@ class VisionTransformerMap(nn.Module):
             self.register_parameter(name, p)
         be = trunk.engine.be
         dev = trunk.engine.device
-        self.attn_pool = AttentionPoolLatent(spec.dim, spec.heads, spec.mlp_dim, spec.ln_eps, backend=be, device=dev)
+        gen = None
+        if seed is not None:      # the pooling head and the classifier draw from the same seed as the trunk: a seeded model is reproducible (and equal on every rank)
+            gen = torch.Generator(); gen.manual_seed(int(seed) + 1)
+        self.attn_pool = AttentionPoolLatent(spec.dim, spec.heads, spec.mlp_dim, spec.ln_eps, backend=be, device=dev, generator=gen)
         self.head = _Holder()
         if spec.num_classes > 0:
-            self.head.weight = nn.Parameter(torch.empty(spec.num_classes, spec.dim, device=dev).normal_(0, 0.02)); self.head.bias = nn.Parameter(torch.zeros(spec.num_classes, device=dev))
+            self.head.weight = nn.Parameter(torch.empty(spec.num_classes, spec.dim).normal_(0, 0.02, generator=gen).to(dev)); self.head.bias = nn.Parameter(torch.zeros(spec.num_classes, device=dev))
 
     def forward_features(self, x: torch.Tensor) -> torch.Tensor:
         return self._trunk[0](x)              # [B, N, D], final-normed
@@ -536,6 +542,8 @@ def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, d
     if not spec.class_token:      # the SigLIP family: attention-pool head (timm's default global_pool for these ids is 'map'); global_pool='' -> token features
         if global_pool == "":
             return VisionTransformer(dataclasses.replace(spec, num_classes=0), device=device, backend=backend)
+        if global_pool not in ("map", "token"):      # ("token" is this function's default argument, i.e. "not given": timm then uses the id's own default, 'map')
+            raise NotImplementedError(f"global_pool={global_pool!r} is not built for the SigLIP ids (only 'map' and '')")
         return VisionTransformerMap(spec, device=device, backend=backend)
     if num_classes == 0 and global_pool != "":
         raise NotImplementedError("num_classes=0 is supported with global_pool='' (token features) only")
@@ -680,10 +688,11 @@ class MapTrainStep:
             p.data = eng.params[off:off + numel].view(shape)
         self.gbig = torch.zeros(cur, dtype=torch.float32, device=dev)
         eng.grads = self.gbig[:n]
+        self._extra_offs = offs
         for p, off in zip(self.extras, offs):
             big[off:off + p.numel()].copy_(p.detach().reshape(-1))
             p.data = big[off:off + p.numel()].view(p.shape)
-            p.grad = self.gbig[off:off + p.numel()].view(p.shape)          # autograd accumulates in place into the flat gradient buffer
+        self._bind_extra_grads()
         eng._weights_version = None
         self.big = big
         self.param_groups = [{"lr": lr, "momentum": momentum, "weight_decay": weight_decay}]
@@ -703,9 +712,22 @@ class MapTrainStep:
             if self.ema is not None:
                 self.ema.copy_(self.big)
 
+    def _bind_extra_grads(self) -> None:
+        """p.grad of the pooling head / classifier = views of the flat gradient buffer, so autograd accumulates in place.  Re-bound before every backward: a
+        model.zero_grad() (set_to_none=True is torch's default) would otherwise leave autograd allocating fresh tensors and the flat buffer at zero -- the head
+        would silently train on weight decay alone and drop out of the clip norm, SAM and the all-reduce."""
+        for p, off in zip(self.extras, self._extra_offs):
+            g = self.gbig[off:off + p.numel()].view(p.shape)
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        """optimizer-protocol no-op: the step zeroes its own flat gradient buffer"""
+
     def _fwd_loss_bwd(self, x, y, y_b, lam, sync: bool = True):
         eng, m = self.eng, self.model
         B = x.shape[0]
+        self._bind_extra_grads()
         self.gbig[eng.n_floats:].zero_()
         tokens = eng.forward(x).view(B, eng.tokens, eng.spec.dim).detach().requires_grad_(True)
         pooled = m.attn_pool(tokens)
