@@ -375,6 +375,67 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
         *(f32x4*)(dst + 4) = (f32x4){ocs[4], ocs[5], ocs[6], ocs[7]};
       }
     }
+  } else if constexpr (E == (E_BIAS | E_RES | E_F32)) {
+    // fp32 output + fp32 residual (proj / fc2 into the residual stream): bias is added in the accumulator layout, 32 x 64 fp32 blocks go through the staging
+    // (16-byte chunk c of row r at position c ^ (r & 15)), and a row pass (4 rows x 256 B per instruction) adds the residual rows and stores -- buffer
+    // descriptors again: no 64-bit address arithmetic, no branch, rows beyond M and columns beyond N fall out of range.
+    float* const slab = (float*)stage;
+    const int rrow = lane >> 4, rc = lane & 15;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((unsigned)p.M * (unsigned)p.ldc * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, (int)((unsigned)p.M * (unsigned)p.ldr * 4u), 0x00020000);
+    if constexpr (DEEP >= 0) W4_WAIT_VM(DEEP);
+    if (p.dbg) ts[0] = __builtin_readcyclecounter();
+#pragma unroll
+    for (int cp = 0; cp < NCT / 2; ++cp) {
+      const int ncol = ncol0 + cp * 64 + rc * 4;
+      const bool nok = ncol < p.N;
+      const unsigned lane_out = nok ? (unsigned)rrow * (unsigned)p.ldc * 4u + (unsigned)ncol * 4u : W4_OOB;
+      const unsigned lane_res = nok ? (unsigned)rrow * (unsigned)p.ldr * 4u + (unsigned)ncol * 4u : W4_OOB;
+      f32x4 bias[2][4];
+#pragma unroll
+      for (int ctl = 0; ctl < 2; ++ctl)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = ncol0 + cp * 64 + ctl * 32 + 8 * g + 4 * hi;
+          bias[ctl][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (n < p.N) bias[ctl][g] = *(const f32x4*)(p.bias + n);
+        }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        // the residual rows of this block: requested first, they travel while the block is staged
+        const unsigned srow_r = (unsigned)(mrow0 + rt * 32) * (unsigned)p.ldr * 4u, srow_o = (unsigned)(mrow0 + rt * 32) * (unsigned)p.ldc * 4u;
+        f32x4 r[8];
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+          const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_res, lane_res, srow_r + (unsigned)(ps * 4) * (unsigned)p.ldr * 4u, 0);
+          r[ps] = (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
+        }
+#pragma unroll
+        for (int ctl = 0; ctl < 2; ++ctl)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x16& a = acc[rt][cp * 2 + ctl];
+            const f32x4 x = {a[4 * g] + bias[ctl][g][0], a[4 * g + 1] + bias[ctl][g][1], a[4 * g + 2] + bias[ctl][g][2], a[4 * g + 3] + bias[ctl][g][3]};
+            *(f32x4*)(slab + l31 * 64 + (((ctl * 8 + 2 * g + hi) ^ (l31 & 15)) << 2)) = x;
+          }
+        W4_EPI_SYNC();
+        f32x4 d[8];
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+          const int row = ps * 4 + rrow;
+          d[ps] = *(const f32x4*)(slab + row * 64 + ((rc ^ (row & 15)) << 2));
+        }
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) d[ps] += r[ps];
+        // (everything that touches the row registers precedes the stores; row block in the vector offset: see the bf16 form above)
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+          const u32x4 o = {__float_as_uint(d[ps][0]), __float_as_uint(d[ps][1]), __float_as_uint(d[ps][2]), __float_as_uint(d[ps][3])};
+          __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, lane_out + (srow_o + (unsigned)(ps * 4) * (unsigned)p.ldc * 4u), 0, 0);
+        }
+        W4_EPI_SYNC();
+      }
+    }
   } else {
     float* const slab = (float*)stage;
     float q8_unused = 0.f;
@@ -707,7 +768,8 @@ bool vdk_gemm_w4_serves(const GemmParams& p, bool trans) {
   const double lim = 2147483648.0 - 65536.0;
   if (p.colsum_part || p.sk_cnt || p.a_row_group > 0) return false;
   if ((p.K % 128) || (p.k_per_split % 128) || p.K < 128) return false;
-  if (((double)p.M + 256.0) * (double)p.ldc * 2.0 >= lim || (p.aux && ((double)p.M + 256.0) * (double)p.ldaux * 2.0 >= lim)) return false;   // bf16 rows leave through 32-bit buffer offsets
+  if (((double)p.M + 256.0) * (double)p.ldc * 4.0 >= lim || (p.aux && ((double)p.M + 256.0) * (double)p.ldaux * 2.0 >= lim) ||
+      (p.residual && ((double)p.M + 256.0) * (double)p.ldr * 4.0 >= lim)) return false;   // bf16 rows leave through 32-bit buffer offsets
   if (!trans) return ((double)p.M + 256.0) * (double)p.lda * 2.0 < lim && ((double)p.N + 256.0) * (double)p.ldb * 2.0 < lim;
   return ((double)p.K + 64.0) * (double)p.lda * 2.0 < lim && ((double)p.K + 64.0) * (double)p.ldb * 2.0 < lim;
 }
@@ -717,7 +779,8 @@ bool vdk_gemm_w4h_serves(const GemmParams& p, bool trans) {
   const double lim = 2147483648.0 - 65536.0;
   if (p.colsum_part || p.sk_cnt || p.a_row_group > 0) return false;
   if ((p.K % 64) || (p.k_per_split % 64) || p.K < 64) return false;
-  if (((double)p.M + 256.0) * (double)p.ldc * 2.0 >= lim || (p.aux && ((double)p.M + 256.0) * (double)p.ldaux * 2.0 >= lim)) return false;
+  if (((double)p.M + 256.0) * (double)p.ldc * 4.0 >= lim || (p.aux && ((double)p.M + 256.0) * (double)p.ldaux * 2.0 >= lim) ||
+      (p.residual && ((double)p.M + 256.0) * (double)p.ldr * 4.0 >= lim)) return false;
   if (!trans) return ((double)p.M + 256.0) * (double)p.lda * 2.0 < lim && ((double)p.N + 256.0) * (double)p.ldb * 2.0 < lim;
   return ((double)p.K + 64.0) * (double)p.lda * 2.0 < lim && ((double)p.K + 64.0) * (double)p.ldb * 2.0 < lim;
 }
