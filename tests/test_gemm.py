@@ -269,3 +269,31 @@ def test_gemm_w4_persistent_walk(be, dev, M, N, K, kern):
         assert be.lib.vdk_gemm_last_kernel() == kern
     finally:
         be.lib.vdk_gemm_force_kernel(0)
+
+
+def test_gemm_w4_row_split_for_the_ragged_round(be, dev):
+    """18 tiles on the emulated 16 CUs, K = 1536: the persistent four-wave kernel takes the 8 tile rows of the whole round, the 256x128 kernel the last row
+    (two launches over row ranges of the same operands); outputs, saved pre-activation and column-sum partials against torch on the same bf16 operands"""
+    torch.manual_seed(13)
+    M, N, K = 2200, 300 // 4 * 4 + 4, 1536       # N = 304 -> 2 column tiles
+    a = (torch.randn(M, K) * 0.5).bfloat16().to(dev); b = (torch.randn(N, K) * 0.1).bfloat16().to(dev)
+    bias = torch.randn(N).to(dev); res = torch.randn(M, N).to(dev); u = torch.randn(M, N).bfloat16().to(dev)
+    ref = a.float() @ b.float().T
+    be.lib.vdk_gemm_force_kernel(5)
+    try:
+        out = ops.gemm_nt(a, b, out_dtype=torch.float32, bias=bias, residual=res, backend=be)
+        assert be.lib.vdk_gemm_last_kernel() == 5
+        assert _rel(out, ref + bias + res) < 1e-5
+        aux = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        out = ops.gemm_nt(a, b, bias=bias, act=ops.ACT_GELU, aux=aux, backend=be)
+        assert _rel(aux.float(), (ref + bias).bfloat16().float()) < 3e-3
+        assert _rel(out.float(), torch.nn.functional.gelu(ref + bias).bfloat16().float()) < 4e-3
+        rows = be.lib.vdk_gemm_c_colsum_rows(M, N, K)
+        part = torch.full((rows, N), float("nan"), dtype=torch.float32, device=dev)
+        out = ops.gemm_nt(a, b, act=ops.ACT_DGELU, aux=u, c_colsum=part, backend=be)
+        uu = u.float().requires_grad_(True)
+        torch.nn.functional.gelu(uu).sum().backward()
+        assert _rel(out.float(), (ref * uu.grad).bfloat16().float()) < 4e-3
+        torch.testing.assert_close(part.sum(0).cpu(), out.float().sum(0).cpu(), rtol=1e-4, atol=2e-3)
+    finally:
+        be.lib.vdk_gemm_force_kernel(0)

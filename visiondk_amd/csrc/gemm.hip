@@ -687,18 +687,29 @@ static bool w4_enabled_env() {
   static const bool on = !(getenv("VDK_GEMM_W4") && atoi(getenv("VDK_GEMM_W4")) == 0);
   return on;
 }
-// ... and which epilogue forms go to the 256x128 / two-workgroups-per-CU form instead (gemm_w4h_kernel): the ones whose epilogue is long (GELU / dGELU arithmetic,
-// fp32 residual traffic) -- a second resident workgroup multiplies meanwhile.  VDK_GEMM_W4H: bit mask over {1: GELU, 2: dGELU, 4: residual, 8: everything else NT, 16: TN}.
-static bool w4h_wanted(int E, bool trans) {
-  static const int mask = getenv("VDK_GEMM_W4H") ? atoi(getenv("VDK_GEMM_W4H")) : (1 | 2 | 4);
+// ... and which problems go to the 256x128 / two-workgroups-per-CU form instead (gemm_w4h_kernel): the ones whose epilogue is long -- a second resident workgroup
+// multiplies meanwhile -- and short problems with few tiles per CU.  VDK_GEMM_W4H (optional): explicit bit mask over {1: GELU, 2: dGELU, 4: residual, 8: other NT, 16: TN}.
+static bool w4h_wanted(int E, bool trans, long M, long N, long K) {
+  static const int mask = getenv("VDK_GEMM_W4H") ? atoi(getenv("VDK_GEMM_W4H")) : -1;
   if (g_force_kernel == 6) return true;
-  if (g_force_kernel == 2 || g_force_kernel == 3 || g_force_kernel == 5 || g_force_kernel == 6 || !w4_enabled_env()) return false;
-  if (trans) return (mask & 16) != 0;
-  if (E == E_GENERIC) return false;
-  if (E & E_GELU) return (mask & 1) != 0;
-  if (E & E_DGELU) return (mask & 2) != 0;
-  if (E & E_RES) return (mask & 4) != 0;
-  return (mask & 8) != 0;
+  if (g_force_kernel == 2 || g_force_kernel == 3 || g_force_kernel == 5 || !w4_enabled_env()) return false;
+  if (mask >= 0) {   // explicit choice per form
+    if (trans) return (mask & 16) != 0;
+    if (E == E_GENERIC) return false;
+    if (E & E_GELU) return (mask & 1) != 0;
+    if (E & E_DGELU) return (mask & 2) != 0;
+    if (E & E_RES) return (mask & 4) != 0;
+    return (mask & 8) != 0;
+  }
+  // default, from tools/bench_gemm_w4.py at the ViT-B/16 shapes (T = 50 432; us, persistent four-wave / 256x128 two-workgroup form):
+  //   dGELU + column sums 393 / 335 -> 256x128;  GELU + saved pre-activation 327 / 336 -> four-wave;  fp32 residual: K 768 111 / 105, K 3072 239 / 255 -> by K;
+  //   light epilogues: N 768 K 768 63 / 56 -> 256x128 when the k-range is short and every CU gets at most ~3 tiles, else four-wave (158-205 / 162-221);  TN -> four-wave
+  if (trans || E == E_GENERIC) return false;
+  if (E & E_DGELU) return true;
+  if (E & E_GELU) return false;
+  if (E & E_RES) return K < 1536;
+  const long tiles = ((M + 255) / 256) * ((N + 255) / 256);
+  return K <= 1024 && tiles <= 3 * 256;
 }
 static bool w4_enabled() {
   return (w4_enabled_env() || g_force_kernel == 5) && g_force_kernel != 2 && g_force_kernel != 3 && g_force_kernel != 6;
@@ -881,7 +892,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   } while (0)
 #define LAUNCH256X(TNF, EE, CSF)                                                                                         \
   do {                                                                                                                   \
-    if (!sk && !(CSF) && w4h_wanted(EE, TNF) && vdk_gemm_w4h_serves(p, TNF) &&                                           \
+    if (!sk && !(CSF) && w4h_wanted(EE, TNF, p.M, p.N, p.K) && vdk_gemm_w4h_serves(p, TNF) &&                                           \
         vdk_gemm_w4h_launch(p, TNF, EE, grid256.y, stream, prof ? (void*)g_prof_ev[g_prof_used] : nullptr,               \
                             prof ? (void*)g_prof_ev[g_prof_used + 1] : nullptr)) { g_last_kernel = 6; break; }           \
     if (!sk && !(CSF) && w4_enabled() && vdk_gemm_w4_serves(p, TNF) &&                                                   \

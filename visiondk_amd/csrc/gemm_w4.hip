@@ -798,17 +798,48 @@ static int w4_cus() {
 #define W4_LAUNCH(TNF, EE)                                                                                                                    \
   do {                                                                                                                                        \
     if (persist) {                                                                                                                            \
-      if (ev0) hipExtLaunchKernelGGL((gemm_w4_kernel<TNF, EE, true>), pgrid, dim3(256), 0, stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, p);   \
+      if (ev0 || ev1) hipExtLaunchKernelGGL((gemm_w4_kernel<TNF, EE, true>), pgrid, dim3(256), 0, stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, p);   \
       else hipLaunchKernelGGL((gemm_w4_kernel<TNF, EE, true>), pgrid, dim3(256), 0, stream, p);                                               \
     } else {                                                                                                                                  \
-      if (ev0) hipExtLaunchKernelGGL((gemm_w4_kernel<TNF, EE, false>), grid, dim3(256), 0, stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, p);   \
+      if (ev0 || ev1) hipExtLaunchKernelGGL((gemm_w4_kernel<TNF, EE, false>), grid, dim3(256), 0, stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, p);   \
       else hipLaunchKernelGGL((gemm_w4_kernel<TNF, EE, false>), grid, dim3(256), 0, stream, p);                                               \
     }                                                                                                                                         \
     return true;                                                                                                                              \
   } while (0)
 
+static bool w4_launch_one(const GemmParams& p, bool trans, int E, unsigned tiles, unsigned splitk, hipStream_t stream, void* ev0, void* ev1);
+
 bool vdk_gemm_w4_launch(const GemmParams& p, bool trans, int E, unsigned tiles, unsigned splitk, void* stream_, void* ev0, void* ev1) {
   hipStream_t stream = (hipStream_t)stream_;
+  const unsigned G = (unsigned)w4_cus();
+  // The ragged last round.  T tiles on G CUs take ceil(T / G) rounds of whole tiles (591 on 256: 2.31 -> 3).  When the tile rows beyond the last whole round are
+  // few (at most G / 2 tiles) and the k-range is long enough to pay for a second launch, the whole rounds go to the persistent kernel and the remaining ROWS to the
+  // 256x128 kernel, whose workgroups then each have a CU to themselves: 2.31 -> ~2.5 rounds.  Both launches are ordinary GEMMs over a row range of the operands.
+  static const bool split_on = !(getenv("VDK_GEMM_W4_SPLIT") && atoi(getenv("VDK_GEMM_W4_SPLIT")) == 0);
+  if (split_on && !trans && splitk == 1 && tiles > G && p.K >= 1536 && E != E_GENERIC && !(E & (E_ROWGRP | E_MSTAT | E_MGRAD | E_SPLITK))) {
+    const unsigned ntn = (unsigned)((p.N + 255) / 256), ntm = (unsigned)((p.M + 255) / 256);
+    const unsigned rows1 = (tiles / G) * G / ntn;         // tile rows covered by whole rounds
+    const unsigned rem_tiles = (ntm - rows1) * ntn;
+    if (rows1 > 0 && rem_tiles > 0 && 2 * rem_tiles <= G) {
+      GemmParams p1 = p, p2 = p;
+      const long m1 = (long)rows1 * 256;
+      p1.M = (int)m1;
+      p2.M = p.M - (int)m1;
+      p2.A = p.A + m1 * p.lda;
+      p2.C = (char*)p.C + m1 * p.ldc * ((E & E_F32) ? 4 : 2);
+      if (p.residual) p2.residual = p.residual + m1 * p.ldr;
+      if (p.aux) p2.aux = p.aux + m1 * p.ldaux;
+      if (p.ocs_part) p2.ocs_part = p.ocs_part + (size_t)rows1 * 2 * p.N;
+      if (vdk_gemm_w4h_serves(p2, false)) {
+        w4_launch_one(p1, false, E, rows1 * ntn, 1u, stream, ev0, nullptr);
+        return vdk_gemm_w4h_launch(p2, false, E, 1u, stream_, nullptr, ev1);
+      }
+    }
+  }
+  return w4_launch_one(p, trans, E, tiles, splitk, stream, ev0, ev1);
+}
+
+static bool w4_launch_one(const GemmParams& p, bool trans, int E, unsigned tiles, unsigned splitk, hipStream_t stream, void* ev0, void* ev1) {
   const dim3 grid(tiles, splitk);
   const unsigned G = (unsigned)w4_cus();
   const bool persist = splitk == 1 && tiles > G;          // more tiles than CUs: walk them (with one tile per workgroup there is nothing to prefetch)
@@ -841,7 +872,7 @@ bool vdk_gemm_w4_launch(const GemmParams& p, bool trans, int E, unsigned tiles, 
 
 #define W4H_LAUNCH(TNF, EE)                                                                                                             \
   do {                                                                                                                                  \
-    if (ev0) hipExtLaunchKernelGGL((gemm_w4h_kernel<TNF, EE>), grid, dim3(256), 0, stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, p);     \
+    if (ev0 || ev1) hipExtLaunchKernelGGL((gemm_w4h_kernel<TNF, EE>), grid, dim3(256), 0, stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, p);     \
     else hipLaunchKernelGGL((gemm_w4h_kernel<TNF, EE>), grid, dim3(256), 0, stream, p);                                                 \
     return true;                                                                                                                        \
   } while (0)
