@@ -64,7 +64,8 @@ def cpu_baseline_vit(seconds_budget: float = 25.0):
 def parity_vit(be, dev):
     """Full-size parity before timing: ViT-B/16 (BASELINE.json configs[1]) forward + backward at batch 8, the HIP engine against the oracle's bf16-operand mode
     (o32 / o64 = float32 / float64 accumulation) and its fp32 mode; `floor` = o32 vs o64, two valid evaluations of the same bf16-operand arithmetic
-    (tests/test_parity_bf16.py explains why no bf16-operand engine can sit below it).  Frobenius-relative errors."""
+    (tests/test_parity_bf16.py explains why no bf16-operand engine can sit below it).  Independent arm: the same fp32 module under torch.autocast("cpu", bfloat16)
+    (`torch_autocast_vs_fp32`: what PyTorch's own bf16 autocast costs this network; `vs_torch_autocast`: the engine against it).  Frobenius-relative errors."""
     from oracle.parity import vit_fwd_bwd_vs_oracle, vit_pair
     ref, model = vit_pair(be, dev, 224, 16, 768, 12, 12, 3072, 1000, seed=2)
     torch.manual_seed(6)
@@ -195,8 +196,13 @@ def bench_cbir(dev, nq=10000, n=1_000_000, d=128, k=100, iters=6, with_cpu=True)
         from oracle import cbir as ocbir
         qs = qry[:64].cpu().numpy(); gs = gal[:500_000].cpu().numpy()
         t0 = time.time(); so, io = ocbir.flat_ip_search(qs, gs, k); dt = time.time() - t0
-        out["cpu_baseline"] = {"value": 64 * 500_000 / dt, "unit": "pairs/sec", "cores": ocbir.usable_cores(), "kind": "port",
-                               "sample": "oracle/cbir_oracle.c (OpenMP, AVX2 fmaf chains): 64 queries x 500k gallery rows, D=128, k=100"}
+        out["cpu_baseline_c_port"] = {"value": 64 * 500_000 / dt, "unit": "pairs/sec", "cores": ocbir.usable_cores(), "kind": "port",
+                                      "sample": "oracle/cbir_oracle.c (OpenMP, AVX2 fmaf chains): 64 queries x 500k gallery rows, D=128, k=100"}
+        # the whole gallery against the oracle: the timed search's own answer for the first 1024 queries x all 1 M rows (the 64 x 500 k check below is a prefix problem)
+        t0 = time.time(); so_f, io_f = ocbir.flat_ip_search(qry[:1024].cpu().numpy(), gal.cpu().numpy(), k); dt_f = time.time() - t0
+        out["parity_full_gallery_vs_oracle"] = {"queries": 1024, "gallery_rows": n, "indices_equal": bool((i[:1024].cpu().numpy() == io_f).all()),
+                                                "scores_bit_equal": bool((s[:1024].cpu().numpy().view("uint32") == so_f.view("uint32")).all()),
+                                                "oracle_seconds": round(dt_f, 2), "oracle_pairs_per_sec": 1024 * n / dt_f}
         # BASELINE.md §3's protocol beside it: the loop the reference's faiss call stands for, torch.topk(q @ G.T, k) in query batches of 256 over the FULL gallery, fp32, all cores
         # (bounded: 4 batches = 1024 queries x 1 M rows, ~3 s; the whole 10 k would be ~30 s)
         torch.set_num_threads(ocbir.usable_cores())
@@ -206,8 +212,9 @@ def bench_cbir(dev, nq=10000, n=1_000_000, d=128, k=100, iters=6, with_cpu=True)
         for i0 in range(0, 1024, 256):
             torch.topk(qh[i0:i0 + 256] @ gh.t(), k)
         dt2 = time.time() - t0
-        out["cpu_baseline_torch_topk"] = {"value": 1024 * n / dt2, "unit": "pairs/sec", "cores": torch.get_num_threads(), "kind": "port",
-                                          "sample": "torch.topk(q @ G.T, 100), fp32, query batches of 256, 4 batches over the full 1 M x 128 gallery"}
+        # (the faster of the two CPU paths, and the one BASELINE.md §3 describes: this is the baseline the GPU number stands beside)
+        out["cpu_baseline"] = {"value": 1024 * n / dt2, "unit": "pairs/sec", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "torch.topk(q @ G.T, 100), fp32, query batches of 256, 4 batches over the full 1 M x 128 gallery"}
         del gh, qh
         # parity on the sample: the GPU's answer restricted to the same gallery prefix
         idx2 = cbir.FlatIPIndex(d, device=dev); idx2.add(gal[:500_000])

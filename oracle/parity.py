@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE: one forward + backward of a HIP engine against three evaluations of the oracle (used by tests/test_parity_bf16.py and by bench.py's
+"""TEST INFRASTRUCTURE: one forward + backward of a HIP engine against four evaluations of the oracle (the fourth: the fp32 module under torch.autocast("cpu", bfloat16)) (used by tests/test_parity_bf16.py and by bench.py's
 `parity` leg, never by the product): bf16 operands with float32 accumulation (`o32`), the same arithmetic with float64 accumulation (`o64`), and plain
 fp32 (what the reference runs on CPU, engine/procedure/train.py:118 with autocast off).  The distance between o32 and o64 -- two valid evaluations of the same
 bf16-operand arithmetic -- is the floor below which no bf16-operand engine can be pinned (see tests/test_parity_bf16.py)."""
@@ -47,6 +47,19 @@ def vit_fwd_bwd_vs_oracle(ref, model, x, y, dev, smoothing=0.05):
             l2.backward()
         evals[name] = (lr.detach().double(), l2.item(), {n: p.grad.detach().double() for n, p in net.named_parameters()})
 
+    # An arm that is not the builder's own arithmetic: the same fp32 module under torch.autocast("cpu", dtype=bfloat16) -- PyTorch's own choice of which ops read
+    # bf16 operands (what engine/procedure/train.py:118 switches on for the reference, CPU op lists instead of CUDA's).  Its distance from fp32 is an independent
+    # measurement of what bf16 operands cost this network; its distance from o32 says how well oracle/bf16ops.py restates autocast.
+    for p in ref.parameters():
+        p.grad = None
+    with bf16ops.precision("fp32"), torch.autocast("cpu", dtype=torch.bfloat16):
+        lr = ref(x)
+        l2 = torch.nn.functional.cross_entropy(lr.float(), y, label_smoothing=smoothing)
+    l2.backward()
+    evals["autocast"] = (lr.detach().double(), l2.item(), {n: p.grad.detach().double() for n, p in ref.named_parameters()})
+    for p in ref.parameters():
+        p.grad = None
+
     def dist(a, b):     # (logits, loss, worst gradient, its name) of evaluation a against evaluation b
         worst, wn = 0.0, None
         for n in a[2]:
@@ -56,7 +69,9 @@ def vit_fwd_bwd_vs_oracle(ref, model, x, y, dev, smoothing=0.05):
         return {"logits": _rel(a[0], b[0]), "loss": abs(a[1] - b[1]) / abs(b[1]), "worst_grad": worst, "worst_grad_name": wn}
 
     e = (logits.detach().double().cpu(), loss.item(), eng)
-    out = {"vs_o32": dist(e, evals["o32"]), "vs_o64": dist(e, evals["o64"]), "vs_fp32": dist(e, evals["fp32"]), "floor_o32_vs_o64": dist(evals["o32"], evals["o64"])}
+    out = {"vs_o32": dist(e, evals["o32"]), "vs_o64": dist(e, evals["o64"]), "vs_fp32": dist(e, evals["fp32"]), "floor_o32_vs_o64": dist(evals["o32"], evals["o64"]),
+           "vs_torch_autocast": dist(e, evals["autocast"]), "torch_autocast_vs_fp32": dist(evals["autocast"], evals["fp32"]),
+           "torch_autocast_vs_o32": dist(evals["autocast"], evals["o32"])}
     for p in model.parameters():
         p.grad = None
     return out

@@ -15,13 +15,19 @@ included (it would miss itself by 5e-3 under a different summation order); it IS
 and the bf16 engine meets it per kernel on identical operands (tests/test_gemm.py, test_attention.py: 1e-5 ... 2e-4).
 
 One full-width block (batch 8): floor 2.6e-3 / 5.0e-3, engine 2.6e-3 / 5.1e-3 and 2.4e-3 / 5.1e-3.
-Absolute bounds, asserted next to the floor criterion (Frobenius-relative): toy widths (2 blocks): logits 2e-3, gradients 6e-3; one full-width block: 6e-3 / 1.2e-2;
-full depth: 1.5e-2 / 3e-2 (each ~3x the measured floor: a dropped term or a wrong scale is O(1))."""
+Absolute bounds, asserted next to the floor criterion (Frobenius-relative), 1.5x the measured engine values: toy widths (2 blocks): logits 2e-3, gradients 6e-3;
+one full-width block: 3.9e-3 / 7.7e-3; full depth: 7.8e-3 / 1.4e-2.
+
+Both arms of that floor are oracle/bf16ops.py, the builder's own restatement of autocast.  The independent arm (round 3): the oracle's plain fp32 module under
+`torch.autocast("cpu", dtype=torch.bfloat16)` -- PyTorch's own choice of which ops read bf16 operands, the mechanism engine/procedure/train.py:118 switches on for the
+reference.  Measured on the 2-block toys (CPU): PyTorch's autocast lands 3.7e-3 ... 5.7e-3 (logits) / 6.5e-3 ... 7.0e-3 (worst gradient) from fp32, the engine
+2.0e-3 ... 3.4e-3 / 5.8e-3 ... 6.4e-3: the engine is CLOSER to the fp32 path than the reference's own mixed-precision mechanism is.  Asserted: the engine's distance
+from fp32 is at most 1.25x torch.autocast's, for logits and for the worst gradient."""
 import pytest
 import torch
 
 LOGITS_TOL_TOY, LOSS_TOL, GRAD_TOL = 2e-3, 1e-3, 6e-3
-LOGITS_TOL_FULL, GRAD_TOL_FULL = 1.5e-2, 3e-2
+LOGITS_TOL_FULL, GRAD_TOL_FULL = 7.8e-3, 1.4e-2
 
 
 from oracle.parity import vit_fwd_bwd_vs_oracle as check_fwd_bwd, vit_pair as _pair  # noqa: E402
@@ -35,6 +41,8 @@ def assert_within_floor(r, logits_tol, grad_tol=GRAD_TOL):
         assert got["worst_grad"] <= 1.5 * fl["worst_grad"] + 1e-5, (side, got, fl)
         assert got["logits"] < logits_tol and got["loss"] < LOSS_TOL and got["worst_grad"] < grad_tol, (side, got)
     assert r["vs_fp32"]["logits"] < 2e-2          # and the engine is a bf16-operand engine, not something else
+    ac = r["torch_autocast_vs_fp32"]              # independent arm: no further from fp32 than PyTorch's own bf16 autocast of the same module
+    assert r["vs_fp32"]["logits"] <= 1.25 * ac["logits"] + 1e-5 and r["vs_fp32"]["worst_grad"] <= 1.25 * ac["worst_grad"] + 1e-5, (r["vs_fp32"], ac)
 
 
 @pytest.mark.parametrize("img,patch,B", [(32, 8, 3), (64, 8, 4), (112, 8, 2)])       # 17, 65 and 197 tokens
@@ -71,4 +79,4 @@ def test_vit_base_width_single_block_vs_bf16_operand_oracle(hip):
     y = torch.randint(0, 1000, (8,))
     r = check_fwd_bwd(ref, model, x, y, "cuda:0")
     print(r)
-    assert_within_floor(r, 6e-3, 1.2e-2)
+    assert_within_floor(r, 3.9e-3, 7.7e-3)

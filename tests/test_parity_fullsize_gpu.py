@@ -5,7 +5,8 @@
 The engines multiply in bf16 (operands rounded, fp32 accumulation, fp32 master weights): against an fp32 oracle every tensor carries the operand-rounding noise of
 its own GEMM chain (2^-9 per operand element, averaged over the contraction, compounding with depth), the same noise the reference's own autocast path has
 against ITS fp32 path; tests/test_parity_bf16.py measures that floor for the ViT and shows the engine sits on it.  Bounds below are Frobenius-relative and were
-set at ~2x the values measured on the MI355X (printed by the test): a dropped term, a wrong scale or a mis-indexed tile is O(1).
+set at 1.5x the values measured on the MI355X (printed by the test; fixed seeds, and the GEMM kernels of all three structures are bit-equal on the same
+operands, so the values do not move with the kernel choice): a dropped term, a wrong scale or a mis-indexed tile is O(1).
 Measured (round 2): ConvNeXt-B + ArcFace 100k, batch 8: embeddings 5.8e-3, loss 9.2e-5, dfeats 1.9e-3, dW 6.1e-3 (worst sampled class column 3.5e-2), worst backbone
 gradient 4.2e-2 (stages.3.blocks.2.mlp.fc2.bias).  ResNet-18, batch 16: loss 4.7e-5; gradients: floor (oracle fp32- vs fp64-accumulate, same bf16 storage points)
 median 0.184 / worst 0.247, engine 0.184 / 0.227 from the fp32 one and 0.185 / 0.242 from the fp64 one -- a train-mode-BatchNorm + ReLU network at random init is
@@ -70,8 +71,9 @@ def test_convnext_base_neck_arcface_100k_forward_backward_vs_oracle(hip):
         worst = max(worst, (r, n))
     res["worst_backbone_grad"] = worst
     print(res)
-    assert res["emb"] < 2e-2 and res["loss"] < 2e-3 and res["dfeats"] < 3e-2 and res["dW"] < 3e-2 and res["dW_sampled_cols"] < 5e-2
-    assert worst[0] < 6e-2, worst
+    # 1.5x the measured 5.8e-3 / 9.2e-5 / 1.9e-3 / 6.1e-3 / 3.5e-2 and 4.2e-2
+    assert res["emb"] < 8.7e-3 and res["loss"] < 1.4e-4 and res["dfeats"] < 2.9e-3 and res["dW"] < 9.2e-3 and res["dW_sampled_cols"] < 5.3e-2, res
+    assert worst[0] < 6.3e-2, worst
 
 
 def test_resnet18_every_gradient_vs_oracle(hip):
@@ -127,9 +129,9 @@ def test_siglip_vit_large_336_forward_backward_vs_oracle(hip):
     errs = sorted(((_rel(got[n].grad, p.grad), n) for n, p in ref.named_parameters()), reverse=True)
     print({"logits_rel": _rel(lo.detach(), lr.detach()), "loss": (loss.item(), loss_r.item()), "worst_grads": errs[:4], "median_grad": errs[len(errs) // 2]})
     # measured on the MI355X: logits 4.2e-3, loss 7.32099 vs 7.32202, worst gradient 8.0e-3 (blocks.0.norm2.weight), median 5.0e-3
-    assert _rel(lo.detach(), lr.detach()) < 8e-3 and abs(loss.item() - loss_r.item()) < 5e-4 * abs(loss_r.item())
-    assert errs[0][0] < 1.5e-2, errs[:4]
-    assert errs[len(errs) // 2][0] < 1e-2
+    assert _rel(lo.detach(), lr.detach()) < 6.3e-3 and abs(loss.item() - loss_r.item()) < 2.1e-4 * abs(loss_r.item())      # 1.5x measured
+    assert errs[0][0] < 1.2e-2, errs[:4]
+    assert errs[len(errs) // 2][0] < 7.5e-3
     # the same model with fp8 operands in the block Linears (current scaling = the calibration step, then delayed scaling from the recorded maxima)
     def run():
         for q in model.parameters():
@@ -143,7 +145,7 @@ def test_siglip_vit_large_336_forward_backward_vs_oracle(hip):
     print({"fp8_current": (lc, ec[0], ec[len(ec) // 2]), "fp8_delayed": (ld, ed[0], ed[len(ed) // 2])})
     # measured: logits 6.8e-2, worst gradient 1.33e-1 (pos_embed), median 7.6e-2 -- e4m3 / e5m2 operands (2^-4 / 2^-3 relative rounding) through 24 blocks; the delayed-scaling
     # pass (fp8 copies written by the producing kernels) reproduces the calibration pass exactly on the same data
-    assert lc < 1e-1 and ld < 1e-1 and ec[0][0] < 2e-1 and ed[0][0] < 2e-1 and ec[len(ec) // 2][0] < 1.2e-1
+    assert lc < 1e-1 and ld < 1e-1 and ec[0][0] < 2e-1 and ed[0][0] < 2e-1 and ec[len(ec) // 2][0] < 1.14e-1      # 1.5x measured
     assert abs(lc - ld) < 1e-6
 
 
@@ -165,5 +167,5 @@ def test_arcface_head_at_one_million_identities_vs_oracle(hip, planes):
            "dW_target_cols": max(_rel(dW[:, c], W.grad[:, c]) for c in y[:32].tolist())}
     print(planes, res)
     # measured: loss 4.9e-6 / 7.4e-8 (1 / 3 planes), dfeats 2.1e-3, dW 2.0e-3, target columns 2.8e-3 (the backward GEMMs take bf16 operands in both modes)
-    tol = {1: (5e-5, 5e-3, 5e-3, 8e-3), 3: (2e-6, 5e-3, 5e-3, 8e-3)}[planes]
+    tol = {1: (7.4e-6, 3.2e-3, 3.0e-3, 4.2e-3), 3: (2e-7, 3.2e-3, 3.0e-3, 4.2e-3)}[planes]      # 1.5x measured (3 planes: the loss is at fp32 summation noise, 2e-7)
     assert res["loss"] < tol[0] and res["dfeats"] < tol[1] and res["dW"] < tol[2] and res["dW_target_cols"] < tol[3], res
