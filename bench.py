@@ -2,14 +2,15 @@
 """bench.py — BASELINE.json's headline metric on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+    (N > 1: either under a launcher -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ... --
+     or bare: with WORLD_SIZE unset, `python bench.py --gpus N` starts its N ranks itself)
 
 Workload (BASELINE.json configs[1]): ViT-B/16 classifier, bf16 MFMA operands / fp32 accumulate + fp32 master weights,
 synthetic ImageNet-1k 224x224, batch 256 PER GPU (weak scaling), one step = forward + CE(label_smoothing 0.05) +
 backward + [RCCL all-reduce of the flat gradient, overlapped] + clip(10) + SGD(0.006, 0.937, 5e-4) + EMA (rank 0), i.e.
 Trainer.compute_loss + Trainer.update of the reference (engine/procedure/train.py:177-215, configs/classification/pet.yaml).
 Inputs are resident in HBM before the timed region.  Secondary metric (same JSON line, key "cbir"): CBIR query-pairs/s,
-10k queries x 1M gallery, D=128, k=100 (configs[3] on one GPU).
+10k queries x 1M gallery, D=128, k=100 (configs[3] on one GPU; at N > 1 the gallery is row-sharded over the ranks, 125 k rows each at N = 8).
 
 Prints ONE JSON line on rank 0 (driver contract) with `roofline` (dominant kernel: the bf16 GEMM, timed live with HIP events
 on its launch stream inside the timed region) and `cpu_baseline` (the oracle restatement timed on this box's host cores,
@@ -231,6 +232,138 @@ def bench_cbir(dev, nq=10000, n=1_000_000, d=128, k=100, iters=6, with_cpu=True)
     return out
 
 
+def _sync(dev):
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+
+
+def _barrier(world):
+    if world > 1:
+        dist.barrier()
+
+
+def _max_over_ranks(dt: float, world: int, dev) -> float:
+    if world == 1:
+        return dt
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def train_leg(be, dev, rank: int, world: int, steps: int, warmup: int, batch: int, spec=None, img: int = 224, classes: int = 1000, events: bool = True,
+              bucket_bytes: int = 24 << 20):
+    """Hot path A on this rank (one process per GPU): W warm-up steps, barrier + sync, K timed steps, sync + barrier, MAX over ranks.
+    Returns (seconds for K steps, final loss, gemm event totals or None, collectives issued).  N > 1: the flat gradient leaves in buckets from inside the backward
+    (visiondk_amd/comm.py), overlapped with the remaining backward kernels.  The same function runs on CPU over gloo with the emulated kernels (tests/test_ddp_gloo.py)."""
+    from visiondk_amd import comm as vcomm, vit
+    if spec is None:
+        spec = vit.spec_from_timm_name("vit_base_patch16_224", classes)
+    model = vit.VisionTransformer(spec, device=dev, backend=be, seed=2)
+    comm = vcomm.GradAllReduce(bucket_bytes=bucket_bytes) if world > 1 else None      # FusedTrainStep broadcasts rank 0's weights (DDP-constructor semantics)
+    step = vit.FusedTrainStep(model, lr=0.006, momentum=0.937, weight_decay=5e-4, label_smoothing=0.05, max_norm=10.0, ema=(rank == 0), comm=comm)
+    g = torch.Generator(device="cpu"); g.manual_seed(1000 + rank)
+    x = torch.randn(batch, 3, img, img, generator=g).to(dev)
+    y = torch.randint(0, classes, (batch,), generator=g).to(dev)
+    for _ in range(warmup):
+        step.step(x, y)
+    _sync(dev); _barrier(world)
+    # live per-launch timing of the dominant kernel (bf16 GEMM) with HIP events on the launch stream
+    launches_per_step = (7 * spec.depth * 2 + 8) * 2            # (a GEMM that splits its rows over two kernels carries one pair per kernel)
+    ev = events and dev.type == "cuda" and os.environ.get("VDK_BENCH_NO_EVENTS") != "1"      # (diagnostic: what the per-launch HIP events themselves cost)
+    if ev:
+        be.check(be.lib.vdk_prof_begin(launches_per_step * steps + 64), "vdk_prof_begin")
+    _sync(dev)
+    t0 = time.perf_counter()
+    for it in range(steps):
+        if ev:      # every GEMM launch of every 4th timed step carries a (start, stop) event pair: a timed dispatch costs ~5 us of queue time, 0.7-1.0 ms per step if all 149 are timed
+            be.lib.vdk_prof_pause(0 if it % GEMM_EVENT_STRIDE == 0 else 1)
+        step.step(x, y)
+    _sync(dev); _barrier(world)
+    dt = time.perf_counter() - t0
+    gemm = None
+    if ev:
+        gemm_ms, gemm_n, gemm_fl, gemm_bytes = C.c_double(0), C.c_int64(0), C.c_double(0), C.c_double(0)
+        be.check(be.lib.vdk_prof_end(C.byref(gemm_ms), C.byref(gemm_n), C.byref(gemm_fl)), "vdk_prof_end")
+        be.check(be.lib.vdk_prof_bytes(C.byref(gemm_bytes)), "vdk_prof_bytes")
+        gemm = {"ms": gemm_ms.value, "n": gemm_n.value, "flops": gemm_fl.value, "bytes": gemm_bytes.value}
+    dt = _max_over_ranks(dt, world, dev)
+    loss = step.loss_value()
+    ncoll = comm.collectives if comm is not None else 0
+    del step, model
+    return dt, loss, gemm, ncoll
+
+
+def cbir_sharded_leg(be, dev, rank: int, world: int, nq: int = 10000, n: int = 1_000_000, d: int = 128, k: int = 100, iters: int = 6, warm: int = 3, cap=None,
+                     check_queries: int = 16):
+    """Hot path B at N > 1: the gallery's rows are sharded over the ranks (n / world each, 125 k at N = 8), every rank owns nq / world of the
+    queries; one search = all-gather of the queries, every rank scans its shard for ALL queries, all-to-all of the per-shard top-k lists, merge
+    (visiondk_amd/cbir.py search_sharded).  Strong scaling: nq x n pairs per search whatever N is.  Timing: barrier + sync, `iters` searches, sync + barrier, MAX
+    over ranks.  Rank 0 checks its first `check_queries` queries against the oracle over the WHOLE gallery (every shard regenerated on the host from its seed)."""
+    from visiondk_amd import cbir
+    rows = [n // world + (1 if r < n % world else 0) for r in range(world)]
+    qn = [nq // world + (1 if r < nq % world else 0) for r in range(world)]
+    base = sum(rows[:rank])
+
+    def shard(r):          # rank r's gallery rows, the same on whichever host generates them
+        g = torch.Generator(device="cpu"); g.manual_seed(7000 + r)
+        return torch.nn.functional.normalize(torch.randn(rows[r], d, generator=g))
+
+    def queries(r):
+        g = torch.Generator(device="cpu"); g.manual_seed(9000 + r)
+        return torch.nn.functional.normalize(torch.randn(qn[r], d, generator=g))
+
+    gal = shard(rank).to(dev); qry = queries(rank).to(dev)
+    kw = {} if cap is None else {"cap": cap}
+    index = cbir.FlatIPIndex(d, backend=be, device=dev, idx_base=base, **kw)
+    index.add(gal)
+    s = i = None
+    for _ in range(warm):
+        s, i = cbir.search_sharded(qry, gal, k, base, backend=be, device=dev, query_counts=qn, index=index)
+    _sync(dev); _barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        s, i = cbir.search_sharded(qry, gal, k, base, backend=be, device=dev, query_counts=qn, index=index)
+    _sync(dev); _barrier(world)
+    dt = _max_over_ranks(time.perf_counter() - t0, world, dev) / iters
+    out = {"metric": "CBIR query-pairs/sec (exact fp32 inner product + top-100), gallery sharded over the ranks", "value": nq * n / dt, "unit": "pairs/sec",
+           "ms_per_search": dt * 1e3, "n_gpus": world, "scaling": "strong",
+           "config": {"workload": f"cbir Q={nq} N={n} D={d} k={k} fp32 gallery, {rows[0]} rows and {qn[0]} queries per rank",
+                      "exchange": "all-gather of the queries, all-to-all of the per-shard top-k lists (scores + global row ids), merge by (score desc, index asc)"}}
+    if rank == 0 and check_queries > 0:
+        from oracle import cbir as ocbir
+        whole = torch.cat([shard(r) for r in range(world)]).numpy()
+        nchk = min(check_queries, qn[0])
+        so, io = ocbir.flat_ip_search(queries(0)[:nchk].numpy(), whole, k)
+        out["parity_vs_oracle"] = {"queries": nchk, "gallery_rows": n, "indices_equal": bool((i[:nchk].cpu().numpy() == io).all()),
+                                   "scores_bit_equal": bool((s[:nchk].cpu().numpy().view("uint32") == so.view("uint32")).all())}
+    return out
+
+
+def rccl_topology_lines(path: str, limit: int = 24):
+    """the ring / tree / transport lines RCCL logged at communicator creation (NCCL_DEBUG=INFO, subsystems INIT + GRAPH, written to `path` by rank 0)"""
+    import re
+    try:
+        with open(path, errors="replace") as f:
+            lines = f.read().splitlines()
+    except OSError:
+        return None
+    pat = re.compile(r"(Ring \d+|Trees? |Channel \d+|channels|xgmi|XGMI|via P2P|via SHM|NET/|RCCL version|NCCL version|comm 0x.* rank 0 nranks)", re.I)
+    keep = [re.sub(r"^\S+:\d+:\d+ \[\d+\] ", "", ln) for ln in lines if pat.search(ln)]
+    return keep[:limit]
+
+
+def self_spawn(n: int):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, the same torch.distributed.run line the driver uses) and
+    pass their output and exit code through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(Path(__file__).resolve()), *sys.argv[1:]]
+    raise SystemExit(subprocess.call(cmd))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,68 +375,38 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_spawn(args.gpus)
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    comm = None
+    rccl_log = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")      # = the CUs GradAllReduce keeps out of the persistent GEMM grids (profiles/r03_w4_contention.json)
+        if rank == 0 and "NCCL_DEBUG" not in os.environ:      # the rings / trees RCCL builds over xGMI, quoted in the JSON line (rank 0's log only)
+            import tempfile
+            rccl_log = os.path.join(tempfile.gettempdir(), f"vdk_rccl_{os.getpid()}.log")
+            os.environ.update({"NCCL_DEBUG": "INFO", "NCCL_DEBUG_SUBSYS": "INIT,GRAPH", "NCCL_DEBUG_FILE": rccl_log})
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    from visiondk_amd import _lib, comm as vcomm, vit
+    from visiondk_amd import _lib
     be = _lib.load()
 
     parity = parity_vit(be, dev) if (world == 1 and rank == 0 and not args.no_parity) else None
-    spec = vit.spec_from_timm_name("vit_base_patch16_224", 1000)
-    model = vit.VisionTransformer(spec, device=dev, seed=2)
-    if world > 1:
-        comm = vcomm.GradAllReduce()          # FusedTrainStep broadcasts rank 0's weights (DDP-constructor semantics)
-    step = vit.FusedTrainStep(model, lr=0.006, momentum=0.937, weight_decay=5e-4, label_smoothing=0.05, max_norm=10.0,
-                              ema=(rank == 0), comm=comm)
-    g = torch.Generator(device="cpu"); g.manual_seed(1000 + rank)
-    x = torch.randn(args.batch, 3, 224, 224, generator=g).to(dev)
-    y = torch.randint(0, 1000, (args.batch,), generator=g).to(dev)
-
-    for _ in range(args.warmup):
-        step.step(x, y)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    # live per-launch timing of the dominant kernel (bf16 GEMM) with HIP events on the launch stream
-    launches_per_step = 7 * spec.depth * 2 + 8
-    if os.environ.get("VDK_BENCH_NO_EVENTS") != "1":      # (diagnostic: what the per-launch HIP events themselves cost)
-        be.check(be.lib.vdk_prof_begin(launches_per_step * args.steps + 64), "vdk_prof_begin")
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev = os.environ.get("VDK_BENCH_NO_EVENTS") != "1"
-    for it in range(args.steps):
-        if ev:      # every GEMM launch of every 4th timed step carries a (start, stop) event pair: a timed dispatch costs ~5 us of queue time, 0.7-1.0 ms per step if all 149 are timed
-            be.lib.vdk_prof_pause(0 if it % GEMM_EVENT_STRIDE == 0 else 1)
-        step.step(x, y)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    gemm_ms, gemm_n, gemm_fl = C.c_double(0), C.c_int64(0), C.c_double(0)
-    be.check(be.lib.vdk_prof_end(C.byref(gemm_ms), C.byref(gemm_n), C.byref(gemm_fl)), "vdk_prof_end")
-    gemm_bytes = C.c_double(0)
-    be.check(be.lib.vdk_prof_bytes(C.byref(gemm_bytes)), "vdk_prof_bytes")
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    loss = step.loss_value()
+    dt, loss, gemm, ncoll = train_leg(be, dev, rank, world, args.steps, args.warmup, args.batch)
+    cbir_n = None
+    if world > 1 and not args.no_cbir:
+        torch.cuda.empty_cache()
+        cbir_n = cbir_sharded_leg(be, dev, rank, world)
 
     if rank == 0:
         imgs = args.batch * world * args.steps
         value = imgs / dt
         per_gpu_tflops = value / world * VIT_FLOP_PER_IMG / 1e12
-        gemm_avg_ms = gemm_ms.value / max(gemm_n.value, 1)
-        gemm_tflops = gemm_fl.value / max(gemm_ms.value, 1e-9) / 1e9
         out = {
             "metric": "images/sec fwd+bwd+optimizer step (ViT-B/16, bs=256 per GPU)", "value": value, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -313,20 +416,31 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": loss},
             "model_flops_utilisation": {"achieved_tflops_per_gpu": per_gpu_tflops, "peak": PEAK_BF16_TFLOPS, "frac": per_gpu_tflops / PEAK_BF16_TFLOPS,
                                         "flop_per_image": VIT_FLOP_PER_IMG},
-            "roofline": {"bound": "mfma", "kernel": "gemm256_bf16_kernel<NT|TN> (+ gemm_bf16_nt_kernel on small shapes)", "achieved": gemm_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": gemm_tflops / PEAK_BF16_TFLOPS, "traffic": pmc_traffic_per_launch(),
-                         "algorithmic_bytes_per_launch": gemm_bytes.value / max(gemm_n.value, 1),
-                         "avg_launch_ms": gemm_avg_ms, "launches": gemm_n.value, "timed_launches": f"every GEMM dispatch of every {GEMM_EVENT_STRIDE}th step of the timed region (start / stop events attached to the dispatch itself)", "flops_per_launch": gemm_fl.value / max(gemm_n.value, 1),
-                         "gemm_share_of_step_time": (gemm_ms.value / max(1, -(-args.steps // GEMM_EVENT_STRIDE))) / (dt / args.steps * 1e3)},
         }
+        if gemm is not None:
+            gemm_avg_ms = gemm["ms"] / max(gemm["n"], 1)
+            gemm_tflops = gemm["flops"] / max(gemm["ms"], 1e-9) / 1e9
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_w4_kernel / gemm_w4h_kernel <NT|TN> (one wave per SIMD, 256x256 / 256x128 tiles; gemm256_bf16_kernel where an operand-side column sum is fused)",
+                               "achieved": gemm_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": gemm_tflops / PEAK_BF16_TFLOPS, "traffic": pmc_traffic_per_launch(),
+                               "algorithmic_bytes_per_launch": gemm["bytes"] / max(gemm["n"], 1),
+                               "avg_launch_ms": gemm_avg_ms, "launches": gemm["n"],
+                               "timed_launches": f"every GEMM dispatch of every {GEMM_EVENT_STRIDE}th step of the timed region (start / stop events attached to the dispatch itself)",
+                               "flops_per_launch": gemm["flops"] / max(gemm["n"], 1),
+                               "gemm_share_of_step_time": (gemm["ms"] / max(1, -(-args.steps // GEMM_EVENT_STRIDE))) / (dt / args.steps * 1e3)}
+        if world > 1:
+            out["exchange"] = {"collectives_per_step": ncoll // max(1, args.steps + args.warmup), "bucket_bytes": 24 << 20,
+                               "what": "bucketed all-reduce (sum) of the flat fp32 gradient over RCCL, issued from inside the backward; 1/world folded into the SGD kernel",
+                               "rccl": rccl_topology_lines(rccl_log) if rccl_log else None}
         if parity is not None:
             out["parity"] = parity
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_vit()
         if world == 1 and not args.no_cbir:
-            del step, model
             torch.cuda.empty_cache()
             out["cbir"] = bench_cbir(dev, with_cpu=not args.no_cpu_baseline)
+        elif cbir_n is not None:
+            out["cbir"] = cbir_n
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

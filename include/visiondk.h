@@ -154,6 +154,12 @@ int vdk_gemm_force_kernel(int32_t which);
  * serve, environment VDK_GEMM_W4=0 disables it), 6 = 256x128 four waves with two workgroups per CU (gemm_w4h_kernel: the default for the long epilogues --
  * GELU, dGELU, fp32 residual; which = 6 forces it; environment VDK_GEMM_W4H = bit mask 1 GELU | 2 dGELU | 4 residual | 8 other NT | 16 TN) */
 int vdk_gemm_last_kernel(void);
+/* leave n CUs (0..128, rounded so that the walk stays a multiple of 8) out of the persistent GEMM grids of this process: a data-parallel host sets it to the number of
+ * channels its collectives run on (visiondk_amd/comm.py: 32), so that an all-reduce in flight on another stream and a persistent GEMM fit on the chip together instead of
+ * the GEMM's static tile walk waiting for the collective to end.  Results do not depend on it.  Environment VDK_GEMM_RESERVE_CUS overrides. */
+int vdk_gemm_reserve_cus(int32_t n);
+/* diagnostic: `workgroups` workgroups (256 threads, 32 KB of LDS) that stay resident for `microseconds` on `stream` -- a stand-in for a collective's kernel in flight */
+int vdk_debug_occupy_cus(int32_t workgroups, int64_t microseconds, void* stream);
 /* profiling aid: when non-NULL, every 256x256 workgroup writes 4 shader-cycle stamps (start, operands landed, main loop done,
  * stores issued) to buf[4 * workgroup]; NULL (default) disables it */
 int vdk_gemm_debug_stamps(void* device_u64_buffer);

@@ -463,3 +463,89 @@ def test_two_rank_map_step_equals_single_process(tmp_path, emu):
         d_single = step.big - p0; d_ddp = r0[sam]["params"] - p0
         rel = ((d_ddp - d_single).norm() / d_single.norm()).item()
         assert rel < (3e-2 if not sam else 2e-1), (sam, rel)      # SAM: the first pass is local (per-rank e(w)), as in the reference's no_sync()
+
+
+# ---- bench.py's own multi-rank code: the two legs the driver's `--gpus N` run executes, on 2 CPU ranks over gloo ---------------------------------------
+def _bench_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["VDK_EMU_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from tests.emu.emu_backend import load_emu
+    from tests.test_vit import SPEC
+    be = load_emu()
+    dev = torch.device("cpu")
+    dt, loss, gemm, ncoll = bench.train_leg(be, dev, rank, world, steps=2, warmup=1, batch=2, spec=SPEC, img=32, classes=10, bucket_bytes=200_000)
+    cb = bench.cbir_sharded_leg(be, dev, rank, world, nq=10, n=301, d=32, k=7, iters=2, warm=1, cap=200, check_queries=5)
+    torch.save({"dt": dt, "loss": loss, "gemm": gemm, "ncoll": ncoll, "cbir": cb}, f"{out_dir}/bench{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_bench_multi_rank_legs_on_two_gloo_ranks(tmp_path, emu):
+    port = 29500 + ((os.getpid() + 389) % 500)
+    mp.start_processes(_bench_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "bench0.pt", weights_only=False); r1 = torch.load(tmp_path / "bench1.pt", weights_only=False)
+    assert r0["dt"] == r1["dt"] > 0                          # MAX over ranks: both report the same time
+    assert r0["ncoll"] == r1["ncoll"] and r0["ncoll"] >= 1 + 3 * 2      # the broadcast + at least two buckets in each of the 3 steps
+    assert r0["loss"] > 0 and r0["gemm"] is None             # (HIP events only on the GPU)
+    c0 = r0["cbir"]
+    assert c0["n_gpus"] == 2 and c0["scaling"] == "strong" and c0["value"] > 0 and r1["cbir"]["value"] == c0["value"]
+    assert c0["parity_vs_oracle"] == {"queries": 5, "gallery_rows": 301, "indices_equal": True, "scores_bit_equal": True}
+    assert "parity_vs_oracle" not in r1["cbir"]
+
+
+def test_bench_spawns_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset re-executes itself under torch.distributed.run (one rank per GPU)"""
+    import subprocess
+    import bench
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd: seen.setdefault("cmd", cmd) and 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "2", "--steps", "3"] and cmd[-5].endswith("bench.py")
+
+
+def test_bucket_schedule_tapers_at_the_gradient_tail(monkeypatch):
+    """GradAllReduce's bucket rule on ViT-B/16-like ready ranges (head, 12 blocks of 7.09 M floats, embeddings): every block its own collective, and nothing
+    large is left for finish_step (the only collective the clipped SGD step waits for with nothing left to hide it)."""
+    from visiondk_amd import comm
+    sizes = []
+
+    class _W:
+        def wait(self): pass
+
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda g=None: 8)
+    monkeypatch.setattr(dist, "get_rank", lambda g=None: 0)
+    monkeypatch.setattr(dist, "all_reduce", lambda t, op=None, group=None, async_op=False: sizes.append(t.numel()) or _W())
+    c = comm.GradAllReduce()
+    blk, stem, head = 7_087_872, 742_656, 770_536
+    total = stem + 12 * blk + head
+    c.begin_step(torch.empty(total))
+    off = total - head
+    c.on_grad_ready(off, head)
+    for _ in range(12):
+        off -= blk
+        c.on_grad_ready(off, blk)
+    before_tail = list(sizes)
+    c.on_grad_ready(0, stem)
+    c.finish_step()
+    assert sum(sizes) == total
+    assert before_tail == [head + blk] + [blk] * 11          # the last block left as soon as it was ready ...
+    assert sizes[len(before_tail):] == [stem]                # ... and only the 3 MB of embedding gradients are exposed
+    # small ranges: the tail halves (a bucket closes when no more than its own size is still to come)
+    sizes.clear()
+    c = comm.GradAllReduce(bucket_bytes=1 << 30)
+    c.begin_step(torch.empty(1024))
+    for o in range(1023, -1, -1):
+        c.on_grad_ready(o, 1)
+    c.finish_step()
+    assert sizes == [512, 256, 128, 64, 32, 16, 8, 4, 2, 1, 1]

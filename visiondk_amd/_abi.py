@@ -88,6 +88,8 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_gemm_c_colsum_rows": (C.c_int, [I32, I32, I32]),
     "vdk_gemm_force_kernel": (C.c_int, [I32]),
     "vdk_gemm_last_kernel": (C.c_int, []),
+    "vdk_gemm_reserve_cus": (C.c_int, [C.c_int32]),
+    "vdk_debug_occupy_cus": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p]),
     "vdk_quant_fp8": (C.c_int, [P, I32, I64, P, P, I32, P, P]),
     "vdk_fp8_scale_update": (C.c_int, [P, P, P, I32, I32, F32, P]),
     "vdk_gemm_fp8_nt": (C.c_int, [P, I32, I32, P, P, P]),

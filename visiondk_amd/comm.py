@@ -7,6 +7,12 @@ soon as the kernels producing that slice are enqueued, and the slice's all-reduc
 (`torch.distributed`, backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).  RCCL orders the collective
 after the producing kernels (stream dependency on the launch stream) and runs it on its own stream, so it overlaps the
 remaining backward kernels.  One process per GPU; sum here, the 1/world factor is folded into the optimizer kernel.
+
+What the optimizer waits for: clip_grad_norm_ needs the norm of the WHOLE reduced gradient (train.py:203-206), so the clipped SGD kernel cannot start on a
+reduced bucket while a later one is in flight -- only the LAST bucket's collective is exposed (everything before it runs under the backward).  The bucket rule
+keeps that last one small: a bucket closes when it reaches `bucket_bytes` or when no more than its own size is still to come, so the gradient's tail (for the
+ViT: block 0, then the embeddings) leaves in pieces of decreasing size instead of one 2-block bucket at the very end.  c10d is the binding to RCCL here on
+purpose ("collectives"): the C-ABI exposes the ready-range callback, the exchange itself is the host framework's.
 """
 from __future__ import annotations
 
@@ -17,8 +23,10 @@ import torch.distributed as dist
 
 
 class GradAllReduce:
-    def __init__(self, group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 32 << 20, always_communicate: bool = False):
-        """always_communicate: issue every collective even in a one-rank group (where they are identities).  The GPU tests use it to drive the real
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 24 << 20, always_communicate: bool = False, reserve_cus: int = 32):
+        """reserve_cus: CUs the persistent GEMM grids leave to the collectives' kernels while this object is active on a GPU (vdk_gemm_reserve_cus: an all-reduce in
+        flight holds one CU per channel; a persistent GEMM whose static tile walk covers every CU would wait for it to END -- measured with a stand-in kernel,
+        tools/w4_contention.py).  always_communicate: issue every collective even in a one-rank group (where they are identities).  The GPU tests use it to drive the real
         stream-ordered RCCL path on a single MI355X (backend "nccl", world_size 1) and require bit-identical results to the communication-free step."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
@@ -26,8 +34,12 @@ class GradAllReduce:
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.active = self.world_size > 1 or always_communicate
+        if self.active and torch.cuda.is_available():
+            from . import _lib
+            be = _lib.load()
+            be.check(be.lib.vdk_gemm_reserve_cus(int(reserve_cus)), "vdk_gemm_reserve_cus")
         self.collectives = 0               # issued so far (tests / logs)
-        self.bucket_bytes = bucket_bytes   # xGMI is per-link bound: fewer, larger collectives than DDP's 25 MB
+        self.bucket_bytes = bucket_bytes   # ViT-B: one 28 MB transformer block per collective (ranges arrive per block); far above the size where a ring over xGMI is latency-bound
         self._grads: Optional[torch.Tensor] = None
         self._pending: List = []
         self._lo = self._hi = None
@@ -65,7 +77,8 @@ class GradAllReduce:
         else:  # non-adjacent: close the current bucket first
             self._flush()
             self._lo, self._hi = offset, offset + numel
-        if (self._hi - self._lo) * 4 >= self.bucket_bytes:
+        size = self._hi - self._lo
+        if size * 4 >= self.bucket_bytes or size >= self._lo:      # full, or the rest of the gradient (offsets below _lo) is no bigger than this bucket
             self._flush()
 
     def finish_step(self) -> None:

@@ -28,6 +28,7 @@
 #endif
 #include "vdk_device.h"
 #include "vdk_host.h"
+#include <atomic>
 #include "vdk_gemm.h"
 #include "vdk_gemm_epilogue.h"
 
@@ -785,14 +786,47 @@ bool vdk_gemm_w4h_serves(const GemmParams& p, bool trans) {
   return ((double)p.K + 64.0) * (double)p.lda * 2.0 < lim && ((double)p.K + 64.0) * (double)p.ldb * 2.0 < lim;
 }
 
+// CUs the persistent walk leaves free (vdk_gemm_reserve_cus; environment VDK_GEMM_RESERVE_CUS overrides).  A persistent grid that covers every CU with a
+// workgroup owning the CU's whole LDS cannot share the chip: a collective's kernel on another stream (RCCL: one workgroup per channel) that occupies R CUs when a
+// GEMM starts keeps R of its workgroups -- and the tiles the static walk gave them -- waiting until the collective ends.  With R CUs left out of the walk both fit.
+static std::atomic<int> g_w4_reserve{0};
+
+extern "C" int vdk_gemm_reserve_cus(int32_t n) {
+  if (n < 0 || n > 128) return vdk_fail(VDK_EINVAL, "vdk_gemm_reserve_cus: 0 <= n <= 128");
+  g_w4_reserve.store(n);
+  return VDK_OK;
+}
+
+// diagnostic (tools/w4_contention.py): `workgroups` workgroups that each hold a CU's LDS share of a collective's kernel for `microseconds`, on `stream` -- stands in for an
+// RCCL all-reduce in flight when the effect of vdk_gemm_reserve_cus is measured on one GPU
+__global__ __launch_bounds__(256) void w4_occupy_kernel(long ticks, int* sink) {
+  __shared__ volatile int pad[8192];                       // 32 KB: cannot share a CU's LDS with a workgroup that owns all of it
+  pad[threadIdx.x] = (int)threadIdx.x;
+#ifndef VDK_EMU
+  asm volatile("v_mov_b32 v127, 0" ::: "v127");            // a 128-register wave, as a collective's kernel is: does not fit beside a wave that owns the SIMD's register file
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+  while ((long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) __builtin_amdgcn_s_sleep(64);
+#endif
+  if (sink && pad[(threadIdx.x + 1) & 255] < 0) *sink = 1;
+}
+
+extern "C" int vdk_debug_occupy_cus(int32_t workgroups, int64_t microseconds, void* stream) {
+  if (workgroups <= 0 || microseconds < 0 || microseconds > 1000000) return vdk_fail(VDK_EINVAL, "vdk_debug_occupy_cus: bad argument");
+  hipLaunchKernelGGL(w4_occupy_kernel, dim3((unsigned)workgroups), dim3(256), 0, (hipStream_t)stream, (long)microseconds * 100, (int*)nullptr);
+  return hipGetLastError() == hipSuccess ? VDK_OK : vdk_fail(VDK_ELAUNCH, "vdk_debug_occupy_cus: launch failed");
+}
+
 static int w4_cus() {
   static int cus = 0;
+  static int env_reserve = getenv("VDK_GEMM_RESERVE_CUS") ? atoi(getenv("VDK_GEMM_RESERVE_CUS")) : -1;
   if (cus == 0) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
     cus = n & ~7;
   }
-  return cus;
+  const int r = env_reserve >= 0 ? env_reserve : g_w4_reserve.load();
+  int g = (cus - r) & ~7;                                  // (the walk wants a multiple of 8: one share per XCD)
+  return g < 8 ? 8 : g;
 }
 
 #define W4_LAUNCH(TNF, EE)                                                                                                                    \
