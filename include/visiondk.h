@@ -37,6 +37,13 @@ extern "C" {
 #define VDK_ACT_NONE 0
 #define VDK_ACT_GELU 1   /* exact-erf GELU (timm Mlp act_layer=nn.GELU); optional pre-activation saved to aux */
 #define VDK_ACT_DGELU 2  /* multiply by GELU'(aux)  (backward of the above) */
+/* the same pair with the derivative evaluated ONCE, in the forward epilogue that already holds erf and exp of the pre-activation: aux (same shape and pitch, 2-byte
+ * elements) receives GELU'(pre-activation) as IEEE fp16 instead of the bf16 pre-activation -- the derivative lies in [-0.13, 1.13], where fp16 keeps 11 significand
+ * bits -- and the backward epilogue is one multiplication (vdk_gemm_bf16_nt only; aux is required).  NOT what the engines use: the reference's autocast evaluates
+ * GELU' from the bf16-ROUNDED pre-activation, and a derivative taken from the unrounded one moves the ViT gradients to 1.54x the oracle's own fp32-vs-fp64
+ * accumulation floor (tests/test_parity_bf16.py allows 1.5x) for 0.7 ms of a 38 ms step (measured negatives). */
+#define VDK_ACT_GELU_SAVE_GRAD 3
+#define VDK_ACT_MUL_AUX 4
 
 const char* vdk_last_error(void);
 int vdk_is_device_build(void);   /* 1 = compiled by hipcc for gfx950 */

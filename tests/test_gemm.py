@@ -297,3 +297,43 @@ def test_gemm_w4_row_split_for_the_ragged_round(be, dev):
         torch.testing.assert_close(part.sum(0).cpu(), out.float().sum(0).cpu(), rtol=1e-4, atol=2e-3)
     finally:
         be.lib.vdk_gemm_force_kernel(0)
+
+
+@pytest.mark.parametrize("kern", [1, 2, 5, 6])
+def test_gemm_gelu_with_saved_derivative(be, dev, kern):
+    """VDK_ACT_GELU_SAVE_GRAD / VDK_ACT_MUL_AUX on every kernel structure: the forward epilogue stores fp16 GELU'(pre-activation) beside bf16 GELU(pre-activation)
+    (bit-equal to what VDK_ACT_GELU stores), the backward epilogue is one multiplication -- with and without the column sums of what it stores; against torch on the same
+    bf16 operands and against the two-evaluation pair (VDK_ACT_GELU + VDK_ACT_DGELU), whose derivative is evaluated from the bf16-rounded pre-activation"""
+    torch.manual_seed(17)
+    M, N, K = 1300, 520, 256
+    a = torch.randn(M, K).bfloat16().to(dev); b = (torch.randn(N, K) * 0.1).bfloat16().to(dev)
+    bias = torch.randn(N).to(dev)
+    ref = a.float() @ b.float().T + bias
+    rr = ref.clone().requires_grad_(True)
+    torch.nn.functional.gelu(rr).sum().backward()
+    dref = rr.grad
+    be.lib.vdk_gemm_force_kernel(kern)
+    try:
+        u = torch.empty(M, N, dtype=torch.bfloat16, device=dev); dsv = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
+        g_old = ops.gemm_nt(a, b, bias=bias, act=ops.ACT_GELU, aux=u, backend=be)
+        g_new = ops.gemm_nt(a, b, bias=bias, act=ops.ACT_GELU_SAVE_GRAD, aux=dsv, backend=be)
+        assert be.lib.vdk_gemm_last_kernel() == kern
+        assert torch.equal(g_old.view(torch.int16), g_new.view(torch.int16))
+        assert (dsv.float() - dref).abs().max().item() < 1.5e-3                             # fp16 spacing at 1 is 9.8e-4 (|GELU'| <= 1.13), fp32 epilogue arithmetic below it
+        assert _rel(dsv.float(), dref) < 4e-4
+        # backward: dY [M, N2] x W^T -> [M, N] scaled by the saved derivative
+        dy = torch.randn(M, K).bfloat16().to(dev)
+        acc = dy.float() @ b.float().T
+        out = ops.gemm_nt(dy, b, act=ops.ACT_MUL_AUX, aux=dsv, backend=be)
+        assert be.lib.vdk_gemm_last_kernel() == kern
+        assert _rel(out.float(), (acc * dsv.float()).bfloat16().float()) < 3e-3
+        out_old = ops.gemm_nt(dy, b, act=ops.ACT_DGELU, aux=u, backend=be)
+        assert _rel(out.float(), out_old.float()) < 6e-3                                     # the two pairs differ by the bf16 rounding of the derivative
+        rows = be.lib.vdk_gemm_c_colsum_rows(M, N, K)
+        if rows > 0:
+            part = torch.full((rows, N), float("nan"), dtype=torch.float32, device=dev)
+            out2 = ops.gemm_nt(dy, b, act=ops.ACT_MUL_AUX, aux=dsv, c_colsum=part, backend=be)
+            assert torch.equal(out2.view(torch.int16), out.view(torch.int16))
+            torch.testing.assert_close(part.sum(0).cpu(), out2.float().sum(0).cpu(), rtol=1e-4, atol=2e-3)
+    finally:
+        be.lib.vdk_gemm_force_kernel(0)

@@ -37,12 +37,16 @@ def main():
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     T = 50432
     res = {"rows": T, "shapes": []}
+    only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
     shapes = [("qkv bias", T, 2304, 768, "bias", False), ("proj bias+res f32", T, 768, 768, "res", False), ("fc1 bias+gelu+aux", T, 3072, 768, "gelu", False),
-              ("fc2 bias+res f32", T, 768, 3072, "res", False), ("dfc2 dgelu+ocs", T, 3072, 768, "dgelu", False), ("dfc1 plain", T, 768, 3072, "plain", False),
+              ("fc1 bias+gelu+saved derivative", T, 3072, 768, "gelud", False), ("fc2 bias+res f32", T, 768, 3072, "res", False), ("dfc2 dgelu+ocs", T, 3072, 768, "dgelu", False),
+              ("dfc2 x saved derivative+ocs", T, 3072, 768, "mulaux", False), ("dfc1 plain", T, 768, 3072, "plain", False),
               ("dproj plain", T, 768, 768, "plain", False), ("dqkv plain", T, 768, 2304, "plain", False),
               ("wgrad qkv", 2304, 768, T, "tn", True), ("wgrad proj", 768, 768, T, "tn", True), ("wgrad fc1", 3072, 768, T, "tn", True), ("wgrad fc2", 768, 3072, T, "tn", True),
               ("4096^3", 4096, 4096, 4096, "plain", False), ("8192^3", 8192, 8192, 8192, "plain", False), ("65536x768x3072", 65536, 768, 3072, "plain", False)]
     for name, M, N, K, ep, trans in shapes:
+        if only and ep not in only:
+            continue
         torch.manual_seed(0)
         if trans:
             a = torch.randn(K, M, device="cuda").bfloat16(); b = torch.randn(K, N, device="cuda").bfloat16()
@@ -57,6 +61,11 @@ def main():
             kw = {"bias": bias, "residual": torch.randn(M, N, device="cuda")}; odt = torch.float32
         elif ep == "gelu":
             kw = {"bias": bias, "act": ops.ACT_GELU, "aux": torch.empty(M, N, device="cuda", dtype=torch.bfloat16)}
+        elif ep == "gelud":
+            kw = {"bias": bias, "act": ops.ACT_GELU_SAVE_GRAD, "aux": torch.empty(M, N, device="cuda", dtype=torch.bfloat16)}
+        elif ep == "mulaux":
+            rows = be.lib.vdk_gemm_c_colsum_rows(M, N, K)
+            kw = {"act": ops.ACT_MUL_AUX, "aux": torch.randn(M, N, device="cuda").bfloat16(), "c_colsum": torch.empty(rows, N, device="cuda")}
         elif ep == "dgelu":
             rows = be.lib.vdk_gemm_c_colsum_rows(M, N, K)
             kw = {"act": ops.ACT_DGELU, "aux": torch.randn(M, N, device="cuda").bfloat16(), "c_colsum": torch.empty(rows, N, device="cuda")}

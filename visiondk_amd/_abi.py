@@ -62,7 +62,7 @@ GRAD_READY_FN = C.CFUNCTYPE(None, P, I64, I64)
 STAT_SYNC_FN = C.CFUNCTYPE(None, P, P, I64)   # vdk_stat_sync_fn(user, stats, n)
 
 BF16, F32_ = 0, 1
-ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_SAVE_GRAD, ACT_MUL_AUX = 0, 1, 2, 3, 4
 
 # name -> (restype, [argtypes])
 SIGNATURES: dict[str, tuple] = {

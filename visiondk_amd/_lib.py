@@ -67,5 +67,7 @@ def load() -> Backend:
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `python -m visiondk_amd.build` "
                 "(visiondk_amd has no CPU fallback)")
-        _default = Backend(C.CDLL(str(LIB_PATH)), device_only=True, name="hip")
+        import os
+        alt = os.environ.get("VDK_HIP_LIB")      # tuning only: another build of the SAME library (kernel A/B on one box, tools/ab_build.py)
+        _default = Backend(C.CDLL(alt if alt else str(LIB_PATH)), device_only=True, name="hip")
     return _default

@@ -821,7 +821,9 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
       return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad convolution geometry (Cin % 8 == 0, K == KH*KW*Cin, M == B*OH*OW)");
   }
   if (d->c_dtype != VDK_BF16 && d->c_dtype != VDK_F32) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad c_dtype");
-  if ((d->act == VDK_ACT_DGELU && !d->aux) || (d->aux && (d->ldaux & 7))) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad aux");
+  if (d->act < VDK_ACT_NONE || d->act > VDK_ACT_MUL_AUX) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad act");
+  if (((d->act == VDK_ACT_DGELU || d->act == VDK_ACT_GELU_SAVE_GRAD || d->act == VDK_ACT_MUL_AUX) && !d->aux) || (d->aux && (d->ldaux & 7)))
+    return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad aux");
   int splitk = d->splitk < 1 ? 1 : d->splitk;
   GemmParams p = {};
   p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C;
@@ -865,6 +867,8 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
     else if (plain_alpha && !rg && !res && d->act == VDK_ACT_NONE && !f32) E = bias ? E_BIAS : 0;
     else if (plain_alpha && !rg && !res && d->act == VDK_ACT_GELU && !f32 && bias && d->aux) E = E_BIAS | E_GELU;
     else if (plain_alpha && !rg && !res && d->act == VDK_ACT_DGELU && !f32 && !bias) E = E_DGELU;
+    else if (plain_alpha && !rg && !res && d->act == VDK_ACT_GELU_SAVE_GRAD && !f32 && bias) E = E_BIAS | E_GELU | E_AUXD;
+    else if (plain_alpha && !rg && !res && d->act == VDK_ACT_MUL_AUX && !f32 && !bias) E = E_DGELU | E_AUXD;
     else if (plain_alpha && !rg && res && d->act == VDK_ACT_NONE && f32 && bias) E = E_BIAS | E_RES | E_F32;
     else if (plain_alpha && rg && res && d->act == VDK_ACT_NONE && f32 && bias) E = E_BIAS | E_RES | E_F32 | E_ROWGRP;
     else if (plain_alpha && !rg && !res && d->act == VDK_ACT_NONE && f32 && !bias) E = E_F32;
@@ -921,10 +925,10 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
     if (d->a_colsum) {
       if (d->M % 256) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: a_colsum needs M % 256 == 0");
       p.colsum_part = d->a_colsum;
-      if (E != 0 && E != E_DGELU && E != E_F32) E = E_GENERIC;   // the by-product is compiled into the dgrad forms only
+      if (E != 0 && E != E_DGELU && E != E_F32) E = E_GENERIC;   // the by-product is compiled into the dgrad forms only (E_DGELU | E_AUXD: run-time-flag path)
     }
     if (d->c_colsum) {   // compiled into the dGELU form (dL/du = bias gradient of fc1) and the plain bf16 form
-      if ((E != E_DGELU && E != 0) || d->a_colsum) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: c_colsum goes with a plain or dGELU bf16 epilogue and without a_colsum");
+      if ((E != E_DGELU && E != (E_DGELU | E_AUXD) && E != 0) || d->a_colsum) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: c_colsum goes with a plain or dGELU bf16 epilogue and without a_colsum");
       p.ocs_part = d->c_colsum;
       E |= E_OCS;
     }
@@ -935,6 +939,9 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
       case E_BIAS: LAUNCH256(false, E_BIAS); break;
       case E_BIAS | E_GELU: LAUNCH256(false, E_BIAS | E_GELU); break;
       case E_DGELU: LAUNCH256CS(E_DGELU); break;
+      case E_BIAS | E_GELU | E_AUXD: LAUNCH256(false, E_BIAS | E_GELU | E_AUXD); break;
+      case E_DGELU | E_AUXD: LAUNCH256(false, E_DGELU | E_AUXD); break;
+      case E_DGELU | E_OCS | E_AUXD: LAUNCH256(false, E_DGELU | E_OCS | E_AUXD); break;
       case E_BIAS | E_RES | E_F32: LAUNCH256(false, E_BIAS | E_RES | E_F32); break;
       case E_BIAS | E_RES | E_F32 | E_ROWGRP: LAUNCH256(false, E_BIAS | E_RES | E_F32 | E_ROWGRP); break;
       case E_SPLITK: LAUNCH256(false, E_SPLITK); break;

@@ -305,6 +305,7 @@ int vdk_gemm_fp8_nt_q8(const VdkGemmDesc* d, int32_t a_fmt, int32_t b_fmt, const
   if (d->splitk > 1 || d->trans || d->conv || d->row_group != 0 || d->a_colsum || (d->c_colsum && d->act != VDK_ACT_DGELU))
     return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_fp8_nt: split-K / TN / conv / row remap stay on the bf16 kernels (c_colsum: with the dGELU epilogue only)");
   if (!((a_fmt == 0 || a_fmt == 1) && b_fmt == 0)) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_fp8_nt: formats (e4m3, e4m3) and (e5m2, e4m3)");
+  if (d->act < VDK_ACT_NONE || d->act > VDK_ACT_DGELU) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_fp8_nt: act NONE, GELU or DGELU");
   if ((d->act == VDK_ACT_DGELU && !d->aux) || (d->aux && (d->ldaux & 7))) return vdk_fail(VDK_EINVAL, "vdk_gemm_fp8_nt: bad aux");
   Fp8Params q;
   GemmParams& p = q.g;

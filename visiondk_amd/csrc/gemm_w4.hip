@@ -40,7 +40,10 @@
 #define W4_RA1 16384
 #define W4_RB0 32768
 #define W4_RB1 49152
-#define W4_OOB 0x80000000u   /* scalar offset of a DMA that must read nothing: beyond every descriptor (operands stay below 2 GB), so it lands zeros */
+#define W4_OOB 0x80000000u
+#ifndef W4_EPI_AHEAD
+#define W4_EPI_AHEAD 1      /* epilogue operand rows (saved GELU operand, fp32 residual) requested one 32-row block ahead; 0 = at the block's start (A/B builds) */
+#endif   /* scalar offset of a DMA that must read nothing: beyond every descriptor (operands stay below 2 GB), so it lands zeros */
 
 #define W4_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))   /* vmcnt(n), n < 64; expcnt / lgkmcnt untouched */
 #define W4_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
@@ -254,7 +257,8 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
   constexpr int RPP = 64 / NCH;           // rows per 64-lane pass
   constexpr int NPS = 32 / RPP;           // passes per 32-row block
   constexpr int ROWB = NCT * 64;          // staged row, bytes
-  constexpr bool FAST = (E == 0 || E == E_BIAS || E == (E_BIAS | E_GELU) || E == E_DGELU || E == (E_DGELU | E_OCS) || E == E_OCS);
+  constexpr int EB = E & ~E_AUXD;                             // (E_AUXD only changes what aux holds)
+  constexpr bool FAST = (E == 0 || E == E_BIAS || EB == (E_BIAS | E_GELU) || EB == E_DGELU || EB == (E_DGELU | E_OCS) || E == E_OCS);
   const int l31 = lane & 31, hi = lane >> 5;
   const int mrow0 = m0 + wr * 128, ncol0 = n0 + wc * (NCT * 32);
   const int swz_w = NCT == 4 ? (l31 & 15) : ((l31 >> 1) & 7);   // staging swizzle of this lane's row
@@ -313,6 +317,14 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
     };
     if constexpr (DEEP >= 0) W4_WAIT_VM(DEEP);                  // deep wait: every DMA group but the newest has landed (the next tile's first k-tile then runs without waits)
     if (p.dbg) ts[0] = __builtin_readcyclecounter();
+    u32x4 auxrows[NPS];
+    auto aux_request = [&](int rt_) {
+      const unsigned srow = (unsigned)(mrow0 + rt_ * 32) * (unsigned)p.ldaux * 2u;
+#pragma unroll
+      for (int ps = 0; ps < NPS; ++ps)
+        auxrows[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_aux, lane_aux, srow + (unsigned)(ps * RPP) * (unsigned)p.ldaux * 2u, 0);   // (out of range: zeros)
+    };
+    if (E & E_DGELU) aux_request(0);
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
       if (p.dbg && rt > 0) ts[rt] = __builtin_readcyclecounter();
@@ -321,14 +333,14 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
 #endif
       u32x2 held[NCT][4];                                         // GELU: the activated values wait here (packed) while the pre-activation rows leave
       if (E & E_DGELU) {
-        // the saved pre-activation u of these 32 rows: whole row segments -> staging -> this lane's layout
-        const unsigned srow = (unsigned)(mrow0 + rt * 32) * (unsigned)p.ldaux * 2u;
+        if (!W4_EPI_AHEAD && rt > 0) aux_request(rt);
+        // the saved operand of these 32 rows (requested one block ahead): whole row segments -> staging -> this lane's layout
 #pragma unroll
         for (int ps = 0; ps < NPS; ++ps) {
           const int row = ps * RPP + rrow;
-          const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs_aux, lane_aux, srow + (unsigned)(ps * RPP) * (unsigned)p.ldaux * 2u, 0);   // (out of range: zeros)
-          *(u32x4*)(stage + row * ROWB + ((rc ^ (NCT == 4 ? (row & 15) : ((row >> 1) & 7))) << 4)) = d;
+          *(u32x4*)(stage + row * ROWB + ((rc ^ (NCT == 4 ? (row & 15) : ((row >> 1) & 7))) << 4)) = auxrows[ps];
         }
+        if (W4_EPI_AHEAD && rt < 3) aux_request(rt + 1);          // travels while this block is multiplied, staged back and stored (a lone wave has nothing else to hide it behind)
         W4_EPI_SYNC();
       }
 #pragma unroll
@@ -339,16 +351,28 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
           float v[4];
           if (E & E_DGELU) {
             const u32x2 u = *(const u32x2*)wp;                  // (the same 8 bytes this lane overwrites below: u goes out, dL/du comes in)
-            v[0] = acc[rt][ct][4 * g + 0] * gelu_grad_f(bf_lo(u[0])); v[1] = acc[rt][ct][4 * g + 1] * gelu_grad_f(bf_hi(u[0]));
-            v[2] = acc[rt][ct][4 * g + 2] * gelu_grad_f(bf_lo(u[1])); v[3] = acc[rt][ct][4 * g + 3] * gelu_grad_f(bf_hi(u[1]));
+            if (E & E_AUXD) {                                   // aux holds GELU'(u) already
+              v[0] = acc[rt][ct][4 * g + 0] * h_lo(u[0]); v[1] = acc[rt][ct][4 * g + 1] * h_hi(u[0]);
+              v[2] = acc[rt][ct][4 * g + 2] * h_lo(u[1]); v[3] = acc[rt][ct][4 * g + 3] * h_hi(u[1]);
+            } else {
+              v[0] = acc[rt][ct][4 * g + 0] * gelu_grad_f(bf_lo(u[0])); v[1] = acc[rt][ct][4 * g + 1] * gelu_grad_f(bf_hi(u[0]));
+              v[2] = acc[rt][ct][4 * g + 2] * gelu_grad_f(bf_lo(u[1])); v[3] = acc[rt][ct][4 * g + 3] * gelu_grad_f(bf_hi(u[1]));
+            }
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = (E & E_BIAS) ? acc[rt][ct][4 * g + e] + bias[ct][g][e] : acc[rt][ct][4 * g + e];
           }
+          if ((E & E_GELU) && (E & E_AUXD)) {                   // GELU and its derivative from one erf / exp: the derivative rows leave through aux
+            float gv[4], dv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gelu_both_f(v[e], gv[e], dv[e]);
+            *(u32x2*)wp = (u32x2){pack_h2(dv[0], dv[1]), pack_h2(dv[2], dv[3])};
+            held[ct][g] = (u32x2){pack_bf2(gv[0], gv[1]), pack_bf2(gv[2], gv[3])};
+          } else
           *(u32x2*)wp = (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
           // (the activations stay in hipcc's order, value pair by value pair on packed fp32 ops: a lone wave issues a VALU instruction every ~8 cycles whatever
           //  the dependencies, so instruction COUNT is the cost -- a stage-by-stage 8-wide form without packed ops measured 10-25 % slower)
-          if (E & E_GELU) held[ct][g] = (u32x2){pack_bf2(gelu_f(v[0]), gelu_f(v[1])), pack_bf2(gelu_f(v[2]), gelu_f(v[3]))};
+          if ((E & E_GELU) && !(E & E_AUXD)) held[ct][g] = (u32x2){pack_bf2(gelu_f(v[0]), gelu_f(v[1])), pack_bf2(gelu_f(v[2]), gelu_f(v[3]))};
 #ifndef VDK_EMU
           if ((E & (E_GELU | E_DGELU)) && g == 3) __builtin_amdgcn_sched_barrier(0);   // 16 activations in flight are plenty; all 64 at once spill
 #endif
@@ -377,7 +401,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
       }
     }
   } else if constexpr (E == (E_BIAS | E_RES | E_F32)) {
-    // fp32 output + fp32 residual (proj / fc2 into the residual stream): bias is added in the accumulator layout, 32 x 64 fp32 blocks go through the staging
+    // fp32 output + fp32 residual (proj / fc2 into the residual stream): 32 x 64 fp32 blocks of the accumulators go through the staging
     // (16-byte chunk c of row r at position c ^ (r & 15)), and a row pass (4 rows x 256 B per instruction) adds the residual rows and stores -- buffer
     // descriptors again: no 64-bit address arithmetic, no branch, rows beyond M and columns beyond N fall out of range.
     float* const slab = (float*)stage;
@@ -386,56 +410,60 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, (int)((unsigned)p.M * (unsigned)p.ldr * 4u), 0x00020000);
     if constexpr (DEEP >= 0) W4_WAIT_VM(DEEP);
     if (p.dbg) ts[0] = __builtin_readcyclecounter();
+    // Bias is added in the row pass (this lane: 4 columns of every row, one f32x4 per column pair) in the order (acc + bias) + residual of the other kernels; the
+    // residual rows of a 32 x 64 block are requested ONE BLOCK AHEAD: a lone wave has nothing to hide the ~2 us of an HBM read behind, and 8 blocks per tile waited for it.
+    constexpr int NCP = NCT / 2, NB = NCP * 4;
+    unsigned lane_out[NCP], lane_res[NCP];
+    f32x4 bias4[NCP];
 #pragma unroll
-    for (int cp = 0; cp < NCT / 2; ++cp) {
+    for (int cp = 0; cp < NCP; ++cp) {
       const int ncol = ncol0 + cp * 64 + rc * 4;
       const bool nok = ncol < p.N;
-      const unsigned lane_out = nok ? (unsigned)rrow * (unsigned)p.ldc * 4u + (unsigned)ncol * 4u : W4_OOB;
-      const unsigned lane_res = nok ? (unsigned)rrow * (unsigned)p.ldr * 4u + (unsigned)ncol * 4u : W4_OOB;
-      f32x4 bias[2][4];
+      lane_out[cp] = nok ? (unsigned)rrow * (unsigned)p.ldc * 4u + (unsigned)ncol * 4u : W4_OOB;
+      lane_res[cp] = nok ? (unsigned)rrow * (unsigned)p.ldr * 4u + (unsigned)ncol * 4u : W4_OOB;
+      bias4[cp] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (nok) bias4[cp] = *(const f32x4*)(p.bias + ncol);
+    }
+    u32x4 rn[8];
+    auto res_request = [&](int b) {
+      const int cp_ = b >> 2, rt_ = b & 3;
+      const unsigned srow_r = (unsigned)(mrow0 + rt_ * 32) * (unsigned)p.ldr * 4u;
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) rn[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, lane_res[cp_], srow_r + (unsigned)(ps * 4) * (unsigned)p.ldr * 4u, 0);
+    };
+    res_request(0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int cp = b >> 2, rt = b & 3;
+      const unsigned srow_o = (unsigned)(mrow0 + rt * 32) * (unsigned)p.ldc * 4u;
+      if (!W4_EPI_AHEAD && b > 0) res_request(b);
+      f32x4 r[8];
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) r[ps] = (f32x4){__uint_as_float(rn[ps][0]), __uint_as_float(rn[ps][1]), __uint_as_float(rn[ps][2]), __uint_as_float(rn[ps][3])};
+      if (W4_EPI_AHEAD && b + 1 < NB) res_request(b + 1);
 #pragma unroll
       for (int ctl = 0; ctl < 2; ++ctl)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int n = ncol0 + cp * 64 + ctl * 32 + 8 * g + 4 * hi;
-          bias[ctl][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (n < p.N) bias[ctl][g] = *(const f32x4*)(p.bias + n);
+          const f32x16& a = acc[rt][cp * 2 + ctl];
+          *(f32x4*)(slab + l31 * 64 + (((ctl * 8 + 2 * g + hi) ^ (l31 & 15)) << 2)) = (f32x4){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
         }
+      W4_EPI_SYNC();
+      f32x4 d[8];
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        // the residual rows of this block: requested first, they travel while the block is staged
-        const unsigned srow_r = (unsigned)(mrow0 + rt * 32) * (unsigned)p.ldr * 4u, srow_o = (unsigned)(mrow0 + rt * 32) * (unsigned)p.ldc * 4u;
-        f32x4 r[8];
-#pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-          const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_res, lane_res, srow_r + (unsigned)(ps * 4) * (unsigned)p.ldr * 4u, 0);
-          r[ps] = (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
-        }
-#pragma unroll
-        for (int ctl = 0; ctl < 2; ++ctl)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x16& a = acc[rt][cp * 2 + ctl];
-            const f32x4 x = {a[4 * g] + bias[ctl][g][0], a[4 * g + 1] + bias[ctl][g][1], a[4 * g + 2] + bias[ctl][g][2], a[4 * g + 3] + bias[ctl][g][3]};
-            *(f32x4*)(slab + l31 * 64 + (((ctl * 8 + 2 * g + hi) ^ (l31 & 15)) << 2)) = x;
-          }
-        W4_EPI_SYNC();
-        f32x4 d[8];
-#pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-          const int row = ps * 4 + rrow;
-          d[ps] = *(const f32x4*)(slab + row * 64 + ((rc ^ (row & 15)) << 2));
-        }
-#pragma unroll
-        for (int ps = 0; ps < 8; ++ps) d[ps] += r[ps];
-        // (everything that touches the row registers precedes the stores; row block in the vector offset: see the bf16 form above)
-#pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-          const u32x4 o = {__float_as_uint(d[ps][0]), __float_as_uint(d[ps][1]), __float_as_uint(d[ps][2]), __float_as_uint(d[ps][3])};
-          __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, lane_out + (srow_o + (unsigned)(ps * 4) * (unsigned)p.ldc * 4u), 0, 0);
-        }
-        W4_EPI_SYNC();
+      for (int ps = 0; ps < 8; ++ps) {
+        const int row = ps * 4 + rrow;
+        d[ps] = *(const f32x4*)(slab + row * 64 + ((rc ^ (row & 15)) << 2));
       }
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) d[ps] = (d[ps] + bias4[cp]) + r[ps];
+      // (everything that touches the row registers precedes the stores; row block in the vector offset: see the bf16 form above)
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {
+        const u32x4 o = {__float_as_uint(d[ps][0]), __float_as_uint(d[ps][1]), __float_as_uint(d[ps][2]), __float_as_uint(d[ps][3])};
+        __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, lane_out[cp] + (srow_o + (unsigned)(ps * 4) * (unsigned)p.ldc * 4u), 0, 0);
+      }
+      W4_EPI_SYNC();
     }
   } else {
     float* const slab = (float*)stage;
@@ -895,6 +923,9 @@ static bool w4_launch_one(const GemmParams& p, bool trans, int E, unsigned tiles
     case E_BIAS: W4_LAUNCH(false, E_BIAS);
     case E_BIAS | E_GELU: W4_LAUNCH(false, E_BIAS | E_GELU);
     case E_DGELU: W4_LAUNCH(false, E_DGELU);
+    case E_BIAS | E_GELU | E_AUXD: W4_LAUNCH(false, E_BIAS | E_GELU | E_AUXD);
+    case E_DGELU | E_AUXD: W4_LAUNCH(false, E_DGELU | E_AUXD);
+    case E_DGELU | E_OCS | E_AUXD: W4_LAUNCH(false, E_DGELU | E_OCS | E_AUXD);
     case E_BIAS | E_RES | E_F32: W4_LAUNCH(false, E_BIAS | E_RES | E_F32);
     case E_BIAS | E_RES | E_F32 | E_ROWGRP: W4_LAUNCH(false, E_BIAS | E_RES | E_F32 | E_ROWGRP);
     case E_SPLITK: W4_LAUNCH(false, E_SPLITK);
@@ -940,6 +971,9 @@ bool vdk_gemm_w4h_launch(const GemmParams& p_, bool trans, int E, unsigned split
     case E_BIAS: W4H_LAUNCH(false, E_BIAS);
     case E_BIAS | E_GELU: W4H_LAUNCH(false, E_BIAS | E_GELU);
     case E_DGELU: W4H_LAUNCH(false, E_DGELU);
+    case E_BIAS | E_GELU | E_AUXD: W4H_LAUNCH(false, E_BIAS | E_GELU | E_AUXD);
+    case E_DGELU | E_AUXD: W4H_LAUNCH(false, E_DGELU | E_AUXD);
+    case E_DGELU | E_OCS | E_AUXD: W4H_LAUNCH(false, E_DGELU | E_OCS | E_AUXD);
     case E_BIAS | E_RES | E_F32: W4H_LAUNCH(false, E_BIAS | E_RES | E_F32);
     case E_BIAS | E_RES | E_F32 | E_ROWGRP: W4H_LAUNCH(false, E_BIAS | E_RES | E_F32 | E_ROWGRP);
     case E_SPLITK: W4H_LAUNCH(false, E_SPLITK);

@@ -150,6 +150,23 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
+// two fp32 -> packed fp16 (round to nearest even) and back
+typedef _Float16 vdk_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_h2(float a, float b) {
+  const vdk_f16x2 h = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ float h_lo(unsigned u) { return (float)__builtin_bit_cast(vdk_f16x2, u)[0]; }
+__device__ __forceinline__ float h_hi(unsigned u) { return (float)__builtin_bit_cast(vdk_f16x2, u)[1]; }
+
+// GELU(x) (bit-identical to gelu_f) and GELU'(x) from one erf / exp evaluation
+__device__ __forceinline__ void gelu_both_f(float x, float& g, float& d) {
+  float e;
+  const float h = 1.0f + erf_as(x * 0.70710678118654752f, e);
+  g = 0.5f * x * h;
+  d = fmaf(x * 0.3989422804014327f, e, 0.5f * h);
+}
+
 // monotone float -> uint32 key (larger float -> larger key)
 __device__ __forceinline__ unsigned f2ord(float f) {
   unsigned u = __float_as_uint(f);

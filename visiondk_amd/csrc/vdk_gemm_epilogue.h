@@ -38,6 +38,15 @@ __device__ __forceinline__ void g_epilogue_store8(const GemmParams& p, long mi, 
         v[2 * e] *= gelu_grad_f(bf_lo(u[e]));
         v[2 * e + 1] *= gelu_grad_f(bf_hi(u[e]));
       }
+    } else if (p.act == VDK_ACT_GELU_SAVE_GRAD) {  // GELU, its derivative saved for the backward pass
+      float d[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gelu_both_f(v[e], v[e], d[e]);
+      *(u32x4*)(p.aux + m * p.ldaux + n) = (u32x4){pack_h2(d[0], d[1]), pack_h2(d[2], d[3]), pack_h2(d[4], d[5]), pack_h2(d[6], d[7])};
+    } else if (p.act == VDK_ACT_MUL_AUX) {  // dL/du = dL/dg * saved gelu'(u) (fp16)
+      u32x4 u = *(const u32x4*)(p.aux + m * p.ldaux + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[2 * e] *= h_lo(u[e]); v[2 * e + 1] *= h_hi(u[e]); }
     }
     if (p.residual) {
       const float* rs = p.residual + mr * p.ldr + n;
@@ -71,6 +80,7 @@ __device__ __forceinline__ void g_epilogue_store8(const GemmParams& p, long mi, 
 #define E_MSTAT 256   /* margin head, pass 1: per-(row, 64-column slice) online-softmax partials of the margin logits; nothing is stored to C */
 #define E_MGRAD 512   /* margin head, pass 2: C = bf16 d(loss)/d(cos) from the row statistics */
 #define E_Q8 1024     /* by-product: fp8(clamp(stored bf16 value * q8_scale)) -> p.q8, max |value| -> p.q8_amax: bit-identical to vdk_quant_fp8 over the stored tensor */
+#define E_AUXD 2048    /* with E_GELU: aux receives fp16 GELU'(pre-activation) instead of the bf16 pre-activation; with E_DGELU: aux holds that derivative (one multiplication) */
 #define E_GENERIC 0x1000
 
 // SWZ: the slab's 16-byte chunk c of row r lives at chunk position c ^ (r & 15) (bank-conflict-free for the row-per-lane writes of gemm_w4.hip)
@@ -157,12 +167,20 @@ __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += bias8[e];
     }
-    if (E & E_GELU) {
+    if ((E & E_GELU) && (E & E_AUXD)) {
+      float dv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gelu_both_f(v[e], v[e], dv[e]);
+      *(u32x4*)(p.aux + mo[ps] * p.ldaux + n) = (u32x4){pack_h2(dv[0], dv[1]), pack_h2(dv[2], dv[3]), pack_h2(dv[4], dv[5]), pack_h2(dv[6], dv[7])};
+    } else if (E & E_GELU) {
       *(u32x4*)(p.aux + mo[ps] * p.ldaux + n) = (u32x4){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
     }
-    if (E & E_DGELU) {
+    if ((E & E_DGELU) && (E & E_AUXD)) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[2 * e] *= h_lo(ux[ps][e]); v[2 * e + 1] *= h_hi(ux[ps][e]); }
+    } else if (E & E_DGELU) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[2 * e] *= gelu_grad_f(bf_lo(ux[ps][e])); v[2 * e + 1] *= gelu_grad_f(bf_hi(ux[ps][e])); }
     }

@@ -525,6 +525,15 @@ static int linear_wgrad(hipStream_t s, const VitDims& d, const WsPlan& w, char* 
 // The partial sums land in column-sum buffer `slot` (0..3) and their reduction is appended to `jobs` for the block's one batched launch.
 // dbx (optional): bias gradient of the Linear whose dY is this GEMM's OUTPUT dX (the previous Linear in the backward order) = column sums of the stored bf16 dX,
 // accumulated in the epilogue (c_colsum by-product, partials in buffer `slot + 4`... the caller passes a distinct slot); *fusedx says whether that happened.
+// qkv.bias gradient as its own column-sum pass (see the call site); VDK_VIT_QKVB_PASS=0 restores the GEMM by-product form
+static bool qkvb_pass(int T, int N, size_t csws_bytes) {
+  static const int env = getenv("VDK_VIT_QKVB_PASS") ? atoi(getenv("VDK_VIT_QKVB_PASS")) : -1;
+  if (env == 0) return false;
+  size_t need = 0;
+  if (vdk_colsum_bf16_workspace_bytes(T, N, &need) != VDK_OK || need > csws_bytes) return false;
+  return true;      // measured on one box (two runs each): 37.47 -> 37.24 ms per ViT-B/16 step, GEMM average 184.8 -> 179.4 us per launch
+}
+
 static int dgrad_with_bias(hipStream_t s, const WsPlan& w, char* base, const bf16_t* dY, int64_t lddy, const bf16_t* Wt, int64_t ldw, void* dX, int64_t lddx, int rows,
                            int in, int out, int act, void* aux, int64_t ldaux, float* db, int* fused, int slot, VdkReduceJob* jobs, int* njobs,
                            float* dbx = nullptr, int* fusedx = nullptr, int slotx = 0) {
@@ -704,6 +713,12 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
       RC(gemm8(s, f8, dqkv, 12 * l + 11, 1, f8.wt8 + p.blkT[l].qkv, 12 * l + 4, 3 * D, dsm, D, T, D, 3 * D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0,
                fcq ? f8.a8 : nullptr));   // dh1
       RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, fcq ? nullptr : grads + b.qkv_b, 0));
+    } else if (one_stream && qkvb_pass(T, 3 * D, w.csws_bytes)) {
+      // qkv.bias = column sums of dqkv (attention's output: no producing GEMM epilogue to ride on) as one pass over it, so that the dh1 GEMM is the plain
+      // one-wave-per-SIMD kernel instead of the eight-wave kernel with the A-tile column-sum by-product (A/B on one box: see DESIGN.md)
+      RC(vdk_colsum_bf16_deferred(dqkv, 3 * D, T, 3 * D, grads + b.qkv_b, base + w.csws + (size_t)3 * w.csws_bytes, w.csws_bytes, s, &jobs[nj], nullptr)); ++nj;
+      RC(gemm(s, dqkv, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // dh1
+      RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, nullptr, 0));
     } else if (one_stream) {
       RC(dgrad_with_bias(s, w, base, dqkv, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, VDK_ACT_NONE, nullptr, 0, grads + b.qkv_b, &fz, 3, jobs, &nj));   // dh1
       RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, fz ? nullptr : grads + b.qkv_b, 0));

@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _abi, _lib
-from ._abi import ACT_DGELU, ACT_GELU, ACT_NONE  # noqa: F401
+from ._abi import ACT_DGELU, ACT_GELU, ACT_GELU_SAVE_GRAD, ACT_MUL_AUX, ACT_NONE  # noqa: F401
 
 
 def _be(backend):
