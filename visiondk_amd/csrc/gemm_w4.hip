@@ -355,24 +355,27 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
               v[0] = acc[rt][ct][4 * g + 0] * h_lo(u[0]); v[1] = acc[rt][ct][4 * g + 1] * h_hi(u[0]);
               v[2] = acc[rt][ct][4 * g + 2] * h_lo(u[1]); v[3] = acc[rt][ct][4 * g + 3] * h_hi(u[1]);
             } else {
-              v[0] = acc[rt][ct][4 * g + 0] * gelu_grad_f(bf_lo(u[0])); v[1] = acc[rt][ct][4 * g + 1] * gelu_grad_f(bf_hi(u[0]));
-              v[2] = acc[rt][ct][4 * g + 2] * gelu_grad_f(bf_lo(u[1])); v[3] = acc[rt][ct][4 * g + 3] * gelu_grad_f(bf_hi(u[1]));
+              const vdk_f32x2 d0 = gelu_grad_f2((vdk_f32x2){bf_lo(u[0]), bf_hi(u[0])}), d1 = gelu_grad_f2((vdk_f32x2){bf_lo(u[1]), bf_hi(u[1])});
+              v[0] = acc[rt][ct][4 * g + 0] * d0[0]; v[1] = acc[rt][ct][4 * g + 1] * d0[1];
+              v[2] = acc[rt][ct][4 * g + 2] * d1[0]; v[3] = acc[rt][ct][4 * g + 3] * d1[1];
             }
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = (E & E_BIAS) ? acc[rt][ct][4 * g + e] + bias[ct][g][e] : acc[rt][ct][4 * g + e];
           }
           if ((E & E_GELU) && (E & E_AUXD)) {                   // GELU and its derivative from one erf / exp: the derivative rows leave through aux
-            float gv[4], dv[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gelu_both_f(v[e], gv[e], dv[e]);
-            *(u32x2*)wp = (u32x2){pack_h2(dv[0], dv[1]), pack_h2(dv[2], dv[3])};
-            held[ct][g] = (u32x2){pack_bf2(gv[0], gv[1]), pack_bf2(gv[2], gv[3])};
+            vdk_f32x2 g0, g1, d0, d1;
+            gelu_both_f2((vdk_f32x2){v[0], v[1]}, g0, d0); gelu_both_f2((vdk_f32x2){v[2], v[3]}, g1, d1);
+            *(u32x2*)wp = (u32x2){pack_h2(d0[0], d0[1]), pack_h2(d1[0], d1[1])};
+            held[ct][g] = (u32x2){pack_bf2(g0[0], g0[1]), pack_bf2(g1[0], g1[1])};
           } else
           *(u32x2*)wp = (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
           // (the activations stay in hipcc's order, value pair by value pair on packed fp32 ops: a lone wave issues a VALU instruction every ~8 cycles whatever
           //  the dependencies, so instruction COUNT is the cost -- a stage-by-stage 8-wide form without packed ops measured 10-25 % slower)
-          if ((E & E_GELU) && !(E & E_AUXD)) held[ct][g] = (u32x2){pack_bf2(gelu_f(v[0]), gelu_f(v[1])), pack_bf2(gelu_f(v[2]), gelu_f(v[3]))};
+          if ((E & E_GELU) && !(E & E_AUXD)) {
+            const vdk_f32x2 g0 = gelu_f2((vdk_f32x2){v[0], v[1]}), g1 = gelu_f2((vdk_f32x2){v[2], v[3]});
+            held[ct][g] = (u32x2){pack_bf2(g0[0], g0[1]), pack_bf2(g1[0], g1[1])};
+          }
 #ifndef VDK_EMU
           if ((E & (E_GELU | E_DGELU)) && g == 3) __builtin_amdgcn_sched_barrier(0);   // 16 activations in flight are plenty; all 64 at once spill
 #endif

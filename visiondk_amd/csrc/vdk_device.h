@@ -139,16 +139,49 @@ __device__ __forceinline__ float erf_as(float z, float& e) {
   const float r = 1.0f - p * t * e;
   return z < 0.f ? -r : r;
 }
-// exact-erf GELU (timm nn.GELU default, approximate='none') and its derivative
-__device__ __forceinline__ float gelu_f(float x) {
-  float e;
-  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f, e));
+// The two terms exact-erf GELU (timm nn.GELU default, approximate='none') and its derivative are made of, from the same approximation: q = erfc(|x| / sqrt 2)
+// (the tail itself, never 1 - erf: no cancellation for negative x) and e = exp(-x^2 / 2).  Constants folded: exp(-x^2 / 2) = 2^-(s^2) with s = x sqrt(log2(e) / 2), and
+// t = 1 / (1 + 0.3275911 |x| / sqrt 2).  x erf(x / sqrt 2) = |x| (1 - q) is even in x, so neither function selects on the sign:
+//   GELU(x) = max(x, 0) - |x| q / 2,      GELU'(x) = 1/2 + copysign(1/2 - q/2, x) + x e / sqrt(2 pi).
+// Written on PAIRS of values: every step except the two transcendentals (v_exp_f32, v_rcp_f32), |x| (an AND) and max(x, 0) is one packed fp32 instruction for two
+// values (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) -- a wave that has its SIMD to itself issues one VALU instruction every ~5 cycles whatever the dependencies,
+// so the epilogues that evaluate these cost their instruction COUNT.  The scalar forms below evaluate the same operations in the same order (bit-identical).
+typedef float vdk_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ vdk_f32x2 vdk_fma2(vdk_f32x2 a, vdk_f32x2 b, vdk_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ void gelu_terms2(vdk_f32x2 x, vdk_f32x2& ax, vdk_f32x2& q, vdk_f32x2& e) {
+  ax = (vdk_f32x2){__uint_as_float(__float_as_uint(x[0]) & 0x7fffffffu), __uint_as_float(__float_as_uint(x[1]) & 0x7fffffffu)};
+  const vdk_f32x2 xx = x * x;
+  const vdk_f32x2 ea = xx * -0.72134752044448170f;             // -log2(e) / 2
+  const vdk_f32x2 den = vdk_fma2(ax, (vdk_f32x2){0.23164188843369479f, 0.23164188843369479f}, (vdk_f32x2){1.0f, 1.0f});   // 0.3275911 / sqrt 2
+  e = (vdk_f32x2){fast_exp2(ea[0]), fast_exp2(ea[1])};
+  const vdk_f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  vdk_f32x2 p = vdk_fma2(t, (vdk_f32x2){1.061405429f, 1.061405429f}, (vdk_f32x2){-1.453152027f, -1.453152027f});
+  p = vdk_fma2(p, t, (vdk_f32x2){1.421413741f, 1.421413741f});
+  p = vdk_fma2(p, t, (vdk_f32x2){-0.284496736f, -0.284496736f});
+  p = vdk_fma2(p, t, (vdk_f32x2){0.254829592f, 0.254829592f});
+  q = (p * t) * e;
 }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-  float e;
-  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f, e));
-  return fmaf(x * 0.3989422804014327f, e, cdf);
+__device__ __forceinline__ vdk_f32x2 gelu_f2(vdk_f32x2 x) {
+  vdk_f32x2 ax, q, e;
+  gelu_terms2(x, ax, q, e);
+  return vdk_fma2(ax * -0.5f, q, (vdk_f32x2){fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)});
 }
+__device__ __forceinline__ vdk_f32x2 gelu_grad_f2(vdk_f32x2 x) {
+  vdk_f32x2 ax, q, e;
+  gelu_terms2(x, ax, q, e);
+  const vdk_f32x2 h = vdk_fma2(q, (vdk_f32x2){-0.5f, -0.5f}, (vdk_f32x2){0.5f, 0.5f});
+  const vdk_f32x2 cdf = (vdk_f32x2){copysignf(h[0], x[0]), copysignf(h[1], x[1])} + 0.5f;
+  return vdk_fma2(x * 0.3989422804014327f, e, cdf);
+}
+__device__ __forceinline__ void gelu_both_f2(vdk_f32x2 x, vdk_f32x2& g, vdk_f32x2& d) {
+  vdk_f32x2 ax, q, e;
+  gelu_terms2(x, ax, q, e);
+  g = vdk_fma2(ax * -0.5f, q, (vdk_f32x2){fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)});
+  const vdk_f32x2 h = vdk_fma2(q, (vdk_f32x2){-0.5f, -0.5f}, (vdk_f32x2){0.5f, 0.5f});
+  d = vdk_fma2(x * 0.3989422804014327f, e, (vdk_f32x2){copysignf(h[0], x[0]), copysignf(h[1], x[1])} + 0.5f);
+}
+__device__ __forceinline__ float gelu_f(float x) { return gelu_f2((vdk_f32x2){x, x})[0]; }
+__device__ __forceinline__ float gelu_grad_f(float x) { return gelu_grad_f2((vdk_f32x2){x, x})[0]; }
 
 // two fp32 -> packed fp16 (round to nearest even) and back
 typedef _Float16 vdk_f16x2 __attribute__((ext_vector_type(2)));
@@ -159,12 +192,10 @@ __device__ __forceinline__ unsigned pack_h2(float a, float b) {
 __device__ __forceinline__ float h_lo(unsigned u) { return (float)__builtin_bit_cast(vdk_f16x2, u)[0]; }
 __device__ __forceinline__ float h_hi(unsigned u) { return (float)__builtin_bit_cast(vdk_f16x2, u)[1]; }
 
-// GELU(x) (bit-identical to gelu_f) and GELU'(x) from one erf / exp evaluation
 __device__ __forceinline__ void gelu_both_f(float x, float& g, float& d) {
-  float e;
-  const float h = 1.0f + erf_as(x * 0.70710678118654752f, e);
-  g = 0.5f * x * h;
-  d = fmaf(x * 0.3989422804014327f, e, 0.5f * h);
+  vdk_f32x2 g2, d2;
+  gelu_both_f2((vdk_f32x2){x, x}, g2, d2);
+  g = g2[0]; d = d2[0];
 }
 
 // monotone float -> uint32 key (larger float -> larger key)

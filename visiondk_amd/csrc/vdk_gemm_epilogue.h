@@ -30,13 +30,14 @@ __device__ __forceinline__ void g_epilogue_store8(const GemmParams& p, long mi, 
         *(u32x4*)(p.aux + m * p.ldaux + n) = u;
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+      for (int e = 0; e < 4; ++e) { const vdk_f32x2 g2 = gelu_f2((vdk_f32x2){v[2 * e], v[2 * e + 1]}); v[2 * e] = g2[0]; v[2 * e + 1] = g2[1]; }
     } else if (p.act == VDK_ACT_DGELU) {  // dL/du = dL/dg * gelu'(u), u = saved pre-activation
       u32x4 u = *(const u32x4*)(p.aux + m * p.ldaux + n);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[2 * e] *= gelu_grad_f(bf_lo(u[e]));
-        v[2 * e + 1] *= gelu_grad_f(bf_hi(u[e]));
+        const vdk_f32x2 d2 = gelu_grad_f2((vdk_f32x2){bf_lo(u[e]), bf_hi(u[e])});
+        v[2 * e] *= d2[0];
+        v[2 * e + 1] *= d2[1];
       }
     } else if (p.act == VDK_ACT_GELU_SAVE_GRAD) {  // GELU, its derivative saved for the backward pass
       float d[8];
@@ -175,14 +176,14 @@ __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float
     } else if (E & E_GELU) {
       *(u32x4*)(p.aux + mo[ps] * p.ldaux + n) = (u32x4){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+      for (int e = 0; e < 4; ++e) { const vdk_f32x2 g2 = gelu_f2((vdk_f32x2){v[2 * e], v[2 * e + 1]}); v[2 * e] = g2[0]; v[2 * e + 1] = g2[1]; }
     }
     if ((E & E_DGELU) && (E & E_AUXD)) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[2 * e] *= h_lo(ux[ps][e]); v[2 * e + 1] *= h_hi(ux[ps][e]); }
     } else if (E & E_DGELU) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[2 * e] *= gelu_grad_f(bf_lo(ux[ps][e])); v[2 * e + 1] *= gelu_grad_f(bf_hi(ux[ps][e])); }
+      for (int e = 0; e < 4; ++e) { const vdk_f32x2 d2 = gelu_grad_f2((vdk_f32x2){bf_lo(ux[ps][e]), bf_hi(ux[ps][e])}); v[2 * e] *= d2[0]; v[2 * e + 1] *= d2[1]; }
     }
     if (E & E_RES) {
 #pragma unroll
