@@ -89,7 +89,7 @@ def pmc_traffic_per_launch():
     """HBM-side bytes per GEMM launch from the committed PMC passes of this same command (rocprofv3 cannot run inside the timed process):
     profiles/r0N_pmc_traffic.json is written by tools/pmc_traffic.py from two `rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE}` runs,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  None if the artifact is absent."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):      # the newest round's passes of this command
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):      # the newest round's passes of this command
         p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             with open(p) as f:
@@ -101,12 +101,14 @@ def pmc_traffic_per_launch():
 
 def pmc_cbir():
     """L2 memory-side bytes of one search from the committed PMC passes of tools/pmc_cbir.py (None if absent)"""
-    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_cbir_pmc.json")
-    try:
-        with open(p) as f:
-            return json.load(f)
-    except (OSError, ValueError):
-        return None
+    for name in ("r03_cbir_pmc.json", "r02_cbir_pmc.json"):
+        p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+        try:
+            with open(p) as f:
+                return json.load(f)
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 def bench_cbir(dev, nq=10000, n=1_000_000, d=128, k=100, iters=6, with_cpu=True):
@@ -116,7 +118,7 @@ def bench_cbir(dev, nq=10000, n=1_000_000, d=128, k=100, iters=6, with_cpu=True)
     g.manual_seed(1)
     qry = cbir.l2_normalize(torch.randn(nq, d, generator=g).to(dev))
 
-    def timed(method, storage="float32", optimistic=False, gal_=None, qry_=None, dim=d, small_lists=False):
+    def timed(method, storage="float32", optimistic=False, gal_=None, qry_=None, dim=d, small_lists=True):
         index = cbir.FlatIPIndex(dim, device=dev, method=method, storage=storage, optimistic=optimistic, small_lists=small_lists)
         index.add(gal if gal_ is None else gal_)
         qq = qry if qry_ is None else qry_
@@ -131,8 +133,8 @@ def bench_cbir(dev, nq=10000, n=1_000_000, d=128, k=100, iters=6, with_cpu=True)
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters, s, i, index.fallbacks
 
-    ms, s, i, fb = timed("prefilter")
-    ms_gs, s_gs, i_gs, fb_s = timed("prefilter", small_lists=True)     # the same stages with 16 384-entry candidate lists (1.5 GB instead of 8.0 GB of workspace) + overflow fallback
+    ms, s, i, fb = timed("prefilter")                                  # default: 16 384-entry candidate lists (1.5 GB of workspace), overflow reported and repaired
+    ms_gs, s_gs, i_gs, fb_s = timed("prefilter", small_lists=False)    # the guaranteed schedule alone: lists of cap entries (8.0 GB), no host read
     ms_g, s_g, i_g, fb_o = timed("prefilter", optimistic=True)      # bootstrap + two stages, overflow-checked (measured slower: more survivors per query)
     ms_scan, s_scan, i_scan, _ = timed("exact_scan")
     ms16, s16, i16, _ = timed("prefilter", storage="float16")      # faiss useFloat16 storage
@@ -168,10 +170,10 @@ def bench_cbir(dev, nq=10000, n=1_000_000, d=128, k=100, iters=6, with_cpu=True)
                                                        "note": f"algorithmic bytes per BASELINE.md §2 (qb={qb}, s_g=4 B): {alg_bytes / 1e9:.2f} GB per search"},
                         "measured_traffic_GBps": None if pmc is None else pmc.get("bytes_per_search", 0) / (ms * 1e-3) / 1e9,
                         "pmc": pmc},
-           "workspace": "guaranteed schedule: candidate lists of cap = 98 304 entries per query (8.0 GB at 10 k queries), cannot overflow, no host read",
-           "small_candidate_lists": {"ms_per_search": ms_gs, "value": nq * n / (ms_gs * 1e-3), "workspace_GB": 1.48, "fallbacks": fb_s,
-                                     "note": "FlatIPIndex(small_lists=True): 16 384-entry lists, overflow reported by the kernels and repaired with the guaranteed schedule (one flag read per search)",
-                                     "bit_equal": bool(torch.equal(i, i_gs) and torch.equal(s.view(torch.int32), s_gs.view(torch.int32)))},
+           "workspace": "default: candidate lists of 16 384 entries per query (1.48 GB at 10 k queries); an overflow is reported by the kernels and repaired with the guaranteed schedule (one flag read per search)",
+           "guaranteed_schedule_only": {"ms_per_search": ms_gs, "value": nq * n / (ms_gs * 1e-3), "workspace_GB": 8.0, "fallbacks": fb_s,
+                                        "note": "FlatIPIndex(small_lists=False): lists of cap = 98 304 entries, cannot overflow, no host read",
+                                        "bit_equal": bool(torch.equal(i, i_gs) and torch.equal(s.view(torch.int32), s_gs.view(torch.int32)))},
            "optimistic_two_stage_schedule": {"ms_per_search": ms_g, "value": nq * n / (ms_g * 1e-3), "fallbacks": fb_o,
                                              "bit_equal": bool(torch.equal(i, i_g) and torch.equal(s.view(torch.int32), s_g.view(torch.int32)))},
            "float16_storage": {"ms_per_search": ms16, "value": nq * n / (ms16 * 1e-3),
@@ -424,7 +426,7 @@ def main():
                                "achieved": gemm_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": gemm_tflops / PEAK_BF16_TFLOPS, "traffic": pmc_traffic_per_launch(),
                                "algorithmic_bytes_per_launch": gemm["bytes"] / max(gemm["n"], 1),
-                               "avg_launch_ms": gemm_avg_ms, "launches": gemm["n"],
+                               "avg_launch_ms": gemm_avg_ms, "launches": gemm["n"], "gemm_calls_per_step": gemm["n"] // max(1, -(-args.steps // GEMM_EVENT_STRIDE)),
                                "timed_launches": f"every GEMM dispatch of every {GEMM_EVENT_STRIDE}th step of the timed region (start / stop events attached to the dispatch itself)",
                                "flops_per_launch": gemm["flops"] / max(gemm["n"], 1),
                                "gemm_share_of_step_time": (gemm["ms"] / max(1, -(-args.steps // GEMM_EVENT_STRIDE))) / (dt / args.steps * 1e3)}

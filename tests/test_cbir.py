@@ -224,8 +224,9 @@ def test_small_candidate_lists_equal_guaranteed_schedule_and_fall_back_on_overfl
     identical rows (every row survives every threshold) overflows the small lists and must take the fallback."""
     rng = np.random.default_rng(11)
     g = ocbir.l2norm_rows(rng.standard_normal((6000, 128), dtype=np.float32)); q = ocbir.l2norm_rows(rng.standard_normal((70, 128), dtype=np.float32))
-    a = cbir.FlatIPIndex(128, backend=be, device=dev, cap=2048); a.add(g)
-    b = cbir.FlatIPIndex(128, backend=be, device=dev, cap=2048, small_lists=True); b.add(g)
+    a = cbir.FlatIPIndex(128, backend=be, device=dev, cap=2048, small_lists=False); a.add(g)
+    b = cbir.FlatIPIndex(128, backend=be, device=dev, cap=2048); b.add(g)      # small_lists=True is the default
+    assert b.small_lists and not a.small_lists
     sa, ia = a.search(q, 50); sb, ib = b.search(q, 50)
     np.testing.assert_array_equal(ia, ib); np.testing.assert_array_equal(sa.view(np.uint32), sb.view(np.uint32))
     so, io = ocbir.flat_ip_search(q, g, 50)

@@ -13,7 +13,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d /tmp/p_$c -o p --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-parity --no-cpu-baseline --no-cbir > $O/pmc_${c}_stdout.txt 2>&1
 done
 F=$(find /tmp/p_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find /tmp/p_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-python $R/tools/pmc_traffic.py "$F" "$W" gemm256 $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
+CALLS=$(python -c "import json;print(7 * json.loads(open('$O/pmc_FETCH_SIZE_stdout.txt').read().strip().splitlines()[-1])['roofline']['gemm_calls_per_step'])")
+python $R/tools/pmc_traffic.py "$F" "$W" gemm $O/pmc_traffic.json $CALLS > $O/pmc_traffic.txt 2>&1
 tail -3 $O/pmc_traffic.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d /tmp/c_$c -o p --output-format csv -- python $R/tools/cbir_pmc_run.py 4 > $O/cbir_pmc_${c}_stdout.txt 2>&1
@@ -21,9 +22,11 @@ done
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/c_SQ -o p --output-format csv -- python $R/tools/cbir_pmc_run.py 4 > $O/cbir_pmc_SQ_stdout.txt 2>&1
 CF=$(find /tmp/c_FETCH_SIZE -name "*counter_collection.csv" | head -1); CW=$(find /tmp/c_WRITE_SIZE -name "*counter_collection.csv" | head -1); CS=$(find /tmp/c_SQ -name "*counter_collection.csv" | head -1)
 python $R/tools/pmc_cbir.py "$CF" "$CW" "${CS:--}" 4 $O/cbir_pmc.json > $O/cbir_pmc.txt 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/c_trace -o t -- python $R/tools/cbir_pmc_run.py 8 > $O/cbir_trace_stdout.txt 2>&1
+python $R/tools/rocpd_stats.py $(find /tmp/c_trace -name "*.db" | head -1) > $O/cbir_kernel_stats.txt
 tail -8 $O/cbir_pmc.txt
 cd $R
-cp $O/pmc_traffic.json profiles/r02_pmc_traffic.json 2>/dev/null; cp $O/cbir_pmc.json profiles/r02_cbir_pmc.json 2>/dev/null    # the bench line below reads them
+cp $O/pmc_traffic.json profiles/r03_pmc_traffic.json 2>/dev/null; cp $O/cbir_pmc.json profiles/r03_cbir_pmc.json 2>/dev/null    # the bench line below reads them
 python bench.py > $O/bench_stdout.txt 2> $O/bench_stderr.txt
 tail -1 $O/bench_stdout.txt > $O/bench.json
 python -c "

@@ -37,7 +37,9 @@ if sys.argv[3] != "-":
     busy = table(sys.argv[3], "SQ_VALU_MFMA_BUSY_CYCLES"); act = table(sys.argv[3], "GRBM_GUI_ACTIVE")
     for k in busy:
         if k in act and act[k][0] > 0:
-            # SQ_VALU_MFMA_BUSY_CYCLES is summed over the SIMDs that report (4 per CU x 256 CUs); GRBM_GUI_ACTIVE are chip cycles
-            out.setdefault("mfma_busy", {})[k] = {"mfma_busy_cycles": busy[k][0], "gui_active_cycles": act[k][0], "busy_per_simd_frac": busy[k][0] / (act[k][0] * 1024)}
+            # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs (4 per CU x 256 CUs); GRBM_GUI_ACTIVE is reported per XCD and rocprofv3 SUMS the 8 XCDs, so the
+            # kernel's duration in clocks is act / 8 and the per-SIMD busy fraction is busy / (1024 * act / 8) = busy / (128 * act)
+            out.setdefault("mfma_busy", {})[k] = {"mfma_busy_cycles": busy[k][0], "gui_active_cycles_summed_over_8_xcds": act[k][0],
+                                                  "busy_per_simd_frac": busy[k][0] / (act[k][0] * 128)}
 print("total per search: %.1f MB" % (out["bytes_per_search"] / 1e6))
 json.dump(out, open(sys.argv[5], "w"), indent=1)

