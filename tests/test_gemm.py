@@ -337,3 +337,21 @@ def test_gemm_gelu_with_saved_derivative(be, dev, kern):
             torch.testing.assert_close(part.sum(0).cpu(), out2.float().sum(0).cpu(), rtol=1e-4, atol=2e-3)
     finally:
         be.lib.vdk_gemm_force_kernel(0)
+
+
+def test_gemm_narrow_output_goes_to_the_256x128_kernel(be, dev, monkeypatch):
+    """128 <= N < 256 with many rows (ConvNeXt's first stage: C = 128) is one column of 256x128 tiles on the two-workgroups-per-CU kernel; below the row threshold the 128x128
+    kernel keeps it.  (The threshold is read once per process: this test only runs the narrow case when the environment of the process already lowered it.)"""
+    import os
+    torch.manual_seed(19)
+    M, N, K = 1100, 136, 192
+    a = torch.randn(M, K).bfloat16().to(dev); b = (torch.randn(N, K) * 0.2).bfloat16().to(dev)
+    bias = torch.randn(N).to(dev); res = torch.randn(M, N).to(dev)
+    ref = a.float() @ b.float().T
+    out = ops.gemm_nt(a, b, out_dtype=torch.float32, bias=bias, residual=res, backend=be)
+    assert _rel(out, ref + bias + res) < 1e-5
+    want = 6 if int(os.environ.get("VDK_GEMM_NARROW_MIN_M", "65536")) <= M else 1
+    assert be.lib.vdk_gemm_last_kernel() == want
+    out = ops.gemm_nt(a, b, backend=be)
+    assert _rel(out.float(), ref.bfloat16().float()) < 3e-3
+    assert be.lib.vdk_gemm_last_kernel() == want

@@ -711,6 +711,12 @@ static bool w4h_wanted(int E, bool trans, long M, long N, long K) {
   const long tiles = ((M + 255) / 256) * ((N + 255) / 256);
   return K <= 1024 && tiles <= 3 * 256;
 }
+// rows from which a 128 <= N < 256 problem goes to the 256x128 kernel (one workgroup per 256 rows: below ~one workgroup per CU the 128x128 kernel has more parallelism);
+// VDK_GEMM_NARROW_MIN_M overrides (tests)
+static long narrow_min_m() {
+  static const long v = getenv("VDK_GEMM_NARROW_MIN_M") ? atol(getenv("VDK_GEMM_NARROW_MIN_M")) : 65536L;
+  return v;
+}
 static bool w4_enabled() {
   return (w4_enabled_env() || g_force_kernel == 5) && g_force_kernel != 2 && g_force_kernel != 3 && g_force_kernel != 6;
 }
@@ -857,7 +863,10 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   const bool prof = g_prof_on && g_prof_used + 2 <= g_prof_ev.size();
   // big problems go to the 256x256 LDS-DMA kernel (needs whole 64-wide k-tiles per split and >= 1 full wave of tiles)
   const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * splitk;
-  const bool big = !d->conv && (g_force_kernel == 2 || g_force_kernel == 3 || g_force_kernel == 5 || g_force_kernel == 6 || ((g_force_kernel == 0 || g_force_kernel == 4) && (d->K % 64 == 0) && (kps % 64 == 0) && tiles256 >= 128 && d->M >= 256 && d->N >= 256));
+  // narrow outputs (128 <= N < 256, many rows: ConvNeXt's first stage, C = 128) are one column of 256x128 tiles for the two-workgroups-per-CU kernel
+  const bool narrow = !d->conv && !d->trans && g_force_kernel == 0 && w4_enabled_env() && (d->K % 64 == 0) && (kps % 64 == 0) && d->N >= 128 && d->N < 256 && d->M >= narrow_min_m() &&
+                      !d->a_colsum && !d->c_colsum && splitk == 1 && vdk_gemm_w4h_serves(p, false);
+  const bool big = !d->conv && (narrow || g_force_kernel == 2 || g_force_kernel == 3 || g_force_kernel == 5 || g_force_kernel == 6 || ((g_force_kernel == 0 || g_force_kernel == 4) && (d->K % 64 == 0) && (kps % 64 == 0) && tiles256 >= 128 && d->M >= 256 && d->N >= 256));
   // compile-time epilogue variant (the common ViT forms); anything else takes the run-time-flag path
   int E = E_GENERIC;
   {
@@ -896,7 +905,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   } while (0)
 #define LAUNCH256X(TNF, EE, CSF)                                                                                         \
   do {                                                                                                                   \
-    if (!sk && !(CSF) && w4h_wanted(EE, TNF, p.M, p.N, p.K) && vdk_gemm_w4h_serves(p, TNF) &&                                           \
+    if (!sk && !(CSF) && (narrow || w4h_wanted(EE, TNF, p.M, p.N, p.K)) && vdk_gemm_w4h_serves(p, TNF) &&                                           \
         vdk_gemm_w4h_launch(p, TNF, EE, grid256.y, stream, prof ? (void*)g_prof_ev[g_prof_used] : nullptr,               \
                             prof ? (void*)g_prof_ev[g_prof_used + 1] : nullptr)) { g_last_kernel = 6; break; }           \
     if (!sk && !(CSF) && w4_enabled() && vdk_gemm_w4_serves(p, TNF) &&                                                   \

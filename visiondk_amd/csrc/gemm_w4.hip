@@ -800,8 +800,8 @@ bool vdk_gemm_w4_serves(const GemmParams& p, bool trans) {
   const double lim = 2147483648.0 - 65536.0;
   if (p.colsum_part || p.sk_cnt || p.a_row_group > 0) return false;
   if ((p.K % 128) || (p.k_per_split % 128) || p.K < 128) return false;
-  if (((double)p.M + 256.0) * (double)p.ldc * 4.0 >= lim || (p.aux && ((double)p.M + 256.0) * (double)p.ldaux * 2.0 >= lim) ||
-      (p.residual && ((double)p.M + 256.0) * (double)p.ldr * 4.0 >= lim)) return false;   // bf16 rows leave through 32-bit buffer offsets
+  if (((double)p.M + 256.0) * (double)p.ldc * (p.c_dtype == VDK_F32 ? 4.0 : 2.0) >= lim || (p.aux && ((double)p.M + 256.0) * (double)p.ldaux * 2.0 >= lim) ||
+      (p.residual && ((double)p.M + 256.0) * (double)p.ldr * 4.0 >= lim)) return false;   // rows leave through 32-bit buffer offsets whose upper half marks "out of range"
   if (!trans) return ((double)p.M + 256.0) * (double)p.lda * 2.0 < lim && ((double)p.N + 256.0) * (double)p.ldb * 2.0 < lim;
   return ((double)p.K + 64.0) * (double)p.lda * 2.0 < lim && ((double)p.K + 64.0) * (double)p.ldb * 2.0 < lim;
 }
@@ -811,7 +811,7 @@ bool vdk_gemm_w4h_serves(const GemmParams& p, bool trans) {
   const double lim = 2147483648.0 - 65536.0;
   if (p.colsum_part || p.sk_cnt || p.a_row_group > 0) return false;
   if ((p.K % 64) || (p.k_per_split % 64) || p.K < 64) return false;
-  if (((double)p.M + 256.0) * (double)p.ldc * 4.0 >= lim || (p.aux && ((double)p.M + 256.0) * (double)p.ldaux * 2.0 >= lim) ||
+  if (((double)p.M + 256.0) * (double)p.ldc * (p.c_dtype == VDK_F32 ? 4.0 : 2.0) >= lim || (p.aux && ((double)p.M + 256.0) * (double)p.ldaux * 2.0 >= lim) ||
       (p.residual && ((double)p.M + 256.0) * (double)p.ldr * 4.0 >= lim)) return false;
   if (!trans) return ((double)p.M + 256.0) * (double)p.lda * 2.0 < lim && ((double)p.N + 256.0) * (double)p.ldb * 2.0 < lim;
   return ((double)p.K + 64.0) * (double)p.lda * 2.0 < lim && ((double)p.K + 64.0) * (double)p.ldb * 2.0 < lim;
