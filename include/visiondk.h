@@ -301,8 +301,20 @@ typedef struct VdkGemmF32Desc {
   int32_t b_kmajor;
   int32_t batch1, batch2;
   int64_t sa1, sa2, sb1, sb2, sc1, sc2;
+  int32_t a_kmajor;           /* 1: A is [K, M] row-major (M % 4 == 0): C = A^T B -- with b_kmajor the weight-gradient form dW[out, in] = dY[t, out]^T X[t, in] */
+  int64_t k_total;            /* > 0: the contraction has k_total rows and is SPLIT over batch1: batch z multiplies rows [z K, min((z + 1) K, k_total)) into its own C slab
+                                 (sa1 = K lda, sb1 = K ldb for k-major operands, sc1 = slab pitch); the caller sums the slabs (vdk_reduce_rows_f32) */
 } VdkGemmF32Desc;
 int vdk_gemm_f32_nt(const VdkGemmF32Desc* d, void* stream);
+/* elementwise / reduction pieces of the fp32-class TRAINING path of the face / CBIR task (the reference runs that loop without autocast, engine/procedure/train.py:217-227):
+ * exact-erf GELU and its derivative with the library erff / expf, a row scale (ConvNeXt layer scale folded into fc2), deterministic column sums of an f32 tensor
+ * (bias gradients) and the inverse of vdk_space_to_depth2_f32 */
+int vdk_gelu_f32(const float* u, float* g, int64_t n, void* stream);
+int vdk_dgelu_f32(float* d_inplace, const float* u, int64_t n, void* stream);
+int vdk_rowscale_f32(const float* in, const float* scale, float* out, int64_t rows, int64_t cols, void* stream);
+int vdk_colsum_f32_workspace_bytes(int64_t T, int32_t N, size_t* bytes);
+int vdk_colsum_f32(const float* x, int64_t ld, int64_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream);
+int vdk_depth_to_space2_f32(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 /* in-place softmax(scale * x) over the first `cols` columns of every row; columns [cols, ld) are zeroed */
 int vdk_softmax_rows_f32(float* x, int64_t ld, int64_t rows, int32_t cols, float scale, void* stream);
 /* fp32 operands of the k = stride convolutions for the precise path: PatchEmbed / ConvNeXt stem (NCHW input, k = c*p*p + ky*p + kx) and the
@@ -479,6 +491,13 @@ int vdk_convnext_forward(const VdkConvNextConfig* cfg, const float* x, const flo
 int vdk_convnext_workspace_f32_bytes(const VdkConvNextConfig* cfg, size_t* bytes);
 int vdk_convnext_forward_f32(const VdkConvNextConfig* cfg, const float* x, const float* params, const void* wx, void* ws, size_t ws_bytes, float* out,
                              void* stream);
+/* The same engine TRAINING in fp32-class arithmetic (feature mode, num_classes = 0): fp32 activations, every contraction on the fp32 MFMA, library erff / expf -- the arithmetic of
+ * the reference's face / CBIR loop, which runs without autocast (engine/procedure/train.py:217-227).  forward keeps in `ws` what backward needs; grads: flat f32, param layout,
+ * fully overwritten; on_ready as in vdk_vit_backward.  `wx` only supplies the tap-major depthwise weights (vdk_convnext_refresh_weights). */
+int vdk_convnext_train_f32_workspace_bytes(const VdkConvNextConfig* cfg, size_t* bytes);
+int vdk_convnext_forward_train_f32(const VdkConvNextConfig* cfg, const float* x, const float* params, const void* wx, void* ws, size_t ws_bytes, float* out, void* stream);
+int vdk_convnext_backward_train_f32(const VdkConvNextConfig* cfg, const float* dout, const float* params, const void* wx, void* ws, size_t ws_bytes, float* grads,
+                                    vdk_grad_ready_fn on_ready, void* user, void* stream);
 /* dout f32 (same shape as out) -> grads (flat fp32, overwritten); on_ready as in vdk_vit_backward.  Classifier mode: dout = dlogits bf16
  * [up(B, 64), up(num_classes, 8)], padding rows / columns zero (as vdk_resnet_backward takes it) */
 int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout, const float* params, const void* wb16, const void* wx, void* ws, size_t ws_bytes,
@@ -542,6 +561,9 @@ int vdk_margin_target_cos_direct(const void* fbt, int64_t ld_f, const void* wb, 
  * smoothing), dcos bf16 [B, lddc] = grad_scale * dLoss/dcos (padding columns zeroed) */
 int vdk_margin_ce(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t C, const int64_t* labels, float label_smoothing,
                   float grad_scale, float* logits, int64_t ldl, float* loss_rows, void* dcos_bf16, int64_t lddc, void* stream);
+/* the same with d(loss)/d(cos) left in fp32 [B, lddc] (padding columns zeroed): head of the fp32-class training mode (FaceTrainStep(precision="fp32")) */
+int vdk_margin_ce_f32(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t C, const int64_t* labels, float label_smoothing, float grad_scale,
+                      float* loss_rows, float* dcos_f32, int64_t lddc, void* stream);
 /* backward of the logits-returning form: dcos bf16 = dlogits * d(logit)/d(cos) */
 /* Class-sharded margin head for data-parallel training with a large identity count (instead of all-reducing the [D, C] head gradient --
  * 2 GB at C = 10^6 -- every rank keeps a column shard of the head, the features are all-gathered and only per-row scalars and the [B, D] feature gradient

@@ -172,3 +172,25 @@ def test_classifier_takes_other_resolutions(be, dev):
     y.sum().backward()
     with pytest.raises(ValueError):
         model(torch.randn(2, 3, 48, 48).to(dev))
+
+
+@pytest.mark.parametrize("B,img,depths,dims", [(2, 32, (1, 1, 2, 1), (8, 16, 24, 32)), (4, 64, (2, 1, 1, 1), (16, 32, 64, 72))])
+def test_fp32_training_mode_vs_oracle(be, dev, B, img, depths, dims):
+    """engine.precision = "fp32" (vdk_convnext_forward_train_f32 / vdk_convnext_backward_train_f32): fp32 activations, every contraction on the fp32 MFMA -- the arithmetic of the
+    reference's face / CBIR loop (no autocast, engine/procedure/train.py:217-227).  Forward map and EVERY parameter gradient against the fp32 oracle at fp32 tolerances."""
+    model, ref = _pair(be, dev, depths, dims, img)
+    model.engine.precision = "fp32"
+    torch.manual_seed(3)
+    x = torch.randn(B, 3, img, img)
+    y = model(x.to(dev))
+    yr = ref(x)
+    rel = ((y.detach().cpu() - yr.detach()).norm() / yr.detach().norm()).item()
+    assert rel < 2e-6, rel
+    dy = torch.randn_like(yr)
+    y.backward(dy.to(dev))
+    yr.backward(dy)
+    for (n, p), (nr, pr) in zip(model.named_parameters(), ref.named_parameters()):
+        assert n == nr
+        g, gr = p.grad.detach().cpu(), pr.grad
+        r = ((g - gr).norm() / (gr.norm() + 1e-12)).item()
+        assert r < 2e-5, (n, r)

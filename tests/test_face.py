@@ -232,3 +232,40 @@ def test_face_train_step_matches_reference_update(be, dev, monkeypatch, layer_wi
     assert _rel(step.ema_small[small_names.index("2.weight")], ema_ref["output_layer.2.weight"]) < 1e-4
     buf_names = [n for n, b in bb.output_layer.named_buffers() if b.dtype.is_floating_point]
     assert _rel(step.ema_buf[buf_names.index("0.running_var")], ema_ref["output_layer.0.running_var"]) < 1e-3
+
+
+def test_face_train_step_fp32_precision_matches_reference_update(be, dev, monkeypatch):
+    """FaceTrainStep(precision="fp32"): the reference's face / CBIR loop has no autocast (engine/procedure/train.py:217-227), so its arithmetic is fp32.  Two clipped
+    steps against torch fp32 (CE -> backward -> clip_grad_norm_ -> SGD): loss 1e-5, every non-degenerate parameter UPDATE within 2e-3 of the oracle's (bf16 mode: 0.12)."""
+    model, ref, img = _build_cnn(be, dev, monkeypatch)
+    head = model.trainingwrapper["head"]
+    rhead = _RefArcFace(head.weight.detach().cpu())
+    bb = model.trainingwrapper["backbone"]
+    lr, mom, wd, max_norm = 0.05, 0.9, 5e-4, 0.5
+    step = face.FaceTrainStep(model, lr=lr, momentum=mom, weight_decay=wd, max_norm=max_norm, ema=False, precision="fp32")
+    assert step.cos_planes == 3 and bb.model.engine.precision == "fp32"
+    params = list(ref.parameters()) + [rhead.weight]
+    opt = torch.optim.SGD(params, lr=lr, momentum=mom, weight_decay=wd)
+    start = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    model.train(); ref.train()
+    torch.manual_seed(5)
+    for it in range(2):
+        x = torch.randn(8, 3, img, img); y = torch.randint(0, 40, (8,))
+        opt.zero_grad()
+        loss_ref = torch.nn.functional.cross_entropy(rhead(ref(x), y), y)
+        loss_ref.backward()
+        total = torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
+        assert total > max_norm
+        opt.step()
+        rows = step.step(x.to(dev), y.to(dev))
+        assert abs(rows.mean().item() - loss_ref.item()) < 2e-5 * abs(loss_ref.item()), (rows.mean().item(), loss_ref.item())
+    got = dict(bb.named_parameters())
+    for n, p in ref.named_parameters():
+        upd_ref = p.detach() - start[n]
+        if upd_ref.norm() < 1e-7:
+            continue
+        r = _rel(got[n].detach().cpu() - start[n], upd_ref)
+        # (a batch-constant shift in front of a train-mode BatchNorm has an analytically zero gradient: those updates are weight decay plus round-off)
+        tol = 0.3 if n in ("output_layer.0.bias", "output_layer.2.bias") else 2e-3
+        assert r < tol, (n, r)
+    assert _rel(head.weight.detach(), rhead.weight.detach()) < 1e-5

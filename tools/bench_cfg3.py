@@ -8,13 +8,14 @@ from visiondk_amd import face
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 ncls = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
+precision = sys.argv[5] if len(sys.argv) > 5 else "bf16"      # "fp32": the fp32-class arithmetic mode (the reference's no-autocast face / CBIR loop)
 planes = int(sys.argv[4]) if len(sys.argv) > 4 else 1      # 1: the head's cosines from single bf16 operands (the reference's autocast arithmetic), 3: split planes (fp32-class)
 dev = torch.device("cuda:0")
 cfg = {"task": "cbir", "image_size": 224, "backbone": {"timm-convnext_base": {"pretrained": False, "image_size": 224, "feat_dim": 512}},
        "head": {"arcface": {"feat_dim": 512, "num_class": ncls, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
 torch.manual_seed(0)
 model = face.get_model(cfg, None, 0).model.train()
-step = face.FaceTrainStep(model, lr=0.01, momentum=0.9, weight_decay=5e-4, max_norm=10.0, ema=True, layer_wise=True, cos_planes=planes)   # cbir.yaml:111-113
+step = face.FaceTrainStep(model, lr=0.01, momentum=0.9, weight_decay=5e-4, max_norm=10.0, ema=True, layer_wise=True, cos_planes=planes, precision=precision)   # cbir.yaml:111-113
 g = torch.Generator(device="cpu"); g.manual_seed(0)
 x = torch.randn(B, 3, 224, 224, generator=g).to(dev)
 y = torch.randint(0, ncls, (B,), generator=g).to(dev)
@@ -29,5 +30,5 @@ torch.cuda.synchronize()
 dt = (time.time() - t0) / steps
 losses.append(rows.mean().item())
 flop = (92.1e9 + 0.15e9 + 3.07e9 * ncls / 1e6) * B
-print(json.dumps({"workload": f"cfg3 ConvNeXt-B + neck512 + ArcFace(C={ncls}) bs={B}, fwd+bwd+clip+SGD+EMA, bf16 operands / fp32 master", "ms_per_step": dt * 1e3,
+print(json.dumps({"workload": f"cfg3 ConvNeXt-B + neck512 + ArcFace(C={ncls}) bs={B}, fwd+bwd+clip+SGD+EMA, " + ("bf16 operands / fp32 master" if precision == "bf16" else "fp32-class arithmetic (fp32 activations, fp32 MFMA)"), "ms_per_step": dt * 1e3,
                   "head_cos_planes": planes, "images_per_sec": B / dt, "tflops": flop / dt / 1e12, "losses": losses, "max_mem_gib": torch.cuda.max_memory_allocated() / 2**30}))

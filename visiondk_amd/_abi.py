@@ -38,7 +38,7 @@ class VitConfig(C.Structure):
 class GemmF32Desc(C.Structure):
     _fields_ = [("A", P), ("lda", I64), ("B", P), ("ldb", I64), ("C", P), ("ldc", I64), ("M", I32), ("N", I32), ("K", I32), ("bias", P), ("residual", P),
                 ("ldr", I64), ("act", I32), ("alpha", C.c_float), ("col_scale", P), ("b_kmajor", I32), ("batch1", I32), ("batch2", I32), ("sa1", I64), ("sa2", I64),
-                ("sb1", I64), ("sb2", I64), ("sc1", I64), ("sc2", I64)]
+                ("sb1", I64), ("sb2", I64), ("sc1", I64), ("sc2", I64), ("a_kmajor", I32), ("k_total", I64)]
 
 
 class ConvNextConfig(C.Structure):
@@ -137,6 +137,7 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_rownorm_fwd": (C.c_int, [P, I32, I32, I32, F32, P, P, P, P, I32, P]),
     "vdk_rownorm_bwd": (C.c_int, [P, P, P, I64, I32, I32, P, P]),
     "vdk_margin_ce": (C.c_int, [C.POINTER(MarginHead), P, I64, I32, I32, P, F32, F32, P, I64, P, P, I64, P]),
+    "vdk_margin_ce_f32": (C.c_int, [C.POINTER(MarginHead), P, I64, I32, I32, P, C.c_float, C.c_float, P, P, I64, P]),
     "vdk_margin_target_cos": (C.c_int, [P, I64, I32, I32, I64, P, P, P]),
     "vdk_margin_stats": (C.c_int, [C.POINTER(MarginHead), P, I64, I32, I32, I64, P, P, P, P]),
     "vdk_margin_grad": (C.c_int, [C.POINTER(MarginHead), P, I64, I32, I32, I64, I64, P, P, P, P, F32, F32, P, I64, P]),
@@ -144,6 +145,12 @@ SIGNATURES: dict[str, tuple] = {
     # native ViT engine
     "vdk_gemm_f32_nt": (C.c_int, [C.POINTER(GemmF32Desc), P]),
     "vdk_softmax_rows_f32": (C.c_int, [P, I64, I64, I32, C.c_float, P]),
+    "vdk_gelu_f32": (C.c_int, [P, P, I64, P]),
+    "vdk_dgelu_f32": (C.c_int, [P, P, I64, P]),
+    "vdk_rowscale_f32": (C.c_int, [P, P, P, I64, I64, P]),
+    "vdk_colsum_f32_workspace_bytes": (C.c_int, [I64, I32, PSZ]),
+    "vdk_colsum_f32": (C.c_int, [P, I64, I64, I32, P, P, SZ, P]),
+    "vdk_depth_to_space2_f32": (C.c_int, [P, P, I32, I32, I32, I32, P]),
     "vdk_patchify_f32": (C.c_int, [P, I32, I32, I32, I32, I32, P, P]),
     "vdk_space_to_depth2_f32": (C.c_int, [P, P, I32, I32, I32, I32, P]),
     "vdk_dwconv7_fwd": (C.c_int, [P, P, P, P, P, P, I32, I32, I32, I32, I32, P]),
@@ -183,6 +190,9 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_vit_forward_f32": (C.c_int, [C.POINTER(VitConfig), P, P, P, SZ, P, P]),
     "vdk_convnext_workspace_f32_bytes": (C.c_int, [C.POINTER(ConvNextConfig), PSZ]),
     "vdk_convnext_forward_f32": (C.c_int, [C.POINTER(ConvNextConfig), P, P, P, P, SZ, P, P]),
+    "vdk_convnext_train_f32_workspace_bytes": (C.c_int, [C.POINTER(ConvNextConfig), PSZ]),
+    "vdk_convnext_forward_train_f32": (C.c_int, [C.POINTER(ConvNextConfig), P, P, P, P, SZ, P, P]),
+    "vdk_convnext_backward_train_f32": (C.c_int, [C.POINTER(ConvNextConfig), P, P, P, P, SZ, P, P, P, P]),
     "vdk_resnet_param_count": (C.c_int, [C.POINTER(ResNetConfig), C.POINTER(I64), C.POINTER(I32), C.POINTER(I64), C.POINTER(I32), PSZ]),
     "vdk_resnet_param_info": (C.c_int, [C.POINTER(ResNetConfig), I32, I32, C.c_char_p, I32, C.POINTER(I64), C.POINTER(I64), C.POINTER(I64), C.POINTER(I32)]),
     "vdk_resnet_workspace_bytes": (C.c_int, [C.POINTER(ResNetConfig), PSZ]),

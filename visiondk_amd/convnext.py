@@ -72,6 +72,11 @@ class ConvNeXtEngine:
         self._out: Optional[torch.Tensor] = None
         self._weights_version = None
         self.buffers = torch.zeros(0, dtype=torch.float32, device=dev)      # no BatchNorm: nothing to broadcast (the train step shared with the ResNet engine asks)
+        # "bf16": bf16 MFMA operands, fp32 accumulation / residual stream / master weights (the reference's autocast arithmetic, classifier loop).
+        # "fp32": forward() / backward() run vdk_convnext_forward_train_f32 / vdk_convnext_backward_train_f32 -- fp32 activations, every contraction on the fp32 MFMA: the
+        # arithmetic of the reference's face / CBIR loop, which has no autocast (engine/procedure/train.py:217-227).  Feature mode only.
+        self.precision = "bf16"
+        self._ws_t32: Optional[torch.Tensor] = None
 
     def _cfg(self, batch: int, img: Optional[int] = None) -> _abi.ConvNextConfig:
         s = self.spec
@@ -126,12 +131,33 @@ class ConvNeXtEngine:
             raise ValueError(f"expected float32 [B, {s.in_chans}, {want}, got {tuple(x.shape)} {x.dtype}")
         x = x.contiguous()
         B, img = x.shape[0], x.shape[2]
+        if self.precision == "fp32":
+            return self._forward_train_f32(x)
         ws = self._workspace(B, img)
         self._ensure_fresh()
         cfg = self._cfg(B, img)
         be = self.be
         be.check(be.lib.vdk_convnext_forward(C.byref(cfg), be.ptr(x), be.ptr(self.params), be.ptr(self.wb16), be.ptr(self.wx), be.ptr(ws), ws.numel(),
                                              be.ptr(self._out), be.stream()), "vdk_convnext_forward")
+        return self._out
+
+    def _forward_train_f32(self, x: torch.Tensor) -> torch.Tensor:
+        if self.spec.num_classes > 0:
+            raise NotImplementedError("precision='fp32' training is built for feature mode (the face / CBIR task)")
+        B = x.shape[0]
+        be = self.be
+        cfg = self._cfg(B)
+        if self._ws_t32 is None or self._ws_batch != B:
+            need = C.c_size_t(0)
+            be.check(be.lib.vdk_convnext_train_f32_workspace_bytes(C.byref(cfg), C.byref(need)), "vdk_convnext_train_f32_workspace_bytes")
+            if self._ws_t32 is None or self._ws_t32.numel() < need.value:
+                self._ws_t32 = None
+                self._ws_t32 = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+            self._ws_batch, self._ws_img = B, self.spec.img_size
+            self._out = torch.empty((B * self.out_hw * self.out_hw, self.out_ch), dtype=torch.float32, device=self.device)
+        self._ensure_fresh()                      # the tap-major depthwise weights live in wx
+        be.check(be.lib.vdk_convnext_forward_train_f32(C.byref(cfg), be.ptr(x), be.ptr(self.params), be.ptr(self.wx), be.ptr(self._ws_t32), self._ws_t32.numel(),
+                                                       be.ptr(self._out), be.stream()), "vdk_convnext_forward_train_f32")
         return self._out
 
     def forward_precise(self, x: torch.Tensor) -> torch.Tensor:
@@ -165,6 +191,10 @@ class ConvNeXtEngine:
         cfg = self._cfg(self._ws_batch, self._ws_img)
         be = self.be
         cb = _abi.GRAD_READY_FN(lambda user, off, n: on_ready(off, n)) if on_ready is not None else _abi.GRAD_READY_FN(0)
+        if self.precision == "fp32":
+            be.check(be.lib.vdk_convnext_backward_train_f32(C.byref(cfg), be.ptr(dout), be.ptr(self.params), be.ptr(self.wx), be.ptr(self._ws_t32), self._ws_t32.numel(),
+                                                            be.ptr(self.grads), cb, None, be.stream()), "vdk_convnext_backward_train_f32")
+            return self.grads
         be.check(be.lib.vdk_convnext_backward(C.byref(cfg), be.ptr(dout), be.ptr(self.params), be.ptr(self.wb16), be.ptr(self.wx), be.ptr(self._ws),
                                               self._ws.numel(), be.ptr(self.grads), cb, None, be.stream()), "vdk_convnext_backward")
         return self.grads

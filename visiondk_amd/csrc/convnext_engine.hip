@@ -43,6 +43,12 @@ int vdk_gemm_a_colsum_rows(int32_t, int32_t, int32_t);
 int vdk_gemm_c_colsum_rows(int32_t, int32_t, int32_t);
 int vdk_patchify_f32(const float*, int32_t, int32_t, int32_t, int32_t, int32_t, float*, void*);
 int vdk_space_to_depth2_f32(const float*, float*, int32_t, int32_t, int32_t, int32_t, void*);
+int vdk_gelu_f32(const float*, float*, int64_t, void*);
+int vdk_dgelu_f32(float*, const float*, int64_t, void*);
+int vdk_rowscale_f32(const float*, const float*, float*, int64_t, int64_t, void*);
+int vdk_colsum_f32_workspace_bytes(int64_t, int32_t, size_t*);
+int vdk_colsum_f32(const float*, int64_t, int64_t, int32_t, float*, void*, size_t, void*);
+int vdk_depth_to_space2_f32(const float*, float*, int32_t, int32_t, int32_t, int32_t, void*);
 int vdk_avgpool_rows_f32_fwd(const float*, float*, int32_t, int32_t, int32_t, void*);
 int vdk_avgpool_rows_f32_bwd(const float*, float*, void*, int32_t, int32_t, int32_t, void*);
 }
@@ -558,6 +564,90 @@ int gemm32(hipStream_t s, const float* A, int64_t lda, const float* B, int64_t l
   g.act = act; g.alpha = 1.0f;
   return vdk_gemm_f32_nt(&g, s);
 }
+
+// ---- fp32-class TRAINING path (feature mode): every activation f32, every contraction on the fp32 MFMA (vdk_gemm_f32_nt), library erff / expf -------------------------
+// The reference runs the face / CBIR training loop WITHOUT autocast (engine/procedure/train.py:217-227): its arithmetic there is fp32.  This is the engine's mode with that
+// arithmetic: forward as vdk_convnext_forward_f32 but keeping what the backward needs, backward with fp32 input- and weight-gradient GEMMs (k-major operands, the
+// contraction over the rows split into slabs and summed in a fixed order).  About 6x slower than the bf16-operand step; parity with the fp32 oracle ~1e-5.
+struct BlkT { size_t t, stats, h, u, g; };
+struct TrainPlan32 {
+  size_t total, patches, y0, stats0, X[4], ds_stats[4], ds_h[4], ds_A[4], head_stats;
+  std::vector<BlkT> blk[4];
+  size_t w2p, b2p, dxa, dxb, dt, du, dh, dA, dhds, dw2p, db2p, slabs, slabs_bytes, lnws, lnws_bytes, csws, csws_bytes, dwws, dwws_bytes;
+};
+int wgrad32_splits(int out, int in, long rows, long* kchunk) {
+  const long tiles = (long)((out + 127) / 128) * ((in + 127) / 128);
+  long S = (1024 + tiles - 1) / tiles;
+  if (S > 64) S = 64;
+  if (S > rows / 256) S = rows / 256;
+  if (S < 1) S = 1;
+  long kc = up((rows + S - 1) / S, 4);
+  S = (rows + kc - 1) / kc;
+  *kchunk = kc;
+  return (int)S;
+}
+void cn_plan_train32(const CnDims& d, TrainPlan32* w) {
+  size_t cur = 0, rc = 0, rm = 0, ra = 0, rh = 0, cm = 0, sl = 0, ln = 0, cs = 0, dww = 0;
+  auto wg = [&](int out, int in, long rows) { long kc; const int S = wgrad32_splits(out, in, rows, &kc); const size_t b = (size_t)S * out * in * 4; if (b > sl) sl = b; };
+  auto cw = [&](long rows, int n) { size_t c = 0; vdk_colsum_f32_workspace_bytes(rows, n, &c); if (c > cs) cs = c; };
+  w->patches = w_take(cur, (size_t)d.R[0] * d.Kst * 4);
+  w->y0 = w_take(cur, (size_t)d.R[0] * d.C[0] * 4);
+  w->stats0 = w_take(cur, (size_t)d.R[0] * 2 * 4);
+  wg(d.C[0], d.Kst, d.R[0]); cw(d.R[0], d.C[0]);
+  { size_t l = 0; vdk_layernorm_bwd_workspace_bytes(d.R[0], d.C[0], &l); if (l > ln) ln = l; }
+  for (int i = 0; i < 4; ++i) {
+    const size_t R = d.R[i], C = d.C[i], M = 4 * C;
+    w->ds_stats[i] = w->ds_h[i] = w->ds_A[i] = 0;
+    if (i > 0) {
+      const size_t Rp = d.R[i - 1], Ci = d.C[i - 1];
+      w->ds_stats[i] = w_take(cur, Rp * 2 * 4); w->ds_h[i] = w_take(cur, Rp * Ci * 4); w->ds_A[i] = w_take(cur, R * 4 * Ci * 4);
+      if (R * 4 * Ci > ra) ra = R * 4 * Ci;
+      if (Rp * Ci > rh) rh = Rp * Ci;
+      wg((int)C, (int)(4 * Ci), (long)R);
+      size_t l = 0; vdk_layernorm_bwd_workspace_bytes((int)Rp, (int)Ci, &l); if (l > ln) ln = l;
+    }
+    w->X[i] = w_take(cur, (size_t)(d.depth[i] + 1) * R * C * 4);
+    w->blk[i].resize(d.depth[i]);
+    for (int j = 0; j < d.depth[i]; ++j) {
+      BlkT& b = w->blk[i][j];
+      b.t = w_take(cur, R * C * 4); b.stats = w_take(cur, R * 2 * 4); b.h = w_take(cur, R * C * 4); b.u = w_take(cur, R * M * 4); b.g = w_take(cur, R * M * 4);
+    }
+    if (R * C > rc) rc = R * C;
+    if (R * M > rm) rm = R * M;
+    if (C * M > cm) cm = C * M;
+    wg((int)C, (int)M, (long)R); wg((int)M, (int)C, (long)R); cw((long)R, (int)M); cw((long)R, (int)C);
+    size_t l = 0; vdk_layernorm_bwd_workspace_bytes((int)R, (int)C, &l); if (l > ln) ln = l;
+    size_t q = 0; vdk_dwconv7_wgrad_workspace_bytes(d.B, d.H[i], d.H[i], (int)C, &q); if (q > dww) dww = q;
+  }
+  w->head_stats = w_take(cur, (size_t)d.R[3] * 2 * 4);
+  { size_t l = 0; vdk_layernorm_bwd_workspace_bytes(d.R[3], d.C[3], &l); if (l > ln) ln = l; }
+  w->w2p = w_take(cur, cm * 4); w->b2p = w_take(cur, 4096 * 4);
+  w->dxa = w_take(cur, rc * 4); w->dxb = w_take(cur, rc * 4); w->dt = w_take(cur, rc * 4); w->du = w_take(cur, rm * 4); w->dh = w_take(cur, rc * 4);
+  w->dA = w_take(cur, ra * 4 + 256); w->dhds = w_take(cur, rh * 4 + 256);
+  w->dw2p = w_take(cur, cm * 4); w->db2p = w_take(cur, 4096 * 4);
+  w->slabs_bytes = sl; w->slabs = w_take(cur, sl + 256);
+  w->lnws_bytes = ln; w->lnws = w_take(cur, ln + 256);
+  w->csws_bytes = cs; w->csws = w_take(cur, cs + 256);
+  w->dwws_bytes = dww; w->dwws = w_take(cur, dww + 256);
+  w->total = cur;
+}
+// dX[rows, in] = dY[rows, out] . W[out, in]   (W read as it lies: k-major B)
+int dgrad32(hipStream_t s, const float* dY, int out, const float* W, int in, float* dX, int rows) {
+  VdkGemmF32Desc g = {};
+  g.A = dY; g.lda = out; g.B = W; g.ldb = in; g.b_kmajor = 1; g.C = dX; g.ldc = in; g.M = rows; g.N = in; g.K = out; g.alpha = 1.0f;
+  return vdk_gemm_f32_nt(&g, s);
+}
+// dW[out, in] = dY[rows, out]^T . X[rows, in]   (both operands k-major; the contraction over the rows split into slabs, summed in slab order)
+int wgrad32(hipStream_t s, const float* dY, int out, const float* X, int in, long rows, float* dW, float* slabs, size_t slabs_bytes) {
+  long kc; const int S = wgrad32_splits(out, in, rows, &kc);
+  if (S > 1 && (size_t)S * out * in * 4 > slabs_bytes) return vdk_fail(VDK_EWORKSPACE, "convnext fp32 training: weight-gradient slabs");
+  VdkGemmF32Desc g = {};
+  g.A = dY; g.lda = out; g.a_kmajor = 1; g.B = X; g.ldb = in; g.b_kmajor = 1; g.C = S > 1 ? slabs : dW; g.ldc = in; g.M = out; g.N = in; g.K = (int)kc; g.alpha = 1.0f;
+  g.batch1 = S; g.batch2 = 1; g.sa1 = kc * out; g.sb1 = kc * in; g.sc1 = (int64_t)out * in; g.k_total = rows;
+  RC(vdk_gemm_f32_nt(&g, s));
+  if (S > 1) RC(vdk_reduce_rows_f32(slabs, (int64_t)out * in, S, (int64_t)out * in, dW, 1.0f, s));
+  return VDK_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -606,6 +696,140 @@ int vdk_convnext_forward_f32(const VdkConvNextConfig* cfg, const float* x, const
   }
   RC(vdk_layernorm_fwd(xa, d.C[3], d.R[3], d.C[3], params + p.head_nw, params + p.head_nb, d.eps, out, d.C[3], VDK_F32, nullptr, nullptr, s));
   return vdk_check_launch("vdk_convnext_forward_f32");
+}
+
+int vdk_convnext_train_f32_workspace_bytes(const VdkConvNextConfig* cfg, size_t* bytes) {
+  CnDims d; RC(cn_dims(cfg, &d));
+  if (!bytes) return vdk_fail(VDK_EINVAL, "null");
+  if (d.ncls > 0) return vdk_fail(VDK_EUNSUPPORTED, "vdk_convnext_train_f32: feature mode only (num_classes = 0)");
+  TrainPlan32 w; cn_plan_train32(d, &w);
+  *bytes = w.total;
+  return VDK_OK;
+}
+
+// training forward in fp32-class arithmetic: out f32 [B * (img/32)^2, dims[3]]; ws keeps the activations for vdk_convnext_backward_train_f32
+int vdk_convnext_forward_train_f32(const VdkConvNextConfig* cfg, const float* x, const float* params, const void* wx, void* ws, size_t ws_bytes, float* out, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  CnDims d; RC(cn_dims(cfg, &d));
+  if (d.ncls > 0) return vdk_fail(VDK_EUNSUPPORTED, "vdk_convnext_forward_train_f32: feature mode only");
+  PLayout p; cn_layout(d, &p);
+  XLayout xl; cn_xlayout(d, &xl);
+  TrainPlan32 w; cn_plan_train32(d, &w);
+  if (!x || !params || !wx || !ws || !out) return vdk_fail(VDK_EINVAL, "vdk_convnext_forward_train_f32: null pointer");
+  if (ws_bytes < w.total) return vdk_fail(VDK_EWORKSPACE, "vdk_convnext_forward_train_f32: workspace too small");
+  char* base = (char*)ws;
+  const char* xb_ = (const char*)wx;
+  float* patches = (float*)(base + w.patches); float* y0 = (float*)(base + w.y0); float* st0 = (float*)(base + w.stats0);
+  float* w2p = (float*)(base + w.w2p); float* b2p = (float*)(base + w.b2p);
+  RC(vdk_patchify_f32(x, d.B, d.Cin, d.img, d.img, 4, patches, s));
+  RC(gemm32(s, patches, d.Kst, params + p.stem_w, d.Kst, y0, d.C[0], d.R[0], d.C[0], d.Kst, params + p.stem_b, nullptr, nullptr, 0, VDK_ACT_NONE));
+  RC(vdk_layernorm_fwd(y0, d.C[0], d.R[0], d.C[0], params + p.stem_nw, params + p.stem_nb, d.eps, base + w.X[0], d.C[0], VDK_F32, st0, st0 + d.R[0], s));
+  for (int i = 0; i < 4; ++i) {
+    const int R = d.R[i], C = d.C[i], M = 4 * C, H = d.H[i];
+    float* X = (float*)(base + w.X[i]);
+    const size_t XS = (size_t)R * C;
+    if (i > 0) {
+      const int Rp = d.R[i - 1], Ci = d.C[i - 1];
+      const float* xprev = (const float*)(base + w.X[i - 1]) + (size_t)d.depth[i - 1] * Rp * Ci;
+      float* dst = (float*)(base + w.ds_stats[i]);
+      RC(vdk_layernorm_fwd(xprev, Ci, Rp, Ci, params + p.st[i].ds_nw, params + p.st[i].ds_nb, d.eps, base + w.ds_h[i], Ci, VDK_F32, dst, dst + Rp, s));
+      RC(vdk_space_to_depth2_f32((const float*)(base + w.ds_h[i]), (float*)(base + w.ds_A[i]), d.B, d.H[i - 1], d.H[i - 1], Ci, s));
+      RC(gemm32(s, (const float*)(base + w.ds_A[i]), 4 * Ci, params + p.st[i].ds_w, 4 * Ci, X, C, R, C, 4 * Ci, params + p.st[i].ds_b, nullptr, nullptr, 0, VDK_ACT_NONE));
+    }
+    for (int j = 0; j < d.depth[i]; ++j) {
+      const BlkP& b = p.st[i].blk[j]; const BlkX& bx = xl.blk[i][j]; const BlkT& bw = w.blk[i][j];
+      float* xin = X + (size_t)j * XS; float* xout = xin + XS;
+      float* t = (float*)(base + bw.t); float* st = (float*)(base + bw.stats); float* h = (float*)(base + bw.h); float* u = (float*)(base + bw.u); float* g = (float*)(base + bw.g);
+      RC(vdk_dwconv7_fwd(xin, (const float*)(xb_ + bx.dwt), params + b.dw_b, nullptr, t, nullptr, d.B, H, H, C, 0, s));
+      RC(vdk_layernorm_fwd(t, C, R, C, params + b.nw, params + b.nb, d.eps, h, C, VDK_F32, st, st + R, s));
+      RC(gemm32(s, h, C, params + b.fc1_w, C, u, M, R, M, C, params + b.fc1_b, nullptr, nullptr, 0, VDK_ACT_NONE));
+      RC(vdk_gelu_f32(u, g, (int64_t)R * M, s));
+      // layer scale folded into fc2 (W2' = gamma (.) W2, b2' = gamma (.) b2), as in the bf16 engine: the backward then never divides by gamma
+      RC(vdk_rowscale_f32(params + b.fc2_w, params + b.gamma, w2p, C, M, s));
+      RC(vdk_rowscale_f32(params + b.fc2_b, params + b.gamma, b2p, C, 1, s));
+      RC(gemm32(s, g, M, w2p, M, xout, C, R, C, M, b2p, nullptr, xin, C, VDK_ACT_NONE));
+    }
+  }
+  const float* xlast = (const float*)(base + w.X[3]) + (size_t)d.depth[3] * d.R[3] * d.C[3];
+  float* hs = (float*)(base + w.head_stats);
+  RC(vdk_layernorm_fwd(xlast, d.C[3], d.R[3], d.C[3], params + p.head_nw, params + p.head_nb, d.eps, out, d.C[3], VDK_F32, hs, hs + d.R[3], s));
+  return vdk_check_launch("vdk_convnext_forward_train_f32");
+}
+
+// dout f32 [B * (img/32)^2, dims[3]] -> grads (flat f32, param layout, fully overwritten).  on_ready: see vdk_vit_backward.
+int vdk_convnext_backward_train_f32(const VdkConvNextConfig* cfg, const float* dout, const float* params, const void* wx, void* ws, size_t ws_bytes, float* grads,
+                                    vdk_grad_ready_fn on_ready, void* user, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  CnDims d; RC(cn_dims(cfg, &d));
+  if (d.ncls > 0) return vdk_fail(VDK_EUNSUPPORTED, "vdk_convnext_backward_train_f32: feature mode only");
+  PLayout p; cn_layout(d, &p);
+  XLayout xl; cn_xlayout(d, &xl);
+  TrainPlan32 w; cn_plan_train32(d, &w);
+  if (!dout || !params || !wx || !ws || !grads) return vdk_fail(VDK_EINVAL, "vdk_convnext_backward_train_f32: null pointer");
+  if (ws_bytes < w.total) return vdk_fail(VDK_EWORKSPACE, "vdk_convnext_backward_train_f32: workspace too small");
+  char* base = (char*)ws;
+  const char* xb_ = (const char*)wx;
+  float* dxa = (float*)(base + w.dxa); float* dxb = (float*)(base + w.dxb); float* dt = (float*)(base + w.dt); float* du = (float*)(base + w.du); float* dh = (float*)(base + w.dh);
+  float* w2p = (float*)(base + w.w2p); float* dw2p = (float*)(base + w.dw2p); float* db2p = (float*)(base + w.db2p);
+  float* slabs = (float*)(base + w.slabs); void* lnws = base + w.lnws; void* csws = base + w.csws;
+  {
+    const float* xlast = (const float*)(base + w.X[3]) + (size_t)d.depth[3] * d.R[3] * d.C[3];
+    const float* hs = (const float*)(base + w.head_stats);
+    RC(vdk_layernorm_bwd(dout, d.C[3], VDK_F32, xlast, d.C[3], hs, hs + d.R[3], params + p.head_nw, nullptr, 0, d.R[3], d.C[3], dxa, d.C[3], nullptr, 0,
+                         grads + p.head_nw, grads + p.head_nb, lnws, w.lnws_bytes, s));
+    if (on_ready) on_ready(user, p.head_nw, p.total - p.head_nw);
+  }
+  for (int i = 3; i >= 0; --i) {
+    const int R = d.R[i], C = d.C[i], M = 4 * C, H = d.H[i];
+    const float* X = (const float*)(base + w.X[i]);
+    const size_t XS = (size_t)R * C;
+    if (C > 4096) return vdk_fail(VDK_EUNSUPPORTED, "vdk_convnext_backward_train_f32: dims <= 4096");
+    for (int j = d.depth[i] - 1; j >= 0; --j) {
+      const BlkP& b = p.st[i].blk[j]; const BlkX& bx = xl.blk[i][j]; const BlkT& bw = w.blk[i][j];
+      const float* xin = X + (size_t)j * XS;
+      const float* st = (const float*)(base + bw.stats);
+      const float* t = (const float*)(base + bw.t); const float* h = (const float*)(base + bw.h); const float* u = (const float*)(base + bw.u); const float* g = (const float*)(base + bw.g);
+      // dxa = dL/d(block output).  MLP branch through the folded fc2
+      RC(vdk_rowscale_f32(params + b.fc2_w, params + b.gamma, w2p, C, M, s));
+      RC(vdk_colsum_f32(dxa, C, R, C, db2p, csws, w.csws_bytes, s));
+      RC(dgrad32(s, dxa, C, w2p, M, du, R));                                             // dL/dg
+      RC(wgrad32(s, dxa, C, g, M, R, dw2p, slabs, w.slabs_bytes));
+      RC(vdk_layerscale_grad(dw2p, db2p, params + b.fc2_w, params + b.fc2_b, params + b.gamma, grads + b.fc2_w, grads + b.fc2_b, grads + b.gamma, C, M, s));
+      RC(vdk_dgelu_f32(du, u, (int64_t)R * M, s));                                       // dL/du
+      RC(vdk_colsum_f32(du, M, R, M, grads + b.fc1_b, csws, w.csws_bytes, s));
+      RC(dgrad32(s, du, M, params + b.fc1_w, C, dh, R));                                 // dL/dh
+      RC(wgrad32(s, du, M, h, C, R, grads + b.fc1_w, slabs, w.slabs_bytes));
+      RC(vdk_layernorm_bwd(dh, C, VDK_F32, t, C, st, st + R, params + b.nw, nullptr, 0, R, C, dt, C, nullptr, 0, grads + b.nw, grads + b.nb, lnws, w.lnws_bytes, s));
+      RC(vdk_dwconv7_wgrad(xin, dt, grads + b.dw_w, grads + b.dw_b, d.B, H, H, C, base + w.dwws, w.dwws_bytes, s));
+      RC(vdk_dwconv7_fwd(dt, (const float*)(xb_ + bx.dwt), nullptr, dxa, dxb, nullptr, d.B, H, H, C, 1, s));   // + the shortcut's gradient
+      { float* sw = dxa; dxa = dxb; dxb = sw; }
+      if (on_ready) on_ready(user, b.gamma, (j + 1 < d.depth[i] ? p.st[i].blk[j + 1].gamma : (i < 3 ? p.st[i + 1].ds_nw : p.head_nw)) - b.gamma);
+    }
+    if (i > 0) {
+      // downsample backward: dxa = dL/dX[i][0] [R, C]
+      const int Rp = d.R[i - 1], Ci = d.C[i - 1];
+      const float* xprev = (const float*)(base + w.X[i - 1]) + (size_t)d.depth[i - 1] * Rp * Ci;
+      const float* dst = (const float*)(base + w.ds_stats[i]);
+      float* dA = (float*)(base + w.dA); float* dhds = (float*)(base + w.dhds);
+      RC(vdk_colsum_f32(dxa, C, R, C, grads + p.st[i].ds_b, csws, w.csws_bytes, s));
+      RC(dgrad32(s, dxa, C, params + p.st[i].ds_w, 4 * Ci, dA, R));
+      RC(wgrad32(s, dxa, C, (const float*)(base + w.ds_A[i]), 4 * Ci, R, grads + p.st[i].ds_w, slabs, w.slabs_bytes));
+      RC(vdk_depth_to_space2_f32(dA, dhds, d.B, d.H[i - 1], d.H[i - 1], Ci, s));
+      RC(vdk_layernorm_bwd(dhds, Ci, VDK_F32, xprev, Ci, dst, dst + Rp, params + p.st[i].ds_nw, nullptr, 0, Rp, Ci, dxb, Ci, nullptr, 0, grads + p.st[i].ds_nw,
+                           grads + p.st[i].ds_nb, lnws, w.lnws_bytes, s));
+      { float* sw = dxa; dxa = dxb; dxb = sw; }
+      if (on_ready) on_ready(user, p.st[i].ds_nw, p.st[i].blk[0].gamma - p.st[i].ds_nw);
+    } else {
+      // stem: X[0][0] = LayerNorm(y0), y0 = patches . Wst^T + b
+      const float* st0 = (const float*)(base + w.stats0);
+      RC(vdk_layernorm_bwd(dxa, d.C[0], VDK_F32, (const float*)(base + w.y0), d.C[0], st0, st0 + d.R[0], params + p.stem_nw, nullptr, 0, d.R[0], d.C[0], dxb, d.C[0], nullptr, 0,
+                           grads + p.stem_nw, grads + p.stem_nb, lnws, w.lnws_bytes, s));
+      RC(vdk_colsum_f32(dxb, d.C[0], d.R[0], d.C[0], grads + p.stem_b, csws, w.csws_bytes, s));
+      RC(wgrad32(s, dxb, d.C[0], (const float*)(base + w.patches), d.Kst, d.R[0], grads + p.stem_w, slabs, w.slabs_bytes));
+      if (on_ready) on_ready(user, 0, p.st[0].blk[0].gamma);
+    }
+  }
+  return vdk_check_launch("vdk_convnext_backward_train_f32");
 }
 
 }  // extern "C"

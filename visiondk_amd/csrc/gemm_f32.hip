@@ -18,7 +18,7 @@
 struct GfArgs {
   const float* A; long lda; const float* B; long ldb; float* C; long ldc;
   int M, N, K;
-  const float* bias; const float* res; const float* cscale; long ldr; int act; float alpha; int b_kmajor;
+  const float* bias; const float* res; const float* cscale; long ldr; int act; float alpha; int b_kmajor; int a_kmajor; long k_total;
   int batch2; long sa1, sa2, sb1, sb2, sc1, sc2;
 };
 
@@ -33,6 +33,10 @@ __global__ __launch_bounds__(512) void gemm_f32_kernel(GfArgs g) {
   const float* A = g.A + z1 * g.sa1 + z2 * g.sa2;
   const float* B = g.B + z1 * g.sb1 + z2 * g.sb2;
   float* C = g.C + z1 * g.sc1 + z2 * g.sc2;
+  // k_total > 0: the first batch index splits the contraction (weight gradients: K = rows of the activation, tiny M x N): batch z1 multiplies k rows
+  // [z1 * K, min((z1 + 1) * K, k_total)) into its own slab of C
+  int Keff = g.K;
+  if (g.k_total > 0) { const long left = g.k_total - (long)z1 * g.K; Keff = left < g.K ? (left > 0 ? (int)left : 0) : g.K; }
 
   f32x16 acc0, acc1;
 #pragma unroll
@@ -41,23 +45,34 @@ __global__ __launch_bounds__(512) void gemm_f32_kernel(GfArgs g) {
   const float* a1p = a0p + 32 * GF_P;
   const float* bp = Bs + (hi * GF_T + ng * 32 + l31) * GF_P;
 
-  for (int kc = 0; kc < g.K; kc += GF_KC) {
+  for (int kc = 0; kc < Keff; kc += GF_KC) {
     __syncthreads();
-    // A tile: rows m0.., k kc..kc+63, row-major (K % 4 == 0, lda % 4 == 0)
+    if (!g.a_kmajor) {
+      // A tile: rows m0.., k kc..kc+63, row-major (K % 4 == 0, lda % 4 == 0)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int id = tid + 512 * j, r = id >> 4, c4 = id & 15, k = kc + 4 * c4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m0 + r < g.M && k < g.K) v = *(const f32x4*)(A + (long)(m0 + r) * g.lda + k);
-      *(f32x2*)(As + (0 * GF_T + r) * GF_P + 2 * c4) = (f32x2){v[0], v[2]};
-      *(f32x2*)(As + (1 * GF_T + r) * GF_P + 2 * c4) = (f32x2){v[1], v[3]};
+      for (int j = 0; j < 4; ++j) {
+        const int id = tid + 512 * j, r = id >> 4, c4 = id & 15, k = kc + 4 * c4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m0 + r < g.M && k < Keff) v = *(const f32x4*)(A + (long)(m0 + r) * g.lda + k);
+        *(f32x2*)(As + (0 * GF_T + r) * GF_P + 2 * c4) = (f32x2){v[0], v[2]};
+        *(f32x2*)(As + (1 * GF_T + r) * GF_P + 2 * c4) = (f32x2){v[1], v[3]};
+      }
+    } else {   // A[k][m] (M % 4 == 0, lda % 4 == 0): the weight-gradient form dW = dY^T X reads dY as it lies
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int id = tid + 512 * j, kl = id >> 5, m4 = id & 31, k = kc + kl, m = m0 + 4 * m4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < Keff && m < g.M) v = *(const f32x4*)(A + (long)k * g.lda + m);
+        float* d = As + ((kl & 1) * GF_T + 4 * m4) * GF_P + (kl >> 1);
+        d[0] = v[0]; d[GF_P] = v[1]; d[2 * GF_P] = v[2]; d[3 * GF_P] = v[3];
+      }
     }
     if (!g.b_kmajor) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int id = tid + 512 * j, r = id >> 4, c4 = id & 15, k = kc + 4 * c4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n0 + r < g.N && k < g.K) v = *(const f32x4*)(B + (long)(n0 + r) * g.ldb + k);
+        if (n0 + r < g.N && k < Keff) v = *(const f32x4*)(B + (long)(n0 + r) * g.ldb + k);
         *(f32x2*)(Bs + (0 * GF_T + r) * GF_P + 2 * c4) = (f32x2){v[0], v[2]};
         *(f32x2*)(Bs + (1 * GF_T + r) * GF_P + 2 * c4) = (f32x2){v[1], v[3]};
       }
@@ -66,7 +81,7 @@ __global__ __launch_bounds__(512) void gemm_f32_kernel(GfArgs g) {
       for (int j = 0; j < 4; ++j) {
         const int id = tid + 512 * j, kl = id >> 5, n4 = id & 31, k = kc + kl, n = n0 + 4 * n4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k < g.K && n < g.N) v = *(const f32x4*)(B + (long)k * g.ldb + n);
+        if (k < Keff && n < g.N) v = *(const f32x4*)(B + (long)k * g.ldb + n);
         float* d = Bs + ((kl & 1) * GF_T + 4 * n4) * GF_P + (kl >> 1);
         d[0] = v[0]; d[GF_P] = v[1]; d[2 * GF_P] = v[2]; d[3 * GF_P] = v[3];
       }
@@ -143,7 +158,96 @@ __global__ __launch_bounds__(256) void s2d2_f32_kernel(const float* __restrict__
   out[((((long)b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * C + c) * 4 + (y & 1) * 2 + (x & 1)] = in[id];
 }
 
+// ---- elementwise pieces of the fp32 TRAINING path (library erff / expf like the GEMM's GELU epilogue) ------------------------------------------
+// g = GELU(u)
+__global__ __launch_bounds__(256) void gelu_f32_kernel(const float* __restrict__ u, float* __restrict__ g, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = ((const f32x4*)u)[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
+    ((f32x4*)g)[i] = o;
+  }
+}
+// d = d * GELU'(u) in place
+__global__ __launch_bounds__(256) void dgelu_f32_kernel(float* __restrict__ d, const float* __restrict__ u, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = ((const f32x4*)u)[i];
+    f32x4 o = ((f32x4*)d)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] *= 0.5f * (1.0f + erff(v[e] * 0.70710678118654752f)) + v[e] * 0.3989422804014327f * expf(-0.5f * v[e] * v[e]);
+    ((f32x4*)d)[i] = o;
+  }
+}
+// out[r][c] = scale[r] * in[r][c]   (layer scale folded into fc2: W2' = gamma (.) W2, b2' = gamma (.) b2 with cols = 1)
+__global__ __launch_bounds__(256) void rowscale_f32_kernel(const float* __restrict__ in, const float* __restrict__ scale, float* __restrict__ out, long rows, long cols) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * cols; i += (long)gridDim.x * 256) out[i] = in[i] * scale[i / cols];
+}
+// partial column sums of an f32 [T, N] tensor: part[split][n] = sum over the split's rows (deterministic; vdk_reduce_rows_f32 combines)
+__global__ __launch_bounds__(256) void colsum_f32_partial_kernel(const float* __restrict__ x, long ld, long T, int N, long rows_per_split, float* __restrict__ part) {
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  __shared__ float red[4][64];
+  float acc = 0.f;
+  const long r0 = (long)blockIdx.y * rows_per_split;
+  long r1 = r0 + rows_per_split; if (r1 > T) r1 = T;
+  if (n < N) for (long r = r0 + sub; r < r1; r += 4) acc += x[r * ld + n];
+  red[sub][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (sub == 0 && n < N) part[(long)blockIdx.y * N + n] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+// inverse of s2d2_f32_kernel: in[(b, y/2, x/2)][c*4 + 2*(y&1) + (x&1)] -> out[(b, y, x)][c]
+__global__ __launch_bounds__(256) void d2s2_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C) {
+  const long n = (long)B * H * W * C;
+  const long id = (long)blockIdx.x * 256 + threadIdx.x;
+  if (id >= n) return;
+  const int c = (int)(id % C);
+  const long p = id / C;
+  const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((long)W * H));
+  out[id] = in[((((long)b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * C + c) * 4 + (y & 1) * 2 + (x & 1)];
+}
+
 extern "C" {
+
+int vdk_gelu_f32(const float* u, float* g, int64_t n, void* stream) {
+  if (!u || !g || n < 0 || (n & 3)) return vdk_fail(VDK_EINVAL, "vdk_gelu_f32: bad argument (n % 4 == 0)");
+  if (n == 0) return VDK_OK;
+  hipLaunchKernelGGL(gelu_f32_kernel, dim3((unsigned)(((n / 4 + 255) / 256) < 8192 ? ((n / 4 + 255) / 256) : 8192)), dim3(256), 0, (hipStream_t)stream, u, g, (long)(n / 4));
+  return vdk_check_launch("vdk_gelu_f32");
+}
+int vdk_dgelu_f32(float* d, const float* u, int64_t n, void* stream) {
+  if (!d || !u || n < 0 || (n & 3)) return vdk_fail(VDK_EINVAL, "vdk_dgelu_f32: bad argument (n % 4 == 0)");
+  if (n == 0) return VDK_OK;
+  hipLaunchKernelGGL(dgelu_f32_kernel, dim3((unsigned)(((n / 4 + 255) / 256) < 8192 ? ((n / 4 + 255) / 256) : 8192)), dim3(256), 0, (hipStream_t)stream, d, u, (long)(n / 4));
+  return vdk_check_launch("vdk_dgelu_f32");
+}
+int vdk_rowscale_f32(const float* in, const float* scale, float* out, int64_t rows, int64_t cols, void* stream) {
+  if (!in || !scale || !out || rows <= 0 || cols <= 0) return vdk_fail(VDK_EINVAL, "vdk_rowscale_f32: bad argument");
+  const long n = rows * cols;
+  hipLaunchKernelGGL(rowscale_f32_kernel, dim3((unsigned)(((n + 255) / 256) < 4096 ? ((n + 255) / 256) : 4096)), dim3(256), 0, (hipStream_t)stream, in, scale, out, (long)rows, (long)cols);
+  return vdk_check_launch("vdk_rowscale_f32");
+}
+static int colsum_f32_splits(long T) { long s = (T + 2047) / 2048; if (s > 1024) s = 1024; if (s < 1) s = 1; return (int)s; }
+int vdk_colsum_f32_workspace_bytes(int64_t T, int32_t N, size_t* bytes) {
+  if (!bytes || T <= 0 || N <= 0) return vdk_fail(VDK_EINVAL, "vdk_colsum_f32_workspace_bytes: bad argument");
+  *bytes = (size_t)colsum_f32_splits(T) * N * 4;
+  return VDK_OK;
+}
+int vdk_reduce_rows_f32(const float*, int64_t, int32_t, int64_t, float*, float, void*);
+/* out[n] = sum over the T rows of x[T, ld] (bias gradients of the fp32 training path); deterministic two-stage sum */
+int vdk_colsum_f32(const float* x, int64_t ld, int64_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !out || T <= 0 || N <= 0 || ld < N) return vdk_fail(VDK_EINVAL, "vdk_colsum_f32: bad argument");
+  const int S = colsum_f32_splits(T);
+  if (!ws || ws_bytes < (size_t)S * N * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_colsum_f32: workspace too small");
+  const long rps = (T + S - 1) / S;
+  hipLaunchKernelGGL(colsum_f32_partial_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)S), dim3(256), 0, (hipStream_t)stream, x, (long)ld, (long)T, (int)N, rps, (float*)ws);
+  return vdk_reduce_rows_f32((const float*)ws, N, S, N, out, 1.0f, stream);
+}
+int vdk_depth_to_space2_f32(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+  if (!in || !out || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_depth_to_space2_f32: bad argument");
+  const long n = (long)B * H * W * C;
+  hipLaunchKernelGGL(d2s2_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, (int)B, (int)H, (int)W, (int)C);
+  return vdk_check_launch("vdk_depth_to_space2_f32");
+}
 
 int vdk_patchify_f32(const float* x, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t patch, float* out, void* stream) {
   if (!x || !out || B <= 0 || Cin <= 0 || patch <= 0 || H % patch || W % patch) return vdk_fail(VDK_EINVAL, "vdk_patchify_f32: bad argument");
@@ -160,14 +264,18 @@ int vdk_space_to_depth2_f32(const float* in, float* out, int32_t B, int32_t H, i
 
 int vdk_gemm_f32_nt(const VdkGemmF32Desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return vdk_fail(VDK_EINVAL, "vdk_gemm_f32_nt: null pointer");
-  if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K & 3) || (d->lda & 3) || (d->ldb & 3)) return vdk_fail(VDK_EINVAL, "vdk_gemm_f32_nt: K, lda, ldb must be multiples of 4");
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->lda & 3) || (d->ldb & 3) || ((d->K & 3) && !(d->a_kmajor && d->b_kmajor)))
+    return vdk_fail(VDK_EINVAL, "vdk_gemm_f32_nt: lda, ldb (and K, unless both operands are k-major) must be multiples of 4");
   if (d->b_kmajor && (d->N & 3)) return vdk_fail(VDK_EINVAL, "vdk_gemm_f32_nt: k-major B needs N % 4 == 0");
+  if (d->a_kmajor && (d->M & 3)) return vdk_fail(VDK_EINVAL, "vdk_gemm_f32_nt: k-major A needs M % 4 == 0");
+  if (d->k_total < 0 || (d->k_total > 0 && (d->batch2 > 1 || (long)(d->batch1 > 0 ? d->batch1 : 1) * d->K < d->k_total)))
+    return vdk_fail(VDK_EINVAL, "vdk_gemm_f32_nt: k_total splits the contraction over batch1 (batch2 <= 1, batch1 * K >= k_total)");
   if (d->act != VDK_ACT_NONE && d->act != VDK_ACT_GELU) return vdk_fail(VDK_EINVAL, "vdk_gemm_f32_nt: act must be NONE or GELU");
   const int b1 = d->batch1 > 0 ? d->batch1 : 1, b2 = d->batch2 > 0 ? d->batch2 : 1;
   if ((long)b1 * b2 > 65535) return vdk_fail(VDK_EINVAL, "vdk_gemm_f32_nt: batch1 * batch2 <= 65535");
   GfArgs g;
   g.A = d->A; g.lda = d->lda; g.B = d->B; g.ldb = d->ldb; g.C = d->C; g.ldc = d->ldc; g.M = d->M; g.N = d->N; g.K = d->K;
-  g.bias = d->bias; g.res = d->residual; g.cscale = d->col_scale; g.ldr = d->ldr; g.act = d->act; g.alpha = d->alpha == 0.0f ? 1.0f : d->alpha; g.b_kmajor = d->b_kmajor;
+  g.bias = d->bias; g.res = d->residual; g.cscale = d->col_scale; g.ldr = d->ldr; g.act = d->act; g.alpha = d->alpha == 0.0f ? 1.0f : d->alpha; g.b_kmajor = d->b_kmajor; g.a_kmajor = d->a_kmajor; g.k_total = d->k_total;
   g.batch2 = b2; g.sa1 = d->sa1; g.sa2 = d->sa2; g.sb1 = d->sb1; g.sb2 = d->sb2; g.sc1 = d->sc1; g.sc2 = d->sc2;
   const unsigned tiles = (unsigned)(((d->M + GF_T - 1) / GF_T) * ((d->N + GF_T - 1) / GF_T));
   hipLaunchKernelGGL(gemm_f32_kernel, dim3(tiles, (unsigned)(b1 * b2)), dim3(512), 0, (hipStream_t)stream, g);

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restric
 // dcos bf16 [Bp?, lddc] = gscale * (softmax - target) * jac (columns C..lddc-1 zeroed).
 __global__ __launch_bounds__(256) void margin_ce_kernel(MarginP P, const float* __restrict__ cosv, long ldc, int C, const long long* __restrict__ y,
                                                         float label_smoothing, float gscale, float* __restrict__ logits, long ldl,
-                                                        float* __restrict__ loss_rows, bf16_t* __restrict__ dcos, long lddc) {
+                                                        float* __restrict__ loss_rows, bf16_t* __restrict__ dcos, long lddc, float* __restrict__ dcos32) {
   __shared__ float red[4];
   const int row = blockIdx.x, tid = threadIdx.x;
   margin_row_params(P, row);
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void margin_ce_kernel(MarginP P, const float* 
     mx = fmaxf(mx, lg); sm += lg;
   }
   mx = block_max<4>(mx, red);
-  if (!loss_rows && !dcos) return;
+  if (!loss_rows && !dcos && !dcos32) return;
   sm = block_sum<4>(sm, red);
   float se = 0.f;
   for (int c = tid; c < C; c += 256) { float lg, jc; margin_eval(P, R, cr[c], c == yt, lg, jc); se += expf(lg - mx); }
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void margin_ce_kernel(MarginP P, const float* 
     float lg, jc; margin_eval(P, R, cr[yt], true, lg, jc);
     loss_rows[row] = lse - (1.0f - label_smoothing) * lg - label_smoothing * (sm / (float)C);
   }
-  if (!dcos) return;
+  if (!dcos && !dcos32) return;
   const float inv = 1.0f / se, epsc = label_smoothing / (float)C;
   for (int c = tid; c < (int)lddc; c += 256) {
     float g = 0.f;
@@ -220,7 +220,8 @@ __global__ __launch_bounds__(256) void margin_ce_kernel(MarginP P, const float* 
       if (c == yt) g -= (1.0f - label_smoothing);
       g *= gscale * jc;
     }
-    dcos[(long)row * lddc + c] = f2bf(g);
+    if (dcos32) dcos32[(long)row * lddc + c] = g;      // the fp32-class training mode keeps the logit gradient unrounded
+    else dcos[(long)row * lddc + c] = f2bf(g);
   }
 }
 // Training form (no logits output) for wide heads: the same arithmetic with 16-byte loads, four of them in flight per thread (a 4-byte strided loop keeps
@@ -498,8 +499,17 @@ int vdk_margin_ce(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_
                        label_smoothing, grad_scale, loss_rows, (bf16_t*)dcos_bf16, (long)lddc);
   else
     hipLaunchKernelGGL(margin_ce_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, P, cosv, (long)ldc, (int)C, (const long long*)labels,
-                       label_smoothing, grad_scale, logits, (long)ldl, loss_rows, (bf16_t*)dcos_bf16, (long)lddc);
+                       label_smoothing, grad_scale, logits, (long)ldl, loss_rows, (bf16_t*)dcos_bf16, (long)lddc, (float*)nullptr);
   return vdk_check_launch("vdk_margin_ce");
+}
+/* vdk_margin_ce with the logit gradient d(loss)/d(cos) left in fp32 [B, lddc] (columns C .. lddc - 1 zeroed): the head of the fp32-class training mode */
+int vdk_margin_ce_f32(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t C, const int64_t* labels, float label_smoothing, float grad_scale,
+                      float* loss_rows, float* dcos_f32, int64_t lddc, void* stream) {
+  MarginP P; int rc = fill_params(h, &P); if (rc) return rc;
+  if (!cosv || !labels || !dcos_f32 || B <= 0 || C <= 0 || lddc < C) return vdk_fail(VDK_EINVAL, "vdk_margin_ce_f32: bad argument");
+  hipLaunchKernelGGL(margin_ce_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, P, cosv, (long)ldc, (int)C, (const long long*)labels, label_smoothing, grad_scale,
+                     (float*)nullptr, 0L, loss_rows, (bf16_t*)nullptr, (long)lddc, dcos_f32);
+  return vdk_check_launch("vdk_margin_ce_f32");
 }
 int vdk_margin_target_cos(const float* cosv, int64_t ldc, int32_t B, int32_t Cloc, int64_t c_base, const int64_t* labels, float* gt, void* stream) {
   if (!cosv || !labels || !gt || B <= 0 || Cloc <= 0) return vdk_fail(VDK_EINVAL, "vdk_margin_target_cos: bad argument");

@@ -138,10 +138,15 @@ class _NeckCNNFn(torch.autograd.Function):
         sm2 = torch.empty(Cc, dtype=torch.float32, device=dev); si2 = torch.empty(Cc, dtype=torch.float32, device=dev)
         sg = getattr(wrapper, "sync_group", False)
         _bn_rows_fwd(be, rows, B * HW, Cc, bn2_w, bn2_b, bn2, training, y2, sm2, si2, sg)
-        h = ops.cast_bf16(y2, backend=be).view(Bp, K)                           # bf16 [Bp, HW*C], pad rows zero
         wperm = lin_w.detach().view(Fd, Cc, HW).permute(0, 2, 1).reshape(Fd, K).contiguous()
-        wb = ops.cast_bf16(wperm, backend=be)
-        z = ops.gemm_nt(h[:B], wb, out_dtype=torch.float32, bias=lin_b.detach(), backend=be)
+        fp32 = getattr(wrapper, "precision", "bf16") == "fp32"      # FaceTrainStep(precision="fp32"): the Linear on the fp32 MFMA, operands as they are
+        if fp32:
+            h, wb = y2.view(Bp, K), wperm
+            z = ops.gemm_f32(h[:B], wb, bias=lin_b.detach(), backend=be)
+        else:
+            h = ops.cast_bf16(y2, backend=be).view(Bp, K)                       # bf16 [Bp, HW*C], pad rows zero
+            wb = ops.cast_bf16(wperm, backend=be)
+            z = ops.gemm_nt(h[:B], wb, out_dtype=torch.float32, bias=lin_b.detach(), backend=be)
         y = torch.empty_like(z)
         sm = torch.empty(Fd, dtype=torch.float32, device=dev); si = torch.empty(Fd, dtype=torch.float32, device=dev)
         _bn_rows_fwd(be, z, B, Fd, bn_w, bn_b, bn, training, y, sm, si, sg)
@@ -163,20 +168,25 @@ class _NeckCNNFn(torch.autograd.Function):
         dz = torch.empty((B, Fd), dtype=torch.float32, device=dev)
         dbn_w = torch.empty(Fd, dtype=torch.float32, device=dev); dbn_b = torch.empty(Fd, dtype=torch.float32, device=dev)
         _bn_rows_bwd(be, dy, z, B, Fd, bn_w, sm, si, dz, dbn_w, dbn_b, ctx.sg)
-        stage = torch.zeros((Bp, _up(Fd, 8)), dtype=torch.float32, device=dev)
-        stage[:B, :Fd].copy_(dz)
-        dzb = ops.cast_bf16(stage, backend=be)
         dlin_b = ops.reduce_rows(dz, backend=be)
-        dwp = ops.gemm_nt(dzb, h, out_dtype=torch.float32, trans=True, backend=be)[:Fd]                      # [F, HW*C]
-        dlin_w = dwp.view(Fd, HW, Cc).permute(0, 2, 1).reshape(Fd, K)                                          # back to the NCHW column order
-        dzt = ops.transpose_pad(dzb, rpad=Bp, backend=be)
-        fpad = dzt.shape[0]
-        if fpad % 64 == 0 and fpad == Fd:
-            dh = ops.gemm_nt(dzt, wb, out_dtype=torch.float32, trans=True, backend=be)                         # [Bp, HW*C]
+        if h.dtype == torch.float32:                                                                           # precision="fp32": both gradients on the fp32 MFMA, operands read as they lie
+            dwp = ops.gemm_f32(dz, h[:B], a_kmajor=True, b_kmajor=True, backend=be)                            # dz^T h: [F, HW*C]
+            dlin_w = dwp.view(Fd, HW, Cc).permute(0, 2, 1).reshape(Fd, K)
+            dh = ops.gemm_f32(dz, wb, b_kmajor=True, backend=be).reshape(B * HW, Cc)                           # dz W': [B, HW*C]
         else:
-            wbt = ops.transpose_pad(wb, rpad=_up(Fd, 8), backend=be)
-            dh = ops.gemm_nt(dzb, wbt, out_dtype=torch.float32, backend=be)
-        dh = dh[:B].reshape(B * HW, Cc)
+            stage = torch.zeros((Bp, _up(Fd, 8)), dtype=torch.float32, device=dev)
+            stage[:B, :Fd].copy_(dz)
+            dzb = ops.cast_bf16(stage, backend=be)
+            dwp = ops.gemm_nt(dzb, h, out_dtype=torch.float32, trans=True, backend=be)[:Fd]                      # [F, HW*C]
+            dlin_w = dwp.view(Fd, HW, Cc).permute(0, 2, 1).reshape(Fd, K)                                          # back to the NCHW column order
+            dzt = ops.transpose_pad(dzb, rpad=Bp, backend=be)
+            fpad = dzt.shape[0]
+            if fpad % 64 == 0 and fpad == Fd:
+                dh = ops.gemm_nt(dzt, wb, out_dtype=torch.float32, trans=True, backend=be)                         # [Bp, HW*C]
+            else:
+                wbt = ops.transpose_pad(wb, rpad=_up(Fd, 8), backend=be)
+                dh = ops.gemm_nt(dzb, wbt, out_dtype=torch.float32, backend=be)
+            dh = dh[:B].reshape(B * HW, Cc)
         dx = torch.empty((B * HW, Cc), dtype=torch.float32, device=dev)
         dbn2_w = torch.empty(Cc, dtype=torch.float32, device=dev); dbn2_b = torch.empty(Cc, dtype=torch.float32, device=dev)
         _bn_rows_bwd(be, dh.contiguous(), rows, B * HW, Cc, bn2_w, sm2, si2, dx, dbn2_w, dbn2_b, ctx.sg)
@@ -386,8 +396,12 @@ class FaceTrainStep:
 
     def __init__(self, model: "FaceTrainingModel", lr: float, momentum: float = 0.9, weight_decay: float = 5e-4, label_smoothing: float = 0.0,
                  max_norm: float = 10.0, ema: bool = True, comm=None, layer_wise: bool = False, shard_head: bool = False, sync_bn: bool = False,
-                 cos_planes: int = 3):
-        """cos_planes: 3 = fp32-class cosines in the head (split-bf16 planes: the reference's CPU path), 1 = single bf16 operands (the reference's GPU path: the head runs
+                 cos_planes: int = 3, precision: str = "bf16"):
+        """precision: "bf16" = bf16 MFMA operands with fp32 accumulation, residual stream and master weights (what the reference's GPU classifier loop computes under
+        autocast); "fp32" = the arithmetic of the reference's face / CBIR loop, which runs WITHOUT autocast (engine/procedure/train.py:217-227): fp32 activations, every
+        contraction of the backbone and of the neck's Linear on the fp32 MFMA, split-plane (fp32-class) cosines in the head -- embeddings ~1e-5 and gradients ~1e-4 from
+        the fp32 oracle at ~1/6 of the bf16 step's speed (CNN backbones; tests/test_face.py, tests/test_parity_fullsize_gpu.py).
+        cos_planes: 3 = fp32-class cosines in the head (split-bf16 planes: the reference's CPU path), 1 = single bf16 operands (the reference's GPU path: the head runs
         under autocast, train.py:118).  shard_head (with comm): every rank keeps the columns [rank * C / world, (rank + 1) * C / world) of the margin head, trains them with
         `heads.sharded_margin_ce` (features all-gathered, per-row softmax statistics and the [B, D] feature gradient all-reduced) and never all-reduces the
         [D, C] head gradient (2 GB at C = 10^6).  `gather_head()` writes the shards back into `head.weight` for evaluation / checkpoints.
@@ -397,10 +411,19 @@ class FaceTrainStep:
         rank 0 at construction and the buffers again before every forward (torch DDP's broadcast_buffers=True, which the reference's
         DDP wrap at vision_engine.py:510 uses); the backbone's flat gradient is all-reduced in buckets while backward is still running, the neck /
         head gradients right after; BatchNorm statistics stay per-rank (the reference's default, SyncBN is its opt-in flag)."""
-        self.cos_planes = cos_planes
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.cos_planes = 3 if precision == "fp32" else cos_planes
         self.model = model
         self.comm = comm
         self.bb = model.trainingwrapper["backbone"]
+        if precision == "fp32" and shard_head:
+            raise NotImplementedError("precision='fp32' with a class-sharded head is not built")
+        if precision == "fp32" and not self.bb.is_cnn:
+            raise NotImplementedError("precision='fp32' is built for the CNN (ConvNeXt) backbones of the face / CBIR task")
+        self.precision = precision
+        self.bb.precision = precision
+        self.bb.model.engine.precision = precision
         # sync_bn (the reference's `sync_bn` flag converts every BatchNorm of the model, engine/vision_engine.py:224-225): the neck's BatchNorm2d / BatchNorm1d
         # all-reduce their batch statistics (forward) and gradient sums (backward) over comm's group
         self.bb.sync_group = comm.group if (sync_bn and comm is not None and comm.active) else False
@@ -487,7 +510,7 @@ class FaceTrainStep:
             self.loss_rows, demb, dW = heads.sharded_margin_ce(self.head, emb.detach(), y, self.hs, self.c0, self.head.weight.shape[1], group=self.comm.group,
                                                               label_smoothing=self.label_smoothing)
         else:
-            self.loss_rows, demb, dW = self.head.margin_ce(emb.detach(), y, self.label_smoothing, cos_planes=self.cos_planes)
+            self.loss_rows, demb, dW = self.head.margin_ce(emb.detach(), y, self.label_smoothing, cos_planes=self.cos_planes, precise=self.precision == "fp32")
         for p in self.small:
             p.grad = None
         emb.backward(demb)

@@ -105,14 +105,42 @@ class _MarginHead(nn.Module):
     def forward(self, feats: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         return _HeadFn.apply(feats, self.weight, labels, self)
 
+    def _margin_ce_f32(self, feats: torch.Tensor, labels: torch.Tensor, label_smoothing: float, grad_scale: Optional[float]):
+        """margin_ce in fp32-class arithmetic throughout (FaceTrainStep(precision="fp32")): the cosines, d(loss)/d(cos) and both gradient products on the fp32 MFMA from
+        fp32 operands -- what the reference's head computes in its no-autocast face / CBIR loop (engine/procedure/train.py:217-227)."""
+        be = self.be
+        w = self.weight.detach()
+        st = _forward_cos(be, feats.contiguous(), w, 1, with_cos=False)      # the fp32 normalised features (fh), 1 / |f| and 1 / |w_c|; the bf16 planes are not used
+        dev = feats.device
+        wn = torch.zeros((st.D, st.Cp), dtype=torch.float32, device=dev)
+        wn[:, :st.C] = w * st.winv[None, :]                                  # unit-norm columns (arcface.py:16 F.normalize(self.weight, dim=0))
+        fh = st.fh
+        cos = ops.gemm_f32(fh, wn, b_kmajor=True, backend=be)                # [B, Cp]
+        loss = torch.empty(st.B, dtype=torch.float32, device=dev)
+        dcos = torch.empty((st.B, st.Cp), dtype=torch.float32, device=dev)
+        gs = 1.0 / st.B if grad_scale is None else grad_scale
+        be.check(be.lib.vdk_margin_ce_f32(C.byref(self.cfg), be.ptr(cos), st.Cp, st.B, st.C, be.ptr(labels), label_smoothing, gs, be.ptr(loss), be.ptr(dcos), st.Cp,
+                                          be.stream()), "vdk_margin_ce_f32")
+        dwh = ops.gemm_f32(fh, dcos, a_kmajor=True, b_kmajor=True, backend=be)                       # f^T dcos: [D, Cp]
+        dW = torch.empty((st.D, st.C), dtype=torch.float32, device=dev)
+        be.check(be.lib.vdk_colnorm_bwd(be.ptr(w), st.C, be.ptr(st.winv), be.ptr(dwh), st.Cp, st.D, st.C, be.ptr(dW), st.C, be.stream()), "vdk_colnorm_bwd")
+        tiles = ((st.B + 127) // 128) * ((st.D + 127) // 128)
+        splits = max(1, min(64, 1024 // tiles, st.Cp // 2048))
+        dfh = ops.gemm_f32(dcos, wn, k_splits=splits, backend=be)                                    # dcos W^T: [B, D], the contraction over the classes in slabs
+        df = torch.empty((st.B, st.D), dtype=torch.float32, device=dev)
+        be.check(be.lib.vdk_rownorm_bwd(be.ptr(st.fh), be.ptr(st.finv), be.ptr(dfh), st.D, st.B, st.D, be.ptr(df), be.stream()), "vdk_rownorm_bwd")
+        return loss, df, dW
+
     def margin_ce(self, feats: torch.Tensor, labels: torch.Tensor, label_smoothing: float = 0.0, grad_scale: Optional[float] = None, cos_planes: int = 3,
-                  fused: Optional[bool] = None):
+                  fused: Optional[bool] = None, precise: bool = False):
         """Fused head + CrossEntropy (mean): returns (loss_rows [B], dfeats [B, D], dweight [D, C]); no autograd, no B x C logits.
         fused=True: the epilogue-fused form (SURVEY K11 to the letter: cos never exists as an fp32 [B, C] tensor; the cos GEMM runs twice with the head applied to its tiles in
         registers).  Measured on the MI355X at B 512, C 10^6: 6.7 ms against 5.8 ms for the default form that writes cos once in fp32 -- the head's ~18 lane-ops per logit run in a
         GEMM epilogue that nothing overlaps (one workgroup per CU), whereas the row kernel runs them at full occupancy -- so it is opt-in (profiles/r02_margin_head.json).
         cos_planes = 1: the cosines from single bf16 operands, as the reference's autocast path computes them (see _forward_cos)"""
         be = self.be
+        if precise:
+            return self._margin_ce_f32(feats, labels, label_smoothing, grad_scale)
         gs_ = None
         if fused:
             # the fused form: the cos GEMM runs twice with the head applied to its tiles in registers (statistics, then the gradient); cos never exists as an fp32 [B, C] tensor

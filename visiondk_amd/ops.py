@@ -473,12 +473,29 @@ def batchnorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma, save_mean, save_invs
 
 
 # ---- precise (fp32 MFMA) path ---------------------------------------------------------------------------------------------
-def gemm_f32(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, act: int = ACT_NONE, alpha: float = 1.0, b_kmajor: bool = False, backend=None):
-    """out f32 [M, N] = epilogue(alpha * a[M, K] @ b[N, K].T)  (b_kmajor: b is [K, N]); fp32 operands, fp32 MFMA"""
+def gemm_f32(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, act: int = ACT_NONE, alpha: float = 1.0, b_kmajor: bool = False, a_kmajor: bool = False,
+             k_splits: int = 1, backend=None):
+    """out f32 [M, N] = epilogue(alpha * a[M, K] @ b[N, K].T)  (b_kmajor: b is [K, N]; a_kmajor: a is [K, M], with b_kmajor the weight-gradient form a.T @ b);
+    fp32 operands, fp32 MFMA.  k_splits > 1: the contraction in that many slabs (a long K with few output tiles), summed in slab order; no epilogue then."""
     be = _be(backend)
     assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1
-    M, K = a.shape
+    K, M = a.shape if a_kmajor else a.shape[::-1]
     N = b.shape[1] if b_kmajor else b.shape[0]
+    if k_splits > 1:
+        assert bias is None and residual is None and act == ACT_NONE and alpha == 1.0
+        kc = ((K + k_splits - 1) // k_splits + 3) // 4 * 4
+        S = (K + kc - 1) // kc
+        slabs = torch.empty((S, M, N), dtype=torch.float32, device=a.device)
+        d = _abi.GemmF32Desc()
+        d.A, d.lda, d.B, d.ldb, d.C, d.ldc = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), slabs.data_ptr(), N
+        d.M, d.N, d.K, d.alpha, d.b_kmajor, d.a_kmajor = M, N, kc, 1.0, int(b_kmajor), int(a_kmajor)
+        d.batch1, d.batch2, d.sc1, d.k_total = S, 1, M * N, K
+        d.sa1 = kc * a.stride(0) if a_kmajor else kc
+        d.sb1 = kc * b.stride(0) if b_kmajor else kc
+        be.check(be.lib.vdk_gemm_f32_nt(C.byref(d), be.stream()), "vdk_gemm_f32_nt")
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        be.check(be.lib.vdk_reduce_rows_f32(be.ptr(slabs), M * N, S, M * N, be.ptr(out), 1.0, be.stream()), "vdk_reduce_rows_f32")
+        return out
     out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     d = _abi.GemmF32Desc()
     d.A, d.lda, d.B, d.ldb, d.C, d.ldc = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), N
@@ -486,7 +503,7 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, act:
     d.bias = bias.data_ptr() if bias is not None else None
     d.residual = residual.data_ptr() if residual is not None else None
     d.ldr = residual.stride(0) if residual is not None else 0
-    d.act, d.alpha, d.b_kmajor = act, alpha, int(b_kmajor)
+    d.act, d.alpha, d.b_kmajor, d.a_kmajor = act, alpha, int(b_kmajor), int(a_kmajor)
     be.check(be.lib.vdk_gemm_f32_nt(C.byref(d), be.stream()), "vdk_gemm_f32_nt")
     return out
 
