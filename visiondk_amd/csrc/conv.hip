@@ -193,21 +193,25 @@ __global__ __launch_bounds__(W * (CC / 4), 2) void dwconv7_rows_kernel(const flo
 
 // ------------------------------------------------------------------------------------ K6 weight / bias gradient
 // dw[c][7i+j] = sum_{b,y,x} dy[b,y,x,c] * in[b, y+i-3, x+j-3, c];  db[c] = sum dy[b,y,x,c].
-// grid: (S slices, ceil(C / 64)); 448 threads = 7 vertical taps x 64 channels; a workgroup walks its share of the (image, tile) list,
-// stages the input tile (with halo) and the dy tile in LDS, and every thread keeps the 7 horizontal taps of its (channel, i) in
-// registers: per output row 8 dy values and 14 inputs feed 56 FMAs.  Partials per slice are combined by vdk_reduce_rows_f32.
+// grid: (S slices, ceil(C / 64)); 448 threads = 2 row halves x 7 vertical taps x 32 channel PAIRS; a workgroup walks its share of the (image, tile) list,
+// stages the input tile (with halo) and the dy tile in LDS, and every thread keeps the 7 horizontal taps of its (channel pair, i) in registers: per output row
+// TW dy pairs and TW + 6 input pairs (8-byte LDS reads) feed 7 TW packed FMAs (v_pk_fma_f32: two channels per instruction).  The first form -- one channel per
+// lane, 4-byte LDS reads, scalar FMAs -- was bound by its instruction count (1850 per item and thread: 227 us at 14 x 14 x 512, batch 512, against an 85 us byte
+// floor); this one issues half of them.  Each row half writes its own partial row: 2 S rows are combined by vdk_reduce_rows_f32.
 template <int TH, int TW>
 __global__ __launch_bounds__(448) void dwconv7_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ dy, float* __restrict__ part, int B,
                                                             int H, int W, int C, int S) {
   constexpr int IH = TH + 6, IW = TW + 6;
   __shared__ __attribute__((aligned(16))) float xs[IH * IW * DW_CC];
   __shared__ __attribute__((aligned(16))) float ds[TH * TW * DW_CC];
-  const int tid = threadIdx.x, cl = tid & 63, ti = tid >> 6;
+  const int tid = threadIdx.x, cp = tid & 31, ti = (tid >> 5) % 7, rg = (tid >> 5) / 7;      // channel pair, vertical tap, row half (rows rg, rg + 2, ...)
   const int tx_n = (W + TW - 1) / TW, ty_n = (H + TH - 1) / TH;
   const long items = (long)B * tx_n * ty_n;
   const int c0 = blockIdx.y * DW_CC;
-  float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float accb = 0.f;
+  vdk_f32x2 acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) acc[j] = (vdk_f32x2){0.f, 0.f};
+  vdk_f32x2 accb = {0.f, 0.f};
   // software pipeline: the next item's tile loads are issued into registers before this item's FMAs and written to LDS after them, so the HBM latency
   // hides under the compute (with one workgroup per CU at 92 KB of LDS, load -> barrier -> compute per item left the CU idle for a round trip per item)
   constexpr int XS_N = IH * IW * (DW_CC / 4), DS_N = TH * TW * (DW_CC / 4), PFX = (XS_N + 447) / 448, PFD = (DS_N + 447) / 448;
@@ -250,28 +254,28 @@ __global__ __launch_bounds__(448) void dwconv7_wgrad_kernel(const float* __restr
     __syncthreads();
     if (it + S < items) fetch(it + S);
 #pragma unroll 1
-    for (int h = 0; h < TH; ++h) {
-      float d[TW], xv[IW];
+    for (int h = rg; h < TH; h += 2) {
+      vdk_f32x2 d[TW], xv[IW];
 #pragma unroll
-      for (int w = 0; w < TW; ++w) d[w] = ds[(h * TW + w) * DW_CC + cl];
+      for (int w = 0; w < TW; ++w) d[w] = *(const vdk_f32x2*)(ds + (h * TW + w) * DW_CC + 2 * cp);
 #pragma unroll
-      for (int w = 0; w < IW; ++w) xv[w] = xs[((h + ti) * IW + w) * DW_CC + cl];
+      for (int w = 0; w < IW; ++w) xv[w] = *(const vdk_f32x2*)(xs + ((h + ti) * IW + w) * DW_CC + 2 * cp);
 #pragma unroll
       for (int j = 0; j < 7; ++j)
 #pragma unroll
-        for (int w = 0; w < TW; ++w) acc[j] = fmaf(d[w], xv[w + j], acc[j]);
+        for (int w = 0; w < TW; ++w) acc[j] = vdk_fma2(d[w], xv[w + j], acc[j]);
       if (ti == 0) {
 #pragma unroll
         for (int w = 0; w < TW; ++w) accb += d[w];
       }
     }
   }
-  const int c = c0 + cl;
-  if (c < C) {
-    float* p = part + (long)blockIdx.x * ((long)C * 50);
+  const int c = c0 + 2 * cp;
+  if (c < C) {     // (C % 4 == 0: a pair never straddles the end)
+    float* p = part + ((long)blockIdx.x * 2 + rg) * ((long)C * 50);
 #pragma unroll
-    for (int j = 0; j < 7; ++j) p[(long)c * 49 + ti * 7 + j] = acc[j];
-    if (ti == 0) p[(long)C * 49 + c] = accb;
+    for (int j = 0; j < 7; ++j) { p[(long)c * 49 + ti * 7 + j] = acc[j][0]; p[(long)(c + 1) * 49 + ti * 7 + j] = acc[j][1]; }
+    if (ti == 0) { p[(long)C * 49 + c] = accb[0]; p[(long)C * 49 + c + 1] = accb[1]; }
   }
 }
 
@@ -422,7 +426,7 @@ static int dw_slices(int B, int H, int W, int C) {
 }
 int vdk_dwconv7_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C, size_t* bytes) {
   if (!bytes || B <= 0 || H <= 0 || W <= 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_dwconv7_wgrad_workspace_bytes: bad argument");
-  *bytes = (size_t)dw_slices(B, H, W, C) * C * 50 * 4;
+  *bytes = (size_t)2 * dw_slices(B, H, W, C) * C * 50 * 4;      // two partial rows (row halves) per slice
   return VDK_OK;
 }
 int vdk_reduce_rows_f32(const float*, int64_t, int32_t, int64_t, float*, float, void*);
@@ -444,19 +448,19 @@ static int dw_wgrad_impl(const float* in, const float* dy, float* dw, float* db,
                          VdkReduceJob* job) {
   if (!in || !dy || !dw || !db || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return vdk_fail(VDK_EINVAL, "vdk_dwconv7_wgrad: bad argument (C % 4 == 0)");
   const int S = dw_slices(B, H, W, C);
-  if (!ws || ws_bytes < (size_t)S * C * 50 * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_dwconv7_wgrad: workspace too small");
+  if (!ws || ws_bytes < (size_t)2 * S * C * 50 * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_dwconv7_wgrad: workspace too small");
   int th, tw; dw_wgrad_tile(H, W, &th, &tw);
   const dim3 grid((unsigned)S, (unsigned)((C + DW_CC - 1) / DW_CC));
   if (th == 14) hipLaunchKernelGGL((dwconv7_wgrad_kernel<14, 14>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
   else if (tw == 14) hipLaunchKernelGGL((dwconv7_wgrad_kernel<7, 14>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
   else if (tw == 7) hipLaunchKernelGGL((dwconv7_wgrad_kernel<7, 7>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
   else hipLaunchKernelGGL((dwconv7_wgrad_kernel<8, 8>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
-  if (job) { *job = VdkReduceJob{(const float*)ws, (long)C * 50, S, (long)C * 50, dw, 1.0f}; return vdk_check_launch("vdk_dwconv7_wgrad"); }
+  if (job) { *job = VdkReduceJob{(const float*)ws, (long)C * 50, 2 * S, (long)C * 50, dw, 1.0f}; return vdk_check_launch("vdk_dwconv7_wgrad"); }
   if (db == dw + (size_t)C * 49)     // conv_dw.weight / conv_dw.bias of the flat gradient buffer: the partial rows [49 C | C] reduce in one launch
-    return vdk_reduce_rows_f32((const float*)ws, (int64_t)C * 50, S, (int64_t)C * 50, dw, 1.0f, stream);
-  int rc = vdk_reduce_rows_f32((const float*)ws, (int64_t)C * 50, S, (int64_t)C * 49, dw, 1.0f, stream);
+    return vdk_reduce_rows_f32((const float*)ws, (int64_t)C * 50, 2 * S, (int64_t)C * 50, dw, 1.0f, stream);
+  int rc = vdk_reduce_rows_f32((const float*)ws, (int64_t)C * 50, 2 * S, (int64_t)C * 49, dw, 1.0f, stream);
   if (rc) return rc;
-  return vdk_reduce_rows_f32((const float*)ws + (size_t)C * 49, (int64_t)C * 50, S, C, db, 1.0f, stream);
+  return vdk_reduce_rows_f32((const float*)ws + (size_t)C * 49, (int64_t)C * 50, 2 * S, C, db, 1.0f, stream);
 }
 
 int vdk_space_to_depth2_bf16(const void* in, void* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t inverse, void* stream) {
