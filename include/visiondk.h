@@ -227,6 +227,9 @@ int vdk_batchnorm1d_bwd(const float* dy, int64_t lddy, const float* x, int64_t l
 
 /* out[c] = scale * sum_{s<S} in[s*ld + c]  (deterministic; pos_embed/cls gradients, partial combines) */
 int vdk_reduce_rows_f32(const float* in, int64_t ld, int32_t S, int64_t n, float* out, float scale, void* stream);
+/* tests: the same reduction through the in-library batch path the engines use (up to 8 reductions per launch); `buf` is SCRATCH: from 1024 partial rows on they are folded onto
+ * the first 64 in place before the final sum (fixed order: bit-reproducible) */
+int vdk_debug_reduce_rows_job(float* buf, int64_t ld, int32_t S, int64_t n, float* out, float scale, void* stream);
 /* out[c] = sum_r in[r][c], in bf16 [T, N] — bias gradient of a Linear */
 int vdk_colsum_bf16_workspace_bytes(int32_t T, int32_t N, size_t* bytes);
 int vdk_colsum_bf16(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream);

@@ -189,3 +189,20 @@ def test_batchnorm_rows_fwd_bwd(be, dev, B, F):
     bn.eval()
     ye, _, _ = ops.batchnorm_fwd(x.to(dev), bn.weight.detach().to(dev), bn.bias.detach().to(dev), rm, rv, training=False, backend=be)
     torch.testing.assert_close(ye.cpu(), bn(x).detach(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("S,n", [(37, 130), (1024, 200), (2500, 72)])
+def test_batch_reduction_folds_tall_jobs(be, dev, S, n):
+    """the engines' batched row reduction: from 1024 partial rows on, the rows are folded onto the first 64 in place (more workgroups than the n / 64 of the final sum);
+    against a float64 sum, and bit-reproducible"""
+    torch.manual_seed(S)
+    ld = n + 6
+    src = torch.randn(S, ld)
+    want = src[:, :n].double().sum(0) * 0.5
+    outs = []
+    for _ in range(2):
+        buf = src.clone().to(dev); out = torch.empty(n, device=dev)
+        be.check(be.lib.vdk_debug_reduce_rows_job(be.ptr(buf), ld, S, n, be.ptr(out), 0.5, be.stream()), "vdk_debug_reduce_rows_job")
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])
+    torch.testing.assert_close(outs[0].double(), want, rtol=1e-5, atol=1e-4)

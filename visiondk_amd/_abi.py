@@ -110,6 +110,7 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_batchnorm1d_fwd": (C.c_int, [P, I64, I32, I32, P, P, F32, F32, I32, P, P, P, I64, P, P, P]),
     "vdk_batchnorm1d_bwd": (C.c_int, [P, I64, P, I64, I32, I32, P, P, P, P, I64, P, P, P]),
     "vdk_reduce_rows_f32": (C.c_int, [P, I64, I32, I64, P, F32, P]),
+    "vdk_debug_reduce_rows_job": (C.c_int, [P, I64, I32, I64, P, F32, P]),
     "vdk_colsum_bf16_workspace_bytes": (C.c_int, [I32, I32, PSZ]),
     "vdk_colsum_bf16": (C.c_int, [P, I64, I32, I32, P, P, SZ, P]),
     "vdk_softmax_ce": (C.c_int, [P, I64, I32, I32, P, P, F32, F32, F32, P, P, I64, P, I64, P]),

@@ -262,6 +262,26 @@ __global__ __launch_bounds__(512) void reduce_rows_batch_kernel(ReduceBatch b) {
     jb.out[c] = (((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]))) * jb.scale;
 }
 
+// A TALL job (thousands of partial rows: the column-sum by-product of a GEMM over 1.6 M rows leaves 12 544 of them) is folded first: row g < 64 of the partial buffer
+// becomes the sum of the rows g, g + 64, g + 128, ... (in place: block (columns, g) reads and writes only rows = g mod 64), 64 x n / 64 workgroups instead of the
+// n / 64 of the batch kernel, whose threads would each walk S / 8 rows with two loads in flight (376 us for 25 MB).  The order of the sum is fixed: bit-reproducible.
+#define RR_FOLD 64
+__global__ __launch_bounds__(512) void reduce_rows_fold_kernel(float* __restrict__ buf, long ld, int S, long n) {
+  __shared__ float red[8][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, g = blockIdx.y;
+  const long c = (long)blockIdx.x * 64 + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < n) {
+    int k = g + RR_FOLD * rl;
+    for (; k + 8 * RR_FOLD < S; k += 16 * RR_FOLD) { s0 += buf[(long)k * ld + c]; s1 += buf[(long)(k + 8 * RR_FOLD) * ld + c]; }
+    if (k < S) s0 += buf[(long)k * ld + c];
+  }
+  red[rl][cl] = s0 + s1;
+  __syncthreads();
+  if (rl == 0 && c < n)
+    buf[(long)g * ld + c] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
+}
+
 // partial[split][c] = sum over this split's rows of in[r][c]  (bf16 input).  Block = 32 column chunks (16 B = 8 columns)
 // x 8 row lanes; every load is 16 B and a wave reads 512 contiguous bytes of a row.
 // Q8: the pass also writes the fp8 copy of the tensor it reads (and its amax) -- the attention backward's dqkv needs both its column sums (qkv.bias) and its e5m2 copy
@@ -727,12 +747,23 @@ int vdk_reduce_rows_batch(const VdkReduceJob* jobs, int n, void* stream) {
     for (int i = i0; i < n && b.n < 8; ++i) {
       if (!jobs[i].in || jobs[i].n <= 0) continue;
       b.first_block[b.n] = blocks;
-      b.job[b.n++] = jobs[i];
+      VdkReduceJob jb = jobs[i];
+      if (jb.S >= 16 * RR_FOLD) {      // tall: fold the partial rows (scratch of the caller) onto the first 64, in place
+        hipLaunchKernelGGL(reduce_rows_fold_kernel, dim3((unsigned)((jb.n + 63) / 64), RR_FOLD), dim3(512), 0, (hipStream_t)stream, (float*)jb.in, (long)jb.ld, (int)jb.S, (long)jb.n);
+        jb.S = RR_FOLD;
+      }
+      b.job[b.n++] = jb;
       blocks += (int)((jobs[i].n + 63) / 64);
     }
     b.first_block[b.n] = blocks;
     if (blocks > 0) hipLaunchKernelGGL(reduce_rows_batch_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, b);
   }
   return vdk_check_launch("vdk_reduce_rows_batch");
+}
+/* tests: one job through vdk_reduce_rows_batch (the in-library batch reduction; `buf` is scratch: a tall job is folded in place) */
+extern "C" int vdk_debug_reduce_rows_job(float* buf, int64_t ld, int32_t S, int64_t n, float* out, float scale, void* stream) {
+  if (!buf || !out || S <= 0 || n <= 0 || ld < n) return vdk_fail(VDK_EINVAL, "vdk_debug_reduce_rows_job: bad argument");
+  const VdkReduceJob jb = {buf, (long)ld, (int)S, (long)n, out, scale};
+  return vdk_reduce_rows_batch(&jb, 1, stream);
 }
 
