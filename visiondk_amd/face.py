@@ -211,7 +211,10 @@ class TimmWrapper(nn.Module):
             tokens, channels = self.model.engine.tokens, self.model.spec.dim
             self.output_layer = nn.Sequential(nn.LayerNorm(channels), nn.Flatten(1), nn.Linear(tokens * channels, feat_dim), nn.BatchNorm1d(feat_dim)).to(dev)
         else:
-            raise NotImplementedError(f"backbone '{model_name}': the HIP engines cover {sorted(vit.TIMM_VITS)} and {sorted(convnext.TIMM_CONVNEXTS)}")
+            # (timm's Swin returns an NHWC map for global_pool='': the reference's wrapper then reads [B, 7, 7, C] as [B, C = 7, H = 7, W = C] and builds BatchNorm2d(7) +
+            #  Linear(49 C, feat_dim) -- timm_wrapper.py:28-37; the Swin classifier is built (visiondk_amd/swin.py), this neck over a 7-"channel" map is not)
+            raise NotImplementedError(f"backbone '{model_name}' for the face / CBIR neck: the HIP engines cover {sorted(vit.TIMM_VITS)} and {sorted(convnext.TIMM_CONVNEXTS)}; "
+                                      "Swin is built as a classifier (visiondk_amd.swin)")
 
     @torch.no_grad()
     def forward_precise(self, x):
@@ -371,7 +374,9 @@ class VisionWrapper:
                 raise NotImplementedError(f"model.{opt}=True is not built on the HIP engines (it raises AttributeError in the reference as well)")
         arch = name[5:].split(".")[0]
         # timm-resnet18 | timm-convnext_* (pet.yaml:21-22) | timm-vit_*
-        factory = resnet.create_model if arch in resnet.TIMM_RESNETS else (convnext.create_model if arch in convnext.TIMM_CONVNEXTS else vit.create_model)
+        from . import swin
+        factory = (resnet.create_model if arch in resnet.TIMM_RESNETS else convnext.create_model if arch in convnext.TIMM_CONVNEXTS else
+                   swin.create_model if arch in swin.TIMM_SWINS else vit.create_model)      # timm-swin_base_patch4_window7_224 is pet.yaml:25's default
         self.model = factory(arch, pretrained=False, num_classes=model_cfg["num_classes"], img_size=model_cfg.get("image_size") or 224, device=device,
                              backend=backend, **kwargs)
         if not model_cfg.get("pretrained", False):

@@ -1,0 +1,406 @@
+"""Swin Transformer (timm `swin_*_patch4_window7_224`) on the HIP kernels -- the DEFAULT backbone of both shipped configs of the reference
+(`timm-swin_base_patch4_window7_224`: configs/classification/pet.yaml:25, configs/faceX/cbir.yaml:26; built by `timm.create_model` in
+models/classifier/classify_model.py:49-54 and models/faceX/backbone/timm_wrapper.py:16-21).
+
+`create_model(name, num_classes=C)` mirrors the timm factory call; the module has timm's state_dict names (oracle/swin_ref.py restates the architecture and is pinned
+against transformers.SwinModel), so reference checkpoints load.  First form of this family here: the model is a torch Module whose arithmetic runs in autograd nodes over
+the library's kernels -- LayerNorm (`vdk_layernorm_fwd/bwd`), every Linear on the bf16 MFMA GEMM with its bias / GELU / residual epilogues (`vdk_gemm_bf16_nt`, weight
+gradients in the TN form), the 49-token window attention with relative-position bias and shifted-window masks (`vdk_window_attention_fwd/bwd`), the pooled head on the fp32
+MFMA.  Window partition, cyclic shift and patch merging are index permutations (views / copies, no arithmetic).  Arithmetic = the reference's autocast path: bf16 operands,
+fp32 accumulation, fp32 residual stream and master weights.  A native one-call engine like the ViT's (flat parameter space, fused optimizer) is the next step for this family.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from ._abi import ACT_DGELU, ACT_GELU, ACT_NONE
+
+WS = 7
+N = WS * WS
+
+
+@dataclass(frozen=True)
+class SwinSpec:
+    img_size: int = 224
+    in_chans: int = 3
+    num_classes: int = 1000
+    embed_dim: int = 128
+    depths: Sequence[int] = (2, 2, 18, 2)
+    heads: Sequence[int] = (4, 8, 16, 32)
+    ln_eps: float = 1e-5
+
+
+TIMM_SWINS = {
+    "swin_tiny_patch4_window7_224": dict(embed_dim=96, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24)),
+    "swin_small_patch4_window7_224": dict(embed_dim=96, depths=(2, 2, 18, 2), heads=(3, 6, 12, 24)),
+    "swin_base_patch4_window7_224": dict(embed_dim=128, depths=(2, 2, 18, 2), heads=(4, 8, 16, 32)),
+    "swin_large_patch4_window7_224": dict(embed_dim=192, depths=(2, 2, 18, 2), heads=(6, 12, 24, 48)),
+}
+
+
+# ---- index helpers (no arithmetic) ------------------------------------------------------------------------------------------------------------
+def _partition(x: torch.Tensor, ws: int) -> torch.Tensor:          # [B, H, W, C] -> [B * nW * ws * ws, C]
+    B, H, W, Cc = x.shape
+    return x.view(B, H // ws, ws, W // ws, ws, Cc).permute(0, 1, 3, 2, 4, 5).reshape(-1, Cc)
+
+
+def _reverse(w: torch.Tensor, ws: int, B: int, H: int, W: int) -> torch.Tensor:
+    Cc = w.shape[-1]
+    return w.view(B, H // ws, W // ws, ws, ws, Cc).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, Cc)
+
+
+def _rel_index(ws: int) -> torch.Tensor:
+    coords = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1)
+
+
+def _shift_mask(H: int, W: int, ws: int, shift: int) -> torch.Tensor:
+    img = torch.zeros(1, H, W, 1)
+    cnt = 0
+    for h in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+        for w in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            img[:, h, w, :] = cnt
+            cnt += 1
+    mw = _partition(img, ws).view(-1, ws * ws)
+    m = mw[:, None, :] - mw[:, :, None]
+    return m.masked_fill(m != 0, -100.0).masked_fill(m == 0, 0.0).contiguous()
+
+
+def _wgrad(be, dyb: torch.Tensor, xb: torch.Tensor) -> torch.Tensor:
+    """dW f32 [N, K] = dY^T X for bf16 dY [T, N], X [T, K]: the TN GEMM straight from both tensors when T % 64 == 0, else through zero-padded transposes"""
+    T, Nn = dyb.shape
+    K = xb.shape[1]
+    if T % 64 == 0 and Nn % 8 == 0 and K % 8 == 0:
+        tiles = ((Nn + 255) // 256) * ((K + 255) // 256)
+        sk = max(1, min(256 // tiles, (T // 64) // 4, 64))
+        return ops.gemm_nt(dyb, xb, out_dtype=torch.float32, trans=True, splitk=sk, backend=be)
+    dyt = ops.transpose_pad(dyb, backend=be)                    # [N, Tp]
+    xt = ops.transpose_pad(xb, backend=be)                      # [K, Tp]
+    return ops.gemm_nt(dyt, xt, out_dtype=torch.float32, backend=be)
+
+
+def _bf(be, t: torch.Tensor) -> torch.Tensor:
+    return t if t.dtype == torch.bfloat16 else ops.cast_bf16(t.contiguous(), backend=be)
+
+
+# ---- autograd nodes over the kernels ----------------------------------------------------------------------------------------------------------
+class _LN(torch.autograd.Function):
+    """LayerNorm over the last dimension of f32 rows -> bf16 (a GEMM operand) or f32 (the residual stream)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, out_dtype, be):
+        x2 = x.contiguous().view(-1, w.numel())
+        y, mean, rstd = ops.layernorm_fwd(x2, w.detach(), b.detach(), eps, out_dtype, backend=be)
+        ctx.save_for_backward(x2, mean, rstd, w)
+        ctx.be, ctx.shape = be, x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd, w = ctx.saved_tensors
+        dy2 = dy.contiguous().view(x2.shape)
+        dx, _, dg, db = ops.layernorm_bwd(dy2, x2, mean, rstd, w.detach(), want_bf16=False, backend=ctx.be)
+        return dx.view(ctx.shape), dg, db, None, None, None
+
+
+class _Lin(torch.autograd.Function):
+    """y = x W^T (+ b) (+ residual): bf16 operands on the MFMA GEMM; y bf16, or f32 when it joins the residual stream"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, residual, out_dtype, be):
+        xb = _bf(be, x.contiguous().view(-1, x.shape[-1]))
+        wb = ops.cast_bf16(w.detach().contiguous(), backend=be)
+        res = residual.contiguous().view(-1, w.shape[0]) if residual is not None else None
+        y = ops.gemm_nt(xb, wb, out_dtype=out_dtype, bias=b.detach() if b is not None else None, residual=res, backend=be)
+        ctx.save_for_backward(xb, w)
+        ctx.be, ctx.has_b, ctx.has_r, ctx.xshape, ctx.xdtype = be, b is not None, residual is not None, x.shape, x.dtype
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, w = ctx.saved_tensors
+        be = ctx.be
+        dy2 = dy.contiguous().view(-1, w.shape[0])
+        dyb = _bf(be, dy2)
+        wt = ops.transpose_cast(w.detach().contiguous(), backend=be)        # bf16 [in, out]: B operand of dX = dY W
+        dx = ops.gemm_nt(dyb, wt[:, :w.shape[0]] if wt.shape[1] != w.shape[0] else wt, out_dtype=torch.bfloat16 if ctx.xdtype == torch.bfloat16 else torch.float32, backend=be)
+        dw = _wgrad(be, dyb, xb)
+        db = ops.colsum_bf16(dyb, backend=be) if ctx.has_b else None
+        dres = dy if ctx.has_r else None
+        return dx.view(ctx.xshape), dw, db, dres, None, None
+
+
+class _Mlp(torch.autograd.Function):
+    """x + fc2(gelu(fc1(h))): fc1 with the GELU epilogue (pre-activation kept), fc2 with the residual epilogue; backward with the dGELU epilogue on the fc2 input-gradient GEMM"""
+
+    @staticmethod
+    def forward(ctx, h, w1, b1, w2, b2, x, be):
+        hb = h.contiguous().view(-1, h.shape[-1])
+        w1b = ops.cast_bf16(w1.detach().contiguous(), backend=be); w2b = ops.cast_bf16(w2.detach().contiguous(), backend=be)
+        u = torch.empty((hb.shape[0], w1.shape[0]), dtype=torch.bfloat16, device=h.device)
+        g = ops.gemm_nt(hb, w1b, bias=b1.detach(), act=ACT_GELU, aux=u, backend=be)
+        y = ops.gemm_nt(g, w2b, out_dtype=torch.float32, bias=b2.detach(), residual=x.contiguous().view(-1, w2.shape[0]), backend=be)
+        ctx.save_for_backward(hb, u, g, w1, w2)
+        ctx.be, ctx.shape = be, x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        hb, u, g, w1, w2 = ctx.saved_tensors
+        be = ctx.be
+        dy2 = dy.contiguous().view(-1, w2.shape[0])
+        dyb = ops.cast_bf16(dy2, backend=be)
+        w2t = ops.transpose_cast(w2.detach().contiguous(), backend=be)       # [4C, C]
+        du = ops.gemm_nt(dyb, w2t, act=ACT_DGELU, aux=u, backend=be)
+        dw2 = _wgrad(be, dyb, g); db2 = ops.colsum_bf16(dyb, backend=be)
+        w1t = ops.transpose_cast(w1.detach().contiguous(), backend=be)       # [C, 4C]
+        dh = ops.gemm_nt(du, w1t, backend=be)
+        dw1 = _wgrad(be, du, hb); db1 = ops.colsum_bf16(du, backend=be)
+        return dh.view(*ctx.shape[:-1], w1.shape[1]), dw1, db1, dw2, db2, dy, None
+
+
+class _WinAttn(torch.autograd.Function):
+    """the attention step of timm's WindowAttention on bf16 qkv rows in (window, token) order"""
+
+    @staticmethod
+    def forward(ctx, qkv, bias, mask, heads, be):
+        T, C3 = qkv.shape
+        Cc = C3 // 3
+        windows = T // N
+        o = torch.empty((T, Cc), dtype=torch.bfloat16, device=qkv.device)
+        lse = torch.empty((windows, heads, N), dtype=torch.float32, device=qkv.device)
+        biasc = bias.detach().contiguous()
+        scale = (Cc // heads) ** -0.5
+        be.check(be.lib.vdk_window_attention_fwd(be.ptr(qkv), C3, be.ptr(o), Cc, be.ptr(lse), be.ptr(biasc), be.ptr(mask), 0 if mask is None else mask.shape[0], windows, heads, N,
+                                                 Cc // heads, scale, be.stream()), "vdk_window_attention_fwd")
+        ctx.save_for_backward(qkv, o, lse, biasc)
+        ctx.mask, ctx.heads, ctx.be, ctx.scale = mask, heads, be, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse, biasc = ctx.saved_tensors
+        be, heads, mask = ctx.be, ctx.heads, ctx.mask
+        T, C3 = qkv.shape
+        Cc = C3 // 3
+        windows = T // N
+        do = _bf(be, do.contiguous())
+        dqkv = torch.empty_like(qkv)
+        dbias = torch.empty((heads, N, N), dtype=torch.float32, device=qkv.device)
+        need = C.c_size_t(0)
+        be.check(be.lib.vdk_window_attention_bwd_workspace_bytes(windows, heads, C.byref(need)), "vdk_window_attention_bwd_workspace_bytes")
+        ws = torch.empty(need.value, dtype=torch.uint8, device=qkv.device)
+        be.check(be.lib.vdk_window_attention_bwd(be.ptr(qkv), C3, be.ptr(o), be.ptr(do), Cc, be.ptr(lse), be.ptr(biasc), be.ptr(mask), 0 if mask is None else mask.shape[0],
+                                                 windows, heads, N, Cc // heads, ctx.scale, be.ptr(dqkv), C3, be.ptr(dbias), be.ptr(ws), ws.numel(), be.stream()),
+                 "vdk_window_attention_bwd")
+        return dqkv, dbias, None, None, None
+
+
+class _BiasGather(torch.autograd.Function):
+    """relative_position_bias_table [169, H] -> bias [H, 49, 49] (an index gather); the backward sums each table entry's <= 49 uses with the row-reduction kernel in a
+    fixed order (an index_add would use atomics)"""
+
+    @staticmethod
+    def forward(ctx, table, index, uses, be):
+        ctx.be, ctx.uses, ctx.shape = be, uses, table.shape
+        return table.detach()[index.view(-1)].view(N, N, -1).permute(2, 0, 1).contiguous()
+
+    @staticmethod
+    def backward(ctx, dbias):
+        H = dbias.shape[0]
+        flat = torch.cat([dbias.reshape(H, N * N), torch.zeros((H, 1), dtype=dbias.dtype, device=dbias.device)], 1)      # slot N*N = 0 for the padding of `uses`
+        g = flat[:, ctx.uses]                                   # [H, 169, 49]: the uses of every table entry
+        g = g.permute(2, 1, 0).contiguous().view(N, -1)         # [49, 169 * H]
+        return ops.reduce_rows(g, backend=ctx.be).view(ctx.shape), None, None, None
+
+
+class _Pool(torch.autograd.Function):
+    """global average pool over the tokens of f32 NHWC rows"""
+
+    @staticmethod
+    def forward(ctx, x, be):
+        B, H, W, Cc = x.shape
+        out = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+        be.check(be.lib.vdk_avgpool_rows_f32_fwd(be.ptr(x.contiguous()), be.ptr(out), B, H * W, Cc, be.stream()), "vdk_avgpool_rows_f32_fwd")
+        ctx.be, ctx.shape = be, x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, Cc = ctx.shape
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dy.device)
+        ctx.be.check(ctx.be.lib.vdk_avgpool_rows_f32_bwd(ctx.be.ptr(dy.contiguous()), ctx.be.ptr(dx), None, B, H * W, Cc, ctx.be.stream()), "vdk_avgpool_rows_f32_bwd")
+        return dx, None
+
+
+# ---- modules with timm's names -------------------------------------------------------------------------------------------------------------------
+class _Holder(nn.Module):
+    pass
+
+
+class WindowAttention(nn.Module):
+    def __init__(self, dim: int, heads: int, be, dev):
+        super().__init__()
+        self.heads, self.be = heads, be
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * WS - 1) ** 2, heads, device=dev))
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
+        idx = _rel_index(WS)
+        self.register_buffer("relative_position_index", idx.to(dev), persistent=False)
+        uses = torch.full(((2 * WS - 1) ** 2, N), N * N, dtype=torch.long)          # for the gather's backward: where each table entry is used (padded with the zero slot)
+        flat = idx.view(-1)
+        for r in range((2 * WS - 1) ** 2):
+            pos = (flat == r).nonzero().view(-1)
+            uses[r, :pos.numel()] = pos
+        self.register_buffer("_uses", uses.to(dev), persistent=False)
+        self.qkv = nn.Linear(dim, 3 * dim, device=dev)
+        self.proj = nn.Linear(dim, dim, device=dev)
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim: int, dev):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, 4 * dim, device=dev)
+        self.fc2 = nn.Linear(4 * dim, dim, device=dev)
+
+
+class SwinBlock(nn.Module):
+    def __init__(self, dim: int, res: int, heads: int, shift: int, eps: float, be, dev):
+        super().__init__()
+        if res < WS or res % WS:
+            raise ValueError("feature maps must be multiples of the 7 x 7 window (img_size % 224 == 0 for the patch4_window7 family)")
+        if res == WS:
+            shift = 0
+        self.res, self.shift, self.eps, self.be, self.heads = res, shift, eps, be, heads
+        self.norm1 = nn.LayerNorm(dim, eps=eps, device=dev)
+        self.attn = WindowAttention(dim, heads, be, dev)
+        self.norm2 = nn.LayerNorm(dim, eps=eps, device=dev)
+        self.mlp = Mlp(dim, dev)
+        self.register_buffer("attn_mask", _shift_mask(res, res, WS, shift).to(dev) if shift else None, persistent=False)
+
+    def forward(self, x):                                       # f32 [B, H, W, C]
+        B, H, W, Cc = x.shape
+        be, a = self.be, self.attn
+        h = _LN.apply(x, self.norm1.weight, self.norm1.bias, self.eps, torch.bfloat16, be)
+        xs = x
+        if self.shift:
+            h = torch.roll(h, (-self.shift, -self.shift), (1, 2)); xs = torch.roll(x, (-self.shift, -self.shift), (1, 2))
+        hw = _partition(h, WS); xw = _partition(xs, WS)            # rows in (window, token) order
+        qkv = _Lin.apply(hw, a.qkv.weight, a.qkv.bias, None, torch.bfloat16, be)
+        bias = _BiasGather.apply(a.relative_position_bias_table, a.relative_position_index, a._uses, be)
+        o = _WinAttn.apply(qkv, bias, self.attn_mask, self.heads, be)
+        y = _Lin.apply(o, a.proj.weight, a.proj.bias, xw, torch.float32, be)          # shortcut added in the GEMM epilogue (window order)
+        y = _reverse(y, WS, B, H, W)
+        if self.shift:
+            y = torch.roll(y, (self.shift, self.shift), (1, 2))
+        h2 = _LN.apply(y, self.norm2.weight, self.norm2.bias, self.eps, torch.bfloat16, be)
+        return _Mlp.apply(h2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, y, be)
+
+
+class PatchMerging(nn.Module):
+    def __init__(self, dim: int, eps: float, be, dev):
+        super().__init__()
+        self.eps, self.be = eps, be
+        self.norm = nn.LayerNorm(4 * dim, eps=eps, device=dev)
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False, device=dev)
+
+    def forward(self, x):
+        B, H, W, Cc = x.shape
+        x = x.reshape(B, H // 2, 2, W // 2, 2, Cc).permute(0, 1, 3, 4, 2, 5).flatten(3)
+        h = _LN.apply(x, self.norm.weight, self.norm.bias, self.eps, torch.bfloat16, self.be)
+        return _Lin.apply(h, self.reduction.weight, None, None, torch.float32, self.be)
+
+
+class SwinStage(nn.Module):
+    def __init__(self, dim_in: int, dim: int, res: int, depth: int, heads: int, downsample: bool, eps: float, be, dev):
+        super().__init__()
+        self.downsample = PatchMerging(dim_in, eps, be, dev) if downsample else nn.Identity()
+        self.blocks = nn.Sequential(*[SwinBlock(dim, res, heads, 0 if j % 2 == 0 else WS // 2, eps, be, dev) for j in range(depth)])
+
+    def forward(self, x):
+        return self.blocks(self.downsample(x))
+
+
+class SwinTransformer(nn.Module):
+    """drop-in for timm.create_model('swin_*_patch4_window7_224', num_classes=C): forward(x [B, 3, 224, 224]) -> logits [B, C]; num_classes = 0: forward_features, the normed
+    NHWC map [B, 7, 7, C_last] (timm's global_pool='' feature output of this family is NHWC)"""
+
+    def __init__(self, spec: SwinSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None):
+        super().__init__()
+        self.spec = spec
+        self.be = backend or _lib.load()
+        dev = device if device is not None else ("cuda" if self.be.device_only else "cpu")
+        if spec.img_size % 224:
+            raise ValueError("the patch4_window7 family needs img_size % 224 == 0 (56 x 56 ... 7 x 7 maps of 7 x 7 windows)")
+        if seed is not None:
+            torch.manual_seed(seed)
+        self.num_classes = spec.num_classes
+        self.patch_embed = _Holder()
+        self.patch_embed.proj = nn.Conv2d(spec.in_chans, spec.embed_dim, 4, 4, device=dev)
+        self.patch_embed.norm = nn.LayerNorm(spec.embed_dim, eps=spec.ln_eps, device=dev)
+        res = spec.img_size // 4
+        layers, dim_in = [], spec.embed_dim
+        for i, (d, h) in enumerate(zip(spec.depths, spec.heads)):
+            dim = spec.embed_dim * 2 ** i
+            if dim // h != 32:
+                raise ValueError("window attention kernels are built for head dim 32 (every timm swin_*_window7_224)")
+            if i > 0:
+                res //= 2
+            layers.append(SwinStage(dim_in, dim, res, d, h, i > 0, spec.ln_eps, self.be, dev))
+            dim_in = dim
+        self.layers = nn.Sequential(*layers)
+        self.norm = nn.LayerNorm(dim_in, eps=spec.ln_eps, device=dev)
+        self.num_features = dim_in
+        self.head = _Holder()
+        self.head.fc = nn.Linear(dim_in, spec.num_classes, device=dev) if spec.num_classes > 0 else nn.Identity()
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        """the reference's override after timm's init (classify_model.py:70-81): N(0, 0.02) for every Conv2d / Linear weight, zeros for Linear bias"""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, mean=0, std=0.02)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, mean=0, std=0.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def forward_features(self, x: torch.Tensor) -> torch.Tensor:
+        s, be = self.spec, self.be
+        if x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (s.in_chans, s.img_size, s.img_size):
+            raise ValueError(f"expected float32 [B, {s.in_chans}, {s.img_size}, {s.img_size}], got {tuple(x.shape)} {x.dtype}")
+        B = x.shape[0]
+        g = s.img_size // 4
+        # 4 x 4 / stride 4 convolution = a Linear over (c, ky, kx) patches (the patch operand is an index permutation of the image)
+        pt = x.reshape(B, s.in_chans, g, 4, g, 4).permute(0, 2, 4, 1, 3, 5).reshape(B * g * g, s.in_chans * 16)
+        pe = self.patch_embed
+        y = _Lin.apply(pt, pe.proj.weight.view(s.embed_dim, -1), pe.proj.bias, None, torch.float32, be)
+        y = _LN.apply(y.view(B, g, g, s.embed_dim), pe.norm.weight, pe.norm.bias, s.ln_eps, torch.float32, be)
+        y = self.layers(y)
+        return _LN.apply(y, self.norm.weight, self.norm.bias, s.ln_eps, torch.float32, be)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        f = self.forward_features(x)
+        if self.num_classes == 0:
+            return f
+        from .vit import _LinearFn
+        return _LinearFn.apply(_Pool.apply(f, self.be), self.head.fc.weight, self.head.fc.bias, self.be)
+
+
+def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, img_size: int = 224, device=None, backend=None, seed: Optional[int] = None, **kw) -> SwinTransformer:
+    """timm.create_model(name, pretrained=..., num_classes=...) for the swin_*_patch4_window7_224 family (models/classifier/classify_model.py:49-54)"""
+    name = name[5:] if name.startswith("timm-") else name
+    if name not in TIMM_SWINS:
+        raise KeyError(f"unknown Swin id {name!r}: {sorted(TIMM_SWINS)}")
+    if pretrained:
+        raise RuntimeError("there is no network here: load a checkpoint with load_state_dict (timm names)")
+    return SwinTransformer(SwinSpec(img_size=img_size, num_classes=num_classes, **TIMM_SWINS[name]), device=device, backend=backend, seed=seed)
