@@ -99,27 +99,31 @@ __global__ __launch_bounds__(256) void window_attn_fwd_kernel(const bf16_t* __re
   }
 }
 
-// one wave walks the windows win = slot, slot + nslot, ... of ONE head (h = wave index mod H); dbias_part: f32 [gridDim.x * 4][N * N] (rows of head h: wave ids = h mod H)
-__global__ __launch_bounds__(256) void window_attn_bwd_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, long ldo,
-                                                              const float* __restrict__ lse, const float* __restrict__ bias, const float* __restrict__ mask, int nW,
-                                                              long nwin, int H, float scale, bf16_t* __restrict__ dqkv, long ldd, float* __restrict__ dbias_part) {
-  __shared__ __attribute__((aligned(16))) float Ks[4][WA_N * WA_HD];      // K rows, later Q rows
-  __shared__ __attribute__((aligned(16))) float Vs[4][WA_N * WA_HD];      // V rows, later dO rows
-  __shared__ __attribute__((aligned(16))) bf16_t Ps[4][WA_N * 52];        // P  [query][key], row pitch 52
-  __shared__ __attribute__((aligned(16))) bf16_t Ds[4][WA_N * 52];        // dS [query][key]
+// one wave walks the windows win = slot, slot + nslot, ... of ONE head (h = wave index mod H); dbias_part: f32 [gridDim.x * 2][N * N] (rows of head h: wave ids = h mod H).
+// Two waves per workgroup (32 KB of LDS each: K / V rows, P and dS, the wave's running d(bias) sum); the j / i loops stay rolled -- fully unrolled (the first form: the
+// bias sums in 49 registers) the kernel needed 5.5 KB of scratch per lane and ran 20x slower than the forward.
+#define WA_BW 2
+__global__ __launch_bounds__(64 * WA_BW) void window_attn_bwd_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                                     long ldo, const float* __restrict__ lse, const float* __restrict__ bias, const float* __restrict__ mask,
+                                                                     int nW, long nwin, int H, float scale, bf16_t* __restrict__ dqkv, long ldd,
+                                                                     float* __restrict__ dbias_part) {
+  __shared__ __attribute__((aligned(16))) float Ks[WA_BW][WA_N * WA_HD];      // K rows, later Q rows
+  __shared__ __attribute__((aligned(16))) float Vs[WA_BW][WA_N * WA_HD];      // V rows, later dO rows
+  __shared__ __attribute__((aligned(16))) bf16_t Ps[WA_BW][WA_N * 52];        // P  [query][key], row pitch 52
+  __shared__ __attribute__((aligned(16))) bf16_t Ds[WA_BW][WA_N * 52];        // dS [query][key]
+  __shared__ float Bs[WA_BW][WA_N * WA_N];                                    // this wave's sum of dS over its windows: lane i owns row i (pitch 49: conflict-free)
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int C = H * WA_HD;
   const bool row = lane < WA_N;
-  const long wid = (long)blockIdx.x * 4 + w, nwave = (long)gridDim.x * 4;
+  const long wid = (long)blockIdx.x * WA_BW + w, nwave = (long)gridDim.x * WA_BW;
   const int h = (int)(wid % H);
-  const long slot = wid / H, nslot = nwave / H;            // (the launcher makes gridDim.x * 4 a multiple of H)
-  float db[WA_N];
-#pragma unroll
-  for (int j = 0; j < WA_N; ++j) db[j] = 0.f;
-  const float* brow = bias + ((long)h * WA_N + (row ? lane : 0)) * WA_N;
+  const long slot = wid / H, nslot = nwave / H;            // (the launcher makes the wave count a multiple of H)
+  const int li = row ? lane : 0;
+  if (row) for (int j = 0; j < WA_N; ++j) Bs[w][lane * WA_N + j] = 0.f;
+  const float* brow = bias + ((long)h * WA_N + li) * WA_N;
   for (long win = slot; win < nwin; win += nslot) {
-    const long r0 = win * WA_N + (row ? lane : 0);
+    const long r0 = win * WA_N + li;
     const bf16_t* base = qkv + r0 * ld + h * WA_HD;
     float q[WA_HD], g[WA_HD], t[WA_HD];
     wa_load_row(base, q);
@@ -141,33 +145,33 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const bf16_t* __re
 #pragma unroll
     for (int d = 0; d < WA_HD; ++d) D = fmaf(g[d], t[d], D);
     VDK_WAVE_LDS_SYNC();
-    const float* mrow = mask ? mask + ((win % nW) * WA_N + (row ? lane : 0)) * WA_N : nullptr;
+    const float* mrow = mask ? mask + ((win % nW) * WA_N + li) * WA_N : nullptr;
     const float l = row ? lse[(win * H + h) * WA_N + lane] : 0.f;
     float dq[WA_HD];
 #pragma unroll
     for (int d = 0; d < WA_HD; ++d) dq[d] = 0.f;
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j < WA_N; ++j) {
       float a = 0.f, dp = 0.f;
+      f32x4 kv[WA_HD / 4];
 #pragma unroll
       for (int d = 0; d < WA_HD; d += 4) {
-        const f32x4 kv = *(const f32x4*)(&Ks[w][j * WA_HD + d]);
+        kv[d / 4] = *(const f32x4*)(&Ks[w][j * WA_HD + d]);
         const f32x4 vv = *(const f32x4*)(&Vs[w][j * WA_HD + d]);
-        a = fmaf(q[d], kv[0], a); a = fmaf(q[d + 1], kv[1], a); a = fmaf(q[d + 2], kv[2], a); a = fmaf(q[d + 3], kv[3], a);
+        a = fmaf(q[d], kv[d / 4][0], a); a = fmaf(q[d + 1], kv[d / 4][1], a); a = fmaf(q[d + 2], kv[d / 4][2], a); a = fmaf(q[d + 3], kv[d / 4][3], a);
         dp = fmaf(g[d], vv[0], dp); dp = fmaf(g[d + 1], vv[1], dp); dp = fmaf(g[d + 2], vv[2], dp); dp = fmaf(g[d + 3], vv[3], dp);
       }
       a = a * scale + brow[j];
       if (mrow) a += mrow[j];
       const float p = fast_exp2((a - l) * WA_LOG2E);
       const float ds = p * (dp - D);                       // d(loss)/dS: also the bias gradient of this (query, key)
-      db[j] += row ? ds : 0.f;
       const bf16_t pb = f2bf(p), dsb = f2bf(ds);            // the operands of dV = P^T dO and dQ / dK = dS K / dS^T Q
-      if (row) { Ps[w][lane * 52 + j] = pb; Ds[w][lane * 52 + j] = dsb; }
+      if (row) { Bs[w][lane * WA_N + j] += ds; Ps[w][lane * 52 + j] = pb; Ds[w][lane * 52 + j] = dsb; }
       const float dsr = bf2f(dsb);
 #pragma unroll
       for (int d = 0; d < WA_HD; d += 4) {
-        const f32x4 kv = *(const f32x4*)(&Ks[w][j * WA_HD + d]);
-        dq[d] = fmaf(dsr, kv[0], dq[d]); dq[d + 1] = fmaf(dsr, kv[1], dq[d + 1]); dq[d + 2] = fmaf(dsr, kv[2], dq[d + 2]); dq[d + 3] = fmaf(dsr, kv[3], dq[d + 3]);
+        dq[d] = fmaf(dsr, kv[d / 4][0], dq[d]); dq[d + 1] = fmaf(dsr, kv[d / 4][1], dq[d + 1]); dq[d + 2] = fmaf(dsr, kv[d / 4][2], dq[d + 2]);
+        dq[d + 3] = fmaf(dsr, kv[d / 4][3], dq[d + 3]);
       }
     }
     bf16_t* drow = dqkv + r0 * ldd + h * WA_HD;
@@ -190,10 +194,9 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const bf16_t* __re
     float dk[WA_HD], dv[WA_HD];
 #pragma unroll
     for (int d = 0; d < WA_HD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
-    const int jj = row ? lane : 0;
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < WA_N; ++i) {
-      const float p = bf2f(Ps[w][i * 52 + jj]), ds = bf2f(Ds[w][i * 52 + jj]);
+      const float p = bf2f(Ps[w][i * 52 + li]), ds = bf2f(Ds[w][i * 52 + li]);
 #pragma unroll
       for (int d = 0; d < WA_HD; d += 4) {
         const f32x4 qv = *(const f32x4*)(&Ks[w][i * WA_HD + d]);
@@ -212,10 +215,10 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const bf16_t* __re
       }
     }
   }
+  VDK_WAVE_LDS_SYNC();
   if (row) {
     float* dst = dbias_part + (wid * WA_N + lane) * WA_N;
-#pragma unroll
-    for (int j = 0; j < WA_N; ++j) dst[j] = db[j];
+    for (int j = 0; j < WA_N; ++j) dst[j] = Bs[w][lane * WA_N + j];
   }
 }
 
@@ -247,7 +250,7 @@ int vdk_window_attention_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, 
 int vdk_window_attention_bwd_workspace_bytes(int64_t windows, int32_t H, size_t* bytes) {
   if (!bytes || windows <= 0 || H <= 0) return vdk_fail(VDK_EINVAL, "vdk_window_attention_bwd_workspace_bytes: bad argument");
   long waves = 4096 / H * H; if (waves > windows * H) waves = windows * H; if (waves < H) waves = H;
-  waves = (waves + 4 * H - 1) / (4 * H) * (4 * H);           // whole workgroups, whole head groups
+  waves = (waves + WA_BW * H - 1) / (WA_BW * H) * (WA_BW * H);           // whole workgroups, whole head groups
   *bytes = (size_t)waves * WA_N * WA_N * 4;
   return VDK_OK;
 }
@@ -260,7 +263,7 @@ int vdk_window_attention_bwd(const void* qkv, int64_t ld, const void* o, const v
   size_t need = 0; vdk_window_attention_bwd_workspace_bytes(windows, H, &need);
   if (!ws || ws_bytes < need) return vdk_fail(VDK_EWORKSPACE, "vdk_window_attention_bwd: workspace too small");
   const long waves = (long)(need / ((size_t)WA_N * WA_N * 4));
-  hipLaunchKernelGGL(window_attn_bwd_kernel, dim3((unsigned)(waves / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld, (const bf16_t*)o, (const bf16_t*)dout,
+  hipLaunchKernelGGL(window_attn_bwd_kernel, dim3((unsigned)(waves / WA_BW)), dim3(64 * WA_BW), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld, (const bf16_t*)o, (const bf16_t*)dout,
                      (long)ldo, lse, bias, mask, (int)nW, (long)windows, (int)H, scale, (bf16_t*)dqkv, (long)ldd, (float*)ws);
   // partial row r belongs to head r mod H: a group of H consecutive rows IS one [H, N, N] tensor, and the sum over the groups (in group order) is d(bias)
   const long nn = (long)WA_N * WA_N;
