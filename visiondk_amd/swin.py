@@ -206,6 +206,20 @@ class _WinAttn(torch.autograd.Function):
         return dqkv, dbias, None, None, None
 
 
+class _Rows(torch.autograd.Function):
+    """y = x[perm] over the rows of a [T, C] tensor for a PERMUTATION perm (image order -> shifted window order in one gather instead of roll + partition copies);
+    backward gathers with the inverse permutation (no index_add: a permutation has no collisions)"""
+
+    @staticmethod
+    def forward(ctx, x, perm, inv):
+        ctx.inv = inv
+        return x.index_select(0, perm)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy.index_select(0, ctx.inv), None, None
+
+
 class _BiasGather(torch.autograd.Function):
     """relative_position_bias_table [169, H] -> bias [H, 49, 49] (an index gather); the backward sums each table entry's <= 49 uses with the row-reduction kernel in a
     fixed order (an index_add would use atomics)"""
@@ -286,22 +300,30 @@ class SwinBlock(nn.Module):
         self.norm2 = nn.LayerNorm(dim, eps=eps, device=dev)
         self.mlp = Mlp(dim, dev)
         self.register_buffer("attn_mask", _shift_mask(res, res, WS, shift).to(dev) if shift else None, persistent=False)
+        self._perm = {}
+
+    def _perms(self, B: int, dev):
+        """row permutation image order -> (cyclically shifted) window order for a batch of B maps, and its inverse"""
+        if B not in self._perm:
+            idx = torch.arange(B * self.res * self.res).view(B, self.res, self.res, 1)
+            if self.shift:
+                idx = torch.roll(idx, (-self.shift, -self.shift), (1, 2))
+            perm = _partition(idx, WS).view(-1)
+            inv = torch.empty_like(perm); inv[perm] = torch.arange(perm.numel())
+            self._perm = {B: (perm.to(dev), inv.to(dev))}
+        return self._perm[B]
 
     def forward(self, x):                                       # f32 [B, H, W, C]
         B, H, W, Cc = x.shape
         be, a = self.be, self.attn
+        perm, inv = self._perms(B, x.device)
         h = _LN.apply(x, self.norm1.weight, self.norm1.bias, self.eps, torch.bfloat16, be)
-        xs = x
-        if self.shift:
-            h = torch.roll(h, (-self.shift, -self.shift), (1, 2)); xs = torch.roll(x, (-self.shift, -self.shift), (1, 2))
-        hw = _partition(h, WS); xw = _partition(xs, WS)            # rows in (window, token) order
+        hw = _Rows.apply(h.view(-1, Cc), perm, inv); xw = _Rows.apply(x.reshape(-1, Cc), perm, inv)      # rows in (window, token) order
         qkv = _Lin.apply(hw, a.qkv.weight, a.qkv.bias, None, torch.bfloat16, be)
         bias = _BiasGather.apply(a.relative_position_bias_table, a.relative_position_index, a._uses, be)
         o = _WinAttn.apply(qkv, bias, self.attn_mask, self.heads, be)
         y = _Lin.apply(o, a.proj.weight, a.proj.bias, xw, torch.float32, be)          # shortcut added in the GEMM epilogue (window order)
-        y = _reverse(y, WS, B, H, W)
-        if self.shift:
-            y = torch.roll(y, (self.shift, self.shift), (1, 2))
+        y = _Rows.apply(y, inv, perm).view(B, H, W, Cc)                               # back to image order
         h2 = _LN.apply(y, self.norm2.weight, self.norm2.bias, self.eps, torch.bfloat16, be)
         return _Mlp.apply(h2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, y, be)
 
