@@ -234,6 +234,68 @@ def bench_cbir(dev, nq=10000, n=1_000_000, d=128, k=100, iters=6, with_cpu=True)
     return out
 
 
+def bench_cfg5(be, dev, batch: int = 128, steps: int = 3):
+    """BASELINE.json configs[4] (stretch) beside the headline: vit_large_patch14_siglip_336 (576 tokens, MAP head), per-GPU batch 128, a Mixup pair every step + SAM (two
+    forward-backward passes), bf16 operands and the engine's fp8 operand mode; and what fp8 costs in accuracy, measured live against the fp32 oracle on a 2-block ViT
+    whose branch weights are scaled 3x (tests/test_vit_fp8.py; the full-size figures of tests/test_parity_fullsize_gpu.py are quoted)."""
+    from oracle.vit_ref import VisionTransformerRef
+    from visiondk_amd import ops, vit
+    out = {"workload": f"cfg5: vit_large_patch14_siglip_336, per-GPU batch {batch}, Mixup pair + SAM (2 fwd/bwd per step), CE ls 0.05, SGD + EMA",
+           "dtype": "bf16 operands | fp8 (e4m3 forward, e5m2 gradients, delayed per-tensor scaling) in the forward / input-gradient GEMMs of the block Linears, bf16 weight gradients"}
+    # ---- tolerance: 2-block ViT, fp8 vs the fp32 oracle and vs the same engine with bf16 operands
+    torch.manual_seed(0)
+    ref = VisionTransformerRef(64, 8, 3, 10, 256, 2, 4, 512)
+    with torch.no_grad():
+        for blk in ref.blocks:
+            for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2):
+                lin.weight.mul_(3.0)
+    small = vit.VisionTransformer(vit.VitSpec(img_size=64, patch_size=8, num_classes=10, dim=256, depth=2, heads=4, mlp_dim=512), device=dev, backend=be, seed=1)
+    small.load_state_dict(ref.state_dict())
+    x = torch.randn(4, 3, 64, 64); y = torch.randint(0, 10, (4,))
+    lr = ref(x); torch.nn.functional.cross_entropy(lr, y).backward()
+    rel = lambda a, b: ((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm().clamp_min(1e-30)).item()
+
+    def fb():
+        for p_ in small.parameters():
+            p_.grad = None
+        lo = small(x.to(dev)); torch.nn.functional.cross_entropy(lo, y.to(dev)).backward()
+        return lo.detach().cpu(), {n: p_.grad.detach().cpu().clone() for n, p_ in small.named_parameters()}
+    l16, g16 = fb()
+    small.engine.enable_fp8(2)
+    l8, g8 = fb()
+    small.engine.enable_fp8(0)
+    out["fp8_tolerance"] = {"model": "2-block ViT (dim 256, 64 x 64 input, branch weights x 3), batch 4, forward + backward vs oracle/vit_ref.py (fp32)",
+                            "fp8_logits_rel": rel(l8, lr.detach()), "fp8_worst_grad_rel": max(rel(g8[n], p_.grad) for n, p_ in ref.named_parameters()),
+                            "bf16_logits_rel": rel(l16, lr.detach()), "bf16_worst_grad_rel": max(rel(g16[n], p_.grad) for n, p_ in ref.named_parameters()),
+                            "full_size_quoted": "vit_large_patch14_siglip_336, 2 images, every gradient vs the fp32 oracle (tests/test_parity_fullsize_gpu.py): bf16 logits 4.2e-3 / worst gradient 8.0e-3; fp8 logits 6.8e-2 / median gradient 7.6e-2 / worst 1.3e-1"}
+    del small, ref
+    # ---- throughput of the real model
+    model = vit.create_model("vit_large_patch14_siglip_336", num_classes=1000, device=dev)
+    ntok = model.engine.tokens
+    flop_img = 3 * 2 * (302.3e6 * ntok + 24 * 2 * ntok * ntok * 1024 + 2 * 1024 * 1024 * ntok)
+    xb = torch.randn(batch, 3, 336, 336, device=dev); ya = torch.randint(0, 1000, (batch,), device=dev)
+    perm = torch.randperm(batch, device=dev); yb = ya[perm].contiguous()
+    for fp8 in (0, 1):
+        model.engine.enable_fp8(fp8)
+        step = vit.MapTrainStep(model, lr=0.006, momentum=0.937, weight_decay=5e-4, label_smoothing=0.05, max_norm=10.0, ema=True, sam=True)
+
+        def one():
+            step.step(ops.mixup(xb, perm, 0.4), ya, yb, 0.4)
+        for _ in range(2):
+            one()
+        torch.cuda.synchronize(); t0 = time.time()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize(); dt = (time.time() - t0) / steps
+        key = "sam_fp8" if fp8 else "sam_bf16"
+        out[key] = {"images_per_sec": batch / dt, "ms_per_step": dt * 1e3, "model_tflops": flop_img * batch * 2 / dt / 1e12, "loss": step.loss_value()}
+        del step
+    model.engine.enable_fp8(0)
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def _sync(dev):
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
@@ -375,6 +437,7 @@ def main():
     ap.add_argument("--no-cbir", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-cfg5", action="store_true")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -438,6 +501,9 @@ def main():
             out["parity"] = parity
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_vit()
+        if world == 1 and not args.no_cfg5:
+            torch.cuda.empty_cache()
+            out["cfg5"] = bench_cfg5(be, dev)
         if world == 1 and not args.no_cbir:
             torch.cuda.empty_cache()
             out["cbir"] = bench_cbir(dev, with_cpu=not args.no_cpu_baseline)
