@@ -147,7 +147,20 @@ __device__ __forceinline__ float erf_as(float z, float& e) {
 // values (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) -- a wave that has its SIMD to itself issues one VALU instruction every ~5 cycles whatever the dependencies,
 // so the epilogues that evaluate these cost their instruction COUNT.  The scalar forms below evaluate the same operations in the same order (bit-identical).
 typedef float vdk_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ vdk_f32x2 vdk_fma2(vdk_f32x2 a, vdk_f32x2 b, vdk_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#ifdef VDK_GELU_SCALAR      /* A/B builds (with -fno-slp-vectorize): the same arithmetic on single-value instructions */
+struct vdk_f32x2s {
+  float v[2];
+  __device__ __forceinline__ float& operator[](int i) { return v[i]; }
+  __device__ __forceinline__ const float& operator[](int i) const { return v[i]; }
+};
+#endif
+__device__ __forceinline__ vdk_f32x2 vdk_fma2(vdk_f32x2 a, vdk_f32x2 b, vdk_f32x2 c) {
+#ifdef VDK_GELU_SCALAR
+  return (vdk_f32x2){__builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1])};
+#else
+  return __builtin_elementwise_fma(a, b, c);
+#endif
+}
 __device__ __forceinline__ void gelu_terms2(vdk_f32x2 x, vdk_f32x2& ax, vdk_f32x2& q, vdk_f32x2& e) {
   ax = (vdk_f32x2){__uint_as_float(__float_as_uint(x[0]) & 0x7fffffffu), __uint_as_float(__float_as_uint(x[1]) & 0x7fffffffu)};
   const vdk_f32x2 xx = x * x;
