@@ -147,52 +147,71 @@ __device__ __forceinline__ float erf_as(float z, float& e) {
 // values (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) -- a wave that has its SIMD to itself issues one VALU instruction every ~5 cycles whatever the dependencies,
 // so the epilogues that evaluate these cost their instruction COUNT.  The scalar forms below evaluate the same operations in the same order (bit-identical).
 typedef float vdk_f32x2 __attribute__((ext_vector_type(2)));
-#ifdef VDK_GELU_SCALAR      /* A/B builds (with -fno-slp-vectorize): the same arithmetic on single-value instructions */
-struct vdk_f32x2s {
-  float v[2];
-  __device__ __forceinline__ float& operator[](int i) { return v[i]; }
-  __device__ __forceinline__ const float& operator[](int i) const { return v[i]; }
-};
-#endif
-__device__ __forceinline__ vdk_f32x2 vdk_fma2(vdk_f32x2 a, vdk_f32x2 b, vdk_f32x2 c) {
-#ifdef VDK_GELU_SCALAR
-  return (vdk_f32x2){__builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1])};
-#else
-  return __builtin_elementwise_fma(a, b, c);
-#endif
-}
-__device__ __forceinline__ void gelu_terms2(vdk_f32x2 x, vdk_f32x2& ax, vdk_f32x2& q, vdk_f32x2& e) {
-  ax = (vdk_f32x2){__uint_as_float(__float_as_uint(x[0]) & 0x7fffffffu), __uint_as_float(__float_as_uint(x[1]) & 0x7fffffffu)};
-  const vdk_f32x2 xx = x * x;
-  const vdk_f32x2 ea = xx * -0.72134752044448170f;             // -log2(e) / 2
-  const vdk_f32x2 den = vdk_fma2(ax, (vdk_f32x2){0.23164188843369479f, 0.23164188843369479f}, (vdk_f32x2){1.0f, 1.0f});   // 0.3275911 / sqrt 2
-  e = (vdk_f32x2){fast_exp2(ea[0]), fast_exp2(ea[1])};
-  const vdk_f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-  vdk_f32x2 p = vdk_fma2(t, (vdk_f32x2){1.061405429f, 1.061405429f}, (vdk_f32x2){-1.453152027f, -1.453152027f});
-  p = vdk_fma2(p, t, (vdk_f32x2){1.421413741f, 1.421413741f});
-  p = vdk_fma2(p, t, (vdk_f32x2){-0.284496736f, -0.284496736f});
-  p = vdk_fma2(p, t, (vdk_f32x2){0.254829592f, 0.254829592f});
+// generic over T = vdk_f32x2 (packed instructions) or float; the per-component pieces (|x| as an AND, v_rcp, v_exp, max, copysign) are overloaded
+__device__ __forceinline__ vdk_f32x2 vdk_fma2(vdk_f32x2 a, vdk_f32x2 b, vdk_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float gx_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ vdk_f32x2 gx_fma(vdk_f32x2 a, vdk_f32x2 b, vdk_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float gx_abs(float x) { return __uint_as_float(__float_as_uint(x) & 0x7fffffffu); }
+__device__ __forceinline__ vdk_f32x2 gx_abs(vdk_f32x2 x) { return (vdk_f32x2){gx_abs(x[0]), gx_abs(x[1])}; }
+__device__ __forceinline__ float gx_exp2(float x) { return fast_exp2(x); }
+__device__ __forceinline__ vdk_f32x2 gx_exp2(vdk_f32x2 x) { return (vdk_f32x2){fast_exp2(x[0]), fast_exp2(x[1])}; }
+__device__ __forceinline__ float gx_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ vdk_f32x2 gx_rcp(vdk_f32x2 x) { return (vdk_f32x2){__builtin_amdgcn_rcpf(x[0]), __builtin_amdgcn_rcpf(x[1])}; }
+__device__ __forceinline__ float gx_max0(float x) { return fmaxf(x, 0.f); }
+__device__ __forceinline__ vdk_f32x2 gx_max0(vdk_f32x2 x) { return (vdk_f32x2){fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)}; }
+__device__ __forceinline__ float gx_copysign(float m, float s) { return copysignf(m, s); }
+__device__ __forceinline__ vdk_f32x2 gx_copysign(vdk_f32x2 m, vdk_f32x2 s) { return (vdk_f32x2){copysignf(m[0], s[0]), copysignf(m[1], s[1])}; }
+template <class T> __device__ __forceinline__ T gx_c(float c);
+template <> __device__ __forceinline__ float gx_c<float>(float c) { return c; }
+template <> __device__ __forceinline__ vdk_f32x2 gx_c<vdk_f32x2>(float c) { return (vdk_f32x2){c, c}; }
+template <class T>
+__device__ __forceinline__ void gelu_terms_t(T x, T& ax, T& q, T& e) {
+  ax = gx_abs(x);
+  const T xx = x * x;
+  const T ea = xx * gx_c<T>(-0.72134752044448170f);             // -log2(e) / 2
+  const T den = gx_fma(ax, gx_c<T>(0.23164188843369479f), gx_c<T>(1.0f));   // 0.3275911 / sqrt 2
+  e = gx_exp2(ea);
+  const T t = gx_rcp(den);
+  T p = gx_fma(t, gx_c<T>(1.061405429f), gx_c<T>(-1.453152027f));
+  p = gx_fma(p, t, gx_c<T>(1.421413741f));
+  p = gx_fma(p, t, gx_c<T>(-0.284496736f));
+  p = gx_fma(p, t, gx_c<T>(0.254829592f));
   q = (p * t) * e;
 }
-__device__ __forceinline__ vdk_f32x2 gelu_f2(vdk_f32x2 x) {
-  vdk_f32x2 ax, q, e;
-  gelu_terms2(x, ax, q, e);
-  return vdk_fma2(ax * -0.5f, q, (vdk_f32x2){fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)});
+template <class T> __device__ __forceinline__ T gelu_t(T x) {
+  T ax, q, e;
+  gelu_terms_t(x, ax, q, e);
+  return gx_fma(ax * gx_c<T>(-0.5f), q, gx_max0(x));
 }
-__device__ __forceinline__ vdk_f32x2 gelu_grad_f2(vdk_f32x2 x) {
-  vdk_f32x2 ax, q, e;
-  gelu_terms2(x, ax, q, e);
-  const vdk_f32x2 h = vdk_fma2(q, (vdk_f32x2){-0.5f, -0.5f}, (vdk_f32x2){0.5f, 0.5f});
-  const vdk_f32x2 cdf = (vdk_f32x2){copysignf(h[0], x[0]), copysignf(h[1], x[1])} + 0.5f;
-  return vdk_fma2(x * 0.3989422804014327f, e, cdf);
+template <class T> __device__ __forceinline__ T gelu_grad_t(T x) {
+  T ax, q, e;
+  gelu_terms_t(x, ax, q, e);
+  const T h = gx_fma(q, gx_c<T>(-0.5f), gx_c<T>(0.5f));
+  return gx_fma(x * gx_c<T>(0.3989422804014327f), e, gx_copysign(h, x) + gx_c<T>(0.5f));
 }
+template <class T> __device__ __forceinline__ void gelu_both_t(T x, T& g, T& d) {
+  T ax, q, e;
+  gelu_terms_t(x, ax, q, e);
+  g = gx_fma(ax * gx_c<T>(-0.5f), q, gx_max0(x));
+  const T h = gx_fma(q, gx_c<T>(-0.5f), gx_c<T>(0.5f));
+  d = gx_fma(x * gx_c<T>(0.3989422804014327f), e, gx_copysign(h, x) + gx_c<T>(0.5f));
+}
+// VDK_GELU_SCALAR (A/B builds, with -fno-slp-vectorize): the same arithmetic on single-value instructions -- bit-identical results.  Measured: single-value forms help the
+// 256x128 kernel, whose epilogue runs beside the other workgroup's MFMAs (dfc2 x GELU' 324 -> 314 us), and cost the 256x256 kernel (307 -> 317 us); a per-kernel choice
+// needs the file compiled without the SLP vectorizer, which put scratch into other variants for 0.04 ms of the step: not adopted (DESIGN_HISTORY.md)
+#ifdef VDK_GELU_SCALAR
+__device__ __forceinline__ vdk_f32x2 gelu_f2(vdk_f32x2 x) { return (vdk_f32x2){gelu_t<float>(x[0]), gelu_t<float>(x[1])}; }
+__device__ __forceinline__ vdk_f32x2 gelu_grad_f2(vdk_f32x2 x) { return (vdk_f32x2){gelu_grad_t<float>(x[0]), gelu_grad_t<float>(x[1])}; }
 __device__ __forceinline__ void gelu_both_f2(vdk_f32x2 x, vdk_f32x2& g, vdk_f32x2& d) {
-  vdk_f32x2 ax, q, e;
-  gelu_terms2(x, ax, q, e);
-  g = vdk_fma2(ax * -0.5f, q, (vdk_f32x2){fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)});
-  const vdk_f32x2 h = vdk_fma2(q, (vdk_f32x2){-0.5f, -0.5f}, (vdk_f32x2){0.5f, 0.5f});
-  d = vdk_fma2(x * 0.3989422804014327f, e, (vdk_f32x2){copysignf(h[0], x[0]), copysignf(h[1], x[1])} + 0.5f);
+  float g0, g1, d0, d1;
+  gelu_both_t<float>(x[0], g0, d0); gelu_both_t<float>(x[1], g1, d1);
+  g = (vdk_f32x2){g0, g1}; d = (vdk_f32x2){d0, d1};
 }
+#else
+__device__ __forceinline__ vdk_f32x2 gelu_f2(vdk_f32x2 x) { return gelu_t<vdk_f32x2>(x); }
+__device__ __forceinline__ vdk_f32x2 gelu_grad_f2(vdk_f32x2 x) { return gelu_grad_t<vdk_f32x2>(x); }
+__device__ __forceinline__ void gelu_both_f2(vdk_f32x2 x, vdk_f32x2& g, vdk_f32x2& d) { gelu_both_t<vdk_f32x2>(x, g, d); }
+#endif
 __device__ __forceinline__ float gelu_f(float x) { return gelu_f2((vdk_f32x2){x, x})[0]; }
 __device__ __forceinline__ float gelu_grad_f(float x) { return gelu_grad_f2((vdk_f32x2){x, x})[0]; }
 
