@@ -123,3 +123,46 @@ def test_swin_base_full_size_forward_backward_vs_oracle(hip):
     print(res)
     # 1.5x the measured 5.9e-3 / 1.1e-3 / 1.1e-2 (a relative_position_bias_table) / 5.6e-3
     assert res["logits"] < 9e-3 and res["loss"] < 1.7e-3 and res["worst_grad"][0] < 1.7e-2 and res["median_grad"][0] < 8.5e-3, res
+
+
+def test_face_model_with_the_default_backbone_of_cbir_yaml(be, dev):
+    """configs/faceX/cbir.yaml:26 `timm-swin_base_patch4_window7_224`: timm's Swin returns NHWC [B, 7, 7, C] for global_pool='' and the reference's TimmWrapper reads any
+    4-D output as [B, channels, h, w] (timm_wrapper.py:28-37): BatchNorm2d(7) over the row index, Flatten, Linear(49 C, feat_dim), BatchNorm1d.  The same module sequence in
+    torch on the oracle's map is the expectation: embedding and every gradient of backbone + neck."""
+    from visiondk_amd import face
+    swin.TIMM_SWINS["swin_test_patch4_window7_224"] = dict(embed_dim=32, depths=(1, 1, 1, 1), heads=(1, 2, 4, 8))
+    torch.manual_seed(0)
+    w = face.TimmWrapper("swin_test_patch4_window7_224", feat_dim=16, image_size=224, pretrained=False, backend=be, device=dev)
+    ref = SwinTransformerRef(img_size=224, num_classes=0, embed_dim=32, depths=(1, 1, 1, 1), heads=(1, 2, 4, 8))
+    C_last = 256
+    neck = torch.nn.Sequential(torch.nn.BatchNorm2d(7), torch.nn.Flatten(1), torch.nn.Linear(7 * 7 * C_last, 16), torch.nn.BatchNorm1d(16))
+    with torch.no_grad():
+        for n, p in list(ref.named_parameters()) + list(neck.named_parameters()):
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+            elif "relative_position_bias_table" in n:
+                p.copy_(torch.randn_like(p) * 0.3)
+            else:
+                p.copy_(torch.randn_like(p) * (0.7 / (p[0].numel() ** 0.5)))
+    w.model.load_state_dict(ref.state_dict(), strict=True)
+    w.output_layer.load_state_dict(neck.state_dict(), strict=True)
+    w.train(); ref.train(); neck.train()
+    x = torch.randn(4, 3, 224, 224)
+    emb = w(x.to(dev)); emb_r = neck(ref(x))          # ref(x): [B, 7, 7, C] NHWC, read by BatchNorm2d / Flatten as [B, 7, 7, C] "NCHW"
+    assert emb.shape == emb_r.shape == (4, 16)
+    assert _rel(emb, emb_r) < 3e-2
+    d = torch.randn(4, 16)
+    emb.backward(d.to(dev)); emb_r.backward(d)
+    got = dict(w.model.named_parameters()); got.update({"neck." + n: p for n, p in w.output_layer.named_parameters()})
+    exp = dict(ref.named_parameters()); exp.update({"neck." + n: p for n, p in neck.named_parameters()})
+    gmax = max(p.grad.norm().item() for p in exp.values())
+    errs = []
+    for n, p in exp.items():
+        if p.grad.norm().item() < 2e-3 * gmax:
+            # (nearly) invisible to the loss: a shift in front of a train-mode BatchNorm -- the neck's Linear bias exactly, the backbone's last norm.bias almost (BatchNorm2d over the
+            # row index removes the mean over (batch, column, CHANNEL)): what is left of these gradients is round-off
+            assert got[n].grad.norm().item() < 1e-2 * gmax, n
+            continue
+        errs.append((_rel(got[n].grad, p.grad), n))
+    errs.sort()
+    assert errs[-1][0] < 1.2e-1 and errs[len(errs) // 2][0] < 3e-2, (errs[-1], errs[len(errs) // 2])

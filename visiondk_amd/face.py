@@ -15,7 +15,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _abi, _lib, convnext, heads, ops, resnet, vit
+from . import _abi, _lib, convnext, heads, ops, resnet, swin, vit
 
 
 def _up(x, a):
@@ -210,11 +210,16 @@ class TimmWrapper(nn.Module):
             self.model = vit.create_model(model_name, pretrained=False, num_classes=0, global_pool="", img_size=image_size, device=dev, backend=self.be)
             tokens, channels = self.model.engine.tokens, self.model.spec.dim
             self.output_layer = nn.Sequential(nn.LayerNorm(channels), nn.Flatten(1), nn.Linear(tokens * channels, feat_dim), nn.BatchNorm1d(feat_dim)).to(dev)
+        elif model_name in swin.TIMM_SWINS:
+            # timm's Swin returns an NHWC map [B, 7, 7, C] for global_pool='', and the reference's wrapper reads ANY 4-D output as [B, channels, h, w]
+            # (timm_wrapper.py:28-37): with this backbone -- the default of cbir.yaml:26 -- its neck is BatchNorm2d(7) over the map's ROW index, Flatten, Linear(7 * 7 * C, feat_dim),
+            # BatchNorm1d.  Reproduced as it is: the NHWC tensor goes into the CNN neck as if it were NCHW.
+            self.model = swin.create_model(model_name, pretrained=False, num_classes=0, img_size=image_size, device=dev, backend=self.be)
+            self.is_cnn = True
+            hw, channels = image_size // 32, self.model.num_features
+            self.output_layer = nn.Sequential(nn.BatchNorm2d(hw), nn.Flatten(1), nn.Linear(hw * hw * channels, feat_dim), nn.BatchNorm1d(feat_dim)).to(dev)
         else:
-            # (timm's Swin returns an NHWC map for global_pool='': the reference's wrapper then reads [B, 7, 7, C] as [B, C = 7, H = 7, W = C] and builds BatchNorm2d(7) +
-            #  Linear(49 C, feat_dim) -- timm_wrapper.py:28-37; the Swin classifier is built (visiondk_amd/swin.py), this neck over a 7-"channel" map is not)
-            raise NotImplementedError(f"backbone '{model_name}' for the face / CBIR neck: the HIP engines cover {sorted(vit.TIMM_VITS)} and {sorted(convnext.TIMM_CONVNEXTS)}; "
-                                      "Swin is built as a classifier (visiondk_amd.swin)")
+            raise NotImplementedError(f"backbone '{model_name}': the HIP engines cover {sorted(vit.TIMM_VITS)}, {sorted(convnext.TIMM_CONVNEXTS)} and {sorted(swin.TIMM_SWINS)}")
 
     @torch.no_grad()
     def forward_precise(self, x):
@@ -374,7 +379,6 @@ class VisionWrapper:
                 raise NotImplementedError(f"model.{opt}=True is not built on the HIP engines (it raises AttributeError in the reference as well)")
         arch = name[5:].split(".")[0]
         # timm-resnet18 | timm-convnext_* (pet.yaml:21-22) | timm-vit_*
-        from . import swin
         factory = (resnet.create_model if arch in resnet.TIMM_RESNETS else convnext.create_model if arch in convnext.TIMM_CONVNEXTS else
                    swin.create_model if arch in swin.TIMM_SWINS else vit.create_model)      # timm-swin_base_patch4_window7_224 is pet.yaml:25's default
         self.model = factory(arch, pretrained=False, num_classes=model_cfg["num_classes"], img_size=model_cfg.get("image_size") or 224, device=device,
@@ -433,6 +437,9 @@ class FaceTrainStep:
         # all-reduce their batch statistics (forward) and gradient sums (backward) over comm's group
         self.bb.sync_group = comm.group if (sync_bn and comm is not None and comm.active) else False
         self.head = model.trainingwrapper["head"]
+        if not hasattr(self.bb.model, "engine"):
+            raise NotImplementedError("FaceTrainStep needs a backbone with a native engine (ViT, ConvNeXt); the Swin backbone trains through autograd under the reference's own "
+                                      "Trainer (torch optimizer over model.parameters())")
         self.eng = self.bb.model.engine
         self.be = self.eng.be
         self.lr, self.momentum, self.weight_decay, self.label_smoothing, self.max_norm = lr, momentum, weight_decay, label_smoothing, max_norm
