@@ -264,6 +264,8 @@ def test_gemm_w4_persistent_walk(be, dev, M, N, K, kern):
         torch.testing.assert_close(part.sum(0).cpu(), out.float().sum(0).cpu(), rtol=1e-4, atol=1e-3)
         out = ops.gemm_nt(a, b, out_dtype=torch.float32, bias=bias, residual=res, backend=be)              # fp32 + residual (slab form)
         assert _rel(out, ref + bias + res) < 1e-5
+        out = ops.gemm_nt(a, b, out_dtype=torch.float32, bias=bias, backend=be)                            # fp32 + bias without residual (ConvNeXt stem / downsample): row-staged form
+        assert _rel(out, ref + bias) < 1e-5
         out = ops.gemm_nt(a, b, out_dtype=torch.float32, alpha=0.5, backend=be)                            # run-time-flag form
         assert _rel(out, 0.5 * ref) < 1e-5
         assert be.lib.vdk_gemm_last_kernel() == kern

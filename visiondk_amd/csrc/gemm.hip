@@ -881,6 +881,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
     else if (plain_alpha && !rg && res && d->act == VDK_ACT_NONE && f32 && bias) E = E_BIAS | E_RES | E_F32;
     else if (plain_alpha && rg && res && d->act == VDK_ACT_NONE && f32 && bias) E = E_BIAS | E_RES | E_F32 | E_ROWGRP;
     else if (plain_alpha && !rg && !res && d->act == VDK_ACT_NONE && f32 && !bias) E = E_F32;
+    else if (plain_alpha && !rg && !res && d->act == VDK_ACT_NONE && f32 && bias) E = E_BIAS | E_F32;      // ConvNeXt's stem / downsample convolutions
   }
   dim3 grid256((unsigned)(((d->M + 255) / 256) * ((d->N + 255) / 256)), (unsigned)splitk);
   // stream-K when the caller lent a workspace (splitk == -1) and whole-tile rounds would leave the last one mostly empty (N = 768 at T = 50 432: 591 tiles = 2.31 rounds)
@@ -952,6 +953,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
       case E_DGELU | E_AUXD: LAUNCH256(false, E_DGELU | E_AUXD); break;
       case E_DGELU | E_OCS | E_AUXD: LAUNCH256(false, E_DGELU | E_OCS | E_AUXD); break;
       case E_BIAS | E_RES | E_F32: LAUNCH256(false, E_BIAS | E_RES | E_F32); break;
+      case E_BIAS | E_F32: LAUNCH256(false, E_BIAS | E_F32); break;
       case E_BIAS | E_RES | E_F32 | E_ROWGRP: LAUNCH256(false, E_BIAS | E_RES | E_F32 | E_ROWGRP); break;
       case E_SPLITK: LAUNCH256(false, E_SPLITK); break;
       case E_F32: LAUNCH256CS(E_F32); break;

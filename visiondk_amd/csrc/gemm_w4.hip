@@ -403,14 +403,15 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
         *(f32x4*)(dst + 4) = (f32x4){ocs[4], ocs[5], ocs[6], ocs[7]};
       }
     }
-  } else if constexpr (E == (E_BIAS | E_RES | E_F32)) {
+  } else if constexpr (E == (E_BIAS | E_RES | E_F32) || E == (E_BIAS | E_F32)) {
+    constexpr bool RES = (E & E_RES) != 0;                      // (E_BIAS | E_F32: the same row pass without the residual rows -- ConvNeXt's downsample / stem outputs)
     // fp32 output + fp32 residual (proj / fc2 into the residual stream): 32 x 64 fp32 blocks of the accumulators go through the staging
     // (16-byte chunk c of row r at position c ^ (r & 15)), and a row pass (4 rows x 256 B per instruction) adds the residual rows and stores -- buffer
     // descriptors again: no 64-bit address arithmetic, no branch, rows beyond M and columns beyond N fall out of range.
     float* const slab = (float*)stage;
     const int rrow = lane >> 4, rc = lane & 15;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((unsigned)p.M * (unsigned)p.ldc * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, (int)((unsigned)p.M * (unsigned)p.ldr * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(RES ? (void*)p.residual : p.C, 0, (int)((unsigned)p.M * (unsigned)(RES ? p.ldr : p.ldc) * 4u), 0x00020000);
     if constexpr (DEEP >= 0) W4_WAIT_VM(DEEP);
     if (p.dbg) ts[0] = __builtin_readcyclecounter();
     // Bias is added in the row pass (this lane: 4 columns of every row, one f32x4 per column pair) in the order (acc + bias) + residual of the other kernels; the
@@ -423,7 +424,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
       const int ncol = ncol0 + cp * 64 + rc * 4;
       const bool nok = ncol < p.N;
       lane_out[cp] = nok ? (unsigned)rrow * (unsigned)p.ldc * 4u + (unsigned)ncol * 4u : W4_OOB;
-      lane_res[cp] = nok ? (unsigned)rrow * (unsigned)p.ldr * 4u + (unsigned)ncol * 4u : W4_OOB;
+      lane_res[cp] = (RES && nok) ? (unsigned)rrow * (unsigned)p.ldr * 4u + (unsigned)ncol * 4u : W4_OOB;
       bias4[cp] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (nok) bias4[cp] = *(const f32x4*)(p.bias + ncol);
     }
@@ -434,16 +435,17 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
 #pragma unroll
       for (int ps = 0; ps < 8; ++ps) rn[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, lane_res[cp_], srow_r + (unsigned)(ps * 4) * (unsigned)p.ldr * 4u, 0);
     };
-    res_request(0);
+    if (RES) res_request(0);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const int cp = b >> 2, rt = b & 3;
       const unsigned srow_o = (unsigned)(mrow0 + rt * 32) * (unsigned)p.ldc * 4u;
-      if (!W4_EPI_AHEAD && b > 0) res_request(b);
+      if (RES && !W4_EPI_AHEAD && b > 0) res_request(b);
       f32x4 r[8];
 #pragma unroll
-      for (int ps = 0; ps < 8; ++ps) r[ps] = (f32x4){__uint_as_float(rn[ps][0]), __uint_as_float(rn[ps][1]), __uint_as_float(rn[ps][2]), __uint_as_float(rn[ps][3])};
-      if (W4_EPI_AHEAD && b + 1 < NB) res_request(b + 1);
+      for (int ps = 0; ps < 8; ++ps)
+        r[ps] = RES ? (f32x4){__uint_as_float(rn[ps][0]), __uint_as_float(rn[ps][1]), __uint_as_float(rn[ps][2]), __uint_as_float(rn[ps][3])} : (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (RES && W4_EPI_AHEAD && b + 1 < NB) res_request(b + 1);
 #pragma unroll
       for (int ctl = 0; ctl < 2; ++ctl)
 #pragma unroll
@@ -459,7 +461,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
         d[ps] = *(const f32x4*)(slab + row * 64 + ((rc ^ (row & 15)) << 2));
       }
 #pragma unroll
-      for (int ps = 0; ps < 8; ++ps) d[ps] = (d[ps] + bias4[cp]) + r[ps];
+      for (int ps = 0; ps < 8; ++ps) d[ps] = RES ? (d[ps] + bias4[cp]) + r[ps] : d[ps] + bias4[cp];
       // (everything that touches the row registers precedes the stores; row block in the vector offset: see the bf16 form above)
 #pragma unroll
       for (int ps = 0; ps < 8; ++ps) {
@@ -930,6 +932,7 @@ static bool w4_launch_one(const GemmParams& p, bool trans, int E, unsigned tiles
     case E_DGELU | E_AUXD: W4_LAUNCH(false, E_DGELU | E_AUXD);
     case E_DGELU | E_OCS | E_AUXD: W4_LAUNCH(false, E_DGELU | E_OCS | E_AUXD);
     case E_BIAS | E_RES | E_F32: W4_LAUNCH(false, E_BIAS | E_RES | E_F32);
+    case E_BIAS | E_F32: W4_LAUNCH(false, E_BIAS | E_F32);
     case E_BIAS | E_RES | E_F32 | E_ROWGRP: W4_LAUNCH(false, E_BIAS | E_RES | E_F32 | E_ROWGRP);
     case E_SPLITK: W4_LAUNCH(false, E_SPLITK);
     case E_F32: W4_LAUNCH(false, E_F32);
@@ -978,6 +981,7 @@ bool vdk_gemm_w4h_launch(const GemmParams& p_, bool trans, int E, unsigned split
     case E_DGELU | E_AUXD: W4H_LAUNCH(false, E_DGELU | E_AUXD);
     case E_DGELU | E_OCS | E_AUXD: W4H_LAUNCH(false, E_DGELU | E_OCS | E_AUXD);
     case E_BIAS | E_RES | E_F32: W4H_LAUNCH(false, E_BIAS | E_RES | E_F32);
+    case E_BIAS | E_F32: W4H_LAUNCH(false, E_BIAS | E_F32);
     case E_BIAS | E_RES | E_F32 | E_ROWGRP: W4H_LAUNCH(false, E_BIAS | E_RES | E_F32 | E_ROWGRP);
     case E_SPLITK: W4H_LAUNCH(false, E_SPLITK);
     case E_F32: W4H_LAUNCH(false, E_F32);
