@@ -166,3 +166,21 @@ def test_face_model_with_the_default_backbone_of_cbir_yaml(be, dev):
         errs.append((_rel(got[n].grad, p.grad), n))
     errs.sort()
     assert errs[-1][0] < 1.2e-1 and errs[len(errs) // 2][0] < 3e-2, (errs[-1], errs[len(errs) // 2])
+
+
+def test_get_model_builds_the_shipped_cbir_config_shape(be, dev):
+    """configs/faceX/cbir.yaml:26-35 as shipped (`timm-swin_base_patch4_window7_224.ms_in22k_ft_in1k`, feat_dim 128, ArcFace over 5000 identities) through get_model ->
+    FaceTrainingWrapper -> BackboneFactory -> TimmWrapper, with a small member of the family standing in for swin_base: logits [B, C], loss.backward() reaches every parameter"""
+    from visiondk_amd import face
+    swin.TIMM_SWINS["swin_test_patch4_window7_224"] = dict(embed_dim=32, depths=(1, 1, 1, 1), heads=(1, 2, 4, 8))
+    cfg = {"task": "cbir", "image_size": 224, "load_from": None,
+           "backbone": {"timm-swin_test_patch4_window7_224.ms_in22k_ft_in1k": {"pretrained": False, "image_size": 224, "feat_dim": 128}},
+           "head": {"arcface": {"feat_dim": 128, "num_class": 50, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
+    torch.manual_seed(0)
+    model = face.get_model(cfg, None, 0, backend=be, device=dev).model.train()
+    x = torch.randn(4, 3, 224, 224).to(dev); y = torch.randint(0, 50, (4,)).to(dev)
+    logits = model(x, y)
+    assert logits.shape == (4, 50)
+    torch.nn.functional.cross_entropy(logits, y).backward()
+    missing = [n for n, p in model.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+    assert not missing, missing
