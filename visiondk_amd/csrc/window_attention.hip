@@ -61,12 +61,14 @@ __global__ __launch_bounds__(256) void window_attn_fwd_kernel(const bf16_t* __re
     float mx = -3.0e38f;
 #pragma unroll
     for (int j = 0; j < WA_N; ++j) {
-      float a = 0.f;
+      vdk_f32x2 a2 = {0.f, 0.f};                           // two partial sums on packed FMAs (v_pk_fma_f32: the kernel is bound by its FMA count)
 #pragma unroll
       for (int d = 0; d < WA_HD; d += 4) {
         const f32x4 kv = *(const f32x4*)(&Ks[w][j * WA_HD + d]);
-        a = fmaf(q[d], kv[0], a); a = fmaf(q[d + 1], kv[1], a); a = fmaf(q[d + 2], kv[2], a); a = fmaf(q[d + 3], kv[3], a);
+        a2 = vdk_fma2((vdk_f32x2){q[d], q[d + 1]}, (vdk_f32x2){kv[0], kv[1]}, a2);
+        a2 = vdk_fma2((vdk_f32x2){q[d + 2], q[d + 3]}, (vdk_f32x2){kv[2], kv[3]}, a2);
       }
+      float a = a2[0] + a2[1];
       a = a * scale + brow[j];
       if (mrow) a += mrow[j];
       s[j] = a;
@@ -76,24 +78,26 @@ __global__ __launch_bounds__(256) void window_attn_fwd_kernel(const bf16_t* __re
 #pragma unroll
     for (int j = 0; j < WA_N; ++j) { s[j] = fast_exp2((s[j] - mx) * WA_LOG2E); sum += s[j]; }
     const float inv = 1.0f / sum;
-    float acc[WA_HD];
+    vdk_f32x2 acc2[WA_HD / 2];
 #pragma unroll
-    for (int d = 0; d < WA_HD; ++d) acc[d] = 0.f;
+    for (int d = 0; d < WA_HD / 2; ++d) acc2[d] = (vdk_f32x2){0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < WA_N; ++j) {
       const float p = bf2f(f2bf(s[j] * inv));              // P rounded once, as the left operand of P v
+      const vdk_f32x2 p2 = {p, p};
 #pragma unroll
       for (int d = 0; d < WA_HD; d += 4) {
         const f32x4 vv = *(const f32x4*)(&Vs[w][j * WA_HD + d]);
-        acc[d] = fmaf(p, vv[0], acc[d]); acc[d + 1] = fmaf(p, vv[1], acc[d + 1]); acc[d + 2] = fmaf(p, vv[2], acc[d + 2]); acc[d + 3] = fmaf(p, vv[3], acc[d + 3]);
+        acc2[d / 2] = vdk_fma2(p2, (vdk_f32x2){vv[0], vv[1]}, acc2[d / 2]);
+        acc2[d / 2 + 1] = vdk_fma2(p2, (vdk_f32x2){vv[2], vv[3]}, acc2[d / 2 + 1]);
       }
     }
     if (row) {
       bf16_t* orow = o + (win * WA_N + lane) * ldo + h * WA_HD;
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        *(u32x4*)(orow + 8 * c) = (u32x4){pack_bf2(acc[8 * c], acc[8 * c + 1]), pack_bf2(acc[8 * c + 2], acc[8 * c + 3]), pack_bf2(acc[8 * c + 4], acc[8 * c + 5]),
-                                          pack_bf2(acc[8 * c + 6], acc[8 * c + 7])};
+        *(u32x4*)(orow + 8 * c) = (u32x4){pack_bf2(acc2[4 * c][0], acc2[4 * c][1]), pack_bf2(acc2[4 * c + 1][0], acc2[4 * c + 1][1]), pack_bf2(acc2[4 * c + 2][0], acc2[4 * c + 2][1]),
+                                          pack_bf2(acc2[4 * c + 3][0], acc2[4 * c + 3][1])};
       if (lse) lse[(win * H + h) * WA_N + lane] = mx + logf(sum);
     }
   }
@@ -147,20 +151,24 @@ __global__ __launch_bounds__(64 * WA_BW) void window_attn_bwd_kernel(const bf16_
     VDK_WAVE_LDS_SYNC();
     const float* mrow = mask ? mask + ((win % nW) * WA_N + li) * WA_N : nullptr;
     const float l = row ? lse[(win * H + h) * WA_N + lane] : 0.f;
-    float dq[WA_HD];
+    vdk_f32x2 dq2[WA_HD / 2];
 #pragma unroll
-    for (int d = 0; d < WA_HD; ++d) dq[d] = 0.f;
+    for (int d = 0; d < WA_HD / 2; ++d) dq2[d] = (vdk_f32x2){0.f, 0.f};
 #pragma unroll 1
     for (int j = 0; j < WA_N; ++j) {
-      float a = 0.f, dp = 0.f;
+      vdk_f32x2 a2 = {0.f, 0.f}, dp2 = {0.f, 0.f};
       f32x4 kv[WA_HD / 4];
 #pragma unroll
       for (int d = 0; d < WA_HD; d += 4) {
         kv[d / 4] = *(const f32x4*)(&Ks[w][j * WA_HD + d]);
         const f32x4 vv = *(const f32x4*)(&Vs[w][j * WA_HD + d]);
-        a = fmaf(q[d], kv[d / 4][0], a); a = fmaf(q[d + 1], kv[d / 4][1], a); a = fmaf(q[d + 2], kv[d / 4][2], a); a = fmaf(q[d + 3], kv[d / 4][3], a);
-        dp = fmaf(g[d], vv[0], dp); dp = fmaf(g[d + 1], vv[1], dp); dp = fmaf(g[d + 2], vv[2], dp); dp = fmaf(g[d + 3], vv[3], dp);
+        a2 = vdk_fma2((vdk_f32x2){q[d], q[d + 1]}, (vdk_f32x2){kv[d / 4][0], kv[d / 4][1]}, a2);
+        a2 = vdk_fma2((vdk_f32x2){q[d + 2], q[d + 3]}, (vdk_f32x2){kv[d / 4][2], kv[d / 4][3]}, a2);
+        dp2 = vdk_fma2((vdk_f32x2){g[d], g[d + 1]}, (vdk_f32x2){vv[0], vv[1]}, dp2);
+        dp2 = vdk_fma2((vdk_f32x2){g[d + 2], g[d + 3]}, (vdk_f32x2){vv[2], vv[3]}, dp2);
       }
+      float a = a2[0] + a2[1];
+      const float dp = dp2[0] + dp2[1];
       a = a * scale + brow[j];
       if (mrow) a += mrow[j];
       const float p = fast_exp2((a - l) * WA_LOG2E);
@@ -168,18 +176,19 @@ __global__ __launch_bounds__(64 * WA_BW) void window_attn_bwd_kernel(const bf16_
       const bf16_t pb = f2bf(p), dsb = f2bf(ds);            // the operands of dV = P^T dO and dQ / dK = dS K / dS^T Q
       if (row) { Bs[w][lane * WA_N + j] += ds; Ps[w][lane * 52 + j] = pb; Ds[w][lane * 52 + j] = dsb; }
       const float dsr = bf2f(dsb);
+      const vdk_f32x2 ds2 = {dsr, dsr};
 #pragma unroll
       for (int d = 0; d < WA_HD; d += 4) {
-        dq[d] = fmaf(dsr, kv[d / 4][0], dq[d]); dq[d + 1] = fmaf(dsr, kv[d / 4][1], dq[d + 1]); dq[d + 2] = fmaf(dsr, kv[d / 4][2], dq[d + 2]);
-        dq[d + 3] = fmaf(dsr, kv[d / 4][3], dq[d + 3]);
+        dq2[d / 2] = vdk_fma2(ds2, (vdk_f32x2){kv[d / 4][0], kv[d / 4][1]}, dq2[d / 2]);
+        dq2[d / 2 + 1] = vdk_fma2(ds2, (vdk_f32x2){kv[d / 4][2], kv[d / 4][3]}, dq2[d / 2 + 1]);
       }
     }
     bf16_t* drow = dqkv + r0 * ldd + h * WA_HD;
     if (row) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        *(u32x4*)(drow + 8 * c) = (u32x4){pack_bf2(dq[8 * c] * scale, dq[8 * c + 1] * scale), pack_bf2(dq[8 * c + 2] * scale, dq[8 * c + 3] * scale),
-                                          pack_bf2(dq[8 * c + 4] * scale, dq[8 * c + 5] * scale), pack_bf2(dq[8 * c + 6] * scale, dq[8 * c + 7] * scale)};
+        *(u32x4*)(drow + 8 * c) = (u32x4){pack_bf2(dq2[4 * c][0] * scale, dq2[4 * c][1] * scale), pack_bf2(dq2[4 * c + 1][0] * scale, dq2[4 * c + 1][1] * scale),
+                                          pack_bf2(dq2[4 * c + 2][0] * scale, dq2[4 * c + 2][1] * scale), pack_bf2(dq2[4 * c + 3][0] * scale, dq2[4 * c + 3][1] * scale)};
     }
     // lane j now owns KEY j: the K / V tiles are replaced by the Q / dO rows (every lane has finished reading them)
     VDK_WAVE_LDS_SYNC();
@@ -191,27 +200,28 @@ __global__ __launch_bounds__(64 * WA_BW) void window_attn_bwd_kernel(const bf16_
       }
     }
     VDK_WAVE_LDS_SYNC();
-    float dk[WA_HD], dv[WA_HD];
+    vdk_f32x2 dk2[WA_HD / 2], dv2[WA_HD / 2];
 #pragma unroll
-    for (int d = 0; d < WA_HD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+    for (int d = 0; d < WA_HD / 2; ++d) { dk2[d] = (vdk_f32x2){0.f, 0.f}; dv2[d] = (vdk_f32x2){0.f, 0.f}; }
 #pragma unroll 1
     for (int i = 0; i < WA_N; ++i) {
       const float p = bf2f(Ps[w][i * 52 + li]), ds = bf2f(Ds[w][i * 52 + li]);
+      const vdk_f32x2 pp = {p, p}, dd = {ds, ds};
 #pragma unroll
       for (int d = 0; d < WA_HD; d += 4) {
         const f32x4 qv = *(const f32x4*)(&Ks[w][i * WA_HD + d]);
         const f32x4 gv = *(const f32x4*)(&Vs[w][i * WA_HD + d]);
-        dk[d] = fmaf(ds, qv[0], dk[d]); dk[d + 1] = fmaf(ds, qv[1], dk[d + 1]); dk[d + 2] = fmaf(ds, qv[2], dk[d + 2]); dk[d + 3] = fmaf(ds, qv[3], dk[d + 3]);
-        dv[d] = fmaf(p, gv[0], dv[d]); dv[d + 1] = fmaf(p, gv[1], dv[d + 1]); dv[d + 2] = fmaf(p, gv[2], dv[d + 2]); dv[d + 3] = fmaf(p, gv[3], dv[d + 3]);
+        dk2[d / 2] = vdk_fma2(dd, (vdk_f32x2){qv[0], qv[1]}, dk2[d / 2]); dk2[d / 2 + 1] = vdk_fma2(dd, (vdk_f32x2){qv[2], qv[3]}, dk2[d / 2 + 1]);
+        dv2[d / 2] = vdk_fma2(pp, (vdk_f32x2){gv[0], gv[1]}, dv2[d / 2]); dv2[d / 2 + 1] = vdk_fma2(pp, (vdk_f32x2){gv[2], gv[3]}, dv2[d / 2 + 1]);
       }
     }
     if (row) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        *(u32x4*)(drow + C + 8 * c) = (u32x4){pack_bf2(dk[8 * c] * scale, dk[8 * c + 1] * scale), pack_bf2(dk[8 * c + 2] * scale, dk[8 * c + 3] * scale),
-                                              pack_bf2(dk[8 * c + 4] * scale, dk[8 * c + 5] * scale), pack_bf2(dk[8 * c + 6] * scale, dk[8 * c + 7] * scale)};
-        *(u32x4*)(drow + 2 * C + 8 * c) = (u32x4){pack_bf2(dv[8 * c], dv[8 * c + 1]), pack_bf2(dv[8 * c + 2], dv[8 * c + 3]), pack_bf2(dv[8 * c + 4], dv[8 * c + 5]),
-                                                  pack_bf2(dv[8 * c + 6], dv[8 * c + 7])};
+        *(u32x4*)(drow + C + 8 * c) = (u32x4){pack_bf2(dk2[4 * c][0] * scale, dk2[4 * c][1] * scale), pack_bf2(dk2[4 * c + 1][0] * scale, dk2[4 * c + 1][1] * scale),
+                                              pack_bf2(dk2[4 * c + 2][0] * scale, dk2[4 * c + 2][1] * scale), pack_bf2(dk2[4 * c + 3][0] * scale, dk2[4 * c + 3][1] * scale)};
+        *(u32x4*)(drow + 2 * C + 8 * c) = (u32x4){pack_bf2(dv2[4 * c][0], dv2[4 * c][1]), pack_bf2(dv2[4 * c + 1][0], dv2[4 * c + 1][1]), pack_bf2(dv2[4 * c + 2][0], dv2[4 * c + 2][1]),
+                                                  pack_bf2(dv2[4 * c + 3][0], dv2[4 * c + 3][1])};
       }
     }
   }
