@@ -313,10 +313,12 @@ int vdk_gemm_f32_nt(const VdkGemmF32Desc* d, void* stream);
  * The attention step of timm's WindowAttention per (window, head): S = (q hd^-0.5) k^T + bias[head] (+ mask[window mod nW]); P = softmax(S); o = P v, with 49 tokens (7 x 7)
  * and head dim 32.  qkv bf16 [windows * 49, ld]: q | k | v thirds of 3 * H * 32 columns, rows in (window, token) order; bias f32 [H, 49, 49] (the relative-position table
  * gathered by the caller); mask f32 [nW, 49, 49] (0 / -100 of the shifted windows) or NULL; lse f32 [windows, H, 49] saved for the backward.  backward: dqkv bf16 (dq | dk | dv),
- * dbias f32 [H, 49, 49] summed over every window in a fixed order (no atomics). */
+ * dbias f32 [H, 49, 49] summed over every window in a fixed order (no atomics).  Both calls take a workspace (the bias + mask re-laid in the MFMA register order; the
+ * backward also the per-wave d(bias) partials). */
 int vdk_window_attention_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, const float* bias, const float* mask, int32_t nW, int64_t windows, int32_t H, int32_t N,
-                             int32_t hd, float scale, void* stream);
-int vdk_window_attention_bwd_workspace_bytes(int64_t windows, int32_t H, size_t* bytes);
+                             int32_t hd, float scale, void* ws, size_t ws_bytes, void* stream);
+int vdk_window_attention_fwd_workspace_bytes(int32_t nW, int32_t H, size_t* bytes);   /* nW = 0 without a mask */
+int vdk_window_attention_bwd_workspace_bytes(int64_t windows, int32_t nW, int32_t H, size_t* bytes);
 int vdk_window_attention_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, const float* bias, const float* mask, int32_t nW,
                              int64_t windows, int32_t H, int32_t N, int32_t hd, float scale, void* dqkv, int64_t ldd, float* dbias, void* ws, size_t ws_bytes, void* stream);
 /* elementwise / reduction pieces of the fp32-class TRAINING path of the face / CBIR task (the reference runs that loop without autocast, engine/procedure/train.py:217-227):

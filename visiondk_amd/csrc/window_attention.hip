@@ -6,230 +6,285 @@
 // step by the host side); mask f32 [nW, N, N] (0 / -100 of the shifted windows) or NULL.  Arithmetic as under the reference's autocast: bf16 operands, fp32 products and
 // sums, softmax in fp32, P rounded to bf16 once as the left operand of P v, o rounded to bf16.
 //
-// Structure: 65 536 tiny problems per layer at batch 256 (49 x 49 x 32): ONE WAVE per (window, head), lane = query row, the window's K / V rows as fp32 in the wave's
-// own LDS (read as broadcasts), the lane's 49 scores in registers.  No workgroup barriers.  This is the first, plain-VALU form (2 x 49 x 32 FMAs per lane and item);
-// the MFMA form (a 64 x 64 x 32 tile per item) is the obvious next step once the family is profiled.
-// Backward: the same mapping recomputes P from the saved row log-sum-exp; dQ is lane-local; dK / dV contract over the queries, i.e. over lanes: P and dS go through the
-// wave's LDS as bf16 [N][N] and lane j then owns key j.  d(bias) = sum of dS over every window of a head: each wave walks the windows of ONE head and keeps the sum of
-// its dS rows in registers; one partial [N, N] per wave, reduced by vdk_reduce_rows_f32 in a fixed order (no atomics: bit-reproducible).
+// Structure: 65 536 tiny problems per layer at batch 256 (49 x 49 x 32), one wave each, no workgroup barriers; see the kernel comment below.  (The first form of this
+// file ran them on plain VALU FMAs with lane = query: 48.7 ms per swin_base step at batch 128 against 40.7 ms with the MFMA form, same box.)
 #include <hip/hip_runtime.h>
 #include "vdk_device.h"
 #include "vdk_host.h"
+#include "vdk_attn_tile.h"
 
 #define WA_N 49
 #define WA_HD 32
 #define WA_LOG2E 1.4426950408889634f
 
-// a lane's row of 32 bf16 -> 32 floats
-__device__ __forceinline__ void wa_load_row(const bf16_t* __restrict__ p, float (&r)[WA_HD]) {
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const u32x4 v = *(const u32x4*)(p + 8 * c);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { r[8 * c + 2 * e] = bf_lo(v[e]); r[8 * c + 2 * e + 1] = bf_hi(v[e]); }
-  }
+#define WA_BW 2                                             // waves per workgroup of the backward
+
+// One wave per (window, head); the 49 tokens are padded to 64 = two 32-row MFMA tiles (v_mfma_f32_32x32x16_bf16, contraction over the head dim 32 = 2 steps).
+// Every product is computed TRANSPOSED so that the softmax axis lies on registers and the query on the lane:
+//     S^T[key][q] = K Q^T    (A = K rows, B = Q rows: both straight 16-byte row fragments from global memory)          C layout: lane = q, registers = keys
+//     O^T[d][q]   = V^T P^T  (A = V through the transposing LDS read, B = P^T: the C-layout registers packed to bf16)   C layout: lane = q, registers = d
+// bias + mask arrive pre-arranged in that C layout (wa_prep_bias_kernel: one f32x4 per 4 registers, -inf on the padded keys), so the padding costs no compares.
+// Backward, per (window, head): S^T and dP^T = V dO^T as above; dS^T = P^T (dP^T - D); dQ^T = K^T dS^T straight from the registers; dV^T = dO^T P and dK^T = Q^T dS contract
+// over the QUERY, which lies on lanes: P (then dS) goes once through a [64][64] bf16 LDS tile and comes back through the transposing read with the key on the lane.
+// 40 MFMAs and ~100 LDS instructions per item against 12.5 k FMAs per lane-row of the VALU form.  d(bias): the wave's dS^T sum over its windows stays in registers in the
+// C layout; partials are reduced in a fixed order (vdk_reduce_rows_f32) and un-permuted by wa_unprep_dbias_kernel.
+#define WA_FRAG 4096                                        // floats of one [64 q][64 keys] tile in fragment order: [qt][kt][lane][16]
+
+// element (qt, kt, lane, r) of the fragment order <-> query 32 qt + (lane & 31), key 32 kt + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+__global__ __launch_bounds__(256) void wa_prep_bias_kernel(const float* __restrict__ bias, const float* __restrict__ mask, int nWm, int H, float* __restrict__ bm) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)nWm * H * WA_FRAG) return;
+  const int r = (int)(i & 15), lane = (int)((i >> 4) & 63), kt = (int)((i >> 10) & 1), qt = (int)((i >> 11) & 1);
+  const long wh = i >> 12; const int h = (int)(wh % H); const long wm = wh / H;
+  const int q = 32 * qt + (lane & 31), key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+  float v = key < WA_N ? 0.f : -INFINITY;
+  if (q < WA_N && key < WA_N) { v = bias[((long)h * WA_N + q) * WA_N + key]; if (mask) v += mask[(wm * WA_N + q) * WA_N + key]; }
+  bm[i] = v;
+}
+__global__ __launch_bounds__(256) void wa_unprep_dbias_kernel(const float* __restrict__ red, int H, float* __restrict__ dbias) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)H * WA_N * WA_N) return;
+  const int key = (int)(i % WA_N); const long hq = i / WA_N; const int q = (int)(hq % WA_N); const long h = hq / WA_N;
+  const int kk = key & 31, hi = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3), lane = (q & 31) + 32 * hi;
+  dbias[i] = red[h * WA_FRAG + ((((q >> 5) * 2 + (key >> 5)) * 64 + lane) << 4) + r];
 }
 
-__global__ __launch_bounds__(256) void window_attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o, long ldo, float* __restrict__ lse,
-                                                              const float* __restrict__ bias, const float* __restrict__ mask, int nW, long items, int H, float scale) {
-  __shared__ __attribute__((aligned(16))) float Ks[4][WA_N * WA_HD];
-  __shared__ __attribute__((aligned(16))) float Vs[4][WA_N * WA_HD];
-  const int lane = threadIdx.x & 63;
+// the two 32-row tiles x two k-steps of a [49][32] bf16 operand as MFMA row fragments: lane (row l31, hi) -> 16 bytes at columns 16 ks + 8 hi; rows >= 49 read row 48
+__device__ __forceinline__ void wa_row_frags(const bf16_t* __restrict__ base, long ld, int l31, int hi, s16x8 (&f)[2][2]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int row = 32 * t + l31 < WA_N ? 32 * t + l31 : WA_N - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) f[t][ks] = *(const s16x8*)(base + (long)row * ld + 16 * ks + 8 * hi);
+  }
+}
+// the same fragments -> a [64][32] bf16 LDS tile with 64-byte rows
+__device__ __forceinline__ void wa_put_rows(unsigned char* tile, const s16x8 (&f)[2][2], int l31, int hi) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) *(s16x8*)(tile + (32 * t + l31) * 64 + 32 * ks + 16 * hi) = f[t][ks];
+}
+// transposed fragment of a 64-byte-row tile: lane = column l31, slots 0..3 = rows t1 + 4 hi + {0..3}, slots 4..7 = the same + 8 (the contraction order of a C-layout
+// tile packed by as_pack_b).  Rows r .. r+3 cover all 64 banks once, the two hi halves take the two passes a 512-byte read needs anyway: no swizzle required.
+__device__ __forceinline__ s16x8 wa_tr32(const unsigned char* tile, int t1, int lane) {
+  const int s = lane & 15, chalf = (lane >> 4) & 1, hi = lane >> 5;
+  const unsigned char* p1 = tile + (t1 + 4 * hi + (s >> 2)) * 64 + 32 * chalf + 8 * (s & 3);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(p1));
+  s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(p1 + 8 * 64));
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+  return r;
+}
+// C-layout tile (kt, qt) as bf16 -> the [64 q][64 keys] LDS tile in the AS layout (128-byte rows, 16-byte chunk ^ as_f(row)); f = the tile's two packed B fragments
+__device__ __forceinline__ void wa_put_pt(unsigned char* tile, const s16x8 (&f)[2], int kt, int qt, int l31, int hi) {
+  const int row = 32 * qt + l31;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const u32x4 u = *(const u32x4*)&f[s];
+    *(u32x2*)(tile + row * AS_ROW + (((4 * kt + 2 * s) ^ as_f(row)) << 4) + 8 * hi) = (u32x2){u[0], u[1]};
+    *(u32x2*)(tile + row * AS_ROW + (((4 * kt + 2 * s + 1) ^ as_f(row)) << 4) + 8 * hi) = (u32x2){u[2], u[3]};
+  }
+}
+// C-layout tile of a transposed product (lane = token row, registers = 4 consecutive head-dim columns per group) -> 8-byte stores into the token's row
+__device__ __forceinline__ void wa_store_t(bf16_t* __restrict__ rowp, const f32x16& x, float mul, int hi) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *(u32x2*)(rowp + 8 * g + 4 * hi) = (u32x2){pack_bf2(x[4 * g] * mul, x[4 * g + 1] * mul), pack_bf2(x[4 * g + 2] * mul, x[4 * g + 3] * mul)};
+}
+__device__ __forceinline__ float wa_dot8(const s16x8& a, const s16x8& b) {
+  const u32x4 ua = *(const u32x4*)&a, ub = *(const u32x4*)&b;
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { s = fmaf(bf_lo(ua[e]), bf_lo(ub[e]), s); s = fmaf(bf_hi(ua[e]), bf_hi(ub[e]), s); }
+  return s;
+}
+
+__global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o, long ldo, float* __restrict__ lse,
+                                                                   const float* __restrict__ bm, int nWm, long items, int H, float scale) {
+  __shared__ __attribute__((aligned(16))) unsigned char Vt[4][64 * 64];
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int C = H * WA_HD;
-  const bool row = lane < WA_N;
   for (long item = (long)blockIdx.x * 4 + w; item < items; item += (long)gridDim.x * 4) {
     const long win = item / H; const int h = (int)(item - win * H);
-    const bf16_t* base = qkv + (win * WA_N + (row ? lane : 0)) * ld + h * WA_HD;
-    float q[WA_HD], t[WA_HD];
-    wa_load_row(base, q);
-    VDK_WAVE_LDS_SYNC();                                  // the previous item's readers are done
-    wa_load_row(base + C, t);
-    if (row) {
+    const bf16_t* base = qkv + win * WA_N * ld + h * WA_HD;
+    s16x8 qf[2][2], kf[2][2], vf[2][2];
+    wa_row_frags(base, ld, l31, hi, qf);
+    wa_row_frags(base + C, ld, l31, hi, kf);
+    wa_row_frags(base + 2 * C, ld, l31, hi, vf);
+    VDK_WAVE_LDS_SYNC();                                  // the previous item's transposing reads are done
+    wa_put_rows(Vt[w], vf, l31, hi);
+    const float* bmp = bm + ((win % nWm) * H + h) * WA_FRAG + lane * 16;
+    s16x8 pf[2][2][2];                                    // [kt][qt][k-step]
 #pragma unroll
-      for (int d = 0; d < WA_HD; d += 4) *(f32x4*)(&Ks[w][lane * WA_HD + d]) = (f32x4){t[d], t[d + 1], t[d + 2], t[d + 3]};
-    }
-    wa_load_row(base + 2 * C, t);
-    if (row) {
+    for (int qt = 0; qt < 2; ++qt) {
+      f32x16 sa[2];
+      float mx = -INFINITY;
 #pragma unroll
-      for (int d = 0; d < WA_HD; d += 4) *(f32x4*)(&Vs[w][lane * WA_HD + d]) = (f32x4){t[d], t[d + 1], t[d + 2], t[d + 3]};
-    }
-    VDK_WAVE_LDS_SYNC();
-    const float* brow = bias + ((long)h * WA_N + (row ? lane : 0)) * WA_N;
-    const float* mrow = mask ? mask + ((win % nW) * WA_N + (row ? lane : 0)) * WA_N : nullptr;
-    float s[WA_N];
-    float mx = -3.0e38f;
+      for (int kt = 0; kt < 2; ++kt) {
+        sa[kt] = as_zero16();
 #pragma unroll
-    for (int j = 0; j < WA_N; ++j) {
-      vdk_f32x2 a2 = {0.f, 0.f};                           // two partial sums on packed FMAs (v_pk_fma_f32: the kernel is bound by its FMA count)
+        for (int ks = 0; ks < 2; ++ks) sa[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qf[qt][ks], sa[kt], 0, 0, 0);
 #pragma unroll
-      for (int d = 0; d < WA_HD; d += 4) {
-        const f32x4 kv = *(const f32x4*)(&Ks[w][j * WA_HD + d]);
-        a2 = vdk_fma2((vdk_f32x2){q[d], q[d + 1]}, (vdk_f32x2){kv[0], kv[1]}, a2);
-        a2 = vdk_fma2((vdk_f32x2){q[d + 2], q[d + 3]}, (vdk_f32x2){kv[2], kv[3]}, a2);
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b = *(const f32x4*)(bmp + (qt * 2 + kt) * 1024 + 4 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float a = fmaf(sa[kt][4 * g + e], scale, b[e]); sa[kt][4 * g + e] = a; mx = fmaxf(mx, a); }
+        }
       }
-      float a = a2[0] + a2[1];
-      a = a * scale + brow[j];
-      if (mrow) a += mrow[j];
-      s[j] = a;
-      mx = fmaxf(mx, a);
-    }
-    float sum = 0.f;
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < WA_N; ++j) { s[j] = fast_exp2((s[j] - mx) * WA_LOG2E); sum += s[j]; }
-    const float inv = 1.0f / sum;
-    vdk_f32x2 acc2[WA_HD / 2];
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-    for (int d = 0; d < WA_HD / 2; ++d) acc2[d] = (vdk_f32x2){0.f, 0.f};
+        for (int r = 0; r < 16; ++r) { const float e = fast_exp2((sa[kt][r] - mx) * WA_LOG2E); sa[kt][r] = e; sum += e; }
+      sum += __shfl_xor(sum, 32);
+      const float inv = 1.0f / sum;
 #pragma unroll
-    for (int j = 0; j < WA_N; ++j) {
-      const float p = bf2f(f2bf(s[j] * inv));              // P rounded once, as the left operand of P v
-      const vdk_f32x2 p2 = {p, p};
+      for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-      for (int d = 0; d < WA_HD; d += 4) {
-        const f32x4 vv = *(const f32x4*)(&Vs[w][j * WA_HD + d]);
-        acc2[d / 2] = vdk_fma2(p2, (vdk_f32x2){vv[0], vv[1]}, acc2[d / 2]);
-        acc2[d / 2 + 1] = vdk_fma2(p2, (vdk_f32x2){vv[2], vv[3]}, acc2[d / 2 + 1]);
+        for (int r = 0; r < 16; ++r) sa[kt][r] *= inv;
+        as_pack_b(sa[kt], pf[kt][qt]);                     // P rounded to bf16 once, as the operand of P v
       }
+      if (lse && hi == 0 && 32 * qt + l31 < WA_N) lse[(win * H + h) * WA_N + 32 * qt + l31] = mx + logf(sum);
     }
-    if (row) {
-      bf16_t* orow = o + (win * WA_N + lane) * ldo + h * WA_HD;
+    VDK_WAVE_LDS_SYNC();                                  // V tile complete
+    s16x8 vt[2][2];
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        *(u32x4*)(orow + 8 * c) = (u32x4){pack_bf2(acc2[4 * c][0], acc2[4 * c][1]), pack_bf2(acc2[4 * c + 1][0], acc2[4 * c + 1][1]), pack_bf2(acc2[4 * c + 2][0], acc2[4 * c + 2][1]),
-                                          pack_bf2(acc2[4 * c + 3][0], acc2[4 * c + 3][1])};
-      if (lse) lse[(win * H + h) * WA_N + lane] = mx + logf(sum);
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) vt[kt][s] = wa_tr32(Vt[w], 32 * kt + 16 * s, lane);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      f32x16 oa = as_zero16();
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt[kt][s], pf[kt][qt][s], oa, 0, 0, 0);
+      if (32 * qt + l31 < WA_N) wa_store_t(o + (win * WA_N + 32 * qt + l31) * ldo + h * WA_HD, oa, 1.0f, hi);
     }
   }
 }
 
-// one wave walks the windows win = slot, slot + nslot, ... of ONE head (h = wave index mod H); dbias_part: f32 [gridDim.x * 2][N * N] (rows of head h: wave ids = h mod H).
-// Two waves per workgroup (32 KB of LDS each: K / V rows, P and dS, the wave's running d(bias) sum); the j / i loops stay rolled -- fully unrolled (the first form: the
-// bias sums in 49 registers) the kernel needed 5.5 KB of scratch per lane and ran 20x slower than the forward.
-#define WA_BW 2
-__global__ __launch_bounds__(64 * WA_BW) void window_attn_bwd_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                                     long ldo, const float* __restrict__ lse, const float* __restrict__ bias, const float* __restrict__ mask,
-                                                                     int nW, long nwin, int H, float scale, bf16_t* __restrict__ dqkv, long ldd,
-                                                                     float* __restrict__ dbias_part) {
-  __shared__ __attribute__((aligned(16))) float Ks[WA_BW][WA_N * WA_HD];      // K rows, later Q rows
-  __shared__ __attribute__((aligned(16))) float Vs[WA_BW][WA_N * WA_HD];      // V rows, later dO rows
-  __shared__ __attribute__((aligned(16))) bf16_t Ps[WA_BW][WA_N * 52];        // P  [query][key], row pitch 52
-  __shared__ __attribute__((aligned(16))) bf16_t Ds[WA_BW][WA_N * 52];        // dS [query][key]
-  __shared__ float Bs[WA_BW][WA_N * WA_N];                                    // this wave's sum of dS over its windows: lane i owns row i (pitch 49: conflict-free)
-  const int lane = threadIdx.x & 63;
+// one wave walks the windows win = slot, slot + nslot, ... of ONE head (h = wave index mod H); dbias_part: f32 [waves][WA_FRAG] in fragment order
+__global__ __launch_bounds__(64 * WA_BW) void window_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                                          long ldo, const float* __restrict__ lse, const float* __restrict__ bm, int nWm, long nwin, int H,
+                                                                          float scale, bf16_t* __restrict__ dqkv, long ldd, float* __restrict__ dbias_part) {
+  __shared__ __attribute__((aligned(16))) unsigned char Kt[WA_BW][64 * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char Qt[WA_BW][64 * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char Gt[WA_BW][64 * 64];     // dO rows
+  __shared__ __attribute__((aligned(16))) unsigned char Pt[WA_BW][64 * AS_ROW]; // P [q][key], then dS [q][key]
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int C = H * WA_HD;
-  const bool row = lane < WA_N;
   const long wid = (long)blockIdx.x * WA_BW + w, nwave = (long)gridDim.x * WA_BW;
   const int h = (int)(wid % H);
   const long slot = wid / H, nslot = nwave / H;            // (the launcher makes the wave count a multiple of H)
-  const int li = row ? lane : 0;
-  if (row) for (int j = 0; j < WA_N; ++j) Bs[w][lane * WA_N + j] = 0.f;
-  const float* brow = bias + ((long)h * WA_N + li) * WA_N;
+  f32x16 dB[2][2];                                         // [kt][qt]
+#pragma unroll
+  for (int a = 0; a < 2; ++a) { dB[a][0] = as_zero16(); dB[a][1] = as_zero16(); }
   for (long win = slot; win < nwin; win += nslot) {
-    const long r0 = win * WA_N + li;
+    const long r0 = win * WA_N;
     const bf16_t* base = qkv + r0 * ld + h * WA_HD;
-    float q[WA_HD], g[WA_HD], t[WA_HD];
-    wa_load_row(base, q);
-    wa_load_row(dout + r0 * ldo + h * WA_HD, g);
+    s16x8 qf[2][2], kf[2][2], vf[2][2], gf[2][2];
+    wa_row_frags(base, ld, l31, hi, qf);
+    wa_row_frags(base + C, ld, l31, hi, kf);
+    wa_row_frags(base + 2 * C, ld, l31, hi, vf);
+    wa_row_frags(dout + r0 * ldo + h * WA_HD, ldo, l31, hi, gf);
+    float D[2], l[2];
+    {
+      s16x8 of[2][2];
+      wa_row_frags(o + r0 * ldo + h * WA_HD, ldo, l31, hi, of);
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {                     // D = rowsum(dO * O) on the rounded tensors
+        float d = wa_dot8(gf[qt][0], of[qt][0]) + wa_dot8(gf[qt][1], of[qt][1]);
+        D[qt] = d + __shfl_xor(d, 32);
+        l[qt] = 32 * qt + l31 < WA_N ? lse[(win * H + h) * WA_N + 32 * qt + l31] : INFINITY;     // padded queries: P = exp(-inf) = 0
+      }
+    }
+    VDK_WAVE_LDS_SYNC();                                  // the previous window's readers are done
+    wa_put_rows(Kt[w], kf, l31, hi);
+    wa_put_rows(Qt[w], qf, l31, hi);
+    wa_put_rows(Gt[w], gf, l31, hi);
+    const float* bmp = bm + ((win % nWm) * H + h) * WA_FRAG + lane * 16;
+    s16x8 dsf[2][2][2];                                   // dS^T as B fragments [kt][qt][k-step]
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        f32x16 sa = as_zero16(), dp = as_zero16();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qf[qt][ks], sa, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][ks], gf[qt][ks], dp, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b = *(const f32x4*)(bmp + (qt * 2 + kt) * 1024 + 4 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            const float p = fast_exp2((fmaf(sa[r], scale, b[e]) - l[qt]) * WA_LOG2E);
+            const float ds = p * (dp[r] - D[qt]);          // d(loss)/dS: also the bias gradient of this (query, key)
+            dB[kt][qt][r] += ds;
+            sa[r] = p; dp[r] = ds;
+          }
+        }
+        s16x8 pfr[2];
+        as_pack_b(sa, pfr);
+        wa_put_pt(Pt[w], pfr, kt, qt, l31, hi);
+        as_pack_b(dp, dsf[kt][qt]);
+      }
     VDK_WAVE_LDS_SYNC();
-    wa_load_row(base + C, t);
-    if (row) {
+    bf16_t* dbase = dqkv + r0 * ldd + h * WA_HD;
+    // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
+    {
+      s16x8 ktr[2][2];
 #pragma unroll
-      for (int d = 0; d < WA_HD; d += 4) *(f32x4*)(&Ks[w][lane * WA_HD + d]) = (f32x4){t[d], t[d + 1], t[d + 2], t[d + 3]};
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) ktr[kt][s] = wa_tr32(Kt[w], 32 * kt + 16 * s, lane);
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        f32x16 acc = as_zero16();
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktr[kt][s], dsf[kt][qt][s], acc, 0, 0, 0);
+        if (32 * qt + l31 < WA_N) wa_store_t(dbase + (long)(32 * qt + l31) * ldd, acc, scale, hi);
+      }
     }
-    wa_load_row(base + 2 * C, t);
-    if (row) {
+    // dV^T[d][key] = sum_q dO^T[d][q] P[q][key]
 #pragma unroll
-      for (int d = 0; d < WA_HD; d += 4) *(f32x4*)(&Vs[w][lane * WA_HD + d]) = (f32x4){t[d], t[d + 1], t[d + 2], t[d + 3]};
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x16 acc = as_zero16();
+#pragma unroll
+      for (int qs = 0; qs < 4; ++qs)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_tr32(Gt[w], 16 * qs, lane), as_tr_frag(Pt[w], 16 * qs, 32 * kt, lane), acc, 0, 0, 0);
+      if (32 * kt + l31 < WA_N) wa_store_t(dbase + (long)(32 * kt + l31) * ldd + 2 * C, acc, 1.0f, hi);
     }
-    // D = rowsum(dO * O) on the rounded tensors
-    wa_load_row(o + r0 * ldo + h * WA_HD, t);
-    float D = 0.f;
+    VDK_WAVE_LDS_SYNC();                                  // P has been read: the tile takes dS
 #pragma unroll
-    for (int d = 0; d < WA_HD; ++d) D = fmaf(g[d], t[d], D);
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) wa_put_pt(Pt[w], dsf[kt][qt], kt, qt, l31, hi);
     VDK_WAVE_LDS_SYNC();
-    const float* mrow = mask ? mask + ((win % nW) * WA_N + li) * WA_N : nullptr;
-    const float l = row ? lse[(win * H + h) * WA_N + lane] : 0.f;
-    vdk_f32x2 dq2[WA_HD / 2];
+    // dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
 #pragma unroll
-    for (int d = 0; d < WA_HD / 2; ++d) dq2[d] = (vdk_f32x2){0.f, 0.f};
-#pragma unroll 1
-    for (int j = 0; j < WA_N; ++j) {
-      vdk_f32x2 a2 = {0.f, 0.f}, dp2 = {0.f, 0.f};
-      f32x4 kv[WA_HD / 4];
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x16 acc = as_zero16();
 #pragma unroll
-      for (int d = 0; d < WA_HD; d += 4) {
-        kv[d / 4] = *(const f32x4*)(&Ks[w][j * WA_HD + d]);
-        const f32x4 vv = *(const f32x4*)(&Vs[w][j * WA_HD + d]);
-        a2 = vdk_fma2((vdk_f32x2){q[d], q[d + 1]}, (vdk_f32x2){kv[d / 4][0], kv[d / 4][1]}, a2);
-        a2 = vdk_fma2((vdk_f32x2){q[d + 2], q[d + 3]}, (vdk_f32x2){kv[d / 4][2], kv[d / 4][3]}, a2);
-        dp2 = vdk_fma2((vdk_f32x2){g[d], g[d + 1]}, (vdk_f32x2){vv[0], vv[1]}, dp2);
-        dp2 = vdk_fma2((vdk_f32x2){g[d + 2], g[d + 3]}, (vdk_f32x2){vv[2], vv[3]}, dp2);
-      }
-      float a = a2[0] + a2[1];
-      const float dp = dp2[0] + dp2[1];
-      a = a * scale + brow[j];
-      if (mrow) a += mrow[j];
-      const float p = fast_exp2((a - l) * WA_LOG2E);
-      const float ds = p * (dp - D);                       // d(loss)/dS: also the bias gradient of this (query, key)
-      const bf16_t pb = f2bf(p), dsb = f2bf(ds);            // the operands of dV = P^T dO and dQ / dK = dS K / dS^T Q
-      if (row) { Bs[w][lane * WA_N + j] += ds; Ps[w][lane * 52 + j] = pb; Ds[w][lane * 52 + j] = dsb; }
-      const float dsr = bf2f(dsb);
-      const vdk_f32x2 ds2 = {dsr, dsr};
-#pragma unroll
-      for (int d = 0; d < WA_HD; d += 4) {
-        dq2[d / 2] = vdk_fma2(ds2, (vdk_f32x2){kv[d / 4][0], kv[d / 4][1]}, dq2[d / 2]);
-        dq2[d / 2 + 1] = vdk_fma2(ds2, (vdk_f32x2){kv[d / 4][2], kv[d / 4][3]}, dq2[d / 2 + 1]);
-      }
-    }
-    bf16_t* drow = dqkv + r0 * ldd + h * WA_HD;
-    if (row) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        *(u32x4*)(drow + 8 * c) = (u32x4){pack_bf2(dq2[4 * c][0] * scale, dq2[4 * c][1] * scale), pack_bf2(dq2[4 * c + 1][0] * scale, dq2[4 * c + 1][1] * scale),
-                                          pack_bf2(dq2[4 * c + 2][0] * scale, dq2[4 * c + 2][1] * scale), pack_bf2(dq2[4 * c + 3][0] * scale, dq2[4 * c + 3][1] * scale)};
-    }
-    // lane j now owns KEY j: the K / V tiles are replaced by the Q / dO rows (every lane has finished reading them)
-    VDK_WAVE_LDS_SYNC();
-    if (row) {
-#pragma unroll
-      for (int d = 0; d < WA_HD; d += 4) {
-        *(f32x4*)(&Ks[w][lane * WA_HD + d]) = (f32x4){q[d], q[d + 1], q[d + 2], q[d + 3]};
-        *(f32x4*)(&Vs[w][lane * WA_HD + d]) = (f32x4){g[d], g[d + 1], g[d + 2], g[d + 3]};
-      }
-    }
-    VDK_WAVE_LDS_SYNC();
-    vdk_f32x2 dk2[WA_HD / 2], dv2[WA_HD / 2];
-#pragma unroll
-    for (int d = 0; d < WA_HD / 2; ++d) { dk2[d] = (vdk_f32x2){0.f, 0.f}; dv2[d] = (vdk_f32x2){0.f, 0.f}; }
-#pragma unroll 1
-    for (int i = 0; i < WA_N; ++i) {
-      const float p = bf2f(Ps[w][i * 52 + li]), ds = bf2f(Ds[w][i * 52 + li]);
-      const vdk_f32x2 pp = {p, p}, dd = {ds, ds};
-#pragma unroll
-      for (int d = 0; d < WA_HD; d += 4) {
-        const f32x4 qv = *(const f32x4*)(&Ks[w][i * WA_HD + d]);
-        const f32x4 gv = *(const f32x4*)(&Vs[w][i * WA_HD + d]);
-        dk2[d / 2] = vdk_fma2(dd, (vdk_f32x2){qv[0], qv[1]}, dk2[d / 2]); dk2[d / 2 + 1] = vdk_fma2(dd, (vdk_f32x2){qv[2], qv[3]}, dk2[d / 2 + 1]);
-        dv2[d / 2] = vdk_fma2(pp, (vdk_f32x2){gv[0], gv[1]}, dv2[d / 2]); dv2[d / 2 + 1] = vdk_fma2(pp, (vdk_f32x2){gv[2], gv[3]}, dv2[d / 2 + 1]);
-      }
-    }
-    if (row) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        *(u32x4*)(drow + C + 8 * c) = (u32x4){pack_bf2(dk2[4 * c][0] * scale, dk2[4 * c][1] * scale), pack_bf2(dk2[4 * c + 1][0] * scale, dk2[4 * c + 1][1] * scale),
-                                              pack_bf2(dk2[4 * c + 2][0] * scale, dk2[4 * c + 2][1] * scale), pack_bf2(dk2[4 * c + 3][0] * scale, dk2[4 * c + 3][1] * scale)};
-        *(u32x4*)(drow + 2 * C + 8 * c) = (u32x4){pack_bf2(dv2[4 * c][0], dv2[4 * c][1]), pack_bf2(dv2[4 * c + 1][0], dv2[4 * c + 1][1]), pack_bf2(dv2[4 * c + 2][0], dv2[4 * c + 2][1]),
-                                                  pack_bf2(dv2[4 * c + 3][0], dv2[4 * c + 3][1])};
-      }
+      for (int qs = 0; qs < 4; ++qs)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_tr32(Qt[w], 16 * qs, lane), as_tr_frag(Pt[w], 16 * qs, 32 * kt, lane), acc, 0, 0, 0);
+      if (32 * kt + l31 < WA_N) wa_store_t(dbase + (long)(32 * kt + l31) * ldd + C, acc, scale, hi);
     }
   }
-  VDK_WAVE_LDS_SYNC();
-  if (row) {
-    float* dst = dbias_part + (wid * WA_N + lane) * WA_N;
-    for (int j = 0; j < WA_N; ++j) dst[j] = Bs[w][lane * WA_N + j];
-  }
+  float* dst = dbias_part + wid * WA_FRAG + lane * 16;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *(f32x4*)(dst + (qt * 2 + kt) * 1024 + 4 * g) = (f32x4){dB[kt][qt][4 * g], dB[kt][qt][4 * g + 1], dB[kt][qt][4 * g + 2], dB[kt][qt][4 * g + 3]};
 }
 
 extern "C" {
@@ -242,26 +297,44 @@ static int wa_check(const void* qkv, int64_t ld, int64_t windows, int32_t H, int
   if (mask && (nW <= 0 || windows % nW)) return vdk_fail(VDK_EINVAL, who);
   return VDK_OK;
 }
+static size_t wa_bm_bytes(int32_t nW, int32_t H) { return (size_t)(nW > 0 ? nW : 1) * H * WA_FRAG * 4; }
+static long wa_bwd_waves(int64_t windows, int32_t H) {
+  long waves = 4096 / H * H; if (waves > windows * H) waves = windows * H; if (waves < H) waves = H;
+  return (waves + WA_BW * H - 1) / (WA_BW * H) * (WA_BW * H);             // whole workgroups, whole head groups
+}
+// bias (+ mask) -> the kernels' fragment order
+static void wa_prep(const float* bias, const float* mask, int32_t nW, int32_t H, float* bm, hipStream_t st) {
+  const int nWm = mask ? nW : 1;
+  const long n = (long)nWm * H * WA_FRAG;
+  hipLaunchKernelGGL(wa_prep_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bias, mask, nWm, (int)H, bm);
+}
 
+/* workspace of vdk_window_attention_fwd: the bias (+ mask) in the kernel's fragment order, (nW or 1) * H * 16 KB */
+int vdk_window_attention_fwd_workspace_bytes(int32_t nW, int32_t H, size_t* bytes) {
+  if (!bytes || nW < 0 || H <= 0) return vdk_fail(VDK_EINVAL, "vdk_window_attention_fwd_workspace_bytes: bad argument");
+  *bytes = wa_bm_bytes(nW, H);
+  return VDK_OK;
+}
 /* timm WindowAttention core (Swin): qkv bf16 [windows * 49, ld] (q | k | v thirds of 3 * H * 32 columns) -> o bf16 [windows * 49, ldo]; lse f32 [windows, H, 49] (may be NULL
  * for inference); bias f32 [H, 49, 49]; mask f32 [nW, 49, 49] or NULL (window w takes mask[w mod nW]) */
 int vdk_window_attention_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, const float* bias, const float* mask, int32_t nW, int64_t windows, int32_t H, int32_t N,
-                             int32_t hd, float scale, void* stream) {
+                             int32_t hd, float scale, void* ws, size_t ws_bytes, void* stream) {
   int rc = wa_check(qkv, ld, windows, H, N, hd, bias, mask, nW, "vdk_window_attention_fwd: bad argument");
   if (rc) return rc;
   if (!o || (ldo & 7) || ldo < H * hd) return vdk_fail(VDK_EINVAL, "vdk_window_attention_fwd: bad argument");
+  if (!ws || ws_bytes < wa_bm_bytes(mask ? nW : 0, H)) return vdk_fail(VDK_EWORKSPACE, "vdk_window_attention_fwd: workspace too small");
   const long items = (long)windows * H;
   long grid = (items + 3) / 4; if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(window_attn_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld, (bf16_t*)o, (long)ldo, lse, bias, mask, (int)nW,
-                     items, (int)H, scale);
+  wa_prep(bias, mask, nW, H, (float*)ws, (hipStream_t)stream);
+  hipLaunchKernelGGL(window_attn_fwd_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld, (bf16_t*)o, (long)ldo, lse, (const float*)ws,
+                     mask ? (int)nW : 1, items, (int)H, scale);
   return vdk_check_launch("vdk_window_attention_fwd");
 }
 
-int vdk_window_attention_bwd_workspace_bytes(int64_t windows, int32_t H, size_t* bytes) {
-  if (!bytes || windows <= 0 || H <= 0) return vdk_fail(VDK_EINVAL, "vdk_window_attention_bwd_workspace_bytes: bad argument");
-  long waves = 4096 / H * H; if (waves > windows * H) waves = windows * H; if (waves < H) waves = H;
-  waves = (waves + WA_BW * H - 1) / (WA_BW * H) * (WA_BW * H);           // whole workgroups, whole head groups
-  *bytes = (size_t)waves * WA_N * WA_N * 4;
+/* workspace of vdk_window_attention_bwd: the prepared bias, one d(bias) partial per wave and their sum, all in fragment order */
+int vdk_window_attention_bwd_workspace_bytes(int64_t windows, int32_t nW, int32_t H, size_t* bytes) {
+  if (!bytes || windows <= 0 || nW < 0 || H <= 0) return vdk_fail(VDK_EINVAL, "vdk_window_attention_bwd_workspace_bytes: bad argument");
+  *bytes = wa_bm_bytes(nW, H) + (size_t)(wa_bwd_waves(windows, H) + H) * WA_FRAG * 4;
   return VDK_OK;
 }
 /* backward: dqkv bf16 [windows * 49, ldd] (dq | dk | dv), dbias f32 [H, 49, 49] (summed over every window; overwritten).  ws: vdk_window_attention_bwd_workspace_bytes */
@@ -270,15 +343,21 @@ int vdk_window_attention_bwd(const void* qkv, int64_t ld, const void* o, const v
   int rc = wa_check(qkv, ld, windows, H, N, hd, bias, mask, nW, "vdk_window_attention_bwd: bad argument");
   if (rc) return rc;
   if (!o || !dout || !lse || !dqkv || !dbias || (ldo & 7) || (ldd & 7) || ldd < 3 * H * hd) return vdk_fail(VDK_EINVAL, "vdk_window_attention_bwd: bad argument");
-  size_t need = 0; vdk_window_attention_bwd_workspace_bytes(windows, H, &need);
+  size_t need = 0; vdk_window_attention_bwd_workspace_bytes(windows, mask ? nW : 0, H, &need);
   if (!ws || ws_bytes < need) return vdk_fail(VDK_EWORKSPACE, "vdk_window_attention_bwd: workspace too small");
-  const long waves = (long)(need / ((size_t)WA_N * WA_N * 4));
-  hipLaunchKernelGGL(window_attn_bwd_kernel, dim3((unsigned)(waves / WA_BW)), dim3(64 * WA_BW), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld, (const bf16_t*)o, (const bf16_t*)dout,
-                     (long)ldo, lse, bias, mask, (int)nW, (long)windows, (int)H, scale, (bf16_t*)dqkv, (long)ldd, (float*)ws);
-  // partial row r belongs to head r mod H: a group of H consecutive rows IS one [H, N, N] tensor, and the sum over the groups (in group order) is d(bias)
-  const long nn = (long)WA_N * WA_N;
-  rc = vdk_reduce_rows_f32((const float*)ws, (int64_t)H * nn, (int32_t)(waves / H), (int64_t)H * nn, dbias, 1.0f, stream);
+  const long waves = wa_bwd_waves(windows, H);
+  float* bm = (float*)ws;
+  float* part = bm + wa_bm_bytes(mask ? nW : 0, H) / 4;
+  float* red = part + waves * WA_FRAG;
+  hipStream_t st = (hipStream_t)stream;
+  wa_prep(bias, mask, nW, H, bm, st);
+  hipLaunchKernelGGL(window_attn_bwd_mfma_kernel, dim3((unsigned)(waves / WA_BW)), dim3(64 * WA_BW), 0, st, (const bf16_t*)qkv, (long)ld, (const bf16_t*)o, (const bf16_t*)dout,
+                     (long)ldo, lse, (const float*)bm, mask ? (int)nW : 1, (long)windows, (int)H, scale, (bf16_t*)dqkv, (long)ldd, part);
+  // partial row r belongs to head r mod H: a group of H consecutive rows IS one [H, 64 x 64] tensor, and the sum over the groups (in group order) is d(bias)
+  rc = vdk_reduce_rows_f32(part, (int64_t)H * WA_FRAG, (int32_t)(waves / H), (int64_t)H * WA_FRAG, red, 1.0f, stream);
   if (rc) return rc;
+  const long n = (long)H * WA_N * WA_N;
+  hipLaunchKernelGGL(wa_unprep_dbias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)red, (int)H, dbias);
   return vdk_check_launch("vdk_window_attention_bwd");
 }
 

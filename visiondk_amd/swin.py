@@ -181,8 +181,12 @@ class _WinAttn(torch.autograd.Function):
         lse = torch.empty((windows, heads, N), dtype=torch.float32, device=qkv.device)
         biasc = bias.detach().contiguous()
         scale = (Cc // heads) ** -0.5
-        be.check(be.lib.vdk_window_attention_fwd(be.ptr(qkv), C3, be.ptr(o), Cc, be.ptr(lse), be.ptr(biasc), be.ptr(mask), 0 if mask is None else mask.shape[0], windows, heads, N,
-                                                 Cc // heads, scale, be.stream()), "vdk_window_attention_fwd")
+        nW = 0 if mask is None else mask.shape[0]
+        need = C.c_size_t(0)
+        be.check(be.lib.vdk_window_attention_fwd_workspace_bytes(nW, heads, C.byref(need)), "vdk_window_attention_fwd_workspace_bytes")
+        ws = torch.empty(need.value, dtype=torch.uint8, device=qkv.device)
+        be.check(be.lib.vdk_window_attention_fwd(be.ptr(qkv), C3, be.ptr(o), Cc, be.ptr(lse), be.ptr(biasc), be.ptr(mask), nW, windows, heads, N, Cc // heads, scale, be.ptr(ws),
+                                                 ws.numel(), be.stream()), "vdk_window_attention_fwd")
         ctx.save_for_backward(qkv, o, lse, biasc)
         ctx.mask, ctx.heads, ctx.be, ctx.scale = mask, heads, be, scale
         return o
@@ -198,7 +202,8 @@ class _WinAttn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dbias = torch.empty((heads, N, N), dtype=torch.float32, device=qkv.device)
         need = C.c_size_t(0)
-        be.check(be.lib.vdk_window_attention_bwd_workspace_bytes(windows, heads, C.byref(need)), "vdk_window_attention_bwd_workspace_bytes")
+        be.check(be.lib.vdk_window_attention_bwd_workspace_bytes(windows, 0 if mask is None else mask.shape[0], heads, C.byref(need)),
+                 "vdk_window_attention_bwd_workspace_bytes")
         ws = torch.empty(need.value, dtype=torch.uint8, device=qkv.device)
         be.check(be.lib.vdk_window_attention_bwd(be.ptr(qkv), C3, be.ptr(o), be.ptr(do), Cc, be.ptr(lse), be.ptr(biasc), be.ptr(mask), 0 if mask is None else mask.shape[0],
                                                  windows, heads, N, Cc // heads, ctx.scale, be.ptr(dqkv), C3, be.ptr(dbias), be.ptr(ws), ws.numel(), be.stream()),
