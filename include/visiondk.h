@@ -314,13 +314,15 @@ int vdk_gemm_f32_nt(const VdkGemmF32Desc* d, void* stream);
  * and head dim 32.  qkv bf16 [windows * 49, ld]: q | k | v thirds of 3 * H * 32 columns, rows in (window, token) order; bias f32 [H, 49, 49] (the relative-position table
  * gathered by the caller); mask f32 [nW, 49, 49] (0 / -100 of the shifted windows) or NULL; lse f32 [windows, H, 49] saved for the backward.  backward: dqkv bf16 (dq | dk | dv),
  * dbias f32 [H, 49, 49] summed over every window in a fixed order (no atomics).  Both calls take a workspace (the bias + mask re-laid in the MFMA register order; the
- * backward also the per-wave d(bias) partials). */
+ * backward also the per-wave d(bias) partials).  rowidx int32 [windows * 49] or NULL: token j of window w is tensor row rowidx[w * 49 + j] of qkv / o / dout / dqkv (timm's
+ * roll + window_partition / window_reverse + roll around the attention in SwinTransformerBlock, as an index: no gather copies). */
 int vdk_window_attention_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, const float* bias, const float* mask, int32_t nW, int64_t windows, int32_t H, int32_t N,
-                             int32_t hd, float scale, void* ws, size_t ws_bytes, void* stream);
+                             int32_t hd, float scale, const int32_t* rowidx, void* ws, size_t ws_bytes, void* stream);
 int vdk_window_attention_fwd_workspace_bytes(int32_t nW, int32_t H, size_t* bytes);   /* nW = 0 without a mask */
 int vdk_window_attention_bwd_workspace_bytes(int64_t windows, int32_t nW, int32_t H, size_t* bytes);
 int vdk_window_attention_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, const float* bias, const float* mask, int32_t nW,
-                             int64_t windows, int32_t H, int32_t N, int32_t hd, float scale, void* dqkv, int64_t ldd, float* dbias, void* ws, size_t ws_bytes, void* stream);
+                             int64_t windows, int32_t H, int32_t N, int32_t hd, float scale, const int32_t* rowidx, void* dqkv, int64_t ldd, float* dbias, void* ws,
+                             size_t ws_bytes, void* stream);
 /* elementwise / reduction pieces of the fp32-class TRAINING path of the face / CBIR task (the reference runs that loop without autocast, engine/procedure/train.py:217-227):
  * exact-erf GELU and its derivative with the library erff / expf, a row scale (ConvNeXt layer scale folded into fc2), deterministic column sums of an f32 tensor
  * (bias gradients) and the inverse of vdk_space_to_depth2_f32 */

@@ -15,8 +15,9 @@ def _rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-12)).item()
 
 
-@pytest.mark.parametrize("windows,heads,nW", [(3, 2, 0), (8, 3, 4)])
-def test_window_attention_fwd_bwd_vs_torch(be, dev, windows, heads, nW):
+@pytest.mark.parametrize("windows,heads,nW,indexed", [(3, 2, 0, False), (8, 3, 4, False), (8, 2, 4, True)])
+def test_window_attention_fwd_bwd_vs_torch(be, dev, windows, heads, nW, indexed):
+    """indexed: the tensors' rows are a permutation of the (window, token) order and the kernels follow the index (timm's roll + window_partition as rowidx)"""
     torch.manual_seed(windows)
     N, hd = 49, 32
     Cc = heads * hd
@@ -38,12 +39,15 @@ def test_window_attention_fwd_bwd_vs_torch(be, dev, windows, heads, nW):
     ref = (p @ v).permute(0, 2, 1, 3).reshape(windows * N, Cc)
     ref.backward(do.float())
     fn = swin._WinAttn.apply
-    qd = qkv.to(dev).requires_grad_(True); bd = bias.to(dev).requires_grad_(True)
-    o = fn(qd, bd, None if mask is None else mask.to(dev).contiguous(), heads, be)
-    assert _rel(o, ref) < 6e-3                       # o and P are bf16
-    o.backward(do.to(dev))
+    perm = torch.randperm(windows * N) if indexed else torch.arange(windows * N)          # (window, token) j lives in tensor row perm[j]
+    scat = lambda t: torch.empty_like(t).index_copy_(0, perm, t)
+    qd = scat(qkv).to(dev).requires_grad_(True); bd = bias.to(dev).requires_grad_(True)
+    o = fn(qd, bd, None if mask is None else mask.to(dev).contiguous(), heads, be, perm.to(torch.int32).to(dev) if indexed else None)
+    assert _rel(o.cpu()[perm], ref) < 6e-3           # o and P are bf16
+    o.backward(scat(do).to(dev))
+    dqkv = qd.grad.cpu()[perm]
     dq, dk, dv = (t.grad.permute(0, 2, 1, 3).reshape(windows * N, Cc) for t in (q, k, v))
-    assert _rel(qd.grad[:, :Cc], dq) < 1.5e-2 and _rel(qd.grad[:, Cc:2 * Cc], dk) < 1.5e-2 and _rel(qd.grad[:, 2 * Cc:], dv) < 1.5e-2
+    assert _rel(dqkv[:, :Cc], dq) < 1.5e-2 and _rel(dqkv[:, Cc:2 * Cc], dk) < 1.5e-2 and _rel(dqkv[:, 2 * Cc:], dv) < 1.5e-2
     assert _rel(bd.grad, br.grad) < 1.5e-2
 
 

@@ -146,10 +146,10 @@ SIGNATURES: dict[str, tuple] = {
     # native ViT engine
     "vdk_gemm_f32_nt": (C.c_int, [C.POINTER(GemmF32Desc), P]),
     "vdk_softmax_rows_f32": (C.c_int, [P, I64, I64, I32, C.c_float, P]),
-    "vdk_window_attention_fwd": (C.c_int, [P, I64, P, I64, P, P, P, I32, I64, I32, I32, I32, F32, P, SZ, P]),
+    "vdk_window_attention_fwd": (C.c_int, [P, I64, P, I64, P, P, P, I32, I64, I32, I32, I32, F32, P, P, SZ, P]),
     "vdk_window_attention_fwd_workspace_bytes": (C.c_int, [I32, I32, PSZ]),
     "vdk_window_attention_bwd_workspace_bytes": (C.c_int, [I64, I32, I32, PSZ]),
-    "vdk_window_attention_bwd": (C.c_int, [P, I64, P, P, I64, P, P, P, I32, I64, I32, I32, I32, F32, P, I64, P, P, SZ, P]),
+    "vdk_window_attention_bwd": (C.c_int, [P, I64, P, P, I64, P, P, P, I32, I64, I32, I32, I32, F32, P, P, I64, P, P, SZ, P]),
     "vdk_gelu_f32": (C.c_int, [P, P, I64, P]),
     "vdk_dgelu_f32": (C.c_int, [P, P, I64, P]),
     "vdk_rowscale_f32": (C.c_int, [P, P, P, I64, I64, P]),

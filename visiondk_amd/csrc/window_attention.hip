@@ -18,6 +18,9 @@
 #define WA_LOG2E 1.4426950408889634f
 
 #define WA_BW 2                                             // waves per workgroup of the backward
+#ifndef WA_BWD_MINW
+#define WA_BWD_MINW 1                                       // waves per SIMD the backward is compiled for
+#endif
 
 // One wave per (window, head); the 49 tokens are padded to 64 = two 32-row MFMA tiles (v_mfma_f32_32x32x16_bf16, contraction over the head dim 32 = 2 steps).
 // Every product is computed TRANSPOSED so that the softmax axis lies on registers and the query on the lane:
@@ -49,14 +52,21 @@ __global__ __launch_bounds__(256) void wa_unprep_dbias_kernel(const float* __res
   dbias[i] = red[h * WA_FRAG + ((((q >> 5) * 2 + (key >> 5)) * 64 + lane) << 4) + r];
 }
 
-// the two 32-row tiles x two k-steps of a [49][32] bf16 operand as MFMA row fragments: lane (row l31, hi) -> 16 bytes at columns 16 ks + 8 hi; rows >= 49 read row 48
-__device__ __forceinline__ void wa_row_frags(const bf16_t* __restrict__ base, long ld, int l31, int hi, s16x8 (&f)[2][2]) {
+// the tensor rows of the lane's two tokens (32 t + l31; tokens >= 49 read token 48: finite filler).  rowidx (optional): token j of window w lives in tensor row
+// rowidx[w * 49 + j] -- the (shifted) window partition as an index instead of gather copies either side of the attention
+__device__ __forceinline__ void wa_rows(const int* __restrict__ rowidx, long win, int l31, long (&ri)[2]) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const int row = 32 * t + l31 < WA_N ? 32 * t + l31 : WA_N - 1;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) f[t][ks] = *(const s16x8*)(base + (long)row * ld + 16 * ks + 8 * hi);
+    const long j = win * WA_N + (32 * t + l31 < WA_N ? 32 * t + l31 : WA_N - 1);
+    ri[t] = rowidx ? (long)rowidx[j] : j;
   }
+}
+// the two 32-row tiles x two k-steps of a [49][32] bf16 operand as MFMA row fragments: lane (row l31, hi) -> 16 bytes at columns 16 ks + 8 hi
+__device__ __forceinline__ void wa_row_frags(const bf16_t* __restrict__ base, long ld, const long (&ri)[2], int hi, s16x8 (&f)[2][2]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) f[t][ks] = *(const s16x8*)(base + ri[t] * ld + 16 * ks + 8 * hi);
 }
 // the same fragments -> a [64][32] bf16 LDS tile with 64-byte rows
 __device__ __forceinline__ void wa_put_rows(unsigned char* tile, const s16x8 (&f)[2][2], int l31, int hi) {
@@ -100,18 +110,21 @@ __device__ __forceinline__ float wa_dot8(const s16x8& a, const s16x8& b) {
 }
 
 __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o, long ldo, float* __restrict__ lse,
-                                                                   const float* __restrict__ bm, int nWm, long items, int H, float scale) {
+                                                                   const float* __restrict__ bm, int nWm, long items, int H, float scale,
+                                                                   const int* __restrict__ rowidx) {
   __shared__ __attribute__((aligned(16))) unsigned char Vt[4][64 * 64];
   const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int C = H * WA_HD;
   for (long item = (long)blockIdx.x * 4 + w; item < items; item += (long)gridDim.x * 4) {
     const long win = item / H; const int h = (int)(item - win * H);
-    const bf16_t* base = qkv + win * WA_N * ld + h * WA_HD;
+    const bf16_t* base = qkv + h * WA_HD;
+    long ri[2];
+    wa_rows(rowidx, win, l31, ri);
     s16x8 qf[2][2], kf[2][2], vf[2][2];
-    wa_row_frags(base, ld, l31, hi, qf);
-    wa_row_frags(base + C, ld, l31, hi, kf);
-    wa_row_frags(base + 2 * C, ld, l31, hi, vf);
+    wa_row_frags(base, ld, ri, hi, qf);
+    wa_row_frags(base + C, ld, ri, hi, kf);
+    wa_row_frags(base + 2 * C, ld, ri, hi, vf);
     VDK_WAVE_LDS_SYNC();                                  // the previous item's transposing reads are done
     wa_put_rows(Vt[w], vf, l31, hi);
     const float* bmp = bm + ((win % nWm) * H + h) * WA_FRAG + lane * 16;
@@ -161,15 +174,16 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int s = 0; s < 2; ++s) oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt[kt][s], pf[kt][qt][s], oa, 0, 0, 0);
-      if (32 * qt + l31 < WA_N) wa_store_t(o + (win * WA_N + 32 * qt + l31) * ldo + h * WA_HD, oa, 1.0f, hi);
+      if (32 * qt + l31 < WA_N) wa_store_t(o + ri[qt] * ldo + h * WA_HD, oa, 1.0f, hi);
     }
   }
 }
 
 // one wave walks the windows win = slot, slot + nslot, ... of ONE head (h = wave index mod H); dbias_part: f32 [waves][WA_FRAG] in fragment order
-__global__ __launch_bounds__(64 * WA_BW) void window_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(64 * WA_BW, WA_BWD_MINW) void window_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                                           long ldo, const float* __restrict__ lse, const float* __restrict__ bm, int nWm, long nwin, int H,
-                                                                          float scale, bf16_t* __restrict__ dqkv, long ldd, float* __restrict__ dbias_part) {
+                                                                          float scale, bf16_t* __restrict__ dqkv, long ldd, float* __restrict__ dbias_part,
+                                                                          const int* __restrict__ rowidx) {
   __shared__ __attribute__((aligned(16))) unsigned char Kt[WA_BW][64 * 64];
   __shared__ __attribute__((aligned(16))) unsigned char Qt[WA_BW][64 * 64];
   __shared__ __attribute__((aligned(16))) unsigned char Gt[WA_BW][64 * 64];     // dO rows
@@ -184,17 +198,18 @@ __global__ __launch_bounds__(64 * WA_BW) void window_attn_bwd_mfma_kernel(const 
 #pragma unroll
   for (int a = 0; a < 2; ++a) { dB[a][0] = as_zero16(); dB[a][1] = as_zero16(); }
   for (long win = slot; win < nwin; win += nslot) {
-    const long r0 = win * WA_N;
-    const bf16_t* base = qkv + r0 * ld + h * WA_HD;
+    const bf16_t* base = qkv + h * WA_HD;
+    long ri[2];
+    wa_rows(rowidx, win, l31, ri);
     s16x8 qf[2][2], kf[2][2], vf[2][2], gf[2][2];
-    wa_row_frags(base, ld, l31, hi, qf);
-    wa_row_frags(base + C, ld, l31, hi, kf);
-    wa_row_frags(base + 2 * C, ld, l31, hi, vf);
-    wa_row_frags(dout + r0 * ldo + h * WA_HD, ldo, l31, hi, gf);
+    wa_row_frags(base, ld, ri, hi, qf);
+    wa_row_frags(base + C, ld, ri, hi, kf);
+    wa_row_frags(base + 2 * C, ld, ri, hi, vf);
+    wa_row_frags(dout + h * WA_HD, ldo, ri, hi, gf);
     float D[2], l[2];
     {
       s16x8 of[2][2];
-      wa_row_frags(o + r0 * ldo + h * WA_HD, ldo, l31, hi, of);
+      wa_row_frags(o + h * WA_HD, ldo, ri, hi, of);
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {                     // D = rowsum(dO * O) on the rounded tensors
         float d = wa_dot8(gf[qt][0], of[qt][0]) + wa_dot8(gf[qt][1], of[qt][1]);
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(64 * WA_BW) void window_attn_bwd_mfma_kernel(const 
         as_pack_b(dp, dsf[kt][qt]);
       }
     VDK_WAVE_LDS_SYNC();
-    bf16_t* dbase = dqkv + r0 * ldd + h * WA_HD;
+    bf16_t* dbase = dqkv + h * WA_HD;
     // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
     {
       s16x8 ktr[2][2];
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(64 * WA_BW) void window_attn_bwd_mfma_kernel(const 
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
           for (int s = 0; s < 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktr[kt][s], dsf[kt][qt][s], acc, 0, 0, 0);
-        if (32 * qt + l31 < WA_N) wa_store_t(dbase + (long)(32 * qt + l31) * ldd, acc, scale, hi);
+        if (32 * qt + l31 < WA_N) wa_store_t(dbase + ri[qt] * ldd, acc, scale, hi);
       }
     }
     // dV^T[d][key] = sum_q dO^T[d][q] P[q][key]
@@ -260,7 +275,7 @@ __global__ __launch_bounds__(64 * WA_BW) void window_attn_bwd_mfma_kernel(const 
 #pragma unroll
       for (int qs = 0; qs < 4; ++qs)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_tr32(Gt[w], 16 * qs, lane), as_tr_frag(Pt[w], 16 * qs, 32 * kt, lane), acc, 0, 0, 0);
-      if (32 * kt + l31 < WA_N) wa_store_t(dbase + (long)(32 * kt + l31) * ldd + 2 * C, acc, 1.0f, hi);
+      if (32 * kt + l31 < WA_N) wa_store_t(dbase + ri[kt] * ldd + 2 * C, acc, 1.0f, hi);
     }
     VDK_WAVE_LDS_SYNC();                                  // P has been read: the tile takes dS
 #pragma unroll
@@ -275,7 +290,7 @@ __global__ __launch_bounds__(64 * WA_BW) void window_attn_bwd_mfma_kernel(const 
 #pragma unroll
       for (int qs = 0; qs < 4; ++qs)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_tr32(Qt[w], 16 * qs, lane), as_tr_frag(Pt[w], 16 * qs, 32 * kt, lane), acc, 0, 0, 0);
-      if (32 * kt + l31 < WA_N) wa_store_t(dbase + (long)(32 * kt + l31) * ldd + C, acc, scale, hi);
+      if (32 * kt + l31 < WA_N) wa_store_t(dbase + ri[kt] * ldd + C, acc, scale, hi);
     }
   }
   float* dst = dbias_part + wid * WA_FRAG + lane * 16;
@@ -316,9 +331,10 @@ int vdk_window_attention_fwd_workspace_bytes(int32_t nW, int32_t H, size_t* byte
   return VDK_OK;
 }
 /* timm WindowAttention core (Swin): qkv bf16 [windows * 49, ld] (q | k | v thirds of 3 * H * 32 columns) -> o bf16 [windows * 49, ldo]; lse f32 [windows, H, 49] (may be NULL
- * for inference); bias f32 [H, 49, 49]; mask f32 [nW, 49, 49] or NULL (window w takes mask[w mod nW]) */
+ * for inference); bias f32 [H, 49, 49]; mask f32 [nW, 49, 49] or NULL (window w takes mask[w mod nW]); rowidx int32 [windows * 49] or NULL: token j of window w is row
+ * rowidx[w * 49 + j] of qkv / o / dout / dqkv (a permutation: the cyclic shift + window partition of timm's block as an index, so the tensors stay in image order) */
 int vdk_window_attention_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, const float* bias, const float* mask, int32_t nW, int64_t windows, int32_t H, int32_t N,
-                             int32_t hd, float scale, void* ws, size_t ws_bytes, void* stream) {
+                             int32_t hd, float scale, const int32_t* rowidx, void* ws, size_t ws_bytes, void* stream) {
   int rc = wa_check(qkv, ld, windows, H, N, hd, bias, mask, nW, "vdk_window_attention_fwd: bad argument");
   if (rc) return rc;
   if (!o || (ldo & 7) || ldo < H * hd) return vdk_fail(VDK_EINVAL, "vdk_window_attention_fwd: bad argument");
@@ -327,7 +343,7 @@ int vdk_window_attention_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, 
   long grid = (items + 3) / 4; if (grid > 4096) grid = 4096;
   wa_prep(bias, mask, nW, H, (float*)ws, (hipStream_t)stream);
   hipLaunchKernelGGL(window_attn_fwd_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld, (bf16_t*)o, (long)ldo, lse, (const float*)ws,
-                     mask ? (int)nW : 1, items, (int)H, scale);
+                     mask ? (int)nW : 1, items, (int)H, scale, (const int*)rowidx);
   return vdk_check_launch("vdk_window_attention_fwd");
 }
 
@@ -339,7 +355,8 @@ int vdk_window_attention_bwd_workspace_bytes(int64_t windows, int32_t nW, int32_
 }
 /* backward: dqkv bf16 [windows * 49, ldd] (dq | dk | dv), dbias f32 [H, 49, 49] (summed over every window; overwritten).  ws: vdk_window_attention_bwd_workspace_bytes */
 int vdk_window_attention_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, const float* bias, const float* mask, int32_t nW,
-                             int64_t windows, int32_t H, int32_t N, int32_t hd, float scale, void* dqkv, int64_t ldd, float* dbias, void* ws, size_t ws_bytes, void* stream) {
+                             int64_t windows, int32_t H, int32_t N, int32_t hd, float scale, const int32_t* rowidx, void* dqkv, int64_t ldd, float* dbias, void* ws, size_t ws_bytes,
+                             void* stream) {
   int rc = wa_check(qkv, ld, windows, H, N, hd, bias, mask, nW, "vdk_window_attention_bwd: bad argument");
   if (rc) return rc;
   if (!o || !dout || !lse || !dqkv || !dbias || (ldo & 7) || (ldd & 7) || ldd < 3 * H * hd) return vdk_fail(VDK_EINVAL, "vdk_window_attention_bwd: bad argument");
@@ -352,7 +369,7 @@ int vdk_window_attention_bwd(const void* qkv, int64_t ld, const void* o, const v
   hipStream_t st = (hipStream_t)stream;
   wa_prep(bias, mask, nW, H, bm, st);
   hipLaunchKernelGGL(window_attn_bwd_mfma_kernel, dim3((unsigned)(waves / WA_BW)), dim3(64 * WA_BW), 0, st, (const bf16_t*)qkv, (long)ld, (const bf16_t*)o, (const bf16_t*)dout,
-                     (long)ldo, lse, (const float*)bm, mask ? (int)nW : 1, (long)windows, (int)H, scale, (bf16_t*)dqkv, (long)ldd, part);
+                     (long)ldo, lse, (const float*)bm, mask ? (int)nW : 1, (long)windows, (int)H, scale, (bf16_t*)dqkv, (long)ldd, part, (const int*)rowidx);
   // partial row r belongs to head r mod H: a group of H consecutive rows IS one [H, 64 x 64] tensor, and the sum over the groups (in group order) is d(bias)
   rc = vdk_reduce_rows_f32(part, (int64_t)H * WA_FRAG, (int32_t)(waves / H), (int64_t)H * WA_FRAG, red, 1.0f, stream);
   if (rc) return rc;

@@ -113,6 +113,38 @@ class _LN(torch.autograd.Function):
         return dx.view(ctx.shape), dg, db, None, None, None
 
 
+class _LNRes(torch.autograd.Function):
+    """(LayerNorm(x) as bf16, x): the block's pre-norm with the shortcut routed through the same node, so that the backward adds the shortcut's gradient inside the
+    LayerNorm backward kernel (its `dres` input) instead of an autograd accumulation pass over the f32 stream.  The f32 dx carries its bf16 copy (written by the same kernel)
+    as `_vdk_bf16`: the next consumer is a GEMM and takes it instead of casting (see _grad_bf16)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, be):
+        x2 = x.contiguous().view(-1, w.numel())
+        y, mean, rstd = ops.layernorm_fwd(x2, w.detach(), b.detach(), eps, torch.bfloat16, backend=be)
+        ctx.save_for_backward(x2, mean, rstd, w)
+        ctx.be, ctx.shape = be, x.shape
+        return y.view(x.shape), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x2, mean, rstd, w = ctx.saved_tensors
+        dy2 = dy.contiguous().view(x2.shape)
+        dr = dres.contiguous().view(x2.shape) if dres is not None else None
+        dx, dxb, dg, db = ops.layernorm_bwd(dy2, x2, mean, rstd, w.detach(), dres=dr, want_bf16=True, backend=ctx.be)
+        dx = dx.view(ctx.shape)
+        dx._vdk_bf16 = dxb
+        return dx, dg, db, None, None
+
+
+def _grad_bf16(be, dy: torch.Tensor, rows: int) -> torch.Tensor:
+    """the bf16 [rows, C] operand of a gradient: the copy its producer attached (_LNRes.backward), else a cast"""
+    c = getattr(dy, "_vdk_bf16", None)
+    if c is not None and c.numel() == dy.numel():
+        return c.view(rows, -1)
+    return _bf(be, dy.contiguous().view(rows, -1))
+
+
 class _Lin(torch.autograd.Function):
     """y = x W^T (+ b) (+ residual): bf16 operands on the MFMA GEMM; y bf16, or f32 when it joins the residual stream"""
 
@@ -130,8 +162,7 @@ class _Lin(torch.autograd.Function):
     def backward(ctx, dy):
         xb, w = ctx.saved_tensors
         be = ctx.be
-        dy2 = dy.contiguous().view(-1, w.shape[0])
-        dyb = _bf(be, dy2)
+        dyb = _grad_bf16(be, dy, dy.numel() // w.shape[0])
         wt = ops.transpose_cast(w.detach().contiguous(), backend=be)        # bf16 [in, out]: B operand of dX = dY W
         dx = ops.gemm_nt(dyb, wt[:, :w.shape[0]] if wt.shape[1] != w.shape[0] else wt, out_dtype=torch.bfloat16 if ctx.xdtype == torch.bfloat16 else torch.float32, backend=be)
         dw = _wgrad(be, dyb, xb)
@@ -158,8 +189,7 @@ class _Mlp(torch.autograd.Function):
     def backward(ctx, dy):
         hb, u, g, w1, w2 = ctx.saved_tensors
         be = ctx.be
-        dy2 = dy.contiguous().view(-1, w2.shape[0])
-        dyb = ops.cast_bf16(dy2, backend=be)
+        dyb = _grad_bf16(be, dy, dy.numel() // w2.shape[0])
         w2t = ops.transpose_cast(w2.detach().contiguous(), backend=be)       # [4C, C]
         du = ops.gemm_nt(dyb, w2t, act=ACT_DGELU, aux=u, backend=be)
         dw2 = _wgrad(be, dyb, g); db2 = ops.colsum_bf16(dyb, backend=be)
@@ -170,10 +200,11 @@ class _Mlp(torch.autograd.Function):
 
 
 class _WinAttn(torch.autograd.Function):
-    """the attention step of timm's WindowAttention on bf16 qkv rows in (window, token) order"""
+    """the attention step of timm's WindowAttention on bf16 qkv rows; rowidx (int32 [T], a permutation) = the tensor row of every (window, token): the cyclic shift and the
+    window partition / reverse of the block as an index inside the kernels, so qkv and o stay in image order (None: rows already in (window, token) order)"""
 
     @staticmethod
-    def forward(ctx, qkv, bias, mask, heads, be):
+    def forward(ctx, qkv, bias, mask, heads, be, rowidx=None):
         T, C3 = qkv.shape
         Cc = C3 // 3
         windows = T // N
@@ -185,10 +216,10 @@ class _WinAttn(torch.autograd.Function):
         need = C.c_size_t(0)
         be.check(be.lib.vdk_window_attention_fwd_workspace_bytes(nW, heads, C.byref(need)), "vdk_window_attention_fwd_workspace_bytes")
         ws = torch.empty(need.value, dtype=torch.uint8, device=qkv.device)
-        be.check(be.lib.vdk_window_attention_fwd(be.ptr(qkv), C3, be.ptr(o), Cc, be.ptr(lse), be.ptr(biasc), be.ptr(mask), nW, windows, heads, N, Cc // heads, scale, be.ptr(ws),
-                                                 ws.numel(), be.stream()), "vdk_window_attention_fwd")
+        be.check(be.lib.vdk_window_attention_fwd(be.ptr(qkv), C3, be.ptr(o), Cc, be.ptr(lse), be.ptr(biasc), be.ptr(mask), nW, windows, heads, N, Cc // heads, scale,
+                                                 be.ptr(rowidx), be.ptr(ws), ws.numel(), be.stream()), "vdk_window_attention_fwd")
         ctx.save_for_backward(qkv, o, lse, biasc)
-        ctx.mask, ctx.heads, ctx.be, ctx.scale = mask, heads, be, scale
+        ctx.mask, ctx.heads, ctx.be, ctx.scale, ctx.rowidx = mask, heads, be, scale, rowidx
         return o
 
     @staticmethod
@@ -206,23 +237,9 @@ class _WinAttn(torch.autograd.Function):
                  "vdk_window_attention_bwd_workspace_bytes")
         ws = torch.empty(need.value, dtype=torch.uint8, device=qkv.device)
         be.check(be.lib.vdk_window_attention_bwd(be.ptr(qkv), C3, be.ptr(o), be.ptr(do), Cc, be.ptr(lse), be.ptr(biasc), be.ptr(mask), 0 if mask is None else mask.shape[0],
-                                                 windows, heads, N, Cc // heads, ctx.scale, be.ptr(dqkv), C3, be.ptr(dbias), be.ptr(ws), ws.numel(), be.stream()),
-                 "vdk_window_attention_bwd")
-        return dqkv, dbias, None, None, None
-
-
-class _Rows(torch.autograd.Function):
-    """y = x[perm] over the rows of a [T, C] tensor for a PERMUTATION perm (image order -> shifted window order in one gather instead of roll + partition copies);
-    backward gathers with the inverse permutation (no index_add: a permutation has no collisions)"""
-
-    @staticmethod
-    def forward(ctx, x, perm, inv):
-        ctx.inv = inv
-        return x.index_select(0, perm)
-
-    @staticmethod
-    def backward(ctx, dy):
-        return dy.index_select(0, ctx.inv), None, None
+                                                 windows, heads, N, Cc // heads, ctx.scale, be.ptr(ctx.rowidx), be.ptr(dqkv), C3, be.ptr(dbias), be.ptr(ws), ws.numel(),
+                                                 be.stream()), "vdk_window_attention_bwd")
+        return dqkv, dbias, None, None, None, None
 
 
 class _BiasGather(torch.autograd.Function):
@@ -308,29 +325,30 @@ class SwinBlock(nn.Module):
         self._perm = {}
 
     def _perms(self, B: int, dev):
-        """row permutation image order -> (cyclically shifted) window order for a batch of B maps, and its inverse"""
+        """the image-order row of every (window, token) of the (cyclically shifted) window partition of a batch of B maps"""
         if B not in self._perm:
             idx = torch.arange(B * self.res * self.res).view(B, self.res, self.res, 1)
             if self.shift:
                 idx = torch.roll(idx, (-self.shift, -self.shift), (1, 2))
-            perm = _partition(idx, WS).view(-1)
-            inv = torch.empty_like(perm); inv[perm] = torch.arange(perm.numel())
-            self._perm = {B: (perm.to(dev), inv.to(dev))}
+            self._perm = {B: _partition(idx, WS).view(-1).to(torch.int32).to(dev)}
         return self._perm[B]
 
     def forward(self, x):                                       # f32 [B, H, W, C]
         B, H, W, Cc = x.shape
+        return self.rows(x.reshape(-1, Cc), B).view(B, H, W, Cc)
+
+    def rows(self, x, B: int):
+        """the block on the f32 token rows [B * H * W, C] in image order.  A stage keeps this 2-D form from block to block: no view nodes between the blocks' autograd nodes,
+        so a gradient reaches its consumer as the very tensor its producer made (with its bf16 copy attached, _LNRes)"""
+        Cc = x.shape[1]
         be, a = self.be, self.attn
-        perm, inv = self._perms(B, x.device)
-        h = _LN.apply(x, self.norm1.weight, self.norm1.bias, self.eps, torch.bfloat16, be)
-        hw = _Rows.apply(h.view(-1, Cc), perm, inv); xw = _Rows.apply(x.reshape(-1, Cc), perm, inv)      # rows in (window, token) order
-        qkv = _Lin.apply(hw, a.qkv.weight, a.qkv.bias, None, torch.bfloat16, be)
+        h, xs = _LNRes.apply(x, self.norm1.weight, self.norm1.bias, self.eps, be)                        # xs = x: the shortcut, routed through the norm's node
+        qkv = _Lin.apply(h, a.qkv.weight, a.qkv.bias, None, torch.bfloat16, be)                          # rows stay in image order: the kernels follow the window index
         bias = _BiasGather.apply(a.relative_position_bias_table, a.relative_position_index, a._uses, be)
-        o = _WinAttn.apply(qkv, bias, self.attn_mask, self.heads, be)
-        y = _Lin.apply(o, a.proj.weight, a.proj.bias, xw, torch.float32, be)          # shortcut added in the GEMM epilogue (window order)
-        y = _Rows.apply(y, inv, perm).view(B, H, W, Cc)                               # back to image order
-        h2 = _LN.apply(y, self.norm2.weight, self.norm2.bias, self.eps, torch.bfloat16, be)
-        return _Mlp.apply(h2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, y, be)
+        o = _WinAttn.apply(qkv, bias, self.attn_mask, self.heads, be, self._perms(B, x.device))
+        y = _Lin.apply(o, a.proj.weight, a.proj.bias, xs, torch.float32, be)                             # shortcut added in the GEMM epilogue
+        h2, ys = _LNRes.apply(y, self.norm2.weight, self.norm2.bias, self.eps, be)
+        return _Mlp.apply(h2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, ys, be)
 
 
 class PatchMerging(nn.Module):
@@ -354,7 +372,12 @@ class SwinStage(nn.Module):
         self.blocks = nn.Sequential(*[SwinBlock(dim, res, heads, 0 if j % 2 == 0 else WS // 2, eps, be, dev) for j in range(depth)])
 
     def forward(self, x):
-        return self.blocks(self.downsample(x))
+        x = self.downsample(x)
+        B, H, W, Cc = x.shape
+        t = x.reshape(-1, Cc)
+        for blk in self.blocks:
+            t = blk.rows(t, B)
+        return t.view(B, H, W, Cc)
 
 
 class SwinTransformer(nn.Module):
