@@ -296,6 +296,54 @@ def bench_cfg5(be, dev, batch: int = 128, steps: int = 3):
     return out
 
 
+def bench_swin(be, dev, batch: int = 128, steps: int = 4):
+    """swin_base_patch4_window7_224 -- the `name:` both shipped configs of the reference default to (pet.yaml:25, cbir.yaml:26) -- beside the headline: the classifier step
+    forward + CE + backward + clip_grad_norm_ + torch SGD (the reference's own Trainer sequence over the module's Parameters; this family runs as autograd nodes over the HIP
+    kernels), and a live check of a 2-stage Swin (logits and the worst parameter gradient) against the fp32 oracle (oracle/swin_ref.py, pinned against transformers.SwinModel)."""
+    from oracle.swin_ref import SwinTransformerRef
+    from visiondk_amd import swin
+    out = {"workload": f"swin_base_patch4_window7_224, 37 classes (pet.yaml), batch {batch}: fwd + CE(ls 0.05) + bwd + clip_grad_norm_ + torch SGD", "dtype": "bf16 operands, fp32 residual stream"}
+    torch.manual_seed(0)
+    ref = SwinTransformerRef(img_size=224, num_classes=7, embed_dim=32, depths=(2, 2), heads=(1, 2))
+    with torch.no_grad():
+        for n_, p_ in ref.named_parameters():
+            if "relative_position_bias_table" in n_:
+                p_.copy_(torch.randn_like(p_) * 0.3)
+    small = swin.SwinTransformer(swin.SwinSpec(img_size=224, num_classes=7, embed_dim=32, depths=(2, 2), heads=(1, 2)), device=dev, backend=be, seed=0)
+    small.load_state_dict(ref.state_dict())
+    x = torch.randn(2, 3, 224, 224); y = torch.randint(0, 7, (2,))
+    lr_ = ref(x); torch.nn.functional.cross_entropy(lr_, y).backward()
+    lo = small(x.to(dev)); torch.nn.functional.cross_entropy(lo, y.to(dev)).backward()
+    rel = lambda a, b: ((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm().clamp_min(1e-30)).item()
+    grads = {n_: rel(p_.grad, dict(ref.named_parameters())[n_].grad) for n_, p_ in small.named_parameters()}
+    worst = max(grads, key=grads.get)
+    out["parity_vs_fp32_oracle"] = {"model": "2-stage Swin (dim 32 / 64, 56 x 56 and 28 x 28 maps: shifted windows, masks, patch merging), batch 2", "logits_rel": rel(lo.detach(), lr_.detach()),
+                                    "worst_grad_rel": grads[worst], "worst_grad": worst,
+                                    "full_size_quoted": "swin_base, every gradient vs the fp32 oracle (tests/test_swin.py): logits 5.9e-3, worst gradient 1.1e-2, median 5.6e-3"}
+    del small, ref
+    model = swin.create_model("swin_base_patch4_window7_224", num_classes=37, device=dev, seed=0)
+    opt = torch.optim.SGD(model.parameters(), lr=0.006, momentum=0.937, weight_decay=5e-4)
+    xb = torch.randn(batch, 3, 224, 224, device=dev); yb = torch.randint(0, 37, (batch,), device=dev)
+
+    def one():
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(model(xb), yb, label_smoothing=0.05)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+        opt.step()
+        return loss
+    for _ in range(2):
+        one()
+    torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(steps):
+        l_ = one()
+    torch.cuda.synchronize(); dt = (time.time() - t0) / steps
+    out.update({"images_per_sec": batch / dt, "ms_per_step": dt * 1e3, "model_tflops": 3 * 15.47e9 * batch / dt / 1e12, "loss": l_.item()})
+    del model, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 def _sync(dev):
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
@@ -438,6 +486,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-cfg5", action="store_true")
+    ap.add_argument("--no-swin", action="store_true")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -504,6 +553,9 @@ def main():
         if world == 1 and not args.no_cfg5:
             torch.cuda.empty_cache()
             out["cfg5"] = bench_cfg5(be, dev)
+        if world == 1 and not args.no_swin:
+            torch.cuda.empty_cache()
+            out["swin"] = bench_swin(be, dev)
         if world == 1 and not args.no_cbir:
             torch.cuda.empty_cache()
             out["cbir"] = bench_cbir(dev, with_cpu=not args.no_cpu_baseline)

@@ -6,11 +6,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-BARGS="--steps 20 --warmup 3 --no-parity --no-cpu-baseline --no-cbir --no-cfg5"
+BARGS="--steps 20 --warmup 3 --no-parity --no-cpu-baseline --no-cbir --no-cfg5 --no-swin"
 rocprofv3 --kernel-trace --stats -d /tmp/p_trace -o t -- python $R/bench.py $BARGS > $O/trace_stdout.txt 2>&1
 python $R/tools/rocpd_stats.py $(find /tmp/p_trace -name "*.db" | head -1) > $O/bench_kernel_stats.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d /tmp/p_$c -o p --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-parity --no-cpu-baseline --no-cbir --no-cfg5 > $O/pmc_${c}_stdout.txt 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d /tmp/p_$c -o p --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-parity --no-cpu-baseline --no-cbir --no-cfg5 --no-swin > $O/pmc_${c}_stdout.txt 2>&1
 done
 F=$(find /tmp/p_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find /tmp/p_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 CALLS=$(python -c "import json;print(7 * json.loads(open('$O/pmc_FETCH_SIZE_stdout.txt').read().strip().splitlines()[-1])['roofline']['gemm_calls_per_step'])")
