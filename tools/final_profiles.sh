@@ -27,7 +27,7 @@ python $R/tools/rocpd_stats.py $(find /tmp/c_trace -name "*.db" | head -1) > $O/
 tail -8 $O/cbir_pmc.txt
 cd $R
 cp $O/pmc_traffic.json profiles/r03_pmc_traffic.json 2>/dev/null; cp $O/cbir_pmc.json profiles/r03_cbir_pmc.json 2>/dev/null    # the bench line below reads them
-python bench.py > $O/bench_stdout.txt 2> $O/bench_stderr.txt
+T0=$(date +%s); python bench.py > $O/bench_stdout.txt 2> $O/bench_stderr.txt; echo "default bench.py wall: $(( $(date +%s) - T0 )) s" | tee $O/bench_wall.txt
 tail -1 $O/bench_stdout.txt > $O/bench.json
 python -c "
 import json;d=json.load(open('$O/bench.json'));print(d['value'],d['ms_per_step'],d['roofline'],d['cpu_baseline']);print(json.dumps(d['cbir'])[:1500])"
