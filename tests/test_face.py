@@ -112,10 +112,10 @@ def test_extract_cbir_eval_embeddings(be, dev):
 
 
 # ---- CNN backbone (timm ConvNeXt) + BatchNorm2d neck: timm_wrapper.py:30-37 ----------------------------------------------------------
-def _build_cnn(be, dev, monkeypatch):
+def _build_cnn(be, dev, monkeypatch, dims=(8, 16, 24, 32), img=32):
     from oracle.convnext_ref import TimmWrapperCNNRef
     from visiondk_amd import convnext
-    depths, dims, img = (1, 1, 2, 1), (8, 16, 24, 32), 32
+    depths = (1, 1, 2, 1)
     monkeypatch.setitem(convnext.TIMM_CONVNEXTS, "convnext_test", dict(depths=depths, dims=dims))
     cfg = {"task": "cbir", "image_size": img,
            "backbone": {"timm-convnext_test": {"pretrained": False, "image_size": img, "feat_dim": 64}},
@@ -164,6 +164,27 @@ def test_cnn_backbone_state_dict_and_training_step(be, dev, monkeypatch):
     for i in (0, 3):   # BatchNorm2d and BatchNorm1d running statistics follow torch's update
         assert _rel(bb.output_layer[i].running_mean, ref.output_layer[i].running_mean) < 2e-2
         assert _rel(bb.output_layer[i].running_var, ref.output_layer[i].running_var) < 2e-2
+
+
+def test_cnn_neck_wide_contraction(be, dev, monkeypatch):
+    """K = HW * C = 1024 columns into the neck's Linear: it runs split over the contraction with the bias added after the combine (at cfg3's K = 50 176 the 4 output tiles
+    would otherwise leave the whole contraction to 4 CUs).  Eval mode: BatchNorm1d does not cancel the bias there."""
+    model, ref, img = _build_cnn(be, dev, monkeypatch, dims=(8, 16, 24, 256), img=64)
+    bb = model.trainingwrapper["backbone"]
+    with torch.no_grad():
+        ref.output_layer[2].bias.add_(torch.randn(64) * 0.5)
+    bb.load_state_dict({k: v.to(dev) for k, v in ref.state_dict().items()}, strict=True)
+    x = torch.randn(4, 3, img, img)
+    ref.eval(); model.eval()
+    with torch.no_grad():
+        exp = ref(x)
+        got = bb(x.to(dev))
+    assert _rel(got, exp) < 2e-2
+    ref.train(); model.train()
+    exp = ref(x); exp.square().sum().backward()
+    got = bb(x.to(dev)); got.square().sum().backward()
+    assert _rel(got, exp) < 2e-2
+    assert _rel(bb.output_layer[2].weight.grad, ref.output_layer[2].weight.grad) < 8e-2
 
 
 def test_cnn_extract_cbir_eval_embeddings(be, dev, monkeypatch):

@@ -146,7 +146,14 @@ class _NeckCNNFn(torch.autograd.Function):
         else:
             h = ops.cast_bf16(y2, backend=be).view(Bp, K)                       # bf16 [Bp, HW*C], pad rows zero
             wb = ops.cast_bf16(wperm, backend=be)
-            z = ops.gemm_nt(h[:B], wb, out_dtype=torch.float32, bias=lin_b.detach(), backend=be)
+            # [B, F] from K = HW * C = 50 176: 4 output tiles of 256 x 256 would leave the contraction to 4 CUs (826 us at B = F = 512); split over K instead
+            tiles = ((B + 255) // 256) * ((Fd + 255) // 256)
+            sk = max(1, min(256 // tiles, K // 64 // 8))
+            if sk > 1 and K % 64 == 0:
+                z = ops.gemm_nt(h[:B], wb, out_dtype=torch.float32, splitk=sk, backend=be)
+                z.add_(lin_b.detach())
+            else:
+                z = ops.gemm_nt(h[:B], wb, out_dtype=torch.float32, bias=lin_b.detach(), backend=be)
         y = torch.empty_like(z)
         sm = torch.empty(Fd, dtype=torch.float32, device=dev); si = torch.empty(Fd, dtype=torch.float32, device=dev)
         _bn_rows_fwd(be, z, B, Fd, bn_w, bn_b, bn, training, y, sm, si, sg)
