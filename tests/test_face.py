@@ -166,6 +166,13 @@ def test_cnn_backbone_state_dict_and_training_step(be, dev, monkeypatch):
         assert _rel(bb.output_layer[i].running_var, ref.output_layer[i].running_var) < 2e-2
 
 
+def test_cnn_neck_tall_batchnorm_path(be, dev, monkeypatch):
+    """the neck's BatchNorm2d over many rows (25 088 at cfg3) runs as the slab-parallel kernel sequence: same loss, gradients and running statistics as the one-kernel form's test"""
+    monkeypatch.setattr(face, "_BN_TALL_ROWS", 4)
+    test_cnn_backbone_state_dict_and_training_step(be, dev, monkeypatch)
+    test_cnn_extract_cbir_eval_embeddings(be, dev, monkeypatch)
+
+
 def test_cnn_neck_wide_contraction(be, dev, monkeypatch):
     """K = HW * C = 1024 columns into the neck's Linear: it runs split over the contraction with the bias added after the combine (at cfg3's K = 50 176 the 4 output tiles
     would otherwise leave the whole contraction to 4 CUs).  Eval mode: BatchNorm1d does not cancel the bias there."""

@@ -22,6 +22,9 @@ def _up(x, a):
     return (x + a - 1) // a * a
 
 
+_BN_TALL_ROWS = 4096      # from this many rows on a per-rank BatchNorm runs as the slab-parallel kernel sequence (partials, combine, apply) that SyncBatchNorm uses
+
+
 def _bn_sync_cb(ws: torch.Tensor, group):
     """vdk_stat_sync_fn of the neck's SyncBatchNorm: SUM all-reduce of the statistics vector the kernel sequence hands over (it lives inside `ws`)"""
     import torch.distributed as dist
@@ -35,23 +38,24 @@ def _bn_sync_cb(ws: torch.Tensor, group):
 def _bn_rows_fwd(be, x, R, Cc, w, b, bn, training, y, sm, si, sync_group):
     """BatchNorm over R rows of x f32 [R, Cc] -> y f32.  sync_group False: the fused per-rank kernel; None / a process group (training): SyncBatchNorm -- statistics
     kernel, all-reduce of (sum x, sum x^2, count), apply (the reference converts every BatchNorm when `sync_bn` is set, engine/vision_engine.py:224-225)."""
-    if sync_group is False or not training:
+    tall = R >= _BN_TALL_ROWS and Cc % 4 == 0          # BatchNorm2d over the map's rows (25 088 x 1024 at cfg3): the slab-parallel kernel sequence; the one-kernel form walks each column with 16 row groups
+    if (sync_group is False or not training) and not tall:
         be.check(be.lib.vdk_batchnorm1d_fwd(be.ptr(x), Cc, R, Cc, be.ptr(w), be.ptr(b), bn.eps, bn.momentum, int(training), be.ptr(bn.running_mean),
                                             be.ptr(bn.running_var), be.ptr(y), Cc, be.ptr(sm), be.ptr(si), be.stream()), "vdk_batchnorm1d_fwd")
         return
     ws = ops._bn_ws(be, R, Cc, x.device)
-    cb = _bn_sync_cb(ws, sync_group)
-    be.check(be.lib.vdk_bn_act_fwd(be.ptr(x), R, Cc, be.ptr(w), be.ptr(b), bn.eps, bn.momentum, 1, be.ptr(bn.running_mean), be.ptr(bn.running_var), None, None, 0,
+    cb = _bn_sync_cb(ws, sync_group) if (sync_group is not False and training) else None
+    be.check(be.lib.vdk_bn_act_fwd(be.ptr(x), R, Cc, be.ptr(w), be.ptr(b), bn.eps, bn.momentum, int(training), be.ptr(bn.running_mean), be.ptr(bn.running_var), None, None, 0,
                                    None, be.ptr(y), be.ptr(sm), be.ptr(si), be.ptr(ws), ws.numel(), cb, None, be.stream()), "vdk_bn_act_fwd")
 
 
 def _bn_rows_bwd(be, dy, x, R, Cc, w, sm, si, dx, dw, db, sync_group):
-    if sync_group is False:
+    if sync_group is False and not (R >= _BN_TALL_ROWS and Cc % 4 == 0):
         be.check(be.lib.vdk_batchnorm1d_bwd(be.ptr(dy), Cc, be.ptr(x), Cc, R, Cc, be.ptr(w), be.ptr(sm), be.ptr(si), be.ptr(dx), Cc, be.ptr(dw), be.ptr(db), be.stream()),
                  "vdk_batchnorm1d_bwd")
         return
     ws = ops._bn_ws(be, R, Cc, x.device)
-    cb = _bn_sync_cb(ws, sync_group)
+    cb = _bn_sync_cb(ws, sync_group) if sync_group is not False else None
     be.check(be.lib.vdk_bn_rows_bwd(be.ptr(x), be.ptr(dy), R, Cc, be.ptr(w), be.ptr(sm), be.ptr(si), be.ptr(dx), be.ptr(dw), be.ptr(db), be.ptr(ws), ws.numel(), cb, None,
                                     be.stream()), "vdk_bn_rows_bwd")
 
