@@ -95,11 +95,23 @@ __device__ __forceinline__ void wa_put_pt(unsigned char* tile, const s16x8 (&f)[
     *(u32x2*)(tile + row * AS_ROW + (((4 * kt + 2 * s + 1) ^ as_f(row)) << 4) + 8 * hi) = (u32x2){u[2], u[3]};
   }
 }
-// C-layout tile of a transposed product (lane = token row, registers = 4 consecutive head-dim columns per group) -> 8-byte stores into the token's row
-__device__ __forceinline__ void wa_store_t(bf16_t* __restrict__ rowp, const f32x16& x, float mul, int hi) {
+// Output rows.  A C-layout tile of a transposed product has lane = token row, registers = head-dim columns: storing it straight from the registers is 8 bytes per lane into
+// 32 different rows per instruction, and the L1 / address path -- not the MFMAs -- then bounds the kernels (swin_base step 36.2 ms; 34.4 ms with the same stores aimed at
+// 8 rows x 64 contiguous bytes, a placement-wrong timing probe).  So the two tiles of an output go through a [64][32] bf16 staging tile in LDS (80-byte pitch: the 8-byte
+// writes of 16 consecutive rows fall on distinct bank pairs) and leave as 16-byte stores, 4 lanes per 64-byte row.
+#define WA_ST_PITCH 80
+__device__ __forceinline__ void wa_stage_t(unsigned char* st, const f32x16& x, float mul, int t, int l31, int hi) {
 #pragma unroll
   for (int g = 0; g < 4; ++g)
-    *(u32x2*)(rowp + 8 * g + 4 * hi) = (u32x2){pack_bf2(x[4 * g] * mul, x[4 * g + 1] * mul), pack_bf2(x[4 * g + 2] * mul, x[4 * g + 3] * mul)};
+    *(u32x2*)(st + (32 * t + l31) * WA_ST_PITCH + (8 * g + 4 * hi) * 2) = (u32x2){pack_bf2(x[4 * g] * mul, x[4 * g + 1] * mul), pack_bf2(x[4 * g + 2] * mul, x[4 * g + 3] * mul)};
+}
+// rows 0..48 of the staging tile -> base + ridx[row] * ld (ridx: the wave's LDS copy of its 49 tensor rows)
+__device__ __forceinline__ void wa_flush_rows(const unsigned char* st, const long* ridx, bf16_t* __restrict__ base, long ld, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 16 * i + (lane >> 2);
+    if (row < WA_N) *(u32x4*)(base + ridx[row] * ld + 8 * (lane & 3)) = *(const u32x4*)(st + row * WA_ST_PITCH + 16 * (lane & 3));
+  }
 }
 __device__ __forceinline__ float wa_dot8(const s16x8& a, const s16x8& b) {
   const u32x4 ua = *(const u32x4*)&a, ub = *(const u32x4*)&b;
@@ -113,6 +125,8 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
                                                                    const float* __restrict__ bm, int nWm, long items, int H, float scale,
                                                                    const int* __restrict__ rowidx) {
   __shared__ __attribute__((aligned(16))) unsigned char Vt[4][64 * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char St[4][64 * WA_ST_PITCH];
+  __shared__ long Ri[4][64];
   const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int C = H * WA_HD;
@@ -125,8 +139,9 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
     wa_row_frags(base, ld, ri, hi, qf);
     wa_row_frags(base + C, ld, ri, hi, kf);
     wa_row_frags(base + 2 * C, ld, ri, hi, vf);
-    VDK_WAVE_LDS_SYNC();                                  // the previous item's transposing reads are done
+    VDK_WAVE_LDS_SYNC();                                  // the previous item's LDS readers are done
     wa_put_rows(Vt[w], vf, l31, hi);
+    if (hi == 0) { Ri[w][l31] = ri[0]; Ri[w][32 + l31] = ri[1]; }
     const float* bmp = bm + ((win % nWm) * H + h) * WA_FRAG + lane * 16;
     s16x8 pf[2][2][2];                                    // [kt][qt][k-step]
 #pragma unroll
@@ -174,8 +189,10 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int s = 0; s < 2; ++s) oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt[kt][s], pf[kt][qt][s], oa, 0, 0, 0);
-      if (32 * qt + l31 < WA_N) wa_store_t(o + ri[qt] * ldo + h * WA_HD, oa, 1.0f, hi);
+      wa_stage_t(St[w], oa, 1.0f, qt, l31, hi);
     }
+    VDK_WAVE_LDS_SYNC();
+    wa_flush_rows(St[w], Ri[w], o + h * WA_HD, ldo, lane);
   }
 }
 
@@ -188,6 +205,8 @@ __global__ __launch_bounds__(64 * WA_BW, WA_BWD_MINW) void window_attn_bwd_mfma_
   __shared__ __attribute__((aligned(16))) unsigned char Qt[WA_BW][64 * 64];
   __shared__ __attribute__((aligned(16))) unsigned char Gt[WA_BW][64 * 64];     // dO rows
   __shared__ __attribute__((aligned(16))) unsigned char Pt[WA_BW][64 * AS_ROW]; // P [q][key], then dS [q][key]
+  __shared__ __attribute__((aligned(16))) unsigned char St[WA_BW][64 * WA_ST_PITCH];   // output staging
+  __shared__ long Ri[WA_BW][64];
   const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int C = H * WA_HD;
@@ -221,6 +240,7 @@ __global__ __launch_bounds__(64 * WA_BW, WA_BWD_MINW) void window_attn_bwd_mfma_
     wa_put_rows(Kt[w], kf, l31, hi);
     wa_put_rows(Qt[w], qf, l31, hi);
     wa_put_rows(Gt[w], gf, l31, hi);
+    if (hi == 0) { Ri[w][l31] = ri[0]; Ri[w][32 + l31] = ri[1]; }
     const float* bmp = bm + ((win % nWm) * H + h) * WA_FRAG + lane * 16;
     s16x8 dsf[2][2][2];                                   // dS^T as B fragments [kt][qt][k-step]
 #pragma unroll
@@ -265,8 +285,10 @@ __global__ __launch_bounds__(64 * WA_BW, WA_BWD_MINW) void window_attn_bwd_mfma_
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
           for (int s = 0; s < 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktr[kt][s], dsf[kt][qt][s], acc, 0, 0, 0);
-        if (32 * qt + l31 < WA_N) wa_store_t(dbase + ri[qt] * ldd, acc, scale, hi);
+        wa_stage_t(St[w], acc, scale, qt, l31, hi);
       }
+      VDK_WAVE_LDS_SYNC();
+      wa_flush_rows(St[w], Ri[w], dbase, ldd, lane);
     }
     // dV^T[d][key] = sum_q dO^T[d][q] P[q][key]
 #pragma unroll
@@ -275,9 +297,11 @@ __global__ __launch_bounds__(64 * WA_BW, WA_BWD_MINW) void window_attn_bwd_mfma_
 #pragma unroll
       for (int qs = 0; qs < 4; ++qs)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_tr32(Gt[w], 16 * qs, lane), as_tr_frag(Pt[w], 16 * qs, 32 * kt, lane), acc, 0, 0, 0);
-      if (32 * kt + l31 < WA_N) wa_store_t(dbase + ri[kt] * ldd + 2 * C, acc, 1.0f, hi);
+      if (kt == 0) VDK_WAVE_LDS_SYNC();                    // dQ has left the staging tile
+      wa_stage_t(St[w], acc, 1.0f, kt, l31, hi);
     }
     VDK_WAVE_LDS_SYNC();                                  // P has been read: the tile takes dS
+    wa_flush_rows(St[w], Ri[w], dbase + 2 * C, ldd, lane);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -290,8 +314,11 @@ __global__ __launch_bounds__(64 * WA_BW, WA_BWD_MINW) void window_attn_bwd_mfma_
 #pragma unroll
       for (int qs = 0; qs < 4; ++qs)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_tr32(Qt[w], 16 * qs, lane), as_tr_frag(Pt[w], 16 * qs, 32 * kt, lane), acc, 0, 0, 0);
-      if (32 * kt + l31 < WA_N) wa_store_t(dbase + ri[kt] * ldd + C, acc, scale, hi);
+      if (kt == 0) VDK_WAVE_LDS_SYNC();                    // dV has left the staging tile
+      wa_stage_t(St[w], acc, scale, kt, l31, hi);
     }
+    VDK_WAVE_LDS_SYNC();
+    wa_flush_rows(St[w], Ri[w], dbase + C, ldd, lane);
   }
   float* dst = dbias_part + wid * WA_FRAG + lane * 16;
 #pragma unroll
