@@ -52,28 +52,32 @@ __global__ __launch_bounds__(256) void wa_unprep_dbias_kernel(const float* __res
   dbias[i] = red[h * WA_FRAG + ((((q >> 5) * 2 + (key >> 5)) * 64 + lane) << 4) + r];
 }
 
-// the tensor rows of the lane's two tokens (32 t + l31; tokens >= 49 read token 48: finite filler).  rowidx (optional): token j of window w lives in tensor row
-// rowidx[w * 49 + j] -- the (shifted) window partition as an index instead of gather copies either side of the attention
-__device__ __forceinline__ void wa_rows(const int* __restrict__ rowidx, long win, int l31, long (&ri)[2]) {
+// Row traffic.  A lane moves 16 bytes of row 16 i + (lane >> 2), i = 0..3 (4 lanes per 64-byte head slice of a token row, 16 rows per instruction): the operands come
+// in by LDS-DMA into [64][32] bf16 tiles (64-byte rows) and the outputs leave the same way round (wa_flush_rows).  Tokens >= 49 read token 48 (finite filler).
+// rowidx (optional): token j of window w lives in tensor row rowidx[w * 49 + j] -- the (shifted) window partition as an index instead of gather copies either side of the
+// attention.  (Row fragments straight from global memory -- 16 bytes per lane from 32 different rows per instruction -- kept the L1 / address path busier than the
+// MFMAs: swin_base step 36.2 ms against 35.5 ms with the loads aimed at 16 rows x 64 contiguous bytes in a placement-wrong timing probe.)
+__device__ __forceinline__ void wa_rows(const int* __restrict__ rowidx, long win, int lane, long (&rr)[4]) {
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const long j = win * WA_N + (32 * t + l31 < WA_N ? 32 * t + l31 : WA_N - 1);
-    ri[t] = rowidx ? (long)rowidx[j] : j;
+  for (int i = 0; i < 4; ++i) {
+    const int t = 16 * i + (lane >> 2);
+    const long j = win * WA_N + (t < WA_N ? t : WA_N - 1);
+    rr[i] = rowidx ? (long)rowidx[j] : j;
   }
 }
-// the two 32-row tiles x two k-steps of a [49][32] bf16 operand as MFMA row fragments: lane (row l31, hi) -> 16 bytes at columns 16 ks + 8 hi
-__device__ __forceinline__ void wa_row_frags(const bf16_t* __restrict__ base, long ld, const long (&ri)[2], int hi, s16x8 (&f)[2][2]) {
+__device__ __forceinline__ void wa_dma_rows(unsigned char* tile, const bf16_t* __restrict__ base, long ld, const long (&rr)[4], int lane) {
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) f[t][ks] = *(const s16x8*)(base + ri[t] * ld + 16 * ks + 8 * hi);
+  for (int i = 0; i < 4; ++i) {
+    const bf16_t* g = base + rr[i] * ld + 8 * (lane & 3);
+    __builtin_amdgcn_global_load_lds(VDK_GLOBAL_PTR(g), VDK_LDS_PTR(tile + i * 1024), 16, 0, 0);
+  }
 }
-// the same fragments -> a [64][32] bf16 LDS tile with 64-byte rows
-__device__ __forceinline__ void wa_put_rows(unsigned char* tile, const s16x8 (&f)[2][2], int l31, int hi) {
+// MFMA row fragments of such a tile: lane (row 32 t + l31, hi) -> the 16 bytes at columns 16 ks + 8 hi
+__device__ __forceinline__ void wa_row_frags(const unsigned char* tile, int l31, int hi, s16x8 (&f)[2][2]) {
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) *(s16x8*)(tile + (32 * t + l31) * 64 + 32 * ks + 16 * hi) = f[t][ks];
+    for (int ks = 0; ks < 2; ++ks) f[t][ks] = *(const s16x8*)(tile + (32 * t + l31) * 64 + 32 * ks + 16 * hi);
 }
 // transposed fragment of a 64-byte-row tile: lane = column l31, slots 0..3 = rows t1 + 4 hi + {0..3}, slots 4..7 = the same + 8 (the contraction order of a C-layout
 // tile packed by as_pack_b).  Rows r .. r+3 cover all 64 banks once, the two hi halves take the two passes a 512-byte read needs anyway: no swizzle required.
@@ -105,12 +109,12 @@ __device__ __forceinline__ void wa_stage_t(unsigned char* st, const f32x16& x, f
   for (int g = 0; g < 4; ++g)
     *(u32x2*)(st + (32 * t + l31) * WA_ST_PITCH + (8 * g + 4 * hi) * 2) = (u32x2){pack_bf2(x[4 * g] * mul, x[4 * g + 1] * mul), pack_bf2(x[4 * g + 2] * mul, x[4 * g + 3] * mul)};
 }
-// rows 0..48 of the staging tile -> base + ridx[row] * ld (ridx: the wave's LDS copy of its 49 tensor rows)
-__device__ __forceinline__ void wa_flush_rows(const unsigned char* st, const long* ridx, bf16_t* __restrict__ base, long ld, int lane) {
+// rows 0..48 of the staging tile -> the tensor rows rr of wa_rows
+__device__ __forceinline__ void wa_flush_rows(const unsigned char* st, const long (&rr)[4], bf16_t* __restrict__ base, long ld, int lane) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = 16 * i + (lane >> 2);
-    if (row < WA_N) *(u32x4*)(base + ridx[row] * ld + 8 * (lane & 3)) = *(const u32x4*)(st + row * WA_ST_PITCH + 16 * (lane & 3));
+    if (row < WA_N) *(u32x4*)(base + rr[i] * ld + 8 * (lane & 3)) = *(const u32x4*)(st + row * WA_ST_PITCH + 16 * (lane & 3));
   }
 }
 __device__ __forceinline__ float wa_dot8(const s16x8& a, const s16x8& b) {
@@ -124,24 +128,27 @@ __device__ __forceinline__ float wa_dot8(const s16x8& a, const s16x8& b) {
 __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o, long ldo, float* __restrict__ lse,
                                                                    const float* __restrict__ bm, int nWm, long items, int H, float scale,
                                                                    const int* __restrict__ rowidx) {
+  __shared__ __attribute__((aligned(16))) unsigned char Qt[4][64 * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char Kt[4][64 * 64];
   __shared__ __attribute__((aligned(16))) unsigned char Vt[4][64 * 64];
   __shared__ __attribute__((aligned(16))) unsigned char St[4][64 * WA_ST_PITCH];
-  __shared__ long Ri[4][64];
   const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int C = H * WA_HD;
   for (long item = (long)blockIdx.x * 4 + w; item < items; item += (long)gridDim.x * 4) {
     const long win = item / H; const int h = (int)(item - win * H);
     const bf16_t* base = qkv + h * WA_HD;
-    long ri[2];
-    wa_rows(rowidx, win, l31, ri);
-    s16x8 qf[2][2], kf[2][2], vf[2][2];
-    wa_row_frags(base, ld, ri, hi, qf);
-    wa_row_frags(base + C, ld, ri, hi, kf);
-    wa_row_frags(base + 2 * C, ld, ri, hi, vf);
+    long rr[4];
+    wa_rows(rowidx, win, lane, rr);
     VDK_WAVE_LDS_SYNC();                                  // the previous item's LDS readers are done
-    wa_put_rows(Vt[w], vf, l31, hi);
-    if (hi == 0) { Ri[w][l31] = ri[0]; Ri[w][32 + l31] = ri[1]; }
+    wa_dma_rows(Qt[w], base, ld, rr, lane);
+    wa_dma_rows(Kt[w], base + C, ld, rr, lane);
+    wa_dma_rows(Vt[w], base + 2 * C, ld, rr, lane);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the wave's DMAs have landed
+    VDK_WAVE_LDS_SYNC();
+    s16x8 qf[2][2], kf[2][2];
+    wa_row_frags(Qt[w], l31, hi, qf);
+    wa_row_frags(Kt[w], l31, hi, kf);
     const float* bmp = bm + ((win % nWm) * H + h) * WA_FRAG + lane * 16;
     s16x8 pf[2][2][2];                                    // [kt][qt][k-step]
 #pragma unroll
@@ -176,7 +183,6 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
       }
       if (lse && hi == 0 && 32 * qt + l31 < WA_N) lse[(win * H + h) * WA_N + 32 * qt + l31] = mx + logf(sum);
     }
-    VDK_WAVE_LDS_SYNC();                                  // V tile complete
     s16x8 vt[2][2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
       wa_stage_t(St[w], oa, 1.0f, qt, l31, hi);
     }
     VDK_WAVE_LDS_SYNC();
-    wa_flush_rows(St[w], Ri[w], o + h * WA_HD, ldo, lane);
+    wa_flush_rows(St[w], rr, o + h * WA_HD, ldo, lane);
   }
 }
 
@@ -205,8 +211,9 @@ __global__ __launch_bounds__(64 * WA_BW, WA_BWD_MINW) void window_attn_bwd_mfma_
   __shared__ __attribute__((aligned(16))) unsigned char Qt[WA_BW][64 * 64];
   __shared__ __attribute__((aligned(16))) unsigned char Gt[WA_BW][64 * 64];     // dO rows
   __shared__ __attribute__((aligned(16))) unsigned char Pt[WA_BW][64 * AS_ROW]; // P [q][key], then dS [q][key]
+  __shared__ __attribute__((aligned(16))) unsigned char Vt[WA_BW][64 * 64];
   __shared__ __attribute__((aligned(16))) unsigned char St[WA_BW][64 * WA_ST_PITCH];   // output staging
-  __shared__ long Ri[WA_BW][64];
+  __shared__ float Dl[WA_BW][64];                                                     // rowsum(dO * O)
   const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int C = H * WA_HD;
@@ -218,29 +225,36 @@ __global__ __launch_bounds__(64 * WA_BW, WA_BWD_MINW) void window_attn_bwd_mfma_
   for (int a = 0; a < 2; ++a) { dB[a][0] = as_zero16(); dB[a][1] = as_zero16(); }
   for (long win = slot; win < nwin; win += nslot) {
     const bf16_t* base = qkv + h * WA_HD;
-    long ri[2];
-    wa_rows(rowidx, win, l31, ri);
-    s16x8 qf[2][2], kf[2][2], vf[2][2], gf[2][2];
-    wa_row_frags(base, ld, ri, hi, qf);
-    wa_row_frags(base + C, ld, ri, hi, kf);
-    wa_row_frags(base + 2 * C, ld, ri, hi, vf);
-    wa_row_frags(dout + h * WA_HD, ldo, ri, hi, gf);
-    float D[2], l[2];
-    {
-      s16x8 of[2][2];
-      wa_row_frags(o + h * WA_HD, ldo, ri, hi, of);
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {                     // D = rowsum(dO * O) on the rounded tensors
-        float d = wa_dot8(gf[qt][0], of[qt][0]) + wa_dot8(gf[qt][1], of[qt][1]);
-        D[qt] = d + __shfl_xor(d, 32);
-        l[qt] = 32 * qt + l31 < WA_N ? lse[(win * H + h) * WA_N + 32 * qt + l31] : INFINITY;     // padded queries: P = exp(-inf) = 0
-      }
-    }
+    long rr[4];
+    wa_rows(rowidx, win, lane, rr);
     VDK_WAVE_LDS_SYNC();                                  // the previous window's readers are done
-    wa_put_rows(Kt[w], kf, l31, hi);
-    wa_put_rows(Qt[w], qf, l31, hi);
-    wa_put_rows(Gt[w], gf, l31, hi);
-    if (hi == 0) { Ri[w][l31] = ri[0]; Ri[w][32 + l31] = ri[1]; }
+    wa_dma_rows(Qt[w], base, ld, rr, lane);
+    wa_dma_rows(Kt[w], base + C, ld, rr, lane);
+    wa_dma_rows(Vt[w], base + 2 * C, ld, rr, lane);
+    wa_dma_rows(Gt[w], dout + h * WA_HD, ldo, rr, lane);
+    u32x4 orow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) orow[i] = *(const u32x4*)(o + h * WA_HD + rr[i] * ldo + 8 * (lane & 3));
+    float l[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) l[qt] = 32 * qt + l31 < WA_N ? lse[(win * H + h) * WA_N + 32 * qt + l31] : INFINITY;     // padded queries: P = exp(-inf) = 0
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the wave's DMAs have landed
+    VDK_WAVE_LDS_SYNC();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                          // D = rowsum(dO * O) on the rounded tensors: 8 products per lane, 4 lanes per row
+      const s16x8 gq = *(const s16x8*)(Gt[w] + i * 1024 + lane * 16);
+      float d = wa_dot8(gq, *(const s16x8*)&orow[i]);
+      d += __shfl_xor(d, 1);
+      d += __shfl_xor(d, 2);
+      if ((lane & 3) == 0) Dl[w][16 * i + (lane >> 2)] = d;
+    }
+    s16x8 qf[2][2], kf[2][2], vf[2][2], gf[2][2];
+    wa_row_frags(Qt[w], l31, hi, qf);
+    wa_row_frags(Kt[w], l31, hi, kf);
+    wa_row_frags(Vt[w], l31, hi, vf);
+    wa_row_frags(Gt[w], l31, hi, gf);
+    VDK_WAVE_LDS_SYNC();
+    const float D[2] = {Dl[w][l31], Dl[w][32 + l31]};
     const float* bmp = bm + ((win % nWm) * H + h) * WA_FRAG + lane * 16;
     s16x8 dsf[2][2][2];                                   // dS^T as B fragments [kt][qt][k-step]
 #pragma unroll
@@ -288,7 +302,7 @@ __global__ __launch_bounds__(64 * WA_BW, WA_BWD_MINW) void window_attn_bwd_mfma_
         wa_stage_t(St[w], acc, scale, qt, l31, hi);
       }
       VDK_WAVE_LDS_SYNC();
-      wa_flush_rows(St[w], Ri[w], dbase, ldd, lane);
+      wa_flush_rows(St[w], rr, dbase, ldd, lane);
     }
     // dV^T[d][key] = sum_q dO^T[d][q] P[q][key]
 #pragma unroll
@@ -301,7 +315,7 @@ __global__ __launch_bounds__(64 * WA_BW, WA_BWD_MINW) void window_attn_bwd_mfma_
       wa_stage_t(St[w], acc, 1.0f, kt, l31, hi);
     }
     VDK_WAVE_LDS_SYNC();                                  // P has been read: the tile takes dS
-    wa_flush_rows(St[w], Ri[w], dbase + 2 * C, ldd, lane);
+    wa_flush_rows(St[w], rr, dbase + 2 * C, ldd, lane);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -318,7 +332,7 @@ __global__ __launch_bounds__(64 * WA_BW, WA_BWD_MINW) void window_attn_bwd_mfma_
       wa_stage_t(St[w], acc, scale, kt, l31, hi);
     }
     VDK_WAVE_LDS_SYNC();
-    wa_flush_rows(St[w], Ri[w], dbase + C, ldd, lane);
+    wa_flush_rows(St[w], rr, dbase + C, ldd, lane);
   }
   float* dst = dbias_part + wid * WA_FRAG + lane * 16;
 #pragma unroll
