@@ -24,7 +24,7 @@
 
 // One wave per (window, head); the 49 tokens are padded to 64 = two 32-row MFMA tiles (v_mfma_f32_32x32x16_bf16, contraction over the head dim 32 = 2 steps).
 // Every product is computed TRANSPOSED so that the softmax axis lies on registers and the query on the lane:
-//     S^T[key][q] = K Q^T    (A = K rows, B = Q rows: both straight 16-byte row fragments from global memory)          C layout: lane = q, registers = keys
+//     S^T[key][q] = K Q^T    (A = K rows, B = Q rows: 16-byte row fragments of the LDS tiles the operands are DMA'd into)     C layout: lane = q, registers = keys
 //     O^T[d][q]   = V^T P^T  (A = V through the transposing LDS read, B = P^T: the C-layout registers packed to bf16)   C layout: lane = q, registers = d
 // bias + mask arrive pre-arranged in that C layout (wa_prep_bias_kernel: one f32x4 per 4 registers, -inf on the padded keys), so the padding costs no compares.
 // Backward, per (window, head): S^T and dP^T = V dO^T as above; dS^T = P^T (dP^T - D); dQ^T = K^T dS^T straight from the registers; dV^T = dO^T P and dK^T = Q^T dS contract
