@@ -113,7 +113,8 @@ def test_gemm256_lds_dma_kernel(be, dev, M, N, K, splitk, kern):
 
 
 @pytest.mark.parametrize("kern", [2, 5, 6])
-@pytest.mark.parametrize("K,M,N,splitk,rg", [(64, 256, 256, 1, 0), (192, 264, 136, 1, 0), (256, 72, 520, 2, 0), (128, 128, 192, 1, 16), (384, 520, 264, 1, 0), (512, 264, 136, 2, 0)])
+@pytest.mark.parametrize("K,M,N,splitk,rg", [(64, 256, 256, 1, 0), (192, 264, 136, 1, 0), (256, 72, 520, 2, 0), (128, 128, 192, 1, 16), (384, 520, 264, 1, 0), (512, 264, 136, 2, 0),
+                                             (1536, 520, 264, 3, 0)])      # 6 tiles x 3 splits = 18 items on the 1-D split-K grid: shares of 3, 3, 2, 2, ... per XCD
 def test_gemm_tn_from_kmajor_operands(be, dev, K, M, N, splitk, rg, kern):
     """wgrad form C = A^T B with A [K, M], B [K, N] read as they lie (ds_read_b64_tr_b16 fragments), incl. the token-row remap"""
     torch.manual_seed(6)

@@ -13,7 +13,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d /tmp/p_$c -o p --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-parity --no-cpu-baseline --no-cbir --no-cfg5 --no-swin > $O/pmc_${c}_stdout.txt 2>&1
 done
 F=$(find /tmp/p_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find /tmp/p_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-CALLS=$(python -c "import json;print(7 * json.loads(open('$O/pmc_FETCH_SIZE_stdout.txt').read().strip().splitlines()[-1])['roofline']['gemm_calls_per_step'])")
+CALLS=$(python -c "import json;print(7 * json.loads([l for l in open('$O/pmc_FETCH_SIZE_stdout.txt') if l.startswith('{\"metric\"')][-1])['roofline']['gemm_calls_per_step'])")
 python $R/tools/pmc_traffic.py "$F" "$W" gemm $O/pmc_traffic.json $CALLS > $O/pmc_traffic.txt 2>&1
 tail -3 $O/pmc_traffic.txt
 for c in FETCH_SIZE WRITE_SIZE; do
