@@ -156,6 +156,7 @@ int vdk_gemm_fp8_nt_q8(const VdkGemmDesc* d, int32_t a_fmt, int32_t b_fmt, const
 int vdk_gemm_c_colsum_rows(int32_t M, int32_t N, int32_t K);   /* rows of VdkGemmDesc.c_colsum, 0 = by-product not available for this problem */
 int vdk_gemm_a_colsum_rows(int32_t M, int32_t N, int32_t K);   /* rows of VdkGemmDesc.a_colsum, 0 = by-product not available for this problem */
 int vdk_gemm_force_kernel(int32_t which);
+int vdk_gemm_force_band_cw(int32_t cw);   /* tests: tile order of the one-wave-per-SIMD kernels in column bands of cw tile columns (-1: decided by size, the default) */
 /* tests / tuning: which structure served the calling thread's last vdk_gemm_bf16_nt / vdk_margin_cos_pass: 1 = 128x128 register-staged, 2 = 256x256 eight waves,
  * 3 = its stream-K form, 5 = 256x256 four waves (one per SIMD, persistent; gemm_w4.hip; the default for big problems; which = 5 forces it wherever it can
  * serve, environment VDK_GEMM_W4=0 disables it), 6 = 256x128 four waves with two workgroups per CU (gemm_w4h_kernel: the default for the long epilogues --

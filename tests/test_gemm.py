@@ -112,6 +112,24 @@ def test_gemm256_lds_dma_kernel(be, dev, M, N, K, splitk, kern):
         be.lib.vdk_gemm_force_kernel(0)
 
 
+@pytest.mark.parametrize("kern,cw", [(5, 1), (5, 2), (5, 3), (6, 2), (6, 3), (6, 5)])
+def test_gemm_column_band_tile_order(be, dev, kern, cw):
+    """the one-wave-per-SIMD kernels walk their tiles in column bands (an XCD stays inside a slice of B that fits its L2): every (row, column) tile is still served exactly
+    once, in bands of equal and of ragged width -- bit-equal to the plain order"""
+    torch.manual_seed(11)
+    M, N, K = 1300, 776, 128                     # 6 x 4 tiles of 256 x 256 (persistent walk: more tiles than the emulated CUs / forced) or 6 x 7 of 256 x 128
+    a = torch.randn(M, K).bfloat16().to(dev); b = torch.randn(N, K).bfloat16().to(dev); bias = torch.randn(N).to(dev)
+    be.lib.vdk_gemm_force_kernel(kern)
+    try:
+        ref = ops.gemm_nt(a, b, bias=bias, act=ops.ACT_GELU, backend=be)
+        assert be.lib.vdk_gemm_last_kernel() == kern
+        be.lib.vdk_gemm_force_band_cw(cw)
+        out = ops.gemm_nt(a, b, bias=bias, act=ops.ACT_GELU, backend=be)
+    finally:
+        be.lib.vdk_gemm_force_kernel(0); be.lib.vdk_gemm_force_band_cw(-1)
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+
+
 @pytest.mark.parametrize("kern", [2, 5, 6])
 @pytest.mark.parametrize("K,M,N,splitk,rg", [(64, 256, 256, 1, 0), (192, 264, 136, 1, 0), (256, 72, 520, 2, 0), (128, 128, 192, 1, 16), (384, 520, 264, 1, 0), (512, 264, 136, 2, 0),
                                              (1536, 520, 264, 3, 0)])      # 6 tiles x 3 splits = 18 items on the 1-D split-K grid: shares of 3, 3, 2, 2, ... per XCD

@@ -87,6 +87,7 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_gemm_a_colsum_rows": (C.c_int, [I32, I32, I32]),
     "vdk_gemm_c_colsum_rows": (C.c_int, [I32, I32, I32]),
     "vdk_gemm_force_kernel": (C.c_int, [I32]),
+    "vdk_gemm_force_band_cw": (C.c_int, [I32]),
     "vdk_gemm_last_kernel": (C.c_int, []),
     "vdk_gemm_reserve_cus": (C.c_int, [C.c_int32]),
     "vdk_debug_occupy_cus": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p]),

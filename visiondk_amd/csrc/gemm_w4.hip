@@ -521,6 +521,16 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------------------------------------------
+// Linear tile id -> (tile row, tile column).  An XCD works through a contiguous range of ids; in plain row-major order that range sweeps ALL tile columns every few
+// rows, i.e. the whole B operand (the weight matrix) again and again: at 4.7 MB (768 x 3072) it does not stay in the XCD's 4 MB L2 and streamed back from the Infinity
+// Cache once per round (PMC: the fc1 GEMM fetched 469 MB for 82 MB of operands, the dGELU GEMM 1134 MB for 392 MB).  With the ids ordered by COLUMN BANDS of `cw`
+// tile columns (row-major inside a band) an XCD stays inside one band whose slice of B fits its L2; the price is that every A row panel is read once per band.
+__device__ __forceinline__ void w4_tile_rc(int tile, int ntn, int ntm, int cw, int& tm, int& tn) {
+  if (cw <= 0 || cw >= ntn) { tm = tile / ntn; tn = tile - tm * ntn; return; }
+  const int per = ntm * cw, band = tile / per, rem = tile - band * per;
+  const int wdt = ntn - band * cw < cw ? ntn - band * cw : cw;          // (the last band may be narrower)
+  tm = rem / wdt; tn = band * cw + rem - tm * wdt;
+}
 // PERSIST: gridDim.x workgroups (a multiple of 8, at most one per CU) walk the output tiles; workgroup b serves the tiles start(x) + s, + s + G/8, ... of its
 // XCD's contiguous share (x = b & 7, s = b >> 3): at any time an XCD's workgroups multiply G/8 consecutive tiles, which share A row panels / the weight matrix
 // in that XCD's L2.  Otherwise: one tile per workgroup (blockIdx.x, same XCD raster) and blockIdx.y = split-K slice.
@@ -568,8 +578,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
   int c_idx = t_idx, c_left = nk;
   unsigned c_ta, c_tb, c_ka = da.kbeg, c_kb = db.kbeg;
   {
-    const int tile = t_start + c_idx;
-    c_ta = w4_tile_base<TN>(da, (tile / ntn) * 256); c_tb = w4_tile_base<TN>(db, (tile % ntn) * 256);
+    int tm_, tn_; w4_tile_rc(t_start + c_idx, ntn, ntm, p.band_cw, tm_, tn_);
+    c_ta = w4_tile_base<TN>(da, tm_ * 256); c_tb = w4_tile_base<TN>(db, tn_ * 256);
   }
 #define W4_CURSOR_ADVANCE()                                                                                         \
   do {                                                                                                              \
@@ -577,8 +587,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
     if (--c_left == 0) {                                                                                            \
       c_idx += t_stride; c_ka = da.kbeg; c_kb = db.kbeg;                                                            \
       if (c_idx < t_cnt) {                                                                                          \
-        const int tile_ = t_start + c_idx;                                                                          \
-        c_ta = w4_tile_base<TN>(da, (tile_ / ntn) * 256); c_tb = w4_tile_base<TN>(db, (tile_ % ntn) * 256);         \
+        int tm_, tn_; w4_tile_rc(t_start + c_idx, ntn, ntm, p.band_cw, tm_, tn_);                                   \
+        c_ta = w4_tile_base<TN>(da, tm_ * 256); c_tb = w4_tile_base<TN>(db, tn_ * 256);                             \
         c_left = nk;                                                                                                \
       } else { c_ta = W4_OOB; c_tb = W4_OOB; c_left = 0x7fffffff; }                                                 \
     }                                                                                                               \
@@ -629,8 +639,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
                  : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[1][3]),
                    "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]), "+a"(acc[3][3]));
 #endif
-    const int tile = t_start + t_idx;
-    const int tn = tile % ntn, tm = tile / ntn;
+    int tm, tn; w4_tile_rc(t_start + t_idx, ntn, ntm, p.band_cw, tm, tn);
     unsigned long long ts[5] = {0, 0, 0, 0, 0};
     w4_epilogue<E, 4, 4>(p, smem + W4_STAGE + w * 8192, acc, lane, wr, wc, tm * 256, tn * 256, z, tm, ts);
     if (p.dbg && tid == 0 && dbg_i < 8) {   // debug only: shader-cycle stamps of this workgroup's first 8 tiles: top, main loop done, epilogue issued
@@ -727,7 +736,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w4h_kernel(GemmParams p) {
     const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tn = tile % ntn, tm = tile / ntn;
+  int tm, tn; w4_tile_rc(tile, ntn, ntm, p.band_cw, tm, tn);
   const int m0 = tm * 256, n0 = tn * 128;
   const int kbeg = z * p.k_per_split;
   int kend = kbeg + p.k_per_split; if (kend > p.K) kend = p.K;
@@ -916,10 +925,27 @@ bool vdk_gemm_w4_launch(const GemmParams& p, bool trans, int E, unsigned tiles, 
   return w4_launch_one(p, trans, E, tiles, splitk, stream, ev0, ev1);
 }
 
+// column-band width of the tile order (0: plain row-major): band when the re-streamed B operand costs more than the repeated A panels.  tile_n: 256 or 128;
+// G: workgroups in flight (one round)
+static int g_force_band_cw = -1;
+extern "C" int vdk_gemm_force_band_cw(int32_t cw) { g_force_band_cw = cw; return VDK_OK; }   /* tests: the band order on small problems (-1: the size rule) */
+static int w4_band_cw(const GemmParams& p, bool trans, unsigned tiles, unsigned G, int tile_n) {
+  if (g_force_band_cw >= 0) return (trans || p.conv_on) ? 0 : g_force_band_cw;
+  static const bool on = [] { const char* e = getenv("VDK_GEMM_BANDS"); return !(e && e[0] == '0'); }();
+  if (!on || trans || p.conv_on) return 0;
+  const double bbytes = (double)p.N * p.K * 2.0, abytes = (double)p.M * p.K * 2.0;
+  if (bbytes <= 2.0e6) return 0;                                       // B stays in an XCD's L2 anyway
+  const int ntn = (p.N + tile_n - 1) / tile_n;
+  int nb = (int)((bbytes + 2.0e6 - 1.0) / 2.0e6); if (nb > ntn) nb = ntn;
+  const double rounds = (double)tiles / (double)G;
+  if (nb < 2 || 8.0 * bbytes * (rounds - 1.0) <= (nb - 1) * abytes) return 0;
+  return (ntn + nb - 1) / nb;
+}
 static bool w4_sk_xcd() { static const bool v = [] { const char* e = getenv("VDK_GEMM_SK_XCD"); return !(e && e[0] == '0'); }(); return v; }
 static bool w4_launch_one(const GemmParams& p_, bool trans, int E, unsigned tiles, unsigned splitk, hipStream_t stream, void* ev0, void* ev1) {
   GemmParams p = p_;
   p.sk_xcd = (splitk > 1 && E == E_SPLITK && w4_sk_xcd()) ? 1 : 0;
+  p.band_cw = splitk == 1 ? w4_band_cw(p, trans, tiles, (unsigned)w4_cus(), 256) : 0;
   const unsigned items = tiles * splitk;
   const dim3 grid = p.sk_xcd ? dim3(8u * ((items + 7u) / 8u), 1u) : dim3(tiles, splitk);
   const unsigned G = (unsigned)w4_cus();
@@ -966,6 +992,7 @@ bool vdk_gemm_w4h_launch(const GemmParams& p_, bool trans, int E, unsigned split
   hipStream_t stream = (hipStream_t)stream_;
   GemmParams p = p_;
   const dim3 grid((unsigned)(((p.M + 255) / 256) * ((p.N + 127) / 128)), splitk);
+  p.band_cw = splitk == 1 ? w4_band_cw(p, trans, grid.x, 2u * (unsigned)w4_cus(), 128) : 0;
   {
     // start delay of the second slot's first workgroups: half of (prologue + main loop at ~2400 cycles per k-tile with a shared pipe + epilogue estimate)
     static const int stag_pct = getenv("VDK_GEMM_W4H_STAGGER") ? atoi(getenv("VDK_GEMM_W4H_STAGGER")) : 0;   // measured null to -2 % at 50 / 100 / 150 % (tools/w4h_stagger_ab.py): the pair drifts apart by itself; opt-in

@@ -30,6 +30,7 @@ struct GemmParams {
   unsigned char* q8; long ldq8; const float* q8_scale; float* q8_amax; int q8_fmt;
   MarginEpi me;              // E_MSTAT / E_MGRAD epilogues (margin-softmax head: cos tiles never leave the registers as fp32)
   unsigned long long* dbg;   // debug only: 4 cycle stamps per workgroup (start, operands landed, main loop done, end)
+  int band_cw;               // gemm_w4_kernel / gemm_w4h_kernel: tile order = column bands of band_cw tile columns, row-major inside a band (0: plain row-major)
   int sk_xcd;                // gemm_w4_kernel, split-K: 1-D grid, a slab's tiles stay on one XCD (see the kernel); 0: grid (tiles, splits)
   int stagger, stagger_lo;   // gemm_w4h_kernel: workgroups stagger_lo .. 2 * stagger_lo - 1 start `stagger` shader cycles late (0: nobody)
 };
