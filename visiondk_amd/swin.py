@@ -6,7 +6,8 @@ models/classifier/classify_model.py:49-54 and models/faceX/backbone/timm_wrapper
 against transformers.SwinModel), so reference checkpoints load.  First form of this family here: the model is a torch Module whose arithmetic runs in autograd nodes over
 the library's kernels -- LayerNorm (`vdk_layernorm_fwd/bwd`), every Linear on the bf16 MFMA GEMM with its bias / GELU / residual epilogues (`vdk_gemm_bf16_nt`, weight
 gradients in the TN form), the 49-token window attention with relative-position bias and shifted-window masks (`vdk_window_attention_fwd/bwd`), the pooled head on the fp32
-MFMA.  Window partition, cyclic shift and patch merging are index permutations (views / copies, no arithmetic).  Arithmetic = the reference's autocast path: bf16 operands,
+MFMA.  The window partition and the cyclic shift are a row index the attention kernels follow (`rowidx`: the token rows stay in image order, no gather copies); patch
+merging is an index permutation.  Arithmetic = the reference's autocast path: bf16 operands,
 fp32 accumulation, fp32 residual stream and master weights.  A native one-call engine like the ViT's (flat parameter space, fused optimizer) is the next step for this family.
 """
 from __future__ import annotations
@@ -19,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from ._abi import ACT_DGELU, ACT_GELU, ACT_NONE
+from ._abi import ACT_DGELU, ACT_GELU
 
 WS = 7
 N = WS * WS
@@ -48,11 +49,6 @@ TIMM_SWINS = {
 def _partition(x: torch.Tensor, ws: int) -> torch.Tensor:          # [B, H, W, C] -> [B * nW * ws * ws, C]
     B, H, W, Cc = x.shape
     return x.view(B, H // ws, ws, W // ws, ws, Cc).permute(0, 1, 3, 2, 4, 5).reshape(-1, Cc)
-
-
-def _reverse(w: torch.Tensor, ws: int, B: int, H: int, W: int) -> torch.Tensor:
-    Cc = w.shape[-1]
-    return w.view(B, H // ws, W // ws, ws, ws, Cc).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, Cc)
 
 
 def _rel_index(ws: int) -> torch.Tensor:
