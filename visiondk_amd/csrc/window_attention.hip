@@ -2,7 +2,7 @@
 // configs of the reference (`timm-swin_base_patch4_window7_224`: configs/classification/pet.yaml:25, configs/faceX/cbir.yaml:26; built by timm.create_model in
 // models/classifier/classify_model.py:49-54 and models/faceX/backbone/timm_wrapper.py:16-21).  Per (window, head):
 //     S = (q * hd^-0.5) k^T + bias[head] (+ mask[window mod nW]);   P = softmax(S);   o = P v            N = 49 tokens (7 x 7), head dim 32
-// qkv: bf16 [W * N, 3 C] rows in (window, token) order, q | k | v thirds, head h at columns h * 32; bias f32 [H, N, N] (the relative-position table gathered once per
+// qkv: bf16 [W * N, 3 C] rows in (window, token) order or reached through a row index, q | k | v thirds, head h at columns h * 32; bias f32 [H, N, N] (the relative-position table gathered once per
 // step by the host side); mask f32 [nW, N, N] (0 / -100 of the shifted windows) or NULL.  Arithmetic as under the reference's autocast: bf16 operands, fp32 products and
 // sums, softmax in fp32, P rounded to bf16 once as the left operand of P v, o rounded to bf16.
 //
@@ -55,8 +55,8 @@ __global__ __launch_bounds__(256) void wa_unprep_dbias_kernel(const float* __res
 // Row traffic.  A lane moves 16 bytes of row 16 i + (lane >> 2), i = 0..3 (4 lanes per 64-byte head slice of a token row, 16 rows per instruction): the operands come
 // in by LDS-DMA into [64][32] bf16 tiles (64-byte rows) and the outputs leave the same way round (wa_flush_rows).  Tokens >= 49 read token 48 (finite filler).
 // rowidx (optional): token j of window w lives in tensor row rowidx[w * 49 + j] -- the (shifted) window partition as an index instead of gather copies either side of the
-// attention.  (Row fragments straight from global memory -- 16 bytes per lane from 32 different rows per instruction -- kept the L1 / address path busier than the
-// MFMAs: swin_base step 36.2 ms against 35.5 ms with the loads aimed at 16 rows x 64 contiguous bytes in a placement-wrong timing probe.)
+// attention.  (Row fragments straight from global memory are 16 bytes per lane from 32 different rows per instruction; this form and the staged stores below together
+// measured 36.24 -> 35.96 ms per swin_base step on one box.  The kernels move a layer's qkv / dO / o / dqkv once and run within 1.8x of that byte floor, DESIGN.md.)
 __device__ __forceinline__ void wa_rows(const int* __restrict__ rowidx, long win, int lane, long (&rr)[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -99,10 +99,9 @@ __device__ __forceinline__ void wa_put_pt(unsigned char* tile, const s16x8 (&f)[
     *(u32x2*)(tile + row * AS_ROW + (((4 * kt + 2 * s + 1) ^ as_f(row)) << 4) + 8 * hi) = (u32x2){u[2], u[3]};
   }
 }
-// Output rows.  A C-layout tile of a transposed product has lane = token row, registers = head-dim columns: storing it straight from the registers is 8 bytes per lane into
-// 32 different rows per instruction, and the L1 / address path -- not the MFMAs -- then bounds the kernels (swin_base step 36.2 ms; 34.4 ms with the same stores aimed at
-// 8 rows x 64 contiguous bytes, a placement-wrong timing probe).  So the two tiles of an output go through a [64][32] bf16 staging tile in LDS (80-byte pitch: the 8-byte
-// writes of 16 consecutive rows fall on distinct bank pairs) and leave as 16-byte stores, 4 lanes per 64-byte row.
+// Output rows.  A C-layout tile of a transposed product has lane = token row, registers = head-dim columns: stored straight from the registers that is 8 bytes per lane
+// into 32 different rows per instruction.  The two tiles of an output go through a [64][32] bf16 staging tile in LDS instead (80-byte pitch: the 8-byte writes of 16
+// consecutive rows fall on distinct bank pairs) and leave as 16-byte stores, 4 lanes per 64-byte row.
 #define WA_ST_PITCH 80
 __device__ __forceinline__ void wa_stage_t(unsigned char* st, const f32x16& x, float mul, int t, int l31, int hi) {
 #pragma unroll
