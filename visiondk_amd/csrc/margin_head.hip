@@ -226,7 +226,9 @@ __global__ __launch_bounds__(256) void margin_ce_kernel(MarginP P, const float* 
 }
 // Training form (no logits output) for wide heads: the same arithmetic with 16-byte loads, four of them in flight per thread (a 4-byte strided loop keeps
 // ~1 KB in flight per workgroup: 1 TB/s at C = 10^6), and an online softmax so that cos is read twice instead of three times.
-#define MCE_U 4
+#ifndef MCE_U
+#define MCE_U 4   // (8 in flight measured the same: 107.8 ms per cfg3 step either way -- the kernel is bound by its arithmetic, not by bytes in flight)
+#endif
 // v_exp_f32 on x * log2(e): 2 instructions against libm expf's ~12 (range reduction + polynomial); relative error ~2^-22 on |x| < 90, i.e. inside the rounding of the
 // softmax sums.  The narrow-head kernel above (golden-vector comparisons) keeps expf.
 __device__ __forceinline__ float vexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
