@@ -324,6 +324,9 @@ int vdk_window_attention_bwd_workspace_bytes(int64_t windows, int32_t nW, int32_
 int vdk_window_attention_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, const float* bias, const float* mask, int32_t nW,
                              int64_t windows, int32_t H, int32_t N, int32_t hd, float scale, const int32_t* rowidx, void* dqkv, int64_t ldd, float* dbias, void* ws,
                              size_t ws_bytes, void* stream);
+/* backward of timm's bias gather relative_position_bias_table[relative_position_index] -> [H, N, N]: dtable f32 [R, H] = sum over the positions (uses int32 [R, U], -1
+ * padded, list order) of dbias f32 [H, NN]: a deterministic gather per table entry instead of an index_add */
+int vdk_relpos_bias_table_grad(const float* dbias, const int32_t* uses, int32_t R, int32_t U, int32_t H, int32_t NN, float* dtable, void* stream);
 /* elementwise / reduction pieces of the fp32-class TRAINING path of the face / CBIR task (the reference runs that loop without autocast, engine/procedure/train.py:217-227):
  * exact-erf GELU and its derivative with the library erff / expf, a row scale (ConvNeXt layer scale folded into fc2), deterministic column sums of an f32 tensor
  * (bias gradients) and the inverse of vdk_space_to_depth2_f32 */

@@ -149,6 +149,7 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_softmax_rows_f32": (C.c_int, [P, I64, I64, I32, C.c_float, P]),
     "vdk_window_attention_fwd": (C.c_int, [P, I64, P, I64, P, P, P, I32, I64, I32, I32, I32, F32, P, P, SZ, P]),
     "vdk_window_attention_fwd_workspace_bytes": (C.c_int, [I32, I32, PSZ]),
+    "vdk_relpos_bias_table_grad": (C.c_int, [P, P, I32, I32, I32, I32, P, P]),
     "vdk_window_attention_bwd_workspace_bytes": (C.c_int, [I64, I32, I32, PSZ]),
     "vdk_window_attention_bwd": (C.c_int, [P, I64, P, P, I64, P, P, P, I32, I64, I32, I32, I32, F32, P, P, I64, P, P, SZ, P]),
     "vdk_gelu_f32": (C.c_int, [P, P, I64, P]),

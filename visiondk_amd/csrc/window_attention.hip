@@ -342,6 +342,17 @@ __global__ __launch_bounds__(64 * WA_BW, WA_BWD_MINW) void window_attn_bwd_mfma_
       for (int g = 0; g < 4; ++g) *(f32x4*)(dst + (qt * 2 + kt) * 1024 + 4 * g) = (f32x4){dB[kt][qt][4 * g], dB[kt][qt][4 * g + 1], dB[kt][qt][4 * g + 2], dB[kt][qt][4 * g + 3]};
 }
 
+// d(relative_position_bias_table)[r][h] = sum of d(bias)[h][pos] over the positions pos of the 49 x 49 map that read table entry r (uses[r][0..U), -1 = none), in list
+// order: a gather per output, no atomics (timm gathers the table with relative_position_index; its backward is an index_add)
+__global__ __launch_bounds__(256) void wa_table_grad_kernel(const float* __restrict__ dbias, const int* __restrict__ uses, int R, int U, int H, int NN, float* __restrict__ dtable) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * H) return;
+  const int r = i / H, h = i - r * H;
+  float s = 0.f;
+  for (int u = 0; u < U; ++u) { const int pos = uses[r * U + u]; if (pos >= 0) s += dbias[(long)h * NN + pos]; }
+  dtable[i] = s;
+}
+
 extern "C" {
 
 int vdk_reduce_rows_f32(const float*, int64_t, int32_t, int64_t, float*, float, void*);
@@ -416,6 +427,14 @@ int vdk_window_attention_bwd(const void* qkv, int64_t ld, const void* o, const v
   const long n = (long)H * WA_N * WA_N;
   hipLaunchKernelGGL(wa_unprep_dbias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)red, (int)H, dbias);
   return vdk_check_launch("vdk_window_attention_bwd");
+}
+
+/* backward of the bias gather bias[h][q][k] = table[index[q][k]][h]: dtable f32 [R, H] from dbias f32 [H, NN]; uses int32 [R, U]: the positions q * N + k whose index is r
+ * (-1 padded), summed in list order */
+int vdk_relpos_bias_table_grad(const float* dbias, const int32_t* uses, int32_t R, int32_t U, int32_t H, int32_t NN, float* dtable, void* stream) {
+  if (!dbias || !uses || !dtable || R <= 0 || U <= 0 || H <= 0 || NN <= 0) return vdk_fail(VDK_EINVAL, "vdk_relpos_bias_table_grad: bad argument");
+  hipLaunchKernelGGL(wa_table_grad_kernel, dim3((unsigned)((R * H + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dbias, (const int*)uses, (int)R, (int)U, (int)H, (int)NN, dtable);
+  return vdk_check_launch("vdk_relpos_bias_table_grad");
 }
 
 }  // extern "C"

@@ -239,8 +239,8 @@ class _WinAttn(torch.autograd.Function):
 
 
 class _BiasGather(torch.autograd.Function):
-    """relative_position_bias_table [169, H] -> bias [H, 49, 49] (an index gather); the backward sums each table entry's <= 49 uses with the row-reduction kernel in a
-    fixed order (an index_add would use atomics)"""
+    """relative_position_bias_table [169, H] -> bias [H, 49, 49] (an index gather); the backward sums each table entry's <= 49 uses in a fixed order with one gather kernel
+    (timm's index backward is an index_add with atomics)"""
 
     @staticmethod
     def forward(ctx, table, index, uses, be):
@@ -249,11 +249,12 @@ class _BiasGather(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dbias):
-        H = dbias.shape[0]
-        flat = torch.cat([dbias.reshape(H, N * N), torch.zeros((H, 1), dtype=dbias.dtype, device=dbias.device)], 1)      # slot N*N = 0 for the padding of `uses`
-        g = flat[:, ctx.uses]                                   # [H, 169, 49]: the uses of every table entry
-        g = g.permute(2, 1, 0).contiguous().view(N, -1)         # [49, 169 * H]
-        return ops.reduce_rows(g, backend=ctx.be).view(ctx.shape), None, None, None
+        be, uses = ctx.be, ctx.uses
+        R, H = ctx.shape
+        dbias = dbias.contiguous()
+        dtable = torch.empty((R, H), dtype=torch.float32, device=dbias.device)
+        be.check(be.lib.vdk_relpos_bias_table_grad(be.ptr(dbias), be.ptr(uses), R, uses.shape[1], H, N * N, be.ptr(dtable), be.stream()), "vdk_relpos_bias_table_grad")
+        return dtable, None, None, None
 
 
 class _Pool(torch.autograd.Function):
@@ -288,11 +289,11 @@ class WindowAttention(nn.Module):
         nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
         idx = _rel_index(WS)
         self.register_buffer("relative_position_index", idx.to(dev), persistent=False)
-        uses = torch.full(((2 * WS - 1) ** 2, N), N * N, dtype=torch.long)          # for the gather's backward: where each table entry is used (padded with the zero slot)
+        uses = torch.full(((2 * WS - 1) ** 2, N), -1, dtype=torch.int32)            # for the gather's backward: where each table entry is used (-1 padded)
         flat = idx.view(-1)
         for r in range((2 * WS - 1) ** 2):
             pos = (flat == r).nonzero().view(-1)
-            uses[r, :pos.numel()] = pos
+            uses[r, :pos.numel()] = pos.to(torch.int32)
         self.register_buffer("_uses", uses.to(dev), persistent=False)
         self.qkv = nn.Linear(dim, 3 * dim, device=dev)
         self.proj = nn.Linear(dim, dim, device=dev)
