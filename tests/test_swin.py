@@ -188,3 +188,28 @@ def test_get_model_builds_the_shipped_cbir_config_shape(be, dev):
     torch.nn.functional.cross_entropy(logits, y).backward()
     missing = [n for n, p in model.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
     assert not missing, missing
+
+
+def test_relpos_table_grad_matches_index_add(be, dev):
+    """d(table) of bias = table[index] as the library's gather (one thread per (entry, head), uses in list order) against torch's index_add"""
+    from visiondk_amd.swin import WindowAttention, _BiasGather
+    torch.manual_seed(3)
+    heads = 3
+    wa = WindowAttention(32 * heads, heads, be, dev)
+    table = torch.randn(169, heads, device=dev, requires_grad=True)
+    g = torch.randn(heads, 49, 49, device=dev)
+    _BiasGather.apply(table, wa.relative_position_index, wa._uses, be).backward(g)
+    ref = torch.zeros(169, heads).index_add_(0, wa.relative_position_index.view(-1).cpu(), g.cpu().permute(1, 2, 0).reshape(-1, heads))
+    assert _rel(table.grad, ref) < 1e-6
+
+
+def test_window_attention_rejects_what_it_does_not_serve(be, dev):
+    """error behaviour at the C ABI: other window sizes / head dims are VDK_EUNSUPPORTED (the host side raises), a short workspace is VDK_EWORKSPACE, nothing is launched"""
+    from visiondk_amd import _abi
+    qkv = torch.zeros(49 * 2, 192, dtype=torch.bfloat16, device=dev); o = torch.zeros(49 * 2, 64, dtype=torch.bfloat16, device=dev)
+    bias = torch.zeros(1, 49, 49, device=dev); ws = torch.zeros(1 << 16, dtype=torch.uint8, device=dev)
+    call = lambda N, hd, nbytes: be.lib.vdk_window_attention_fwd(be.ptr(qkv), 192, be.ptr(o), 64, None, be.ptr(bias), None, 0, 2, 1, N, hd, 0.17, None, be.ptr(ws), nbytes, be.stream())
+    assert call(49, 32, ws.numel()) == 0
+    assert call(64, 32, ws.numel()) == _abi.EUNSUPPORTED and call(49, 64, ws.numel()) == _abi.EUNSUPPORTED
+    rc = call(49, 32, 1024)
+    assert rc != 0 and rc != _abi.EUNSUPPORTED and b"workspace" in be.lib.vdk_last_error()
