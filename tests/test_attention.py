@@ -166,3 +166,30 @@ def test_attention_streaming_kernels_at_short_n(be, dev, B, N, H, monkeypatch):
     assert _rel(lse, lseref) < 1e-5 and _rel(o.float(), oref) < 6e-3
     assert _rel(o.float(), o_s.float()) < 6e-3
     assert _rel(d.float(), d_s.float()) < 2e-3
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 17, 2), (1, 50, 1), (2, 64, 1), (1, 197, 2), (3, 100, 1), (1, 224, 1)])
+@pytest.mark.parametrize("grid", [0, 2])
+def test_attention_bwd_one_pass_form(be, dev, B, N, H, grid, monkeypatch):
+    """VDK_ATTN_BWD_FORM=4: the one-pass backward (wave = key tile, query tiles in the outer loop, partial dQ tiles handed to a reducer wave).  dK / dV are the two-kernel
+    form's arithmetic bit for bit; dQ is the same products summed key tile by key tile (fp32) instead of inside one accumulator: equal to rounding.  grid = 2: a workgroup
+    walks over several (batch, head) items."""
+    torch.manual_seed(5)
+    D = H * 64
+    qkv = (torch.randn(B, N, 3 * D) * 1.4).bfloat16()
+    qkv[0, N // 2, :D] *= 3.0
+    qkv = qkv.to(dev)
+    dout = torch.randn(B, N, D).bfloat16().to(dev)
+    o, lse = ops.attention_fwd(qkv, H, backend=be)
+    ref = ops.attention_bwd(qkv, o, dout, lse, H, backend=be)          # the default two-kernel form
+    if grid:
+        monkeypatch.setenv("VDK_ATTN_GRID", str(grid))
+    monkeypatch.setenv("VDK_ATTN_BWD_FORM", "4")
+    got = ops.attention_bwd(qkv, o, dout, lse, H, backend=be)
+    monkeypatch.delenv("VDK_ATTN_BWD_FORM")
+    assert torch.equal(got[..., D:], ref[..., D:])                      # dK, dV
+    assert _rel(got[..., :D].float(), ref[..., :D].float()) < 3e-3      # dQ: bf16 outputs of two summation orders
+    qr = qkv.float().requires_grad_(True)
+    oref, _ = _ref(qr, H)
+    oref.backward(dout.float())
+    assert _rel(got[..., :D].float(), qr.grad[..., :D]) < 1.5e-2

@@ -611,6 +611,171 @@ __global__ __launch_bounds__(256, 2) void attn_s_bwd_q_kernel(const bf16_t* __re
   }
 }
 
+// =====================================================================================  backward (one pass: 5 GEMM-equivalents, no recomputation)  [form 4]
+// BUILT AND PARITY-TESTED ON THE EMULATOR, NOT YET MEASURED ON THE MI355X (the round's GPU minutes were spent): opt-in through VDK_ATTN_BWD_FORM=4.
+// A workgroup of 8 waves per (batch, head); wave w < nt owns KEY tile w for the whole item (its K / V row fragments stay in registers, its K tile also lies in LDS for the
+// transposing reads), wave 7 is the dQ reducer.  The query tiles go by in the OUTER loop (Q_j / dO_j arrive by DMA into a double-buffered 2 x 8 KB), so that
+//   * S = Q_j K^T and dP = dO_j V^T are computed once, with the key on the lane, and dV^T / dK^T accumulate in registers straight from the packed P / dS (the kv kernel's
+//     arithmetic, bit for bit);
+//   * dQ_j -- the one product that contracts over the key, i.e. over lanes and over WAVES -- is formed per wave from its 32 x 32 dS (transposed through 2 KB of LDS) as
+//     a partial dQ_j^T tile in the C layout (8 KB fp32), handed to the reducer through the wave's slot and summed there in wave order (deterministic), one rounding at the
+//     store.  The reducer works on tile j while the key waves are already in tile j + 1; two barriers per query tile.
+// LDS: 16 KB (Q_j, dO_j x 2) + 28 KB (K tiles) + 56 KB (partials) + 14 KB (dS transposes) + 32 KB (store tiles) + lse / D = 148 KB: one workgroup per CU, seven
+// independent MFMA streams.
+__device__ __forceinline__ s16x8 as_tr_frag64(const unsigned char* tile, int t1, int lane) {     // transposed fragment of a 64-byte-row tile (no swizzle): lane = column l31
+  const int s = lane & 15, chalf = (lane >> 4) & 1, hi = lane >> 5;
+  const unsigned char* p1 = tile + (t1 + 4 * hi + (s >> 2)) * 64 + 32 * chalf + 8 * (s & 3);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(p1));
+  s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(p1 + 8 * 64));
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+  return r;
+}
+template <int NKT>
+__global__ __launch_bounds__(512) void attn_s_bwd1p_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld,
+                                                           const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, long ldo, const float* __restrict__ lse,
+                                                           bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long ldd, int N, int H, float scale,
+                                                           int nitems) {
+  VDK_DYN_LDS(smem);
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NP = 32 * NKT;
+  constexpr int NPC = (NP * 8 + 511) / 512;
+  unsigned char* const QO = smem;                                     // [buffer 2][Q | dO][32 rows x 128 B]
+  unsigned char* const Kt = smem + 16384 + w * 4096;                  // this wave's K tile (waves < nt)
+  unsigned char* const Part = smem + 16384 + 7 * 4096;                // [7][8 KB] partial dQ^T tiles, C layout
+  unsigned char* const DsT = Part + 7 * 8192 + w * 2048;              // this wave's dS [key][q] bf16, 64-byte rows
+  unsigned char* const Wt = Part + 7 * 8192 + 7 * 2048 + w * 4096;    // this wave's store tile
+  float* const lse2 = (float*)(Part + 7 * 8192 + 7 * 2048 + 8 * 4096);
+  float* const Dv = lse2 + NP;
+  const int nt = (N + 31) >> 5;
+  const float scale2 = scale * VDK_LOG2E;
+  const bool ragged = (N & 31) != 0;
+  const AsLane al = as_lane(lane);
+  const bool keyw = w < nt;                                           // (wave-uniform)
+  // one DMA instruction per wave fills a quarter of one operand's 32-row tile: waves 0..3 Q, 4..7 dO
+  auto request_tile = [&](int j, int buf, long off, long offo) {
+    const int q0 = j * 32, part = w & 3;
+    if (w < 4) as_dma_rows(QO + buf * 8192, q + off + (long)q0 * ld, ld, N - q0, 32, part, 4, lane);
+    else as_dma_rows(QO + buf * 8192 + 4096, dout + offo + (long)q0 * ldo, ldo, N - q0, 32, part, 4, lane);
+  };
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / H, h = item - b * H;
+    const long off = (long)b * N * ld + h * 64, offo = (long)b * N * ldo + h * 64;
+    __syncthreads();                                                  // the previous item is finished everywhere
+    request_tile(0, 0, off, offo);
+    s16x8 kf[4], vf[4];
+    if (keyw) {
+      as_dma_rows(Kt, k + off + (long)(w * 32) * ld, ld, N - w * 32, 32, 0, 1, lane);
+      const int krow = w * 32 + l31;
+      const long kr = (long)(krow < N ? krow : N - 1) * ld;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { kf[ks] = *(const s16x8*)(k + off + kr + ks * 16 + hi * 8); vf[ks] = *(const s16x8*)(v + off + kr + ks * 16 + hi * 8); }
+    }
+    // D = rowsum(dO * O) on the rounded tensors, straight from global memory: 8 lanes per row
+#pragma unroll
+    for (int p = 0; p < NPC; ++p) {
+      const int id = tid + 512 * p, row = id >> 3, cp = id & 7;
+      float d = 0.f;
+      if (row < N) {
+        const u32x4 a = *(const u32x4*)(dout + offo + (long)row * ldo + cp * 8), c = *(const u32x4*)(o + offo + (long)row * ldo + cp * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { d = fmaf(bf_lo(a[e]), bf_lo(c[e]), d); d = fmaf(bf_hi(a[e]), bf_hi(c[e]), d); }
+      }
+      d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
+      if (row < NP && cp == 0) Dv[row] = row < N ? d : 0.f;
+    }
+    for (int i = tid; i < NP; i += 512) lse2[i] = i < N ? lse[((long)b * H + h) * N + i] * VDK_LOG2E : 0.f;
+    f32x16 gk0 = as_zero16(), gk1 = as_zero16(), gv0 = as_zero16(), gv1 = as_zero16();
+    __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0)
+    __syncthreads();
+    for (int j = 0; j < nt; ++j) {
+      const int q0 = j * 32, buf = j & 1;
+      const unsigned char* Qs = QO + buf * 8192;
+      const unsigned char* Os = Qs + 4096;
+      if (j + 1 < nt) request_tile(j + 1, buf ^ 1, off, offo);        // (that buffer's readers passed the barrier that closed tile j - 1)
+      f32x16 pq0 = as_zero16(), pq1 = as_zero16();
+      if (keyw) {
+        f32x16 st = as_zero16(), dp = as_zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Qs, al, ks), kf[ks], st, 0, 0, 0);   // S[q][key]: lane = key, registers = queries
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Os, al, ks), vf[ks], dp, 0, 0, 0);   // dP[q][key]
+        }
+        f32x16 pv, ds;
+        const bool edge = ragged && j == nt - 1;                      // rows of the last query tile beyond N (the DMA filled them with row N - 1): silenced
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 lv = *(const f32x4*)(lse2 + q0 + 8 * g + 4 * hi);
+          const f32x4 dd = *(const f32x4*)(Dv + q0 + 8 * g + 4 * hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            float p = fast_exp2(fmaf(st[r], scale2, -lv[e]));
+            if (edge && q0 + 8 * g + 4 * hi + e >= N) p = 0.f;
+            pv[r] = p;
+            ds[r] = p * (dp[r] - dd[e]);
+          }
+        }
+        s16x8 pf[2], df[2];
+        as_pack_b(pv, pf);
+        as_pack_b(ds, df);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          gv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Os + 16 * s2 * AS_ROW, al, 0), pf[s2], gv0, 0, 0, 0);     // dV^T[d][key] += dO^T P
+          gv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Os + 16 * s2 * AS_ROW, al, 1), pf[s2], gv1, 0, 0, 0);
+          gk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Qs + 16 * s2 * AS_ROW, al, 0), df[s2], gk0, 0, 0, 0);     // dK^T[d][key] += Q^T dS
+          gk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Qs + 16 * s2 * AS_ROW, al, 1), df[s2], gk1, 0, 0, 0);
+        }
+        // dS [q][key] (lane = key, registers = queries) -> LDS as [key][q]; read back transposed: lane = query, slots = keys -- the B operand of dQ^T = K^T dS^T.
+        // Lanes of keys beyond N hold dS of a duplicated key row: their contribution must not reach dQ.
+        const bool kval = w * 32 + l31 < N;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          u32x4 u = *(const u32x4*)&df[s2];
+          if (!kval) u = (u32x4){0u, 0u, 0u, 0u};
+          *(u32x2*)(DsT + l31 * 64 + (8 * (2 * s2) + 4 * hi) * 2) = (u32x2){u[0], u[1]};
+          *(u32x2*)(DsT + l31 * 64 + (8 * (2 * s2 + 1) + 4 * hi) * 2) = (u32x2){u[2], u[3]};
+        }
+        VDK_WAVE_LDS_SYNC();
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const s16x8 dst = as_tr_frag64(DsT, 16 * s2, lane);
+          pq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Kt + 16 * s2 * AS_ROW, al, 0), dst, pq0, 0, 0, 0);                 // dQ_j^T[d][q] (this key tile's share)
+          pq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Kt + 16 * s2 * AS_ROW, al, 1), dst, pq1, 0, 0, 0);
+        }
+      }
+      __syncthreads();                                                // the reducer has read tile j - 1's partials
+      if (keyw) {
+        float* slot = (float*)(Part + w * 8192) + lane * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          *(f32x4*)(slot + g * 256) = (f32x4){pq0[4 * g], pq0[4 * g + 1], pq0[4 * g + 2], pq0[4 * g + 3]};
+          *(f32x4*)(slot + (4 + g) * 256) = (f32x4){pq1[4 * g], pq1[4 * g + 1], pq1[4 * g + 2], pq1[4 * g + 3]};
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);                             // the next tile's DMAs have landed
+      __syncthreads();                                                // partials of tile j complete, tile j + 1's operands in place
+      if (w == 7) {                                                   // (its pq0 / pq1 are still zero: they become the sum)
+        f32x16& gq0 = pq0; f32x16& gq1 = pq1;
+        for (int s = 0; s < nt; ++s) {                                // wave order: deterministic
+          const float* slot = (const float*)(Part + s * 8192) + lane * 4;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 a = *(const f32x4*)(slot + g * 256), c = *(const f32x4*)(slot + (4 + g) * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gq0[4 * g + e] += a[e]; gq1[4 * g + e] += c[e]; }
+          }
+        }
+        as_store_tile(Wt, gq0, gq1, scale, dq + (long)b * N * ldd + h * 64, ldd, q0, N, lane);
+      }
+    }
+    if (keyw) {
+      as_store_tile(Wt, gk0, gk1, scale, dk + (long)b * N * ldd + h * 64, ldd, w * 32, N, lane);
+      as_store_tile(Wt, gv0, gv1, 1.0f, dv + (long)b * N * ldd + h * 64, ldd, w * 32, N, lane);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------------
 template <int NKT>
 static int launch_fwd(const bf16_t* base, long D, long ld, bf16_t* o, long ldo, float* lse, int B, int N, int H, float scale, int grid, hipStream_t s) {
@@ -666,7 +831,17 @@ static int launch_bwd3(const bf16_t* base, long D, long ld, const bf16_t* o, con
                      scale, B * H);
   return VDK_OK;
 }
-static int g_bwd_form = -1;        // -1: environment VDK_ATTN_BWD_FORM (default 3); 3 = split recompute form (two kernels, 2 workgroups / CU), 2 = one-kernel recompute form, 1 = fused form with the shared dQ tile
+template <int NKT>
+static int launch_bwd1p(const bf16_t* base, long D, long ld, const bf16_t* o, const bf16_t* dout, long ldo, const float* lse, bf16_t* dbase, long ldd, int B, int N, int H,
+                        float scale, int grid, hipStream_t s) {
+  const size_t lds = 16384 + 7 * 4096 + 7 * 8192 + 7 * 2048 + 8 * 4096 + (size_t)NKT * 32 * 8;
+  if (hipFuncSetAttribute((const void*)attn_s_bwd1p_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return vdk_fail(VDK_ELAUNCH, "vdk_attention_bwd: LDS attribute");
+  hipLaunchKernelGGL((attn_s_bwd1p_kernel<NKT>), dim3((unsigned)grid), dim3(512), lds, s, base, base + D, base + 2 * D, ld, o, dout, ldo, lse, dbase, dbase + D, dbase + 2 * D, ldd,
+                     N, H, scale, B * H);
+  return VDK_OK;
+}
+static int g_bwd_form = -1;        // -1: environment VDK_ATTN_BWD_FORM (default 3); 4 = one pass with the dQ hand-over (not yet measured); 3 = split recompute form (two kernels, 2 workgroups / CU), 2 = one-kernel recompute form, 1 = fused form with the shared dQ tile
 int vdk_attention_small_bwd_form(int form) { g_bwd_form = form; return VDK_OK; }
 
 static int grid_cap(int dflt);
@@ -710,6 +885,13 @@ int vdk_attention_small_bwd(const void* qkv, int64_t ld, const void* o, const vo
   hipStream_t s = (hipStream_t)stream;
   int form = g_bwd_form;
   if (form < 0) { const char* e = getenv("VDK_ATTN_BWD_FORM"); form = e ? atoi(e) : 3; }
+  if (form == 4) {
+    switch (nkt) {
+#define B4(n) case n: return launch_bwd1p<n>(base, D, ld, (const bf16_t*)o, (const bf16_t*)dout, ldo, lse, (bf16_t*)dqkv, ldd, B, N, H, scale, grid, s);
+      B4(1) B4(2) B4(3) B4(4) B4(5) B4(6) B4(7)
+#undef B4
+    }
+  }
   if (form == 3) {
     int rc = VDK_EUNSUPPORTED;
     switch (nkt) {
