@@ -549,3 +549,54 @@ def test_bucket_schedule_tapers_at_the_gradient_tail(monkeypatch):
         c.on_grad_ready(o, 1)
     c.finish_step()
     assert sizes == [512, 256, 128, 64, 32, 16, 8, 4, 2, 1, 1]
+
+
+# ---- Swin (the reference's default backbone) under the reference's own wrapping: torch DistributedDataParallel over the module's autograd nodes ------------------------
+def _swin_spec():
+    from visiondk_amd import swin
+    return swin.SwinSpec(img_size=224, num_classes=5, embed_dim=32, depths=(2, 1), heads=(1, 2))
+
+
+def _swin_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["VDK_EMU_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.emu.emu_backend import load_emu
+    from visiondk_amd import swin
+    be = load_emu()
+    model = swin.SwinTransformer(_swin_spec(), device="cpu", backend=be, seed=200 + rank)      # ranks start DIFFERENT: DDP broadcasts rank 0's weights
+    ddp = torch.nn.parallel.DistributedDataParallel(model)                                      # engine/vision_engine.py:313
+    opt = torch.optim.SGD(ddp.parameters(), lr=0.05, momentum=0.9)
+    torch.manual_seed(9)
+    x = torch.randn(2, 3, 224, 224); y = torch.randint(0, 5, (2,))
+    loss = torch.nn.functional.cross_entropy(ddp(x[rank:rank + 1]), y[rank:rank + 1])
+    loss.backward()
+    opt.step()
+    torch.save({"params": {n: p.detach().clone() for n, p in model.named_parameters()}, "grads": {n: p.grad.clone() for n, p in model.named_parameters()}},
+               f"{out_dir}/swin{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_two_rank_swin_under_torch_ddp_equals_whole_batch(tmp_path, emu):
+    """every parameter of the Swin module gets its gradient through the autograd nodes (DDP would hang or raise on an unused one), the replicas stay identical, and the
+    averaged gradient equals the whole-batch gradient of a single process"""
+    port = 29500 + (os.getpid() % 500) + 37
+    mp.start_processes(_swin_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "swin0.pt"); r1 = torch.load(tmp_path / "swin1.pt")
+    for n in r0["params"]:
+        assert torch.equal(r0["params"][n], r1["params"][n]), n
+        assert torch.equal(r0["grads"][n], r1["grads"][n]), n
+    from visiondk_amd import swin
+    model = swin.SwinTransformer(_swin_spec(), device="cpu", backend=emu, seed=200)
+    torch.manual_seed(9)
+    x = torch.randn(2, 3, 224, 224); y = torch.randint(0, 5, (2,))
+    torch.nn.functional.cross_entropy(model(x), y).backward()
+    gmax = max(p.grad.norm().item() for p in model.parameters())
+    for n, p in model.named_parameters():
+        if p.grad.norm().item() < 1e-3 * gmax:
+            continue
+        rel = ((r0["grads"][n] - p.grad).norm() / p.grad.norm()).item()
+        assert rel < 3e-2, (n, rel)                          # bf16 rounding differs with the batch split, the mathematics is identical
