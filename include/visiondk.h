@@ -132,6 +132,9 @@ typedef struct VdkGemmDesc {
                               (sum the rows -> colsum(A) = bias gradient of the Linear whose dY is this dgrad GEMM's A); error if that kernel does not serve the problem */
   float* c_colsum;         /* optional by-product of the 256x256 NT kernel with a plain or dGELU bf16 epilogue: f32 [vdk_gemm_c_colsum_rows(M, N, K)][N] partial column sums of the
                               STORED (bf16-rounded) output (sum the rows -> colsum(C) = bias gradient of the Linear whose dY this GEMM's output is) */
+  int32_t ab_dtype;        /* format of A, B, aux and a 16-bit C: VDK_BF16 (0, the default of a zeroed descriptor) or VDK_F16 -- IEEE half operands on v_mfma_f32_32x32x16_f16,
+                              what the reference's `torch.autocast(device_type=...)` gives its matmuls on a GPU (engine/procedure/train.py:118: no dtype => float16).  With
+                              VDK_F16 a 16-bit output is requested as c_dtype = VDK_F16.  fp16 operands exclude conv, a_colsum and stream-K. */
 } VdkGemmDesc;
 int vdk_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t splitk, size_t* bytes);
 int vdk_gemm_streamk_workspace_bytes(size_t* bytes);
@@ -166,6 +169,7 @@ int vdk_gemm_last_kernel(void);
  * channels its collectives run on (visiondk_amd/comm.py: 32), so that an all-reduce in flight on another stream and a persistent GEMM fit on the chip together instead of
  * the GEMM's static tile walk waiting for the collective to end.  Results do not depend on it.  Environment VDK_GEMM_RESERVE_CUS overrides. */
 int vdk_gemm_reserve_cus(int32_t n);
+int vdk_gemm_reserved_cus(void);   /* the value in force (so that a caller can scope a reserve to a window and restore what it found) */
 /* diagnostic: `workgroups` workgroups (256 threads, 32 KB of LDS) that stay resident for `microseconds` on `stream` -- a stand-in for a collective's kernel in flight */
 int vdk_debug_occupy_cus(int32_t workgroups, int64_t microseconds, void* stream);
 /* profiling aid: when non-NULL, every 256x256 workgroup writes 4 shader-cycle stamps (start, operands landed, main loop done,
@@ -201,6 +205,14 @@ int vdk_attention_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* 
 /* backward: dqkv bf16 [B, N, 3, H, 64] (row stride lddqkv); dvec: f32 scratch [B, H, N]. */
 int vdk_attention_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv,
                       int64_t lddqkv, float* dvec, int32_t B, int32_t N, int32_t H, int32_t head_dim, float scale, void* stream);
+/* vdk_attention_fwd / vdk_attention_bwd with the 16-bit format of q, k, v, o, dO, dqkv as a parameter: dtype = VDK_BF16 | VDK_F16.  VDK_F16 is the arithmetic of the
+ * reference's GPU path: `torch.autocast(device_type=...)` (engine/procedure/train.py:118) without a dtype is float16, so timm's Attention (softmax(q k^T / sqrt(hd)) v
+ * behind models/classifier/classify_model.py:49-54) reads fp16 operands there; P and dS are rounded to fp16 where the bf16 kernels round to bf16.  The short- and the
+ * long-sequence kernels serve both formats; the flash-style kernels of round 1 (vdk_attention_force_legacy) are bf16 only -> VDK_EUNSUPPORTED. */
+int vdk_attention_fwd_dt(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H, int32_t head_dim, float scale, int32_t dtype,
+                         void* stream);
+int vdk_attention_bwd_dt(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv, int64_t lddqkv, float* dvec, int32_t B,
+                         int32_t N, int32_t H, int32_t head_dim, float scale, int32_t dtype, void* stream);
 
 /* F.layer_norm over the last dim (timm blocks' norm1/norm2 and the final norm, eps 1e-6).  x: f32 rows at
  * stride ldx (so the final norm can run on the cls rows only: ldx = N*C); y: bf16 or f32; mean/rstd: f32 [T]
@@ -247,6 +259,14 @@ int vdk_softmax_ce(const float* logits, int64_t ldl, int32_t B, int32_t C, const
 int vdk_bce_logits(const float* logits, int64_t ldl, const float* targets, int64_t ldt, int32_t B, int32_t C, float grad_scale,
                    float focal_gamma, float focal_alpha, float* loss_rows, void* dlogits_bf16, int64_t lddl, float* dlogits_f32, int64_t lddf,
                    void* stream);
+/* vdk_softmax_ce / vdk_bce_logits under GradScaler (engine/procedure/train.py:205 `scaler.scale(loss).backward()`): the gradient written to dlogits16 (dl_dtype =
+ * VDK_BF16 | VDK_F16) and dlogits_f32 is multiplied by grad_scale AND by the device scalar loss_scale[0] (NULL: 1) -- the loss scale lives on the device so that a skipped
+ * step or a grown scale costs no host round trip.  loss_rows stay unscaled. */
+int vdk_softmax_ce_amp(const float* logits, int64_t ldl, int32_t B, int32_t C, const int64_t* ya, const int64_t* yb, float lam, float label_smoothing, float grad_scale,
+                       const float* loss_scale, float* loss_rows, void* dlogits16, int64_t lddl, int32_t dl_dtype, float* dlogits_f32, int64_t lddf, void* stream);
+int vdk_bce_logits_amp(const float* logits, int64_t ldl, const float* targets, int64_t ldt, int32_t B, int32_t C, float grad_scale, const float* loss_scale,
+                       float focal_gamma, float focal_alpha, float* loss_rows, void* dlogits16, int64_t lddl, int32_t dl_dtype, float* dlogits_f32, int64_t lddf,
+                       void* stream);
 
 /* PatchEmbed.proj (Conv2d(3, D, p, stride p)) as an im2col-free GEMM operand: out bf16 [B*gh*gw, Kp],
  * column k = c*p*p + ky*p + kx, zero-padded to Kp (Kp % 8 == 0). */
@@ -255,6 +275,7 @@ int vdk_patchify_bf16(const float* x, int32_t B, int32_t Cin, int32_t H, int32_t
 /* tok[b, 0, :] = cls_token + pos_embed[0]  (timm _pos_embed: cat cls, then add pos) */
 int vdk_cls_rows(float* tok, int64_t batch_stride, int32_t B, int32_t D, const float* cls, const float* pos0, void* stream);
 int vdk_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream);
+int vdk_cast_f32_f16(const float* in, void* out, int64_t n, void* stream);   /* the same cast to IEEE half (fp16 operand mode, VdkVitConfig.operand) */
 /* out[c][r] (bf16) = in[r][c] (f32): the [in,out] copy of a Linear weight for dgrad */
 int vdk_transpose_cast_f32_bf16(const float* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, int32_t Rpad,
                                 void* stream);
@@ -273,6 +294,16 @@ int vdk_sgd_step(float* params, const float* grads, float* momentum_buf, float* 
  * are read from DEVICE memory `hyper` f32 [5] when the kernel runs. */
 int vdk_sgd_step_graph(float* params, const float* grads, float* momentum_buf, float* ema, void* params_bf16, int64_t n, const float* hyper, float grad_scale,
                        const float* normsq, float max_norm, void* stream);
+/* Trainer.update under GradScaler (engine/procedure/train.py:203-215; GradScaler built at engine/vision_engine.py:232): `scaler.unscale_` + `clip_grad_norm_` +
+ * `scaler.step(optimizer)` + ModelEMA.update in the one pass of vdk_sgd_step.  The gradients (and normsq = their sum of squares, vdk_sumsq_f32) carry the loss scale
+ * loss_state[0] (device; NULL: none): g / scale is what is clipped and applied; when normsq is not finite (an inf / NaN anywhere in the gradient) parameters and momentum are
+ * left untouched -- GradScaler.step skips optimizer.step() -- while the EMA still moves (the reference calls ema.update(model) regardless).  params16 (may be NULL) is
+ * refreshed in p16_dtype = VDK_BF16 | VDK_F16: the engine's operand copy of the weights.  Call vdk_loss_scale_update afterwards (`scaler.update()`, train.py:211):
+ * loss_state f32 [3] = {scale, growth tracker, skipped-step count}; non-finite normsq: scale *= backoff_factor, tracker = 0; otherwise tracker += 1 and, at
+ * growth_interval, scale *= growth_factor, tracker = 0 (torch.cuda.amp.GradScaler defaults: init 65536, growth 2, backoff 0.5, interval 2000). */
+int vdk_sgd_step_amp(float* params, const float* grads, float* momentum_buf, float* ema, void* params16, int32_t p16_dtype, int64_t n, float lr, float momentum,
+                     float weight_decay, float grad_scale, const float* loss_state, const float* normsq, float max_norm, float ema_decay, int32_t first_step, void* stream);
+int vdk_loss_scale_update(float* loss_state, const float* normsq, float growth_factor, float backoff_factor, int32_t growth_interval, void* stream);
 /* SAM.first_step (engine/optimizer.py:43-55,77-87): normsq_out = sum((|p| or 1) * g)^2; old_params = params;
  * params += (p^2 or 1) * g * rho / (sqrt(normsq) + 1e-12).  second_step = copy old_params back + vdk_sgd_step on the new grads.
  * ws: vdk_sumsq_workspace_bytes(). */
@@ -387,6 +418,10 @@ typedef struct VdkVitConfig {
   float* fp8_state;        /* fp8 != 0: f32 [3][12 * depth]: amax | scale | 1 / scale; slot 12 l + k, k = 0..3 h1, attn out, h2, gelu out (e4m3), 4..7 qkv / proj / fc1 / fc2
                               weights (e4m3), 8..11 dL/d(fc2 out), dL/du, dL/d(proj out), dL/dqkv (e5m2).  Initialise scale = 1/scale = 1, amax = 0; call vdk_vit_fp8_update
                               after every backward. */
+  int32_t operand;         /* VDK_BF16 (0): bf16 GEMM operands / saved activations (BASELINE.json configs[1] "bf16").  VDK_F16: IEEE fp16 -- the reference's own GPU arithmetic
+                              (engine/procedure/train.py:118 `torch.autocast(device_type=...)` without a dtype = float16, with GradScaler train.py:205-211): wb16 / wt16, every
+                              saved activation and every gradient tensor of the engine are fp16; the caller scales dlogits by the loss scale (vdk_softmax_ce_amp) and the
+                              optimizer un-scales (vdk_sgd_step_amp).  Same speed (same MFMA rate), 8x smaller operand rounding.  Excludes fp8. */
 } VdkVitConfig;
 typedef void (*vdk_grad_ready_fn)(void* user, int64_t offset, int64_t numel);
 

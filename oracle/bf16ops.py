@@ -1,17 +1,23 @@
-"""TEST INFRASTRUCTURE: the oracle's second arithmetic mode — "bf16 operands, fp32 accumulate".
+"""TEST INFRASTRUCTURE: the oracle's 16-bit-operand arithmetic modes -- "bf16 operands, fp32 accumulate" and "fp16 operands, fp32 accumulate".
 
-The reference trains its classifier under `torch.cuda.amp.autocast` (/root/reference engine/procedure/train.py:118,
-`with autocast(enabled=self.cuda)`): every matmul-shaped op (Linear, conv-as-GEMM, the two attention products) reads
-bf16 operands and accumulates in fp32, everything else (LayerNorm, softmax, GELU, residual adds, the loss) is fp32
-arithmetic on fp32 values.  The fp32 oracle (autocast off, what the reference does on CPU) cannot tell an engine that
-rounds its GEMM operands to bf16 from one that is simply wrong by 1e-2; this mode can: it restates the SAME network with
-a bf16 rounding at exactly the tensors autocast holds in bf16, so that what is left between it and the HIP engine is
-fp32 summation order (1e-6) plus the rare element whose rounding flips — tests require <= 1e-3.
+The reference trains its classifier under autocast (/root/reference engine/procedure/train.py:118, `with torch.autocast(device_type=self.device.type,
+enabled=(self.device != cpu))`): no dtype argument, so on a GPU the autocast dtype is torch's default for the device type, **float16**, and the loop wraps the backward
+in a GradScaler (train.py:205-211, engine/vision_engine.py:232).  Every matmul-shaped op (Linear, conv-as-GEMM, the two attention products) then reads fp16 operands and
+accumulates in fp32; everything else (LayerNorm, softmax, GELU, residual adds, the loss) is fp32 arithmetic on fp32 values.  (Rounds 1-3 of this repo described that path
+as bf16: wrong for the reference, right for BASELINE.json's configs[1], which names bf16.  Both formats are restated here and both are engine modes.)
 
-Rounding points (forward -> the same tensors' gradients are rounded on the way back, like autocast's bf16 outputs):
+The fp32 oracle (autocast off, what the reference does on CPU) cannot tell an engine that rounds its GEMM operands to 16 bits from one that is simply wrong by that
+much; these modes can: they restate the SAME network with a rounding to the chosen format at exactly the tensors autocast holds in 16 bits, so that what is left between
+the oracle and the HIP engine is fp32 summation order plus the rare element whose rounding flips.
+
+mode "fp16_operands": rounding to IEEE half (10 mantissa bits: 8x finer than bf16).  Gradients are carried through the narrow exponent by a loss scale exactly as
+GradScaler does: callers multiply the loss by S before backward() and divide the gradients by S afterwards (tests/, oracle/parity.py); overflow to inf is the caller's to
+detect, as in the reference.
+
+Rounding points (forward -> the same tensors' gradients are rounded on the way back, like autocast's 16-bit outputs):
   * Linear / conv-as-GEMM: both operands;  dgrad and wgrad: dY rounded, db = column sums of the rounded dY
   * `q(x)` boundaries: LayerNorm outputs, the fused qkv projection's output, the attention output
-  * GELU: output rounded; the backward multiplies by gelu'(bf16(u)) and rounds the product (the pre-activation is KEPT in bf16)
+  * GELU: output rounded; the backward multiplies by gelu'(r(u)) and rounds the product (the pre-activation is KEPT in 16 bits)
   * attention: softmax probabilities (normalised, fp32) are rounded once as the left operand of P.V; backward re-derives
     P from the row log-sum-exp, rounds P for dV and dS = P*(dP - D) for dQ / dK; D = rowsum(dO * O) on the rounded tensors
 Nothing here is imported by the product (`visiondk_amd/`); tests/ and bench.py's parity leg only.
@@ -24,7 +30,8 @@ import math
 import torch
 import torch.nn.functional as F
 
-_MODE = "fp32"      # "fp32" (reference on CPU: autocast off) | "bf16_operands" (reference under autocast, restated)
+_MODE = "fp32"      # "fp32" (reference on CPU: autocast off) | "bf16_operands" | "fp16_operands" (the reference under autocast on a GPU, restated)
+_RDT = {"bf16_operands": torch.bfloat16, "fp16_operands": torch.float16}
 
 
 def mode() -> str:
@@ -34,7 +41,7 @@ def mode() -> str:
 @contextlib.contextmanager
 def precision(m: str):
     global _MODE
-    assert m in ("fp32", "bf16_operands"), m
+    assert m in ("fp32", "bf16_operands", "fp16_operands"), m
     old, _MODE = _MODE, m
     try:
         yield
@@ -43,9 +50,9 @@ def precision(m: str):
 
 
 def rb(t: torch.Tensor) -> torch.Tensor:
-    """round to bfloat16 (nearest even) and back to the tensor's own dtype (float32; float64 when the oracle itself is run in double precision to
-    measure how much of a deviation is the fp32 summation order of the oracle, tests/test_parity_bf16.py)"""
-    return t.to(torch.bfloat16).to(t.dtype)
+    """round to the mode's 16-bit format (nearest even; bfloat16 outside a 16-bit mode, as before) and back to the tensor's own dtype (float32; float64 when the oracle
+    itself is run in double precision to measure how much of a deviation is the fp32 summation order of the oracle, tests/test_parity_bf16.py)"""
+    return t.to(_RDT.get(_MODE, torch.bfloat16)).to(t.dtype)
 
 
 class _Boundary(torch.autograd.Function):
@@ -60,7 +67,7 @@ class _Boundary(torch.autograd.Function):
 
 def q(x: torch.Tensor) -> torch.Tensor:
     """a tensor autocast holds in bf16: value rounded going forward, gradient rounded coming back"""
-    return _Boundary.apply(x) if _MODE == "bf16_operands" else x
+    return _Boundary.apply(x) if _MODE != "fp32" else x
 
 
 class _LinearBf16(torch.autograd.Function):

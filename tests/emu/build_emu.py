@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import hashlib
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -28,7 +29,10 @@ def build(force: bool = False) -> Path:
     def one(src: Path) -> tuple[Path, bool]:
         obj = OBJ / (src.stem + ".o")
         tag = OBJ / (src.stem + ".tag")
-        d = hashlib.sha256(src.read_bytes() + hd.encode()).hexdigest()
+        body = src.read_bytes()
+        for inc in re.findall(rb'#include "([^"]+\.hip)"', body):
+            body += (CSRC / inc.decode()).read_bytes()
+        d = hashlib.sha256(body + hd.encode()).hexdigest()
         if obj.exists() and tag.exists() and tag.read_text() == d and not force:
             return obj, False
         r = subprocess.run([CXX, *FLAGS, "-c", str(src), "-o", str(obj)], capture_output=True, text=True)

@@ -21,7 +21,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("A", P), ("lda", I64), ("B", P), ("ldb", I64), ("C", P), ("ldc", I64),
                 ("M", I32), ("N", I32), ("K", I32), ("c_dtype", I32),
                 ("bias", P), ("residual", P), ("ldr", I64), ("act", I32), ("aux", P), ("ldaux", I64),
-                ("alpha", F32), ("splitk", I32), ("row_group", I32), ("trans", I32), ("a_row_group", I32), ("conv", P), ("a_colsum", P), ("c_colsum", P)]
+                ("alpha", F32), ("splitk", I32), ("row_group", I32), ("trans", I32), ("a_row_group", I32), ("conv", P), ("a_colsum", P), ("c_colsum", P), ("ab_dtype", I32)]
 
 
 class ConvGeom(C.Structure):
@@ -32,7 +32,7 @@ class ConvGeom(C.Structure):
 class VitConfig(C.Structure):
     """VdkVitConfig of include/visiondk.h"""
     _fields_ = [("batch", I32), ("img_size", I32), ("patch_size", I32), ("in_chans", I32), ("dim", I32), ("depth", I32),
-                ("heads", I32), ("mlp_dim", I32), ("num_classes", I32), ("ln_eps", F32), ("no_class_token", I32), ("fp8", I32), ("fp8_w", P), ("fp8_state", P)]
+                ("heads", I32), ("mlp_dim", I32), ("num_classes", I32), ("ln_eps", F32), ("no_class_token", I32), ("fp8", I32), ("fp8_w", P), ("fp8_state", P), ("operand", I32)]
 
 
 class GemmF32Desc(C.Structure):
@@ -90,6 +90,7 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_gemm_force_band_cw": (C.c_int, [I32]),
     "vdk_gemm_last_kernel": (C.c_int, []),
     "vdk_gemm_reserve_cus": (C.c_int, [C.c_int32]),
+    "vdk_gemm_reserved_cus": (C.c_int, []),
     "vdk_debug_occupy_cus": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p]),
     "vdk_quant_fp8": (C.c_int, [P, I32, I64, P, P, I32, P, P]),
     "vdk_fp8_scale_update": (C.c_int, [P, P, P, I32, I32, F32, P]),
@@ -104,6 +105,8 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_attention_force_legacy": (C.c_int, [I32]),
     "vdk_attention_fwd": (C.c_int, [P, I64, P, I64, P, I32, I32, I32, I32, F32, P]),
     "vdk_attention_bwd": (C.c_int, [P, I64, P, P, I64, P, P, I64, P, I32, I32, I32, I32, F32, P]),
+    "vdk_attention_fwd_dt": (C.c_int, [P, I64, P, I64, P, I32, I32, I32, I32, F32, I32, P]),
+    "vdk_attention_bwd_dt": (C.c_int, [P, I64, P, P, I64, P, P, I64, P, I32, I32, I32, I32, F32, I32, P]),
     "vdk_layernorm_fwd": (C.c_int, [P, I64, I32, I32, P, P, F32, P, I64, I32, P, P, P]),
     "vdk_layernorm_fwd_q8": (C.c_int, [P, I64, I32, I32, P, P, C.c_float, P, I64, P, P, P, I64, I32, P, P, P]),
     "vdk_layernorm_bwd_workspace_bytes": (C.c_int, [I32, I32, PSZ]),
@@ -116,14 +119,19 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_colsum_bf16": (C.c_int, [P, I64, I32, I32, P, P, SZ, P]),
     "vdk_softmax_ce": (C.c_int, [P, I64, I32, I32, P, P, F32, F32, F32, P, P, I64, P, I64, P]),
     "vdk_bce_logits": (C.c_int, [P, I64, P, I64, I32, I32, F32, F32, F32, P, P, I64, P, I64, P]),
+    "vdk_softmax_ce_amp": (C.c_int, [P, I64, I32, I32, P, P, F32, F32, F32, P, P, P, I64, I32, P, I64, P]),
+    "vdk_bce_logits_amp": (C.c_int, [P, I64, P, I64, I32, I32, F32, P, F32, F32, P, P, I64, I32, P, I64, P]),
     "vdk_patchify_bf16": (C.c_int, [P, I32, I32, I32, I32, I32, P, I32, P]),
     "vdk_cls_rows": (C.c_int, [P, I64, I32, I32, P, P, P]),
     "vdk_cast_f32_bf16": (C.c_int, [P, P, I64, P]),
+    "vdk_cast_f32_f16": (C.c_int, [P, P, I64, P]),
     "vdk_transpose_cast_f32_bf16": (C.c_int, [P, I64, I32, I32, P, I64, I32, P]),
     "vdk_sumsq_workspace_bytes": (C.c_int, [PSZ]),
     "vdk_sumsq_f32": (C.c_int, [P, I64, P, P, SZ, P]),
     "vdk_sgd_step": (C.c_int, [P, P, P, P, P, I64, F32, F32, F32, F32, P, F32, F32, I32, P]),
     "vdk_sgd_step_graph": (C.c_int, [P, P, P, P, P, I64, P, F32, P, F32, P]),
+    "vdk_sgd_step_amp": (C.c_int, [P, P, P, P, P, I32, I64, F32, F32, F32, F32, P, P, F32, F32, I32, P]),
+    "vdk_loss_scale_update": (C.c_int, [P, P, F32, F32, I32, P]),
     "vdk_mixup": (C.c_int, [P, P, F32, I32, I64, P, P]),
     "vdk_sam_first_step": (C.c_int, [P, P, P, I64, F32, I32, P, P, SZ, P]),
     "vdk_ohem_mask": (C.c_int, [P, I64, I32, I32, P, I32, F32, I64, P, P, P]),

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import hashlib
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -54,7 +55,10 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     def compile_one(src: Path) -> Path:
         obj = OBJ / (src.stem + ".o")
         tag = OBJ / (src.stem + ".tag")
-        d = hashlib.sha256(src.read_bytes() + hdr_dig.encode()).hexdigest()
+        body = src.read_bytes()
+        for inc in re.findall(rb'#include "([^"]+\.hip)"', body):      # a translation unit that instantiates another source file (gemm_w4_f16.hip) follows its edits
+            body += (CSRC / inc.decode()).read_bytes()
+        d = hashlib.sha256(body + hdr_dig.encode()).hexdigest()
         if obj.exists() and tag.exists() and tag.read_text() == d and not force:
             return obj
         cmd = [HIPCC, *FLAGS, "-c", str(src), "-o", str(obj)]

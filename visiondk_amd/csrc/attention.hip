@@ -379,13 +379,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 }
 
 // short sequences (attention_small.hip): everything of one (batch, head) item in LDS, exact softmax, fused backward
-int vdk_attention_small_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H, float scale, void* stream);
+int vdk_attention_small_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H, float scale, int opf, void* stream);
 int vdk_attention_small_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv, int64_t ldd, float* dvec, int32_t B, int32_t N,
-                            int32_t H, float scale, void* stream);
+                            int32_t H, float scale, int opf, void* stream);
 // long sequences (attention_long.hip): K / V streamed through a double-buffered LDS chunk by LDS-DMA, online softmax
-int vdk_attention_long_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H, float scale, void* stream);
+int vdk_attention_long_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H, float scale, int opf, void* stream);
 int vdk_attention_long_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv, int64_t ldd, float* dvec, int32_t B, int32_t N,
-                           int32_t H, float scale, void* stream);
+                           int32_t H, float scale, int opf, void* stream);
 static int g_attn_legacy = -1;   // -1: env VDK_ATTN_LEGACY decides; 0 / 1: forced by vdk_attention_force_legacy (A/B benchmarking, tests of the long-sequence kernels at small N)
 static bool attn_legacy() {
   if (g_attn_legacy >= 0) return g_attn_legacy == 1;
@@ -404,23 +404,33 @@ static bool attn_long_bwd_off() {      // A/B: VDK_ATTN_LONG_BWD=0 keeps the fla
 
 extern "C" {
 
+int vdk_attention_fwd_dt(const void*, int64_t, void*, int64_t, float*, int32_t, int32_t, int32_t, int32_t, float, int32_t, void*);
+int vdk_attention_bwd_dt(const void*, int64_t, const void*, const void*, int64_t, const float*, void*, int64_t, float*, int32_t, int32_t, int32_t, int32_t, float, int32_t, void*);
 int vdk_attention_force_legacy(int32_t on) { g_attn_legacy = on < 0 ? -1 : (on ? 1 : 0); return VDK_OK; }
 
 // qkv: bf16 [B, N, 3, H, 64] (timm's fused qkv Linear output, row stride ld = 3*H*64); o: bf16 [B, N, H*64];
 // lse: f32 [B, H, N] (saved for backward; may be NULL for inference).
 int vdk_attention_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H,
                       int32_t head_dim, float scale, void* stream) {
-  if (!qkv || !o || B <= 0 || N <= 0 || H <= 0) return vdk_fail(VDK_EINVAL, "vdk_attention_fwd: bad argument");
+  return vdk_attention_fwd_dt(qkv, ld, o, ldo, lse, B, N, H, head_dim, scale, VDK_BF16, stream);
+}
+// the same with the tensors' 16-bit format as a parameter: dtype VDK_BF16 | VDK_F16 (fp16: q, k, v, o and the probabilities P are IEEE half -- the reference's autocast
+// arithmetic, engine/procedure/train.py:118)
+int vdk_attention_fwd_dt(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H,
+                         int32_t head_dim, float scale, int32_t dtype, void* stream) {
+  if (!qkv || !o || B <= 0 || N <= 0 || H <= 0 || (dtype != VDK_BF16 && dtype != VDK_F16)) return vdk_fail(VDK_EINVAL, "vdk_attention_fwd: bad argument");
+  const int opf = dtype == VDK_F16 ? VDK_OPF_F16 : VDK_OPF_BF16;
   if (head_dim != A_HD) return vdk_fail(VDK_EUNSUPPORTED, "vdk_attention_fwd: head_dim must be 64");
   if ((ld & 7) || (ldo & 7)) return vdk_fail(VDK_EINVAL, "vdk_attention_fwd: ld % 8");
   if (N <= 256 && N < attn_long_min() && !attn_legacy()) {
-    const int rc = vdk_attention_small_fwd(qkv, ld, o, ldo, lse, B, N, H, scale, stream);
+    const int rc = vdk_attention_small_fwd(qkv, ld, o, ldo, lse, B, N, H, scale, opf, stream);
     if (rc != VDK_EUNSUPPORTED) return rc ? rc : vdk_check_launch("vdk_attention_fwd");
   }
   if ((N > 256 || N >= attn_long_min()) && !attn_legacy()) {
-    const int rc = vdk_attention_long_fwd(qkv, ld, o, ldo, lse, B, N, H, scale, stream);
+    const int rc = vdk_attention_long_fwd(qkv, ld, o, ldo, lse, B, N, H, scale, opf, stream);
     return rc ? rc : vdk_check_launch("vdk_attention_fwd");
   }
+  if (opf) return vdk_fail(VDK_EUNSUPPORTED, "vdk_attention_fwd: the flash-style kernels of round 1 (vdk_attention_force_legacy) are bf16 only");
   const bf16_t* base = (const bf16_t*)qkv;
   const long D = (long)H * A_HD;
   int grid = B * H;
@@ -435,18 +445,24 @@ int vdk_attention_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* 
 // dqkv: bf16 [B, N, 3, H, 64] like qkv.  dvec: f32 scratch [B, H, N].
 int vdk_attention_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv,
                       int64_t lddqkv, float* dvec, int32_t B, int32_t N, int32_t H, int32_t head_dim, float scale, void* stream_) {
+  return vdk_attention_bwd_dt(qkv, ld, o, dout, ldo, lse, dqkv, lddqkv, dvec, B, N, H, head_dim, scale, VDK_BF16, stream_);
+}
+int vdk_attention_bwd_dt(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv,
+                         int64_t lddqkv, float* dvec, int32_t B, int32_t N, int32_t H, int32_t head_dim, float scale, int32_t dtype, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!qkv || !o || !dout || !lse || !dqkv || !dvec || B <= 0 || N <= 0 || H <= 0) return vdk_fail(VDK_EINVAL, "vdk_attention_bwd: bad argument");
+  if (!qkv || !o || !dout || !lse || !dqkv || !dvec || B <= 0 || N <= 0 || H <= 0 || (dtype != VDK_BF16 && dtype != VDK_F16)) return vdk_fail(VDK_EINVAL, "vdk_attention_bwd: bad argument");
+  const int opf = dtype == VDK_F16 ? VDK_OPF_F16 : VDK_OPF_BF16;
   if (head_dim != A_HD) return vdk_fail(VDK_EUNSUPPORTED, "vdk_attention_bwd: head_dim must be 64");
   if ((ld & 7) || (ldo & 7) || (lddqkv & 7)) return vdk_fail(VDK_EINVAL, "vdk_attention_bwd: ld % 8");
   if (N <= 224 && N < attn_long_min() && !attn_legacy()) {
-    const int rc = vdk_attention_small_bwd(qkv, ld, o, dout, ldo, lse, dqkv, lddqkv, dvec, B, N, H, scale, stream_);
+    const int rc = vdk_attention_small_bwd(qkv, ld, o, dout, ldo, lse, dqkv, lddqkv, dvec, B, N, H, scale, opf, stream_);
     if (rc != VDK_EUNSUPPORTED) return rc ? rc : vdk_check_launch("vdk_attention_bwd");
   }
   if ((N > 224 || N >= attn_long_min()) && !attn_legacy() && !attn_long_bwd_off()) {
-    const int rc = vdk_attention_long_bwd(qkv, ld, o, dout, ldo, lse, dqkv, lddqkv, dvec, B, N, H, scale, stream_);
+    const int rc = vdk_attention_long_bwd(qkv, ld, o, dout, ldo, lse, dqkv, lddqkv, dvec, B, N, H, scale, opf, stream_);
     return rc ? rc : vdk_check_launch("vdk_attention_bwd");
   }
+  if (opf) return vdk_fail(VDK_EUNSUPPORTED, "vdk_attention_bwd: the flash-style kernels of round 1 are bf16 only");
   const bf16_t* base = (const bf16_t*)qkv;
   bf16_t* dbase = (bf16_t*)dqkv;
   const long D = (long)H * A_HD;

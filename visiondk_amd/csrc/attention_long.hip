@@ -39,6 +39,7 @@ __device__ __forceinline__ void al_dma_chunk(unsigned char* buf, const bf16_t* _
 }
 
 // LDS (dynamic): chunk buffer 0 | chunk buffer 1 | 4 wave store tiles of 4 KB
+template <int OF>
 __global__ __launch_bounds__(256, 2) void attn_l_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld,
                                                             bf16_t* __restrict__ o, long ldo, float* __restrict__ lse, int N, int H, float scale, int nitems, int G) {
   VDK_DYN_LDS(smem);
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void attn_l_fwd_kernel(const bf16_t* __rest
         st[kt] = as_zero16();
         if (kt < nv) {
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Kb + kt * 32 * AS_ROW, al, ks), qf[ks], st[kt], 0, 0, 0);
+          for (int ks = 0; ks < 4; ++ks) st[kt] = vdk_mfma32<OF>(as_row_frag_l(Kb + kt * 32 * AS_ROW, al, ks), qf[ks], st[kt]);
         }
       }
       if (key0 + AL_CROWS > N) {                                     // the last chunk holds keys beyond N (wave-uniform)
@@ -123,17 +124,17 @@ __global__ __launch_bounds__(256, 2) void attn_l_fwd_kernel(const bf16_t* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) { const float p = fast_exp2(fmaf(st[kt][r], scale2, -m)); st[kt][r] = p; l += p; }
         s16x8 pf[2];
-        as_pack_b(st[kt], pf);
+        as_pack_b<OF>(st[kt], pf);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Vb + (kt * 32 + 16 * s) * AS_ROW, al, 0), pf[s], o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Vb + (kt * 32 + 16 * s) * AS_ROW, al, 1), pf[s], o1, 0, 0, 0);
+          o0 = vdk_mfma32<OF>(as_tr_frag_l(Vb + (kt * 32 + 16 * s) * AS_ROW, al, 0), pf[s], o0);
+          o1 = vdk_mfma32<OF>(as_tr_frag_l(Vb + (kt * 32 + 16 * s) * AS_ROW, al, 1), pf[s], o1);
         }
       }
     }
     if (active) {
       l += __shfl_xor(l, 32);
-      as_store_tile(Wt, o0, o1, 1.0f / l, o + (long)b * N * ldo + h * 64, ldo, qt * 32, N, lane);
+      as_store_tile<OF>(Wt, o0, o1, 1.0f / l, o + (long)b * N * ldo + h * 64, ldo, qt * 32, N, lane);
       if (lse && hi == 0 && qrow < N) lse[((long)b * H + h) * N + qrow] = (m + log2f(l)) * 0.6931471805599453f;
     }
     t = tn;
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(256, 2) void attn_l_fwd_kernel(const bf16_t* __rest
 //   q kernel:  unit = (b, head, group of 4 query tiles); Q / dO / O fragments from global, K / V chunks through the double buffer, dQ^T (lane = query) in registers.
 //   kv kernel: unit = (b, head, group of 4 key tiles); K / V fragments from global, Q / dO chunks through the double buffer together with the chunk's 96 lse and D values
 //              (staged through one register per thread: loaded under the previous chunk, written to LDS before the chunk's barrier); dK^T, dV^T (lane = key) in registers.
+template <int OF>
 __global__ __launch_bounds__(256, 2) void attn_l_bwd_q_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld,
                                                               const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, long ldo, const float* __restrict__ lse,
                                                               float* __restrict__ dvec, bf16_t* __restrict__ dq, long ldd, int N, int H, float scale, int nitems, int G) {
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void attn_l_bwd_q_kernel(const bf16_t* __re
       const u32x4 of = *(const u32x4*)(o + offo + (long)qr * ldo + ks * 16 + hi * 8);
       const u32x4 gu = *(const u32x4*)&gf[ks];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { dsum = fmaf(bf_lo(gu[e]), bf_lo(of[e]), dsum); dsum = fmaf(bf_hi(gu[e]), bf_hi(of[e]), dsum); }
+      for (int e = 0; e < 4; ++e) { dsum = fmaf(op_lo<OF>(gu[e]), op_lo<OF>(of[e]), dsum); dsum = fmaf(op_hi<OF>(gu[e]), op_hi<OF>(of[e]), dsum); }
     }
     dsum += __shfl_xor(dsum, 32);                                    // the two half-waves hold the two halves of a query's 64 channels
     const float lq = lse[((long)b * H + h) * N + qr] * VDK_LOG2E;
@@ -209,8 +211,8 @@ __global__ __launch_bounds__(256, 2) void attn_l_bwd_q_kernel(const bf16_t* __re
         f32x16 st = as_zero16(), dp = as_zero16();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Kb + kt * 32 * AS_ROW, al, ks), qf[ks], st, 0, 0, 0);   // S^T[key][q]: lane = query, registers = keys
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Vb + kt * 32 * AS_ROW, al, ks), gf[ks], dp, 0, 0, 0);   // dP^T[key][q]
+          st = vdk_mfma32<OF>(as_row_frag_l(Kb + kt * 32 * AS_ROW, al, ks), qf[ks], st);   // S^T[key][q]: lane = query, registers = keys
+          dp = vdk_mfma32<OF>(as_row_frag_l(Vb + kt * 32 * AS_ROW, al, ks), gf[ks], dp);   // dP^T[key][q]
         }
         f32x16 ds;
 #pragma unroll
@@ -220,21 +222,22 @@ __global__ __launch_bounds__(256, 2) void attn_l_bwd_q_kernel(const bf16_t* __re
           ds[r] = p * (dp[r] - dsum);
         }
         s16x8 df[2];
-        as_pack_b(ds, df);
+        as_pack_b<OF>(ds, df);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          gq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Kb + (kt * 32 + 16 * s2) * AS_ROW, al, 0), df[s2], gq0, 0, 0, 0);   // dQ^T[d][q] += K^T dS^T
-          gq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Kb + (kt * 32 + 16 * s2) * AS_ROW, al, 1), df[s2], gq1, 0, 0, 0);
+          gq0 = vdk_mfma32<OF>(as_tr_frag_l(Kb + (kt * 32 + 16 * s2) * AS_ROW, al, 0), df[s2], gq0);   // dQ^T[d][q] += K^T dS^T
+          gq1 = vdk_mfma32<OF>(as_tr_frag_l(Kb + (kt * 32 + 16 * s2) * AS_ROW, al, 1), df[s2], gq1);
         }
       }
     }
-    if (active) as_store_tile(Wt, gq0, gq1, scale, dq + (long)b * N * ldd + h * 64, ldd, qt * 32, N, lane);
+    if (active) as_store_tile<OF>(Wt, gq0, gq1, scale, dq + (long)b * N * ldd + h * 64, ldd, qt * 32, N, lane);
     t = tn;
     item = itemn;
   }
 }
 
 #define AL_BUFKV (AL_BUF + 1024)           // Q rows | dO rows | 128 lse values | 128 D values
+template <int OF>
 __global__ __launch_bounds__(256, 2) void attn_l_bwd_kv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld,
                                                                const bf16_t* __restrict__ dout, long ldo, const float* __restrict__ lse, const float* __restrict__ dvec,
                                                                bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long ldd, int N, int H, float scale, int nitems, int G) {
@@ -298,8 +301,8 @@ __global__ __launch_bounds__(256, 2) void attn_l_bwd_kv_kernel(const bf16_t* __r
         f32x16 st = as_zero16(), dp = as_zero16();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Qb + qt * 32 * AS_ROW, al, ks), kf[ks], st, 0, 0, 0);   // S[q][key]: lane = key, registers = queries
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Ob + qt * 32 * AS_ROW, al, ks), vf[ks], dp, 0, 0, 0);   // dP[q][key]
+          st = vdk_mfma32<OF>(as_row_frag_l(Qb + qt * 32 * AS_ROW, al, ks), kf[ks], st);   // S[q][key]: lane = key, registers = queries
+          dp = vdk_mfma32<OF>(as_row_frag_l(Ob + qt * 32 * AS_ROW, al, ks), vf[ks], dp);   // dP[q][key]
         }
         f32x16 pv, ds;
 #pragma unroll
@@ -316,20 +319,20 @@ __global__ __launch_bounds__(256, 2) void attn_l_bwd_kv_kernel(const bf16_t* __r
           }
         }
         s16x8 pf[2], df[2];
-        as_pack_b(pv, pf);
-        as_pack_b(ds, df);
+        as_pack_b<OF>(pv, pf);
+        as_pack_b<OF>(ds, df);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          gv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Ob + (qt * 32 + 16 * s2) * AS_ROW, al, 0), pf[s2], gv0, 0, 0, 0);     // dV^T[d][key] += dO^T P
-          gv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Ob + (qt * 32 + 16 * s2) * AS_ROW, al, 1), pf[s2], gv1, 0, 0, 0);
-          gk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Qb + (qt * 32 + 16 * s2) * AS_ROW, al, 0), df[s2], gk0, 0, 0, 0);     // dK^T[d][key] += Q^T dS
-          gk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Qb + (qt * 32 + 16 * s2) * AS_ROW, al, 1), df[s2], gk1, 0, 0, 0);
+          gv0 = vdk_mfma32<OF>(as_tr_frag_l(Ob + (qt * 32 + 16 * s2) * AS_ROW, al, 0), pf[s2], gv0);     // dV^T[d][key] += dO^T P
+          gv1 = vdk_mfma32<OF>(as_tr_frag_l(Ob + (qt * 32 + 16 * s2) * AS_ROW, al, 1), pf[s2], gv1);
+          gk0 = vdk_mfma32<OF>(as_tr_frag_l(Qb + (qt * 32 + 16 * s2) * AS_ROW, al, 0), df[s2], gk0);     // dK^T[d][key] += Q^T dS
+          gk1 = vdk_mfma32<OF>(as_tr_frag_l(Qb + (qt * 32 + 16 * s2) * AS_ROW, al, 1), df[s2], gk1);
         }
       }
     }
     if (active) {
-      as_store_tile(Wt, gk0, gk1, scale, dk + (long)b * N * ldd + h * 64, ldd, kt * 32, N, lane);
-      as_store_tile(Wt, gv0, gv1, 1.0f, dv + (long)b * N * ldd + h * 64, ldd, kt * 32, N, lane);
+      as_store_tile<OF>(Wt, gk0, gk1, scale, dk + (long)b * N * ldd + h * 64, ldd, kt * 32, N, lane);
+      as_store_tile<OF>(Wt, gv0, gv1, 1.0f, dv + (long)b * N * ldd + h * 64, ldd, kt * 32, N, lane);
     }
     t = tn;
     item = itemn;
@@ -343,37 +346,47 @@ static int al_grid(long units) {
   return (int)((grid + 7) / 8 * 8);                                  // every XCD residue must be present: items are dealt to XCDs by item mod 8
 }
 
-// dqkv: bf16 [B, N, 3, H, 64]; dvec: f32 scratch [B, H, N]
-int vdk_attention_long_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv, int64_t ldd, float* dvec, int32_t B, int32_t N,
-                           int32_t H, float scale, void* stream) {
+// dqkv: bf16 [B, N, 3, H, 64]; dvec: f32 scratch [B, H, N].  opf: the tensors' 16-bit format (VDK_OPF_BF16 | VDK_OPF_F16)
+template <int OF>
+static int al_launch_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv, int64_t ldd, float* dvec, int32_t B, int32_t N,
+                         int32_t H, float scale, void* stream) {
   const bf16_t* base = (const bf16_t*)qkv;
   bf16_t* dbase = (bf16_t*)dqkv;
   const long D = (long)H * 64;
   const int nt = (N + 31) / 32, G = (nt + 3) / 4;
   const int grid = al_grid((long)B * H * G);
   const size_t lds_q = 2 * AL_BUF + 4 * 4096, lds_kv = 2 * AL_BUFKV + 4 * 4096;
-  if (hipFuncSetAttribute((const void*)attn_l_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q) != hipSuccess ||
-      hipFuncSetAttribute((const void*)attn_l_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv) != hipSuccess)
+  if (hipFuncSetAttribute((const void*)attn_l_bwd_q_kernel<OF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q) != hipSuccess ||
+      hipFuncSetAttribute((const void*)attn_l_bwd_kv_kernel<OF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv) != hipSuccess)
     return vdk_fail(VDK_ELAUNCH, "vdk_attention_bwd: LDS attribute");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_l_bwd_q_kernel, dim3((unsigned)grid), dim3(256), lds_q, s, base, base + D, base + 2 * D, (long)ld, (const bf16_t*)o, (const bf16_t*)dout, (long)ldo, lse, dvec,
+  hipLaunchKernelGGL(attn_l_bwd_q_kernel<OF>, dim3((unsigned)grid), dim3(256), lds_q, s, base, base + D, base + 2 * D, (long)ld, (const bf16_t*)o, (const bf16_t*)dout, (long)ldo, lse, dvec,
                      dbase, (long)ldd, (int)N, (int)H, scale, (int)(B * H), G);
-  hipLaunchKernelGGL(attn_l_bwd_kv_kernel, dim3((unsigned)grid), dim3(256), lds_kv, s, base, base + D, base + 2 * D, (long)ld, (const bf16_t*)dout, (long)ldo, lse, (const float*)dvec,
+  hipLaunchKernelGGL(attn_l_bwd_kv_kernel<OF>, dim3((unsigned)grid), dim3(256), lds_kv, s, base, base + D, base + 2 * D, (long)ld, (const bf16_t*)dout, (long)ldo, lse, (const float*)dvec,
                      dbase + D, dbase + 2 * D, (long)ldd, (int)N, (int)H, scale, (int)(B * H), G);
   return VDK_OK;
 }
+int vdk_attention_long_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv, int64_t ldd, float* dvec, int32_t B, int32_t N,
+                           int32_t H, float scale, int opf, void* stream) {
+  return opf ? al_launch_bwd<VDK_OPF_F16>(qkv, ld, o, dout, ldo, lse, dqkv, ldd, dvec, B, N, H, scale, stream)
+             : al_launch_bwd<0>(qkv, ld, o, dout, ldo, lse, dqkv, ldd, dvec, B, N, H, scale, stream);
+}
 
 // in-library entry point (attention.hip routes N > 256 here)
-int vdk_attention_long_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H, float scale, void* stream) {
+template <int OF>
+static int al_launch_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H, float scale, void* stream) {
   const bf16_t* base = (const bf16_t*)qkv;
   const long D = (long)H * 64;
   const int nt = (N + 31) / 32, G = (nt + 3) / 4;
   const long units = (long)B * H * G;
   const int grid = al_grid(units);
   const size_t lds = 2 * AL_BUF + 4 * 4096;
-  if (hipFuncSetAttribute((const void*)attn_l_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  if (hipFuncSetAttribute((const void*)attn_l_fwd_kernel<OF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return vdk_fail(VDK_ELAUNCH, "vdk_attention_fwd: LDS attribute");
-  hipLaunchKernelGGL(attn_l_fwd_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, base, base + D, base + 2 * D, (long)ld, (bf16_t*)o, (long)ldo, lse, (int)N, (int)H,
+  hipLaunchKernelGGL(attn_l_fwd_kernel<OF>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, base, base + D, base + 2 * D, (long)ld, (bf16_t*)o, (long)ldo, lse, (int)N, (int)H,
                      scale, (int)(B * H), G);
   return VDK_OK;
+}
+int vdk_attention_long_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H, float scale, int opf, void* stream) {
+  return opf ? al_launch_fwd<VDK_OPF_F16>(qkv, ld, o, ldo, lse, B, N, H, scale, stream) : al_launch_fwd<0>(qkv, ld, o, ldo, lse, B, N, H, scale, stream);
 }

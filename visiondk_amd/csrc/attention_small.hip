@@ -26,7 +26,7 @@
 // =====================================================================================  forward
 // LDS (dynamic): Q [R8 rows] | K [R8] | V [R8] | zero rows up to 32*NKT of the V array.  R8 = N rounded up to 8.  Tile reads beyond R8 fall into the
 // next array (finite data whose contribution is masked) or into the zero rows (V: P is exactly 0 there).  A wave's O tile is staged in its own Q rows.
-template <int NKT>
+template <int NKT, int OF = 0>
 __global__ __launch_bounds__(256, (NKT <= 7 ? 2 : 1)) void attn_s_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld,
                                                                               bf16_t* __restrict__ o, long ldo, float* __restrict__ lse, int N, int H, float scale, int nitems) {
   VDK_DYN_LDS(smem);
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, (NKT <= 7 ? 2 : 1)) void attn_s_fwd_kernel(con
       for (int kt = 0; kt < NKT; ++kt) {
         st[kt] = as_zero16();
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Ks + kt * 32 * AS_ROW, al, ks), qf[ks], st[kt], 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks) st[kt] = vdk_mfma32<OF>(as_row_frag_l(Ks + kt * 32 * AS_ROW, al, ks), qf[ks], st[kt]);
       }
       if (N & 31) {                                    // ragged last key tile (wave-uniform)
 #pragma unroll
@@ -87,14 +87,14 @@ __global__ __launch_bounds__(256, (NKT <= 7 ? 2 : 1)) void attn_s_fwd_kernel(con
 #pragma unroll
         for (int r = 0; r < 16; ++r) pn[r] = st[kt][r] * inv;
         s16x8 pf[2];
-        as_pack_b(pn, pf);
+        as_pack_b<OF>(pn, pf);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Vs + (kt * 32 + 16 * s) * AS_ROW, al, 0), pf[s], o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Vs + (kt * 32 + 16 * s) * AS_ROW, al, 1), pf[s], o1, 0, 0, 0);
+          o0 = vdk_mfma32<OF>(as_tr_frag_l(Vs + (kt * 32 + 16 * s) * AS_ROW, al, 0), pf[s], o0);
+          o1 = vdk_mfma32<OF>(as_tr_frag_l(Vs + (kt * 32 + 16 * s) * AS_ROW, al, 1), pf[s], o1);
         }
       }
-      as_store_tile(Qs + qt * 32 * AS_ROW, o0, o1, 1.0f, o + (long)b * N * ldo + h * 64, ldo, qt * 32, N, lane);
+      as_store_tile<OF>(Qs + qt * 32 * AS_ROW, o0, o1, 1.0f, o + (long)b * N * ldo + h * 64, ldo, qt * 32, N, lane);
       if (lse && hi == 0 && qrow < N) lse[((long)b * H + h) * N + qrow] = (m2 + log2f(l)) * 0.6931471805599453f;
     }
   }
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(512, 2) void attn_s_bwd2_kernel(const bf16_t* __res
 //   kv kernel: Q, dO LDS-resident; a wave takes key tiles w, w+4, ...: K / V fragments straight from global, dK^T / dV^T in registers.  It also computes
 //              D = rowsum(dO * O) (it holds dO) and writes it to `dvec` for the q kernel.
 //   q kernel:  K, V LDS-resident; a wave takes query tiles w, w+4, ...: Q / dO fragments straight from global, transposed products (lane = query), dQ^T in registers.
-template <int NKT>
+template <int NKT, int OF = 0>
 __global__ __launch_bounds__(256, 2) void attn_s_bwd_kv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld,
                                                                const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, long ldo, const float* __restrict__ lse,
                                                                float* __restrict__ dvec, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long ldd, int N, int H, float scale,
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void attn_s_bwd_kv_kernel(const bf16_t* __r
       if (row < NP) {
         const u32x4 a = *(const u32x4*)(Os + row * AS_ROW + ((cp ^ as_f(row)) << 4));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { d = fmaf(bf_lo(a[e]), bf_lo(opiece[p][e]), d); d = fmaf(bf_hi(a[e]), bf_hi(opiece[p][e]), d); }
+        for (int e = 0; e < 4; ++e) { d = fmaf(op_lo<OF>(a[e]), op_lo<OF>(opiece[p][e]), d); d = fmaf(op_hi<OF>(a[e]), op_hi<OF>(opiece[p][e]), d); }
       }
       d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
       if (row < NP && cp == 0) { Dv[row] = row < N ? d : 0.f; if (row < N) dvec[((long)b * H + h) * N + row] = d; }
@@ -509,8 +509,8 @@ __global__ __launch_bounds__(256, 2) void attn_s_bwd_kv_kernel(const bf16_t* __r
         f32x16 st = as_zero16(), dp = as_zero16();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Qs + q0 * AS_ROW, al, ks), kf[ks], st, 0, 0, 0);   // S[q][key]: lane = key, registers = queries
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Os + q0 * AS_ROW, al, ks), vf[ks], dp, 0, 0, 0);   // dP[q][key]
+          st = vdk_mfma32<OF>(as_row_frag_l(Qs + q0 * AS_ROW, al, ks), kf[ks], st);   // S[q][key]: lane = key, registers = queries
+          dp = vdk_mfma32<OF>(as_row_frag_l(Os + q0 * AS_ROW, al, ks), vf[ks], dp);   // dP[q][key]
         }
         f32x16 pv, ds;
         // Masking: only rows of the last query tile beyond N must be silenced (they would add into valid sums).  Lanes of keys beyond N need nothing: a lane is a column
@@ -530,23 +530,23 @@ __global__ __launch_bounds__(256, 2) void attn_s_bwd_kv_kernel(const bf16_t* __r
           }
         }
         s16x8 pf[2], df[2];
-        as_pack_b(pv, pf);
-        as_pack_b(ds, df);
+        as_pack_b<OF>(pv, pf);
+        as_pack_b<OF>(ds, df);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          gv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Os + (q0 + 16 * s2) * AS_ROW, al, 0), pf[s2], gv0, 0, 0, 0);     // dV^T[d][key] += dO^T P
-          gv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Os + (q0 + 16 * s2) * AS_ROW, al, 1), pf[s2], gv1, 0, 0, 0);
-          gk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Qs + (q0 + 16 * s2) * AS_ROW, al, 0), df[s2], gk0, 0, 0, 0);     // dK^T[d][key] += Q^T dS
-          gk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Qs + (q0 + 16 * s2) * AS_ROW, al, 1), df[s2], gk1, 0, 0, 0);
+          gv0 = vdk_mfma32<OF>(as_tr_frag_l(Os + (q0 + 16 * s2) * AS_ROW, al, 0), pf[s2], gv0);     // dV^T[d][key] += dO^T P
+          gv1 = vdk_mfma32<OF>(as_tr_frag_l(Os + (q0 + 16 * s2) * AS_ROW, al, 1), pf[s2], gv1);
+          gk0 = vdk_mfma32<OF>(as_tr_frag_l(Qs + (q0 + 16 * s2) * AS_ROW, al, 0), df[s2], gk0);     // dK^T[d][key] += Q^T dS
+          gk1 = vdk_mfma32<OF>(as_tr_frag_l(Qs + (q0 + 16 * s2) * AS_ROW, al, 1), df[s2], gk1);
         }
       }
-      as_store_tile(Wt, gk0, gk1, scale, dk + (long)b * N * ldd + h * 64, ldd, kt * 32, N, lane);
-      as_store_tile(Wt, gv0, gv1, 1.0f, dv + (long)b * N * ldd + h * 64, ldd, kt * 32, N, lane);
+      as_store_tile<OF>(Wt, gk0, gk1, scale, dk + (long)b * N * ldd + h * 64, ldd, kt * 32, N, lane);
+      as_store_tile<OF>(Wt, gv0, gv1, 1.0f, dv + (long)b * N * ldd + h * 64, ldd, kt * 32, N, lane);
     }
   }
 }
 
-template <int NKT>
+template <int NKT, int OF = 0>
 __global__ __launch_bounds__(256, 2) void attn_s_bwd_q_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld,
                                                               const bf16_t* __restrict__ dout, long ldo, const float* __restrict__ lse, const float* __restrict__ dvec,
                                                               bf16_t* __restrict__ dq, long ldd, int N, int H, float scale, int nitems) {
@@ -587,8 +587,8 @@ __global__ __launch_bounds__(256, 2) void attn_s_bwd_q_kernel(const bf16_t* __re
         f32x16 st = as_zero16(), dp = as_zero16();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Ks + k0 * AS_ROW, al, ks), qf[ks], st, 0, 0, 0);   // S^T[key][q]: lane = query, registers = keys
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_row_frag_l(Vs + k0 * AS_ROW, al, ks), gf[ks], dp, 0, 0, 0);   // dP^T[key][q]
+          st = vdk_mfma32<OF>(as_row_frag_l(Ks + k0 * AS_ROW, al, ks), qf[ks], st);   // S^T[key][q]: lane = query, registers = keys
+          dp = vdk_mfma32<OF>(as_row_frag_l(Vs + k0 * AS_ROW, al, ks), gf[ks], dp);   // dP^T[key][q]
         }
         f32x16 ds;
         const bool edge = ragged && kt == NKT - 1;                     // keys beyond N in the last key tile; a lane (= query) beyond N only spoils its own, unstored column
@@ -599,14 +599,14 @@ __global__ __launch_bounds__(256, 2) void attn_s_bwd_q_kernel(const bf16_t* __re
           ds[r] = p * (dp[r] - dq_);
         }
         s16x8 df[2];
-        as_pack_b(ds, df);
+        as_pack_b<OF>(ds, df);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          gq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Ks + (k0 + 16 * s2) * AS_ROW, al, 0), df[s2], gq0, 0, 0, 0);     // dQ^T[d][q] += K^T dS^T
-          gq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_tr_frag_l(Ks + (k0 + 16 * s2) * AS_ROW, al, 1), df[s2], gq1, 0, 0, 0);
+          gq0 = vdk_mfma32<OF>(as_tr_frag_l(Ks + (k0 + 16 * s2) * AS_ROW, al, 0), df[s2], gq0);     // dQ^T[d][q] += K^T dS^T
+          gq1 = vdk_mfma32<OF>(as_tr_frag_l(Ks + (k0 + 16 * s2) * AS_ROW, al, 1), df[s2], gq1);
         }
       }
-      as_store_tile(Wt, gq0, gq1, scale, dq + (long)b * N * ldd + h * 64, ldd, qt * 32, N, lane);
+      as_store_tile<OF>(Wt, gq0, gq1, scale, dq + (long)b * N * ldd + h * 64, ldd, qt * 32, N, lane);
     }
   }
 }
@@ -777,13 +777,13 @@ __global__ __launch_bounds__(512) void attn_s_bwd1p_kernel(const bf16_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
-template <int NKT>
+template <int NKT, int OF>
 static int launch_fwd(const bf16_t* base, long D, long ld, bf16_t* o, long ldo, float* lse, int B, int N, int H, float scale, int grid, hipStream_t s) {
   const int R8 = (N + 7) & ~7;
   const size_t lds = (size_t)(2 * R8 + 32 * NKT) * AS_ROW;
-  if (hipFuncSetAttribute((const void*)attn_s_fwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  if (hipFuncSetAttribute((const void*)attn_s_fwd_kernel<NKT, OF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return vdk_fail(VDK_ELAUNCH, "vdk_attention_fwd: LDS attribute");
-  hipLaunchKernelGGL((attn_s_fwd_kernel<NKT>), dim3((unsigned)grid), dim3(256), lds, s, base, base + D, base + 2 * D, ld, o, ldo, lse, N, H, scale, B * H);
+  hipLaunchKernelGGL((attn_s_fwd_kernel<NKT, OF>), dim3((unsigned)grid), dim3(256), lds, s, base, base + D, base + 2 * D, ld, o, ldo, lse, N, H, scale, B * H);
   return VDK_OK;
 }
 template <int NKT>
@@ -813,21 +813,21 @@ static int launch_bwd2(const bf16_t* base, long D, long ld, const bf16_t* o, con
   return VDK_OK;
 }
 static int grid_cap3(int dflt);
-template <int NKT>
+template <int NKT, int OF>
 static int launch_bwd3(const bf16_t* base, long D, long ld, const bf16_t* o, const bf16_t* dout, long ldo, const float* lse, float* dvec, bf16_t* dbase, long ldd, int B, int N,
                        int H, float scale, hipStream_t s) {
   const int R8 = (N + 7) & ~7, NP = 32 * NKT;
   const size_t lds_kv = (size_t)(R8 + NP) * AS_ROW + 4 * 4096 + (size_t)NP * 8, lds_q = (size_t)(R8 + NP) * AS_ROW + 4 * 4096;
   if (lds_kv > 80 * 1024 || !dvec) return VDK_EUNSUPPORTED;             // two workgroups per CU are the point
-  if (hipFuncSetAttribute((const void*)attn_s_bwd_kv_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv) != hipSuccess ||
-      hipFuncSetAttribute((const void*)attn_s_bwd_q_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q) != hipSuccess)
+  if (hipFuncSetAttribute((const void*)attn_s_bwd_kv_kernel<NKT, OF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv) != hipSuccess ||
+      hipFuncSetAttribute((const void*)attn_s_bwd_q_kernel<NKT, OF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q) != hipSuccess)
     return vdk_fail(VDK_ELAUNCH, "vdk_attention_bwd: LDS attribute");
   int grid = B * H;
   const int cap = grid_cap3(512);
   if (grid > cap) grid = cap;
-  hipLaunchKernelGGL((attn_s_bwd_kv_kernel<NKT>), dim3((unsigned)grid), dim3(256), lds_kv, s, base, base + D, base + 2 * D, ld, o, dout, ldo, lse, dvec, dbase + D, dbase + 2 * D, ldd,
+  hipLaunchKernelGGL((attn_s_bwd_kv_kernel<NKT, OF>), dim3((unsigned)grid), dim3(256), lds_kv, s, base, base + D, base + 2 * D, ld, o, dout, ldo, lse, dvec, dbase + D, dbase + 2 * D, ldd,
                      N, H, scale, B * H);
-  hipLaunchKernelGGL((attn_s_bwd_q_kernel<NKT>), dim3((unsigned)grid), dim3(256), lds_q, s, base, base + D, base + 2 * D, ld, dout, ldo, lse, (const float*)dvec, dbase, ldd, N, H,
+  hipLaunchKernelGGL((attn_s_bwd_q_kernel<NKT, OF>), dim3((unsigned)grid), dim3(256), lds_q, s, base, base + D, base + 2 * D, ld, dout, ldo, lse, (const float*)dvec, dbase, ldd, N, H,
                      scale, B * H);
   return VDK_OK;
 }
@@ -852,7 +852,7 @@ static int grid_cap(int dflt) {
 }
 
 // in-library entry points (attention.hip routes N <= 256 / N <= 224 here); return VDK_EUNSUPPORTED to let the caller fall back
-int vdk_attention_small_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H, float scale, void* stream) {
+int vdk_attention_small_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H, float scale, int opf, void* stream) {
   const int nkt = (N + 31) / 32;
   if (nkt < 1 || nkt > 8) return VDK_EUNSUPPORTED;
   const bf16_t* base = (const bf16_t*)qkv;
@@ -862,19 +862,15 @@ int vdk_attention_small_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, f
   if (grid > cap) grid = cap;
   hipStream_t s = (hipStream_t)stream;
   switch (nkt) {
-    case 1: return launch_fwd<1>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s);
-    case 2: return launch_fwd<2>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s);
-    case 3: return launch_fwd<3>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s);
-    case 4: return launch_fwd<4>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s);
-    case 5: return launch_fwd<5>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s);
-    case 6: return launch_fwd<6>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s);
-    case 7: return launch_fwd<7>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s);
-    default: return launch_fwd<8>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s);
+#define FW(n) case n: return opf ? launch_fwd<n, VDK_OPF_F16>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s) : launch_fwd<n, 0>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s);
+    FW(1) FW(2) FW(3) FW(4) FW(5) FW(6) FW(7)
+    default: return opf ? launch_fwd<8, VDK_OPF_F16>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s) : launch_fwd<8, 0>(base, D, ld, (bf16_t*)o, ldo, lse, B, N, H, scale, grid, s);
+#undef FW
   }
 }
 
 int vdk_attention_small_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv, int64_t ldd, float* dvec, int32_t B, int32_t N,
-                            int32_t H, float scale, void* stream) {
+                            int32_t H, float scale, int opf, void* stream) {
   const int nkt = (N + 31) / 32;
   if (nkt < 1 || nkt > 7) return VDK_EUNSUPPORTED;
   const bf16_t* base = (const bf16_t*)qkv;
@@ -885,6 +881,7 @@ int vdk_attention_small_bwd(const void* qkv, int64_t ld, const void* o, const vo
   hipStream_t s = (hipStream_t)stream;
   int form = g_bwd_form;
   if (form < 0) { const char* e = getenv("VDK_ATTN_BWD_FORM"); form = e ? atoi(e) : 3; }
+  if (opf) form = 3;          // fp16 operands: the default two-kernel form (the A/B forms 1 / 2 / 4 are bf16 only)
   if (form == 4) {
     switch (nkt) {
 #define B4(n) case n: return launch_bwd1p<n>(base, D, ld, (const bf16_t*)o, (const bf16_t*)dout, ldo, lse, (bf16_t*)dqkv, ldd, B, N, H, scale, grid, s);
@@ -895,11 +892,12 @@ int vdk_attention_small_bwd(const void* qkv, int64_t ld, const void* o, const vo
   if (form == 3) {
     int rc = VDK_EUNSUPPORTED;
     switch (nkt) {
-#define B3(n) case n: rc = launch_bwd3<n>(base, D, ld, (const bf16_t*)o, (const bf16_t*)dout, ldo, lse, dvec, (bf16_t*)dqkv, ldd, B, N, H, scale, s); break;
+#define B3(n) case n: rc = opf ? launch_bwd3<n, VDK_OPF_F16>(base, D, ld, (const bf16_t*)o, (const bf16_t*)dout, ldo, lse, dvec, (bf16_t*)dqkv, ldd, B, N, H, scale, s) \
+                           : launch_bwd3<n, 0>(base, D, ld, (const bf16_t*)o, (const bf16_t*)dout, ldo, lse, dvec, (bf16_t*)dqkv, ldd, B, N, H, scale, s); break;
       B3(1) B3(2) B3(3) B3(4) B3(5) B3(6) B3(7)
 #undef B3
     }
-    if (rc != VDK_EUNSUPPORTED) return rc;
+    if (rc != VDK_EUNSUPPORTED || opf) return rc;
     form = 2;
   }
 #define BW(n) (form == 2 ? launch_bwd2<n>(base, D, ld, (const bf16_t*)o, (const bf16_t*)dout, ldo, lse, (bf16_t*)dqkv, ldd, B, N, H, scale, grid, s) \

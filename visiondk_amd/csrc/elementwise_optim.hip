@@ -11,6 +11,7 @@
 #include "vdk_host.h"
 
 // P[(b*gh*gw + gy*gw + gx)][c*ps*ps + ky*ps + kx] = x[b][c][gy*ps+ky][gx*ps+kx]   (bf16, K padded to Kp with 0)
+template <int OF = 0>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, int B, int Cin, int H, int W, int ps,
                                                        bf16_t* __restrict__ out, int Kp) {
   const int gh = H / ps, gw = W / ps, K = Cin * ps * ps;
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
       v[e] = t;
     }
   }
-  *(u32x4*)(out + m * Kp + kc) = (u32x4){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+  *(u32x4*)(out + m * Kp + kc) = (u32x4){pack_op2<OF>(v[0], v[1]), pack_op2<OF>(v[2], v[3]), pack_op2<OF>(v[4], v[5]), pack_op2<OF>(v[6], v[7])};
 }
 
 // tok[b][0][:] = cls + pos[0]
@@ -56,11 +57,12 @@ __global__ __launch_bounds__(256) void cls_rows_kernel(float* __restrict__ tok, 
   tok[(long)b * batch_stride + d] = cls[d] + pos0[d];
 }
 
+template <int OF = 0>
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n4) {
   long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   f32x4 v = *(const f32x4*)(in + i * 4);
-  *(u32x2*)(out + i * 4) = (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+  *(u32x2*)(out + i * 4) = (u32x2){pack_op2<OF>(v[0], v[1]), pack_op2<OF>(v[2], v[3])};
 }
 
 // out[c][r] (bf16, ld ldo) = in[r][c] (fp32, ld ldi); zero-fills rows r in [R, Rpad) of the output columns
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
 // the same for a table of jobs passed by value (<= TC_MAX per launch): block -> job by a scan over the tile prefix sums
 #define TC_MAX 64
 struct TcTable { VdkTcItem it[TC_MAX]; int tile0[TC_MAX + 1]; int n; };
+template <int OF = 0>
 __global__ __launch_bounds__(256) void transpose_cast_batch_kernel(TcTable t) {
   __shared__ float tile[64][65];
   int j = 0;
@@ -101,16 +104,17 @@ __global__ __launch_bounds__(256) void transpose_cast_batch_kernel(TcTable t) {
   for (int i = 0; i < 16; ++i) {
     int col = i * 4 + (tid >> 6), row = tid & 63;
     int gc = c0 + col, gr = r0 + row;
-    if (gc < a.C && gr < a.Rpad) out[(long)gc * a.ldo + gr] = f2bf(tile[row][col]);
+    if (gc < a.C && gr < a.Rpad) out[(long)gc * a.ldo + gr] = f2op<OF>(tile[row][col]);
   }
 }
 
+template <int OF = 0>
 __global__ __launch_bounds__(256) void cast_pad_rows_kernel(const float* __restrict__ in, long ldi, int R, int Cc, bf16_t* __restrict__ out, long ldo) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)R * ldo) return;
   const int c = (int)(i % ldo);
   const long r = i / ldo;
-  out[i] = f2bf(c < Cc ? in[r * ldi + c] : 0.f);
+  out[i] = f2op<OF>(c < Cc ? in[r * ldi + c] : 0.f);
 }
 // partial[b] = sum of g[i]^2 over the block's slice
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ partial) {
@@ -141,16 +145,31 @@ struct SgdArgs {
   int first_step;
   const float* hyper;    // device [5] or NULL: lr, momentum, weight_decay, ema_decay, first_step (!= 0) override the by-value fields, so that a step
                          // captured in a hipGraph can be replayed while the schedule and the EMA warm-up move on
+  const float* loss_scale;   // device scalar or NULL: GradScaler's scale S -- the gradients (and normsq) carry it: g / S is what is clipped and applied
+                             // (scaler.unscale_, train.py:208), and a non-finite sum g^2 skips the whole update (scaler.step, train.py:210)
 };
 // torch.nn.utils.clip_grad_norm_: coef = clamp(max_norm / (norm + 1e-6), max=1); g *= coef
 // torch.optim.SGD (nesterov=False, dampening=0): g += wd*p; buf = first ? g : mom*buf + g; p -= lr*buf
 // ModelEMA.update: v = d*v + (1-d)*p
+template <int OF = 0>
 __global__ __launch_bounds__(256) void sgd_step_kernel(SgdArgs a) {
   if (a.hyper) { a.lr = a.hyper[0]; a.momentum = a.hyper[1]; a.weight_decay = a.hyper[2]; a.ema_decay = a.hyper[3]; a.first_step = a.hyper[4] != 0.f; }
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const long n4 = (a.n + 3) >> 2;
   if (i >= n4) return;
   float coef = a.grad_scale;
+  if (a.loss_scale) {
+    // inf / NaN anywhere in the scaled gradient makes its sum of squares non-finite: GradScaler.step skips optimizer.step(); the reference's loop still runs
+    // ema.update(model) on the unchanged weights (train.py:210-215), and so does this pass
+    if (a.normsq && !(fabsf(a.normsq[0]) < 3.0e38f)) {
+      if (!a.ema) return;
+      const long base = i * 4;
+      for (long j = base; j < a.n && j < base + 4; ++j) a.ema[j] = a.ema[j] * a.ema_decay + (1.0f - a.ema_decay) * a.p[j];
+      return;
+    }
+    a.grad_scale /= a.loss_scale[0];
+    coef = a.grad_scale;
+  }
   if (a.normsq) {
     float nrm = sqrtf(a.normsq[0]) * fabsf(a.grad_scale);
     float c = a.max_norm / (nrm + 1e-6f);
@@ -175,7 +194,7 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(SgdArgs a) {
       for (int e = 0; e < 4; ++e) v[e] = v[e] * a.ema_decay + (1.0f - a.ema_decay) * p[e];
       *(f32x4*)(a.ema + base) = v;
     }
-    if (a.pb) *(u32x2*)(a.pb + base) = (u32x2){pack_bf2(p[0], p[1]), pack_bf2(p[2], p[3])};
+    if (a.pb) *(u32x2*)(a.pb + base) = (u32x2){pack_op2<OF>(p[0], p[1]), pack_op2<OF>(p[2], p[3])};
   } else {
     for (long j = base; j < a.n; ++j) {
       float p = a.p[j];
@@ -185,9 +204,20 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(SgdArgs a) {
       p -= a.lr * buf;
       a.p[j] = p;
       if (a.ema) a.ema[j] = a.ema[j] * a.ema_decay + (1.0f - a.ema_decay) * p;
-      if (a.pb) a.pb[j] = f2bf(p);
+      if (a.pb) a.pb[j] = f2op<OF>(p);
     }
   }
+}
+
+// torch.cuda.amp.GradScaler.update (train.py:211) on the device: state = {scale, growth tracker, skipped steps}.  found_inf = the scaled gradient's sum of squares is
+// not finite.  found_inf: scale *= backoff, tracker = 0; else ++tracker == growth_interval: scale *= growth, tracker = 0.  (torch defaults: 65536, 2, 0.5, 2000.)
+__global__ void loss_scale_update_kernel(float* __restrict__ state, const float* __restrict__ normsq, float growth, float backoff, int interval) {
+  if (threadIdx.x || blockIdx.x) return;
+  const bool bad = !(fabsf(normsq[0]) < 3.0e38f);
+  float sc = state[0], tr = state[1];
+  if (bad) { sc *= backoff; tr = 0.f; state[2] += 1.f; }
+  else { tr += 1.f; if (tr >= (float)interval) { const float g = sc * growth; if (g < 3.0e38f) sc = g; tr = 0.f; } }
+  state[0] = sc; state[1] = tr;
 }
 
 // out[b] = lam * x[b] + (1 - lam) * x[perm[b]]   (mixup_data, train.py:24-32)
@@ -290,7 +320,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   }
 }
 
-int vdk_transpose_cast_batch(const VdkTcItem* items, int n, void* stream) {
+int vdk_transpose_cast_batch(const VdkTcItem* items, int n, void* stream, int opf) {
   if (!items || n < 0) return vdk_fail(VDK_EINVAL, "vdk_transpose_cast_batch: bad argument");
   for (int base = 0; base < n; base += TC_MAX) {
     TcTable t;
@@ -303,28 +333,45 @@ int vdk_transpose_cast_batch(const VdkTcItem* items, int n, void* stream) {
       tiles += ((a.Rpad + 63) / 64) * ((a.C + 63) / 64);
     }
     t.tile0[t.n] = tiles;
-    hipLaunchKernelGGL(transpose_cast_batch_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, t);
+    if (opf) hipLaunchKernelGGL(transpose_cast_batch_kernel<VDK_OPF_F16>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, t);
+    else hipLaunchKernelGGL(transpose_cast_batch_kernel<0>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, t);
   }
   return vdk_check_launch("vdk_transpose_cast_batch");
 }
 
-int vdk_cast_pad_rows(const float* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, void* stream) {
+int vdk_cast_pad_rows(const float* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, void* stream, int opf) {
   if (!in || !out || R <= 0 || C <= 0 || ldo < C || ldi < C) return vdk_fail(VDK_EINVAL, "vdk_cast_pad_rows: bad argument");
-  hipLaunchKernelGGL(cast_pad_rows_kernel, dim3((unsigned)(((long)R * ldo + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, (long)ldi, (int)R, (int)C, (bf16_t*)out,
+  if (opf) hipLaunchKernelGGL(cast_pad_rows_kernel<VDK_OPF_F16>, dim3((unsigned)(((long)R * ldo + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, (long)ldi, (int)R, (int)C,
+                              (bf16_t*)out, (long)ldo);
+  else
+  hipLaunchKernelGGL(cast_pad_rows_kernel<0>, dim3((unsigned)(((long)R * ldo + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, (long)ldi, (int)R, (int)C, (bf16_t*)out,
                      (long)ldo);
   return vdk_check_launch("vdk_cast_pad_rows");
+}
+
+int vdk_patchify_16(const float* x, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t patch, void* out, int32_t Kp, int opf, void* stream) {
+  if (!x || !out || B <= 0 || Cin <= 0 || patch <= 0 || H % patch || W % patch || (Kp & 7) || Kp < Cin * patch * patch)
+    return vdk_fail(VDK_EINVAL, "vdk_patchify_bf16: bad argument");
+  long nchunk = (long)B * (H / patch) * (W / patch) * (Kp / 8);
+  if (opf) hipLaunchKernelGGL(patchify_kernel<VDK_OPF_F16>, dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (int)B, (int)Cin, (int)H, (int)W, (int)patch,
+                              (bf16_t*)out, (int)Kp);
+  else hipLaunchKernelGGL(patchify_kernel<0>, dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (int)B, (int)Cin,
+                          (int)H, (int)W, (int)patch, (bf16_t*)out, (int)Kp);
+  return vdk_check_launch("vdk_patchify_bf16");
+}
+int vdk_cast_f32_16(const float* in, void* out, int64_t n, int opf, void* stream) {
+  if (!in || !out || n < 0 || (n & 3)) return vdk_fail(VDK_EINVAL, "vdk_cast_f32_bf16: n % 4 == 0 required");
+  if (n == 0) return VDK_OK;
+  if (opf) hipLaunchKernelGGL(cast_f32_bf16_kernel<VDK_OPF_F16>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, (long)(n / 4));
+  else hipLaunchKernelGGL(cast_f32_bf16_kernel<0>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, (long)(n / 4));
+  return vdk_check_launch("vdk_cast_f32_bf16");
 }
 
 extern "C" {
 
 int vdk_patchify_bf16(const float* x, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t patch, void* out, int32_t Kp,
                       void* stream) {
-  if (!x || !out || B <= 0 || Cin <= 0 || patch <= 0 || H % patch || W % patch || (Kp & 7) || Kp < Cin * patch * patch)
-    return vdk_fail(VDK_EINVAL, "vdk_patchify_bf16: bad argument");
-  long nchunk = (long)B * (H / patch) * (W / patch) * (Kp / 8);
-  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (int)B, (int)Cin,
-                     (int)H, (int)W, (int)patch, (bf16_t*)out, (int)Kp);
-  return vdk_check_launch("vdk_patchify_bf16");
+  return vdk_patchify_16(x, B, Cin, H, W, patch, out, Kp, VDK_OPF_BF16, stream);
 }
 
 int vdk_cls_rows(float* tok, int64_t batch_stride, int32_t B, int32_t D, const float* cls, const float* pos0, void* stream) {
@@ -334,13 +381,8 @@ int vdk_cls_rows(float* tok, int64_t batch_stride, int32_t B, int32_t D, const f
   return vdk_check_launch("vdk_cls_rows");
 }
 
-int vdk_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream) {
-  if (!in || !out || n < 0 || (n & 3)) return vdk_fail(VDK_EINVAL, "vdk_cast_f32_bf16: n % 4 == 0 required");
-  if (n == 0) return VDK_OK;
-  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out,
-                     (long)(n / 4));
-  return vdk_check_launch("vdk_cast_f32_bf16");
-}
+int vdk_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream) { return vdk_cast_f32_16(in, out, n, VDK_OPF_BF16, stream); }
+int vdk_cast_f32_f16(const float* in, void* out, int64_t n, void* stream) { return vdk_cast_f32_16(in, out, n, VDK_OPF_F16, stream); }
 
 int vdk_transpose_cast_f32_bf16(const float* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, int32_t Rpad,
                                 void* stream) {
@@ -369,15 +411,16 @@ int vdk_sumsq_f32(const float* g, int64_t n, float* out, void* ws, size_t ws_byt
 // holding sum g^2 of the UNscaled grads, or NULL to skip clipping.  m / ema / params_bf16 may be NULL.
 static int sgd_launch(const char* what, float* params, const float* grads, float* momentum_buf, float* ema, void* params_bf16, int64_t n, float lr, float momentum,
                       float weight_decay, float grad_scale, const float* normsq, float max_norm, float ema_decay, int32_t first_step, const float* hyper,
-                      void* stream) {
+                      void* stream, int pb_opf = 0, const float* loss_scale = nullptr) {
   if (!params || !grads || !momentum_buf || n < 0) return vdk_fail(VDK_EINVAL, "vdk_sgd_step: bad argument");
   if (n == 0) return VDK_OK;
   SgdArgs a;
   a.p = params; a.g = grads; a.m = momentum_buf; a.ema = ema; a.pb = (bf16_t*)params_bf16; a.n = n;
   a.lr = lr; a.momentum = momentum; a.weight_decay = weight_decay; a.max_norm = max_norm; a.ema_decay = ema_decay;
-  a.grad_scale = grad_scale; a.normsq = normsq; a.first_step = first_step; a.hyper = hyper;
+  a.grad_scale = grad_scale; a.normsq = normsq; a.first_step = first_step; a.hyper = hyper; a.loss_scale = loss_scale;
   long n4 = (n + 3) / 4;
-  hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  if (pb_opf) hipLaunchKernelGGL(sgd_step_kernel<VDK_OPF_F16>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(sgd_step_kernel<0>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return vdk_check_launch(what);
 }
 int vdk_sgd_step(float* params, const float* grads, float* momentum_buf, float* ema, void* params_bf16, int64_t n, float lr,
@@ -392,6 +435,23 @@ int vdk_sgd_step_graph(float* params, const float* grads, float* momentum_buf, f
                        const float* normsq, float max_norm, void* stream) {
   if (!hyper) return vdk_fail(VDK_EINVAL, "vdk_sgd_step_graph: hyper is NULL");
   return sgd_launch("vdk_sgd_step_graph", params, grads, momentum_buf, ema, params_bf16, n, 0.f, 0.f, 0.f, grad_scale, normsq, max_norm, 0.f, 0, hyper, stream);
+}
+
+// vdk_sgd_step under GradScaler (train.py:205-211): the gradients carry the loss scale loss_state[0] (device); they are un-scaled, clipped and applied in the same pass,
+// the whole update is skipped when normsq is not finite, and params16 is refreshed in `p16_dtype` (VDK_BF16 | VDK_F16).  Follow with vdk_loss_scale_update.
+int vdk_sgd_step_amp(float* params, const float* grads, float* momentum_buf, float* ema, void* params16, int32_t p16_dtype, int64_t n, float lr, float momentum,
+                     float weight_decay, float grad_scale, const float* loss_state, const float* normsq, float max_norm, float ema_decay, int32_t first_step, void* stream) {
+  if (p16_dtype != VDK_BF16 && p16_dtype != VDK_F16) return vdk_fail(VDK_EINVAL, "vdk_sgd_step_amp: bad p16_dtype");
+  if (loss_state && !normsq) return vdk_fail(VDK_EINVAL, "vdk_sgd_step_amp: a loss scale needs normsq (the overflow check reads it)");
+  return sgd_launch("vdk_sgd_step_amp", params, grads, momentum_buf, ema, params16, n, lr, momentum, weight_decay, grad_scale, normsq, max_norm, ema_decay, first_step,
+                    nullptr, stream, p16_dtype == VDK_F16 ? VDK_OPF_F16 : VDK_OPF_BF16, loss_state);
+}
+// GradScaler.update (train.py:211): loss_state f32 [3] = {scale, growth tracker, skipped steps} on the device, normsq = the sum of squares vdk_sgd_step_amp looked at
+int vdk_loss_scale_update(float* loss_state, const float* normsq, float growth_factor, float backoff_factor, int32_t growth_interval, void* stream) {
+  if (!loss_state || !normsq || !(growth_factor >= 1.0f) || !(backoff_factor > 0.f && backoff_factor <= 1.0f) || growth_interval < 1)
+    return vdk_fail(VDK_EINVAL, "vdk_loss_scale_update: bad argument");
+  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_state, normsq, growth_factor, backoff_factor, (int)growth_interval);
+  return vdk_check_launch("vdk_loss_scale_update");
 }
 
 // SAM.first_step: normsq_out[0] = sum ((|p| | 1) * g)^2, then p_old = p; p += (p^2 | 1) * g * rho / (sqrt(normsq) + 1e-12)

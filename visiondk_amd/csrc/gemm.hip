@@ -81,7 +81,7 @@ __device__ __forceinline__ void g_load_tile_conv(u32x4 (&r)[4], const GemmParams
   }
 }
 
-template <bool CONV>
+template <bool CONV, int OF = 0>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmParams p) {
   // 2 buffers x (A 128 rows + B 128 rows) x 144 B = 73,728 B; reused as the fp32 epilogue tile (67,584 B)
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 128 * G_PITCH * 2];
@@ -140,10 +140,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmParams p) {
       s16x8 a1 = *(const s16x8*)(a_base + 32 * G_PITCH + ks * 16);
       s16x8 b0 = *(const s16x8*)(b_base + ks * 16);
       s16x8 b1 = *(const s16x8*)(b_base + 32 * G_PITCH + ks * 16);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+      acc[0][0] = vdk_mfma32<OF>(a0, b0, acc[0][0]);
+      acc[0][1] = vdk_mfma32<OF>(a0, b1, acc[0][1]);
+      acc[1][0] = vdk_mfma32<OF>(a1, b0, acc[1][0]);
+      acc[1][1] = vdk_mfma32<OF>(a1, b1, acc[1][1]);
     }
     if (kt + 1 < nk) {
       g_store_tile(ra, As + (cur ^ 1) * 128 * G_PITCH);
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
     }
-    g_epilogue_store8(p, mi, n, v, z);
+    g_epilogue_store8<OF>(p, mi, n, v, z);
   }
 }
 
@@ -617,6 +617,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
 }
 
 // out[i] = alpha * sum_s slabs[s][i]  (deterministic split-K combine), optional bf16 output
+template <int OF = 0>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int S, long n4 /*=MN/4*/,
                                                             long mn, float alpha, float* __restrict__ outf,
                                                             bf16_t* __restrict__ outb) {
@@ -629,10 +630,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
   s *= alpha;
   if (outf) *(f32x4*)(outf + i * 4) = s;
-  if (outb) *(u32x2*)(outb + i * 4) = (u32x2){pack_bf2(s[0], s[1]), pack_bf2(s[2], s[3])};
+  if (outb) *(u32x2*)(outb + i * 4) = (u32x2){pack_op2<OF>(s[0], s[1]), pack_op2<OF>(s[2], s[3])};
 }
 
 // out[c][r] = in[r][c] for r < R, 0 for R <= r < Rpad (bf16).  64x64 tiles through LDS.
+template <int OF = 0>
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, long ldi, int R, int Cc,
                                                              bf16_t* __restrict__ out, long ldo, int Rpad, int row_group,
                                                              float* __restrict__ colsum_partial) {
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
   __syncthreads();
   if (colsum_partial && tid < 64 && c0 + tid < Cc) {  // bias gradient rides along: per-row-tile column sums
     float sacc = 0.f;
-    for (int r = 0; r < 64; ++r) sacc += bf2f(tile[r][tid]);
+    for (int r = 0; r < 64; ++r) sacc += op2f<OF>(tile[r][tid]);
     colsum_partial[(long)blockIdx.x * Cc + c0 + tid] = sacc;
   }
   for (int i = 0; i < 8; ++i) {
@@ -826,7 +828,12 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
         d->K != c->KH * c->KW * c->Cin || (d->M % (c->OH * c->OW)))
       return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad convolution geometry (Cin % 8 == 0, K == KH*KW*Cin, M == B*OH*OW)");
   }
-  if (d->c_dtype != VDK_BF16 && d->c_dtype != VDK_F32) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad c_dtype");
+  if (d->ab_dtype != VDK_BF16 && d->ab_dtype != VDK_F16) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: ab_dtype must be VDK_BF16 or VDK_F16");
+  const int opf = d->ab_dtype == VDK_F16 ? VDK_OPF_F16 : VDK_OPF_BF16;
+  // a 16-bit output is written in the operand format (c_dtype names it: VDK_BF16 with bf16 operands, VDK_F16 with fp16 operands)
+  if (d->c_dtype != VDK_F32 && d->c_dtype != (opf ? VDK_F16 : VDK_BF16)) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad c_dtype (VDK_F32, or the operand format)");
+  if (opf && (d->a_colsum || d->conv || d->splitk == -1))
+    return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: fp16 operands are served by the four-wave and the 128x128 kernels (no a_colsum, no implicit convolution, no stream-K)");
   if (d->act < VDK_ACT_NONE || d->act > VDK_ACT_MUL_AUX) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad act");
   if (((d->act == VDK_ACT_DGELU || d->act == VDK_ACT_GELU_SAVE_GRAD || d->act == VDK_ACT_MUL_AUX) && !d->aux) || (d->aux && (d->ldaux & 7)))
     return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad aux");
@@ -835,7 +842,8 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C;
   p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
   p.M = d->M; p.N = d->N; p.K = d->K;
-  p.c_dtype = d->c_dtype; p.bias = (const float*)d->bias; p.residual = (const float*)d->residual; p.ldr = d->ldr;
+  p.opf = opf;
+  p.c_dtype = d->c_dtype == VDK_F32 ? VDK_F32 : VDK_BF16; p.bias = (const float*)d->bias; p.residual = (const float*)d->residual; p.ldr = d->ldr;
   p.act = d->act; p.aux = (bf16_t*)d->aux; p.ldaux = d->ldaux; p.alpha = d->alpha; p.row_group = d->row_group < 0 ? -d->row_group : d->row_group; p.row_shift = d->row_group > 0 ? 1 : 0; p.a_row_group = d->a_row_group;
   p.splitk = splitk; p.slabs = nullptr; p.sk_cnt = nullptr; p.dbg = (unsigned long long*)g_dbg_ptr;
   p.colsum_part = nullptr; p.ocs_part = nullptr;
@@ -870,7 +878,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   // compile-time epilogue variant (the common ViT forms); anything else takes the run-time-flag path
   int E = E_GENERIC;
   {
-    const bool bias = d->bias != nullptr, res = d->residual != nullptr, f32 = d->c_dtype == VDK_F32, rg = d->row_group != 0;
+    const bool bias = d->bias != nullptr, res = d->residual != nullptr, f32 = p.c_dtype == VDK_F32, rg = d->row_group != 0;
     const bool plain_alpha = d->alpha == 1.0f;
     if (splitk > 1) E = E_SPLITK;
     else if (plain_alpha && !rg && !res && d->act == VDK_ACT_NONE && !f32) E = bias ? E_BIAS : 0;
@@ -906,6 +914,14 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   } while (0)
 #define LAUNCH256X(TNF, EE, CSF)                                                                                         \
   do {                                                                                                                   \
+    if (opf) {   /* fp16 operands: the four-wave kernels' fp16 instantiation (gemm_w4_f16.hip), whichever form serves the problem */                 \
+      void* e0_ = prof ? (void*)g_prof_ev[g_prof_used] : nullptr; void* e1_ = prof ? (void*)g_prof_ev[g_prof_used + 1] : nullptr;                \
+      const bool hfirst_ = narrow || w4h_wanted(EE, TNF, p.M, p.N, p.K) || !(w4_enabled() && vdk_gemm_w4_serves(p, TNF));                         \
+      if (hfirst_ && vdk_gemm_w4h_serves(p, TNF) && vdk_gemm_w4h_launch_f16(p, TNF, EE, grid256.y, stream, e0_, e1_)) { g_last_kernel = 6; break; }   \
+      if (vdk_gemm_w4_serves(p, TNF) && vdk_gemm_w4_launch_f16(p, TNF, EE, grid256.x, grid256.y, stream, e0_, e1_)) { g_last_kernel = 5; break; }     \
+      if (vdk_gemm_w4h_serves(p, TNF) && vdk_gemm_w4h_launch_f16(p, TNF, EE, grid256.y, stream, e0_, e1_)) { g_last_kernel = 6; break; }          \
+      fp16_unserved = true; break;                                                                                        \
+    }                                                                                                                    \
     if (!sk && !(CSF) && (narrow || w4h_wanted(EE, TNF, p.M, p.N, p.K)) && vdk_gemm_w4h_serves(p, TNF) &&                                           \
         vdk_gemm_w4h_launch(p, TNF, EE, grid256.y, stream, prof ? (void*)g_prof_ev[g_prof_used] : nullptr,               \
                             prof ? (void*)g_prof_ev[g_prof_used + 1] : nullptr)) { g_last_kernel = 6; break; }           \
@@ -922,6 +938,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
     if (p.colsum_part) VDK_GEMM_LAUNCH((gemm256_bf16_kernel<false, EE, false, true>), grid256, dim3(512));                \
     else LAUNCH256X(false, EE, false);                                                                                   \
   } while (0)
+  bool fp16_unserved = false;
   if (d->trans) {
     if ((d->K % 64) || (kps % 64) || (d->M & 7) || d->M < 8 || d->N < 8)
       return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: trans=1 needs K and the split size to be multiples of 64 and M % 8 == 0");
@@ -970,13 +987,20 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
     VDK_GEMM_LAUNCH(gemm_bf16_nt_kernel<true>, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256));
   } else {
     g_last_kernel = 1;
-    VDK_GEMM_LAUNCH(gemm_bf16_nt_kernel<false>, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256));
+    if (opf) VDK_GEMM_LAUNCH((gemm_bf16_nt_kernel<false, VDK_OPF_F16>), dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256));
+    else VDK_GEMM_LAUNCH(gemm_bf16_nt_kernel<false>, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256));
+  }
+  if (fp16_unserved) {
+    // (a big NT problem the four-wave kernels cannot address -- operands beyond 2 GB -- still runs, on the 128x128 kernel; TN has no other home)
+    if (d->trans) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: this fp16 TN problem is outside the four-wave kernels' range");
+    g_last_kernel = 1;
+    VDK_GEMM_LAUNCH((gemm_bf16_nt_kernel<false, VDK_OPF_F16>), dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256));
   }
   if (prof) {   // the GEMM kernel only (the split-K combine is a separate, HBM-bound kernel)
     g_prof_flops.push_back(2.0 * d->M * d->N * d->K);
     {
       const double mn = (double)d->M * d->N;
-      double b = ((double)d->M * d->K + (double)d->N * d->K) * 2.0 + mn * (d->c_dtype == VDK_F32 ? 4.0 : 2.0);
+      double b = ((double)d->M * d->K + (double)d->N * d->K) * 2.0 + mn * (p.c_dtype == VDK_F32 ? 4.0 : 2.0);
       if (d->residual) b += mn * 4.0;
       if (d->aux) b += mn * 2.0;
       if (d->bias) b += d->N * 4.0;
@@ -987,10 +1011,13 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   }
   if (splitk > 1) {
     long mn = (long)d->M * d->N, n4 = mn / 4;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream,
+    if (opf) hipLaunchKernelGGL(splitk_reduce_kernel<VDK_OPF_F16>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, (const float*)p.slabs, splitk, n4, mn, d->alpha,
+                                p.c_dtype == VDK_F32 ? (float*)d->C : (float*)nullptr, p.c_dtype == VDK_BF16 ? (bf16_t*)d->C : (bf16_t*)nullptr);
+    else
+    hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream,
                        (const float*)p.slabs, splitk, n4, mn, d->alpha,
-                       d->c_dtype == VDK_F32 ? (float*)d->C : (float*)nullptr,
-                       d->c_dtype == VDK_BF16 ? (bf16_t*)d->C : (bf16_t*)nullptr);
+                       p.c_dtype == VDK_F32 ? (float*)d->C : (float*)nullptr,
+                       p.c_dtype == VDK_BF16 ? (bf16_t*)d->C : (bf16_t*)nullptr);
   }
   return vdk_check_launch("vdk_gemm_bf16_nt");
 }
@@ -1029,12 +1056,21 @@ int vdk_margin_cos_pass(const VdkMarginHead* h, int32_t pass, const void* fbt, i
 // vdk_reduce_rows_f32(colsum_partial, C, ceil(Rpad/64), C, db, 1).
 int vdk_transpose_bf16(const void* in, int64_t ldi, int32_t R, int32_t Cc, void* out, int64_t ldo, int32_t Rpad,
                        int32_t in_row_group, float* colsum_partial, void* stream) {
-  if (!in || !out || R < 0 || Cc <= 0 || Rpad < R || (Rpad & 1) || ldo < Rpad || (ldi & 1) || (ldo & 1))
-    return vdk_fail(VDK_EINVAL, "vdk_transpose_bf16: bad argument");
-  if (Rpad == 0) return VDK_OK;
-  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((Rpad + 63) / 64), (unsigned)((Cc + 63) / 64)), dim3(256), 0,
-                     (hipStream_t)stream, (const bf16_t*)in, (long)ldi, (int)R, (int)Cc, (bf16_t*)out, (long)ldo, (int)Rpad, (int)in_row_group, colsum_partial);
-  return vdk_check_launch("vdk_transpose_bf16");
+  return vdk_transpose_16(in, ldi, R, Cc, out, ldo, Rpad, in_row_group, colsum_partial, VDK_OPF_BF16, stream);
 }
 
 }  // extern "C"
+
+// (the transpose itself moves 16-bit words whatever they encode; only the column-sum by-product reads values: opf = their format)
+int vdk_transpose_16(const void* in, int64_t ldi, int32_t R, int32_t Cc, void* out, int64_t ldo, int32_t Rpad, int32_t in_row_group, float* colsum_partial, int opf,
+                     void* stream) {
+  if (!in || !out || R < 0 || Cc <= 0 || Rpad < R || (Rpad & 1) || ldo < Rpad || (ldi & 1) || (ldo & 1))
+    return vdk_fail(VDK_EINVAL, "vdk_transpose_bf16: bad argument");
+  if (Rpad == 0) return VDK_OK;
+  const dim3 grid((unsigned)((Rpad + 63) / 64), (unsigned)((Cc + 63) / 64));
+  if (opf) hipLaunchKernelGGL(transpose_bf16_kernel<VDK_OPF_F16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (long)ldi, (int)R, (int)Cc, (bf16_t*)out,
+                              (long)ldo, (int)Rpad, (int)in_row_group, colsum_partial);
+  else hipLaunchKernelGGL(transpose_bf16_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (long)ldi, (int)R, (int)Cc, (bf16_t*)out, (long)ldo,
+                          (int)Rpad, (int)in_row_group, colsum_partial);
+  return vdk_check_launch("vdk_transpose_bf16");
+}

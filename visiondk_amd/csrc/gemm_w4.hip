@@ -32,6 +32,17 @@
 #include "vdk_gemm.h"
 #include "vdk_gemm_epilogue.h"
 
+// VDK_W4_OF: the operand format this translation unit instantiates (vdk_device.h: 0 = bf16, 1 = fp16).  gemm_w4_f16.hip defines it to 1 and includes this file:
+// the kernels are templates over OF (distinct symbols), the two launchers get an _f16 suffix there, and the format-independent host helpers are compiled here only.
+#ifndef VDK_W4_OF
+#define VDK_W4_OF 0
+#endif
+#if VDK_W4_OF == 0
+#define W4_SYM(name) name
+#else
+#define W4_SYM(name) name##_f16
+#endif
+
 #define W4_REGION 16384
 #define W4_TILEBUF 65536
 #define W4_STAGE 131072
@@ -172,20 +183,20 @@ __device__ __forceinline__ s16x8 w4_frag(const unsigned char* region, const unsi
 // c[i][j]: i = A block (rows of C), j = B block (columns of C); the MFMA is (B fragment, A fragment): D rows = C columns, so lane l holds C row l & 31.
 // RD: the phase reads 8 fragments from `rd_region` through offsets rd_off into RDST[2][4].  It issues the 4 pieces of (dma, is_region, is_sub) at scalar offset so0.
 // FIRST: the accumulators start from zero (first k-tile of an output tile).
-template <bool TN, bool RD, bool FIRST>
+template <bool TN, bool RD, bool FIRST, int OF>
 __device__ __forceinline__ void w4_phase(f32x16 (&c00), f32x16 (&c01), f32x16 (&c10), f32x16 (&c11), const s16x8 (&X)[2][4], const s16x8 (&Y)[2][4],
                                          const unsigned char* rd_region, const unsigned* rd_off, s16x8 (&RDST)[2][4],
                                          const W4Dma& dma, unsigned char* is_region, int is_sub, unsigned so0, int w) {
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Y[0][ks], X[0][ks], (FIRST && ks == 0) ? zero : c00, 0, 0, 0);
+    c00 = vdk_mfma32<OF>(Y[0][ks], X[0][ks], (FIRST && ks == 0) ? zero : c00);
     if (RD) RDST[0][ks] = w4_frag<TN>(rd_region, rd_off, 0, ks);
-    c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Y[1][ks], X[0][ks], (FIRST && ks == 0) ? zero : c01, 0, 0, 0);
+    c01 = vdk_mfma32<OF>(Y[1][ks], X[0][ks], (FIRST && ks == 0) ? zero : c01);
     if (RD) RDST[1][ks] = w4_frag<TN>(rd_region, rd_off, 1, ks);
-    c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Y[0][ks], X[1][ks], (FIRST && ks == 0) ? zero : c10, 0, 0, 0);
+    c10 = vdk_mfma32<OF>(Y[0][ks], X[1][ks], (FIRST && ks == 0) ? zero : c10);
     w4_piece(dma, is_region + (4 * w + ks) * 1024, is_sub, ks, so0);
-    c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Y[1][ks], X[1][ks], (FIRST && ks == 0) ? zero : c11, 0, 0, 0);
+    c11 = vdk_mfma32<OF>(Y[1][ks], X[1][ks], (FIRST && ks == 0) ? zero : c11);
   }
   // the order above is the order wanted in the instruction stream: one LDS read (TN: one pair) or one DMA piece in the shadow of each MFMA, never a batch in
   // front of the phase (left alone, the scheduler hoists all 8 reads and 4 pieces above the first MFMA: ~100 idle matrix-pipe cycles per phase)
@@ -215,26 +226,26 @@ __device__ __forceinline__ void w4_phase_end() {
   if constexpr (V >= 0) W4_WAIT_VM(V);
   W4_WAIT_LGKM0();          // this phase's fragment reads have returned: the next phase may multiply them, and (after its barrier) anyone may overwrite their region
 }
-template <bool TN, int CUR, int VM, bool FIRST, bool NEXT>
+template <bool TN, int CUR, int VM, bool FIRST, bool NEXT, int OF>
 __device__ __forceinline__ void w4_ktile(unsigned char* smem, const W4Frag<TN>& F, const W4Dma& da, const W4Dma& db, unsigned soa, unsigned sob, int w, f32x16 (&acc)[4][4],
                                          s16x8 (&A0)[2][4], s16x8 (&A1)[2][4], s16x8 (&B0)[2][4], s16x8 (&B1)[2][4], s16x8 (&B0N)[2][4]) {
   unsigned char* const buf = smem + CUR * W4_TILEBUF;
   unsigned char* const nbuf = smem + (CUR ^ 1) * W4_TILEBUF;
   // P1: A0 x B0; read B1(t); refill RA0 (read in P3 of the previous k-tile)
   W4_BAR();
-  w4_phase<TN, true, FIRST>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], A0, B0, buf + W4_RB1, F.b, B1, da, buf + W4_RA0, 0, soa, w);
+  w4_phase<TN, true, FIRST, OF>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], A0, B0, buf + W4_RB1, F.b, B1, da, buf + W4_RA0, 0, soa, w);
   w4_phase_end<VM>();
   // P2: A0 x B1; read A1(t); refill RB0 (read in P4 of the previous k-tile)
   W4_BAR();
-  w4_phase<TN, true, FIRST>(acc[0][2], acc[0][3], acc[1][2], acc[1][3], A0, B1, buf + W4_RA1, F.a, A1, db, buf + W4_RB0, 0, sob, w);
+  w4_phase<TN, true, FIRST, OF>(acc[0][2], acc[0][3], acc[1][2], acc[1][3], A0, B1, buf + W4_RA1, F.a, A1, db, buf + W4_RB0, 0, sob, w);
   w4_phase_end<VM>();
   // P3: A1 x B1; read A0(t+1); refill RB1 (read in P1)
   W4_BAR();
-  w4_phase<TN, NEXT, FIRST>(acc[2][2], acc[2][3], acc[3][2], acc[3][3], A1, B1, nbuf + W4_RA0, F.a, A0, db, buf + W4_RB1, 1, sob, w);
+  w4_phase<TN, NEXT, FIRST, OF>(acc[2][2], acc[2][3], acc[3][2], acc[3][3], A1, B1, nbuf + W4_RA0, F.a, A0, db, buf + W4_RB1, 1, sob, w);
   w4_phase_end<VM>();
   // P4: A1 x B0; read B0(t+1); refill RA1 (read in P2)
   W4_BAR();
-  w4_phase<TN, NEXT, FIRST>(acc[2][0], acc[2][1], acc[3][0], acc[3][1], A1, B0, nbuf + W4_RB0, F.b, B0N, da, buf + W4_RA1, 1, soa, w);
+  w4_phase<TN, NEXT, FIRST, OF>(acc[2][0], acc[2][1], acc[3][0], acc[3][1], A1, B0, nbuf + W4_RB0, F.b, B0N, da, buf + W4_RA1, 1, soa, w);
   w4_phase_end<VM>();
 }
 
@@ -251,7 +262,7 @@ __device__ __forceinline__ void w4_ktile(unsigned char* smem, const W4Frag<TN>& 
 #endif
 // NCT: 32-column blocks per wave (4: the 256x256 tile of gemm_w4_kernel, staging rows of 256 B, 4 rows per 64-lane pass; 2: the 256x128 tile of gemm_w4h_kernel,
 // staging rows of 128 B with chunk c of row r at position c ^ ((r >> 1) & 7), 8 rows per pass).  DEEP: vmcnt waited for before the first global access (-1: none).
-template <int E, int NCT, int DEEP>
+template <int E, int NCT, int DEEP, int OF>
 __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* stage, f32x16 (&acc)[4][NCT], int lane, int wr, int wc, int m0, int n0, int z, int tm, unsigned long long (&ts)[5]) {
   constexpr int NCH = NCT * 4;            // 16-byte chunks per staged row
   constexpr int RPP = 64 / NCH;           // rows per 64-lane pass
@@ -304,7 +315,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
 #pragma unroll
         for (int ps = 0; ps < NPS; ++ps)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { ocs[2 * e] += bf_lo(d[ps][e]); ocs[2 * e + 1] += bf_hi(d[ps][e]); }
+          for (int e = 0; e < 4; ++e) { ocs[2 * e] += op_lo<OF>(d[ps][e]); ocs[2 * e + 1] += op_hi<OF>(d[ps][e]); }
       }
       // Everything that reads the row registers comes BEFORE the stores, and the row block goes into the VECTOR offset.  Measured on the MI355X with
       // buffer_store_dwordx4 v[a:a+3], v, s[..], s offen followed within four instructions by VALU writes of v[a:a+3] (the column-sum arithmetic): dword 1 of
@@ -355,7 +366,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
               v[0] = acc[rt][ct][4 * g + 0] * h_lo(u[0]); v[1] = acc[rt][ct][4 * g + 1] * h_hi(u[0]);
               v[2] = acc[rt][ct][4 * g + 2] * h_lo(u[1]); v[3] = acc[rt][ct][4 * g + 3] * h_hi(u[1]);
             } else {
-              const vdk_f32x2 d0 = gelu_grad_f2((vdk_f32x2){bf_lo(u[0]), bf_hi(u[0])}), d1 = gelu_grad_f2((vdk_f32x2){bf_lo(u[1]), bf_hi(u[1])});
+              const vdk_f32x2 d0 = gelu_grad_f2((vdk_f32x2){op_lo<OF>(u[0]), op_hi<OF>(u[0])}), d1 = gelu_grad_f2((vdk_f32x2){op_lo<OF>(u[1]), op_hi<OF>(u[1])});
               v[0] = acc[rt][ct][4 * g + 0] * d0[0]; v[1] = acc[rt][ct][4 * g + 1] * d0[1];
               v[2] = acc[rt][ct][4 * g + 2] * d1[0]; v[3] = acc[rt][ct][4 * g + 3] * d1[1];
             }
@@ -367,14 +378,14 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
             vdk_f32x2 g0, g1, d0, d1;
             gelu_both_f2((vdk_f32x2){v[0], v[1]}, g0, d0); gelu_both_f2((vdk_f32x2){v[2], v[3]}, g1, d1);
             *(u32x2*)wp = (u32x2){pack_h2(d0[0], d0[1]), pack_h2(d1[0], d1[1])};
-            held[ct][g] = (u32x2){pack_bf2(g0[0], g0[1]), pack_bf2(g1[0], g1[1])};
+            held[ct][g] = (u32x2){pack_op2<OF>(g0[0], g0[1]), pack_op2<OF>(g1[0], g1[1])};
           } else
-          *(u32x2*)wp = (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+          *(u32x2*)wp = (u32x2){pack_op2<OF>(v[0], v[1]), pack_op2<OF>(v[2], v[3])};
           // (the activations stay in hipcc's order, value pair by value pair on packed fp32 ops: a lone wave issues a VALU instruction every ~8 cycles whatever
           //  the dependencies, so instruction COUNT is the cost -- a stage-by-stage 8-wide form without packed ops measured 10-25 % slower)
           if ((E & E_GELU) && !(E & E_AUXD)) {
             const vdk_f32x2 g0 = gelu_f2((vdk_f32x2){v[0], v[1]}), g1 = gelu_f2((vdk_f32x2){v[2], v[3]});
-            held[ct][g] = (u32x2){pack_bf2(g0[0], g0[1]), pack_bf2(g1[0], g1[1])};
+            held[ct][g] = (u32x2){pack_op2<OF>(g0[0], g0[1]), pack_op2<OF>(g1[0], g1[1])};
           }
 #ifndef VDK_EMU
           if ((E & (E_GELU | E_DGELU)) && g == 3) __builtin_amdgcn_sched_barrier(0);   // 16 activations in flight are plenty; all 64 at once spill
@@ -499,7 +510,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
         W4_EPI_SYNC();
         const long mbase = (long)mrow0 + rt * 32;
         if (E != E_GENERIC) {
-          h_epilogue_half<E, 4, true>(p, slab, lane, mbase, ncol, z, bias8, ocs8, q8_unused);
+          h_epilogue_half<E, 4, true, OF>(p, slab, lane, mbase, ncol, z, bias8, ocs8, q8_unused);
         } else {
 #pragma unroll
           for (int pass = 0; pass < 4; ++pass) {
@@ -510,7 +521,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
               f32x4 x0 = *(const f32x4*)(slab + row * 64 + ((ch ^ sw) << 2)), x1 = *(const f32x4*)(slab + row * 64 + (((ch + 1) ^ sw) << 2));
 #pragma unroll
               for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
-              g_epilogue_store8(p, mi, ncol, v, z);
+              g_epilogue_store8<OF>(p, mi, ncol, v, z);
             }
           }
         }
@@ -535,7 +546,7 @@ __device__ __forceinline__ void w4_tile_rc(int tile, int ntn, int ntm, int cw, i
 // XCD's contiguous share (x = b & 7, s = b >> 3): at any time an XCD's workgroups multiply G/8 consecutive tiles, which share A row panels / the weight matrix
 // in that XCD's L2.  Otherwise: one tile per workgroup (blockIdx.x, same XCD raster) and blockIdx.y = split-K slice.
 // Every k-range holds an even number (>= 2) of whole k-tiles (launcher).
-template <bool TN, int E, bool PERSIST>
+template <bool TN, int E, bool PERSIST, int OF>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[W4_SMEM];   // 128 KB operand ring + 32 KB epilogue staging: the CU's whole LDS, one object
   const int tid = threadIdx.x, lane = tid & 63;
@@ -620,15 +631,15 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
       for (int ks = 0; ks < 4; ++ks) { A0[rt][ks] = w4_frag<TN>(smem + W4_RA0, F.a, rt, ks); BX[rt][ks] = w4_frag<TN>(smem + W4_RB0, F.b, rt, ks); }
     __builtin_amdgcn_sched_barrier(0);
     W4_WAIT_LGKM0();
-    w4_ktile<TN, 0, -1, true, true>(smem, F, da, db, c_ta + c_ka, c_tb + c_kb, w, acc, A0, A1, BX, B1, BY);
+    w4_ktile<TN, 0, -1, true, true, OF>(smem, F, da, db, c_ta + c_ka, c_tb + c_kb, w, acc, A0, A1, BX, B1, BY);
     W4_CURSOR_ADVANCE();
     for (int t = 2; t < nk; t += 2) {
-      w4_ktile<TN, 1, 20, false, true>(smem, F, da, db, c_ta + c_ka, c_tb + c_kb, w, acc, A0, A1, BY, B1, BX);
+      w4_ktile<TN, 1, 20, false, true, OF>(smem, F, da, db, c_ta + c_ka, c_tb + c_kb, w, acc, A0, A1, BY, B1, BX);
       W4_CURSOR_ADVANCE();
-      w4_ktile<TN, 0, 20, false, true>(smem, F, da, db, c_ta + c_ka, c_tb + c_kb, w, acc, A0, A1, BX, B1, BY);
+      w4_ktile<TN, 0, 20, false, true, OF>(smem, F, da, db, c_ta + c_ka, c_tb + c_kb, w, acc, A0, A1, BX, B1, BY);
       W4_CURSOR_ADVANCE();
     }
-    w4_ktile<TN, 1, 20, false, false>(smem, F, da, db, c_ta + c_ka, c_tb + c_kb, w, acc, A0, A1, BY, B1, BX);
+    w4_ktile<TN, 1, 20, false, false, OF>(smem, F, da, db, c_ta + c_ka, c_tb + c_kb, w, acc, A0, A1, BY, B1, BX);
     W4_CURSOR_ADVANCE();
     if (p.dbg) t_main = __builtin_readcyclecounter();
     // The accumulators become opaque here: without it the compiler reads (and shuffles) them from inside the last MFMA phase, a few wait states behind the MFMA
@@ -641,7 +652,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
 #endif
     int tm, tn; w4_tile_rc(t_start + t_idx, ntn, ntm, p.band_cw, tm, tn);
     unsigned long long ts[5] = {0, 0, 0, 0, 0};
-    w4_epilogue<E, 4, 4>(p, smem + W4_STAGE + w * 8192, acc, lane, wr, wc, tm * 256, tn * 256, z, tm, ts);
+    w4_epilogue<E, 4, 4, OF>(p, smem + W4_STAGE + w * 8192, acc, lane, wr, wc, tm * 256, tn * 256, z, tm, ts);
     if (p.dbg && tid == 0 && dbg_i < 8) {   // debug only: shader-cycle stamps of this workgroup's first 8 tiles: top, main loop done, epilogue issued
       unsigned long long* o = p.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + dbg_i) * 8;   /* (debug stamps index the launch grid, not the item order) */
       o[0] = t_top; o[1] = t_main; o[2] = __builtin_readcyclecounter(); o[3] = (unsigned long long)(t_start + t_idx);
@@ -667,7 +678,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
 #define W4H_SMEM 81920
 #define W4H_SLOT 16384
 
-template <bool TN, bool FIRST>
+template <bool TN, bool FIRST, int OF>
 __device__ __forceinline__ void w4h_ktile(unsigned char* smem, const W4Frag<TN>& F, const W4Dma& da, const W4Dma& db, unsigned s_a1n /* RA1(t+1) */, unsigned s_a0nn /* RA0(t+2) */,
                                           unsigned s_bnn /* RB(t+2) */, int w, unsigned oA0, unsigned oB, unsigned oA1, unsigned oA0n, unsigned oBn,
                                           f32x16 (&acc)[4][2], s16x8 (&A0)[2][4], s16x8 (&A1)[2][4], s16x8 (&B)[2][4]) {
@@ -676,14 +687,14 @@ __device__ __forceinline__ void w4h_ktile(unsigned char* smem, const W4Frag<TN>&
   W4_BAR();
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B[0][ks], A0[0][ks], (FIRST && ks == 0) ? zero : acc[0][0], 0, 0, 0);
+    acc[0][0] = vdk_mfma32<OF>(B[0][ks], A0[0][ks], (FIRST && ks == 0) ? zero : acc[0][0]);
     A1[0][ks] = w4_frag<TN>(smem + oA1, F.a, 0, ks);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B[1][ks], A0[0][ks], (FIRST && ks == 0) ? zero : acc[0][1], 0, 0, 0);
+    acc[0][1] = vdk_mfma32<OF>(B[1][ks], A0[0][ks], (FIRST && ks == 0) ? zero : acc[0][1]);
     A1[1][ks] = w4_frag<TN>(smem + oA1, F.a, 1, ks);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B[0][ks], A0[1][ks], (FIRST && ks == 0) ? zero : acc[1][0], 0, 0, 0);
+    acc[1][0] = vdk_mfma32<OF>(B[0][ks], A0[1][ks], (FIRST && ks == 0) ? zero : acc[1][0]);
     // issue order inside the phase: the 4 pieces of RA1(t+1) first, then the 4 of RA0(t+2) (the vmcnt(8) of the phase ends counts on it)
     if (ks < 2) w4_piece(da, smem + oA0 + (4 * w + 2 * ks) * 1024, 1, 2 * ks, s_a1n); else w4_piece(da, smem + oB + (4 * w + 2 * (ks - 2)) * 1024, 0, 2 * (ks - 2), s_a0nn);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B[1][ks], A0[1][ks], (FIRST && ks == 0) ? zero : acc[1][1], 0, 0, 0);
+    acc[1][1] = vdk_mfma32<OF>(B[1][ks], A0[1][ks], (FIRST && ks == 0) ? zero : acc[1][1]);
     if (ks < 2) w4_piece(da, smem + oA0 + (4 * w + 2 * ks + 1) * 1024, 1, 2 * ks + 1, s_a1n); else w4_piece(da, smem + oB + (4 * w + 2 * (ks - 2) + 1) * 1024, 0, 2 * (ks - 2) + 1, s_a0nn);
   }
 #ifndef VDK_EMU
@@ -700,13 +711,13 @@ __device__ __forceinline__ void w4h_ktile(unsigned char* smem, const W4Frag<TN>&
   W4_BAR();
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B[0][ks], A1[0][ks], (FIRST && ks == 0) ? zero : acc[2][0], 0, 0, 0);
+    acc[2][0] = vdk_mfma32<OF>(B[0][ks], A1[0][ks], (FIRST && ks == 0) ? zero : acc[2][0]);
     A0[0][ks] = w4_frag<TN>(smem + oA0n, F.a, 0, ks);
-    acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B[1][ks], A1[0][ks], (FIRST && ks == 0) ? zero : acc[2][1], 0, 0, 0);
+    acc[2][1] = vdk_mfma32<OF>(B[1][ks], A1[0][ks], (FIRST && ks == 0) ? zero : acc[2][1]);
     A0[1][ks] = w4_frag<TN>(smem + oA0n, F.a, 1, ks);
-    acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B[0][ks], A1[1][ks], (FIRST && ks == 0) ? zero : acc[3][0], 0, 0, 0);
+    acc[3][0] = vdk_mfma32<OF>(B[0][ks], A1[1][ks], (FIRST && ks == 0) ? zero : acc[3][0]);
     w4_piece(db, smem + oA1 + (4 * w + ks) * 1024, 0, ks, s_bnn);
-    acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B[1][ks], A1[1][ks], (FIRST && ks == 0) ? zero : acc[3][1], 0, 0, 0);
+    acc[3][1] = vdk_mfma32<OF>(B[1][ks], A1[1][ks], (FIRST && ks == 0) ? zero : acc[3][1]);
     B[0][ks] = w4_frag<TN>(smem + oBn, F.b, 0, ks);      // (k-tile t+1's fragments, into the registers the four MFMAs above have just read)
     B[1][ks] = w4_frag<TN>(smem + oBn, F.b, 1, ks);
   }
@@ -722,7 +733,7 @@ __device__ __forceinline__ void w4h_ktile(unsigned char* smem, const W4Frag<TN>&
   w4_phase_end<8>();
 }
 
-template <bool TN, int E>
+template <bool TN, int E, int OF>
 __global__ __launch_bounds__(256, 2) void gemm_w4h_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[W4H_SMEM];   // 5 region slots; the epilogue staging (4 x 8 KB) reuses the first two
   const int tid = threadIdx.x, lane = tid & 63;
@@ -786,10 +797,10 @@ __global__ __launch_bounds__(256, 2) void gemm_w4h_kernel(GemmParams p) {
   if (p.dbg) t_land = __builtin_readcyclecounter();
   unsigned q5 = 0;                                        // (3 t) mod 5
 #define W4H_SLOT_OF(i) ((((q5 + (i)) >= 5u) ? (q5 + (i) - 5u) : (q5 + (i))) * (unsigned)W4H_SLOT)
-  w4h_ktile<TN, true>(smem, F, da, db, W4H_KA(1), W4H_KA(2), W4H_KB(2), w, W4H_SLOT_OF(0), W4H_SLOT_OF(1), W4H_SLOT_OF(2), W4H_SLOT_OF(3), W4H_SLOT_OF(4), acc, A0, A1, B);
+  w4h_ktile<TN, true, OF>(smem, F, da, db, W4H_KA(1), W4H_KA(2), W4H_KB(2), w, W4H_SLOT_OF(0), W4H_SLOT_OF(1), W4H_SLOT_OF(2), W4H_SLOT_OF(3), W4H_SLOT_OF(4), acc, A0, A1, B);
   q5 = 3;
   for (int t = 1; t < nk; ++t) {
-    w4h_ktile<TN, false>(smem, F, da, db, W4H_KA(t + 1), W4H_KA(t + 2), W4H_KB(t + 2), w, W4H_SLOT_OF(0), W4H_SLOT_OF(1), W4H_SLOT_OF(2), W4H_SLOT_OF(3), W4H_SLOT_OF(4), acc, A0, A1, B);
+    w4h_ktile<TN, false, OF>(smem, F, da, db, W4H_KA(t + 1), W4H_KA(t + 2), W4H_KB(t + 2), w, W4H_SLOT_OF(0), W4H_SLOT_OF(1), W4H_SLOT_OF(2), W4H_SLOT_OF(3), W4H_SLOT_OF(4), acc, A0, A1, B);
     q5 = q5 + 3 >= 5 ? q5 - 2 : q5 + 3;
   }
 #undef W4H_SLOT_OF
@@ -803,7 +814,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w4h_kernel(GemmParams p) {
                : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
 #endif
   unsigned long long ts[5] = {0, 0, 0, 0, 0};
-  w4_epilogue<E, 2, -1>(p, smem + w * 8192, acc, lane, wr, wc, m0, n0, z, tm, ts);
+  w4_epilogue<E, 2, -1, OF>(p, smem + w * 8192, acc, lane, wr, wc, m0, n0, z, tm, ts);
   if (p.dbg && tid == 0) {   // debug only: shader-cycle stamps (start, first operands landed, main loop done, epilogue entered, its 32-row blocks 1..3, end)
     unsigned long long* o = p.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
     o[0] = t_top; o[1] = t_main; o[2] = __builtin_readcyclecounter(); o[3] = t_land; o[4] = ts[0];
@@ -817,6 +828,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w4h_kernel(GemmParams p) {
 // ---- launcher (called by vdk_gemm_bf16_nt / vdk_margin_cos_pass in gemm.hip) ------------------------------------------------------------------------
 // Serves what the 8-wave 256x256 kernel serves except its a_colsum by-product, the token-row remap of the A operand and stream-K.  Operand byte sizes stay
 // below 2 GB (32-bit buffer offsets, W4_OOB beyond them); every split holds an even number of k-tiles.
+#if VDK_W4_OF == 0
 bool vdk_gemm_w4_serves(const GemmParams& p, bool trans) {
   const double lim = 2147483648.0 - 65536.0;
   if (p.colsum_part || p.sk_cnt || p.a_row_group > 0) return false;
@@ -848,6 +860,7 @@ extern "C" int vdk_gemm_reserve_cus(int32_t n) {
   g_w4_reserve.store(n);
   return VDK_OK;
 }
+extern "C" int vdk_gemm_reserved_cus(void) { return g_w4_reserve.load(); }
 
 // diagnostic (tools/w4_contention.py): `workgroups` workgroups that each hold a CU's LDS share of a collective's kernel for `microseconds`, on `stream` -- stands in for an
 // RCCL all-reduce in flight when the effect of vdk_gemm_reserve_cus is measured on one GPU
@@ -868,7 +881,7 @@ extern "C" int vdk_debug_occupy_cus(int32_t workgroups, int64_t microseconds, vo
   return hipGetLastError() == hipSuccess ? VDK_OK : vdk_fail(VDK_ELAUNCH, "vdk_debug_occupy_cus: launch failed");
 }
 
-static int w4_cus() {
+int vdk_gemm_w4_cus() {
   static int cus = 0;
   static int env_reserve = getenv("VDK_GEMM_RESERVE_CUS") ? atoi(getenv("VDK_GEMM_RESERVE_CUS")) : -1;
   if (cus == 0) {
@@ -880,22 +893,28 @@ static int w4_cus() {
   int g = (cus - r) & ~7;                                  // (the walk wants a multiple of 8: one share per XCD)
   return g < 8 ? 8 : g;
 }
+int g_w4_force_band_cw = -1;
+extern "C" int vdk_gemm_force_band_cw(int32_t cw) { g_w4_force_band_cw = cw; return VDK_OK; }   /* tests: the band order on small problems (-1: the size rule) */
+#else
+extern int g_w4_force_band_cw;
+#endif
+static int w4_cus() { return vdk_gemm_w4_cus(); }
 
 #define W4_LAUNCH(TNF, EE)                                                                                                                    \
   do {                                                                                                                                        \
     if (persist) {                                                                                                                            \
-      if (ev0 || ev1) hipExtLaunchKernelGGL((gemm_w4_kernel<TNF, EE, true>), pgrid, dim3(256), 0, stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, p);   \
-      else hipLaunchKernelGGL((gemm_w4_kernel<TNF, EE, true>), pgrid, dim3(256), 0, stream, p);                                               \
+      if (ev0 || ev1) hipExtLaunchKernelGGL((gemm_w4_kernel<TNF, EE, true, VDK_W4_OF>), pgrid, dim3(256), 0, stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, p);   \
+      else hipLaunchKernelGGL((gemm_w4_kernel<TNF, EE, true, VDK_W4_OF>), pgrid, dim3(256), 0, stream, p);                                               \
     } else {                                                                                                                                  \
-      if (ev0 || ev1) hipExtLaunchKernelGGL((gemm_w4_kernel<TNF, EE, false>), grid, dim3(256), 0, stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, p);   \
-      else hipLaunchKernelGGL((gemm_w4_kernel<TNF, EE, false>), grid, dim3(256), 0, stream, p);                                               \
+      if (ev0 || ev1) hipExtLaunchKernelGGL((gemm_w4_kernel<TNF, EE, false, VDK_W4_OF>), grid, dim3(256), 0, stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, p);   \
+      else hipLaunchKernelGGL((gemm_w4_kernel<TNF, EE, false, VDK_W4_OF>), grid, dim3(256), 0, stream, p);                                               \
     }                                                                                                                                         \
     return true;                                                                                                                              \
   } while (0)
 
 static bool w4_launch_one(const GemmParams& p, bool trans, int E, unsigned tiles, unsigned splitk, hipStream_t stream, void* ev0, void* ev1);
 
-bool vdk_gemm_w4_launch(const GemmParams& p, bool trans, int E, unsigned tiles, unsigned splitk, void* stream_, void* ev0, void* ev1) {
+bool W4_SYM(vdk_gemm_w4_launch)(const GemmParams& p, bool trans, int E, unsigned tiles, unsigned splitk, void* stream_, void* ev0, void* ev1) {
   hipStream_t stream = (hipStream_t)stream_;
   const unsigned G = (unsigned)w4_cus();
   // The ragged last round.  T tiles on G CUs take ceil(T / G) rounds of whole tiles (591 on 256: 2.31 -> 3).  When the tile rows beyond the last whole round are
@@ -918,7 +937,7 @@ bool vdk_gemm_w4_launch(const GemmParams& p, bool trans, int E, unsigned tiles, 
       if (p.ocs_part) p2.ocs_part = p.ocs_part + (size_t)rows1 * 2 * p.N;
       if (vdk_gemm_w4h_serves(p2, false)) {
         w4_launch_one(p1, false, E, rows1 * ntn, 1u, stream, ev0, nullptr);
-        return vdk_gemm_w4h_launch(p2, false, E, 1u, stream_, nullptr, ev1);
+        return W4_SYM(vdk_gemm_w4h_launch)(p2, false, E, 1u, stream_, nullptr, ev1);
       }
     }
   }
@@ -927,10 +946,8 @@ bool vdk_gemm_w4_launch(const GemmParams& p, bool trans, int E, unsigned tiles, 
 
 // column-band width of the tile order (0: plain row-major): band when the re-streamed B operand costs more than the repeated A panels.  tile_n: 256 or 128;
 // G: workgroups in flight (one round)
-static int g_force_band_cw = -1;
-extern "C" int vdk_gemm_force_band_cw(int32_t cw) { g_force_band_cw = cw; return VDK_OK; }   /* tests: the band order on small problems (-1: the size rule) */
 static int w4_band_cw(const GemmParams& p, bool trans, unsigned tiles, unsigned G, int tile_n) {
-  if (g_force_band_cw >= 0) return (trans || p.conv_on) ? 0 : g_force_band_cw;
+  if (g_w4_force_band_cw >= 0) return (trans || p.conv_on) ? 0 : g_w4_force_band_cw;
   static const bool on = [] { const char* e = getenv("VDK_GEMM_BANDS"); return !(e && e[0] == '0'); }();
   if (!on || trans || p.conv_on) return 0;
   const double bbytes = (double)p.N * p.K * 2.0, abytes = (double)p.M * p.K * 2.0;
@@ -983,12 +1000,12 @@ static bool w4_launch_one(const GemmParams& p_, bool trans, int E, unsigned tile
 
 #define W4H_LAUNCH(TNF, EE)                                                                                                             \
   do {                                                                                                                                  \
-    if (ev0 || ev1) hipExtLaunchKernelGGL((gemm_w4h_kernel<TNF, EE>), grid, dim3(256), 0, stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, p);     \
-    else hipLaunchKernelGGL((gemm_w4h_kernel<TNF, EE>), grid, dim3(256), 0, stream, p);                                                 \
+    if (ev0 || ev1) hipExtLaunchKernelGGL((gemm_w4h_kernel<TNF, EE, VDK_W4_OF>), grid, dim3(256), 0, stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, p);     \
+    else hipLaunchKernelGGL((gemm_w4h_kernel<TNF, EE, VDK_W4_OF>), grid, dim3(256), 0, stream, p);                                                 \
     return true;                                                                                                                        \
   } while (0)
 
-bool vdk_gemm_w4h_launch(const GemmParams& p_, bool trans, int E, unsigned splitk, void* stream_, void* ev0, void* ev1) {
+bool W4_SYM(vdk_gemm_w4h_launch)(const GemmParams& p_, bool trans, int E, unsigned splitk, void* stream_, void* ev0, void* ev1) {
   hipStream_t stream = (hipStream_t)stream_;
   GemmParams p = p_;
   const dim3 grid((unsigned)(((p.M + 255) / 256) * ((p.N + 127) / 128)), splitk);

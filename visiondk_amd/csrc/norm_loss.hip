@@ -39,7 +39,7 @@ __device__ __forceinline__ void ln_q8_publish(float am, float* amax, int lane, f
     if (m > *(volatile float*)amax) atomicMax((unsigned*)amax, __float_as_uint(m));      // non-negative floats order like their bit patterns
   }
 }
-template <bool OUT_BF16, int MAXJ, bool Q8 = false>
+template <bool OUT_BF16 /* 16-bit output in operand format OF (else fp32) */, int MAXJ, bool Q8 = false, int OF = 0>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx, int T, int C,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, void* __restrict__ y, long ldy, float* __restrict__ mean,
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mu) * rs * g[e] + b[e];
       if (OUT_BF16) {
-        const u32x2 ob = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+        const u32x2 ob = {pack_op2<OF>(o[0], o[1]), pack_op2<OF>(o[2], o[3])};
         *(u32x2*)((bf16_t*)y + (long)row * ldy + c) = ob;
         if (Q8) *(unsigned*)(q8.out + (long)row * q8.ld + c) = ln_q8_pack4(ob, q8s, q8lim, q8.fmt, q8am);
       }
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // C <= 128: a row is at most 32 lanes x 4 floats, so a wave takes TWO rows (one per half) instead of idling half of its lanes; same arithmetic per row
 // (the half-wave butterfly adds the same 32 lane partials in the same order as the full-wave one does when lanes 32..63 hold zeros)
-template <bool OUT_BF16>
+template <bool OUT_BF16, int OF = 0>
 __global__ __launch_bounds__(256) void ln_fwd_narrow_kernel(const float* __restrict__ x, long ldx, int T, int C, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, void* __restrict__ y, long ldy, float* __restrict__ mean,
                                                             float* __restrict__ rstd) {
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void ln_fwd_narrow_kernel(const float* __restr
     float o4[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) o4[e] = (v[e] - mu) * rs * g[e] + b[e];
-    if (OUT_BF16) *(u32x2*)((bf16_t*)y + (long)row * ldy + c) = (u32x2){pack_bf2(o4[0], o4[1]), pack_bf2(o4[2], o4[3])};
+    if (OUT_BF16) *(u32x2*)((bf16_t*)y + (long)row * ldy + c) = (u32x2){pack_op2<OF>(o4[0], o4[1]), pack_op2<OF>(o4[2], o4[3])};
     else *(f32x4*)((float*)y + (long)row * ldy + c) = (f32x4){o4[0], o4[1], o4[2], o4[3]};
   }
 }
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void ln_fwd_narrow_kernel(const float* __restr
 // dgamma = sum dy * xhat, dbeta = sum dy.   MAXJ * 256 >= C.
 // OCS: also per-block column sums of the bf16-rounded output dxb (= the bias gradient of the Linear whose dY this tensor is: the producer sums what it stores,
 // instead of the consuming dgrad GEMM re-reading its A tiles from LDS) -> pout [block][C].
-template <int MAXJ, bool DY_BF16, bool OCS, bool Q8 = false>
+template <int MAXJ, bool DY_BF16 /* 16-bit dy in operand format OF (else fp32) */, bool OCS, bool Q8 = false, int OF = 0 /* format of a 16-bit dy and of dxb */>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, long lddy, const float* __restrict__ x,
                                                      long ldx, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         float d[4];
         if (DY_BF16) {
           u32x2 u = *(const u32x2*)((const bf16_t*)dy + (long)row * lddy + c);
-          d[0] = bf_lo(u[0]); d[1] = bf_hi(u[0]); d[2] = bf_lo(u[1]); d[3] = bf_hi(u[1]);
+          d[0] = op_lo<OF>(u[0]); d[1] = op_hi<OF>(u[0]); d[2] = op_lo<OF>(u[1]); d[3] = op_hi<OF>(u[1]);
         } else {
           f32x4 u = *(const f32x4*)((const float*)dy + (long)row * lddy + c);
           d[0] = u[0]; d[1] = u[1]; d[2] = u[2]; d[3] = u[3];
@@ -193,9 +193,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         }
         if (dx) *(f32x4*)(dx + (long)row * lddx + c) = (f32x4){o[0], o[1], o[2], o[3]};
         if (dxb) {
-          const u32x2 ob = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+          const u32x2 ob = {pack_op2<OF>(o[0], o[1]), pack_op2<OF>(o[2], o[3])};
           *(u32x2*)(dxb + (long)row * lddxb + c) = ob;
-          if (OCS) { ao[j][0] += bf_lo(ob[0]); ao[j][1] += bf_hi(ob[0]); ao[j][2] += bf_lo(ob[1]); ao[j][3] += bf_hi(ob[1]); }
+          if (OCS) { ao[j][0] += op_lo<OF>(ob[0]); ao[j][1] += op_hi<OF>(ob[0]); ao[j][2] += op_lo<OF>(ob[1]); ao[j][3] += op_hi<OF>(ob[1]); }
           if (Q8) *(unsigned*)(q8.out + (long)row * q8.ld + c) = ln_q8_pack4(ob, q8s, q8lim, q8.fmt, q8am);
         }
       }
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(512) void reduce_rows_fold_kernel(float* __restrict
 // x 8 row lanes; every load is 16 B and a wave reads 512 contiguous bytes of a row.
 // Q8: the pass also writes the fp8 copy of the tensor it reads (and its amax) -- the attention backward's dqkv needs both its column sums (qkv.bias) and its e5m2 copy
 // (operand of the next fp8 GEMM) in the engine's fp8 mode: one read instead of two.
-template <bool Q8>
+template <bool Q8, int OF = 0>
 __global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const bf16_t* __restrict__ in, long ld, int T, int N,
                                                                   int rows_per_split, float* __restrict__ partial, LnQ8 q8) {
   __shared__ float red[8][32][9];
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const bf16_t* 
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(u[k][e]); acc[2 * e + 1] += bf_hi(u[k][e]); }
+        for (int e = 0; e < 4; ++e) { acc[2 * e] += op_lo<OF>(u[k][e]); acc[2 * e + 1] += op_hi<OF>(u[k][e]); }
         if (Q8) *(u32x2*)(q8.out + (long)(r + 8 * k) * q8.ld + c) = (u32x2){ln_q8_pack4((u32x2){u[k][0], u[k][1]}, q8s, q8lim, q8.fmt, q8am),
                                                                            ln_q8_pack4((u32x2){u[k][2], u[k][3]}, q8s, q8lim, q8.fmt, q8am)};
       }
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const bf16_t* 
     for (; r < r1; r += 8) {
       u32x4 u = *(const u32x4*)(in + (long)r * ld + c);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(u[e]); acc[2 * e + 1] += bf_hi(u[e]); }
+      for (int e = 0; e < 4; ++e) { acc[2 * e] += op_lo<OF>(u[e]); acc[2 * e + 1] += op_hi<OF>(u[e]); }
       if (Q8) *(u32x2*)(q8.out + (long)r * q8.ld + c) = (u32x2){ln_q8_pack4((u32x2){u[0], u[1]}, q8s, q8lim, q8.fmt, q8am), ln_q8_pack4((u32x2){u[2], u[3]}, q8s, q8lim, q8.fmt, q8am)};
     }
   }
@@ -341,12 +341,16 @@ __global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const bf16_t* 
 //   dlogits = gscale * (softmax - (1-eps) * (lam*1[ya] + (1-lam)*1[yb]) - eps/C)
 // one workgroup per row.  dlogits bf16 [B, lddl] with columns C..lddl-1 zeroed (they pad the K dim of
 // the head dgrad/wgrad GEMMs).
+// OF: format of the 16-bit dlogits.  gscale_dev (optional, device scalar): multiplies gscale -- GradScaler's loss scale (train.py:205 `scaler.scale(loss).backward()`),
+// read on the device so that a skipped step / a grown scale needs no host round trip.
+template <int OF = 0>
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, long ldl, int C,
                                                          const long long* __restrict__ ya, const long long* __restrict__ yb,
                                                          float lam, float eps, float gscale, float* __restrict__ loss_rows,
                                                          bf16_t* __restrict__ dlogits, long lddl, float* __restrict__ dlogits_f32,
-                                                         long lddf) {
+                                                         long lddf, const float* __restrict__ gscale_dev = nullptr) {
   __shared__ float red[4];
+  if (gscale_dev) gscale *= gscale_dev[0];
   const int row = blockIdx.x, tid = threadIdx.x;
   const float* x = logits + (long)row * ldl;
   float mx = -3.0e38f, sm = 0.f;
@@ -372,18 +376,20 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
       g *= gscale;
       if (dlogits_f32) dlogits_f32[(long)row * lddf + c] = g;
     }
-    if (dlogits && c < (int)lddl) dlogits[(long)row * lddl + c] = f2bf(g);
+    if (dlogits && c < (int)lddl) dlogits[(long)row * lddl + c] = f2op<OF>(g);
   }
 }
 
 // BCE-with-logits: loss_e = max(x,0) - x*t + log1p(exp(-|x|)); d = (sigmoid(x) - t) * gscale.
 // focal_gamma > 0: FocalLoss(BCEWithLogits) of models/losses/loss.py:27-54: loss_e *= alpha_t * (1 - p_t)^gamma with
 // p_t = t*p + (1-t)*(1-p), alpha_t = t*alpha + (1-t)*(1-alpha); the gradient differentiates the modulating factor too.
+template <int OF = 0>
 __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ logits, long ldl, const float* __restrict__ tgt,
                                                          long ldt, int C, float gscale, float focal_gamma, float focal_alpha,
                                                          float* __restrict__ loss_rows, bf16_t* __restrict__ dlogits, long lddl,
-                                                         float* __restrict__ dlogits_f32, long lddf) {
+                                                         float* __restrict__ dlogits_f32, long lddf, const float* __restrict__ gscale_dev = nullptr) {
   __shared__ float red[4];
+  if (gscale_dev) gscale *= gscale_dev[0];
   const int row = blockIdx.x, tid = threadIdx.x;
   float s = 0.f;
   for (int c = tid; c < (int)lddl || c < C; c += 256) {
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict
       }
       if (dlogits_f32) dlogits_f32[(long)row * lddf + c] = g;
     }
-    if (dlogits && c < (int)lddl) dlogits[(long)row * lddl + c] = f2bf(g);
+    if (dlogits && c < (int)lddl) dlogits[(long)row * lddl + c] = f2op<OF>(g);
   }
   s = block_sum<4>(s, red);
   if (tid == 0 && loss_rows) loss_rows[row] = s;
@@ -531,12 +537,14 @@ int vdk_layernorm_fwd(const float* x, int64_t ldx, int32_t T, int32_t C, const f
   if (T == 0) return VDK_OK;
   if (C > 4096) return vdk_fail(VDK_EUNSUPPORTED, "vdk_layernorm_fwd: C <= 4096");
   dim3 grid((unsigned)((T + 3) / 4));
-#define LNF(BF, MJ) hipLaunchKernelGGL((ln_fwd_kernel<BF, MJ>), grid, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta, eps, y, \
-                                       (long)ldy, mean, rstd)
-  const bool bf = y_dtype == VDK_BF16;
+#define LNF(BF, MJ) do { if (f16) hipLaunchKernelGGL((ln_fwd_kernel<true, MJ, false, VDK_OPF_F16>), grid, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta, eps, y, (long)ldy, mean, rstd); \
+                          else hipLaunchKernelGGL((ln_fwd_kernel<BF, MJ>), grid, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta, eps, y, (long)ldy, mean, rstd); } while (0)
+  if (y_dtype != VDK_BF16 && y_dtype != VDK_F32 && y_dtype != VDK_F16) return vdk_fail(VDK_EINVAL, "vdk_layernorm_fwd: bad y_dtype");
+  const bool bf = y_dtype == VDK_BF16, f16 = y_dtype == VDK_F16;
   if (C <= 128) {
     const dim3 g8((unsigned)((T + 7) / 8));
-    if (bf) hipLaunchKernelGGL((ln_fwd_narrow_kernel<true>), g8, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta, eps, y, (long)ldy, mean, rstd);
+    if (f16) hipLaunchKernelGGL((ln_fwd_narrow_kernel<true, VDK_OPF_F16>), g8, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta, eps, y, (long)ldy, mean, rstd);
+    else if (bf) hipLaunchKernelGGL((ln_fwd_narrow_kernel<true>), g8, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta, eps, y, (long)ldy, mean, rstd);
     else hipLaunchKernelGGL((ln_fwd_narrow_kernel<false>), g8, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (int)T, (int)C, gamma, beta, eps, y, (long)ldy, mean, rstd);
   }
   else if (C <= 256) { if (bf) LNF(true, 1); else LNF(false, 1); }
@@ -591,8 +599,11 @@ int vdk_layernorm_bwd_workspace_bytes(int32_t T, int32_t C, size_t* bytes) {
 static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean,
                        const float* rstd, const float* gamma, const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx,
                        int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                       void* stream_, VdkReduceJob* deferred, float* dxb_colsum = nullptr, VdkReduceJob* deferred2 = nullptr, const LnQ8* q8 = nullptr) {
+                       void* stream_, VdkReduceJob* deferred, float* dxb_colsum = nullptr, VdkReduceJob* deferred2 = nullptr, const LnQ8* q8 = nullptr, int opf = 0) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (dy_dtype == VDK_F16) opf = VDK_OPF_F16;          // (an fp32 dy with an fp16 dxb: opf passed by the in-library caller)
+  if (dy_dtype != VDK_BF16 && dy_dtype != VDK_F32 && dy_dtype != VDK_F16) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: bad dy_dtype");
+  if (opf && dy_dtype == VDK_BF16) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: bf16 dy with an fp16 output copy");
   if (!dy || !x || !mean || !rstd || !gamma || !dgamma || !dbeta || T <= 0 || C <= 0 || (C & 3) || C > 4096)
     return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: bad argument (C % 4 == 0, C <= 4096)");
   const int nb = ln_bwd_blocks(T, C);
@@ -603,12 +614,14 @@ static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const flo
   float* pg = (float*)ws; float* pb = pg + C;          // rows of 2C: [dgamma partial | dbeta partial]
   float* po = pg + (size_t)2 * nb * C;                 // rows of C: column sums of dxb
   const int rpb = (T + nb - 1) / nb;
-  const bool bf = dy_dtype == VDK_BF16;
-#define LNB(MJ, BF, OC) hipLaunchKernelGGL((ln_bwd_kernel<MJ, BF, OC>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
-                                           mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po)
+  const bool bf = dy_dtype != VDK_F32;
+#define LNB(MJ, BF, OC) do { if (opf) hipLaunchKernelGGL((ln_bwd_kernel<MJ, BF, OC, false, VDK_OPF_F16>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
+                                           mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po); \
+                             else hipLaunchKernelGGL((ln_bwd_kernel<MJ, BF, OC>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
+                                           mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po); } while (0)
   // MAXJ = 3 (C <= 768, ViT-B) keeps the kernel at <= 128 VGPRs = 4 blocks per CU: T / 64 = 788 blocks are then ONE round on 256 CUs (at 3 per CU they are two: +45 %)
   if (q8) {
-    if (!ocs || !bf || !q8->out || (q8->ld & 3)) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: the fp8 copy needs bf16 dy, the column-sum form and ld % 4 == 0");
+    if (!ocs || !bf || opf || !q8->out || (q8->ld & 3)) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: the fp8 copy needs bf16 dy, the column-sum form and ld % 4 == 0");
 #define LNBQ(MJ) hipLaunchKernelGGL((ln_bwd_kernel<MJ, true, true, true>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
                                     mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po, *q8)
     if (C <= 768) LNBQ(3); else LNBQ(4);
@@ -659,17 +672,25 @@ int vdk_colsum_bf16_workspace_bytes(int32_t T, int32_t N, size_t* bytes) {
 }
 // out[c] = sum_r in[r][c]  (bias gradient of a Linear: column sum of dY), N % 8 == 0, ld % 8 == 0
 int vdk_colsum_bf16(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream_) {
+  return vdk_colsum_16(in, ld, T, N, out, ws, ws_bytes, VDK_OPF_BF16, stream_);
+}
+}  // extern "C"
+int vdk_colsum_16(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, int opf, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!in || !out || T <= 0 || N <= 0 || (N & 7) || (ld & 7)) return vdk_fail(VDK_EINVAL, "vdk_colsum_bf16: bad argument (N, ld % 8 == 0)");
   const int S = colsum_splits(T, N);
   if (!ws || ws_bytes < (size_t)S * N * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_colsum_bf16: workspace too small");
   const int rps = (T + S - 1) / S;
+  if (opf) hipLaunchKernelGGL((colsum_bf16_partial_kernel<false, VDK_OPF_F16>), dim3((unsigned)((N / 8 + 31) / 32), (unsigned)S), dim3(256), 0, stream,
+                              (const bf16_t*)in, (long)ld, (int)T, (int)N, rps, (float*)ws, LnQ8());
+  else
   hipLaunchKernelGGL(colsum_bf16_partial_kernel<false>, dim3((unsigned)((N / 8 + 31) / 32), (unsigned)S), dim3(256), 0, stream,
                      (const bf16_t*)in, (long)ld, (int)T, (int)N, rps, (float*)ws, LnQ8());
   hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((N + 63) / 64)), dim3(512), 0, stream, (const float*)ws, (long)N, S,
                      (long)N, out, 1.0f);
   return vdk_check_launch("vdk_colsum_bf16");
 }
+extern "C" {
 
 int vdk_batchnorm1d_fwd(const float* x, int64_t ldx, int32_t B, int32_t F, const float* gamma, const float* beta, float eps, float momentum,
                         int32_t training, float* running_mean, float* running_var, float* y, int64_t ldy, float* save_mean, float* save_invstd,
@@ -697,23 +718,40 @@ int vdk_batchnorm1d_bwd(const float* dy, int64_t lddy, const float* x, int64_t l
   return vdk_check_launch("vdk_batchnorm1d_bwd");
 }
 
+int vdk_softmax_ce_amp(const float* logits, int64_t ldl, int32_t B, int32_t C, const int64_t* ya, const int64_t* yb, float lam,
+                       float label_smoothing, float grad_scale, const float* loss_scale, float* loss_rows, void* dlogits16, int64_t lddl, int32_t dl_dtype,
+                       float* dlogits_f32, int64_t lddf, void* stream) {
+  if (!logits || !ya || B <= 0 || C <= 0 || (dlogits16 && lddl < C) || (dl_dtype != VDK_BF16 && dl_dtype != VDK_F16)) return vdk_fail(VDK_EINVAL, "vdk_softmax_ce: bad argument");
+  if (dl_dtype == VDK_F16)
+    hipLaunchKernelGGL(softmax_ce_kernel<VDK_OPF_F16>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, logits, (long)ldl, (int)C, (const long long*)ya, (const long long*)yb, lam,
+                       label_smoothing, grad_scale, loss_rows, (bf16_t*)dlogits16, (long)(dlogits16 ? lddl : 0), dlogits_f32, (long)lddf, loss_scale);
+  else
+    hipLaunchKernelGGL(softmax_ce_kernel<0>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, logits, (long)ldl, (int)C, (const long long*)ya, (const long long*)yb, lam,
+                       label_smoothing, grad_scale, loss_rows, (bf16_t*)dlogits16, (long)(dlogits16 ? lddl : 0), dlogits_f32, (long)lddf, loss_scale);
+  return vdk_check_launch("vdk_softmax_ce");
+}
 int vdk_softmax_ce(const float* logits, int64_t ldl, int32_t B, int32_t C, const int64_t* ya, const int64_t* yb, float lam,
                    float label_smoothing, float grad_scale, float* loss_rows, void* dlogits_bf16, int64_t lddl,
                    float* dlogits_f32, int64_t lddf, void* stream) {
-  if (!logits || !ya || B <= 0 || C <= 0 || (dlogits_bf16 && lddl < C)) return vdk_fail(VDK_EINVAL, "vdk_softmax_ce: bad argument");
-  hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, logits, (long)ldl, (int)C,
-                     (const long long*)ya, (const long long*)yb, lam, label_smoothing, grad_scale, loss_rows,
-                     (bf16_t*)dlogits_bf16, (long)(dlogits_bf16 ? lddl : 0), dlogits_f32, (long)lddf);
-  return vdk_check_launch("vdk_softmax_ce");
+  return vdk_softmax_ce_amp(logits, ldl, B, C, ya, yb, lam, label_smoothing, grad_scale, nullptr, loss_rows, dlogits_bf16, lddl, VDK_BF16, dlogits_f32, lddf, stream);
 }
 
+int vdk_bce_logits_amp(const float* logits, int64_t ldl, const float* targets, int64_t ldt, int32_t B, int32_t C, float grad_scale, const float* loss_scale,
+                       float focal_gamma, float focal_alpha, float* loss_rows, void* dlogits16, int64_t lddl, int32_t dl_dtype, float* dlogits_f32, int64_t lddf,
+                       void* stream) {
+  if (!logits || !targets || B <= 0 || C <= 0 || (dlogits16 && lddl < C) || (dl_dtype != VDK_BF16 && dl_dtype != VDK_F16)) return vdk_fail(VDK_EINVAL, "vdk_bce_logits: bad argument");
+  if (dl_dtype == VDK_F16)
+    hipLaunchKernelGGL(bce_logits_kernel<VDK_OPF_F16>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, logits, (long)ldl, targets, (long)ldt, (int)C, grad_scale, focal_gamma,
+                       focal_alpha, loss_rows, (bf16_t*)dlogits16, (long)(dlogits16 ? lddl : 0), dlogits_f32, (long)lddf, loss_scale);
+  else
+    hipLaunchKernelGGL(bce_logits_kernel<0>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, logits, (long)ldl, targets, (long)ldt, (int)C, grad_scale, focal_gamma,
+                       focal_alpha, loss_rows, (bf16_t*)dlogits16, (long)(dlogits16 ? lddl : 0), dlogits_f32, (long)lddf, loss_scale);
+  return vdk_check_launch("vdk_bce_logits");
+}
 int vdk_bce_logits(const float* logits, int64_t ldl, const float* targets, int64_t ldt, int32_t B, int32_t C, float grad_scale,
                    float focal_gamma, float focal_alpha, float* loss_rows, void* dlogits_bf16, int64_t lddl, float* dlogits_f32, int64_t lddf,
                    void* stream) {
-  if (!logits || !targets || B <= 0 || C <= 0 || (dlogits_bf16 && lddl < C)) return vdk_fail(VDK_EINVAL, "vdk_bce_logits: bad argument");
-  hipLaunchKernelGGL(bce_logits_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, logits, (long)ldl, targets, (long)ldt,
-                     (int)C, grad_scale, focal_gamma, focal_alpha, loss_rows, (bf16_t*)dlogits_bf16, (long)(dlogits_bf16 ? lddl : 0), dlogits_f32, (long)lddf);
-  return vdk_check_launch("vdk_bce_logits");
+  return vdk_bce_logits_amp(logits, ldl, targets, ldt, B, C, grad_scale, nullptr, focal_gamma, focal_alpha, loss_rows, dlogits_bf16, lddl, VDK_BF16, dlogits_f32, lddf, stream);
 }
 
 }  // extern "C"
@@ -722,18 +760,20 @@ int vdk_bce_logits(const float* logits, int64_t ldl, const float* targets, int64
 // LayerNorm backward whose dgamma | dbeta partial-sum reduction is left to the caller: *job describes it (job->in == NULL if it was done here after all)
 int vdk_layernorm_bwd_deferred(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
                                const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx, int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta,
-                               void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job, float* dxb_colsum, VdkReduceJob* job2, const LnQ8* dxb_q8) {
-  return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, mean, rstd, gamma, dres, lddres, T, C, dx, lddx, dxb, lddxb, dgamma, dbeta, ws, ws_bytes, stream, job, dxb_colsum, job2, dxb_q8);
+                               void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job, float* dxb_colsum, VdkReduceJob* job2, const LnQ8* dxb_q8, int opf) {
+  return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, mean, rstd, gamma, dres, lddres, T, C, dx, lddx, dxb, lddxb, dgamma, dbeta, ws, ws_bytes, stream, job, dxb_colsum, job2, dxb_q8, opf);
 }
 // vdk_colsum_bf16 whose final reduction over the row splits is left to the caller (*job describes it)
-int vdk_colsum_bf16_deferred(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream_, VdkReduceJob* job, const LnQ8* q8) {
+int vdk_colsum_bf16_deferred(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream_, VdkReduceJob* job, const LnQ8* q8, int opf) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!in || !out || !job || T <= 0 || N <= 0 || (N & 7) || (ld & 7) || (q8 && (!q8->out || (q8->ld & 7)))) return vdk_fail(VDK_EINVAL, "vdk_colsum_bf16: bad argument (N, ld % 8 == 0)");
   const int S = colsum_splits(T, N);
   if (!ws || ws_bytes < (size_t)S * N * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_colsum_bf16: workspace too small");
   const int rps = (T + S - 1) / S;
   const dim3 grid((unsigned)((N / 8 + 31) / 32), (unsigned)S);
-  if (q8) hipLaunchKernelGGL(colsum_bf16_partial_kernel<true>, grid, dim3(256), 0, stream, (const bf16_t*)in, (long)ld, (int)T, (int)N, rps, (float*)ws, *q8);
+  if (q8 && opf) return vdk_fail(VDK_EINVAL, "vdk_colsum_bf16: the fp8 copy goes with bf16 tensors");
+  if (opf) hipLaunchKernelGGL((colsum_bf16_partial_kernel<false, VDK_OPF_F16>), grid, dim3(256), 0, stream, (const bf16_t*)in, (long)ld, (int)T, (int)N, rps, (float*)ws, LnQ8());
+  else if (q8) hipLaunchKernelGGL(colsum_bf16_partial_kernel<true>, grid, dim3(256), 0, stream, (const bf16_t*)in, (long)ld, (int)T, (int)N, rps, (float*)ws, *q8);
   else hipLaunchKernelGGL(colsum_bf16_partial_kernel<false>, grid, dim3(256), 0, stream, (const bf16_t*)in, (long)ld, (int)T, (int)N, rps, (float*)ws, LnQ8());
   *job = VdkReduceJob{(const float*)ws, (long)N, S, (long)N, out, 1.0f};
   return vdk_check_launch("vdk_colsum_bf16");

@@ -71,15 +71,17 @@ __device__ __forceinline__ f32x16 as_zero16() {
   return z;
 }
 // 16 C-layout values -> the two B-operand fragments (k-slot j of step s <-> accumulator register 8*s + j)
+template <int OF = 0>
 __device__ __forceinline__ void as_pack_b(const f32x16& p, s16x8 (&f)[2]) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    u32x4 u = {pack_bf2(p[8 * s + 0], p[8 * s + 1]), pack_bf2(p[8 * s + 2], p[8 * s + 3]), pack_bf2(p[8 * s + 4], p[8 * s + 5]), pack_bf2(p[8 * s + 6], p[8 * s + 7])};
+    u32x4 u = {pack_op2<OF>(p[8 * s + 0], p[8 * s + 1]), pack_op2<OF>(p[8 * s + 2], p[8 * s + 3]), pack_op2<OF>(p[8 * s + 4], p[8 * s + 5]), pack_op2<OF>(p[8 * s + 6], p[8 * s + 7])};
     f[s] = *(s16x8*)&u;
   }
 }
 // a wave's 32 x 64 bf16 output tile (C-layout of a transposed product: lane = row, registers = 4 consecutive columns per group) -> its private 4 KB
 // LDS tile (16-byte chunk ^ (row & 7)) -> 128-byte coalesced global rows
+template <int OF = 0>
 __device__ __forceinline__ void as_store_tile(unsigned char* tile, const f32x16& x0, const f32x16& x1, float mul, bf16_t* __restrict__ dst, long ld, int row0, int N,
                                               int lane) {
   const int l31 = lane & 31, hi = lane >> 5;
@@ -87,8 +89,8 @@ __device__ __forceinline__ void as_store_tile(unsigned char* tile, const f32x16&
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int ch = g ^ (l31 & 7), ch1 = (4 + g) ^ (l31 & 7);
-      *(u32x2*)(tile + l31 * AS_ROW + (ch << 4) + 8 * hi) = (u32x2){pack_bf2(x0[4 * g] * mul, x0[4 * g + 1] * mul), pack_bf2(x0[4 * g + 2] * mul, x0[4 * g + 3] * mul)};
-      *(u32x2*)(tile + l31 * AS_ROW + (ch1 << 4) + 8 * hi) = (u32x2){pack_bf2(x1[4 * g] * mul, x1[4 * g + 1] * mul), pack_bf2(x1[4 * g + 2] * mul, x1[4 * g + 3] * mul)};
+      *(u32x2*)(tile + l31 * AS_ROW + (ch << 4) + 8 * hi) = (u32x2){pack_op2<OF>(x0[4 * g] * mul, x0[4 * g + 1] * mul), pack_op2<OF>(x0[4 * g + 2] * mul, x0[4 * g + 3] * mul)};
+      *(u32x2*)(tile + l31 * AS_ROW + (ch1 << 4) + 8 * hi) = (u32x2){pack_op2<OF>(x1[4 * g] * mul, x1[4 * g + 1] * mul), pack_op2<OF>(x1[4 * g + 2] * mul, x1[4 * g + 3] * mul)};
     }
   }
   VDK_WAVE_LDS_SYNC();

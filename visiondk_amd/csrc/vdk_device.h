@@ -84,6 +84,49 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
+// two fp32 -> packed fp16 (round to nearest even) and back
+typedef _Float16 vdk_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 vdk_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pack_h2(float a, float b) {
+  const vdk_f16x2 h = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ float h_lo(unsigned u) { return (float)__builtin_bit_cast(vdk_f16x2, u)[0]; }
+__device__ __forceinline__ float h_hi(unsigned u) { return (float)__builtin_bit_cast(vdk_f16x2, u)[1]; }
+
+// ---- the 16-bit OPERAND FORMAT of the GEMM path (template parameter OF of every kernel that reads or writes GEMM operands) -----------------------------
+// OF = 0: bfloat16 (BASELINE.json configs[1] "bf16").  OF = 1: IEEE fp16 -- what the reference's `torch.autocast(device_type=...)` (engine/procedure/train.py:118, no
+// dtype argument => float16 on a GPU) holds its matmul operands in, with GradScaler's loss scale (train.py:205-211) carrying the gradients through the narrower
+// exponent.  Same storage (bf16_t = 16 raw bits), same MFMA rate (v_mfma_f32_32x32x16_f16 = v_mfma_f32_32x32x16_bf16), 8x smaller operand rounding.
+#define VDK_OPF_BF16 0
+#define VDK_OPF_F16 1
+template <int OF> __device__ __forceinline__ unsigned pack_op2(float lo, float hi) { if constexpr (OF == VDK_OPF_F16) return pack_h2(lo, hi); else return pack_bf2(lo, hi); }
+template <int OF> __device__ __forceinline__ float op_lo(unsigned w) { if constexpr (OF == VDK_OPF_F16) return h_lo(w); else return bf_lo(w); }
+template <int OF> __device__ __forceinline__ float op_hi(unsigned w) { if constexpr (OF == VDK_OPF_F16) return h_hi(w); else return bf_hi(w); }
+template <int OF> __device__ __forceinline__ float op2f(bf16_t h) {
+  if constexpr (OF == VDK_OPF_F16) return (float)__builtin_bit_cast(_Float16, h); else return bf2f(h);
+}
+template <int OF> __device__ __forceinline__ bf16_t f2op(float f) {
+  if constexpr (OF == VDK_OPF_F16) { const _Float16 h = (_Float16)f; return __builtin_bit_cast(bf16_t, h); } else return f2bf(f);
+}
+// D = A B + C on 32x32x16 / 16x16x32 tiles of 16-bit operands (fragment layouts are the same for both formats)
+template <int OF> __device__ __forceinline__ f32x16 vdk_mfma32(s16x8 a, s16x8 b, f32x16 c) {
+#ifdef VDK_EMU
+  return emu_mfma_32x32x16_op<OF>(a, b, c);
+#else
+  if constexpr (OF == VDK_OPF_F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vdk_f16x8, a), __builtin_bit_cast(vdk_f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+template <int OF> __device__ __forceinline__ f32x4 vdk_mfma16(s16x8 a, s16x8 b, f32x4 c) {
+#ifdef VDK_EMU
+  return emu_mfma_16x16x32_op<OF>(a, b, c);
+#else
+  if constexpr (OF == VDK_OPF_F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vdk_f16x8, a), __builtin_bit_cast(vdk_f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+
 // ---- wave / block reductions -------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -214,15 +257,6 @@ __device__ __forceinline__ void gelu_both_f2(vdk_f32x2 x, vdk_f32x2& g, vdk_f32x
 #endif
 __device__ __forceinline__ float gelu_f(float x) { return gelu_f2((vdk_f32x2){x, x})[0]; }
 __device__ __forceinline__ float gelu_grad_f(float x) { return gelu_grad_f2((vdk_f32x2){x, x})[0]; }
-
-// two fp32 -> packed fp16 (round to nearest even) and back
-typedef _Float16 vdk_f16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pack_h2(float a, float b) {
-  const vdk_f16x2 h = {(_Float16)a, (_Float16)b};
-  return __builtin_bit_cast(unsigned, h);
-}
-__device__ __forceinline__ float h_lo(unsigned u) { return (float)__builtin_bit_cast(vdk_f16x2, u)[0]; }
-__device__ __forceinline__ float h_hi(unsigned u) { return (float)__builtin_bit_cast(vdk_f16x2, u)[1]; }
 
 __device__ __forceinline__ void gelu_both_f(float x, float& g, float& d) {
   vdk_f32x2 g2, d2;

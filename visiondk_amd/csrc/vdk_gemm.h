@@ -33,14 +33,20 @@ struct GemmParams {
   int band_cw;               // gemm_w4_kernel / gemm_w4h_kernel: tile order = column bands of band_cw tile columns, row-major inside a band (0: plain row-major)
   int sk_xcd;                // gemm_w4_kernel, split-K: 1-D grid, a slab's tiles stay on one XCD (see the kernel); 0: grid (tiles, splits)
   int stagger, stagger_lo;   // gemm_w4h_kernel: workgroups stagger_lo .. 2 * stagger_lo - 1 start `stagger` shader cycles late (0: nobody)
+  int opf;                   // operand format of A, B, a 16-bit C and aux: VDK_OPF_BF16 | VDK_OPF_F16 (VdkGemmDesc.ab_dtype)
 };
 
 // in-library launcher (no descriptor copy through the C ABI)
 extern "C" int vdk_gemm_bf16_nt(const VdkGemmDesc* d, void* ws, size_t ws_bytes, void* stream);
 extern "C" int vdk_transpose_bf16(const void* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, int32_t Rpad, int32_t in_row_group, float* colsum_partial, void* stream);
+int vdk_transpose_16(const void* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, int32_t Rpad, int32_t in_row_group, float* colsum_partial, int opf, void* stream);
 
 // gemm_w4.hip: the 4-wave (one wave per SIMD) 256x256 kernel.  serves(): the problem fits its 32-bit buffer offsets and asks for no by-product it lacks.
 bool vdk_gemm_w4_serves(const GemmParams& p, bool trans);
 bool vdk_gemm_w4_launch(const GemmParams& p, bool trans, int E, unsigned tiles, unsigned splitk, void* stream, void* ev0, void* ev1);
 bool vdk_gemm_w4h_serves(const GemmParams& p, bool trans);
 bool vdk_gemm_w4h_launch(const GemmParams& p, bool trans, int E, unsigned splitk, void* stream, void* ev0, void* ev1);
+// the same kernels instantiated for fp16 operands (gemm_w4_f16.hip); GemmParams.opf selects between them in gemm.hip
+bool vdk_gemm_w4_launch_f16(const GemmParams& p, bool trans, int E, unsigned tiles, unsigned splitk, void* stream, void* ev0, void* ev1);
+bool vdk_gemm_w4h_launch_f16(const GemmParams& p, bool trans, int E, unsigned splitk, void* stream, void* ev0, void* ev1);
+int vdk_gemm_w4_cus();      // workgroups of the persistent walk (CUs minus the reserve)

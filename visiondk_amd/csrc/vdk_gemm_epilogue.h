@@ -4,6 +4,7 @@
 #include "vdk_gemm.h"
 
 // ---- shared fused epilogue for one 8-wide row chunk: v[8] = raw accumulators of C[mi][n..n+7] -----------------------
+template <int OF = 0>
 __device__ __forceinline__ void g_epilogue_store8(const GemmParams& p, long mi, int n, float (&v)[8], int z) {
     // token-row remap (patch embedding -> token buffer): output row skips one cls slot per group and the
     // residual (pos_embed) row repeats per group
@@ -26,7 +27,7 @@ __device__ __forceinline__ void g_epilogue_store8(const GemmParams& p, long mi, 
     }
     if (p.act == VDK_ACT_GELU) {
       if (p.aux) {  // keep the pre-activation for the backward pass
-        u32x4 u = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        u32x4 u = {pack_op2<OF>(v[0], v[1]), pack_op2<OF>(v[2], v[3]), pack_op2<OF>(v[4], v[5]), pack_op2<OF>(v[6], v[7])};
         *(u32x4*)(p.aux + m * p.ldaux + n) = u;
       }
 #pragma unroll
@@ -35,7 +36,7 @@ __device__ __forceinline__ void g_epilogue_store8(const GemmParams& p, long mi, 
       u32x4 u = *(const u32x4*)(p.aux + m * p.ldaux + n);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const vdk_f32x2 d2 = gelu_grad_f2((vdk_f32x2){bf_lo(u[e]), bf_hi(u[e])});
+        const vdk_f32x2 d2 = gelu_grad_f2((vdk_f32x2){op_lo<OF>(u[e]), op_hi<OF>(u[e])});
         v[2 * e] *= d2[0];
         v[2 * e + 1] *= d2[1];
       }
@@ -60,7 +61,7 @@ __device__ __forceinline__ void g_epilogue_store8(const GemmParams& p, long mi, 
       *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
       *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
     } else {
-      u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+      u32x4 o = {pack_op2<OF>(v[0], v[1]), pack_op2<OF>(v[2], v[3]), pack_op2<OF>(v[4], v[5]), pack_op2<OF>(v[6], v[7])};
       *(u32x4*)((bf16_t*)p.C + m * p.ldc + n) = o;
     }
 }
@@ -85,7 +86,7 @@ __device__ __forceinline__ void g_epilogue_store8(const GemmParams& p, long mi, 
 #define E_GENERIC 0x1000
 
 // SWZ: the slab's 16-byte chunk c of row r lives at chunk position c ^ (r & 15) (bank-conflict-free for the row-per-lane writes of gemm_w4.hip)
-template <int E, int NPS = 8 /* row passes: the slab holds NPS * 8 rows x 64 fp32 */, bool SWZ = false>
+template <int E, int NPS = 8 /* row passes: the slab holds NPS * 8 rows x 64 fp32 */, bool SWZ = false, int OF = 0 /* operand format of the 16-bit output / aux */>
 __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float* slab, int lane, long mbase /* first row of this slab */,
                                                 int n, int z, const float (&bias8)[8], float (&ocs)[8], float& q8am) {
   // this lane: rows mbase + pass*8 + (lane >> 3), pass = 0..NPS-1, columns n .. n+7
@@ -174,7 +175,7 @@ __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float
       for (int e = 0; e < 8; ++e) gelu_both_f(v[e], v[e], dv[e]);
       *(u32x4*)(p.aux + mo[ps] * p.ldaux + n) = (u32x4){pack_h2(dv[0], dv[1]), pack_h2(dv[2], dv[3]), pack_h2(dv[4], dv[5]), pack_h2(dv[6], dv[7])};
     } else if (E & E_GELU) {
-      *(u32x4*)(p.aux + mo[ps] * p.ldaux + n) = (u32x4){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+      *(u32x4*)(p.aux + mo[ps] * p.ldaux + n) = (u32x4){pack_op2<OF>(v[0], v[1]), pack_op2<OF>(v[2], v[3]), pack_op2<OF>(v[4], v[5]), pack_op2<OF>(v[6], v[7])};
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const vdk_f32x2 g2 = gelu_f2((vdk_f32x2){v[2 * e], v[2 * e + 1]}); v[2 * e] = g2[0]; v[2 * e + 1] = g2[1]; }
     }
@@ -183,7 +184,7 @@ __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float
       for (int e = 0; e < 4; ++e) { v[2 * e] *= h_lo(ux[ps][e]); v[2 * e + 1] *= h_hi(ux[ps][e]); }
     } else if (E & E_DGELU) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const vdk_f32x2 d2 = gelu_grad_f2((vdk_f32x2){bf_lo(ux[ps][e]), bf_hi(ux[ps][e])}); v[2 * e] *= d2[0]; v[2 * e + 1] *= d2[1]; }
+      for (int e = 0; e < 4; ++e) { const vdk_f32x2 d2 = gelu_grad_f2((vdk_f32x2){op_lo<OF>(ux[ps][e]), op_hi<OF>(ux[ps][e])}); v[2 * e] *= d2[0]; v[2 * e + 1] *= d2[1]; }
     }
     if (E & E_RES) {
 #pragma unroll
@@ -214,17 +215,17 @@ __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float
       *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
       *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
     } else {
-      const u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+      const u32x4 o = {pack_op2<OF>(v[0], v[1]), pack_op2<OF>(v[2], v[3]), pack_op2<OF>(v[4], v[5]), pack_op2<OF>(v[6], v[7])};
       *(u32x4*)((bf16_t*)p.C + mo[ps] * p.ldc + n) = o;
       if (E & E_OCS) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { ocs[2 * e] += bf_lo(o[e]); ocs[2 * e + 1] += bf_hi(o[e]); }
+        for (int e = 0; e < 4; ++e) { ocs[2 * e] += op_lo<OF>(o[e]); ocs[2 * e + 1] += op_hi<OF>(o[e]); }
       }
       if (E & E_Q8) {
         float c[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float a = bf_lo(o[e]), b = bf_hi(o[e]);
+          const float a = op_lo<OF>(o[e]), b = op_hi<OF>(o[e]);
           q8am = fmaxf(q8am, fmaxf(fabsf(a), fabsf(b)));
           c[2 * e] = fminf(fmaxf(a * q8s, -q8lim), q8lim); c[2 * e + 1] = fminf(fmaxf(b * q8s, -q8lim), q8lim);
         }

@@ -13,9 +13,12 @@ int vdk_check_launch(const char* what);
 // In-library helper (C++ linkage, not part of the C ABI): many transpose + cast jobs (out[c][r] bf16 = in[r][c] f32, rows [R, Rpad) zero-filled) in ONE launch.
 // A weight refresh of a 12-layer ViT is 49 such jobs of ~10 us each; as separate launches they sit at the launch-latency floor.
 struct VdkTcItem { const float* in; void* out; int ldi, R, C, ldo, Rpad; };
-int vdk_transpose_cast_batch(const VdkTcItem* items, int n, void* stream);
+int vdk_transpose_cast_batch(const VdkTcItem* items, int n, void* stream, int opf = 0 /* output format: VDK_OPF_BF16 | VDK_OPF_F16 (vdk_device.h) */);
 // out bf16 [R, ldo] = in f32 [R, C] (row stride ldi) with the columns [C, ldo) zero-filled (operand copies of weights whose row length is not a multiple of 8)
-int vdk_cast_pad_rows(const float* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, void* stream);
+int vdk_cast_pad_rows(const float* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, void* stream, int opf = 0);
+// vdk_patchify_bf16 / vdk_cast_f32_bf16 with the 16-bit output format as a parameter
+int vdk_patchify_16(const float* x, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t patch, void* out, int32_t Kp, int opf, void* stream);
+int vdk_cast_f32_16(const float* in, void* out, int64_t n, int opf, void* stream);
 
 // fp8 copy of a LayerNorm kernel's bf16 output (fp8 mode of the ViT engine): out [rows, ld] bytes = fp8(clamp(value * scale[0])), amax[0] = max(amax[0], max |value|)
 struct LnQ8 { unsigned char* out; long ld; const float* scale; float* amax; int fmt; };
@@ -24,7 +27,9 @@ struct VdkReduceJob { const float* in; long ld; int S; long n; float* out; float
 int vdk_reduce_rows_batch(const VdkReduceJob* jobs, int n, void* stream);
 
 int vdk_colsum_bf16_deferred(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job,
-                             const LnQ8* q8 = nullptr /* the pass also writes the fp8 copy of `in` (rows of ld bytes) and its amax */);
+                             const LnQ8* q8 = nullptr /* the pass also writes the fp8 copy of `in` (rows of ld bytes) and its amax */,
+                             int opf = 0 /* format of `in`: VDK_OPF_BF16 | VDK_OPF_F16 (vdk_device.h) */);
+int vdk_colsum_16(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, int opf, void* stream);
 // vdk_dwconv7_wgrad whose reduction over the per-slice partials [S][49 C | C] is left to the caller (needs db == dw + 49 C: the flat gradient buffer's layout)
 int vdk_dwconv7_wgrad_deferred(const float* in, const float* dy, float* dw, float* db, int32_t B, int32_t H, int32_t W, int32_t C, void* ws, size_t ws_bytes, void* stream,
                                VdkReduceJob* job);
@@ -32,4 +37,5 @@ int vdk_layernorm_bwd_deferred(const void* dy, int64_t lddy, int32_t dy_dtype, c
                                const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx, int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta,
                                void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job,
                                float* dxb_colsum = nullptr /* [C]: column sums of the bf16 output dxb (a Linear's bias gradient), reduction described by *job2 */, VdkReduceJob* job2 = nullptr,
-                               const LnQ8* dxb_q8 = nullptr /* with dxb_colsum, C <= 1024, bf16 dy: dxb's fp8 copy rides along */);
+                               const LnQ8* dxb_q8 = nullptr /* with dxb_colsum, C <= 1024, bf16 dy: dxb's fp8 copy rides along */,
+                               int opf = 0 /* format of a 16-bit dy and of dxb (dy_dtype VDK_F16 implies fp16; an fp32 dy takes it from here) */);

@@ -31,6 +31,8 @@ int vdk_colsum_bf16(const void*, int64_t, int32_t, int32_t, float*, void*, size_
 int vdk_attention_fwd(const void*, int64_t, void*, int64_t, float*, int32_t, int32_t, int32_t, int32_t, float, void*);
 int vdk_attention_bwd(const void*, int64_t, const void*, const void*, int64_t, const float*, void*, int64_t, float*, int32_t, int32_t, int32_t,
                       int32_t, float, void*);
+int vdk_attention_fwd_dt(const void*, int64_t, void*, int64_t, float*, int32_t, int32_t, int32_t, int32_t, float, int32_t, void*);
+int vdk_attention_bwd_dt(const void*, int64_t, const void*, const void*, int64_t, const float*, void*, int64_t, float*, int32_t, int32_t, int32_t, int32_t, float, int32_t, void*);
 int vdk_patchify_bf16(const float*, int32_t, int32_t, int32_t, int32_t, int32_t, void*, int32_t, void*);
 int vdk_cls_rows(float*, int64_t, int32_t, int32_t, const float*, const float*, void*);
 int vdk_cast_f32_bf16(const float*, void*, int64_t, void*);
@@ -46,10 +48,16 @@ int vdk_gemm_fp8_nt_q8(const VdkGemmDesc*, int32_t, int32_t, const float*, const
 int vdk_layernorm_fwd_q8(const float*, int64_t, int32_t, int32_t, const float*, const float*, float, void*, int64_t, float*, float*, void*, int64_t, int32_t, const float*, float*, void*);
 }
 
+
+// Operand format of the engine call in progress on this thread: every entry point sets it from VdkVitConfig.operand before it enqueues anything, the helpers below read
+// it (an engine call runs to completion on its thread).  DT16 = the dtype code of the 16-bit tensors.
+static thread_local int t_opf = VDK_OPF_BF16;
+#define DT16 (t_opf ? VDK_F16 : VDK_BF16)
+
 static inline int64_t up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 struct VitDims {
-  int B, img, ps, Cin, D, L, H, M, C, Cp, np, N, T, Kraw, Kpe, Tp, Bp, cls, fp8;   // cls: 1 = class token in row 0 of every image's token block   // Kraw = in_chans * patch^2, Kpe = Kraw padded to 8 (patch 14: 588 -> 592)
+  int B, img, ps, Cin, D, L, H, M, C, Cp, np, N, T, Kraw, Kpe, Tp, Bp, cls, fp8, opf /* operand format: VDK_OPF_BF16 | VDK_OPF_F16 (VdkVitConfig.operand) */;   // cls: 1 = class token in row 0 of every image's token block   // Kraw = in_chans * patch^2, Kpe = Kraw padded to 8 (patch 14: 588 -> 592)
   float eps;
 };
 static int vit_dims(const VdkVitConfig* c, VitDims* d) {
@@ -72,6 +80,9 @@ static int vit_dims(const VdkVitConfig* c, VitDims* d) {
   d->Bp = (int)up(d->B, 64);
   d->fp8 = c->fp8;
   if (d->fp8 < 0 || d->fp8 > 2) return vdk_fail(VDK_EINVAL, "vit: fp8 must be 0, 1 or 2");
+  if (c->operand != VDK_BF16 && c->operand != VDK_F16) return vdk_fail(VDK_EINVAL, "vit: operand must be VDK_BF16 or VDK_F16");
+  d->opf = c->operand == VDK_F16 ? VDK_OPF_F16 : VDK_OPF_BF16;
+  if (d->opf && d->fp8) return vdk_fail(VDK_EUNSUPPORTED, "vit: the fp8 mode goes with bf16 operands");
   if (d->fp8 && (d->D < 256 || (d->D % 128) || (d->M % 128))) return vdk_fail(VDK_EUNSUPPORTED, "vit: the fp8 mode needs dim >= 256, dim and mlp_dim % 128 == 0");
   return VDK_OK;
 }
@@ -336,8 +347,8 @@ static int gemm(hipStream_t s, const void* A, int64_t lda, const void* B, int64_
                 const float* bias, const float* res, int64_t ldr, int act, void* aux, int64_t ldaux, int splitk, int row_group, void* ws,
                 size_t wsb) {
   VdkGemmDesc g = {};
-  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.c_dtype = cdt; g.bias = bias;
-  g.residual = res; g.ldr = ldr; g.act = act; g.aux = aux; g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = splitk; g.row_group = row_group;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.c_dtype = cdt == VDK_F32 ? VDK_F32 : DT16; g.bias = bias;
+  g.residual = res; g.ldr = ldr; g.act = act; g.aux = aux; g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = splitk; g.row_group = row_group; g.ab_dtype = DT16;
   return vdk_gemm_bf16_nt(&g, ws, wsb, s);
 }
 
@@ -380,7 +391,8 @@ int vdk_vit_refresh_weights(const VdkVitConfig* cfg, const float* params, void* 
   VitDims d; RC(vit_dims(cfg, &d));
   PLayout p; RC(vit_layout(d, &p));
   if (!params || !wb16 || !wt16) return vdk_fail(VDK_EINVAL, "vdk_vit_refresh_weights: null pointer");
-  if (!skip_wb16) RC(vdk_cast_f32_bf16(params, wb16, p.total, stream));
+  t_opf = d.opf;
+  if (!skip_wb16) RC(vdk_cast_f32_16(params, wb16, p.total, t_opf, stream));
   bf16_t* wt = (bf16_t*)wt16;
   std::vector<VdkTcItem> jobs;      // every [in, out] transposed operand copy of the step in one launch (49 jobs for 12 layers)
   auto add = [&](const float* in, int ldi, int R, int Cc, bf16_t* out, int ldo, int Rpad) { jobs.push_back(VdkTcItem{in, out, ldi, R, Cc, ldo, Rpad}); };
@@ -391,7 +403,7 @@ int vdk_vit_refresh_weights(const VdkVitConfig* cfg, const float* params, void* 
     add(params + p.blk[l].fc2_w, d.M, d.D, d.M, wt + p.blkT[l].fc2, d.D, d.D);
   }
   if (d.C > 0) add(params + p.head_w, d.D, d.Cp, d.D, wt + p.headT, d.Cp, d.Cp);
-  RC(vdk_transpose_cast_batch(jobs.data(), (int)jobs.size(), stream));
+  RC(vdk_transpose_cast_batch(jobs.data(), (int)jobs.size(), stream, t_opf));
   if (d.fp8) {     // e4m3 copies of the block Linears' weights, both orientations, one scale per tensor taken from the weights themselves (current scaling)
     F8 f; RC(f8_init(cfg, d, p, &f, nullptr, nullptr));
     hipStream_t s = (hipStream_t)stream;
@@ -427,6 +439,7 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
   WsPlan w; RC(vit_plan(d, &w));
   if (!x || !params || !wb16 || !ws || !logits) return vdk_fail(VDK_EINVAL, "vdk_vit_forward: null pointer");
   if (ws_bytes < w.total) return vdk_fail(VDK_EWORKSPACE, "vdk_vit_forward: workspace too small");
+  t_opf = d.opf;
   char* base = (char*)ws;
   const bf16_t* wb = (const bf16_t*)wb16;
   const int T = d.T, D = d.D, M = d.M;
@@ -436,10 +449,10 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
 
   // patch embedding: im2col-free operand + GEMM whose epilogue drops each patch row at its token slot and adds pos_embed
   bf16_t* patches = (bf16_t*)(base + w.patches);
-  RC(vdk_patchify_bf16(x, d.B, d.Cin, d.img, d.img, d.ps, patches, d.Kpe, s));
+  RC(vdk_patchify_16(x, d.B, d.Cin, d.img, d.img, d.ps, patches, d.Kpe, t_opf, s));
   const bf16_t* pew = wb + p.pe_w;
   if (d.Kraw != d.Kpe) {           // rows of 588 bf16 are not 16-byte aligned: the GEMM reads a zero-padded [D, Kpe] copy rebuilt from the master weights
-    RC(vdk_cast_pad_rows(params + p.pe_w, d.Kraw, D, d.Kraw, base + w.pepad, d.Kpe, s));
+    RC(vdk_cast_pad_rows(params + p.pe_w, d.Kraw, D, d.Kraw, base + w.pepad, d.Kpe, s, t_opf));
     pew = (const bf16_t*)(base + w.pepad);
   }
   RC(gemm(s, patches, d.Kpe, pew, d.Kpe, X, D, d.B * d.np, D, d.Kpe, VDK_F32, params + p.pe_b, params + p.pos, D, VDK_ACT_NONE,
@@ -471,13 +484,13 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
       RC(gemm8(s, f8, g, sl + 3, 0, f8.w8 + b.fc2_w, sl + 7, M, xout, D, T, D, M, VDK_F32, params + b.fc2_b, xmid, D, VDK_ACT_NONE, nullptr, 0, fq ? f8.a8b : nullptr));
       continue;
     }
-    RC(vdk_layernorm_fwd(xin, D, T, D, params + b.n1w, params + b.n1b, d.eps, h1, D, VDK_BF16, mean1, rstd1, s));
-    RC(gemm(s, h1, D, wb + b.qkv_w, D, qkv, 3 * D, T, 3 * D, D, VDK_BF16, params + b.qkv_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
-    RC(vdk_attention_fwd(qkv, 3 * D, o, D, lse, d.B, d.N, d.H, 64, scale, s));
+    RC(vdk_layernorm_fwd(xin, D, T, D, params + b.n1w, params + b.n1b, d.eps, h1, D, DT16, mean1, rstd1, s));
+    RC(gemm(s, h1, D, wb + b.qkv_w, D, qkv, 3 * D, T, 3 * D, D, DT16, params + b.qkv_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
+    RC(vdk_attention_fwd_dt(qkv, 3 * D, o, D, lse, d.B, d.N, d.H, 64, scale, DT16, s));
     RC(gemm(s, o, D, wb + b.proj_w, D, xmid, D, T, D, D, VDK_F32, params + b.proj_b, xin, D, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
     // x = x + fc2(gelu(fc1(norm2(x))))
-    RC(vdk_layernorm_fwd(xmid, D, T, D, params + b.n2w, params + b.n2b, d.eps, h2, D, VDK_BF16, mean2, rstd2, s));
-    RC(gemm(s, h2, D, wb + b.fc1_w, D, g, M, T, M, D, VDK_BF16, params + b.fc1_b, nullptr, 0, VDK_ACT_GELU, u, M, 1, 0, nullptr, 0));
+    RC(vdk_layernorm_fwd(xmid, D, T, D, params + b.n2w, params + b.n2b, d.eps, h2, D, DT16, mean2, rstd2, s));
+    RC(gemm(s, h2, D, wb + b.fc1_w, D, g, M, T, M, D, DT16, params + b.fc1_b, nullptr, 0, VDK_ACT_GELU, u, M, 1, 0, nullptr, 0));
     RC(gemm(s, g, M, wb + b.fc2_w, M, xout, D, T, D, M, VDK_F32, params + b.fc2_b, xmid, D, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
   }
   float* xl = X + (size_t)(2 * d.L) * XS;
@@ -489,7 +502,7 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
   }
   // final norm on the class-token rows only (LayerNorm is per token; global_pool='token' keeps token 0), then the head
   bf16_t* hf = (bf16_t*)(base + w.hf);
-  RC(vdk_layernorm_fwd(xl, (int64_t)d.N * D, d.B, D, params + p.norm_w, params + p.norm_b, d.eps, hf, D, VDK_BF16, meanf, rstdf, s));
+  RC(vdk_layernorm_fwd(xl, (int64_t)d.N * D, d.B, D, params + p.norm_w, params + p.norm_b, d.eps, hf, D, DT16, meanf, rstdf, s));
   RC(gemm(s, hf, D, wb + p.head_w, D, logits, d.Cp, d.B, d.Cp, D, VDK_F32, params + p.head_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
   return VDK_OK;
 }
@@ -500,19 +513,21 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
 // rides along with the dY transpose.
 static int linear_wgrad(hipStream_t s, const VitDims& d, const WsPlan& w, char* base, const bf16_t* dY, int64_t lddy, const bf16_t* Xa,
                         int64_t ldx, int rows, int rows_pad, int out, int in, float* dW, float* db, int dy_row_group) {
-  if ((rows % 64) == 0 && (out % 8) == 0 && (in % 8) == 0 && out >= 8 && in >= 8) {
+  // (fp16 operands: the token-row remap of dY -- the patch embedding's weight gradient reads the rows of the [B, 1 + np, D] gradient minus the cls rows -- is a feature of
+  //  the eight-wave bf16 TN kernel only; that one GEMM per step takes the transposing path below: two passes over [B np, D] tensors, ~0.2 % of a ViT-B/16 step)
+  if ((rows % 64) == 0 && (out % 8) == 0 && (in % 8) == 0 && out >= 8 && in >= 8 && !(t_opf && dy_row_group != 0)) {
     const int sk = wgrad_splitk_tn(out, in, rows);
     VdkGemmDesc g = {};
     g.A = dY; g.lda = lddy; g.B = Xa; g.ldb = ldx; g.C = dW; g.ldc = in; g.M = out; g.N = in; g.K = rows; g.c_dtype = VDK_F32;
-    g.alpha = 1.0f; g.splitk = sk; g.trans = 1; g.a_row_group = dy_row_group;
+    g.alpha = 1.0f; g.splitk = sk; g.trans = 1; g.a_row_group = dy_row_group; g.ab_dtype = DT16;
     RC(vdk_gemm_bf16_nt(&g, base + w.slabs, w.slabs_bytes, s));
-    if (db && dy_row_group == 0) RC(vdk_colsum_bf16(dY, lddy, rows, out, db, base + w.csws + 4 * w.csws_bytes, w.csws_bytes, s));
+    if (db && dy_row_group == 0) RC(vdk_colsum_16(dY, lddy, rows, out, db, base + w.csws + 4 * w.csws_bytes, w.csws_bytes, t_opf, s));
     return VDK_OK;
   }
   bf16_t* tA = (bf16_t*)(base + w.tA); bf16_t* tB = (bf16_t*)(base + w.tB);
   float* csp = (db && dy_row_group == 0) ? (float*)(base + w.csws + 4 * w.csws_bytes) : nullptr;   // bias gradient rides along with the dY transpose
-  RC(vdk_transpose_bf16(dY, lddy, rows, out, tA, rows_pad, rows_pad, dy_row_group, csp, s));
-  RC(vdk_transpose_bf16(Xa, ldx, rows, in, tB, rows_pad, rows_pad, 0, nullptr, s));
+  RC(vdk_transpose_16(dY, lddy, rows, out, tA, rows_pad, rows_pad, dy_row_group, csp, t_opf, s));
+  RC(vdk_transpose_16(Xa, ldx, rows, in, tB, rows_pad, rows_pad, 0, nullptr, t_opf, s));
   const int sk = wgrad_splitk(out, in, rows_pad);
   RC(gemm(s, tA, rows_pad, tB, rows_pad, dW, in, out, in, rows_pad, VDK_F32, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, sk, 0, base + w.slabs,
           w.slabs_bytes));
@@ -538,15 +553,15 @@ static int dgrad_with_bias(hipStream_t s, const WsPlan& w, char* base, const bf1
                            int in, int out, int act, void* aux, int64_t ldaux, float* db, int* fused, int slot, VdkReduceJob* jobs, int* njobs,
                            float* dbx = nullptr, int* fusedx = nullptr, int slotx = 0) {
   const int prow = db ? vdk_gemm_a_colsum_rows(rows, in, out) : 0;
-  *fused = (db && prow > 0 && (size_t)prow * out * 4 <= w.csws_bytes) ? 1 : 0;
+  *fused = (db && !t_opf && prow > 0 && (size_t)prow * out * 4 <= w.csws_bytes) ? 1 : 0;      // (the A-tile column sums are a by-product of the eight-wave bf16 kernel only)
   const int xrow = dbx ? vdk_gemm_c_colsum_rows(rows, in, out) : 0;
   const int fx = (dbx && !*fused && xrow > 0 && (size_t)xrow * in * 4 <= w.csws_bytes) ? 1 : 0;
   if (fusedx) *fusedx = fx;
   float* const part = (float*)(base + w.csws + (size_t)slot * w.csws_bytes);
   float* const partx = (float*)(base + w.csws + (size_t)slotx * w.csws_bytes);
   VdkGemmDesc g = {};
-  g.A = dY; g.lda = lddy; g.B = Wt; g.ldb = ldw; g.C = dX; g.ldc = lddx; g.M = rows; g.N = in; g.K = out; g.c_dtype = VDK_BF16; g.act = act; g.aux = aux;
-  g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = 1;
+  g.A = dY; g.lda = lddy; g.B = Wt; g.ldb = ldw; g.C = dX; g.ldc = lddx; g.M = rows; g.N = in; g.K = out; g.c_dtype = DT16; g.act = act; g.aux = aux;
+  g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = 1; g.ab_dtype = DT16;
   if (*fused) g.a_colsum = part;
   if (fx) g.c_colsum = partx;
   RC(vdk_gemm_bf16_nt(&g, nullptr, 0, s));
@@ -570,6 +585,7 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
   WsPlan w; RC(vit_plan(d, &w));
   if (!dlogits || !params || !wb16 || !wt16 || !ws || !grads) return vdk_fail(VDK_EINVAL, "vdk_vit_backward: null pointer");
   if (ws_bytes < w.total) return vdk_fail(VDK_EWORKSPACE, "vdk_vit_backward: workspace too small");
+  t_opf = d.opf;
   char* base = (char*)ws;
   const bf16_t* wt = (const bf16_t*)wt16;
   const int T = d.T, D = d.D, M = d.M;
@@ -596,27 +612,27 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
     // feature mode: `dlogits` is dL/d norm(x) for all tokens, f32 [B*N, D]
     float* xl = X + (size_t)(2 * d.L) * XS;
     float* meanf = stats + (size_t)d.L * 4 * T; float* rstdf = meanf + T;
-    RC(vdk_layernorm_bwd(dlogits, D, VDK_F32, xl, D, meanf, rstdf, params + p.norm_w, nullptr, 0, T, D, dxa, D, DXAB(d.L - 1), D, grads + p.norm_w,
-                         grads + p.norm_b, lnws, w.lnws_bytes, s));
+    RC(vdk_layernorm_bwd_deferred(dlogits, D, VDK_F32, xl, D, meanf, rstdf, params + p.norm_w, nullptr, 0, T, D, dxa, D, DXAB(d.L - 1), D, grads + p.norm_w,
+                                  grads + p.norm_b, lnws, w.lnws_bytes, s, nullptr, nullptr, nullptr, nullptr, t_opf));
     if (on_ready) on_ready(user, p.norm_w, p.total - p.norm_w);
   } else {
     const bf16_t* dl = (const bf16_t*)dlogits;
     bf16_t* hf = (bf16_t*)(base + w.hf);
     RC(linear_wgrad(s, d, w, base, dl, d.Cp, hf, D, d.B, d.Bp, d.Cp, D, grads + p.head_w, grads + p.head_b, 0));
     bf16_t* dhf = (bf16_t*)(base + w.dhf);
-    RC(gemm(s, dl, d.Cp, wt + p.headT, d.Cp, dhf, D, d.B, D, d.Cp, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
+    RC(gemm(s, dl, d.Cp, wt + p.headT, d.Cp, dhf, D, d.B, D, d.Cp, DT16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
     if (hipMemsetAsync(dxa, 0, XS * 4, s) != hipSuccess || hipMemsetAsync(DXAB(d.L - 1), 0, XS * 2, s) != hipSuccess)
       return vdk_fail(VDK_ELAUNCH, "vdk_vit_backward: memset failed");
     float* xl = X + (size_t)(2 * d.L) * XS;
     float* meanf = stats + (size_t)d.L * 4 * T; float* rstdf = meanf + T;
     if (s2 == s && D <= 1024) {   // db of the last block's fc2 = column sums of DXAB(L-1) (only the cls rows are non-zero): by-product of this kernel
       VdkReduceJob fj[2];
-      RC(vdk_layernorm_bwd_deferred(dhf, D, VDK_BF16, xl, (int64_t)d.N * D, meanf, rstdf, params + p.norm_w, nullptr, 0, d.B, D, dxa, (int64_t)d.N * D, DXAB(d.L - 1),
+      RC(vdk_layernorm_bwd_deferred(dhf, D, DT16, xl, (int64_t)d.N * D, meanf, rstdf, params + p.norm_w, nullptr, 0, d.B, D, dxa, (int64_t)d.N * D, DXAB(d.L - 1),
                                     (int64_t)d.N * D, grads + p.norm_w, grads + p.norm_b, lnws, w.lnws_bytes, s, &fj[0], grads + p.blk[d.L - 1].fc2_b, &fj[1]));
       if (fj[0].in) RC(vdk_reduce_rows_batch(fj, 2, s)); else RC(vdk_reduce_rows_batch(fj + 1, 1, s));
       last_fc2_bias_done = true;
     } else
-    RC(vdk_layernorm_bwd(dhf, D, VDK_BF16, xl, (int64_t)d.N * D, meanf, rstdf, params + p.norm_w, nullptr, 0, d.B, D, dxa, (int64_t)d.N * D, DXAB(d.L - 1),
+    RC(vdk_layernorm_bwd(dhf, D, DT16, xl, (int64_t)d.N * D, meanf, rstdf, params + p.norm_w, nullptr, 0, d.B, D, dxa, (int64_t)d.N * D, DXAB(d.L - 1),
                          (int64_t)d.N * D, grads + p.norm_w, grads + p.norm_b, lnws, w.lnws_bytes, s));
     if (on_ready) on_ready(user, p.norm_w, p.total - p.norm_w);
   }
@@ -666,7 +682,7 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
                          grads + b.fc1_b, &fx, 1));   // du
       RC(linear_wgrad(s2, d, w, base, dxab, D, g, M, T, d.Tp, D, M, grads + b.fc2_w, (fz || have_fc2b) ? nullptr : grads + b.fc2_b, 0));
       if (fx) {
-        RC(gemm(s, du, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // dh2
+        RC(gemm(s, du, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, DT16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // dh2
         fz = 1;
       } else {
         RC(dgrad_with_bias(s, w, base, du, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, VDK_ACT_NONE, nullptr, 0, grads + b.fc1_b, &fz, 1, jobs, &nj));   // dh2
@@ -674,15 +690,15 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
       RC(linear_wgrad(s2, d, w, base, du, M, h2, D, T, d.Tp, M, D, grads + b.fc1_w, fz ? nullptr : grads + b.fc1_b, 0));
     } else {
       RC(linear_wgrad(s2, d, w, base, dxab, D, g, M, T, d.Tp, D, M, grads + b.fc2_w, grads + b.fc2_b, 0));
-      RC(gemm(s, dxab, D, wt + p.blkT[l].fc2, D, du, M, T, M, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_DGELU, u, M, 1, 0, nullptr, 0));   // du
+      RC(gemm(s, dxab, D, wt + p.blkT[l].fc2, D, du, M, T, M, D, DT16, nullptr, nullptr, 0, VDK_ACT_DGELU, u, M, 1, 0, nullptr, 0));   // du
       RC(ev_order(ev_p++, s, s2));
       RC(linear_wgrad(s2, d, w, base, du, M, h2, D, T, d.Tp, M, D, grads + b.fc1_w, grads + b.fc1_b, 0));
-      RC(gemm(s, du, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // dh2
+      RC(gemm(s, du, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, DT16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // dh2
     }
     const bool ocs_ln = one_stream && D <= 1024;
     const bool lq = f8.mode && f8_fused(f8) && ocs_ln;               // the norm backward kernels write the e5m2 copies of dxmb / DXAB(l - 1) into the operand scratch
     const LnQ8 q8m = {f8.a8, (long)D, f8.sc + 12 * l + 10, f8.amax + 12 * l + 10, 1};
-    RC(vdk_layernorm_bwd_deferred(dsm, D, VDK_BF16, xmid, D, mean2, rstd2, params + b.n2w, dxa, D, T, D, dxm, D, dxmb, D, grads + b.n2w, grads + b.n2b, lnws0,
+    RC(vdk_layernorm_bwd_deferred(dsm, D, DT16, xmid, D, mean2, rstd2, params + b.n2w, dxa, D, T, D, dxm, D, dxmb, D, grads + b.n2w, grads + b.n2b, lnws0,
                                   w.lnws_bytes, s, &jobs[nj], ocs_ln ? grads + b.proj_b : nullptr, ocs_ln ? &jobs[nj + 1] : nullptr, lq ? &q8m : nullptr));
     nj += ocs_ln ? 2 : 1;
     // attention branch: dxm / dxmb hold dL/dx_mid
@@ -691,16 +707,16 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
       RC(gemm8(s, f8, dxmb, 12 * l + 10, 1, f8.wt8 + p.blkT[l].proj, 12 * l + 5, D, dsm, D, T, D, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, lq ? f8.a8 : nullptr));   // do
       RC(linear_wgrad(s2, d, w, base, dxmb, D, o, D, T, d.Tp, D, D, grads + b.proj_w, ocs_ln ? nullptr : grads + b.proj_b, 0));
     } else if (one_stream && ocs_ln) {
-      RC(gemm(s, dxmb, D, wt + p.blkT[l].proj, D, dsm, D, T, D, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // do
+      RC(gemm(s, dxmb, D, wt + p.blkT[l].proj, D, dsm, D, T, D, D, DT16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // do
       RC(linear_wgrad(s2, d, w, base, dxmb, D, o, D, T, d.Tp, D, D, grads + b.proj_w, nullptr, 0));
     } else if (one_stream) {
       RC(dgrad_with_bias(s, w, base, dxmb, D, wt + p.blkT[l].proj, D, dsm, D, T, D, D, VDK_ACT_NONE, nullptr, 0, grads + b.proj_b, &fz, 2, jobs, &nj));   // do
       RC(linear_wgrad(s2, d, w, base, dxmb, D, o, D, T, d.Tp, D, D, grads + b.proj_w, fz ? nullptr : grads + b.proj_b, 0));
     } else {
       RC(linear_wgrad(s2, d, w, base, dxmb, D, o, D, T, d.Tp, D, D, grads + b.proj_w, grads + b.proj_b, 0));
-      RC(gemm(s, dxmb, D, wt + p.blkT[l].proj, D, dsm, D, T, D, D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // do
+      RC(gemm(s, dxmb, D, wt + p.blkT[l].proj, D, dsm, D, T, D, D, DT16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // do
     }
-    RC(vdk_attention_bwd(qkv, 3 * D, o, dsm, D, lse, dqkv, 3 * D, dvec, d.B, d.N, d.H, 64, 0.125f, s));                                    // dqkv
+    RC(vdk_attention_bwd_dt(qkv, 3 * D, o, dsm, D, lse, dqkv, 3 * D, dvec, d.B, d.N, d.H, 64, 0.125f, DT16, s));                                    // dqkv
     RC(ev_order(ev_p++, s, s2));
     if (f8.mode) {
       // dqkv is attention's output: its column sums (qkv.bias) and its e5m2 copy (operand of the dh1 GEMM) come from ONE pass over it
@@ -716,20 +732,20 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
     } else if (one_stream && qkvb_pass(T, 3 * D, w.csws_bytes)) {
       // qkv.bias = column sums of dqkv (attention's output: no producing GEMM epilogue to ride on) as one pass over it, so that the dh1 GEMM is the plain
       // one-wave-per-SIMD kernel instead of the eight-wave kernel with the A-tile column-sum by-product (A/B on one box: see DESIGN.md)
-      RC(vdk_colsum_bf16_deferred(dqkv, 3 * D, T, 3 * D, grads + b.qkv_b, base + w.csws + (size_t)3 * w.csws_bytes, w.csws_bytes, s, &jobs[nj], nullptr)); ++nj;
-      RC(gemm(s, dqkv, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // dh1
+      RC(vdk_colsum_bf16_deferred(dqkv, 3 * D, T, 3 * D, grads + b.qkv_b, base + w.csws + (size_t)3 * w.csws_bytes, w.csws_bytes, s, &jobs[nj], nullptr, t_opf)); ++nj;
+      RC(gemm(s, dqkv, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, DT16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // dh1
       RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, nullptr, 0));
     } else if (one_stream) {
       RC(dgrad_with_bias(s, w, base, dqkv, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, VDK_ACT_NONE, nullptr, 0, grads + b.qkv_b, &fz, 3, jobs, &nj));   // dh1
       RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, fz ? nullptr : grads + b.qkv_b, 0));
     } else {
       RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, grads + b.qkv_b, 0));
-      RC(gemm(s, dqkv, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));  // dh1
+      RC(gemm(s, dqkv, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, DT16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));  // dh1
     }
     const bool ocs_n1 = ocs_ln && l > 0;      // DXAB(l - 1) is dY of block l-1's fc2 (for l == 0 it feeds the patch embedding, whose bias comes from d pos_embed)
     const bool lq1 = lq && ocs_n1;
     const LnQ8 q8a = {f8.a8, (long)D, f8.sc + 12 * (l - 1) + 8, f8.amax + 12 * (l - 1) + 8, 1};
-    RC(vdk_layernorm_bwd_deferred(dsm, D, VDK_BF16, xin, D, mean1, rstd1, params + b.n1w, dxm, D, T, D, dxa, D, DXAB(l - 1), D, grads + b.n1w, grads + b.n1b, lnws1,
+    RC(vdk_layernorm_bwd_deferred(dsm, D, DT16, xin, D, mean1, rstd1, params + b.n1w, dxm, D, T, D, dxa, D, DXAB(l - 1), D, grads + b.n1w, grads + b.n1b, lnws1,
                                   w.lnws_bytes, s, &jobs[nj], ocs_n1 ? grads + p.blk[l - 1].fc2_b : nullptr, ocs_n1 ? &jobs[nj + 1] : nullptr, lq1 ? &q8a : nullptr));
     dxab8_ready = lq1;
     nj += ocs_n1 ? 2 : 1;

@@ -18,14 +18,25 @@ def _be(backend):
     return backend or _lib.load()
 
 
-def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=torch.bfloat16, bias: Optional[torch.Tensor] = None,
+_H16 = (torch.bfloat16, torch.float16)      # the two 16-bit operand formats of the GEMM path (VdkGemmDesc.ab_dtype / VdkVitConfig.operand)
+
+
+def _dt(dtype) -> int:
+    """torch dtype -> the ABI's dtype code"""
+    return {torch.bfloat16: _abi.BF16, torch.float16: _abi.F16_, torch.float32: _abi.F32_}[dtype]
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=None, bias: Optional[torch.Tensor] = None,
             residual: Optional[torch.Tensor] = None, act: int = ACT_NONE, aux: Optional[torch.Tensor] = None,
             alpha: float = 1.0, splitk: int = 1, out: Optional[torch.Tensor] = None, row_group: int = 0,
             trans: bool = False, a_row_group: int = 0, a_rows: Optional[int] = None, a_colsum: Optional[torch.Tensor] = None,
             streamk_ws: Optional[torch.Tensor] = None, c_colsum: Optional[torch.Tensor] = None, backend=None) -> torch.Tensor:
-    """out[M,N] = epilogue(alpha * a[M,K] @ b[N,K].T); a, b bf16 (row stride may exceed K).  streamk_ws: persistent workspace from streamk_workspace() -> stream-K allowed"""
+    """out[M,N] = epilogue(alpha * a[M,K] @ b[N,K].T); a, b bf16 or (both) fp16 (row stride may exceed K); out_dtype: fp32 or the operands' format (the default).
+    streamk_ws: persistent workspace from streamk_workspace() -> stream-K allowed"""
     be = _be(backend)
-    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
+    assert a.dtype in _H16 and b.dtype == a.dtype and a.dim() == 2 and b.dim() == 2
+    out_dtype = a.dtype if out_dtype is None else out_dtype
+    assert out_dtype in (torch.float32, a.dtype) and (aux is None or aux.dtype in _H16)
     assert a.stride(1) == 1 and b.stride(1) == 1 and (trans or a.shape[1] == b.shape[1])
     if trans:   # a: [K(+), M], b: [K(+), N]
         K, M = (a_rows if a_rows is not None else a.shape[0]), a.shape[1]
@@ -40,7 +51,8 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=torch.bfloat16, bias:
     d.B, d.ldb = b.data_ptr(), b.stride(0)
     d.C, d.ldc = out.data_ptr(), out.stride(0)
     d.M, d.N, d.K = M, N, K
-    d.c_dtype = _abi.F32_ if out.dtype == torch.float32 else _abi.BF16
+    d.c_dtype = _dt(out.dtype)
+    d.ab_dtype = _dt(a.dtype)
     d.bias = be.ptr(bias) if bias is not None else None
     d.residual = residual.data_ptr() if residual is not None else None
     d.ldr = residual.stride(0) if residual is not None else 0
@@ -167,9 +179,10 @@ def attention_fwd(qkv: torch.Tensor, heads: int, scale: Optional[float] = None, 
     D = three_d // 3
     hd = D // heads
     scale = hd ** -0.5 if scale is None else scale
-    o = torch.empty((B, N, D), dtype=torch.bfloat16, device=qkv.device)
+    assert qkv.dtype in _H16
+    o = torch.empty((B, N, D), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
-    be.check(be.lib.vdk_attention_fwd(be.ptr(qkv), three_d, be.ptr(o), D, be.ptr(lse), B, N, heads, hd, scale, be.stream()),
+    be.check(be.lib.vdk_attention_fwd_dt(be.ptr(qkv), three_d, be.ptr(o), D, be.ptr(lse), B, N, heads, hd, scale, _dt(qkv.dtype), be.stream()),
              "vdk_attention_fwd")
     return o, lse
 
@@ -183,8 +196,9 @@ def attention_bwd(qkv, o, dout, lse, heads: int, scale: Optional[float] = None, 
     dqkv = torch.empty_like(qkv)
     dvec = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
     dout = dout.contiguous()      # keep the (possibly new) tensor alive across the launch: a temporary would be freed before the kernel is enqueued
-    be.check(be.lib.vdk_attention_bwd(be.ptr(qkv), three_d, be.ptr(o), be.ptr(dout), D, be.ptr(lse), be.ptr(dqkv),
-                                      three_d, be.ptr(dvec), B, N, heads, hd, scale, be.stream()), "vdk_attention_bwd")
+    assert qkv.dtype in _H16 and o.dtype == qkv.dtype and dout.dtype == qkv.dtype
+    be.check(be.lib.vdk_attention_bwd_dt(be.ptr(qkv), three_d, be.ptr(o), be.ptr(dout), D, be.ptr(lse), be.ptr(dqkv),
+                                         three_d, be.ptr(dvec), B, N, heads, hd, scale, _dt(qkv.dtype), be.stream()), "vdk_attention_bwd")
     return dqkv
 
 
@@ -199,7 +213,7 @@ def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float = 1e-6, out_dtype=tor
     mean = torch.empty(T, dtype=torch.float32, device=x.device)
     rstd = torch.empty(T, dtype=torch.float32, device=x.device)
     be.check(be.lib.vdk_layernorm_fwd(be.ptr(x), ldx, T, C_, be.ptr(gamma), be.ptr(beta), eps, be.ptr(y), C_,
-                                      _abi.BF16 if out_dtype == torch.bfloat16 else _abi.F32_, be.ptr(mean), be.ptr(rstd),
+                                      _dt(out_dtype), be.ptr(mean), be.ptr(rstd),
                                       be.stream()), "vdk_layernorm_fwd")
     return y, mean, rstd
 
@@ -219,16 +233,16 @@ def layernorm_fwd_q8(x: torch.Tensor, gamma, beta, scale: Optional[torch.Tensor]
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, want_bf16=True, backend=None):
-    """-> (dx f32 [T,C], dx bf16 or None, dgamma, dbeta)"""
+    """-> (dx f32 [T,C], dx in dy's 16-bit format (bf16 for an fp32 dy) or None, dgamma, dbeta)"""
     be = _be(backend)
     C_ = gamma.numel()
     T = mean.numel()
     dx = torch.empty((T, C_), dtype=torch.float32, device=x.device)
-    dxb = torch.empty((T, C_), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    dxb = torch.empty((T, C_), dtype=dy.dtype if dy.dtype in _H16 else torch.bfloat16, device=x.device) if want_bf16 else None
     dg = torch.empty(C_, dtype=torch.float32, device=x.device)
     db = torch.empty(C_, dtype=torch.float32, device=x.device)
     ws, n = _ws(be, be.lib.vdk_layernorm_bwd_workspace_bytes, T, C_, device=x.device)
-    be.check(be.lib.vdk_layernorm_bwd(be.ptr(dy), C_, _abi.BF16 if dy.dtype == torch.bfloat16 else _abi.F32_, be.ptr(x), C_,
+    be.check(be.lib.vdk_layernorm_bwd(be.ptr(dy), C_, _dt(dy.dtype), be.ptr(x), C_,
                                       be.ptr(mean), be.ptr(rstd), be.ptr(gamma), be.ptr(dres), C_, T, C_, be.ptr(dx), C_,
                                       be.ptr(dxb), C_, be.ptr(dg), be.ptr(db), be.ptr(ws), n, be.stream()), "vdk_layernorm_bwd")
     return dx, dxb, dg, db
@@ -252,16 +266,16 @@ def colsum_bf16(x: torch.Tensor, backend=None) -> torch.Tensor:
 
 
 def softmax_ce(logits, ya, yb=None, lam: float = 1.0, label_smoothing: float = 0.0, grad_scale: float = 1.0,
-               pad_to: Optional[int] = None, backend=None):
-    """-> (loss_rows f32 [B], dlogits bf16 [B, pad_to], dlogits f32 [B, C])"""
+               pad_to: Optional[int] = None, backend=None, dl_dtype=torch.bfloat16, loss_scale: Optional[torch.Tensor] = None):
+    """-> (loss_rows f32 [B], dlogits (dl_dtype: bf16 | fp16) [B, pad_to], dlogits f32 [B, C]); loss_scale: f32 device scalar multiplied into both gradients (GradScaler)"""
     be = _be(backend)
     B, C_ = logits.shape
     pad_to = pad_to or (C_ + 7) // 8 * 8
     loss = torch.empty(B, dtype=torch.float32, device=logits.device)
-    dlb = torch.empty((B, pad_to), dtype=torch.bfloat16, device=logits.device)
+    dlb = torch.empty((B, pad_to), dtype=dl_dtype, device=logits.device)
     dlf = torch.empty((B, C_), dtype=torch.float32, device=logits.device)
-    be.check(be.lib.vdk_softmax_ce(be.ptr(logits), C_, B, C_, be.ptr(ya), be.ptr(yb), lam, label_smoothing, grad_scale,
-                                   be.ptr(loss), be.ptr(dlb), pad_to, be.ptr(dlf), C_, be.stream()), "vdk_softmax_ce")
+    be.check(be.lib.vdk_softmax_ce_amp(be.ptr(logits), C_, B, C_, be.ptr(ya), be.ptr(yb), lam, label_smoothing, grad_scale, be.ptr(loss_scale),
+                                       be.ptr(loss), be.ptr(dlb), pad_to, _dt(dl_dtype), be.ptr(dlf), C_, be.stream()), "vdk_softmax_ce")
     return loss, dlb, dlf
 
 

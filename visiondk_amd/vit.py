@@ -63,12 +63,19 @@ def spec_from_timm_name(name: str, num_classes: int, img_size: Optional[int] = N
     return VitSpec(num_classes=num_classes, **kw)
 
 
+OPERANDS = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+
 class VitEngine:
-    def __init__(self, spec: VitSpec, device=None, backend: Optional[_lib.Backend] = None):
+    def __init__(self, spec: VitSpec, device=None, backend: Optional[_lib.Backend] = None, operand: str = "bf16"):
         self.spec = spec
         self.be = backend or _lib.load()
         self.device = torch.device(device if device is not None else ("cuda" if self.be.device_only else "cpu"))
-        self.fp8 = 0                     # 0 = bf16 operands; see enable_fp8
+        # 16-bit format of the GEMM operands / saved activations / gradient tensors: "bf16" (BASELINE.json configs[1]) or "fp16" -- what the reference's
+        # `torch.autocast(device_type=...)` (engine/procedure/train.py:118, no dtype => float16 on a GPU) computes in; see set_operand()
+        assert operand in OPERANDS, operand
+        self.operand = operand
+        self.fp8 = 0                     # 0 = 16-bit operands; see enable_fp8
         self.fp8_w: Optional[torch.Tensor] = None
         self.fp8_state: Optional[torch.Tensor] = None
         cfg = self._cfg(1)
@@ -86,8 +93,8 @@ class VitEngine:
         dev = self.device
         self.params = torch.zeros(self.n_floats, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(self.n_floats, dtype=torch.float32, device=dev)
-        self.wb16 = torch.zeros(self.n_floats, dtype=torch.bfloat16, device=dev)
-        self.wt16 = torch.zeros(self.n_transposed, dtype=torch.bfloat16, device=dev)
+        self.wb16 = torch.zeros(self.n_floats, dtype=self.op_dtype, device=dev)
+        self.wt16 = torch.zeros(self.n_transposed, dtype=self.op_dtype, device=dev)
         self.cp = (spec.num_classes + 7) // 8 * 8          # 0 in feature mode (num_classes == 0)
         self.tokens = (spec.img_size // spec.patch_size) ** 2 + (1 if spec.class_token else 0)
         self._ws: Optional[torch.Tensor] = None
@@ -113,10 +120,27 @@ class VitEngine:
         return new
 
     # ---- plumbing ------------------------------------------------------------------------------
+    @property
+    def op_dtype(self) -> torch.dtype:
+        return OPERANDS[self.operand]
+
+    def set_operand(self, operand: str) -> None:
+        """switch the engine between bf16 and fp16 operands (weights stay the fp32 master copy; the 16-bit copies are rebuilt on the next forward)"""
+        assert operand in OPERANDS, operand
+        if operand == self.operand:
+            return
+        if operand == "fp16" and self.fp8:
+            raise RuntimeError("the fp8 mode goes with bf16 operands")
+        self.operand = operand
+        self.wb16 = torch.zeros(self.n_floats, dtype=self.op_dtype, device=self.device)
+        self.wt16 = torch.zeros(self.n_transposed, dtype=self.op_dtype, device=self.device)
+        self._weights_version = None
+
     def _cfg(self, batch: int) -> _abi.VitConfig:
         s = self.spec
         return _abi.VitConfig(batch, s.img_size, s.patch_size, s.in_chans, s.dim, s.depth, s.heads, s.mlp_dim, s.num_classes, s.ln_eps, 0 if s.class_token else 1,
-                              self.fp8, self.be.ptr(self.fp8_w) if self.fp8 else None, self.be.ptr(self.fp8_state) if self.fp8 else None)
+                              self.fp8, self.be.ptr(self.fp8_w) if self.fp8 else None, self.be.ptr(self.fp8_state) if self.fp8 else None,
+                              _abi.F16_ if self.operand == "fp16" else _abi.BF16)
 
     def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
         for n, off, numel, shape in self.entries:
@@ -151,6 +175,8 @@ class VitEngine:
         scaling; mode 1 = delayed scaling (this step's scale from the last step's amax), 2 = current scaling (an amax pass per tensor: calibration), 0 = off.
         Weight gradients, attention, LayerNorm, the embeddings and the head stay as they are.  Call fp8_update() after every backward."""
         assert mode in (0, 1, 2)
+        if mode and self.operand != "bf16":
+            raise RuntimeError("the fp8 mode goes with bf16 operands")
         if mode and self.fp8_w is None:
             L = self.spec.depth
             self.fp8_w = torch.zeros(self.n_floats + self.n_transposed, dtype=torch.uint8, device=self.device)
@@ -207,11 +233,11 @@ class VitEngine:
         return out
 
     def backward(self, dlogits_bf16: torch.Tensor, on_ready: Optional[Callable[[int, int], None]] = None) -> torch.Tensor:
-        """dlogits bf16 [B, Cp] (feature mode: d tokens f32 [B*N, D]) -> self.grads (flat fp32, overwritten).  Needs the
+        """dlogits [B, Cp] in the operand format (feature mode: d tokens f32 [B*N, D]) -> self.grads (flat fp32, overwritten).  Needs the
         workspace of the matching forward."""
         if self.cp:
             B = dlogits_bf16.shape[0]
-            assert dlogits_bf16.dtype == torch.bfloat16 and dlogits_bf16.shape[1] == self.cp and B == self._ws_batch
+            assert dlogits_bf16.dtype == self.op_dtype and dlogits_bf16.shape[1] == self.cp and B == self._ws_batch
         else:
             B = dlogits_bf16.shape[0] // self.tokens
             assert dlogits_bf16.dtype == torch.float32 and dlogits_bf16.shape == (B * self.tokens, self.spec.dim) and B == self._ws_batch
@@ -253,8 +279,10 @@ class _VitFunction(torch.autograd.Function):
         # bf16 + zero-padded columns for the head GEMMs: one cast kernel on a padded staging buffer
         stage = torch.zeros((B, eng.cp), dtype=torch.float32, device=dlogits.device)
         stage[:, :Cn].copy_(dlogits)
-        dl = torch.empty((B, eng.cp), dtype=torch.bfloat16, device=dlogits.device)
-        be.check(be.lib.vdk_cast_f32_bf16(be.ptr(stage), be.ptr(dl), stage.numel(), be.stream()), "vdk_cast_f32_bf16")
+        # (fp16 operands: under the reference's GradScaler the incoming gradient already carries the loss scale, train.py:205)
+        dl = torch.empty((B, eng.cp), dtype=eng.op_dtype, device=dlogits.device)
+        cast = be.lib.vdk_cast_f32_f16 if eng.operand == "fp16" else be.lib.vdk_cast_f32_bf16
+        be.check(cast(be.ptr(stage), be.ptr(dl), stage.numel(), be.stream()), "vdk_cast_f32_bf16")
         g = eng.backward(dl)
         grads = tuple(g[off:off + numel].view(shape) for (_, off, numel, shape) in eng.entries)
         return (None, None) + grads
@@ -271,10 +299,10 @@ class VisionTransformer(nn.Module):
     parameter-only holder modules, so named_parameters()/state_dict()/load_state_dict() carry timm's key names at any nesting
     depth; every Parameter is a view into the engine's flat fp32 buffer."""
 
-    def __init__(self, spec: VitSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None):
+    def __init__(self, spec: VitSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None, operand: str = "bf16"):
         super().__init__()
         self.spec = spec
-        self.engine = VitEngine(spec, device=device, backend=backend)
+        self.engine = VitEngine(spec, device=device, backend=backend, operand=operand)
         self.num_classes = spec.num_classes
         self._plist = []
         for name, off, numel, shape in self.engine.entries:
@@ -337,7 +365,7 @@ class VisionTransformer(nn.Module):
                 raise RuntimeError("visiondk_amd ViT lives on the GPU (no CPU fallback)")
             eng = self.engine
             eng.device = probe.device
-            for attr in ("params", "grads", "wb16", "wt16"):
+            for attr in ("params", "grads", "wb16", "wt16"):      # (.to keeps each buffer's dtype: fp32 masters, 16-bit operand copies)
                 setattr(eng, attr, getattr(eng, attr).to(probe.device))
             eng._ws, eng._ws_batch, eng._weights_version = None, -1, None
             for (name, off, numel, shape), (_, p) in zip(eng.entries, self._plist):
@@ -533,7 +561,7 @@ class VisionTransformerMap(nn.Module):
 
 
 def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, device=None, backend=None, img_size=None,
-                 global_pool: str = "token", **kwargs) -> VisionTransformer:
+                 global_pool: str = "token", operand: str = "bf16", **kwargs) -> VisionTransformer:
     """`timm.create_model(name, pretrained=..., num_classes=...)` for the ids in TIMM_VITS.  `num_classes=0, global_pool=''`
     (what TimmWrapper asks for, timm_wrapper.py:16-21) gives the feature model: forward -> final-normed tokens [B, N, D]."""
     if pretrained:
@@ -541,13 +569,15 @@ def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, d
     spec = spec_from_timm_name(name, num_classes, img_size)
     if not spec.class_token:      # the SigLIP family: attention-pool head (timm's default global_pool for these ids is 'map'); global_pool='' -> token features
         if global_pool == "":
-            return VisionTransformer(dataclasses.replace(spec, num_classes=0), device=device, backend=backend)
+            return VisionTransformer(dataclasses.replace(spec, num_classes=0), device=device, backend=backend, operand=operand)
         if global_pool not in ("map", "token"):      # ("token" is this function's default argument, i.e. "not given": timm then uses the id's own default, 'map')
             raise NotImplementedError(f"global_pool={global_pool!r} is not built for the SigLIP ids (only 'map' and '')")
+        if operand != "bf16":
+            raise NotImplementedError("the attention-pool head (global_pool='map') runs on bf16 operands")
         return VisionTransformerMap(spec, device=device, backend=backend)
     if num_classes == 0 and global_pool != "":
         raise NotImplementedError("num_classes=0 is supported with global_pool='' (token features) only")
-    return VisionTransformer(spec, device=device, backend=backend)
+    return VisionTransformer(spec, device=device, backend=backend, operand=operand)
 
 
 # =====================================================================================================
@@ -557,11 +587,16 @@ class FusedTrainStep:
     loss = CE(label_smoothing) [mixup: lam*CE(ya) + (1-lam)*CE(yb)]  ->  backward  ->  [all-reduce(mean) of the flat
     gradient in buckets, overlapped with the rest of backward]  ->  clip_grad_norm_(max_norm)  ->  SGD(momentum,
     weight_decay)  ->  ModelEMA.update  ->  bf16 weight refresh.   (train.py:196,203-215; optimizer.py:119-121; ema.py:28-37)
+
+    fp16 operands (`model.engine.operand == "fp16"`, the reference's autocast dtype): the step also does what the reference's GradScaler does around it
+    (vision_engine.py:232, train.py:205-211) -- the loss gradient is multiplied by a loss scale that lives on the device (`loss_state` = [scale, growth tracker, skipped
+    steps], torch's defaults: 65536, x2 every 2000 clean steps, x0.5 on overflow), the optimizer pass un-scales, and a step whose gradient holds an inf / NaN is skipped.
+    No host synchronisation anywhere: `loss_scale()` / `skipped_steps()` read the state back when asked.
     """
 
     def __init__(self, model: VisionTransformer, lr: float, momentum: float = 0.937, weight_decay: float = 5e-4,
                  label_smoothing: float = 0.0, max_norm: float = 10.0, ema: bool = True, comm=None, sam: bool = False,
-                 sam_rho: float = 0.05, sam_adaptive: bool = True):
+                 sam_rho: float = 0.05, sam_adaptive: bool = True, init_scale: float = 65536.0):
         self.model = model
         self.eng = model.engine
         self.be = self.eng.be
@@ -581,6 +616,12 @@ class FusedTrainStep:
         self._sumsq_ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
         self._loss_rows: Optional[torch.Tensor] = None
         self._dl: Optional[torch.Tensor] = None
+        # GradScaler state on the device (fp16 operands only): scale, growth tracker, skipped-step count
+        self.amp = self.eng.operand == "fp16"
+        self.growth_factor, self.backoff_factor, self.growth_interval = 2.0, 0.5, 2000
+        self.loss_state = torch.tensor([init_scale, 0.0, 0.0], dtype=torch.float32, device=dev) if self.amp else None
+        if self.amp and sam:
+            raise NotImplementedError("update_sam calls loss.backward() without the scaler (train.py:157-170): the SAM step runs on bf16 operands")
         # Trainer reads param_groups[0]['lr'] and WRITES 'momentum' after the warm-up (vision_engine.py:169-171,350-352): every step reads all three from here
         self.param_groups = [{"lr": lr, "momentum": momentum, "weight_decay": weight_decay}]
         if comm is not None and comm.active:          # DDP-constructor semantics: every rank starts from rank 0's weights
@@ -594,10 +635,10 @@ class FusedTrainStep:
         logits = eng.forward(x)
         if self._loss_rows is None or self._loss_rows.shape[0] != B:
             self._loss_rows = torch.empty(B, dtype=torch.float32, device=eng.device)
-            self._dl = torch.empty((B, eng.cp), dtype=torch.bfloat16, device=eng.device)
-        be.check(be.lib.vdk_softmax_ce(be.ptr(logits), eng.cp, B, eng.spec.num_classes, be.ptr(y), be.ptr(y_b), lam,
-                                       self.label_smoothing, 1.0 / B, be.ptr(self._loss_rows), be.ptr(self._dl), eng.cp, None, 0,
-                                       be.stream()), "vdk_softmax_ce")
+            self._dl = torch.empty((B, eng.cp), dtype=eng.op_dtype, device=eng.device)
+        be.check(be.lib.vdk_softmax_ce_amp(be.ptr(logits), eng.cp, B, eng.spec.num_classes, be.ptr(y), be.ptr(y_b), lam,
+                                           self.label_smoothing, 1.0 / B, be.ptr(self.loss_state), be.ptr(self._loss_rows), be.ptr(self._dl), eng.cp,
+                                           _abi.F16_ if self.amp else _abi.BF16, None, 0, be.stream()), "vdk_softmax_ce")
         if self.comm is not None and sync:
             self.comm.begin_step(eng.grads)
             eng.backward(self._dl, on_ready=self.comm.on_grad_ready)
@@ -647,11 +688,26 @@ class FusedTrainStep:
         self._fwd_loss_bwd(x, y, y_b, lam, sync=True)
         be.check(be.lib.vdk_sumsq_f32(be.ptr(eng.grads), eng.n_floats, be.ptr(self._normsq), be.ptr(self._sumsq_ws),
                                       self._sumsq_ws.numel(), be.stream()), "vdk_sumsq_f32")
-        be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema),
-                                     be.ptr(eng.wb16), eng.n_floats, lr, momentum, weight_decay, 1.0 / world,
-                                     be.ptr(self._normsq), self.max_norm, d, int(self.updates == 1), be.stream()), "vdk_sgd_step")
+        if self.amp:
+            be.check(be.lib.vdk_sgd_step_amp(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema), be.ptr(eng.wb16), _abi.F16_,
+                                             eng.n_floats, lr, momentum, weight_decay, 1.0 / world, be.ptr(self.loss_state), be.ptr(self._normsq), self.max_norm, d,
+                                             int(self.updates == 1), be.stream()), "vdk_sgd_step_amp")
+            be.check(be.lib.vdk_loss_scale_update(be.ptr(self.loss_state), be.ptr(self._normsq), self.growth_factor, self.backoff_factor, self.growth_interval,
+                                                  be.stream()), "vdk_loss_scale_update")
+        else:
+            be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema),
+                                         be.ptr(eng.wb16), eng.n_floats, lr, momentum, weight_decay, 1.0 / world,
+                                         be.ptr(self._normsq), self.max_norm, d, int(self.updates == 1), be.stream()), "vdk_sgd_step")
         eng.refresh_weights(skip_wb16=True)
         return self._loss_rows
+
+    def loss_scale(self) -> float:
+        """GradScaler.get_scale(): the current loss scale (a device->host read; 1.0 on bf16 operands)"""
+        return float(self.loss_state[0].item()) if self.amp else 1.0
+
+    def skipped_steps(self) -> int:
+        """steps whose scaled gradient overflowed and were skipped (GradScaler's found_inf path)"""
+        return int(self.loss_state[2].item()) if self.amp else 0
 
     def loss_value(self) -> float:
         """mean loss of the last step (this is the only device->host sync; the reference does it every step, train.py:122)."""
