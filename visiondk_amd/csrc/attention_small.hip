@@ -776,6 +776,191 @@ __global__ __launch_bounds__(512) void attn_s_bwd1p_kernel(const bf16_t* __restr
   }
 }
 
+// =====================================================================================  backward (one pass, dS exchanged between the waves)  [form 5]
+// The one-pass structure of form 4 (wave = key tile, query tiles in the outer loop: S, dP, P, dS once; dV^T / dK^T in registers, bit for bit the kv kernel's arithmetic)
+// with a different answer to "dQ_j contracts over the key, i.e. over waves".  Form 4 let every key wave form a PARTIAL dQ_j tile (8 KB fp32) and a reducer wave add the
+// seven up: 112 KB of LDS traffic and ~1.5 k serial cycles per query tile.  Here the waves exchange dS itself -- 2 KB of 16-bit values per wave and tile, [key][query] rows in
+// a double-buffered 2 x 16 KB -- and the dQ_j^T tile (64 x 32) is split by OUTPUT block: wave w owns the 16 x 16 block (d block w >> 1, query block w & 1) and contracts it
+// over ALL keys with seven v_mfma_f32_16x16x32, so nobody sums partials, the result is deterministic, every wave carries the same load, and ONE barrier per query tile is
+// enough (it publishes tile j's dS and the landed Q / dO of tile j + 1; the dS buffer of tile j is rewritten two tiles later, behind the next barrier).
+// MFMA work per pair: 16 x 32x32x16 + 7/8 x 16x16x32 against 28 in the two-kernel form; one exp per score instead of two.
+// One workgroup per CU has nobody to hide a memory round trip behind, so nothing inside the tile loop waits for one: Q_j / dO_j tiles travel TWO tiles ahead through a ring
+// of three buffers (the only vector-memory operations in the loop, so the single s_waitcnt before the barrier is a counted one: "all but the newest request"), and dQ is
+// staged in LDS and leaves once per item as whole 128-byte rows.
+// K^T fragments of the dQ role: re-read from the K tiles (KR = false, the default: 0 bytes of scratch) or held in 28 registers (KR = true: 256 VGPRs + spills, slower).
+// LDS: 24 KB (Q_j, dO_j x 3) + 28 KB (K tiles, later the waves' store tiles) + 2 x 15.75 KB (dS) + 31.5 KB (dQ rows) + lse / D = 117 KB; 8 waves x 256 registers.
+#define A5_PITCH 72                       /* bytes per key row of the dS exchange: 32 queries x 2 B + 8 (the 8-byte writes of 32 key lanes then hit 32 distinct bank pairs) */
+#define A5_QPITCH 144                     /* bytes per query row of the dQ staging: 64 d x 2 B + 16 */
+template <int NKT, int OF, bool KR>
+__global__ __launch_bounds__(512) void attn_s_bwd5_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld,
+                                                          const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, long ldo, const float* __restrict__ lse,
+                                                          bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long ldd, int N, int H, float scale,
+                                                          int nitems, int dbg /* timing experiments only (VDK_ATTN5_DBG): 1 skip the key phase, 2 the dQ phase, 4 D, 8 the stores */) {
+  VDK_DYN_LDS(smem);
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NP = 32 * NKT;
+  constexpr int NPC = (NP * 8 + 511) / 512;
+  constexpr int DSB = NP * A5_PITCH;                                  // one dS buffer
+  unsigned char* const QO = smem;                                     // [buffer 3][Q | dO][32 rows x 128 B]
+  unsigned char* const Kall = smem + 3 * 8192;                        // [NKT][4 KB] K tiles; tile w doubles as wave w's store tile at the end of the item
+  unsigned char* const Kt = Kall + w * 4096;
+  unsigned char* const Ds = Kall + NKT * 4096;                        // [2][NP rows x A5_PITCH] dS [key][query]
+  unsigned char* const DQs = Ds + 2 * DSB;                            // [NP rows x A5_QPITCH] dQ [query][d], 16-bit, already scaled
+  float* const lse2 = (float*)(DQs + NP * A5_QPITCH);
+  float* const Dv = lse2 + NP;
+  constexpr int nt = NKT;                                             // (the launcher instantiates NKT = ceil(N / 32): every tile loop is a compile-time loop)
+  const float scale2 = scale * VDK_LOG2E;
+  const bool ragged = (N & 31) != 0;
+  const AsLane al = as_lane(lane);
+  const bool keyw = w < nt;                                           // (wave-uniform)
+  // dQ role: block (d block db, query block qb) of the 64 x 32 tile dQ_j^T; operand fragments of v_mfma_f32_16x16x32: lane l -> row / column l & 15, k = 8 (l >> 4) + e.
+  // A transposing read hands lane i (of a 16-lane group g) element i & 3 of the 8-byte chunks addressed by lanes (i >> 2) + {0, 4, 8, 12}: source lane a points at key row
+  // 8 g + (a >> 2) (+ 4 for slots 4..7), chunk a & 3 of the block's 16 columns.
+  const int db = w >> 1, qb = w & 1;
+  const int a16 = lane & 15, g4 = lane >> 4;
+  const int trow = 8 * g4 + (a16 >> 2);                               // key row inside a 32-key step
+  const int ds_off = trow * A5_PITCH + qb * 32 + 8 * (a16 & 3);       // dS^T fragment (B): + (32 t) * A5_PITCH, second read + 4 * A5_PITCH
+  int kt_off[2];                                                      // K^T fragment (A) inside a 4 KB K tile (swizzled 16-byte chunks): first / second read
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+    const int r = trow + 4 * h2, byte = 32 * db + 8 * (a16 & 3);
+    kt_off[h2] = r * AS_ROW + (((byte >> 4) ^ as_f(r)) << 4) + (byte & 8);
+  }
+  // one DMA instruction per wave fills a quarter of one operand's 32-row tile: waves 0..3 Q, 4..7 dO
+  auto request_tile = [&](int j, int buf, long off, long offo) {
+    const int q0 = j * 32, part = w & 3;
+    if (w < 4) as_dma_rows(QO + buf * 8192, q + off + (long)q0 * ld, ld, N - q0, 32, part, 4, lane);
+    else as_dma_rows(QO + buf * 8192 + 4096, dout + offo + (long)q0 * ldo, ldo, N - q0, 32, part, 4, lane);
+  };
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / H, h = item - b * H;
+    const long off = (long)b * N * ld + h * 64, offo = (long)b * N * ldo + h * 64;
+    __syncthreads();                                                  // the previous item is finished everywhere (its store tiles = this item's K tiles)
+    request_tile(0, 0, off, offo);
+    if (nt > 1) request_tile(1, 1, off, offo);
+    s16x8 kf[4], vf[4];
+    if (keyw) {
+      as_dma_rows(Kt, k + off + (long)(w * 32) * ld, ld, N - w * 32, 32, 0, 1, lane);
+      const int krow = w * 32 + l31;
+      const long kr = (long)(krow < N ? krow : N - 1) * ld;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { kf[ks] = *(const s16x8*)(k + off + kr + ks * 16 + hi * 8); vf[ks] = *(const s16x8*)(v + off + kr + ks * 16 + hi * 8); }
+    }
+    // D = rowsum(dO * O) on the rounded tensors, straight from global memory: 8 lanes per row (these loads share the prologue's one memory round trip)
+#pragma unroll
+    for (int p = 0; p < NPC; ++p) {
+      const int id = tid + 512 * p, row = id >> 3, cp = id & 7;
+      float d = 0.f;
+      if (row < N && !(dbg & 4)) {
+        const u32x4 a = *(const u32x4*)(dout + offo + (long)row * ldo + cp * 8), c = *(const u32x4*)(o + offo + (long)row * ldo + cp * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { d = fmaf(op_lo<OF>(a[e]), op_lo<OF>(c[e]), d); d = fmaf(op_hi<OF>(a[e]), op_hi<OF>(c[e]), d); }
+      }
+      d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
+      if (row < NP && cp == 0) Dv[row] = row < N ? d : 0.f;
+    }
+    for (int i = tid; i < NP; i += 512) lse2[i] = i < N ? lse[((long)b * H + h) * N + i] * VDK_LOG2E : 0.f;
+    f32x16 gk0 = as_zero16(), gk1 = as_zero16(), gv0 = as_zero16(), gv1 = as_zero16();
+    __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0)
+    __syncthreads();
+    s16x8 ktf[KR ? NKT : 1];
+    if (KR) {
+#pragma unroll
+      for (int t = 0; t < NKT; ++t) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(Kall + t * 4096 + kt_off[0]));
+        const s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(Kall + t * 4096 + kt_off[1]));
+        ktf[t] = (s16x8){lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+      }
+    }
+#pragma unroll 1
+    for (int j = 0; j < nt; ++j) {
+      const int q0 = j * 32, buf = j % 3, dbuf = j & 1;
+      const unsigned char* Qs = QO + buf * 8192;
+      const unsigned char* Os = Qs + 4096;
+      unsigned char* const Dsj = Ds + dbuf * DSB;
+      if (j + 2 < nt) request_tile(j + 2, (j + 2) % 3, off, offo);    // (that buffer held tile j - 1: its readers passed the barrier that closed tile j - 1)
+      if (keyw && !(dbg & 1)) {
+        f32x16 st = as_zero16(), dp = as_zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          st = vdk_mfma32<OF>(as_row_frag_l(Qs, al, ks), kf[ks], st);   // S[q][key]: lane = key, registers = queries
+          dp = vdk_mfma32<OF>(as_row_frag_l(Os, al, ks), vf[ks], dp);   // dP[q][key]
+        }
+        f32x16 pv, ds;
+        const bool edge = ragged && j == nt - 1;                      // rows of the last query tile beyond N (the DMA filled them with row N - 1): silenced
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 lv = *(const f32x4*)(lse2 + q0 + 8 * g + 4 * hi);
+          const f32x4 dd = *(const f32x4*)(Dv + q0 + 8 * g + 4 * hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            float p = fast_exp2(fmaf(st[r], scale2, -lv[e]));
+            if (edge && q0 + 8 * g + 4 * hi + e >= N) p = 0.f;
+            pv[r] = p;
+            ds[r] = p * (dp[r] - dd[e]);
+          }
+        }
+        s16x8 pf[2], df[2];
+        as_pack_b<OF>(pv, pf);
+        as_pack_b<OF>(ds, df);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          gv0 = vdk_mfma32<OF>(as_tr_frag_l(Os + 16 * s2 * AS_ROW, al, 0), pf[s2], gv0);     // dV^T[d][key] += dO^T P
+          gv1 = vdk_mfma32<OF>(as_tr_frag_l(Os + 16 * s2 * AS_ROW, al, 1), pf[s2], gv1);
+          gk0 = vdk_mfma32<OF>(as_tr_frag_l(Qs + 16 * s2 * AS_ROW, al, 0), df[s2], gk0);     // dK^T[d][key] += Q^T dS
+          gk1 = vdk_mfma32<OF>(as_tr_frag_l(Qs + 16 * s2 * AS_ROW, al, 1), df[s2], gk1);
+        }
+        // dS [q][key] (lane = key, registers = queries) -> the exchange buffer as [key][q] rows.  Lanes of keys beyond N hold dS of a duplicated key row: zero.
+        const bool kval = w * 32 + l31 < N;
+        unsigned char* const drow = Dsj + (w * 32 + l31) * A5_PITCH + 8 * hi;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          u32x4 u = *(const u32x4*)&df[s2];
+          if (!kval) u = (u32x4){0u, 0u, 0u, 0u};
+          *(u32x2*)(drow + 32 * s2) = (u32x2){u[0], u[1]};           // queries 16 s2 + 4 hi + 0..3
+          *(u32x2*)(drow + 32 * s2 + 16) = (u32x2){u[2], u[3]};      // queries 16 s2 + 8 + 4 hi + 0..3
+        }
+      }
+      // tile j + 1 (requested one tile ago) must have landed before the barrier publishes it; tile j + 2's request -- this wave's newest, one instruction -- may still travel
+      if (j + 2 < nt) __builtin_amdgcn_s_waitcnt(0x0F71); else __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(1) | vmcnt(0)
+      __syncthreads();                                                // tile j's dS complete, tile j + 1's operands in place
+      // dQ_j^T block (16 d x 16 q) = sum over the key steps of K^T[16 d x 32 keys] . dS^T[32 keys x 16 q]
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (!(dbg & 2))
+#pragma unroll
+      for (int t = 0; t < NKT; ++t) {
+        const unsigned char* bp = Dsj + t * 32 * A5_PITCH + ds_off;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(bp));
+        const s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(bp + 4 * A5_PITCH));
+        const s16x8 bfrag = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+        if (KR) {
+          acc = vdk_mfma16<OF>(ktf[t], bfrag, acc);
+        } else {
+          const s16x4 klo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(Kall + t * 4096 + kt_off[0]));
+          const s16x4 kup = __builtin_amdgcn_ds_read_tr16_b64_v4i16(VDK_LDS_S16X4(Kall + t * 4096 + kt_off[1]));
+          acc = vdk_mfma16<OF>((s16x8){klo[0], klo[1], klo[2], klo[3], kup[0], kup[1], kup[2], kup[3]}, bfrag, acc);
+        }
+      }
+      // C layout: lane -> query column l & 15, rows d = 4 (l >> 4) + 0..3: four consecutive d of one query row = 8 bytes of its staged row
+      *(u32x2*)(DQs + (q0 + 16 * qb + a16) * A5_QPITCH + 32 * db + 8 * g4) = (u32x2){pack_op2<OF>(acc[0] * scale, acc[1] * scale), pack_op2<OF>(acc[2] * scale, acc[3] * scale)};
+    }
+    __syncthreads();                                                  // every dQ block is staged; the last tile's dQ phase is done with the K tiles
+    if (dbg & 8) continue;
+    if (keyw) {      // (the K tile is free to stage the stores)
+      as_store_tile<OF>(Kt, gk0, gk1, scale, dk + (long)b * N * ldd + h * 64, ldd, w * 32, N, lane);
+      as_store_tile<OF>(Kt, gv0, gv1, 1.0f, dv + (long)b * N * ldd + h * 64, ldd, w * 32, N, lane);
+    }
+    // dQ rows leave as whole 128-byte rows: 8 threads per row
+#pragma unroll
+    for (int p = 0; p < NPC; ++p) {
+      const int id = tid + 512 * p, row = id >> 3, cp = id & 7;
+      if (row < N) *(u32x4*)(dq + (long)b * N * ldd + h * 64 + (long)row * ldd + cp * 8) = *(const u32x4*)(DQs + row * A5_QPITCH + cp * 16);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------------
 template <int NKT, int OF>
 static int launch_fwd(const bf16_t* base, long D, long ld, bf16_t* o, long ldo, float* lse, int B, int N, int H, float scale, int grid, hipStream_t s) {
@@ -841,7 +1026,28 @@ static int launch_bwd1p(const bf16_t* base, long D, long ld, const bf16_t* o, co
                      N, H, scale, B * H);
   return VDK_OK;
 }
-static int g_bwd_form = -1;        // -1: environment VDK_ATTN_BWD_FORM (default 3); 4 = one pass with the dQ hand-over (not yet measured); 3 = split recompute form (two kernels, 2 workgroups / CU), 2 = one-kernel recompute form, 1 = fused form with the shared dQ tile
+template <int NKT, int OF>
+static int launch_bwd5(const bf16_t* base, long D, long ld, const bf16_t* o, const bf16_t* dout, long ldo, const float* lse, bf16_t* dbase, long ldd, int B, int N, int H,
+                       float scale, int grid, hipStream_t s) {
+  const size_t lds = 3 * 8192 + (size_t)NKT * 4096 + 2 * (size_t)(32 * NKT) * A5_PITCH + (size_t)(32 * NKT) * A5_QPITCH + (size_t)NKT * 32 * 8;
+  const char* edbg = getenv("VDK_ATTN5_DBG");
+  const int dbg = edbg ? atoi(edbg) : 0;
+  const char* ekt = getenv("VDK_ATTN5_KT");      // A/B: VDK_ATTN5_KT=regs keeps the K^T fragments of the dQ role in registers (read per launch; default: re-read from LDS)
+  const bool kregs = ekt && ekt[0] == 'r';
+  if (kregs) {
+    if (hipFuncSetAttribute((const void*)attn_s_bwd5_kernel<NKT, OF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return vdk_fail(VDK_ELAUNCH, "vdk_attention_bwd: LDS attribute");
+    hipLaunchKernelGGL((attn_s_bwd5_kernel<NKT, OF, true>), dim3((unsigned)grid), dim3(512), lds, s, base, base + D, base + 2 * D, ld, o, dout, ldo, lse, dbase, dbase + D, dbase + 2 * D,
+                       ldd, N, H, scale, B * H, dbg);
+  } else {
+    if (hipFuncSetAttribute((const void*)attn_s_bwd5_kernel<NKT, OF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return vdk_fail(VDK_ELAUNCH, "vdk_attention_bwd: LDS attribute");
+    hipLaunchKernelGGL((attn_s_bwd5_kernel<NKT, OF, false>), dim3((unsigned)grid), dim3(512), lds, s, base, base + D, base + 2 * D, ld, o, dout, ldo, lse, dbase, dbase + D, dbase + 2 * D,
+                       ldd, N, H, scale, B * H, dbg);
+  }
+  return VDK_OK;
+}
+static int g_bwd_form = -1;        // -1: environment VDK_ATTN_BWD_FORM (default 5); 5 = one pass, dS exchanged between the waves, dQ split by output block; 4 = one pass with partial dQ tiles + a reducer wave (slower); 3 = split recompute form (two kernels, 2 workgroups / CU); 2 = one-kernel recompute form; 1 = fused form with the shared dQ tile
 int vdk_attention_small_bwd_form(int form) { g_bwd_form = form; return VDK_OK; }
 
 static int grid_cap(int dflt);
@@ -880,8 +1086,16 @@ int vdk_attention_small_bwd(const void* qkv, int64_t ld, const void* o, const vo
   if (grid > cap) grid = cap;
   hipStream_t s = (hipStream_t)stream;
   int form = g_bwd_form;
-  if (form < 0) { const char* e = getenv("VDK_ATTN_BWD_FORM"); form = e ? atoi(e) : 3; }
-  if (opf) form = 3;          // fp16 operands: the default two-kernel form (the A/B forms 1 / 2 / 4 are bf16 only)
+  if (form < 0) { const char* e = getenv("VDK_ATTN_BWD_FORM"); form = e ? atoi(e) : 5; }      // default: the one-pass form with the dS exchange (measured 236-254 us against 272-313 us for the two kernels, profiles/r04_attention_ab.json)
+  if (opf && form != 5) form = 3;          // fp16 operands: the two-kernel form or form 5 (the A/B forms 1 / 2 / 4 are bf16 only)
+  if (form == 5) {
+    switch (nkt) {
+#define B5(n) case n: return opf ? launch_bwd5<n, VDK_OPF_F16>(base, D, ld, (const bf16_t*)o, (const bf16_t*)dout, ldo, lse, (bf16_t*)dqkv, ldd, B, N, H, scale, grid, s) \
+                                 : launch_bwd5<n, 0>(base, D, ld, (const bf16_t*)o, (const bf16_t*)dout, ldo, lse, (bf16_t*)dqkv, ldd, B, N, H, scale, grid, s);
+      B5(1) B5(2) B5(3) B5(4) B5(5) B5(6) B5(7)
+#undef B5
+    }
+  }
   if (form == 4) {
     switch (nkt) {
 #define B4(n) case n: return launch_bwd1p<n>(base, D, ld, (const bf16_t*)o, (const bf16_t*)dout, ldo, lse, (bf16_t*)dqkv, ldd, B, N, H, scale, grid, s);

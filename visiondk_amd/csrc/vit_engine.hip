@@ -53,6 +53,15 @@ int vdk_layernorm_fwd_q8(const float*, int64_t, int32_t, int32_t, const float*, 
 // it (an engine call runs to completion on its thread).  DT16 = the dtype code of the 16-bit tensors.
 static thread_local int t_opf = VDK_OPF_BF16;
 #define DT16 (t_opf ? VDK_F16 : VDK_BF16)
+// What the MLP keeps for the backward pass in `u` [T, mlp_dim]: the pre-activation in the operand format (the backward evaluates GELU' of it inside the dfc2 epilogue), or --
+// VDK_VIT_GELU_SAVED_GRAD=1 -- GELU'(pre-activation) evaluated once in the fc1 epilogue from the SAME erf / exp terms as GELU itself and stored as fp16 (the backward's
+// epilogue is then one multiplication).  Measured per layer at ViT-B/16 (profiles/r03_gemm_ab.json): forward 305 -> 332 us, backward 321 -> 282 us.
+static bool gelu_saved_grad() {
+  static const int v = [] { const char* e = getenv("VDK_VIT_GELU_SAVED_GRAD"); return e ? atoi(e) : 0; }();
+  return v != 0;
+}
+#define ACT_FC1 (gelu_saved_grad() ? VDK_ACT_GELU_SAVE_GRAD : VDK_ACT_GELU)
+#define ACT_DFC2 (gelu_saved_grad() ? VDK_ACT_MUL_AUX : VDK_ACT_DGELU)
 
 static inline int64_t up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
@@ -490,7 +499,7 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
     RC(gemm(s, o, D, wb + b.proj_w, D, xmid, D, T, D, D, VDK_F32, params + b.proj_b, xin, D, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
     // x = x + fc2(gelu(fc1(norm2(x))))
     RC(vdk_layernorm_fwd(xmid, D, T, D, params + b.n2w, params + b.n2b, d.eps, h2, D, DT16, mean2, rstd2, s));
-    RC(gemm(s, h2, D, wb + b.fc1_w, D, g, M, T, M, D, DT16, params + b.fc1_b, nullptr, 0, VDK_ACT_GELU, u, M, 1, 0, nullptr, 0));
+    RC(gemm(s, h2, D, wb + b.fc1_w, D, g, M, T, M, D, DT16, params + b.fc1_b, nullptr, 0, ACT_FC1, u, M, 1, 0, nullptr, 0));
     RC(gemm(s, g, M, wb + b.fc2_w, M, xout, D, T, D, M, VDK_F32, params + b.fc2_b, xmid, D, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));
   }
   float* xl = X + (size_t)(2 * d.L) * XS;
@@ -678,7 +687,7 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
       // (dGELU epilogue below), proj.bias with dxmb (norm2 backward below); only qkv.bias still comes from the A tiles of the dh1 GEMM (dqkv is attention's output).
       int fx = 0;
       const bool have_fc2b = (l == d.L - 1) ? last_fc2_bias_done : fc2_bias_from_norm1;
-      RC(dgrad_with_bias(s, w, base, dxab, D, wt + p.blkT[l].fc2, D, du, M, T, M, D, VDK_ACT_DGELU, u, M, have_fc2b ? nullptr : grads + b.fc2_b, &fz, 0, jobs, &nj,
+      RC(dgrad_with_bias(s, w, base, dxab, D, wt + p.blkT[l].fc2, D, du, M, T, M, D, ACT_DFC2, u, M, have_fc2b ? nullptr : grads + b.fc2_b, &fz, 0, jobs, &nj,
                          grads + b.fc1_b, &fx, 1));   // du
       RC(linear_wgrad(s2, d, w, base, dxab, D, g, M, T, d.Tp, D, M, grads + b.fc2_w, (fz || have_fc2b) ? nullptr : grads + b.fc2_b, 0));
       if (fx) {
@@ -690,7 +699,7 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
       RC(linear_wgrad(s2, d, w, base, du, M, h2, D, T, d.Tp, M, D, grads + b.fc1_w, fz ? nullptr : grads + b.fc1_b, 0));
     } else {
       RC(linear_wgrad(s2, d, w, base, dxab, D, g, M, T, d.Tp, D, M, grads + b.fc2_w, grads + b.fc2_b, 0));
-      RC(gemm(s, dxab, D, wt + p.blkT[l].fc2, D, du, M, T, M, D, DT16, nullptr, nullptr, 0, VDK_ACT_DGELU, u, M, 1, 0, nullptr, 0));   // du
+      RC(gemm(s, dxab, D, wt + p.blkT[l].fc2, D, du, M, T, M, D, DT16, nullptr, nullptr, 0, ACT_DFC2, u, M, 1, 0, nullptr, 0));   // du
       RC(ev_order(ev_p++, s, s2));
       RC(linear_wgrad(s2, d, w, base, du, M, h2, D, T, d.Tp, M, D, grads + b.fc1_w, grads + b.fc1_b, 0));
       RC(gemm(s, du, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, DT16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // dh2
