@@ -559,6 +559,27 @@ int vdk_convnext_backward_train_f32(const VdkConvNextConfig* cfg, const float* d
 int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout, const float* params, const void* wb16, const void* wx, void* ws, size_t ws_bytes,
                           float* grads, vdk_grad_ready_fn on_ready, void* user, void* stream);
 
+/* ---- collectives of the multi-GPU paths for a host without a process group of its own: RCCL over xGMI, one process per GPU ------------------------------
+ * Replaces, for a C / C++ host, what the reference gets from torch.distributed: the process group of main.py:39-40 and the gradient all-reduce of the DistributedDataParallel
+ * wrap (engine/vision_engine.py:313,510), plus the query all-gather of the gallery-sharded search.  (The Python host of this repository drives the same exchange through c10d,
+ * visiondk_amd/comm.py.)  librccl is dlopen()ed at first use -- environment VDK_RCCL_LIB names it explicitly -- so single-GPU hosts never load it.
+ *   vdk_comm_unique_id : 128 bytes (ncclUniqueId) created on one rank; the host distributes them to every rank (its own rendezvous).
+ *   vdk_comm_init      : collective over all ranks, on the caller's current device: communicator + a dedicated stream for the collectives.
+ *   vdk_allreduce_bucket : SUM all-reduce of grads[offset, offset + numel) in place, ordered after everything enqueued on launch_stream so far, on the communicator's stream:
+ *                          called from the vdk_grad_ready_fn callback of vdk_vit_backward / vdk_convnext_backward / vdk_resnet_backward it overlaps the rest of the backward.
+ *                          The 1/world factor belongs to the optimizer (vdk_sgd_step's grad_scale).
+ *   vdk_comm_finish    : launch_stream waits on the device for every collective issued since the last finish (call before vdk_sumsq_f32 / vdk_sgd_step).
+ *   vdk_allgather      : recv[r * bytes_per_rank, ...) = rank r's `send` (the sharded search gathers every rank's query embeddings); ordered with launch_stream both ways. */
+typedef struct VdkComm VdkComm;
+int vdk_comm_unique_id(void* id128);
+int vdk_comm_init(const void* id128, int32_t rank, int32_t world, VdkComm** comm);
+int vdk_comm_destroy(VdkComm* comm);
+int vdk_comm_rank(const VdkComm* comm);
+int vdk_comm_world(const VdkComm* comm);
+int vdk_allreduce_bucket(VdkComm* comm, float* grads, int64_t offset, int64_t numel, void* launch_stream);
+int vdk_comm_finish(VdkComm* comm, void* launch_stream);
+int vdk_allgather(VdkComm* comm, const void* send, void* recv, int64_t bytes_per_rank, void* launch_stream);
+
 /* ---- native ResNet engine: timm BasicBlock ResNets (resnet18 / resnet34) over flat buffers ---------------------------------------------
  * Replaces `self.model(images)` + `loss.backward()` for the classifier built by timm.create_model('resnet18', num_classes=C)
  * (models/classifier/classify_model.py:49-54; `timm-resnet18` is the reference's CPU plumbing config).  Semantics restated from timm 0.9.16

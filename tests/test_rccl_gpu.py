@@ -143,3 +143,74 @@ def test_sharded_gallery_search_through_rccl(hip, rccl):
     so, io = ocbir.flat_ip_search(qry.numpy(), gal.numpy(), 100)
     np.testing.assert_array_equal(i.cpu().numpy(), io)
     np.testing.assert_array_equal(s.cpu().numpy().view("uint32"), so.view("uint32"))
+
+
+def test_c_abi_collectives_drive_the_backward_without_c10d(hip):
+    """SURVEY 8(b)'s vdk_comm_init / vdk_allreduce_bucket / vdk_allgather (csrc/comm.hip: RCCL by dlopen, its own stream, event-ordered against the launch stream), the way a
+    C host would use them: the ready-range callback of vdk_vit_backward issues the bucket's all-reduce, vdk_comm_finish joins before the optimizer.  One rank (a one-GPU
+    box): every collective is an identity, so the step must equal the communication-free one bit for bit -- what is proven is that the path executes in stream order."""
+    import ctypes as C
+    from tests.test_vit import SPEC
+    from visiondk_amd import _abi, vit
+    lib = hip.lib
+    uid = (C.c_ubyte * 128)()
+    hip.check(lib.vdk_comm_unique_id(uid), "vdk_comm_unique_id")
+    comm = C.c_void_p()
+    hip.check(lib.vdk_comm_init(uid, 0, 1, C.byref(comm)), "vdk_comm_init")
+    assert lib.vdk_comm_rank(comm) == 0 and lib.vdk_comm_world(comm) == 1
+    try:
+        # all-gather (the sharded search's query exchange)
+        q = torch.randn(40, 128, device="cuda:0"); out = torch.empty_like(q)
+        hip.check(lib.vdk_allgather(comm, q.data_ptr(), out.data_ptr(), q.numel() * 4, hip.stream()), "vdk_allgather")
+        torch.cuda.synchronize()
+        assert torch.equal(q, out)
+        res = []
+        for use_comm in (False, True):
+            model = vit.VisionTransformer(SPEC, device="cuda:0", backend=hip, seed=11)
+            eng = model.engine
+            torch.manual_seed(7)
+            x = torch.randn(8, 3, 32, 32).cuda(); y = torch.randint(0, 10, (8,)).cuda()
+            logits = eng.forward(x)
+            from visiondk_amd import ops
+            _, dl, _ = ops.softmax_ce(logits[:, :10].contiguous(), y, grad_scale=1.0 / 8, pad_to=eng.cp, backend=hip)
+            calls = []
+
+            def on_ready(off, n):
+                calls.append((off, n))
+                hip.check(lib.vdk_allreduce_bucket(comm, eng.grads.data_ptr(), off, n, hip.stream()), "vdk_allreduce_bucket")
+
+            eng.backward(dl, on_ready=on_ready if use_comm else None)
+            if use_comm:
+                hip.check(lib.vdk_comm_finish(comm, hip.stream()), "vdk_comm_finish")
+                assert len(calls) >= 3 and sum(n for _, n in calls) == eng.n_floats      # every slice of the flat gradient went through a collective exactly once
+            g2 = ops.sumsq(eng.grads, backend=hip)
+            torch.cuda.synchronize()
+            res.append((eng.grads.clone(), g2.item()))
+        assert torch.equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    finally:
+        hip.check(lib.vdk_comm_destroy(comm), "vdk_comm_destroy")
+
+
+def test_cu_reserve_is_scoped_to_the_backward_window(hip, rccl):
+    """GradAllReduce holds CUs back from the persistent GEMM grids only while a collective can be in flight: from the step's first bucket to finish_step (round 3 set the
+    reserve process-wide in the constructor).  Outside a step -- forward, optimizer, evaluation, CBIR -- vdk_gemm_reserved_cus() is what it was before."""
+    from tests.test_vit import SPEC
+    from visiondk_amd import comm, vit
+    lib = hip.lib
+    before = lib.vdk_gemm_reserved_cus()
+    c = comm.GradAllReduce(bucket_bytes=100_000, always_communicate=True, reserve_cus=32)
+    assert lib.vdk_gemm_reserved_cus() == before                       # constructing it reserves nothing
+    model = vit.VisionTransformer(SPEC, device="cuda:0", backend=hip, seed=11)
+    step = vit.FusedTrainStep(model, lr=0.01, comm=c)
+    seen = []
+    orig = c._flush
+
+    def spy():
+        orig(); seen.append(lib.vdk_gemm_reserved_cus())
+
+    c._flush = spy
+    x = torch.randn(8, 3, 32, 32).cuda(); y = torch.randint(0, 10, (8,)).cuda()
+    step.step(x, y)
+    torch.cuda.synchronize()
+    assert seen and all(v == max(32, before) for v in seen)             # held while buckets are being issued ...
+    assert lib.vdk_gemm_reserved_cus() == before                        # ... and given back when the step's collectives have been joined

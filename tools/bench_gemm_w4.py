@@ -3,7 +3,10 @@
 
 Interleaved rounds in one process (cdna_hip_programming.md rule 24), random operands (rule 25); also: outputs of the two kernels compared
 (same k order per element -> expected bit-equal), and a repeat screen of the four-wave kernel (20 launches against the first).
-    python tools/bench_gemm_w4.py [out.json] [rounds]
+    python tools/bench_gemm_w4.py [out.json] [rounds] [epilogues|-] [bf16|fp16]
+Round 4: a VENDOR column (same box, same tensors): `torch.matmul` = hipBLASLt / rocBLAS computing the bare matrix product of the same operands (no bias, no activation, no
+residual, 16-bit output; for the TN shapes a.T @ b) -- the external yard-stick for "how close to what this part does on these shapes" (SURVEY section 7 allows the vendor
+library as a comparison, never in the product), and `rel_err_vs_vendor` for the plain / TN shapes.  Fourth argument: the operand format (fp16: kernels 5 and 6 only).
 """
 import json
 import sys
@@ -37,7 +40,10 @@ def main():
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     T = 50432
     res = {"rows": T, "shapes": []}
-    only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
+    only = sys.argv[3].split(",") if len(sys.argv) > 3 and sys.argv[3] != "-" else None
+    dt = torch.float16 if (len(sys.argv) > 4 and sys.argv[4] == "fp16") else torch.bfloat16
+    kerns = (5, 6) if dt == torch.float16 else (2, 5, 6)
+    res["operand"] = "fp16" if dt == torch.float16 else "bf16"
     shapes = [("qkv bias", T, 2304, 768, "bias", False), ("proj bias+res f32", T, 768, 768, "res", False), ("fc1 bias+gelu+aux", T, 3072, 768, "gelu", False),
               ("fc1 bias+gelu+saved derivative", T, 3072, 768, "gelud", False), ("fc2 bias+res f32", T, 768, 3072, "res", False), ("dfc2 dgelu+ocs", T, 3072, 768, "dgelu", False),
               ("dfc2 x saved derivative+ocs", T, 3072, 768, "mulaux", False), ("dfc1 plain", T, 768, 3072, "plain", False),
@@ -49,26 +55,26 @@ def main():
             continue
         torch.manual_seed(0)
         if trans:
-            a = torch.randn(K, M, device="cuda").bfloat16(); b = torch.randn(K, N, device="cuda").bfloat16()
+            a = torch.randn(K, M, device="cuda").to(dt); b = torch.randn(K, N, device="cuda").to(dt)
         else:
-            a = torch.randn(M, K, device="cuda").bfloat16(); b = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+            a = torch.randn(M, K, device="cuda").to(dt); b = (torch.randn(N, K, device="cuda") * 0.05).to(dt)
         bias = torch.randn(N, device="cuda")
         kw = {}
-        odt = torch.bfloat16
+        odt = dt
         if ep == "bias":
             kw = {"bias": bias}
         elif ep == "res":
             kw = {"bias": bias, "residual": torch.randn(M, N, device="cuda")}; odt = torch.float32
         elif ep == "gelu":
-            kw = {"bias": bias, "act": ops.ACT_GELU, "aux": torch.empty(M, N, device="cuda", dtype=torch.bfloat16)}
+            kw = {"bias": bias, "act": ops.ACT_GELU, "aux": torch.empty(M, N, device="cuda", dtype=dt)}
         elif ep == "gelud":
-            kw = {"bias": bias, "act": ops.ACT_GELU_SAVE_GRAD, "aux": torch.empty(M, N, device="cuda", dtype=torch.bfloat16)}
+            kw = {"bias": bias, "act": ops.ACT_GELU_SAVE_GRAD, "aux": torch.empty(M, N, device="cuda", dtype=dt)}
         elif ep == "mulaux":
             rows = be.lib.vdk_gemm_c_colsum_rows(M, N, K)
-            kw = {"act": ops.ACT_MUL_AUX, "aux": torch.randn(M, N, device="cuda").bfloat16(), "c_colsum": torch.empty(rows, N, device="cuda")}
+            kw = {"act": ops.ACT_MUL_AUX, "aux": torch.randn(M, N, device="cuda").to(dt), "c_colsum": torch.empty(rows, N, device="cuda")}
         elif ep == "dgelu":
             rows = be.lib.vdk_gemm_c_colsum_rows(M, N, K)
-            kw = {"act": ops.ACT_DGELU, "aux": torch.randn(M, N, device="cuda").bfloat16(), "c_colsum": torch.empty(rows, N, device="cuda")}
+            kw = {"act": ops.ACT_DGELU, "aux": torch.randn(M, N, device="cuda").to(dt), "c_colsum": torch.empty(rows, N, device="cuda")}
         elif ep == "tn":
             kw = {"trans": True, "splitk": tn_splitk(M, N, K)}; odt = torch.float32
         o = torch.empty(M, N, dtype=odt, device="cuda")
@@ -77,14 +83,17 @@ def main():
             be.lib.vdk_gemm_force_kernel(kern)
             ops.gemm_nt(a, b, out=o, backend=be, **kw)
 
-        run(2); assert be.lib.vdk_gemm_last_kernel() == 2; r2 = o.clone()
+        if 2 in kerns:
+            run(2); assert be.lib.vdk_gemm_last_kernel() == 2; r2 = o.clone()
         o.fill_(float("nan"))
         run(6); assert be.lib.vdk_gemm_last_kernel() == 6; r6 = o.clone()
         o.fill_(float("nan"))
         run(5); assert be.lib.vdk_gemm_last_kernel() == 5; r5 = o.clone()
         torch.cuda.synchronize()
+        if 2 not in kerns:
+            r2 = r5
         maxdiff = (r2.float() - r5.float()).abs().max().item()
-        nbad = int((r2 != r5).sum().item()) + int((r2 != r6).sum().item())
+        nbad = int((r2 != r5).sum().item()) + int((r5 != r6).sum().item())
         # repeat screen: the four-wave kernel against its own first result
         unstable = 0
         for _ in range(10):
@@ -96,22 +105,40 @@ def main():
         if M * N <= 4096 * 4096 and ep in ("plain", "tn"):
             ref = (a.float().T @ b.float()) if trans else (a.float() @ b.float().T)
             ref_err = ((r5.float() - ref).norm() / ref.norm()).item()
-        t = {2: [], 5: [], 6: []}
+        # the vendor library on the same tensors: the bare product
+        vo = torch.empty(M, N, dtype=dt, device="cuda")
+        at = a.t() if trans else a
+        bt = b if trans else b.t()
+        vendor = lambda: torch.matmul(at, bt, out=vo)
+        vendor(); torch.cuda.synchronize()
+        vend_err = None
+        if ep in ("plain", "tn"):
+            vend_err = ((r5.float() - vo.float()).norm() / vo.float().norm()).item()
+        t = {k: [] for k in kerns}
+        t["v"] = []
         iters = 10
-        for kern in (2, 5, 6):
+        for kern in kerns:
             timed(lambda: run(kern), 3)
+        timed(vendor, 3)
         for _ in range(rounds):
-            for kern in (2, 5, 6):
+            for kern in kerns:
                 t[kern].append(timed(lambda: run(kern), iters))
+            t["v"].append(timed(vendor, iters))
         fl = 2.0 * M * N * K
-        rec = {"name": name, "M": M, "N": N, "K": K, "epilogue": ep, "maxdiff_w8_w4": maxdiff, "n_differ": nbad, "unstable_repeats": unstable, "rel_err_vs_torch": ref_err}
-        for kern, key in ((2, "w8"), (5, "w4"), (6, "w4h")):
+        rec = {"name": name, "M": M, "N": N, "K": K, "epilogue": ep, "maxdiff_w8_w4": maxdiff, "n_differ": nbad, "unstable_repeats": unstable, "rel_err_vs_torch": ref_err,
+               "rel_err_vs_vendor": vend_err}
+        for kern, key in ((2, "w8"), (5, "w4"), (6, "w4h"), ("v", "vendor")):
+            if kern not in t:
+                continue
             ts = sorted(t[kern])
             rec[key + "_us_median"] = ts[len(ts) // 2] * 1e6
             rec[key + "_us_min"] = ts[0] * 1e6
             rec[key + "_tflops_median"] = fl / ts[len(ts) // 2] / 1e12
-        rec["speedup"] = rec["w8_us_median"] / rec["w4_us_median"]
-        rec["speedup_h"] = rec["w8_us_median"] / rec["w4h_us_median"]
+        best = min(rec["w4_us_median"], rec["w4h_us_median"])
+        rec["vendor_bare_product_over_best"] = rec["vendor_us_median"] / best       # > 1: this library's kernel WITH its epilogue beats the vendor's bare product
+        if "w8_us_median" in rec:
+            rec["speedup"] = rec["w8_us_median"] / rec["w4_us_median"]
+            rec["speedup_h"] = rec["w8_us_median"] / rec["w4h_us_median"]
         res["shapes"].append(rec)
         print(json.dumps(rec), flush=True)
     be.lib.vdk_gemm_force_kernel(0)

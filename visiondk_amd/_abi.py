@@ -136,6 +136,15 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_sam_first_step": (C.c_int, [P, P, P, I64, F32, I32, P, P, SZ, P]),
     "vdk_ohem_mask": (C.c_int, [P, I64, I32, I32, P, I32, F32, I64, P, P, P]),
     "vdk_topk_rows": (C.c_int, [P, I64, I32, I32, I32, P, P, P]),
+    # collectives for hosts without a process group (csrc/comm.hip, RCCL by dlopen)
+    "vdk_comm_unique_id": (C.c_int, [P]),
+    "vdk_comm_init": (C.c_int, [P, I32, I32, C.POINTER(P)]),
+    "vdk_comm_destroy": (C.c_int, [P]),
+    "vdk_comm_rank": (C.c_int, [P]),
+    "vdk_comm_world": (C.c_int, [P]),
+    "vdk_allreduce_bucket": (C.c_int, [P, P, I64, I64, P]),
+    "vdk_comm_finish": (C.c_int, [P, P]),
+    "vdk_allgather": (C.c_int, [P, P, P, I64, P]),
     # margin-softmax heads
     "vdk_margin_cos_pass": (C.c_int, [P, I32, P, I64, P, I64, I32, I32, I32, I32, I32, P, P, P, P, P, F32, F32, P, I64, P]),
     "vdk_margin_rowstat": (C.c_int, [P, I64, P, I32, I32, F32, P, P, P]),

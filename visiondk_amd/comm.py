@@ -34,10 +34,15 @@ class GradAllReduce:
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.active = self.world_size > 1 or always_communicate
-        if self.active and torch.cuda.is_available():
+        # The reserve is scoped to the window in which a collective can actually be in flight: it is set when the step's FIRST bucket is issued (from inside the backward)
+        # and the previous value is restored in finish_step().  Forward, loss, optimizer -- and anything else in the process: evaluation, CBIR, another model -- run
+        # their persistent GEMM grids on every CU.  (Round 3 set it process-wide in the constructor and never restored it.)
+        self._reserve = int(reserve_cus) if (self.active and torch.cuda.is_available()) else 0
+        self._be = None
+        self._reserve_prev: Optional[int] = None
+        if self._reserve:
             from . import _lib
-            be = _lib.load()
-            be.check(be.lib.vdk_gemm_reserve_cus(int(reserve_cus)), "vdk_gemm_reserve_cus")
+            self._be = _lib.load()
         self.collectives = 0               # issued so far (tests / logs)
         self.bucket_bytes = bucket_bytes   # ViT-B: one 28 MB transformer block per collective (ranges arrive per block); far above the size where a ring over xGMI is latency-bound
         self._grads: Optional[torch.Tensor] = None
@@ -57,10 +62,33 @@ class GradAllReduce:
         self._grads = flat_grads
         self._pending = []
         self._lo = self._hi = None
+        self._sent_lo = flat_grads.numel()      # lower end of what has been issued so far: ranges that arrive top-down keep extending directly below it
+
+    def _hold_cus(self) -> None:
+        if self._reserve and self._reserve_prev is None:
+            self._reserve_prev = int(self._be.lib.vdk_gemm_reserved_cus())
+            self._be.check(self._be.lib.vdk_gemm_reserve_cus(max(self._reserve, self._reserve_prev)), "vdk_gemm_reserve_cus")
+
+    def _release_cus(self) -> None:
+        if self._reserve_prev is not None:
+            self._be.check(self._be.lib.vdk_gemm_reserve_cus(self._reserve_prev), "vdk_gemm_reserve_cus")
+            self._reserve_prev = None
+
+    def close(self) -> None:
+        """give the CUs back if a step was abandoned between begin_step and finish_step"""
+        self._release_cus()
+
+    def __del__(self):
+        try:
+            self._release_cus()
+        except Exception:
+            pass
 
     def _flush(self) -> None:
         if self._lo is None:
             return
+        self._hold_cus()                      # from here until finish_step a collective may be in flight beside the remaining backward GEMMs
+        self._sent_lo = min(self._sent_lo, self._lo)
         sl = self._grads[self._lo:self._hi]
         self._pending.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.collectives += 1
@@ -78,7 +106,10 @@ class GradAllReduce:
             self._flush()
             self._lo, self._hi = offset, offset + numel
         size = self._hi - self._lo
-        if size * 4 >= self.bucket_bytes or size >= self._lo:      # full, or the rest of the gradient (offsets below _lo) is no bigger than this bucket
+        # full -- or (top-down arrival only: this bucket sits directly below everything issued so far, so what is still to come are the offsets below _lo) the rest of
+        # the gradient is no bigger than this bucket.  For any other arrival order _lo says nothing about what is left and only the size rule applies.
+        top_down = self._hi == self._sent_lo
+        if size * 4 >= self.bucket_bytes or (top_down and size >= self._lo):
             self._flush()
 
     def finish_step(self) -> None:
@@ -88,3 +119,4 @@ class GradAllReduce:
         for w in self._pending:
             w.wait()          # makes the launch stream wait for the collective (no host sync on NCCL/RCCL)
         self._pending = []
+        self._release_cus()   # everything enqueued from here on runs after the last collective: the persistent GEMMs get the whole chip back

@@ -469,7 +469,7 @@ static int dw_wgrad_impl(const float* in, const float* dy, float* dw, float* db,
   else if (tw == 14) hipLaunchKernelGGL((dwconv7_wgrad_kernel<7, 14>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
   else if (tw == 7) hipLaunchKernelGGL((dwconv7_wgrad_kernel<7, 7>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
   else hipLaunchKernelGGL((dwconv7_wgrad_kernel<8, 8>), grid, dim3(448), 0, (hipStream_t)stream, in, dy, (float*)ws, (int)B, (int)H, (int)W, (int)C, S);
-  if (job) { *job = VdkReduceJob{(const float*)ws, (long)C * 50, 2 * S, (long)C * 50, dw, 1.0f}; return vdk_check_launch("vdk_dwconv7_wgrad"); }
+  if (job) { *job = VdkReduceJob{(float*)ws, (long)C * 50, 2 * S, (long)C * 50, dw, 1.0f}; return vdk_check_launch("vdk_dwconv7_wgrad"); }
   if (db == dw + (size_t)C * 49)     // conv_dw.weight / conv_dw.bias of the flat gradient buffer: the partial rows [49 C | C] reduce in one launch
     return vdk_reduce_rows_f32((const float*)ws, (int64_t)C * 50, 2 * S, (int64_t)C * 50, dw, 1.0f, stream);
   int rc = vdk_reduce_rows_f32((const float*)ws, (int64_t)C * 50, 2 * S, (int64_t)C * 49, dw, 1.0f, stream);

@@ -471,7 +471,7 @@ int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout_, const
         // The block's four small reductions (fc1.bias from the dGELU epilogue's column sums, the fc2' bias column sums, LayerNorm dgamma | dbeta, depthwise dw | db) run as
         // ONE launch after the depthwise weight-gradient kernel; the layer-scale kernel that needs db2p follows it.
         VdkReduceJob jobs[4]; int nj = 0;
-        jobs[nj++] = VdkReduceJob{(const float*)(base + w.csws), (long)M, xrow, (long)M, grads + b.fc1_b, 1.0f};
+        jobs[nj++] = VdkReduceJob{(float*)(base + w.csws), (long)M, xrow, (long)M, grads + b.fc1_b, 1.0f};
         const bool tn = (R % 64) == 0 && b.dw_b == b.dw_w + (int64_t)C * 49;
         if (tn) {
           RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + bw.g), R, C, M, dw2p, nullptr));

@@ -270,6 +270,9 @@ int vdk_gemm_f32_nt(const VdkGemmF32Desc* d, void* stream) {
   if (d->a_kmajor && (d->M & 3)) return vdk_fail(VDK_EINVAL, "vdk_gemm_f32_nt: k-major A needs M % 4 == 0");
   if (d->k_total < 0 || (d->k_total > 0 && (d->batch2 > 1 || (long)(d->batch1 > 0 ? d->batch1 : 1) * d->K < d->k_total)))
     return vdk_fail(VDK_EINVAL, "vdk_gemm_f32_nt: k_total splits the contraction over batch1 (batch2 <= 1, batch1 * K >= k_total)");
+  // the row-major operand tiles are loaded four k at a time and guarded by k < Keff only: a last slab whose length is not a multiple of 4 would read past the contraction
+  if (d->k_total > 0 && (d->k_total & 3) && !(d->a_kmajor && d->b_kmajor))
+    return vdk_fail(VDK_EINVAL, "vdk_gemm_f32_nt: k_total % 4 == 0 unless both operands are k-major");
   if (d->act != VDK_ACT_NONE && d->act != VDK_ACT_GELU) return vdk_fail(VDK_EINVAL, "vdk_gemm_f32_nt: act must be NONE or GELU");
   const int b1 = d->batch1 > 0 ? d->batch1 : 1, b2 = d->batch2 > 0 ? d->batch2 : 1;
   if ((long)b1 * b2 > 65535) return vdk_fail(VDK_EINVAL, "vdk_gemm_f32_nt: batch1 * batch2 <= 65535");

@@ -775,7 +775,7 @@ int vdk_colsum_bf16_deferred(const void* in, int64_t ld, int32_t T, int32_t N, f
   if (opf) hipLaunchKernelGGL((colsum_bf16_partial_kernel<false, VDK_OPF_F16>), grid, dim3(256), 0, stream, (const bf16_t*)in, (long)ld, (int)T, (int)N, rps, (float*)ws, LnQ8());
   else if (q8) hipLaunchKernelGGL(colsum_bf16_partial_kernel<true>, grid, dim3(256), 0, stream, (const bf16_t*)in, (long)ld, (int)T, (int)N, rps, (float*)ws, *q8);
   else hipLaunchKernelGGL(colsum_bf16_partial_kernel<false>, grid, dim3(256), 0, stream, (const bf16_t*)in, (long)ld, (int)T, (int)N, rps, (float*)ws, LnQ8());
-  *job = VdkReduceJob{(const float*)ws, (long)N, S, (long)N, out, 1.0f};
+  *job = VdkReduceJob{(float*)ws, (long)N, S, (long)N, out, 1.0f};
   return vdk_check_launch("vdk_colsum_bf16");
 }
 int vdk_reduce_rows_batch(const VdkReduceJob* jobs, int n, void* stream) {

@@ -23,7 +23,10 @@ int vdk_cast_f32_16(const float* in, void* out, int64_t n, int opf, void* stream
 // fp8 copy of a LayerNorm kernel's bf16 output (fp8 mode of the ViT engine): out [rows, ld] bytes = fp8(clamp(value * scale[0])), amax[0] = max(amax[0], max |value|)
 struct LnQ8 { unsigned char* out; long ld; const float* scale; float* amax; int fmt; };
 // out[c] = scale * sum_{s < S} in[s * ld + c], c < n: one of up to 8 row reductions that vdk_reduce_rows_batch runs in a single launch
-struct VdkReduceJob { const float* in; long ld; int S; long n; float* out; float scale; };
+// `in` is SCRATCH of the caller: a tall job (S >= 1024 partial rows) is folded IN PLACE onto its first 64 rows before the final reduction (reduce_rows_fold_kernel), so
+// the partial buffer must not be read again afterwards and two jobs of a batch must not share rows of it.  Every in-library producer (LayerNorm / column-sum / depthwise
+// weight-gradient partials) hands its own workspace slice; that is why the pointer is not const.
+struct VdkReduceJob { float* in; long ld; int S; long n; float* out; float scale; };
 int vdk_reduce_rows_batch(const VdkReduceJob* jobs, int n, void* stream);
 
 int vdk_colsum_bf16_deferred(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job,

@@ -237,6 +237,8 @@ class TimmWrapper(nn.Module):
         """Evaluation embedding with fp32 activations and fp32-MFMA contractions end to end (backbone + neck in eval mode): agrees with the reference's
         PyTorch-CPU fp32 embedding to ~1e-6, so downstream cosine top-k lists match the reference's.  Used by FeatureExtractor(precise=True)."""
         be, ol = self.be, self.output_layer
+        if not hasattr(self.model, "forward_precise"):
+            raise NotImplementedError("forward_precise (fp32-MFMA evaluation) is built for the ViT and ConvNeXt engines; the Swin backbone evaluates on bf16 operands")
         feat = self.model.forward_precise(x)
         B = x.shape[0]
         if self.is_cnn:
@@ -439,18 +441,19 @@ class FaceTrainStep:
         self.bb = model.trainingwrapper["backbone"]
         if precision == "fp32" and shard_head:
             raise NotImplementedError("precision='fp32' with a class-sharded head is not built")
-        if precision == "fp32" and not self.bb.is_cnn:
-            raise NotImplementedError("precision='fp32' is built for the CNN (ConvNeXt) backbones of the face / CBIR task")
+        if not hasattr(self.bb.model, "engine"):
+            raise NotImplementedError("FaceTrainStep needs a backbone with a native engine (ViT, ConvNeXt); the Swin backbone trains through autograd under the reference's own "
+                                      "Trainer (torch optimizer over model.parameters())")
+        if precision == "fp32" and not hasattr(self.bb.model.engine, "precision"):
+            raise NotImplementedError("precision='fp32' is built for the ConvNeXt backbones of the face / CBIR task (the engine with an fp32-class training mode)")
         self.precision = precision
         self.bb.precision = precision
-        self.bb.model.engine.precision = precision
+        if hasattr(self.bb.model.engine, "precision"):
+            self.bb.model.engine.precision = precision
         # sync_bn (the reference's `sync_bn` flag converts every BatchNorm of the model, engine/vision_engine.py:224-225): the neck's BatchNorm2d / BatchNorm1d
         # all-reduce their batch statistics (forward) and gradient sums (backward) over comm's group
         self.bb.sync_group = comm.group if (sync_bn and comm is not None and comm.active) else False
         self.head = model.trainingwrapper["head"]
-        if not hasattr(self.bb.model, "engine"):
-            raise NotImplementedError("FaceTrainStep needs a backbone with a native engine (ViT, ConvNeXt); the Swin backbone trains through autograd under the reference's own "
-                                      "Trainer (torch optimizer over model.parameters())")
         self.eng = self.bb.model.engine
         self.be = self.eng.be
         self.lr, self.momentum, self.weight_decay, self.label_smoothing, self.max_norm = lr, momentum, weight_decay, label_smoothing, max_norm

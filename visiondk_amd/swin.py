@@ -129,15 +129,17 @@ class _LNRes(torch.autograd.Function):
         dr = dres.contiguous().view(x2.shape) if dres is not None else None
         dx, dxb, dg, db = ops.layernorm_bwd(dy2, x2, mean, rstd, w.detach(), dres=dr, want_bf16=True, backend=ctx.be)
         dx = dx.view(ctx.shape)
-        dx._vdk_bf16 = dxb
+        dx._vdk_bf16 = (dxb, dx._version, dx.data_ptr())      # valid only while this very tensor reaches the consumer unmodified (see _grad_bf16)
         return dx, dg, db, None, None
 
 
 def _grad_bf16(be, dy: torch.Tensor, rows: int) -> torch.Tensor:
     """the bf16 [rows, C] operand of a gradient: the copy its producer attached (_LNRes.backward), else a cast"""
     c = getattr(dy, "_vdk_bf16", None)
-    if c is not None and c.numel() == dy.numel():
-        return c.view(rows, -1)
+    # the attached copy is trusted only if the gradient is still the producer's tensor, untouched: an in-place accumulation (a second consumer of the activation, a
+    # tensor hook) bumps _version, a re-materialised sum has another data pointer -- then the copy is stale and the gradient is cast again
+    if c is not None and c[0].numel() == dy.numel() and c[1] == dy._version and c[2] == dy.data_ptr():
+        return c[0].view(rows, -1)
     return _bf(be, dy.contiguous().view(rows, -1))
 
 
