@@ -309,11 +309,11 @@ def bench_cfg5(be, dev, batch: int = 128, steps: int = 3):
 
 def bench_swin(be, dev, batch: int = 128, steps: int = 4):
     """swin_base_patch4_window7_224 -- the `name:` both shipped configs of the reference default to (pet.yaml:25, cbir.yaml:26) -- beside the headline: the classifier step
-    forward + CE + backward + clip_grad_norm_ + torch SGD (the reference's own Trainer sequence over the module's Parameters; this family runs as autograd nodes over the HIP
-    kernels), and a live check of a 2-stage Swin (logits and the worst parameter gradient) against the fp32 oracle (oracle/swin_ref.py, pinned against transformers.SwinModel)."""
+    forward + CE + backward + clip_grad_norm_ + SGD + EMA through the native engine (csrc/swin_engine.hip: one C-ABI call forward, one backward) under vit.FusedTrainStep,
+    and a live check of a 2-stage Swin (logits and the worst parameter gradient) against the fp32 oracle (oracle/swin_ref.py, pinned against transformers.SwinModel)."""
     from oracle.swin_ref import SwinTransformerRef
-    from visiondk_amd import swin
-    out = {"workload": f"swin_base_patch4_window7_224, 37 classes (pet.yaml), batch {batch}: fwd + CE(ls 0.05) + bwd + clip_grad_norm_ + torch SGD", "dtype": "bf16 operands, fp32 residual stream"}
+    from visiondk_amd import swin, vit
+    out = {"workload": f"swin_base_patch4_window7_224, 37 classes (pet.yaml), batch {batch}: fwd + CE(ls 0.05) + bwd + clip_grad_norm_ + SGD + EMA (native engine, fused step)", "dtype": "bf16 operands, fp32 residual stream"}
     torch.manual_seed(0)
     ref = SwinTransformerRef(img_size=224, num_classes=7, embed_dim=32, depths=(2, 2), heads=(1, 2))
     with torch.no_grad():
@@ -332,25 +332,17 @@ def bench_swin(be, dev, batch: int = 128, steps: int = 4):
                                     "worst_grad_rel": grads[worst], "worst_grad": worst,
                                     "full_size_quoted": "swin_base, every gradient vs the fp32 oracle (tests/test_swin.py): logits 5.9e-3, worst gradient 1.1e-2, median 5.6e-3"}
     del small, ref
-    model = swin.create_model("swin_base_patch4_window7_224", num_classes=37, device=dev, seed=0)
-    opt = torch.optim.SGD(model.parameters(), lr=0.006, momentum=0.937, weight_decay=5e-4)
+    model = swin.create_model("swin_base_patch4_window7_224", num_classes=37, device=dev, backend=be, seed=0)
+    fused = vit.FusedTrainStep(model, lr=0.006, momentum=0.937, weight_decay=5e-4, label_smoothing=0.05, max_norm=10.0, ema=True)
     xb = torch.randn(batch, 3, 224, 224, device=dev); yb = torch.randint(0, 37, (batch,), device=dev)
-
-    def one():
-        opt.zero_grad(set_to_none=True)
-        loss = torch.nn.functional.cross_entropy(model(xb), yb, label_smoothing=0.05)
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
-        opt.step()
-        return loss
     for _ in range(2):
-        one()
+        fused.step(xb, yb)
     torch.cuda.synchronize(); t0 = time.time()
     for _ in range(steps):
-        l_ = one()
+        fused.step(xb, yb)
     torch.cuda.synchronize(); dt = (time.time() - t0) / steps
-    out.update({"images_per_sec": batch / dt, "ms_per_step": dt * 1e3, "model_tflops": 3 * 15.47e9 * batch / dt / 1e12, "loss": l_.item()})
-    del model, opt
+    out.update({"images_per_sec": batch / dt, "ms_per_step": dt * 1e3, "model_tflops": 3 * 15.47e9 * batch / dt / 1e12, "loss": fused.loss_value()})
+    del model, fused
     torch.cuda.empty_cache()
     return out
 

@@ -559,6 +559,29 @@ int vdk_convnext_backward_train_f32(const VdkConvNextConfig* cfg, const float* d
 int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout, const float* params, const void* wb16, const void* wx, void* ws, size_t ws_bytes,
                           float* grads, vdk_grad_ready_fn on_ready, void* user, void* stream);
 
+/* ---- native Swin engine: timm `swin_{tiny,small,base,large}_patch4_window7_224` over flat buffers (csrc/swin_engine.hip) -------------------------------------------------
+ * Replaces `self.model(images)` + `loss.backward()` for the backbone BOTH shipped configs of the reference select by default (`timm-swin_base_patch4_window7_224`:
+ * configs/classification/pet.yaml:25, configs/faceX/cbir.yaml:26; built by timm.create_model in models/classifier/classify_model.py:49-54 and
+ * models/faceX/backbone/timm_wrapper.py:16-21).  Semantics restated from timm 0.9.16 (oracle/swin_ref.py, pinned against transformers.SwinModel).  Same protocol as the ViT
+ * engine: flat fp32 params / grads in timm state_dict order with timm names (vdk_swin_param_info), wb16 = the bf16 copy in the same layout, wt16 = [in, out] bf16 copies of
+ * every Linear for the input-gradient GEMMs (vdk_swin_refresh_weights), one call per forward and one per backward on one stream, activations in the caller's workspace.
+ * num_classes = 0 is timm's forward_features: the final-normed NHWC map as rows f32 [B * 49 * (img / 224)^2, 8 * embed_dim] (what TimmWrapper's neck consumes). */
+typedef struct VdkSwinConfig {
+  int32_t batch, img_size, in_chans, embed_dim;
+  int32_t depths[4], heads[4];
+  int32_t num_classes;
+  float ln_eps;
+} VdkSwinConfig;
+int vdk_swin_param_count(const VdkSwinConfig* cfg, int64_t* n_floats, int32_t* n_tensors, int64_t* n_transposed);
+int vdk_swin_param_info(const VdkSwinConfig* cfg, int32_t index, char* name, int32_t name_cap, int64_t* offset, int64_t* numel, int64_t* shape4, int32_t* ndim);
+int vdk_swin_workspace_bytes(const VdkSwinConfig* cfg, size_t* bytes);
+int vdk_swin_refresh_weights(const VdkSwinConfig* cfg, const float* params, void* wb16, void* wt16, int32_t skip_wb16, void* stream);
+/* x f32 [B, in_chans, img, img] -> out f32: logits [B, up(num_classes, 8)] or the feature rows (see above); activations stay in ws */
+int vdk_swin_forward(const VdkSwinConfig* cfg, const float* x, const float* params, const void* wb16, void* ws, size_t ws_bytes, float* out, void* stream);
+/* dout: dlogits bf16 [B, up(num_classes, 8)] (padding columns zero), or f32 feature-row gradients -> grads (flat fp32, overwritten); on_ready as in vdk_vit_backward */
+int vdk_swin_backward(const VdkSwinConfig* cfg, const void* dout, const float* params, const void* wb16, const void* wt16, void* ws, size_t ws_bytes, float* grads,
+                      vdk_grad_ready_fn on_ready, void* user, void* stream);
+
 /* ---- collectives of the multi-GPU paths for a host without a process group of its own: RCCL over xGMI, one process per GPU ------------------------------
  * Replaces, for a C / C++ host, what the reference gets from torch.distributed: the process group of main.py:39-40 and the gradient all-reduce of the DistributedDataParallel
  * wrap (engine/vision_engine.py:313,510), plus the query all-gather of the gallery-sharded search.  (The Python host of this repository drives the same exchange through c10d,

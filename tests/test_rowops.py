@@ -11,7 +11,8 @@ def _rel(a, b):
     return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 
 
-@pytest.mark.parametrize("T,C", [(10, 768), (7, 64), (33, 1024), (5, 1536), (21, 128), (9, 96), (17, 256)])   # C <= 128: two rows per wave
+@pytest.mark.parametrize("T,C", [(10, 768), (7, 64), (33, 1024), (5, 1536), (21, 128), (9, 96), (17, 256), (150, 128), (77, 512), (210, 256), (300, 384)])
+# (C <= 128: a row is half a wave; C <= 512: two rows per wave and pass in the backward; T > 64: several blocks, ragged last pass)
 def test_layernorm_fwd_bwd(be, dev, T, C):
     torch.manual_seed(0)
     x = (torch.randn(T, C) * 2 + 0.5).to(dev)

@@ -213,3 +213,92 @@ def test_window_attention_rejects_what_it_does_not_serve(be, dev):
     assert call(64, 32, ws.numel()) == _abi.EUNSUPPORTED and call(49, 64, ws.numel()) == _abi.EUNSUPPORTED
     rc = call(49, 32, 1024)
     assert rc != 0 and rc != _abi.EUNSUPPORTED and b"workspace" in be.lib.vdk_last_error()
+
+
+# ---- the native engine (one C-ABI call per forward / backward) against the autograd-node form over the same kernels --------------------------------------------
+
+@pytest.mark.parametrize("depths,heads,ncls", [((2, 2), (1, 2), 0), ((1, 2, 1, 1), (1, 2, 4, 8), 0), ((2, 1), (1, 2), 6)])
+def test_native_engine_equals_autograd_form(be, dev, depths, heads, ncls):
+    """vdk_swin_forward / vdk_swin_backward run the kernels of the autograd-node model in the same order on the same operands: in feature mode (what TimmWrapper asks for)
+    the map is bit-identical and the gradients agree to fp32 summation order; with the classifier head the engine's pooled row is rounded to bf16 for the head GEMM
+    (the ViT engine's convention) where the autograd form keeps it fp32, so logits agree to bf16 resolution"""
+    spec = swin.SwinSpec(img_size=224, num_classes=ncls, embed_dim=32, depths=depths, heads=heads)
+    nat = swin.SwinTransformer(spec, device=dev, backend=be, seed=5)
+    ag = swin.SwinTransformerAutograd(spec, device=dev, backend=be, seed=6)
+    with torch.no_grad():
+        for n, p in nat.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    assert [n for n, _ in nat.named_parameters()] == [n for n, _ in ag.named_parameters()]
+    ag.load_state_dict(nat.state_dict(), strict=True)
+    torch.manual_seed(1)
+    x = torch.randn(2, 3, 224, 224).to(dev)
+    y, ya = nat(x), ag(x)
+    assert y.shape == ya.shape
+    d = torch.randn_like(y)
+    y.backward(d); ya.backward(d)
+    if ncls == 0:
+        assert torch.equal(y, ya)
+        tol = 1e-5
+    else:
+        assert _rel(y, ya) < 6e-3
+        tol = 2e-2
+    for (n, p), (_, pa) in zip(nat.named_parameters(), ag.named_parameters()):
+        assert p.grad is not None and _rel(p.grad, pa.grad) < tol, (n, _rel(p.grad, pa.grad))
+
+
+def test_fused_train_step_over_the_swin_engine(be, dev):
+    """vit.FusedTrainStep (CE with label smoothing -> backward -> clip_grad_norm_ -> SGD -> EMA in device kernels) drives the Swin engine through the same
+    protocol as the ViT engine: 3 steps against the reference's Trainer.update on the fp32 oracle"""
+    from oracle.vit_ref import train_step_reference
+    from visiondk_amd import vit
+    model, ref = _pair(be, dev, 224, 32, (2, 2), (1, 2), 7, seed=2)
+    hyp = dict(lr=0.01, momentum=0.937, weight_decay=5e-4)
+    step = vit.FusedTrainStep(model, label_smoothing=0.05, max_norm=10.0, ema=True, **hyp)
+    init = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    ema_ref = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    bufs = None
+    torch.manual_seed(11)
+    for it in range(3):
+        x = torch.randn(4, 3, 224, 224); y = torch.randint(0, 7, (4,))
+        _, loss_ref, _, _, bufs = train_step_reference(ref, x, y, label_smoothing=0.05, max_norm=10.0, momentum_bufs=bufs, ema=ema_ref, updates=it, **hyp)
+        step.step(x.to(dev), y.to(dev))
+        assert abs(step.loss_value() - loss_ref.item()) < 1e-2 * abs(loss_ref.item()), (it, step.loss_value(), loss_ref.item())
+    sd = model.state_dict()
+    errs = sorted((_rel(sd[n].cpu() - init[n], p.detach() - init[n]), n) for n, p in ref.named_parameters())
+    assert errs[-1][0] < 1.2e-1 and errs[len(errs) // 2][0] < 4e-2, (errs[-1], errs[len(errs) // 2])
+    for n in ema_ref:
+        assert _rel(model.engine.view(step.ema, n).cpu() - init[n], ema_ref[n] - init[n]) < 1.2e-1, n
+
+
+def test_face_train_step_over_the_swin_engine(be, dev):
+    """cbir.yaml as shipped (Swin backbone + BatchNorm2d(7) neck + ArcFace): FaceTrainStep == loss.backward() through the module tree + clip_grad_norm_ + SGD, one step
+    from the same weights (the same kernels both ways: the update each tensor receives agrees to summation order)"""
+    import copy
+    from visiondk_amd import face
+    swin.TIMM_SWINS["swin_test_patch4_window7_224"] = dict(embed_dim=32, depths=(1, 1, 1, 1), heads=(1, 2, 4, 8))
+    cfg = {"task": "cbir", "image_size": 224, "load_from": None,
+           "backbone": {"timm-swin_test_patch4_window7_224": {"pretrained": False, "image_size": 224, "feat_dim": 64}},
+           "head": {"arcface": {"feat_dim": 64, "num_class": 24, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
+    torch.manual_seed(0)
+    m1 = face.get_model(cfg, None, 0, backend=be, device=dev).model.train()
+    m2 = copy.deepcopy(m1)
+    init = {n: p.detach().clone() for n, p in m1.named_parameters()}
+    x = torch.randn(6, 3, 224, 224).to(dev); y = torch.randint(0, 24, (6,)).to(dev)
+    lr, mom, wd, mx = 0.05, 0.9, 5e-4, 1.0
+    step = face.FaceTrainStep(m1, lr=lr, momentum=mom, weight_decay=wd, max_norm=mx, ema=False)
+    loss_rows = step.step(x, y)
+    opt = torch.optim.SGD(m2.parameters(), lr=lr, momentum=mom, weight_decay=wd)
+    loss = torch.nn.functional.cross_entropy(m2(x, y), y)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(m2.parameters(), mx)
+    opt.step()
+    assert abs(loss_rows.mean().item() - loss.item()) < 2e-3 * abs(loss.item())
+    errs = []
+    for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        d1, d2 = p.detach() - init[n], q.detach() - init[n]
+        if d2.norm().item() < 1e-7:
+            continue
+        errs.append((_rel(d1, d2), n))
+    errs.sort()
+    assert errs[-1][0] < 3e-2, errs[-3:]

@@ -50,9 +50,17 @@ class ResNetConfig(C.Structure):
                 ("bn_momentum", C.c_float), ("mid", I32 * 4), ("stem_width", I32)]
 
 
+class SwinConfig(C.Structure):
+    """VdkSwinConfig of include/visiondk.h"""
+    _fields_ = [("batch", I32), ("img_size", I32), ("in_chans", I32), ("embed_dim", I32), ("depths", I32 * 4), ("heads", I32 * 4), ("num_classes", I32), ("ln_eps", C.c_float)]
+
+
 class MarginHead(C.Structure):
     """VdkMarginHead of include/visiondk.h"""
     _fields_ = [("mode", I32), ("scale", F32), ("margin", F32), ("margin_am", F32), ("mv_weight", F32), ("row_margin", P)]
+
+    def __deepcopy__(self, memo):      # ModelEMA deep-copies the model (models/ema.py:22) and the head module keeps one of these; row_margin is a per-call pointer
+        return MarginHead(self.mode, self.scale, self.margin, self.margin_am, self.mv_weight, None)
 
 
 F16_ = 2   # VDK_F16
@@ -194,6 +202,12 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_vit_refresh_weights": (C.c_int, [C.POINTER(VitConfig), P, P, P, I32, P]),
     "vdk_vit_forward": (C.c_int, [C.POINTER(VitConfig), P, P, P, P, SZ, P, P]),
     "vdk_vit_backward": (C.c_int, [C.POINTER(VitConfig), P, P, P, P, P, SZ, P, P, P, P, P]),
+    "vdk_swin_param_count": (C.c_int, [C.POINTER(SwinConfig), C.POINTER(I64), C.POINTER(I32), C.POINTER(I64)]),
+    "vdk_swin_param_info": (C.c_int, [C.POINTER(SwinConfig), I32, C.c_char_p, I32, C.POINTER(I64), C.POINTER(I64), C.POINTER(I64), C.POINTER(I32)]),
+    "vdk_swin_workspace_bytes": (C.c_int, [C.POINTER(SwinConfig), PSZ]),
+    "vdk_swin_refresh_weights": (C.c_int, [C.POINTER(SwinConfig), P, P, P, I32, P]),
+    "vdk_swin_forward": (C.c_int, [C.POINTER(SwinConfig), P, P, P, P, SZ, P, P]),
+    "vdk_swin_backward": (C.c_int, [C.POINTER(SwinConfig), P, P, P, P, P, SZ, P, P, P, P]),
     "vdk_conv_weight_prep": (C.c_int, [P, P, P, I32, I32, I32, I32, I32, P]),
     "vdk_conv_wgrad_unpermute": (C.c_int, [P, P, I32, I32, I32, I32, I32, P]),
     "vdk_nchw_to_nhwc_bf16": (C.c_int, [P, P, I32, I32, I32, I32, I32, P]),

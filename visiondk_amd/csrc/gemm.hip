@@ -707,10 +707,14 @@ static bool w4h_wanted(int E, bool trans, long M, long N, long K) {
   //   dGELU + column sums 393 / 335 -> 256x128;  GELU + saved pre-activation 327 / 336 -> four-wave;  fp32 residual: K 768 111 / 105, K 3072 239 / 255 -> by K;
   //   light epilogues: N 768 K 768 63 / 56 -> 256x128 when the k-range is short and every CU gets at most ~3 tiles, else four-wave (158-205 / 162-221);  TN -> four-wave
   if (trans || E == E_GENERIC) return false;
-  if (E & E_DGELU) return true;
-  if (E & E_GELU) return false;
-  if (E & E_RES) return K < 1536;
   const long tiles = ((M + 255) / 256) * ((N + 255) / 256);
+  // round 4, tools/bench_gemm_swin.py (swin_base at batch 128; us, four-wave / 256x128): fewer 256x256 tiles than CUs -> the half tiles are twice the parallelism
+  // (6 272 rows, stage 4: N 1024 K 4096 69 / 51, N 1024 K 1024 29 / 22, N 3072 -> 1024 52 / 39), whatever the epilogue
+  if (tiles < 256) return true;
+  if (E & E_DGELU) return true;
+  // GELU: the four-wave kernel's whole-tile rounds against hardware-dispatched half tiles -- 25 088 x 2048 x 512 (stage 3) is 784 tiles = 3.06 rounds, 99 / 90 us
+  if (E & E_GELU) return K <= 768 && (double)tiles / (double)((tiles + 255) / 256 * 256) < 0.8;
+  if (E & E_RES) return K < 1536;
   return K <= 1024 && tiles <= 3 * 256;
 }
 // rows from which a 128 <= N < 256 problem goes to the 256x128 kernel (one workgroup per 256 rows: below ~one workgroup per CU the 128x128 kernel has more parallelism);
@@ -747,7 +751,8 @@ int vdk_gemm_a_colsum_rows(int32_t M, int32_t N, int32_t K) {
 /* rows of the c_colsum by-product ([rows][N] f32: column sums of the stored bf16 output per (row tile, wave row)) if the 256x256 NT kernel serves (M, N, K), else 0 */
 int vdk_gemm_c_colsum_rows(int32_t M, int32_t N, int32_t K) {
   const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  const bool big = g_force_kernel == 2 || g_force_kernel == 3 || g_force_kernel == 5 || g_force_kernel == 6 || ((g_force_kernel == 0 || g_force_kernel == 4) && (K % 64 == 0) && tiles256 >= 128 && M >= 256 && N >= 256);
+  const long tiles_h = w4_enabled_env() ? (long)((M + 255) / 256) * ((N + 127) / 128) : 0;      // (the dispatcher's second admission rule: half tiles of the 256x128 kernel)
+  const bool big = g_force_kernel == 2 || g_force_kernel == 3 || g_force_kernel == 5 || g_force_kernel == 6 || ((g_force_kernel == 0 || g_force_kernel == 4) && (K % 64 == 0) && (tiles256 >= 128 || tiles_h >= 128) && M >= 256 && N >= 256);
   return (big && (K % 64 == 0)) ? 2 * ((M + 255) / 256) : 0;
 }
 
@@ -871,10 +876,12 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   const bool prof = g_prof_on && g_prof_used + 2 <= g_prof_ev.size();
   // big problems go to the 256x256 LDS-DMA kernel (needs whole 64-wide k-tiles per split and >= 1 full wave of tiles)
   const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * splitk;
+  // ... or >= 128 of the 256x128 kernel's tiles (6 272 x 1024 outputs: 100 whole tiles, 200 half tiles; the 128x128 kernel ran those at 0.6-0.7 of the half-tile form)
+  const long tiles_h = (!d->trans && splitk == 1 && !d->a_colsum && w4_enabled_env()) ? (long)((d->M + 255) / 256) * ((d->N + 127) / 128) : 0;
   // narrow outputs (128 <= N < 256, many rows: ConvNeXt's first stage, C = 128) are one column of 256x128 tiles for the two-workgroups-per-CU kernel
   const bool narrow = !d->conv && !d->trans && g_force_kernel == 0 && w4_enabled_env() && (d->K % 64 == 0) && (kps % 64 == 0) && d->N >= 128 && d->N < 256 && d->M >= narrow_min_m() &&
                       !d->a_colsum && !d->c_colsum && splitk == 1 && vdk_gemm_w4h_serves(p, false);
-  const bool big = !d->conv && (narrow || g_force_kernel == 2 || g_force_kernel == 3 || g_force_kernel == 5 || g_force_kernel == 6 || ((g_force_kernel == 0 || g_force_kernel == 4) && (d->K % 64 == 0) && (kps % 64 == 0) && tiles256 >= 128 && d->M >= 256 && d->N >= 256));
+  const bool big = !d->conv && (narrow || g_force_kernel == 2 || g_force_kernel == 3 || g_force_kernel == 5 || g_force_kernel == 6 || ((g_force_kernel == 0 || g_force_kernel == 4) && (d->K % 64 == 0) && (kps % 64 == 0) && (tiles256 >= 128 || tiles_h >= 128) && d->M >= 256 && d->N >= 256));
   // compile-time epilogue variant (the common ViT forms); anything else takes the run-time-flag path
   int E = E_GENERIC;
   {

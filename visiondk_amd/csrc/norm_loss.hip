@@ -129,17 +129,23 @@ __global__ __launch_bounds__(256) void ln_fwd_narrow_kernel(const float* __restr
 // dgamma = sum dy * xhat, dbeta = sum dy.   MAXJ * 256 >= C.
 // OCS: also per-block column sums of the bf16-rounded output dxb (= the bias gradient of the Linear whose dY this tensor is: the producer sums what it stores,
 // instead of the consuming dgrad GEMM re-reading its A tiles from LDS) -> pout [block][C].
-template <int MAXJ, bool DY_BF16 /* 16-bit dy in operand format OF (else fp32) */, bool OCS, bool Q8 = false, int OF = 0 /* format of a 16-bit dy and of dxb */>
+// NR rows per wave and pass, all loaded (x, dy and the residual gradient) before the first reduction: with narrow rows (Swin's 128 .. 512 channels) a wave's single row
+// is too few bytes in flight to stream at HBM rate.  HALF (C <= 128): a row is 32 lanes, so a wave takes two rows side by side.
+template <int MAXJ, bool DY_BF16 /* 16-bit dy in operand format OF (else fp32) */, bool OCS, bool Q8 = false, int OF = 0 /* format of a 16-bit dy and of dxb */, int NR = 1,
+          bool HALF = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, long lddy, const float* __restrict__ x,
                                                      long ldx, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      long lddres, int T, int C, int rows_per_block, float* __restrict__ dx,
                                                      long lddx, bf16_t* __restrict__ dxb, long lddxb,
                                                      float* __restrict__ pgamma, float* __restrict__ pbeta, float* __restrict__ pout, LnQ8 q8 = LnQ8()) {
+  static_assert(!HALF || MAXJ == 1, "HALF: one 128-column slab");
   __shared__ float red[4][MAXJ * 256];
   float q8s = 1.0f, q8lim = 448.0f, q8am = 0.f;
   if (Q8) { q8s = q8.scale ? q8.scale[0] : 1.0f; q8lim = q8.fmt == 0 ? 448.0f : 57344.0f; }
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int HS = HALF ? 2 : 1, RW = NR * HS;          // rows a wave holds per pass
+  const int cl = HALF ? (lane & 31) : lane, sub = HALF ? (lane >> 5) : 0;
   const int r0 = blockIdx.x * rows_per_block;
   int r1 = r0 + rows_per_block; if (r1 > T) r1 = T;
   float ag[MAXJ][4], ab[MAXJ][4], ao[OCS ? MAXJ : 1][4];
@@ -148,55 +154,72 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 #pragma unroll
     for (int e = 0; e < 4; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; if (OCS) ao[j][e] = 0.f; }
   const float invC = 1.0f / (float)C;
-  for (int row = r0 + w; row < r1; row += 4) {
-    const float mu = mean[row], rs = rstd[row];
-    const float* xr = x + (long)row * ldx;
-    float s1 = 0.f, s2 = 0.f;
-    float gk[MAXJ][4], xh[MAXJ][4];
+  for (int rb = r0 + w * RW; rb < r1; rb += 4 * RW) {
+    float rs[NR], s1[NR], s2[NR];
+    float gk[NR][MAXJ][4], xh[NR][MAXJ][4], rv[NR][MAXJ][4];
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-      const int c = lane * 4 + j * 256;
-      if (c < C) {
-        f32x4 xv = *(const f32x4*)(xr + c);
-        f32x4 gm = *(const f32x4*)(gamma + c);
-        float d[4];
-        if (DY_BF16) {
-          u32x2 u = *(const u32x2*)((const bf16_t*)dy + (long)row * lddy + c);
-          d[0] = op_lo<OF>(u[0]); d[1] = op_hi<OF>(u[0]); d[2] = op_lo<OF>(u[1]); d[3] = op_hi<OF>(u[1]);
-        } else {
-          f32x4 u = *(const f32x4*)((const float*)dy + (long)row * lddy + c);
-          d[0] = u[0]; d[1] = u[1]; d[2] = u[2]; d[3] = u[3];
-        }
+    for (int k = 0; k < NR; ++k) {
+      const int row = rb + k * HS + sub;
+      const bool ok = row < r1;
+      const float mu = ok ? mean[row] : 0.f;
+      rs[k] = ok ? rstd[row] : 0.f;
+      s1[k] = 0.f; s2[k] = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float h = (xv[e] - mu) * rs;
-          float g = d[e] * gm[e];
-          xh[j][e] = h; gk[j][e] = g;
-          s1 += g; s2 = fmaf(g, h, s2);
-          ag[j][e] = fmaf(d[e], h, ag[j][e]);
-          ab[j][e] += d[e];
+      for (int j = 0; j < MAXJ; ++j) {
+        const int c = cl * 4 + j * 256;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gk[k][j][e] = 0.f; xh[k][j][e] = 0.f; rv[k][j][e] = 0.f; }
+        if (ok && c < C) {
+          f32x4 xv = *(const f32x4*)(x + (long)row * ldx + c);
+          f32x4 gm = *(const f32x4*)(gamma + c);
+          float d[4];
+          if (DY_BF16) {
+            u32x2 u = *(const u32x2*)((const bf16_t*)dy + (long)row * lddy + c);
+            d[0] = op_lo<OF>(u[0]); d[1] = op_hi<OF>(u[0]); d[2] = op_lo<OF>(u[1]); d[3] = op_hi<OF>(u[1]);
+          } else {
+            f32x4 u = *(const f32x4*)((const float*)dy + (long)row * lddy + c);
+            d[0] = u[0]; d[1] = u[1]; d[2] = u[2]; d[3] = u[3];
+          }
+          if (dres) {
+            f32x4 r4 = *(const f32x4*)(dres + (long)row * lddres + c);
+            rv[k][j][0] = r4[0]; rv[k][j][1] = r4[1]; rv[k][j][2] = r4[2]; rv[k][j][3] = r4[3];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float h = (xv[e] - mu) * rs[k];
+            float g = d[e] * gm[e];
+            xh[k][j][e] = h; gk[k][j][e] = g;
+            s1[k] += g; s2[k] = fmaf(g, h, s2[k]);
+            ag[j][e] = fmaf(d[e], h, ag[j][e]);
+            ab[j][e] += d[e];
+          }
         }
       }
     }
-    s1 = wave_sum(s1) * invC; s2 = wave_sum(s2) * invC;
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-      const int c = lane * 4 + j * 256;
-      if (c < C) {
-        float o[4];
+    for (int k = 0; k < NR; ++k) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rs * (gk[j][e] - s1 - xh[j][e] * s2);
-        if (dres) {
-          f32x4 rv = *(const f32x4*)(dres + (long)row * lddres + c);
+      for (int m = HALF ? 16 : 32; m >= 1; m >>= 1) { s1[k] += __shfl_xor(s1[k], m); s2[k] += __shfl_xor(s2[k], m); }
+      s1[k] *= invC; s2[k] *= invC;
+    }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] += rv[e];
-        }
-        if (dx) *(f32x4*)(dx + (long)row * lddx + c) = (f32x4){o[0], o[1], o[2], o[3]};
-        if (dxb) {
-          const u32x2 ob = {pack_op2<OF>(o[0], o[1]), pack_op2<OF>(o[2], o[3])};
-          *(u32x2*)(dxb + (long)row * lddxb + c) = ob;
-          if (OCS) { ao[j][0] += op_lo<OF>(ob[0]); ao[j][1] += op_hi<OF>(ob[0]); ao[j][2] += op_lo<OF>(ob[1]); ao[j][3] += op_hi<OF>(ob[1]); }
-          if (Q8) *(unsigned*)(q8.out + (long)row * q8.ld + c) = ln_q8_pack4(ob, q8s, q8lim, q8.fmt, q8am);
+    for (int k = 0; k < NR; ++k) {
+      const int row = rb + k * HS + sub;
+      const bool ok = row < r1;
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        const int c = cl * 4 + j * 256;
+        if (ok && c < C) {
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = rs[k] * (gk[k][j][e] - s1[k] - xh[k][j][e] * s2[k]) + rv[k][j][e];
+          if (dx) *(f32x4*)(dx + (long)row * lddx + c) = (f32x4){o[0], o[1], o[2], o[3]};
+          if (dxb) {
+            const u32x2 ob = {pack_op2<OF>(o[0], o[1]), pack_op2<OF>(o[2], o[3])};
+            *(u32x2*)(dxb + (long)row * lddxb + c) = ob;
+            if (OCS) { ao[j][0] += op_lo<OF>(ob[0]); ao[j][1] += op_hi<OF>(ob[0]); ao[j][2] += op_lo<OF>(ob[1]); ao[j][3] += op_hi<OF>(ob[1]); }
+            if (Q8) *(unsigned*)(q8.out + (long)row * q8.ld + c) = ln_q8_pack4(ob, q8s, q8lim, q8.fmt, q8am);
+          }
         }
       }
     }
@@ -212,7 +235,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
       for (int e = 0; e < 4; ++e) red[w][j * 256 + lane * 4 + e] = ph == 0 ? ag[j][e] : (ph == 1 ? ab[j][e] : ao[OCS ? j : 0][e]);
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
-      const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+      float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+      if (HALF) v += (red[0][c + 128] + red[1][c + 128]) + (red[2][c + 128] + red[3][c + 128]);      // (lanes 32..63 = the odd rows, stored at columns 128 + c)
       // per-block partials side by side, [block][2C]: one reduction launch serves dgamma and dbeta when they are adjacent in the gradient buffer
       if (ph == 0) pgamma[(long)blockIdx.x * 2 * C + c] = v;
       else if (ph == 1) pbeta[(long)blockIdx.x * 2 * C + c] = v;
@@ -581,7 +605,8 @@ int vdk_reduce_rows_f32(const float* in, int64_t ld, int32_t S, int64_t n, float
 }
 
 static inline int ln_bwd_blocks(int T, int C) {
-  int nb = (T + 63) / 64;          // 64 rows per block: enough waves in flight to stream at HBM rate
+  int nb = (T + 15) / 16;          // >= 16 rows per block (4 per wave); the kernel is HBM-bound and what streams is waves in flight: 25 088 rows (ViT-B bs 128, Swin-B stage 3)
+                                   // as 64-row blocks were 392 blocks = 1.5 per CU of the 4 that fit (68 us against a 22 us byte floor)
   // never more blocks than are resident at once: C <= 768 runs 4 blocks per CU (<= 128 VGPRs), wider rows 3 (136 VGPRs) -- T / 64 = 1152 blocks of ViT-L/14 at 336 were 1.5
   // rounds on 768 slots, i.e. the time of two; one round of fatter blocks costs 1.5
   const int slots = C <= 768 ? 1024 : 768;
@@ -615,11 +640,14 @@ static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const flo
   float* po = pg + (size_t)2 * nb * C;                 // rows of C: column sums of dxb
   const int rpb = (T + nb - 1) / nb;
   const bool bf = dy_dtype != VDK_F32;
-#define LNB(MJ, BF, OC) do { if (opf) hipLaunchKernelGGL((ln_bwd_kernel<MJ, BF, OC, false, VDK_OPF_F16>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
+#define LNB(MJ, BF, OC, NR, HF) do { if (opf) hipLaunchKernelGGL((ln_bwd_kernel<MJ, BF, OC, false, VDK_OPF_F16, NR, HF>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
                                            mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po); \
-                             else hipLaunchKernelGGL((ln_bwd_kernel<MJ, BF, OC>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
+                             else hipLaunchKernelGGL((ln_bwd_kernel<MJ, BF, OC, false, VDK_OPF_BF16, NR, HF>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
                                            mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po); } while (0)
-  // MAXJ = 3 (C <= 768, ViT-B) keeps the kernel at <= 128 VGPRs = 4 blocks per CU: T / 64 = 788 blocks are then ONE round on 256 CUs (at 3 per CU they are two: +45 %)
+#define LNB2(MJ, NR, HF) do { if (ocs) { if (bf) LNB(MJ, true, true, NR, HF); else LNB(MJ, false, true, NR, HF); } \
+                              else { if (bf) LNB(MJ, true, false, NR, HF); else LNB(MJ, false, false, NR, HF); } } while (0)
+  // MAXJ = 3 (C <= 768, ViT-B) keeps the kernel at <= 128 VGPRs = 4 blocks per CU; the narrower rows of the Swin / ConvNeXt stages take two rows per wave and pass
+  // (C <= 128: four, a row being half a wave)
   if (q8) {
     if (!ocs || !bf || opf || !q8->out || (q8->ld & 3)) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: the fp8 copy needs bf16 dy, the column-sum form and ld % 4 == 0");
 #define LNBQ(MJ) hipLaunchKernelGGL((ln_bwd_kernel<MJ, true, true, true>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
@@ -627,11 +655,13 @@ static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const flo
     if (C <= 768) LNBQ(3); else LNBQ(4);
 #undef LNBQ
   }
-  else if (ocs && C <= 768) { if (bf) LNB(3, true, true); else LNB(3, false, true); }
-  else if (ocs) { if (bf) LNB(4, true, true); else LNB(4, false, true); }
-  else if (C <= 768) { if (bf) LNB(3, true, false); else LNB(3, false, false); }
-  else if (C <= 1024) { if (bf) LNB(4, true, false); else LNB(4, false, false); }
-  else { if (bf) LNB(16, true, false); else LNB(16, false, false); }
+  else if (C <= 128) LNB2(1, 2, true);
+  else if (C <= 256) LNB2(1, 2, false);
+  else if (C <= 512) LNB2(2, 2, false);
+  else if (C <= 768) LNB2(3, 1, false);
+  else if (C <= 1024) LNB2(4, 1, false);
+  else { if (bf) LNB(16, true, false, 1, false); else LNB(16, false, false, 1, false); }
+#undef LNB2
 #undef LNB
   if (ocs) *deferred2 = VdkReduceJob{po, (long)C, nb, (long)C, dxb_colsum, 1.0f};
   if (deferred && dbeta == dgamma + C) {      // the caller batches the partial-sum reduction with others (vdk_reduce_rows_batch)

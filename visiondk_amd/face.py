@@ -442,8 +442,8 @@ class FaceTrainStep:
         if precision == "fp32" and shard_head:
             raise NotImplementedError("precision='fp32' with a class-sharded head is not built")
         if not hasattr(self.bb.model, "engine"):
-            raise NotImplementedError("FaceTrainStep needs a backbone with a native engine (ViT, ConvNeXt); the Swin backbone trains through autograd under the reference's own "
-                                      "Trainer (torch optimizer over model.parameters())")
+            raise NotImplementedError("FaceTrainStep needs a backbone with a native engine (ViT, ConvNeXt, Swin with native=True); the autograd-node Swin trains under "
+                                      "the reference's own Trainer (torch optimizer over model.parameters())")
         if precision == "fp32" and not hasattr(self.bb.model.engine, "precision"):
             raise NotImplementedError("precision='fp32' is built for the ConvNeXt backbones of the face / CBIR task (the engine with an fp32-class training mode)")
         self.precision = precision
@@ -525,7 +525,11 @@ class FaceTrainStep:
                 dist.broadcast(b, src=0, group=self.comm.group)
         # forward: backbone engine -> neck (autograd node over the HIP kernels) -> fused head + CE
         out = eng.forward(x)
-        if bb.is_cnn:
+        is_swin = isinstance(eng, swin.SwinEngine)
+        if is_swin:                # the NHWC map goes into the CNN neck as it is (TimmWrapper: the reference reads any 4-D output as [B, channels, h, w])
+            r = int(round(eng.map_rows ** 0.5))
+            feat = out.view(B, r, r, eng.features).detach().requires_grad_(True)
+        elif bb.is_cnn:
             feat = out.view(B, eng.out_hw, eng.out_hw, eng.out_ch).permute(0, 3, 1, 2).detach().requires_grad_(True)
         else:
             feat = out.view(B, eng.tokens, eng.spec.dim).detach().requires_grad_(True)
@@ -543,7 +547,10 @@ class FaceTrainStep:
         if not self.shard_head:
             self.head.weight.grad = dW
         dfeat = feat.grad
-        dfeat = dfeat.permute(0, 2, 3, 1).contiguous().view(-1, eng.out_ch) if bb.is_cnn else dfeat.contiguous().view(-1, eng.spec.dim)
+        if is_swin:
+            dfeat = dfeat.contiguous().view(-1, eng.features)
+        else:
+            dfeat = dfeat.permute(0, 2, 3, 1).contiguous().view(-1, eng.out_ch) if bb.is_cnn else dfeat.contiguous().view(-1, eng.spec.dim)
         if active:
             import torch.distributed as dist
             self.comm.begin_step(eng.grads)

@@ -8,7 +8,12 @@ the library's kernels -- LayerNorm (`vdk_layernorm_fwd/bwd`), every Linear on th
 gradients in the TN form), the 49-token window attention with relative-position bias and shifted-window masks (`vdk_window_attention_fwd/bwd`), the pooled head on the fp32
 MFMA.  The window partition and the cyclic shift are a row index the attention kernels follow (`rowidx`: the token rows stay in image order, no gather copies); patch
 merging is an index permutation.  Arithmetic = the reference's autocast path: bf16 operands,
-fp32 accumulation, fp32 residual stream and master weights.  A native one-call engine like the ViT's (flat parameter space, fused optimizer) is the next step for this family.
+fp32 accumulation, fp32 residual stream and master weights.
+
+Round 4: `SwinTransformer` is now a thin module over the NATIVE engine (csrc/swin_engine.hip: `vdk_swin_forward` / `vdk_swin_backward`, one C call each over a flat
+parameter space, like the ViT engine), so `vit.FusedTrainStep` (fused clip + SGD + EMA, bucketed gradient all-reduce) and `face.FaceTrainStep` drive it.  The first form --
+a torch Module whose arithmetic runs in ~35 autograd nodes per block over the same kernels -- stays as `SwinTransformerAutograd` (`create_model(..., native=False)`): the
+tests require both to produce the same logits and gradients, it is the second implementation the engine is checked against.
 """
 from __future__ import annotations
 
@@ -379,9 +384,9 @@ class SwinStage(nn.Module):
         return t.view(B, H, W, Cc)
 
 
-class SwinTransformer(nn.Module):
-    """drop-in for timm.create_model('swin_*_patch4_window7_224', num_classes=C): forward(x [B, 3, 224, 224]) -> logits [B, C]; num_classes = 0: forward_features, the normed
-    NHWC map [B, 7, 7, C_last] (timm's global_pool='' feature output of this family is NHWC)"""
+class SwinTransformerAutograd(nn.Module):
+    """(first form, kept as the engine's cross-check) timm.create_model('swin_*_patch4_window7_224', num_classes=C) as autograd nodes over the kernels: forward(x [B, 3, 224,
+    224]) -> logits [B, C]; num_classes = 0: forward_features, the normed NHWC map [B, 7, 7, C_last] (timm's global_pool='' feature output of this family is NHWC)"""
 
     def __init__(self, spec: SwinSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None):
         super().__init__()
@@ -445,11 +450,243 @@ class SwinTransformer(nn.Module):
         return _LinearFn.apply(_Pool.apply(f, self.be), self.head.fc.weight, self.head.fc.bias, self.be)
 
 
-def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, img_size: int = 224, device=None, backend=None, seed: Optional[int] = None, **kw) -> SwinTransformer:
-    """timm.create_model(name, pretrained=..., num_classes=...) for the swin_*_patch4_window7_224 family (models/classifier/classify_model.py:49-54)"""
+# =====================================================================================================================================================
+# the native engine
+class SwinEngine:
+    """owns the flat HBM buffers (fp32 master params, bf16 operand copies, grads, workspace) and calls vdk_swin_forward / vdk_swin_backward; the interface of vit.VitEngine
+    (forward -> padded logits, backward(dlogits bf16), refresh_weights, params / grads / wb16 / n_floats / cp), so the fused train steps take either"""
+
+    operand = "bf16"
+    op_dtype = torch.bfloat16
+    fp8 = 0
+
+    def __init__(self, spec: SwinSpec, device=None, backend: Optional[_lib.Backend] = None):
+        from . import _abi
+        self.spec = spec
+        self.be = backend or _lib.load()
+        self.device = torch.device(device if device is not None else ("cuda" if self.be.device_only else "cpu"))
+        cfg = self._cfg(1)
+        nf, nt, ntr = _abi.I64(0), _abi.I32(0), _abi.I64(0)
+        self.be.check(self.be.lib.vdk_swin_param_count(C.byref(cfg), C.byref(nf), C.byref(nt), C.byref(ntr)), "vdk_swin_param_count")
+        self.n_floats, self.n_tensors, self.n_transposed = nf.value, nt.value, ntr.value
+        self.entries = []
+        name = C.create_string_buffer(96)
+        off, numel, ndim = _abi.I64(0), _abi.I64(0), _abi.I32(0)
+        shape = (_abi.I64 * 4)()
+        for i in range(self.n_tensors):
+            self.be.check(self.be.lib.vdk_swin_param_info(C.byref(cfg), i, name, 96, C.byref(off), C.byref(numel), shape, C.byref(ndim)), "vdk_swin_param_info")
+            self.entries.append((name.value.decode(), off.value, numel.value, tuple(shape[j] for j in range(ndim.value))))
+        dev = self.device
+        self.params = torch.zeros(self.n_floats, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(self.n_floats, dtype=torch.float32, device=dev)
+        self.wb16 = torch.zeros(self.n_floats, dtype=torch.bfloat16, device=dev)
+        self.wt16 = torch.zeros(self.n_transposed, dtype=torch.bfloat16, device=dev)
+        self.cp = (spec.num_classes + 7) // 8 * 8
+        nst = len(spec.depths)
+        self.features = spec.embed_dim * 2 ** (nst - 1)
+        self.map_rows = (spec.img_size // 4 // 2 ** (nst - 1)) ** 2      # rows of the final map per image (49 for the 4-stage family at 224)
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_batch = -1
+        self._out: Optional[torch.Tensor] = None
+        self._weights_version = None
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = object.__new__(SwinEngine)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            setattr(new, k, v if k == "be" else copy.deepcopy(v, memo))
+        return new
+
+    def _cfg(self, batch: int):
+        from . import _abi
+        s = self.spec
+        I4 = _abi.I32 * 4
+        pad = lambda t: I4(*(tuple(t) + (0,) * (4 - len(t))))      # shallower members of the family (tests): trailing zeros
+        return _abi.SwinConfig(batch, s.img_size, s.in_chans, s.embed_dim, pad(s.depths), pad(s.heads), s.num_classes, s.ln_eps)
+
+    def _workspace(self, batch: int) -> torch.Tensor:
+        if self._ws is None or self._ws_batch != batch:
+            need = C.c_size_t(0)
+            cfg = self._cfg(batch)
+            self.be.check(self.be.lib.vdk_swin_workspace_bytes(C.byref(cfg), C.byref(need)), "vdk_swin_workspace_bytes")
+            if self._ws is None or self._ws.numel() < need.value:
+                self._ws = None
+                self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+            self._ws_batch = batch
+            shape = (batch, self.cp) if self.cp else (batch * self.map_rows, self.features)
+            self._out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        return self._ws
+
+    def refresh_weights(self, skip_wb16: bool = False) -> None:
+        cfg = self._cfg(1)
+        be = self.be
+        be.check(be.lib.vdk_swin_refresh_weights(C.byref(cfg), be.ptr(self.params), be.ptr(self.wb16), be.ptr(self.wt16), int(skip_wb16), be.stream()), "vdk_swin_refresh_weights")
+        self._weights_version = self.params._version
+
+    def _ensure_fresh(self) -> None:
+        if self._weights_version != self.params._version:
+            self.refresh_weights()
+
+    def fp8_update(self) -> None:      # (protocol of the fused train step: this family has no fp8 mode)
+        pass
+
+    def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        """the tensor `name` (timm key) inside a flat buffer laid out like params (grads, a momentum or EMA buffer of the fused step)"""
+        for n, off, numel, shape in self.entries:
+            if n == name:
+                return flat[off:off + numel].view(shape)
+        raise KeyError(name)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x f32 [B, C, H, W] -> logits f32 [B, Cp] (padded columns beyond num_classes) or, in feature mode, the normed map rows f32 [B * 49, 8 E]"""
+        s = self.spec
+        if x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (s.in_chans, s.img_size, s.img_size):
+            raise ValueError(f"expected float32 [B, {s.in_chans}, {s.img_size}, {s.img_size}], got {tuple(x.shape)} {x.dtype}")
+        x = x.contiguous()
+        B = x.shape[0]
+        ws = self._workspace(B)
+        self._ensure_fresh()
+        cfg = self._cfg(B)
+        be = self.be
+        be.check(be.lib.vdk_swin_forward(C.byref(cfg), be.ptr(x), be.ptr(self.params), be.ptr(self.wb16), be.ptr(ws), ws.numel(), be.ptr(self._out), be.stream()), "vdk_swin_forward")
+        return self._out
+
+    def backward(self, dout: torch.Tensor, on_ready=None) -> torch.Tensor:
+        """dlogits bf16 [B, Cp] (feature mode: f32 [B * 49, 8 E]) -> self.grads (flat fp32, overwritten); needs the workspace of the matching forward"""
+        from . import _abi
+        B = dout.shape[0] if self.cp else dout.shape[0] // self.map_rows
+        assert B == self._ws_batch and dout.is_contiguous()
+        assert (dout.dtype == torch.bfloat16 and dout.shape[1] == self.cp) if self.cp else (dout.dtype == torch.float32 and dout.shape[1] == self.features)
+        cfg = self._cfg(B)
+        be = self.be
+        cb = _abi.GRAD_READY_FN(lambda user, off, n: on_ready(off, n)) if on_ready is not None else _abi.GRAD_READY_FN(0)
+        be.check(be.lib.vdk_swin_backward(C.byref(cfg), be.ptr(dout), be.ptr(self.params), be.ptr(self.wb16), be.ptr(self.wt16), be.ptr(self._ws), self._ws.numel(),
+                                          be.ptr(self.grads), cb, None, be.stream()), "vdk_swin_backward")
+        return self.grads
+
+
+class _SwinFunction(torch.autograd.Function):
+    """model(x) as ONE autograd node: forward = vdk_swin_forward, backward = vdk_swin_backward"""
+
+    @staticmethod
+    def forward(ctx, x, module, *params):
+        eng = module.engine
+        module._sync_flat()
+        out = eng.forward(x)
+        ctx.module = module
+        if eng.cp == 0:
+            r = int(round(eng.map_rows ** 0.5))
+            return out.view(x.shape[0], r, r, eng.features).clone()
+        return out[:, :eng.spec.num_classes].clone()
+
+    @staticmethod
+    def backward(ctx, dout):
+        module = ctx.module
+        eng = module.engine
+        be = eng.be
+        if eng.cp == 0:
+            g = eng.backward(dout.contiguous().view(-1, eng.features))
+        else:
+            B, Cn = dout.shape
+            stage = torch.zeros((B, eng.cp), dtype=torch.float32, device=dout.device)
+            stage[:, :Cn].copy_(dout)
+            dl = torch.empty((B, eng.cp), dtype=torch.bfloat16, device=dout.device)
+            be.check(be.lib.vdk_cast_f32_bf16(be.ptr(stage), be.ptr(dl), stage.numel(), be.stream()), "vdk_cast_f32_bf16")
+            g = eng.backward(dl)
+        grads = tuple(g[off:off + numel].view(shape) for (_, off, numel, shape) in eng.entries)
+        return (None, None) + grads
+
+
+class SwinTransformer(nn.Module):
+    """Drop-in for the object `timm.create_model('swin_*_patch4_window7_224', pretrained=False, num_classes=C)` hands the reference, on the native engine.  The module tree
+    mirrors timm's (patch_embed.proj / norm, layers.i.downsample.{norm, reduction}, layers.i.blocks.j.{norm1, attn.{relative_position_bias_table, qkv, proj}, norm2,
+    mlp.{fc1, fc2}}, norm, head.fc) with parameter-only holders, so named_parameters() / state_dict() / load_state_dict() carry timm's key names; every Parameter is a view
+    into the engine's flat fp32 buffer.  forward(x [B, 3, 224, 224]) -> logits [B, C]; num_classes = 0: the normed NHWC map [B, 7, 7, C_last] (timm's forward_features)."""
+
+    def __init__(self, spec: SwinSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None):
+        super().__init__()
+        self.spec = spec
+        self.engine = SwinEngine(spec, device=device, backend=backend)
+        self.be = self.engine.be
+        self.num_classes = spec.num_classes
+        self.num_features = self.engine.features
+        self._plist = []
+        for name, off, numel, shape in self.engine.entries:
+            p = nn.Parameter(self.engine.params[off:off + numel].view(shape))
+            parts = name.split(".")
+            m = self
+            for part in parts[:-1]:
+                if part not in m._modules:
+                    m.add_module(part, _Holder())
+                m = m._modules[part]
+            m.register_parameter(parts[-1], p)
+            self._plist.append((name, p))
+        self.reset_parameters(seed)
+
+    def reset_parameters(self, seed: Optional[int] = None) -> None:
+        """timm's defaults + the reference's override after them (classify_model.py:70-81): N(0, 0.02) for every Conv2d / Linear weight, zeros for Linear bias (the
+        convolution's bias keeps its default), LayerNorm (1, 0), relative_position_bias_table trunc_normal(0.02)"""
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(seed if seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
+        s = self.spec
+        with torch.no_grad():
+            for name, p in self._plist:
+                if name.endswith("norm.weight") or name.endswith("norm1.weight") or name.endswith("norm2.weight"):
+                    v = torch.ones(p.shape)
+                elif name.endswith("relative_position_bias_table"):
+                    v = torch.empty(p.shape).normal_(0, 0.02, generator=gen).clamp_(-2.0, 2.0)
+                elif name == "patch_embed.proj.bias":
+                    bound = 1.0 / (s.in_chans * 16) ** 0.5
+                    v = (torch.rand(p.shape, generator=gen) * 2 - 1) * bound
+                elif name.endswith(".bias"):
+                    v = torch.zeros(p.shape)
+                else:
+                    v = torch.empty(p.shape).normal_(0, 0.02, generator=gen)
+                p.copy_(v.to(p.device))
+
+    def _sync_flat(self) -> None:
+        eng = self.engine
+        base = eng.params.data_ptr()
+        for (name, off, numel, shape), (_, p) in zip(eng.entries, self._plist):
+            if p.data_ptr() != base + off * 4:
+                with torch.no_grad():
+                    eng.params[off:off + numel].view(shape).copy_(p.detach().to(eng.device))
+                    p.data = eng.params[off:off + numel].view(shape)
+
+    def _apply(self, fn, recurse=True):
+        probe = fn(torch.zeros(1, dtype=torch.float32, device=self.engine.device))
+        if probe.device != self.engine.device or probe.dtype != torch.float32:
+            if probe.dtype != torch.float32:
+                raise RuntimeError("visiondk_amd Swin keeps fp32 master weights; bf16 copies are internal")
+            if self.engine.be.device_only and probe.device.type != "cuda":
+                raise RuntimeError("visiondk_amd Swin lives on the GPU (no CPU fallback)")
+            eng = self.engine
+            eng.device = probe.device
+            for attr in ("params", "grads", "wb16", "wt16"):
+                setattr(eng, attr, getattr(eng, attr).to(probe.device))
+            eng._ws, eng._ws_batch, eng._weights_version = None, -1, None
+            for (name, off, numel, shape), (_, p) in zip(eng.entries, self._plist):
+                p.data = eng.params[off:off + numel].view(shape)
+        return self
+
+    def forward_features(self, x: torch.Tensor) -> torch.Tensor:
+        if self.num_classes != 0:
+            raise RuntimeError("forward_features: build the model with num_classes=0 (the feature model TimmWrapper asks for)")
+        return self.forward(x)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return _SwinFunction.apply(x, self, *[p for _, p in self._plist])
+
+
+def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, img_size: int = 224, device=None, backend=None, seed: Optional[int] = None,
+                 native: bool = True, **kw):
+    """timm.create_model(name, pretrained=..., num_classes=...) for the swin_*_patch4_window7_224 family (models/classifier/classify_model.py:49-54); native=False: the
+    autograd-node form of round 3 (the engine's cross-check)"""
     name = name[5:] if name.startswith("timm-") else name
     if name not in TIMM_SWINS:
         raise KeyError(f"unknown Swin id {name!r}: {sorted(TIMM_SWINS)}")
     if pretrained:
         raise RuntimeError("there is no network here: load a checkpoint with load_state_dict (timm names)")
-    return SwinTransformer(SwinSpec(img_size=img_size, num_classes=num_classes, **TIMM_SWINS[name]), device=device, backend=backend, seed=seed)
+    cls = SwinTransformer if native else SwinTransformerAutograd
+    return cls(SwinSpec(img_size=img_size, num_classes=num_classes, **TIMM_SWINS[name]), device=device, backend=backend, seed=seed)
