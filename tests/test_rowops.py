@@ -192,10 +192,10 @@ def test_batchnorm_rows_fwd_bwd(be, dev, B, F):
     torch.testing.assert_close(ye.cpu(), bn(x).detach(), rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("S,n", [(37, 130), (1024, 200), (2500, 72)])
+@pytest.mark.parametrize("S,n", [(37, 130), (256, 40), (1004, 1024), (1024, 200), (2047, 50), (2500, 72)])
 def test_batch_reduction_folds_tall_jobs(be, dev, S, n):
-    """the engines' batched row reduction: from 1024 partial rows on, the rows are folded onto the first 64 in place (more workgroups than the n / 64 of the final sum);
-    against a float64 sum, and bit-reproducible"""
+    """the engines' batched row reduction: 256 .. 2047 partial rows go to the 16-column x 32-row-group form, from 2048 on the rows are folded onto the first 64 in place
+    (more workgroups than the n / 64 of the final sum); against a float64 sum, and bit-reproducible"""
     torch.manual_seed(S)
     ld = n + 6
     src = torch.randn(S, ld)

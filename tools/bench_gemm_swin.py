@@ -32,12 +32,15 @@ def main():
     dt = torch.bfloat16
     res = []
     stages = [(401408, 128, 2), (100352, 256, 2), (25088, 512, 18), (6272, 1024, 2)]
+    only = sys.argv[3] if len(sys.argv) > 3 else None          # e.g. "tn": only the weight-gradient forms
     tot_auto = tot_best = 0.0
     for T, C, nblk in stages:
         shapes = [("qkv", T, 3 * C, C, "bias"), ("proj", T, C, C, "res"), ("fc1", T, 4 * C, C, "gelu"), ("fc2", T, C, 4 * C, "res"), ("dfc2", T, 4 * C, C, "dgelu"),
                   ("dfc1", T, C, 4 * C, "plain"), ("dproj", T, C, C, "plain"), ("dqkv", T, C, 3 * C, "plain"),
                   ("wg_qkv", 3 * C, C, T, "tn"), ("wg_proj", C, C, T, "tn"), ("wg_fc1", 4 * C, C, T, "tn"), ("wg_fc2", C, 4 * C, T, "tn")]
         for name, M, N, K, ep in shapes:
+            if only and ep != only:
+                continue
             torch.manual_seed(0)
             trans = ep == "tn"
             if trans:
@@ -60,8 +63,9 @@ def main():
             variants = {}
             if trans:
                 r = tn_rule(M, N, K)
-                for s in sorted({max(1, r // 2), r, min(64, r * 2), min(64, r * 4)}):
+                for s in sorted({max(1, r // 2), r, min(64, r * 2)}):
                     variants[f"tn_split{s}" + ("(rule)" if s == r else "")] = (0, {"trans": True, "splitk": s})
+                    variants[f"tn_k6_split{s}"] = (6, {"trans": True, "splitk": s})
             else:
                 for kern, lab in ((0, "auto"), (1, "k1_128x128"), (5, "k5_w4"), (6, "k6_w4h")):
                     variants[lab] = (kern, kw)

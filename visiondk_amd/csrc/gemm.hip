@@ -691,6 +691,8 @@ static bool w4_enabled_env() {
 }
 // ... and which problems go to the 256x128 / two-workgroups-per-CU form instead (gemm_w4h_kernel): the ones whose epilogue is long -- a second resident workgroup
 // multiplies meanwhile -- and short problems with few tiles per CU.  VDK_GEMM_W4H (optional): explicit bit mask over {1: GELU, 2: dGELU, 4: residual, 8: other NT, 16: TN}.
+static thread_local int t_tn_half = 0;
+void vdk_gemm_tn_prefer_half(int on) { t_tn_half = on; }
 static bool w4h_wanted(int E, bool trans, long M, long N, long K) {
   static const int mask = getenv("VDK_GEMM_W4H") ? atoi(getenv("VDK_GEMM_W4H")) : -1;
   if (g_force_kernel == 6) return true;
@@ -706,11 +708,13 @@ static bool w4h_wanted(int E, bool trans, long M, long N, long K) {
   // default, from tools/bench_gemm_w4.py at the ViT-B/16 shapes (T = 50 432; us, persistent four-wave / 256x128 two-workgroup form):
   //   dGELU + column sums 393 / 335 -> 256x128;  GELU + saved pre-activation 327 / 336 -> four-wave;  fp32 residual: K 768 111 / 105, K 3072 239 / 255 -> by K;
   //   light epilogues: N 768 K 768 63 / 56 -> 256x128 when the k-range is short and every CU gets at most ~3 tiles, else four-wave (158-205 / 162-221);  TN -> four-wave
-  if (trans || E == E_GENERIC) return false;
+  if (trans) return t_tn_half != 0;
+  if (E == E_GENERIC) return false;
   const long tiles = ((M + 255) / 256) * ((N + 255) / 256);
-  // round 4, tools/bench_gemm_swin.py (swin_base at batch 128; us, four-wave / 256x128): fewer 256x256 tiles than CUs -> the half tiles are twice the parallelism
-  // (6 272 rows, stage 4: N 1024 K 4096 69 / 51, N 1024 K 1024 29 / 22, N 3072 -> 1024 52 / 39), whatever the epilogue
-  if (tiles < 256) return true;
+  // round 4, tools/bench_gemm_swin.py (swin_base at batch 128; us, four-wave / 256x128): fewer 256x256 tiles than HALF the CUs -> the half tiles are twice the parallelism
+  // (6 272 rows, stage 4: N 1024 K 4096 69 / 51, N 1024 K 1024 29 / 22, N 3072 -> 1024 52 / 39), whatever the epilogue.  (196 tiles -- 25 088 x 512 -- still prefer the
+  // four-wave kernel when K is long: K 2048 49 / 53, in the step 50 / 66.)
+  if (tiles < 128) return true;
   if (E & E_DGELU) return true;
   // GELU: the four-wave kernel's whole-tile rounds against hardware-dispatched half tiles -- 25 088 x 2048 x 512 (stage 3) is 784 tiles = 3.06 rounds, 99 / 90 us
   if (E & E_GELU) return K <= 768 && (double)tiles / (double)((tiles + 255) / 256 * 256) < 0.8;

@@ -286,6 +286,33 @@ __global__ __launch_bounds__(512) void reduce_rows_batch_kernel(ReduceBatch b) {
     jb.out[c] = (((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]))) * jb.scale;
 }
 
+// The same for jobs of several hundred to a few thousand partial rows (the LayerNorm backward leaves one per workgroup: ~1000): 16 columns x 32 row groups per workgroup,
+// four loads in flight per thread -- S = 1004 is 8 dependent steps instead of the 63 of the form above (28 us -> launch-latency floor).  first_block counts 16-column blocks.
+__global__ __launch_bounds__(512) void reduce_rows_batch_tall_kernel(ReduceBatch b) {
+  __shared__ float red[32][17];
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.first_block[j + 1]) ++j;
+  const VdkReduceJob jb = b.job[j];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const long c = (long)((int)blockIdx.x - b.first_block[j]) * 16 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < jb.n) {
+    int k = rg;
+    for (; k + 96 < jb.S; k += 128) {
+      s0 += jb.in[(long)k * jb.ld + c]; s1 += jb.in[(long)(k + 32) * jb.ld + c]; s2 += jb.in[(long)(k + 64) * jb.ld + c]; s3 += jb.in[(long)(k + 96) * jb.ld + c];
+    }
+    for (; k < jb.S; k += 32) s0 += jb.in[(long)k * jb.ld + c];
+  }
+  red[rg][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && c < jb.n) {
+    float t[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t[g] = (red[4 * g][cl] + red[4 * g + 1][cl]) + (red[4 * g + 2][cl] + red[4 * g + 3][cl]);
+    jb.out[c] = (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) * jb.scale;
+  }
+}
+
 // A TALL job (thousands of partial rows: the column-sum by-product of a GEMM over 1.6 M rows leaves 12 544 of them) is folded first: row g < 64 of the partial buffer
 // becomes the sum of the rows g, g + 64, g + 128, ... (in place: block (columns, g) reads and writes only rows = g mod 64), 64 x n / 64 workgroups instead of the
 // n / 64 of the batch kernel, whose threads would each walk S / 8 rows with two loads in flight (376 us for 25 MB).  The order of the sum is fixed: bit-reproducible.
@@ -612,6 +639,8 @@ static inline int ln_bwd_blocks(int T, int C) {
   const int slots = C <= 768 ? 1024 : 768;
   if (nb > slots) nb = slots;
   if (nb < 1) nb = 1;
+  const int rpb = (T + nb - 1) / nb;
+  nb = (T + rpb - 1) / rpb;        // no empty blocks: their zero partial rows would only lengthen the reduction (25 088 rows: 1004 blocks of 25, not 1024)
   return nb;
 }
 int vdk_layernorm_bwd_workspace_bytes(int32_t T, int32_t C, size_t* bytes) {
@@ -813,20 +842,27 @@ int vdk_reduce_rows_batch(const VdkReduceJob* jobs, int n, void* stream) {
   for (int i0 = 0; i0 < n; i0 += 8) {
     ReduceBatch b;
     b.n = 0;
+    int maxS = 0;
+    for (int i = i0; i < n && i < i0 + 8; ++i) if (jobs[i].in && jobs[i].n > 0 && jobs[i].S > maxS) maxS = jobs[i].S;
+    const bool tall = maxS >= 4 * RR_FOLD && maxS < 32 * RR_FOLD;      // 256 .. 2047 partial rows: the 32-row-group form; beyond: fold first (below)
+    const int cw = tall ? 16 : 64;
     int blocks = 0;
-    for (int i = i0; i < n && b.n < 8; ++i) {
+    for (int i = i0; i < n && i < i0 + 8; ++i) {
       if (!jobs[i].in || jobs[i].n <= 0) continue;
       b.first_block[b.n] = blocks;
       VdkReduceJob jb = jobs[i];
-      if (jb.S >= 16 * RR_FOLD) {      // tall: fold the partial rows (scratch of the caller) onto the first 64, in place
+      if (!tall && jb.S >= 16 * RR_FOLD) {      // very tall: fold the partial rows (scratch of the caller) onto the first 64, in place
         hipLaunchKernelGGL(reduce_rows_fold_kernel, dim3((unsigned)((jb.n + 63) / 64), RR_FOLD), dim3(512), 0, (hipStream_t)stream, (float*)jb.in, (long)jb.ld, (int)jb.S, (long)jb.n);
         jb.S = RR_FOLD;
       }
       b.job[b.n++] = jb;
-      blocks += (int)((jobs[i].n + 63) / 64);
+      blocks += (int)((jobs[i].n + cw - 1) / cw);
     }
     b.first_block[b.n] = blocks;
-    if (blocks > 0) hipLaunchKernelGGL(reduce_rows_batch_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, b);
+    if (blocks > 0) {
+      if (tall) hipLaunchKernelGGL(reduce_rows_batch_tall_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, b);
+      else hipLaunchKernelGGL(reduce_rows_batch_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, b);
+    }
   }
   return vdk_check_launch("vdk_reduce_rows_batch");
 }

@@ -25,6 +25,13 @@
 #include "vdk_host.h"
 #include "vdk_gemm.h"
 
+// window_attention.hip, in-library forms: bias tile prepared once per block and step from the table, kept for the backward; d(table) from the fragment-order d(bias)
+size_t vdk_wa_bm_bytes(int32_t nW, int32_t H);
+size_t vdk_wa_bwd_scratch_bytes(int64_t windows, int32_t H);
+int vdk_wa_prep_table(const float* table, const float* mask, int32_t nW, int32_t H, float* bm, void* stream);
+int vdk_wa_fwd_bm(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, const float* bm, int32_t nWm, int64_t windows, int32_t H, float scale, const int32_t* rowidx, void* stream);
+int vdk_wa_bwd_bm(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, const float* bm, int32_t nWm, int64_t windows, int32_t H, float scale,
+                  const int32_t* rowidx, void* dqkv, int64_t ldd, void* scratch, size_t scratch_bytes, const int32_t* uses, int32_t R, int32_t U, float* dtable, void* stream);
 extern "C" {
 int vdk_layernorm_fwd(const float*, int64_t, int32_t, int32_t, const float*, const float*, float, void*, int64_t, int32_t, float*, float*, void*);
 int vdk_layernorm_bwd_workspace_bytes(int32_t, int32_t, size_t*);
@@ -179,6 +186,24 @@ int wgrad_splitk_tn(int M, int N, int K) {      // (vit_engine.hip's rule: tiles
   if (s < 1) s = 1;
   return s;
 }
+// ... and which of them run on the 256x128 two-workgroup kernel with the split count of ITS tiles (tools/bench_gemm_swin.py, swin_base at batch 128; us, four-wave at its
+// rule / half-tile form): outputs of at most one whole tile's worth of elements, where a 256x256 tile is mostly padding (128 x 128 over 401 408 rows 117 / 76, 384 x 128
+// 140 / 125, 256 x 256 over 100 352 rows 52 / 45), and outputs so large that the slabs' write + re-read weighs more than the parallelism of many splits (2048 x 512 over
+// 25 088 rows 66 / 59, 4096 x 1024 over 6 272 rows 67 / 59, 3072 x 1024 56 / 49); in between the four-wave kernel keeps them (1536 x 512 56 / 57, 1024 x 256 81 / 110)
+bool wgrad_tn_half(int M, int N) {
+  const long mn = (long)M * N;
+  return mn <= 65536 || mn >= (1L << 20);
+}
+int wgrad_splitk_tn_half(int M, int N, int K) {
+  const int tiles = ((M + 255) / 256) * ((N + 127) / 128);
+  int s = 256 / tiles;
+  const int kt = K / 64;
+  if (s > kt / 4) s = kt / 4;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  return s;
+}
+int wgrad_tn_splits(int M, int N, int K) { return wgrad_tn_half(M, N) ? wgrad_splitk_tn_half(M, N, K) : wgrad_splitk_tn(M, N, K); }
 int wgrad_splitk(int M, int N, int K) {
   if (K < 4096) return 1;
   int tiles = ((M + 127) / 128) * ((N + 127) / 128);
@@ -210,14 +235,15 @@ void sw_plan(const SwDims& d, WsPlan* w) {
       if (T * C4 > maxTD) maxTD = T * C4;
       size_t ln = 0; vdk_layernorm_bwd_workspace_bytes((int)T, (int)C4, &ln); if (ln > lnmax) lnmax = ln;
       if (C4 > trows) trows = C4;
-      { int k1 = wgrad_splitk((int)C, (int)C4, (int)up(T, 64)), k2 = wgrad_splitk_tn((int)C, (int)C4, (int)T); size_t b = (size_t)(k1 > k2 ? k1 : k2) * C * C4 * 4; if (b > sl) sl = b; }
+      { int k1 = wgrad_splitk((int)C, (int)C4, (int)up(T, 64)), k2 = wgrad_tn_splits((int)C, (int)C4, (int)T); size_t b = (size_t)(k1 > k2 ? k1 : k2) * C * C4 * 4; if (b > sl) sl = b; }
     }
     s.blk.resize(d.depth[i]);
     for (int j = 0; j < d.depth[i]; ++j) {
       BlkW& b = s.blk[j];
       b.x = w_take(cur, T * C * 4); b.xmid = w_take(cur, T * C * 4); b.stats = w_take(cur, T * 4 * 4);
       b.h1 = w_take(cur, T * C * 2); b.qkv = w_take(cur, T * 3 * C * 2); b.lse = w_take(cur, T * H * 4); b.o = w_take(cur, T * C * 2);
-      b.h2 = w_take(cur, T * C * 2); b.u = w_take(cur, T * M * 2); b.g = w_take(cur, T * M * 2); b.bias = w_take(cur, H * SW_N * SW_N * 4);
+      b.h2 = w_take(cur, T * C * 2); b.u = w_take(cur, T * M * 2); b.g = w_take(cur, T * M * 2);
+      b.bias = w_take(cur, vdk_wa_bm_bytes(((j & 1) && d.res[i] > SW_WS) ? (int)nW : 0, (int)H));       // bias (+ shift mask) in the attention kernels' fragment order
     }
     s.xout = w_take(cur, T * C * 4);
     if (T * C > maxTD) maxTD = T * C;
@@ -227,19 +253,18 @@ void sw_plan(const SwDims& d, WsPlan* w) {
     if ((long)up(T, 64) > tcols) tcols = (long)up(T, 64);
     if (M > trows) trows = M;
     const int sh[4][2] = {{(int)M, (int)C}, {(int)C, (int)M}, {3 * (int)C, (int)C}, {(int)C, (int)C}};
-    for (auto& q : sh) { int k1 = wgrad_splitk(q[0], q[1], (int)up(T, 64)), k2 = wgrad_splitk_tn(q[0], q[1], (int)T); size_t b = (size_t)(k1 > k2 ? k1 : k2) * q[0] * q[1] * 4; if (b > sl) sl = b; }
+    for (auto& q : sh) { int k1 = wgrad_splitk(q[0], q[1], (int)up(T, 64)), k2 = wgrad_tn_splits(q[0], q[1], (int)T); size_t b = (size_t)(k1 > k2 ? k1 : k2) * q[0] * q[1] * 4; if (b > sl) sl = b; }
     size_t ln = 0; vdk_layernorm_bwd_workspace_bytes((int)T, (int)C, &ln); if (ln > lnmax) lnmax = ln;
     size_t cs = 0; vdk_colsum_bf16_workspace_bytes((int)T, (int)M, &cs); if (cs > csmax) csmax = cs;
     { size_t c3 = (size_t)2 * ((T + 255) / 256) * M * 4; if (c3 > csmax) csmax = c3; }
-    size_t wa = 0; vdk_window_attention_bwd_workspace_bytes((int64_t)(T / SW_N), d.res[i] > SW_WS ? nW : 0, (int)H, &wa); if (wa > wamax) wamax = wa;
-    size_t wf = 0; vdk_window_attention_fwd_workspace_bytes(d.res[i] > SW_WS ? nW : 0, (int)H, &wf); if (wf > wamax) wamax = wf;
+    const size_t wa = vdk_wa_bwd_scratch_bytes((int64_t)(T / SW_N), (int)H); if (wa > wamax) wamax = wa;
   }
   const size_t T3 = (size_t)d.T[d.nst - 1], D = d.dim[d.nst - 1];
   w->fmap = w_take(cur, T3 * D * 4); w->fstats = w_take(cur, T3 * 2 * 4);
   w->pooled = w_take(cur, (size_t)d.B * D * 4); w->hf = w_take(cur, (size_t)d.Bp * D * 2);
   // the patch embedding's LayerNorm backward and weight gradient
   { size_t ln = 0; vdk_layernorm_bwd_workspace_bytes((int)d.T[0], d.E, &ln); if (ln > lnmax) lnmax = ln;
-    int k1 = wgrad_splitk(d.E, d.Kpe, (int)up(d.T[0], 64)), k2 = wgrad_splitk_tn(d.E, d.Kpe, (int)d.T[0]); size_t b = (size_t)(k1 > k2 ? k1 : k2) * d.E * d.Kpe * 4; if (b > sl) sl = b;
+    int k1 = wgrad_splitk(d.E, d.Kpe, (int)up(d.T[0], 64)), k2 = wgrad_tn_splits(d.E, d.Kpe, (int)d.T[0]); size_t b = (size_t)(k1 > k2 ? k1 : k2) * d.E * d.Kpe * 4; if (b > sl) sl = b;
     size_t cs = 0; vdk_colsum_bf16_workspace_bytes((int)d.T[0], d.E, &cs); if (cs > csmax) csmax = cs;
     if ((size_t)d.Kpe > trows) trows = d.Kpe; }
   if (d.C > 0) {
@@ -341,8 +366,12 @@ int linear_wgrad(hipStream_t s, const WsPlan& w, char* base, const bf16_t* dY, i
   if ((rows % 64) == 0 && (out % 8) == 0 && (in % 8) == 0 && out >= 8 && in >= 8) {
     VdkGemmDesc g = {};
     g.A = dY; g.lda = lddy; g.B = Xa; g.ldb = ldx; g.C = dW; g.ldc = in; g.M = out; g.N = in; g.K = rows; g.c_dtype = VDK_F32; g.alpha = 1.0f;
-    g.splitk = wgrad_splitk_tn(out, in, rows); g.trans = 1;
-    RC(vdk_gemm_bf16_nt(&g, base + w.slabs, w.slabs_bytes, s));
+    const bool half = wgrad_tn_half(out, in);
+    g.splitk = wgrad_tn_splits(out, in, rows); g.trans = 1;
+    vdk_gemm_tn_prefer_half(half ? 1 : 0);
+    const int rc = vdk_gemm_bf16_nt(&g, base + w.slabs, w.slabs_bytes, s);
+    vdk_gemm_tn_prefer_half(0);
+    RC(rc);
     if (db) RC(vdk_colsum_16(dY, lddy, rows, out, db, base + w.csws + 5 * w.csws_bytes, w.csws_bytes, VDK_OPF_BF16, s));
     return VDK_OK;
   }
@@ -462,9 +491,9 @@ int vdk_swin_forward(const VdkSwinConfig* cfg, const float* x, const float* para
       // x = x + proj(W-MSA(norm1(x)))
       RC(vdk_layernorm_fwd(xin, C, T, C, params + b.n1w, params + b.n1b, d.eps, h1, C, VDK_BF16, st, st + T, s));
       RC(gemm(s, h1, C, wb + b.qkv_w, C, qkv, 3 * C, T, 3 * C, C, VDK_BF16, params + b.qkv_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));
-      hipLaunchKernelGGL(swin_bias_gather_kernel, dim3((unsigned)((H * SW_N * SW_N + 255) / 256)), dim3(256), 0, s, params + b.table, H, bias);
-      RC(vdk_window_attention_fwd(qkv, 3 * C, o, C, (float*)(base + bw.lse), bias, shifted ? (const float*)(base + sw_.mask) : nullptr, shifted ? nW : 0, (int64_t)(T / SW_N), H, SW_N,
-                                  32, 0.17677669529663687f /* 32^-0.5 */, (const int32_t*)(base + (shifted ? sw_.rowidx3 : sw_.rowidx0)), base + w.waws, w.waws_bytes, s));
+      RC(vdk_wa_prep_table(params + b.table, shifted ? (const float*)(base + sw_.mask) : nullptr, shifted ? nW : 0, H, bias, s));
+      RC(vdk_wa_fwd_bm(qkv, 3 * C, o, C, (float*)(base + bw.lse), bias, shifted ? nW : 1, (int64_t)(T / SW_N), H, 0.17677669529663687f /* 32^-0.5 */,
+                       (const int32_t*)(base + (shifted ? sw_.rowidx3 : sw_.rowidx0)), s));
       RC(gemm(s, o, C, wb + b.proj_w, C, xmid, C, T, C, C, VDK_F32, params + b.proj_b, xin, C, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));
       // x = x + fc2(gelu(fc1(norm2(x))))
       RC(vdk_layernorm_fwd(xmid, C, T, C, params + b.n2w, params + b.n2b, d.eps, h2, C, VDK_BF16, st + 2 * (size_t)T, st + 3 * (size_t)T, s));
@@ -546,7 +575,9 @@ int vdk_swin_backward(const VdkSwinConfig* cfg, const void* dout, const float* p
       float* part1 = (float*)csws(0);
       RC(gemm(s, dxab, C, wt + b.t2, C, du, M, T, M, C, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_DGELU, u, M, 1, nullptr, 0, fo ? part1 : nullptr));   // du
       if (fo) jobs[nj++] = VdkReduceJob{part1, (long)M, xrow, (long)M, grads + b.fc1_b, 1.0f};
-      RC(linear_wgrad(s, w, base, dxab, C, g, M, T, C, M, grads + b.fc2_w, grads + b.fc2_b));
+      // fc2.bias = column sums of dxab: a by-product of the LayerNorm backward that stored it (norm1 of the block after this one, below), except for a stage's last block
+      const bool fc2b_done = C <= 1024 && j + 1 < d.depth[i];
+      RC(linear_wgrad(s, w, base, dxab, C, g, M, T, C, M, grads + b.fc2_w, fc2b_done ? nullptr : grads + b.fc2_b));
       RC(gemm(s, du, M, wt + b.t1, M, dsm, C, T, C, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));   // dh2
       RC(linear_wgrad(s, w, base, du, M, h2, C, T, M, C, grads + b.fc1_w, fo ? nullptr : grads + b.fc1_b));
       // norm2 backward + the shortcut: dxm / dxmb = dL/dx_mid; proj.bias = column sums of the bf16 copy it stores
@@ -557,17 +588,17 @@ int vdk_swin_backward(const VdkSwinConfig* cfg, const void* dout, const float* p
       // attention branch
       RC(gemm(s, dxmb, C, wt + b.tp, C, dsm, C, T, C, C, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));   // do
       RC(linear_wgrad(s, w, base, dxmb, C, o, C, T, C, C, grads + b.proj_w, ocs ? nullptr : grads + b.proj_b));
-      RC(vdk_window_attention_bwd(qkv, 3 * C, o, dsm, C, (const float*)(base + bw.lse), (const float*)(base + bw.bias), shifted ? (const float*)(base + sw_.mask) : nullptr,
-                                  shifted ? nW : 0, (int64_t)(T / SW_N), H, SW_N, 32, 0.17677669529663687f, (const int32_t*)(base + (shifted ? sw_.rowidx3 : sw_.rowidx0)), dqkv, 3 * C,
-                                  dbias, base + w.waws, w.waws_bytes, s));
-      RC(vdk_relpos_bias_table_grad(dbias, (const int32_t*)(base + w.uses), SW_NREL, SW_N, H, SW_N * SW_N, grads + b.table, s));
+      RC(vdk_wa_bwd_bm(qkv, 3 * C, o, dsm, C, (const float*)(base + bw.lse), (const float*)(base + bw.bias), shifted ? nW : 1, (int64_t)(T / SW_N), H, 0.17677669529663687f,
+                       (const int32_t*)(base + (shifted ? sw_.rowidx3 : sw_.rowidx0)), dqkv, 3 * C, base + w.waws, w.waws_bytes, (const int32_t*)(base + w.uses), SW_NREL, SW_N,
+                       grads + b.table, s));
       RC(vdk_colsum_bf16_deferred(dqkv, 3 * C, T, 3 * C, grads + b.qkv_b, csws(2), w.csws_bytes, s, &jobs[nj], nullptr, VDK_OPF_BF16)); ++nj;
       RC(gemm(s, dqkv, 3 * C, wt + b.tq, 3 * C, dsm, C, T, C, 3 * C, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));   // dh1
       RC(linear_wgrad(s, w, base, dqkv, 3 * C, h1, C, T, 3 * C, C, grads + b.qkv_w, nullptr));
       // norm1 backward + the shortcut: dxa / dxab = dL/dx_in (= dL/dx_out of the block before)
+      const bool ocs1 = ocs && j > 0;      // dxab = dL/dx_out of block j - 1: its column sums are that block's fc2.bias gradient
       RC(vdk_layernorm_bwd_deferred(dsm, C, VDK_BF16, xin, C, st, st + T, params + b.n1w, dxm, C, T, C, dxa, C, dxab, C, grads + b.n1w, grads + b.n1b, lnws1, w.lnws_bytes, s,
-                                    &jobs[nj]));
-      ++nj;
+                                    &jobs[nj], ocs1 ? grads + sp.blk[j - 1].fc2_b : nullptr, ocs1 ? &jobs[nj + 1] : nullptr));
+      nj += ocs1 ? 2 : 1;
       RC(vdk_reduce_rows_batch(jobs, nj, s));
       if (on_ready) {
         const int64_t lo = b.n1w;

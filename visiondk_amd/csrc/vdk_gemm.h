@@ -39,6 +39,9 @@ struct GemmParams {
 // in-library launcher (no descriptor copy through the C ABI)
 extern "C" int vdk_gemm_bf16_nt(const VdkGemmDesc* d, void* ws, size_t ws_bytes, void* stream);
 extern "C" int vdk_transpose_bf16(const void* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, int32_t Rpad, int32_t in_row_group, float* colsum_partial, void* stream);
+// in-library hint for the NEXT TN (trans = 1) problems of this thread: 1 = the 256x128 two-workgroup kernel where it serves, 0 = the dispatcher's own choice (four-wave).
+// The Swin engine's weight gradients use it (tools/bench_gemm_swin.py: with half the splits the half-tile form wins for tiny and for very large outputs).
+void vdk_gemm_tn_prefer_half(int on);
 int vdk_transpose_16(const void* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, int32_t Rpad, int32_t in_row_group, float* colsum_partial, int opf, void* stream);
 
 // gemm_w4.hip: the 4-wave (one wave per SIMD) 256x256 kernel.  serves(): the problem fits its 32-bit buffer offsets and asks for no by-product it lacks.

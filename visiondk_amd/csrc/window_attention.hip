@@ -44,6 +44,22 @@ __global__ __launch_bounds__(256) void wa_prep_bias_kernel(const float* __restri
   if (q < WA_N && key < WA_N) { v = bias[((long)h * WA_N + q) * WA_N + key]; if (mask) v += mask[(wm * WA_N + q) * WA_N + key]; }
   bm[i] = v;
 }
+// the same straight from the relative-position table [169][H] (bias[h][q][key] = table[index(q, key)][h], timm's gather per forward): the Swin engine's form, one launch
+// per block and forward; the backward reads the prepared tile again
+__global__ __launch_bounds__(256) void wa_prep_table_kernel(const float* __restrict__ table, const float* __restrict__ mask, int nWm, int H, float* __restrict__ bm) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)nWm * H * WA_FRAG) return;
+  const int r = (int)(i & 15), lane = (int)((i >> 4) & 63), kt = (int)((i >> 10) & 1), qt = (int)((i >> 11) & 1);
+  const long wh = i >> 12; const int h = (int)(wh % H); const long wm = wh / H;
+  const int q = 32 * qt + (lane & 31), key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+  float v = key < WA_N ? 0.f : -INFINITY;
+  if (q < WA_N && key < WA_N) {
+    const int rel = (q / 7 - key / 7 + 6) * 13 + (q % 7 - key % 7 + 6);
+    v = table[rel * H + h];
+    if (mask) v += mask[(wm * WA_N + q) * WA_N + key];
+  }
+  bm[i] = v;
+}
 __global__ __launch_bounds__(256) void wa_unprep_dbias_kernel(const float* __restrict__ red, int H, float* __restrict__ dbias) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)H * WA_N * WA_N) return;
@@ -353,6 +369,23 @@ __global__ __launch_bounds__(256) void wa_table_grad_kernel(const float* __restr
   dtable[i] = s;
 }
 
+// ... and its gradient straight from the reduced d(bias) in fragment order: one wave per table entry, lane = one of the <= 49 positions that read it, a wave sum per head
+__global__ __launch_bounds__(256) void wa_table_grad_frag_kernel(const float* __restrict__ red, const int* __restrict__ uses, int R, int U, int H, float* __restrict__ dtable) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const int pos = lane < U ? uses[r * U + lane] : -1;
+  int off = -1;
+  if (pos >= 0) {
+    const int q = pos / WA_N, key = pos - q * WA_N;
+    const int kk = key & 31, hi = (kk >> 2) & 1, rr = (kk & 3) + 4 * (kk >> 3), ln = (q & 31) + 32 * hi;
+    off = ((((q >> 5) * 2 + (key >> 5)) * 64 + ln) << 4) + rr;
+  }
+  for (int h = 0; h < H; ++h) {
+    const float v = wave_sum(off >= 0 ? red[(long)h * WA_FRAG + off] : 0.f);
+    if (lane == 0) dtable[r * H + h] = v;
+  }
+}
+
 extern "C" {
 
 int vdk_reduce_rows_f32(const float*, int64_t, int32_t, int64_t, float*, float, void*);
@@ -438,3 +471,36 @@ int vdk_relpos_bias_table_grad(const float* dbias, const int32_t* uses, int32_t 
 }
 
 }  // extern "C"
+
+// ---- in-library forms for the Swin engine (csrc/swin_engine.hip): the bias tile is prepared ONCE per block and step, straight from the relative-position table, and kept
+// for the backward; d(table) comes from the reduced fragment-order d(bias) in one launch (no un-permute, no [H, 49, 49] tensor in between)
+size_t vdk_wa_bm_bytes(int32_t nW, int32_t H) { return wa_bm_bytes(nW, H); }
+size_t vdk_wa_bwd_scratch_bytes(int64_t windows, int32_t H) { return (size_t)(wa_bwd_waves(windows, H) + H) * WA_FRAG * 4; }
+int vdk_wa_prep_table(const float* table, const float* mask, int32_t nW, int32_t H, float* bm, void* stream) {
+  const int nWm = mask ? nW : 1;
+  const long n = (long)nWm * H * WA_FRAG;
+  hipLaunchKernelGGL(wa_prep_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, mask, nWm, (int)H, bm);
+  return VDK_OK;
+}
+int vdk_wa_fwd_bm(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, const float* bm, int32_t nWm, int64_t windows, int32_t H, float scale, const int32_t* rowidx, void* stream) {
+  const long items = (long)windows * H;
+  long grid = (items + 3) / 4; if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(window_attn_fwd_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld, (bf16_t*)o, (long)ldo, lse, bm, (int)nWm, items,
+                     (int)H, scale, (const int*)rowidx);
+  return vdk_check_launch("vdk_wa_fwd_bm");
+}
+int vdk_wa_bwd_bm(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, const float* bm, int32_t nWm, int64_t windows, int32_t H, float scale,
+                  const int32_t* rowidx, void* dqkv, int64_t ldd, void* scratch, size_t scratch_bytes, const int32_t* uses, int32_t R, int32_t U, float* dtable, void* stream) {
+  if (U > 64) return vdk_fail(VDK_EINVAL, "vdk_wa_bwd_bm: at most 64 uses per table entry");
+  if (!scratch || scratch_bytes < vdk_wa_bwd_scratch_bytes(windows, H)) return vdk_fail(VDK_EWORKSPACE, "vdk_wa_bwd_bm: scratch too small");
+  const long waves = wa_bwd_waves(windows, H);
+  float* part = (float*)scratch;
+  float* red = part + waves * WA_FRAG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(window_attn_bwd_mfma_kernel, dim3((unsigned)(waves / WA_BW)), dim3(64 * WA_BW), 0, st, (const bf16_t*)qkv, (long)ld, (const bf16_t*)o, (const bf16_t*)dout,
+                     (long)ldo, lse, bm, (int)nWm, (long)windows, (int)H, scale, (bf16_t*)dqkv, (long)ldd, part, (const int*)rowidx);
+  const int rc = vdk_reduce_rows_f32(part, (int64_t)H * WA_FRAG, (int32_t)(waves / H), (int64_t)H * WA_FRAG, red, 1.0f, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(wa_table_grad_frag_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, (const float*)red, (const int*)uses, (int)R, (int)U, (int)H, dtable);
+  return vdk_check_launch("vdk_wa_bwd_bm");
+}
