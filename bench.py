@@ -98,7 +98,7 @@ def pmc_traffic_per_launch():
     """HBM-side bytes per GEMM launch from the committed PMC passes of this same command (rocprofv3 cannot run inside the timed process):
     profiles/r0N_pmc_traffic.json is written by tools/pmc_traffic.py from two `rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE}` runs,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  None if the artifact is absent."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):      # the newest round's passes of this command
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):      # the newest round's passes of this command
         p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             with open(p) as f:
@@ -110,7 +110,7 @@ def pmc_traffic_per_launch():
 
 def pmc_cbir():
     """L2 memory-side bytes of one search from the committed PMC passes of tools/pmc_cbir.py (None if absent)"""
-    for name in ("r03_cbir_pmc.json", "r02_cbir_pmc.json"):
+    for name in ("r04_cbir_pmc.json", "r03_cbir_pmc.json", "r02_cbir_pmc.json"):
         p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             with open(p) as f:

@@ -10,10 +10,10 @@ BARGS="--steps 20 --warmup 3 --no-parity --no-cpu-baseline --no-cbir --no-cfg5 -
 rocprofv3 --kernel-trace --stats -d /tmp/p_trace -o t -- python $R/bench.py $BARGS > $O/trace_stdout.txt 2>&1
 python $R/tools/rocpd_stats.py $(find /tmp/p_trace -name "*.db" | head -1) > $O/bench_kernel_stats.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d /tmp/p_$c -o p --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-parity --no-cpu-baseline --no-cbir --no-cfg5 --no-swin > $O/pmc_${c}_stdout.txt 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d /tmp/p_$c -o p --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-parity --no-cpu-baseline --no-cbir --no-cfg5 --no-swin --no-other-operand > $O/pmc_${c}_stdout.txt 2>&1
 done
 F=$(find /tmp/p_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find /tmp/p_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-CALLS=$(python -c "import json;print(7 * json.loads([l for l in open('$O/pmc_FETCH_SIZE_stdout.txt') if l.startswith('{\"metric\"')][-1])['roofline']['gemm_calls_per_step'])")
+CALLS=$(python -c "import json;print(7 * json.loads([l for l in open('$O/pmc_FETCH_SIZE_stdout.txt') if l.startswith('{\"metric\"')][-1])['roofline']['dominant_kernel']['gemm_calls_per_step'])")
 python $R/tools/pmc_traffic.py "$F" "$W" gemm $O/pmc_traffic.json $CALLS > $O/pmc_traffic.txt 2>&1
 tail -3 $O/pmc_traffic.txt
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -26,8 +26,15 @@ rocprofv3 --kernel-trace --stats -d /tmp/c_trace -o t -- python $R/tools/cbir_pm
 python $R/tools/rocpd_stats.py $(find /tmp/c_trace -name "*.db" | head -1) > $O/cbir_kernel_stats.txt
 tail -8 $O/cbir_pmc.txt
 cd $R
-cp $O/pmc_traffic.json profiles/r03_pmc_traffic.json 2>/dev/null; cp $O/cbir_pmc.json profiles/r03_cbir_pmc.json 2>/dev/null    # the bench line below reads them
+cp $O/pmc_traffic.json profiles/r04_pmc_traffic.json 2>/dev/null; cp $O/cbir_pmc.json profiles/r04_cbir_pmc.json 2>/dev/null    # the bench line below reads them
 T0=$(date +%s); python bench.py > $O/bench_stdout.txt 2> $O/bench_stderr.txt; echo "default bench.py wall: $(( $(date +%s) - T0 )) s" | tee $O/bench_wall.txt
 tail -1 $O/bench_stdout.txt > $O/bench.json
 python -c "
 import json;d=json.load(open('$O/bench.json'));print(d['value'],d['ms_per_step'],d['roofline'],d['cpu_baseline']);print(json.dumps(d['cbir'])[:1500])"
+# the other measured configurations of SURVEY 8(d): swin_base (the shipped YAMLs' default backbone) through the native engine, and cfg3 (ConvNeXt-B + ArcFace over 1 M classes)
+cd /tmp
+python $R/tools/bench_swin.py 128 10 native > $O/swin_native.json 2>/dev/null; cat $O/swin_native.json
+rocprofv3 --kernel-trace --stats -d /tmp/s_trace -o t -- python $R/tools/bench_swin.py 128 5 native > $O/swin_trace_stdout.txt 2>&1
+python $R/tools/rocpd_stats.py $(find /tmp/s_trace -name "*.db" | head -1) > $O/swin_kernel_stats.txt
+python $R/tools/rocpd_seq.py $(find /tmp/s_trace -name "*.db" | head -1) > $O/swin_step_sequence.txt
+python $R/tools/bench_cfg3.py 512 5 > $O/cfg3.json 2>/dev/null; cat $O/cfg3.json
