@@ -313,37 +313,43 @@ def bench_swin(be, dev, batch: int = 128, steps: int = 4):
     and a live check of a 2-stage Swin (logits and the worst parameter gradient) against the fp32 oracle (oracle/swin_ref.py, pinned against transformers.SwinModel)."""
     from oracle.swin_ref import SwinTransformerRef
     from visiondk_amd import swin, vit
-    out = {"workload": f"swin_base_patch4_window7_224, 37 classes (pet.yaml), batch {batch}: fwd + CE(ls 0.05) + bwd + clip_grad_norm_ + SGD + EMA (native engine, fused step)", "dtype": "bf16 operands, fp32 residual stream"}
+    out = {"workload": f"swin_base_patch4_window7_224, 37 classes (pet.yaml), batch {batch}: fwd + CE(ls 0.05) + bwd + clip_grad_norm_ + SGD + EMA (native engine, fused step)", "dtype": "fp16 operands (the reference's autocast dtype), fp32 residual stream; bf16 beside it"}
     torch.manual_seed(0)
     ref = SwinTransformerRef(img_size=224, num_classes=7, embed_dim=32, depths=(2, 2), heads=(1, 2))
     with torch.no_grad():
         for n_, p_ in ref.named_parameters():
             if "relative_position_bias_table" in n_:
                 p_.copy_(torch.randn_like(p_) * 0.3)
-    small = swin.SwinTransformer(swin.SwinSpec(img_size=224, num_classes=7, embed_dim=32, depths=(2, 2), heads=(1, 2)), device=dev, backend=be, seed=0)
+    small = swin.SwinTransformer(swin.SwinSpec(img_size=224, num_classes=7, embed_dim=32, depths=(2, 2), heads=(1, 2)), device=dev, backend=be, seed=0, operand="fp16")
     small.load_state_dict(ref.state_dict())
     x = torch.randn(2, 3, 224, 224); y = torch.randint(0, 7, (2,))
     lr_ = ref(x); torch.nn.functional.cross_entropy(lr_, y).backward()
-    lo = small(x.to(dev)); torch.nn.functional.cross_entropy(lo, y.to(dev)).backward()
+    lo = small(x.to(dev)); (torch.nn.functional.cross_entropy(lo, y.to(dev)) * 256.0).backward()          # (GradScaler: scaled backward, unscaled below)
     rel = lambda a, b: ((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm().clamp_min(1e-30)).item()
-    grads = {n_: rel(p_.grad, dict(ref.named_parameters())[n_].grad) for n_, p_ in small.named_parameters()}
+    grads = {n_: rel(p_.grad / 256.0, dict(ref.named_parameters())[n_].grad) for n_, p_ in small.named_parameters()}
     worst = max(grads, key=grads.get)
-    out["parity_vs_fp32_oracle"] = {"model": "2-stage Swin (dim 32 / 64, 56 x 56 and 28 x 28 maps: shifted windows, masks, patch merging), batch 2", "logits_rel": rel(lo.detach(), lr_.detach()),
+    out["parity_vs_fp32_oracle"] = {"operand": "fp16", "model": "2-stage Swin (dim 32 / 64, 56 x 56 and 28 x 28 maps: shifted windows, masks, patch merging), batch 2", "logits_rel": rel(lo.detach(), lr_.detach()),
                                     "worst_grad_rel": grads[worst], "worst_grad": worst,
-                                    "full_size_quoted": "swin_base, every gradient vs the fp32 oracle (tests/test_swin.py): logits 5.9e-3, worst gradient 1.1e-2, median 5.6e-3"}
+                                    "full_size_quoted": "swin_base, every gradient vs the fp32 oracle (tests/test_swin.py): bf16 operands logits 5.9e-3, worst gradient 1.1e-2; fp16 operands asserted <= 1e-3 / <= 5e-3"}
     del small, ref
-    model = swin.create_model("swin_base_patch4_window7_224", num_classes=37, device=dev, backend=be, seed=0)
-    fused = vit.FusedTrainStep(model, lr=0.006, momentum=0.937, weight_decay=5e-4, label_smoothing=0.05, max_norm=10.0, ema=True)
     xb = torch.randn(batch, 3, 224, 224, device=dev); yb = torch.randint(0, 37, (batch,), device=dev)
-    for _ in range(2):
-        fused.step(xb, yb)
-    torch.cuda.synchronize(); t0 = time.time()
-    for _ in range(steps):
-        fused.step(xb, yb)
-    torch.cuda.synchronize(); dt = (time.time() - t0) / steps
-    out.update({"images_per_sec": batch / dt, "ms_per_step": dt * 1e3, "model_tflops": 3 * 15.47e9 * batch / dt / 1e12, "loss": fused.loss_value()})
-    del model, fused
-    torch.cuda.empty_cache()
+    for operand in ("fp16", "bf16"):          # fp16: the reference's autocast dtype (GradScaler protocol inside the fused step); bf16 beside it
+        model = swin.create_model("swin_base_patch4_window7_224", num_classes=37, device=dev, backend=be, seed=0, operand=operand)
+        fused = vit.FusedTrainStep(model, lr=0.006, momentum=0.937, weight_decay=5e-4, label_smoothing=0.05, max_norm=10.0, ema=True)
+        for _ in range(2):
+            fused.step(xb, yb)
+        torch.cuda.synchronize(); t0 = time.time()
+        for _ in range(steps):
+            fused.step(xb, yb)
+        torch.cuda.synchronize(); dt = (time.time() - t0) / steps
+        rec = {"images_per_sec": batch / dt, "ms_per_step": dt * 1e3, "model_tflops": 3 * 15.47e9 * batch / dt / 1e12, "loss": fused.loss_value()}
+        if operand == "fp16":
+            out.update(rec)
+            out["operand"] = "fp16"
+        else:
+            out["bf16_operands"] = rec
+        del model, fused
+        torch.cuda.empty_cache()
     return out
 
 

@@ -571,6 +571,7 @@ typedef struct VdkSwinConfig {
   int32_t depths[4], heads[4];
   int32_t num_classes;
   float ln_eps;
+  int32_t operand;        /* VDK_BF16 | VDK_F16: format of the GEMM / attention operands and of the saved 16-bit activations (fp16 = the reference's autocast dtype, train.py:118) */
 } VdkSwinConfig;
 int vdk_swin_param_count(const VdkSwinConfig* cfg, int64_t* n_floats, int32_t* n_tensors, int64_t* n_transposed);
 int vdk_swin_param_info(const VdkSwinConfig* cfg, int32_t index, char* name, int32_t name_cap, int64_t* offset, int64_t* numel, int64_t* shape4, int32_t* ndim);

@@ -52,7 +52,8 @@ class ResNetConfig(C.Structure):
 
 class SwinConfig(C.Structure):
     """VdkSwinConfig of include/visiondk.h"""
-    _fields_ = [("batch", I32), ("img_size", I32), ("in_chans", I32), ("embed_dim", I32), ("depths", I32 * 4), ("heads", I32 * 4), ("num_classes", I32), ("ln_eps", C.c_float)]
+    _fields_ = [("batch", I32), ("img_size", I32), ("in_chans", I32), ("embed_dim", I32), ("depths", I32 * 4), ("heads", I32 * 4), ("num_classes", I32), ("ln_eps", C.c_float),
+                ("operand", I32)]
 
 
 class MarginHead(C.Structure):

@@ -29,9 +29,10 @@
 size_t vdk_wa_bm_bytes(int32_t nW, int32_t H);
 size_t vdk_wa_bwd_scratch_bytes(int64_t windows, int32_t H);
 int vdk_wa_prep_table(const float* table, const float* mask, int32_t nW, int32_t H, float* bm, void* stream);
-int vdk_wa_fwd_bm(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, const float* bm, int32_t nWm, int64_t windows, int32_t H, float scale, const int32_t* rowidx, void* stream);
+int vdk_wa_fwd_bm(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, const float* bm, int32_t nWm, int64_t windows, int32_t H, float scale, const int32_t* rowidx, int opf,
+                  void* stream);
 int vdk_wa_bwd_bm(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, const float* bm, int32_t nWm, int64_t windows, int32_t H, float scale,
-                  const int32_t* rowidx, void* dqkv, int64_t ldd, void* scratch, size_t scratch_bytes, const int32_t* uses, int32_t R, int32_t U, float* dtable, void* stream);
+                  const int32_t* rowidx, void* dqkv, int64_t ldd, void* scratch, size_t scratch_bytes, const int32_t* uses, int32_t R, int32_t U, float* dtable, int opf, void* stream);
 extern "C" {
 int vdk_layernorm_fwd(const float*, int64_t, int32_t, int32_t, const float*, const float*, float, void*, int64_t, int32_t, float*, float*, void*);
 int vdk_layernorm_bwd_workspace_bytes(int32_t, int32_t, size_t*);
@@ -57,18 +58,26 @@ static inline int64_t up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 namespace {
 
+// operand format of the running call (VdkSwinConfig.operand): bf16, or fp16 = the reference's autocast dtype (engine/procedure/train.py:118); set at every entry point, as in
+// vit_engine.hip.  DT16 = the dtype code of the 16-bit tensors.
+thread_local int t_opf = VDK_OPF_BF16;
+#define DT16 (t_opf ? VDK_F16 : VDK_BF16)
+
 struct SwDims {
   int B, img, Cin, E, depth[4], heads[4], dim[4], res[4], nblk;
   int nst;                 // stages in use: the leading non-zero entries of depths (timm's family has 4; shallower members serve the tests)
   long T[4];               // token rows per stage = B * res^2
   int C, Cp, Bp, Kpe;      // classes (0: feature mode), padded to 8; batch padded to 64; K of the patch-embedding GEMM (in_chans * 16)
   float eps;
+  int opf;                 // VDK_OPF_BF16 | VDK_OPF_F16
 };
 int sw_dims(const VdkSwinConfig* c, SwDims* d) {
   if (!c) return vdk_fail(VDK_EINVAL, "swin: null config");
   if (c->batch <= 0 || c->img_size <= 0 || (c->img_size % 224) || c->in_chans <= 0 || c->embed_dim <= 0 || (c->embed_dim % 32) || c->num_classes < 0)
     return vdk_fail(VDK_EINVAL, "swin: bad config (img_size % 224 == 0: 7 x 7 windows on every stage's map; embed_dim % 32 == 0)");
   if ((c->in_chans * 16) & 7) return vdk_fail(VDK_EUNSUPPORTED, "swin: in_chans * 16 must be a multiple of 8");
+  if (c->operand != VDK_BF16 && c->operand != VDK_F16) return vdk_fail(VDK_EINVAL, "swin: operand must be VDK_BF16 or VDK_F16");
+  d->opf = c->operand == VDK_F16 ? VDK_OPF_F16 : VDK_OPF_BF16;
   d->B = c->batch; d->img = c->img_size; d->Cin = c->in_chans; d->E = c->embed_dim; d->eps = c->ln_eps; d->nblk = 0;
   d->C = c->num_classes; d->Cp = (int)up(c->num_classes, 8); d->Bp = (int)up(c->batch, 64); d->Kpe = c->in_chans * 16;
   int res = c->img_size / 4;
@@ -357,29 +366,29 @@ __global__ __launch_bounds__(256) void swin_merge_kernel(const float* __restrict
 int gemm(hipStream_t s, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K, int cdt, const float* bias, const float* res, int64_t ldr,
          int act, void* aux, int64_t ldaux, int splitk, void* ws, size_t wsb, float* c_colsum = nullptr) {
   VdkGemmDesc g = {};
-  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.c_dtype = cdt; g.bias = bias; g.residual = res; g.ldr = ldr; g.act = act; g.aux = aux;
-  g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = splitk; g.c_colsum = c_colsum;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.c_dtype = cdt == VDK_F32 ? VDK_F32 : DT16; g.bias = bias; g.residual = res; g.ldr = ldr;
+  g.act = act; g.aux = aux; g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = splitk; g.c_colsum = c_colsum; g.ab_dtype = DT16;
   return vdk_gemm_bf16_nt(&g, ws, wsb, s);
 }
 // dW[out, in] = dY^T X (+ db = colsum(dY) when db != nullptr): TN GEMM straight from the row-major tensors when rows % 64 == 0, else through zero-padded transposes
 int linear_wgrad(hipStream_t s, const WsPlan& w, char* base, const bf16_t* dY, int64_t lddy, const bf16_t* Xa, int64_t ldx, int rows, int out, int in, float* dW, float* db) {
   if ((rows % 64) == 0 && (out % 8) == 0 && (in % 8) == 0 && out >= 8 && in >= 8) {
     VdkGemmDesc g = {};
-    g.A = dY; g.lda = lddy; g.B = Xa; g.ldb = ldx; g.C = dW; g.ldc = in; g.M = out; g.N = in; g.K = rows; g.c_dtype = VDK_F32; g.alpha = 1.0f;
+    g.A = dY; g.lda = lddy; g.B = Xa; g.ldb = ldx; g.C = dW; g.ldc = in; g.M = out; g.N = in; g.K = rows; g.c_dtype = VDK_F32; g.alpha = 1.0f; g.ab_dtype = DT16;
     const bool half = wgrad_tn_half(out, in);
     g.splitk = wgrad_tn_splits(out, in, rows); g.trans = 1;
     vdk_gemm_tn_prefer_half(half ? 1 : 0);
     const int rc = vdk_gemm_bf16_nt(&g, base + w.slabs, w.slabs_bytes, s);
     vdk_gemm_tn_prefer_half(0);
     RC(rc);
-    if (db) RC(vdk_colsum_16(dY, lddy, rows, out, db, base + w.csws + 5 * w.csws_bytes, w.csws_bytes, VDK_OPF_BF16, s));
+    if (db) RC(vdk_colsum_16(dY, lddy, rows, out, db, base + w.csws + 5 * w.csws_bytes, w.csws_bytes, t_opf, s));
     return VDK_OK;
   }
   const int rows_pad = (int)up(rows, 64);
   bf16_t* tA = (bf16_t*)(base + w.tA); bf16_t* tB = (bf16_t*)(base + w.tB);
   float* csp = db ? (float*)(base + w.csws + 5 * w.csws_bytes) : nullptr;
-  RC(vdk_transpose_bf16(dY, lddy, rows, out, tA, rows_pad, rows_pad, 0, csp, s));
-  RC(vdk_transpose_bf16(Xa, ldx, rows, in, tB, rows_pad, rows_pad, 0, nullptr, s));
+  RC(vdk_transpose_16(dY, lddy, rows, out, tA, rows_pad, rows_pad, 0, csp, t_opf, s));
+  RC(vdk_transpose_16(Xa, ldx, rows, in, tB, rows_pad, rows_pad, 0, nullptr, t_opf, s));
   RC(gemm(s, tA, rows_pad, tB, rows_pad, dW, in, out, in, rows_pad, VDK_F32, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, wgrad_splitk(out, in, rows_pad), base + w.slabs, w.slabs_bytes));
   if (csp) RC(vdk_reduce_rows_f32(csp, out, (rows_pad + 63) / 64, out, db, 1.0f, s));
   return VDK_OK;
@@ -391,6 +400,7 @@ extern "C" {
 
 int vdk_swin_param_count(const VdkSwinConfig* cfg, int64_t* n_floats, int32_t* n_tensors, int64_t* n_transposed) {
   SwDims d; RC(sw_dims(cfg, &d));
+  t_opf = d.opf;
   PLayout p; sw_layout(d, &p);
   if (n_floats) *n_floats = p.total;
   if (n_tensors) *n_tensors = (int32_t)p.entries.size();
@@ -400,6 +410,7 @@ int vdk_swin_param_count(const VdkSwinConfig* cfg, int64_t* n_floats, int32_t* n
 
 int vdk_swin_param_info(const VdkSwinConfig* cfg, int32_t index, char* name, int32_t name_cap, int64_t* offset, int64_t* numel, int64_t* shape4, int32_t* ndim) {
   SwDims d; RC(sw_dims(cfg, &d));
+  t_opf = d.opf;
   PLayout p; sw_layout(d, &p);
   if (index < 0 || index >= (int)p.entries.size()) return vdk_fail(VDK_EINVAL, "vdk_swin_param_info: index out of range");
   const PEntry& e = p.entries[index];
@@ -413,6 +424,7 @@ int vdk_swin_param_info(const VdkSwinConfig* cfg, int32_t index, char* name, int
 
 int vdk_swin_workspace_bytes(const VdkSwinConfig* cfg, size_t* bytes) {
   SwDims d; RC(sw_dims(cfg, &d));
+  t_opf = d.opf;
   WsPlan w; sw_plan(d, &w);
   if (!bytes) return vdk_fail(VDK_EINVAL, "null");
   *bytes = w.total;
@@ -423,9 +435,10 @@ int vdk_swin_workspace_bytes(const VdkSwinConfig* cfg, size_t* bytes) {
 // transposes the input-gradient GEMMs read -- one batched launch for all of them
 int vdk_swin_refresh_weights(const VdkSwinConfig* cfg, const float* params, void* wb16, void* wt16, int32_t skip_wb16, void* stream) {
   SwDims d; RC(sw_dims(cfg, &d));
+  t_opf = d.opf;
   PLayout p; sw_layout(d, &p);
   if (!params || !wb16 || !wt16) return vdk_fail(VDK_EINVAL, "vdk_swin_refresh_weights: null pointer");
-  if (!skip_wb16) RC(vdk_cast_f32_16(params, wb16, p.total, VDK_OPF_BF16, stream));
+  if (!skip_wb16) RC(vdk_cast_f32_16(params, wb16, p.total, t_opf, stream));
   bf16_t* wt = (bf16_t*)wt16;
   std::vector<VdkTcItem> jobs;
   auto add = [&](int64_t off, int R, int Cc, int64_t toff) { jobs.push_back(VdkTcItem{params + off, wt + toff, Cc, R, Cc, R, R}); };
@@ -435,7 +448,7 @@ int vdk_swin_refresh_weights(const VdkSwinConfig* cfg, const float* params, void
     for (const BlkP& b : p.st[i].blk) { add(b.qkv_w, 3 * C, C, b.tq); add(b.proj_w, C, C, b.tp); add(b.fc1_w, M, C, b.t1); add(b.fc2_w, C, M, b.t2); }
   }
   if (d.C > 0) add(p.fc_w, d.Cp, d.dim[d.nst - 1], p.fc_t);
-  return vdk_transpose_cast_batch(jobs.data(), (int)jobs.size(), stream, VDK_OPF_BF16);
+  return vdk_transpose_cast_batch(jobs.data(), (int)jobs.size(), stream, t_opf);
 }
 
 // x: f32 [B, Cin, img, img] -> out f32: logits [B, Cp] (columns C..Cp-1 padding) or, in feature mode (num_classes = 0), the normed NHWC map [B * 49 * (img / 224)^2, D]
@@ -443,6 +456,7 @@ int vdk_swin_refresh_weights(const VdkSwinConfig* cfg, const float* params, void
 int vdk_swin_forward(const VdkSwinConfig* cfg, const float* x, const float* params, const void* wb16, void* ws, size_t ws_bytes, float* out, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   SwDims d; RC(sw_dims(cfg, &d));
+  t_opf = d.opf;
   PLayout p; sw_layout(d, &p);
   WsPlan w; sw_plan(d, &w);
   if (!x || !params || !wb16 || !ws || !out) return vdk_fail(VDK_EINVAL, "vdk_swin_forward: null pointer");
@@ -462,7 +476,7 @@ int vdk_swin_forward(const VdkSwinConfig* cfg, const float* x, const float* para
   }
   // patch embedding: patch operand (an index permutation of the image) x Linear, then its LayerNorm -> the residual stream of stage 0
   bf16_t* patches = (bf16_t*)(base + w.patches);
-  RC(vdk_patchify_16(x, d.B, d.Cin, d.img, d.img, 4, patches, d.Kpe, VDK_OPF_BF16, s));
+  RC(vdk_patchify_16(x, d.B, d.Cin, d.img, d.img, 4, patches, d.Kpe, t_opf, s));
   float* petmp = (float*)(base + w.petmp); float* pest = (float*)(base + w.pestats);
   RC(gemm(s, patches, d.Kpe, wb + p.pe_w, d.Kpe, petmp, d.E, (int)d.T[0], d.E, d.Kpe, VDK_F32, params + p.pe_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));
   RC(vdk_layernorm_fwd(petmp, d.E, (int)d.T[0], d.E, params + p.pe_nw, params + p.pe_nb, d.eps, base + w.st[0].blk[0].x, d.E, VDK_F32, pest, pest + d.T[0], s));
@@ -476,7 +490,7 @@ int vdk_swin_forward(const VdkSwinConfig* cfg, const float* x, const float* para
       float* mg = (float*)(base + sw_.mg); float* mst = (float*)(base + sw_.mstats); bf16_t* mh = (bf16_t*)(base + sw_.mh);
       const long n4 = d.T[i - 1] * (d.dim[i - 1] / 4);
       hipLaunchKernelGGL(swin_merge_kernel<false>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, xprev, mg, d.B, d.res[i - 1], d.dim[i - 1]);
-      RC(vdk_layernorm_fwd(mg, C4, T, C4, params + sp.ds_nw, params + sp.ds_nb, d.eps, mh, C4, VDK_BF16, mst, mst + T, s));
+      RC(vdk_layernorm_fwd(mg, C4, T, C4, params + sp.ds_nw, params + sp.ds_nb, d.eps, mh, C4, DT16, mst, mst + T, s));
       RC(gemm(s, mh, C4, wb + sp.ds_w, C4, base + sw_.blk[0].x, C, T, C, C4, VDK_F32, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));
     }
     for (int j = 0; j < d.depth[i]; ++j) {
@@ -489,15 +503,15 @@ int vdk_swin_forward(const VdkSwinConfig* cfg, const float* x, const float* para
       bf16_t* u = (bf16_t*)(base + bw.u); bf16_t* g = (bf16_t*)(base + bw.g);
       float* bias = (float*)(base + bw.bias);
       // x = x + proj(W-MSA(norm1(x)))
-      RC(vdk_layernorm_fwd(xin, C, T, C, params + b.n1w, params + b.n1b, d.eps, h1, C, VDK_BF16, st, st + T, s));
-      RC(gemm(s, h1, C, wb + b.qkv_w, C, qkv, 3 * C, T, 3 * C, C, VDK_BF16, params + b.qkv_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));
+      RC(vdk_layernorm_fwd(xin, C, T, C, params + b.n1w, params + b.n1b, d.eps, h1, C, DT16, st, st + T, s));
+      RC(gemm(s, h1, C, wb + b.qkv_w, C, qkv, 3 * C, T, 3 * C, C, DT16, params + b.qkv_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));
       RC(vdk_wa_prep_table(params + b.table, shifted ? (const float*)(base + sw_.mask) : nullptr, shifted ? nW : 0, H, bias, s));
       RC(vdk_wa_fwd_bm(qkv, 3 * C, o, C, (float*)(base + bw.lse), bias, shifted ? nW : 1, (int64_t)(T / SW_N), H, 0.17677669529663687f /* 32^-0.5 */,
-                       (const int32_t*)(base + (shifted ? sw_.rowidx3 : sw_.rowidx0)), s));
+                       (const int32_t*)(base + (shifted ? sw_.rowidx3 : sw_.rowidx0)), t_opf, s));
       RC(gemm(s, o, C, wb + b.proj_w, C, xmid, C, T, C, C, VDK_F32, params + b.proj_b, xin, C, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));
       // x = x + fc2(gelu(fc1(norm2(x))))
-      RC(vdk_layernorm_fwd(xmid, C, T, C, params + b.n2w, params + b.n2b, d.eps, h2, C, VDK_BF16, st + 2 * (size_t)T, st + 3 * (size_t)T, s));
-      RC(gemm(s, h2, C, wb + b.fc1_w, C, g, M, T, M, C, VDK_BF16, params + b.fc1_b, nullptr, 0, VDK_ACT_GELU, u, M, 1, nullptr, 0));
+      RC(vdk_layernorm_fwd(xmid, C, T, C, params + b.n2w, params + b.n2b, d.eps, h2, C, DT16, st + 2 * (size_t)T, st + 3 * (size_t)T, s));
+      RC(gemm(s, h2, C, wb + b.fc1_w, C, g, M, T, M, C, DT16, params + b.fc1_b, nullptr, 0, VDK_ACT_GELU, u, M, 1, nullptr, 0));
       RC(gemm(s, g, M, wb + b.fc2_w, M, xout, C, T, C, M, VDK_F32, params + b.fc2_b, xmid, C, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));
     }
     xprev = (const float*)(base + sw_.xout);
@@ -512,7 +526,7 @@ int vdk_swin_forward(const VdkSwinConfig* cfg, const float* x, const float* para
   RC(vdk_layernorm_fwd(xprev, D, T3, D, params + p.norm_w, params + p.norm_b, d.eps, fmap, D, VDK_F32, fst, fst + T3, s));
   RC(vdk_avgpool_rows_f32_fwd(fmap, pooled, d.B, T3 / d.B, D, s));
   if (d.Bp != d.B && hipMemsetAsync(hf + (size_t)d.B * D, 0, (size_t)(d.Bp - d.B) * D * 2, s) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vdk_swin_forward: memset failed");
-  RC(vdk_cast_f32_16(pooled, hf, (int64_t)d.B * D, VDK_OPF_BF16, s));
+  RC(vdk_cast_f32_16(pooled, hf, (int64_t)d.B * D, t_opf, s));
   RC(gemm(s, hf, D, wb + p.fc_w, D, out, d.Cp, d.B, d.Cp, D, VDK_F32, params + p.fc_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));
   return vdk_check_launch("vdk_swin_forward");
 }
@@ -524,6 +538,7 @@ int vdk_swin_backward(const VdkSwinConfig* cfg, const void* dout, const float* p
                       vdk_grad_ready_fn on_ready, void* user, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   SwDims d; RC(sw_dims(cfg, &d));
+  t_opf = d.opf;
   PLayout p; sw_layout(d, &p);
   WsPlan w; sw_plan(d, &w);
   if (!dout || !params || !wb16 || !wt16 || !ws || !grads) return vdk_fail(VDK_EINVAL, "vdk_swin_backward: null pointer");
@@ -542,7 +557,7 @@ int vdk_swin_backward(const VdkSwinConfig* cfg, const void* dout, const float* p
   // ---- head + final norm: dxa / dxab = dL/d(stage 3 output) ----------------------------------------------------------------------------
   if (d.C == 0) {
     RC(vdk_layernorm_bwd_deferred(dout, D, VDK_F32, xlast, D, fst, fst + T3, params + p.norm_w, nullptr, 0, T3, D, dxa, D, dxab, D, grads + p.norm_w, grads + p.norm_b, lnws0,
-                                  w.lnws_bytes, s, nullptr));
+                                  w.lnws_bytes, s, nullptr, nullptr, nullptr, nullptr, t_opf));
     if (on_ready) on_ready(user, p.norm_w, p.total - p.norm_w);
   } else {
     const bf16_t* dl = (const bf16_t*)dout;
@@ -553,7 +568,7 @@ int vdk_swin_backward(const VdkSwinConfig* cfg, const void* dout, const float* p
     float* dmap = dxm;      // (scratch: d(normed map) f32 [T3, D])
     RC(vdk_avgpool_rows_f32_bwd(dpool, dmap, nullptr, d.B, T3 / d.B, D, s));
     RC(vdk_layernorm_bwd_deferred(dmap, D, VDK_F32, xlast, D, fst, fst + T3, params + p.norm_w, nullptr, 0, T3, D, dxa, D, dxab, D, grads + p.norm_w, grads + p.norm_b, lnws0,
-                                  w.lnws_bytes, s, nullptr));
+                                  w.lnws_bytes, s, nullptr, nullptr, nullptr, nullptr, t_opf));
     if (on_ready) on_ready(user, p.norm_w, p.total - p.norm_w);
   }
   // ---- stages, last to first -------------------------------------------------------------------------------------------------------------
@@ -573,30 +588,30 @@ int vdk_swin_backward(const VdkSwinConfig* cfg, const void* dout, const float* p
       const int xrow = vdk_gemm_c_colsum_rows(T, M, C);
       const bool fo = xrow > 0 && (size_t)xrow * M * 4 <= w.csws_bytes;
       float* part1 = (float*)csws(0);
-      RC(gemm(s, dxab, C, wt + b.t2, C, du, M, T, M, C, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_DGELU, u, M, 1, nullptr, 0, fo ? part1 : nullptr));   // du
+      RC(gemm(s, dxab, C, wt + b.t2, C, du, M, T, M, C, DT16, nullptr, nullptr, 0, VDK_ACT_DGELU, u, M, 1, nullptr, 0, fo ? part1 : nullptr));   // du
       if (fo) jobs[nj++] = VdkReduceJob{part1, (long)M, xrow, (long)M, grads + b.fc1_b, 1.0f};
       // fc2.bias = column sums of dxab: a by-product of the LayerNorm backward that stored it (norm1 of the block after this one, below), except for a stage's last block
       const bool fc2b_done = C <= 1024 && j + 1 < d.depth[i];
       RC(linear_wgrad(s, w, base, dxab, C, g, M, T, C, M, grads + b.fc2_w, fc2b_done ? nullptr : grads + b.fc2_b));
-      RC(gemm(s, du, M, wt + b.t1, M, dsm, C, T, C, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));   // dh2
+      RC(gemm(s, du, M, wt + b.t1, M, dsm, C, T, C, M, DT16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));   // dh2
       RC(linear_wgrad(s, w, base, du, M, h2, C, T, M, C, grads + b.fc1_w, fo ? nullptr : grads + b.fc1_b));
       // norm2 backward + the shortcut: dxm / dxmb = dL/dx_mid; proj.bias = column sums of the bf16 copy it stores
       const bool ocs = C <= 1024;
-      RC(vdk_layernorm_bwd_deferred(dsm, C, VDK_BF16, xmid, C, st + 2 * (size_t)T, st + 3 * (size_t)T, params + b.n2w, dxa, C, T, C, dxm, C, dxmb, C, grads + b.n2w, grads + b.n2b,
+      RC(vdk_layernorm_bwd_deferred(dsm, C, DT16, xmid, C, st + 2 * (size_t)T, st + 3 * (size_t)T, params + b.n2w, dxa, C, T, C, dxm, C, dxmb, C, grads + b.n2w, grads + b.n2b,
                                     lnws0, w.lnws_bytes, s, &jobs[nj], ocs ? grads + b.proj_b : nullptr, ocs ? &jobs[nj + 1] : nullptr));
       nj += ocs ? 2 : 1;
       // attention branch
-      RC(gemm(s, dxmb, C, wt + b.tp, C, dsm, C, T, C, C, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));   // do
+      RC(gemm(s, dxmb, C, wt + b.tp, C, dsm, C, T, C, C, DT16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));   // do
       RC(linear_wgrad(s, w, base, dxmb, C, o, C, T, C, C, grads + b.proj_w, ocs ? nullptr : grads + b.proj_b));
       RC(vdk_wa_bwd_bm(qkv, 3 * C, o, dsm, C, (const float*)(base + bw.lse), (const float*)(base + bw.bias), shifted ? nW : 1, (int64_t)(T / SW_N), H, 0.17677669529663687f,
                        (const int32_t*)(base + (shifted ? sw_.rowidx3 : sw_.rowidx0)), dqkv, 3 * C, base + w.waws, w.waws_bytes, (const int32_t*)(base + w.uses), SW_NREL, SW_N,
-                       grads + b.table, s));
-      RC(vdk_colsum_bf16_deferred(dqkv, 3 * C, T, 3 * C, grads + b.qkv_b, csws(2), w.csws_bytes, s, &jobs[nj], nullptr, VDK_OPF_BF16)); ++nj;
-      RC(gemm(s, dqkv, 3 * C, wt + b.tq, 3 * C, dsm, C, T, C, 3 * C, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));   // dh1
+                       grads + b.table, t_opf, s));
+      RC(vdk_colsum_bf16_deferred(dqkv, 3 * C, T, 3 * C, grads + b.qkv_b, csws(2), w.csws_bytes, s, &jobs[nj], nullptr, t_opf)); ++nj;
+      RC(gemm(s, dqkv, 3 * C, wt + b.tq, 3 * C, dsm, C, T, C, 3 * C, DT16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));   // dh1
       RC(linear_wgrad(s, w, base, dqkv, 3 * C, h1, C, T, 3 * C, C, grads + b.qkv_w, nullptr));
       // norm1 backward + the shortcut: dxa / dxab = dL/dx_in (= dL/dx_out of the block before)
       const bool ocs1 = ocs && j > 0;      // dxab = dL/dx_out of block j - 1: its column sums are that block's fc2.bias gradient
-      RC(vdk_layernorm_bwd_deferred(dsm, C, VDK_BF16, xin, C, st, st + T, params + b.n1w, dxm, C, T, C, dxa, C, dxab, C, grads + b.n1w, grads + b.n1b, lnws1, w.lnws_bytes, s,
+      RC(vdk_layernorm_bwd_deferred(dsm, C, DT16, xin, C, st, st + T, params + b.n1w, dxm, C, T, C, dxa, C, dxab, C, grads + b.n1w, grads + b.n1b, lnws1, w.lnws_bytes, s,
                                     &jobs[nj], ocs1 ? grads + sp.blk[j - 1].fc2_b : nullptr, ocs1 ? &jobs[nj + 1] : nullptr));
       nj += ocs1 ? 2 : 1;
       RC(vdk_reduce_rows_batch(jobs, nj, s));
@@ -610,12 +625,12 @@ int vdk_swin_backward(const VdkSwinConfig* cfg, const void* dout, const float* p
       const int C4 = 4 * d.dim[i - 1], Cp_ = d.dim[i - 1];
       const float* mg = (const float*)(base + sw_.mg); const float* mst = (const float*)(base + sw_.mstats); const bf16_t* mh = (const bf16_t*)(base + sw_.mh);
       RC(linear_wgrad(s, w, base, dxab, C, mh, C4, T, C, C4, grads + sp.ds_w, nullptr));
-      RC(gemm(s, dxab, C, wt + sp.ds_t, C, dsm, C4, T, C4, C, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));   // d(norm output) bf16 [T, 4 C_prev]
-      RC(vdk_layernorm_bwd_deferred(dsm, C4, VDK_BF16, mg, C4, mst, mst + T, params + sp.ds_nw, nullptr, 0, T, C4, dxm, C4, nullptr, 0, grads + sp.ds_nw, grads + sp.ds_nb, lnws0,
+      RC(gemm(s, dxab, C, wt + sp.ds_t, C, dsm, C4, T, C4, C, DT16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));   // d(norm output) bf16 [T, 4 C_prev]
+      RC(vdk_layernorm_bwd_deferred(dsm, C4, DT16, mg, C4, mst, mst + T, params + sp.ds_nw, nullptr, 0, T, C4, dxm, C4, nullptr, 0, grads + sp.ds_nw, grads + sp.ds_nb, lnws0,
                                     w.lnws_bytes, s, nullptr));
       const long n4 = d.T[i - 1] * (Cp_ / 4);
       hipLaunchKernelGGL(swin_merge_kernel<true>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)dxm, dxa, d.B, d.res[i - 1], Cp_);
-      RC(vdk_cast_f32_16(dxa, dxab, d.T[i - 1] * Cp_, VDK_OPF_BF16, s));
+      RC(vdk_cast_f32_16(dxa, dxab, d.T[i - 1] * Cp_, t_opf, s));
       if (on_ready) on_ready(user, sp.ds_nw, sp.blk[0].n1w - sp.ds_nw);
     }
   }
@@ -624,7 +639,7 @@ int vdk_swin_backward(const VdkSwinConfig* cfg, const void* dout, const float* p
     const float* petmp = (const float*)(base + w.petmp); const float* pest = (const float*)(base + w.pestats);
     const int T0 = (int)d.T[0];
     RC(vdk_layernorm_bwd_deferred(dxa, d.E, VDK_F32, petmp, d.E, pest, pest + T0, params + p.pe_nw, nullptr, 0, T0, d.E, nullptr, 0, dxmb, d.E, grads + p.pe_nw, grads + p.pe_nb, lnws0,
-                                  w.lnws_bytes, s, nullptr));
+                                  w.lnws_bytes, s, nullptr, nullptr, nullptr, nullptr, t_opf));
     RC(linear_wgrad(s, w, base, dxmb, d.E, (const bf16_t*)(base + w.patches), d.Kpe, T0, d.E, d.Kpe, grads + p.pe_w, grads + p.pe_b));
     if (on_ready) on_ready(user, 0, p.st[0].blk[0].n1w);
   }

@@ -129,10 +129,11 @@ __device__ __forceinline__ void wa_put_pt(unsigned char* tile, const s16x8 (&f)[
 // into 32 different rows per instruction.  The two tiles of an output go through a [64][32] bf16 staging tile in LDS instead (80-byte pitch: the 8-byte writes of 16
 // consecutive rows fall on distinct bank pairs) and leave as 16-byte stores, 4 lanes per 64-byte row.
 #define WA_ST_PITCH 80
+template <int OF = 0>
 __device__ __forceinline__ void wa_stage_t(unsigned char* st, const f32x16& x, float mul, int t, int l31, int hi) {
 #pragma unroll
   for (int g = 0; g < 4; ++g)
-    *(u32x2*)(st + (32 * t + l31) * WA_ST_PITCH + (8 * g + 4 * hi) * 2) = (u32x2){pack_bf2(x[4 * g] * mul, x[4 * g + 1] * mul), pack_bf2(x[4 * g + 2] * mul, x[4 * g + 3] * mul)};
+    *(u32x2*)(st + (32 * t + l31) * WA_ST_PITCH + (8 * g + 4 * hi) * 2) = (u32x2){pack_op2<OF>(x[4 * g] * mul, x[4 * g + 1] * mul), pack_op2<OF>(x[4 * g + 2] * mul, x[4 * g + 3] * mul)};
 }
 // rows 0..48 of the staging tile -> the tensor rows rr of wa_rows
 __device__ __forceinline__ void wa_flush_rows(const unsigned char* st, const long (&rr)[4], bf16_t* __restrict__ base, long ld, int lane) {
@@ -142,14 +143,16 @@ __device__ __forceinline__ void wa_flush_rows(const unsigned char* st, const lon
     if (row < WA_N) *(u32x4*)(base + rr[i] * ld + 8 * (lane & 3)) = *(const u32x4*)(st + row * WA_ST_PITCH + 16 * (lane & 3));
   }
 }
+template <int OF = 0>
 __device__ __forceinline__ float wa_dot8(const s16x8& a, const s16x8& b) {
   const u32x4 ua = *(const u32x4*)&a, ub = *(const u32x4*)&b;
   float s = 0.f;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { s = fmaf(bf_lo(ua[e]), bf_lo(ub[e]), s); s = fmaf(bf_hi(ua[e]), bf_hi(ub[e]), s); }
+  for (int e = 0; e < 4; ++e) { s = fmaf(op_lo<OF>(ua[e]), op_lo<OF>(ub[e]), s); s = fmaf(op_hi<OF>(ua[e]), op_hi<OF>(ub[e]), s); }
   return s;
 }
 
+template <int OF /* operand format of qkv / o: VDK_OPF_BF16 | VDK_OPF_F16 */>
 __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o, long ldo, float* __restrict__ lse,
                                                                    const float* __restrict__ bm, int nWm, long items, int H, float scale,
                                                                    const int* __restrict__ rowidx) {
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
       for (int kt = 0; kt < 2; ++kt) {
         sa[kt] = as_zero16();
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) sa[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qf[qt][ks], sa[kt], 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks) sa[kt] = vdk_mfma32<OF>(kf[kt][ks], qf[qt][ks], sa[kt]);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 b = bq[qt][kt][g];
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
       for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sa[kt][r] *= inv;
-        as_pack_b(sa[kt], pf[kt][qt]);                     // P rounded to bf16 once, as the operand of P v
+        as_pack_b<OF>(sa[kt], pf[kt][qt]);                     // P rounded to bf16 once, as the operand of P v
       }
       if (lse && hi == 0 && 32 * qt + l31 < WA_N) lse[(win * H + h) * WA_N + 32 * qt + l31] = mx + logf(sum);
     }
@@ -234,8 +237,8 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt[kt][s], pf[kt][qt][s], oa, 0, 0, 0);
-      wa_stage_t(St[w], oa, 1.0f, qt, l31, hi);
+        for (int s = 0; s < 2; ++s) oa = vdk_mfma32<OF>(vt[kt][s], pf[kt][qt][s], oa);
+      wa_stage_t<OF>(St[w], oa, 1.0f, qt, l31, hi);
     }
     VDK_WAVE_LDS_SYNC();
     wa_flush_rows(St[w], rr, o + h * WA_HD, ldo, lane);
@@ -243,6 +246,7 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
 }
 
 // one wave walks the windows win = slot, slot + nslot, ... of ONE head (h = wave index mod H); dbias_part: f32 [waves][WA_FRAG] in fragment order
+template <int OF>
 __global__ __launch_bounds__(64 * WA_BW, WA_BWD_MINW) void window_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                                           long ldo, const float* __restrict__ lse, const float* __restrict__ bm, int nWm, long nwin, int H,
                                                                           float scale, bf16_t* __restrict__ dqkv, long ldd, float* __restrict__ dbias_part,
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(64 * WA_BW, WA_BWD_MINW) void window_attn_bwd_mfma_
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                          // D = rowsum(dO * O) on the rounded tensors: 8 products per lane, 4 lanes per row
       const s16x8 gq = *(const s16x8*)(Gt[w] + i * 1024 + lane * 16);
-      float d = wa_dot8(gq, *(const s16x8*)&orow[i]);
+      float d = wa_dot8<OF>(gq, *(const s16x8*)&orow[i]);
       d += __shfl_xor(d, 1);
       d += __shfl_xor(d, 2);
       if ((lane & 3) == 0) Dl[w][16 * i + (lane >> 2)] = d;
@@ -319,9 +323,9 @@ __global__ __launch_bounds__(64 * WA_BW, WA_BWD_MINW) void window_attn_bwd_mfma_
       for (int qt = 0; qt < 2; ++qt) {
         f32x16 sa = as_zero16(), dp = as_zero16();
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qf[qt][ks], sa, 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks) sa = vdk_mfma32<OF>(kf[kt][ks], qf[qt][ks], sa);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][ks], gf[qt][ks], dp, 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks) dp = vdk_mfma32<OF>(vf[kt][ks], gf[qt][ks], dp);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 b = bq[qt][kt][g];
@@ -335,9 +339,9 @@ __global__ __launch_bounds__(64 * WA_BW, WA_BWD_MINW) void window_attn_bwd_mfma_
           }
         }
         s16x8 pfr[2];
-        as_pack_b(sa, pfr);
+        as_pack_b<OF>(sa, pfr);
         wa_put_pt(Pt[w], pfr, kt, qt, l31, hi);
-        as_pack_b(dp, dsf[kt][qt]);
+        as_pack_b<OF>(dp, dsf[kt][qt]);
       }
     VDK_WAVE_LDS_SYNC();
     bf16_t* dbase = dqkv + h * WA_HD;
@@ -354,8 +358,8 @@ __global__ __launch_bounds__(64 * WA_BW, WA_BWD_MINW) void window_attn_bwd_mfma_
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-          for (int s = 0; s < 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktr[kt][s], dsf[kt][qt][s], acc, 0, 0, 0);
-        wa_stage_t(St[w], acc, scale, qt, l31, hi);
+          for (int s = 0; s < 2; ++s) acc = vdk_mfma32<OF>(ktr[kt][s], dsf[kt][qt][s], acc);
+        wa_stage_t<OF>(St[w], acc, scale, qt, l31, hi);
       }
       VDK_WAVE_LDS_SYNC();
       wa_flush_rows(St[w], rr, dbase, ldd, lane);
@@ -366,9 +370,9 @@ __global__ __launch_bounds__(64 * WA_BW, WA_BWD_MINW) void window_attn_bwd_mfma_
       f32x16 acc = as_zero16();
 #pragma unroll
       for (int qs = 0; qs < 4; ++qs)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_tr32(Gt[w], 16 * qs, lane), as_tr_frag(Pt[w], 16 * qs, 32 * kt, lane), acc, 0, 0, 0);
+        acc = vdk_mfma32<OF>(wa_tr32(Gt[w], 16 * qs, lane), as_tr_frag(Pt[w], 16 * qs, 32 * kt, lane), acc);
       if (kt == 0) VDK_WAVE_LDS_SYNC();                    // dQ has left the staging tile
-      wa_stage_t(St[w], acc, 1.0f, kt, l31, hi);
+      wa_stage_t<OF>(St[w], acc, 1.0f, kt, l31, hi);
     }
     VDK_WAVE_LDS_SYNC();                                  // P has been read: the tile takes dS
     wa_flush_rows(St[w], rr, dbase + 2 * C, ldd, lane);
@@ -383,9 +387,9 @@ __global__ __launch_bounds__(64 * WA_BW, WA_BWD_MINW) void window_attn_bwd_mfma_
       f32x16 acc = as_zero16();
 #pragma unroll
       for (int qs = 0; qs < 4; ++qs)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_tr32(Qt[w], 16 * qs, lane), as_tr_frag(Pt[w], 16 * qs, 32 * kt, lane), acc, 0, 0, 0);
+        acc = vdk_mfma32<OF>(wa_tr32(Qt[w], 16 * qs, lane), as_tr_frag(Pt[w], 16 * qs, 32 * kt, lane), acc);
       if (kt == 0) VDK_WAVE_LDS_SYNC();                    // dV has left the staging tile
-      wa_stage_t(St[w], acc, scale, kt, l31, hi);
+      wa_stage_t<OF>(St[w], acc, scale, kt, l31, hi);
     }
     VDK_WAVE_LDS_SYNC();
     wa_flush_rows(St[w], rr, dbase + C, ldd, lane);
@@ -600,8 +604,9 @@ static int wa_check(const void* qkv, int64_t ld, int64_t windows, int32_t H, int
 static size_t wa_bm_bytes(int32_t nW, int32_t H) { return (size_t)(nW > 0 ? nW : 1) * H * WA_FRAG * 4; }
 // VDK_WA_BWD=2: the two-waves-per-SIMD form (A/B runs); default: the one-wave-per-SIMD form
 static bool wa_bwd_v1() { const char* e = getenv("VDK_WA_BWD"); return !(e && atoi(e) == 2); }
-#define WA_LAUNCH_BWD(GRID, ST, ...) do { if (wa_bwd_v1()) hipLaunchKernelGGL(window_attn_bwd_mfma_kernel, GRID, dim3(64 * WA_BW), 0, ST, __VA_ARGS__); \
-                                          else hipLaunchKernelGGL(window_attn_bwd2_mfma_kernel, GRID, dim3(64 * WA_BW), 0, ST, __VA_ARGS__); } while (0)
+#define WA_LAUNCH_BWD(OPF, GRID, ST, ...) do { if (OPF) hipLaunchKernelGGL(window_attn_bwd_mfma_kernel<VDK_OPF_F16>, GRID, dim3(64 * WA_BW), 0, ST, __VA_ARGS__); \
+                                               else if (wa_bwd_v1()) hipLaunchKernelGGL(window_attn_bwd_mfma_kernel<VDK_OPF_BF16>, GRID, dim3(64 * WA_BW), 0, ST, __VA_ARGS__); \
+                                               else hipLaunchKernelGGL(window_attn_bwd2_mfma_kernel, GRID, dim3(64 * WA_BW), 0, ST, __VA_ARGS__); } while (0)
 static long wa_bwd_waves(int64_t windows, int32_t H) {
   long waves = 4096 / H * H; if (waves > windows * H) waves = windows * H; if (waves < H) waves = H;
   return (waves + WA_BW * H - 1) / (WA_BW * H) * (WA_BW * H);             // whole workgroups, whole head groups
@@ -631,7 +636,7 @@ int vdk_window_attention_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, 
   const long items = (long)windows * H;
   long grid = (items + 3) / 4; if (grid > 4096) grid = 4096;
   wa_prep(bias, mask, nW, H, (float*)ws, (hipStream_t)stream);
-  hipLaunchKernelGGL(window_attn_fwd_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld, (bf16_t*)o, (long)ldo, lse, (const float*)ws,
+  hipLaunchKernelGGL(window_attn_fwd_mfma_kernel<VDK_OPF_BF16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld, (bf16_t*)o, (long)ldo, lse, (const float*)ws,
                      mask ? (int)nW : 1, items, (int)H, scale, (const int*)rowidx);
   return vdk_check_launch("vdk_window_attention_fwd");
 }
@@ -657,7 +662,7 @@ int vdk_window_attention_bwd(const void* qkv, int64_t ld, const void* o, const v
   float* red = part + waves * WA_FRAG;
   hipStream_t st = (hipStream_t)stream;
   wa_prep(bias, mask, nW, H, bm, st);
-  WA_LAUNCH_BWD(dim3((unsigned)(waves / WA_BW)), st, (const bf16_t*)qkv, (long)ld, (const bf16_t*)o, (const bf16_t*)dout,
+  WA_LAUNCH_BWD(0, dim3((unsigned)(waves / WA_BW)), st, (const bf16_t*)qkv, (long)ld, (const bf16_t*)o, (const bf16_t*)dout,
                 (long)ldo, lse, (const float*)bm, mask ? (int)nW : 1, (long)windows, (int)H, scale, (bf16_t*)dqkv, (long)ldd, part, (const int*)rowidx);
   // partial row r belongs to head r mod H: a group of H consecutive rows IS one [H, 64 x 64] tensor, and the sum over the groups (in group order) is d(bias)
   rc = vdk_reduce_rows_f32(part, (int64_t)H * WA_FRAG, (int32_t)(waves / H), (int64_t)H * WA_FRAG, red, 1.0f, stream);
@@ -687,22 +692,25 @@ int vdk_wa_prep_table(const float* table, const float* mask, int32_t nW, int32_t
   hipLaunchKernelGGL(wa_prep_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, mask, nWm, (int)H, bm);
   return VDK_OK;
 }
-int vdk_wa_fwd_bm(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, const float* bm, int32_t nWm, int64_t windows, int32_t H, float scale, const int32_t* rowidx, void* stream) {
+int vdk_wa_fwd_bm(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, const float* bm, int32_t nWm, int64_t windows, int32_t H, float scale, const int32_t* rowidx, int opf,
+                  void* stream) {
   const long items = (long)windows * H;
   long grid = (items + 3) / 4; if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(window_attn_fwd_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld, (bf16_t*)o, (long)ldo, lse, bm, (int)nWm, items,
-                     (int)H, scale, (const int*)rowidx);
+  if (opf) hipLaunchKernelGGL(window_attn_fwd_mfma_kernel<VDK_OPF_F16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld, (bf16_t*)o, (long)ldo, lse, bm, (int)nWm,
+                              items, (int)H, scale, (const int*)rowidx);
+  else hipLaunchKernelGGL(window_attn_fwd_mfma_kernel<VDK_OPF_BF16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld, (bf16_t*)o, (long)ldo, lse, bm, (int)nWm,
+                          items, (int)H, scale, (const int*)rowidx);
   return vdk_check_launch("vdk_wa_fwd_bm");
 }
 int vdk_wa_bwd_bm(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, const float* bm, int32_t nWm, int64_t windows, int32_t H, float scale,
-                  const int32_t* rowidx, void* dqkv, int64_t ldd, void* scratch, size_t scratch_bytes, const int32_t* uses, int32_t R, int32_t U, float* dtable, void* stream) {
+                  const int32_t* rowidx, void* dqkv, int64_t ldd, void* scratch, size_t scratch_bytes, const int32_t* uses, int32_t R, int32_t U, float* dtable, int opf, void* stream) {
   if (U > 64) return vdk_fail(VDK_EINVAL, "vdk_wa_bwd_bm: at most 64 uses per table entry");
   if (!scratch || scratch_bytes < vdk_wa_bwd_scratch_bytes(windows, H)) return vdk_fail(VDK_EWORKSPACE, "vdk_wa_bwd_bm: scratch too small");
   const long waves = wa_bwd_waves(windows, H);
   float* part = (float*)scratch;
   float* red = part + waves * WA_FRAG;
   hipStream_t st = (hipStream_t)stream;
-  WA_LAUNCH_BWD(dim3((unsigned)(waves / WA_BW)), st, (const bf16_t*)qkv, (long)ld, (const bf16_t*)o, (const bf16_t*)dout,
+  WA_LAUNCH_BWD(opf, dim3((unsigned)(waves / WA_BW)), st, (const bf16_t*)qkv, (long)ld, (const bf16_t*)o, (const bf16_t*)dout,
                 (long)ldo, lse, bm, (int)nWm, (long)windows, (int)H, scale, (bf16_t*)dqkv, (long)ldd, part, (const int*)rowidx);
   const int rc = vdk_reduce_rows_f32(part, (int64_t)H * WA_FRAG, (int32_t)(waves / H), (int64_t)H * WA_FRAG, red, 1.0f, stream);
   if (rc) return rc;

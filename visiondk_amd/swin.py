@@ -456,12 +456,15 @@ class SwinEngine:
     """owns the flat HBM buffers (fp32 master params, bf16 operand copies, grads, workspace) and calls vdk_swin_forward / vdk_swin_backward; the interface of vit.VitEngine
     (forward -> padded logits, backward(dlogits bf16), refresh_weights, params / grads / wb16 / n_floats / cp), so the fused train steps take either"""
 
-    operand = "bf16"
-    op_dtype = torch.bfloat16
     fp8 = 0
 
-    def __init__(self, spec: SwinSpec, device=None, backend: Optional[_lib.Backend] = None):
+    def __init__(self, spec: SwinSpec, device=None, backend: Optional[_lib.Backend] = None, operand: str = "bf16"):
         from . import _abi
+        from .vit import OPERANDS
+        assert operand in OPERANDS, operand
+        # 16-bit format of the GEMM / window-attention operands and the saved activations: "bf16", or "fp16" = what the reference's `torch.autocast(device_type=...)`
+        # (engine/procedure/train.py:118, no dtype => float16 on a GPU) computes in; vit.FusedTrainStep then runs the GradScaler protocol of train.py:203-215 around the step
+        self.operand = operand
         self.spec = spec
         self.be = backend or _lib.load()
         self.device = torch.device(device if device is not None else ("cuda" if self.be.device_only else "cpu"))
@@ -479,8 +482,8 @@ class SwinEngine:
         dev = self.device
         self.params = torch.zeros(self.n_floats, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(self.n_floats, dtype=torch.float32, device=dev)
-        self.wb16 = torch.zeros(self.n_floats, dtype=torch.bfloat16, device=dev)
-        self.wt16 = torch.zeros(self.n_transposed, dtype=torch.bfloat16, device=dev)
+        self.wb16 = torch.zeros(self.n_floats, dtype=self.op_dtype, device=dev)
+        self.wt16 = torch.zeros(self.n_transposed, dtype=self.op_dtype, device=dev)
         self.cp = (spec.num_classes + 7) // 8 * 8
         nst = len(spec.depths)
         self.features = spec.embed_dim * 2 ** (nst - 1)
@@ -488,6 +491,22 @@ class SwinEngine:
         self._ws: Optional[torch.Tensor] = None
         self._ws_batch = -1
         self._out: Optional[torch.Tensor] = None
+        self._weights_version = None
+
+    @property
+    def op_dtype(self) -> torch.dtype:
+        from .vit import OPERANDS
+        return OPERANDS[self.operand]
+
+    def set_operand(self, operand: str) -> None:
+        """switch between bf16 and fp16 operands (the fp32 master weights stay; the 16-bit copies are rebuilt on the next forward)"""
+        from .vit import OPERANDS
+        assert operand in OPERANDS, operand
+        if operand == self.operand:
+            return
+        self.operand = operand
+        self.wb16 = torch.zeros(self.n_floats, dtype=self.op_dtype, device=self.device)
+        self.wt16 = torch.zeros(self.n_transposed, dtype=self.op_dtype, device=self.device)
         self._weights_version = None
 
     def __deepcopy__(self, memo):
@@ -503,7 +522,7 @@ class SwinEngine:
         s = self.spec
         I4 = _abi.I32 * 4
         pad = lambda t: I4(*(tuple(t) + (0,) * (4 - len(t))))      # shallower members of the family (tests): trailing zeros
-        return _abi.SwinConfig(batch, s.img_size, s.in_chans, s.embed_dim, pad(s.depths), pad(s.heads), s.num_classes, s.ln_eps)
+        return _abi.SwinConfig(batch, s.img_size, s.in_chans, s.embed_dim, pad(s.depths), pad(s.heads), s.num_classes, s.ln_eps, _abi.F16_ if self.operand == "fp16" else _abi.BF16)
 
     def _workspace(self, batch: int) -> torch.Tensor:
         if self._ws is None or self._ws_batch != batch:
@@ -553,11 +572,11 @@ class SwinEngine:
         return self._out
 
     def backward(self, dout: torch.Tensor, on_ready=None) -> torch.Tensor:
-        """dlogits bf16 [B, Cp] (feature mode: f32 [B * 49, 8 E]) -> self.grads (flat fp32, overwritten); needs the workspace of the matching forward"""
+        """dlogits in the operand format [B, Cp] (feature mode: f32 [B * 49, 8 E]) -> self.grads (flat fp32, overwritten); needs the workspace of the matching forward"""
         from . import _abi
         B = dout.shape[0] if self.cp else dout.shape[0] // self.map_rows
         assert B == self._ws_batch and dout.is_contiguous()
-        assert (dout.dtype == torch.bfloat16 and dout.shape[1] == self.cp) if self.cp else (dout.dtype == torch.float32 and dout.shape[1] == self.features)
+        assert (dout.dtype == self.op_dtype and dout.shape[1] == self.cp) if self.cp else (dout.dtype == torch.float32 and dout.shape[1] == self.features)
         cfg = self._cfg(B)
         be = self.be
         cb = _abi.GRAD_READY_FN(lambda user, off, n: on_ready(off, n)) if on_ready is not None else _abi.GRAD_READY_FN(0)
@@ -591,8 +610,9 @@ class _SwinFunction(torch.autograd.Function):
             B, Cn = dout.shape
             stage = torch.zeros((B, eng.cp), dtype=torch.float32, device=dout.device)
             stage[:, :Cn].copy_(dout)
-            dl = torch.empty((B, eng.cp), dtype=torch.bfloat16, device=dout.device)
-            be.check(be.lib.vdk_cast_f32_bf16(be.ptr(stage), be.ptr(dl), stage.numel(), be.stream()), "vdk_cast_f32_bf16")
+            dl = torch.empty((B, eng.cp), dtype=eng.op_dtype, device=dout.device)
+            cast = be.lib.vdk_cast_f32_f16 if eng.operand == "fp16" else be.lib.vdk_cast_f32_bf16
+            be.check(cast(be.ptr(stage), be.ptr(dl), stage.numel(), be.stream()), "vdk_cast_f32_16")
             g = eng.backward(dl)
         grads = tuple(g[off:off + numel].view(shape) for (_, off, numel, shape) in eng.entries)
         return (None, None) + grads
@@ -604,10 +624,10 @@ class SwinTransformer(nn.Module):
     mlp.{fc1, fc2}}, norm, head.fc) with parameter-only holders, so named_parameters() / state_dict() / load_state_dict() carry timm's key names; every Parameter is a view
     into the engine's flat fp32 buffer.  forward(x [B, 3, 224, 224]) -> logits [B, C]; num_classes = 0: the normed NHWC map [B, 7, 7, C_last] (timm's forward_features)."""
 
-    def __init__(self, spec: SwinSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None):
+    def __init__(self, spec: SwinSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None, operand: str = "bf16"):
         super().__init__()
         self.spec = spec
-        self.engine = SwinEngine(spec, device=device, backend=backend)
+        self.engine = SwinEngine(spec, device=device, backend=backend, operand=operand)
         self.be = self.engine.be
         self.num_classes = spec.num_classes
         self.num_features = self.engine.features
@@ -680,7 +700,7 @@ class SwinTransformer(nn.Module):
 
 
 def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, img_size: int = 224, device=None, backend=None, seed: Optional[int] = None,
-                 native: bool = True, **kw):
+                 native: bool = True, operand: str = "bf16", **kw):
     """timm.create_model(name, pretrained=..., num_classes=...) for the swin_*_patch4_window7_224 family (models/classifier/classify_model.py:49-54); native=False: the
     autograd-node form of round 3 (the engine's cross-check)"""
     name = name[5:] if name.startswith("timm-") else name
@@ -688,5 +708,9 @@ def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, i
         raise KeyError(f"unknown Swin id {name!r}: {sorted(TIMM_SWINS)}")
     if pretrained:
         raise RuntimeError("there is no network here: load a checkpoint with load_state_dict (timm names)")
-    cls = SwinTransformer if native else SwinTransformerAutograd
-    return cls(SwinSpec(img_size=img_size, num_classes=num_classes, **TIMM_SWINS[name]), device=device, backend=backend, seed=seed)
+    spec = SwinSpec(img_size=img_size, num_classes=num_classes, **TIMM_SWINS[name])
+    if native:
+        return SwinTransformer(spec, device=device, backend=backend, seed=seed, operand=operand)
+    if operand != "bf16":
+        raise NotImplementedError("the autograd-node form runs on bf16 operands; fp16 is the native engine's (native=True)")
+    return SwinTransformerAutograd(spec, device=device, backend=backend, seed=seed)
