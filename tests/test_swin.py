@@ -380,7 +380,7 @@ def test_fused_step_fp16_swin_runs_the_grad_scaler_protocol(be, dev):
     torch.manual_seed(5)
     bufs = None
     for it in range(2):
-        x = torch.randn(4, 3, 224, 224); y = torch.randint(0, 7, (4,))
+        x = torch.randn(2, 3, 224, 224); y = torch.randint(0, 7, (2,))
         _, loss_ref, _, _, bufs = train_step_reference(ref, x, y, label_smoothing=0.05, max_norm=10.0, momentum_bufs=bufs, ema=None, updates=it, **hyp)
         step.step(x.to(dev), y.to(dev))
         assert abs(step.loss_value() - loss_ref.item()) < 2e-3 * abs(loss_ref.item())

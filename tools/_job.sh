@@ -1,3 +1,3 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_swin.py -x -q -m gpu -s 2>&1 | grep -E "passed|failed|logits|Error" | tail -6
-for op in fp16 bf16 fp16 bf16; do timeout 300 python tools/bench_swin.py 128 10 native $op 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['operand'], d['ms_per_step'], d['losses'])"; done
+timeout 3000 python -m pytest tests/ -x -q -m gpu > gpurun_out/gpu_tests_full.log 2>&1; grep -E "passed|failed" gpurun_out/gpu_tests_full.log | tail -2
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3

@@ -32,7 +32,9 @@ def main():
     dt = torch.bfloat16
     res = []
     stages = [(401408, 128, 2), (100352, 256, 2), (25088, 512, 18), (6272, 1024, 2)]
-    only = sys.argv[3] if len(sys.argv) > 3 else None          # e.g. "tn": only the weight-gradient forms
+    only = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else None          # e.g. "tn": only the weight-gradient forms
+    if len(sys.argv) > 4:          # other row counts / widths, "rows:channels:blocks,..." (e.g. ConvNeXt-B at batch 512: 1605632:128:3,401408:256:3,100352:512:27,25088:1024:3)
+        stages = [tuple(int(v) for v in t.split(":")) for t in sys.argv[4].split(",")]
     tot_auto = tot_best = 0.0
     for T, C, nblk in stages:
         shapes = [("qkv", T, 3 * C, C, "bias"), ("proj", T, C, C, "res"), ("fc1", T, 4 * C, C, "gelu"), ("fc2", T, C, 4 * C, "res"), ("dfc2", T, 4 * C, C, "dgelu"),
