@@ -65,7 +65,10 @@ def main():
             variants = {}
             if trans:
                 r = tn_rule(M, N, K)
-                for s in sorted({max(1, r // 2), r, min(64, r * 2)}):
+                cand = {max(1, r // 2), r, min(64, r * 2)}
+                if ((M + 255) // 256) * ((N + 127) // 128) <= 4:          # tiny outputs: one or two tiles -- more splits than the rule's cap of 64 (one workgroup per split and tile)
+                    cand |= {128, 256, 512}
+                for s in sorted(cand):
                     variants[f"tn_split{s}" + ("(rule)" if s == r else "")] = (0, {"trans": True, "splitk": s})
                     variants[f"tn_k6_split{s}"] = (6, {"trans": True, "splitk": s})
             else:
