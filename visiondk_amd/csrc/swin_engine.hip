@@ -38,13 +38,6 @@ int vdk_layernorm_fwd(const float*, int64_t, int32_t, int32_t, const float*, con
 int vdk_layernorm_bwd_workspace_bytes(int32_t, int32_t, size_t*);
 int vdk_colsum_bf16_workspace_bytes(int32_t, int32_t, size_t*);
 int vdk_reduce_rows_f32(const float*, int64_t, int32_t, int64_t, float*, float, void*);
-int vdk_window_attention_fwd_workspace_bytes(int32_t, int32_t, size_t*);
-int vdk_window_attention_fwd(const void*, int64_t, void*, int64_t, float*, const float*, const float*, int32_t, int64_t, int32_t, int32_t, int32_t, float, const int32_t*, void*,
-                             size_t, void*);
-int vdk_window_attention_bwd_workspace_bytes(int64_t, int32_t, int32_t, size_t*);
-int vdk_window_attention_bwd(const void*, int64_t, const void*, const void*, int64_t, const float*, const float*, const float*, int32_t, int64_t, int32_t, int32_t, int32_t, float,
-                             const int32_t*, void*, int64_t, float*, void*, size_t, void*);
-int vdk_relpos_bias_table_grad(const float*, const int32_t*, int32_t, int32_t, int32_t, int32_t, float*, void*);
 int vdk_avgpool_rows_f32_fwd(const float*, float*, int32_t, int32_t, int32_t, void*);
 int vdk_avgpool_rows_f32_bwd(const float*, float*, void*, int32_t, int32_t, int32_t, void*);
 int vdk_gemm_c_colsum_rows(int32_t, int32_t, int32_t);
@@ -180,7 +173,7 @@ struct WsPlan {
   StageW st[4];
   size_t fmap, fstats, pooled, hf;        // f32 [T3, D]; 2 x [T3]; f32 [B, D]; bf16 [Bp, D]
   // backward scratch (sized for the largest stage)
-  size_t dxa, dxm, dxab, dxmb, dsm, du, dqkv, dbias, dpool, dhf;
+  size_t dxa, dxm, dxab, dxmb, dsm, du, dqkv, dpool, dhf;
   size_t tA, tB, slabs, slabs_bytes, lnws, lnws_bytes, csws, csws_bytes, waws, waws_bytes;
   long tcols; size_t trows;
 };
@@ -227,7 +220,7 @@ void sw_plan(const SwDims& d, WsPlan* w) {
   w->patches = w_take(cur, (size_t)d.T[0] * d.Kpe * 2);
   w->petmp = w_take(cur, (size_t)d.T[0] * d.E * 4);
   w->pestats = w_take(cur, (size_t)d.T[0] * 2 * 4);
-  size_t maxTD = 0, maxTM = 0, maxT3 = 0, maxHN = 0, sl = 0, trows = 0;
+  size_t maxTD = 0, maxTM = 0, maxT3 = 0, sl = 0, trows = 0;
   long tcols = d.Bp;
   size_t lnmax = 0, csmax = 0, wamax = 0;
   for (int i = 0; i < d.nst; ++i) {
@@ -258,7 +251,6 @@ void sw_plan(const SwDims& d, WsPlan* w) {
     if (T * C > maxTD) maxTD = T * C;
     if (T * M > maxTM) maxTM = T * M;
     if (T * 3 * C > maxT3) maxT3 = T * 3 * C;
-    if (H * SW_N * SW_N > maxHN) maxHN = H * SW_N * SW_N;
     if ((long)up(T, 64) > tcols) tcols = (long)up(T, 64);
     if (M > trows) trows = M;
     const int sh[4][2] = {{(int)M, (int)C}, {(int)C, (int)M}, {3 * (int)C, (int)C}, {(int)C, (int)C}};
@@ -285,7 +277,6 @@ void sw_plan(const SwDims& d, WsPlan* w) {
   w->dxa = w_take(cur, maxTD * 4); w->dxm = w_take(cur, maxTD * 4);
   w->dxab = w_take(cur, maxTD * 2); w->dxmb = w_take(cur, maxTD * 2); w->dsm = w_take(cur, maxTD * 2);
   w->du = w_take(cur, maxTM * 2); w->dqkv = w_take(cur, maxT3 * 2);
-  w->dbias = w_take(cur, maxHN * 4);
   w->dpool = w_take(cur, (size_t)d.B * D * 4); w->dhf = w_take(cur, (size_t)d.Bp * D * 2);
   w->trows = trows; w->tcols = tcols;
   w->tA = w_take(cur, trows * (size_t)tcols * 2); w->tB = w_take(cur, trows * (size_t)tcols * 2);
@@ -326,13 +317,6 @@ __global__ __launch_bounds__(256) void swin_mask_kernel(float* __restrict__ mask
 }
 __device__ __forceinline__ int swin_rel(int qi, int kj) {      // relative_position_index[q][k] = (yq - yk + 6) * 13 + (xq - xk + 6)
   return (qi / SW_WS - kj / SW_WS + SW_WS - 1) * (2 * SW_WS - 1) + (qi % SW_WS - kj % SW_WS + SW_WS - 1);
-}
-// bias[h][q][k] = table[index[q][k]][h]   (the gather timm does per forward)
-__global__ __launch_bounds__(256) void swin_bias_gather_kernel(const float* __restrict__ table, int H, float* __restrict__ bias) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= H * SW_N * SW_N) return;
-  const int kj = i % SW_N, qi = (i / SW_N) % SW_N, h = i / (SW_N * SW_N);
-  bias[i] = table[swin_rel(qi, kj) * H + h];
 }
 // uses[r][0 .. U): the positions q * 49 + k that read table entry r, ascending, -1 padded (U = 49)
 __global__ void swin_uses_kernel(int* __restrict__ uses) {
@@ -548,7 +532,6 @@ int vdk_swin_backward(const VdkSwinConfig* cfg, const void* dout, const float* p
   float* dxa = (float*)(base + w.dxa); float* dxm = (float*)(base + w.dxm);
   bf16_t* dxab = (bf16_t*)(base + w.dxab); bf16_t* dxmb = (bf16_t*)(base + w.dxmb); bf16_t* dsm = (bf16_t*)(base + w.dsm);
   bf16_t* du = (bf16_t*)(base + w.du); bf16_t* dqkv = (bf16_t*)(base + w.dqkv);
-  float* dbias = (float*)(base + w.dbias);
   char* lnws0 = base + w.lnws; char* lnws1 = lnws0 + w.lnws_bytes;
   auto csws = [&](int slot) { return base + w.csws + (size_t)slot * w.csws_bytes; };
   const int T3 = (int)d.T[d.nst - 1], D = d.dim[d.nst - 1];
