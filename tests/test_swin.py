@@ -411,3 +411,27 @@ def test_swin_base_full_size_fp16_meets_the_stated_tolerance(hip):
     res = {"logits": _rel(y, yr), "loss": abs(loss.item() - loss_r.item()) / abs(loss_r.item()), "worst_grad": errs[-1], "median_grad": errs[len(errs) // 2]}
     print(res)
     assert res["logits"] <= 1e-3 and res["worst_grad"][0] <= 5e-3, res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["swin_tiny_patch4_window7_224", "swin_large_patch4_window7_224"])
+def test_swin_family_full_size_fp16_meets_the_stated_tolerance(hip, name):
+    """the other widths of the family (96 and 192 channels: K = 96 / 192 GEMMs, 3 .. 48 heads) at full size on fp16 operands against the fp32 oracle: <= 1e-3 / <= 5e-3, and
+    a fused training step runs"""
+    from visiondk_amd import vit
+    torch.manual_seed(0)
+    cfg = swin.TIMM_SWINS[name]
+    model = swin.create_model(name, num_classes=37, device="cuda:0", backend=hip, operand="fp16")
+    ref = SwinTransformerRef(num_classes=37, embed_dim=cfg["embed_dim"], depths=cfg["depths"], heads=cfg["heads"])
+    model.load_state_dict(ref.state_dict(), strict=True)
+    x = torch.randn(2, 3, 224, 224); t = torch.randint(0, 37, (2,))
+    y = model(x.cuda()); yr = ref(x)
+    s = 1024.0
+    (torch.nn.functional.cross_entropy(y, t.cuda()) * s).backward(); torch.nn.functional.cross_entropy(yr, t).backward()
+    errs = sorted((_rel(p.grad / s, pr.grad), n) for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()))
+    print(name, _rel(y, yr), errs[-1])
+    assert _rel(y, yr) <= 1e-3 and errs[-1][0] <= 5e-3, (_rel(y, yr), errs[-1])
+    step = vit.FusedTrainStep(model, lr=0.01)
+    xb = torch.randn(16, 3, 224, 224, device="cuda"); yb = torch.randint(0, 37, (16,), device="cuda")
+    step.step(xb, yb)
+    assert step.loss_value() == step.loss_value() and step.skipped_steps() == 0          # finite, no overflow at the initial scale
