@@ -246,3 +246,21 @@ def test_set_operand_switches_an_existing_model(be, dev):
         lb2 = model(x.to(dev)).clone()
     assert torch.equal(lb, lb2)
     assert _rel(lh, want) < 0.35 * _rel(lb, want) and _rel(lh, want) <= NORTH_STAR_LOGITS
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,dim,depth,heads,mlp", [("vit_small_patch16_224", 384, 12, 6, 1536), ("vit_large_patch16_224", 1024, 24, 16, 4096)])
+def test_vit_family_full_size_fp16_operands_within_the_stated_tolerance(hip, name, dim, depth, heads, mlp):
+    """the narrower and the wider / deeper members of the family (384 and 1024 channels, 24 blocks) at full size on fp16 operands against ONE fp32 evaluation of the oracle
+    (the base model's test above also runs the operand-rounded and float64 arms): the same literal bounds"""
+    from oracle.parity import vit_pair
+    ref, model = vit_pair(hip, "cuda:0", 224, 16, dim, depth, heads, mlp, 1000, seed=2, operand="fp16")
+    torch.manual_seed(6)
+    x = torch.randn(2, 3, 224, 224); y = torch.randint(0, 1000, (2,))
+    S = 1024.0
+    lo = model(x.cuda()); lr = ref(x)
+    (torch.nn.functional.cross_entropy(lo, y.cuda(), label_smoothing=0.05) * S).backward()
+    torch.nn.functional.cross_entropy(lr, y, label_smoothing=0.05).backward()
+    errs = sorted((_rel(p.grad / S, pr.grad), n) for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()))
+    print(name, _rel(lo, lr), errs[-1])
+    assert _rel(lo, lr) <= NORTH_STAR_LOGITS and errs[-1][0] <= NORTH_STAR_GRAD, (_rel(lo, lr), errs[-1])
