@@ -72,6 +72,25 @@ def test_wide_head_fused_form_equals_autograd_form(be, dev, tag):
     assert _rel(df, feats.grad) < 2e-2 and _rel(dW, h.weight.grad) < 2e-2
 
 
+def test_arcface_fast_path_equals_the_generic_evaluation(be, dev, monkeypatch):
+    """wide ArcFace heads (cfg3: 10^6 identities) evaluate the margin once per row -- the target's logit and jacobian -- and every other entry as s * clamp(cos) with a
+    select; VDK_MARGIN_GENERIC=1 runs the generic per-entry evaluation: the same expressions, so loss rows and both gradients are bit-identical.  Includes cosines pushed
+    outside [-1, 1] (the clamp's zero jacobian) and a target beyond cos(pi - m) (the fallback branch)."""
+    torch.manual_seed(7)
+    D, Cn, B = 64, 5003, 6
+    h = heads.ArcFace(D, Cn, margin_arc=0.35, margin_am=0.1, scale=32, backend=be, device=dev)
+    feats = torch.randn(B, D, device=dev)
+    with torch.no_grad():
+        h.weight[:, 5] = -feats[1] * 3.0            # target of row 1 nearly opposite: cos < cos(pi - m)
+    labels = torch.tensor([0, 5, 1234, 4096, 17, 4999], device=dev)
+    outs = []
+    for generic in ("0", "1"):
+        monkeypatch.setenv("VDK_MARGIN_GENERIC", generic)
+        outs.append(h.margin_ce(feats, labels, label_smoothing=0.1))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("tag", ["arcface", "circle", "mv_am"])
 def test_sharded_form_with_one_shard_equals_fused_form(be, dev, tag):
     """heads.sharded_margin_ce without a process group = one shard holding every class: its three local passes (target cosine, statistics, gradient) must

@@ -232,6 +232,9 @@ __global__ __launch_bounds__(256) void margin_ce_kernel(MarginP P, const float* 
 // v_exp_f32 on x * log2(e): 2 instructions against libm expf's ~12 (range reduction + polynomial); relative error ~2^-22 on |x| < 90, i.e. inside the rounding of the
 // softmax sums.  The narrow-head kernel above (golden-vector comparisons) keeps expf.
 __device__ __forceinline__ float vexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+// ARC (ArcFace without per-row margins -- cfg3's head): every entry but the row's target is s * clamp(cos), so the margin function is evaluated ONCE per row (the target's
+// logit and jacobian) and an entry costs a clamp, a multiply and a select instead of the generic evaluation's branches; the same expressions, bit-identical results.
+template <bool ARC>
 __global__ __launch_bounds__(256) void margin_ce_vec_kernel(MarginP P, const float* __restrict__ cosv, long ldc, int C, const long long* __restrict__ y,
                                                             float label_smoothing, float gscale, float* __restrict__ loss_rows, bf16_t* __restrict__ dcos,
                                                             long lddc) {
@@ -241,10 +244,19 @@ __global__ __launch_bounds__(256) void margin_ce_vec_kernel(MarginP P, const flo
   const float* cr = cosv + (long)row * ldc;
   const int yt = (int)y[row];
   const RowCtx R = margin_row_ctx(P, cr[yt]);
+  float lg_t = 0.f, jc_t = 0.f;
+  if (ARC) margin_eval(P, R, cr[yt], true, lg_t, jc_t);
+  auto ev = [&](float cv, bool tg, float& lg, float& jc) {
+    if (ARC) {
+      const float c = fminf(fmaxf(cv, -1.0f), 1.0f);
+      lg = tg ? lg_t : P.s * c;
+      jc = tg ? jc_t : (c == cv ? P.s : 0.0f);          // s * (1 inside the clamp's range, 0 outside)
+    } else margin_eval(P, R, cv, tg, lg, jc);
+  };
   const int C4 = C & ~3;
   float m = -3.0e38f, se = 0.f, sm = 0.f;
   auto visit = [&](float cv, int c) {
-    float lg, jc; margin_eval(P, R, cv, c == yt, lg, jc);
+    float lg, jc; ev(cv, c == yt, lg, jc);
     sm += lg;
     if (lg > m) { se *= vexp(m - lg); m = lg; }
     se += vexp(lg - m);
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(256) void margin_ce_vec_kernel(MarginP P, const flo
   auto visit4 = [&](const f32x4& cv, int c) {
     float lg[4], jc;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) margin_eval(P, R, cv[e], c + e == yt, lg[e], jc);
+    for (int e = 0; e < 4; ++e) ev(cv[e], c + e == yt, lg[e], jc);
     sm += (lg[0] + lg[1]) + (lg[2] + lg[3]);
     const float m4 = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
     if (m4 > m) { se *= vexp(m - m4); m = m4; }
@@ -280,7 +292,7 @@ __global__ __launch_bounds__(256) void margin_ce_vec_kernel(MarginP P, const flo
   if (!dcos) return;
   const float inv = 1.0f / se, epsc = label_smoothing / (float)C;
   auto grad = [&](float cv, int c) -> float {
-    float lg, jc; margin_eval(P, R, cv, c == yt, lg, jc);
+    float lg, jc; ev(cv, c == yt, lg, jc);
     float g = vexp(lg - mx) * inv - epsc;
     if (c == yt) g -= (1.0f - label_smoothing);
     return g * gscale * jc;
@@ -496,8 +508,13 @@ int vdk_margin_ce(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_
   if (!cosv || !labels || B <= 0 || C <= 0 || (dcos_bf16 && lddc < C)) return vdk_fail(VDK_EINVAL, "vdk_margin_ce: bad argument");
   const bool vec = !logits && (loss_rows || dcos_bf16) && C >= 4096 && (ldc & 3) == 0 && ((size_t)cosv & 15) == 0 &&
                    (!dcos_bf16 || ((lddc & 3) == 0 && ((size_t)dcos_bf16 & 7) == 0));
-  if (vec)
-    hipLaunchKernelGGL(margin_ce_vec_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, P, cosv, (long)ldc, (int)C, (const long long*)labels,
+  const char* genv = getenv("VDK_MARGIN_GENERIC");      // A/B and tests: =1 runs the generic evaluation also for ArcFace (read per call)
+  const bool generic_env = genv && atoi(genv) == 1;
+  if (vec && P.mode == VDK_HEAD_ARCFACE && !P.row_margin && !generic_env)
+    hipLaunchKernelGGL(margin_ce_vec_kernel<true>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, P, cosv, (long)ldc, (int)C, (const long long*)labels,
+                       label_smoothing, grad_scale, loss_rows, (bf16_t*)dcos_bf16, (long)lddc);
+  else if (vec)
+    hipLaunchKernelGGL(margin_ce_vec_kernel<false>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, P, cosv, (long)ldc, (int)C, (const long long*)labels,
                        label_smoothing, grad_scale, loss_rows, (bf16_t*)dcos_bf16, (long)lddc);
   else
     hipLaunchKernelGGL(margin_ce_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, P, cosv, (long)ldc, (int)C, (const long long*)labels,
