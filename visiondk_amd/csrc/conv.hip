@@ -370,6 +370,39 @@ __global__ __launch_bounds__(256) void lscale_weight_prep_kernel(const float* __
   w2p[i] = v;
   w2pt[(long)k * C + c] = v;
 }
+// Every block's weight preparation in ONE launch (the engine's refresh after an optimizer step was 2 launches per block: ~75 launches of 5-25 us for ConvNeXt-B): job j
+// covers workgroups [first[j], first[j + 1]); element i of a job does the layer-scale fold of W2[i] and, while i < 49 C, the tap-major copy of the depthwise weight.
+struct CnPrepBatch { CnPrepJob job[40]; int first[41]; int n; };
+__global__ __launch_bounds__(256) void cn_prep_batch_kernel(CnPrepBatch b) {
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.first[j + 1]) ++j;
+  const CnPrepJob jb = b.job[j];
+  const long i = (long)((int)blockIdx.x - b.first[j]) * 256 + threadIdx.x;
+  const int C = jb.C, M = jb.M;
+  if (i < (long)C * 49) { const int t = (int)(i / C), c = (int)(i % C); jb.dwt[i] = jb.dw_w[c * 49 + t]; }
+  if (i < C) jb.b2p[i] = jb.gamma[i] * jb.b2[i];
+  if (i >= (long)C * M) return;
+  const int k = (int)(i % M), c = (int)(i / M);
+  const bf16_t v = f2bf(jb.gamma[c] * jb.w2[i]);
+  jb.w2p[i] = v;
+  jb.w2pt[(long)k * C + c] = v;
+}
+// in-library: n <= 40 blocks per call
+int vdk_convnext_prep_blocks(const CnPrepJob* jobs, int n, void* stream) {
+  for (int i0 = 0; i0 < n; i0 += 40) {
+    CnPrepBatch b; b.n = 0;
+    int blocks = 0;
+    for (int i = i0; i < n && i < i0 + 40; ++i) {
+      b.first[b.n] = blocks; b.job[b.n++] = jobs[i];
+      const long span = (long)jobs[i].C * (jobs[i].M > 49 ? jobs[i].M : 49);      // the longer of the two index ranges
+      blocks += (int)((span + 255) / 256);
+    }
+    b.first[b.n] = blocks;
+    if (blocks > 0) hipLaunchKernelGGL(cn_prep_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, b);
+  }
+  return vdk_check_launch("vdk_convnext_prep_blocks");
+}
+
 // chain rule back through the fold (one wave per output channel c):
 //   dW2[c][k] = gamma[c] dW2p[c][k];  db2[c] = gamma[c] db2p[c];  dgamma[c] = sum_k dW2p[c][k] W2[c][k] + db2p[c] b2[c]
 __global__ __launch_bounds__(256) void lscale_grad_kernel(const float* __restrict__ dw2p, const float* __restrict__ db2p, const float* __restrict__ w2,

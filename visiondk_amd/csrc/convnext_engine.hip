@@ -342,16 +342,18 @@ int vdk_convnext_refresh_weights(const VdkConvNextConfig* cfg, const float* para
   if (!skip_wb16) RC(vdk_cast_f32_bf16(params, wb16, p.total, stream));
   char* xb = (char*)wx;
   std::vector<VdkTcItem> jobs;      // the fc1^T (and head.fc^T) copies of all blocks in one launch
+  std::vector<CnPrepJob> prep;      // ... and every block's depthwise tap-major copy + layer-scale fold in another (conv.hip: cn_prep_batch_kernel)
   for (int i = 0; i < 4; ++i) {
     const int C = d.C[i], M = 4 * C;
     if (i > 0) RC(vdk_conv2x2_weight_prep(params + p.st[i].ds_w, xb + x.dsw[i], xb + x.dswt[i], C, d.C[i - 1], stream));
     for (int j = 0; j < d.depth[i]; ++j) {
       const BlkP& b = p.st[i].blk[j]; const BlkX& bx = x.blk[i][j];
-      RC(vdk_dwconv7_weight_prep(params + b.dw_w, (float*)(xb + bx.dwt), C, stream));
       jobs.push_back(VdkTcItem{params + b.fc1_w, xb + bx.fc1t, C, M, C, M, M});
-      RC(vdk_layerscale_weight_prep(params + b.fc2_w, params + b.fc2_b, params + b.gamma, xb + bx.fc2p, xb + bx.fc2pt, (float*)(xb + bx.b2p), C, M, stream));
+      prep.push_back(CnPrepJob{params + b.dw_w, (float*)(xb + bx.dwt), params + b.fc2_w, params + b.fc2_b, params + b.gamma, (bf16_t*)(xb + bx.fc2p), (bf16_t*)(xb + bx.fc2pt),
+                               (float*)(xb + bx.b2p), C, M});
     }
   }
+  RC(vdk_convnext_prep_blocks(prep.data(), (int)prep.size(), stream));
   if (d.ncls > 0) jobs.push_back(VdkTcItem{params + p.fc_w, xb + x.fct, d.C[3], d.Cp, d.C[3], d.Cp, d.Cp});
   return vdk_transpose_cast_batch(jobs.data(), (int)jobs.size(), stream);
 }

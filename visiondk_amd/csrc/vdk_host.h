@@ -42,3 +42,7 @@ int vdk_layernorm_bwd_deferred(const void* dy, int64_t lddy, int32_t dy_dtype, c
                                float* dxb_colsum = nullptr /* [C]: column sums of the bf16 output dxb (a Linear's bias gradient), reduction described by *job2 */, VdkReduceJob* job2 = nullptr,
                                const LnQ8* dxb_q8 = nullptr /* with dxb_colsum, C <= 1024, bf16 dy: dxb's fp8 copy rides along */,
                                int opf = 0 /* format of a 16-bit dy and of dxb (dy_dtype VDK_F16 implies fp16; an fp32 dy takes it from here) */);
+
+// conv.hip: every ConvNeXt block's weight preparation in one launch (depthwise weight tap-major, layer scale folded into fc2 in both orientations); in-library
+struct CnPrepJob { const float* dw_w; float* dwt; const float* w2; const float* b2; const float* gamma; unsigned short* w2p; unsigned short* w2pt; float* b2p; int C, M; };
+int vdk_convnext_prep_blocks(const CnPrepJob* jobs, int n, void* stream);
