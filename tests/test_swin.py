@@ -435,3 +435,16 @@ def test_swin_family_full_size_fp16_meets_the_stated_tolerance(hip, name):
     xb = torch.randn(16, 3, 224, 224, device="cuda"); yb = torch.randint(0, 37, (16,), device="cuda")
     step.step(xb, yb)
     assert step.loss_value() == step.loss_value() and step.skipped_steps() == 0          # finite, no overflow at the initial scale
+
+
+def test_face_train_step_rejects_fp16_operand_engines(be, dev):
+    """the face / CBIR loop of the reference has no autocast and no GradScaler: its step object refuses an fp16-operand backbone instead of writing bf16 operand copies over it"""
+    from visiondk_amd import face
+    swin.TIMM_SWINS["swin_test_patch4_window7_224"] = dict(embed_dim=32, depths=(1, 1, 1, 1), heads=(1, 2, 4, 8))
+    cfg = {"task": "cbir", "image_size": 224, "load_from": None,
+           "backbone": {"timm-swin_test_patch4_window7_224": {"pretrained": False, "image_size": 224, "feat_dim": 64}},
+           "head": {"arcface": {"feat_dim": 64, "num_class": 24, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
+    m = face.get_model(cfg, None, 0, backend=be, device=dev).model.train()
+    m.trainingwrapper["backbone"].model.engine.set_operand("fp16")
+    with pytest.raises(NotImplementedError):
+        face.FaceTrainStep(m, lr=0.01, momentum=0.9, weight_decay=5e-4)

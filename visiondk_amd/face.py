@@ -444,6 +444,9 @@ class FaceTrainStep:
         if not hasattr(self.bb.model, "engine"):
             raise NotImplementedError("FaceTrainStep needs a backbone with a native engine (ViT, ConvNeXt, Swin with native=True); the autograd-node Swin trains under "
                                       "the reference's own Trainer (torch optimizer over model.parameters())")
+        if getattr(self.bb.model.engine, "operand", "bf16") != "bf16":
+            raise NotImplementedError("FaceTrainStep runs the backbone on bf16 operands (or precision='fp32'): the reference's face / CBIR loop has no autocast and no GradScaler "
+                                      "(engine/procedure/train.py:217-227); fp16 operands belong to the classifier loop (vit.FusedTrainStep)")
         if precision == "fp32" and not hasattr(self.bb.model.engine, "precision"):
             raise NotImplementedError("precision='fp32' is built for the ConvNeXt backbones of the face / CBIR task (the engine with an fp32-class training mode)")
         self.precision = precision
