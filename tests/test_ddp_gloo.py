@@ -35,6 +35,46 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _worker_fp16(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["VDK_EMU_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.emu.emu_backend import load_emu
+    from tests.test_vit import SPEC
+    from visiondk_amd import comm, vit
+    be = load_emu()
+    model = vit.VisionTransformer(SPEC, device="cpu", backend=be, seed=100 + rank, operand="fp16")
+    c = comm.GradAllReduce(bucket_bytes=200_000)
+    c.broadcast_params(model.engine.params, src=0, engine=model.engine)
+    # rank 0 keeps the EMA like the bench does; the first step overflows on purpose (scale 2^30): BOTH ranks must skip it and halve their scale
+    step = vit.FusedTrainStep(model, lr=0.01, label_smoothing=0.05, ema=(rank == 0), comm=c, init_scale=2.0 ** 30)
+    torch.manual_seed(7)
+    x = torch.randn(4, 3, 32, 32); y = torch.randint(0, 10, (4,))
+    lo, hi = rank * 2, rank * 2 + 2
+    p0 = model.engine.params.clone()
+    step.step(x[lo:hi], y[lo:hi])
+    skipped_first = bool(torch.equal(model.engine.params, p0)) and step.skipped_steps() == 1
+    step.loss_state[0] = 1024.0                                   # (a usable scale for the second step)
+    step.step(x[lo:hi], y[lo:hi])
+    torch.save({"params": model.engine.params.clone(), "skipped_first": skipped_first, "skipped": step.skipped_steps(), "scale": step.loss_scale()}, f"{out_dir}/rank{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_two_rank_fp16_step_skips_and_steps_in_lockstep(tmp_path, emu):
+    """fp16 operands under data parallelism: the inf check runs on the ALL-REDUCED gradient inside the optimizer kernel, so every rank takes the same skip / step decision
+    (train.py:205-211 under DDP: `scaler.step` sees the averaged gradients) and the replicas stay bit-identical"""
+    port = 29500 + ((os.getpid() + 211) % 500)
+    mp.start_processes(_worker_fp16, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "rank0.pt"); r1 = torch.load(tmp_path / "rank1.pt")
+    assert r0["skipped_first"] and r1["skipped_first"]
+    assert r0["skipped"] == r1["skipped"] == 1 and r0["scale"] == r1["scale"]
+    assert torch.equal(r0["params"], r1["params"])
+    assert torch.isfinite(r0["params"]).all()
+
+
 @pytest.mark.slow
 def test_two_rank_step_equals_single_process(tmp_path, emu):
     port = 29500 + (os.getpid() % 500)
