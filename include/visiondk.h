@@ -135,6 +135,9 @@ typedef struct VdkGemmDesc {
   int32_t ab_dtype;        /* format of A, B, aux and a 16-bit C: VDK_BF16 (0, the default of a zeroed descriptor) or VDK_F16 -- IEEE half operands on v_mfma_f32_32x32x16_f16,
                               what the reference's `torch.autocast(device_type=...)` gives its matmuls on a GPU (engine/procedure/train.py:118: no dtype => float16).  With
                               VDK_F16 a 16-bit output is requested as c_dtype = VDK_F16.  fp16 operands exclude conv, a_colsum and stream-K. */
+  const float* col_scale;  /* NULL, or f32 [N]: the accumulator of column n is multiplied by col_scale[n] BEFORE bias / residual -- C = residual + (acc * col_scale + bias).
+                              ConvNeXt's layer scale (x + gamma * fc2(g), timm ConvNeXtBlock behind models/faceX/backbone/timm_wrapper.py:16-21) in the fc2 epilogue when the
+                              operands are fp16: gamma (1e-6 at timm's init) folded into an fp16 weight would underflow.  fp32 outputs with a bias only (act NONE, no split-K). */
 } VdkGemmDesc;
 int vdk_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t splitk, size_t* bytes);
 int vdk_gemm_streamk_workspace_bytes(size_t* bytes);
@@ -516,6 +519,10 @@ int vdk_avgpool_bwd(const void* dfeat, int64_t ld, float* dout, int32_t B, int32
 /* global average pool over the HW rows of every image of an f32 NHWC map, and its backward (f32 and / or bf16 map gradient): timm's classifier heads */
 int vdk_avgpool_rows_f32_fwd(const float* in, float* out, int32_t B, int32_t HW, int32_t C, void* stream);
 int vdk_avgpool_rows_f32_bwd(const float* dpool, float* dmap, void* dmap_bf16, int32_t B, int32_t HW, int32_t C, void* stream);
+/* x[i] *= scale[0] (reciprocal != 0: x[i] /= scale[0]) with the factor read from DEVICE memory when the kernel runs: GradScaler's loss scale entering a gradient tensor at the
+ * boundary of an fp16 graph (`scaler.scale(loss).backward()`, engine/procedure/train.py:205; FaceTrainStep multiplies d(loss)/d(embedding)), and a gradient region kept at a
+ * power-of-two scale returning to its size (the ConvNeXt engine's fc1 gradients under fp16 operands).  x 16-byte aligned. */
+int vdk_scale_dev_f32(float* x, int64_t n, const float* scale, int32_t reciprocal, void* stream);
 int vdk_preprocess_workspace_bytes(int32_t B, int32_t S, int32_t max_side, size_t* bytes);
 int vdk_preprocess_resize_pad_normalize(const uint8_t* pixels, const int64_t* offsets, const int32_t* wh, int32_t B, int32_t S, int32_t max_side, float mean0,
                                         float mean1, float mean2, float std0, float std1, float std2, float* out, int32_t* status, void* ws, size_t ws_bytes,
@@ -533,6 +540,10 @@ typedef struct VdkConvNextConfig {
   float ln_eps;
   int32_t num_classes;   /* 0: feature mode (num_classes=0, global_pool=''), what TimmWrapper builds; > 0: timm's classifier head -- global average pool ->
                           * head.norm -> head.fc -- what VisionWrapper.create_model builds (models/classifier/classify_model.py:49-54, `timm-convnext_*`) */
+  int32_t operand;       /* VDK_BF16 (0) | VDK_F16: format of the GEMM operands, the saved 16-bit activations and the 16-bit gradient tensors (wb16 / wx copies included).
+                          * VDK_F16 is what the face / CBIR step uses to stay within 1e-3 of the reference's fp32 loop (engine/procedure/train.py:217-227, no autocast there) and
+                          * what the classifier loop's autocast computes in (train.py:118); the caller multiplies the loss scale into dout (GradScaler, train.py:205) and
+                          * un-scales in the optimizer (vdk_sgd_step_amp).  The layer scale is then applied in the fc2 epilogue (VdkGemmDesc.col_scale), see csrc/convnext_engine.hip */
 } VdkConvNextConfig;
 /* flat parameter layout (timm state_dict order and names) + size of `wx`, the derived operand copies kept next to `wb16` */
 int vdk_convnext_param_count(const VdkConvNextConfig* cfg, int64_t* n_floats, int32_t* n_tensors, size_t* wx_bytes);
@@ -645,6 +656,11 @@ int vdk_attn_pool_bwd(const float* q, const void* kv, int64_t ldkv, const float*
 int vdk_colnorm_fwd(const float* W, int64_t ldw, int32_t D, int32_t C, int32_t Cp, float eps, float* inv, void* Wb, int64_t ldb, int32_t planes, void* stream);
 int vdk_colnorm_bwd(const float* W, int64_t ldw, const float* inv, const float* dWh, int64_t ldg, int32_t D, int32_t C, float* dW, int64_t ldo,
                     void* stream);
+/* vdk_colnorm_fwd / vdk_rownorm_fwd with the format of the planes as a parameter: dtype = VDK_BF16 | VDK_F16.  fp16 planes (hi = fp16(v), lo = fp16(v - hi)) are the
+ * operands of a head that runs under GradScaler with fp16 gradients (FaceTrainStep over an fp16 backbone): the cosines keep their fp32-class accuracy (|v| <= 1, the low
+ * plane's subnormals resolve 6e-8), and the two backward products read the hi plane with 8x less operand rounding than bf16's. */
+int vdk_colnorm_fwd_dt(const float* W, int64_t ldw, int32_t D, int32_t C, int32_t Cp, float eps, float* inv, void* Wb, int64_t ldb, int32_t planes, int32_t dtype, void* stream);
+int vdk_rownorm_fwd_dt(const float* f, int32_t B, int32_t Bp, int32_t D, float eps, float* fh, void* fb, void* fbt, float* inv, int32_t planes, int32_t dtype, void* stream);
 /* F.normalize(feats): fh f32 [B, D]; fb bf16 [Bp, D]; fbt bf16 [3D, Bp] = transposed split planes (hi, lo, hi), so that the
  * K = 3D GEMM fbt^T . Wb accumulates hi*hi + lo*hi + hi*lo (fp32-class cos); rows/cols B..Bp-1 zero; inv f32 [B] */
 int vdk_rownorm_fwd(const float* f, int32_t B, int32_t Bp, int32_t D, float eps, float* fh, void* fb, void* fbt, float* inv, int32_t planes, void* stream);
@@ -662,6 +678,10 @@ int vdk_margin_target_cos_direct(const void* fbt, int64_t ld_f, const void* wb, 
  * smoothing), dcos bf16 [B, lddc] = grad_scale * dLoss/dcos (padding columns zeroed) */
 int vdk_margin_ce(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t C, const int64_t* labels, float label_smoothing,
                   float grad_scale, float* logits, int64_t ldl, float* loss_rows, void* dcos_bf16, int64_t lddc, void* stream);
+/* vdk_margin_ce under GradScaler (`scaler.scale(loss).backward()`, engine/procedure/train.py:205): dcos (dc_dtype = VDK_BF16 | VDK_F16) = loss_scale[0] * grad_scale *
+ * dLoss/dcos with the scale read from DEVICE memory (NULL: 1); loss_rows and logits are never scaled */
+int vdk_margin_ce_amp(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t C, const int64_t* labels, float label_smoothing, float grad_scale,
+                      const float* loss_scale, float* logits, int64_t ldl, float* loss_rows, void* dcos16, int64_t lddc, int32_t dc_dtype, void* stream);
 /* the same with d(loss)/d(cos) left in fp32 [B, lddc] (padding columns zeroed): head of the fp32-class training mode (FaceTrainStep(precision="fp32")) */
 int vdk_margin_ce_f32(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t C, const int64_t* labels, float label_smoothing, float grad_scale,
                       float* loss_rows, float* dcos_f32, int64_t lddc, void* stream);

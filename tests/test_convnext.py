@@ -7,15 +7,15 @@ from oracle.convnext_ref import ConvNeXtRef
 from visiondk_amd import convnext
 
 
-def _pair(be, dev, depths, dims, img, seed=0, num_classes=0):
+def _pair(be, dev, depths, dims, img, seed=0, num_classes=0, operand="bf16", gamma=None):
     spec = convnext.ConvNeXtSpec(img_size=img, depths=depths, dims=dims, num_classes=num_classes)
-    model = convnext.ConvNeXt(spec, device=dev, backend=be, seed=seed)
+    model = convnext.ConvNeXt(spec, device=dev, backend=be, seed=seed, operand=operand)
     ref = ConvNeXtRef(3, depths, dims, num_classes=num_classes)
     torch.manual_seed(seed)
     with torch.no_grad():   # non-trivial values everywhere (timm's init leaves biases at 0 and gamma at 1e-6: gradients would hide bugs)
         for n, p in ref.named_parameters():
             if n.endswith("gamma"):
-                p.copy_(torch.rand_like(p) * 0.5 + 0.25)
+                p.copy_(torch.rand_like(p) * 0.5 + 0.25 if gamma is None else gamma * (1.0 + torch.rand_like(p)))
             elif p.dim() == 1:
                 p.add_(torch.randn_like(p) * 0.1)
             else:
@@ -194,3 +194,59 @@ def test_fp32_training_mode_vs_oracle(be, dev, B, img, depths, dims):
         g, gr = p.grad.detach().cpu(), pr.grad
         r = ((g - gr).norm() / (gr.norm() + 1e-12)).item()
         assert r < 2e-5, (n, r)
+
+
+@pytest.mark.parametrize("gamma", [None, 1e-6])
+def test_fp16_operands_forward_backward_vs_oracle(be, dev, gamma):
+    """VdkConvNextConfig.operand = VDK_F16: 8x less operand rounding than bf16 -- map 6e-4 / gradients <= 2e-3 from the fp32 oracle here (bf16: 4e-3 / 1.2e-2) -- also at
+    timm's layer-scale init gamma = 1e-6, where gamma (.) W2 would underflow fp16: the forward applies gamma in the fc2 epilogue (VdkGemmDesc.col_scale), the backward runs the
+    branch at the block's power-of-two scale r and un-scales in LayerNorm backward (dy_scale) and over the fc1 gradients.  The output gradient carries a loss scale as
+    under GradScaler; the engine's gradients carry it too."""
+    model, ref = _pair(be, dev, (1, 1, 2, 1), (8, 16, 24, 32), 32, operand="fp16", gamma=gamma)
+    assert model.engine.wb16.dtype == torch.float16
+    torch.manual_seed(3)
+    x = torch.randn(2, 3, 32, 32)
+    y = model(x.to(dev)); yr = ref(x)
+    assert ((y.detach().cpu() - yr.detach()).norm() / yr.detach().norm()).item() < 1.5e-3
+    dy = torch.randn_like(yr)
+    S = 1024.0
+    y.backward((dy * S).to(dev)); yr.backward(dy)
+    worst = []
+    for (n, p), (nr, pr) in zip(model.named_parameters(), ref.named_parameters()):
+        assert n == nr
+        r = ((p.grad.detach().cpu() / S - pr.grad).norm() / (pr.grad.norm() + 1e-30)).item()
+        worst.append((r, n))
+        assert r < 5e-3, (n, r)
+    worst.sort()
+    assert worst[len(worst) // 2][0] < 2e-3, worst[len(worst) // 2]
+
+
+def test_fp16_classifier_train_step_runs_the_grad_scaler_protocol(be, dev):
+    """ClassifierTrainStep over an fp16 ConvNeXt classifier (the reference's autocast dtype, train.py:118) == CE -> scaled backward -> unscale -> clip -> SGD on the fp32
+    oracle, updates within 2e-2 (bf16: 0.12); an overflowing scale skips the step and halves the scale (scaler.step / scaler.update, train.py:209-211)."""
+    from visiondk_amd import resnet
+    ncls, img = 6, 32
+    model, ref = _pair(be, dev, (1, 1, 1, 1), (8, 16, 24, 32), img, num_classes=ncls, operand="fp16")
+    lr, mom, wd, max_norm = 0.05, 0.9, 5e-4, 0.05
+    step = resnet.ClassifierTrainStep(model, lr=lr, momentum=mom, weight_decay=wd, loss="ce", label_smoothing=0.1, max_norm=max_norm, ema=False, init_scale=4096.0)
+    assert step.amp
+    opt = torch.optim.SGD(ref.parameters(), lr=lr, momentum=mom, weight_decay=wd)
+    start = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    torch.manual_seed(5)
+    x = torch.randn(5, 3, img, img); t = torch.randint(0, ncls, (5,))
+    loss_r = torch.nn.functional.cross_entropy(ref(x), t, label_smoothing=0.1)
+    loss_r.backward()
+    assert torch.nn.utils.clip_grad_norm_(list(ref.parameters()), max_norm=max_norm) > max_norm
+    opt.step()
+    rows = step.step(x.to(dev), t.to(dev))
+    assert abs(rows.mean().item() - loss_r.item()) < 2e-3 * abs(loss_r.item())
+    assert step.skipped_steps() == 0
+    got = dict(model.named_parameters())
+    for n, p in ref.named_parameters():
+        upd_ref, upd = p.detach() - start[n], got[n].detach().cpu() - start[n]
+        r = ((upd - upd_ref).norm() / (upd_ref.norm() + 1e-12)).item()
+        assert r < 2e-2, (n, r)
+    step.load_scaler_state_dict(dict(step.scaler_state_dict(), scale=2.0 ** 40))
+    before = model.engine.params.clone()
+    step.step(x.to(dev), t.to(dev))
+    assert step.skipped_steps() == 1 and step.loss_scale() == 2.0 ** 39 and torch.equal(model.engine.params, before)

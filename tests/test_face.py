@@ -112,13 +112,13 @@ def test_extract_cbir_eval_embeddings(be, dev):
 
 
 # ---- CNN backbone (timm ConvNeXt) + BatchNorm2d neck: timm_wrapper.py:30-37 ----------------------------------------------------------
-def _build_cnn(be, dev, monkeypatch, dims=(8, 16, 24, 32), img=32):
+def _build_cnn(be, dev, monkeypatch, dims=(8, 16, 24, 32), img=32, operand="bf16"):
     from oracle.convnext_ref import TimmWrapperCNNRef
     from visiondk_amd import convnext
     depths = (1, 1, 2, 1)
     monkeypatch.setitem(convnext.TIMM_CONVNEXTS, "convnext_test", dict(depths=depths, dims=dims))
     cfg = {"task": "cbir", "image_size": img,
-           "backbone": {"timm-convnext_test": {"pretrained": False, "image_size": img, "feat_dim": 64}},
+           "backbone": {"timm-convnext_test": {"pretrained": False, "image_size": img, "feat_dim": 64, "operand": operand}},
            "head": {"arcface": {"feat_dim": 64, "num_class": 40, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
     torch.manual_seed(0)
     model = face.get_model(cfg, None, 0, backend=be, device=dev).model
@@ -297,3 +297,57 @@ def test_face_train_step_fp32_precision_matches_reference_update(be, dev, monkey
         tol = 0.3 if n in ("output_layer.0.bias", "output_layer.2.bias") else 2e-3
         assert r < tol, (n, r)
     assert _rel(head.weight.detach(), rhead.weight.detach()) < 1e-5
+
+
+def test_face_train_step_fp16_operands_under_the_grad_scaler(be, dev, monkeypatch):
+    """FaceTrainStep over an fp16 backbone (TimmWrapper(operand="fp16")): backbone, neck and head multiply fp16 operands and the step runs the GradScaler protocol the
+    reference's face loop runs too (Trainer.update(model, loss, self.scaler, ...), engine/procedure/train.py:199,203-215).  Two clipped steps against torch fp32: loss within
+    2e-3, every non-degenerate parameter UPDATE within 2e-2 of the oracle's (the bf16 step: 0.12), the head within 2e-4 (bf16: 1e-3); then a step whose loss scale
+    overflows fp16 is skipped (weights and momentum untouched, scale halved, counter up) exactly as scaler.step / scaler.update do."""
+    model, ref, img = _build_cnn(be, dev, monkeypatch, operand="fp16")
+    head = model.trainingwrapper["head"]
+    rhead = _RefArcFace(head.weight.detach().cpu())
+    bb = model.trainingwrapper["backbone"]
+    assert bb.model.engine.operand == "fp16" and bb.model.engine.wb16.dtype == torch.float16
+    lr, mom, wd, max_norm = 0.05, 0.9, 5e-4, 0.5
+    step = face.FaceTrainStep(model, lr=lr, momentum=mom, weight_decay=wd, max_norm=max_norm, ema=False, init_scale=1024.0)
+    assert step.amp and step.loss_scale() == 1024.0
+    params = list(ref.parameters()) + [rhead.weight]
+    opt = torch.optim.SGD(params, lr=lr, momentum=mom, weight_decay=wd)
+    start = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    model.train(); ref.train()
+    torch.manual_seed(5)
+    for it in range(2):
+        x = torch.randn(8, 3, img, img); y = torch.randint(0, 40, (8,))
+        opt.zero_grad()
+        loss_ref = torch.nn.functional.cross_entropy(rhead(ref(x), y), y)
+        loss_ref.backward()
+        assert torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm) > max_norm
+        opt.step()
+        rows = step.step(x.to(dev), y.to(dev))
+        assert abs(rows.mean().item() - loss_ref.item()) < 2e-3 * abs(loss_ref.item()), (rows.mean().item(), loss_ref.item())
+    assert step.skipped_steps() == 0 and step.loss_scale() == 1024.0
+    got = dict(bb.named_parameters())
+    worst = (0.0, None)
+    for n, p in ref.named_parameters():
+        upd_ref = p.detach() - start[n]
+        if upd_ref.norm() < 1e-7:
+            continue
+        r = _rel(got[n].detach().cpu() - start[n], upd_ref)
+        tol = 0.3 if n in ("output_layer.0.bias", "output_layer.2.bias") else 2e-2
+        assert r < tol, (n, r)
+        if n not in ("output_layer.0.bias", "output_layer.2.bias"):
+            worst = max(worst, (r, n))
+    print("fp16 face step: worst update error", worst)
+    assert _rel(head.weight.detach(), rhead.weight.detach()) < 2e-4
+    # overflow: a loss scale beyond fp16's range makes the scaled gradients inf -> the step is skipped, the scale backs off
+    sd = step.scaler_state_dict()
+    assert sd["scale"] == 1024.0 and sd["_growth_tracker"] == 2 and sd["growth_interval"] == 2000
+    step.load_scaler_state_dict(dict(sd, scale=2.0 ** 40))
+    before = {n: p.detach().clone() for n, p in bb.named_parameters()}
+    hw = head.weight.detach().clone(); mom0 = step.mom_flat.clone()
+    step.step(x.to(dev), y.to(dev))
+    assert step.skipped_steps() == 1 and step.loss_scale() == 2.0 ** 39
+    for n, p in bb.named_parameters():
+        assert torch.equal(p.detach(), before[n]), n
+    assert torch.equal(head.weight.detach(), hw) and torch.equal(step.mom_flat, mom0)

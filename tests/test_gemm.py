@@ -376,3 +376,32 @@ def test_gemm_narrow_output_goes_to_the_256x128_kernel(be, dev, monkeypatch):
     out = ops.gemm_nt(a, b, backend=be)
     assert _rel(out.float(), ref.bfloat16().float()) < 3e-3
     assert be.lib.vdk_gemm_last_kernel() == want
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kern", [1, 2, 5, 6])
+def test_gemm_col_scale_before_bias_and_residual(be, dev, kern, dtype):
+    """VdkGemmDesc.col_scale: C = residual + (acc * col_scale + bias) -- ConvNeXt's layer scale in the fc2 epilogue under fp16 operands (gamma = 1e-6 cannot be folded into
+    an fp16 weight).  Every kernel structure that can serve the problem, ragged M / N, with and without the residual; a NULL col_scale leaves the epilogue bit-identical."""
+    if kern == 2 and dtype == torch.float16:
+        pytest.skip("the eight-wave kernel is bf16 only")
+    M, N, K = 1300, 776, 256
+    torch.manual_seed(12)
+    a = torch.randn(M, K).to(dtype).to(dev); b = (torch.randn(N, K) * 0.3).to(dtype).to(dev)
+    bias = torch.randn(N).to(dev); res = torch.randn(M, N).to(dev)
+    cs = (torch.rand(N) * 2e-6).to(dev); cs[::7] = 0.5
+    ref = a.float() @ b.float().T
+    be.lib.vdk_gemm_force_kernel(kern)
+    try:
+        out = ops.gemm_nt(a, b, out_dtype=torch.float32, bias=bias, residual=res, col_scale=cs, backend=be)
+        assert be.lib.vdk_gemm_last_kernel() == kern
+        assert _rel(out - res, ref * cs + bias) < 2e-5
+        out = ops.gemm_nt(a, b, out_dtype=torch.float32, bias=bias, col_scale=cs, backend=be)
+        assert _rel(out, ref * cs + bias) < 1e-5
+        one = ops.gemm_nt(a, b, out_dtype=torch.float32, bias=bias, residual=res, col_scale=torch.ones(N, device=dev), backend=be)
+        none = ops.gemm_nt(a, b, out_dtype=torch.float32, bias=bias, residual=res, backend=be)
+        assert torch.equal(one, none)
+    finally:
+        be.lib.vdk_gemm_force_kernel(0)
+    with pytest.raises(Exception):      # 16-bit outputs / activations / split-K do not take it
+        ops.gemm_nt(a, b, bias=bias, col_scale=cs, backend=be)

@@ -21,7 +21,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("A", P), ("lda", I64), ("B", P), ("ldb", I64), ("C", P), ("ldc", I64),
                 ("M", I32), ("N", I32), ("K", I32), ("c_dtype", I32),
                 ("bias", P), ("residual", P), ("ldr", I64), ("act", I32), ("aux", P), ("ldaux", I64),
-                ("alpha", F32), ("splitk", I32), ("row_group", I32), ("trans", I32), ("a_row_group", I32), ("conv", P), ("a_colsum", P), ("c_colsum", P), ("ab_dtype", I32)]
+                ("alpha", F32), ("splitk", I32), ("row_group", I32), ("trans", I32), ("a_row_group", I32), ("conv", P), ("a_colsum", P), ("c_colsum", P), ("ab_dtype", I32), ("col_scale", P)]
 
 
 class ConvGeom(C.Structure):
@@ -42,7 +42,7 @@ class GemmF32Desc(C.Structure):
 
 
 class ConvNextConfig(C.Structure):
-    _fields_ = [("batch", I32), ("img_size", I32), ("in_chans", I32), ("depths", I32 * 4), ("dims", I32 * 4), ("ln_eps", C.c_float), ("num_classes", I32)]
+    _fields_ = [("batch", I32), ("img_size", I32), ("in_chans", I32), ("depths", I32 * 4), ("dims", I32 * 4), ("ln_eps", C.c_float), ("num_classes", I32), ("operand", I32)]
 
 
 class ResNetConfig(C.Structure):
@@ -161,10 +161,13 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_attn_pool_fwd": (C.c_int, [P, P, I64, I32, I32, I32, F32, P, I64, P, P]),
     "vdk_attn_pool_bwd": (C.c_int, [P, P, I64, P, P, I64, I32, I32, I32, F32, P, I64, P, P]),
     "vdk_colnorm_fwd": (C.c_int, [P, I64, I32, I32, I32, F32, P, P, I64, I32, P]),
+    "vdk_colnorm_fwd_dt": (C.c_int, [P, I64, I32, I32, I32, F32, P, P, I64, I32, I32, P]),
+    "vdk_rownorm_fwd_dt": (C.c_int, [P, I32, I32, I32, F32, P, P, P, P, I32, I32, P]),
     "vdk_colnorm_bwd": (C.c_int, [P, I64, P, P, I64, I32, I32, P, I64, P]),
     "vdk_rownorm_fwd": (C.c_int, [P, I32, I32, I32, F32, P, P, P, P, I32, P]),
     "vdk_rownorm_bwd": (C.c_int, [P, P, P, I64, I32, I32, P, P]),
     "vdk_margin_ce": (C.c_int, [C.POINTER(MarginHead), P, I64, I32, I32, P, F32, F32, P, I64, P, P, I64, P]),
+    "vdk_margin_ce_amp": (C.c_int, [C.POINTER(MarginHead), P, I64, I32, I32, P, F32, F32, P, P, I64, P, P, I64, I32, P]),
     "vdk_margin_ce_f32": (C.c_int, [C.POINTER(MarginHead), P, I64, I32, I32, P, C.c_float, C.c_float, P, P, I64, P]),
     "vdk_margin_target_cos": (C.c_int, [P, I64, I32, I32, I64, P, P, P]),
     "vdk_margin_stats": (C.c_int, [C.POINTER(MarginHead), P, I64, I32, I32, I64, P, P, P, P]),
@@ -222,6 +225,7 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_avgpool_fwd": (C.c_int, [P, P, I32, I32, I32, I32, P]),
     "vdk_avgpool_bwd": (C.c_int, [P, I64, P, I32, I32, I32, P]),
     "vdk_avgpool_rows_f32_fwd": (C.c_int, [P, P, I32, I32, I32, P]),
+    "vdk_scale_dev_f32": (C.c_int, [P, I64, P, I32, P]),
     "vdk_avgpool_rows_f32_bwd": (C.c_int, [P, P, P, I32, I32, I32, P]),
     "vdk_preprocess_workspace_bytes": (C.c_int, [I32, I32, I32, PSZ]),
     "vdk_preprocess_resize_pad_normalize": (C.c_int, [P, P, P, I32, I32, I32, F32, F32, F32, F32, F32, F32, P, P, P, SZ, P]),

@@ -42,8 +42,15 @@ TIMM_CONVNEXTS = {
 class ConvNeXtEngine:
     """Owns the flat HBM buffers (fp32 master params, bf16 / derived operand copies, grads, workspace); calls vdk_convnext_*."""
 
-    def __init__(self, spec: ConvNeXtSpec, device=None, backend: Optional[_lib.Backend] = None):
+    def __init__(self, spec: ConvNeXtSpec, device=None, backend: Optional[_lib.Backend] = None, operand: str = "bf16"):
+        """operand: "bf16" | "fp16" -- the format of the GEMM operands, saved 16-bit activations and 16-bit gradient tensors (VdkConvNextConfig.operand).  fp16 is the
+        reference's autocast dtype on a GPU (engine/procedure/train.py:118) and the format that keeps the face / CBIR embeddings within 1e-3 of its fp32 loop (train.py:217-227);
+        the train steps then run GradScaler's protocol (loss scale into the output gradient, un-scale + inf check in the optimizer kernel)."""
+        if operand not in ("bf16", "fp16"):
+            raise ValueError("operand must be 'bf16' or 'fp16'")
         self.spec = spec
+        self.operand = operand
+        self.dt16 = torch.float16 if operand == "fp16" else torch.bfloat16
         self.be = backend or _lib.load()
         self.device = torch.device(device if device is not None else ("cuda" if self.be.device_only else "cpu"))
         cfg = self._cfg(1)
@@ -61,7 +68,7 @@ class ConvNeXtEngine:
         dev = self.device
         self.params = torch.zeros(self.n_floats, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(self.n_floats, dtype=torch.float32, device=dev)
-        self.wb16 = torch.zeros(self.n_floats, dtype=torch.bfloat16, device=dev)
+        self.wb16 = torch.zeros(self.n_floats, dtype=self.dt16, device=dev)
         self.wx = torch.zeros(wx.value, dtype=torch.uint8, device=dev)
         self.out_hw = spec.img_size // 32
         self.out_ch = spec.dims[3]
@@ -80,7 +87,8 @@ class ConvNeXtEngine:
 
     def _cfg(self, batch: int, img: Optional[int] = None) -> _abi.ConvNextConfig:
         s = self.spec
-        return _abi.ConvNextConfig(batch, img or s.img_size, s.in_chans, (_abi.I32 * 4)(*s.depths), (_abi.I32 * 4)(*s.dims), s.ln_eps, s.num_classes)
+        return _abi.ConvNextConfig(batch, img or s.img_size, s.in_chans, (_abi.I32 * 4)(*s.depths), (_abi.I32 * 4)(*s.dims), s.ln_eps, s.num_classes,
+                                   _abi.F16_ if self.operand == "fp16" else _abi.BF16)
 
     def _workspace(self, batch: int, img: Optional[int] = None) -> torch.Tensor:
         """keyed on (batch, image size): the classifier (global average pool head) takes any multiple of 32 -- the reference's progressive resizing
@@ -114,7 +122,7 @@ class ConvNeXtEngine:
             self.refresh_weights()
 
     def dlogits_rows(self, batch: int) -> int:
-        """rows of the bf16 dlogits buffer backward() expects in classifier mode (the fc weight gradient contracts over 64-row K tiles)"""
+        """rows of the 16-bit dlogits buffer backward() expects in classifier mode (the fc weight gradient contracts over 64-row K tiles)"""
         return (batch + 63) // 64 * 64
 
     def forward(self, x: torch.Tensor, training: bool = True, sync_group=False) -> torch.Tensor:
@@ -182,10 +190,10 @@ class ConvNeXtEngine:
         return out
 
     def backward(self, dout: torch.Tensor, on_ready: Optional[Callable[[int, int], None]] = None, sync_group=False) -> torch.Tensor:
-        """dout f32 [B*h*w, C] (feature mode) or dlogits bf16 [up(B, 64), cp] with zero padding (classifier mode) -> self.grads (flat fp32, overwritten).
-        Needs the workspace of the matching forward."""
+        """dout f32 [B*h*w, C] (feature mode) or dlogits in the operand format [up(B, 64), cp] with zero padding (classifier mode) -> self.grads (flat fp32,
+        overwritten).  Needs the workspace of the matching forward.  fp16 operands: dout carries the caller's loss scale, and so do the gradients."""
         if self.spec.num_classes > 0:
-            assert dout.dtype == torch.bfloat16 and dout.is_contiguous() and tuple(dout.shape) == ((self._ws_batch + 63) // 64 * 64, self.cp)
+            assert dout.dtype == self.dt16 and dout.is_contiguous() and tuple(dout.shape) == ((self._ws_batch + 63) // 64 * 64, self.cp)
         else:
             assert dout.dtype == torch.float32 and dout.is_contiguous() and dout.shape == self._out.shape
         cfg = self._cfg(self._ws_batch, self._ws_img)
@@ -220,8 +228,8 @@ class _ConvNeXtFunction(torch.autograd.Function):
         eng = ctx.module.engine
         if eng.spec.num_classes > 0:
             B, n = dout.shape
-            d = torch.zeros(((B + 63) // 64 * 64, eng.cp), dtype=torch.bfloat16, device=dout.device)
-            d[:B, :n] = dout.to(torch.bfloat16)
+            d = torch.zeros(((B + 63) // 64 * 64, eng.cp), dtype=eng.dt16, device=dout.device)
+            d[:B, :n] = dout.to(eng.dt16)
         else:
             d = dout.permute(0, 2, 3, 1).contiguous().view(-1, eng.out_ch)
         g = eng.backward(d)
@@ -236,10 +244,10 @@ class ConvNeXt(nn.Module):
     """Drop-in for `timm.create_model('convnext_*', pretrained=False, num_classes=0, global_pool='')` (feature mode, TimmWrapper) and for
     `timm.create_model('convnext_*', num_classes=N)` (classifier: head = global average pool -> head.norm -> head.fc, VisionWrapper)."""
 
-    def __init__(self, spec: ConvNeXtSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None):
+    def __init__(self, spec: ConvNeXtSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None, operand: str = "bf16"):
         super().__init__()
         self.spec = spec
-        self.engine = ConvNeXtEngine(spec, device=device, backend=backend)
+        self.engine = ConvNeXtEngine(spec, device=device, backend=backend, operand=operand)
         self.num_classes = spec.num_classes
         self.num_features = spec.dims[3]
         self._plist = []
@@ -313,7 +321,7 @@ class ConvNeXt(nn.Module):
 
 
 def create_model(name: str, pretrained: bool = False, num_classes: int = 0, global_pool: str = "", device=None, backend=None, img_size: int = 224,
-                 **kwargs) -> ConvNeXt:
+                 operand: str = "bf16", **kwargs) -> ConvNeXt:
     if name not in TIMM_CONVNEXTS:
         raise NotImplementedError(f"timm model '{name}' is not covered by the HIP engine yet (have: {sorted(TIMM_CONVNEXTS)})")
     if num_classes == 0 and global_pool != "":
@@ -322,4 +330,6 @@ def create_model(name: str, pretrained: bool = False, num_classes: int = 0, glob
         raise NotImplementedError("the classifier head is built with timm's default global average pool")
     if pretrained:
         raise RuntimeError("pretrained weights need network access; load a checkpoint with load_state_dict instead")
-    return ConvNeXt(ConvNeXtSpec(img_size=img_size, num_classes=num_classes, **TIMM_CONVNEXTS[name]), device=device, backend=backend)
+    if kwargs:
+        raise TypeError(f"convnext.create_model: unsupported keyword arguments {sorted(kwargs)}")
+    return ConvNeXt(ConvNeXtSpec(img_size=img_size, num_classes=num_classes, **TIMM_CONVNEXTS[name]), device=device, backend=backend, operand=operand)

@@ -106,10 +106,10 @@ int vdk_comm_init(const void* id128, int32_t rank, int32_t world, VdkComm** out)
 
 int vdk_comm_destroy(VdkComm* c) {
   if (!c) return VDK_OK;
-  hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->stream);
   g_rccl.CommDestroy(c->comm);
-  hipEventDestroy(c->ready); hipEventDestroy(c->done);
-  hipStreamDestroy(c->stream);
+  (void)hipEventDestroy(c->ready); (void)hipEventDestroy(c->done);
+  (void)hipStreamDestroy(c->stream);
   free(c);
   return VDK_OK;
 }

@@ -27,7 +27,7 @@
 template <int TH, int TW>
 __global__ __launch_bounds__(TW * (DWF_CC / 4)) void dwconv7_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
                                                           const float* res, float* out /* may alias res */, bf16_t* __restrict__ outb, int B, int H,
-                                                          int W, int C, int flip) {
+                                                          int W, int C, int flip, int opf /* format of outb: VDK_OPF_BF16 | VDK_OPF_F16 */) {
   constexpr int IH = TH + 6, IW = TW + 6, NT = TW * (DWF_CC / 4);
   __shared__ __attribute__((aligned(16))) float xs[IH * IW * DWF_CC];
   __shared__ __attribute__((aligned(16))) float ws[49 * DWF_CC];            // 12 544 B
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(TW * (DWF_CC / 4)) void dwconv7_kernel(const float*
         f32x4 v = acc[o];
         if (res) { const f32x4 r4 = *(const f32x4*)(res + off); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
         if (out) *(f32x4*)(out + off) = v;
-        if (outb) *(u32x2*)(outb + off) = (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        if (outb) *(u32x2*)(outb + off) = opf ? (u32x2){pack_h2(v[0], v[1]), pack_h2(v[2], v[3])} : (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
       }
     }
   }
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(TW * (DWF_CC / 4)) void dwconv7_kernel(const float*
 template <int W, int CC>
 __global__ __launch_bounds__(W * (CC / 4), 2) void dwconv7_rows_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
                                                                       const float* res, float* out /* may alias res */, bf16_t* __restrict__ outb, int B, int C,
-                                                                      int flip) {
+                                                                      int flip, int opf /* format of outb: VDK_OPF_BF16 | VDK_OPF_F16 */) {
   constexpr int H = W, IW = W + 6, CQ = CC / 4, NT = W * CQ, RD = 13, NEW = 7;
   __shared__ __attribute__((aligned(16))) float ring[RD * IW * CC];
   __shared__ __attribute__((aligned(16))) float ws[49 * CC];
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(W * (CC / 4), 2) void dwconv7_rows_kernel(const flo
           v[0] += rf[o][0]; v[1] += rf[o][1]; v[2] += rf[o][2]; v[3] += rf[o][3];
 #endif
           if (out) *(f32x4*)(out + off) = v;
-          if (outb) *(u32x2*)(outb + off) = (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+          if (outb) *(u32x2*)(outb + off) = opf ? (u32x2){pack_h2(v[0], v[1]), pack_h2(v[2], v[3])} : (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
         }
       }
       if (more || next_img) {
@@ -320,13 +320,13 @@ __global__ __launch_bounds__(256) void avgpool_rows_f32_fwd_kernel(const float* 
   out[i] = s / (float)HW;
 }
 __global__ __launch_bounds__(256) void avgpool_rows_f32_bwd_kernel(const float* __restrict__ dpool, float* __restrict__ dmap, bf16_t* __restrict__ dmapb, int B, int HW,
-                                                                   int C) {
+                                                                   int C, int opf) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)B * HW * C) return;
   const int c = (int)(i % C), b = (int)(i / ((long)HW * C));
   const float g = dpool[(long)b * C + c] / (float)HW;
   if (dmap) dmap[i] = g;
-  if (dmapb) dmapb[i] = f2bf(g);
+  if (dmapb) dmapb[i] = opf ? f2op<VDK_OPF_F16>(g) : f2bf(g);
 }
 
 // ------------------------------------------------------------------------------------ weight preparation
@@ -339,13 +339,13 @@ __global__ __launch_bounds__(256) void dw_weight_prep_kernel(const float* __rest
 }
 // 2x2 conv weight [Co][Ci][2][2] -> wb bf16 [Co][4*Ci] with k = (2*ky + kx) * Ci + ci, and its transpose wtb bf16 [4*Ci][Co]
 __global__ __launch_bounds__(256) void conv2x2_weight_prep_kernel(const float* __restrict__ w, bf16_t* __restrict__ wb, bf16_t* __restrict__ wtb, int Co,
-                                                                  int Ci) {
+                                                                  int Ci, int opf) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)Co * Ci * 4) return;
   const int q = (int)(i & 3);
   const long rest = i >> 2;
   const int ci = (int)(rest % Ci), co = (int)(rest / Ci);
-  const bf16_t v = f2bf(w[i]);
+  const bf16_t v = opf ? f2op<VDK_OPF_F16>(w[i]) : f2bf(w[i]);
   const long k = (long)q * Ci + ci;
   wb[(long)co * 4 * Ci + k] = v;
   wtb[k * Co + co] = v;
@@ -373,19 +373,53 @@ __global__ __launch_bounds__(256) void lscale_weight_prep_kernel(const float* __
 // Every block's weight preparation in ONE launch (the engine's refresh after an optimizer step was 2 launches per block: ~75 launches of 5-25 us for ConvNeXt-B): job j
 // covers workgroups [first[j], first[j + 1]); element i of a job does the layer-scale fold of W2[i] and, while i < 49 C, the tap-major copy of the depthwise weight.
 struct CnPrepBatch { CnPrepJob job[40]; int first[41]; int n; };
+// fp16 operands (jb.rs != NULL): gamma is NOT folded into the forward operand -- gamma (1e-6 at timm's init) times a weight of ~0.02 is below fp16's smallest subnormal -- so
+//   w2p  = fp16(W2)                      forward B operand; the fc2 GEMM applies gamma as VdkGemmDesc.col_scale, b2p = gamma (.) b2 as its bias
+//   w2pt = fp16((gamma r) (.) W2)^T      backward B operand, r = 2^-floor(log2 max|gamma|) (max |gamma r| in [1, 2)): the branch's gradients du, dh live at r times their
+//                                        true size in fp16 and return through rs[1] = 1 / r (LayerNorm backward's dy_scale, the fc1 gradients' final scaling)
+//   rs   = {r, 1 / r}
 __global__ __launch_bounds__(256) void cn_prep_batch_kernel(CnPrepBatch b) {
+  __shared__ float redm[4];
   int j = 0;
   while (j + 1 < b.n && (int)blockIdx.x >= b.first[j + 1]) ++j;
   const CnPrepJob jb = b.job[j];
   const long i = (long)((int)blockIdx.x - b.first[j]) * 256 + threadIdx.x;
   const int C = jb.C, M = jb.M;
+  float r = 1.0f;
+  if (jb.rs) {       // (uniform per workgroup: every workgroup of a job finds the same maximum, C reads from the L2)
+    float m = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, fabsf(jb.gamma[c]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+    int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 127;      // floor(log2 m) for normal m; zero / subnormal -> -127
+    if (!(m > 0.f) || !(m < 3.0e38f)) e = 0;
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    r = __uint_as_float((unsigned)(127 - e) << 23);
+    if (i == 0) { jb.rs[0] = r; jb.rs[1] = __uint_as_float((unsigned)(127 + e) << 23); }
+  }
   if (i < (long)C * 49) { const int t = (int)(i / C), c = (int)(i % C); jb.dwt[i] = jb.dw_w[c * 49 + t]; }
   if (i < C) jb.b2p[i] = jb.gamma[i] * jb.b2[i];
   if (i >= (long)C * M) return;
   const int k = (int)(i % M), c = (int)(i / M);
+  if (jb.rs) {
+    jb.w2p[i] = f2op<VDK_OPF_F16>(jb.w2[i]);
+    jb.w2pt[(long)k * C + c] = f2op<VDK_OPF_F16>((jb.gamma[c] * r) * jb.w2[i]);
+    return;
+  }
   const bf16_t v = f2bf(jb.gamma[c] * jb.w2[i]);
   jb.w2p[i] = v;
   jb.w2pt[(long)k * C + c] = v;
+}
+// x[i] *= s[0] (or / s[0]): a gradient region that was kept at a power-of-two scale returns to its true size (ConvNeXt's fc1 gradients under fp16 operands), and the
+// loss scale enters a gradient tensor at the boundary of the fp16 graph (FaceTrainStep: d(loss)/d(embedding) x GradScaler's scale, engine/procedure/train.py:205)
+__global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ x, long n, const float* __restrict__ s, int reciprocal) {
+  const float f = reciprocal ? 1.0f / s[0] : s[0];
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 4 <= n) { f32x4 v = *(f32x4*)(x + i); v[0] *= f; v[1] *= f; v[2] *= f; v[3] *= f; *(f32x4*)(x + i) = v; }
+  else for (long j = i; j < n; ++j) x[j] *= f;
 }
 // in-library: n <= 40 blocks per call
 int vdk_convnext_prep_blocks(const CnPrepJob* jobs, int n, void* stream) {
@@ -435,16 +469,16 @@ static unsigned dw_rows_grid(int B, int nchunk) {
   if (per_chunk < 1) per_chunk = 1;
   return (unsigned)per_chunk * (unsigned)nchunk;
 }
-int vdk_dwconv7_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out, void* out_bf16, int32_t B, int32_t H, int32_t W,
-                    int32_t C, int32_t flip, void* stream) {
+int vdk_dwconv7_fwd_16(const float* in, const float* wt, const float* bias, const float* res, float* out, void* out_bf16, int32_t B, int32_t H, int32_t W,
+                       int32_t C, int32_t flip, int32_t opf, void* stream) {
   if (!in || !wt || (!out && !out_bf16) || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return vdk_fail(VDK_EINVAL, "vdk_dwconv7_fwd: bad argument (C % 4 == 0)");
   const unsigned cy = (unsigned)((C + DWF_CC - 1) / DWF_CC);
 #define DW_LAUNCH(TH, TW)                                                                                                                          \
   hipLaunchKernelGGL((dwconv7_kernel<TH, TW>), dim3((unsigned)(((W + TW - 1) / TW) * ((H + TH - 1) / TH)) * (unsigned)B, cy), dim3(TW * (DWF_CC / 4)), 0, \
-                     (hipStream_t)stream, in, wt, bias, res, out, (bf16_t*)out_bf16, (int)B, (int)H, (int)W, (int)C, (int)flip)
+                     (hipStream_t)stream, in, wt, bias, res, out, (bf16_t*)out_bf16, (int)B, (int)H, (int)W, (int)C, (int)flip, (int)opf)
 #define DW_ROWS(WW, CCC)                                                                                                                             \
   hipLaunchKernelGGL((dwconv7_rows_kernel<WW, CCC>), dim3(dw_rows_grid(B, (C + CCC - 1) / CCC)), dim3(WW * (CCC / 4)), 0, (hipStream_t)stream, in, wt, bias, \
-                     res, out, (bf16_t*)out_bf16, (int)B, (int)C, (int)flip)
+                     res, out, (bf16_t*)out_bf16, (int)B, (int)C, (int)flip, (int)opf)
   if (H == W && W == 56) DW_ROWS(56, 32);      // 32 channels = one 128-byte line per pixel (with 16 the two halves of a line went to different XCDs: 669 -> 640 us)
   else if (H == W && W == 28) DW_ROWS(28, 32);
   else if (H == W && W == 14) DW_ROWS(14, 64);
@@ -455,6 +489,10 @@ int vdk_dwconv7_fwd(const float* in, const float* wt, const float* bias, const f
 #undef DW_LAUNCH
 #undef DW_ROWS
   return vdk_check_launch("vdk_dwconv7_fwd");
+}
+int vdk_dwconv7_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out, void* out_bf16, int32_t B, int32_t H, int32_t W,
+                    int32_t C, int32_t flip, void* stream) {
+  return vdk_dwconv7_fwd_16(in, wt, bias, res, out, out_bf16, B, H, W, C, flip, VDK_OPF_BF16, stream);
 }
 
 static void dw_wgrad_tile(int H, int W, int* th, int* tw) {
@@ -523,11 +561,14 @@ int vdk_avgpool_rows_f32_fwd(const float* in, float* out, int32_t B, int32_t HW,
   hipLaunchKernelGGL(avgpool_rows_f32_fwd_kernel, dim3((unsigned)(((long)B * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, (int)B, (int)HW, (int)C);
   return vdk_check_launch("vdk_avgpool_rows_f32_fwd");
 }
-int vdk_avgpool_rows_f32_bwd(const float* dpool, float* dmap, void* dmap_bf16, int32_t B, int32_t HW, int32_t C, void* stream) {
-  if (!dpool || (!dmap && !dmap_bf16) || B <= 0 || HW <= 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_avgpool_rows_f32_bwd: bad argument");
-  hipLaunchKernelGGL(avgpool_rows_f32_bwd_kernel, dim3((unsigned)(((long)B * HW * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dpool, dmap, (bf16_t*)dmap_bf16,
-                     (int)B, (int)HW, (int)C);
+int vdk_avgpool_rows_f32_bwd_16(const float* dpool, float* dmap, void* dmap16, int32_t B, int32_t HW, int32_t C, int32_t opf, void* stream) {
+  if (!dpool || (!dmap && !dmap16) || B <= 0 || HW <= 0 || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_avgpool_rows_f32_bwd: bad argument");
+  hipLaunchKernelGGL(avgpool_rows_f32_bwd_kernel, dim3((unsigned)(((long)B * HW * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dpool, dmap, (bf16_t*)dmap16,
+                     (int)B, (int)HW, (int)C, (int)opf);
   return vdk_check_launch("vdk_avgpool_rows_f32_bwd");
+}
+int vdk_avgpool_rows_f32_bwd(const float* dpool, float* dmap, void* dmap_bf16, int32_t B, int32_t HW, int32_t C, void* stream) {
+  return vdk_avgpool_rows_f32_bwd_16(dpool, dmap, dmap_bf16, B, HW, C, VDK_OPF_BF16, stream);
 }
 
 int vdk_dwconv7_weight_prep(const float* w, float* wt, int32_t C, void* stream) {
@@ -535,11 +576,14 @@ int vdk_dwconv7_weight_prep(const float* w, float* wt, int32_t C, void* stream) 
   hipLaunchKernelGGL(dw_weight_prep_kernel, dim3((unsigned)((C * 49 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, wt, (int)C);
   return vdk_check_launch("vdk_dwconv7_weight_prep");
 }
-int vdk_conv2x2_weight_prep(const float* w, void* wb, void* wtb, int32_t Co, int32_t Ci, void* stream) {
+int vdk_conv2x2_weight_prep_16(const float* w, void* wb, void* wtb, int32_t Co, int32_t Ci, int32_t opf, void* stream) {
   if (!w || !wb || !wtb || Co <= 0 || Ci <= 0) return vdk_fail(VDK_EINVAL, "vdk_conv2x2_weight_prep: bad argument");
   hipLaunchKernelGGL(conv2x2_weight_prep_kernel, dim3((unsigned)(((long)Co * Ci * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wb, (bf16_t*)wtb,
-                     (int)Co, (int)Ci);
+                     (int)Co, (int)Ci, (int)opf);
   return vdk_check_launch("vdk_conv2x2_weight_prep");
+}
+int vdk_conv2x2_weight_prep(const float* w, void* wb, void* wtb, int32_t Co, int32_t Ci, void* stream) {
+  return vdk_conv2x2_weight_prep_16(w, wb, wtb, Co, Ci, VDK_OPF_BF16, stream);
 }
 int vdk_conv2x2_wgrad_unpermute(const float* dwp, float* dw, int32_t Co, int32_t Ci, void* stream) {
   if (!dwp || !dw || Co <= 0 || Ci <= 0) return vdk_fail(VDK_EINVAL, "vdk_conv2x2_wgrad_unpermute: bad argument");
@@ -551,6 +595,11 @@ int vdk_layerscale_weight_prep(const float* w2, const float* b2, const float* ga
   hipLaunchKernelGGL(lscale_weight_prep_kernel, dim3((unsigned)(((long)C * M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w2, b2, gamma, (bf16_t*)w2p,
                      (bf16_t*)w2pt, b2p, (int)C, (int)M);
   return vdk_check_launch("vdk_layerscale_weight_prep");
+}
+int vdk_scale_dev_f32(float* x, int64_t n, const float* scale, int32_t reciprocal, void* stream) {
+  if (!x || !scale || n <= 0 || ((size_t)x & 15)) return vdk_fail(VDK_EINVAL, "vdk_scale_dev_f32: bad argument (x 16-byte aligned)");
+  hipLaunchKernelGGL(scale_dev_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long)n, scale, (int)reciprocal);
+  return vdk_check_launch("vdk_scale_dev_f32");
 }
 int vdk_layerscale_grad(const float* dw2p, const float* db2p, const float* w2, const float* b2, const float* gamma, float* dw2, float* db2, float* dgamma,
                         int32_t C, int32_t M, void* stream) {

@@ -9,12 +9,19 @@
 // bias / GELU / residual epilogues, LayerNorm2d is the row LayerNorm kernel, and only the depthwise 7x7 (csrc/conv.hip) is new.
 // The layer scale is folded into fc2 at weight-refresh time (W2' = gamma (.) W2), so it costs nothing on the activation path; its
 // gradient comes from weight-sized tensors (vdk_layerscale_grad).  One C call per forward, one per backward; no allocation, no sync.
+//
+// Operand format (VdkConvNextConfig.operand): bf16 (above), or fp16 -- 8x smaller operand rounding, what brings the embeddings of the face / CBIR path inside 1e-3 of the
+// reference's fp32 arithmetic (engine/procedure/train.py:217-227 runs that loop without autocast) at the bf16 step's speed; gradients then carry GradScaler's loss scale
+// (train.py:205-211).  fp16 cannot hold gamma (.) W2 at timm's gamma = 1e-6, so in that mode fc2 multiplies the PLAIN weight and applies gamma in its epilogue
+// (VdkGemmDesc.col_scale), and the backward runs the branch at a per-block power-of-two scale r (conv.hip: cn_prep_batch_kernel): du' = r du, dh' = r dh in fp16,
+// LayerNorm backward multiplies 1 / r back in (fp32), the fc1 gradients are rescaled in place.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
 #include <vector>
 #include "vdk_device.h"
 #include "vdk_host.h"
+#include "vdk_gemm.h"
 
 extern "C" {
 int vdk_gemm_bf16_nt(const VdkGemmDesc*, void*, size_t, void*);
@@ -51,6 +58,7 @@ int vdk_colsum_f32(const float*, int64_t, int64_t, int32_t, float*, void*, size_
 int vdk_depth_to_space2_f32(const float*, float*, int32_t, int32_t, int32_t, int32_t, void*);
 int vdk_avgpool_rows_f32_fwd(const float*, float*, int32_t, int32_t, int32_t, void*);
 int vdk_avgpool_rows_f32_bwd(const float*, float*, void*, int32_t, int32_t, int32_t, void*);
+int vdk_scale_dev_f32(float*, int64_t, const float*, int32_t, void*);
 }
 
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
@@ -58,7 +66,12 @@ static inline int64_t up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 namespace {
 
+// operand format of the running call (VdkConvNextConfig.operand), set at every entry point as in vit_engine.hip / swin_engine.hip; DT16 = the dtype code of the 16-bit tensors
+thread_local int t_opf = VDK_OPF_BF16;
+#define DT16 (t_opf ? VDK_F16 : VDK_BF16)
+
 struct CnDims {
+  int opf;                // VDK_OPF_BF16 | VDK_OPF_F16
   int B, img, Cin, Kst;   // Kst = Cin * 16: K of the stem GEMM
   int depth[4], C[4], H[4], R[4];
   int nblk;
@@ -70,6 +83,8 @@ int cn_dims(const VdkConvNextConfig* c, CnDims* d) {
   if (c->batch <= 0 || c->img_size <= 0 || (c->img_size % 32) || c->in_chans <= 0) return vdk_fail(VDK_EINVAL, "convnext: bad config (img_size % 32 == 0)");
   d->B = c->batch; d->img = c->img_size; d->Cin = c->in_chans; d->Kst = c->in_chans * 16; d->eps = c->ln_eps; d->nblk = 0;
   if (c->num_classes < 0) return vdk_fail(VDK_EINVAL, "convnext: num_classes < 0");
+  if (c->operand != VDK_BF16 && c->operand != VDK_F16) return vdk_fail(VDK_EINVAL, "convnext: operand must be VDK_BF16 or VDK_F16");
+  d->opf = c->operand == VDK_F16 ? VDK_OPF_F16 : VDK_OPF_BF16;
   d->ncls = c->num_classes; d->Cp = (int)up(c->num_classes, 8); d->Bp = (int)up(c->batch, 64);
   for (int i = 0; i < 4; ++i) {
     if (c->depths[i] <= 0 || c->dims[i] <= 0 || (c->dims[i] & 7)) return vdk_fail(VDK_EINVAL, "convnext: bad config (dims % 8 == 0, depths > 0)");
@@ -143,7 +158,7 @@ void cn_layout(const CnDims& d, PLayout* p) {
 
 // derived operand copies (`wx`, byte offsets): per block the tap-major depthwise weight, fc1^T, the layer-scale-folded fc2 and its
 // transpose + bias; per downsample the (ky,kx,cin)-ordered weight and its transpose
-struct BlkX { size_t dwt, fc1t, fc2p, fc2pt, b2p; };
+struct BlkX { size_t dwt, fc1t, fc2p, fc2pt, b2p, rs; };   // rs: f32 {r, 1 / r}, the block's branch scale under fp16 operands
 struct XLayout { size_t total; size_t dsw[4], dswt[4]; std::vector<BlkX> blk[4]; size_t fct; };   // fct: head.fc^T [C3, Cp] bf16 (classifier mode)
 size_t w_take(size_t& cur, size_t n) { size_t o = cur; cur = (cur + n + 255) & ~(size_t)255; return o; }
 void cn_xlayout(const CnDims& d, XLayout* x) {
@@ -155,7 +170,7 @@ void cn_xlayout(const CnDims& d, XLayout* x) {
     x->blk[i].resize(d.depth[i]);
     for (int j = 0; j < d.depth[i]; ++j) {
       BlkX& b = x->blk[i][j];
-      b.dwt = w_take(cur, 49 * C * 4); b.fc1t = w_take(cur, C * M * 2); b.fc2p = w_take(cur, C * M * 2); b.fc2pt = w_take(cur, C * M * 2); b.b2p = w_take(cur, C * 4);
+      b.dwt = w_take(cur, 49 * C * 4); b.fc1t = w_take(cur, C * M * 2); b.fc2p = w_take(cur, C * M * 2); b.fc2pt = w_take(cur, C * M * 2); b.b2p = w_take(cur, C * 4); b.rs = w_take(cur, 8);
     }
   }
   x->fct = d.ncls > 0 ? w_take(cur, (size_t)d.C[3] * d.Cp * 2) : 0;
@@ -253,11 +268,12 @@ void cn_plan(const CnDims& d, WsPlan* w) {
   w->total = cur;
 }
 
+// cdt: VDK_F32, or VDK_BF16 = "the 16-bit operand format" (translated to the running call's DT16)
 int gemm(hipStream_t s, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K, int cdt, const float* bias,
-         const float* res, int64_t ldr, int act, void* aux, int64_t ldaux) {
+         const float* res, int64_t ldr, int act, void* aux, int64_t ldaux, const float* col_scale = nullptr) {
   VdkGemmDesc g = {};
-  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.c_dtype = cdt; g.bias = bias;
-  g.residual = res; g.ldr = ldr; g.act = act; g.aux = aux; g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = 1;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.c_dtype = cdt == VDK_F32 ? VDK_F32 : DT16; g.bias = bias;
+  g.residual = res; g.ldr = ldr; g.act = act; g.aux = aux; g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = 1; g.ab_dtype = DT16; g.col_scale = col_scale;
   return vdk_gemm_bf16_nt(&g, nullptr, 0, s);
 }
 // dW[out,in] = dY^T X, db = colsum(dY)   (dY bf16 [rows,out], X bf16 [rows,in]); TN LDS-DMA kernel when rows % 64 == 0, else explicit transposes
@@ -265,17 +281,17 @@ int linear_wgrad(hipStream_t s, const WsPlan& w, char* base, const bf16_t* dY, c
   if ((rows % 64) == 0) {
     VdkGemmDesc g = {};
     g.A = dY; g.lda = out; g.B = X; g.ldb = in; g.C = dW; g.ldc = in; g.M = out; g.N = in; g.K = rows; g.c_dtype = VDK_F32;
-    g.alpha = 1.0f; g.splitk = wgrad_splitk_tn(out, in, rows); g.trans = 1;
+    g.alpha = 1.0f; g.splitk = wgrad_splitk_tn(out, in, rows); g.trans = 1; g.ab_dtype = DT16;
     RC(vdk_gemm_bf16_nt(&g, base + w.slabs, w.slabs_bytes, s));
-    return db ? vdk_colsum_bf16(dY, out, rows, out, db, base + w.csws, w.csws_bytes, s) : VDK_OK;
+    return db ? vdk_colsum_16(dY, out, rows, out, db, base + w.csws, w.csws_bytes, t_opf, s) : VDK_OK;
   }
   const int rp = (int)up(rows, 64);
   bf16_t* tA = (bf16_t*)(base + w.tA); bf16_t* tB = (bf16_t*)(base + w.tB);
   float* csp = db ? (float*)(base + w.csws) : nullptr;
-  RC(vdk_transpose_bf16(dY, out, rows, out, tA, rp, rp, 0, csp, s));
-  RC(vdk_transpose_bf16(X, in, rows, in, tB, rp, rp, 0, nullptr, s));
+  RC(vdk_transpose_16(dY, out, rows, out, tA, rp, rp, 0, csp, t_opf, s));
+  RC(vdk_transpose_16(X, in, rows, in, tB, rp, rp, 0, nullptr, t_opf, s));
   VdkGemmDesc g = {};
-  g.A = tA; g.lda = rp; g.B = tB; g.ldb = rp; g.C = dW; g.ldc = in; g.M = out; g.N = in; g.K = rp; g.c_dtype = VDK_F32; g.alpha = 1.0f;
+  g.A = tA; g.lda = rp; g.B = tB; g.ldb = rp; g.C = dW; g.ldc = in; g.M = out; g.N = in; g.K = rp; g.c_dtype = VDK_F32; g.alpha = 1.0f; g.ab_dtype = DT16;
   g.splitk = wgrad_splitk(out, in, rp);
   RC(vdk_gemm_bf16_nt(&g, base + w.slabs, w.slabs_bytes, s));
   return db ? vdk_reduce_rows_f32(csp, out, (rp + 63) / 64, out, db, 1.0f, s) : VDK_OK;
@@ -287,10 +303,10 @@ int linear_wgrad(hipStream_t s, const WsPlan& w, char* base, const bf16_t* dY, c
 int dgrad_with_bias(hipStream_t s, const WsPlan& w, char* base, const void* dY, const void* Wt, void* dX, int rows, int in, int out, int act, void* aux, float* db,
                     int* fused) {
   const int prow = vdk_gemm_a_colsum_rows(rows, in, out);
-  *fused = (db && prow > 0 && (size_t)prow * out * 4 <= w.csws_bytes) ? 1 : 0;
+  *fused = (db && !t_opf && prow > 0 && (size_t)prow * out * 4 <= w.csws_bytes) ? 1 : 0;      // (the A-tile column sums are a by-product of the eight-wave bf16 kernel only)
   VdkGemmDesc g = {};
-  g.A = dY; g.lda = out; g.B = Wt; g.ldb = out; g.C = dX; g.ldc = in; g.M = rows; g.N = in; g.K = out; g.c_dtype = VDK_BF16; g.act = act; g.aux = aux; g.ldaux = in;
-  g.alpha = 1.0f; g.splitk = 1;
+  g.A = dY; g.lda = out; g.B = Wt; g.ldb = out; g.C = dX; g.ldc = in; g.M = rows; g.N = in; g.K = out; g.c_dtype = DT16; g.act = act; g.aux = aux; g.ldaux = in;
+  g.alpha = 1.0f; g.splitk = 1; g.ab_dtype = DT16;
   if (*fused) g.a_colsum = (float*)(base + w.csws);
   RC(vdk_gemm_bf16_nt(&g, nullptr, 0, s));
   if (*fused) RC(vdk_reduce_rows_f32((const float*)(base + w.csws), out, prow, out, db, 1.0f, s));
@@ -339,23 +355,24 @@ int vdk_convnext_refresh_weights(const VdkConvNextConfig* cfg, const float* para
   PLayout p; cn_layout(d, &p);
   XLayout x; cn_xlayout(d, &x);
   if (!params || !wb16 || !wx) return vdk_fail(VDK_EINVAL, "vdk_convnext_refresh_weights: null pointer");
-  if (!skip_wb16) RC(vdk_cast_f32_bf16(params, wb16, p.total, stream));
+  t_opf = d.opf;
+  if (!skip_wb16) RC(vdk_cast_f32_16(params, wb16, p.total, t_opf, stream));
   char* xb = (char*)wx;
   std::vector<VdkTcItem> jobs;      // the fc1^T (and head.fc^T) copies of all blocks in one launch
   std::vector<CnPrepJob> prep;      // ... and every block's depthwise tap-major copy + layer-scale fold in another (conv.hip: cn_prep_batch_kernel)
   for (int i = 0; i < 4; ++i) {
     const int C = d.C[i], M = 4 * C;
-    if (i > 0) RC(vdk_conv2x2_weight_prep(params + p.st[i].ds_w, xb + x.dsw[i], xb + x.dswt[i], C, d.C[i - 1], stream));
+    if (i > 0) RC(vdk_conv2x2_weight_prep_16(params + p.st[i].ds_w, xb + x.dsw[i], xb + x.dswt[i], C, d.C[i - 1], t_opf, stream));
     for (int j = 0; j < d.depth[i]; ++j) {
       const BlkP& b = p.st[i].blk[j]; const BlkX& bx = x.blk[i][j];
       jobs.push_back(VdkTcItem{params + b.fc1_w, xb + bx.fc1t, C, M, C, M, M});
       prep.push_back(CnPrepJob{params + b.dw_w, (float*)(xb + bx.dwt), params + b.fc2_w, params + b.fc2_b, params + b.gamma, (bf16_t*)(xb + bx.fc2p), (bf16_t*)(xb + bx.fc2pt),
-                               (float*)(xb + bx.b2p), C, M});
+                               (float*)(xb + bx.b2p), C, M, t_opf ? (float*)(xb + bx.rs) : nullptr});
     }
   }
   RC(vdk_convnext_prep_blocks(prep.data(), (int)prep.size(), stream));
   if (d.ncls > 0) jobs.push_back(VdkTcItem{params + p.fc_w, xb + x.fct, d.C[3], d.Cp, d.C[3], d.Cp, d.Cp});
-  return vdk_transpose_cast_batch(jobs.data(), (int)jobs.size(), stream);
+  return vdk_transpose_cast_batch(jobs.data(), (int)jobs.size(), stream, t_opf);
 }
 
 // x f32 [B, Cin, img, img] (NCHW, as the reference's dataloader hands it) -> out f32 [B * (img/32)^2, dims[3]]: the head-normed map in NHWC rows
@@ -371,11 +388,12 @@ int vdk_convnext_forward(const VdkConvNextConfig* cfg, const float* x, const flo
   char* base = (char*)ws;
   const bf16_t* wb = (const bf16_t*)wb16;
   const char* xb = (const char*)wx;
+  t_opf = d.opf;
   // stem: Conv2d(Cin, C0, 4, stride 4) as patchify + GEMM, then LayerNorm2d
   bf16_t* patches = (bf16_t*)(base + w.patches);
   float* y0 = (float*)(base + w.y0);
   float* st0 = (float*)(base + w.stats0);
-  RC(vdk_patchify_bf16(x, d.B, d.Cin, d.img, d.img, 4, patches, d.Kst, s));
+  RC(vdk_patchify_16(x, d.B, d.Cin, d.img, d.img, 4, patches, d.Kst, t_opf, s));
   RC(gemm(s, patches, d.Kst, wb + p.stem_w, d.Kst, y0, d.C[0], d.R[0], d.C[0], d.Kst, VDK_F32, params + p.stem_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0));
   RC(vdk_layernorm_fwd(y0, d.C[0], d.R[0], d.C[0], params + p.stem_nw, params + p.stem_nb, d.eps, base + w.X[0], d.C[0], VDK_F32, st0, st0 + d.R[0], s));
   for (int i = 0; i < 4; ++i) {
@@ -387,7 +405,7 @@ int vdk_convnext_forward(const VdkConvNextConfig* cfg, const float* x, const flo
       const int Rp = d.R[i - 1], Ci = d.C[i - 1];
       const float* xprev = (const float*)(base + w.X[i - 1]) + (size_t)d.depth[i - 1] * Rp * Ci;
       float* dst = (float*)(base + w.ds_stats[i]);
-      RC(vdk_layernorm_fwd(xprev, Ci, Rp, Ci, params + p.st[i].ds_nw, params + p.st[i].ds_nb, d.eps, base + w.ds_h[i], Ci, VDK_BF16, dst, dst + Rp, s));
+      RC(vdk_layernorm_fwd(xprev, Ci, Rp, Ci, params + p.st[i].ds_nw, params + p.st[i].ds_nb, d.eps, base + w.ds_h[i], Ci, DT16, dst, dst + Rp, s));
       RC(vdk_space_to_depth2_bf16(base + w.ds_h[i], base + w.ds_A[i], d.B, d.H[i - 1], d.H[i - 1], Ci, 0, s));
       RC(gemm(s, base + w.ds_A[i], 4 * Ci, xb + xl.dsw[i], 4 * Ci, X, C, R, C, 4 * Ci, VDK_F32, params + p.st[i].ds_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0));
     }
@@ -396,9 +414,10 @@ int vdk_convnext_forward(const VdkConvNextConfig* cfg, const float* x, const flo
       float* xin = X + (size_t)j * XS; float* xout = xin + XS;
       float* t = (float*)(base + bw.t); float* st = (float*)(base + bw.stats);
       RC(vdk_dwconv7_fwd(xin, (const float*)(xb + bx.dwt), params + b.dw_b, nullptr, t, nullptr, d.B, H, H, C, 0, s));
-      RC(vdk_layernorm_fwd(t, C, R, C, params + b.nw, params + b.nb, d.eps, base + bw.h, C, VDK_BF16, st, st + R, s));
+      RC(vdk_layernorm_fwd(t, C, R, C, params + b.nw, params + b.nb, d.eps, base + bw.h, C, DT16, st, st + R, s));
       RC(gemm(s, base + bw.h, C, wb + b.fc1_w, C, base + bw.g, M, R, M, C, VDK_BF16, params + b.fc1_b, nullptr, 0, VDK_ACT_GELU, base + bw.u, M));
-      RC(gemm(s, base + bw.g, M, xb + bx.fc2p, M, xout, C, R, C, M, VDK_F32, (const float*)(xb + bx.b2p), xin, C, VDK_ACT_NONE, nullptr, 0));
+      // fp16 operands: plain W2, gamma applied to the accumulators (col_scale), b2p = gamma (.) b2; bf16: gamma folded into fc2p
+      RC(gemm(s, base + bw.g, M, xb + bx.fc2p, M, xout, C, R, C, M, VDK_F32, (const float*)(xb + bx.b2p), xin, C, VDK_ACT_NONE, nullptr, 0, t_opf ? params + b.gamma : nullptr));
     }
   }
   const float* xlast = (const float*)(base + w.X[3]) + (size_t)d.depth[3] * d.R[3] * d.C[3];
@@ -407,7 +426,7 @@ int vdk_convnext_forward(const VdkConvNextConfig* cfg, const float* x, const flo
     float* pooled = (float*)(base + w.pooled); float* ps = (float*)(base + w.pstats);
     RC(vdk_avgpool_rows_f32_fwd(xlast, pooled, d.B, d.H[3] * d.H[3], d.C[3], s));
     if (d.Bp > d.B && hipMemsetAsync(base + w.feat + (size_t)d.B * d.C[3] * 2, 0, (size_t)(d.Bp - d.B) * d.C[3] * 2, s) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vdk_convnext_forward: memset");
-    RC(vdk_layernorm_fwd(pooled, d.C[3], d.B, d.C[3], params + p.head_nw, params + p.head_nb, d.eps, base + w.feat, d.C[3], VDK_BF16, ps, ps + d.B, s));
+    RC(vdk_layernorm_fwd(pooled, d.C[3], d.B, d.C[3], params + p.head_nw, params + p.head_nb, d.eps, base + w.feat, d.C[3], DT16, ps, ps + d.B, s));
     RC(gemm(s, base + w.feat, d.C[3], wb + p.fc_w, d.C[3], out, d.Cp, d.B, d.Cp, d.C[3], VDK_F32, params + p.fc_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0));
     return vdk_check_launch("vdk_convnext_forward");
   }
@@ -429,6 +448,7 @@ int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout_, const
   if (ws_bytes < w.total) return vdk_fail(VDK_EWORKSPACE, "vdk_convnext_backward: workspace too small");
   char* base = (char*)ws;
   const char* xb = (const char*)wx;
+  t_opf = d.opf;
   float* dxa = (float*)(base + w.dxa); bf16_t* dxb = (bf16_t*)(base + w.dxb);
   float* dt = (float*)(base + w.dt); bf16_t* du = (bf16_t*)(base + w.du); bf16_t* dh = (bf16_t*)(base + w.dh);
   float* dw2p = (float*)(base + w.dw2p); float* db2p = (float*)(base + w.db2p);
@@ -442,13 +462,13 @@ int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout_, const
     const float* ps = (const float*)(base + w.pstats);
     RC(vdk_layernorm_bwd(base + w.dfeat, d.C[3], VDK_F32, (const float*)(base + w.pooled), d.C[3], ps, ps + d.B, params + p.head_nw, nullptr, 0, d.B, d.C[3],
                          (float*)(base + w.dpool), d.C[3], nullptr, 0, grads + p.head_nw, grads + p.head_nb, lnws, w.lnws_bytes, s));
-    RC(vdk_avgpool_rows_f32_bwd((const float*)(base + w.dpool), dxa, dxb, d.B, d.H[3] * d.H[3], d.C[3], s));
+    RC(vdk_avgpool_rows_f32_bwd_16((const float*)(base + w.dpool), dxa, dxb, d.B, d.H[3] * d.H[3], d.C[3], t_opf, s));
     if (on_ready) on_ready(user, p.head_nw, p.total - p.head_nw);
   } else {
     const float* xlast = (const float*)(base + w.X[3]) + (size_t)d.depth[3] * d.R[3] * d.C[3];
     const float* hs = (const float*)(base + w.head_stats);
-    RC(vdk_layernorm_bwd(dout, d.C[3], VDK_F32, xlast, d.C[3], hs, hs + d.R[3], params + p.head_nw, nullptr, 0, d.R[3], d.C[3], dxa, d.C[3], dxb, d.C[3],
-                         grads + p.head_nw, grads + p.head_nb, lnws, w.lnws_bytes, s));
+    RC(vdk_layernorm_bwd_deferred(dout, d.C[3], VDK_F32, xlast, d.C[3], hs, hs + d.R[3], params + p.head_nw, nullptr, 0, d.R[3], d.C[3], dxa, d.C[3], dxb, d.C[3],
+                                  grads + p.head_nw, grads + p.head_nb, lnws, w.lnws_bytes, s, nullptr, nullptr, nullptr, nullptr, t_opf));
     if (on_ready) on_ready(user, p.head_nw, p.total - p.head_nw);
   }
   for (int i = 3; i >= 0; --i) {
@@ -462,13 +482,17 @@ int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout_, const
       const float* st = (const float*)(base + bw.stats);
       // dxa / dxb = dL/d(block output).  MLP branch with the layer scale folded into fc2; the bias gradients ride along with the dgrad GEMMs when possible
       int fz = 0;
+      // fp16 operands: fc2pt holds ((gamma r) (.) W2)^T, so du, dh and the fc1 gradients come out r times their size (r = the block's power-of-two branch scale, rs[0]);
+      // LayerNorm backward multiplies rs[1] = 1 / r into dh as it loads it, and the fc1 weight / bias gradients (adjacent in the flat buffer) are rescaled in place.
+      const float* bsc = t_opf ? (const float*)(xb + bx.rs) + 1 : nullptr;
+      auto fc1_unscale = [&]() -> int { return bsc ? vdk_scale_dev_f32(grads + b.fc1_w, b.fc2_w - b.fc1_w, bsc, 0, s) : VDK_OK; };
       // fc1.bias = column sums of du, accumulated by the dGELU epilogue that stores du (c_colsum: the PRODUCER sums what it writes); the fc2' bias is a column-sum pass over
       // the [R, C] gradient dxb (4x narrower than du).  Both input-gradient GEMMs then run the plain 225-register variants instead of the a_colsum ones (256 + spills).
       const int xrow = vdk_gemm_c_colsum_rows(R, M, C);
       if (xrow > 0 && (size_t)xrow * M * 4 <= w.csws_bytes) {
         VdkGemmDesc g = {};
-        g.A = dxb; g.lda = C; g.B = xb + bx.fc2pt; g.ldb = C; g.C = du; g.ldc = M; g.M = R; g.N = M; g.K = C; g.c_dtype = VDK_BF16; g.act = VDK_ACT_DGELU; g.aux = base + bw.u;
-        g.ldaux = M; g.alpha = 1.0f; g.splitk = 1; g.c_colsum = (float*)(base + w.csws);
+        g.A = dxb; g.lda = C; g.B = xb + bx.fc2pt; g.ldb = C; g.C = du; g.ldc = M; g.M = R; g.N = M; g.K = C; g.c_dtype = DT16; g.act = VDK_ACT_DGELU; g.aux = base + bw.u;
+        g.ldaux = M; g.alpha = 1.0f; g.splitk = 1; g.c_colsum = (float*)(base + w.csws); g.ab_dtype = DT16;
         RC(vdk_gemm_bf16_nt(&g, nullptr, 0, s));
         // The block's four small reductions (fc1.bias from the dGELU epilogue's column sums, the fc2' bias column sums, LayerNorm dgamma | dbeta, depthwise dw | db) run as
         // ONE launch after the depthwise weight-gradient kernel; the layer-scale kernel that needs db2p follows it.
@@ -477,19 +501,20 @@ int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout_, const
         const bool tn = (R % 64) == 0 && b.dw_b == b.dw_w + (int64_t)C * 49;
         if (tn) {
           RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + bw.g), R, C, M, dw2p, nullptr));
-          RC(vdk_colsum_bf16_deferred(dxb, C, R, C, db2p, base + w.csws2, w.csws_bytes, s, &jobs[nj])); ++nj;
+          RC(vdk_colsum_bf16_deferred(dxb, C, R, C, db2p, base + w.csws2, w.csws_bytes, s, &jobs[nj], nullptr, t_opf)); ++nj;
         } else {
           RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + bw.g), R, C, M, dw2p, db2p));        // db2p by vdk_colsum_bf16 / the transposes' by-product inside
         }
         RC(gemm(s, du, M, xb + bx.fc1t, M, dh, C, R, C, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0));
         RC(linear_wgrad(s, w, base, du, (const bf16_t*)(base + bw.h), R, M, C, grads + b.fc1_w, nullptr));
         if (tn) {
-          RC(vdk_layernorm_bwd_deferred(dh, C, VDK_BF16, (const float*)(base + bw.t), C, st, st + R, params + b.nw, nullptr, 0, R, C, dt, C, nullptr, 0, grads + b.nw,
-                                        grads + b.nb, lnws, w.lnws_bytes, s, &jobs[nj])); ++nj;
+          RC(vdk_layernorm_bwd_deferred(dh, C, DT16, (const float*)(base + bw.t), C, st, st + R, params + b.nw, nullptr, 0, R, C, dt, C, nullptr, 0, grads + b.nw,
+                                        grads + b.nb, lnws, w.lnws_bytes, s, &jobs[nj], nullptr, nullptr, nullptr, t_opf, bsc)); ++nj;
           RC(vdk_dwconv7_wgrad_deferred(xin, dt, grads + b.dw_w, grads + b.dw_b, d.B, H, H, C, base + w.dwws, w.dwws_bytes, s, &jobs[nj])); ++nj;
           RC(vdk_reduce_rows_batch(jobs, nj, s));
+          RC(fc1_unscale());
           RC(vdk_layerscale_grad(dw2p, db2p, params + b.fc2_w, params + b.fc2_b, params + b.gamma, grads + b.fc2_w, grads + b.fc2_b, grads + b.gamma, C, M, s));
-          RC(vdk_dwconv7_fwd(dt, (const float*)(xb + bx.dwt), nullptr, dxa, dxa, dxb, d.B, H, H, C, 1, s));
+          RC(vdk_dwconv7_fwd_16(dt, (const float*)(xb + bx.dwt), nullptr, dxa, dxa, dxb, d.B, H, H, C, 1, t_opf, s));
           if (on_ready) {
             const int64_t end = (j + 1 < d.depth[i]) ? p.st[i].blk[j + 1].gamma : (i < 3 ? p.st[i + 1].ds_nw : p.head_nw);
             on_ready(user, b.gamma, end - b.gamma);
@@ -497,6 +522,7 @@ int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout_, const
           continue;
         }
         RC(vdk_reduce_rows_batch(jobs, nj, s));
+        RC(fc1_unscale());
         RC(vdk_layerscale_grad(dw2p, db2p, params + b.fc2_w, params + b.fc2_b, params + b.gamma, grads + b.fc2_w, grads + b.fc2_b, grads + b.gamma, C, M, s));
       } else {
       RC(dgrad_with_bias(s, w, base, dxb, xb + bx.fc2pt, du, R, M, C, VDK_ACT_DGELU, base + bw.u, db2p, &fz));
@@ -504,12 +530,13 @@ int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout_, const
       RC(vdk_layerscale_grad(dw2p, db2p, params + b.fc2_w, params + b.fc2_b, params + b.gamma, grads + b.fc2_w, grads + b.fc2_b, grads + b.gamma, C, M, s));
       RC(dgrad_with_bias(s, w, base, du, xb + bx.fc1t, dh, R, C, M, VDK_ACT_NONE, nullptr, grads + b.fc1_b, &fz));
       RC(linear_wgrad(s, w, base, du, (const bf16_t*)(base + bw.h), R, M, C, grads + b.fc1_w, fz ? nullptr : grads + b.fc1_b));
+      RC(fc1_unscale());
       }
-      RC(vdk_layernorm_bwd(dh, C, VDK_BF16, (const float*)(base + bw.t), C, st, st + R, params + b.nw, nullptr, 0, R, C, dt, C, nullptr, 0, grads + b.nw,
-                           grads + b.nb, lnws, w.lnws_bytes, s));
+      RC(vdk_layernorm_bwd_deferred(dh, C, DT16, (const float*)(base + bw.t), C, st, st + R, params + b.nw, nullptr, 0, R, C, dt, C, nullptr, 0, grads + b.nw,
+                                    grads + b.nb, lnws, w.lnws_bytes, s, nullptr, nullptr, nullptr, nullptr, t_opf, bsc));
       // depthwise conv: weight/bias gradient, then input gradient + shortcut gradient (in place on dxa) and its bf16 copy
       RC(vdk_dwconv7_wgrad(xin, dt, grads + b.dw_w, grads + b.dw_b, d.B, H, H, C, base + w.dwws, w.dwws_bytes, s));
-      RC(vdk_dwconv7_fwd(dt, (const float*)(xb + bx.dwt), nullptr, dxa, dxa, dxb, d.B, H, H, C, 1, s));
+      RC(vdk_dwconv7_fwd_16(dt, (const float*)(xb + bx.dwt), nullptr, dxa, dxa, dxb, d.B, H, H, C, 1, t_opf, s));
       if (on_ready) {
         const int64_t end = (j + 1 < d.depth[i]) ? p.st[i].blk[j + 1].gamma : (i < 3 ? p.st[i + 1].ds_nw : p.head_nw);
         on_ready(user, b.gamma, end - b.gamma);
@@ -521,18 +548,18 @@ int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout_, const
       float* dwdsp = (float*)(base + w.dwdsp);
       RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + w.ds_A[i]), R, C, 4 * Ci, dwdsp, grads + p.st[i].ds_b));
       RC(vdk_conv2x2_wgrad_unpermute(dwdsp, grads + p.st[i].ds_w, C, Ci, s));
-      RC(gemm(s, dxb, C, xb + xl.dswt[i], C, base + w.dA, 4 * Ci, R, 4 * Ci, C, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0));
+      RC(gemm(s, dxb, C, xb + xl.dswt[i], C, base + w.dA, 4 * Ci, R, 4 * Ci, C, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0));      // (VDK_BF16 = "the operand format")
       RC(vdk_space_to_depth2_bf16(base + w.dA, base + w.dhds, d.B, d.H[i - 1], d.H[i - 1], Ci, 1, s));
       const float* xprev = (const float*)(base + w.X[i - 1]) + (size_t)d.depth[i - 1] * Rp * Ci;
       const float* dst = (const float*)(base + w.ds_stats[i]);
-      RC(vdk_layernorm_bwd(base + w.dhds, Ci, VDK_BF16, xprev, Ci, dst, dst + Rp, params + p.st[i].ds_nw, nullptr, 0, Rp, Ci, dxa, Ci, dxb, Ci,
+      RC(vdk_layernorm_bwd(base + w.dhds, Ci, DT16, xprev, Ci, dst, dst + Rp, params + p.st[i].ds_nw, nullptr, 0, Rp, Ci, dxa, Ci, dxb, Ci,
                            grads + p.st[i].ds_nw, grads + p.st[i].ds_nb, lnws, w.lnws_bytes, s));
       if (on_ready) on_ready(user, p.st[i].ds_nw, p.st[i].blk[0].gamma - p.st[i].ds_nw);
     } else {
       // stem: LayerNorm2d backward (bf16 gradient of the conv output), then the conv's weight / bias gradient
       const float* st0 = (const float*)(base + w.stats0);
-      RC(vdk_layernorm_bwd(dxa, C, VDK_F32, (const float*)(base + w.y0), C, st0, st0 + R, params + p.stem_nw, nullptr, 0, R, C, nullptr, 0, dh, C,
-                           grads + p.stem_nw, grads + p.stem_nb, lnws, w.lnws_bytes, s));
+      RC(vdk_layernorm_bwd_deferred(dxa, C, VDK_F32, (const float*)(base + w.y0), C, st0, st0 + R, params + p.stem_nw, nullptr, 0, R, C, nullptr, 0, dh, C,
+                                    grads + p.stem_nw, grads + p.stem_nb, lnws, w.lnws_bytes, s, nullptr, nullptr, nullptr, nullptr, t_opf));
       RC(linear_wgrad(s, w, base, dh, (const bf16_t*)(base + w.patches), R, C, d.Kst, grads + p.stem_w, grads + p.stem_b));
       if (on_ready) on_ready(user, 0, p.st[0].blk[0].gamma);
     }

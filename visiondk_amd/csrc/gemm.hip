@@ -856,6 +856,9 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   p.act = d->act; p.aux = (bf16_t*)d->aux; p.ldaux = d->ldaux; p.alpha = d->alpha; p.row_group = d->row_group < 0 ? -d->row_group : d->row_group; p.row_shift = d->row_group > 0 ? 1 : 0; p.a_row_group = d->a_row_group;
   p.splitk = splitk; p.slabs = nullptr; p.sk_cnt = nullptr; p.dbg = (unsigned long long*)g_dbg_ptr;
   p.colsum_part = nullptr; p.ocs_part = nullptr;
+  p.cscale = d->col_scale;
+  if (d->col_scale && (d->c_dtype != VDK_F32 || !d->bias || d->act != VDK_ACT_NONE || d->splitk > 1 || d->trans || d->row_group != 0 || (d->N & 7)))
+    return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: col_scale goes with an fp32 output, a bias, act NONE, N % 8 == 0 and neither split-K, TN nor a row remap");
   p.conv_on = d->conv != nullptr;
   if (d->conv) {
     const VdkConvGeom* c = d->conv;

@@ -429,7 +429,8 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
     // residual rows of a 32 x 64 block are requested ONE BLOCK AHEAD: a lone wave has nothing to hide the ~2 us of an HBM read behind, and 8 blocks per tile waited for it.
     constexpr int NCP = NCT / 2, NB = NCP * 4;
     unsigned lane_out[NCP], lane_res[NCP];
-    f32x4 bias4[NCP];
+    f32x4 bias4[NCP], cs4[NCP];
+    const bool csc = p.cscale != nullptr;                       // VdkGemmDesc.col_scale: acc * col_scale before bias / residual (wave-uniform; absent: not a single extra operation)
 #pragma unroll
     for (int cp = 0; cp < NCP; ++cp) {
       const int ncol = ncol0 + cp * 64 + rc * 4;
@@ -437,7 +438,9 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
       lane_out[cp] = nok ? (unsigned)rrow * (unsigned)p.ldc * 4u + (unsigned)ncol * 4u : W4_OOB;
       lane_res[cp] = (RES && nok) ? (unsigned)rrow * (unsigned)p.ldr * 4u + (unsigned)ncol * 4u : W4_OOB;
       bias4[cp] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      cs4[cp] = (f32x4){1.f, 1.f, 1.f, 1.f};
       if (nok) bias4[cp] = *(const f32x4*)(p.bias + ncol);
+      if (nok && csc) cs4[cp] = *(const f32x4*)(p.cscale + ncol);
     }
     u32x4 rn[8];
     auto res_request = [&](int b) {
@@ -470,6 +473,10 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
       for (int ps = 0; ps < 8; ++ps) {
         const int row = ps * 4 + rrow;
         d[ps] = *(const f32x4*)(slab + row * 64 + ((rc ^ (row & 15)) << 2));
+      }
+      if (csc) {
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) d[ps] = d[ps] * cs4[cp];
       }
 #pragma unroll
       for (int ps = 0; ps < 8; ++ps) d[ps] = RES ? (d[ps] + bias4[cp]) + r[ps] : d[ps] + bias4[cp];

@@ -19,6 +19,8 @@
 // contraction dim, Wb [3D, ldb]: rows [0,D) = hi(W^), [D,2D) = hi(W^), [2D,3D) = lo(W^) with lo = bf16(W^ - hi).  Paired with the
 // feature planes (hi, lo, hi) the cos GEMM accumulates hi*hi + lo*hi + hi*lo: fp32-class accuracy (~2^-16) on the bf16 MFMA
 // pipe.  Columns C..Cp-1 are zero.  The backward GEMMs use the first plane only.
+// OF: format of the planes -- bf16, or fp16 (VDK_OPF_F16: hi = fp16(v), lo = fp16(v - hi); the same three products, the operands of an fp16 head)
+template <int OF = 0>
 __global__ __launch_bounds__(256) void colnorm_fwd_kernel(const float* __restrict__ W, long ldw, int D, int C, int Cp, float eps,
                                                           float* __restrict__ inv, bf16_t* __restrict__ Wb, long ldb, int planes) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -29,8 +31,8 @@ __global__ __launch_bounds__(256) void colnorm_fwd_kernel(const float* __restric
   if (c < C && inv) inv[c] = iv;
   for (int d = 0; d < D; ++d) {
     const float v = c < C ? W[(long)d * ldw + c] * iv : 0.f;
-    const bf16_t h = f2bf(v);
-    const bf16_t l = f2bf(v - bf2f(h));
+    const bf16_t h = f2op<OF>(v);
+    const bf16_t l = f2op<OF>(v - op2f<OF>(h));
     Wb[(long)d * ldb + c] = h;
     if (planes == 3) { Wb[(long)(D + d) * ldb + c] = h; Wb[(long)(2 * D + d) * ldb + c] = l; }
   }
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void colnorm_bwd_kernel(const float* __restric
 // Tiled forms (D <= 16 * 32, 16-byte aligned rows): a 512-thread block owns 64 columns x all D rows as 32 row groups x 16 column quads; every thread keeps
 // its D / 32 rows x 4 columns in registers, so W (and dW^) are read from HBM exactly once with 16-byte loads, many in flight (the thread-per-column loops above
 // issue one dependent 4-byte load at a time: 1.6 / 1.9 ms at C = 10^6 where 5 / 6 GB of traffic cost 1.0 / 1.2 ms).  planes: 3 = (hi, hi, lo), 1 = hi only.
-template <int RPT>
+template <int RPT, int OF = 0>
 __global__ __launch_bounds__(512) void colnorm_fwd_tiled_kernel(const float* __restrict__ W, long ldw, int D, int C, int Cp, float eps, float* __restrict__ inv,
                                                                 bf16_t* __restrict__ Wb, long ldb, int planes) {
   __shared__ float red[32][65];
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(512) void colnorm_fwd_tiled_kernel(const float* __r
     if (d >= D) continue;
     float n[4]; bf16_t h[4], l[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { n[e] = v[i][e] * iv[e]; h[e] = f2bf(n[e]); l[e] = f2bf(n[e] - bf2f(h[e])); }
+    for (int e = 0; e < 4; ++e) { n[e] = v[i][e] * iv[e]; h[e] = f2op<OF>(n[e]); l[e] = f2op<OF>(n[e] - op2f<OF>(h[e])); }
     const u32x2 hv = {(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
     *(u32x2*)(Wb + (long)d * ldb + c0) = hv;
     if (planes == 3) {
@@ -150,6 +152,7 @@ __global__ __launch_bounds__(512) void colnorm_bwd_tiled_kernel(const float* __r
 }
 // f f32 [B, D] -> f^ as f32 [B, D], bf16 [Bp, D] (hi plane, backward operand) and the transposed split planes
 // fbt [3D, Bp] = (hi, lo, hi) for the cos GEMM; inv[B]; rows B..Bp-1 zero.  one wave per row
+template <int OF = 0>
 __global__ __launch_bounds__(256) void rownorm_fwd_kernel(const float* __restrict__ f, int B, int Bp, int D, float eps, float* __restrict__ fh,
                                                           bf16_t* __restrict__ fb, bf16_t* __restrict__ fbt, float* __restrict__ inv, int planes) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -162,8 +165,8 @@ __global__ __launch_bounds__(256) void rownorm_fwd_kernel(const float* __restric
   for (int d = lane; d < D; d += 64) {
     const float v = row < B ? f[(long)row * D + d] * iv : 0.f;
     if (row < B) fh[(long)row * D + d] = v;
-    const bf16_t h = f2bf(v);
-    const bf16_t l = f2bf(v - bf2f(h));
+    const bf16_t h = f2op<OF>(v);
+    const bf16_t l = f2op<OF>(v - op2f<OF>(h));
     fb[(long)row * D + d] = h;
     fbt[(long)d * Bp + row] = h;
     if (planes == 3) { fbt[(long)(D + d) * Bp + row] = l; fbt[(long)(2 * D + d) * Bp + row] = h; }
@@ -186,8 +189,10 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restric
 // dcos bf16 [Bp?, lddc] = gscale * (softmax - target) * jac (columns C..lddc-1 zeroed).
 __global__ __launch_bounds__(256) void margin_ce_kernel(MarginP P, const float* __restrict__ cosv, long ldc, int C, const long long* __restrict__ y,
                                                         float label_smoothing, float gscale, float* __restrict__ logits, long ldl,
-                                                        float* __restrict__ loss_rows, bf16_t* __restrict__ dcos, long lddc, float* __restrict__ dcos32) {
+                                                        float* __restrict__ loss_rows, bf16_t* __restrict__ dcos, long lddc, float* __restrict__ dcos32,
+                                                        int opf = 0 /* format of dcos */, const float* __restrict__ lscale = nullptr /* device loss scale multiplied into gscale */) {
   __shared__ float red[4];
+  if (lscale) gscale *= lscale[0];
   const int row = blockIdx.x, tid = threadIdx.x;
   margin_row_params(P, row);
   const float* cr = cosv + (long)row * ldc;
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(256) void margin_ce_kernel(MarginP P, const float* 
       g *= gscale * jc;
     }
     if (dcos32) dcos32[(long)row * lddc + c] = g;      // the fp32-class training mode keeps the logit gradient unrounded
-    else dcos[(long)row * lddc + c] = f2bf(g);
+    else dcos[(long)row * lddc + c] = opf ? f2op<VDK_OPF_F16>(g) : f2bf(g);
   }
 }
 // Training form (no logits output) for wide heads: the same arithmetic with 16-byte loads, four of them in flight per thread (a 4-byte strided loop keeps
@@ -234,11 +239,14 @@ __global__ __launch_bounds__(256) void margin_ce_kernel(MarginP P, const float* 
 __device__ __forceinline__ float vexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 // ARC (ArcFace without per-row margins -- cfg3's head): every entry but the row's target is s * clamp(cos), so the margin function is evaluated ONCE per row (the target's
 // logit and jacobian) and an entry costs a clamp, a multiply and a select instead of the generic evaluation's branches; the same expressions, bit-identical results.
-template <bool ARC>
+// OF: format of dcos (bf16 | fp16).  lscale: GradScaler's loss scale on the device, multiplied into gscale -- with fp16 the softmax gradient of a 10^6-way head
+// (p ~ 1e-6 times s / B) is far below fp16's normal range unscaled; the loss value itself is never scaled.
+template <bool ARC, int OF = 0>
 __global__ __launch_bounds__(256) void margin_ce_vec_kernel(MarginP P, const float* __restrict__ cosv, long ldc, int C, const long long* __restrict__ y,
                                                             float label_smoothing, float gscale, float* __restrict__ loss_rows, bf16_t* __restrict__ dcos,
-                                                            long lddc) {
+                                                            long lddc, const float* __restrict__ lscale = nullptr) {
   __shared__ float red[4];
+  if (lscale) gscale *= lscale[0];
   const int row = blockIdx.x, tid = threadIdx.x;
   margin_row_params(P, row);
   const float* cr = cosv + (long)row * ldc;
@@ -305,10 +313,10 @@ __global__ __launch_bounds__(256) void margin_ce_vec_kernel(MarginP P, const flo
 #pragma unroll
     for (int u = 0; u < MCE_U; ++u) {
       const int c = base + u * 1024;
-      if (c < C4) *(u32x2*)(dr + c) = (u32x2){pack_bf2(grad(v[u][0], c), grad(v[u][1], c + 1)), pack_bf2(grad(v[u][2], c + 2), grad(v[u][3], c + 3))};
+      if (c < C4) *(u32x2*)(dr + c) = (u32x2){pack_op2<OF>(grad(v[u][0], c), grad(v[u][1], c + 1)), pack_op2<OF>(grad(v[u][2], c + 2), grad(v[u][3], c + 3))};
     }
   }
-  for (int c = C4 + tid; c < (int)lddc; c += 256) dr[c] = f2bf(c < C ? grad(cr[c], c) : 0.f);
+  for (int c = C4 + tid; c < (int)lddc; c += 256) dr[c] = f2op<OF>(c < C ? grad(cr[c], c) : 0.f);
 }
 // ---- class-sharded head (one shard of the weight per GPU: SURVEY 8(e), "class-sharded head") -----------------------------------------------------
 // The softmax of a row spans all shards, so the fused kernel above splits into three local passes around two small all-reduces:
@@ -450,19 +458,28 @@ __global__ __launch_bounds__(256) void margin_target_cos_direct_kernel(const bf1
 
 extern "C" {
 
-int vdk_colnorm_fwd(const float* W, int64_t ldw, int32_t D, int32_t C, int32_t Cp, float eps, float* inv, void* Wb, int64_t ldb, int32_t planes, void* stream) {
-  if (!W || !Wb || D <= 0 || C <= 0 || Cp < C || (planes != 1 && planes != 3)) return vdk_fail(VDK_EINVAL, "vdk_colnorm_fwd: bad argument (planes = 1 or 3)");
+int vdk_colnorm_fwd_dt(const float* W, int64_t ldw, int32_t D, int32_t C, int32_t Cp, float eps, float* inv, void* Wb, int64_t ldb, int32_t planes, int32_t dtype, void* stream) {
+  if (!W || !Wb || D <= 0 || C <= 0 || Cp < C || (planes != 1 && planes != 3) || (dtype != VDK_BF16 && dtype != VDK_F16))
+    return vdk_fail(VDK_EINVAL, "vdk_colnorm_fwd: bad argument (planes = 1 or 3, dtype VDK_BF16 | VDK_F16)");
   const bool tiled = D <= 512 && (ldw % 4 == 0) && (ldb % 4 == 0) && (Cp % 4 == 0) && (((uintptr_t)W | (uintptr_t)Wb) % 16 == 0);
+  const bool f16 = dtype == VDK_F16;
   if (tiled) {
     const dim3 grid((unsigned)((Cp + 63) / 64));
-#define CNF(R) hipLaunchKernelGGL((colnorm_fwd_tiled_kernel<R>), grid, dim3(512), 0, (hipStream_t)stream, W, (long)ldw, (int)D, (int)C, (int)Cp, eps, inv, (bf16_t*)Wb, (long)ldb, (int)planes)
+#define CNF(R) do { if (f16) hipLaunchKernelGGL((colnorm_fwd_tiled_kernel<R, VDK_OPF_F16>), grid, dim3(512), 0, (hipStream_t)stream, W, (long)ldw, (int)D, (int)C, (int)Cp, eps, inv, (bf16_t*)Wb, (long)ldb, (int)planes); \
+                    else hipLaunchKernelGGL((colnorm_fwd_tiled_kernel<R, 0>), grid, dim3(512), 0, (hipStream_t)stream, W, (long)ldw, (int)D, (int)C, (int)Cp, eps, inv, (bf16_t*)Wb, (long)ldb, (int)planes); } while (0)
     if (D <= 128) CNF(4); else if (D <= 256) CNF(8); else CNF(16);
 #undef CNF
+  } else if (f16) {
+    hipLaunchKernelGGL(colnorm_fwd_kernel<VDK_OPF_F16>, dim3((unsigned)((Cp + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, (long)ldw, (int)D, (int)C, (int)Cp, eps,
+                       inv, (bf16_t*)Wb, (long)ldb, (int)planes);
   } else {
-    hipLaunchKernelGGL(colnorm_fwd_kernel, dim3((unsigned)((Cp + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, (long)ldw, (int)D, (int)C, (int)Cp, eps,
+    hipLaunchKernelGGL(colnorm_fwd_kernel<0>, dim3((unsigned)((Cp + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, (long)ldw, (int)D, (int)C, (int)Cp, eps,
                        inv, (bf16_t*)Wb, (long)ldb, (int)planes);
   }
   return vdk_check_launch("vdk_colnorm_fwd");
+}
+int vdk_colnorm_fwd(const float* W, int64_t ldw, int32_t D, int32_t C, int32_t Cp, float eps, float* inv, void* Wb, int64_t ldb, int32_t planes, void* stream) {
+  return vdk_colnorm_fwd_dt(W, ldw, D, C, Cp, eps, inv, Wb, ldb, planes, VDK_BF16, stream);
 }
 int vdk_colnorm_bwd(const float* W, int64_t ldw, const float* inv, const float* dWh, int64_t ldg, int32_t D, int32_t C, float* dW, int64_t ldo,
                     void* stream) {
@@ -480,11 +497,19 @@ int vdk_colnorm_bwd(const float* W, int64_t ldw, const float* inv, const float* 
   }
   return vdk_check_launch("vdk_colnorm_bwd");
 }
-int vdk_rownorm_fwd(const float* f, int32_t B, int32_t Bp, int32_t D, float eps, float* fh, void* fb, void* fbt, float* inv, int32_t planes, void* stream) {
-  if (!f || !fh || !fb || !fbt || !inv || B <= 0 || Bp < B || D <= 0 || (planes != 1 && planes != 3)) return vdk_fail(VDK_EINVAL, "vdk_rownorm_fwd: bad argument");
-  hipLaunchKernelGGL(rownorm_fwd_kernel, dim3((unsigned)((Bp + 3) / 4)), dim3(256), 0, (hipStream_t)stream, f, (int)B, (int)Bp, (int)D, eps, fh, (bf16_t*)fb,
-                     (bf16_t*)fbt, inv, (int)planes);
+int vdk_rownorm_fwd_dt(const float* f, int32_t B, int32_t Bp, int32_t D, float eps, float* fh, void* fb, void* fbt, float* inv, int32_t planes, int32_t dtype, void* stream) {
+  if (!f || !fh || !fb || !fbt || !inv || B <= 0 || Bp < B || D <= 0 || (planes != 1 && planes != 3) || (dtype != VDK_BF16 && dtype != VDK_F16))
+    return vdk_fail(VDK_EINVAL, "vdk_rownorm_fwd: bad argument");
+  if (dtype == VDK_F16)
+    hipLaunchKernelGGL(rownorm_fwd_kernel<VDK_OPF_F16>, dim3((unsigned)((Bp + 3) / 4)), dim3(256), 0, (hipStream_t)stream, f, (int)B, (int)Bp, (int)D, eps, fh, (bf16_t*)fb,
+                       (bf16_t*)fbt, inv, (int)planes);
+  else
+    hipLaunchKernelGGL(rownorm_fwd_kernel<0>, dim3((unsigned)((Bp + 3) / 4)), dim3(256), 0, (hipStream_t)stream, f, (int)B, (int)Bp, (int)D, eps, fh, (bf16_t*)fb,
+                       (bf16_t*)fbt, inv, (int)planes);
   return vdk_check_launch("vdk_rownorm_fwd");
+}
+int vdk_rownorm_fwd(const float* f, int32_t B, int32_t Bp, int32_t D, float eps, float* fh, void* fb, void* fbt, float* inv, int32_t planes, void* stream) {
+  return vdk_rownorm_fwd_dt(f, B, Bp, D, eps, fh, fb, fbt, inv, planes, VDK_BF16, stream);
 }
 int vdk_rownorm_bwd(const float* fh, const float* inv, const float* dfh, int64_t lddfh, int32_t B, int32_t D, float* df, void* stream) {
   if (!fh || !inv || !dfh || !df || B <= 0 || D <= 0) return vdk_fail(VDK_EINVAL, "vdk_rownorm_bwd: bad argument");
@@ -502,24 +527,28 @@ int vdk_margin_target_cos_direct(const void* fbt, int64_t ld_f, const void* wb, 
                      (int)K, (int)B, (const long long*)labels, gt);
   return vdk_check_launch("vdk_margin_target_cos_direct");
 }
-int vdk_margin_ce(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t C, const int64_t* labels, float label_smoothing,
-                  float grad_scale, float* logits, int64_t ldl, float* loss_rows, void* dcos_bf16, int64_t lddc, void* stream) {
+int vdk_margin_ce_amp(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t C, const int64_t* labels, float label_smoothing,
+                      float grad_scale, const float* loss_scale, float* logits, int64_t ldl, float* loss_rows, void* dcos_bf16, int64_t lddc, int32_t dc_dtype, void* stream) {
   MarginP P; int rc = fill_params(h, &P); if (rc) return rc;
-  if (!cosv || !labels || B <= 0 || C <= 0 || (dcos_bf16 && lddc < C)) return vdk_fail(VDK_EINVAL, "vdk_margin_ce: bad argument");
+  if (!cosv || !labels || B <= 0 || C <= 0 || (dcos_bf16 && lddc < C) || (dc_dtype != VDK_BF16 && dc_dtype != VDK_F16)) return vdk_fail(VDK_EINVAL, "vdk_margin_ce: bad argument");
+  const bool f16 = dc_dtype == VDK_F16;
   const bool vec = !logits && (loss_rows || dcos_bf16) && C >= 4096 && (ldc & 3) == 0 && ((size_t)cosv & 15) == 0 &&
                    (!dcos_bf16 || ((lddc & 3) == 0 && ((size_t)dcos_bf16 & 7) == 0));
   const char* genv = getenv("VDK_MARGIN_GENERIC");      // A/B and tests: =1 runs the generic evaluation also for ArcFace (read per call)
   const bool generic_env = genv && atoi(genv) == 1;
-  if (vec && P.mode == VDK_HEAD_ARCFACE && !P.row_margin && !generic_env)
-    hipLaunchKernelGGL(margin_ce_vec_kernel<true>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, P, cosv, (long)ldc, (int)C, (const long long*)labels,
-                       label_smoothing, grad_scale, loss_rows, (bf16_t*)dcos_bf16, (long)lddc);
-  else if (vec)
-    hipLaunchKernelGGL(margin_ce_vec_kernel<false>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, P, cosv, (long)ldc, (int)C, (const long long*)labels,
-                       label_smoothing, grad_scale, loss_rows, (bf16_t*)dcos_bf16, (long)lddc);
+#define MCV(ARC, OF) hipLaunchKernelGGL((margin_ce_vec_kernel<ARC, OF>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, P, cosv, (long)ldc, (int)C, (const long long*)labels, \
+                                        label_smoothing, grad_scale, loss_rows, (bf16_t*)dcos_bf16, (long)lddc, loss_scale)
+  if (vec && P.mode == VDK_HEAD_ARCFACE && !P.row_margin && !generic_env) { if (f16) MCV(true, VDK_OPF_F16); else MCV(true, 0); }
+  else if (vec) { if (f16) MCV(false, VDK_OPF_F16); else MCV(false, 0); }
   else
     hipLaunchKernelGGL(margin_ce_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, P, cosv, (long)ldc, (int)C, (const long long*)labels,
-                       label_smoothing, grad_scale, logits, (long)ldl, loss_rows, (bf16_t*)dcos_bf16, (long)lddc, (float*)nullptr);
+                       label_smoothing, grad_scale, logits, (long)ldl, loss_rows, (bf16_t*)dcos_bf16, (long)lddc, (float*)nullptr, f16 ? 1 : 0, loss_scale);
+#undef MCV
   return vdk_check_launch("vdk_margin_ce");
+}
+int vdk_margin_ce(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t C, const int64_t* labels, float label_smoothing,
+                  float grad_scale, float* logits, int64_t ldl, float* loss_rows, void* dcos_bf16, int64_t lddc, void* stream) {
+  return vdk_margin_ce_amp(h, cosv, ldc, B, C, labels, label_smoothing, grad_scale, nullptr, logits, ldl, loss_rows, dcos_bf16, lddc, VDK_BF16, stream);
 }
 /* vdk_margin_ce with the logit gradient d(loss)/d(cos) left in fp32 [B, lddc] (columns C .. lddc - 1 zeroed): the head of the fp32-class training mode */
 int vdk_margin_ce_f32(const VdkMarginHead* h, const float* cosv, int64_t ldc, int32_t B, int32_t C, const int64_t* labels, float label_smoothing, float grad_scale,

@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      long lddres, int T, int C, int rows_per_block, float* __restrict__ dx,
                                                      long lddx, bf16_t* __restrict__ dxb, long lddxb,
-                                                     float* __restrict__ pgamma, float* __restrict__ pbeta, float* __restrict__ pout, LnQ8 q8 = LnQ8()) {
+                                                     float* __restrict__ pgamma, float* __restrict__ pbeta, float* __restrict__ pout, LnQ8 q8 = LnQ8(),
+                                                     const float* __restrict__ dy_scale = nullptr /* device scalar: dy is multiplied by dy_scale[0] as it is loaded (a gradient branch kept at its own power-of-two scale: ConvNeXt's layer-scale branch under fp16 operands) */) {
   static_assert(!HALF || MAXJ == 1, "HALF: one 128-column slab");
   __shared__ float red[4][MAXJ * 256];
   float q8s = 1.0f, q8lim = 448.0f, q8am = 0.f;
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 #pragma unroll
     for (int e = 0; e < 4; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; if (OCS) ao[j][e] = 0.f; }
   const float invC = 1.0f / (float)C;
+  const float dsc = dy_scale ? dy_scale[0] : 1.0f;
   for (int rb = r0 + w * RW; rb < r1; rb += 4 * RW) {
     float rs[NR], s1[NR], s2[NR];
     float gk[NR][MAXJ][4], xh[NR][MAXJ][4], rv[NR][MAXJ][4];
@@ -180,6 +182,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
             f32x4 u = *(const f32x4*)((const float*)dy + (long)row * lddy + c);
             d[0] = u[0]; d[1] = u[1]; d[2] = u[2]; d[3] = u[3];
           }
+          if (dy_scale) { d[0] *= dsc; d[1] *= dsc; d[2] *= dsc; d[3] *= dsc; }
           if (dres) {
             f32x4 r4 = *(const f32x4*)(dres + (long)row * lddres + c);
             rv[k][j][0] = r4[0]; rv[k][j][1] = r4[1]; rv[k][j][2] = r4[2]; rv[k][j][3] = r4[3];
@@ -653,7 +656,8 @@ int vdk_layernorm_bwd_workspace_bytes(int32_t T, int32_t C, size_t* bytes) {
 static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean,
                        const float* rstd, const float* gamma, const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx,
                        int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                       void* stream_, VdkReduceJob* deferred, float* dxb_colsum = nullptr, VdkReduceJob* deferred2 = nullptr, const LnQ8* q8 = nullptr, int opf = 0) {
+                       void* stream_, VdkReduceJob* deferred, float* dxb_colsum = nullptr, VdkReduceJob* deferred2 = nullptr, const LnQ8* q8 = nullptr, int opf = 0,
+                       const float* dy_scale = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
   if (dy_dtype == VDK_F16) opf = VDK_OPF_F16;          // (an fp32 dy with an fp16 dxb: opf passed by the in-library caller)
   if (dy_dtype != VDK_BF16 && dy_dtype != VDK_F32 && dy_dtype != VDK_F16) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: bad dy_dtype");
@@ -670,15 +674,15 @@ static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const flo
   const int rpb = (T + nb - 1) / nb;
   const bool bf = dy_dtype != VDK_F32;
 #define LNB(MJ, BF, OC, NR, HF) do { if (opf) hipLaunchKernelGGL((ln_bwd_kernel<MJ, BF, OC, false, VDK_OPF_F16, NR, HF>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
-                                           mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po); \
+                                           mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po, LnQ8(), dy_scale); \
                              else hipLaunchKernelGGL((ln_bwd_kernel<MJ, BF, OC, false, VDK_OPF_BF16, NR, HF>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
-                                           mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po); } while (0)
+                                           mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po, LnQ8(), dy_scale); } while (0)
 #define LNB2(MJ, NR, HF) do { if (ocs) { if (bf) LNB(MJ, true, true, NR, HF); else LNB(MJ, false, true, NR, HF); } \
                               else { if (bf) LNB(MJ, true, false, NR, HF); else LNB(MJ, false, false, NR, HF); } } while (0)
   // MAXJ = 3 (C <= 768, ViT-B) keeps the kernel at <= 128 VGPRs = 4 blocks per CU; the narrower rows of the Swin / ConvNeXt stages take two rows per wave and pass
   // (C <= 128: four, a row being half a wave)
   if (q8) {
-    if (!ocs || !bf || opf || !q8->out || (q8->ld & 3)) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: the fp8 copy needs bf16 dy, the column-sum form and ld % 4 == 0");
+    if (!ocs || !bf || opf || dy_scale || !q8->out || (q8->ld & 3)) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: the fp8 copy needs bf16 dy, the column-sum form and ld % 4 == 0");
 #define LNBQ(MJ) hipLaunchKernelGGL((ln_bwd_kernel<MJ, true, true, true>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
                                     mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po, *q8)
     if (C <= 768) LNBQ(3); else LNBQ(4);
@@ -819,8 +823,8 @@ int vdk_bce_logits(const float* logits, int64_t ldl, const float* targets, int64
 // LayerNorm backward whose dgamma | dbeta partial-sum reduction is left to the caller: *job describes it (job->in == NULL if it was done here after all)
 int vdk_layernorm_bwd_deferred(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
                                const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx, int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta,
-                               void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job, float* dxb_colsum, VdkReduceJob* job2, const LnQ8* dxb_q8, int opf) {
-  return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, mean, rstd, gamma, dres, lddres, T, C, dx, lddx, dxb, lddxb, dgamma, dbeta, ws, ws_bytes, stream, job, dxb_colsum, job2, dxb_q8, opf);
+                               void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job, float* dxb_colsum, VdkReduceJob* job2, const LnQ8* dxb_q8, int opf, const float* dy_scale) {
+  return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, mean, rstd, gamma, dres, lddres, T, C, dx, lddx, dxb, lddxb, dgamma, dbeta, ws, ws_bytes, stream, job, dxb_colsum, job2, dxb_q8, opf, dy_scale);
 }
 // vdk_colsum_bf16 whose final reduction over the row splits is left to the caller (*job describes it)
 int vdk_colsum_bf16_deferred(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream_, VdkReduceJob* job, const LnQ8* q8, int opf) {

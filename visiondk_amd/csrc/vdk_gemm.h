@@ -34,6 +34,7 @@ struct GemmParams {
   int sk_xcd;                // gemm_w4_kernel, split-K: 1-D grid, a slab's tiles stay on one XCD (see the kernel); 0: grid (tiles, splits)
   int stagger, stagger_lo;   // gemm_w4h_kernel: workgroups stagger_lo .. 2 * stagger_lo - 1 start `stagger` shader cycles late (0: nobody)
   int opf;                   // operand format of A, B, a 16-bit C and aux: VDK_OPF_BF16 | VDK_OPF_F16 (VdkGemmDesc.ab_dtype)
+  const float* cscale;       // VdkGemmDesc.col_scale: per-column factor of the accumulator, applied before bias / residual (fp32-output epilogues)
 };
 
 // in-library launcher (no descriptor copy through the C ABI)

@@ -20,6 +20,11 @@ __device__ __forceinline__ void g_epilogue_store8(const GemmParams& p, long mi, 
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
     }
+    if (p.cscale) {
+      f32x4 c0 = *(const f32x4*)(p.cscale + n), c1 = *(const f32x4*)(p.cscale + n + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] *= c0[e]; v[4 + e] *= c1[e]; }
+    }
     if (p.bias) {
       f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
 #pragma unroll
@@ -164,6 +169,11 @@ __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float
       float* dst = p.slabs + ((long)z * p.M + (mbase + row)) * p.N + n;
       *(f32x4*)dst = x0; *(f32x4*)(dst + 4) = x1;
       continue;
+    }
+    if ((E & E_F32) && p.cscale) {      // VdkGemmDesc.col_scale (fp32-output forms): acc * col_scale, then bias / residual
+      const f32x4 c0 = *(const f32x4*)(p.cscale + n), c1 = *(const f32x4*)(p.cscale + n + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] *= c0[e]; v[4 + e] *= c1[e]; }
     }
     if (E & E_BIAS) {
 #pragma unroll

@@ -41,8 +41,16 @@ int vdk_layernorm_bwd_deferred(const void* dy, int64_t lddy, int32_t dy_dtype, c
                                void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job,
                                float* dxb_colsum = nullptr /* [C]: column sums of the bf16 output dxb (a Linear's bias gradient), reduction described by *job2 */, VdkReduceJob* job2 = nullptr,
                                const LnQ8* dxb_q8 = nullptr /* with dxb_colsum, C <= 1024, bf16 dy: dxb's fp8 copy rides along */,
-                               int opf = 0 /* format of a 16-bit dy and of dxb (dy_dtype VDK_F16 implies fp16; an fp32 dy takes it from here) */);
+                               int opf = 0 /* format of a 16-bit dy and of dxb (dy_dtype VDK_F16 implies fp16; an fp32 dy takes it from here) */,
+                               const float* dy_scale = nullptr /* device scalar multiplied into dy as it is loaded (job == nullptr: the reductions run inside) */);
 
 // conv.hip: every ConvNeXt block's weight preparation in one launch (depthwise weight tap-major, layer scale folded into fc2 in both orientations); in-library
-struct CnPrepJob { const float* dw_w; float* dwt; const float* w2; const float* b2; const float* gamma; unsigned short* w2p; unsigned short* w2pt; float* b2p; int C, M; };
+struct CnPrepJob { const float* dw_w; float* dwt; const float* w2; const float* b2; const float* gamma; unsigned short* w2p; unsigned short* w2pt; float* b2p; int C, M;
+                   float* rs; /* NULL: bf16 operands, gamma folded into both copies.  else f32 [2] = {r, 1 / r}: fp16 operands (see cn_prep_batch_kernel) */ };
 int vdk_convnext_prep_blocks(const CnPrepJob* jobs, int n, void* stream);
+
+// conv.hip kernels with the 16-bit output format as a parameter (in-library; the C-ABI names are the bf16 forms)
+extern "C" int vdk_dwconv7_fwd_16(const float* in, const float* wt, const float* bias, const float* res, float* out, void* out16, int32_t B, int32_t H, int32_t W, int32_t C,
+                                  int32_t flip, int32_t opf, void* stream);
+extern "C" int vdk_avgpool_rows_f32_bwd_16(const float* dpool, float* dmap, void* dmap16, int32_t B, int32_t HW, int32_t C, int32_t opf, void* stream);
+extern "C" int vdk_conv2x2_weight_prep_16(const float* w, void* wb, void* wtb, int32_t Co, int32_t Ci, int32_t opf, void* stream);

@@ -74,12 +74,13 @@ class _NeckFn(torch.autograd.Function):
         tokens = tokens.contiguous()
         bn = wrapper.output_layer[3]
         # LayerNorm over C (eps 1e-5: nn.LayerNorm default, timm_wrapper.py:42) -> bf16 rows, viewed as [Bp, N*D] (pad rows zero)
-        h = torch.zeros((Bp, K), dtype=torch.bfloat16, device=dev)
+        dt16 = getattr(wrapper, "dt16", torch.bfloat16)      # the backbone's operand format (bf16 | fp16)
+        h = torch.zeros((Bp, K), dtype=dt16, device=dev)
         mean = torch.empty(B * N, dtype=torch.float32, device=dev)
         rstd = torch.empty(B * N, dtype=torch.float32, device=dev)
-        be.check(be.lib.vdk_layernorm_fwd(be.ptr(tokens), D, B * N, D, be.ptr(ln_w), be.ptr(ln_b), 1e-5, be.ptr(h), D, _abi.BF16, be.ptr(mean),
-                                          be.ptr(rstd), be.stream()), "vdk_layernorm_fwd")
-        wb = ops.cast_bf16(lin_w.detach().contiguous(), backend=be)                      # [F, N*D] bf16
+        be.check(be.lib.vdk_layernorm_fwd(be.ptr(tokens), D, B * N, D, be.ptr(ln_w), be.ptr(ln_b), 1e-5, be.ptr(h), D, _abi.F16_ if dt16 == torch.float16 else _abi.BF16,
+                                          be.ptr(mean), be.ptr(rstd), be.stream()), "vdk_layernorm_fwd")
+        wb = ops.cast_16(lin_w.detach().contiguous(), dt16, backend=be)                  # [F, N*D] 16-bit
         z = ops.gemm_nt(h[:B], wb, out_dtype=torch.float32, bias=lin_b.detach(), backend=be)     # [B, F]
         y = torch.empty_like(z)
         training = bool(wrapper.training)
@@ -104,10 +105,9 @@ class _NeckFn(torch.autograd.Function):
         dz = torch.empty((B, Fd), dtype=torch.float32, device=dev)
         dbn_w = torch.empty(Fd, dtype=torch.float32, device=dev); dbn_b = torch.empty(Fd, dtype=torch.float32, device=dev)
         _bn_rows_bwd(be, dy, z, B, Fd, bn_w, sm, si, dz, dbn_w, dbn_b, ctx.sg)
-        dzb = torch.zeros((Bp, _up(Fd, 8)), dtype=torch.bfloat16, device=dev)
         stage = torch.zeros((Bp, _up(Fd, 8)), dtype=torch.float32, device=dev)
         stage[:B, :Fd].copy_(dz)
-        be.check(be.lib.vdk_cast_f32_bf16(be.ptr(stage), be.ptr(dzb), stage.numel(), be.stream()), "vdk_cast_f32_bf16")
+        dzb = ops.cast_16(stage, h.dtype, backend=be)
         dlin_b = ops.reduce_rows(dz, backend=be)
         # dW [F, N*D] = dz^T h : TN kernel straight from dz [Bp, F] and h [Bp, N*D]
         dlin_w = ops.gemm_nt(dzb, h, out_dtype=torch.float32, trans=True, backend=be)[:Fd]
@@ -115,10 +115,10 @@ class _NeckFn(torch.autograd.Function):
         dzt = ops.transpose_pad(dzb, rpad=Bp, backend=be)                    # [Fp, Bp]
         fpad = dzt.shape[0]
         if fpad % 64 == 0 and fpad == Fd:
-            dh = ops.gemm_nt(dzt, wb, out_dtype=torch.bfloat16, trans=True, backend=be)            # [Bp, N*D]
+            dh = ops.gemm_nt(dzt, wb, out_dtype=h.dtype, trans=True, backend=be)                   # [Bp, N*D]
         else:   # feature dims that are not multiples of 64: NT kernel against an explicit W^T copy
             wbt = ops.transpose_pad(wb, rpad=_up(Fd, 8), backend=be)          # [N*D, Fp]
-            dh = ops.gemm_nt(dzb, wbt, out_dtype=torch.bfloat16, backend=be)
+            dh = ops.gemm_nt(dzb, wbt, out_dtype=h.dtype, backend=be)
         dtok, _, dln_w, dln_b = ops.layernorm_bwd(dh[:B].reshape(B * N, D), tokens.view(B * N, D), mean, rstd, ln_w, want_bf16=False, backend=be)
         return dtok.view(B, N, D), dln_w, dln_b, dlin_w.contiguous(), dlin_b, dbn_w, dbn_b, None
 
@@ -148,8 +148,9 @@ class _NeckCNNFn(torch.autograd.Function):
             h, wb = y2.view(Bp, K), wperm
             z = ops.gemm_f32(h[:B], wb, bias=lin_b.detach(), backend=be)
         else:
-            h = ops.cast_bf16(y2, backend=be).view(Bp, K)                       # bf16 [Bp, HW*C], pad rows zero
-            wb = ops.cast_bf16(wperm, backend=be)
+            dt16 = getattr(wrapper, "dt16", torch.bfloat16)                    # the backbone's operand format (bf16 | fp16)
+            h = ops.cast_16(y2, dt16, backend=be).view(Bp, K)                  # 16-bit [Bp, HW*C], pad rows zero
+            wb = ops.cast_16(wperm, dt16, backend=be)
             # [B, F] from K = HW * C = 50 176: 4 output tiles of 256 x 256 would leave the contraction to 4 CUs (826 us at B = F = 512); split over K instead
             tiles = ((B + 255) // 256) * ((Fd + 255) // 256)
             sk = max(1, min(256 // tiles, K // 64 // 8))
@@ -187,7 +188,7 @@ class _NeckCNNFn(torch.autograd.Function):
         else:
             stage = torch.zeros((Bp, _up(Fd, 8)), dtype=torch.float32, device=dev)
             stage[:B, :Fd].copy_(dz)
-            dzb = ops.cast_bf16(stage, backend=be)
+            dzb = ops.cast_16(stage, h.dtype, backend=be)
             dwp = ops.gemm_nt(dzb, h, out_dtype=torch.float32, trans=True, backend=be)[:Fd]                      # [F, HW*C]
             dlin_w = dwp.view(Fd, HW, Cc).permute(0, 2, 1).reshape(Fd, K)                                          # back to the NCHW column order
             dzt = ops.transpose_pad(dzb, rpad=Bp, backend=be)
@@ -208,24 +209,32 @@ class TimmWrapper(nn.Module):
     """models/faceX/backbone/timm_wrapper.py: timm backbone without head/pool + embedding neck -> [B, feat_dim]."""
 
     def __init__(self, model_name: str, feat_dim: int, image_size: int, pretrained: bool = True, backend: Optional[_lib.Backend] = None,
-                 device=None, **kwargs):
+                 device=None, operand: str = "bf16", **kwargs):
+        """operand: "bf16" | "fp16", the 16-bit format of the backbone's and the neck's GEMM operands.  The reference runs this path in fp32 (no autocast in the face / CBIR
+        loop, engine/procedure/train.py:217-227): fp16 operands keep the embeddings within 1e-3 and the gradients within 5e-3 of that arithmetic at the bf16 speed
+        (tests/test_parity_fullsize_gpu.py), with FaceTrainStep running the GradScaler protocol the reference's loop also runs (train.py:205-211)."""
         super().__init__()
+        if operand not in ("bf16", "fp16"):
+            raise ValueError("operand must be 'bf16' or 'fp16'")
         self.be = backend or _lib.load()
         dev = device if device is not None else ("cuda" if self.be.device_only else "cpu")
         self.is_cnn = model_name in convnext.TIMM_CONVNEXTS
+        self.operand = operand
+        self.dt16 = torch.float16 if operand == "fp16" else torch.bfloat16
         if self.is_cnn:
-            self.model = convnext.create_model(model_name, pretrained=False, num_classes=0, global_pool="", img_size=image_size, device=dev, backend=self.be)
+            self.model = convnext.create_model(model_name, pretrained=False, num_classes=0, global_pool="", img_size=image_size, device=dev, backend=self.be,
+                                               operand=operand)
             channels, hw = self.model.engine.out_ch, self.model.engine.out_hw
             self.output_layer = nn.Sequential(nn.BatchNorm2d(channels), nn.Flatten(1), nn.Linear(channels * hw * hw, feat_dim), nn.BatchNorm1d(feat_dim)).to(dev)
         elif model_name in vit.TIMM_VITS:
-            self.model = vit.create_model(model_name, pretrained=False, num_classes=0, global_pool="", img_size=image_size, device=dev, backend=self.be)
+            self.model = vit.create_model(model_name, pretrained=False, num_classes=0, global_pool="", img_size=image_size, device=dev, backend=self.be, operand=operand)
             tokens, channels = self.model.engine.tokens, self.model.spec.dim
             self.output_layer = nn.Sequential(nn.LayerNorm(channels), nn.Flatten(1), nn.Linear(tokens * channels, feat_dim), nn.BatchNorm1d(feat_dim)).to(dev)
         elif model_name in swin.TIMM_SWINS:
             # timm's Swin returns an NHWC map [B, 7, 7, C] for global_pool='', and the reference's wrapper reads ANY 4-D output as [B, channels, h, w]
             # (timm_wrapper.py:28-37): with this backbone -- the default of cbir.yaml:26 -- its neck is BatchNorm2d(7) over the map's ROW index, Flatten, Linear(7 * 7 * C, feat_dim),
             # BatchNorm1d.  Reproduced as it is: the NHWC tensor goes into the CNN neck as if it were NCHW.
-            self.model = swin.create_model(model_name, pretrained=False, num_classes=0, img_size=image_size, device=dev, backend=self.be)
+            self.model = swin.create_model(model_name, pretrained=False, num_classes=0, img_size=image_size, device=dev, backend=self.be, operand=operand)
             self.is_cnn = True
             hw, channels = image_size // 32, self.model.num_features
             self.output_layer = nn.Sequential(nn.BatchNorm2d(hw), nn.Flatten(1), nn.Linear(hw * hw * channels, feat_dim), nn.BatchNorm1d(feat_dim)).to(dev)
@@ -274,8 +283,9 @@ class BackboneFactory:
     def get_backbone(self):
         assert self.name.startswith("timm-"), "backbone id must look like timm-<timm model id>"
         model_id = self.name[5:].split(".")[0]          # 'timm-vit_base_patch16_224.augreg2_in21k_ft_in1k' -> architecture id
+        # `operand` is this library's own key next to the reference's three (backbone_def.py:17-24): "bf16" | "fp16" (TimmWrapper)
         return TimmWrapper(model_id, feat_dim=self.param["feat_dim"], image_size=self.param["image_size"],
-                           pretrained=False, **self.kw)
+                           pretrained=False, operand=self.param.get("operand", "bf16"), **self.kw)
 
 
 class FaceTrainingModel(nn.Module):
@@ -418,11 +428,19 @@ class FaceTrainStep:
 
     def __init__(self, model: "FaceTrainingModel", lr: float, momentum: float = 0.9, weight_decay: float = 5e-4, label_smoothing: float = 0.0,
                  max_norm: float = 10.0, ema: bool = True, comm=None, layer_wise: bool = False, shard_head: bool = False, sync_bn: bool = False,
-                 cos_planes: int = 3, precision: str = "bf16"):
-        """precision: "bf16" = bf16 MFMA operands with fp32 accumulation, residual stream and master weights (what the reference's GPU classifier loop computes under
-        autocast); "fp32" = the arithmetic of the reference's face / CBIR loop, which runs WITHOUT autocast (engine/procedure/train.py:217-227): fp32 activations, every
+                 cos_planes: int = 3, precision: str = "bf16", init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5,
+                 growth_interval: int = 2000):
+        """precision: "bf16" = 16-bit MFMA operands in the BACKBONE's operand format (TimmWrapper(operand=...): bf16 or fp16) with fp32 accumulation, residual stream and
+        master weights; "fp32" = the arithmetic of the reference's face / CBIR loop, which runs WITHOUT autocast (engine/procedure/train.py:217-227): fp32 activations, every
         contraction of the backbone and of the neck's Linear on the fp32 MFMA, split-plane (fp32-class) cosines in the head -- embeddings ~1e-5 and gradients ~1e-4 from
         the fp32 oracle at ~1/6 of the bf16 step's speed (CNN backbones; tests/test_face.py, tests/test_parity_fullsize_gpu.py).
+        An fp16 backbone (operand="fp16") is the fast mode that meets north_star's tolerance against that fp32 loop (embeddings <= 1e-3, gradients <= 5e-3 at ConvNeXt-B +
+        ArcFace(10^6), tests/test_parity_fullsize_gpu.py): backbone, neck and head multiply fp16 operands, and the step runs the GradScaler protocol the reference's face
+        loop runs as well -- `Trainer.update(model, loss, self.scaler, ...)` (engine/procedure/train.py:199,203-215; the scaler is enabled on a GPU, vision_engine.py:232;
+        only autocast is absent from that loop): the loss scale (device state {scale, growth tracker, skipped steps}; init_scale / growth_factor / backoff_factor /
+        growth_interval = GradScaler's defaults) is multiplied into d(loss)/d(cos), every gradient carries it, vdk_sgd_step_amp un-scales, and a step whose gradients hold an
+        inf / NaN is skipped while the EMA still moves.  With bf16 / fp32 arithmetic the scale stays 1 and only the inf / NaN skip remains -- exactly what the reference's
+        scaler does for fp32 gradients.
         cos_planes: 3 = fp32-class cosines in the head (split-bf16 planes: the reference's CPU path), 1 = single bf16 operands (the reference's GPU path: the head runs
         under autocast, train.py:118).  shard_head (with comm): every rank keeps the columns [rank * C / world, (rank + 1) * C / world) of the margin head, trains them with
         `heads.sharded_margin_ce` (features all-gathered, per-row softmax statistics and the [B, D] feature gradient all-reduced) and never all-reduces the
@@ -444,9 +462,13 @@ class FaceTrainStep:
         if not hasattr(self.bb.model, "engine"):
             raise NotImplementedError("FaceTrainStep needs a backbone with a native engine (ViT, ConvNeXt, Swin with native=True); the autograd-node Swin trains under "
                                       "the reference's own Trainer (torch optimizer over model.parameters())")
-        if getattr(self.bb.model.engine, "operand", "bf16") != "bf16":
-            raise NotImplementedError("FaceTrainStep runs the backbone on bf16 operands (or precision='fp32'): the reference's face / CBIR loop has no autocast and no GradScaler "
-                                      "(engine/procedure/train.py:217-227); fp16 operands belong to the classifier loop (vit.FusedTrainStep)")
+        self.amp = getattr(self.bb.model.engine, "operand", "bf16") == "fp16"
+        if self.amp and getattr(self.bb, "operand", "fp16") != "fp16":
+            raise ValueError("an fp16 backbone engine under a TimmWrapper built with operand='bf16': build the wrapper with operand='fp16' (its neck follows the format)")
+        if self.amp and precision == "fp32":
+            raise ValueError("precision='fp32' runs fp32 activations: build the backbone with operand='bf16' (its 16-bit copies are not used in that mode)")
+        if self.amp and shard_head:
+            raise NotImplementedError("the class-sharded head is built for bf16 operands (its three passes take no loss scale yet)")
         if precision == "fp32" and not hasattr(self.bb.model.engine, "precision"):
             raise NotImplementedError("precision='fp32' is built for the ConvNeXt backbones of the face / CBIR task (the engine with an fp32-class training mode)")
         self.precision = precision
@@ -477,6 +499,9 @@ class FaceTrainStep:
         self._zero_m = [mk(b) for b in self.buffers]
         self._nsq = torch.zeros(1, dtype=torch.float32, device=self.eng.device)
         self._nsq_part = torch.zeros(1, dtype=torch.float32, device=self.eng.device)
+        # GradScaler state on the device (see the docstring): fp16 -> dynamic scale; otherwise the scale is pinned at 1 and the state only carries the inf / NaN skip
+        self.loss_state = torch.tensor([init_scale if self.amp else 1.0, 0.0, 0.0], dtype=torch.float32, device=self.eng.device)
+        self.growth_factor, self.backoff_factor, self.growth_interval = (growth_factor, backoff_factor, growth_interval) if self.amp else (1.0, 1.0, 1 << 30)
         need = C.c_size_t(0)
         self.be.check(self.be.lib.vdk_sumsq_workspace_bytes(C.byref(need)), "vdk_sumsq_workspace_bytes")
         self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.eng.device)
@@ -543,7 +568,8 @@ class FaceTrainStep:
             self.loss_rows, demb, dW = heads.sharded_margin_ce(self.head, emb.detach(), y, self.hs, self.c0, self.head.weight.shape[1], group=self.comm.group,
                                                               label_smoothing=self.label_smoothing)
         else:
-            self.loss_rows, demb, dW = self.head.margin_ce(emb.detach(), y, self.label_smoothing, cos_planes=self.cos_planes, precise=self.precision == "fp32")
+            self.loss_rows, demb, dW = self.head.margin_ce(emb.detach(), y, self.label_smoothing, cos_planes=self.cos_planes, precise=self.precision == "fp32",
+                                                           operand="fp16" if self.amp else "bf16", loss_scale=self.loss_state if self.amp else None)
         for p in self.small:
             p.grad = None
         emb.backward(demb)
@@ -578,21 +604,44 @@ class FaceTrainStep:
             dist.all_reduce(self._nsq_head, op=dist.ReduceOp.SUM, group=self.comm.group)
             self._nsq += self._nsq_head
         first = int(self.updates == 1)
-        be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.mom_flat), be.ptr(self.ema_flat), be.ptr(eng.wb16), eng.n_floats, lr,
-                                     mom, wd, 1.0 / world, be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step")
+        # scaler.unscale_ + clip + scaler.step + ema.update in one pass per buffer (train.py:205-215): every gradient carries loss_state[0]; a non-finite norm skips the update
+        ls = be.ptr(self.loss_state)
+        p16 = _abi.F16_ if self.amp else _abi.BF16
+        be.check(be.lib.vdk_sgd_step_amp(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.mom_flat), be.ptr(self.ema_flat), be.ptr(eng.wb16), p16, eng.n_floats, lr,
+                                         mom, wd, 1.0 / world, ls, be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step_amp")
         for p, m, e in zip(self.small, self.mom_small, self.ema_small):
             g = p.grad.contiguous()
             is_head = p is self.head.weight
-            be.check(be.lib.vdk_sgd_step(be.ptr(p.data), be.ptr(g), be.ptr(m), be.ptr(e), None, p.numel(), lr_head if is_head else lr, mom_head if is_head else mom,
-                                         wd_head if is_head else wd, 1.0 / world, be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step")
+            be.check(be.lib.vdk_sgd_step_amp(be.ptr(p.data), be.ptr(g), be.ptr(m), be.ptr(e), None, p16, p.numel(), lr_head if is_head else lr, mom_head if is_head else mom,
+                                             wd_head if is_head else wd, 1.0 / world, ls, be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step_amp")
         if self.shard_head:
-            be.check(be.lib.vdk_sgd_step(be.ptr(self.hs), be.ptr(dW), be.ptr(self.hs_mom), be.ptr(self.hs_ema), None, self.hs.numel(), lr_head, mom_head,
-                                         wd_head, 1.0 / world, be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step")
+            be.check(be.lib.vdk_sgd_step_amp(be.ptr(self.hs), be.ptr(dW), be.ptr(self.hs_mom), be.ptr(self.hs_ema), None, p16, self.hs.numel(), lr_head, mom_head,
+                                             wd_head, 1.0 / world, ls, be.ptr(self._nsq), self.max_norm, d, first, be.stream()), "vdk_sgd_step_amp")
+        be.check(be.lib.vdk_loss_scale_update(ls, be.ptr(self._nsq), self.growth_factor, self.backoff_factor, self.growth_interval, be.stream()), "vdk_loss_scale_update")
         for b, z, zm, e in zip(self.buffers, self._zero, self._zero_m, self.ema_buf):   # EMA of the BatchNorm running statistics (lr = 0: value untouched)
             be.check(be.lib.vdk_sgd_step(be.ptr(b), be.ptr(z), be.ptr(zm), be.ptr(e), None, b.numel(), 0.0, 0.0, 0.0, 1.0, None, self.max_norm, d, first,
                                          be.stream()), "vdk_sgd_step")
         eng.refresh_weights(skip_wb16=True)
         return self.loss_rows
+
+    def loss_scale(self) -> float:
+        """GradScaler.get_scale() (one device read)"""
+        return float(self.loss_state[0].item())
+
+    def skipped_steps(self) -> int:
+        return int(self.loss_state[2].item())
+
+    def scaler_state_dict(self) -> dict:
+        """`scaler.state_dict()` as the reference checkpoints it (engine/vision_engine.py:296,397): torch.cuda.amp.GradScaler's keys"""
+        st = self.loss_state.tolist()
+        return {"scale": st[0], "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor, "growth_interval": self.growth_interval,
+                "_growth_tracker": int(st[1])}
+
+    def load_scaler_state_dict(self, sd: dict) -> None:
+        if not sd:
+            return
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(sd["growth_factor"]), float(sd["backoff_factor"]), int(sd["growth_interval"])
+        self.loss_state[0] = float(sd["scale"]); self.loss_state[1] = float(sd.get("_growth_tracker", 0))
 
     def gather_head(self, ema: bool = False) -> torch.Tensor:
         """shard_head: all-gather the column shards (or their EMA) into `head.weight` ([D, C], every rank) for evaluation and checkpoints"""

@@ -24,22 +24,24 @@ class _HeadState:
     __slots__ = ("cos", "fh", "fb", "fbt", "finv", "winv", "wb", "B", "Bp", "C", "Cp", "D")
 
 
-def _forward_cos(be, feats: torch.Tensor, weight: torch.Tensor, planes: int = 3, with_cos: bool = True) -> _HeadState:
+def _forward_cos(be, feats: torch.Tensor, weight: torch.Tensor, planes: int = 3, with_cos: bool = True, dtype=torch.bfloat16) -> _HeadState:
     """planes = 3: cos from split-bf16 planes (hi*hi + lo*hi + hi*lo: fp32-class, what the reference's CPU path computes); planes = 1: one bf16 plane per operand --
-    exactly the reference's GPU path, where train.py:118 runs the head under autocast and torch.mm(feats, kernel_norm) rounds both operands to bf16"""
+    exactly the reference's GPU path, where train.py:118 runs the head under autocast and torch.mm(feats, kernel_norm) rounds both operands to bf16.
+    dtype: format of the planes (torch.bfloat16 | torch.float16: the head of an fp16 train step, vdk_colnorm_fwd_dt)"""
     st = _HeadState()
+    dtc = _abi.F16_ if dtype == torch.float16 else _abi.BF16
     B, D = feats.shape
     Cn = weight.shape[1]
     st.B, st.D, st.C, st.Bp, st.Cp = B, D, Cn, _up(B, 64), _up(Cn, 8)
     dev = feats.device
     st.winv = torch.empty(Cn, dtype=torch.float32, device=dev)
-    st.wb = torch.empty((planes * D, st.Cp), dtype=torch.bfloat16, device=dev)   # split planes (hi, hi, lo) along K
-    be.check(be.lib.vdk_colnorm_fwd(be.ptr(weight), Cn, D, Cn, st.Cp, 1e-12, be.ptr(st.winv), be.ptr(st.wb), st.Cp, planes, be.stream()), "vdk_colnorm_fwd")
+    st.wb = torch.empty((planes * D, st.Cp), dtype=dtype, device=dev)   # split planes (hi, hi, lo) along K
+    be.check(be.lib.vdk_colnorm_fwd_dt(be.ptr(weight), Cn, D, Cn, st.Cp, 1e-12, be.ptr(st.winv), be.ptr(st.wb), st.Cp, planes, dtc, be.stream()), "vdk_colnorm_fwd")
     st.fh = torch.empty((B, D), dtype=torch.float32, device=dev)
-    st.fb = torch.empty((st.Bp, D), dtype=torch.bfloat16, device=dev)
-    st.fbt = torch.empty((planes * D, st.Bp), dtype=torch.bfloat16, device=dev)  # split planes (hi, lo, hi)
+    st.fb = torch.empty((st.Bp, D), dtype=dtype, device=dev)
+    st.fbt = torch.empty((planes * D, st.Bp), dtype=dtype, device=dev)  # split planes (hi, lo, hi)
     st.finv = torch.empty(B, dtype=torch.float32, device=dev)
-    be.check(be.lib.vdk_rownorm_fwd(be.ptr(feats), B, st.Bp, D, 1e-12, be.ptr(st.fh), be.ptr(st.fb), be.ptr(st.fbt), be.ptr(st.finv), planes, be.stream()),
+    be.check(be.lib.vdk_rownorm_fwd_dt(be.ptr(feats), B, st.Bp, D, 1e-12, be.ptr(st.fh), be.ptr(st.fb), be.ptr(st.fbt), be.ptr(st.finv), planes, dtc, be.stream()),
              "vdk_rownorm_fwd")
     # cos[Bp, Cp] = f^ . W^ : TN kernel over K = 3D split planes (hi*hi + lo*hi + hi*lo), A = fbt [3D, Bp], B = wb [3D, Cp]
     st.cos = ops.gemm_nt(st.fbt, st.wb, out_dtype=torch.float32, trans=True, backend=be) if with_cos else None
@@ -132,15 +134,27 @@ class _MarginHead(nn.Module):
         return loss, df, dW
 
     def margin_ce(self, feats: torch.Tensor, labels: torch.Tensor, label_smoothing: float = 0.0, grad_scale: Optional[float] = None, cos_planes: int = 3,
-                  fused: Optional[bool] = None, precise: bool = False):
+                  fused: Optional[bool] = None, precise: bool = False, operand: str = "bf16", loss_scale: Optional[torch.Tensor] = None):
         """Fused head + CrossEntropy (mean): returns (loss_rows [B], dfeats [B, D], dweight [D, C]); no autograd, no B x C logits.
         fused=True: the epilogue-fused form (SURVEY K11 to the letter: cos never exists as an fp32 [B, C] tensor; the cos GEMM runs twice with the head applied to its tiles in
         registers).  Measured on the MI355X at B 512, C 10^6: 6.7 ms against 5.8 ms for the default form that writes cos once in fp32 -- the head's ~18 lane-ops per logit run in a
         GEMM epilogue that nothing overlaps (one workgroup per CU), whereas the row kernel runs them at full occupancy -- so it is opt-in (profiles/r02_margin_head.json).
-        cos_planes = 1: the cosines from single bf16 operands, as the reference's autocast path computes them (see _forward_cos)"""
+        cos_planes = 1: the cosines from single bf16 operands, as the reference's autocast path computes them (see _forward_cos)
+        operand = "fp16": fp16 planes and an fp16 d(loss)/d(cos) -- 8x less operand rounding in the two gradient products than bf16; loss_scale (a device scalar, GradScaler's
+        scale: engine/procedure/train.py:205) is multiplied into d(loss)/d(cos), so dfeats and dweight come back SCALED and the caller un-scales in its optimizer pass
+        (FaceTrainStep over an fp16 backbone).  Without it the softmax gradient of a wide head underflows fp16."""
         be = self.be
         if precise:
+            if loss_scale is not None:
+                raise ValueError("precise=True computes unscaled fp32 gradients")
             return self._margin_ce_f32(feats, labels, label_smoothing, grad_scale)
+        if operand not in ("bf16", "fp16"):
+            raise ValueError("operand must be 'bf16' or 'fp16'")
+        dt16 = torch.float16 if operand == "fp16" else torch.bfloat16
+        if operand == "fp16" or loss_scale is not None:
+            if fused:
+                raise NotImplementedError("the epilogue-fused form is built for bf16 operands without a loss scale")
+            fused = False
         gs_ = None
         if fused:
             # the fused form: the cos GEMM runs twice with the head applied to its tiles in registers (statistics, then the gradient); cos never exists as an fp32 [B, C] tensor
@@ -171,14 +185,14 @@ class _MarginHead(nn.Module):
                 be.check(rc, "vdk_margin_cos_pass")
             st.cos = ops.gemm_nt(st.fbt, st.wb, out_dtype=torch.float32, trans=True, backend=be)      # shapes the 256x256 TN kernel does not serve: the materialised form
         else:
-            st = _forward_cos(be, feats.contiguous(), self.weight.detach(), cos_planes)
+            st = _forward_cos(be, feats.contiguous(), self.weight.detach(), cos_planes, dtype=dt16)
         loss = torch.empty(st.B, dtype=torch.float32, device=feats.device)
-        dcos = torch.empty((st.Bp, st.Cp), dtype=torch.bfloat16, device=feats.device)    # rows < B are written whole (padding columns zeroed) by the kernel
+        dcos = torch.empty((st.Bp, st.Cp), dtype=dt16, device=feats.device)    # rows < B are written whole (padding columns zeroed) by the kernel
         if st.Bp > st.B:
             dcos[st.B:].zero_()
         gs = 1.0 / st.B if grad_scale is None else grad_scale
-        be.check(be.lib.vdk_margin_ce(C.byref(self.cfg), be.ptr(st.cos), st.Cp, st.B, st.C, be.ptr(labels), label_smoothing, gs, None, 0, be.ptr(loss),
-                                      be.ptr(dcos), st.Cp, be.stream()), "vdk_margin_ce")
+        be.check(be.lib.vdk_margin_ce_amp(C.byref(self.cfg), be.ptr(st.cos), st.Cp, st.B, st.C, be.ptr(labels), label_smoothing, gs, be.ptr(loss_scale), None, 0, be.ptr(loss),
+                                          be.ptr(dcos), st.Cp, _abi.F16_ if operand == "fp16" else _abi.BF16, be.stream()), "vdk_margin_ce")
         df, dW = _backward_from_dcos(be, st, self.weight.detach(), dcos)
         return loss, df, dW
 

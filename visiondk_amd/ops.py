@@ -30,7 +30,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=None, bias: Optional[
             residual: Optional[torch.Tensor] = None, act: int = ACT_NONE, aux: Optional[torch.Tensor] = None,
             alpha: float = 1.0, splitk: int = 1, out: Optional[torch.Tensor] = None, row_group: int = 0,
             trans: bool = False, a_row_group: int = 0, a_rows: Optional[int] = None, a_colsum: Optional[torch.Tensor] = None,
-            streamk_ws: Optional[torch.Tensor] = None, c_colsum: Optional[torch.Tensor] = None, backend=None) -> torch.Tensor:
+            streamk_ws: Optional[torch.Tensor] = None, c_colsum: Optional[torch.Tensor] = None, col_scale: Optional[torch.Tensor] = None, backend=None) -> torch.Tensor:
     """out[M,N] = epilogue(alpha * a[M,K] @ b[N,K].T); a, b bf16 or (both) fp16 (row stride may exceed K); out_dtype: fp32 or the operands' format (the default).
     streamk_ws: persistent workspace from streamk_workspace() -> stream-K allowed"""
     be = _be(backend)
@@ -65,6 +65,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=None, bias: Optional[
     d.trans = int(trans)
     d.a_row_group = a_row_group
     d.a_colsum = a_colsum.data_ptr() if a_colsum is not None else None      # f32 [vdk_gemm_a_colsum_rows(M, N, K), K] by-product (sum rows -> colsum(a))
+    d.col_scale = be.ptr(col_scale) if col_scale is not None else None       # f32 [N]: acc * col_scale before bias / residual (VdkGemmDesc.col_scale)
     d.c_colsum = c_colsum.data_ptr() if c_colsum is not None else None      # f32 [vdk_gemm_c_colsum_rows(M, N, K), N] by-product (sum rows -> colsum(stored bf16 out))
     for t in (a, b, out, residual, aux):
         if t is not None and be.device_only and not t.is_cuda:
@@ -152,8 +153,12 @@ def gemm_fp8_nt(a8: torch.Tensor, b8: torch.Tensor, a_scale_inv: Optional[torch.
 
 def transpose_pad(x: torch.Tensor, rpad: Optional[int] = None, backend=None, rows: Optional[int] = None,
                   row_group: int = 0, colsum_partial: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x bf16 [R, C] -> [C, Rpad] with zero-filled padding columns (Rpad even, default: R rounded up to 64)."""
+    """x bf16 [R, C] -> [C, Rpad] with zero-filled padding columns (Rpad even, default: R rounded up to 64).  An fp16 tensor moves as its 16-bit patterns (no arithmetic
+    without colsum_partial) and comes back as fp16."""
     be = _be(backend)
+    if x.dtype == torch.float16:
+        assert colsum_partial is None
+        return transpose_pad(x.view(torch.bfloat16), rpad, backend, rows, row_group).view(torch.float16)
     assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
     R, Cc = x.shape
     if rows is not None:
@@ -306,6 +311,25 @@ def cast_bf16(x: torch.Tensor, backend=None) -> torch.Tensor:
     out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     be.check(be.lib.vdk_cast_f32_bf16(be.ptr(x), be.ptr(out), x.numel(), be.stream()), "vdk_cast_f32_bf16")
     return out
+
+
+def cast_16(x: torch.Tensor, dtype=torch.bfloat16, backend=None) -> torch.Tensor:
+    """x f32 -> the 16-bit operand format `dtype` (torch.bfloat16 | torch.float16)"""
+    if dtype == torch.bfloat16:
+        return cast_bf16(x, backend=backend)
+    assert dtype == torch.float16
+    be = _be(backend)
+    out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    be.check(be.lib.vdk_cast_f32_f16(be.ptr(x), be.ptr(out), x.numel(), be.stream()), "vdk_cast_f32_f16")
+    return out
+
+
+def scale_dev(x: torch.Tensor, scale: torch.Tensor, reciprocal: bool = False, backend=None) -> torch.Tensor:
+    """x (f32, contiguous) *= scale[0] in place, the factor read on the device (vdk_scale_dev_f32: GradScaler's loss scale entering a gradient tensor)"""
+    be = _be(backend)
+    assert x.dtype == torch.float32 and x.is_contiguous() and scale.dtype == torch.float32
+    be.check(be.lib.vdk_scale_dev_f32(be.ptr(x), x.numel(), be.ptr(scale), int(reciprocal), be.stream()), "vdk_scale_dev_f32")
+    return x
 
 
 def transpose_cast(w: torch.Tensor, rpad: Optional[int] = None, backend=None) -> torch.Tensor:

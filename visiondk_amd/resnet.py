@@ -278,8 +278,12 @@ class ResNetTrainStep:
 
     def __init__(self, model: ResNet, lr: float, momentum: float = 0.937, weight_decay: float = 5e-4, loss: str = "bce", label_smoothing: float = 0.0,
                  max_norm: float = 10.0, ema: bool = True, comm=None, sync_bn: bool = False, graph: bool = False, sam: bool = False, sam_rho: float = 0.05,
-                 sam_adaptive: bool = True):
-        """sam: Trainer.update_sam (train.py:150-175) over engine/optimizer.py's SAM(base SGD): forward-backward at w with LOCAL gradients, climb to w + e(w),
+                 sam_adaptive: bool = True, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5, growth_interval: int = 2000):
+        """An engine with fp16 operands (convnext.create_model(..., operand="fp16"): the reference's autocast dtype on a GPU, train.py:118) runs the step under the
+        GradScaler protocol of Trainer.update (train.py:203-215), as vit.FusedTrainStep does: the loss scale lives on the device ({scale, growth tracker, skipped steps};
+        init_scale / growth_factor / backoff_factor / growth_interval = torch's defaults), the loss kernel multiplies it into dlogits, vdk_sgd_step_amp un-scales, checks for
+        inf / NaN and skips the update while the EMA still moves, vdk_loss_scale_update grows / backs off.
+        sam: Trainer.update_sam (train.py:150-175) over engine/optimizer.py's SAM(base SGD): forward-backward at w with LOCAL gradients, climb to w + e(w),
         forward-backward there with the BatchNorm running statistics frozen (momentum 0) and the gradients all-reduced, back to w, base SGD step
         (no clipping on this path), EMA; the returned loss is the first pass's.
         graph: capture the whole step (about 250 launches of a few microseconds each at ResNet-18 / bs 32: launch-bound) once per batch shape in a hipGraph
@@ -290,6 +294,12 @@ class ResNetTrainStep:
         before every forward (torch DDP's broadcast_buffers), the flat gradient all-reduced in buckets from inside vdk_resnet_backward; BatchNorm statistics
         stay per rank (SyncBN is the reference's opt-in flag and is not built)."""
         assert loss in ("bce", "ce")
+        self.amp = getattr(model.engine, "operand", "bf16") == "fp16"
+        if self.amp and (sam or graph):
+            raise NotImplementedError("fp16 operands (GradScaler protocol) are built for the eager SGD step; SAM / graph replay run on bf16 operands")
+        self.dt16 = torch.float16 if self.amp else torch.bfloat16
+        self.loss_state = torch.tensor([init_scale, 0.0, 0.0], dtype=torch.float32, device=model.engine.device) if self.amp else None
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
         self.comm = comm
         self.sync_group = (comm.group if (sync_bn and comm is not None and comm.active) else False)
         self.model, self.eng, self.be = model, model.engine, model.engine.be
@@ -431,7 +441,9 @@ class ResNetTrainStep:
         B, ncls = x.shape[0], eng.spec.num_classes
         if self.loss_rows is None or self.loss_rows.shape[0] != B:
             self.loss_rows = torch.empty(B, dtype=torch.float32, device=eng.device)
-            self._dl = torch.zeros((self._dl_rows(B), eng.cp), dtype=torch.bfloat16, device=eng.device)
+            self._dl = torch.zeros((self._dl_rows(B), eng.cp), dtype=self.dt16, device=eng.device)
+        ls = be.ptr(self.loss_state) if self.amp else None                    # the device loss scale the loss kernels multiply into dlogits (GradScaler.scale(loss), train.py:205)
+        dlt = _abi.F16_ if self.amp else _abi.BF16
 
         def fwd_loss_bwd(sync: bool, bn_momentum=None):
             kw = {} if bn_momentum is None else {"bn_momentum": bn_momentum}
@@ -446,13 +458,17 @@ class ResNetTrainStep:
                                                    None, 0, be.ptr(gg), eng.cp, be.stream()), "vdk_bce_logits")
                 self.loss_rows.mul_(lam).add_(rows2, alpha=1.0 - lam)
                 g1.add_(g2)
-                be.check(be.lib.vdk_cast_f32_bf16(be.ptr(g1), be.ptr(self._dl), g1.numel(), be.stream()), "vdk_cast_f32_bf16")
+                if self.amp:
+                    be.check(be.lib.vdk_scale_dev_f32(be.ptr(g1), g1.numel(), ls, 0, be.stream()), "vdk_scale_dev_f32")
+                    be.check(be.lib.vdk_cast_f32_f16(be.ptr(g1), be.ptr(self._dl), g1.numel(), be.stream()), "vdk_cast_f32_f16")
+                else:
+                    be.check(be.lib.vdk_cast_f32_bf16(be.ptr(g1), be.ptr(self._dl), g1.numel(), be.stream()), "vdk_cast_f32_bf16")
             elif self.loss == "bce":
-                be.check(be.lib.vdk_bce_logits(be.ptr(logits), eng.cp, be.ptr(y), y.stride(0), B, ncls, 1.0 / (B * ncls), self.focal_gamma, self.focal_alpha, be.ptr(self.loss_rows),
-                                               be.ptr(self._dl), eng.cp, None, 0, be.stream()), "vdk_bce_logits")
+                be.check(be.lib.vdk_bce_logits_amp(be.ptr(logits), eng.cp, be.ptr(y), y.stride(0), B, ncls, 1.0 / (B * ncls), ls, self.focal_gamma, self.focal_alpha,
+                                                   be.ptr(self.loss_rows), be.ptr(self._dl), eng.cp, dlt, None, 0, be.stream()), "vdk_bce_logits")
             else:
-                be.check(be.lib.vdk_softmax_ce(be.ptr(logits), eng.cp, B, ncls, be.ptr(y), be.ptr(y_b), lam, self.label_smoothing, 1.0 / B, be.ptr(self.loss_rows),
-                                               be.ptr(self._dl), eng.cp, None, 0, be.stream()), "vdk_softmax_ce")
+                be.check(be.lib.vdk_softmax_ce_amp(be.ptr(logits), eng.cp, B, ncls, be.ptr(y), be.ptr(y_b), lam, self.label_smoothing, 1.0 / B, ls, be.ptr(self.loss_rows),
+                                                   be.ptr(self._dl), eng.cp, dlt, None, 0, be.stream()), "vdk_softmax_ce")
             if active and sync:
                 self.comm.begin_step(eng.grads)
                 eng.backward(self._dl, on_ready=self.comm.on_grad_ready, sync_group=self.sync_group)
@@ -485,14 +501,41 @@ class ResNetTrainStep:
                                                    be.ptr(hyper[5:]), 1.0, None, self.max_norm, be.stream()), "vdk_sgd_step_graph")
         else:
             d = 0.9999 * (1 - math.exp(-self.updates / 2000)) if self.ema is not None else 0.0
-            be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema), be.ptr(eng.wb16), eng.n_floats, g["lr"],
-                                         g["momentum"], g["weight_decay"], 1.0 / world, nsq, self.max_norm, d, int(self.updates == 1), be.stream()),
-                     "vdk_sgd_step")
+            if self.amp:      # scaler.unscale_ + clip + scaler.step (skipped on inf / NaN) + ema.update, then scaler.update (train.py:205-215)
+                be.check(be.lib.vdk_sgd_step_amp(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema), be.ptr(eng.wb16), _abi.F16_, eng.n_floats,
+                                                 g["lr"], g["momentum"], g["weight_decay"], 1.0 / world, ls, nsq, self.max_norm, d, int(self.updates == 1), be.stream()),
+                         "vdk_sgd_step_amp")
+                be.check(be.lib.vdk_loss_scale_update(ls, nsq, self.growth_factor, self.backoff_factor, self.growth_interval, be.stream()), "vdk_loss_scale_update")
+            else:
+                be.check(be.lib.vdk_sgd_step(be.ptr(eng.params), be.ptr(eng.grads), be.ptr(self.momentum_buf), be.ptr(self.ema), be.ptr(eng.wb16), eng.n_floats, g["lr"],
+                                             g["momentum"], g["weight_decay"], 1.0 / world, nsq, self.max_norm, d, int(self.updates == 1), be.stream()),
+                         "vdk_sgd_step")
             if self.ema_buffers is not None:      # lr = 0: the statistics themselves are untouched, their EMA moves with the same decay
                 be.check(be.lib.vdk_sgd_step(be.ptr(eng.buffers), be.ptr(self._zero_b), be.ptr(self._zero_bm), be.ptr(self.ema_buffers), None, eng.buffers.numel(), 0.0, 0.0, 0.0,
                                              1.0, None, self.max_norm, d, int(self.updates == 1), be.stream()), "vdk_sgd_step")
         eng.refresh_weights(skip_wb16=True)
         return self.loss_rows
+
+
+    def loss_scale(self) -> float:
+        return float(self.loss_state[0].item()) if self.amp else 1.0
+
+    def skipped_steps(self) -> int:
+        return int(self.loss_state[2].item()) if self.amp else 0
+
+    def scaler_state_dict(self) -> dict:
+        """`scaler.state_dict()` as the reference checkpoints it (engine/vision_engine.py:296,397); {} without a scaler (bf16 operands), like a disabled GradScaler"""
+        if not self.amp:
+            return {}
+        st = self.loss_state.tolist()
+        return {"scale": st[0], "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor, "growth_interval": self.growth_interval,
+                "_growth_tracker": int(st[1])}
+
+    def load_scaler_state_dict(self, sd: dict) -> None:
+        if not sd or not self.amp:
+            return
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(sd["growth_factor"]), float(sd["backoff_factor"]), int(sd["growth_interval"])
+        self.loss_state[0] = float(sd["scale"]); self.loss_state[1] = float(sd.get("_growth_tracker", 0))
 
 
 ClassifierTrainStep = ResNetTrainStep      # engine-agnostic: needs forward(x, training) -> logits f32 [B, cp], backward(dlogits bf16), flat params / grads / wb16

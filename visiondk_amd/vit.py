@@ -709,6 +709,21 @@ class FusedTrainStep:
         """steps whose scaled gradient overflowed and were skipped (GradScaler's found_inf path)"""
         return int(self.loss_state[2].item()) if self.amp else 0
 
+    def scaler_state_dict(self) -> dict:
+        """`scaler.state_dict()` with torch.cuda.amp.GradScaler's keys -- what the reference checkpoints and restores (engine/vision_engine.py:296,397), so a resumed fp16
+        run continues at the scale it had reached instead of re-discovering it through skipped steps; {} on bf16 operands (a disabled GradScaler's state_dict)."""
+        if not self.amp:
+            return {}
+        st = self.loss_state.tolist()
+        return {"scale": st[0], "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor, "growth_interval": self.growth_interval,
+                "_growth_tracker": int(st[1])}
+
+    def load_scaler_state_dict(self, sd: dict) -> None:
+        if not sd or not self.amp:
+            return
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(sd["growth_factor"]), float(sd["backoff_factor"]), int(sd["growth_interval"])
+        self.loss_state[0] = float(sd["scale"]); self.loss_state[1] = float(sd.get("_growth_tracker", 0))
+
     def loss_value(self) -> float:
         """mean loss of the last step (this is the only device->host sync; the reference does it every step, train.py:122)."""
         return float(self._loss_rows.mean().item())
