@@ -405,3 +405,26 @@ def test_gemm_col_scale_before_bias_and_residual(be, dev, kern, dtype):
         be.lib.vdk_gemm_force_kernel(0)
     with pytest.raises(Exception):      # 16-bit outputs / activations / split-K do not take it
         ops.gemm_nt(a, b, bias=bias, col_scale=cs, backend=be)
+
+
+def test_gemm_fp16_row_blocks_for_tensors_beyond_32_bit_offsets(be, dev, monkeypatch):
+    """fp16 problems whose output / residual / aux rows would exceed the four-wave kernels' 32-bit buffer offsets (the margin head at C = 10^6: [512, 10^6] fp32) run as row
+    blocks; the limit is lowered here so that small problems take the path.  NT with bias + residual, NT with GELU + aux, TN (weight-gradient form): bit-equal to one launch."""
+    torch.manual_seed(13)
+    M, N, K = 1100, 520, 128
+    a = torch.randn(M, K).half().to(dev); b = (torch.randn(N, K) * 0.3).half().to(dev)
+    bias = torch.randn(N).to(dev); res = torch.randn(M, N).to(dev)
+    at = torch.randn(K * 2, 776).half().to(dev); bt = torch.randn(K * 2, N).half().to(dev)
+    def run():
+        o1 = ops.gemm_nt(a, b, out_dtype=torch.float32, bias=bias, residual=res, backend=be)
+        aux = torch.empty(M, N, dtype=torch.float16, device=dev)
+        o2 = ops.gemm_nt(a, b, bias=bias, act=ops.ACT_GELU, aux=aux, backend=be)
+        o3 = ops.gemm_nt(at, bt, out_dtype=torch.float32, trans=True, backend=be)
+        return o1, o2, aux, o3
+    whole = run()
+    monkeypatch.setenv("VDK_GEMM_ROWBLOCK_LIMIT", str((256 + 256) * N * 4 + 1024))      # fp32 rows of N: blocks of 256 rows
+    parts = run()
+    for w, q in zip(whole, parts):
+        assert torch.equal(w, q)
+    ref = at.float().T @ bt.float()
+    assert _rel(parts[3], ref) < 1e-5

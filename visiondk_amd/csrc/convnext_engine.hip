@@ -221,6 +221,7 @@ void cn_plan(const CnDims& d, WsPlan* w) {
     if (c2 > cs) cs = c2;
     if (c1 > cs) cs = c1;
     { const size_t c3 = (size_t)2 * ((rows + 255) / 256) * out * 4; if (c3 > cs) cs = c3; }   // a_colsum / c_colsum by-products of the dgrad GEMMs
+    { const size_t c4 = (size_t)1024 * out * 4; if (c4 > cs) cs = c4; }                         // vdk_colsum_f32_deferred: at most 1024 row splits (fp16 operands: bias gradients from the fp32 stream)
     if (rows % 64) { const size_t t = (size_t)(out > in ? out : in) * up(rows, 64) * 2; if (t > tr) tr = t; }
   };
   wg(d.C[0], d.Kst, d.R[0]);
@@ -501,9 +502,15 @@ int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout_, const
         const bool tn = (R % 64) == 0 && b.dw_b == b.dw_w + (int64_t)C * 49;
         if (tn) {
           RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + bw.g), R, C, M, dw2p, nullptr));
-          RC(vdk_colsum_bf16_deferred(dxb, C, R, C, db2p, base + w.csws2, w.csws_bytes, s, &jobs[nj], nullptr, t_opf)); ++nj;
+          // fc2' bias gradient = column sums of the block-output gradient.  The neck's BatchNorm makes those sums cancel (sum over rows of a BatchNorm input gradient
+          // is zero; LayerNorm2d only perturbs that): |sum| ~ 0.03 x the l2 of the column, so summing the 16-bit COPY costs 30 x its rounding (5.6e-3 in fp16, 4e-2 in
+          // bf16 on stages.3's last block).  fp16 operands sum the fp32 stream dxa instead; bf16 keeps rounds 1-4's arithmetic.
+          if (t_opf) RC(vdk_colsum_f32_deferred(dxa, C, R, C, db2p, base + w.csws2, w.csws_bytes, s, &jobs[nj]));
+          else RC(vdk_colsum_bf16_deferred(dxb, C, R, C, db2p, base + w.csws2, w.csws_bytes, s, &jobs[nj], nullptr, t_opf));
+          ++nj;
         } else {
-          RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + bw.g), R, C, M, dw2p, db2p));        // db2p by vdk_colsum_bf16 / the transposes' by-product inside
+          RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + bw.g), R, C, M, dw2p, t_opf ? nullptr : db2p));        // db2p by vdk_colsum_bf16 / the transposes' by-product inside
+          if (t_opf) RC(vdk_colsum_f32(dxa, C, R, C, db2p, base + w.csws2, w.csws_bytes, s));
         }
         RC(gemm(s, du, M, xb + bx.fc1t, M, dh, C, R, C, M, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0));
         RC(linear_wgrad(s, w, base, du, (const bf16_t*)(base + bw.h), R, M, C, grads + b.fc1_w, nullptr));
@@ -526,7 +533,8 @@ int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout_, const
         RC(vdk_layerscale_grad(dw2p, db2p, params + b.fc2_w, params + b.fc2_b, params + b.gamma, grads + b.fc2_w, grads + b.fc2_b, grads + b.gamma, C, M, s));
       } else {
       RC(dgrad_with_bias(s, w, base, dxb, xb + bx.fc2pt, du, R, M, C, VDK_ACT_DGELU, base + bw.u, db2p, &fz));
-      RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + bw.g), R, C, M, dw2p, fz ? nullptr : db2p));
+      RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + bw.g), R, C, M, dw2p, (fz || t_opf) ? nullptr : db2p));
+      if (t_opf) RC(vdk_colsum_f32(dxa, C, R, C, db2p, base + w.csws2, w.csws_bytes, s));
       RC(vdk_layerscale_grad(dw2p, db2p, params + b.fc2_w, params + b.fc2_b, params + b.gamma, grads + b.fc2_w, grads + b.fc2_b, grads + b.gamma, C, M, s));
       RC(dgrad_with_bias(s, w, base, du, xb + bx.fc1t, dh, R, C, M, VDK_ACT_NONE, nullptr, grads + b.fc1_b, &fz));
       RC(linear_wgrad(s, w, base, du, (const bf16_t*)(base + bw.h), R, M, C, grads + b.fc1_w, fz ? nullptr : grads + b.fc1_b));
@@ -546,7 +554,8 @@ int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout_, const
       // dxa / dxb = dL/d(downsample conv output) [R, C]
       const int Rp = d.R[i - 1], Ci = d.C[i - 1];
       float* dwdsp = (float*)(base + w.dwdsp);
-      RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + w.ds_A[i]), R, C, 4 * Ci, dwdsp, grads + p.st[i].ds_b));
+      RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + w.ds_A[i]), R, C, 4 * Ci, dwdsp, t_opf ? nullptr : grads + p.st[i].ds_b));
+      if (t_opf) RC(vdk_colsum_f32(dxa, C, R, C, grads + p.st[i].ds_b, base + w.csws2, w.csws_bytes, s));      // the downsample conv's bias gradient from the fp32 stream (see the blocks)
       RC(vdk_conv2x2_wgrad_unpermute(dwdsp, grads + p.st[i].ds_w, C, Ci, s));
       RC(gemm(s, dxb, C, xb + xl.dswt[i], C, base + w.dA, 4 * Ci, R, 4 * Ci, C, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0));      // (VDK_BF16 = "the operand format")
       RC(vdk_space_to_depth2_bf16(base + w.dA, base + w.dhds, d.B, d.H[i - 1], d.H[i - 1], Ci, 1, s));

@@ -831,6 +831,34 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: empty problem");
   if ((d->K & 7) || (d->N & 7) || (!d->conv && (d->lda & 7)) || (d->ldb & 7) || (d->ldc & 7))
     return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: K, N, lda, ldb, ldc must be multiples of 8");
+  // fp16 operands run on the four-wave kernels only, whose rows leave (and arrive) through 32-bit buffer offsets: an output, residual, aux or NT-A tensor of 2 GB or more
+  // (the margin head at C = 10^6: cos and dW^ are [512, 10^6] fp32) is computed in ROW BLOCKS that fit -- the same kernels on sub-problems, every output element from the same
+  // k-order, so the result does not depend on the split.
+  if (d->ab_dtype == VDK_F16 && !d->conv && d->splitk <= 1 && d->splitk != -1 && d->row_group == 0 && !d->a_colsum && !d->c_colsum && d->a_row_group == 0) {
+    double lim = 2147483648.0 - 65536.0;
+    if (const char* e = getenv("VDK_GEMM_ROWBLOCK_LIMIT")) { const double v = atof(e); if (v > 0) lim = v; }      // tests: exercise the row-block path on small problems
+    double rowb = (double)d->ldc * (d->c_dtype == VDK_F32 ? 4.0 : 2.0);
+    if (d->aux && (double)d->ldaux * 2.0 > rowb) rowb = (double)d->ldaux * 2.0;
+    if (d->residual && (double)d->ldr * 4.0 > rowb) rowb = (double)d->ldr * 4.0;
+    if (!d->trans && (double)d->lda * 2.0 > rowb) rowb = (double)d->lda * 2.0;
+    if (((double)d->M + 256.0) * rowb >= lim) {
+      long mb = (long)(lim / rowb) - 256;
+      mb = mb / 256 * 256;
+      if (mb >= 256) {
+        for (long m0 = 0; m0 < d->M; m0 += mb) {
+          GemmDesc sub = *d;
+          sub.M = (int32_t)((d->M - m0) < mb ? (d->M - m0) : mb);
+          sub.A = d->trans ? (const void*)((const bf16_t*)d->A + m0) : (const void*)((const bf16_t*)d->A + m0 * d->lda);
+          sub.C = d->c_dtype == VDK_F32 ? (void*)((float*)d->C + m0 * d->ldc) : (void*)((bf16_t*)d->C + m0 * d->ldc);
+          if (d->residual) sub.residual = d->residual + m0 * d->ldr;
+          if (d->aux) sub.aux = (void*)((bf16_t*)d->aux + m0 * d->ldaux);
+          const int rc = vdk_gemm_bf16_nt(&sub, ws, ws_bytes, stream_);
+          if (rc) return rc;
+        }
+        return VDK_OK;
+      }
+    }
+  }
   if (d->conv) {
     const VdkConvGeom* c = d->conv;
     if (d->trans || c->Cin <= 0 || (c->Cin & 7) || c->KH <= 0 || c->KW <= 0 || c->stride <= 0 || c->pad < 0 || c->OH <= 0 || c->OW <= 0 || c->H <= 0 || c->W <= 0 ||

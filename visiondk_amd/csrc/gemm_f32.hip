@@ -195,6 +195,33 @@ __global__ __launch_bounds__(256) void colsum_f32_partial_kernel(const float* __
   __syncthreads();
   if (sub == 0 && n < N) part[(long)blockIdx.y * N + n] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
+// The same for wide, tall tensors streamed at HBM rate (the ConvNeXt engine's fc2 / downsample bias gradients from the fp32 residual-stream gradient, 100 k rows x 512):
+// a workgroup = 32 column quads (16-byte loads, 128 columns) x 8 row groups, four loads in flight per thread.  N % 4 == 0, ld % 4 == 0, x 16-byte aligned.
+__global__ __launch_bounds__(256) void colsum_f32_partial4_kernel(const float* __restrict__ x, long ld, long T, int N, long rows_per_split, float* __restrict__ part) {
+  __shared__ float red[8][132];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int n = blockIdx.x * 128 + tx * 4;
+  const long r0 = (long)blockIdx.y * rows_per_split;
+  long r1 = r0 + rows_per_split; if (r1 > T) r1 = T;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  if (n < N) {
+    long r = r0 + ty;
+    for (; r + 24 < r1; r += 32) {
+      const f32x4 v0 = *(const f32x4*)(x + r * ld + n), v1 = *(const f32x4*)(x + (r + 8) * ld + n), v2 = *(const f32x4*)(x + (r + 16) * ld + n), v3 = *(const f32x4*)(x + (r + 24) * ld + n);
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; r < r1; r += 8) a0 += *(const f32x4*)(x + r * ld + n);
+  }
+  const f32x4 a = (a0 + a1) + (a2 + a3);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[ty][tx * 4 + e] = a[e];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int c = threadIdx.x;
+    if (blockIdx.x * 128 + c < N)
+      part[(long)blockIdx.y * N + blockIdx.x * 128 + c] = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) + ((red[4][c] + red[5][c]) + (red[6][c] + red[7][c]));
+  }
+}
 // inverse of s2d2_f32_kernel: in[(b, y/2, x/2)][c*4 + 2*(y&1) + (x&1)] -> out[(b, y, x)][c]
 __global__ __launch_bounds__(256) void d2s2_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C) {
   const long n = (long)B * H * W * C;
@@ -206,6 +233,7 @@ __global__ __launch_bounds__(256) void d2s2_f32_kernel(const float* __restrict__
   out[id] = in[((((long)b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * C + c) * 4 + (y & 1) * 2 + (x & 1)];
 }
 
+int vdk_colsum_f32_deferred(const float* x, int64_t ld, int64_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job);
 extern "C" {
 
 int vdk_gelu_f32(const float* u, float* g, int64_t n, void* stream) {
@@ -229,19 +257,37 @@ int vdk_rowscale_f32(const float* in, const float* scale, float* out, int64_t ro
 static int colsum_f32_splits(long T) { long s = (T + 2047) / 2048; if (s > 1024) s = 1024; if (s < 1) s = 1; return (int)s; }
 int vdk_colsum_f32_workspace_bytes(int64_t T, int32_t N, size_t* bytes) {
   if (!bytes || T <= 0 || N <= 0) return vdk_fail(VDK_EINVAL, "vdk_colsum_f32_workspace_bytes: bad argument");
-  *bytes = (size_t)colsum_f32_splits(T) * N * 4;
+  *bytes = (size_t)(T >= 4096 ? 1024 : colsum_f32_splits(T)) * N * 4;      // (the wide form takes up to 1024 row splits)
   return VDK_OK;
 }
 int vdk_reduce_rows_f32(const float*, int64_t, int32_t, int64_t, float*, float, void*);
 /* out[n] = sum over the T rows of x[T, ld] (bias gradients of the fp32 training path); deterministic two-stage sum */
 int vdk_colsum_f32(const float* x, int64_t ld, int64_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream) {
-  if (!x || !out || T <= 0 || N <= 0 || ld < N) return vdk_fail(VDK_EINVAL, "vdk_colsum_f32: bad argument");
-  const int S = colsum_f32_splits(T);
+  VdkReduceJob job;
+  const int rc = vdk_colsum_f32_deferred(x, ld, T, N, out, ws, ws_bytes, stream, &job);
+  if (rc) return rc;
+  return vdk_reduce_rows_f32(job.in, job.ld, job.S, job.n, job.out, job.scale, stream);
+}
+}  // extern "C"
+// vdk_colsum_f32 whose final reduction over the row splits is left to the caller (*job describes it; in-library, see vdk_host.h)
+int vdk_colsum_f32_deferred(const float* x, int64_t ld, int64_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job) {
+  if (!x || !out || !job || T <= 0 || N <= 0 || ld < N) return vdk_fail(VDK_EINVAL, "vdk_colsum_f32: bad argument");
+  int S = colsum_f32_splits(T);
+  const bool wide = (N % 4 == 0) && (ld % 4 == 0) && (((size_t)x & 15) == 0) && T >= 4096;
+  if (wide) {        // about 1024 workgroups, at least 64 rows each (as vdk_colsum_bf16's split rule)
+    const int bx = (N + 127) / 128;
+    long target = 1024 / bx; if (target < 128) target = 128;
+    long s2 = (T + 63) / 64; if (s2 > target) s2 = target; if (s2 > 1024) s2 = 1024;
+    S = (int)s2;
+  }
   if (!ws || ws_bytes < (size_t)S * N * 4) return vdk_fail(VDK_EWORKSPACE, "vdk_colsum_f32: workspace too small");
   const long rps = (T + S - 1) / S;
-  hipLaunchKernelGGL(colsum_f32_partial_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)S), dim3(256), 0, (hipStream_t)stream, x, (long)ld, (long)T, (int)N, rps, (float*)ws);
-  return vdk_reduce_rows_f32((const float*)ws, N, S, N, out, 1.0f, stream);
+  if (wide) hipLaunchKernelGGL(colsum_f32_partial4_kernel, dim3((unsigned)((N + 127) / 128), (unsigned)S), dim3(256), 0, (hipStream_t)stream, x, (long)ld, (long)T, (int)N, rps, (float*)ws);
+  else hipLaunchKernelGGL(colsum_f32_partial_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)S), dim3(256), 0, (hipStream_t)stream, x, (long)ld, (long)T, (int)N, rps, (float*)ws);
+  *job = VdkReduceJob{(float*)ws, (long)N, S, (long)N, out, 1.0f};
+  return vdk_check_launch("vdk_colsum_f32");
 }
+extern "C" {
 int vdk_depth_to_space2_f32(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
   if (!in || !out || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0) return vdk_fail(VDK_EINVAL, "vdk_depth_to_space2_f32: bad argument");
   const long n = (long)B * H * W * C;

@@ -54,3 +54,5 @@ extern "C" int vdk_dwconv7_fwd_16(const float* in, const float* wt, const float*
                                   int32_t flip, int32_t opf, void* stream);
 extern "C" int vdk_avgpool_rows_f32_bwd_16(const float* dpool, float* dmap, void* dmap16, int32_t B, int32_t HW, int32_t C, int32_t opf, void* stream);
 extern "C" int vdk_conv2x2_weight_prep_16(const float* w, void* wb, void* wtb, int32_t Co, int32_t Ci, int32_t opf, void* stream);
+// vdk_colsum_f32 (csrc/gemm_f32.hip) with the reduction over its row splits left to the caller's vdk_reduce_rows_batch
+int vdk_colsum_f32_deferred(const float* x, int64_t ld, int64_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job);
