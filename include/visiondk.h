@@ -138,6 +138,10 @@ typedef struct VdkGemmDesc {
   const float* col_scale;  /* NULL, or f32 [N]: the accumulator of column n is multiplied by col_scale[n] BEFORE bias / residual -- C = residual + (acc * col_scale + bias).
                               ConvNeXt's layer scale (x + gamma * fc2(g), timm ConvNeXtBlock behind models/faceX/backbone/timm_wrapper.py:16-21) in the fc2 epilogue when the
                               operands are fp16: gamma (1e-6 at timm's init) folded into an fp16 weight would underflow.  fp32 outputs with a bias only (act NONE, no split-K). */
+  const float* row_scale;  /* NULL, or f32 [ceil(M / rows_per_scale)]: C = residual + row_scale[m / rows_per_scale] * (acc + bias) -- stochastic depth (timm DropPath: the branch of
+                              sample b is multiplied by mask_b / keep_prob before the shortcut is added; timm's Swin builds with drop_path_rate = 0.1 behind
+                              models/classifier/classify_model.py:49-54) in the proj / fc2 epilogues, one factor per sample.  Same restrictions as col_scale, and a residual. */
+  int32_t rows_per_scale;  /* rows of C that share one row_scale entry (tokens per image) */
 } VdkGemmDesc;
 int vdk_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t splitk, size_t* bytes);
 int vdk_gemm_streamk_workspace_bytes(size_t* bytes);
@@ -583,6 +587,11 @@ typedef struct VdkSwinConfig {
   int32_t num_classes;
   float ln_eps;
   int32_t operand;        /* VDK_BF16 | VDK_F16: format of the GEMM / attention operands and of the saved 16-bit activations (fp16 = the reference's autocast dtype, train.py:118) */
+  const float* drop_path; /* NULL (evaluation, or drop_path_rate = 0), or DEVICE f32 [2 * sum(depths)][batch]: stochastic depth.  timm builds swin_* with drop_path_rate = 0.1 when the
+                           * reference calls timm.create_model(name, ...) (models/classifier/classify_model.py:49-54; rates linspace(0, 0.1, sum(depths)) over the blocks): in
+                           * training every block's two branches are multiplied per SAMPLE by mask / keep_prob before the shortcut is added.  Row 2 * k is block k's attention
+                           * branch, row 2 * k + 1 its MLP branch; entry [b] = 0 or 1 / keep_prob, drawn by the caller per step; forward and the backward of that forward get the
+                           * same buffer.  The proj / fc2 epilogues apply it (VdkGemmDesc.row_scale), the backward scales the 16-bit gradient copies the branch GEMMs read. */
 } VdkSwinConfig;
 int vdk_swin_param_count(const VdkSwinConfig* cfg, int64_t* n_floats, int32_t* n_tensors, int64_t* n_transposed);
 int vdk_swin_param_info(const VdkSwinConfig* cfg, int32_t index, char* name, int32_t name_cap, int64_t* offset, int64_t* numel, int64_t* shape4, int32_t* ndim);
@@ -590,7 +599,10 @@ int vdk_swin_workspace_bytes(const VdkSwinConfig* cfg, size_t* bytes);
 int vdk_swin_refresh_weights(const VdkSwinConfig* cfg, const float* params, void* wb16, void* wt16, int32_t skip_wb16, void* stream);
 /* x f32 [B, in_chans, img, img] -> out f32: logits [B, up(num_classes, 8)] or the feature rows (see above); activations stay in ws */
 int vdk_swin_forward(const VdkSwinConfig* cfg, const float* x, const float* params, const void* wb16, void* ws, size_t ws_bytes, float* out, void* stream);
-/* dout: dlogits bf16 [B, up(num_classes, 8)] (padding columns zero), or f32 feature-row gradients -> grads (flat fp32, overwritten); on_ready as in vdk_vit_backward */
+/* dout: dlogits bf16 [B, up(num_classes, 8)] (padding columns zero), or f32 feature-row gradients -> grads (flat fp32, overwritten); on_ready as in vdk_vit_backward.
+ * `grads` must be ZERO-INITIALISED ONCE by its owner: every tensor's gradient is overwritten by each call, but the alignment gaps of the flat layout (tensors start at multiples
+ * of 64 floats: the 96 / 192-wide vectors and the 169 x heads tables leave some) are never written, and vdk_sumsq_f32 (the clip norm), vdk_allreduce_bucket and the fp16
+ * overflow check all run over the whole n_floats. */
 int vdk_swin_backward(const VdkSwinConfig* cfg, const void* dout, const float* params, const void* wb16, const void* wt16, void* ws, size_t ws_bytes, float* grads,
                       vdk_grad_ready_fn on_ready, void* user, void* stream);
 

@@ -105,6 +105,9 @@ class SwinBlock(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = Mlp(dim)
         self.register_buffer("attn_mask", shifted_window_mask(res, res, ws, shift) if shift > 0 else None, persistent=False)
+        # timm DropPath (stochastic depth) on both branches: per-sample factors mask / keep_prob, handed in by the test so that oracle and engine drop the same samples
+        # (timm: `x = x + self.drop_path1(attn branch); x = x + self.drop_path2(mlp branch)`; drop_path(x) = x * bernoulli(keep_prob) / keep_prob per sample, training only)
+        self.drop = None                       # None, or (f1 [B], f2 [B])
 
     def forward(self, x):                      # [B, H, W, C]
         B, H, W, C = x.shape
@@ -116,8 +119,12 @@ class SwinBlock(nn.Module):
         h = window_reverse(w.view(-1, self.ws, self.ws, C), self.ws, H, W)
         if self.shift:
             h = torch.roll(h, (self.shift, self.shift), (1, 2))
-        x = x + h
-        return x + self.mlp(self.norm2(x))
+        if self.drop is None:
+            x = x + h
+            return x + self.mlp(self.norm2(x))
+        f1, f2 = self.drop
+        x = x + h * f1.view(B, 1, 1, 1)
+        return x + self.mlp(self.norm2(x)) * f2.view(B, 1, 1, 1)
 
 
 class PatchMerging(nn.Module):
@@ -180,6 +187,14 @@ class SwinTransformerRef(nn.Module):
         self.norm = nn.LayerNorm(dim_in)
         self.head = _Head(dim_in, num_classes)
         self.num_features = dim_in
+
+    def set_drop_path(self, factors):
+        """factors [2 * blocks, B] (row 2 k: block k's attention branch, 2 k + 1: its MLP branch; entries 0 or 1 / keep_prob), or None to switch stochastic depth off"""
+        k = 0
+        for stage in self.layers:
+            for blk in stage.blocks:
+                blk.drop = None if factors is None else (factors[2 * k], factors[2 * k + 1])
+                k += 1
 
     def forward_features(self, x):
         return self.norm(self.layers(self.patch_embed(x)))        # [B, H/32, W/32, C]

@@ -111,7 +111,7 @@ def test_get_model_routes_the_default_backbone_of_pet_yaml(be, dev):
 def test_swin_base_full_size_forward_backward_vs_oracle(hip):
     """swin_base_patch4_window7_224 (depths 2-2-18-2, 87 M parameters), 2 images, 37 classes: logits, loss and every parameter gradient against the fp32 oracle"""
     torch.manual_seed(0)
-    model = swin.create_model("swin_base_patch4_window7_224", num_classes=37, device="cuda:0", backend=hip)
+    model = swin.create_model("swin_base_patch4_window7_224", num_classes=37, device="cuda:0", backend=hip, drop_path_rate=0.0)
     ref = SwinTransformerRef(num_classes=37)
     with torch.no_grad():
         for n, p in ref.named_parameters():
@@ -395,7 +395,7 @@ def test_swin_base_full_size_fp16_meets_the_stated_tolerance(hip):
     """swin_base_patch4_window7_224 on fp16 operands, 2 images, 37 classes, every parameter gradient against the fp32 oracle: north_star's bar, asserted literally --
     logits <= 1e-3, every gradient <= 5e-3"""
     torch.manual_seed(0)
-    model = swin.create_model("swin_base_patch4_window7_224", num_classes=37, device="cuda:0", backend=hip, operand="fp16")
+    model = swin.create_model("swin_base_patch4_window7_224", num_classes=37, device="cuda:0", backend=hip, operand="fp16", drop_path_rate=0.0)
     ref = SwinTransformerRef(num_classes=37)
     with torch.no_grad():
         for n, p in ref.named_parameters():
@@ -421,7 +421,7 @@ def test_swin_family_full_size_fp16_meets_the_stated_tolerance(hip, name):
     from visiondk_amd import vit
     torch.manual_seed(0)
     cfg = swin.TIMM_SWINS[name]
-    model = swin.create_model(name, num_classes=37, device="cuda:0", backend=hip, operand="fp16")
+    model = swin.create_model(name, num_classes=37, device="cuda:0", backend=hip, operand="fp16", drop_path_rate=0.0)
     ref = SwinTransformerRef(num_classes=37, embed_dim=cfg["embed_dim"], depths=cfg["depths"], heads=cfg["heads"])
     model.load_state_dict(ref.state_dict(), strict=True)
     x = torch.randn(2, 3, 224, 224); t = torch.randint(0, 37, (2,))
@@ -448,3 +448,79 @@ def test_face_train_step_rejects_fp16_operand_engines(be, dev):
     m.trainingwrapper["backbone"].model.engine.set_operand("fp16")
     with pytest.raises(NotImplementedError):
         face.FaceTrainStep(m, lr=0.01, momentum=0.9, weight_decay=5e-4)
+
+
+@pytest.mark.parametrize("depths,heads,ncls,operand", [((2, 2), (1, 2), 6, "bf16"), ((1, 2, 1, 1), (1, 2, 4, 8), 0, "fp16")])
+def test_stochastic_depth_matches_timm_drop_path(be, dev, depths, heads, ncls, operand):
+    """timm builds swin_* with drop_path_rate = 0.1: in train mode both branches of block k are multiplied per sample by Bernoulli(keep_k) / keep_k before the shortcut is
+    added (keep_k = 1 - 0.1 k / (n - 1)).  The engine applies the factors in the proj / fc2 epilogues (VdkGemmDesc.row_scale) and, in the backward, to the 16-bit gradient
+    copies the branch GEMMs read.  With the SAME factors handed to the oracle (oracle/swin_ref.py: set_drop_path) the map / logits and every gradient agree as they do without
+    stochastic depth; eval mode never drops; the factors drawn by the engine itself have timm's distribution."""
+    spec = swin.SwinSpec(img_size=224, num_classes=ncls, embed_dim=32, depths=depths, heads=heads)
+    model = swin.SwinTransformer(spec, device=dev, backend=be, seed=3, operand=operand, drop_path_rate=0.5)      # a high rate: several samples really drop in a 4-sample batch
+    ref = SwinTransformerRef(img_size=224, num_classes=ncls, embed_dim=32, depths=depths, heads=heads)
+    torch.manual_seed(7)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "relative_position_bias_table" in n:
+                p.copy_(torch.randn_like(p) * 0.3)
+            elif p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+            else:
+                p.copy_(torch.randn_like(p) * (0.7 / (p[0].numel() ** 0.5)))
+    model.load_state_dict(ref.state_dict(), strict=True)
+    B, nb = 4, sum(depths)
+    eng = model.engine
+    torch.manual_seed(11)
+    fac = eng.draw_drop_path(B)
+    assert tuple(fac.shape) == (2 * nb, B)
+    keep = 1.0 - torch.linspace(0, 0.5, nb).repeat_interleave(2)
+    for r in range(2 * nb):      # every entry is 0 or 1 / keep_prob of its block; block 0 never drops
+        assert all(abs(v) < 1e-7 or abs(v - 1.0 / keep[r].item()) < 1e-6 for v in fac[r].tolist())
+    assert torch.all(fac[:2] == 1.0)
+    fac[3, 1] = 0.0; fac[2, 0] = 0.0                       # make sure both kinds of branch drop at least once
+    x = torch.randn(B, 3, 224, 224)
+    ref.train(); ref.set_drop_path(fac.cpu())
+    yr = ref(x)
+    out = eng.forward(x.to(dev), training=True, drop_path=fac)
+    if ncls:
+        y = out[:, :ncls]
+        tol_f, tol_g = (2e-2, 6e-2) if operand == "bf16" else (3e-3, 1e-2)
+    else:
+        y = out.view(B, 7, 7, -1)
+        tol_f, tol_g = (2e-2, 6e-2) if operand == "bf16" else (3e-3, 1e-2)
+    assert _rel(y.cpu(), yr.detach()) < tol_f, _rel(y.cpu(), yr.detach())
+    d = torch.randn_like(yr)
+    yr.backward(d)
+    if ncls:
+        dl = torch.zeros((B, eng.cp), dtype=eng.op_dtype, device=dev)
+        dl[:, :ncls] = d.to(dev).to(eng.op_dtype)
+        g = eng.backward(dl)
+    else:
+        g = eng.backward(d.to(dev).contiguous().view(-1, eng.features))
+    exp = dict(ref.named_parameters())
+    for name, off, numel, shape in eng.entries:
+        r = _rel(g[off:off + numel].view(shape).cpu(), exp[name].grad)
+        assert r < tol_g, (name, r)
+    # the same forward without the factors differs (the drop really happened), and evaluation never drops
+    ref.set_drop_path(None)
+    assert _rel(y.cpu(), ref(x).detach()) > 5e-2
+    model.eval()
+    ye = model(x.to(dev))
+    ref.eval()
+    assert _rel(ye.detach().cpu(), ref(x).detach()) < tol_f
+    # model(x) in train() mode draws its own factors from torch's generator: reproducible under manual_seed, different across calls
+    model.train()
+    torch.manual_seed(5); a = model(x.to(dev)).detach().clone()
+    torch.manual_seed(5); b = model(x.to(dev)).detach().clone()
+    c = model(x.to(dev)).detach()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def test_create_model_has_timms_drop_path_default_and_refuses_unknown_kwargs(be, dev, monkeypatch):
+    monkeypatch.setitem(swin.TIMM_SWINS, "swin_test_patch4_window7_224", dict(embed_dim=32, depths=(1, 1), heads=(1, 2)))
+    m = swin.create_model("swin_test_patch4_window7_224", num_classes=3, device=dev, backend=be)
+    assert m.engine.drop_path_rate == 0.1                      # timm's default for the family, what timm.create_model(name, **{}) builds (classify_model.py:49-54)
+    assert swin.create_model("swin_test_patch4_window7_224", num_classes=3, device=dev, backend=be, drop_path_rate=0.0).engine.draw_drop_path(4) is None
+    with pytest.raises(TypeError):
+        swin.create_model("swin_test_patch4_window7_224", num_classes=3, device=dev, backend=be, attn_drop_rate=0.1)

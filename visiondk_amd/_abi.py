@@ -21,7 +21,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("A", P), ("lda", I64), ("B", P), ("ldb", I64), ("C", P), ("ldc", I64),
                 ("M", I32), ("N", I32), ("K", I32), ("c_dtype", I32),
                 ("bias", P), ("residual", P), ("ldr", I64), ("act", I32), ("aux", P), ("ldaux", I64),
-                ("alpha", F32), ("splitk", I32), ("row_group", I32), ("trans", I32), ("a_row_group", I32), ("conv", P), ("a_colsum", P), ("c_colsum", P), ("ab_dtype", I32), ("col_scale", P)]
+                ("alpha", F32), ("splitk", I32), ("row_group", I32), ("trans", I32), ("a_row_group", I32), ("conv", P), ("a_colsum", P), ("c_colsum", P), ("ab_dtype", I32), ("col_scale", P), ("row_scale", P), ("rows_per_scale", I32)]
 
 
 class ConvGeom(C.Structure):
@@ -53,7 +53,7 @@ class ResNetConfig(C.Structure):
 class SwinConfig(C.Structure):
     """VdkSwinConfig of include/visiondk.h"""
     _fields_ = [("batch", I32), ("img_size", I32), ("in_chans", I32), ("embed_dim", I32), ("depths", I32 * 4), ("heads", I32 * 4), ("num_classes", I32), ("ln_eps", C.c_float),
-                ("operand", I32)]
+                ("operand", I32), ("drop_path", P)]
 
 
 class MarginHead(C.Structure):

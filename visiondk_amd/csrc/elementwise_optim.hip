@@ -367,6 +367,27 @@ int vdk_cast_f32_16(const float* in, void* out, int64_t n, int opf, void* stream
   return vdk_check_launch("vdk_cast_f32_bf16");
 }
 
+// x16[r, c] *= rs[r / rps] in place (C % 8 == 0, 16-byte chunks): see vdk_rowscale_16 in vdk_host.h
+template <int OF>
+__global__ __launch_bounds__(256) void rowscale16_kernel(bf16_t* __restrict__ x, long T, int C, const float* __restrict__ rs, int rps) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c8 = C / 8;
+  if (i >= T * c8) return;
+  const long r = i / c8;
+  const float f = rs[r / rps];
+  u32x4 v = *(u32x4*)(x + i * 8);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = pack_op2<OF>(op_lo<OF>(v[e]) * f, op_hi<OF>(v[e]) * f);
+  *(u32x4*)(x + i * 8) = v;
+}
+int vdk_rowscale_16(void* x16, int64_t T, int32_t C, const float* rs, int32_t rps, int opf, void* stream) {
+  if (!x16 || !rs || T <= 0 || C <= 0 || (C & 7) || rps <= 0) return vdk_fail(VDK_EINVAL, "vdk_rowscale_16: bad argument (C % 8 == 0)");
+  const long n = T * (C / 8);
+  if (opf) hipLaunchKernelGGL(rowscale16_kernel<VDK_OPF_F16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x16, (long)T, (int)C, rs, (int)rps);
+  else hipLaunchKernelGGL(rowscale16_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x16, (long)T, (int)C, rs, (int)rps);
+  return vdk_check_launch("vdk_rowscale_16");
+}
+
 extern "C" {
 
 int vdk_patchify_bf16(const float* x, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t patch, void* out, int32_t Kp,

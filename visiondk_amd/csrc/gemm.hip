@@ -852,6 +852,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
           sub.C = d->c_dtype == VDK_F32 ? (void*)((float*)d->C + m0 * d->ldc) : (void*)((bf16_t*)d->C + m0 * d->ldc);
           if (d->residual) sub.residual = d->residual + m0 * d->ldr;
           if (d->aux) sub.aux = (void*)((bf16_t*)d->aux + m0 * d->ldaux);
+          if (d->row_scale) { if (m0 % d->rows_per_scale) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: row blocks do not align with rows_per_scale"); sub.row_scale = d->row_scale + m0 / d->rows_per_scale; }
           const int rc = vdk_gemm_bf16_nt(&sub, ws, ws_bytes, stream_);
           if (rc) return rc;
         }
@@ -885,6 +886,9 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   p.splitk = splitk; p.slabs = nullptr; p.sk_cnt = nullptr; p.dbg = (unsigned long long*)g_dbg_ptr;
   p.colsum_part = nullptr; p.ocs_part = nullptr;
   p.cscale = d->col_scale;
+  p.rscale = d->row_scale; p.rps = d->rows_per_scale;
+  if (d->row_scale && (d->rows_per_scale <= 0 || d->c_dtype != VDK_F32 || !d->bias || !d->residual || d->act != VDK_ACT_NONE || d->splitk > 1 || d->trans || d->row_group != 0))
+    return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: row_scale goes with rows_per_scale > 0, an fp32 output, a bias, a residual, act NONE and neither split-K, TN nor a row remap");
   if (d->col_scale && (d->c_dtype != VDK_F32 || !d->bias || d->act != VDK_ACT_NONE || d->splitk > 1 || d->trans || d->row_group != 0 || (d->N & 7)))
     return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: col_scale goes with an fp32 output, a bias, act NONE, N % 8 == 0 and neither split-K, TN nor a row remap");
   p.conv_on = d->conv != nullptr;

@@ -311,7 +311,7 @@ int vdk_gemm_fp8_nt_q8(const VdkGemmDesc* d, int32_t a_fmt, int32_t b_fmt, const
   GemmParams& p = q.g;
   p.A = nullptr; p.B = nullptr; p.C = d->C; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.M = d->M; p.N = d->N; p.K = d->K; p.c_dtype = d->c_dtype;
   p.bias = (const float*)d->bias; p.residual = (const float*)d->residual; p.ldr = d->ldr; p.act = d->act; p.aux = (bf16_t*)d->aux; p.ldaux = d->ldaux;
-  p.alpha = d->alpha; p.row_group = 0; p.row_shift = 0; p.a_row_group = 0; p.splitk = 1; p.k_per_split = d->K; p.slabs = nullptr; p.colsum_part = nullptr; p.ocs_part = (float*)d->c_colsum; p.conv_on = 0; p.dbg = nullptr; p.cscale = nullptr; p.opf = 0;
+  p.alpha = d->alpha; p.row_group = 0; p.row_shift = 0; p.a_row_group = 0; p.splitk = 1; p.k_per_split = d->K; p.slabs = nullptr; p.colsum_part = nullptr; p.ocs_part = (float*)d->c_colsum; p.conv_on = 0; p.dbg = nullptr; p.cscale = nullptr; p.rscale = nullptr; p.rps = 1; p.opf = 0;
   q.A = (const unsigned char*)d->A; q.B = (const unsigned char*)d->B; q.a_scale_inv = a_scale_inv; q.b_scale_inv = b_scale_inv;
   const bool bias = d->bias != nullptr, res = d->residual != nullptr, f32 = d->c_dtype == VDK_F32;
   int E = -1;

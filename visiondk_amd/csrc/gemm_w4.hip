@@ -478,6 +478,15 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) d[ps] = d[ps] * cs4[cp];
       }
+      if (RES && p.rscale) {      // VdkGemmDesc.row_scale (stochastic depth): residual + factor(sample of this row) * (acc + bias); rows beyond M read the last entry (never stored)
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+          int row = mrow0 + rt * 32 + ps * 4 + rrow;
+          row = row < p.M ? row : p.M - 1;
+          const float f = p.rscale[row / p.rps];
+          d[ps] = (d[ps] + bias4[cp]) * f + r[ps];
+        }
+      } else
 #pragma unroll
       for (int ps = 0; ps < 8; ++ps) d[ps] = RES ? (d[ps] + bias4[cp]) + r[ps] : d[ps] + bias4[cp];
       // (everything that touches the row registers precedes the stores; row block in the vector offset: see the bf16 form above)

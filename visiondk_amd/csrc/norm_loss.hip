@@ -139,7 +139,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      long lddres, int T, int C, int rows_per_block, float* __restrict__ dx,
                                                      long lddx, bf16_t* __restrict__ dxb, long lddxb,
                                                      float* __restrict__ pgamma, float* __restrict__ pbeta, float* __restrict__ pout, LnQ8 q8 = LnQ8(),
-                                                     const float* __restrict__ dy_scale = nullptr /* device scalar: dy is multiplied by dy_scale[0] as it is loaded (a gradient branch kept at its own power-of-two scale: ConvNeXt's layer-scale branch under fp16 operands) */) {
+                                                     const float* __restrict__ dy_scale = nullptr /* device scalar: dy is multiplied by dy_scale[0] as it is loaded (a gradient branch kept at its own power-of-two scale: ConvNeXt's layer-scale branch under fp16 operands) */,
+                                                     const float* __restrict__ dxb_rs = nullptr /* per-sample factor of the 16-bit COPY dxb only (dx stays): dxb = 16bit(dx * dxb_rs[row / dxb_rps]) -- the
+                                                     gradient entering a residual branch under stochastic depth (timm DropPath: mask_b / keep_prob), whose GEMMs read dxb */, int dxb_rps = 1) {
   static_assert(!HALF || MAXJ == 1, "HALF: one 128-column slab");
   __shared__ float red[4][MAXJ * 256];
   float q8s = 1.0f, q8lim = 448.0f, q8am = 0.f;
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
           for (int e = 0; e < 4; ++e) o[e] = rs[k] * (gk[k][j][e] - s1[k] - xh[k][j][e] * s2[k]) + rv[k][j][e];
           if (dx) *(f32x4*)(dx + (long)row * lddx + c) = (f32x4){o[0], o[1], o[2], o[3]};
           if (dxb) {
+            if (dxb_rs) { const float f = dxb_rs[row / dxb_rps]; o[0] *= f; o[1] *= f; o[2] *= f; o[3] *= f; }
             const u32x2 ob = {pack_op2<OF>(o[0], o[1]), pack_op2<OF>(o[2], o[3])};
             *(u32x2*)(dxb + (long)row * lddxb + c) = ob;
             if (OCS) { ao[j][0] += op_lo<OF>(ob[0]); ao[j][1] += op_hi<OF>(ob[0]); ao[j][2] += op_lo<OF>(ob[1]); ao[j][3] += op_hi<OF>(ob[1]); }
@@ -657,7 +660,7 @@ static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const flo
                        const float* rstd, const float* gamma, const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx,
                        int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                        void* stream_, VdkReduceJob* deferred, float* dxb_colsum = nullptr, VdkReduceJob* deferred2 = nullptr, const LnQ8* q8 = nullptr, int opf = 0,
-                       const float* dy_scale = nullptr) {
+                       const float* dy_scale = nullptr, const float* dxb_rs = nullptr, int dxb_rps = 1) {
   hipStream_t stream = (hipStream_t)stream_;
   if (dy_dtype == VDK_F16) opf = VDK_OPF_F16;          // (an fp32 dy with an fp16 dxb: opf passed by the in-library caller)
   if (dy_dtype != VDK_BF16 && dy_dtype != VDK_F32 && dy_dtype != VDK_F16) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: bad dy_dtype");
@@ -674,15 +677,15 @@ static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const flo
   const int rpb = (T + nb - 1) / nb;
   const bool bf = dy_dtype != VDK_F32;
 #define LNB(MJ, BF, OC, NR, HF) do { if (opf) hipLaunchKernelGGL((ln_bwd_kernel<MJ, BF, OC, false, VDK_OPF_F16, NR, HF>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
-                                           mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po, LnQ8(), dy_scale); \
+                                           mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po, LnQ8(), dy_scale, dxb_rs, dxb_rps); \
                              else hipLaunchKernelGGL((ln_bwd_kernel<MJ, BF, OC, false, VDK_OPF_BF16, NR, HF>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
-                                           mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po, LnQ8(), dy_scale); } while (0)
+                                           mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po, LnQ8(), dy_scale, dxb_rs, dxb_rps); } while (0)
 #define LNB2(MJ, NR, HF) do { if (ocs) { if (bf) LNB(MJ, true, true, NR, HF); else LNB(MJ, false, true, NR, HF); } \
                               else { if (bf) LNB(MJ, true, false, NR, HF); else LNB(MJ, false, false, NR, HF); } } while (0)
   // MAXJ = 3 (C <= 768, ViT-B) keeps the kernel at <= 128 VGPRs = 4 blocks per CU; the narrower rows of the Swin / ConvNeXt stages take two rows per wave and pass
   // (C <= 128: four, a row being half a wave)
   if (q8) {
-    if (!ocs || !bf || opf || dy_scale || !q8->out || (q8->ld & 3)) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: the fp8 copy needs bf16 dy, the column-sum form and ld % 4 == 0");
+    if (!ocs || !bf || opf || dy_scale || dxb_rs || !q8->out || (q8->ld & 3)) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: the fp8 copy needs bf16 dy, the column-sum form and ld % 4 == 0");
 #define LNBQ(MJ) hipLaunchKernelGGL((ln_bwd_kernel<MJ, true, true, true>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, \
                                     mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po, *q8)
     if (C <= 768) LNBQ(3); else LNBQ(4);
@@ -823,8 +826,10 @@ int vdk_bce_logits(const float* logits, int64_t ldl, const float* targets, int64
 // LayerNorm backward whose dgamma | dbeta partial-sum reduction is left to the caller: *job describes it (job->in == NULL if it was done here after all)
 int vdk_layernorm_bwd_deferred(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
                                const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx, int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta,
-                               void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job, float* dxb_colsum, VdkReduceJob* job2, const LnQ8* dxb_q8, int opf, const float* dy_scale) {
-  return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, mean, rstd, gamma, dres, lddres, T, C, dx, lddx, dxb, lddxb, dgamma, dbeta, ws, ws_bytes, stream, job, dxb_colsum, job2, dxb_q8, opf, dy_scale);
+                               void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job, float* dxb_colsum, VdkReduceJob* job2, const LnQ8* dxb_q8, int opf, const float* dy_scale, const float* dxb_rs, int dxb_rps) {
+  if (dxb_rs && (!dxb || dxb_rps <= 0)) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: dxb_rs needs dxb and dxb_rps > 0");
+  return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, mean, rstd, gamma, dres, lddres, T, C, dx, lddx, dxb, lddxb, dgamma, dbeta, ws, ws_bytes, stream, job, dxb_colsum, job2, dxb_q8, opf, dy_scale,
+                     dxb_rs, dxb_rps);
 }
 // vdk_colsum_bf16 whose final reduction over the row splits is left to the caller (*job describes it)
 int vdk_colsum_bf16_deferred(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream_, VdkReduceJob* job, const LnQ8* q8, int opf) {

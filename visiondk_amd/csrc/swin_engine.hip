@@ -63,6 +63,7 @@ struct SwDims {
   int C, Cp, Bp, Kpe;      // classes (0: feature mode), padded to 8; batch padded to 64; K of the patch-embedding GEMM (in_chans * 16)
   float eps;
   int opf;                 // VDK_OPF_BF16 | VDK_OPF_F16
+  const float* dp;         // VdkSwinConfig.drop_path: f32 [2 * nblk][B] per-sample branch factors (stochastic depth), or nullptr
 };
 int sw_dims(const VdkSwinConfig* c, SwDims* d) {
   if (!c) return vdk_fail(VDK_EINVAL, "swin: null config");
@@ -71,6 +72,7 @@ int sw_dims(const VdkSwinConfig* c, SwDims* d) {
   if ((c->in_chans * 16) & 7) return vdk_fail(VDK_EUNSUPPORTED, "swin: in_chans * 16 must be a multiple of 8");
   if (c->operand != VDK_BF16 && c->operand != VDK_F16) return vdk_fail(VDK_EINVAL, "swin: operand must be VDK_BF16 or VDK_F16");
   d->opf = c->operand == VDK_F16 ? VDK_OPF_F16 : VDK_OPF_BF16;
+  d->dp = c->drop_path;
   d->B = c->batch; d->img = c->img_size; d->Cin = c->in_chans; d->E = c->embed_dim; d->eps = c->ln_eps; d->nblk = 0;
   d->C = c->num_classes; d->Cp = (int)up(c->num_classes, 8); d->Bp = (int)up(c->batch, 64); d->Kpe = c->in_chans * 16;
   int res = c->img_size / 4;
@@ -270,7 +272,7 @@ void sw_plan(const SwDims& d, WsPlan* w) {
     if ((size_t)d.Kpe > trows) trows = d.Kpe; }
   if (d.C > 0) {
     if ((size_t)d.Cp > trows) trows = d.Cp;
-    { int k1 = wgrad_splitk(d.Cp, (int)D, d.Bp); size_t b = (size_t)k1 * d.Cp * D * 4; if (b > sl) sl = b; }
+    { int k1 = wgrad_splitk(d.Cp, (int)D, d.Bp), k2 = wgrad_tn_splits(d.Cp, (int)D, d.B); size_t b = (size_t)(k1 > k2 ? k1 : k2) * d.Cp * D * 4; if (b > sl) sl = b; }      // (batch % 64 == 0: linear_wgrad takes the TN form with its own split count)
     size_t cs = (size_t)((d.Bp + 63) / 64) * d.Cp * 4; if (cs > csmax) csmax = cs;
   }
   if (D > trows) trows = D;
@@ -348,8 +350,9 @@ __global__ __launch_bounds__(256) void swin_merge_kernel(const float* __restrict
 
 // ---------------------------------------------------------------------------------------------------------------- GEMM helpers (as in vit_engine.hip)
 int gemm(hipStream_t s, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K, int cdt, const float* bias, const float* res, int64_t ldr,
-         int act, void* aux, int64_t ldaux, int splitk, void* ws, size_t wsb, float* c_colsum = nullptr) {
+         int act, void* aux, int64_t ldaux, int splitk, void* ws, size_t wsb, float* c_colsum = nullptr, const float* row_scale = nullptr, int rows_per_scale = 0) {
   VdkGemmDesc g = {};
+  g.row_scale = row_scale; g.rows_per_scale = rows_per_scale;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.c_dtype = cdt == VDK_F32 ? VDK_F32 : DT16; g.bias = bias; g.residual = res; g.ldr = ldr;
   g.act = act; g.aux = aux; g.ldaux = ldaux; g.alpha = 1.0f; g.splitk = splitk; g.c_colsum = c_colsum; g.ab_dtype = DT16;
   return vdk_gemm_bf16_nt(&g, ws, wsb, s);
@@ -465,10 +468,12 @@ int vdk_swin_forward(const VdkSwinConfig* cfg, const float* x, const float* para
   RC(gemm(s, patches, d.Kpe, wb + p.pe_w, d.Kpe, petmp, d.E, (int)d.T[0], d.E, d.Kpe, VDK_F32, params + p.pe_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));
   RC(vdk_layernorm_fwd(petmp, d.E, (int)d.T[0], d.E, params + p.pe_nw, params + p.pe_nb, d.eps, base + w.st[0].blk[0].x, d.E, VDK_F32, pest, pest + d.T[0], s));
   const float* xprev = nullptr;      // output of the previous stage
+  int kblk = 0;                      // running block index: rows 2 k / 2 k + 1 of the drop-path factors
   for (int i = 0; i < d.nst; ++i) {
     const StageW& sw_ = w.st[i]; const StageP& sp = p.st[i];
     const int T = (int)d.T[i], C = d.dim[i], M = 4 * C, H = d.heads[i];
     const int nW = (d.res[i] / SW_WS) * (d.res[i] / SW_WS);
+    const int tpi = T / d.B;         // tokens per image: rows that share a drop-path factor
     if (i > 0) {      // PatchMerging in front of the stage
       const int C4 = 4 * d.dim[i - 1];
       float* mg = (float*)(base + sw_.mg); float* mst = (float*)(base + sw_.mstats); bf16_t* mh = (bf16_t*)(base + sw_.mh);
@@ -477,9 +482,10 @@ int vdk_swin_forward(const VdkSwinConfig* cfg, const float* x, const float* para
       RC(vdk_layernorm_fwd(mg, C4, T, C4, params + sp.ds_nw, params + sp.ds_nb, d.eps, mh, C4, DT16, mst, mst + T, s));
       RC(gemm(s, mh, C4, wb + sp.ds_w, C4, base + sw_.blk[0].x, C, T, C, C4, VDK_F32, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));
     }
-    for (int j = 0; j < d.depth[i]; ++j) {
+    for (int j = 0; j < d.depth[i]; ++j, ++kblk) {
       const BlkW& bw = sw_.blk[j]; const BlkP& b = sp.blk[j];
       const bool shifted = (j & 1) && d.res[i] > SW_WS;
+      const float* dp1 = d.dp ? d.dp + (size_t)(2 * kblk) * d.B : nullptr; const float* dp2 = d.dp ? dp1 + d.B : nullptr;      // stochastic depth: x + factor_b * branch(x)
       float* xin = (float*)(base + bw.x); float* xmid = (float*)(base + bw.xmid);
       float* xout = (float*)(base + (j + 1 < d.depth[i] ? sw_.blk[j + 1].x : sw_.xout));
       float* st = (float*)(base + bw.stats);
@@ -492,11 +498,11 @@ int vdk_swin_forward(const VdkSwinConfig* cfg, const float* x, const float* para
       RC(vdk_wa_prep_table(params + b.table, shifted ? (const float*)(base + sw_.mask) : nullptr, shifted ? nW : 0, H, bias, s));
       RC(vdk_wa_fwd_bm(qkv, 3 * C, o, C, (float*)(base + bw.lse), bias, shifted ? nW : 1, (int64_t)(T / SW_N), H, 0.17677669529663687f /* 32^-0.5 */,
                        (const int32_t*)(base + (shifted ? sw_.rowidx3 : sw_.rowidx0)), t_opf, s));
-      RC(gemm(s, o, C, wb + b.proj_w, C, xmid, C, T, C, C, VDK_F32, params + b.proj_b, xin, C, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));
+      RC(gemm(s, o, C, wb + b.proj_w, C, xmid, C, T, C, C, VDK_F32, params + b.proj_b, xin, C, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0, nullptr, dp1, tpi));
       // x = x + fc2(gelu(fc1(norm2(x))))
       RC(vdk_layernorm_fwd(xmid, C, T, C, params + b.n2w, params + b.n2b, d.eps, h2, C, DT16, st + 2 * (size_t)T, st + 3 * (size_t)T, s));
       RC(gemm(s, h2, C, wb + b.fc1_w, C, g, M, T, M, C, DT16, params + b.fc1_b, nullptr, 0, VDK_ACT_GELU, u, M, 1, nullptr, 0));
-      RC(gemm(s, g, M, wb + b.fc2_w, M, xout, C, T, C, M, VDK_F32, params + b.fc2_b, xmid, C, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));
+      RC(gemm(s, g, M, wb + b.fc2_w, M, xout, C, T, C, M, VDK_F32, params + b.fc2_b, xmid, C, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0, nullptr, dp2, tpi));
     }
     xprev = (const float*)(base + sw_.xout);
   }
@@ -537,10 +543,18 @@ int vdk_swin_backward(const VdkSwinConfig* cfg, const void* dout, const float* p
   const int T3 = (int)d.T[d.nst - 1], D = d.dim[d.nst - 1];
   const float* xlast = (const float*)(base + w.st[d.nst - 1].xout);
   float* fst = (float*)(base + w.fstats);
+  // Stochastic depth in the backward: a branch's input gradient is factor_b * dL/dx_out, and every GEMM of the branch reads the 16-BIT copy of that gradient -- so the kernel that
+  // stores a copy (the LayerNorm backward in front of it, or the stage-boundary cast) multiplies the factor of the branch that will read it into the copy only; the fp32
+  // stream (the shortcut's gradient) stays.  dpf(k, which): block k's attention (0) / MLP (1) factors.
+  int nblk_total = 0;
+  for (int i = 0; i < d.nst; ++i) nblk_total += d.depth[i];
+  auto dpf = [&](int k, int which) -> const float* { return d.dp ? d.dp + (size_t)(2 * k + which) * d.B : nullptr; };
+  int kblk = nblk_total - 1;
+  const int tpi3 = T3 / d.B;
   // ---- head + final norm: dxa / dxab = dL/d(stage 3 output) ----------------------------------------------------------------------------
   if (d.C == 0) {
     RC(vdk_layernorm_bwd_deferred(dout, D, VDK_F32, xlast, D, fst, fst + T3, params + p.norm_w, nullptr, 0, T3, D, dxa, D, dxab, D, grads + p.norm_w, grads + p.norm_b, lnws0,
-                                  w.lnws_bytes, s, nullptr, nullptr, nullptr, nullptr, t_opf));
+                                  w.lnws_bytes, s, nullptr, nullptr, nullptr, nullptr, t_opf, nullptr, dpf(kblk, 1), tpi3));
     if (on_ready) on_ready(user, p.norm_w, p.total - p.norm_w);
   } else {
     const bf16_t* dl = (const bf16_t*)dout;
@@ -551,7 +565,7 @@ int vdk_swin_backward(const VdkSwinConfig* cfg, const void* dout, const float* p
     float* dmap = dxm;      // (scratch: d(normed map) f32 [T3, D])
     RC(vdk_avgpool_rows_f32_bwd(dpool, dmap, nullptr, d.B, T3 / d.B, D, s));
     RC(vdk_layernorm_bwd_deferred(dmap, D, VDK_F32, xlast, D, fst, fst + T3, params + p.norm_w, nullptr, 0, T3, D, dxa, D, dxab, D, grads + p.norm_w, grads + p.norm_b, lnws0,
-                                  w.lnws_bytes, s, nullptr, nullptr, nullptr, nullptr, t_opf));
+                                  w.lnws_bytes, s, nullptr, nullptr, nullptr, nullptr, t_opf, nullptr, dpf(kblk, 1), tpi3));
     if (on_ready) on_ready(user, p.norm_w, p.total - p.norm_w);
   }
   // ---- stages, last to first -------------------------------------------------------------------------------------------------------------
@@ -559,7 +573,8 @@ int vdk_swin_backward(const VdkSwinConfig* cfg, const void* dout, const float* p
     const StageW& sw_ = w.st[i]; const StageP& sp = p.st[i];
     const int T = (int)d.T[i], C = d.dim[i], M = 4 * C, H = d.heads[i];
     const int nW = (d.res[i] / SW_WS) * (d.res[i] / SW_WS);
-    for (int j = d.depth[i] - 1; j >= 0; --j) {
+    const int tpi = T / d.B;
+    for (int j = d.depth[i] - 1; j >= 0; --j, --kblk) {
       const BlkW& bw = sw_.blk[j]; const BlkP& b = sp.blk[j];
       const bool shifted = (j & 1) && d.res[i] > SW_WS;
       const float* xin = (const float*)(base + bw.x); const float* xmid = (const float*)(base + bw.xmid);
@@ -581,7 +596,7 @@ int vdk_swin_backward(const VdkSwinConfig* cfg, const void* dout, const float* p
       // norm2 backward + the shortcut: dxm / dxmb = dL/dx_mid; proj.bias = column sums of the bf16 copy it stores
       const bool ocs = C <= 1024;
       RC(vdk_layernorm_bwd_deferred(dsm, C, DT16, xmid, C, st + 2 * (size_t)T, st + 3 * (size_t)T, params + b.n2w, dxa, C, T, C, dxm, C, dxmb, C, grads + b.n2w, grads + b.n2b,
-                                    lnws0, w.lnws_bytes, s, &jobs[nj], ocs ? grads + b.proj_b : nullptr, ocs ? &jobs[nj + 1] : nullptr));
+                                    lnws0, w.lnws_bytes, s, &jobs[nj], ocs ? grads + b.proj_b : nullptr, ocs ? &jobs[nj + 1] : nullptr, nullptr, 0, nullptr, dpf(kblk, 0), tpi));
       nj += ocs ? 2 : 1;
       // attention branch
       RC(gemm(s, dxmb, C, wt + b.tp, C, dsm, C, T, C, C, DT16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));   // do
@@ -595,7 +610,8 @@ int vdk_swin_backward(const VdkSwinConfig* cfg, const void* dout, const float* p
       // norm1 backward + the shortcut: dxa / dxab = dL/dx_in (= dL/dx_out of the block before)
       const bool ocs1 = ocs && j > 0;      // dxab = dL/dx_out of block j - 1: its column sums are that block's fc2.bias gradient
       RC(vdk_layernorm_bwd_deferred(dsm, C, DT16, xin, C, st, st + T, params + b.n1w, dxm, C, T, C, dxa, C, dxab, C, grads + b.n1w, grads + b.n1b, lnws1, w.lnws_bytes, s,
-                                    &jobs[nj], ocs1 ? grads + sp.blk[j - 1].fc2_b : nullptr, ocs1 ? &jobs[nj + 1] : nullptr));
+                                    &jobs[nj], ocs1 ? grads + sp.blk[j - 1].fc2_b : nullptr, ocs1 ? &jobs[nj + 1] : nullptr, nullptr, 0, nullptr,
+                                    j > 0 ? dpf(kblk - 1, 1) : nullptr, tpi));      // (j == 0: the copy goes to the PatchMerging / patch-embedding backward, not to a branch)
       nj += ocs1 ? 2 : 1;
       RC(vdk_reduce_rows_batch(jobs, nj, s));
       if (on_ready) {
@@ -614,6 +630,7 @@ int vdk_swin_backward(const VdkSwinConfig* cfg, const void* dout, const float* p
       const long n4 = d.T[i - 1] * (Cp_ / 4);
       hipLaunchKernelGGL(swin_merge_kernel<true>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)dxm, dxa, d.B, d.res[i - 1], Cp_);
       RC(vdk_cast_f32_16(dxa, dxab, d.T[i - 1] * Cp_, t_opf, s));
+      if (d.dp) RC(vdk_rowscale_16(dxab, d.T[i - 1], Cp_, dpf(kblk, 1), (int)(d.T[i - 1] / d.B), t_opf, s));      // (kblk: already the previous stage's last block) its MLP branch reads this copy
       if (on_ready) on_ready(user, sp.ds_nw, sp.blk[0].n1w - sp.ds_nw);
     }
   }

@@ -35,6 +35,7 @@ struct GemmParams {
   int stagger, stagger_lo;   // gemm_w4h_kernel: workgroups stagger_lo .. 2 * stagger_lo - 1 start `stagger` shader cycles late (0: nobody)
   int opf;                   // operand format of A, B, a 16-bit C and aux: VDK_OPF_BF16 | VDK_OPF_F16 (VdkGemmDesc.ab_dtype)
   const float* cscale;       // VdkGemmDesc.col_scale: per-column factor of the accumulator, applied before bias / residual (fp32-output epilogues)
+  const float* rscale; int rps;   // VdkGemmDesc.row_scale / rows_per_scale: C = residual + rscale[m / rps] * (acc + bias) (fp32-output epilogues with a residual)
 };
 
 // in-library launcher (no descriptor copy through the C ABI)

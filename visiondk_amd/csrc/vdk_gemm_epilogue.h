@@ -55,6 +55,11 @@ __device__ __forceinline__ void g_epilogue_store8(const GemmParams& p, long mi, 
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[2 * e] *= h_lo(u[e]); v[2 * e + 1] *= h_hi(u[e]); }
     }
+    if (p.rscale) {      // VdkGemmDesc.row_scale: the branch (acc + bias) times its sample's factor, then the shortcut
+      const float f = p.rscale[mi / p.rps];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= f;
+    }
     if (p.residual) {
       const float* rs = p.residual + mr * p.ldr + n;
       f32x4 r0 = *(const f32x4*)rs, r1 = *(const f32x4*)(rs + 4);
@@ -197,6 +202,11 @@ __device__ __forceinline__ void h_epilogue_half(const GemmParams& p, const float
       for (int e = 0; e < 4; ++e) { const vdk_f32x2 d2 = gelu_grad_f2((vdk_f32x2){op_lo<OF>(ux[ps][e]), op_hi<OF>(ux[ps][e])}); v[2 * e] *= d2[0]; v[2 * e + 1] *= d2[1]; }
     }
     if (E & E_RES) {
+      if (p.rscale) {
+        const float f = p.rscale[(mbase + row) / p.rps];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= f;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] += r0[ps][e]; v[4 + e] += r1[ps][e]; }
     }

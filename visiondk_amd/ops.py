@@ -30,7 +30,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=None, bias: Optional[
             residual: Optional[torch.Tensor] = None, act: int = ACT_NONE, aux: Optional[torch.Tensor] = None,
             alpha: float = 1.0, splitk: int = 1, out: Optional[torch.Tensor] = None, row_group: int = 0,
             trans: bool = False, a_row_group: int = 0, a_rows: Optional[int] = None, a_colsum: Optional[torch.Tensor] = None,
-            streamk_ws: Optional[torch.Tensor] = None, c_colsum: Optional[torch.Tensor] = None, col_scale: Optional[torch.Tensor] = None, backend=None) -> torch.Tensor:
+            streamk_ws: Optional[torch.Tensor] = None, c_colsum: Optional[torch.Tensor] = None, col_scale: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None, rows_per_scale: int = 0, backend=None) -> torch.Tensor:
     """out[M,N] = epilogue(alpha * a[M,K] @ b[N,K].T); a, b bf16 or (both) fp16 (row stride may exceed K); out_dtype: fp32 or the operands' format (the default).
     streamk_ws: persistent workspace from streamk_workspace() -> stream-K allowed"""
     be = _be(backend)
@@ -65,6 +65,8 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=None, bias: Optional[
     d.trans = int(trans)
     d.a_row_group = a_row_group
     d.a_colsum = a_colsum.data_ptr() if a_colsum is not None else None      # f32 [vdk_gemm_a_colsum_rows(M, N, K), K] by-product (sum rows -> colsum(a))
+    d.row_scale = be.ptr(row_scale) if row_scale is not None else None       # f32 [ceil(M / rows_per_scale)]: residual + row_scale[m // rows_per_scale] * (acc + bias) (stochastic depth)
+    d.rows_per_scale = rows_per_scale
     d.col_scale = be.ptr(col_scale) if col_scale is not None else None       # f32 [N]: acc * col_scale before bias / residual (VdkGemmDesc.col_scale)
     d.c_colsum = c_colsum.data_ptr() if c_colsum is not None else None      # f32 [vdk_gemm_c_colsum_rows(M, N, K), N] by-product (sum rows -> colsum(stored bf16 out))
     for t in (a, b, out, residual, aux):

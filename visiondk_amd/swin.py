@@ -466,6 +466,11 @@ class SwinEngine:
         # (engine/procedure/train.py:118, no dtype => float16 on a GPU) computes in; vit.FusedTrainStep then runs the GradScaler protocol of train.py:203-215 around the step
         self.operand = operand
         self.spec = spec
+        # Stochastic depth (timm DropPath).  timm builds swin_* with drop_path_rate = 0.1 (block k of n gets rate 0.1 * k / (n - 1)); in training every block's two branches are
+        # multiplied per sample by mask / keep_prob before the shortcut is added.  forward(training=True) draws the factors [2 * blocks, B] on the device from torch's generator
+        # and hands them to the engine (VdkSwinConfig.drop_path); the backward of that forward reads the same buffer.  0.0: no factors, the epilogues are untouched.
+        self.drop_path_rate = 0.0
+        self._dp: Optional[torch.Tensor] = None
         self.be = backend or _lib.load()
         self.device = torch.device(device if device is not None else ("cuda" if self.be.device_only else "cpu"))
         cfg = self._cfg(1)
@@ -522,7 +527,20 @@ class SwinEngine:
         s = self.spec
         I4 = _abi.I32 * 4
         pad = lambda t: I4(*(tuple(t) + (0,) * (4 - len(t))))      # shallower members of the family (tests): trailing zeros
-        return _abi.SwinConfig(batch, s.img_size, s.in_chans, s.embed_dim, pad(s.depths), pad(s.heads), s.num_classes, s.ln_eps, _abi.F16_ if self.operand == "fp16" else _abi.BF16)
+        dp = self._dp if (self._dp is not None and self._dp.shape[1] == batch) else None
+        return _abi.SwinConfig(batch, s.img_size, s.in_chans, s.embed_dim, pad(s.depths), pad(s.heads), s.num_classes, s.ln_eps, _abi.F16_ if self.operand == "fp16" else _abi.BF16,
+                               self.be.ptr(dp))
+
+    def draw_drop_path(self, batch: int) -> Optional[torch.Tensor]:
+        """factors f32 [2 * blocks, batch] = Bernoulli(keep_prob) / keep_prob per (branch, sample) (timm's drop_path(): `x.new_empty(shape).bernoulli_(keep_prob).div_(keep_prob)`);
+        block k's keep_prob = 1 - drop_path_rate * k / (blocks - 1), the same for its two branches.  None when drop_path_rate == 0."""
+        if self.drop_path_rate <= 0.0:
+            return None
+        n = sum(self.spec.depths)
+        rates = torch.linspace(0, self.drop_path_rate, n, device=self.device).repeat_interleave(2)      # timm: [x.tolist() for x in torch.linspace(0, drop_path_rate, sum(depths)).split(depths)]
+        keep = (1.0 - rates).unsqueeze(1)
+        u = torch.rand((2 * n, batch), device=self.device)
+        return ((u < keep).to(torch.float32) / keep).contiguous()
 
     def _workspace(self, batch: int) -> torch.Tensor:
         if self._ws is None or self._ws_batch != batch:
@@ -557,8 +575,9 @@ class SwinEngine:
                 return flat[off:off + numel].view(shape)
         raise KeyError(name)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """x f32 [B, C, H, W] -> logits f32 [B, Cp] (padded columns beyond num_classes) or, in feature mode, the normed map rows f32 [B * 49, 8 E]"""
+    def forward(self, x: torch.Tensor, training: bool = True, drop_path: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x f32 [B, C, H, W] -> logits f32 [B, Cp] (padded columns beyond num_classes) or, in feature mode, the normed map rows f32 [B * 49, 8 E].
+        training: stochastic depth is active (drop_path_rate > 0): factors are drawn per call, or taken from `drop_path` ([2 * blocks, B], tests hand the oracle the same ones)."""
         s = self.spec
         if x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (s.in_chans, s.img_size, s.img_size):
             raise ValueError(f"expected float32 [B, {s.in_chans}, {s.img_size}, {s.img_size}], got {tuple(x.shape)} {x.dtype}")
@@ -566,6 +585,10 @@ class SwinEngine:
         B = x.shape[0]
         ws = self._workspace(B)
         self._ensure_fresh()
+        self._dp = None
+        if training:
+            self._dp = drop_path.to(self.device, torch.float32).contiguous() if drop_path is not None else self.draw_drop_path(B)
+            assert self._dp is None or tuple(self._dp.shape) == (2 * sum(s.depths), B)
         cfg = self._cfg(B)
         be = self.be
         be.check(be.lib.vdk_swin_forward(C.byref(cfg), be.ptr(x), be.ptr(self.params), be.ptr(self.wb16), be.ptr(ws), ws.numel(), be.ptr(self._out), be.stream()), "vdk_swin_forward")
@@ -592,7 +615,7 @@ class _SwinFunction(torch.autograd.Function):
     def forward(ctx, x, module, *params):
         eng = module.engine
         module._sync_flat()
-        out = eng.forward(x)
+        out = eng.forward(x, training=module.training)
         ctx.module = module
         if eng.cp == 0:
             r = int(round(eng.map_rows ** 0.5))
@@ -624,10 +647,13 @@ class SwinTransformer(nn.Module):
     mlp.{fc1, fc2}}, norm, head.fc) with parameter-only holders, so named_parameters() / state_dict() / load_state_dict() carry timm's key names; every Parameter is a view
     into the engine's flat fp32 buffer.  forward(x [B, 3, 224, 224]) -> logits [B, C]; num_classes = 0: the normed NHWC map [B, 7, 7, C_last] (timm's forward_features)."""
 
-    def __init__(self, spec: SwinSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None, operand: str = "bf16"):
+    def __init__(self, spec: SwinSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None, operand: str = "bf16", drop_path_rate: float = 0.0):
         super().__init__()
+        if not 0.0 <= drop_path_rate < 1.0:
+            raise ValueError("0 <= drop_path_rate < 1")
         self.spec = spec
         self.engine = SwinEngine(spec, device=device, backend=backend, operand=operand)
+        self.engine.drop_path_rate = float(drop_path_rate)      # stochastic depth in train() mode (SwinEngine.draw_drop_path); create_model's default is timm's 0.1
         self.be = self.engine.be
         self.num_classes = spec.num_classes
         self.num_features = self.engine.features
@@ -700,9 +726,14 @@ class SwinTransformer(nn.Module):
 
 
 def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, img_size: int = 224, device=None, backend=None, seed: Optional[int] = None,
-                 native: bool = True, operand: str = "bf16", **kw):
+                 native: bool = True, operand: str = "bf16", drop_path_rate: float = 0.1, global_pool: Optional[str] = None, **kw):
     """timm.create_model(name, pretrained=..., num_classes=...) for the swin_*_patch4_window7_224 family (models/classifier/classify_model.py:49-54); native=False: the
-    autograd-node form of round 3 (the engine's cross-check)"""
+    autograd-node form of round 3 (the engine's cross-check).  drop_path_rate: timm's own default for this family is 0.1 (stochastic depth in train mode); the yaml's
+    `kwargs` reach it as they reach timm.  Keyword arguments timm would act on and this engine does not build are refused, not swallowed."""
+    if kw:
+        raise TypeError(f"swin.create_model: unsupported keyword arguments {sorted(kw)} (built: drop_path_rate, img_size, operand)")
+    if global_pool not in (None, "", "avg"):
+        raise NotImplementedError("global_pool: timm's default average pool (classifier) or '' (feature map)")
     name = name[5:] if name.startswith("timm-") else name
     if name not in TIMM_SWINS:
         raise KeyError(f"unknown Swin id {name!r}: {sorted(TIMM_SWINS)}")
@@ -710,7 +741,9 @@ def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, i
         raise RuntimeError("there is no network here: load a checkpoint with load_state_dict (timm names)")
     spec = SwinSpec(img_size=img_size, num_classes=num_classes, **TIMM_SWINS[name])
     if native:
-        return SwinTransformer(spec, device=device, backend=backend, seed=seed, operand=operand)
+        return SwinTransformer(spec, device=device, backend=backend, seed=seed, operand=operand, drop_path_rate=drop_path_rate)
+    if drop_path_rate not in (0.0, 0.1):      # (0.1 = the default nobody asked for: the cross-check form never drops)
+        raise NotImplementedError("stochastic depth is built into the native engine (native=True)")
     if operand != "bf16":
         raise NotImplementedError("the autograd-node form runs on bf16 operands; fp16 is the native engine's (native=True)")
     return SwinTransformerAutograd(spec, device=device, backend=backend, seed=seed)
