@@ -623,6 +623,16 @@ int vdk_comm_init(const void* id128, int32_t rank, int32_t world, VdkComm** comm
 int vdk_comm_destroy(VdkComm* comm);
 int vdk_comm_rank(const VdkComm* comm);
 int vdk_comm_world(const VdkComm* comm);
+/* Timing trace of the collectives against the launch stream (diagnostic; the one-GPU evidence that a bucket's all-reduce runs while the backward is still executing --
+ * torch DDP's overlap at engine/vision_engine.py:313,510).  vdk_comm_trace(c, 1) clears and arms it: every vdk_allreduce_bucket then records a start event on the collectives'
+ * stream, vdk_comm_trace_close_last its end event (after anything the caller put behind it on vdk_comm_stream(c): tests enqueue vdk_debug_occupy_cus there as a stand-in for a
+ * multi-GPU collective's kernel), vdk_comm_mark a time stamp on the launch stream.  vdk_comm_trace_read SYNCHRONISES and returns milliseconds after mark 0:
+ * ar_ms [2 * n_ar] = (start, end) pairs, numel [n_ar], marks_ms [n_marks]. */
+int vdk_comm_trace(VdkComm* c, int32_t enable);
+int vdk_comm_trace_close_last(VdkComm* c);
+int vdk_comm_mark(VdkComm* c, void* launch_stream);
+int vdk_comm_trace_read(VdkComm* c, float* ar_ms, int64_t* numel, int32_t ar_cap, int32_t* n_ar, float* marks_ms, int32_t marks_cap, int32_t* n_marks);
+void* vdk_comm_stream(VdkComm* c);
 int vdk_allreduce_bucket(VdkComm* comm, float* grads, int64_t offset, int64_t numel, void* launch_stream);
 int vdk_comm_finish(VdkComm* comm, void* launch_stream);
 int vdk_allgather(VdkComm* comm, const void* send, void* recv, int64_t bytes_per_rank, void* launch_stream);

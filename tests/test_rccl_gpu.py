@@ -214,3 +214,58 @@ def test_cu_reserve_is_scoped_to_the_backward_window(hip, rccl):
     torch.cuda.synchronize()
     assert seen and all(v == max(32, before) for v in seen)             # held while buckets are being issued ...
     assert lib.vdk_gemm_reserved_cus() == before                        # ... and given back when the step's collectives have been joined
+
+
+def _overlap_run(hip, batch, steps, route_kw):
+    """ViT-B/16 fused steps; returns (ms per step, params, the last step's trace or None)"""
+    from visiondk_amd import comm, vit
+    model = vit.VisionTransformer(vit.spec_from_timm_name("vit_base_patch16_224", 1000), device="cuda:0", backend=hip, seed=3, operand="fp16")
+    c = comm.GradAllReduce(always_communicate=True, **route_kw) if route_kw is not None else None
+    step = vit.FusedTrainStep(model, lr=0.006, label_smoothing=0.05, ema=True, comm=c)
+    torch.manual_seed(9)
+    x = torch.randn(batch, 3, 224, 224).cuda(); y = torch.randint(0, 1000, (batch,)).cuda()
+    for _ in range(2):
+        step.step(x, y)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        step.step(x, y)
+    e1.record(); torch.cuda.synchronize()
+    tr = c.trace_read() if (c is not None and route_kw.get("trace")) else None
+    out = (e0.elapsed_time(e1) / steps, model.engine.params.clone(), tr)
+    if c is not None:
+        c.close()
+    return out
+
+
+def test_c_abi_route_equals_c10d_route_and_the_plain_step(hip, rccl):
+    """GradAllReduce(route="abi"): the same buckets through vdk_comm_init / vdk_allreduce_bucket / vdk_comm_finish (csrc/comm.hip: RCCL on the library's own stream) instead of
+    c10d -- bit-identical weights to the c10d route and to the communication-free step"""
+    plain = _overlap_run(hip, 8, 1, None)
+    c10d = _overlap_run(hip, 8, 1, {"route": "c10d"})
+    abi = _overlap_run(hip, 8, 1, {"route": "abi"})
+    assert torch.equal(plain[1], c10d[1]) and torch.equal(plain[1], abi[1])
+
+
+def test_allreduce_buckets_run_while_the_backward_is_still_executing(hip, rccl):
+    """The one-GPU evidence of torch DDP's overlap (engine/vision_engine.py:313,510).  ViT-B/16, batch 64, buckets through the C-ABI route with the timing trace on and a
+    STAND-IN for the multi-GPU collective behind every (one-rank, hence empty) all-reduce: a kernel holding 32 CUs on the collectives' stream for the time an 8-GPU ring
+    all-reduce of that bucket takes at a pessimistic 150 GB/s bus bandwidth (2 * 7/8 * bytes / bandwidth = 11.7 us per MB: 4 ms for the 346 MB gradient).
+      * the first bucket's all-reduce STARTS before the backward's last kernel ends, and all but the gradient's tail END before it;
+      * the step gets slower by far less than the collectives' total duration: they ran under the backward (the weights stay bit-identical: the stand-in moves no data)."""
+    plain_ms, plain_params, _ = _overlap_run(hip, 64, 4, None)
+    kw = {"route": "abi", "trace": True, "standin_us_per_mb": 11.7}
+    ms, params, tr = _overlap_run(hip, 64, 4, kw)
+    assert torch.equal(params, plain_params)
+    ar, marks = tr["allreduce_ms"], tr["marks_ms"]
+    assert len(ar) >= 4 and len(marks) == 3
+    bwd_end = marks[1]
+    total = sum(e - s for s, e in ar)
+    print({"plain_ms": plain_ms, "with_standin_ms": ms, "collectives": len(ar), "collective_ms_total": total, "backward_ms": bwd_end, "first_start_ms": ar[0][0],
+           "ended_before_backward_end": sum(1 for s, e in ar if e <= bwd_end), "exposed_tail_ms": marks[2] - marks[1]})
+    assert total > 2.0                                            # the stand-ins really ran (about 4 ms per step)
+    assert ar[0][0] < 0.5 * bwd_end                               # the first bucket leaves in the first half of the backward ...
+    assert sum(1 for s, e in ar if e <= bwd_end) >= len(ar) - 2   # ... and only the gradient's tail is still in flight when the backward ends
+    assert marks[2] - marks[1] < 0.5 * total                      # what the optimizer waits for is the tail, not the sum
+    assert ms - plain_ms < 0.6 * total                            # the step pays a fraction of the collectives' duration

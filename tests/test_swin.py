@@ -150,6 +150,8 @@ def test_face_model_with_the_default_backbone_of_cbir_yaml(be, dev):
                 p.copy_(torch.randn_like(p) * (0.7 / (p[0].numel() ** 0.5)))
     w.model.load_state_dict(ref.state_dict(), strict=True)
     w.output_layer.load_state_dict(neck.state_dict(), strict=True)
+    assert w.model.engine.drop_path_rate == 0.1          # what timm.create_model(model_name, ...) builds inside the reference's TimmWrapper (timm_wrapper.py:16-21)
+    w.model.engine.drop_path_rate = 0.0                  # this comparison is against the oracle without stochastic depth (test_stochastic_depth_matches_timm_drop_path covers it)
     w.train(); ref.train(); neck.train()
     x = torch.randn(4, 3, 224, 224)
     emb = w(x.to(dev)); emb_r = neck(ref(x))          # ref(x): [B, 7, 7, C] NHWC, read by BatchNorm2d / Flatten as [B, 7, 7, C] "NCHW"
@@ -282,6 +284,7 @@ def test_face_train_step_over_the_swin_engine(be, dev):
            "head": {"arcface": {"feat_dim": 64, "num_class": 24, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
     torch.manual_seed(0)
     m1 = face.get_model(cfg, None, 0, backend=be, device=dev).model.train()
+    m1.trainingwrapper["backbone"].model.engine.drop_path_rate = 0.0      # (two independent passes would draw different masks)
     m2 = copy.deepcopy(m1)
     init = {n: p.detach().clone() for n, p in m1.named_parameters()}
     x = torch.randn(6, 3, 224, 224).to(dev); y = torch.randint(0, 24, (6,)).to(dev)
@@ -437,17 +440,29 @@ def test_swin_family_full_size_fp16_meets_the_stated_tolerance(hip, name):
     assert step.loss_value() == step.loss_value() and step.skipped_steps() == 0          # finite, no overflow at the initial scale
 
 
-def test_face_train_step_rejects_fp16_operand_engines(be, dev):
-    """the face / CBIR loop of the reference has no autocast and no GradScaler: its step object refuses an fp16-operand backbone instead of writing bf16 operand copies over it"""
+def test_face_train_step_takes_fp16_operand_engines_under_the_grad_scaler(be, dev):
+    """FaceTrainStep over an fp16 Swin backbone (cbir.yaml:26's default backbone, `operand: fp16` beside the reference's three backbone keys): the GradScaler protocol of
+    Trainer.update (train.py:203-215) runs inside the step, a finite step leaves the scale alone; an engine switched to fp16 under a wrapper built for bf16 (its neck would
+    multiply bf16 operands against fp16 gradients) is refused."""
     from visiondk_amd import face
     swin.TIMM_SWINS["swin_test_patch4_window7_224"] = dict(embed_dim=32, depths=(1, 1, 1, 1), heads=(1, 2, 4, 8))
     cfg = {"task": "cbir", "image_size": 224, "load_from": None,
-           "backbone": {"timm-swin_test_patch4_window7_224": {"pretrained": False, "image_size": 224, "feat_dim": 64}},
+           "backbone": {"timm-swin_test_patch4_window7_224": {"pretrained": False, "image_size": 224, "feat_dim": 64, "operand": "fp16"}},
            "head": {"arcface": {"feat_dim": 64, "num_class": 24, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
+    torch.manual_seed(0)
     m = face.get_model(cfg, None, 0, backend=be, device=dev).model.train()
-    m.trainingwrapper["backbone"].model.engine.set_operand("fp16")
-    with pytest.raises(NotImplementedError):
-        face.FaceTrainStep(m, lr=0.01, momentum=0.9, weight_decay=5e-4)
+    step = face.FaceTrainStep(m, lr=0.01, momentum=0.9, weight_decay=5e-4, init_scale=256.0)
+    assert step.amp
+    x = torch.randn(4, 3, 224, 224).to(dev); y = torch.randint(0, 24, (4,)).to(dev)
+    before = m.trainingwrapper["backbone"].model.engine.params.clone()
+    rows = step.step(x, y)
+    assert torch.isfinite(rows).all() and step.skipped_steps() == 0 and step.loss_scale() == 256.0
+    assert not torch.equal(m.trainingwrapper["backbone"].model.engine.params, before)
+    cfg["backbone"]["timm-swin_test_patch4_window7_224"]["operand"] = "bf16"
+    m2 = face.get_model(cfg, None, 0, backend=be, device=dev).model.train()
+    m2.trainingwrapper["backbone"].model.engine.set_operand("fp16")
+    with pytest.raises(ValueError):
+        face.FaceTrainStep(m2, lr=0.01, momentum=0.9, weight_decay=5e-4)
 
 
 @pytest.mark.parametrize("depths,heads,ncls,operand", [((2, 2), (1, 2), 6, "bf16"), ((1, 2, 1, 1), (1, 2, 4, 8), 0, "fp16")])

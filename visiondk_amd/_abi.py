@@ -153,6 +153,11 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_comm_world": (C.c_int, [P]),
     "vdk_allreduce_bucket": (C.c_int, [P, P, I64, I64, P]),
     "vdk_comm_finish": (C.c_int, [P, P]),
+    "vdk_comm_trace": (C.c_int, [P, I32]),
+    "vdk_comm_trace_close_last": (C.c_int, [P]),
+    "vdk_comm_mark": (C.c_int, [P, P]),
+    "vdk_comm_trace_read": (C.c_int, [P, P, P, I32, C.POINTER(I32), P, I32, C.POINTER(I32)]),
+    "vdk_comm_stream": (C.c_void_p, [P]),
     "vdk_allgather": (C.c_int, [P, P, P, I64, P]),
     # margin-softmax heads
     "vdk_margin_cos_pass": (C.c_int, [P, I32, P, I64, P, I64, I32, I32, I32, I32, I32, P, P, P, P, P, F32, F32, P, I64, P]),

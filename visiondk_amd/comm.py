@@ -13,6 +13,10 @@ reduced bucket while a later one is in flight -- only the LAST bucket's collecti
 keeps that last one small: a bucket closes when it reaches `bucket_bytes` or when no more than its own size is still to come, so the gradient's tail (for the
 ViT: block 0, then the embeddings) leaves in pieces of decreasing size instead of one 2-block bucket at the very end.  c10d is the binding to RCCL here on
 purpose ("collectives"): the C-ABI exposes the ready-range callback, the exchange itself is the host framework's.
+
+route="abi" sends the same buckets through the library's own collectives instead (csrc/comm.hip: vdk_comm_init / vdk_allreduce_bucket / vdk_comm_finish -- RCCL on the
+communicator's own stream, ordered by events): what a C / C++ host without a process group uses, driven here so that both routes run the same tests.  The unique id travels
+over the torch process group once, at construction.  `trace=True` arms the timing trace (vdk_comm_trace): where every all-reduce sits in time relative to the backward.
 """
 from __future__ import annotations
 
@@ -23,8 +27,13 @@ import torch.distributed as dist
 
 
 class GradAllReduce:
-    def __init__(self, group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 24 << 20, always_communicate: bool = False, reserve_cus: int = 32):
-        """reserve_cus: CUs the persistent GEMM grids leave to the collectives' kernels while this object is active on a GPU (vdk_gemm_reserve_cus: an all-reduce in
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 24 << 20, always_communicate: bool = False, reserve_cus: int = 32,
+                 route: str = "c10d", trace: bool = False, standin_us_per_mb: float = 0.0, standin_cus: Optional[int] = None):
+        """route: "c10d" (torch.distributed issues the all-reduce) or "abi" (vdk_allreduce_bucket on the library's communicator; GPU only).
+        trace (route "abi"): record where each all-reduce runs in time (read with trace_read()).  standin_us_per_mb (route "abi", diagnostics on ONE GPU, where a collective
+        over a single rank moves nothing): behind every all-reduce a kernel that holds `reserve_cus` CUs for standin_us_per_mb microseconds per MB of the bucket runs on the
+        collectives' stream -- the footprint of an 8-GPU ring all-reduce of that bucket -- so that the exposure of the exchange can be measured without a second GPU.
+        reserve_cus: CUs the persistent GEMM grids leave to the collectives' kernels while this object is active on a GPU (vdk_gemm_reserve_cus: an all-reduce in
         flight holds one CU per channel; a persistent GEMM whose static tile walk covers every CU would wait for it to END -- measured with a stand-in kernel,
         tools/w4_contention.py).  always_communicate: issue every collective even in a one-rank group (where they are identities).  The GPU tests use it to drive the real
         stream-ordered RCCL path on a single MI355X (backend "nccl", world_size 1) and require bit-identical results to the communication-free step."""
@@ -43,6 +52,37 @@ class GradAllReduce:
         if self._reserve:
             from . import _lib
             self._be = _lib.load()
+        if route not in ("c10d", "abi"):
+            raise ValueError("route must be 'c10d' or 'abi'")
+        self.route = route
+        self._comm = None
+        self._trace = bool(trace)
+        self._standin = float(standin_us_per_mb)
+        self._standin_cus = standin_cus
+        if route == "abi" and self.active:
+            import ctypes as C
+            from . import _lib
+            if not torch.cuda.is_available():
+                raise RuntimeError("route='abi' drives RCCL through the C ABI: GPU only (the CPU tests use c10d / gloo)")
+            self._be = self._be or _lib.load()
+            be = self._be
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if self.rank == 0:
+                buf = (C.c_ubyte * 128)()
+                be.check(be.lib.vdk_comm_unique_id(buf), "vdk_comm_unique_id")
+                uid = torch.tensor(list(buf), dtype=torch.uint8)
+            if self.world_size > 1:      # the 128 bytes travel over the host's process group (any backend)
+                t = uid.cuda() if dist.get_backend(group) == "nccl" else uid
+                dist.broadcast(t, src=0, group=group)
+                uid = t.cpu()
+            raw = (C.c_ubyte * 128)(*uid.tolist())
+            handle = C.c_void_p()
+            be.check(be.lib.vdk_comm_init(raw, self.rank, self.world_size, C.byref(handle)), "vdk_comm_init")
+            self._comm = handle
+            if self._trace:
+                be.check(be.lib.vdk_comm_trace(self._comm, 1), "vdk_comm_trace")
+        elif trace or standin_us_per_mb:
+            raise ValueError("trace / standin_us_per_mb belong to route='abi'")
         self.collectives = 0               # issued so far (tests / logs)
         self.bucket_bytes = bucket_bytes   # ViT-B: one 28 MB transformer block per collective (ranges arrive per block); far above the size where a ring over xGMI is latency-bound
         self._grads: Optional[torch.Tensor] = None
@@ -63,6 +103,9 @@ class GradAllReduce:
         self._pending = []
         self._lo = self._hi = None
         self._sent_lo = flat_grads.numel()      # lower end of what has been issued so far: ranges that arrive top-down keep extending directly below it
+        if self._comm is not None and self._trace:
+            self._be.check(self._be.lib.vdk_comm_trace(self._comm, 1), "vdk_comm_trace")          # a fresh trace per step; mark 0 = the backward is about to be enqueued
+            self._be.check(self._be.lib.vdk_comm_mark(self._comm, self._be.stream()), "vdk_comm_mark")
 
     def _hold_cus(self) -> None:
         if self._reserve and self._reserve_prev is None:
@@ -75,12 +118,26 @@ class GradAllReduce:
             self._reserve_prev = None
 
     def close(self) -> None:
-        """give the CUs back if a step was abandoned between begin_step and finish_step"""
+        """give the CUs back if a step was abandoned between begin_step and finish_step; destroy the library's communicator (route "abi")"""
         self._release_cus()
+        if self._comm is not None:
+            self._be.lib.vdk_comm_destroy(self._comm)
+            self._comm = None
+
+    def trace_read(self) -> dict:
+        """route "abi" with trace=True, after a step: {"marks_ms": [0, backward enqueued and executed up to here, ...], "allreduce_ms": [(start, end), ...], "numel": [...]}
+        in milliseconds after begin_step's mark (synchronises)."""
+        import ctypes as C
+        be = self._be
+        n_ar, n_m = C.c_int32(0), C.c_int32(0)
+        ar = (C.c_float * 512)(); numel = (C.c_int64 * 256)(); marks = (C.c_float * 64)()
+        be.check(be.lib.vdk_comm_trace_read(self._comm, ar, numel, 256, C.byref(n_ar), marks, 64, C.byref(n_m)), "vdk_comm_trace_read")
+        return {"marks_ms": [marks[i] for i in range(n_m.value)], "allreduce_ms": [(ar[2 * i], ar[2 * i + 1]) for i in range(n_ar.value)],
+                "numel": [numel[i] for i in range(n_ar.value)]}
 
     def __del__(self):
         try:
-            self._release_cus()
+            self.close()
         except Exception:
             pass
 
@@ -89,8 +146,19 @@ class GradAllReduce:
             return
         self._hold_cus()                      # from here until finish_step a collective may be in flight beside the remaining backward GEMMs
         self._sent_lo = min(self._sent_lo, self._lo)
-        sl = self._grads[self._lo:self._hi]
-        self._pending.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self._comm is not None:
+            be = self._be
+            n = self._hi - self._lo
+            be.check(be.lib.vdk_allreduce_bucket(self._comm, be.ptr(self._grads), self._lo, n, be.stream()), "vdk_allreduce_bucket")
+            if self._standin > 0.0:      # one GPU: a kernel with the footprint of the multi-GPU collective (CUs held for the time the ring would take) behind the no-op all-reduce
+                us = int(self._standin * n * 4 / 1e6)
+                if us > 0:
+                    be.check(be.lib.vdk_debug_occupy_cus(self._standin_cus if self._standin_cus else max(self._reserve, 1), us, be.lib.vdk_comm_stream(self._comm)), "vdk_debug_occupy_cus")
+            if self._trace:
+                be.check(be.lib.vdk_comm_trace_close_last(self._comm), "vdk_comm_trace_close_last")
+        else:
+            sl = self._grads[self._lo:self._hi]
+            self._pending.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.collectives += 1
         self._lo = self._hi = None
 
@@ -116,6 +184,12 @@ class GradAllReduce:
         if not self.active:
             return
         self._flush()
+        if self._comm is not None:
+            if self._trace:      # mark 1: everything the backward enqueued has executed up to here
+                self._be.check(self._be.lib.vdk_comm_mark(self._comm, self._be.stream()), "vdk_comm_mark")
+            self._be.check(self._be.lib.vdk_comm_finish(self._comm, self._be.stream()), "vdk_comm_finish")      # the launch stream waits on the device
+            if self._trace:      # mark 2: ... and every collective has landed (what the clip / optimizer kernels wait for)
+                self._be.check(self._be.lib.vdk_comm_mark(self._comm, self._be.stream()), "vdk_comm_mark")
         for w in self._pending:
             w.wait()          # makes the launch stream wait for the collective (no host sync on NCCL/RCCL)
         self._pending = []
