@@ -102,7 +102,9 @@ def test_two_rank_step_equals_single_process(tmp_path, emu):
 
 
 # ---- face / CBIR task: 2-rank FaceTrainStep (ConvNeXt backbone + BatchNorm neck + ArcFace) and sharded gallery search --------------------------
-FACE_CFG = {"task": "cbir", "image_size": 32, "backbone": {"timm-convnext_test": {"pretrained": False, "image_size": 32, "feat_dim": 64}},
+# (operand bf16: these tests compare gradients bit for bit across ranks; the fp16 default would start at GradScaler's 65 536 and skip the first tiny-batch steps -- the
+# skip / back-off in lockstep across ranks is test_two_gloo_ranks_on_fp16_operands...; the class-sharded head is built for bf16)
+FACE_CFG = {"task": "cbir", "image_size": 32, "backbone": {"timm-convnext_test": {"pretrained": False, "image_size": 32, "feat_dim": 64, "operand": "bf16"}},
             "head": {"arcface": {"feat_dim": 64, "num_class": 24, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
 
 

@@ -37,7 +37,7 @@ def test_convnext_base_neck_arcface_100k_forward_backward_vs_oracle(hip):
     from oracle.convnext_ref import TimmWrapperCNNRef
     from visiondk_amd import face
     C, B = 100_000, 8
-    cfg = {"task": "cbir", "image_size": 224, "backbone": {"timm-convnext_base": {"pretrained": False, "image_size": 224, "feat_dim": 512}},
+    cfg = {"task": "cbir", "image_size": 224, "backbone": {"timm-convnext_base": {"pretrained": False, "image_size": 224, "feat_dim": 512, "operand": "bf16"}},
            "head": {"arcface": {"feat_dim": 512, "num_class": C, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
     torch.manual_seed(0)
     model = face.get_model(cfg, None, 0, backend=hip, device="cuda:0").model.train()
@@ -134,7 +134,7 @@ def test_convnext_base_neck_arcface_100k_fp32_precision_vs_oracle(hip):
     from oracle.convnext_ref import TimmWrapperCNNRef
     from visiondk_amd import face
     C, B = 100_000, 8
-    cfg = {"task": "cbir", "image_size": 224, "backbone": {"timm-convnext_base": {"pretrained": False, "image_size": 224, "feat_dim": 512}},
+    cfg = {"task": "cbir", "image_size": 224, "backbone": {"timm-convnext_base": {"pretrained": False, "image_size": 224, "feat_dim": 512, "operand": "bf16"}},
            "head": {"arcface": {"feat_dim": 512, "num_class": C, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
     torch.manual_seed(0)
     model = face.get_model(cfg, None, 0, backend=hip, device="cuda:0").model.train()

@@ -68,7 +68,7 @@ def test_vit_base_step_with_32mb_buckets_through_rccl(hip, rccl):
 def _face_model(be, seed, classes=24):
     from visiondk_amd import convnext, face
     convnext.TIMM_CONVNEXTS["convnext_test"] = dict(depths=(1, 1, 1, 1), dims=(8, 16, 24, 32))
-    cfg = {"task": "cbir", "image_size": 32, "backbone": {"timm-convnext_test": {"pretrained": False, "image_size": 32, "feat_dim": 64}},
+    cfg = {"task": "cbir", "image_size": 32, "backbone": {"timm-convnext_test": {"pretrained": False, "image_size": 32, "feat_dim": 64, "operand": "bf16"}},
            "head": {"arcface": {"feat_dim": 64, "num_class": classes, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
     torch.manual_seed(seed)
     model = face.get_model(cfg, None, 0, backend=be, device="cuda:0").model.train()

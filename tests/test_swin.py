@@ -280,7 +280,7 @@ def test_face_train_step_over_the_swin_engine(be, dev):
     from visiondk_amd import face
     swin.TIMM_SWINS["swin_test_patch4_window7_224"] = dict(embed_dim=32, depths=(1, 1, 1, 1), heads=(1, 2, 4, 8))
     cfg = {"task": "cbir", "image_size": 224, "load_from": None,
-           "backbone": {"timm-swin_test_patch4_window7_224": {"pretrained": False, "image_size": 224, "feat_dim": 64}},
+           "backbone": {"timm-swin_test_patch4_window7_224": {"pretrained": False, "image_size": 224, "feat_dim": 64, "operand": "bf16"}},      # the same kernels both ways: bf16, no loss scale
            "head": {"arcface": {"feat_dim": 64, "num_class": 24, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
     torch.manual_seed(0)
     m1 = face.get_model(cfg, None, 0, backend=be, device=dev).model.train()
