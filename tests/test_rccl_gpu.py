@@ -248,24 +248,30 @@ def test_c_abi_route_equals_c10d_route_and_the_plain_step(hip, rccl):
     assert torch.equal(plain[1], c10d[1]) and torch.equal(plain[1], abi[1])
 
 
-def test_allreduce_buckets_run_while_the_backward_is_still_executing(hip, rccl):
-    """The one-GPU evidence of torch DDP's overlap (engine/vision_engine.py:313,510).  ViT-B/16, batch 64, buckets through the C-ABI route with the timing trace on and a
-    STAND-IN for the multi-GPU collective behind every (one-rank, hence empty) all-reduce: a kernel holding 32 CUs on the collectives' stream for the time an 8-GPU ring
-    all-reduce of that bucket takes at a pessimistic 150 GB/s bus bandwidth (2 * 7/8 * bytes / bandwidth = 11.7 us per MB: 4 ms for the 346 MB gradient).
-      * the first bucket's all-reduce STARTS before the backward's last kernel ends, and all but the gradient's tail END before it;
-      * the step gets slower by far less than the collectives' total duration: they ran under the backward (the weights stay bit-identical: the stand-in moves no data)."""
-    plain_ms, plain_params, _ = _overlap_run(hip, 64, 4, None)
-    kw = {"route": "abi", "trace": True, "standin_us_per_mb": 11.7}
-    ms, params, tr = _overlap_run(hip, 64, 4, kw)
-    assert torch.equal(params, plain_params)
-    ar, marks = tr["allreduce_ms"], tr["marks_ms"]
-    assert len(ar) >= 4 and len(marks) == 3
-    bwd_end = marks[1]
-    total = sum(e - s for s, e in ar)
-    print({"plain_ms": plain_ms, "with_standin_ms": ms, "collectives": len(ar), "collective_ms_total": total, "backward_ms": bwd_end, "first_start_ms": ar[0][0],
-           "ended_before_backward_end": sum(1 for s, e in ar if e <= bwd_end), "exposed_tail_ms": marks[2] - marks[1]})
-    assert total > 2.0                                            # the stand-ins really ran (about 4 ms per step)
+def test_allreduce_buckets_run_while_the_backward_is_still_executing(hip):
+    """The one-GPU evidence of torch DDP's overlap (engine/vision_engine.py:313,510): tools/overlap_probe.py in a FRESH process (ViT-B/16, batch 64, fp16 fused step; buckets
+    through the C-ABI route with the timing trace on).  A one-rank all-reduce moves nothing, so behind every one a STAND-IN kernel holds 32 CUs on the collectives' stream for
+    the time an 8-GPU ring all-reduce of that bucket takes at a pessimistic 150 GB/s bus bandwidth (2 * 7/8 * bytes / bandwidth = 11.7 us per MB: 4 ms for the 346 MB gradient).
+      * the first bucket's all-reduce STARTS in the first half of the backward, and all but the gradient's tail END before the backward's last kernel;
+      * what the optimizer waits for after the backward is the tail, not the sum;
+      * the step gets slower by a fraction of the collectives' total duration: they ran under the backward.
+    (A fresh process because the measurement is about hardware-queue concurrency: after the ~400 tests of a whole-suite run the process owns so many HIP streams that the
+    driver time-slices its queues and every cross-stream overlap degrades -- observed in round 5; a training process has the two streams this probe has.)"""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "overlap_probe.py"), "64", "150"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    st = d["standin"]
+    ar, total, bwd_end = st["allreduce_intervals_ms"], st["collective_ms_total"], st["backward_end_ms"]
+    print({k: st[k] for k in ("ms_step", "collectives_per_step", "collective_ms_total", "backward_end_ms", "ended_before_backward_end", "exposed_tail_ms",
+                              "step_cost_of_the_exchange_ms", "hidden_fraction")}, "plain", d["ms_plain"])
+    assert len(ar) >= 4 and total > 2.0                           # the stand-ins really ran (about 4 ms per step)
     assert ar[0][0] < 0.5 * bwd_end                               # the first bucket leaves in the first half of the backward ...
-    assert sum(1 for s, e in ar if e <= bwd_end) >= len(ar) - 2   # ... and only the gradient's tail is still in flight when the backward ends
-    assert marks[2] - marks[1] < 0.5 * total                      # what the optimizer waits for is the tail, not the sum
-    assert ms - plain_ms < 0.6 * total                            # the step pays a fraction of the collectives' duration
+    assert st["ended_before_backward_end"] >= len(ar) - 2         # ... and only the gradient's tail is still in flight when the backward ends
+    assert st["exposed_tail_ms"] < 0.5 * total                    # what the optimizer waits for is the tail, not the sum
+    assert st["step_cost_of_the_exchange_ms"] < 0.5 * total       # the step pays a fraction of the collectives' duration
+    assert abs(d["ms_abi_route_empty_collectives"] - d["ms_plain"]) < 0.05 * d["ms_plain"]      # the plumbing itself (callbacks, events, empty collectives) is in the noise

@@ -386,7 +386,7 @@ int vdk_attention_small_bwd(const void* qkv, int64_t ld, const void* o, const vo
 int vdk_attention_long_fwd(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, int32_t B, int32_t N, int32_t H, float scale, int opf, void* stream);
 int vdk_attention_long_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv, int64_t ldd, float* dvec, int32_t B, int32_t N,
                            int32_t H, float scale, int opf, void* stream);
-static int g_attn_legacy = -1;   // -1: env VDK_ATTN_LEGACY decides; 0 / 1: forced by vdk_attention_force_legacy (A/B benchmarking, tests of the long-sequence kernels at small N)
+static thread_local int g_attn_legacy = -1;   // -1: env VDK_ATTN_LEGACY decides; 0 / 1: forced by vdk_attention_force_legacy (A/B benchmarking, tests of the long-sequence kernels at small N)
 static bool attn_legacy() {
   if (g_attn_legacy >= 0) return g_attn_legacy == 1;
   const char* e = getenv("VDK_ATTN_LEGACY");

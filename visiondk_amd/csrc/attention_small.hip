@@ -1047,7 +1047,7 @@ static int launch_bwd5(const bf16_t* base, long D, long ld, const bf16_t* o, con
   }
   return VDK_OK;
 }
-static int g_bwd_form = -1;        // -1: environment VDK_ATTN_BWD_FORM (default 5); 5 = one pass, dS exchanged between the waves, dQ split by output block; 4 = one pass with partial dQ tiles + a reducer wave (slower); 3 = split recompute form (two kernels, 2 workgroups / CU); 2 = one-kernel recompute form; 1 = fused form with the shared dQ tile
+static thread_local int g_bwd_form = -1;        // -1: environment VDK_ATTN_BWD_FORM (default 5); 5 = one pass, dS exchanged between the waves, dQ split by output block; 4 = one pass with partial dQ tiles + a reducer wave (slower); 3 = split recompute form (two kernels, 2 workgroups / CU); 2 = one-kernel recompute form; 1 = fused form with the shared dQ tile
 int vdk_attention_small_bwd_form(int form) { g_bwd_form = form; return VDK_OK; }
 
 static int grid_cap(int dflt);

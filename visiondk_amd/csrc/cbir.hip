@@ -886,9 +886,15 @@ __global__ void cbir_fill_from_lists_kernel(CbirCand cand, const float* __restri
 }
 
 // ---- second stream + events of the pipelined schedule (created once per process; timing disabled) ------------------------------------------------------
+// (per calling thread AND per device: a stream / event belongs to the device that was current when it was created; one process per GPU is the usual host, a multi-device
+//  process gets one set per device)
+#include <map>
 #include <vector>
-static hipStream_t g_cb_s2 = nullptr;
-static std::vector<hipEvent_t> g_cb_ev;
+struct CbSide { hipStream_t s2 = nullptr; std::vector<hipEvent_t> ev; };
+static thread_local std::map<int, CbSide> g_cb_side;
+static CbSide& cb_side() { int dev = 0; (void)hipGetDevice(&dev); return g_cb_side[dev]; }
+#define g_cb_s2 (cb_side().s2)
+#define g_cb_ev (cb_side().ev)
 static int g_cb_pipeline = -1;
 static bool cb_pipeline_enabled() {
   // default OFF: measured on the MI355X (10 k x 1 M x 128, k = 100) the pipelined schedule is SLOWER, 5.1 ms against 3.6 - 3.85 ms sequential -- the ranking

@@ -674,14 +674,16 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 // (hipExtLaunchKernelGGL: the timestamps of the dispatch packet's own completion signal -- no extra packets in the queue; bracketing with hipEventRecord cost
 // 1.0 ms of the 43 ms step, two marker packets around each of its 149 GEMMs); vdk_prof_end() synchronises and returns total GEMM time, launches and flops.
 #include <vector>
-static std::vector<hipEvent_t> g_prof_ev;
-static std::vector<double> g_prof_flops;
-static double g_prof_bytes = 0.0;   // algorithmic bytes of the profiled launches: every operand / output / epilogue tensor counted once
-static size_t g_prof_used = 0;
-static bool g_prof_on = false;
-static void* g_dbg_ptr = nullptr;
-static int g_force_kernel = 0;   // 0 auto, 1 = 128x128 register-staged, 2 = 256x256 LDS-DMA, 3 = 256x256 stream-K whenever a workspace is passed, 4 = never stream-K (tests / A-B benchmarking)
-static int g_sk_grid = 0;        // stream-K workgroups; 0 = one per CU of the current device
+// Tuning / test knobs and the profiling hooks are PER CALLING THREAD (no process-global mutable state on the compute path): a host thread that forces a kernel
+// structure or times its launches does not change what another thread's calls do.
+static thread_local std::vector<hipEvent_t> g_prof_ev;
+static thread_local std::vector<double> g_prof_flops;
+static thread_local double g_prof_bytes = 0.0;   // algorithmic bytes of the profiled launches: every operand / output / epilogue tensor counted once
+static thread_local size_t g_prof_used = 0;
+static thread_local bool g_prof_on = false;
+static thread_local void* g_dbg_ptr = nullptr;
+static thread_local int g_force_kernel = 0;   // 0 auto, 1 = 128x128 register-staged, 2 = 256x256 LDS-DMA, 3 = 256x256 stream-K whenever a workspace is passed, 4 = never stream-K (tests / A-B benchmarking)
+static thread_local int g_sk_grid = 0;        // stream-K workgroups; 0 = one per CU of the current device
 static thread_local int g_last_kernel = 0;
 // which 256x256 structure serves the big problems: the 4-wave kernel of gemm_w4.hip (default) or the 8-wave kernel above (VDK_GEMM_W4=0, vdk_gemm_force_kernel(2 / 3);
 // vdk_gemm_force_kernel(5) = the 4-wave kernel whenever it can serve)

@@ -331,11 +331,14 @@ __global__ void vit_fp8_update_kernel(float* __restrict__ amax, float* __restric
   amax[i] = 0.f;
 }
 
-// Events that order the main (dgrad) stream and the side (wgrad) stream of vdk_vit_backward.  Created once per process,
+// Events that order the main (dgrad) stream and the side (wgrad) stream of vdk_vit_backward.  Created once per (thread, device),
 // timing disabled, re-recorded on every call (the only library-owned state; streams and memory stay the caller's).
+#include <map>
 #include <vector>
-static std::vector<hipEvent_t> g_ev;
+static thread_local std::map<int, std::vector<hipEvent_t>> g_ev_dev;      // per calling thread and per device (an event belongs to the device current at its creation)
 static int ev_get(size_t i, hipEvent_t* e) {
+  int dev = 0; (void)hipGetDevice(&dev);
+  std::vector<hipEvent_t>& g_ev = g_ev_dev[dev];
   while (g_ev.size() <= i) {
     hipEvent_t x;
     if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vit: hipEventCreate failed");
