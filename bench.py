@@ -98,7 +98,7 @@ def pmc_traffic_per_launch():
     """HBM-side bytes per GEMM launch from the committed PMC passes of this same command (rocprofv3 cannot run inside the timed process):
     profiles/r0N_pmc_traffic.json is written by tools/pmc_traffic.py from two `rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE}` runs,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  None if the artifact is absent."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):      # the newest round's passes of this command
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):      # the newest round's passes of this command
         p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             with open(p) as f:
@@ -110,7 +110,7 @@ def pmc_traffic_per_launch():
 
 def pmc_cbir():
     """L2 memory-side bytes of one search from the committed PMC passes of tools/pmc_cbir.py (None if absent)"""
-    for name in ("r04_cbir_pmc.json", "r03_cbir_pmc.json", "r02_cbir_pmc.json"):
+    for name in ("r05_cbir_pmc.json", "r04_cbir_pmc.json", "r03_cbir_pmc.json", "r02_cbir_pmc.json"):
         p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             with open(p) as f:
@@ -302,6 +302,10 @@ def bench_cfg5(be, dev, batch: int = 128, steps: int = 3):
         out[key] = {"images_per_sec": batch / dt, "ms_per_step": dt * 1e3, "model_tflops": flop_img * batch * 2 / dt / 1e12, "loss": step.loss_value()}
         del step
     model.engine.enable_fp8(0)
+    # Which of the two is cfg5's number: BASELINE.json configs[4] says "fp8 MFMA", north_star says logits within 1e-3 of the reference.  The fp8 operand
+    # mode is two orders outside that tolerance (fp8_tolerance above: an e4m3 operand carries 2^-4 of rounding), its weight gradients still run in bf16 and its kernel is the
+    # eight-wave structure -- so the figure that stands for cfg5 is the 16-bit step, and fp8 stays an opt-in experiment reported beside it.
+    out["headline"] = {"key": "sam_bf16", "why": "fp8 operands miss the stated tolerance by ~100x (fp8_tolerance); the conforming 16-bit step is cfg5's figure, fp8 is reported beside it as an opt-in mode"}
     del model
     torch.cuda.empty_cache()
     return out
@@ -313,7 +317,8 @@ def bench_swin(be, dev, batch: int = 128, steps: int = 4):
     and a live check of a 2-stage Swin (logits and the worst parameter gradient) against the fp32 oracle (oracle/swin_ref.py, pinned against transformers.SwinModel)."""
     from oracle.swin_ref import SwinTransformerRef
     from visiondk_amd import swin, vit
-    out = {"workload": f"swin_base_patch4_window7_224, 37 classes (pet.yaml), batch {batch}: fwd + CE(ls 0.05) + bwd + clip_grad_norm_ + SGD + EMA (native engine, fused step)", "dtype": "fp16 operands (the reference's autocast dtype), fp32 residual stream; bf16 beside it"}
+    out = {"workload": f"swin_base_patch4_window7_224, 37 classes (pet.yaml), batch {batch}: fwd + CE(ls 0.05) + bwd + clip_grad_norm_ + SGD + EMA (native engine, fused step)", "dtype": "fp16 operands (the reference's autocast dtype), fp32 residual stream; bf16 beside it",
+           "drop_path_rate": 0.1}      # timm's default for the family: stochastic depth is ON in the timed steps, as it is in the reference's training loop
     torch.manual_seed(0)
     ref = SwinTransformerRef(img_size=224, num_classes=7, embed_dim=32, depths=(2, 2), heads=(1, 2))
     with torch.no_grad():

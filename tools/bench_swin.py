@@ -45,4 +45,4 @@ losses.append(value(l))
 flop = 3 * 15.47e9 * B
 print(json.dumps({"workload": f"swin_base_patch4_window7_224, 37 classes, bs {B}: fwd + CE + bwd + clip + SGD" + (" + EMA (native engine + fused step)" if form == "native" else
                                                                                                                 " (autograd nodes over the HIP kernels + torch SGD)"),
-                  "operand": operand, "ms_per_step": dt * 1e3, "images_per_sec": B / dt, "model_tflops": flop / dt / 1e12, "losses": losses, "max_mem_gib": torch.cuda.max_memory_allocated() / 2**30}))
+                  "operand": operand, "drop_path_rate": getattr(getattr(model, "engine", None), "drop_path_rate", 0.0), "ms_per_step": dt * 1e3, "images_per_sec": B / dt, "model_tflops": flop / dt / 1e12, "losses": losses, "max_mem_gib": torch.cuda.max_memory_allocated() / 2**30}))

@@ -26,7 +26,7 @@ rocprofv3 --kernel-trace --stats -d /tmp/c_trace -o t -- python $R/tools/cbir_pm
 python $R/tools/rocpd_stats.py $(find /tmp/c_trace -name "*.db" | head -1) > $O/cbir_kernel_stats.txt
 tail -8 $O/cbir_pmc.txt
 cd $R
-cp $O/pmc_traffic.json profiles/r04_pmc_traffic.json 2>/dev/null; cp $O/cbir_pmc.json profiles/r04_cbir_pmc.json 2>/dev/null    # the bench line below reads them
+cp $O/pmc_traffic.json profiles/r05_pmc_traffic.json 2>/dev/null; cp $O/cbir_pmc.json profiles/r05_cbir_pmc.json 2>/dev/null    # the bench line below reads them
 T0=$(date +%s); python bench.py > $O/bench_stdout.txt 2> $O/bench_stderr.txt; echo "default bench.py wall: $(( $(date +%s) - T0 )) s" | tee $O/bench_wall.txt
 tail -1 $O/bench_stdout.txt > $O/bench.json
 python -c "
@@ -38,3 +38,9 @@ rocprofv3 --kernel-trace --stats -d /tmp/s_trace -o t -- python $R/tools/bench_s
 python $R/tools/rocpd_stats.py $(find /tmp/s_trace -name "*.db" | head -1) > $O/swin_kernel_stats.txt
 python $R/tools/rocpd_seq.py $(find /tmp/s_trace -name "*.db" | head -1) > $O/swin_step_sequence.txt
 python $R/tools/bench_cfg3.py 512 5 > $O/cfg3.json 2>/dev/null; cat $O/cfg3.json
+rocprofv3 --kernel-trace --stats -d /tmp/f_trace -o t -- python $R/tools/bench_cfg3.py 512 3 > $O/cfg3_trace_stdout.txt 2>&1
+python $R/tools/rocpd_stats.py $(find /tmp/f_trace -name "*.db" | head -1) > $O/cfg3_kernel_stats.txt
+# housekeeping re-timings on the current build: cfg1 (ResNet-18 plumbing config), the ConvNeXt-B classifier, cfg4's embedding extraction, the one-GPU overlap probe
+python $R/tools/bench_cfg1.py 32 20 > $O/cfg1.json 2>/dev/null; cat $O/cfg1.json
+python $R/tools/bench_cfg4.py 2048 256 > $O/cfg4.json 2>/dev/null; cat $O/cfg4.json
+python $R/tools/overlap_probe.py 256 150 2>/dev/null | grep '^{' > $O/overlap.json; cut -c1-300 $O/overlap.json
