@@ -719,6 +719,8 @@ static bool w4h_wanted(int E, bool trans, long M, long N, long K) {
   if (tiles < 128) return true;
   if (E & E_DGELU) return true;
   // GELU: the four-wave kernel's whole-tile rounds against hardware-dispatched half tiles -- 25 088 x 2048 x 512 (stage 3) is 784 tiles = 3.06 rounds, 99 / 90 us
+  static const long gelu_k = getenv("VDK_GEMM_W4H_GELU_K") ? atol(getenv("VDK_GEMM_W4H_GELU_K")) : 0;      // A/B: GELU problems with K <= this go to the two-workgroup form
+  if ((E & E_GELU) && gelu_k > 0 && K <= gelu_k) return true;
   if (E & E_GELU) return K <= 768 && (double)tiles / (double)((tiles + 255) / 256 * 256) < 0.8;
   if (E & E_RES) return K < 1536;
   return K <= 1024 && tiles <= 3 * 256;
