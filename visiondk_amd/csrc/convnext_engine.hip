@@ -69,6 +69,16 @@ namespace {
 // operand format of the running call (VdkConvNextConfig.operand), set at every entry point as in vit_engine.hip / swin_engine.hip; DT16 = the dtype code of the 16-bit tensors
 thread_local int t_opf = VDK_OPF_BF16;
 #define DT16 (t_opf ? VDK_F16 : VDK_BF16)
+// What a block keeps in `u` for the backward (as csrc/vit_engine.hip): the pre-activation in the operand format, or fp16 GELU'(pre-activation) from the fc1 epilogue, so that
+// the dfc2 epilogue is one multiplication.  At ConvNeXt's K = 128 .. 1024 the GELU GEMMs are epilogue-bound and the trade pays: cfg3 109.55 -> 108.53 ms in two interleaved
+// rounds on one box.  DEFAULT with fp16 operands, where it costs no accuracy (u is rounded to fp16 either way; the parity at C = 10^6 is unchanged: worst gradient 4.09e-3
+// against 4.07e-3); bf16 operands keep rounds 1-4's arithmetic.  VDK_CN_GELU_SAVED_GRAD=0 / 1 forces it off / on for both formats.
+bool cn_saved_grad() {
+  static const int v = [] { const char* e = getenv("VDK_CN_GELU_SAVED_GRAD"); return e ? atoi(e) : -1; }();
+  return v < 0 ? t_opf != 0 : v != 0;
+}
+#define CN_ACT_FC1 (cn_saved_grad() ? VDK_ACT_GELU_SAVE_GRAD : VDK_ACT_GELU)
+#define CN_ACT_DFC2 (cn_saved_grad() ? VDK_ACT_MUL_AUX : VDK_ACT_DGELU)
 
 struct CnDims {
   int opf;                // VDK_OPF_BF16 | VDK_OPF_F16
@@ -416,7 +426,7 @@ int vdk_convnext_forward(const VdkConvNextConfig* cfg, const float* x, const flo
       float* t = (float*)(base + bw.t); float* st = (float*)(base + bw.stats);
       RC(vdk_dwconv7_fwd(xin, (const float*)(xb + bx.dwt), params + b.dw_b, nullptr, t, nullptr, d.B, H, H, C, 0, s));
       RC(vdk_layernorm_fwd(t, C, R, C, params + b.nw, params + b.nb, d.eps, base + bw.h, C, DT16, st, st + R, s));
-      RC(gemm(s, base + bw.h, C, wb + b.fc1_w, C, base + bw.g, M, R, M, C, VDK_BF16, params + b.fc1_b, nullptr, 0, VDK_ACT_GELU, base + bw.u, M));
+      RC(gemm(s, base + bw.h, C, wb + b.fc1_w, C, base + bw.g, M, R, M, C, VDK_BF16, params + b.fc1_b, nullptr, 0, CN_ACT_FC1, base + bw.u, M));
       // fp16 operands: plain W2, gamma applied to the accumulators (col_scale), b2p = gamma (.) b2; bf16: gamma folded into fc2p
       RC(gemm(s, base + bw.g, M, xb + bx.fc2p, M, xout, C, R, C, M, VDK_F32, (const float*)(xb + bx.b2p), xin, C, VDK_ACT_NONE, nullptr, 0, t_opf ? params + b.gamma : nullptr));
     }
@@ -492,7 +502,7 @@ int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout_, const
       const int xrow = vdk_gemm_c_colsum_rows(R, M, C);
       if (xrow > 0 && (size_t)xrow * M * 4 <= w.csws_bytes) {
         VdkGemmDesc g = {};
-        g.A = dxb; g.lda = C; g.B = xb + bx.fc2pt; g.ldb = C; g.C = du; g.ldc = M; g.M = R; g.N = M; g.K = C; g.c_dtype = DT16; g.act = VDK_ACT_DGELU; g.aux = base + bw.u;
+        g.A = dxb; g.lda = C; g.B = xb + bx.fc2pt; g.ldb = C; g.C = du; g.ldc = M; g.M = R; g.N = M; g.K = C; g.c_dtype = DT16; g.act = CN_ACT_DFC2; g.aux = base + bw.u;
         g.ldaux = M; g.alpha = 1.0f; g.splitk = 1; g.c_colsum = (float*)(base + w.csws); g.ab_dtype = DT16;
         RC(vdk_gemm_bf16_nt(&g, nullptr, 0, s));
         // The block's four small reductions (fc1.bias from the dGELU epilogue's column sums, the fc2' bias column sums, LayerNorm dgamma | dbeta, depthwise dw | db) run as
@@ -532,7 +542,7 @@ int vdk_convnext_backward(const VdkConvNextConfig* cfg, const void* dout_, const
         RC(fc1_unscale());
         RC(vdk_layerscale_grad(dw2p, db2p, params + b.fc2_w, params + b.fc2_b, params + b.gamma, grads + b.fc2_w, grads + b.fc2_b, grads + b.gamma, C, M, s));
       } else {
-      RC(dgrad_with_bias(s, w, base, dxb, xb + bx.fc2pt, du, R, M, C, VDK_ACT_DGELU, base + bw.u, db2p, &fz));
+      RC(dgrad_with_bias(s, w, base, dxb, xb + bx.fc2pt, du, R, M, C, CN_ACT_DFC2, base + bw.u, db2p, &fz));
       RC(linear_wgrad(s, w, base, dxb, (const bf16_t*)(base + bw.g), R, C, M, dw2p, (fz || t_opf) ? nullptr : db2p));
       if (t_opf) RC(vdk_colsum_f32(dxa, C, R, C, db2p, base + w.csws2, w.csws_bytes, s));
       RC(vdk_layerscale_grad(dw2p, db2p, params + b.fc2_w, params + b.fc2_b, params + b.gamma, grads + b.fc2_w, grads + b.fc2_b, grads + b.gamma, C, M, s));
