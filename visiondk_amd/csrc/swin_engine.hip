@@ -55,6 +55,12 @@ namespace {
 // vit_engine.hip.  DT16 = the dtype code of the 16-bit tensors.
 thread_local int t_opf = VDK_OPF_BF16;
 #define DT16 (t_opf ? VDK_F16 : VDK_BF16)
+// the MLP's saved tensor `u`: the pre-activation, or (default with fp16 operands, as in vit_engine.hip / convnext_engine.hip; VDK_SWIN_GELU_SAVED_GRAD=0 / 1 forces it) fp16
+// GELU'(pre-activation) written by the fc1 epilogue, which turns the dfc2 epilogue into one multiplication
+bool sw_saved_grad() {
+  static const int v = [] { const char* e = getenv("VDK_SWIN_GELU_SAVED_GRAD"); return e ? atoi(e) : -1; }();
+  return v < 0 ? t_opf != 0 : v != 0;
+}
 
 struct SwDims {
   int B, img, Cin, E, depth[4], heads[4], dim[4], res[4], nblk;
@@ -501,7 +507,7 @@ int vdk_swin_forward(const VdkSwinConfig* cfg, const float* x, const float* para
       RC(gemm(s, o, C, wb + b.proj_w, C, xmid, C, T, C, C, VDK_F32, params + b.proj_b, xin, C, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0, nullptr, dp1, tpi));
       // x = x + fc2(gelu(fc1(norm2(x))))
       RC(vdk_layernorm_fwd(xmid, C, T, C, params + b.n2w, params + b.n2b, d.eps, h2, C, DT16, st + 2 * (size_t)T, st + 3 * (size_t)T, s));
-      RC(gemm(s, h2, C, wb + b.fc1_w, C, g, M, T, M, C, DT16, params + b.fc1_b, nullptr, 0, VDK_ACT_GELU, u, M, 1, nullptr, 0));
+      RC(gemm(s, h2, C, wb + b.fc1_w, C, g, M, T, M, C, DT16, params + b.fc1_b, nullptr, 0, sw_saved_grad() ? VDK_ACT_GELU_SAVE_GRAD : VDK_ACT_GELU, u, M, 1, nullptr, 0));
       RC(gemm(s, g, M, wb + b.fc2_w, M, xout, C, T, C, M, VDK_F32, params + b.fc2_b, xmid, C, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0, nullptr, dp2, tpi));
     }
     xprev = (const float*)(base + sw_.xout);
@@ -586,7 +592,7 @@ int vdk_swin_backward(const VdkSwinConfig* cfg, const void* dout, const float* p
       const int xrow = vdk_gemm_c_colsum_rows(T, M, C);
       const bool fo = xrow > 0 && (size_t)xrow * M * 4 <= w.csws_bytes;
       float* part1 = (float*)csws(0);
-      RC(gemm(s, dxab, C, wt + b.t2, C, du, M, T, M, C, DT16, nullptr, nullptr, 0, VDK_ACT_DGELU, u, M, 1, nullptr, 0, fo ? part1 : nullptr));   // du
+      RC(gemm(s, dxab, C, wt + b.t2, C, du, M, T, M, C, DT16, nullptr, nullptr, 0, sw_saved_grad() ? VDK_ACT_MUL_AUX : VDK_ACT_DGELU, u, M, 1, nullptr, 0, fo ? part1 : nullptr));   // du
       if (fo) jobs[nj++] = VdkReduceJob{part1, (long)M, xrow, (long)M, grads + b.fc1_b, 1.0f};
       // fc2.bias = column sums of dxab: a by-product of the LayerNorm backward that stored it (norm1 of the block after this one, below), except for a stage's last block
       const bool fc2b_done = C <= 1024 && j + 1 < d.depth[i];

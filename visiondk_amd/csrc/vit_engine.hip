@@ -56,9 +56,11 @@ static thread_local int t_opf = VDK_OPF_BF16;
 // What the MLP keeps for the backward pass in `u` [T, mlp_dim]: the pre-activation in the operand format (the backward evaluates GELU' of it inside the dfc2 epilogue), or --
 // VDK_VIT_GELU_SAVED_GRAD=1 -- GELU'(pre-activation) evaluated once in the fc1 epilogue from the SAME erf / exp terms as GELU itself and stored as fp16 (the backward's
 // epilogue is then one multiplication).  Measured per layer at ViT-B/16 (profiles/r03_gemm_ab.json): forward 305 -> 332 us, backward 321 -> 282 us.
+// Round 5: DEFAULT with fp16 operands -- `u` is rounded to fp16 either way, so the saved derivative costs no accuracy there (logits are bit-identical: the forward's GELU value
+// does not change), and the step gains what round 4 measured; bf16 operands keep the pre-activation.  VDK_VIT_GELU_SAVED_GRAD=0 / 1 forces it for both formats.
 static bool gelu_saved_grad() {
-  static const int v = [] { const char* e = getenv("VDK_VIT_GELU_SAVED_GRAD"); return e ? atoi(e) : 0; }();
-  return v != 0;
+  static const int v = [] { const char* e = getenv("VDK_VIT_GELU_SAVED_GRAD"); return e ? atoi(e) : -1; }();
+  return v < 0 ? t_opf != 0 : v != 0;
 }
 #define ACT_FC1 (gelu_saved_grad() ? VDK_ACT_GELU_SAVE_GRAD : VDK_ACT_GELU)
 #define ACT_DFC2 (gelu_saved_grad() ? VDK_ACT_MUL_AUX : VDK_ACT_DGELU)
