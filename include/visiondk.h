@@ -106,6 +106,10 @@ int vdk_cbir_merge_topk(const float* scores, const int64_t* idx, int32_t S, int6
  * (rows = input pixels, A = dY [B, H, W, Cin=Cout], source pixel (oy + pad - ky)/stride when it divides).  Cin % 8 == 0; K == KH*KW*Cin. */
 typedef struct VdkConvGeom {
   int32_t Cin, H, W, OH, OW, KH, KW, stride, pad, transposed;
+  int32_t rows;   /* VdkGemmDesc.trans = 1 only -- the WEIGHT GRADIENT of the convolution without an im2col matrix: A = dY [rows, Cout] (row m = (b, oy, ox), lda = Cout), B = the
+                   * NHWC input [batch, H, W, Cin] gathered on the fly as the k-major im2col operand [rows, KH*KW*Cin] (ldb ignored), C = dW' f32 [Cout, KH*KW*Cin] (column
+                   * order of vdk_conv_weight_prep; vdk_conv_wgrad_unpermute brings it back to [Cout][Cin][KH][KW]).  rows = batch * OH * OW (< 2^24) is the number of VALID
+                   * contraction rows; VdkGemmDesc.K is that number rounded up to a multiple of 128 (rows beyond `rows` read as zeros).  transposed = 0, N = KH*KW*Cin. */
 } VdkConvGeom;
 typedef struct VdkGemmDesc {
   const void* A; int64_t lda;

@@ -32,6 +32,25 @@ def test_implicit_conv_fwd_dgrad_wgrad(be, dev, B, Ci, Co, H, W, k, s, p):
     dwp = (dyb.view(-1, Co).float().t() @ col.float())                                   # the GEMM itself is covered by test_gemm; here the layouts
     dw = ops.conv_wgrad_unpermute(dwp.contiguous(), Ci, k, k, backend=be)
     torch.testing.assert_close(dw.cpu(), wr.grad, rtol=1e-4, atol=1e-3)
+    # the engine's form: no im2col matrix, the TN kernel gathers its B tiles from the NHWC input (VdkConvGeom.rows) -- whole and split along the pixels
+    for sk in (1, 2):
+        dwi = ops.conv_wgrad_implicit(dyb.view(-1, Co), a, oh=OH, ow=OW, kh=k, kw=k, stride=s, pad=p, splitk=sk, backend=be)
+        torch.testing.assert_close(dwi.cpu(), dwp.cpu(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,k,s,p", [(5, 40, 264, 13, 3, 1, 1), (3, 72, 16, 21, 3, 2, 1)])
+def test_implicit_wgrad_several_tiles_and_ragged_rows(be, dev, B, Ci, Co, H, k, s, p):
+    """More than one 256-column tile of taps x channels (a tile boundary inside a tap), more than one 256-row tile of output channels, several k-tiles with a ragged last one
+    (rows not a multiple of 64), split-K: the gathered weight gradient equals dY^T . im2col(x) of the explicit matrix."""
+    torch.manual_seed(3)
+    OH = (H + 2 * p - k) // s + 1
+    a = torch.randn(B, H, H, Ci).bfloat16().to(dev)
+    dyb = torch.randn(B * OH * OH, Co).bfloat16().to(dev)
+    col = ops.im2col(a, OH, OH, k, k, s, p, backend=be)
+    want = dyb.float().cpu().t() @ col.float().cpu()
+    for sk in (1, 3):
+        got = ops.conv_wgrad_implicit(dyb, a, oh=OH, ow=OH, kh=k, kw=k, stride=s, pad=p, splitk=sk, backend=be)
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-4, atol=2e-3)
 
 
 @pytest.mark.parametrize("R,C,res_dtype,relu", [(300, 16, None, True), (1000, 72, torch.bfloat16, True), (520, 8, torch.float32, True), (257, 64, None, False)])
@@ -127,5 +146,8 @@ def test_resnet18_convs_at_bench_shapes_on_identical_bf16_operands(hip, name, Ci
         dwp = ops.gemm_nt(ops.transpose_pad(dyb.view(rows, Co), rpad=rp, backend=be), ops.transpose_pad(col, rpad=rp, backend=be), out_dtype=torch.float32, splitk=sk, backend=be)
     dw = ops.conv_wgrad_unpermute(dwp, Ci, k, k, backend=be)
     e_wgrad = rel(dw, wr.grad)
-    print(name, {"fwd": e_fwd, "dgrad": e_dgrad, "wgrad": e_wgrad})
-    assert e_fwd < 1e-5 and e_dgrad < 1e-5 and e_wgrad < 1e-5, (name, e_fwd, e_dgrad, e_wgrad)
+    # the form the engine runs: the im2col operand gathered inside the TN kernel
+    dwi = ops.conv_wgrad_implicit(dyb.view(rows, Co), a, oh=OH, ow=OH, kh=k, kw=k, stride=s, pad=p, splitk=max(1, min(16, rows // 4096)), backend=be)
+    e_wgrad_i = rel(ops.conv_wgrad_unpermute(dwi, Ci, k, k, backend=be), wr.grad)
+    print(name, {"fwd": e_fwd, "dgrad": e_dgrad, "wgrad": e_wgrad, "wgrad_implicit": e_wgrad_i})
+    assert e_fwd < 1e-5 and e_dgrad < 1e-5 and e_wgrad < 1e-5 and e_wgrad_i < 1e-5, (name, e_fwd, e_dgrad, e_wgrad, e_wgrad_i)

@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
 
 class ConvGeom(C.Structure):
     """VdkConvGeom of include/visiondk.h"""
-    _fields_ = [("Cin", I32), ("H", I32), ("W", I32), ("OH", I32), ("OW", I32), ("KH", I32), ("KW", I32), ("stride", I32), ("pad", I32), ("transposed", I32)]
+    _fields_ = [("Cin", I32), ("H", I32), ("W", I32), ("OH", I32), ("OW", I32), ("KH", I32), ("KW", I32), ("stride", I32), ("pad", I32), ("transposed", I32), ("rows", I32)]
 
 
 class VitConfig(C.Structure):

@@ -866,9 +866,14 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   }
   if (d->conv) {
     const VdkConvGeom* c = d->conv;
-    if (d->trans || c->Cin <= 0 || (c->Cin & 7) || c->KH <= 0 || c->KW <= 0 || c->stride <= 0 || c->pad < 0 || c->OH <= 0 || c->OW <= 0 || c->H <= 0 || c->W <= 0 ||
-        d->K != c->KH * c->KW * c->Cin || (d->M % (c->OH * c->OW)))
-      return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad convolution geometry (Cin % 8 == 0, K == KH*KW*Cin, M == B*OH*OW)");
+    if (c->Cin <= 0 || (c->Cin & 7) || c->KH <= 0 || c->KW <= 0 || c->stride <= 0 || c->pad < 0 || c->OH <= 0 || c->OW <= 0 || c->H <= 0 || c->W <= 0)
+      return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad convolution geometry (Cin % 8 == 0)");
+    if (!d->trans && (d->K != c->KH * c->KW * c->Cin || (d->M % (c->OH * c->OW))))
+      return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad convolution geometry (K == KH*KW*Cin, M == B*OH*OW)");
+    // trans = 1: the weight gradient with the im2col operand gathered on the fly (VdkConvGeom.rows); the four-wave TN kernel serves it
+    if (d->trans && (c->transposed || d->N != c->KH * c->KW * c->Cin || c->rows <= 0 || c->rows >= (1 << 24) || (c->rows % (c->OH * c->OW)) || d->K < c->rows || (d->K % 128) ||
+                     d->K - c->rows >= 128 || d->ab_dtype != VDK_BF16 || d->a_row_group != 0))
+      return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad weight-gradient geometry (N == KH*KW*Cin, rows == B*OH*OW < 2^24, K == rows rounded up to 128, bf16)");
   }
   if (d->ab_dtype != VDK_BF16 && d->ab_dtype != VDK_F16) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: ab_dtype must be VDK_BF16 or VDK_F16");
   const int opf = d->ab_dtype == VDK_F16 ? VDK_OPF_F16 : VDK_OPF_BF16;
@@ -899,6 +904,7 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   if (d->conv) {
     const VdkConvGeom* c = d->conv;
     p.cCin = c->Cin; p.cH = c->H; p.cW = c->W; p.cOH = c->OH; p.cOW = c->OW; p.cKH = c->KH; p.cKW = c->KW; p.cstride = c->stride; p.cpad = c->pad; p.ctrans = c->transposed;
+    p.crows = c->rows;
   }
   int kps = d->K;
   if (splitk > 1) {
@@ -989,7 +995,13 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
     else LAUNCH256X(false, EE, false);                                                                                   \
   } while (0)
   bool fp16_unserved = false;
-  if (d->trans) {
+  if (d->trans && d->conv) {      // the implicit weight gradient lives in the four-wave kernel only
+    if ((kps % 128) || (d->M & 7) || d->M < 8 || !vdk_gemm_w4_serves(p, true)) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: this implicit weight gradient is outside the four-wave TN kernel's range");
+    void* e0_ = prof ? (void*)g_prof_ev[g_prof_used] : nullptr; void* e1_ = prof ? (void*)g_prof_ev[g_prof_used + 1] : nullptr;
+    if (!vdk_gemm_w4_launch(p, true, E == E_SPLITK ? E_SPLITK : (E == E_F32 ? E_F32 : E_GENERIC), grid256.x, grid256.y, stream, e0_, e1_))
+      return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: implicit weight gradient: no kernel");
+    g_last_kernel = 5;
+  } else if (d->trans) {
     if ((d->K % 64) || (kps % 64) || (d->M & 7) || d->M < 8 || d->N < 8)
       return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: trans=1 needs K and the split size to be multiples of 64 and M % 8 == 0");
     switch (E) {

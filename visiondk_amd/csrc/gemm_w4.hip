@@ -96,13 +96,41 @@ struct W4Dma {
   unsigned kbeg;             // scalar: byte offset of a tile's first k-tile
   unsigned wave_off;         // scalar: this wave's share inside a tile, bytes
   unsigned ldb;              // scalar: operand row pitch, bytes
+  // conv != 0 (TN B operand of the implicit weight gradient, VdkConvGeom.rows): the k-major im2col operand [rows, KH*KW*Cin] is GATHERED from the NHWC input -- the source of
+  // a lane's 16 bytes is ((b H + oy stride + ky - pad) W + ox stride + kx - pad) Cin + ci for k-row (b, oy, ox) and column (ky, kx, ci), or nothing (zeros) in the padding.
+  // The lane's column part (cy / cx / cib per region half) is fixed per output tile; its k-row changes with every piece: two divisions by constants per piece and lane, in
+  // the shadow of the MFMAs.  `so0` of w4_piece is then the k-tile's first k-row (kstep = 64 rows, tile base 0), >= 2^31 once the cursor has run off the end.
+  int conv;
+  int cH, cW, cOW, cHW, cCin, cKW, cstride, cpad, crows, cN;
+  float inv_hw, inv_w;
+  unsigned w16, kr;          // 16 * wave, the lane's k-row inside a piece
+  unsigned ncol0;            // the lane's first column inside a 256-column tile for region half 0 (half 1: + 64)
+  int cy[2], cx[2]; unsigned cib[2]; int cok[2];
 };
+// n / d and n % d for 0 <= n < 2^24, d < 2^24: float quotient (exactly representable operands), corrected by at most one either way
+__device__ __forceinline__ void w4_divmod(unsigned n, int d, float inv, int& q, int& r) {
+  q = (int)((float)n * inv);
+  r = (int)n - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) { ++q; r -= d; }
+}
+// the lane's column part for the output tile whose first column is n0
+__device__ __forceinline__ void w4_conv_set_tile(W4Dma& d, int n0) {
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+    const int n = n0 + (int)d.ncol0 + sub * 64;
+    const int tap = n / d.cCin, ci = n - tap * d.cCin, ky = tap / d.cKW, kx = tap - ky * d.cKW;
+    d.cok[sub] = n < d.cN;
+    d.cy[sub] = ky - d.cpad; d.cx[sub] = kx - d.cpad; d.cib[sub] = (unsigned)ci * 2u;
+  }
+}
 
 template <bool TN>
 __device__ __forceinline__ void w4_dma_init(W4Dma& d, const bf16_t* base, long ld, int extent /* operand rows (NT) */, int K, int kbeg, int w, int lane,
                                             unsigned blk = 128u /* operand rows (NT) / columns (TN) between the two halves of a region: 128, or 64 for the 128-wide B of gemm_w4h_kernel */) {
   const unsigned ldb = (unsigned)ld * 2u;
   d.ldb = ldb;
+  d.conv = 0;
   if (!TN) {
     d.rs = w4_make_rsrc(base, (unsigned)extent * ldb);
     const unsigned i = (unsigned)lane >> 3, cp = (unsigned)lane & 7u;
@@ -131,6 +159,19 @@ __device__ __forceinline__ unsigned w4_tile_base(const W4Dma& d, int origin) {
 }
 // piece j of region `sub` of the k-tile at scalar offset so0 (tile base + k offset)
 __device__ __forceinline__ void w4_piece(const W4Dma& d, unsigned char* dst, int sub, int j, unsigned so0) {
+  if (d.conv) {      // (wave-uniform) gathered im2col operand: see W4Dma
+    const unsigned rr = so0 + d.w16 + 4u * (unsigned)j + d.kr;
+    unsigned voff = W4_OOB;
+    if (rr < (unsigned)d.crows && d.cok[sub]) {
+      int b, rem, oy, ox;
+      w4_divmod(rr, d.cHW, d.inv_hw, b, rem);
+      w4_divmod((unsigned)rem, d.cOW, d.inv_w, oy, ox);
+      const int iy = oy * d.cstride + d.cy[sub], ix = ox * d.cstride + d.cx[sub];
+      if ((unsigned)iy < (unsigned)d.cH && (unsigned)ix < (unsigned)d.cW) voff = (unsigned)(((b * d.cH + iy) * d.cW + ix) * d.cCin) * 2u + d.cib[sub];
+    }
+    W4_DMA16(d.rs, voff, dst, 0u);
+    return;
+  }
   const unsigned so = so0 + (unsigned)sub * d.sub_stride + (unsigned)j * d.piece_stride;
   W4_DMA16(d.rs, (j & 1) ? d.voff1 : d.voff0, dst, so);
 }
@@ -596,8 +637,19 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
   if (t_idx >= t_cnt || nk < 2) return;                   // (uniform: the whole workgroup leaves before any barrier)
 
   W4Dma da, db;
-  w4_dma_init<TN>(da, p.A, p.lda, p.M, p.K, kbeg, w, lane);
+  const bool convb = TN && p.conv_on;      // the implicit weight gradient: B gathered from the NHWC input, A's valid rows end at crows (K is crows rounded up)
+  w4_dma_init<TN>(da, p.A, p.lda, p.M, convb ? p.crows : p.K, kbeg, w, lane);
   w4_dma_init<TN>(db, p.B, p.ldb, p.N, p.K, kbeg, w, lane);
+  if (convb) {
+    db.conv = 1;
+    db.cH = p.cH; db.cW = p.cW; db.cOW = p.cOW; db.cHW = p.cOH * p.cOW; db.cCin = p.cCin; db.cKW = p.cKW; db.cstride = p.cstride; db.cpad = p.cpad; db.crows = p.crows; db.cN = p.N;
+    db.inv_hw = 1.0f / (float)db.cHW; db.inv_w = 1.0f / (float)db.cOW;
+    db.rs = w4_make_rsrc(p.B, (unsigned)((long)(p.crows / db.cHW) * p.cH * p.cW * p.cCin * 2));
+    db.w16 = (unsigned)(16 * w);
+    db.kr = (unsigned)lane >> 4;
+    { const unsigned cp = (unsigned)lane & 15u, c = cp ^ (4u * (db.kr & 3u)); db.ncol0 = (c >> 3) * 128u + (c & 7u) * 8u; }
+    db.kbeg = (unsigned)kbeg; db.kstep = 64u; db.wave_off = 0u;
+  }
   W4Frag<TN> F;
   w4_frag_init<TN>(F, wr, wc, lane);
 
@@ -607,6 +659,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
   {
     int tm_, tn_; w4_tile_rc(t_start + c_idx, ntn, ntm, p.band_cw, tm_, tn_);
     c_ta = w4_tile_base<TN>(da, tm_ * 256); c_tb = w4_tile_base<TN>(db, tn_ * 256);
+    if (convb) { c_tb = 0u; w4_conv_set_tile(db, tn_ * 256); }
   }
 #define W4_CURSOR_ADVANCE()                                                                                         \
   do {                                                                                                              \
@@ -616,6 +669,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
       if (c_idx < t_cnt) {                                                                                          \
         int tm_, tn_; w4_tile_rc(t_start + c_idx, ntn, ntm, p.band_cw, tm_, tn_);                                   \
         c_ta = w4_tile_base<TN>(da, tm_ * 256); c_tb = w4_tile_base<TN>(db, tn_ * 256);                             \
+        if (convb) { c_tb = 0u; w4_conv_set_tile(db, tn_ * 256); }                                                  \
         c_left = nk;                                                                                                \
       } else { c_ta = W4_OOB; c_tb = W4_OOB; c_left = 0x7fffffff; }                                                 \
     }                                                                                                               \
@@ -848,6 +902,11 @@ __global__ __launch_bounds__(256, 2) void gemm_w4h_kernel(GemmParams p) {
 bool vdk_gemm_w4_serves(const GemmParams& p, bool trans) {
   const double lim = 2147483648.0 - 65536.0;
   if (p.colsum_part || p.sk_cnt || p.a_row_group > 0) return false;
+  if (p.conv_on) {      // only the implicit weight gradient (TN, B gathered): input tensor and dY below 2 GB
+    if (!trans || (p.K % 128) || (p.k_per_split % 128) || p.K < 128) return false;
+    const double in_bytes = (double)(p.crows / (p.cOH * p.cOW)) * p.cH * p.cW * p.cCin * 2.0;
+    return in_bytes < lim && ((double)p.crows + 64.0) * (double)p.lda * 2.0 < lim && ((double)p.M + 256.0) * (double)p.ldc * 4.0 < lim;
+  }
   if ((p.K % 128) || (p.k_per_split % 128) || p.K < 128) return false;
   if (((double)p.M + 256.0) * (double)p.ldc * (p.c_dtype == VDK_F32 ? 4.0 : 2.0) >= lim || (p.aux && ((double)p.M + 256.0) * (double)p.ldaux * 2.0 >= lim) ||
       (p.residual && ((double)p.M + 256.0) * (double)p.ldr * 4.0 >= lim)) return false;   // rows leave through 32-bit buffer offsets whose upper half marks "out of range"
@@ -858,7 +917,7 @@ bool vdk_gemm_w4_serves(const GemmParams& p, bool trans) {
 // the 256x128 / two-workgroups-per-CU form: any whole number of k-tiles; same size limits
 bool vdk_gemm_w4h_serves(const GemmParams& p, bool trans) {
   const double lim = 2147483648.0 - 65536.0;
-  if (p.colsum_part || p.sk_cnt || p.a_row_group > 0) return false;
+  if (p.colsum_part || p.sk_cnt || p.a_row_group > 0 || p.conv_on) return false;
   if ((p.K % 64) || (p.k_per_split % 64) || p.K < 64) return false;
   if (((double)p.M + 256.0) * (double)p.ldc * (p.c_dtype == VDK_F32 ? 4.0 : 2.0) >= lim || (p.aux && ((double)p.M + 256.0) * (double)p.ldaux * 2.0 >= lim) ||
       (p.residual && ((double)p.M + 256.0) * (double)p.ldr * 4.0 >= lim)) return false;

@@ -5,7 +5,7 @@
 //
 // MI355X design: activations are NHWC (bf16 conv operands, f32 conv outputs kept for BatchNorm's backward); every convolution is an
 // implicit GEMM on the MFMA kernel (VdkGemmDesc.conv: the A tile is gathered from the NHWC tensor, no im2col buffer) in forward AND in the input gradient
-// (transposed gather of dY); only the weight gradient materialises an im2col matrix, because its contraction runs over pixels (TN GEMM dY^T . col).
+// (transposed gather of dY) AND in the weight gradient (TN GEMM dY^T . col whose col tiles the four-wave kernel gathers from the NHWC input: VdkConvGeom.rows).
 // BatchNorm + shortcut + ReLU is one fused pass (csrc/resnet_ops.hip).  One C call per forward, one per backward; no allocation, no sync.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -167,8 +167,8 @@ void rn_plan(const RnDims& d, WsPlan* w) {
   w->ap = w_take(cur, (size_t)d.Rp * d.stem.co * 2); w->apk = w_take(cur, (size_t)d.Rp * d.stem.co);   // pooled map and its argmax bytes
   size_t rc = (size_t)d.R0 * d.stem.co, colmax = (size_t)d.R0 * 49 * d.Cinp, dwpmax = (size_t)d.stem.co * 49 * d.Cinp, sl = 0, bn = 0, cs = 0, tr = 0;
   auto wg = [&](int out, int in, int rows) {
-    const int k1 = wgrad_splitk(out, in, (int)up(rows, 64)), k2 = wgrad_splitk_tn(out, in, rows);
-    const size_t b = (size_t)(k1 > k2 ? k1 : k2) * out * in * 4; if (b > sl) sl = b;
+    const int k1 = wgrad_splitk(out, in, (int)up(rows, 64)), k2 = wgrad_splitk_tn(out, in, rows), k3 = wgrad_splitk_tn(out, in, (int)up(rows, 128));
+    const size_t b = (size_t)(k1 > k2 ? (k1 > k3 ? k1 : k3) : (k2 > k3 ? k2 : k3)) * out * in * 4; if (b > sl) sl = b;
     size_t c2 = 0; vdk_colsum_bf16_workspace_bytes(rows, out, &c2);
     const size_t c1 = (size_t)((up(rows, 64) + 63) / 64) * out * 4;
     if (c2 > cs) cs = c2;
@@ -250,12 +250,27 @@ int linear_wgrad(hipStream_t s, const WsPlan& w, char* base, const bf16_t* dY, c
   if (db) RC(vdk_reduce_rows_f32(csp, out, (rp + 63) / 64, out, db, 1.0f, s));
   return VDK_OK;
 }
-// weight gradient of one convolution: explicit im2col of its input (the only im2col in the engine), TN GEMM, back to [Co][Ci][k][k]
+// weight gradient of one convolution, dW'[Co, KH*KW*Cip] = dY^T . im2col(input).  The im2col operand is never written: the four-wave TN kernel gathers its B tiles from the
+// NHWC input (VdkConvGeom.rows); VDK_RN_WGRAD_IM2COL=1 (A/B switch) or a geometry that kernel refuses takes the explicit im2col + TN GEMM instead.  Then back to [Co][Ci][k][k].
+bool rn_wgrad_implicit() {
+  static const bool on = [] { const char* e = getenv("VDK_RN_WGRAD_IM2COL"); return !(e && e[0] == '1'); }();
+  return on;
+}
 int conv_wgrad(hipStream_t s, const WsPlan& w, char* base, const Conv& c, int B, const bf16_t* dY, const void* in_nhwc, float* dW) {
-  bf16_t* col = (bf16_t*)(base + w.col);
   float* dwp = (float*)(base + w.dwp);
+  const int rows = B * c.hout * c.hout, N = c.k * c.k * c.cip;
+  if (rn_wgrad_implicit() && rows < (1 << 24) && !(c.co & 7)) {
+    VdkConvGeom g = {c.cip, c.hin, c.hin, c.hout, c.hout, c.k, c.k, c.s, c.p, 0, rows};
+    VdkGemmDesc d = {};
+    d.A = dY; d.lda = c.co; d.B = in_nhwc; d.ldb = N; d.C = dwp; d.ldc = N; d.M = c.co; d.N = N; d.K = (int)up(rows, 128); d.c_dtype = VDK_F32; d.alpha = 1.0f;
+    d.splitk = wgrad_splitk_tn(c.co, N, d.K); d.trans = 1; d.conv = &g;
+    const int rc = vdk_gemm_bf16_nt(&d, base + w.slabs, w.slabs_bytes, s);
+    if (rc == VDK_OK) return vdk_conv_wgrad_unpermute(dwp, dW, c.co, c.ci, c.cip, c.k, c.k, s);
+    if (rc != VDK_EUNSUPPORTED) return rc;
+  }
+  bf16_t* col = (bf16_t*)(base + w.col);
   RC(vdk_im2col_bf16(in_nhwc, col, B, c.hin, c.hin, c.cip, c.hout, c.hout, c.k, c.k, c.s, c.p, s));
-  RC(linear_wgrad(s, w, base, dY, col, B * c.hout * c.hout, c.co, c.k * c.k * c.cip, dwp, nullptr));
+  RC(linear_wgrad(s, w, base, dY, col, rows, c.co, N, dwp, nullptr));
   return vdk_conv_wgrad_unpermute(dwp, dW, c.co, c.ci, c.cip, c.k, c.k, s);
 }
 

@@ -26,6 +26,7 @@ struct GemmParams {
   float* colsum_part;        // 256-kernel, NT only: per (row tile, wave) column sums of A, f32 [ceil(M/256)*8][K] (bias gradient fused into the dgrad GEMM)
   // implicit-GEMM convolution (conv_on): A is an NHWC tensor gathered on the fly, see VdkConvGeom
   int conv_on, cCin, cH, cW, cOH, cOW, cKH, cKW, cstride, cpad, ctrans;
+  int crows;                 // conv_on with TN (the weight gradient): valid contraction rows = batch * OH * OW; K is crows rounded up (VdkConvGeom.rows)
   // E_Q8: an fp8 copy of the stored bf16 output rides along (the A operand of the next fp8 GEMM: no separate quantisation pass over the tensor)
   unsigned char* q8; long ldq8; const float* q8_scale; float* q8_amax; int q8_fmt;
   MarginEpi me;              // E_MSTAT / E_MGRAD epilogues (margin-softmax head: cos tiles never leave the registers as fp32)

@@ -588,6 +588,25 @@ def conv_gemm(a_nhwc: torch.Tensor, wmat: torch.Tensor, *, oh: int, ow: int, kh:
     return out
 
 
+def conv_wgrad_implicit(dy: torch.Tensor, a_nhwc: torch.Tensor, *, oh: int, ow: int, kh: int, kw: int, stride: int, pad: int, splitk: int = 1, backend=None) -> torch.Tensor:
+    """dW' f32 [Co, kh*kw*Cin] = dy^T . im2col(a): dy bf16 [B*oh*ow, Co], a bf16 [B,H,W,Cin]; the im2col operand is gathered inside the TN GEMM (VdkConvGeom.rows)."""
+    be = _be(backend)
+    B, H, W, Cin = a_nhwc.shape
+    rows, Co = dy.shape
+    assert rows == B * oh * ow and dy.is_contiguous() and a_nhwc.is_contiguous()
+    N = kh * kw * Cin
+    out = torch.empty((Co, N), dtype=torch.float32, device=dy.device)
+    geom = _abi.ConvGeom(Cin, H, W, oh, ow, kh, kw, stride, pad, 0, rows)
+    d = _abi.GemmDesc()
+    d.A, d.lda, d.B, d.ldb, d.C, d.ldc = dy.data_ptr(), Co, a_nhwc.data_ptr(), N, out.data_ptr(), N
+    d.M, d.N, d.K = Co, N, (rows + 127) // 128 * 128
+    d.c_dtype, d.act, d.alpha, d.splitk, d.trans = _abi.F32_, ACT_NONE, 1.0, splitk, 1
+    d.conv = C.cast(C.pointer(geom), C.c_void_p)
+    ws = torch.empty((max(splitk, 1) * Co * N + 64,), dtype=torch.float32, device=dy.device)
+    be.check(be.lib.vdk_gemm_bf16_nt(C.byref(d), be.ptr(ws), ws.numel() * 4, be.stream()), "vdk_gemm_bf16_nt(conv wgrad)")
+    return out
+
+
 def im2col(a_nhwc: torch.Tensor, oh: int, ow: int, kh: int, kw: int, stride: int, pad: int, backend=None) -> torch.Tensor:
     be = _be(backend)
     B, H, W, Cc = a_nhwc.shape
