@@ -297,43 +297,56 @@ void sw_plan(const SwDims& d, WsPlan* w) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------- small kernels
-// token (window w = (b, wy, wx), j = (ty, tx)) of the window partition of the map rolled by -shift lives in image-order row  b res^2 + ((7 wy + ty + shift) mod res) res + (7 wx + tx + shift) mod res
-__global__ __launch_bounds__(256) void swin_rowidx_kernel(int* __restrict__ out, int B, int res, int shift) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const long n = (long)B * res * res;
-  if (i >= n) return;
-  const int nw = res / SW_WS;
-  const int j = (int)(i % SW_N);
-  const long wi = i / SW_N;
-  const int wx = (int)(wi % nw), wy = (int)((wi / nw) % nw), b = (int)(wi / ((long)nw * nw));
-  const int y = (SW_WS * wy + j / SW_WS + shift) % res, x = (SW_WS * wx + j % SW_WS + shift) % res;
-  out[i] = (int)((long)b * res * res + (long)y * res + x);
-}
-// timm's attn_mask of a shifted block: region ids of the rolled frame (rows / columns < res - 7, < res - shift, rest), 0 inside a region pair, -100 across
-__global__ __launch_bounds__(256) void swin_mask_kernel(float* __restrict__ mask, int res, int shift) {
-  const int nw = res / SW_WS;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long)nw * nw * SW_N * SW_N) return;
-  const int kj = (int)(i % SW_N), qi = (int)((i / SW_N) % SW_N);
-  const int wi = (int)(i / (SW_N * SW_N)), wx = wi % nw, wy = wi / nw;
-  auto reg = [&](int t) {
-    const int y = SW_WS * wy + t / SW_WS, x = SW_WS * wx + t % SW_WS;
-    const int ry = y < res - SW_WS ? 0 : (y < res - shift ? 1 : 2), rx = x < res - SW_WS ? 0 : (x < res - shift ? 1 : 2);
-    return ry * 3 + rx;
-  };
-  mask[i] = reg(qi) == reg(kj) ? 0.0f : -100.0f;
-}
+// The index tables of a batch size, ALL in one launch (round 5: they were 12 launches per forward, one of them a single workgroup walking 169 x 2401 pairs for 250 us).
+// A segment per table; a thread finds its segment by a linear scan of <= 13 entries travelling in the kernel arguments.
+//   kind 0  rowidx: token (window w = (b, wy, wx), j = (ty, tx)) of the window partition of the map rolled by -shift lives in image-order row
+//                   b res^2 + ((7 wy + ty + shift) mod res) res + (7 wx + tx + shift) mod res
+//   kind 1  timm's attn_mask of a shifted block: region ids of the rolled frame (rows / columns < res - 7, < res - shift, rest), 0 inside a region pair, -100 across
+//   kind 2  uses[r][0 .. 49): the positions q * 49 + k that read table entry r, ascending, -1 padded
 __device__ __forceinline__ int swin_rel(int qi, int kj) {      // relative_position_index[q][k] = (yq - yk + 6) * 13 + (xq - xk + 6)
   return (qi / SW_WS - kj / SW_WS + SW_WS - 1) * (2 * SW_WS - 1) + (qi % SW_WS - kj % SW_WS + SW_WS - 1);
 }
-// uses[r][0 .. U): the positions q * 49 + k that read table entry r, ascending, -1 padded (U = 49)
-__global__ void swin_uses_kernel(int* __restrict__ uses) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= SW_NREL) return;
-  int n = 0;
-  for (int pos = 0; pos < SW_N * SW_N; ++pos)
-    if (swin_rel(pos / SW_N, pos % SW_N) == r) uses[r * SW_N + n++] = pos;
-  for (; n < SW_N; ++n) uses[r * SW_N + n] = -1;
+struct SwTableSeg { long first; void* out; int kind, B, res, shift; };
+struct SwTables { SwTableSeg seg[13]; int n; long total; };
+__global__ __launch_bounds__(256) void swin_tables_kernel(SwTables t) {
+  const long gi = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gi >= t.total) return;
+  int k = 0;
+  while (k + 1 < t.n && gi >= t.seg[k + 1].first) ++k;
+  const SwTableSeg sg = t.seg[k];
+  const long i = gi - sg.first;
+  const int res = sg.res, shift = sg.shift, nw = res / SW_WS;
+  if (sg.kind == 0) {
+    const int j = (int)(i % SW_N);
+    const long wi = i / SW_N;
+    const int wx = (int)(wi % nw), wy = (int)((wi / nw) % nw), b = (int)(wi / ((long)nw * nw));
+    const int y = (SW_WS * wy + j / SW_WS + shift) % res, x = (SW_WS * wx + j % SW_WS + shift) % res;
+    ((int*)sg.out)[i] = (int)((long)b * res * res + (long)y * res + x);
+  } else if (sg.kind == 1) {
+    const int kj = (int)(i % SW_N), qi = (int)((i / SW_N) % SW_N);
+    const int wi = (int)(i / (SW_N * SW_N)), wx = wi % nw, wy = wi / nw;
+    auto reg = [&](int tk) {
+      const int y = SW_WS * wy + tk / SW_WS, x = SW_WS * wx + tk % SW_WS;
+      const int ry = y < res - SW_WS ? 0 : (y < res - shift ? 1 : 2), rx = x < res - SW_WS ? 0 : (x < res - shift ? 1 : 2);
+      return ry * 3 + rx;
+    };
+    ((float*)sg.out)[i] = reg(qi) == reg(kj) ? 0.0f : -100.0f;
+  } else {
+    // entry r = (dy + 6) * 13 + (dx + 6) is read by the pairs (q, k) with yq - yk = dy, xq - xk = dx: at most one k per q, so the ascending positions are the valid q in
+    // order; thread (r, q) places its own pair at its rank among them, and pads slot q when q >= their number (7 - |dy|) (7 - |dx|).
+    const int r = (int)(i / SW_N), q = (int)(i % SW_N);
+    const int dy = r / (2 * SW_WS - 1) - (SW_WS - 1), dx = r % (2 * SW_WS - 1) - (SW_WS - 1);
+    auto key_of = [&](int qq) { const int yk = qq / SW_WS - dy, xk = qq % SW_WS - dx; return (yk >= 0 && yk < SW_WS && xk >= 0 && xk < SW_WS) ? yk * SW_WS + xk : -1; };
+    int* const uses = (int*)sg.out;
+    const int kq = key_of(q);
+    if (kq >= 0) {
+      int n = 0;
+      for (int qq = 0; qq < q; ++qq) n += key_of(qq) >= 0;
+      uses[r * SW_N + n] = q * SW_N + kq;
+    }
+    const int cnt = (SW_WS - (dy < 0 ? -dy : dy)) * (SW_WS - (dx < 0 ? -dx : dx));
+    if (q >= cnt) uses[r * SW_N + q] = -1;
+  }
 }
 // PatchMerging's gather: out[(b, y2, x2)][(xp * 2 + yp) * C + c] = in[(b, 2 y2 + yp, 2 x2 + xp)][c]   (timm: reshape(B, H/2, 2, W/2, 2, C).permute(0, 1, 3, 4, 2, 5).flatten(3))
 // INVERSE = the scatter of the gradient (same index map, roles swapped)
@@ -457,15 +470,18 @@ int vdk_swin_forward(const VdkSwinConfig* cfg, const float* x, const float* para
   char* base = (char*)ws;
   const bf16_t* wb = (const bf16_t*)wb16;
   // index tables of this batch size (a few tiny launches; they stay in the workspace for the backward)
-  hipLaunchKernelGGL(swin_uses_kernel, dim3(1), dim3(256), 0, s, (int*)(base + w.uses));
-  for (int i = 0; i < d.nst; ++i) {
-    const long T = d.T[i];
-    hipLaunchKernelGGL(swin_rowidx_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, (int*)(base + w.st[i].rowidx0), d.B, d.res[i], 0);
-    if (d.res[i] > SW_WS) {
-      hipLaunchKernelGGL(swin_rowidx_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, (int*)(base + w.st[i].rowidx3), d.B, d.res[i], SW_WS / 2);
-      const long nm = (long)(d.res[i] / SW_WS) * (d.res[i] / SW_WS) * SW_N * SW_N;
-      hipLaunchKernelGGL(swin_mask_kernel, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s, (float*)(base + w.st[i].mask), d.res[i], SW_WS / 2);
+  {
+    SwTables t; t.n = 0; t.total = 0;
+    auto seg = [&](void* out, long count, int kind, int res, int shift) { t.seg[t.n++] = SwTableSeg{t.total, out, kind, d.B, res, shift}; t.total += count; };
+    seg(base + w.uses, (long)SW_NREL * SW_N, 2, SW_WS, 0);
+    for (int i = 0; i < d.nst; ++i) {
+      seg(base + w.st[i].rowidx0, d.T[i], 0, d.res[i], 0);
+      if (d.res[i] > SW_WS) {
+        seg(base + w.st[i].rowidx3, d.T[i], 0, d.res[i], SW_WS / 2);
+        seg(base + w.st[i].mask, (long)(d.res[i] / SW_WS) * (d.res[i] / SW_WS) * SW_N * SW_N, 1, d.res[i], SW_WS / 2);
+      }
     }
+    hipLaunchKernelGGL(swin_tables_kernel, dim3((unsigned)((t.total + 255) / 256)), dim3(256), 0, s, t);
   }
   // patch embedding: patch operand (an index permutation of the image) x Linear, then its LayerNorm -> the residual stream of stage 0
   bf16_t* patches = (bf16_t*)(base + w.patches);
@@ -473,6 +489,16 @@ int vdk_swin_forward(const VdkSwinConfig* cfg, const float* x, const float* para
   float* petmp = (float*)(base + w.petmp); float* pest = (float*)(base + w.pestats);
   RC(gemm(s, patches, d.Kpe, wb + p.pe_w, d.Kpe, petmp, d.E, (int)d.T[0], d.E, d.Kpe, VDK_F32, params + p.pe_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));
   RC(vdk_layernorm_fwd(petmp, d.E, (int)d.T[0], d.E, params + p.pe_nw, params + p.pe_nb, d.eps, base + w.st[0].blk[0].x, d.E, VDK_F32, pest, pest + d.T[0], s));
+  {      // every block's additive attention tile (relative-position bias + shift mask) from the current tables: one launch; the backward reads them again
+    std::vector<VdkWaPrepJob> jobs;
+    for (int i = 0; i < d.nst; ++i)
+      for (int j = 0; j < d.depth[i]; ++j) {
+        const bool shifted = (j & 1) && d.res[i] > SW_WS;
+        jobs.push_back(VdkWaPrepJob{params + p.st[i].blk[j].table, shifted ? (const float*)(base + w.st[i].mask) : nullptr, (float*)(base + w.st[i].blk[j].bias),
+                                    shifted ? (d.res[i] / SW_WS) * (d.res[i] / SW_WS) : 0, d.heads[i]});
+      }
+    RC(vdk_wa_prep_table_batch(jobs.data(), (int)jobs.size(), s));
+  }
   const float* xprev = nullptr;      // output of the previous stage
   int kblk = 0;                      // running block index: rows 2 k / 2 k + 1 of the drop-path factors
   for (int i = 0; i < d.nst; ++i) {
@@ -501,7 +527,6 @@ int vdk_swin_forward(const VdkSwinConfig* cfg, const float* x, const float* para
       // x = x + proj(W-MSA(norm1(x)))
       RC(vdk_layernorm_fwd(xin, C, T, C, params + b.n1w, params + b.n1b, d.eps, h1, C, DT16, st, st + T, s));
       RC(gemm(s, h1, C, wb + b.qkv_w, C, qkv, 3 * C, T, 3 * C, C, DT16, params + b.qkv_b, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0));
-      RC(vdk_wa_prep_table(params + b.table, shifted ? (const float*)(base + sw_.mask) : nullptr, shifted ? nW : 0, H, bias, s));
       RC(vdk_wa_fwd_bm(qkv, 3 * C, o, C, (float*)(base + bw.lse), bias, shifted ? nW : 1, (int64_t)(T / SW_N), H, 0.17677669529663687f /* 32^-0.5 */,
                        (const int32_t*)(base + (shifted ? sw_.rowidx3 : sw_.rowidx0)), t_opf, s));
       RC(gemm(s, o, C, wb + b.proj_w, C, xmid, C, T, C, C, VDK_F32, params + b.proj_b, xin, C, VDK_ACT_NONE, nullptr, 0, 1, nullptr, 0, nullptr, dp1, tpi));

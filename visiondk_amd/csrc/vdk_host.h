@@ -26,6 +26,9 @@ struct LnQ8 { unsigned char* out; long ld; const float* scale; float* amax; int 
 // `in` is SCRATCH of the caller: a tall job (S >= 1024 partial rows) is folded IN PLACE onto its first 64 rows before the final reduction (reduce_rows_fold_kernel), so
 // the partial buffer must not be read again afterwards and two jobs of a batch must not share rows of it.  Every in-library producer (LayerNorm / column-sum / depthwise
 // weight-gradient partials) hands its own workspace slice; that is why the pointer is not const.
+// one block's additive attention tile for vdk_wa_prep_table_batch (csrc/window_attention.hip): bm <- table (+ mask of nW windows when mask != null)
+struct VdkWaPrepJob { const float* table; const float* mask; float* bm; int nW, H; };
+int vdk_wa_prep_table_batch(const VdkWaPrepJob* jobs, int n, void* stream);
 struct VdkReduceJob { float* in; long ld; int S; long n; float* out; float scale; };
 int vdk_reduce_rows_batch(const VdkReduceJob* jobs, int n, void* stream);
 

@@ -60,6 +60,27 @@ __global__ __launch_bounds__(256) void wa_prep_table_kernel(const float* __restr
   }
   bm[i] = v;
 }
+// every block's tile in ONE launch (the Swin engine's forward: 24 of the launches above were 24 x 5 us at the launch floor); jobs travel in the kernel arguments
+struct WaPrepBatch { VdkWaPrepJob job[32]; long first[33]; int n; };
+__global__ __launch_bounds__(256) void wa_prep_table_batch_kernel(WaPrepBatch b) {
+  const long gi = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gi >= b.first[b.n]) return;
+  int k = 0;
+  while (k + 1 < b.n && gi >= b.first[k + 1]) ++k;
+  const VdkWaPrepJob jb = b.job[k];
+  const long i = gi - b.first[k];
+  const int H = jb.H;
+  const int r = (int)(i & 15), lane = (int)((i >> 4) & 63), kt = (int)((i >> 10) & 1), qt = (int)((i >> 11) & 1);
+  const long wh = i >> 12; const int h = (int)(wh % H); const long wm = wh / H;
+  const int q = 32 * qt + (lane & 31), key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+  float v = key < WA_N ? 0.f : -INFINITY;
+  if (q < WA_N && key < WA_N) {
+    const int rel = (q / 7 - key / 7 + 6) * 13 + (q % 7 - key % 7 + 6);
+    v = jb.table[rel * H + h];
+    if (jb.mask) v += jb.mask[(wm * WA_N + q) * WA_N + key];
+  }
+  jb.bm[i] = v;
+}
 __global__ __launch_bounds__(256) void wa_unprep_dbias_kernel(const float* __restrict__ red, int H, float* __restrict__ dbias) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)H * WA_N * WA_N) return;
@@ -691,6 +712,20 @@ int vdk_wa_prep_table(const float* table, const float* mask, int32_t nW, int32_t
   const long n = (long)nWm * H * WA_FRAG;
   hipLaunchKernelGGL(wa_prep_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, mask, nWm, (int)H, bm);
   return VDK_OK;
+}
+int vdk_wa_prep_table_batch(const VdkWaPrepJob* jobs, int n, void* stream) {
+  if (n < 0 || (n > 0 && !jobs)) return vdk_fail(VDK_EINVAL, "vdk_wa_prep_table_batch: bad argument");
+  for (int i0 = 0; i0 < n; i0 += 32) {
+    WaPrepBatch b; b.n = 0; long tot = 0;
+    for (int i = i0; i < n && i < i0 + 32; ++i) {
+      b.first[b.n] = tot;
+      b.job[b.n++] = jobs[i];
+      tot += (long)(jobs[i].mask ? jobs[i].nW : 1) * jobs[i].H * WA_FRAG;
+    }
+    b.first[b.n] = tot;
+    if (tot > 0) hipLaunchKernelGGL(wa_prep_table_batch_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b);
+  }
+  return vdk_check_launch("vdk_wa_prep_table_batch");
 }
 int vdk_wa_fwd_bm(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, const float* bm, int32_t nWm, int64_t windows, int32_t H, float scale, const int32_t* rowidx, int opf,
                   void* stream) {

@@ -537,10 +537,13 @@ class SwinEngine:
         if self.drop_path_rate <= 0.0:
             return None
         n = sum(self.spec.depths)
-        rates = torch.linspace(0, self.drop_path_rate, n, device=self.device).repeat_interleave(2)      # timm: [x.tolist() for x in torch.linspace(0, drop_path_rate, sum(depths)).split(depths)]
-        keep = (1.0 - rates).unsqueeze(1)
+        if getattr(self, "_dp_const", None) is None or self._dp_const[0] != self.drop_path_rate:      # the constants once: three launches per draw (rand, <, where)
+            rates = torch.linspace(0, self.drop_path_rate, n, device=self.device).repeat_interleave(2)  # timm: [x.tolist() for x in torch.linspace(0, drop_path_rate, sum(depths)).split(depths)]
+            keep = (1.0 - rates).unsqueeze(1)
+            self._dp_const = (self.drop_path_rate, keep, 1.0 / keep, torch.zeros((), device=self.device))
+        _, keep, inv_keep, zero = self._dp_const
         u = torch.rand((2 * n, batch), device=self.device)
-        return ((u < keep).to(torch.float32) / keep).contiguous()
+        return torch.where(u < keep, inv_keep, zero).contiguous()
 
     def _workspace(self, batch: int) -> torch.Tensor:
         if self._ws is None or self._ws_batch != batch:
