@@ -44,6 +44,9 @@ TIMM_VITS = {
     "vit_small_patch16_224": dict(dim=384, depth=12, heads=6, mlp_dim=1536),
     "vit_base_patch16_224": dict(dim=768, depth=12, heads=12, mlp_dim=3072),
     "vit_base_patch32_224": dict(dim=768, depth=12, heads=12, mlp_dim=3072, patch_size=32),
+    # 28 x 28 + 1 = 785 tokens: the streaming attention kernels (csrc/attention_long.hip); `vit_base_patch8_224.dino` is an alternative listed in the shipped YAMLs (cbir.yaml:8)
+    "vit_small_patch8_224": dict(dim=384, depth=12, heads=6, mlp_dim=1536, patch_size=8),
+    "vit_base_patch8_224": dict(dim=768, depth=12, heads=12, mlp_dim=3072, patch_size=8),
     "vit_large_patch16_224": dict(dim=1024, depth=24, heads=16, mlp_dim=4096),
     "vit_base_patch16_384": dict(dim=768, depth=12, heads=12, mlp_dim=3072, img_size=384),
     "vit_large_patch14_224": dict(dim=1024, depth=24, heads=16, mlp_dim=4096, patch_size=14),
