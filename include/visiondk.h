@@ -448,7 +448,10 @@ int vdk_vit_refresh_weights(const VdkVitConfig* cfg, const float* params, void* 
 /* x f32 [B, in_chans, img, img] -> logits f32 [B, Cp], Cp = num_classes rounded up to 8 */
 int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params, const void* wb16, void* ws, size_t ws_bytes,
                     float* logits, void* stream);
-/* dlogits bf16 [B, Cp] -> grads (flat fp32, overwritten).  on_ready: see csrc/vit_engine.hip (DDP bucket hook). */
+/* dlogits bf16 [B, Cp] -> grads (flat fp32, overwritten).  on_ready: see csrc/vit_engine.hip (DDP bucket hook).
+ * ALL FOUR ENGINES (vit / swin / convnext / resnet): `grads` has the layout of `params` (tensors at multiples of 64 floats) and must be ZERO-INITIALISED ONCE by its owner --
+ * a backward overwrites every tensor's gradient but never the alignment gaps between tensors (a 1000-wide bias leaves 24 floats), and the passes over the whole flat buffer
+ * (vdk_sumsq_f32 for the clip norm, vdk_allreduce_bucket, the fp16 overflow check of vdk_sgd_step_amp) read them. */
 int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* params, const void* wb16, const void* wt16, void* ws,
                      size_t ws_bytes, float* grads, vdk_grad_ready_fn on_ready, void* user, void* stream, void* side_stream);
 /* PRECISE forward (evaluation / embedding extraction): same network, fp32 activations, every contraction on the fp32 MFMA, reads the fp32 master
