@@ -515,6 +515,11 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU fallback)"
+    # DIAGNOSTIC, never a measurement: VDK_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and exchanges over gloo, so that the N > 1 code path of this file (bucketed gradient
+    # exchange inside the backward, max-over-ranks timing, the sharded search, the JSON assembly) can be executed end to end on a 1-GPU box; the line says so in `diagnostic`
+    share_gpu = world > 1 and os.environ.get("VDK_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rccl_log = None
@@ -525,7 +530,10 @@ def main():
             import tempfile
             rccl_log = os.path.join(tempfile.gettempdir(), f"vdk_rccl_{os.getpid()}.log")
             os.environ.update({"NCCL_DEBUG": "INFO", "NCCL_DEBUG_SUBSYS": "INIT,GRAPH", "NCCL_DEBUG_FILE": rccl_log})
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from visiondk_amd import _lib
     be = _lib.load()
 
@@ -574,6 +582,8 @@ def main():
                                "timed_launches": f"every GEMM dispatch of every {GEMM_EVENT_STRIDE}th step of the timed region (start / stop events attached to the dispatch itself)",
                                "flops_per_launch": gemm["flops"] / max(gemm["n"], 1),
                                "gemm_share_of_step_time": (gemm["ms"] / max(1, -(-args.steps // GEMM_EVENT_STRIDE))) / (dt / args.steps * 1e3)}
+        if share_gpu:
+            out["diagnostic"] = "VDK_BENCH_SHARE_GPU=1: all ranks on ONE GPU, gloo exchange -- exercises the N > 1 code path, the numbers are not a measurement"
         if world > 1:
             out["exchange"] = {"collectives_per_step": ncoll // max(1, args.steps + args.warmup), "bucket_bytes": 24 << 20,
                                "what": "bucketed all-reduce (sum) of the flat fp32 gradient over RCCL, issued from inside the backward; 1/world folded into the SGD kernel",

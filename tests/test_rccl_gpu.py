@@ -275,3 +275,29 @@ def test_allreduce_buckets_run_while_the_backward_is_still_executing(hip):
     assert st["exposed_tail_ms"] < 0.5 * total                    # what the optimizer waits for is the tail, not the sum
     assert st["step_cost_of_the_exchange_ms"] < 0.5 * total       # the step pays a fraction of the collectives' duration
     assert abs(d["ms_abi_route_empty_collectives"] - d["ms_plain"]) < 0.05 * d["ms_plain"]      # the plumbing itself (callbacks, events, empty collectives) is in the noise
+
+
+def test_bench_two_ranks_code_path_on_one_gpu(hip):
+    """The driver launches `bench.py --gpus N` under torch.distributed.run with one rank per GPU; this box has one.  VDK_BENCH_SHARE_GPU=1 (a diagnostic switch of bench.py,
+    flagged in its line) puts both ranks on cuda:0 and exchanges over gloo, so the whole N > 1 path of the file runs end to end here: weights broadcast, the bucketed
+    gradient exchange issued from inside the backward, barrier + max-over-ranks timing, the sharded search (all-gather of the queries, all-to-all of the per-shard top-k
+    lists, merge) checked bit for bit against the oracle over the WHOLE gallery, and the one JSON line from rank 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, VDK_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(root))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, "rank 0 prints ONE line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak" and "diagnostic" in d
+    assert d["exchange"]["collectives_per_step"] >= 4                                  # the flat gradient left in buckets, every step
+    assert d["roofline"]["frac"] > 0 and d["value"] > 0
+    c = d["cbir"]
+    assert c["n_gpus"] == 2 and c["scaling"] == "strong" and c["parity_vs_oracle"]["indices_equal"] and c["parity_vs_oracle"]["scores_bit_equal"]
