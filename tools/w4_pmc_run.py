@@ -1,4 +1,5 @@
-"""One GEMM shape launched a few times with a forced kernel structure (for rocprofv3 --pmc passes).  usage: w4_pmc_run.py KERN M N K [trans] [iters]"""
+"""One GEMM shape launched a few times with a forced kernel structure (for rocprofv3 --pmc passes).  usage: w4_pmc_run.py KERN M N K [trans] [iters]
+KERN = -1: the vendor library's kernel for the same bare product (torch.matmul -> hipBLASLt / rocBLAS; the comparison VERDICT r4 asked for, never on the product path)."""
 import sys
 from pathlib import Path
 import torch
@@ -14,7 +15,11 @@ if trans:
 else:
     a = torch.randn(M, K, device="cuda").bfloat16(); b = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
 o = torch.empty(M, N, dtype=torch.float32 if trans else torch.bfloat16, device="cuda")
-be.lib.vdk_gemm_force_kernel(kern)
-for _ in range(iters):
-    ops.gemm_nt(a, b, out=o, trans=trans, backend=be)
+if kern < 0:
+    for _ in range(iters):
+        o = torch.matmul(a.t(), b) if trans else torch.matmul(a, b.t())
+else:
+    be.lib.vdk_gemm_force_kernel(kern)
+    for _ in range(iters):
+        ops.gemm_nt(a, b, out=o, trans=trans, backend=be)
 torch.cuda.synchronize()
