@@ -10,13 +10,16 @@ from visiondk_amd import build as vb  # noqa: E402
 
 
 def main():
-    name, src, defs = sys.argv[1], sys.argv[2], sys.argv[3:]
+    name, srcs, defs = sys.argv[1], sys.argv[2].split(","), sys.argv[3:]      # several sources: comma-separated (gemm_w4.hip,gemm_w4_f16.hip)
     vb.build(verbose=False)
     out = vb.OBJ / "ab"; out.mkdir(exist_ok=True)
-    srcp = vb.CSRC / src
-    obj = out / f"{name}_{srcp.stem}.o"
-    subprocess.run([vb.HIPCC, *vb.FLAGS, *defs, "-c", str(srcp), "-o", str(obj)], check=True)
-    objs = [str(obj) if p.stem == srcp.stem else str(vb.OBJ / (p.stem + ".o")) for p in vb.sources()]
+    var = {}
+    for src in srcs:
+        srcp = vb.CSRC / src
+        obj = out / f"{name}_{srcp.stem}.o"
+        subprocess.run([vb.HIPCC, *vb.FLAGS, *defs, "-c", str(srcp), "-o", str(obj)], check=True)
+        var[srcp.stem] = str(obj)
+    objs = [var.get(p.stem, str(vb.OBJ / (p.stem + ".o"))) for p in vb.sources()]
     lib = out / f"lib{name}.so"
     subprocess.run([vb.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *objs], check=True)
     print(lib)
