@@ -251,3 +251,21 @@ def test_default_initialisation_follows_torch_manual_seed(be, dev):
     torch.manual_seed(123); b = vit.VisionTransformer(SPEC, device=dev, backend=be)
     torch.manual_seed(124); c = vit.VisionTransformer(SPEC, device=dev, backend=be)
     assert torch.equal(a.engine.params, b.engine.params) and not torch.equal(a.engine.params, c.engine.params)
+
+
+def test_qkv_bias_gradient_from_the_attention_backward(be, dev, monkeypatch):
+    """qkv.bias = column sums of dqkv.  The one-pass attention backward delivers per-image partials of them with its stores (vdk_attention_bwd_cs; round 5) and the engine
+    reduces those over the batch.  VDK_ATTN_GRID=3 makes every workgroup walk several (image, head) items, so the hand-over of the partials behind the NEXT item's first
+    barrier -- and behind the loop for the last one -- is what runs; the gradient must equal the oracle's like every other one, for 2 heads x 7 images = 14 items."""
+    monkeypatch.setenv("VDK_ATTN_GRID", "3")
+    ref, model = _pair(be, dev)
+    torch.manual_seed(11)
+    x = torch.randn(7, 3, 32, 32); y = torch.randint(0, 10, (7,))
+    torch.nn.functional.cross_entropy(ref(x), y).backward()
+    torch.nn.functional.cross_entropy(model(x.to(dev)), y.to(dev)).backward()
+    seen = 0
+    for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()):
+        if n.endswith("attn.qkv.bias"):
+            assert _rel(p.grad, pr.grad) < 3e-2, (n, _rel(p.grad, pr.grad))
+            seen += 1
+    assert seen == SPEC.depth

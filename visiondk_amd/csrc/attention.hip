@@ -393,6 +393,8 @@ static bool attn_legacy() {
   return e && e[0] == '1';
 }
 
+void vdk_attention_small_want_colsum(float*);      // attention_small.hip (C++ linkage, like vdk_attention_small_bwd above)
+int vdk_attention_small_colsum_produced();
 static int attn_long_min() {           // A/B and tests: VDK_ATTN_LONG_MIN=n routes every N >= n to the streaming kernels of attention_long.hip (default: beyond the LDS-resident range)
   const char* e = getenv("VDK_ATTN_LONG_MIN");                          // (read per launch: the tests switch it inside one process)
   return e ? atoi(e) : 1 << 30;
@@ -443,6 +445,16 @@ int vdk_attention_fwd_dt(const void* qkv, int64_t ld, void* o, int64_t ldo, floa
 }
 
 // dqkv: bf16 [B, N, 3, H, 64] like qkv.  dvec: f32 scratch [B, H, N].
+// the same backward with the qkv.bias gradient's partials as a by-product where the chosen kernel can deliver them (the one-pass small-N form): cspart f32 [B][3 * H * 64]
+// = per image the column sums of its dq | dk | dv rows as stored; *produced = 1 when written (the caller reduces over B), 0 otherwise (the caller sums dqkv itself)
+int vdk_attention_bwd_cs(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv, int64_t lddqkv, float* dvec, int32_t B, int32_t N,
+                         int32_t H, int32_t head_dim, float scale, int32_t dtype, float* cspart, int32_t* produced, void* stream_) {
+  vdk_attention_small_want_colsum(cspart);
+  const int rc = vdk_attention_bwd_dt(qkv, ld, o, dout, ldo, lse, dqkv, lddqkv, dvec, B, N, H, head_dim, scale, dtype, stream_);
+  if (produced) *produced = rc == VDK_OK ? vdk_attention_small_colsum_produced() : 0;
+  vdk_attention_small_want_colsum(nullptr);
+  return rc;
+}
 int vdk_attention_bwd(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, void* dqkv,
                       int64_t lddqkv, float* dvec, int32_t B, int32_t N, int32_t H, int32_t head_dim, float scale, void* stream_) {
   return vdk_attention_bwd_dt(qkv, ld, o, dout, ldo, lse, dqkv, lddqkv, dvec, B, N, H, head_dim, scale, VDK_BF16, stream_);

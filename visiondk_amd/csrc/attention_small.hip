@@ -795,7 +795,9 @@ template <int NKT, int OF, bool KR>
 __global__ __launch_bounds__(512) void attn_s_bwd5_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld,
                                                           const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, long ldo, const float* __restrict__ lse,
                                                           bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long ldd, int N, int H, float scale,
-                                                          int nitems, int dbg /* timing experiments only (VDK_ATTN5_DBG): 1 skip the key phase, 2 the dQ phase, 4 D, 8 the stores */) {
+                                                          int nitems, int dbg /* timing experiments only (VDK_ATTN5_DBG): 1 skip the key phase, 2 the dQ phase, 4 D, 8 the stores */,
+                                                          float* __restrict__ cspart /* optional f32 [B][3][H][64]: column sums over the item's tokens of the dq / dk / dv rows AS STORED
+                                                                                        (the qkv.bias gradient's partial per image: no second pass over dqkv) */) {
   VDK_DYN_LDS(smem);
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -809,6 +811,7 @@ __global__ __launch_bounds__(512) void attn_s_bwd5_kernel(const bf16_t* __restri
   unsigned char* const DQs = Ds + 2 * DSB;                            // [NP rows x A5_QPITCH] dQ [query][d], 16-bit, already scaled
   float* const lse2 = (float*)(DQs + NP * A5_QPITCH);
   float* const Dv = lse2 + NP;
+  float* const CSs = Dv + NP;                                         // [3: q, k, v][8 waves][64 d] column-sum partials of the item's stored rows (cspart != nullptr)
   constexpr int nt = NKT;                                             // (the launcher instantiates NKT = ceil(N / 32): every tile loop is a compile-time loop)
   const float scale2 = scale * VDK_LOG2E;
   const bool ragged = (N & 31) != 0;
@@ -833,10 +836,20 @@ __global__ __launch_bounds__(512) void attn_s_bwd5_kernel(const bf16_t* __restri
     if (w < 4) as_dma_rows(QO + buf * 8192, q + off + (long)q0 * ld, ld, N - q0, 32, part, 4, lane);
     else as_dma_rows(QO + buf * 8192 + 4096, dout + offo + (long)q0 * ldo, ldo, N - q0, 32, part, 4, lane);
   };
+  int pb = -1, ph = 0;                                                // the item whose column-sum partials wait in CSs
+  auto cs_flush = [&]() {
+    if (tid < 192) {
+      const int which = tid >> 6, col = tid & 63, nw = which == 0 ? 8 : nt;
+      float t = 0.f;
+      for (int ww = 0; ww < nw; ++ww) t += CSs[(which * 8 + ww) * 64 + col];
+      cspart[(((long)pb * 3 + which) * H + ph) * 64 + col] = t;
+    }
+  };
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int b = item / H, h = item - b * H;
     const long off = (long)b * N * ld + h * 64, offo = (long)b * N * ldo + h * 64;
     __syncthreads();                                                  // the previous item is finished everywhere (its store tiles = this item's K tiles)
+    if (cspart && pb >= 0) cs_flush();                                // (CSs is written again at the END of this item, several barriers from here)
     request_tile(0, 0, off, offo);
     if (nt > 1) request_tile(1, 1, off, offo);
     s16x8 kf[4], vf[4];
@@ -948,17 +961,79 @@ __global__ __launch_bounds__(512) void attn_s_bwd5_kernel(const bf16_t* __restri
     }
     __syncthreads();                                                  // every dQ block is staged; the last tile's dQ phase is done with the K tiles
     if (dbg & 8) continue;
-    if (keyw) {      // (the K tile is free to stage the stores)
-      as_store_tile<OF>(Kt, gk0, gk1, scale, dk + (long)b * N * ldd + h * 64, ldd, w * 32, N, lane);
-      as_store_tile<OF>(Kt, gv0, gv1, 1.0f, dv + (long)b * N * ldd + h * 64, ldd, w * 32, N, lane);
-    }
-    // dQ rows leave as whole 128-byte rows: 8 threads per row
+    if (!cspart) {
+      if (keyw) {      // (the K tile is free to stage the stores)
+        as_store_tile<OF>(Kt, gk0, gk1, scale, dk + (long)b * N * ldd + h * 64, ldd, w * 32, N, lane);
+        as_store_tile<OF>(Kt, gv0, gv1, 1.0f, dv + (long)b * N * ldd + h * 64, ldd, w * 32, N, lane);
+      }
+      // dQ rows leave as whole 128-byte rows: 8 threads per row
 #pragma unroll
-    for (int p = 0; p < NPC; ++p) {
-      const int id = tid + 512 * p, row = id >> 3, cp = id & 7;
-      if (row < N) *(u32x4*)(dq + (long)b * N * ldd + h * 64 + (long)row * ldd + cp * 8) = *(const u32x4*)(DQs + row * A5_QPITCH + cp * 16);
+      for (int p = 0; p < NPC; ++p) {
+        const int id = tid + 512 * p, row = id >> 3, cp = id & 7;
+        if (row < N) *(u32x4*)(dq + (long)b * N * ldd + h * 64 + (long)row * ldd + cp * 8) = *(const u32x4*)(DQs + row * A5_QPITCH + cp * 16);
+      }
+      continue;
     }
+    // the same stores, and on the way the column sums of what is stored: a lane adds up the 8 columns of its 16-byte chunk over its rows, the 8 lanes of a wave that own
+    // the same chunk (lane & 7) are folded with three shuffles, lanes 0..7 then hold the wave's 64 sums; a last pass adds the waves up in wave order (deterministic)
+    auto cs_add = [&](float (&cs)[8], const u32x4& v) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { cs[2 * e] += op_lo<OF>(v[e]); cs[2 * e + 1] += op_hi<OF>(v[e]); }
+    };
+    auto cs_put = [&](float (&cs)[8], int which) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { float t = cs[e]; t += __shfl_xor(t, 8); t += __shfl_xor(t, 16); t += __shfl_xor(t, 32); cs[e] = t; }
+      if (lane < 8) {
+        float* dst = CSs + (which * 8 + w) * 64 + lane * 8;
+        *(f32x4*)dst = (f32x4){cs[0], cs[1], cs[2], cs[3]}; *(f32x4*)(dst + 4) = (f32x4){cs[4], cs[5], cs[6], cs[7]};
+      }
+    };
+    if (keyw) {
+#pragma unroll
+      for (int which = 1; which <= 2; ++which) {
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        bf16_t* const dst = (which == 1 ? dk : dv) + (long)b * N * ldd + h * 64;
+        const f32x16& x0 = which == 1 ? gk0 : gv0; const f32x16& x1 = which == 1 ? gk1 : gv1;
+        const float mul = which == 1 ? scale : 1.0f;
+        const int row0 = w * 32;
+        if (row0 + l31 < N) {      // (as_store_tile, with the rows read back for the sums)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int ch = g ^ (l31 & 7), ch1 = (4 + g) ^ (l31 & 7);
+            *(u32x2*)(Kt + l31 * AS_ROW + (ch << 4) + 8 * hi) = (u32x2){pack_op2<OF>(x0[4 * g] * mul, x0[4 * g + 1] * mul), pack_op2<OF>(x0[4 * g + 2] * mul, x0[4 * g + 3] * mul)};
+            *(u32x2*)(Kt + l31 * AS_ROW + (ch1 << 4) + 8 * hi) = (u32x2){pack_op2<OF>(x1[4 * g] * mul, x1[4 * g + 1] * mul), pack_op2<OF>(x1[4 * g + 2] * mul, x1[4 * g + 3] * mul)};
+          }
+        }
+        VDK_WAVE_LDS_SYNC();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int r = 8 * p + (lane >> 3), cp = lane & 7;
+          if (row0 + r < N) {
+            const u32x4 v = *(const u32x4*)(Kt + r * AS_ROW + ((cp ^ (r & 7)) << 4));
+            *(u32x4*)(dst + (long)(row0 + r) * ldd + cp * 8) = v;
+            cs_add(cs, v);
+          }
+        }
+        VDK_WAVE_LDS_SYNC();
+        cs_put(cs, which);
+      }
+    }
+    {
+      float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int p = 0; p < NPC; ++p) {
+        const int id = tid + 512 * p, row = id >> 3, cp = id & 7;
+        if (row < N) {
+          const u32x4 v = *(const u32x4*)(DQs + row * A5_QPITCH + cp * 16);
+          *(u32x4*)(dq + (long)b * N * ldd + h * 64 + (long)row * ldd + cp * 8) = v;
+          cs_add(cs, v);
+        }
+      }
+      cs_put(cs, 0);
+    }
+    pb = b; ph = h;      // the waves' partials are added up behind the NEXT item's first barrier (or behind the loop): no barrier of its own
   }
+  if (cspart && pb >= 0) { __syncthreads(); cs_flush(); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
@@ -1026,10 +1101,17 @@ static int launch_bwd1p(const bf16_t* base, long D, long ld, const bf16_t* o, co
                      N, H, scale, B * H);
   return VDK_OK;
 }
+// the caller's wish for the column-sum by-product of the next backward (form 5 only) and whether the launch produced it: vdk_attention_bwd_cs (attention.hip)
+static thread_local float* t_cspart = nullptr;
+static thread_local int t_cs_produced = 0;
+void vdk_attention_small_want_colsum(float* cspart) { t_cspart = cspart; t_cs_produced = 0; }
+int vdk_attention_small_colsum_produced() { return t_cs_produced; }
 template <int NKT, int OF>
 static int launch_bwd5(const bf16_t* base, long D, long ld, const bf16_t* o, const bf16_t* dout, long ldo, const float* lse, bf16_t* dbase, long ldd, int B, int N, int H,
                        float scale, int grid, hipStream_t s) {
-  const size_t lds = 3 * 8192 + (size_t)NKT * 4096 + 2 * (size_t)(32 * NKT) * A5_PITCH + (size_t)(32 * NKT) * A5_QPITCH + (size_t)NKT * 32 * 8;
+  const size_t lds = 3 * 8192 + (size_t)NKT * 4096 + 2 * (size_t)(32 * NKT) * A5_PITCH + (size_t)(32 * NKT) * A5_QPITCH + (size_t)NKT * 32 * 8 + 3 * 8 * 64 * 4;
+  float* const cspart = t_cspart;
+  if (cspart) t_cs_produced = 1;
   const char* edbg = getenv("VDK_ATTN5_DBG");
   const int dbg = edbg ? atoi(edbg) : 0;
   const char* ekt = getenv("VDK_ATTN5_KT");      // A/B: VDK_ATTN5_KT=regs keeps the K^T fragments of the dQ role in registers (read per launch; default: re-read from LDS)
@@ -1038,12 +1120,12 @@ static int launch_bwd5(const bf16_t* base, long D, long ld, const bf16_t* o, con
     if (hipFuncSetAttribute((const void*)attn_s_bwd5_kernel<NKT, OF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return vdk_fail(VDK_ELAUNCH, "vdk_attention_bwd: LDS attribute");
     hipLaunchKernelGGL((attn_s_bwd5_kernel<NKT, OF, true>), dim3((unsigned)grid), dim3(512), lds, s, base, base + D, base + 2 * D, ld, o, dout, ldo, lse, dbase, dbase + D, dbase + 2 * D,
-                       ldd, N, H, scale, B * H, dbg);
+                       ldd, N, H, scale, B * H, dbg, cspart);
   } else {
     if (hipFuncSetAttribute((const void*)attn_s_bwd5_kernel<NKT, OF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return vdk_fail(VDK_ELAUNCH, "vdk_attention_bwd: LDS attribute");
     hipLaunchKernelGGL((attn_s_bwd5_kernel<NKT, OF, false>), dim3((unsigned)grid), dim3(512), lds, s, base, base + D, base + 2 * D, ld, o, dout, ldo, lse, dbase, dbase + D, dbase + 2 * D,
-                       ldd, N, H, scale, B * H, dbg);
+                       ldd, N, H, scale, B * H, dbg, cspart);
   }
   return VDK_OK;
 }

@@ -33,6 +33,8 @@ int vdk_attention_bwd(const void*, int64_t, const void*, const void*, int64_t, c
                       int32_t, float, void*);
 int vdk_attention_fwd_dt(const void*, int64_t, void*, int64_t, float*, int32_t, int32_t, int32_t, int32_t, float, int32_t, void*);
 int vdk_attention_bwd_dt(const void*, int64_t, const void*, const void*, int64_t, const float*, void*, int64_t, float*, int32_t, int32_t, int32_t, int32_t, float, int32_t, void*);
+int vdk_attention_bwd_cs(const void*, int64_t, const void*, const void*, int64_t, const float*, void*, int64_t, float*, int32_t, int32_t, int32_t, int32_t, float, int32_t, float*, int32_t*,
+                         void*);
 int vdk_patchify_bf16(const float*, int32_t, int32_t, int32_t, int32_t, int32_t, void*, int32_t, void*);
 int vdk_cls_rows(float*, int64_t, int32_t, int32_t, const float*, const float*, void*);
 int vdk_cast_f32_bf16(const float*, void*, int64_t, void*);
@@ -730,7 +732,15 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
       RC(linear_wgrad(s2, d, w, base, dxmb, D, o, D, T, d.Tp, D, D, grads + b.proj_w, grads + b.proj_b, 0));
       RC(gemm(s, dxmb, D, wt + p.blkT[l].proj, D, dsm, D, T, D, D, DT16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // do
     }
-    RC(vdk_attention_bwd_dt(qkv, 3 * D, o, dsm, D, lse, dqkv, 3 * D, dvec, d.B, d.N, d.H, 64, 0.125f, DT16, s));                                    // dqkv
+    // dqkv; with the one-pass small-N kernel the qkv.bias gradient's per-image partials (column sums of the dq | dk | dv rows it stores) come out of the same launch
+    // (round 5: the separate pass over dqkv was 13 x 42 us per ViT-B/16 step); VDK_VIT_QKVB_ATTN=0 keeps that pass
+    int32_t qkvb_done = 0;
+    {
+      static const bool fuse_on = !(getenv("VDK_VIT_QKVB_ATTN") && atoi(getenv("VDK_VIT_QKVB_ATTN")) == 0);
+      float* csp = (fuse_on && !f8.mode && one_stream && (size_t)d.B * 3 * D * 4 <= w.csws_bytes) ? (float*)(base + w.csws + (size_t)3 * w.csws_bytes) : nullptr;
+      RC(vdk_attention_bwd_cs(qkv, 3 * D, o, dsm, D, lse, dqkv, 3 * D, dvec, d.B, d.N, d.H, 64, 0.125f, DT16, csp, &qkvb_done, s));
+      if (qkvb_done) { jobs[nj] = VdkReduceJob{csp, (long)3 * D, d.B, (long)3 * D, grads + b.qkv_b, 1.0f}; ++nj; }
+    }
     RC(ev_order(ev_p++, s, s2));
     if (f8.mode) {
       // dqkv is attention's output: its column sums (qkv.bias) and its e5m2 copy (operand of the dh1 GEMM) come from ONE pass over it
@@ -743,10 +753,10 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
       RC(gemm8(s, f8, dqkv, 12 * l + 11, 1, f8.wt8 + p.blkT[l].qkv, 12 * l + 4, 3 * D, dsm, D, T, D, 3 * D, VDK_BF16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0,
                fcq ? f8.a8 : nullptr));   // dh1
       RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, fcq ? nullptr : grads + b.qkv_b, 0));
-    } else if (one_stream && qkvb_pass(T, 3 * D, w.csws_bytes)) {
+    } else if (one_stream && (qkvb_done || qkvb_pass(T, 3 * D, w.csws_bytes))) {
       // qkv.bias = column sums of dqkv (attention's output: no producing GEMM epilogue to ride on) as one pass over it, so that the dh1 GEMM is the plain
       // one-wave-per-SIMD kernel instead of the eight-wave kernel with the A-tile column-sum by-product (A/B on one box: see DESIGN.md)
-      RC(vdk_colsum_bf16_deferred(dqkv, 3 * D, T, 3 * D, grads + b.qkv_b, base + w.csws + (size_t)3 * w.csws_bytes, w.csws_bytes, s, &jobs[nj], nullptr, t_opf)); ++nj;
+      if (!qkvb_done) { RC(vdk_colsum_bf16_deferred(dqkv, 3 * D, T, 3 * D, grads + b.qkv_b, base + w.csws + (size_t)3 * w.csws_bytes, w.csws_bytes, s, &jobs[nj], nullptr, t_opf)); ++nj; }
       RC(gemm(s, dqkv, 3 * D, wt + p.blkT[l].qkv, 3 * D, dsm, D, T, D, 3 * D, DT16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // dh1
       RC(linear_wgrad(s2, d, w, base, dqkv, 3 * D, h1, D, T, d.Tp, 3 * D, D, grads + b.qkv_w, nullptr, 0));
     } else if (one_stream) {
