@@ -28,7 +28,6 @@
 // window_attention.hip, in-library forms: bias tile prepared once per block and step from the table, kept for the backward; d(table) from the fragment-order d(bias)
 size_t vdk_wa_bm_bytes(int32_t nW, int32_t H);
 size_t vdk_wa_bwd_scratch_bytes(int64_t windows, int32_t H);
-int vdk_wa_prep_table(const float* table, const float* mask, int32_t nW, int32_t H, float* bm, void* stream);
 int vdk_wa_fwd_bm(const void* qkv, int64_t ld, void* o, int64_t ldo, float* lse, const float* bm, int32_t nWm, int64_t windows, int32_t H, float scale, const int32_t* rowidx, int opf,
                   void* stream);
 int vdk_wa_bwd_bm(const void* qkv, int64_t ld, const void* o, const void* dout, int64_t ldo, const float* lse, const float* bm, int32_t nWm, int64_t windows, int32_t H, float scale,

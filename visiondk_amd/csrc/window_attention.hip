@@ -44,23 +44,9 @@ __global__ __launch_bounds__(256) void wa_prep_bias_kernel(const float* __restri
   if (q < WA_N && key < WA_N) { v = bias[((long)h * WA_N + q) * WA_N + key]; if (mask) v += mask[(wm * WA_N + q) * WA_N + key]; }
   bm[i] = v;
 }
-// the same straight from the relative-position table [169][H] (bias[h][q][key] = table[index(q, key)][h], timm's gather per forward): the Swin engine's form, one launch
-// per block and forward; the backward reads the prepared tile again
-__global__ __launch_bounds__(256) void wa_prep_table_kernel(const float* __restrict__ table, const float* __restrict__ mask, int nWm, int H, float* __restrict__ bm) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long)nWm * H * WA_FRAG) return;
-  const int r = (int)(i & 15), lane = (int)((i >> 4) & 63), kt = (int)((i >> 10) & 1), qt = (int)((i >> 11) & 1);
-  const long wh = i >> 12; const int h = (int)(wh % H); const long wm = wh / H;
-  const int q = 32 * qt + (lane & 31), key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-  float v = key < WA_N ? 0.f : -INFINITY;
-  if (q < WA_N && key < WA_N) {
-    const int rel = (q / 7 - key / 7 + 6) * 13 + (q % 7 - key % 7 + 6);
-    v = table[rel * H + h];
-    if (mask) v += mask[(wm * WA_N + q) * WA_N + key];
-  }
-  bm[i] = v;
-}
-// every block's tile in ONE launch (the Swin engine's forward: 24 of the launches above were 24 x 5 us at the launch floor); jobs travel in the kernel arguments
+// bias[h][q][key] = table[index(q, key)][h] (+ the shift mask) straight from the relative-position table [169][H], in the attention kernels' fragment order (timm gathers
+// it per forward); the backward reads the prepared tile again.
+// Every block's tile in ONE launch (the Swin engine's forward; one launch per block was 24 x 5 us at the launch floor); jobs travel in the kernel arguments
 struct WaPrepBatch { VdkWaPrepJob job[32]; long first[33]; int n; };
 __global__ __launch_bounds__(256) void wa_prep_table_batch_kernel(WaPrepBatch b) {
   const long gi = (long)blockIdx.x * 256 + threadIdx.x;
@@ -707,12 +693,6 @@ int vdk_relpos_bias_table_grad(const float* dbias, const int32_t* uses, int32_t 
 // for the backward; d(table) comes from the reduced fragment-order d(bias) in one launch (no un-permute, no [H, 49, 49] tensor in between)
 size_t vdk_wa_bm_bytes(int32_t nW, int32_t H) { return wa_bm_bytes(nW, H); }
 size_t vdk_wa_bwd_scratch_bytes(int64_t windows, int32_t H) { return (size_t)(wa_bwd_waves(windows, H) + H) * WA_FRAG * 4; }
-int vdk_wa_prep_table(const float* table, const float* mask, int32_t nW, int32_t H, float* bm, void* stream) {
-  const int nWm = mask ? nW : 1;
-  const long n = (long)nWm * H * WA_FRAG;
-  hipLaunchKernelGGL(wa_prep_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, mask, nWm, (int)H, bm);
-  return VDK_OK;
-}
 int vdk_wa_prep_table_batch(const VdkWaPrepJob* jobs, int n, void* stream) {
   if (n < 0 || (n > 0 && !jobs)) return vdk_fail(VDK_EINVAL, "vdk_wa_prep_table_batch: bad argument");
   for (int i0 = 0; i0 < n; i0 += 32) {
