@@ -18,6 +18,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _init(rank, world, port):
     sys.path.insert(0, str(ROOT))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -57,7 +64,7 @@ def _vit_worker(rank, world, port, out_dir, operand):
 
 
 def test_two_ranks_on_the_gpu_equal_a_single_process_on_the_whole_batch(tmp_path, hip):
-    port = 29500 + ((os.getpid() + 17) % 400)
+    port = _free_port()
     mp.start_processes(_vit_worker, args=(2, port, str(tmp_path), "bf16"), nprocs=2, join=True, start_method="spawn")
     r0 = torch.load(tmp_path / "rank0.pt"); r1 = torch.load(tmp_path / "rank1.pt")
     assert r0["collectives"] >= 3                              # the gradient really left in buckets
@@ -81,7 +88,7 @@ def test_two_ranks_on_the_gpu_equal_a_single_process_on_the_whole_batch(tmp_path
 
 def test_two_ranks_on_the_gpu_fp16_skip_and_step_in_lockstep(tmp_path, hip):
     """the inf check runs on the ALL-REDUCED gradient inside the optimizer kernel: every rank takes the same skip / step decision (train.py:205-211 under DDP)"""
-    port = 29500 + ((os.getpid() + 59) % 400)
+    port = _free_port()
     mp.start_processes(_vit_worker, args=(2, port, str(tmp_path), "fp16"), nprocs=2, join=True, start_method="spawn")
     r0 = torch.load(tmp_path / "rank0.pt"); r1 = torch.load(tmp_path / "rank1.pt")
     assert r0["skipped_first"] and r1["skipped_first"]
@@ -118,7 +125,7 @@ def _face_worker(rank, world, port, out_dir):
 
 
 def test_two_ranks_on_the_gpu_face_step_and_sharded_search(tmp_path, hip):
-    port = 29500 + ((os.getpid() + 137) % 400)
+    port = _free_port()
     mp.start_processes(_face_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
     r0 = torch.load(tmp_path / "face0.pt"); r1 = torch.load(tmp_path / "face1.pt")
     for k in r0["init"]:
@@ -185,7 +192,7 @@ def _resnet_single(hip, init, lr):
 
 
 def test_two_ranks_on_the_gpu_resnet_step(tmp_path, hip):
-    port = 29500 + ((os.getpid() + 271) % 400)
+    port = _free_port()
     mp.start_processes(_resnet_worker, args=(2, port, str(tmp_path), False), nprocs=2, join=True, start_method="spawn")
     r0 = torch.load(tmp_path / "rn0.pt"); r1 = torch.load(tmp_path / "rn1.pt")
     assert torch.equal(r0["init"], r1["init"]) and torch.equal(r0["params"], r1["params"]) and torch.equal(r0["grads"], r1["grads"])
@@ -201,7 +208,7 @@ def test_two_ranks_on_the_gpu_resnet_step(tmp_path, hip):
 
 
 def test_two_ranks_on_the_gpu_syncbn_equals_single_process(tmp_path, hip):
-    port = 29500 + ((os.getpid() + 389) % 400)
+    port = _free_port()
     mp.start_processes(_resnet_worker, args=(2, port, str(tmp_path), True), nprocs=2, join=True, start_method="spawn")
     r0 = torch.load(tmp_path / "rn0.pt"); r1 = torch.load(tmp_path / "rn1.pt")
     assert torch.equal(r0["params"], r1["params"]) and torch.equal(r0["grads"], r1["grads"])
@@ -238,7 +245,7 @@ def _sharded_head_worker(rank, world, port, out_dir):
 
 
 def test_two_ranks_on_the_gpu_class_sharded_head_equals_full_head(tmp_path, hip):
-    port = 29500 + ((os.getpid() + 457) % 400)
+    port = _free_port()
     mp.start_processes(_sharded_head_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
     r = [torch.load(tmp_path / f"sh{i}.pt") for i in range(2)]
     from visiondk_amd import heads
@@ -277,7 +284,7 @@ def _convnext_cls_worker(rank, world, port, out_dir):
 
 
 def test_two_ranks_on_the_gpu_convnext_classifier_step(tmp_path, hip):
-    port = 29500 + ((os.getpid() + 331) % 400)
+    port = _free_port()
     mp.start_processes(_convnext_cls_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
     r0 = torch.load(tmp_path / "cn0.pt"); r1 = torch.load(tmp_path / "cn1.pt")
     from visiondk_amd import convnext, resnet
@@ -319,7 +326,7 @@ def _swin_worker(rank, world, port, out_dir):
 
 
 def test_two_ranks_on_the_gpu_native_swin_step_equals_whole_batch(tmp_path, hip):
-    port = 29500 + ((os.getpid() + 37) % 400)
+    port = _free_port()
     mp.start_processes(_swin_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
     r0 = torch.load(tmp_path / "swin0.pt"); r1 = torch.load(tmp_path / "swin1.pt")
     assert r0["collectives"] >= 2
@@ -381,7 +388,7 @@ def _face_shard_worker(rank, world, port, out_dir):
 
 
 def test_two_ranks_on_the_gpu_face_step_with_class_sharded_head(tmp_path, hip):
-    port = 29500 + ((os.getpid() + 223) % 400)
+    port = _free_port()
     mp.start_processes(_face_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
     r0 = torch.load(tmp_path / "fs0.pt"); r1 = torch.load(tmp_path / "fs1.pt")
     rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
@@ -409,7 +416,7 @@ def _face_syncbn_worker(rank, world, port, out_dir):
 
 
 def test_two_ranks_on_the_gpu_face_step_with_sync_batchnorm_equals_whole_batch(tmp_path, hip):
-    port = 29500 + ((os.getpid() + 301) % 400)
+    port = _free_port()
     mp.start_processes(_face_syncbn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
     r0 = torch.load(tmp_path / "sbn0.pt"); r1 = torch.load(tmp_path / "sbn1.pt")
     from visiondk_amd import face

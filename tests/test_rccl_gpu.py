@@ -289,7 +289,9 @@ def test_bench_two_ranks_code_path_on_one_gpu(hip):
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     env = dict(os.environ, VDK_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(root))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
