@@ -433,6 +433,9 @@ typedef struct VdkVitConfig {
                               (engine/procedure/train.py:118 `torch.autocast(device_type=...)` without a dtype = float16, with GradScaler train.py:205-211): wb16 / wt16, every
                               saved activation and every gradient tensor of the engine are fp16; the caller scales dlogits by the loss scale (vdk_softmax_ce_amp) and the
                               optimizer un-scales (vdk_sgd_step_amp).  Same speed (same MFMA rate), 8x smaller operand rounding.  Excludes fp8. */
+  int32_t pre_norm;        /* 1: timm pre_norm=True (the CLIP ViTs, `vit_*_clip_*`: models/classifier/classify_model.py:49-54 builds them by id): a LayerNorm `norm_pre` between the
+                              embedding (patches + pos_embed, class token) and the first block, and a patch embedding WITHOUT bias (timm: bias = not pre_norm).  The flat layout
+                              keeps the bias slot (it stays zero and is not reported by vdk_vit_param_info) and gains norm_pre.weight / norm_pre.bias behind it. */
 } VdkVitConfig;
 typedef void (*vdk_grad_ready_fn)(void* user, int64_t offset, int64_t numel);
 

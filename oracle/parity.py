@@ -16,16 +16,16 @@ def _rel(a, b):
     return ((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm().clamp_min(1e-30)).item()
 
 
-def vit_pair(be, dev, img, patch, dim, depth, heads, mlp, classes, seed=0, operand="bf16"):
+def vit_pair(be, dev, img, patch, dim, depth, heads, mlp, classes, seed=0, operand="bf16", pre_norm=False, eps=1e-6):
     torch.manual_seed(seed)
-    ref = VisionTransformerRef(img, patch, 3, classes, dim, depth, heads, mlp)       # reference initialisation (classify_model.py:70-81)
+    ref = VisionTransformerRef(img, patch, 3, classes, dim, depth, heads, mlp, eps=eps, pre_norm=pre_norm)       # reference initialisation (classify_model.py:70-81)
     with torch.no_grad():                                                            # every bias / norm / cls path carries signal
         for n, p in ref.named_parameters():
             if p.dim() == 1:
                 p.add_(torch.randn_like(p) * 0.05)
         ref.cls_token.add_(torch.randn_like(ref.cls_token) * 0.02)
     from visiondk_amd import vit
-    model = vit.VisionTransformer(vit.VitSpec(img_size=img, patch_size=patch, num_classes=classes, dim=dim, depth=depth, heads=heads, mlp_dim=mlp), device=dev, backend=be, seed=1,
+    model = vit.VisionTransformer(vit.VitSpec(img_size=img, patch_size=patch, num_classes=classes, dim=dim, depth=depth, heads=heads, mlp_dim=mlp, ln_eps=eps, pre_norm=pre_norm), device=dev, backend=be, seed=1,
                                   operand=operand)
     model.load_state_dict(ref.state_dict())
     return ref, model

@@ -17,6 +17,8 @@ timm 0.9.16 VisionTransformer (vit_base_patch16_224 defaults) as restated:
               attn = softmax((q * hd**-0.5) @ k^T, dim=-1); x = (attn @ v).transpose(1,2).reshape(B,N,D); proj = Linear(D,D)
       - mlp: fc1 = Linear(D, 4D) -> nn.GELU() (exact erf) -> fc2 = Linear(4D, D)
   * norm = LayerNorm(D, eps=1e-6) on all tokens; global_pool='token' -> x[:, 0]; fc_norm = Identity; head = Linear(D, C)
+  * pre_norm=True (the CLIP ViTs, `vit_*_clip_*`): patch_embed.proj has NO bias (timm: `bias=not pre_norm`), `norm_pre = LayerNorm(D, eps)` is applied to the
+    embedded tokens (after the class token and pos_embed) in front of the blocks, norm eps 1e-5; pinned against transformers.CLIPVisionModel (tests/test_oracle_vit.py)
 state_dict key names equal timm's, so reference checkpoints (`ckpt['model']`, vision_engine.py:387-403) load.
 """
 from __future__ import annotations
@@ -31,9 +33,9 @@ from . import bf16ops as ops   # fp32 mode = plain torch (bit-identical to F.lin
 
 
 class PatchEmbed(nn.Module):
-    def __init__(self, patch_size: int, in_chans: int, embed_dim: int):
+    def __init__(self, patch_size: int, in_chans: int, embed_dim: int, bias: bool = True):
         super().__init__()
-        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=True)
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=bias)
 
     def forward(self, x):
         if ops.mode() == "fp32":
@@ -43,7 +45,7 @@ class PatchEmbed(nn.Module):
         p = self.proj.kernel_size[0]
         B, Cc, H, W = x.shape
         pt = x.reshape(B, Cc, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B, (H // p) * (W // p), Cc * p * p)
-        return ops.linear(pt, self.proj.weight.reshape(self.proj.out_channels, -1), self.proj.bias, bias_grad_unrounded=True)
+        return ops.linear(pt, self.proj.weight.reshape(self.proj.out_channels, -1), self.proj.bias, bias_grad_unrounded=self.proj.bias is not None)
 
 
 class Attention(nn.Module):
@@ -89,13 +91,14 @@ class Block(nn.Module):
 
 class VisionTransformerRef(nn.Module):
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12, num_heads=12,
-                 mlp_dim=None, eps=1e-6):
+                 mlp_dim=None, eps=1e-6, pre_norm=False):
         super().__init__()
         mlp_dim = mlp_dim or 4 * embed_dim
         n = (img_size // patch_size) ** 2 + 1
-        self.patch_embed = PatchEmbed(patch_size, in_chans, embed_dim)
+        self.patch_embed = PatchEmbed(patch_size, in_chans, embed_dim, bias=not pre_norm)
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         self.pos_embed = nn.Parameter(torch.randn(1, n, embed_dim) * .02)
+        self.norm_pre = nn.LayerNorm(embed_dim, eps=eps) if pre_norm else nn.Identity()
         self.blocks = nn.Sequential(*[Block(embed_dim, num_heads, mlp_dim, eps) for _ in range(depth)])
         self.norm = nn.LayerNorm(embed_dim, eps=eps)
         self.head = nn.Linear(embed_dim, num_classes)
@@ -117,7 +120,7 @@ class VisionTransformerRef(nn.Module):
     def forward_features(self, x):
         x = self.patch_embed(x)
         x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1)
-        x = x + self.pos_embed
+        x = self.norm_pre(x + self.pos_embed)
         x = self.blocks(x)
         return self.norm(x)
 
@@ -126,7 +129,7 @@ class VisionTransformerRef(nn.Module):
             return self.head(self.forward_features(x)[:, 0])
         # LayerNorm is per token: norm(x)[:, 0] == norm(x[:, 0]); the engine normalises the class-token rows only
         x = self.patch_embed(x)
-        x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embed
+        x = self.norm_pre(torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embed)
         x = self.blocks(x)
         return ops.linear(ops.q(self.norm(x[:, 0])), self.head.weight, self.head.bias)
 

@@ -250,15 +250,15 @@ def test_set_operand_switches_an_existing_model(be, dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,patch,dim,depth,heads,mlp", [("vit_small_patch16_224", 16, 384, 12, 6, 1536), ("vit_large_patch16_224", 16, 1024, 24, 16, 4096),
-                                                            ("vit_base_patch8_224", 8, 768, 12, 12, 3072)])
+                                                            ("vit_base_patch8_224", 8, 768, 12, 12, 3072), ("vit_base_patch16_clip_224", 16, 768, 12, 12, 3072)])
 def test_vit_family_full_size_fp16_operands_within_the_stated_tolerance(hip, name, patch, dim, depth, heads, mlp):
-    """the narrower and the wider / deeper members of the family (384 and 1024 channels, 24 blocks) and the 785-token one (patch 8: the streaming attention kernels) at full
+    """the narrower and the wider / deeper members of the family (384 and 1024 channels, 24 blocks) the 785-token one (patch 8: the streaming attention kernels) and a CLIP one (pre_norm) at full
     size on fp16 operands against ONE fp32 evaluation of the oracle (the base model's test above also runs the operand-rounded and float64 arms): the same literal bounds"""
     from oracle.parity import vit_pair
     from visiondk_amd import vit
     tv = vit.TIMM_VITS[name]
     assert (tv["dim"], tv["depth"], tv["heads"], tv["mlp_dim"], tv.get("patch_size", 16)) == (dim, depth, heads, mlp, patch)      # the id table is what is tested
-    ref, model = vit_pair(hip, "cuda:0", 224, patch, dim, depth, heads, mlp, 1000, seed=2, operand="fp16")
+    ref, model = vit_pair(hip, "cuda:0", 224, patch, dim, depth, heads, mlp, 1000, seed=2, operand="fp16", pre_norm=tv.get("pre_norm", False), eps=tv.get("ln_eps", 1e-6))
     torch.manual_seed(6)
     x = torch.randn(2, 3, 224, 224); y = torch.randint(0, 1000, (2,))
     S = 1024.0

@@ -119,3 +119,58 @@ def test_siglip_map_pool_ref_matches_transformers():
     assert ((feats - out.last_hidden_state).norm() / out.last_hidden_state.norm()).item() < 1e-5
     assert ((pooled - out.pooler_output).norm() / out.pooler_output.norm()).item() < 1e-5
     assert list(sd.keys())[:3] == ["pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias"] and "attn_pool.latent" in sd and "cls_token" not in sd
+
+
+def test_clip_pre_norm_ref_matches_transformers():
+    """timm's CLIP ViTs (`vit_*_clip_*`: pre_norm=True, patch embedding without a bias, LayerNorm eps 1e-5) as restated by VisionTransformerRef(pre_norm=True), pinned against
+    the independent `transformers.CLIPVisionModel` (class embedding + position embedding -> pre_layrnorm -> pre-norm encoder layers; hidden_act gelu: the laion / datacomp
+    weights timm's plain clip ids carry; the quick-GELU ones are separate timm ids).  last_hidden_state there is in front of post_layernorm: compared with the tokens before
+    `norm`."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    torch.manual_seed(0)
+    D, depth, heads, img, ps = 64, 2, 2, 32, 8
+    ref = VisionTransformerRef(img, ps, 3, 10, D, depth, heads, mlp_dim=4 * D, eps=1e-5, pre_norm=True).eval()
+    assert ref.patch_embed.proj.bias is None and "norm_pre.weight" in ref.state_dict() and "patch_embed.proj.bias" not in ref.state_dict()
+    with torch.no_grad():
+        for p in ref.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+        ref.cls_token.add_(torch.randn_like(ref.cls_token) * 0.1)
+    cfg = CLIPVisionConfig(hidden_size=D, intermediate_size=4 * D, num_hidden_layers=depth, num_attention_heads=heads, num_channels=3, image_size=img, patch_size=ps,
+                           hidden_act="gelu", layer_norm_eps=1e-5, attention_dropout=0.0)
+    hf = CLIPVisionModel(cfg).eval()
+    sd, hsd = ref.state_dict(), hf.state_dict()
+
+    def put(name, value):
+        assert hsd[name].shape == value.shape, (name, hsd[name].shape, value.shape)
+        hsd[name] = value.clone()
+
+    pre = "vision_model." if "vision_model.embeddings.class_embedding" in hsd else ""      # (the prefix depends on the transformers version)
+    put(pre + "embeddings.class_embedding", sd["cls_token"].view(D))
+    put(pre + "embeddings.position_embedding.weight", sd["pos_embed"][0])
+    put(pre + "embeddings.patch_embedding.weight", sd["patch_embed.proj.weight"])
+    ln_pre = "pre_layrnorm" if pre + "pre_layrnorm.weight" in hsd else "pre_layernorm"      # (the attribute's spelling in transformers)
+    for kind in ("weight", "bias"):
+        put(pre + f"{ln_pre}.{kind}", sd[f"norm_pre.{kind}"])
+        put(pre + f"post_layernorm.{kind}", sd[f"norm.{kind}"])
+    for i in range(depth):
+        w, b = sd[f"blocks.{i}.attn.qkv.weight"], sd[f"blocks.{i}.attn.qkv.bias"]
+        for j, nm in enumerate(["q_proj", "k_proj", "v_proj"]):
+            put(pre + f"encoder.layers.{i}.self_attn.{nm}.weight", w[j * D:(j + 1) * D])
+            put(pre + f"encoder.layers.{i}.self_attn.{nm}.bias", b[j * D:(j + 1) * D])
+        for kind in ("weight", "bias"):
+            put(pre + f"encoder.layers.{i}.self_attn.out_proj.{kind}", sd[f"blocks.{i}.attn.proj.{kind}"])
+            put(pre + f"encoder.layers.{i}.layer_norm1.{kind}", sd[f"blocks.{i}.norm1.{kind}"])
+            put(pre + f"encoder.layers.{i}.layer_norm2.{kind}", sd[f"blocks.{i}.norm2.{kind}"])
+            put(pre + f"encoder.layers.{i}.mlp.fc1.{kind}", sd[f"blocks.{i}.mlp.fc1.{kind}"])
+            put(pre + f"encoder.layers.{i}.mlp.fc2.{kind}", sd[f"blocks.{i}.mlp.fc2.{kind}"])
+    hf.load_state_dict(hsd)
+    x = torch.randn(3, 3, img, img)
+    with torch.no_grad():
+        tokens = ref.blocks(ref.norm_pre(torch.cat([ref.cls_token.expand(3, -1, -1), ref.patch_embed(x)], 1) + ref.pos_embed))      # in front of `norm`
+        out = hf(pixel_values=x)
+        rel = ((tokens - out.last_hidden_state).norm() / out.last_hidden_state.norm()).item()
+        assert rel < 1e-5, rel
+        pooled = ref.forward_features(x)[:, 0]                                               # norm(tokens)[:, 0] = transformers' pooler_output (post_layernorm of the class token)
+        relp = ((pooled - out.pooler_output).norm() / out.pooler_output.norm()).item()
+        assert relp < 1e-5, relp

@@ -269,3 +269,88 @@ def test_qkv_bias_gradient_from_the_attention_backward(be, dev, monkeypatch):
             assert _rel(p.grad, pr.grad) < 3e-2, (n, _rel(p.grad, pr.grad))
             seen += 1
     assert seen == SPEC.depth
+
+
+# ---- timm pre_norm=True: the CLIP ViTs (`vit_*_clip_*`; cbir.yaml lists vit_base_patch16_clip_224.laion2b_ft_in1k) ----------------------------------------------------------
+PRE_SPEC = vit.VitSpec(img_size=32, patch_size=8, in_chans=3, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256, ln_eps=1e-5, pre_norm=True)
+
+
+def _pre_pair(be, dev, seed=0, operand="bf16"):
+    torch.manual_seed(seed)
+    ref = VisionTransformerRef(PRE_SPEC.img_size, PRE_SPEC.patch_size, 3, PRE_SPEC.num_classes, PRE_SPEC.dim, PRE_SPEC.depth, PRE_SPEC.heads, PRE_SPEC.mlp_dim, eps=1e-5, pre_norm=True)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.05)
+        ref.cls_token.add_(torch.randn_like(ref.cls_token) * 0.02)
+        ref.patch_embed.proj.weight.mul_(8.0); ref.pos_embed.mul_(8.0)      # an embedding of O(1): norm_pre then has something to normalise
+    model = vit.VisionTransformer(PRE_SPEC, device=dev, backend=be, seed=1, operand=operand)
+    model.load_state_dict(ref.state_dict())
+    return ref, model
+
+
+def test_pre_norm_state_dict_names_follow_timm(be, dev):
+    ref, model = _pre_pair(be, dev)
+    names = [n for n, _ in model.named_parameters()]
+    assert names == [n for n, _ in ref.named_parameters()]                 # cls_token, pos_embed, patch_embed.proj.weight, norm_pre.{weight, bias}, blocks..., norm, head
+    assert "norm_pre.weight" in names and "patch_embed.proj.bias" not in names
+    fresh = vit.VisionTransformer(PRE_SPEC, device=dev, backend=be, seed=4)
+    sd = fresh.state_dict()
+    assert torch.equal(sd["norm_pre.weight"].cpu(), torch.ones(PRE_SPEC.dim)) and torch.equal(sd["norm_pre.bias"].cpu(), torch.zeros(PRE_SPEC.dim))
+
+
+@pytest.mark.parametrize("operand", ["bf16", "fp16"])
+def test_pre_norm_forward_backward_vs_oracle(be, dev, operand):
+    ref, model = _pre_pair(be, dev, operand=operand)
+    torch.manual_seed(5)
+    x = torch.randn(3, 3, 32, 32); y = torch.randint(0, 10, (3,))
+    S = 256.0 if operand == "fp16" else 1.0
+    logits_ref = ref(x)
+    torch.nn.functional.cross_entropy(logits_ref, y, label_smoothing=0.05).backward()
+    logits = model(x.to(dev))
+    (torch.nn.functional.cross_entropy(logits, y.to(dev), label_smoothing=0.05) * S).backward()
+    tol_l, tol_g = (2e-2, 6e-2) if operand == "bf16" else (3e-3, 1e-2)
+    assert _rel(logits, logits_ref) < tol_l, _rel(logits, logits_ref)
+    for (n, p), (nr, pr) in zip(model.named_parameters(), ref.named_parameters()):
+        assert n == nr and p.grad is not None, n
+        assert _rel(p.grad / S, pr.grad) < tol_g, (n, _rel(p.grad / S, pr.grad))
+    # the unreported bias slot of the patch embedding holds zeros and its gradient is zero: the optimizer leaves it alone
+    eng = model.engine
+    assert float(eng.params.abs().sum()) > 0
+    listed = torch.zeros(eng.n_floats, dtype=torch.bool)
+    for _, off, numel, _ in eng.entries:
+        listed[off:off + numel] = True
+    assert float(eng.params.cpu()[~listed].abs().max()) == 0.0 and float(eng.grads.cpu()[~listed].abs().max()) == 0.0
+
+
+def test_pre_norm_precise_forward_vs_oracle(be, dev):
+    ref, model = _pre_pair(be, dev)
+    torch.manual_seed(6)
+    x = torch.randn(2, 3, 32, 32)
+    with torch.no_grad():
+        want = ref(x)
+        got = model.forward_precise(x.to(dev))
+    assert _rel(got, want) < 1e-4, _rel(got, want)
+
+
+def test_pre_norm_fused_step_vs_reference_step(be, dev):
+    ref, model = _pre_pair(be, dev, seed=3)
+    hyp = dict(lr=0.01, momentum=0.937, weight_decay=5e-4)
+    step = vit.FusedTrainStep(model, label_smoothing=0.05, max_norm=10.0, ema=False, **hyp)
+    init_sd = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    bufs = None
+    torch.manual_seed(11)
+    for it in range(2):
+        x = torch.randn(4, 3, 32, 32); y = torch.randint(0, 10, (4,))
+        _, loss_ref, _, _, bufs = train_step_reference(ref, x, y, label_smoothing=0.05, max_norm=10.0, momentum_bufs=bufs, ema=None, updates=it, **hyp)
+        step.step(x.to(dev), y.to(dev))
+        assert abs(step.loss_value() - loss_ref.item()) < 1e-2 * abs(loss_ref.item())
+    sd = model.state_dict()
+    for n, p in ref.named_parameters():
+        assert _rel(sd[n].cpu() - init_sd[n], p.detach() - init_sd[n]) < 8e-2, n
+
+
+def test_clip_ids_build(be, dev):
+    for name in ("vit_base_patch32_clip_224", "vit_base_patch16_clip_224", "vit_large_patch14_clip_224", "vit_large_patch14_clip_336"):
+        spec = vit.spec_from_timm_name(name, 7)
+        assert spec.pre_norm and spec.ln_eps == 1e-5

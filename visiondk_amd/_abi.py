@@ -32,7 +32,7 @@ class ConvGeom(C.Structure):
 class VitConfig(C.Structure):
     """VdkVitConfig of include/visiondk.h"""
     _fields_ = [("batch", I32), ("img_size", I32), ("patch_size", I32), ("in_chans", I32), ("dim", I32), ("depth", I32),
-                ("heads", I32), ("mlp_dim", I32), ("num_classes", I32), ("ln_eps", F32), ("no_class_token", I32), ("fp8", I32), ("fp8_w", P), ("fp8_state", P), ("operand", I32)]
+                ("heads", I32), ("mlp_dim", I32), ("num_classes", I32), ("ln_eps", F32), ("no_class_token", I32), ("fp8", I32), ("fp8_w", P), ("fp8_state", P), ("operand", I32), ("pre_norm", I32)]
 
 
 class GemmF32Desc(C.Structure):

@@ -70,7 +70,7 @@ static bool gelu_saved_grad() {
 static inline int64_t up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 struct VitDims {
-  int B, img, ps, Cin, D, L, H, M, C, Cp, np, N, T, Kraw, Kpe, Tp, Bp, cls, fp8, opf /* operand format: VDK_OPF_BF16 | VDK_OPF_F16 (VdkVitConfig.operand) */;   // cls: 1 = class token in row 0 of every image's token block   // Kraw = in_chans * patch^2, Kpe = Kraw padded to 8 (patch 14: 588 -> 592)
+  int B, img, ps, Cin, D, L, H, M, C, Cp, np, N, T, Kraw, Kpe, Tp, Bp, cls, pre /* VdkVitConfig.pre_norm */, fp8, opf /* operand format: VDK_OPF_BF16 | VDK_OPF_F16 (VdkVitConfig.operand) */;   // cls: 1 = class token in row 0 of every image's token block   // Kraw = in_chans * patch^2, Kpe = Kraw padded to 8 (patch 14: 588 -> 592)
   float eps;
 };
 static int vit_dims(const VdkVitConfig* c, VitDims* d) {
@@ -85,6 +85,8 @@ static int vit_dims(const VdkVitConfig* c, VitDims* d) {
   d->Kpe = (int)up(d->Kraw, 8);     // patch 14 (timm vit_*_patch14_*: K = 588): the GEMM operands are zero-padded copies, the parameter itself stays [D, Kraw]
   d->np = (d->img / d->ps) * (d->img / d->ps);
   d->cls = c->no_class_token ? 0 : 1;
+  d->pre = c->pre_norm ? 1 : 0;
+  if (d->pre && c->fp8) return vdk_fail(VDK_EUNSUPPORTED, "vit: pre_norm and the fp8 mode are not combined");
   if (!d->cls && d->C > 0) return vdk_fail(VDK_EUNSUPPORTED, "vit: no_class_token is feature mode only (num_classes == 0)");
   d->N = d->np + d->cls;
   d->T = d->B * d->N;
@@ -104,7 +106,7 @@ static int vit_dims(const VdkVitConfig* c, VitDims* d) {
 struct PEntry { char name[64]; int64_t off, numel; int64_t shape[4]; int ndim; };
 struct PLayout {
   // offsets into the flat fp32/bf16 buffers
-  int64_t cls, pos, pe_w, pe_b, norm_w, norm_b, head_w, head_b, total;
+  int64_t cls, pos, pe_w, pe_b, npre_w, npre_b, norm_w, norm_b, head_w, head_b, total;      // (pre_norm: pe_b stays allocated and zero, npre_* = norm_pre)
   struct Blk { int64_t n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b; };
   Blk blk[64];
   // offsets into the transposed-weight buffer (bf16 elements)
@@ -119,6 +121,8 @@ static int vit_layout(const VitDims& d, PLayout* p) {
   p->pos = p_take(cur, (int64_t)d.N * d.D);
   p->pe_w = p_take(cur, (int64_t)d.D * d.Kraw);
   p->pe_b = p_take(cur, d.D);
+  p->npre_w = p->npre_b = 0;
+  if (d.pre) { p->npre_w = p_take(cur, d.D); p->npre_b = p_take(cur, d.D); }
   for (int l = 0; l < d.L; ++l) {
     PLayout::Blk& b = p->blk[l];
     b.n1w = p_take(cur, d.D); b.n1b = p_take(cur, d.D);
@@ -156,16 +160,18 @@ static void pe_set(PEntry* e, const char* name, int64_t off, int ndim, int64_t s
 // timm state_dict order and names; head rows are reported unpadded ([C, D]; the padding rows
 // follow in memory and must stay zero).
 static int vit_entry(const VitDims& d, const PLayout& p, int idx, PEntry* e) {
-  const int per = 12, ntens = 4 + per * d.L + (d.C > 0 ? 4 : 2);   // feature mode (num_classes = 0) has no head
+  const int per = 12, nb0 = d.pre ? 5 : 4, ntens = nb0 + per * d.L + (d.C > 0 ? 4 : 2);   // feature mode (num_classes = 0) has no head; pre_norm: norm_pre.{weight, bias} instead of patch_embed.proj.bias
   if (!d.cls) { if (idx < 0) return -1; ++idx; }                    // class_token=False: the state dict starts at pos_embed
   if (idx < 0 || idx >= ntens) return -1;
   char nm[64];
   if (idx == 0) { pe_set(e, "cls_token", p.cls, 3, 1, 1, d.D); return 0; }
   if (idx == 1) { pe_set(e, "pos_embed", p.pos, 3, 1, d.N, d.D); return 0; }
   if (idx == 2) { pe_set(e, "patch_embed.proj.weight", p.pe_w, 4, d.D, d.Cin, d.ps, d.ps); return 0; }
-  if (idx == 3) { pe_set(e, "patch_embed.proj.bias", p.pe_b, 1, d.D); return 0; }
-  if (idx < 4 + per * d.L) {
-    int l = (idx - 4) / per, k = (idx - 4) % per;
+  if (idx == 3 && !d.pre) { pe_set(e, "patch_embed.proj.bias", p.pe_b, 1, d.D); return 0; }
+  if (idx == 3) { pe_set(e, "norm_pre.weight", p.npre_w, 1, d.D); return 0; }
+  if (idx == 4 && d.pre) { pe_set(e, "norm_pre.bias", p.npre_b, 1, d.D); return 0; }
+  if (idx < nb0 + per * d.L) {
+    int l = (idx - nb0) / per, k = (idx - nb0) % per;
     const PLayout::Blk& b = p.blk[l];
     static const char* suffix[12] = {"norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
                                      "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"};
@@ -186,7 +192,7 @@ static int vit_entry(const VitDims& d, const PLayout& p, int idx, PEntry* e) {
     }
     return 0;
   }
-  int k = idx - 4 - per * d.L;
+  int k = idx - nb0 - per * d.L;
   if (k == 0) pe_set(e, "norm.weight", p.norm_w, 1, d.D);
   else if (k == 1) pe_set(e, "norm.bias", p.norm_b, 1, d.D);
   else if (k == 2) pe_set(e, "head.weight", p.head_w, 2, d.C, d.D);
@@ -200,6 +206,7 @@ struct WsPlan {
   size_t patches;            // bf16 [B*np, Kpe]
   size_t pepad, dwpe;        // Kraw != Kpe only: bf16 [D, Kpe] zero-padded copy of patch_embed.proj.weight, f32 [D, Kpe] its padded gradient
   size_t X;                  // fp32 (2L+1) x [T, D]  : X[2l] block input, X[2l+1] after attention, X[2L] output
+  size_t xe, pstats;         // pre_norm only: fp32 [T, D] the embedding in front of norm_pre, fp32 2 x [T] its row statistics
   size_t stats;              // fp32 L x 4 x [T] (mean1, rstd1, mean2, rstd2) + 2 x [B]
   size_t h1, qkv, lse, o, h2, u, g;   // per-layer strides below
   size_t s_h, s_qkv, s_lse, s_u;      // per-layer sizes in bytes
@@ -246,6 +253,8 @@ static int vit_plan(const VitDims& d, WsPlan* w) {
   w->pepad = w->dwpe = 0;
   if (d.Kraw != d.Kpe) { w->pepad = w_take(cur, D * d.Kpe * 2); w->dwpe = w_take(cur, D * d.Kpe * 4); }
   w->X = w_take(cur, (2 * L + 1) * T * D * 4);
+  w->xe = w->pstats = 0;
+  if (d.pre) { w->xe = w_take(cur, T * D * 4); w->pstats = w_take(cur, 2 * T * 4); }
   w->stats = w_take(cur, (L * 4 * T + 2 * T) * 4);   // + final norm: B rows (token pooling) or all T rows (feature mode)
   w->s_h = T * D * 2; w->s_qkv = T * 3 * D * 2; w->s_lse = (size_t)d.B * d.H * d.N * 4; w->s_u = T * M * 2;
   w->h1 = w_take(cur, L * w->s_h); w->qkv = w_take(cur, L * w->s_qkv); w->lse = w_take(cur, L * w->s_lse);
@@ -374,7 +383,7 @@ int vdk_vit_param_count(const VdkVitConfig* cfg, int64_t* n_floats, int32_t* n_t
   VitDims d; RC(vit_dims(cfg, &d));
   PLayout p; RC(vit_layout(d, &p));
   if (n_floats) *n_floats = p.total;
-  if (n_tensors) *n_tensors = 3 + d.cls + 12 * d.L + (d.C > 0 ? 4 : 2);
+  if (n_tensors) *n_tensors = 3 + d.pre + d.cls + 12 * d.L + (d.C > 0 ? 4 : 2);
   if (n_transposed) *n_transposed = p.totalT;
   return VDK_OK;
 }
@@ -471,9 +480,14 @@ int vdk_vit_forward(const VdkVitConfig* cfg, const float* x, const float* params
     RC(vdk_cast_pad_rows(params + p.pe_w, d.Kraw, D, d.Kraw, base + w.pepad, d.Kpe, s, t_opf));
     pew = (const bf16_t*)(base + w.pepad);
   }
-  RC(gemm(s, patches, d.Kpe, pew, d.Kpe, X, D, d.B * d.np, D, d.Kpe, VDK_F32, params + p.pe_b, params + p.pos, D, VDK_ACT_NONE,
-          nullptr, 0, 1, d.cls ? d.np : -d.np, nullptr, 0));
-  if (d.cls) RC(vdk_cls_rows(X, (int64_t)d.N * D, d.B, D, params + p.cls, params + p.pos, s));
+  float* const X0 = d.pre ? (float*)(base + w.xe) : X;      // pre_norm: the embedding lands in front of norm_pre, whose output is block 0's input
+  RC(gemm(s, patches, d.Kpe, pew, d.Kpe, X0, D, d.B * d.np, D, d.Kpe, VDK_F32, params + p.pe_b, params + p.pos, D, VDK_ACT_NONE,
+          nullptr, 0, 1, d.cls ? d.np : -d.np, nullptr, 0));      // (pre_norm: the bias slot holds zeros -- timm builds that patch embedding without a bias)
+  if (d.cls) RC(vdk_cls_rows(X0, (int64_t)d.N * D, d.B, D, params + p.cls, params + p.pos, s));
+  if (d.pre) {
+    float* ps = (float*)(base + w.pstats);
+    RC(vdk_layernorm_fwd(X0, D, T, D, params + p.npre_w, params + p.npre_b, d.eps, X, D, VDK_F32, ps, ps + T, s));
+  }
 
   const float scale = 0.125f;  // head_dim ** -0.5, head_dim == 64
   F8 f8; RC(f8_init(cfg, d, p, &f8, (unsigned char*)(base + w.a8), (unsigned char*)(base + w.a8b)));
@@ -784,11 +798,19 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
   // ---- embeddings -------------------------------------------------------------------------------------
   {
     float* dposall = (float*)(base + w.dposall);
-    // d pos_embed[n] = sum_b dx0[b, n];  d cls = d pos_embed[0];  d patch bias = sum_{n >= 1} d pos_embed[n]
-    RC(vdk_reduce_rows_f32(dxa, (int64_t)d.N * D, d.B, (int64_t)d.N * D, grads + p.pos, 1.0f, s));
+    const float* dx0 = dxa;      // dL/d(embedding)
+    if (d.pre) {      // norm_pre backward: dxa = dL/d(block 0's input) -> dxm = dL/d(embedding), its 16-bit copy (the patch embedding's dY) over DXAB(-1), norm_pre's own gradients
+      const float* ps = (const float*)(base + w.pstats);
+      RC(vdk_layernorm_bwd_deferred(dxa, D, VDK_F32, (const float*)(base + w.xe), D, ps, ps + T, params + p.npre_w, nullptr, 0, T, D, dxm, D, DXAB(-1), D, grads + p.npre_w,
+                                    grads + p.npre_b, lnws, w.lnws_bytes, s, nullptr, nullptr, nullptr, nullptr, t_opf));
+      dx0 = dxm;
+    }
+    // d pos_embed[n] = sum_b dx0[b, n];  d cls = d pos_embed[0];  d patch bias = sum_{n >= 1} d pos_embed[n] (pre_norm: there is no such bias, its slot's gradient stays zero)
+    RC(vdk_reduce_rows_f32(dx0, (int64_t)d.N * D, d.B, (int64_t)d.N * D, grads + p.pos, 1.0f, s));
     if (d.cls && hipMemcpyAsync(grads + p.cls, grads + p.pos, (size_t)D * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
       return vdk_fail(VDK_ELAUNCH, "vdk_vit_backward: memcpy failed");
-    RC(vdk_reduce_rows_f32(grads + p.pos + (size_t)d.cls * D, D, d.np, D, grads + p.pe_b, 1.0f, s));
+    if (!d.pre) RC(vdk_reduce_rows_f32(grads + p.pos + (size_t)d.cls * D, D, d.np, D, grads + p.pe_b, 1.0f, s));
+    else if (hipMemsetAsync(grads + p.pe_b, 0, (size_t)D * 4, s) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vdk_vit_backward: memset failed");
     (void)dposall;
     bf16_t* patches = (bf16_t*)(base + w.patches);
     const int rows = d.B * d.np, rows_pad = (int)up(rows, 64);
@@ -871,6 +893,10 @@ int vdk_vit_forward_f32(const VdkVitConfig* cfg, const float* x, const float* pa
     RC(vdk_gemm_f32_nt(&g, s));
   }
   if (d.cls) RC(vdk_cls_rows(xa, (int64_t)N * D, d.B, D, params + p.cls, params + p.pos, s));
+  if (d.pre) {      // norm_pre (the bias slot of the patch embedding holds zeros in this mode)
+    RC(vdk_layernorm_fwd(xa, D, T, D, params + p.npre_w, params + p.npre_b, d.eps, xb, D, VDK_F32, nullptr, nullptr, s));
+    float* t = xa; xa = xb; xb = t;
+  }
   for (int l = 0; l < d.L; ++l) {
     const PLayout::Blk& b = p.blk[l];
     RC(vdk_layernorm_fwd(xa, D, T, D, params + b.n1w, params + b.n1b, d.eps, h, D, VDK_F32, nullptr, nullptr, s));

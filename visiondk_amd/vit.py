@@ -36,6 +36,7 @@ class VitSpec:
     mlp_dim: int = 3072
     ln_eps: float = 1e-6
     class_token: bool = True      # timm class_token=False (the SigLIP ViTs): tokens are the patches only; feature mode (num_classes=0) in the engine
+    pre_norm: bool = False        # timm pre_norm=True (the CLIP ViTs): LayerNorm `norm_pre` in front of the blocks, patch embedding without a bias
 
 
 # timm 0.9.16 model ids the engine covers (head_dim 64; patch 14 works through zero-padded operand copies of the patch-embedding weight)
@@ -50,6 +51,11 @@ TIMM_VITS = {
     "vit_large_patch16_224": dict(dim=1024, depth=24, heads=16, mlp_dim=4096),
     "vit_base_patch16_384": dict(dim=768, depth=12, heads=12, mlp_dim=3072, img_size=384),
     "vit_large_patch14_224": dict(dim=1024, depth=24, heads=16, mlp_dim=4096, patch_size=14),
+    # the CLIP ViTs (pre_norm=True, LayerNorm eps 1e-5; GELU -- the quick-GELU ids are separate models); `vit_base_patch16_clip_224.laion2b_ft_in1k` is listed in the shipped YAMLs
+    "vit_base_patch32_clip_224": dict(dim=768, depth=12, heads=12, mlp_dim=3072, patch_size=32, pre_norm=True, ln_eps=1e-5),
+    "vit_base_patch16_clip_224": dict(dim=768, depth=12, heads=12, mlp_dim=3072, pre_norm=True, ln_eps=1e-5),
+    "vit_large_patch14_clip_224": dict(dim=1024, depth=24, heads=16, mlp_dim=4096, patch_size=14, pre_norm=True, ln_eps=1e-5),
+    "vit_large_patch14_clip_336": dict(dim=1024, depth=24, heads=16, mlp_dim=4096, patch_size=14, img_size=336, pre_norm=True, ln_eps=1e-5),
     # class_token=False + global_pool='map' (SigLIP): served by VisionTransformerMap
     "vit_base_patch16_siglip_224": dict(dim=768, depth=12, heads=12, mlp_dim=3072, class_token=False),
     "vit_large_patch16_siglip_256": dict(dim=1024, depth=24, heads=16, mlp_dim=4096, img_size=256, class_token=False),
@@ -143,7 +149,7 @@ class VitEngine:
         s = self.spec
         return _abi.VitConfig(batch, s.img_size, s.patch_size, s.in_chans, s.dim, s.depth, s.heads, s.mlp_dim, s.num_classes, s.ln_eps, 0 if s.class_token else 1,
                               self.fp8, self.be.ptr(self.fp8_w) if self.fp8 else None, self.be.ptr(self.fp8_state) if self.fp8 else None,
-                              _abi.F16_ if self.operand == "fp16" else _abi.BF16)
+                              _abi.F16_ if self.operand == "fp16" else _abi.BF16, 1 if s.pre_norm else 0)
 
     def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
         for n, off, numel, shape in self.entries:
@@ -338,7 +344,7 @@ class VisionTransformer(nn.Module):
                     v = torch.empty(p.shape).normal_(0, 0.02, generator=gen).clamp_(-2.0, 2.0)
                 elif name == "cls_token":
                     v = torch.empty(p.shape).normal_(0, 1e-6, generator=gen)
-                elif name.endswith("norm1.weight") or name.endswith("norm2.weight") or name == "norm.weight":
+                elif name.endswith("norm1.weight") or name.endswith("norm2.weight") or name in ("norm.weight", "norm_pre.weight"):
                     v = torch.ones(p.shape)
                 elif name == "patch_embed.proj.bias":
                     bound = 1.0 / math.sqrt(s.in_chans * s.patch_size * s.patch_size)
