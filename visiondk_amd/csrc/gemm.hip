@@ -717,12 +717,15 @@ static bool w4h_wanted(int E, bool trans, long M, long N, long K) {
   // (6 272 rows, stage 4: N 1024 K 4096 69 / 51, N 1024 K 1024 29 / 22, N 3072 -> 1024 52 / 39), whatever the epilogue.  (196 tiles -- 25 088 x 512 -- still prefer the
   // four-wave kernel when K is long: K 2048 49 / 53, in the step 50 / 66.)
   if (tiles < 128) return true;
+  // round 6 (tools/r6_stagger_ab.py, persistent walk with its start phase): the one-multiplication dGELU form (saved derivative) 275-281 us four-wave against 285.5; the
+  // form that evaluates GELU' stays with the two-workgroup kernel (323 against 340-355)
+  if ((E & E_DGELU) && (E & E_AUXD) && tiles > 256) return false;
   if (E & E_DGELU) return true;
   // GELU: the four-wave kernel's whole-tile rounds against hardware-dispatched half tiles -- 25 088 x 2048 x 512 (stage 3) is 784 tiles = 3.06 rounds, 99 / 90 us
   static const long gelu_k = getenv("VDK_GEMM_W4H_GELU_K") ? atol(getenv("VDK_GEMM_W4H_GELU_K")) : 0;      // A/B: GELU problems with K <= this go to the two-workgroup form
   if ((E & E_GELU) && gelu_k > 0 && K <= gelu_k) return true;
   if (E & E_GELU) return K <= 768 && (double)tiles / (double)((tiles + 255) / 256 * 256) < 0.8;
-  if (E & E_RES) return K < 1536;
+  if (E & E_RES) return K < 1536 && tiles <= 256;      // (round 6: more tiles than CUs -> the persistent walk with its start phase: proj + fp32 residual 102-105 us against 107 us)
   return K <= 1024 && tiles <= 3 * 256;
 }
 // rows from which a 128 <= N < 256 problem goes to the 256x128 kernel (one workgroup per 256 rows: below ~one workgroup per CU the 128x128 kernel has more parallelism);

@@ -29,6 +29,8 @@
 #include "vdk_device.h"
 #include "vdk_host.h"
 #include <atomic>
+#include <string.h>
+#include <stdlib.h>
 #include "vdk_gemm.h"
 #include "vdk_gemm_epilogue.h"
 
@@ -635,6 +637,24 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
   int kend = kbeg + p.k_per_split; if (kend > p.K) kend = p.K;
   const int nk = (kend - kbeg) / 64;
   if (t_idx >= t_cnt || nk < 2) return;                   // (uniform: the whole workgroup leaves before any barrier)
+#ifndef VDK_EMU
+  // Start phase of the persistent walk (p.stagger shader cycles ~ one tile period; 0: off).  Equal tiles keep all CUs in lock-step: every workgroup multiplies, then every
+  // workgroup runs its epilogue, so the HBM traffic of the epilogues (fp32 residual in / out: 512 KB per tile) comes in chip-wide bursts during which no MFMA runs, and the
+  // main loops leave HBM idle.  Workgroups that walk one tile fewer than the busiest ones have a tile period of slack: they start a hashed fraction of it late
+  // (stagger_lo = 1: every workgroup is delayed by a hashed fraction of half a period, slack or not -- experiments).
+  if (PERSIST && p.stagger > 0) {
+    const int max_tcnt = (nwg >> 3) + ((nwg & 7) ? 1 : 0);
+    const int my_cnt = (t_cnt - t_idx + t_stride - 1) / t_stride, max_cnt = (max_tcnt + t_stride - 1) / t_stride;
+    const unsigned hsh = ((unsigned)blockIdx.x * 0x9E3779B1u) >> 16;                    // uniform in [0, 65536)
+    long delay = 0;
+    if (my_cnt < max_cnt) delay = ((long)p.stagger * (long)hsh) >> 16;
+    else if (p.stagger_lo == 1) delay = ((long)p.stagger * (long)hsh) >> 17;
+    if (delay > 0) {
+      const unsigned long long t0 = __builtin_readcyclecounter();
+      while ((long)(__builtin_readcyclecounter() - t0) < delay) __builtin_amdgcn_s_sleep(16);
+    }
+  }
+#endif
 
   W4Dma da, db;
   const bool convb = TN && p.conv_on;      // the implicit weight gradient: B gathered from the NHWC input, A's valid rows end at crows (K is crows rounded up)
@@ -995,7 +1015,9 @@ bool W4_SYM(vdk_gemm_w4_launch)(const GemmParams& p, bool trans, int E, unsigned
   // The ragged last round.  T tiles on G CUs take ceil(T / G) rounds of whole tiles (591 on 256: 2.31 -> 3).  When the tile rows beyond the last whole round are
   // few (at most G / 2 tiles) and the k-range is long enough to pay for a second launch, the whole rounds go to the persistent kernel and the remaining ROWS to the
   // 256x128 kernel, whose workgroups then each have a CU to themselves: 2.31 -> ~2.5 rounds.  Both launches are ordinary GEMMs over a row range of the operands.
-  static const bool split_on = !(getenv("VDK_GEMM_W4_SPLIT") && atoi(getenv("VDK_GEMM_W4_SPLIT")) == 0);
+  // (round 6: off by default -- with the start phase of the walk the unsplit persistent launch is the faster one: fc2 247.7 against 253.6 us, dfc1 213.6 / 216.8, dqkv 161.7 / 164.6;
+  //  VDK_GEMM_W4_SPLIT=1 restores the two-launch form; re-read per launch: A/B runs in one process)
+  const bool split_on = getenv("VDK_GEMM_W4_SPLIT") && atoi(getenv("VDK_GEMM_W4_SPLIT")) == 1;
   if (split_on && !trans && splitk == 1 && tiles > G && p.K >= 1536 && E != E_GENERIC && !(E & (E_ROWGRP | E_MSTAT | E_MGRAD | E_SPLITK))) {
     const unsigned ntn = (unsigned)((p.N + 255) / 256), ntm = (unsigned)((p.M + 255) / 256);
     const unsigned rows1 = (tiles / G) * G / ntn;         // tile rows covered by whole rounds
@@ -1043,6 +1065,21 @@ static bool w4_launch_one(const GemmParams& p_, bool trans, int E, unsigned tile
   const unsigned G = (unsigned)w4_cus();
   const bool persist = splitk == 1 && tiles > G;          // more tiles than CUs: walk them (with one tile per workgroup there is nothing to prefetch)
   const dim3 pgrid(G, 1u);
+  p.stagger = 0; p.stagger_lo = 0;
+  if (persist) {
+    // start phase of the walk (see the kernel): percent of an estimated tile period; VDK_GEMM_W4_STAGGER = "<percent>[,all]" is re-read per launch (A/B runs in one process)
+    // Measured (tools/r6_stagger_ab.py, ViT-B/16 shapes at T = 50 432, fp16, us, off / 50 % / 90 % / 100 % for everybody): proj + fp32 residual 116.5 / 104.7 / 102.4 / 109.7,
+    // fc2 + residual 261.5 / 247.7 / 247.7 / 270.9, dfc2 x saved derivative 284.5 / 275.0 / 280.8 / 286.4, dfc1 220.4 / 214.8 / 213.6 / 234.8, dqkv 169.0 / 163.8 / 161.7 / 176.8.
+    int pct = 75, all = 0;
+    if (const char* e = getenv("VDK_GEMM_W4_STAGGER")) { pct = atoi(e); all = strstr(e, "all") != nullptr; }
+    if (pct > 0) {
+      const int nk = p.K / 64;
+      int epi = 6000;
+      if (E != E_GENERIC && (E & E_GELU)) epi = 20000; else if (E != E_GENERIC && (E & E_DGELU)) epi = 20000; else if (E == E_GENERIC || (E & (E_RES | E_F32))) epi = 25000;
+      p.stagger = (int)((long)(nk * 2300 + epi) * pct / 100);
+      p.stagger_lo = all;
+    }
+  }
   if (trans) {
     switch (E) {
       case E_SPLITK: W4_LAUNCH(true, E_SPLITK);

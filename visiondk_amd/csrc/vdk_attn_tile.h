@@ -18,6 +18,26 @@ __device__ __forceinline__ void as_dma_rows(unsigned char* arr, const bf16_t* __
     __builtin_amdgcn_global_load_lds(VDK_GLOBAL_PTR(g), VDK_LDS_PTR(arr + j * 1024), 16, 0, 0);
   }
 }
+// The same rows by an LDS-DMA the compiler does not see (inline asm, cdna_hip_programming.md section 5.7).  With the builtin form hipcc keeps the DMA on its own vmcnt
+// scoreboard: it waits vmcnt(0) in front of the next ds_read_b64_tr_b16 and in front of every __syncthreads(), i.e. a tile requested two tiles ahead was waited for inside
+// the tile that requested it (one exposed memory round trip per query tile of the one-pass backward).  The caller counts completion by hand (s_waitcnt vmcnt(n)) and makes
+// the rows visible to the other waves with a barrier behind that wait.
+__device__ __forceinline__ void as_dma16_raw(const bf16_t* g, unsigned char* lds_dst) {
+#ifdef VDK_EMU
+  __builtin_amdgcn_global_load_lds(VDK_GLOBAL_PTR(g), VDK_LDS_PTR(lds_dst), 16, 0, 0);
+#else
+  const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)VDK_LDS_PTR(lds_dst));
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory");
+#endif
+}
+__device__ __forceinline__ void as_dma_rows_raw(unsigned char* arr, const bf16_t* __restrict__ src, long ld, int N, int R8, int w, int nw, int lane) {
+  for (int j = w; j < (R8 >> 3); j += nw) {
+    const int row = 8 * j + (lane >> 3);
+    const int c = (lane & 7) ^ as_f(row);
+    const int srow = row < N ? row : N - 1;
+    as_dma16_raw(src + (long)srow * ld + c * 8, arr + j * 1024);
+  }
+}
 // MFMA A/B fragment of a row-major staged tile: lane (row, hi) -> the 16 bytes at k = 16*ks + 8*hi
 __device__ __forceinline__ s16x8 as_row_frag(const unsigned char* arr, int row, int ks, int hi) {
   return *(const s16x8*)(arr + row * AS_ROW + (((2 * ks + hi) ^ as_f(row)) << 4));
