@@ -9,6 +9,7 @@ be = _lib.load()
 kern, M, N, K = (int(x) for x in sys.argv[1:5])
 trans = len(sys.argv) > 5 and sys.argv[5] == "1"
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 5
+splitk = int(sys.argv[7]) if len(sys.argv) > 7 else 1
 torch.manual_seed(0)
 if trans:
     a = torch.randn(K, M, device="cuda").bfloat16(); b = torch.randn(K, N, device="cuda").bfloat16()
@@ -21,5 +22,5 @@ if kern < 0:
 else:
     be.lib.vdk_gemm_force_kernel(kern)
     for _ in range(iters):
-        ops.gemm_nt(a, b, out=o, trans=trans, backend=be)
+        ops.gemm_nt(a, b, out=o, trans=trans, backend=be, **({"splitk": splitk} if splitk > 1 else {}))
 torch.cuda.synchronize()

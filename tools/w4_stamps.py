@@ -8,16 +8,22 @@ be = _lib.load()
 M, N, K = (int(x) for x in sys.argv[1:4])
 ep = sys.argv[4] if len(sys.argv) > 4 else "plain"
 torch.manual_seed(0)
-a = torch.randn(M, K, device="cuda").bfloat16(); b = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+import os
+DT = torch.float16 if os.environ.get("DT", "bf16") == "fp16" else torch.bfloat16
+a = torch.randn(M, K, device="cuda").to(DT); b = (torch.randn(N, K, device="cuda") * 0.05).to(DT)
 bias = torch.randn(N, device="cuda")
 kw = {}
-odt = torch.bfloat16
+odt = DT
 if ep == "bias": kw = {"bias": bias}
 elif ep == "res": kw = {"bias": bias, "residual": torch.randn(M, N, device="cuda")}; odt = torch.float32
-elif ep == "gelu": kw = {"bias": bias, "act": ops.ACT_GELU, "aux": torch.empty(M, N, device="cuda", dtype=torch.bfloat16)}
+elif ep == "gelu": kw = {"bias": bias, "act": ops.ACT_GELU, "aux": torch.empty(M, N, device="cuda", dtype=DT)}
+elif ep == "gelud": kw = {"bias": bias, "act": ops.ACT_GELU_SAVE_GRAD, "aux": torch.empty(M, N, device="cuda", dtype=DT)}
+elif ep == "mulaux":
+    rows = be.lib.vdk_gemm_c_colsum_rows(M, N, K)
+    kw = {"act": ops.ACT_MUL_AUX, "aux": torch.randn(M, N, device="cuda").to(DT), "c_colsum": torch.empty(rows, N, device="cuda")}
 elif ep == "dgelu":
     rows = be.lib.vdk_gemm_c_colsum_rows(M, N, K)
-    kw = {"act": ops.ACT_DGELU, "aux": torch.randn(M, N, device="cuda").bfloat16(), "c_colsum": torch.empty(rows, N, device="cuda")}
+    kw = {"act": ops.ACT_DGELU, "aux": torch.randn(M, N, device="cuda").to(DT), "c_colsum": torch.empty(rows, N, device="cuda")}
 o = torch.empty(M, N, dtype=odt, device="cuda")
 be.lib.vdk_gemm_force_kernel(5)
 for _ in range(3):

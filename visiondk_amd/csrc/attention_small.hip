@@ -117,6 +117,15 @@ __global__ __launch_bounds__(256, (NKT <= 7 ? 2 : 1)) void attn_s_fwd_kernel(con
 // K^T fragments of the dQ role and the K / V row fragments of the key role are re-read from the K / V tiles (held in registers they push the kernel past 256: spills).
 // LDS: 24 KB (Q_j, dO_j x 3) + 2 x 28 KB (K, V tiles) + 2 x 15.75 KB (dS; at an item's end the waves' store tiles) + 31.5 KB (dQ rows) + lse / D + 6 KB = 151 KB; 8 waves x 256 registers.
 #define A5_PITCH 72                       /* bytes per key row of the dS exchange: 32 queries x 2 B + 8 (the 8-byte writes of 32 key lanes then hit 32 distinct bank pairs) */
+#ifndef A5_KVREG
+#define A5_KVREG 1                       /* the wave's K / V row fragments: 1 = read once per item into registers, 0 = re-read from the LDS tiles in every key phase */
+#endif
+#ifndef A5_SWAP
+#define A5_SWAP 1                        /* 1: waves 0..3 run key phase j + 1 before dQ phase j, waves 4..7 after it */
+#endif
+#ifndef A5_KP
+#define A5_KP 1                          /* key-phase order: 0 = the scheduler's (MFMAs, VALU, MFMAs), 1 = MFMAs interleaved with the softmax arithmetic by hand */
+#endif
 #define A5_QPITCH 144                     /* bytes per query row of the dQ staging: 64 d x 2 B + 16 */
 template <int NKT, int OF>
 __global__ __launch_bounds__(512) void attn_s_bwd5_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long ld,
@@ -230,8 +239,18 @@ __global__ __launch_bounds__(512) void attn_s_bwd5_kernel(const bf16_t* __restri
     __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): this item's requests (and the previous item's stores)
     __syncthreads();
     if (cspart && pb >= 0) cs_flush();                                // (CSs is written again at the END of this item, several barriers from here)
-#pragma unroll 1
-    for (int j = 0; j < nt; ++j) {
+    s16x8 kfr[4], vfr[4];                                             // the wave's K / V row fragments for the whole item, from its landed tiles
+#if A5_KVREG
+    if (keyw) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { kfr[ks] = as_row_frag_l(Kt, al, ks); vfr[ks] = as_row_frag_l(Vt, al, ks); }
+    }
+#endif
+    // One query tile = a key phase (S, dP, P, dS; dV / dK accumulate; dS to the exchange buffer) and a dQ phase (the wave's 16 x 16 block of dQ_j^T over all keys) with the
+    // tile's one barrier between them.  Between barrier j and barrier j + 1 a wave owes the dQ phase of tile j and the key phase of tile j + 1, in either order (different dS
+    // buffers, different ring buffers).  A5_SWAP: the first wave of every SIMD (waves 0..3) takes the key phase first, the second one (waves 4..7) the dQ phase, so the two
+    // do not run the same pipe at the same time (released by the same barrier, both began with the 8 MFMAs of the key phase).
+    auto key_phase = [&](int j) {
       const int q0 = j * 32, buf = j % 3, dbuf = j & 1;
       const unsigned char* Qs = QO + buf * 8192;
       const unsigned char* Os = Qs + 4096;
@@ -239,13 +258,15 @@ __global__ __launch_bounds__(512) void attn_s_bwd5_kernel(const bf16_t* __restri
       if (j + 2 < nt) request_tile(j + 2, (j + 2) % 3, off, offo, lane);    // (that buffer held tile j - 1: its readers passed the barrier that closed tile j - 1)
       if (keyw && !(dbg & 1)) {
         f32x16 st = as_zero16(), dp = as_zero16();
+        f32x16 pv, ds;
+        s16x8 pf[2], df[2];
+        const bool edge = ragged && j == nt - 1;                      // rows of the last query tile beyond N (the DMA filled them with row N - 1): silenced
+#if A5_KP == 0
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           st = vdk_mfma32<OF>(as_row_frag_l(Qs, al, ks), as_row_frag_l(Kt, al, ks), st);   // S[q][key]: lane = key, registers = queries
           dp = vdk_mfma32<OF>(as_row_frag_l(Os, al, ks), as_row_frag_l(Vt, al, ks), dp);   // dP[q][key]
         }
-        f32x16 pv, ds;
-        const bool edge = ragged && j == nt - 1;                      // rows of the last query tile beyond N (the DMA filled them with row N - 1): silenced
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 lv = *(const f32x4*)(lse2 + q0 + 8 * g + 4 * hi);
@@ -259,7 +280,6 @@ __global__ __launch_bounds__(512) void attn_s_bwd5_kernel(const bf16_t* __restri
             ds[r] = p * (dp[r] - dd[e]);
           }
         }
-        s16x8 pf[2], df[2];
         as_pack_b<OF>(pv, pf);
         as_pack_b<OF>(ds, df);
 #pragma unroll
@@ -269,6 +289,61 @@ __global__ __launch_bounds__(512) void attn_s_bwd5_kernel(const bf16_t* __restri
           gk0 = vdk_mfma32<OF>(as_tr_frag_l(Qs + 16 * s2 * AS_ROW, al, 0), df[s2], gk0);     // dK^T[d][key] += Q^T dS
           gk1 = vdk_mfma32<OF>(as_tr_frag_l(Qs + 16 * s2 * AS_ROW, al, 1), df[s2], gk1);
         }
+#else
+        // The same arithmetic in an order that gives every MFMA something to run beside.  Left to the scheduler the phase is 8 MFMAs, ~150 VALU instructions, 8 MFMAs,
+        // and the two waves of a SIMD -- released by the same barrier -- do each part at the same time: matrix pipe against matrix pipe, then VALU against VALU
+        // (measured: ~2600 cycles per key phase where the MFMAs of both waves are ~1000).  Here: the 4 S MFMAs, then each dP MFMA followed by the exponentials of 4
+        // rows of S (independent of dP), each dV MFMA followed by 4 rows of dS, then the dK MFMAs; sched_barrier keeps the pieces in this order.
+#define A5_SB() __builtin_amdgcn_sched_barrier(0)
+#ifdef VDK_EMU
+#define A5_PIN(x) ((void)0)
+#else
+#define A5_PIN(x) asm volatile("" : "+v"(x))
+#endif
+        s16x8 qf[4], of_[4], kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qf[ks] = as_row_frag_l(Qs, al, ks); kf[ks] = A5_KVREG ? kfr[ks] : as_row_frag_l(Kt, al, ks); }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) st = vdk_mfma32<OF>(qf[ks], kf[ks], st);               // S[q][key]: lane = key, registers = queries
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { of_[ks] = as_row_frag_l(Os, al, ks); vf[ks] = A5_KVREG ? vfr[ks] : as_row_frag_l(Vt, al, ks); }
+        A5_SB();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          dp = vdk_mfma32<OF>(of_[g], vf[g], dp);                                              // dP[q][key]
+          const f32x4 lv = *(const f32x4*)(lse2 + q0 + 8 * g + 4 * hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pv[4 * g + e] = fast_exp2(fmaf(st[4 * g + e], scale2, -lv[e]));
+          A5_SB();
+        }
+        if (edge) {                                                   // (wave-uniform)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (q0 + 8 * (r >> 2) + 4 * hi + (r & 3) >= N) pv[r] = 0.f;
+        }
+        as_pack_b<OF>(pv, pf);
+        A5_SB();
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int dh = 0; dh < 2; ++dh) {
+            const s16x8 tf = as_tr_frag_l(Os + 16 * s2 * AS_ROW, al, dh);
+            if (dh == 0) gv0 = vdk_mfma32<OF>(tf, pf[s2], gv0); else gv1 = vdk_mfma32<OF>(tf, pf[s2], gv1);      // dV^T[d][key] += dO^T P
+            const int g = 2 * s2 + dh;
+            const f32x4 dd = *(const f32x4*)(Dv + q0 + 8 * g + 4 * hi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ds[4 * g + e] = pv[4 * g + e] * (dp[4 * g + e] - dd[e]); A5_PIN(ds[4 * g + e]); }      // (pinned: left alone the optimiser sinks these behind the last MFMA)
+            A5_SB();
+          }
+        as_pack_b<OF>(ds, df);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          gk0 = vdk_mfma32<OF>(as_tr_frag_l(Qs + 16 * s2 * AS_ROW, al, 0), df[s2], gk0);     // dK^T[d][key] += Q^T dS
+          gk1 = vdk_mfma32<OF>(as_tr_frag_l(Qs + 16 * s2 * AS_ROW, al, 1), df[s2], gk1);
+        }
+#undef A5_SB
+#undef A5_PIN
+#endif
         // dS [q][key] (lane = key, registers = queries) -> the exchange buffer as [key][q] rows.  Lanes of keys beyond N hold dS of a duplicated key row: zero.
         const bool kval = w * 32 + l31 < N;
         unsigned char* const drow = Dsj + (w * 32 + l31) * A5_PITCH + 8 * hi;
@@ -280,9 +355,10 @@ __global__ __launch_bounds__(512) void attn_s_bwd5_kernel(const bf16_t* __restri
           *(u32x2*)(drow + 32 * s2 + 16) = (u32x2){u[2], u[3]};      // queries 16 s2 + 8 + 4 hi + 0..3
         }
       }
-      // tile j + 1 (requested one tile ago) must have landed before the barrier publishes it; tile j + 2's request -- this wave's newest, one instruction -- may still travel
-      if (j + 2 < nt) __builtin_amdgcn_s_waitcnt(0x0F71); else __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(1) | vmcnt(0)
-      __syncthreads();                                                // tile j's dS complete, tile j + 1's operands in place
+    };
+    auto dq_phase = [&](int j) {
+      const int q0 = j * 32, dbuf = j & 1;
+      unsigned char* const Dsj = Ds + dbuf * DSB;
       // dQ_j^T block (16 d x 16 q) = sum over the key steps of K^T[16 d x 32 keys] . dS^T[32 keys x 16 q]
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       if (!(dbg & 2))
@@ -298,6 +374,17 @@ __global__ __launch_bounds__(512) void attn_s_bwd5_kernel(const bf16_t* __restri
       }
       // C layout: lane -> query column l & 15, rows d = 4 (l >> 4) + 0..3: four consecutive d of one query row = 8 bytes of its staged row
       *(u32x2*)(DQs + (q0 + 16 * qb + a16) * A5_QPITCH + 32 * db + 8 * g4) = (u32x2){pack_op2<OF>(acc[0] * scale, acc[1] * scale), pack_op2<OF>(acc[2] * scale, acc[3] * scale)};
+    };
+    key_phase(0);
+#pragma unroll 1
+    for (int j = 0; j < nt; ++j) {
+      // tile j + 1 (requested one tile ago) must have landed before the barrier publishes it; tile j + 2's request -- this wave's newest, one instruction -- may still travel
+      if (j + 2 < nt) __builtin_amdgcn_s_waitcnt(0x0F71); else __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(1) | vmcnt(0)
+      __syncthreads();                                                // tile j's dS complete, tile j + 1's operands in place
+      const bool keyfirst = A5_SWAP && w < 4;                         // (wave-uniform)
+      if (keyfirst && j + 1 < nt) key_phase(j + 1);
+      dq_phase(j);
+      if (!keyfirst && j + 1 < nt) key_phase(j + 1);
     }
     __syncthreads();                                                  // every dQ block is staged; the last tile's dQ phase is done with the K tiles and the dS buffers
     int ln = lane, td = tid;
