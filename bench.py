@@ -247,12 +247,13 @@ def bench_cbir(dev, nq=10000, n=1_000_000, d=128, k=100, iters=6, with_cpu=True)
 
 def bench_cfg5(be, dev, batch: int = 128, steps: int = 3):
     """BASELINE.json configs[4] (stretch) beside the headline: vit_large_patch14_siglip_336 (576 tokens, MAP head), per-GPU batch 128, a Mixup pair every step + SAM (two
-    forward-backward passes), bf16 operands and the engine's fp8 operand mode; and what fp8 costs in accuracy, measured live against the fp32 oracle on a 2-block ViT
-    whose branch weights are scaled 3x (tests/test_vit_fp8.py; the full-size figures of tests/test_parity_fullsize_gpu.py are quoted)."""
+    forward-backward passes) on fp16 operands (the headline: the mode that meets north_star's tolerance at full size, tests/test_fp16_operands.py), bf16 operands and the
+    engine's fp8 operand mode beside it; and what fp8 costs in accuracy, measured live against the fp32 oracle on a 2-block ViT whose branch weights are scaled 3x
+    (tests/test_vit_fp8.py; the full-size figures of tests/test_parity_fullsize_gpu.py are quoted)."""
     from oracle.vit_ref import VisionTransformerRef
     from visiondk_amd import ops, vit
     out = {"workload": f"cfg5: vit_large_patch14_siglip_336, per-GPU batch {batch}, Mixup pair + SAM (2 fwd/bwd per step), CE ls 0.05, SGD + EMA",
-           "dtype": "bf16 operands | fp8 (e4m3 forward, e5m2 gradients, delayed per-tensor scaling) in the forward / input-gradient GEMMs of the block Linears, bf16 weight gradients"}
+           "dtype": "fp16 operands + GradScaler protocol (headline) | bf16 operands | fp8 (e4m3 forward, e5m2 gradients, delayed per-tensor scaling) in the forward / input-gradient GEMMs of the block Linears, bf16 weight gradients"}
     # ---- tolerance: 2-block ViT, fp8 vs the fp32 oracle and vs the same engine with bf16 operands
     torch.manual_seed(0)
     ref = VisionTransformerRef(64, 8, 3, 10, 256, 2, 4, 512)
@@ -278,15 +279,15 @@ def bench_cfg5(be, dev, batch: int = 128, steps: int = 3):
     out["fp8_tolerance"] = {"model": "2-block ViT (dim 256, 64 x 64 input, branch weights x 3), batch 4, forward + backward vs oracle/vit_ref.py (fp32)",
                             "fp8_logits_rel": rel(l8, lr.detach()), "fp8_worst_grad_rel": max(rel(g8[n], p_.grad) for n, p_ in ref.named_parameters()),
                             "bf16_logits_rel": rel(l16, lr.detach()), "bf16_worst_grad_rel": max(rel(g16[n], p_.grad) for n, p_ in ref.named_parameters()),
-                            "full_size_quoted": "vit_large_patch14_siglip_336, 2 images, every gradient vs the fp32 oracle (tests/test_parity_fullsize_gpu.py): bf16 logits 4.2e-3 / worst gradient 8.0e-3; fp8 logits 6.8e-2 / median gradient 7.6e-2 / worst 1.3e-1"}
+                            "full_size_quoted": "vit_large_patch14_siglip_336, 2 images, every gradient vs the fp32 oracle: fp16 operands asserted <= 1e-3 / <= 5e-3 (tests/test_fp16_operands.py); bf16 logits 4.2e-3 / worst gradient 8.0e-3; fp8 logits 6.8e-2 / median gradient 7.6e-2 / worst 1.3e-1 (tests/test_parity_fullsize_gpu.py)"}
     del small, ref
     # ---- throughput of the real model
-    model = vit.create_model("vit_large_patch14_siglip_336", num_classes=1000, device=dev)
-    ntok = model.engine.tokens
-    flop_img = 3 * 2 * (302.3e6 * ntok + 24 * 2 * ntok * ntok * 1024 + 2 * 1024 * 1024 * ntok)
     xb = torch.randn(batch, 3, 336, 336, device=dev); ya = torch.randint(0, 1000, (batch,), device=dev)
     perm = torch.randperm(batch, device=dev); yb = ya[perm].contiguous()
-    for fp8 in (0, 1):
+    for key, operand, fp8 in (("sam_fp16", "fp16", 0), ("sam_bf16", "bf16", 0), ("sam_fp8", "bf16", 1)):
+        model = vit.create_model("vit_large_patch14_siglip_336", num_classes=1000, device=dev, operand=operand)
+        ntok = model.engine.tokens
+        flop_img = 3 * 2 * (302.3e6 * ntok + 24 * 2 * ntok * ntok * 1024 + 2 * 1024 * 1024 * ntok)
         model.engine.enable_fp8(fp8)
         step = vit.MapTrainStep(model, lr=0.006, momentum=0.937, weight_decay=5e-4, label_smoothing=0.05, max_norm=10.0, ema=True, sam=True)
 
@@ -298,16 +299,19 @@ def bench_cfg5(be, dev, batch: int = 128, steps: int = 3):
         for _ in range(steps):
             one()
         torch.cuda.synchronize(); dt = (time.time() - t0) / steps
-        key = "sam_fp8" if fp8 else "sam_bf16"
         out[key] = {"images_per_sec": batch / dt, "ms_per_step": dt * 1e3, "model_tflops": flop_img * batch * 2 / dt / 1e12, "loss": step.loss_value()}
-        del step
-    model.engine.enable_fp8(0)
-    # Which of the two is cfg5's number: BASELINE.json configs[4] says "fp8 MFMA", north_star says logits within 1e-3 of the reference.  The fp8 operand
-    # mode is two orders outside that tolerance (fp8_tolerance above: an e4m3 operand carries 2^-4 of rounding), its weight gradients still run in bf16 and its kernel is the
-    # eight-wave structure -- so the figure that stands for cfg5 is the 16-bit step, and fp8 stays an opt-in experiment reported beside it.
-    out["headline"] = {"key": "sam_bf16", "why": "fp8 operands miss the stated tolerance by ~100x (fp8_tolerance); the conforming 16-bit step is cfg5's figure, fp8 is reported beside it as an opt-in mode"}
-    del model
-    torch.cuda.empty_cache()
+        if operand == "fp16":
+            out[key]["loss_scale"] = step.loss_scale(); out[key]["skipped_steps"] = step.skipped_steps()
+        model.engine.enable_fp8(0)
+        del step, model
+        torch.cuda.empty_cache()
+    # Which figure stands for cfg5: BASELINE.json configs[4] says "fp8 MFMA", north_star says logits within 1e-3 of the reference.  The fp8 operand mode is two orders outside
+    # that tolerance (fp8_tolerance above: an e4m3 operand carries 2^-4 of rounding) and bf16 operands measure 4.2e-3 / 8.0e-3 at full size; fp16 operands -- the
+    # reference's own autocast dtype -- meet 1e-3 / 5e-3 literally on this model (tests/test_fp16_operands.py).  SAM under fp16: the reference's update_sam calls
+    # loss.backward() without its GradScaler (train.py:157-170); this step runs both passes at the scaler's current loss scale (e(w) is invariant under it), un-scales in the
+    # base step, and an overflow in either pass skips the update, restores w and halves the scale (vit.MapTrainStep).
+    out["headline"] = {"key": "sam_fp16", "tolerance_met": True,
+                       "why": "fp16 operands meet north_star's 1e-3 / 5e-3 at full size (asserted in tests/test_fp16_operands.py); bf16 (4.2e-3 / 8.0e-3) and fp8 (6.8e-2) are reported beside it as non-conforming opt-in modes"}
     return out
 
 

@@ -682,6 +682,11 @@ int vdk_resnet_backward(const VdkResNetConfig* cfg, const void* dlogits, const f
 int vdk_attn_pool_fwd(const float* q, const void* kv, int64_t ldkv, int32_t B, int32_t N, int32_t H, float scale, float* out, int64_t ldo, float* probs, void* stream);
 int vdk_attn_pool_bwd(const float* q, const void* kv, int64_t ldkv, const float* probs, const float* dout, int64_t lddo, int32_t B, int32_t N, int32_t H, float scale,
                       void* dkv, int64_t lddkv, float* dq_part, void* stream);
+/* the same with the 16-bit format of kv / dkv as a parameter (VDK_BF16 | VDK_F16: the trunk's operand format; fp16 = the reference's autocast arithmetic, train.py:118) */
+int vdk_attn_pool_fwd_dt(const float* q, const void* kv, int64_t ldkv, int32_t B, int32_t N, int32_t H, float scale, float* out, int64_t ldo, float* probs, int32_t dtype,
+                         void* stream);
+int vdk_attn_pool_bwd_dt(const float* q, const void* kv, int64_t ldkv, const float* probs, const float* dout, int64_t lddo, int32_t B, int32_t N, int32_t H, float scale,
+                         void* dkv, int64_t lddkv, float* dq_part, int32_t dtype, void* stream);
 
 /* F.normalize(W, dim=0): inv[c] = 1/max(||W[:,c]||, eps); Wb = bf16 [3D, ldb]: the normalised weight as split planes
  * (hi, hi, lo) stacked along the contraction dim (rows [0,D) alone are the plain bf16 copy); columns C..Cp-1 zero */

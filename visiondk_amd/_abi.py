@@ -165,6 +165,8 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_margin_target_cos_direct": (C.c_int, [P, I64, P, I64, I32, I32, P, P, P]),
     "vdk_attn_pool_fwd": (C.c_int, [P, P, I64, I32, I32, I32, F32, P, I64, P, P]),
     "vdk_attn_pool_bwd": (C.c_int, [P, P, I64, P, P, I64, I32, I32, I32, F32, P, I64, P, P]),
+    "vdk_attn_pool_fwd_dt": (C.c_int, [P, P, I64, I32, I32, I32, F32, P, I64, P, I32, P]),
+    "vdk_attn_pool_bwd_dt": (C.c_int, [P, P, I64, P, P, I64, I32, I32, I32, F32, P, I64, P, I32, P]),
     "vdk_colnorm_fwd": (C.c_int, [P, I64, I32, I32, I32, F32, P, P, I64, I32, P]),
     "vdk_colnorm_fwd_dt": (C.c_int, [P, I64, I32, I32, I32, F32, P, P, I64, I32, I32, P]),
     "vdk_rownorm_fwd_dt": (C.c_int, [P, I32, I32, I32, F32, P, P, P, P, I32, I32, P]),

@@ -10,6 +10,7 @@
 
 #define AP_MAXN 4096   // keys per image (probabilities live in LDS)
 
+template <int OF>
 __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const float* __restrict__ q, const bf16_t* __restrict__ kv, long ldkv, int N, int H, float scale,
                                                             float* __restrict__ out, long ldo, float* __restrict__ probs) {
   __shared__ float p_s[AP_MAXN];
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const float* __restr
     for (int c = 0; c < 8; ++c) {
       const u32x4 u = kr[c];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { s = fmaf(qr[c * 8 + 2 * e], bf_lo(u[e]), s); s = fmaf(qr[c * 8 + 2 * e + 1], bf_hi(u[e]), s); }
+      for (int e = 0; e < 4; ++e) { s = fmaf(qr[c * 8 + 2 * e], op_lo<OF>(u[e]), s); s = fmaf(qr[c * 8 + 2 * e + 1], op_hi<OF>(u[e]), s); }
     }
     p_s[n] = s;
     mx = fmaxf(mx, s);
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const float* __restr
   // out[d] = sum_n p[n] v[n][d]: 4 key groups x 64 channels
   const int d = tid & 63, g = tid >> 6;
   float a = 0.f;
-  for (int n = g; n < N; n += 4) a = fmaf(p_s[n], bf2f(vb[(long)n * ldkv + d]), a);
+  for (int n = g; n < N; n += 4) a = fmaf(p_s[n], op2f<OF>(vb[(long)n * ldkv + d]), a);
   acc_s[g][d] = a;
   __syncthreads();
   if (tid < 64) out[(long)b * ldo + h * 64 + tid] = (acc_s[0][tid] + acc_s[1][tid]) + (acc_s[2][tid] + acc_s[3][tid]);
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const float* __restr
 
 // dout f32 [B, H*64] -> dkv bf16 [B*N, 2*H*64] (dk | dv), dq_part f32 [B, H*64] (sum over images = dL/dq)
 //   dp[n] = <dout[h], v[n]>, ds[n] = p[n] (dp[n] - sum_m p[m] dp[m]), dk[n] = scale * ds[n] q[h], dv[n] = p[n] dout[h], dq[h] += scale * sum_n ds[n] k[n]
+template <int OF>
 __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const float* __restrict__ q, const bf16_t* __restrict__ kv, long ldkv, const float* __restrict__ probs,
                                                             const float* __restrict__ dout, long lddo, int N, int H, float scale, bf16_t* __restrict__ dkv,
                                                             long lddkv, float* __restrict__ dq_part) {
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const float* __restr
     for (int c = 0; c < 8; ++c) {
       const u32x4 u = vr[c];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { s = fmaf(gr[c * 8 + 2 * e], bf_lo(u[e]), s); s = fmaf(gr[c * 8 + 2 * e + 1], bf_hi(u[e]), s); }
+      for (int e = 0; e < 4; ++e) { s = fmaf(gr[c * 8 + 2 * e], op_lo<OF>(u[e]), s); s = fmaf(gr[c * 8 + 2 * e + 1], op_hi<OF>(u[e]), s); }
     }
     ds_s[n] = s;
     dot = fmaf(pr[n], s, dot);
@@ -89,9 +91,9 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const float* __restr
   float a = 0.f;
   for (int n = g; n < N; n += 4) {
     const float ds = ds_s[n];
-    dkb[(long)n * lddkv + d] = f2bf(ds * qd);
-    dvb[(long)n * lddkv + d] = f2bf(pr[n] * gd);
-    a = fmaf(ds, bf2f(kb[(long)n * ldkv + d]), a);
+    dkb[(long)n * lddkv + d] = f2op<OF>(ds * qd);
+    dvb[(long)n * lddkv + d] = f2op<OF>(pr[n] * gd);
+    a = fmaf(ds, op2f<OF>(kb[(long)n * ldkv + d]), a);
   }
   acc_s[g][d] = a;
   __syncthreads();
@@ -100,20 +102,38 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const float* __restr
 
 extern "C" {
 
-int vdk_attn_pool_fwd(const float* q, const void* kv, int64_t ldkv, int32_t B, int32_t N, int32_t H, float scale, float* out, int64_t ldo, float* probs, void* stream) {
-  if (!q || !kv || !out || B <= 0 || N <= 0 || H <= 0 || N > AP_MAXN || (ldkv & 7) || ldkv < 2L * H * 64)
+// kv / dkv: 16-bit [B*N, 2*H*64] in the format `dtype` (VDK_BF16 | VDK_F16: the trunk's operand format)
+int vdk_attn_pool_fwd_dt(const float* q, const void* kv, int64_t ldkv, int32_t B, int32_t N, int32_t H, float scale, float* out, int64_t ldo, float* probs, int32_t dtype,
+                         void* stream) {
+  if (!q || !kv || !out || B <= 0 || N <= 0 || H <= 0 || N > AP_MAXN || (ldkv & 7) || ldkv < 2L * H * 64 || (dtype != VDK_BF16 && dtype != VDK_F16))
     return vdk_fail(VDK_EINVAL, "vdk_attn_pool_fwd: bad argument (head_dim 64, N <= 4096, ldkv % 8 == 0)");
-  hipLaunchKernelGGL(attn_pool_fwd_kernel, dim3((unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, q, (const bf16_t*)kv, (long)ldkv, (int)N, (int)H, scale, out,
-                     (long)ldo, probs);
+  if (dtype == VDK_F16)
+    hipLaunchKernelGGL(attn_pool_fwd_kernel<VDK_OPF_F16>, dim3((unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, q, (const bf16_t*)kv, (long)ldkv, (int)N, (int)H, scale, out,
+                       (long)ldo, probs);
+  else
+    hipLaunchKernelGGL(attn_pool_fwd_kernel<VDK_OPF_BF16>, dim3((unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, q, (const bf16_t*)kv, (long)ldkv, (int)N, (int)H, scale, out,
+                       (long)ldo, probs);
   return vdk_check_launch("vdk_attn_pool_fwd");
+}
+int vdk_attn_pool_bwd_dt(const float* q, const void* kv, int64_t ldkv, const float* probs, const float* dout, int64_t lddo, int32_t B, int32_t N, int32_t H, float scale,
+                         void* dkv, int64_t lddkv, float* dq_part, int32_t dtype, void* stream) {
+  if (!q || !kv || !probs || !dout || !dkv || !dq_part || B <= 0 || N <= 0 || H <= 0 || N > AP_MAXN || (ldkv & 7) || ldkv < 2L * H * 64 || lddkv < 2L * H * 64 ||
+      (dtype != VDK_BF16 && dtype != VDK_F16))
+    return vdk_fail(VDK_EINVAL, "vdk_attn_pool_bwd: bad argument");
+  if (dtype == VDK_F16)
+    hipLaunchKernelGGL(attn_pool_bwd_kernel<VDK_OPF_F16>, dim3((unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, q, (const bf16_t*)kv, (long)ldkv, probs, dout, (long)lddo,
+                       (int)N, (int)H, scale, (bf16_t*)dkv, (long)lddkv, dq_part);
+  else
+    hipLaunchKernelGGL(attn_pool_bwd_kernel<VDK_OPF_BF16>, dim3((unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, q, (const bf16_t*)kv, (long)ldkv, probs, dout, (long)lddo,
+                       (int)N, (int)H, scale, (bf16_t*)dkv, (long)lddkv, dq_part);
+  return vdk_check_launch("vdk_attn_pool_bwd");
+}
+int vdk_attn_pool_fwd(const float* q, const void* kv, int64_t ldkv, int32_t B, int32_t N, int32_t H, float scale, float* out, int64_t ldo, float* probs, void* stream) {
+  return vdk_attn_pool_fwd_dt(q, kv, ldkv, B, N, H, scale, out, ldo, probs, VDK_BF16, stream);
 }
 int vdk_attn_pool_bwd(const float* q, const void* kv, int64_t ldkv, const float* probs, const float* dout, int64_t lddo, int32_t B, int32_t N, int32_t H, float scale,
                       void* dkv, int64_t lddkv, float* dq_part, void* stream) {
-  if (!q || !kv || !probs || !dout || !dkv || !dq_part || B <= 0 || N <= 0 || H <= 0 || N > AP_MAXN || (ldkv & 7) || ldkv < 2L * H * 64 || lddkv < 2L * H * 64)
-    return vdk_fail(VDK_EINVAL, "vdk_attn_pool_bwd: bad argument");
-  hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3((unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, q, (const bf16_t*)kv, (long)ldkv, probs, dout, (long)lddo,
-                     (int)N, (int)H, scale, (bf16_t*)dkv, (long)lddkv, dq_part);
-  return vdk_check_launch("vdk_attn_pool_bwd");
+  return vdk_attn_pool_bwd_dt(q, kv, ldkv, probs, dout, lddo, B, N, H, scale, dkv, lddkv, dq_part, VDK_BF16, stream);
 }
 
 }  // extern "C"

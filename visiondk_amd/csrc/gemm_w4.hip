@@ -54,6 +54,9 @@
 #define W4_RB0 32768
 #define W4_RB1 49152
 #define W4_OOB 0x80000000u
+#ifndef W4_AUX_PREFETCH
+#define W4_AUX_PREFETCH 0   /* dGELU forms of the persistent kernel: the first block's saved-operand rows are requested in front of the tile's last k-tile (0: at the epilogue's start) */
+#endif
 #ifndef W4_EPI_AHEAD
 #define W4_EPI_AHEAD 1      /* epilogue operand rows (saved GELU operand, fp32 residual) requested one 32-row block ahead; 0 = at the block's start (A/B builds) */
 #endif   /* scalar offset of a DMA that must read nothing: beyond every descriptor (operands stay below 2 GB), so it lands zeros */
@@ -306,7 +309,8 @@ __device__ __forceinline__ void w4_ktile(unsigned char* smem, const W4Frag<TN>& 
 // NCT: 32-column blocks per wave (4: the 256x256 tile of gemm_w4_kernel, staging rows of 256 B, 4 rows per 64-lane pass; 2: the 256x128 tile of gemm_w4h_kernel,
 // staging rows of 128 B with chunk c of row r at position c ^ ((r >> 1) & 7), 8 rows per pass).  DEEP: vmcnt waited for before the first global access (-1: none).
 template <int E, int NCT, int DEEP, int OF>
-__device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* stage, f32x16 (&acc)[4][NCT], int lane, int wr, int wc, int m0, int n0, int z, int tm, unsigned long long (&ts)[5]) {
+__device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* stage, f32x16 (&acc)[4][NCT], int lane, int wr, int wc, int m0, int n0, int z, int tm, unsigned long long (&ts)[5],
+                                            const u32x4* auxpre = nullptr /* E_DGELU: the saved operand's rows of the first 32-row block, requested by the caller (w4_aux_prefetch) */) {
   constexpr int NCH = NCT * 4;            // 16-byte chunks per staged row
   constexpr int RPP = 64 / NCH;           // rows per 64-lane pass
   constexpr int NPS = 32 / RPP;           // passes per 32-row block
@@ -378,7 +382,12 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
       for (int ps = 0; ps < NPS; ++ps)
         auxrows[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_aux, lane_aux, srow + (unsigned)(ps * RPP) * (unsigned)p.ldaux * 2u, 0);   // (out of range: zeros)
     };
-    if (E & E_DGELU) aux_request(0);
+    if (E & E_DGELU) {
+      if (auxpre) {
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) auxrows[ps] = auxpre[ps];
+      } else aux_request(0);
+    }
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
       if (p.dbg && rt > 0) ts[rt] = __builtin_readcyclecounter();
@@ -590,6 +599,21 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
   }
 }
 
+// The dGELU epilogues multiply by a saved operand (GELU'(u) or u) that arrives as whole row segments, one 32-row block ahead of its use -- except the FIRST block of a
+// tile, whose rows are requested when the epilogue begins: a lone wave then sits through one memory round trip per tile (cycle stamps, dfc2 of ViT-B/16: first block 8.1 k
+// cycles, the others 3.1 k).  W4_AUX_PREFETCH = 1 requests that first block in front of the tile's LAST k-tile, with the lane / row mapping of w4_epilogue's fast form
+// (NCT = 4).  Measured (tools/r6_gemm_quick.py, same box, two rounds): 322.6 / 319.9 us without, 324.0 / 321.8 us with -- the 32 registers it holds across the last
+// k-tile cost what the round trip saved (11 spilled registers instead of 6): off.
+__device__ __forceinline__ void w4_aux_prefetch(const GemmParams& p, u32x4 (&pre)[8], int lane, int wr, int wc, int m0, int n0) {
+  const int rrow = lane >> 4, rc = lane & 15;
+  const int mrow0 = m0 + wr * 128, ncol = n0 + wc * 128 + rc * 8;
+  const unsigned lane_aux = ncol < p.N ? (unsigned)rrow * (unsigned)p.ldaux * 2u + (unsigned)ncol * 2u : W4_OOB;
+  const __amdgpu_buffer_rsrc_t rs_aux = __builtin_amdgcn_make_buffer_rsrc((void*)p.aux, 0, (int)((unsigned)p.M * (unsigned)p.ldaux * 2u), 0x00020000);
+  const unsigned srow = (unsigned)mrow0 * (unsigned)p.ldaux * 2u;
+#pragma unroll
+  for (int ps = 0; ps < 8; ++ps) pre[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_aux, lane_aux, srow + (unsigned)(ps * 4) * (unsigned)p.ldaux * 2u, 0);
+}
+
 // ---- the kernel -----------------------------------------------------------------------------------------------------------------------
 // Linear tile id -> (tile row, tile column).  An XCD works through a contiguous range of ids; in plain row-major order that range sweeps ALL tile columns every few
 // rows, i.e. the whole B operand (the weight matrix) again and again: at 4.7 MB (768 x 3072) it does not stay in the XCD's 4 MB L2 and streamed back from the Infinity
@@ -729,6 +753,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
       w4_ktile<TN, 0, 20, false, true, OF>(smem, F, da, db, c_ta + c_ka, c_tb + c_kb, w, acc, A0, A1, BX, B1, BY);
       W4_CURSOR_ADVANCE();
     }
+    int tm, tn; w4_tile_rc(t_start + t_idx, ntn, ntm, p.band_cw, tm, tn);
+    constexpr bool AUXPRE = W4_AUX_PREFETCH && !TN && E != E_GENERIC && (E & E_DGELU) && ((E & ~(E_AUXD | E_OCS)) == E_DGELU);
+    u32x4 auxpre[8];
+    if constexpr (AUXPRE) w4_aux_prefetch(p, auxpre, lane, wr, wc, tm * 256, tn * 256);
     w4_ktile<TN, 1, 20, false, false, OF>(smem, F, da, db, c_ta + c_ka, c_tb + c_kb, w, acc, A0, A1, BY, B1, BX);
     W4_CURSOR_ADVANCE();
     if (p.dbg) t_main = __builtin_readcyclecounter();
@@ -740,9 +768,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
                  : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[1][3]),
                    "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]), "+a"(acc[3][3]));
 #endif
-    int tm, tn; w4_tile_rc(t_start + t_idx, ntn, ntm, p.band_cw, tm, tn);
     unsigned long long ts[5] = {0, 0, 0, 0, 0};
-    w4_epilogue<E, 4, 4, OF>(p, smem + W4_STAGE + w * 8192, acc, lane, wr, wc, tm * 256, tn * 256, z, tm, ts);
+    w4_epilogue<E, 4, 4, OF>(p, smem + W4_STAGE + w * 8192, acc, lane, wr, wc, tm * 256, tn * 256, z, tm, ts, AUXPRE ? auxpre : nullptr);
     if (p.dbg && tid == 0 && dbg_i < 8) {   // debug only: shader-cycle stamps of this workgroup's first 8 tiles: top, main loop done, epilogue issued
       unsigned long long* o = p.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + dbg_i) * 8;   /* (debug stamps index the launch grid, not the item order) */
       o[0] = t_top; o[1] = t_main; o[2] = __builtin_readcyclecounter(); o[3] = (unsigned long long)(t_start + t_idx);
@@ -1018,7 +1045,8 @@ bool W4_SYM(vdk_gemm_w4_launch)(const GemmParams& p, bool trans, int E, unsigned
   // (round 6: off by default -- with the start phase of the walk the unsplit persistent launch is the faster one: fc2 247.7 against 253.6 us, dfc1 213.6 / 216.8, dqkv 161.7 / 164.6;
   //  VDK_GEMM_W4_SPLIT=1 restores the two-launch form; re-read per launch: A/B runs in one process)
   const bool split_on = getenv("VDK_GEMM_W4_SPLIT") && atoi(getenv("VDK_GEMM_W4_SPLIT")) == 1;
-  if (split_on && !trans && splitk == 1 && tiles > G && p.K >= 1536 && E != E_GENERIC && !(E & (E_ROWGRP | E_MSTAT | E_MGRAD | E_SPLITK))) {
+  const int split_min_k = getenv("VDK_GEMM_W4_SPLIT_K") ? atoi(getenv("VDK_GEMM_W4_SPLIT_K")) : 1536;
+  if (split_on && !trans && splitk == 1 && tiles > G && p.K >= split_min_k && E != E_GENERIC && !(E & (E_ROWGRP | E_MSTAT | E_MGRAD | E_SPLITK))) {
     const unsigned ntn = (unsigned)((p.N + 255) / 256), ntm = (unsigned)((p.M + 255) / 256);
     const unsigned rows1 = (tiles / G) * G / ntn;         // tile rows covered by whole rounds
     const unsigned rem_tiles = (ntm - rows1) * ntn;

@@ -427,12 +427,13 @@ class _AttnPoolFn(torch.autograd.Function):
         H = mod.num_heads
         dev = tokens.device
         tok = tokens.detach().contiguous().view(B * N, D)
-        tb = ops.cast_bf16(tok, backend=be)
-        kv = ops.gemm_nt(tb, ops.cast_bf16(kv_w.detach().contiguous(), backend=be), bias=kv_b.detach(), backend=be)          # bf16 [T, 2D]
+        odt = mod.op_dtype                                                  # the trunk's operand format: bf16, or fp16 (the reference's autocast dtype)
+        tb = ops.cast_16(tok, odt, backend=be)
+        kv = ops.gemm_nt(tb, ops.cast_16(kv_w.detach().contiguous(), odt, backend=be), bias=kv_b.detach(), backend=be)          # 16-bit [T, 2D]
         q = ops.gemm_f32(latent.detach().reshape(1, D).contiguous(), q_w.detach(), bias=q_b.detach(), backend=be).view(D)
         pooled = torch.empty((B, D), dtype=torch.float32, device=dev)
         probs = torch.empty((B, H, N), dtype=torch.float32, device=dev)
-        be.check(be.lib.vdk_attn_pool_fwd(be.ptr(q), be.ptr(kv), 2 * D, B, N, H, mod.scale, be.ptr(pooled), D, be.ptr(probs), be.stream()), "vdk_attn_pool_fwd")
+        be.check(be.lib.vdk_attn_pool_fwd_dt(be.ptr(q), be.ptr(kv), 2 * D, B, N, H, mod.scale, be.ptr(pooled), D, be.ptr(probs), ops._dt(odt), be.stream()), "vdk_attn_pool_fwd")
         y1 = ops.gemm_f32(pooled, proj_w.detach(), bias=proj_b.detach(), backend=be)
         h, mean, rstd = ops.layernorm_fwd(y1, n_w.detach(), n_b.detach(), eps=mod.eps, out_dtype=torch.float32, backend=be)
         u = ops.gemm_f32(h, fc1_w.detach(), bias=fc1_b.detach(), backend=be)
@@ -459,10 +460,11 @@ class _AttnPoolFn(torch.autograd.Function):
         dy1, _, dn_w, dn_b = ops.layernorm_bwd(dh, y1, mean, rstd, n_w.detach(), dres=dout, want_bf16=False, backend=be)   # + the skip connection
         dproj_w, dproj_b = _wgrad_f32(dy1, pooled, be), dy1.sum(0)
         dpooled = f32(dy1, proj_w, b_kmajor=True)
-        dkv = torch.empty((B * N, 2 * D), dtype=torch.bfloat16, device=dev)
+        odt = kv.dtype
+        dkv = torch.empty((B * N, 2 * D), dtype=odt, device=dev)
         dq_part = torch.empty((B, D), dtype=torch.float32, device=dev)
-        be.check(be.lib.vdk_attn_pool_bwd(be.ptr(q), be.ptr(kv), 2 * D, be.ptr(probs), be.ptr(dpooled), D, B, N, H, mod.scale, be.ptr(dkv), 2 * D, be.ptr(dq_part),
-                                          be.stream()), "vdk_attn_pool_bwd")
+        be.check(be.lib.vdk_attn_pool_bwd_dt(be.ptr(q), be.ptr(kv), 2 * D, be.ptr(probs), be.ptr(dpooled), D, B, N, H, mod.scale, be.ptr(dkv), 2 * D, be.ptr(dq_part),
+                                             ops._dt(odt), be.stream()), "vdk_attn_pool_bwd")
         dq = ops.reduce_rows(dq_part, backend=be)                          # [D]
         lat = latent.detach().reshape(1, D)
         dq_w, dq_b = dq.view(D, 1) * lat, dq
@@ -473,8 +475,13 @@ class _AttnPoolFn(torch.autograd.Function):
         else:
             Tp = (T + 63) // 64 * 64
             dkv_w = ops.gemm_nt(ops.transpose_pad(dkv, rpad=Tp, backend=be), ops.transpose_pad(tb, rpad=Tp, backend=be), out_dtype=torch.float32, backend=be)
-        dkv_b = ops.colsum_bf16(dkv, backend=be)
-        dtok = ops.gemm_nt(dkv, ops.transpose_cast(kv_w.detach().contiguous(), backend=be), out_dtype=torch.float32, backend=be)   # [T, D] = dkv . Wkv
+        if odt == torch.bfloat16:
+            dkv_b = ops.colsum_bf16(dkv, backend=be)
+            wkv_t = ops.transpose_cast(kv_w.detach().contiguous(), backend=be)
+        else:      # fp16: the [2D] column sums and the [D, 2D] transposed weight copy through torch (2 of the step's ~10^3 launches; fp32 accumulation)
+            dkv_b = torch.sum(dkv, dim=0, dtype=torch.float32)
+            wkv_t = kv_w.detach().t().contiguous().to(odt)
+        dtok = ops.gemm_nt(dkv, wkv_t, out_dtype=torch.float32, backend=be)   # [T, D] = dkv . Wkv
         return (dtok.view(B, N, D), dlatent, dq_w, dq_b, dkv_w, dkv_b, dproj_w, dproj_b, dn_w, dn_b, dfc1_w, dfc1_b, dfc2_w, dfc2_b, None)
 
 
@@ -483,9 +490,10 @@ class AttentionPoolLatent(nn.Module):
     parameter names equal timm's (latent, q, kv, proj, norm, mlp.fc1, mlp.fc2).  head_dim 64."""
 
     def __init__(self, dim: int, num_heads: int, mlp_dim: Optional[int] = None, eps: float = 1e-6, backend: Optional[_lib.Backend] = None, device=None,
-                 generator: Optional[torch.Generator] = None):
+                 generator: Optional[torch.Generator] = None, op_dtype=torch.bfloat16):
         super().__init__()
         assert dim == num_heads * 64, "head_dim must be 64"
+        self.op_dtype = op_dtype             # 16-bit format of the kv Linear's operands and of kv / dkv (the trunk's)
         self.be = backend or _lib.load()
         dev = device if device is not None else ("cuda" if self.be.device_only else "cpu")
         self.num_heads, self.scale, self.eps = num_heads, 0.125, eps
@@ -537,12 +545,12 @@ class VisionTransformerMap(nn.Module):
     """timm VisionTransformer(class_token=False, global_pool='map', num_classes=C): the vit_*_siglip_* family (BASELINE.json configs[4]).  The trunk is the native
     engine in feature mode without a class token; attn_pool and head run as autograd nodes over the same kernels.  state_dict names equal timm's."""
 
-    def __init__(self, spec: VitSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None):
+    def __init__(self, spec: VitSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None, operand: str = "bf16"):
         super().__init__()
         import dataclasses
         self.spec = spec
         self.num_classes = spec.num_classes
-        trunk = VisionTransformer(dataclasses.replace(spec, num_classes=0, class_token=False), device=device, backend=backend, seed=seed)
+        trunk = VisionTransformer(dataclasses.replace(spec, num_classes=0, class_token=False), device=device, backend=backend, seed=seed, operand=operand)
         self.engine = trunk.engine
         self._trunk = [trunk]                 # not a registered submodule: its parameters are re-registered below under timm's flat names
         for name, child in trunk._modules.items():
@@ -554,7 +562,7 @@ class VisionTransformerMap(nn.Module):
         gen = None
         if seed is not None:      # the pooling head and the classifier draw from the same seed as the trunk: a seeded model is reproducible (and equal on every rank)
             gen = torch.Generator(); gen.manual_seed(int(seed) + 1)
-        self.attn_pool = AttentionPoolLatent(spec.dim, spec.heads, spec.mlp_dim, spec.ln_eps, backend=be, device=dev, generator=gen)
+        self.attn_pool = AttentionPoolLatent(spec.dim, spec.heads, spec.mlp_dim, spec.ln_eps, backend=be, device=dev, generator=gen, op_dtype=trunk.engine.op_dtype)
         self.head = _Holder()
         if spec.num_classes > 0:
             self.head.weight = nn.Parameter(torch.empty(spec.num_classes, spec.dim).normal_(0, 0.02, generator=gen).to(dev)); self.head.bias = nn.Parameter(torch.zeros(spec.num_classes, device=dev))
@@ -563,6 +571,7 @@ class VisionTransformerMap(nn.Module):
         return self._trunk[0](x)              # [B, N, D], final-normed
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self.attn_pool.op_dtype = self.engine.op_dtype          # (follows engine.set_operand)
         pooled = self.attn_pool(self.forward_features(x))
         if self.num_classes == 0:
             return pooled
@@ -581,9 +590,7 @@ def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, d
             return VisionTransformer(dataclasses.replace(spec, num_classes=0), device=device, backend=backend, operand=operand)
         if global_pool not in ("map", "token"):      # ("token" is this function's default argument, i.e. "not given": timm then uses the id's own default, 'map')
             raise NotImplementedError(f"global_pool={global_pool!r} is not built for the SigLIP ids (only 'map' and '')")
-        if operand != "bf16":
-            raise NotImplementedError("the attention-pool head (global_pool='map') runs on bf16 operands")
-        return VisionTransformerMap(spec, device=device, backend=backend)
+        return VisionTransformerMap(spec, device=device, backend=backend, operand=operand)
     if num_classes == 0 and global_pool != "":
         raise NotImplementedError("num_classes=0 is supported with global_pool='' (token features) only")
     return VisionTransformer(spec, device=device, backend=backend, operand=operand)
@@ -747,7 +754,7 @@ class MapTrainStep:
     step's first pass stays local (model.no_sync(), train.py:157-159)."""
 
     def __init__(self, model: VisionTransformerMap, lr: float, momentum: float = 0.937, weight_decay: float = 5e-4, label_smoothing: float = 0.0,
-                 max_norm: float = 10.0, ema: bool = True, sam: bool = False, sam_rho: float = 0.05, sam_adaptive: bool = True, comm=None):
+                 max_norm: float = 10.0, ema: bool = True, sam: bool = False, sam_rho: float = 0.05, sam_adaptive: bool = True, comm=None, init_scale: float = 65536.0):
         self.model, self.eng = model, model.engine
         self.comm = comm
         eng = self.eng
@@ -787,6 +794,15 @@ class MapTrainStep:
         self._sumsq_ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
         self.updates = 0
         self._loss_rows = None
+        # fp16 operands (the reference's autocast dtype): the GradScaler protocol of FusedTrainStep -- loss scale on the device, un-scaling inside the optimizer pass, a step
+        # whose gradient holds an inf / NaN is skipped and the scale backed off.  The SAM step: the reference's update_sam (train.py:150-175) calls loss.backward() WITHOUT
+        # the scaler, i.e. its fp16 gradients are unscaled and small ones flush to zero; here both passes of a SAM step run at the current loss scale (e(w) = rho g / |g| is
+        # invariant under it), the base step un-scales, and an overflow in either pass -- the first one poisons e(w) and with it the second -- reaches the second pass's
+        # gradient norm: the update is skipped, the weights return to w (they are restored before the base step anyway) and the scale halves.  Same arithmetic as the
+        # reference wherever nothing overflows or underflows; where fp16 would have flushed a gradient the scaled pass keeps it.
+        self.amp = eng.operand == "fp16"
+        self.growth_factor, self.backoff_factor, self.growth_interval = 2.0, 0.5, 2000
+        self.loss_state = torch.tensor([init_scale, 0.0, 0.0], dtype=torch.float32, device=dev) if self.amp else None
         if comm is not None and comm.active:          # DDP-constructor semantics: every rank starts from rank 0's weights (trunk and head alike)
             comm.broadcast_params(self.big, src=0, engine=eng)
             if self.ema is not None:
@@ -813,6 +829,8 @@ class MapTrainStep:
         pooled = m.attn_pool(tokens)
         logits = _LinearFn.apply(pooled, m.head.weight, m.head.bias, self.be)
         self._loss_rows, _, dlf = ops.softmax_ce(logits.detach().contiguous(), y, y_b, lam, self.label_smoothing, 1.0 / B, backend=self.be)
+        if self.amp:
+            ops.scale_dev(dlf, self.loss_state, backend=self.be)        # scaler.scale(loss).backward(): the loss scale enters with the loss gradient
         logits.backward(dlf)
         dtok = tokens.grad.contiguous().view(-1, eng.spec.dim)
         if self.comm is not None and sync and self.comm.active:
@@ -838,9 +856,21 @@ class MapTrainStep:
         gs = 1.0 / (self.comm.world_size if self.comm is not None else 1)
 
         def sgd(normsq):
+            ex = lambda t: be.ptr(t[n:]) if t is not None else None
+            if self.amp:
+                # (the norm of the scaled gradient is what detects an overflow; normsq None = "no clipping" (SAM's base step): the norm is still taken, the clip disabled)
+                be.check(be.lib.vdk_sumsq_f32(be.ptr(self.gbig), self.n_total, be.ptr(self._normsq), be.ptr(self._sumsq_ws), self._sumsq_ws.numel(), be.stream()), "vdk_sumsq_f32")
+                mx = self.max_norm if normsq is not None else 3.0e38
+                be.check(be.lib.vdk_sgd_step_amp(be.ptr(self.big), be.ptr(self.gbig), be.ptr(self.momentum_buf), be.ptr(self.ema), be.ptr(eng.wb16), _abi.F16_, n, lr, momentum,
+                                                 weight_decay, gs, be.ptr(self.loss_state), be.ptr(self._normsq), mx, d, first, be.stream()), "vdk_sgd_step_amp")
+                be.check(be.lib.vdk_sgd_step_amp(ex(self.big), ex(self.gbig), ex(self.momentum_buf), ex(self.ema), None, _abi.F16_, nx, lr, momentum, weight_decay, gs,
+                                                 be.ptr(self.loss_state), be.ptr(self._normsq), mx, d, first, be.stream()), "vdk_sgd_step_amp")
+                be.check(be.lib.vdk_loss_scale_update(be.ptr(self.loss_state), be.ptr(self._normsq), self.growth_factor, self.backoff_factor, self.growth_interval,
+                                                      be.stream()), "vdk_loss_scale_update")
+                eng.refresh_weights(skip_wb16=True)
+                return
             be.check(be.lib.vdk_sgd_step(be.ptr(self.big), be.ptr(self.gbig), be.ptr(self.momentum_buf), be.ptr(self.ema), be.ptr(eng.wb16), n, lr, momentum,
                                          weight_decay, gs, normsq, self.max_norm, d, first, be.stream()), "vdk_sgd_step")
-            ex = lambda t: be.ptr(t[n:]) if t is not None else None
             be.check(be.lib.vdk_sgd_step(ex(self.big), ex(self.gbig), ex(self.momentum_buf), ex(self.ema), None, nx, lr, momentum, weight_decay, gs, normsq,
                                          self.max_norm, d, first, be.stream()), "vdk_sgd_step")
             eng.refresh_weights(skip_wb16=True)
@@ -857,9 +887,16 @@ class MapTrainStep:
             self._loss_rows = loss_first
             return self._loss_rows
         self._fwd_loss_bwd(x, y, y_b, lam)
-        be.check(be.lib.vdk_sumsq_f32(be.ptr(self.gbig), self.n_total, be.ptr(self._normsq), be.ptr(self._sumsq_ws), self._sumsq_ws.numel(), be.stream()), "vdk_sumsq_f32")
+        if not self.amp:
+            be.check(be.lib.vdk_sumsq_f32(be.ptr(self.gbig), self.n_total, be.ptr(self._normsq), be.ptr(self._sumsq_ws), self._sumsq_ws.numel(), be.stream()), "vdk_sumsq_f32")
         sgd(be.ptr(self._normsq))
         return self._loss_rows
+
+    def loss_scale(self) -> float:
+        return float(self.loss_state[0].item()) if self.amp else 1.0
+
+    def skipped_steps(self) -> int:
+        return int(self.loss_state[2].item()) if self.amp else 0
 
     def loss_value(self) -> float:
         return float(self._loss_rows.mean().item())
