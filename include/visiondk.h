@@ -660,7 +660,13 @@ typedef struct VdkResNetConfig {
   int32_t mid[4];        /* all 0: BasicBlock network (resnet18 / 34), `widths` = block channels.  > 0: Bottleneck network (resnet50 / 101 / 152,
                           * wide_resnet*_2): inner width of the 1x1 -> 3x3 -> 1x1 blocks, `widths` = block OUTPUT channels (4 x planes) */
   int32_t stem_width;    /* 0: widths[0] (basic) or 64 (bottleneck) */
+  int32_t operand_dtype; /* VDK_BF16 (0, the default of a zeroed config) or VDK_F16: the 16-bit format of every convolution / fc operand, saved activation and gradient operand --
+                          * IEEE half is what the reference's `torch.autocast(device_type=...)` computes in on a GPU (engine/procedure/train.py:118), with GradScaler's loss scale
+                          * carrying the gradients (dlogits arrives scaled, the optimizer un-scales).  8x smaller operand rounding at the same MFMA rate. */
 } VdkResNetConfig;
+/* the calling thread's 16-bit format for the NHWC / BatchNorm / pooling functions of csrc/resnet_ops.hip (vdk_nchw_to_nhwc_bf16, vdk_bn_act_*, vdk_maxpool3s2_*, vdk_avgpool_*,
+ * vdk_conv_weight_prep): VDK_BF16 (default) | VDK_F16.  The engine entry points below set it from VdkResNetConfig.operand_dtype and restore bf16 on return. */
+int vdk_resnet_ops_format(int32_t dtype);
 /* trainable parameters live in one flat f32 buffer (params / grads), BatchNorm running statistics in another (buffers); `wx` = derived operand copies */
 int vdk_resnet_param_count(const VdkResNetConfig* cfg, int64_t* n_floats, int32_t* n_tensors, int64_t* n_buffer_floats, int32_t* n_buffers, size_t* wx_bytes);
 /* which = 0: parameters, 1: buffers (running_mean / running_var); timm state_dict names */

@@ -98,25 +98,30 @@ class ResNetRef(nn.Module):
         return self.fc(self.forward_features(x).mean((-2, -1)))
 
 
-def _q(t):
-    """bf16 round trip with a straight-through gradient: where the engine stores an activation in bf16"""
-    return t + (t.bfloat16().to(t.dtype) - t).detach()
+def _q(t, dtype=torch.bfloat16):
+    """16-bit round trip (bf16, or fp16 for the engine's operand="fp16" mode) with a straight-through gradient: where the engine stores an activation in 16 bits"""
+    return t + (t.to(dtype).to(t.dtype) - t).detach()
 
 
-def forward_bf16_storage(ref, x):
+def forward_16bit_storage(ref, x, dtype=torch.bfloat16):
     """The oracle's forward with the engine's storage precision made explicit: conv operands (image, activations) are bf16, conv outputs / BatchNorm /
     shortcut sums are fp32, the BatchNorm'd shortcut stays fp32.  With ReLU + small-batch BatchNorm a plain fp32 run differs from ANY bf16 run by tens of
     percent in the gradients (a pre-activation that rounds across zero flips its mask; torch's own CPU autocast shows 25-40 % here), so the comparison
     has to put the rounding points in the same places."""
     F = torch.nn.functional
-    a = ref.maxpool(_q(F.relu(ref.bn1(ref.conv1(_q(x))))))
+    q = lambda t: _q(t, dtype)
+    a = ref.maxpool(q(F.relu(ref.bn1(ref.conv1(q(x))))))
     for i in range(1, 5):
         for blk in getattr(ref, f"layer{i}"):
             idn = a if blk.downsample is None else blk.downsample(a)
-            a1 = _q(F.relu(blk.bn1(blk.conv1(a))))
+            a1 = q(F.relu(blk.bn1(blk.conv1(a))))
             if hasattr(blk, "conv3"):                       # Bottleneck
-                a2 = _q(F.relu(blk.bn2(blk.conv2(a1))))
-                a = _q(F.relu(blk.bn3(blk.conv3(a2)) + idn))
+                a2 = q(F.relu(blk.bn2(blk.conv2(a1))))
+                a = q(F.relu(blk.bn3(blk.conv3(a2)) + idn))
             else:
-                a = _q(F.relu(blk.bn2(blk.conv2(a1)) + idn))
-    return ref.fc(_q(a.mean((-2, -1))))
+                a = q(F.relu(blk.bn2(blk.conv2(a1)) + idn))
+    return ref.fc(q(a.mean((-2, -1))))
+
+
+def forward_bf16_storage(ref, x):
+    return forward_16bit_storage(ref, x, torch.bfloat16)

@@ -47,7 +47,7 @@ class ConvNextConfig(C.Structure):
 
 class ResNetConfig(C.Structure):
     _fields_ = [("batch", I32), ("img_size", I32), ("in_chans", I32), ("widths", I32 * 4), ("depths", I32 * 4), ("num_classes", I32), ("bn_eps", C.c_float),
-                ("bn_momentum", C.c_float), ("mid", I32 * 4), ("stem_width", I32)]
+                ("bn_momentum", C.c_float), ("mid", I32 * 4), ("stem_width", I32), ("operand_dtype", I32)]
 
 
 class SwinConfig(C.Structure):
@@ -243,6 +243,7 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_convnext_train_f32_workspace_bytes": (C.c_int, [C.POINTER(ConvNextConfig), PSZ]),
     "vdk_convnext_forward_train_f32": (C.c_int, [C.POINTER(ConvNextConfig), P, P, P, P, SZ, P, P]),
     "vdk_convnext_backward_train_f32": (C.c_int, [C.POINTER(ConvNextConfig), P, P, P, P, SZ, P, P, P, P]),
+    "vdk_resnet_ops_format": (C.c_int, [I32]),
     "vdk_resnet_param_count": (C.c_int, [C.POINTER(ResNetConfig), C.POINTER(I64), C.POINTER(I32), C.POINTER(I64), C.POINTER(I32), PSZ]),
     "vdk_resnet_param_info": (C.c_int, [C.POINTER(ResNetConfig), I32, I32, C.c_char_p, I32, C.POINTER(I64), C.POINTER(I64), C.POINTER(I64), C.POINTER(I32)]),
     "vdk_resnet_workspace_bytes": (C.c_int, [C.POINTER(ResNetConfig), PSZ]),

@@ -875,15 +875,15 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
       return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad convolution geometry (K == KH*KW*Cin, M == B*OH*OW)");
     // trans = 1: the weight gradient with the im2col operand gathered on the fly (VdkConvGeom.rows); the four-wave TN kernel serves it
     if (d->trans && (c->transposed || d->N != c->KH * c->KW * c->Cin || c->rows <= 0 || c->rows >= (1 << 24) || (c->rows % (c->OH * c->OW)) || d->K < c->rows || (d->K % 128) ||
-                     d->K - c->rows >= 128 || d->ab_dtype != VDK_BF16 || d->a_row_group != 0))
-      return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad weight-gradient geometry (N == KH*KW*Cin, rows == B*OH*OW < 2^24, K == rows rounded up to 128, bf16)");
+                     d->K - c->rows >= 128 || d->a_row_group != 0))
+      return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad weight-gradient geometry (N == KH*KW*Cin, rows == B*OH*OW < 2^24, K == rows rounded up to 128)");
   }
   if (d->ab_dtype != VDK_BF16 && d->ab_dtype != VDK_F16) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: ab_dtype must be VDK_BF16 or VDK_F16");
   const int opf = d->ab_dtype == VDK_F16 ? VDK_OPF_F16 : VDK_OPF_BF16;
   // a 16-bit output is written in the operand format (c_dtype names it: VDK_BF16 with bf16 operands, VDK_F16 with fp16 operands)
   if (d->c_dtype != VDK_F32 && d->c_dtype != (opf ? VDK_F16 : VDK_BF16)) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad c_dtype (VDK_F32, or the operand format)");
-  if (opf && (d->a_colsum || d->conv || d->splitk == -1))
-    return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: fp16 operands are served by the four-wave and the 128x128 kernels (no a_colsum, no implicit convolution, no stream-K)");
+  if (opf && (d->a_colsum || d->splitk == -1))
+    return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: fp16 operands are served by the four-wave and the 128x128 kernels (no a_colsum, no stream-K)");
   if (d->act < VDK_ACT_NONE || d->act > VDK_ACT_MUL_AUX) return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad act");
   if (((d->act == VDK_ACT_DGELU || d->act == VDK_ACT_GELU_SAVE_GRAD || d->act == VDK_ACT_MUL_AUX) && !d->aux) || (d->aux && (d->ldaux & 7)))
     return vdk_fail(VDK_EINVAL, "vdk_gemm_bf16_nt: bad aux");
@@ -1001,7 +1001,8 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
   if (d->trans && d->conv) {      // the implicit weight gradient lives in the four-wave kernel only
     if ((kps % 128) || (d->M & 7) || d->M < 8 || !vdk_gemm_w4_serves(p, true)) return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: this implicit weight gradient is outside the four-wave TN kernel's range");
     void* e0_ = prof ? (void*)g_prof_ev[g_prof_used] : nullptr; void* e1_ = prof ? (void*)g_prof_ev[g_prof_used + 1] : nullptr;
-    if (!vdk_gemm_w4_launch(p, true, E == E_SPLITK ? E_SPLITK : (E == E_F32 ? E_F32 : E_GENERIC), grid256.x, grid256.y, stream, e0_, e1_))
+    const int ew_ = E == E_SPLITK ? E_SPLITK : (E == E_F32 ? E_F32 : E_GENERIC);
+    if (!(opf ? vdk_gemm_w4_launch_f16(p, true, ew_, grid256.x, grid256.y, stream, e0_, e1_) : vdk_gemm_w4_launch(p, true, ew_, grid256.x, grid256.y, stream, e0_, e1_)))
       return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: implicit weight gradient: no kernel");
     g_last_kernel = 5;
   } else if (d->trans) {
@@ -1049,7 +1050,8 @@ int vdk_gemm_bf16_nt(const GemmDesc* d, void* ws, size_t ws_bytes, void* stream_
     return vdk_fail(VDK_EUNSUPPORTED, "vdk_gemm_bf16_nt: a_colsum / c_colsum are by-products of the 256x256 NT kernel only (see vdk_gemm_a_colsum_rows)");
   else if (d->conv) {
     g_last_kernel = 1;
-    VDK_GEMM_LAUNCH(gemm_bf16_nt_kernel<true>, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256));
+    if (opf) VDK_GEMM_LAUNCH((gemm_bf16_nt_kernel<true, VDK_OPF_F16>), dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256));
+    else VDK_GEMM_LAUNCH(gemm_bf16_nt_kernel<true>, dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256));
   } else {
     g_last_kernel = 1;
     if (opf) VDK_GEMM_LAUNCH((gemm_bf16_nt_kernel<false, VDK_OPF_F16>), dim3((unsigned)(ntn * ntm), (unsigned)splitk), dim3(256));

@@ -20,6 +20,8 @@ int vdk_reduce_rows_f32(const float*, int64_t, int32_t, int64_t, float*, float, 
 int vdk_colsum_bf16_workspace_bytes(int32_t, int32_t, size_t*);
 int vdk_colsum_bf16(const void*, int64_t, int32_t, int32_t, float*, void*, size_t, void*);
 int vdk_cast_f32_bf16(const float*, void*, int64_t, void*);
+int vdk_cast_f32_f16(const float*, void*, int64_t, void*);
+int vdk_resnet_ops_format(int32_t);
 int vdk_transpose_cast_f32_bf16(const float*, int64_t, int32_t, int32_t, void*, int64_t, int32_t, void*);
 int vdk_transpose_bf16(const void*, int64_t, int32_t, int32_t, void*, int64_t, int32_t, int32_t, float*, void*);
 int vdk_conv_weight_prep(const float*, void*, void*, int32_t, int32_t, int32_t, int32_t, int32_t, void*);
@@ -38,9 +40,17 @@ int vdk_avgpool_bwd(const void*, int64_t, float*, int32_t, int32_t, int32_t, voi
 }
 
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+int vdk_colsum_16(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, int opf, void* stream);      // (C++ linkage: norm_loss.hip, gemm.hip)
+int vdk_transpose_16(const void* in, int64_t ldi, int32_t R, int32_t C, void* out, int64_t ldo, int32_t Rpad, int32_t in_row_group, float* colsum_partial, int opf, void* stream);
 
 namespace {
 inline int64_t up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+// operand format of the running engine call (VdkResNetConfig.operand_dtype): every GEMM descriptor and 16-bit helper below reads it
+thread_local int t_dt16 = VDK_BF16;
+struct FmtGuard {      // sets the format for csrc/resnet_ops.hip's functions and for this file, restores bf16 when the entry point returns
+  explicit FmtGuard(int dt) { t_dt16 = dt == VDK_F16 ? VDK_F16 : VDK_BF16; vdk_resnet_ops_format(t_dt16); }
+  ~FmtGuard() { t_dt16 = VDK_BF16; vdk_resnet_ops_format(VDK_BF16); }
+};
 
 struct Conv { int ci, cip, co, k, s, p, hin, hout; int64_t w; size_t wf, wd; };         // w: param offset; wf / wd: byte offsets in wx
 struct Bn { int c; int64_t g, b, rm, rv; };                                                // param offsets (g, b), buffer offsets (rm, rv)
@@ -225,7 +235,7 @@ int conv_gemm(hipStream_t s, const Conv& c, int B, bool transposed, const void* 
     g = {c.co, c.hout, c.hout, c.hin, c.hin, c.k, c.k, c.s, c.p, 1};
     d.M = B * c.hin * c.hin; d.N = c.cip; d.K = c.k * c.k * c.co;
   }
-  d.A = A; d.B = W; d.ldb = d.K; d.C = Cout; d.ldc = d.N; d.c_dtype = cdt; d.residual = res; d.ldr = d.N; d.alpha = 1.0f; d.splitk = 1; d.conv = &g;
+  d.A = A; d.B = W; d.ldb = d.K; d.C = Cout; d.ldc = d.N; d.c_dtype = cdt; d.residual = res; d.ldr = d.N; d.alpha = 1.0f; d.splitk = 1; d.conv = &g; d.ab_dtype = t_dt16;
   return vdk_gemm_bf16_nt(&d, nullptr, 0, s);
 }
 // dW[out, in] = dY^T X (dY bf16 [rows, out], X bf16 [rows, in]); db optional
@@ -233,18 +243,18 @@ int linear_wgrad(hipStream_t s, const WsPlan& w, char* base, const bf16_t* dY, c
   if ((rows % 64) == 0) {
     VdkGemmDesc g = {};
     g.A = dY; g.lda = out; g.B = X; g.ldb = in; g.C = dW; g.ldc = in; g.M = out; g.N = in; g.K = rows; g.c_dtype = VDK_F32;
-    g.alpha = 1.0f; g.splitk = wgrad_splitk_tn(out, in, rows); g.trans = 1;
+    g.alpha = 1.0f; g.splitk = wgrad_splitk_tn(out, in, rows); g.trans = 1; g.ab_dtype = t_dt16;
     RC(vdk_gemm_bf16_nt(&g, base + w.slabs, w.slabs_bytes, s));
-    if (db) RC(vdk_colsum_bf16(dY, out, rows, out, db, base + w.csws, w.csws_bytes, s));
+    if (db) RC(vdk_colsum_16(dY, out, rows, out, db, base + w.csws, w.csws_bytes, t_dt16 == VDK_F16 ? VDK_OPF_F16 : VDK_OPF_BF16, s));
     return VDK_OK;
   }
   const int rp = (int)up(rows, 64);
   bf16_t* tA = (bf16_t*)(base + w.tA); bf16_t* tB = (bf16_t*)(base + w.tB);
   float* csp = db ? (float*)(base + w.csws) : nullptr;
-  RC(vdk_transpose_bf16(dY, out, rows, out, tA, rp, rp, 0, csp, s));
-  RC(vdk_transpose_bf16(X, in, rows, in, tB, rp, rp, 0, nullptr, s));
+  RC(vdk_transpose_16(dY, out, rows, out, tA, rp, rp, 0, csp, t_dt16 == VDK_F16 ? VDK_OPF_F16 : VDK_OPF_BF16, s));
+  RC(vdk_transpose_16(X, in, rows, in, tB, rp, rp, 0, nullptr, t_dt16 == VDK_F16 ? VDK_OPF_F16 : VDK_OPF_BF16, s));
   VdkGemmDesc g = {};
-  g.A = tA; g.lda = rp; g.B = tB; g.ldb = rp; g.C = dW; g.ldc = in; g.M = out; g.N = in; g.K = rp; g.c_dtype = VDK_F32; g.alpha = 1.0f;
+  g.A = tA; g.lda = rp; g.B = tB; g.ldb = rp; g.C = dW; g.ldc = in; g.M = out; g.N = in; g.K = rp; g.c_dtype = VDK_F32; g.alpha = 1.0f; g.ab_dtype = t_dt16;
   g.splitk = wgrad_splitk(out, in, rp);
   RC(vdk_gemm_bf16_nt(&g, base + w.slabs, w.slabs_bytes, s));
   if (db) RC(vdk_reduce_rows_f32(csp, out, (rp + 63) / 64, out, db, 1.0f, s));
@@ -263,7 +273,7 @@ int conv_wgrad(hipStream_t s, const WsPlan& w, char* base, const Conv& c, int B,
     VdkConvGeom g = {c.cip, c.hin, c.hin, c.hout, c.hout, c.k, c.k, c.s, c.p, 0, rows};
     VdkGemmDesc d = {};
     d.A = dY; d.lda = c.co; d.B = in_nhwc; d.ldb = N; d.C = dwp; d.ldc = N; d.M = c.co; d.N = N; d.K = (int)up(rows, 128); d.c_dtype = VDK_F32; d.alpha = 1.0f;
-    d.splitk = wgrad_splitk_tn(c.co, N, d.K); d.trans = 1; d.conv = &g;
+    d.splitk = wgrad_splitk_tn(c.co, N, d.K); d.trans = 1; d.conv = &g; d.ab_dtype = t_dt16;
     const int rc = vdk_gemm_bf16_nt(&d, base + w.slabs, w.slabs_bytes, s);
     if (rc == VDK_OK) return vdk_conv_wgrad_unpermute(dwp, dW, c.co, c.ci, c.cip, c.k, c.k, s);
     if (rc != VDK_EUNSUPPORTED) return rc;
@@ -312,11 +322,15 @@ int vdk_resnet_workspace_bytes(const VdkResNetConfig* cfg, size_t* bytes) {
 int vdk_resnet_refresh_weights(const VdkResNetConfig* cfg, const float* params, void* wb16, void* wx, int32_t skip_wb16, void* stream) {
   RnDims d; RC(rn_dims(cfg, &d));
   if (!params || !wb16 || !wx) return vdk_fail(VDK_EINVAL, "vdk_resnet_refresh_weights: null pointer");
-  if (!skip_wb16) RC(vdk_cast_f32_bf16(params, wb16, d.ptotal, stream));
+  FmtGuard fmt(cfg->operand_dtype);
+  if (!skip_wb16) RC(t_dt16 == VDK_F16 ? vdk_cast_f32_f16(params, wb16, d.ptotal, stream) : vdk_cast_f32_bf16(params, wb16, d.ptotal, stream));
   char* xb = (char*)wx;
   auto prep = [&](const Conv& c) { return vdk_conv_weight_prep(params + c.w, xb + c.wf, c.wd ? xb + c.wd : nullptr, c.co, c.ci, c.cip, c.k, c.k, stream); };
   RC(prep(d.stem));
   for (const Blk& b : d.blk) { RC(prep(b.c1)); RC(prep(b.c2)); if (b.bott) RC(prep(b.c3)); if (b.ds) RC(prep(b.cd)); }
+  if (t_dt16 == VDK_F16) {      // fc^T in IEEE half: cast (the refreshed wb16 holds fc.weight already; with skip_wb16 the caller's optimizer pass wrote it) + 16-bit transpose
+    return vdk_transpose_16((const bf16_t*)wb16 + d.fc_w, d.wlast, d.Cp, d.wlast, xb + d.fct, d.Cp, d.Cp, 0, nullptr, VDK_OPF_F16, stream);
+  }
   return vdk_transpose_cast_f32_bf16(params + d.fc_w, d.wlast, d.Cp, d.wlast, xb + d.fct, d.Cp, d.Cp, stream);
 }
 
@@ -327,6 +341,7 @@ int vdk_resnet_forward(const VdkResNetConfig* cfg, const float* x, const float* 
   RnDims d; RC(rn_dims(cfg, &d));
   WsPlan w; rn_plan(d, &w);
   if (!x || !params || !buffers || !wb16 || !wx || !ws || !logits) return vdk_fail(VDK_EINVAL, "vdk_resnet_forward: null pointer");
+  FmtGuard fmt(cfg->operand_dtype);
   if (ws_bytes < w.total) return vdk_fail(VDK_EWORKSPACE, "vdk_resnet_forward: workspace too small");
   char* base = (char*)ws; const char* xb = (const char*)wx;
   void* bnws = base + w.bnws;
@@ -364,7 +379,7 @@ int vdk_resnet_forward(const VdkResNetConfig* cfg, const float* x, const float* 
   RC(vdk_avgpool_fwd(ain, base + w.feat, d.B, d.Bp, last.c2.hout * last.c2.hout, d.wlast, s));
   VdkGemmDesc g = {};
   g.A = base + w.feat; g.lda = d.wlast; g.B = (const bf16_t*)wb16 + d.fc_w; g.ldb = d.wlast; g.C = logits; g.ldc = d.Cp; g.M = d.B; g.N = d.Cp; g.K = d.wlast;
-  g.c_dtype = VDK_F32; g.bias = params + d.fc_b; g.alpha = 1.0f; g.splitk = 1;
+  g.c_dtype = VDK_F32; g.bias = params + d.fc_b; g.alpha = 1.0f; g.splitk = 1; g.ab_dtype = t_dt16;
   RC(vdk_gemm_bf16_nt(&g, nullptr, 0, s));
   return vdk_check_launch("vdk_resnet_forward");
 }
@@ -376,6 +391,7 @@ int vdk_resnet_backward(const VdkResNetConfig* cfg, const void* dlogits, const f
   RnDims d; RC(rn_dims(cfg, &d));
   WsPlan w; rn_plan(d, &w);
   if (!dlogits || !params || !wb16 || !wx || !ws || !grads) return vdk_fail(VDK_EINVAL, "vdk_resnet_backward: null pointer");
+  FmtGuard fmt(cfg->operand_dtype);
   if (ws_bytes < w.total) return vdk_fail(VDK_EWORKSPACE, "vdk_resnet_backward: workspace too small");
   char* base = (char*)ws; const char* xb = (const char*)wx;
   float* da = (float*)(base + w.da); float* db = (float*)(base + w.db); bf16_t* dyb = (bf16_t*)(base + w.dyb);
@@ -391,8 +407,8 @@ int vdk_resnet_backward(const VdkResNetConfig* cfg, const void* dlogits, const f
   RC(linear_wgrad(s, w, base, (const bf16_t*)dlogits, (const bf16_t*)(base + w.feat), d.B, d.Cp, d.wlast, grads + d.fc_w, grads + d.fc_b));
   {
     VdkGemmDesc g = {};
-    g.A = dlogits; g.lda = d.Cp; g.B = xb + d.fct; g.ldb = d.Cp; g.C = base + w.dfeat; g.ldc = d.wlast; g.M = d.B; g.N = d.wlast; g.K = d.Cp; g.c_dtype = VDK_BF16;
-    g.alpha = 1.0f; g.splitk = 1;
+    g.A = dlogits; g.lda = d.Cp; g.B = xb + d.fct; g.ldb = d.Cp; g.C = base + w.dfeat; g.ldc = d.wlast; g.M = d.B; g.N = d.wlast; g.K = d.Cp; g.c_dtype = t_dt16;
+    g.alpha = 1.0f; g.splitk = 1; g.ab_dtype = t_dt16;
     RC(vdk_gemm_bf16_nt(&g, nullptr, 0, s));
   }
   RC(vdk_avgpool_bwd(base + w.dfeat, d.wlast, da, d.B, hw, d.wlast, s));

@@ -40,8 +40,13 @@ TIMM_RESNETS = {
 
 
 class ResNetEngine:
-    def __init__(self, spec: ResNetSpec, device=None, backend: Optional[_lib.Backend] = None):
+    def __init__(self, spec: ResNetSpec, device=None, backend: Optional[_lib.Backend] = None, operand: str = "bf16"):
+        # operand: the 16-bit format of every convolution / fc operand, saved activation and gradient operand -- "bf16", or "fp16" = what the reference's
+        # `torch.autocast(device_type=...)` (engine/procedure/train.py:118, no dtype => float16 on a GPU) computes in, with GradScaler's loss scale around the backward
+        assert operand in ("bf16", "fp16"), operand
         self.spec = spec
+        self.operand = operand
+        self.op_dtype = torch.float16 if operand == "fp16" else torch.bfloat16
         self.be = backend or _lib.load()
         self.device = torch.device(device if device is not None else ("cuda" if self.be.device_only else "cpu"))
         cfg = self._cfg(1)
@@ -65,7 +70,7 @@ class ResNetEngine:
         self.params = torch.zeros(nf.value, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(nf.value, dtype=torch.float32, device=dev)
         self.buffers = torch.zeros(nbf.value, dtype=torch.float32, device=dev)
-        self.wb16 = torch.zeros(nf.value, dtype=torch.bfloat16, device=dev)
+        self.wb16 = torch.zeros(nf.value, dtype=self.op_dtype, device=dev)
         self.wx = torch.zeros(wx.value, dtype=torch.uint8, device=dev)
         self.cp = (spec.num_classes + 7) // 8 * 8
         self._ws: Optional[torch.Tensor] = None
@@ -76,7 +81,8 @@ class ResNetEngine:
     def _cfg(self, batch: int, img: Optional[int] = None, bn_momentum: Optional[float] = None) -> _abi.ResNetConfig:
         s = self.spec
         return _abi.ResNetConfig(batch, img or s.img_size, s.in_chans, (_abi.I32 * 4)(*s.widths), (_abi.I32 * 4)(*s.depths), s.num_classes, s.bn_eps,
-                                 s.bn_momentum if bn_momentum is None else bn_momentum, (_abi.I32 * 4)(*s.mid), s.stem_width)
+                                 s.bn_momentum if bn_momentum is None else bn_momentum, (_abi.I32 * 4)(*s.mid), s.stem_width,
+                                 _abi.F16_ if self.operand == "fp16" else _abi.BF16)
 
     def _workspace(self, batch: int, img: int) -> torch.Tensor:
         """keyed on (batch, image size): the reference's progressive resizing (engine/vision_engine.py:181-222) changes the input resolution between
@@ -130,7 +136,7 @@ class ResNetEngine:
 
     def backward(self, dlogits_bf16: torch.Tensor, on_ready: Optional[Callable[[int, int], None]] = None, sync_group=False) -> torch.Tensor:
         B = dlogits_bf16.shape[0]
-        assert dlogits_bf16.dtype == torch.bfloat16 and dlogits_bf16.shape[1] == self.cp and B == self._ws_batch[0]
+        assert dlogits_bf16.dtype == self.op_dtype and dlogits_bf16.shape[1] == self.cp and B == self._ws_batch[0]      # (in the engine's operand format)
         cfg = self._cfg(B, self._ws_batch[1])
         be = self.be
         cb = _abi.GRAD_READY_FN(lambda user, off, n: on_ready(off, n)) if on_ready is not None else _abi.GRAD_READY_FN(0)
@@ -155,8 +161,9 @@ class _ResNetFunction(torch.autograd.Function):
         B, Cn = dlogits.shape
         stage = torch.zeros((B, eng.cp), dtype=torch.float32, device=dlogits.device)
         stage[:, :Cn].copy_(dlogits)
-        dl = torch.empty((B, eng.cp), dtype=torch.bfloat16, device=dlogits.device)
-        be.check(be.lib.vdk_cast_f32_bf16(be.ptr(stage), be.ptr(dl), stage.numel(), be.stream()), "vdk_cast_f32_bf16")
+        dl = torch.empty((B, eng.cp), dtype=eng.op_dtype, device=dlogits.device)
+        cast = be.lib.vdk_cast_f32_f16 if eng.operand == "fp16" else be.lib.vdk_cast_f32_bf16      # (fp16: the incoming gradient carries GradScaler's loss scale, train.py:205)
+        be.check(cast(be.ptr(stage), be.ptr(dl), stage.numel(), be.stream()), "vdk_cast_f32_16")
         g = eng.backward(dl)
         return (None, None) + tuple(g[off:off + numel].view(shape) for (_, off, numel, shape) in eng.entries)
 
@@ -168,10 +175,10 @@ class _Holder(nn.Module):
 class ResNet(nn.Module):
     """Drop-in for `timm.create_model('resnet18' | 'resnet34', pretrained=False, num_classes=C)`."""
 
-    def __init__(self, spec: ResNetSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None):
+    def __init__(self, spec: ResNetSpec, device=None, backend: Optional[_lib.Backend] = None, seed: Optional[int] = None, operand: str = "bf16"):
         super().__init__()
         self.spec = spec
-        self.engine = ResNetEngine(spec, device=device, backend=backend)
+        self.engine = ResNetEngine(spec, device=device, backend=backend, operand=operand)
         self.num_classes = spec.num_classes
         eng = self.engine
         self._plist, self._blist = [], []
@@ -262,12 +269,13 @@ class ResNet(nn.Module):
         return self.engine.forward(x, self.training)[:, :self.spec.num_classes].clone()
 
 
-def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, device=None, backend=None, img_size: Optional[int] = None, **kwargs) -> ResNet:
+def create_model(name: str, pretrained: bool = False, num_classes: int = 1000, device=None, backend=None, img_size: Optional[int] = None, operand: str = "bf16",
+                 **kwargs) -> ResNet:
     if name not in TIMM_RESNETS:
         raise NotImplementedError(f"timm model '{name}' is not covered by the HIP engine yet (have: {sorted(TIMM_RESNETS)})")
     if pretrained:
         raise RuntimeError("pretrained weights need network access; load a checkpoint with load_state_dict instead")
-    return ResNet(ResNetSpec(img_size=img_size or 224, num_classes=num_classes, **TIMM_RESNETS[name]), device=device, backend=backend)
+    return ResNet(ResNetSpec(img_size=img_size or 224, num_classes=num_classes, **TIMM_RESNETS[name]), device=device, backend=backend, operand=operand)
 
 
 class ResNetTrainStep:
