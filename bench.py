@@ -98,7 +98,7 @@ def pmc_traffic_per_launch():
     """HBM-side bytes per GEMM launch from the committed PMC passes of this same command (rocprofv3 cannot run inside the timed process):
     profiles/r0N_pmc_traffic.json is written by tools/pmc_traffic.py from two `rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE}` runs,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  None if the artifact is absent."""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):      # the newest round's passes of this command
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):      # the newest round's passes of this command
         p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             with open(p) as f:
@@ -110,7 +110,7 @@ def pmc_traffic_per_launch():
 
 def pmc_cbir():
     """L2 memory-side bytes of one search from the committed PMC passes of tools/pmc_cbir.py (None if absent)"""
-    for name in ("r05_cbir_pmc.json", "r04_cbir_pmc.json", "r03_cbir_pmc.json", "r02_cbir_pmc.json"):
+    for name in ("r06_cbir_pmc.json", "r05_cbir_pmc.json", "r04_cbir_pmc.json", "r03_cbir_pmc.json", "r02_cbir_pmc.json"):
         p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             with open(p) as f:
@@ -315,6 +315,37 @@ def bench_cfg5(be, dev, batch: int = 128, steps: int = 3):
     return out
 
 
+def bench_cfg3(be, dev, batch: int = 512, steps: int = 4, ncls: int = 1_000_000):
+    """BASELINE.json configs[2] on one GPU: ConvNeXt-Base + neck (feat_dim 512) + ArcFace(C = 10^6, m = .35, s = 32), batch 512 -- one step = compute_loss(face=True) +
+    Trainer.update (forward, fused margin head + CE that never writes the B x C logits, backward, clip 10, layer-wise SGD, EMA; /root/reference/configs/faceX/cbir.yaml:30-37,
+    engine/procedure/train.py:217-280) on fp16 operands with the GradScaler protocol: the mode tests/test_parity_fullsize_gpu.py holds to north_star's tolerance against the
+    reference's fp32 loop at C = 10^6.  The head's class dimension is what the 8-GPU configuration shards; here it is whole (2 GB of fp32 weights + momentum + EMA)."""
+    from visiondk_amd import face
+    cfg = {"task": "cbir", "image_size": 224, "backbone": {"timm-convnext_base": {"pretrained": False, "image_size": 224, "feat_dim": 512, "operand": "fp16"}},
+           "head": {"arcface": {"feat_dim": 512, "num_class": ncls, "margin_arc": 0.35, "margin_am": 0.0, "scale": 32}}}
+    torch.manual_seed(0)
+    model = face.get_model(cfg, None, 0).model.train()
+    step = face.FaceTrainStep(model, lr=0.01, momentum=0.9, weight_decay=5e-4, max_norm=10.0, ema=True, layer_wise=True)
+    g = torch.Generator(device="cpu"); g.manual_seed(0)
+    x = torch.randn(batch, 3, 224, 224, generator=g).to(dev)
+    y = torch.randint(0, ncls, (batch,), generator=g).to(dev)
+    for _ in range(2):
+        step.step(x, y)
+    torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(steps):
+        rows = step.step(x, y)
+    torch.cuda.synchronize(); dt = (time.time() - t0) / steps
+    flop_img = 92.1e9 + 0.15e9 + 3.07e9 * ncls / 1e6          # ConvNeXt-B fwd+bwd (3 x 2 x 15.35 GMAC), neck, the 512 x C head fwd + two backward products
+    out = {"workload": f"cfg3: convnext_base + neck 512 + ArcFace(C = {ncls}), batch {batch}: fwd + fused margin CE + bwd + clip + layer-wise SGD + EMA, fp16 operands + GradScaler protocol",
+           "dtype": "fp16", "images_per_sec": batch / dt, "ms_per_step": dt * 1e3, "loss": rows.mean().item(), "loss_scale": step.loss_scale(), "skipped_steps": step.skipped_steps(),
+           "roofline": {"bound": "mfma", "achieved": flop_img * batch / dt / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": flop_img * batch / dt / 1e12 / PEAK_BF16_TFLOPS,
+                        "traffic": None, "flop_per_image": flop_img},
+           "parity": "tests/test_parity_fullsize_gpu.py: embeddings <= 1e-3 and every gradient <= 5e-3 against the reference's fp32 loop at C = 10^6 (fp16 operands)"}
+    del step, model, x, y
+    torch.cuda.empty_cache()
+    return out
+
+
 def bench_swin(be, dev, batch: int = 128, steps: int = 4):
     """swin_base_patch4_window7_224 -- the `name:` both shipped configs of the reference default to (pet.yaml:25, cbir.yaml:26) -- beside the headline: the classifier step
     forward + CE + backward + clip_grad_norm_ + SGD + EMA through the native engine (csrc/swin_engine.hip: one C-ABI call forward, one backward) under vit.FusedTrainStep,
@@ -507,6 +538,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-cfg5", action="store_true")
     ap.add_argument("--no-swin", action="store_true")
+    ap.add_argument("--no-cfg3", action="store_true")
     ap.add_argument("--operand", choices=("fp16", "bf16"), default="fp16",
                     help="16-bit operand format of the headline leg: fp16 = the reference's autocast dtype + GradScaler (train.py:118,205-211), bf16 = BASELINE.json configs[1]'s word; the other one is timed beside it")
     ap.add_argument("--no-other-operand", action="store_true")
@@ -613,6 +645,9 @@ def main():
         if world == 1 and not args.no_swin:
             torch.cuda.empty_cache()
             out["swin"] = bench_swin(be, dev)
+        if world == 1 and not args.no_cfg3:
+            torch.cuda.empty_cache()
+            out["cfg3"] = bench_cfg3(be, dev)
         if world == 1 and not args.no_cbir:
             torch.cuda.empty_cache()
             out["cbir"] = bench_cbir(dev, with_cpu=not args.no_cpu_baseline)

@@ -149,7 +149,6 @@ typedef struct VdkGemmDesc {
 } VdkGemmDesc;
 int vdk_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t splitk, size_t* bytes);
 int vdk_gemm_streamk_workspace_bytes(size_t* bytes);
-int vdk_gemm_streamk_grid(int32_t workgroups);   /* tests / tuning: persistent workgroups of the stream-K launch (multiple of 8; 0 = one per CU) */
 int vdk_gemm_bf16_nt(const VdkGemmDesc* d, void* ws, size_t ws_bytes, void* stream);
 /* OCP fp8 operands on the block-scaled MFMA (csrc/gemm_fp8.hip): the Linear GEMMs of BASELINE.json configs[4] ("SigLIP ViT-L/14 336 ... fp8 MFMA"; the reference has
  * no fp8 code -- this is timm's Linear, models/classifier/classify_model.py:49-54, under per-tensor delayed scaling).  fmt 0 = e4m3 (activations, weights), 1 = e5m2 (gradients).
@@ -165,27 +164,13 @@ int vdk_gemm_fp8_nt(const VdkGemmDesc* d, int32_t a_fmt, int32_t b_fmt, const fl
  * quantisation pass over it (2 B read + 1 B written per element) disappears.  GELU (+ bias + aux) and DGELU epilogues only, bf16 C, N % 64 == 0, ldo8 % 8 == 0. */
 int vdk_gemm_fp8_nt_q8(const VdkGemmDesc* d, int32_t a_fmt, int32_t b_fmt, const float* a_scale_inv, const float* b_scale_inv, void* out8, int64_t ldo8, int32_t out_fmt,
                        const float* out_scale, float* out_amax, void* stream);
-/* tests / A-B benchmarking only: 0 = automatic choice, 1 = 128x128 register-staged kernel, 2 = 256x256 LDS-DMA kernel
- * (the latter still requires K and the split size to be multiples of 64), 3 = stream-K whenever splitk == -1 lends a workspace, 4 = never stream-K. */
 int vdk_gemm_c_colsum_rows(int32_t M, int32_t N, int32_t K);   /* rows of VdkGemmDesc.c_colsum, 0 = by-product not available for this problem */
 int vdk_gemm_a_colsum_rows(int32_t M, int32_t N, int32_t K);   /* rows of VdkGemmDesc.a_colsum, 0 = by-product not available for this problem */
-int vdk_gemm_force_kernel(int32_t which);
-int vdk_gemm_force_band_cw(int32_t cw);   /* tests: tile order of the one-wave-per-SIMD kernels in column bands of cw tile columns (-1: decided by size, the default) */
-/* tests / tuning: which structure served the calling thread's last vdk_gemm_bf16_nt / vdk_margin_cos_pass: 1 = 128x128 register-staged, 2 = 256x256 eight waves,
- * 3 = its stream-K form, 5 = 256x256 four waves (one per SIMD, persistent; gemm_w4.hip; the default for big problems; which = 5 forces it wherever it can
- * serve, environment VDK_GEMM_W4=0 disables it), 6 = 256x128 four waves with two workgroups per CU (gemm_w4h_kernel: the default for the long epilogues --
- * GELU, dGELU, fp32 residual; which = 6 forces it; environment VDK_GEMM_W4H = bit mask 1 GELU | 2 dGELU | 4 residual | 8 other NT | 16 TN) */
-int vdk_gemm_last_kernel(void);
 /* leave n CUs (0..128, rounded so that the walk stays a multiple of 8) out of the persistent GEMM grids of this process: a data-parallel host sets it to the number of
  * channels its collectives run on (visiondk_amd/comm.py: 32), so that an all-reduce in flight on another stream and a persistent GEMM fit on the chip together instead of
  * the GEMM's static tile walk waiting for the collective to end.  Results do not depend on it.  Environment VDK_GEMM_RESERVE_CUS overrides. */
 int vdk_gemm_reserve_cus(int32_t n);
 int vdk_gemm_reserved_cus(void);   /* the value in force (so that a caller can scope a reserve to a window and restore what it found) */
-/* diagnostic: `workgroups` workgroups (256 threads, 32 KB of LDS) that stay resident for `microseconds` on `stream` -- a stand-in for a collective's kernel in flight */
-int vdk_debug_occupy_cus(int32_t workgroups, int64_t microseconds, void* stream);
-/* profiling aid: when non-NULL, every 256x256 workgroup writes 4 shader-cycle stamps (start, operands landed, main loop done,
- * stores issued) to buf[4 * workgroup]; NULL (default) disables it */
-int vdk_gemm_debug_stamps(void* device_u64_buffer);
 
 /* live GEMM timing for bench.py's `roofline` (HIP events on the launch stream around every GEMM kernel):
  * begin(max_launches) pre-creates the events; end() synchronises and returns the totals since begin(). */
@@ -205,7 +190,6 @@ int vdk_transpose_bf16(const void* in, int64_t ldi, int32_t R, int32_t C, void* 
  * (csrc/attention_small.hip); longer sequences: forward and recompute-form backward with the other operand streamed through a double-buffered LDS chunk
  * (csrc/attention_long.hip).  on = 1 forces the round-1 flash-style kernels of csrc/attention.hip at every N (A/B timing, tests), 0 the default
  * routing, -1 hands the choice back to the VDK_ATTN_LEGACY environment variable. */
-int vdk_attention_force_legacy(int32_t on);
 
 /* timm Attention core: softmax(q k^T * scale) v per head, flash-style (the N x N matrix is never
  * written).  qkv: bf16 [B, N, 3, H, 64] = the fused qkv Linear output (row stride ld elements);
@@ -253,7 +237,6 @@ int vdk_batchnorm1d_bwd(const float* dy, int64_t lddy, const float* x, int64_t l
 int vdk_reduce_rows_f32(const float* in, int64_t ld, int32_t S, int64_t n, float* out, float scale, void* stream);
 /* tests: the same reduction through the in-library batch path the engines use (up to 8 reductions per launch); `buf` is SCRATCH: from 1024 partial rows on they are folded onto
  * the first 64 in place before the final sum (fixed order: bit-reproducible) */
-int vdk_debug_reduce_rows_job(float* buf, int64_t ld, int32_t S, int64_t n, float* out, float scale, void* stream);
 /* out[c] = sum_r in[r][c], in bf16 [T, N] — bias gradient of a Linear */
 int vdk_colsum_bf16_workspace_bytes(int32_t T, int32_t N, size_t* bytes);
 int vdk_colsum_bf16(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream);

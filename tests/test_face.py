@@ -351,3 +351,23 @@ def test_face_train_step_fp16_operands_under_the_grad_scaler(be, dev, monkeypatc
     for n, p in bb.named_parameters():
         assert torch.equal(p.detach(), before[n]), n
     assert torch.equal(head.weight.detach(), hw) and torch.equal(step.mom_flat, mom0)
+
+
+def test_face_train_step_bf16_ignores_a_scaler_state_on_resume(be, dev, monkeypatch):
+    """A bf16 backbone has no GradScaler: a scaler state restored from a checkpoint of an fp16 run (or of the reference: scale 65536, engine/vision_engine.py:296,397) must
+    not reach loss_state -- vdk_sgd_step_amp divides by it while the bf16 passes never scale.  The step after such a resume equals the step without it, bit for bit."""
+    runs = []
+    for resume in (False, True):
+        model, ref, img = _build_cnn(be, dev, monkeypatch, operand="bf16")
+        step = face.FaceTrainStep(model, lr=0.05, momentum=0.9, weight_decay=5e-4, max_norm=0.5, ema=False)
+        assert not step.amp and step.scaler_state_dict() == {}
+        if resume:
+            step.load_scaler_state_dict({"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 7})
+        assert step.loss_scale() == 1.0
+        torch.manual_seed(5)
+        x = torch.randn(8, 3, img, img); y = torch.randint(0, 40, (8,))
+        step.step(x.to(dev), y.to(dev))
+        bb = model.trainingwrapper["backbone"]
+        runs.append({n: p.detach().clone() for n, p in bb.named_parameters()})
+    for n in runs[0]:
+        assert torch.equal(runs[0][n], runs[1][n]), n

@@ -307,32 +307,6 @@ def test_face_train_step_over_the_swin_engine(be, dev):
     assert errs[-1][0] < 3e-2, errs[-3:]
 
 
-@pytest.mark.parametrize("windows,heads,nW,indexed", [(5, 2, 0, False), (12, 3, 4, True)])
-def test_window_attention_bwd_two_wave_form_equals_one_wave_form(be, dev, windows, heads, nW, indexed, monkeypatch):
-    """the backward at two waves per SIMD (key tiles one at a time, V's tile reused as staging: 20 KB of LDS per wave) (VDK_WA_BWD=2) against the default one-wave form: the same
-    products in the same order per element -- dqkv and d(bias) bit-equal"""
-    torch.manual_seed(windows + 7)
-    N, hd = 49, 32
-    Cc = heads * hd
-    qkv = torch.randn(windows * N, 3 * Cc).bfloat16().to(dev)
-    bias = (torch.randn(heads, N, N) * 0.5).to(dev).requires_grad_(True)
-    mask = None
-    if nW:
-        mask = torch.where(torch.rand(nW, N, N) < 0.3, torch.full((), -100.0), torch.zeros(()))
-        mask[:, torch.arange(N), torch.arange(N)] = 0.0
-        mask = mask.to(dev).contiguous()
-    do = torch.randn(windows * N, Cc).bfloat16().to(dev)
-    perm = (torch.randperm(windows * N) if indexed else torch.arange(windows * N)).to(torch.int32).to(dev)
-    outs = []
-    for form in ("1", "2"):
-        monkeypatch.setenv("VDK_WA_BWD", form)
-        q = qkv.clone().requires_grad_(True); b = bias.detach().clone().requires_grad_(True)
-        o = swin._WinAttn.apply(q, b, mask, heads, be, perm if indexed else None)
-        o.backward(do)
-        outs.append((q.grad.clone(), b.grad.clone()))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-
-
 # ---- fp16 operands: the reference's autocast dtype (engine/procedure/train.py:118); north_star's bar of 1e-3 logits / 5e-3 gradients against the fp32 path ----------------
 
 def _fp16_vs_bf16(be, dev, depths, heads, ncls, scale=256.0):

@@ -6,11 +6,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-BARGS="--steps 20 --warmup 3 --no-parity --no-cpu-baseline --no-cbir --no-cfg5 --no-swin"
+BARGS="--steps 20 --warmup 3 --no-parity --no-cpu-baseline --no-cbir --no-cfg5 --no-swin --no-cfg3"
 rocprofv3 --kernel-trace --stats -d /tmp/p_trace -o t -- python $R/bench.py $BARGS > $O/trace_stdout.txt 2>&1
 python $R/tools/rocpd_stats.py $(find /tmp/p_trace -name "*.db" | head -1) > $O/bench_kernel_stats.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d /tmp/p_$c -o p --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-parity --no-cpu-baseline --no-cbir --no-cfg5 --no-swin --no-other-operand > $O/pmc_${c}_stdout.txt 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d /tmp/p_$c -o p --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-parity --no-cpu-baseline --no-cbir --no-cfg5 --no-swin --no-cfg3 --no-other-operand > $O/pmc_${c}_stdout.txt 2>&1
 done
 F=$(find /tmp/p_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find /tmp/p_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 CALLS=$(python -c "import json;print(7 * json.loads([l for l in open('$O/pmc_FETCH_SIZE_stdout.txt') if l.startswith('{\"metric\"')][-1])['roofline']['dominant_kernel']['gemm_calls_per_step'])")
@@ -26,7 +26,7 @@ rocprofv3 --kernel-trace --stats -d /tmp/c_trace -o t -- python $R/tools/cbir_pm
 python $R/tools/rocpd_stats.py $(find /tmp/c_trace -name "*.db" | head -1) > $O/cbir_kernel_stats.txt
 tail -8 $O/cbir_pmc.txt
 cd $R
-cp $O/pmc_traffic.json profiles/r05_pmc_traffic.json 2>/dev/null; cp $O/cbir_pmc.json profiles/r05_cbir_pmc.json 2>/dev/null    # the bench line below reads them
+cp $O/pmc_traffic.json profiles/r06_pmc_traffic.json 2>/dev/null; cp $O/cbir_pmc.json profiles/r06_cbir_pmc.json 2>/dev/null    # the bench line below reads them
 T0=$(date +%s); python bench.py > $O/bench_stdout.txt 2> $O/bench_stderr.txt; echo "default bench.py wall: $(( $(date +%s) - T0 )) s" | tee $O/bench_wall.txt
 tail -1 $O/bench_stdout.txt > $O/bench.json
 python -c "

@@ -1,6 +1,6 @@
 #!/bin/bash
 # copy the round's judged summaries from gpurun_out/final (scratch, merged back by gpurun) into profiles/ (tracked)
-R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out/final; P=$R/profiles; N=${1:-r05}
+R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out/final; P=$R/profiles; N=${1:-r06}
 cp $O/bench.json $P/${N}_bench.json
 cp $O/bench_kernel_stats.txt $P/${N}_bench_kernel_stats.txt
 cp $O/pmc_traffic.json $P/${N}_pmc_traffic.json; cp $O/pmc_traffic.txt $P/${N}_pmc_traffic.txt

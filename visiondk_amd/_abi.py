@@ -91,27 +91,20 @@ SIGNATURES: dict[str, tuple] = {
     # hot path A: dense ops
     "vdk_gemm_splitk_workspace_bytes": (C.c_int, [I32, I32, I32, PSZ]),
     "vdk_gemm_streamk_workspace_bytes": (C.c_int, [PSZ]),
-    "vdk_gemm_streamk_grid": (C.c_int, [I32]),
     "vdk_gemm_bf16_nt": (C.c_int, [C.POINTER(GemmDesc), P, SZ, P]),
     "vdk_gemm_a_colsum_rows": (C.c_int, [I32, I32, I32]),
     "vdk_gemm_c_colsum_rows": (C.c_int, [I32, I32, I32]),
-    "vdk_gemm_force_kernel": (C.c_int, [I32]),
-    "vdk_gemm_force_band_cw": (C.c_int, [I32]),
-    "vdk_gemm_last_kernel": (C.c_int, []),
     "vdk_gemm_reserve_cus": (C.c_int, [C.c_int32]),
     "vdk_gemm_reserved_cus": (C.c_int, []),
-    "vdk_debug_occupy_cus": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p]),
     "vdk_quant_fp8": (C.c_int, [P, I32, I64, P, P, I32, P, P]),
     "vdk_fp8_scale_update": (C.c_int, [P, P, P, I32, I32, F32, P]),
     "vdk_gemm_fp8_nt": (C.c_int, [P, I32, I32, P, P, P]),
     "vdk_gemm_fp8_nt_q8": (C.c_int, [P, I32, I32, P, P, P, I64, I32, P, P, P]),
-    "vdk_gemm_debug_stamps": (C.c_int, [P]),
     "vdk_prof_begin": (C.c_int, [I32]),
     "vdk_prof_pause": (C.c_int, [I32]),
     "vdk_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(I64), C.POINTER(C.c_double)]),
     "vdk_prof_bytes": (C.c_int, [C.POINTER(C.c_double)]),
     "vdk_transpose_bf16": (C.c_int, [P, I64, I32, I32, P, I64, I32, I32, P, P]),
-    "vdk_attention_force_legacy": (C.c_int, [I32]),
     "vdk_attention_fwd": (C.c_int, [P, I64, P, I64, P, I32, I32, I32, I32, F32, P]),
     "vdk_attention_bwd": (C.c_int, [P, I64, P, P, I64, P, P, I64, P, I32, I32, I32, I32, F32, P]),
     "vdk_attention_fwd_dt": (C.c_int, [P, I64, P, I64, P, I32, I32, I32, I32, F32, I32, P]),
@@ -123,7 +116,6 @@ SIGNATURES: dict[str, tuple] = {
     "vdk_batchnorm1d_fwd": (C.c_int, [P, I64, I32, I32, P, P, F32, F32, I32, P, P, P, I64, P, P, P]),
     "vdk_batchnorm1d_bwd": (C.c_int, [P, I64, P, I64, I32, I32, P, P, P, P, I64, P, P, P]),
     "vdk_reduce_rows_f32": (C.c_int, [P, I64, I32, I64, P, F32, P]),
-    "vdk_debug_reduce_rows_job": (C.c_int, [P, I64, I32, I64, P, F32, P]),
     "vdk_colsum_bf16_workspace_bytes": (C.c_int, [I32, I32, PSZ]),
     "vdk_colsum_bf16": (C.c_int, [P, I64, I32, I32, P, P, SZ, P]),
     "vdk_softmax_ce": (C.c_int, [P, I64, I32, I32, P, P, F32, F32, F32, P, P, I64, P, I64, P]),
@@ -263,6 +255,19 @@ class VdkError(RuntimeError):
     pass
 
 
+# tuning / debug / test knobs (csrc/vdk_internal.h): exported by the library, not part of the ABI a host binds
+INTERNAL = {
+    "vdk_gemm_streamk_grid": (C.c_int, [I32]),
+    "vdk_gemm_force_kernel": (C.c_int, [I32]),
+    "vdk_gemm_force_band_cw": (C.c_int, [I32]),
+    "vdk_gemm_last_kernel": (C.c_int, []),
+    "vdk_debug_occupy_cus": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p]),
+    "vdk_gemm_debug_stamps": (C.c_int, [P]),
+    "vdk_attention_force_legacy": (C.c_int, [I32]),
+    "vdk_debug_reduce_rows_job": (C.c_int, [P, I64, I32, I64, P, F32, P]),
+}
+
+
 def bind(lib: C.CDLL) -> list[str]:
     bound = []
     for name, (res, args) in SIGNATURES.items():
@@ -270,6 +275,11 @@ def bind(lib: C.CDLL) -> list[str]:
         fn.restype = res
         fn.argtypes = args
         bound.append(name)
+    for name, (res, args) in INTERNAL.items():      # (knobs: bound when present)
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     return bound
 
 

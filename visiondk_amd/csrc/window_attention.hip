@@ -424,151 +424,6 @@ __device__ __forceinline__ void wa_put_ph(unsigned char* tile, const s16x8 (&f)[
     *(u32x2*)(tile + row * 64 + 32 * s + 16 + 8 * hi) = (u32x2){u[2], u[3]};
   }
 }
-// one 32-row half (t) of an output: staged rows -> tensor rows (16-byte stores, 4 lanes per row)
-__device__ __forceinline__ void wa_flush_half(const unsigned char* st, const long (&rr)[4], bf16_t* __restrict__ base, long ld, int lane, int t) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = 32 * t + 16 * i + (lane >> 2);
-    if (row < WA_N) *(u32x4*)(base + rr[2 * t + i] * ld + 8 * (lane & 3)) = *(const u32x4*)(st + row * WA_ST_PITCH + 16 * (lane & 3));
-  }
-}
-__device__ __forceinline__ void wa_stage_rows(unsigned char* st, const f32x16& x, float mul, int t, int l31, int hi) {      // rows >= 49 are not staged (the tile is 49 x 80 B)
-  if (32 * t + l31 < WA_N) wa_stage_t(st, x, mul, t, l31, hi);
-}
-__global__ __launch_bounds__(64 * WA_BW, 2) void window_attn_bwd2_mfma_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                                       long ldo, const float* __restrict__ lse, const float* __restrict__ bm, int nWm, long nwin, int H, float scale,
-                                                                       bf16_t* __restrict__ dqkv, long ldd, float* __restrict__ dbias_part, const int* __restrict__ rowidx) {
-  __shared__ __attribute__((aligned(16))) unsigned char Kt[WA_BW][64 * 64];
-  __shared__ __attribute__((aligned(16))) unsigned char Qt[WA_BW][64 * 64];
-  __shared__ __attribute__((aligned(16))) unsigned char Gt[WA_BW][64 * 64];     // dO rows
-  __shared__ __attribute__((aligned(16))) unsigned char Vs[WA_BW][64 * 64];     // V rows, then the output staging (49 x WA_ST_PITCH <= 4096)
-  __shared__ __attribute__((aligned(16))) unsigned char Ph[WA_BW][64 * 64];     // rowsum(dO * O) (first 256 B), then P / dS [64 q][32 keys of the current key tile]
-  static_assert(WA_N * WA_ST_PITCH <= 64 * 64, "the staging rows fit V's tile");
-  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int C = H * WA_HD;
-  const long wid = (long)blockIdx.x * WA_BW + w, nwave = (long)gridDim.x * WA_BW;
-  const int h = (int)(wid % H);
-  const long slot = wid / H, nslot = nwave / H;
-  float* Dl = (float*)Ph[w];
-  f32x16 dB[2][2];                                         // [kt][qt]
-#pragma unroll
-  for (int a = 0; a < 2; ++a) { dB[a][0] = as_zero16(); dB[a][1] = as_zero16(); }
-  for (long win = slot; win < nwin; win += nslot) {
-    const bf16_t* base = qkv + h * WA_HD;
-    long rr[4];
-    wa_rows(rowidx, win, lane, rr);
-    VDK_WAVE_LDS_SYNC();                                  // the previous window's readers are done
-    wa_dma_rows(Qt[w], base, ld, rr, lane);
-    wa_dma_rows(Kt[w], base + C, ld, rr, lane);
-    wa_dma_rows(Vs[w], base + 2 * C, ld, rr, lane);
-    wa_dma_rows(Gt[w], dout + h * WA_HD, ldo, rr, lane);
-    u32x4 orow[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) orow[i] = *(const u32x4*)(o + h * WA_HD + rr[i] * ldo + 8 * (lane & 3));
-    float l[2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) l[qt] = 32 * qt + l31 < WA_N ? lse[(win * H + h) * WA_N + 32 * qt + l31] : INFINITY;
-    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
-    VDK_WAVE_LDS_SYNC();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const s16x8 gq = *(const s16x8*)(Gt[w] + i * 1024 + lane * 16);
-      float d = wa_dot8(gq, *(const s16x8*)&orow[i]);
-      d += __shfl_xor(d, 1);
-      d += __shfl_xor(d, 2);
-      if ((lane & 3) == 0) Dl[16 * i + (lane >> 2)] = d;
-    }
-    s16x8 vf[2][2];                                      // V's row fragments stay in registers (its tile becomes the staging); Q / dO / K fragments are re-read per use
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) vf[t][ks] = *(const s16x8*)(Vs[w] + (32 * t + l31) * 64 + 32 * ks + 16 * hi);
-    VDK_WAVE_LDS_SYNC();
-    const float D[2] = {Dl[l31], Dl[32 + l31]};
-    VDK_WAVE_LDS_SYNC();                                  // D has been read: the tile takes P; V's fragments are in registers: its tile takes the outputs
-    const float* bmp = bm + ((win % nWm) * H + h) * WA_FRAG + lane * 16;
-    bf16_t* dbase = dqkv + h * WA_HD;
-    f32x16 dq[2] = {as_zero16(), as_zero16()};            // dQ^T[d][q], per query tile
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      __builtin_amdgcn_sched_barrier(0);                  // (keep the two key tiles' phases apart: hoisted loads of the second cost the registers the first needs)
-      s16x8 kf[2], dsf[2][2];                             // K row fragments of this key tile; dS^T as B fragments [qt][k-step]
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) kf[ks] = *(const s16x8*)(Kt[w] + (32 * kt + l31) * 64 + 32 * ks + 16 * hi);
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        __builtin_amdgcn_sched_barrier(0);
-        f32x16 sa = as_zero16(), dp = as_zero16();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-          sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], *(const s16x8*)(Qt[w] + (32 * qt + l31) * 64 + 32 * ks + 16 * hi), sa, 0, 0, 0);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][ks], *(const s16x8*)(Gt[w] + (32 * qt + l31) * 64 + 32 * ks + 16 * hi), dp, 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 b = *(const f32x4*)(bmp + (qt * 2 + kt) * 1024 + 4 * g);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * g + e;
-            const float p = fast_exp2((fmaf(sa[r], scale, b[e]) - l[qt]) * WA_LOG2E);
-            const float ds = p * (dp[r] - D[qt]);
-            dB[kt][qt][r] += ds;
-            sa[r] = p; dp[r] = ds;
-          }
-        }
-        s16x8 pfr[2];
-        as_pack_b(sa, pfr);
-        wa_put_ph(Ph[w], pfr, qt, l31, hi);
-        as_pack_b(dp, dsf[qt]);
-      }
-      VDK_WAVE_LDS_SYNC();
-      __builtin_amdgcn_sched_barrier(0);
-      // dV^T[d][key] = sum_q dO^T[d][q] P[q][key], keys of this tile
-      {
-        f32x16 acc = as_zero16();
-#pragma unroll
-        for (int qs = 0; qs < 4; ++qs) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_tr32(Gt[w], 16 * qs, lane), wa_tr32(Ph[w], 16 * qs, lane), acc, 0, 0, 0);
-        VDK_WAVE_LDS_SYNC();                              // P has been read (the tile takes dS); the previous flush has left the staging rows
-        wa_stage_rows(Vs[w], acc, 1.0f, kt, l31, hi);
-      }
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt) wa_put_ph(Ph[w], dsf[qt], qt, l31, hi);
-      VDK_WAVE_LDS_SYNC();
-      wa_flush_half(Vs[w], rr, dbase + 2 * C, ldd, lane, kt);
-      // dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
-      {
-        f32x16 acc = as_zero16();
-#pragma unroll
-        for (int qs = 0; qs < 4; ++qs) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_tr32(Qt[w], 16 * qs, lane), wa_tr32(Ph[w], 16 * qs, lane), acc, 0, 0, 0);
-        VDK_WAVE_LDS_SYNC();                              // dV's rows have left the staging tile; dS has been read
-        wa_stage_rows(Vs[w], acc, scale, kt, l31, hi);
-      }
-      // dQ^T[d][q] += sum over this tile's keys of K^T[d][key] dS^T[key][q]
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const s16x8 ktr = wa_tr32(Kt[w], 32 * kt + 16 * s2, lane);
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) dq[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktr, dsf[qt][s2], dq[qt], 0, 0, 0);
-      }
-      VDK_WAVE_LDS_SYNC();
-      wa_flush_half(Vs[w], rr, dbase + C, ldd, lane, kt);
-    }
-    VDK_WAVE_LDS_SYNC();                                  // dK's rows have left the staging tile
-    wa_stage_rows(Vs[w], dq[0], scale, 0, l31, hi);
-    wa_stage_rows(Vs[w], dq[1], scale, 1, l31, hi);
-    VDK_WAVE_LDS_SYNC();
-    wa_flush_rows(Vs[w], rr, dbase, ldd, lane);
-  }
-  float* dst = dbias_part + wid * WA_FRAG + lane * 16;
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) *(f32x4*)(dst + (qt * 2 + kt) * 1024 + 4 * g) = (f32x4){dB[kt][qt][4 * g], dB[kt][qt][4 * g + 1], dB[kt][qt][4 * g + 2], dB[kt][qt][4 * g + 3]};
-}
 
 // d(relative_position_bias_table)[r][h] = sum of d(bias)[h][pos] over the positions pos of the 49 x 49 map that read table entry r (uses[r][0..U), -1 = none), in list
 // order: a gather per output, no atomics (timm gathers the table with relative_position_index; its backward is an index_add)
@@ -609,11 +464,8 @@ static int wa_check(const void* qkv, int64_t ld, int64_t windows, int32_t H, int
   return VDK_OK;
 }
 static size_t wa_bm_bytes(int32_t nW, int32_t H) { return (size_t)(nW > 0 ? nW : 1) * H * WA_FRAG * 4; }
-// VDK_WA_BWD=2: the two-waves-per-SIMD form (A/B runs); default: the one-wave-per-SIMD form
-static bool wa_bwd_v1() { const char* e = getenv("VDK_WA_BWD"); return !(e && atoi(e) == 2); }
 #define WA_LAUNCH_BWD(OPF, GRID, ST, ...) do { if (OPF) hipLaunchKernelGGL(window_attn_bwd_mfma_kernel<VDK_OPF_F16>, GRID, dim3(64 * WA_BW), 0, ST, __VA_ARGS__); \
-                                               else if (wa_bwd_v1()) hipLaunchKernelGGL(window_attn_bwd_mfma_kernel<VDK_OPF_BF16>, GRID, dim3(64 * WA_BW), 0, ST, __VA_ARGS__); \
-                                               else hipLaunchKernelGGL(window_attn_bwd2_mfma_kernel, GRID, dim3(64 * WA_BW), 0, ST, __VA_ARGS__); } while (0)
+                                               else hipLaunchKernelGGL(window_attn_bwd_mfma_kernel<VDK_OPF_BF16>, GRID, dim3(64 * WA_BW), 0, ST, __VA_ARGS__); } while (0)
 static long wa_bwd_waves(int64_t windows, int32_t H) {
   long waves = 4096 / H * H; if (waves > windows * H) waves = windows * H; if (waves < H) waves = H;
   return (waves + WA_BW * H - 1) / (WA_BW * H) * (WA_BW * H);             // whole workgroups, whole head groups

@@ -634,13 +634,18 @@ class FaceTrainStep:
         return int(self.loss_state[2].item())
 
     def scaler_state_dict(self) -> dict:
-        """`scaler.state_dict()` as the reference checkpoints it (engine/vision_engine.py:296,397): torch.cuda.amp.GradScaler's keys"""
+        """`scaler.state_dict()` as the reference checkpoints it (engine/vision_engine.py:296,397): torch.cuda.amp.GradScaler's keys; {} without a scaler (bf16 / fp32
+        backbone), like a disabled GradScaler"""
+        if not self.amp:
+            return {}
         st = self.loss_state.tolist()
         return {"scale": st[0], "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor, "growth_interval": self.growth_interval,
                 "_growth_tracker": int(st[1])}
 
     def load_scaler_state_dict(self, sd: dict) -> None:
-        if not sd:
+        # (a bf16 / fp32 backbone has no scaler: a state carried over from an fp16 run or from a reference checkpoint -- scale 65536, vision_engine.py:296,397 -- is ignored,
+        #  as vit.FusedTrainStep and resnet.ResNetTrainStep do; written into loss_state it would make vdk_sgd_step_amp divide unscaled gradients by 65536)
+        if not sd or not self.amp:
             return
         self.growth_factor, self.backoff_factor, self.growth_interval = float(sd["growth_factor"]), float(sd["backoff_factor"]), int(sd["growth_interval"])
         self.loss_state[0] = float(sd["scale"]); self.loss_state[1] = float(sd.get("_growth_tracker", 0))
