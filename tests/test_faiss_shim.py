@@ -254,3 +254,52 @@ def test_reference_trainer_update_drives_the_hip_vit(emu):
     e = dict(ema.ema.named_parameters())
     n0 = "blocks.0.mlp.fc1.weight"
     assert not torch.equal(e[n0], got[n0].detach()) and (e[n0] - got[n0].detach()).abs().max() < 1e-2      # the deep-copied EMA model moved towards the weights
+
+
+TRAINER_GOLD = Path(__file__).resolve().parent / "golden" / "trainer_update_reference_run.npz"
+
+
+@pytest.mark.parametrize("operand", ["fp16", "bf16"])
+def test_committed_trainer_update_fixture(be, dev, operand):
+    """tests/golden/trainer_update_reference_run.npz (written by make_trainer_update_golden.py from the reference's own Trainer.update on the fp32 PyTorch-CPU path: three
+    steps of scaler.scale(loss).backward / unscale_ / clip / step / update / ema.update) against the HIP library's step on the same seeds -- on the emulator and, where
+    /root/reference does not exist, on the MI355X: the loss sequence and the final weights of every parameter.  fp16 operands (the reference's autocast dtype) with the
+    GradScaler protocol at the fixture's initial scale; bf16 beside it with its 8x coarser bounds."""
+    from oracle.vit_ref import VisionTransformerRef
+    from visiondk_amd import vit
+    z = np.load(TRAINER_GOLD)
+    c = {k[4:]: float(z[k]) for k in z.files if k.startswith("cfg_")}
+    img, patch, classes, dim, depth, heads, mlp = (int(c[k]) for k in ("img", "patch", "classes", "dim", "depth", "heads", "mlp"))
+    torch.manual_seed(int(c["seed_model"]))
+    ref = VisionTransformerRef(img, patch, 3, classes, dim, depth, heads, mlp)
+    start = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    model = vit.VisionTransformer(vit.VitSpec(img_size=img, patch_size=patch, num_classes=classes, dim=dim, depth=depth, heads=heads, mlp_dim=mlp), device=dev, backend=be, seed=0,
+                                  operand=operand)
+    model.load_state_dict(ref.state_dict())
+    step = vit.FusedTrainStep(model, lr=c["lr"], momentum=c["momentum"], weight_decay=c["weight_decay"], label_smoothing=c["label_smoothing"], max_norm=10.0, ema=True,
+                              init_scale=c["init_scale"])
+    g = torch.Generator(); g.manual_seed(int(c["seed_data"]))
+    losses = []
+    for _ in range(int(c["steps"])):
+        x = torch.randn(int(c["batch"]), 3, img, img, generator=g); y = torch.randint(0, classes, (int(c["batch"]),), generator=g)
+        step.step(x.to(dev), y.to(dev))
+        losses.append(step.loss_value())
+    ltol, utol = (3e-4, 5e-3) if operand == "fp16" else (3e-3, 5e-2)      # measured: losses 1.2e-5 / 1.9e-4, worst update 8.5e-4 / 6.4e-3
+    assert np.allclose(losses, z["losses"], rtol=ltol), (losses, z["losses"])
+    if operand == "fp16":
+        assert step.loss_scale() == float(z["scale_after"]) and step.skipped_steps() == 0
+    got = dict(model.named_parameters())
+    worst = (0.0, None)
+    for n, w0 in start.items():
+        want = torch.from_numpy(z["w:" + n])
+        upd_ref = want - w0
+        d = ((got[n].detach().cpu() - w0 - upd_ref).norm() / upd_ref.norm().clamp_min(1e-12)).item()
+        worst = max(worst, (d, n))
+        assert d < utol, (n, d)
+    print(operand, "losses", losses, "worst update error", worst)
+    n0 = "blocks.0.mlp.fc1.weight"
+    eng = model.engine
+    off, numel, shape = next((o, m, s) for (nm, o, m, s) in eng.entries if nm == n0)
+    e_ref = torch.from_numpy(z["ema:" + n0])
+    e = step.ema[off:off + numel].view(shape).cpu()
+    assert ((e - e_ref).norm() / (e_ref - start[n0]).norm().clamp_min(1e-12)).item() < max(utol, 2e-2)      # the EMA moved the same way (relative to its own movement)

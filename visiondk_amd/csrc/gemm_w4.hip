@@ -1046,6 +1046,8 @@ bool W4_SYM(vdk_gemm_w4_launch)(const GemmParams& p, bool trans, int E, unsigned
   //  VDK_GEMM_W4_SPLIT=1 restores the two-launch form; re-read per launch: A/B runs in one process)
   const bool split_on = getenv("VDK_GEMM_W4_SPLIT") && atoi(getenv("VDK_GEMM_W4_SPLIT")) == 1;
   const int split_min_k = getenv("VDK_GEMM_W4_SPLIT_K") ? atoi(getenv("VDK_GEMM_W4_SPLIT_K")) : 1536;
+  // (round 6, measured and removed: the rows beyond the whole rounds as a 3-way split-K launch of this kernel + a slab reduce / epilogue pass -- fc2 277.4 -> 273.2 / 282.0 us,
+  //  dfc1 245.2 -> 239.5 / 244.6, dqkv 165.6 -> 177.1 / 177.8, same box, two rounds: the two launch boundaries and 64 MB of slab traffic cost what the idle CUs gained)
   if (split_on && !trans && splitk == 1 && tiles > G && p.K >= split_min_k && E != E_GENERIC && !(E & (E_ROWGRP | E_MSTAT | E_MGRAD | E_SPLITK))) {
     const unsigned ntn = (unsigned)((p.N + 255) / 256), ntm = (unsigned)((p.M + 255) / 256);
     const unsigned rows1 = (tiles / G) * G / ntn;         // tile rows covered by whole rounds
