@@ -76,7 +76,10 @@ int vdk_cbir_search_fast(const float* Q, int64_t nq, const float* G, const void*
 /* vdk_cbir_search_fast generalised (csrc/cbir.hip): D <= 512 (face embeddings, timm_wrapper.py:33-47), fp16 gallery STORAGE (g_dtype VDK_F16: G holds half rows; faiss
  * GpuClonerOptions.useFloat16 at engine/cbir/evaluation.py:157-162), and schedule 1 = bootstrap + two stages with candidate lists of `cap` entries whose overflow is
  * REPORTED in *overflow_out (device u32) instead of being impossible by construction -- the caller repeats with schedule 0 if it is set.  Gb / gmax_bits from
- * vdk_cbir_prepare_gallery (Gb = bf16 [N, DP], DP = D rounded up to 128).  Workspace: vdk_cbir_fast2_workspace_bytes. */
+ * vdk_cbir_prepare_gallery (Gb = bf16 [N, DP], DP = D rounded up to 128).  Workspace: vdk_cbir_fast2_workspace_bytes.
+ * schedule >= 1024: stages of `schedule` rows with lists of `cap` entries (overflow reported).  schedule <= -1024: the same stages, ranked between the stages on the
+ * pre-filter's approximate scores (every row within the error band of the k-th best is kept; only the rows kept at the end are re-scored exactly: same results, a
+ * fifth of the gallery rows gathered); k <= 256; a band wider than the kernel's slots is reported through *overflow_out as well. */
 int vdk_cbir_fast2_workspace_bytes(int64_t nq, int32_t D, int32_t k, int64_t cap, size_t* bytes);
 int vdk_cbir_search_fast2(const float* Q, int64_t nq, const void* G, int32_t g_dtype, const void* Gb, const uint32_t* gmax_bits, int64_t N, int32_t D, int32_t k,
                           int64_t idx_base, float* out_scores, int64_t* out_idx, int64_t cap, int32_t schedule, uint32_t* overflow_out, void* ws, size_t ws_bytes,

@@ -437,6 +437,7 @@ static inline emu_s16x4 emu_ds_read_tr16_b64(const void* p) {
 #define __builtin_amdgcn_wave_barrier() emu::wave_barrier()
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_alignbit(hi_, lo_, sh_) ((unsigned)(((((unsigned long long)(unsigned)(hi_)) << 32) | (unsigned)(lo_)) >> ((sh_) & 31)))   /* v_alignbit_b32 */
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)

@@ -236,3 +236,26 @@ def test_small_candidate_lists_equal_guaranteed_schedule_and_fall_back_on_overfl
     sc, ic = c.search(q[:4], 10)
     assert c.fallbacks == 1
     np.testing.assert_array_equal(ic, np.tile(np.arange(10), (4, 1)))
+
+
+def test_approximate_ranking_keeps_the_error_band_and_falls_back_when_it_is_too_wide(be, dev):
+    """FlatIPIndex(approx_rank=True), the default: the stages rank on the pre-filter's approximate scores and keep every row within 2 eps of the k-th best; only the rows
+    kept at the end are re-scored.  Bit-equal to the exact schedules -- with a cluster of near-ties inside the band (kept: 300 rows), and with one wider than the kernel's
+    448 slots (600 rows: reported like a list overflow, the exact schedule repeats the search)."""
+    rng = np.random.default_rng(23)
+    g = ocbir.l2norm_rows(rng.standard_normal((20000, 128), dtype=np.float32)); q = ocbir.l2norm_rows(rng.standard_normal((9, 128), dtype=np.float32))
+    for cluster, fallbacks in ((300, 0), (600, 1)):
+        gg = g.copy()
+        base = q[0].copy()
+        for j in range(cluster):                      # near-ties for query 0: copies of the query itself, the last bits of a few coordinates moved
+            r = base.copy(); c = rng.integers(0, 128, 3)
+            r[c] = np.nextafter(r[c], np.float32(np.inf) * (1 if j % 2 else -1)).astype(np.float32)
+            gg[100 + 31 * j] = r
+        a = cbir.FlatIPIndex(128, backend=be, device=dev, cap=4096); a.add(gg)
+        b = cbir.FlatIPIndex(128, backend=be, device=dev, cap=4096, approx_rank=False); b.add(gg)
+        assert a.approx_rank and not b.approx_rank
+        sa, ia = a.search(q, 10); sb, ib = b.search(q, 10)
+        so, io = ocbir.flat_ip_search(q, gg, 10)
+        assert a.fallbacks == fallbacks and b.fallbacks == 0
+        np.testing.assert_array_equal(ia, io); np.testing.assert_array_equal(ib, io)
+        np.testing.assert_array_equal(sa.view(np.uint32), so.view(np.uint32)); np.testing.assert_array_equal(sb.view(np.uint32), so.view(np.uint32))

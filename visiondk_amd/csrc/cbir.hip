@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void cbir_rank_wave_kernel(const float* __rest
 //     the select kernel ranks them -> results are bit-identical to the exact scan, at bf16 MFMA speed.
 #define CF_BQ 512
 #define CF_BG 128
-#define CF_WE 768      // staged survivors per wave
+#define CF_WE 512      // staged survivors per wave
 
 // Qb / Gb rows: bf16 [rows, 128] (zero padded); norms3[row] = (||x||, ||bf16(x)||, ||bf16(x) - x||), each rounded up
 __global__ __launch_bounds__(256) void cbir_cast_rows_kernel(const float* __restrict__ x, long n, int D, int DP, bf16_t* __restrict__ xb, float* __restrict__ norms3) {
@@ -540,45 +540,67 @@ __device__ __forceinline__ float cbir_eps(const float* __restrict__ qn3, long q,
 // minus eps_q, is a lower bound of the exact k-th best score (k distinct rows reach it), i.e. a valid filter threshold before
 // any row is ranked: the scan starts with a tight cut instead of a pass-everything ramp (cbir_boot_thr_kernel).
 // survivors of one 32 x 32 accumulator block (lane = query QL of the wave, register r = row ROWB + (r & 3) + 8 (r >> 2) + 4 hi) -> the wave's staging arrays.
-// Only lanes that own a survivor build their row mask; slots are handed out lane by lane through SGPRs (v_readlane of each owner's count): no atomics,
-// no LDS round trip on the wave's critical path.  LAST: the tile may reach past r_end (rows there are clamped copies).
+// `m` = the lane's maximum over the block (the cheap reject that precedes this).  Only lanes that own a survivor build their row mask; slots are handed out lane by
+// lane through SGPRs (v_readlane of each owner's count): no atomics, no LDS round trip on the wave's critical path.  A survivor travels with its approximate score
+// (the approximate-ranking schedule ranks on it): an owner's only survivor -- the usual case -- IS its maximum `m`; the value of any other one comes from a
+// select chain over the 16 registers (a lane-dependent register index has no cheaper form).  LAST: the tile may reach past r_end (rows there are clamped copies).
+// (round 6, measured and dropped: one v_cmp per register into scalar masks, OR-ed on the scalar unit, with the emission under per-register scalar branches -- the
+//  score then has a static register index -- was 0.5 ms SLOWER per search: the taken branches of the survivor path cost more than the per-lane masks here.)
+#define CF_EMIT_OWNED(ACC, PM, POS, QL, ROWB)                                                                                                      \
+  do {                                                                                                                                            \
+    unsigned mm_ = (PM);                                                                                                                          \
+    const bool single_ = (mm_ & (mm_ - 1u)) == 0u;                                                                                                 \
+    while (mm_) {                                                                                                                                 \
+      const int r = 15 - (__ffs(mm_) - 1);      /* CF_ROWBIT */                                                                                   \
+      mm_ &= mm_ - 1;                                                                                                                             \
+      float v_ = m;                                                                                                                               \
+      if (!single_) { v_ = (ACC)[0]; _Pragma("unroll") for (int j_ = 1; j_ < 16; ++j_) v_ = r == j_ ? (ACC)[j_] : v_; }                             \
+      e_idx[w][POS] = (int)(idx_base + (ROWB) + (r & 3) + 8 * (r >> 2) + 4 * hi);                                                                  \
+      e_score[w][POS] = v_;                                                                                                                       \
+      e_q[w][POS] = (unsigned char)(QL);                                                                                                          \
+      ++(POS);                                                                                                                                    \
+    }                                                                                                                                             \
+  } while (0)
+// row mask of a lane: bit 15 - r <-> register r.  cut - acc is negative exactly when acc > cut (no difference of distinct floats rounds to +0), so one subtraction
+// and one funnel shift (v_alignbit: pm = pm << 1 | sign) per register, against compare + select + or
+#define CF_ROWBIT(r) (15 - (r))
 #define CF_STAGE(ACC, CUTV, QL, ROWB, LAST)                                                                                                       \
   do {                                                                                                                                            \
-    const bool own_ = m > (CUTV);                                                                                                                 \
     unsigned pm = 0;                                                                                                                              \
-    if (own_) {                                                                                                                                   \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) pm |= (unsigned)((ACC)[r] > (CUTV)) << r;                                                     \
-      if (LAST) {                                                                                                                                 \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                                            \
-          if ((ROWB) + (r & 3) + 8 * (r >> 2) + 4 * hi >= r_end) pm &= ~(1u << r);                                                                 \
-      }                                                                                                                                           \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) pm = __builtin_amdgcn_alignbit(pm, __float_as_uint((CUTV) - (ACC)[r]), 31);                     \
+    pm &= 0xffffu;                                                                                                                                \
+    if (LAST) {                                                                                                                                   \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                                              \
+        if ((ROWB) + (r & 3) + 8 * (r >> 2) + 4 * hi >= r_end) pm &= ~(1u << CF_ROWBIT(r));                                                        \
     }                                                                                                                                             \
     const unsigned c = (unsigned)__popc(pm);                                                                                                      \
-    unsigned long long bl = __ballot(c != 0);                                                                                                     \
-    unsigned pos = 0;   /* worst case 64 lanes x 16 rows = 1024 > CF_WE: a flush may be needed between two owners */                              \
-    for (unsigned long long b = bl; b; b &= b - 1) {                                                                                              \
-      const int L = __ffsll(b) - 1;                                                                                                               \
-      const unsigned cL = (unsigned)VDK_READLANE(c, L);                                                                                           \
-      if (wcnt + cL > CF_WE) {   /* stage what was granted so far, then flush (uniform branch) */                                                 \
-        if (c && (bl & ~b & (1ull << lane))) {                                                                                                    \
-          unsigned pp = pos, mm = pm;                                                                                                             \
-          while (mm) { const int r = __ffs(mm) - 1; mm &= mm - 1; e_idx[w][pp] = (int)(idx_base + (ROWB) + (r & 3) + 8 * (r >> 2) + 4 * hi); e_q[w][pp] = (unsigned char)(QL); ++pp; } \
-        }                                                                                                                                         \
-        bl = b;   /* owners before L are done */                                                                                                  \
-        CF_FLUSH();                                                                                                                               \
-      }                                                                                                                                           \
-      if (lane == L) pos = wcnt;                                                                                                                  \
-      wcnt += cL;                                                                                                                                 \
+    /* slots: exclusive prefix sum of the lanes' counts (<= 16: five bit planes, a ballot and a masked popcount each) */                           \
+    unsigned pre_ = 0, tot_ = 0;                                                                                                                  \
+    _Pragma("unroll") for (int b_ = 0; b_ < 5; ++b_) {                                                                                             \
+      const unsigned long long pl_ = __ballot((c >> b_) & 1u);                                                                                    \
+      pre_ += (unsigned)__popcll(pl_ & lane_lt) << b_;                                                                                            \
+      tot_ += (unsigned)__popcll(pl_) << b_;                                                                                                      \
     }                                                                                                                                             \
-    if (c && (bl & (1ull << lane))) {                                                                                                             \
-      unsigned mm = pm;                                                                                                                           \
-      while (mm) {                                                                                                                                \
-        const int r = __ffs(mm) - 1;                                                                                                              \
-        mm &= mm - 1;                                                                                                                             \
-        e_idx[w][pos] = (int)(idx_base + (ROWB) + (r & 3) + 8 * (r >> 2) + 4 * hi);                                                                \
-        e_q[w][pos] = (unsigned char)(QL);                                                                                                        \
-        ++pos;                                                                                                                                    \
+    if (wcnt + tot_ > CF_WE) { CF_FLUSH(); }                                                                                                       \
+    if (tot_ <= CF_WE) {                                                                                                                          \
+      unsigned pos = wcnt + pre_;                                                                                                                 \
+      if (c) CF_EMIT_OWNED(ACC, pm, pos, QL, ROWB);                                                                                               \
+      wcnt += tot_;                                                                                                                               \
+    } else {   /* more survivors in one block than the staging holds (a pass-everything stage): lane by lane, flushing in between */              \
+      unsigned long long bl = __ballot(c != 0);                                                                                                   \
+      unsigned pos = 0;                                                                                                                           \
+      for (unsigned long long b = bl; b; b &= b - 1) {                                                                                            \
+        const int L = __ffsll(b) - 1;                                                                                                             \
+        const unsigned cL = (unsigned)VDK_READLANE(c, L);                                                                                         \
+        if (wcnt + cL > CF_WE) {   /* stage what was granted so far, then flush (uniform branch) */                                               \
+          if (c && (bl & ~b & (1ull << lane))) { unsigned pp = pos; CF_EMIT_OWNED(ACC, pm, pp, QL, ROWB); }                                        \
+          bl = b;   /* owners before L are done */                                                                                                \
+          CF_FLUSH();                                                                                                                             \
+        }                                                                                                                                         \
+        if (lane == L) pos = wcnt;                                                                                                                \
+        wcnt += cL;                                                                                                                               \
       }                                                                                                                                           \
+      if (c && (bl & (1ull << lane))) CF_EMIT_OWNED(ACC, pm, pos, QL, ROWB);                                                                       \
     }                                                                                                                                             \
   } while (0)
 #define CF_NBUF 3
@@ -586,10 +608,11 @@ template <bool BOOT>
 __global__ __launch_bounds__(512) void cbir_prefilter_kernel(const bf16_t* __restrict__ Qb, const float* __restrict__ qnorm, long nq,
                                                              const bf16_t* __restrict__ Gb, const unsigned* __restrict__ gmax_bits, long g_begin,
                                                              long g_end, long rows_per_split, int nsplit, long idx_base,
-                                                             const float* __restrict__ thr, CbirCand cand, float* __restrict__ gm, long gm_ld) {
+                                                             const float* __restrict__ thr, CbirCand cand, float* __restrict__ gm, long gm_ld, int phased) {
   __shared__ __attribute__((aligned(16))) unsigned char Gs[CF_NBUF * CF_BG * 256];   // 3 x 32 KB
   // survivors are staged per WAVE (no shared counter, no workgroup barrier): slots come from ballots, flushes are wave-local
   __shared__ int e_idx[8][CF_WE];
+  __shared__ float e_score[8][CF_WE];          // the approximate score s' of the survivor (the approximate-ranking schedule ranks on it; the exact schedules ignore it)
   __shared__ unsigned short e_rank[8][CF_WE];
   __shared__ unsigned char e_q[8][CF_WE];
   __shared__ unsigned f_cnt[8][64], f_base[8][64];
@@ -629,17 +652,18 @@ __global__ __launch_bounds__(512) void cbir_prefilter_kernel(const bf16_t* __res
   do {                                                                                                                    \
     f_cnt[w][lane] = 0;                                                                                                   \
     VDK_WAVE_LDS_SYNC();                                                                                                  \
-    for (unsigned i_ = lane; i_ < wcnt; i_ += 64) e_rank[w][i_] = (unsigned short)atomicAdd(&f_cnt[w][e_q[w][i_]], 1u);      \
+    const unsigned ns_ = wcnt < CF_WE ? wcnt : CF_WE;   /* (entries beyond the staging went straight to the lists) */      \
+    for (unsigned i_ = lane; i_ < ns_; i_ += 64) e_rank[w][i_] = (unsigned short)atomicAdd(&f_cnt[w][e_q[w][i_]], 1u);       \
     VDK_WAVE_LDS_SYNC();                                                                                                  \
     {                                                                                                                     \
       const unsigned c_ = f_cnt[w][lane];                                                                                 \
       f_base[w][lane] = c_ ? atomicAdd(&cand.cnt[qw0 + lane], c_) : 0u;                                                     \
     }                                                                                                                     \
     VDK_WAVE_LDS_SYNC();                                                                                                  \
-    for (unsigned i_ = lane; i_ < wcnt; i_ += 64) {                                                                       \
+    for (unsigned i_ = lane; i_ < ns_; i_ += 64) {                                                                        \
       const unsigned ql_ = e_q[w][i_];                                                                                    \
       const long pos_ = (long)f_base[w][ql_] + e_rank[w][i_];                                                             \
-      if (pos_ < cand.cap) cand.idx[(qw0 + ql_) * cand.cap + pos_] = e_idx[w][i_];                                        \
+      if (pos_ < cand.cap) { cand.idx[(qw0 + ql_) * cand.cap + pos_] = e_idx[w][i_]; cand.score[(qw0 + ql_) * cand.cap + pos_] = e_score[w][i_]; } \
       else atomicOr(cand.overflow, 1u);                                                                                   \
     }                                                                                                                     \
     VDK_WAVE_LDS_SYNC();                                                                                                  \
@@ -659,73 +683,88 @@ __global__ __launch_bounds__(512) void cbir_prefilter_kernel(const bf16_t* __res
       __builtin_amdgcn_global_load_lds(VDK_GLOBAL_PTR(src), VDK_LDS_PTR(dst), 16, 0, 0);                                   \
     }                                                                                                                     \
   } while (0)
+  // A fragments run two k-steps ahead of the MFMAs that consume them (hipcc alone emits read -> wait -> 4 MFMAs per k-step, exposing the LDS latency 16 times per
+  // tile); the first two of the second half are fetched during the first half's last k-steps.
+#define CF_ALD(hh, ks, rt) (*(const s16x8*)(Gt + ((hh) * 64 + (rt) * 32 + l31) * 256 + ((((ks) * 2 + hi) ^ (l31 & 15)) * 16)))
+  // the 32 MFMAs of one 64-row half of the tile at Gt: ACC[row block][query block] = rows x this wave's 64 queries
+#define CF_MFMA_HALF(H, ACC)                                                                                              \
+  do {                                                                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                                     \
+      const int step = (H) * 8 + ks;           /* 0..15 over the tile */                                                  \
+      if (step + 2 < 16) {                                                                                                \
+        const int nh = (step + 2) >> 3, nks = (step + 2) & 7;                                                             \
+        af[(step + 2) % 3][0] = CF_ALD(nh, nks, 0);                                                                       \
+        af[(step + 2) % 3][1] = CF_ALD(nh, nks, 1);                                                                       \
+      }                                                                                                                   \
+      __builtin_amdgcn_sched_barrier(0);   /* keep the reads up here: the scheduler otherwise sinks them next to their use */ \
+      _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                                                     \
+        _Pragma("unroll") for (int qt = 0; qt < 2; ++qt)   /* (the first k-step starts from the zero block: no 64 v_mov per half) */ \
+          (ACC)[rt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[step % 3][rt], qf[qt][ks], ks == 0 ? zero16 : (ACC)[rt][qt], 0, 0, 0);   \
+      __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    }                                                                                                                     \
+  } while (0)
+  // the filter of one half (tile TT, half H): per 32 x 32 block the lane's maximum against its cut -- a cheap reject; the survivors' slow path is rare after the first stages
+#define CF_FILTER_HALF(H, ACC, TT, LASTT)                                                                                 \
+  do {                                                                                                                    \
+    const long row0_ = r_begin + (TT) * CF_BG + (H) * 64;                                                                  \
+    _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                                                       \
+      _Pragma("unroll") for (int qt = 0; qt < 2; ++qt) {                                                                   \
+        if (BOOT) {                                                                                                       \
+          float m = (ACC)[rt][qt][0];                                                                                     \
+          _Pragma("unroll") for (int r = 1; r < 16; ++r) m = fmaxf(m, (ACC)[rt][qt][r]);                                   \
+          bm[qt] = fmaxf(bm[qt], m);   /* rows past r_end are copies of row r_end - 1 (clamped DMA): the maximum is unaffected */ \
+          if ((H) == 1 && rt == 1) {   /* tile complete: one group maximum per (query, 128-row tile) */                    \
+            const float tm = fmaxf(bm[qt], __shfl_xor(bm[qt], 32));                                                       \
+            const long q = q0 + w * 64 + qt * 32 + l31;                                                                   \
+            if (hi == 0 && q < nq) gm[q * gm_ld + (r_begin - g_begin) / CF_BG + (TT)] = tm;                                \
+            bm[qt] = __uint_as_float(0xff800000u);                                                                        \
+          }                                                                                                               \
+        } else {                                                                                                          \
+          float m = (ACC)[rt][qt][0];                                                                                     \
+          _Pragma("unroll") for (int r = 1; r < 16; ++r) m = fmaxf(m, (ACC)[rt][qt][r]);                                   \
+          if (__any(m > cut[qt])) CF_STAGE((ACC)[rt][qt], cut[qt], qt * 32 + l31, row0_ + rt * 32, (LASTT));               \
+        }                                                                                                                 \
+      }                                                                                                                   \
+  } while (0)
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   CF_ISSUE(0, 0);
   if (ntile > 1) CF_ISSUE(1, 1);
   if (ntile > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | 4); else __builtin_amdgcn_s_waitcnt(0x0F70);   // tile 0 landed
   __syncthreads();
   int cur = 0;
+  // Two waves share a SIMD (wave w and w + 4) and one matrix pipe.  Left in step by the tile barrier, both multiply (contending for the pipe) and then both filter
+  // (the pipe idle).  With `phased` the second group passes the tile barrier BEFORE its second filter instead of after it: the program order is the same
+  // (M(h0) F(h0) M(h1) F(h1), the filter works on registers only), but the group then runs half a tile behind in role --
+  //     group A:  M(h0)  F(h0)  M(h1)  F(h1) | barrier        group B:  F(prev h1)  M(h0)  F(h0)  M(h1) | barrier
+  // so in every slot one wave of a SIMD owns the matrix pipe and the other the vector ALU.
+  const bool grp_b = !BOOT && phased && w >= 4;
+  f32x16 acc[2][2];
   for (long t = 0; t < ntile; ++t) {
     // ring slot (cur + 2) % 3 was consumed during iteration t - 1 (everybody passed the barrier that ended it)
     int nxt2 = cur + 2; if (nxt2 >= CF_NBUF) nxt2 -= CF_NBUF;
     if (t + 2 < ntile) CF_ISSUE(nxt2, t + 2);
     const unsigned char* Gt = Gs + cur * (CF_BG * 256);
-    // A fragments run two k-steps ahead of the MFMAs that consume them (hipcc alone emits read -> wait -> 4 MFMAs per k-step,
-    // exposing the LDS latency 16 times per tile); the first two of the second half are fetched before the first half's filter
-#define CF_ALD(hh, ks, rt) (*(const s16x8*)(Gt + ((hh) * 64 + (rt) * 32 + l31) * 256 + ((((ks) * 2 + hi) ^ (l31 & 15)) * 16)))
     s16x8 af[3][2];
     af[0][0] = CF_ALD(0, 0, 0); af[0][1] = CF_ALD(0, 0, 1);
     af[1][0] = CF_ALD(0, 1, 0); af[1][1] = CF_ALD(0, 1, 1);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      f32x16 acc[2][2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const int step = h * 8 + ks;           // 0..15 over the tile
-        if (step + 2 < 16) {
-          const int nh = (step + 2) >> 3, nks = (step + 2) & 7;
-          af[(step + 2) % 3][0] = CF_ALD(nh, nks, 0);
-          af[(step + 2) % 3][1] = CF_ALD(nh, nks, 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep the reads up here: the scheduler otherwise sinks them next to their use
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-          for (int qt = 0; qt < 2; ++qt) acc[rt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[step % 3][rt], qf[qt][ks], acc[rt][qt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // cheap reject: per 32x32 block the lane's maximum against its cut; the survivors' slow path is rare after the first stages
-      const long row0 = r_begin + t * CF_BG + h * 64;
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-          float m = acc[rt][qt][0];
-#pragma unroll
-          for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rt][qt][r]);
-          if (BOOT) {
-            bm[qt] = fmaxf(bm[qt], m);   // rows past r_end are copies of row r_end - 1 (clamped DMA): the maximum is unaffected
-            if (h == 1 && rt == 1) {     // tile complete: one group maximum per (query, 128-row tile)
-              const float tm = fmaxf(bm[qt], __shfl_xor(bm[qt], 32));
-              const long q = q0 + w * 64 + qt * 32 + l31;
-              if (hi == 0 && q < nq) gm[q * gm_ld + (r_begin - g_begin) / CF_BG + t] = tm;
-              bm[qt] = __uint_as_float(0xff800000u);
-            }
-          } else if (__any(m > cut[qt])) {
-            CF_STAGE(acc[rt][qt], cut[qt], qt * 32 + l31, row0 + rt * 32, t == ntile - 1);
-          }
-        }
-        }
+    CF_MFMA_HALF(0, acc);
+    CF_FILTER_HALF(0, acc, t, t == ntile - 1);
+    CF_MFMA_HALF(1, acc);
     // tile t + 1 must have landed: only tile t + 2's four DMAs may still be in flight
-    if (t + 2 < ntile) __builtin_amdgcn_s_waitcnt(0x0F70 | 4); else __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
+    if (grp_b) {
+      if (t + 2 < ntile) __builtin_amdgcn_s_waitcnt(0x0F70 | 4); else __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+    }
+    CF_FILTER_HALF(1, acc, t, t == ntile - 1);
+    if (!grp_b) {
+      if (t + 2 < ntile) __builtin_amdgcn_s_waitcnt(0x0F70 | 4); else __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+    }
     cur = cur + 1 == CF_NBUF ? 0 : cur + 1;
   }
+#undef CF_MFMA_HALF
+#undef CF_FILTER_HALF
+#undef CF_ALD
 #undef CF_ISSUE
   if (!BOOT && wcnt) { CF_FLUSH(); }
 }
@@ -744,12 +783,14 @@ __global__ __launch_bounds__(512) void cbir_prefilter_wide_kernel(const bf16_t* 
   constexpr int TILEB = 32 * RB;        // one ring slot
   __shared__ __attribute__((aligned(16))) unsigned char Gs[CF_NBUF * TILEB];
   __shared__ int e_idx[8][CF_WE];
+  __shared__ float e_score[8][CF_WE];          // the approximate score s' of the survivor (the approximate-ranking schedule ranks on it; the exact schedules ignore it)
   __shared__ unsigned short e_rank[8][CF_WE];
   __shared__ unsigned char e_q[8][CF_WE];
   __shared__ unsigned f_cnt[8][64], f_base[8][64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
+  const unsigned long long lane_lt = (1ull << lane) - 1ull;
   unsigned wcnt = 0;
   const int split = blockIdx.x % nsplit;
   const long q0 = (long)(blockIdx.x / nsplit) * 256;
@@ -804,10 +845,10 @@ __global__ __launch_bounds__(512) void cbir_prefilter_wide_kernel(const bf16_t* 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = acc0[r] + acc1[r];
+    const long row0 = r_begin + t * 32;
     float m = acc[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-    const long row0 = r_begin + t * 32;
     if (BOOT) {
       const float tm = fmaxf(m, __shfl_xor(m, 32));
       if (hi == 0 && ok) gm[q * gm_ld + (r_begin - g_begin) / 32 + t] = tm;
@@ -823,6 +864,138 @@ __global__ __launch_bounds__(512) void cbir_prefilter_wide_kernel(const bf16_t* 
 }
 #undef CF_FLUSH
 #undef CF_STAGE
+#undef CF_EMIT_OWNED
+#undef CF_ROWBIT
+
+// ---- approximate ranking between the stages (rank_mode 1 of vdk_cbir_search_fast2: schedule <= -1024) ---------------------------------------------------------------
+// The exact schedules re-score every survivor of every stage with the fp32 fmaf chain: ~650 gathered gallery rows per query over a 10^6-row scan, 3.3 of the 4.6 GB a
+// search moved (PMC, round 4/5).  Here a stage's survivors are ranked on the approximate score s' the pre-filter already holds (|s' - s| <= eps_q):
+//   * k rows with s' >= kth(s') each have s >= kth(s') - eps, so L = kth(s') - eps is a lower bound of the exact k-th best score: thr[q] = L, and the next stage's
+//     filter s' > thr - eps is the same test the exact schedules apply;
+//   * a row can only belong to the exact top-k if s >= L, i.e. s' >= kth(s') - 2 eps: every such row is KEPT between the stages (k + a band of a few dozen rows on
+//     continuous data), nothing else is;
+//   * only the rows kept at the END get the exact fmaf chain (~130 per query instead of ~650 over the scan), are sorted on (exact score desc, index asc)
+//     and the first k leave: the kept set contains the exact top-k, so the output is bit-identical to the exact schedules'.
+// More than CA_KEEP rows inside the band (masses of near-duplicates) raises the overflow flag: the caller repeats with an exact schedule.  k <= 256.
+// Between the stages nothing is sorted: a wave holds a query's entries in registers (8 per lane), finds the k-th largest s' by a most-significant-bit-first
+// selection on the ordered bit patterns (32 steps of "how many keys >= prefix | bit": compares into scalar masks, popcounts on the scalar unit), keeps what is inside
+// the band and writes it back compacted -- no LDS, ~2 us per query, 32 waves per CU.  Only the last stage sorts (exact keys, wave-synchronous bitonic steps in LDS).
+#define CA_SLOTS 512     // entries a wave ranks per pass (kept + new; longer lists take more passes)
+#define CA_KEEP 448      // kept entries per query between the stages
+// the largest v with |{keys >= v}| >= k (keys: 8 per lane, 0 = empty slot); k >= 1
+__device__ __forceinline__ unsigned cbir_wave_kth(const unsigned (&key)[CA_SLOTS / 64], unsigned k) {
+  unsigned prefix = 0u;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned c = prefix | (1u << bit);
+    unsigned cnt = 0;
+#pragma unroll
+    for (int j = 0; j < CA_SLOTS / 64; ++j) cnt += (unsigned)__popcll(__ballot(key[j] >= c));
+    if (cnt >= k) prefix = c;
+  }
+  return prefix;
+}
+template <bool FINAL>
+__global__ __launch_bounds__(256) void cbir_rank_approx_kernel(const float* __restrict__ Q, const float* __restrict__ G, int D, long idx_base, CbirCand cand, long nq, int k,
+                                                               float* __restrict__ thr, float* __restrict__ out_score, long long* __restrict__ out_idx,
+                                                               unsigned* __restrict__ carry, int g_half, const float* __restrict__ qnorm,
+                                                               const unsigned* __restrict__ gmax_bits) {
+  __shared__ unsigned long long keys_all[FINAL ? 4 : 1][FINAL ? CA_SLOTS : 1];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long q = (long)blockIdx.x * 4 + w;
+  if (q >= nq) return;   // wave-uniform
+  const unsigned long long lane_lt = (1ull << lane) - 1ull;
+  unsigned n_all = cand.cnt[q];
+  if ((long)n_all > cand.cap) n_all = (unsigned)cand.cap;      // (the pre-filter has raised the overflow flag)
+  float* cs = cand.score + q * cand.cap;
+  int* ci = cand.idx + q * cand.cap;
+  const float eps = cbir_eps(qnorm, q, gmax_bits);
+  float kth = __uint_as_float(0xff800000u);
+  unsigned have = 0, consumed = 0;
+  bool over = false;
+  float sc[CA_SLOTS / 64];
+  int gi[CA_SLOTS / 64];
+  bool keep[CA_SLOTS / 64];
+  // entries [0, carry) are the rows kept by the previous stage, the rest this stage's survivors: all carry s' and are ranked alike.  A pass takes the kept rows
+  // (slots [0, have)) and as many unread ones as fit; one pass in practice.
+  do {
+    unsigned take = n_all - consumed;
+    if (take > CA_SLOTS - have) take = CA_SLOTS - have;
+    const unsigned n = have + take;
+    unsigned key[CA_SLOTS / 64];
+#pragma unroll
+    for (int j = 0; j < CA_SLOTS / 64; ++j) {
+      const unsigned e = lane + 64u * j;                        // logical entry: kept ones first
+      key[j] = 0u; sc[j] = 0.f; gi[j] = 0; keep[j] = e < n;
+      if (e < n) {
+        const unsigned slot = e < have ? e : consumed + (e - have);
+        sc[j] = cs[slot]; gi[j] = ci[slot];
+        key[j] = f2ord(sc[j]) | 1u;                             // (never 0: an empty slot's key; the last bit of the order is irrelevant inside a 2 eps band)
+      }
+    }
+    consumed += take;
+    have = n;
+    if (n >= (unsigned)k) {
+      kth = fmaxf(kth, ord2f(cbir_wave_kth(key, (unsigned)k) & ~1u));      // (bit 0 cleared: never above the true k-th best)
+      const float bound = kth - 2.0f * eps;
+      unsigned base = 0;
+#pragma unroll
+      for (int j = 0; j < CA_SLOTS / 64; ++j) {
+        keep[j] = keep[j] && !(sc[j] < bound);
+        const unsigned long long mk = __ballot(keep[j]);
+        const unsigned pos = base + (unsigned)__popcll(mk & lane_lt);
+        if (keep[j] && pos >= CA_KEEP) { keep[j] = false; over = true; }
+        if (keep[j] && (!FINAL || consumed < n_all)) { cs[pos] = sc[j]; ci[pos] = gi[j]; }      // compacted to the front (every slot read above is in registers)
+        base += (unsigned)__popcll(mk);
+      }
+      over = __any(over);
+      have = base > CA_KEEP ? CA_KEEP : base;
+    }
+  } while (consumed < n_all);
+  if (over && lane == 0) atomicOr(cand.overflow, 1u);
+  if (!FINAL) {
+    if (lane == 0) {
+      carry[q] = have;
+      cand.cnt[q] = have;
+      if (have >= (unsigned)k) thr[q] = fmaxf(thr[q], kth - eps);
+    }
+    return;
+  }
+  // the end of the scan: exact scores of the kept rows (the oracle's k-ordered fmaf chain), exact order, first k out
+  unsigned long long* K = keys_all[w];
+  const float* qrow = Q + q * (long)D;
+  unsigned base = 0;
+#pragma unroll
+  for (int j = 0; j < CA_SLOTS / 64; ++j) {
+    const unsigned long long mk = __ballot(keep[j]);
+    if (keep[j]) K[base + (unsigned)__popcll(mk & lane_lt)] = cbir_key(cbir_exact_ip_any(qrow, G, (long)gi[j] - idx_base, D, g_half), gi[j]);
+    base += (unsigned)__popcll(mk);
+  }
+  have = base;
+  unsigned sortn = 64; while (sortn < have) sortn <<= 1;
+  for (unsigned i = have + lane; i < sortn; i += 64) K[i] = ~0ull;
+  VDK_WAVE_LDS_SYNC();
+  for (unsigned size = 2; size <= sortn; size <<= 1)
+    for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+      for (unsigned p = lane; p < (sortn >> 1); p += 64) {
+        const unsigned lo = ((p / stride) * 2 * stride) + (p % stride), hi2 = lo + stride;
+        const bool asc = ((lo & size) == 0);
+        const unsigned long long a = K[lo], b = K[hi2];
+        if ((a > b) == asc) { K[lo] = b; K[hi2] = a; }
+      }
+      VDK_WAVE_LDS_SYNC();
+    }
+  for (int i = lane; i < k; i += 64) {
+    if ((unsigned)i < have) {
+      const unsigned long long key = K[i];
+      out_score[q * k + i] = ord2f(~(unsigned)(key >> 32));
+      out_idx[q * k + i] = (long long)(int)(unsigned)(key & 0xffffffffu);
+    } else {
+      out_score[q * k + i] = -3.4028234663852886e38f;
+      out_idx[q * k + i] = -1;
+    }
+  }
+}
 
 // thr[q] = (k-th largest of the G group maxima) - eps_q (see BOOT above).  One workgroup per query, bitonic sort in LDS.
 #define CF_BOOT_MAXG 4096
@@ -845,6 +1018,27 @@ __global__ __launch_bounds__(256) void cbir_boot_thr_kernel(const float* __restr
       __syncthreads();
     }
   if (tid == 0) thr[q] = ord2f(~keys[k - 1]) - cbir_eps(qnorm, q, gmax_bits);
+}
+
+// the same threshold for G <= 1024 group maxima (k <= 256 and the default sample of 4 k tiles): a wave per query, the maxima in registers, the k-th largest by the
+// bitwise selection of cbir_rank_approx_kernel -- no sort, no LDS, no workgroup barrier (the sorting kernel above: 67-88 us at 10 k queries)
+__global__ __launch_bounds__(256) void cbir_boot_thr_wave_kernel(const float* __restrict__ gm, int G, int k, const float* __restrict__ qnorm,
+                                                                 const unsigned* __restrict__ gmax_bits, float* __restrict__ thr, long nq) {
+  const int lane = threadIdx.x & 63;
+  const long q = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= nq) return;   // wave-uniform
+  unsigned key[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { const int i = lane + 64 * j; key[j] = i < G ? f2ord(gm[q * G + i]) : 0u; }
+  unsigned prefix = 0u;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned c = prefix | (1u << bit);
+    unsigned cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cnt += (unsigned)__popcll(__ballot(key[j] >= c));
+    if (cnt >= (unsigned)k) prefix = c;
+  }
+  if (lane == 0) thr[q] = ord2f(prefix) - cbir_eps(qnorm, q, gmax_bits);
 }
 
 // exact scores of the new candidates of every query: entries [carry[q], cnt[q]) of its list.  One workgroup per query; one
@@ -924,11 +1118,13 @@ __global__ void cbir_arm_kernel(unsigned* __restrict__ cnt_a, unsigned* __restri
   if (i < nq) { cnt_a[i] = reserve; cnt_b[i] = reserve; }
 }
 
+// wave groups of the D <= 128 pre-filter in opposite roles (see the kernel); VDK_CBIR_PHASED=0 restores the in-step form (A/B)
+static int cb_phased() { static const int v = [] { const char* e = getenv("VDK_CBIR_PHASED"); return (e && e[0] == '0') ? 0 : 1; }(); return v; }
 template <bool BOOT>
 static void cb_launch_prefilter(hipStream_t stream, int DP, unsigned grid, const bf16_t* Qb, const float* qnorm, long nq, const bf16_t* Gb, const unsigned* gmax_bits, long begin,
                                 long end, long rps, int nsplit, long idx_base, const float* thr, const CbirCand& cand, float* gm, long gm_ld) {
   switch (DP) {
-    case 128: hipLaunchKernelGGL(cbir_prefilter_kernel<BOOT>, dim3(grid), dim3(512), 0, stream, Qb, qnorm, nq, Gb, gmax_bits, begin, end, rps, nsplit, idx_base, thr, cand, gm, gm_ld); break;
+    case 128: hipLaunchKernelGGL(cbir_prefilter_kernel<BOOT>, dim3(grid), dim3(512), 0, stream, Qb, qnorm, nq, Gb, gmax_bits, begin, end, rps, nsplit, idx_base, thr, cand, gm, gm_ld, cb_phased()); break;
     case 256: hipLaunchKernelGGL((cbir_prefilter_wide_kernel<BOOT, 16>), dim3(grid), dim3(512), 0, stream, Qb, qnorm, nq, Gb, gmax_bits, begin, end, rps, nsplit, idx_base, thr, cand, gm, gm_ld); break;
     case 384: hipLaunchKernelGGL((cbir_prefilter_wide_kernel<BOOT, 24>), dim3(grid), dim3(512), 0, stream, Qb, qnorm, nq, Gb, gmax_bits, begin, end, rps, nsplit, idx_base, thr, cand, gm, gm_ld); break;
     default: hipLaunchKernelGGL((cbir_prefilter_wide_kernel<BOOT, 32>), dim3(grid), dim3(512), 0, stream, Qb, qnorm, nq, Gb, gmax_bits, begin, end, rps, nsplit, idx_base, thr, cand, gm, gm_ld); break;
@@ -1087,6 +1283,10 @@ int vdk_cbir_search_fast2(const float* Q, int64_t nq, const void* G, int32_t g_d
     return vdk_fail(VDK_EINVAL, "vdk_cbir_search_fast2: bad argument (need D % 4 == 0, D <= 512, 1 <= k <= 1024)");
   if (g_dtype != VDK_F32 && g_dtype != VDK_F16) return vdk_fail(VDK_EINVAL, "vdk_cbir_search_fast2: g_dtype must be VDK_F32 or VDK_F16");
   if (g_dtype == VDK_F16 && (D & 7)) return vdk_fail(VDK_EINVAL, "vdk_cbir_search_fast2: fp16 storage needs D % 8 == 0");
+  // schedule <= -1024: stages of -schedule rows like schedule >= 1024, RANKED ON THE APPROXIMATE SCORES between the stages (cbir_rank_approx_kernel); k <= 256
+  const bool approx = schedule <= -1024;
+  if (approx) { if (k > 256) return vdk_fail(VDK_EINVAL, "vdk_cbir_search_fast2: the approximate-ranking schedule serves k <= 256"); schedule = -schedule; }
+  if (schedule < 0) return vdk_fail(VDK_EINVAL, "vdk_cbir_search_fast2: schedule must be 0, 1, >= 1024 or <= -1024");
   if (idx_base + N > 0x7fffffffLL) return vdk_fail(VDK_EINVAL, "vdk_cbir_search_fast2: index range exceeds int32");
   if (nq == 0) return VDK_OK;
   const int DP = cb_dp(D), g_half = g_dtype == VDK_F16;
@@ -1130,8 +1330,10 @@ int vdk_cbir_search_fast2(const float* Q, int64_t nq, const void* G, int32_t g_d
     const long rps = ((NG + ns - 1) / ns) * BG;
     cb_launch_prefilter<true>(stream, DP, (unsigned)(qblocks * ns), Qb, qnorm, (long)nq, (const bf16_t*)Gb, (const unsigned*)gmax_bits, 0L, NG * BG, rps, (int)ns, (long)idx_base,
                               thr, cand, gm, NG);
-    hipLaunchKernelGGL(cbir_boot_thr_kernel, dim3((unsigned)nq), dim3(256), 0, stream, (const float*)gm, (int)NG, (int)k, (const float*)qnorm,
-                       (const unsigned*)gmax_bits, thr);
+    if (NG <= 1024) hipLaunchKernelGGL(cbir_boot_thr_wave_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, (const float*)gm, (int)NG, (int)k, (const float*)qnorm,
+                                       (const unsigned*)gmax_bits, thr, (long)nq);
+    else hipLaunchKernelGGL(cbir_boot_thr_kernel, dim3((unsigned)nq), dim3(256), 0, stream, (const float*)gm, (int)NG, (int)k, (const float*)qnorm,
+                            (const unsigned*)gmax_bits, thr);
     stage = max_stage;   // the cut is already tight: no ramp
     booted = true;
   }
@@ -1142,7 +1344,7 @@ int vdk_cbir_search_fast2(const float* Q, int64_t nq, const void* G, int32_t g_d
   // the scan is on the critical path.  Two list sets alternate; a list's slots [0, k) are reserved for the carried top-k, which the ranking writes into the
   // OTHER set; stage i + 1 filters with the threshold of stage i - 1 (any earlier threshold is a valid lower bound: the results stay bit-identical,
   // a few more rows survive).  Dependencies: P(i) after R(i-2) [threshold, list reuse]; R(i) after P(i) and R(i-1) [same stream].
-  const bool pipelined = !optimistic && k <= 256 && cb_pipeline_enabled() && (N - begin) > 2 * stage;
+  const bool pipelined = !approx && !optimistic && k <= 256 && cb_pipeline_enabled() && (N - begin) > 2 * stage;
   hipStream_t s2 = stream;
   if (pipelined) {
     s2 = cb_side_stream();
@@ -1169,6 +1371,11 @@ int vdk_cbir_search_fast2(const float* Q, int64_t nq, const void* G, int32_t g_d
       if (cb_order(1, stream, s2)) return vdk_fail(VDK_ELAUNCH, "vdk_cbir_search_fast2: event");                                   // R(i) after P(i)
       cb_rank(s2, Q, Gf, (int)D, (long)idx_base, cur, (long)nq, (int)k, thr, out_scores, (long long*)out_idx, (int)(end == N), carry, g_half, &oth, (int)k);
       if (cb_record(2 + si % 4, s2)) return vdk_fail(VDK_ELAUNCH, "vdk_cbir_search_fast2: event");
+    } else if (approx) {
+      if (end == N) hipLaunchKernelGGL(cbir_rank_approx_kernel<true>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, Q, Gf, (int)D, (long)idx_base, cand, (long)nq, (int)k,
+                                       thr, out_scores, (long long*)out_idx, carry, g_half, (const float*)qnorm, (const unsigned*)gmax_bits);
+      else hipLaunchKernelGGL(cbir_rank_approx_kernel<false>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, Q, Gf, (int)D, (long)idx_base, cand, (long)nq, (int)k,
+                              thr, out_scores, (long long*)out_idx, carry, g_half, (const float*)qnorm, (const unsigned*)gmax_bits);
     } else {
       cb_rank(stream, Q, Gf, (int)D, (long)idx_base, cand, (long)nq, (int)k, thr, out_scores, (long long*)out_idx, (int)(end == N), carry, g_half);
     }
@@ -1179,7 +1386,7 @@ int vdk_cbir_search_fast2(const float* Q, int64_t nq, const void* G, int32_t g_d
   }
   if (pipelined && si > 0 && cb_wait(2 + (si - 1) % 4, stream)) return vdk_fail(VDK_ELAUNCH, "vdk_cbir_search_fast2: event");      // join: results are ordered before what follows on `stream`
   if (N == 0)
-    cb_rank(stream, Q, Gf, (int)D, (long)idx_base, cand, (long)nq, (int)k, thr, out_scores, (long long*)out_idx, 1, carry, g_half);
+    cb_rank(stream, Q, Gf, (int)D, (long)idx_base, cand, (long)nq, (int)k, thr, out_scores, (long long*)out_idx, 1, carry, g_half);      // (empty lists: pads)
   if (overflow_out && hipMemcpyAsync(overflow_out, cand.overflow, 4, hipMemcpyDeviceToDevice, stream) != hipSuccess)
     return vdk_fail(VDK_ELAUNCH, "vdk_cbir_search_fast2: memcpy failed");
   return vdk_check_launch("vdk_cbir_search_fast2");
