@@ -11,6 +11,7 @@ gal = cbir.l2_normalize(torch.randn(1_000_000, 128, generator=g).to(dev))
 g.manual_seed(1)
 qry = cbir.l2_normalize(torch.randn(10_000, 128, generator=g).to(dev))
 kw = {} if mode == "default" else {"small_lists": mode == "small"}
+if os.environ.get("CBIR_CAP"): kw["cap"] = int(os.environ["CBIR_CAP"])
 index = cbir.FlatIPIndex(128, device=dev, **kw)
 index.add(gal)
 for _ in range(4):
@@ -21,5 +22,5 @@ e0.record()
 for _ in range(iters):
     s, i = index.search(qry, 100)
 e1.record(); torch.cuda.synchronize()
-print(mode, {k: v for k, v in os.environ.items() if k.startswith("VDK_CBIR")}, "ms/search %.3f" % (e0.elapsed_time(e1) / iters), "fallbacks", index.fallbacks,
+print(mode, {k: v for k, v in os.environ.items() if k.startswith("VDK_CBIR") or k.startswith("CBIR_")}, "ms/search %.3f" % (e0.elapsed_time(e1) / iters), "fallbacks", index.fallbacks,
       "checksum", int(i.sum().item()), float(s.double().sum().item()))

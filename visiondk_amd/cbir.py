@@ -21,9 +21,9 @@ import torch
 from . import _lib
 
 METRIC_INNER_PRODUCT = 0  # faiss.METRIC_INNER_PRODUCT
-DEFAULT_CAP = 98304       # candidate-list capacity per query of the GUARANTEED schedule = rows per stage + k (csrc/cbir.hip).  Swept on the MI355X at 10 k x 1 M:
-                          # 32 k 4.21 ms, 64 k 3.88, 96 k 3.54, 128 k 3.53, 192 k 3.69, 256 k 3.89 (fewer launches against looser thresholds per stage); the lists
-                          # are address space more than memory: a search touches ~10^3 of a query's 98 304 slots
+DEFAULT_CAP = 131072      # candidate-list capacity per query of the GUARANTEED schedule = rows per stage + k (csrc/cbir.hip).  Swept on the MI355X at 10 k x 1 M:
+                          # round 6 (approximate ranking): 32 k 3.85 ms, 48 k 3.53, 64 k 3.40, 96 k 3.30, 128 k 3.23, 192 k 3.25 (fewer launches against looser
+                          # thresholds per stage; round 3's exact ranking: 96 k 3.54, 128 k 3.53); with small_lists the lists hold SMALL_LIST_CAP entries
 SMALL_LIST_CAP = 16384    # staged schedule with small candidate lists (`small_lists=True`): stages of cap - k rows like the guaranteed schedule, lists of this many entries
 OPTIMISTIC_CAP = 8192     # ... of the optimistic schedule (bootstrap + two stages; ~10^3 survivors per query in a 10^6-row scan; overflow is detected and repaired)
 

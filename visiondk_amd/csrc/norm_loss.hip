@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void ln_fwd_narrow_kernel(const float* __restr
 // NR rows per wave and pass, all loaded (x, dy and the residual gradient) before the first reduction: with narrow rows (Swin's 128 .. 512 channels) a wave's single row
 // is too few bytes in flight to stream at HBM rate.  HALF (C <= 128): a row is 32 lanes, so a wave takes two rows side by side.
 template <int MAXJ, bool DY_BF16 /* 16-bit dy in operand format OF (else fp32) */, bool OCS, bool Q8 = false, int OF = 0 /* format of a 16-bit dy and of dxb */, int NR = 1,
-          bool HALF = false>
+          bool HALF = false, bool DR16 = false /* the residual gradient arrives as 16-bit rows (dres16, format OF) instead of fp32 dres */>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, long lddy, const float* __restrict__ x,
                                                      long ldx, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      float* __restrict__ pgamma, float* __restrict__ pbeta, float* __restrict__ pout, LnQ8 q8 = LnQ8(),
                                                      const float* __restrict__ dy_scale = nullptr /* device scalar: dy is multiplied by dy_scale[0] as it is loaded (a gradient branch kept at its own power-of-two scale: ConvNeXt's layer-scale branch under fp16 operands) */,
                                                      const float* __restrict__ dxb_rs = nullptr /* per-sample factor of the 16-bit COPY dxb only (dx stays): dxb = 16bit(dx * dxb_rs[row / dxb_rps]) -- the
-                                                     gradient entering a residual branch under stochastic depth (timm DropPath: mask_b / keep_prob), whose GEMMs read dxb */, int dxb_rps = 1) {
+                                                     gradient entering a residual branch under stochastic depth (timm DropPath: mask_b / keep_prob), whose GEMMs read dxb */, int dxb_rps = 1,
+                                                     const bf16_t* __restrict__ dres16 = nullptr) {
   static_assert(!HALF || MAXJ == 1, "HALF: one 128-column slab");
   __shared__ float red[4][MAXJ * 256];
   float q8s = 1.0f, q8lim = 448.0f, q8am = 0.f;
@@ -185,7 +186,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
             d[0] = u[0]; d[1] = u[1]; d[2] = u[2]; d[3] = u[3];
           }
           if (dy_scale) { d[0] *= dsc; d[1] *= dsc; d[2] *= dsc; d[3] *= dsc; }
-          if (dres) {
+          if (DR16) {
+            const u32x2 r2 = *(const u32x2*)(dres16 + (long)row * lddres + c);
+            rv[k][j][0] = op_lo<OF>(r2[0]); rv[k][j][1] = op_hi<OF>(r2[0]); rv[k][j][2] = op_lo<OF>(r2[1]); rv[k][j][3] = op_hi<OF>(r2[1]);
+          } else if (dres) {
             f32x4 r4 = *(const f32x4*)(dres + (long)row * lddres + c);
             rv[k][j][0] = r4[0]; rv[k][j][1] = r4[1]; rv[k][j][2] = r4[2]; rv[k][j][3] = r4[3];
           }
@@ -660,8 +664,11 @@ static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const flo
                        const float* rstd, const float* gamma, const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx,
                        int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                        void* stream_, VdkReduceJob* deferred, float* dxb_colsum = nullptr, VdkReduceJob* deferred2 = nullptr, const LnQ8* q8 = nullptr, int opf = 0,
-                       const float* dy_scale = nullptr, const float* dxb_rs = nullptr, int dxb_rps = 1) {
+                       const float* dy_scale = nullptr, const float* dxb_rs = nullptr, int dxb_rps = 1, const void* dres16 = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (dres16) {      // the 16-bit residual-gradient stream of the ViT engine's fp16 mode: C <= 768, 16-bit dy, the column-sum form (one instantiation)
+    if (!(dy_dtype == VDK_F16) || !dxb_colsum || C > 768 || C <= 512 || q8 || dy_scale || dxb_rs) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: dres16 serves the fp16 column-sum form at 512 < C <= 768");
+  }
   if (dy_dtype == VDK_F16) opf = VDK_OPF_F16;          // (an fp32 dy with an fp16 dxb: opf passed by the in-library caller)
   if (dy_dtype != VDK_BF16 && dy_dtype != VDK_F32 && dy_dtype != VDK_F16) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: bad dy_dtype");
   if (opf && dy_dtype == VDK_BF16) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: bf16 dy with an fp16 output copy");
@@ -690,6 +697,11 @@ static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const flo
                                     mean, rstd, gamma, dres, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po, *q8)
     if (C <= 768) LNBQ(3); else LNBQ(4);
 #undef LNBQ
+  }
+  else if (dres16) {
+    hipLaunchKernelGGL((ln_bwd_kernel<3, true, true, false, VDK_OPF_F16, 1, false, true>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, mean, rstd, gamma,
+                       (const float*)nullptr, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po, LnQ8(), (const float*)nullptr, (const float*)nullptr, 1,
+                       (const bf16_t*)dres16);
   }
   else if (C <= 128) LNB2(1, 2, true);
   else if (C <= 256) LNB2(1, 2, false);
@@ -826,10 +838,11 @@ int vdk_bce_logits(const float* logits, int64_t ldl, const float* targets, int64
 // LayerNorm backward whose dgamma | dbeta partial-sum reduction is left to the caller: *job describes it (job->in == NULL if it was done here after all)
 int vdk_layernorm_bwd_deferred(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
                                const float* dres, int64_t lddres, int32_t T, int32_t C, float* dx, int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta,
-                               void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job, float* dxb_colsum, VdkReduceJob* job2, const LnQ8* dxb_q8, int opf, const float* dy_scale, const float* dxb_rs, int dxb_rps) {
+                               void* ws, size_t ws_bytes, void* stream, VdkReduceJob* job, float* dxb_colsum, VdkReduceJob* job2, const LnQ8* dxb_q8, int opf, const float* dy_scale, const float* dxb_rs, int dxb_rps,
+                               const void* dres16) {
   if (dxb_rs && (!dxb || dxb_rps <= 0)) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: dxb_rs needs dxb and dxb_rps > 0");
   return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, mean, rstd, gamma, dres, lddres, T, C, dx, lddx, dxb, lddxb, dgamma, dbeta, ws, ws_bytes, stream, job, dxb_colsum, job2, dxb_q8, opf, dy_scale,
-                     dxb_rs, dxb_rps);
+                     dxb_rs, dxb_rps, dres16);
 }
 // vdk_colsum_bf16 whose final reduction over the row splits is left to the caller (*job describes it)
 int vdk_colsum_bf16_deferred(const void* in, int64_t ld, int32_t T, int32_t N, float* out, void* ws, size_t ws_bytes, void* stream_, VdkReduceJob* job, const LnQ8* q8, int opf) {

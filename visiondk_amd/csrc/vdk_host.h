@@ -46,7 +46,9 @@ int vdk_layernorm_bwd_deferred(const void* dy, int64_t lddy, int32_t dy_dtype, c
                                const LnQ8* dxb_q8 = nullptr /* with dxb_colsum, C <= 1024, bf16 dy: dxb's fp8 copy rides along */,
                                int opf = 0 /* format of a 16-bit dy and of dxb (dy_dtype VDK_F16 implies fp16; an fp32 dy takes it from here) */,
                                const float* dy_scale = nullptr /* device scalar multiplied into dy as it is loaded (job == nullptr: the reductions run inside) */,
-                               const float* dxb_rs = nullptr /* per-sample factor of the 16-bit copy: dxb = 16bit(dx * dxb_rs[row / dxb_rps]) (stochastic depth) */, int dxb_rps = 1);
+                               const float* dxb_rs = nullptr /* per-sample factor of the 16-bit copy: dxb = 16bit(dx * dxb_rs[row / dxb_rps]) (stochastic depth) */, int dxb_rps = 1,
+                               const void* dres16 = nullptr /* the residual gradient as 16-bit rows (fp16, pitch lddres) instead of fp32 `dres`: the ViT engine's fp16 mode keeps the
+                               residual-gradient stream in 16 bits (its copy for the next GEMM IS the stream) */);
 // x16[r, :] *= rs[r / rps] in place (16-bit operand format opf): the same factor for a 16-bit gradient copy that no LayerNorm backward produced (stage boundaries of the Swin engine)
 int vdk_rowscale_16(void* x16, int64_t T, int32_t C, const float* rs, int32_t rps, int opf, void* stream);
 

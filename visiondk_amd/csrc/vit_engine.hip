@@ -726,8 +726,17 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
       RC(gemm(s, du, M, wt + p.blkT[l].fc1, M, dsm, D, T, D, M, DT16, nullptr, nullptr, 0, VDK_ACT_NONE, nullptr, 0, 1, 0, nullptr, 0));   // dh2
     }
     const bool ocs_ln = one_stream && D <= 1024;
+    // fp16 operands: the residual-gradient stream travels in 16 bits.  Every norm backward writes dL/dx twice -- fp32 for the next norm backward's residual term, 16-bit
+    // for the next GEMM -- and reads the fp32 one back: 310 of its 620 MB per launch at ViT-B/16 (the kernel streams at HBM rate, so bytes are its time).  With g16 the
+    // 16-bit copy is the stream: the sum is formed in fp32 registers and rounded once per norm (24 roundings of 2^-11 down the trunk; measured against the fp32 oracle
+    // in tests/test_fp16_operands.py and bench.py's parity block, bound 5e-3 on every gradient).  bf16 (8 mantissa bits) keeps the fp32 stream.
+    static const bool g16_on = !(getenv("VDK_VIT_G16") && atoi(getenv("VDK_VIT_G16")) == 0);
+    const bool g16 = g16_on && ocs_ln && !f8.mode && t_opf == VDK_OPF_F16 && D > 512 && D <= 768;
     const bool lq = f8.mode && f8_fused(f8) && ocs_ln;               // the norm backward kernels write the e5m2 copies of dxmb / DXAB(l - 1) into the operand scratch
     const LnQ8 q8m = {f8.a8, (long)D, f8.sc + 12 * l + 10, f8.amax + 12 * l + 10, 1};
+    if (g16) RC(vdk_layernorm_bwd_deferred(dsm, D, DT16, xmid, D, mean2, rstd2, params + b.n2w, nullptr, D, T, D, nullptr, D, dxmb, D, grads + b.n2w, grads + b.n2b, lnws0,
+                                           w.lnws_bytes, s, &jobs[nj], grads + b.proj_b, &jobs[nj + 1], nullptr, 0, nullptr, nullptr, 1, dxab));
+    else
     RC(vdk_layernorm_bwd_deferred(dsm, D, DT16, xmid, D, mean2, rstd2, params + b.n2w, dxa, D, T, D, dxm, D, dxmb, D, grads + b.n2w, grads + b.n2b, lnws0,
                                   w.lnws_bytes, s, &jobs[nj], ocs_ln ? grads + b.proj_b : nullptr, ocs_ln ? &jobs[nj + 1] : nullptr, lq ? &q8m : nullptr));
     nj += ocs_ln ? 2 : 1;
@@ -783,6 +792,13 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
     const bool ocs_n1 = ocs_ln && l > 0;      // DXAB(l - 1) is dY of block l-1's fc2 (for l == 0 it feeds the patch embedding, whose bias comes from d pos_embed)
     const bool lq1 = lq && ocs_n1;
     const LnQ8 q8a = {f8.a8, (long)D, f8.sc + 12 * (l - 1) + 8, f8.amax + 12 * (l - 1) + 8, 1};
+    if (g16 && l > 0) RC(vdk_layernorm_bwd_deferred(dsm, D, DT16, xin, D, mean1, rstd1, params + b.n1w, nullptr, D, T, D, nullptr, D, DXAB(l - 1), D, grads + b.n1w, grads + b.n1b, lnws1,
+                                                    w.lnws_bytes, s, &jobs[nj], grads + p.blk[l - 1].fc2_b, &jobs[nj + 1], nullptr, 0, nullptr, nullptr, 1, dxmb));
+    else if (g16) {      // block 0: the embeddings' gradients want the fp32 tensor (d pos_embed sums it over the batch); the column-sum by-product has no taker here
+      float* const dummy_cs = (float*)(base + w.csws);      // (scratch: the sums are not used)
+      RC(vdk_layernorm_bwd_deferred(dsm, D, DT16, xin, D, mean1, rstd1, params + b.n1w, nullptr, D, T, D, dxa, D, DXAB(l - 1), D, grads + b.n1w, grads + b.n1b, lnws1,
+                                    w.lnws_bytes, s, &jobs[nj], dummy_cs, &jobs[nj + 1], nullptr, 0, nullptr, nullptr, 1, dxmb));
+    } else
     RC(vdk_layernorm_bwd_deferred(dsm, D, DT16, xin, D, mean1, rstd1, params + b.n1w, dxm, D, T, D, dxa, D, DXAB(l - 1), D, grads + b.n1w, grads + b.n1b, lnws1,
                                   w.lnws_bytes, s, &jobs[nj], ocs_n1 ? grads + p.blk[l - 1].fc2_b : nullptr, ocs_n1 ? &jobs[nj + 1] : nullptr, lq1 ? &q8a : nullptr));
     dxab8_ready = lq1;
