@@ -667,7 +667,7 @@ static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const flo
                        const float* dy_scale = nullptr, const float* dxb_rs = nullptr, int dxb_rps = 1, const void* dres16 = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
   if (dres16) {      // the 16-bit residual-gradient stream of the ViT engine's fp16 mode: C <= 768, 16-bit dy, the column-sum form (one instantiation)
-    if (!(dy_dtype == VDK_F16) || !dxb_colsum || C > 768 || C <= 512 || q8 || dy_scale || dxb_rs) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: dres16 serves the fp16 column-sum form at 512 < C <= 768");
+    if (!(dy_dtype == VDK_F16) || !dxb_colsum || C > 1024 || C <= 512 || q8 || dy_scale || dxb_rs) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: dres16 serves the fp16 column-sum form at 512 < C <= 1024");
   }
   if (dy_dtype == VDK_F16) opf = VDK_OPF_F16;          // (an fp32 dy with an fp16 dxb: opf passed by the in-library caller)
   if (dy_dtype != VDK_BF16 && dy_dtype != VDK_F32 && dy_dtype != VDK_F16) return vdk_fail(VDK_EINVAL, "vdk_layernorm_bwd: bad dy_dtype");
@@ -699,9 +699,11 @@ static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const flo
 #undef LNBQ
   }
   else if (dres16) {
-    hipLaunchKernelGGL((ln_bwd_kernel<3, true, true, false, VDK_OPF_F16, 1, false, true>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, mean, rstd, gamma,
-                       (const float*)nullptr, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po, LnQ8(), (const float*)nullptr, (const float*)nullptr, 1,
-                       (const bf16_t*)dres16);
+#define LNB16(MJ) hipLaunchKernelGGL((ln_bwd_kernel<MJ, true, true, false, VDK_OPF_F16, 1, false, true>), dim3((unsigned)nb), dim3(256), 0, stream, dy, (long)lddy, x, (long)ldx, mean, rstd, \
+                       gamma, (const float*)nullptr, (long)lddres, (int)T, (int)C, rpb, dx, (long)lddx, (bf16_t*)dxb, (long)lddxb, pg, pb, po, LnQ8(), (const float*)nullptr,          \
+                       (const float*)nullptr, 1, (const bf16_t*)dres16)
+    if (C <= 768) LNB16(3); else LNB16(4);
+#undef LNB16
   }
   else if (C <= 128) LNB2(1, 2, true);
   else if (C <= 256) LNB2(1, 2, false);

@@ -731,7 +731,7 @@ int vdk_vit_backward(const VdkVitConfig* cfg, const void* dlogits, const float* 
     // 16-bit copy is the stream: the sum is formed in fp32 registers and rounded once per norm (24 roundings of 2^-11 down the trunk; measured against the fp32 oracle
     // in tests/test_fp16_operands.py and bench.py's parity block, bound 5e-3 on every gradient).  bf16 (8 mantissa bits) keeps the fp32 stream.
     static const bool g16_on = !(getenv("VDK_VIT_G16") && atoi(getenv("VDK_VIT_G16")) == 0);
-    const bool g16 = g16_on && ocs_ln && !f8.mode && t_opf == VDK_OPF_F16 && D > 512 && D <= 768;
+    const bool g16 = g16_on && ocs_ln && !f8.mode && t_opf == VDK_OPF_F16 && D > 512 && D <= 1024;
     const bool lq = f8.mode && f8_fused(f8) && ocs_ln;               // the norm backward kernels write the e5m2 copies of dxmb / DXAB(l - 1) into the operand scratch
     const LnQ8 q8m = {f8.a8, (long)D, f8.sc + 12 * l + 10, f8.amax + 12 * l + 10, 1};
     if (g16) RC(vdk_layernorm_bwd_deferred(dsm, D, DT16, xmid, D, mean2, rstd2, params + b.n2w, nullptr, D, T, D, nullptr, D, dxmb, D, grads + b.n2w, grads + b.n2b, lnws0,
