@@ -783,6 +783,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
 #undef W4_CURSOR_ADVANCE
 }
 
+// (round 6, measured null: s_setprio 3 in this kernel's main loop and 0 in its epilogue -- the multiplying workgroup ahead of the other one's epilogue arithmetic in the issue
+//  arbitration -- changed no ViT shape by more than +-1 % (fc1 + GELU 329-333 us either way); the same in the CBIR scan's two wave groups: 3.167 / 3.173 ms)
 // =====================================================================================================================================
 // gemm_w4h_kernel — the same building blocks as a 256 x 128 tile with TWO workgroups per CU (80 KB of LDS and 256 registers per wave each): every SIMD hosts
 // one wave of each workgroup, so while one workgroup runs its epilogue (the GELU / dGELU arithmetic, the fp32 residual traffic: 30-70 k cycles in which a
