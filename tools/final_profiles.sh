@@ -42,6 +42,7 @@ rocprofv3 --kernel-trace --stats -d /tmp/f_trace -o t -- python $R/tools/bench_c
 python $R/tools/rocpd_stats.py $(find /tmp/f_trace -name "*.db" | head -1) > $O/cfg3_kernel_stats.txt
 # housekeeping re-timings on the current build: cfg1 (ResNet-18 plumbing config), the ConvNeXt-B classifier, cfg4's embedding extraction, the one-GPU overlap probe
 python $R/tools/bench_cfg1.py 32 20 > $O/cfg1.json 2>/dev/null; cat $O/cfg1.json
+python $R/tools/bench_cfg1.py 32 20 resnet18 fp16 > $O/cfg1_fp16.json 2>/dev/null; cat $O/cfg1_fp16.json      # the conforming-format arm (eager launches: the GradScaler step is not graph-captured)
 python $R/tools/bench_cfg1.py 64 10 resnet50 > $O/resnet50.json 2>/dev/null; cut -c1-300 $O/resnet50.json
 python $R/tools/bench_cfg4.py 2048 256 > $O/cfg4.json 2>/dev/null; cat $O/cfg4.json
 python $R/tools/overlap_probe.py 256 150 2>/dev/null | grep '^{' > $O/overlap.json; cut -c1-300 $O/overlap.json
