@@ -494,6 +494,8 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
       if (nok) bias4[cp] = *(const f32x4*)(p.bias + ncol);
       if (nok && csc) cs4[cp] = *(const f32x4*)(p.cscale + ncol);
     }
+    // (round 6, measured and dropped: two / three blocks of residual rows in flight instead of one -- proj + residual 97.0 -> 108 / 127 us, fc2 246 -> 251 / 277: the 32 / 64
+    //  extra registers do not exist beside the 256 accumulators and what the persistent walk keeps across the epilogue: 19 / 28 spilled registers)
     u32x4 rn[8];
     auto res_request = [&](int b) {
       const int cp_ = b >> 2, rt_ = b & 3;
