@@ -132,8 +132,9 @@ class GradAllReduce:
         n_ar, n_m = C.c_int32(0), C.c_int32(0)
         ar = (C.c_float * 512)(); numel = (C.c_int64 * 256)(); marks = (C.c_float * 64)()
         be.check(be.lib.vdk_comm_trace_read(self._comm, ar, numel, 256, C.byref(n_ar), marks, 64, C.byref(n_m)), "vdk_comm_trace_read")
-        return {"marks_ms": [marks[i] for i in range(n_m.value)], "allreduce_ms": [(ar[2 * i], ar[2 * i + 1]) for i in range(n_ar.value)],
-                "numel": [numel[i] for i in range(n_ar.value)]}
+        na, nm = min(n_ar.value, 256), min(n_m.value, 64)      # the library reports the RECORDED counts; the buffers above hold 256 collectives / 64 marks
+        return {"marks_ms": [marks[i] for i in range(nm)], "allreduce_ms": [(ar[2 * i], ar[2 * i + 1]) for i in range(na)],
+                "numel": [numel[i] for i in range(na)], "recorded": (n_ar.value, n_m.value)}
 
     def __del__(self):
         try:

@@ -675,7 +675,9 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 // 1.0 ms of the 43 ms step, two marker packets around each of its 149 GEMMs); vdk_prof_end() synchronises and returns total GEMM time, launches and flops.
 #include <vector>
 // Tuning / test knobs and the profiling hooks are PER CALLING THREAD (no process-global mutable state on the compute path): a host thread that forces a kernel
-// structure or times its launches does not change what another thread's calls do.
+// structure or times its launches does not change what another thread's calls do.  Consequence for PyTorch hosts: autograd runs Function.backward on its own worker
+// threads, so a knob armed on the Python main thread (vdk_gemm_force_kernel, vdk_prof_begin) reaches the launches of the native engines' C calls made from that thread --
+// the fused steps and bench.py -- but NOT GEMMs launched from the backward of the autograd-node forms (_NeckFn, _SwinFunction, SwinTransformerAutograd).
 static thread_local std::vector<hipEvent_t> g_prof_ev;
 static thread_local std::vector<double> g_prof_flops;
 static thread_local double g_prof_bytes = 0.0;   // algorithmic bytes of the profiled launches: every operand / output / epilogue tensor counted once

@@ -469,8 +469,9 @@ class FaceTrainStep:
             raise ValueError("an fp16 backbone engine under a TimmWrapper built with operand='bf16': build the wrapper with operand='fp16' (its neck follows the format)")
         if self.amp and precision == "fp32":
             raise ValueError("precision='fp32' runs fp32 activations: build the backbone with operand='bf16' (its 16-bit copies are not used in that mode)")
-        if self.amp and shard_head:
-            raise NotImplementedError("the class-sharded head is built for bf16 operands (its three passes take no loss scale yet)")
+        if self.amp and shard_head and comm is not None and comm.active:      # (an inactive communicator -- one rank -- never shards: nothing to refuse)
+            raise NotImplementedError("the class-sharded head is built for bf16 operands (its three passes take no loss scale yet): build the backbone with "
+                                      "operand='bf16' -- `backbone: {timm-...: {operand: bf16}}` in the config -- when shard_head=True is used across ranks")
         if precision == "fp32" and not hasattr(self.bb.model.engine, "precision"):
             raise NotImplementedError("precision='fp32' is built for the ConvNeXt backbones of the face / CBIR task (the engine with an fp32-class training mode)")
         self.precision = precision

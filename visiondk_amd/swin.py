@@ -522,12 +522,15 @@ class SwinEngine:
             setattr(new, k, v if k == "be" else copy.deepcopy(v, memo))
         return new
 
-    def _cfg(self, batch: int):
+    def _cfg(self, batch: int, pass_dp: bool = False):
         from . import _abi
         s = self.spec
         I4 = _abi.I32 * 4
         pad = lambda t: I4(*(tuple(t) + (0,) * (4 - len(t))))      # shallower members of the family (tests): trailing zeros
-        dp = self._dp if (self._dp is not None and self._dp.shape[1] == batch) else None
+        if pass_dp and self._dp is not None and self._dp.shape[1] != batch:
+            raise RuntimeError(f"stochastic-depth factors of a forward at batch {self._dp.shape[1]} under a call at batch {batch}: a backward must follow ITS forward "
+                               "(the engine keeps one forward's workspace and factors)")
+        dp = self._dp if pass_dp else None      # (only forward / backward read the factors: layout, workspace and weight-refresh calls pass none)
         return _abi.SwinConfig(batch, s.img_size, s.in_chans, s.embed_dim, pad(s.depths), pad(s.heads), s.num_classes, s.ln_eps, _abi.F16_ if self.operand == "fp16" else _abi.BF16,
                                self.be.ptr(dp))
 
@@ -589,10 +592,11 @@ class SwinEngine:
         ws = self._workspace(B)
         self._ensure_fresh()
         self._dp = None
+        self._fwd_serial = getattr(self, "_fwd_serial", 0) + 1      # (the workspace and the factors below belong to THIS forward: _SwinFunction.backward checks it is still the last one)
         if training:
             self._dp = drop_path.to(self.device, torch.float32).contiguous() if drop_path is not None else self.draw_drop_path(B)
             assert self._dp is None or tuple(self._dp.shape) == (2 * sum(s.depths), B)
-        cfg = self._cfg(B)
+        cfg = self._cfg(B, pass_dp=True)
         be = self.be
         be.check(be.lib.vdk_swin_forward(C.byref(cfg), be.ptr(x), be.ptr(self.params), be.ptr(self.wb16), be.ptr(ws), ws.numel(), be.ptr(self._out), be.stream()), "vdk_swin_forward")
         return self._out
@@ -603,7 +607,7 @@ class SwinEngine:
         B = dout.shape[0] if self.cp else dout.shape[0] // self.map_rows
         assert B == self._ws_batch and dout.is_contiguous()
         assert (dout.dtype == self.op_dtype and dout.shape[1] == self.cp) if self.cp else (dout.dtype == torch.float32 and dout.shape[1] == self.features)
-        cfg = self._cfg(B)
+        cfg = self._cfg(B, pass_dp=True)
         be = self.be
         cb = _abi.GRAD_READY_FN(lambda user, off, n: on_ready(off, n)) if on_ready is not None else _abi.GRAD_READY_FN(0)
         be.check(be.lib.vdk_swin_backward(C.byref(cfg), be.ptr(dout), be.ptr(self.params), be.ptr(self.wb16), be.ptr(self.wt16), be.ptr(self._ws), self._ws.numel(),
@@ -620,6 +624,7 @@ class _SwinFunction(torch.autograd.Function):
         module._sync_flat()
         out = eng.forward(x, training=module.training)
         ctx.module = module
+        ctx.serial = eng._fwd_serial
         if eng.cp == 0:
             r = int(round(eng.map_rows ** 0.5))
             return out.view(x.shape[0], r, r, eng.features).clone()
@@ -630,6 +635,9 @@ class _SwinFunction(torch.autograd.Function):
         module = ctx.module
         eng = module.engine
         be = eng.be
+        if eng._fwd_serial != ctx.serial:
+            raise RuntimeError("another forward ran through this Swin engine since the one being differentiated: its saved activations and stochastic-depth factors are gone "
+                               "(one engine keeps ONE forward's workspace; run backward before the next forward)")
         if eng.cp == 0:
             g = eng.backward(dout.contiguous().view(-1, eng.features))
         else:
