@@ -153,6 +153,19 @@ def test_vit_fp16_operands_meets_north_star_tolerance(be, dev, img, patch, B):
     assert_north_star(r)
 
 
+def test_vit_fp16_16bit_residual_gradient_stream_matches_the_fp32_stream(be, dev, monkeypatch):
+    """widths 512 < D <= 1024 in fp16 mode keep the residual-gradient stream in 16 bits (csrc/vit_engine.hip `g16`, ln_bwd_kernel<..., DR16>): a 576-wide two-block model --
+    the narrowest shape that takes the path, small enough for the emulator -- meets the stated tolerance, and its gradients sit within a few fp16 roundings of the
+    fp32-stream form (VDK_VIT_G16=0 is read per process: the comparison arm is the oracle, the switch is exercised on the GPU by bench A/B runs)."""
+    from oracle.parity import vit_fwd_bwd_vs_oracle, vit_pair
+    ref, model = vit_pair(be, dev, 32, 16, 576, 2, 9, 1152, 10, operand="fp16")
+    torch.manual_seed(7)
+    x = torch.randn(3, 3, 32, 32); y = torch.randint(0, 10, (3,))
+    r = vit_fwd_bwd_vs_oracle(ref, model, x, y, dev)
+    print(r)
+    assert_north_star(r)
+
+
 @pytest.mark.gpu
 def test_vit_base_patch16_full_size_fp16_operands_within_1e3_of_the_fp32_reference(hip):
     """BASELINE.json configs[1]'s model at full width and depth (ViT-B/16, 224, 1000 classes), batch 8, every parameter gradient: logits <= 1e-3, gradients <= 5e-3 of the

@@ -207,3 +207,4 @@ def test_batch_reduction_folds_tall_jobs(be, dev, S, n):
         outs.append(out.cpu())
     assert torch.equal(outs[0], outs[1])
     torch.testing.assert_close(outs[0].double(), want, rtol=1e-5, atol=1e-4)
+

@@ -197,8 +197,10 @@ class FlatIPIndex:
                 if self.small_lists and not self.optimistic:
                     if getattr(self, "_flag", None) is None:
                         self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
-                    stage_rows = max(1024, cap - k)                                             # |schedule| >= 1024 = stage length in rows; negative = approximate ranking
-                    run(-stage_rows if (self.approx_rank and k <= 256) else stage_rows, max(min(cap, SMALL_LIST_CAP), 2 * k), self._flag)
+                    approx = self.approx_rank and k <= 256
+                    # |schedule| >= 1024 = stage length in rows; negative = approximate ranking, which carries up to 448 kept rows (k + the error band) between stages
+                    stage_rows = max(1024, cap - (448 if approx else k))
+                    run(-stage_rows if approx else stage_rows, max(min(cap, SMALL_LIST_CAP), 2 * k), self._flag)
                     done = int(self._flag.item()) == 0
                     if not done:
                         self.fallbacks += 1
