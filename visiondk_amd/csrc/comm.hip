@@ -135,16 +135,26 @@ int vdk_comm_destroy(VdkComm* c) {
 int vdk_allreduce_bucket(VdkComm* c, float* grads, int64_t offset, int64_t numel, void* launch_stream) {
   if (!c || !grads || offset < 0 || numel < 0) return vdk_fail(VDK_EINVAL, "vdk_allreduce_bucket: bad argument");
   if (numel == 0) return VDK_OK;
+  // (more than VDK_COMM_READY_RING collectives in flight before vdk_comm_finish re-use an event whose wait may not have been consumed: re-recording it then orders the
+  //  OLDER collective behind newer kernels -- later, never earlier -- so results stay correct; only the overlap of that one bucket suffers.  64 covers 2 GB at 32 MB.)
   hipEvent_t ready = c->ready_ring[c->ready_next]; c->ready_next = (c->ready_next + 1) % VDK_COMM_READY_RING;
   if (hipEventRecord(ready, (hipStream_t)launch_stream) != hipSuccess || hipStreamWaitEvent(c->stream, ready, 0) != hipSuccess)
     return vdk_fail(VDK_ELAUNCH, "vdk_allreduce_bucket: event record / wait failed");
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->trace) {
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventRecord(e0, c->stream) != hipSuccess) return vdk_fail(VDK_ELAUNCH, "vdk_allreduce_bucket: trace event");
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventRecord(e0, c->stream) != hipSuccess) {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      return vdk_fail(VDK_ELAUNCH, "vdk_allreduce_bucket: trace event");
+    }
   }
   static const bool skip = getenv("VDK_COMM_SKIP_RCCL") && atoi(getenv("VDK_COMM_SKIP_RCCL")) > 0;      // diagnosis only: everything but the RCCL call itself
   const ncclResult_t r = skip ? ncclSuccess : g_rccl.AllReduce(grads + offset, grads + offset, (size_t)numel, ncclFloat32, ncclSum, c->comm, c->stream);
-  if (r != ncclSuccess) return rccl_fail("ncclAllReduce", r);
+  if (r != ncclSuccess) {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return rccl_fail("ncclAllReduce", r);
+  }
   if (c->trace) { c->ar0.push_back(e0); c->ar1.push_back(e1); c->ar_numel.push_back(numel); }      // (the end event is recorded by vdk_comm_trace_close_last, after an optional stand-in)
   ++c->issued;
   return VDK_OK;
@@ -203,6 +213,8 @@ int vdk_comm_finish(VdkComm* c, void* launch_stream) {
 // work after it
 int vdk_allgather(VdkComm* c, const void* send, void* recv, int64_t bytes_per_rank, void* launch_stream) {
   if (!c || !send || !recv || bytes_per_rank <= 0) return vdk_fail(VDK_EINVAL, "vdk_allgather: bad argument");
+  // (more than VDK_COMM_READY_RING collectives in flight before vdk_comm_finish re-use an event whose wait may not have been consumed: re-recording it then orders the
+  //  OLDER collective behind newer kernels -- later, never earlier -- so results stay correct; only the overlap of that one bucket suffers.  64 covers 2 GB at 32 MB.)
   hipEvent_t ready = c->ready_ring[c->ready_next]; c->ready_next = (c->ready_next + 1) % VDK_COMM_READY_RING;
   if (hipEventRecord(ready, (hipStream_t)launch_stream) != hipSuccess || hipStreamWaitEvent(c->stream, ready, 0) != hipSuccess)
     return vdk_fail(VDK_ELAUNCH, "vdk_allgather: event record / wait failed");
