@@ -57,6 +57,9 @@
 #ifndef W4_AUX_PREFETCH
 #define W4_AUX_PREFETCH 0   /* dGELU forms of the persistent kernel: the first block's saved-operand rows are requested in front of the tile's last k-tile (0: at the epilogue's start) */
 #endif
+#ifndef W4_STORE_POLICY
+#define W4_STORE_POLICY 2   /* cache policy of the 16-bit epilogue stores: 2 = nt (see rows_out), 0 = default (A/B builds) */
+#endif
 #ifndef W4_EPI_AHEAD
 #define W4_EPI_AHEAD 1      /* epilogue operand rows (saved GELU operand, fp32 residual) requested one 32-row block ahead; 0 = at the block's start (A/B builds) */
 #endif   /* scalar offset of a DMA that must read nothing: beyond every descriptor (operands stay below 2 GB), so it lands zeros */
@@ -368,9 +371,13 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
       // buffer_store_dwordx4 v[a:a+3], v, s[..], s offen followed within four instructions by VALU writes of v[a:a+3] (the column-sum arithmetic): dword 1 of
       // lanes 12-15 / 28-31 / 44-47 / 60-63 reached memory already overwritten.  The compiler pads the wide-store data hazard only for the form without a
       // scalar-offset register.
+      // Non-temporal stores (cache policy nt): what these epilogues write -- activations and gradients of [tokens, features] size, the saved GELU operand -- is either
+      // re-read only after far more than the Infinity Cache's 256 MB has streamed by, or larger than it on its own; written with the default policy it evicts the operand
+      // panels and weights the GEMMs DO re-read.  Round 6, same-box A/B of the ViT-B/16 step: 35.85 -> 35.12 ms (the saved operand alone: 35.4); swin_base 29.5 -> 28.8 ms, cfg3 108.0 -> 106.4 ms.
+      // (A run-time choice per launch -- a wave-uniform branch around the stores -- cost 1.4 ms of the step in spills: the policy is a compile-time constant.)
 #pragma unroll
       for (int ps = 0; ps < NPS; ++ps)
-        __builtin_amdgcn_raw_buffer_store_b128(d[ps], rs, lane_off + (srow + (unsigned)(ps * RPP) * ldbytes), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(d[ps], rs, lane_off + (srow + (unsigned)(ps * RPP) * ldbytes), 0, W4_STORE_POLICY);
       W4_EPI_SYNC();
     };
     if constexpr (DEEP >= 0) W4_WAIT_VM(DEEP);                  // deep wait: every DMA group but the newest has landed (the next tile's first k-tile then runs without waits)
