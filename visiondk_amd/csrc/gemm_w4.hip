@@ -374,7 +374,9 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
       // Non-temporal stores (cache policy nt): what these epilogues write -- activations and gradients of [tokens, features] size, the saved GELU operand -- is either
       // re-read only after far more than the Infinity Cache's 256 MB has streamed by, or larger than it on its own; written with the default policy it evicts the operand
       // panels and weights the GEMMs DO re-read.  Round 6, same-box A/B of the ViT-B/16 step: 35.85 -> 35.12 ms (the saved operand alone: 35.4); swin_base 29.5 -> 28.8 ms, cfg3 108.0 -> 106.4 ms.
-      // (A run-time choice per launch -- a wave-uniform branch around the stores -- cost 1.4 ms of the step in spills: the policy is a compile-time constant.)
+      // (A run-time choice per launch -- a wave-uniform branch around the stores -- cost 1.4 ms of the step in spills: the policy is a compile-time constant.
+      //  The same policy measured null, +-0.1 ms, on every other stream of the step: the fp32 residual rows in and out, the saved-operand loads of the dGELU forms,
+      //  LayerNorm backward's saved input, the attention backward's dq / dk / dv rows, the split-K slab reduce, the optimizer pass.)
 #pragma unroll
       for (int ps = 0; ps < NPS; ++ps)
         __builtin_amdgcn_raw_buffer_store_b128(d[ps], rs, lane_off + (srow + (unsigned)(ps * RPP) * ldbytes), 0, W4_STORE_POLICY);
