@@ -376,7 +376,8 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, unsigned char* 
       // panels and weights the GEMMs DO re-read.  Round 6, same-box A/B of the ViT-B/16 step: 35.85 -> 35.12 ms (the saved operand alone: 35.4); swin_base 29.5 -> 28.8 ms, cfg3 108.0 -> 106.4 ms.
       // (A run-time choice per launch -- a wave-uniform branch around the stores -- cost 1.4 ms of the step in spills: the policy is a compile-time constant.
       //  The same policy measured null, +-0.1 ms, on every other stream of the step: the fp32 residual rows in and out, the saved-operand loads of the dGELU forms,
-      //  LayerNorm backward's saved input, the attention backward's dq / dk / dv rows, the split-K slab reduce, the optimizer pass.)
+      //  LayerNorm backward's saved input, the attention backward's dq / dk / dv rows, the split-K slab reduce, the optimizer pass; non-temporal operand DMAs of the
+      //  weight-gradient GEMMs -- every operand byte is read by one XCD once -- cost 0.25 ms: 34.8 -> 35.05.)
 #pragma unroll
       for (int ps = 0; ps < NPS; ++ps)
         __builtin_amdgcn_raw_buffer_store_b128(d[ps], rs, lane_off + (srow + (unsigned)(ps * RPP) * ldbytes), 0, W4_STORE_POLICY);
