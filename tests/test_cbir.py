@@ -264,14 +264,15 @@ def test_approximate_ranking_keeps_the_error_band_and_falls_back_when_it_is_too_
 def test_approximate_ranking_long_lists_take_several_passes(be, dev):
     """no bootstrap (N / 128 < k) and a gallery sorted by similarity to query 0: every row of a stage beats the running threshold, so a stage leaves thousands of survivors
     and the wave-per-query ranking walks its list in passes of 512 slots (kept rows first).  k = 200 stays inside the 448 kept slots; at k = 256 -- the largest k the
-    approximate schedule serves -- the band around the k-th best in the dense middle of this gallery (~190 rows within 2 eps) does not: reported, repeated exactly."""
+    approximate schedule serves -- the band around the k-th best in the dense middle of this gallery (~190 rows within 2 eps) is at the limit of the slots: whether a
+    pass overflows depends on the order in which the hardware appended the survivors (the emulator's order does); reported and repeated exactly when it happens."""
     q, g = _data(3, 6000, 128, seed=29)
     order = np.argsort(g @ q[0])
     g = np.ascontiguousarray(g[order])
-    for k, fallbacks in ((100, 0), (200, 0), (256, 1)):
+    for k, fallbacks in ((100, (0,)), (200, (0,)), (256, (0, 1))):
         a = cbir.FlatIPIndex(128, backend=be, device=dev, cap=4096); a.add(g)
         s, i = a.search(q, k)
         so, io = ocbir.flat_ip_search(q, g, k)
-        assert a.approx_rank and a.fallbacks == fallbacks
+        assert a.approx_rank and a.fallbacks in fallbacks
         np.testing.assert_array_equal(i, io)
         np.testing.assert_array_equal(s.view(np.uint32), so.view(np.uint32))
