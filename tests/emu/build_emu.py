@@ -21,6 +21,19 @@ FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-mfma"
 
 
 def build(force: bool = False) -> Path:
+    """(pytest -n: several workers call this at once -- one builds under an exclusive file lock, the others wait and find everything up to date; the library is linked to
+    a temporary name and renamed, so nobody maps a half-written file)"""
+    import fcntl
+    OBJ.mkdir(exist_ok=True)
+    with open(OBJ / ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool) -> Path:
     srcs = sorted(CSRC.glob("*.hip")) + [HERE / "hip_emu.cpp"]
     hdrs = sorted(CSRC.glob("*.h")) + [HERE / "hip_emu.h"] + sorted((ROOT / "include").glob("*.h"))
     OBJ.mkdir(exist_ok=True)
@@ -46,11 +59,13 @@ def build(force: bool = False) -> Path:
         res = list(ex.map(one, srcs))
     if LIB.exists() and not any(ch for _, ch in res) and not force:
         return LIB
-    r = subprocess.run([CXX, "-shared", "-fPIC", "-o", str(LIB), *[str(o) for o, _ in res], "-lpthread"],
+    tmp = LIB.with_suffix(f".so.tmp{os.getpid()}")
+    r = subprocess.run([CXX, "-shared", "-fPIC", "-o", str(tmp), *[str(o) for o, _ in res], "-lpthread"],
                        capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
         raise RuntimeError("emu link failed")
+    os.replace(tmp, LIB)
     return LIB
 
 
