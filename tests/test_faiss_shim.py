@@ -267,6 +267,8 @@ def test_committed_trainer_update_fixture(be, dev, operand):
     GradScaler protocol at the fixture's initial scale; bf16 beside it with its 8x coarser bounds."""
     from oracle.vit_ref import VisionTransformerRef
     from visiondk_amd import vit
+    if operand == "bf16" and not be.device_only:
+        pytest.skip("the bf16 arm runs on the MI355X only (70 s on the emulator; the fp16 arm covers the emulated path)")
     z = np.load(TRAINER_GOLD)
     c = {k[4:]: float(z[k]) for k in z.files if k.startswith("cfg_")}
     img, patch, classes, dim, depth, heads, mlp = (int(c[k]) for k in ("img", "patch", "classes", "dim", "depth", "heads", "mlp"))
