@@ -724,7 +724,9 @@ static bool w4h_wanted(int E, bool trans, long M, long N, long K) {
   if ((E & E_DGELU) && (E & E_AUXD) && tiles > 256) return false;
   if (E & E_DGELU) return true;
   // GELU: the four-wave kernel's whole-tile rounds against hardware-dispatched half tiles -- 25 088 x 2048 x 512 (stage 3) is 784 tiles = 3.06 rounds, 99 / 90 us
-  static const long gelu_k = getenv("VDK_GEMM_W4H_GELU_K") ? atol(getenv("VDK_GEMM_W4H_GELU_K")) : 0;      // A/B: GELU problems with K <= this go to the two-workgroup form
+  // (round 6, after the epilogue stores became non-temporal: fc1 + GELU of ViT-B/16 on the two-workgroup form, whose second workgroup multiplies under the activation
+  //  arithmetic, is 0.45 ms per step ahead in same-box A/B -- 34.78 / 34.83 against 35.19 / 35.40 ms; cfg3 -0.3 ms, swin_base -0.05: K <= 768 is the default now)
+  static const long gelu_k = getenv("VDK_GEMM_W4H_GELU_K") ? atol(getenv("VDK_GEMM_W4H_GELU_K")) : 768;      // GELU problems with K <= this go to the two-workgroup form
   if ((E & E_GELU) && gelu_k > 0 && K <= gelu_k) return true;
   if (E & E_GELU) return K <= 768 && (double)tiles / (double)((tiles + 255) / 256 * 256) < 0.8;
   if (E & E_RES) return K < 1536 && tiles <= 256;      // (round 6: more tiles than CUs -> the persistent walk with its start phase: proj + fp32 residual 102-105 us against 107 us)
