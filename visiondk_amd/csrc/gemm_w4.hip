@@ -280,6 +280,8 @@ __device__ __forceinline__ void w4_ktile(unsigned char* smem, const W4Frag<TN>& 
                                          s16x8 (&A0)[2][4], s16x8 (&A1)[2][4], s16x8 (&B0)[2][4], s16x8 (&B1)[2][4], s16x8 (&B0N)[2][4]) {
   unsigned char* const buf = smem + CUR * W4_TILEBUF;
   unsigned char* const nbuf = smem + (CUR ^ 1) * W4_TILEBUF;
+  // (round 6: TWO barriers per k-tile -- in front of P1 and P3, vmcnt(16) at the ends of P2 and P4, none at the ends of P1 and P3: valid, bit-equal, and 0.3 ms per
+  //  ViT-B/16 step SLOWER, 34.67 -> 35.0: the four barriers keep the four SIMDs' read bursts and DMA issues in step.  Four stay.)
   // P1: A0 x B0; read B1(t); refill RA0 (read in P3 of the previous k-tile)
   W4_BAR();
   w4_phase<TN, true, FIRST, OF>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], A0, B0, buf + W4_RB1, F.b, B1, da, buf + W4_RA0, 0, soa, w);
